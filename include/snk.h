@@ -1,0 +1,96 @@
+/* snk.h -- C ABI of libsnk: MI355X-native k-mer count + de Bruijn unitig graph (Supernova hot path).
+ *
+ * This is the drop-in boundary of SURVEY.md section 8(b), row b5.  The reference has no C ABI on this
+ * path; its seams are
+ *   - the C++ entry  buildReadQGraph48(...)            lib/assembly/src/paths/long/BuildReadQGraph48.h:24-34
+ *   - its tail       buildHBVFromEdges(...)            lib/assembly/src/paths/long/HBVFromEdges.h:27-28
+ *   - the unitig hand-off file (.bv) tada -> DF        lib/tada/src/debruijn.rs:895-929,
+ *                                                      lib/assembly/src/paths/long/BuildReadQGraph48.cc:1640-1642
+ *   - the stage argv/MRO contracts (ASSEMBLER_DF, MSP/SHARD_ASM/MAIN_ASM_SN)
+ *                                                      mro/_assembler_stages.mro:24-39, lib/tada/mro/_asm_stages.mro:53-80
+ * Every entry point below names the reference interface it replaces.  Plain pointers and sizes only.
+ *
+ * Conventions
+ *   - return value: 0 = SNK_OK, negative = error; the message is left in the caller's `err` buffer
+ *     (NUL terminated, truncated to errcap) and is also retrievable with snk_last_error().
+ *   - base codes A=0 C=1 G=2 T=3; every non-ACGT input character maps to A
+ *     (lib/tada/src/kmer/mod.rs:311-319, lib/assembly/src/10X/ParseBarcodedFastqs.cc:87-88).
+ *   - packed read rows: `row_words` u32 words per read, base i of a read in word i>>4, bits
+ *     31-2*(i&15)..30-2*(i&15) (MSB first; the same order as KMer<K>'s storage words, kmers/KMer.h:153-160).
+ *   - k-mer keys are 4 u32 words MSB-first (K=48 uses words 0..2, word 3 = 0; K=60 uses all four with
+ *     the low 8 bits of word 3 zero); lexicographic order on words == order on bases (KMer.h:305-311).
+ *   - context byte = pred one-hot << 4 | succ one-hot in the k-mer's canonical orientation
+ *     (kmers/KMerContext.h:27-28), after the adjacency prune (kmers/ReadPather.h:346-385).
+ *   - barcode ids: int32 per read, 0 = no barcode, -1 = "ignore the barcode rule for this read"
+ *     (BuildReadQGraph48.cc:108-114,158-159), >0 = barcode ordinal.
+ *   - "dev" entry points take device pointers (HBM resident) and a hipStream_t passed as void*.
+ */
+#ifndef SNK_H_
+#define SNK_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SNK_OK 0
+#define SNK_E_ARG (-1)      /* bad argument */
+#define SNK_E_HIP (-2)      /* HIP runtime error (message carries hipGetErrorString) */
+#define SNK_E_NOGPU (-3)    /* no gfx950 device visible: the product path never falls back to the CPU */
+#define SNK_E_NOMEM (-4)    /* device/host allocation failed (adapter maps it to exit 99, system/RunTime.cc:195-221) */
+#define SNK_E_IO (-5)
+#define SNK_E_UNSUPPORTED (-6)
+#define SNK_E_INTERNAL (-7)
+
+typedef struct snk_ctx snk_ctx; /* one per process per GPU: owns streams, arena, scratch */
+
+/* thresholds of the path; defaults = CS-build constants K=48 MIN_FREQ=3 MIN_BC=2 MIN_QUAL=7
+ * (lib/assembly/src/10X/DF.cc:138-141,181-184; mro/_assembler.mro:44; lib/tada/mro/_asm_sn.mro:15) */
+typedef struct snk_params {
+    uint32_t K;            /* 48 or 60 */
+    uint32_t min_qual;     /* 7 */
+    uint32_t min_freq;     /* 3 */
+    uint32_t min_bc;       /* 0,1,2 (2 = reference default; >2 is SNK_E_UNSUPPORTED on device) */
+    uint32_t n_buckets;    /* 0 = choose from the k-mer instance count */
+    uint32_t flags;        /* SNK_F_* */
+} snk_params;
+#define SNK_F_NO_GRAPH 1u      /* stop after the retained k-mer table (count only) */
+
+const char* snk_version(void);
+const char* snk_last_error(void);
+void snk_params_default(snk_params* p);
+
+/* ---- context ------------------------------------------------------------------------------------ */
+int snk_ctx_create(int device, snk_ctx** out, char* err, size_t errcap);
+void snk_ctx_destroy(snk_ctx* ctx);
+
+/* ---- synthetic linked reads; counter-based, bit-identical host vs device ---------- */
+typedef struct snk_synth_params {
+    uint64_t seed;
+    uint64_t n_reads;          /* total reads of the data set (pairs are reads 2q, 2q+1) */
+    uint64_t genome_len;       /* 0 -> n_reads*read_len/56 (56x coverage)              */
+    uint32_t read_len;         /* 150 */
+    uint32_t mol_len;          /* 50000 (clamped to genome_len) */
+    uint32_t mols_per_bc;      /* 10 */
+    uint32_t pairs_per_bc;     /* 400 (=> 800 reads per barcode) */
+    uint32_t insert_min;       /* 300 */
+    uint32_t insert_span;      /* 101 (insert uniform in [300,400]) */
+    uint32_t sub_ppm;          /* substitution probability per base, parts per million (2000) */
+    uint32_t unbarcoded_ppm;   /* pairs with bc=0 (20000) */
+    uint32_t lowq_tail_ppm;    /* reads with a Q2 tail (50000) */
+    uint32_t tail_max;         /* tail length uniform in [0,tail_max] (40) */
+    uint32_t err_cdf[4];       /* filled by snk_synth_default: P(#errors<=j)*2^32 for j=0..3 */
+} snk_synth_params;
+void snk_synth_default(snk_synth_params* sp, uint64_t n_reads, uint64_t seed, int error_free);
+/* host generator: reads [first, first+n).  rows: n*row_words u32; quals: n*qstride bytes (raw phred);
+ * bc: n int32.  Any output pointer may be NULL. */
+int snk_synth_host(const snk_synth_params* sp, uint64_t first, uint64_t n, uint32_t* rows, uint32_t row_words,
+                   uint8_t* quals, uint32_t qstride, int32_t* bc);
+int snk_synth_dev(snk_ctx* ctx, const snk_synth_params* sp, uint64_t first, uint64_t n, void* d_rows,
+                  uint32_t row_words, void* d_quals, uint32_t qstride, void* d_bc, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNK_H_ */

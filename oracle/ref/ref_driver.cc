@@ -1,0 +1,210 @@
+// oracle/ref/ref_driver.cc -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+//
+// Driver around the *real* reference path B (lib/assembly, C++): it #includes the
+// reference translation unit so that the anonymous-namespace functions
+//   createDict   (paths/long/BuildReadQGraph48.cc:218-325)
+//   buildEdges   (paths/long/BuildReadQGraph48.cc:514-541)
+// are callable, then mirrors the body of buildReadQGraph48 (:1688-1774, pPaths==nullptr
+// branch) and dumps every intermediate the parity tests pin:
+//   goodlens.u32   per-read good length            (GoodLenTailFinder :65-89)
+//   kmers.bin      sorted retained k-mers: 3xu32 key, u32 count, u8 ctx(+3 pad)
+//   unitigs.txt    canonical unitigs sorted by BVComp (HBVFromEdges.cc:106-111)
+//   hbv.txt        buildHBVFromEdges result on the *sorted* unitigs
+//   stats/histogram_kmer_count.json  (written by the reference itself)
+// Built only by oracle/ref/build_ref.sh from the sources where they lie in
+// /root/reference; the binary lands in oracle/_ref/ (git-ignored).
+//
+// usage: snref_driver <in.snkr> <outdir> [threads=8] [mode=dump|time] [minQual=7 minFreq=3 minBC=2]
+
+#include "paths/long/BuildReadQGraph48.cc"
+
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+namespace {
+
+struct Input {
+    uint64_t n = 0;
+    uint32_t stride = 0;
+    uint32_t has_bc = 0;
+    int64_t ign_bc_below = 0;
+    std::vector<uint16_t> len;
+    std::vector<uint8_t> bases, quals;
+    std::vector<int32_t> bc;
+};
+
+void die(const char* msg) { fprintf(stderr, "snref_driver: %s\n", msg); exit(2); }
+
+void rd(FILE* f, void* p, size_t n) { if (n && fread(p, 1, n, f) != n) die("short read"); }
+
+Input load(const char* path) {
+    FILE* f = fopen(path, "rb");
+    if (!f) die("cannot open input");
+    char magic[8];
+    rd(f, magic, 8);
+    if (memcmp(magic, "SNKRD001", 8)) die("bad magic");
+    Input in;
+    rd(f, &in.n, 8); rd(f, &in.stride, 4); rd(f, &in.has_bc, 4); rd(f, &in.ign_bc_below, 8);
+    in.len.resize(in.n); rd(f, in.len.data(), in.n * 2);
+    in.bases.resize(in.n * in.stride); rd(f, in.bases.data(), in.bases.size());
+    in.quals.resize(in.n * in.stride); rd(f, in.quals.data(), in.quals.size());
+    if (in.has_bc) { in.bc.resize(in.n); rd(f, in.bc.data(), in.n * 4); }
+    fclose(f);
+    return in;
+}
+
+struct KRec { uint32_t k[3]; uint32_t count; uint8_t ctx; uint8_t pad[3]; };
+
+std::string bvstr(bvec const& b) {
+    std::string s(b.size(), 'A');
+    for (unsigned i = 0; i < b.size(); ++i) s[i] = "ACGT"[b[i]];
+    return s;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    RunTime();
+    if (argc < 3) die("usage: snref_driver <in.snkr> <outdir> [threads] [dump|time] [minQual minFreq minBC]");
+    std::string inpath = argv[1], outdir = argv[2];
+    unsigned nt = argc > 3 ? atoi(argv[3]) : 8;
+    std::string mode = argc > 4 ? argv[4] : "dump";
+    unsigned minQual = argc > 5 ? atoi(argv[5]) : 7;
+    unsigned minFreq = argc > 6 ? atoi(argv[6]) : 3;
+    unsigned minBC = argc > 7 ? atoi(argv[7]) : 2;
+    SetThreads(nt, False);
+
+    Input in = load(inpath.c_str());
+    String work(outdir.c_str());
+    Mkpath(work + "/data");
+
+    vecbvec reads;
+    reads.reserve(in.n);
+    ObjectManager<VecPQVec> quals(work + "/data/frag_reads_orig.qualp");
+    VecPQVec& pq = quals.create();
+    pq.reserve(in.n);
+    size_t nInst = 0;
+    {
+        bvec b;
+        qvec q;
+        for (uint64_t r = 0; r < in.n; ++r) {
+            unsigned L = in.len[r];
+            b.resize(L);
+            q.resize(L);
+            const uint8_t* bp = &in.bases[r * in.stride];
+            const uint8_t* qp = &in.quals[r * in.stride];
+            for (unsigned i = 0; i < L; ++i) {
+                unsigned code;
+                switch (bp[i]) {
+                    case 'C': code = 1; break;
+                    case 'G': code = 2; break;
+                    case 'T': code = 3; break;
+                    default: code = 0;  // A and every non-ACGT (N->A, 10X/ParseBarcodedFastqs.cc:87-88)
+                }
+                b.Set(i, code);
+                q[i] = qp[i];
+            }
+            reads.push_back(b);
+            pq.push_back(PQVec(q));
+        }
+    }
+    vec<int32_t> bc;
+    if (in.has_bc) bc.assign(in.bc.begin(), in.bc.end());
+    vec<int32_t> const* bcp = in.has_bc ? &bc : nullptr;
+
+    if (mode == "time") {
+        // whole reference path (count + unitigs + HBV, no read pathing), timed as the CPU baseline
+        HyperBasevector hbv;
+        // k-mer instances = sum over reads of max(0, goodlen-K+1) is printed by the caller; here only wall time
+        auto t0 = std::chrono::steady_clock::now();
+        buildReadQGraph48(work, "/data/frag_reads_orig", "", reads, quals, False, False, minQual, minFreq,
+                          in.ign_bc_below, minBC, bcp, .75, 0, "", True, False, &hbv, nullptr, 0.5, False);
+        double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        printf("SNREF_TIME seconds=%.6f threads=%u reads=%lu hbv_edges=%d hbv_vertices=%d\n", s, nt,
+               (unsigned long)in.n, hbv.EdgeObjectCount(), hbv.N());
+        return 0;
+    }
+
+    // ---- good lengths (same functor the reference uses inside createDict)
+    {
+        std::vector<unsigned> goodLens(reads.size());
+        parallelForBatch(0ul, reads.size(), 100000, GoodLenTailFinder(quals.load(), minQual, &goodLens));
+        FILE* f = fopen((outdir + "/goodlens.u32").c_str(), "wb");
+        fwrite(goodLens.data(), 4, goodLens.size(), f);
+        fclose(f);
+        for (unsigned g : goodLens) if (g >= K + 1) nInst += g - K + 1;
+    }
+
+    // ---- count + filter + contexts + adjacency prune
+    Dict<BCWrapper>* pDict =
+        createDict(work, reads, quals, minQual, minFreq, in.ign_bc_below, 0.5, minBC, bcp);
+    {
+        std::vector<KRec> recs;
+        recs.reserve(pDict->size());
+        for (auto const& hhs : *pDict)
+            for (auto const& e : hhs) {
+                KRec r;
+                memset(&r, 0, sizeof r);
+                for (unsigned w = 0; w < 3; ++w) {
+                    uint32_t v = 0;
+                    for (unsigned i = 0; i < 16; ++i) v = (v << 2) | e[w * 16 + i];
+                    r.k[w] = v;
+                }
+                r.count = e.getKDef().getCount();
+                KMerContext c = e.getKDef().getContext();
+                r.ctx = (uint8_t)((c.getPredecessors() << 4) | c.getSuccessors());
+                recs.push_back(r);
+            }
+        std::sort(recs.begin(), recs.end(), [](KRec const& a, KRec const& b) {
+            for (int w = 0; w < 3; ++w) if (a.k[w] != b.k[w]) return a.k[w] < b.k[w];
+            return false;
+        });
+        FILE* f = fopen((outdir + "/kmers.bin").c_str(), "wb");
+        fwrite(recs.data(), sizeof(KRec), recs.size(), f);
+        fclose(f);
+    }
+
+    // ---- unitigs
+    vecbvec edges;
+    edges.reserve(pDict->size() / 100);
+    buildEdges(*pDict, &edges);
+    delete pDict;
+
+    std::vector<size_t> order(edges.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+        bvec const& x = edges[a]; bvec const& y = edges[b];
+        if (x.size() != y.size()) return x.size() > y.size();
+        return x < y;
+    });
+    vecbvec sorted;
+    sorted.reserve(edges.size());
+    for (size_t i : order) sorted.push_back(edges[i]);
+    {
+        FILE* f = fopen((outdir + "/unitigs.txt").c_str(), "w");
+        for (size_t i = 0; i < sorted.size(); ++i) fprintf(f, "%s\n", bvstr(sorted[i]).c_str());
+        fclose(f);
+    }
+
+    // ---- graph from (sorted) unitigs
+    HyperBasevector hbv;
+    vec<int> fwd, rev;
+    buildHBVFromEdges(sorted, K, &hbv, &fwd, &rev);
+    {
+        vec<int> to_left, to_right;
+        hbv.ToLeft(to_left);
+        hbv.ToRight(to_right);
+        FILE* f = fopen((outdir + "/hbv.txt").c_str(), "w");
+        fprintf(f, "N %d E %d U %lu\n", hbv.N(), hbv.EdgeObjectCount(), (unsigned long)sorted.size());
+        for (int e = 0; e < hbv.EdgeObjectCount(); ++e)
+            fprintf(f, "E %d %d %d %s\n", e, to_left[e], to_right[e], bvstr(hbv.EdgeObject(e)).c_str());
+        for (size_t u = 0; u < sorted.size(); ++u) fprintf(f, "X %lu %d %d\n", (unsigned long)u, fwd[u], rev[u]);
+        fclose(f);
+    }
+    printf("SNREF_DUMP reads=%lu kmer_instances=%lu unitigs=%lu hbv_edges=%d hbv_vertices=%d\n",
+           (unsigned long)in.n, (unsigned long)nInst, (unsigned long)sorted.size(), hbv.EdgeObjectCount(), hbv.N());
+    return 0;
+}

@@ -1,0 +1,72 @@
+"""Build libsnk.so (HIP/gfx950 kernels + C ABI) in-tree with hipcc.
+
+hipcc cross-compiles gfx950 without a GPU, so this runs on the CPU-only build container as well as
+on the MI355X box.  The shared object is written next to this file (supernova_amd/libsnk.so): it is
+git-ignored but travels with the gpurun snapshot.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+CSRC = HERE / "csrc"
+OBJ = HERE / "csrc" / "_obj"
+LIB = HERE / "libsnk.so"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
+    "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-ffp-contract=off",
+]
+
+
+def _sources() -> list[Path]:
+    return sorted(CSRC.glob("*.hip"))
+
+
+def _newest_header() -> float:
+    hs = list(CSRC.glob("*.h")) + [HERE.parent / "include" / "snk.h"]
+    return max(h.stat().st_mtime for h in hs)
+
+
+def build(force: bool = False, verbose: bool = True) -> Path:
+    OBJ.mkdir(exist_ok=True)
+    hdr = _newest_header()
+    todo = []
+    objs = []
+    for src in _sources():
+        obj = OBJ / (src.stem + ".o")
+        objs.append(obj)
+        if force or not obj.exists() or obj.stat().st_mtime < max(src.stat().st_mtime, hdr):
+            todo.append((src, obj))
+
+    def cc(job):
+        src, obj = job
+        cmd = [HIPCC, *FLAGS, "-c", str(src), "-o", str(obj)]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stdout}\n{r.stderr}")
+        if r.stderr.strip() and verbose:
+            print(r.stderr, file=sys.stderr)
+
+    if todo:
+        with ThreadPoolExecutor(max_workers=min(8, len(todo))) as ex:
+            list(ex.map(cc, todo))
+    if todo or not LIB.exists() or any(o.stat().st_mtime > LIB.stat().st_mtime for o in objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

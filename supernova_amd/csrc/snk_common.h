@@ -1,0 +1,103 @@
+// snk_common.h -- host+device primitives shared by every translation unit of libsnk.
+//
+// Bit-level conventions (reference lib/assembly/src/kmers/KMer.h:153-160,344-350
+// and lib/tada/src/kmer/mod.rs:527-537):
+//   base code A=0 C=1 G=2 T=3, complement = b ^ 3
+//   packed read row : u32 words, base i in word i>>4 at bits [31-2*(i&15) .. 30-2*(i&15)]  (MSB first)
+//   k-mer           : 128-bit value (hi,lo), base i at bits 127-2i..126-2i, low 128-2K bits zero.
+//                     For K=48 the top 96 bits equal KMer<48>'s three u32 words; word-lexicographic
+//                     order == lexicographic order on bases (KMer.h:305-311).
+//   context byte    : pred one-hot <<4 | succ one-hot  (KMerContext.h:27-28,36-37,55-56)
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SNK_HD __host__ __device__ __forceinline__
+#else
+#define SNK_HD static inline
+#endif
+
+// ---------------------------------------------------------------- hashing (counter based RNG + table hash)
+SNK_HD uint64_t snk_mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+SNK_HD uint64_t snk_rng(uint64_t seed, uint64_t stream, uint64_t ctr) {
+    return snk_mix64(seed ^ snk_mix64(stream * 0xD1B54A32D192ED03ull + ctr));
+}
+SNK_HD uint32_t snk_mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+
+// ---------------------------------------------------------------- 128-bit k-mer value
+struct snk_kmer {
+    uint64_t hi, lo;
+};
+SNK_HD bool snk_kmer_lt(snk_kmer a, snk_kmer b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
+SNK_HD bool snk_kmer_eq(snk_kmer a, snk_kmer b) { return a.hi == b.hi && a.lo == b.lo; }
+
+// reverse the 32 two-bit groups of a 64-bit word
+SNK_HD uint64_t snk_rev2(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    x = __brevll(x);
+    return ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+#else
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+    x = ((x >> 8) & 0x00FF00FF00FF00FFull) | ((x & 0x00FF00FF00FF00FFull) << 8);
+    x = ((x >> 16) & 0x0000FFFF0000FFFFull) | ((x & 0x0000FFFF0000FFFFull) << 16);
+    return (x >> 32) | (x << 32);
+#endif
+}
+// reverse complement of a K-base value (K even or odd, K<=64); SURVEY App. A.3
+template <int K>
+SNK_HD snk_kmer snk_kmer_rc(snk_kmer k) {
+    uint64_t a = snk_rev2(~k.lo), b = snk_rev2(~k.hi);  // full 64-group reversal: (a,b)
+    constexpr int S = 128 - 2 * K;                      // drop the reversed padding
+    snk_kmer r;
+    if (S == 0) { r.hi = a; r.lo = b; }
+    else if (S < 64) { r.hi = (a << S) | (b >> (64 - S)); r.lo = b << S; }
+    else if (S == 64) { r.hi = b; r.lo = 0; }
+    else { r.hi = b << (S - 64); r.lo = 0; }
+    return r;
+}
+// append base b on the right (drop the leftmost): KMer::toSuccessor, KMer.h:203-216
+template <int K>
+SNK_HD snk_kmer snk_kmer_succ(snk_kmer k, uint32_t b) {
+    snk_kmer r;
+    r.hi = (k.hi << 2) | (k.lo >> 62);
+    r.lo = (k.lo << 2) | ((uint64_t)b << (128 - 2 * K));
+    if (K <= 32) { r.hi = (k.hi << 2) | ((uint64_t)b << (64 - 2 * K)); r.lo = 0; }
+    return r;
+}
+// prepend base b on the left (drop the rightmost): KMer::toPredecessor, KMer.h:189-201
+template <int K>
+SNK_HD snk_kmer snk_kmer_pred(snk_kmer k, uint32_t b) {
+    snk_kmer r;
+    r.lo = (k.lo >> 2) | (k.hi << 62);
+    r.hi = (k.hi >> 2) | ((uint64_t)b << 62);
+    if (K <= 32) { r.lo = 0; r.hi &= ~((K == 32) ? 0ull : ((1ull << (64 - 2 * K)) - 1)); }
+    else { r.lo &= ~((K == 64) ? 0ull : ((1ull << (128 - 2 * K)) - 1)); }
+    return r;
+}
+template <int K>
+SNK_HD uint32_t snk_kmer_base(snk_kmer k, int i) {
+    return i < 32 ? (uint32_t)(k.hi >> (62 - 2 * i)) & 3u : (uint32_t)(k.lo >> (62 - 2 * (i - 32))) & 3u;
+}
+// reverse-complement a context byte = reverse its 8 bits (KMerContext.cc:19 gRCVals)
+SNK_HD uint32_t snk_ctx_rc(uint32_t c) {
+    c = ((c >> 4) & 0x0F) | ((c & 0x0F) << 4);
+    c = ((c >> 2) & 0x33) | ((c & 0x33) << 2);
+    c = ((c >> 1) & 0x55) | ((c & 0x55) << 1);
+    return c;
+}
+SNK_HD uint64_t snk_kmer_hash(snk_kmer k) { return snk_mix64(k.hi ^ snk_mix64(k.lo + 0x632BE59BD9B4E019ull)); }
+
+// base i of a packed row
+SNK_HD uint32_t snk_row_base(const uint32_t* row, int i) { return (row[i >> 4] >> (30 - 2 * (i & 15))) & 3u; }

@@ -1,0 +1,36 @@
+// snk_ctx.h -- library-internal context: device, streams, error reporting, scratch arena.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/snk.h"
+
+struct snk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;   // library-owned default stream
+    int n_cu = 256;
+    size_t lds_per_block = 65536;
+    // bump arena for call-scoped scratch (reset at the start of each top-level call)
+    std::vector<void*> blocks;
+    size_t total_alloc = 0;
+};
+
+void snk_set_error(char* err, size_t errcap, const char* fmt, ...);
+int snk_fail(int code, char* err, size_t errcap, const char* fmt, ...);
+
+#define SNK_HIP_TRY(expr)                                                                          \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return snk_fail(_e == hipErrorOutOfMemory ? SNK_E_NOMEM : SNK_E_HIP, err, errcap,      \
+                            "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+// scratch allocation owned by the ctx; freed by snk_ctx_release_scratch / destroy
+int snk_ctx_alloc(snk_ctx* ctx, size_t bytes, void** out, char* err, size_t errcap);
+void snk_ctx_release_scratch(snk_ctx* ctx);

@@ -1,0 +1,80 @@
+"""ctypes binding of libsnk.so (the C ABI declared in include/snk.h).
+
+This is what a reference-side maintainer's ctypes/cffi stub would look like; the
+package's host logic sits on top of it.  There is no CPU fallback: if the shared object is missing
+or no gfx950 device is visible, calls fail loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libsnk.so"
+
+
+class SnkError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libsnk error {code}: {msg}")
+        self.code = code
+
+
+class SnkParams(C.Structure):
+    _fields_ = [("K", C.c_uint32), ("min_qual", C.c_uint32), ("min_freq", C.c_uint32), ("min_bc", C.c_uint32),
+                ("n_buckets", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class SnkSynthParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("n_reads", C.c_uint64), ("genome_len", C.c_uint64), ("read_len", C.c_uint32),
+                ("mol_len", C.c_uint32), ("mols_per_bc", C.c_uint32), ("pairs_per_bc", C.c_uint32),
+                ("insert_min", C.c_uint32), ("insert_span", C.c_uint32), ("sub_ppm", C.c_uint32),
+                ("unbarcoded_ppm", C.c_uint32), ("lowq_tail_ppm", C.c_uint32), ("tail_max", C.c_uint32),
+                ("err_cdf", C.c_uint32 * 4)]
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libsnk.so (built in-tree by supernova_amd.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise FileNotFoundError(
+            f"{LIB_PATH} is missing: run `python -m supernova_amd.build` (hipcc, gfx950). "
+            "supernova_amd has no CPU fallback.")
+    lib = C.CDLL(str(LIB_PATH))
+    _declare(lib)
+    _lib = lib
+    return lib
+
+
+def _declare(lib: C.CDLL) -> None:
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
+    cp, sz = C.c_char_p, C.c_size_t
+    P = C.POINTER
+    sig = {
+        "snk_version": (cp, []),
+        "snk_last_error": (cp, []),
+        "snk_params_default": (None, [P(SnkParams)]),
+        "snk_ctx_create": (C.c_int, [C.c_int, P(vp), cp, sz]),
+        "snk_ctx_destroy": (None, [vp]),
+        "snk_synth_default": (None, [P(SnkSynthParams), u64, u64, C.c_int]),
+        "snk_synth_host": (C.c_int, [P(SnkSynthParams), u64, u64, vp, u32, vp, u32, vp]),
+        "snk_synth_dev": (C.c_int, [vp, P(SnkSynthParams), u64, u64, vp, u32, vp, u32, vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    lib._snk_declared = tuple(sig)
+
+
+def check(code: int) -> None:
+    if code != 0:
+        raise SnkError(code, load().snk_last_error().decode(errors="replace"))
+
+
+def exported_symbols() -> tuple[str, ...]:
+    return load()._snk_declared

@@ -1,0 +1,53 @@
+"""Test-side I/O for the executable reference oracle (oracle/_ref/snref_driver) and golden fixtures.
+
+SNKRD001 input file (little endian): magic[8], u64 n, u32 stride, u32 has_bc, i64 ign_bc_below,
+u16 len[n], u8 bases_ascii[n*stride], u8 quals[n*stride], i32 bc[n].
+"""
+from __future__ import annotations
+
+import json
+import struct
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+REF_DRIVER = ROOT / "oracle" / "_ref" / "snref_driver"
+GOLDEN = ROOT / "tests" / "golden"
+
+KREC = np.dtype([("k", "<u4", 3), ("count", "<u4"), ("ctx", "u1"), ("pad", "u1", 3)])
+
+
+def write_snkrd(path, lens, bases_ascii, quals, bc=None, ign_bc_below=0):
+    n, stride = bases_ascii.shape
+    with open(path, "wb") as f:
+        f.write(b"SNKRD001")
+        f.write(struct.pack("<QIIq", n, stride, 1 if bc is not None else 0, ign_bc_below))
+        f.write(np.asarray(lens, dtype="<u2").tobytes())
+        f.write(np.ascontiguousarray(bases_ascii, dtype=np.uint8).tobytes())
+        f.write(np.ascontiguousarray(quals, dtype=np.uint8).tobytes())
+        if bc is not None:
+            f.write(np.asarray(bc, dtype="<i4").tobytes())
+
+
+def run_ref(snkrd, outdir, threads=8, mode="dump", min_qual=7, min_freq=3, min_bc=2, timeout=3600):
+    outdir = Path(outdir)
+    outdir.mkdir(parents=True, exist_ok=True)
+    r = subprocess.run([str(REF_DRIVER), str(snkrd), str(outdir), str(threads), mode, str(min_qual), str(min_freq),
+                        str(min_bc)], capture_output=True, text=True, timeout=timeout)
+    if r.returncode != 0:
+        raise RuntimeError(f"snref_driver failed ({r.returncode}):\n{r.stdout[-4000:]}\n{r.stderr[-4000:]}")
+    return r.stdout
+
+
+def read_ref_dump(outdir):
+    outdir = Path(outdir)
+    out = {}
+    out["goodlens"] = np.fromfile(outdir / "goodlens.u32", dtype="<u4")
+    out["kmers"] = np.fromfile(outdir / "kmers.bin", dtype=KREC)
+    out["unitigs"] = (outdir / "unitigs.txt").read_text().split()
+    out["hbv"] = (outdir / "hbv.txt").read_text()
+    hist = outdir / "stats" / "histogram_kmer_count.json"
+    out["hist"] = json.loads(hist.read_text()) if hist.exists() else None
+    return out
