@@ -1,0 +1,40 @@
+"""Load golden cases (tests/golden/*.npz, produced by the reference via make_golden.py)."""
+from __future__ import annotations
+
+from pathlib import Path
+
+import numpy as np
+
+from supernova_amd import synth
+
+GOLD = Path(__file__).resolve().parent / "golden"
+CASES = ["synth_2k_err", "synth_6k_clean", "synth_20k_err", "adversarial"]
+
+
+class Case:
+    def __init__(self, name: str):
+        z = np.load(GOLD / f"{name}.npz")
+        self.name = name
+        self.lens = z["lens"]
+        self.rows = z["rows"]
+        self.quals = z["quals"]
+        self.bc = z["bc"]
+        self.ign_bc_below = int(z["ign_bc_below"])
+        self.read_len = self.quals.shape[1]
+        self.codes = synth.unpack_rows(self.rows, self.read_len)
+        self.exp_goodlens = z["exp_goodlens"]
+        self.exp_keys = z["exp_keys"]          # [n,3] u32
+        self.exp_counts = z["exp_counts"]
+        self.exp_ctx = z["exp_ctx"]
+        self.exp_unitigs = bytes(z["exp_unitigs"]).decode().split("\n") if len(z["exp_unitigs"]) else []
+        self.exp_hbv = bytes(z["exp_hbv"]).decode()
+        self.exp_hist = z["exp_hist"]
+
+
+_cache: dict[str, Case] = {}
+
+
+def load(name: str) -> Case:
+    if name not in _cache:
+        _cache[name] = Case(name)
+    return _cache[name]

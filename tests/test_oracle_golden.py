@@ -1,0 +1,107 @@
+"""Pin the CPU oracle (oracle/snk_oracle.c) against the reference's own outputs and known-answer tests.
+
+Golden vectors: tests/golden/*.npz, dumped from the reference binary (path B, lib/assembly) by
+tests/golden/make_golden.py.  Known-answer tests restated from the reference's Rust unit tests.
+"""
+import numpy as np
+import pytest
+
+import goldens
+import oracle_lib
+
+
+@pytest.mark.parametrize("name", goldens.CASES)
+def test_oracle_matches_reference(name):
+    c = goldens.load(name)
+    gl = oracle_lib.good_lens(c.quals, c.lens, K=48, min_qual=7)
+    assert np.array_equal(gl, c.exp_goodlens)
+    o = oracle_lib.OracleResult(c.codes, gl, c.bc, K=48, min_freq=3, min_bc=2, ign_bc_below=c.ign_bc_below)
+    assert o.keys.shape[0] == c.exp_keys.shape[0]
+    assert np.array_equal(o.keys[:, :3], c.exp_keys)
+    assert np.all(o.keys[:, 3] == 0)
+    assert np.array_equal(np.minimum(o.counts, (1 << 24) - 1), c.exp_counts)   # B saturates at 2^24-1 (ReadPather.h:128-129)
+    assert np.array_equal(o.ctx, c.exp_ctx)
+    assert o.unitigs == c.exp_unitigs
+    assert o.hbv_text() == c.exp_hbv
+    hist = np.bincount(np.minimum(o.counts, (1 << 24) - 1)) if len(o.counts) else np.zeros(0, np.int64)
+    assert np.array_equal(hist, c.exp_hist)       # stats/histogram_kmer_count.json (BuildReadQGraph48.cc:199-216)
+
+
+def test_qv_trim_read_kat():
+    """lib/tada/src/cmd_msp.rs:329-350 test_qv_trim_read (min_qual 10, K=48), expectation formula at :347."""
+    quals = np.frombuffer(
+        b"FFFFFFFFIFFFFFFFFFFIIIFFBFIFFFFIFBFFIBFIFBBFFIFFIFFFFFFFFFFFBBBBBBBBBB07BB7BB<BBBBBBBBBB", dtype=np.uint8)
+    K = 48
+    n = len(quals)
+    for i in range(n):
+        q = quals.copy()
+        q[i] = 34
+        got = int(oracle_lib.good_lens((q - 33)[None, :], n, K=K, min_qual=10)[0])
+        exp = n if i < n - K else (i if i >= K else 0)
+        assert got == exp, (i, got, exp)
+
+
+def test_msp_slices_cover_all_kmers():
+    """lib/tada/src/msp/mod.rs:202-220 test_slice: union of k-mers over MSP slices == all k-mers (k=50,p=8)."""
+    rng = np.random.default_rng(7)
+    k, p = 50, 8
+    perm = rng.permutation(1 << (2 * p)).astype(np.uint32)
+    for it in range(50):
+        seq = rng.integers(0, 4, int(rng.integers(k, 400)), dtype=np.uint8)
+        sl = oracle_lib.msp_scan(k, p, seq, perm)
+        s = bytes(seq)
+        allk = {s[i:i + k] for i in range(len(s) - k + 1)}
+        got = set()
+        for (_v, mp, st, ln) in sl:
+            assert ln >= k and ln <= 2 * k - p
+            assert st <= mp and mp + p <= st + ln
+            for i in range(st, st + ln - k + 1):
+                got.add(s[i:i + k])
+        assert got == allk
+
+
+def test_msp_shard_consistency():
+    """lib/tada/src/kmer/mod.rs:1102-1150 check_consistent_shard: a k-mer (either strand) always gets the same value."""
+    rng = np.random.default_rng(11)
+    k, p = 48, 8
+    perm = rng.permutation(1 << (2 * p)).astype(np.uint32)
+    seen = {}
+    base = rng.integers(0, 4, 300, dtype=np.uint8)
+    for it in range(60):
+        seq = base.copy()
+        for _ in range(3):
+            seq[int(rng.integers(0, len(seq)))] = rng.integers(0, 4)
+        if it & 1:
+            seq = (3 - seq[::-1]).astype(np.uint8)
+        s = bytes(seq)
+        for (v, _mp, st, ln) in oracle_lib.msp_scan(k, p, seq, perm):
+            for i in range(st, st + ln - k + 1):
+                km = s[i:i + k]
+                rc = bytes(3 - b for b in reversed(km))
+                key = min(km, rc)
+                assert seen.setdefault(key, v) == v
+
+
+def test_bv_roundtrip(tmp_path):
+    """.bv hand-off format round trip (lib/tada/src/sim_tests.rs:142-179; debruijn.rs:895-929)."""
+    import ctypes as C
+    lib = oracle_lib.load()
+    c = goldens.load("adversarial")
+    o = oracle_lib.OracleResult(c.codes, c.exp_goodlens, c.bc, ign_bc_below=c.ign_bc_below, hbv=False)
+    u = oracle_lib.Unitigs()
+    off = np.ascontiguousarray(o.unitig_off, dtype=np.uint64)
+    b = np.ascontiguousarray(o.unitig_bases, dtype=np.uint8)
+    u.n = len(o.unitigs)
+    u.off = off.ctypes.data_as(C.POINTER(C.c_uint64))
+    u.bases = b.ctypes.data_as(C.POINTER(C.c_uint8))
+    path = str(tmp_path / "x.bv").encode()
+    assert lib.sno_write_bv(path, C.byref(u)) == 0
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"BINWRITE" and int.from_bytes(raw[8:16], "little") == len(o.unitigs)
+    v = oracle_lib.Unitigs()
+    assert lib.sno_read_bv(path, C.byref(v)) == 0
+    assert v.n == u.n
+    off2 = np.ctypeslib.as_array(v.off, shape=(v.n + 1,))
+    assert np.array_equal(off2, off)
+    assert np.array_equal(np.ctypeslib.as_array(v.bases, shape=(int(off[-1]),)), b)
+    lib.sno_unitigs_free(C.byref(v))
