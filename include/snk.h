@@ -90,6 +90,66 @@ int snk_synth_host(const snk_synth_params* sp, uint64_t first, uint64_t n, uint3
 int snk_synth_dev(snk_ctx* ctx, const snk_synth_params* sp, uint64_t first, uint64_t n, void* d_rows,
                   uint32_t row_words, void* d_quals, uint32_t qstride, void* d_bc, void* stream);
 
+
+/* ---- device-resident path -------------------------------------------------------------------------- */
+/* K1: replaces GoodLenTailFinder (BuildReadQGraph48.cc:65-89) / find_trim_len (lib/tada/src/cmd_msp.rs:129-146).
+ * d_quals: n_reads rows of qstride bytes (raw phred, no +33); d_lens: u16 per read or NULL (= read_len);
+ * d_good_len: u16 per read out. */
+int snk_dev_trim(snk_ctx* ctx, const void* d_quals, uint32_t qstride, const void* d_lens, uint32_t read_len,
+                 uint64_t n_reads, uint32_t K, uint32_t min_qual, void* d_good_len, void* stream);
+/* K2: replaces base_to_bits (lib/tada/src/kmer/mod.rs:311-319): ASCII rows -> packed 2-bit rows. */
+int snk_dev_pack_ascii(snk_ctx* ctx, const void* d_ascii, uint32_t astride, uint32_t read_len, uint64_t n_reads,
+                       void* d_rows, uint32_t row_words, void* stream);
+
+typedef struct snk_dev_reads {
+    uint64_t n_reads;
+    const void* rows;         /* u32[n_reads*row_words] packed bases (HBM) */
+    uint32_t row_words;
+    uint32_t read_len;        /* <= 256 */
+    const void* lens;         /* u16[n_reads] or NULL (all reads are read_len long) */
+    const void* quals;        /* u8[n_reads*qstride] raw phred, or NULL if good_len is given */
+    uint32_t qstride;
+    uint32_t reserved0;
+    const void* good_len;     /* u16[n_reads] precomputed trim, or NULL */
+    const void* bc;           /* i32[n_reads] barcode ids, or NULL (no barcode rule) */
+    int64_t ign_bc_below;     /* reads with global index < this get bc = -1 (BuildReadQGraph48.cc:158-159) */
+    uint64_t read_index_base; /* global index of read 0 of this slab (multi-GPU slabs) */
+} snk_dev_reads;
+
+/* All pointers are device pointers owned by the context; they stay valid until the next
+ * snk_dev_count_graph call on the same context or snk_ctx_destroy. */
+typedef struct snk_dev_result {
+    uint64_t n_reads;
+    uint64_t n_instances;        /* sum over reads of max(0, good_len-K+1), reads with good_len < K+1 excluded */
+    uint64_t n_supermers;
+    uint64_t n_buckets;
+    const void* good_len;        /* u16[n_reads] */
+    uint64_t n_kmers;            /* retained canonical k-mers */
+    const void* keys;            /* n_kmers x 16 bytes: little-endian 128-bit value = {u64 lo, u64 hi}; base i of the
+                                    k-mer at bits 127-2i..126-2i; ascending */
+    const void* counts;          /* u32[n_kmers] */
+    const void* ctx;             /* u8[n_kmers] pruned context bytes */
+    const void* spectrum;        /* u64[spectrum_bins]: retained k-mers per count (histogram_kmer_count.json) */
+    uint32_t spectrum_bins;
+    uint32_t n_circles;
+    uint64_t n_unitigs;
+    uint64_t unitig_total_bases;
+    const void* unitig_off;      /* u64[n_unitigs+1] */
+    const void* unitig_bases;    /* u8 base codes, canonical orientation, unitigs ordered by their head k-mer */
+    uint32_t rank_rounds;
+    uint32_t buckets_split;
+    uint32_t max_slots_used;
+    uint32_t reserved1;
+    uint64_t scratch_bytes;
+    float phase_ms[8];           /* trim, msp histogram, msp scatter, count, sort, prune+unitigs, -, total */
+} snk_dev_result;
+
+/* Replaces the body of buildReadQGraph48 (BuildReadQGraph48.cc:1688-1774, pPaths==nullptr) up to and
+ * including buildEdges; == tada MSP -> SHARD_ASM -> MAIN_ASM_SN.  Inputs already resident in HBM. */
+int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const snk_params* p, snk_dev_result* out, void* stream,
+                        char* err, size_t errcap);
+int snk_dev_download(snk_ctx* ctx, const void* d_src, void* h_dst, size_t bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,7 +57,7 @@ extern "C" int snk_ctx_create(int device, snk_ctx** out, char* err, size_t errca
     snk_ctx* c = new snk_ctx();
     c->device = device;
     c->n_cu = prop.multiProcessorCount;
-    hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    hipError_t se = hipStreamCreate(&c->stream);   // blocking stream: ordered after work on the legacy default stream
     if (se != hipSuccess) {
         delete c;
         return snk_fail(SNK_E_HIP, err, errcap, "hipStreamCreate failed: %s", hipGetErrorString(se));

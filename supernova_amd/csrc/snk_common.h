@@ -55,15 +55,26 @@ SNK_HD uint64_t snk_rev2(uint64_t x) {
     return (x >> 32) | (x << 32);
 #endif
 }
+SNK_HD uint32_t snk_rev2_32(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    x = __brev(x);
+    return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+#else
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+    x = ((x >> 8) & 0x00FF00FFu) | ((x & 0x00FF00FFu) << 8);
+    return (x >> 16) | (x << 16);
+#endif
+}
 // reverse complement of a K-base value (K even or odd, K<=64); SURVEY App. A.3
 template <int K>
 SNK_HD snk_kmer snk_kmer_rc(snk_kmer k) {
     uint64_t a = snk_rev2(~k.lo), b = snk_rev2(~k.hi);  // full 64-group reversal: (a,b)
     constexpr int S = 128 - 2 * K;                      // drop the reversed padding
     snk_kmer r;
-    if (S == 0) { r.hi = a; r.lo = b; }
-    else if (S < 64) { r.hi = (a << S) | (b >> (64 - S)); r.lo = b << S; }
-    else if (S == 64) { r.hi = b; r.lo = 0; }
+    if constexpr (S == 0) { r.hi = a; r.lo = b; }
+    else if constexpr (S < 64) { r.hi = (a << S) | (b >> (64 - S)); r.lo = b << S; }
+    else if constexpr (S == 64) { r.hi = b; r.lo = 0; }
     else { r.hi = b << (S - 64); r.lo = 0; }
     return r;
 }
@@ -71,9 +82,8 @@ SNK_HD snk_kmer snk_kmer_rc(snk_kmer k) {
 template <int K>
 SNK_HD snk_kmer snk_kmer_succ(snk_kmer k, uint32_t b) {
     snk_kmer r;
-    r.hi = (k.hi << 2) | (k.lo >> 62);
-    r.lo = (k.lo << 2) | ((uint64_t)b << (128 - 2 * K));
-    if (K <= 32) { r.hi = (k.hi << 2) | ((uint64_t)b << (64 - 2 * K)); r.lo = 0; }
+    if constexpr (K <= 32) { r.hi = (k.hi << 2) | ((uint64_t)b << (64 - 2 * K)); r.lo = 0; }
+    else { r.hi = (k.hi << 2) | (k.lo >> 62); r.lo = (k.lo << 2) | ((uint64_t)b << (128 - 2 * K)); }
     return r;
 }
 // prepend base b on the left (drop the rightmost): KMer::toPredecessor, KMer.h:189-201
@@ -82,8 +92,9 @@ SNK_HD snk_kmer snk_kmer_pred(snk_kmer k, uint32_t b) {
     snk_kmer r;
     r.lo = (k.lo >> 2) | (k.hi << 62);
     r.hi = (k.hi >> 2) | ((uint64_t)b << 62);
-    if (K <= 32) { r.lo = 0; r.hi &= ~((K == 32) ? 0ull : ((1ull << (64 - 2 * K)) - 1)); }
-    else { r.lo &= ~((K == 64) ? 0ull : ((1ull << (128 - 2 * K)) - 1)); }
+    if constexpr (K < 32) { r.lo = 0; r.hi &= ~((1ull << (64 - 2 * K)) - 1); }
+    else if constexpr (K == 32) { r.lo = 0; }
+    else if constexpr (K < 64) { r.lo &= ~((1ull << (128 - 2 * K)) - 1); }
     return r;
 }
 template <int K>
@@ -97,7 +108,26 @@ SNK_HD uint32_t snk_ctx_rc(uint32_t c) {
     c = ((c >> 1) & 0x55) | ((c & 0x55) << 1);
     return c;
 }
-SNK_HD uint64_t snk_kmer_hash(snk_kmer k) { return snk_mix64(k.hi ^ snk_mix64(k.lo + 0x632BE59BD9B4E019ull)); }
+// two independent 32-bit hashes of a k-mer value (murmur3-style word mixing, separate seeds/finalisers)
+SNK_HD uint32_t snk_rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+SNK_HD void snk_kmer_hash2(snk_kmer k, uint32_t* h1out, uint32_t* h2out) {
+    uint32_t w[4] = {(uint32_t)(k.hi >> 32), (uint32_t)k.hi, (uint32_t)(k.lo >> 32), (uint32_t)k.lo};
+    uint32_t h1 = 0x9747b28cu, h2 = 0x3c6ef372u;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 4; ++i) {
+        uint32_t x = w[i] * 0xcc9e2d51u;
+        x = snk_rotl32(x, 15);
+        uint32_t y = x * 0x1b873593u;
+        h1 ^= y;
+        h1 = snk_rotl32(h1, 13) * 5u + 0xe6546b64u;
+        h2 ^= snk_rotl32(x, 7) * 0x85ebca77u;
+        h2 = snk_rotl32(h2, 11) * 5u + 0x561ccd1bu;
+    }
+    *h1out = snk_mix32(h1);
+    *h2out = snk_mix32(h2 ^ 0xdeadbeefu);
+}
 
 // base i of a packed row
 SNK_HD uint32_t snk_row_base(const uint32_t* row, int i) { return (row[i >> 4] >> (30 - 2 * (i & 15))) & 3u; }

@@ -1,0 +1,34 @@
+// snk_kernels.h -- internal launch interfaces between the translation units of libsnk.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "snk_common.h"
+
+#define SNK_M 16  // minimiser length (bases)
+
+typedef unsigned __int128 snk_u128;
+
+// ---- snk_msp.hip
+size_t snk_msp_lds_bytes(uint32_t K, uint32_t M, uint32_t row_words);
+int snk_launch_msp(uint32_t K, bool scatter, hipStream_t st, const uint32_t* rows, uint32_t row_words,
+                   const uint16_t* good_len, const int32_t* bc, int64_t ign_bc_below, uint64_t read_index_base,
+                   uint64_t n_reads, uint32_t NB, uint32_t* hist_or_cursor, void* records, unsigned long long* n_inst,
+                   char* err, size_t errcap);
+
+// ---- snk_count.hip
+struct snk_count_args {
+    const uint4* records;          // supermer records, 2 x uint4 each
+    const uint64_t* seg_off;       // [nseg][NB+1] absolute record offsets of every bucket in every segment
+    uint32_t nseg;
+    uint32_t NB;
+    uint32_t min_freq;
+    uint32_t bc_mode;              // 0: no barcode rule, 1: >=1 barcode>0 (or ignore-rule read), 2: >=2 distinct
+    snk_u128* out_keys;            // canonical k-mer values (hi<<64|lo)
+    uint64_t* out_vals;            // count << 8 | raw context byte
+    uint64_t out_cap;
+    unsigned long long* out_cursor;
+    uint32_t* status;              // [0] output overflow, [1] split depth exceeded, [2] buckets split, [3] max slots used
+};
+int snk_launch_count(uint32_t K, hipStream_t st, const snk_count_args& a, char* err, size_t errcap);
+uint32_t snk_count_slots(uint32_t K);   // LDS table slots per workgroup

@@ -1,0 +1,110 @@
+// snk_trim.hip -- K1 quality trim and K2 ASCII -> 2-bit packing.
+//
+// K1 replaces GoodLenTailFinder (lib/assembly/src/paths/long/BuildReadQGraph48.cc:65-89) ==
+//    find_trim_len (lib/tada/src/cmd_msp.rs:129-146): scanning from the 3' end, the first run of K
+//    consecutive quals >= min_qual ends the scan; good length = run start + K, else 0.
+// K2 replaces base_to_bits (lib/tada/src/kmer/mod.rs:311-319) / the N->A rule of
+//    10X/ParseBarcodedFastqs.cc:87-88.
+//
+// Both are HBM-streaming byte kernels.  K1 reads only the tail of each quality row that the scan
+// really needs (a clean read stops after K bytes), in 4-byte words.
+#include "snk_ctx.h"
+#include "snk_common.h"
+
+__global__ void __launch_bounds__(256) snk_trim_kernel(const uint8_t* __restrict__ quals, uint32_t qstride,
+                                                       const uint16_t* __restrict__ lens, uint32_t read_len,
+                                                       uint64_t n_reads, uint32_t K, uint32_t min_qual,
+                                                       uint16_t* __restrict__ good_len) {
+    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint8_t* q = quals + r * (uint64_t)qstride;
+    int len = lens ? lens[r] : (int)read_len;
+    uint32_t good = 0;
+    int result = 0;
+    int i = len;
+    // unaligned head (from the end) byte-wise until i is a multiple of 4 relative to the row base alignment
+    const bool row_aligned = ((qstride & 3u) == 0) && ((((uintptr_t)quals) & 3u) == 0);
+    if (row_aligned) {
+        while (i > 0 && (i & 3)) {
+            --i;
+            if (q[i] < min_qual) good = 0;
+            else if (++good == K) { result = i + (int)K; i = -1; break; }
+        }
+        while (i >= 4) {
+            uint32_t w = *reinterpret_cast<const uint32_t*>(q + i - 4);
+            bool done = false;
+#pragma unroll
+            for (int b = 3; b >= 0; --b) {
+                uint32_t v = (w >> (8 * b)) & 0xFFu;
+                if (!done) {
+                    if (v < min_qual) good = 0;
+                    else if (++good == K) { result = i - 4 + b + (int)K; done = true; }
+                }
+            }
+            if (done) { i = -1; break; }
+            i -= 4;
+        }
+    }
+    while (i > 0) {
+        --i;
+        if (q[i] < min_qual) good = 0;
+        else if (++good == K) { result = i + (int)K; break; }
+    }
+    good_len[r] = (uint16_t)result;
+}
+
+extern "C" int snk_dev_trim(snk_ctx* ctx, const void* d_quals, uint32_t qstride, const void* d_lens, uint32_t read_len,
+                            uint64_t n_reads, uint32_t K, uint32_t min_qual, void* d_good_len, void* stream) {
+    char* err = nullptr;
+    size_t errcap = 0;
+    if (!ctx || !d_quals || !d_good_len) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_trim: NULL argument");
+    if (read_len > 65535 || qstride < read_len) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_trim: bad read_len/qstride");
+    if (n_reads == 0) return SNK_OK;
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    uint64_t nb = (n_reads + 255) / 256;
+    hipLaunchKernelGGL(snk_trim_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const uint8_t*)d_quals, qstride,
+                       (const uint16_t*)d_lens, read_len, n_reads, K, min_qual, (uint16_t*)d_good_len);
+    SNK_HIP_TRY(hipGetLastError());
+    return SNK_OK;
+}
+
+// one thread per output word (16 bases)
+__global__ void __launch_bounds__(256) snk_pack_kernel(const uint8_t* __restrict__ ascii, uint32_t astride,
+                                                       uint32_t read_len, uint64_t n_reads, uint32_t* __restrict__ rows,
+                                                       uint32_t row_words) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t total = n_reads * row_words;
+    if (t >= total) return;
+    uint64_t r = t / row_words;
+    uint32_t w = (uint32_t)(t - r * row_words);
+    const uint8_t* a = ascii + r * (uint64_t)astride;
+    uint32_t v = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 16; ++j) {
+        uint32_t i = w * 16 + j;
+        uint32_t code = 0;
+        if (i < read_len) {
+            uint8_t c = a[i];
+            code = (c == 'C') ? 1u : (c == 'G') ? 2u : (c == 'T') ? 3u : 0u;
+        }
+        v = (v << 2) | code;
+    }
+    rows[t] = v;
+}
+
+extern "C" int snk_dev_pack_ascii(snk_ctx* ctx, const void* d_ascii, uint32_t astride, uint32_t read_len,
+                                  uint64_t n_reads, void* d_rows, uint32_t row_words, void* stream) {
+    char* err = nullptr;
+    size_t errcap = 0;
+    if (!ctx || !d_ascii || !d_rows) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_pack_ascii: NULL argument");
+    if (row_words * 16 < read_len || astride < read_len)
+        return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_pack_ascii: stride too small");
+    if (n_reads == 0) return SNK_OK;
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    uint64_t total = n_reads * row_words;
+    uint64_t nb = (total + 255) / 256;
+    hipLaunchKernelGGL(snk_pack_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const uint8_t*)d_ascii, astride, read_len,
+                       n_reads, (uint32_t*)d_rows, row_words);
+    SNK_HIP_TRY(hipGetLastError());
+    return SNK_OK;
+}

@@ -1,0 +1,186 @@
+"""Host-side engine: one process per GPU, device memory and streams through torch, compute in libsnk.
+
+`Engine.count_graph` is the Python face of the C++ entry the reference exposes for this path,
+buildReadQGraph48 (lib/assembly/src/paths/long/BuildReadQGraph48.h:24-34): same thresholds
+(minQual, minFreq, minBC, ignBcBelow), same outputs (retained k-mer dictionary with pruned contexts,
+canonical unitigs), with reads resident in HBM.  No CPU fallback: without libsnk.so or without a
+gfx950 device every call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+
+PHASES = ("trim", "msp_hist", "msp_scatter", "count", "sort", "graph", "-", "total")
+
+
+@dataclass
+class Params:
+    K: int = 48
+    min_qual: int = 7      # lib/tada/mro/_asm_sn.mro:15, 10X/DF.cc:141
+    min_freq: int = 3      # mro/_assembler.mro:44, 10X/DF.cc:139
+    min_bc: int = 2        # 10X/DF.cc:140
+    n_buckets: int = 0
+    graph: bool = True
+
+    def to_c(self) -> _lib.SnkParams:
+        p = _lib.SnkParams()
+        p.K, p.min_qual, p.min_freq, p.min_bc = self.K, self.min_qual, self.min_freq, self.min_bc
+        p.n_buckets = self.n_buckets
+        p.flags = 0 if self.graph else 1
+        return p
+
+
+class Result:
+    """Device-resident result of one count_graph call (valid until the next call on the same engine)."""
+
+    def __init__(self, engine: "Engine", raw: _lib.SnkDevResult, K: int):
+        self._e = engine
+        self.raw = raw
+        self.K = K
+        for f in ("n_reads", "n_instances", "n_supermers", "n_buckets", "n_kmers", "n_unitigs", "unitig_total_bases",
+                  "n_circles", "rank_rounds", "buckets_split", "max_slots_used", "scratch_bytes"):
+            setattr(self, f, int(getattr(raw, f)))
+        self.phase_ms = {PHASES[i]: float(raw.phase_ms[i]) for i in range(8) if PHASES[i] != "-"}
+
+    def _dl(self, ptr, nbytes, dtype, shape):
+        out = np.empty(shape, dtype=dtype)
+        if nbytes:
+            self._e._download(ptr, out.ctypes.data, nbytes)
+        return out
+
+    def good_len(self) -> np.ndarray:
+        return self._dl(self.raw.good_len, self.n_reads * 2, np.uint16, (self.n_reads,))
+
+    def keys(self) -> np.ndarray:
+        """[n_kmers, 4] u32 words MSB-first (include/snk.h key convention), ascending."""
+        lohi = self._dl(self.raw.keys, self.n_kmers * 16, np.uint64, (self.n_kmers, 2))
+        lo, hi = lohi[:, 0], lohi[:, 1]
+        w = np.empty((self.n_kmers, 4), dtype=np.uint32)
+        w[:, 0] = hi >> np.uint64(32)
+        w[:, 1] = hi & np.uint64(0xFFFFFFFF)
+        w[:, 2] = lo >> np.uint64(32)
+        w[:, 3] = lo & np.uint64(0xFFFFFFFF)
+        return w
+
+    def counts(self) -> np.ndarray:
+        return self._dl(self.raw.counts, self.n_kmers * 4, np.uint32, (self.n_kmers,))
+
+    def ctx(self) -> np.ndarray:
+        return self._dl(self.raw.ctx, self.n_kmers, np.uint8, (self.n_kmers,))
+
+    def spectrum(self) -> np.ndarray:
+        nb = int(self.raw.spectrum_bins)
+        return self._dl(self.raw.spectrum, nb * 8, np.uint64, (nb,))
+
+    def unitig_arrays(self):
+        off = self._dl(self.raw.unitig_off, (self.n_unitigs + 1) * 8, np.uint64, (self.n_unitigs + 1,))
+        bases = self._dl(self.raw.unitig_bases, self.unitig_total_bases, np.uint8, (self.unitig_total_bases,))
+        return off, bases
+
+    def unitigs(self) -> list[str]:
+        """Canonical unitigs sorted by (length desc, lexicographic) = BVComp, HBVFromEdges.cc:106-111."""
+        off, bases = self.unitig_arrays()
+        asc = np.frombuffer(b"ACGT", dtype=np.uint8)[bases].tobytes().decode()
+        us = [asc[int(off[i]):int(off[i + 1])] for i in range(self.n_unitigs)]
+        us.sort(key=lambda s: (-len(s), s))
+        return us
+
+
+class Engine:
+    def __init__(self, device: int | None = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("supernova_amd.Engine needs a gfx950 GPU (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        self.lib = _lib.load()
+        self.device = torch.cuda.current_device() if device is None else device
+        h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = self.lib.snk_ctx_create(self.device, C.byref(h), err, 512)
+        if rc != 0:
+            raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+        self._ctx = h
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self.lib.snk_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _download(self, dptr, hptr, nbytes):
+        _lib.check(self.lib.snk_dev_download(self._ctx, dptr, hptr, nbytes, self._stream()))
+
+    # ---- synthetic reads straight into HBM
+    def synth(self, sp: _lib.SnkSynthParams, first: int = 0, n: int | None = None, qstride: int | None = None):
+        n = sp.n_reads - first if n is None else n
+        rw = (sp.read_len + 15) // 16
+        qs = qstride or ((sp.read_len + 15) // 16 * 16)
+        dev = torch.device("cuda", self.device)
+        rows = torch.empty((n, rw), dtype=torch.int32, device=dev)
+        quals = torch.empty((n, qs), dtype=torch.uint8, device=dev)
+        bc = torch.empty((n,), dtype=torch.int32, device=dev)
+        _lib.check(self.lib.snk_synth_dev(self._ctx, C.byref(sp), first, n, rows.data_ptr(), rw, quals.data_ptr(), qs,
+                                          bc.data_ptr(), self._stream()))
+        return rows, quals, bc
+
+    def trim(self, quals: torch.Tensor, read_len: int, K: int = 48, min_qual: int = 7, lens: torch.Tensor | None = None):
+        n, qs = quals.shape
+        out = torch.empty((n,), dtype=torch.int16, device=quals.device)
+        _lib.check(self.lib.snk_dev_trim(self._ctx, quals.data_ptr(), qs, lens.data_ptr() if lens is not None else None,
+                                         read_len, n, K, min_qual, out.data_ptr(), self._stream()))
+        return out
+
+    def pack_ascii(self, ascii_rows: torch.Tensor, read_len: int):
+        n, stride = ascii_rows.shape
+        rw = (read_len + 15) // 16
+        rows = torch.empty((n, rw), dtype=torch.int32, device=ascii_rows.device)
+        _lib.check(self.lib.snk_dev_pack_ascii(self._ctx, ascii_rows.data_ptr(), stride, read_len, n, rows.data_ptr(), rw,
+                                               self._stream()))
+        return rows
+
+    def count_graph(self, rows: torch.Tensor, read_len: int, quals: torch.Tensor | None = None,
+                    bc: torch.Tensor | None = None, lens: torch.Tensor | None = None,
+                    good_len: torch.Tensor | None = None, params: Params | None = None, ign_bc_below: int = 0,
+                    read_index_base: int = 0) -> Result:
+        params = params or Params()
+        assert rows.is_cuda and rows.dtype == torch.int32 and rows.is_contiguous()
+        r = _lib.SnkDevReads()
+        r.n_reads = rows.shape[0]
+        r.rows = rows.data_ptr()
+        r.row_words = rows.shape[1]
+        r.read_len = read_len
+        if lens is not None:
+            assert lens.dtype == torch.int16 and lens.is_cuda
+            r.lens = lens.data_ptr()
+        if quals is not None:
+            assert quals.dtype == torch.uint8 and quals.is_cuda and quals.is_contiguous()
+            r.quals = quals.data_ptr()
+            r.qstride = quals.shape[1]
+        if good_len is not None:
+            assert good_len.dtype == torch.int16 and good_len.is_cuda
+            r.good_len = good_len.data_ptr()
+        if bc is not None:
+            assert bc.dtype == torch.int32 and bc.is_cuda
+            r.bc = bc.data_ptr()
+        r.ign_bc_below = ign_bc_below
+        r.read_index_base = read_index_base
+        p = params.to_c()
+        raw = _lib.SnkDevResult()
+        err = C.create_string_buffer(512)
+        rc = self.lib.snk_dev_count_graph(self._ctx, C.byref(r), C.byref(p), C.byref(raw), self._stream(), err, 512)
+        if rc != 0:
+            raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+        return Result(self, raw, params.K)

@@ -32,6 +32,23 @@ class SnkSynthParams(C.Structure):
                 ("err_cdf", C.c_uint32 * 4)]
 
 
+class SnkDevReads(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("rows", C.c_void_p), ("row_words", C.c_uint32), ("read_len", C.c_uint32),
+                ("lens", C.c_void_p), ("quals", C.c_void_p), ("qstride", C.c_uint32), ("reserved0", C.c_uint32),
+                ("good_len", C.c_void_p), ("bc", C.c_void_p), ("ign_bc_below", C.c_int64),
+                ("read_index_base", C.c_uint64)]
+
+
+class SnkDevResult(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("n_instances", C.c_uint64), ("n_supermers", C.c_uint64),
+                ("n_buckets", C.c_uint64), ("good_len", C.c_void_p), ("n_kmers", C.c_uint64), ("keys", C.c_void_p),
+                ("counts", C.c_void_p), ("ctx", C.c_void_p), ("spectrum", C.c_void_p), ("spectrum_bins", C.c_uint32),
+                ("n_circles", C.c_uint32), ("n_unitigs", C.c_uint64), ("unitig_total_bases", C.c_uint64),
+                ("unitig_off", C.c_void_p), ("unitig_bases", C.c_void_p), ("rank_rounds", C.c_uint32),
+                ("buckets_split", C.c_uint32), ("max_slots_used", C.c_uint32), ("reserved1", C.c_uint32),
+                ("scratch_bytes", C.c_uint64), ("phase_ms", C.c_float * 8)]
+
+
 _lib = None
 
 
@@ -63,6 +80,10 @@ def _declare(lib: C.CDLL) -> None:
         "snk_synth_default": (None, [P(SnkSynthParams), u64, u64, C.c_int]),
         "snk_synth_host": (C.c_int, [P(SnkSynthParams), u64, u64, vp, u32, vp, u32, vp]),
         "snk_synth_dev": (C.c_int, [vp, P(SnkSynthParams), u64, u64, vp, u32, vp, u32, vp, vp]),
+        "snk_dev_trim": (C.c_int, [vp, vp, u32, vp, u32, u64, u32, u32, vp, vp]),
+        "snk_dev_pack_ascii": (C.c_int, [vp, vp, u32, u32, u64, vp, u32, vp]),
+        "snk_dev_count_graph": (C.c_int, [vp, P(SnkDevReads), P(SnkParams), P(SnkDevResult), vp, cp, sz]),
+        "snk_dev_download": (C.c_int, [vp, vp, vp, sz, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
