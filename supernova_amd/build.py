@@ -58,7 +58,10 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         with ThreadPoolExecutor(max_workers=min(8, len(todo))) as ex:
             list(ex.map(cc, todo))
     if todo or not LIB.exists() or any(o.stat().st_mtime > LIB.stat().st_mtime for o in objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
+        # The HIP runtime is NOT a DT_NEEDED of libsnk.so: the host process supplies it (torch's bundled
+        # libamdhip64 when the host is Python/torch, /opt/rocm's otherwise -- see supernova_amd/lib.py and
+        # INTEGRATION.md).  Two HIP runtimes in one process do not work.
+        cmd = [os.environ.get("CXX", "g++"), "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -323,19 +323,44 @@ inline unsigned nblk(uint64_t n) { return (unsigned)((n + TB - 1) / TB); }
         ptr = (type*)_p;                                                                \
     } while (0)
 
-// sort (keys, vals) by the 2K significant key bits; results replace the inputs' roles via out pointers
+__global__ void __launch_bounds__(256) sorted_check_kernel(const snk_u128* __restrict__ keys, uint64_t n, uint32_t* __restrict__ bad) {
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i + 1 >= n) return;
+    if (!(keys[i] < keys[i + 1])) *bad = 1u;   // retained k-mers are distinct: strictly ascending
+}
+
+// sort (keys, vals) by key.  Only the top 2K bits are significant; rocPRIM's bit-range path is used for
+// large inputs (onesweep) and the full 128-bit sort for small ones (its single-block/merge path mis-sorts
+// 128-bit keys when begin_bit != 0 -- ROCm 7.2, see tools/probe/sort128.hip).  The result is verified.
 int snk_graph_sort(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t n, snk_u128* keys_in, uint64_t* vals_in,
                    snk_u128* keys_out, uint64_t* vals_out, char* err, size_t errcap) {
     if (n == 0) return SNK_OK;
-    size_t tmp_bytes = 0;
-    SNK_HIP_TRY(rocprim::radix_sort_pairs((void*)nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n,
-                                          128u - 2u * K, 128u, st));
-    void* tmp = nullptr;
-    int rc = snk_ctx_alloc(ctx, tmp_bytes, &tmp, err, errcap);
-    if (rc) return rc;
-    SNK_HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 128u - 2u * K,
-                                          128u, st));
-    return SNK_OK;
+    uint32_t* bad = nullptr;
+    {
+        void* q;
+        int rc = snk_ctx_alloc(ctx, 16, &q, err, errcap);
+        if (rc) return rc;
+        bad = (uint32_t*)q;
+    }
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        unsigned begin_bit = (attempt == 0 && n >= (8u << 20)) ? 128u - 2u * K : 0u;
+        size_t tmp_bytes = 0;
+        SNK_HIP_TRY(rocprim::radix_sort_pairs((void*)nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n,
+                                              begin_bit, 128u, st));
+        void* tmp = nullptr;
+        int rc = snk_ctx_alloc(ctx, tmp_bytes, &tmp, err, errcap);
+        if (rc) return rc;
+        SNK_HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, begin_bit,
+                                              128u, st));
+        SNK_HIP_TRY(hipMemsetAsync(bad, 0, 4, st));
+        hipLaunchKernelGGL(sorted_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, keys_out, n, bad);
+        uint32_t h_bad = 0;
+        SNK_HIP_TRY(hipMemcpyAsync(&h_bad, bad, 4, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(hipStreamSynchronize(st));
+        if (!h_bad) return SNK_OK;
+        if (begin_bit == 0) break;
+    }
+    return snk_fail(SNK_E_INTERNAL, err, errcap, "retained k-mer table is not strictly ascending after the sort");
 }
 
 template <int K>

@@ -61,10 +61,30 @@ def load() -> C.CDLL:
         raise FileNotFoundError(
             f"{LIB_PATH} is missing: run `python -m supernova_amd.build` (hipcc, gfx950). "
             "supernova_amd has no CPU fallback.")
+    _preload_hip_runtime()
     lib = C.CDLL(str(LIB_PATH))
     _declare(lib)
     _lib = lib
     return lib
+
+
+def _preload_hip_runtime() -> None:
+    """libsnk.so leaves the hip* symbols undefined; bind them to the ONE HIP runtime of this process:
+    torch's bundled libamdhip64 when torch is installed (so device pointers/streams are shared with torch),
+    else the system ROCm one."""
+    import os
+    cands = []
+    try:
+        import torch  # noqa: F401  (loads its libamdhip64 first)
+        cands.append(Path(torch.__file__).parent / "lib" / "libamdhip64.so")
+    except Exception:  # pragma: no cover
+        pass
+    cands += [Path(os.environ.get("ROCM_PATH", "/opt/rocm")) / "lib" / "libamdhip64.so"]
+    for c in cands:
+        if c.exists():
+            C.CDLL(str(c), mode=C.RTLD_GLOBAL)
+            return
+    raise FileNotFoundError("no libamdhip64.so found (torch bundle or $ROCM_PATH/lib)")
 
 
 def _declare(lib: C.CDLL) -> None:
