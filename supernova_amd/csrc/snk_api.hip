@@ -67,26 +67,55 @@ extern "C" int snk_ctx_create(int device, snk_ctx** out, char* err, size_t errca
 }
 
 int snk_ctx_alloc(snk_ctx* ctx, size_t bytes, void** out, char* err, size_t errcap) {
-    void* p = nullptr;
     if (bytes == 0) bytes = 256;
+    bytes = (bytes + 255) & ~(size_t)255;
+    // best fit among the free cached blocks (never waste more than 2x)
+    int best = -1;
+    for (size_t i = 0; i < ctx->blocks.size(); ++i) {
+        const snk_ctx::block& b = ctx->blocks[i];
+        if (!b.used && b.bytes >= bytes && b.bytes <= 2 * bytes + (1u << 20) &&
+            (best < 0 || b.bytes < ctx->blocks[best].bytes))
+            best = (int)i;
+    }
+    if (best >= 0) {
+        ctx->blocks[best].used = true;
+        ctx->total_alloc += ctx->blocks[best].bytes;
+        *out = ctx->blocks[best].p;
+        return SNK_OK;
+    }
+    void* p = nullptr;
     hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        snk_ctx_trim_cache(ctx);
+        e = hipMalloc(&p, bytes);
+    }
     if (e != hipSuccess)
         return snk_fail(SNK_E_NOMEM, err, errcap, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-    ctx->blocks.push_back(p);
+    ctx->blocks.push_back({p, bytes, true});
     ctx->total_alloc += bytes;
+    ctx->cached_bytes += bytes;
     *out = p;
     return SNK_OK;
 }
 void snk_ctx_release_scratch(snk_ctx* ctx) {
-    for (void* p : ctx->blocks) (void)hipFree(p);
-    ctx->blocks.clear();
+    for (auto& b : ctx->blocks) b.used = false;
     ctx->total_alloc = 0;
+}
+void snk_ctx_trim_cache(snk_ctx* ctx) {
+    std::vector<snk_ctx::block> keep;
+    for (auto& b : ctx->blocks) {
+        if (b.used) keep.push_back(b);
+        else { (void)hipFree(b.p); ctx->cached_bytes -= b.bytes; }
+    }
+    ctx->blocks.swap(keep);
 }
 
 extern "C" void snk_ctx_destroy(snk_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     snk_ctx_release_scratch(ctx);
+    snk_ctx_trim_cache(ctx);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -24,8 +24,8 @@ namespace {
 
 constexpr uint32_t BC_MULTI = 0xFFFFFFFEu;
 constexpr uint32_t BC_IGN = 0xFFFFFFFFu;
-constexpr uint32_t CNT_LOCK = 0x80000000u;
 constexpr int MAX_SPLIT_LOG2 = 16;
+#define LDS_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 
 template <int K> struct lo_t { typedef uint32_t type; };       // K<=48: only the top 32 bits of lo are used
 template <> struct lo_t<60> { typedef uint64_t type; };
@@ -40,145 +40,177 @@ template <> __device__ __forceinline__ uint64_t lo_unpack<60>(uint64_t v) { retu
 template <int K, int THREADS, int SLOTS>
 __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
     typedef typename lo_t<K>::type lo_type;
+    constexpr int WMAX = K - SNK_M + 1;                  // k-mers per supermer, at most
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint64_t* khi = reinterpret_cast<uint64_t*>(smem_raw);                         // [SLOTS]
     lo_type* klo = reinterpret_cast<lo_type*>(khi + SLOTS);                         // [SLOTS]
-    uint32_t* cnt = reinterpret_cast<uint32_t*>(klo + SLOTS);                       // [SLOTS] 0 empty, LOCK while being claimed
-    uint32_t* bcs = cnt + SLOTS;                                                    // [SLOTS]
+    uint32_t* tag = reinterpret_cast<uint32_t*>(klo + SLOTS);                       // [SLOTS] 0 empty | fingerprint(31) | ready(1)
+    uint32_t* cnt = tag + SLOTS;                                                    // [SLOTS] observations
+    uint32_t* bcs = cnt + SLOTS;                                                    // [SLOTS] barcode state
     uint32_t* ctxw = bcs + SLOTS;                                                   // [SLOTS/4] context bytes
-    uint32_t* ctl = ctxw + SLOTS / 4;                                               // control words
-    // ctl[0] stack pointer, ctl[1] occupied slots, ctl[2] overflow flag, ctl[3] current split log2, ctl[4] current split id
-    // ctl[8..8+2*MAX) split stack
-    volatile uint32_t* vctl = ctl;
+    uint32_t* rec = ctxw + SLOTS / 4;                                               // [8][THREADS] staged supermer records
+    uint32_t* pre = rec + 8 * THREADS;                                              // [THREADS+1] k-mer prefix sums of the batch
+    uint32_t* ctl = pre + THREADS + 4;                                              // [64] control words
+    uint8_t* owner = reinterpret_cast<uint8_t*>(ctl + 64);                          // [THREADS*WMAX] k-mer -> supermer of the batch
+    // ctl[0] stack pointer, ctl[1] occupied slots, ctl[2] overflow flag, ctl[3] split log2, ctl[4] split id,
+    // ctl[5] valid entries of the sub-pass, ctl[6..7] reserved base (lo,hi), ctl[8] placement counter,
+    // ctl[9..12] wave totals for the batch scan, ctl[16..16+2*MAX) split stack
+    static_assert(THREADS <= 256, "owner[] holds 8-bit batch indices");
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
     const uint32_t bucket = blockIdx.x;
     constexpr uint32_t LIMIT = SLOTS - THREADS - 64;   // claims allowed before a sub-pass is declared overflowing
 
-    if (tid == 0) { ctl[0] = 1; ctl[8] = 0; ctl[9] = 0; }
+    if (tid == 0) { ctl[0] = 1; ctl[16] = 0; ctl[17] = 0; }
     uint32_t splits_done = 0;
     for (;;) {
         __syncthreads();
-        if (vctl[0] == 0) break;
+        if (LDS_LOAD(&ctl[0]) == 0) break;
         __syncthreads();
         if (tid == 0) {
             uint32_t sp = ctl[0] - 1;
             ctl[0] = sp;
-            ctl[3] = ctl[8 + 2 * sp];
-            ctl[4] = ctl[9 + 2 * sp];
+            ctl[3] = ctl[16 + 2 * sp];
+            ctl[4] = ctl[17 + 2 * sp];
             ctl[1] = 0;
             ctl[2] = 0;
         }
-        for (int s = tid; s < SLOTS; s += THREADS) { cnt[s] = 0; bcs[s] = 0; }
+        for (int s = tid; s < SLOTS; s += THREADS) { tag[s] = 0; cnt[s] = 0; bcs[s] = 0; }
         for (int s = tid; s < SLOTS / 4; s += THREADS) ctxw[s] = 0;
         __syncthreads();
-        const uint32_t split_lg = vctl[3], split_id = vctl[4];
+        const uint32_t split_lg = LDS_LOAD(&ctl[3]), split_id = LDS_LOAD(&ctl[4]);
         const uint32_t split_mask = (1u << split_lg) - 1u;
 
         for (uint32_t seg = 0; seg < a.nseg; ++seg) {
             const uint64_t beg = a.seg_off[(uint64_t)seg * (a.NB + 1) + bucket];
             const uint64_t end = a.seg_off[(uint64_t)seg * (a.NB + 1) + bucket + 1];
             for (uint64_t base = beg; base < end; base += THREADS) {
+                // ---- stage one batch of supermer records (coalesced 32-byte loads) and scan their k-mer counts
                 const uint64_t idx = base + tid;
                 uint32_t nkm = 0;
-                snk_kmer f = {0, 0}, rc = {0, 0};
-                uint64_t t_hi = 0, t_lo = 0;
-                uint32_t pred = 0, havepred = 0, hasR = 0;
-                int32_t bc = 0;
-                if (idx < end && vctl[2] == 0) {
-                    uint4 r0 = a.records[idx * 2], r1 = a.records[idx * 2 + 1];
-                    uint64_t X0 = ((uint64_t)r0.x << 32) | r0.y, X1 = ((uint64_t)r0.z << 32) | r0.w;
-                    uint64_t X2 = ((uint64_t)r1.x << 32) | r1.y, X3 = (uint64_t)(r1.z & 0xFFFFF000u) << 32;
-                    uint32_t meta = r1.z & 0xFFFu;
-                    nkm = meta & 0x7Fu;
-                    uint32_t hasL = (meta >> 7) & 1u;
-                    hasR = (meta >> 8) & 1u;
-                    bc = (int32_t)r1.w;
-                    havepred = hasL;
-                    pred = (uint32_t)(X0 >> 62);
-                    const uint32_t s = 2u * hasL;              // first k-mer starts at base hasL of the record
-                    // first k-mer = 2K bits at bit offset s
-                    uint64_t A0 = s ? ((X0 << s) | (X1 >> (64 - s))) : X0;
-                    uint64_t A1 = s ? ((X1 << s) | (X2 >> (64 - s))) : X1;
-                    f.hi = A0;
-                    f.lo = A1 & ~((1ull << (128 - 2 * K)) - 1ull);
-                    rc = snk_kmer_rc<K>(f);
-                    // tail = bases following the first k-mer, MSB aligned: bit offset s + 2K  (in [64,128))
-                    const uint32_t off = s + 2u * K - 64u;     // offset inside (X1,X2,X3)
-                    t_hi = (X1 << off) | (X2 >> (64 - off));
-                    t_lo = (X2 << off) | (X3 >> (64 - off));
+                if (idx < end) {
+                    const uint4 r0 = a.records[idx * 2], r1 = a.records[idx * 2 + 1];
+                    rec[0 * THREADS + tid] = r0.x; rec[1 * THREADS + tid] = r0.y; rec[2 * THREADS + tid] = r0.z;
+                    rec[3 * THREADS + tid] = r0.w; rec[4 * THREADS + tid] = r1.x; rec[5 * THREADS + tid] = r1.y;
+                    rec[6 * THREADS + tid] = r1.z; rec[7 * THREADS + tid] = r1.w;
+                    nkm = r1.z & 0x7Fu;
                 }
-                uint32_t maxn = nkm;
-                for (int o = 32; o > 0; o >>= 1) { uint32_t v = __shfl_xor(maxn, o); maxn = v > maxn ? v : maxn; }
-                for (uint32_t j = 0; j < maxn; ++j) {
-                    if (j < nkm) {
-                        const uint32_t nb = (uint32_t)(t_hi >> 62);
-                        const uint32_t havesucc = (j + 1 < nkm) ? 1u : hasR;
-                        uint32_t ctx = (havepred ? (0x10u << pred) : 0u) | (havesucc ? (1u << nb) : 0u);
-                        const bool rev = snk_kmer_lt(rc, f);      // isRev(): store the reverse complement (:164)
-                        const snk_kmer c = rev ? rc : f;
+                uint32_t incl = nkm;
+                for (int o = 1; o < 64; o <<= 1) { uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+                if (lane == 63) ctl[9 + wv] = incl;
+                __syncthreads();
+                uint32_t woff = 0, total = 0;
+                for (int w = 0; w < THREADS / 64; ++w) { uint32_t t = ctl[9 + w]; if (w < wv) woff += t; total += t; }
+                const uint32_t mypre = woff + incl - nkm;
+                pre[tid] = mypre;
+                for (uint32_t j = 0; j < nkm; ++j) owner[mypre + j] = (uint8_t)tid;
+                __syncthreads();
+                // ---- one lane per k-mer instance: a wave inserts 64 different k-mers of consecutive supermers, so
+                //      copies of the same k-mer (identical supermers of other reads) are spread over time, not lanes
+                const bool ovf_seen = LDS_LOAD(&ctl[2]) != 0;
+                for (uint32_t g0 = 0; g0 < total && !ovf_seen; g0 += THREADS) {
+                    const uint32_t g = g0 + tid;
+                    if (g < total) {
+                        const uint32_t i = owner[g];
+                        const uint32_t j = g - pre[i];
+                        const uint32_t m6 = rec[6 * THREADS + i];
+                        const uint32_t n_i = m6 & 0x7Fu, hasL = (m6 >> 7) & 1u, hasR = (m6 >> 8) & 1u;
+                        const int32_t bc = (int32_t)rec[7 * THREADS + i];
+                        const uint32_t o = hasL + j;                     // first base of the k-mer inside the record
+                        const uint32_t wi = (2u * o) >> 5, sh = (2u * o) & 31u;
+                        uint32_t W[5];
+#pragma unroll
+                        for (uint32_t q = 0; q < 5; ++q) {
+                            const uint32_t x = wi + q;
+                            uint32_t v = x < 7 ? rec[x * THREADS + i] : 0u;
+                            if (x == 6) v &= 0xFFFFF000u;
+                            W[q] = v;
+                        }
+                        const uint64_t A = ((uint64_t)W[0] << 32) | W[1], B = ((uint64_t)W[2] << 32) | W[3], C = (uint64_t)W[4] << 32;
+                        snk_kmer f;
+                        f.hi = sh ? ((A << sh) | (B >> (64 - sh))) : A;
+                        const uint64_t lo_un = sh ? ((B << sh) | (C >> (64 - sh))) : B;
+                        f.lo = lo_un & ~((1ull << (128 - 2 * K)) - 1ull);
+                        const uint32_t nb = (uint32_t)(lo_un >> (126 - 2 * K)) & 3u;       // base after the k-mer
+                        const uint32_t havesucc = (j + 1 < n_i) ? 1u : hasR;
+                        const uint32_t havepred = o ? 1u : 0u;
+                        uint32_t pb;
+                        if (sh) pb = (W[0] >> (32 - sh)) & 3u;
+                        else pb = (wi ? rec[(wi - 1) * THREADS + i] : 0u) & 3u;
+                        uint32_t ctx = (havepred ? (0x10u << pb) : 0u) | (havesucc ? (1u << nb) : 0u);
+                        const snk_kmer r = snk_kmer_rc<K>(f);
+                        const bool rev = snk_kmer_lt(r, f);          // isRev(): store the reverse complement (:164)
+                        const snk_kmer c = rev ? r : f;
                         if (rev) ctx = snk_ctx_rc(ctx);
                         uint32_t h1, h2;
                         snk_kmer_hash2(c, &h1, &h2);
-                        if ((h2 & split_mask) == split_id) {
-                            uint32_t slot = (uint32_t)(((uint64_t)h1 * SLOTS) >> 32);
+                        if (a.dbg == 1) { if (h1 == 0x12345u && h2 == 0x54321u) a.status[3] = 7; }
+                        else if ((h2 & split_mask) == split_id) {
+                            // double hashing (odd stride, power-of-two table): a wave waits for its slowest lane, so the
+                            // tail of the probe-length distribution matters more than its mean
+                            uint32_t slot = h1 & (SLOTS - 1);
+                            const uint32_t stride = ((h1 >> 16) ^ (h2 >> 20)) | 1u;
                             const lo_type clo = lo_pack<K>(c.lo);
+                            const uint32_t mytag = (h2 & ~1u) | 2u;     // never 0; bit 0 = key words are in place
+                            bool found = false;
+                            // find-or-claim: the loop body is one tag load; key words are only read on a fingerprint hit
                             for (;;) {
-                                uint32_t cv = __hip_atomic_load(&cnt[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                if (cv == 0) {
-                                    if (vctl[2]) { nkm = 0; break; }   // sub-pass already declared overflowing: stop claiming
-                                    uint32_t old = atomicCAS(&cnt[slot], 0u, CNT_LOCK);
-                                    if (old == 0) {
+                                uint32_t t = __hip_atomic_load(&tag[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                if (t == 0) {
+                                    if (LDS_LOAD(&ctl[2])) break;        // sub-pass already declared overflowing: stop claiming
+                                    t = atomicCAS(&tag[slot], 0u, mytag);
+                                    if (t == 0) {
                                         khi[slot] = c.hi;
                                         klo[slot] = clo;
-                                        bcs[slot] = bc > 0 ? (uint32_t)bc : (bc == -1 ? BC_IGN : 0u);
-                                        if (ctx) atomicOr(&ctxw[slot >> 2], ctx << (8 * (slot & 3)));
-                                        __hip_atomic_store(&cnt[slot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                        __hip_atomic_store(&tag[slot], mytag | 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                                         uint32_t occ = atomicAdd(&ctl[1], 1u);
-                                        if (occ >= LIMIT) vctl[2] = 1;
+                                        if (occ >= LIMIT) __hip_atomic_store(&ctl[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                        found = true;
                                         break;
                                     }
-                                    continue;   // lost the race: look at the same slot again
                                 }
-                                if (cv == CNT_LOCK) continue;
-                                if (khi[slot] == c.hi && klo[slot] == clo) {
-                                    atomicAdd(&cnt[slot], 1u);
-                                    if (ctx) atomicOr(&ctxw[slot >> 2], ctx << (8 * (slot & 3)));
-                                    if (bc == -1) atomicMax(&bcs[slot], BC_IGN);
-                                    else if (bc > 0) {
-                                        uint32_t ob = atomicCAS(&bcs[slot], 0u, (uint32_t)bc);
-                                        if (ob != 0 && ob != (uint32_t)bc && ob < BC_MULTI) atomicMax(&bcs[slot], BC_MULTI);
-                                    }
-                                    break;
+                                if ((t & ~1u) == mytag) {
+                                    if (!(t & 1u)) continue;             // same fingerprint, key not written yet: look again
+                                    if (khi[slot] == c.hi && klo[slot] == clo) { found = true; break; }
                                 }
-                                slot = slot + 1 == SLOTS ? 0 : slot + 1;
+                                slot = (slot + stride) & (SLOTS - 1);
+                            }
+                            if (found && a.dbg != 2) {
+                                atomicAdd(&cnt[slot], 1u);
+                                if (ctx) atomicOr(&ctxw[slot >> 2], ctx << (8 * (slot & 3)));
+                                if (bc == -1) atomicMax(&bcs[slot], BC_IGN);
+                                else if (bc > 0) {
+                                    uint32_t ob = atomicCAS(&bcs[slot], 0u, (uint32_t)bc);
+                                    if (ob != 0 && ob != (uint32_t)bc && ob < BC_MULTI) atomicMax(&bcs[slot], BC_MULTI);
+                                }
                             }
                         }
-                        // roll to the next k-mer of the supermer
-                        pred = (uint32_t)(f.hi >> 62);
-                        havepred = 1;
-                        f = snk_kmer_succ<K>(f, nb);
-                        rc = snk_kmer_pred<K>(rc, nb ^ 3u);
-                        t_hi = (t_hi << 2) | (t_lo >> 62);
-                        t_lo <<= 2;
                     }
                 }
+                __syncthreads();   // rec/pre/owner are rewritten by the next batch
             }
         }
         __syncthreads();
-        if (vctl[2]) {   // too many distinct k-mers for one table: split this sub-pass in two by one more hash bit
+        if (LDS_LOAD(&ctl[2])) {   // too many distinct k-mers for one table: split this sub-pass in two by one more hash bit
             if (tid == 0) {
                 if (split_lg >= MAX_SPLIT_LOG2) { atomicExch(&a.status[1], 1u); }
                 else {
-                    uint32_t sp = vctl[0];
-                    ctl[8 + 2 * sp] = split_lg + 1; ctl[9 + 2 * sp] = split_id;
-                    ctl[10 + 2 * sp] = split_lg + 1; ctl[11 + 2 * sp] = split_id | (1u << split_lg);
+                    uint32_t sp = LDS_LOAD(&ctl[0]);
+                    ctl[16 + 2 * sp] = split_lg + 1; ctl[17 + 2 * sp] = split_id;
+                    ctl[18 + 2 * sp] = split_lg + 1; ctl[19 + 2 * sp] = split_id | (1u << split_lg);
                     ctl[0] = sp + 2;
                 }
             }
             ++splits_done;
             continue;
         }
-        // K8: filter + compact the surviving entries to the global table
+        // K8: filter + compact the surviving entries to the global table.  Device-scope atomics on one
+        // address are served at the memory side (the XCD L2s are not coherent) at tens of ns each, so the
+        // table is cut into n_regions regions with their own cursors and every sub-pass does ONE global
+        // atomic: count the survivors in LDS, reserve, then place.
+        if (tid == 0) { ctl[5] = 0; ctl[8] = 0; }
+        __syncthreads();
+        uint32_t myvalid = 0;
         for (int s0 = 0; s0 < SLOTS; s0 += THREADS) {
             const int s = s0 + tid;
             const uint32_t c = cnt[s];
@@ -187,36 +219,51 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
                 const uint32_t b = bcs[s];
                 ok = a.bc_mode == 1 ? (b != 0) : (b >= BC_MULTI);
             }
-            const unsigned long long m = __ballot(ok);
-            if (m) {
-                const int lane = tid & 63;
-                unsigned long long basepos = 0;
-                if (lane == 0) basepos = atomicAdd(a.out_cursor, (unsigned long long)__popcll(m));
-                basepos = __shfl(basepos, 0);
-                if (ok) {
-                    const uint64_t pos = basepos + __popcll(m & ((1ull << lane) - 1ull));
-                    if (pos < a.out_cap) {
+            if (ok) ++myvalid;
+            else cnt[s] = 0;              // survivors keep their count, everything else is cleared
+        }
+        for (int o = 32; o > 0; o >>= 1) myvalid += __shfl_xor(myvalid, o);
+        if (lane == 0 && myvalid) atomicAdd(&ctl[5], myvalid);
+        __syncthreads();
+        const uint32_t nvalid = LDS_LOAD(&ctl[5]);
+        if (nvalid) {
+            const uint32_t region = bucket % a.n_regions;
+            if (tid == 0) {
+                unsigned long long b0 = atomicAdd(&a.region_cursor[region], (unsigned long long)nvalid);
+                ctl[6] = (uint32_t)b0;
+                ctl[7] = (uint32_t)(b0 >> 32);
+            }
+            __syncthreads();
+            const uint64_t rbase = ((uint64_t)LDS_LOAD(&ctl[7]) << 32) | LDS_LOAD(&ctl[6]);
+            if (rbase + nvalid <= a.region_cap) {
+                const uint64_t gbase = (uint64_t)region * a.region_cap + rbase;
+                for (int s0 = 0; s0 < SLOTS; s0 += THREADS) {
+                    const int s = s0 + tid;
+                    const uint32_t c = cnt[s];
+                    if (c) {
+                        const uint32_t pos = atomicAdd(&ctl[8], 1u);
                         const uint32_t cx = (ctxw[s >> 2] >> (8 * (s & 3))) & 0xFFu;
-                        a.out_keys[pos] = ((snk_u128)khi[s] << 64) | (snk_u128)lo_unpack<K>(klo[s]);
-                        a.out_vals[pos] = ((uint64_t)c << 8) | cx;
-                    } else {
-                        a.status[0] = 1;
+                        a.out_keys[gbase + pos] = ((snk_u128)khi[s] << 64) | (snk_u128)lo_unpack<K>(klo[s]);
+                        a.out_vals[gbase + pos] = ((uint64_t)c << 8) | cx;
                     }
                 }
+            } else if (tid == 0) {
+                a.status[0] = 1;
             }
         }
-        if (tid == 0) atomicMax(&a.status[3], vctl[1]);
+        if (tid == 0) atomicMax(&a.status[3], LDS_LOAD(&ctl[1]));
     }
     if (tid == 0 && splits_done) atomicAdd(&a.status[2], 1u);
 }
 
 template <int K> struct cfg;
-template <> struct cfg<48> { static constexpr int THREADS = 512; static constexpr int SLOTS = 3072; };
-template <> struct cfg<60> { static constexpr int THREADS = 512; static constexpr int SLOTS = 2560; };
+template <> struct cfg<48> { static constexpr int THREADS = 256; static constexpr int SLOTS = 2048; };
+template <> struct cfg<60> { static constexpr int THREADS = 256; static constexpr int SLOTS = 2048; };
 
 template <int K>
 size_t lds_bytes() {
-    return (size_t)cfg<K>::SLOTS * (8 + sizeof(typename lo_t<K>::type) + 4 + 4 + 1) + 4 * (8 + 2 * (MAX_SPLIT_LOG2 + 3) * 2);
+    constexpr size_t T = cfg<K>::THREADS, S = cfg<K>::SLOTS;
+    return S * (8 + sizeof(typename lo_t<K>::type) + 4 + 4 + 4) + S + 4 * (8 * T + T + 4 + 64) + T * (K - SNK_M + 1) + 16;
 }
 
 template <int K>
@@ -230,6 +277,30 @@ int launch(hipStream_t st, const snk_count_args& a, char* err, size_t errcap) {
 }
 
 }  // namespace
+
+namespace {
+__global__ void __launch_bounds__(256) compact_regions_kernel(const snk_u128* __restrict__ keys_in, const uint64_t* __restrict__ vals_in,
+                                                              uint64_t region_cap, const unsigned long long* __restrict__ cursor,
+                                                              const unsigned long long* __restrict__ off,
+                                                              snk_u128* __restrict__ keys_out, uint64_t* __restrict__ vals_out) {
+    const uint32_t r = blockIdx.x;
+    const uint64_t n = cursor[r], src = (uint64_t)r * region_cap, dst = off[r];
+    for (uint64_t i = threadIdx.x; i < n; i += 256) {
+        keys_out[dst + i] = keys_in[src + i];
+        vals_out[dst + i] = vals_in[src + i];
+    }
+}
+}  // namespace
+
+int snk_launch_compact_regions(hipStream_t st, const snk_u128* keys_in, const uint64_t* vals_in, uint64_t region_cap,
+                               uint32_t n_regions, const unsigned long long* region_cursor,
+                               const unsigned long long* region_off, snk_u128* keys_out, uint64_t* vals_out, char* err,
+                               size_t errcap) {
+    hipLaunchKernelGGL(compact_regions_kernel, dim3(n_regions), dim3(256), 0, st, keys_in, vals_in, region_cap, region_cursor,
+                       region_off, keys_out, vals_out);
+    SNK_HIP_TRY(hipGetLastError());
+    return SNK_OK;
+}
 
 uint32_t snk_count_slots(uint32_t K) { return K == 60 ? cfg<60>::SLOTS : cfg<48>::SLOTS; }
 

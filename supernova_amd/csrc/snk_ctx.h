@@ -15,9 +15,13 @@ struct snk_ctx {
     hipStream_t stream = nullptr;   // library-owned default stream
     int n_cu = 256;
     size_t lds_per_block = 65536;
-    // bump arena for call-scoped scratch (reset at the start of each top-level call)
-    std::vector<void*> blocks;
-    size_t total_alloc = 0;
+    // caching arena for call-scoped scratch: blocks are handed out by best fit, returned to the cache at the
+    // start of the next top-level call (no hipFree/hipMalloc in steady state), released on destroy or OOM
+    struct block { void* p; size_t bytes; bool used; };
+    std::vector<block> blocks;
+    size_t total_alloc = 0;     // bytes handed out in the current call
+    size_t cached_bytes = 0;    // bytes held by the arena
+    uint64_t last_n_kmers = 0, last_n_instances = 0;   // sizing hint from the previous call
 };
 
 void snk_set_error(char* err, size_t errcap, const char* fmt, ...);
@@ -33,4 +37,5 @@ int snk_fail(int code, char* err, size_t errcap, const char* fmt, ...);
 
 // scratch allocation owned by the ctx; freed by snk_ctx_release_scratch / destroy
 int snk_ctx_alloc(snk_ctx* ctx, size_t bytes, void** out, char* err, size_t errcap);
-void snk_ctx_release_scratch(snk_ctx* ctx);
+void snk_ctx_release_scratch(snk_ctx* ctx);   // return every block to the cache
+void snk_ctx_trim_cache(snk_ctx* ctx);        // hipFree every unused cached block

@@ -24,11 +24,18 @@ struct snk_count_args {
     uint32_t NB;
     uint32_t min_freq;
     uint32_t bc_mode;              // 0: no barcode rule, 1: >=1 barcode>0 (or ignore-rule read), 2: >=2 distinct
-    snk_u128* out_keys;            // canonical k-mer values (hi<<64|lo)
+    snk_u128* out_keys;            // canonical k-mer values (hi<<64|lo); region r owns [r*region_cap, (r+1)*region_cap)
     uint64_t* out_vals;            // count << 8 | raw context byte
-    uint64_t out_cap;
-    unsigned long long* out_cursor;
+    uint64_t region_cap;
+    uint32_t n_regions;
+    unsigned long long* region_cursor;   // [n_regions] entries used per region
+    uint32_t dbg;                  // profiling aid: 1 = roll+hash only, 2 = no updates after the probe (results invalid)
     uint32_t* status;              // [0] output overflow, [1] split depth exceeded, [2] buckets split, [3] max slots used
 };
 int snk_launch_count(uint32_t K, hipStream_t st, const snk_count_args& a, char* err, size_t errcap);
 uint32_t snk_count_slots(uint32_t K);   // LDS table slots per workgroup
+// gather the used prefix of every region into one dense table; region_off = exclusive scan of region_cursor
+int snk_launch_compact_regions(hipStream_t st, const snk_u128* keys_in, const uint64_t* vals_in, uint64_t region_cap,
+                               uint32_t n_regions, const unsigned long long* region_cursor,
+                               const unsigned long long* region_off, snk_u128* keys_out, uint64_t* vals_out, char* err,
+                               size_t errcap);

@@ -6,7 +6,7 @@
 //   shardio write path          lib/tada/external/rust-shardio/src/shard.rs:184-211 (group by shard)
 //   and, for path B, the hash->(pass,bin) map of MapReduceEngine.h:315-326.
 // Shard assignment is internal to the reference (App. A.10): counts and unitigs do not depend on it.
-// This build uses M=16-mers ordered by a 24-bit hash of the canonical M-mer (strand symmetric, so a
+// This build uses M=16-mers ordered by a 32-bit hash of the canonical M-mer (strand symmetric, so a
 // k-mer and its reverse complement always land in the same bucket -- the invariant of
 // check_consistent_shard, lib/tada/src/kmer/mod.rs:1102-1150).
 //
@@ -44,7 +44,22 @@ __device__ __forceinline__ uint32_t mmer_key(const uint32_t* rowL, int tid, uint
     if (M == 16) { code = x; rcode = rx; }
     else { code = x >> (32 - 2 * M); rcode = rx & ((1u << (2 * M)) - 1u); }
     uint32_t c = code < rcode ? code : rcode;
-    return (snk_mix32(c) & 0xFFFFFF00u) | (uint32_t)p;
+    return snk_mix32(c);
+}
+
+// Bucket of the supermer whose minimiser sits at position p.  Two rules make this safe:
+//  * it must NOT be taken from the ordering key directly: minimisers are window minima of that key, so
+//    their keys crowd near zero (a Beta(1,w) law) and most supermers would fall into the lowest few
+//    percent of the buckets -- the key is re-mixed first;
+//  * it must be a function of the ordering key ONLY (not of the M-mer or its position): when two
+//    different M-mers of a window tie on the key, the two strands may pick different ones, and a k-mer
+//    and its reverse complement must still meet in one bucket.
+template <int M>
+__device__ __forceinline__ uint32_t mmer_bucket(const uint32_t* rowL, int tid, uint32_t row_words, int p, uint32_t NB) {
+    uint32_t key = mmer_key<M>(rowL, tid, row_words, p);
+    uint32_t h = snk_mix32(key ^ 0x5bd1e995u) * 0x9E3779B1u;
+    h ^= h >> 15;
+    return (uint32_t)(((uint64_t)h * NB) >> 32);
 }
 
 // extract 32 bits starting at base `a + 16*j` of the row column
@@ -67,8 +82,9 @@ __global__ void __launch_bounds__(BD) snk_msp_kernel(const uint32_t* __restrict_
     constexpr int W = K - M + 1;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* rowL = smem;                              // [row_words][BD]
-    uint32_t* sfx = rowL + (size_t)row_words * BD;      // [W][BD]
-    uint32_t* lst = sfx + (size_t)W * BD;               // [LCAP][BD]
+    uint32_t* sfx = rowL + (size_t)row_words * BD;      // [W][BD] suffix minima (ordering key)
+    uint16_t* lst = reinterpret_cast<uint16_t*>(sfx + (size_t)W * BD);   // [LCAP][BD] minimiser position << 8 | first k-mer
+    uint8_t* sfxp = reinterpret_cast<uint8_t*>(lst + (size_t)LCAP * BD);  // [W][BD] position of the suffix minimum
     const int tid = threadIdx.x;
     const uint64_t r0 = (uint64_t)blockIdx.x * BD;
     // coalesced stage of the workgroup's rows
@@ -90,7 +106,7 @@ __global__ void __launch_bounds__(BD) snk_msp_kernel(const uint32_t* __restrict_
     int32_t mybc = 0;
     if (SCATTER && g) mybc = (bc && (int64_t)(read_index_base + r) >= ign_bc_below) ? bc[r] : -1;
 
-    uint32_t cur = 0xFFFFFFFFu;   // key of the open supermer
+    int curpos = -1;              // minimiser position of the open supermer
     int cnt = 0;                  // closed+open supermer starts in the list
 
     // emit list entries [0, upto) ; entry e covers k-mers [start_e, start_{e+1}-1], the last one ends at last_end
@@ -101,8 +117,8 @@ __global__ void __launch_bounds__(BD) snk_msp_kernel(const uint32_t* __restrict_
             if (e < upto) {
                 uint32_t ent = lst[e * BD + tid];
                 uint32_t s = ent & 0xFFu;
-                uint32_t en = (e + 1 < upto) ? ((lst[(e + 1) * BD + tid] & 0xFFu) - 1u) : (uint32_t)last_end;
-                uint32_t bucket = (uint32_t)(((uint64_t)(ent >> 8) * NB) >> 24);
+                uint32_t en = (e + 1 < upto) ? (((uint32_t)lst[(e + 1) * BD + tid] & 0xFFu) - 1u) : (uint32_t)last_end;
+                uint32_t bucket = mmer_bucket<M>(rowL, tid, row_words, (int)(ent >> 8), NB);
                 if (!SCATTER) {
                     atomicAdd(&hist_or_cursor[bucket], 1u);
                 } else {
@@ -135,39 +151,43 @@ __global__ void __launch_bounds__(BD) snk_msp_kernel(const uint32_t* __restrict_
     int maxblocks = nblocks;
     for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(maxblocks, off); maxblocks = o > maxblocks ? o : maxblocks; }
     for (int b = 0; b < maxblocks; ++b) {
-        // suffix minima of block b (positions b*W .. b*W+W-1), right to left
+        // suffix minima of block b (positions b*W .. b*W+W-1), right to left; "<=" keeps the leftmost on ties
         uint32_t run = 0xFFFFFFFFu;
+        int runp = 0;
         for (int t = W - 1; t >= 0; --t) {
             int p = b * W + t;
-            uint32_t key = p < npos ? mmer_key<M>(rowL, tid, row_words, p) : 0xFFFFFFFFu;
-            run = key < run ? key : run;
+            if (p < npos) {
+                uint32_t key = mmer_key<M>(rowL, tid, row_words, p);
+                if (key <= run) { run = key; runp = p; }
+            }
             sfx[t * BD + tid] = run;
+            sfxp[t * BD + tid] = (uint8_t)runp;
         }
         // k-mers of block b: window = suffix of block b from t  U  prefix of block b+1 of length t
         uint32_t pfx = 0xFFFFFFFFu;
+        int pfxp = 0;
         for (int t = 0; t < W; ++t) {
             int i = b * W + t;
             uint32_t sv = sfx[t * BD + tid];
-            uint32_t cand = sv < pfx ? sv : pfx;
-            bool isnew = (i < nk) && (cand != cur);
+            int candp = (sv <= pfx) ? (int)sfxp[t * BD + tid] : pfxp;    // the suffix part lies left of the prefix part
+            bool isnew = (i < nk) && (candp != curpos);
             if (__any(isnew && cnt == LCAP)) {     // some lane's list is full: every lane of the wave drains its list
-                int keep_open = cnt > 0 ? 1 : 0;   // the open supermer (last entry) stays
-                if (cnt > keep_open) {
-                    flush(cnt - keep_open, (int)(lst[(cnt - 1) * BD + tid] & 0xFFu) - 1);
-                    lst[tid] = lst[(cnt - 1) * BD + tid];
-                    cnt = keep_open;
-                } else {
-                    flush(0, 0);
-                }
+                // the open supermer (last entry) stays; flush() has wave-wide shuffles, so it is called uniformly
+                const int upto = cnt > 0 ? cnt - 1 : 0;
+                const int last_end = cnt > 0 ? (int)(lst[(cnt - 1) * BD + tid] & 0xFFu) - 1 : 0;
+                flush(upto, last_end);
+                if (cnt > 0) { lst[tid] = lst[(cnt - 1) * BD + tid]; cnt = 1; }
             }
             if (isnew) {
-                cur = cand;
-                lst[cnt * BD + tid] = (cand & 0xFFFFFF00u) | (uint32_t)i;
+                curpos = candp;
+                lst[cnt * BD + tid] = (uint16_t)(((uint32_t)candp << 8) | (uint32_t)i);   // minimiser position | first k-mer
                 ++cnt;
             }
             int p2 = (b + 1) * W + t;
-            uint32_t k2 = p2 < npos ? mmer_key<M>(rowL, tid, row_words, p2) : 0xFFFFFFFFu;
-            pfx = k2 < pfx ? k2 : pfx;
+            if (p2 < npos) {
+                uint32_t k2 = mmer_key<M>(rowL, tid, row_words, p2);
+                if (k2 < pfx) { pfx = k2; pfxp = p2; }
+            }
         }
     }
     flush(cnt, nk - 1);
@@ -182,7 +202,7 @@ __global__ void __launch_bounds__(BD) snk_msp_kernel(const uint32_t* __restrict_
 }  // namespace
 
 size_t snk_msp_lds_bytes(uint32_t K, uint32_t M, uint32_t row_words) {
-    return (size_t)(row_words + (K - M + 1) + LCAP) * BD * 4;
+    return (size_t)(row_words + (K - M + 1)) * BD * 4 + (size_t)LCAP * BD * 2 + (size_t)(K - M + 1) * BD + 64;
 }
 
 template <int K, int M>

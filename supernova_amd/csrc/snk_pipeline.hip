@@ -12,6 +12,8 @@
 
 #include <stdlib.h>
 
+#include <vector>
+
 #include "snk_ctx.h"
 #include "snk_common.h"
 #include "snk_graph.h"
@@ -85,7 +87,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     uint32_t NB = p->n_buckets;
     if (NB == 0) {
         uint64_t inst_ub = n_reads * (uint64_t)(in->read_len >= K ? in->read_len - K + 1 : 0);
-        uint32_t target = env_u32("SNK_TARGET_INST", K == 48 ? 14000u : 11000u);
+        uint32_t target = env_u32("SNK_TARGET_INST", K == 48 ? 4500u : 4000u);
         uint64_t nb = (inst_ub + target - 1) / target;
         if (nb < 1) nb = 1;
         if (nb > (1u << 22)) nb = 1u << 22;
@@ -136,18 +138,28 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     if (rc) return rc;
     tm.mark();  // 3
 
-    // ---- K5-K8 count + filter (retry with a larger output table if the estimate was too small)
-    uint64_t cap = h_ninst / (p->min_freq > 1 ? 6 : 1) + 1024;
-    if (p->min_freq >= 3 && cap > h_ninst / 3 + 1024) cap = h_ninst / 3 + 1024;
-    snk_u128 *keys_a = nullptr, *keys_b = nullptr;
-    uint64_t *vals_a = nullptr, *vals_b = nullptr;
+    // ---- K5-K8 count + filter into a region-partitioned table, then gather the regions densely.
+    // Every retained k-mer has >= min_freq instances; deep coverage retains far fewer (56x: ~1/38 of them).
+    uint32_t n_regions = NB < 4096 ? NB : 4096;
+    uint64_t est = h_ninst / (p->min_freq > 1 ? 8 : 1) + 4096;
+    if (ctx->last_n_kmers && ctx->last_n_instances == h_ninst) est = ctx->last_n_kmers + ctx->last_n_kmers / 2 + 4096;
+    uint64_t region_cap = est / n_regions + 64;
+    snk_u128 *keys_r = nullptr, *keys_a = nullptr, *keys_b = nullptr;
+    uint64_t *vals_r = nullptr, *vals_a = nullptr, *vals_b = nullptr;
+    unsigned long long *rcur = nullptr, *roff = nullptr;
     uint64_t n_kmers = 0;
     uint32_t h_status[4] = {0, 0, 0, 0};
-    for (int attempt = 0; attempt < 4; ++attempt) {
+    {
         void* q;
-        if ((rc = snk_ctx_alloc(ctx, cap * 16, &q, err, errcap))) return rc; keys_a = (snk_u128*)q;
-        if ((rc = snk_ctx_alloc(ctx, cap * 8, &q, err, errcap))) return rc; vals_a = (uint64_t*)q;
-        SNK_HIP_TRY(hipMemsetAsync(counters + 1, 0, 8, st));
+        if ((rc = snk_ctx_alloc(ctx, (n_regions + 1) * 8ull, &q, err, errcap))) return rc; rcur = (unsigned long long*)q;
+        if ((rc = snk_ctx_alloc(ctx, (n_regions + 1) * 8ull, &q, err, errcap))) return rc; roff = (unsigned long long*)q;
+    }
+    std::vector<unsigned long long> h_rcur(n_regions);
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        void* q;
+        if ((rc = snk_ctx_alloc(ctx, region_cap * n_regions * 16, &q, err, errcap))) return rc; keys_r = (snk_u128*)q;
+        if ((rc = snk_ctx_alloc(ctx, region_cap * n_regions * 8, &q, err, errcap))) return rc; vals_r = (uint64_t*)q;
+        SNK_HIP_TRY(hipMemsetAsync(rcur, 0, (n_regions + 1) * 8ull, st));
         SNK_HIP_TRY(hipMemsetAsync(status, 0, 16, st));
         snk_count_args ca;
         ca.records = (const uint4*)records;
@@ -156,25 +168,48 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
         ca.NB = NB;
         ca.min_freq = p->min_freq;
         ca.bc_mode = in->bc ? p->min_bc : 0;    // no barcode vector -> bc_test is always true (:176-178)
-        ca.out_keys = keys_a;
-        ca.out_vals = vals_a;
-        ca.out_cap = cap;
-        ca.out_cursor = counters + 1;
+        ca.out_keys = keys_r;
+        ca.out_vals = vals_r;
+        ca.region_cap = region_cap;
+        ca.n_regions = n_regions;
+        ca.region_cursor = rcur;
         ca.status = status;
+        ca.dbg = env_u32("SNK_COUNT_DBG", 0);
         if ((rc = snk_launch_count(K, st, ca, err, errcap))) return rc;
-        unsigned long long h_nk = 0;
-        SNK_HIP_TRY(hipMemcpyAsync(&h_nk, counters + 1, 8, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(hipMemcpyAsync(h_rcur.data(), rcur, n_regions * 8ull, hipMemcpyDeviceToHost, st));
         SNK_HIP_TRY(hipMemcpyAsync(h_status, status, 16, hipMemcpyDeviceToHost, st));
         SNK_HIP_TRY(hipStreamSynchronize(st));
+        if (ca.dbg >= 2) {
+            unsigned long long d[3];
+            (void)hipMemcpy(d, status + 4, 24, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[snk dbg] lane probe iterations %llu, wave-level iterations %llu, max lane iterations in one probe %llu\n", d[0], d[1], d[2]);
+        }
         if (h_status[1]) return snk_fail(SNK_E_INTERNAL, err, errcap, "count: bucket split depth exceeded");
-        n_kmers = h_nk;
-        if (!h_status[0] && n_kmers <= cap) break;
-        if (attempt == 3) return snk_fail(SNK_E_INTERNAL, err, errcap, "count: output table overflow (%llu > %llu)", h_nk, (unsigned long long)cap);
-        cap = h_nk + 1024;    // exact size is known now
+        unsigned long long mx = 0;
+        n_kmers = 0;
+        for (uint32_t r = 0; r < n_regions; ++r) { n_kmers += h_rcur[r]; if (h_rcur[r] > mx) mx = h_rcur[r]; }
+        if (!h_status[0] && mx <= region_cap) break;
+        if (attempt == 2) return snk_fail(SNK_E_INTERNAL, err, errcap, "count: region overflow (%llu > %llu)", mx, (unsigned long long)region_cap);
+        region_cap = mx + 64;     // exact requirement is known now (cursors keep counting past the cap)
+    }
+    {
+        // exclusive offsets of the regions (host: n_regions <= 4096) and the dense gather
+        std::vector<unsigned long long> h_off(n_regions + 1);
+        unsigned long long acc = 0;
+        for (uint32_t r = 0; r < n_regions; ++r) { h_off[r] = acc; acc += h_rcur[r]; }
+        h_off[n_regions] = acc;
+        SNK_HIP_TRY(hipMemcpyAsync(roff, h_off.data(), (n_regions + 1) * 8ull, hipMemcpyHostToDevice, st));
+        void* q;
+        if ((rc = snk_ctx_alloc(ctx, (n_kmers + 1) * 16, &q, err, errcap))) return rc; keys_a = (snk_u128*)q;
+        if ((rc = snk_ctx_alloc(ctx, (n_kmers + 1) * 8, &q, err, errcap))) return rc; vals_a = (uint64_t*)q;
+        if ((rc = snk_launch_compact_regions(st, keys_r, vals_r, region_cap, n_regions, rcur, roff, keys_a, vals_a, err, errcap))) return rc;
+        SNK_HIP_TRY(hipStreamSynchronize(st));   // h_off is a stack vector: the upload must finish before it goes away
     }
     out->buckets_split = h_status[2];
     out->max_slots_used = h_status[3];
     out->n_kmers = n_kmers;
+    ctx->last_n_kmers = n_kmers;
+    ctx->last_n_instances = h_ninst;
     tm.mark();  // 4
 
     // ---- sort by key
