@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- Gk-mers/s through count+graph at k=48 on synthetic linked reads (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path (trim -> minimiser partition -> [all-to-all] -> LDS count/filter ->
+sort -> prune -> unitigs) over one batch of synthetic reads that is already resident in HBM.
+N=1 workload: BASELINE.json configs[1], 100 M x 150 bp, k=48 (override with --reads).  N>1: weak
+scaling, every rank owns --reads reads of one (N x reads)-read data set, k-mer space sharded by
+minimiser bucket, one all-to-all of supermer records per step.
+
+Rank 0 prints ONE JSON line with the contract fields plus `roofline` (dominant kernel, algorithmic bytes
+per launch / HIP-event launch time, SURVEY.md 8(d): 32.65 B per k-mer instance at K=48) and, at N=1,
+`cpu_baseline` (the reference's own C++ path -- oracle/_ref/snref_driver -- timed on this box's host
+cores on a bounded sample; falls back to the single-thread C port in oracle/ when the binary is absent).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+ALG_BYTES_PER_KMER = {48: 32.65, 60: 40.8}
+HBM_PEAK_GBS = 8000.0                          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+METRIC = "Gk-mers/s through count+graph at k=48, 1.2B×150bp; bit-exact counts"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=float, default=1e8, help="reads per GPU")
+    ap.add_argument("--k", type=int, default=48)
+    ap.add_argument("--error-free", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=float, default=1e6, help="reads of the workload timed on the host cores")
+    return ap.parse_args()
+
+
+def cpu_baseline(sp_full, K: int, sample_reads: int):
+    """Reference CPU path on a bounded sample (first `sample_reads` reads of a data set with the same coverage)."""
+    import numpy as np
+    from supernova_amd import synth
+    n = int(sample_reads)
+    sp = synth.synth_params(n, seed=sp_full.seed, error_free=(sp_full.sub_ppm == 0))
+    rows, quals, bc = synth.synth_host(sp)
+    cores = os.cpu_count() or 1
+    drv = ROOT / "oracle" / "_ref" / "snref_driver"
+    if K == 48 and drv.exists():
+        sys.path.insert(0, str(ROOT / "tests"))
+        import refio
+        asc = synth.codes_to_ascii(synth.unpack_rows(rows, sp.read_len))
+        with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as td:
+            refio.write_snkrd(Path(td) / "in.snkrd", np.full(n, sp.read_len), asc, quals, bc)
+            out = refio.run_ref(Path(td) / "in.snkrd", Path(td) / "out", threads=cores, mode="time", timeout=1800)
+        m = re.search(r"SNREF_TIME seconds=([0-9.]+) threads=(\d+) reads=(\d+) kmer_instances=(\d+)", out)
+        secs, inst = float(m.group(1)), int(m.group(4))
+        return {"value": inst / secs / 1e9, "unit": "Gk-mers/s", "cores": cores, "kind": "reference",
+                "sample": f"{n} reads x {sp.read_len} bp of the same synthetic model ({inst} k-mer instances), "
+                          f"buildReadQGraph48 (count+unitigs+HBV, no read pathing), {secs:.2f} s on {cores} threads"}
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle_lib
+    n = min(n, 200_000)
+    gl = oracle_lib.good_lens(quals[:n], sp.read_len, K=K)
+    t0 = time.time()
+    o = oracle_lib.OracleResult(synth.unpack_rows(rows[:n], sp.read_len), gl, bc[:n], K=K, hbv=False)
+    secs = time.time() - t0
+    return {"value": o.n_instances / secs / 1e9, "unit": "Gk-mers/s", "cores": 1, "kind": "port",
+            "sample": f"{n} reads x {sp.read_len} bp, oracle/snk_oracle.c count+unitigs, {secs:.2f} s single thread"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from supernova_amd import synth
+    from supernova_amd.engine import Engine, Params
+
+    K = args.k
+    per_gpu = int(args.reads)
+    total_reads = per_gpu * world
+    eng = Engine(local_rank)
+    sp = synth.synth_params(total_reads, seed=0x5EED0000 + (1 if world == 1 else 2), error_free=args.error_free)
+    rows, quals, bc = eng.synth(sp, first=rank * per_gpu, n=per_gpu)
+    torch.cuda.synchronize()
+    params = Params(K=K)
+
+    if world == 1:
+        def step():
+            return eng.count_graph(rows, sp.read_len, quals=quals, bc=bc, params=params)
+    else:
+        from supernova_amd.sharded import ShardedEngine
+        sh = ShardedEngine(eng, dist)
+
+        def step():
+            return sh.count_graph(rows, sp.read_len, quals=quals, bc=bc, params=params, read_index_base=rank * per_gpu)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    res = None
+    for _ in range(args.warmup):
+        res = step()
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for _ in range(args.steps):
+        res = step()
+        kernel_ms.append(dict(res.kernel_ms))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    inst_local = res.n_instances_input if hasattr(res, "n_instances_input") else res.n_instances
+    if world > 1:
+        t = torch.tensor([elapsed, float(inst_local)], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+        inst_total = float(tsum[1])
+    else:
+        inst_total = float(inst_local)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = inst_total * args.steps / elapsed / 1e9
+        # dominant kernel: the LDS count/filter kernel (one launch per step per GPU); units per launch =
+        # the k-mer instances this rank's launch reduces
+        count_ms = sum(k["count"] for k in kernel_ms) / len(kernel_ms)
+        units = float(res.n_instances)
+        achieved = units * ALG_BYTES_PER_KMER[K] / (count_ms * 1e-3) / 1e9
+        traffic = None
+        tf = ROOT / "profiles" / "traffic.json"
+        if tf.exists():
+            try:
+                tj = json.loads(tf.read_text())
+                if tj.get("reads_per_gpu") == per_gpu and tj.get("K") == K:
+                    traffic = tj.get("count_kernel_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": METRIC, "value": value, "unit": "Gk-mers/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"{total_reads} x {sp.read_len} bp synthetic linked reads "
+                                   f"({'error-free' if args.error_free else '0.2% substitutions, Q2 tails on 5%'}), "
+                                   f"k={K}, {'1xMI355X count+graph' if world == 1 else f'{world}xMI355X minimiser-sharded all-to-all'}",
+                       "reads_per_gpu": per_gpu, "k": K, "kmer_instances": int(inst_total),
+                       "retained_kmers_rank0": int(res.n_kmers), "unitigs_rank0": int(res.n_unitigs),
+                       "phase_ms_rank0": {k: round(v, 3) for k, v in res.phase_ms.items()}},
+            "roofline": {"bound": "hbm", "kernel": "snk_count_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "launch_ms": count_ms, "units_per_launch": units, "alg_bytes_per_unit": ALG_BYTES_PER_KMER[K]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(sp, K, args.cpu_sample)
+            except Exception as ex:  # the baseline is a report, never a reason to lose the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "Gk-mers/s", "cores": os.cpu_count(), "kind": "reference",
+                                       "sample": f"failed: {ex}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -142,6 +142,7 @@ typedef struct snk_dev_result {
     uint32_t reserved1;
     uint64_t scratch_bytes;
     float phase_ms[8];           /* trim, msp histogram, msp scatter, count, sort, prune+unitigs, -, total */
+    float kernel_ms[4];          /* HIP-event time of single launches: msp histogram, msp scatter, count (LDS reduce), - */
 } snk_dev_result;
 
 /* Replaces the body of buildReadQGraph48 (BuildReadQGraph48.cc:1688-1774, pPaths==nullptr) up to and

@@ -118,13 +118,17 @@ int main(int argc, char** argv) {
     if (mode == "time") {
         // whole reference path (count + unitigs + HBV, no read pathing), timed as the CPU baseline
         HyperBasevector hbv;
-        // k-mer instances = sum over reads of max(0, goodlen-K+1) is printed by the caller; here only wall time
+        {   // k-mer instances of the sample (untimed): sum over reads with goodlen >= K+1 of goodlen-K+1
+            std::vector<unsigned> goodLens(reads.size());
+            parallelForBatch(0ul, reads.size(), 100000, GoodLenTailFinder(quals.load(), minQual, &goodLens));
+            for (unsigned g : goodLens) if (g >= K + 1) nInst += g - K + 1;
+        }
         auto t0 = std::chrono::steady_clock::now();
         buildReadQGraph48(work, "/data/frag_reads_orig", "", reads, quals, False, False, minQual, minFreq,
                           in.ign_bc_below, minBC, bcp, .75, 0, "", True, False, &hbv, nullptr, 0.5, False);
         double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        printf("SNREF_TIME seconds=%.6f threads=%u reads=%lu hbv_edges=%d hbv_vertices=%d\n", s, nt,
-               (unsigned long)in.n, hbv.EdgeObjectCount(), hbv.N());
+        printf("SNREF_TIME seconds=%.6f threads=%u reads=%lu kmer_instances=%lu hbv_edges=%d hbv_vertices=%d\n", s, nt,
+               (unsigned long)in.n, (unsigned long)nInst, hbv.EdgeObjectCount(), hbv.N());
         return 0;
     }
 

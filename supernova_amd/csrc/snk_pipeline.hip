@@ -110,9 +110,12 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     SNK_HIP_TRY(hipMemsetAsync(hist, 0, (NB + 1) * 4ull, st));
     SNK_HIP_TRY(hipMemsetAsync(counters, 0, 64, st));
     SNK_HIP_TRY(hipMemsetAsync(status, 0, 64, st));
+    phase_timer kt(st);   // single-launch timings (events on the launch stream right around the kernel)
+    kt.mark();  // 0
     int rc = snk_launch_msp(K, false, st, (const uint32_t*)in->rows, in->row_words, good_len, (const int32_t*)in->bc,
                             in->ign_bc_below, in->read_index_base, n_reads, NB, hist, nullptr, counters, err, errcap);
     if (rc) return rc;
+    kt.mark();  // 1
     {
         size_t tb = 0;
         SNK_HIP_TRY(rocprim::exclusive_scan((void*)nullptr, tb, hist, cursor, 0u, (size_t)(NB + 1), rocprim::plus<uint32_t>(), st));
@@ -133,9 +136,11 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     // ---- K4 scatter pass
     void* records = nullptr;
     if ((rc = snk_ctx_alloc(ctx, (size_t)h_nsuper * 32 + 32, &records, err, errcap))) return rc;
+    kt.mark();  // 2
     rc = snk_launch_msp(K, true, st, (const uint32_t*)in->rows, in->row_words, good_len, (const int32_t*)in->bc,
                         in->ign_bc_below, in->read_index_base, n_reads, NB, cursor, records, nullptr, err, errcap);
     if (rc) return rc;
+    kt.mark();  // 3
     tm.mark();  // 3
 
     // ---- K5-K8 count + filter into a region-partitioned table, then gather the regions densely.
@@ -175,7 +180,10 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
         ca.region_cursor = rcur;
         ca.status = status;
         ca.dbg = env_u32("SNK_COUNT_DBG", 0);
+        if (kt.n > 4) kt.n = 4;
+        kt.mark();  // 4
         if ((rc = snk_launch_count(K, st, ca, err, errcap))) return rc;
+        kt.mark();  // 5
         SNK_HIP_TRY(hipMemcpyAsync(h_rcur.data(), rcur, n_regions * 8ull, hipMemcpyDeviceToHost, st));
         SNK_HIP_TRY(hipMemcpyAsync(h_status, status, 16, hipMemcpyDeviceToHost, st));
         SNK_HIP_TRY(hipStreamSynchronize(st));
@@ -246,6 +254,9 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     out->phase_ms[4] = tm.ms(4, 5);
     out->phase_ms[5] = tm.ms(5, 6);
     out->phase_ms[7] = tm.ms(0, 6);
+    out->kernel_ms[0] = kt.ms(0, 1);
+    out->kernel_ms[1] = kt.ms(2, 3);
+    out->kernel_ms[2] = kt.ms(4, 5);
     out->scratch_bytes = ctx->total_alloc;
     return SNK_OK;
 }

@@ -47,6 +47,8 @@ class Result:
                   "n_circles", "rank_rounds", "buckets_split", "max_slots_used", "scratch_bytes"):
             setattr(self, f, int(getattr(raw, f)))
         self.phase_ms = {PHASES[i]: float(raw.phase_ms[i]) for i in range(8) if PHASES[i] != "-"}
+        self.kernel_ms = {"msp_hist": float(raw.kernel_ms[0]), "msp_scatter": float(raw.kernel_ms[1]),
+                          "count": float(raw.kernel_ms[2])}
 
     def _dl(self, ptr, nbytes, dtype, shape):
         out = np.empty(shape, dtype=dtype)
