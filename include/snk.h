@@ -151,6 +151,60 @@ int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const snk_params*
                         char* err, size_t errcap);
 int snk_dev_download(snk_ctx* ctx, const void* d_src, void* h_dst, size_t bytes, void* stream);
 
+/* ---- minimiser-sharded multi-GPU path ------------------------------------------------
+ * One process per GPU.  The k-mer space is cut into NB_total minimiser buckets; rank r owns buckets
+ * [r*NB_total/world, (r+1)*NB_total/world).  The host runs the exchanges between the stages (RCCL
+ * all-to-all over xGMI); the reference's counterpart is the shardio file exchange + per-shard assembly +
+ * global join of tada (rust-shardio/src/shard.rs:184-211,488-493; cmd_shard_asm.rs:37-94;
+ * cmd_main_asm.rs:25-89) and the in-memory swizzle of MapReduceEngine.h:362-385.  Device pointers; pointers
+ * returned by a stage stay valid until the next snk_shard_hist on that context. */
+/* trim + supermer histogram over all NB_total buckets (d_hist: u32[NB_total]) */
+int snk_shard_hist(snk_ctx* ctx, const snk_dev_reads* in, const snk_params* p, uint32_t rank, uint32_t world,
+                   uint32_t NB_total, void* d_hist, uint64_t* n_instances, void* stream, char* err, size_t errcap);
+/* d_offsets: u32[NB_total+1] exclusive scan of d_hist; d_records: 32 bytes per supermer, bucket-major */
+int snk_shard_scatter(snk_ctx* ctx, const void* d_offsets, void* d_records, void* stream, char* err, size_t errcap);
+/* count the records received for my buckets: d_seg_off u64[world*(NB_total/world+1)] absolute record offsets */
+int snk_shard_count(snk_ctx* ctx, const void* d_records, const void* d_seg_off, uint64_t n_inst_hint, int has_bc,
+                    uint64_t* n_kmers, void* stream, char* err, size_t errcap);
+/* adjacency prune with remote membership queries (24 bytes each, answers 4 bytes each) */
+int snk_shard_prune_plan(snk_ctx* ctx, uint64_t* h_qcount /* [world] */, void* stream, char* err, size_t errcap);
+int snk_shard_prune_fill(snk_ctx* ctx, const void* d_qoff /* u64[world+1] */, void* d_qbuf, void* stream, char* err, size_t errcap);
+int snk_shard_prune_answer(snk_ctx* ctx, const void* d_queries, uint64_t nq, void* d_ans, void* stream, char* err, size_t errcap);
+int snk_shard_prune_apply(snk_ctx* ctx, const void* d_qbuf, const void* d_ans, uint64_t nq, const void* d_qoff, void* stream,
+                          char* err, size_t errcap);
+typedef struct snk_shard_frags {
+    uint64_t n_kmers;            /* this rank's share of the retained table */
+    const void* keys;            /* as snk_dev_result.keys */
+    const void* counts;
+    const void* ctx;
+    const void* spectrum;
+    uint32_t spectrum_bins;
+    uint32_t n_circles;
+    uint64_t n_frags;            /* local unitig fragments (tada's sedges) */
+    uint64_t total_bases;
+    const void* nk;              /* u32[n_frags] k-mers per fragment */
+    const void* hl_self;         /* u64[2*n_frags] global state id of each fragment end */
+    const void* hl_nb;           /* u64[2*n_frags] global state id the end wants to link to, or ~0 */
+    const void* boff;            /* u64[n_frags+1] */
+    const void* bases;           /* u8 base codes */
+    uint32_t rank_rounds, buckets_split, max_slots_used, reserved;
+    float count_ms, sort_ms, count_kernel_ms, reserved_f;
+} snk_shard_frags;
+/* d_node_off: u64[world+1] exclusive scan of the ranks' n_kmers (global node numbering) */
+int snk_shard_fragments(snk_ctx* ctx, const void* d_node_off, uint64_t my_node_off, snk_shard_frags* out, void* stream,
+                        char* err, size_t errcap);
+typedef struct snk_shard_unitigs {
+    uint64_t n_unitigs, total_bases;
+    const void* unitig_off;      /* u64[n_unitigs+1] */
+    const void* unitig_bases;    /* u8 base codes, canonical orientation */
+    const void* unitig_circular; /* u8[n_unitigs]: circle spanning ranks, cut at an arbitrary k-mer (host rotates) */
+    uint32_t n_circles, rank_rounds;
+} snk_shard_unitigs;
+/* rank 0: join the gathered fragments of every rank (tada MAIN_ASM_SN build_edges) */
+int snk_shard_join(snk_ctx* ctx, uint32_t K, uint64_t n_frags, const void* d_nk, const void* d_hl_self, const void* d_hl_nb,
+                   const void* d_boff, const void* d_bases, uint64_t total_bases, snk_shard_unitigs* out, void* stream,
+                   char* err, size_t errcap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -116,6 +116,7 @@ extern "C" void snk_ctx_destroy(snk_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     snk_ctx_release_scratch(ctx);
     snk_ctx_trim_cache(ctx);
+    if (ctx->shard) snk_shard_state_free(ctx->shard);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -129,5 +129,32 @@ SNK_HD void snk_kmer_hash2(snk_kmer k, uint32_t* h1out, uint32_t* h2out) {
     *h2out = snk_mix32(h2 ^ 0xdeadbeefu);
 }
 
+// ---------------------------------------------------------------- minimiser order and bucket (shared by K3/K4 and
+// the sharded graph stage, which must find the bucket -- hence the owner rank -- of an arbitrary k-mer)
+// ordering key of an M=16-mer given its code and its reverse complement's code: hash of the canonical one
+SNK_HD uint32_t snk_minimizer_key(uint32_t code, uint32_t rcode) { return snk_mix32(code < rcode ? code : rcode); }
+// bucket = re-mixed ordering key (see snk_msp.hip: never the raw key, never anything but the key)
+SNK_HD uint32_t snk_bucket_of_key(uint32_t key, uint32_t NB) {
+    uint32_t h = snk_mix32(key ^ 0x5bd1e995u) * 0x9E3779B1u;
+    h ^= h >> 15;
+    return (uint32_t)(((uint64_t)h * NB) >> 32);
+}
+// bucket of a k-mer = bucket of the minimum ordering key over its K-15 16-mers (strand symmetric)
+template <int K>
+SNK_HD uint32_t snk_bucket_of_kmer(snk_kmer k, uint32_t NB) {
+    uint32_t best = 0xFFFFFFFFu;
+    for (int p = 0; p + 16 <= K; ++p) {
+        uint64_t v;
+        if (p == 0) v = k.hi;
+        else if (p < 32) v = (k.hi << (2 * p)) | (k.lo >> (64 - 2 * p));
+        else if (p == 32) v = k.lo;
+        else v = k.lo << (2 * p - 64);
+        uint32_t x = (uint32_t)(v >> 32);
+        uint32_t key = snk_minimizer_key(x, snk_rev2_32(~x));
+        best = key < best ? key : best;
+    }
+    return snk_bucket_of_key(best, NB);
+}
+
 // base i of a packed row
 SNK_HD uint32_t snk_row_base(const uint32_t* row, int i) { return (row[i >> 4] >> (30 - 2 * (i & 15))) & 3u; }

@@ -1,0 +1,189 @@
+// snk_dist.hip -- C ABI of the minimiser-sharded (multi-GPU) path: stage entry points between which the host
+// runs the exchanges (torch.distributed over RCCL/xGMI).  SURVEY.md 8(e); the reference's counterpart is the
+// shardio exchange + per-shard processing + global join of tada
+// (lib/tada/external/rust-shardio/src/shard.rs:184-211,488-493; cmd_shard_asm.rs:37-94; cmd_main_asm.rs:25-89)
+// and the thread swizzle of MapReduceEngine.h:362-385.
+//
+//   rank r:  snk_shard_hist  -> [all-to-all of bucket counts] -> snk_shard_scatter -> [all-to-all of records]
+//            -> snk_shard_count -> snk_shard_prune_plan/fill -> [all-to-all of queries] -> snk_shard_prune_answer
+//            -> [all-to-all of answers] -> snk_shard_prune_apply -> snk_shard_fragments -> [gather to rank 0]
+//   rank 0:  snk_shard_join
+#include <string.h>
+
+#include <vector>
+
+#include "snk_ctx.h"
+#include "snk_common.h"
+#include "snk_graph.h"
+#include "snk_kernels.h"
+#include "snk_stages.h"
+
+struct snk_shard_state {
+    snk_dev_reads reads;
+    snk_params params;
+    uint32_t rank = 0, world = 1, NB_total = 0, NBl = 0;
+    const uint16_t* good_len = nullptr;
+    uint32_t* cursor = nullptr;
+    uint32_t* status = nullptr;
+    snk_table tab{};
+    snk_dist_graph g{};
+    snk_phase_timer* tm = nullptr;
+};
+
+static snk_shard_state* state_of(snk_ctx* ctx) {
+    if (!ctx->shard) ctx->shard = new snk_shard_state();
+    return static_cast<snk_shard_state*>(ctx->shard);
+}
+void snk_shard_state_free(void* p) { delete static_cast<snk_shard_state*>(p); }
+
+extern "C" int snk_shard_hist(snk_ctx* ctx, const snk_dev_reads* in, const snk_params* p, uint32_t rank, uint32_t world,
+                              uint32_t NB_total, void* d_hist, uint64_t* n_instances, void* stream, char* err, size_t errcap) {
+    if (!ctx || !in || !p || !d_hist) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_hist: NULL argument");
+    if (p->K != 48 && p->K != 60) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "K=%u is not supported (48 or 60)", p->K);
+    if (p->min_bc > 2) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "min_bc=%u: the device barcode rule supports 0, 1, 2", p->min_bc);
+    if (world == 0 || rank >= world || NB_total == 0 || NB_total % world) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_hist: NB_total must be a positive multiple of world");
+    if (world > 0x7FFF) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "world > 32767");
+    if (!in->rows || in->row_words * 16 < in->read_len || in->read_len > 256 || (!in->quals && !in->good_len))
+        return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_hist: bad reads");
+    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    snk_ctx_release_scratch(ctx);
+    snk_shard_state* S = state_of(ctx);
+    S->reads = *in;
+    S->params = *p;
+    S->rank = rank; S->world = world; S->NB_total = NB_total; S->NBl = NB_total / world;
+    const uint16_t* good_len = (const uint16_t*)in->good_len;
+    int rc;
+    if (!good_len) {
+        void* gl;
+        if ((rc = snk_ctx_alloc(ctx, in->n_reads * 2 + 2, &gl, err, errcap))) return rc;
+        rc = snk_dev_trim(ctx, in->quals, in->qstride, in->lens, in->read_len, in->n_reads, p->K, p->min_qual, gl, st);
+        if (rc) return snk_fail(rc, err, errcap, "%s", snk_last_error());
+        good_len = (const uint16_t*)gl;
+    }
+    S->good_len = good_len;
+    void* q;
+    if ((rc = snk_ctx_alloc(ctx, (NB_total + 1) * 4ull, &q, err, errcap))) return rc; S->cursor = (uint32_t*)q;
+    if ((rc = snk_ctx_alloc(ctx, 64, &q, err, errcap))) return rc; S->status = (uint32_t*)q;
+    unsigned long long* counter;
+    if ((rc = snk_ctx_alloc(ctx, 64, &q, err, errcap))) return rc; counter = (unsigned long long*)q;
+    SNK_HIP_TRY(hipMemsetAsync(d_hist, 0, (size_t)NB_total * 4, st));
+    SNK_HIP_TRY(hipMemsetAsync(counter, 0, 64, st));
+    SNK_HIP_TRY(hipMemsetAsync(S->status, 0, 64, st));
+    rc = snk_launch_msp(p->K, false, st, (const uint32_t*)in->rows, in->row_words, good_len, (const int32_t*)in->bc, in->ign_bc_below,
+                        in->read_index_base, in->n_reads, NB_total, (uint32_t*)d_hist, nullptr, counter, err, errcap);
+    if (rc) return rc;
+    unsigned long long h = 0;
+    SNK_HIP_TRY(hipMemcpyAsync(&h, counter, 8, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    if (n_instances) *n_instances = h;
+    return SNK_OK;
+}
+
+extern "C" int snk_shard_scatter(snk_ctx* ctx, const void* d_offsets, void* d_records, void* stream, char* err, size_t errcap) {
+    if (!ctx || !ctx->shard || !d_offsets || !d_records) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_scatter: NULL argument / no session");
+    snk_shard_state* S = state_of(ctx);
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    SNK_HIP_TRY(hipMemcpyAsync(S->cursor, d_offsets, (S->NB_total + 1) * 4ull, hipMemcpyDeviceToDevice, st));
+    const snk_dev_reads& in = S->reads;
+    return snk_launch_msp(S->params.K, true, st, (const uint32_t*)in.rows, in.row_words, S->good_len, (const int32_t*)in.bc, in.ign_bc_below,
+                          in.read_index_base, in.n_reads, S->NB_total, S->cursor, d_records, nullptr, err, errcap);
+}
+
+extern "C" int snk_shard_count(snk_ctx* ctx, const void* d_records, const void* d_seg_off, uint64_t n_inst_hint, int has_bc,
+                               uint64_t* n_kmers, void* stream, char* err, size_t errcap) {
+    if (!ctx || !ctx->shard || !d_seg_off) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_count: NULL argument / no session");
+    snk_shard_state* S = state_of(ctx);
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    int rc = snk_stage_count_table(ctx, st, S->params.K, d_records, (const uint64_t*)d_seg_off, S->world, S->NBl, S->params.min_freq,
+                                   has_bc ? S->params.min_bc : 0u, n_inst_hint, S->status, &S->tab, err, errcap);
+    if (rc) return rc;
+    if (n_kmers) *n_kmers = S->tab.n;
+    return SNK_OK;
+}
+
+extern "C" int snk_shard_prune_plan(snk_ctx* ctx, uint64_t* h_qcount, void* stream, char* err, size_t errcap) {
+    if (!ctx || !ctx->shard || !h_qcount) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_prune_plan: NULL argument / no session");
+    snk_shard_state* S = state_of(ctx);
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    snk_dist_graph& g = S->g;
+    memset(&g, 0, sizeof g);
+    g.K = S->params.K; g.rank = S->rank; g.world = S->world; g.NB_total = S->NB_total; g.NBl = S->NBl;
+    g.do_prune = S->params.min_freq > 1 ? 1u : 0u;
+    g.n = S->tab.n; g.keys = S->tab.keys; g.vals = S->tab.vals;
+    int rc = snk_dist_prune_plan(ctx, st, &g, err, errcap);
+    if (rc) return rc;
+    std::vector<unsigned long long> h(S->world);
+    SNK_HIP_TRY(hipMemcpyAsync(h.data(), g.qcount, S->world * 8ull, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    for (uint32_t r = 0; r < S->world; ++r) h_qcount[r] = h[r];
+    return SNK_OK;
+}
+extern "C" int snk_shard_prune_fill(snk_ctx* ctx, const void* d_qoff, void* d_qbuf, void* stream, char* err, size_t errcap) {
+    if (!ctx || !ctx->shard || !d_qoff) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_prune_fill: NULL argument / no session");
+    snk_shard_state* S = state_of(ctx);
+    return snk_dist_fill_queries(ctx, stream ? (hipStream_t)stream : ctx->stream, &S->g, (const unsigned long long*)d_qoff, d_qbuf, err, errcap);
+}
+extern "C" int snk_shard_prune_answer(snk_ctx* ctx, const void* d_queries, uint64_t nq, void* d_ans, void* stream, char* err, size_t errcap) {
+    if (!ctx || !ctx->shard) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_prune_answer: no session");
+    snk_shard_state* S = state_of(ctx);
+    return snk_dist_answer(ctx, stream ? (hipStream_t)stream : ctx->stream, &S->g, d_queries, nq, d_ans, err, errcap);
+}
+extern "C" int snk_shard_prune_apply(snk_ctx* ctx, const void* d_qbuf, const void* d_ans, uint64_t nq, const void* d_qoff, void* stream,
+                                     char* err, size_t errcap) {
+    if (!ctx || !ctx->shard) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_prune_apply: no session");
+    snk_shard_state* S = state_of(ctx);
+    return snk_dist_apply(ctx, stream ? (hipStream_t)stream : ctx->stream, &S->g, d_qbuf, d_ans, nq, (const unsigned long long*)d_qoff, err, errcap);
+}
+
+extern "C" int snk_shard_fragments(snk_ctx* ctx, const void* d_node_off, uint64_t my_node_off, snk_shard_frags* out, void* stream,
+                                   char* err, size_t errcap) {
+    if (!ctx || !ctx->shard || !out || !d_node_off) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_fragments: NULL argument / no session");
+    snk_shard_state* S = state_of(ctx);
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    snk_frag_out fo;
+    int rc = snk_dist_fragments(ctx, st, &S->g, (const unsigned long long*)d_node_off, my_node_off, &fo, err, errcap);
+    if (rc) return rc;
+    memset(out, 0, sizeof *out);
+    out->n_kmers = S->tab.n;
+    out->keys = S->tab.keys;
+    out->counts = S->g.counts;
+    out->ctx = S->g.ctx;
+    out->spectrum = fo.spectrum;
+    out->spectrum_bins = fo.spectrum_bins;
+    out->n_frags = fo.n_frags;
+    out->total_bases = fo.total_bases;
+    out->nk = fo.nk;
+    out->hl_self = fo.hl_self;
+    out->hl_nb = fo.hl_nb;
+    out->boff = fo.boff;
+    out->bases = fo.bases;
+    out->n_circles = fo.n_circles;
+    out->rank_rounds = fo.rank_rounds;
+    out->buckets_split = S->tab.buckets_split;
+    out->max_slots_used = S->tab.max_slots_used;
+    out->count_ms = S->tab.count_ms;
+    out->sort_ms = S->tab.sort_ms;
+    out->count_kernel_ms = S->tab.count_kernel_ms;
+    return SNK_OK;
+}
+
+extern "C" int snk_shard_join(snk_ctx* ctx, uint32_t K, uint64_t n_frags, const void* d_nk, const void* d_hl_self, const void* d_hl_nb,
+                              const void* d_boff, const void* d_bases, uint64_t total_bases, snk_shard_unitigs* out, void* stream,
+                              char* err, size_t errcap) {
+    if (!ctx || !out) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_join: NULL argument");
+    if (K != 48 && K != 60) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "K=%u is not supported (48 or 60)", K);
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    snk_join_out jo;
+    int rc = snk_dist_join(ctx, st, K, n_frags, (const uint32_t*)d_nk, (const unsigned long long*)d_hl_self,
+                           (const unsigned long long*)d_hl_nb, (const uint64_t*)d_boff, (const uint8_t*)d_bases, total_bases, &jo, err, errcap);
+    if (rc) return rc;
+    out->n_unitigs = jo.n_unitigs;
+    out->total_bases = jo.total_bases;
+    out->unitig_off = jo.unitig_off;
+    out->unitig_bases = jo.unitig_bases;
+    out->unitig_circular = jo.unitig_circular;
+    out->n_circles = jo.n_circles;
+    out->rank_rounds = jo.rank_rounds;
+    return SNK_OK;
+}

@@ -20,3 +20,51 @@ int snk_graph_sort(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t n, snk_u12
                    snk_u128* keys_out, uint64_t* vals_out, char* err, size_t errcap);
 int snk_graph_build(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_u128* keys, const uint64_t* vals, uint64_t n,
                     uint32_t do_prune, bool want_unitigs, snk_graph_out* out, char* err, size_t errcap);
+
+// ---- sharded graph stage (snk_graph.hip, second half)
+struct snk_dist_graph {
+    uint32_t K, rank, world, NB_total, NBl, do_prune;
+    uint64_t n;
+    const snk_u128* keys;
+    const uint64_t* vals;
+    unsigned long long* index;
+    uint64_t index_mask;
+    uint8_t* ctx;
+    uint32_t* counts;
+    uint8_t* pend;
+    uint8_t* dest;
+    uint32_t* nbr_local;
+    uint32_t* rq_idx;
+    uint16_t* rq_meta;
+    unsigned long long* qcount;    // [world] queries per destination rank (device)
+    unsigned long long* qcursor;
+};
+struct snk_frag_out {
+    uint64_t n_frags, total_bases;
+    uint32_t* nk;
+    unsigned long long* hl_self;
+    unsigned long long* hl_nb;
+    uint64_t* boff;
+    uint8_t* bases;
+    unsigned long long* spectrum;
+    uint32_t spectrum_bins, n_circles, rank_rounds;
+};
+struct snk_join_out {
+    uint64_t n_unitigs, total_bases;
+    uint64_t* unitig_off;
+    uint8_t* unitig_bases;
+    uint8_t* unitig_circular;   // 1: a circle that spans ranks, cut at an arbitrary k-mer (host rotates it)
+    uint32_t n_circles, rank_rounds;
+};
+int snk_dist_prune_plan(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, char* err, size_t errcap);
+int snk_dist_fill_queries(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, const unsigned long long* d_qoff, void* d_qbuf,
+                          char* err, size_t errcap);
+int snk_dist_answer(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, const void* d_queries, uint64_t nq, void* d_ans, char* err,
+                    size_t errcap);
+int snk_dist_apply(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, const void* d_qbuf, const void* d_ans, uint64_t nq,
+                   const unsigned long long* d_qoff, char* err, size_t errcap);
+int snk_dist_fragments(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, const unsigned long long* d_node_off,
+                       unsigned long long my_node_off, snk_frag_out* out, char* err, size_t errcap);
+int snk_dist_join(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const uint32_t* nk, const unsigned long long* hl_self,
+                  const unsigned long long* hl_nb, const uint64_t* boff, const uint8_t* fbases, uint64_t total_fbases,
+                  snk_join_out* out, char* err, size_t errcap);

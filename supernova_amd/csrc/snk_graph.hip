@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(TB) cyc_round_kernel(const uint32_t* __restric
 }
 // cut every circle at the left side of its minimum k-mer
 __global__ void __launch_bounds__(TB) cyc_cut_kernel(const uint32_t* __restrict__ mn, uint64_t n, uint32_t* __restrict__ link,
-                                                     uint32_t* __restrict__ n_cut) {
+                                                     uint32_t* __restrict__ n_cut, uint8_t* __restrict__ circ_state) {
     uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x;
     if (i >= n) return;
     uint64_t s = 2 * i + 1;
@@ -196,6 +196,7 @@ __global__ void __launch_bounds__(TB) cyc_cut_kernel(const uint32_t* __restrict_
         uint32_t partner = link[s];
         link[s] = NONE;
         if (partner != NONE) link[partner] = NONE;
+        if (circ_state) { circ_state[s] = 1; if (partner != NONE) circ_state[partner] = 1; }   // both new terminals
         atomicAdd(n_cut, 1u);
     }
 }
@@ -363,6 +364,76 @@ int snk_graph_sort(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t n, snk_u12
     return snk_fail(SNK_E_INTERNAL, err, errcap, "retained k-mer table is not strictly ascending after the sort");
 }
 
+// weighted start of the ranking (fragment join): the distance counts k-mers, not hops
+__global__ void __launch_bounds__(TB) rank_init_w_kernel(const uint32_t* __restrict__ link, const uint32_t* __restrict__ w,
+                                                         uint64_t ns, uint32_t* __restrict__ nxt, uint32_t* __restrict__ dist,
+                                                         uint32_t* __restrict__ tail) {
+    uint64_t s = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (s >= ns) return;
+    uint32_t l = link[s];
+    if (l == NONE) { nxt[s] = NONE; dist[s] = 0; tail[s] = (uint32_t)s; }
+    else { nxt[s] = l ^ 1u; dist[s] = w[l >> 1]; tail[s] = l ^ 1u; }
+}
+// List ranking over the 2n directed states (node, exit side) of a degree<=2 link graph: for every state the
+// number of steps (or summed weights) to the end of its path and the terminal state.  Smooth circles are cut
+// at the left side of their minimum node and ranked again.  link[] is modified by the cut.
+static int rank_lists(snk_ctx* ctx, hipStream_t st, uint32_t* link, uint64_t n, const uint32_t* weights, uint8_t* circ /* per state, nullable */,
+                      const uint32_t** dist_out, const uint32_t** tail_out, uint32_t* n_circles, uint32_t* rounds,
+                      char* err, size_t errcap) {
+    const uint64_t ns = 2 * n;
+    uint32_t *nxt[2], *dst[2], *tl[2];
+    for (int b = 0; b < 2; ++b) { G_ALLOC(nxt[b], uint32_t, ns); G_ALLOC(dst[b], uint32_t, ns); G_ALLOC(tl[b], uint32_t, ns); }
+    uint32_t* flags;   // [0] changed, [1] circles cut
+    G_ALLOC(flags, uint32_t, 4);
+    uint32_t* h_flags = nullptr;
+    SNK_HIP_TRY(hipHostMalloc((void**)&h_flags, 16, hipHostMallocDefault));
+    int max_rounds = 2;
+    while ((1ull << (max_rounds - 1)) < ns) ++max_rounds;
+    int cur = 0;
+    uint32_t rounds_total = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        cur = 0;
+        if (weights) hipLaunchKernelGGL(rank_init_w_kernel, dim3(nblk(ns)), dim3(TB), 0, st, link, weights, ns, nxt[0], dst[0], tl[0]);
+        else hipLaunchKernelGGL(rank_init_kernel, dim3(nblk(ns)), dim3(TB), 0, st, link, ns, nxt[0], dst[0], tl[0]);
+        bool converged = false;
+        for (int r = 0; r < max_rounds; ++r) {
+            SNK_HIP_TRY(hipMemsetAsync(flags, 0, 4, st));
+            hipLaunchKernelGGL(rank_round_kernel, dim3(nblk(ns)), dim3(TB), 0, st, nxt[cur], dst[cur], tl[cur], ns,
+                               nxt[cur ^ 1], dst[cur ^ 1], tl[cur ^ 1], flags);
+            cur ^= 1;
+            ++rounds_total;
+            SNK_HIP_TRY(hipMemcpyAsync(h_flags, flags, 4, hipMemcpyDeviceToHost, st));
+            SNK_HIP_TRY(hipStreamSynchronize(st));
+            if (h_flags[0] == 0) { converged = true; break; }
+        }
+        if (converged) break;
+        if (attempt == 1) { (void)hipHostFree(h_flags); return snk_fail(SNK_E_INTERNAL, err, errcap, "unitig ranking did not converge after the circle cut"); }
+        // smooth circles: find each circle's minimum k-mer (index order == key order), cut there, rank again
+        uint32_t *jump[2] = {dst[cur ^ 1], tl[cur ^ 1]};   // reuse the spare ranking buffers
+        uint32_t* mn[2];
+        G_ALLOC(mn[0], uint32_t, ns);
+        G_ALLOC(mn[1], uint32_t, ns);
+        hipLaunchKernelGGL(cyc_init_kernel, dim3(nblk(ns)), dim3(TB), 0, st, nxt[cur], link, ns, jump[0], mn[0]);
+        int c2 = 0;
+        for (int r = 0; r < max_rounds; ++r) {
+            hipLaunchKernelGGL(cyc_round_kernel, dim3(nblk(ns)), dim3(TB), 0, st, jump[c2], mn[c2], ns, jump[c2 ^ 1], mn[c2 ^ 1]);
+            c2 ^= 1;
+        }
+        SNK_HIP_TRY(hipMemsetAsync(flags + 1, 0, 4, st));
+        hipLaunchKernelGGL(cyc_cut_kernel, dim3(nblk(n)), dim3(TB), 0, st, mn[c2], n, link, flags + 1, circ);
+        SNK_HIP_TRY(hipGetLastError());
+    }
+    SNK_HIP_TRY(hipMemcpyAsync(h_flags, flags, 8, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    *n_circles = h_flags[1];
+    *rounds = rounds_total;
+    (void)hipHostFree(h_flags);
+    *dist_out = dst[cur];
+    *tail_out = tl[cur];
+    return SNK_OK;
+}
+
+
 template <int K>
 static int graph_impl(snk_ctx* ctx, hipStream_t st, const snk_u128* keys, const uint64_t* vals, uint64_t n,
                       uint32_t do_prune, bool want_unitigs, snk_graph_out* out, char* err, size_t errcap) {
@@ -406,53 +477,12 @@ static int graph_impl(snk_ctx* ctx, hipStream_t st, const snk_u128* keys, const 
     hipLaunchKernelGGL((link_kernel<K>), dim3(nblk(ns)), dim3(TB), 0, st, keys, ctx_out, nbr, n, link);
     SNK_HIP_TRY(hipGetLastError());
 
-    uint32_t *nxt[2], *dst[2], *tl[2];
-    for (int b = 0; b < 2; ++b) { G_ALLOC(nxt[b], uint32_t, ns); G_ALLOC(dst[b], uint32_t, ns); G_ALLOC(tl[b], uint32_t, ns); }
-    uint32_t* flags;   // [0] changed, [1] circles cut
-    G_ALLOC(flags, uint32_t, 4);
-    uint32_t* h_flags = nullptr;
-    SNK_HIP_TRY(hipHostMalloc((void**)&h_flags, 16, hipHostMallocDefault));
-    int max_rounds = 2;
-    while ((1ull << (max_rounds - 1)) < ns) ++max_rounds;
-    int cur = 0;
-    uint32_t rounds_total = 0;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        cur = 0;
-        hipLaunchKernelGGL(rank_init_kernel, dim3(nblk(ns)), dim3(TB), 0, st, link, ns, nxt[0], dst[0], tl[0]);
-        bool converged = false;
-        for (int r = 0; r < max_rounds; ++r) {
-            SNK_HIP_TRY(hipMemsetAsync(flags, 0, 4, st));
-            hipLaunchKernelGGL(rank_round_kernel, dim3(nblk(ns)), dim3(TB), 0, st, nxt[cur], dst[cur], tl[cur], ns,
-                               nxt[cur ^ 1], dst[cur ^ 1], tl[cur ^ 1], flags);
-            cur ^= 1;
-            ++rounds_total;
-            SNK_HIP_TRY(hipMemcpyAsync(h_flags, flags, 4, hipMemcpyDeviceToHost, st));
-            SNK_HIP_TRY(hipStreamSynchronize(st));
-            if (h_flags[0] == 0) { converged = true; break; }
-        }
-        if (converged) break;
-        if (attempt == 1) { (void)hipHostFree(h_flags); return snk_fail(SNK_E_INTERNAL, err, errcap, "unitig ranking did not converge after the circle cut"); }
-        // smooth circles: find each circle's minimum k-mer (index order == key order), cut there, rank again
-        uint32_t *jump[2] = {dst[cur ^ 1], tl[cur ^ 1]};   // reuse the spare ranking buffers
-        uint32_t* mn[2];
-        G_ALLOC(mn[0], uint32_t, ns);
-        G_ALLOC(mn[1], uint32_t, ns);
-        hipLaunchKernelGGL(cyc_init_kernel, dim3(nblk(ns)), dim3(TB), 0, st, nxt[cur], link, ns, jump[0], mn[0]);
-        int c2 = 0;
-        for (int r = 0; r < max_rounds; ++r) {
-            hipLaunchKernelGGL(cyc_round_kernel, dim3(nblk(ns)), dim3(TB), 0, st, jump[c2], mn[c2], ns, jump[c2 ^ 1], mn[c2 ^ 1]);
-            c2 ^= 1;
-        }
-        SNK_HIP_TRY(hipMemsetAsync(flags + 1, 0, 4, st));
-        hipLaunchKernelGGL(cyc_cut_kernel, dim3(nblk(n)), dim3(TB), 0, st, mn[c2], n, link, flags + 1);
-        SNK_HIP_TRY(hipGetLastError());
+    const uint32_t* dist = nullptr;
+    const uint32_t* tail = nullptr;
+    {
+        int rc = rank_lists(ctx, st, link, n, nullptr, nullptr, &dist, &tail, &out->n_circles, &out->rank_rounds, err, errcap);
+        if (rc) return rc;
     }
-    SNK_HIP_TRY(hipMemcpyAsync(h_flags, flags, 8, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
-    out->n_circles = h_flags[1];
-    out->rank_rounds = rounds_total;
-    const uint32_t* dist = dst[cur];
-    const uint32_t* tail = tl[cur];
 
     uint8_t* prev;
     G_ALLOC(prev, uint8_t, ns);
@@ -478,13 +508,12 @@ static int graph_impl(snk_ctx* ctx, hipStream_t st, const snk_u128* keys, const 
         SNK_HIP_TRY(rocprim::exclusive_scan(tmp, t1, hflag, hidx, 0u, (size_t)(n + 1), rocprim::plus<uint32_t>(), st));
         SNK_HIP_TRY(rocprim::exclusive_scan(tmp, t2, hlen, hoff, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), st));
     }
-    uint64_t* h_tot = reinterpret_cast<uint64_t*>(h_flags);
+    uint64_t h_tot = 0;
     uint32_t h_nu = 0;
     SNK_HIP_TRY(hipMemcpyAsync(&h_nu, hidx + n, 4, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipMemcpyAsync(h_tot, hoff + n, 8, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipMemcpyAsync(&h_tot, hoff + n, 8, hipMemcpyDeviceToHost, st));
     SNK_HIP_TRY(hipStreamSynchronize(st));
-    uint64_t n_unitigs = h_nu, total_bases = h_tot[0];
-    (void)hipHostFree(h_flags);
+    uint64_t n_unitigs = h_nu, total_bases = h_tot;
     uint64_t *poff, *uoff;
     uint8_t* bases;
     G_ALLOC(poff, uint64_t, ns);
@@ -506,4 +535,552 @@ int snk_graph_build(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_u128* ke
     if (K == 48) return graph_impl<48>(ctx, st, keys, vals, n, do_prune, want_unitigs, out, err, errcap);
     if (K == 60) return graph_impl<60>(ctx, st, keys, vals, n, do_prune, want_unitigs, out, err, errcap);
     return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "K=%u is not supported (48 or 60)", K);
+}
+
+// =====================================================================================================================
+// Sharded graph stage: every rank owns the retained k-mers of its minimiser buckets.
+//   * prune: neighbours that are not in the local table are either absent (their bucket is ours) or live on
+//     another rank -> one round of membership queries (all-to-all) resolves them;
+//   * links: a link whose two k-mers live on one rank is decided there; a side whose single neighbour is remote
+//     ends the local fragment and exports a "half link" (my terminal state -> remote state).  Two half links
+//     that point at each other are a link (the reciprocal-unique rule of BuildReadQGraph48.cc:408-428 checked
+//     half on each owner);
+//   * local fragments are ranked and emitted per rank (tada's per-shard sedges, lib/tada/src/debruijn.rs:296-320),
+//     rank 0 joins them (tada's MAIN_ASM_SN build_edges, debruijn.rs:733-776) with the same list ranking,
+//     weighted by k-mers, then applies the reference's canonical orientation.
+// =====================================================================================================================
+namespace {
+
+constexpr unsigned long long NONE64 = ~0ull;
+
+template <int K>
+__global__ void __launch_bounds__(TB) prune_dist_kernel(const snk_u128* __restrict__ keys, const uint64_t* __restrict__ vals,
+                                                        uint64_t n, const unsigned long long* __restrict__ tab, uint64_t mask,
+                                                        uint32_t NB_total, uint32_t NBl, uint32_t me,
+                                                        uint8_t* __restrict__ ctx_out, uint32_t* __restrict__ count_out,
+                                                        uint8_t* __restrict__ pend, uint8_t* __restrict__ dest,
+                                                        uint32_t* __restrict__ nbr_local,
+                                                        unsigned long long* __restrict__ qcount) {
+    uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    snk_kmer k = load_key(keys, i);
+    uint64_t v = vals[i];
+    uint32_t c = (uint32_t)(v & 0xFFu);
+    count_out[i] = (uint32_t)(v >> 8);
+    uint32_t keep = 0, pmask = 0;
+    uint32_t nb0 = NONE, nb1 = NONE;
+    for (uint32_t bit = 0; bit < 8; ++bit) {
+        if (!(c & (1u << bit))) continue;
+        snk_kmer y = bit < 4 ? snk_kmer_succ<K>(k, bit) : snk_kmer_pred<K>(k, bit - 4);
+        uint32_t rev;
+        int64_t j = find_any<K>(keys, tab, mask, y, &rev);
+        if (j >= 0) {
+            keep |= 1u << bit;
+            if (bit < 4) nb0 = ((uint32_t)j << 1) | rev; else nb1 = ((uint32_t)j << 1) | rev;
+        } else {
+            uint32_t owner = snk_bucket_of_kmer<K>(y, NB_total) / NBl;
+            if (owner != me) {                       // lives (if anywhere) on another rank: ask
+                keep |= 1u << bit;
+                pmask |= 1u << bit;
+                dest[8 * i + bit] = (uint8_t)owner;
+                atomicAdd(&qcount[owner], 1ull);
+            }                                        // else: its bucket is ours and it is not retained -> pruned
+        }
+    }
+    ctx_out[i] = (uint8_t)keep;
+    pend[i] = (uint8_t)pmask;
+    nbr_local[2 * i + 0] = nb0;
+    nbr_local[2 * i + 1] = nb1;
+}
+
+// query record: 3 x u64 = key lo, key hi, (node | bit << 32 | rev << 40)
+template <int K>
+__global__ void __launch_bounds__(TB) fill_queries_kernel(const snk_u128* __restrict__ keys, uint64_t n,
+                                                          const uint8_t* __restrict__ pend, const uint8_t* __restrict__ dest,
+                                                          unsigned long long* __restrict__ qcursor,
+                                                          unsigned long long* __restrict__ qbuf) {
+    uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    uint32_t pm = pend[i];
+    if (!pm) return;
+    snk_kmer k = load_key(keys, i);
+    for (uint32_t bit = 0; bit < 8; ++bit) {
+        if (!(pm & (1u << bit))) continue;
+        snk_kmer y = bit < 4 ? snk_kmer_succ<K>(k, bit) : snk_kmer_pred<K>(k, bit - 4);
+        snk_kmer r = snk_kmer_rc<K>(y);
+        bool rev = snk_kmer_lt(r, y);
+        snk_kmer c = rev ? r : y;
+        unsigned long long slot = atomicAdd(&qcursor[dest[8 * i + bit]], 1ull);
+        qbuf[3 * slot + 0] = c.lo;
+        qbuf[3 * slot + 1] = c.hi;
+        qbuf[3 * slot + 2] = (unsigned long long)i | ((unsigned long long)bit << 32) | ((unsigned long long)(rev ? 1 : 0) << 40);
+    }
+}
+
+__global__ void __launch_bounds__(TB) answer_kernel(const unsigned long long* __restrict__ q, uint64_t nq,
+                                                    const snk_u128* __restrict__ keys, const unsigned long long* __restrict__ tab,
+                                                    uint64_t mask, uint32_t* __restrict__ ans) {
+    uint64_t t = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (t >= nq) return;
+    snk_kmer k;
+    k.lo = q[3 * t];
+    k.hi = q[3 * t + 1];
+    int64_t j = index_find(keys, tab, mask, k);
+    ans[t] = j >= 0 ? (uint32_t)j : NONE;
+}
+
+// answers come back in the order the queries were sent; qoff[r]..qoff[r+1] went to rank r
+__global__ void __launch_bounds__(TB) apply_answers_kernel(const unsigned long long* __restrict__ q, const uint32_t* __restrict__ ans,
+                                                           uint64_t nq, const unsigned long long* __restrict__ qoff, uint32_t world,
+                                                           uint32_t do_prune, uint32_t* __restrict__ ctx_words,
+                                                           uint32_t* __restrict__ rq_idx, uint16_t* __restrict__ rq_meta) {
+    uint64_t t = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (t >= nq) return;
+    unsigned long long m = q[3 * t + 2];
+    uint64_t i = (uint32_t)m;
+    uint32_t bit = (uint32_t)(m >> 32) & 0xFFu, rev = (uint32_t)(m >> 40) & 1u;
+    uint32_t a = ans[t];
+    uint32_t rank = 0;
+    while (rank + 1 < world && t >= qoff[rank + 1]) ++rank;
+    uint32_t side = bit >> 2;
+    if (a == NONE) {
+        if (do_prune) atomicAnd(&ctx_words[i >> 2], ~((1u << bit) << (8 * (i & 3))));
+    } else {
+        rq_idx[2 * i + side] = a;
+        rq_meta[2 * i + side] = (uint16_t)(rank | (rev << 15));
+    }
+}
+
+template <int K>
+__global__ void __launch_bounds__(TB) link_dist_kernel(const snk_u128* __restrict__ keys, const uint8_t* __restrict__ ctx,
+                                                       const uint8_t* __restrict__ pend, const uint32_t* __restrict__ nbr_local,
+                                                       const uint32_t* __restrict__ rq_idx, const uint16_t* __restrict__ rq_meta,
+                                                       uint64_t n, const unsigned long long* __restrict__ node_off,
+                                                       uint32_t* __restrict__ link, unsigned long long* __restrict__ hl_nb) {
+    uint64_t s = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (s >= 2 * n) return;
+    uint64_t i = s >> 1;
+    uint32_t side = (uint32_t)(s & 1);
+    uint32_t c = ctx[i];
+    uint32_t bits = side ? (c >> 4) : (c & 15u);
+    uint32_t out = NONE;
+    unsigned long long hl = NONE64;
+    if (__popc(bits) == 1) {
+        uint32_t b = __ffs(bits) - 1;
+        snk_kmer ki = load_key(keys, i);
+        if (!snk_kmer_eq(ki, snk_kmer_rc<K>(ki))) {
+            bool remote = (pend[i] >> (4 * side + b)) & 1u;
+            if (!remote) {
+                uint32_t nb = nbr_local[s];
+                if (nb != NONE) {
+                    uint32_t j = nb >> 1, rev = nb & 1u;
+                    snk_kmer kj = load_key(keys, j);
+                    uint32_t fs = side ^ 1u ^ rev;
+                    uint32_t cj = ctx[j];
+                    uint32_t deg = fs ? __popc(cj & 0xF0u) : __popc(cj & 0x0Fu);
+                    if (!snk_kmer_eq(kj, snk_kmer_rc<K>(kj)) && deg == 1) out = (j << 1) | fs;
+                }
+            } else {
+                uint32_t a = rq_idx[s];
+                if (a != NONE) {
+                    snk_kmer y = side ? snk_kmer_pred<K>(ki, b) : snk_kmer_succ<K>(ki, b);
+                    if (!snk_kmer_eq(y, snk_kmer_rc<K>(y))) {
+                        uint32_t meta = rq_meta[s];
+                        uint32_t rank = meta & 0x7FFFu, rev = meta >> 15;
+                        uint32_t fs = side ^ 1u ^ rev;
+                        hl = 2ull * (node_off[rank] + a) + fs;
+                    }
+                }
+            }
+        }
+    }
+    link[s] = out;
+    hl_nb[s] = hl;
+}
+
+// per fragment (head node = the node at position 0 walking from terminal pid): k-mer count and the two half links
+__global__ void __launch_bounds__(TB) frag_desc_kernel(const uint32_t* __restrict__ dist, const uint32_t* __restrict__ tail,
+                                                       const uint32_t* __restrict__ hflag, const uint32_t* __restrict__ hidx,
+                                                       const unsigned long long* __restrict__ hl_nb_state, uint64_t n,
+                                                       unsigned long long my_state_base, uint32_t* __restrict__ nk,
+                                                       unsigned long long* __restrict__ hl_self, unsigned long long* __restrict__ hl_nb) {
+    uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (i >= n || !hflag[i]) return;
+    node_place p = place_of(dist, tail, i);
+    uint32_t f = hidx[i];
+    nk[f] = p.n;
+    hl_self[2 * f + 0] = my_state_base + p.pid;
+    hl_self[2 * f + 1] = my_state_base + p.other;
+    hl_nb[2 * f + 0] = hl_nb_state[p.pid];
+    hl_nb[2 * f + 1] = hl_nb_state[p.other];
+}
+
+// ---- join (rank 0)
+__global__ void __launch_bounds__(TB) jhash_build_kernel(const unsigned long long* __restrict__ hl_self, uint64_t ne,
+                                                         unsigned long long* __restrict__ hk, uint32_t* __restrict__ hv, uint64_t mask) {
+    uint64_t e = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (e >= ne) return;
+    unsigned long long key = hl_self[e] + 1;
+    uint64_t slot = snk_mix64(key) & mask;
+    for (;;) {
+        unsigned long long old = atomicCAS(&hk[slot], 0ull, key);
+        if (old == 0ull) { hv[slot] = (uint32_t)e; break; }
+        slot = (slot + 1) & mask;
+    }
+}
+__global__ void __launch_bounds__(TB) jmatch_kernel(const unsigned long long* __restrict__ hl_self, const unsigned long long* __restrict__ hl_nb,
+                                                    uint64_t ne, const unsigned long long* __restrict__ hk, const uint32_t* __restrict__ hv,
+                                                    uint64_t mask, uint32_t* __restrict__ flink) {
+    uint64_t e = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (e >= ne) return;
+    unsigned long long nb = hl_nb[e];
+    uint32_t out = NONE;
+    if (nb != NONE64) {
+        unsigned long long key = nb + 1;
+        uint64_t slot = snk_mix64(key) & mask;
+        for (;;) {
+            unsigned long long h = hk[slot];
+            if (h == 0ull) break;
+            if (h == key) {
+                uint32_t e2 = __hip_atomic_load(&hv[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (hl_nb[e2] == hl_self[e]) out = e2;      // the other owner points back at me: a link
+                break;
+            }
+            slot = (slot + 1) & mask;
+        }
+    }
+    flink[e] = out;
+}
+
+struct frag_place { uint32_t pid, other; uint64_t N; uint64_t koff; bool rc; };
+__device__ __forceinline__ frag_place frag_place_of(const uint32_t* dist, const uint32_t* tail, const uint32_t* nk, uint64_t f) {
+    uint32_t tL = tail[2 * f], tR = tail[2 * f + 1];
+    uint32_t dL = dist[2 * f], dR = dist[2 * f + 1];
+    frag_place p;
+    p.N = (uint64_t)dL + dR + nk[f];
+    if (tL < tR) { p.pid = tL; p.other = tR; p.koff = dL; p.rc = false; }
+    else { p.pid = tR; p.other = tL; p.koff = dR; p.rc = true; }
+    return p;
+}
+__global__ void __launch_bounds__(TB) jhead_kernel(const uint32_t* __restrict__ dist, const uint32_t* __restrict__ tail,
+                                                   const uint32_t* __restrict__ nk, uint64_t F, uint32_t K,
+                                                   uint32_t* __restrict__ hflag, uint64_t* __restrict__ hlen) {
+    uint64_t f = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (f >= F) return;
+    frag_place p = frag_place_of(dist, tail, nk, f);
+    bool head = p.koff == 0 && (p.pid >> 1) == (uint32_t)f;
+    hflag[f] = head ? 1u : 0u;
+    hlen[f] = head ? p.N + K - 1 : 0ull;
+}
+__global__ void __launch_bounds__(TB) jhead_place_kernel(const uint32_t* __restrict__ tail, const uint32_t* __restrict__ hflag,
+                                                         const uint32_t* __restrict__ hidx, const uint64_t* __restrict__ hoff,
+                                                         const uint8_t* __restrict__ circ, uint64_t F, uint64_t* __restrict__ poff,
+                                                         uint64_t* __restrict__ uoff, uint8_t* __restrict__ ucirc) {
+    uint64_t f = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (f >= F || !hflag[f]) return;
+    uint32_t tL = tail[2 * f], tR = tail[2 * f + 1];
+    uint32_t pid = tL < tR ? tL : tR;
+    poff[pid] = hoff[f];
+    uoff[hidx[f]] = hoff[f];
+    ucirc[hidx[f]] = circ[pid];
+}
+// number of 256-base chunks of every fragment (work items of the copy kernel)
+__global__ void __launch_bounds__(TB) jchunks_kernel(const uint64_t* __restrict__ boff, uint64_t F, uint32_t* __restrict__ nch) {
+    uint64_t f = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (f >= F) return;
+    nch[f] = (uint32_t)((boff[f + 1] - boff[f] + 255) / 256);
+}
+__global__ void __launch_bounds__(TB) jchunk_owner_kernel(const uint32_t* __restrict__ choff, uint64_t F, uint32_t* __restrict__ owner) {
+    uint64_t f = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (f >= F) return;
+    if (choff[f + 1] > choff[f]) owner[choff[f]] = (uint32_t)f;
+}
+// provisional unitig sequences: every fragment copies all of its bases (the K-1 overlaps write equal values)
+__global__ void __launch_bounds__(256) jemit_kernel(const uint32_t* __restrict__ owner, const uint32_t* __restrict__ choff,
+                                                    const uint64_t* __restrict__ boff, const uint8_t* __restrict__ fbases,
+                                                    const uint32_t* __restrict__ dist, const uint32_t* __restrict__ tail,
+                                                    const uint32_t* __restrict__ nk, const uint64_t* __restrict__ poff,
+                                                    uint8_t* __restrict__ prov) {
+    const uint32_t item = blockIdx.x;
+    const uint32_t f = owner[item];
+    const uint64_t len = boff[f + 1] - boff[f];
+    const uint64_t p0 = (uint64_t)(item - choff[f]) * 256 + threadIdx.x;
+    if (p0 >= len) return;
+    frag_place p = frag_place_of(dist, tail, nk, f);
+    const uint64_t base = poff[p.pid] + p.koff;
+    uint8_t b = fbases[boff[f] + p0];
+    if (!p.rc) prov[base + p0] = b;
+    else prov[base + (len - 1 - p0)] = (uint8_t)(b ^ 3u);
+}
+// canonical form of every unitig (dna/CanonicalForm.h:35-48) decided on the provisional sequence
+__global__ void __launch_bounds__(TB) jform_kernel(const uint64_t* __restrict__ uoff, uint64_t U, const uint8_t* __restrict__ prov,
+                                                   uint8_t* __restrict__ urev) {
+    uint64_t u = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (u >= U) return;
+    const uint8_t* b = prov + uoff[u];
+    uint64_t len = uoff[u + 1] - uoff[u];
+    uint8_t rev = 0;
+    if (len & 1) rev = (b[len / 2] & 2) ? 1 : 0;
+    else {
+        for (uint64_t i = 0, j = len; i < j; ++i) {
+            uint8_t f = b[i], r = (uint8_t)(b[--j] ^ 3);
+            if (f < r) break;
+            if (r < f) { rev = 1; break; }
+        }
+    }
+    urev[u] = rev;
+}
+__global__ void __launch_bounds__(TB) jfinal_kernel(const uint64_t* __restrict__ uoff, const uint32_t* __restrict__ uowner_of_chunk,
+                                                    const uint32_t* __restrict__ uchoff, const uint8_t* __restrict__ urev,
+                                                    const uint8_t* __restrict__ prov, uint8_t* __restrict__ out) {
+    const uint32_t item = blockIdx.x;
+    const uint32_t u = uowner_of_chunk[item];
+    const uint64_t len = uoff[u + 1] - uoff[u];
+    const uint64_t p0 = (uint64_t)(item - uchoff[u]) * 256 + threadIdx.x;
+    if (p0 >= len) return;
+    const uint64_t o = uoff[u];
+    out[o + p0] = urev[u] ? (uint8_t)(prov[o + len - 1 - p0] ^ 3u) : prov[o + p0];
+}
+
+}  // namespace
+
+// exclusive scan helper (u32 and u64), n+1 entries with a zero sentinel appended by the caller
+template <typename T>
+static int excl_scan(snk_ctx* ctx, hipStream_t st, const T* in, T* out, size_t count, char* err, size_t errcap) {
+    size_t tb = 0;
+    SNK_HIP_TRY(rocprim::exclusive_scan((void*)nullptr, tb, in, out, (T)0, count, rocprim::plus<T>(), st));
+    void* tmp;
+    int rc = snk_ctx_alloc(ctx, tb, &tmp, err, errcap);
+    if (rc) return rc;
+    SNK_HIP_TRY(rocprim::exclusive_scan(tmp, tb, in, out, (T)0, count, rocprim::plus<T>(), st));
+    return SNK_OK;
+}
+// owner of every chunk from per-owner chunk counts: scatter the owner id at its first chunk, then max-scan
+static int chunk_owners(snk_ctx* ctx, hipStream_t st, uint32_t* nch /*[count+1], last = 0*/, uint64_t count, uint32_t** choff_out,
+                        uint32_t** owner_out, uint32_t* total_out, char* err, size_t errcap) {
+    uint32_t* choff;
+    G_ALLOC(choff, uint32_t, count + 1);
+    int rc = excl_scan<uint32_t>(ctx, st, nch, choff, count + 1, err, errcap);
+    if (rc) return rc;
+    uint32_t total = 0;
+    SNK_HIP_TRY(hipMemcpyAsync(&total, choff + count, 4, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    uint32_t* owner;
+    G_ALLOC(owner, uint32_t, (uint64_t)total + 1);
+    SNK_HIP_TRY(hipMemsetAsync(owner, 0, ((uint64_t)total + 1) * 4, st));
+    hipLaunchKernelGGL(jchunk_owner_kernel, dim3(nblk(count)), dim3(TB), 0, st, choff, count, owner);
+    if (total) {
+        size_t tb = 0;
+        SNK_HIP_TRY(rocprim::inclusive_scan((void*)nullptr, tb, owner, owner, (size_t)total, rocprim::maximum<uint32_t>(), st));
+        void* tmp;
+        if ((rc = snk_ctx_alloc(ctx, tb, &tmp, err, errcap))) return rc;
+        SNK_HIP_TRY(rocprim::inclusive_scan(tmp, tb, owner, owner, (size_t)total, rocprim::maximum<uint32_t>(), st));
+    }
+    *choff_out = choff;
+    *owner_out = owner;
+    *total_out = total;
+    return SNK_OK;
+}
+
+template <int K>
+static int dist_prune_plan_impl(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, char* err, size_t errcap) {
+    const uint64_t n = g->n;
+    uint64_t tg = 1024;
+    while (tg < 2 * n) tg <<= 1;
+    G_ALLOC(g->index, unsigned long long, tg);
+    g->index_mask = tg - 1;
+    SNK_HIP_TRY(hipMemsetAsync(g->index, 0, tg * 8, st));
+    if (n) hipLaunchKernelGGL(index_build_kernel, dim3(nblk(n)), dim3(TB), 0, st, g->keys, n, g->index, tg - 1);
+    uint32_t* ctxw;
+    G_ALLOC(ctxw, uint32_t, n / 4 + 2);
+    SNK_HIP_TRY(hipMemsetAsync(ctxw, 0, (n / 4 + 2) * 4, st));
+    g->ctx = reinterpret_cast<uint8_t*>(ctxw);
+    G_ALLOC(g->counts, uint32_t, n + 1);
+    G_ALLOC(g->pend, uint8_t, n + 1);
+    G_ALLOC(g->dest, uint8_t, 8 * n + 8);
+    G_ALLOC(g->nbr_local, uint32_t, 2 * n + 2);
+    G_ALLOC(g->rq_idx, uint32_t, 2 * n + 2);
+    G_ALLOC(g->rq_meta, uint16_t, 2 * n + 2);
+    G_ALLOC(g->qcount, unsigned long long, g->world + 1);
+    G_ALLOC(g->qcursor, unsigned long long, g->world + 1);
+    SNK_HIP_TRY(hipMemsetAsync(g->qcount, 0, (g->world + 1) * 8ull, st));
+    SNK_HIP_TRY(hipMemsetAsync(g->rq_idx, 0xFF, (2 * n + 2) * 4, st));
+    if (n) hipLaunchKernelGGL((prune_dist_kernel<K>), dim3(nblk(n)), dim3(TB), 0, st, g->keys, g->vals, n, g->index, g->index_mask,
+                              g->NB_total, g->NBl, g->rank, g->ctx, g->counts, g->pend, g->dest, g->nbr_local, g->qcount);
+    SNK_HIP_TRY(hipGetLastError());
+    return SNK_OK;
+}
+int snk_dist_prune_plan(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, char* err, size_t errcap) {
+    return g->K == 48 ? dist_prune_plan_impl<48>(ctx, st, g, err, errcap) : dist_prune_plan_impl<60>(ctx, st, g, err, errcap);
+}
+int snk_dist_fill_queries(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, const unsigned long long* d_qoff, void* d_qbuf,
+                          char* err, size_t errcap) {
+    SNK_HIP_TRY(hipMemcpyAsync(g->qcursor, d_qoff, (g->world + 1) * 8ull, hipMemcpyDeviceToDevice, st));
+    if (g->n) {
+        if (g->K == 48) hipLaunchKernelGGL((fill_queries_kernel<48>), dim3(nblk(g->n)), dim3(TB), 0, st, g->keys, g->n, g->pend, g->dest, g->qcursor, (unsigned long long*)d_qbuf);
+        else hipLaunchKernelGGL((fill_queries_kernel<60>), dim3(nblk(g->n)), dim3(TB), 0, st, g->keys, g->n, g->pend, g->dest, g->qcursor, (unsigned long long*)d_qbuf);
+    }
+    SNK_HIP_TRY(hipGetLastError());
+    return SNK_OK;
+}
+int snk_dist_answer(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, const void* d_queries, uint64_t nq, void* d_ans, char* err,
+                    size_t errcap) {
+    if (nq) hipLaunchKernelGGL(answer_kernel, dim3(nblk(nq)), dim3(TB), 0, st, (const unsigned long long*)d_queries, nq, g->keys, g->index, g->index_mask, (uint32_t*)d_ans);
+    SNK_HIP_TRY(hipGetLastError());
+    return SNK_OK;
+}
+int snk_dist_apply(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, const void* d_qbuf, const void* d_ans, uint64_t nq,
+                   const unsigned long long* d_qoff, char* err, size_t errcap) {
+    if (nq) hipLaunchKernelGGL(apply_answers_kernel, dim3(nblk(nq)), dim3(TB), 0, st, (const unsigned long long*)d_qbuf, (const uint32_t*)d_ans, nq, d_qoff, g->world, g->do_prune, reinterpret_cast<uint32_t*>(g->ctx), g->rq_idx, g->rq_meta);
+    SNK_HIP_TRY(hipGetLastError());
+    return SNK_OK;
+}
+
+template <int K>
+static int dist_fragments_impl(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, const unsigned long long* d_node_off,
+                               unsigned long long my_node_off, snk_frag_out* out, char* err, size_t errcap) {
+    memset(out, 0, sizeof *out);
+    const uint64_t n = g->n, ns = 2 * n;
+    // spectrum of this rank's share
+    constexpr uint32_t NBINS = 65536;
+    unsigned long long* bins;
+    G_ALLOC(bins, unsigned long long, NBINS);
+    SNK_HIP_TRY(hipMemsetAsync(bins, 0, NBINS * 8, st));
+    if (n) { unsigned gsz = nblk(n); if (gsz > 2048) gsz = 2048; hipLaunchKernelGGL(spectrum_kernel, dim3(gsz), dim3(TB), 0, st, g->counts, n, bins, NBINS); }
+    out->spectrum = bins;
+    out->spectrum_bins = NBINS;
+    if (n == 0) {
+        G_ALLOC(out->boff, uint64_t, 1);
+        SNK_HIP_TRY(hipMemsetAsync(out->boff, 0, 8, st));
+        return SNK_OK;
+    }
+    uint32_t* link;
+    unsigned long long* hl_state;
+    G_ALLOC(link, uint32_t, ns);
+    G_ALLOC(hl_state, unsigned long long, ns);
+    hipLaunchKernelGGL((link_dist_kernel<K>), dim3(nblk(ns)), dim3(TB), 0, st, g->keys, g->ctx, g->pend, g->nbr_local, g->rq_idx, g->rq_meta, n, d_node_off, link, hl_state);
+    SNK_HIP_TRY(hipGetLastError());
+    const uint32_t *dist, *tail;
+    int rc = rank_lists(ctx, st, link, n, nullptr, nullptr, &dist, &tail, &out->n_circles, &out->rank_rounds, err, errcap);
+    if (rc) return rc;
+    uint8_t* prev;
+    G_ALLOC(prev, uint8_t, ns);
+    SNK_HIP_TRY(hipMemsetAsync(prev, 0, ns, st));    // fragments keep the pid -> other orientation
+    uint32_t *hflag, *hidx;
+    uint64_t *hlen, *hoff;
+    G_ALLOC(hflag, uint32_t, n + 1);
+    G_ALLOC(hidx, uint32_t, n + 1);
+    G_ALLOC(hlen, uint64_t, n + 1);
+    G_ALLOC(hoff, uint64_t, n + 1);
+    SNK_HIP_TRY(hipMemsetAsync(hflag + n, 0, 4, st));
+    SNK_HIP_TRY(hipMemsetAsync(hlen + n, 0, 8, st));
+    hipLaunchKernelGGL(head_kernel, dim3(nblk(n)), dim3(TB), 0, st, dist, tail, prev, n, (uint32_t)K, hflag, hlen);
+    if ((rc = excl_scan<uint32_t>(ctx, st, hflag, hidx, n + 1, err, errcap))) return rc;
+    if ((rc = excl_scan<uint64_t>(ctx, st, hlen, hoff, n + 1, err, errcap))) return rc;
+    uint32_t h_nf = 0;
+    uint64_t h_tot = 0;
+    SNK_HIP_TRY(hipMemcpyAsync(&h_nf, hidx + n, 4, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipMemcpyAsync(&h_tot, hoff + n, 8, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    uint64_t* poff;
+    G_ALLOC(poff, uint64_t, ns);
+    G_ALLOC(out->boff, uint64_t, (uint64_t)h_nf + 1);
+    G_ALLOC(out->bases, uint8_t, h_tot + 1);
+    G_ALLOC(out->nk, uint32_t, (uint64_t)h_nf + 1);
+    G_ALLOC(out->hl_self, unsigned long long, 2ull * h_nf + 2);
+    G_ALLOC(out->hl_nb, unsigned long long, 2ull * h_nf + 2);
+    hipLaunchKernelGGL(head_place_kernel, dim3(nblk(n)), dim3(TB), 0, st, tail, hflag, hidx, hoff, n, poff, out->boff);
+    SNK_HIP_TRY(hipMemcpyAsync(out->boff + h_nf, hoff + n, 8, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL((emit_kernel<K>), dim3(nblk(n)), dim3(TB), 0, st, g->keys, dist, tail, prev, poff, n, out->bases);
+    hipLaunchKernelGGL(frag_desc_kernel, dim3(nblk(n)), dim3(TB), 0, st, dist, tail, hflag, hidx, hl_state, n, 2ull * my_node_off, out->nk, out->hl_self, out->hl_nb);
+    SNK_HIP_TRY(hipGetLastError());
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    out->n_frags = h_nf;
+    out->total_bases = h_tot;
+    return SNK_OK;
+}
+int snk_dist_fragments(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, const unsigned long long* d_node_off,
+                       unsigned long long my_node_off, snk_frag_out* out, char* err, size_t errcap) {
+    return g->K == 48 ? dist_fragments_impl<48>(ctx, st, g, d_node_off, my_node_off, out, err, errcap)
+                      : dist_fragments_impl<60>(ctx, st, g, d_node_off, my_node_off, out, err, errcap);
+}
+
+// rank 0: fragments of every rank -> canonical unitigs
+int snk_dist_join(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const uint32_t* nk, const unsigned long long* hl_self,
+                  const unsigned long long* hl_nb, const uint64_t* boff, const uint8_t* fbases, uint64_t total_fbases,
+                  snk_join_out* out, char* err, size_t errcap) {
+    memset(out, 0, sizeof *out);
+    if (F == 0) {
+        G_ALLOC(out->unitig_off, uint64_t, 1);
+        SNK_HIP_TRY(hipMemsetAsync(out->unitig_off, 0, 8, st));
+        return SNK_OK;
+    }
+    if (F >= (1ull << 31)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "more than 2^31 fragments at the join (%llu)", (unsigned long long)F);
+    const uint64_t ne = 2 * F;
+    uint64_t tg = 1024;
+    while (tg < 2 * ne) tg <<= 1;
+    unsigned long long* hk;
+    uint32_t *hv, *flink;
+    G_ALLOC(hk, unsigned long long, tg);
+    G_ALLOC(hv, uint32_t, tg);
+    G_ALLOC(flink, uint32_t, ne);
+    SNK_HIP_TRY(hipMemsetAsync(hk, 0, tg * 8, st));
+    hipLaunchKernelGGL(jhash_build_kernel, dim3(nblk(ne)), dim3(TB), 0, st, hl_self, ne, hk, hv, tg - 1);
+    hipLaunchKernelGGL(jmatch_kernel, dim3(nblk(ne)), dim3(TB), 0, st, hl_self, hl_nb, ne, hk, hv, tg - 1, flink);
+    SNK_HIP_TRY(hipGetLastError());
+    uint8_t* circ;     // per fragment-end state: terminal created by cutting a circle
+    G_ALLOC(circ, uint8_t, ne + 1);
+    SNK_HIP_TRY(hipMemsetAsync(circ, 0, ne + 1, st));
+    const uint32_t *dist, *tail;
+    int rc = rank_lists(ctx, st, flink, F, nk, circ, &dist, &tail, &out->n_circles, &out->rank_rounds, err, errcap);
+    if (rc) return rc;
+    uint32_t *hflag, *hidx;
+    uint64_t *hlen, *hoff;
+    G_ALLOC(hflag, uint32_t, F + 1);
+    G_ALLOC(hidx, uint32_t, F + 1);
+    G_ALLOC(hlen, uint64_t, F + 1);
+    G_ALLOC(hoff, uint64_t, F + 1);
+    SNK_HIP_TRY(hipMemsetAsync(hflag + F, 0, 4, st));
+    SNK_HIP_TRY(hipMemsetAsync(hlen + F, 0, 8, st));
+    hipLaunchKernelGGL(jhead_kernel, dim3(nblk(F)), dim3(TB), 0, st, dist, tail, nk, F, K, hflag, hlen);
+    if ((rc = excl_scan<uint32_t>(ctx, st, hflag, hidx, F + 1, err, errcap))) return rc;
+    if ((rc = excl_scan<uint64_t>(ctx, st, hlen, hoff, F + 1, err, errcap))) return rc;
+    uint32_t h_nu = 0;
+    uint64_t h_tot = 0;
+    SNK_HIP_TRY(hipMemcpyAsync(&h_nu, hidx + F, 4, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipMemcpyAsync(&h_tot, hoff + F, 8, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    const uint64_t U = h_nu;
+    uint64_t *poff, *uoff;
+    uint8_t *ucirc, *prov, *final_bases, *urev;
+    G_ALLOC(poff, uint64_t, ne);
+    G_ALLOC(uoff, uint64_t, U + 1);
+    G_ALLOC(ucirc, uint8_t, U + 1);
+    G_ALLOC(urev, uint8_t, U + 1);
+    G_ALLOC(prov, uint8_t, h_tot + 1);
+    G_ALLOC(final_bases, uint8_t, h_tot + 1);
+    hipLaunchKernelGGL(jhead_place_kernel, dim3(nblk(F)), dim3(TB), 0, st, tail, hflag, hidx, hoff, circ, F, poff, uoff, ucirc);
+    SNK_HIP_TRY(hipMemcpyAsync(uoff + U, hoff + F, 8, hipMemcpyDeviceToDevice, st));
+    // copy every fragment into place (256-base work items)
+    uint32_t *nch, *choff, *owner, total_items = 0;
+    G_ALLOC(nch, uint32_t, F + 1);
+    SNK_HIP_TRY(hipMemsetAsync(nch + F, 0, 4, st));
+    hipLaunchKernelGGL(jchunks_kernel, dim3(nblk(F)), dim3(TB), 0, st, boff, F, nch);
+    if ((rc = chunk_owners(ctx, st, nch, F, &choff, &owner, &total_items, err, errcap))) return rc;
+    if (total_items) hipLaunchKernelGGL(jemit_kernel, dim3(total_items), dim3(256), 0, st, owner, choff, boff, fbases, dist, tail, nk, poff, prov);
+    hipLaunchKernelGGL(jform_kernel, dim3(nblk(U)), dim3(TB), 0, st, uoff, U, prov, urev);
+    uint32_t *unch, *uchoff, *uowner, utotal = 0;
+    G_ALLOC(unch, uint32_t, U + 1);
+    SNK_HIP_TRY(hipMemsetAsync(unch + U, 0, 4, st));
+    hipLaunchKernelGGL(jchunks_kernel, dim3(nblk(U)), dim3(TB), 0, st, uoff, U, unch);
+    if ((rc = chunk_owners(ctx, st, unch, U, &uchoff, &uowner, &utotal, err, errcap))) return rc;
+    if (utotal) hipLaunchKernelGGL(jfinal_kernel, dim3(utotal), dim3(256), 0, st, uoff, uowner, uchoff, urev, prov, final_bases);
+    SNK_HIP_TRY(hipGetLastError());
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    out->n_unitigs = U;
+    out->total_bases = h_tot;
+    out->unitig_off = uoff;
+    out->unitig_bases = final_bases;
+    out->unitig_circular = ucirc;
+    return SNK_OK;
 }

@@ -43,8 +43,7 @@ __device__ __forceinline__ uint32_t mmer_key(const uint32_t* rowL, int tid, uint
     uint32_t code, rcode;
     if (M == 16) { code = x; rcode = rx; }
     else { code = x >> (32 - 2 * M); rcode = rx & ((1u << (2 * M)) - 1u); }
-    uint32_t c = code < rcode ? code : rcode;
-    return snk_mix32(c);
+    return snk_minimizer_key(code, rcode);
 }
 
 // Bucket of the supermer whose minimiser sits at position p.  Two rules make this safe:
@@ -56,10 +55,7 @@ __device__ __forceinline__ uint32_t mmer_key(const uint32_t* rowL, int tid, uint
 //    and its reverse complement must still meet in one bucket.
 template <int M>
 __device__ __forceinline__ uint32_t mmer_bucket(const uint32_t* rowL, int tid, uint32_t row_words, int p, uint32_t NB) {
-    uint32_t key = mmer_key<M>(rowL, tid, row_words, p);
-    uint32_t h = snk_mix32(key ^ 0x5bd1e995u) * 0x9E3779B1u;
-    h ^= h >> 15;
-    return (uint32_t)(((uint64_t)h * NB) >> 32);
+    return snk_bucket_of_key(mmer_key<M>(rowL, tid, row_words, p), NB);
 }
 
 // extract 32 bits starting at base `a + 16*j` of the row column

@@ -18,6 +18,7 @@
 #include "snk_common.h"
 #include "snk_graph.h"
 #include "snk_kernels.h"
+#include "snk_stages.h"
 
 namespace {
 
@@ -26,29 +27,9 @@ __global__ void widen_offsets_kernel(const uint32_t* __restrict__ in, uint64_t* 
     if (i < n) out[i] = in[i];
 }
 
-struct phase_timer {
-    hipStream_t st;
-    hipEvent_t ev[16];
-    int n = 0;
-    bool ok = true;
-    explicit phase_timer(hipStream_t s) : st(s) {
-        for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) ok = false;
-    }
-    ~phase_timer() { for (auto& e : ev) (void)hipEventDestroy(e); }
-    void mark() { if (ok && n < 16) (void)hipEventRecord(ev[n++], st); }
-    float ms(int a, int b) {
-        float t = 0;
-        if (!ok || a >= n || b >= n) return 0;
-        (void)hipEventSynchronize(ev[b]);
-        (void)hipEventElapsedTime(&t, ev[a], ev[b]);
-        return t;
-    }
-};
+typedef snk_phase_timer phase_timer;
 
-uint32_t env_u32(const char* name, uint32_t dflt) {
-    const char* v = getenv(name);
-    return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
-}
+#define env_u32 snk_env_u32
 
 }  // namespace
 
@@ -143,92 +124,20 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     kt.mark();  // 3
     tm.mark();  // 3
 
-    // ---- K5-K8 count + filter into a region-partitioned table, then gather the regions densely.
-    // Every retained k-mer has >= min_freq instances; deep coverage retains far fewer (56x: ~1/38 of them).
-    uint32_t n_regions = NB < 4096 ? NB : 4096;
-    uint64_t est = h_ninst / (p->min_freq > 1 ? 8 : 1) + 4096;
-    if (ctx->last_n_kmers && ctx->last_n_instances == h_ninst) est = ctx->last_n_kmers + ctx->last_n_kmers / 2 + 4096;
-    uint64_t region_cap = est / n_regions + 64;
-    snk_u128 *keys_r = nullptr, *keys_a = nullptr, *keys_b = nullptr;
-    uint64_t *vals_r = nullptr, *vals_a = nullptr, *vals_b = nullptr;
-    unsigned long long *rcur = nullptr, *roff = nullptr;
-    uint64_t n_kmers = 0;
-    uint32_t h_status[4] = {0, 0, 0, 0};
-    {
-        void* q;
-        if ((rc = snk_ctx_alloc(ctx, (n_regions + 1) * 8ull, &q, err, errcap))) return rc; rcur = (unsigned long long*)q;
-        if ((rc = snk_ctx_alloc(ctx, (n_regions + 1) * 8ull, &q, err, errcap))) return rc; roff = (unsigned long long*)q;
-    }
-    std::vector<unsigned long long> h_rcur(n_regions);
-    for (int attempt = 0; attempt < 3; ++attempt) {
-        void* q;
-        if ((rc = snk_ctx_alloc(ctx, region_cap * n_regions * 16, &q, err, errcap))) return rc; keys_r = (snk_u128*)q;
-        if ((rc = snk_ctx_alloc(ctx, region_cap * n_regions * 8, &q, err, errcap))) return rc; vals_r = (uint64_t*)q;
-        SNK_HIP_TRY(hipMemsetAsync(rcur, 0, (n_regions + 1) * 8ull, st));
-        SNK_HIP_TRY(hipMemsetAsync(status, 0, 16, st));
-        snk_count_args ca;
-        ca.records = (const uint4*)records;
-        ca.seg_off = seg_off;
-        ca.nseg = 1;
-        ca.NB = NB;
-        ca.min_freq = p->min_freq;
-        ca.bc_mode = in->bc ? p->min_bc : 0;    // no barcode vector -> bc_test is always true (:176-178)
-        ca.out_keys = keys_r;
-        ca.out_vals = vals_r;
-        ca.region_cap = region_cap;
-        ca.n_regions = n_regions;
-        ca.region_cursor = rcur;
-        ca.status = status;
-        ca.dbg = env_u32("SNK_COUNT_DBG", 0);
-        if (kt.n > 4) kt.n = 4;
-        kt.mark();  // 4
-        if ((rc = snk_launch_count(K, st, ca, err, errcap))) return rc;
-        kt.mark();  // 5
-        SNK_HIP_TRY(hipMemcpyAsync(h_rcur.data(), rcur, n_regions * 8ull, hipMemcpyDeviceToHost, st));
-        SNK_HIP_TRY(hipMemcpyAsync(h_status, status, 16, hipMemcpyDeviceToHost, st));
-        SNK_HIP_TRY(hipStreamSynchronize(st));
-        if (ca.dbg >= 2) {
-            unsigned long long d[3];
-            (void)hipMemcpy(d, status + 4, 24, hipMemcpyDeviceToHost);
-            fprintf(stderr, "[snk dbg] lane probe iterations %llu, wave-level iterations %llu, max lane iterations in one probe %llu\n", d[0], d[1], d[2]);
-        }
-        if (h_status[1]) return snk_fail(SNK_E_INTERNAL, err, errcap, "count: bucket split depth exceeded");
-        unsigned long long mx = 0;
-        n_kmers = 0;
-        for (uint32_t r = 0; r < n_regions; ++r) { n_kmers += h_rcur[r]; if (h_rcur[r] > mx) mx = h_rcur[r]; }
-        if (!h_status[0] && mx <= region_cap) break;
-        if (attempt == 2) return snk_fail(SNK_E_INTERNAL, err, errcap, "count: region overflow (%llu > %llu)", mx, (unsigned long long)region_cap);
-        region_cap = mx + 64;     // exact requirement is known now (cursors keep counting past the cap)
-    }
-    {
-        // exclusive offsets of the regions (host: n_regions <= 4096) and the dense gather
-        std::vector<unsigned long long> h_off(n_regions + 1);
-        unsigned long long acc = 0;
-        for (uint32_t r = 0; r < n_regions; ++r) { h_off[r] = acc; acc += h_rcur[r]; }
-        h_off[n_regions] = acc;
-        SNK_HIP_TRY(hipMemcpyAsync(roff, h_off.data(), (n_regions + 1) * 8ull, hipMemcpyHostToDevice, st));
-        void* q;
-        if ((rc = snk_ctx_alloc(ctx, (n_kmers + 1) * 16, &q, err, errcap))) return rc; keys_a = (snk_u128*)q;
-        if ((rc = snk_ctx_alloc(ctx, (n_kmers + 1) * 8, &q, err, errcap))) return rc; vals_a = (uint64_t*)q;
-        if ((rc = snk_launch_compact_regions(st, keys_r, vals_r, region_cap, n_regions, rcur, roff, keys_a, vals_a, err, errcap))) return rc;
-        SNK_HIP_TRY(hipStreamSynchronize(st));   // h_off is a stack vector: the upload must finish before it goes away
-    }
-    out->buckets_split = h_status[2];
-    out->max_slots_used = h_status[3];
+    // ---- K5-K8 count + filter + gather + sort
+    snk_table tab;
+    rc = snk_stage_count_table(ctx, st, K, records, seg_off, 1, NB, p->min_freq, in->bc ? p->min_bc : 0u, h_ninst, status,
+                               &tab, err, errcap);
+    if (rc) return rc;
+    const uint64_t n_kmers = tab.n;
+    snk_u128* keys_b = tab.keys;
+    uint64_t* vals_b = tab.vals;
+    out->buckets_split = tab.buckets_split;
+    out->max_slots_used = tab.max_slots_used;
     out->n_kmers = n_kmers;
-    ctx->last_n_kmers = n_kmers;
-    ctx->last_n_instances = h_ninst;
-    tm.mark();  // 4
-
-    // ---- sort by key
-    {
-        void* q;
-        if ((rc = snk_ctx_alloc(ctx, (n_kmers + 1) * 16, &q, err, errcap))) return rc; keys_b = (snk_u128*)q;
-        if ((rc = snk_ctx_alloc(ctx, (n_kmers + 1) * 8, &q, err, errcap))) return rc; vals_b = (uint64_t*)q;
-        if ((rc = snk_graph_sort(ctx, st, K, n_kmers, keys_a, vals_a, keys_b, vals_b, err, errcap))) return rc;
-    }
     out->keys = keys_b;
-    tm.mark();  // 5
+    tm.mark();  // 4 (count+gather) and 5 (sort) are reported from the stage's own events
+    tm.mark();
 
     // ---- prune + unitigs
     snk_graph_out go;
@@ -250,13 +159,13 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     out->phase_ms[0] = tm.ms(0, 1);
     out->phase_ms[1] = tm.ms(1, 2);
     out->phase_ms[2] = tm.ms(2, 3);
-    out->phase_ms[3] = tm.ms(3, 4);
-    out->phase_ms[4] = tm.ms(4, 5);
+    out->phase_ms[3] = tab.count_ms;
+    out->phase_ms[4] = tab.sort_ms;
     out->phase_ms[5] = tm.ms(5, 6);
     out->phase_ms[7] = tm.ms(0, 6);
     out->kernel_ms[0] = kt.ms(0, 1);
     out->kernel_ms[1] = kt.ms(2, 3);
-    out->kernel_ms[2] = kt.ms(4, 5);
+    out->kernel_ms[2] = tab.count_kernel_ms;
     out->scratch_bytes = ctx->total_alloc;
     return SNK_OK;
 }

@@ -1,0 +1,36 @@
+// snk_stages.h -- internal stage interfaces shared by snk_pipeline.hip and snk_dist.hip.
+#pragma once
+#include "snk_ctx.h"
+#include "snk_kernels.h"
+
+struct snk_phase_timer {
+    hipStream_t st;
+    hipEvent_t ev[16];
+    int n = 0;
+    bool ok = true;
+    explicit snk_phase_timer(hipStream_t s) : st(s) {
+        for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) ok = false;
+    }
+    ~snk_phase_timer() { for (auto& e : ev) (void)hipEventDestroy(e); }
+    void mark() { if (ok && n < 16) (void)hipEventRecord(ev[n++], st); }
+    float ms(int a, int b) {
+        float t = 0;
+        if (!ok || a >= n || b >= n) return 0;
+        (void)hipEventSynchronize(ev[b]);
+        (void)hipEventElapsedTime(&t, ev[a], ev[b]);
+        return t;
+    }
+};
+
+struct snk_table {
+    uint64_t n;
+    snk_u128* keys;      // sorted ascending
+    uint64_t* vals;      // count << 8 | raw context
+    uint32_t buckets_split, max_slots_used;
+    float count_ms, sort_ms, count_kernel_ms;
+};
+
+uint32_t snk_env_u32(const char* name, uint32_t dflt);
+int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* records, const uint64_t* seg_off,
+                          uint32_t nseg, uint32_t NB, uint32_t min_freq, uint32_t bc_mode, uint64_t n_inst_hint,
+                          uint32_t* status, snk_table* out, char* err, size_t errcap);

@@ -49,6 +49,21 @@ class SnkDevResult(C.Structure):
                 ("scratch_bytes", C.c_uint64), ("phase_ms", C.c_float * 8), ("kernel_ms", C.c_float * 4)]
 
 
+class SnkShardFrags(C.Structure):
+    _fields_ = [("n_kmers", C.c_uint64), ("keys", C.c_void_p), ("counts", C.c_void_p), ("ctx", C.c_void_p),
+                ("spectrum", C.c_void_p), ("spectrum_bins", C.c_uint32), ("n_circles", C.c_uint32),
+                ("n_frags", C.c_uint64), ("total_bases", C.c_uint64), ("nk", C.c_void_p), ("hl_self", C.c_void_p),
+                ("hl_nb", C.c_void_p), ("boff", C.c_void_p), ("bases", C.c_void_p), ("rank_rounds", C.c_uint32),
+                ("buckets_split", C.c_uint32), ("max_slots_used", C.c_uint32), ("reserved", C.c_uint32),
+                ("count_ms", C.c_float), ("sort_ms", C.c_float), ("count_kernel_ms", C.c_float), ("reserved_f", C.c_float)]
+
+
+class SnkShardUnitigs(C.Structure):
+    _fields_ = [("n_unitigs", C.c_uint64), ("total_bases", C.c_uint64), ("unitig_off", C.c_void_p),
+                ("unitig_bases", C.c_void_p), ("unitig_circular", C.c_void_p), ("n_circles", C.c_uint32),
+                ("rank_rounds", C.c_uint32)]
+
+
 _lib = None
 
 
@@ -104,6 +119,15 @@ def _declare(lib: C.CDLL) -> None:
         "snk_dev_pack_ascii": (C.c_int, [vp, vp, u32, u32, u64, vp, u32, vp]),
         "snk_dev_count_graph": (C.c_int, [vp, P(SnkDevReads), P(SnkParams), P(SnkDevResult), vp, cp, sz]),
         "snk_dev_download": (C.c_int, [vp, vp, vp, sz, vp]),
+        "snk_shard_hist": (C.c_int, [vp, P(SnkDevReads), P(SnkParams), u32, u32, u32, vp, P(u64), vp, cp, sz]),
+        "snk_shard_scatter": (C.c_int, [vp, vp, vp, vp, cp, sz]),
+        "snk_shard_count": (C.c_int, [vp, vp, vp, u64, C.c_int, P(u64), vp, cp, sz]),
+        "snk_shard_prune_plan": (C.c_int, [vp, P(u64), vp, cp, sz]),
+        "snk_shard_prune_fill": (C.c_int, [vp, vp, vp, vp, cp, sz]),
+        "snk_shard_prune_answer": (C.c_int, [vp, vp, u64, vp, vp, cp, sz]),
+        "snk_shard_prune_apply": (C.c_int, [vp, vp, vp, u64, vp, vp, cp, sz]),
+        "snk_shard_fragments": (C.c_int, [vp, vp, u64, P(SnkShardFrags), vp, cp, sz]),
+        "snk_shard_join": (C.c_int, [vp, u32, u64, vp, vp, vp, vp, vp, u64, P(SnkShardUnitigs), vp, cp, sz]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

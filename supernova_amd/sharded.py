@@ -1,0 +1,402 @@
+"""Minimiser-sharded multi-GPU host logic: one process per GPU, torch.distributed for the
+exchanges (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests of the plumbing).
+
+The k-mer space is cut into NB_total minimiser buckets, rank r owns a contiguous range.  Per step:
+  all-to-all #1  bucket histograms (u32 per bucket)            -> segment offsets on the owner
+  all-to-all #2  supermer records (32 B each)                  -> every k-mer instance meets its owner
+  all-to-all #3  membership queries for cross-rank neighbours  (24 B each, ~0.15 per retained k-mer)
+  all-to-all #4  answers (4 B each)
+  gather         local unitig fragments -> rank 0, which joins them (tada's MAIN_ASM_SN)
+Reference counterpart: the shardio exchange files + SHARD_ASM chunks + MAIN_ASM_SN of lib/tada
+(rust-shardio/src/shard.rs:184-211,488-493; cmd_shard_asm.rs:37-94; cmd_main_asm.rs:25-89).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from .engine import Engine, Params
+
+
+# ------------------------------------------------------------------------------------------------ communicators
+class TorchComm:
+    """Exchanges over torch.distributed.  all_to_all_single on NCCL/RCCL; point-to-point fallback on gloo."""
+
+    def __init__(self, dist):
+        self.dist = dist
+        self.rank = dist.get_rank()
+        self.world = dist.get_world_size()
+        self._native_a2a = dist.get_backend() == "nccl"
+
+    def allreduce_sum_int(self, v: int, device) -> int:
+        t = torch.tensor([v], dtype=torch.int64, device=device)
+        self.dist.all_reduce(t)
+        return int(t.item())
+
+    def all_gather_int(self, v: int, device) -> list[int]:
+        t = torch.tensor([v], dtype=torch.int64, device=device)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [int(x.item()) for x in out]
+
+    def _a2a(self, out: torch.Tensor, inp: torch.Tensor, out_splits, in_splits):
+        if self._native_a2a:
+            self.dist.all_to_all_single(out, inp, out_splits, in_splits)
+            return
+        ins = list(torch.split(inp, in_splits)) if sum(in_splits) else [inp[:0] for _ in in_splits]
+        outs = list(torch.split(out, out_splits)) if sum(out_splits) else [out[:0] for _ in out_splits]
+        reqs = []
+        for p in range(self.world):
+            if p == self.rank:
+                outs[p].copy_(ins[p])
+                continue
+            if in_splits[p]:
+                reqs.append(self.dist.isend(ins[p].contiguous(), p))
+            if out_splits[p]:
+                reqs.append(self.dist.irecv(outs[p], p))
+        for r in reqs:
+            r.wait()
+
+    def all_to_all_v(self, send: torch.Tensor, send_counts: list[int]):
+        """send: 1-D uint8; send_counts[p] bytes go to rank p.  Returns (recv uint8, recv_counts)."""
+        dev = send.device
+        sc = torch.tensor(send_counts, dtype=torch.int64, device=dev)
+        rc = torch.empty_like(sc)
+        self._a2a(rc, sc, [1] * self.world, [1] * self.world)
+        recv_counts = [int(x) for x in rc.tolist()]
+        recv = torch.empty(sum(recv_counts), dtype=torch.uint8, device=dev)
+        self._a2a(recv, send, recv_counts, list(send_counts))
+        return recv, recv_counts
+
+    def all_to_all_equal(self, send: torch.Tensor) -> torch.Tensor:
+        """send: [world, m] -> recv [world, m]; row p goes to rank p."""
+        recv = torch.empty_like(send)
+        m = send.shape[1]
+        self._a2a(recv.view(-1), send.contiguous().view(-1), [m] * self.world, [m] * self.world)
+        return recv
+
+    def barrier(self):
+        self.dist.barrier()
+
+
+class SimWorld:
+    """W in-process ranks (threads) that exchange through shared lists -- the SPMD code path of the real
+    multi-GPU run on ONE GPU (tests), with the transport replaced by tensor copies."""
+
+    def __init__(self, world: int):
+        self.world = world
+        self.barrier_obj = threading.Barrier(world)
+        self.slots = [None] * world
+
+    def comm(self, rank: int) -> "SimComm":
+        return SimComm(self, rank)
+
+
+class SimComm:
+    def __init__(self, w: SimWorld, rank: int):
+        self.w, self.rank, self.world = w, rank, w.world
+
+    def _exchange(self, obj):
+        self.w.slots[self.rank] = obj
+        self.w.barrier_obj.wait()
+        allv = list(self.w.slots)
+        self.w.barrier_obj.wait()
+        return allv
+
+    def allreduce_sum_int(self, v, device):
+        return sum(self._exchange(int(v)))
+
+    def all_gather_int(self, v, device):
+        return [int(x) for x in self._exchange(int(v))]
+
+    def all_to_all_v(self, send, send_counts):
+        torch.cuda.synchronize()
+        allv = self._exchange((send, list(send_counts)))
+        parts, counts = [], []
+        for (t, sc) in allv:
+            off = sum(sc[: self.rank])
+            parts.append(t[off: off + sc[self.rank]])
+            counts.append(sc[self.rank])
+        recv = torch.cat(parts) if parts else send[:0]
+        torch.cuda.synchronize()
+        self.w.barrier_obj.wait()     # nobody reuses its send buffer before everyone has copied
+        return recv, counts
+
+    def all_to_all_equal(self, send):
+        m = send.shape[1]
+        recv, _ = self.all_to_all_v(send.contiguous().view(-1).view(torch.uint8),
+                                    [m * send.element_size()] * self.world)
+        return recv.view(send.dtype).view(self.world, m)
+
+    def barrier(self):
+        self.w.barrier_obj.wait()
+
+
+# ------------------------------------------------------------------------------------------------ planning helpers
+def plan_buckets(total_inst_upper: int, world: int, K: int) -> int:
+    target = int(os.environ.get("SNK_TARGET_INST", "4500" if K == 48 else "4000"))
+    nb = max(1, -(-total_inst_upper // target))
+    nb = min(nb, 1 << 24)
+    return -(-nb // world) * world
+
+
+def owner_record_counts(offsets: torch.Tensor, world: int) -> list[int]:
+    """offsets: int64[NB_total+1] exclusive scan of the bucket histogram -> records per owner rank."""
+    nbl = (offsets.numel() - 1) // world
+    bnd = offsets[::nbl]
+    return [int(x) for x in (bnd[1:] - bnd[:-1]).tolist()]
+
+
+def segment_offsets(hist_recv: torch.Tensor, recv_record_counts: list[int]) -> torch.Tensor:
+    """hist_recv [world, NBl] (row s = source s's supermers per local bucket) -> int64 [world, NBl+1] absolute offsets."""
+    w, nbl = hist_recv.shape
+    seg = torch.zeros((w, nbl + 1), dtype=torch.int64, device=hist_recv.device)
+    seg[:, 1:] = torch.cumsum(hist_recv.to(torch.int64), dim=1)
+    base = torch.zeros(w, dtype=torch.int64, device=hist_recv.device)
+    if w > 1:
+        base[1:] = torch.cumsum(torch.tensor(recv_record_counts[:-1], dtype=torch.int64, device=hist_recv.device), 0)
+    return (seg + base[:, None]).contiguous()
+
+
+COMP = np.array([3, 2, 1, 0], dtype=np.uint8)
+
+
+def canonicalize_circle(codes: np.ndarray, K: int) -> np.ndarray:
+    """A closed circle sequence (n+K-1 bases, last K-1 == first K-1) cut at an arbitrary k-mer -> the reference's
+    form: rotated to start at its minimum canonical k-mer in forward orientation (canonicalizeCircle,
+    BuildReadQGraph48.cc:375-397), then bvec-canonical (addEdge :481-485).  Host side: circles that span ranks are rare."""
+    n = len(codes) - (K - 1)
+    ring = codes[:n]
+    best = None
+    for strand in (0, 1):
+        seq = ring if strand == 0 else COMP[ring[::-1]]
+        ext = np.concatenate([seq, seq[:K - 1]])
+        for i in range(n):
+            km = bytes(ext[i:i + K])
+            if best is None or km < best[0]:
+                best = (km, strand, i)
+    _, strand, i = best
+    seq = ring if strand == 0 else COMP[ring[::-1]]
+    rot = np.concatenate([seq[i:], seq[:i]])
+    out = np.concatenate([rot, rot[:K - 1]])
+    L = len(out)
+    if L & 1:
+        rev = bool(out[L // 2] & 2)
+    else:
+        rc = COMP[out[::-1]]
+        rev = bytes(rc) < bytes(out)
+    return COMP[out[::-1]].copy() if rev else out
+
+
+# ------------------------------------------------------------------------------------------------ the SPMD step
+class ShardedResult:
+    def __init__(self, eng: Engine, K: int):
+        self._e = eng
+        self.K = K
+        self.phase_ms = {}
+        self.kernel_ms = {}
+
+    def _dl(self, ptr, nbytes, dtype, shape):
+        out = np.empty(shape, dtype=dtype)
+        if nbytes:
+            self._e._download(ptr, out.ctypes.data, nbytes)
+        return out
+
+    def keys(self):
+        lohi = self._dl(self.frags.keys, self.n_kmers * 16, np.uint64, (self.n_kmers, 2))
+        lo, hi = lohi[:, 0], lohi[:, 1]
+        w = np.empty((self.n_kmers, 4), dtype=np.uint32)
+        w[:, 0] = hi >> np.uint64(32); w[:, 1] = hi & np.uint64(0xFFFFFFFF)
+        w[:, 2] = lo >> np.uint64(32); w[:, 3] = lo & np.uint64(0xFFFFFFFF)
+        return w
+
+    def counts(self):
+        return self._dl(self.frags.counts, self.n_kmers * 4, np.uint32, (self.n_kmers,))
+
+    def ctx(self):
+        return self._dl(self.frags.ctx, self.n_kmers, np.uint8, (self.n_kmers,))
+
+    def spectrum(self):
+        nb = int(self.frags.spectrum_bins)
+        return self._dl(self.frags.spectrum, nb * 8, np.uint64, (nb,))
+
+    def unitigs(self) -> list[str]:
+        """rank 0 only: canonical unitigs of the whole data set, sorted by BVComp."""
+        u = self.joined
+        off = self._dl(u.unitig_off, (u.n_unitigs + 1) * 8, np.uint64, (u.n_unitigs + 1,))
+        bases = self._dl(u.unitig_bases, u.total_bases, np.uint8, (u.total_bases,))
+        circ = self._dl(u.unitig_circular, u.n_unitigs, np.uint8, (u.n_unitigs,))
+        lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+        out = []
+        for i in range(u.n_unitigs):
+            seg = bases[int(off[i]):int(off[i + 1])]
+            if circ[i]:
+                seg = canonicalize_circle(seg, self.K)
+            out.append(lut[seg].tobytes().decode())
+        out.sort(key=lambda s: (-len(s), s))
+        return out
+
+
+class ShardedEngine:
+    def __init__(self, engine: Engine, dist_or_comm):
+        self.eng = engine
+        self.comm = dist_or_comm if hasattr(dist_or_comm, "all_to_all_v") else TorchComm(dist_or_comm)
+
+    def count_graph(self, rows, read_len, quals=None, bc=None, lens=None, good_len=None, params: Params | None = None,
+                    ign_bc_below: int = 0, read_index_base: int = 0) -> ShardedResult:
+        e, comm, lib = self.eng, self.comm, self.eng.lib
+        W, me = comm.world, comm.rank
+        params = params or Params()
+        K = params.K
+        dev = rows.device
+        st = e._stream()
+        err = C.create_string_buffer(512)
+
+        def chk(rc):
+            if rc != 0:
+                raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
+        ev[0].record()
+        r = _lib.SnkDevReads()
+        r.n_reads, r.rows, r.row_words, r.read_len = rows.shape[0], rows.data_ptr(), rows.shape[1], read_len
+        if lens is not None:
+            r.lens = lens.data_ptr()
+        if quals is not None:
+            r.quals, r.qstride = quals.data_ptr(), quals.shape[1]
+        if good_len is not None:
+            r.good_len = good_len.data_ptr()
+        if bc is not None:
+            r.bc = bc.data_ptr()
+        r.ign_bc_below, r.read_index_base = ign_bc_below, read_index_base
+        p = params.to_c()
+
+        inst_ub = comm.allreduce_sum_int(rows.shape[0] * max(0, read_len - K + 1), dev)
+        NB_total = params.n_buckets if params.n_buckets else plan_buckets(inst_ub, W, K)
+        NB_total = -(-NB_total // W) * W
+        NBl = NB_total // W
+        # ---- stage 1: trim + histogram
+        hist = torch.empty(NB_total, dtype=torch.int32, device=dev)
+        ninst = C.c_uint64(0)
+        chk(lib.snk_shard_hist(e._ctx, C.byref(r), C.byref(p), me, W, NB_total, hist.data_ptr(), C.byref(ninst), st, err, 512))
+        ev[1].record()
+        off64 = torch.zeros(NB_total + 1, dtype=torch.int64, device=dev)
+        off64[1:] = torch.cumsum(hist.to(torch.int64), 0)
+        n_super = int(off64[-1].item())
+        if n_super >= (1 << 32):
+            raise _lib.SnkError(-6, "more than 2^32 supermers on one rank")
+        # the kernel reads u32; int32 storage holds the same bit patterns (values >= 2^31 wrap)
+        offsets = torch.where(off64 >= (1 << 31), off64 - (1 << 32), off64).to(torch.int32)
+        send = torch.empty(max(n_super, 1) * 32, dtype=torch.uint8, device=dev)
+        chk(lib.snk_shard_scatter(e._ctx, offsets.data_ptr(), send.data_ptr(), st, err, 512))
+        ev[2].record()
+        # ---- exchange #1/#2: histograms and records
+        send_counts = owner_record_counts(off64, W)
+        hist_recv = comm.all_to_all_equal(hist.view(W, NBl))
+        recv, recv_bytes = comm.all_to_all_v(send[: n_super * 32], [c * 32 for c in send_counts])
+        seg_off = segment_offsets(hist_recv, [b // 32 for b in recv_bytes])
+        ev[3].record()
+        # ---- stage 3: count
+        nk = C.c_uint64(0)
+        chk(lib.snk_shard_count(e._ctx, recv.data_ptr(), seg_off.data_ptr(), inst_ub // W, 1 if bc is not None else 0,
+                                C.byref(nk), st, err, 512))
+        ev[4].record()
+        # ---- stage 4: prune with remote queries
+        qcount = (C.c_uint64 * W)()
+        chk(lib.snk_shard_prune_plan(e._ctx, qcount, st, err, 512))
+        qc = [int(x) for x in qcount]
+        qoff = torch.zeros(W + 1, dtype=torch.int64, device=dev)
+        qoff[1:] = torch.cumsum(torch.tensor(qc, dtype=torch.int64, device=dev), 0)
+        nq = sum(qc)
+        qbuf = torch.empty(max(nq, 1) * 24, dtype=torch.uint8, device=dev)
+        chk(lib.snk_shard_prune_fill(e._ctx, qoff.data_ptr(), qbuf.data_ptr(), st, err, 512))
+        qin, qin_bytes = comm.all_to_all_v(qbuf[: nq * 24], [c * 24 for c in qc])
+        nq_in = qin.numel() // 24
+        ans = torch.empty(max(nq_in, 1) * 4, dtype=torch.uint8, device=dev)
+        chk(lib.snk_shard_prune_answer(e._ctx, qin.data_ptr(), nq_in, ans.data_ptr(), st, err, 512))
+        ans_back, _ = comm.all_to_all_v(ans[: nq_in * 4], [b // 24 * 4 for b in qin_bytes])
+        assert ans_back.numel() == nq * 4
+        chk(lib.snk_shard_prune_apply(e._ctx, qbuf.data_ptr(), ans_back.data_ptr(), nq, qoff.data_ptr(), st, err, 512))
+        ev[5].record()
+        # ---- stage 5: local fragments
+        all_n = comm.all_gather_int(int(nk.value), dev)
+        node_off = torch.zeros(W + 1, dtype=torch.int64, device=dev)
+        node_off[1:] = torch.cumsum(torch.tensor(all_n, dtype=torch.int64, device=dev), 0)
+        fr = _lib.SnkShardFrags()
+        chk(lib.snk_shard_fragments(e._ctx, node_off.data_ptr(), int(node_off[me].item()), C.byref(fr), st, err, 512))
+        ev[6].record()
+        # ---- gather fragments on rank 0 and join
+        res = ShardedResult(e, K)
+        res.frags = fr
+        res.n_kmers = int(fr.n_kmers)
+        res.n_instances = int(ninst.value)
+        res.n_supermers = n_super
+        res.n_buckets = NB_total
+        res.n_queries = nq
+        res.n_frags = int(fr.n_frags)
+        F = int(fr.n_frags)
+
+        def dcopy(ptr, nbytes):
+            """device-to-device copy of a library-owned buffer into a torch tensor (send buffer)."""
+            t = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+            if nbytes:
+                torch.cuda.current_stream().synchronize()
+                _copy_d2d(t.data_ptr(), ptr, nbytes)
+            return t[:nbytes]
+
+        to0 = lambda n: [n if q == 0 else 0 for q in range(W)]
+        t_nk, _ = comm.all_to_all_v(dcopy(fr.nk, F * 4), to0(F * 4))
+        t_self, _ = comm.all_to_all_v(dcopy(fr.hl_self, F * 16), to0(F * 16))
+        t_nb, _ = comm.all_to_all_v(dcopy(fr.hl_nb, F * 16), to0(F * 16))
+        boff = dcopy(fr.boff, (F + 1) * 8).view(torch.int64)
+        lens_f = (boff[1:] - boff[:-1]).contiguous()
+        t_len, _ = comm.all_to_all_v(lens_f.view(torch.uint8), to0(F * 8))
+        t_bases, _ = comm.all_to_all_v(dcopy(fr.bases, int(fr.total_bases)), to0(int(fr.total_bases)))
+        res.joined = None
+        res.n_unitigs = 0
+        if me == 0:
+            Ft = t_nk.numel() // 4
+            lens_all = t_len.view(torch.int64)
+            boff_all = torch.zeros(Ft + 1, dtype=torch.int64, device=dev)
+            boff_all[1:] = torch.cumsum(lens_all, 0)
+            un = _lib.SnkShardUnitigs()
+            chk(lib.snk_shard_join(e._ctx, K, Ft, t_nk.data_ptr(), t_self.data_ptr(), t_nb.data_ptr(), boff_all.data_ptr(),
+                                   t_bases.data_ptr(), t_bases.numel(), C.byref(un), st, err, 512))
+            res.joined = un
+            res.n_unitigs = int(un.n_unitigs)
+            res._keep = (t_nk, t_self, t_nb, boff_all, t_bases)
+        ev[7].record()
+        torch.cuda.synchronize()
+        names = ["hist", "scatter", "exchange", "count", "prune", "fragments", "join"]
+        res.phase_ms = {names[i]: ev[i].elapsed_time(ev[i + 1]) for i in range(7)}
+        res.phase_ms["total"] = ev[0].elapsed_time(ev[7])
+        res.kernel_ms = {"count": float(fr.count_kernel_ms), "msp_hist": 0.0, "msp_scatter": 0.0}
+        res.buckets_split = int(fr.buckets_split)
+        return res
+
+
+def _copy_d2d(dst_ptr: int, src_ptr: int, nbytes: int) -> None:
+    """hipMemcpy device-to-device through the process's HIP runtime (the one torch uses)."""
+    hip = _hip()
+    rc = hip.hipMemcpy(C.c_void_p(dst_ptr), C.c_void_p(src_ptr), C.c_size_t(nbytes), 3)  # hipMemcpyDeviceToDevice = 3
+    if rc != 0:
+        raise RuntimeError(f"hipMemcpy D2D failed ({rc})")
+
+
+_hip_handle = None
+
+
+def _hip():
+    global _hip_handle
+    if _hip_handle is None:
+        from pathlib import Path
+        cand = Path(torch.__file__).parent / "lib" / "libamdhip64.so"
+        _hip_handle = C.CDLL(str(cand if cand.exists() else "libamdhip64.so"), mode=C.RTLD_GLOBAL)
+        _hip_handle.hipMemcpy.restype = C.c_int
+        _hip_handle.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    return _hip_handle
