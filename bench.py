@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--error-free", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=float, default=1e6, help="reads of the workload timed on the host cores")
+    ap.add_argument("--sharded", action="store_true", help="force the sharded (multi-GPU) code path even with one rank")
     return ap.parse_args()
 
 
@@ -95,9 +96,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.sharded
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from supernova_amd import synth
     from supernova_amd.engine import Engine, Params
@@ -111,7 +115,7 @@ def main():
     torch.cuda.synchronize()
     params = Params(K=K)
 
-    if world == 1:
+    if not use_dist:
         def step():
             return eng.count_graph(rows, sp.read_len, quals=quals, bc=bc, params=params)
     else:
@@ -122,7 +126,7 @@ def main():
             return sh.count_graph(rows, sp.read_len, quals=quals, bc=bc, params=params, read_index_base=rank * per_gpu)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -180,6 +184,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launch_ms": count_ms, "units_per_launch": units, "alg_bytes_per_unit": ALG_BYTES_PER_KMER[K]},
         }
+        out["config"]["path"] = "sharded" if use_dist else "single"
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(sp, K, args.cpu_sample)
@@ -187,7 +192,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "Gk-mers/s", "cores": os.cpu_count(), "kind": "reference",
                                        "sample": f"failed: {ex}"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -31,6 +31,7 @@
 #include "snk_common.h"
 #include "snk_kernels.h"
 #include "snk_graph.h"
+#include "snk_stages.h"
 
 namespace {
 
@@ -377,7 +378,7 @@ __global__ void __launch_bounds__(TB) rank_init_w_kernel(const uint32_t* __restr
 // List ranking over the 2n directed states (node, exit side) of a degree<=2 link graph: for every state the
 // number of steps (or summed weights) to the end of its path and the terminal state.  Smooth circles are cut
 // at the left side of their minimum node and ranked again.  link[] is modified by the cut.
-static int rank_lists(snk_ctx* ctx, hipStream_t st, uint32_t* link, uint64_t n, const uint32_t* weights, uint8_t* circ /* per state, nullable */,
+static int rank_lists_wyllie(snk_ctx* ctx, hipStream_t st, uint32_t* link, uint64_t n, const uint32_t* weights, uint8_t* circ /* per state, nullable */,
                       const uint32_t** dist_out, const uint32_t** tail_out, uint32_t* n_circles, uint32_t* rounds,
                       char* err, size_t errcap) {
     const uint64_t ns = 2 * n;
@@ -433,6 +434,140 @@ static int rank_lists(snk_ctx* ctx, hipStream_t st, uint32_t* link, uint64_t n, 
     return SNK_OK;
 }
 
+
+// ---- work-efficient ranking: sparse ruling set.  Wyllie's pointer jumping touches every state log2(len) times
+// (21-28 rounds of random 12-byte gathers on the benchmark, 60% of the whole step); here every state is touched
+// twice: list heads and a hashed 1/64 sample of the states are "splitters", each walks to the next splitter, the
+// short splitter list is ranked by pointer jumping, and a second walk hands the ranks to the states in between.
+constexpr uint32_t SPLIT_MASK = 63;
+__device__ __forceinline__ bool sampled_state(uint32_t s) { return ((snk_mix32(s >> 1) >> 7) & SPLIT_MASK) == 0; }
+
+__global__ void __launch_bounds__(TB) spl_mark_kernel(const uint32_t* __restrict__ link, uint64_t ns, uint8_t* __restrict__ spl,
+                                                      uint32_t* __restrict__ flag32) {
+    uint64_t s = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (s >= ns) return;
+    bool head = link[s ^ 1] == NONE;                 // nobody walks into s: it starts a list
+    bool sp = head || sampled_state((uint32_t)s);
+    spl[s] = sp ? 1 : 0;
+    flag32[s] = sp ? 1u : 0u;
+}
+__global__ void __launch_bounds__(TB) spl_collect_kernel(const uint8_t* __restrict__ spl, const uint32_t* __restrict__ sid, uint64_t ns,
+                                                         uint32_t* __restrict__ spl_state) {
+    uint64_t s = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (s >= ns || !spl[s]) return;
+    spl_state[sid[s]] = (uint32_t)s;
+}
+__global__ void __launch_bounds__(TB) spl_walk1_kernel(const uint32_t* __restrict__ link, const uint8_t* __restrict__ spl,
+                                                       const uint32_t* __restrict__ sid, const uint32_t* __restrict__ spl_state,
+                                                       const uint32_t* __restrict__ w, uint64_t m, uint32_t* __restrict__ rnxt,
+                                                       uint32_t* __restrict__ rdist, uint32_t* __restrict__ rtail) {
+    uint64_t k = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (k >= m) return;
+    uint32_t cur = spl_state[k];
+    uint32_t d = 0, nx = NONE;
+    for (;;) {
+        uint32_t l = link[cur];
+        if (l == NONE) { nx = NONE; break; }
+        cur = l ^ 1u;
+        d += w ? w[cur >> 1] : 1u;
+        if (spl[cur]) { nx = sid[cur]; break; }
+    }
+    rnxt[k] = nx;
+    rdist[k] = d;
+    rtail[k] = cur;        // the terminal state when nx == NONE (overwritten by the jumping otherwise)
+}
+__global__ void __launch_bounds__(TB) spl_walk2_kernel(const uint32_t* __restrict__ link, const uint8_t* __restrict__ spl,
+                                                       const uint32_t* __restrict__ spl_state, const uint32_t* __restrict__ w,
+                                                       const uint32_t* __restrict__ rdist, const uint32_t* __restrict__ rtail, uint64_t m,
+                                                       uint32_t* __restrict__ dist, uint32_t* __restrict__ tail) {
+    uint64_t k = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (k >= m) return;
+    uint32_t cur = spl_state[k];
+    uint32_t d = rdist[k];
+    const uint32_t t = rtail[k];
+    for (;;) {
+        dist[cur] = d;
+        tail[cur] = t;
+        uint32_t l = link[cur];
+        if (l == NONE) break;
+        cur = l ^ 1u;
+        if (spl[cur]) break;
+        d -= w ? w[cur >> 1] : 1u;
+    }
+}
+__global__ void __launch_bounds__(TB) unranked_check_kernel(const uint32_t* __restrict__ tail, uint64_t ns, uint32_t* __restrict__ flag) {
+    uint64_t s = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (s < ns && tail[s] == NONE) *flag = 1u;
+}
+
+static int rank_lists(snk_ctx* ctx, hipStream_t st, uint32_t* link, uint64_t n, const uint32_t* weights, uint8_t* circ /* per state, nullable */,
+                      const uint32_t** dist_out, const uint32_t** tail_out, uint32_t* n_circles, uint32_t* rounds,
+                      char* err, size_t errcap) {
+    const uint64_t ns = 2 * n;
+    if (ns < 4096 || snk_env_u32("SNK_RANK_WYLLIE", 0))
+        return rank_lists_wyllie(ctx, st, link, n, weights, circ, dist_out, tail_out, n_circles, rounds, err, errcap);
+    uint8_t* spl;
+    uint32_t *flag32, *sid;
+    G_ALLOC(spl, uint8_t, ns + 1);
+    G_ALLOC(flag32, uint32_t, ns + 1);
+    G_ALLOC(sid, uint32_t, ns + 1);
+    SNK_HIP_TRY(hipMemsetAsync(flag32 + ns, 0, 4, st));
+    hipLaunchKernelGGL(spl_mark_kernel, dim3(nblk(ns)), dim3(TB), 0, st, link, ns, spl, flag32);
+    {
+        size_t tb = 0;
+        SNK_HIP_TRY(rocprim::exclusive_scan((void*)nullptr, tb, flag32, sid, 0u, (size_t)(ns + 1), rocprim::plus<uint32_t>(), st));
+        void* tmp;
+        int rc = snk_ctx_alloc(ctx, tb, &tmp, err, errcap);
+        if (rc) return rc;
+        SNK_HIP_TRY(rocprim::exclusive_scan(tmp, tb, flag32, sid, 0u, (size_t)(ns + 1), rocprim::plus<uint32_t>(), st));
+    }
+    uint32_t m32 = 0;
+    SNK_HIP_TRY(hipMemcpyAsync(&m32, sid + ns, 4, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    const uint64_t m = m32;
+    uint32_t* spl_state = flag32;      // flag32 is dead after the scan: reuse it for the compacted splitter list
+    if (m) hipLaunchKernelGGL(spl_collect_kernel, dim3(nblk(ns)), dim3(TB), 0, st, spl, sid, ns, spl_state);
+    uint32_t *rn[2], *rd[2], *rt[2];
+    for (int b = 0; b < 2; ++b) { G_ALLOC(rn[b], uint32_t, m + 1); G_ALLOC(rd[b], uint32_t, m + 1); G_ALLOC(rt[b], uint32_t, m + 1); }
+    if (m) hipLaunchKernelGGL(spl_walk1_kernel, dim3(nblk(m)), dim3(TB), 0, st, link, spl, sid, spl_state, weights, m, rn[0], rd[0], rt[0]);
+    SNK_HIP_TRY(hipGetLastError());
+    // pointer jumping on the splitter list
+    uint32_t* flags;
+    G_ALLOC(flags, uint32_t, 4);
+    uint32_t h_flag = 0;
+    int max_rounds = 2;
+    while ((1ull << (max_rounds - 1)) < m + 1) ++max_rounds;
+    int cur = 0;
+    uint32_t r_done = 0;
+    bool converged = (m == 0);
+    for (int r = 0; r < max_rounds && !converged; ++r) {
+        SNK_HIP_TRY(hipMemsetAsync(flags, 0, 4, st));
+        hipLaunchKernelGGL(rank_round_kernel, dim3(nblk(m)), dim3(TB), 0, st, rn[cur], rd[cur], rt[cur], m, rn[cur ^ 1], rd[cur ^ 1], rt[cur ^ 1], flags);
+        cur ^= 1;
+        ++r_done;
+        SNK_HIP_TRY(hipMemcpyAsync(&h_flag, flags, 4, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(hipStreamSynchronize(st));
+        if (h_flag == 0) converged = true;
+    }
+    if (!converged)      // a circle that contains splitters: let the general algorithm find, cut and rank it
+        return rank_lists_wyllie(ctx, st, link, n, weights, circ, dist_out, tail_out, n_circles, rounds, err, errcap);
+    uint32_t *dist, *tail;
+    G_ALLOC(dist, uint32_t, ns);
+    G_ALLOC(tail, uint32_t, ns);
+    SNK_HIP_TRY(hipMemsetAsync(tail, 0xFF, ns * 4, st));
+    if (m) hipLaunchKernelGGL(spl_walk2_kernel, dim3(nblk(m)), dim3(TB), 0, st, link, spl, spl_state, weights, rd[cur], rt[cur], m, dist, tail);
+    SNK_HIP_TRY(hipMemsetAsync(flags, 0, 4, st));
+    hipLaunchKernelGGL(unranked_check_kernel, dim3(nblk(ns)), dim3(TB), 0, st, tail, ns, flags);
+    SNK_HIP_TRY(hipMemcpyAsync(&h_flag, flags, 4, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    if (h_flag)          // states no walk reached: a circle without a splitter
+        return rank_lists_wyllie(ctx, st, link, n, weights, circ, dist_out, tail_out, n_circles, rounds, err, errcap);
+    *dist_out = dist;
+    *tail_out = tail;
+    *n_circles = 0;
+    *rounds = r_done;
+    return SNK_OK;
+}
 
 template <int K>
 static int graph_impl(snk_ctx* ctx, hipStream_t st, const snk_u128* keys, const uint64_t* vals, uint64_t n,
