@@ -56,7 +56,7 @@ feudal/FeudalFileWriter feudal/FieldVec feudal/Generic feudal/Mempool feudal/Oob
 graph/Digraph kmers/KMerContext kmers/ReadPather
 math/Matrix math/Permutation math/PowerOf2
 paths/HyperBasevector paths/KmerBaseBroker paths/KmerPath paths/KmerPathInterval
-paths/long/ExtendReadPath paths/long/HBVFromEdges paths/long/ReadPath
+paths/long/ExtendReadPath paths/long/HBVFromEdges paths/long/ReadPath paths/long/ReadPathTools paths/long/ShortKmerReadPather 10X/paths/ReadPathVecX 10X/paths/ReadPathParser 10X/paths/ReadPathX
 random/RNGen
 system/Assert system/ErrNo system/Exit system/MemTracker system/ProcBuf system/RunTime system/SysConf
 system/System system/Thread system/ThreadsafeIO system/UseGDB system/WorklistUtils
@@ -75,7 +75,9 @@ export -f compile_one
 export CXX FLAGS OV S W
 echo "$CLOSURE $EXTRA" | tr ' ' '\n' | grep -v '^$' | xargs -P "$(nproc)" -I{} bash -c 'compile_one {}'
 $CXX $FLAGS -c "$HERE/ref_driver.cc" -o "$W/obj/ref_driver.o"
+$CXX $FLAGS -DSNK_REF_K60 -c "$HERE/ref_driver.cc" -o "$W/obj/ref_driver60.o"
 # archive, so that only the members the driver really reaches are linked (the closure list is a superset)
-ar rcs "$W/libref.a" $(ls "$W"/obj/*.o | grep -v -e ref_driver.o -e LinkTimestamp.o)
+ar rcs "$W/libref.a" $(ls "$W"/obj/*.o | grep -v -e ref_driver.o -e ref_driver60.o -e LinkTimestamp.o)
 $CXX -fopenmp -o "$OUT/snref_driver" "$W/obj/ref_driver.o" "$W/obj/LinkTimestamp.o" "$W/libref.a" -lz -lpthread
-echo "build_ref: built $OUT/snref_driver"
+$CXX -fopenmp -o "$OUT/snref_driver60" "$W/obj/ref_driver60.o" "$W/obj/LinkTimestamp.o" "$W/libref.a" -lz -lpthread
+echo "build_ref: built $OUT/snref_driver and $OUT/snref_driver60"

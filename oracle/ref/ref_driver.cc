@@ -16,7 +16,22 @@
 //
 // usage: snref_driver <in.snkr> <outdir> [threads=8] [mode=dump|time] [minQual=7 minFreq=3 minBC=2]
 
+#ifdef SNK_REF_K60
+// K=60 variant of the reference (paths/long/BuildReadQGraph60.cc: createDict :148, buildEdges :378); it has no
+// barcode rule, so the barcode vector of the input is ignored.
+#include "paths/long/BuildReadQGraph60.cc"
+#include "system/RunTime.h"
+#include "system/System.h"
+#include "feudal/ObjectManager.h"
+#include "feudal/PQVec.h"
+#include "paths/HyperBasevector.h"
+#include "paths/long/HBVFromEdges.h"
+#include "ParallelVecUtilities.h"
+#define SNK_KW 4
+#else
 #include "paths/long/BuildReadQGraph48.cc"
+#define SNK_KW 3
+#endif
 
 #include <chrono>
 #include <cstdint>
@@ -56,7 +71,7 @@ Input load(const char* path) {
     return in;
 }
 
-struct KRec { uint32_t k[3]; uint32_t count; uint8_t ctx; uint8_t pad[3]; };
+struct KRec { uint32_t k[SNK_KW]; uint32_t count; uint8_t ctx; uint8_t pad[3]; };
 
 std::string bvstr(bvec const& b) {
     std::string s(b.size(), 'A');
@@ -124,8 +139,12 @@ int main(int argc, char** argv) {
             for (unsigned g : goodLens) if (g >= K + 1) nInst += g - K + 1;
         }
         auto t0 = std::chrono::steady_clock::now();
+#ifdef SNK_REF_K60
+        buildReadQGraph60(reads, quals, False, False, minQual, minFreq, .75, 0, "", True, False, &hbv, nullptr, 0.5, False);
+#else
         buildReadQGraph48(work, "/data/frag_reads_orig", "", reads, quals, False, False, minQual, minFreq,
                           in.ign_bc_below, minBC, bcp, .75, 0, "", True, False, &hbv, nullptr, 0.5, False);
+#endif
         double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         printf("SNREF_TIME seconds=%.6f threads=%u reads=%lu kmer_instances=%lu hbv_edges=%d hbv_vertices=%d\n", s, nt,
                (unsigned long)in.n, (unsigned long)nInst, hbv.EdgeObjectCount(), hbv.N());
@@ -143,8 +162,12 @@ int main(int argc, char** argv) {
     }
 
     // ---- count + filter + contexts + adjacency prune
+#ifdef SNK_REF_K60
+    Dict* pDict = createDict(reads, quals, minQual, minFreq, 0.5);
+#else
     Dict<BCWrapper>* pDict =
         createDict(work, reads, quals, minQual, minFreq, in.ign_bc_below, 0.5, minBC, bcp);
+#endif
     {
         std::vector<KRec> recs;
         recs.reserve(pDict->size());
@@ -152,9 +175,9 @@ int main(int argc, char** argv) {
             for (auto const& e : hhs) {
                 KRec r;
                 memset(&r, 0, sizeof r);
-                for (unsigned w = 0; w < 3; ++w) {
+                for (unsigned w = 0; w < SNK_KW; ++w) {
                     uint32_t v = 0;
-                    for (unsigned i = 0; i < 16; ++i) v = (v << 2) | e[w * 16 + i];
+                    for (unsigned i = 0; i < 16; ++i) v = (v << 2) | (w * 16 + i < K ? e[w * 16 + i] : 0);
                     r.k[w] = v;
                 }
                 r.count = e.getKDef().getCount();
@@ -163,7 +186,7 @@ int main(int argc, char** argv) {
                 recs.push_back(r);
             }
         std::sort(recs.begin(), recs.end(), [](KRec const& a, KRec const& b) {
-            for (int w = 0; w < 3; ++w) if (a.k[w] != b.k[w]) return a.k[w] < b.k[w];
+            for (int w = 0; w < SNK_KW; ++w) if (a.k[w] != b.k[w]) return a.k[w] < b.k[w];
             return false;
         });
         FILE* f = fopen((outdir + "/kmers.bin").c_str(), "wb");

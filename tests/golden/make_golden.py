@@ -139,6 +139,9 @@ CASES = {
 }
 
 
+K60_CASES = ("adversarial", "synth_20k_err")
+
+
 def make(name: str) -> None:
     case = CASES[name]()
     with tempfile.TemporaryDirectory() as td:
@@ -146,6 +149,18 @@ def make(name: str) -> None:
         refio.write_snkrd(td / "in.snkrd", case["lens"], case["ascii"], case["quals"], case["bc"], case["ign_bc_below"])
         log = refio.run_ref(td / "in.snkrd", td / "out")
         d = refio.read_ref_dump(td / "out")
+        if name in K60_CASES:
+            # the reference's K=60 variant (BuildReadQGraph60.cc; frequency rule only, no barcode rule)
+            log60 = refio.run_ref(td / "in.snkrd", td / "out60", K=60)
+            d60 = refio.read_ref_dump(td / "out60", K=60)
+            s60 = [l for l in log60.splitlines() if l.startswith("SNREF_DUMP")][-1]
+            np.savez_compressed(
+                GOLD / f"{name}_k60.npz", exp_goodlens=d60["goodlens"], exp_keys=d60["kmers"]["k"],
+                exp_counts=d60["kmers"]["count"], exp_ctx=d60["kmers"]["ctx"],
+                exp_unitigs=np.frombuffer("\n".join(d60["unitigs"]).encode(), dtype=np.uint8),
+                exp_hbv=np.frombuffer(d60["hbv"].encode(), dtype=np.uint8),
+                ref_summary=np.frombuffer(s60.encode(), dtype=np.uint8))
+            print(f"{name}_k60: {s60}")
     summary = [l for l in log.splitlines() if l.startswith("SNREF_DUMP")][-1]
     codes = synth.ascii_to_codes(case["ascii"])
     out = GOLD / f"{name}.npz"

@@ -38,3 +38,20 @@ def load(name: str) -> Case:
     if name not in _cache:
         _cache[name] = Case(name)
     return _cache[name]
+
+
+class Case60:
+    """K=60 expectations of a base case, dumped from the reference's BuildReadQGraph60 (no barcode rule)."""
+
+    def __init__(self, name: str):
+        z = np.load(GOLD / f"{name}_k60.npz")
+        self.base = load(name)
+        self.exp_goodlens = z["exp_goodlens"]
+        self.exp_keys = z["exp_keys"]          # [n,4] u32
+        self.exp_counts = z["exp_counts"]
+        self.exp_ctx = z["exp_ctx"]
+        self.exp_unitigs = bytes(z["exp_unitigs"]).decode().split("\n") if len(z["exp_unitigs"]) else []
+        self.exp_hbv = bytes(z["exp_hbv"]).decode()
+
+
+K60_CASES = ["adversarial", "synth_20k_err"]

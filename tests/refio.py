@@ -17,6 +17,8 @@ REF_DRIVER = ROOT / "oracle" / "_ref" / "snref_driver"
 GOLDEN = ROOT / "tests" / "golden"
 
 KREC = np.dtype([("k", "<u4", 3), ("count", "<u4"), ("ctx", "u1"), ("pad", "u1", 3)])
+KREC60 = np.dtype([("k", "<u4", 4), ("count", "<u4"), ("ctx", "u1"), ("pad", "u1", 3)])
+REF_DRIVER60 = ROOT / "oracle" / "_ref" / "snref_driver60"
 
 
 def write_snkrd(path, lens, bases_ascii, quals, bc=None, ign_bc_below=0):
@@ -31,21 +33,21 @@ def write_snkrd(path, lens, bases_ascii, quals, bc=None, ign_bc_below=0):
             f.write(np.asarray(bc, dtype="<i4").tobytes())
 
 
-def run_ref(snkrd, outdir, threads=8, mode="dump", min_qual=7, min_freq=3, min_bc=2, timeout=3600):
+def run_ref(snkrd, outdir, threads=8, mode="dump", min_qual=7, min_freq=3, min_bc=2, timeout=3600, K=48):
     outdir = Path(outdir)
     outdir.mkdir(parents=True, exist_ok=True)
-    r = subprocess.run([str(REF_DRIVER), str(snkrd), str(outdir), str(threads), mode, str(min_qual), str(min_freq),
+    r = subprocess.run([str(REF_DRIVER if K == 48 else REF_DRIVER60), str(snkrd), str(outdir), str(threads), mode, str(min_qual), str(min_freq),
                         str(min_bc)], capture_output=True, text=True, timeout=timeout)
     if r.returncode != 0:
         raise RuntimeError(f"snref_driver failed ({r.returncode}):\n{r.stdout[-4000:]}\n{r.stderr[-4000:]}")
     return r.stdout
 
 
-def read_ref_dump(outdir):
+def read_ref_dump(outdir, K=48):
     outdir = Path(outdir)
     out = {}
     out["goodlens"] = np.fromfile(outdir / "goodlens.u32", dtype="<u4")
-    out["kmers"] = np.fromfile(outdir / "kmers.bin", dtype=KREC)
+    out["kmers"] = np.fromfile(outdir / "kmers.bin", dtype=KREC if K == 48 else KREC60)
     out["unitigs"] = (outdir / "unitigs.txt").read_text().split()
     out["hbv"] = (outdir / "hbv.txt").read_text()
     hist = outdir / "stats" / "histogram_kmer_count.json"

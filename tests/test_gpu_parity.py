@@ -124,3 +124,38 @@ def test_pack_ascii_and_trim_kernels(engine):
     for mq in (7, 10, 31):
         g = engine.trim(quals, c.read_len, K=48, min_qual=mq, lens=lens).cpu().numpy().view(np.uint16)
         assert np.array_equal(g.astype(np.uint32), oracle_lib.good_lens(c.quals, c.lens, K=48, min_qual=mq))
+
+
+@pytest.mark.parametrize("name,use_bc", [("adversarial", True), ("synth_20k_err", False)])
+def test_k60_vs_oracle(engine, name, use_bc):
+    """K=60 (long-k config): key 120 bit, supermers up to 106 bases.  The reference's BuildReadQGraph60 has no barcode
+    rule, so K=60 is checked against the C oracle (same algorithm, K generic)."""
+    from supernova_amd.engine import Params
+    c = goldens.load(name)
+    rows, quals, bc, lens = _to_dev(c)
+    res = engine.count_graph(rows, c.read_len, quals=quals, bc=bc if use_bc else None, lens=lens, params=Params(K=60),
+                             ign_bc_below=c.ign_bc_below)
+    gl = oracle_lib.good_lens(c.quals, c.lens, K=60, min_qual=7)
+    o = oracle_lib.OracleResult(c.codes, gl, c.bc if use_bc else None, K=60, ign_bc_below=c.ign_bc_below, hbv=False)
+    assert np.array_equal(res.good_len().astype(np.uint32), gl)
+    assert res.n_instances == o.n_instances
+    k = res.keys()
+    assert np.array_equal(k, o.keys)
+    assert np.array_equal(res.counts(), o.counts)
+    assert np.array_equal(res.ctx(), o.ctx)
+    assert res.unitigs() == o.unitigs
+
+
+@pytest.mark.parametrize("name", goldens.K60_CASES)
+def test_k60_golden(engine, name):
+    """K=60 against golden vectors dumped from the reference's BuildReadQGraph60 (no barcode rule => bc=None)."""
+    from supernova_amd.engine import Params
+    g = goldens.Case60(name)
+    c = g.base
+    rows, quals, bc, lens = _to_dev(c)
+    res = engine.count_graph(rows, c.read_len, quals=quals, bc=None, lens=lens, params=Params(K=60))
+    assert np.array_equal(res.good_len().astype(np.uint32), g.exp_goodlens)
+    assert np.array_equal(res.keys(), g.exp_keys)
+    assert np.array_equal(np.minimum(res.counts(), (1 << 24) - 1), g.exp_counts)
+    assert np.array_equal(res.ctx(), g.exp_ctx)
+    assert res.unitigs() == g.exp_unitigs

@@ -84,3 +84,48 @@ def test_sharded_matches_reference(snk, W, name):
 def test_sharded_many_small_buckets(snk):
     c = goldens.load("adversarial")
     check(run_world(4, c, n_buckets=4 * 997), c)
+
+
+def test_sharded_k60(snk):
+    """K=60 through the sharded path (2 ranks) against the C oracle."""
+    import oracle_lib
+    c = goldens.load("adversarial")
+    import torch
+    from supernova_amd.engine import Engine, Params
+    from supernova_amd.sharded import ShardedEngine, SimWorld
+    W = 2
+    world = SimWorld(W)
+    dev = torch.device("cuda", 0)
+    n = c.rows.shape[0]
+    bounds = [n * r // W for r in range(W + 1)]
+    out, errs = [None] * W, []
+
+    def worker(r):
+        try:
+            e = Engine(0)
+            lo, hi = bounds[r], bounds[r + 1]
+            res = ShardedEngine(e, world.comm(r)).count_graph(
+                torch.from_numpy(c.rows[lo:hi].view(np.int32).copy()).to(dev), c.read_len,
+                quals=torch.from_numpy(np.ascontiguousarray(c.quals[lo:hi])).to(dev),
+                bc=torch.from_numpy(c.bc[lo:hi].astype(np.int32)).to(dev),
+                lens=torch.from_numpy(c.lens[lo:hi].astype(np.uint16).view(np.int16)).to(dev),
+                params=Params(K=60), ign_bc_below=c.ign_bc_below, read_index_base=lo)
+            out[r] = dict(keys=res.keys(), counts=res.counts(), ctx=res.ctx(), unitigs=res.unitigs() if r == 0 else None)
+            e.close()
+        except BaseException as ex:  # noqa: BLE001
+            errs.append(ex)
+            world.barrier_obj.abort()
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(W)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    if errs:
+        raise errs[0]
+    gl = oracle_lib.good_lens(c.quals, c.lens, K=60)
+    o = oracle_lib.OracleResult(c.codes, gl, c.bc, K=60, ign_bc_below=c.ign_bc_below, hbv=False)
+    keys = np.concatenate([x["keys"] for x in out])
+    order = np.lexsort((keys[:, 3], keys[:, 2], keys[:, 1], keys[:, 0]))
+    assert np.array_equal(keys[order], o.keys)
+    assert np.array_equal(np.concatenate([x["counts"] for x in out])[order], o.counts)
+    assert np.array_equal(np.concatenate([x["ctx"] for x in out])[order], o.ctx)
+    assert out[0]["unitigs"] == o.unitigs

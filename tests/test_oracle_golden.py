@@ -105,3 +105,18 @@ def test_bv_roundtrip(tmp_path):
     assert np.array_equal(off2, off)
     assert np.array_equal(np.ctypeslib.as_array(v.bases, shape=(int(off[-1]),)), b)
     lib.sno_unitigs_free(C.byref(v))
+
+
+@pytest.mark.parametrize("name", goldens.K60_CASES)
+def test_oracle_k60_matches_reference(name):
+    """K=60 pin: the reference's BuildReadQGraph60 (frequency rule only -> oracle run without a barcode vector)."""
+    g = goldens.Case60(name)
+    c = g.base
+    gl = oracle_lib.good_lens(c.quals, c.lens, K=60, min_qual=7)
+    assert np.array_equal(gl, g.exp_goodlens)
+    o = oracle_lib.OracleResult(c.codes, gl, None, K=60, min_freq=3)
+    assert np.array_equal(o.keys, g.exp_keys)
+    assert np.array_equal(np.minimum(o.counts, (1 << 24) - 1), g.exp_counts)
+    assert np.array_equal(o.ctx, g.exp_ctx)
+    assert o.unitigs == g.exp_unitigs
+    assert o.hbv_text() == g.exp_hbv
