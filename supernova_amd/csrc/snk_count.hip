@@ -25,6 +25,12 @@ namespace {
 constexpr uint32_t BC_MULTI = 0xFFFFFFFEu;
 constexpr uint32_t BC_IGN = 0xFFFFFFFFu;
 constexpr int MAX_SPLIT_LOG2 = 16;
+#ifndef SNK_COUNT_THREADS
+#define SNK_COUNT_THREADS 768
+#endif
+#ifndef SNK_COUNT_SLOTS
+#define SNK_COUNT_SLOTS 2048
+#endif
 #define LDS_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 
 template <int K> struct lo_t { typedef uint32_t type; };       // K<=48: only the top 32 bits of lo are used
@@ -39,6 +45,7 @@ template <> __device__ __forceinline__ uint64_t lo_unpack<60>(uint64_t v) { retu
 
 template <int K, int THREADS, int SLOTS>
 __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
+    constexpr int BATCH = 256;                           // supermers staged per batch (owner[] holds 8-bit indices)
     typedef typename lo_t<K>::type lo_type;
     constexpr int WMAX = K - SNK_M + 1;                  // k-mers per supermer, at most
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -48,14 +55,14 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
     uint32_t* cnt = tag + SLOTS;                                                    // [SLOTS] observations
     uint32_t* bcs = cnt + SLOTS;                                                    // [SLOTS] barcode state
     uint32_t* ctxw = bcs + SLOTS;                                                   // [SLOTS/4] context bytes
-    uint32_t* rec = ctxw + SLOTS / 4;                                               // [8][THREADS] staged supermer records
-    uint32_t* pre = rec + 8 * THREADS;                                              // [THREADS+1] k-mer prefix sums of the batch
-    uint32_t* ctl = pre + THREADS + 4;                                              // [64] control words
-    uint8_t* owner = reinterpret_cast<uint8_t*>(ctl + 64);                          // [THREADS*WMAX] k-mer -> supermer of the batch
+    uint32_t* rec = ctxw + SLOTS / 4;                                               // [8][BATCH] staged supermer records
+    uint32_t* pre = rec + 8 * BATCH;                                                // [BATCH+1] k-mer prefix sums of the batch
+    uint32_t* ctl = pre + BATCH + 4;                                                // [64] control words
+    uint8_t* owner = reinterpret_cast<uint8_t*>(ctl + 64);                          // [BATCH*WMAX] k-mer -> supermer of the batch
     // ctl[0] stack pointer, ctl[1] occupied slots, ctl[2] overflow flag, ctl[3] split log2, ctl[4] split id,
     // ctl[5] valid entries of the sub-pass, ctl[6..7] reserved base (lo,hi), ctl[8] placement counter,
     // ctl[9..12] wave totals for the batch scan, ctl[16..16+2*MAX) split stack
-    static_assert(THREADS <= 256, "owner[] holds 8-bit batch indices");
+    static_assert(THREADS >= BATCH && THREADS % 64 == 0, "the first BATCH threads stage the records");
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const uint32_t bucket = blockIdx.x;
@@ -84,26 +91,28 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
         for (uint32_t seg = 0; seg < a.nseg; ++seg) {
             const uint64_t beg = a.seg_off[(uint64_t)seg * (a.NB + 1) + bucket];
             const uint64_t end = a.seg_off[(uint64_t)seg * (a.NB + 1) + bucket + 1];
-            for (uint64_t base = beg; base < end; base += THREADS) {
+            for (uint64_t base = beg; base < end; base += BATCH) {
                 // ---- stage one batch of supermer records (coalesced 32-byte loads) and scan their k-mer counts
                 const uint64_t idx = base + tid;
                 uint32_t nkm = 0;
-                if (idx < end) {
+                if (tid < BATCH && idx < end) {
                     const uint4 r0 = a.records[idx * 2], r1 = a.records[idx * 2 + 1];
-                    rec[0 * THREADS + tid] = r0.x; rec[1 * THREADS + tid] = r0.y; rec[2 * THREADS + tid] = r0.z;
-                    rec[3 * THREADS + tid] = r0.w; rec[4 * THREADS + tid] = r1.x; rec[5 * THREADS + tid] = r1.y;
-                    rec[6 * THREADS + tid] = r1.z; rec[7 * THREADS + tid] = r1.w;
+                    rec[0 * BATCH + tid] = r0.x; rec[1 * BATCH + tid] = r0.y; rec[2 * BATCH + tid] = r0.z;
+                    rec[3 * BATCH + tid] = r0.w; rec[4 * BATCH + tid] = r1.x; rec[5 * BATCH + tid] = r1.y;
+                    rec[6 * BATCH + tid] = r1.z; rec[7 * BATCH + tid] = r1.w;
                     nkm = r1.z & 0x7Fu;
                 }
                 uint32_t incl = nkm;
                 for (int o = 1; o < 64; o <<= 1) { uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-                if (lane == 63) ctl[9 + wv] = incl;
+                if (lane == 63 && wv < BATCH / 64) ctl[9 + wv] = incl;
                 __syncthreads();
                 uint32_t woff = 0, total = 0;
-                for (int w = 0; w < THREADS / 64; ++w) { uint32_t t = ctl[9 + w]; if (w < wv) woff += t; total += t; }
-                const uint32_t mypre = woff + incl - nkm;
-                pre[tid] = mypre;
-                for (uint32_t j = 0; j < nkm; ++j) owner[mypre + j] = (uint8_t)tid;
+                for (int w = 0; w < BATCH / 64; ++w) { uint32_t t = ctl[9 + w]; if (w < wv) woff += t; total += t; }
+                if (tid < BATCH) {
+                    const uint32_t mypre = woff + incl - nkm;
+                    pre[tid] = mypre;
+                    for (uint32_t j = 0; j < nkm; ++j) owner[mypre + j] = (uint8_t)tid;
+                }
                 __syncthreads();
                 // ---- one lane per k-mer instance: a wave inserts 64 different k-mers of consecutive supermers, so
                 //      copies of the same k-mer (identical supermers of other reads) are spread over time, not lanes
@@ -113,16 +122,16 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
                     if (g < total) {
                         const uint32_t i = owner[g];
                         const uint32_t j = g - pre[i];
-                        const uint32_t m6 = rec[6 * THREADS + i];
+                        const uint32_t m6 = rec[6 * BATCH + i];
                         const uint32_t n_i = m6 & 0x7Fu, hasL = (m6 >> 7) & 1u, hasR = (m6 >> 8) & 1u;
-                        const int32_t bc = (int32_t)rec[7 * THREADS + i];
+                        const int32_t bc = (int32_t)rec[7 * BATCH + i];
                         const uint32_t o = hasL + j;                     // first base of the k-mer inside the record
                         const uint32_t wi = (2u * o) >> 5, sh = (2u * o) & 31u;
                         uint32_t W[5];
 #pragma unroll
                         for (uint32_t q = 0; q < 5; ++q) {
                             const uint32_t x = wi + q;
-                            uint32_t v = x < 7 ? rec[x * THREADS + i] : 0u;
+                            uint32_t v = x < 7 ? rec[x * BATCH + i] : 0u;
                             if (x == 6) v &= 0xFFFFF000u;
                             W[q] = v;
                         }
@@ -136,7 +145,7 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
                         const uint32_t havepred = o ? 1u : 0u;
                         uint32_t pb;
                         if (sh) pb = (W[0] >> (32 - sh)) & 3u;
-                        else pb = (wi ? rec[(wi - 1) * THREADS + i] : 0u) & 3u;
+                        else pb = (wi ? rec[(wi - 1) * BATCH + i] : 0u) & 3u;
                         uint32_t ctx = (havepred ? (0x10u << pb) : 0u) | (havesucc ? (1u << nb) : 0u);
                         const snk_kmer r = snk_kmer_rc<K>(f);
                         const bool rev = snk_kmer_lt(r, f);          // isRev(): store the reverse complement (:164)
@@ -211,8 +220,7 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
         if (tid == 0) { ctl[5] = 0; ctl[8] = 0; }
         __syncthreads();
         uint32_t myvalid = 0;
-        for (int s0 = 0; s0 < SLOTS; s0 += THREADS) {
-            const int s = s0 + tid;
+        for (int s = tid; s < SLOTS; s += THREADS) {      // SLOTS need not be a multiple of THREADS
             const uint32_t c = cnt[s];
             bool ok = c >= a.min_freq && c != 0;
             if (ok && a.bc_mode) {
@@ -237,8 +245,7 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
             const uint64_t rbase = ((uint64_t)LDS_LOAD(&ctl[7]) << 32) | LDS_LOAD(&ctl[6]);
             if (rbase + nvalid <= a.region_cap) {
                 const uint64_t gbase = (uint64_t)region * a.region_cap + rbase;
-                for (int s0 = 0; s0 < SLOTS; s0 += THREADS) {
-                    const int s = s0 + tid;
+                for (int s = tid; s < SLOTS; s += THREADS) {
                     const uint32_t c = cnt[s];
                     if (c) {
                         const uint32_t pos = atomicAdd(&ctl[8], 1u);
@@ -257,13 +264,13 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
 }
 
 template <int K> struct cfg;
-template <> struct cfg<48> { static constexpr int THREADS = 256; static constexpr int SLOTS = 2048; };
-template <> struct cfg<60> { static constexpr int THREADS = 256; static constexpr int SLOTS = 2048; };
+template <> struct cfg<48> { static constexpr int THREADS = SNK_COUNT_THREADS; static constexpr int SLOTS = SNK_COUNT_SLOTS; };
+template <> struct cfg<60> { static constexpr int THREADS = SNK_COUNT_THREADS; static constexpr int SLOTS = SNK_COUNT_SLOTS; };
 
 template <int K>
 size_t lds_bytes() {
-    constexpr size_t T = cfg<K>::THREADS, S = cfg<K>::SLOTS;
-    return S * (8 + sizeof(typename lo_t<K>::type) + 4 + 4 + 4) + S + 4 * (8 * T + T + 4 + 64) + T * (K - SNK_M + 1) + 16;
+    constexpr size_t S = cfg<K>::SLOTS, B = 256;
+    return S * (8 + sizeof(typename lo_t<K>::type) + 4 + 4 + 4) + S + 4 * (8 * B + B + 4 + 64) + B * (K - SNK_M + 1) + 16;
 }
 
 template <int K>

@@ -25,6 +25,8 @@ struct snk_shard_state {
     const uint16_t* good_len = nullptr;
     uint32_t* cursor = nullptr;
     uint32_t* status = nullptr;
+    uint16_t* slist = nullptr;
+    uint8_t* scount = nullptr;
     snk_table tab{};
     snk_dist_graph g{};
     snk_phase_timer* tm = nullptr;
@@ -67,11 +69,13 @@ extern "C" int snk_shard_hist(snk_ctx* ctx, const snk_dev_reads* in, const snk_p
     if ((rc = snk_ctx_alloc(ctx, 64, &q, err, errcap))) return rc; S->status = (uint32_t*)q;
     unsigned long long* counter;
     if ((rc = snk_ctx_alloc(ctx, 64, &q, err, errcap))) return rc; counter = (unsigned long long*)q;
+    if ((rc = snk_ctx_alloc(ctx, (size_t)SNK_MSP_LCAP * in->n_reads * 2 + 64, &q, err, errcap))) return rc; S->slist = (uint16_t*)q;
+    if ((rc = snk_ctx_alloc(ctx, in->n_reads + 64, &q, err, errcap))) return rc; S->scount = (uint8_t*)q;
     SNK_HIP_TRY(hipMemsetAsync(d_hist, 0, (size_t)NB_total * 4, st));
     SNK_HIP_TRY(hipMemsetAsync(counter, 0, 64, st));
     SNK_HIP_TRY(hipMemsetAsync(S->status, 0, 64, st));
     rc = snk_launch_msp(p->K, false, st, (const uint32_t*)in->rows, in->row_words, good_len, (const int32_t*)in->bc, in->ign_bc_below,
-                        in->read_index_base, in->n_reads, NB_total, (uint32_t*)d_hist, nullptr, counter, err, errcap);
+                        in->read_index_base, in->n_reads, NB_total, (uint32_t*)d_hist, nullptr, counter, S->slist, S->scount, err, errcap);
     if (rc) return rc;
     unsigned long long h = 0;
     SNK_HIP_TRY(hipMemcpyAsync(&h, counter, 8, hipMemcpyDeviceToHost, st));
@@ -87,7 +91,7 @@ extern "C" int snk_shard_scatter(snk_ctx* ctx, const void* d_offsets, void* d_re
     SNK_HIP_TRY(hipMemcpyAsync(S->cursor, d_offsets, (S->NB_total + 1) * 4ull, hipMemcpyDeviceToDevice, st));
     const snk_dev_reads& in = S->reads;
     return snk_launch_msp(S->params.K, true, st, (const uint32_t*)in.rows, in.row_words, S->good_len, (const int32_t*)in.bc, in.ign_bc_below,
-                          in.read_index_base, in.n_reads, S->NB_total, S->cursor, d_records, nullptr, err, errcap);
+                          in.read_index_base, in.n_reads, S->NB_total, S->cursor, d_records, nullptr, S->slist, S->scount, err, errcap);
 }
 
 extern "C" int snk_shard_count(snk_ctx* ctx, const void* d_records, const void* d_seg_off, uint64_t n_inst_hint, int has_bc,

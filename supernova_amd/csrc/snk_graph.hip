@@ -216,9 +216,12 @@ struct node_place {
     uint32_t pos;     // position walking from terminal `pid`
     bool rc;          // traversed as reverse complement when walking from `pid`
 };
-__device__ __forceinline__ node_place place_of(const uint32_t* dist, const uint32_t* tail, uint64_t i) {
-    uint32_t tR = tail[2 * i], tL = tail[2 * i + 1];
-    uint32_t dR = dist[2 * i], dL = dist[2 * i + 1];
+// rk[state] = (distance to the end of the path, terminal state): one 8-byte record per state, so the ranking's
+// second walk does one scattered store per state instead of two
+__device__ __forceinline__ node_place place_of(const uint2* rk, uint64_t i) {
+    const uint2 a = rk[2 * i], b = rk[2 * i + 1];
+    uint32_t tR = a.y, tL = b.y;
+    uint32_t dR = a.x, dL = b.x;
     node_place p;
     p.n = dR + dL + 1u;
     if (tL < tR) { p.pid = tL; p.other = tR; p.pos = dL; p.rc = false; }
@@ -228,11 +231,10 @@ __device__ __forceinline__ node_place place_of(const uint32_t* dist, const uint3
 
 // REV decision per path (getCanonicalForm, dna/CanonicalForm.h:35-48); written by exactly one node of the path
 template <int K>
-__global__ void __launch_bounds__(TB) orient_kernel(const snk_u128* __restrict__ keys, const uint32_t* __restrict__ dist,
-                                                    const uint32_t* __restrict__ tail, uint64_t n, uint8_t* __restrict__ prev) {
+__global__ void __launch_bounds__(TB) orient_kernel(const snk_u128* __restrict__ keys, const uint2* __restrict__ rk, uint64_t n, uint8_t* __restrict__ prev) {
     uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x;
     if (i >= n) return;
-    node_place p = place_of(dist, tail, i);
+    node_place p = place_of(rk, i);
     uint64_t L = (uint64_t)K + p.n - 1;
     snk_kmer k = load_key(keys, i);
     if (L & 1) {
@@ -252,36 +254,36 @@ __global__ void __launch_bounds__(TB) orient_kernel(const snk_u128* __restrict__
 }
 
 // head flags and unitig lengths
-__global__ void __launch_bounds__(TB) head_kernel(const uint32_t* __restrict__ dist, const uint32_t* __restrict__ tail,
+__global__ void __launch_bounds__(TB) head_kernel(const uint2* __restrict__ rk,
                                                   const uint8_t* __restrict__ prev, uint64_t n, uint32_t K,
                                                   uint32_t* __restrict__ hflag, uint64_t* __restrict__ hlen) {
     uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x;
     if (i >= n) return;
-    node_place p = place_of(dist, tail, i);
+    node_place p = place_of(rk, i);
     uint32_t pos = prev[p.pid] ? p.n - 1u - p.pos : p.pos;
     bool head = pos == 0;
     hflag[i] = head ? 1u : 0u;
     hlen[i] = head ? (uint64_t)K + p.n - 1 : 0ull;
 }
-__global__ void __launch_bounds__(TB) head_place_kernel(const uint32_t* __restrict__ tail, const uint32_t* __restrict__ hflag,
+__global__ void __launch_bounds__(TB) head_place_kernel(const uint2* __restrict__ rk, const uint32_t* __restrict__ hflag,
                                                         const uint32_t* __restrict__ hidx, const uint64_t* __restrict__ hoff,
                                                         uint64_t n, uint64_t* __restrict__ poff, uint64_t* __restrict__ unitig_off) {
     uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x;
     if (i >= n) return;
     if (hflag[i]) {
-        uint32_t tR = tail[2 * i], tL = tail[2 * i + 1];
+        uint32_t tR = rk[2 * i].y, tL = rk[2 * i + 1].y;
         uint32_t pid = tL < tR ? tL : tR;
         poff[pid] = hoff[i];
         unitig_off[hidx[i]] = hoff[i];
     }
 }
 template <int K>
-__global__ void __launch_bounds__(TB) emit_kernel(const snk_u128* __restrict__ keys, const uint32_t* __restrict__ dist,
-                                                  const uint32_t* __restrict__ tail, const uint8_t* __restrict__ prev,
+__global__ void __launch_bounds__(TB) emit_kernel(const snk_u128* __restrict__ keys, const uint2* __restrict__ rk,
+                                                  const uint8_t* __restrict__ prev,
                                                   const uint64_t* __restrict__ poff, uint64_t n, uint8_t* __restrict__ bases) {
     uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x;
     if (i >= n) return;
-    node_place p = place_of(dist, tail, i);
+    node_place p = place_of(rk, i);
     bool flip = prev[p.pid] != 0;
     uint32_t pos = flip ? p.n - 1u - p.pos : p.pos;
     bool rc = flip ? !p.rc : p.rc;
@@ -375,11 +377,17 @@ __global__ void __launch_bounds__(TB) rank_init_w_kernel(const uint32_t* __restr
     if (l == NONE) { nxt[s] = NONE; dist[s] = 0; tail[s] = (uint32_t)s; }
     else { nxt[s] = l ^ 1u; dist[s] = w[l >> 1]; tail[s] = l ^ 1u; }
 }
+__global__ void __launch_bounds__(TB) rank_zip_kernel(const uint32_t* __restrict__ dist, const uint32_t* __restrict__ tail, uint64_t ns,
+                                                      uint2* __restrict__ rk) {
+    uint64_t s = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (s < ns) rk[s] = make_uint2(dist[s], tail[s]);
+}
+
 // List ranking over the 2n directed states (node, exit side) of a degree<=2 link graph: for every state the
 // number of steps (or summed weights) to the end of its path and the terminal state.  Smooth circles are cut
 // at the left side of their minimum node and ranked again.  link[] is modified by the cut.
 static int rank_lists_wyllie(snk_ctx* ctx, hipStream_t st, uint32_t* link, uint64_t n, const uint32_t* weights, uint8_t* circ /* per state, nullable */,
-                      const uint32_t** dist_out, const uint32_t** tail_out, uint32_t* n_circles, uint32_t* rounds,
+                      const uint2** rk_out, uint32_t* n_circles, uint32_t* rounds,
                       char* err, size_t errcap) {
     const uint64_t ns = 2 * n;
     uint32_t *nxt[2], *dst[2], *tl[2];
@@ -429,8 +437,11 @@ static int rank_lists_wyllie(snk_ctx* ctx, hipStream_t st, uint32_t* link, uint6
     *n_circles = h_flags[1];
     *rounds = rounds_total;
     (void)hipHostFree(h_flags);
-    *dist_out = dst[cur];
-    *tail_out = tl[cur];
+    uint2* rkz;
+    G_ALLOC(rkz, uint2, ns);
+    hipLaunchKernelGGL(rank_zip_kernel, dim3(nblk(ns)), dim3(TB), 0, st, dst[cur], tl[cur], ns, rkz);
+    SNK_HIP_TRY(hipGetLastError());
+    *rk_out = rkz;
     return SNK_OK;
 }
 
@@ -479,15 +490,14 @@ __global__ void __launch_bounds__(TB) spl_walk1_kernel(const uint32_t* __restric
 __global__ void __launch_bounds__(TB) spl_walk2_kernel(const uint32_t* __restrict__ link, const uint8_t* __restrict__ spl,
                                                        const uint32_t* __restrict__ spl_state, const uint32_t* __restrict__ w,
                                                        const uint32_t* __restrict__ rdist, const uint32_t* __restrict__ rtail, uint64_t m,
-                                                       uint32_t* __restrict__ dist, uint32_t* __restrict__ tail) {
+                                                       uint2* __restrict__ rk) {
     uint64_t k = (uint64_t)blockIdx.x * TB + threadIdx.x;
     if (k >= m) return;
     uint32_t cur = spl_state[k];
     uint32_t d = rdist[k];
     const uint32_t t = rtail[k];
     for (;;) {
-        dist[cur] = d;
-        tail[cur] = t;
+        rk[cur] = make_uint2(d, t);
         uint32_t l = link[cur];
         if (l == NONE) break;
         cur = l ^ 1u;
@@ -495,17 +505,17 @@ __global__ void __launch_bounds__(TB) spl_walk2_kernel(const uint32_t* __restric
         d -= w ? w[cur >> 1] : 1u;
     }
 }
-__global__ void __launch_bounds__(TB) unranked_check_kernel(const uint32_t* __restrict__ tail, uint64_t ns, uint32_t* __restrict__ flag) {
+__global__ void __launch_bounds__(TB) unranked_check_kernel(const uint2* __restrict__ rk, uint64_t ns, uint32_t* __restrict__ flag) {
     uint64_t s = (uint64_t)blockIdx.x * TB + threadIdx.x;
-    if (s < ns && tail[s] == NONE) *flag = 1u;
+    if (s < ns && rk[s].y == NONE) *flag = 1u;
 }
 
 static int rank_lists(snk_ctx* ctx, hipStream_t st, uint32_t* link, uint64_t n, const uint32_t* weights, uint8_t* circ /* per state, nullable */,
-                      const uint32_t** dist_out, const uint32_t** tail_out, uint32_t* n_circles, uint32_t* rounds,
+                      const uint2** rk_out, uint32_t* n_circles, uint32_t* rounds,
                       char* err, size_t errcap) {
     const uint64_t ns = 2 * n;
     if (ns < 4096 || snk_env_u32("SNK_RANK_WYLLIE", 0))
-        return rank_lists_wyllie(ctx, st, link, n, weights, circ, dist_out, tail_out, n_circles, rounds, err, errcap);
+        return rank_lists_wyllie(ctx, st, link, n, weights, circ, rk_out, n_circles, rounds, err, errcap);
     uint8_t* spl;
     uint32_t *flag32, *sid;
     G_ALLOC(spl, uint8_t, ns + 1);
@@ -550,20 +560,18 @@ static int rank_lists(snk_ctx* ctx, hipStream_t st, uint32_t* link, uint64_t n, 
         if (h_flag == 0) converged = true;
     }
     if (!converged)      // a circle that contains splitters: let the general algorithm find, cut and rank it
-        return rank_lists_wyllie(ctx, st, link, n, weights, circ, dist_out, tail_out, n_circles, rounds, err, errcap);
-    uint32_t *dist, *tail;
-    G_ALLOC(dist, uint32_t, ns);
-    G_ALLOC(tail, uint32_t, ns);
-    SNK_HIP_TRY(hipMemsetAsync(tail, 0xFF, ns * 4, st));
-    if (m) hipLaunchKernelGGL(spl_walk2_kernel, dim3(nblk(m)), dim3(TB), 0, st, link, spl, spl_state, weights, rd[cur], rt[cur], m, dist, tail);
+        return rank_lists_wyllie(ctx, st, link, n, weights, circ, rk_out, n_circles, rounds, err, errcap);
+    uint2* rk;
+    G_ALLOC(rk, uint2, ns);
+    SNK_HIP_TRY(hipMemsetAsync(rk, 0xFF, ns * 8, st));
+    if (m) hipLaunchKernelGGL(spl_walk2_kernel, dim3(nblk(m)), dim3(TB), 0, st, link, spl, spl_state, weights, rd[cur], rt[cur], m, rk);
     SNK_HIP_TRY(hipMemsetAsync(flags, 0, 4, st));
-    hipLaunchKernelGGL(unranked_check_kernel, dim3(nblk(ns)), dim3(TB), 0, st, tail, ns, flags);
+    hipLaunchKernelGGL(unranked_check_kernel, dim3(nblk(ns)), dim3(TB), 0, st, rk, ns, flags);
     SNK_HIP_TRY(hipMemcpyAsync(&h_flag, flags, 4, hipMemcpyDeviceToHost, st));
     SNK_HIP_TRY(hipStreamSynchronize(st));
     if (h_flag)          // states no walk reached: a circle without a splitter
-        return rank_lists_wyllie(ctx, st, link, n, weights, circ, dist_out, tail_out, n_circles, rounds, err, errcap);
-    *dist_out = dist;
-    *tail_out = tail;
+        return rank_lists_wyllie(ctx, st, link, n, weights, circ, rk_out, n_circles, rounds, err, errcap);
+    *rk_out = rk;
     *n_circles = 0;
     *rounds = r_done;
     return SNK_OK;
@@ -612,17 +620,16 @@ static int graph_impl(snk_ctx* ctx, hipStream_t st, const snk_u128* keys, const 
     hipLaunchKernelGGL((link_kernel<K>), dim3(nblk(ns)), dim3(TB), 0, st, keys, ctx_out, nbr, n, link);
     SNK_HIP_TRY(hipGetLastError());
 
-    const uint32_t* dist = nullptr;
-    const uint32_t* tail = nullptr;
+    const uint2* rk = nullptr;
     {
-        int rc = rank_lists(ctx, st, link, n, nullptr, nullptr, &dist, &tail, &out->n_circles, &out->rank_rounds, err, errcap);
+        int rc = rank_lists(ctx, st, link, n, nullptr, nullptr, &rk, &out->n_circles, &out->rank_rounds, err, errcap);
         if (rc) return rc;
     }
 
     uint8_t* prev;
     G_ALLOC(prev, uint8_t, ns);
     SNK_HIP_TRY(hipMemsetAsync(prev, 0, ns, st));
-    hipLaunchKernelGGL((orient_kernel<K>), dim3(nblk(n)), dim3(TB), 0, st, keys, dist, tail, n, prev);
+    hipLaunchKernelGGL((orient_kernel<K>), dim3(nblk(n)), dim3(TB), 0, st, keys, rk, n, prev);
     uint32_t *hflag, *hidx;
     uint64_t *hlen, *hoff;
     G_ALLOC(hflag, uint32_t, n + 1);
@@ -631,7 +638,7 @@ static int graph_impl(snk_ctx* ctx, hipStream_t st, const snk_u128* keys, const 
     G_ALLOC(hoff, uint64_t, n + 1);
     SNK_HIP_TRY(hipMemsetAsync(hflag + n, 0, 4, st));
     SNK_HIP_TRY(hipMemsetAsync(hlen + n, 0, 8, st));
-    hipLaunchKernelGGL(head_kernel, dim3(nblk(n)), dim3(TB), 0, st, dist, tail, prev, n, (uint32_t)K, hflag, hlen);
+    hipLaunchKernelGGL(head_kernel, dim3(nblk(n)), dim3(TB), 0, st, rk, prev, n, (uint32_t)K, hflag, hlen);
     SNK_HIP_TRY(hipGetLastError());
     {
         size_t t1 = 0, t2 = 0;
@@ -654,9 +661,9 @@ static int graph_impl(snk_ctx* ctx, hipStream_t st, const snk_u128* keys, const 
     G_ALLOC(poff, uint64_t, ns);
     G_ALLOC(uoff, uint64_t, n_unitigs + 1);
     G_ALLOC(bases, uint8_t, total_bases);
-    hipLaunchKernelGGL(head_place_kernel, dim3(nblk(n)), dim3(TB), 0, st, tail, hflag, hidx, hoff, n, poff, uoff);
+    hipLaunchKernelGGL(head_place_kernel, dim3(nblk(n)), dim3(TB), 0, st, rk, hflag, hidx, hoff, n, poff, uoff);
     SNK_HIP_TRY(hipMemcpyAsync(uoff + n_unitigs, hoff + n, 8, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL((emit_kernel<K>), dim3(nblk(n)), dim3(TB), 0, st, keys, dist, tail, prev, poff, n, bases);
+    hipLaunchKernelGGL((emit_kernel<K>), dim3(nblk(n)), dim3(TB), 0, st, keys, rk, prev, poff, n, bases);
     SNK_HIP_TRY(hipGetLastError());
     out->n_unitigs = n_unitigs;
     out->total_bases = total_bases;
@@ -834,14 +841,14 @@ __global__ void __launch_bounds__(TB) link_dist_kernel(const snk_u128* __restric
 }
 
 // per fragment (head node = the node at position 0 walking from terminal pid): k-mer count and the two half links
-__global__ void __launch_bounds__(TB) frag_desc_kernel(const uint32_t* __restrict__ dist, const uint32_t* __restrict__ tail,
+__global__ void __launch_bounds__(TB) frag_desc_kernel(const uint2* __restrict__ rk,
                                                        const uint32_t* __restrict__ hflag, const uint32_t* __restrict__ hidx,
                                                        const unsigned long long* __restrict__ hl_nb_state, uint64_t n,
                                                        unsigned long long my_state_base, uint32_t* __restrict__ nk,
                                                        unsigned long long* __restrict__ hl_self, unsigned long long* __restrict__ hl_nb) {
     uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x;
     if (i >= n || !hflag[i]) return;
-    node_place p = place_of(dist, tail, i);
+    node_place p = place_of(rk, i);
     uint32_t f = hidx[i];
     nk[f] = p.n;
     hl_self[2 * f + 0] = my_state_base + p.pid;
@@ -888,32 +895,33 @@ __global__ void __launch_bounds__(TB) jmatch_kernel(const unsigned long long* __
 }
 
 struct frag_place { uint32_t pid, other; uint64_t N; uint64_t koff; bool rc; };
-__device__ __forceinline__ frag_place frag_place_of(const uint32_t* dist, const uint32_t* tail, const uint32_t* nk, uint64_t f) {
-    uint32_t tL = tail[2 * f], tR = tail[2 * f + 1];
-    uint32_t dL = dist[2 * f], dR = dist[2 * f + 1];
+__device__ __forceinline__ frag_place frag_place_of(const uint2* rk, const uint32_t* nk, uint64_t f) {
+    const uint2 a = rk[2 * f], b = rk[2 * f + 1];
+    uint32_t tL = a.y, tR = b.y;
+    uint32_t dL = a.x, dR = b.x;
     frag_place p;
     p.N = (uint64_t)dL + dR + nk[f];
     if (tL < tR) { p.pid = tL; p.other = tR; p.koff = dL; p.rc = false; }
     else { p.pid = tR; p.other = tL; p.koff = dR; p.rc = true; }
     return p;
 }
-__global__ void __launch_bounds__(TB) jhead_kernel(const uint32_t* __restrict__ dist, const uint32_t* __restrict__ tail,
+__global__ void __launch_bounds__(TB) jhead_kernel(const uint2* __restrict__ rk,
                                                    const uint32_t* __restrict__ nk, uint64_t F, uint32_t K,
                                                    uint32_t* __restrict__ hflag, uint64_t* __restrict__ hlen) {
     uint64_t f = (uint64_t)blockIdx.x * TB + threadIdx.x;
     if (f >= F) return;
-    frag_place p = frag_place_of(dist, tail, nk, f);
+    frag_place p = frag_place_of(rk, nk, f);
     bool head = p.koff == 0 && (p.pid >> 1) == (uint32_t)f;
     hflag[f] = head ? 1u : 0u;
     hlen[f] = head ? p.N + K - 1 : 0ull;
 }
-__global__ void __launch_bounds__(TB) jhead_place_kernel(const uint32_t* __restrict__ tail, const uint32_t* __restrict__ hflag,
+__global__ void __launch_bounds__(TB) jhead_place_kernel(const uint2* __restrict__ rk, const uint32_t* __restrict__ hflag,
                                                          const uint32_t* __restrict__ hidx, const uint64_t* __restrict__ hoff,
                                                          const uint8_t* __restrict__ circ, uint64_t F, uint64_t* __restrict__ poff,
                                                          uint64_t* __restrict__ uoff, uint8_t* __restrict__ ucirc) {
     uint64_t f = (uint64_t)blockIdx.x * TB + threadIdx.x;
     if (f >= F || !hflag[f]) return;
-    uint32_t tL = tail[2 * f], tR = tail[2 * f + 1];
+    uint32_t tL = rk[2 * f].y, tR = rk[2 * f + 1].y;
     uint32_t pid = tL < tR ? tL : tR;
     poff[pid] = hoff[f];
     uoff[hidx[f]] = hoff[f];
@@ -933,7 +941,7 @@ __global__ void __launch_bounds__(TB) jchunk_owner_kernel(const uint32_t* __rest
 // provisional unitig sequences: every fragment copies all of its bases (the K-1 overlaps write equal values)
 __global__ void __launch_bounds__(256) jemit_kernel(const uint32_t* __restrict__ owner, const uint32_t* __restrict__ choff,
                                                     const uint64_t* __restrict__ boff, const uint8_t* __restrict__ fbases,
-                                                    const uint32_t* __restrict__ dist, const uint32_t* __restrict__ tail,
+                                                    const uint2* __restrict__ rk,
                                                     const uint32_t* __restrict__ nk, const uint64_t* __restrict__ poff,
                                                     uint8_t* __restrict__ prov) {
     const uint32_t item = blockIdx.x;
@@ -941,7 +949,7 @@ __global__ void __launch_bounds__(256) jemit_kernel(const uint32_t* __restrict__
     const uint64_t len = boff[f + 1] - boff[f];
     const uint64_t p0 = (uint64_t)(item - choff[f]) * 256 + threadIdx.x;
     if (p0 >= len) return;
-    frag_place p = frag_place_of(dist, tail, nk, f);
+    frag_place p = frag_place_of(rk, nk, f);
     const uint64_t base = poff[p.pid] + p.koff;
     uint8_t b = fbases[boff[f] + p0];
     if (!p.rc) prov[base + p0] = b;
@@ -1095,8 +1103,8 @@ static int dist_fragments_impl(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, 
     G_ALLOC(hl_state, unsigned long long, ns);
     hipLaunchKernelGGL((link_dist_kernel<K>), dim3(nblk(ns)), dim3(TB), 0, st, g->keys, g->ctx, g->pend, g->nbr_local, g->rq_idx, g->rq_meta, n, d_node_off, link, hl_state);
     SNK_HIP_TRY(hipGetLastError());
-    const uint32_t *dist, *tail;
-    int rc = rank_lists(ctx, st, link, n, nullptr, nullptr, &dist, &tail, &out->n_circles, &out->rank_rounds, err, errcap);
+    const uint2* rk;
+    int rc = rank_lists(ctx, st, link, n, nullptr, nullptr, &rk, &out->n_circles, &out->rank_rounds, err, errcap);
     if (rc) return rc;
     uint8_t* prev;
     G_ALLOC(prev, uint8_t, ns);
@@ -1109,7 +1117,7 @@ static int dist_fragments_impl(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, 
     G_ALLOC(hoff, uint64_t, n + 1);
     SNK_HIP_TRY(hipMemsetAsync(hflag + n, 0, 4, st));
     SNK_HIP_TRY(hipMemsetAsync(hlen + n, 0, 8, st));
-    hipLaunchKernelGGL(head_kernel, dim3(nblk(n)), dim3(TB), 0, st, dist, tail, prev, n, (uint32_t)K, hflag, hlen);
+    hipLaunchKernelGGL(head_kernel, dim3(nblk(n)), dim3(TB), 0, st, rk, prev, n, (uint32_t)K, hflag, hlen);
     if ((rc = excl_scan<uint32_t>(ctx, st, hflag, hidx, n + 1, err, errcap))) return rc;
     if ((rc = excl_scan<uint64_t>(ctx, st, hlen, hoff, n + 1, err, errcap))) return rc;
     uint32_t h_nf = 0;
@@ -1124,10 +1132,10 @@ static int dist_fragments_impl(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, 
     G_ALLOC(out->nk, uint32_t, (uint64_t)h_nf + 1);
     G_ALLOC(out->hl_self, unsigned long long, 2ull * h_nf + 2);
     G_ALLOC(out->hl_nb, unsigned long long, 2ull * h_nf + 2);
-    hipLaunchKernelGGL(head_place_kernel, dim3(nblk(n)), dim3(TB), 0, st, tail, hflag, hidx, hoff, n, poff, out->boff);
+    hipLaunchKernelGGL(head_place_kernel, dim3(nblk(n)), dim3(TB), 0, st, rk, hflag, hidx, hoff, n, poff, out->boff);
     SNK_HIP_TRY(hipMemcpyAsync(out->boff + h_nf, hoff + n, 8, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL((emit_kernel<K>), dim3(nblk(n)), dim3(TB), 0, st, g->keys, dist, tail, prev, poff, n, out->bases);
-    hipLaunchKernelGGL(frag_desc_kernel, dim3(nblk(n)), dim3(TB), 0, st, dist, tail, hflag, hidx, hl_state, n, 2ull * my_node_off, out->nk, out->hl_self, out->hl_nb);
+    hipLaunchKernelGGL((emit_kernel<K>), dim3(nblk(n)), dim3(TB), 0, st, g->keys, rk, prev, poff, n, out->bases);
+    hipLaunchKernelGGL(frag_desc_kernel, dim3(nblk(n)), dim3(TB), 0, st, rk, hflag, hidx, hl_state, n, 2ull * my_node_off, out->nk, out->hl_self, out->hl_nb);
     SNK_HIP_TRY(hipGetLastError());
     SNK_HIP_TRY(hipStreamSynchronize(st));
     out->n_frags = h_nf;
@@ -1166,8 +1174,8 @@ int snk_dist_join(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
     uint8_t* circ;     // per fragment-end state: terminal created by cutting a circle
     G_ALLOC(circ, uint8_t, ne + 1);
     SNK_HIP_TRY(hipMemsetAsync(circ, 0, ne + 1, st));
-    const uint32_t *dist, *tail;
-    int rc = rank_lists(ctx, st, flink, F, nk, circ, &dist, &tail, &out->n_circles, &out->rank_rounds, err, errcap);
+    const uint2* rk;
+    int rc = rank_lists(ctx, st, flink, F, nk, circ, &rk, &out->n_circles, &out->rank_rounds, err, errcap);
     if (rc) return rc;
     uint32_t *hflag, *hidx;
     uint64_t *hlen, *hoff;
@@ -1177,7 +1185,7 @@ int snk_dist_join(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
     G_ALLOC(hoff, uint64_t, F + 1);
     SNK_HIP_TRY(hipMemsetAsync(hflag + F, 0, 4, st));
     SNK_HIP_TRY(hipMemsetAsync(hlen + F, 0, 8, st));
-    hipLaunchKernelGGL(jhead_kernel, dim3(nblk(F)), dim3(TB), 0, st, dist, tail, nk, F, K, hflag, hlen);
+    hipLaunchKernelGGL(jhead_kernel, dim3(nblk(F)), dim3(TB), 0, st, rk, nk, F, K, hflag, hlen);
     if ((rc = excl_scan<uint32_t>(ctx, st, hflag, hidx, F + 1, err, errcap))) return rc;
     if ((rc = excl_scan<uint64_t>(ctx, st, hlen, hoff, F + 1, err, errcap))) return rc;
     uint32_t h_nu = 0;
@@ -1194,7 +1202,7 @@ int snk_dist_join(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
     G_ALLOC(urev, uint8_t, U + 1);
     G_ALLOC(prov, uint8_t, h_tot + 1);
     G_ALLOC(final_bases, uint8_t, h_tot + 1);
-    hipLaunchKernelGGL(jhead_place_kernel, dim3(nblk(F)), dim3(TB), 0, st, tail, hflag, hidx, hoff, circ, F, poff, uoff, ucirc);
+    hipLaunchKernelGGL(jhead_place_kernel, dim3(nblk(F)), dim3(TB), 0, st, rk, hflag, hidx, hoff, circ, F, poff, uoff, ucirc);
     SNK_HIP_TRY(hipMemcpyAsync(uoff + U, hoff + F, 8, hipMemcpyDeviceToDevice, st));
     // copy every fragment into place (256-base work items)
     uint32_t *nch, *choff, *owner, total_items = 0;
@@ -1202,7 +1210,7 @@ int snk_dist_join(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
     SNK_HIP_TRY(hipMemsetAsync(nch + F, 0, 4, st));
     hipLaunchKernelGGL(jchunks_kernel, dim3(nblk(F)), dim3(TB), 0, st, boff, F, nch);
     if ((rc = chunk_owners(ctx, st, nch, F, &choff, &owner, &total_items, err, errcap))) return rc;
-    if (total_items) hipLaunchKernelGGL(jemit_kernel, dim3(total_items), dim3(256), 0, st, owner, choff, boff, fbases, dist, tail, nk, poff, prov);
+    if (total_items) hipLaunchKernelGGL(jemit_kernel, dim3(total_items), dim3(256), 0, st, owner, choff, boff, fbases, rk, nk, poff, prov);
     hipLaunchKernelGGL(jform_kernel, dim3(nblk(U)), dim3(TB), 0, st, uoff, U, prov, urev);
     uint32_t *unch, *uchoff, *uowner, utotal = 0;
     G_ALLOC(unch, uint32_t, U + 1);

@@ -14,7 +14,9 @@ size_t snk_msp_lds_bytes(uint32_t K, uint32_t M, uint32_t row_words);
 int snk_launch_msp(uint32_t K, bool scatter, hipStream_t st, const uint32_t* rows, uint32_t row_words,
                    const uint16_t* good_len, const int32_t* bc, int64_t ign_bc_below, uint64_t read_index_base,
                    uint64_t n_reads, uint32_t NB, uint32_t* hist_or_cursor, void* records, unsigned long long* n_inst,
+                   uint16_t* slist /* [SNK_MSP_LCAP][n_reads] or NULL */, uint8_t* scount /* [n_reads] or NULL */,
                    char* err, size_t errcap);
+#define SNK_MSP_LCAP 16
 
 // ---- snk_count.hip
 struct snk_count_args {

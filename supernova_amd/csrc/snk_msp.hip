@@ -74,7 +74,8 @@ __global__ void __launch_bounds__(BD) snk_msp_kernel(const uint32_t* __restrict_
                                                      uint64_t read_index_base, uint64_t n_reads, uint32_t NB,
                                                      uint32_t* __restrict__ hist_or_cursor,
                                                      uint4* __restrict__ records,
-                                                     unsigned long long* __restrict__ n_inst_out) {
+                                                     unsigned long long* __restrict__ n_inst_out,
+                                                     uint16_t* __restrict__ slist, uint8_t* __restrict__ scount) {
     constexpr int W = K - M + 1;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* rowL = smem;                              // [row_words][BD]
@@ -143,7 +144,20 @@ __global__ void __launch_bounds__(BD) snk_msp_kernel(const uint32_t* __restrict_
         }
     };
 
-    const int nblocks = (nk + W - 1) / W;
+    // The histogram pass saves every read's supermer list (minimiser position, first k-mer; <= LCAP entries,
+    // [entry][read] so that a wave's accesses coalesce); the scatter pass replays it instead of scanning again.
+    // A read whose list overflowed is marked 0xFF and its wave falls back to the scan.
+    bool overflowed = false;
+    bool replay = false;
+    if (SCATTER && scount) {
+        uint32_t sc = (r < n_reads) ? scount[r] : 0u;
+        replay = !__any(sc == 0xFFu);
+        if (replay) {
+            cnt = (int)sc;
+            for (int e = 0; e < cnt; ++e) lst[e * BD + tid] = slist[(uint64_t)e * n_reads + r];
+        }
+    }
+    const int nblocks = replay ? 0 : (nk + W - 1) / W;
     int maxblocks = nblocks;
     for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(maxblocks, off); maxblocks = o > maxblocks ? o : maxblocks; }
     for (int b = 0; b < maxblocks; ++b) {
@@ -172,6 +186,7 @@ __global__ void __launch_bounds__(BD) snk_msp_kernel(const uint32_t* __restrict_
                 const int upto = cnt > 0 ? cnt - 1 : 0;
                 const int last_end = cnt > 0 ? (int)(lst[(cnt - 1) * BD + tid] & 0xFFu) - 1 : 0;
                 flush(upto, last_end);
+                overflowed = true;
                 if (cnt > 0) { lst[tid] = lst[(cnt - 1) * BD + tid]; cnt = 1; }
             }
             if (isnew) {
@@ -185,6 +200,10 @@ __global__ void __launch_bounds__(BD) snk_msp_kernel(const uint32_t* __restrict_
                 if (k2 < pfx) { pfx = k2; pfxp = p2; }
             }
         }
+    }
+    if (!SCATTER && scount && r < n_reads) {
+        scount[r] = overflowed ? (uint8_t)0xFF : (uint8_t)cnt;
+        if (!overflowed) for (int e = 0; e < cnt; ++e) slist[(uint64_t)e * n_reads + r] = lst[e * BD + tid];
     }
     flush(cnt, nk - 1);
 
@@ -204,17 +223,18 @@ size_t snk_msp_lds_bytes(uint32_t K, uint32_t M, uint32_t row_words) {
 template <int K, int M>
 static int launch_msp(bool scatter, hipStream_t st, const uint32_t* rows, uint32_t row_words, const uint16_t* good_len,
                       const int32_t* bc, int64_t ign_bc_below, uint64_t read_index_base, uint64_t n_reads, uint32_t NB,
-                      uint32_t* hist_or_cursor, void* records, unsigned long long* n_inst, char* err, size_t errcap) {
+                      uint32_t* hist_or_cursor, void* records, unsigned long long* n_inst, uint16_t* slist, uint8_t* scount,
+                      char* err, size_t errcap) {
     size_t lds = snk_msp_lds_bytes(K, M, row_words);
     unsigned nb = (unsigned)((n_reads + BD - 1) / BD);
     if (scatter) {
         SNK_HIP_TRY(hipFuncSetAttribute((const void*)snk_msp_kernel<K, M, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((snk_msp_kernel<K, M, true>), dim3(nb), dim3(BD), lds, st, rows, row_words, good_len, bc,
-                           ign_bc_below, read_index_base, n_reads, NB, hist_or_cursor, (uint4*)records, n_inst);
+                           ign_bc_below, read_index_base, n_reads, NB, hist_or_cursor, (uint4*)records, n_inst, slist, scount);
     } else {
         SNK_HIP_TRY(hipFuncSetAttribute((const void*)snk_msp_kernel<K, M, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((snk_msp_kernel<K, M, false>), dim3(nb), dim3(BD), lds, st, rows, row_words, good_len, bc,
-                           ign_bc_below, read_index_base, n_reads, NB, hist_or_cursor, (uint4*)records, n_inst);
+                           ign_bc_below, read_index_base, n_reads, NB, hist_or_cursor, (uint4*)records, n_inst, slist, scount);
     }
     SNK_HIP_TRY(hipGetLastError());
     return SNK_OK;
@@ -223,12 +243,12 @@ static int launch_msp(bool scatter, hipStream_t st, const uint32_t* rows, uint32
 int snk_launch_msp(uint32_t K, bool scatter, hipStream_t st, const uint32_t* rows, uint32_t row_words,
                    const uint16_t* good_len, const int32_t* bc, int64_t ign_bc_below, uint64_t read_index_base,
                    uint64_t n_reads, uint32_t NB, uint32_t* hist_or_cursor, void* records, unsigned long long* n_inst,
-                   char* err, size_t errcap) {
+                   uint16_t* slist, uint8_t* scount, char* err, size_t errcap) {
     if (n_reads == 0) return SNK_OK;
     if (row_words > 16) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "reads longer than 256 bases are not supported (row_words=%u)", row_words);
     if (K == 48)
-        return launch_msp<48, SNK_M>(scatter, st, rows, row_words, good_len, bc, ign_bc_below, read_index_base, n_reads, NB, hist_or_cursor, records, n_inst, err, errcap);
+        return launch_msp<48, SNK_M>(scatter, st, rows, row_words, good_len, bc, ign_bc_below, read_index_base, n_reads, NB, hist_or_cursor, records, n_inst, slist, scount, err, errcap);
     if (K == 60)
-        return launch_msp<60, SNK_M>(scatter, st, rows, row_words, good_len, bc, ign_bc_below, read_index_base, n_reads, NB, hist_or_cursor, records, n_inst, err, errcap);
+        return launch_msp<60, SNK_M>(scatter, st, rows, row_words, good_len, bc, ign_bc_below, read_index_base, n_reads, NB, hist_or_cursor, records, n_inst, slist, scount, err, errcap);
     return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "K=%u is not supported (48 or 60)", K);
 }

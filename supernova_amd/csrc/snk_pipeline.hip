@@ -68,7 +68,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     uint32_t NB = p->n_buckets;
     if (NB == 0) {
         uint64_t inst_ub = n_reads * (uint64_t)(in->read_len >= K ? in->read_len - K + 1 : 0);
-        uint32_t target = env_u32("SNK_TARGET_INST", K == 48 ? 4500u : 4000u);
+        uint32_t target = env_u32("SNK_TARGET_INST", K == 48 ? 4000u : 3500u);
         uint64_t nb = (inst_ub + target - 1) / target;
         if (nb < 1) nb = 1;
         if (nb > (1u << 22)) nb = 1u << 22;
@@ -91,10 +91,18 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     SNK_HIP_TRY(hipMemsetAsync(hist, 0, (NB + 1) * 4ull, st));
     SNK_HIP_TRY(hipMemsetAsync(counters, 0, 64, st));
     SNK_HIP_TRY(hipMemsetAsync(status, 0, 64, st));
+    uint16_t* slist = nullptr;
+    uint8_t* scount = nullptr;
+    {
+        void* q;
+        int rc2;
+        if ((rc2 = snk_ctx_alloc(ctx, (size_t)SNK_MSP_LCAP * n_reads * 2 + 64, &q, err, errcap))) return rc2; slist = (uint16_t*)q;
+        if ((rc2 = snk_ctx_alloc(ctx, n_reads + 64, &q, err, errcap))) return rc2; scount = (uint8_t*)q;
+    }
     phase_timer kt(st);   // single-launch timings (events on the launch stream right around the kernel)
     kt.mark();  // 0
     int rc = snk_launch_msp(K, false, st, (const uint32_t*)in->rows, in->row_words, good_len, (const int32_t*)in->bc,
-                            in->ign_bc_below, in->read_index_base, n_reads, NB, hist, nullptr, counters, err, errcap);
+                            in->ign_bc_below, in->read_index_base, n_reads, NB, hist, nullptr, counters, slist, scount, err, errcap);
     if (rc) return rc;
     kt.mark();  // 1
     {
@@ -119,7 +127,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     if ((rc = snk_ctx_alloc(ctx, (size_t)h_nsuper * 32 + 32, &records, err, errcap))) return rc;
     kt.mark();  // 2
     rc = snk_launch_msp(K, true, st, (const uint32_t*)in->rows, in->row_words, good_len, (const int32_t*)in->bc,
-                        in->ign_bc_below, in->read_index_base, n_reads, NB, cursor, records, nullptr, err, errcap);
+                        in->ign_bc_below, in->read_index_base, n_reads, NB, cursor, records, nullptr, slist, scount, err, errcap);
     if (rc) return rc;
     kt.mark();  // 3
     tm.mark();  // 3

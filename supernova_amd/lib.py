@@ -9,8 +9,10 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
+import os as _os
+
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libsnk.so"
+LIB_PATH = Path(_os.environ.get("SNK_LIB_PATH", str(_HERE / "libsnk.so")))   # override = tuning builds (tools/build_variant.sh)
 
 
 class SnkError(RuntimeError):
