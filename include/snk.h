@@ -205,6 +205,67 @@ int snk_shard_join(snk_ctx* ctx, uint32_t K, uint64_t n_frags, const void* d_nk,
                    const void* d_boff, const void* d_bases, uint64_t total_bases, snk_shard_unitigs* out, void* stream,
                    char* err, size_t errcap);
 
+/* ---- host-pointer convenience + graph hand-off -------------- */
+typedef struct snk_reads {
+    uint64_t n_reads;
+    uint32_t read_len;          /* row length in bases (<= 256); per-read lengths in `lens` */
+    uint32_t reserved;
+    const uint8_t* ascii;       /* n_reads*read_len base characters (non-ACGT -> A), or NULL if rows given */
+    const uint32_t* rows;       /* packed rows (row_words = ceil(read_len/16)), or NULL if ascii given */
+    const uint16_t* lens;       /* per-read length or NULL */
+    const uint8_t* quals;       /* n_reads*read_len raw phred (no +33), or NULL if good_len given */
+    const uint16_t* good_len;   /* precomputed trim or NULL */
+    const int32_t* bc;          /* barcode ids or NULL */
+    int64_t ign_bc_below;
+} snk_reads;
+
+typedef struct snk_result {
+    uint64_t n_instances;
+    uint64_t n_kmers;
+    uint32_t* kmers;            /* n_kmers*4 words MSB-first, ascending */
+    uint32_t* counts;
+    uint8_t* ctx;
+    uint64_t n_unitigs;
+    uint64_t* unitig_off;       /* n_unitigs+1 */
+    uint8_t* unitig_bases;      /* base codes; unitigs canonical, ordered by BVComp (len desc, lexicographic;
+                                   lib/assembly/src/paths/long/HBVFromEdges.cc:106-111) */
+    uint64_t* spectrum;         /* spectrum_bins */
+    uint32_t spectrum_bins;
+    uint32_t reserved;
+    float phase_ms[8];
+} snk_result;
+
+/* Replaces buildReadQGraph48(..., pPaths=nullptr) up to the unitigs for host-resident inputs
+ * (BuildReadQGraph48.h:24-34).  Uploads over PCIe, runs snk_dev_count_graph, downloads and orders the result.
+ * Outputs are malloc'ed by the library and released by snk_free. */
+int snk_count_graph(snk_ctx* ctx, const snk_reads* in, const snk_params* p, snk_result* out, char* err, size_t errcap);
+void snk_free(snk_result* r);
+
+/* a13: the unitig hand-off file tada writes and DF reads through MSPEDGES= ("BINWRITE", u64 count, per entry u32
+ * length + ceil(len/4) bytes, base j at bits 2*(j%4)): writer TempGraph::write_to_sn_format
+ * lib/tada/src/debruijn.rs:895-929, reader BuildReadQGraph48.cc:1640-1642. */
+int snk_write_bv(const char* path, uint64_t n_unitigs, const uint64_t* unitig_off, const uint8_t* unitig_bases,
+                 char* err, size_t errcap);
+int snk_read_bv(const char* path, uint64_t* n_unitigs, uint64_t** unitig_off, uint8_t** unitig_bases, char* err,
+                size_t errcap);   /* outputs malloc'ed; free() them */
+
+/* a14: buildHBVFromEdges (lib/assembly/src/paths/long/HBVFromEdges.cc:244-296): vertices = distinct (K-1)-mer
+ * unitig ends, HBV edges = every unitig and its reverse complement (palindromes once), ids assigned by the
+ * reference's deterministic flood fill over the BVComp edge order.  Unitigs must be in BVComp order.
+ * Host-side (the reference's own step is a sequential flood fill; small next to counting). */
+typedef struct snk_hbv {
+    int32_t n_vertices, n_edges;
+    int32_t* v_left;            /* per HBV edge */
+    int32_t* v_right;
+    int32_t* src_unitig;        /* per HBV edge: unitig it is a copy (or reverse complement) of */
+    uint8_t* is_rc;
+    int32_t* fwd_xlat;          /* per unitig: HBV edge id of the forward / reverse-complement copy */
+    int32_t* rev_xlat;
+} snk_hbv;
+int snk_hbv_from_unitigs(uint32_t K, uint64_t n_unitigs, const uint64_t* unitig_off, const uint8_t* unitig_bases,
+                         snk_hbv* out, char* err, size_t errcap);
+void snk_hbv_free(snk_hbv* h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,27 @@ class SnkShardUnitigs(C.Structure):
                 ("rank_rounds", C.c_uint32)]
 
 
+class SnkReads(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("read_len", C.c_uint32), ("reserved", C.c_uint32), ("ascii", C.c_void_p),
+                ("rows", C.c_void_p), ("lens", C.c_void_p), ("quals", C.c_void_p), ("good_len", C.c_void_p),
+                ("bc", C.c_void_p), ("ign_bc_below", C.c_int64)]
+
+
+class SnkResult(C.Structure):
+    _fields_ = [("n_instances", C.c_uint64), ("n_kmers", C.c_uint64), ("kmers", C.POINTER(C.c_uint32)),
+                ("counts", C.POINTER(C.c_uint32)), ("ctx", C.POINTER(C.c_uint8)), ("n_unitigs", C.c_uint64),
+                ("unitig_off", C.POINTER(C.c_uint64)), ("unitig_bases", C.POINTER(C.c_uint8)),
+                ("spectrum", C.POINTER(C.c_uint64)), ("spectrum_bins", C.c_uint32), ("reserved", C.c_uint32),
+                ("phase_ms", C.c_float * 8)]
+
+
+class SnkHbv(C.Structure):
+    _fields_ = [("n_vertices", C.c_int32), ("n_edges", C.c_int32), ("v_left", C.POINTER(C.c_int32)),
+                ("v_right", C.POINTER(C.c_int32)), ("src_unitig", C.POINTER(C.c_int32)),
+                ("is_rc", C.POINTER(C.c_uint8)), ("fwd_xlat", C.POINTER(C.c_int32)),
+                ("rev_xlat", C.POINTER(C.c_int32))]
+
+
 _lib = None
 
 
@@ -121,6 +142,12 @@ def _declare(lib: C.CDLL) -> None:
         "snk_dev_pack_ascii": (C.c_int, [vp, vp, u32, u32, u64, vp, u32, vp]),
         "snk_dev_count_graph": (C.c_int, [vp, P(SnkDevReads), P(SnkParams), P(SnkDevResult), vp, cp, sz]),
         "snk_dev_download": (C.c_int, [vp, vp, vp, sz, vp]),
+        "snk_count_graph": (C.c_int, [vp, P(SnkReads), P(SnkParams), P(SnkResult), cp, sz]),
+        "snk_free": (None, [P(SnkResult)]),
+        "snk_write_bv": (C.c_int, [cp, u64, vp, vp, cp, sz]),
+        "snk_read_bv": (C.c_int, [cp, P(u64), P(P(u64)), P(P(C.c_uint8)), cp, sz]),
+        "snk_hbv_from_unitigs": (C.c_int, [u32, u64, vp, vp, P(SnkHbv), cp, sz]),
+        "snk_hbv_free": (None, [P(SnkHbv)]),
         "snk_shard_hist": (C.c_int, [vp, P(SnkDevReads), P(SnkParams), u32, u32, u32, vp, P(u64), vp, cp, sz]),
         "snk_shard_scatter": (C.c_int, [vp, vp, vp, vp, cp, sz]),
         "snk_shard_count": (C.c_int, [vp, vp, vp, u64, C.c_int, P(u64), vp, cp, sz]),

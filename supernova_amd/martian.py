@@ -1,0 +1,227 @@
+"""Martian stage adapter: the `_ASM_SN` operator surface (lib/tada/mro/_asm_sn.mro:7-33) on one MI355X.
+
+It speaks the exec-stage protocol of the reference's Rust adapter (lib/tada/external/martian/src/lib.rs):
+argv `<exe> martian <stage> <split|main|join> <metadata_path> <files_path> <run_file>` (:142-159), reads
+`_args`/`_outs`/`_chunk_defs`/`_chunk_outs`, writes `_stage_defs`/`_outs`/`_complete`, errors go to `_errors`
+(:568-602), every file it writes is journalled as `<run_file>.<name>` (:181-200), `_log` lines carry the same
+timestamp format (:135-141, 244-251).
+
+Stage ASM_SN_GPU replaces MSP + SHARD_ASM + MAIN_ASM_SN:
+  FASTH parse          lib/tada/src/multifastq.rs:72-126     (9-line records, barcode "SEQ-gemgroup[,raw]")
+  barcode ids          lib/tada/src/utils.rs:101-164          (whitelist index + 1 + (gem_group-1)*N, 0 = not whitelisted)
+  count + graph        libsnk (include/snk.h) -- semantics of path B (SURVEY.md App. A.9 lists where tada differs:
+                       a read trimmed to exactly K bases contributes no k-mer here)
+  asm_graph.bv         lib/tada/src/debruijn.rs:895-929
+"""
+from __future__ import annotations
+
+import datetime
+import gzip
+import json
+import os
+import sys
+import traceback
+from pathlib import Path
+
+import numpy as np
+
+METADATA_PREFIX = "_"
+
+
+# ------------------------------------------------------------------------------------------------ ingest
+class BcIndexer:
+    """lib/tada/src/utils.rs:101-164."""
+
+    def __init__(self, lines):
+        self.bc_map = {}
+        i = 0
+        for l in lines:
+            self.bc_map[l.rstrip("\n")] = i
+            i += 1
+        self.num_bcs = i
+
+    @classmethod
+    def from_file(cls, path):
+        with open(path) as f:
+            return cls(f)
+
+    def get_bc_id(self, bc: str):
+        if "-" in bc:
+            seq, gg = bc.split("-")[:2]
+            idx = self.bc_map.get(seq)
+            g = int(gg)
+        else:
+            idx = self.bc_map.get(bc)
+            g = 1
+        if idx is None:
+            return None
+        return (g - 1) * self.num_bcs + idx + 1
+
+
+def read_fasth(paths, indexer: BcIndexer):
+    """FASTH records -> (ascii u8[n,L], quals u8[n,L] raw phred, lens u16[n], bc i32[n]); R1 = read 2q, R2 = 2q+1
+    (cmd_msp.rs:160-181)."""
+    seqs, quals, bcs = [], [], []
+    for p in paths:
+        with gzip.open(p, "rt") as f:
+            while True:
+                head = f.readline()
+                if not head:
+                    break
+                r1, q1, r2, q2 = (f.readline().rstrip("\n") for _ in range(4))
+                bc = f.readline().rstrip("\n")
+                for _ in range(3):
+                    f.readline()
+                seq = bc.split(",")[0] if "," in bc else bc
+                b = indexer.get_bc_id(seq) or 0
+                seqs += [r1, r2]
+                quals += [q1, q2]
+                bcs += [b, b]
+    n = len(seqs)
+    L = max((len(s) for s in seqs), default=1)
+    asc = np.full((n, L), ord("A"), dtype=np.uint8)
+    qa = np.zeros((n, L), dtype=np.uint8)
+    lens = np.zeros(n, dtype=np.uint16)
+    for i, (s, q) in enumerate(zip(seqs, quals)):
+        lens[i] = len(s)
+        asc[i, :len(s)] = np.frombuffer(s.encode(), dtype=np.uint8)
+        qa[i, :len(q)] = np.frombuffer(q.encode(), dtype=np.uint8) - 33
+    return asc, qa, lens, np.asarray(bcs, dtype=np.int32)
+
+
+# ------------------------------------------------------------------------------------------------ compute
+def count_graph_host(asc, quals, lens, bc, K=48, min_qual=7, min_freq=3, min_bc=2, device=0):
+    """One call of the host-pointer C ABI (snk_count_graph); returns (off u64, bases u8) of the BVComp-ordered unitigs."""
+    import ctypes as C
+    from . import lib as _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    err = C.create_string_buffer(512)
+    rc = lib.snk_ctx_create(device, C.byref(h), err, 512)
+    if rc:
+        raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+    try:
+        asc = np.ascontiguousarray(asc, dtype=np.uint8)
+        quals = np.ascontiguousarray(quals, dtype=np.uint8)
+        lens = np.ascontiguousarray(lens, dtype=np.uint16)
+        bc = np.ascontiguousarray(bc, dtype=np.int32)
+        r = _lib.SnkReads()
+        r.n_reads, r.read_len = asc.shape[0], asc.shape[1]
+        r.ascii, r.quals, r.lens, r.bc = asc.ctypes.data, quals.ctypes.data, lens.ctypes.data, bc.ctypes.data
+        p = _lib.SnkParams()
+        p.K, p.min_qual, p.min_freq, p.min_bc = K, min_qual, min_freq, min_bc
+        out = _lib.SnkResult()
+        rc = lib.snk_count_graph(h, C.byref(r), C.byref(p), C.byref(out), err, 512)
+        if rc:
+            raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+        U = out.n_unitigs
+        off = np.ctypeslib.as_array(out.unitig_off, shape=(U + 1,)).copy()
+        tot = int(off[-1])
+        bases = np.ctypeslib.as_array(out.unitig_bases, shape=(max(tot, 1),))[:tot].copy()
+        stats = dict(n_instances=int(out.n_instances), n_kmers=int(out.n_kmers), n_unitigs=int(U))
+        lib.snk_free(C.byref(out))
+        return off, bases, stats
+    finally:
+        lib.snk_ctx_destroy(h)
+
+
+class AsmSnGpu:
+    """MartianStage (lib/tada/external/martian/src/lib.rs:407-411): split / main / join."""
+    name = "asm_sn_gpu"
+
+    def split(self, args):
+        # one chunk: the whole job fits one MI355X (288 GB); mirrors MAIN_ASM_SN's single chunk (cmd_main_asm.rs:184-193)
+        return {"chunks": [{"__mem_gb": 64, "__threads": 4}]}
+
+    def main(self, args, outs, files_path="."):
+        from . import graphio
+        indexer = BcIndexer.from_file(args["barcode_whitelist"])
+        asc, quals, lens, bc = read_fasth(args["fastqs"], indexer)
+        off, bases, stats = count_graph_host(asc, quals, lens, bc, K=48, min_qual=int(args.get("trim_min_qual", 7)),
+                                             min_freq=int(args.get("min_kmer_obs", 3)), min_bc=2)
+        path = outs.get("asm_graph") or str(Path(files_path) / "asm_graph.bv")
+        graphio.write_bv(path, off, bases)
+        outs = dict(outs)
+        outs["asm_graph"] = path
+        self.stats = stats
+        return outs
+
+    def join(self, args, outs, chunk_defs, chunk_outs):
+        outs = dict(outs)
+        outs["asm_graph"] = chunk_outs[0]["asm_graph"]
+        return outs
+
+
+STAGES = {AsmSnGpu.name: AsmSnGpu}
+
+
+# ------------------------------------------------------------------------------------------------ protocol
+class Metadata:
+    def __init__(self, stage_name, stage_type, metadata_path, files_path, run_file):
+        self.stage_name, self.stage_type = stage_name, stage_type
+        self.metadata_path, self.files_path, self.run_file = metadata_path, files_path, run_file
+        self._journalled = set()
+
+    def path(self, name):
+        return os.path.join(self.metadata_path, METADATA_PREFIX + name)
+
+    def journal(self, name, force=False):
+        jn = name if self.stage_type == "main" else f"{self.stage_type}_{name}"
+        if jn in self._journalled and not force:
+            return
+        rf = f"{self.run_file}.{jn}"
+        with open(rf + ".tmp", "w") as f:
+            f.write(datetime.datetime.now().strftime("%Y-%m-%d %H:%M:%S"))
+        os.replace(rf + ".tmp", rf)
+        self._journalled.add(jn)
+
+    def write_raw(self, name, text):
+        with open(self.path(name), "w") as f:
+            f.write(text)
+        self.journal(name)
+
+    def write_json(self, name, obj):
+        self.write_raw(name, json.dumps(obj, indent=2))
+
+    def read_json(self, name):
+        with open(self.path(name)) as f:
+            return json.load(f)
+
+    def log(self, level, message):
+        with open(self.path("log"), "a") as f:
+            f.write(f"{datetime.datetime.now().strftime('%Y-%m-%d %H:%M:%S')} [{level}] {message}\n")
+        self.journal("log")
+
+    def complete(self):
+        self.write_raw("complete", datetime.datetime.now().strftime("%Y-%m-%d %H:%M:%S"))
+
+
+def martian_main(argv) -> int:
+    """argv = [stage_name, split|main|join, metadata_path, files_path, run_file]"""
+    md = Metadata(*argv[:5])
+    md.log("time", "__start__")
+    try:
+        stage = STAGES[md.stage_name]()
+        if md.stage_type == "split":
+            md.write_json("stage_defs", stage.split(md.read_json("args")))
+        elif md.stage_type == "main":
+            outs = stage.main(md.read_json("args"), md.read_json("outs"), md.files_path)
+            md.write_json("outs", outs)
+        elif md.stage_type == "join":
+            outs = stage.join(md.read_json("args"), md.read_json("outs"), md.read_json("chunk_defs"), md.read_json("chunk_outs"))
+            md.write_json("outs", outs)
+        else:
+            raise ValueError(f"Unrecognized stage type {md.stage_type}")
+        md.complete()
+        return 0
+    except BaseException:  # noqa: BLE001 -- the protocol wants every failure in _errors
+        md.write_raw("errors", traceback.format_exc())
+        return 1
+
+
+if __name__ == "__main__":
+    a = sys.argv[1:]
+    if len(a) >= 6 and a[0] == "martian":
+        sys.exit(martian_main(a[1:]))
+    print("usage: python -m supernova_amd.martian martian <stage> <split|main|join> <metadata_path> <files_path> <run_file>", file=sys.stderr)
+    sys.exit(2)

@@ -1,0 +1,53 @@
+"""Host-side product functions behind the C ABI that need no GPU: the .bv hand-off file and the graph-from-unitigs
+step (buildHBVFromEdges), checked against the reference's golden vectors."""
+import numpy as np
+import pytest
+
+import goldens
+
+
+@pytest.mark.parametrize("name", goldens.CASES)
+def test_hbv_from_unitigs_matches_reference(snk, name):
+    from supernova_amd import graphio
+    c = goldens.load(name)
+    off, bases = graphio.unitigs_to_arrays(c.exp_unitigs)
+    h = graphio.hbv_from_unitigs(48, off, bases)
+    assert graphio.hbv_text(c.exp_unitigs, h) == c.exp_hbv
+
+
+@pytest.mark.parametrize("name", goldens.K60_CASES)
+def test_hbv_k60_matches_reference(snk, name):
+    from supernova_amd import graphio
+    g = goldens.Case60(name)
+    off, bases = graphio.unitigs_to_arrays(g.exp_unitigs)
+    assert graphio.hbv_text(g.exp_unitigs, graphio.hbv_from_unitigs(60, off, bases)) == g.exp_hbv
+
+
+def test_bv_roundtrip_and_layout(snk, tmp_path):
+    """.bv: "BINWRITE", u64 count, per entry u32 length + ceil(len/4) bytes, base j at bits 2*(j%4)
+    (lib/tada/src/debruijn.rs:895-929; round trip as in sim_tests.rs:142-179)."""
+    from supernova_amd import graphio
+    c = goldens.load("adversarial")
+    off, bases = graphio.unitigs_to_arrays(c.exp_unitigs)
+    p = tmp_path / "asm_graph.bv"
+    graphio.write_bv(p, off, bases)
+    raw = p.read_bytes()
+    assert raw[:8] == b"BINWRITE" and int.from_bytes(raw[8:16], "little") == len(c.exp_unitigs)
+    l0 = int.from_bytes(raw[16:20], "little")
+    assert l0 == len(c.exp_unitigs[0])
+    first4 = ["ACGT".index(ch) for ch in c.exp_unitigs[0][:4]]
+    assert raw[20] == first4[0] | first4[1] << 2 | first4[2] << 4 | first4[3] << 6
+    assert len(raw) == 16 + sum(4 + (len(u) + 3) // 4 for u in c.exp_unitigs)
+    off2, bases2 = graphio.read_bv(p)
+    assert np.array_equal(off2, off) and np.array_equal(bases2, bases)
+    # the oracle's independent writer produces the same bytes
+    import ctypes as C
+    import oracle_lib
+    lib = oracle_lib.load()
+    u = oracle_lib.Unitigs()
+    u.n = len(c.exp_unitigs)
+    u.off = off.ctypes.data_as(C.POINTER(C.c_uint64))
+    u.bases = bases.ctypes.data_as(C.POINTER(C.c_uint8))
+    p2 = tmp_path / "oracle.bv"
+    assert lib.sno_write_bv(str(p2).encode(), C.byref(u)) == 0
+    assert p2.read_bytes() == raw
