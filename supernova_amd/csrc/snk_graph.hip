@@ -581,7 +581,18 @@ template <int K>
 static int graph_impl(snk_ctx* ctx, hipStream_t st, const snk_u128* keys, const uint64_t* vals, uint64_t n,
                       uint32_t do_prune, bool want_unitigs, snk_graph_out* out, char* err, size_t errcap) {
     memset(out, 0, sizeof *out);
-    if (n == 0) return SNK_OK;
+    if (n == 0) {      // nothing retained: empty but well-formed outputs
+        constexpr uint32_t NB0 = 65536;
+        G_ALLOC(out->spectrum, unsigned long long, NB0);
+        SNK_HIP_TRY(hipMemsetAsync(out->spectrum, 0, NB0 * 8, st));
+        out->spectrum_bins = NB0;
+        G_ALLOC(out->unitig_off, uint64_t, 2);
+        SNK_HIP_TRY(hipMemsetAsync(out->unitig_off, 0, 16, st));
+        G_ALLOC(out->unitig_bases, uint8_t, 16);
+        G_ALLOC(out->ctx, uint8_t, 16);
+        G_ALLOC(out->counts, uint32_t, 4);
+        return SNK_OK;
+    }
     if (n >= (1ull << 31)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "more than 2^31 retained k-mers on one GPU (%llu)", (unsigned long long)n);
     // index
     uint64_t tg = 1024;

@@ -159,3 +159,99 @@ def test_k60_golden(engine, name):
     assert np.array_equal(np.minimum(res.counts(), (1 << 24) - 1), g.exp_counts)
     assert np.array_equal(res.ctx(), g.exp_ctx)
     assert res.unitigs() == g.exp_unitigs
+
+
+def _random_reads(rng, genome_len, n, L, nbc=20, err=0.002):
+    g = rng.integers(0, 4, genome_len, dtype=np.uint8)
+    codes = np.zeros((n, L), dtype=np.uint8)
+    quals = np.full((n, L), 30, dtype=np.uint8)
+    lens = np.full(n, L, dtype=np.uint16)
+    for i in range(n):
+        ln = L if rng.random() < 0.8 else int(rng.integers(20, L + 1))
+        s = int(rng.integers(0, genome_len - ln + 1))
+        r = g[s:s + ln].copy()
+        if rng.random() < 0.5:
+            r = (3 - r[::-1]).astype(np.uint8)
+        e = rng.random(ln) < err
+        r[e] = (r[e] + 1) & 3
+        quals[i, :ln][e] = 12
+        if rng.random() < 0.1:
+            quals[i, int(rng.integers(0, ln)):ln] = 2
+        codes[i, :ln] = r
+        lens[i] = ln
+    bc = rng.integers(0, nbc + 1, n).astype(np.int32)
+    return codes, quals, lens, bc
+
+
+@pytest.mark.parametrize("L,K", [(250, 48), (256, 60), (49, 48), (61, 60), (100, 48)])
+def test_read_length_extremes_vs_oracle(engine, L, K):
+    """Maximum row length (256 bases = 16 words), reads of exactly K+1 bases (2 k-mers), ragged lengths."""
+    import torch
+    from supernova_amd import synth
+    from supernova_amd.engine import Params
+    rng = np.random.default_rng(1000 + L + K)
+    codes, quals, lens, bc = _random_reads(rng, 3000, 1500 if L > 100 else 6000, L)
+    dev = torch.device("cuda", 0)
+    rows = torch.from_numpy(synth.pack_rows(codes).view(np.int32)).to(dev)
+    res = engine.count_graph(rows, L, quals=torch.from_numpy(quals).to(dev), bc=torch.from_numpy(bc).to(dev),
+                             lens=torch.from_numpy(lens.view(np.int16)).to(dev), params=Params(K=K))
+    gl = oracle_lib.good_lens(quals, lens, K=K)
+    o = oracle_lib.OracleResult(codes, gl, bc, K=K, hbv=False)
+    assert np.array_equal(res.good_len().astype(np.uint32), gl)
+    assert res.n_instances == o.n_instances
+    assert np.array_equal(res.keys(), o.keys)
+    assert np.array_equal(res.counts(), o.counts) and np.array_equal(res.ctx(), o.ctx)
+    assert res.unitigs() == o.unitigs
+
+
+def test_empty_and_degenerate_inputs(engine):
+    """No reads; reads that are all too short / all low quality (no k-mer at all); a single read."""
+    import torch
+    from supernova_amd import synth
+    from supernova_amd.engine import Params
+    dev = torch.device("cuda", 0)
+    L = 150
+    for n, qv in [(0, 30), (64, 2), (1, 30), (300, 30)]:
+        rng = np.random.default_rng(n + qv)
+        codes = rng.integers(0, 4, (n, L), dtype=np.uint8)
+        quals = np.full((n, L), qv, dtype=np.uint8)
+        lens = np.full(n, 40 if n == 300 else L, dtype=np.uint16)      # 300 reads of 40 bases: shorter than K+1
+        rows = torch.from_numpy(synth.pack_rows(codes).view(np.int32).reshape(n, 10)).to(dev)
+        res = engine.count_graph(rows, L, quals=torch.from_numpy(quals).to(dev), bc=None,
+                                 lens=torch.from_numpy(lens.view(np.int16)).to(dev), params=Params(K=48))
+        exp_inst = 103 if (n == 1 and qv == 30) else 0
+        assert res.n_instances == exp_inst
+        assert res.n_kmers == 0 and res.n_unitigs == 0       # a single read never reaches min_freq = 3
+        assert res.keys().shape == (0, 4) and res.unitigs() == []
+
+
+def test_repeatability_and_full_size_properties(engine):
+    """Size-independent properties on a 2 M-read workload (too big for the oracle in the test budget): two runs are
+    bit-identical; keys strictly ascending; every count >= min_freq; sum(len-K+1) over unitigs == retained k-mers;
+    every unitig is in canonical orientation; spectrum sums to the table size."""
+    from supernova_amd import synth
+    from supernova_amd.engine import Params
+    sp = synth.synth_params(2_000_000, seed=0x5EED0777)
+    rows, quals, bc = engine.synth(sp)
+    a = engine.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48))
+    ka, ca, xa, ua = a.keys(), a.counts(), a.ctx(), a.unitig_arrays()
+    b = engine.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48, n_buckets=40009))
+    assert np.array_equal(ka, b.keys()) and np.array_equal(ca, b.counts()) and np.array_equal(xa, b.ctx())
+    ub = b.unitig_arrays()
+    assert np.array_equal(ua[0], ub[0]) and np.array_equal(ua[1], ub[1])
+    k64 = (ka[:, 0].astype(np.uint64) << np.uint64(32)) | ka[:, 1]
+    lo64 = (ka[:, 2].astype(np.uint64) << np.uint64(32)) | ka[:, 3]
+    asc = (k64[1:] > k64[:-1]) | ((k64[1:] == k64[:-1]) & (lo64[1:] > lo64[:-1]))
+    assert asc.all() and ca.min() >= 3
+    off, bases = ua
+    lens = (off[1:] - off[:-1]).astype(np.int64)
+    assert int((lens - 47).sum()) == a.n_kmers
+    assert int(a.spectrum().sum()) == a.n_kmers
+    for i in range(len(lens)):                      # canonical form of every unitig (dna/CanonicalForm.h:35-48)
+        s = bases[int(off[i]):int(off[i + 1])]
+        if len(s) & 1:
+            assert not (s[len(s) // 2] & 2)
+        else:
+            rc = (3 - s[::-1]).astype(np.uint8)
+            j = int(np.argmax(s != rc)) if (s != rc).any() else -1
+            assert j < 0 or s[j] < rc[j]
