@@ -40,7 +40,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=float, default=1e8, help="reads per GPU")
     ap.add_argument("--k", type=int, default=48)
     ap.add_argument("--error-free", action="store_true")

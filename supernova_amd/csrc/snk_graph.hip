@@ -468,40 +468,53 @@ __global__ void __launch_bounds__(TB) spl_collect_kernel(const uint8_t* __restri
     if (s >= ns || !spl[s]) return;
     spl_state[sid[s]] = (uint32_t)s;
 }
-__global__ void __launch_bounds__(TB) spl_walk1_kernel(const uint32_t* __restrict__ link, const uint8_t* __restrict__ spl,
-                                                       const uint32_t* __restrict__ sid, const uint32_t* __restrict__ spl_state,
+// one 8-byte record per state for the walks: link (32) | splitter id (31) | is-splitter (1) -- a walk step is then
+// ONE random HBM transaction instead of two (link[] and spl[]): the walks are transaction bound (PMC: ~128 B
+// fetched per step with separate arrays)
+__global__ void __launch_bounds__(TB) spl_pack_kernel(const uint32_t* __restrict__ link, const uint8_t* __restrict__ spl,
+                                                      const uint32_t* __restrict__ sid, uint64_t ns, unsigned long long* __restrict__ wrec) {
+    uint64_t s = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (s >= ns) return;
+    unsigned long long r = link[s];
+    if (spl[s]) r |= ((unsigned long long)sid[s] << 32) | (1ull << 63);
+    wrec[s] = r;
+}
+__global__ void __launch_bounds__(TB) spl_walk1_kernel(const unsigned long long* __restrict__ wrec, const uint32_t* __restrict__ spl_state,
                                                        const uint32_t* __restrict__ w, uint64_t m, uint32_t* __restrict__ rnxt,
                                                        uint32_t* __restrict__ rdist, uint32_t* __restrict__ rtail) {
     uint64_t k = (uint64_t)blockIdx.x * TB + threadIdx.x;
     if (k >= m) return;
     uint32_t cur = spl_state[k];
+    unsigned long long rec = wrec[cur];
     uint32_t d = 0, nx = NONE;
     for (;;) {
-        uint32_t l = link[cur];
+        uint32_t l = (uint32_t)rec;
         if (l == NONE) { nx = NONE; break; }
         cur = l ^ 1u;
+        rec = wrec[cur];
         d += w ? w[cur >> 1] : 1u;
-        if (spl[cur]) { nx = sid[cur]; break; }
+        if (rec >> 63) { nx = (uint32_t)(rec >> 32) & 0x7FFFFFFFu; break; }
     }
     rnxt[k] = nx;
     rdist[k] = d;
     rtail[k] = cur;        // the terminal state when nx == NONE (overwritten by the jumping otherwise)
 }
-__global__ void __launch_bounds__(TB) spl_walk2_kernel(const uint32_t* __restrict__ link, const uint8_t* __restrict__ spl,
-                                                       const uint32_t* __restrict__ spl_state, const uint32_t* __restrict__ w,
-                                                       const uint32_t* __restrict__ rdist, const uint32_t* __restrict__ rtail, uint64_t m,
-                                                       uint2* __restrict__ rk) {
+__global__ void __launch_bounds__(TB) spl_walk2_kernel(const unsigned long long* __restrict__ wrec, const uint32_t* __restrict__ spl_state,
+                                                       const uint32_t* __restrict__ w, const uint32_t* __restrict__ rdist,
+                                                       const uint32_t* __restrict__ rtail, uint64_t m, uint2* __restrict__ rk) {
     uint64_t k = (uint64_t)blockIdx.x * TB + threadIdx.x;
     if (k >= m) return;
     uint32_t cur = spl_state[k];
+    unsigned long long rec = wrec[cur];
     uint32_t d = rdist[k];
     const uint32_t t = rtail[k];
     for (;;) {
         rk[cur] = make_uint2(d, t);
-        uint32_t l = link[cur];
+        uint32_t l = (uint32_t)rec;
         if (l == NONE) break;
         cur = l ^ 1u;
-        if (spl[cur]) break;
+        rec = wrec[cur];
+        if (rec >> 63) break;
         d -= w ? w[cur >> 1] : 1u;
     }
 }
@@ -539,7 +552,10 @@ static int rank_lists(snk_ctx* ctx, hipStream_t st, uint32_t* link, uint64_t n, 
     if (m) hipLaunchKernelGGL(spl_collect_kernel, dim3(nblk(ns)), dim3(TB), 0, st, spl, sid, ns, spl_state);
     uint32_t *rn[2], *rd[2], *rt[2];
     for (int b = 0; b < 2; ++b) { G_ALLOC(rn[b], uint32_t, m + 1); G_ALLOC(rd[b], uint32_t, m + 1); G_ALLOC(rt[b], uint32_t, m + 1); }
-    if (m) hipLaunchKernelGGL(spl_walk1_kernel, dim3(nblk(m)), dim3(TB), 0, st, link, spl, sid, spl_state, weights, m, rn[0], rd[0], rt[0]);
+    unsigned long long* wrec;
+    G_ALLOC(wrec, unsigned long long, ns);
+    hipLaunchKernelGGL(spl_pack_kernel, dim3(nblk(ns)), dim3(TB), 0, st, link, spl, sid, ns, wrec);
+    if (m) hipLaunchKernelGGL(spl_walk1_kernel, dim3(nblk(m)), dim3(TB), 0, st, wrec, spl_state, weights, m, rn[0], rd[0], rt[0]);
     SNK_HIP_TRY(hipGetLastError());
     // pointer jumping on the splitter list
     uint32_t* flags;
@@ -564,7 +580,7 @@ static int rank_lists(snk_ctx* ctx, hipStream_t st, uint32_t* link, uint64_t n, 
     uint2* rk;
     G_ALLOC(rk, uint2, ns);
     SNK_HIP_TRY(hipMemsetAsync(rk, 0xFF, ns * 8, st));
-    if (m) hipLaunchKernelGGL(spl_walk2_kernel, dim3(nblk(m)), dim3(TB), 0, st, link, spl, spl_state, weights, rd[cur], rt[cur], m, rk);
+    if (m) hipLaunchKernelGGL(spl_walk2_kernel, dim3(nblk(m)), dim3(TB), 0, st, wrec, spl_state, weights, rd[cur], rt[cur], m, rk);
     SNK_HIP_TRY(hipMemsetAsync(flags, 0, 4, st));
     hipLaunchKernelGGL(unranked_check_kernel, dim3(nblk(ns)), dim3(TB), 0, st, rk, ns, flags);
     SNK_HIP_TRY(hipMemcpyAsync(&h_flag, flags, 4, hipMemcpyDeviceToHost, st));
