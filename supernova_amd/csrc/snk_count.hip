@@ -58,7 +58,9 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
     uint32_t* rec = ctxw + SLOTS / 4;                                               // [8][BATCH] staged supermer records
     uint32_t* pre = rec + 8 * BATCH;                                                // [BATCH+1] k-mer prefix sums of the batch
     uint32_t* ctl = pre + BATCH + 4;                                                // [64] control words
-    uint8_t* owner = reinterpret_cast<uint8_t*>(ctl + 64);                          // [BATCH*WMAX] k-mer -> supermer of the batch
+    uint32_t* dd = ctl + 64;                                                        // [2*BATCH] supermer de-duplication table (leader index + 1)
+    uint32_t* wgt = dd + 2 * BATCH;                                                 // [BATCH] copies folded into each leader
+    uint8_t* owner = reinterpret_cast<uint8_t*>(wgt + BATCH);                       // [BATCH*WMAX] k-mer -> supermer of the batch
     // ctl[0] stack pointer, ctl[1] occupied slots, ctl[2] overflow flag, ctl[3] split log2, ctl[4] split id,
     // ctl[5] valid entries of the sub-pass, ctl[6..7] reserved base (lo,hi), ctl[8] placement counter,
     // ctl[9..12] wave totals for the batch scan, ctl[16..16+2*MAX) split stack
@@ -99,8 +101,50 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
                     const uint4 r0 = a.records[idx * 2], r1 = a.records[idx * 2 + 1];
                     rec[0 * BATCH + tid] = r0.x; rec[1 * BATCH + tid] = r0.y; rec[2 * BATCH + tid] = r0.z;
                     rec[3 * BATCH + tid] = r0.w; rec[4 * BATCH + tid] = r1.x; rec[5 * BATCH + tid] = r1.y;
-                    rec[6 * BATCH + tid] = r1.z; rec[7 * BATCH + tid] = r1.w;
+                    rec[6 * BATCH + tid] = r1.z;
+                    // word 7 becomes the barcode STATE of the (possibly merged) supermer: none / id / MULTI / IGN
+                    const int32_t b = (int32_t)r1.w;
+                    rec[7 * BATCH + tid] = b > 0 ? (uint32_t)b : (b == -1 ? BC_IGN : 0u);
                     nkm = r1.z & 0x7Fu;
+                    wgt[tid] = 1;
+                }
+                for (int q = tid; q < 2 * BATCH; q += THREADS) dd[q] = 0;
+                __syncthreads();
+                // ---- fold identical supermers: at 56x coverage ~3 of 4 reads over a locus yield the SAME record (same
+                //      bases, same flanks); only their barcodes differ.  The first one becomes the leader and carries a
+                //      weight and a merged barcode state, the copies insert nothing (2.5x fewer k-mer insertions).
+                if (a.dbg != 4 && tid < BATCH && nkm) {
+                    uint32_t w[7];
+#pragma unroll
+                    for (int q = 0; q < 7; ++q) w[q] = rec[q * BATCH + tid];
+                    uint32_t h = w[0] * 0x9E3779B1u;
+#pragma unroll
+                    for (int q = 1; q < 7; ++q) h = (h ^ w[q]) * 0x85EBCA77u + (h >> 15);
+                    h ^= h >> 13;
+                    uint32_t s = h & (2 * BATCH - 1);
+                    for (;;) {
+                        uint32_t v = LDS_LOAD(&dd[s]);
+                        if (v == 0) {
+                            v = atomicCAS(&dd[s], 0u, (uint32_t)tid + 1u);
+                            if (v == 0) break;                               // I lead this record
+                        }
+                        const uint32_t L = v - 1u;
+                        bool same = true;
+#pragma unroll
+                        for (int q = 0; q < 7; ++q) same &= rec[q * BATCH + L] == w[q];
+                        if (same) {
+                            atomicAdd(&wgt[L], 1u);
+                            const uint32_t mine = rec[7 * BATCH + tid];
+                            if (mine >= BC_MULTI) atomicMax(&rec[7 * BATCH + L], mine);
+                            else if (mine) {
+                                uint32_t ob = atomicCAS(&rec[7 * BATCH + L], 0u, mine);
+                                if (ob != 0 && ob != mine && ob < BC_MULTI) atomicMax(&rec[7 * BATCH + L], BC_MULTI);
+                            }
+                            nkm = 0;
+                            break;
+                        }
+                        s = (s + 1) & (2 * BATCH - 1);
+                    }
                 }
                 uint32_t incl = nkm;
                 for (int o = 1; o < 64; o <<= 1) { uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
@@ -124,7 +168,8 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
                         const uint32_t j = g - pre[i];
                         const uint32_t m6 = rec[6 * BATCH + i];
                         const uint32_t n_i = m6 & 0x7Fu, hasL = (m6 >> 7) & 1u, hasR = (m6 >> 8) & 1u;
-                        const int32_t bc = (int32_t)rec[7 * BATCH + i];
+                        const uint32_t bst = rec[7 * BATCH + i];                  // merged barcode state of the supermer
+                        const uint32_t wt = wgt[i];
                         const uint32_t o = hasL + j;                     // first base of the k-mer inside the record
                         const uint32_t wi = (2u * o) >> 5, sh = (2u * o) & 31u;
                         uint32_t W[5];
@@ -185,12 +230,12 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
                                 slot = (slot + stride) & (SLOTS - 1);
                             }
                             if (found && a.dbg != 2) {
-                                atomicAdd(&cnt[slot], 1u);
+                                atomicAdd(&cnt[slot], wt);
                                 if (ctx) atomicOr(&ctxw[slot >> 2], ctx << (8 * (slot & 3)));
-                                if (bc == -1) atomicMax(&bcs[slot], BC_IGN);
-                                else if (bc > 0) {
-                                    uint32_t ob = atomicCAS(&bcs[slot], 0u, (uint32_t)bc);
-                                    if (ob != 0 && ob != (uint32_t)bc && ob < BC_MULTI) atomicMax(&bcs[slot], BC_MULTI);
+                                if (bst >= BC_MULTI) atomicMax(&bcs[slot], bst);
+                                else if (bst) {
+                                    uint32_t ob = atomicCAS(&bcs[slot], 0u, bst);
+                                    if (ob != 0 && ob != bst && ob < BC_MULTI) atomicMax(&bcs[slot], BC_MULTI);
                                 }
                             }
                         }
@@ -270,7 +315,7 @@ template <> struct cfg<60> { static constexpr int THREADS = SNK_COUNT_THREADS; s
 template <int K>
 size_t lds_bytes() {
     constexpr size_t S = cfg<K>::SLOTS, B = 256;
-    return S * (8 + sizeof(typename lo_t<K>::type) + 4 + 4 + 4) + S + 4 * (8 * B + B + 4 + 64) + B * (K - SNK_M + 1) + 16;
+    return S * (8 + sizeof(typename lo_t<K>::type) + 4 + 4 + 4) + S + 4 * (8 * B + B + 4 + 64 + 2 * B + B) + B * (K - SNK_M + 1) + 16;
 }
 
 template <int K>
