@@ -79,8 +79,11 @@ __global__ void __launch_bounds__(BD) snk_msp_kernel(const uint32_t* __restrict_
     constexpr int W = K - M + 1;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* rowL = smem;                              // [row_words][BD]
-    uint32_t* sfx = rowL + (size_t)row_words * BD;      // [W][BD] suffix minima (ordering key)
-    uint16_t* lst = reinterpret_cast<uint16_t*>(sfx + (size_t)W * BD);   // [LCAP][BD] minimiser position << 8 | first k-mer
+    // Only the POSITION of every suffix minimum is kept in LDS (1 byte per entry); its key is recomputed when the
+    // position changes (a few times per block).  Dropping the 4-byte key column cuts the LDS footprint from 59 KB
+    // to 26 KB per workgroup -> 6 instead of 2 workgroups per CU; the kernel is latency bound (PMC: 22 % VALU
+    // utilisation at 8 waves/CU), so occupancy is what pays.
+    uint16_t* lst = reinterpret_cast<uint16_t*>(rowL + (size_t)row_words * BD);   // [LCAP][BD] minimiser position << 8 | first k-mer
     uint8_t* sfxp = reinterpret_cast<uint8_t*>(lst + (size_t)LCAP * BD);  // [W][BD] position of the suffix minimum
     const int tid = threadIdx.x;
     const uint64_t r0 = (uint64_t)blockIdx.x * BD;
@@ -170,16 +173,18 @@ __global__ void __launch_bounds__(BD) snk_msp_kernel(const uint32_t* __restrict_
                 uint32_t key = mmer_key<M>(rowL, tid, row_words, p);
                 if (key <= run) { run = key; runp = p; }
             }
-            sfx[t * BD + tid] = run;
-            sfxp[t * BD + tid] = (uint8_t)runp;
+            sfxp[t * BD + tid] = (uint8_t)(run == 0xFFFFFFFFu ? 0xFF : runp);     // 0xFF: no valid position in this suffix
         }
         // k-mers of block b: window = suffix of block b from t  U  prefix of block b+1 of length t
         uint32_t pfx = 0xFFFFFFFFu;
         int pfxp = 0;
+        uint32_t sv = 0xFFFFFFFFu;
+        int svp = -1;
         for (int t = 0; t < W; ++t) {
             int i = b * W + t;
-            uint32_t sv = sfx[t * BD + tid];
-            int candp = (sv <= pfx) ? (int)sfxp[t * BD + tid] : pfxp;    // the suffix part lies left of the prefix part
+            const int sp = (int)sfxp[t * BD + tid];
+            if (sp != svp) { svp = sp; sv = sp == 0xFF ? 0xFFFFFFFFu : mmer_key<M>(rowL, tid, row_words, sp); }
+            int candp = (sv <= pfx) ? sp : pfxp;    // the suffix part lies left of the prefix part
             bool isnew = (i < nk) && (candp != curpos);
             if (__any(isnew && cnt == LCAP)) {     // some lane's list is full: every lane of the wave drains its list
                 // the open supermer (last entry) stays; flush() has wave-wide shuffles, so it is called uniformly
@@ -217,7 +222,7 @@ __global__ void __launch_bounds__(BD) snk_msp_kernel(const uint32_t* __restrict_
 }  // namespace
 
 size_t snk_msp_lds_bytes(uint32_t K, uint32_t M, uint32_t row_words) {
-    return (size_t)(row_words + (K - M + 1)) * BD * 4 + (size_t)LCAP * BD * 2 + (size_t)(K - M + 1) * BD + 64;
+    return (size_t)row_words * BD * 4 + (size_t)LCAP * BD * 2 + (size_t)(K - M + 1) * BD + 64;
 }
 
 template <int K, int M>
