@@ -266,6 +266,19 @@ int snk_hbv_from_unitigs(uint32_t K, uint64_t n_unitigs, const uint64_t* unitig_
                          snk_hbv* out, char* err, size_t errcap);
 void snk_hbv_free(snk_hbv* h);
 
+/* ---- stage-input formats of ASSEMBLER_DF (mro/_assembler_stages.mro:24-39) ----------- */
+/* reads.fastb = feudal MasterVec<BaseVec>: 24-byte control block (feudal/FeudalControlBlock.h:157-166), the packed
+ * bases (2 bits, base j at bits 2*(j%4), feudal/FieldVec.h:586-603), (N+1) u64 file offsets, N u32 lengths.
+ * Output: packed rows in libsnk's layout (row_words = ceil(max_len/16)), lengths; malloc'ed, free() them. */
+int snk_read_fastb(const char* path, uint64_t* n_reads, uint32_t* max_len, uint16_t** lens, uint32_t** rows, char* err,
+                   size_t errcap);
+/* reads.qualp = feudal MasterVec<PQVec>: per read a chain of byte-aligned blocks [nQs:8][nBits:3][minQ:6][nQs x nBits]
+ * ended by a 0 byte (feudal/PQVec.cc:86-127).  quals: caller buffer n_reads*qstride (raw phred). */
+int snk_read_qualp(const char* path, uint64_t n_reads, uint32_t qstride, uint8_t* quals, char* err, size_t errcap);
+/* reads.bci = BINWRITE vec<int64_t>: bci[b]..bci[b+1] = read range of barcode ordinal b, b = 0 unbarcoded
+ * (10X/ParseBarcodedFastqs.cc:284-293); expanded to one barcode id per read as DF does (10X/DF.cc:464-469). */
+int snk_read_bci(const char* path, uint64_t n_reads, int32_t* bc_per_read, uint64_t* n_barcodes, char* err, size_t errcap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -130,6 +130,26 @@ int main(int argc, char** argv) {
     if (in.has_bc) bc.assign(in.bc.begin(), in.bc.end());
     vec<int32_t> const* bcp = in.has_bc ? &bc : nullptr;
 
+    if (mode == "formats") {
+        // the stage-input files of ASSEMBLER_DF written by the reference's own writers (data fixtures for the
+        // product's format readers): <out>/reads.fastb (MasterVec<BaseVec>), reads.qualp (VecPQVec), reads.bci
+        // (BINWRITE vec<int64_t>: read range of every barcode ordinal, 10X/ParseBarcodedFastqs.cc:284-293)
+        reads.WriteAll(work + "/reads.fastb");
+        quals.newFile(work + "/reads.qualp");
+        quals.store();
+        vec<int64_t> bci;
+        int32_t maxbc = 0;
+        for (uint64_t r = 0; r < in.n; ++r) maxbc = std::max(maxbc, in.bc[r]);
+        bci.resize(maxbc + 2, 0);
+        for (uint64_t r = 0; r < in.n; ++r) {
+            if (r && in.bc[r] < in.bc[r - 1]) die("formats mode needs reads sorted by barcode");
+            bci[in.bc[r] + 1]++;
+        }
+        for (size_t b = 1; b < bci.size(); ++b) bci[b] += bci[b - 1];
+        BinaryWriter::writeFile(work + "/reads.bci", bci);
+        printf("SNREF_FORMATS reads=%lu barcodes=%d\n", (unsigned long)in.n, maxbc);
+        return 0;
+    }
     if (mode == "time") {
         // whole reference path (count + unitigs + HBV, no read pathing), timed as the CPU baseline
         HyperBasevector hbv;

@@ -1,0 +1,137 @@
+"""ASSEMBLER_DF stage adapter (mro/_assembler_stages.mro:24-39) with the graph built on the MI355X.
+
+Mirror of the reference's stage code mro/stages/denovo/df/__init__.py (Python 2; not importable here):
+  split   :8-12     one chunk; the reference reserves 2048 GB / 28 threads for the CPU dictionary -- the GPU path
+                    needs host memory only for the stage inputs
+  main    :81-173   filename-head check (:84-88), DF argv (:123-139), exit-code -> message mapping (:63-79),
+                    *.mm files moved into stats/ (:172-173)
+  join    :14-15
+What changes: when `mspedges` is not supplied by an upstream `_ASM_SN`, this stage computes the unitigs itself
+(reads.fastb/.qualp/.bci -> libsnk -> asm_graph.bv) and hands them to the stock `DF` binary through `MSPEDGES=`
+(10X/DF.cc:86-207, RunStages.cc:404-413): DF then skips createDict/buildEdges and continues with
+buildGraphFromMSP -> read pathing -> ... unchanged.
+"""
+from __future__ import annotations
+
+import glob
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+
+def split(args):
+    return {"chunks": [{"__mem_gb": 256, "__threads": 28, "__special": "asmlarge"}]}
+
+
+def join(args, outs, chunk_defs, chunk_outs):
+    shutil.move(chunk_outs[0]["default"], outs["default"])
+
+
+def check_exclude(path: str, ext: str) -> str:
+    head, tail = path[:-len(ext)], path[-len(ext):]
+    if tail != ext:
+        raise Exception("file has incorrect extension: " + path)
+    return head
+
+
+def process_return_code(returncode: int):
+    msg = None
+    if returncode < 0:
+        sig = {-9: "KILL signal", -1: "HUP signal", -2: "INT signal", -15: "TERM signal"}.get(returncode, "signal")
+        msg = ("A Supernova process was terminated with a %s (code: %d). This may have been sent by you, your IT admin, "
+               "or automatically by the system itself (e.g. the out-of-memory killer)." % (sig, -returncode))
+    elif returncode == 99:
+        msg = ("Supernova terminated because of insufficient memory. The stage _stdout file may contain additional "
+               "useful information, e.g., whether any competing processes were running.")
+    return msg
+
+
+def build_df_command(args: dict, out_dir: str, mspedges: str | None) -> list[str]:
+    """The argv of df/__init__.py:123-139 (select_frac is pinned to 1.0 there, :121)."""
+    cmd = ["DF", "LR_SELECT_FRAC={:.8f}".format(1.0), "LR=" + args["reads"], "OUT_DIR=" + out_dir,
+           "MAX_MEM_GB=" + str(args.get("__mem_gb")), "NUM_THREADS=" + str(args.get("__threads"))]
+    if mspedges is not None:
+        cmd.append("MSPEDGES={}".format(mspedges))
+    if args.get("pipeline_id") is not None:
+        cmd.append("PIPELINE={}".format(args["pipeline_id"]))
+    if args.get("known_sample_id") is not None:
+        cmd.append("SAMPLE={}".format(args["known_sample_id"]))
+    if args.get("addin") is not None and "DF" in args["addin"]:
+        cmd.extend(args["addin"]["DF"].split())
+    if args.get("nodebugmem") is None or not args["nodebugmem"]:
+        cmd.append("TRACK_SOME_MEMORY=True")
+    return cmd
+
+
+def load_stage_inputs(reads: str, quals: str, bci: str):
+    """fastb/qualp/bci -> (rows, lens, quals, bc, read_len); bc = barcode ordinal per read (10X/DF.cc:464-469)."""
+    from . import formats
+    rows, lens, mx = formats.read_fastb(reads)
+    n = rows.shape[0]
+    q = formats.read_qualp(quals, n, max(mx, 1))
+    bc, _ = formats.read_bci(bci, n)
+    return rows, lens, q, bc, mx
+
+
+def compute_mspedges(args: dict, out_dir: str, device: int = 0, bc_start: int = 0) -> str:
+    """Unitigs of the stage inputs on the GPU -> <out_dir>/asm_graph.bv (what _ASM_SN.asm_graph would have supplied)."""
+    import ctypes as C
+    from . import graphio, lib as _lib
+    rows, lens, q, bc, mx = load_stage_inputs(args["reads"], args["quals"], args["bci"])
+    lib = _lib.load()
+    h = C.c_void_p()
+    err = C.create_string_buffer(512)
+    rc = lib.snk_ctx_create(device, C.byref(h), err, 512)
+    if rc:
+        raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+    try:
+        r = _lib.SnkReads()
+        rows = np.ascontiguousarray(rows)
+        r.n_reads, r.read_len = rows.shape[0], max(mx, 1)
+        r.rows, r.lens, r.quals, r.bc = rows.ctypes.data, lens.ctypes.data, q.ctypes.data, bc.ctypes.data
+        r.ign_bc_below = bc_start                      # "barcoded datatypes start at" (RunStages.cc:398, DF.cc:358-363)
+        p = _lib.SnkParams()
+        p.K, p.min_qual, p.min_freq, p.min_bc = 48, 7, 3, 2     # CS-build constants, 10X/DF.cc:138-141
+        out = _lib.SnkResult()
+        rc = lib.snk_count_graph(h, C.byref(r), C.byref(p), C.byref(out), err, 512)
+        if rc:
+            raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+        U = out.n_unitigs
+        off = np.ctypeslib.as_array(out.unitig_off, shape=(U + 1,)).copy()
+        tot = int(off[-1])
+        bases = np.ctypeslib.as_array(out.unitig_bases, shape=(max(tot, 1),))[:tot].copy()
+        lib.snk_free(C.byref(out))
+    finally:
+        lib.snk_ctx_destroy(h)
+    os.makedirs(out_dir, exist_ok=True)
+    path = str(Path(out_dir) / "asm_graph.bv")
+    graphio.write_bv(path, off, bases)
+    return path
+
+
+def main(args: dict, outs: dict, run_df: bool = True):
+    h1 = check_exclude(args["reads"], ".fastb")
+    h2 = check_exclude(args["quals"], ".qualp")
+    h3 = check_exclude(args["bci"], ".bci")
+    if h1 != h2 or h2 != h3:
+        raise Exception("something wrong with filenames passed in")
+    out_dir = outs["default"]
+    mspedges = args.get("mspedges")
+    if mspedges is None:
+        mspedges = compute_mspedges(args, out_dir)
+    cmd = build_df_command(args, out_dir, mspedges)
+    print(" ".join(cmd))
+    if run_df:
+        df_bin = os.environ.get("SNK_DF_BIN") or shutil.which("DF")
+        if df_bin is None:
+            raise RuntimeError("the stock DF binary is not on PATH (set SNK_DF_BIN); unitigs are in " + mspedges)
+        try:
+            subprocess.check_call([df_bin] + cmd[1:])
+        except subprocess.CalledProcessError as e:
+            raise RuntimeError(process_return_code(e.returncode) or f"DF failed with exit code {e.returncode}")
+        for f in glob.glob("*.mm"):
+            shutil.move(f, os.path.join(out_dir, "stats"))
+    return cmd

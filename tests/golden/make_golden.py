@@ -180,6 +180,26 @@ def make(name: str) -> None:
 
 GOLD = Path(__file__).resolve().parent
 
+
+def make_formats() -> None:
+    """tests/golden/formats/: the ASSEMBLER_DF stage inputs (reads.fastb / reads.qualp / reads.bci) of the
+    synth_2k_err reads sorted by barcode, written by the REFERENCE's own writers (vecbvec::WriteAll,
+    ObjectManager<VecPQVec>::store, BinaryWriter::writeFile) through `snref_driver ... formats`."""
+    import shutil
+    case = CASES["synth_2k_err"]()
+    order = np.argsort(case["bc"], kind="stable")
+    out = GOLD / "formats"
+    out.mkdir(exist_ok=True)
+    with tempfile.TemporaryDirectory() as td:
+        td = Path(td)
+        refio.write_snkrd(td / "in.snkrd", case["lens"][order], case["ascii"][order], case["quals"][order], case["bc"][order])
+        print(refio.run_ref(td / "in.snkrd", td / "out", mode="formats").splitlines()[-1])
+        for f in ("reads.fastb", "reads.qualp", "reads.bci"):
+            shutil.copy(td / "out" / f, out / f)
+    np.save(out / "order.npy", order.astype(np.int32))
+
+
 if __name__ == "__main__":
-    for nm in (sys.argv[1:] or list(CASES)):
-        make(nm)
+    names = sys.argv[1:] or list(CASES) + ["formats"]
+    for nm in names:
+        make_formats() if nm == "formats" else make(nm)
