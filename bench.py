@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=float, default=1e6, help="reads of the workload timed on the host cores")
     ap.add_argument("--sharded", action="store_true", help="force the sharded (multi-GPU) code path even with one rank")
+    ap.add_argument("--unsorted-table", action="store_true", help="leave the retained table in bucket order (SNK_F_UNSORTED_TABLE)")
+    ap.add_argument("--global-graph", action="store_true", help="global graph stage instead of the bucket-local one")
     return ap.parse_args()
 
 
@@ -113,7 +115,7 @@ def main():
     sp = synth.synth_params(total_reads, seed=0x5EED0000 + (1 if world == 1 else 2), error_free=args.error_free)
     rows, quals, bc = eng.synth(sp, first=rank * per_gpu, n=per_gpu)
     torch.cuda.synchronize()
-    params = Params(K=K)
+    params = Params(K=K, sorted_table=not args.unsorted_table, global_graph=args.global_graph)
 
     if not use_dist:
         def step():
@@ -179,7 +181,10 @@ def main():
                                    f"k={K}, {'1xMI355X count+graph' if world == 1 else f'{world}xMI355X minimiser-sharded all-to-all'}",
                        "reads_per_gpu": per_gpu, "k": K, "kmer_instances": int(inst_total),
                        "retained_kmers_rank0": int(res.n_kmers), "unitigs_rank0": int(res.n_unitigs),
-                       "phase_ms_rank0": {k: round(v, 3) for k, v in res.phase_ms.items()}},
+                       "phase_ms_rank0": {k: round(v, 3) for k, v in res.phase_ms.items()},
+                       "graph_ms_rank0": {k: round(v, 3) for k, v in getattr(res, "graph_ms", {}).items()},
+                       "table_order": "bucket" if args.unsorted_table else "key",
+                       "fragments_rank0": int(getattr(res, "n_fragments", 0))},
             "roofline": {"bound": "hbm", "kernel": "snk_count_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launch_ms": count_ms, "units_per_launch": units, "alg_bytes_per_unit": ALG_BYTES_PER_KMER[K]},

@@ -56,6 +56,10 @@ typedef struct snk_params {
     uint32_t flags;        /* SNK_F_* */
 } snk_params;
 #define SNK_F_NO_GRAPH 1u      /* stop after the retained k-mer table (count only) */
+#define SNK_F_UNSORTED_TABLE 2u /* leave the retained table in bucket order (the reference's dictionary is an unordered
+                                  hash set, kmers/ReadPather.h:189-245); default: keys ascending */
+#define SNK_F_GLOBAL_GRAPH 4u   /* use the global graph stage (sort + HBM index + list ranking over all k-mers) instead
+                                  of the bucket-local one; same results, kept as a cross-check */
 
 const char* snk_version(void);
 const char* snk_last_error(void);
@@ -126,7 +130,7 @@ typedef struct snk_dev_result {
     const void* good_len;        /* u16[n_reads] */
     uint64_t n_kmers;            /* retained canonical k-mers */
     const void* keys;            /* n_kmers x 16 bytes: little-endian 128-bit value = {u64 lo, u64 hi}; base i of the
-                                    k-mer at bits 127-2i..126-2i; ascending */
+                                    k-mer at bits 127-2i..126-2i; ascending unless SNK_F_UNSORTED_TABLE */
     const void* counts;          /* u32[n_kmers] */
     const void* ctx;             /* u8[n_kmers] pruned context bytes */
     const void* spectrum;        /* u64[spectrum_bins]: retained k-mers per count (histogram_kmer_count.json) */
@@ -135,7 +139,7 @@ typedef struct snk_dev_result {
     uint64_t n_unitigs;
     uint64_t unitig_total_bases;
     const void* unitig_off;      /* u64[n_unitigs+1] */
-    const void* unitig_bases;    /* u8 base codes, canonical orientation, unitigs ordered by their head k-mer */
+    const void* unitig_bases;    /* u8 base codes, canonical orientation, unitigs ordered by their first K bases */
     uint32_t rank_rounds;
     uint32_t buckets_split;
     uint32_t max_slots_used;
@@ -143,6 +147,9 @@ typedef struct snk_dev_result {
     uint64_t scratch_bytes;
     float phase_ms[8];           /* trim, msp histogram, msp scatter, count, sort, prune+unitigs, -, total */
     float kernel_ms[4];          /* HIP-event time of single launches: msp histogram, msp scatter, count (LDS reduce), - */
+    uint64_t n_boundary;         /* bucket-local graph: k-mers with a neighbour outside their bucket chunk */
+    uint64_t n_fragments;        /* bucket-local graph: local unitig fragments joined at the end */
+    float graph_ms[8];           /* bucket-local graph: local prune, boundary resolve, fragments, join, table sort+spectrum */
 } snk_dev_result;
 
 /* Replaces the body of buildReadQGraph48 (BuildReadQGraph48.cc:1688-1774, pPaths==nullptr) up to and

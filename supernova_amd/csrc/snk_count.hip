@@ -290,6 +290,14 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
             const uint64_t rbase = ((uint64_t)LDS_LOAD(&ctl[7]) << 32) | LDS_LOAD(&ctl[6]);
             if (rbase + nvalid <= a.region_cap) {
                 const uint64_t gbase = (uint64_t)region * a.region_cap + rbase;
+                // chunk descriptor for the bucket-local graph stage: the survivors of one sub-pass are contiguous
+                if (tid == 0 && a.chunk_n) {
+                    if (split_lg == 0) { a.chunk_n[bucket] = nvalid; a.chunk_base[bucket] = (uint32_t)rbase; }
+                    else {
+                        const uint32_t e = atomicAdd(&a.status[4], 1u);
+                        if (e < a.extra_cap) a.extra[e] = make_uint4(bucket, (uint32_t)rbase, nvalid, (split_lg << 24) | split_id);
+                    }
+                }
                 for (int s = tid; s < SLOTS; s += THREADS) {
                     const uint32_t c = cnt[s];
                     if (c) {

@@ -14,6 +14,8 @@ struct snk_graph_out {
     uint8_t* unitig_bases;        // base codes, canonical orientation, ordered by head k-mer
     uint32_t n_circles;
     uint32_t rank_rounds;
+    uint64_t n_boundary;          // bucket-local path: k-mers with a neighbour outside their chunk
+    uint64_t n_fragments;         // bucket-local path: local unitig fragments handed to the join
 };
 
 int snk_graph_sort(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t n, snk_u128* keys_in, uint64_t* vals_in,
@@ -53,8 +55,8 @@ struct snk_join_out {
     uint64_t n_unitigs, total_bases;
     uint64_t* unitig_off;
     uint8_t* unitig_bases;
-    uint8_t* unitig_circular;   // 1: a circle that spans ranks, cut at an arbitrary k-mer (host rotates it)
-    uint32_t n_circles, rank_rounds;
+    uint8_t* unitig_circular;   // 1: a circle that spanned fragments (already rotated to the reference's cut)
+    uint32_t n_circles, rank_rounds, n_circles_rotated;
 };
 int snk_dist_prune_plan(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, char* err, size_t errcap);
 int snk_dist_fill_queries(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, const unsigned long long* d_qoff, void* d_qbuf,
@@ -68,3 +70,9 @@ int snk_dist_fragments(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, const un
 int snk_dist_join(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const uint32_t* nk, const unsigned long long* hl_self,
                   const unsigned long long* hl_nb, const uint64_t* boff, const uint8_t* fbases, uint64_t total_fbases,
                   snk_join_out* out, char* err, size_t errcap);
+
+// ---- bucket-local graph stage (snk_local.hip): table in chunk order -> pruned contexts + canonical unitigs
+struct snk_table;
+int snk_local_graph(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_table* tab, uint32_t do_prune, bool want_unitigs,
+                    bool sort_table, snk_graph_out* out, snk_u128** keys_final, float* ms /* [5] or NULL */, char* err, size_t errcap);
+int snk_launch_spectrum(hipStream_t st, const uint32_t* counts, uint64_t n, unsigned long long* bins, uint32_t nbins);

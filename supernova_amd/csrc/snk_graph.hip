@@ -960,6 +960,12 @@ __global__ void __launch_bounds__(TB) jchunks_kernel(const uint64_t* __restrict_
     if (f >= F) return;
     nch[f] = (uint32_t)((boff[f + 1] - boff[f] + 255) / 256);
 }
+// fragments: length = k-mers + K - 1 (their start offsets need not be contiguous)
+__global__ void __launch_bounds__(TB) jchunks_nk_kernel(const uint32_t* __restrict__ nk, uint32_t K, uint64_t F, uint32_t* __restrict__ nch) {
+    uint64_t f = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (f >= F) return;
+    nch[f] = (nk[f] + K - 1 + 255) / 256;
+}
 __global__ void __launch_bounds__(TB) jchunk_owner_kernel(const uint32_t* __restrict__ choff, uint64_t F, uint32_t* __restrict__ owner) {
     uint64_t f = (uint64_t)blockIdx.x * TB + threadIdx.x;
     if (f >= F) return;
@@ -970,10 +976,10 @@ __global__ void __launch_bounds__(256) jemit_kernel(const uint32_t* __restrict__
                                                     const uint64_t* __restrict__ boff, const uint8_t* __restrict__ fbases,
                                                     const uint2* __restrict__ rk,
                                                     const uint32_t* __restrict__ nk, const uint64_t* __restrict__ poff,
-                                                    uint8_t* __restrict__ prov) {
+                                                    uint32_t K, uint8_t* __restrict__ prov) {
     const uint32_t item = blockIdx.x;
     const uint32_t f = owner[item];
-    const uint64_t len = boff[f + 1] - boff[f];
+    const uint64_t len = (uint64_t)nk[f] + K - 1;
     const uint64_t p0 = (uint64_t)(item - choff[f]) * 256 + threadIdx.x;
     if (p0 >= len) return;
     frag_place p = frag_place_of(rk, nk, f);
@@ -1010,6 +1016,101 @@ __global__ void __launch_bounds__(TB) jfinal_kernel(const uint64_t* __restrict__
     if (p0 >= len) return;
     const uint64_t o = uoff[u];
     out[o + p0] = urev[u] ? (uint8_t)(prov[o + len - 1 - p0] ^ 3u) : prov[o + p0];
+}
+
+__global__ void __launch_bounds__(TB) jcirc_list_kernel(const uint8_t* __restrict__ ucirc, uint64_t U, uint32_t* __restrict__ clist,
+                                                        uint32_t* __restrict__ cnt) {
+    uint64_t u = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (u < U && ucirc[u]) clist[atomicAdd(cnt, 1u)] = (uint32_t)u;
+}
+// One workgroup per circular unitig.  prov holds the closed sequence (N k-mers, N+K-1 bases, the last K-1 repeat the
+// first K-1) cut at an arbitrary k-mer.  Reference form (canonicalizeCircle, BuildReadQGraph48.cc:375-397): the circle
+// starts at its minimum canonical k-mer read forward.  Candidates: the k-mer at ring position j on strand 0, and its
+// reverse complement, which sits at position (N-K-j) mod N of the reverse-complemented ring.
+template <int K>
+__global__ void __launch_bounds__(256) jcircle_kernel(const uint32_t* __restrict__ clist, const uint64_t* __restrict__ uoff,
+                                                      uint8_t* __restrict__ prov, uint8_t* __restrict__ tmp) {
+    __shared__ uint64_t bhi[256], blo[256];
+    __shared__ uint32_t bpos[256];      // rotation << 1 | strand
+    __shared__ uint32_t win;
+    const uint32_t u = clist[blockIdx.x];
+    const uint64_t o = uoff[u];
+    const uint64_t len = uoff[u + 1] - o;
+    const uint64_t N = len - (K - 1);
+    uint8_t* ring = prov + o;
+    const int tid = threadIdx.x;
+    const uint64_t seg = (N + 255) / 256;
+    const uint64_t a = (uint64_t)tid * seg, b = a + seg < N ? a + seg : N;
+    snk_kmer best;
+    best.hi = ~0ull; best.lo = ~0ull;
+    uint32_t bp = 0xFFFFFFFFu;
+    if (a < N) {
+        snk_kmer f;
+        f.hi = 0; f.lo = 0;
+        for (int q = 0; q < K; ++q) f = snk_kmer_succ<K>(f, ring[a + q]);
+        for (uint64_t j = a; j < b; ++j) {
+            if (j > a) f = snk_kmer_succ<K>(f, ring[j + K - 1]);
+            const snk_kmer r = snk_kmer_rc<K>(f);
+            const uint32_t p0 = (uint32_t)j << 1;
+            const uint32_t p1 = (uint32_t)((N - (K + j) % N) % N) << 1 | 1u;
+            if (snk_kmer_lt(f, best) || (snk_kmer_eq(f, best) && p0 < bp)) { best = f; bp = p0; }
+            if (snk_kmer_lt(r, best) || (snk_kmer_eq(r, best) && p1 < bp)) { best = r; bp = p1; }
+        }
+    }
+    bhi[tid] = best.hi; blo[tid] = best.lo; bpos[tid] = bp;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t w = 0;
+        for (int t = 1; t < 256; ++t) {
+            const bool lt = bhi[t] < bhi[w] || (bhi[t] == bhi[w] && (blo[t] < blo[w] || (blo[t] == blo[w] && bpos[t] < bpos[w])));
+            if (lt) w = t;
+        }
+        win = bpos[w];
+    }
+    __syncthreads();
+    const uint64_t i = win >> 1;
+    const bool strand = win & 1u;
+    uint8_t* t = tmp + o;
+    for (uint64_t p = tid; p < len; p += 256) {
+        if (!strand) t[p] = ring[(i + p) % N];
+        else t[p] = (uint8_t)(ring[(2 * N - 1 - (i + p) % N) % N] ^ 3u);
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (uint64_t p = tid; p < len; p += 256) ring[p] = t[p];
+}
+
+// deterministic output order: unitigs sorted by their first K bases (every k-mer belongs to exactly one unitig)
+template <int K>
+__global__ void __launch_bounds__(TB) jorder_key_kernel(const uint64_t* __restrict__ uoff, const uint8_t* __restrict__ bases, uint64_t U,
+                                                        snk_u128* __restrict__ key, uint32_t* __restrict__ idx) {
+    uint64_t u = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (u >= U) return;
+    const uint8_t* b = bases + uoff[u];
+    snk_kmer f;
+    f.hi = 0; f.lo = 0;
+    for (int q = 0; q < K; ++q) f = snk_kmer_succ<K>(f, b[q]);
+    key[u] = ((snk_u128)f.hi << 64) | (snk_u128)f.lo;
+    idx[u] = (uint32_t)u;
+}
+__global__ void __launch_bounds__(TB) jorder_len_kernel(const uint64_t* __restrict__ uoff, const uint32_t* __restrict__ idx, uint64_t U,
+                                                        uint64_t* __restrict__ len) {
+    uint64_t r = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (r > U) return;
+    len[r] = r < U ? uoff[idx[r] + 1] - uoff[idx[r]] : 0ull;
+}
+__global__ void __launch_bounds__(256) jorder_copy_kernel(const uint32_t* __restrict__ owner, const uint32_t* __restrict__ choff,
+                                                          const uint64_t* __restrict__ noff, const uint64_t* __restrict__ uoff,
+                                                          const uint32_t* __restrict__ idx, const uint8_t* __restrict__ in,
+                                                          const uint8_t* __restrict__ circ_in, uint8_t* __restrict__ out,
+                                                          uint8_t* __restrict__ circ_out) {
+    const uint32_t item = blockIdx.x;
+    const uint32_t r = owner[item];
+    const uint64_t len = noff[r + 1] - noff[r];
+    const uint64_t p0 = (uint64_t)(item - choff[r]) * 256 + threadIdx.x;
+    if (p0 == 0) circ_out[r] = circ_in[idx[r]];
+    if (p0 >= len) return;
+    out[noff[r] + p0] = in[uoff[idx[r]] + p0];
 }
 
 }  // namespace
@@ -1235,9 +1336,25 @@ int snk_dist_join(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
     uint32_t *nch, *choff, *owner, total_items = 0;
     G_ALLOC(nch, uint32_t, F + 1);
     SNK_HIP_TRY(hipMemsetAsync(nch + F, 0, 4, st));
-    hipLaunchKernelGGL(jchunks_kernel, dim3(nblk(F)), dim3(TB), 0, st, boff, F, nch);
+    hipLaunchKernelGGL(jchunks_nk_kernel, dim3(nblk(F)), dim3(TB), 0, st, nk, K, F, nch);
     if ((rc = chunk_owners(ctx, st, nch, F, &choff, &owner, &total_items, err, errcap))) return rc;
-    if (total_items) hipLaunchKernelGGL(jemit_kernel, dim3(total_items), dim3(256), 0, st, owner, choff, boff, fbases, rk, nk, poff, prov);
+    if (total_items) hipLaunchKernelGGL(jemit_kernel, dim3(total_items), dim3(256), 0, st, owner, choff, boff, fbases, rk, nk, poff, K, prov);
+    // circles that were cut at an arbitrary fragment boundary: rotate to the reference's cut (minimum k-mer, forward)
+    {
+        uint32_t *clist, *ccnt;
+        G_ALLOC(clist, uint32_t, U + 1);
+        G_ALLOC(ccnt, uint32_t, 4);
+        SNK_HIP_TRY(hipMemsetAsync(ccnt, 0, 4, st));
+        hipLaunchKernelGGL(jcirc_list_kernel, dim3(nblk(U)), dim3(TB), 0, st, ucirc, U, clist, ccnt);
+        uint32_t h_nc = 0;
+        SNK_HIP_TRY(hipMemcpyAsync(&h_nc, ccnt, 4, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(hipStreamSynchronize(st));
+        if (h_nc) {
+            if (K == 48) hipLaunchKernelGGL((jcircle_kernel<48>), dim3(h_nc), dim3(256), 0, st, clist, uoff, prov, final_bases);
+            else hipLaunchKernelGGL((jcircle_kernel<60>), dim3(h_nc), dim3(256), 0, st, clist, uoff, prov, final_bases);
+        }
+        out->n_circles_rotated = h_nc;
+    }
     hipLaunchKernelGGL(jform_kernel, dim3(nblk(U)), dim3(TB), 0, st, uoff, U, prov, urev);
     uint32_t *unch, *uchoff, *uowner, utotal = 0;
     G_ALLOC(unch, uint32_t, U + 1);
@@ -1246,11 +1363,54 @@ int snk_dist_join(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
     if ((rc = chunk_owners(ctx, st, unch, U, &uchoff, &uowner, &utotal, err, errcap))) return rc;
     if (utotal) hipLaunchKernelGGL(jfinal_kernel, dim3(utotal), dim3(256), 0, st, uoff, uowner, uchoff, urev, prov, final_bases);
     SNK_HIP_TRY(hipGetLastError());
+    // deterministic order (fragment ids depend on the order in which workgroups reserved their output)
+    uint64_t* noff = uoff;
+    uint8_t* obases = final_bases;
+    uint8_t* ocirc = ucirc;
+    if (U > 1) {
+        snk_u128 *ok_in, *ok_out;
+        uint32_t *oi_in, *oi_out;
+        uint64_t* olen;
+        G_ALLOC(ok_in, snk_u128, U + 1);
+        G_ALLOC(ok_out, snk_u128, U + 1);
+        G_ALLOC(oi_in, uint32_t, U + 1);
+        G_ALLOC(oi_out, uint32_t, U + 1);
+        G_ALLOC(olen, uint64_t, U + 1);
+        G_ALLOC(noff, uint64_t, U + 1);
+        G_ALLOC(ocirc, uint8_t, U + 1);
+        obases = prov;         // the provisional buffer is dead: reuse it for the ordered copy
+        if (K == 48) hipLaunchKernelGGL((jorder_key_kernel<48>), dim3(nblk(U)), dim3(TB), 0, st, uoff, final_bases, U, ok_in, oi_in);
+        else hipLaunchKernelGGL((jorder_key_kernel<60>), dim3(nblk(U)), dim3(TB), 0, st, uoff, final_bases, U, ok_in, oi_in);
+        {
+            size_t tb = 0;
+            SNK_HIP_TRY(rocprim::radix_sort_pairs((void*)nullptr, tb, ok_in, ok_out, oi_in, oi_out, (size_t)U, 0u, 128u, st));
+            void* tmp;
+            if ((rc = snk_ctx_alloc(ctx, tb, &tmp, err, errcap))) return rc;
+            SNK_HIP_TRY(rocprim::radix_sort_pairs(tmp, tb, ok_in, ok_out, oi_in, oi_out, (size_t)U, 0u, 128u, st));
+        }
+        hipLaunchKernelGGL(jorder_len_kernel, dim3(nblk(U + 1)), dim3(TB), 0, st, uoff, oi_out, U, olen);
+        if ((rc = excl_scan<uint64_t>(ctx, st, olen, noff, U + 1, err, errcap))) return rc;
+        uint32_t *onch, *ochoff, *oowner, ototal = 0;
+        G_ALLOC(onch, uint32_t, U + 1);
+        SNK_HIP_TRY(hipMemsetAsync(onch + U, 0, 4, st));
+        hipLaunchKernelGGL(jchunks_kernel, dim3(nblk(U)), dim3(TB), 0, st, noff, U, onch);
+        if ((rc = chunk_owners(ctx, st, onch, U, &ochoff, &oowner, &ototal, err, errcap))) return rc;
+        if (ototal) hipLaunchKernelGGL(jorder_copy_kernel, dim3(ototal), dim3(256), 0, st, oowner, ochoff, noff, uoff, oi_out, final_bases, ucirc, obases, ocirc);
+        SNK_HIP_TRY(hipGetLastError());
+    }
     SNK_HIP_TRY(hipStreamSynchronize(st));
     out->n_unitigs = U;
     out->total_bases = h_tot;
-    out->unitig_off = uoff;
-    out->unitig_bases = final_bases;
-    out->unitig_circular = ucirc;
+    out->unitig_off = noff;
+    out->unitig_bases = obases;
+    out->unitig_circular = ocirc;
     return SNK_OK;
+}
+
+int snk_launch_spectrum(hipStream_t st, const uint32_t* counts, uint64_t n, unsigned long long* bins, uint32_t nbins) {
+    if (n == 0) return 0;
+    unsigned g = nblk(n);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(spectrum_kernel, dim3(g), dim3(TB), 0, st, counts, n, bins, nbins);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
 }

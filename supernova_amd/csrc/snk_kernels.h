@@ -31,8 +31,12 @@ struct snk_count_args {
     uint64_t region_cap;
     uint32_t n_regions;
     unsigned long long* region_cursor;   // [n_regions] entries used per region
+    uint32_t* chunk_n;             // [NB] survivors of an unsplit bucket (0 when it split or has none), or NULL
+    uint32_t* chunk_base;          // [NB] their offset inside region (bucket % n_regions)
+    uint4* extra;                  // sub-passes of split buckets: (bucket, offset, n, split_lg << 24 | split_id); count in status[4]
+    uint32_t extra_cap;
     uint32_t dbg;                  // profiling aid: 1 = roll+hash only, 2 = no updates after the probe (results invalid)
-    uint32_t* status;              // [0] output overflow, [1] split depth exceeded, [2] buckets split, [3] max slots used
+    uint32_t* status;              // [0] output overflow, [1] split depth exceeded, [2] buckets split, [3] max slots used, [4] extra chunks
 };
 int snk_launch_count(uint32_t K, hipStream_t st, const snk_count_args& a, char* err, size_t errcap);
 uint32_t snk_count_slots(uint32_t K);   // LDS table slots per workgroup

@@ -1,0 +1,625 @@
+// snk_local.hip -- bucket-local graph stage: adjacency prune, links and unitig fragments inside the CU.
+//
+// What it replaces: the same reference code as snk_graph.hip (recomputeAdjacencies, kmers/ReadPather.h:346-385;
+// EdgeBuilder, paths/long/BuildReadQGraph48.cc:327-541) -- structured like tada, which assembles every shard on
+// its own ("sedges", lib/tada/src/debruijn.rs:147-320) and joins the pieces afterwards (build_edges, :539-776).
+//
+// Why: the retained k-mers of one minimiser bucket leave the count kernel as one contiguous chunk (<= 1216 k-mers,
+// ~100 on average) and ~94 % of all de Bruijn adjacencies connect two k-mers of the same bucket (consecutive k-mers
+// of a read share their minimiser).  The global formulation (snk_graph.hip: sort, HBM hash index, one random probe
+// per context bit, list ranking over all 2n states) pays HBM-random-access prices for what is bucket-local work.
+// Here a workgroup loads one chunk into LDS and does, without leaving the CU:
+//   L1  membership of every neighbour through an LDS hash of the chunk; neighbours that are not in the chunk are
+//       either provably absent (their minimiser bucket -- and sub-pass -- is this one) or "pending";
+//   G   only k-mers with a pending bit (the bucket boundary, ~12 %) enter a global HBM index; pending bits are
+//       resolved with one probe each;
+//   L2  reciprocal-unique links inside the chunk, maximal local paths ("fragments") by short serial walks in LDS,
+//       local smooth circles cut at their minimum k-mer; every fragment is written once (pid -> other orientation)
+//       together with its two half links (the single remote neighbour of each end, if any).
+// The fragments (one per ~17 k-mers) are then joined by the code that joins the per-rank fragments of the
+// multi-GPU path (snk_dist_join): hash match of mutual half links, list ranking weighted by k-mers, copy into
+// place, reference orientation, circles rotated to their minimum k-mer.
+#include <string.h>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+#include "snk_ctx.h"
+#include "snk_common.h"
+#include "snk_kernels.h"
+#include "snk_graph.h"
+#include "snk_stages.h"
+
+namespace {
+
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+constexpr unsigned long long NONE64 = ~0ull;
+constexpr uint16_t NONE16 = 0xFFFFu;
+constexpr int TB = 256;
+inline unsigned nblk(uint64_t n) { return (unsigned)((n + TB - 1) / TB); }
+
+struct chunk_src {
+    const uint32_t* chunk_n;
+    const uint32_t* chunk_base;
+    const uint4* extra;
+    const unsigned long long* region_off;
+    uint32_t NB, n_extra, n_regions;
+};
+struct chunk_t {
+    uint32_t bucket, n, lg, id;
+    uint64_t base;
+};
+__device__ __forceinline__ chunk_t chunk_get(const chunk_src& cs, uint32_t c) {
+    chunk_t k;
+    uint32_t off = 0;
+    if (c < cs.NB) {
+        k.bucket = c; k.n = cs.chunk_n[c]; k.lg = 0; k.id = 0;
+        if (k.n) off = cs.chunk_base[c];
+    } else {
+        const uint4 e = cs.extra[c - cs.NB];
+        k.bucket = e.x; off = e.y; k.n = e.z; k.lg = e.w >> 24; k.id = e.w & 0xFFFFFFu;
+    }
+    k.base = cs.region_off[k.bucket % cs.n_regions] + off;
+    return k;
+}
+
+__device__ __forceinline__ snk_kmer load_key(const snk_u128* keys, uint64_t i) {
+    const uint64_t* p = reinterpret_cast<const uint64_t*>(keys + i);
+    snk_kmer k;
+    k.lo = p[0];
+    k.hi = p[1];
+    return k;
+}
+__device__ __forceinline__ uint32_t lhash(uint64_t hi, uint64_t lo) {
+    uint32_t x = (uint32_t)(hi >> 32) * 0x9E3779B1u ^ (uint32_t)hi * 0x85EBCA77u ^ (uint32_t)(lo >> 32) * 0xC2B2AE3Du ^
+                 (uint32_t)lo * 0x27D4EB2Fu;
+    return snk_mix32(x);
+}
+template <int K>
+__device__ __forceinline__ uint32_t oriented_base(snk_kmer k, bool rc, int idx) {
+    return rc ? (snk_kmer_base<K>(k, K - 1 - idx) ^ 3u) : snk_kmer_base<K>(k, idx);
+}
+
+// ---------------------------------------------------------------------------------------------- L1: local prune
+template <int K, int CAP, int T, bool BIG>
+__global__ void __launch_bounds__(T) bl_prune_kernel(chunk_src cs, const uint32_t* __restrict__ biglist_in,
+                                                     const snk_u128* __restrict__ keys, const uint64_t* __restrict__ vals,
+                                                     uint32_t do_prune, uint8_t* __restrict__ ctx_out,
+                                                     uint32_t* __restrict__ count_out, uint8_t* __restrict__ pend_out,
+                                                     uint32_t* __restrict__ nbr_out, uint32_t* __restrict__ nbnd,
+                                                     uint32_t* __restrict__ biglist, uint32_t* __restrict__ nbig) {
+    constexpr int HT = CAP <= 256 ? 512 : 4096;
+    __shared__ uint64_t khi[CAP], klo[CAP];
+    __shared__ uint32_t ht[HT];
+    __shared__ uint32_t bcnt;
+    const int tid = threadIdx.x;
+    const uint32_t c = BIG ? biglist_in[blockIdx.x] : blockIdx.x;
+    const chunk_t ch = chunk_get(cs, c);
+    if (ch.n == 0) return;
+    if (!BIG && ch.n > (uint32_t)CAP) {
+        if (tid == 0) biglist[atomicAdd(nbig, 1u)] = c;
+        return;
+    }
+    const uint32_t n = ch.n;
+    for (int s = tid; s < HT; s += T) ht[s] = 0;
+    if (tid == 0) bcnt = 0;
+    for (uint32_t i = tid; i < n; i += T) {
+        const snk_kmer k = load_key(keys, ch.base + i);
+        khi[i] = k.hi;
+        klo[i] = k.lo;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += T) {
+        uint32_t slot = lhash(khi[i], klo[i]) & (HT - 1);
+        for (;;) {
+            const uint32_t old = atomicCAS(&ht[slot], 0u, i + 1u);
+            if (old == 0u) break;
+            slot = (slot + 1) & (HT - 1);
+        }
+    }
+    __syncthreads();
+    const uint32_t split_mask = (1u << ch.lg) - 1u;
+    uint32_t mybnd = 0;
+    for (uint32_t i0 = 0; i0 < n; i0 += T) {
+        const uint32_t i = i0 + tid;
+        const bool act = i < n;
+        snk_kmer k;
+        k.hi = act ? khi[i] : 0ull;
+        k.lo = act ? klo[i] : 0ull;
+        const uint64_t v = act ? vals[ch.base + i] : 0ull;
+        const uint32_t c0 = (uint32_t)(v & 0xFFu);
+        uint32_t keep = 0, miss = 0, nb0 = NONE, nb1 = NONE;
+        for (uint32_t bit = 0; bit < 8; ++bit) {
+            if (!(c0 & (1u << bit))) continue;
+            const snk_kmer y = bit < 4 ? snk_kmer_succ<K>(k, bit) : snk_kmer_pred<K>(k, bit - 4);
+            const snk_kmer r = snk_kmer_rc<K>(y);
+            const bool rev = snk_kmer_lt(r, y);
+            const snk_kmer cy = rev ? r : y;
+            int32_t j = -1;
+            uint32_t slot = lhash(cy.hi, cy.lo) & (HT - 1);
+            for (;;) {
+                const uint32_t e = ht[slot];
+                if (e == 0u) break;
+                if (khi[e - 1] == cy.hi && klo[e - 1] == cy.lo) { j = (int32_t)(e - 1); break; }
+                slot = (slot + 1) & (HT - 1);
+            }
+            if (j >= 0) {
+                keep |= 1u << bit;
+                if (bit < 4) nb0 = ((uint32_t)j << 1) | (rev ? 1u : 0u); else nb1 = ((uint32_t)j << 1) | (rev ? 1u : 0u);
+            } else miss |= 1u << bit;
+        }
+        // Neighbours that are not in this chunk: absent for certain iff this very sub-pass would have counted them, i.e.
+        // their minimiser bucket is this one (and their split hash this sub-pass's).  A neighbour shares all but one of
+        // its M-mers with k, so its minimum ordering key = min(minimum over the shared ones, key of the new M-mer): the
+        // 33 keys of k are evaluated once, by every lane of the wave together (no divergence), each miss costs one more.
+        uint32_t pm = 0;
+        if (__any(miss != 0)) {
+            uint32_t minA = 0xFFFFFFFFu, minB = 0xFFFFFFFFu;      // over M-mer positions 1..K-M (successors) / 0..K-M-1 (predecessors)
+            for (int p = 0; p + SNK_M <= K; ++p) {
+                uint64_t w;
+                if (p == 0) w = k.hi;
+                else if (p < 32) w = (k.hi << (2 * p)) | (k.lo >> (64 - 2 * p));
+                else if (p == 32) w = k.lo;
+                else w = k.lo << (2 * p - 64);
+                const uint32_t x = (uint32_t)(w >> 32);
+                const uint32_t key = snk_minimizer_key(x, snk_rev2_32(~x));
+                if (p > 0) minA = key < minA ? key : minA;
+                if (p + SNK_M < K) minB = key < minB ? key : minB;
+            }
+            for (uint32_t bit = 0; bit < 8; ++bit) {
+                if (!(miss & (1u << bit))) continue;
+                uint32_t x;      // the one M-mer of the neighbour that k does not have
+                if (bit < 4) {   // last M bases of succ(k, b): the last M-1 bases of k followed by b
+                    const snk_kmer y = snk_kmer_succ<K>(k, bit);
+                    constexpr int p = K - SNK_M;
+                    const uint64_t w = p < 32 ? ((y.hi << (2 * p)) | (y.lo >> (64 - 2 * p))) : (p == 32 ? y.lo : (y.lo << (2 * p - 64)));
+                    x = (uint32_t)(w >> 32);
+                } else {         // first M bases of pred(k, b)
+                    x = (uint32_t)(snk_kmer_pred<K>(k, bit - 4).hi >> 32);
+                }
+                const uint32_t nkey = snk_minimizer_key(x, snk_rev2_32(~x));
+                const uint32_t shared = bit < 4 ? minA : minB;
+                const uint32_t mk = nkey < shared ? nkey : shared;
+                bool here = snk_bucket_of_key(mk, cs.NB) == ch.bucket;
+                if (here && ch.lg) {
+                    const snk_kmer y = bit < 4 ? snk_kmer_succ<K>(k, bit) : snk_kmer_pred<K>(k, bit - 4);
+                    const snk_kmer r = snk_kmer_rc<K>(y);
+                    uint32_t h1, h2;
+                    snk_kmer_hash2(snk_kmer_lt(r, y) ? r : y, &h1, &h2);
+                    here = (h2 & split_mask) == ch.id;
+                }
+                if (here) { if (!do_prune) keep |= 1u << bit; }
+                else { keep |= 1u << bit; pm |= 1u << bit; }
+            }
+        }
+        if (!act) continue;
+        const uint64_t gi = ch.base + i;
+        ctx_out[gi] = (uint8_t)keep;
+        pend_out[gi] = (uint8_t)pm;
+        count_out[gi] = (uint32_t)(v >> 8);
+        nbr_out[2 * gi + 0] = nb0;
+        nbr_out[2 * gi + 1] = nb1;
+        if (pm) ++mybnd;
+    }
+    if (mybnd) atomicAdd(&bcnt, mybnd);
+    __syncthreads();
+    if (tid == 0) nbnd[c] = bcnt;
+}
+
+// ---------------------------------------------------------------------------------------------- G: boundary index
+__global__ void __launch_bounds__(TB) bl_index_build_kernel(const snk_u128* __restrict__ keys, const uint8_t* __restrict__ pend,
+                                                            uint64_t n, unsigned long long* __restrict__ tab, uint64_t mask) {
+    const uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (i >= n || !pend[i]) return;
+    const snk_kmer k = load_key(keys, i);
+    uint32_t h1, h2;
+    snk_kmer_hash2(k, &h1, &h2);
+    uint64_t slot = (((uint64_t)h1 << 32) | h2) & mask;
+    const unsigned long long ent = ((unsigned long long)h1 << 32) | (unsigned long long)(i + 1);
+    for (;;) {
+        const unsigned long long old = atomicCAS(&tab[slot], 0ull, ent);
+        if (old == 0ull) break;
+        slot = (slot + 1) & mask;
+    }
+}
+template <int K>
+__global__ void __launch_bounds__(TB) bl_resolve_kernel(const snk_u128* __restrict__ keys, const uint8_t* __restrict__ pend,
+                                                        uint64_t n, const unsigned long long* __restrict__ tab, uint64_t mask,
+                                                        uint32_t do_prune, uint8_t* __restrict__ ctx, uint32_t* __restrict__ rq) {
+    const uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t pm = pend[i];
+    if (!pm) return;
+    const snk_kmer k = load_key(keys, i);
+    uint32_t c = ctx[i];
+    for (uint32_t bit = 0; bit < 8; ++bit) {
+        if (!(pm & (1u << bit))) continue;
+        const snk_kmer y = bit < 4 ? snk_kmer_succ<K>(k, bit) : snk_kmer_pred<K>(k, bit - 4);
+        const snk_kmer r = snk_kmer_rc<K>(y);
+        const bool rev = snk_kmer_lt(r, y);
+        const snk_kmer cy = rev ? r : y;
+        uint32_t h1, h2;
+        snk_kmer_hash2(cy, &h1, &h2);
+        uint64_t slot = (((uint64_t)h1 << 32) | h2) & mask;
+        int64_t j = -1;
+        for (;;) {
+            const unsigned long long e = tab[slot];
+            if (e == 0ull) break;
+            if ((uint32_t)(e >> 32) == h1) {
+                const uint64_t idx = (uint32_t)e - 1u;
+                if (snk_kmer_eq(load_key(keys, idx), cy)) { j = (int64_t)idx; break; }
+            }
+            slot = (slot + 1) & mask;
+        }
+        if (j >= 0) rq[2 * i + (bit >> 2)] = ((uint32_t)j << 1) | (rev ? 1u : 0u);
+        else if (do_prune) c &= ~(1u << bit);
+    }
+    ctx[i] = (uint8_t)c;
+}
+
+// ---------------------------------------------------------------------------------------------- L2: fragments
+template <int K, int CAP, int T, bool BIG, bool EMIT>
+__global__ void __launch_bounds__(T) bl_frag_kernel(chunk_src cs, const uint32_t* __restrict__ biglist_in,
+                                                    const snk_u128* __restrict__ keys, const uint8_t* __restrict__ ctx,
+                                                    const uint8_t* __restrict__ pend, const uint32_t* __restrict__ nbr,
+                                                    const uint32_t* __restrict__ rq, uint32_t* __restrict__ nfrag,
+                                                    const uint32_t* __restrict__ foff, const uint64_t* __restrict__ boff,
+                                                    uint32_t* __restrict__ nk, unsigned long long* __restrict__ hl_self,
+                                                    unsigned long long* __restrict__ hl_nb, uint64_t* __restrict__ bstart,
+                                                    uint8_t* __restrict__ fbases) {
+    __shared__ uint64_t khi[CAP], klo[CAP];
+    __shared__ uint32_t nbL[2 * CAP];
+    __shared__ uint16_t lnk[2 * CAP];
+    __shared__ uint8_t ctxL[CAP], pendL[CAP], palL[CAP], vis[CAP];
+    __shared__ uint32_t fcnt, bcnt;
+    const int tid = threadIdx.x;
+    const uint32_t c = BIG ? biglist_in[blockIdx.x] : blockIdx.x;
+    const chunk_t ch = chunk_get(cs, c);
+    if (ch.n == 0) return;
+    if (!BIG && ch.n > (uint32_t)CAP) return;
+    const uint32_t n = ch.n;
+    if (tid == 0) { fcnt = 0; bcnt = 0; }
+    for (uint32_t i = tid; i < n; i += T) {
+        const uint64_t gi = ch.base + i;
+        const snk_kmer k = load_key(keys, gi);
+        khi[i] = k.hi;
+        klo[i] = k.lo;
+        palL[i] = snk_kmer_eq(k, snk_kmer_rc<K>(k)) ? 1 : 0;
+        ctxL[i] = ctx[gi];
+        pendL[i] = pend[gi];
+        vis[i] = 0;
+        nbL[2 * i] = nbr[2 * gi];
+        nbL[2 * i + 1] = nbr[2 * gi + 1];
+    }
+    __syncthreads();
+    // reciprocal-unique links inside the chunk (BuildReadQGraph48.cc:408-428): state = node << 1 | exit side
+    for (uint32_t s = tid; s < 2 * n; s += T) {
+        const uint32_t i = s >> 1, side = s & 1u;
+        const uint32_t cc = ctxL[i];
+        const uint32_t bits = side ? (cc >> 4) : (cc & 15u);
+        uint16_t out = NONE16;
+        if (__popc(bits) == 1) {
+            const uint32_t b = __ffs(bits) - 1;
+            if (!((pendL[i] >> (4 * side + b)) & 1u)) {
+                const uint32_t nb = nbL[s];
+                if (nb != NONE) {
+                    const uint32_t j = nb >> 1, rev = nb & 1u;
+                    const uint32_t fs = side ^ 1u ^ rev;
+                    const uint32_t cj = ctxL[j];
+                    const uint32_t deg = fs ? __popc(cj & 0xF0u) : __popc(cj & 0x0Fu);
+                    if (deg == 1 && !palL[i] && !palL[j]) out = (uint16_t)((j << 1) | fs);
+                }
+            }
+        }
+        lnk[s] = out;
+    }
+    __syncthreads();
+
+    // half link of a fragment end: the single remote neighbour of that side (decided half on each owner)
+    auto half_link = [&](uint32_t s) -> unsigned long long {
+        const uint32_t i = s >> 1, side = s & 1u;
+        const uint32_t cc = ctxL[i];
+        const uint32_t bits = side ? (cc >> 4) : (cc & 15u);
+        if (__popc(bits) != 1 || palL[i]) return NONE64;
+        const uint32_t b = __ffs(bits) - 1;
+        if (!((pendL[i] >> (4 * side + b)) & 1u)) return NONE64;
+        const uint32_t a = rq[2 * (ch.base + i) + side];
+        if (a == NONE) return NONE64;
+        snk_kmer k;
+        k.hi = khi[i];
+        k.lo = klo[i];
+        const snk_kmer y = side ? snk_kmer_pred<K>(k, b) : snk_kmer_succ<K>(k, b);
+        if (snk_kmer_eq(y, snk_kmer_rc<K>(y))) return NONE64;
+        const uint32_t rev = a & 1u, fs = side ^ 1u ^ rev;
+        return 2ull * (a >> 1) + fs;
+    };
+    // write one fragment: `cnt` nodes starting at terminal state t (the node is read with side t&1 as its back)
+    auto emit = [&](uint32_t t, uint32_t other, uint32_t cnt, bool with_half) {
+        const uint32_t f = foff[c] + atomicAdd(&fcnt, 1u);
+        const uint64_t bo = boff[c] + atomicAdd(&bcnt, cnt + (uint32_t)K - 1u);
+        nk[f] = cnt;
+        hl_self[2 * (uint64_t)f] = 2ull * ch.base + t;
+        hl_self[2 * (uint64_t)f + 1] = 2ull * ch.base + other;
+        hl_nb[2 * (uint64_t)f] = with_half ? half_link(t) : NONE64;
+        hl_nb[2 * (uint64_t)f + 1] = with_half ? half_link(other) : NONE64;
+        bstart[f] = bo;
+        snk_kmer k;
+        k.hi = khi[t >> 1];
+        k.lo = klo[t >> 1];
+        const bool rc0 = (t & 1u) == 0;
+        for (int b = 0; b < K; ++b) fbases[bo + b] = (uint8_t)oriented_base<K>(k, rc0, b);
+        uint32_t cur = t ^ 1u;
+        for (uint32_t pos = 1; pos < cnt; ++pos) {
+            const uint32_t l = lnk[cur];
+            const uint32_t j = l >> 1;
+            k.hi = khi[j];
+            k.lo = klo[j];
+            fbases[bo + (K - 1) + pos] = (uint8_t)oriented_base<K>(k, (l & 1u) == 0, K - 1);
+            cur = l ^ 1u;
+        }
+    };
+
+    uint32_t myfrags = 0;
+    for (uint32_t s = tid; s < 2 * n; s += T) {
+        if (lnk[s] != NONE16) continue;
+        uint32_t cur = s ^ 1u, len = 1;
+        vis[s >> 1] = 1;
+        for (;;) {
+            const uint32_t l = lnk[cur];
+            if (l == NONE16 || len > n) break;
+            vis[l >> 1] = 1;
+            cur = l ^ 1u;
+            ++len;
+        }
+        if (s < cur && len <= n) {
+            ++myfrags;
+            if (EMIT) emit(s, cur, len, true);
+        }
+    }
+    __syncthreads();
+    // nodes no terminal walk reached lie on smooth circles inside the chunk: cut at the left side of the minimum k-mer
+    // (canonicalizeCircle, BuildReadQGraph48.cc:375-397); the circle's minimum node emits it
+    for (uint32_t i = tid; i < n; i += T) {
+        if (vis[i]) continue;
+        uint32_t cur = i << 1, mn = i, cnt = 1;
+        bool closed = false;
+        while (cnt <= n) {
+            const uint32_t l = lnk[cur];
+            if (l == NONE16) break;
+            const uint32_t j = l >> 1;
+            if (j == i) { closed = true; break; }
+            if (khi[j] < khi[mn] || (khi[j] == khi[mn] && klo[j] < klo[mn])) mn = j;
+            cur = l ^ 1u;
+            ++cnt;
+        }
+        if (closed && mn == i) {
+            ++myfrags;
+            if (EMIT) {
+                uint32_t e = (i << 1) ^ 0u;     // exit state of the last node: walk cnt-1 links from (i, side 0)
+                for (uint32_t q = 1; q < cnt; ++q) e = lnk[e] ^ 1u;
+                emit((i << 1) | 1u, e, cnt, false);
+            }
+        }
+    }
+    if (!EMIT) {
+        if (myfrags) atomicAdd(&fcnt, myfrags);
+        __syncthreads();
+        if (tid == 0) nfrag[c] = fcnt;
+    }
+}
+
+__global__ void __launch_bounds__(TB) bl_chunk_bases_kernel(chunk_src cs, const uint32_t* __restrict__ nfrag, uint32_t nchunks,
+                                                            uint32_t K, uint64_t* __restrict__ nbases) {
+    const uint32_t c = blockIdx.x * TB + threadIdx.x;
+    if (c > nchunks) return;
+    if (c == nchunks) { nbases[c] = 0; return; }
+    uint32_t n;
+    if (c < cs.NB) n = cs.chunk_n[c];
+    else n = cs.extra[c - cs.NB].z;
+    nbases[c] = nfrag[c] ? (uint64_t)n + (uint64_t)(K - 1) * nfrag[c] : 0ull;
+}
+
+__global__ void __launch_bounds__(TB) bl_pack_vals_kernel(const uint32_t* __restrict__ counts, const uint8_t* __restrict__ ctx,
+                                                          uint64_t n, uint64_t* __restrict__ vals) {
+    const uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (i < n) vals[i] = ((uint64_t)counts[i] << 8) | ctx[i];
+}
+__global__ void __launch_bounds__(TB) bl_unpack_vals_kernel(const uint64_t* __restrict__ vals, uint64_t n,
+                                                            uint32_t* __restrict__ counts, uint8_t* __restrict__ ctx) {
+    const uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (i < n) { counts[i] = (uint32_t)(vals[i] >> 8); ctx[i] = (uint8_t)(vals[i] & 0xFFu); }
+}
+
+}  // namespace
+
+#define G_ALLOC(ptr, type, count)                                                       \
+    do {                                                                                \
+        void* _p = nullptr;                                                             \
+        int _rc = snk_ctx_alloc(ctx, sizeof(type) * (size_t)(count), &_p, err, errcap); \
+        if (_rc) return _rc;                                                            \
+        ptr = (type*)_p;                                                                \
+    } while (0)
+
+template <typename T>
+static int excl_scan(snk_ctx* ctx, hipStream_t st, const T* in, T* out, size_t count, char* err, size_t errcap) {
+    size_t tb = 0;
+    SNK_HIP_TRY(rocprim::exclusive_scan((void*)nullptr, tb, in, out, (T)0, count, rocprim::plus<T>(), st));
+    void* tmp;
+    int rc = snk_ctx_alloc(ctx, tb, &tmp, err, errcap);
+    if (rc) return rc;
+    SNK_HIP_TRY(rocprim::exclusive_scan(tmp, tb, in, out, (T)0, count, rocprim::plus<T>(), st));
+    return SNK_OK;
+}
+
+constexpr int SCAP = 256, ST = 64;      // small chunks: one wave per chunk
+constexpr int BCAP = 1280, BT = 256;    // big chunks (a count sub-pass retains at most SLOTS - THREADS - 64 = 1216 k-mers)
+
+template <int K>
+static int local_graph_impl(snk_ctx* ctx, hipStream_t st, const snk_table* tab, uint32_t do_prune, bool want_unitigs,
+                            bool sort_table, snk_graph_out* out, snk_u128** keys_final, float* ms, char* err, size_t errcap) {
+    memset(out, 0, sizeof *out);
+    const uint64_t n = tab->n;
+    *keys_final = tab->keys;
+    constexpr uint32_t NBINS = 65536;
+    G_ALLOC(out->spectrum, unsigned long long, NBINS);
+    SNK_HIP_TRY(hipMemsetAsync(out->spectrum, 0, NBINS * 8, st));
+    out->spectrum_bins = NBINS;
+    if (n == 0) {
+        G_ALLOC(out->unitig_off, uint64_t, 2);
+        SNK_HIP_TRY(hipMemsetAsync(out->unitig_off, 0, 16, st));
+        G_ALLOC(out->unitig_bases, uint8_t, 16);
+        G_ALLOC(out->ctx, uint8_t, 16);
+        G_ALLOC(out->counts, uint32_t, 4);
+        return SNK_OK;
+    }
+    if (n >= (1ull << 31)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "more than 2^31 retained k-mers on one GPU (%llu)", (unsigned long long)n);
+    if (snk_count_slots(K) > (uint32_t)BCAP + 768u + 64u)
+        return snk_fail(SNK_E_INTERNAL, err, errcap, "bucket-local graph: chunk capacity %d is below the count table's limit", BCAP);
+    snk_phase_timer tm(st);
+    tm.mark();  // 0
+    chunk_src cs;
+    cs.chunk_n = tab->chunk_n;
+    cs.chunk_base = tab->chunk_base;
+    cs.extra = tab->extra;
+    cs.region_off = tab->region_off;
+    cs.NB = tab->NB;
+    cs.n_extra = tab->n_extra;
+    cs.n_regions = tab->n_regions;
+    const uint32_t nchunks = tab->NB + tab->n_extra;
+    uint8_t *ctxo, *pend;
+    uint32_t *counts, *nbr, *rq, *nbnd, *biglist, *ctr;
+    G_ALLOC(ctxo, uint8_t, n + 16);
+    G_ALLOC(pend, uint8_t, n + 16);
+    G_ALLOC(counts, uint32_t, n + 4);
+    G_ALLOC(nbr, uint32_t, 2 * n + 2);
+    G_ALLOC(rq, uint32_t, 2 * n + 2);
+    G_ALLOC(nbnd, uint32_t, (uint64_t)nchunks + 1);
+    G_ALLOC(biglist, uint32_t, n / SCAP + 2);
+    G_ALLOC(ctr, uint32_t, 16);
+    SNK_HIP_TRY(hipMemsetAsync(nbnd, 0, ((uint64_t)nchunks + 1) * 4, st));
+    SNK_HIP_TRY(hipMemsetAsync(ctr, 0, 64, st));
+    SNK_HIP_TRY(hipMemsetAsync(rq, 0xFF, (2 * n + 2) * 4, st));
+    hipLaunchKernelGGL((bl_prune_kernel<K, SCAP, ST, false>), dim3(nchunks), dim3(ST), 0, st, cs, (const uint32_t*)nullptr,
+                       tab->keys, tab->vals, do_prune, ctxo, counts, pend, nbr, nbnd, biglist, ctr);
+    SNK_HIP_TRY(hipGetLastError());
+    uint32_t h_nbig = 0;
+    SNK_HIP_TRY(hipMemcpyAsync(&h_nbig, ctr, 4, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    if (h_nbig)
+        hipLaunchKernelGGL((bl_prune_kernel<K, BCAP, BT, true>), dim3(h_nbig), dim3(BT), 0, st, cs, (const uint32_t*)biglist,
+                           tab->keys, tab->vals, do_prune, ctxo, counts, pend, nbr, nbnd, biglist, ctr);
+    SNK_HIP_TRY(hipGetLastError());
+    // boundary k-mers
+    unsigned long long* d_sum;
+    G_ALLOC(d_sum, unsigned long long, 2);
+    {
+        size_t tb = 0;
+        auto in = rocprim::make_transform_iterator(nbnd, [] __device__(uint32_t v) { return (unsigned long long)v; });
+        SNK_HIP_TRY(rocprim::reduce((void*)nullptr, tb, in, d_sum, 0ull, (size_t)nchunks, rocprim::plus<unsigned long long>(), st));
+        void* tmp;
+        int rc = snk_ctx_alloc(ctx, tb, &tmp, err, errcap);
+        if (rc) return rc;
+        SNK_HIP_TRY(rocprim::reduce(tmp, tb, in, d_sum, 0ull, (size_t)nchunks, rocprim::plus<unsigned long long>(), st));
+    }
+    unsigned long long h_bnd = 0;
+    SNK_HIP_TRY(hipMemcpyAsync(&h_bnd, d_sum, 8, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    tm.mark();  // 1
+    uint64_t tg = 1024;
+    while (tg < 2 * h_bnd) tg <<= 1;
+    unsigned long long* index;
+    G_ALLOC(index, unsigned long long, tg);
+    SNK_HIP_TRY(hipMemsetAsync(index, 0, tg * 8, st));
+    if (h_bnd) {
+        hipLaunchKernelGGL(bl_index_build_kernel, dim3(nblk(n)), dim3(TB), 0, st, tab->keys, pend, n, index, tg - 1);
+        hipLaunchKernelGGL((bl_resolve_kernel<K>), dim3(nblk(n)), dim3(TB), 0, st, tab->keys, pend, n, index, tg - 1, do_prune, ctxo, rq);
+    }
+    SNK_HIP_TRY(hipGetLastError());
+    tm.mark();  // 2
+    out->n_boundary = h_bnd;
+    if (want_unitigs) {
+        uint32_t *nfrag, *foff;
+        uint64_t *nbases, *boff;
+        G_ALLOC(nfrag, uint32_t, (uint64_t)nchunks + 1);
+        G_ALLOC(foff, uint32_t, (uint64_t)nchunks + 1);
+        G_ALLOC(nbases, uint64_t, (uint64_t)nchunks + 1);
+        G_ALLOC(boff, uint64_t, (uint64_t)nchunks + 1);
+        SNK_HIP_TRY(hipMemsetAsync(nfrag, 0, ((uint64_t)nchunks + 1) * 4, st));
+        hipLaunchKernelGGL((bl_frag_kernel<K, SCAP, ST, false, false>), dim3(nchunks), dim3(ST), 0, st, cs, (const uint32_t*)nullptr,
+                           tab->keys, ctxo, pend, nbr, rq, nfrag, (const uint32_t*)nullptr, (const uint64_t*)nullptr, (uint32_t*)nullptr,
+                           (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint64_t*)nullptr, (uint8_t*)nullptr);
+        if (h_nbig)
+            hipLaunchKernelGGL((bl_frag_kernel<K, BCAP, BT, true, false>), dim3(h_nbig), dim3(BT), 0, st, cs, (const uint32_t*)biglist,
+                               tab->keys, ctxo, pend, nbr, rq, nfrag, (const uint32_t*)nullptr, (const uint64_t*)nullptr, (uint32_t*)nullptr,
+                               (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint64_t*)nullptr, (uint8_t*)nullptr);
+        hipLaunchKernelGGL(bl_chunk_bases_kernel, dim3(nblk((uint64_t)nchunks + 1)), dim3(TB), 0, st, cs, nfrag, nchunks, (uint32_t)K, nbases);
+        SNK_HIP_TRY(hipGetLastError());
+        int rc;
+        if ((rc = excl_scan<uint32_t>(ctx, st, nfrag, foff, (size_t)nchunks + 1, err, errcap))) return rc;
+        if ((rc = excl_scan<uint64_t>(ctx, st, nbases, boff, (size_t)nchunks + 1, err, errcap))) return rc;
+        uint32_t h_F = 0;
+        uint64_t h_B = 0;
+        SNK_HIP_TRY(hipMemcpyAsync(&h_F, foff + nchunks, 4, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(hipMemcpyAsync(&h_B, boff + nchunks, 8, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(hipStreamSynchronize(st));
+        uint32_t* fnk;
+        unsigned long long *hl_self, *hl_nb;
+        uint64_t* bstart;
+        uint8_t* fbases;
+        G_ALLOC(fnk, uint32_t, (uint64_t)h_F + 1);
+        G_ALLOC(hl_self, unsigned long long, 2ull * h_F + 2);
+        G_ALLOC(hl_nb, unsigned long long, 2ull * h_F + 2);
+        G_ALLOC(bstart, uint64_t, (uint64_t)h_F + 2);
+        G_ALLOC(fbases, uint8_t, h_B + 16);
+        hipLaunchKernelGGL((bl_frag_kernel<K, SCAP, ST, false, true>), dim3(nchunks), dim3(ST), 0, st, cs, (const uint32_t*)nullptr,
+                           tab->keys, ctxo, pend, nbr, rq, nfrag, foff, boff, fnk, hl_self, hl_nb, bstart, fbases);
+        if (h_nbig)
+            hipLaunchKernelGGL((bl_frag_kernel<K, BCAP, BT, true, true>), dim3(h_nbig), dim3(BT), 0, st, cs, (const uint32_t*)biglist,
+                               tab->keys, ctxo, pend, nbr, rq, nfrag, foff, boff, fnk, hl_self, hl_nb, bstart, fbases);
+        SNK_HIP_TRY(hipGetLastError());
+        tm.mark();  // 3
+        snk_join_out jo;
+        rc = snk_dist_join(ctx, st, K, h_F, fnk, hl_self, hl_nb, bstart, fbases, h_B, &jo, err, errcap);
+        if (rc) return rc;
+        tm.mark();  // 4
+        out->n_unitigs = jo.n_unitigs;
+        out->total_bases = jo.total_bases;
+        out->unitig_off = jo.unitig_off;
+        out->unitig_bases = jo.unitig_bases;
+        out->n_circles = jo.n_circles;
+        out->rank_rounds = jo.rank_rounds;
+        out->n_fragments = h_F;
+    } else {
+        G_ALLOC(out->unitig_off, uint64_t, 2);
+        SNK_HIP_TRY(hipMemsetAsync(out->unitig_off, 0, 16, st));
+        G_ALLOC(out->unitig_bases, uint8_t, 16);
+        tm.mark();
+        tm.mark();
+    }
+    out->ctx = ctxo;
+    out->counts = counts;
+    if (sort_table) {
+        uint64_t *v_in, *v_out;
+        snk_u128* k_out;
+        G_ALLOC(v_in, uint64_t, n + 1);
+        G_ALLOC(v_out, uint64_t, n + 1);
+        G_ALLOC(k_out, snk_u128, n + 1);
+        hipLaunchKernelGGL(bl_pack_vals_kernel, dim3(nblk(n)), dim3(TB), 0, st, counts, ctxo, n, v_in);
+        int rc = snk_graph_sort(ctx, st, K, n, tab->keys, v_in, k_out, v_out, err, errcap);
+        if (rc) return rc;
+        hipLaunchKernelGGL(bl_unpack_vals_kernel, dim3(nblk(n)), dim3(TB), 0, st, v_out, n, counts, ctxo);
+        *keys_final = k_out;
+    }
+    if ((int)snk_launch_spectrum(st, counts, n, out->spectrum, NBINS)) return snk_fail(SNK_E_HIP, err, errcap, "spectrum launch failed");
+    tm.mark();  // 5
+    SNK_HIP_TRY(hipGetLastError());
+    if (ms) { ms[0] = tm.ms(0, 1); ms[1] = tm.ms(1, 2); ms[2] = tm.ms(2, 3); ms[3] = tm.ms(3, 4); ms[4] = tm.ms(4, 5); }
+    return SNK_OK;
+}
+
+int snk_local_graph(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_table* tab, uint32_t do_prune, bool want_unitigs,
+                    bool sort_table, snk_graph_out* out, snk_u128** keys_final, float* ms, char* err, size_t errcap) {
+    if (tab->sorted) return snk_fail(SNK_E_INTERNAL, err, errcap, "bucket-local graph needs the table in chunk order");
+    if (K == 48) return local_graph_impl<48>(ctx, st, tab, do_prune, want_unitigs, sort_table, out, keys_final, ms, err, errcap);
+    if (K == 60) return local_graph_impl<60>(ctx, st, tab, do_prune, want_unitigs, sort_table, out, keys_final, ms, err, errcap);
+    return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "K=%u is not supported (48 or 60)", K);
+}

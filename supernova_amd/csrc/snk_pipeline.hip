@@ -132,26 +132,35 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     kt.mark();  // 3
     tm.mark();  // 3
 
-    // ---- K5-K8 count + filter + gather + sort
+    // ---- K5-K8 count + filter + gather (+ sort for the global graph stage)
+    const bool local_graph = !(p->flags & SNK_F_GLOBAL_GRAPH) && !env_u32("SNK_GLOBAL_GRAPH", 0);
     snk_table tab;
     rc = snk_stage_count_table(ctx, st, K, records, seg_off, 1, NB, p->min_freq, in->bc ? p->min_bc : 0u, h_ninst, status,
-                               &tab, err, errcap);
+                               !local_graph, &tab, err, errcap);
     if (rc) return rc;
     const uint64_t n_kmers = tab.n;
-    snk_u128* keys_b = tab.keys;
-    uint64_t* vals_b = tab.vals;
     out->buckets_split = tab.buckets_split;
     out->max_slots_used = tab.max_slots_used;
     out->n_kmers = n_kmers;
-    out->keys = keys_b;
+    out->keys = tab.keys;
     tm.mark();  // 4 (count+gather) and 5 (sort) are reported from the stage's own events
     tm.mark();
 
     // ---- prune + unitigs
     snk_graph_out go;
-    rc = snk_graph_build(ctx, st, K, keys_b, vals_b, n_kmers, p->min_freq > 1 ? 1u : 0u, !(p->flags & SNK_F_NO_GRAPH), &go,
-                         err, errcap);
-    if (rc) return rc;
+    if (local_graph) {
+        snk_u128* keys_final = nullptr;
+        rc = snk_local_graph(ctx, st, K, &tab, p->min_freq > 1 ? 1u : 0u, !(p->flags & SNK_F_NO_GRAPH),
+                             !(p->flags & SNK_F_UNSORTED_TABLE), &go, &keys_final, out->graph_ms, err, errcap);
+        if (rc) return rc;
+        out->keys = keys_final;
+        out->n_boundary = go.n_boundary;
+        out->n_fragments = go.n_fragments;
+    } else {
+        rc = snk_graph_build(ctx, st, K, tab.keys, tab.vals, n_kmers, p->min_freq > 1 ? 1u : 0u, !(p->flags & SNK_F_NO_GRAPH), &go,
+                             err, errcap);
+        if (rc) return rc;
+    }
     tm.mark();  // 6
     SNK_HIP_TRY(hipStreamSynchronize(st));
     out->counts = go.counts;

@@ -24,13 +24,22 @@ struct snk_phase_timer {
 
 struct snk_table {
     uint64_t n;
-    snk_u128* keys;      // sorted ascending
+    snk_u128* keys;      // sorted ascending (sorted == true) or in chunk order
     uint64_t* vals;      // count << 8 | raw context
     uint32_t buckets_split, max_slots_used;
     float count_ms, sort_ms, count_kernel_ms;
+    // chunk order (sorted == false): the survivors of every count sub-pass are contiguous; chunk c < NB is bucket c
+    // (unsplit), chunk NB + e is extra[e] (a sub-pass of a split bucket).  Dense position of a chunk =
+    // region_off[bucket % n_regions] + offset.
+    bool sorted;
+    uint32_t NB, n_regions, n_extra;
+    const uint32_t* chunk_n;
+    const uint32_t* chunk_base;
+    const uint4* extra;
+    const unsigned long long* region_off;
 };
 
 uint32_t snk_env_u32(const char* name, uint32_t dflt);
 int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* records, const uint64_t* seg_off,
                           uint32_t nseg, uint32_t NB, uint32_t min_freq, uint32_t bc_mode, uint64_t n_inst_hint,
-                          uint32_t* status, snk_table* out, char* err, size_t errcap);
+                          uint32_t* status, bool want_sort, snk_table* out, char* err, size_t errcap);

@@ -27,12 +27,14 @@ class Params:
     min_bc: int = 2        # 10X/DF.cc:140
     n_buckets: int = 0
     graph: bool = True
+    sorted_table: bool = True     # False: leave the retained table in bucket order (SNK_F_UNSORTED_TABLE)
+    global_graph: bool = False    # True: the global graph stage (SNK_F_GLOBAL_GRAPH), a cross-check of the bucket-local one
 
     def to_c(self) -> _lib.SnkParams:
         p = _lib.SnkParams()
         p.K, p.min_qual, p.min_freq, p.min_bc = self.K, self.min_qual, self.min_freq, self.min_bc
         p.n_buckets = self.n_buckets
-        p.flags = 0 if self.graph else 1
+        p.flags = (0 if self.graph else 1) | (0 if self.sorted_table else 2) | (4 if self.global_graph else 0)
         return p
 
 
@@ -44,11 +46,14 @@ class Result:
         self.raw = raw
         self.K = K
         for f in ("n_reads", "n_instances", "n_supermers", "n_buckets", "n_kmers", "n_unitigs", "unitig_total_bases",
-                  "n_circles", "rank_rounds", "buckets_split", "max_slots_used", "scratch_bytes"):
+                  "n_circles", "rank_rounds", "buckets_split", "max_slots_used", "scratch_bytes", "n_boundary",
+                  "n_fragments"):
             setattr(self, f, int(getattr(raw, f)))
         self.phase_ms = {PHASES[i]: float(raw.phase_ms[i]) for i in range(8) if PHASES[i] != "-"}
         self.kernel_ms = {"msp_hist": float(raw.kernel_ms[0]), "msp_scatter": float(raw.kernel_ms[1]),
                           "count": float(raw.kernel_ms[2])}
+        names = ("local_prune", "boundary", "fragments", "join", "table")
+        self.graph_ms = {names[i]: float(raw.graph_ms[i]) for i in range(5)}
 
     def _dl(self, ptr, nbytes, dtype, shape):
         out = np.empty(shape, dtype=dtype)

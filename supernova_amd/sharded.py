@@ -70,7 +70,12 @@ class TorchComm:
         self._a2a(rc, sc, [1] * self.world, [1] * self.world)
         recv_counts = [int(x) for x in rc.tolist()]
         recv = torch.empty(sum(recv_counts), dtype=torch.uint8, device=dev)
-        self._a2a(recv, send, recv_counts, list(send_counts))
+        # widest element type that divides every segment: multi-GB segments stay far below 2^31 elements
+        for width, dt in ((8, torch.int64), (4, torch.int32), (1, torch.uint8)):
+            if all(c % width == 0 for c in recv_counts) and all(c % width == 0 for c in send_counts) \
+                    and send.data_ptr() % width == 0 and recv.data_ptr() % width == 0:
+                break
+        self._a2a(recv.view(dt), send.view(dt), [c // width for c in recv_counts], [c // width for c in send_counts])
         return recv, recv_counts
 
     def all_to_all_equal(self, send: torch.Tensor) -> torch.Tensor:
@@ -169,7 +174,8 @@ COMP = np.array([3, 2, 1, 0], dtype=np.uint8)
 def canonicalize_circle(codes: np.ndarray, K: int) -> np.ndarray:
     """A closed circle sequence (n+K-1 bases, last K-1 == first K-1) cut at an arbitrary k-mer -> the reference's
     form: rotated to start at its minimum canonical k-mer in forward orientation (canonicalizeCircle,
-    BuildReadQGraph48.cc:375-397), then bvec-canonical (addEdge :481-485).  Host side: circles that span ranks are rare."""
+    BuildReadQGraph48.cc:375-397), then bvec-canonical (addEdge :481-485).  numpy statement of what the join's
+    jcircle_kernel does on the device; used by the tests only."""
     n = len(codes) - (K - 1)
     ring = codes[:n]
     best = None
@@ -230,14 +236,8 @@ class ShardedResult:
         u = self.joined
         off = self._dl(u.unitig_off, (u.n_unitigs + 1) * 8, np.uint64, (u.n_unitigs + 1,))
         bases = self._dl(u.unitig_bases, u.total_bases, np.uint8, (u.total_bases,))
-        circ = self._dl(u.unitig_circular, u.n_unitigs, np.uint8, (u.n_unitigs,))
         lut = np.frombuffer(b"ACGT", dtype=np.uint8)
-        out = []
-        for i in range(u.n_unitigs):
-            seg = bases[int(off[i]):int(off[i + 1])]
-            if circ[i]:
-                seg = canonicalize_circle(seg, self.K)
-            out.append(lut[seg].tobytes().decode())
+        out = [lut[bases[int(off[i]):int(off[i + 1])]].tobytes().decode() for i in range(u.n_unitigs)]
         out.sort(key=lambda s: (-len(s), s))
         return out
 

@@ -12,6 +12,13 @@ import oracle_lib
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["local", "global"], autouse=True)
+def graph_stage(request, monkeypatch):
+    """Every parity test runs twice: bucket-local graph stage (default) and the global one (cross-check)."""
+    monkeypatch.setenv("SNK_GLOBAL_GRAPH", "1" if request.param == "global" else "0")
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def engine(snk):
     import torch
@@ -255,3 +262,37 @@ def test_repeatability_and_full_size_properties(engine):
             rc = (3 - s[::-1]).astype(np.uint8)
             j = int(np.argmax(s != rc)) if (s != rc).any() else -1
             assert j < 0 or s[j] < rc[j]
+
+
+def test_unsorted_table_mode(engine, graph_stage):
+    """SNK_F_UNSORTED_TABLE: same table (as a set) and the same unitigs, keys left in bucket order."""
+    from supernova_amd.engine import Params
+    c = goldens.load("adversarial")
+    rows, quals, bc, lens = _to_dev(c)
+    res = engine.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, params=Params(K=48, sorted_table=False),
+                             ign_bc_below=c.ign_bc_below)
+    k, cnt, ctx = res.keys(), res.counts(), res.ctx()
+    order = np.lexsort((k[:, 2], k[:, 1], k[:, 0]))
+    assert np.array_equal(k[order][:, :3], c.exp_keys)
+    assert np.array_equal(np.minimum(cnt[order], (1 << 24) - 1), c.exp_counts)
+    assert np.array_equal(ctx[order], c.exp_ctx)
+    assert res.unitigs() == c.exp_unitigs
+    if graph_stage == "local":
+        assert res.n_fragments >= res.n_unitigs and res.n_boundary > 0
+
+
+def test_unitig_order_is_deterministic(engine, graph_stage):
+    """Unitigs leave the device ordered by their first K bases, independent of workgroup scheduling."""
+    c = goldens.load("synth_20k_err")
+    rows, quals, bc, lens = _to_dev(c)
+    outs = []
+    for _ in range(3):
+        res = engine.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, ign_bc_below=c.ign_bc_below)
+        off, bases = res.unitig_arrays()
+        outs.append((off.copy(), bases.copy()))
+    for o, b in outs[1:]:
+        assert np.array_equal(o, outs[0][0]) and np.array_equal(b, outs[0][1])
+    off, bases = outs[0]
+    firsts = [bytes(bases[int(off[i]):int(off[i]) + 48]) for i in range(len(off) - 1)]
+    if graph_stage == "local":
+        assert firsts == sorted(firsts)
