@@ -960,33 +960,26 @@ __global__ void __launch_bounds__(TB) jchunks_kernel(const uint64_t* __restrict_
     if (f >= F) return;
     nch[f] = (uint32_t)((boff[f + 1] - boff[f] + 255) / 256);
 }
-// fragments: length = k-mers + K - 1 (their start offsets need not be contiguous)
-__global__ void __launch_bounds__(TB) jchunks_nk_kernel(const uint32_t* __restrict__ nk, uint32_t K, uint64_t F, uint32_t* __restrict__ nch) {
-    uint64_t f = (uint64_t)blockIdx.x * TB + threadIdx.x;
-    if (f >= F) return;
-    nch[f] = (nk[f] + K - 1 + 255) / 256;
-}
 __global__ void __launch_bounds__(TB) jchunk_owner_kernel(const uint32_t* __restrict__ choff, uint64_t F, uint32_t* __restrict__ owner) {
     uint64_t f = (uint64_t)blockIdx.x * TB + threadIdx.x;
     if (f >= F) return;
     if (choff[f + 1] > choff[f]) owner[choff[f]] = (uint32_t)f;
 }
-// provisional unitig sequences: every fragment copies all of its bases (the K-1 overlaps write equal values)
-__global__ void __launch_bounds__(256) jemit_kernel(const uint32_t* __restrict__ owner, const uint32_t* __restrict__ choff,
-                                                    const uint64_t* __restrict__ boff, const uint8_t* __restrict__ fbases,
+// provisional unitig sequences: every fragment copies all of its bases (the K-1 overlaps write equal values).
+// Fragments are short (K-1 + ~17 bases): 8 lanes per fragment, 32 fragments per workgroup, no per-chunk owner tables.
+__global__ void __launch_bounds__(256) jemit_kernel(uint64_t F, const uint64_t* __restrict__ boff, const uint8_t* __restrict__ fbases,
                                                     const uint2* __restrict__ rk,
                                                     const uint32_t* __restrict__ nk, const uint64_t* __restrict__ poff,
                                                     uint32_t K, uint8_t* __restrict__ prov) {
-    const uint32_t item = blockIdx.x;
-    const uint32_t f = owner[item];
+    const uint64_t f = (uint64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+    if (f >= F) return;
+    const uint32_t sub = threadIdx.x & 7u;
     const uint64_t len = (uint64_t)nk[f] + K - 1;
-    const uint64_t p0 = (uint64_t)(item - choff[f]) * 256 + threadIdx.x;
-    if (p0 >= len) return;
-    frag_place p = frag_place_of(rk, nk, f);
-    const uint64_t base = poff[p.pid] + p.koff;
-    uint8_t b = fbases[boff[f] + p0];
-    if (!p.rc) prov[base + p0] = b;
-    else prov[base + (len - 1 - p0)] = (uint8_t)(b ^ 3u);
+    const frag_place p = frag_place_of(rk, nk, f);
+    const uint8_t* src = fbases + boff[f];
+    uint8_t* dst = prov + poff[p.pid] + p.koff;
+    if (!p.rc) for (uint64_t q = sub; q < len; q += 8) dst[q] = src[q];
+    else for (uint64_t q = sub; q < len; q += 8) dst[len - 1 - q] = (uint8_t)(src[q] ^ 3u);
 }
 // canonical form of every unitig (dna/CanonicalForm.h:35-48) decided on the provisional sequence
 __global__ void __launch_bounds__(TB) jform_kernel(const uint64_t* __restrict__ uoff, uint64_t U, const uint8_t* __restrict__ prov,
@@ -1332,13 +1325,8 @@ int snk_dist_join(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
     G_ALLOC(final_bases, uint8_t, h_tot + 1);
     hipLaunchKernelGGL(jhead_place_kernel, dim3(nblk(F)), dim3(TB), 0, st, rk, hflag, hidx, hoff, circ, F, poff, uoff, ucirc);
     SNK_HIP_TRY(hipMemcpyAsync(uoff + U, hoff + F, 8, hipMemcpyDeviceToDevice, st));
-    // copy every fragment into place (256-base work items)
-    uint32_t *nch, *choff, *owner, total_items = 0;
-    G_ALLOC(nch, uint32_t, F + 1);
-    SNK_HIP_TRY(hipMemsetAsync(nch + F, 0, 4, st));
-    hipLaunchKernelGGL(jchunks_nk_kernel, dim3(nblk(F)), dim3(TB), 0, st, nk, K, F, nch);
-    if ((rc = chunk_owners(ctx, st, nch, F, &choff, &owner, &total_items, err, errcap))) return rc;
-    if (total_items) hipLaunchKernelGGL(jemit_kernel, dim3(total_items), dim3(256), 0, st, owner, choff, boff, fbases, rk, nk, poff, K, prov);
+    // copy every fragment into place
+    hipLaunchKernelGGL(jemit_kernel, dim3((unsigned)((F + 31) / 32)), dim3(256), 0, st, F, boff, fbases, rk, nk, poff, K, prov);
     // circles that were cut at an arbitrary fragment boundary: rotate to the reference's cut (minimum k-mer, forward)
     {
         uint32_t *clist, *ccnt;

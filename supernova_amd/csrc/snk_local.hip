@@ -48,17 +48,26 @@ struct chunk_t {
     uint32_t bucket, n, lg, id;
     uint64_t base;
 };
-__device__ __forceinline__ chunk_t chunk_get(const chunk_src& cs, uint32_t c) {
-    chunk_t k;
-    uint32_t off = 0;
+// one 16-byte record per chunk (dense position, k-mers, bucket, split_lg << 24 | split_id): every chunk kernel starts
+// with ONE load instead of a chain of three dependent ones
+__global__ void __launch_bounds__(256) bl_chunk_desc_kernel(chunk_src cs, uint32_t nchunks, uint4* __restrict__ desc) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= nchunks) return;
+    uint32_t bucket, n, off = 0, meta = 0;
     if (c < cs.NB) {
-        k.bucket = c; k.n = cs.chunk_n[c]; k.lg = 0; k.id = 0;
-        if (k.n) off = cs.chunk_base[c];
+        bucket = c; n = cs.chunk_n[c];
+        if (n) off = cs.chunk_base[c];
     } else {
         const uint4 e = cs.extra[c - cs.NB];
-        k.bucket = e.x; off = e.y; k.n = e.z; k.lg = e.w >> 24; k.id = e.w & 0xFFFFFFu;
+        bucket = e.x; off = e.y; n = e.z; meta = e.w;
     }
-    k.base = cs.region_off[k.bucket % cs.n_regions] + off;
+    const uint64_t base = cs.region_off[bucket % cs.n_regions] + off;
+    desc[c] = make_uint4((uint32_t)base, n, bucket, meta);
+}
+__device__ __forceinline__ chunk_t chunk_get(const uint4* __restrict__ desc, uint32_t c) {
+    const uint4 d = desc[c];
+    chunk_t k;
+    k.base = d.x; k.n = d.y; k.bucket = d.z; k.lg = d.w >> 24; k.id = d.w & 0xFFFFFFu;
     return k;
 }
 
@@ -81,7 +90,7 @@ __device__ __forceinline__ uint32_t oriented_base(snk_kmer k, bool rc, int idx) 
 
 // ---------------------------------------------------------------------------------------------- L1: local prune
 template <int K, int CAP, int T, bool BIG>
-__global__ void __launch_bounds__(T) bl_prune_kernel(chunk_src cs, const uint32_t* __restrict__ biglist_in,
+__global__ void __launch_bounds__(T) bl_prune_kernel(const uint4* __restrict__ desc, uint32_t NB, const uint32_t* __restrict__ biglist_in,
                                                      const snk_u128* __restrict__ keys, const uint64_t* __restrict__ vals,
                                                      uint32_t do_prune, uint8_t* __restrict__ ctx_out,
                                                      uint32_t* __restrict__ count_out, uint8_t* __restrict__ pend_out,
@@ -93,7 +102,7 @@ __global__ void __launch_bounds__(T) bl_prune_kernel(chunk_src cs, const uint32_
     __shared__ uint32_t bcnt;
     const int tid = threadIdx.x;
     const uint32_t c = BIG ? biglist_in[blockIdx.x] : blockIdx.x;
-    const chunk_t ch = chunk_get(cs, c);
+    const chunk_t ch = chunk_get(desc, c);
     if (ch.n == 0) return;
     if (!BIG && ch.n > (uint32_t)CAP) {
         if (tid == 0) biglist[atomicAdd(nbig, 1u)] = c;
@@ -102,10 +111,18 @@ __global__ void __launch_bounds__(T) bl_prune_kernel(chunk_src cs, const uint32_
     const uint32_t n = ch.n;
     for (int s = tid; s < HT; s += T) ht[s] = 0;
     if (tid == 0) bcnt = 0;
-    for (uint32_t i = tid; i < n; i += T) {
-        const snk_kmer k = load_key(keys, ch.base + i);
-        khi[i] = k.hi;
-        klo[i] = k.lo;
+    constexpr int NPT = (CAP + T - 1) / T;             // nodes per thread
+    uint64_t myv[NPT];
+#pragma unroll
+    for (int q = 0; q < NPT; ++q) {
+        const uint32_t i = tid + q * T;
+        myv[q] = 0;
+        if (i < n) {
+            const snk_kmer k = load_key(keys, ch.base + i);
+            myv[q] = vals[ch.base + i];
+            khi[i] = k.hi;
+            klo[i] = k.lo;
+        }
     }
     __syncthreads();
     for (uint32_t i = tid; i < n; i += T) {
@@ -119,13 +136,19 @@ __global__ void __launch_bounds__(T) bl_prune_kernel(chunk_src cs, const uint32_
     __syncthreads();
     const uint32_t split_mask = (1u << ch.lg) - 1u;
     uint32_t mybnd = 0;
-    for (uint32_t i0 = 0; i0 < n; i0 += T) {
+    __shared__ uint16_t mlist[8 * T];        // misses of the current batch of T nodes: thread << 3 | bit
+    __shared__ uint32_t resL[T];             // per thread: keep bits | pending bits << 8 decided for its misses
+    __shared__ uint32_t mcnt;
+#pragma unroll
+    for (int q = 0; q < NPT; ++q) {
+        const uint32_t i0 = q * T;
+        if (i0 >= n) break;
         const uint32_t i = i0 + tid;
         const bool act = i < n;
         snk_kmer k;
         k.hi = act ? khi[i] : 0ull;
         k.lo = act ? klo[i] : 0ull;
-        const uint64_t v = act ? vals[ch.base + i] : 0ull;
+        const uint64_t v = myv[q];
         const uint32_t c0 = (uint32_t)(v & 0xFFu);
         uint32_t keep = 0, miss = 0, nb0 = NONE, nb1 = NONE;
         for (uint32_t bit = 0; bit < 8; ++bit) {
@@ -149,48 +172,75 @@ __global__ void __launch_bounds__(T) bl_prune_kernel(chunk_src cs, const uint32_
         }
         // Neighbours that are not in this chunk: absent for certain iff this very sub-pass would have counted them, i.e.
         // their minimiser bucket is this one (and their split hash this sub-pass's).  A neighbour shares all but one of
-        // its M-mers with k, so its minimum ordering key = min(minimum over the shared ones, key of the new M-mer): the
-        // 33 keys of k are evaluated once, by every lane of the wave together (no divergence), each miss costs one more.
-        uint32_t pm = 0;
-        if (__any(miss != 0)) {
-            uint32_t minA = 0xFFFFFFFFu, minB = 0xFFFFFFFFu;      // over M-mer positions 1..K-M (successors) / 0..K-M-1 (predecessors)
-            for (int p = 0; p + SNK_M <= K; ++p) {
-                uint64_t w;
-                if (p == 0) w = k.hi;
-                else if (p < 32) w = (k.hi << (2 * p)) | (k.lo >> (64 - 2 * p));
-                else if (p == 32) w = k.lo;
-                else w = k.lo << (2 * p - 64);
-                const uint32_t x = (uint32_t)(w >> 32);
-                const uint32_t key = snk_minimizer_key(x, snk_rev2_32(~x));
-                if (p > 0) minA = key < minA ? key : minA;
-                if (p + SNK_M < K) minB = key < minB ? key : minB;
-            }
-            for (uint32_t bit = 0; bit < 8; ++bit) {
-                if (!(miss & (1u << bit))) continue;
-                uint32_t x;      // the one M-mer of the neighbour that k does not have
-                if (bit < 4) {   // last M bases of succ(k, b): the last M-1 bases of k followed by b
-                    const snk_kmer y = snk_kmer_succ<K>(k, bit);
-                    constexpr int p = K - SNK_M;
-                    const uint64_t w = p < 32 ? ((y.hi << (2 * p)) | (y.lo >> (64 - 2 * p))) : (p == 32 ? y.lo : (y.lo << (2 * p - 64)));
-                    x = (uint32_t)(w >> 32);
-                } else {         // first M bases of pred(k, b)
-                    x = (uint32_t)(snk_kmer_pred<K>(k, bit - 4).hi >> 32);
+        // its M-mers with k, so its minimum ordering key = min(minimum over the K-M shared ones, key of the new M-mer).
+        // The misses of the batch (~0.15 per k-mer) are gathered into a dense list and classified by FOUR lanes each,
+        // which split the shared M-mers between them -- instead of every lane of the wave idling through the scan
+        // of the few lanes that have a miss.
+        if (tid == 0) mcnt = 0;
+        resL[tid] = 0;
+        __syncthreads();
+        if (miss) {
+            uint32_t pos = atomicAdd(&mcnt, (uint32_t)__popc(miss));
+            for (uint32_t bit = 0; bit < 8; ++bit)
+                if (miss & (1u << bit)) mlist[pos++] = (uint16_t)((tid << 3) | bit);
+        }
+        __syncthreads();
+        const uint32_t nm = mcnt;
+        constexpr int SH = K - SNK_M;            // shared M-mers of a k-mer and its neighbour
+        constexpr int PER = (SH + 3) / 4;
+        for (uint32_t it0 = 0; it0 < nm; it0 += T / 4) {
+            const uint32_t item = it0 + (tid >> 2), sub = tid & 3u;
+            const bool on = item < nm;
+            const uint32_t ent = on ? mlist[item] : 0u;
+            const uint32_t th = ent >> 3, bit = ent & 7u;
+            const uint32_t ni = i0 + th;
+            snk_kmer kk;
+            kk.hi = on ? khi[ni] : 0ull;
+            kk.lo = on ? klo[ni] : 0ull;
+            const int first = bit < 4 ? 1 : 0;   // successors share positions 1..K-M, predecessors 0..K-M-1
+            uint32_t mk = 0xFFFFFFFFu;
+            for (int t = 0; t < PER; ++t) {
+                const int sp = (int)sub * PER + t;
+                if (sp < SH) {
+                    const int pp = first + sp;
+                    uint64_t w;
+                    if (pp == 0) w = kk.hi;
+                    else if (pp < 32) w = (kk.hi << (2 * pp)) | (kk.lo >> (64 - 2 * pp));
+                    else if (pp == 32) w = kk.lo;
+                    else w = kk.lo << (2 * pp - 64);
+                    const uint32_t x = (uint32_t)(w >> 32);
+                    const uint32_t key = snk_minimizer_key(x, snk_rev2_32(~x));
+                    mk = key < mk ? key : mk;
                 }
+            }
+            { const uint32_t o = __shfl_xor(mk, 1); mk = o < mk ? o : mk; }
+            { const uint32_t o = __shfl_xor(mk, 2); mk = o < mk ? o : mk; }
+            if (on && sub == 0) {
+                const snk_kmer y = bit < 4 ? snk_kmer_succ<K>(kk, bit) : snk_kmer_pred<K>(kk, bit - 4);
+                uint32_t x;      // the one M-mer of the neighbour that k does not have
+                if (bit < 4) {
+                    constexpr int pl = K - SNK_M;
+                    const uint64_t w = pl < 32 ? ((y.hi << (2 * pl)) | (y.lo >> (64 - 2 * pl))) : (pl == 32 ? y.lo : (y.lo << (2 * pl - 64)));
+                    x = (uint32_t)(w >> 32);
+                } else x = (uint32_t)(y.hi >> 32);
                 const uint32_t nkey = snk_minimizer_key(x, snk_rev2_32(~x));
-                const uint32_t shared = bit < 4 ? minA : minB;
-                const uint32_t mk = nkey < shared ? nkey : shared;
-                bool here = snk_bucket_of_key(mk, cs.NB) == ch.bucket;
+                if (nkey < mk) mk = nkey;
+                bool here = snk_bucket_of_key(mk, NB) == ch.bucket;
                 if (here && ch.lg) {
-                    const snk_kmer y = bit < 4 ? snk_kmer_succ<K>(k, bit) : snk_kmer_pred<K>(k, bit - 4);
                     const snk_kmer r = snk_kmer_rc<K>(y);
                     uint32_t h1, h2;
                     snk_kmer_hash2(snk_kmer_lt(r, y) ? r : y, &h1, &h2);
                     here = (h2 & split_mask) == ch.id;
                 }
-                if (here) { if (!do_prune) keep |= 1u << bit; }
-                else { keep |= 1u << bit; pm |= 1u << bit; }
+                if (here) { if (!do_prune) atomicOr(&resL[th], 1u << bit); }
+                else atomicOr(&resL[th], (1u << bit) | (0x100u << bit));
             }
         }
+        __syncthreads();
+        const uint32_t res = resL[tid];
+        keep |= res & 0xFFu;
+        const uint32_t pm = res >> 8;
+        __syncthreads();
         if (!act) continue;
         const uint64_t gi = ch.base + i;
         ctx_out[gi] = (uint8_t)keep;
@@ -221,44 +271,70 @@ __global__ void __launch_bounds__(TB) bl_index_build_kernel(const snk_u128* __re
         slot = (slot + 1) & mask;
     }
 }
+// Only ~12 % of the k-mers have a pending bit: a workgroup scans 2048 pend bytes (8 per lane, one 8-byte load),
+// gathers the boundary k-mers into an LDS list and resolves them with all lanes busy.
 template <int K>
 __global__ void __launch_bounds__(TB) bl_resolve_kernel(const snk_u128* __restrict__ keys, const uint8_t* __restrict__ pend,
                                                         uint64_t n, const unsigned long long* __restrict__ tab, uint64_t mask,
                                                         uint32_t do_prune, uint8_t* __restrict__ ctx, uint32_t* __restrict__ rq) {
-    const uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t pm = pend[i];
-    if (!pm) return;
-    const snk_kmer k = load_key(keys, i);
-    uint32_t c = ctx[i];
-    for (uint32_t bit = 0; bit < 8; ++bit) {
-        if (!(pm & (1u << bit))) continue;
-        const snk_kmer y = bit < 4 ? snk_kmer_succ<K>(k, bit) : snk_kmer_pred<K>(k, bit - 4);
-        const snk_kmer r = snk_kmer_rc<K>(y);
-        const bool rev = snk_kmer_lt(r, y);
-        const snk_kmer cy = rev ? r : y;
-        uint32_t h1, h2;
-        snk_kmer_hash2(cy, &h1, &h2);
-        uint64_t slot = (((uint64_t)h1 << 32) | h2) & mask;
-        int64_t j = -1;
-        for (;;) {
-            const unsigned long long e = tab[slot];
-            if (e == 0ull) break;
-            if ((uint32_t)(e >> 32) == h1) {
-                const uint64_t idx = (uint32_t)e - 1u;
-                if (snk_kmer_eq(load_key(keys, idx), cy)) { j = (int64_t)idx; break; }
-            }
-            slot = (slot + 1) & mask;
+    constexpr int SPAN = 8 * TB;
+    __shared__ uint16_t list[SPAN];
+    __shared__ uint32_t cnt;
+    const uint64_t base = (uint64_t)blockIdx.x * SPAN;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    {
+        const uint64_t i8 = base + 8ull * threadIdx.x;
+        unsigned long long w = 0;
+        if (i8 + 8 <= n) w = *reinterpret_cast<const unsigned long long*>(pend + i8);    // pend is allocated with 16 spare bytes
+        else for (uint64_t q = i8; q < n; ++q) w |= (unsigned long long)pend[q] << (8 * (q - i8));
+        if (w) {
+            uint32_t m = 0;
+            for (int q = 0; q < 8; ++q) if ((w >> (8 * q)) & 0xFFull) ++m;
+            uint32_t pos = atomicAdd(&cnt, m);
+            for (int q = 0; q < 8; ++q) if ((w >> (8 * q)) & 0xFFull) list[pos++] = (uint16_t)(8 * threadIdx.x + q);
         }
-        if (j >= 0) rq[2 * i + (bit >> 2)] = ((uint32_t)j << 1) | (rev ? 1u : 0u);
-        else if (do_prune) c &= ~(1u << bit);
     }
-    ctx[i] = (uint8_t)c;
+    __syncthreads();
+    const uint32_t m = cnt;
+    for (uint32_t it = threadIdx.x; it < m; it += TB) {
+        const uint64_t i = base + list[it];
+        const uint32_t pm = pend[i];
+        const snk_kmer k = load_key(keys, i);
+        uint32_t c = ctx[i];
+        for (uint32_t bit = 0; bit < 8; ++bit) {
+            if (!(pm & (1u << bit))) continue;
+            const snk_kmer y = bit < 4 ? snk_kmer_succ<K>(k, bit) : snk_kmer_pred<K>(k, bit - 4);
+            const snk_kmer r = snk_kmer_rc<K>(y);
+            const bool rev = snk_kmer_lt(r, y);
+            const snk_kmer cy = rev ? r : y;
+            uint32_t h1, h2;
+            snk_kmer_hash2(cy, &h1, &h2);
+            uint64_t slot = (((uint64_t)h1 << 32) | h2) & mask;
+            int64_t j = -1;
+            for (;;) {
+                const unsigned long long e = tab[slot];
+                if (e == 0ull) break;
+                if ((uint32_t)(e >> 32) == h1) {
+                    const uint64_t idx = (uint32_t)e - 1u;
+                    if (snk_kmer_eq(load_key(keys, idx), cy)) { j = (int64_t)idx; break; }
+                }
+                slot = (slot + 1) & mask;
+            }
+            if (j >= 0) rq[2 * i + (bit >> 2)] = ((uint32_t)j << 1) | (rev ? 1u : 0u);
+            else if (do_prune) c &= ~(1u << bit);
+        }
+        ctx[i] = (uint8_t)c;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- L2: fragments
+// Paths inside a chunk are ranked by pointer jumping in LDS (<= log2(2n)+1 rounds over the 2n exit states), so every
+// node knows its fragment (= smaller terminal state), its position and its orientation, and writes its own base;
+// the K-base head k-mers are written by K lanes each.  COUNT pass: fragments per chunk (exact output sizing);
+// EMIT pass: the same ranking, then the writes.
 template <int K, int CAP, int T, bool BIG, bool EMIT>
-__global__ void __launch_bounds__(T) bl_frag_kernel(chunk_src cs, const uint32_t* __restrict__ biglist_in,
+__global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ desc, const uint32_t* __restrict__ biglist_in,
                                                     const snk_u128* __restrict__ keys, const uint8_t* __restrict__ ctx,
                                                     const uint8_t* __restrict__ pend, const uint32_t* __restrict__ nbr,
                                                     const uint32_t* __restrict__ rq, uint32_t* __restrict__ nfrag,
@@ -266,18 +342,23 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(chunk_src cs, const uint32_t
                                                     uint32_t* __restrict__ nk, unsigned long long* __restrict__ hl_self,
                                                     unsigned long long* __restrict__ hl_nb, uint64_t* __restrict__ bstart,
                                                     uint8_t* __restrict__ fbases) {
+    constexpr int SPT = (2 * CAP + T - 1) / T;        // states per thread
     __shared__ uint64_t khi[CAP], klo[CAP];
-    __shared__ uint32_t nbL[2 * CAP];
-    __shared__ uint16_t lnk[2 * CAP];
-    __shared__ uint8_t ctxL[CAP], pendL[CAP], palL[CAP], vis[CAP];
-    __shared__ uint32_t fcnt, bcnt;
+    __shared__ uint16_t nbL[2 * CAP];                  // local neighbour << 1 | rev (chunk-local indices fit 16 bits)
+    __shared__ uint16_t lnk[2 * CAP], nxt[2 * CAP], dst[2 * CAP], tl[2 * CAP];
+    __shared__ uint16_t foffL[2 * CAP];               // per pid terminal: offset of the fragment's bases inside the chunk's output
+    __shared__ uint16_t hnode[CAP];                    // heads: node << 1 | rc
+    __shared__ uint8_t ctxL[CAP], pendL[CAP], palL[CAP];
+    __shared__ uint32_t fcnt, bcnt, changed;
     const int tid = threadIdx.x;
     const uint32_t c = BIG ? biglist_in[blockIdx.x] : blockIdx.x;
-    const chunk_t ch = chunk_get(cs, c);
+    const chunk_t ch = chunk_get(desc, c);
     if (ch.n == 0) return;
     if (!BIG && ch.n > (uint32_t)CAP) return;
     const uint32_t n = ch.n;
-    if (tid == 0) { fcnt = 0; bcnt = 0; }
+    const uint32_t c_foff = EMIT ? foff[c] : 0u;       // issued now, needed after the ranking
+    const uint64_t c_boff = EMIT ? boff[c] : 0ull;
+    if (tid == 0) { fcnt = 0; bcnt = 0; changed = 0; }
     for (uint32_t i = tid; i < n; i += T) {
         const uint64_t gi = ch.base + i;
         const snk_kmer k = load_key(keys, gi);
@@ -286,9 +367,9 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(chunk_src cs, const uint32_t
         palL[i] = snk_kmer_eq(k, snk_kmer_rc<K>(k)) ? 1 : 0;
         ctxL[i] = ctx[gi];
         pendL[i] = pend[gi];
-        vis[i] = 0;
-        nbL[2 * i] = nbr[2 * gi];
-        nbL[2 * i + 1] = nbr[2 * gi + 1];
+        const uint32_t n0 = nbr[2 * gi], n1 = nbr[2 * gi + 1];
+        nbL[2 * i] = n0 == NONE ? NONE16 : (uint16_t)n0;
+        nbL[2 * i + 1] = n1 == NONE ? NONE16 : (uint16_t)n1;
     }
     __syncthreads();
     // reciprocal-unique links inside the chunk (BuildReadQGraph48.cc:408-428): state = node << 1 | exit side
@@ -301,7 +382,7 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(chunk_src cs, const uint32_t
             const uint32_t b = __ffs(bits) - 1;
             if (!((pendL[i] >> (4 * side + b)) & 1u)) {
                 const uint32_t nb = nbL[s];
-                if (nb != NONE) {
+                if (nb != NONE16) {
                     const uint32_t j = nb >> 1, rev = nb & 1u;
                     const uint32_t fs = side ^ 1u ^ rev;
                     const uint32_t cj = ctxL[j];
@@ -311,6 +392,42 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(chunk_src cs, const uint32_t
             }
         }
         lnk[s] = out;
+        if (out == NONE16) { nxt[s] = NONE16; dst[s] = 0; tl[s] = (uint16_t)s; }
+        else { nxt[s] = out ^ 1u; dst[s] = 1; tl[s] = out ^ 1u; }
+    }
+    __syncthreads();
+    // pointer jumping: nxt/dst/tl[s] = state reached / hops / terminal when leaving through exit state s
+    int max_rounds = 2;
+    while ((1u << (max_rounds - 1)) < 2 * n) ++max_rounds;
+    for (int round = 0; round < max_rounds; ++round) {
+        uint16_t rn[SPT], rd[SPT], rt[SPT];
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) {
+            const uint32_t s = tid + q * T;
+            rn[q] = NONE16;
+            if (s < 2 * n) {
+                const uint16_t n1 = nxt[s];
+                if (n1 != NONE16) {
+                    rn[q] = nxt[n1];
+                    rd[q] = (uint16_t)(dst[s] + dst[n1]);
+                    rt[q] = tl[n1];
+                    any = true;
+                } else { rd[q] = dst[s]; rt[q] = tl[s]; }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) {
+            const uint32_t s = tid + q * T;
+            if (s < 2 * n) { nxt[s] = rn[q]; dst[s] = rd[q]; tl[s] = rt[q]; }
+        }
+        if (any) changed = 1;
+        __syncthreads();
+        const bool go = changed != 0;
+        __syncthreads();
+        if (tid == 0) changed = 0;
+        if (!go) break;
     }
     __syncthreads();
 
@@ -332,54 +449,38 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(chunk_src cs, const uint32_t
         const uint32_t rev = a & 1u, fs = side ^ 1u ^ rev;
         return 2ull * (a >> 1) + fs;
     };
-    // write one fragment: `cnt` nodes starting at terminal state t (the node is read with side t&1 as its back)
-    auto emit = [&](uint32_t t, uint32_t other, uint32_t cnt, bool with_half) {
-        const uint32_t f = foff[c] + atomicAdd(&fcnt, 1u);
-        const uint64_t bo = boff[c] + atomicAdd(&bcnt, cnt + (uint32_t)K - 1u);
+    // fragment descriptor; returns the offset of its bases
+    auto describe = [&](uint32_t pid, uint32_t other, uint32_t cnt, bool with_half, uint32_t head_node, bool head_rc) {
+        const uint32_t lf = atomicAdd(&fcnt, 1u);
+        const uint32_t rel = atomicAdd(&bcnt, cnt + (uint32_t)K - 1u);
+        const uint64_t f = (uint64_t)c_foff + lf;
         nk[f] = cnt;
-        hl_self[2 * (uint64_t)f] = 2ull * ch.base + t;
-        hl_self[2 * (uint64_t)f + 1] = 2ull * ch.base + other;
-        hl_nb[2 * (uint64_t)f] = with_half ? half_link(t) : NONE64;
-        hl_nb[2 * (uint64_t)f + 1] = with_half ? half_link(other) : NONE64;
-        bstart[f] = bo;
-        snk_kmer k;
-        k.hi = khi[t >> 1];
-        k.lo = klo[t >> 1];
-        const bool rc0 = (t & 1u) == 0;
-        for (int b = 0; b < K; ++b) fbases[bo + b] = (uint8_t)oriented_base<K>(k, rc0, b);
-        uint32_t cur = t ^ 1u;
-        for (uint32_t pos = 1; pos < cnt; ++pos) {
-            const uint32_t l = lnk[cur];
-            const uint32_t j = l >> 1;
-            k.hi = khi[j];
-            k.lo = klo[j];
-            fbases[bo + (K - 1) + pos] = (uint8_t)oriented_base<K>(k, (l & 1u) == 0, K - 1);
-            cur = l ^ 1u;
-        }
+        hl_self[2 * f] = 2ull * ch.base + pid;
+        hl_self[2 * f + 1] = 2ull * ch.base + other;
+        hl_nb[2 * f] = with_half ? half_link(pid) : NONE64;
+        hl_nb[2 * f + 1] = with_half ? half_link(other) : NONE64;
+        bstart[f] = c_boff + rel;
+        foffL[pid] = (uint16_t)rel;
+        hnode[lf] = (uint16_t)((head_node << 1) | (head_rc ? 1u : 0u));
+        return rel;
     };
 
     uint32_t myfrags = 0;
-    for (uint32_t s = tid; s < 2 * n; s += T) {
-        if (lnk[s] != NONE16) continue;
-        uint32_t cur = s ^ 1u, len = 1;
-        vis[s >> 1] = 1;
-        for (;;) {
-            const uint32_t l = lnk[cur];
-            if (l == NONE16 || len > n) break;
-            vis[l >> 1] = 1;
-            cur = l ^ 1u;
-            ++len;
-        }
-        if (s < cur && len <= n) {
+    // nodes on open paths: position and orientation from the two ranks (walking from the smaller terminal)
+    for (uint32_t i = tid; i < n; i += T) {
+        if (nxt[2 * i] != NONE16) continue;               // on a circle
+        const uint32_t tR = tl[2 * i], tL = tl[2 * i + 1], dR = dst[2 * i], dL = dst[2 * i + 1];
+        const bool fwd = tL < tR;
+        const uint32_t pos = fwd ? dL : dR;
+        if (pos == 0) {
             ++myfrags;
-            if (EMIT) emit(s, cur, len, true);
+            if (EMIT) describe(fwd ? tL : tR, fwd ? tR : tL, dR + dL + 1u, true, i, !fwd);
         }
     }
-    __syncthreads();
-    // nodes no terminal walk reached lie on smooth circles inside the chunk: cut at the left side of the minimum k-mer
-    // (canonicalizeCircle, BuildReadQGraph48.cc:375-397); the circle's minimum node emits it
+    // nodes no terminal is reachable from lie on smooth circles inside the chunk: cut at the left side of the minimum
+    // k-mer (canonicalizeCircle, BuildReadQGraph48.cc:375-397); the circle's minimum node describes and writes it
     for (uint32_t i = tid; i < n; i += T) {
-        if (vis[i]) continue;
+        if (nxt[2 * i] == NONE16) continue;
         uint32_t cur = i << 1, mn = i, cnt = 1;
         bool closed = false;
         while (cnt <= n) {
@@ -394,9 +495,18 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(chunk_src cs, const uint32_t
         if (closed && mn == i) {
             ++myfrags;
             if (EMIT) {
-                uint32_t e = (i << 1) ^ 0u;     // exit state of the last node: walk cnt-1 links from (i, side 0)
+                uint32_t e = i << 1;                       // exit state of the last node: cnt-1 links from (i, side 0)
                 for (uint32_t q = 1; q < cnt; ++q) e = lnk[e] ^ 1u;
-                emit((i << 1) | 1u, e, cnt, false);
+                const uint32_t rel = describe((i << 1) | 1u, e, cnt, false, i, false);
+                uint32_t curs = i << 1;
+                for (uint32_t pos = 1; pos < cnt; ++pos) {
+                    const uint32_t l = lnk[curs];
+                    snk_kmer k;
+                    k.hi = khi[l >> 1];
+                    k.lo = klo[l >> 1];
+                    fbases[c_boff + rel + (K - 1) + pos] = (uint8_t)oriented_base<K>(k, (l & 1u) == 0, K - 1);
+                    curs = l ^ 1u;
+                }
             }
         }
     }
@@ -404,17 +514,49 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(chunk_src cs, const uint32_t
         if (myfrags) atomicAdd(&fcnt, myfrags);
         __syncthreads();
         if (tid == 0) nfrag[c] = fcnt;
+        return;
+    }
+    __syncthreads();
+    // every path node writes its last base at its position
+    for (uint32_t i = tid; i < n; i += T) {
+        if (nxt[2 * i] != NONE16) continue;
+        const uint32_t tR = tl[2 * i], tL = tl[2 * i + 1], dR = dst[2 * i], dL = dst[2 * i + 1];
+        const bool fwd = tL < tR;
+        const uint32_t pos = fwd ? dL : dR;
+        if (pos == 0) continue;
+        snk_kmer k;
+        k.hi = khi[i];
+        k.lo = klo[i];
+        fbases[c_boff + foffL[fwd ? tL : tR] + (K - 1) + pos] = (uint8_t)oriented_base<K>(k, !fwd, K - 1);
+    }
+    // head k-mers: K lanes per head
+    const uint32_t nheads = fcnt;
+    constexpr int HPI = T / 64;                            // heads per iteration: one wave each
+    for (uint32_t h0 = 0; h0 < nheads; h0 += HPI) {
+        const uint32_t h = h0 + (tid >> 6);
+        const int q = tid & 63;
+        if (h < nheads && q < K) {
+            const uint32_t hn = hnode[h];
+            const uint32_t i = hn >> 1;
+            const bool rc = hn & 1u;
+            // the head's pid: recompute from the node (circle heads: (i,1))
+            uint32_t pid;
+            if (nxt[2 * i] != NONE16) pid = (i << 1) | 1u;
+            else { const uint32_t tR = tl[2 * i], tL = tl[2 * i + 1]; pid = tL < tR ? tL : tR; }
+            snk_kmer k;
+            k.hi = khi[i];
+            k.lo = klo[i];
+            fbases[c_boff + foffL[pid] + q] = (uint8_t)oriented_base<K>(k, rc, q);
+        }
     }
 }
 
-__global__ void __launch_bounds__(TB) bl_chunk_bases_kernel(chunk_src cs, const uint32_t* __restrict__ nfrag, uint32_t nchunks,
+__global__ void __launch_bounds__(TB) bl_chunk_bases_kernel(const uint4* __restrict__ desc, const uint32_t* __restrict__ nfrag, uint32_t nchunks,
                                                             uint32_t K, uint64_t* __restrict__ nbases) {
     const uint32_t c = blockIdx.x * TB + threadIdx.x;
     if (c > nchunks) return;
     if (c == nchunks) { nbases[c] = 0; return; }
-    uint32_t n;
-    if (c < cs.NB) n = cs.chunk_n[c];
-    else n = cs.extra[c - cs.NB].z;
+    const uint32_t n = desc[c].y;
     nbases[c] = nfrag[c] ? (uint64_t)n + (uint64_t)(K - 1) * nfrag[c] : 0ull;
 }
 
@@ -485,6 +627,9 @@ static int local_graph_impl(snk_ctx* ctx, hipStream_t st, const snk_table* tab, 
     cs.n_extra = tab->n_extra;
     cs.n_regions = tab->n_regions;
     const uint32_t nchunks = tab->NB + tab->n_extra;
+    uint4* desc;
+    G_ALLOC(desc, uint4, (uint64_t)nchunks + 1);
+    hipLaunchKernelGGL(bl_chunk_desc_kernel, dim3((nchunks + 255) / 256), dim3(256), 0, st, cs, nchunks, desc);
     uint8_t *ctxo, *pend;
     uint32_t *counts, *nbr, *rq, *nbnd, *biglist, *ctr;
     G_ALLOC(ctxo, uint8_t, n + 16);
@@ -498,14 +643,14 @@ static int local_graph_impl(snk_ctx* ctx, hipStream_t st, const snk_table* tab, 
     SNK_HIP_TRY(hipMemsetAsync(nbnd, 0, ((uint64_t)nchunks + 1) * 4, st));
     SNK_HIP_TRY(hipMemsetAsync(ctr, 0, 64, st));
     SNK_HIP_TRY(hipMemsetAsync(rq, 0xFF, (2 * n + 2) * 4, st));
-    hipLaunchKernelGGL((bl_prune_kernel<K, SCAP, ST, false>), dim3(nchunks), dim3(ST), 0, st, cs, (const uint32_t*)nullptr,
+    hipLaunchKernelGGL((bl_prune_kernel<K, SCAP, ST, false>), dim3(nchunks), dim3(ST), 0, st, (const uint4*)desc, cs.NB, (const uint32_t*)nullptr,
                        tab->keys, tab->vals, do_prune, ctxo, counts, pend, nbr, nbnd, biglist, ctr);
     SNK_HIP_TRY(hipGetLastError());
     uint32_t h_nbig = 0;
     SNK_HIP_TRY(hipMemcpyAsync(&h_nbig, ctr, 4, hipMemcpyDeviceToHost, st));
     SNK_HIP_TRY(hipStreamSynchronize(st));
     if (h_nbig)
-        hipLaunchKernelGGL((bl_prune_kernel<K, BCAP, BT, true>), dim3(h_nbig), dim3(BT), 0, st, cs, (const uint32_t*)biglist,
+        hipLaunchKernelGGL((bl_prune_kernel<K, BCAP, BT, true>), dim3(h_nbig), dim3(BT), 0, st, (const uint4*)desc, cs.NB, (const uint32_t*)biglist,
                            tab->keys, tab->vals, do_prune, ctxo, counts, pend, nbr, nbnd, biglist, ctr);
     SNK_HIP_TRY(hipGetLastError());
     // boundary k-mers
@@ -531,7 +676,7 @@ static int local_graph_impl(snk_ctx* ctx, hipStream_t st, const snk_table* tab, 
     SNK_HIP_TRY(hipMemsetAsync(index, 0, tg * 8, st));
     if (h_bnd) {
         hipLaunchKernelGGL(bl_index_build_kernel, dim3(nblk(n)), dim3(TB), 0, st, tab->keys, pend, n, index, tg - 1);
-        hipLaunchKernelGGL((bl_resolve_kernel<K>), dim3(nblk(n)), dim3(TB), 0, st, tab->keys, pend, n, index, tg - 1, do_prune, ctxo, rq);
+        hipLaunchKernelGGL((bl_resolve_kernel<K>), dim3((unsigned)((n + 8 * TB - 1) / (8 * TB))), dim3(TB), 0, st, tab->keys, pend, n, index, tg - 1, do_prune, ctxo, rq);
     }
     SNK_HIP_TRY(hipGetLastError());
     tm.mark();  // 2
@@ -544,14 +689,14 @@ static int local_graph_impl(snk_ctx* ctx, hipStream_t st, const snk_table* tab, 
         G_ALLOC(nbases, uint64_t, (uint64_t)nchunks + 1);
         G_ALLOC(boff, uint64_t, (uint64_t)nchunks + 1);
         SNK_HIP_TRY(hipMemsetAsync(nfrag, 0, ((uint64_t)nchunks + 1) * 4, st));
-        hipLaunchKernelGGL((bl_frag_kernel<K, SCAP, ST, false, false>), dim3(nchunks), dim3(ST), 0, st, cs, (const uint32_t*)nullptr,
+        hipLaunchKernelGGL((bl_frag_kernel<K, SCAP, ST, false, false>), dim3(nchunks), dim3(ST), 0, st, (const uint4*)desc, (const uint32_t*)nullptr,
                            tab->keys, ctxo, pend, nbr, rq, nfrag, (const uint32_t*)nullptr, (const uint64_t*)nullptr, (uint32_t*)nullptr,
                            (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint64_t*)nullptr, (uint8_t*)nullptr);
         if (h_nbig)
-            hipLaunchKernelGGL((bl_frag_kernel<K, BCAP, BT, true, false>), dim3(h_nbig), dim3(BT), 0, st, cs, (const uint32_t*)biglist,
+            hipLaunchKernelGGL((bl_frag_kernel<K, BCAP, BT, true, false>), dim3(h_nbig), dim3(BT), 0, st, (const uint4*)desc, (const uint32_t*)biglist,
                                tab->keys, ctxo, pend, nbr, rq, nfrag, (const uint32_t*)nullptr, (const uint64_t*)nullptr, (uint32_t*)nullptr,
                                (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint64_t*)nullptr, (uint8_t*)nullptr);
-        hipLaunchKernelGGL(bl_chunk_bases_kernel, dim3(nblk((uint64_t)nchunks + 1)), dim3(TB), 0, st, cs, nfrag, nchunks, (uint32_t)K, nbases);
+        hipLaunchKernelGGL(bl_chunk_bases_kernel, dim3(nblk((uint64_t)nchunks + 1)), dim3(TB), 0, st, (const uint4*)desc, nfrag, nchunks, (uint32_t)K, nbases);
         SNK_HIP_TRY(hipGetLastError());
         int rc;
         if ((rc = excl_scan<uint32_t>(ctx, st, nfrag, foff, (size_t)nchunks + 1, err, errcap))) return rc;
@@ -570,10 +715,10 @@ static int local_graph_impl(snk_ctx* ctx, hipStream_t st, const snk_table* tab, 
         G_ALLOC(hl_nb, unsigned long long, 2ull * h_F + 2);
         G_ALLOC(bstart, uint64_t, (uint64_t)h_F + 2);
         G_ALLOC(fbases, uint8_t, h_B + 16);
-        hipLaunchKernelGGL((bl_frag_kernel<K, SCAP, ST, false, true>), dim3(nchunks), dim3(ST), 0, st, cs, (const uint32_t*)nullptr,
+        hipLaunchKernelGGL((bl_frag_kernel<K, SCAP, ST, false, true>), dim3(nchunks), dim3(ST), 0, st, (const uint4*)desc, (const uint32_t*)nullptr,
                            tab->keys, ctxo, pend, nbr, rq, nfrag, foff, boff, fnk, hl_self, hl_nb, bstart, fbases);
         if (h_nbig)
-            hipLaunchKernelGGL((bl_frag_kernel<K, BCAP, BT, true, true>), dim3(h_nbig), dim3(BT), 0, st, cs, (const uint32_t*)biglist,
+            hipLaunchKernelGGL((bl_frag_kernel<K, BCAP, BT, true, true>), dim3(h_nbig), dim3(BT), 0, st, (const uint4*)desc, (const uint32_t*)biglist,
                                tab->keys, ctxo, pend, nbr, rq, nfrag, foff, boff, fnk, hl_self, hl_nb, bstart, fbases);
         SNK_HIP_TRY(hipGetLastError());
         tm.mark();  // 3
