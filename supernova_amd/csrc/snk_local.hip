@@ -90,7 +90,7 @@ __device__ __forceinline__ uint32_t oriented_base(snk_kmer k, bool rc, int idx) 
 
 // ---------------------------------------------------------------------------------------------- L1: local prune
 template <int K, int CAP, int T, bool BIG>
-__global__ void __launch_bounds__(T) bl_prune_kernel(const uint4* __restrict__ desc, uint32_t NB, const uint32_t* __restrict__ biglist_in,
+__device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __restrict__ desc, uint32_t NB,
                                                      const snk_u128* __restrict__ keys, const uint64_t* __restrict__ vals,
                                                      uint32_t do_prune, uint8_t* __restrict__ ctx_out,
                                                      uint32_t* __restrict__ count_out, uint8_t* __restrict__ pend_out,
@@ -101,7 +101,6 @@ __global__ void __launch_bounds__(T) bl_prune_kernel(const uint4* __restrict__ d
     __shared__ uint32_t ht[HT];
     __shared__ uint32_t bcnt;
     const int tid = threadIdx.x;
-    const uint32_t c = BIG ? biglist_in[blockIdx.x] : blockIdx.x;
     const chunk_t ch = chunk_get(desc, c);
     if (ch.n == 0) return;
     if (!BIG && ch.n > (uint32_t)CAP) {
@@ -109,6 +108,7 @@ __global__ void __launch_bounds__(T) bl_prune_kernel(const uint4* __restrict__ d
         return;
     }
     const uint32_t n = ch.n;
+    __syncthreads();      // the previous chunk of this workgroup is done with the LDS arrays
     for (int s = tid; s < HT; s += T) ht[s] = 0;
     if (tid == 0) bcnt = 0;
     constexpr int NPT = (CAP + T - 1) / T;             // nodes per thread
@@ -151,8 +151,8 @@ __global__ void __launch_bounds__(T) bl_prune_kernel(const uint4* __restrict__ d
         const uint64_t v = myv[q];
         const uint32_t c0 = (uint32_t)(v & 0xFFu);
         uint32_t keep = 0, miss = 0, nb0 = NONE, nb1 = NONE;
-        for (uint32_t bit = 0; bit < 8; ++bit) {
-            if (!(c0 & (1u << bit))) continue;
+        for (uint32_t rem = c0; rem; rem &= rem - 1) {      // a k-mer has ~2 set bits: iterate over them, not over all 8
+            const uint32_t bit = __ffs(rem) - 1;
             const snk_kmer y = bit < 4 ? snk_kmer_succ<K>(k, bit) : snk_kmer_pred<K>(k, bit - 4);
             const snk_kmer r = snk_kmer_rc<K>(y);
             const bool rev = snk_kmer_lt(r, y);
@@ -254,6 +254,21 @@ __global__ void __launch_bounds__(T) bl_prune_kernel(const uint4* __restrict__ d
     __syncthreads();
     if (tid == 0) nbnd[c] = bcnt;
 }
+template <int K, int CAP, int T, bool BIG>
+__global__ void __launch_bounds__(T) bl_prune_kernel(const uint4* __restrict__ desc, uint32_t NB, const uint32_t* __restrict__ biglist_in,
+                                                     uint32_t nchunks, uint32_t cpw,
+                                                     const snk_u128* __restrict__ keys, const uint64_t* __restrict__ vals,
+                                                     uint32_t do_prune, uint8_t* __restrict__ ctx_out,
+                                                     uint32_t* __restrict__ count_out, uint8_t* __restrict__ pend_out,
+                                                     uint32_t* __restrict__ nbr_out, uint32_t* __restrict__ nbnd,
+                                                     uint32_t* __restrict__ biglist, uint32_t* __restrict__ nbig) {
+    for (uint32_t r = 0; r < cpw; ++r) {
+        const uint32_t w = blockIdx.x * cpw + r;
+        if (w >= nchunks) return;
+        bl_prune_chunk<K, CAP, T, BIG>(BIG ? biglist_in[w] : w, desc, NB, keys, vals, do_prune, ctx_out, count_out, pend_out, nbr_out,
+                                       nbnd, biglist, nbig);
+    }
+}
 
 // ---------------------------------------------------------------------------------------------- G: boundary index
 __global__ void __launch_bounds__(TB) bl_index_build_kernel(const snk_u128* __restrict__ keys, const uint8_t* __restrict__ pend,
@@ -302,8 +317,8 @@ __global__ void __launch_bounds__(TB) bl_resolve_kernel(const snk_u128* __restri
         const uint32_t pm = pend[i];
         const snk_kmer k = load_key(keys, i);
         uint32_t c = ctx[i];
-        for (uint32_t bit = 0; bit < 8; ++bit) {
-            if (!(pm & (1u << bit))) continue;
+        for (uint32_t rem = pm; rem; rem &= rem - 1) {
+            const uint32_t bit = __ffs(rem) - 1;
             const snk_kmer y = bit < 4 ? snk_kmer_succ<K>(k, bit) : snk_kmer_pred<K>(k, bit - 4);
             const snk_kmer r = snk_kmer_rc<K>(y);
             const bool rev = snk_kmer_lt(r, y);
@@ -404,6 +419,7 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
         bool any = false;
 #pragma unroll
         for (int q = 0; q < SPT; ++q) {
+            if ((uint32_t)(q * T) >= 2 * n) break;       // uniform: a typical chunk fills 4 of the 8 slots
             const uint32_t s = tid + q * T;
             rn[q] = NONE16;
             if (s < 2 * n) {
@@ -419,6 +435,7 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < SPT; ++q) {
+            if ((uint32_t)(q * T) >= 2 * n) break;
             const uint32_t s = tid + q * T;
             if (s < 2 * n) { nxt[s] = rn[q]; dst[s] = rd[q]; tl[s] = rt[q]; }
         }
@@ -643,15 +660,16 @@ static int local_graph_impl(snk_ctx* ctx, hipStream_t st, const snk_table* tab, 
     SNK_HIP_TRY(hipMemsetAsync(nbnd, 0, ((uint64_t)nchunks + 1) * 4, st));
     SNK_HIP_TRY(hipMemsetAsync(ctr, 0, 64, st));
     SNK_HIP_TRY(hipMemsetAsync(rq, 0xFF, (2 * n + 2) * 4, st));
-    hipLaunchKernelGGL((bl_prune_kernel<K, SCAP, ST, false>), dim3(nchunks), dim3(ST), 0, st, (const uint4*)desc, cs.NB, (const uint32_t*)nullptr,
-                       tab->keys, tab->vals, do_prune, ctxo, counts, pend, nbr, nbnd, biglist, ctr);
+    const uint32_t cpw = snk_env_u32("SNK_BL_CPW", 1);
+    hipLaunchKernelGGL((bl_prune_kernel<K, SCAP, ST, false>), dim3((nchunks + cpw - 1) / cpw), dim3(ST), 0, st, (const uint4*)desc, cs.NB, (const uint32_t*)nullptr,
+                       nchunks, cpw, tab->keys, tab->vals, do_prune, ctxo, counts, pend, nbr, nbnd, biglist, ctr);
     SNK_HIP_TRY(hipGetLastError());
     uint32_t h_nbig = 0;
     SNK_HIP_TRY(hipMemcpyAsync(&h_nbig, ctr, 4, hipMemcpyDeviceToHost, st));
     SNK_HIP_TRY(hipStreamSynchronize(st));
     if (h_nbig)
         hipLaunchKernelGGL((bl_prune_kernel<K, BCAP, BT, true>), dim3(h_nbig), dim3(BT), 0, st, (const uint4*)desc, cs.NB, (const uint32_t*)biglist,
-                           tab->keys, tab->vals, do_prune, ctxo, counts, pend, nbr, nbnd, biglist, ctr);
+                           h_nbig, 1u, tab->keys, tab->vals, do_prune, ctxo, counts, pend, nbr, nbnd, biglist, ctr);
     SNK_HIP_TRY(hipGetLastError());
     // boundary k-mers
     unsigned long long* d_sum;
