@@ -6,7 +6,9 @@
          bench.py --gpus N --steps K --warmup W
 
 One step = one pass of the hot path (trim -> minimiser partition -> [all-to-all] -> LDS count/filter ->
-sort -> prune -> unitigs) over one batch of synthetic reads that is already resident in HBM.
+bucket-local prune/links/fragments -> fragment join -> canonical unitigs) over one batch of synthetic reads that
+is already resident in HBM.  Outputs of a step, all on the device: the retained k-mer table (keys, counts, pruned
+contexts; in minimiser-bucket order unless --sorted-table), the k-mer spectrum and the canonical unitigs.
 N=1 workload: BASELINE.json configs[1], 100 M x 150 bp, k=48 (override with --reads).  N>1: weak
 scaling, every rank owns --reads reads of one (N x reads)-read data set, k-mer space sharded by
 minimiser bucket, one all-to-all of supermer records per step.
@@ -47,7 +49,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=float, default=1e6, help="reads of the workload timed on the host cores")
     ap.add_argument("--sharded", action="store_true", help="force the sharded (multi-GPU) code path even with one rank")
-    ap.add_argument("--unsorted-table", action="store_true", help="leave the retained table in bucket order (SNK_F_UNSORTED_TABLE)")
+    ap.add_argument("--sorted-table", action="store_true",
+                    help="also sort the retained k-mer table by key (+~40 ms; the reference's dictionary is an unordered hash set, "
+                         "the default leaves the table in minimiser-bucket order = SNK_F_UNSORTED_TABLE)")
     ap.add_argument("--global-graph", action="store_true", help="global graph stage instead of the bucket-local one")
     return ap.parse_args()
 
@@ -115,7 +119,7 @@ def main():
     sp = synth.synth_params(total_reads, seed=0x5EED0000 + (1 if world == 1 else 2), error_free=args.error_free)
     rows, quals, bc = eng.synth(sp, first=rank * per_gpu, n=per_gpu)
     torch.cuda.synchronize()
-    params = Params(K=K, sorted_table=not args.unsorted_table, global_graph=args.global_graph)
+    params = Params(K=K, sorted_table=args.sorted_table, global_graph=args.global_graph)
 
     if not use_dist:
         def step():
@@ -183,7 +187,7 @@ def main():
                        "retained_kmers_rank0": int(res.n_kmers), "unitigs_rank0": int(res.n_unitigs),
                        "phase_ms_rank0": {k: round(v, 3) for k, v in res.phase_ms.items()},
                        "graph_ms_rank0": {k: round(v, 3) for k, v in getattr(res, "graph_ms", {}).items()},
-                       "table_order": "bucket" if args.unsorted_table else "key",
+                       "table_order": "key" if args.sorted_table else "bucket",
                        "fragments_rank0": int(getattr(res, "n_fragments", 0))},
             "roofline": {"bound": "hbm", "kernel": "snk_count_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -143,10 +143,10 @@ typedef struct snk_dev_result {
     uint32_t rank_rounds;
     uint32_t buckets_split;
     uint32_t max_slots_used;
-    uint32_t reserved1;
+    uint32_t n_overflow;         /* supermers that did not fit their bucket's fixed capacity (second count segment) */
     uint64_t scratch_bytes;
-    float phase_ms[8];           /* trim, msp histogram, msp scatter, count, sort, prune+unitigs, -, total */
-    float kernel_ms[4];          /* HIP-event time of single launches: msp histogram, msp scatter, count (LDS reduce), - */
+    float phase_ms[8];           /* trim, partition plan, minimiser partition, count, sort, prune+unitigs, -, total */
+    float kernel_ms[4];          /* HIP-event time of single launches: -, minimiser partition, count (LDS reduce), - */
     uint64_t n_boundary;         /* bucket-local graph: k-mers with a neighbour outside their bucket chunk */
     uint64_t n_fragments;        /* bucket-local graph: local unitig fragments joined at the end */
     float graph_ms[8];           /* bucket-local graph: local prune, boundary resolve, fragments, join, table sort+spectrum */

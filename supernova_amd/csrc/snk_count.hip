@@ -91,8 +91,8 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
         const uint32_t split_mask = (1u << split_lg) - 1u;
 
         for (uint32_t seg = 0; seg < a.nseg; ++seg) {
-            const uint64_t beg = a.seg_off[(uint64_t)seg * (a.NB + 1) + bucket];
-            const uint64_t end = a.seg_off[(uint64_t)seg * (a.NB + 1) + bucket + 1];
+            const uint64_t beg = a.seg_beg[(uint64_t)seg * a.seg_stride + bucket];
+            const uint64_t end = a.seg_end[(uint64_t)seg * a.seg_stride + bucket];
             for (uint64_t base = beg; base < end; base += BATCH) {
                 // ---- stage one batch of supermer records (coalesced 32-byte loads) and scan their k-mer counts
                 const uint64_t idx = base + tid;

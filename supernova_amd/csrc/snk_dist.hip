@@ -99,7 +99,7 @@ extern "C" int snk_shard_count(snk_ctx* ctx, const void* d_records, const void* 
     if (!ctx || !ctx->shard || !d_seg_off) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_count: NULL argument / no session");
     snk_shard_state* S = state_of(ctx);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-    int rc = snk_stage_count_table(ctx, st, S->params.K, d_records, (const uint64_t*)d_seg_off, S->world, S->NBl, S->params.min_freq,
+    int rc = snk_stage_count_table(ctx, st, S->params.K, d_records, (const uint64_t*)d_seg_off, (const uint64_t*)d_seg_off + 1, S->NBl + 1, S->world, S->NBl, S->params.min_freq,
                                    has_bc ? S->params.min_bc : 0u, n_inst_hint, S->status, true, &S->tab, err, errcap);
     if (rc) return rc;
     if (n_kmers) *n_kmers = S->tab.n;

@@ -15,8 +15,16 @@
 // free).  The window minimum is computed without data-dependent control flow by the block
 // decomposition (suffix minima of window-sized blocks in an LDS column, running prefix minimum in a
 // register), so a wave never serialises on "rescan on expiry".  Supermer starts are appended to a
-// short per-thread LDS list and emitted in a second, short loop (histogram pass: one atomic per
-// supermer; scatter pass: slot reservation + one 32-byte record).
+// short per-thread LDS list and emitted in a second, short loop.
+//
+// Three modes share the scan:
+//   SINGLE (the one-GPU path): ONE pass.  Every bucket owns `cap` record slots (cap = expected supermers per bucket
+//          + 25 % + 4 sigma; the expectation is exact bookkeeping: k-mer instances are known after the trim, a
+//          random-order minimiser starts a supermer every (W+1)/2 k-mers); a supermer takes slot atomicAdd(cursor) of
+//          its bucket, the few that do not fit go to an overflow list that is grouped by bucket afterwards and read
+//          by the count kernel as a second segment.  Correctness never depends on the estimate.
+//   HIST / REPLAY (the sharded path, which needs exact, contiguous per-destination send buffers): pass 1 counts
+//          supermers per bucket and saves every read's supermer list, pass 2 replays the lists into exact offsets.
 //
 // Supermer record (32 B, two 16-byte stores), words MSB-first like a read row:
 //   bits [0, 2*n_ext)      the supermer bases including one flanking base on each side when the read
@@ -67,22 +75,18 @@ __device__ __forceinline__ uint32_t row_window(const uint32_t* rowL, int tid, ui
     return s ? ((w0 << s) | (w1 >> (32u - s))) : w0;
 }
 
-template <int K, int M, bool SCATTER>
-__global__ void __launch_bounds__(BD) snk_msp_kernel(const uint32_t* __restrict__ rows, uint32_t row_words,
-                                                     const uint16_t* __restrict__ good_len,
-                                                     const int32_t* __restrict__ bc, int64_t ign_bc_below,
-                                                     uint64_t read_index_base, uint64_t n_reads, uint32_t NB,
-                                                     uint32_t* __restrict__ hist_or_cursor,
-                                                     uint4* __restrict__ records,
-                                                     unsigned long long* __restrict__ n_inst_out,
-                                                     uint16_t* __restrict__ slist, uint8_t* __restrict__ scount) {
+enum { MSP_HIST = 0, MSP_REPLAY = 1, MSP_SINGLE = 2 };
+
+template <int K, int M, int MODE>
+__global__ void __launch_bounds__(BD) snk_msp_kernel(snk_msp_args a) {
     constexpr int W = K - M + 1;
+    constexpr bool WRITES = MODE != MSP_HIST;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t row_words = a.row_words;
+    const uint32_t NB = a.NB;
+    const uint64_t n_reads = a.n_reads;
     uint32_t* rowL = smem;                              // [row_words][BD]
-    // Only the POSITION of every suffix minimum is kept in LDS (1 byte per entry); its key is recomputed when the
-    // position changes (a few times per block).  Dropping the 4-byte key column cuts the LDS footprint from 59 KB
-    // to 26 KB per workgroup -> 6 instead of 2 workgroups per CU; the kernel is latency bound (PMC: 22 % VALU
-    // utilisation at 8 waves/CU), so occupancy is what pays.
+    // Only the POSITION of every suffix minimum is kept in LDS (1 byte per entry); the keys live in registers.
     uint16_t* lst = reinterpret_cast<uint16_t*>(rowL + (size_t)row_words * BD);   // [LCAP][BD] minimiser position << 8 | first k-mer
     uint8_t* sfxp = reinterpret_cast<uint8_t*>(lst + (size_t)LCAP * BD);  // [W][BD] position of the suffix minimum
     const int tid = threadIdx.x;
@@ -91,7 +95,7 @@ __global__ void __launch_bounds__(BD) snk_msp_kernel(const uint32_t* __restrict_
     {
         uint64_t nrows = n_reads - r0 < (uint64_t)BD ? n_reads - r0 : (uint64_t)BD;
         uint32_t total = (uint32_t)nrows * row_words;
-        const uint32_t* src = rows + r0 * row_words;
+        const uint32_t* src = a.rows + r0 * row_words;
         for (uint32_t idx = tid; idx < total; idx += BD) {
             uint32_t t = idx / row_words, w = idx - t * row_words;
             rowL[w * BD + t] = src[idx];
@@ -99,17 +103,23 @@ __global__ void __launch_bounds__(BD) snk_msp_kernel(const uint32_t* __restrict_
     }
     __syncthreads();
     const uint64_t r = r0 + tid;
-    int g = (r < n_reads) ? (int)good_len[r] : 0;
+    int g = (r < n_reads) ? (int)a.good_len[r] : 0;
     if (g < K + 1) g = 0;                               // reads with fewer than 2 k-mers are skipped (:160)
     const int nk = g ? g - K + 1 : 0;
     const int npos = g ? g - M + 1 : 0;
     int32_t mybc = 0;
-    if (SCATTER && g) mybc = (bc && (int64_t)(read_index_base + r) >= ign_bc_below) ? bc[r] : -1;
+    if (WRITES && g) mybc = (a.bc && (int64_t)(a.read_index_base + r) >= a.ign_bc_below) ? a.bc[r] : -1;
 
     int curpos = -1;              // minimiser position of the open supermer
     int cnt = 0;                  // closed+open supermer starts in the list
 
-    // emit list entries [0, upto) ; entry e covers k-mers [start_e, start_{e+1}-1], the last one ends at last_end
+    // emit list entries [0, upto) ; entry e covers k-mers [start_e, start_{e+1}-1], the last one ends at last_end.
+    // Measured on the 100 M-read workload (tools/msp_probe.py, SNK_MSP_DBG): scan + record stores 33 ms, the same with
+    // the 0.68 G slot reservations 65 ms, with the reservations issued but their return values unused 31 ms: random
+    // global atomics run at ~27 G/s (tools/probe/atomics.hip) and overlap with the scan when nobody waits for them, but
+    // a wave that needs the returned slot pays the full round trip.  Tried without gain: all reservations of a read
+    // issued before the records are built (16 more registers cost occupancy, 68 ms); software pipelining -- issue after
+    // block b, consume after block b+1 (69 ms); workgroup / wavefront scope (64 ms).
     auto flush = [&](int upto, int last_end) {
         int maxn = upto;
         for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(maxn, off); maxn = o > maxn ? o : maxn; }
@@ -119,104 +129,187 @@ __global__ void __launch_bounds__(BD) snk_msp_kernel(const uint32_t* __restrict_
                 uint32_t s = ent & 0xFFu;
                 uint32_t en = (e + 1 < upto) ? (((uint32_t)lst[(e + 1) * BD + tid] & 0xFFu) - 1u) : (uint32_t)last_end;
                 uint32_t bucket = mmer_bucket<M>(rowL, tid, row_words, (int)(ent >> 8), NB);
-                if (!SCATTER) {
-                    atomicAdd(&hist_or_cursor[bucket], 1u);
+                if (MODE == MSP_HIST) {
+                    atomicAdd(&a.hist_or_cursor[bucket], 1u);
                 } else {
-                    uint32_t slot = atomicAdd(&hist_or_cursor[bucket], 1u);
-                    uint32_t n_kmers = en - s + 1u;
-                    uint32_t hasL = s > 0 ? 1u : 0u;
-                    uint32_t hasR = (en + (uint32_t)K < (uint32_t)g) ? 1u : 0u;
-                    uint32_t a = s - hasL;
-                    uint32_t bits = 2u * (n_kmers + (uint32_t)K - 1u + hasL + hasR);
-                    uint32_t w[8];
-#pragma unroll
-                    for (uint32_t j = 0; j < 7; ++j) {
-                        uint32_t x = row_window(rowL, tid, row_words, a, j);
-                        uint32_t lo = 32u * j;
-                        if (bits <= lo) x = 0u;
-                        else if (bits - lo < 32u) x &= ~(0xFFFFFFFFu >> (bits - lo));
-                        w[j] = x;
+                    const uint32_t slot = a.dbg == 2 ? ((ent * 2654435761u) % (a.cap ? a.cap : 1u)) : (a.dbg == 3 ? __hip_atomic_fetch_add(&a.hist_or_cursor[bucket], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : (a.dbg == 4 ? __hip_atomic_fetch_add(&a.hist_or_cursor[bucket], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : atomicAdd(&a.hist_or_cursor[bucket], 1u)));
+                    uint64_t at = slot;                                    // REPLAY: the cursor holds absolute record offsets
+                    bool ok = true;
+                    if (MODE == MSP_SINGLE) {
+                        if (slot < a.cap) at = (uint64_t)bucket * a.cap + slot;
+                        else {
+                            const uint32_t o = atomicAdd(a.ovf_cursor, 1u);
+                            if (o < a.ovf_cap) { at = a.ovf_base + o; a.ovf_bucket[o] = bucket; }
+                            else ok = false;                               // the host sees ovf_cursor > ovf_cap and re-runs
+                        }
                     }
-                    w[6] |= n_kmers | (hasL << 7) | (hasR << 8);
-                    w[7] = (uint32_t)mybc;
-                    uint4* dst = records + (size_t)slot * 2;
-                    dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
-                    dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+                    if (ok && a.dbg != 1) {
+                        uint32_t n_kmers = en - s + 1u;
+                        uint32_t hasL = s > 0 ? 1u : 0u;
+                        uint32_t hasR = (en + (uint32_t)K < (uint32_t)g) ? 1u : 0u;
+                        uint32_t a0 = s - hasL;
+                        uint32_t bits = 2u * (n_kmers + (uint32_t)K - 1u + hasL + hasR);
+                        uint32_t w[8];
+#pragma unroll
+                        for (uint32_t j = 0; j < 7; ++j) {
+                            uint32_t x = row_window(rowL, tid, row_words, a0, j);
+                            uint32_t lo = 32u * j;
+                            if (bits <= lo) x = 0u;
+                            else if (bits - lo < 32u) x &= ~(0xFFFFFFFFu >> (bits - lo));
+                            w[j] = x;
+                        }
+                        w[6] |= n_kmers | (hasL << 7) | (hasR << 8);
+                        w[7] = (uint32_t)mybc;
+                        uint4* dst = a.records + at * 2;
+                        dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+                        dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+                    }
                 }
             }
         }
     };
 
-    // The histogram pass saves every read's supermer list (minimiser position, first k-mer; <= LCAP entries,
-    // [entry][read] so that a wave's accesses coalesce); the scatter pass replays it instead of scanning again.
-    // A read whose list overflowed is marked 0xFF and its wave falls back to the scan.
+    // REPLAY: the histogram pass saved every read's supermer list (minimiser position, first k-mer; <= LCAP entries,
+    // [entry][read] so that a wave's accesses coalesce).  A read whose list overflowed is marked 0xFF and its wave
+    // falls back to the scan.
     bool overflowed = false;
     bool replay = false;
-    if (SCATTER && scount) {
-        uint32_t sc = (r < n_reads) ? scount[r] : 0u;
+    if (MODE == MSP_REPLAY && a.scount) {
+        uint32_t sc = (r < n_reads) ? a.scount[r] : 0u;
         replay = !__any(sc == 0xFFu);
         if (replay) {
             cnt = (int)sc;
-            for (int e = 0; e < cnt; ++e) lst[e * BD + tid] = slist[(uint64_t)e * n_reads + r];
+            for (int e = 0; e < cnt; ++e) lst[e * BD + tid] = a.slist[(uint64_t)e * n_reads + r];
         }
     }
     const int nblocks = replay ? 0 : (nk + W - 1) / W;
     int maxblocks = nblocks;
     for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(maxblocks, off); maxblocks = o > maxblocks ? o : maxblocks; }
+    // Every ordering key is computed ONCE, by one forward roll over the read: x = the 16 bases at the current
+    // position, rx = their reverse complement, both updated with the next base (the row word is consumed two bits
+    // at a time; all lanes are at the same position, so the refill is a uniform branch).  kk[t] (registers, static
+    // indices -- both passes are fully unrolled) holds the raw keys of the next block after a forward pass and that
+    // block's suffix-minimum keys after its suffix pass.
+    static_assert(M == 16, "the rolling window below is one 32-bit word");
+    uint32_t kk[W];
+    uint32_t x = 0, rx = 0, cw = 0;
+    int rp = 0;                                  // position of x
+    auto roll = [&]() {                          // advance x/rx to position rp+1
+        const int nb = rp + M;                   // index of the incoming base
+        if ((nb & 15) == 0) { const uint32_t wi = (uint32_t)nb >> 4; cw = wi < row_words ? rowL[wi * BD + tid] : 0u; }
+        const uint32_t base = cw >> 30;
+        cw <<= 2;
+        x = (x << 2) | base;
+        rx = (rx >> 2) | ((base ^ 3u) << 30);
+        ++rp;
+    };
+    if (maxblocks > 0) {
+        x = rowL[tid];
+        rx = snk_rev2_32(~x);
+        cw = row_words > 1 ? rowL[BD + tid] : 0u;
+#pragma unroll
+        for (int t = 0; t < W; ++t) {            // raw keys of block 0
+            kk[t] = (t < npos) ? snk_minimizer_key(x, rx) : 0xFFFFFFFFu;
+            roll();
+        }
+    }
     for (int b = 0; b < maxblocks; ++b) {
         // suffix minima of block b (positions b*W .. b*W+W-1), right to left; "<=" keeps the leftmost on ties
         uint32_t run = 0xFFFFFFFFu;
         int runp = 0;
+#pragma unroll
         for (int t = W - 1; t >= 0; --t) {
-            int p = b * W + t;
-            if (p < npos) {
-                uint32_t key = mmer_key<M>(rowL, tid, row_words, p);
-                if (key <= run) { run = key; runp = p; }
-            }
+            const uint32_t key = kk[t];
+            if ((b * W + t) < npos && key <= run) { run = key; runp = b * W + t; }
+            kk[t] = run;
             sfxp[t * BD + tid] = (uint8_t)(run == 0xFFFFFFFFu ? 0xFF : runp);     // 0xFF: no valid position in this suffix
         }
-        // k-mers of block b: window = suffix of block b from t  U  prefix of block b+1 of length t
-        uint32_t pfx = 0xFFFFFFFFu;
-        int pfxp = 0;
-        uint32_t sv = 0xFFFFFFFFu;
-        int svp = -1;
-        for (int t = 0; t < W; ++t) {
-            int i = b * W + t;
-            const int sp = (int)sfxp[t * BD + tid];
-            if (sp != svp) { svp = sp; sv = sp == 0xFF ? 0xFFFFFFFFu : mmer_key<M>(rowL, tid, row_words, sp); }
-            int candp = (sv <= pfx) ? sp : pfxp;    // the suffix part lies left of the prefix part
-            bool isnew = (i < nk) && (candp != curpos);
-            if (__any(isnew && cnt == LCAP)) {     // some lane's list is full: every lane of the wave drains its list
-                // the open supermer (last entry) stays; flush() has wave-wide shuffles, so it is called uniformly
-                const int upto = cnt > 0 ? cnt - 1 : 0;
-                const int last_end = cnt > 0 ? (int)(lst[(cnt - 1) * BD + tid] & 0xFFu) - 1 : 0;
-                flush(upto, last_end);
-                overflowed = true;
-                if (cnt > 0) { lst[tid] = lst[(cnt - 1) * BD + tid]; cnt = 1; }
+        // k-mers of block b: window = suffix of block b from t  U  prefix of block b+1 of length t.  Fast path: no
+        // list drain inside the unrolled loop; a lane whose list is full only notes it, and the block is redone below.
+        const int curpos0 = curpos, cnt0 = cnt;
+        bool lost = false;
+        {
+            uint32_t pfx = 0xFFFFFFFFu;
+            int pfxp = 0;
+#pragma unroll
+            for (int t = 0; t < W; ++t) {
+                const int i = b * W + t;
+                const int sp = (int)sfxp[t * BD + tid];
+                const uint32_t sv = kk[t];
+                const int candp = (sv <= pfx) ? sp : pfxp;    // the suffix part lies left of the prefix part
+                const bool isnew = (i < nk) && (candp != curpos);
+                if (isnew) {
+                    curpos = candp;
+                    if (cnt < LCAP) { lst[cnt * BD + tid] = (uint16_t)(((uint32_t)candp << 8) | (uint32_t)i); ++cnt; }
+                    else lost = true;
+                }
+                const int p2 = (b + 1) * W + t;          // == rp: the roll is exactly one block ahead
+                const bool v2 = p2 < npos;
+                const uint32_t k2 = v2 ? snk_minimizer_key(x, rx) : 0xFFFFFFFFu;
+                kk[t] = k2;
+                if (v2 && k2 < pfx) { pfx = k2; pfxp = p2; }
+                roll();
             }
-            if (isnew) {
-                curpos = candp;
-                lst[cnt * BD + tid] = (uint16_t)(((uint32_t)candp << 8) | (uint32_t)i);   // minimiser position | first k-mer
-                ++cnt;
-            }
-            int p2 = (b + 1) * W + t;
-            if (p2 < npos) {
-                uint32_t k2 = mmer_key<M>(rowL, tid, row_words, p2);
-                if (k2 < pfx) { pfx = k2; pfxp = p2; }
+        }
+        if (__any(lost)) {
+            // some read of the wave has more than LCAP supermers (low-complexity sequence): redo this block with the
+            // list drained whenever it is full.  Keys come from the staged rows again (kk already holds block b+1).
+            curpos = curpos0;
+            cnt = cnt0;
+            uint32_t pfx = 0xFFFFFFFFu;
+            int pfxp = 0;
+            uint32_t sv = 0xFFFFFFFFu;
+            int svp = -1;
+            for (int t = 0; t < W; ++t) {
+                const int i = b * W + t;
+                const int sp = (int)sfxp[t * BD + tid];
+                if (sp != svp) { svp = sp; sv = sp == 0xFF ? 0xFFFFFFFFu : mmer_key<M>(rowL, tid, row_words, sp); }
+                const int candp = (sv <= pfx) ? sp : pfxp;
+                const bool isnew = (i < nk) && (candp != curpos);
+                if (__any(isnew && cnt == LCAP)) {     // every lane of the wave drains its list; the open supermer stays
+                    const int upto = cnt > 0 ? cnt - 1 : 0;
+                    const int last_end = cnt > 0 ? (int)(lst[(cnt - 1) * BD + tid] & 0xFFu) - 1 : 0;
+                    flush(upto, last_end);
+                    overflowed = true;
+                    if (cnt > 0) { lst[tid] = lst[(cnt - 1) * BD + tid]; cnt = 1; }
+                }
+                if (isnew) {
+                    curpos = candp;
+                    lst[cnt * BD + tid] = (uint16_t)(((uint32_t)candp << 8) | (uint32_t)i);
+                    ++cnt;
+                }
+                const int p2 = (b + 1) * W + t;
+                if (p2 < npos) {
+                    const uint32_t k2 = mmer_key<M>(rowL, tid, row_words, p2);
+                    if (k2 < pfx) { pfx = k2; pfxp = p2; }
+                }
             }
         }
     }
-    if (!SCATTER && scount && r < n_reads) {
-        scount[r] = overflowed ? (uint8_t)0xFF : (uint8_t)cnt;
-        if (!overflowed) for (int e = 0; e < cnt; ++e) slist[(uint64_t)e * n_reads + r] = lst[e * BD + tid];
+    if (MODE == MSP_HIST && a.scount && r < n_reads) {
+        a.scount[r] = overflowed ? (uint8_t)0xFF : (uint8_t)cnt;
+        if (!overflowed) for (int e = 0; e < cnt; ++e) a.slist[(uint64_t)e * n_reads + r] = lst[e * BD + tid];
     }
     flush(cnt, nk - 1);
 
-    if (!SCATTER) {
+    if (MODE != MSP_REPLAY && a.n_inst_out) {
         unsigned long long v = (unsigned long long)nk;
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        if ((tid & 63) == 0 && v) atomicAdd(n_inst_out, v);
+        if ((tid & 63) == 0 && v) atomicAdd(a.n_inst_out, v);
     }
+}
+
+// k-mer instances and reads that contribute any (exact sizing of the single pass)
+__global__ void __launch_bounds__(256) snk_msp_plan_kernel(const uint16_t* __restrict__ good_len, uint64_t n_reads, uint32_t K,
+                                                           unsigned long long* __restrict__ out /* [0] instances, [1] live reads */) {
+    unsigned long long inst = 0, live = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < n_reads; r += stride) {
+        const uint32_t g = good_len[r];
+        if (g >= K + 1) { inst += g - K + 1; ++live; }
+    }
+    for (int off = 32; off > 0; off >>= 1) { inst += __shfl_xor(inst, off); live += __shfl_xor(live, off); }
+    if ((threadIdx.x & 63) == 0 && live) { atomicAdd(&out[0], inst); atomicAdd(&out[1], live); }
 }
 
 }  // namespace
@@ -225,35 +318,50 @@ size_t snk_msp_lds_bytes(uint32_t K, uint32_t M, uint32_t row_words) {
     return (size_t)row_words * BD * 4 + (size_t)LCAP * BD * 2 + (size_t)(K - M + 1) * BD + 64;
 }
 
-template <int K, int M>
-static int launch_msp(bool scatter, hipStream_t st, const uint32_t* rows, uint32_t row_words, const uint16_t* good_len,
-                      const int32_t* bc, int64_t ign_bc_below, uint64_t read_index_base, uint64_t n_reads, uint32_t NB,
-                      uint32_t* hist_or_cursor, void* records, unsigned long long* n_inst, uint16_t* slist, uint8_t* scount,
-                      char* err, size_t errcap) {
-    size_t lds = snk_msp_lds_bytes(K, M, row_words);
-    unsigned nb = (unsigned)((n_reads + BD - 1) / BD);
-    if (scatter) {
-        SNK_HIP_TRY(hipFuncSetAttribute((const void*)snk_msp_kernel<K, M, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((snk_msp_kernel<K, M, true>), dim3(nb), dim3(BD), lds, st, rows, row_words, good_len, bc,
-                           ign_bc_below, read_index_base, n_reads, NB, hist_or_cursor, (uint4*)records, n_inst, slist, scount);
-    } else {
-        SNK_HIP_TRY(hipFuncSetAttribute((const void*)snk_msp_kernel<K, M, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((snk_msp_kernel<K, M, false>), dim3(nb), dim3(BD), lds, st, rows, row_words, good_len, bc,
-                           ign_bc_below, read_index_base, n_reads, NB, hist_or_cursor, (uint4*)records, n_inst, slist, scount);
-    }
+template <int K, int M, int MODE>
+static int launch_msp_mode(hipStream_t st, const snk_msp_args& a, char* err, size_t errcap) {
+    size_t lds = snk_msp_lds_bytes(K, M, a.row_words);
+    unsigned nb = (unsigned)((a.n_reads + BD - 1) / BD);
+    SNK_HIP_TRY(hipFuncSetAttribute((const void*)snk_msp_kernel<K, M, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((snk_msp_kernel<K, M, MODE>), dim3(nb), dim3(BD), lds, st, a);
     SNK_HIP_TRY(hipGetLastError());
     return SNK_OK;
+}
+template <int K>
+static int launch_msp_k(int mode, hipStream_t st, const snk_msp_args& a, char* err, size_t errcap) {
+    if (mode == MSP_HIST) return launch_msp_mode<K, SNK_M, MSP_HIST>(st, a, err, errcap);
+    if (mode == MSP_REPLAY) return launch_msp_mode<K, SNK_M, MSP_REPLAY>(st, a, err, errcap);
+    return launch_msp_mode<K, SNK_M, MSP_SINGLE>(st, a, err, errcap);
+}
+
+int snk_launch_msp_args(uint32_t K, int mode, hipStream_t st, const snk_msp_args& a, char* err, size_t errcap) {
+    if (a.n_reads == 0) return SNK_OK;
+    if (a.row_words > 16) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "reads longer than 256 bases are not supported (row_words=%u)", a.row_words);
+    if (K == 48) return launch_msp_k<48>(mode, st, a, err, errcap);
+    if (K == 60) return launch_msp_k<60>(mode, st, a, err, errcap);
+    return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "K=%u is not supported (48 or 60)", K);
 }
 
 int snk_launch_msp(uint32_t K, bool scatter, hipStream_t st, const uint32_t* rows, uint32_t row_words,
                    const uint16_t* good_len, const int32_t* bc, int64_t ign_bc_below, uint64_t read_index_base,
                    uint64_t n_reads, uint32_t NB, uint32_t* hist_or_cursor, void* records, unsigned long long* n_inst,
                    uint16_t* slist, uint8_t* scount, char* err, size_t errcap) {
-    if (n_reads == 0) return SNK_OK;
-    if (row_words > 16) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "reads longer than 256 bases are not supported (row_words=%u)", row_words);
-    if (K == 48)
-        return launch_msp<48, SNK_M>(scatter, st, rows, row_words, good_len, bc, ign_bc_below, read_index_base, n_reads, NB, hist_or_cursor, records, n_inst, slist, scount, err, errcap);
-    if (K == 60)
-        return launch_msp<60, SNK_M>(scatter, st, rows, row_words, good_len, bc, ign_bc_below, read_index_base, n_reads, NB, hist_or_cursor, records, n_inst, slist, scount, err, errcap);
-    return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "K=%u is not supported (48 or 60)", K);
+    snk_msp_args a;
+    memset(&a, 0, sizeof a);
+    a.rows = rows; a.row_words = row_words; a.good_len = good_len; a.bc = bc; a.ign_bc_below = ign_bc_below;
+    a.read_index_base = read_index_base; a.n_reads = n_reads; a.NB = NB; a.hist_or_cursor = hist_or_cursor;
+    a.records = (uint4*)records; a.n_inst_out = n_inst; a.slist = slist; a.scount = scount;
+    return snk_launch_msp_args(K, scatter ? MSP_REPLAY : MSP_HIST, st, a, err, errcap);
+}
+
+int snk_launch_msp_plan(hipStream_t st, const uint16_t* good_len, uint64_t n_reads, uint32_t K, unsigned long long* out2,
+                        char* err, size_t errcap) {
+    SNK_HIP_TRY(hipMemsetAsync(out2, 0, 16, st));
+    if (n_reads) {
+        unsigned g = (unsigned)((n_reads + 255) / 256);
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(snk_msp_plan_kernel, dim3(g), dim3(256), 0, st, good_len, n_reads, K, out2);
+    }
+    SNK_HIP_TRY(hipGetLastError());
+    return SNK_OK;
 }

@@ -21,8 +21,8 @@ uint32_t snk_env_u32(const char* name, uint32_t dflt) {
 
 // K5-K8 + gather + sort: supermer records of NB buckets (nseg segments) -> dense retained table sorted by key.
 // status: device u32[16] scratch words.
-int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* records, const uint64_t* seg_off,
-                          uint32_t nseg, uint32_t NB, uint32_t min_freq, uint32_t bc_mode, uint64_t n_inst_hint,
+int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* records, const uint64_t* seg_beg,
+                          const uint64_t* seg_end, uint32_t seg_stride, uint32_t nseg, uint32_t NB, uint32_t min_freq, uint32_t bc_mode, uint64_t n_inst_hint,
                           uint32_t* status, bool want_sort, snk_table* out, char* err, size_t errcap) {
     int rc;
     snk_phase_timer tm(st), kt(st);
@@ -65,7 +65,9 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
         SNK_HIP_TRY(hipMemsetAsync(status, 0, 32, st));
         snk_count_args ca;
         ca.records = (const uint4*)records;
-        ca.seg_off = seg_off;
+        ca.seg_beg = seg_beg;
+        ca.seg_end = seg_end;
+        ca.seg_stride = seg_stride;
         ca.nseg = nseg;
         ca.NB = NB;
         ca.min_freq = min_freq;

@@ -46,7 +46,7 @@ class Result:
         self.raw = raw
         self.K = K
         for f in ("n_reads", "n_instances", "n_supermers", "n_buckets", "n_kmers", "n_unitigs", "unitig_total_bases",
-                  "n_circles", "rank_rounds", "buckets_split", "max_slots_used", "scratch_bytes", "n_boundary",
+                  "n_circles", "rank_rounds", "buckets_split", "max_slots_used", "scratch_bytes", "n_boundary", "n_overflow",
                   "n_fragments"):
             setattr(self, f, int(getattr(raw, f)))
         self.phase_ms = {PHASES[i]: float(raw.phase_ms[i]) for i in range(8) if PHASES[i] != "-"}

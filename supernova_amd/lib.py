@@ -47,7 +47,7 @@ class SnkDevResult(C.Structure):
                 ("counts", C.c_void_p), ("ctx", C.c_void_p), ("spectrum", C.c_void_p), ("spectrum_bins", C.c_uint32),
                 ("n_circles", C.c_uint32), ("n_unitigs", C.c_uint64), ("unitig_total_bases", C.c_uint64),
                 ("unitig_off", C.c_void_p), ("unitig_bases", C.c_void_p), ("rank_rounds", C.c_uint32),
-                ("buckets_split", C.c_uint32), ("max_slots_used", C.c_uint32), ("reserved1", C.c_uint32),
+                ("buckets_split", C.c_uint32), ("max_slots_used", C.c_uint32), ("n_overflow", C.c_uint32),
                 ("scratch_bytes", C.c_uint64), ("phase_ms", C.c_float * 8), ("kernel_ms", C.c_float * 4),
                 ("n_boundary", C.c_uint64), ("n_fragments", C.c_uint64), ("graph_ms", C.c_float * 8)]
 

@@ -296,3 +296,16 @@ def test_unitig_order_is_deterministic(engine, graph_stage):
     firsts = [bytes(bases[int(off[i]):int(off[i]) + 48]) for i in range(len(off) - 1)]
     if graph_stage == "local":
         assert firsts == sorted(firsts)
+
+
+@pytest.mark.parametrize("pct", [100, 60, 10])
+def test_partition_overflow_segment(engine, monkeypatch, pct):
+    """The single-pass minimiser partition gives every bucket a fixed number of record slots; supermers beyond it go
+    through the overflow list (second count segment).  Shrinking the capacity must not change any result."""
+    monkeypatch.setenv("SNK_MSP_CAP_PCT", str(pct))
+    c = goldens.load("synth_20k_err")
+    rows, quals, bc, lens = _to_dev(c)
+    res = engine.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, ign_bc_below=c.ign_bc_below)
+    _check_against(res, c.exp_keys, c.exp_counts, c.exp_ctx, c.exp_unitigs, c.exp_goodlens, c.exp_hist)
+    if pct < 100:
+        assert res.n_overflow > 0
