@@ -181,7 +181,7 @@ int snk_shard_prune_apply(snk_ctx* ctx, const void* d_qbuf, const void* d_ans, u
                           char* err, size_t errcap);
 typedef struct snk_shard_frags {
     uint64_t n_kmers;            /* this rank's share of the retained table */
-    const void* keys;            /* as snk_dev_result.keys */
+    const void* keys;            /* as snk_dev_result.keys, in bucket order (not sorted) */
     const void* counts;
     const void* ctx;
     const void* spectrum;
@@ -192,7 +192,7 @@ typedef struct snk_shard_frags {
     const void* nk;              /* u32[n_frags] k-mers per fragment */
     const void* hl_self;         /* u64[2*n_frags] global state id of each fragment end */
     const void* hl_nb;           /* u64[2*n_frags] global state id the end wants to link to, or ~0 */
-    const void* boff;            /* u64[n_frags+1] */
+    const void* boff;            /* u64[n_frags] offset of every fragment's bases (nk + K - 1 of them) in `bases` */
     const void* bases;           /* u8 base codes */
     uint32_t rank_rounds, buckets_split, max_slots_used, reserved;
     float count_ms, sort_ms, count_kernel_ms, reserved_f;
@@ -204,7 +204,7 @@ typedef struct snk_shard_unitigs {
     uint64_t n_unitigs, total_bases;
     const void* unitig_off;      /* u64[n_unitigs+1] */
     const void* unitig_bases;    /* u8 base codes, canonical orientation */
-    const void* unitig_circular; /* u8[n_unitigs]: circle spanning ranks, cut at an arbitrary k-mer (host rotates) */
+    const void* unitig_circular; /* u8[n_unitigs]: 1 = a circle that spanned fragments (already rotated to the reference's cut) */
     uint32_t n_circles, rank_rounds;
 } snk_shard_unitigs;
 /* rank 0: join the gathered fragments of every rank (tada MAIN_ASM_SN build_edges) */

@@ -29,6 +29,7 @@ struct snk_shard_state {
     uint8_t* scount = nullptr;
     snk_table tab{};
     snk_dist_graph g{};
+    snk_bl_state bl{};
     snk_phase_timer* tm = nullptr;
 };
 
@@ -100,7 +101,7 @@ extern "C" int snk_shard_count(snk_ctx* ctx, const void* d_records, const void* 
     snk_shard_state* S = state_of(ctx);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     int rc = snk_stage_count_table(ctx, st, S->params.K, d_records, (const uint64_t*)d_seg_off, (const uint64_t*)d_seg_off + 1, S->NBl + 1, S->world, S->NBl, S->params.min_freq,
-                                   has_bc ? S->params.min_bc : 0u, n_inst_hint, S->status, true, &S->tab, err, errcap);
+                                   has_bc ? S->params.min_bc : 0u, n_inst_hint, S->status, false, &S->tab, err, errcap);
     if (rc) return rc;
     if (n_kmers) *n_kmers = S->tab.n;
     return SNK_OK;
@@ -110,23 +111,29 @@ extern "C" int snk_shard_prune_plan(snk_ctx* ctx, uint64_t* h_qcount, void* stre
     if (!ctx || !ctx->shard || !h_qcount) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_prune_plan: NULL argument / no session");
     snk_shard_state* S = state_of(ctx);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    // bucket-local prune (snk_local.hip); only neighbours owned by another rank become queries
+    snk_bl_state& B = S->bl;
+    memset(&B, 0, sizeof B);
+    B.tab = &S->tab;
+    B.K = S->params.K; B.rank = S->rank; B.world = S->world; B.NB_total = S->NB_total; B.NBl = S->NBl;
+    B.do_prune = S->params.min_freq > 1 ? 1u : 0u;
+    std::vector<unsigned long long> h(S->world);
+    int rc = snk_bl_dist_plan(ctx, st, &B, h.data(), err, errcap);
+    if (rc) return rc;
+    for (uint32_t r = 0; r < S->world; ++r) h_qcount[r] = h[r];
+    // the answering / applying kernels of the global sharded stage work on the same arrays
     snk_dist_graph& g = S->g;
     memset(&g, 0, sizeof g);
-    g.K = S->params.K; g.rank = S->rank; g.world = S->world; g.NB_total = S->NB_total; g.NBl = S->NBl;
-    g.do_prune = S->params.min_freq > 1 ? 1u : 0u;
+    g.K = B.K; g.rank = B.rank; g.world = B.world; g.NB_total = B.NB_total; g.NBl = B.NBl; g.do_prune = B.do_prune;
     g.n = S->tab.n; g.keys = S->tab.keys; g.vals = S->tab.vals;
-    int rc = snk_dist_prune_plan(ctx, st, &g, err, errcap);
-    if (rc) return rc;
-    std::vector<unsigned long long> h(S->world);
-    SNK_HIP_TRY(hipMemcpyAsync(h.data(), g.qcount, S->world * 8ull, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
-    for (uint32_t r = 0; r < S->world; ++r) h_qcount[r] = h[r];
+    g.index = B.index; g.index_mask = B.index_mask;
+    g.ctx = B.ctx; g.counts = B.counts; g.rq_idx = B.rq_idx; g.rq_meta = B.rq_meta;
     return SNK_OK;
 }
 extern "C" int snk_shard_prune_fill(snk_ctx* ctx, const void* d_qoff, void* d_qbuf, void* stream, char* err, size_t errcap) {
     if (!ctx || !ctx->shard || !d_qoff) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_prune_fill: NULL argument / no session");
     snk_shard_state* S = state_of(ctx);
-    return snk_dist_fill_queries(ctx, stream ? (hipStream_t)stream : ctx->stream, &S->g, (const unsigned long long*)d_qoff, d_qbuf, err, errcap);
+    return snk_bl_dist_fill(ctx, stream ? (hipStream_t)stream : ctx->stream, &S->bl, (const unsigned long long*)d_qoff, d_qbuf, err, errcap);
 }
 extern "C" int snk_shard_prune_answer(snk_ctx* ctx, const void* d_queries, uint64_t nq, void* d_ans, void* stream, char* err, size_t errcap) {
     if (!ctx || !ctx->shard) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_prune_answer: no session");
@@ -146,13 +153,13 @@ extern "C" int snk_shard_fragments(snk_ctx* ctx, const void* d_node_off, uint64_
     snk_shard_state* S = state_of(ctx);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     snk_frag_out fo;
-    int rc = snk_dist_fragments(ctx, st, &S->g, (const unsigned long long*)d_node_off, my_node_off, &fo, err, errcap);
+    int rc = snk_bl_dist_fragments(ctx, st, &S->bl, (const unsigned long long*)d_node_off, my_node_off, &fo, err, errcap);
     if (rc) return rc;
     memset(out, 0, sizeof *out);
     out->n_kmers = S->tab.n;
     out->keys = S->tab.keys;
-    out->counts = S->g.counts;
-    out->ctx = S->g.ctx;
+    out->counts = S->bl.counts;
+    out->ctx = S->bl.ctx;
     out->spectrum = fo.spectrum;
     out->spectrum_bins = fo.spectrum_bins;
     out->n_frags = fo.n_frags;

@@ -73,6 +73,24 @@ int snk_dist_join(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
 
 // ---- bucket-local graph stage (snk_local.hip): table in chunk order -> pruned contexts + canonical unitigs
 struct snk_table;
+struct snk_bl_state {          // device arrays of the bucket-local stage (indexed by table position / chunk)
+    const snk_table* tab;
+    uint32_t K, rank, world, NB_total, NBl, do_prune, force_dist;
+    uint4* desc;
+    uint32_t nchunks, nbig;
+    uint32_t* biglist;
+    uint8_t *ctx, *pend, *premote;
+    uint32_t *counts, *nbr, *rq;
+    uint32_t* rq_idx;          // sharded: answers of the remote membership queries
+    uint16_t* rq_meta;
+    unsigned long long* index; // boundary k-mers only
+    uint64_t index_mask, n_boundary;
+    unsigned long long *qcount, *qcursor;
+};
+int snk_bl_dist_plan(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, unsigned long long* h_qcount, char* err, size_t errcap);
+int snk_bl_dist_fill(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, const unsigned long long* d_qoff, void* d_qbuf, char* err, size_t errcap);
+int snk_bl_dist_fragments(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, const unsigned long long* d_node_off, unsigned long long my_node_off,
+                          snk_frag_out* out, char* err, size_t errcap);
 int snk_local_graph(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_table* tab, uint32_t do_prune, bool want_unitigs,
                     bool sort_table, snk_graph_out* out, snk_u128** keys_final, float* ms /* [5] or NULL */, char* err, size_t errcap);
 int snk_launch_spectrum(hipStream_t st, const uint32_t* counts, uint64_t n, unsigned long long* bins, uint32_t nbins);

@@ -48,6 +48,11 @@ struct chunk_t {
     uint32_t bucket, n, lg, id;
     uint64_t base;
 };
+// sharded runs: this rank owns global buckets [bucket_base, bucket_base + NBl); NBl == 0 -> one GPU owns everything
+struct bl_shard {
+    uint32_t bucket_base, NBl, me;
+    uint8_t* premote;            // [n] pending bits whose k-mer belongs to another rank, or NULL
+};
 // one 16-byte record per chunk (dense position, k-mers, bucket, split_lg << 24 | split_id): every chunk kernel starts
 // with ONE load instead of a chain of three dependent ones
 __global__ void __launch_bounds__(256) bl_chunk_desc_kernel(chunk_src cs, uint32_t nchunks, uint4* __restrict__ desc) {
@@ -90,7 +95,7 @@ __device__ __forceinline__ uint32_t oriented_base(snk_kmer k, bool rc, int idx) 
 
 // ---------------------------------------------------------------------------------------------- L1: local prune
 template <int K, int CAP, int T, bool BIG>
-__device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __restrict__ desc, uint32_t NB,
+__device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __restrict__ desc, uint32_t NB, bl_shard sh,
                                                      const snk_u128* __restrict__ keys, const uint64_t* __restrict__ vals,
                                                      uint32_t do_prune, uint8_t* __restrict__ ctx_out,
                                                      uint32_t* __restrict__ count_out, uint8_t* __restrict__ pend_out,
@@ -225,7 +230,9 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
                 } else x = (uint32_t)(y.hi >> 32);
                 const uint32_t nkey = snk_minimizer_key(x, snk_rev2_32(~x));
                 if (nkey < mk) mk = nkey;
-                bool here = snk_bucket_of_key(mk, NB) == ch.bucket;
+                const uint32_t gb = snk_bucket_of_key(mk, NB);               // global bucket id of the neighbour
+                bool here = gb == sh.bucket_base + ch.bucket;
+                const bool remote = sh.NBl && gb / sh.NBl != sh.me;              // lives (if anywhere) on another rank
                 if (here && ch.lg) {
                     const snk_kmer r = snk_kmer_rc<K>(y);
                     uint32_t h1, h2;
@@ -233,18 +240,19 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
                     here = (h2 & split_mask) == ch.id;
                 }
                 if (here) { if (!do_prune) atomicOr(&resL[th], 1u << bit); }
-                else atomicOr(&resL[th], (1u << bit) | (0x100u << bit));
+                else atomicOr(&resL[th], (1u << bit) | (0x100u << bit) | (remote ? (0x10000u << bit) : 0u));
             }
         }
         __syncthreads();
         const uint32_t res = resL[tid];
         keep |= res & 0xFFu;
-        const uint32_t pm = res >> 8;
+        const uint32_t pm = (res >> 8) & 0xFFu;
         __syncthreads();
         if (!act) continue;
         const uint64_t gi = ch.base + i;
         ctx_out[gi] = (uint8_t)keep;
         pend_out[gi] = (uint8_t)pm;
+        if (sh.premote) sh.premote[gi] = (uint8_t)(res >> 16);
         count_out[gi] = (uint32_t)(v >> 8);
         nbr_out[2 * gi + 0] = nb0;
         nbr_out[2 * gi + 1] = nb1;
@@ -255,7 +263,7 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
     if (tid == 0) nbnd[c] = bcnt;
 }
 template <int K, int CAP, int T, bool BIG>
-__global__ void __launch_bounds__(T) bl_prune_kernel(const uint4* __restrict__ desc, uint32_t NB, const uint32_t* __restrict__ biglist_in,
+__global__ void __launch_bounds__(T) bl_prune_kernel(const uint4* __restrict__ desc, uint32_t NB, bl_shard sh, const uint32_t* __restrict__ biglist_in,
                                                      uint32_t nchunks, uint32_t cpw,
                                                      const snk_u128* __restrict__ keys, const uint64_t* __restrict__ vals,
                                                      uint32_t do_prune, uint8_t* __restrict__ ctx_out,
@@ -265,7 +273,7 @@ __global__ void __launch_bounds__(T) bl_prune_kernel(const uint4* __restrict__ d
     for (uint32_t r = 0; r < cpw; ++r) {
         const uint32_t w = blockIdx.x * cpw + r;
         if (w >= nchunks) return;
-        bl_prune_chunk<K, CAP, T, BIG>(BIG ? biglist_in[w] : w, desc, NB, keys, vals, do_prune, ctx_out, count_out, pend_out, nbr_out,
+        bl_prune_chunk<K, CAP, T, BIG>(BIG ? biglist_in[w] : w, desc, NB, sh, keys, vals, do_prune, ctx_out, count_out, pend_out, nbr_out,
                                        nbnd, biglist, nbig);
     }
 }
@@ -291,7 +299,8 @@ __global__ void __launch_bounds__(TB) bl_index_build_kernel(const snk_u128* __re
 template <int K>
 __global__ void __launch_bounds__(TB) bl_resolve_kernel(const snk_u128* __restrict__ keys, const uint8_t* __restrict__ pend,
                                                         uint64_t n, const unsigned long long* __restrict__ tab, uint64_t mask,
-                                                        uint32_t do_prune, uint8_t* __restrict__ ctx, uint32_t* __restrict__ rq) {
+                                                        uint32_t do_prune, uint8_t* __restrict__ ctx, uint32_t* __restrict__ rq,
+                                                        const uint8_t* __restrict__ premote) {
     constexpr int SPAN = 8 * TB;
     __shared__ uint16_t list[SPAN];
     __shared__ uint32_t cnt;
@@ -314,7 +323,7 @@ __global__ void __launch_bounds__(TB) bl_resolve_kernel(const snk_u128* __restri
     const uint32_t m = cnt;
     for (uint32_t it = threadIdx.x; it < m; it += TB) {
         const uint64_t i = base + list[it];
-        const uint32_t pm = pend[i];
+        const uint32_t pm = pend[i] & (premote ? ~(uint32_t)premote[i] : 0xFFu);
         const snk_kmer k = load_key(keys, i);
         uint32_t c = ctx[i];
         for (uint32_t rem = pm; rem; rem &= rem - 1) {
@@ -348,11 +357,18 @@ __global__ void __launch_bounds__(TB) bl_resolve_kernel(const snk_u128* __restri
 // node knows its fragment (= smaller terminal state), its position and its orientation, and writes its own base;
 // the K-base head k-mers are written by K lanes each.  COUNT pass: fragments per chunk (exact output sizing);
 // EMIT pass: the same ranking, then the writes.
-template <int K, int CAP, int T, bool BIG, bool EMIT>
+struct bl_dist_args {          // sharded runs: remote neighbours and the global node numbering
+    const uint8_t* premote;
+    const uint32_t* rq_idx;
+    const uint16_t* rq_meta;
+    const unsigned long long* node_off;
+    unsigned long long my_node_off;
+};
+template <int K, int CAP, int T, bool BIG, bool EMIT, bool DIST>
 __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ desc, const uint32_t* __restrict__ biglist_in,
                                                     const snk_u128* __restrict__ keys, const uint8_t* __restrict__ ctx,
                                                     const uint8_t* __restrict__ pend, const uint32_t* __restrict__ nbr,
-                                                    const uint32_t* __restrict__ rq, uint32_t* __restrict__ nfrag,
+                                                    const uint32_t* __restrict__ rq, bl_dist_args da, uint32_t* __restrict__ nfrag,
                                                     const uint32_t* __restrict__ foff, const uint64_t* __restrict__ boff,
                                                     uint32_t* __restrict__ nk, unsigned long long* __restrict__ hl_self,
                                                     unsigned long long* __restrict__ hl_nb, uint64_t* __restrict__ bstart,
@@ -456,15 +472,23 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
         if (__popc(bits) != 1 || palL[i]) return NONE64;
         const uint32_t b = __ffs(bits) - 1;
         if (!((pendL[i] >> (4 * side + b)) & 1u)) return NONE64;
-        const uint32_t a = rq[2 * (ch.base + i) + side];
-        if (a == NONE) return NONE64;
         snk_kmer k;
         k.hi = khi[i];
         k.lo = klo[i];
         const snk_kmer y = side ? snk_kmer_pred<K>(k, b) : snk_kmer_succ<K>(k, b);
         if (snk_kmer_eq(y, snk_kmer_rc<K>(y))) return NONE64;
+        const uint64_t gi = ch.base + i;
+        if (DIST && ((da.premote[gi] >> (4 * side + b)) & 1u)) {         // the neighbour lives on another rank
+            const uint32_t a = da.rq_idx[2 * gi + side];
+            if (a == NONE) return NONE64;
+            const uint32_t meta = da.rq_meta[2 * gi + side];
+            const uint32_t fs = side ^ 1u ^ (meta >> 15);
+            return 2ull * (da.node_off[meta & 0x7FFFu] + a) + fs;
+        }
+        const uint32_t a = rq[2 * gi + side];
+        if (a == NONE) return NONE64;
         const uint32_t rev = a & 1u, fs = side ^ 1u ^ rev;
-        return 2ull * (a >> 1) + fs;
+        return 2ull * ((DIST ? da.my_node_off : 0ull) + (a >> 1)) + fs;
     };
     // fragment descriptor; returns the offset of its bases
     auto describe = [&](uint32_t pid, uint32_t other, uint32_t cnt, bool with_half, uint32_t head_node, bool head_rc) {
@@ -472,8 +496,8 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
         const uint32_t rel = atomicAdd(&bcnt, cnt + (uint32_t)K - 1u);
         const uint64_t f = (uint64_t)c_foff + lf;
         nk[f] = cnt;
-        hl_self[2 * f] = 2ull * ch.base + pid;
-        hl_self[2 * f + 1] = 2ull * ch.base + other;
+        hl_self[2 * f] = 2ull * ((DIST ? da.my_node_off : 0ull) + ch.base) + pid;
+        hl_self[2 * f + 1] = 2ull * ((DIST ? da.my_node_off : 0ull) + ch.base) + other;
         hl_nb[2 * f] = with_half ? half_link(pid) : NONE64;
         hl_nb[2 * f + 1] = with_half ? half_link(other) : NONE64;
         bstart[f] = c_boff + rel;
@@ -612,6 +636,209 @@ static int excl_scan(snk_ctx* ctx, hipStream_t st, const T* in, T* out, size_t c
 constexpr int SCAP = 256, ST = 64;      // small chunks: one wave per chunk
 constexpr int BCAP = 1280, BT = 256;    // big chunks (a count sub-pass retains at most SLOTS - THREADS - 64 = 1216 k-mers)
 
+namespace {
+// ---- sharded runs: membership queries for pending neighbours that belong to another rank
+// query record: 3 x u64 = key lo, key hi, (node | bit << 32 | rev << 40)   (same as snk_graph.hip's sharded stage)
+constexpr int QSPAN = 8 * TB;
+template <int K, bool FILL>
+__global__ void __launch_bounds__(TB) bl_query_kernel(const snk_u128* __restrict__ keys, const uint8_t* __restrict__ premote, uint64_t n,
+                                                      uint32_t NB_total, uint32_t NBl, uint32_t world,
+                                                      unsigned long long* __restrict__ qcount_or_cursor,
+                                                      unsigned long long* __restrict__ qbuf) {
+    extern __shared__ unsigned long long dynq[];          // [world] counts, then reserved bases
+    __shared__ uint16_t list[QSPAN];
+    __shared__ uint32_t cnt;
+    uint32_t* lcur = reinterpret_cast<uint32_t*>(dynq + world);   // [world] local cursors
+    const uint64_t base = (uint64_t)blockIdx.x * QSPAN;
+    if (threadIdx.x == 0) cnt = 0;
+    for (uint32_t r = threadIdx.x; r < world; r += TB) { dynq[r] = 0; lcur[r] = 0; }
+    __syncthreads();
+    {
+        const uint64_t i8 = base + 8ull * threadIdx.x;
+        unsigned long long w = 0;
+        if (i8 + 8 <= n) w = *reinterpret_cast<const unsigned long long*>(premote + i8);
+        else for (uint64_t q = i8; q < n; ++q) w |= (unsigned long long)premote[q] << (8 * (q - i8));
+        if (w) {
+            uint32_t m = 0;
+            for (int q = 0; q < 8; ++q) if ((w >> (8 * q)) & 0xFFull) ++m;
+            uint32_t pos = atomicAdd(&cnt, m);
+            for (int q = 0; q < 8; ++q) if ((w >> (8 * q)) & 0xFFull) list[pos++] = (uint16_t)(8 * threadIdx.x + q);
+        }
+    }
+    __syncthreads();
+    const uint32_t m = cnt;
+    // pass 1: queries per destination rank
+    for (uint32_t it = threadIdx.x; it < m; it += TB) {
+        const uint64_t i = base + list[it];
+        const snk_kmer k = load_key(keys, i);
+        for (uint32_t rem = premote[i]; rem; rem &= rem - 1) {
+            const uint32_t bit = __ffs(rem) - 1;
+            const snk_kmer y = bit < 4 ? snk_kmer_succ<K>(k, bit) : snk_kmer_pred<K>(k, bit - 4);
+            const uint32_t owner = snk_bucket_of_kmer<K>(y, NB_total) / NBl;
+            atomicAdd(&dynq[owner], 1ull);
+        }
+    }
+    __syncthreads();
+    for (uint32_t r = threadIdx.x; r < world; r += TB) {
+        const unsigned long long c = dynq[r];
+        if (c) dynq[r] = FILL ? atomicAdd(&qcount_or_cursor[r], c) : (atomicAdd(&qcount_or_cursor[r], c), 0ull);
+    }
+    if (!FILL) return;
+    __syncthreads();
+    // pass 2: every query takes a slot of its destination's segment
+    for (uint32_t it = threadIdx.x; it < m; it += TB) {
+        const uint64_t i = base + list[it];
+        const snk_kmer k = load_key(keys, i);
+        for (uint32_t rem = premote[i]; rem; rem &= rem - 1) {
+            const uint32_t bit = __ffs(rem) - 1;
+            const snk_kmer y = bit < 4 ? snk_kmer_succ<K>(k, bit) : snk_kmer_pred<K>(k, bit - 4);
+            const uint32_t owner = snk_bucket_of_kmer<K>(y, NB_total) / NBl;
+            const snk_kmer r = snk_kmer_rc<K>(y);
+            const bool rev = snk_kmer_lt(r, y);
+            const snk_kmer c = rev ? r : y;
+            const unsigned long long slot = dynq[owner] + atomicAdd(&lcur[owner], 1u);
+            qbuf[3 * slot + 0] = c.lo;
+            qbuf[3 * slot + 1] = c.hi;
+            qbuf[3 * slot + 2] = (unsigned long long)i | ((unsigned long long)bit << 32) | ((unsigned long long)(rev ? 1 : 0) << 40);
+        }
+    }
+}
+}  // namespace
+
+// ---- stage 1: chunk records, local prune, boundary index, pending bits of this rank resolved
+template <int K>
+static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* err, size_t errcap) {
+    const snk_table* tab = B->tab;
+    const uint64_t n = tab->n;
+    chunk_src cs;
+    cs.chunk_n = tab->chunk_n;
+    cs.chunk_base = tab->chunk_base;
+    cs.extra = tab->extra;
+    cs.region_off = tab->region_off;
+    cs.NB = tab->NB;
+    cs.n_extra = tab->n_extra;
+    cs.n_regions = tab->n_regions;
+    const uint32_t nchunks = tab->NB + tab->n_extra;
+    B->nchunks = nchunks;
+    G_ALLOC(B->desc, uint4, (uint64_t)nchunks + 1);
+    hipLaunchKernelGGL(bl_chunk_desc_kernel, dim3((nchunks + 255) / 256), dim3(256), 0, st, cs, nchunks, B->desc);
+    uint32_t *nbnd, *ctr;
+    G_ALLOC(B->ctx, uint8_t, n + 16);
+    G_ALLOC(B->pend, uint8_t, n + 16);
+    G_ALLOC(B->counts, uint32_t, n + 4);
+    G_ALLOC(B->nbr, uint32_t, 2 * n + 2);
+    G_ALLOC(B->rq, uint32_t, 2 * n + 2);
+    G_ALLOC(nbnd, uint32_t, (uint64_t)nchunks + 1);
+    G_ALLOC(B->biglist, uint32_t, n / SCAP + 2);
+    G_ALLOC(ctr, uint32_t, 16);
+    B->premote = nullptr;
+    if (B->world > 1 || B->force_dist) {
+        G_ALLOC(B->premote, uint8_t, n + 16);
+        SNK_HIP_TRY(hipMemsetAsync(B->premote, 0, n + 16, st));
+    }
+    SNK_HIP_TRY(hipMemsetAsync(nbnd, 0, ((uint64_t)nchunks + 1) * 4, st));
+    SNK_HIP_TRY(hipMemsetAsync(ctr, 0, 64, st));
+    SNK_HIP_TRY(hipMemsetAsync(B->rq, 0xFF, (2 * n + 2) * 4, st));
+    bl_shard sh;
+    sh.bucket_base = B->premote ? B->rank * B->NBl : 0u;
+    sh.NBl = B->premote ? B->NBl : 0u;
+    sh.me = B->rank;
+    sh.premote = B->premote;
+    const uint32_t NBh = B->premote ? B->NB_total : tab->NB;      // bucket count of the minimiser hash
+    const uint32_t cpw = 1;
+    hipLaunchKernelGGL((bl_prune_kernel<K, SCAP, ST, false>), dim3((nchunks + cpw - 1) / cpw), dim3(ST), 0, st, (const uint4*)B->desc, NBh, sh,
+                       (const uint32_t*)nullptr, nchunks, cpw, tab->keys, tab->vals, B->do_prune, B->ctx, B->counts, B->pend, B->nbr, nbnd,
+                       B->biglist, ctr);
+    SNK_HIP_TRY(hipGetLastError());
+    uint32_t h_nbig = 0;
+    SNK_HIP_TRY(hipMemcpyAsync(&h_nbig, ctr, 4, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    B->nbig = h_nbig;
+    if (h_nbig)
+        hipLaunchKernelGGL((bl_prune_kernel<K, BCAP, BT, true>), dim3(h_nbig), dim3(BT), 0, st, (const uint4*)B->desc, NBh, sh,
+                           (const uint32_t*)B->biglist, h_nbig, 1u, tab->keys, tab->vals, B->do_prune, B->ctx, B->counts, B->pend, B->nbr,
+                           nbnd, B->biglist, ctr);
+    SNK_HIP_TRY(hipGetLastError());
+    unsigned long long* d_sum;
+    G_ALLOC(d_sum, unsigned long long, 2);
+    {
+        size_t tb = 0;
+        auto in = rocprim::make_transform_iterator(nbnd, [] __device__(uint32_t v) { return (unsigned long long)v; });
+        SNK_HIP_TRY(rocprim::reduce((void*)nullptr, tb, in, d_sum, 0ull, (size_t)nchunks, rocprim::plus<unsigned long long>(), st));
+        void* tmp;
+        int rc = snk_ctx_alloc(ctx, tb, &tmp, err, errcap);
+        if (rc) return rc;
+        SNK_HIP_TRY(rocprim::reduce(tmp, tb, in, d_sum, 0ull, (size_t)nchunks, rocprim::plus<unsigned long long>(), st));
+    }
+    unsigned long long h_bnd = 0;
+    SNK_HIP_TRY(hipMemcpyAsync(&h_bnd, d_sum, 8, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    B->n_boundary = h_bnd;
+    uint64_t tg = 1024;
+    while (tg < 2 * h_bnd) tg <<= 1;
+    G_ALLOC(B->index, unsigned long long, tg);
+    B->index_mask = tg - 1;
+    SNK_HIP_TRY(hipMemsetAsync(B->index, 0, tg * 8, st));
+    if (h_bnd) {
+        hipLaunchKernelGGL(bl_index_build_kernel, dim3(nblk(n)), dim3(TB), 0, st, tab->keys, B->pend, n, B->index, tg - 1);
+        hipLaunchKernelGGL((bl_resolve_kernel<K>), dim3((unsigned)((n + 8 * TB - 1) / (8 * TB))), dim3(TB), 0, st, tab->keys, B->pend, n,
+                           B->index, tg - 1, B->do_prune, B->ctx, B->rq, (const uint8_t*)B->premote);
+    }
+    SNK_HIP_TRY(hipGetLastError());
+    return SNK_OK;
+}
+
+// ---- stage 2: fragments of every chunk (exact sizing pass, then the writes)
+template <int K, bool DIST>
+static int bl_fragments_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, const bl_dist_args& da, snk_frag_out* out, char* err,
+                             size_t errcap) {
+    const snk_table* tab = B->tab;
+    const uint32_t nchunks = B->nchunks, h_nbig = B->nbig;
+    uint32_t *nfrag, *foff;
+    uint64_t *nbases, *boff;
+    G_ALLOC(nfrag, uint32_t, (uint64_t)nchunks + 1);
+    G_ALLOC(foff, uint32_t, (uint64_t)nchunks + 1);
+    G_ALLOC(nbases, uint64_t, (uint64_t)nchunks + 1);
+    G_ALLOC(boff, uint64_t, (uint64_t)nchunks + 1);
+    SNK_HIP_TRY(hipMemsetAsync(nfrag, 0, ((uint64_t)nchunks + 1) * 4, st));
+    hipLaunchKernelGGL((bl_frag_kernel<K, SCAP, ST, false, false, DIST>), dim3(nchunks), dim3(ST), 0, st, (const uint4*)B->desc,
+                       (const uint32_t*)nullptr, tab->keys, B->ctx, B->pend, B->nbr, B->rq, da, nfrag, (const uint32_t*)nullptr,
+                       (const uint64_t*)nullptr, (uint32_t*)nullptr, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                       (uint64_t*)nullptr, (uint8_t*)nullptr);
+    if (h_nbig)
+        hipLaunchKernelGGL((bl_frag_kernel<K, BCAP, BT, true, false, DIST>), dim3(h_nbig), dim3(BT), 0, st, (const uint4*)B->desc,
+                           (const uint32_t*)B->biglist, tab->keys, B->ctx, B->pend, B->nbr, B->rq, da, nfrag, (const uint32_t*)nullptr,
+                           (const uint64_t*)nullptr, (uint32_t*)nullptr, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                           (uint64_t*)nullptr, (uint8_t*)nullptr);
+    hipLaunchKernelGGL(bl_chunk_bases_kernel, dim3(nblk((uint64_t)nchunks + 1)), dim3(TB), 0, st, (const uint4*)B->desc, nfrag, nchunks,
+                       (uint32_t)K, nbases);
+    SNK_HIP_TRY(hipGetLastError());
+    int rc;
+    if ((rc = excl_scan<uint32_t>(ctx, st, nfrag, foff, (size_t)nchunks + 1, err, errcap))) return rc;
+    if ((rc = excl_scan<uint64_t>(ctx, st, nbases, boff, (size_t)nchunks + 1, err, errcap))) return rc;
+    uint32_t h_F = 0;
+    uint64_t h_B = 0;
+    SNK_HIP_TRY(hipMemcpyAsync(&h_F, foff + nchunks, 4, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipMemcpyAsync(&h_B, boff + nchunks, 8, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    G_ALLOC(out->nk, uint32_t, (uint64_t)h_F + 1);
+    G_ALLOC(out->hl_self, unsigned long long, 2ull * h_F + 2);
+    G_ALLOC(out->hl_nb, unsigned long long, 2ull * h_F + 2);
+    G_ALLOC(out->boff, uint64_t, (uint64_t)h_F + 2);
+    G_ALLOC(out->bases, uint8_t, h_B + 16);
+    hipLaunchKernelGGL((bl_frag_kernel<K, SCAP, ST, false, true, DIST>), dim3(nchunks), dim3(ST), 0, st, (const uint4*)B->desc,
+                       (const uint32_t*)nullptr, tab->keys, B->ctx, B->pend, B->nbr, B->rq, da, nfrag, foff, boff, out->nk, out->hl_self,
+                       out->hl_nb, out->boff, out->bases);
+    if (h_nbig)
+        hipLaunchKernelGGL((bl_frag_kernel<K, BCAP, BT, true, true, DIST>), dim3(h_nbig), dim3(BT), 0, st, (const uint4*)B->desc,
+                           (const uint32_t*)B->biglist, tab->keys, B->ctx, B->pend, B->nbr, B->rq, da, nfrag, foff, boff, out->nk,
+                           out->hl_self, out->hl_nb, out->boff, out->bases);
+    SNK_HIP_TRY(hipGetLastError());
+    out->n_frags = h_F;
+    out->total_bases = h_B;
+    return SNK_OK;
+}
+
 template <int K>
 static int local_graph_impl(snk_ctx* ctx, hipStream_t st, const snk_table* tab, uint32_t do_prune, bool want_unitigs,
                             bool sort_table, snk_graph_out* out, snk_u128** keys_final, float* ms, char* err, size_t errcap) {
@@ -635,113 +862,26 @@ static int local_graph_impl(snk_ctx* ctx, hipStream_t st, const snk_table* tab, 
         return snk_fail(SNK_E_INTERNAL, err, errcap, "bucket-local graph: chunk capacity %d is below the count table's limit", BCAP);
     snk_phase_timer tm(st);
     tm.mark();  // 0
-    chunk_src cs;
-    cs.chunk_n = tab->chunk_n;
-    cs.chunk_base = tab->chunk_base;
-    cs.extra = tab->extra;
-    cs.region_off = tab->region_off;
-    cs.NB = tab->NB;
-    cs.n_extra = tab->n_extra;
-    cs.n_regions = tab->n_regions;
-    const uint32_t nchunks = tab->NB + tab->n_extra;
-    uint4* desc;
-    G_ALLOC(desc, uint4, (uint64_t)nchunks + 1);
-    hipLaunchKernelGGL(bl_chunk_desc_kernel, dim3((nchunks + 255) / 256), dim3(256), 0, st, cs, nchunks, desc);
-    uint8_t *ctxo, *pend;
-    uint32_t *counts, *nbr, *rq, *nbnd, *biglist, *ctr;
-    G_ALLOC(ctxo, uint8_t, n + 16);
-    G_ALLOC(pend, uint8_t, n + 16);
-    G_ALLOC(counts, uint32_t, n + 4);
-    G_ALLOC(nbr, uint32_t, 2 * n + 2);
-    G_ALLOC(rq, uint32_t, 2 * n + 2);
-    G_ALLOC(nbnd, uint32_t, (uint64_t)nchunks + 1);
-    G_ALLOC(biglist, uint32_t, n / SCAP + 2);
-    G_ALLOC(ctr, uint32_t, 16);
-    SNK_HIP_TRY(hipMemsetAsync(nbnd, 0, ((uint64_t)nchunks + 1) * 4, st));
-    SNK_HIP_TRY(hipMemsetAsync(ctr, 0, 64, st));
-    SNK_HIP_TRY(hipMemsetAsync(rq, 0xFF, (2 * n + 2) * 4, st));
-    const uint32_t cpw = snk_env_u32("SNK_BL_CPW", 1);
-    hipLaunchKernelGGL((bl_prune_kernel<K, SCAP, ST, false>), dim3((nchunks + cpw - 1) / cpw), dim3(ST), 0, st, (const uint4*)desc, cs.NB, (const uint32_t*)nullptr,
-                       nchunks, cpw, tab->keys, tab->vals, do_prune, ctxo, counts, pend, nbr, nbnd, biglist, ctr);
-    SNK_HIP_TRY(hipGetLastError());
-    uint32_t h_nbig = 0;
-    SNK_HIP_TRY(hipMemcpyAsync(&h_nbig, ctr, 4, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
-    if (h_nbig)
-        hipLaunchKernelGGL((bl_prune_kernel<K, BCAP, BT, true>), dim3(h_nbig), dim3(BT), 0, st, (const uint4*)desc, cs.NB, (const uint32_t*)biglist,
-                           h_nbig, 1u, tab->keys, tab->vals, do_prune, ctxo, counts, pend, nbr, nbnd, biglist, ctr);
-    SNK_HIP_TRY(hipGetLastError());
-    // boundary k-mers
-    unsigned long long* d_sum;
-    G_ALLOC(d_sum, unsigned long long, 2);
-    {
-        size_t tb = 0;
-        auto in = rocprim::make_transform_iterator(nbnd, [] __device__(uint32_t v) { return (unsigned long long)v; });
-        SNK_HIP_TRY(rocprim::reduce((void*)nullptr, tb, in, d_sum, 0ull, (size_t)nchunks, rocprim::plus<unsigned long long>(), st));
-        void* tmp;
-        int rc = snk_ctx_alloc(ctx, tb, &tmp, err, errcap);
-        if (rc) return rc;
-        SNK_HIP_TRY(rocprim::reduce(tmp, tb, in, d_sum, 0ull, (size_t)nchunks, rocprim::plus<unsigned long long>(), st));
-    }
-    unsigned long long h_bnd = 0;
-    SNK_HIP_TRY(hipMemcpyAsync(&h_bnd, d_sum, 8, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    snk_bl_state B;
+    memset(&B, 0, sizeof B);
+    B.tab = tab;
+    B.K = K;
+    B.world = 1;
+    B.do_prune = do_prune;
+    int rc = bl_prune_impl<K>(ctx, st, &B, err, errcap);
+    if (rc) return rc;
     tm.mark();  // 1
-    uint64_t tg = 1024;
-    while (tg < 2 * h_bnd) tg <<= 1;
-    unsigned long long* index;
-    G_ALLOC(index, unsigned long long, tg);
-    SNK_HIP_TRY(hipMemsetAsync(index, 0, tg * 8, st));
-    if (h_bnd) {
-        hipLaunchKernelGGL(bl_index_build_kernel, dim3(nblk(n)), dim3(TB), 0, st, tab->keys, pend, n, index, tg - 1);
-        hipLaunchKernelGGL((bl_resolve_kernel<K>), dim3((unsigned)((n + 8 * TB - 1) / (8 * TB))), dim3(TB), 0, st, tab->keys, pend, n, index, tg - 1, do_prune, ctxo, rq);
-    }
-    SNK_HIP_TRY(hipGetLastError());
     tm.mark();  // 2
-    out->n_boundary = h_bnd;
+    out->n_boundary = B.n_boundary;
     if (want_unitigs) {
-        uint32_t *nfrag, *foff;
-        uint64_t *nbases, *boff;
-        G_ALLOC(nfrag, uint32_t, (uint64_t)nchunks + 1);
-        G_ALLOC(foff, uint32_t, (uint64_t)nchunks + 1);
-        G_ALLOC(nbases, uint64_t, (uint64_t)nchunks + 1);
-        G_ALLOC(boff, uint64_t, (uint64_t)nchunks + 1);
-        SNK_HIP_TRY(hipMemsetAsync(nfrag, 0, ((uint64_t)nchunks + 1) * 4, st));
-        hipLaunchKernelGGL((bl_frag_kernel<K, SCAP, ST, false, false>), dim3(nchunks), dim3(ST), 0, st, (const uint4*)desc, (const uint32_t*)nullptr,
-                           tab->keys, ctxo, pend, nbr, rq, nfrag, (const uint32_t*)nullptr, (const uint64_t*)nullptr, (uint32_t*)nullptr,
-                           (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint64_t*)nullptr, (uint8_t*)nullptr);
-        if (h_nbig)
-            hipLaunchKernelGGL((bl_frag_kernel<K, BCAP, BT, true, false>), dim3(h_nbig), dim3(BT), 0, st, (const uint4*)desc, (const uint32_t*)biglist,
-                               tab->keys, ctxo, pend, nbr, rq, nfrag, (const uint32_t*)nullptr, (const uint64_t*)nullptr, (uint32_t*)nullptr,
-                               (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint64_t*)nullptr, (uint8_t*)nullptr);
-        hipLaunchKernelGGL(bl_chunk_bases_kernel, dim3(nblk((uint64_t)nchunks + 1)), dim3(TB), 0, st, (const uint4*)desc, nfrag, nchunks, (uint32_t)K, nbases);
-        SNK_HIP_TRY(hipGetLastError());
-        int rc;
-        if ((rc = excl_scan<uint32_t>(ctx, st, nfrag, foff, (size_t)nchunks + 1, err, errcap))) return rc;
-        if ((rc = excl_scan<uint64_t>(ctx, st, nbases, boff, (size_t)nchunks + 1, err, errcap))) return rc;
-        uint32_t h_F = 0;
-        uint64_t h_B = 0;
-        SNK_HIP_TRY(hipMemcpyAsync(&h_F, foff + nchunks, 4, hipMemcpyDeviceToHost, st));
-        SNK_HIP_TRY(hipMemcpyAsync(&h_B, boff + nchunks, 8, hipMemcpyDeviceToHost, st));
-        SNK_HIP_TRY(hipStreamSynchronize(st));
-        uint32_t* fnk;
-        unsigned long long *hl_self, *hl_nb;
-        uint64_t* bstart;
-        uint8_t* fbases;
-        G_ALLOC(fnk, uint32_t, (uint64_t)h_F + 1);
-        G_ALLOC(hl_self, unsigned long long, 2ull * h_F + 2);
-        G_ALLOC(hl_nb, unsigned long long, 2ull * h_F + 2);
-        G_ALLOC(bstart, uint64_t, (uint64_t)h_F + 2);
-        G_ALLOC(fbases, uint8_t, h_B + 16);
-        hipLaunchKernelGGL((bl_frag_kernel<K, SCAP, ST, false, true>), dim3(nchunks), dim3(ST), 0, st, (const uint4*)desc, (const uint32_t*)nullptr,
-                           tab->keys, ctxo, pend, nbr, rq, nfrag, foff, boff, fnk, hl_self, hl_nb, bstart, fbases);
-        if (h_nbig)
-            hipLaunchKernelGGL((bl_frag_kernel<K, BCAP, BT, true, true>), dim3(h_nbig), dim3(BT), 0, st, (const uint4*)desc, (const uint32_t*)biglist,
-                               tab->keys, ctxo, pend, nbr, rq, nfrag, foff, boff, fnk, hl_self, hl_nb, bstart, fbases);
-        SNK_HIP_TRY(hipGetLastError());
+        snk_frag_out fo;
+        memset(&fo, 0, sizeof fo);
+        bl_dist_args da;
+        memset(&da, 0, sizeof da);
+        if ((rc = bl_fragments_impl<K, false>(ctx, st, &B, da, &fo, err, errcap))) return rc;
         tm.mark();  // 3
         snk_join_out jo;
-        rc = snk_dist_join(ctx, st, K, h_F, fnk, hl_self, hl_nb, bstart, fbases, h_B, &jo, err, errcap);
+        rc = snk_dist_join(ctx, st, K, fo.n_frags, fo.nk, fo.hl_self, fo.hl_nb, fo.boff, fo.bases, fo.total_bases, &jo, err, errcap);
         if (rc) return rc;
         tm.mark();  // 4
         out->n_unitigs = jo.n_unitigs;
@@ -750,7 +890,7 @@ static int local_graph_impl(snk_ctx* ctx, hipStream_t st, const snk_table* tab, 
         out->unitig_bases = jo.unitig_bases;
         out->n_circles = jo.n_circles;
         out->rank_rounds = jo.rank_rounds;
-        out->n_fragments = h_F;
+        out->n_fragments = fo.n_frags;
     } else {
         G_ALLOC(out->unitig_off, uint64_t, 2);
         SNK_HIP_TRY(hipMemsetAsync(out->unitig_off, 0, 16, st));
@@ -758,21 +898,21 @@ static int local_graph_impl(snk_ctx* ctx, hipStream_t st, const snk_table* tab, 
         tm.mark();
         tm.mark();
     }
-    out->ctx = ctxo;
-    out->counts = counts;
+    out->ctx = B.ctx;
+    out->counts = B.counts;
     if (sort_table) {
         uint64_t *v_in, *v_out;
         snk_u128* k_out;
         G_ALLOC(v_in, uint64_t, n + 1);
         G_ALLOC(v_out, uint64_t, n + 1);
         G_ALLOC(k_out, snk_u128, n + 1);
-        hipLaunchKernelGGL(bl_pack_vals_kernel, dim3(nblk(n)), dim3(TB), 0, st, counts, ctxo, n, v_in);
-        int rc = snk_graph_sort(ctx, st, K, n, tab->keys, v_in, k_out, v_out, err, errcap);
+        hipLaunchKernelGGL(bl_pack_vals_kernel, dim3(nblk(n)), dim3(TB), 0, st, B.counts, B.ctx, n, v_in);
+        rc = snk_graph_sort(ctx, st, K, n, tab->keys, v_in, k_out, v_out, err, errcap);
         if (rc) return rc;
-        hipLaunchKernelGGL(bl_unpack_vals_kernel, dim3(nblk(n)), dim3(TB), 0, st, v_out, n, counts, ctxo);
+        hipLaunchKernelGGL(bl_unpack_vals_kernel, dim3(nblk(n)), dim3(TB), 0, st, v_out, n, B.counts, B.ctx);
         *keys_final = k_out;
     }
-    if ((int)snk_launch_spectrum(st, counts, n, out->spectrum, NBINS)) return snk_fail(SNK_E_HIP, err, errcap, "spectrum launch failed");
+    if ((int)snk_launch_spectrum(st, B.counts, n, out->spectrum, NBINS)) return snk_fail(SNK_E_HIP, err, errcap, "spectrum launch failed");
     tm.mark();  // 5
     SNK_HIP_TRY(hipGetLastError());
     if (ms) { ms[0] = tm.ms(0, 1); ms[1] = tm.ms(1, 2); ms[2] = tm.ms(2, 3); ms[3] = tm.ms(3, 4); ms[4] = tm.ms(4, 5); }
@@ -785,4 +925,78 @@ int snk_local_graph(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_table* t
     if (K == 48) return local_graph_impl<48>(ctx, st, tab, do_prune, want_unitigs, sort_table, out, keys_final, ms, err, errcap);
     if (K == 60) return local_graph_impl<60>(ctx, st, tab, do_prune, want_unitigs, sort_table, out, keys_final, ms, err, errcap);
     return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "K=%u is not supported (48 or 60)", K);
+}
+
+// ---- sharded stages (snk_dist.hip drives them; the host runs the exchanges in between)
+int snk_bl_dist_plan(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, unsigned long long* h_qcount, char* err, size_t errcap) {
+    B->force_dist = 1;
+    const uint64_t n = B->tab->n;
+    G_ALLOC(B->qcount, unsigned long long, B->world + 1);
+    G_ALLOC(B->qcursor, unsigned long long, B->world + 1);
+    G_ALLOC(B->rq_idx, uint32_t, 2 * n + 2);
+    G_ALLOC(B->rq_meta, uint16_t, 2 * n + 2);
+    SNK_HIP_TRY(hipMemsetAsync(B->qcount, 0, (B->world + 1) * 8ull, st));
+    SNK_HIP_TRY(hipMemsetAsync(B->rq_idx, 0xFF, (2 * n + 2) * 4, st));
+    for (uint32_t r = 0; r < B->world; ++r) h_qcount[r] = 0;
+    if (n == 0) {
+        G_ALLOC(B->ctx, uint8_t, 16);
+        G_ALLOC(B->counts, uint32_t, 4);
+        G_ALLOC(B->index, unsigned long long, 1024);
+        SNK_HIP_TRY(hipMemsetAsync(B->index, 0, 1024 * 8, st));
+        B->index_mask = 1023;
+        return SNK_OK;
+    }
+    if (n >= (1ull << 31)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "more than 2^31 retained k-mers on one GPU (%llu)", (unsigned long long)n);
+    int rc = B->K == 48 ? bl_prune_impl<48>(ctx, st, B, err, errcap) : bl_prune_impl<60>(ctx, st, B, err, errcap);
+    if (rc) return rc;
+    const size_t lds = (size_t)B->world * 12 + 16;
+    const unsigned grid = (unsigned)((n + QSPAN - 1) / QSPAN);
+    if (B->K == 48) hipLaunchKernelGGL((bl_query_kernel<48, false>), dim3(grid), dim3(TB), lds, st, B->tab->keys, (const uint8_t*)B->premote, n, B->NB_total, B->NBl, B->world, B->qcount, (unsigned long long*)nullptr);
+    else hipLaunchKernelGGL((bl_query_kernel<60, false>), dim3(grid), dim3(TB), lds, st, B->tab->keys, (const uint8_t*)B->premote, n, B->NB_total, B->NBl, B->world, B->qcount, (unsigned long long*)nullptr);
+    SNK_HIP_TRY(hipGetLastError());
+    SNK_HIP_TRY(hipMemcpyAsync(h_qcount, B->qcount, B->world * 8ull, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    return SNK_OK;
+}
+int snk_bl_dist_fill(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, const unsigned long long* d_qoff, void* d_qbuf, char* err, size_t errcap) {
+    const uint64_t n = B->tab->n;
+    if (n == 0) return SNK_OK;
+    SNK_HIP_TRY(hipMemcpyAsync(B->qcursor, d_qoff, (B->world + 1) * 8ull, hipMemcpyDeviceToDevice, st));
+    const size_t lds = (size_t)B->world * 12 + 16;
+    const unsigned grid = (unsigned)((n + QSPAN - 1) / QSPAN);
+    if (B->K == 48) hipLaunchKernelGGL((bl_query_kernel<48, true>), dim3(grid), dim3(TB), lds, st, B->tab->keys, (const uint8_t*)B->premote, n, B->NB_total, B->NBl, B->world, B->qcursor, (unsigned long long*)d_qbuf);
+    else hipLaunchKernelGGL((bl_query_kernel<60, true>), dim3(grid), dim3(TB), lds, st, B->tab->keys, (const uint8_t*)B->premote, n, B->NB_total, B->NBl, B->world, B->qcursor, (unsigned long long*)d_qbuf);
+    SNK_HIP_TRY(hipGetLastError());
+    return SNK_OK;
+}
+int snk_bl_dist_fragments(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, const unsigned long long* d_node_off, unsigned long long my_node_off,
+                          snk_frag_out* out, char* err, size_t errcap) {
+    memset(out, 0, sizeof *out);
+    const uint64_t n = B->tab->n;
+    constexpr uint32_t NBINS = 65536;
+    unsigned long long* bins;
+    G_ALLOC(bins, unsigned long long, NBINS);
+    SNK_HIP_TRY(hipMemsetAsync(bins, 0, NBINS * 8, st));
+    out->spectrum = bins;
+    out->spectrum_bins = NBINS;
+    if (n == 0) {
+        G_ALLOC(out->boff, uint64_t, 2);
+        SNK_HIP_TRY(hipMemsetAsync(out->boff, 0, 16, st));
+        G_ALLOC(out->bases, uint8_t, 16);
+        G_ALLOC(out->nk, uint32_t, 4);
+        G_ALLOC(out->hl_self, unsigned long long, 2);
+        G_ALLOC(out->hl_nb, unsigned long long, 2);
+        return SNK_OK;
+    }
+    if ((int)snk_launch_spectrum(st, B->counts, n, bins, NBINS)) return snk_fail(SNK_E_HIP, err, errcap, "spectrum launch failed");
+    bl_dist_args da;
+    da.premote = B->premote;
+    da.rq_idx = B->rq_idx;
+    da.rq_meta = B->rq_meta;
+    da.node_off = d_node_off;
+    da.my_node_off = my_node_off;
+    int rc = B->K == 48 ? bl_fragments_impl<48, true>(ctx, st, B, da, out, err, errcap) : bl_fragments_impl<60, true>(ctx, st, B, da, out, err, errcap);
+    if (rc) return rc;
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    return SNK_OK;
 }

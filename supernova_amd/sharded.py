@@ -350,26 +350,30 @@ class ShardedEngine:
             return t[:nbytes]
 
         to0 = lambda n: [n if q == 0 else 0 for q in range(W)]
+        TB = int(fr.total_bases)
         t_nk, _ = comm.all_to_all_v(dcopy(fr.nk, F * 4), to0(F * 4))
         t_self, _ = comm.all_to_all_v(dcopy(fr.hl_self, F * 16), to0(F * 16))
         t_nb, _ = comm.all_to_all_v(dcopy(fr.hl_nb, F * 16), to0(F * 16))
-        boff = dcopy(fr.boff, (F + 1) * 8).view(torch.int64)
-        lens_f = (boff[1:] - boff[:-1]).contiguous()
-        t_len, _ = comm.all_to_all_v(lens_f.view(torch.uint8), to0(F * 8))
-        t_bases, _ = comm.all_to_all_v(dcopy(fr.bases, int(fr.total_bases)), to0(int(fr.total_bases)))
+        t_start, start_bytes = comm.all_to_all_v(dcopy(fr.boff, F * 8), to0(F * 8))
+        t_bases, base_bytes = comm.all_to_all_v(dcopy(fr.bases, TB), to0(TB))
         res.joined = None
         res.n_unitigs = 0
         if me == 0:
             Ft = t_nk.numel() // 4
-            lens_all = t_len.view(torch.int64)
-            boff_all = torch.zeros(Ft + 1, dtype=torch.int64, device=dev)
-            boff_all[1:] = torch.cumsum(lens_all, 0)
+            # fragment starts are offsets into their rank's base buffer: shift by the buffers in front
+            starts = t_start.view(torch.int64)
+            shift = torch.zeros(W + 1, dtype=torch.int64, device=dev)
+            shift[1:] = torch.cumsum(torch.tensor(base_bytes, dtype=torch.int64, device=dev), 0)
+            per_rank = torch.tensor([b // 8 for b in start_bytes], dtype=torch.int64, device=dev)
+            starts_all = (starts + torch.repeat_interleave(shift[:W], per_rank)).contiguous()
+            if starts_all.numel() == 0:
+                starts_all = torch.zeros(1, dtype=torch.int64, device=dev)
             un = _lib.SnkShardUnitigs()
-            chk(lib.snk_shard_join(e._ctx, K, Ft, t_nk.data_ptr(), t_self.data_ptr(), t_nb.data_ptr(), boff_all.data_ptr(),
+            chk(lib.snk_shard_join(e._ctx, K, Ft, t_nk.data_ptr(), t_self.data_ptr(), t_nb.data_ptr(), starts_all.data_ptr(),
                                    t_bases.data_ptr(), t_bases.numel(), C.byref(un), st, err, 512))
             res.joined = un
             res.n_unitigs = int(un.n_unitigs)
-            res._keep = (t_nk, t_self, t_nb, boff_all, t_bases)
+            res._keep = (t_nk, t_self, t_nb, starts_all, t_bases)
         ev[7].record()
         torch.cuda.synchronize()
         names = ["hist", "scatter", "exchange", "count", "prune", "fragments", "join"]
