@@ -53,6 +53,10 @@ def parse():
                     help="also sort the retained k-mer table by key (+~40 ms; the reference's dictionary is an unordered hash set, "
                          "the default leaves the table in minimiser-bucket order = SNK_F_UNSORTED_TABLE)")
     ap.add_argument("--global-graph", action="store_true", help="global graph stage instead of the bucket-local one")
+    ap.add_argument("--grouped", action="store_true",
+                    help="BASELINE config 5: per-barcode local graphs (group = barcode, frequency rule only, --min-freq); "
+                         "replicas only for N>1 (every rank owns whole barcodes, no collective)")
+    ap.add_argument("--min-freq", type=int, default=3)
     return ap.parse_args()
 
 
@@ -119,9 +123,17 @@ def main():
     sp = synth.synth_params(total_reads, seed=0x5EED0000 + (1 if world == 1 else 2), error_free=args.error_free)
     rows, quals, bc = eng.synth(sp, first=rank * per_gpu, n=per_gpu)
     torch.cuda.synchronize()
-    params = Params(K=K, sorted_table=args.sorted_table, global_graph=args.global_graph)
+    params = Params(K=K, sorted_table=args.sorted_table, global_graph=args.global_graph, min_freq=args.min_freq)
+    if args.grouped:
+        assert per_gpu % (2 * sp.pairs_per_bc) == 0, "--grouped: reads per GPU must be a multiple of the reads per barcode"
+        params = Params(K=K, sorted_table=False, grouped=True, min_bc=0, min_freq=args.min_freq)
 
-    if not use_dist:
+    if args.grouped:
+        use_dist_collectives = False
+
+        def step():      # replicas only: the barcodes of this rank's slab belong to nobody else
+            return eng.count_graph(rows, sp.read_len, quals=quals, bc=None, group=bc, params=params)
+    elif not use_dist:
         def step():
             return eng.count_graph(rows, sp.read_len, quals=quals, bc=bc, params=params)
     else:
@@ -193,7 +205,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launch_ms": count_ms, "units_per_launch": units, "alg_bytes_per_unit": ALG_BYTES_PER_KMER[K]},
         }
-        out["config"]["path"] = "sharded" if use_dist else "single"
+        out["config"]["path"] = "grouped-replicas" if args.grouped else ("sharded" if use_dist else "single")
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(sp, K, args.cpu_sample)

@@ -58,6 +58,10 @@ typedef struct snk_params {
 #define SNK_F_NO_GRAPH 1u      /* stop after the retained k-mer table (count only) */
 #define SNK_F_UNSORTED_TABLE 2u /* leave the retained table in bucket order (the reference's dictionary is an unordered
                                   hash set, kmers/ReadPather.h:189-245); default: keys ascending */
+#define SNK_F_GROUPED 8u        /* per-group graphs (BASELINE config 5: per-barcode local graphs): reads carry a group id
+                                  (snk_dev_reads.group); k-mers are counted, pruned and walked per (group, k-mer); every
+                                  unitig reports its group.  K=48, frequency rule only.  The group id is returned in the
+                                  32 low bits of every key. */
 #define SNK_F_GLOBAL_GRAPH 4u   /* use the global graph stage (sort + HBM index + list ranking over all k-mers) instead
                                   of the bucket-local one; same results, kept as a cross-check */
 
@@ -118,6 +122,7 @@ typedef struct snk_dev_reads {
     const void* bc;           /* i32[n_reads] barcode ids, or NULL (no barcode rule) */
     int64_t ign_bc_below;     /* reads with global index < this get bc = -1 (BuildReadQGraph48.cc:158-159) */
     uint64_t read_index_base; /* global index of read 0 of this slab (multi-GPU slabs) */
+    const void* group;        /* u32[n_reads] group id per read (SNK_F_GROUPED), or NULL */
 } snk_dev_reads;
 
 /* All pointers are device pointers owned by the context; they stay valid until the next
@@ -149,6 +154,8 @@ typedef struct snk_dev_result {
     float kernel_ms[4];          /* HIP-event time of single launches: -, minimiser partition, count (LDS reduce), - */
     uint64_t n_boundary;         /* bucket-local graph: k-mers with a neighbour outside their bucket chunk */
     uint64_t n_fragments;        /* bucket-local graph: local unitig fragments joined at the end */
+    const void* unitig_group;    /* u32[n_unitigs] group of every unitig (SNK_F_GROUPED; unitigs ordered by group, then by
+                                    their first K bases), else NULL */
     float graph_ms[8];           /* bucket-local graph: local prune, boundary resolve, fragments, join, table sort+spectrum */
 } snk_dev_result;
 

@@ -139,6 +139,9 @@ SNK_HD uint32_t snk_bucket_of_key(uint32_t key, uint32_t NB) {
     h ^= h >> 15;
     return (uint32_t)(((uint64_t)h * NB) >> 32);
 }
+// grouped runs (per-barcode local graphs, BASELINE config 5): a k-mer belongs to (group, k-mer); the group id rides in
+// the 32 low bits of the 128-bit key (free at K=48) and is folded into the bucket choice
+SNK_HD uint32_t snk_group_mix(uint32_t group) { return snk_mix32(group * 0x9E3779B1u + 0x7F4A7C15u); }
 // bucket of a k-mer = bucket of the minimum ordering key over its K-15 16-mers (strand symmetric)
 template <int K>
 SNK_HD uint32_t snk_bucket_of_kmer(snk_kmer k, uint32_t NB) {

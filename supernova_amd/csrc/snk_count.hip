@@ -43,10 +43,19 @@ template <int K> __device__ __forceinline__ uint64_t lo_unpack(typename lo_t<K>:
 template <> __device__ __forceinline__ uint64_t lo_unpack<48>(uint32_t v) { return (uint64_t)v << 32; }
 template <> __device__ __forceinline__ uint64_t lo_unpack<60>(uint64_t v) { return v; }
 
-template <int K, int THREADS, int SLOTS>
+template <int K, bool G> struct klo_t { typedef typename lo_t<K>::type type; };
+template <int K> struct klo_t<K, true> { typedef uint64_t type; };      // grouped: the low 32 bits carry the group id
+template <int K, bool G> __device__ __forceinline__ typename klo_t<K, G>::type klo_pack(uint64_t lo) {
+    if constexpr (G) return lo; else return lo_pack<K>(lo);
+}
+template <int K, bool G> __device__ __forceinline__ uint64_t klo_unpack(typename klo_t<K, G>::type v) {
+    if constexpr (G) return v; else return lo_unpack<K>(v);
+}
+
+template <int K, int THREADS, int SLOTS, bool GROUPED>
 __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
     constexpr int BATCH = 256;                           // supermers staged per batch (owner[] holds 8-bit indices)
-    typedef typename lo_t<K>::type lo_type;
+    typedef typename klo_t<K, GROUPED>::type lo_type;
     constexpr int WMAX = K - SNK_M + 1;                  // k-mers per supermer, at most
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint64_t* khi = reinterpret_cast<uint64_t*>(smem_raw);                         // [SLOTS]
@@ -67,7 +76,7 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
     static_assert(THREADS >= BATCH && THREADS % 64 == 0, "the first BATCH threads stage the records");
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
-    const uint32_t bucket = blockIdx.x;
+    const uint32_t bucket = blockIdx.x + a.bucket0;
     constexpr uint32_t LIMIT = SLOTS - THREADS - 64;   // claims allowed before a sub-pass is declared overflowing
 
     if (tid == 0) { ctl[0] = 1; ctl[16] = 0; ctl[17] = 0; }
@@ -104,7 +113,7 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
                     rec[6 * BATCH + tid] = r1.z;
                     // word 7 becomes the barcode STATE of the (possibly merged) supermer: none / id / MULTI / IGN
                     const int32_t b = (int32_t)r1.w;
-                    rec[7 * BATCH + tid] = b > 0 ? (uint32_t)b : (b == -1 ? BC_IGN : 0u);
+                    rec[7 * BATCH + tid] = GROUPED ? r1.w : (b > 0 ? (uint32_t)b : (b == -1 ? BC_IGN : 0u));
                     nkm = r1.z & 0x7Fu;
                     wgt[tid] = 1;
                 }
@@ -132,9 +141,10 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
                         bool same = true;
 #pragma unroll
                         for (int q = 0; q < 7; ++q) same &= rec[q * BATCH + L] == w[q];
+                        if (GROUPED) same &= rec[7 * BATCH + L] == rec[7 * BATCH + tid];     // same bases in another group: not a copy
                         if (same) {
                             atomicAdd(&wgt[L], 1u);
-                            const uint32_t mine = rec[7 * BATCH + tid];
+                            const uint32_t mine = GROUPED ? 0u : rec[7 * BATCH + tid];
                             if (mine >= BC_MULTI) atomicMax(&rec[7 * BATCH + L], mine);
                             else if (mine) {
                                 uint32_t ob = atomicCAS(&rec[7 * BATCH + L], 0u, mine);
@@ -168,7 +178,8 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
                         const uint32_t j = g - pre[i];
                         const uint32_t m6 = rec[6 * BATCH + i];
                         const uint32_t n_i = m6 & 0x7Fu, hasL = (m6 >> 7) & 1u, hasR = (m6 >> 8) & 1u;
-                        const uint32_t bst = rec[7 * BATCH + i];                  // merged barcode state of the supermer
+                        const uint32_t w7 = rec[7 * BATCH + i];
+                        const uint32_t bst = GROUPED ? 0u : w7;                   // merged barcode state of the supermer
                         const uint32_t wt = wgt[i];
                         const uint32_t o = hasL + j;                     // first base of the k-mer inside the record
                         const uint32_t wi = (2u * o) >> 5, sh = (2u * o) & 31u;
@@ -194,8 +205,9 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
                         uint32_t ctx = (havepred ? (0x10u << pb) : 0u) | (havesucc ? (1u << nb) : 0u);
                         const snk_kmer r = snk_kmer_rc<K>(f);
                         const bool rev = snk_kmer_lt(r, f);          // isRev(): store the reverse complement (:164)
-                        const snk_kmer c = rev ? r : f;
+                        snk_kmer c = rev ? r : f;
                         if (rev) ctx = snk_ctx_rc(ctx);
+                        if (GROUPED) c.lo |= (uint64_t)w7;           // (group, k-mer) is the counted entity
                         uint32_t h1, h2;
                         snk_kmer_hash2(c, &h1, &h2);
                         if (a.dbg == 1) { if (h1 == 0x12345u && h2 == 0x54321u) a.status[3] = 7; }
@@ -204,7 +216,7 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
                             // tail of the probe-length distribution matters more than its mean
                             uint32_t slot = h1 & (SLOTS - 1);
                             const uint32_t stride = ((h1 >> 16) ^ (h2 >> 20)) | 1u;
-                            const lo_type clo = lo_pack<K>(c.lo);
+                            const lo_type clo = klo_pack<K, GROUPED>(c.lo);
                             const uint32_t mytag = (h2 & ~1u) | 2u;     // never 0; bit 0 = key words are in place
                             bool found = false;
                             // find-or-claim: the loop body is one tag load; key words are only read on a fingerprint hit
@@ -303,7 +315,7 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
                     if (c) {
                         const uint32_t pos = atomicAdd(&ctl[8], 1u);
                         const uint32_t cx = (ctxw[s >> 2] >> (8 * (s & 3))) & 0xFFu;
-                        a.out_keys[gbase + pos] = ((snk_u128)khi[s] << 64) | (snk_u128)lo_unpack<K>(klo[s]);
+                        a.out_keys[gbase + pos] = ((snk_u128)khi[s] << 64) | (snk_u128)klo_unpack<K, GROUPED>(klo[s]);
                         a.out_vals[gbase + pos] = ((uint64_t)c << 8) | cx;
                     }
                 }
@@ -320,18 +332,25 @@ template <int K> struct cfg;
 template <> struct cfg<48> { static constexpr int THREADS = SNK_COUNT_THREADS; static constexpr int SLOTS = SNK_COUNT_SLOTS; };
 template <> struct cfg<60> { static constexpr int THREADS = SNK_COUNT_THREADS; static constexpr int SLOTS = SNK_COUNT_SLOTS; };
 
-template <int K>
+template <int K, bool G>
 size_t lds_bytes() {
     constexpr size_t S = cfg<K>::SLOTS, B = 256;
-    return S * (8 + sizeof(typename lo_t<K>::type) + 4 + 4 + 4) + S + 4 * (8 * B + B + 4 + 64 + 2 * B + B) + B * (K - SNK_M + 1) + 16;
+    return S * (8 + sizeof(typename klo_t<K, G>::type) + 4 + 4 + 4) + S + 4 * (8 * B + B + 4 + 64 + 2 * B + B) + B * (K - SNK_M + 1) + 16;
 }
 
-template <int K>
+template <int K, bool G>
 int launch(hipStream_t st, const snk_count_args& a, char* err, size_t errcap) {
-    auto kern = snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS>;
-    size_t lds = lds_bytes<K>();
+    auto kern = snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G>;
+    size_t lds = lds_bytes<K, G>();
     SNK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(a.NB), dim3(cfg<K>::THREADS), lds, st, a);
+    // a launch is limited to 2^32 threads in total: buckets go out in slices of 4 M workgroups
+    constexpr uint32_t SLICE = 1u << 22;
+    snk_count_args b = a;
+    for (uint32_t b0 = 0; b0 < a.NB; b0 += SLICE) {
+        b.bucket0 = b0;
+        const uint32_t nb = a.NB - b0 < SLICE ? a.NB - b0 : SLICE;
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(cfg<K>::THREADS), lds, st, b);
+    }
     SNK_HIP_TRY(hipGetLastError());
     return SNK_OK;
 }
@@ -366,7 +385,11 @@ uint32_t snk_count_slots(uint32_t K) { return K == 60 ? cfg<60>::SLOTS : cfg<48>
 
 int snk_launch_count(uint32_t K, hipStream_t st, const snk_count_args& a, char* err, size_t errcap) {
     if (a.NB == 0) return SNK_OK;
-    if (K == 48) return launch<48>(st, a, err, errcap);
-    if (K == 60) return launch<60>(st, a, err, errcap);
+    if (a.grouped) {
+        if (K != 48 || a.bc_mode) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "grouped counting needs K=48 and no barcode rule");
+        return launch<48, true>(st, a, err, errcap);
+    }
+    if (K == 48) return launch<48, false>(st, a, err, errcap);
+    if (K == 60) return launch<60, false>(st, a, err, errcap);
     return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "K=%u is not supported (48 or 60)", K);
 }

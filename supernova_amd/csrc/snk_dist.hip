@@ -101,7 +101,7 @@ extern "C" int snk_shard_count(snk_ctx* ctx, const void* d_records, const void* 
     snk_shard_state* S = state_of(ctx);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     int rc = snk_stage_count_table(ctx, st, S->params.K, d_records, (const uint64_t*)d_seg_off, (const uint64_t*)d_seg_off + 1, S->NBl + 1, S->world, S->NBl, S->params.min_freq,
-                                   has_bc ? S->params.min_bc : 0u, n_inst_hint, S->status, false, &S->tab, err, errcap);
+                                   has_bc ? S->params.min_bc : 0u, 0u, n_inst_hint, S->status, false, &S->tab, err, errcap);
     if (rc) return rc;
     if (n_kmers) *n_kmers = S->tab.n;
     return SNK_OK;

@@ -12,6 +12,7 @@ struct snk_graph_out {
     uint64_t total_bases;
     uint64_t* unitig_off;         // [n_unitigs+1] offsets into unitig_bases
     uint8_t* unitig_bases;        // base codes, canonical orientation, ordered by head k-mer
+    uint32_t* unitig_group;       // grouped runs: group of every unitig, else NULL
     uint32_t n_circles;
     uint32_t rank_rounds;
     uint64_t n_boundary;          // bucket-local path: k-mers with a neighbour outside their chunk
@@ -50,12 +51,14 @@ struct snk_frag_out {
     uint8_t* bases;
     unsigned long long* spectrum;
     uint32_t spectrum_bins, n_circles, rank_rounds;
+    uint32_t* fgroup;          // grouped runs: group of every fragment, else NULL
 };
 struct snk_join_out {
     uint64_t n_unitigs, total_bases;
     uint64_t* unitig_off;
     uint8_t* unitig_bases;
     uint8_t* unitig_circular;   // 1: a circle that spanned fragments (already rotated to the reference's cut)
+    uint32_t* unitig_group;     // grouped runs (fgroup given): group of every unitig; unitigs ordered by (group, first K bases)
     uint32_t n_circles, rank_rounds, n_circles_rotated;
 };
 int snk_dist_prune_plan(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, char* err, size_t errcap);
@@ -69,7 +72,7 @@ int snk_dist_fragments(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, const un
                        unsigned long long my_node_off, snk_frag_out* out, char* err, size_t errcap);
 int snk_dist_join(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const uint32_t* nk, const unsigned long long* hl_self,
                   const unsigned long long* hl_nb, const uint64_t* boff, const uint8_t* fbases, uint64_t total_fbases,
-                  snk_join_out* out, char* err, size_t errcap);
+                  snk_join_out* out, char* err, size_t errcap, const uint32_t* fgroup = nullptr);
 
 // ---- bucket-local graph stage (snk_local.hip): table in chunk order -> pruned contexts + canonical unitigs
 struct snk_table;
@@ -92,5 +95,6 @@ int snk_bl_dist_fill(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, const unsign
 int snk_bl_dist_fragments(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, const unsigned long long* d_node_off, unsigned long long my_node_off,
                           snk_frag_out* out, char* err, size_t errcap);
 int snk_local_graph(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_table* tab, uint32_t do_prune, bool want_unitigs,
-                    bool sort_table, snk_graph_out* out, snk_u128** keys_final, float* ms /* [5] or NULL */, char* err, size_t errcap);
+                    bool sort_table, bool grouped, snk_graph_out* out, snk_u128** keys_final, float* ms /* [5] or NULL */, char* err,
+                    size_t errcap);
 int snk_launch_spectrum(hipStream_t st, const uint32_t* counts, uint64_t n, unsigned long long* bins, uint32_t nbins);

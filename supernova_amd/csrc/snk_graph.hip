@@ -945,7 +945,8 @@ __global__ void __launch_bounds__(TB) jhead_kernel(const uint2* __restrict__ rk,
 __global__ void __launch_bounds__(TB) jhead_place_kernel(const uint2* __restrict__ rk, const uint32_t* __restrict__ hflag,
                                                          const uint32_t* __restrict__ hidx, const uint64_t* __restrict__ hoff,
                                                          const uint8_t* __restrict__ circ, uint64_t F, uint64_t* __restrict__ poff,
-                                                         uint64_t* __restrict__ uoff, uint8_t* __restrict__ ucirc) {
+                                                         uint64_t* __restrict__ uoff, uint8_t* __restrict__ ucirc,
+                                                         const uint32_t* __restrict__ fgroup, uint32_t* __restrict__ ugroup) {
     uint64_t f = (uint64_t)blockIdx.x * TB + threadIdx.x;
     if (f >= F || !hflag[f]) return;
     uint32_t tL = rk[2 * f].y, tR = rk[2 * f + 1].y;
@@ -953,6 +954,7 @@ __global__ void __launch_bounds__(TB) jhead_place_kernel(const uint2* __restrict
     poff[pid] = hoff[f];
     uoff[hidx[f]] = hoff[f];
     ucirc[hidx[f]] = circ[pid];
+    if (fgroup) ugroup[hidx[f]] = fgroup[f];
 }
 // number of 256-base chunks of every fragment (work items of the copy kernel)
 __global__ void __launch_bounds__(TB) jchunks_kernel(const uint64_t* __restrict__ boff, uint64_t F, uint32_t* __restrict__ nch) {
@@ -1076,14 +1078,17 @@ __global__ void __launch_bounds__(256) jcircle_kernel(const uint32_t* __restrict
 // deterministic output order: unitigs sorted by their first K bases (every k-mer belongs to exactly one unitig)
 template <int K>
 __global__ void __launch_bounds__(TB) jorder_key_kernel(const uint64_t* __restrict__ uoff, const uint8_t* __restrict__ bases, uint64_t U,
-                                                        snk_u128* __restrict__ key, uint32_t* __restrict__ idx) {
+                                                        const uint32_t* __restrict__ ugroup, snk_u128* __restrict__ key,
+                                                        uint32_t* __restrict__ idx) {
     uint64_t u = (uint64_t)blockIdx.x * TB + threadIdx.x;
     if (u >= U) return;
     const uint8_t* b = bases + uoff[u];
     snk_kmer f;
     f.hi = 0; f.lo = 0;
     for (int q = 0; q < K; ++q) f = snk_kmer_succ<K>(f, b[q]);
-    key[u] = ((snk_u128)f.hi << 64) | (snk_u128)f.lo;
+    snk_u128 k = ((snk_u128)f.hi << 64) | (snk_u128)f.lo;
+    if (ugroup) k = ((snk_u128)ugroup[u] << 96) | (k >> 32);      // grouped runs (K=48: 96 key bits): group-major order
+    key[u] = k;
     idx[u] = (uint32_t)u;
 }
 __global__ void __launch_bounds__(TB) jorder_len_kernel(const uint64_t* __restrict__ uoff, const uint32_t* __restrict__ idx, uint64_t U,
@@ -1096,12 +1101,13 @@ __global__ void __launch_bounds__(256) jorder_copy_kernel(const uint32_t* __rest
                                                           const uint64_t* __restrict__ noff, const uint64_t* __restrict__ uoff,
                                                           const uint32_t* __restrict__ idx, const uint8_t* __restrict__ in,
                                                           const uint8_t* __restrict__ circ_in, uint8_t* __restrict__ out,
-                                                          uint8_t* __restrict__ circ_out) {
+                                                          uint8_t* __restrict__ circ_out, const uint32_t* __restrict__ grp_in,
+                                                          uint32_t* __restrict__ grp_out) {
     const uint32_t item = blockIdx.x;
     const uint32_t r = owner[item];
     const uint64_t len = noff[r + 1] - noff[r];
     const uint64_t p0 = (uint64_t)(item - choff[r]) * 256 + threadIdx.x;
-    if (p0 == 0) circ_out[r] = circ_in[idx[r]];
+    if (p0 == 0) { circ_out[r] = circ_in[idx[r]]; if (grp_in) grp_out[r] = grp_in[idx[r]]; }
     if (p0 >= len) return;
     out[noff[r] + p0] = in[uoff[idx[r]] + p0];
 }
@@ -1272,7 +1278,7 @@ int snk_dist_fragments(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, const un
 // rank 0: fragments of every rank -> canonical unitigs
 int snk_dist_join(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const uint32_t* nk, const unsigned long long* hl_self,
                   const unsigned long long* hl_nb, const uint64_t* boff, const uint8_t* fbases, uint64_t total_fbases,
-                  snk_join_out* out, char* err, size_t errcap) {
+                  snk_join_out* out, char* err, size_t errcap, const uint32_t* fgroup) {
     memset(out, 0, sizeof *out);
     if (F == 0) {
         G_ALLOC(out->unitig_off, uint64_t, 1);
@@ -1321,9 +1327,11 @@ int snk_dist_join(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
     G_ALLOC(uoff, uint64_t, U + 1);
     G_ALLOC(ucirc, uint8_t, U + 1);
     G_ALLOC(urev, uint8_t, U + 1);
+    uint32_t* ugroup = nullptr;
+    if (fgroup) G_ALLOC(ugroup, uint32_t, U + 1);
     G_ALLOC(prov, uint8_t, h_tot + 1);
     G_ALLOC(final_bases, uint8_t, h_tot + 1);
-    hipLaunchKernelGGL(jhead_place_kernel, dim3(nblk(F)), dim3(TB), 0, st, rk, hflag, hidx, hoff, circ, F, poff, uoff, ucirc);
+    hipLaunchKernelGGL(jhead_place_kernel, dim3(nblk(F)), dim3(TB), 0, st, rk, hflag, hidx, hoff, circ, F, poff, uoff, ucirc, fgroup, ugroup);
     SNK_HIP_TRY(hipMemcpyAsync(uoff + U, hoff + F, 8, hipMemcpyDeviceToDevice, st));
     // copy every fragment into place
     hipLaunchKernelGGL(jemit_kernel, dim3((unsigned)((F + 31) / 32)), dim3(256), 0, st, F, boff, fbases, rk, nk, poff, K, prov);
@@ -1355,6 +1363,7 @@ int snk_dist_join(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
     uint64_t* noff = uoff;
     uint8_t* obases = final_bases;
     uint8_t* ocirc = ucirc;
+    uint32_t* ogroup = ugroup;
     if (U > 1) {
         snk_u128 *ok_in, *ok_out;
         uint32_t *oi_in, *oi_out;
@@ -1366,9 +1375,10 @@ int snk_dist_join(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
         G_ALLOC(olen, uint64_t, U + 1);
         G_ALLOC(noff, uint64_t, U + 1);
         G_ALLOC(ocirc, uint8_t, U + 1);
+        if (ugroup) G_ALLOC(ogroup, uint32_t, U + 1);
         obases = prov;         // the provisional buffer is dead: reuse it for the ordered copy
-        if (K == 48) hipLaunchKernelGGL((jorder_key_kernel<48>), dim3(nblk(U)), dim3(TB), 0, st, uoff, final_bases, U, ok_in, oi_in);
-        else hipLaunchKernelGGL((jorder_key_kernel<60>), dim3(nblk(U)), dim3(TB), 0, st, uoff, final_bases, U, ok_in, oi_in);
+        if (K == 48) hipLaunchKernelGGL((jorder_key_kernel<48>), dim3(nblk(U)), dim3(TB), 0, st, uoff, final_bases, U, (const uint32_t*)ugroup, ok_in, oi_in);
+        else hipLaunchKernelGGL((jorder_key_kernel<60>), dim3(nblk(U)), dim3(TB), 0, st, uoff, final_bases, U, (const uint32_t*)ugroup, ok_in, oi_in);
         {
             size_t tb = 0;
             SNK_HIP_TRY(rocprim::radix_sort_pairs((void*)nullptr, tb, ok_in, ok_out, oi_in, oi_out, (size_t)U, 0u, 128u, st));
@@ -1383,7 +1393,7 @@ int snk_dist_join(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
         SNK_HIP_TRY(hipMemsetAsync(onch + U, 0, 4, st));
         hipLaunchKernelGGL(jchunks_kernel, dim3(nblk(U)), dim3(TB), 0, st, noff, U, onch);
         if ((rc = chunk_owners(ctx, st, onch, U, &ochoff, &oowner, &ototal, err, errcap))) return rc;
-        if (ototal) hipLaunchKernelGGL(jorder_copy_kernel, dim3(ototal), dim3(256), 0, st, oowner, ochoff, noff, uoff, oi_out, final_bases, ucirc, obases, ocirc);
+        if (ototal) hipLaunchKernelGGL(jorder_copy_kernel, dim3(ototal), dim3(256), 0, st, oowner, ochoff, noff, uoff, oi_out, final_bases, ucirc, obases, ocirc, (const uint32_t*)ugroup, ogroup);
         SNK_HIP_TRY(hipGetLastError());
     }
     SNK_HIP_TRY(hipStreamSynchronize(st));
@@ -1392,6 +1402,7 @@ int snk_dist_join(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
     out->unitig_off = noff;
     out->unitig_bases = obases;
     out->unitig_circular = ocirc;
+    out->unitig_group = ogroup;
     return SNK_OK;
 }
 

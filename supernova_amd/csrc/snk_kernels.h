@@ -22,6 +22,7 @@ struct snk_msp_args {
     uint32_t row_words;
     const uint16_t* good_len;
     const int32_t* bc;
+    const uint32_t* group;         // grouped runs: group id per read (then record word 7 = group), else NULL
     int64_t ign_bc_below;
     uint64_t read_index_base, n_reads;
     uint32_t NB;
@@ -55,6 +56,8 @@ struct snk_count_args {
     uint32_t NB;
     uint32_t min_freq;
     uint32_t bc_mode;              // 0: no barcode rule, 1: >=1 barcode>0 (or ignore-rule read), 2: >=2 distinct
+    uint32_t bucket0;              // first bucket of this launch (set by the launcher)
+    uint32_t grouped;              // record word 7 is a group id that becomes the low 32 bits of the key (K=48 only)
     snk_u128* out_keys;            // canonical k-mer values (hi<<64|lo); region r owns [r*region_cap, (r+1)*region_cap)
     uint64_t* out_vals;            // count << 8 | raw context byte
     uint64_t region_cap;

@@ -94,7 +94,7 @@ __device__ __forceinline__ uint32_t oriented_base(snk_kmer k, bool rc, int idx) 
 }
 
 // ---------------------------------------------------------------------------------------------- L1: local prune
-template <int K, int CAP, int T, bool BIG>
+template <int K, int CAP, int T, bool BIG, bool GR>
 __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __restrict__ desc, uint32_t NB, bl_shard sh,
                                                      const snk_u128* __restrict__ keys, const uint64_t* __restrict__ vals,
                                                      uint32_t do_prune, uint8_t* __restrict__ ctx_out,
@@ -153,6 +153,8 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
         snk_kmer k;
         k.hi = act ? khi[i] : 0ull;
         k.lo = act ? klo[i] : 0ull;
+        uint64_t tag = 0;                                    // grouped runs: the group id in the low 32 key bits
+        if (GR) { tag = k.lo & 0xFFFFFFFFull; k.lo &= ~0xFFFFFFFFull; }
         const uint64_t v = myv[q];
         const uint32_t c0 = (uint32_t)(v & 0xFFu);
         uint32_t keep = 0, miss = 0, nb0 = NONE, nb1 = NONE;
@@ -161,7 +163,8 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
             const snk_kmer y = bit < 4 ? snk_kmer_succ<K>(k, bit) : snk_kmer_pred<K>(k, bit - 4);
             const snk_kmer r = snk_kmer_rc<K>(y);
             const bool rev = snk_kmer_lt(r, y);
-            const snk_kmer cy = rev ? r : y;
+            snk_kmer cy = rev ? r : y;
+            if (GR) cy.lo |= tag;                            // neighbours live in the same group
             int32_t j = -1;
             uint32_t slot = lhash(cy.hi, cy.lo) & (HT - 1);
             for (;;) {
@@ -202,6 +205,8 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
             snk_kmer kk;
             kk.hi = on ? khi[ni] : 0ull;
             kk.lo = on ? klo[ni] : 0ull;
+            uint64_t ktag = 0;
+            if (GR) { ktag = kk.lo & 0xFFFFFFFFull; kk.lo &= ~0xFFFFFFFFull; }
             const int first = bit < 4 ? 1 : 0;   // successors share positions 1..K-M, predecessors 0..K-M-1
             uint32_t mk = 0xFFFFFFFFu;
             for (int t = 0; t < PER; ++t) {
@@ -230,13 +235,15 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
                 } else x = (uint32_t)(y.hi >> 32);
                 const uint32_t nkey = snk_minimizer_key(x, snk_rev2_32(~x));
                 if (nkey < mk) mk = nkey;
-                const uint32_t gb = snk_bucket_of_key(mk, NB);               // global bucket id of the neighbour
+                const uint32_t gb = snk_bucket_of_key(mk ^ (GR ? snk_group_mix((uint32_t)ktag) : 0u), NB);   // (global) bucket of the neighbour
                 bool here = gb == sh.bucket_base + ch.bucket;
                 const bool remote = sh.NBl && gb / sh.NBl != sh.me;              // lives (if anywhere) on another rank
                 if (here && ch.lg) {
                     const snk_kmer r = snk_kmer_rc<K>(y);
+                    snk_kmer cn = snk_kmer_lt(r, y) ? r : y;
+                    if (GR) cn.lo |= ktag;
                     uint32_t h1, h2;
-                    snk_kmer_hash2(snk_kmer_lt(r, y) ? r : y, &h1, &h2);
+                    snk_kmer_hash2(cn, &h1, &h2);
                     here = (h2 & split_mask) == ch.id;
                 }
                 if (here) { if (!do_prune) atomicOr(&resL[th], 1u << bit); }
@@ -262,7 +269,7 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
     __syncthreads();
     if (tid == 0) nbnd[c] = bcnt;
 }
-template <int K, int CAP, int T, bool BIG>
+template <int K, int CAP, int T, bool BIG, bool GR>
 __global__ void __launch_bounds__(T) bl_prune_kernel(const uint4* __restrict__ desc, uint32_t NB, bl_shard sh, const uint32_t* __restrict__ biglist_in,
                                                      uint32_t nchunks, uint32_t cpw,
                                                      const snk_u128* __restrict__ keys, const uint64_t* __restrict__ vals,
@@ -273,7 +280,7 @@ __global__ void __launch_bounds__(T) bl_prune_kernel(const uint4* __restrict__ d
     for (uint32_t r = 0; r < cpw; ++r) {
         const uint32_t w = blockIdx.x * cpw + r;
         if (w >= nchunks) return;
-        bl_prune_chunk<K, CAP, T, BIG>(BIG ? biglist_in[w] : w, desc, NB, sh, keys, vals, do_prune, ctx_out, count_out, pend_out, nbr_out,
+        bl_prune_chunk<K, CAP, T, BIG, GR>(BIG ? biglist_in[w] : w, desc, NB, sh, keys, vals, do_prune, ctx_out, count_out, pend_out, nbr_out,
                                        nbnd, biglist, nbig);
     }
 }
@@ -296,7 +303,7 @@ __global__ void __launch_bounds__(TB) bl_index_build_kernel(const snk_u128* __re
 }
 // Only ~12 % of the k-mers have a pending bit: a workgroup scans 2048 pend bytes (8 per lane, one 8-byte load),
 // gathers the boundary k-mers into an LDS list and resolves them with all lanes busy.
-template <int K>
+template <int K, bool GR>
 __global__ void __launch_bounds__(TB) bl_resolve_kernel(const snk_u128* __restrict__ keys, const uint8_t* __restrict__ pend,
                                                         uint64_t n, const unsigned long long* __restrict__ tab, uint64_t mask,
                                                         uint32_t do_prune, uint8_t* __restrict__ ctx, uint32_t* __restrict__ rq,
@@ -324,14 +331,17 @@ __global__ void __launch_bounds__(TB) bl_resolve_kernel(const snk_u128* __restri
     for (uint32_t it = threadIdx.x; it < m; it += TB) {
         const uint64_t i = base + list[it];
         const uint32_t pm = pend[i] & (premote ? ~(uint32_t)premote[i] : 0xFFu);
-        const snk_kmer k = load_key(keys, i);
+        snk_kmer k = load_key(keys, i);
+        uint64_t tag = 0;
+        if (GR) { tag = k.lo & 0xFFFFFFFFull; k.lo &= ~0xFFFFFFFFull; }
         uint32_t c = ctx[i];
         for (uint32_t rem = pm; rem; rem &= rem - 1) {
             const uint32_t bit = __ffs(rem) - 1;
             const snk_kmer y = bit < 4 ? snk_kmer_succ<K>(k, bit) : snk_kmer_pred<K>(k, bit - 4);
             const snk_kmer r = snk_kmer_rc<K>(y);
             const bool rev = snk_kmer_lt(r, y);
-            const snk_kmer cy = rev ? r : y;
+            snk_kmer cy = rev ? r : y;
+            if (GR) cy.lo |= tag;
             uint32_t h1, h2;
             snk_kmer_hash2(cy, &h1, &h2);
             uint64_t slot = (((uint64_t)h1 << 32) | h2) & mask;
@@ -364,7 +374,7 @@ struct bl_dist_args {          // sharded runs: remote neighbours and the global
     const unsigned long long* node_off;
     unsigned long long my_node_off;
 };
-template <int K, int CAP, int T, bool BIG, bool EMIT, bool DIST>
+template <int K, int CAP, int T, bool BIG, bool EMIT, bool DIST, bool GR>
 __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ desc, const uint32_t* __restrict__ biglist_in,
                                                     const snk_u128* __restrict__ keys, const uint8_t* __restrict__ ctx,
                                                     const uint8_t* __restrict__ pend, const uint32_t* __restrict__ nbr,
@@ -372,7 +382,7 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
                                                     const uint32_t* __restrict__ foff, const uint64_t* __restrict__ boff,
                                                     uint32_t* __restrict__ nk, unsigned long long* __restrict__ hl_self,
                                                     unsigned long long* __restrict__ hl_nb, uint64_t* __restrict__ bstart,
-                                                    uint8_t* __restrict__ fbases) {
+                                                    uint8_t* __restrict__ fbases, uint32_t* __restrict__ fgroup) {
     constexpr int SPT = (2 * CAP + T - 1) / T;        // states per thread
     __shared__ uint64_t khi[CAP], klo[CAP];
     __shared__ uint16_t nbL[2 * CAP];                  // local neighbour << 1 | rev (chunk-local indices fit 16 bits)
@@ -395,7 +405,9 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
         const snk_kmer k = load_key(keys, gi);
         khi[i] = k.hi;
         klo[i] = k.lo;
-        palL[i] = snk_kmer_eq(k, snk_kmer_rc<K>(k)) ? 1 : 0;
+        snk_kmer kb = k;
+        if (GR) kb.lo &= ~0xFFFFFFFFull;                   // the group id is not part of the sequence
+        palL[i] = snk_kmer_eq(kb, snk_kmer_rc<K>(kb)) ? 1 : 0;
         ctxL[i] = ctx[gi];
         pendL[i] = pend[gi];
         const uint32_t n0 = nbr[2 * gi], n1 = nbr[2 * gi + 1];
@@ -474,7 +486,7 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
         if (!((pendL[i] >> (4 * side + b)) & 1u)) return NONE64;
         snk_kmer k;
         k.hi = khi[i];
-        k.lo = klo[i];
+        k.lo = GR ? (klo[i] & ~0xFFFFFFFFull) : klo[i];
         const snk_kmer y = side ? snk_kmer_pred<K>(k, b) : snk_kmer_succ<K>(k, b);
         if (snk_kmer_eq(y, snk_kmer_rc<K>(y))) return NONE64;
         const uint64_t gi = ch.base + i;
@@ -501,6 +513,7 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
         hl_nb[2 * f] = with_half ? half_link(pid) : NONE64;
         hl_nb[2 * f + 1] = with_half ? half_link(other) : NONE64;
         bstart[f] = c_boff + rel;
+        if (GR) fgroup[f] = (uint32_t)klo[head_node];
         foffL[pid] = (uint16_t)rel;
         hnode[lf] = (uint16_t)((head_node << 1) | (head_rc ? 1u : 0u));
         return rel;
@@ -706,7 +719,7 @@ __global__ void __launch_bounds__(TB) bl_query_kernel(const snk_u128* __restrict
 }  // namespace
 
 // ---- stage 1: chunk records, local prune, boundary index, pending bits of this rank resolved
-template <int K>
+template <int K, bool GR>
 static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* err, size_t errcap) {
     const snk_table* tab = B->tab;
     const uint64_t n = tab->n;
@@ -746,7 +759,7 @@ static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* er
     sh.premote = B->premote;
     const uint32_t NBh = B->premote ? B->NB_total : tab->NB;      // bucket count of the minimiser hash
     const uint32_t cpw = 1;
-    hipLaunchKernelGGL((bl_prune_kernel<K, SCAP, ST, false>), dim3((nchunks + cpw - 1) / cpw), dim3(ST), 0, st, (const uint4*)B->desc, NBh, sh,
+    hipLaunchKernelGGL((bl_prune_kernel<K, SCAP, ST, false, GR>), dim3((nchunks + cpw - 1) / cpw), dim3(ST), 0, st, (const uint4*)B->desc, NBh, sh,
                        (const uint32_t*)nullptr, nchunks, cpw, tab->keys, tab->vals, B->do_prune, B->ctx, B->counts, B->pend, B->nbr, nbnd,
                        B->biglist, ctr);
     SNK_HIP_TRY(hipGetLastError());
@@ -755,7 +768,7 @@ static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* er
     SNK_HIP_TRY(hipStreamSynchronize(st));
     B->nbig = h_nbig;
     if (h_nbig)
-        hipLaunchKernelGGL((bl_prune_kernel<K, BCAP, BT, true>), dim3(h_nbig), dim3(BT), 0, st, (const uint4*)B->desc, NBh, sh,
+        hipLaunchKernelGGL((bl_prune_kernel<K, BCAP, BT, true, GR>), dim3(h_nbig), dim3(BT), 0, st, (const uint4*)B->desc, NBh, sh,
                            (const uint32_t*)B->biglist, h_nbig, 1u, tab->keys, tab->vals, B->do_prune, B->ctx, B->counts, B->pend, B->nbr,
                            nbnd, B->biglist, ctr);
     SNK_HIP_TRY(hipGetLastError());
@@ -781,7 +794,7 @@ static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* er
     SNK_HIP_TRY(hipMemsetAsync(B->index, 0, tg * 8, st));
     if (h_bnd) {
         hipLaunchKernelGGL(bl_index_build_kernel, dim3(nblk(n)), dim3(TB), 0, st, tab->keys, B->pend, n, B->index, tg - 1);
-        hipLaunchKernelGGL((bl_resolve_kernel<K>), dim3((unsigned)((n + 8 * TB - 1) / (8 * TB))), dim3(TB), 0, st, tab->keys, B->pend, n,
+        hipLaunchKernelGGL((bl_resolve_kernel<K, GR>), dim3((unsigned)((n + 8 * TB - 1) / (8 * TB))), dim3(TB), 0, st, tab->keys, B->pend, n,
                            B->index, tg - 1, B->do_prune, B->ctx, B->rq, (const uint8_t*)B->premote);
     }
     SNK_HIP_TRY(hipGetLastError());
@@ -789,7 +802,7 @@ static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* er
 }
 
 // ---- stage 2: fragments of every chunk (exact sizing pass, then the writes)
-template <int K, bool DIST>
+template <int K, bool DIST, bool GR>
 static int bl_fragments_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, const bl_dist_args& da, snk_frag_out* out, char* err,
                              size_t errcap) {
     const snk_table* tab = B->tab;
@@ -801,15 +814,15 @@ static int bl_fragments_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, cons
     G_ALLOC(nbases, uint64_t, (uint64_t)nchunks + 1);
     G_ALLOC(boff, uint64_t, (uint64_t)nchunks + 1);
     SNK_HIP_TRY(hipMemsetAsync(nfrag, 0, ((uint64_t)nchunks + 1) * 4, st));
-    hipLaunchKernelGGL((bl_frag_kernel<K, SCAP, ST, false, false, DIST>), dim3(nchunks), dim3(ST), 0, st, (const uint4*)B->desc,
+    hipLaunchKernelGGL((bl_frag_kernel<K, SCAP, ST, false, false, DIST, GR>), dim3(nchunks), dim3(ST), 0, st, (const uint4*)B->desc,
                        (const uint32_t*)nullptr, tab->keys, B->ctx, B->pend, B->nbr, B->rq, da, nfrag, (const uint32_t*)nullptr,
                        (const uint64_t*)nullptr, (uint32_t*)nullptr, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                       (uint64_t*)nullptr, (uint8_t*)nullptr);
+                       (uint64_t*)nullptr, (uint8_t*)nullptr, (uint32_t*)nullptr);
     if (h_nbig)
-        hipLaunchKernelGGL((bl_frag_kernel<K, BCAP, BT, true, false, DIST>), dim3(h_nbig), dim3(BT), 0, st, (const uint4*)B->desc,
+        hipLaunchKernelGGL((bl_frag_kernel<K, BCAP, BT, true, false, DIST, GR>), dim3(h_nbig), dim3(BT), 0, st, (const uint4*)B->desc,
                            (const uint32_t*)B->biglist, tab->keys, B->ctx, B->pend, B->nbr, B->rq, da, nfrag, (const uint32_t*)nullptr,
                            (const uint64_t*)nullptr, (uint32_t*)nullptr, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                           (uint64_t*)nullptr, (uint8_t*)nullptr);
+                           (uint64_t*)nullptr, (uint8_t*)nullptr, (uint32_t*)nullptr);
     hipLaunchKernelGGL(bl_chunk_bases_kernel, dim3(nblk((uint64_t)nchunks + 1)), dim3(TB), 0, st, (const uint4*)B->desc, nfrag, nchunks,
                        (uint32_t)K, nbases);
     SNK_HIP_TRY(hipGetLastError());
@@ -826,20 +839,22 @@ static int bl_fragments_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, cons
     G_ALLOC(out->hl_nb, unsigned long long, 2ull * h_F + 2);
     G_ALLOC(out->boff, uint64_t, (uint64_t)h_F + 2);
     G_ALLOC(out->bases, uint8_t, h_B + 16);
-    hipLaunchKernelGGL((bl_frag_kernel<K, SCAP, ST, false, true, DIST>), dim3(nchunks), dim3(ST), 0, st, (const uint4*)B->desc,
+    out->fgroup = nullptr;
+    if (GR) G_ALLOC(out->fgroup, uint32_t, (uint64_t)h_F + 1);
+    hipLaunchKernelGGL((bl_frag_kernel<K, SCAP, ST, false, true, DIST, GR>), dim3(nchunks), dim3(ST), 0, st, (const uint4*)B->desc,
                        (const uint32_t*)nullptr, tab->keys, B->ctx, B->pend, B->nbr, B->rq, da, nfrag, foff, boff, out->nk, out->hl_self,
-                       out->hl_nb, out->boff, out->bases);
+                       out->hl_nb, out->boff, out->bases, out->fgroup);
     if (h_nbig)
-        hipLaunchKernelGGL((bl_frag_kernel<K, BCAP, BT, true, true, DIST>), dim3(h_nbig), dim3(BT), 0, st, (const uint4*)B->desc,
+        hipLaunchKernelGGL((bl_frag_kernel<K, BCAP, BT, true, true, DIST, GR>), dim3(h_nbig), dim3(BT), 0, st, (const uint4*)B->desc,
                            (const uint32_t*)B->biglist, tab->keys, B->ctx, B->pend, B->nbr, B->rq, da, nfrag, foff, boff, out->nk,
-                           out->hl_self, out->hl_nb, out->boff, out->bases);
+                           out->hl_self, out->hl_nb, out->boff, out->bases, out->fgroup);
     SNK_HIP_TRY(hipGetLastError());
     out->n_frags = h_F;
     out->total_bases = h_B;
     return SNK_OK;
 }
 
-template <int K>
+template <int K, bool GR>
 static int local_graph_impl(snk_ctx* ctx, hipStream_t st, const snk_table* tab, uint32_t do_prune, bool want_unitigs,
                             bool sort_table, snk_graph_out* out, snk_u128** keys_final, float* ms, char* err, size_t errcap) {
     memset(out, 0, sizeof *out);
@@ -868,7 +883,7 @@ static int local_graph_impl(snk_ctx* ctx, hipStream_t st, const snk_table* tab, 
     B.K = K;
     B.world = 1;
     B.do_prune = do_prune;
-    int rc = bl_prune_impl<K>(ctx, st, &B, err, errcap);
+    int rc = bl_prune_impl<K, GR>(ctx, st, &B, err, errcap);
     if (rc) return rc;
     tm.mark();  // 1
     tm.mark();  // 2
@@ -878,16 +893,17 @@ static int local_graph_impl(snk_ctx* ctx, hipStream_t st, const snk_table* tab, 
         memset(&fo, 0, sizeof fo);
         bl_dist_args da;
         memset(&da, 0, sizeof da);
-        if ((rc = bl_fragments_impl<K, false>(ctx, st, &B, da, &fo, err, errcap))) return rc;
+        if ((rc = bl_fragments_impl<K, false, GR>(ctx, st, &B, da, &fo, err, errcap))) return rc;
         tm.mark();  // 3
         snk_join_out jo;
-        rc = snk_dist_join(ctx, st, K, fo.n_frags, fo.nk, fo.hl_self, fo.hl_nb, fo.boff, fo.bases, fo.total_bases, &jo, err, errcap);
+        rc = snk_dist_join(ctx, st, K, fo.n_frags, fo.nk, fo.hl_self, fo.hl_nb, fo.boff, fo.bases, fo.total_bases, &jo, err, errcap, fo.fgroup);
         if (rc) return rc;
         tm.mark();  // 4
         out->n_unitigs = jo.n_unitigs;
         out->total_bases = jo.total_bases;
         out->unitig_off = jo.unitig_off;
         out->unitig_bases = jo.unitig_bases;
+        out->unitig_group = jo.unitig_group;
         out->n_circles = jo.n_circles;
         out->rank_rounds = jo.rank_rounds;
         out->n_fragments = fo.n_frags;
@@ -920,10 +936,14 @@ static int local_graph_impl(snk_ctx* ctx, hipStream_t st, const snk_table* tab, 
 }
 
 int snk_local_graph(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_table* tab, uint32_t do_prune, bool want_unitigs,
-                    bool sort_table, snk_graph_out* out, snk_u128** keys_final, float* ms, char* err, size_t errcap) {
+                    bool sort_table, bool grouped, snk_graph_out* out, snk_u128** keys_final, float* ms, char* err, size_t errcap) {
     if (tab->sorted) return snk_fail(SNK_E_INTERNAL, err, errcap, "bucket-local graph needs the table in chunk order");
-    if (K == 48) return local_graph_impl<48>(ctx, st, tab, do_prune, want_unitigs, sort_table, out, keys_final, ms, err, errcap);
-    if (K == 60) return local_graph_impl<60>(ctx, st, tab, do_prune, want_unitigs, sort_table, out, keys_final, ms, err, errcap);
+    if (grouped) {
+        if (K != 48) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "grouped graphs need K=48");
+        return local_graph_impl<48, true>(ctx, st, tab, do_prune, want_unitigs, sort_table, out, keys_final, ms, err, errcap);
+    }
+    if (K == 48) return local_graph_impl<48, false>(ctx, st, tab, do_prune, want_unitigs, sort_table, out, keys_final, ms, err, errcap);
+    if (K == 60) return local_graph_impl<60, false>(ctx, st, tab, do_prune, want_unitigs, sort_table, out, keys_final, ms, err, errcap);
     return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "K=%u is not supported (48 or 60)", K);
 }
 
@@ -947,7 +967,7 @@ int snk_bl_dist_plan(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, unsigned lon
         return SNK_OK;
     }
     if (n >= (1ull << 31)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "more than 2^31 retained k-mers on one GPU (%llu)", (unsigned long long)n);
-    int rc = B->K == 48 ? bl_prune_impl<48>(ctx, st, B, err, errcap) : bl_prune_impl<60>(ctx, st, B, err, errcap);
+    int rc = B->K == 48 ? bl_prune_impl<48, false>(ctx, st, B, err, errcap) : bl_prune_impl<60, false>(ctx, st, B, err, errcap);
     if (rc) return rc;
     const size_t lds = (size_t)B->world * 12 + 16;
     const unsigned grid = (unsigned)((n + QSPAN - 1) / QSPAN);
@@ -995,7 +1015,7 @@ int snk_bl_dist_fragments(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, const u
     da.rq_meta = B->rq_meta;
     da.node_off = d_node_off;
     da.my_node_off = my_node_off;
-    int rc = B->K == 48 ? bl_fragments_impl<48, true>(ctx, st, B, da, out, err, errcap) : bl_fragments_impl<60, true>(ctx, st, B, da, out, err, errcap);
+    int rc = B->K == 48 ? bl_fragments_impl<48, true, false>(ctx, st, B, da, out, err, errcap) : bl_fragments_impl<60, true, false>(ctx, st, B, da, out, err, errcap);
     if (rc) return rc;
     SNK_HIP_TRY(hipStreamSynchronize(st));
     return SNK_OK;

@@ -62,8 +62,8 @@ __device__ __forceinline__ uint32_t mmer_key(const uint32_t* rowL, int tid, uint
 //    different M-mers of a window tie on the key, the two strands may pick different ones, and a k-mer
 //    and its reverse complement must still meet in one bucket.
 template <int M>
-__device__ __forceinline__ uint32_t mmer_bucket(const uint32_t* rowL, int tid, uint32_t row_words, int p, uint32_t NB) {
-    return snk_bucket_of_key(mmer_key<M>(rowL, tid, row_words, p), NB);
+__device__ __forceinline__ uint32_t mmer_bucket(const uint32_t* rowL, int tid, uint32_t row_words, int p, uint32_t NB, uint32_t gmix) {
+    return snk_bucket_of_key(mmer_key<M>(rowL, tid, row_words, p) ^ gmix, NB);
 }
 
 // extract 32 bits starting at base `a + 16*j` of the row column
@@ -109,17 +109,18 @@ __global__ void __launch_bounds__(BD) snk_msp_kernel(snk_msp_args a) {
     const int npos = g ? g - M + 1 : 0;
     int32_t mybc = 0;
     if (WRITES && g) mybc = (a.bc && (int64_t)(a.read_index_base + r) >= a.ign_bc_below) ? a.bc[r] : -1;
+    uint32_t gmix = 0;                                   // grouped runs: word 7 of the record carries the group id
+    if (a.group && g) { const uint32_t grp = a.group[r]; gmix = snk_group_mix(grp); mybc = (int32_t)grp; }
 
     int curpos = -1;              // minimiser position of the open supermer
     int cnt = 0;                  // closed+open supermer starts in the list
 
     // emit list entries [0, upto) ; entry e covers k-mers [start_e, start_{e+1}-1], the last one ends at last_end.
-    // Measured on the 100 M-read workload (tools/msp_probe.py, SNK_MSP_DBG): scan + record stores 33 ms, the same with
-    // the 0.68 G slot reservations 65 ms, with the reservations issued but their return values unused 31 ms: random
-    // global atomics run at ~27 G/s (tools/probe/atomics.hip) and overlap with the scan when nobody waits for them, but
-    // a wave that needs the returned slot pays the full round trip.  Tried without gain: all reservations of a read
-    // issued before the records are built (16 more registers cost occupancy, 68 ms); software pipelining -- issue after
-    // block b, consume after block b+1 (69 ms); workgroup / wavefront scope (64 ms).
+    // Measured on the 100 M-read workload (tools/msp_probe.py, SNK_MSP_DBG): scan + record stores 33 ms; with the
+    // 0.68 G slot reservations 38 ms (random global atomics run at ~27 G/s, tools/probe/atomics.hip, and overlap with
+    // other waves' scans).  What made this kernel take 65 ms for a while was the OVERFLOW path: with a capacity of
+    // mean + 4 sqrt(mean), 1.7 % of the supermers overflowed (bucket occupancy is far from Poisson, see the sizing in
+    // snk_pipeline.hip) and each took a returning atomic on the ONE overflow cursor (tools/msp_probe2.py).
     auto flush = [&](int upto, int last_end) {
         int maxn = upto;
         for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(maxn, off); maxn = o > maxn ? o : maxn; }
@@ -128,7 +129,7 @@ __global__ void __launch_bounds__(BD) snk_msp_kernel(snk_msp_args a) {
                 uint32_t ent = lst[e * BD + tid];
                 uint32_t s = ent & 0xFFu;
                 uint32_t en = (e + 1 < upto) ? (((uint32_t)lst[(e + 1) * BD + tid] & 0xFFu) - 1u) : (uint32_t)last_end;
-                uint32_t bucket = mmer_bucket<M>(rowL, tid, row_words, (int)(ent >> 8), NB);
+                uint32_t bucket = mmer_bucket<M>(rowL, tid, row_words, (int)(ent >> 8), NB, gmix);
                 if (MODE == MSP_HIST) {
                     atomicAdd(&a.hist_or_cursor[bucket], 1u);
                 } else {
@@ -138,7 +139,12 @@ __global__ void __launch_bounds__(BD) snk_msp_kernel(snk_msp_args a) {
                     if (MODE == MSP_SINGLE) {
                         if (slot < a.cap) at = (uint64_t)bucket * a.cap + slot;
                         else {
-                            const uint32_t o = atomicAdd(a.ovf_cursor, 1u);
+                            // overflow list: ONE reservation per wave (same-address atomics are served one at a time)
+                            const unsigned long long m = __ballot(1);
+                            const int lane = tid & 63, leader = __ffsll((long long)m) - 1;
+                            uint32_t o = 0;
+                            if (lane == leader) o = atomicAdd(a.ovf_cursor, (uint32_t)__popcll(m));
+                            o = __shfl(o, leader) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                             if (o < a.ovf_cap) { at = a.ovf_base + o; a.ovf_bucket[o] = bucket; }
                             else ok = false;                               // the host sees ovf_cursor > ovf_cap and re-runs
                         }

@@ -100,6 +100,13 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     if (in->n_reads && (!in->rows || in->row_words * 16 < in->read_len || in->read_len > 256))
         return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_count_graph: bad rows/read_len (read_len <= 256)");
     if (in->n_reads && !in->good_len && !in->quals) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_count_graph: need quals or good_len");
+    const bool grouped = (p->flags & SNK_F_GROUPED) != 0;
+    if (grouped) {
+        if (p->K != 48) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "SNK_F_GROUPED: the group id rides in the 32 key bits that are free at K=48 only");
+        if (!in->group) return snk_fail(SNK_E_ARG, err, errcap, "SNK_F_GROUPED: snk_dev_reads.group is NULL");
+        if (p->min_bc > 0 && in->bc) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "SNK_F_GROUPED: per-group graphs use the frequency rule only (min_bc = 0)");
+        if ((p->flags & SNK_F_GLOBAL_GRAPH) || snk_env_u32("SNK_GLOBAL_GRAPH", 0)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "SNK_F_GROUPED needs the bucket-local graph stage");
+    }
     SNK_HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     snk_ctx_release_scratch(ctx);
@@ -142,10 +149,14 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     out->n_instances = h_ninst;
     uint32_t NB = p->n_buckets;
     if (NB == 0) {
-        uint32_t target = env_u32("SNK_TARGET_INST", K == 48 ? 4000u : 3500u);
+        // instances per bucket: sized so that the DISTINCT k-mers of a bucket fit the LDS table (1216 claims).  At 56x
+        // coverage 4000 instances hold ~500 distinct k-mers; per-barcode groups see every locus once or twice, so
+        // nearly every instance is distinct there
+        uint32_t target = env_u32("SNK_TARGET_INST", grouped ? 900u : (K == 48 ? 4000u : 3500u));
         uint64_t nb = (h_ninst + target - 1) / target;
+        const uint64_t nb_max = grouped ? (1ull << 24) : (1ull << 22);
         if (nb < 1) nb = 1;
-        if (nb > (1u << 22)) nb = 1u << 22;
+        if (nb > nb_max) nb = nb_max;
         NB = (uint32_t)nb;
     }
     out->n_buckets = NB;
@@ -153,7 +164,12 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     // a random-order minimiser starts a new supermer every (W+1)/2 k-mers, and every contributing read starts one
     const double est_super = (double)h_ninst * 2.0 / (Wm + 1) + (double)h_plan[1];
     const double mean = est_super / NB;
-    uint64_t cap64 = (uint64_t)(mean * 1.25 + 4.0 * sqrt(mean) + 32.0);
+    // Bucket occupancy is NOT Poisson in the supermers: a minimiser site of the genome contributes one supermer per
+    // read that covers it (~38 at 56x), so a 4000-instance bucket holds only ~7 sites and its supermer count has a
+    // relative sigma of ~37 %.  With 1.25 x mean + 4 sqrt(mean) 1.7 % of the supermers overflowed and their
+    // reservations on the single overflow cursor cost 30 ms (tools/msp_probe2.py).  2.5 x mean is > 5 sigma of the site
+    // count at 56x and generous below; the slots that stay empty are never touched.
+    uint64_t cap64 = (uint64_t)(mean * 2.5 + 64.0);
     cap64 = cap64 * env_u32("SNK_MSP_CAP_PCT", 100) / 100;
     if (cap64 < 2) cap64 = 2;
     cap64 = (cap64 + 1) & ~1ull;
@@ -183,6 +199,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
         memset(&ma, 0, sizeof ma);
         ma.rows = (const uint32_t*)in->rows; ma.row_words = in->row_words; ma.good_len = good_len; ma.bc = (const int32_t*)in->bc;
         ma.ign_bc_below = in->ign_bc_below; ma.read_index_base = in->read_index_base; ma.n_reads = n_reads; ma.NB = NB;
+        ma.group = grouped ? (const uint32_t*)in->group : nullptr;
         ma.hist_or_cursor = cursor; ma.records = (uint4*)records; ma.cap = cap; ma.ovf_cap = (uint32_t)ovf_cap;
         ma.ovf_base = (uint64_t)NB * cap; ma.ovf_bucket = ovf_bucket; ma.ovf_cursor = status + 8;
         ma.dbg = env_u32("SNK_MSP_DBG", 0);
@@ -215,7 +232,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     // ---- K5-K8 count + filter + gather (+ sort for the global graph stage)
     const bool local_graph = !(p->flags & SNK_F_GLOBAL_GRAPH) && !env_u32("SNK_GLOBAL_GRAPH", 0);
     snk_table tab;
-    rc = snk_stage_count_table(ctx, st, K, records, seg, seg + NB, 2 * NB, nseg, NB, p->min_freq, in->bc ? p->min_bc : 0u, h_ninst, status,
+    rc = snk_stage_count_table(ctx, st, K, records, seg, seg + NB, 2 * NB, nseg, NB, p->min_freq, (in->bc && !grouped) ? p->min_bc : 0u, grouped ? 1u : 0u, h_ninst, status,
                                !local_graph, &tab, err, errcap);
     if (rc) return rc;
     const uint64_t n_kmers = tab.n;
@@ -231,7 +248,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     if (local_graph) {
         snk_u128* keys_final = nullptr;
         rc = snk_local_graph(ctx, st, K, &tab, p->min_freq > 1 ? 1u : 0u, !(p->flags & SNK_F_NO_GRAPH),
-                             !(p->flags & SNK_F_UNSORTED_TABLE), &go, &keys_final, out->graph_ms, err, errcap);
+                             !(p->flags & SNK_F_UNSORTED_TABLE), grouped, &go, &keys_final, out->graph_ms, err, errcap);
         if (rc) return rc;
         out->keys = keys_final;
         out->n_boundary = go.n_boundary;
@@ -251,6 +268,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     out->unitig_total_bases = go.total_bases;
     out->unitig_off = go.unitig_off;
     out->unitig_bases = go.unitig_bases;
+    out->unitig_group = go.unitig_group;
     out->n_circles = go.n_circles;
     out->rank_rounds = go.rank_rounds;
     out->phase_ms[0] = tm.ms(0, 1);

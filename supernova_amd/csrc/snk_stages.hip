@@ -22,7 +22,7 @@ uint32_t snk_env_u32(const char* name, uint32_t dflt) {
 // K5-K8 + gather + sort: supermer records of NB buckets (nseg segments) -> dense retained table sorted by key.
 // status: device u32[16] scratch words.
 int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* records, const uint64_t* seg_beg,
-                          const uint64_t* seg_end, uint32_t seg_stride, uint32_t nseg, uint32_t NB, uint32_t min_freq, uint32_t bc_mode, uint64_t n_inst_hint,
+                          const uint64_t* seg_end, uint32_t seg_stride, uint32_t nseg, uint32_t NB, uint32_t min_freq, uint32_t bc_mode, uint32_t grouped, uint64_t n_inst_hint,
                           uint32_t* status, bool want_sort, snk_table* out, char* err, size_t errcap) {
     int rc;
     snk_phase_timer tm(st), kt(st);
@@ -72,6 +72,8 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
         ca.NB = NB;
         ca.min_freq = min_freq;
         ca.bc_mode = bc_mode;
+        ca.grouped = grouped;
+        ca.bucket0 = 0;
         ca.out_keys = keys_r;
         ca.out_vals = vals_r;
         ca.region_cap = region_cap;

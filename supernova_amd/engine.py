@@ -29,12 +29,14 @@ class Params:
     graph: bool = True
     sorted_table: bool = True     # False: leave the retained table in bucket order (SNK_F_UNSORTED_TABLE)
     global_graph: bool = False    # True: the global graph stage (SNK_F_GLOBAL_GRAPH), a cross-check of the bucket-local one
+    grouped: bool = False         # True: per-group graphs (SNK_F_GROUPED); count_graph(group=...) gives the group of every read
 
     def to_c(self) -> _lib.SnkParams:
         p = _lib.SnkParams()
         p.K, p.min_qual, p.min_freq, p.min_bc = self.K, self.min_qual, self.min_freq, self.min_bc
         p.n_buckets = self.n_buckets
-        p.flags = (0 if self.graph else 1) | (0 if self.sorted_table else 2) | (4 if self.global_graph else 0)
+        p.flags = ((0 if self.graph else 1) | (0 if self.sorted_table else 2) | (4 if self.global_graph else 0)
+                   | (8 if self.grouped else 0))
         return p
 
 
@@ -52,8 +54,8 @@ class Result:
         self.phase_ms = {PHASES[i]: float(raw.phase_ms[i]) for i in range(8) if PHASES[i] != "-"}
         self.kernel_ms = {"msp_hist": float(raw.kernel_ms[0]), "msp_scatter": float(raw.kernel_ms[1]),
                           "count": float(raw.kernel_ms[2])}
-        names = ("local_prune", "boundary", "fragments", "join", "table")
-        self.graph_ms = {names[i]: float(raw.graph_ms[i]) for i in range(5)}
+        names = ("local_prune", "-", "fragments", "join", "table")     # local_prune includes the boundary index + resolve
+        self.graph_ms = {names[i]: float(raw.graph_ms[i]) for i in range(5) if names[i] != "-"}
 
     def _dl(self, ptr, nbytes, dtype, shape):
         out = np.empty(shape, dtype=dtype)
@@ -89,6 +91,10 @@ class Result:
         off = self._dl(self.raw.unitig_off, (self.n_unitigs + 1) * 8, np.uint64, (self.n_unitigs + 1,))
         bases = self._dl(self.raw.unitig_bases, self.unitig_total_bases, np.uint8, (self.unitig_total_bases,))
         return off, bases
+
+    def unitig_groups(self) -> np.ndarray:
+        """Grouped runs: group id of every unitig (same order as unitig_arrays())."""
+        return self._dl(self.raw.unitig_group, self.n_unitigs * 4, np.uint32, (self.n_unitigs,))
 
     def unitigs(self) -> list[str]:
         """Canonical unitigs sorted by (length desc, lexicographic) = BVComp, HBVFromEdges.cc:106-111."""
@@ -161,7 +167,7 @@ class Engine:
     def count_graph(self, rows: torch.Tensor, read_len: int, quals: torch.Tensor | None = None,
                     bc: torch.Tensor | None = None, lens: torch.Tensor | None = None,
                     good_len: torch.Tensor | None = None, params: Params | None = None, ign_bc_below: int = 0,
-                    read_index_base: int = 0) -> Result:
+                    read_index_base: int = 0, group: torch.Tensor | None = None) -> Result:
         params = params or Params()
         assert rows.is_cuda and rows.dtype == torch.int32 and rows.is_contiguous()
         r = _lib.SnkDevReads()
@@ -184,6 +190,9 @@ class Engine:
             r.bc = bc.data_ptr()
         r.ign_bc_below = ign_bc_below
         r.read_index_base = read_index_base
+        if group is not None:
+            assert group.dtype == torch.int32 and group.is_cuda and group.is_contiguous()
+            r.group = group.data_ptr()
         p = params.to_c()
         raw = _lib.SnkDevResult()
         err = C.create_string_buffer(512)

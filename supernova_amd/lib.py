@@ -38,7 +38,7 @@ class SnkDevReads(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("rows", C.c_void_p), ("row_words", C.c_uint32), ("read_len", C.c_uint32),
                 ("lens", C.c_void_p), ("quals", C.c_void_p), ("qstride", C.c_uint32), ("reserved0", C.c_uint32),
                 ("good_len", C.c_void_p), ("bc", C.c_void_p), ("ign_bc_below", C.c_int64),
-                ("read_index_base", C.c_uint64)]
+                ("read_index_base", C.c_uint64), ("group", C.c_void_p)]
 
 
 class SnkDevResult(C.Structure):
@@ -49,7 +49,8 @@ class SnkDevResult(C.Structure):
                 ("unitig_off", C.c_void_p), ("unitig_bases", C.c_void_p), ("rank_rounds", C.c_uint32),
                 ("buckets_split", C.c_uint32), ("max_slots_used", C.c_uint32), ("n_overflow", C.c_uint32),
                 ("scratch_bytes", C.c_uint64), ("phase_ms", C.c_float * 8), ("kernel_ms", C.c_float * 4),
-                ("n_boundary", C.c_uint64), ("n_fragments", C.c_uint64), ("graph_ms", C.c_float * 8)]
+                ("n_boundary", C.c_uint64), ("n_fragments", C.c_uint64), ("unitig_group", C.c_void_p),
+                ("graph_ms", C.c_float * 8)]
 
 
 class SnkShardFrags(C.Structure):

@@ -309,3 +309,43 @@ def test_partition_overflow_segment(engine, monkeypatch, pct):
     _check_against(res, c.exp_keys, c.exp_counts, c.exp_ctx, c.exp_unitigs, c.exp_goodlens, c.exp_hist)
     if pct < 100:
         assert res.n_overflow > 0
+
+
+def test_grouped_per_barcode_graphs(engine, graph_stage):
+    """BASELINE config 5: per-group (per-barcode) local graphs.  One grouped run == the oracle applied to every group's
+    reads on its own (frequency rule only): tables, pruned contexts and unitigs per group."""
+    import torch
+    from supernova_amd import synth
+    from supernova_amd.engine import Params
+    if graph_stage == "global":
+        pytest.skip("grouped runs use the bucket-local stage")
+    c = goldens.load("synth_20k_err")
+    rng = np.random.default_rng(7)
+    n = c.rows.shape[0]
+    NG = 5
+    group = (c.bc.astype(np.int64) % NG).astype(np.int32)
+    group[rng.random(n) < 0.1] = NG + 3                     # a sparse extra group with a large id gap
+    rows, quals, bc, lens = _to_dev(c)
+    g_dev = torch.from_numpy(group).to(rows.device)
+    res = engine.count_graph(rows, c.read_len, quals=quals, bc=None, lens=lens, group=g_dev,
+                             params=Params(K=48, min_freq=2, min_bc=0, grouped=True, sorted_table=False))
+    k, cnt, ctx = res.keys(), res.counts(), res.ctx()
+    off, bases = res.unitig_arrays()
+    ug = res.unitig_groups()
+    assert np.all(np.diff(ug.astype(np.int64)) >= 0)                      # group-major order
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    total = 0
+    for gid in np.unique(group):
+        sel = group == gid
+        o = oracle_lib.OracleResult(c.codes[sel], c.exp_goodlens[sel], None, min_freq=2, min_bc=0, hbv=False)
+        m = k[:, 3] == gid
+        kk, cc, xx = k[m], cnt[m], ctx[m]
+        order = np.lexsort((kk[:, 2], kk[:, 1], kk[:, 0]))
+        assert np.array_equal(kk[order][:, :3], o.keys[:, :3]), gid
+        assert np.array_equal(cc[order], o.counts), gid
+        assert np.array_equal(xx[order], o.ctx), gid
+        us = sorted((lut[bases[int(off[u]):int(off[u + 1])]].tobytes().decode() for u in np.nonzero(ug == gid)[0]),
+                    key=lambda t: (-len(t), t))
+        assert us == o.unitigs, gid
+        total += m.sum()
+    assert total == k.shape[0]

@@ -107,3 +107,20 @@ def test_gloo_world2_exchange():
     for p in ps:
         p.join(timeout=60)
     assert all(ok for (_r, ok, _n) in res), res
+
+
+def test_group_partition_balanced_and_contiguous():
+    """C5 (per-barcode graphs) shards without a collective: contiguous group ranges balanced by read count."""
+    from supernova_amd.grouped import partition_groups, read_slab
+    rng = np.random.default_rng(3)
+    sizes = rng.integers(1, 2000, 5000)
+    for world in (1, 2, 3, 8):
+        b = partition_groups(sizes, world)
+        assert b[0] == 0 and b[-1] == len(sizes) and np.all(np.diff(b) >= 0)
+        loads = [sizes[b[r]:b[r + 1]].sum() for r in range(world)]
+        assert max(loads) - min(loads) <= 2 * sizes.max()
+        bci = np.concatenate([[0], np.cumsum(sizes)])
+        slabs = [read_slab(bci, b, r) for r in range(world)]
+        assert slabs[0][0] == 0 and slabs[-1][1] == sizes.sum()
+        assert all(slabs[r][1] == slabs[r + 1][0] for r in range(world - 1))
+    assert list(partition_groups(np.array([5]), 4)) == [0, 0, 0, 0, 1] or partition_groups(np.array([5]), 4)[-1] == 1
