@@ -23,10 +23,8 @@ struct snk_shard_state {
     snk_params params;
     uint32_t rank = 0, world = 1, NB_total = 0, NBl = 0;
     const uint16_t* good_len = nullptr;
-    uint32_t* cursor = nullptr;
     uint32_t* status = nullptr;
-    uint16_t* slist = nullptr;
-    uint8_t* scount = nullptr;
+    snk_partition part{};
     snk_table tab{};
     snk_dist_graph g{};
     snk_bl_state bl{};
@@ -66,22 +64,16 @@ extern "C" int snk_shard_hist(snk_ctx* ctx, const snk_dev_reads* in, const snk_p
     }
     S->good_len = good_len;
     void* q;
-    if ((rc = snk_ctx_alloc(ctx, (NB_total + 1) * 4ull, &q, err, errcap))) return rc; S->cursor = (uint32_t*)q;
     if ((rc = snk_ctx_alloc(ctx, 64, &q, err, errcap))) return rc; S->status = (uint32_t*)q;
-    unsigned long long* counter;
-    if ((rc = snk_ctx_alloc(ctx, 64, &q, err, errcap))) return rc; counter = (unsigned long long*)q;
-    if ((rc = snk_ctx_alloc(ctx, (size_t)SNK_MSP_LCAP * in->n_reads * 2 + 64, &q, err, errcap))) return rc; S->slist = (uint16_t*)q;
-    if ((rc = snk_ctx_alloc(ctx, in->n_reads + 64, &q, err, errcap))) return rc; S->scount = (uint8_t*)q;
-    SNK_HIP_TRY(hipMemsetAsync(d_hist, 0, (size_t)NB_total * 4, st));
-    SNK_HIP_TRY(hipMemsetAsync(counter, 0, 64, st));
     SNK_HIP_TRY(hipMemsetAsync(S->status, 0, 64, st));
-    rc = snk_launch_msp(p->K, false, st, (const uint32_t*)in->rows, in->row_words, good_len, (const int32_t*)in->bc, in->ign_bc_below,
-                        in->read_index_base, in->n_reads, NB_total, (uint32_t*)d_hist, nullptr, counter, S->slist, S->scount, err, errcap);
-    if (rc) return rc;
-    unsigned long long h = 0;
-    SNK_HIP_TRY(hipMemcpyAsync(&h, counter, 8, hipMemcpyDeviceToHost, st));
+    // one partition pass into fixed-capacity bucket slots (as on one GPU); the histogram is its cursor array, the
+    // "scatter" stage compacts the slots into the caller's exact, destination-contiguous send buffer
+    unsigned long long h_plan[2] = {0, 0};
+    if ((rc = snk_stage_partition_plan(ctx, st, p->K, good_len, in->n_reads, h_plan, err, errcap))) return rc;
+    if ((rc = snk_stage_partition(ctx, st, p->K, in, good_len, NB_total, h_plan[0], h_plan[1], false, S->status, &S->part, err, errcap))) return rc;
+    SNK_HIP_TRY(hipMemcpyAsync(d_hist, S->part.cursor, (size_t)NB_total * 4, hipMemcpyDeviceToDevice, st));
     SNK_HIP_TRY(hipStreamSynchronize(st));
-    if (n_instances) *n_instances = h;
+    if (n_instances) *n_instances = h_plan[0];
     return SNK_OK;
 }
 
@@ -89,10 +81,7 @@ extern "C" int snk_shard_scatter(snk_ctx* ctx, const void* d_offsets, void* d_re
     if (!ctx || !ctx->shard || !d_offsets || !d_records) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_scatter: NULL argument / no session");
     snk_shard_state* S = state_of(ctx);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-    SNK_HIP_TRY(hipMemcpyAsync(S->cursor, d_offsets, (S->NB_total + 1) * 4ull, hipMemcpyDeviceToDevice, st));
-    const snk_dev_reads& in = S->reads;
-    return snk_launch_msp(S->params.K, true, st, (const uint32_t*)in.rows, in.row_words, S->good_len, (const int32_t*)in.bc, in.ign_bc_below,
-                          in.read_index_base, in.n_reads, S->NB_total, S->cursor, d_records, nullptr, S->slist, S->scount, err, errcap);
+    return snk_stage_partition_compact(st, &S->part, (const uint32_t*)d_offsets, d_records, err, errcap);
 }
 
 extern "C" int snk_shard_count(snk_ctx* ctx, const void* d_records, const void* d_seg_off, uint64_t n_inst_hint, int has_bc,

@@ -30,65 +30,7 @@ __global__ void widen_offsets_kernel(const uint32_t* __restrict__ in, uint64_t* 
 
 typedef snk_phase_timer phase_timer;
 
-// segment tables of the single-pass partition: layout seg[0..NB) = begin of segment 0, [NB..2NB) = end of segment 0,
-// [2NB..3NB) = begin of segment 1 (overflow), [3NB..4NB) = end of segment 1
-__global__ void __launch_bounds__(256) seg0_kernel(const uint32_t* __restrict__ cursor, uint32_t NB, uint32_t cap,
-                                                   uint64_t* __restrict__ seg, unsigned long long* __restrict__ total) {
-    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
-    unsigned long long v = 0;
-    if (b < NB) {
-        const uint32_t c = cursor[b];
-        v = c;
-        seg[b] = (uint64_t)b * cap;
-        seg[NB + b] = (uint64_t)b * cap + (c < cap ? c : cap);
-        seg[2ull * NB + b] = 0;
-        seg[3ull * NB + b] = 0;
-    }
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(total, v);
-}
-__global__ void __launch_bounds__(256) iota_kernel(uint32_t* __restrict__ v, uint32_t n) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) v[i] = i;
-}
-__global__ void __launch_bounds__(256) ovf_gather_kernel(const uint4* rec, uint64_t src_base, uint64_t dst_base,
-                                                         const uint32_t* __restrict__ idx, const uint32_t* __restrict__ key, uint32_t n,
-                                                         uint32_t NB, uint4* out, uint64_t* __restrict__ seg) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t s = (src_base + idx[i]) * 2, d = (dst_base + i) * 2;
-    out[d] = rec[s];
-    out[d + 1] = rec[s + 1];
-    const uint32_t b = key[i];
-    if (i == 0 || key[i - 1] != b) seg[2ull * NB + b] = dst_base + i;
-    if (i + 1 == n || key[i + 1] != b) seg[3ull * NB + b] = dst_base + i + 1;
-}
-
 #define env_u32 snk_env_u32
-
-int snk_msp_segments(snk_ctx* ctx, hipStream_t st, uint32_t NB, uint32_t cap, const uint32_t* cursor, uint4* records, uint64_t ovf_base,
-                     uint64_t ovf_cap, const uint32_t* ovf_bucket, uint32_t n_ovf, uint64_t* seg, unsigned long long* d_total, char* err,
-                     size_t errcap) {
-    SNK_HIP_TRY(hipMemsetAsync(d_total, 0, 8, st));
-    hipLaunchKernelGGL(seg0_kernel, dim3((NB + 255) / 256), dim3(256), 0, st, cursor, NB, cap, seg, d_total);
-    if (n_ovf) {
-        uint32_t *idx_in, *idx_out, *key_out;
-        void* q;
-        int rc;
-        if ((rc = snk_ctx_alloc(ctx, (size_t)n_ovf * 4 + 16, &q, err, errcap))) return rc; idx_in = (uint32_t*)q;
-        if ((rc = snk_ctx_alloc(ctx, (size_t)n_ovf * 4 + 16, &q, err, errcap))) return rc; idx_out = (uint32_t*)q;
-        if ((rc = snk_ctx_alloc(ctx, (size_t)n_ovf * 4 + 16, &q, err, errcap))) return rc; key_out = (uint32_t*)q;
-        hipLaunchKernelGGL(iota_kernel, dim3((n_ovf + 255) / 256), dim3(256), 0, st, idx_in, n_ovf);
-        size_t tb = 0;
-        SNK_HIP_TRY(rocprim::radix_sort_pairs((void*)nullptr, tb, ovf_bucket, key_out, idx_in, idx_out, (size_t)n_ovf, 0u, 32u, st));
-        if ((rc = snk_ctx_alloc(ctx, tb, &q, err, errcap))) return rc;
-        SNK_HIP_TRY(rocprim::radix_sort_pairs(q, tb, ovf_bucket, key_out, idx_in, idx_out, (size_t)n_ovf, 0u, 32u, st));
-        hipLaunchKernelGGL(ovf_gather_kernel, dim3((n_ovf + 255) / 256), dim3(256), 0, st, records, ovf_base, ovf_base + ovf_cap, idx_out,
-                           key_out, n_ovf, NB, records, seg);
-    }
-    SNK_HIP_TRY(hipGetLastError());
-    return SNK_OK;
-}
 
 }  // namespace
 
@@ -131,20 +73,16 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     tm.mark();  // 1
 
     // ---- K3/K4 minimiser partition in ONE pass: exact k-mer instance count -> expected supermers -> fixed bucket capacity
-    unsigned long long* counters = nullptr;   // [0] instances, [1] live reads
     uint32_t* status = nullptr;
     {
         void* q;
         int rc;
-        if ((rc = snk_ctx_alloc(ctx, 64, &q, err, errcap))) return rc; counters = (unsigned long long*)q;
         if ((rc = snk_ctx_alloc(ctx, 64, &q, err, errcap))) return rc; status = (uint32_t*)q;
     }
     SNK_HIP_TRY(hipMemsetAsync(status, 0, 64, st));
-    int rc = snk_launch_msp_plan(st, good_len, n_reads, K, counters, err, errcap);
-    if (rc) return rc;
     unsigned long long h_plan[2] = {0, 0};
-    SNK_HIP_TRY(hipMemcpyAsync(h_plan, counters, 16, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    int rc = snk_stage_partition_plan(ctx, st, K, good_len, n_reads, h_plan, err, errcap);
+    if (rc) return rc;
     const unsigned long long h_ninst = h_plan[0];
     out->n_instances = h_ninst;
     uint32_t NB = p->n_buckets;
@@ -160,73 +98,15 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
         NB = (uint32_t)nb;
     }
     out->n_buckets = NB;
-    const uint32_t Wm = K - SNK_M + 1;
-    // a random-order minimiser starts a new supermer every (W+1)/2 k-mers, and every contributing read starts one
-    const double est_super = (double)h_ninst * 2.0 / (Wm + 1) + (double)h_plan[1];
-    const double mean = est_super / NB;
-    // Bucket occupancy is NOT Poisson in the supermers: a minimiser site of the genome contributes one supermer per
-    // read that covers it (~38 at 56x), so a 4000-instance bucket holds only ~7 sites and its supermer count has a
-    // relative sigma of ~37 %.  With 1.25 x mean + 4 sqrt(mean) 1.7 % of the supermers overflowed and their
-    // reservations on the single overflow cursor cost 30 ms (tools/msp_probe2.py).  2.5 x mean is > 5 sigma of the site
-    // count at 56x and generous below; the slots that stay empty are never touched.
-    uint64_t cap64 = (uint64_t)(mean * 2.5 + 64.0);
-    cap64 = cap64 * env_u32("SNK_MSP_CAP_PCT", 100) / 100;
-    if (cap64 < 2) cap64 = 2;
-    cap64 = (cap64 + 1) & ~1ull;
-    if (cap64 * NB >= (1ull << 40) || cap64 >= (1ull << 31)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "bucket capacity out of range");
-    const uint32_t cap = (uint32_t)cap64;
-    uint64_t ovf_cap = (uint64_t)(est_super / 16) + 65536;
     tm.mark();  // 2
-    uint32_t* cursor = nullptr;
-    uint64_t* seg = nullptr;           // [2 segments][beg NB | end NB]
-    {
-        void* q;
-        if ((rc = snk_ctx_alloc(ctx, (NB + 1) * 4ull, &q, err, errcap))) return rc; cursor = (uint32_t*)q;
-        if ((rc = snk_ctx_alloc(ctx, 4ull * NB * 8 + 64, &q, err, errcap))) return rc; seg = (uint64_t*)q;
-    }
-    phase_timer kt(st);   // single-launch timings (events on the launch stream right around the kernel)
-    void* records = nullptr;
-    uint32_t* ovf_bucket = nullptr;
-    uint32_t h_novf = 0;
-    for (int attempt = 0; attempt < 3; ++attempt) {
-        if (ovf_cap >= (1ull << 31)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "supermer overflow list too large");
-        void* q;
-        if ((rc = snk_ctx_alloc(ctx, ((size_t)NB * cap + 2 * ovf_cap) * 32 + 64, &records, err, errcap))) return rc;
-        if ((rc = snk_ctx_alloc(ctx, ovf_cap * 4 + 64, &q, err, errcap))) return rc; ovf_bucket = (uint32_t*)q;
-        SNK_HIP_TRY(hipMemsetAsync(cursor, 0, (NB + 1) * 4ull, st));
-        SNK_HIP_TRY(hipMemsetAsync(status + 8, 0, 4, st));
-        snk_msp_args ma;
-        memset(&ma, 0, sizeof ma);
-        ma.rows = (const uint32_t*)in->rows; ma.row_words = in->row_words; ma.good_len = good_len; ma.bc = (const int32_t*)in->bc;
-        ma.ign_bc_below = in->ign_bc_below; ma.read_index_base = in->read_index_base; ma.n_reads = n_reads; ma.NB = NB;
-        ma.group = grouped ? (const uint32_t*)in->group : nullptr;
-        ma.hist_or_cursor = cursor; ma.records = (uint4*)records; ma.cap = cap; ma.ovf_cap = (uint32_t)ovf_cap;
-        ma.ovf_base = (uint64_t)NB * cap; ma.ovf_bucket = ovf_bucket; ma.ovf_cursor = status + 8;
-        ma.dbg = env_u32("SNK_MSP_DBG", 0);
-        kt.n = 0;
-        kt.mark();  // 0
-        if ((rc = snk_launch_msp_args(K, SNK_MSP_MODE_SINGLE, st, ma, err, errcap))) return rc;
-        kt.mark();  // 1
-        SNK_HIP_TRY(hipMemcpyAsync(&h_novf, status + 8, 4, hipMemcpyDeviceToHost, st));
-        SNK_HIP_TRY(hipStreamSynchronize(st));
-        if (h_novf <= ovf_cap) break;
-        if (attempt == 2) return snk_fail(SNK_E_INTERNAL, err, errcap, "supermer overflow list too small (%u > %llu)", h_novf, (unsigned long long)ovf_cap);
-        ovf_cap = (uint64_t)h_novf + 65536;
-    }
-    uint32_t nseg = 1;
-    {
-        // segment 0: the fixed-capacity slots; segment 1: the overflow records grouped by bucket
-        unsigned long long* d_total = counters + 4;
-        int rc2 = snk_msp_segments(ctx, st, NB, cap, cursor, (uint4*)records, (uint64_t)NB * cap, ovf_cap, ovf_bucket, h_novf, seg, d_total,
-                                   err, errcap);
-        if (rc2) return rc2;
-        unsigned long long h_total = 0;
-        SNK_HIP_TRY(hipMemcpyAsync(&h_total, d_total, 8, hipMemcpyDeviceToHost, st));
-        SNK_HIP_TRY(hipStreamSynchronize(st));
-        out->n_supermers = h_total;
-        if (h_novf) nseg = 2;
-    }
-    out->n_overflow = h_novf;
+    snk_partition part;
+    rc = snk_stage_partition(ctx, st, K, in, good_len, NB, h_plan[0], h_plan[1], grouped, status, &part, err, errcap);
+    if (rc) return rc;
+    void* records = part.records;
+    uint64_t* seg = part.seg;
+    const uint32_t nseg = part.nseg;
+    out->n_supermers = part.n_supermers;
+    out->n_overflow = part.n_overflow;
     tm.mark();  // 3
 
     // ---- K5-K8 count + filter + gather (+ sort for the global graph stage)
@@ -279,7 +159,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     out->phase_ms[5] = tm.ms(5, 6);
     out->phase_ms[7] = tm.ms(0, 6);
     out->kernel_ms[0] = 0.f;
-    out->kernel_ms[1] = kt.ms(0, 1);
+    out->kernel_ms[1] = part.kernel_ms;
     out->kernel_ms[2] = tab.count_kernel_ms;
     out->scratch_bytes = ctx->total_alloc;
     return SNK_OK;

@@ -4,6 +4,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <stdlib.h>
+#include <math.h>
 
 #include <vector>
 
@@ -149,5 +150,182 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
     out->count_ms = tm.ms(0, 1);
     out->sort_ms = tm.ms(1, 2);
     out->count_kernel_ms = kt.ms(0, 1);
+    return SNK_OK;
+}
+
+// ===================================================================================================================
+// Minimiser partition in one pass (snk_msp.hip, MODE SINGLE): bucket b owns records [b*cap, (b+1)*cap), what does not
+// fit goes to an overflow list that is grouped by bucket here (segment 1 of the count kernel's input).
+namespace {
+// segment tables of the single-pass partition: layout seg[0..NB) = begin of segment 0, [NB..2NB) = end of segment 0,
+// [2NB..3NB) = begin of segment 1 (overflow), [3NB..4NB) = end of segment 1
+__global__ void __launch_bounds__(256) seg0_kernel(const uint32_t* __restrict__ cursor, uint32_t NB, uint32_t cap,
+                                                   uint64_t* __restrict__ seg, unsigned long long* __restrict__ total) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    unsigned long long v = 0;
+    if (b < NB) {
+        const uint32_t c = cursor[b];
+        v = c;
+        seg[b] = (uint64_t)b * cap;
+        seg[NB + b] = (uint64_t)b * cap + (c < cap ? c : cap);
+        seg[2ull * NB + b] = 0;
+        seg[3ull * NB + b] = 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(total, v);
+}
+__global__ void __launch_bounds__(256) iota_kernel(uint32_t* __restrict__ v, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) v[i] = i;
+}
+__global__ void __launch_bounds__(256) ovf_gather_kernel(const uint4* rec, uint64_t src_base, uint64_t dst_base,
+                                                         const uint32_t* __restrict__ idx, const uint32_t* __restrict__ key, uint32_t n,
+                                                         uint32_t NB, uint4* out, uint64_t* __restrict__ seg) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t s = (src_base + idx[i]) * 2, d = (dst_base + i) * 2;
+    out[d] = rec[s];
+    out[d + 1] = rec[s + 1];
+    const uint32_t b = key[i];
+    if (i == 0 || key[i - 1] != b) seg[2ull * NB + b] = dst_base + i;
+    if (i + 1 == n || key[i + 1] != b) seg[3ull * NB + b] = dst_base + i + 1;
+}
+
+
+// sharded runs: copy the used slots (+ overflow records) of every bucket to exact offsets of a compact send buffer
+__global__ void __launch_bounds__(256) compact_buckets_kernel(const uint4* __restrict__ rec, const uint64_t* __restrict__ seg, uint32_t NB,
+                                                              const uint32_t* __restrict__ offsets, uint4* __restrict__ out) {
+    const uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= NB) return;
+    const uint32_t lane = threadIdx.x & 63;
+    uint64_t dst = (uint64_t)offsets[b] * 2;
+    for (int sgm = 0; sgm < 2; ++sgm) {
+        const uint64_t beg = seg[(2ull * sgm) * NB + b] * 2, end = seg[(2ull * sgm + 1) * NB + b] * 2;
+        for (uint64_t q = beg + lane; q < end; q += 64) out[dst + (q - beg)] = rec[q];
+        dst += end - beg;
+    }
+}
+}  // namespace
+
+static int snk_msp_segments(snk_ctx* ctx, hipStream_t st, uint32_t NB, uint32_t cap, const uint32_t* cursor, uint4* records, uint64_t ovf_base,
+                     uint64_t ovf_cap, const uint32_t* ovf_bucket, uint32_t n_ovf, uint64_t* seg, unsigned long long* d_total, char* err,
+                     size_t errcap) {
+    SNK_HIP_TRY(hipMemsetAsync(d_total, 0, 8, st));
+    hipLaunchKernelGGL(seg0_kernel, dim3((NB + 255) / 256), dim3(256), 0, st, cursor, NB, cap, seg, d_total);
+    if (n_ovf) {
+        uint32_t *idx_in, *idx_out, *key_out;
+        void* q;
+        int rc;
+        if ((rc = snk_ctx_alloc(ctx, (size_t)n_ovf * 4 + 16, &q, err, errcap))) return rc; idx_in = (uint32_t*)q;
+        if ((rc = snk_ctx_alloc(ctx, (size_t)n_ovf * 4 + 16, &q, err, errcap))) return rc; idx_out = (uint32_t*)q;
+        if ((rc = snk_ctx_alloc(ctx, (size_t)n_ovf * 4 + 16, &q, err, errcap))) return rc; key_out = (uint32_t*)q;
+        hipLaunchKernelGGL(iota_kernel, dim3((n_ovf + 255) / 256), dim3(256), 0, st, idx_in, n_ovf);
+        size_t tb = 0;
+        SNK_HIP_TRY(rocprim::radix_sort_pairs((void*)nullptr, tb, ovf_bucket, key_out, idx_in, idx_out, (size_t)n_ovf, 0u, 32u, st));
+        if ((rc = snk_ctx_alloc(ctx, tb, &q, err, errcap))) return rc;
+        SNK_HIP_TRY(rocprim::radix_sort_pairs(q, tb, ovf_bucket, key_out, idx_in, idx_out, (size_t)n_ovf, 0u, 32u, st));
+        hipLaunchKernelGGL(ovf_gather_kernel, dim3((n_ovf + 255) / 256), dim3(256), 0, st, records, ovf_base, ovf_base + ovf_cap, idx_out,
+                           key_out, n_ovf, NB, records, seg);
+    }
+    SNK_HIP_TRY(hipGetLastError());
+    return SNK_OK;
+}
+
+
+int snk_stage_partition_plan(snk_ctx* ctx, hipStream_t st, uint32_t K, const uint16_t* good_len, uint64_t n_reads,
+                             unsigned long long h_plan[2], char* err, size_t errcap) {
+    unsigned long long* counters;
+    void* q;
+    int rc;
+    if ((rc = snk_ctx_alloc(ctx, 64, &q, err, errcap))) return rc;
+    counters = (unsigned long long*)q;
+    if ((rc = snk_launch_msp_plan(st, good_len, n_reads, K, counters, err, errcap))) return rc;
+    SNK_HIP_TRY(hipMemcpyAsync(h_plan, counters, 16, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    return SNK_OK;
+}
+
+int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_reads* in, const uint16_t* good_len, uint32_t NB,
+                        unsigned long long n_inst, unsigned long long n_live, bool grouped, uint32_t* status, snk_partition* out,
+                        char* err, size_t errcap) {
+    memset(out, 0, sizeof *out);
+    const uint64_t n_reads = in->n_reads;
+    const uint32_t Wm = K - SNK_M + 1;
+    // a random-order minimiser starts a new supermer every (W+1)/2 k-mers, and every contributing read starts one
+    const double est_super = (double)n_inst * 2.0 / (Wm + 1) + (double)n_live;
+    const double mean = est_super / NB;
+    // Bucket occupancy is NOT Poisson in the supermers: a minimiser site of the genome contributes one supermer per
+    // read that covers it (~38 at 56x), so a 4000-instance bucket holds only ~7 sites and its supermer count has a
+    // relative sigma of ~37 %.  With 1.25 x mean + 4 sqrt(mean) 1.7 % of the supermers overflowed and their
+    // reservations on the single overflow cursor cost 30 ms (tools/msp_probe2.py).  2.5 x mean is > 5 sigma of the site
+    // count at 56x and generous below; the slots that stay empty are never touched.
+    uint64_t cap64 = (uint64_t)(mean * 2.5 + 64.0);
+    cap64 = cap64 * env_u32("SNK_MSP_CAP_PCT", 100) / 100;
+    if (cap64 < 2) cap64 = 2;
+    cap64 = (cap64 + 1) & ~1ull;
+    if (cap64 * NB >= (1ull << 40) || cap64 >= (1ull << 31)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "bucket capacity out of range");
+    const uint32_t cap = (uint32_t)cap64;
+    uint64_t ovf_cap = (uint64_t)(est_super / 16) + 65536;
+    int rc;
+    uint32_t* cursor = nullptr;
+    uint64_t* seg = nullptr;           // [2 segments][beg NB | end NB]
+    unsigned long long* d_total = nullptr;
+    {
+        void* q;
+        if ((rc = snk_ctx_alloc(ctx, (NB + 1) * 4ull, &q, err, errcap))) return rc; cursor = (uint32_t*)q;
+        if ((rc = snk_ctx_alloc(ctx, 4ull * NB * 8 + 64, &q, err, errcap))) return rc; seg = (uint64_t*)q;
+        if ((rc = snk_ctx_alloc(ctx, 64, &q, err, errcap))) return rc; d_total = (unsigned long long*)q;
+    }
+    snk_phase_timer kt(st);
+    void* records = nullptr;
+    uint32_t* ovf_bucket = nullptr;
+    uint32_t h_novf = 0;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        if (ovf_cap >= (1ull << 31)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "supermer overflow list too large");
+        void* q;
+        if ((rc = snk_ctx_alloc(ctx, ((size_t)NB * cap + 2 * ovf_cap) * 32 + 64, &records, err, errcap))) return rc;
+        if ((rc = snk_ctx_alloc(ctx, ovf_cap * 4 + 64, &q, err, errcap))) return rc; ovf_bucket = (uint32_t*)q;
+        SNK_HIP_TRY(hipMemsetAsync(cursor, 0, (NB + 1) * 4ull, st));
+        SNK_HIP_TRY(hipMemsetAsync(status + 8, 0, 4, st));
+        snk_msp_args ma;
+        memset(&ma, 0, sizeof ma);
+        ma.rows = (const uint32_t*)in->rows; ma.row_words = in->row_words; ma.good_len = good_len; ma.bc = (const int32_t*)in->bc;
+        ma.ign_bc_below = in->ign_bc_below; ma.read_index_base = in->read_index_base; ma.n_reads = n_reads; ma.NB = NB;
+        ma.group = grouped ? (const uint32_t*)in->group : nullptr;
+        ma.hist_or_cursor = cursor; ma.records = (uint4*)records; ma.cap = cap; ma.ovf_cap = (uint32_t)ovf_cap;
+        ma.ovf_base = (uint64_t)NB * cap; ma.ovf_bucket = ovf_bucket; ma.ovf_cursor = status + 8;
+        ma.dbg = env_u32("SNK_MSP_DBG", 0);
+        kt.n = 0;
+        kt.mark();  // 0
+        if ((rc = snk_launch_msp_args(K, SNK_MSP_MODE_SINGLE, st, ma, err, errcap))) return rc;
+        kt.mark();  // 1
+        SNK_HIP_TRY(hipMemcpyAsync(&h_novf, status + 8, 4, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(hipStreamSynchronize(st));
+        if (h_novf <= ovf_cap) break;
+        if (attempt == 2) return snk_fail(SNK_E_INTERNAL, err, errcap, "supermer overflow list too small (%u > %llu)", h_novf, (unsigned long long)ovf_cap);
+        ovf_cap = (uint64_t)h_novf + 65536;
+    }
+    // segment 0: the fixed-capacity slots; segment 1: the overflow records grouped by bucket
+    if ((rc = snk_msp_segments(ctx, st, NB, cap, cursor, (uint4*)records, (uint64_t)NB * cap, ovf_cap, ovf_bucket, h_novf, seg, d_total, err, errcap))) return rc;
+    unsigned long long h_total = 0;
+    SNK_HIP_TRY(hipMemcpyAsync(&h_total, d_total, 8, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    out->NB = NB;
+    out->cap = cap;
+    out->nseg = h_novf ? 2u : 1u;
+    out->n_overflow = h_novf;
+    out->n_supermers = h_total;
+    out->records = records;
+    out->cursor = cursor;
+    out->seg = seg;
+    out->kernel_ms = kt.ms(0, 1);
+    return SNK_OK;
+}
+
+int snk_stage_partition_compact(hipStream_t st, const snk_partition* part, const uint32_t* d_offsets, void* d_out, char* err, size_t errcap) {
+    if (part->NB == 0) return SNK_OK;
+    hipLaunchKernelGGL(compact_buckets_kernel, dim3((part->NB + 3) / 4), dim3(256), 0, st, (const uint4*)part->records, part->seg, part->NB,
+                       d_offsets, (uint4*)d_out);
+    SNK_HIP_TRY(hipGetLastError());
     return SNK_OK;
 }
