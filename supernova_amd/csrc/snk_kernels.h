@@ -11,11 +11,6 @@ typedef unsigned __int128 snk_u128;
 
 // ---- snk_msp.hip
 size_t snk_msp_lds_bytes(uint32_t K, uint32_t M, uint32_t row_words);
-int snk_launch_msp(uint32_t K, bool scatter, hipStream_t st, const uint32_t* rows, uint32_t row_words,
-                   const uint16_t* good_len, const int32_t* bc, int64_t ign_bc_below, uint64_t read_index_base,
-                   uint64_t n_reads, uint32_t NB, uint32_t* hist_or_cursor, void* records, unsigned long long* n_inst,
-                   uint16_t* slist /* [SNK_MSP_LCAP][n_reads] or NULL */, uint8_t* scount /* [n_reads] or NULL */,
-                   char* err, size_t errcap);
 #define SNK_MSP_LCAP 16
 struct snk_msp_args {
     const uint32_t* rows;
@@ -26,12 +21,9 @@ struct snk_msp_args {
     int64_t ign_bc_below;
     uint64_t read_index_base, n_reads;
     uint32_t NB;
-    uint32_t* hist_or_cursor;      // HIST: bucket histogram; REPLAY: absolute record offsets; SINGLE: per-bucket cursors from 0
+    uint32_t* cursor;              // [NB] supermers of every bucket, counted from 0
     uint4* records;
-    unsigned long long* n_inst_out;
-    uint16_t* slist;               // HIST -> REPLAY hand-over, or NULL
-    uint8_t* scount;
-    // SINGLE: bucket b owns records [b*cap, (b+1)*cap); what does not fit goes to [ovf_base, ovf_base+ovf_cap)
+    // bucket b owns records [b*cap, (b+1)*cap); what does not fit goes to [ovf_base, ovf_base+ovf_cap)
     uint32_t cap;
     uint32_t ovf_cap;
     uint64_t ovf_base;
@@ -39,10 +31,7 @@ struct snk_msp_args {
     uint32_t* ovf_cursor;          // [1] overflow records wanted (keeps counting past ovf_cap)
     uint32_t dbg;                  // profiling aid (results invalid): 1 = no record stores, 2 = no slot atomics
 };
-#define SNK_MSP_MODE_HIST 0
-#define SNK_MSP_MODE_REPLAY 1
-#define SNK_MSP_MODE_SINGLE 2
-int snk_launch_msp_args(uint32_t K, int mode, hipStream_t st, const snk_msp_args& a, char* err, size_t errcap);
+int snk_launch_msp(uint32_t K, hipStream_t st, const snk_msp_args& a, char* err, size_t errcap);
 int snk_launch_msp_plan(hipStream_t st, const uint16_t* good_len, uint64_t n_reads, uint32_t K, unsigned long long* out2,
                         char* err, size_t errcap);
 

@@ -17,20 +17,12 @@
 // register), so a wave never serialises on "rescan on expiry".  Supermer starts are appended to a
 // short per-thread LDS list and emitted in a second, short loop.
 //
-// Three modes share the scan:
-//   SINGLE (the one-GPU path): ONE pass.  Every bucket owns `cap` record slots (cap = expected supermers per bucket
-//          + 25 % + 4 sigma; the expectation is exact bookkeeping: k-mer instances are known after the trim, a
-//          random-order minimiser starts a supermer every (W+1)/2 k-mers); a supermer takes slot atomicAdd(cursor) of
-//          its bucket, the few that do not fit go to an overflow list that is grouped by bucket afterwards and read
-//          by the count kernel as a second segment.  Correctness never depends on the estimate.
-//   HIST / REPLAY (the sharded path, which needs exact, contiguous per-destination send buffers): pass 1 counts
-//          supermers per bucket and saves every read's supermer list, pass 2 replays the lists into exact offsets.
-//
-// Supermer record (32 B, two 16-byte stores), words MSB-first like a read row:
-//   bits [0, 2*n_ext)      the supermer bases including one flanking base on each side when the read
-//                          has one inside its good length (n_ext <= 2K-M+2)
-//   word 6 bits 0..11      n_kmers (7 bits) | hasL << 7 | hasR << 8
-//   word 7                 barcode (int32; -1 = ignore-rule read, BuildReadQGraph48.cc:158-159)
+// ONE pass: every bucket owns `cap` record slots (cap = 2.5 x the expected supermers per bucket; the expectation is
+// exact bookkeeping: k-mer instances are known after the trim, a random-order minimiser starts a supermer every
+// (W+1)/2 k-mers); a supermer takes slot atomicAdd(cursor) of its bucket, the few that do not fit go to an overflow
+// list that is grouped by bucket afterwards and read by the count kernel as a second segment.  Correctness never
+// depends on the estimate.  The sharded path runs the same pass and then compacts the used slots into its exact,
+// destination-contiguous send buffer (snk_stages.hip).
 #include "snk_ctx.h"
 #include "snk_common.h"
 #include "snk_kernels.h"
@@ -75,12 +67,9 @@ __device__ __forceinline__ uint32_t row_window(const uint32_t* rowL, int tid, ui
     return s ? ((w0 << s) | (w1 >> (32u - s))) : w0;
 }
 
-enum { MSP_HIST = 0, MSP_REPLAY = 1, MSP_SINGLE = 2 };
-
-template <int K, int M, int MODE>
+template <int K, int M>
 __global__ void __launch_bounds__(BD) snk_msp_kernel(snk_msp_args a) {
     constexpr int W = K - M + 1;
-    constexpr bool WRITES = MODE != MSP_HIST;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t row_words = a.row_words;
     const uint32_t NB = a.NB;
@@ -108,7 +97,7 @@ __global__ void __launch_bounds__(BD) snk_msp_kernel(snk_msp_args a) {
     const int nk = g ? g - K + 1 : 0;
     const int npos = g ? g - M + 1 : 0;
     int32_t mybc = 0;
-    if (WRITES && g) mybc = (a.bc && (int64_t)(a.read_index_base + r) >= a.ign_bc_below) ? a.bc[r] : -1;
+    if (g) mybc = (a.bc && (int64_t)(a.read_index_base + r) >= a.ign_bc_below) ? a.bc[r] : -1;
     uint32_t gmix = 0;                                   // grouped runs: word 7 of the record carries the group id
     if (a.group && g) { const uint32_t grp = a.group[r]; gmix = snk_group_mix(grp); mybc = (int32_t)grp; }
 
@@ -130,24 +119,20 @@ __global__ void __launch_bounds__(BD) snk_msp_kernel(snk_msp_args a) {
                 uint32_t s = ent & 0xFFu;
                 uint32_t en = (e + 1 < upto) ? (((uint32_t)lst[(e + 1) * BD + tid] & 0xFFu) - 1u) : (uint32_t)last_end;
                 uint32_t bucket = mmer_bucket<M>(rowL, tid, row_words, (int)(ent >> 8), NB, gmix);
-                if (MODE == MSP_HIST) {
-                    atomicAdd(&a.hist_or_cursor[bucket], 1u);
-                } else {
-                    const uint32_t slot = a.dbg == 2 ? ((ent * 2654435761u) % (a.cap ? a.cap : 1u)) : (a.dbg == 3 ? __hip_atomic_fetch_add(&a.hist_or_cursor[bucket], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : (a.dbg == 4 ? __hip_atomic_fetch_add(&a.hist_or_cursor[bucket], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : atomicAdd(&a.hist_or_cursor[bucket], 1u)));
-                    uint64_t at = slot;                                    // REPLAY: the cursor holds absolute record offsets
+                {
+                    const uint32_t slot = a.dbg == 2 ? ((ent * 2654435761u) % (a.cap ? a.cap : 1u)) : atomicAdd(&a.cursor[bucket], 1u);
+                    uint64_t at = 0;
                     bool ok = true;
-                    if (MODE == MSP_SINGLE) {
-                        if (slot < a.cap) at = (uint64_t)bucket * a.cap + slot;
-                        else {
-                            // overflow list: ONE reservation per wave (same-address atomics are served one at a time)
-                            const unsigned long long m = __ballot(1);
-                            const int lane = tid & 63, leader = __ffsll((long long)m) - 1;
-                            uint32_t o = 0;
-                            if (lane == leader) o = atomicAdd(a.ovf_cursor, (uint32_t)__popcll(m));
-                            o = __shfl(o, leader) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                            if (o < a.ovf_cap) { at = a.ovf_base + o; a.ovf_bucket[o] = bucket; }
-                            else ok = false;                               // the host sees ovf_cursor > ovf_cap and re-runs
-                        }
+                    if (slot < a.cap) at = (uint64_t)bucket * a.cap + slot;
+                    else {
+                        // overflow list: ONE reservation per wave (same-address atomics are served one at a time)
+                        const unsigned long long m = __ballot(1);
+                        const int lane = tid & 63, leader = __ffsll((long long)m) - 1;
+                        uint32_t o = 0;
+                        if (lane == leader) o = atomicAdd(a.ovf_cursor, (uint32_t)__popcll(m));
+                        o = __shfl(o, leader) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                        if (o < a.ovf_cap) { at = a.ovf_base + o; a.ovf_bucket[o] = bucket; }
+                        else ok = false;                               // the host sees ovf_cursor > ovf_cap and re-runs
                     }
                     if (ok && a.dbg != 1) {
                         uint32_t n_kmers = en - s + 1u;
@@ -175,20 +160,7 @@ __global__ void __launch_bounds__(BD) snk_msp_kernel(snk_msp_args a) {
         }
     };
 
-    // REPLAY: the histogram pass saved every read's supermer list (minimiser position, first k-mer; <= LCAP entries,
-    // [entry][read] so that a wave's accesses coalesce).  A read whose list overflowed is marked 0xFF and its wave
-    // falls back to the scan.
-    bool overflowed = false;
-    bool replay = false;
-    if (MODE == MSP_REPLAY && a.scount) {
-        uint32_t sc = (r < n_reads) ? a.scount[r] : 0u;
-        replay = !__any(sc == 0xFFu);
-        if (replay) {
-            cnt = (int)sc;
-            for (int e = 0; e < cnt; ++e) lst[e * BD + tid] = a.slist[(uint64_t)e * n_reads + r];
-        }
-    }
-    const int nblocks = replay ? 0 : (nk + W - 1) / W;
+    const int nblocks = (nk + W - 1) / W;
     int maxblocks = nblocks;
     for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(maxblocks, off); maxblocks = o > maxblocks ? o : maxblocks; }
     // Every ordering key is computed ONCE, by one forward roll over the read: x = the 16 bases at the current
@@ -276,7 +248,6 @@ __global__ void __launch_bounds__(BD) snk_msp_kernel(snk_msp_args a) {
                     const int upto = cnt > 0 ? cnt - 1 : 0;
                     const int last_end = cnt > 0 ? (int)(lst[(cnt - 1) * BD + tid] & 0xFFu) - 1 : 0;
                     flush(upto, last_end);
-                    overflowed = true;
                     if (cnt > 0) { lst[tid] = lst[(cnt - 1) * BD + tid]; cnt = 1; }
                 }
                 if (isnew) {
@@ -292,17 +263,8 @@ __global__ void __launch_bounds__(BD) snk_msp_kernel(snk_msp_args a) {
             }
         }
     }
-    if (MODE == MSP_HIST && a.scount && r < n_reads) {
-        a.scount[r] = overflowed ? (uint8_t)0xFF : (uint8_t)cnt;
-        if (!overflowed) for (int e = 0; e < cnt; ++e) a.slist[(uint64_t)e * n_reads + r] = lst[e * BD + tid];
-    }
     flush(cnt, nk - 1);
 
-    if (MODE != MSP_REPLAY && a.n_inst_out) {
-        unsigned long long v = (unsigned long long)nk;
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        if ((tid & 63) == 0 && v) atomicAdd(a.n_inst_out, v);
-    }
 }
 
 // k-mer instances and reads that contribute any (exact sizing of the single pass)
@@ -324,40 +286,22 @@ size_t snk_msp_lds_bytes(uint32_t K, uint32_t M, uint32_t row_words) {
     return (size_t)row_words * BD * 4 + (size_t)LCAP * BD * 2 + (size_t)(K - M + 1) * BD + 64;
 }
 
-template <int K, int M, int MODE>
-static int launch_msp_mode(hipStream_t st, const snk_msp_args& a, char* err, size_t errcap) {
+template <int K, int M>
+static int launch_msp_k(hipStream_t st, const snk_msp_args& a, char* err, size_t errcap) {
     size_t lds = snk_msp_lds_bytes(K, M, a.row_words);
     unsigned nb = (unsigned)((a.n_reads + BD - 1) / BD);
-    SNK_HIP_TRY(hipFuncSetAttribute((const void*)snk_msp_kernel<K, M, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((snk_msp_kernel<K, M, MODE>), dim3(nb), dim3(BD), lds, st, a);
+    SNK_HIP_TRY(hipFuncSetAttribute((const void*)snk_msp_kernel<K, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((snk_msp_kernel<K, M>), dim3(nb), dim3(BD), lds, st, a);
     SNK_HIP_TRY(hipGetLastError());
     return SNK_OK;
 }
-template <int K>
-static int launch_msp_k(int mode, hipStream_t st, const snk_msp_args& a, char* err, size_t errcap) {
-    if (mode == MSP_HIST) return launch_msp_mode<K, SNK_M, MSP_HIST>(st, a, err, errcap);
-    if (mode == MSP_REPLAY) return launch_msp_mode<K, SNK_M, MSP_REPLAY>(st, a, err, errcap);
-    return launch_msp_mode<K, SNK_M, MSP_SINGLE>(st, a, err, errcap);
-}
 
-int snk_launch_msp_args(uint32_t K, int mode, hipStream_t st, const snk_msp_args& a, char* err, size_t errcap) {
+int snk_launch_msp(uint32_t K, hipStream_t st, const snk_msp_args& a, char* err, size_t errcap) {
     if (a.n_reads == 0) return SNK_OK;
     if (a.row_words > 16) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "reads longer than 256 bases are not supported (row_words=%u)", a.row_words);
-    if (K == 48) return launch_msp_k<48>(mode, st, a, err, errcap);
-    if (K == 60) return launch_msp_k<60>(mode, st, a, err, errcap);
+    if (K == 48) return launch_msp_k<48, SNK_M>(st, a, err, errcap);
+    if (K == 60) return launch_msp_k<60, SNK_M>(st, a, err, errcap);
     return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "K=%u is not supported (48 or 60)", K);
-}
-
-int snk_launch_msp(uint32_t K, bool scatter, hipStream_t st, const uint32_t* rows, uint32_t row_words,
-                   const uint16_t* good_len, const int32_t* bc, int64_t ign_bc_below, uint64_t read_index_base,
-                   uint64_t n_reads, uint32_t NB, uint32_t* hist_or_cursor, void* records, unsigned long long* n_inst,
-                   uint16_t* slist, uint8_t* scount, char* err, size_t errcap) {
-    snk_msp_args a;
-    memset(&a, 0, sizeof a);
-    a.rows = rows; a.row_words = row_words; a.good_len = good_len; a.bc = bc; a.ign_bc_below = ign_bc_below;
-    a.read_index_base = read_index_base; a.n_reads = n_reads; a.NB = NB; a.hist_or_cursor = hist_or_cursor;
-    a.records = (uint4*)records; a.n_inst_out = n_inst; a.slist = slist; a.scount = scount;
-    return snk_launch_msp_args(K, scatter ? MSP_REPLAY : MSP_HIST, st, a, err, errcap);
 }
 
 int snk_launch_msp_plan(hipStream_t st, const uint16_t* good_len, uint64_t n_reads, uint32_t K, unsigned long long* out2,

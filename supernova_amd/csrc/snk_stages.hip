@@ -292,12 +292,12 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
         ma.rows = (const uint32_t*)in->rows; ma.row_words = in->row_words; ma.good_len = good_len; ma.bc = (const int32_t*)in->bc;
         ma.ign_bc_below = in->ign_bc_below; ma.read_index_base = in->read_index_base; ma.n_reads = n_reads; ma.NB = NB;
         ma.group = grouped ? (const uint32_t*)in->group : nullptr;
-        ma.hist_or_cursor = cursor; ma.records = (uint4*)records; ma.cap = cap; ma.ovf_cap = (uint32_t)ovf_cap;
+        ma.cursor = cursor; ma.records = (uint4*)records; ma.cap = cap; ma.ovf_cap = (uint32_t)ovf_cap;
         ma.ovf_base = (uint64_t)NB * cap; ma.ovf_bucket = ovf_bucket; ma.ovf_cursor = status + 8;
         ma.dbg = env_u32("SNK_MSP_DBG", 0);
         kt.n = 0;
         kt.mark();  // 0
-        if ((rc = snk_launch_msp_args(K, SNK_MSP_MODE_SINGLE, st, ma, err, errcap))) return rc;
+        if ((rc = snk_launch_msp(K, st, ma, err, errcap))) return rc;
         kt.mark();  // 1
         SNK_HIP_TRY(hipMemcpyAsync(&h_novf, status + 8, 4, hipMemcpyDeviceToHost, st));
         SNK_HIP_TRY(hipStreamSynchronize(st));

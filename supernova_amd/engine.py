@@ -16,7 +16,7 @@ import torch
 
 from . import lib as _lib
 
-PHASES = ("trim", "msp_hist", "msp_scatter", "count", "sort", "graph", "-", "total")
+PHASES = ("trim", "plan", "partition", "count", "sort", "graph", "-", "total")
 
 
 @dataclass
@@ -52,7 +52,7 @@ class Result:
                   "n_fragments"):
             setattr(self, f, int(getattr(raw, f)))
         self.phase_ms = {PHASES[i]: float(raw.phase_ms[i]) for i in range(8) if PHASES[i] != "-"}
-        self.kernel_ms = {"msp_hist": float(raw.kernel_ms[0]), "msp_scatter": float(raw.kernel_ms[1]),
+        self.kernel_ms = {"partition": float(raw.kernel_ms[1]),
                           "count": float(raw.kernel_ms[2])}
         names = ("local_prune", "-", "fragments", "join", "table")     # local_prune includes the boundary index + resolve
         self.graph_ms = {names[i]: float(raw.graph_ms[i]) for i in range(5) if names[i] != "-"}

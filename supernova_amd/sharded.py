@@ -376,10 +376,10 @@ class ShardedEngine:
             res._keep = (t_nk, t_self, t_nb, starts_all, t_bases)
         ev[7].record()
         torch.cuda.synchronize()
-        names = ["hist", "scatter", "exchange", "count", "prune", "fragments", "join"]
+        names = ["partition", "compact", "exchange", "count", "prune", "fragments", "join"]
         res.phase_ms = {names[i]: ev[i].elapsed_time(ev[i + 1]) for i in range(7)}
         res.phase_ms["total"] = ev[0].elapsed_time(ev[7])
-        res.kernel_ms = {"count": float(fr.count_kernel_ms), "msp_hist": 0.0, "msp_scatter": 0.0}
+        res.kernel_ms = {"count": float(fr.count_kernel_ms)}
         res.buckets_split = int(fr.buckets_split)
         return res
 

@@ -15,6 +15,6 @@ for dbg in [int(x) for x in (sys.argv[2].split(',') if len(sys.argv) > 2 else '0
     for rep in range(2):
         try:
             res = e.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48, graph=False, sorted_table=False))
-            print("dbg", dbg, "rep", rep, "msp kernel ms", round(res.kernel_ms["msp_scatter"], 2), "count", round(res.kernel_ms["count"], 2), flush=True)
+            print("dbg", dbg, "rep", rep, "msp kernel ms", round(res.kernel_ms["partition"], 2), "count", round(res.kernel_ms["count"], 2), flush=True)
         except Exception as ex:
             print("dbg", dbg, "failed:", str(ex)[:100], flush=True)

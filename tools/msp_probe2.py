@@ -13,7 +13,7 @@ rows, quals, bc = e.synth(sp)
 def run(tag, **kw):
     for rep in range(2):
         res = e.count_graph(rows, 150, quals=quals, **kw)
-    print(f"{tag:40s} msp {res.kernel_ms['msp_scatter']:.1f} ms  count {res.kernel_ms['count']:.1f}  NB {res.n_buckets} super {res.n_supermers} ovf {res.n_overflow} kmers {res.n_kmers}", flush=True)
+    print(f"{tag:40s} msp {res.kernel_ms['partition']:.1f} ms  count {res.kernel_ms['count']:.1f}  NB {res.n_buckets} super {res.n_supermers} ovf {res.n_overflow} kmers {res.n_kmers}", flush=True)
 run("ungrouped, bc rule", bc=bc, params=Params(graph=False, sorted_table=False))
 run("ungrouped, no bc array", bc=None, params=Params(graph=False, sorted_table=False))
 run("grouped (bucket target 900)", bc=None, group=bc, params=Params(graph=False, sorted_table=False, grouped=True, min_bc=0))
