@@ -81,6 +81,12 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
 
     if (tid == 0) { ctl[0] = 1; ctl[16] = 0; ctl[17] = 0; }
     uint32_t splits_done = 0;
+    // issued before the table is cleared: the bounds of segment 0 and the first batch of records (two dependent HBM
+    // round trips that every workgroup used to wait for after its first barrier)
+    const uint64_t beg0 = a.seg_beg[bucket], end0 = a.seg_end[bucket];
+    uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = make_uint4(0, 0, 0, 0);
+    if (tid < BATCH && beg0 + tid < end0) { pf0 = a.records[(beg0 + tid) * 2]; pf1 = a.records[(beg0 + tid) * 2 + 1]; }
+    bool first_batch = true;
     for (;;) {
         __syncthreads();
         if (LDS_LOAD(&ctl[0]) == 0) break;
@@ -93,21 +99,23 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
             ctl[1] = 0;
             ctl[2] = 0;
         }
-        for (int s = tid; s < SLOTS; s += THREADS) { tag[s] = 0; cnt[s] = 0; bcs[s] = 0; }
+        for (int s = tid; s < SLOTS; s += THREADS) tag[s] = 0;      // cnt/bcs of a slot are initialised by the lane that claims it
         for (int s = tid; s < SLOTS / 4; s += THREADS) ctxw[s] = 0;
         __syncthreads();
         const uint32_t split_lg = LDS_LOAD(&ctl[3]), split_id = LDS_LOAD(&ctl[4]);
         const uint32_t split_mask = (1u << split_lg) - 1u;
 
         for (uint32_t seg = 0; seg < a.nseg; ++seg) {
-            const uint64_t beg = a.seg_beg[(uint64_t)seg * a.seg_stride + bucket];
-            const uint64_t end = a.seg_end[(uint64_t)seg * a.seg_stride + bucket];
+            const uint64_t beg = seg ? a.seg_beg[(uint64_t)seg * a.seg_stride + bucket] : beg0;
+            const uint64_t end = seg ? a.seg_end[(uint64_t)seg * a.seg_stride + bucket] : end0;
             for (uint64_t base = beg; base < end; base += BATCH) {
                 // ---- stage one batch of supermer records (coalesced 32-byte loads) and scan their k-mer counts
                 const uint64_t idx = base + tid;
                 uint32_t nkm = 0;
+                const bool use_pf = first_batch && seg == 0 && base == beg0;
+                first_batch = false;
                 if (tid < BATCH && idx < end) {
-                    const uint4 r0 = a.records[idx * 2], r1 = a.records[idx * 2 + 1];
+                    const uint4 r0 = use_pf ? pf0 : a.records[idx * 2], r1 = use_pf ? pf1 : a.records[idx * 2 + 1];
                     rec[0 * BATCH + tid] = r0.x; rec[1 * BATCH + tid] = r0.y; rec[2 * BATCH + tid] = r0.z;
                     rec[3 * BATCH + tid] = r0.w; rec[4 * BATCH + tid] = r1.x; rec[5 * BATCH + tid] = r1.y;
                     rec[6 * BATCH + tid] = r1.z;
@@ -228,6 +236,8 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
                                     if (t == 0) {
                                         khi[slot] = c.hi;
                                         klo[slot] = clo;
+                                        cnt[slot] = 0;
+                                        bcs[slot] = 0;
                                         __hip_atomic_store(&tag[slot], mytag | 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                                         uint32_t occ = atomicAdd(&ctl[1], 1u);
                                         if (occ >= LIMIT) __hip_atomic_store(&ctl[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -278,7 +288,7 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
         __syncthreads();
         uint32_t myvalid = 0;
         for (int s = tid; s < SLOTS; s += THREADS) {      // SLOTS need not be a multiple of THREADS
-            const uint32_t c = cnt[s];
+            const uint32_t c = tag[s] ? cnt[s] : 0u;       // unclaimed slots hold stale counts
             bool ok = c >= a.min_freq && c != 0;
             if (ok && a.bc_mode) {
                 const uint32_t b = bcs[s];
