@@ -259,7 +259,7 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
     // relative sigma of ~37 %.  With 1.25 x mean + 4 sqrt(mean) 1.7 % of the supermers overflowed and their
     // reservations on the single overflow cursor cost 30 ms (tools/msp_probe2.py).  2.5 x mean is > 5 sigma of the site
     // count at 56x and generous below; the slots that stay empty are never touched.
-    uint64_t cap64 = (uint64_t)(mean * 2.5 + 64.0);
+    uint64_t cap64 = (uint64_t)(mean * 2.5 + 32.0);
     cap64 = cap64 * env_u32("SNK_MSP_CAP_PCT", 100) / 100;
     if (cap64 < 2) cap64 = 2;
     cap64 = (cap64 + 1) & ~1ull;
