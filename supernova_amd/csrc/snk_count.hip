@@ -54,7 +54,9 @@ template <int K, bool G> __device__ __forceinline__ uint64_t klo_unpack(typename
 
 template <int K, int THREADS, int SLOTS, bool GROUPED>
 __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
-    constexpr int BATCH = 256;                           // supermers staged per batch (owner[] holds 8-bit indices)
+    constexpr int BATCH = K > 48 ? 192 : 256;            // supermers staged per batch (owner[] holds 8-bit indices); K=60: 192
+                                                         // keeps the workgroup under 80 KB of LDS, i.e. two per CU
+    constexpr int DD = 512;                              // de-duplication table slots (power of two >= 2*BATCH)
     typedef typename klo_t<K, GROUPED>::type lo_type;
     constexpr int WMAX = K - SNK_M + 1;                  // k-mers per supermer, at most
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -67,8 +69,8 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
     uint32_t* rec = ctxw + SLOTS / 4;                                               // [8][BATCH] staged supermer records
     uint32_t* pre = rec + 8 * BATCH;                                                // [BATCH+1] k-mer prefix sums of the batch
     uint32_t* ctl = pre + BATCH + 4;                                                // [64] control words
-    uint32_t* dd = ctl + 64;                                                        // [2*BATCH] supermer de-duplication table (leader index + 1)
-    uint32_t* wgt = dd + 2 * BATCH;                                                 // [BATCH] copies folded into each leader
+    uint32_t* dd = ctl + 64;                                                        // [DD] supermer de-duplication table (leader index + 1)
+    uint32_t* wgt = dd + DD;                                                 // [BATCH] copies folded into each leader
     uint8_t* owner = reinterpret_cast<uint8_t*>(wgt + BATCH);                       // [BATCH*WMAX] k-mer -> supermer of the batch
     // ctl[0] stack pointer, ctl[1] occupied slots, ctl[2] overflow flag, ctl[3] split log2, ctl[4] split id,
     // ctl[5] valid entries of the sub-pass, ctl[6..7] reserved base (lo,hi), ctl[8] placement counter,
@@ -125,7 +127,7 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
                     nkm = r1.z & 0x7Fu;
                     wgt[tid] = 1;
                 }
-                for (int q = tid; q < 2 * BATCH; q += THREADS) dd[q] = 0;
+                for (int q = tid; q < DD; q += THREADS) dd[q] = 0;
                 __syncthreads();
                 // ---- fold identical supermers: at 56x coverage ~3 of 4 reads over a locus yield the SAME record (same
                 //      bases, same flanks); only their barcodes differ.  The first one becomes the leader and carries a
@@ -138,7 +140,7 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
 #pragma unroll
                     for (int q = 1; q < 7; ++q) h = (h ^ w[q]) * 0x85EBCA77u + (h >> 15);
                     h ^= h >> 13;
-                    uint32_t s = h & (2 * BATCH - 1);
+                    uint32_t s = h & (DD - 1);
                     for (;;) {
                         uint32_t v = LDS_LOAD(&dd[s]);
                         if (v == 0) {
@@ -161,7 +163,7 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
                             nkm = 0;
                             break;
                         }
-                        s = (s + 1) & (2 * BATCH - 1);
+                        s = (s + 1) & (DD - 1);
                     }
                 }
                 uint32_t incl = nkm;
@@ -344,8 +346,8 @@ template <> struct cfg<60> { static constexpr int THREADS = SNK_COUNT_THREADS; s
 
 template <int K, bool G>
 size_t lds_bytes() {
-    constexpr size_t S = cfg<K>::SLOTS, B = 256;
-    return S * (8 + sizeof(typename klo_t<K, G>::type) + 4 + 4 + 4) + S + 4 * (8 * B + B + 4 + 64 + 2 * B + B) + B * (K - SNK_M + 1) + 16;
+    constexpr size_t S = cfg<K>::SLOTS, B = K > 48 ? 192 : 256, DD = 512;
+    return S * (8 + sizeof(typename klo_t<K, G>::type) + 4 + 4 + 4) + S + 4 * (8 * B + B + 4 + 64 + DD + B) + B * (K - SNK_M + 1) + 16;
 }
 
 template <int K, bool G>
