@@ -203,7 +203,9 @@ def main():
                        "fragments_rank0": int(getattr(res, "n_fragments", 0))},
             "roofline": {"bound": "hbm", "kernel": "snk_count_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "launch_ms": count_ms, "units_per_launch": units, "alg_bytes_per_unit": ALG_BYTES_PER_KMER[K]},
+                         "launch_ms": count_ms, "units_per_launch": units, "alg_bytes_per_unit": ALG_BYTES_PER_KMER[K],
+                         # the whole job against the chips' HBM roofline
+                         "pipeline_frac": value * ALG_BYTES_PER_KMER[K] / (world * HBM_PEAK_GBS)},
         }
         out["config"]["path"] = "grouped-replicas" if args.grouped else ("sharded" if use_dist else "single")
         if world == 1 and not args.no_cpu_baseline:

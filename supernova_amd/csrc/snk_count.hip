@@ -58,7 +58,8 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
                                                          // keeps the workgroup under 80 KB of LDS, i.e. two per CU
     constexpr int DD = 512;                              // de-duplication table slots (power of two >= 2*BATCH)
     typedef typename klo_t<K, GROUPED>::type lo_type;
-    constexpr int WMAX = K - SNK_M + 1;                  // k-mers per supermer, at most
+    constexpr int WMAX = K - SNK_M + 1;                  // k-mers per supermer, at most (sizes owner[])
+    (void)WMAX;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint64_t* khi = reinterpret_cast<uint64_t*>(smem_raw);                         // [SLOTS]
     lo_type* klo = reinterpret_cast<lo_type*>(khi + SLOTS);                         // [SLOTS]

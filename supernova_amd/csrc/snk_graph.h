@@ -34,13 +34,8 @@ struct snk_dist_graph {
     uint64_t index_mask;
     uint8_t* ctx;
     uint32_t* counts;
-    uint8_t* pend;
-    uint8_t* dest;
-    uint32_t* nbr_local;
-    uint32_t* rq_idx;
+    uint32_t* rq_idx;              // answers of the remote membership queries
     uint16_t* rq_meta;
-    unsigned long long* qcount;    // [world] queries per destination rank (device)
-    unsigned long long* qcursor;
 };
 struct snk_frag_out {
     uint64_t n_frags, total_bases;
@@ -61,15 +56,10 @@ struct snk_join_out {
     uint32_t* unitig_group;     // grouped runs (fgroup given): group of every unitig; unitigs ordered by (group, first K bases)
     uint32_t n_circles, rank_rounds, n_circles_rotated;
 };
-int snk_dist_prune_plan(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, char* err, size_t errcap);
-int snk_dist_fill_queries(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, const unsigned long long* d_qoff, void* d_qbuf,
-                          char* err, size_t errcap);
 int snk_dist_answer(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, const void* d_queries, uint64_t nq, void* d_ans, char* err,
                     size_t errcap);
 int snk_dist_apply(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, const void* d_qbuf, const void* d_ans, uint64_t nq,
                    const unsigned long long* d_qoff, char* err, size_t errcap);
-int snk_dist_fragments(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, const unsigned long long* d_node_off,
-                       unsigned long long my_node_off, snk_frag_out* out, char* err, size_t errcap);
 int snk_dist_join(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const uint32_t* nk, const unsigned long long* hl_self,
                   const unsigned long long* hl_nb, const uint64_t* boff, const uint8_t* fbases, uint64_t total_fbases,
                   snk_join_out* out, char* err, size_t errcap, const uint32_t* fgroup = nullptr);
@@ -97,4 +87,5 @@ int snk_bl_dist_fragments(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, const u
 int snk_local_graph(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_table* tab, uint32_t do_prune, bool want_unitigs,
                     bool sort_table, bool grouped, snk_graph_out* out, snk_u128** keys_final, float* ms /* [5] or NULL */, char* err,
                     size_t errcap);
-int snk_launch_spectrum(hipStream_t st, const uint32_t* counts, uint64_t n, unsigned long long* bins, uint32_t nbins);
+int snk_spectrum(snk_ctx* ctx, hipStream_t st, const uint32_t* counts, uint64_t n, unsigned long long** bins_out, uint32_t* nbins_out,
+                 char* err, size_t errcap);

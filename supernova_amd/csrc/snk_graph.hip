@@ -306,6 +306,7 @@ __global__ void __launch_bounds__(TB) spectrum_kernel(const uint32_t* __restrict
     uint64_t stride = (uint64_t)gridDim.x * TB;
     for (uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x; i < n; i += stride) {
         uint32_t c = counts[i];
+        if (c > 0xFFFFFFu) c = 0xFFFFFFu;            // the reference's KDef count saturates at 2^24-1 (kmers/ReadPather.h:128-129,145)
         if (c >= nbins) c = nbins - 1;
         if (c < (uint32_t)SPEC_LDS) atomicAdd(&h[c], 1u);
         else atomicAdd(&bins[c], 1ull);
@@ -628,17 +629,10 @@ static int graph_impl(snk_ctx* ctx, hipStream_t st, const snk_u128* keys, const 
     out->ctx = ctx_out;
     out->counts = count_out;
     // spectrum
-    constexpr uint32_t NBINS = 65536;
-    unsigned long long* bins;
-    G_ALLOC(bins, unsigned long long, NBINS);
-    SNK_HIP_TRY(hipMemsetAsync(bins, 0, NBINS * 8, st));
     {
-        unsigned g = nblk(n);
-        if (g > 2048) g = 2048;
-        hipLaunchKernelGGL(spectrum_kernel, dim3(g), dim3(TB), 0, st, count_out, n, bins, NBINS);
+        int rc = snk_spectrum(ctx, st, count_out, n, &out->spectrum, &out->spectrum_bins, err, errcap);
+        if (rc) return rc;
     }
-    out->spectrum = bins;
-    out->spectrum_bins = NBINS;
     if (!want_unitigs) return SNK_OK;
 
     const uint64_t ns = 2 * n;
@@ -707,84 +701,17 @@ int snk_graph_build(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_u128* ke
 }
 
 // =====================================================================================================================
-// Sharded graph stage: every rank owns the retained k-mers of its minimiser buckets.
-//   * prune: neighbours that are not in the local table are either absent (their bucket is ours) or live on
-//     another rank -> one round of membership queries (all-to-all) resolves them;
-//   * links: a link whose two k-mers live on one rank is decided there; a side whose single neighbour is remote
-//     ends the local fragment and exports a "half link" (my terminal state -> remote state).  Two half links
-//     that point at each other are a link (the reciprocal-unique rule of BuildReadQGraph48.cc:408-428 checked
-//     half on each owner);
-//   * local fragments are ranked and emitted per rank (tada's per-shard sedges, lib/tada/src/debruijn.rs:296-320),
-//     rank 0 joins them (tada's MAIN_ASM_SN build_edges, debruijn.rs:733-776) with the same list ranking,
-//     weighted by k-mers, then applies the reference's canonical orientation.
+// Sharded graph stage and fragment join.  The per-rank work (prune, links, fragments) is the bucket-
+// local stage of snk_local.hip; here live the pieces that answer membership queries of other ranks and the join:
+//   * a side whose single neighbour lives in another chunk (same rank or not) ends its fragment and exports a "half
+//     link" (my terminal state -> the neighbour's state).  Two half links that point at each other are a link (the
+//     reciprocal-unique rule of BuildReadQGraph48.cc:408-428 checked half on each owner);
+//   * the fragments (tada's per-shard sedges, lib/tada/src/debruijn.rs:296-320) are joined (tada's MAIN_ASM_SN
+//     build_edges, debruijn.rs:733-776) by list ranking weighted by k-mers, then get the reference's orientation.
 // =====================================================================================================================
 namespace {
 
 constexpr unsigned long long NONE64 = ~0ull;
-
-template <int K>
-__global__ void __launch_bounds__(TB) prune_dist_kernel(const snk_u128* __restrict__ keys, const uint64_t* __restrict__ vals,
-                                                        uint64_t n, const unsigned long long* __restrict__ tab, uint64_t mask,
-                                                        uint32_t NB_total, uint32_t NBl, uint32_t me,
-                                                        uint8_t* __restrict__ ctx_out, uint32_t* __restrict__ count_out,
-                                                        uint8_t* __restrict__ pend, uint8_t* __restrict__ dest,
-                                                        uint32_t* __restrict__ nbr_local,
-                                                        unsigned long long* __restrict__ qcount) {
-    uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x;
-    if (i >= n) return;
-    snk_kmer k = load_key(keys, i);
-    uint64_t v = vals[i];
-    uint32_t c = (uint32_t)(v & 0xFFu);
-    count_out[i] = (uint32_t)(v >> 8);
-    uint32_t keep = 0, pmask = 0;
-    uint32_t nb0 = NONE, nb1 = NONE;
-    for (uint32_t bit = 0; bit < 8; ++bit) {
-        if (!(c & (1u << bit))) continue;
-        snk_kmer y = bit < 4 ? snk_kmer_succ<K>(k, bit) : snk_kmer_pred<K>(k, bit - 4);
-        uint32_t rev;
-        int64_t j = find_any<K>(keys, tab, mask, y, &rev);
-        if (j >= 0) {
-            keep |= 1u << bit;
-            if (bit < 4) nb0 = ((uint32_t)j << 1) | rev; else nb1 = ((uint32_t)j << 1) | rev;
-        } else {
-            uint32_t owner = snk_bucket_of_kmer<K>(y, NB_total) / NBl;
-            if (owner != me) {                       // lives (if anywhere) on another rank: ask
-                keep |= 1u << bit;
-                pmask |= 1u << bit;
-                dest[8 * i + bit] = (uint8_t)owner;
-                atomicAdd(&qcount[owner], 1ull);
-            }                                        // else: its bucket is ours and it is not retained -> pruned
-        }
-    }
-    ctx_out[i] = (uint8_t)keep;
-    pend[i] = (uint8_t)pmask;
-    nbr_local[2 * i + 0] = nb0;
-    nbr_local[2 * i + 1] = nb1;
-}
-
-// query record: 3 x u64 = key lo, key hi, (node | bit << 32 | rev << 40)
-template <int K>
-__global__ void __launch_bounds__(TB) fill_queries_kernel(const snk_u128* __restrict__ keys, uint64_t n,
-                                                          const uint8_t* __restrict__ pend, const uint8_t* __restrict__ dest,
-                                                          unsigned long long* __restrict__ qcursor,
-                                                          unsigned long long* __restrict__ qbuf) {
-    uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x;
-    if (i >= n) return;
-    uint32_t pm = pend[i];
-    if (!pm) return;
-    snk_kmer k = load_key(keys, i);
-    for (uint32_t bit = 0; bit < 8; ++bit) {
-        if (!(pm & (1u << bit))) continue;
-        snk_kmer y = bit < 4 ? snk_kmer_succ<K>(k, bit) : snk_kmer_pred<K>(k, bit - 4);
-        snk_kmer r = snk_kmer_rc<K>(y);
-        bool rev = snk_kmer_lt(r, y);
-        snk_kmer c = rev ? r : y;
-        unsigned long long slot = atomicAdd(&qcursor[dest[8 * i + bit]], 1ull);
-        qbuf[3 * slot + 0] = c.lo;
-        qbuf[3 * slot + 1] = c.hi;
-        qbuf[3 * slot + 2] = (unsigned long long)i | ((unsigned long long)bit << 32) | ((unsigned long long)(rev ? 1 : 0) << 40);
-    }
-}
 
 __global__ void __launch_bounds__(TB) answer_kernel(const unsigned long long* __restrict__ q, uint64_t nq,
                                                     const snk_u128* __restrict__ keys, const unsigned long long* __restrict__ tab,
@@ -818,70 +745,6 @@ __global__ void __launch_bounds__(TB) apply_answers_kernel(const unsigned long l
         rq_idx[2 * i + side] = a;
         rq_meta[2 * i + side] = (uint16_t)(rank | (rev << 15));
     }
-}
-
-template <int K>
-__global__ void __launch_bounds__(TB) link_dist_kernel(const snk_u128* __restrict__ keys, const uint8_t* __restrict__ ctx,
-                                                       const uint8_t* __restrict__ pend, const uint32_t* __restrict__ nbr_local,
-                                                       const uint32_t* __restrict__ rq_idx, const uint16_t* __restrict__ rq_meta,
-                                                       uint64_t n, const unsigned long long* __restrict__ node_off,
-                                                       uint32_t* __restrict__ link, unsigned long long* __restrict__ hl_nb) {
-    uint64_t s = (uint64_t)blockIdx.x * TB + threadIdx.x;
-    if (s >= 2 * n) return;
-    uint64_t i = s >> 1;
-    uint32_t side = (uint32_t)(s & 1);
-    uint32_t c = ctx[i];
-    uint32_t bits = side ? (c >> 4) : (c & 15u);
-    uint32_t out = NONE;
-    unsigned long long hl = NONE64;
-    if (__popc(bits) == 1) {
-        uint32_t b = __ffs(bits) - 1;
-        snk_kmer ki = load_key(keys, i);
-        if (!snk_kmer_eq(ki, snk_kmer_rc<K>(ki))) {
-            bool remote = (pend[i] >> (4 * side + b)) & 1u;
-            if (!remote) {
-                uint32_t nb = nbr_local[s];
-                if (nb != NONE) {
-                    uint32_t j = nb >> 1, rev = nb & 1u;
-                    snk_kmer kj = load_key(keys, j);
-                    uint32_t fs = side ^ 1u ^ rev;
-                    uint32_t cj = ctx[j];
-                    uint32_t deg = fs ? __popc(cj & 0xF0u) : __popc(cj & 0x0Fu);
-                    if (!snk_kmer_eq(kj, snk_kmer_rc<K>(kj)) && deg == 1) out = (j << 1) | fs;
-                }
-            } else {
-                uint32_t a = rq_idx[s];
-                if (a != NONE) {
-                    snk_kmer y = side ? snk_kmer_pred<K>(ki, b) : snk_kmer_succ<K>(ki, b);
-                    if (!snk_kmer_eq(y, snk_kmer_rc<K>(y))) {
-                        uint32_t meta = rq_meta[s];
-                        uint32_t rank = meta & 0x7FFFu, rev = meta >> 15;
-                        uint32_t fs = side ^ 1u ^ rev;
-                        hl = 2ull * (node_off[rank] + a) + fs;
-                    }
-                }
-            }
-        }
-    }
-    link[s] = out;
-    hl_nb[s] = hl;
-}
-
-// per fragment (head node = the node at position 0 walking from terminal pid): k-mer count and the two half links
-__global__ void __launch_bounds__(TB) frag_desc_kernel(const uint2* __restrict__ rk,
-                                                       const uint32_t* __restrict__ hflag, const uint32_t* __restrict__ hidx,
-                                                       const unsigned long long* __restrict__ hl_nb_state, uint64_t n,
-                                                       unsigned long long my_state_base, uint32_t* __restrict__ nk,
-                                                       unsigned long long* __restrict__ hl_self, unsigned long long* __restrict__ hl_nb) {
-    uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x;
-    if (i >= n || !hflag[i]) return;
-    node_place p = place_of(rk, i);
-    uint32_t f = hidx[i];
-    nk[f] = p.n;
-    hl_self[2 * f + 0] = my_state_base + p.pid;
-    hl_self[2 * f + 1] = my_state_base + p.other;
-    hl_nb[2 * f + 0] = hl_nb_state[p.pid];
-    hl_nb[2 * f + 1] = hl_nb_state[p.other];
 }
 
 // ---- join (rank 0)
@@ -1152,47 +1015,6 @@ static int chunk_owners(snk_ctx* ctx, hipStream_t st, uint32_t* nch /*[count+1],
     return SNK_OK;
 }
 
-template <int K>
-static int dist_prune_plan_impl(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, char* err, size_t errcap) {
-    const uint64_t n = g->n;
-    uint64_t tg = 1024;
-    while (tg < 2 * n) tg <<= 1;
-    G_ALLOC(g->index, unsigned long long, tg);
-    g->index_mask = tg - 1;
-    SNK_HIP_TRY(hipMemsetAsync(g->index, 0, tg * 8, st));
-    if (n) hipLaunchKernelGGL(index_build_kernel, dim3(nblk(n)), dim3(TB), 0, st, g->keys, n, g->index, tg - 1);
-    uint32_t* ctxw;
-    G_ALLOC(ctxw, uint32_t, n / 4 + 2);
-    SNK_HIP_TRY(hipMemsetAsync(ctxw, 0, (n / 4 + 2) * 4, st));
-    g->ctx = reinterpret_cast<uint8_t*>(ctxw);
-    G_ALLOC(g->counts, uint32_t, n + 1);
-    G_ALLOC(g->pend, uint8_t, n + 1);
-    G_ALLOC(g->dest, uint8_t, 8 * n + 8);
-    G_ALLOC(g->nbr_local, uint32_t, 2 * n + 2);
-    G_ALLOC(g->rq_idx, uint32_t, 2 * n + 2);
-    G_ALLOC(g->rq_meta, uint16_t, 2 * n + 2);
-    G_ALLOC(g->qcount, unsigned long long, g->world + 1);
-    G_ALLOC(g->qcursor, unsigned long long, g->world + 1);
-    SNK_HIP_TRY(hipMemsetAsync(g->qcount, 0, (g->world + 1) * 8ull, st));
-    SNK_HIP_TRY(hipMemsetAsync(g->rq_idx, 0xFF, (2 * n + 2) * 4, st));
-    if (n) hipLaunchKernelGGL((prune_dist_kernel<K>), dim3(nblk(n)), dim3(TB), 0, st, g->keys, g->vals, n, g->index, g->index_mask,
-                              g->NB_total, g->NBl, g->rank, g->ctx, g->counts, g->pend, g->dest, g->nbr_local, g->qcount);
-    SNK_HIP_TRY(hipGetLastError());
-    return SNK_OK;
-}
-int snk_dist_prune_plan(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, char* err, size_t errcap) {
-    return g->K == 48 ? dist_prune_plan_impl<48>(ctx, st, g, err, errcap) : dist_prune_plan_impl<60>(ctx, st, g, err, errcap);
-}
-int snk_dist_fill_queries(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, const unsigned long long* d_qoff, void* d_qbuf,
-                          char* err, size_t errcap) {
-    SNK_HIP_TRY(hipMemcpyAsync(g->qcursor, d_qoff, (g->world + 1) * 8ull, hipMemcpyDeviceToDevice, st));
-    if (g->n) {
-        if (g->K == 48) hipLaunchKernelGGL((fill_queries_kernel<48>), dim3(nblk(g->n)), dim3(TB), 0, st, g->keys, g->n, g->pend, g->dest, g->qcursor, (unsigned long long*)d_qbuf);
-        else hipLaunchKernelGGL((fill_queries_kernel<60>), dim3(nblk(g->n)), dim3(TB), 0, st, g->keys, g->n, g->pend, g->dest, g->qcursor, (unsigned long long*)d_qbuf);
-    }
-    SNK_HIP_TRY(hipGetLastError());
-    return SNK_OK;
-}
 int snk_dist_answer(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, const void* d_queries, uint64_t nq, void* d_ans, char* err,
                     size_t errcap) {
     if (nq) hipLaunchKernelGGL(answer_kernel, dim3(nblk(nq)), dim3(TB), 0, st, (const unsigned long long*)d_queries, nq, g->keys, g->index, g->index_mask, (uint32_t*)d_ans);
@@ -1204,75 +1026,6 @@ int snk_dist_apply(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, const void* 
     if (nq) hipLaunchKernelGGL(apply_answers_kernel, dim3(nblk(nq)), dim3(TB), 0, st, (const unsigned long long*)d_qbuf, (const uint32_t*)d_ans, nq, d_qoff, g->world, g->do_prune, reinterpret_cast<uint32_t*>(g->ctx), g->rq_idx, g->rq_meta);
     SNK_HIP_TRY(hipGetLastError());
     return SNK_OK;
-}
-
-template <int K>
-static int dist_fragments_impl(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, const unsigned long long* d_node_off,
-                               unsigned long long my_node_off, snk_frag_out* out, char* err, size_t errcap) {
-    memset(out, 0, sizeof *out);
-    const uint64_t n = g->n, ns = 2 * n;
-    // spectrum of this rank's share
-    constexpr uint32_t NBINS = 65536;
-    unsigned long long* bins;
-    G_ALLOC(bins, unsigned long long, NBINS);
-    SNK_HIP_TRY(hipMemsetAsync(bins, 0, NBINS * 8, st));
-    if (n) { unsigned gsz = nblk(n); if (gsz > 2048) gsz = 2048; hipLaunchKernelGGL(spectrum_kernel, dim3(gsz), dim3(TB), 0, st, g->counts, n, bins, NBINS); }
-    out->spectrum = bins;
-    out->spectrum_bins = NBINS;
-    if (n == 0) {
-        G_ALLOC(out->boff, uint64_t, 1);
-        SNK_HIP_TRY(hipMemsetAsync(out->boff, 0, 8, st));
-        return SNK_OK;
-    }
-    uint32_t* link;
-    unsigned long long* hl_state;
-    G_ALLOC(link, uint32_t, ns);
-    G_ALLOC(hl_state, unsigned long long, ns);
-    hipLaunchKernelGGL((link_dist_kernel<K>), dim3(nblk(ns)), dim3(TB), 0, st, g->keys, g->ctx, g->pend, g->nbr_local, g->rq_idx, g->rq_meta, n, d_node_off, link, hl_state);
-    SNK_HIP_TRY(hipGetLastError());
-    const uint2* rk;
-    int rc = rank_lists(ctx, st, link, n, nullptr, nullptr, &rk, &out->n_circles, &out->rank_rounds, err, errcap);
-    if (rc) return rc;
-    uint8_t* prev;
-    G_ALLOC(prev, uint8_t, ns);
-    SNK_HIP_TRY(hipMemsetAsync(prev, 0, ns, st));    // fragments keep the pid -> other orientation
-    uint32_t *hflag, *hidx;
-    uint64_t *hlen, *hoff;
-    G_ALLOC(hflag, uint32_t, n + 1);
-    G_ALLOC(hidx, uint32_t, n + 1);
-    G_ALLOC(hlen, uint64_t, n + 1);
-    G_ALLOC(hoff, uint64_t, n + 1);
-    SNK_HIP_TRY(hipMemsetAsync(hflag + n, 0, 4, st));
-    SNK_HIP_TRY(hipMemsetAsync(hlen + n, 0, 8, st));
-    hipLaunchKernelGGL(head_kernel, dim3(nblk(n)), dim3(TB), 0, st, rk, prev, n, (uint32_t)K, hflag, hlen);
-    if ((rc = excl_scan<uint32_t>(ctx, st, hflag, hidx, n + 1, err, errcap))) return rc;
-    if ((rc = excl_scan<uint64_t>(ctx, st, hlen, hoff, n + 1, err, errcap))) return rc;
-    uint32_t h_nf = 0;
-    uint64_t h_tot = 0;
-    SNK_HIP_TRY(hipMemcpyAsync(&h_nf, hidx + n, 4, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipMemcpyAsync(&h_tot, hoff + n, 8, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
-    uint64_t* poff;
-    G_ALLOC(poff, uint64_t, ns);
-    G_ALLOC(out->boff, uint64_t, (uint64_t)h_nf + 1);
-    G_ALLOC(out->bases, uint8_t, h_tot + 1);
-    G_ALLOC(out->nk, uint32_t, (uint64_t)h_nf + 1);
-    G_ALLOC(out->hl_self, unsigned long long, 2ull * h_nf + 2);
-    G_ALLOC(out->hl_nb, unsigned long long, 2ull * h_nf + 2);
-    hipLaunchKernelGGL(head_place_kernel, dim3(nblk(n)), dim3(TB), 0, st, rk, hflag, hidx, hoff, n, poff, out->boff);
-    SNK_HIP_TRY(hipMemcpyAsync(out->boff + h_nf, hoff + n, 8, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL((emit_kernel<K>), dim3(nblk(n)), dim3(TB), 0, st, g->keys, rk, prev, poff, n, out->bases);
-    hipLaunchKernelGGL(frag_desc_kernel, dim3(nblk(n)), dim3(TB), 0, st, rk, hflag, hidx, hl_state, n, 2ull * my_node_off, out->nk, out->hl_self, out->hl_nb);
-    SNK_HIP_TRY(hipGetLastError());
-    SNK_HIP_TRY(hipStreamSynchronize(st));
-    out->n_frags = h_nf;
-    out->total_bases = h_tot;
-    return SNK_OK;
-}
-int snk_dist_fragments(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, const unsigned long long* d_node_off,
-                       unsigned long long my_node_off, snk_frag_out* out, char* err, size_t errcap) {
-    return g->K == 48 ? dist_fragments_impl<48>(ctx, st, g, d_node_off, my_node_off, out, err, errcap)
-                      : dist_fragments_impl<60>(ctx, st, g, d_node_off, my_node_off, out, err, errcap);
 }
 
 // rank 0: fragments of every rank -> canonical unitigs
@@ -1406,10 +1159,35 @@ int snk_dist_join(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
     return SNK_OK;
 }
 
-int snk_launch_spectrum(hipStream_t st, const uint32_t* counts, uint64_t n, unsigned long long* bins, uint32_t nbins) {
-    if (n == 0) return 0;
-    unsigned g = nblk(n);
-    if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(spectrum_kernel, dim3(g), dim3(TB), 0, st, counts, n, bins, nbins);
-    return hipGetLastError() == hipSuccess ? 0 : 1;
+// k-mer spectrum with as many bins as the largest (saturated) count needs -- WriteKmerSpectrum grows its vector to
+// count+1 (BuildReadQGraph48.cc:199-216); at least 65536 bins
+int snk_spectrum(snk_ctx* ctx, hipStream_t st, const uint32_t* counts, uint64_t n, unsigned long long** bins_out, uint32_t* nbins_out,
+                 char* err, size_t errcap) {
+    uint32_t h_max = 0;
+    if (n) {
+        uint32_t* d_max;
+        G_ALLOC(d_max, uint32_t, 4);
+        size_t tb = 0;
+        SNK_HIP_TRY(rocprim::reduce((void*)nullptr, tb, counts, d_max, 0u, (size_t)n, rocprim::maximum<uint32_t>(), st));
+        void* tmp;
+        int rc = snk_ctx_alloc(ctx, tb, &tmp, err, errcap);
+        if (rc) return rc;
+        SNK_HIP_TRY(rocprim::reduce(tmp, tb, counts, d_max, 0u, (size_t)n, rocprim::maximum<uint32_t>(), st));
+        SNK_HIP_TRY(hipMemcpyAsync(&h_max, d_max, 4, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(hipStreamSynchronize(st));
+    }
+    if (h_max > 0xFFFFFFu) h_max = 0xFFFFFFu;
+    const uint32_t nbins = h_max + 1 > 65536u ? h_max + 1 : 65536u;
+    unsigned long long* bins;
+    G_ALLOC(bins, unsigned long long, nbins);
+    SNK_HIP_TRY(hipMemsetAsync(bins, 0, (size_t)nbins * 8, st));
+    if (n) {
+        unsigned g = nblk(n);
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(spectrum_kernel, dim3(g), dim3(TB), 0, st, counts, n, bins, nbins);
+        SNK_HIP_TRY(hipGetLastError());
+    }
+    *bins_out = bins;
+    *nbins_out = nbins;
+    return SNK_OK;
 }

@@ -860,11 +860,9 @@ static int local_graph_impl(snk_ctx* ctx, hipStream_t st, const snk_table* tab, 
     memset(out, 0, sizeof *out);
     const uint64_t n = tab->n;
     *keys_final = tab->keys;
-    constexpr uint32_t NBINS = 65536;
-    G_ALLOC(out->spectrum, unsigned long long, NBINS);
-    SNK_HIP_TRY(hipMemsetAsync(out->spectrum, 0, NBINS * 8, st));
-    out->spectrum_bins = NBINS;
     if (n == 0) {
+        int rc0 = snk_spectrum(ctx, st, nullptr, 0, &out->spectrum, &out->spectrum_bins, err, errcap);
+        if (rc0) return rc0;
         G_ALLOC(out->unitig_off, uint64_t, 2);
         SNK_HIP_TRY(hipMemsetAsync(out->unitig_off, 0, 16, st));
         G_ALLOC(out->unitig_bases, uint8_t, 16);
@@ -928,7 +926,7 @@ static int local_graph_impl(snk_ctx* ctx, hipStream_t st, const snk_table* tab, 
         hipLaunchKernelGGL(bl_unpack_vals_kernel, dim3(nblk(n)), dim3(TB), 0, st, v_out, n, B.counts, B.ctx);
         *keys_final = k_out;
     }
-    if ((int)snk_launch_spectrum(st, B.counts, n, out->spectrum, NBINS)) return snk_fail(SNK_E_HIP, err, errcap, "spectrum launch failed");
+    if ((rc = snk_spectrum(ctx, st, B.counts, n, &out->spectrum, &out->spectrum_bins, err, errcap))) return rc;
     tm.mark();  // 5
     SNK_HIP_TRY(hipGetLastError());
     if (ms) { ms[0] = tm.ms(0, 1); ms[1] = tm.ms(1, 2); ms[2] = tm.ms(2, 3); ms[3] = tm.ms(3, 4); ms[4] = tm.ms(4, 5); }
@@ -993,12 +991,10 @@ int snk_bl_dist_fragments(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, const u
                           snk_frag_out* out, char* err, size_t errcap) {
     memset(out, 0, sizeof *out);
     const uint64_t n = B->tab->n;
-    constexpr uint32_t NBINS = 65536;
-    unsigned long long* bins;
-    G_ALLOC(bins, unsigned long long, NBINS);
-    SNK_HIP_TRY(hipMemsetAsync(bins, 0, NBINS * 8, st));
-    out->spectrum = bins;
-    out->spectrum_bins = NBINS;
+    {
+        int rc0 = snk_spectrum(ctx, st, n ? B->counts : nullptr, n, &out->spectrum, &out->spectrum_bins, err, errcap);
+        if (rc0) return rc0;
+    }
     if (n == 0) {
         G_ALLOC(out->boff, uint64_t, 2);
         SNK_HIP_TRY(hipMemsetAsync(out->boff, 0, 16, st));
@@ -1008,7 +1004,6 @@ int snk_bl_dist_fragments(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, const u
         G_ALLOC(out->hl_nb, unsigned long long, 2);
         return SNK_OK;
     }
-    if ((int)snk_launch_spectrum(st, B->counts, n, bins, NBINS)) return snk_fail(SNK_E_HIP, err, errcap, "spectrum launch failed");
     bl_dist_args da;
     da.premote = B->premote;
     da.rq_idx = B->rq_idx;

@@ -349,3 +349,55 @@ def test_grouped_per_barcode_graphs(engine, graph_stage):
         assert us == o.unitigs, gid
         total += m.sum()
     assert total == k.shape[0]
+
+
+def _repeat_rich_reads(n_reads, seed):
+    """Low-complexity torture at scale: dispersed repeats, poly-A runs, short-period tandem repeats, planted palindromes.
+    Exercises what random sequence never does: supermer lists that overflow, buckets that split, chunks above 256 k-mers,
+    circles inside one bucket."""
+    rng = np.random.default_rng(seed)
+    G = rng.integers(0, 4, 150_000).astype(np.uint8)
+    elem = rng.integers(0, 4, 300).astype(np.uint8)
+    for p0 in rng.integers(0, len(G) - 400, 40):
+        G[p0:p0 + 300] = elem
+    for p0 in rng.integers(0, len(G) - 400, 25):
+        G[p0:p0 + int(rng.integers(60, 220))] = 0                       # poly-A
+    for p0 in rng.integers(0, len(G) - 400, 40):
+        per = int(rng.integers(1, 13))
+        unit = rng.integers(0, 4, per).astype(np.uint8)
+        ln = int(rng.integers(100, 320))
+        G[p0:p0 + ln] = np.resize(unit, ln)                             # tandem repeat
+    for p0 in rng.integers(0, len(G) - 400, 6):
+        h = rng.integers(0, 4, 24).astype(np.uint8)
+        G[p0:p0 + 48] = np.concatenate([h, (3 - h)[::-1]])              # reverse-complement palindrome (a 1-k-mer unitig)
+    L = 150
+    st = rng.integers(0, len(G) - L, n_reads)
+    codes = G[st[:, None] + np.arange(L)[None, :]]
+    flip = rng.random(n_reads) < 0.5
+    codes[flip] = (3 - codes[flip])[:, ::-1]
+    err = rng.random(codes.shape) < 0.003
+    codes = np.where(err, (codes + rng.integers(1, 4, codes.shape)) % 4, codes).astype(np.uint8)
+    quals = np.where(err, 12, 30).astype(np.uint8)
+    tails = rng.random(n_reads) < 0.05
+    tl = rng.integers(1, 50, n_reads)
+    quals[tails[:, None] & (np.arange(L)[None, :] >= (L - tl)[:, None])] = 2
+    bc = rng.integers(0, 40, n_reads).astype(np.int32)
+    return np.ascontiguousarray(codes), quals, bc
+
+
+def test_repeat_rich_vs_oracle(engine):
+    import torch
+    from supernova_amd import synth
+    from supernova_amd.engine import Params
+    codes, quals, bc = _repeat_rich_reads(60_000, 99)
+    dev = torch.device("cuda", 0)
+    rows = torch.from_numpy(synth.pack_rows(codes).view(np.int32)).to(dev)
+    res = engine.count_graph(rows, 150, quals=torch.from_numpy(quals).to(dev), bc=torch.from_numpy(bc).to(dev),
+                             params=Params(K=48, n_buckets=61))          # few buckets: splits and big chunks
+    gl = oracle_lib.good_lens(quals, 150)
+    o = oracle_lib.OracleResult(codes, gl, bc, hbv=False)
+    hist = np.bincount(np.minimum(o.counts, (1 << 24) - 1)).astype(np.int64)
+    _check_against(res, o.keys[:, :3], np.minimum(o.counts, (1 << 24) - 1), o.ctx, o.unitigs, gl, hist)
+    assert res.buckets_split > 0
+    res2 = engine.count_graph(rows, 150, quals=torch.from_numpy(quals).to(dev), bc=torch.from_numpy(bc).to(dev), params=Params(K=48))
+    _check_against(res2, o.keys[:, :3], np.minimum(o.counts, (1 << 24) - 1), o.ctx, o.unitigs, gl, hist)
