@@ -54,12 +54,14 @@ template <int K, bool G> __device__ __forceinline__ uint64_t klo_unpack(typename
 
 template <int K, int THREADS, int SLOTS, bool GROUPED>
 __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
-    constexpr int BATCH = K > 48 ? 192 : 256;            // supermers staged per batch (owner[] holds 8-bit indices); K=60: 192
-                                                         // keeps the workgroup under 80 KB of LDS, i.e. two per CU
-    constexpr int DD = 512;                              // de-duplication table slots (power of two >= 2*BATCH)
+    // supermers staged per batch.  A 4000-instance bucket holds ~270 (sigma ~100): with 512 slots nearly every bucket is
+    // ONE batch (with 256, 55 % of the buckets ran a second, mostly empty batch through all the phases below).  K=60 and
+    // grouped runs have 64-bit low key words: 256 keeps the workgroup under 80 KB of LDS, i.e. two per CU.
+    constexpr int BATCH = (K == 48 && !GROUPED) ? 512 : 256;
+    constexpr int DD = 2 * BATCH;                        // de-duplication table slots
     typedef typename klo_t<K, GROUPED>::type lo_type;
-    constexpr int WMAX = K - SNK_M + 1;                  // k-mers per supermer, at most (sizes owner[])
-    (void)WMAX;
+    constexpr int WMAX = K - SNK_M + 1;                  // k-mers per supermer, at most
+    constexpr int NCI = BATCH * WMAX / 32 + 2;           // coarse instance index: one entry per 32 k-mer instances
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint64_t* khi = reinterpret_cast<uint64_t*>(smem_raw);                         // [SLOTS]
     lo_type* klo = reinterpret_cast<lo_type*>(khi + SLOTS);                         // [SLOTS]
@@ -68,14 +70,15 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
     uint32_t* bcs = cnt + SLOTS;                                                    // [SLOTS] barcode state
     uint32_t* ctxw = bcs + SLOTS;                                                   // [SLOTS/4] context bytes
     uint32_t* rec = ctxw + SLOTS / 4;                                               // [8][BATCH] staged supermer records
-    uint32_t* pre = rec + 8 * BATCH;                                                // [BATCH+1] k-mer prefix sums of the batch
-    uint32_t* ctl = pre + BATCH + 4;                                                // [64] control words
+    uint32_t* ctl = rec + 8 * BATCH;                                                // [64] control words
     uint32_t* dd = ctl + 64;                                                        // [DD] supermer de-duplication table (leader index + 1)
-    uint32_t* wgt = dd + DD;                                                 // [BATCH] copies folded into each leader
-    uint8_t* owner = reinterpret_cast<uint8_t*>(wgt + BATCH);                       // [BATCH*WMAX] k-mer -> supermer of the batch
+    uint32_t* wgt = dd + DD;                                                        // [BATCH] copies folded into each leader
+    uint16_t* lead = reinterpret_cast<uint16_t*>(wgt + BATCH);                      // [BATCH] r-th leading (non-folded) supermer
+    uint16_t* lpre = lead + BATCH;                                                  // [BATCH+2] its first k-mer instance (+ sentinel)
+    uint16_t* cidx = lpre + BATCH + 2;                                              // [NCI] leader rank that owns instance 32*w
     // ctl[0] stack pointer, ctl[1] occupied slots, ctl[2] overflow flag, ctl[3] split log2, ctl[4] split id,
     // ctl[5] valid entries of the sub-pass, ctl[6..7] reserved base (lo,hi), ctl[8] placement counter,
-    // ctl[9..12] wave totals for the batch scan, ctl[16..16+2*MAX) split stack
+    // ctl[16..16+2*MAX) split stack (MAX = 17 levels -> up to ctl[51]), ctl[52..59] wave totals of the batch scan
     static_assert(THREADS >= BATCH && THREADS % 64 == 0, "the first BATCH threads stage the records");
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
@@ -167,17 +170,25 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
                         s = (s + 1) & (DD - 1);
                     }
                 }
-                uint32_t incl = nkm;
+                // one packed scan over the supermers: k-mer instances (low 16 bits) and leaders (high 16 bits)
+                const uint32_t sv = nkm | (nkm ? 0x10000u : 0u);
+                uint32_t incl = sv;
                 for (int o = 1; o < 64; o <<= 1) { uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-                if (lane == 63 && wv < BATCH / 64) ctl[9 + wv] = incl;
+                if (lane == 63 && wv < BATCH / 64) ctl[52 + wv] = incl;
                 __syncthreads();
-                uint32_t woff = 0, total = 0;
-                for (int w = 0; w < BATCH / 64; ++w) { uint32_t t = ctl[9 + w]; if (w < wv) woff += t; total += t; }
-                if (tid < BATCH) {
-                    const uint32_t mypre = woff + incl - nkm;
-                    pre[tid] = mypre;
-                    for (uint32_t j = 0; j < nkm; ++j) owner[mypre + j] = (uint8_t)tid;
+                uint32_t woff = 0, tot = 0;
+                for (int w = 0; w < BATCH / 64; ++w) { uint32_t t = ctl[52 + w]; if (w < wv) woff += t; tot += t; }
+                const uint32_t total = tot & 0xFFFFu, nlead = tot >> 16;
+                if (tid < BATCH && nkm) {
+                    // instance -> supermer map without a byte per instance: leaders in order, their first instance, and
+                    // for every 32nd instance the leader that owns it (a lane then walks 0-3 leaders forward)
+                    const uint32_t ex = woff + incl - sv;
+                    const uint32_t off = ex & 0xFFFFu, r = ex >> 16;
+                    lead[r] = (uint16_t)tid;
+                    lpre[r] = (uint16_t)off;
+                    for (uint32_t w = (off + 31u) >> 5; (w << 5) < off + nkm; ++w) cidx[w] = (uint16_t)r;
                 }
+                if (tid == 0) lpre[nlead] = (uint16_t)total;
                 __syncthreads();
                 // ---- one lane per k-mer instance: a wave inserts 64 different k-mers of consecutive supermers, so
                 //      copies of the same k-mer (identical supermers of other reads) are spread over time, not lanes
@@ -185,8 +196,10 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
                 for (uint32_t g0 = 0; g0 < total && !ovf_seen; g0 += THREADS) {
                     const uint32_t g = g0 + tid;
                     if (g < total) {
-                        const uint32_t i = owner[g];
-                        const uint32_t j = g - pre[i];
+                        uint32_t lr = cidx[g >> 5];
+                        while (lpre[lr + 1] <= g) ++lr;
+                        const uint32_t i = lead[lr];
+                        const uint32_t j = g - lpre[lr];
                         const uint32_t m6 = rec[6 * BATCH + i];
                         const uint32_t n_i = m6 & 0x7Fu, hasL = (m6 >> 7) & 1u, hasR = (m6 >> 8) & 1u;
                         const uint32_t w7 = rec[7 * BATCH + i];
@@ -347,8 +360,8 @@ template <> struct cfg<60> { static constexpr int THREADS = SNK_COUNT_THREADS; s
 
 template <int K, bool G>
 size_t lds_bytes() {
-    constexpr size_t S = cfg<K>::SLOTS, B = K > 48 ? 192 : 256, DD = 512;
-    return S * (8 + sizeof(typename klo_t<K, G>::type) + 4 + 4 + 4) + S + 4 * (8 * B + B + 4 + 64 + DD + B) + B * (K - SNK_M + 1) + 16;
+    constexpr size_t S = cfg<K>::SLOTS, B = (K == 48 && !G) ? 512 : 256, DD = 2 * B, NCI = B * (K - SNK_M + 1) / 32 + 2;
+    return S * (8 + sizeof(typename klo_t<K, G>::type) + 4 + 4 + 4) + S + 4 * (8 * B + 64 + DD + B) + 2 * (B + B + 2 + NCI) + 16;
 }
 
 template <int K, bool G>
