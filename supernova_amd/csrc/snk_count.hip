@@ -88,7 +88,9 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
     if (tid == 0) { ctl[0] = 1; ctl[16] = 0; ctl[17] = 0; }
     uint32_t splits_done = 0;
     // issued before the table is cleared: the bounds of segment 0 and the first batch of records (two dependent HBM
-    // round trips that every workgroup used to wait for after its first barrier)
+    // round trips that every workgroup used to wait for after its first barrier).  Persistent workgroups that prefetch
+    // the NEXT bucket during the current one were tried twice: the prefetch registers (16 live across a whole bucket)
+    // push the kernel from 71 to 92 VGPRs = one workgroup per CU (116 ms), and capped at 80 VGPRs it spills (82 ms).
     const uint64_t beg0 = a.seg_beg[bucket], end0 = a.seg_end[bucket];
     uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = make_uint4(0, 0, 0, 0);
     if (tid < BATCH && beg0 + tid < end0) { pf0 = a.records[(beg0 + tid) * 2]; pf1 = a.records[(beg0 + tid) * 2 + 1]; }

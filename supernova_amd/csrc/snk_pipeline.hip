@@ -90,7 +90,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
         // instances per bucket: sized so that the DISTINCT k-mers of a bucket fit the LDS table (1216 claims).  At 56x
         // coverage 4000 instances hold ~500 distinct k-mers; per-barcode groups see every locus once or twice, so
         // nearly every instance is distinct there
-        uint32_t target = env_u32("SNK_TARGET_INST", grouped ? 900u : (K == 48 ? 4000u : 3500u));
+        uint32_t target = env_u32("SNK_TARGET_INST", grouped ? 900u : (K == 48 ? 5000u : 3500u));
         uint64_t nb = (h_ninst + target - 1) / target;
         const uint64_t nb_max = grouped ? (1ull << 24) : (1ull << 22);
         if (nb < 1) nb = 1;
