@@ -67,7 +67,28 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    _build_host(verbose)
     return LIB
+
+
+BIN = HERE / "bin"
+
+
+def _build_host(verbose: bool) -> None:
+    """C++ host programs above the C ABI (plain g++): here the process owns the HIP runtime, so they link /opt/rocm's."""
+    BIN.mkdir(exist_ok=True)
+    rocm_lib = Path(os.environ.get("ROCM_PATH", "/opt/rocm")) / "lib"
+    for src in sorted((CSRC / "host").glob("*.cc")):
+        exe = BIN / src.stem
+        if exe.exists() and exe.stat().st_mtime >= max(src.stat().st_mtime, LIB.stat().st_mtime):
+            continue
+        cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", str(src), "-o", str(exe), f"-L{HERE}", "-lsnk",
+               f"-L{rocm_lib}", "-lamdhip64", f"-Wl,-rpath,{HERE}", f"-Wl,-rpath,{rocm_lib}", "-Wl,-rpath,$ORIGIN/.."]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"host program {src.name} failed to build:\n{r.stdout}\n{r.stderr}")
 
 
 if __name__ == "__main__":
