@@ -401,3 +401,29 @@ def test_repeat_rich_vs_oracle(engine):
     assert res.buckets_split > 0
     res2 = engine.count_graph(rows, 150, quals=torch.from_numpy(quals).to(dev), bc=torch.from_numpy(bc).to(dev), params=Params(K=48))
     _check_against(res2, o.keys[:, :3], np.minimum(o.counts, (1 << 24) - 1), o.ctx, o.unitigs, gl, hist)
+
+
+def test_vs_reference_binary_200k(engine, graph_stage, tmp_path):
+    """The reference ITSELF (oracle/_ref/snref_driver, built from /root/reference by oracle/ref/build_ref.sh and carried to
+    the GPU box) against the HIP path on a fresh seeded 200 k-read workload of the bench's model -- no committed fixture in
+    between: good lengths, retained table, contexts, spectrum, unitigs, bit for bit."""
+    import os
+    import torch
+    import refio
+    from supernova_amd import synth
+    if graph_stage == "global":
+        pytest.skip("one stage is enough for this one")
+    if not refio.REF_DRIVER.exists():
+        pytest.skip("oracle/_ref/snref_driver not built (needs /root/reference in the build container)")
+    n = 200_000
+    sp = synth.synth_params(n, seed=0x5EED0777)
+    rows, quals, bc = synth.synth_host(sp)
+    asc = synth.codes_to_ascii(synth.unpack_rows(rows, 150))
+    refio.write_snkrd(tmp_path / "in.snkrd", np.full(n, 150), asc, quals, bc)
+    refio.run_ref(tmp_path / "in.snkrd", tmp_path / "out", threads=min(32, os.cpu_count() or 8))
+    d = refio.read_ref_dump(tmp_path / "out")
+    dev = torch.device("cuda", 0)
+    res = engine.count_graph(torch.from_numpy(rows.view(np.int32)).to(dev), 150, quals=torch.from_numpy(quals).to(dev),
+                             bc=torch.from_numpy(bc).to(dev))
+    hist = np.asarray(d["hist"]["vals"], dtype=np.int64)
+    _check_against(res, d["kmers"]["k"], d["kmers"]["count"], d["kmers"]["ctx"], d["unitigs"], d["goodlens"], hist)
