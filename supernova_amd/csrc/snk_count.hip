@@ -32,6 +32,11 @@ constexpr int MAX_SPLIT_LOG2 = 16;
 #define SNK_COUNT_SLOTS 2048
 #endif
 #define LDS_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#ifdef SNK_COUNT_PROF
+#define PROF(n) do { if (tid == 0) { const long long _t = clock64(); atomicAdd(&a.prof[n], (unsigned long long)(_t - prof_t)); prof_t = _t; } } while (0)
+#else
+#define PROF(n) do {} while (0)
+#endif
 
 template <int K> struct lo_t { typedef uint32_t type; };       // K<=48: only the top 32 bits of lo are used
 template <> struct lo_t<60> { typedef uint64_t type; };
@@ -57,7 +62,7 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
     // supermers staged per batch.  A 4000-instance bucket holds ~270 (sigma ~100): with 512 slots nearly every bucket is
     // ONE batch (with 256, 55 % of the buckets ran a second, mostly empty batch through all the phases below).  K=60 and
     // grouped runs have 64-bit low key words: 256 keeps the workgroup under 80 KB of LDS, i.e. two per CU.
-    constexpr int BATCH = (K == 48 && !GROUPED) ? 512 : 256;
+    constexpr int BATCH = (K == 48 && !GROUPED && SLOTS >= 2048) ? 512 : 256;
     constexpr int DD = 2 * BATCH;                        // de-duplication table slots
     typedef typename klo_t<K, GROUPED>::type lo_type;
     constexpr int WMAX = K - SNK_M + 1;                  // k-mers per supermer, at most
@@ -87,6 +92,9 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
 
     if (tid == 0) { ctl[0] = 1; ctl[16] = 0; ctl[17] = 0; }
     uint32_t splits_done = 0;
+#ifdef SNK_COUNT_PROF
+    long long prof_t = clock64();
+#endif
     // issued before the table is cleared: the bounds of segment 0 and the first batch of records (two dependent HBM
     // round trips that every workgroup used to wait for after its first barrier).  Persistent workgroups that prefetch
     // the NEXT bucket during the current one were tried twice: the prefetch registers (16 live across a whole bucket)
@@ -94,11 +102,13 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
     const uint64_t beg0 = a.seg_beg[bucket], end0 = a.seg_end[bucket];
     uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = make_uint4(0, 0, 0, 0);
     if (tid < BATCH && beg0 + tid < end0) { pf0 = a.records[(beg0 + tid) * 2]; pf1 = a.records[(beg0 + tid) * 2 + 1]; }
+    // (computing the first record's address as bucket * cap, so that the loads need no bounds, changed nothing: 73 ms)
     bool first_batch = true;
     for (;;) {
         __syncthreads();
         if (LDS_LOAD(&ctl[0]) == 0) break;
         __syncthreads();
+        PROF(0);
         if (tid == 0) {
             uint32_t sp = ctl[0] - 1;
             ctl[0] = sp;
@@ -110,6 +120,7 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
         for (int s = tid; s < SLOTS; s += THREADS) tag[s] = 0;      // cnt/bcs of a slot are initialised by the lane that claims it
         for (int s = tid; s < SLOTS / 4; s += THREADS) ctxw[s] = 0;
         __syncthreads();
+        PROF(1);
         const uint32_t split_lg = LDS_LOAD(&ctl[3]), split_id = LDS_LOAD(&ctl[4]);
         const uint32_t split_mask = (1u << split_lg) - 1u;
 
@@ -135,6 +146,7 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
                 }
                 for (int q = tid; q < DD; q += THREADS) dd[q] = 0;
                 __syncthreads();
+                PROF(2);
                 // ---- fold identical supermers: at 56x coverage ~3 of 4 reads over a locus yield the SAME record (same
                 //      bases, same flanks); only their barcodes differ.  The first one becomes the leader and carries a
                 //      weight and a merged barcode state, the copies insert nothing (2.5x fewer k-mer insertions).
@@ -178,6 +190,7 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
                 for (int o = 1; o < 64; o <<= 1) { uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
                 if (lane == 63 && wv < BATCH / 64) ctl[52 + wv] = incl;
                 __syncthreads();
+                PROF(3);
                 uint32_t woff = 0, tot = 0;
                 for (int w = 0; w < BATCH / 64; ++w) { uint32_t t = ctl[52 + w]; if (w < wv) woff += t; tot += t; }
                 const uint32_t total = tot & 0xFFFFu, nlead = tot >> 16;
@@ -192,6 +205,7 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
                 }
                 if (tid == 0) lpre[nlead] = (uint16_t)total;
                 __syncthreads();
+                PROF(4);
                 // ---- one lane per k-mer instance: a wave inserts 64 different k-mers of consecutive supermers, so
                 //      copies of the same k-mer (identical supermers of other reads) are spread over time, not lanes
                 const bool ovf_seen = LDS_LOAD(&ctl[2]) != 0;
@@ -282,6 +296,7 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
                     }
                 }
                 __syncthreads();   // rec/pre/owner are rewritten by the next batch
+                PROF(5);
             }
         }
         __syncthreads();
@@ -304,6 +319,7 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
         // atomic: count the survivors in LDS, reserve, then place.
         if (tid == 0) { ctl[5] = 0; ctl[8] = 0; }
         __syncthreads();
+        PROF(6);
         uint32_t myvalid = 0;
         for (int s = tid; s < SLOTS; s += THREADS) {      // SLOTS need not be a multiple of THREADS
             const uint32_t c = tag[s] ? cnt[s] : 0u;       // unclaimed slots hold stale counts
@@ -352,6 +368,7 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
             }
         }
         if (tid == 0) atomicMax(&a.status[3], LDS_LOAD(&ctl[1]));
+        PROF(7);
     }
     if (tid == 0 && splits_done) atomicAdd(&a.status[2], 1u);
 }
@@ -362,7 +379,7 @@ template <> struct cfg<60> { static constexpr int THREADS = SNK_COUNT_THREADS; s
 
 template <int K, bool G>
 size_t lds_bytes() {
-    constexpr size_t S = cfg<K>::SLOTS, B = (K == 48 && !G) ? 512 : 256, DD = 2 * B, NCI = B * (K - SNK_M + 1) / 32 + 2;
+    constexpr size_t S = cfg<K>::SLOTS, B = (K == 48 && !G && S >= 2048) ? 512 : 256, DD = 2 * B, NCI = B * (K - SNK_M + 1) / 32 + 2;
     return S * (8 + sizeof(typename klo_t<K, G>::type) + 4 + 4 + 4) + S + 4 * (8 * B + 64 + DD + B) + 2 * (B + B + 2 + NCI) + 16;
 }
 

@@ -56,6 +56,7 @@ struct snk_count_args {
     uint32_t* chunk_base;          // [NB] their offset inside region (bucket % n_regions)
     uint4* extra;                  // sub-passes of split buckets: (bucket, offset, n, split_lg << 24 | split_id); count in status[4]
     uint32_t extra_cap;
+    unsigned long long* prof;      // SNK_COUNT_PROF builds: [8] clock cycles of thread 0 per phase, summed over workgroups
     uint32_t dbg;                  // profiling aid: 1 = roll+hash only, 2 = no updates after the probe (results invalid)
     uint32_t* status;              // [0] output overflow, [1] split depth exceeded, [2] buckets split, [3] max slots used, [4] extra chunks
 };

@@ -86,6 +86,15 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
         ca.extra = extra;
         ca.extra_cap = extra_cap;
         ca.dbg = env_u32("SNK_COUNT_DBG", 0);
+        ca.prof = nullptr;
+#ifdef SNK_COUNT_PROF
+        {
+            void* pq;
+            if ((rc = snk_ctx_alloc(ctx, 64, &pq, err, errcap))) return rc;
+            ca.prof = (unsigned long long*)pq;
+            SNK_HIP_TRY(hipMemsetAsync(ca.prof, 0, 64, st));
+        }
+#endif
         kt.n = 0;
         kt.mark();
         if ((rc = snk_launch_count(K, st, ca, err, errcap))) return rc;
@@ -93,6 +102,16 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
         SNK_HIP_TRY(hipMemcpyAsync(h_rcur.data(), rcur, n_regions * 8ull, hipMemcpyDeviceToHost, st));
         SNK_HIP_TRY(hipMemcpyAsync(h_status, status, 32, hipMemcpyDeviceToHost, st));
         SNK_HIP_TRY(hipStreamSynchronize(st));
+#ifdef SNK_COUNT_PROF
+        {
+            unsigned long long hp[8];
+            (void)hipMemcpy(hp, ca.prof, 64, hipMemcpyDeviceToHost);
+            unsigned long long tot = 0;
+            for (int q = 0; q < 8; ++q) tot += hp[q];
+            fprintf(stderr, "[snk prof] count kernel, cycles of thread 0 per phase (%% of total): control %.1f, clear %.1f, stage %.1f, dedupe+scan %.1f, map %.1f, insert %.1f, emit-count %.1f, emit-write %.1f\n",
+                    100.0 * hp[0] / tot, 100.0 * hp[1] / tot, 100.0 * hp[2] / tot, 100.0 * hp[3] / tot, 100.0 * hp[4] / tot, 100.0 * hp[5] / tot, 100.0 * hp[6] / tot, 100.0 * hp[7] / tot);
+        }
+#endif
         if (ca.dbg >= 2) {
             unsigned long long d[3];
             (void)hipMemcpy(d, status + 4, 24, hipMemcpyDeviceToHost);
