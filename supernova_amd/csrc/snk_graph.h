@@ -47,6 +47,7 @@ struct snk_frag_out {
     unsigned long long* spectrum;
     uint32_t spectrum_bins, n_circles, rank_rounds;
     uint32_t* fgroup;          // grouped runs: group of every fragment, else NULL
+    uint32_t* sfrag;           // one-GPU runs: [2n] terminal state -> 2*fragment + end, else NULL
 };
 struct snk_join_out {
     uint64_t n_unitigs, total_bases;
@@ -62,7 +63,8 @@ int snk_dist_apply(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, const void* 
                    const unsigned long long* d_qoff, char* err, size_t errcap);
 int snk_dist_join(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const uint32_t* nk, const unsigned long long* hl_self,
                   const unsigned long long* hl_nb, const uint64_t* boff, const uint8_t* fbases, uint64_t total_fbases,
-                  snk_join_out* out, char* err, size_t errcap, const uint32_t* fgroup = nullptr);
+                  snk_join_out* out, char* err, size_t errcap, const uint32_t* fgroup = nullptr, const uint32_t* sfrag = nullptr,
+                  uint64_t n_states = 0);
 
 // ---- bucket-local graph stage (snk_local.hip): table in chunk order -> pruned contexts + canonical unitigs
 struct snk_table;

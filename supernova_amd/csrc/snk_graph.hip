@@ -784,6 +784,24 @@ __global__ void __launch_bounds__(TB) jmatch_kernel(const unsigned long long* __
     flink[e] = out;
 }
 
+// one-GPU runs: every fragment end registered itself under its terminal state (sfrag[state] = 2*fragment + end), so the
+// partner of a half link is one load away -- no hash table over the 2F ends.  Entries of non-terminal states are never
+// written; a half link only ever names a terminal state, and the back-check below rejects anything else.
+__global__ void __launch_bounds__(TB) jmatch_direct_kernel(const unsigned long long* __restrict__ hl_self,
+                                                           const unsigned long long* __restrict__ hl_nb, uint64_t ne,
+                                                           const uint32_t* __restrict__ sfrag, uint64_t n_states,
+                                                           uint32_t* __restrict__ flink) {
+    uint64_t e = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (e >= ne) return;
+    const unsigned long long nb = hl_nb[e];
+    uint32_t out = NONE;
+    if (nb != NONE64 && nb < n_states) {
+        const uint32_t e2 = sfrag[nb];
+        if (e2 < ne && hl_self[e2] == nb && hl_nb[e2] == hl_self[e]) out = e2;
+    }
+    flink[e] = out;
+}
+
 struct frag_place { uint32_t pid, other; uint64_t N; uint64_t koff; bool rc; };
 __device__ __forceinline__ frag_place frag_place_of(const uint2* rk, const uint32_t* nk, uint64_t f) {
     const uint2 a = rk[2 * f], b = rk[2 * f + 1];
@@ -1031,7 +1049,7 @@ int snk_dist_apply(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, const void* 
 // rank 0: fragments of every rank -> canonical unitigs
 int snk_dist_join(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const uint32_t* nk, const unsigned long long* hl_self,
                   const unsigned long long* hl_nb, const uint64_t* boff, const uint8_t* fbases, uint64_t total_fbases,
-                  snk_join_out* out, char* err, size_t errcap, const uint32_t* fgroup) {
+                  snk_join_out* out, char* err, size_t errcap, const uint32_t* fgroup, const uint32_t* sfrag, uint64_t n_states) {
     memset(out, 0, sizeof *out);
     if (F == 0) {
         G_ALLOC(out->unitig_off, uint64_t, 1);
@@ -1040,16 +1058,21 @@ int snk_dist_join(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
     }
     if (F >= (1ull << 31)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "more than 2^31 fragments at the join (%llu)", (unsigned long long)F);
     const uint64_t ne = 2 * F;
-    uint64_t tg = 1024;
-    while (tg < 2 * ne) tg <<= 1;
-    unsigned long long* hk;
-    uint32_t *hv, *flink;
-    G_ALLOC(hk, unsigned long long, tg);
-    G_ALLOC(hv, uint32_t, tg);
+    uint32_t* flink;
     G_ALLOC(flink, uint32_t, ne);
-    SNK_HIP_TRY(hipMemsetAsync(hk, 0, tg * 8, st));
-    hipLaunchKernelGGL(jhash_build_kernel, dim3(nblk(ne)), dim3(TB), 0, st, hl_self, ne, hk, hv, tg - 1);
-    hipLaunchKernelGGL(jmatch_kernel, dim3(nblk(ne)), dim3(TB), 0, st, hl_self, hl_nb, ne, hk, hv, tg - 1, flink);
+    if (sfrag) {
+        hipLaunchKernelGGL(jmatch_direct_kernel, dim3(nblk(ne)), dim3(TB), 0, st, hl_self, hl_nb, ne, sfrag, n_states, flink);
+    } else {
+        uint64_t tg = 1024;
+        while (tg < 2 * ne) tg <<= 1;
+        unsigned long long* hk;
+        uint32_t* hv;
+        G_ALLOC(hk, unsigned long long, tg);
+        G_ALLOC(hv, uint32_t, tg);
+        SNK_HIP_TRY(hipMemsetAsync(hk, 0, tg * 8, st));
+        hipLaunchKernelGGL(jhash_build_kernel, dim3(nblk(ne)), dim3(TB), 0, st, hl_self, ne, hk, hv, tg - 1);
+        hipLaunchKernelGGL(jmatch_kernel, dim3(nblk(ne)), dim3(TB), 0, st, hl_self, hl_nb, ne, hk, hv, tg - 1, flink);
+    }
     SNK_HIP_TRY(hipGetLastError());
     uint8_t* circ;     // per fragment-end state: terminal created by cutting a circle
     G_ALLOC(circ, uint8_t, ne + 1);

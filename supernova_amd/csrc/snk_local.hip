@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
                                                     const uint32_t* __restrict__ foff, const uint64_t* __restrict__ boff,
                                                     uint32_t* __restrict__ nk, unsigned long long* __restrict__ hl_self,
                                                     unsigned long long* __restrict__ hl_nb, uint64_t* __restrict__ bstart,
-                                                    uint8_t* __restrict__ fbases, uint32_t* __restrict__ fgroup) {
+                                                    uint8_t* __restrict__ fbases, uint32_t* __restrict__ fgroup, uint32_t* __restrict__ sfrag) {
     constexpr int SPT = (2 * CAP + T - 1) / T;        // states per thread
     __shared__ uint64_t khi[CAP], klo[CAP];
     __shared__ uint16_t nbL[2 * CAP];                  // local neighbour << 1 | rev (chunk-local indices fit 16 bits)
@@ -513,6 +513,7 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
         hl_nb[2 * f] = with_half ? half_link(pid) : NONE64;
         hl_nb[2 * f + 1] = with_half ? half_link(other) : NONE64;
         bstart[f] = c_boff + rel;
+        if (!DIST && sfrag) { sfrag[2 * ch.base + pid] = (uint32_t)(2 * f); sfrag[2 * ch.base + other] = (uint32_t)(2 * f + 1); }
         if (GR) fgroup[f] = (uint32_t)klo[head_node];
         foffL[pid] = (uint16_t)rel;
         hnode[lf] = (uint16_t)((head_node << 1) | (head_rc ? 1u : 0u));
@@ -817,12 +818,12 @@ static int bl_fragments_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, cons
     hipLaunchKernelGGL((bl_frag_kernel<K, SCAP, ST, false, false, DIST, GR>), dim3(nchunks), dim3(ST), 0, st, (const uint4*)B->desc,
                        (const uint32_t*)nullptr, tab->keys, B->ctx, B->pend, B->nbr, B->rq, da, nfrag, (const uint32_t*)nullptr,
                        (const uint64_t*)nullptr, (uint32_t*)nullptr, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                       (uint64_t*)nullptr, (uint8_t*)nullptr, (uint32_t*)nullptr);
+                       (uint64_t*)nullptr, (uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
     if (h_nbig)
         hipLaunchKernelGGL((bl_frag_kernel<K, BCAP, BT, true, false, DIST, GR>), dim3(h_nbig), dim3(BT), 0, st, (const uint4*)B->desc,
                            (const uint32_t*)B->biglist, tab->keys, B->ctx, B->pend, B->nbr, B->rq, da, nfrag, (const uint32_t*)nullptr,
                            (const uint64_t*)nullptr, (uint32_t*)nullptr, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                           (uint64_t*)nullptr, (uint8_t*)nullptr, (uint32_t*)nullptr);
+                           (uint64_t*)nullptr, (uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
     hipLaunchKernelGGL(bl_chunk_bases_kernel, dim3(nblk((uint64_t)nchunks + 1)), dim3(TB), 0, st, (const uint4*)B->desc, nfrag, nchunks,
                        (uint32_t)K, nbases);
     SNK_HIP_TRY(hipGetLastError());
@@ -841,13 +842,15 @@ static int bl_fragments_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, cons
     G_ALLOC(out->bases, uint8_t, h_B + 16);
     out->fgroup = nullptr;
     if (GR) G_ALLOC(out->fgroup, uint32_t, (uint64_t)h_F + 1);
+    out->sfrag = nullptr;
+    if (!DIST) G_ALLOC(out->sfrag, uint32_t, 2 * tab->n + 2);
     hipLaunchKernelGGL((bl_frag_kernel<K, SCAP, ST, false, true, DIST, GR>), dim3(nchunks), dim3(ST), 0, st, (const uint4*)B->desc,
                        (const uint32_t*)nullptr, tab->keys, B->ctx, B->pend, B->nbr, B->rq, da, nfrag, foff, boff, out->nk, out->hl_self,
-                       out->hl_nb, out->boff, out->bases, out->fgroup);
+                       out->hl_nb, out->boff, out->bases, out->fgroup, out->sfrag);
     if (h_nbig)
         hipLaunchKernelGGL((bl_frag_kernel<K, BCAP, BT, true, true, DIST, GR>), dim3(h_nbig), dim3(BT), 0, st, (const uint4*)B->desc,
                            (const uint32_t*)B->biglist, tab->keys, B->ctx, B->pend, B->nbr, B->rq, da, nfrag, foff, boff, out->nk,
-                           out->hl_self, out->hl_nb, out->boff, out->bases, out->fgroup);
+                           out->hl_self, out->hl_nb, out->boff, out->bases, out->fgroup, out->sfrag);
     SNK_HIP_TRY(hipGetLastError());
     out->n_frags = h_F;
     out->total_bases = h_B;
@@ -894,7 +897,7 @@ static int local_graph_impl(snk_ctx* ctx, hipStream_t st, const snk_table* tab, 
         if ((rc = bl_fragments_impl<K, false, GR>(ctx, st, &B, da, &fo, err, errcap))) return rc;
         tm.mark();  // 3
         snk_join_out jo;
-        rc = snk_dist_join(ctx, st, K, fo.n_frags, fo.nk, fo.hl_self, fo.hl_nb, fo.boff, fo.bases, fo.total_bases, &jo, err, errcap, fo.fgroup);
+        rc = snk_dist_join(ctx, st, K, fo.n_frags, fo.nk, fo.hl_self, fo.hl_nb, fo.boff, fo.bases, fo.total_bases, &jo, err, errcap, fo.fgroup, fo.sfrag, 2 * n);
         if (rc) return rc;
         tm.mark();  // 4
         out->n_unitigs = jo.n_unitigs;
