@@ -48,6 +48,7 @@ struct snk_frag_out {
     uint32_t spectrum_bins, n_circles, rank_rounds;
     uint32_t* fgroup;          // grouped runs: group of every fragment, else NULL
     uint32_t* sfrag;           // one-GPU runs: [2n] terminal state -> 2*fragment + end, else NULL
+    uint32_t n_local_circles;  // smooth circles inside one chunk (their fragments sit behind the paths')
 };
 struct snk_join_out {
     uint64_t n_unitigs, total_bases;

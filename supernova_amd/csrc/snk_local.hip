@@ -23,6 +23,8 @@
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 
+#include <type_traits>
+
 #include "snk_ctx.h"
 #include "snk_common.h"
 #include "snk_kernels.h"
@@ -367,6 +369,14 @@ __global__ void __launch_bounds__(TB) bl_resolve_kernel(const snk_u128* __restri
 // node knows its fragment (= smaller terminal state), its position and its orientation, and writes its own base;
 // the K-base head k-mers are written by K lanes each.  COUNT pass: fragments per chunk (exact output sizing);
 // EMIT pass: the same ranking, then the writes.
+// Smooth circles that lie inside one chunk (tiny tandem repeats) are rare: the sizing pass counts only the open paths
+// of a chunk (terminal states / 2, no ranking needed) and the circles take their fragment slots from a small pool behind
+// the paths' slots.  cur keeps counting past the capacity; the host re-runs the emit pass with a larger pool then.
+struct bl_extra_pool {
+    unsigned long long* cur;       // [0] fragments, [1] bases
+    uint64_t f0, b0;               // first pool fragment / base
+    uint64_t fcap, bcap;
+};
 struct bl_dist_args {          // sharded runs: remote neighbours and the global node numbering
     const uint8_t* premote;
     const uint32_t* rq_idx;
@@ -382,11 +392,16 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
                                                     const uint32_t* __restrict__ foff, const uint64_t* __restrict__ boff,
                                                     uint32_t* __restrict__ nk, unsigned long long* __restrict__ hl_self,
                                                     unsigned long long* __restrict__ hl_nb, uint64_t* __restrict__ bstart,
-                                                    uint8_t* __restrict__ fbases, uint32_t* __restrict__ fgroup, uint32_t* __restrict__ sfrag) {
+                                                    uint8_t* __restrict__ fbases, uint32_t* __restrict__ fgroup, uint32_t* __restrict__ sfrag, bl_extra_pool xp) {
     constexpr int SPT = (2 * CAP + T - 1) / T;        // states per thread
     __shared__ uint64_t khi[CAP], klo[CAP];
     __shared__ uint16_t nbL[2 * CAP];                  // local neighbour << 1 | rev (chunk-local indices fit 16 bits)
-    __shared__ uint16_t lnk[2 * CAP], nxt[2 * CAP], dst[2 * CAP], tl[2 * CAP];
+    // ranking record of an exit state: next state | hops << FB | terminal << 2 FB (one LDS word per state)
+    typedef typename std::conditional<(CAP <= 256), uint32_t, uint64_t>::type wrec_t;
+    constexpr int FB = CAP <= 256 ? 10 : 16;
+    constexpr uint32_t FM = (1u << FB) - 1u;           // field mask == "no next state"
+    __shared__ uint16_t lnk[2 * CAP];
+    __shared__ wrec_t wr[2 * CAP];
     __shared__ uint16_t foffL[2 * CAP];               // per pid terminal: offset of the fragment's bases inside the chunk's output
     __shared__ uint16_t hnode[CAP];                    // heads: node << 1 | rc
     __shared__ uint8_t ctxL[CAP], pendL[CAP], palL[CAP];
@@ -416,6 +431,7 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
     }
     __syncthreads();
     // reciprocal-unique links inside the chunk (BuildReadQGraph48.cc:408-428): state = node << 1 | exit side
+    uint32_t myterm = 0;
     for (uint32_t s = tid; s < 2 * n; s += T) {
         const uint32_t i = s >> 1, side = s & 1u;
         const uint32_t cc = ctxL[i];
@@ -435,29 +451,37 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
             }
         }
         lnk[s] = out;
-        if (out == NONE16) { nxt[s] = NONE16; dst[s] = 0; tl[s] = (uint16_t)s; }
-        else { nxt[s] = out ^ 1u; dst[s] = 1; tl[s] = out ^ 1u; }
+        if (!EMIT) { if (out == NONE16) ++myterm; }
+        else if (out == NONE16) wr[s] = (wrec_t)FM | ((wrec_t)s << (2 * FB));
+        else wr[s] = (wrec_t)(out ^ 1u) | ((wrec_t)1 << FB) | ((wrec_t)(out ^ 1u) << (2 * FB));
+    }
+    if (!EMIT) {      // sizing pass: a chunk has (terminal states / 2) open paths
+        if (myterm) atomicAdd(&fcnt, myterm);
+        __syncthreads();
+        if (tid == 0) nfrag[c] = fcnt >> 1;
+        return;
     }
     __syncthreads();
     // pointer jumping: nxt/dst/tl[s] = state reached / hops / terminal when leaving through exit state s
     int max_rounds = 2;
     while ((1u << (max_rounds - 1)) < 2 * n) ++max_rounds;
     for (int round = 0; round < max_rounds; ++round) {
-        uint16_t rn[SPT], rd[SPT], rt[SPT];
+        wrec_t rr[SPT];
         bool any = false;
 #pragma unroll
         for (int q = 0; q < SPT; ++q) {
             if ((uint32_t)(q * T) >= 2 * n) break;       // uniform: a typical chunk fills 4 of the 8 slots
             const uint32_t s = tid + q * T;
-            rn[q] = NONE16;
             if (s < 2 * n) {
-                const uint16_t n1 = nxt[s];
-                if (n1 != NONE16) {
-                    rn[q] = nxt[n1];
-                    rd[q] = (uint16_t)(dst[s] + dst[n1]);
-                    rt[q] = tl[n1];
+                const wrec_t a0 = wr[s];
+                const uint32_t n1 = (uint32_t)a0 & FM;
+                rr[q] = a0;
+                if (n1 != FM) {
+                    const wrec_t a1 = wr[n1];
+                    const uint32_t d = (((uint32_t)(a0 >> FB) & FM) + ((uint32_t)(a1 >> FB) & FM)) & FM;   // hops (garbage on circles)
+                    rr[q] = (a1 & (wrec_t)FM) | ((wrec_t)d << FB) | (a1 & ((wrec_t)FM << (2 * FB)));
                     any = true;
-                } else { rd[q] = dst[s]; rt[q] = tl[s]; }
+                }
             }
         }
         __syncthreads();
@@ -465,7 +489,7 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
         for (int q = 0; q < SPT; ++q) {
             if ((uint32_t)(q * T) >= 2 * n) break;
             const uint32_t s = tid + q * T;
-            if (s < 2 * n) { nxt[s] = rn[q]; dst[s] = rd[q]; tl[s] = rt[q]; }
+            if (s < 2 * n) wr[s] = rr[q];
         }
         if (any) changed = 1;
         __syncthreads();
@@ -475,6 +499,9 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
         if (!go) break;
     }
     __syncthreads();
+    auto w_next = [&](uint32_t st) -> uint32_t { return (uint32_t)wr[st] & FM; };
+    auto w_dist = [&](uint32_t st) -> uint32_t { return (uint32_t)(wr[st] >> FB) & FM; };
+    auto w_tail = [&](uint32_t st) -> uint32_t { return (uint32_t)(wr[st] >> (2 * FB)) & FM; };
 
     // half link of a fragment end: the single remote neighbour of that side (decided half on each owner)
     auto half_link = [&](uint32_t s) -> unsigned long long {
@@ -520,22 +547,18 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
         return rel;
     };
 
-    uint32_t myfrags = 0;
     // nodes on open paths: position and orientation from the two ranks (walking from the smaller terminal)
     for (uint32_t i = tid; i < n; i += T) {
-        if (nxt[2 * i] != NONE16) continue;               // on a circle
-        const uint32_t tR = tl[2 * i], tL = tl[2 * i + 1], dR = dst[2 * i], dL = dst[2 * i + 1];
+        if (w_next(2 * i) != FM) continue;                // on a circle
+        const uint32_t tR = w_tail(2 * i), tL = w_tail(2 * i + 1), dR = w_dist(2 * i), dL = w_dist(2 * i + 1);
         const bool fwd = tL < tR;
         const uint32_t pos = fwd ? dL : dR;
-        if (pos == 0) {
-            ++myfrags;
-            if (EMIT) describe(fwd ? tL : tR, fwd ? tR : tL, dR + dL + 1u, true, i, !fwd);
-        }
+        if (pos == 0) describe(fwd ? tL : tR, fwd ? tR : tL, dR + dL + 1u, true, i, !fwd);
     }
     // nodes no terminal is reachable from lie on smooth circles inside the chunk: cut at the left side of the minimum
     // k-mer (canonicalizeCircle, BuildReadQGraph48.cc:375-397); the circle's minimum node describes and writes it
     for (uint32_t i = tid; i < n; i += T) {
-        if (nxt[2 * i] == NONE16) continue;
+        if (w_next(2 * i) == FM) continue;
         uint32_t cur = i << 1, mn = i, cnt = 1;
         bool closed = false;
         while (cnt <= n) {
@@ -548,34 +571,42 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
             ++cnt;
         }
         if (closed && mn == i) {
-            ++myfrags;
-            if (EMIT) {
+            // a circle inside the chunk: its slot comes from the pool behind the paths' slots
+            const unsigned long long xf = atomicAdd(&xp.cur[0], 1ull);
+            const unsigned long long xb = atomicAdd(&xp.cur[1], (unsigned long long)(cnt + K - 1));
+            if (xf < xp.fcap && xb + cnt + K - 1 <= xp.bcap) {
                 uint32_t e = i << 1;                       // exit state of the last node: cnt-1 links from (i, side 0)
                 for (uint32_t q = 1; q < cnt; ++q) e = lnk[e] ^ 1u;
-                const uint32_t rel = describe((i << 1) | 1u, e, cnt, false, i, false);
+                const uint64_t f = xp.f0 + xf, bo = xp.b0 + xb;
+                const uint32_t pid = (i << 1) | 1u;
+                nk[f] = cnt;
+                hl_self[2 * f] = 2ull * ((DIST ? da.my_node_off : 0ull) + ch.base) + pid;
+                hl_self[2 * f + 1] = 2ull * ((DIST ? da.my_node_off : 0ull) + ch.base) + e;
+                hl_nb[2 * f] = NONE64;
+                hl_nb[2 * f + 1] = NONE64;
+                bstart[f] = bo;
+                if (!DIST && sfrag) { sfrag[2 * ch.base + pid] = (uint32_t)(2 * f); sfrag[2 * ch.base + e] = (uint32_t)(2 * f + 1); }
+                if (GR) fgroup[f] = (uint32_t)klo[i];
+                snk_kmer k;
+                k.hi = khi[i];
+                k.lo = klo[i];
+                for (int b = 0; b < K; ++b) fbases[bo + b] = (uint8_t)oriented_base<K>(k, false, b);
                 uint32_t curs = i << 1;
                 for (uint32_t pos = 1; pos < cnt; ++pos) {
                     const uint32_t l = lnk[curs];
-                    snk_kmer k;
                     k.hi = khi[l >> 1];
                     k.lo = klo[l >> 1];
-                    fbases[c_boff + rel + (K - 1) + pos] = (uint8_t)oriented_base<K>(k, (l & 1u) == 0, K - 1);
+                    fbases[bo + (K - 1) + pos] = (uint8_t)oriented_base<K>(k, (l & 1u) == 0, K - 1);
                     curs = l ^ 1u;
                 }
             }
         }
     }
-    if (!EMIT) {
-        if (myfrags) atomicAdd(&fcnt, myfrags);
-        __syncthreads();
-        if (tid == 0) nfrag[c] = fcnt;
-        return;
-    }
     __syncthreads();
     // every path node writes its last base at its position
     for (uint32_t i = tid; i < n; i += T) {
-        if (nxt[2 * i] != NONE16) continue;
-        const uint32_t tR = tl[2 * i], tL = tl[2 * i + 1], dR = dst[2 * i], dL = dst[2 * i + 1];
+        if (w_next(2 * i) != FM) continue;
+        const uint32_t tR = w_tail(2 * i), tL = w_tail(2 * i + 1), dR = w_dist(2 * i), dL = w_dist(2 * i + 1);
         const bool fwd = tL < tR;
         const uint32_t pos = fwd ? dL : dR;
         if (pos == 0) continue;
@@ -594,10 +625,8 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
             const uint32_t hn = hnode[h];
             const uint32_t i = hn >> 1;
             const bool rc = hn & 1u;
-            // the head's pid: recompute from the node (circle heads: (i,1))
-            uint32_t pid;
-            if (nxt[2 * i] != NONE16) pid = (i << 1) | 1u;
-            else { const uint32_t tR = tl[2 * i], tL = tl[2 * i + 1]; pid = tL < tR ? tL : tR; }
+            const uint32_t tR = w_tail(2 * i), tL = w_tail(2 * i + 1);     // only open paths have list entries
+            const uint32_t pid = tL < tR ? tL : tR;
             snk_kmer k;
             k.hi = khi[i];
             k.lo = klo[i];
@@ -815,15 +844,18 @@ static int bl_fragments_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, cons
     G_ALLOC(nbases, uint64_t, (uint64_t)nchunks + 1);
     G_ALLOC(boff, uint64_t, (uint64_t)nchunks + 1);
     SNK_HIP_TRY(hipMemsetAsync(nfrag, 0, ((uint64_t)nchunks + 1) * 4, st));
+    bl_extra_pool xp0;
+    memset(&xp0, 0, sizeof xp0);
+    // sizing pass: open paths per chunk (links only, no ranking)
     hipLaunchKernelGGL((bl_frag_kernel<K, SCAP, ST, false, false, DIST, GR>), dim3(nchunks), dim3(ST), 0, st, (const uint4*)B->desc,
                        (const uint32_t*)nullptr, tab->keys, B->ctx, B->pend, B->nbr, B->rq, da, nfrag, (const uint32_t*)nullptr,
                        (const uint64_t*)nullptr, (uint32_t*)nullptr, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                       (uint64_t*)nullptr, (uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
+                       (uint64_t*)nullptr, (uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, xp0);
     if (h_nbig)
         hipLaunchKernelGGL((bl_frag_kernel<K, BCAP, BT, true, false, DIST, GR>), dim3(h_nbig), dim3(BT), 0, st, (const uint4*)B->desc,
                            (const uint32_t*)B->biglist, tab->keys, B->ctx, B->pend, B->nbr, B->rq, da, nfrag, (const uint32_t*)nullptr,
                            (const uint64_t*)nullptr, (uint32_t*)nullptr, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                           (uint64_t*)nullptr, (uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
+                           (uint64_t*)nullptr, (uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, xp0);
     hipLaunchKernelGGL(bl_chunk_bases_kernel, dim3(nblk((uint64_t)nchunks + 1)), dim3(TB), 0, st, (const uint4*)B->desc, nfrag, nchunks,
                        (uint32_t)K, nbases);
     SNK_HIP_TRY(hipGetLastError());
@@ -835,25 +867,46 @@ static int bl_fragments_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, cons
     SNK_HIP_TRY(hipMemcpyAsync(&h_F, foff + nchunks, 4, hipMemcpyDeviceToHost, st));
     SNK_HIP_TRY(hipMemcpyAsync(&h_B, boff + nchunks, 8, hipMemcpyDeviceToHost, st));
     SNK_HIP_TRY(hipStreamSynchronize(st));
-    G_ALLOC(out->nk, uint32_t, (uint64_t)h_F + 1);
-    G_ALLOC(out->hl_self, unsigned long long, 2ull * h_F + 2);
-    G_ALLOC(out->hl_nb, unsigned long long, 2ull * h_F + 2);
-    G_ALLOC(out->boff, uint64_t, (uint64_t)h_F + 2);
-    G_ALLOC(out->bases, uint8_t, h_B + 16);
-    out->fgroup = nullptr;
-    if (GR) G_ALLOC(out->fgroup, uint32_t, (uint64_t)h_F + 1);
-    out->sfrag = nullptr;
-    if (!DIST) G_ALLOC(out->sfrag, uint32_t, 2 * tab->n + 2);
-    hipLaunchKernelGGL((bl_frag_kernel<K, SCAP, ST, false, true, DIST, GR>), dim3(nchunks), dim3(ST), 0, st, (const uint4*)B->desc,
-                       (const uint32_t*)nullptr, tab->keys, B->ctx, B->pend, B->nbr, B->rq, da, nfrag, foff, boff, out->nk, out->hl_self,
-                       out->hl_nb, out->boff, out->bases, out->fgroup, out->sfrag);
-    if (h_nbig)
-        hipLaunchKernelGGL((bl_frag_kernel<K, BCAP, BT, true, true, DIST, GR>), dim3(h_nbig), dim3(BT), 0, st, (const uint4*)B->desc,
-                           (const uint32_t*)B->biglist, tab->keys, B->ctx, B->pend, B->nbr, B->rq, da, nfrag, foff, boff, out->nk,
-                           out->hl_self, out->hl_nb, out->boff, out->bases, out->fgroup, out->sfrag);
-    SNK_HIP_TRY(hipGetLastError());
-    out->n_frags = h_F;
-    out->total_bases = h_B;
+    // the open paths' bases: every node once + K-1 per path; circle nodes are not in any path, their bases come from the pool
+    unsigned long long* xcur;
+    G_ALLOC(xcur, unsigned long long, 2);
+    uint64_t xf_cap = 4096 + h_F / 256, xb_cap = xf_cap * (K + 63);
+    unsigned long long h_x[2] = {0, 0};
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        G_ALLOC(out->nk, uint32_t, (uint64_t)h_F + xf_cap + 1);
+        G_ALLOC(out->hl_self, unsigned long long, 2ull * (h_F + xf_cap) + 2);
+        G_ALLOC(out->hl_nb, unsigned long long, 2ull * (h_F + xf_cap) + 2);
+        G_ALLOC(out->boff, uint64_t, (uint64_t)h_F + xf_cap + 2);
+        G_ALLOC(out->bases, uint8_t, h_B + xb_cap + 16);
+        out->fgroup = nullptr;
+        if (GR) G_ALLOC(out->fgroup, uint32_t, (uint64_t)h_F + xf_cap + 1);
+        out->sfrag = nullptr;
+        if (!DIST) G_ALLOC(out->sfrag, uint32_t, 2 * tab->n + 2);
+        SNK_HIP_TRY(hipMemsetAsync(xcur, 0, 16, st));
+        bl_extra_pool xp;
+        xp.cur = xcur;
+        xp.f0 = h_F;
+        xp.b0 = h_B;
+        xp.fcap = xf_cap;
+        xp.bcap = xb_cap;
+        hipLaunchKernelGGL((bl_frag_kernel<K, SCAP, ST, false, true, DIST, GR>), dim3(nchunks), dim3(ST), 0, st, (const uint4*)B->desc,
+                           (const uint32_t*)nullptr, tab->keys, B->ctx, B->pend, B->nbr, B->rq, da, nfrag, foff, boff, out->nk, out->hl_self,
+                           out->hl_nb, out->boff, out->bases, out->fgroup, out->sfrag, xp);
+        if (h_nbig)
+            hipLaunchKernelGGL((bl_frag_kernel<K, BCAP, BT, true, true, DIST, GR>), dim3(h_nbig), dim3(BT), 0, st, (const uint4*)B->desc,
+                               (const uint32_t*)B->biglist, tab->keys, B->ctx, B->pend, B->nbr, B->rq, da, nfrag, foff, boff, out->nk,
+                               out->hl_self, out->hl_nb, out->boff, out->bases, out->fgroup, out->sfrag, xp);
+        SNK_HIP_TRY(hipGetLastError());
+        SNK_HIP_TRY(hipMemcpyAsync(h_x, xcur, 16, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(hipStreamSynchronize(st));
+        if (h_x[0] <= xf_cap && h_x[1] <= xb_cap) break;
+        if (attempt == 1) return snk_fail(SNK_E_INTERNAL, err, errcap, "bucket-local graph: circle pool overflow");
+        xf_cap = h_x[0] + 64;          // exact requirement (the counters keep counting past the capacity)
+        xb_cap = h_x[1] + 64;
+    }
+    out->n_frags = h_F + h_x[0];
+    out->total_bases = h_B + h_x[1];
+    out->n_local_circles = (uint32_t)h_x[0];
     return SNK_OK;
 }
 
