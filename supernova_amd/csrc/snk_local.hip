@@ -870,7 +870,8 @@ static int bl_fragments_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, cons
     // the open paths' bases: every node once + K-1 per path; circle nodes are not in any path, their bases come from the pool
     unsigned long long* xcur;
     G_ALLOC(xcur, unsigned long long, 2);
-    uint64_t xf_cap = 4096 + h_F / 256, xb_cap = xf_cap * (K + 63);
+    const uint32_t pool0 = snk_env_u32("SNK_BL_POOL", 4096);                 // SNK_BL_POOL=0: tests force the exact re-run
+    uint64_t xf_cap = pool0 ? pool0 + h_F / 256 : 0, xb_cap = xf_cap * (K + 63);
     unsigned long long h_x[2] = {0, 0};
     for (int attempt = 0; attempt < 2; ++attempt) {
         G_ALLOC(out->nk, uint32_t, (uint64_t)h_F + xf_cap + 1);

@@ -427,3 +427,12 @@ def test_vs_reference_binary_200k(engine, graph_stage, tmp_path):
                              bc=torch.from_numpy(bc).to(dev))
     hist = np.asarray(d["hist"]["vals"], dtype=np.int64)
     _check_against(res, d["kmers"]["k"], d["kmers"]["count"], d["kmers"]["ctx"], d["unitigs"], d["goodlens"], hist)
+
+
+def test_circle_pool_retry(engine, monkeypatch):
+    """Circles inside one chunk take their fragment slots from a small pool; an empty pool must trigger the exact re-run."""
+    monkeypatch.setenv("SNK_BL_POOL", "0")
+    c = goldens.load("adversarial")
+    rows, quals, bc, lens = _to_dev(c)
+    res = engine.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, ign_bc_below=c.ign_bc_below)
+    _check_against(res, c.exp_keys, c.exp_counts, c.exp_ctx, c.exp_unitigs, c.exp_goodlens, c.exp_hist)
