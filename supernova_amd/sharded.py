@@ -62,14 +62,15 @@ class TorchComm:
         for r in reqs:
             r.wait()
 
-    def all_to_all_v(self, send: torch.Tensor, send_counts: list[int]):
-        """send: 1-D uint8; send_counts[p] bytes go to rank p.  Returns (recv uint8, recv_counts)."""
+    def all_to_all_v(self, send: torch.Tensor, send_counts: list[int], alloc=None):
+        """send: 1-D uint8; send_counts[p] bytes go to rank p.  Returns (recv uint8, recv_counts).
+        alloc(nbytes) -> uint8 tensor supplies the receive buffer (default: torch.empty)."""
         dev = send.device
         sc = torch.tensor(send_counts, dtype=torch.int64, device=dev)
         rc = torch.empty_like(sc)
         self._a2a(rc, sc, [1] * self.world, [1] * self.world)
         recv_counts = [int(x) for x in rc.tolist()]
-        recv = torch.empty(sum(recv_counts), dtype=torch.uint8, device=dev)
+        recv = alloc(sum(recv_counts)) if alloc else torch.empty(sum(recv_counts), dtype=torch.uint8, device=dev)
         # widest element type that divides every segment: multi-GB segments stay far below 2^31 elements
         for width, dt in ((8, torch.int64), (4, torch.int32), (1, torch.uint8)):
             if all(c % width == 0 for c in recv_counts) and all(c % width == 0 for c in send_counts) \
@@ -119,7 +120,7 @@ class SimComm:
     def all_gather_int(self, v, device):
         return [int(x) for x in self._exchange(int(v))]
 
-    def all_to_all_v(self, send, send_counts):
+    def all_to_all_v(self, send, send_counts, alloc=None):
         torch.cuda.synchronize()
         allv = self._exchange((send, list(send_counts)))
         parts, counts = [], []
@@ -242,10 +243,29 @@ class ShardedResult:
         return out
 
 
+class _BufferPool:
+    """Grow-only named byte buffers reused across steps: the send / receive / query buffers are tens of GB, and a fresh
+    torch.empty of that size is a device allocation (milliseconds each) whenever the caching allocator has no block of
+    the right size left."""
+
+    def __init__(self, device):
+        self.device = device
+        self.bufs: dict[str, torch.Tensor] = {}
+
+    def get(self, name: str, nbytes: int) -> torch.Tensor:
+        b = self.bufs.get(name)
+        if b is None or b.numel() < nbytes:
+            self.bufs.pop(name, None)
+            b = torch.empty(int(nbytes * 1.1) + 4096, dtype=torch.uint8, device=self.device)
+            self.bufs[name] = b
+        return b[:nbytes]
+
+
 class ShardedEngine:
     def __init__(self, engine: Engine, dist_or_comm):
         self.eng = engine
         self.comm = dist_or_comm if hasattr(dist_or_comm, "all_to_all_v") else TorchComm(dist_or_comm)
+        self.pool = None
 
     def count_graph(self, rows, read_len, quals=None, bc=None, lens=None, good_len=None, params: Params | None = None,
                     ign_bc_below: int = 0, read_index_base: int = 0) -> ShardedResult:
@@ -256,6 +276,9 @@ class ShardedEngine:
         dev = rows.device
         st = e._stream()
         err = C.create_string_buffer(512)
+        if self.pool is None or self.pool.device != dev:
+            self.pool = _BufferPool(dev)
+        pool = self.pool
 
         def chk(rc):
             if rc != 0:
@@ -292,13 +315,13 @@ class ShardedEngine:
             raise _lib.SnkError(-6, "more than 2^32 supermers on one rank")
         # the kernel reads u32; int32 storage holds the same bit patterns (values >= 2^31 wrap)
         offsets = torch.where(off64 >= (1 << 31), off64 - (1 << 32), off64).to(torch.int32)
-        send = torch.empty(max(n_super, 1) * 32, dtype=torch.uint8, device=dev)
+        send = pool.get("send", max(n_super, 1) * 32)
         chk(lib.snk_shard_scatter(e._ctx, offsets.data_ptr(), send.data_ptr(), st, err, 512))
         ev[2].record()
         # ---- exchange #1/#2: histograms and records
         send_counts = owner_record_counts(off64, W)
         hist_recv = comm.all_to_all_equal(hist.view(W, NBl))
-        recv, recv_bytes = comm.all_to_all_v(send[: n_super * 32], [c * 32 for c in send_counts])
+        recv, recv_bytes = comm.all_to_all_v(send[: n_super * 32], [c * 32 for c in send_counts], alloc=lambda nb: pool.get("recv", nb))
         seg_off = segment_offsets(hist_recv, [b // 32 for b in recv_bytes])
         ev[3].record()
         # ---- stage 3: count
@@ -313,13 +336,13 @@ class ShardedEngine:
         qoff = torch.zeros(W + 1, dtype=torch.int64, device=dev)
         qoff[1:] = torch.cumsum(torch.tensor(qc, dtype=torch.int64, device=dev), 0)
         nq = sum(qc)
-        qbuf = torch.empty(max(nq, 1) * 24, dtype=torch.uint8, device=dev)
+        qbuf = pool.get("qbuf", max(nq, 1) * 24)
         chk(lib.snk_shard_prune_fill(e._ctx, qoff.data_ptr(), qbuf.data_ptr(), st, err, 512))
-        qin, qin_bytes = comm.all_to_all_v(qbuf[: nq * 24], [c * 24 for c in qc])
+        qin, qin_bytes = comm.all_to_all_v(qbuf[: nq * 24], [c * 24 for c in qc], alloc=lambda nb: pool.get("qin", nb))
         nq_in = qin.numel() // 24
-        ans = torch.empty(max(nq_in, 1) * 4, dtype=torch.uint8, device=dev)
+        ans = pool.get("ans", max(nq_in, 1) * 4)
         chk(lib.snk_shard_prune_answer(e._ctx, qin.data_ptr(), nq_in, ans.data_ptr(), st, err, 512))
-        ans_back, _ = comm.all_to_all_v(ans[: nq_in * 4], [b // 24 * 4 for b in qin_bytes])
+        ans_back, _ = comm.all_to_all_v(ans[: nq_in * 4], [b // 24 * 4 for b in qin_bytes], alloc=lambda nb: pool.get("ans_back", nb))
         assert ans_back.numel() == nq * 4
         chk(lib.snk_shard_prune_apply(e._ctx, qbuf.data_ptr(), ans_back.data_ptr(), nq, qoff.data_ptr(), st, err, 512))
         ev[5].record()
@@ -341,9 +364,9 @@ class ShardedEngine:
         res.n_frags = int(fr.n_frags)
         F = int(fr.n_frags)
 
-        def dcopy(ptr, nbytes):
-            """device-to-device copy of a library-owned buffer into a torch tensor (send buffer)."""
-            t = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        def dcopy(name, ptr, nbytes):
+            """device-to-device copy of a library-owned buffer into a pooled torch tensor (send buffer)."""
+            t = pool.get(name, max(nbytes, 8))
             if nbytes:
                 torch.cuda.current_stream().synchronize()
                 _copy_d2d(t.data_ptr(), ptr, nbytes)
@@ -351,11 +374,11 @@ class ShardedEngine:
 
         to0 = lambda n: [n if q == 0 else 0 for q in range(W)]
         TB = int(fr.total_bases)
-        t_nk, _ = comm.all_to_all_v(dcopy(fr.nk, F * 4), to0(F * 4))
-        t_self, _ = comm.all_to_all_v(dcopy(fr.hl_self, F * 16), to0(F * 16))
-        t_nb, _ = comm.all_to_all_v(dcopy(fr.hl_nb, F * 16), to0(F * 16))
-        t_start, start_bytes = comm.all_to_all_v(dcopy(fr.boff, F * 8), to0(F * 8))
-        t_bases, base_bytes = comm.all_to_all_v(dcopy(fr.bases, TB), to0(TB))
+        t_nk, _ = comm.all_to_all_v(dcopy("s_nk", fr.nk, F * 4), to0(F * 4), alloc=lambda nb: pool.get("g_nk", nb))
+        t_self, _ = comm.all_to_all_v(dcopy("s_self", fr.hl_self, F * 16), to0(F * 16), alloc=lambda nb: pool.get("g_self", nb))
+        t_nb, _ = comm.all_to_all_v(dcopy("s_nb", fr.hl_nb, F * 16), to0(F * 16), alloc=lambda nb: pool.get("g_nb", nb))
+        t_start, start_bytes = comm.all_to_all_v(dcopy("s_start", fr.boff, F * 8), to0(F * 8), alloc=lambda nb: pool.get("g_start", nb))
+        t_bases, base_bytes = comm.all_to_all_v(dcopy("s_bases", fr.bases, TB), to0(TB), alloc=lambda nb: pool.get("g_bases", nb))
         res.joined = None
         res.n_unitigs = 0
         if me == 0:
