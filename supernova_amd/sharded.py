@@ -25,13 +25,12 @@ from .engine import Engine, Params
 
 # ------------------------------------------------------------------------------------------------ communicators
 class TorchComm:
-    """Exchanges over torch.distributed.  all_to_all_single on NCCL/RCCL; point-to-point fallback on gloo."""
+    """Exchanges over torch.distributed (RCCL on the GPU box, gloo in the CPU tests): grouped point-to-point sends."""
 
     def __init__(self, dist):
         self.dist = dist
         self.rank = dist.get_rank()
         self.world = dist.get_world_size()
-        self._native_a2a = dist.get_backend() == "nccl"
 
     def allreduce_sum_int(self, v: int, device) -> int:
         t = torch.tensor([v], dtype=torch.int64, device=device)
@@ -44,23 +43,33 @@ class TorchComm:
         self.dist.all_gather(out, t)
         return [int(x.item()) for x in out]
 
+    # Largest single message handed to the transport.  RCCL 2.26 (ROCm 7.0) moves only the first half of a message to
+    # the rank itself once it exceeds 1 GiB (`all_to_all_single`, world 1, any dtype -- tools/dbg_a2a.py); the sharded
+    # exchange has multi-GB segments, so every segment goes out in pieces, and the piece a rank owes itself is a plain copy.
+    CHUNK_BYTES = 256 << 20
+
     def _a2a(self, out: torch.Tensor, inp: torch.Tensor, out_splits, in_splits):
-        if self._native_a2a:
-            self.dist.all_to_all_single(out, inp, out_splits, in_splits)
-            return
-        ins = list(torch.split(inp, in_splits)) if sum(in_splits) else [inp[:0] for _ in in_splits]
-        outs = list(torch.split(out, out_splits)) if sum(out_splits) else [out[:0] for _ in out_splits]
-        reqs = []
-        for p in range(self.world):
-            if p == self.rank:
-                outs[p].copy_(ins[p])
+        """Variable all-to-all of 1-D tensors: in_splits[p] elements of `inp` go to rank p, out_splits[p] arrive from it."""
+        W, me = self.world, self.rank
+        ch = max(1, self.CHUNK_BYTES // inp.element_size())
+        in_off = [0] * (W + 1)
+        out_off = [0] * (W + 1)
+        for p in range(W):
+            in_off[p + 1] = in_off[p] + int(in_splits[p])
+            out_off[p + 1] = out_off[p] + int(out_splits[p])
+        if in_splits[me]:
+            out[out_off[me]:out_off[me + 1]].copy_(inp[in_off[me]:in_off[me + 1]])
+        ops = []
+        for p in range(W):
+            if p == me:
                 continue
-            if in_splits[p]:
-                reqs.append(self.dist.isend(ins[p].contiguous(), p))
-            if out_splits[p]:
-                reqs.append(self.dist.irecv(outs[p], p))
-        for r in reqs:
-            r.wait()
+            for c0 in range(0, int(in_splits[p]), ch):
+                ops.append(self.dist.P2POp(self.dist.isend, inp[in_off[p] + c0:in_off[p] + min(c0 + ch, int(in_splits[p]))], p))
+            for c0 in range(0, int(out_splits[p]), ch):
+                ops.append(self.dist.P2POp(self.dist.irecv, out[out_off[p] + c0:out_off[p] + min(c0 + ch, int(out_splits[p]))], p))
+        if ops:
+            for r in self.dist.batch_isend_irecv(ops):
+                r.wait()
 
     def all_to_all_v(self, send: torch.Tensor, send_counts: list[int], alloc=None):
         """send: 1-D uint8; send_counts[p] bytes go to rank p.  Returns (recv uint8, recv_counts).

@@ -130,3 +130,28 @@ def test_sharded_k60(snk):
     assert np.array_equal(np.concatenate([x["counts"] for x in out])[order], o.counts)
     assert np.array_equal(np.concatenate([x["ctx"] for x in out])[order], o.ctx)
     assert out[0]["unitigs"] == o.unitigs
+
+
+def test_rccl_world1_exchange_multi_gib(snk):
+    """A real RCCL group of one rank: the exchange must deliver every byte of a multi-GiB segment.  (RCCL 2.26 moves only the
+    first half of a > 1 GiB message a rank sends to itself through all_to_all_single; TorchComm copies that segment itself and
+    cuts the others into pieces.)"""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from supernova_amd.sharded import TorchComm
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        dev = torch.device("cuda", 0)
+        n = (5 << 29) + 4096 * 3            # 2.5 GiB + a ragged tail
+        src = torch.empty(n, dtype=torch.uint8, device=dev)
+        src.view(torch.int32).copy_(torch.arange(n // 4, dtype=torch.int32, device=dev))
+        recv, rb = TorchComm(dist).all_to_all_v(src, [n])
+        torch.cuda.synchronize()
+        assert rb == [n] and torch.equal(recv, src)
+    finally:
+        dist.destroy_process_group()

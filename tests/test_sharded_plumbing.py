@@ -91,6 +91,18 @@ def _worker(rank, world, port, q):
             ok &= list(blk[:, 2]) == list(range(b - a))
     ok &= comm.allreduce_sum_int(rank + 1, torch.device("cpu")) == world * (world + 1) // 2
     ok &= comm.all_gather_int(10 + rank, torch.device("cpu")) == [10 + r for r in range(world)]
+    # segments far larger than one transport message: every segment travels in many ragged pieces
+    TorchComm.CHUNK_BYTES = 1000
+    big = torch.arange(0, 70_001 + 13 * rank, dtype=torch.int64) * (rank + 1)
+    cnt = [(big.numel() // 3) * 8, (big.numel() - big.numel() // 3) * 8]
+    back, rb = comm.all_to_all_v(big.view(torch.uint8), cnt)
+    for src in range(world):
+        n_src = 70_001 + 13 * src
+        full = torch.arange(0, n_src, dtype=torch.int64) * (src + 1)
+        lo = 0 if rank == 0 else n_src // 3
+        ln = n_src // 3 if rank == 0 else n_src - n_src // 3
+        a = sum(rb[:src]) // 8
+        ok &= rb[src] == ln * 8 and bool(torch.equal(back.view(torch.int64)[a:a + ln], full[lo:lo + ln]))
     q.put((rank, ok, int(got.shape[0])))
     dist.destroy_process_group()
 
