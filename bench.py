@@ -57,6 +57,7 @@ def parse():
                     help="BASELINE config 5: per-barcode local graphs (group = barcode, frequency rule only, --min-freq); "
                          "replicas only for N>1 (every rank owns whole barcodes, no collective)")
     ap.add_argument("--min-freq", type=int, default=3)
+    ap.add_argument("--no-verify", action="store_true", help="skip the untimed self-check of the sharded path")
     return ap.parse_args()
 
 
@@ -148,6 +149,39 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- untimed self-check of the sharded path: a small data set through the SAME exchanges, compared on rank 0 with the
+    # one-GPU path over all of its reads (retained table as a multiset checksum, unitigs as a set).  A transport that
+    # drops or garbles bytes shows up here, not as a fast wrong number.
+    verified = None
+    if use_dist and not args.grouped and not args.no_verify:
+        import hashlib
+        import numpy as np
+        per_v = 2_000_000
+        spv = synth.synth_params(per_v * world, seed=0x5EED0F00 + world, error_free=args.error_free)
+        rv, qv, bv = eng.synth(spv, first=rank * per_v, n=per_v)
+        resv = sh.count_graph(rv, spv.read_len, quals=qv, bc=bv, params=params, read_index_base=rank * per_v)
+        kv = resv.keys().astype(np.uint64)
+        mixed = (kv[:, 0] * np.uint64(0x9E3779B97F4A7C15) + kv[:, 1] * np.uint64(0xC2B2AE3D27D4EB4F) + kv[:, 2] * np.uint64(0x165667B19E3779F9)
+                 + resv.counts().astype(np.uint64) * np.uint64(0x27D4EB2F165667C5) + resv.ctx().astype(np.uint64) * np.uint64(0x85EBCA77C2B2AE63))
+        uv = resv.unitigs() if rank == 0 else None       # fetched now: the next call on this engine recycles the result buffers
+        loc = torch.tensor([int(kv.shape[0]), int(mixed.sum(dtype=np.uint64) >> np.uint64(1))], dtype=torch.int64, device="cuda")
+        if world > 1:
+            dist.all_reduce(loc)
+        if rank == 0:
+            ra, qa, ba = eng.synth(spv, first=0, n=per_v * world)
+            ref = eng.count_graph(ra, spv.read_len, quals=qa, bc=ba, params=params)
+            kr = ref.keys().astype(np.uint64)
+            mr = (kr[:, 0] * np.uint64(0x9E3779B97F4A7C15) + kr[:, 1] * np.uint64(0xC2B2AE3D27D4EB4F) + kr[:, 2] * np.uint64(0x165667B19E3779F9)
+                  + ref.counts().astype(np.uint64) * np.uint64(0x27D4EB2F165667C5) + ref.ctx().astype(np.uint64) * np.uint64(0x85EBCA77C2B2AE63))
+            # per-rank sums were halved before the reduction (int64 transport): compare modulo the lost low bits
+            same_table = int(loc[0]) == kr.shape[0] and abs(int(loc[1]) - int(mr.sum(dtype=np.uint64) >> np.uint64(1))) <= world
+            h = lambda us: hashlib.sha256("\n".join(us).encode()).hexdigest()
+            same_unitigs = h(uv) == h(ref.unitigs())
+            verified = bool(same_table and same_unitigs)
+            del ra, qa, ba, ref
+        del rv, qv, bv, resv
+        barrier()
+
     res = None
     for _ in range(args.warmup):
         res = step()
@@ -208,6 +242,9 @@ def main():
                          "pipeline_frac": value * ALG_BYTES_PER_KMER[K] / (world * HBM_PEAK_GBS)},
         }
         out["config"]["path"] = "grouped-replicas" if args.grouped else ("sharded" if use_dist else "single")
+        if verified is not None:
+            out["config"]["sharded_self_check"] = "passed" if verified else "FAILED"
+
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(sp, K, args.cpu_sample)
