@@ -1,3 +1,4 @@
+"""The sharded step over a real one-rank RCCL group vs the simulated transport; every exchange is compared byte for byte."""
 import os, sys
 sys.path.insert(0, "/root/repo")
 import torch, torch.distributed as dist
