@@ -98,6 +98,13 @@ int snk_ctx_alloc(snk_ctx* ctx, size_t bytes, void** out, char* err, size_t errc
     *out = p;
     return SNK_OK;
 }
+// hand one block back to the cache in the middle of a call (the big ones: supermer slots after the count, count regions
+// after the gather) so that later stages of the same call can reuse the memory
+void snk_ctx_release_block(snk_ctx* ctx, const void* p) {
+    if (!p) return;
+    for (auto& b : ctx->blocks)
+        if (b.p == p && b.used) { b.used = false; ctx->total_alloc -= b.bytes; return; }
+}
 void snk_ctx_release_scratch(snk_ctx* ctx) {
     for (auto& b : ctx->blocks) b.used = false;
     ctx->total_alloc = 0;

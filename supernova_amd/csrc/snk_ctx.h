@@ -22,6 +22,7 @@ struct snk_ctx {
     size_t total_alloc = 0;     // bytes handed out in the current call
     size_t cached_bytes = 0;    // bytes held by the arena
     uint64_t last_n_kmers = 0, last_n_instances = 0;   // sizing hint from the previous call
+    uint32_t last_extra = 0;                           // split sub-passes the previous call recorded
     void* shard = nullptr;      // snk_shard_state (snk_dist.hip)
 };
 
@@ -39,5 +40,6 @@ int snk_fail(int code, char* err, size_t errcap, const char* fmt, ...);
 // scratch allocation owned by the ctx; freed by snk_ctx_release_scratch / destroy
 int snk_ctx_alloc(snk_ctx* ctx, size_t bytes, void** out, char* err, size_t errcap);
 void snk_ctx_release_scratch(snk_ctx* ctx);   // return every block to the cache
+void snk_ctx_release_block(snk_ctx* ctx, const void* p);   // return one block to the cache (no-op for unknown pointers)
 void snk_ctx_trim_cache(snk_ctx* ctx);        // hipFree every unused cached block
 void snk_shard_state_free(void* p);

@@ -81,7 +81,7 @@ extern "C" int snk_shard_scatter(snk_ctx* ctx, const void* d_offsets, void* d_re
     if (!ctx || !ctx->shard || !d_offsets || !d_records) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_scatter: NULL argument / no session");
     snk_shard_state* S = state_of(ctx);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-    return snk_stage_partition_compact(st, &S->part, (const uint32_t*)d_offsets, d_records, err, errcap);
+    return snk_stage_partition_compact(ctx, st, &S->part, (const uint32_t*)d_offsets, d_records, err, errcap);
 }
 
 extern "C" int snk_shard_count(snk_ctx* ctx, const void* d_records, const void* d_seg_off, uint64_t n_inst_hint, int has_bc,

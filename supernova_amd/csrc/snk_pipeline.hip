@@ -115,6 +115,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     rc = snk_stage_count_table(ctx, st, K, records, seg, seg + NB, 2 * NB, nseg, NB, p->min_freq, (in->bc && !grouped) ? p->min_bc : 0u, grouped ? 1u : 0u, h_ninst, status,
                                !local_graph, &tab, err, errcap);
     if (rc) return rc;
+    snk_ctx_release_block(ctx, records);       // 2.5x-capacity supermer slots: the graph stage may reuse the memory
     const uint64_t n_kmers = tab.n;
     out->buckets_split = tab.buckets_split;
     out->max_slots_used = tab.max_slots_used;

@@ -31,7 +31,7 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
     // ---- K5-K8 count + filter into a region-partitioned table, then gather the regions densely.
     // Every retained k-mer has >= min_freq instances; deep coverage retains far fewer (56x: ~1/38 of them).
     uint32_t n_regions = NB < 4096 ? NB : 4096;
-    uint64_t est = n_inst_hint / (min_freq > 1 ? 8 : 1) + 4096;
+    uint64_t est = n_inst_hint / (min_freq > 1 ? 12 : 1) + 4096;     // first call only; a wrong guess costs one re-run
     if (ctx->last_n_kmers && ctx->last_n_instances == n_inst_hint) est = ctx->last_n_kmers + ctx->last_n_kmers / 2 + 4096;
     uint64_t region_cap = est / n_regions + 64;
     snk_u128 *keys_r = nullptr, *keys_a = nullptr, *keys_b = nullptr;
@@ -52,7 +52,9 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
         void* q;
         if ((rc = snk_ctx_alloc(ctx, (NB + 1) * 4ull, &q, err, errcap))) return rc; chunk_n = (uint32_t*)q;
         if ((rc = snk_ctx_alloc(ctx, (NB + 1) * 4ull, &q, err, errcap))) return rc; chunk_base = (uint32_t*)q;
-        extra_cap = 1u << 16;
+        // sub-passes of split buckets: a few per cent of the buckets split once; remember what the last call needed
+        extra_cap = NB / 8 > (1u << 16) ? NB / 8 : (1u << 16);
+        if (ctx->last_extra > extra_cap) extra_cap = ctx->last_extra + ctx->last_extra / 4;
     }
     for (int attempt = 0; attempt < 4; ++attempt) {
         void* q;
@@ -124,6 +126,8 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
         const bool extra_ovf = !want_sort && h_status[4] > extra_cap;
         if (!h_status[0] && mx <= region_cap && !extra_ovf) break;
         if (attempt == 3) return snk_fail(SNK_E_INTERNAL, err, errcap, "count: region overflow (%llu > %llu)", mx, (unsigned long long)region_cap);
+        snk_ctx_release_block(ctx, keys_r);
+        snk_ctx_release_block(ctx, vals_r);
         if (mx > region_cap) region_cap = mx + 64;     // exact requirement is known now (cursors keep counting past the cap)
         if (extra_ovf) extra_cap = h_status[4] + 64;
     }
@@ -139,6 +143,8 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
         if ((rc = snk_ctx_alloc(ctx, (n_kmers + 1) * 8, &q, err, errcap))) return rc; vals_a = (uint64_t*)q;
         if ((rc = snk_launch_compact_regions(st, keys_r, vals_r, region_cap, n_regions, rcur, roff, keys_a, vals_a, err, errcap))) return rc;
         SNK_HIP_TRY(hipStreamSynchronize(st));   // h_off is a stack vector: the upload must finish before it goes away
+        snk_ctx_release_block(ctx, keys_r);      // the region-partitioned copy is dead: later stages may reuse it
+        snk_ctx_release_block(ctx, vals_r);
     }
     out->buckets_split = h_status[2];
     out->max_slots_used = h_status[3];
@@ -150,6 +156,7 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
     out->NB = NB;
     out->n_regions = n_regions;
     out->n_extra = want_sort ? 0u : h_status[4];
+    if (!want_sort) ctx->last_extra = h_status[4];
     out->chunk_n = chunk_n;
     out->chunk_base = chunk_base;
     out->extra = extra;
@@ -322,6 +329,8 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
         SNK_HIP_TRY(hipStreamSynchronize(st));
         if (h_novf <= ovf_cap) break;
         if (attempt == 2) return snk_fail(SNK_E_INTERNAL, err, errcap, "supermer overflow list too small (%u > %llu)", h_novf, (unsigned long long)ovf_cap);
+        snk_ctx_release_block(ctx, records);
+        snk_ctx_release_block(ctx, ovf_bucket);
         ovf_cap = (uint64_t)h_novf + 65536;
     }
     // segment 0: the fixed-capacity slots; segment 1: the overflow records grouped by bucket
@@ -341,10 +350,13 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
     return SNK_OK;
 }
 
-int snk_stage_partition_compact(hipStream_t st, const snk_partition* part, const uint32_t* d_offsets, void* d_out, char* err, size_t errcap) {
+int snk_stage_partition_compact(snk_ctx* ctx, hipStream_t st, const snk_partition* part, const uint32_t* d_offsets, void* d_out, char* err,
+                                size_t errcap) {
     if (part->NB == 0) return SNK_OK;
     hipLaunchKernelGGL(compact_buckets_kernel, dim3((part->NB + 3) / 4), dim3(256), 0, st, (const uint4*)part->records, part->seg, part->NB,
                        d_offsets, (uint4*)d_out);
     SNK_HIP_TRY(hipGetLastError());
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    snk_ctx_release_block(ctx, part->records);      // the slot layout is dead once the send buffer is filled
     return SNK_OK;
 }
