@@ -80,6 +80,7 @@ int snk_ctx_alloc(snk_ctx* ctx, size_t bytes, void** out, char* err, size_t errc
     if (best >= 0) {
         ctx->blocks[best].used = true;
         ctx->total_alloc += ctx->blocks[best].bytes;
+        if (ctx->total_alloc > ctx->peak_alloc) ctx->peak_alloc = ctx->total_alloc;
         *out = ctx->blocks[best].p;
         return SNK_OK;
     }
@@ -94,6 +95,7 @@ int snk_ctx_alloc(snk_ctx* ctx, size_t bytes, void** out, char* err, size_t errc
         return snk_fail(SNK_E_NOMEM, err, errcap, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     ctx->blocks.push_back({p, bytes, true});
     ctx->total_alloc += bytes;
+    if (ctx->total_alloc > ctx->peak_alloc) ctx->peak_alloc = ctx->total_alloc;
     ctx->cached_bytes += bytes;
     *out = p;
     return SNK_OK;
@@ -108,6 +110,7 @@ void snk_ctx_release_block(snk_ctx* ctx, const void* p) {
 void snk_ctx_release_scratch(snk_ctx* ctx) {
     for (auto& b : ctx->blocks) b.used = false;
     ctx->total_alloc = 0;
+    ctx->peak_alloc = 0;
 }
 void snk_ctx_trim_cache(snk_ctx* ctx) {
     std::vector<snk_ctx::block> keep;

@@ -19,7 +19,8 @@ struct snk_ctx {
     // start of the next top-level call (no hipFree/hipMalloc in steady state), released on destroy or OOM
     struct block { void* p; size_t bytes; bool used; };
     std::vector<block> blocks;
-    size_t total_alloc = 0;     // bytes handed out in the current call
+    size_t total_alloc = 0;     // bytes handed out in the current call (minus blocks returned mid-call)
+    size_t peak_alloc = 0;      // its maximum during the call
     size_t cached_bytes = 0;    // bytes held by the arena
     uint64_t last_n_kmers = 0, last_n_instances = 0;   // sizing hint from the previous call
     uint32_t last_extra = 0;                           // split sub-passes the previous call recorded

@@ -162,7 +162,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     out->kernel_ms[0] = 0.f;
     out->kernel_ms[1] = part.kernel_ms;
     out->kernel_ms[2] = tab.count_kernel_ms;
-    out->scratch_bytes = ctx->total_alloc;
+    out->scratch_bytes = ctx->peak_alloc;
     return SNK_OK;
 }
 
