@@ -62,6 +62,8 @@ typedef struct snk_params {
                                   (snk_dev_reads.group); k-mers are counted, pruned and walked per (group, k-mer); every
                                   unitig reports its group.  K=48, frequency rule only.  The group id is returned in the
                                   32 low bits of every key. */
+#define SNK_F_NO_TABLE 16u      /* snk_count_graph (host pointers): do not download the retained table (kmers/counts/ctx stay
+                                  NULL, n_kmers is still reported) -- callers at the .bv seam only need the unitigs */
 #define SNK_F_GLOBAL_GRAPH 4u   /* use the global graph stage (sort + HBM index + list ranking over all k-mers) instead
                                   of the bucket-local one; same results, kept as a cross-check */
 

@@ -79,6 +79,7 @@ int main(int argc, char** argv) {
     p.min_qual = (uint32_t)atoi(kv["MIN_QUAL"].c_str());
     p.min_freq = (uint32_t)atoi(kv["MIN_FREQ"].c_str());
     p.min_bc = (uint32_t)atoi(kv["MIN_BC"].c_str());
+    p.flags |= SNK_F_NO_TABLE;                      // the hand-off is the unitigs (+ the spectrum), not the dictionary
     snk_reads in;
     memset(&in, 0, sizeof in);
     in.n_reads = n_reads;

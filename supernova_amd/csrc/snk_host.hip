@@ -63,19 +63,24 @@ extern "C" int snk_count_graph(snk_ctx* ctx, const snk_reads* in, const snk_para
     dr.n_reads = n; dr.rows = d_rows.p; dr.row_words = rw; dr.read_len = L; dr.lens = d_lens.p;
     dr.quals = d_quals.p; dr.qstride = L; dr.good_len = d_gl.p; dr.bc = d_bc.p; dr.ign_bc_below = in->ign_bc_below;
     snk_dev_result r;
-    int rc = snk_dev_count_graph(ctx, &dr, p, &r, st, err, errcap);
+    snk_params pp = *p;
+    const bool want_table = !(p->flags & SNK_F_NO_TABLE);
+    if (!want_table) pp.flags |= SNK_F_UNSORTED_TABLE;          // nobody will look at the table: do not sort it
+    int rc = snk_dev_count_graph(ctx, &dr, &pp, &r, st, err, errcap);
     if (rc) return rc;
     out->n_instances = r.n_instances;
     out->n_kmers = r.n_kmers;
     out->spectrum_bins = r.spectrum_bins;
     memcpy(out->phase_ms, r.phase_ms, sizeof out->phase_ms);
-    const uint64_t nk = r.n_kmers;
-    out->kmers = (uint32_t*)malloc(std::max<size_t>(nk * 16, 16));
-    out->counts = (uint32_t*)malloc(std::max<size_t>(nk * 4, 16));
-    out->ctx = (uint8_t*)malloc(std::max<size_t>(nk, 16));
+    const uint64_t nk = want_table ? r.n_kmers : 0;
+    if (want_table) {
+        out->kmers = (uint32_t*)malloc(std::max<size_t>(nk * 16, 16));
+        out->counts = (uint32_t*)malloc(std::max<size_t>(nk * 4, 16));
+        out->ctx = (uint8_t*)malloc(std::max<size_t>(nk, 16));
+    }
     out->spectrum = (uint64_t*)malloc(std::max<size_t>((size_t)r.spectrum_bins * 8, 16));
     std::vector<uint64_t> lohi(nk * 2);
-    if (!out->kmers || !out->counts || !out->ctx || !out->spectrum) { snk_free(out); return snk_fail(SNK_E_NOMEM, err, errcap, "snk_count_graph: host allocation failed"); }
+    if ((want_table && (!out->kmers || !out->counts || !out->ctx)) || !out->spectrum) { snk_free(out); return snk_fail(SNK_E_NOMEM, err, errcap, "snk_count_graph: host allocation failed"); }
     if (nk) {
         SNK_HIP_TRY(hipMemcpyAsync(lohi.data(), r.keys, nk * 16, hipMemcpyDeviceToHost, st));
         SNK_HIP_TRY(hipMemcpyAsync(out->counts, r.counts, nk * 4, hipMemcpyDeviceToHost, st));
