@@ -216,10 +216,23 @@ typedef struct snk_shard_unitigs {
     const void* unitig_circular; /* u8[n_unitigs]: 1 = a circle that spanned fragments (already rotated to the reference's cut) */
     uint32_t n_circles, rank_rounds;
 } snk_shard_unitigs;
+/* Fragment links decided on the owners (optional; without it rank 0 matches the half links itself): every fragment
+ * end whose half link names a state of rank q asks q (24 bytes), q answers with the global id of the fragment end that
+ * sits on that state and points back, or ~0 (4 bytes).  my_frag_off = fragments of the ranks in front of this one.
+ * After snk_shard_links_apply, *d_flink is u32[2*n_frags]: global fragment-end id linked to each local end, or ~0. */
+int snk_shard_links_plan(snk_ctx* ctx, uint64_t my_frag_off, uint64_t* h_qcount /* [world] */, void* stream, char* err, size_t errcap);
+int snk_shard_links_fill(snk_ctx* ctx, const void* d_qoff /* u64[world+1] */, void* d_qbuf, void* stream, char* err, size_t errcap);
+int snk_shard_links_answer(snk_ctx* ctx, const void* d_queries, uint64_t nq, void* d_ans, void* stream, char* err, size_t errcap);
+int snk_shard_links_apply(snk_ctx* ctx, const void* d_qbuf, const void* d_ans, uint64_t nq, const void** d_flink, void* stream,
+                          char* err, size_t errcap);
 /* rank 0: join the gathered fragments of every rank (tada MAIN_ASM_SN build_edges) */
 int snk_shard_join(snk_ctx* ctx, uint32_t K, uint64_t n_frags, const void* d_nk, const void* d_hl_self, const void* d_hl_nb,
                    const void* d_boff, const void* d_bases, uint64_t total_bases, snk_shard_unitigs* out, void* stream,
                    char* err, size_t errcap);
+/* the same with the links already decided (d_flink: u32[2*n_frags], modified; d_hl_self/d_hl_nb may then be NULL) */
+int snk_shard_join_linked(snk_ctx* ctx, uint32_t K, uint64_t n_frags, const void* d_nk, const void* d_hl_self, const void* d_hl_nb,
+                          void* d_flink, const void* d_boff, const void* d_bases, uint64_t total_bases, snk_shard_unitigs* out,
+                          void* stream, char* err, size_t errcap);
 
 /* ---- host-pointer convenience + graph hand-off -------------- */
 typedef struct snk_reads {

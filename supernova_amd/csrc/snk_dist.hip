@@ -28,6 +28,10 @@ struct snk_shard_state {
     snk_table tab{};
     snk_dist_graph g{};
     snk_bl_state bl{};
+    snk_frag_out frags{};              // this rank's fragments (valid from snk_shard_fragments on)
+    const unsigned long long* d_node_off = nullptr;
+    unsigned long long my_node_off = 0, my_end_base = 0;
+    unsigned long long *lq_count = nullptr, *lq_cursor = nullptr;
     snk_phase_timer* tm = nullptr;
 };
 
@@ -144,6 +148,9 @@ extern "C" int snk_shard_fragments(snk_ctx* ctx, const void* d_node_off, uint64_
     snk_frag_out fo;
     int rc = snk_bl_dist_fragments(ctx, st, &S->bl, (const unsigned long long*)d_node_off, my_node_off, &fo, err, errcap);
     if (rc) return rc;
+    S->frags = fo;
+    S->d_node_off = (const unsigned long long*)d_node_off;
+    S->my_node_off = my_node_off;
     memset(out, 0, sizeof *out);
     out->n_kmers = S->tab.n;
     out->keys = S->tab.keys;
@@ -168,15 +175,65 @@ extern "C" int snk_shard_fragments(snk_ctx* ctx, const void* d_node_off, uint64_
     return SNK_OK;
 }
 
+// ---- fragment links decided on the owners (instead of a hash match over every end on rank 0)
+extern "C" int snk_shard_links_plan(snk_ctx* ctx, uint64_t my_frag_off, uint64_t* h_qcount, void* stream, char* err, size_t errcap) {
+    if (!ctx || !ctx->shard || !h_qcount) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_links_plan: NULL argument / no session");
+    snk_shard_state* S = state_of(ctx);
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    S->my_end_base = 2ull * my_frag_off;
+    void* q;
+    int rc;
+    if ((rc = snk_ctx_alloc(ctx, (S->world + 1) * 8ull, &q, err, errcap))) return rc; S->lq_count = (unsigned long long*)q;
+    if ((rc = snk_ctx_alloc(ctx, (S->world + 1) * 8ull, &q, err, errcap))) return rc; S->lq_cursor = (unsigned long long*)q;
+    SNK_HIP_TRY(hipMemsetAsync(S->lq_count, 0, (S->world + 1) * 8ull, st));
+    if ((rc = snk_dist_links_query(ctx, st, false, &S->frags, S->d_node_off, S->world, S->my_end_base, S->lq_count, nullptr, err, errcap))) return rc;
+    std::vector<unsigned long long> h(S->world);
+    SNK_HIP_TRY(hipMemcpyAsync(h.data(), S->lq_count, S->world * 8ull, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    for (uint32_t r = 0; r < S->world; ++r) h_qcount[r] = h[r];
+    return SNK_OK;
+}
+extern "C" int snk_shard_links_fill(snk_ctx* ctx, const void* d_qoff, void* d_qbuf, void* stream, char* err, size_t errcap) {
+    if (!ctx || !ctx->shard || !d_qoff) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_links_fill: NULL argument / no session");
+    snk_shard_state* S = state_of(ctx);
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    SNK_HIP_TRY(hipMemcpyAsync(S->lq_cursor, d_qoff, (S->world + 1) * 8ull, hipMemcpyDeviceToDevice, st));
+    return snk_dist_links_query(ctx, st, true, &S->frags, S->d_node_off, S->world, S->my_end_base, S->lq_cursor, d_qbuf, err, errcap);
+}
+extern "C" int snk_shard_links_answer(snk_ctx* ctx, const void* d_queries, uint64_t nq, void* d_ans, void* stream, char* err, size_t errcap) {
+    if (!ctx || !ctx->shard) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_links_answer: no session");
+    snk_shard_state* S = state_of(ctx);
+    return snk_dist_links_answer(ctx, stream ? (hipStream_t)stream : ctx->stream, &S->frags, d_queries, nq, 2ull * S->my_node_off, 2ull * S->tab.n,
+                                 S->my_end_base, d_ans, err, errcap);
+}
+extern "C" int snk_shard_links_apply(snk_ctx* ctx, const void* d_qbuf, const void* d_ans, uint64_t nq, const void** d_flink, void* stream,
+                                     char* err, size_t errcap) {
+    if (!ctx || !ctx->shard || !d_flink) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_links_apply: NULL argument / no session");
+    snk_shard_state* S = state_of(ctx);
+    uint32_t* fl = nullptr;
+    int rc = snk_dist_links_apply(ctx, stream ? (hipStream_t)stream : ctx->stream, &S->frags, d_qbuf, d_ans, nq, &fl, err, errcap);
+    if (rc) return rc;
+    *d_flink = fl;
+    return SNK_OK;
+}
+
 extern "C" int snk_shard_join(snk_ctx* ctx, uint32_t K, uint64_t n_frags, const void* d_nk, const void* d_hl_self, const void* d_hl_nb,
                               const void* d_boff, const void* d_bases, uint64_t total_bases, snk_shard_unitigs* out, void* stream,
                               char* err, size_t errcap) {
+    return snk_shard_join_linked(ctx, K, n_frags, d_nk, d_hl_self, d_hl_nb, nullptr, d_boff, d_bases, total_bases, out, stream, err, errcap);
+}
+
+extern "C" int snk_shard_join_linked(snk_ctx* ctx, uint32_t K, uint64_t n_frags, const void* d_nk, const void* d_hl_self, const void* d_hl_nb,
+                                     void* d_flink, const void* d_boff, const void* d_bases, uint64_t total_bases, snk_shard_unitigs* out,
+                                     void* stream, char* err, size_t errcap) {
     if (!ctx || !out) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_join: NULL argument");
+    if (!d_flink && (!d_hl_self || !d_hl_nb)) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_join: need half links or links");
     if (K != 48 && K != 60) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "K=%u is not supported (48 or 60)", K);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     snk_join_out jo;
     int rc = snk_dist_join(ctx, st, K, n_frags, (const uint32_t*)d_nk, (const unsigned long long*)d_hl_self,
-                           (const unsigned long long*)d_hl_nb, (const uint64_t*)d_boff, (const uint8_t*)d_bases, total_bases, &jo, err, errcap);
+                           (const unsigned long long*)d_hl_nb, (const uint64_t*)d_boff, (const uint8_t*)d_bases, total_bases, &jo, err, errcap, nullptr, nullptr, 0,
+                           (uint32_t*)d_flink);
     if (rc) return rc;
     out->n_unitigs = jo.n_unitigs;
     out->total_bases = jo.total_bases;

@@ -65,7 +65,13 @@ int snk_dist_apply(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, const void* 
 int snk_dist_join(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const uint32_t* nk, const unsigned long long* hl_self,
                   const unsigned long long* hl_nb, const uint64_t* boff, const uint8_t* fbases, uint64_t total_fbases,
                   snk_join_out* out, char* err, size_t errcap, const uint32_t* fgroup = nullptr, const uint32_t* sfrag = nullptr,
-                  uint64_t n_states = 0);
+                  uint64_t n_states = 0, uint32_t* flink_given = nullptr);
+int snk_dist_links_query(snk_ctx* ctx, hipStream_t st, bool fill, const snk_frag_out* fr, const unsigned long long* d_node_off, uint32_t world,
+                         unsigned long long my_end_base, unsigned long long* d_count_or_cursor, void* d_qbuf, char* err, size_t errcap);
+int snk_dist_links_answer(snk_ctx* ctx, hipStream_t st, const snk_frag_out* fr, const void* d_queries, uint64_t nq, unsigned long long my_state_base,
+                          uint64_t n_local_states, unsigned long long my_end_base, void* d_ans, char* err, size_t errcap);
+int snk_dist_links_apply(snk_ctx* ctx, hipStream_t st, const snk_frag_out* fr, const void* d_qbuf, const void* d_ans, uint64_t nq, uint32_t** flink_out,
+                         char* err, size_t errcap);
 
 // ---- bucket-local graph stage (snk_local.hip): table in chunk order -> pruned contexts + canonical unitigs
 struct snk_table;

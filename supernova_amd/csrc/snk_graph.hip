@@ -802,6 +802,62 @@ __global__ void __launch_bounds__(TB) jmatch_direct_kernel(const unsigned long l
     flink[e] = out;
 }
 
+// ---- sharded runs: fragment links decided on the owners.  An end whose half link names a state of rank q asks q (24 bytes:
+// target state, my state, my global end id | my local end << 32); q looks the state up in its terminal-state table and
+// answers with the global id of the end that sits there and points back, or NONE.
+template <bool FILL>
+__global__ void __launch_bounds__(TB) jlink_query_kernel(const unsigned long long* __restrict__ hl_self, const unsigned long long* __restrict__ hl_nb,
+                                                         uint64_t ne, const unsigned long long* __restrict__ node_off, uint32_t world,
+                                                         unsigned long long my_end_base, unsigned long long* __restrict__ qcount_or_cursor,
+                                                         unsigned long long* __restrict__ qbuf) {
+    extern __shared__ unsigned long long dynl[];          // [world] counts -> reserved bases, then [world] u32 local cursors
+    uint32_t* lcur = reinterpret_cast<uint32_t*>(dynl + world);
+    for (uint32_t r = threadIdx.x; r < world; r += TB) { dynl[r] = 0; lcur[r] = 0; }
+    __syncthreads();
+    const uint64_t e = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    unsigned long long nb = NONE64;
+    uint32_t owner = 0;
+    if (e < ne) nb = hl_nb[e];
+    if (nb != NONE64) {
+        const unsigned long long node = nb >> 1;
+        while (owner + 1 < world && node >= node_off[owner + 1]) ++owner;
+        atomicAdd(&dynl[owner], 1ull);
+    }
+    __syncthreads();
+    for (uint32_t r = threadIdx.x; r < world; r += TB) {
+        const unsigned long long c = dynl[r];
+        if (c) dynl[r] = FILL ? atomicAdd(&qcount_or_cursor[r], c) : (atomicAdd(&qcount_or_cursor[r], c), 0ull);
+    }
+    if (!FILL) return;
+    __syncthreads();
+    if (nb != NONE64) {
+        const unsigned long long slot = dynl[owner] + atomicAdd(&lcur[owner], 1u);
+        qbuf[3 * slot + 0] = nb;
+        qbuf[3 * slot + 1] = hl_self[e];
+        qbuf[3 * slot + 2] = (my_end_base + e) | ((unsigned long long)e << 32);
+    }
+}
+__global__ void __launch_bounds__(TB) jlink_answer_kernel(const unsigned long long* __restrict__ q, uint64_t nq,
+                                                          const unsigned long long* __restrict__ hl_self, const unsigned long long* __restrict__ hl_nb,
+                                                          uint64_t ne, const uint32_t* __restrict__ sfrag, unsigned long long my_state_base,
+                                                          uint64_t n_local_states, unsigned long long my_end_base, uint32_t* __restrict__ ans) {
+    const uint64_t t = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (t >= nq) return;
+    const unsigned long long target = q[3 * t], asker = q[3 * t + 1];
+    uint32_t out = NONE;
+    if (target >= my_state_base && target - my_state_base < n_local_states) {
+        const uint32_t e2 = sfrag[target - my_state_base];
+        if (e2 < ne && hl_self[e2] == target && hl_nb[e2] == asker) out = (uint32_t)(my_end_base + e2);
+    }
+    ans[t] = out;
+}
+__global__ void __launch_bounds__(TB) jlink_apply_kernel(const unsigned long long* __restrict__ q, const uint32_t* __restrict__ ans, uint64_t nq,
+                                                         uint32_t* __restrict__ flink) {
+    const uint64_t t = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (t >= nq) return;
+    flink[(uint32_t)(q[3 * t + 2] >> 32)] = ans[t];
+}
+
 struct frag_place { uint32_t pid, other; uint64_t N; uint64_t koff; bool rc; };
 __device__ __forceinline__ frag_place frag_place_of(const uint2* rk, const uint32_t* nk, uint64_t f) {
     const uint2 a = rk[2 * f], b = rk[2 * f + 1];
@@ -1049,7 +1105,8 @@ int snk_dist_apply(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, const void* 
 // rank 0: fragments of every rank -> canonical unitigs
 int snk_dist_join(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const uint32_t* nk, const unsigned long long* hl_self,
                   const unsigned long long* hl_nb, const uint64_t* boff, const uint8_t* fbases, uint64_t total_fbases,
-                  snk_join_out* out, char* err, size_t errcap, const uint32_t* fgroup, const uint32_t* sfrag, uint64_t n_states) {
+                  snk_join_out* out, char* err, size_t errcap, const uint32_t* fgroup, const uint32_t* sfrag, uint64_t n_states,
+                  uint32_t* flink_given) {
     memset(out, 0, sizeof *out);
     if (F == 0) {
         G_ALLOC(out->unitig_off, uint64_t, 1);
@@ -1058,9 +1115,10 @@ int snk_dist_join(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
     }
     if (F >= (1ull << 31)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "more than 2^31 fragments at the join (%llu)", (unsigned long long)F);
     const uint64_t ne = 2 * F;
-    uint32_t* flink;
-    G_ALLOC(flink, uint32_t, ne);
-    if (sfrag) {
+    uint32_t* flink = flink_given;          // sharded runs: the links were decided on the owners (jlink_* kernels)
+    if (!flink) G_ALLOC(flink, uint32_t, ne);
+    if (flink_given) {
+    } else if (sfrag) {
         hipLaunchKernelGGL(jmatch_direct_kernel, dim3(nblk(ne)), dim3(TB), 0, st, hl_self, hl_nb, ne, sfrag, n_states, flink);
     } else {
         uint64_t tg = 1024;
@@ -1212,5 +1270,37 @@ int snk_spectrum(snk_ctx* ctx, hipStream_t st, const uint32_t* counts, uint64_t 
     }
     *bins_out = bins;
     *nbins_out = nbins;
+    return SNK_OK;
+}
+
+// ---- sharded runs: link matching on the owners
+int snk_dist_links_query(snk_ctx* ctx, hipStream_t st, bool fill, const snk_frag_out* fr, const unsigned long long* d_node_off, uint32_t world,
+                         unsigned long long my_end_base, unsigned long long* d_count_or_cursor, void* d_qbuf, char* err, size_t errcap) {
+    const uint64_t ne = 2 * fr->n_frags;
+    if (ne == 0) return SNK_OK;
+    if (ne >= (1ull << 32)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "more than 2^31 fragments on one rank");
+    const size_t lds = (size_t)world * 12 + 16;
+    if (fill) hipLaunchKernelGGL((jlink_query_kernel<true>), dim3(nblk(ne)), dim3(TB), lds, st, fr->hl_self, fr->hl_nb, ne, d_node_off, world, my_end_base, d_count_or_cursor, (unsigned long long*)d_qbuf);
+    else hipLaunchKernelGGL((jlink_query_kernel<false>), dim3(nblk(ne)), dim3(TB), lds, st, fr->hl_self, fr->hl_nb, ne, d_node_off, world, my_end_base, d_count_or_cursor, (unsigned long long*)nullptr);
+    SNK_HIP_TRY(hipGetLastError());
+    return SNK_OK;
+}
+int snk_dist_links_answer(snk_ctx* ctx, hipStream_t st, const snk_frag_out* fr, const void* d_queries, uint64_t nq, unsigned long long my_state_base,
+                          uint64_t n_local_states, unsigned long long my_end_base, void* d_ans, char* err, size_t errcap) {
+    if (nq) hipLaunchKernelGGL(jlink_answer_kernel, dim3(nblk(nq)), dim3(TB), 0, st, (const unsigned long long*)d_queries, nq, fr->hl_self, fr->hl_nb,
+                               2 * fr->n_frags, fr->sfrag, my_state_base, n_local_states, my_end_base, (uint32_t*)d_ans);
+    SNK_HIP_TRY(hipGetLastError());
+    return SNK_OK;
+}
+int snk_dist_links_apply(snk_ctx* ctx, hipStream_t st, const snk_frag_out* fr, const void* d_qbuf, const void* d_ans, uint64_t nq, uint32_t** flink_out,
+                         char* err, size_t errcap) {
+    const uint64_t ne = 2 * fr->n_frags;
+    uint32_t* flink;
+    G_ALLOC(flink, uint32_t, ne + 2);
+    SNK_HIP_TRY(hipMemsetAsync(flink, 0xFF, (ne + 2) * 4, st));
+    if (nq) hipLaunchKernelGGL(jlink_apply_kernel, dim3(nblk(nq)), dim3(TB), 0, st, (const unsigned long long*)d_qbuf, (const uint32_t*)d_ans, nq, flink);
+    SNK_HIP_TRY(hipGetLastError());
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    *flink_out = flink;
     return SNK_OK;
 }

@@ -540,7 +540,7 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
         hl_nb[2 * f] = with_half ? half_link(pid) : NONE64;
         hl_nb[2 * f + 1] = with_half ? half_link(other) : NONE64;
         bstart[f] = c_boff + rel;
-        if (!DIST && sfrag) { sfrag[2 * ch.base + pid] = (uint32_t)(2 * f); sfrag[2 * ch.base + other] = (uint32_t)(2 * f + 1); }
+        if (sfrag) { sfrag[2 * ch.base + pid] = (uint32_t)(2 * f); sfrag[2 * ch.base + other] = (uint32_t)(2 * f + 1); }
         if (GR) fgroup[f] = (uint32_t)klo[head_node];
         foffL[pid] = (uint16_t)rel;
         hnode[lf] = (uint16_t)((head_node << 1) | (head_rc ? 1u : 0u));
@@ -585,7 +585,7 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
                 hl_nb[2 * f] = NONE64;
                 hl_nb[2 * f + 1] = NONE64;
                 bstart[f] = bo;
-                if (!DIST && sfrag) { sfrag[2 * ch.base + pid] = (uint32_t)(2 * f); sfrag[2 * ch.base + e] = (uint32_t)(2 * f + 1); }
+                if (sfrag) { sfrag[2 * ch.base + pid] = (uint32_t)(2 * f); sfrag[2 * ch.base + e] = (uint32_t)(2 * f + 1); }
                 if (GR) fgroup[f] = (uint32_t)klo[i];
                 snk_kmer k;
                 k.hi = khi[i];
@@ -881,8 +881,7 @@ static int bl_fragments_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, cons
         G_ALLOC(out->bases, uint8_t, h_B + xb_cap + 16);
         out->fgroup = nullptr;
         if (GR) G_ALLOC(out->fgroup, uint32_t, (uint64_t)h_F + xf_cap + 1);
-        out->sfrag = nullptr;
-        if (!DIST) G_ALLOC(out->sfrag, uint32_t, 2 * tab->n + 2);
+        G_ALLOC(out->sfrag, uint32_t, 2 * tab->n + 2);      // terminal state (local numbering) -> 2 * local fragment + end
         SNK_HIP_TRY(hipMemsetAsync(xcur, 0, 16, st));
         bl_extra_pool xp;
         xp.cur = xcur;

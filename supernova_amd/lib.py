@@ -162,6 +162,11 @@ def _declare(lib: C.CDLL) -> None:
         "snk_shard_prune_apply": (C.c_int, [vp, vp, vp, u64, vp, vp, cp, sz]),
         "snk_shard_fragments": (C.c_int, [vp, vp, u64, P(SnkShardFrags), vp, cp, sz]),
         "snk_shard_join": (C.c_int, [vp, u32, u64, vp, vp, vp, vp, vp, u64, P(SnkShardUnitigs), vp, cp, sz]),
+        "snk_shard_join_linked": (C.c_int, [vp, u32, u64, vp, vp, vp, vp, vp, vp, u64, P(SnkShardUnitigs), vp, cp, sz]),
+        "snk_shard_links_plan": (C.c_int, [vp, u64, P(u64), vp, cp, sz]),
+        "snk_shard_links_fill": (C.c_int, [vp, vp, vp, vp, cp, sz]),
+        "snk_shard_links_answer": (C.c_int, [vp, vp, u64, vp, vp, cp, sz]),
+        "snk_shard_links_apply": (C.c_int, [vp, vp, vp, u64, P(vp), vp, cp, sz]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

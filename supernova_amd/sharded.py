@@ -6,7 +6,8 @@ The k-mer space is cut into NB_total minimiser buckets, rank r owns a contiguous
   all-to-all #2  supermer records (32 B each)                  -> every k-mer instance meets its owner
   all-to-all #3  membership queries for cross-rank neighbours  (24 B each, ~0.15 per retained k-mer)
   all-to-all #4  answers (4 B each)
-  gather         local unitig fragments -> rank 0, which joins them (tada's MAIN_ASM_SN)
+  all-to-all #5/#6  fragment-link queries (24 B per fragment end with a remote neighbour) and answers (4 B)
+  gather         fragments (k-mers, links, bases) -> rank 0, which ranks and writes them (tada's MAIN_ASM_SN)
 Reference counterpart: the shardio exchange files + SHARD_ASM chunks + MAIN_ASM_SN of lib/tada
 (rust-shardio/src/shard.rs:184-211,488-493; cmd_shard_asm.rs:37-94; cmd_main_asm.rs:25-89).
 """
@@ -381,11 +382,35 @@ class ShardedEngine:
                 _copy_d2d(t.data_ptr(), ptr, nbytes)
             return t[:nbytes]
 
+        # ---- links between fragments, decided on the owners: an end asks the rank that owns the state it points at
+        all_F = comm.all_gather_int(F, dev)
+        frag_off = [0]
+        for x in all_F:
+            frag_off.append(frag_off[-1] + x)
+        if 2 * frag_off[-1] >= (1 << 32):
+            raise _lib.SnkError(-6, "more than 2^31 fragments in the job")
+        lq = (C.c_uint64 * W)()
+        chk(lib.snk_shard_links_plan(e._ctx, frag_off[me], lq, st, err, 512))
+        lqc = [int(x) for x in lq]
+        lqoff = torch.zeros(W + 1, dtype=torch.int64, device=dev)
+        lqoff[1:] = torch.cumsum(torch.tensor(lqc, dtype=torch.int64, device=dev), 0)
+        nlq = sum(lqc)
+        lqbuf = pool.get("lqbuf", max(nlq, 1) * 24)
+        chk(lib.snk_shard_links_fill(e._ctx, lqoff.data_ptr(), lqbuf.data_ptr(), st, err, 512))
+        lqin, lqin_bytes = comm.all_to_all_v(lqbuf[: nlq * 24], [c * 24 for c in lqc], alloc=lambda nb: pool.get("lqin", nb))
+        nlq_in = lqin.numel() // 24
+        lans = pool.get("lans", max(nlq_in, 1) * 4)
+        chk(lib.snk_shard_links_answer(e._ctx, lqin.data_ptr(), nlq_in, lans.data_ptr(), st, err, 512))
+        lans_back, _ = comm.all_to_all_v(lans[: nlq_in * 4], [b // 24 * 4 for b in lqin_bytes], alloc=lambda nb: pool.get("lans_back", nb))
+        assert lans_back.numel() == nlq * 4
+        flink_p = C.c_void_p()
+        chk(lib.snk_shard_links_apply(e._ctx, lqbuf.data_ptr(), lans_back.data_ptr(), nlq, C.byref(flink_p), st, err, 512))
+        res.n_link_queries = nlq
+        # ---- gather on rank 0: k-mers per fragment, links, starts, bases
         to0 = lambda n: [n if q == 0 else 0 for q in range(W)]
         TB = int(fr.total_bases)
         t_nk, _ = comm.all_to_all_v(dcopy("s_nk", fr.nk, F * 4), to0(F * 4), alloc=lambda nb: pool.get("g_nk", nb))
-        t_self, _ = comm.all_to_all_v(dcopy("s_self", fr.hl_self, F * 16), to0(F * 16), alloc=lambda nb: pool.get("g_self", nb))
-        t_nb, _ = comm.all_to_all_v(dcopy("s_nb", fr.hl_nb, F * 16), to0(F * 16), alloc=lambda nb: pool.get("g_nb", nb))
+        t_link, _ = comm.all_to_all_v(dcopy("s_link", flink_p.value, F * 8), to0(F * 8), alloc=lambda nb: pool.get("g_link", nb))
         t_start, start_bytes = comm.all_to_all_v(dcopy("s_start", fr.boff, F * 8), to0(F * 8), alloc=lambda nb: pool.get("g_start", nb))
         t_bases, base_bytes = comm.all_to_all_v(dcopy("s_bases", fr.bases, TB), to0(TB), alloc=lambda nb: pool.get("g_bases", nb))
         res.joined = None
@@ -400,12 +425,14 @@ class ShardedEngine:
             starts_all = (starts + torch.repeat_interleave(shift[:W], per_rank)).contiguous()
             if starts_all.numel() == 0:
                 starts_all = torch.zeros(1, dtype=torch.int64, device=dev)
+            if t_link.numel() == 0:
+                t_link = torch.zeros(8, dtype=torch.uint8, device=dev)
             un = _lib.SnkShardUnitigs()
-            chk(lib.snk_shard_join(e._ctx, K, Ft, t_nk.data_ptr(), t_self.data_ptr(), t_nb.data_ptr(), starts_all.data_ptr(),
-                                   t_bases.data_ptr(), t_bases.numel(), C.byref(un), st, err, 512))
+            chk(lib.snk_shard_join_linked(e._ctx, K, Ft, t_nk.data_ptr(), None, None, t_link.data_ptr(), starts_all.data_ptr(),
+                                          t_bases.data_ptr(), t_bases.numel(), C.byref(un), st, err, 512))
             res.joined = un
             res.n_unitigs = int(un.n_unitigs)
-            res._keep = (t_nk, t_self, t_nb, starts_all, t_bases)
+            res._keep = (t_nk, t_link, starts_all, t_bases)
         ev[7].record()
         torch.cuda.synchronize()
         names = ["partition", "compact", "exchange", "count", "prune", "fragments", "join"]
