@@ -6,10 +6,43 @@
 // K2 replaces base_to_bits (lib/tada/src/kmer/mod.rs:311-319) / the N->A rule of
 //    10X/ParseBarcodedFastqs.cc:87-88.
 //
-// Both are HBM-streaming byte kernels.  K1 reads only the tail of each quality row that the scan
-// really needs (a clean read stops after K bytes), in 4-byte words.
+// Both are HBM-streaming byte kernels.  K1 stops at the first run (a clean read is decided by its last K bytes).
 #include "snk_ctx.h"
 #include "snk_common.h"
+#include "snk_stages.h"
+
+// the scan of one quality row (global or LDS memory); rows whose base is 4-byte aligned are read in words
+__device__ __forceinline__ int snk_trim_row(const uint8_t* q, int len, bool row_aligned, uint32_t K, uint32_t min_qual) {
+    uint32_t good = 0;
+    int i = len;
+    if (row_aligned) {
+        while (i > 0 && (i & 3)) {
+            --i;
+            if (q[i] < min_qual) good = 0;
+            else if (++good == K) return i + (int)K;
+        }
+        while (i >= 4) {
+            uint32_t w = *reinterpret_cast<const uint32_t*>(q + i - 4);
+            int found = -1;
+#pragma unroll
+            for (int b = 3; b >= 0; --b) {
+                uint32_t v = (w >> (8 * b)) & 0xFFu;
+                if (found < 0) {
+                    if (v < min_qual) good = 0;
+                    else if (++good == K) found = i - 4 + b + (int)K;
+                }
+            }
+            if (found >= 0) return found;
+            i -= 4;
+        }
+    }
+    while (i > 0) {
+        --i;
+        if (q[i] < min_qual) good = 0;
+        else if (++good == K) return i + (int)K;
+    }
+    return 0;
+}
 
 __global__ void __launch_bounds__(256) snk_trim_kernel(const uint8_t* __restrict__ quals, uint32_t qstride,
                                                        const uint16_t* __restrict__ lens, uint32_t read_len,
@@ -19,38 +52,33 @@ __global__ void __launch_bounds__(256) snk_trim_kernel(const uint8_t* __restrict
     if (r >= n_reads) return;
     const uint8_t* q = quals + r * (uint64_t)qstride;
     int len = lens ? lens[r] : (int)read_len;
-    uint32_t good = 0;
-    int result = 0;
-    int i = len;
-    // unaligned head (from the end) byte-wise until i is a multiple of 4 relative to the row base alignment
     const bool row_aligned = ((qstride & 3u) == 0) && ((((uintptr_t)quals) & 3u) == 0);
-    if (row_aligned) {
-        while (i > 0 && (i & 3)) {
-            --i;
-            if (q[i] < min_qual) good = 0;
-            else if (++good == K) { result = i + (int)K; i = -1; break; }
-        }
-        while (i >= 4) {
-            uint32_t w = *reinterpret_cast<const uint32_t*>(q + i - 4);
-            bool done = false;
-#pragma unroll
-            for (int b = 3; b >= 0; --b) {
-                uint32_t v = (w >> (8 * b)) & 0xFFu;
-                if (!done) {
-                    if (v < min_qual) good = 0;
-                    else if (++good == K) { result = i - 4 + b + (int)K; done = true; }
-                }
-            }
-            if (done) { i = -1; break; }
-            i -= 4;
-        }
+    good_len[r] = (uint16_t)snk_trim_row(q, len, row_aligned, K, min_qual);
+}
+
+// Tiled form for short rows (qstride % 4 == 0, 256 rows fit in LDS): the 256 rows of a workgroup are contiguous
+// in memory, so they are streamed into LDS with 16-byte loads (every fetched byte of every cache line is used; a
+// lane that walks its own row in global memory keeps 64 different lines in flight per load and stalls on the
+// miss queue), then each lane scans its row out of LDS.
+__global__ void __launch_bounds__(256) snk_trim_tile_kernel(const uint8_t* __restrict__ quals, uint32_t qstride,
+                                                            const uint16_t* __restrict__ lens, uint32_t read_len,
+                                                            uint64_t n_reads, uint32_t K, uint32_t min_qual,
+                                                            uint16_t* __restrict__ good_len) {
+    extern __shared__ uint4 tile4[];
+    uint8_t* tile = reinterpret_cast<uint8_t*>(tile4);
+    const uint64_t r0 = (uint64_t)blockIdx.x * 256;
+    const uint64_t rows_here = n_reads - r0 < 256 ? n_reads - r0 : 256;
+    const uint32_t bytes = (uint32_t)rows_here * qstride;
+    const uint8_t* src = quals + r0 * qstride;             // 16-byte aligned: 256 * qstride is a multiple of 16
+    for (uint32_t o = threadIdx.x * 16; o < bytes; o += 256 * 16) {
+        if (o + 16 <= bytes) *reinterpret_cast<uint4*>(tile + o) = *reinterpret_cast<const uint4*>(src + o);
+        else for (uint32_t j = o; j < bytes; ++j) tile[j] = src[j];
     }
-    while (i > 0) {
-        --i;
-        if (q[i] < min_qual) good = 0;
-        else if (++good == K) { result = i + (int)K; break; }
-    }
-    good_len[r] = (uint16_t)result;
+    __syncthreads();
+    if (threadIdx.x >= rows_here) return;
+    const uint64_t r = r0 + threadIdx.x;
+    int len = lens ? lens[r] : (int)read_len;
+    good_len[r] = (uint16_t)snk_trim_row(tile + threadIdx.x * qstride, len, true, K, min_qual);
 }
 
 extern "C" int snk_dev_trim(snk_ctx* ctx, const void* d_quals, uint32_t qstride, const void* d_lens, uint32_t read_len,
@@ -62,8 +90,13 @@ extern "C" int snk_dev_trim(snk_ctx* ctx, const void* d_quals, uint32_t qstride,
     if (n_reads == 0) return SNK_OK;
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     uint64_t nb = (n_reads + 255) / 256;
-    hipLaunchKernelGGL(snk_trim_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const uint8_t*)d_quals, qstride,
-                       (const uint16_t*)d_lens, read_len, n_reads, K, min_qual, (uint16_t*)d_good_len);
+    const bool tiled = (qstride & 3u) == 0 && qstride <= 160 && (((uintptr_t)d_quals) & 15u) == 0 && !snk_env_u32("SNK_TRIM_ROWWISE", 0);
+    if (tiled)
+        hipLaunchKernelGGL(snk_trim_tile_kernel, dim3((unsigned)nb), dim3(256), 256 * qstride, st, (const uint8_t*)d_quals, qstride,
+                           (const uint16_t*)d_lens, read_len, n_reads, K, min_qual, (uint16_t*)d_good_len);
+    else
+        hipLaunchKernelGGL(snk_trim_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const uint8_t*)d_quals, qstride,
+                           (const uint16_t*)d_lens, read_len, n_reads, K, min_qual, (uint16_t*)d_good_len);
     SNK_HIP_TRY(hipGetLastError());
     return SNK_OK;
 }

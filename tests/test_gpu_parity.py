@@ -131,6 +131,15 @@ def test_pack_ascii_and_trim_kernels(engine):
     for mq in (7, 10, 31):
         g = engine.trim(quals, c.read_len, K=48, min_qual=mq, lens=lens).cpu().numpy().view(np.uint16)
         assert np.array_equal(g.astype(np.uint32), oracle_lib.good_lens(c.quals, c.lens, K=48, min_qual=mq))
+    # rows padded to a multiple of 4 bytes take the LDS-tiled kernel: ragged lengths, a row count that is not a
+    # multiple of the 256-row tile, garbage in the padding
+    rng = np.random.default_rng(5)
+    for n in (1, 255, 257, 1000, len(c.lens)):
+        qp = rng.integers(0, 41, (n, 152), dtype=np.uint8)
+        qp[:, :c.read_len] = c.quals[:n]
+        for mq, K in ((7, 48), (10, 60)):
+            g = engine.trim(torch.from_numpy(qp).to(dev), c.read_len, K=K, min_qual=mq, lens=lens[:n].contiguous()).cpu().numpy().view(np.uint16)
+            assert np.array_equal(g.astype(np.uint32), oracle_lib.good_lens(c.quals[:n], c.lens[:n], K=K, min_qual=mq))
 
 
 @pytest.mark.parametrize("name,use_bc", [("adversarial", True), ("synth_20k_err", False)])
