@@ -281,7 +281,11 @@ int snk_read_bv(const char* path, uint64_t* n_unitigs, uint64_t** unitig_off, ui
 /* a14: buildHBVFromEdges (lib/assembly/src/paths/long/HBVFromEdges.cc:244-296): vertices = distinct (K-1)-mer
  * unitig ends, HBV edges = every unitig and its reverse complement (palindromes once), ids assigned by the
  * reference's deterministic flood fill over the BVComp edge order.  Unitigs must be in BVComp order.
- * Host-side (the reference's own step is a sequential flood fill; small next to counting). */
+ * snk_hbv_from_unitigs takes host arrays in BVComp order.  snk_dev_hbv takes the device-resident unitigs of
+ * snk_dev_count_graph (any order): BVComp ranking, the
+ * (K-1)-mer end keys, their sort and the vertex classes are computed on the device (what the reference runs through
+ * its MapReduce engine, HBVFromEdges.cc:136-168,257-262); the id hand-out, a breadth-first flood whose ids ARE the
+ * visiting order (:170-238), runs on the host over the downloaded classes. */
 typedef struct snk_hbv {
     int32_t n_vertices, n_edges;
     int32_t* v_left;            /* per HBV edge */
@@ -290,9 +294,14 @@ typedef struct snk_hbv {
     uint8_t* is_rc;
     int32_t* fwd_xlat;          /* per unitig: HBV edge id of the forward / reverse-complement copy */
     int32_t* rev_xlat;
+    int32_t* bvcomp_order;      /* snk_dev_hbv: per BVComp rank (the unitig numbering above) the index of that unitig
+                                   in the caller's device arrays; NULL from snk_hbv_from_unitigs (input already ranked) */
 } snk_hbv;
 int snk_hbv_from_unitigs(uint32_t K, uint64_t n_unitigs, const uint64_t* unitig_off, const uint8_t* unitig_bases,
                          snk_hbv* out, char* err, size_t errcap);
+/* device_ms (optional): time of the device part, HIP events */
+int snk_dev_hbv(snk_ctx* ctx, uint32_t K, uint64_t n_unitigs, const void* d_unitig_off, const void* d_unitig_bases,
+                snk_hbv* out, float* device_ms, void* stream, char* err, size_t errcap);
 void snk_hbv_free(snk_hbv* h);
 
 /* ---- stage-input formats of ASSEMBLER_DF (mro/_assembler_stages.mro:24-39) ----------- */

@@ -1,0 +1,328 @@
+// snk_hbv.hip -- a14: the graph-from-unitigs step, buildHBVFromEdges (lib/assembly/src/paths/long/HBVFromEdges.cc:244-296).
+//
+//   VertexDictBuilder::map (:136-145) emits 4 edge ends per unitig (2 for a palindrome); a vertex is one distinct
+//   (K-1)-mer and lists its incident (edge, rc) pairs in EEComp order (:113-122); HBVBuilder (:170-238) floods from
+//   every edge in BVComp order (:106-111: length descending, then lexicographic), forward copies first, and hands out
+//   vertex and edge ids in visiting order.
+//
+// Two entry points produce the same snk_hbv:
+//   snk_hbv_from_unitigs : host arrays that are already in BVComp order (the .bv file, snk_count_graph's output)
+//   snk_dev_hbv          : unitigs resident in HBM, in any order (the output of snk_dev_count_graph).
+//        The data-parallel part -- what the reference runs through its MapReduce engine -- is done on the device:
+//        BVComp rank of every unitig (radix sort by first k-mer -- two unitigs never share it, so it decides the
+//        lexicographic comparison -- then a stable one by length), the palindrome test, the 4U (K-1)-mer end keys
+//        (128-bit, MSB first), their stable radix sort (EEComp == generation order), vertex classes by a flag scan.
+//        Only the id hand-out, a breadth-first flood that is sequential by definition (ids are visiting order), runs
+//        on the host over the downloaded classes: 4U + U + #vertices words.
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include <rocprim/rocprim.hpp>
+
+#include "snk_ctx.h"
+#include "snk_common.h"
+#include "snk_kernels.h"
+
+namespace {
+
+// ee[]: edge ends in vertex-major order, code = rank*4 + rc*2 + distal; run_beg[v..v+1] delimits vertex class v;
+// vtx_of[code] = class (or -1).  Fills every array of `out`.
+int hbv_flood(uint64_t U, const uint8_t* pal, const uint32_t* ee, uint64_t n_ee, const int32_t* vtx_of, const uint64_t* run_beg,
+              uint64_t nruns, snk_hbv* out, char* err, size_t errcap) {
+    out->n_vertices = (int32_t)nruns;
+    out->fwd_xlat = (int32_t*)malloc(U * 4);
+    out->rev_xlat = (int32_t*)malloc(U * 4);
+    out->v_left = (int32_t*)malloc(2 * U * 4);
+    out->v_right = (int32_t*)malloc(2 * U * 4);
+    out->src_unitig = (int32_t*)malloc(2 * U * 4);
+    out->is_rc = (uint8_t*)malloc(2 * U);
+    if (!out->fwd_xlat || !out->rev_xlat || !out->v_left || !out->v_right || !out->src_unitig || !out->is_rc) {
+        snk_hbv_free(out);
+        return snk_fail(SNK_E_NOMEM, err, errcap, "snk_hbv: host allocation failed");
+    }
+    for (uint64_t i = 0; i < U; ++i) out->fwd_xlat[i] = out->rev_xlat[i] = -1;
+    std::vector<int32_t> vid(nruns, -1);
+    int32_t next_v = 0, next_e = 0;
+    std::vector<uint64_t> q;          // FIFO: [head, size); emptied whenever a component is finished
+    size_t head = 0;
+    auto done = [&](uint64_t e, int rc) { return (rc ? out->rev_xlat : out->fwd_xlat)[e] != -1; };
+    (void)n_ee;
+    for (int pass = 0; pass < 2; ++pass)
+        for (uint64_t e0 = 0; e0 < U; ++e0) {
+            if (done(e0, pass)) continue;
+            q.clear();
+            head = 0;
+            q.push_back(e0 * 2 + pass);
+            while (head < q.size()) {
+                const uint64_t x = q[head++];
+                const uint64_t e = x >> 1;
+                const int rc = (int)(x & 1);
+                if (done(e, rc)) continue;
+                int32_t r1 = vtx_of[e * 4 + rc * 2 + 0], r2 = vtx_of[e * 4 + rc * 2 + 1];
+                if (pal[e] && rc) { r1 = vtx_of[e * 4 + 0]; r2 = vtx_of[e * 4 + 1]; }
+                if (vid[r1] == -1) vid[r1] = next_v++;
+                if (vid[r2] == -1) vid[r2] = next_v++;
+                const int32_t id = next_e++;
+                out->v_left[id] = vid[r1]; out->v_right[id] = vid[r2];
+                out->src_unitig[id] = (int32_t)e; out->is_rc[id] = (uint8_t)rc;
+                if (!rc || pal[e]) out->fwd_xlat[e] = id;
+                if (rc || pal[e]) out->rev_xlat[e] = id;
+                for (int side = 0; side < 2; ++side) {
+                    const int32_t r = side ? r2 : r1;
+                    for (uint64_t j = run_beg[r]; j < run_beg[r + 1]; ++j) {
+                        const uint64_t ed = ee[j] >> 2;
+                        const int erc = (int)((ee[j] >> 1) & 1u);
+                        if (!done(ed, erc)) q.push_back(ed * 2 + erc);
+                    }
+                }
+            }
+        }
+    out->n_edges = next_e;
+    return SNK_OK;
+}
+
+}  // namespace
+
+extern "C" int snk_hbv_from_unitigs(uint32_t K, uint64_t U, const uint64_t* off, const uint8_t* bases, snk_hbv* out, char* err, size_t errcap) {
+    if (!out) return snk_fail(SNK_E_ARG, err, errcap, "snk_hbv_from_unitigs: NULL argument");
+    memset(out, 0, sizeof *out);
+    if (U == 0) return SNK_OK;
+    if (U >= (1ull << 30)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_hbv_from_unitigs: too many unitigs");
+    const uint32_t kl = K - 1;
+    auto base_of = [&](uint32_t code, uint32_t j) -> uint8_t {
+        const uint64_t e = code >> 2;
+        const uint8_t* b = bases + off[e];
+        const uint64_t len = off[e + 1] - off[e];
+        const uint64_t p = (code & 1u) ? len - kl + j : j;
+        return (code & 2u) ? (uint8_t)(b[len - 1 - p] ^ 3) : b[p];
+    };
+    auto seq_cmp = [&](uint32_t a, uint32_t b) -> int {
+        for (uint32_t j = 0; j < kl; ++j) { uint8_t x = base_of(a, j), y = base_of(b, j); if (x != y) return x < y ? -1 : 1; }
+        return 0;
+    };
+    std::vector<uint8_t> pal(U);
+    std::vector<uint32_t> ee;
+    ee.reserve(4 * U);
+    for (uint64_t e = 0; e < U; ++e) {
+        const uint8_t* b = bases + off[e];
+        const uint64_t len = off[e + 1] - off[e];
+        if (len < K) return snk_fail(SNK_E_ARG, err, errcap, "snk_hbv_from_unitigs: unitig %llu shorter than K", (unsigned long long)e);
+        bool p = (len & 1) == 0;                       // getCanonicalForm == PALINDROME (dna/CanonicalForm.h:35-48)
+        for (uint64_t i = 0, j = len; p && i < j; ++i) { --j; if (b[i] != (uint8_t)(b[j] ^ 3)) p = false; }
+        pal[e] = p;
+        ee.push_back((uint32_t)e * 4 + 0);
+        ee.push_back((uint32_t)e * 4 + 1);
+        if (!p) { ee.push_back((uint32_t)e * 4 + 2); ee.push_back((uint32_t)e * 4 + 3); }
+    }
+    // EEComp: BVComp of the containers (== index order, the input is sorted), then rc, then position == code order
+    std::sort(ee.begin(), ee.end(), [&](uint32_t a, uint32_t b) {
+        int c = seq_cmp(a, b);
+        return c ? c < 0 : a < b;
+    });
+    std::vector<int32_t> vtx_of(4 * U, -1);
+    std::vector<uint64_t> run_beg;
+    for (uint64_t i = 0; i < ee.size();) {
+        uint64_t j = i + 1;
+        while (j < ee.size() && seq_cmp(ee[i], ee[j]) == 0) ++j;
+        for (uint64_t q = i; q < j; ++q) vtx_of[ee[q]] = (int32_t)run_beg.size();
+        run_beg.push_back(i);
+        i = j;
+    }
+    const uint64_t nruns = run_beg.size();
+    run_beg.push_back(ee.size());
+    return hbv_flood(U, pal.data(), ee.data(), ee.size(), vtx_of.data(), run_beg.data(), nruns, out, err, errcap);
+}
+
+extern "C" void snk_hbv_free(snk_hbv* h) {
+    if (!h) return;
+    free(h->v_left); free(h->v_right); free(h->src_unitig); free(h->is_rc); free(h->fwd_xlat); free(h->rev_xlat); free(h->bvcomp_order);
+    memset(h, 0, sizeof *h);
+}
+
+// ------------------------------------------------------------------------------------------------ device part
+namespace {
+
+constexpr int HB = 256;
+
+// per unitig: its first K bases as a 128-bit key (the lexicographic part of BVComp: two unitigs never share their
+// first k-mer), the palindrome flag, the "shorter than K" flag
+__global__ void __launch_bounds__(HB) hbv_head_kernel(const uint64_t* __restrict__ off, const uint8_t* __restrict__ bases, uint64_t U,
+                                                      uint32_t K, snk_u128* __restrict__ fkey, uint32_t* __restrict__ idx,
+                                                      uint8_t* __restrict__ pal, uint32_t* __restrict__ flags /* [0] short, [1] #palindromes */) {
+    const uint64_t u = (uint64_t)blockIdx.x * HB + threadIdx.x;
+    if (u >= U) return;
+    const uint64_t b0 = off[u], len = off[u + 1] - b0;
+    idx[u] = (uint32_t)u;
+    const uint8_t* b = bases + b0;
+    if (len < K) { atomicOr(&flags[0], 1u); fkey[u] = 0; pal[u] = 0; return; }
+    snk_u128 k = 0;
+    for (uint32_t j = 0; j < K; ++j) k = (k << 2) | (snk_u128)(b[j] & 3u);
+    fkey[u] = k;
+    // getCanonicalForm == PALINDROME (dna/CanonicalForm.h:35-48); a mismatch shows up within a few bases
+    bool p = (len & 1) == 0;
+    for (uint64_t i = 0, j = len; p && i < j; ++i) { --j; if (b[i] != (uint8_t)(b[j] ^ 3)) p = false; }
+    pal[u] = p ? 1 : 0;
+    if (p) atomicAdd(&flags[1], 1u);
+}
+
+// second key of the ranking: length descending, taken in first-k-mer order (the sort that follows is stable)
+__global__ void __launch_bounds__(HB) hbv_lenkey_kernel(const uint64_t* __restrict__ off, const uint32_t* __restrict__ idx1, uint64_t U,
+                                                        uint64_t* __restrict__ lkey) {
+    const uint64_t i = (uint64_t)blockIdx.x * HB + threadIdx.x;
+    if (i >= U) return;
+    const uint32_t u = idx1[i];
+    lkey[i] = ~(off[u + 1] - off[u]);
+}
+
+// one thread per (BVComp rank, end): the (K-1)-mer of that end of that strand, MSB first; ends a palindrome does not
+// have sort last (all ones: a real key leaves the low 128 - 2(K-1) bits zero)
+__global__ void __launch_bounds__(HB) hbv_ends_kernel(const uint64_t* __restrict__ off, const uint8_t* __restrict__ bases,
+                                                      const uint32_t* __restrict__ order, const uint8_t* __restrict__ pal, uint64_t U,
+                                                      uint32_t K, snk_u128* __restrict__ keys, uint32_t* __restrict__ codes,
+                                                      uint8_t* __restrict__ pal_ranked) {
+    const uint64_t t = (uint64_t)blockIdx.x * HB + threadIdx.x;
+    if (t >= 4 * U) return;
+    const uint64_t r = t >> 2;
+    const uint32_t rc = (uint32_t)(t >> 1) & 1u, distal = (uint32_t)t & 1u;
+    const uint32_t u = order[r];
+    const uint64_t b0 = off[u], len = off[u + 1] - b0;
+    const uint8_t* b = bases + b0;
+    const uint32_t kl = K - 1;
+    codes[t] = (uint32_t)t;
+    if ((t & 3) == 0) pal_ranked[r] = pal[u];
+    if (rc && pal[u]) { keys[t] = ~(snk_u128)0; return; }
+    // forward strand: bases [p0, p0+kl); reverse strand: complement of the mirrored range, read backwards
+    const uint64_t p0 = distal ? len - kl : 0;
+    snk_u128 k = 0;
+    if (!rc) for (uint32_t j = 0; j < kl; ++j) k = (k << 2) | (snk_u128)(b[p0 + j] & 3u);
+    else for (uint32_t j = 0; j < kl; ++j) k = (k << 2) | (snk_u128)((b[len - 1 - (p0 + j)] ^ 3u) & 3u);
+    keys[t] = k << (128 - 2 * kl);
+}
+
+__global__ void __launch_bounds__(HB) hbv_flag_kernel(const snk_u128* __restrict__ keys, uint64_t n, uint32_t* __restrict__ flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * HB + threadIdx.x;
+    if (i >= n) return;
+    flag[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+
+// cls[i] = inclusive scan of the flags = class + 1
+__global__ void __launch_bounds__(HB) hbv_class_kernel(const uint32_t* __restrict__ cls, const uint32_t* __restrict__ flag,
+                                                       const uint32_t* __restrict__ codes, uint64_t n, int32_t* __restrict__ vtx_of,
+                                                       uint64_t* __restrict__ run_beg) {
+    const uint64_t i = (uint64_t)blockIdx.x * HB + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = cls[i] - 1u;
+    vtx_of[codes[i]] = (int32_t)c;
+    if (flag[i]) run_beg[c] = i;
+}
+
+// scratch of one call: handed back to the arena when the call returns (the unitigs it reads are scratch of the
+// preceding snk_dev_count_graph and must stay)
+struct scratch_list {
+    snk_ctx* ctx;
+    std::vector<void*> p;
+    ~scratch_list() { for (void* q : p) snk_ctx_release_block(ctx, q); }
+};
+
+template <typename T>
+int dalloc(scratch_list& sl, size_t n, T** out, char* err, size_t errcap) {
+    void* q = nullptr;
+    int rc = snk_ctx_alloc(sl.ctx, std::max<size_t>(n * sizeof(T), 16), &q, err, errcap);
+    if (!rc) sl.p.push_back(q);
+    *out = (T*)q;
+    return rc;
+}
+
+}  // namespace
+
+extern "C" int snk_dev_hbv(snk_ctx* ctx, uint32_t K, uint64_t U, const void* d_unitig_off, const void* d_unitig_bases, snk_hbv* out,
+                           float* device_ms, void* stream, char* err, size_t errcap) {
+    if (!ctx || !out) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_hbv: NULL argument");
+    memset(out, 0, sizeof *out);
+    if (device_ms) *device_ms = 0.f;
+    if (K != 48 && K != 60) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "K=%u is not supported (48 or 60)", K);
+    if (U == 0) return SNK_OK;
+    if (!d_unitig_off || !d_unitig_bases) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_hbv: NULL unitig arrays");
+    if (U >= (1ull << 30)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_dev_hbv: too many unitigs");
+    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    const uint64_t* off = (const uint64_t*)d_unitig_off;
+    const uint8_t* bases = (const uint8_t*)d_unitig_bases;
+    const uint64_t n4 = 4 * U;
+    int rc;
+    scratch_list sl{ctx, {}};
+    uint64_t *lkey, *lkey2, *run_beg;
+    uint32_t *idx, *order, *codes, *codes2, *flag, *cls, *flags;
+    uint8_t *pal, *palr;
+    snk_u128 *keys, *keys2;
+    int32_t* vtx_of;
+    if ((rc = dalloc(sl, U, &lkey, err, errcap)) || (rc = dalloc(sl, U, &lkey2, err, errcap)) || (rc = dalloc(sl, U, &idx, err, errcap)) ||
+        (rc = dalloc(sl, U, &order, err, errcap)) || (rc = dalloc(sl, U, &pal, err, errcap)) || (rc = dalloc(sl, U, &palr, err, errcap)) ||
+        (rc = dalloc(sl, n4, &keys, err, errcap)) || (rc = dalloc(sl, n4, &keys2, err, errcap)) || (rc = dalloc(sl, n4, &codes, err, errcap)) ||
+        (rc = dalloc(sl, n4, &codes2, err, errcap)) || (rc = dalloc(sl, n4, &flag, err, errcap)) || (rc = dalloc(sl, n4, &cls, err, errcap)) ||
+        (rc = dalloc(sl, n4, &vtx_of, err, errcap)) || (rc = dalloc(sl, n4 + 1, &run_beg, err, errcap)) || (rc = dalloc(sl, 4, &flags, err, errcap)))
+        return rc;
+    hipEvent_t e0, e1;
+    SNK_HIP_TRY(hipEventCreate(&e0));
+    SNK_HIP_TRY(hipEventCreate(&e1));
+    SNK_HIP_TRY(hipEventRecord(e0, st));
+    SNK_HIP_TRY(hipMemsetAsync(flags, 0, 16, st));
+    const unsigned gU = (unsigned)((U + HB - 1) / HB), g4 = (unsigned)((n4 + HB - 1) / HB);
+    hipLaunchKernelGGL(hbv_head_kernel, dim3(gU), dim3(HB), 0, st, off, bases, U, K, keys, idx, pal, flags);
+    // BVComp rank: sort by first k-mer, then stable sort by descending length
+    size_t tmp_bytes = 0, tb2 = 0, tb3 = 0;
+    SNK_HIP_TRY(rocprim::radix_sort_pairs((void*)nullptr, tmp_bytes, lkey, lkey2, idx, order, (size_t)U, 0u, 64u, st));
+    SNK_HIP_TRY(rocprim::radix_sort_pairs((void*)nullptr, tb2, keys, keys2, codes, codes2, (size_t)n4, 0u, 128u, st));
+    SNK_HIP_TRY(rocprim::inclusive_scan((void*)nullptr, tb3, flag, cls, (size_t)n4, rocprim::plus<uint32_t>(), st));
+    tmp_bytes = std::max(tmp_bytes, std::max(tb2, tb3));
+    uint8_t* tmp = nullptr;
+    if ((rc = dalloc(sl, tmp_bytes, &tmp, err, errcap))) return rc;
+    size_t tbx = tmp_bytes;
+    SNK_HIP_TRY(rocprim::radix_sort_pairs(tmp, tbx, keys, keys2, idx, codes, (size_t)U, 0u, 128u, st));   // codes = first-k-mer order
+    hipLaunchKernelGGL(hbv_lenkey_kernel, dim3(gU), dim3(HB), 0, st, off, codes, U, lkey);
+    tbx = tmp_bytes;
+    SNK_HIP_TRY(rocprim::radix_sort_pairs(tmp, tbx, lkey, lkey2, codes, order, (size_t)U, 0u, 64u, st));
+    hipLaunchKernelGGL(hbv_ends_kernel, dim3(g4), dim3(HB), 0, st, off, bases, order, pal, U, K, keys, codes, palr);
+    // vertex-major order of the ends: stable sort by the (K-1)-mer; inside a vertex the generation order (rank, rc,
+    // position) is EEComp
+    tbx = tmp_bytes;
+    SNK_HIP_TRY(rocprim::radix_sort_pairs(tmp, tbx, keys, keys2, codes, codes2, (size_t)n4, 0u, 128u, st));
+    uint32_t h_flags[4] = {0, 0, 0, 0};
+    SNK_HIP_TRY(hipMemcpyAsync(h_flags, flags, 16, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    if (h_flags[0]) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_hbv: a unitig is shorter than K");
+    const uint64_t n_ee = n4 - 2ull * h_flags[1];            // the missing ends of palindromes sorted last
+    const unsigned ge = (unsigned)((n_ee + HB - 1) / HB);
+    hipLaunchKernelGGL(hbv_flag_kernel, dim3(ge), dim3(HB), 0, st, keys2, n_ee, flag);
+    tbx = tmp_bytes;
+    SNK_HIP_TRY(rocprim::inclusive_scan(tmp, tbx, flag, cls, (size_t)n_ee, rocprim::plus<uint32_t>(), st));
+    SNK_HIP_TRY(hipMemsetAsync(vtx_of, 0xFF, n4 * 4, st));
+    hipLaunchKernelGGL(hbv_class_kernel, dim3(ge), dim3(HB), 0, st, cls, flag, codes2, n_ee, vtx_of, run_beg);
+    SNK_HIP_TRY(hipGetLastError());
+    SNK_HIP_TRY(hipEventRecord(e1, st));
+    uint32_t nruns = 0;
+    SNK_HIP_TRY(hipMemcpyAsync(&nruns, cls + (n_ee - 1), 4, hipMemcpyDeviceToHost, st));
+    std::vector<uint32_t> h_ee(n_ee), h_order(U);
+    std::vector<int32_t> h_vtx(n4);
+    std::vector<uint8_t> h_pal(U);
+    SNK_HIP_TRY(hipMemcpyAsync(h_ee.data(), codes2, n_ee * 4, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipMemcpyAsync(h_vtx.data(), vtx_of, n4 * 4, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipMemcpyAsync(h_pal.data(), palr, U, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipMemcpyAsync(h_order.data(), order, U * 4, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    std::vector<uint64_t> h_run(nruns + 1);
+    SNK_HIP_TRY(hipMemcpy(h_run.data(), run_beg, (size_t)nruns * 8, hipMemcpyDeviceToHost));
+    h_run[nruns] = n_ee;
+    if (device_ms) (void)hipEventElapsedTime(device_ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    rc = hbv_flood(U, h_pal.data(), h_ee.data(), n_ee, h_vtx.data(), h_run.data(), nruns, out, err, errcap);
+    if (rc) return rc;
+    out->bvcomp_order = (int32_t*)malloc(U * 4);
+    if (!out->bvcomp_order) { snk_hbv_free(out); return snk_fail(SNK_E_NOMEM, err, errcap, "snk_dev_hbv: host allocation failed"); }
+    for (uint64_t i = 0; i < U; ++i) out->bvcomp_order[i] = (int32_t)h_order[i];
+    return SNK_OK;
+}

@@ -1,13 +1,11 @@
-// snk_host.hip -- host-pointer convenience entry point, the .bv hand-off file and the graph-from-unitigs step.
+// snk_host.hip -- host-pointer convenience entry point, the .bv hand-off file (the graph-from-unitigs step lives in snk_hbv.hip).
 //   snk_count_graph      : buildReadQGraph48 for host-resident reads (lib/assembly/src/paths/long/BuildReadQGraph48.h:24-34)
 //   snk_write_bv/read_bv : lib/tada/src/debruijn.rs:895-929 <-> BuildReadQGraph48.cc:1640-1642
-//   snk_hbv_from_unitigs : buildHBVFromEdges, lib/assembly/src/paths/long/HBVFromEdges.cc:244-296
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
-#include <deque>
 #include <numeric>
 #include <vector>
 
@@ -169,106 +167,4 @@ extern "C" int snk_read_bv(const char* path, uint64_t* n_unitigs, uint64_t** off
     memcpy(*off_out, off.data(), (n + 1) * 8);
     if (!bases.empty()) memcpy(*bases_out, bases.data(), bases.size());
     return SNK_OK;
-}
-
-// ---------------------------------------------------------------------------------------------- a14
-// HBVFromEdges.cc: VertexDictBuilder::map (:136-145) emits 4 edge ends per unitig (2 for a palindrome); a vertex
-// is one distinct (K-1)-mer and lists its incident (edge, rc) pairs in EEComp order (:113-122); HBVBuilder
-// (:170-238) floods from every edge in BVComp order, forward copies first, assigning vertex and edge ids.
-extern "C" int snk_hbv_from_unitigs(uint32_t K, uint64_t U, const uint64_t* off, const uint8_t* bases, snk_hbv* out, char* err, size_t errcap) {
-    if (!out) return snk_fail(SNK_E_ARG, err, errcap, "snk_hbv_from_unitigs: NULL argument");
-    memset(out, 0, sizeof *out);
-    if (U == 0) return SNK_OK;
-    if (U >= (1ull << 30)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_hbv_from_unitigs: too many unitigs");
-    const uint32_t kl = K - 1;
-    struct eend { uint32_t edge; uint8_t rc, distal; };
-    auto base_of = [&](const eend& e, uint32_t j) -> uint8_t {
-        const uint8_t* b = bases + off[e.edge];
-        const uint64_t len = off[e.edge + 1] - off[e.edge];
-        const uint64_t p = e.distal ? len - kl + j : j;
-        return e.rc ? (uint8_t)(b[len - 1 - p] ^ 3) : b[p];
-    };
-    auto seq_cmp = [&](const eend& a, const eend& b) -> int {
-        for (uint32_t j = 0; j < kl; ++j) { uint8_t x = base_of(a, j), y = base_of(b, j); if (x != y) return x < y ? -1 : 1; }
-        return 0;
-    };
-    std::vector<uint8_t> pal(U);
-    std::vector<eend> ee;
-    ee.reserve(4 * U);
-    for (uint64_t e = 0; e < U; ++e) {
-        const uint8_t* b = bases + off[e];
-        const uint64_t len = off[e + 1] - off[e];
-        if (len < K) return snk_fail(SNK_E_ARG, err, errcap, "snk_hbv_from_unitigs: unitig %llu shorter than K", (unsigned long long)e);
-        bool p = (len & 1) == 0;                       // getCanonicalForm == PALINDROME (dna/CanonicalForm.h:35-48)
-        for (uint64_t i = 0, j = len; p && i < j; ++i) { --j; if (b[i] != (uint8_t)(b[j] ^ 3)) p = false; }
-        pal[e] = p;
-        ee.push_back({(uint32_t)e, 0, 0});
-        ee.push_back({(uint32_t)e, 0, 1});
-        if (!p) { ee.push_back({(uint32_t)e, 1, 0}); ee.push_back({(uint32_t)e, 1, 1}); }
-    }
-    std::sort(ee.begin(), ee.end(), [&](const eend& a, const eend& b) {
-        int c = seq_cmp(a, b);
-        if (c) return c < 0;
-        if (a.edge != b.edge) return a.edge < b.edge;   // BVComp order == index order (input is sorted)
-        if (a.rc != b.rc) return a.rc < b.rc;
-        return a.distal < b.distal;
-    });
-    std::vector<int32_t> vtx_of(4 * U, -1);
-    std::vector<uint64_t> run_beg;
-    for (uint64_t i = 0; i < ee.size();) {
-        uint64_t j = i + 1;
-        while (j < ee.size() && seq_cmp(ee[i], ee[j]) == 0) ++j;
-        for (uint64_t q = i; q < j; ++q) vtx_of[(uint64_t)ee[q].edge * 4 + ee[q].rc * 2 + ee[q].distal] = (int32_t)run_beg.size();
-        run_beg.push_back(i);
-        i = j;
-    }
-    const uint64_t nruns = run_beg.size();
-    run_beg.push_back(ee.size());
-    out->n_vertices = (int32_t)nruns;
-    out->fwd_xlat = (int32_t*)malloc(U * 4);
-    out->rev_xlat = (int32_t*)malloc(U * 4);
-    out->v_left = (int32_t*)malloc(2 * U * 4);
-    out->v_right = (int32_t*)malloc(2 * U * 4);
-    out->src_unitig = (int32_t*)malloc(2 * U * 4);
-    out->is_rc = (uint8_t*)malloc(2 * U);
-    if (!out->fwd_xlat || !out->rev_xlat || !out->v_left || !out->v_right || !out->src_unitig || !out->is_rc) { snk_hbv_free(out); return snk_fail(SNK_E_NOMEM, err, errcap, "snk_hbv_from_unitigs: host allocation failed"); }
-    for (uint64_t i = 0; i < U; ++i) out->fwd_xlat[i] = out->rev_xlat[i] = -1;
-    std::vector<int32_t> vid(nruns, -1);
-    int32_t next_v = 0, next_e = 0;
-    std::deque<uint64_t> q;
-    auto done = [&](uint64_t e, int rc) { return (rc ? out->rev_xlat : out->fwd_xlat)[e] != -1; };
-    for (int pass = 0; pass < 2; ++pass)
-        for (uint64_t e0 = 0; e0 < U; ++e0) {
-            if (done(e0, pass)) continue;
-            q.push_back(e0 * 2 + pass);
-            while (!q.empty()) {
-                const uint64_t x = q.front();
-                q.pop_front();
-                const uint64_t e = x >> 1;
-                const int rc = (int)(x & 1);
-                if (done(e, rc)) continue;
-                int32_t r1 = vtx_of[e * 4 + rc * 2 + 0], r2 = vtx_of[e * 4 + rc * 2 + 1];
-                if (pal[e] && rc) { r1 = vtx_of[e * 4 + 0]; r2 = vtx_of[e * 4 + 1]; }
-                if (vid[r1] == -1) vid[r1] = next_v++;
-                if (vid[r2] == -1) vid[r2] = next_v++;
-                const int32_t id = next_e++;
-                out->v_left[id] = vid[r1]; out->v_right[id] = vid[r2];
-                out->src_unitig[id] = (int32_t)e; out->is_rc[id] = (uint8_t)rc;
-                if (!rc || pal[e]) out->fwd_xlat[e] = id;
-                if (rc || pal[e]) out->rev_xlat[e] = id;
-                for (int side = 0; side < 2; ++side) {
-                    const int32_t r = side ? r2 : r1;
-                    for (uint64_t j = run_beg[r]; j < run_beg[r + 1]; ++j)
-                        if (!done(ee[j].edge, ee[j].rc)) q.push_back((uint64_t)ee[j].edge * 2 + ee[j].rc);
-                }
-            }
-        }
-    out->n_edges = next_e;
-    return SNK_OK;
-}
-
-extern "C" void snk_hbv_free(snk_hbv* h) {
-    if (!h) return;
-    free(h->v_left); free(h->v_right); free(h->src_unitig); free(h->is_rc); free(h->fwd_xlat); free(h->rev_xlat);
-    memset(h, 0, sizeof *h);
 }

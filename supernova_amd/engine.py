@@ -96,6 +96,25 @@ class Result:
         """Grouped runs: group id of every unitig (same order as unitig_arrays())."""
         return self._dl(self.raw.unitig_group, self.n_unitigs * 4, np.uint32, (self.n_unitigs,))
 
+    def hbv(self) -> dict:
+        """The graph from the device-resident unitigs (buildHBVFromEdges, HBVFromEdges.cc:244-296; snk_dev_hbv):
+        vertex ids per HBV edge, fwd/rev translation per unitig, numbered in BVComp order; 'order'[r] = index of the
+        rank-r unitig in unitig_arrays().  Must be called before the engine's next count_graph."""
+        h = _lib.SnkHbv()
+        ms = C.c_float(0)
+        err = C.create_string_buffer(512)
+        rc = self._e.lib.snk_dev_hbv(self._e._ctx, int(self.K), self.n_unitigs, self.raw.unitig_off, self.raw.unitig_bases,
+                                     C.byref(h), C.byref(ms), self._e._stream(), err, 512)
+        if rc:
+            raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+        ne, nu = h.n_edges, self.n_unitigs
+        arr = lambda p, m, dt: (np.ctypeslib.as_array(p, shape=(m,)).astype(dt).copy() if m else np.zeros(0, dt))
+        out = dict(n_vertices=h.n_vertices, n_edges=ne, v_left=arr(h.v_left, ne, np.int32), v_right=arr(h.v_right, ne, np.int32),
+                   src=arr(h.src_unitig, ne, np.int32), is_rc=arr(h.is_rc, ne, np.uint8), fwd=arr(h.fwd_xlat, nu, np.int32),
+                   rev=arr(h.rev_xlat, nu, np.int32), order=arr(h.bvcomp_order, nu, np.int32), device_ms=float(ms.value))
+        self._e.lib.snk_hbv_free(C.byref(h))
+        return out
+
     def unitigs(self) -> list[str]:
         """Canonical unitigs sorted by (length desc, lexicographic) = BVComp, HBVFromEdges.cc:106-111."""
         off, bases = self.unitig_arrays()

@@ -86,7 +86,7 @@ class SnkHbv(C.Structure):
     _fields_ = [("n_vertices", C.c_int32), ("n_edges", C.c_int32), ("v_left", C.POINTER(C.c_int32)),
                 ("v_right", C.POINTER(C.c_int32)), ("src_unitig", C.POINTER(C.c_int32)),
                 ("is_rc", C.POINTER(C.c_uint8)), ("fwd_xlat", C.POINTER(C.c_int32)),
-                ("rev_xlat", C.POINTER(C.c_int32))]
+                ("rev_xlat", C.POINTER(C.c_int32)), ("bvcomp_order", C.POINTER(C.c_int32))]
 
 
 _lib = None
@@ -149,6 +149,7 @@ def _declare(lib: C.CDLL) -> None:
         "snk_write_bv": (C.c_int, [cp, u64, vp, vp, cp, sz]),
         "snk_read_bv": (C.c_int, [cp, P(u64), P(P(u64)), P(P(C.c_uint8)), cp, sz]),
         "snk_hbv_from_unitigs": (C.c_int, [u32, u64, vp, vp, P(SnkHbv), cp, sz]),
+        "snk_dev_hbv": (C.c_int, [vp, u32, u64, vp, vp, P(SnkHbv), P(C.c_float), vp, cp, sz]),
         "snk_hbv_free": (None, [P(SnkHbv)]),
         "snk_read_fastb": (C.c_int, [cp, P(u64), P(u32), P(P(C.c_uint16)), P(P(u32)), cp, sz]),
         "snk_read_qualp": (C.c_int, [cp, u64, u32, vp, cp, sz]),

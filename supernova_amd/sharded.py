@@ -60,15 +60,19 @@ class TorchComm:
             out_off[p + 1] = out_off[p] + int(out_splits[p])
         if in_splits[me]:
             out[out_off[me]:out_off[me + 1]].copy_(inp[in_off[me]:in_off[me + 1]])
-        ops = []
-        for p in range(W):
-            if p == me:
-                continue
-            for c0 in range(0, int(in_splits[p]), ch):
-                ops.append(self.dist.P2POp(self.dist.isend, inp[in_off[p] + c0:in_off[p] + min(c0 + ch, int(in_splits[p]))], p))
-            for c0 in range(0, int(out_splits[p]), ch):
-                ops.append(self.dist.P2POp(self.dist.irecv, out[out_off[p] + c0:out_off[p] + min(c0 + ch, int(out_splits[p]))], p))
-        if ops:
+        # round j carries the j-th piece of every segment: one send and one receive per peer and group, the
+        # pattern of an all-to-all (both sides derive the same piece count from the exchanged sizes)
+        n_rounds = max([0] + [-(-int(x) // ch) for p in range(W) if p != me for x in (in_splits[p], out_splits[p])])
+        for j in range(n_rounds):
+            ops = []
+            for p in range(W):
+                if p == me:
+                    continue
+                c0 = j * ch
+                if c0 < int(in_splits[p]):
+                    ops.append(self.dist.P2POp(self.dist.isend, inp[in_off[p] + c0:in_off[p] + min(c0 + ch, int(in_splits[p]))], p))
+                if c0 < int(out_splits[p]):
+                    ops.append(self.dist.P2POp(self.dist.irecv, out[out_off[p] + c0:out_off[p] + min(c0 + ch, int(out_splits[p]))], p))
             for r in self.dist.batch_isend_irecv(ops):
                 r.wait()
 

@@ -445,3 +445,54 @@ def test_circle_pool_retry(engine, monkeypatch):
     rows, quals, bc, lens = _to_dev(c)
     res = engine.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, ign_bc_below=c.ign_bc_below)
     _check_against(res, c.exp_keys, c.exp_counts, c.exp_ctx, c.exp_unitigs, c.exp_goodlens, c.exp_hist)
+
+
+@pytest.mark.parametrize("name,K", [(n, 48) for n in goldens.CASES] + [(n, 60) for n in goldens.K60_CASES])
+def test_device_hbv_matches_reference(engine, graph_stage, name, K):
+    """a14 on the device (snk_dev_hbv): BVComp ranking, (K-1)-mer end keys, vertex classes in HBM, id flood on the host
+    -- the text dump equals the reference's buildHBVFromEdges output (golden), and the host-array entry point."""
+    from supernova_amd import graphio
+    from supernova_amd.engine import Params
+    c = goldens.load(name)
+    rows, quals, bc, lens = _to_dev(c)
+    exp = c if K == 48 else goldens.Case60(name)
+    res = engine.count_graph(rows, c.read_len, quals=quals, bc=bc if K == 48 else None, lens=lens, params=Params(K=K),
+                             ign_bc_below=c.ign_bc_below)
+    off, bases = res.unitig_arrays()
+    h = res.hbv()
+    asc = np.frombuffer(b"ACGT", dtype=np.uint8)[bases].tobytes().decode()
+    dev_order = [asc[int(off[i]):int(off[i + 1])] for i in range(res.n_unitigs)]
+    ranked = [dev_order[i] for i in h["order"]]
+    assert ranked == exp.exp_unitigs                     # BVComp order, computed on the device
+    assert graphio.hbv_text(ranked, h) == exp.exp_hbv
+    off2, bases2 = graphio.unitigs_to_arrays(ranked)
+    h2 = graphio.hbv_from_unitigs(K, off2, bases2)
+    for k in ("v_left", "v_right", "src", "is_rc", "fwd", "rev"):
+        assert np.array_equal(h[k], h2[k]), k
+    # a second call on the same result (scratch of the first was handed back, the unitigs were not)
+    assert np.array_equal(res.hbv()["v_left"], h["v_left"])
+
+
+def test_device_hbv_many_unitigs(engine):
+    """Error-rich reads at low coverage: hundreds of thousands of short unitigs, equal lengths everywhere (the BVComp
+    tie-break) -- device result == host-array entry point on the BVComp-sorted unitigs."""
+    from supernova_amd import graphio, synth
+    from supernova_amd.engine import Params
+    sp = synth.synth_params(400_000, seed=0x5EED0042)
+    rows, quals, bc = engine.synth(sp)
+    res = engine.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48, min_freq=1, min_bc=0))
+    assert res.n_unitigs > 50_000
+    off, bases = res.unitig_arrays()
+    h = res.hbv()
+    us = res.unitigs()
+    lens = np.diff(off).astype(np.int64)
+    ranked_len = lens[h["order"]]
+    assert np.all(np.diff(ranked_len) <= 0)
+    asc = np.frombuffer(b"ACGT", dtype=np.uint8)[bases].tobytes().decode()
+    ranked = [asc[int(off[i]):int(off[i + 1])] for i in h["order"]]
+    assert ranked == us
+    off2, bases2 = graphio.unitigs_to_arrays(us)
+    h2 = graphio.hbv_from_unitigs(48, off2, bases2)
+    assert h["n_vertices"] == h2["n_vertices"] and h["n_edges"] == h2["n_edges"]
+    for k in ("v_left", "v_right", "src", "is_rc", "fwd", "rev"):
+        assert np.array_equal(h[k], h2[k]), k
