@@ -19,6 +19,7 @@
 #include "snk_ctx.h"
 #include "snk_common.h"
 #include "snk_kernels.h"
+#include "snk_stages.h"
 
 namespace {
 
@@ -58,7 +59,7 @@ template <int K, bool G> __device__ __forceinline__ uint64_t klo_unpack(typename
 }
 
 template <int K, int THREADS, int SLOTS, bool GROUPED>
-__global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
+__global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a) {
     // supermers staged per batch.  A 4000-instance bucket holds ~270 (sigma ~100): with 512 slots nearly every bucket is
     // ONE batch (with 256, 55 % of the buckets ran a second, mostly empty batch through all the phases below).  K=60 and
     // grouped runs have 64-bit low key words: 256 keeps the workgroup under 80 KB of LDS, i.e. two per CU.
@@ -87,22 +88,23 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
     static_assert(THREADS >= BATCH && THREADS % 64 == 0, "the first BATCH threads stage the records");
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
-    const uint32_t bucket = blockIdx.x + a.bucket0;
     constexpr uint32_t LIMIT = SLOTS - THREADS - 64;   // claims allowed before a sub-pass is declared overflowing
-
-    if (tid == 0) { ctl[0] = 1; ctl[16] = 0; ctl[17] = 0; }
-    uint32_t splits_done = 0;
 #ifdef SNK_COUNT_PROF
     long long prof_t = clock64();
 #endif
+    // a.bucket_stride != 0: the grid is one residency wave of workgroups and each walks buckets blockIdx.x, +stride, ...
+    // (no dispatch gap between buckets); 0: one bucket per workgroup
+    for (uint32_t bucket = blockIdx.x + a.bucket0; bucket < a.NB; bucket += a.bucket_stride) {
+    if (tid == 0) { ctl[0] = 1; ctl[16] = 0; ctl[17] = 0; }
+    uint32_t splits_done = 0;
     // issued before the table is cleared: the bounds of segment 0 and the first batch of records (two dependent HBM
-    // round trips that every workgroup used to wait for after its first barrier).  Persistent workgroups that prefetch
-    // the NEXT bucket during the current one were tried twice: the prefetch registers (16 live across a whole bucket)
-    // push the kernel from 71 to 92 VGPRs = one workgroup per CU (116 ms), and capped at 80 VGPRs it spills (82 ms).
+    // round trips that every workgroup used to wait for after its first barrier).  Prefetching the NEXT bucket was tried
+    // three times: at the start of the current bucket the 16 registers live across the insert phase push the kernel
+    // from 71 to 92 VGPRs = one workgroup per CU (116 ms), capped at 80 VGPRs it spills (82 ms); bounds during the
+    // filter scan + records during the placement loop keeps the register count but runs 77 ms instead of 73.
     const uint64_t beg0 = a.seg_beg[bucket], end0 = a.seg_end[bucket];
     uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = make_uint4(0, 0, 0, 0);
     if (tid < BATCH && beg0 + tid < end0) { pf0 = a.records[(beg0 + tid) * 2]; pf1 = a.records[(beg0 + tid) * 2 + 1]; }
-    // (computing the first record's address as bucket * cap, so that the loads need no bounds, changed nothing: 73 ms)
     bool first_batch = true;
     for (;;) {
         __syncthreads();
@@ -371,6 +373,9 @@ __global__ void __launch_bounds__(THREADS) snk_count_kernel(snk_count_args a) {
         PROF(7);
     }
     if (tid == 0 && splits_done) atomicAdd(&a.status[2], 1u);
+    if (a.bucket_stride == 0) break;
+    __syncthreads();          // every thread has left the sub-pass loop before ctl[] is re-initialised
+    }
 }
 
 template <int K> struct cfg;
@@ -388,12 +393,31 @@ int launch(hipStream_t st, const snk_count_args& a, char* err, size_t errcap) {
     auto kern = snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G>;
     size_t lds = lds_bytes<K, G>();
     SNK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    // a launch is limited to 2^32 threads in total: buckets go out in slices of 4 M workgroups
-    constexpr uint32_t SLICE = 1u << 22;
     snk_count_args b = a;
+    // Workgroups walk buckets w, w + grid, ...: 2 M one-bucket workgroups spend ~8 % of the kernel in dispatch (73.7 ms);
+    // exactly one residency wave (grid = 2 x CUs) is no better (73.5: whoever finishes early idles to the end); 32-64
+    // waves keep both the dispatch cost and the tail small (67.3 ms at 1e8 reads).  SNK_COUNT_PERSIST=0: one bucket each.
+    const uint32_t persist = snk_env_u32("SNK_COUNT_PERSIST", 32);
+    if (persist) {
+        int per_cu = 0, dev = 0, n_cu = 256;
+        SNK_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, cfg<K>::THREADS, lds));
+        SNK_HIP_TRY(hipGetDevice(&dev));
+        SNK_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        uint64_t grid = (uint64_t)(per_cu > 0 ? per_cu : 1) * (uint64_t)n_cu * persist;
+        if (grid > a.NB) grid = a.NB;
+        b.bucket0 = 0;
+        b.bucket_stride = (uint32_t)grid;
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(cfg<K>::THREADS), lds, st, b);
+        SNK_HIP_TRY(hipGetLastError());
+        return SNK_OK;
+    }
+    // one bucket per workgroup.  A launch is limited to 2^32 threads in total: buckets go out in slices of 4 M workgroups
+    constexpr uint32_t SLICE = 1u << 22;
+    b.bucket_stride = 0;
     for (uint32_t b0 = 0; b0 < a.NB; b0 += SLICE) {
         b.bucket0 = b0;
         const uint32_t nb = a.NB - b0 < SLICE ? a.NB - b0 : SLICE;
+        b.NB = b0 + nb;
         hipLaunchKernelGGL(kern, dim3(nb), dim3(cfg<K>::THREADS), lds, st, b);
     }
     SNK_HIP_TRY(hipGetLastError());

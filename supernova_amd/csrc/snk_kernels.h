@@ -46,6 +46,7 @@ struct snk_count_args {
     uint32_t min_freq;
     uint32_t bc_mode;              // 0: no barcode rule, 1: >=1 barcode>0 (or ignore-rule read), 2: >=2 distinct
     uint32_t bucket0;              // first bucket of this launch (set by the launcher)
+    uint32_t bucket_stride;        // persistent launch: workgroup w counts buckets w, w + stride, ... (0: one bucket each)
     uint32_t grouped;              // record word 7 is a group id that becomes the low 32 bits of the key (K=48 only)
     snk_u128* out_keys;            // canonical k-mer values (hi<<64|lo); region r owns [r*region_cap, (r+1)*region_cap)
     uint64_t* out_vals;            // count << 8 | raw context byte
