@@ -6,7 +6,9 @@
 #include <stdint.h>
 __device__ __forceinline__ uint32_t mix(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
 template <int PER, int MODE, int STRIDE = 1>   // STRIDE: counters padded to one per STRIDE words
-// MODE 0: non-returning, 1: returning serial chain (value feeds the next address), 2: returning independent
+// MODE 0: non-returning, 1: returning serial chain (value feeds the next address), 2: returning independent,
+// 3: returning, WORKGROUP scope (executes in the issuing XCD's L2, no cross-XCD coherence), 4: the same on a counter
+//    range private to the XCD (block b runs on XCD b % 8)
 __global__ void __launch_bounds__(256) probe(uint32_t* ctr, uint32_t nb, uint32_t* sink) {
 #define CTR(i) ctr[(size_t)(i) * STRIDE]
     uint32_t t = blockIdx.x * 256 + threadIdx.x;
@@ -21,6 +23,8 @@ __global__ void __launch_bounds__(256) probe(uint32_t* ctr, uint32_t nb, uint32_
         for (int i = 0; i < PER; ++i) {
             uint32_t a = mix(t * PER + i + (MODE == 1 ? (acc & 1u) : 0u)) % nb;
             if (MODE == 0) atomicAdd(&CTR(a), 1u);
+            else if (MODE == 3) acc += __hip_atomic_fetch_add(&CTR(a), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else if (MODE == 4) acc += __hip_atomic_fetch_add(&CTR((a % (nb / 8)) + (nb / 8) * (blockIdx.x & 7u)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             else acc += atomicAdd(&CTR(a), 1u);
         }
     }
@@ -51,5 +55,8 @@ int main() {
     run<1, 1, 4>("returning, 1/thread, counters 16 B apart", ctr, nb, sink, total);
     run<1, 1, 16>("returning, 1/thread, counters 64 B apart", ctr, nb, sink, total);
     run<1, 0, 16>("non-returning, counters 64 B apart", ctr, nb, sink, total);
+    run<1, 3>("returning, workgroup scope", ctr, nb, sink, total);
+    run<1, 4>("returning, workgroup scope, XCD-private", ctr, nb, sink, total);
+    run<8, 4>("same, 8/thread chain", ctr, nb, sink, total);
     return 0;
 }
