@@ -46,13 +46,17 @@ __device__ __forceinline__ uint32_t mmer_key(const uint32_t* rowL, int tid, uint
     return snk_minimizer_key(code, rcode);
 }
 
-// Bucket of a supermer = snk_bucket_of_key(ordering key of its minimiser).  Two rules make this safe:
+// Bucket of the supermer whose minimiser sits at position p.  Two rules make this safe:
 //  * it must NOT be taken from the ordering key directly: minimisers are window minima of that key, so
 //    their keys crowd near zero (a Beta(1,w) law) and most supermers would fall into the lowest few
 //    percent of the buckets -- the key is re-mixed first;
 //  * it must be a function of the ordering key ONLY (not of the M-mer or its position): when two
 //    different M-mers of a window tie on the key, the two strands may pick different ones, and a k-mer
 //    and its reverse complement must still meet in one bucket.
+template <int M>
+__device__ __forceinline__ uint32_t mmer_bucket(const uint32_t* rowL, int tid, uint32_t row_words, int p, uint32_t NB, uint32_t gmix) {
+    return snk_bucket_of_key(mmer_key<M>(rowL, tid, row_words, p) ^ gmix, NB);
+}
 
 // extract 32 bits starting at base `a + 16*j` of the row column
 __device__ __forceinline__ uint32_t row_window(const uint32_t* rowL, int tid, uint32_t row_words, uint32_t a, uint32_t j) {
@@ -63,8 +67,13 @@ __device__ __forceinline__ uint32_t row_window(const uint32_t* rowL, int tid, ui
     return s ? ((w0 << s) | (w1 >> (32u - s))) : w0;
 }
 
+// Occupancy is what overlaps one wave's emit loop (slot atomics, scattered stores: device throughput limits) with other
+// waves' scans: 26.8 KB of LDS admit five workgroups per CU, and at K=48 the kernel fits 96 VGPRs with two spills
+// (36.0 -> 33.0 ms at 1e8 reads against the 105 registers / four waves per SIMD the compiler picks on its own).  Keeping
+// the minimisers' keys in a second LDS list to save their re-derivation in the emit loop costs the fifth workgroup and
+// was dropped again; six waves per SIMD (80 VGPRs) spill 28 registers.  K=60 (45 keys in registers) stays at four.
 template <int K, int M>
-__global__ void __launch_bounds__(BD) snk_msp_kernel(snk_msp_args a) {
+__global__ void __launch_bounds__(BD, K == 48 ? 5 : 4) snk_msp_kernel(snk_msp_args a) {
     constexpr int W = K - M + 1;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t row_words = a.row_words;
@@ -72,12 +81,8 @@ __global__ void __launch_bounds__(BD) snk_msp_kernel(snk_msp_args a) {
     const uint64_t n_reads = a.n_reads;
     uint32_t* rowL = smem;                              // [row_words][BD]
     // Only the POSITION of every suffix minimum is kept in LDS (1 byte per entry); the keys live in registers.
-    // supermer starts of the thread: the ordering key of the minimiser (known for free when the window minimum changes;
-    // re-deriving it from the position in the emit loop cost two LDS loads, a funnel shift, a 32-bit reverse
-    // complement and the hash per supermer) and the first k-mer
-    uint32_t* lstk = rowL + (size_t)row_words * BD;                        // [LCAP][BD] ordering key of the minimiser
-    uint8_t* lst = reinterpret_cast<uint8_t*>(lstk + (size_t)LCAP * BD);  // [LCAP][BD] first k-mer
-    uint8_t* sfxp = lst + (size_t)LCAP * BD;                              // [W][BD] position of the suffix minimum
+    uint16_t* lst = reinterpret_cast<uint16_t*>(rowL + (size_t)row_words * BD);   // [LCAP][BD] minimiser position << 8 | first k-mer
+    uint8_t* sfxp = reinterpret_cast<uint8_t*>(lst + (size_t)LCAP * BD);  // [W][BD] position of the suffix minimum
     const int tid = threadIdx.x;
     const uint64_t r0 = (uint64_t)blockIdx.x * BD;
     // coalesced stage of the workgroup's rows
@@ -116,10 +121,10 @@ __global__ void __launch_bounds__(BD) snk_msp_kernel(snk_msp_args a) {
         for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(maxn, off); maxn = o > maxn ? o : maxn; }
         for (int e = 0; e < maxn; ++e) {
             if (e < upto) {
-                const uint32_t s = lst[e * BD + tid];
-                const uint32_t ent = lstk[e * BD + tid];
-                uint32_t en = (e + 1 < upto) ? ((uint32_t)lst[(e + 1) * BD + tid] - 1u) : (uint32_t)last_end;
-                uint32_t bucket = snk_bucket_of_key(ent ^ gmix, NB);
+                uint32_t ent = lst[e * BD + tid];
+                uint32_t s = ent & 0xFFu;
+                uint32_t en = (e + 1 < upto) ? (((uint32_t)lst[(e + 1) * BD + tid] & 0xFFu) - 1u) : (uint32_t)last_end;
+                uint32_t bucket = mmer_bucket<M>(rowL, tid, row_words, (int)(ent >> 8), NB, gmix);
                 {
                     const uint32_t slot = a.dbg == 2 ? ((ent * 2654435761u) % (a.cap ? a.cap : 1u)) : atomicAdd(&a.cursor[bucket], 1u);
                     uint64_t at = 0;
@@ -219,7 +224,7 @@ __global__ void __launch_bounds__(BD) snk_msp_kernel(snk_msp_args a) {
                 const bool isnew = (i < nk) && (candp != curpos);
                 if (isnew) {
                     curpos = candp;
-                    if (cnt < LCAP) { lst[cnt * BD + tid] = (uint8_t)i; lstk[cnt * BD + tid] = (sv <= pfx) ? sv : pfx; ++cnt; }
+                    if (cnt < LCAP) { lst[cnt * BD + tid] = (uint16_t)(((uint32_t)candp << 8) | (uint32_t)i); ++cnt; }
                     else lost = true;
                 }
                 const int p2 = (b + 1) * W + t;          // == rp: the roll is exactly one block ahead
@@ -247,14 +252,13 @@ __global__ void __launch_bounds__(BD) snk_msp_kernel(snk_msp_args a) {
                 const bool isnew = (i < nk) && (candp != curpos);
                 if (__any(isnew && cnt == LCAP)) {     // every lane of the wave drains its list; the open supermer stays
                     const int upto = cnt > 0 ? cnt - 1 : 0;
-                    const int last_end = cnt > 0 ? (int)lst[(cnt - 1) * BD + tid] - 1 : 0;
+                    const int last_end = cnt > 0 ? (int)(lst[(cnt - 1) * BD + tid] & 0xFFu) - 1 : 0;
                     flush(upto, last_end);
-                    if (cnt > 0) { lst[tid] = lst[(cnt - 1) * BD + tid]; lstk[tid] = lstk[(cnt - 1) * BD + tid]; cnt = 1; }
+                    if (cnt > 0) { lst[tid] = lst[(cnt - 1) * BD + tid]; cnt = 1; }
                 }
                 if (isnew) {
                     curpos = candp;
-                    lst[cnt * BD + tid] = (uint8_t)i;
-                    lstk[cnt * BD + tid] = (sv <= pfx) ? sv : pfx;
+                    lst[cnt * BD + tid] = (uint16_t)(((uint32_t)candp << 8) | (uint32_t)i);
                     ++cnt;
                 }
                 const int p2 = (b + 1) * W + t;
@@ -285,7 +289,7 @@ __global__ void __launch_bounds__(256) snk_msp_plan_kernel(const uint16_t* __res
 }  // namespace
 
 size_t snk_msp_lds_bytes(uint32_t K, uint32_t M, uint32_t row_words) {
-    return (size_t)row_words * BD * 4 + (size_t)LCAP * BD * 5 + (size_t)(K - M + 1) * BD + 64;
+    return (size_t)row_words * BD * 4 + (size_t)LCAP * BD * 2 + (size_t)(K - M + 1) * BD + 64;
 }
 
 template <int K, int M>
