@@ -182,7 +182,9 @@ def main():
         del rv, qv, bv, resv
         barrier()
 
-    res = None
+    # setup: one untimed call allocates the library's caching arena and the exchange buffer pool (tens of GB of
+    # hipMalloc, ~2 s); from the second call on a step allocates nothing.  Then the W warm-up steps the caller asked for.
+    res = step()
     for _ in range(args.warmup):
         res = step()
     barrier()
