@@ -104,7 +104,11 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
                                                      uint32_t* __restrict__ nbr_out, uint32_t* __restrict__ nbnd,
                                                      uint32_t* __restrict__ biglist, uint32_t* __restrict__ nbig) {
     constexpr int HT = CAP <= 256 ? 512 : 4096;
-    __shared__ uint64_t khi[CAP], klo[CAP];
+    // at K=48 without groups only the top 32 bits of the low key word are sequence (LDS per chunk = waves per CU)
+    typedef typename std::conditional<(K <= 48 && !GR), uint32_t, uint64_t>::type klo_w;
+    constexpr int KLS = (K <= 48 && !GR) ? 32 : 0;
+    __shared__ uint64_t khi[CAP];
+    __shared__ klo_w klo[CAP];
     __shared__ uint32_t ht[HT];
     __shared__ uint32_t bcnt;
     const int tid = threadIdx.x;
@@ -128,12 +132,12 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
             const snk_kmer k = load_key(keys, ch.base + i);
             myv[q] = vals[ch.base + i];
             khi[i] = k.hi;
-            klo[i] = k.lo;
+            klo[i] = (klo_w)(k.lo >> KLS);
         }
     }
     __syncthreads();
     for (uint32_t i = tid; i < n; i += T) {
-        uint32_t slot = lhash(khi[i], klo[i]) & (HT - 1);
+        uint32_t slot = lhash(khi[i], (uint64_t)klo[i] << KLS) & (HT - 1);
         for (;;) {
             const uint32_t old = atomicCAS(&ht[slot], 0u, i + 1u);
             if (old == 0u) break;
@@ -154,7 +158,7 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
         const bool act = i < n;
         snk_kmer k;
         k.hi = act ? khi[i] : 0ull;
-        k.lo = act ? klo[i] : 0ull;
+        k.lo = act ? ((uint64_t)klo[i] << KLS) : 0ull;
         uint64_t tag = 0;                                    // grouped runs: the group id in the low 32 key bits
         if (GR) { tag = k.lo & 0xFFFFFFFFull; k.lo &= ~0xFFFFFFFFull; }
         const uint64_t v = myv[q];
@@ -172,7 +176,7 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
             for (;;) {
                 const uint32_t e = ht[slot];
                 if (e == 0u) break;
-                if (khi[e - 1] == cy.hi && klo[e - 1] == cy.lo) { j = (int32_t)(e - 1); break; }
+                if (khi[e - 1] == cy.hi && ((uint64_t)klo[e - 1] << KLS) == cy.lo) { j = (int32_t)(e - 1); break; }
                 slot = (slot + 1) & (HT - 1);
             }
             if (j >= 0) {
@@ -206,7 +210,7 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
             const uint32_t ni = i0 + th;
             snk_kmer kk;
             kk.hi = on ? khi[ni] : 0ull;
-            kk.lo = on ? klo[ni] : 0ull;
+            kk.lo = on ? ((uint64_t)klo[ni] << KLS) : 0ull;
             uint64_t ktag = 0;
             if (GR) { ktag = kk.lo & 0xFFFFFFFFull; kk.lo &= ~0xFFFFFFFFull; }
             const int first = bit < 4 ? 1 : 0;   // successors share positions 1..K-M, predecessors 0..K-M-1
@@ -394,7 +398,13 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
                                                     unsigned long long* __restrict__ hl_nb, uint64_t* __restrict__ bstart,
                                                     uint8_t* __restrict__ fbases, uint32_t* __restrict__ fgroup, uint32_t* __restrict__ sfrag, bl_extra_pool xp) {
     constexpr int SPT = (2 * CAP + T - 1) / T;        // states per thread
-    __shared__ uint64_t khi[CAP], klo[CAP];
+    // LDS per chunk decides how many chunk waves a CU holds (one wave each): at K=48 without groups only the top 32
+    // bits of the low key word are sequence, and the neighbour list (dead once the links are built) shares its memory
+    // with the fragment offsets (written after the ranking): 10.5 -> 8.3 KB, 15 -> 18 waves per CU
+    typedef typename std::conditional<(K <= 48 && !GR), uint32_t, uint64_t>::type klo_w;
+    constexpr int KLS = (K <= 48 && !GR) ? 32 : 0;
+    __shared__ uint64_t khi[CAP];
+    __shared__ klo_w klo[CAP];
     __shared__ uint16_t nbL[2 * CAP];                  // local neighbour << 1 | rev (chunk-local indices fit 16 bits)
     // ranking record of an exit state: next state | hops << FB | terminal << 2 FB (one LDS word per state)
     typedef typename std::conditional<(CAP <= 256), uint32_t, uint64_t>::type wrec_t;
@@ -402,7 +412,7 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
     constexpr uint32_t FM = (1u << FB) - 1u;           // field mask == "no next state"
     __shared__ uint16_t lnk[2 * CAP];
     __shared__ wrec_t wr[2 * CAP];
-    __shared__ uint16_t foffL[2 * CAP];               // per pid terminal: offset of the fragment's bases inside the chunk's output
+    uint16_t* foffL = nbL;                             // per pid terminal: offset of the fragment's bases inside the chunk's output
     __shared__ uint16_t hnode[CAP];                    // heads: node << 1 | rc
     __shared__ uint8_t ctxL[CAP], pendL[CAP], palL[CAP];
     __shared__ uint32_t fcnt, bcnt, changed;
@@ -419,7 +429,7 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
         const uint64_t gi = ch.base + i;
         const snk_kmer k = load_key(keys, gi);
         khi[i] = k.hi;
-        klo[i] = k.lo;
+        klo[i] = (klo_w)(k.lo >> KLS);
         snk_kmer kb = k;
         if (GR) kb.lo &= ~0xFFFFFFFFull;                   // the group id is not part of the sequence
         palL[i] = snk_kmer_eq(kb, snk_kmer_rc<K>(kb)) ? 1 : 0;
@@ -513,7 +523,7 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
         if (!((pendL[i] >> (4 * side + b)) & 1u)) return NONE64;
         snk_kmer k;
         k.hi = khi[i];
-        k.lo = GR ? (klo[i] & ~0xFFFFFFFFull) : klo[i];
+        k.lo = GR ? ((uint64_t)klo[i] & ~0xFFFFFFFFull) : ((uint64_t)klo[i] << KLS);
         const snk_kmer y = side ? snk_kmer_pred<K>(k, b) : snk_kmer_succ<K>(k, b);
         if (snk_kmer_eq(y, snk_kmer_rc<K>(y))) return NONE64;
         const uint64_t gi = ch.base + i;
@@ -589,13 +599,13 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
                 if (GR) fgroup[f] = (uint32_t)klo[i];
                 snk_kmer k;
                 k.hi = khi[i];
-                k.lo = klo[i];
+                k.lo = (uint64_t)klo[i] << KLS;
                 for (int b = 0; b < K; ++b) fbases[bo + b] = (uint8_t)oriented_base<K>(k, false, b);
                 uint32_t curs = i << 1;
                 for (uint32_t pos = 1; pos < cnt; ++pos) {
                     const uint32_t l = lnk[curs];
                     k.hi = khi[l >> 1];
-                    k.lo = klo[l >> 1];
+                    k.lo = (uint64_t)klo[l >> 1] << KLS;
                     fbases[bo + (K - 1) + pos] = (uint8_t)oriented_base<K>(k, (l & 1u) == 0, K - 1);
                     curs = l ^ 1u;
                 }
@@ -612,7 +622,7 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
         if (pos == 0) continue;
         snk_kmer k;
         k.hi = khi[i];
-        k.lo = klo[i];
+        k.lo = (uint64_t)klo[i] << KLS;
         fbases[c_boff + foffL[fwd ? tL : tR] + (K - 1) + pos] = (uint8_t)oriented_base<K>(k, !fwd, K - 1);
     }
     // head k-mers: K lanes per head
@@ -629,7 +639,7 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
             const uint32_t pid = tL < tR ? tL : tR;
             snk_kmer k;
             k.hi = khi[i];
-            k.lo = klo[i];
+            k.lo = (uint64_t)klo[i] << KLS;
             fbases[c_boff + foffL[pid] + q] = (uint8_t)oriented_base<K>(k, rc, q);
         }
     }
