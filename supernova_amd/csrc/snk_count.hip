@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     uint16_t* lead = reinterpret_cast<uint16_t*>(wgt + BATCH);                      // [BATCH] r-th leading (non-folded) supermer
     uint16_t* lpre = lead + BATCH;                                                  // [BATCH+2] its first k-mer instance (+ sentinel)
     uint16_t* cidx = lpre + BATCH + 2;                                              // [NCI] leader rank that owns instance 32*w
-    // ctl[0] stack pointer, ctl[1] occupied slots, ctl[2] overflow flag, ctl[3] split log2, ctl[4] split id,
+    // ctl[0] unused, ctl[1] occupied slots, ctl[2] overflow flag, ctl[3] split log2, ctl[4] split id,
     // ctl[5] valid entries of the sub-pass, ctl[6..7] reserved base (lo,hi), ctl[8] placement counter,
     // ctl[16..16+2*MAX) split stack (MAX = 17 levels -> up to ctl[51]), ctl[52..59] wave totals of the batch scan
     static_assert(THREADS >= BATCH && THREADS % 64 == 0, "the first BATCH threads stage the records");
@@ -95,7 +95,10 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     // a.bucket_stride != 0: the grid is one residency wave of workgroups and each walks buckets blockIdx.x, +stride, ...
     // (no dispatch gap between buckets); 0: one bucket per workgroup
     for (uint32_t bucket = blockIdx.x + a.bucket0; bucket < a.NB; bucket += a.bucket_stride) {
-    if (tid == 0) { ctl[0] = 1; ctl[16] = 0; ctl[17] = 0; }
+    // depth of the split stack: every thread keeps its own copy (the control flow is uniform), so the sub-pass loop needs
+    // no barrier-protected LDS read to decide whether it is done
+    uint32_t sp = 1;
+    if (tid == 0) { ctl[16] = 0; ctl[17] = 0; }
     uint32_t splits_done = 0;
     // issued before the table is cleared: the bounds of segment 0 and the first batch of records (two dependent HBM
     // round trips that every workgroup used to wait for after its first barrier).  Prefetching the NEXT bucket was tried
@@ -106,25 +109,17 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = make_uint4(0, 0, 0, 0);
     if (tid < BATCH && beg0 + tid < end0) { pf0 = a.records[(beg0 + tid) * 2]; pf1 = a.records[(beg0 + tid) * 2 + 1]; }
     bool first_batch = true;
-    for (;;) {
-        __syncthreads();
-        if (LDS_LOAD(&ctl[0]) == 0) break;
-        __syncthreads();
+    while (sp) {
+        __syncthreads();          // the previous sub-pass / bucket is done with the table; stack entries are visible
         PROF(0);
-        if (tid == 0) {
-            uint32_t sp = ctl[0] - 1;
-            ctl[0] = sp;
-            ctl[3] = ctl[16 + 2 * sp];
-            ctl[4] = ctl[17 + 2 * sp];
-            ctl[1] = 0;
-            ctl[2] = 0;
-        }
+        --sp;
+        const uint32_t split_lg = LDS_LOAD(&ctl[16 + 2 * sp]), split_id = LDS_LOAD(&ctl[17 + 2 * sp]);
+        const uint32_t split_mask = (1u << split_lg) - 1u;
+        if (tid == 0) { ctl[1] = 0; ctl[2] = 0; ctl[5] = 0; ctl[8] = 0; }
         for (int s = tid; s < SLOTS; s += THREADS) tag[s] = 0;      // cnt/bcs of a slot are initialised by the lane that claims it
         for (int s = tid; s < SLOTS / 4; s += THREADS) ctxw[s] = 0;
         __syncthreads();
         PROF(1);
-        const uint32_t split_lg = LDS_LOAD(&ctl[3]), split_id = LDS_LOAD(&ctl[4]);
-        const uint32_t split_mask = (1u << split_lg) - 1u;
 
         for (uint32_t seg = 0; seg < a.nseg; ++seg) {
             const uint64_t beg = seg ? a.seg_beg[(uint64_t)seg * a.seg_stride + bucket] : beg0;
@@ -301,16 +296,15 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                 PROF(5);
             }
         }
-        __syncthreads();
+        // (every batch ends with a barrier: the overflow flag and the table are final here)
         if (LDS_LOAD(&ctl[2])) {   // too many distinct k-mers for one table: split this sub-pass in two by one more hash bit
-            if (tid == 0) {
-                if (split_lg >= MAX_SPLIT_LOG2) { atomicExch(&a.status[1], 1u); }
-                else {
-                    uint32_t sp = LDS_LOAD(&ctl[0]);
+            if (split_lg >= MAX_SPLIT_LOG2) { if (tid == 0) atomicExch(&a.status[1], 1u); }
+            else {
+                if (tid == 0) {
                     ctl[16 + 2 * sp] = split_lg + 1; ctl[17 + 2 * sp] = split_id;
                     ctl[18 + 2 * sp] = split_lg + 1; ctl[19 + 2 * sp] = split_id | (1u << split_lg);
-                    ctl[0] = sp + 2;
                 }
+                sp += 2;
             }
             ++splits_done;
             continue;
@@ -319,8 +313,6 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
         // address are served at the memory side (the XCD L2s are not coherent) at tens of ns each, so the
         // table is cut into n_regions regions with their own cursors and every sub-pass does ONE global
         // atomic: count the survivors in LDS, reserve, then place.
-        if (tid == 0) { ctl[5] = 0; ctl[8] = 0; }
-        __syncthreads();
         PROF(6);
         uint32_t myvalid = 0;
         for (int s = tid; s < SLOTS; s += THREADS) {      // SLOTS need not be a multiple of THREADS
@@ -374,7 +366,6 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     }
     if (tid == 0 && splits_done) atomicAdd(&a.status[2], 1u);
     if (a.bucket_stride == 0) break;
-    __syncthreads();          // every thread has left the sub-pass loop before ctl[] is re-initialised
     }
 }
 
