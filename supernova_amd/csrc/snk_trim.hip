@@ -70,9 +70,20 @@ __global__ void __launch_bounds__(256) snk_trim_tile_kernel(const uint8_t* __res
     const uint64_t rows_here = n_reads - r0 < 256 ? n_reads - r0 : 256;
     const uint32_t bytes = (uint32_t)rows_here * qstride;
     const uint8_t* src = quals + r0 * qstride;             // 16-byte aligned: 256 * qstride is a multiple of 16
-    for (uint32_t o = threadIdx.x * 16; o < bytes; o += 256 * 16) {
-        if (o + 16 <= bytes) *reinterpret_cast<uint4*>(tile + o) = *reinterpret_cast<const uint4*>(src + o);
-        else for (uint32_t j = o; j < bytes; ++j) tile[j] = src[j];
+    // all loads of a thread are issued before the first LDS store (up to 10 x 16 bytes in flight per lane)
+    constexpr int NV = 10;                                  // 256 rows x 160 bytes / (256 threads x 16 bytes)
+    uint4 v[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        const uint32_t o = (threadIdx.x + q * 256) * 16;
+        v[q] = make_uint4(0, 0, 0, 0);
+        if (o + 16 <= bytes) v[q] = *reinterpret_cast<const uint4*>(src + o);
+    }
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        const uint32_t o = (threadIdx.x + q * 256) * 16;
+        if (o + 16 <= bytes) *reinterpret_cast<uint4*>(tile + o) = v[q];
+        else if (o < bytes) for (uint32_t j = o; j < bytes; ++j) tile[j] = src[j];
     }
     __syncthreads();
     if (threadIdx.x >= rows_here) return;

@@ -320,6 +320,22 @@ def test_partition_overflow_segment(engine, monkeypatch, pct):
         assert res.n_overflow > 0
 
 
+@pytest.mark.parametrize("persist,n_buckets", [(0, 0), (1, 0), (32, 3), (32, 5000), (1000, 5000)])
+def test_count_launch_shapes(engine, monkeypatch, persist, n_buckets):
+    """The count kernel's workgroups walk strided bucket lists (SNK_COUNT_PERSIST residency waves; 0 = one bucket per
+    workgroup): fewer buckets than workgroups, one wave, many waves, more waves than buckets -- same results, including
+    the split path (3 buckets for 20 k reads overflow the LDS table)."""
+    monkeypatch.setenv("SNK_COUNT_PERSIST", str(persist))
+    from supernova_amd.engine import Params
+    c = goldens.load("synth_20k_err")
+    rows, quals, bc, lens = _to_dev(c)
+    res = engine.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, params=Params(K=48, n_buckets=n_buckets),
+                             ign_bc_below=c.ign_bc_below)
+    if n_buckets == 3:
+        assert res.buckets_split >= 1
+    _check_against(res, c.exp_keys, c.exp_counts, c.exp_ctx, c.exp_unitigs, c.exp_goodlens, c.exp_hist)
+
+
 def test_grouped_per_barcode_graphs(engine, graph_stage):
     """BASELINE config 5: per-group (per-barcode) local graphs.  One grouped run == the oracle applied to every group's
     reads on its own (frequency rule only): tables, pruned contexts and unitigs per group."""
