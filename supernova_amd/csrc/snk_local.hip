@@ -124,15 +124,22 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
     if (tid == 0) bcnt = 0;
     constexpr int NPT = (CAP + T - 1) / T;             // nodes per thread
     uint64_t myv[NPT];
+    snk_kmer kq[NPT];
 #pragma unroll
-    for (int q = 0; q < NPT; ++q) {
+    for (int q = 0; q < NPT; ++q) {          // all loads first, then the LDS stores
         const uint32_t i = tid + q * T;
         myv[q] = 0;
         if (i < n) {
-            const snk_kmer k = load_key(keys, ch.base + i);
+            kq[q] = load_key(keys, ch.base + i);
             myv[q] = vals[ch.base + i];
-            khi[i] = k.hi;
-            klo[i] = (klo_w)(k.lo >> KLS);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NPT; ++q) {
+        const uint32_t i = tid + q * T;
+        if (i < n) {
+            khi[i] = kq[q].hi;
+            klo[i] = (klo_w)(kq[q].lo >> KLS);
         }
     }
     __syncthreads();
@@ -425,19 +432,38 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
     const uint32_t c_foff = EMIT ? foff[c] : 0u;       // issued now, needed after the ranking
     const uint64_t c_boff = EMIT ? boff[c] : 0ull;
     if (tid == 0) { fcnt = 0; bcnt = 0; changed = 0; }
-    for (uint32_t i = tid; i < n; i += T) {
-        const uint64_t gi = ch.base + i;
-        const snk_kmer k = load_key(keys, gi);
-        khi[i] = k.hi;
-        klo[i] = (klo_w)(k.lo >> KLS);
-        snk_kmer kb = k;
-        if (GR) kb.lo &= ~0xFFFFFFFFull;                   // the group id is not part of the sequence
-        palL[i] = snk_kmer_eq(kb, snk_kmer_rc<K>(kb)) ? 1 : 0;
-        ctxL[i] = ctx[gi];
-        pendL[i] = pend[gi];
-        const uint32_t n0 = nbr[2 * gi], n1 = nbr[2 * gi + 1];
-        nbL[2 * i] = n0 == NONE ? NONE16 : (uint16_t)n0;
-        nbL[2 * i + 1] = n1 == NONE ? NONE16 : (uint16_t)n1;
+    {   // every load of the chunk is issued before the first LDS store (a chunk wave starts with 5 loads per node)
+        constexpr int NPT = (CAP + T - 1) / T;
+        snk_kmer kq[NPT];
+        uint32_t cq[NPT], pq[NPT];
+        uint2 nq[NPT];
+#pragma unroll
+        for (int q = 0; q < NPT; ++q) {
+            const uint32_t i = tid + q * T;
+            if (i < n) {
+                const uint64_t gi = ch.base + i;
+                kq[q] = load_key(keys, gi);
+                cq[q] = ctx[gi];
+                pq[q] = pend[gi];
+                nq[q] = *reinterpret_cast<const uint2*>(nbr + 2 * gi);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NPT; ++q) {
+            const uint32_t i = tid + q * T;
+            if (i < n) {
+                const snk_kmer k = kq[q];
+                khi[i] = k.hi;
+                klo[i] = (klo_w)(k.lo >> KLS);
+                snk_kmer kb = k;
+                if (GR) kb.lo &= ~0xFFFFFFFFull;               // the group id is not part of the sequence
+                palL[i] = snk_kmer_eq(kb, snk_kmer_rc<K>(kb)) ? 1 : 0;
+                ctxL[i] = (uint8_t)cq[q];
+                pendL[i] = (uint8_t)pq[q];
+                nbL[2 * i] = nq[q].x == NONE ? NONE16 : (uint16_t)nq[q].x;
+                nbL[2 * i + 1] = nq[q].y == NONE ? NONE16 : (uint16_t)nq[q].y;
+            }
+        }
     }
     __syncthreads();
     // reciprocal-unique links inside the chunk (BuildReadQGraph48.cc:408-428): state = node << 1 | exit side

@@ -90,9 +90,20 @@ __global__ void __launch_bounds__(BD, K == 48 ? 5 : 4) snk_msp_kernel(snk_msp_ar
         uint64_t nrows = n_reads - r0 < (uint64_t)BD ? n_reads - r0 : (uint64_t)BD;
         uint32_t total = (uint32_t)nrows * row_words;
         const uint32_t* src = a.rows + r0 * row_words;
-        for (uint32_t idx = tid; idx < total; idx += BD) {
-            uint32_t t = idx / row_words, w = idx - t * row_words;
-            rowL[w * BD + t] = src[idx];
+        // row_words (<= 16) words per thread, all loads in flight before the first LDS store
+        uint32_t v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint32_t idx = tid + q * BD;
+            v[q] = ((uint32_t)q < row_words && idx < total) ? src[idx] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint32_t idx = tid + q * BD;
+            if ((uint32_t)q < row_words && idx < total) {
+                const uint32_t t = idx / row_words, w = idx - t * row_words;
+                rowL[w * BD + t] = v[q];
+            }
         }
     }
     __syncthreads();
