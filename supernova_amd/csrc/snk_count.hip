@@ -34,7 +34,8 @@ constexpr int MAX_SPLIT_LOG2 = 16;
 #endif
 #define LDS_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #ifdef SNK_COUNT_PROF
-#define PROF(n) do { if (tid == 0) { const long long _t = clock64(); atomicAdd(&a.prof[n], (unsigned long long)(_t - prof_t)); prof_t = _t; } } while (0)
+// thread 0's cycles per phase, accumulated in registers and added to the global counters once per workgroup
+#define PROF(n) do { if (tid == 0) { const long long _t = clock64(); prof_acc[n] += (unsigned long long)(_t - prof_t); prof_t = _t; } } while (0)
 #else
 #define PROF(n) do {} while (0)
 #endif
@@ -91,6 +92,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     constexpr uint32_t LIMIT = SLOTS - THREADS - 64;   // claims allowed before a sub-pass is declared overflowing
 #ifdef SNK_COUNT_PROF
     long long prof_t = clock64();
+    unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     // a.bucket_stride != 0: the grid is one residency wave of workgroups and each walks buckets blockIdx.x, +stride, ...
     // (no dispatch gap between buckets); 0: one bucket per workgroup
@@ -331,11 +333,20 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
         const uint32_t nvalid = LDS_LOAD(&ctl[5]);
         if (nvalid) {
             const uint32_t region = bucket % a.n_regions;
-            if (tid == 0) {
-                unsigned long long b0 = atomicAdd(&a.region_cursor[region], (unsigned long long)nvalid);
-                ctl[6] = (uint32_t)b0;
-                ctl[7] = (uint32_t)(b0 >> 32);
+            // the reservation is a device-scope atomic (a round trip of microseconds): it is issued first, every thread
+            // collects its survivors (LDS reads, placement order) while it is in flight, and only then is the
+            // returned base published
+            unsigned long long b0 = 0;
+            if (tid == 0) b0 = atomicAdd(&a.region_cursor[region], (unsigned long long)nvalid);
+            constexpr int SPT = (SLOTS + THREADS - 1) / THREADS;
+            uint32_t e_pos[SPT];           // (holding keys and values here as well costs 14 spilled registers)
+#pragma unroll
+            for (int q = 0; q < SPT; ++q) {
+                const int s = tid + q * THREADS;
+                e_pos[q] = 0xFFFFFFFFu;
+                if (s < SLOTS && cnt[s]) e_pos[q] = atomicAdd(&ctl[8], 1u);
             }
+            if (tid == 0) { ctl[6] = (uint32_t)b0; ctl[7] = (uint32_t)(b0 >> 32); }
             __syncthreads();
             const uint64_t rbase = ((uint64_t)LDS_LOAD(&ctl[7]) << 32) | LDS_LOAD(&ctl[6]);
             if (rbase + nvalid <= a.region_cap) {
@@ -348,15 +359,14 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                         if (e < a.extra_cap) a.extra[e] = make_uint4(bucket, (uint32_t)rbase, nvalid, (split_lg << 24) | split_id);
                     }
                 }
-                for (int s = tid; s < SLOTS; s += THREADS) {
-                    const uint32_t c = cnt[s];
-                    if (c) {
-                        const uint32_t pos = atomicAdd(&ctl[8], 1u);
+#pragma unroll
+                for (int q = 0; q < SPT; ++q)
+                    if (e_pos[q] != 0xFFFFFFFFu) {
+                        const int s = tid + q * THREADS;
                         const uint32_t cx = (ctxw[s >> 2] >> (8 * (s & 3))) & 0xFFu;
-                        a.out_keys[gbase + pos] = ((snk_u128)khi[s] << 64) | (snk_u128)klo_unpack<K, GROUPED>(klo[s]);
-                        a.out_vals[gbase + pos] = ((uint64_t)c << 8) | cx;
+                        a.out_keys[gbase + e_pos[q]] = ((snk_u128)khi[s] << 64) | (snk_u128)klo_unpack<K, GROUPED>(klo[s]);
+                        a.out_vals[gbase + e_pos[q]] = ((uint64_t)cnt[s] << 8) | cx;
                     }
-                }
             } else if (tid == 0) {
                 a.status[0] = 1;
             }
@@ -367,6 +377,9 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     if (tid == 0 && splits_done) atomicAdd(&a.status[2], 1u);
     if (a.bucket_stride == 0) break;
     }
+#ifdef SNK_COUNT_PROF
+    if (tid == 0) for (int q = 0; q < 8; ++q) atomicAdd(&a.prof[q], prof_acc[q]);
+#endif
 }
 
 template <int K> struct cfg;
