@@ -422,11 +422,15 @@ class ShardedEngine:
         if me == 0:
             Ft = t_nk.numel() // 4
             # fragment starts are offsets into their rank's base buffer: shift by the buffers in front
-            starts = t_start.view(torch.int64)
-            shift = torch.zeros(W + 1, dtype=torch.int64, device=dev)
-            shift[1:] = torch.cumsum(torch.tensor(base_bytes, dtype=torch.int64, device=dev), 0)
-            per_rank = torch.tensor([b // 8 for b in start_bytes], dtype=torch.int64, device=dev)
-            starts_all = (starts + torch.repeat_interleave(shift[:W], per_rank)).contiguous()
+            # (in place, one slice per source rank: torch.repeat_interleave over the fragments took 6.8 ms per 17.5 M)
+            starts_all = t_start.view(torch.int64)
+            a, shift = 0, 0
+            for q in range(W):
+                nq = start_bytes[q] // 8
+                if shift and nq:
+                    starts_all[a:a + nq] += shift
+                a += nq
+                shift += base_bytes[q]
             if starts_all.numel() == 0:
                 starts_all = torch.zeros(1, dtype=torch.int64, device=dev)
             if t_link.numel() == 0:
