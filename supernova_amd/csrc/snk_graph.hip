@@ -451,15 +451,14 @@ static int rank_lists_wyllie(snk_ctx* ctx, hipStream_t st, uint32_t* link, uint6
 // (21-28 rounds of random 12-byte gathers on the benchmark, 60% of the whole step); here every state is touched
 // twice: list heads and a hashed 1/64 sample of the states are "splitters", each walks to the next splitter, the
 // short splitter list is ranked by pointer jumping, and a second walk hands the ranks to the states in between.
-constexpr uint32_t SPLIT_MASK = 63;
-__device__ __forceinline__ bool sampled_state(uint32_t s) { return ((snk_mix32(s >> 1) >> 7) & SPLIT_MASK) == 0; }
+__device__ __forceinline__ bool sampled_state(uint32_t s, uint32_t split_mask) { return ((snk_mix32(s >> 1) >> 7) & split_mask) == 0; }
 
-__global__ void __launch_bounds__(TB) spl_mark_kernel(const uint32_t* __restrict__ link, uint64_t ns, uint8_t* __restrict__ spl,
-                                                      uint32_t* __restrict__ flag32) {
+__global__ void __launch_bounds__(TB) spl_mark_kernel(const uint32_t* __restrict__ link, uint64_t ns, uint32_t split_mask,
+                                                      uint8_t* __restrict__ spl, uint32_t* __restrict__ flag32) {
     uint64_t s = (uint64_t)blockIdx.x * TB + threadIdx.x;
     if (s >= ns) return;
     bool head = link[s ^ 1] == NONE;                 // nobody walks into s: it starts a list
-    bool sp = head || sampled_state((uint32_t)s);
+    bool sp = head || sampled_state((uint32_t)s, split_mask);
     spl[s] = sp ? 1 : 0;
     flag32[s] = sp ? 1u : 0u;
 }
@@ -536,7 +535,8 @@ static int rank_lists(snk_ctx* ctx, hipStream_t st, uint32_t* link, uint64_t n, 
     G_ALLOC(flag32, uint32_t, ns + 1);
     G_ALLOC(sid, uint32_t, ns + 1);
     SNK_HIP_TRY(hipMemsetAsync(flag32 + ns, 0, 4, st));
-    hipLaunchKernelGGL(spl_mark_kernel, dim3(nblk(ns)), dim3(TB), 0, st, link, ns, spl, flag32);
+    const uint32_t split_mask = (1u << snk_env_u32("SNK_SPLIT_LOG2", 6)) - 1u;
+    hipLaunchKernelGGL(spl_mark_kernel, dim3(nblk(ns)), dim3(TB), 0, st, link, ns, split_mask, spl, flag32);
     {
         size_t tb = 0;
         SNK_HIP_TRY(rocprim::exclusive_scan((void*)nullptr, tb, flag32, sid, 0u, (size_t)(ns + 1), rocprim::plus<uint32_t>(), st));
