@@ -273,6 +273,55 @@ def test_repeatability_and_full_size_properties(engine):
             assert j < 0 or s[j] < rc[j]
 
 
+class _DevArr:
+    """A device array of the library seen by torch (no copy): __cuda_array_interface__ over the raw pointer."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def test_full_size_properties_1e8(engine, graph_stage):
+    """BASELINE config 2 at its full size (100 M x 150 bp, 10.2 G k-mer instances, one GPU), checked on the device through
+    size-independent properties: strictly ascending keys, every count >= min_freq, spectrum and unitig lengths add up
+    to the table size, and -- the checksum of checksums -- table and unitigs are identical when the same reads go
+    through a different bucket count (different supermer grouping, different chunking, different fragments)."""
+    import torch
+    from supernova_amd import synth
+    from supernova_amd.engine import Params
+    if graph_stage == "global":
+        pytest.skip("one pass over the full size is enough; the global stage is cross-checked on the small cases")
+    n = 100_000_000
+    sp = synth.synth_params(n, seed=0x5EED0002)
+    rows, quals, bc = engine.synth(sp)
+
+    def run(nb):
+        r = engine.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48, n_buckets=nb))
+        nk = r.n_kmers
+        keys = torch.as_tensor(_DevArr(r.raw.keys, 2 * nk, "<i8"), device="cuda").view(nk, 2)      # lo, hi
+        cnt = torch.as_tensor(_DevArr(r.raw.counts, nk, "<i4"), device="cuda")
+        ctx = torch.as_tensor(_DevArr(r.raw.ctx, nk, "|u1"), device="cuda")
+        lo, hi = keys[:, 0], keys[:, 1]
+        # ascending as unsigned 128-bit numbers: flip the sign bit to compare int64 as uint64
+        f = lambda t: t ^ torch.tensor(-(1 << 63), dtype=torch.int64, device="cuda")
+        h0, h1, l0, l1 = f(hi[:-1]), f(hi[1:]), f(lo[:-1]), f(lo[1:])
+        assert bool(((h1 > h0) | ((h1 == h0) & (l1 > l0))).all())
+        assert int(cnt.min()) >= 3
+        chk = (hi * 0x9E3779B97F4A7C15 + lo * 0x42B2AE3D27D4EB4F + cnt.to(torch.int64) * 0x165667B19E3779F9
+               + ctx.to(torch.int64) * 0x27D4EB2F165667C5).sum()
+        spec = torch.as_tensor(_DevArr(r.raw.spectrum, int(r.raw.spectrum_bins), "<i8"), device="cuda")
+        assert int(spec.sum()) == nk
+        off = torch.as_tensor(_DevArr(r.raw.unitig_off, r.n_unitigs + 1, "<i8"), device="cuda")
+        bases = torch.as_tensor(_DevArr(r.raw.unitig_bases, r.unitig_total_bases, "|u1"), device="cuda")
+        assert int((off[1:] - off[:-1] - 47).sum()) == nk
+        return dict(n_inst=r.n_instances, nk=nk, chk=int(chk), nu=r.n_unitigs, off=off.clone(), bases=bases.clone())
+
+    a = run(0)
+    assert a["n_inst"] > 10_000_000_000 and a["nk"] > 200_000_000
+    b = run(1_500_007)
+    assert (a["n_inst"], a["nk"], a["chk"], a["nu"]) == (b["n_inst"], b["nk"], b["chk"], b["nu"])
+    assert torch.equal(a["off"], b["off"]) and torch.equal(a["bases"], b["bases"])
+
+
 def test_unsorted_table_mode(engine, graph_stage):
     """SNK_F_UNSORTED_TABLE: same table (as a set) and the same unitigs, keys left in bucket order."""
     from supernova_amd.engine import Params
