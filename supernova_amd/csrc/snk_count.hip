@@ -26,6 +26,7 @@ namespace {
 constexpr uint32_t BC_MULTI = 0xFFFFFFFEu;
 constexpr uint32_t BC_IGN = 0xFFFFFFFFu;
 constexpr int MAX_SPLIT_LOG2 = 16;
+#define SNK_COUNT_MAXSEG 32      // record segments per bucket (sharded runs: one per source rank)
 #ifndef SNK_COUNT_THREADS
 #define SNK_COUNT_THREADS 768
 #endif
@@ -80,7 +81,8 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     uint32_t* ctl = rec + 8 * BATCH;                                                // [64] control words
     uint32_t* dd = ctl + 64;                                                        // [DD] supermer de-duplication table (leader index + 1)
     uint32_t* wgt = dd + DD;                                                        // [BATCH] copies folded into each leader
-    uint16_t* lead = reinterpret_cast<uint16_t*>(wgt + BATCH);                      // [BATCH] r-th leading (non-folded) supermer
+    uint32_t* segi = wgt + BATCH;                                                   // [3][MAXSEG] segment start (lo, hi), length
+    uint16_t* lead = reinterpret_cast<uint16_t*>(segi + 3 * SNK_COUNT_MAXSEG);      // [BATCH] r-th leading (non-folded) supermer
     uint16_t* lpre = lead + BATCH;                                                  // [BATCH+2] its first k-mer instance (+ sentinel)
     uint16_t* cidx = lpre + BATCH + 2;                                              // [NCI] leader rank that owns instance 32*w
     // ctl[0] unused, ctl[1] occupied slots, ctl[2] overflow flag, ctl[3] split log2, ctl[4] split id,
@@ -110,6 +112,12 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     const uint64_t beg0 = a.seg_beg[bucket], end0 = a.seg_end[bucket];
     uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = make_uint4(0, 0, 0, 0);
     if (tid < BATCH && beg0 + tid < end0) { pf0 = a.records[(beg0 + tid) * 2]; pf1 = a.records[(beg0 + tid) * 2 + 1]; }
+    // more than one segment (sharded runs: one per source rank): the segments are counted as ONE concatenated record
+    // stream -- batches stay full and identical supermers from different sources fold -- so every thread needs all bounds
+    if (a.nseg > 1 && tid < (int)a.nseg) {
+        const uint64_t b = a.seg_beg[(uint64_t)tid * a.seg_stride + bucket], e = a.seg_end[(uint64_t)tid * a.seg_stride + bucket];
+        segi[tid] = (uint32_t)b; segi[SNK_COUNT_MAXSEG + tid] = (uint32_t)(b >> 32); segi[2 * SNK_COUNT_MAXSEG + tid] = (uint32_t)(e - b);
+    }
     bool first_batch = true;
     while (sp) {
         __syncthreads();          // the previous sub-pass / bucket is done with the table; stack entries are visible
@@ -123,16 +131,23 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
         __syncthreads();
         PROF(1);
 
-        for (uint32_t seg = 0; seg < a.nseg; ++seg) {
-            const uint64_t beg = seg ? a.seg_beg[(uint64_t)seg * a.seg_stride + bucket] : beg0;
-            const uint64_t end = seg ? a.seg_end[(uint64_t)seg * a.seg_stride + bucket] : end0;
-            for (uint64_t base = beg; base < end; base += BATCH) {
+        uint32_t total_v = (uint32_t)(end0 - beg0);           // records of the bucket over all segments
+        if (a.nseg > 1) { total_v = 0; for (uint32_t sg = 0; sg < a.nseg; ++sg) total_v += LDS_LOAD(&segi[2 * SNK_COUNT_MAXSEG + sg]); }
+        {
+            for (uint32_t vb = 0; vb < total_v; vb += BATCH) {
                 // ---- stage one batch of supermer records (coalesced 32-byte loads) and scan their k-mer counts
-                const uint64_t idx = base + tid;
+                const uint32_t v = vb + tid;
                 uint32_t nkm = 0;
-                const bool use_pf = first_batch && seg == 0 && base == beg0;
+                bool use_pf = first_batch && vb == 0;           // the prefetch holds records beg0 + tid of segment 0
                 first_batch = false;
-                if (tid < BATCH && idx < end) {
+                if (tid < BATCH && v < total_v) {
+                    uint64_t idx = beg0 + v;
+                    if (a.nseg > 1) {
+                        uint32_t acc = 0, sg = 0;
+                        for (; sg + 1 < a.nseg; ++sg) { const uint32_t l = segi[2 * SNK_COUNT_MAXSEG + sg]; if (v < acc + l) break; acc += l; }
+                        idx = (((uint64_t)segi[SNK_COUNT_MAXSEG + sg] << 32) | segi[sg]) + (v - acc);
+                        use_pf = use_pf && sg == 0;
+                    }
                     const uint4 r0 = use_pf ? pf0 : a.records[idx * 2], r1 = use_pf ? pf1 : a.records[idx * 2 + 1];
                     rec[0 * BATCH + tid] = r0.x; rec[1 * BATCH + tid] = r0.y; rec[2 * BATCH + tid] = r0.z;
                     rec[3 * BATCH + tid] = r0.w; rec[4 * BATCH + tid] = r1.x; rec[5 * BATCH + tid] = r1.y;
@@ -389,7 +404,7 @@ template <> struct cfg<60> { static constexpr int THREADS = SNK_COUNT_THREADS; s
 template <int K, bool G>
 size_t lds_bytes() {
     constexpr size_t S = cfg<K>::SLOTS, B = (K == 48 && !G && S >= 2048) ? 512 : 256, DD = 2 * B, NCI = B * (K - SNK_M + 1) / 32 + 2;
-    return S * (8 + sizeof(typename klo_t<K, G>::type) + 4 + 4 + 4) + S + 4 * (8 * B + 64 + DD + B) + 2 * (B + B + 2 + NCI) + 16;
+    return S * (8 + sizeof(typename klo_t<K, G>::type) + 4 + 4 + 4) + S + 4 * (8 * B + 64 + DD + B + 3 * SNK_COUNT_MAXSEG) + 2 * (B + B + 2 + NCI) + 16;
 }
 
 template <int K, bool G>
@@ -458,6 +473,7 @@ uint32_t snk_count_slots(uint32_t K) { return K == 60 ? cfg<60>::SLOTS : cfg<48>
 
 int snk_launch_count(uint32_t K, hipStream_t st, const snk_count_args& a, char* err, size_t errcap) {
     if (a.NB == 0) return SNK_OK;
+    if (a.nseg > SNK_COUNT_MAXSEG) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "more than %d record segments per bucket (nseg=%u)", SNK_COUNT_MAXSEG, a.nseg);
     if (a.grouped) {
         if (K != 48 || a.bc_mode) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "grouped counting needs K=48 and no barcode rule");
         return launch<48, true>(st, a, err, errcap);
