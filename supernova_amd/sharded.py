@@ -108,10 +108,15 @@ class SimWorld:
     """W in-process ranks (threads) that exchange through shared lists -- the SPMD code path of the real
     multi-GPU run on ONE GPU (tests), with the transport replaced by tensor copies."""
 
-    def __init__(self, world: int):
+    def __init__(self, world: int, serial: bool = False):
+        """serial=True: between two exchanges the ranks compute one after the other (rank 0 first), so the per-rank phase
+        timings are those of a rank that has the GPU to itself (tools/sim_scale.py)."""
         self.world = world
         self.barrier_obj = threading.Barrier(world)
         self.slots = [None] * world
+        self.serial = serial
+        self.turn = threading.Condition()
+        self.turn_of = 0
 
     def comm(self, rank: int) -> "SimComm":
         return SimComm(self, rank)
@@ -121,18 +126,40 @@ class SimComm:
     def __init__(self, w: SimWorld, rank: int):
         self.w, self.rank, self.world = w, rank, w.world
 
+    def _end_section(self):       # my compute section is over: the next rank may start its own
+        if self.w.serial:
+            torch.cuda.synchronize()
+            with self.w.turn:
+                while self.w.turn_of != self.rank:
+                    self.w.turn.wait()
+                self.w.turn_of = self.rank + 1
+                self.w.turn.notify_all()
+
+    def _begin_section(self):     # after an exchange: wait until every lower rank has finished its section
+        if self.w.serial:
+            with self.w.turn:
+                while self.w.turn_of != self.rank:
+                    self.w.turn.wait()
+
     def _exchange(self, obj):
+        self._end_section()
         self.w.slots[self.rank] = obj
         self.w.barrier_obj.wait()
         allv = list(self.w.slots)
+        if self.w.serial and self.rank == 0:
+            self.w.turn_of = 0
         self.w.barrier_obj.wait()
         return allv
 
     def allreduce_sum_int(self, v, device):
-        return sum(self._exchange(int(v)))
+        r = sum(self._exchange(int(v)))
+        self._begin_section()
+        return r
 
     def all_gather_int(self, v, device):
-        return [int(x) for x in self._exchange(int(v))]
+        r = [int(x) for x in self._exchange(int(v))]
+        self._begin_section()
+        return r
 
     def all_to_all_v(self, send, send_counts, alloc=None):
         torch.cuda.synchronize()
@@ -145,6 +172,7 @@ class SimComm:
         recv = torch.cat(parts) if parts else send[:0]
         torch.cuda.synchronize()
         self.w.barrier_obj.wait()     # nobody reuses its send buffer before everyone has copied
+        self._begin_section()
         return recv, counts
 
     def all_to_all_equal(self, send):
@@ -154,7 +182,8 @@ class SimComm:
         return recv.view(send.dtype).view(self.world, m)
 
     def barrier(self):
-        self.w.barrier_obj.wait()
+        self._exchange(None)
+        self._begin_section()
 
 
 # ------------------------------------------------------------------------------------------------ planning helpers

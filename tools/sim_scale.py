@@ -1,5 +1,6 @@
 """W simulated ranks on ONE GPU at bench-like sizes: per-rank phase timings of the sharded path (the rank-0
-join is the serial part).  usage: python tools/sim_scale.py W reads_per_rank [reps]"""
+join is the serial part).  usage: python tools/sim_scale.py W reads_per_rank [reps] [serial]
+(serial: the ranks compute one after the other between exchanges, so every phase time is that of a rank alone on the GPU)"""
 import sys, threading, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -10,7 +11,7 @@ from supernova_amd.engine import Engine, Params
 from supernova_amd.sharded import ShardedEngine, SimWorld
 
 W = int(sys.argv[1]); per = int(float(sys.argv[2])); reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-world = SimWorld(W)
+world = SimWorld(W, serial=len(sys.argv) > 4 and sys.argv[4] == 'serial')
 sp = synth.synth_params(W * per, seed=0x5EED0002)
 out = [None] * W
 errs = []
@@ -20,10 +21,14 @@ def worker(r):
         torch.cuda.set_device(0)
         e = Engine(0)
         rows, quals, bc = e.synth(sp, first=r * per, n=per)
-        sh = ShardedEngine(e, world.comm(r))
+        c = world.comm(r)
+        sh = ShardedEngine(e, c)
         for rep in range(reps):
             torch.cuda.synchronize(); world.barrier_obj.wait(); t0 = time.time()
+            if r == 0: world.turn_of = 0
+            c._begin_section()
             res = sh.count_graph(rows, sp.read_len, quals=quals, bc=bc, params=Params(K=48), read_index_base=r * per)
+            c._end_section()
             torch.cuda.synchronize(); t1 = time.time()
             out[r] = (t1 - t0, res.phase_ms, res.n_kmers, res.n_frags, res.n_queries, res.n_unitigs, res.n_instances)
             world.barrier_obj.wait()
