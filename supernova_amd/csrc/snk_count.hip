@@ -60,7 +60,7 @@ template <int K, bool G> __device__ __forceinline__ uint64_t klo_unpack(typename
     if constexpr (G) return v; else return lo_unpack<K>(v);
 }
 
-template <int K, int THREADS, int SLOTS, bool GROUPED>
+template <int K, int THREADS, int SLOTS, bool GROUPED, bool MULTI>      // MULTI: more than one record segment per bucket
 __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a) {
     // supermers staged per batch.  A 4000-instance bucket holds ~270 (sigma ~100): with 512 slots nearly every bucket is
     // ONE batch (with 256, 55 % of the buckets ran a second, mostly empty batch through all the phases below).  K=60 and
@@ -81,10 +81,10 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     uint32_t* ctl = rec + 8 * BATCH;                                                // [64] control words
     uint32_t* dd = ctl + 64;                                                        // [DD] supermer de-duplication table (leader index + 1)
     uint32_t* wgt = dd + DD;                                                        // [BATCH] copies folded into each leader
-    uint32_t* segi = wgt + BATCH;                                                   // [3][MAXSEG] segment start (lo, hi), length
-    uint16_t* lead = reinterpret_cast<uint16_t*>(segi + 3 * SNK_COUNT_MAXSEG);      // [BATCH] r-th leading (non-folded) supermer
+    uint16_t* lead = reinterpret_cast<uint16_t*>(wgt + BATCH);                      // [BATCH] r-th leading (non-folded) supermer
     uint16_t* lpre = lead + BATCH;                                                  // [BATCH+2] its first k-mer instance (+ sentinel)
     uint16_t* cidx = lpre + BATCH + 2;                                              // [NCI] leader rank that owns instance 32*w
+    uint32_t* segi = reinterpret_cast<uint32_t*>(smem_raw + (((size_t)(reinterpret_cast<unsigned char*>(cidx + NCI) - smem_raw) + 15) & ~(size_t)15));   // [3][MAXSEG] segment start (lo, hi), length
     // ctl[0] unused, ctl[1] occupied slots, ctl[2] overflow flag, ctl[3] split log2, ctl[4] split id,
     // ctl[5] valid entries of the sub-pass, ctl[6..7] reserved base (lo,hi), ctl[8] placement counter,
     // ctl[16..16+2*MAX) split stack (MAX = 17 levels -> up to ctl[51]), ctl[52..59] wave totals of the batch scan
@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     if (tid < BATCH && beg0 + tid < end0) { pf0 = a.records[(beg0 + tid) * 2]; pf1 = a.records[(beg0 + tid) * 2 + 1]; }
     // more than one segment (sharded runs: one per source rank): the segments are counted as ONE concatenated record
     // stream -- batches stay full and identical supermers from different sources fold -- so every thread needs all bounds
-    if (a.nseg > 1 && tid < (int)a.nseg) {
+    if (MULTI && tid < (int)a.nseg) {
         const uint64_t b = a.seg_beg[(uint64_t)tid * a.seg_stride + bucket], e = a.seg_end[(uint64_t)tid * a.seg_stride + bucket];
         segi[tid] = (uint32_t)b; segi[SNK_COUNT_MAXSEG + tid] = (uint32_t)(b >> 32); segi[2 * SNK_COUNT_MAXSEG + tid] = (uint32_t)(e - b);
     }
@@ -131,18 +131,19 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
         __syncthreads();
         PROF(1);
 
-        uint32_t total_v = (uint32_t)(end0 - beg0);           // records of the bucket over all segments
-        if (a.nseg > 1) { total_v = 0; for (uint32_t sg = 0; sg < a.nseg; ++sg) total_v += LDS_LOAD(&segi[2 * SNK_COUNT_MAXSEG + sg]); }
+        // iteration space: absolute record indices of the one segment, or offsets into the concatenation of all segments
+        uint64_t vbeg = beg0, vend = end0;
+        if (MULTI) { vbeg = 0; vend = 0; for (uint32_t sg = 0; sg < a.nseg; ++sg) vend += LDS_LOAD(&segi[2 * SNK_COUNT_MAXSEG + sg]); }
         {
-            for (uint32_t vb = 0; vb < total_v; vb += BATCH) {
+            for (uint64_t base = vbeg; base < vend; base += BATCH) {
                 // ---- stage one batch of supermer records (coalesced 32-byte loads) and scan their k-mer counts
-                const uint32_t v = vb + tid;
+                uint64_t idx = base + tid;
                 uint32_t nkm = 0;
-                bool use_pf = first_batch && vb == 0;           // the prefetch holds records beg0 + tid of segment 0
+                bool use_pf = first_batch && base == vbeg;      // the prefetch holds records beg0 + tid of segment 0
                 first_batch = false;
-                if (tid < BATCH && v < total_v) {
-                    uint64_t idx = beg0 + v;
-                    if (a.nseg > 1) {
+                if (tid < BATCH && idx < vend) {
+                    if (MULTI) {
+                        const uint32_t v = (uint32_t)idx;
                         uint32_t acc = 0, sg = 0;
                         for (; sg + 1 < a.nseg; ++sg) { const uint32_t l = segi[2 * SNK_COUNT_MAXSEG + sg]; if (v < acc + l) break; acc += l; }
                         idx = (((uint64_t)segi[SNK_COUNT_MAXSEG + sg] << 32) | segi[sg]) + (v - acc);
@@ -404,12 +405,12 @@ template <> struct cfg<60> { static constexpr int THREADS = SNK_COUNT_THREADS; s
 template <int K, bool G>
 size_t lds_bytes() {
     constexpr size_t S = cfg<K>::SLOTS, B = (K == 48 && !G && S >= 2048) ? 512 : 256, DD = 2 * B, NCI = B * (K - SNK_M + 1) / 32 + 2;
-    return S * (8 + sizeof(typename klo_t<K, G>::type) + 4 + 4 + 4) + S + 4 * (8 * B + 64 + DD + B + 3 * SNK_COUNT_MAXSEG) + 2 * (B + B + 2 + NCI) + 16;
+    return S * (8 + sizeof(typename klo_t<K, G>::type) + 4 + 4 + 4) + S + 4 * (8 * B + 64 + DD + B) + 2 * (B + B + 2 + NCI) + 16 + 4 * 3 * SNK_COUNT_MAXSEG + 16;
 }
 
 template <int K, bool G>
 int launch(hipStream_t st, const snk_count_args& a, char* err, size_t errcap) {
-    auto kern = snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G>;
+    auto kern = a.nseg > 1 ? snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G, true> : snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G, false>;
     size_t lds = lds_bytes<K, G>();
     SNK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     snk_count_args b = a;
