@@ -233,6 +233,12 @@ int snk_shard_join(snk_ctx* ctx, uint32_t K, uint64_t n_frags, const void* d_nk,
 int snk_shard_join_linked(snk_ctx* ctx, uint32_t K, uint64_t n_frags, const void* d_nk, const void* d_hl_self, const void* d_hl_nb,
                           void* d_flink, const void* d_boff, const void* d_bases, uint64_t total_bases, snk_shard_unitigs* out,
                           void* stream, char* err, size_t errcap);
+/* fragment bases on the wire (the gather to rank 0): 2 bits per base, 16 bases per 32-bit word, base j at bits 2j --
+ * the .bv byte packing (lib/tada/src/debruijn.rs:895-929).  snk_pack2_bytes(n) = size of the packed buffer. */
+uint64_t snk_pack2_bytes(uint64_t n_bases);
+int snk_dev_pack2(snk_ctx* ctx, const void* d_bases, uint64_t n_bases, void* d_packed, void* stream);
+int snk_dev_unpack2(snk_ctx* ctx, const void* d_packed, uint64_t n_bases, void* d_bases, void* stream);
+
 
 /* ---- host-pointer convenience + graph hand-off -------------- */
 typedef struct snk_reads {

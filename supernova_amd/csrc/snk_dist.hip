@@ -244,3 +244,72 @@ extern "C" int snk_shard_join_linked(snk_ctx* ctx, uint32_t K, uint64_t n_frags,
     out->rank_rounds = jo.rank_rounds;
     return SNK_OK;
 }
+
+
+// ---- fragment bases on the wire: 2 bits per base (the gather to rank 0 is the only place where bases cross xGMI)
+namespace {
+__global__ void __launch_bounds__(256) pack2_kernel(const uint8_t* __restrict__ in, uint64_t n, uint8_t* __restrict__ out) {
+    // one thread per 16 bases -> one 32-bit word (base j of a byte at bits 2*(j%4), as in the .bv packing)
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t b0 = t * 16;
+    if (b0 >= n) return;
+    uint32_t w = 0;
+    if (b0 + 16 <= n) {
+        const uint4 v = *reinterpret_cast<const uint4*>(in + b0);
+        const uint32_t q[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w |= ((q[k] >> (8 * j)) & 3u) << (2 * (4 * k + j));
+    } else {
+        for (uint64_t j = 0; b0 + j < n; ++j) w |= (uint32_t)(in[b0 + j] & 3u) << (2 * j);
+    }
+    reinterpret_cast<uint32_t*>(out)[t] = w;
+}
+__global__ void __launch_bounds__(256) unpack2_kernel(const uint8_t* __restrict__ in, uint64_t n, uint8_t* __restrict__ out) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t b0 = t * 16;
+    if (b0 >= n) return;
+    const uint32_t w = reinterpret_cast<const uint32_t*>(in)[t];
+    if (b0 + 16 <= n && ((uintptr_t)(out + b0) & 15u) == 0) {
+        uint32_t q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            q[k] = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q[k] |= ((w >> (2 * (4 * k + j))) & 3u) << (8 * j);
+        }
+        *reinterpret_cast<uint4*>(out + b0) = make_uint4(q[0], q[1], q[2], q[3]);
+    } else {
+        for (uint64_t j = 0; j < 16 && b0 + j < n; ++j) out[b0 + j] = (uint8_t)((w >> (2 * j)) & 3u);
+    }
+}
+}  // namespace
+
+extern "C" uint64_t snk_pack2_bytes(uint64_t n_bases) { return ((n_bases + 15) / 16) * 4; }
+
+extern "C" int snk_dev_pack2(snk_ctx* ctx, const void* d_bases, uint64_t n_bases, void* d_packed, void* stream) {
+    char* err = nullptr;
+    size_t errcap = 0;
+    if (!ctx || (n_bases && (!d_bases || !d_packed))) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_pack2: NULL argument");
+    if (((uintptr_t)d_bases & 15u) || ((uintptr_t)d_packed & 3u)) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_pack2: bases must be 16-byte, packed 4-byte aligned");
+    if (n_bases == 0) return SNK_OK;
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    const uint64_t nt = (n_bases + 15) / 16;
+    hipLaunchKernelGGL(pack2_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, (const uint8_t*)d_bases, n_bases, (uint8_t*)d_packed);
+    SNK_HIP_TRY(hipGetLastError());
+    return SNK_OK;
+}
+
+extern "C" int snk_dev_unpack2(snk_ctx* ctx, const void* d_packed, uint64_t n_bases, void* d_bases, void* stream) {
+    char* err = nullptr;
+    size_t errcap = 0;
+    if (!ctx || (n_bases && (!d_bases || !d_packed))) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_unpack2: NULL argument");
+    if ((uintptr_t)d_packed & 3u) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_unpack2: packed input must be 4-byte aligned");
+    if (n_bases == 0) return SNK_OK;
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    const uint64_t nt = (n_bases + 15) / 16;
+    hipLaunchKernelGGL(unpack2_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, (const uint8_t*)d_packed, n_bases, (uint8_t*)d_bases);
+    SNK_HIP_TRY(hipGetLastError());
+    return SNK_OK;
+}

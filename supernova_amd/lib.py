@@ -154,6 +154,9 @@ def _declare(lib: C.CDLL) -> None:
         "snk_read_fastb": (C.c_int, [cp, P(u64), P(u32), P(P(C.c_uint16)), P(P(u32)), cp, sz]),
         "snk_read_qualp": (C.c_int, [cp, u64, u32, vp, cp, sz]),
         "snk_read_bci": (C.c_int, [cp, u64, vp, P(u64), cp, sz]),
+        "snk_pack2_bytes": (u64, [u64]),
+        "snk_dev_pack2": (C.c_int, [vp, vp, u64, vp, vp]),
+        "snk_dev_unpack2": (C.c_int, [vp, vp, u64, vp, vp]),
         "snk_shard_hist": (C.c_int, [vp, P(SnkDevReads), P(SnkParams), u32, u32, u32, vp, P(u64), vp, cp, sz]),
         "snk_shard_scatter": (C.c_int, [vp, vp, vp, vp, cp, sz]),
         "snk_shard_count": (C.c_int, [vp, vp, vp, u64, C.c_int, P(u64), vp, cp, sz]),

@@ -445,7 +445,28 @@ class ShardedEngine:
         t_nk, _ = comm.all_to_all_v(dcopy("s_nk", fr.nk, F * 4), to0(F * 4), alloc=lambda nb: pool.get("g_nk", nb))
         t_link, _ = comm.all_to_all_v(dcopy("s_link", flink_p.value, F * 8), to0(F * 8), alloc=lambda nb: pool.get("g_link", nb))
         t_start, start_bytes = comm.all_to_all_v(dcopy("s_start", fr.boff, F * 8), to0(F * 8), alloc=lambda nb: pool.get("g_start", nb))
-        t_bases, base_bytes = comm.all_to_all_v(dcopy("s_bases", fr.bases, TB), to0(TB), alloc=lambda nb: pool.get("g_bases", nb))
+        if W == 1:
+            t_bases, base_bytes = comm.all_to_all_v(dcopy("s_bases", fr.bases, TB), to0(TB), alloc=lambda nb: pool.get("g_bases", nb))
+        else:
+            # the bases are the bulk of the gather (1 byte per k-mer + 47 per fragment): they cross xGMI at 2 bits each
+            all_TB = comm.all_gather_int(TB, dev)
+            pb = int(lib.snk_pack2_bytes(TB))
+            t_pk = pool.get("s_bases2", max(pb, 8))
+            if TB:
+                chk(lib.snk_dev_pack2(e._ctx, fr.bases, TB, t_pk.data_ptr(), st))
+                torch.cuda.current_stream().synchronize()
+            t_pk_all, pk_bytes = comm.all_to_all_v(t_pk[:pb], to0(pb), alloc=lambda nb: pool.get("g_bases2", nb))
+            base_bytes = [0] * W
+            t_bases = t_pk_all[:0]
+            if me == 0:
+                base_bytes = [((x + 15) // 16) * 16 for x in all_TB]          # every rank's bases start 16-byte aligned
+                t_bases = pool.get("g_bases", max(sum(base_bytes), 16))[:sum(base_bytes)]
+                a = b = 0
+                for q in range(W):
+                    if all_TB[q]:
+                        chk(lib.snk_dev_unpack2(e._ctx, t_pk_all.data_ptr() + a, all_TB[q], t_bases.data_ptr() + b, st))
+                    a += pk_bytes[q]
+                    b += base_bytes[q]
         res.joined = None
         res.n_unitigs = 0
         if me == 0:
