@@ -368,8 +368,11 @@ __global__ void __launch_bounds__(TB) bl_resolve_kernel(const snk_u128* __restri
                 }
                 slot = (slot + 1) & mask;
             }
+            // rq[] is not initialised: every pending bit that survives gets its entry here (a side with two surviving
+            // bits is a branch and its entry is never read)
             if (j >= 0) rq[2 * i + (bit >> 2)] = ((uint32_t)j << 1) | (rev ? 1u : 0u);
             else if (do_prune) c &= ~(1u << bit);
+            else rq[2 * i + (bit >> 2)] = NONE;
         }
         ctx[i] = (uint8_t)c;
     }
@@ -817,7 +820,6 @@ static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* er
     }
     SNK_HIP_TRY(hipMemsetAsync(nbnd, 0, ((uint64_t)nchunks + 1) * 4, st));
     SNK_HIP_TRY(hipMemsetAsync(ctr, 0, 64, st));
-    SNK_HIP_TRY(hipMemsetAsync(B->rq, 0xFF, (2 * n + 2) * 4, st));
     bl_shard sh;
     sh.bucket_base = B->premote ? B->rank * B->NBl : 0u;
     sh.NBl = B->premote ? B->NBl : 0u;

@@ -289,7 +289,19 @@ __global__ void __launch_bounds__(256) snk_msp_plan_kernel(const uint16_t* __res
                                                            unsigned long long* __restrict__ out /* [0] instances, [1] live reads */) {
     unsigned long long inst = 0, live = 0;
     const uint64_t stride = (uint64_t)gridDim.x * 256;
-    for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < n_reads; r += stride) {
+    // eight lengths per 16-byte load (the array is allocated with slack; the tail is handled one by one)
+    const uint64_t n8 = (((uintptr_t)good_len & 15u) == 0) ? n_reads / 8 : 0;
+    for (uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x; q < n8; q += stride) {
+        const uint4 v = reinterpret_cast<const uint4*>(good_len)[q];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t g0 = w[j] & 0xFFFFu, g1 = w[j] >> 16;
+            if (g0 >= K + 1) { inst += g0 - K + 1; ++live; }
+            if (g1 >= K + 1) { inst += g1 - K + 1; ++live; }
+        }
+    }
+    for (uint64_t r = n8 * 8 + (uint64_t)blockIdx.x * 256 + threadIdx.x; r < n_reads; r += stride) {
         const uint32_t g = good_len[r];
         if (g >= K + 1) { inst += g - K + 1; ++live; }
     }
@@ -325,8 +337,8 @@ int snk_launch_msp_plan(hipStream_t st, const uint16_t* good_len, uint64_t n_rea
                         char* err, size_t errcap) {
     SNK_HIP_TRY(hipMemsetAsync(out2, 0, 16, st));
     if (n_reads) {
-        unsigned g = (unsigned)((n_reads + 255) / 256);
-        if (g > 4096) g = 4096;
+        unsigned g = (unsigned)((n_reads / 8 + 255) / 256 + 1);
+        if (g > 2048) g = 2048;
         hipLaunchKernelGGL(snk_msp_plan_kernel, dim3(g), dim3(256), 0, st, good_len, n_reads, K, out2);
     }
     SNK_HIP_TRY(hipGetLastError());
