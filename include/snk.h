@@ -310,6 +310,21 @@ int snk_dev_hbv(snk_ctx* ctx, uint32_t K, uint64_t n_unitigs, const void* d_unit
                 snk_hbv* out, float* device_ms, void* stream, char* err, size_t errcap);
 void snk_hbv_free(snk_hbv* h);
 
+/* ---- f3: barcode ids on the device --------------------------------------------------------------
+ * BcIndexer, lib/tada/src/utils.rs:101-164: whitelist line -> index (identical lines: the last one wins); a read's
+ * barcode field "SEQ[-gg][,raw]" (FASTH line 6, lib/tada/src/multifastq.rs:72-126) gets
+ *     id = index(SEQ) + 1 + (gg - 1) * lines(whitelist),   gg = 1 without a "-gg" suffix,   0 = not on the whitelist.
+ * snk_bc_index_create takes the bytes of the whitelist file (lines of at most 32 bytes, any characters);
+ * snk_dev_bc_ids reads n_reads fields of `stride` bytes each (zero padded, resident in HBM) and writes int32 ids.
+ * Errors follow the reference's panics: a gem group that is not a decimal u8 ("invalid gem group string", :138),
+ * an id beyond 2^31 ("BC id overflowed", :157). */
+typedef struct snk_bc_index snk_bc_index;
+int snk_bc_index_create(snk_ctx* ctx, const char* whitelist, size_t bytes, snk_bc_index** out, char* err, size_t errcap);
+void snk_bc_index_destroy(snk_bc_index* ix);
+uint32_t snk_bc_index_lines(const snk_bc_index* ix);
+int snk_dev_bc_ids(snk_ctx* ctx, const snk_bc_index* ix, const void* d_fields, uint32_t stride, uint64_t n_reads, void* d_ids,
+                   void* stream, char* err, size_t errcap);
+
 /* ---- stage-input formats of ASSEMBLER_DF (mro/_assembler_stages.mro:24-39) ----------- */
 /* reads.fastb = feudal MasterVec<BaseVec>: 24-byte control block (feudal/FeudalControlBlock.h:157-166), the packed
  * bases (2 bits, base j at bits 2*(j%4), feudal/FieldVec.h:586-603), (N+1) u64 file offsets, N u32 lengths.

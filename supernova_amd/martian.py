@@ -58,7 +58,60 @@ class BcIndexer:
         return (g - 1) * self.num_bcs + idx + 1
 
 
-def read_fasth(paths, indexer: BcIndexer):
+class DeviceBcIndexer:
+    """The same mapping computed on the MI355X (snk_bc_index_create / snk_dev_bc_ids, include/snk.h): the whitelist lives
+    in HBM, the barcode fields of all reads are looked up by one kernel."""
+    FIELD = 64
+
+    def __init__(self, whitelist_bytes: bytes, device: int = 0):
+        import ctypes as C
+        from . import lib as _lib
+        self._C, self._lib_mod = C, _lib
+        self.lib = _lib.load()
+        self.device = device
+        self._ctx = C.c_void_p()
+        self._ix = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = self.lib.snk_ctx_create(device, C.byref(self._ctx), err, 512)
+        if rc:
+            raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+        rc = self.lib.snk_bc_index_create(self._ctx, whitelist_bytes, len(whitelist_bytes), C.byref(self._ix), err, 512)
+        if rc:
+            self.lib.snk_ctx_destroy(self._ctx)
+            raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+        self.num_bcs = int(self.lib.snk_bc_index_lines(self._ix))
+
+    @classmethod
+    def from_file(cls, path, device: int = 0):
+        with open(path, "rb") as f:
+            return cls(f.read(), device)
+
+    def ids_of_fields(self, fields: np.ndarray) -> np.ndarray:
+        """fields: uint8 [n, stride], one zero-padded barcode field ("SEQ[-gg][,raw]") per row -> int32 ids (0 = none)."""
+        import torch
+        C = self._C
+        fields = np.ascontiguousarray(fields, dtype=np.uint8)
+        n, stride = fields.shape
+        dev = torch.device("cuda", self.device)
+        d_f = torch.from_numpy(fields).to(dev)
+        d_ids = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize(dev)
+        err = C.create_string_buffer(512)
+        rc = self.lib.snk_dev_bc_ids(self._ctx, self._ix, d_f.data_ptr(), stride, n, d_ids.data_ptr(), None, err, 512)
+        if rc:
+            raise self._lib_mod.SnkError(rc, err.value.decode(errors="replace"))
+        return d_ids[:n].cpu().numpy()
+
+    def close(self):
+        if self._ix:
+            self.lib.snk_bc_index_destroy(self._ix)
+            self._ix = None
+        if self._ctx:
+            self.lib.snk_ctx_destroy(self._ctx)
+            self._ctx = None
+
+
+def read_fasth(paths, indexer):
     """FASTH records -> (ascii u8[n,L], quals u8[n,L] raw phred, lens u16[n], bc i32[n]); R1 = read 2q, R2 = 2q+1
     (cmd_msp.rs:160-181)."""
     seqs, quals, bcs = [], [], []
@@ -73,10 +126,22 @@ def read_fasth(paths, indexer: BcIndexer):
                 for _ in range(3):
                     f.readline()
                 seq = bc.split(",")[0] if "," in bc else bc
-                b = indexer.get_bc_id(seq) or 0
                 seqs += [r1, r2]
                 quals += [q1, q2]
-                bcs += [b, b]
+                bcs.append(seq)
+    if hasattr(indexer, "ids_of_fields"):       # one device lookup for all read pairs
+        F = indexer.FIELD
+        fields = np.zeros((len(bcs), F), dtype=np.uint8)
+        for i, sq in enumerate(bcs):
+            raw = sq.encode()
+            if len(raw) > F:
+                # longer than any whitelist line + gem group: keep the sequence part recognisably too long
+                raw = raw[:F]
+            fields[i, :len(raw)] = np.frombuffer(raw, dtype=np.uint8)
+        ids = indexer.ids_of_fields(fields)
+    else:
+        ids = np.array([indexer.get_bc_id(sq) or 0 for sq in bcs], dtype=np.int32)
+    bcs = np.repeat(np.asarray(ids, dtype=np.int32), 2)
     n = len(seqs)
     L = max((len(s) for s in seqs), default=1)
     asc = np.full((n, L), ord("A"), dtype=np.uint8)
@@ -86,7 +151,7 @@ def read_fasth(paths, indexer: BcIndexer):
         lens[i] = len(s)
         asc[i, :len(s)] = np.frombuffer(s.encode(), dtype=np.uint8)
         qa[i, :len(q)] = np.frombuffer(q.encode(), dtype=np.uint8) - 33
-    return asc, qa, lens, np.asarray(bcs, dtype=np.int32)
+    return asc, qa, lens, np.asarray(bcs, dtype=np.int32).reshape(-1)
 
 
 # ------------------------------------------------------------------------------------------------ compute
@@ -135,8 +200,11 @@ class AsmSnGpu:
 
     def main(self, args, outs, files_path="."):
         from . import graphio
-        indexer = BcIndexer.from_file(args["barcode_whitelist"])
-        asc, quals, lens, bc = read_fasth(args["fastqs"], indexer)
+        indexer = DeviceBcIndexer.from_file(args["barcode_whitelist"])      # no GPU: fails here, like every entry point
+        try:
+            asc, quals, lens, bc = read_fasth(args["fastqs"], indexer)
+        finally:
+            indexer.close()
         off, bases, stats = count_graph_host(asc, quals, lens, bc, K=48, min_qual=int(args.get("trim_min_qual", 7)),
                                              min_freq=int(args.get("min_kmer_obs", 3)), min_bc=2)
         path = outs.get("asm_graph") or str(Path(files_path) / "asm_graph.bv")

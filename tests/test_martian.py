@@ -23,6 +23,57 @@ def test_bc_indexer_kat():
     assert ix.get_bc_id("AACG-1") is None and ix.get_bc_id("AACG") is None
 
 
+@pytest.mark.gpu
+def test_device_bc_indexer_matches_host_and_kat():
+    """f3: barcode ids on the device == BcIndexer (utils.rs:101-164): the reference's KAT (:435-448), duplicate whitelist
+    lines (last wins), CRLF, gem groups, raw-barcode suffixes, non-ACGT and over-long sequences, 200 k random fields; the
+    reference's two panics come back as errors."""
+    from supernova_amd.martian import BcIndexer, DeviceBcIndexer
+    from supernova_amd.lib import SnkError
+
+    def fields_of(strs, F=64):
+        a = np.zeros((len(strs), F), dtype=np.uint8)
+        for i, s in enumerate(strs):
+            b = s.encode()[:F]
+            a[i, :len(b)] = np.frombuffer(b, dtype=np.uint8)
+        return a
+
+    kat = DeviceBcIndexer(b"ACGTA\nACGTC\nACGTG\nACGTT")
+    q = ["ACGTA-1", "ACGTA", "ACGTA-2", "ACGTT-1", "ACGTT-2", "AACG-1", "AACG", "ACGTA-1,NNNNN", "ACGTA-2-x"]
+    assert kat.ids_of_fields(fields_of(q)).tolist() == [1, 1, 5, 4, 8, 0, 0, 1, 5]
+    for bad in ("ACGTA-", "ACGTA-x", "ACGTA-300", "ACGTA-0"):
+        with pytest.raises(SnkError):
+            kat.ids_of_fields(fields_of([bad]))
+    kat.close()
+
+    rng = np.random.default_rng(11)
+    wl = ["".join("ACGT"[i] for i in rng.integers(0, 4, 16)) for _ in range(50_000)]
+    wl[777] = wl[3]                         # duplicate line: the later index wins
+    wl[900] = "ACGTNNNNACGTNNNN"             # any characters are allowed in a whitelist line
+    text = ("\r\n".join(wl[:100]) + "\r\n" + "\n".join(wl[100:]) + "\n").encode()
+    host = BcIndexer([l + "\n" for l in wl])
+    dev = DeviceBcIndexer(text)
+    assert dev.num_bcs == host.num_bcs == len(wl)
+    qs = []
+    for _ in range(200_000):
+        r = rng.random()
+        s = wl[int(rng.integers(0, len(wl)))] if r < 0.8 else "".join("ACGTN"[i] for i in rng.integers(0, 5, int(rng.integers(1, 40))))
+        if rng.random() < 0.02:
+            s = s[:-1] + "N"
+        t = rng.random()
+        if t < 0.5:
+            s += f"-{int(rng.integers(1, 9))}"
+        if rng.random() < 0.3:
+            s += ",RAWBARCODE"
+        qs.append(s)
+    qs += [wl[3], wl[777] + "-3", wl[900] + "-2"]
+    exp = np.array([host.get_bc_id(s.split(",")[0]) or 0 for s in qs], dtype=np.int32)
+    got = dev.ids_of_fields(fields_of(qs))
+    assert np.array_equal(got, exp)
+    assert got[-3] == 777 + 1 and (exp > 0).sum() > 100_000
+    dev.close()
+
+
 def make_fasth(c, tmp_path, n_files=2):
     """Golden synthetic case -> FASTH files (R1 = read 2q, R2 = read 2q+1 share the barcode) + whitelist."""
     from supernova_amd import synth
