@@ -338,6 +338,14 @@ int snk_read_qualp(const char* path, uint64_t n_reads, uint32_t qstride, uint8_t
  * (10X/ParseBarcodedFastqs.cc:284-293); expanded to one barcode id per read as DF does (10X/DF.cc:464-469). */
 int snk_read_bci(const char* path, uint64_t n_reads, int32_t* bc_per_read, uint64_t* n_barcodes, char* err, size_t errcap);
 
+/* FASTH = the barcode-sorted read-pair text format of the tada stages (MultiFastqIter, lib/tada/src/multifastq.rs:69-127):
+ * gzip, 9 lines per pair (header, R1, Q1, R2, Q2, barcode field, 3 ignored lines).  Returns malloc'ed arrays (free with
+ * snk_host_free): ASCII bases and raw phred values in rows of `stride` bytes (read 2q = R1, 2q+1 = R2, cmd_msp.rs:160-181),
+ * lengths, and one zero-padded 64-byte barcode field per PAIR (part before the first ',') for snk_dev_bc_ids. */
+int snk_read_fasth(const char* path, uint32_t stride, uint64_t* n_reads, uint32_t* max_len, uint8_t** ascii, uint8_t** quals,
+                   uint16_t** lens, uint8_t** bc_fields, char* err, size_t errcap);
+void snk_host_free(void* p);
+
 #ifdef __cplusplus
 }
 #endif

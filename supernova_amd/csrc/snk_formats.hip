@@ -7,7 +7,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <string>
 #include <vector>
+
+#include <zlib.h>
 
 #include "snk_ctx.h"
 
@@ -159,3 +163,86 @@ extern "C" int snk_read_bci(const char* path, uint64_t n_reads, int32_t* bc, uin
     if (n_barcodes) *n_barcodes = m - 1;
     return SNK_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------- FASTH (f3)
+// MultiFastqIter (lib/tada/src/multifastq.rs:69-127): gzip'ed text, 9 lines per read pair -- header, R1, Q1, R2, Q2,
+// barcode field ("SEQ-gg[,raw]"), three more lines that the assembler ignores.  R1 becomes read 2q, R2 read 2q+1
+// (cmd_msp.rs:160-181).  Output: ASCII bases and raw phred values (quality characters - 33) in rows of `stride` bytes,
+// the read lengths, and one zero-padded 64-byte barcode field per PAIR (the input of snk_dev_bc_ids).
+namespace {
+bool gz_line(gzFile f, std::string& out) {          // one line without its terminator; false at end of file
+    out.clear();
+    char buf[4096];
+    bool any = false;
+    while (gzgets(f, buf, sizeof buf)) {
+        any = true;
+        const size_t n = strlen(buf);
+        out.append(buf, n);
+        if (n && buf[n - 1] == '\n') break;
+    }
+    if (!any) return false;
+    if (!out.empty() && out.back() == '\n') out.pop_back();
+    if (!out.empty() && out.back() == '\r') out.pop_back();
+    return true;
+}
+}  // namespace
+
+extern "C" int snk_read_fasth(const char* path, uint32_t stride, uint64_t* n_reads, uint32_t* max_len, uint8_t** ascii, uint8_t** quals,
+                              uint16_t** lens, uint8_t** bc_fields, char* err, size_t errcap) {
+    if (!path || !n_reads || !ascii || !quals || !lens || !bc_fields) return snk_fail(SNK_E_ARG, err, errcap, "snk_read_fasth: NULL argument");
+    if (stride == 0 || stride > 65535) return snk_fail(SNK_E_ARG, err, errcap, "snk_read_fasth: bad row stride");
+    *n_reads = 0; *ascii = nullptr; *quals = nullptr; *lens = nullptr; *bc_fields = nullptr;
+    if (max_len) *max_len = 0;
+    gzFile f = gzopen(path, "rb");
+    if (!f) return snk_fail(SNK_E_IO, err, errcap, "snk_read_fasth: cannot open %s", path);
+    gzbuffer(f, 1 << 20);
+    std::vector<uint8_t> A, Q, B;
+    std::vector<uint16_t> L;
+    std::string head, ln[8];
+    uint32_t mx = 0;
+    uint64_t pairs = 0;
+    int rc = SNK_OK;
+    while (gz_line(f, head)) {
+        bool ok = true;
+        for (int q = 0; q < 8 && ok; ++q) ok = gz_line(f, ln[q]);
+        if (!ok) { rc = snk_fail(SNK_E_IO, err, errcap, "%s: truncated record %llu", path, (unsigned long long)pairs); break; }
+        for (int m = 0; m < 2 && rc == SNK_OK; ++m) {
+            const std::string &r = ln[2 * m], &q = ln[2 * m + 1];
+            if (r.size() > stride) { rc = snk_fail(SNK_E_UNSUPPORTED, err, errcap, "%s: a read of %zu bases does not fit rows of %u", path, r.size(), stride); break; }
+            if (q.size() != r.size()) { rc = snk_fail(SNK_E_IO, err, errcap, "%s: record %llu: %zu bases but %zu qualities", path, (unsigned long long)pairs, r.size(), q.size()); break; }
+            const size_t o = A.size();
+            A.resize(o + stride, (uint8_t)'A');
+            Q.resize(o + stride, 0);
+            memcpy(&A[o], r.data(), r.size());
+            for (size_t i = 0; i < q.size(); ++i) Q[o + i] = (uint8_t)(q[i] - 33);
+            L.push_back((uint16_t)r.size());
+            if (r.size() > mx) mx = (uint32_t)r.size();
+        }
+        if (rc != SNK_OK) break;
+        const size_t ob = B.size();
+        B.resize(ob + 64, 0);
+        const std::string& bc = ln[4];
+        const size_t cut = bc.find(',');                       // only the part before the first ',' is the barcode
+        const size_t nb = std::min<size_t>(cut == std::string::npos ? bc.size() : cut, 64);
+        memcpy(&B[ob], bc.data(), nb);
+        ++pairs;
+    }
+    gzclose(f);
+    if (rc != SNK_OK) return rc;
+    auto dup = [](const void* src, size_t bytes) -> void* { void* p = malloc(bytes ? bytes : 16); if (p && bytes) memcpy(p, src, bytes); return p; };
+    *ascii = (uint8_t*)dup(A.data(), A.size());
+    *quals = (uint8_t*)dup(Q.data(), Q.size());
+    *lens = (uint16_t*)dup(L.data(), L.size() * 2);
+    *bc_fields = (uint8_t*)dup(B.data(), B.size());
+    if (!*ascii || !*quals || !*lens || !*bc_fields) {
+        free(*ascii); free(*quals); free(*lens); free(*bc_fields);
+        *ascii = *quals = *bc_fields = nullptr; *lens = nullptr;
+        return snk_fail(SNK_E_NOMEM, err, errcap, "snk_read_fasth: host allocation failed");
+    }
+    *n_reads = 2 * pairs;
+    if (max_len) *max_len = mx;
+    return SNK_OK;
+}
+
+extern "C" void snk_host_free(void* p) { free(p); }

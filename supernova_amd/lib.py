@@ -154,6 +154,8 @@ def _declare(lib: C.CDLL) -> None:
         "snk_read_fastb": (C.c_int, [cp, P(u64), P(u32), P(P(C.c_uint16)), P(P(u32)), cp, sz]),
         "snk_read_qualp": (C.c_int, [cp, u64, u32, vp, cp, sz]),
         "snk_read_bci": (C.c_int, [cp, u64, vp, P(u64), cp, sz]),
+        "snk_read_fasth": (C.c_int, [cp, u32, P(u64), P(u32), P(P(C.c_uint8)), P(P(C.c_uint8)), P(P(C.c_uint16)), P(P(C.c_uint8)), cp, sz]),
+        "snk_host_free": (None, [vp]),
         "snk_bc_index_create": (C.c_int, [vp, cp, sz, P(vp), cp, sz]),
         "snk_bc_index_destroy": (None, [vp]),
         "snk_bc_index_lines": (u32, [vp]),

@@ -111,9 +111,40 @@ class DeviceBcIndexer:
             self._ctx = None
 
 
+def read_fasth_native(paths):
+    """The C++ reader of libsnk (snk_read_fasth, zlib): -> (ascii u8[n,L], quals u8[n,L], lens u16[n], fields u8[n/2,64])."""
+    import ctypes as C
+    from . import lib as _lib
+    lib = _lib.load()
+    STRIDE = 256
+    parts = []
+    for p in paths:
+        n, mx = C.c_uint64(0), C.c_uint32(0)
+        pa, pq, pf = C.POINTER(C.c_uint8)(), C.POINTER(C.c_uint8)(), C.POINTER(C.c_uint8)()
+        pl = C.POINTER(C.c_uint16)()
+        err = C.create_string_buffer(512)
+        rc = lib.snk_read_fasth(str(p).encode(), STRIDE, C.byref(n), C.byref(mx), C.byref(pa), C.byref(pq), C.byref(pl), C.byref(pf), err, 512)
+        if rc:
+            raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+        nr = int(n.value)
+        take = lambda ptr, shape, dt: (np.ctypeslib.as_array(ptr, shape=shape).astype(dt).copy() if nr else np.zeros(shape, dt))
+        parts.append((take(pa, (nr, STRIDE), np.uint8), take(pq, (nr, STRIDE), np.uint8), take(pl, (nr,), np.uint16),
+                      take(pf, (nr // 2, 64), np.uint8), int(mx.value)))
+        for ptr in (pa, pq, pl, pf):
+            lib.snk_host_free(ptr)
+    L = max([x[4] for x in parts] + [1])
+    cat = lambda i: np.concatenate([x[i] for x in parts]) if parts else np.zeros((0,), np.uint8)
+    return cat(0)[:, :L].copy(), cat(1)[:, :L].copy(), cat(2), cat(3)
+
+
 def read_fasth(paths, indexer):
     """FASTH records -> (ascii u8[n,L], quals u8[n,L] raw phred, lens u16[n], bc i32[n]); R1 = read 2q, R2 = 2q+1
-    (cmd_msp.rs:160-181)."""
+    (cmd_msp.rs:160-181).  With a device indexer the files are parsed by the library's C++ reader and the barcode ids
+    come from one kernel; the pure-Python parser below is the restatement the tests compare it with."""
+    if hasattr(indexer, "ids_of_fields"):
+        asc, qa, lens, fields = read_fasth_native(paths)
+        ids = indexer.ids_of_fields(fields) if len(fields) else np.zeros(0, np.int32)
+        return asc, qa, lens, np.repeat(np.asarray(ids, dtype=np.int32), 2)
     seqs, quals, bcs = [], [], []
     for p in paths:
         with gzip.open(p, "rt") as f:
@@ -129,18 +160,7 @@ def read_fasth(paths, indexer):
                 seqs += [r1, r2]
                 quals += [q1, q2]
                 bcs.append(seq)
-    if hasattr(indexer, "ids_of_fields"):       # one device lookup for all read pairs
-        F = indexer.FIELD
-        fields = np.zeros((len(bcs), F), dtype=np.uint8)
-        for i, sq in enumerate(bcs):
-            raw = sq.encode()
-            if len(raw) > F:
-                # longer than any whitelist line + gem group: keep the sequence part recognisably too long
-                raw = raw[:F]
-            fields[i, :len(raw)] = np.frombuffer(raw, dtype=np.uint8)
-        ids = indexer.ids_of_fields(fields)
-    else:
-        ids = np.array([indexer.get_bc_id(sq) or 0 for sq in bcs], dtype=np.int32)
+    ids = np.array([indexer.get_bc_id(sq) or 0 for sq in bcs], dtype=np.int32)
     bcs = np.repeat(np.asarray(ids, dtype=np.int32), 2)
     n = len(seqs)
     L = max((len(s) for s in seqs), default=1)

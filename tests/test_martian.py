@@ -123,6 +123,41 @@ def test_fasth_ingest(tmp_path):
     assert len(set(m.values())) == len(m)
 
 
+def test_native_fasth_reader_matches_python(snk, tmp_path):
+    """snk_read_fasth (C++/zlib, CPU-only code of libsnk) == the Python restatement of MultiFastqIter on the same files:
+    bases, qualities, lengths and the barcode fields (part before the first ','), gzip and plain text, ragged lengths."""
+    from supernova_amd.martian import BcIndexer, read_fasth, read_fasth_native
+    c = goldens.load("synth_2k_err")
+    files, wl = make_fasth(c, tmp_path, n_files=3)
+    plain = tmp_path / "plain.fasth"
+    plain.write_bytes(gzip.open(files[0], "rb").read())
+    # ragged lengths, CRLF line ends, a barcode field without gem group or raw part, an empty read
+    rag = tmp_path / "ragged.fasth.gz"
+    rng = np.random.default_rng(2)
+    with gzip.open(rag, "wt", newline="") as f:
+        for q in range(300):
+            eol = "\r\n" if q % 3 == 0 else "\n"
+            f.write(f"@rag{q}" + eol)
+            for _ in range(2):
+                L = int(rng.integers(0, 200)) if q else 0
+                f.write("".join("ACGTN"[i] for i in rng.integers(0, 5, L)) + eol)
+                f.write("".join(chr(33 + int(v)) for v in rng.integers(0, 42, L)) + eol)
+            f.write(("ACGTACGTACGTACGT" if q % 2 else "TTTTACGTACGTACGT-2,RAW") + eol + "FFFF" + eol + "ACGT" + eol + "FFFF" + eol)
+    for fl in (files, [str(plain)] + files[1:], [str(rag)], files + [str(rag)]):
+        asc, qa, lens, fields = read_fasth_native(fl)
+        ix = BcIndexer.from_file(wl)
+        asc_p, qa_p, lens_p, bc_p = read_fasth([f if f != str(plain) else files[0] for f in fl], ix)
+        assert np.array_equal(lens, lens_p) and asc.shape == asc_p.shape
+        assert np.array_equal(asc, asc_p) and np.array_equal(qa, qa_p)
+        ids = np.array([ix.get_bc_id(bytes(f[:int(np.argmax(f == 0)) if (f == 0).any() else 64]).decode()) or 0 for f in fields], dtype=np.int32)
+        assert np.array_equal(np.repeat(ids, 2), bc_p)
+    bad = tmp_path / "trunc.fasth"
+    bad.write_text("@h\nACGT\nIIII\nACGT\n")
+    from supernova_amd.lib import SnkError
+    with pytest.raises(SnkError):
+        read_fasth_native([str(bad)])
+
+
 def _run_stage(tmp_path, stage_type, args=None, outs=None, extra=None, env=None):
     md = tmp_path / f"md_{stage_type}"
     md.mkdir()
