@@ -182,6 +182,12 @@ int snk_shard_scatter(snk_ctx* ctx, const void* d_offsets, void* d_records, void
 /* count the records received for my buckets: d_seg_off u64[world*(NB_total/world+1)] absolute record offsets */
 int snk_shard_count(snk_ctx* ctx, const void* d_records, const void* d_seg_off, uint64_t n_inst_hint, int has_bc,
                     uint64_t* n_kmers, void* stream, char* err, size_t errcap);
+/* the same, counting the local buckets in n_ranges ranges [bounds[r], bounds[r+1]) (bounds[0] = 0, bounds[n] = local
+ * buckets): ready(user, r) is called right before range r is launched, so the caller can make the stream wait for the
+ * records of that range while the ranges before it are being counted (exchange overlapped with counting). */
+int snk_shard_count_ranged(snk_ctx* ctx, const void* d_records, const void* d_seg_off, uint64_t n_inst_hint, int has_bc,
+                           uint32_t n_ranges, const uint32_t* bounds, int (*ready)(void* user, uint32_t r), void* user,
+                           uint64_t* n_kmers, void* stream, char* err, size_t errcap);
 /* adjacency prune with remote membership queries (24 bytes each, answers 4 bytes each) */
 int snk_shard_prune_plan(snk_ctx* ctx, uint64_t* h_qcount /* [world] */, void* stream, char* err, size_t errcap);
 int snk_shard_prune_fill(snk_ctx* ctx, const void* d_qoff /* u64[world+1] */, void* d_qbuf, void* stream, char* err, size_t errcap);

@@ -414,6 +414,8 @@ int launch(hipStream_t st, const snk_count_args& a, char* err, size_t errcap) {
     size_t lds = lds_bytes<K, G>();
     SNK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     snk_count_args b = a;
+    const uint32_t first = a.bucket0, last = a.NB;          // the launch covers buckets [first, last)
+    if (first >= last) return SNK_OK;
     // Workgroups walk buckets w, w + grid, ...: 2 M one-bucket workgroups spend ~8 % of the kernel in dispatch (73.7 ms);
     // exactly one residency wave (grid = 2 x CUs) is no better (73.5: whoever finishes early idles to the end); 32-64
     // waves keep both the dispatch cost and the tail small (67.3 ms at 1e8 reads).  SNK_COUNT_PERSIST=0: one bucket each.
@@ -424,8 +426,7 @@ int launch(hipStream_t st, const snk_count_args& a, char* err, size_t errcap) {
         SNK_HIP_TRY(hipGetDevice(&dev));
         SNK_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
         uint64_t grid = (uint64_t)(per_cu > 0 ? per_cu : 1) * (uint64_t)n_cu * persist;
-        if (grid > a.NB) grid = a.NB;
-        b.bucket0 = 0;
+        if (grid > last - first) grid = last - first;
         b.bucket_stride = (uint32_t)grid;
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(cfg<K>::THREADS), lds, st, b);
         SNK_HIP_TRY(hipGetLastError());
@@ -434,9 +435,9 @@ int launch(hipStream_t st, const snk_count_args& a, char* err, size_t errcap) {
     // one bucket per workgroup.  A launch is limited to 2^32 threads in total: buckets go out in slices of 4 M workgroups
     constexpr uint32_t SLICE = 1u << 22;
     b.bucket_stride = 0;
-    for (uint32_t b0 = 0; b0 < a.NB; b0 += SLICE) {
+    for (uint32_t b0 = first; b0 < last; b0 += SLICE) {
         b.bucket0 = b0;
-        const uint32_t nb = a.NB - b0 < SLICE ? a.NB - b0 : SLICE;
+        const uint32_t nb = last - b0 < SLICE ? last - b0 : SLICE;
         b.NB = b0 + nb;
         hipLaunchKernelGGL(kern, dim3(nb), dim3(cfg<K>::THREADS), lds, st, b);
     }

@@ -100,6 +100,22 @@ extern "C" int snk_shard_count(snk_ctx* ctx, const void* d_records, const void* 
     return SNK_OK;
 }
 
+extern "C" int snk_shard_count_ranged(snk_ctx* ctx, const void* d_records, const void* d_seg_off, uint64_t n_inst_hint, int has_bc,
+                                      uint32_t n_ranges, const uint32_t* bounds, int (*ready)(void*, uint32_t), void* user,
+                                      uint64_t* n_kmers, void* stream, char* err, size_t errcap) {
+    if (!ctx || !ctx->shard || !d_seg_off || (n_ranges && !bounds)) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_count_ranged: NULL argument / no session");
+    snk_shard_state* S = state_of(ctx);
+    if (n_ranges && (bounds[0] != 0 || bounds[n_ranges] != S->NBl)) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_count_ranged: the ranges must cover the local buckets");
+    for (uint32_t r = 0; r < n_ranges; ++r) if (bounds[r] > bounds[r + 1]) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_count_ranged: descending range bounds");
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    snk_count_ranges rg{n_ranges, bounds, ready, user};
+    int rc = snk_stage_count_table(ctx, st, S->params.K, d_records, (const uint64_t*)d_seg_off, (const uint64_t*)d_seg_off + 1, S->NBl + 1, S->world, S->NBl, S->params.min_freq,
+                                   has_bc ? S->params.min_bc : 0u, 0u, n_inst_hint, S->status, false, &S->tab, err, errcap, n_ranges ? &rg : nullptr);
+    if (rc) return rc;
+    if (n_kmers) *n_kmers = S->tab.n;
+    return SNK_OK;
+}
+
 extern "C" int snk_shard_prune_plan(snk_ctx* ctx, uint64_t* h_qcount, void* stream, char* err, size_t errcap) {
     if (!ctx || !ctx->shard || !h_qcount) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_prune_plan: NULL argument / no session");
     snk_shard_state* S = state_of(ctx);

@@ -40,9 +40,18 @@ struct snk_table {
 };
 
 uint32_t snk_env_u32(const char* name, uint32_t dflt);
+// optional: the first count launch goes out in bucket ranges [bounds[r], bounds[r+1]); ready(user, r) is called before
+// range r is launched (the sharded path makes the stream wait for that range's records there)
+struct snk_count_ranges {
+    uint32_t n;
+    const uint32_t* bounds;
+    int (*ready)(void* user, uint32_t r);
+    void* user;
+};
 int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* records, const uint64_t* seg_beg,
                           const uint64_t* seg_end, uint32_t seg_stride, uint32_t nseg, uint32_t NB, uint32_t min_freq, uint32_t bc_mode, uint32_t grouped, uint64_t n_inst_hint,
-                          uint32_t* status, bool want_sort, snk_table* out, char* err, size_t errcap);
+                          uint32_t* status, bool want_sort, snk_table* out, char* err, size_t errcap,
+                          const snk_count_ranges* ranges = nullptr);
 
 // ---- minimiser partition in one pass (fixed bucket capacity + overflow segment)
 struct snk_partition {

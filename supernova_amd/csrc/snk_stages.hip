@@ -24,7 +24,7 @@ uint32_t snk_env_u32(const char* name, uint32_t dflt) {
 // status: device u32[16] scratch words.
 int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* records, const uint64_t* seg_beg,
                           const uint64_t* seg_end, uint32_t seg_stride, uint32_t nseg, uint32_t NB, uint32_t min_freq, uint32_t bc_mode, uint32_t grouped, uint64_t n_inst_hint,
-                          uint32_t* status, bool want_sort, snk_table* out, char* err, size_t errcap) {
+                          uint32_t* status, bool want_sort, snk_table* out, char* err, size_t errcap, const snk_count_ranges* ranges) {
     int rc;
     snk_phase_timer tm(st), kt(st);
     tm.mark();
@@ -99,7 +99,17 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
 #endif
         kt.n = 0;
         kt.mark();
-        if ((rc = snk_launch_count(K, st, ca, err, errcap))) return rc;
+        if (attempt == 0 && ranges && ranges->n) {
+            // the records of bucket range r may still be on their way: the caller's hook makes the stream wait for
+            // them, the ranges before it are being counted meanwhile
+            for (uint32_t r = 0; r < ranges->n; ++r) {
+                if (ranges->ready && (rc = ranges->ready(ranges->user, r))) return snk_fail(SNK_E_ARG, err, errcap, "count: the range hook failed for range %u (%d)", r, rc);
+                snk_count_args cr = ca;
+                cr.bucket0 = ranges->bounds[r];
+                cr.NB = ranges->bounds[r + 1];
+                if ((rc = snk_launch_count(K, st, cr, err, errcap))) return rc;
+            }
+        } else if ((rc = snk_launch_count(K, st, ca, err, errcap))) return rc;
         kt.mark();
         SNK_HIP_TRY(hipMemcpyAsync(h_rcur.data(), rcur, n_regions * 8ull, hipMemcpyDeviceToHost, st));
         SNK_HIP_TRY(hipMemcpyAsync(h_status, status, 32, hipMemcpyDeviceToHost, st));

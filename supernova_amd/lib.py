@@ -89,6 +89,8 @@ class SnkHbv(C.Structure):
                 ("rev_xlat", C.POINTER(C.c_int32)), ("bvcomp_order", C.POINTER(C.c_int32))]
 
 
+RANGE_READY = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32)      # int ready(void* user, uint32_t range)
+
 _lib = None
 
 
@@ -166,6 +168,7 @@ def _declare(lib: C.CDLL) -> None:
         "snk_shard_hist": (C.c_int, [vp, P(SnkDevReads), P(SnkParams), u32, u32, u32, vp, P(u64), vp, cp, sz]),
         "snk_shard_scatter": (C.c_int, [vp, vp, vp, vp, cp, sz]),
         "snk_shard_count": (C.c_int, [vp, vp, vp, u64, C.c_int, P(u64), vp, cp, sz]),
+        "snk_shard_count_ranged": (C.c_int, [vp, vp, vp, u64, C.c_int, u32, P(u32), RANGE_READY, vp, P(u64), vp, cp, sz]),
         "snk_shard_prune_plan": (C.c_int, [vp, P(u64), vp, cp, sz]),
         "snk_shard_prune_fill": (C.c_int, [vp, vp, vp, vp, cp, sz]),
         "snk_shard_prune_answer": (C.c_int, [vp, vp, u64, vp, vp, cp, sz]),

@@ -93,6 +93,39 @@ class TorchComm:
         self._a2a(recv.view(dt), send.view(dt), [c // width for c in recv_counts], [c // width for c in send_counts])
         return recv, recv_counts
 
+    def exchange_ranged(self, send: torch.Tensor, recv: torch.Tensor, soff, roff, n_ranges: int):
+        """The record exchange cut into bucket ranges: bytes soff[p][r]..soff[p][r+1] of `send` go to rank p and land at
+        roff[me-as-source...] on its side; here bytes roff[p][r]..roff[p][r+1] of `recv` arrive from rank p.  Everything is
+        issued at once, range by range (so the transport delivers range 0 first); returns one list of work handles per
+        range -- waiting on them makes the current stream wait for that range only (the count kernel of range r runs
+        while range r+1 is still on the wire).  The rank's own share is a plain copy."""
+        W, me = self.world, self.rank
+        s64, r64 = send.view(torch.int64), recv.view(torch.int64)
+        ch = max(1, self.CHUNK_BYTES // 8)
+        if soff[me][n_ranges] > soff[me][0]:
+            r64[roff[me][0] // 8: roff[me][n_ranges] // 8].copy_(s64[soff[me][0] // 8: soff[me][n_ranges] // 8])
+        works = []
+        for r in range(n_ranges):
+            wr = []
+            cnt_s = [(soff[p][r + 1] - soff[p][r]) // 8 for p in range(W)]
+            cnt_r = [(roff[p][r + 1] - roff[p][r]) // 8 for p in range(W)]
+            n_rounds = max([0] + [-(-x // ch) for p in range(W) if p != me for x in (cnt_s[p], cnt_r[p])])
+            for j in range(n_rounds):
+                ops = []
+                for p in range(W):
+                    if p == me:
+                        continue
+                    c0 = j * ch
+                    if c0 < cnt_s[p]:
+                        a = soff[p][r] // 8 + c0
+                        ops.append(self.dist.P2POp(self.dist.isend, s64[a: a + min(ch, cnt_s[p] - c0)], p))
+                    if c0 < cnt_r[p]:
+                        a = roff[p][r] // 8 + c0
+                        ops.append(self.dist.P2POp(self.dist.irecv, r64[a: a + min(ch, cnt_r[p] - c0)], p))
+                wr += list(self.dist.batch_isend_irecv(ops))
+            works.append(wr)
+        return works
+
     def all_to_all_equal(self, send: torch.Tensor) -> torch.Tensor:
         """send: [world, m] -> recv [world, m]; row p goes to rank p."""
         recv = torch.empty_like(send)
@@ -174,6 +207,18 @@ class SimComm:
         self.w.barrier_obj.wait()     # nobody reuses its send buffer before everyone has copied
         self._begin_section()
         return recv, counts
+
+    def exchange_ranged(self, send, recv, soff, roff, n_ranges):
+        torch.cuda.synchronize()
+        allv = self._exchange((send, soff))
+        for src, (t, so) in enumerate(allv):
+            a, b = so[self.rank][0], so[self.rank][n_ranges]
+            if b > a:
+                recv[roff[src][0]: roff[src][n_ranges]].copy_(t[a:b])
+        torch.cuda.synchronize()
+        self.w.barrier_obj.wait()     # nobody reuses its send buffer before everyone has copied
+        self._begin_section()
+        return [[] for _ in range(n_ranges)]
 
     def all_to_all_equal(self, send):
         m = send.shape[1]
@@ -364,13 +409,44 @@ class ShardedEngine:
         # ---- exchange #1/#2: histograms and records
         send_counts = owner_record_counts(off64, W)
         hist_recv = comm.all_to_all_equal(hist.view(W, NBl))
-        recv, recv_bytes = comm.all_to_all_v(send[: n_super * 32], [c * 32 for c in send_counts], alloc=lambda nb: pool.get("recv", nb))
-        seg_off = segment_offsets(hist_recv, [b // 32 for b in recv_bytes])
-        ev[3].record()
-        # ---- stage 3: count
         nk = C.c_uint64(0)
-        chk(lib.snk_shard_count(e._ctx, recv.data_ptr(), seg_off.data_ptr(), inst_ub // W, 1 if bc is not None else 0,
-                                C.byref(nk), st, err, 512))
+        R = int(os.environ.get("SNK_EXCHANGE_RANGES", "4")) if W > 1 else 1
+        if R > 1 and hasattr(comm, "exchange_ranged"):
+            # the records travel in R bucket ranges and range r is counted while range r+1 is still on the wire: both
+            # sides know every piece size from the histograms, so nothing but the records is exchanged
+            recv_counts = [int(x) for x in hist_recv.to(torch.int64).sum(dim=1).tolist()]
+            seg_off = segment_offsets(hist_recv, recv_counts)
+            recv = pool.get("recv", max(sum(recv_counts), 1) * 32)
+            bounds = [NBl * q // R for q in range(R + 1)]
+            bidx = torch.tensor(bounds, dtype=torch.int64, device=dev)
+            soff = (off64[(torch.arange(W, device=dev, dtype=torch.int64) * NBl)[:, None] + bidx[None, :]] * 32).tolist()
+            roff = (seg_off[:, bidx] * 32).tolist()
+            works = comm.exchange_ranged(send, recv, soff, roff, R)
+            ev[3].record()
+            failure = []
+
+            def ready(_user, q):
+                try:
+                    for wk in works[q]:
+                        wk.wait()
+                    return 0
+                except BaseException as ex:          # a ctypes callback must not raise
+                    failure.append(ex)
+                    return 1
+            cb = _lib.RANGE_READY(ready)
+            barr = (C.c_uint32 * (R + 1))(*bounds)
+            rc = lib.snk_shard_count_ranged(e._ctx, recv.data_ptr(), seg_off.data_ptr(), inst_ub // W, 1 if bc is not None else 0,
+                                            R, barr, cb, None, C.byref(nk), st, err, 512)
+            if failure:
+                raise failure[0]
+            chk(rc)
+        else:
+            recv, recv_bytes = comm.all_to_all_v(send[: n_super * 32], [c * 32 for c in send_counts], alloc=lambda nb: pool.get("recv", nb))
+            seg_off = segment_offsets(hist_recv, [b // 32 for b in recv_bytes])
+            ev[3].record()
+            # ---- stage 3: count
+            chk(lib.snk_shard_count(e._ctx, recv.data_ptr(), seg_off.data_ptr(), inst_ub // W, 1 if bc is not None else 0,
+                                    C.byref(nk), st, err, 512))
         ev[4].record()
         # ---- stage 4: prune with remote queries
         qcount = (C.c_uint64 * W)()

@@ -103,6 +103,38 @@ def _worker(rank, world, port, q):
         ln = n_src // 3 if rank == 0 else n_src - n_src // 3
         a = sum(rb[:src]) // 8
         ok &= rb[src] == ln * 8 and bool(torch.equal(back.view(torch.int64)[a:a + ln], full[lo:lo + ln]))
+    # the ranged record exchange (counting overlaps the transfer): R bucket ranges, pieces of 1000 bytes, ranges waited
+    # for one by one in order; every rank checks what it received against what the sources hold
+    R, NBl2 = 3, 6
+    def src_hist(s):          # records per (dest, local bucket) of source s, 32-byte records
+        return np.random.default_rng(500 + s).integers(0, 40, (world, NBl2)).astype(np.int64)
+    def src_send(s):          # dest-major, bucket-ascending: record k of (s -> p, bucket b) carries (s, p, b, k)
+        h = src_hist(s)
+        rows = [(s, p, b, k) for p in range(world) for b in range(NBl2) for k in range(h[p, b])]
+        a = np.zeros((len(rows), 4), dtype=np.int64)
+        a[:] = np.array(rows, dtype=np.int64).reshape(-1, 4) if rows else a
+        return a
+    h_me = src_hist(rank)
+    send2 = torch.from_numpy(src_send(rank).copy()).view(torch.uint8).view(-1)
+    off = np.zeros(world * NBl2 + 1, dtype=np.int64)
+    off[1:] = np.cumsum(h_me.reshape(-1))
+    bounds = [NBl2 * r // R for r in range(R + 1)]
+    soff = [[int(off[p * NBl2 + b]) * 32 for b in bounds] for p in range(world)]
+    hr = np.stack([src_hist(s)[rank] for s in range(world)])            # what I receive: [source, local bucket]
+    seg2 = segment_offsets(torch.from_numpy(hr), [int(x) for x in hr.sum(axis=1)])
+    roff = [[int(seg2[s, b]) * 32 for b in bounds] for s in range(world)]
+    recv2 = torch.zeros(int(hr.sum()) * 32, dtype=torch.uint8)
+    works = comm.exchange_ranged(send2, recv2, soff, roff, R)
+    ok &= len(works) == R
+    g2 = recv2.view(torch.int64).view(-1, 4).numpy()
+    for r in range(R):
+        for wk in works[r]:
+            wk.wait()
+        for s in range(world):
+            for b in range(bounds[r], bounds[r + 1]):
+                blk = g2[int(seg2[s, b]):int(seg2[s, b + 1])]
+                ok &= blk.shape[0] == hr[s, b] and bool(np.all(blk[:, 0] == s)) and bool(np.all(blk[:, 1] == rank)) and bool(np.all(blk[:, 2] == b))
+                ok &= list(blk[:, 3]) == list(range(blk.shape[0]))
     q.put((rank, ok, int(got.shape[0])))
     dist.destroy_process_group()
 
