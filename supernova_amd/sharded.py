@@ -410,7 +410,7 @@ class ShardedEngine:
         send_counts = owner_record_counts(off64, W)
         hist_recv = comm.all_to_all_equal(hist.view(W, NBl))
         nk = C.c_uint64(0)
-        R = int(os.environ.get("SNK_EXCHANGE_RANGES", "4")) if W > 1 else 1
+        R = int(os.environ.get("SNK_EXCHANGE_RANGES", "4" if W > 1 else "1"))
         if R > 1 and hasattr(comm, "exchange_ranged"):
             # the records travel in R bucket ranges and range r is counted while range r+1 is still on the wire: both
             # sides know every piece size from the histograms, so nothing but the records is exchanged
