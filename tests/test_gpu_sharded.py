@@ -87,6 +87,15 @@ def test_sharded_many_small_buckets(snk):
     check(run_world(4, c, n_buckets=4 * 997), c)
 
 
+@pytest.mark.parametrize("n_buckets", [0, 8 * 3])
+def test_sharded_eight_ranks(snk, n_buckets):
+    """Eight simulated ranks: every bucket is counted from eight record segments as one concatenated stream (ranged
+    exchange, four count launches); with 24 buckets in all, batches span several segments and the buckets split."""
+    c = goldens.load("synth_20k_err")
+    out = run_world(8, c, n_buckets=n_buckets)
+    check(out, c)
+
+
 def test_sharded_k60(snk):
     """K=60 through the sharded path (2 ranks) against the C oracle."""
     import oracle_lib
