@@ -220,6 +220,31 @@ def test_read_length_extremes_vs_oracle(engine, L, K):
     assert res.unitigs() == o.unitigs
 
 
+@pytest.mark.parametrize("n_buckets", [4, 5, 6])
+def test_k60_sparse_chunks_of_a_thousand_fragments(engine, graph_stage, n_buckets):
+    """Low coverage, no filter, K=60, ~18 k retained k-mers per bucket: the buckets split 16-32 ways by hash, the
+    sub-passes of ~1150 k-mers hold almost only one-k-mer fragments, i.e. more than 65535 fragment bases per chunk -- the
+    per-chunk base offsets need 32 bits (found by tools/fuzz_parity.py in a five-rank sharded run; 16-bit offsets
+    garbled a few bases of ~90 unitigs, differently in every run)."""
+    import torch
+    from supernova_amd import synth
+    from supernova_amd.engine import Params
+    rng = np.random.default_rng(4242)
+    codes, quals, lens, bc = _random_reads(rng, 120_000, 2400, 151, err=0.0)
+    dev = torch.device("cuda", 0)
+    rows = torch.from_numpy(synth.pack_rows(codes).view(np.int32)).to(dev)
+    res = engine.count_graph(rows, 151, quals=torch.from_numpy(quals).to(dev), bc=torch.from_numpy(bc).to(dev),
+                             lens=torch.from_numpy(lens.view(np.int16)).to(dev),
+                             params=Params(K=60, min_freq=1, min_bc=0, n_buckets=n_buckets))
+    gl = oracle_lib.good_lens(quals, lens, K=60)
+    o = oracle_lib.OracleResult(codes, gl, bc, K=60, min_freq=1, min_bc=0, hbv=False)
+    assert res.n_kmers > 60_000 and res.buckets_split >= n_buckets
+    if graph_stage == "local":
+        assert res.n_fragments > 0.8 * res.n_kmers
+    assert np.array_equal(res.keys(), o.keys) and np.array_equal(res.ctx(), o.ctx)
+    assert res.unitigs() == o.unitigs
+
+
 def test_empty_and_degenerate_inputs(engine):
     """No reads; reads that are all too short / all low quality (no k-mer at all); a single read."""
     import torch
