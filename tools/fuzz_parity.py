@@ -50,8 +50,11 @@ bad = 0
 for case in range(n_cases):
     K = 48 if rng.random() < 0.7 else 60
     L = int(rng.choice([100, 150, 151, 250]))
-    G = int(rng.choice([500, 3000, 20000, 120000]))
+    G = int(rng.choice([500, 3000, 20000, 120000, 120000, 1000000]))
     cov = float(rng.choice([3, 8, 30, 60]))
+    if G >= 1000000: cov = min(cov, 30.0)
+    cap_pct = int(rng.choice([100, 100, 100, 60, 10]))       # shrink the partition's bucket capacity: overflow segment
+    os.environ["SNK_MSP_CAP_PCT"] = str(cap_pct)
     n = max(10, int(G * cov / L))
     err = float(rng.choice([0.0, 0.002, 0.01]))
     nbc = int(rng.choice([1, 3, 40]))
@@ -74,7 +77,7 @@ for case in range(n_cases):
     rows = torch.from_numpy(synth.pack_rows(codes).view(np.int32)).to(dev)
     dq = torch.from_numpy(quals).to(dev); dbc = torch.from_numpy(bc).to(dev) if use_bc else None
     dl = torch.from_numpy(lens.view(np.int16)).to(dev)
-    tag = f"case {case}: K={K} L={L} G={G} n={n} err={err} nbc={nbc} min_freq={min_freq} min_bc={min_bc} nb={nb} bc={use_bc} -> {o.keys.shape[0]} k-mers, {len(o.unitigs)} unitigs"
+    tag = f"case {case}: K={K} L={L} G={G} n={n} err={err} nbc={nbc} min_freq={min_freq} min_bc={min_bc} nb={nb} bc={use_bc} cap%={cap_pct} -> {o.keys.shape[0]} k-mers, {len(o.unitigs)} unitigs"
     ok = True
     for glob in (0, 1):
         os.environ["SNK_GLOBAL_GRAPH"] = str(glob)
