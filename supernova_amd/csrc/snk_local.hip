@@ -422,9 +422,13 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
     constexpr uint32_t FM = (1u << FB) - 1u;           // field mask == "no next state"
     __shared__ uint16_t lnk[2 * CAP];
     __shared__ wrec_t wr[2 * CAP];
-    uint16_t* foffL = nbL;                             // per pid terminal: index of its fragment among the chunk's fragments
-    __shared__ uint32_t frel[CAP];                     // per fragment of the chunk: offset of its bases inside the chunk's output
-                                                       // (32 bits: 1216 one-k-mer fragments at K=60 are 72960 bases)
+    // offset of a fragment's bases inside the chunk's output.  A chunk of n k-mers in F fragments has n + (K-1) F <= CAP K
+    // bases: 16 bits do (per terminal state, in the dead neighbour list) unless CAP K > 65535 -- the 1280-node variant at
+    // K=60, where 1216 one-k-mer fragments are 72960 bases: there the terminal state keeps the fragment's index and the
+    // offsets are 32-bit words per fragment
+    constexpr bool WIDE = (uint32_t)CAP * (uint32_t)K > 65535u;
+    uint16_t* foffL = nbL;
+    __shared__ uint32_t frel[WIDE ? CAP : 1];
     __shared__ uint16_t hnode[CAP];                    // heads: node << 1 | rc
     __shared__ uint8_t ctxL[CAP], pendL[CAP], palL[CAP];
     __shared__ uint32_t fcnt, bcnt, changed;
@@ -583,8 +587,8 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
         bstart[f] = c_boff + rel;
         if (sfrag) { sfrag[2 * ch.base + pid] = (uint32_t)(2 * f); sfrag[2 * ch.base + other] = (uint32_t)(2 * f + 1); }
         if (GR) fgroup[f] = (uint32_t)klo[head_node];
-        foffL[pid] = (uint16_t)lf;
-        frel[lf] = rel;
+        if (WIDE) { foffL[pid] = (uint16_t)lf; frel[lf] = rel; }
+        else foffL[pid] = (uint16_t)rel;
         hnode[lf] = (uint16_t)((head_node << 1) | (head_rc ? 1u : 0u));
         return rel;
     };
@@ -655,7 +659,8 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
         snk_kmer k;
         k.hi = khi[i];
         k.lo = (uint64_t)klo[i] << KLS;
-        fbases[c_boff + frel[foffL[fwd ? tL : tR]] + (K - 1) + pos] = (uint8_t)oriented_base<K>(k, !fwd, K - 1);
+        const uint32_t fo = foffL[fwd ? tL : tR];
+        fbases[c_boff + (WIDE ? frel[fo] : fo) + (K - 1) + pos] = (uint8_t)oriented_base<K>(k, !fwd, K - 1);
     }
     // head k-mers: K lanes per head
     const uint32_t nheads = fcnt;
@@ -667,10 +672,13 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
             const uint32_t hn = hnode[h];
             const uint32_t i = hn >> 1;
             const bool rc = hn & 1u;
+            uint32_t fo;
+            if (WIDE) fo = frel[h];                               // head h belongs to fragment h of the chunk
+            else { const uint32_t tR = w_tail(2 * i), tL = w_tail(2 * i + 1); fo = foffL[tL < tR ? tL : tR]; }
             snk_kmer k;
             k.hi = khi[i];
             k.lo = (uint64_t)klo[i] << KLS;
-            fbases[c_boff + frel[h] + q] = (uint8_t)oriented_base<K>(k, rc, q);     // head h belongs to fragment h of the chunk
+            fbases[c_boff + fo + q] = (uint8_t)oriented_base<K>(k, rc, q);
         }
     }
 }
