@@ -97,6 +97,13 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
         if (nb > nb_max) nb = nb_max;
         NB = (uint32_t)nb;
     }
+    {
+        // a caller's bucket count is honoured down to ~1 M k-mer instances per bucket: a bucket is counted by ONE
+        // workgroup that re-reads all its records in every hash-split sub-pass, so 20 M instances in one bucket would be
+        // thousands of passes over a million records (finite, but minutes)
+        const uint64_t nb_floor = (h_ninst >> 20) + 1;
+        if (NB < nb_floor) NB = (uint32_t)nb_floor;
+    }
     out->n_buckets = NB;
     tm.mark();  // 2
     snk_partition part;

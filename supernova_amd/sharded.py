@@ -389,6 +389,7 @@ class ShardedEngine:
 
         inst_ub = comm.allreduce_sum_int(rows.shape[0] * max(0, read_len - K + 1), dev)
         NB_total = params.n_buckets if params.n_buckets else plan_buckets(inst_ub, W, K)
+        NB_total = max(NB_total, (inst_ub >> 20) + 1)      # at most ~1 M instances per bucket (one workgroup counts a bucket)
         NB_total = -(-NB_total // W) * W
         NBl = NB_total // W
         # ---- stage 1: trim + histogram

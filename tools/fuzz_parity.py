@@ -50,7 +50,7 @@ bad = 0
 for case in range(n_cases):
     K = 48 if rng.random() < 0.7 else 60
     L = int(rng.choice([100, 150, 151, 250]))
-    G = int(rng.choice([500, 3000, 20000, 120000, 120000, 1000000]))
+    G = int(rng.choice([500, 3000, 3000, 20000, 20000, 20000, 120000, 120000, 120000, 120000, 120000, 1000000]))
     cov = float(rng.choice([3, 8, 30, 60]))
     if G >= 1000000: cov = min(cov, 30.0)
     cap_pct = int(rng.choice([100, 100, 100, 60, 10]))       # shrink the partition's bucket capacity: overflow segment
@@ -62,9 +62,13 @@ for case in range(n_cases):
     nb = int(rng.choice([0, 0, 1, 5, 97, 4099]))
     use_bc = rng.random() < 0.8
     codes, quals, lens, bc = make_reads(rng, G, n, L, err, nbc, rng.random() < 0.6)
-    if only >= 0 and case != only:
+    if only >= 0 and case != only:          # consume the same random draws as a full run of this case
+        if K == 48 and rng.random() < 0.4:
+            ng_ = int(rng.choice([1, 2, 7])); rng.integers(0, ng_, n); rng.choice([1, 1000])
         rng.choice([2, 3, 5, 8])
         continue
+    if only >= 0:
+        print(f"replaying case {case}: K={K} L={L} G={G} n={n} err={err} nbc={nbc} min_freq={min_freq} min_bc={min_bc} nb={nb} bc={use_bc} cap%={cap_pct}", flush=True)
     gl = oracle_lib.good_lens(quals, lens, K=K)
     if min_freq == 1 and use_bc and min_bc > 0:
         min_bc = 0          # without the prune (min_freq 1) a barcode filter leaves contexts that point at dropped k-mers:
@@ -81,11 +85,38 @@ for case in range(n_cases):
     ok = True
     for glob in (0, 1):
         os.environ["SNK_GLOBAL_GRAPH"] = str(glob)
+        if only >= 0: print("  single leg, global =", glob, flush=True)
         r = eng.count_graph(rows, L, quals=dq, bc=dbc, lens=dl, params=Params(K=K, min_freq=min_freq, min_bc=min_bc, n_buckets=nb))
         if not same(r.keys(), r.counts(), r.ctx(), r.unitigs(), o):
             ok = False; print("MISMATCH single", "global" if glob else "local", tag, flush=True)
     os.environ["SNK_GLOBAL_GRAPH"] = "0"
+    if K == 48 and rng.random() < 0.4:
+        # per-group graphs (BASELINE config 5): one grouped run == the oracle applied to every group's reads on its own
+        NG = int(rng.choice([1, 2, 7]))
+        group = rng.integers(0, NG, n).astype(np.int32) * int(rng.choice([1, 1000]))
+        if only >= 0: print("  grouped leg, NG =", NG, flush=True)
+        r = eng.count_graph(rows, L, quals=dq, bc=None, lens=dl, group=torch.from_numpy(group).to(dev),
+                            params=Params(K=48, min_freq=min_freq, min_bc=0, grouped=True, sorted_table=False, n_buckets=nb))
+        k, cnt, ctx = r.keys(), r.counts(), r.ctx()
+        off, bases = r.unitig_arrays(); ug = r.unitig_groups()
+        lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+        gok = bool(np.all(np.diff(ug.astype(np.int64)) >= 0))
+        tot = 0
+        for gid in np.unique(group):
+            sel = group == gid
+            og = oracle_lib.OracleResult(codes[sel], gl[sel], None, K=48, min_freq=min_freq, min_bc=0, hbv=False)
+            m = k[:, 3] == gid
+            kk, cc, xx = k[m], cnt[m], ctx[m]
+            order = np.lexsort((kk[:, 2], kk[:, 1], kk[:, 0]))
+            us = sorted((lut[bases[int(off[u]):int(off[u + 1])]].tobytes().decode() for u in np.nonzero(ug == gid)[0]), key=lambda t: (-len(t), t))
+            gok &= (kk.shape[0] == og.keys.shape[0] and np.array_equal(kk[order][:, :3], og.keys[:, :3]) and np.array_equal(cc[order], og.counts)
+                    and np.array_equal(xx[order], og.ctx) and us == og.unitigs)
+            tot += int(m.sum())
+        gok &= tot == k.shape[0]
+        if not gok:
+            ok = False; print("MISMATCH grouped NG=%d" % NG, tag, flush=True)
     W = int(rng.choice([2, 3, 5, 8]))
+    if only >= 0: print("  sharded leg, W =", W, flush=True)
     world = SimWorld(W); bounds = [n * q // W for q in range(W + 1)]; out = [None] * W; errs = []
     def worker(q):
         try:
