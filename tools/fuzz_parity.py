@@ -89,6 +89,17 @@ for case in range(n_cases):
         r = eng.count_graph(rows, L, quals=dq, bc=dbc, lens=dl, params=Params(K=K, min_freq=min_freq, min_bc=min_bc, n_buckets=nb))
         if not same(r.keys(), r.counts(), r.ctx(), r.unitigs(), o):
             ok = False; print("MISMATCH single", "global" if glob else "local", tag, flush=True)
+        elif r.n_unitigs:
+            # a14 on the device (snk_dev_hbv) against the host-array entry point on the BVComp-sorted unitigs
+            from supernova_amd import graphio
+            h = r.hbv()
+            off_d, bases_d = r.unitig_arrays()
+            lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+            ranked = [lut[bases_d[int(off_d[i]):int(off_d[i + 1])]].tobytes().decode() for i in h["order"]]
+            off2, bases2 = graphio.unitigs_to_arrays(o.unitigs)
+            h2 = graphio.hbv_from_unitigs(K, off2, bases2)
+            if ranked != o.unitigs or any(not np.array_equal(h[kx], h2[kx]) for kx in ("v_left", "v_right", "src", "is_rc", "fwd", "rev")):
+                ok = False; print("MISMATCH hbv", "global" if glob else "local", tag, flush=True)
     os.environ["SNK_GLOBAL_GRAPH"] = "0"
     if K == 48 and rng.random() < 0.4:
         # per-group graphs (BASELINE config 5): one grouped run == the oracle applied to every group's reads on its own
