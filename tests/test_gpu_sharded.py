@@ -96,6 +96,52 @@ def test_sharded_eight_ranks(snk, n_buckets):
     check(out, c)
 
 
+def test_sharded_engine_reuse_across_inputs(snk):
+    """One engine + ShardedEngine per rank (pooled exchange buffers, cached arena) over inputs of changing size: every
+    call is checked against the reference's golden vectors -- stale buffer contents or sizes would show."""
+    import torch
+    from supernova_amd.engine import Engine, Params
+    from supernova_amd.sharded import ShardedEngine, SimWorld
+    W = 2
+    world = SimWorld(W)
+    dev = torch.device("cuda", 0)
+    names = ["synth_20k_err", "synth_2k_err", "adversarial", "synth_6k_clean", "synth_20k_err", "synth_2k_err"]
+    cases = [goldens.load(nm) for nm in names]
+    outs, errs = [[None] * W for _ in names], []
+
+    def worker(r):
+        try:
+            torch.cuda.set_device(0)
+            e = Engine(0)
+            sh = ShardedEngine(e, world.comm(r))
+            for ci, c in enumerate(cases):
+                n = c.rows.shape[0]
+                lo, hi = n * r // W, n * (r + 1) // W
+                rows = torch.from_numpy(c.rows[lo:hi].view(np.int32).copy()).to(dev)
+                quals = torch.from_numpy(np.ascontiguousarray(c.quals[lo:hi])).to(dev)
+                bc = torch.from_numpy(c.bc[lo:hi].astype(np.int32)).to(dev)
+                lens = torch.from_numpy(c.lens[lo:hi].astype(np.uint16).view(np.int16)).to(dev)
+                res = sh.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, params=Params(K=48),
+                                     ign_bc_below=c.ign_bc_below, read_index_base=lo)
+                outs[ci][r] = dict(keys=res.keys(), counts=res.counts(), ctx=res.ctx(), spectrum=res.spectrum(),
+                                   n_instances=res.n_instances, n_frags=res.n_frags, n_queries=res.n_queries,
+                                   unitigs=res.unitigs() if r == 0 else None)
+            e.close()
+        except BaseException as ex:  # noqa: BLE001
+            errs.append(ex)
+            world.barrier_obj.abort()
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(W)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if errs:
+        raise errs[0]
+    for ci, c in enumerate(cases):
+        check(outs[ci], c)
+
+
 def test_sharded_k60(snk):
     """K=60 through the sharded path (2 ranks) against the C oracle."""
     import oracle_lib
