@@ -61,6 +61,9 @@ for case in range(n_cases):
     min_freq = int(rng.choice([1, 2, 3, 4])); min_bc = int(rng.choice([0, 1, 2]))
     nb = int(rng.choice([0, 0, 1, 5, 97, 4099]))
     use_bc = rng.random() < 0.8
+    if os.environ.get("FUZZ_PROFILE") == "deep":      # few huge buckets, nothing filtered: deep hash splits, big sparse chunks
+        G = int(rng.choice([120000, 300000])); cov = float(rng.choice([3, 8])); n = max(10, int(G * cov / L))
+        min_freq = 1; nb = int(rng.choice([1, 2, 3, 5, 7])); err = float(rng.choice([0.0, 0.01]))
     codes, quals, lens, bc = make_reads(rng, G, n, L, err, nbc, rng.random() < 0.6)
     if only >= 0 and case != only:          # consume the same random draws as a full run of this case
         if K == 48 and rng.random() < 0.4:
