@@ -171,10 +171,13 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
         const uint64_t v = myv[q];
         const uint32_t c0 = (uint32_t)(v & 0xFFu);
         uint32_t keep = 0, miss = 0, nb0 = NONE, nb1 = NONE;
+        // the reverse complement of a neighbour follows from the k-mer's own in one shift: rc(succ(k, b)) =
+        // pred(rc(k), 3 - b) and rc(pred(k, b)) = succ(rc(k), 3 - b) -- one 128-bit reversal per node, not per neighbour
+        const snk_kmer kr = snk_kmer_rc<K>(k);
         for (uint32_t rem = c0; rem; rem &= rem - 1) {      // a k-mer has ~2 set bits: iterate over them, not over all 8
             const uint32_t bit = __ffs(rem) - 1;
             const snk_kmer y = bit < 4 ? snk_kmer_succ<K>(k, bit) : snk_kmer_pred<K>(k, bit - 4);
-            const snk_kmer r = snk_kmer_rc<K>(y);
+            const snk_kmer r = bit < 4 ? snk_kmer_pred<K>(kr, 3u - bit) : snk_kmer_succ<K>(kr, 7u - bit);
             const bool rev = snk_kmer_lt(r, y);
             snk_kmer cy = rev ? r : y;
             if (GR) cy.lo |= tag;                            // neighbours live in the same group
@@ -348,10 +351,11 @@ __global__ void __launch_bounds__(TB) bl_resolve_kernel(const snk_u128* __restri
         uint64_t tag = 0;
         if (GR) { tag = k.lo & 0xFFFFFFFFull; k.lo &= ~0xFFFFFFFFull; }
         uint32_t c = ctx[i];
+        const snk_kmer kr = snk_kmer_rc<K>(k);              // rc of a neighbour = one shift of rc(k), see bl_prune_chunk
         for (uint32_t rem = pm; rem; rem &= rem - 1) {
             const uint32_t bit = __ffs(rem) - 1;
             const snk_kmer y = bit < 4 ? snk_kmer_succ<K>(k, bit) : snk_kmer_pred<K>(k, bit - 4);
-            const snk_kmer r = snk_kmer_rc<K>(y);
+            const snk_kmer r = bit < 4 ? snk_kmer_pred<K>(kr, 3u - bit) : snk_kmer_succ<K>(kr, 7u - bit);
             const bool rev = snk_kmer_lt(r, y);
             snk_kmer cy = rev ? r : y;
             if (GR) cy.lo |= tag;
