@@ -224,7 +224,7 @@ def test_read_length_extremes_vs_oracle(engine, L, K):
 def test_k60_sparse_chunks_of_a_thousand_fragments(engine, graph_stage, n_buckets):
     """Low coverage, no filter, K=60, ~18 k retained k-mers per bucket: the buckets split 16-32 ways by hash, the
     sub-passes of ~1150 k-mers hold almost only one-k-mer fragments, i.e. more than 65535 fragment bases per chunk -- the
-    per-chunk base offsets need 32 bits (found by tools/fuzz_parity.py in a five-rank sharded run; 16-bit offsets
+    per-chunk base offsets need 32 bits (found by tests/tools/fuzz_parity.py in a five-rank sharded run; 16-bit offsets
     garbled a few bases of ~90 unitigs, differently in every run)."""
     import torch
     from supernova_amd import synth

@@ -1,8 +1,8 @@
-"""Triage aid: replay one case of tools/fuzz_parity.py and vary one factor at a time."""
+"""Triage aid: replay one case of tests/tools/fuzz_parity.py and vary one factor at a time."""
 import os, sys, threading, itertools
 from pathlib import Path
-ROOT = Path(__file__).resolve().parent.parent
-sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests")); sys.path.insert(0, str(ROOT / "tools"))
+ROOT = Path(__file__).resolve().parent.parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests")); sys.path.insert(0, str(ROOT / "tests" / "tools"))
 import numpy as np, torch
 import oracle_lib
 from supernova_amd import synth
@@ -12,8 +12,8 @@ sys.argv = [sys.argv[0]]
 seed, want = 777, 52
 rng = np.random.default_rng(seed)
 import importlib.util
-spec = importlib.util.spec_from_file_location("fz", ROOT / "tools" / "fuzz_parity.py")
-src = (ROOT / "tools" / "fuzz_parity.py").read_text()
+spec = importlib.util.spec_from_file_location("fz", ROOT / "tests" / "tools" / "fuzz_parity.py")
+src = (ROOT / "tests" / "tools" / "fuzz_parity.py").read_text()
 ns = {}
 exec(src[src.index("def make_reads"):src.index("def same")], {"np": np}, ns)
 make_reads = ns["make_reads"]

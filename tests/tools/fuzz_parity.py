@@ -1,9 +1,9 @@
 """Randomised parity sweep: the HIP path (single-GPU, both graph stages, and W simulated ranks) against the C oracle
 (oracle/snk_oracle.c) over random genomes / read sets / parameters.  Test infrastructure, like tests/: it may use the oracle.
-usage: python tools/fuzz_parity.py [n_cases] [seed]"""
+usage: python tests/tools/fuzz_parity.py [n_cases] [seed]"""
 import os, sys, threading
 from pathlib import Path
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import numpy as np
 import torch

@@ -1,9 +1,9 @@
 """Large parity run on the GPU box: HIP path vs the reference binary itself (oracle/_ref/snref_driver) on a seeded
 synthetic workload of the bench's model.  Bit-exact table (key, count, context) and unitigs.
-usage: python tools/parity_vs_ref.py [n_reads=1000000] [error_free]"""
+usage: python tests/tools/parity_vs_ref.py [n_reads=1000000] [error_free]"""
 import sys, tempfile, time
 from pathlib import Path
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import numpy as np, torch
 import refio
