@@ -257,7 +257,7 @@ int sno_count(const uint8_t* bases, uint32_t stride, const uint32_t* good_len, c
                 ctx = (uint8_t*)realloc(ctx, cap);
             }
             key_words(v[i].k, key + 4 * nk);
-            cnt[nk] = count > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)count;
+            cnt[nk] = count > 0xFFFFFFull ? 0xFFFFFFu : (uint32_t)count; /* KDef::setCount saturates at MAX_OFFSET = 2^24-1, kmers/ReadPather.h:127-131,145 */
             ctx[nk] = c;
             ++nk;
         }

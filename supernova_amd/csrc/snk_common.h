@@ -119,6 +119,21 @@ SNK_HD void snk_kmer_hash2(snk_kmer k, uint32_t* h1out, uint32_t* h2out) {
     *h1out = snk_mix32(a ^ 0x9747b28cu);
     *h2out = snk_mix32(b + 0x3c6ef372u);
 }
+// The count kernel's hash (once per inserted k-mer, so it is kept short: one multiply per key word, one avalanche round for
+// the slot word h1, one more multiply for the tag / split word h2).  W3 = false: the low key word is known to be zero
+// (K <= 48, ungrouped) and is left out -- the value is the same as with W3 = true on such a key.  The bucket-local graph
+// stage derives the hash-split id of a neighbour from h2 (snk_local.hip), so both sides use this function.
+template <bool W3>
+SNK_HD void snk_kmer_hash_count(snk_kmer k, uint32_t* h1out, uint32_t* h2out) {
+    const uint32_t w0 = (uint32_t)(k.hi >> 32), w1 = (uint32_t)k.hi, w2 = (uint32_t)(k.lo >> 32), w3 = (uint32_t)k.lo;
+    uint32_t a = (w0 * 0xcc9e2d51u) ^ snk_rotl32(w1 * 0x1b873593u, 13) ^ (w2 * 0x85ebca77u);
+    if (W3) a ^= snk_rotl32(w3 * 0xc2b2ae3du, 19);
+    a ^= a >> 16; a *= 0x7feb352du; a ^= a >> 15;
+    uint32_t b = a * 0x846ca68bu;
+    b ^= b >> 16;
+    *h1out = a;
+    *h2out = b;
+}
 
 // ---------------------------------------------------------------- minimiser order and bucket (shared by K3/K4 and
 // the sharded graph stage, which must find the bucket -- hence the owner rank -- of an arbitrary k-mer)

@@ -34,6 +34,11 @@ constexpr int MAX_SPLIT_LOG2 = 16;
 #define SNK_COUNT_SLOTS 2048
 #endif
 #define LDS_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+// Workgroup barrier that orders LDS traffic only.  Inside this kernel the threads of a workgroup talk to each other through
+// LDS exclusively; __syncthreads() also drains every outstanding HBM access of the wave (s_waitcnt vmcnt(0)): the prefetched
+// records of the next bucket, the survivors' stores.  Loaded values are still waited for where they are used (the compiler's
+// own s_waitcnt).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #ifdef SNK_COUNT_PROF
 // thread 0's cycles per phase, accumulated in registers and added to the global counters once per workgroup
 #define PROF(n) do { if (tid == 0) { const long long _t = clock64(); prof_acc[n] += (unsigned long long)(_t - prof_t); prof_t = _t; } } while (0)
@@ -85,6 +90,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     uint16_t* lpre = lead + BATCH;                                                  // [BATCH+2] its first k-mer instance (+ sentinel)
     uint16_t* cidx = lpre + BATCH + 2;                                              // [NCI] leader rank that owns instance 32*w
     uint32_t* segi = reinterpret_cast<uint32_t*>(smem_raw + (((size_t)(reinterpret_cast<unsigned char*>(cidx + NCI) - smem_raw) + 15) & ~(size_t)15));   // [3][MAXSEG] segment start (lo, hi), length
+    uint16_t* olist = reinterpret_cast<uint16_t*>(segi + 3 * SNK_COUNT_MAXSEG);     // [LIMIT] claimed slots in claim order (the filter walks these, not the table)
     // ctl[0] unused, ctl[1] occupied slots, ctl[2] overflow flag, ctl[3] split log2, ctl[4] split id,
     // ctl[5] valid entries of the sub-pass, ctl[6..7] reserved base (lo,hi), ctl[8] placement counter,
     // ctl[16..16+2*MAX) split stack (MAX = 17 levels -> up to ctl[51]), ctl[52..59] wave totals of the batch scan
@@ -96,22 +102,30 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     long long prof_t = clock64();
     unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-    // a.bucket_stride != 0: the grid is one residency wave of workgroups and each walks buckets blockIdx.x, +stride, ...
-    // (no dispatch gap between buckets); 0: one bucket per workgroup
-    for (uint32_t bucket = blockIdx.x + a.bucket0; bucket < a.NB; bucket += a.bucket_stride) {
+    // The grid is a few residency waves of workgroups; workgroup w counts the buckets b == w (mod grid) of [bucket0, NB)
+    // (no dispatch gap between buckets) and OWNS output region w: its survivors go out behind each other at a cursor the
+    // workgroup keeps itself.  The first version reserved every sub-pass's chunk with a device-scope atomic on one of 4096
+    // region cursors: a round trip of microseconds per bucket that all twelve waves waited for at a barrier.  A region is
+    // continued across launches (the ranged launches of the sharded path): the cursor is read at the start, written at the end.
+    const uint32_t G = a.bucket_stride;
+    unsigned long long rcur = a.region_cursor[blockIdx.x];          // uniform: every thread keeps the same value
+    uint32_t bucket = a.bucket0 + (blockIdx.x + G - a.bucket0 % G) % G;
+    // bounds of the workgroup's first bucket; afterwards the NEXT bucket's bounds are fetched (scalar loads: the index is
+    // uniform) while the current one is counted, and its first batch of records right after the last insert phase
+    uint64_t beg0 = 0, end0 = 0;
+    if (bucket < a.NB) { beg0 = a.seg_beg[bucket]; end0 = a.seg_end[bucket]; }
+    uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = make_uint4(0, 0, 0, 0);
+    if (tid < BATCH && beg0 + tid < end0) { pf0 = a.records[(beg0 + tid) * 2]; pf1 = a.records[(beg0 + tid) * 2 + 1]; }
+    for (; bucket < a.NB; bucket += G) {
     // depth of the split stack: every thread keeps its own copy (the control flow is uniform), so the sub-pass loop needs
     // no barrier-protected LDS read to decide whether it is done
     uint32_t sp = 1;
     if (tid == 0) { ctl[16] = 0; ctl[17] = 0; }
     uint32_t splits_done = 0;
-    // issued before the table is cleared: the bounds of segment 0 and the first batch of records (two dependent HBM
-    // round trips that every workgroup used to wait for after its first barrier).  Prefetching the NEXT bucket was tried
-    // three times: at the start of the current bucket the 16 registers live across the insert phase push the kernel
-    // from 71 to 92 VGPRs = one workgroup per CU (116 ms), capped at 80 VGPRs it spills (82 ms); bounds during the
-    // filter scan + records during the placement loop keeps the register count but runs 77 ms instead of 73.
-    const uint64_t beg0 = a.seg_beg[bucket], end0 = a.seg_end[bucket];
-    uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = make_uint4(0, 0, 0, 0);
-    if (tid < BATCH && beg0 + tid < end0) { pf0 = a.records[(beg0 + tid) * 2]; pf1 = a.records[(beg0 + tid) * 2 + 1]; }
+    const uint32_t nbucket = bucket + G;
+    uint64_t nbeg = 0, nend = 0;
+    if (nbucket < a.NB) { nbeg = a.seg_beg[nbucket]; nend = a.seg_end[nbucket]; }
+    uint4 nf0 = make_uint4(0, 0, 0, 0), nf1 = make_uint4(0, 0, 0, 0);
     // more than one segment (sharded runs: one per source rank): the segments are counted as ONE concatenated record
     // stream -- batches stay full and identical supermers from different sources fold -- so every thread needs all bounds
     if (MULTI && tid < (int)a.nseg) {
@@ -120,7 +134,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     }
     bool first_batch = true;
     while (sp) {
-        __syncthreads();          // the previous sub-pass / bucket is done with the table; stack entries are visible
+        lds_barrier();          // the previous sub-pass / bucket is done with the table; stack entries are visible
         PROF(0);
         --sp;
         const uint32_t split_lg = LDS_LOAD(&ctl[16 + 2 * sp]), split_id = LDS_LOAD(&ctl[17 + 2 * sp]);
@@ -128,7 +142,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
         if (tid == 0) { ctl[1] = 0; ctl[2] = 0; ctl[5] = 0; ctl[8] = 0; }
         for (int s = tid; s < SLOTS; s += THREADS) tag[s] = 0;      // cnt/bcs of a slot are initialised by the lane that claims it
         for (int s = tid; s < SLOTS / 4; s += THREADS) ctxw[s] = 0;
-        __syncthreads();
+        lds_barrier();
         PROF(1);
 
         // iteration space: absolute record indices of the one segment, or offsets into the concatenation of all segments
@@ -160,7 +174,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                     wgt[tid] = 1;
                 }
                 for (int q = tid; q < DD; q += THREADS) dd[q] = 0;
-                __syncthreads();
+                lds_barrier();
                 PROF(2);
                 // ---- fold identical supermers: at 56x coverage ~3 of 4 reads over a locus yield the SAME record (same
                 //      bases, same flanks); only their barcodes differ.  The first one becomes the leader and carries a
@@ -204,7 +218,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                 uint32_t incl = sv;
                 for (int o = 1; o < 64; o <<= 1) { uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
                 if (lane == 63 && wv < BATCH / 64) ctl[52 + wv] = incl;
-                __syncthreads();
+                lds_barrier();
                 PROF(3);
                 uint32_t woff = 0, tot = 0;
                 for (int w = 0; w < BATCH / 64; ++w) { uint32_t t = ctl[52 + w]; if (w < wv) woff += t; tot += t; }
@@ -219,7 +233,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                     for (uint32_t w = (off + 31u) >> 5; (w << 5) < off + nkm; ++w) cidx[w] = (uint16_t)r;
                 }
                 if (tid == 0) lpre[nlead] = (uint16_t)total;
-                __syncthreads();
+                lds_barrier();
                 PROF(4);
                 // ---- one lane per k-mer instance: a wave inserts 64 different k-mers of consecutive supermers, so
                 //      copies of the same k-mer (identical supermers of other reads) are spread over time, not lanes
@@ -264,7 +278,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                         if (rev) ctx = snk_ctx_rc(ctx);
                         if (GROUPED) c.lo |= (uint64_t)w7;           // (group, k-mer) is the counted entity
                         uint32_t h1, h2;
-                        snk_kmer_hash2(c, &h1, &h2);
+                        snk_kmer_hash_count<(K > 48) || GROUPED>(c, &h1, &h2);
                         if (a.dbg == 1) { if (h1 == 0x12345u && h2 == 0x54321u) a.status[3] = 7; }
                         else if ((h2 & split_mask) == split_id) {
                             // double hashing (odd stride, power-of-two table): a wave waits for its slowest lane, so the
@@ -288,6 +302,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                                         __hip_atomic_store(&tag[slot], mytag | 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                                         uint32_t occ = atomicAdd(&ctl[1], 1u);
                                         if (occ >= LIMIT) __hip_atomic_store(&ctl[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                        else olist[occ] = (uint16_t)slot;
                                         found = true;
                                         break;
                                     }
@@ -310,7 +325,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                         }
                     }
                 }
-                __syncthreads();   // rec/pre/owner are rewritten by the next batch
+                lds_barrier();   // rec/pre/owner are rewritten by the next batch
                 PROF(5);
             }
         }
@@ -327,72 +342,70 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
             ++splits_done;
             continue;
         }
-        // K8: filter + compact the surviving entries to the global table.  Device-scope atomics on one
-        // address are served at the memory side (the XCD L2s are not coherent) at tens of ns each, so the
-        // table is cut into n_regions regions with their own cursors and every sub-pass does ONE global
-        // atomic: count the survivors in LDS, reserve, then place.
+        // K8: filter + write the surviving entries behind the workgroup's cursor in its own output region, in ONE pass over the
+        // slots that were claimed (olist; a 5000-instance bucket claims ~500 of the 2048 slots, most of them by k-mers seen
+        // once): the first version scanned the whole table twice (count the survivors, then rank and write them) with a
+        // device-scope reservation and two barriers in between -- a quarter of the kernel.  A survivor's position is the
+        // running cursor + its rank (one LDS atomic per wave); the cursor moves on after the one barrier that follows.
         PROF(6);
-        uint32_t myvalid = 0;
-        for (int s = tid; s < SLOTS; s += THREADS) {      // SLOTS need not be a multiple of THREADS
-            const uint32_t c = tag[s] ? cnt[s] : 0u;       // unclaimed slots hold stale counts
-            bool ok = c >= a.min_freq && c != 0;
-            if (ok && a.bc_mode) {
-                const uint32_t b = bcs[s];
-                ok = a.bc_mode == 1 ? (b != 0) : (b >= BC_MULTI);
+        // the last sub-pass of the bucket is past its insert phase: the next bucket's first records can be on their way while
+        // this one's survivors are written (the registers are free here; nothing waits for the loads before the next bucket
+        // stages them -- the barriers order LDS only)
+        if (sp == 0 && tid < BATCH && nbeg + tid < nend) { nf0 = a.records[(nbeg + tid) * 2]; nf1 = a.records[(nbeg + tid) * 2 + 1]; }
+        const uint32_t nocc = LDS_LOAD(&ctl[1]);          // < LIMIT here (the overflow case went the other way)
+        const uint64_t rbase = rcur;
+        const uint64_t gbase = (uint64_t)blockIdx.x * a.region_cap + rbase;
+        for (uint32_t e0 = 0; e0 < nocc; e0 += THREADS) {
+            const uint32_t e = e0 + tid;
+            uint32_t s = 0, c = 0;
+            bool ok = false;
+            if (e < nocc) {
+                s = olist[e];
+                c = cnt[s];
+                ok = c >= a.min_freq && c != 0;
+                if (ok && a.bc_mode) {
+                    const uint32_t b = bcs[s];
+                    ok = a.bc_mode == 1 ? (b != 0) : (b >= BC_MULTI);
+                }
             }
-            if (ok) ++myvalid;
-            else cnt[s] = 0;              // survivors keep their count, everything else is cleared
+            const unsigned long long m = __ballot(ok);
+            if (m) {
+                const int leader = __ffsll((long long)m) - 1;
+                uint32_t b = 0;
+                if (lane == leader) b = atomicAdd(&ctl[8], (uint32_t)__popcll(m));
+                b = __shfl(b, leader);
+                const uint64_t pos = rbase + b + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (ok && pos < a.region_cap) {
+                    const uint64_t at = gbase - rbase + pos;
+                    const uint32_t cx = (ctxw[s >> 2] >> (8 * (s & 3))) & 0xFFu;
+                    a.out_keys[at] = ((snk_u128)khi[s] << 64) | (snk_u128)klo_unpack<K, GROUPED>(klo[s]);
+                    a.out_vals[at] = ((uint64_t)(c < 0xFFFFFFu ? c : 0xFFFFFFu) << 8) | cx;   // KDef::setCount saturates at 2^24-1 (kmers/ReadPather.h:127-131,145)
+                }
+            }
         }
-        for (int o = 32; o > 0; o >>= 1) myvalid += __shfl_xor(myvalid, o);
-        if (lane == 0 && myvalid) atomicAdd(&ctl[5], myvalid);
-        __syncthreads();
-        const uint32_t nvalid = LDS_LOAD(&ctl[5]);
+        lds_barrier();
+        const uint32_t nvalid = LDS_LOAD(&ctl[8]);
         if (nvalid) {
-            const uint32_t region = bucket % a.n_regions;
-            // the reservation is a device-scope atomic (a round trip of microseconds): it is issued first, every thread
-            // collects its survivors (LDS reads, placement order) while it is in flight, and only then is the
-            // returned base published
-            unsigned long long b0 = 0;
-            if (tid == 0) b0 = atomicAdd(&a.region_cursor[region], (unsigned long long)nvalid);
-            constexpr int SPT = (SLOTS + THREADS - 1) / THREADS;
-            uint32_t e_pos[SPT];           // (holding keys and values here as well costs 14 spilled registers)
-#pragma unroll
-            for (int q = 0; q < SPT; ++q) {
-                const int s = tid + q * THREADS;
-                e_pos[q] = 0xFFFFFFFFu;
-                if (s < SLOTS && cnt[s]) e_pos[q] = atomicAdd(&ctl[8], 1u);
-            }
-            if (tid == 0) { ctl[6] = (uint32_t)b0; ctl[7] = (uint32_t)(b0 >> 32); }
-            __syncthreads();
-            const uint64_t rbase = ((uint64_t)LDS_LOAD(&ctl[7]) << 32) | LDS_LOAD(&ctl[6]);
-            if (rbase + nvalid <= a.region_cap) {
-                const uint64_t gbase = (uint64_t)region * a.region_cap + rbase;
-                // chunk descriptor for the bucket-local graph stage: the survivors of one sub-pass are contiguous
-                if (tid == 0 && a.chunk_n) {
+            rcur += nvalid;                       // keeps counting past the capacity: the host learns what the region needs
+            if (tid == 0) {
+                if (rbase + nvalid > a.region_cap) a.status[0] = 1;
+                else if (a.chunk_n) {
+                    // chunk descriptor for the bucket-local graph stage: the survivors of one sub-pass are contiguous
                     if (split_lg == 0) { a.chunk_n[bucket] = nvalid; a.chunk_base[bucket] = (uint32_t)rbase; }
                     else {
                         const uint32_t e = atomicAdd(&a.status[4], 1u);
                         if (e < a.extra_cap) a.extra[e] = make_uint4(bucket, (uint32_t)rbase, nvalid, (split_lg << 24) | split_id);
                     }
                 }
-#pragma unroll
-                for (int q = 0; q < SPT; ++q)
-                    if (e_pos[q] != 0xFFFFFFFFu) {
-                        const int s = tid + q * THREADS;
-                        const uint32_t cx = (ctxw[s >> 2] >> (8 * (s & 3))) & 0xFFu;
-                        a.out_keys[gbase + e_pos[q]] = ((snk_u128)khi[s] << 64) | (snk_u128)klo_unpack<K, GROUPED>(klo[s]);
-                        a.out_vals[gbase + e_pos[q]] = ((uint64_t)cnt[s] << 8) | cx;
-                    }
-            } else if (tid == 0) {
-                a.status[0] = 1;
             }
         }
         if (tid == 0) atomicMax(&a.status[3], LDS_LOAD(&ctl[1]));
         PROF(7);
     }
     if (tid == 0 && splits_done) atomicAdd(&a.status[2], 1u);
-    if (a.bucket_stride == 0) break;
+    beg0 = nbeg; end0 = nend; pf0 = nf0; pf1 = nf1;
     }
+    if (tid == 0) a.region_cursor[blockIdx.x] = rcur;
 #ifdef SNK_COUNT_PROF
     if (tid == 0) for (int q = 0; q < 8; ++q) atomicAdd(&a.prof[q], prof_acc[q]);
 #endif
@@ -405,7 +418,7 @@ template <> struct cfg<60> { static constexpr int THREADS = SNK_COUNT_THREADS; s
 template <int K, bool G>
 size_t lds_bytes() {
     constexpr size_t S = cfg<K>::SLOTS, B = (K == 48 && !G && S >= 2048) ? 512 : 256, DD = 2 * B, NCI = B * (K - SNK_M + 1) / 32 + 2;
-    return S * (8 + sizeof(typename klo_t<K, G>::type) + 4 + 4 + 4) + S + 4 * (8 * B + 64 + DD + B) + 2 * (B + B + 2 + NCI) + 16 + 4 * 3 * SNK_COUNT_MAXSEG + 16;
+    return S * (8 + sizeof(typename klo_t<K, G>::type) + 4 + 4 + 4) + S + 4 * (8 * B + 64 + DD + B) + 2 * (B + B + 2 + NCI) + 16 + 4 * 3 * SNK_COUNT_MAXSEG + 2 * (S - cfg<K>::THREADS - 64) + 16;
 }
 
 template <int K, bool G>
@@ -413,35 +426,34 @@ int launch(hipStream_t st, const snk_count_args& a, char* err, size_t errcap) {
     auto kern = a.nseg > 1 ? snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G, true> : snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G, false>;
     size_t lds = lds_bytes<K, G>();
     SNK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (a.bucket0 >= a.NB) return SNK_OK;          // the launch covers buckets [bucket0, NB)
+    // one workgroup per output region, every launch of a table (the ranged launches of the sharded path) with the same grid:
+    // workgroup w counts the buckets == w (mod n_regions) and appends to region w
     snk_count_args b = a;
-    const uint32_t first = a.bucket0, last = a.NB;          // the launch covers buckets [first, last)
-    if (first >= last) return SNK_OK;
-    // Workgroups walk buckets w, w + grid, ...: 2 M one-bucket workgroups spend ~8 % of the kernel in dispatch (73.7 ms);
-    // exactly one residency wave (grid = 2 x CUs) is no better (73.5: whoever finishes early idles to the end); 32-64
-    // waves keep both the dispatch cost and the tail small (67.3 ms at 1e8 reads).  SNK_COUNT_PERSIST=0: one bucket each.
-    const uint32_t persist = snk_env_u32("SNK_COUNT_PERSIST", 32);
-    if (persist) {
-        int per_cu = 0, dev = 0, n_cu = 256;
-        SNK_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, cfg<K>::THREADS, lds));
-        SNK_HIP_TRY(hipGetDevice(&dev));
-        SNK_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        uint64_t grid = (uint64_t)(per_cu > 0 ? per_cu : 1) * (uint64_t)n_cu * persist;
-        if (grid > last - first) grid = last - first;
-        b.bucket_stride = (uint32_t)grid;
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(cfg<K>::THREADS), lds, st, b);
-        SNK_HIP_TRY(hipGetLastError());
-        return SNK_OK;
-    }
-    // one bucket per workgroup.  A launch is limited to 2^32 threads in total: buckets go out in slices of 4 M workgroups
-    constexpr uint32_t SLICE = 1u << 22;
-    b.bucket_stride = 0;
-    for (uint32_t b0 = first; b0 < last; b0 += SLICE) {
-        b.bucket0 = b0;
-        const uint32_t nb = last - b0 < SLICE ? last - b0 : SLICE;
-        b.NB = b0 + nb;
-        hipLaunchKernelGGL(kern, dim3(nb), dim3(cfg<K>::THREADS), lds, st, b);
-    }
+    b.bucket_stride = a.n_regions;
+    hipLaunchKernelGGL(kern, dim3(a.n_regions), dim3(cfg<K>::THREADS), lds, st, b);
     SNK_HIP_TRY(hipGetLastError());
+    return SNK_OK;
+}
+
+// Workgroups walk strided bucket lists: 2 M one-bucket workgroups spend ~8 % of the kernel in dispatch (73.7 ms at 1e8
+// reads); exactly one residency wave (grid = 2 x CUs) is no better (73.5: whoever finishes early idles to the end); 32-64
+// waves keep both the dispatch cost and the tail small (67.3 ms).  SNK_COUNT_PERSIST sets the number of residency waves.
+template <int K, bool G>
+int regions(uint32_t nseg, uint32_t NB, uint32_t* out, char* err, size_t errcap) {
+    auto kern = nseg > 1 ? snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G, true> : snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G, false>;
+    size_t lds = lds_bytes<K, G>();
+    SNK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    uint32_t persist = snk_env_u32("SNK_COUNT_PERSIST", 32);
+    if (persist == 0) persist = 1;
+    int per_cu = 0, dev = 0, n_cu = 256;
+    SNK_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, cfg<K>::THREADS, lds));
+    SNK_HIP_TRY(hipGetDevice(&dev));
+    SNK_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    uint64_t grid = (uint64_t)(per_cu > 0 ? per_cu : 1) * (uint64_t)n_cu * persist;
+    if (grid > NB) grid = NB;
+    if (grid > (1u << 20)) grid = 1u << 20;
+    *out = grid ? (uint32_t)grid : 1u;
     return SNK_OK;
 }
 
@@ -472,6 +484,12 @@ int snk_launch_compact_regions(hipStream_t st, const snk_u128* keys_in, const ui
 }
 
 uint32_t snk_count_slots(uint32_t K) { return K == 60 ? cfg<60>::SLOTS : cfg<48>::SLOTS; }
+
+int snk_count_regions(uint32_t K, uint32_t grouped, uint32_t nseg, uint32_t NB, uint32_t* n_regions, char* err, size_t errcap) {
+    if (grouped) return regions<48, true>(nseg, NB, n_regions, err, errcap);
+    if (K == 60) return regions<60, false>(nseg, NB, n_regions, err, errcap);
+    return regions<48, false>(nseg, NB, n_regions, err, errcap);
+}
 
 int snk_launch_count(uint32_t K, hipStream_t st, const snk_count_args& a, char* err, size_t errcap) {
     if (a.NB == 0) return SNK_OK;

@@ -259,7 +259,7 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
                     snk_kmer cn = snk_kmer_lt(r, y) ? r : y;
                     if (GR) cn.lo |= ktag;
                     uint32_t h1, h2;
-                    snk_kmer_hash2(cn, &h1, &h2);
+                    snk_kmer_hash_count<(K > 48) || GR>(cn, &h1, &h2);       // the count kernel's split function
                     here = (h2 & split_mask) == ch.id;
                 }
                 if (here) { if (!do_prune) atomicOr(&resL[th], 1u << bit); }

@@ -30,7 +30,8 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
     tm.mark();
     // ---- K5-K8 count + filter into a region-partitioned table, then gather the regions densely.
     // Every retained k-mer has >= min_freq instances; deep coverage retains far fewer (56x: ~1/38 of them).
-    uint32_t n_regions = NB < 4096 ? NB : 4096;
+    uint32_t n_regions = 1;
+    if ((rc = snk_count_regions(K, grouped, nseg, NB, &n_regions, err, errcap))) return rc;
     uint64_t est = n_inst_hint / (min_freq > 1 ? 12 : 1) + 4096;     // first call only; a wrong guess costs one re-run
     if (ctx->last_n_kmers && ctx->last_n_instances == n_inst_hint) est = ctx->last_n_kmers + ctx->last_n_kmers / 2 + 4096;
     uint64_t region_cap = est / n_regions + 64;
@@ -129,7 +130,7 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
             (void)hipMemcpy(d, status + 4, 24, hipMemcpyDeviceToHost);
             fprintf(stderr, "[snk dbg] lane probe iterations %llu, wave-level iterations %llu, max lane iterations in one probe %llu\n", d[0], d[1], d[2]);
         }
-        if (h_status[1]) return snk_fail(SNK_E_INTERNAL, err, errcap, "count: bucket split depth exceeded");
+        if (h_status[1]) return snk_fail(SNK_E_INTERNAL, err, errcap, h_status[1] == 2 ? "count: a table probe did not terminate" : "count: bucket split depth exceeded");
         unsigned long long mx = 0;
         n_kmers = 0;
         for (uint32_t r = 0; r < n_regions; ++r) { n_kmers += h_rcur[r]; if (h_rcur[r] > mx) mx = h_rcur[r]; }
@@ -142,7 +143,7 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
         if (extra_ovf) extra_cap = h_status[4] + 64;
     }
     {
-        // exclusive offsets of the regions (host: n_regions <= 4096) and the dense gather
+        // exclusive offsets of the regions (host: one region per count workgroup, ~16 k) and the dense gather
         std::vector<unsigned long long> h_off(n_regions + 1);
         unsigned long long acc = 0;
         for (uint32_t r = 0; r < n_regions; ++r) { h_off[r] = acc; acc += h_rcur[r]; }

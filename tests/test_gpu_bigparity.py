@@ -1,0 +1,112 @@
+"""Parity above the size of committed dumps: the HIP path against SHA-256 fixtures of the REFERENCE ITSELF
+(tests/golden/big_hashes.json, made by tests/golden/make_big_hashes.py from oracle/_ref/snref_driver[60] in the build
+container) on BASELINE config 1 (10 M x 150 bp, seed 0x5EED0001) and a 2 M-read instance of the same
+model -- one GPU, and 8 simulated ranks of the minimiser-sharded path.  Equal digests = bit-equal good lengths, retained
+table (keys, counts, pruned contexts), spectrum and canonical unitigs (tests/bighash.py).
+
+The device generator is the host generator bit for bit (test_gpu_parity.py::test_synth_vs_oracle), so the reads are made
+in HBM directly."""
+import json
+import threading
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import bighash
+
+pytestmark = pytest.mark.gpu
+
+FIX = Path(__file__).resolve().parent / "golden" / "big_hashes.json"
+HASHES = json.loads(FIX.read_text()) if FIX.exists() else {}
+FIELDS = ("n_reads", "n_kmers", "n_unitigs", "unitig_bases", "goodlens", "keys", "counts", "ctx", "hist", "unitigs")
+
+
+def _case(name):
+    if name not in HASHES:
+        pytest.skip(f"{name}: no fixture in tests/golden/big_hashes.json (made in the build container)")
+    return HASHES[name]
+
+
+def _compare(dg, exp, fields=FIELDS):
+    bad = [f for f in fields if dg[f] != exp[f]]
+    assert not bad, {f: (dg[f], exp[f]) for f in bad}
+
+
+@pytest.mark.parametrize("name", ["c1_2m", "c1_10m", "c1_2m_k60", "c1_10m_k60"])
+def test_one_gpu_vs_reference_digest(snk, name):
+    import torch
+    from supernova_amd import synth
+    from supernova_amd.engine import Engine, Params
+    exp = _case(name)
+    K = exp["K"]
+    e = Engine(0)
+    try:
+        sp = synth.synth_params(exp["n_reads"], seed=exp["seed"])
+        rows, quals, bc = e.synth(sp)
+        # the reference's K=60 variant has no barcode rule: run without a barcode vector there
+        res = e.count_graph(rows, sp.read_len, quals=quals, bc=bc if K == 48 else None, params=Params(K=K))
+        hist = res.spectrum().astype(np.int64)
+        dg = bighash.digest(res.good_len().astype(np.uint32), res.keys(), res.counts(), res.ctx(), res.unitigs(), hist,
+                            kw=3 if K == 48 else 4)
+        if exp.get("hist_from") != "reference json":
+            # no spectrum file from the reference's K=60 variant: the fixture's histogram is over the retained counts
+            hist = np.bincount(np.minimum(res.counts(), (1 << 24) - 1)).astype(np.int64)
+            dg["hist"] = bighash.digest(np.zeros(0), np.zeros((0, 4)), [], [], [], hist)["hist"]
+        _compare(dg, exp)
+    finally:
+        e.close()
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("name,W", [("c1_2m", 8), ("c1_10m", 8), ("c1_2m_k60", 3)])
+def test_simulated_ranks_vs_reference_digest(snk, name, W):
+    """The minimiser-sharded SPMD code (W ranks as threads on one GPU, tensor copies as the transport): the union of
+    the ranks' tables and the joined unitigs against the same reference digests."""
+    import torch
+    from supernova_amd import synth
+    from supernova_amd.engine import Engine, Params
+    from supernova_amd.sharded import ShardedEngine, SimWorld
+    exp = _case(name)
+    K, n = exp["K"], exp["n_reads"]
+    world = SimWorld(W)
+    bounds = [(n * r // W) & ~1 for r in range(W)] + [n]       # mates stay together
+    out, errs = [None] * W, []
+
+    def worker(r):
+        try:
+            torch.cuda.set_device(0)
+            e = Engine(0)
+            lo, hi = bounds[r], bounds[r + 1]
+            sp = synth.synth_params(n, seed=exp["seed"])
+            rows, quals, bc = e.synth(sp, first=lo, n=hi - lo)
+            sh = ShardedEngine(e, world.comm(r))
+            res = sh.count_graph(rows, sp.read_len, quals=quals, bc=bc if K == 48 else None, params=Params(K=K),
+                                 read_index_base=lo)
+            out[r] = dict(keys=res.keys(), counts=res.counts(), ctx=res.ctx(), spectrum=res.spectrum().astype(np.int64),
+                          unitigs=res.unitigs() if r == 0 else None)
+            e.close()
+        except BaseException as ex:  # noqa: BLE001
+            errs.append(ex)
+            world.barrier_obj.abort()
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(W)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if errs:
+        raise errs[0]
+    keys = np.concatenate([o["keys"] for o in out])
+    counts = np.concatenate([o["counts"] for o in out])
+    ctx = np.concatenate([o["ctx"] for o in out])
+    order = np.lexsort((keys[:, 3], keys[:, 2], keys[:, 1], keys[:, 0]))
+    keys, counts, ctx = keys[order], counts[order], ctx[order]
+    if exp.get("hist_from") == "reference json":
+        nb = max(len(o["spectrum"]) for o in out)
+        hist = sum(np.pad(o["spectrum"], (0, nb - len(o["spectrum"]))) for o in out)
+    else:
+        hist = np.bincount(np.minimum(counts, (1 << 24) - 1)).astype(np.int64)
+    dg = bighash.digest(np.zeros(n, np.uint32), keys, counts, ctx, out[0]["unitigs"], hist, kw=3 if K == 48 else 4)
+    _compare(dg, exp, fields=tuple(f for f in FIELDS if f != "goodlens"))
+    torch.cuda.empty_cache()

@@ -11,12 +11,13 @@ n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100_000_000
 e = Engine(0)
 sp = synth.synth_params(n, seed=0x5EED0001)
 rows, quals, bc = e.synth(sp)
-for dbg in (0, 1, 2, 4):
+modes = tuple(int(x) for x in sys.argv[2].split(',')) if len(sys.argv) > 2 else (0, 1, 2, 4)
+for dbg in modes:
     os.environ["SNK_COUNT_DBG"] = str(dbg)
     for rep in range(2):
         try:
             res = e.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48, graph=False, sorted_table=False))
-            msg = f"count kernel {res.kernel_ms['count']:.1f} ms, retained {res.n_kmers}"
+            msg = f"count kernel {res.kernel_ms['count']:.1f} ms, partition kernel {res.kernel_ms['partition']:.1f} ms, retained {res.n_kmers}, split {res.buckets_split}, max slots {res.max_slots_used}"
         except Exception as ex:
             msg = "failed: " + str(ex)[:80]
     print("dbg", dbg, msg, flush=True)
