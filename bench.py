@@ -164,7 +164,9 @@ def main():
         mixed = (kv[:, 0] * np.uint64(0x9E3779B97F4A7C15) + kv[:, 1] * np.uint64(0xC2B2AE3D27D4EB4F) + kv[:, 2] * np.uint64(0x165667B19E3779F9)
                  + resv.counts().astype(np.uint64) * np.uint64(0x27D4EB2F165667C5) + resv.ctx().astype(np.uint64) * np.uint64(0x85EBCA77C2B2AE63))
         uv = resv.unitigs() if rank == 0 else None       # fetched now: the next call on this engine recycles the result buffers
-        loc = torch.tensor([int(kv.shape[0]), int(mixed.sum(dtype=np.uint64) >> np.uint64(1))], dtype=torch.int64, device="cuda")
+        # exact 64-bit multiset checksum over an int64 transport: the two 32-bit halves are reduced separately
+        msum = int(mixed.sum(dtype=np.uint64))
+        loc = torch.tensor([int(kv.shape[0]), msum & 0xFFFFFFFF, msum >> 32], dtype=torch.int64, device="cuda")
         if world > 1:
             dist.all_reduce(loc)
         if rank == 0:
@@ -173,8 +175,8 @@ def main():
             kr = ref.keys().astype(np.uint64)
             mr = (kr[:, 0] * np.uint64(0x9E3779B97F4A7C15) + kr[:, 1] * np.uint64(0xC2B2AE3D27D4EB4F) + kr[:, 2] * np.uint64(0x165667B19E3779F9)
                   + ref.counts().astype(np.uint64) * np.uint64(0x27D4EB2F165667C5) + ref.ctx().astype(np.uint64) * np.uint64(0x85EBCA77C2B2AE63))
-            # per-rank sums were halved before the reduction (int64 transport): compare modulo the lost low bits
-            same_table = int(loc[0]) == kr.shape[0] and abs(int(loc[1]) - int(mr.sum(dtype=np.uint64) >> np.uint64(1))) <= world
+            got = (int(loc[1]) + (int(loc[2]) << 32)) & 0xFFFFFFFFFFFFFFFF
+            same_table = int(loc[0]) == kr.shape[0] and got == int(mr.sum(dtype=np.uint64))
             h = lambda us: hashlib.sha256("\n".join(us).encode()).hexdigest()
             same_unitigs = h(uv) == h(ref.unitigs())
             verified = bool(same_table and same_unitigs)
@@ -246,6 +248,9 @@ def main():
         out["config"]["path"] = "grouped-replicas" if args.grouped else ("sharded" if use_dist else "single")
         if verified is not None:
             out["config"]["sharded_self_check"] = "passed" if verified else "FAILED"
+            if not verified:        # a wrong result is not a performance number
+                out["value"] = None
+                out["invalid"] = "the sharded path's self-check against the one-GPU path failed"
 
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -255,7 +260,13 @@ def main():
                                        "sample": f"failed: {ex}"}
         print(json.dumps(out), flush=True)
     if use_dist:
+        if use_dist and not args.grouped and not args.no_verify:         # every rank leaves with the same exit code
+            vt = torch.tensor([1 if verified else 0], dtype=torch.int64, device="cuda")
+            dist.broadcast(vt, 0)
+            verified = bool(int(vt.item()))
         dist.destroy_process_group()
+    if verified is False:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

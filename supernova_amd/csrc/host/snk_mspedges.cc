@@ -9,7 +9,8 @@
 //   LR=<head>.fastb        reads; <head>.qualp and <head>.bci must exist next to it (DF.cc:265-272)
 //   OUT=<file.bv>          unitigs in the .bv hand-off format (lib/tada/src/debruijn.rs:895-929)
 //   K=48|60  MIN_QUAL=7  MIN_FREQ=3  MIN_BC=2      CS-build defaults, 10X/DF.cc:138-141
-//   BC_START=0             reads below this index ignore the barcode rule (DF.cc:358-363, BuildReadQGraph48.cc:158-159)
+//   BC_START=<n>           reads below this index ignore the barcode rule (BuildReadQGraph48.cc:158-159); default: what DF
+//                          derives from <head>.dti -- the start of the first 10X dataset (DF.cc:358-363) -- or 0 without one
 //   DEVICE=0               GPU ordinal
 //   SPECTRUM=<file.json>   optional: k-mer spectrum as DF writes it to stats/histogram_kmer_count.json
 // Exit codes follow the reference's conventions: 0 ok, 1 fatal (FatalErr), 99 out of memory (system/RunTime.cc:195-221).
@@ -38,11 +39,29 @@ std::string head_of(const std::string& path, const char* ext) {
     return path.substr(0, path.size() - n);
 }
 
+// <head>.dti = BINWRITE vec<DataSet>, DataSet = {ReadDataType dt (u8, padded to 8 bytes); int64 start} (10X/DfTools.h:23-46):
+// start of the first UNBAR_10X (2) / BAR_10X (3) dataset, 0 when there is none or no file
+long long bc_start_from_dti(const std::string& head) {
+    FILE* f = fopen((head + ".dti").c_str(), "rb");
+    if (!f) return 0;
+    char magic[8];
+    uint64_t n = 0;
+    long long out = 0;
+    if (fread(magic, 1, 8, f) == 8 && memcmp(magic, "BINWRITE", 8) == 0 && fread(&n, 8, 1, f) == 1) {
+        for (uint64_t i = 0; i < n && i < (1u << 20); ++i) {
+            unsigned char rec[16];
+            if (fread(rec, 1, 16, f) != 16) fatal(SNK_E_IO, "dataset index", "truncated .dti");
+            if (rec[0] == 2 || rec[0] == 3) { int64_t st; memcpy(&st, rec + 8, 8); out = st; break; }
+        }
+    } else { fclose(f); fatal(SNK_E_IO, "dataset index", "not a BINWRITE file"); }
+    fclose(f);
+    return out;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
-    std::map<std::string, std::string> kv = {{"K", "48"}, {"MIN_QUAL", "7"}, {"MIN_FREQ", "3"}, {"MIN_BC", "2"},
-                                             {"BC_START", "0"}, {"DEVICE", "0"}};
+    std::map<std::string, std::string> kv = {{"K", "48"}, {"MIN_QUAL", "7"}, {"MIN_FREQ", "3"}, {"MIN_BC", "2"}, {"DEVICE", "0"}};
     for (int i = 1; i < argc; ++i) {
         const char* eq = strchr(argv[i], '=');
         if (!eq) fatal(SNK_E_ARG, "argument is not KEY=VALUE", argv[i]);
@@ -50,7 +69,7 @@ int main(int argc, char** argv) {
     }
     if (!kv.count("LR") || !kv.count("OUT")) {
         fprintf(stderr, "usage: snk_mspedges LR=<reads.fastb> OUT=<asm_graph.bv> [K=48] [MIN_QUAL=7] [MIN_FREQ=3] [MIN_BC=2] "
-                        "[BC_START=0] [DEVICE=0] [SPECTRUM=<file.json>]\n");
+                        "[BC_START=<from .dti>] [DEVICE=0] [SPECTRUM=<file.json>]\n");
         return 1;
     }
     const std::string head = head_of(kv["LR"], ".fastb");
@@ -88,7 +107,7 @@ int main(int argc, char** argv) {
     in.lens = lens;
     in.quals = quals.data();
     in.bc = bc.data();
-    in.ign_bc_below = atoll(kv["BC_START"].c_str());
+    in.ign_bc_below = kv.count("BC_START") ? atoll(kv["BC_START"].c_str()) : bc_start_from_dti(head);
     snk_result r;
     if ((rc = snk_count_graph(ctx, &in, &p, &r, err, sizeof err))) fatal(rc, "count+graph", err);
     fprintf(stderr, "snk_mspedges: %llu k-mer instances, %llu retained k-mers, %llu unitigs; device %.1f ms\n",

@@ -15,6 +15,7 @@ size_t snk_msp_lds_bytes(uint32_t K, uint32_t M, uint32_t row_words);
 struct snk_msp_args {
     const uint32_t* rows;
     uint32_t row_words;
+    uint32_t read_len;             // bases per row that are real (good lengths are clamped to it)
     const uint16_t* good_len;
     const int32_t* bc;
     const uint32_t* group;         // grouped runs: group id per read (then record word 7 = group), else NULL

@@ -109,6 +109,7 @@ __global__ void __launch_bounds__(BD, K == 48 ? 5 : 4) snk_msp_kernel(snk_msp_ar
     __syncthreads();
     const uint64_t r = r0 + tid;
     int g = (r < n_reads) ? (int)a.good_len[r] : 0;
+    if (g > (int)a.read_len) g = (int)a.read_len;     // a caller-supplied good length never reaches past the packed row
     if (g < K + 1) g = 0;                               // reads with fewer than 2 k-mers are skipped (:160)
     const int nk = g ? g - K + 1 : 0;
     const int npos = g ? g - M + 1 : 0;

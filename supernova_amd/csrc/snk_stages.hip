@@ -326,7 +326,7 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
         SNK_HIP_TRY(hipMemsetAsync(status + 8, 0, 4, st));
         snk_msp_args ma;
         memset(&ma, 0, sizeof ma);
-        ma.rows = (const uint32_t*)in->rows; ma.row_words = in->row_words; ma.good_len = good_len; ma.bc = (const int32_t*)in->bc;
+        ma.rows = (const uint32_t*)in->rows; ma.row_words = in->row_words; ma.read_len = in->read_len; ma.good_len = good_len; ma.bc = (const int32_t*)in->bc;
         ma.ign_bc_below = in->ign_bc_below; ma.read_index_base = in->read_index_base; ma.n_reads = n_reads; ma.NB = NB;
         ma.group = grouped ? (const uint32_t*)in->group : nullptr;
         ma.cursor = cursor; ma.records = (uint4*)records; ma.cap = cap; ma.ovf_cap = (uint32_t)ovf_cap;

@@ -52,6 +52,7 @@ __global__ void __launch_bounds__(256) snk_trim_kernel(const uint8_t* __restrict
     if (r >= n_reads) return;
     const uint8_t* q = quals + r * (uint64_t)qstride;
     int len = lens ? lens[r] : (int)read_len;
+    if (len > (int)read_len) len = (int)read_len;      // a length beyond the row (bad caller data, mismatched fastb/qualp pair) must not walk off it
     const bool row_aligned = ((qstride & 3u) == 0) && ((((uintptr_t)quals) & 3u) == 0);
     good_len[r] = (uint16_t)snk_trim_row(q, len, row_aligned, K, min_qual);
 }
@@ -89,6 +90,7 @@ __global__ void __launch_bounds__(256) snk_trim_tile_kernel(const uint8_t* __res
     if (threadIdx.x >= rows_here) return;
     const uint64_t r = r0 + threadIdx.x;
     int len = lens ? lens[r] : (int)read_len;
+    if (len > (int)read_len) len = (int)read_len;      // a length beyond the row (bad caller data, mismatched fastb/qualp pair) must not walk off it
     good_len[r] = (uint16_t)snk_trim_row(tile + threadIdx.x * qstride, len, true, K, min_qual);
 }
 

@@ -16,10 +16,26 @@ from __future__ import annotations
 import glob
 import os
 import shutil
+import struct
 import subprocess
 from pathlib import Path
 
 import numpy as np
+
+
+# Martian hands a `src py` stage record objects (attribute access: args.reads, outs.default, chunk_outs[0].default --
+# mro/stages/denovo/df/__init__.py:14-15,81-139); the tests and the C++-side callers use plain dicts.  Both are accepted.
+def _get(rec, name, default=None):
+    if isinstance(rec, dict):
+        return rec.get(name, default)
+    return getattr(rec, name, default)
+
+
+def _set(rec, name, value):
+    if isinstance(rec, dict):
+        rec[name] = value
+    else:
+        setattr(rec, name, value)
 
 
 def split(args):
@@ -27,7 +43,7 @@ def split(args):
 
 
 def join(args, outs, chunk_defs, chunk_outs):
-    shutil.move(chunk_outs[0]["default"], outs["default"])
+    shutil.move(_get(chunk_outs[0], "default"), _get(outs, "default"))
 
 
 def check_exclude(path: str, ext: str) -> str:
@@ -49,21 +65,64 @@ def process_return_code(returncode: int):
     return msg
 
 
-def build_df_command(args: dict, out_dir: str, mspedges: str | None) -> list[str]:
+def build_df_command(args, out_dir: str, mspedges: str | None) -> list[str]:
     """The argv of df/__init__.py:123-139 (select_frac is pinned to 1.0 there, :121)."""
-    cmd = ["DF", "LR_SELECT_FRAC={:.8f}".format(1.0), "LR=" + args["reads"], "OUT_DIR=" + out_dir,
-           "MAX_MEM_GB=" + str(args.get("__mem_gb")), "NUM_THREADS=" + str(args.get("__threads"))]
+    cmd = ["DF", "LR_SELECT_FRAC={:.8f}".format(1.0), "LR=" + _get(args, "reads"), "OUT_DIR=" + out_dir,
+           "MAX_MEM_GB=" + str(_get(args, "__mem_gb")), "NUM_THREADS=" + str(_get(args, "__threads"))]
     if mspedges is not None:
         cmd.append("MSPEDGES={}".format(mspedges))
-    if args.get("pipeline_id") is not None:
-        cmd.append("PIPELINE={}".format(args["pipeline_id"]))
-    if args.get("known_sample_id") is not None:
-        cmd.append("SAMPLE={}".format(args["known_sample_id"]))
-    if args.get("addin") is not None and "DF" in args["addin"]:
-        cmd.extend(args["addin"]["DF"].split())
-    if args.get("nodebugmem") is None or not args["nodebugmem"]:
+    if _get(args, "pipeline_id") is not None:
+        cmd.append("PIPELINE={}".format(_get(args, "pipeline_id")))
+    if _get(args, "known_sample_id") is not None:
+        cmd.append("SAMPLE={}".format(_get(args, "known_sample_id")))
+    addin = _get(args, "addin")
+    if addin is not None and "DF" in addin:
+        cmd.extend(addin["DF"].split())
+    if _get(args, "nodebugmem") is None or not _get(args, "nodebugmem"):
         cmd.append("TRACK_SOME_MEMORY=True")
     return cmd
+
+
+# ReadDataType, 10X/DfTools.h:23-28
+_UNBAR_10X, _BAR_10X = 2, 3
+
+
+def read_dti(path) -> list[tuple[int, int]]:
+    """<head>.dti = BINWRITE vec<DataSet>; DataSet = {ReadDataType dt (u8, padded to 8); int64 start}, trivially
+    serialisable (10X/DfTools.h:30-46).  Returns [(dt, start), ...]."""
+    raw = Path(path).read_bytes()
+    if len(raw) < 16 or raw[:8] != b"BINWRITE":
+        raise Exception("not a BINWRITE file: " + str(path))
+    (n,) = struct.unpack_from("<Q", raw, 8)
+    if 16 + 16 * n > len(raw):
+        raise Exception("truncated dataset index: " + str(path))
+    return [(raw[16 + 16 * i], struct.unpack_from("<q", raw, 24 + 16 * i)[0]) for i in range(n)]
+
+
+def bc_start_of(head: str) -> int:
+    """Index of the first read of a 10X datatype: reads below it ignore the barcode rule (10X/DF.cc:358-363 ->
+    buildReadQGraph48's ignBcBelow, RunStages.cc:398).  No .dti next to the reads (a bare fastb/qualp/bci triple, as the
+    tests use): every read is barcoded data, start 0."""
+    dti = head + ".dti"
+    if not os.path.exists(dti):
+        return 0
+    for dt, start in read_dti(dti):
+        if dt in (_UNBAR_10X, _BAR_10X):          # "R data must come first"
+            return int(start)
+    return 0
+
+
+def graph_params_of(args) -> dict:
+    """K / MIN_FREQ / MIN_BC / MIN_QUAL as the stock DF would see them: its defaults (10X/DF.cc:138-141) overridden by
+    KEY=VALUE words of addin["DF"] (df/__init__.py:135-136) -- the GPU-built graph must be the one DF would have built."""
+    out = {"K": 48, "MIN_FREQ": 3, "MIN_BC": 2, "MIN_QUAL": 7}
+    addin = _get(args, "addin")
+    if addin is not None and "DF" in addin:
+        for word in addin["DF"].split():
+            k, _, v = word.partition("=")
+            if k in out:
+                out[k] = int(v)
+    return out
 
 
 def load_stage_inputs(reads: str, quals: str, bci: str):
@@ -76,11 +135,15 @@ def load_stage_inputs(reads: str, quals: str, bci: str):
     return rows, lens, q, bc, mx
 
 
-def compute_mspedges(args: dict, out_dir: str, device: int = 0, bc_start: int = 0) -> str:
+def compute_mspedges(args, out_dir: str, device: int = 0, bc_start: int | None = None) -> str:
     """Unitigs of the stage inputs on the GPU -> <out_dir>/asm_graph.bv (what _ASM_SN.asm_graph would have supplied)."""
     import ctypes as C
     from . import graphio, lib as _lib
-    rows, lens, q, bc, mx = load_stage_inputs(args["reads"], args["quals"], args["bci"])
+    reads = _get(args, "reads")
+    rows, lens, q, bc, mx = load_stage_inputs(reads, _get(args, "quals"), _get(args, "bci"))
+    if bc_start is None:
+        bc_start = bc_start_of(reads[:-len(".fastb")])
+    gp = graph_params_of(args)
     lib = _lib.load()
     h = C.c_void_p()
     err = C.create_string_buffer(512)
@@ -94,7 +157,8 @@ def compute_mspedges(args: dict, out_dir: str, device: int = 0, bc_start: int = 
         r.rows, r.lens, r.quals, r.bc = rows.ctypes.data, lens.ctypes.data, q.ctypes.data, bc.ctypes.data
         r.ign_bc_below = bc_start                      # "barcoded datatypes start at" (RunStages.cc:398, DF.cc:358-363)
         p = _lib.SnkParams()
-        p.K, p.min_qual, p.min_freq, p.min_bc = 48, 7, 3, 2     # CS-build constants, 10X/DF.cc:138-141
+        p.K, p.min_qual, p.min_freq, p.min_bc = gp["K"], gp["MIN_QUAL"], gp["MIN_FREQ"], gp["MIN_BC"]
+        p.flags = 16                                   # SNK_F_NO_TABLE: the hand-off is the unitigs
         out = _lib.SnkResult()
         rc = lib.snk_count_graph(h, C.byref(r), C.byref(p), C.byref(out), err, 512)
         if rc:
@@ -112,16 +176,18 @@ def compute_mspedges(args: dict, out_dir: str, device: int = 0, bc_start: int = 
     return path
 
 
-def main(args: dict, outs: dict, run_df: bool = True):
-    h1 = check_exclude(args["reads"], ".fastb")
-    h2 = check_exclude(args["quals"], ".qualp")
-    h3 = check_exclude(args["bci"], ".bci")
+def main(args, outs, run_df: bool = True):
+    print("__threads=", _get(args, "__threads"))
+    print("__mem_gb=", _get(args, "__mem_gb"))
+    h1 = check_exclude(_get(args, "reads"), ".fastb")
+    h2 = check_exclude(_get(args, "quals"), ".qualp")
+    h3 = check_exclude(_get(args, "bci"), ".bci")
     if h1 != h2 or h2 != h3:
         raise Exception("something wrong with filenames passed in")
-    out_dir = outs["default"]
-    mspedges = args.get("mspedges")
+    out_dir = _get(outs, "default")
+    mspedges = _get(args, "mspedges")
     if mspedges is None:
-        mspedges = compute_mspedges(args, out_dir)
+        mspedges = compute_mspedges(args, out_dir, device=int(os.environ.get("SNK_DEVICE", "0")))
     cmd = build_df_command(args, out_dir, mspedges)
     print(" ".join(cmd))
     if run_df:
