@@ -163,10 +163,13 @@ def main():
         kv = resv.keys().astype(np.uint64)
         mixed = (kv[:, 0] * np.uint64(0x9E3779B97F4A7C15) + kv[:, 1] * np.uint64(0xC2B2AE3D27D4EB4F) + kv[:, 2] * np.uint64(0x165667B19E3779F9)
                  + resv.counts().astype(np.uint64) * np.uint64(0x27D4EB2F165667C5) + resv.ctx().astype(np.uint64) * np.uint64(0x85EBCA77C2B2AE63))
-        uv = resv.unitigs() if rank == 0 else None       # fetched now: the next call on this engine recycles the result buffers
+        # every rank wrote the unitigs whose head fragment it owns: their union is compared as an order-independent sum of
+        # 64-bit hashes (fetched now: the next call on this engine recycles the result buffers)
+        uh = sum(int.from_bytes(hashlib.sha256(u.encode()).digest()[:8], "little") for u in resv.unitigs()) & 0xFFFFFFFFFFFFFFFF
+        nu_loc = int(resv.n_unitigs)
         # exact 64-bit multiset checksum over an int64 transport: the two 32-bit halves are reduced separately
         msum = int(mixed.sum(dtype=np.uint64))
-        loc = torch.tensor([int(kv.shape[0]), msum & 0xFFFFFFFF, msum >> 32], dtype=torch.int64, device="cuda")
+        loc = torch.tensor([int(kv.shape[0]), msum & 0xFFFFFFFF, msum >> 32, nu_loc, uh & 0xFFFFFFFF, uh >> 32], dtype=torch.int64, device="cuda")
         if world > 1:
             dist.all_reduce(loc)
         if rank == 0:
@@ -177,8 +180,9 @@ def main():
                   + ref.counts().astype(np.uint64) * np.uint64(0x27D4EB2F165667C5) + ref.ctx().astype(np.uint64) * np.uint64(0x85EBCA77C2B2AE63))
             got = (int(loc[1]) + (int(loc[2]) << 32)) & 0xFFFFFFFFFFFFFFFF
             same_table = int(loc[0]) == kr.shape[0] and got == int(mr.sum(dtype=np.uint64))
-            h = lambda us: hashlib.sha256("\n".join(us).encode()).hexdigest()
-            same_unitigs = h(uv) == h(ref.unitigs())
+            ur = ref.unitigs()
+            uhr = sum(int.from_bytes(hashlib.sha256(u.encode()).digest()[:8], "little") for u in ur) & 0xFFFFFFFFFFFFFFFF
+            same_unitigs = int(loc[3]) == len(ur) and ((int(loc[4]) + (int(loc[5]) << 32)) & 0xFFFFFFFFFFFFFFFF) == uhr
             verified = bool(same_table and same_unitigs)
             del ra, qa, ba, ref
         del rv, qv, bv, resv

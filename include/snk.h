@@ -239,6 +239,20 @@ int snk_shard_join(snk_ctx* ctx, uint32_t K, uint64_t n_frags, const void* d_nk,
 int snk_shard_join_linked(snk_ctx* ctx, uint32_t K, uint64_t n_frags, const void* d_nk, const void* d_hl_self, const void* d_hl_nb,
                           void* d_flink, const void* d_boff, const void* d_bases, uint64_t total_bases, snk_shard_unitigs* out,
                           void* stream, char* err, size_t errcap);
+/* Owner-side join (replaces the rank-0 funnel of tada's MAIN_ASM_SN, lib/tada/src/cmd_main_asm.rs:25-89,184-193; its
+ * build_edges is lib/tada/src/debruijn.rs:733-776): every rank all-gathers the LINKS (u32[2F] global end ids from
+ * snk_shard_links_apply) and k-mer counts (u32[F]) of all fragments, ranks the lists, places its own fragments and sends each
+ * to the rank that owns its unitig's head fragment, which writes the unitig.  d_frag_off: u64[world+1] fragments in front of
+ * every rank.  snk_shard_place -> fragments / base bytes this rank owes every owner; snk_shard_route_fill writes the 32-byte
+ * headers and the bases grouped by owner at the given offsets (two all-to-alls follow); snk_shard_emit turns what arrived
+ * (d_hdr_seg / d_base_seg: first header / first base byte of every source rank, u64[world+1]) into this rank's unitigs. */
+int snk_shard_place(snk_ctx* ctx, uint32_t K, uint64_t n_frags_total, const void* d_nk_all, void* d_flink_all, const void* d_frag_off,
+                    uint64_t my_frag_off, uint64_t* h_frags_to /* [world] */, uint64_t* h_bases_to /* [world] */, void* stream, char* err,
+                    size_t errcap);
+int snk_shard_route_fill(snk_ctx* ctx, uint32_t K, const void* d_frag_off, const void* d_hdr_off, const void* d_base_off, void* d_hdr, void* d_bases,
+                         void* stream, char* err, size_t errcap);
+int snk_shard_emit(snk_ctx* ctx, uint32_t K, uint64_t n_recv, const void* d_hdr, const void* d_hdr_seg, const void* d_base_seg, const void* d_bases,
+                   snk_shard_unitigs* out, void* stream, char* err, size_t errcap);
 /* fragment bases on the wire (the gather to rank 0): 2 bits per base, 16 bases per 32-bit word, base j at bits 2j --
  * the .bv byte packing (lib/tada/src/debruijn.rs:895-929).  snk_pack2_bytes(n) = size of the packed buffer. */
 uint64_t snk_pack2_bytes(uint64_t n_bases);

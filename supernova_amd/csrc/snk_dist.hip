@@ -32,6 +32,13 @@ struct snk_shard_state {
     const unsigned long long* d_node_off = nullptr;
     unsigned long long my_node_off = 0, my_end_base = 0;
     unsigned long long *lq_count = nullptr, *lq_cursor = nullptr;
+    // owner-side join: placement of this rank's fragments, destination rank of each, route cursors
+    snk_placement pl{};
+    uint32_t* dest = nullptr;
+    unsigned long long *rt_count = nullptr, *rt_cursor = nullptr;      // [2][world]: fragments, base bytes
+    unsigned long long my_frag_off = 0;
+    uint64_t n_frags_total = 0;
+    uint32_t join_circles = 0, join_rounds = 0;
     snk_phase_timer* tm = nullptr;
 };
 
@@ -261,6 +268,163 @@ extern "C" int snk_shard_join_linked(snk_ctx* ctx, uint32_t K, uint64_t n_frags,
     return SNK_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Owner-side join (no rank-0 funnel).  tada's MAIN_ASM_SN is one process (lib/tada/src/cmd_main_asm.rs:25-89,184-193) and so
+// was the first version of this path: every fragment travelled to rank 0, which ranked and wrote all unitigs -- serial in
+// the size of the job.  Now the only thing every rank sees of the whole job is the LINK structure (8 + 4 bytes per fragment,
+// all-gathered): it ranks the fragment lists, places its own fragments (unitig = the smaller terminal state, offset,
+// strand) and sends each fragment's bases to the rank that owns the unitig's head fragment, which writes the unitig.
+//   snk_shard_place       links + k-mer counts of all ranks -> placement of my fragments, fragments / bases per owner
+//   snk_shard_route_fill  32-byte headers + bases grouped by owner (the two send buffers of one all-to-all each)
+//   snk_shard_emit        headers + bases received -> this rank's unitigs (canonical, circles rotated, ordered)
+namespace {
+constexpr unsigned long long RT_RC = 1ull, RT_CIRC = 2ull, RT_HEAD = 4ull;
+__device__ __forceinline__ uint32_t owner_of_frag(const unsigned long long* __restrict__ frag_off, uint32_t world, unsigned long long g) {
+    uint32_t r = 0;
+    while (r + 1 < world && g >= frag_off[r + 1]) ++r;
+    return r;
+}
+// FILL = false: count fragments and base bytes per owner; true: write header and bases at reserved positions.
+// header (4 x u64): pid | gfid << 32;  nk | flags << 32;  koff (heads: N);  offset of the bases inside the owner's segment
+template <bool FILL>
+__global__ void __launch_bounds__(256) route_kernel(uint64_t Fl, unsigned long long f0, const uint32_t* __restrict__ nk, const uint32_t* __restrict__ pl_pid,
+                                                    const unsigned long long* __restrict__ pl_koff, const unsigned long long* __restrict__ pl_N,
+                                                    const uint8_t* __restrict__ pl_circ, const unsigned long long* __restrict__ frag_off, uint32_t world,
+                                                    uint32_t K, const uint64_t* __restrict__ boff, const uint8_t* __restrict__ bases,
+                                                    unsigned long long* __restrict__ cnt_or_cur /* [2][world] */, unsigned long long* __restrict__ hdr,
+                                                    uint8_t* __restrict__ bout, const unsigned long long* __restrict__ base_seg /* [world] byte offset of every owner's segment */) {
+    const uint64_t f = (uint64_t)blockIdx.x * 32 + (threadIdx.x >> 3);       // 8 lanes per fragment (the copy)
+    if (f >= Fl) return;
+    const uint32_t sub = threadIdx.x & 7u;
+    const uint32_t pid = pl_pid[f];
+    const uint32_t owner = owner_of_frag(frag_off, world, pid >> 1);
+    const uint64_t len = (uint64_t)nk[f] + K - 1;
+    if (!FILL) {
+        if (sub == 0) { atomicAdd(&cnt_or_cur[owner], 1ull); atomicAdd(&cnt_or_cur[world + owner], (unsigned long long)len); }
+        return;
+    }
+    unsigned long long slot = 0, bo = 0;
+    if (sub == 0) { slot = atomicAdd(&cnt_or_cur[owner], 1ull); bo = atomicAdd(&cnt_or_cur[world + owner], (unsigned long long)len); }
+    slot = __shfl(slot, (threadIdx.x & 63) & ~7u);
+    bo = __shfl(bo, (threadIdx.x & 63) & ~7u);
+    if (sub == 0) {
+        const unsigned long long ko = pl_koff[f];
+        const unsigned long long g = f0 + f;
+        const bool head = (ko & ~(1ull << 63)) == 0 && (pid >> 1) == (uint32_t)g;
+        const unsigned long long flags = ((ko >> 63) ? RT_RC : 0ull) | (pl_circ[f] ? RT_CIRC : 0ull) | (head ? RT_HEAD : 0ull);
+        hdr[4 * slot + 0] = (unsigned long long)pid | (g << 32);
+        hdr[4 * slot + 1] = (unsigned long long)nk[f] | (flags << 32);
+        hdr[4 * slot + 2] = head ? pl_N[f] : (ko & ~(1ull << 63));
+        hdr[4 * slot + 3] = bo - base_seg[owner];
+    }
+    const uint8_t* src = bases + boff[f];
+    uint8_t* dst = bout + bo;
+    for (uint64_t q = sub; q < len; q += 8) dst[q] = src[q];
+}
+// received headers -> the arrays snk_join_emit wants; hdr_seg / base_seg: first header / first base byte of every source rank
+__global__ void __launch_bounds__(256) unroute_kernel(const unsigned long long* __restrict__ hdr, uint64_t F, const unsigned long long* __restrict__ hdr_seg,
+                                                      const unsigned long long* __restrict__ base_seg, uint32_t world, uint32_t* __restrict__ nk,
+                                                      uint32_t* __restrict__ gfid, uint32_t* __restrict__ pid, unsigned long long* __restrict__ koff,
+                                                      unsigned long long* __restrict__ N, uint8_t* __restrict__ circ, uint64_t* __restrict__ boff) {
+    const uint64_t f = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (f >= F) return;
+    uint32_t src = 0;
+    while (src + 1 < world && f >= hdr_seg[src + 1]) ++src;
+    const unsigned long long w0 = hdr[4 * f], w1 = hdr[4 * f + 1], w2 = hdr[4 * f + 2], w3 = hdr[4 * f + 3];
+    const unsigned long long flags = w1 >> 32;
+    pid[f] = (uint32_t)w0;
+    gfid[f] = (uint32_t)(w0 >> 32);
+    nk[f] = (uint32_t)w1;
+    const bool head = flags & RT_HEAD;
+    koff[f] = (head ? 0ull : w2) | ((flags & RT_RC) ? (1ull << 63) : 0ull);
+    N[f] = head ? w2 : 0ull;
+    circ[f] = (flags & RT_CIRC) ? 1 : 0;
+    boff[f] = base_seg[src] + w3;
+}
+}  // namespace
+
+extern "C" int snk_shard_place(snk_ctx* ctx, uint32_t K, uint64_t n_frags_total, const void* d_nk_all, void* d_flink_all, const void* d_frag_off,
+                               uint64_t my_frag_off, uint64_t* h_frags_to /* [world] */, uint64_t* h_bases_to /* [world] */, void* stream, char* err,
+                               size_t errcap) {
+    if (!ctx || !ctx->shard || !d_frag_off || !h_frags_to || !h_bases_to) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_place: NULL argument / no session");
+    snk_shard_state* S = state_of(ctx);
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    const uint64_t Fl = S->frags.n_frags;
+    if (2 * n_frags_total >= (1ull << 32)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "more than 2^31 fragments in the job");
+    S->my_frag_off = my_frag_off;
+    S->n_frags_total = n_frags_total;
+    const uint2* rk = nullptr;
+    uint8_t* circ = nullptr;
+    int rc = snk_join_rank(ctx, st, n_frags_total, (const uint32_t*)d_nk_all, (uint32_t*)d_flink_all, &rk, &circ, &S->join_circles, &S->join_rounds, err, errcap);
+    if (rc) return rc;
+    if ((rc = snk_join_place(ctx, st, rk, (const uint32_t*)d_nk_all, circ, my_frag_off, Fl, &S->pl, err, errcap))) return rc;
+    void* q;
+    if ((rc = snk_ctx_alloc(ctx, 2ull * (S->world + 1) * 8, &q, err, errcap))) return rc; S->rt_count = (unsigned long long*)q;
+    if ((rc = snk_ctx_alloc(ctx, 2ull * (S->world + 1) * 8, &q, err, errcap))) return rc; S->rt_cursor = (unsigned long long*)q;
+    SNK_HIP_TRY(hipMemsetAsync(S->rt_count, 0, 2ull * (S->world + 1) * 8, st));
+    if (Fl) hipLaunchKernelGGL((route_kernel<false>), dim3((unsigned)((Fl + 31) / 32)), dim3(256), 0, st, Fl, (unsigned long long)my_frag_off, S->frags.nk, S->pl.pid, S->pl.koff,
+                               S->pl.N, S->pl.circ, (const unsigned long long*)d_frag_off, S->world, K, S->frags.boff, S->frags.bases, S->rt_count, nullptr, nullptr, nullptr);
+    SNK_HIP_TRY(hipGetLastError());
+    std::vector<unsigned long long> h(2 * S->world);
+    SNK_HIP_TRY(hipMemcpyAsync(h.data(), S->rt_count, 2ull * S->world * 8, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    for (uint32_t r = 0; r < S->world; ++r) { h_frags_to[r] = h[r]; h_bases_to[r] = h[S->world + r]; }
+    return SNK_OK;
+}
+
+extern "C" int snk_shard_route_fill(snk_ctx* ctx, uint32_t K, const void* d_frag_off, const void* d_hdr_off /* u64[world]: first header of every owner */,
+                                    const void* d_base_off /* u64[world]: first base byte of every owner */, void* d_hdr, void* d_bases, void* stream,
+                                    char* err, size_t errcap) {
+    if (!ctx || !ctx->shard || !d_frag_off || !d_hdr_off || !d_base_off) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_route_fill: NULL argument / no session");
+    snk_shard_state* S = state_of(ctx);
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    const uint64_t Fl = S->frags.n_frags;
+    SNK_HIP_TRY(hipMemcpyAsync(S->rt_cursor, d_hdr_off, S->world * 8ull, hipMemcpyDeviceToDevice, st));
+    SNK_HIP_TRY(hipMemcpyAsync(S->rt_cursor + S->world, d_base_off, S->world * 8ull, hipMemcpyDeviceToDevice, st));
+    if (Fl) hipLaunchKernelGGL((route_kernel<true>), dim3((unsigned)((Fl + 31) / 32)), dim3(256), 0, st, Fl, (unsigned long long)S->my_frag_off, S->frags.nk, S->pl.pid, S->pl.koff,
+                               S->pl.N, S->pl.circ, (const unsigned long long*)d_frag_off, S->world, K, S->frags.boff, S->frags.bases, S->rt_cursor,
+                               (unsigned long long*)d_hdr, (uint8_t*)d_bases, (const unsigned long long*)d_base_off);
+    SNK_HIP_TRY(hipGetLastError());
+    return SNK_OK;
+}
+
+extern "C" int snk_shard_emit(snk_ctx* ctx, uint32_t K, uint64_t n_recv, const void* d_hdr, const void* d_hdr_seg /* u64[world+1] */,
+                              const void* d_base_seg /* u64[world+1] */, const void* d_bases, snk_shard_unitigs* out, void* stream, char* err, size_t errcap) {
+    if (!ctx || !ctx->shard || !out) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_emit: NULL argument / no session");
+    if (K != 48 && K != 60) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "K=%u is not supported (48 or 60)", K);
+    snk_shard_state* S = state_of(ctx);
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    uint32_t *nk, *gfid, *pid;
+    unsigned long long *koff, *N;
+    uint8_t* circ;
+    uint64_t* boff;
+    void* q;
+    int rc;
+    if ((rc = snk_ctx_alloc(ctx, (n_recv + 1) * 4, &q, err, errcap))) return rc; nk = (uint32_t*)q;
+    if ((rc = snk_ctx_alloc(ctx, (n_recv + 1) * 4, &q, err, errcap))) return rc; gfid = (uint32_t*)q;
+    if ((rc = snk_ctx_alloc(ctx, (n_recv + 1) * 4, &q, err, errcap))) return rc; pid = (uint32_t*)q;
+    if ((rc = snk_ctx_alloc(ctx, (n_recv + 1) * 8, &q, err, errcap))) return rc; koff = (unsigned long long*)q;
+    if ((rc = snk_ctx_alloc(ctx, (n_recv + 1) * 8, &q, err, errcap))) return rc; N = (unsigned long long*)q;
+    if ((rc = snk_ctx_alloc(ctx, (n_recv + 1), &q, err, errcap))) return rc; circ = (uint8_t*)q;
+    if ((rc = snk_ctx_alloc(ctx, (n_recv + 2) * 8, &q, err, errcap))) return rc; boff = (uint64_t*)q;
+    if (n_recv) hipLaunchKernelGGL(unroute_kernel, dim3((unsigned)((n_recv + 255) / 256)), dim3(256), 0, st, (const unsigned long long*)d_hdr, n_recv,
+                                   (const unsigned long long*)d_hdr_seg, (const unsigned long long*)d_base_seg, S->world, nk, gfid, pid, koff, N, circ, boff);
+    SNK_HIP_TRY(hipGetLastError());
+    snk_join_out jo;
+    // every pid received here is a terminal state of one of this rank's own fragments
+    rc = snk_join_emit(ctx, st, K, n_recv, nk, gfid, pid, koff, N, circ, (uint32_t)(2 * S->my_frag_off), 2 * S->frags.n_frags, boff, (const uint8_t*)d_bases,
+                       nullptr, &jo, err, errcap);
+    if (rc) return rc;
+    out->n_unitigs = jo.n_unitigs;
+    out->total_bases = jo.total_bases;
+    out->unitig_off = jo.unitig_off;
+    out->unitig_bases = jo.unitig_bases;
+    out->unitig_circular = jo.unitig_circular;
+    out->n_circles = S->join_circles;
+    out->rank_rounds = S->join_rounds;
+    return SNK_OK;
+}
 
 // ---- fragment bases on the wire: 2 bits per base (the gather to rank 0 is the only place where bases cross xGMI)
 namespace {

@@ -58,6 +58,20 @@ struct snk_join_out {
     uint32_t* unitig_group;     // grouped runs (fgroup given): group of every unitig; unitigs ordered by (group, first K bases)
     uint32_t n_circles, rank_rounds, n_circles_rotated;
 };
+// placement of fragments inside their unitigs (snk_graph.hip: jplace_kernel), device arrays
+struct snk_placement {
+    uint32_t* pid;               // terminal state that names the unitig
+    unsigned long long* koff;    // k-mers in front of the fragment | 1 << 63: read from its right end
+    unsigned long long* N;       // k-mers of the whole unitig
+    uint8_t* circ;               // the unitig is a circle that was cut at an arbitrary fragment
+};
+int snk_join_rank(snk_ctx* ctx, hipStream_t st, uint64_t F, const uint32_t* nk, uint32_t* flink, const uint2** rk_out, uint8_t** circ_out,
+                  uint32_t* n_circles, uint32_t* rounds, char* err, size_t errcap);
+int snk_join_place(snk_ctx* ctx, hipStream_t st, const uint2* rk, const uint32_t* nk, const uint8_t* circ, uint64_t f0, uint64_t Fl,
+                   snk_placement* pl, char* err, size_t errcap);
+int snk_join_emit(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const uint32_t* nk, const uint32_t* gfid, const uint32_t* pl_pid,
+                  const unsigned long long* pl_koff, const unsigned long long* pl_N, const uint8_t* pl_circ, uint32_t pid_base, uint64_t n_pid,
+                  const uint64_t* boff, const uint8_t* fbases, const uint32_t* fgroup, snk_join_out* out, char* err, size_t errcap);
 int snk_dist_answer(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, const void* d_queries, uint64_t nq, void* d_ans, char* err,
                     size_t errcap);
 int snk_dist_apply(snk_ctx* ctx, hipStream_t st, snk_dist_graph* g, const void* d_qbuf, const void* d_ans, uint64_t nq,

@@ -869,28 +869,47 @@ __device__ __forceinline__ frag_place frag_place_of(const uint2* rk, const uint3
     else { p.pid = tR; p.other = tL; p.koff = dR; p.rc = true; }
     return p;
 }
-__global__ void __launch_bounds__(TB) jhead_kernel(const uint2* __restrict__ rk,
-                                                   const uint32_t* __restrict__ nk, uint64_t F, uint32_t K,
+// Placement of the fragments [f0, f0 + Fl) of a ranked fragment list: the unitig a fragment belongs to is named by the
+// smaller of its two terminal states (pid), koff = k-mers in front of it when the unitig is read from that end, rc = it
+// is read from its right end.  The fragment whose own left/right state IS pid (koff == 0) heads the unitig; N = k-mers of
+// the whole unitig.  Everything the emission needs -- the ranking itself stays behind (sharded runs rank the job's whole
+// fragment list and place only their own fragments).
+constexpr unsigned long long PL_RC = 1ull << 63;
+__global__ void __launch_bounds__(TB) jplace_kernel(const uint2* __restrict__ rk, const uint32_t* __restrict__ nk, const uint8_t* __restrict__ circ,
+                                                    uint64_t f0, uint64_t Fl, uint32_t* __restrict__ pl_pid, unsigned long long* __restrict__ pl_koff,
+                                                    unsigned long long* __restrict__ pl_N, uint8_t* __restrict__ pl_circ) {
+    const uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (i >= Fl) return;
+    const frag_place p = frag_place_of(rk, nk, f0 + i);
+    pl_pid[i] = p.pid;
+    pl_koff[i] = p.koff | (p.rc ? PL_RC : 0ull);
+    pl_N[i] = p.N;
+    pl_circ[i] = circ[p.pid];
+}
+// gfid: global id of every fragment (NULL: fragment f is f); a head is the fragment that owns its unitig's terminal state
+__global__ void __launch_bounds__(TB) jhead_kernel(const uint32_t* __restrict__ pl_pid, const unsigned long long* __restrict__ pl_koff,
+                                                   const unsigned long long* __restrict__ pl_N, const uint32_t* __restrict__ gfid, uint64_t F, uint32_t K,
                                                    uint32_t* __restrict__ hflag, uint64_t* __restrict__ hlen) {
     uint64_t f = (uint64_t)blockIdx.x * TB + threadIdx.x;
     if (f >= F) return;
-    frag_place p = frag_place_of(rk, nk, f);
-    bool head = p.koff == 0 && (p.pid >> 1) == (uint32_t)f;
+    const uint32_t me = gfid ? gfid[f] : (uint32_t)f;
+    bool head = (pl_koff[f] & ~PL_RC) == 0 && (pl_pid[f] >> 1) == me;
     hflag[f] = head ? 1u : 0u;
-    hlen[f] = head ? p.N + K - 1 : 0ull;
+    hlen[f] = head ? pl_N[f] + K - 1 : 0ull;
 }
-__global__ void __launch_bounds__(TB) jhead_place_kernel(const uint2* __restrict__ rk, const uint32_t* __restrict__ hflag,
+// poff is indexed by (pid - pid_base): the terminal states of this rank's own fragments (every unitig is emitted by the
+// rank that owns its head fragment)
+__global__ void __launch_bounds__(TB) jhead_place_kernel(const uint32_t* __restrict__ pl_pid, const uint8_t* __restrict__ pl_circ,
+                                                         const uint32_t* __restrict__ hflag,
                                                          const uint32_t* __restrict__ hidx, const uint64_t* __restrict__ hoff,
-                                                         const uint8_t* __restrict__ circ, uint64_t F, uint64_t* __restrict__ poff,
+                                                         uint64_t F, uint32_t pid_base, uint64_t* __restrict__ poff,
                                                          uint64_t* __restrict__ uoff, uint8_t* __restrict__ ucirc,
                                                          const uint32_t* __restrict__ fgroup, uint32_t* __restrict__ ugroup) {
     uint64_t f = (uint64_t)blockIdx.x * TB + threadIdx.x;
     if (f >= F || !hflag[f]) return;
-    uint32_t tL = rk[2 * f].y, tR = rk[2 * f + 1].y;
-    uint32_t pid = tL < tR ? tL : tR;
-    poff[pid] = hoff[f];
+    poff[pl_pid[f] - pid_base] = hoff[f];
     uoff[hidx[f]] = hoff[f];
-    ucirc[hidx[f]] = circ[pid];
+    ucirc[hidx[f]] = pl_circ[f];
     if (fgroup) ugroup[hidx[f]] = fgroup[f];
 }
 // number of 256-base chunks of every fragment (work items of the copy kernel)
@@ -907,17 +926,17 @@ __global__ void __launch_bounds__(TB) jchunk_owner_kernel(const uint32_t* __rest
 // provisional unitig sequences: every fragment copies all of its bases (the K-1 overlaps write equal values).
 // Fragments are short (K-1 + ~17 bases): 8 lanes per fragment, 32 fragments per workgroup, no per-chunk owner tables.
 __global__ void __launch_bounds__(256) jemit_kernel(uint64_t F, const uint64_t* __restrict__ boff, const uint8_t* __restrict__ fbases,
-                                                    const uint2* __restrict__ rk,
-                                                    const uint32_t* __restrict__ nk, const uint64_t* __restrict__ poff,
+                                                    const uint32_t* __restrict__ pl_pid, const unsigned long long* __restrict__ pl_koff,
+                                                    const uint32_t* __restrict__ nk, const uint64_t* __restrict__ poff, uint32_t pid_base,
                                                     uint32_t K, uint8_t* __restrict__ prov) {
     const uint64_t f = (uint64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
     if (f >= F) return;
     const uint32_t sub = threadIdx.x & 7u;
     const uint64_t len = (uint64_t)nk[f] + K - 1;
-    const frag_place p = frag_place_of(rk, nk, f);
+    const unsigned long long ko = pl_koff[f];
     const uint8_t* src = fbases + boff[f];
-    uint8_t* dst = prov + poff[p.pid] + p.koff;
-    if (!p.rc) for (uint64_t q = sub; q < len; q += 8) dst[q] = src[q];
+    uint8_t* dst = prov + poff[pl_pid[f] - pid_base] + (ko & ~PL_RC);
+    if (!(ko & PL_RC)) for (uint64_t q = sub; q < len; q += 8) dst[q] = src[q];
     else for (uint64_t q = sub; q < len; q += 8) dst[len - 1 - q] = (uint8_t)(src[q] ^ 3u);
 }
 // canonical form of every unitig (dna/CanonicalForm.h:35-48) decided on the provisional sequence
@@ -1108,11 +1127,7 @@ int snk_dist_join(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
                   snk_join_out* out, char* err, size_t errcap, const uint32_t* fgroup, const uint32_t* sfrag, uint64_t n_states,
                   uint32_t* flink_given) {
     memset(out, 0, sizeof *out);
-    if (F == 0) {
-        G_ALLOC(out->unitig_off, uint64_t, 1);
-        SNK_HIP_TRY(hipMemsetAsync(out->unitig_off, 0, 8, st));
-        return SNK_OK;
-    }
+    if (F == 0) return snk_join_emit(ctx, st, K, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, out, err, errcap);
     if (F >= (1ull << 31)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "more than 2^31 fragments at the join (%llu)", (unsigned long long)F);
     const uint64_t ne = 2 * F;
     uint32_t* flink = flink_given;          // sharded runs: the links were decided on the owners (jlink_* kernels)
@@ -1138,6 +1153,54 @@ int snk_dist_join(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
     const uint2* rk;
     int rc = rank_lists(ctx, st, flink, F, nk, circ, &rk, &out->n_circles, &out->rank_rounds, err, errcap);
     if (rc) return rc;
+    snk_placement pl;
+    if ((rc = snk_join_place(ctx, st, rk, nk, circ, 0, F, &pl, err, errcap))) return rc;
+    const uint32_t nc = out->n_circles, rr = out->rank_rounds;
+    if ((rc = snk_join_emit(ctx, st, K, F, nk, nullptr, pl.pid, pl.koff, pl.N, pl.circ, 0, ne, boff, fbases, fgroup, out, err, errcap))) return rc;
+    out->n_circles = nc;
+    out->rank_rounds = rr;
+    return SNK_OK;
+}
+
+// ranking of a whole fragment list (sharded runs: every rank holds the job's links and k-mer counts) -- rk[2F], circ[2F]
+int snk_join_rank(snk_ctx* ctx, hipStream_t st, uint64_t F, const uint32_t* nk, uint32_t* flink, const uint2** rk_out, uint8_t** circ_out,
+                  uint32_t* n_circles, uint32_t* rounds, char* err, size_t errcap) {
+    if (F >= (1ull << 31)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "more than 2^31 fragments at the join (%llu)", (unsigned long long)F);
+    uint8_t* circ;
+    G_ALLOC(circ, uint8_t, 2 * F + 1);
+    SNK_HIP_TRY(hipMemsetAsync(circ, 0, 2 * F + 1, st));
+    *circ_out = circ;
+    *n_circles = 0;
+    *rounds = 0;
+    if (F == 0) { *rk_out = nullptr; return SNK_OK; }
+    return rank_lists(ctx, st, flink, F, nk, circ, rk_out, n_circles, rounds, err, errcap);
+}
+
+int snk_join_place(snk_ctx* ctx, hipStream_t st, const uint2* rk, const uint32_t* nk, const uint8_t* circ, uint64_t f0, uint64_t Fl,
+                   snk_placement* pl, char* err, size_t errcap) {
+    memset(pl, 0, sizeof *pl);
+    G_ALLOC(pl->pid, uint32_t, Fl + 1);
+    G_ALLOC(pl->koff, unsigned long long, Fl + 1);
+    G_ALLOC(pl->N, unsigned long long, Fl + 1);
+    G_ALLOC(pl->circ, uint8_t, Fl + 1);
+    if (Fl) hipLaunchKernelGGL(jplace_kernel, dim3(nblk(Fl)), dim3(TB), 0, st, rk, nk, circ, f0, Fl, pl->pid, pl->koff, pl->N, pl->circ);
+    SNK_HIP_TRY(hipGetLastError());
+    return SNK_OK;
+}
+
+// Emission of the unitigs whose head fragment is among the F fragments given (one-GPU runs: all of them; sharded runs:
+// the fragments routed to this rank, the owner of their unitig's head): heads -> offsets, every fragment copied into
+// place, circles rotated to the reference's cut, canonical orientation, deterministic order.
+int snk_join_emit(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const uint32_t* nk, const uint32_t* gfid, const uint32_t* pl_pid,
+                  const unsigned long long* pl_koff, const unsigned long long* pl_N, const uint8_t* pl_circ, uint32_t pid_base, uint64_t n_pid,
+                  const uint64_t* boff, const uint8_t* fbases, const uint32_t* fgroup, snk_join_out* out, char* err, size_t errcap) {
+    memset(out, 0, sizeof *out);
+    if (F == 0) {
+        G_ALLOC(out->unitig_off, uint64_t, 1);
+        SNK_HIP_TRY(hipMemsetAsync(out->unitig_off, 0, 8, st));
+        return SNK_OK;
+    }
+    int rc;
     uint32_t *hflag, *hidx;
     uint64_t *hlen, *hoff;
     G_ALLOC(hflag, uint32_t, F + 1);
@@ -1146,7 +1209,7 @@ int snk_dist_join(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
     G_ALLOC(hoff, uint64_t, F + 1);
     SNK_HIP_TRY(hipMemsetAsync(hflag + F, 0, 4, st));
     SNK_HIP_TRY(hipMemsetAsync(hlen + F, 0, 8, st));
-    hipLaunchKernelGGL(jhead_kernel, dim3(nblk(F)), dim3(TB), 0, st, rk, nk, F, K, hflag, hlen);
+    hipLaunchKernelGGL(jhead_kernel, dim3(nblk(F)), dim3(TB), 0, st, pl_pid, pl_koff, pl_N, gfid, F, K, hflag, hlen);
     if ((rc = excl_scan<uint32_t>(ctx, st, hflag, hidx, F + 1, err, errcap))) return rc;
     if ((rc = excl_scan<uint64_t>(ctx, st, hlen, hoff, F + 1, err, errcap))) return rc;
     uint32_t h_nu = 0;
@@ -1157,7 +1220,7 @@ int snk_dist_join(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
     const uint64_t U = h_nu;
     uint64_t *poff, *uoff;
     uint8_t *ucirc, *prov, *final_bases, *urev;
-    G_ALLOC(poff, uint64_t, ne);
+    G_ALLOC(poff, uint64_t, n_pid + 1);
     G_ALLOC(uoff, uint64_t, U + 1);
     G_ALLOC(ucirc, uint8_t, U + 1);
     G_ALLOC(urev, uint8_t, U + 1);
@@ -1165,10 +1228,10 @@ int snk_dist_join(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
     if (fgroup) G_ALLOC(ugroup, uint32_t, U + 1);
     G_ALLOC(prov, uint8_t, h_tot + 1);
     G_ALLOC(final_bases, uint8_t, h_tot + 1);
-    hipLaunchKernelGGL(jhead_place_kernel, dim3(nblk(F)), dim3(TB), 0, st, rk, hflag, hidx, hoff, circ, F, poff, uoff, ucirc, fgroup, ugroup);
+    hipLaunchKernelGGL(jhead_place_kernel, dim3(nblk(F)), dim3(TB), 0, st, pl_pid, pl_circ, hflag, hidx, hoff, F, pid_base, poff, uoff, ucirc, fgroup, ugroup);
     SNK_HIP_TRY(hipMemcpyAsync(uoff + U, hoff + F, 8, hipMemcpyDeviceToDevice, st));
     // copy every fragment into place
-    hipLaunchKernelGGL(jemit_kernel, dim3((unsigned)((F + 31) / 32)), dim3(256), 0, st, F, boff, fbases, rk, nk, poff, K, prov);
+    hipLaunchKernelGGL(jemit_kernel, dim3((unsigned)((F + 31) / 32)), dim3(256), 0, st, F, boff, fbases, pl_pid, pl_koff, nk, poff, pid_base, K, prov);
     // circles that were cut at an arbitrary fragment boundary: rotate to the reference's cut (minimum k-mer, forward)
     {
         uint32_t *clist, *ccnt;

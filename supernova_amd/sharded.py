@@ -126,6 +126,40 @@ class TorchComm:
             works.append(wr)
         return works
 
+    def all_gather_v(self, send: torch.Tensor, counts: list[int], alloc=None) -> torch.Tensor:
+        """send: 1-D uint8 of counts[me] bytes; returns the concatenation of every rank's buffer in rank order (counts = bytes
+        per rank, known to everybody).  Built from the same grouped point-to-point pieces as the all-to-all."""
+        W, me = self.world, self.rank
+        total = sum(counts)
+        out = alloc(total) if alloc else torch.empty(total, dtype=torch.uint8, device=send.device)
+        off = [0] * (W + 1)
+        for p in range(W):
+            off[p + 1] = off[p] + int(counts[p])
+        if counts[me]:
+            out[off[me]:off[me + 1]].copy_(send[:counts[me]])
+        for width, dt in ((8, torch.int64), (4, torch.int32), (1, torch.uint8)):
+            if all(c % width == 0 for c in counts) and send.data_ptr() % width == 0 and out.data_ptr() % width == 0:
+                break
+        s_v, o_v = send[:counts[me]].view(dt), out.view(dt)
+        ch = max(1, self.CHUNK_BYTES // width)
+        n_me = counts[me] // width
+        n_rounds = max([0] + [-(-(int(c) // width) // ch) for c in counts])
+        for j in range(n_rounds):
+            ops = []
+            c0 = j * ch
+            for p in range(W):
+                if p == me:
+                    continue
+                if c0 < n_me:
+                    ops.append(self.dist.P2POp(self.dist.isend, s_v[c0:min(c0 + ch, n_me)], p))
+                n_p = counts[p] // width
+                if c0 < n_p:
+                    ops.append(self.dist.P2POp(self.dist.irecv, o_v[off[p] // width + c0: off[p] // width + min(c0 + ch, n_p)], p))
+            if ops:
+                for r in self.dist.batch_isend_irecv(ops):
+                    r.wait()
+        return out
+
     def all_to_all_equal(self, send: torch.Tensor) -> torch.Tensor:
         """send: [world, m] -> recv [world, m]; row p goes to rank p."""
         recv = torch.empty_like(send)
@@ -220,6 +254,15 @@ class SimComm:
         self._begin_section()
         return [[] for _ in range(n_ranges)]
 
+    def all_gather_v(self, send, counts, alloc=None):
+        torch.cuda.synchronize()
+        allv = self._exchange(send[:counts[self.rank]])
+        out = torch.cat(list(allv)) if allv else send[:0]
+        torch.cuda.synchronize()
+        self.w.barrier_obj.wait()
+        self._begin_section()
+        return out
+
     def all_to_all_equal(self, send):
         m = send.shape[1]
         recv, _ = self.all_to_all_v(send.contiguous().view(-1).view(torch.uint8),
@@ -255,6 +298,27 @@ def segment_offsets(hist_recv: torch.Tensor, recv_record_counts: list[int]) -> t
     if w > 1:
         base[1:] = torch.cumsum(torch.tensor(recv_record_counts[:-1], dtype=torch.int64, device=hist_recv.device), 0)
     return (seg + base[:, None]).contiguous()
+
+
+def route_offsets(frags_to: list[int], bases_to: list[int]):
+    """Owner-side join, sender: fragments / base bytes owed to every owner -> (first header per owner [W+1], first base byte per
+    owner [W+1], padded base bytes per owner): every owner's bases start 16-byte aligned in the send buffer."""
+    bpad = [-(-int(b) // 16) * 16 for b in bases_to]
+    hoff, boff = [0], [0]
+    for f, b in zip(frags_to, bpad):
+        hoff.append(hoff[-1] + int(f))
+        boff.append(boff[-1] + b)
+    return hoff, boff, bpad
+
+
+def recv_segments(hdr_bytes: list[int], base_bytes: list[int]):
+    """Owner-side join, receiver: bytes that arrived from every source -> (first header per source [W+1], first base byte per
+    source [W+1]); a header's base offset is relative to its source's segment."""
+    hseg, bseg = [0], [0]
+    for h, b in zip(hdr_bytes, base_bytes):
+        hseg.append(hseg[-1] + int(h) // 32)
+        bseg.append(bseg[-1] + int(b))
+    return hseg, bseg
 
 
 COMP = np.array([3, 2, 1, 0], dtype=np.uint8)
@@ -321,8 +385,11 @@ class ShardedResult:
         return self._dl(self.frags.spectrum, nb * 8, np.uint64, (nb,))
 
     def unitigs(self) -> list[str]:
-        """rank 0 only: canonical unitigs of the whole data set, sorted by BVComp."""
+        """Canonical unitigs this rank wrote, sorted by BVComp: with the owner-side join every rank holds the unitigs whose
+        head fragment it owns (their union over the ranks is the data set's unitig set); with join="rank0" rank 0 holds all."""
         u = self.joined
+        if u is None:
+            return []
         off = self._dl(u.unitig_off, (u.n_unitigs + 1) * 8, np.uint64, (u.n_unitigs + 1,))
         bases = self._dl(u.unitig_bases, u.total_bases, np.uint8, (u.total_bases,))
         lut = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -350,10 +417,14 @@ class _BufferPool:
 
 
 class ShardedEngine:
-    def __init__(self, engine: Engine, dist_or_comm):
+    def __init__(self, engine: Engine, dist_or_comm, join: str | None = None):
+        """join = "owner" (default): every rank writes the unitigs whose head fragment it owns -- no rank holds the whole job;
+        "rank0": the first version, every fragment travels to rank 0 (tada's single-process MAIN_ASM_SN); SNK_JOIN overrides."""
         self.eng = engine
         self.comm = dist_or_comm if hasattr(dist_or_comm, "all_to_all_v") else TorchComm(dist_or_comm)
         self.pool = None
+        self.join = join or os.environ.get("SNK_JOIN", "owner")
+        assert self.join in ("owner", "rank0")
 
     def count_graph(self, rows, read_len, quals=None, bc=None, lens=None, good_len=None, params: Params | None = None,
                     ign_bc_below: int = 0, read_index_base: int = 0) -> ShardedResult:
@@ -516,58 +587,87 @@ class ShardedEngine:
         flink_p = C.c_void_p()
         chk(lib.snk_shard_links_apply(e._ctx, lqbuf.data_ptr(), lans_back.data_ptr(), nlq, C.byref(flink_p), st, err, 512))
         res.n_link_queries = nlq
-        # ---- gather on rank 0: k-mers per fragment, links, starts, bases
-        to0 = lambda n: [n if q == 0 else 0 for q in range(W)]
-        TB = int(fr.total_bases)
-        t_nk, _ = comm.all_to_all_v(dcopy("s_nk", fr.nk, F * 4), to0(F * 4), alloc=lambda nb: pool.get("g_nk", nb))
-        t_link, _ = comm.all_to_all_v(dcopy("s_link", flink_p.value, F * 8), to0(F * 8), alloc=lambda nb: pool.get("g_link", nb))
-        t_start, start_bytes = comm.all_to_all_v(dcopy("s_start", fr.boff, F * 8), to0(F * 8), alloc=lambda nb: pool.get("g_start", nb))
-        if W == 1:
-            t_bases, base_bytes = comm.all_to_all_v(dcopy("s_bases", fr.bases, TB), to0(TB), alloc=lambda nb: pool.get("g_bases", nb))
-        else:
-            # the bases are the bulk of the gather (1 byte per k-mer + 47 per fragment): they cross xGMI at 2 bits each
-            all_TB = comm.all_gather_int(TB, dev)
-            pb = int(lib.snk_pack2_bytes(TB))
-            t_pk = pool.get("s_bases2", max(pb, 8))
-            if TB:
-                chk(lib.snk_dev_pack2(e._ctx, fr.bases, TB, t_pk.data_ptr(), st))
-                torch.cuda.current_stream().synchronize()
-            t_pk_all, pk_bytes = comm.all_to_all_v(t_pk[:pb], to0(pb), alloc=lambda nb: pool.get("g_bases2", nb))
-            base_bytes = [0] * W
-            t_bases = t_pk_all[:0]
-            if me == 0:
-                base_bytes = [((x + 15) // 16) * 16 for x in all_TB]          # every rank's bases start 16-byte aligned
-                t_bases = pool.get("g_bases", max(sum(base_bytes), 16))[:sum(base_bytes)]
-                a = b = 0
-                for q in range(W):
-                    if all_TB[q]:
-                        chk(lib.snk_dev_unpack2(e._ctx, t_pk_all.data_ptr() + a, all_TB[q], t_bases.data_ptr() + b, st))
-                    a += pk_bytes[q]
-                    b += base_bytes[q]
-        res.joined = None
-        res.n_unitigs = 0
-        if me == 0:
-            Ft = t_nk.numel() // 4
-            # fragment starts are offsets into their rank's base buffer: shift by the buffers in front
-            # (in place, one slice per source rank: torch.repeat_interleave over the fragments took 6.8 ms per 17.5 M)
-            starts_all = t_start.view(torch.int64)
-            a, shift = 0, 0
-            for q in range(W):
-                nq = start_bytes[q] // 8
-                if shift and nq:
-                    starts_all[a:a + nq] += shift
-                a += nq
-                shift += base_bytes[q]
-            if starts_all.numel() == 0:
-                starts_all = torch.zeros(1, dtype=torch.int64, device=dev)
-            if t_link.numel() == 0:
-                t_link = torch.zeros(8, dtype=torch.uint8, device=dev)
+        if self.join == "owner":
+            # ---- owner-side join: every rank sees the job's LINK structure only (12 bytes per fragment), ranks the fragment
+            # lists, places its own fragments and sends each to the rank that owns its unitig's head, which writes the unitig
+            Ft = frag_off[-1]
+            nk_all = comm.all_gather_v(dcopy("s_nk", fr.nk, F * 4), [x * 4 for x in all_F], alloc=lambda nb: pool.get("g_nk", max(nb, 8))[:nb])
+            fl_all = comm.all_gather_v(dcopy("s_link", flink_p.value, F * 8), [x * 8 for x in all_F], alloc=lambda nb: pool.get("g_link", max(nb, 8))[:nb])
+            d_frag_off = torch.tensor(frag_off, dtype=torch.int64, device=dev)
+            fto, bto = (C.c_uint64 * W)(), (C.c_uint64 * W)()
+            chk(lib.snk_shard_place(e._ctx, K, Ft, nk_all.data_ptr(), fl_all.data_ptr(), d_frag_off.data_ptr(), frag_off[me], fto, bto, st, err, 512))
+            fto, bto = [int(x) for x in fto], [int(x) for x in bto]
+            hoff, boff_, bpad = route_offsets(fto, bto)
+            d_hoff = torch.tensor(hoff[:W], dtype=torch.int64, device=dev)
+            d_boff = torch.tensor(boff_[:W], dtype=torch.int64, device=dev)
+            hdr = pool.get("s_hdr", max(hoff[-1], 1) * 32)
+            sb = pool.get("s_bases", max(boff_[-1], 16))
+            chk(lib.snk_shard_route_fill(e._ctx, K, d_frag_off.data_ptr(), d_hoff.data_ptr(), d_boff.data_ptr(), hdr.data_ptr(), sb.data_ptr(), st, err, 512))
+            torch.cuda.current_stream().synchronize()
+            hdr_in, hdr_bytes = comm.all_to_all_v(hdr[: hoff[-1] * 32], [c * 32 for c in fto], alloc=lambda nb: pool.get("g_hdr", max(nb, 8))[:nb])
+            b_in, b_bytes = comm.all_to_all_v(sb[: boff_[-1]], bpad, alloc=lambda nb: pool.get("g_bases", max(nb, 16))[:nb])
+            hseg, bseg = recv_segments(hdr_bytes, b_bytes)
+            d_hseg = torch.tensor(hseg, dtype=torch.int64, device=dev)
+            d_bseg = torch.tensor(bseg, dtype=torch.int64, device=dev)
             un = _lib.SnkShardUnitigs()
-            chk(lib.snk_shard_join_linked(e._ctx, K, Ft, t_nk.data_ptr(), None, None, t_link.data_ptr(), starts_all.data_ptr(),
-                                          t_bases.data_ptr(), t_bases.numel(), C.byref(un), st, err, 512))
+            chk(lib.snk_shard_emit(e._ctx, K, hseg[-1], hdr_in.data_ptr(), d_hseg.data_ptr(), d_bseg.data_ptr(), b_in.data_ptr(), C.byref(un), st, err, 512))
             res.joined = un
             res.n_unitigs = int(un.n_unitigs)
-            res._keep = (t_nk, t_link, starts_all, t_bases)
+            res.exchange_bytes_join = (Ft * 12, hoff[-1] * 32 + boff_[-1])
+            res._keep = (nk_all, fl_all, hdr_in, b_in, d_hseg, d_bseg, d_frag_off)
+        else:
+            # ---- gather on rank 0: k-mers per fragment, links, starts, bases
+            to0 = lambda n: [n if q == 0 else 0 for q in range(W)]
+            TB = int(fr.total_bases)
+            t_nk, _ = comm.all_to_all_v(dcopy("s_nk", fr.nk, F * 4), to0(F * 4), alloc=lambda nb: pool.get("g_nk", nb))
+            t_link, _ = comm.all_to_all_v(dcopy("s_link", flink_p.value, F * 8), to0(F * 8), alloc=lambda nb: pool.get("g_link", nb))
+            t_start, start_bytes = comm.all_to_all_v(dcopy("s_start", fr.boff, F * 8), to0(F * 8), alloc=lambda nb: pool.get("g_start", nb))
+            if W == 1:
+                t_bases, base_bytes = comm.all_to_all_v(dcopy("s_bases", fr.bases, TB), to0(TB), alloc=lambda nb: pool.get("g_bases", nb))
+            else:
+                # the bases are the bulk of the gather (1 byte per k-mer + 47 per fragment): they cross xGMI at 2 bits each
+                all_TB = comm.all_gather_int(TB, dev)
+                pb = int(lib.snk_pack2_bytes(TB))
+                t_pk = pool.get("s_bases2", max(pb, 8))
+                if TB:
+                    chk(lib.snk_dev_pack2(e._ctx, fr.bases, TB, t_pk.data_ptr(), st))
+                    torch.cuda.current_stream().synchronize()
+                t_pk_all, pk_bytes = comm.all_to_all_v(t_pk[:pb], to0(pb), alloc=lambda nb: pool.get("g_bases2", nb))
+                base_bytes = [0] * W
+                t_bases = t_pk_all[:0]
+                if me == 0:
+                    base_bytes = [((x + 15) // 16) * 16 for x in all_TB]          # every rank's bases start 16-byte aligned
+                    t_bases = pool.get("g_bases", max(sum(base_bytes), 16))[:sum(base_bytes)]
+                    a = b = 0
+                    for q in range(W):
+                        if all_TB[q]:
+                            chk(lib.snk_dev_unpack2(e._ctx, t_pk_all.data_ptr() + a, all_TB[q], t_bases.data_ptr() + b, st))
+                        a += pk_bytes[q]
+                        b += base_bytes[q]
+            res.joined = None
+            res.n_unitigs = 0
+            if me == 0:
+                Ft = t_nk.numel() // 4
+                # fragment starts are offsets into their rank's base buffer: shift by the buffers in front
+                # (in place, one slice per source rank: torch.repeat_interleave over the fragments took 6.8 ms per 17.5 M)
+                starts_all = t_start.view(torch.int64)
+                a, shift = 0, 0
+                for q in range(W):
+                    nq = start_bytes[q] // 8
+                    if shift and nq:
+                        starts_all[a:a + nq] += shift
+                    a += nq
+                    shift += base_bytes[q]
+                if starts_all.numel() == 0:
+                    starts_all = torch.zeros(1, dtype=torch.int64, device=dev)
+                if t_link.numel() == 0:
+                    t_link = torch.zeros(8, dtype=torch.uint8, device=dev)
+                un = _lib.SnkShardUnitigs()
+                chk(lib.snk_shard_join_linked(e._ctx, K, Ft, t_nk.data_ptr(), None, None, t_link.data_ptr(), starts_all.data_ptr(),
+                                              t_bases.data_ptr(), t_bases.numel(), C.byref(un), st, err, 512))
+                res.joined = un
+                res.n_unitigs = int(un.n_unitigs)
+                res._keep = (t_nk, t_link, starts_all, t_bases)
         ev[7].record()
         torch.cuda.synchronize()
         names = ["partition", "compact", "exchange", "count", "prune", "fragments", "join"]

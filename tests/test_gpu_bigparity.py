@@ -84,7 +84,7 @@ def test_simulated_ranks_vs_reference_digest(snk, name, W):
             res = sh.count_graph(rows, sp.read_len, quals=quals, bc=bc if K == 48 else None, params=Params(K=K),
                                  read_index_base=lo)
             out[r] = dict(keys=res.keys(), counts=res.counts(), ctx=res.ctx(), spectrum=res.spectrum().astype(np.int64),
-                          unitigs=res.unitigs() if r == 0 else None)
+                          unitigs=res.unitigs())
             e.close()
         except BaseException as ex:  # noqa: BLE001
             errs.append(ex)
@@ -107,6 +107,6 @@ def test_simulated_ranks_vs_reference_digest(snk, name, W):
         hist = sum(np.pad(o["spectrum"], (0, nb - len(o["spectrum"]))) for o in out)
     else:
         hist = np.bincount(np.minimum(counts, (1 << 24) - 1)).astype(np.int64)
-    dg = bighash.digest(np.zeros(n, np.uint32), keys, counts, ctx, out[0]["unitigs"], hist, kw=3 if K == 48 else 4)
+    dg = bighash.digest(np.zeros(n, np.uint32), keys, counts, ctx, [u for o in out for u in o["unitigs"]], hist, kw=3 if K == 48 else 4)
     _compare(dg, exp, fields=tuple(f for f in FIELDS if f != "goodlens"))
     torch.cuda.empty_cache()

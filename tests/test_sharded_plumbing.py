@@ -135,6 +135,48 @@ def _worker(rank, world, port, q):
                 blk = g2[int(seg2[s, b]):int(seg2[s, b + 1])]
                 ok &= blk.shape[0] == hr[s, b] and bool(np.all(blk[:, 0] == s)) and bool(np.all(blk[:, 1] == rank)) and bool(np.all(blk[:, 2] == b))
                 ok &= list(blk[:, 3]) == list(range(blk.shape[0]))
+    # ---- owner-side join plumbing: the links of every rank are all-gathered (ragged sizes, many pieces) ...
+    from supernova_amd.sharded import recv_segments, route_offsets
+    sizes = [8 * (3000 + 977 * r) for r in range(world)]
+    mine = (torch.arange(sizes[rank] // 8, dtype=torch.int64) * 7 + rank).view(torch.uint8)
+    allg = comm.all_gather_v(mine, sizes)
+    a = 0
+    for r in range(world):
+        ok &= bool(torch.equal(allg[a:a + sizes[r]].view(torch.int64), torch.arange(sizes[r] // 8, dtype=torch.int64) * 7 + r))
+        a += sizes[r]
+    # ... and every fragment travels to the owner of its unitig: 32-byte headers and the bases in two all-to-alls, a header's
+    # base offset relative to its source's (16-byte aligned) segment -- the arithmetic of ShardedEngine, modelled with numpy
+    rs = np.random.default_rng(900 + rank)
+    nf = 500 + 37 * rank
+    owner = rs.integers(0, world, nf)
+    flen = rs.integers(48, 130, nf)
+    fto = [int((owner == p).sum()) for p in range(world)]
+    bto = [int(flen[owner == p].sum()) for p in range(world)]
+    hoff, boff, bpad = route_offsets(fto, bto)
+    hdr = np.zeros((hoff[-1], 4), dtype=np.int64)
+    sb = np.zeros(boff[-1], dtype=np.uint8)
+    hc, bcur = list(hoff[:world]), list(boff[:world])
+    for f in range(nf):
+        p = int(owner[f])
+        hdr[hc[p]] = (rank, f, flen[f], bcur[p] - boff[p])
+        sb[bcur[p]:bcur[p] + flen[f]] = (np.arange(flen[f]) * 3 + f + 11 * rank) & 0xFF
+        hc[p] += 1
+        bcur[p] += int(flen[f])
+    hin, hb = comm.all_to_all_v(torch.from_numpy(hdr).view(torch.uint8).view(-1), [c * 32 for c in fto])
+    bin_, bb = comm.all_to_all_v(torch.from_numpy(sb), bpad)
+    hseg, bseg = recv_segments(hb, bb)
+    H = hin.view(torch.int64).view(-1, 4).numpy()
+    B = bin_.numpy()
+    for src in range(world):
+        src_rng = np.random.default_rng(900 + src)
+        nfs = 500 + 37 * src
+        o2 = src_rng.integers(0, world, nfs)
+        ok &= hseg[src + 1] - hseg[src] == int((o2 == rank).sum())
+        for i in range(hseg[src], hseg[src + 1]):
+            s_, f_, ln, bo = (int(x) for x in H[i])
+            ok &= s_ == src and o2[f_] == rank
+            got_b = B[bseg[src] + bo: bseg[src] + bo + ln]
+            ok &= bool(np.array_equal(got_b, ((np.arange(ln) * 3 + f_ + 11 * src) & 0xFF).astype(np.uint8)))
     q.put((rank, ok, int(got.shape[0])))
     dist.destroy_process_group()
 

@@ -140,7 +140,7 @@ for case in range(n_cases):
             rr = sh.count_graph(rows[lo:hi].contiguous(), L, quals=dq[lo:hi].contiguous(), bc=None if dbc is None else dbc[lo:hi].contiguous(),
                                 lens=dl[lo:hi].contiguous(), params=Params(K=K, min_freq=min_freq, min_bc=min_bc, n_buckets=(nb // W + 1) * W if nb else 0),
                                 read_index_base=lo)
-            out[q] = (rr.keys(), rr.counts(), rr.ctx(), rr.unitigs() if q == 0 else None); e.close()
+            out[q] = (rr.keys(), rr.counts(), rr.ctx(), rr.unitigs()); e.close()
         except BaseException as ex:
             errs.append(ex); world.barrier_obj.abort()
     ts = [threading.Thread(target=worker, args=(q,)) for q in range(W)]
@@ -150,6 +150,7 @@ for case in range(n_cases):
     else:
         keys = np.concatenate([x[0] for x in out]); cnt = np.concatenate([x[1] for x in out]); ctx = np.concatenate([x[2] for x in out])
         order = np.lexsort((keys[:, 3], keys[:, 2], keys[:, 1], keys[:, 0]))
+        out[0] = out[0][:3] + (sorted((u for x in out for u in x[3]), key=lambda s: (-len(s), s)),)      # every rank wrote the unitigs it owns
         if not same(keys[order], cnt[order], ctx[order], out[0][3], o):
             ok = False; print("MISMATCH sharded W=%d" % W, tag, flush=True)
             k2, c2, x2 = keys[order], cnt[order], ctx[order]
