@@ -249,6 +249,18 @@ int snk_shard_join_linked(snk_ctx* ctx, uint32_t K, uint64_t n_frags, const void
 int snk_shard_place(snk_ctx* ctx, uint32_t K, uint64_t n_frags_total, const void* d_nk_all, void* d_flink_all, const void* d_frag_off,
                     uint64_t my_frag_off, uint64_t* h_frags_to /* [world] */, uint64_t* h_bases_to /* [world] */, void* stream, char* err,
                     size_t errcap);
+/* The ranking itself partitioned over the ranks (a rank walks 1/world of the splitters of the ruling-set scheme; only the
+ * streaming set-up and the short splitter list are replicated): snk_shard_prank_begin -> all-gather of *d_w1_share (16 B per
+ * splitter, shares [m*r/world, m*(r+1)/world)) -> snk_shard_prank_walk (*circles = 1: some list is a circle, rank the
+ * replicated way with snk_shard_place; else records owed to every owner) -> snk_shard_prank_route -> all-to-all (16 B per
+ * state) -> snk_shard_place_ranked (same outputs as snk_shard_place). */
+int snk_shard_prank_begin(snk_ctx* ctx, uint64_t n_frags_total, const void* d_nk_all, void* d_flink_all, uint64_t my_frag_off,
+                          uint64_t* n_splitters, const void** d_w1_share, void* stream, char* err, size_t errcap);
+int snk_shard_prank_walk(snk_ctx* ctx, const void* d_w1_all, const void* d_frag_off, uint64_t* h_recs_to /* [world] */, uint32_t* circles,
+                         void* stream, char* err, size_t errcap);
+int snk_shard_prank_route(snk_ctx* ctx, const void* d_frag_off, const void* d_rec_off, void* d_out, void* stream, char* err, size_t errcap);
+int snk_shard_place_ranked(snk_ctx* ctx, uint32_t K, const void* d_recs, uint64_t n_recs, const void* d_frag_off, uint64_t* h_frags_to,
+                           uint64_t* h_bases_to, void* stream, char* err, size_t errcap);
 int snk_shard_route_fill(snk_ctx* ctx, uint32_t K, const void* d_frag_off, const void* d_hdr_off, const void* d_base_off, void* d_hdr, void* d_bases,
                          void* stream, char* err, size_t errcap);
 int snk_shard_emit(snk_ctx* ctx, uint32_t K, uint64_t n_recv, const void* d_hdr, const void* d_hdr_seg, const void* d_base_seg, const void* d_bases,

@@ -39,6 +39,8 @@ struct snk_shard_state {
     unsigned long long my_frag_off = 0;
     uint64_t n_frags_total = 0;
     uint32_t join_circles = 0, join_rounds = 0;
+    snk_prank pr{};
+    const uint32_t* nk_all = nullptr;
     snk_phase_timer* tm = nullptr;
 };
 
@@ -286,7 +288,10 @@ __device__ __forceinline__ uint32_t owner_of_frag(const unsigned long long* __re
     return r;
 }
 // FILL = false: count fragments and base bytes per owner; true: write header and bases at reserved positions.
-// header (4 x u64): pid | gfid << 32;  nk | flags << 32;  koff (heads: N);  offset of the bases inside the owner's segment
+// header (4 x u64): pid | gfid << 32;  nk | flags << 32;  koff (heads: N);  offset of the bases inside the owner's segment.
+// One fragment per thread for the bookkeeping: the workgroup adds up its fragments and bytes per owner in LDS and goes to
+// the `world` device counters once per owner (2 M fragments on the same few addresses, one device atomic each, took 100 ms);
+// then the bases are copied by 8 lanes per fragment.
 template <bool FILL>
 __global__ void __launch_bounds__(256) route_kernel(uint64_t Fl, unsigned long long f0, const uint32_t* __restrict__ nk, const uint32_t* __restrict__ pl_pid,
                                                     const unsigned long long* __restrict__ pl_koff, const unsigned long long* __restrict__ pl_N,
@@ -294,21 +299,37 @@ __global__ void __launch_bounds__(256) route_kernel(uint64_t Fl, unsigned long l
                                                     uint32_t K, const uint64_t* __restrict__ boff, const uint8_t* __restrict__ bases,
                                                     unsigned long long* __restrict__ cnt_or_cur /* [2][world] */, unsigned long long* __restrict__ hdr,
                                                     uint8_t* __restrict__ bout, const unsigned long long* __restrict__ base_seg /* [world] byte offset of every owner's segment */) {
-    const uint64_t f = (uint64_t)blockIdx.x * 32 + (threadIdx.x >> 3);       // 8 lanes per fragment (the copy)
-    if (f >= Fl) return;
-    const uint32_t sub = threadIdx.x & 7u;
-    const uint32_t pid = pl_pid[f];
-    const uint32_t owner = owner_of_frag(frag_off, world, pid >> 1);
-    const uint64_t len = (uint64_t)nk[f] + K - 1;
-    if (!FILL) {
-        if (sub == 0) { atomicAdd(&cnt_or_cur[owner], 1ull); atomicAdd(&cnt_or_cur[world + owner], (unsigned long long)len); }
-        return;
+    extern __shared__ unsigned long long dynr[];          // [world] fragments -> reserved first header, [world] bytes -> reserved first byte
+    __shared__ unsigned long long c_src[256], c_dst[256];
+    __shared__ uint32_t c_len[256];
+    unsigned long long* lfr = dynr;
+    unsigned long long* lby = dynr + world;
+    for (uint32_t r = threadIdx.x; r < 2 * world; r += 256) dynr[r] = 0;
+    __syncthreads();
+    const uint64_t f = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t pid = 0, owner = 0;
+    uint64_t len = 0;
+    unsigned long long lslot = 0, lbo = 0;
+    if (f < Fl) {
+        pid = pl_pid[f];
+        owner = owner_of_frag(frag_off, world, pid >> 1);
+        len = (uint64_t)nk[f] + K - 1;
+        lslot = atomicAdd(&lfr[owner], 1ull);
+        lbo = atomicAdd(&lby[owner], (unsigned long long)len);
     }
-    unsigned long long slot = 0, bo = 0;
-    if (sub == 0) { slot = atomicAdd(&cnt_or_cur[owner], 1ull); bo = atomicAdd(&cnt_or_cur[world + owner], (unsigned long long)len); }
-    slot = __shfl(slot, (threadIdx.x & 63) & ~7u);
-    bo = __shfl(bo, (threadIdx.x & 63) & ~7u);
-    if (sub == 0) {
+    __syncthreads();
+    for (uint32_t r = threadIdx.x; r < world; r += 256) {
+        const unsigned long long cf = lfr[r], cb = lby[r];
+        if (cf) {
+            const unsigned long long a = atomicAdd(&cnt_or_cur[r], cf), b = atomicAdd(&cnt_or_cur[world + r], cb);
+            lfr[r] = a; lby[r] = b;
+        }
+    }
+    if (!FILL) return;
+    __syncthreads();
+    c_len[threadIdx.x] = 0;
+    if (f < Fl) {
+        const unsigned long long slot = lfr[owner] + lslot, bo = lby[owner] + lbo;
         const unsigned long long ko = pl_koff[f];
         const unsigned long long g = f0 + f;
         const bool head = (ko & ~(1ull << 63)) == 0 && (pid >> 1) == (uint32_t)g;
@@ -317,10 +338,18 @@ __global__ void __launch_bounds__(256) route_kernel(uint64_t Fl, unsigned long l
         hdr[4 * slot + 1] = (unsigned long long)nk[f] | (flags << 32);
         hdr[4 * slot + 2] = head ? pl_N[f] : (ko & ~(1ull << 63));
         hdr[4 * slot + 3] = bo - base_seg[owner];
+        c_src[threadIdx.x] = boff[f];
+        c_dst[threadIdx.x] = bo;
+        c_len[threadIdx.x] = (uint32_t)len;
     }
-    const uint8_t* src = bases + boff[f];
-    uint8_t* dst = bout + bo;
-    for (uint64_t q = sub; q < len; q += 8) dst[q] = src[q];
+    __syncthreads();
+    const uint32_t sub = threadIdx.x & 7u;
+    for (uint32_t i = threadIdx.x >> 3; i < 256; i += 32) {
+        const uint32_t n = c_len[i];
+        const uint8_t* src = bases + c_src[i];
+        uint8_t* dst = bout + c_dst[i];
+        for (uint32_t q = sub; q < n; q += 8) dst[q] = src[q];
+    }
 }
 // received headers -> the arrays snk_join_emit wants; hdr_seg / base_seg: first header / first base byte of every source rank
 __global__ void __launch_bounds__(256) unroute_kernel(const unsigned long long* __restrict__ hdr, uint64_t F, const unsigned long long* __restrict__ hdr_seg,
@@ -344,26 +373,18 @@ __global__ void __launch_bounds__(256) unroute_kernel(const unsigned long long* 
 }
 }  // namespace
 
-extern "C" int snk_shard_place(snk_ctx* ctx, uint32_t K, uint64_t n_frags_total, const void* d_nk_all, void* d_flink_all, const void* d_frag_off,
-                               uint64_t my_frag_off, uint64_t* h_frags_to /* [world] */, uint64_t* h_bases_to /* [world] */, void* stream, char* err,
-                               size_t errcap) {
-    if (!ctx || !ctx->shard || !d_frag_off || !h_frags_to || !h_bases_to) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_place: NULL argument / no session");
-    snk_shard_state* S = state_of(ctx);
-    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+// placement of this rank's fragments from a ranking (whole list: rk_f0 = 0; own states only: rk_f0 = my_frag_off) and the
+// fragments / base bytes owed to every owner
+static int place_and_count(snk_ctx* ctx, snk_shard_state* S, hipStream_t st, uint32_t K, const uint2* rk, uint64_t rk_f0, const uint8_t* circ,
+                           const uint32_t* nk_all, const void* d_frag_off, uint64_t* h_frags_to, uint64_t* h_bases_to, char* err, size_t errcap) {
     const uint64_t Fl = S->frags.n_frags;
-    if (2 * n_frags_total >= (1ull << 32)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "more than 2^31 fragments in the job");
-    S->my_frag_off = my_frag_off;
-    S->n_frags_total = n_frags_total;
-    const uint2* rk = nullptr;
-    uint8_t* circ = nullptr;
-    int rc = snk_join_rank(ctx, st, n_frags_total, (const uint32_t*)d_nk_all, (uint32_t*)d_flink_all, &rk, &circ, &S->join_circles, &S->join_rounds, err, errcap);
-    if (rc) return rc;
-    if ((rc = snk_join_place(ctx, st, rk, (const uint32_t*)d_nk_all, circ, my_frag_off, Fl, &S->pl, err, errcap))) return rc;
+    int rc;
+    if ((rc = snk_join_place(ctx, st, rk, nk_all, circ, S->my_frag_off, Fl, &S->pl, err, errcap, rk_f0))) return rc;
     void* q;
     if ((rc = snk_ctx_alloc(ctx, 2ull * (S->world + 1) * 8, &q, err, errcap))) return rc; S->rt_count = (unsigned long long*)q;
     if ((rc = snk_ctx_alloc(ctx, 2ull * (S->world + 1) * 8, &q, err, errcap))) return rc; S->rt_cursor = (unsigned long long*)q;
     SNK_HIP_TRY(hipMemsetAsync(S->rt_count, 0, 2ull * (S->world + 1) * 8, st));
-    if (Fl) hipLaunchKernelGGL((route_kernel<false>), dim3((unsigned)((Fl + 31) / 32)), dim3(256), 0, st, Fl, (unsigned long long)my_frag_off, S->frags.nk, S->pl.pid, S->pl.koff,
+    if (Fl) hipLaunchKernelGGL((route_kernel<false>), dim3((unsigned)((Fl + 255) / 256)), dim3(256), 2ull * S->world * 8, st, Fl, (unsigned long long)S->my_frag_off, S->frags.nk, S->pl.pid, S->pl.koff,
                                S->pl.N, S->pl.circ, (const unsigned long long*)d_frag_off, S->world, K, S->frags.boff, S->frags.bases, S->rt_count, nullptr, nullptr, nullptr);
     SNK_HIP_TRY(hipGetLastError());
     std::vector<unsigned long long> h(2 * S->world);
@@ -371,6 +392,83 @@ extern "C" int snk_shard_place(snk_ctx* ctx, uint32_t K, uint64_t n_frags_total,
     SNK_HIP_TRY(hipStreamSynchronize(st));
     for (uint32_t r = 0; r < S->world; ++r) { h_frags_to[r] = h[r]; h_bases_to[r] = h[S->world + r]; }
     return SNK_OK;
+}
+
+extern "C" int snk_shard_place(snk_ctx* ctx, uint32_t K, uint64_t n_frags_total, const void* d_nk_all, void* d_flink_all, const void* d_frag_off,
+                               uint64_t my_frag_off, uint64_t* h_frags_to /* [world] */, uint64_t* h_bases_to /* [world] */, void* stream, char* err,
+                               size_t errcap) {
+    if (!ctx || !ctx->shard || !d_frag_off || !h_frags_to || !h_bases_to) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_place: NULL argument / no session");
+    snk_shard_state* S = state_of(ctx);
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    if (2 * n_frags_total >= (1ull << 32)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "more than 2^31 fragments in the job");
+    S->my_frag_off = my_frag_off;
+    S->n_frags_total = n_frags_total;
+    const uint2* rk = nullptr;
+    uint8_t* circ = nullptr;
+    int rc = snk_join_rank(ctx, st, n_frags_total, (const uint32_t*)d_nk_all, (uint32_t*)d_flink_all, &rk, &circ, &S->join_circles, &S->join_rounds, err, errcap);
+    if (rc) return rc;
+    return place_and_count(ctx, S, st, K, rk, 0, circ, (const uint32_t*)d_nk_all, d_frag_off, h_frags_to, h_bases_to, err, errcap);
+}
+
+// ---- the ranking partitioned over the ranks (snk_graph.hip: snk_prank_*): begin -> [all-gather of 16 B per splitter] -> walk ->
+// [all-to-all of 16 B per state] -> snk_shard_place_ranked.  *circles = 1 after the walk: a list is a circle, use snk_shard_place.
+extern "C" int snk_shard_prank_begin(snk_ctx* ctx, uint64_t n_frags_total, const void* d_nk_all, void* d_flink_all, uint64_t my_frag_off,
+                                     uint64_t* n_splitters, const void** d_w1_share, void* stream, char* err, size_t errcap) {
+    if (!ctx || !ctx->shard || !n_splitters || !d_w1_share) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_prank_begin: NULL argument / no session");
+    snk_shard_state* S = state_of(ctx);
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    if (2 * n_frags_total >= (1ull << 32)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "more than 2^31 fragments in the job");
+    S->my_frag_off = my_frag_off;
+    S->n_frags_total = n_frags_total;
+    S->nk_all = (const uint32_t*)d_nk_all;
+    int rc = snk_prank_begin(ctx, st, n_frags_total, (const uint32_t*)d_nk_all, (uint32_t*)d_flink_all, S->rank, S->world, &S->pr, err, errcap);
+    if (rc) return rc;
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    *n_splitters = S->pr.m;
+    *d_w1_share = S->pr.w1_share;
+    return SNK_OK;
+}
+extern "C" int snk_shard_prank_walk(snk_ctx* ctx, const void* d_w1_all, const void* d_frag_off, uint64_t* h_recs_to /* [world] */, uint32_t* circles,
+                                    void* stream, char* err, size_t errcap) {
+    if (!ctx || !ctx->shard || !h_recs_to || !circles) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_prank_walk: NULL argument / no session");
+    snk_shard_state* S = state_of(ctx);
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    S->join_circles = 0;
+    int rc = snk_prank_walk(ctx, st, &S->pr, (const uint4*)d_w1_all, circles, &S->join_rounds, err, errcap);
+    if (rc) return rc;
+    for (uint32_t r = 0; r < S->world; ++r) h_recs_to[r] = 0;
+    if (*circles) return SNK_OK;
+    void* q;
+    if ((rc = snk_ctx_alloc(ctx, (S->world + 1) * 8ull, &q, err, errcap))) return rc;
+    unsigned long long* cnt = (unsigned long long*)q;
+    SNK_HIP_TRY(hipMemsetAsync(cnt, 0, (S->world + 1) * 8ull, st));
+    if ((rc = snk_prank_route(ctx, st, &S->pr, false, (const unsigned long long*)d_frag_off, S->world, cnt, nullptr, err, errcap))) return rc;
+    std::vector<unsigned long long> h(S->world);
+    SNK_HIP_TRY(hipMemcpyAsync(h.data(), cnt, S->world * 8ull, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    for (uint32_t r = 0; r < S->world; ++r) h_recs_to[r] = h[r];
+    return SNK_OK;
+}
+extern "C" int snk_shard_prank_route(snk_ctx* ctx, const void* d_frag_off, const void* d_rec_off /* u64[world]: first record of every owner */, void* d_out,
+                                     void* stream, char* err, size_t errcap) {
+    if (!ctx || !ctx->shard || !d_rec_off) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_prank_route: NULL argument / no session");
+    snk_shard_state* S = state_of(ctx);
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    void* q;
+    int rc;
+    if ((rc = snk_ctx_alloc(ctx, (S->world + 1) * 8ull, &q, err, errcap))) return rc;
+    SNK_HIP_TRY(hipMemcpyAsync(q, d_rec_off, S->world * 8ull, hipMemcpyDeviceToDevice, st));
+    return snk_prank_route(ctx, st, &S->pr, true, (const unsigned long long*)d_frag_off, S->world, (unsigned long long*)q, d_out, err, errcap);
+}
+extern "C" int snk_shard_place_ranked(snk_ctx* ctx, uint32_t K, const void* d_recs, uint64_t n_recs, const void* d_frag_off, uint64_t* h_frags_to,
+                                      uint64_t* h_bases_to, void* stream, char* err, size_t errcap) {
+    if (!ctx || !ctx->shard || !d_frag_off || !h_frags_to || !h_bases_to) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_place_ranked: NULL argument / no session");
+    snk_shard_state* S = state_of(ctx);
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    const uint2* rk = nullptr;
+    int rc = snk_prank_apply(ctx, st, d_recs, n_recs, 2ull * S->my_frag_off, 2ull * S->frags.n_frags, &rk, err, errcap);
+    if (rc) return rc;
+    return place_and_count(ctx, S, st, K, rk, S->my_frag_off, nullptr, S->nk_all, d_frag_off, h_frags_to, h_bases_to, err, errcap);
 }
 
 extern "C" int snk_shard_route_fill(snk_ctx* ctx, uint32_t K, const void* d_frag_off, const void* d_hdr_off /* u64[world]: first header of every owner */,
@@ -382,7 +480,7 @@ extern "C" int snk_shard_route_fill(snk_ctx* ctx, uint32_t K, const void* d_frag
     const uint64_t Fl = S->frags.n_frags;
     SNK_HIP_TRY(hipMemcpyAsync(S->rt_cursor, d_hdr_off, S->world * 8ull, hipMemcpyDeviceToDevice, st));
     SNK_HIP_TRY(hipMemcpyAsync(S->rt_cursor + S->world, d_base_off, S->world * 8ull, hipMemcpyDeviceToDevice, st));
-    if (Fl) hipLaunchKernelGGL((route_kernel<true>), dim3((unsigned)((Fl + 31) / 32)), dim3(256), 0, st, Fl, (unsigned long long)S->my_frag_off, S->frags.nk, S->pl.pid, S->pl.koff,
+    if (Fl) hipLaunchKernelGGL((route_kernel<true>), dim3((unsigned)((Fl + 255) / 256)), dim3(256), 2ull * S->world * 8, st, Fl, (unsigned long long)S->my_frag_off, S->frags.nk, S->pl.pid, S->pl.koff,
                                S->pl.N, S->pl.circ, (const unsigned long long*)d_frag_off, S->world, K, S->frags.boff, S->frags.bases, S->rt_cursor,
                                (unsigned long long*)d_hdr, (uint8_t*)d_bases, (const unsigned long long*)d_base_off);
     SNK_HIP_TRY(hipGetLastError());

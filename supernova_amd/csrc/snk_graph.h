@@ -68,7 +68,24 @@ struct snk_placement {
 int snk_join_rank(snk_ctx* ctx, hipStream_t st, uint64_t F, const uint32_t* nk, uint32_t* flink, const uint2** rk_out, uint8_t** circ_out,
                   uint32_t* n_circles, uint32_t* rounds, char* err, size_t errcap);
 int snk_join_place(snk_ctx* ctx, hipStream_t st, const uint2* rk, const uint32_t* nk, const uint8_t* circ, uint64_t f0, uint64_t Fl,
-                   snk_placement* pl, char* err, size_t errcap);
+                   snk_placement* pl, char* err, size_t errcap, uint64_t rk_f0 = 0);
+// partitioned ranking of the job's fragment lists (sharded runs): replicated streaming setup, walks for a 1/world share
+struct snk_prank {
+    uint64_t ns, m, k0, k1, n_rec;
+    const uint32_t* w;
+    uint32_t* link;
+    unsigned long long* wrec;
+    uint32_t* spl_state;
+    uint4* w1_share;           // [k1-k0] first walk of this rank's splitters: next splitter, distance, tail, states
+    uint4* rec;                // [n_rec] second walk: state, distance, terminal, 0
+};
+int snk_prank_begin(snk_ctx* ctx, hipStream_t st, uint64_t F, const uint32_t* nk, uint32_t* link, uint32_t rank, uint32_t world, snk_prank* P, char* err,
+                    size_t errcap);
+int snk_prank_walk(snk_ctx* ctx, hipStream_t st, snk_prank* P, const uint4* w1_all, uint32_t* circles, uint32_t* rounds, char* err, size_t errcap);
+int snk_prank_route(snk_ctx* ctx, hipStream_t st, snk_prank* P, bool fill, const unsigned long long* d_frag_off, uint32_t world,
+                    unsigned long long* d_cnt_or_cur, void* d_out, char* err, size_t errcap);
+int snk_prank_apply(snk_ctx* ctx, hipStream_t st, const void* d_rec, uint64_t n, unsigned long long state_base, uint64_t n_local_states,
+                    const uint2** rk_out, char* err, size_t errcap);
 int snk_join_emit(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const uint32_t* nk, const uint32_t* gfid, const uint32_t* pl_pid,
                   const unsigned long long* pl_koff, const unsigned long long* pl_N, const uint8_t* pl_circ, uint32_t pid_base, uint64_t n_pid,
                   const uint64_t* boff, const uint8_t* fbases, const uint32_t* fgroup, snk_join_out* out, char* err, size_t errcap);

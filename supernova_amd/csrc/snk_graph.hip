@@ -594,6 +594,101 @@ static int rank_lists(snk_ctx* ctx, hipStream_t st, uint32_t* link, uint64_t n, 
     return SNK_OK;
 }
 
+namespace {
+// ---- partitioned ranking (sharded runs, owner-side join).  Every rank holds the job's whole link structure (all-gathered),
+// but ranking it in full on every rank would cost each of them what the rank-0 funnel cost one.  The ruling-set scheme
+// splits naturally: marking and packing are streaming passes (replicated, ~30 B per state); the two walks -- the random
+// access part -- are done for a 1/world share of the splitters per rank; what leaves a rank is 16 B per splitter after
+// walk 1 (all-gather) and 16 B per visited state after walk 2 (to the state's owner).  The splitter list itself (1/64 of
+// the states) is jumped on every rank.  Lists that are circles are not handled here: the caller falls back to the
+// replicated ranking (snk_join_rank) when it is told so -- the decision is the same on every rank because it is taken
+// from replicated data.
+__global__ void __launch_bounds__(TB) spl_walk1p_kernel(const unsigned long long* __restrict__ wrec, const uint32_t* __restrict__ spl_state,
+                                                        const uint32_t* __restrict__ w, uint64_t k0, uint64_t cnt, uint4* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (i >= cnt) return;
+    uint32_t cur = spl_state[k0 + i];
+    unsigned long long rec = wrec[cur];
+    uint32_t d = 0, nx = NONE, steps = 1;
+    for (;;) {
+        const uint32_t l = (uint32_t)rec;
+        if (l == NONE) { nx = NONE; break; }
+        cur = l ^ 1u;
+        rec = wrec[cur];
+        d += w[cur >> 1];
+        if (rec >> 63) { nx = (uint32_t)(rec >> 32) & 0x7FFFFFFFu; break; }
+        ++steps;
+    }
+    out[i] = make_uint4(nx, d, cur, steps);      // cur = the terminal state when nx == NONE
+}
+__global__ void __launch_bounds__(TB) prank_unzip_kernel(const uint4* __restrict__ all, uint64_t m, uint32_t* __restrict__ rn, uint32_t* __restrict__ rd,
+                                                         uint32_t* __restrict__ rt, unsigned long long* __restrict__ total_steps) {
+    const uint64_t k = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    unsigned long long st = 0;
+    if (k < m) { const uint4 v = all[k]; rn[k] = v.x; rd[k] = v.y; rt[k] = v.z; st = v.w; }
+    for (int o = 32; o > 0; o >>= 1) st += __shfl_xor(st, o);
+    if ((threadIdx.x & 63) == 0 && st) atomicAdd(total_steps, st);
+}
+__global__ void __launch_bounds__(TB) prank_steps_kernel(const uint4* __restrict__ all, uint64_t k0, uint64_t cnt, uint64_t* __restrict__ steps) {
+    const uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (i <= cnt) steps[i] = i < cnt ? all[k0 + i].w : 0ull;
+}
+// second walk of this rank's share: one 16-byte record (state, distance, terminal, 0) per visited state, at positions known
+// from the step counts of the first walk
+__global__ void __launch_bounds__(TB) spl_walk2p_kernel(const unsigned long long* __restrict__ wrec, const uint32_t* __restrict__ spl_state,
+                                                        const uint32_t* __restrict__ w, const uint32_t* __restrict__ rdist, const uint32_t* __restrict__ rtail,
+                                                        uint64_t k0, uint64_t cnt, const uint64_t* __restrict__ pos, uint4* __restrict__ rec_out) {
+    const uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (i >= cnt) return;
+    uint32_t cur = spl_state[k0 + i];
+    unsigned long long rec = wrec[cur];
+    uint32_t d = rdist[k0 + i];
+    const uint32_t t = rtail[k0 + i];
+    uint64_t p = pos[i];
+    for (;;) {
+        rec_out[p++] = make_uint4(cur, d, t, 0u);
+        const uint32_t l = (uint32_t)rec;
+        if (l == NONE) break;
+        cur = l ^ 1u;
+        rec = wrec[cur];
+        if (rec >> 63) break;
+        d -= w[cur >> 1];
+    }
+}
+// records to the owners of their states: count / fill with the per-owner sums taken in LDS first
+template <bool FILL>
+__global__ void __launch_bounds__(256) prank_route_kernel(const uint4* __restrict__ rec, uint64_t n, const unsigned long long* __restrict__ frag_off, uint32_t world,
+                                                          unsigned long long* __restrict__ cnt_or_cur, uint4* __restrict__ out) {
+    extern __shared__ unsigned long long dynp[];
+    for (uint32_t r = threadIdx.x; r < world; r += 256) dynp[r] = 0;
+    __syncthreads();
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    uint32_t owner = 0;
+    unsigned long long ls = 0;
+    if (i < n) {
+        v = rec[i];
+        const unsigned long long g = v.x >> 1;
+        while (owner + 1 < world && g >= frag_off[owner + 1]) ++owner;
+        ls = atomicAdd(&dynp[owner], 1ull);
+    }
+    __syncthreads();
+    for (uint32_t r = threadIdx.x; r < world; r += 256) { const unsigned long long c = dynp[r]; if (c) dynp[r] = atomicAdd(&cnt_or_cur[r], c); }
+    if (!FILL) return;
+    __syncthreads();
+    if (i < n) out[dynp[owner] + ls] = v;
+}
+__global__ void __launch_bounds__(TB) prank_apply_kernel(const uint4* __restrict__ rec, uint64_t n, unsigned long long state_base, uint64_t n_local_states,
+                                                         uint2* __restrict__ rk, uint32_t* __restrict__ bad) {
+    const uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    const uint4 v = rec[i];
+    const unsigned long long s = (unsigned long long)v.x - state_base;
+    if (s < n_local_states) rk[s] = make_uint2(v.y, v.z);
+    else *bad = 1u;
+}
+}  // namespace
+
 template <int K>
 static int graph_impl(snk_ctx* ctx, hipStream_t st, const snk_u128* keys, const uint64_t* vals, uint64_t n,
                       uint32_t do_prune, bool want_unitigs, snk_graph_out* out, char* err, size_t errcap) {
@@ -875,16 +970,23 @@ __device__ __forceinline__ frag_place frag_place_of(const uint2* rk, const uint3
 // the whole unitig.  Everything the emission needs -- the ranking itself stays behind (sharded runs rank the job's whole
 // fragment list and place only their own fragments).
 constexpr unsigned long long PL_RC = 1ull << 63;
-__global__ void __launch_bounds__(TB) jplace_kernel(const uint2* __restrict__ rk, const uint32_t* __restrict__ nk, const uint8_t* __restrict__ circ,
+// rk covers the fragments from rk_f0 on (0: the whole list; sharded runs with the partitioned ranking: this rank's own);
+// circ == NULL: no circle was cut
+__global__ void __launch_bounds__(TB) jplace_kernel(const uint2* __restrict__ rk, uint64_t rk_f0, const uint32_t* __restrict__ nk, const uint8_t* __restrict__ circ,
                                                     uint64_t f0, uint64_t Fl, uint32_t* __restrict__ pl_pid, unsigned long long* __restrict__ pl_koff,
                                                     unsigned long long* __restrict__ pl_N, uint8_t* __restrict__ pl_circ) {
     const uint64_t i = (uint64_t)blockIdx.x * TB + threadIdx.x;
     if (i >= Fl) return;
-    const frag_place p = frag_place_of(rk, nk, f0 + i);
+    const uint2 a = rk[2 * (f0 + i - rk_f0)], b = rk[2 * (f0 + i - rk_f0) + 1];
+    const uint32_t w = nk[f0 + i];
+    frag_place p;
+    p.N = (uint64_t)a.x + b.x + w;
+    if (a.y < b.y) { p.pid = a.y; p.other = b.y; p.koff = a.x; p.rc = false; }
+    else { p.pid = b.y; p.other = a.y; p.koff = b.x; p.rc = true; }
     pl_pid[i] = p.pid;
     pl_koff[i] = p.koff | (p.rc ? PL_RC : 0ull);
     pl_N[i] = p.N;
-    pl_circ[i] = circ[p.pid];
+    pl_circ[i] = circ ? circ[p.pid] : 0;
 }
 // gfid: global id of every fragment (NULL: fragment f is f); a head is the fragment that owns its unitig's terminal state
 __global__ void __launch_bounds__(TB) jhead_kernel(const uint32_t* __restrict__ pl_pid, const unsigned long long* __restrict__ pl_koff,
@@ -1177,13 +1279,13 @@ int snk_join_rank(snk_ctx* ctx, hipStream_t st, uint64_t F, const uint32_t* nk, 
 }
 
 int snk_join_place(snk_ctx* ctx, hipStream_t st, const uint2* rk, const uint32_t* nk, const uint8_t* circ, uint64_t f0, uint64_t Fl,
-                   snk_placement* pl, char* err, size_t errcap) {
+                   snk_placement* pl, char* err, size_t errcap, uint64_t rk_f0) {
     memset(pl, 0, sizeof *pl);
     G_ALLOC(pl->pid, uint32_t, Fl + 1);
     G_ALLOC(pl->koff, unsigned long long, Fl + 1);
     G_ALLOC(pl->N, unsigned long long, Fl + 1);
     G_ALLOC(pl->circ, uint8_t, Fl + 1);
-    if (Fl) hipLaunchKernelGGL(jplace_kernel, dim3(nblk(Fl)), dim3(TB), 0, st, rk, nk, circ, f0, Fl, pl->pid, pl->koff, pl->N, pl->circ);
+    if (Fl) hipLaunchKernelGGL(jplace_kernel, dim3(nblk(Fl)), dim3(TB), 0, st, rk, rk_f0, nk, circ, f0, Fl, pl->pid, pl->koff, pl->N, pl->circ);
     SNK_HIP_TRY(hipGetLastError());
     return SNK_OK;
 }
@@ -1365,5 +1467,125 @@ int snk_dist_links_apply(snk_ctx* ctx, hipStream_t st, const snk_frag_out* fr, c
     SNK_HIP_TRY(hipGetLastError());
     SNK_HIP_TRY(hipStreamSynchronize(st));
     *flink_out = flink;
+    return SNK_OK;
+}
+
+int snk_prank_begin(snk_ctx* ctx, hipStream_t st, uint64_t F, const uint32_t* nk, uint32_t* link, uint32_t rank, uint32_t world, snk_prank* P, char* err,
+                    size_t errcap) {
+    memset(P, 0, sizeof *P);
+    const uint64_t ns = 2 * F;
+    P->ns = ns; P->w = nk; P->link = link;
+    if (F >= (1ull << 31)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "more than 2^31 fragments at the join (%llu)", (unsigned long long)F);
+    uint8_t* spl;
+    uint32_t *flag32, *sid;
+    G_ALLOC(spl, uint8_t, ns + 1);
+    G_ALLOC(flag32, uint32_t, ns + 1);
+    G_ALLOC(sid, uint32_t, ns + 1);
+    SNK_HIP_TRY(hipMemsetAsync(flag32 + ns, 0, 4, st));
+    const uint32_t split_mask = (1u << snk_env_u32("SNK_SPLIT_LOG2", 6)) - 1u;
+    if (ns) hipLaunchKernelGGL(spl_mark_kernel, dim3(nblk(ns)), dim3(TB), 0, st, link, ns, split_mask, spl, flag32);
+    {
+        size_t tb = 0;
+        SNK_HIP_TRY(rocprim::exclusive_scan((void*)nullptr, tb, flag32, sid, 0u, (size_t)(ns + 1), rocprim::plus<uint32_t>(), st));
+        void* tmp;
+        int rc = snk_ctx_alloc(ctx, tb, &tmp, err, errcap);
+        if (rc) return rc;
+        SNK_HIP_TRY(rocprim::exclusive_scan(tmp, tb, flag32, sid, 0u, (size_t)(ns + 1), rocprim::plus<uint32_t>(), st));
+    }
+    uint32_t m32 = 0;
+    SNK_HIP_TRY(hipMemcpyAsync(&m32, sid + ns, 4, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    const uint64_t m = m32;
+    P->m = m;
+    P->spl_state = flag32;             // flag32 is dead after the scan: reuse it for the compacted splitter list
+    if (m) hipLaunchKernelGGL(spl_collect_kernel, dim3(nblk(ns)), dim3(TB), 0, st, spl, sid, ns, P->spl_state);
+    G_ALLOC(P->wrec, unsigned long long, ns + 1);
+    if (ns) hipLaunchKernelGGL(spl_pack_kernel, dim3(nblk(ns)), dim3(TB), 0, st, link, spl, sid, ns, P->wrec);
+    P->k0 = m * rank / world;
+    P->k1 = m * (rank + 1) / world;
+    const uint64_t cnt = P->k1 - P->k0;
+    G_ALLOC(P->w1_share, uint4, cnt + 1);
+    if (cnt) hipLaunchKernelGGL(spl_walk1p_kernel, dim3(nblk(cnt)), dim3(TB), 0, st, P->wrec, P->spl_state, nk, P->k0, cnt, P->w1_share);
+    SNK_HIP_TRY(hipGetLastError());
+    return SNK_OK;
+}
+
+// w1_all: the first walk's results of all ranks in splitter order.  *circles = 1: some list is a circle (the caller ranks the
+// replicated way); else rec_out / n_rec = this rank's share of (state, distance, terminal) records.
+int snk_prank_walk(snk_ctx* ctx, hipStream_t st, snk_prank* P, const uint4* w1_all, uint32_t* circles, uint32_t* rounds, char* err, size_t errcap) {
+    const uint64_t m = P->m;
+    *circles = 0;
+    *rounds = 0;
+    P->n_rec = 0;
+    uint32_t *rn[2], *rd[2], *rt[2];
+    for (int b = 0; b < 2; ++b) { G_ALLOC(rn[b], uint32_t, m + 1); G_ALLOC(rd[b], uint32_t, m + 1); G_ALLOC(rt[b], uint32_t, m + 1); }
+    unsigned long long* tot;
+    uint32_t* flags;
+    G_ALLOC(tot, unsigned long long, 2);
+    G_ALLOC(flags, uint32_t, 4);
+    SNK_HIP_TRY(hipMemsetAsync(tot, 0, 8, st));
+    if (m) hipLaunchKernelGGL(prank_unzip_kernel, dim3(nblk(m)), dim3(TB), 0, st, w1_all, m, rn[0], rd[0], rt[0], tot);
+    unsigned long long h_tot = 0;
+    SNK_HIP_TRY(hipMemcpyAsync(&h_tot, tot, 8, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    if (h_tot != P->ns) { *circles = 1; return SNK_OK; }          // states no walk reached: a circle without a splitter
+    uint32_t h_flag = 0;
+    int max_rounds = 2;
+    while ((1ull << (max_rounds - 1)) < m + 1) ++max_rounds;
+    int cur = 0;
+    bool converged = (m == 0);
+    for (int r = 0; r < max_rounds && !converged; ++r) {
+        SNK_HIP_TRY(hipMemsetAsync(flags, 0, 4, st));
+        hipLaunchKernelGGL(rank_round_kernel, dim3(nblk(m)), dim3(TB), 0, st, rn[cur], rd[cur], rt[cur], m, rn[cur ^ 1], rd[cur ^ 1], rt[cur ^ 1], flags);
+        cur ^= 1;
+        ++*rounds;
+        SNK_HIP_TRY(hipMemcpyAsync(&h_flag, flags, 4, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(hipStreamSynchronize(st));
+        if (h_flag == 0) converged = true;
+    }
+    if (!converged) { *circles = 1; return SNK_OK; }               // a circle that contains splitters
+    const uint64_t cnt = P->k1 - P->k0;
+    uint64_t *steps, *pos;
+    G_ALLOC(steps, uint64_t, cnt + 1);
+    G_ALLOC(pos, uint64_t, cnt + 1);
+    hipLaunchKernelGGL(prank_steps_kernel, dim3(nblk(cnt + 1)), dim3(TB), 0, st, w1_all, P->k0, cnt, steps);
+    int rc = excl_scan<uint64_t>(ctx, st, steps, pos, cnt + 1, err, errcap);
+    if (rc) return rc;
+    uint64_t n_rec = 0;
+    SNK_HIP_TRY(hipMemcpyAsync(&n_rec, pos + cnt, 8, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    G_ALLOC(P->rec, uint4, n_rec + 1);
+    if (cnt) hipLaunchKernelGGL(spl_walk2p_kernel, dim3(nblk(cnt)), dim3(TB), 0, st, P->wrec, P->spl_state, P->w, rd[cur], rt[cur], P->k0, cnt, pos, P->rec);
+    SNK_HIP_TRY(hipGetLastError());
+    P->n_rec = n_rec;
+    return SNK_OK;
+}
+
+int snk_prank_route(snk_ctx* ctx, hipStream_t st, snk_prank* P, bool fill, const unsigned long long* d_frag_off, uint32_t world,
+                    unsigned long long* d_cnt_or_cur, void* d_out, char* err, size_t errcap) {
+    if (!P->n_rec) return SNK_OK;
+    const unsigned nb = (unsigned)((P->n_rec + 255) / 256);
+    if (fill) hipLaunchKernelGGL((prank_route_kernel<true>), dim3(nb), dim3(256), world * 8ull, st, P->rec, P->n_rec, d_frag_off, world, d_cnt_or_cur, (uint4*)d_out);
+    else hipLaunchKernelGGL((prank_route_kernel<false>), dim3(nb), dim3(256), world * 8ull, st, P->rec, P->n_rec, d_frag_off, world, d_cnt_or_cur, (uint4*)nullptr);
+    SNK_HIP_TRY(hipGetLastError());
+    return SNK_OK;
+}
+
+// the records that arrived -> rk of this rank's own states [state_base, state_base + n_local_states)
+int snk_prank_apply(snk_ctx* ctx, hipStream_t st, const void* d_rec, uint64_t n, unsigned long long state_base, uint64_t n_local_states,
+                    const uint2** rk_out, char* err, size_t errcap) {
+    uint2* rk;
+    uint32_t* flag;
+    G_ALLOC(rk, uint2, n_local_states + 1);
+    G_ALLOC(flag, uint32_t, 4);
+    SNK_HIP_TRY(hipMemsetAsync(rk, 0xFF, (n_local_states + 1) * 8, st));
+    SNK_HIP_TRY(hipMemsetAsync(flag, 0, 8, st));
+    if (n) hipLaunchKernelGGL(prank_apply_kernel, dim3(nblk(n)), dim3(TB), 0, st, (const uint4*)d_rec, n, state_base, n_local_states, rk, flag);
+    if (n_local_states) hipLaunchKernelGGL(unranked_check_kernel, dim3(nblk(n_local_states)), dim3(TB), 0, st, (const uint2*)rk, n_local_states, flag + 1);
+    uint32_t h[2] = {0, 0};
+    SNK_HIP_TRY(hipMemcpyAsync(h, flag, 8, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    if (h[0] || h[1]) return snk_fail(SNK_E_INTERNAL, err, errcap, "partitioned ranking: %s", h[0] ? "a record for a foreign state arrived" : "a local state was not ranked");
+    *rk_out = rk;
     return SNK_OK;
 }

@@ -181,6 +181,10 @@ def _declare(lib: C.CDLL) -> None:
         "snk_shard_links_answer": (C.c_int, [vp, vp, u64, vp, vp, cp, sz]),
         "snk_shard_links_apply": (C.c_int, [vp, vp, vp, u64, P(vp), vp, cp, sz]),
         "snk_shard_place": (C.c_int, [vp, u32, u64, vp, vp, vp, u64, P(u64), P(u64), vp, cp, sz]),
+        "snk_shard_prank_begin": (C.c_int, [vp, u64, vp, vp, u64, P(u64), P(vp), vp, cp, sz]),
+        "snk_shard_prank_walk": (C.c_int, [vp, vp, vp, P(u64), P(u32), vp, cp, sz]),
+        "snk_shard_prank_route": (C.c_int, [vp, vp, vp, vp, vp, cp, sz]),
+        "snk_shard_place_ranked": (C.c_int, [vp, u32, vp, u64, vp, P(u64), P(u64), vp, cp, sz]),
         "snk_shard_route_fill": (C.c_int, [vp, u32, vp, vp, vp, vp, vp, vp, cp, sz]),
         "snk_shard_emit": (C.c_int, [vp, u32, u64, vp, vp, vp, vp, P(SnkShardUnitigs), vp, cp, sz]),
     }

@@ -425,6 +425,9 @@ class ShardedEngine:
         self.pool = None
         self.join = join or os.environ.get("SNK_JOIN", "owner")
         assert self.join in ("owner", "rank0")
+        # owner-side join: "partitioned" = every rank walks 1/W of the ranking (lists that are circles fall back to "replicated")
+        self.rank_mode = os.environ.get("SNK_JOIN_RANK", "partitioned")
+        assert self.rank_mode in ("partitioned", "replicated")
 
     def count_graph(self, rows, read_len, quals=None, bc=None, lens=None, good_len=None, params: Params | None = None,
                     ign_bc_below: int = 0, read_index_base: int = 0) -> ShardedResult:
@@ -595,7 +598,33 @@ class ShardedEngine:
             fl_all = comm.all_gather_v(dcopy("s_link", flink_p.value, F * 8), [x * 8 for x in all_F], alloc=lambda nb: pool.get("g_link", max(nb, 8))[:nb])
             d_frag_off = torch.tensor(frag_off, dtype=torch.int64, device=dev)
             fto, bto = (C.c_uint64 * W)(), (C.c_uint64 * W)()
-            chk(lib.snk_shard_place(e._ctx, K, Ft, nk_all.data_ptr(), fl_all.data_ptr(), d_frag_off.data_ptr(), frag_off[me], fto, bto, st, err, 512))
+            ranked = False
+            if self.rank_mode == "partitioned":
+                # the two walks of the ruling-set ranking for a 1/W share of the splitters on every rank; 16 B per splitter
+                # (all-gather) and 16 B per state (to its owner) cross the links
+                m_spl, w1p = C.c_uint64(0), C.c_void_p()
+                chk(lib.snk_shard_prank_begin(e._ctx, Ft, nk_all.data_ptr(), fl_all.data_ptr(), frag_off[me], C.byref(m_spl), C.byref(w1p), st, err, 512))
+                m = int(m_spl.value)
+                shares = [(m * (q + 1) // W - m * q // W) * 16 for q in range(W)]
+                w1_all = comm.all_gather_v(dcopy("s_w1", w1p.value, shares[me]), shares, alloc=lambda nb: pool.get("g_w1", max(nb, 16))[:nb])
+                rto, circ = (C.c_uint64 * W)(), C.c_uint32(0)
+                chk(lib.snk_shard_prank_walk(e._ctx, w1_all.data_ptr(), d_frag_off.data_ptr(), rto, C.byref(circ), st, err, 512))
+                if not circ.value:
+                    rto = [int(x) for x in rto]
+                    roff_ = [0]
+                    for q in range(W):
+                        roff_.append(roff_[-1] + rto[q])
+                    d_roff = torch.tensor(roff_[:W], dtype=torch.int64, device=dev)
+                    rsend = pool.get("s_rk", max(roff_[-1], 1) * 16)
+                    chk(lib.snk_shard_prank_route(e._ctx, d_frag_off.data_ptr(), d_roff.data_ptr(), rsend.data_ptr(), st, err, 512))
+                    torch.cuda.current_stream().synchronize()
+                    rk_in, _ = comm.all_to_all_v(rsend[: roff_[-1] * 16], [c * 16 for c in rto], alloc=lambda nb: pool.get("g_rk", max(nb, 16))[:nb])
+                    chk(lib.snk_shard_place_ranked(e._ctx, K, rk_in.data_ptr(), rk_in.numel() // 16, d_frag_off.data_ptr(), fto, bto, st, err, 512))
+                    ranked = True
+                    res.exchange_bytes_rank = (m * 16, roff_[-1] * 16)
+            if not ranked:      # a list is a circle (same verdict on every rank: it comes from replicated data), or rank_mode == "replicated"
+                chk(lib.snk_shard_place(e._ctx, K, Ft, nk_all.data_ptr(), fl_all.data_ptr(), d_frag_off.data_ptr(), frag_off[me], fto, bto, st, err, 512))
+            res.join_ranking = "partitioned" if ranked else "replicated"
             fto, bto = [int(x) for x in fto], [int(x) for x in bto]
             hoff, boff_, bpad = route_offsets(fto, bto)
             d_hoff = torch.tensor(hoff[:W], dtype=torch.int64, device=dev)

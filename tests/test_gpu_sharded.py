@@ -36,7 +36,7 @@ def run_world(W, case, n_buckets=0):
                                  ign_bc_below=case.ign_bc_below, read_index_base=lo)
             out[r] = dict(keys=res.keys(), counts=res.counts(), ctx=res.ctx(), spectrum=res.spectrum(),
                           n_instances=res.n_instances, n_frags=res.n_frags, n_queries=res.n_queries,
-                          unitigs=res.unitigs())
+                          unitigs=res.unitigs(), ranking=getattr(res, "join_ranking", None))
             e.close()
         except BaseException as ex:  # noqa: BLE001
             errs.append(ex)
@@ -85,6 +85,9 @@ def test_sharded_matches_reference(snk, W, name):
     check(out, c)
     if W > 1:
         assert sum(o["n_queries"] for o in out) > 0      # the cross-rank prune really ran
+    # the ranking is partitioned over the ranks unless some fragment list is a circle (the plasmids of the adversarial case):
+    # then every rank ranks the replicated way -- both routes are exercised, every rank takes the same one
+    assert {o["ranking"] for o in out} == ({"replicated"} if name == "adversarial" else {"partitioned"})
 
 
 def test_sharded_many_small_buckets(snk):
