@@ -250,6 +250,20 @@ def main():
                          "pipeline_frac": value * ALG_BYTES_PER_KMER[K] / (world * HBM_PEAK_GBS)},
         }
         out["config"]["path"] = "grouped-replicas" if args.grouped else ("sharded" if use_dist else "single")
+        if use_dist and not args.grouped:
+            # the multi-GPU breakdown of rank 0's last step: sections of the join ("(x)" = an exchange, incl. the wait for the
+            # slowest peer), bytes this rank put on the links per exchange, ranks of the RCCL group
+            rec_b = int(res.n_supermers) * 32 * (world - 1) // world
+            out["config"]["multi_gpu"] = {
+                "rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "join": sh.join,
+                "join_ranking": getattr(res, "join_ranking", None),
+                "join_ms_rank0": {k: round(v, 3) for k, v in getattr(res, "join_ms", {}).items()},
+                "exchange_bytes_rank0": {"supermer_records": rec_b, "prune_queries": int(res.n_queries) * 28,
+                                         "link_queries": int(getattr(res, "n_link_queries", 0)) * 28,
+                                         "link_structure_allgather": int(getattr(res, "exchange_bytes_join", (0, 0))[0]),
+                                         "ranking": list(getattr(res, "exchange_bytes_rank", (0, 0))),
+                                         "fragments_to_owners": int(getattr(res, "exchange_bytes_join", (0, 0))[1])},
+                "fragments_rank0": int(res.n_frags), "unitigs_written_by_rank0": int(res.n_unitigs)}
         if verified is not None:
             out["config"]["sharded_self_check"] = "passed" if verified else "FAILED"
             if not verified:        # a wrong result is not a performance number

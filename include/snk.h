@@ -64,6 +64,8 @@ typedef struct snk_params {
                                   32 low bits of every key. */
 #define SNK_F_NO_TABLE 16u      /* snk_count_graph (host pointers): do not download the retained table (kmers/counts/ctx stay
                                   NULL, n_kmers is still reported) -- callers at the .bv seam only need the unitigs */
+#define SNK_F_BV_IMAGE 32u      /* snk_count_graph (host pointers): return the unitigs as the bytes of the .bv hand-off file
+                                   (snk_result.bv_image, packed on the device) instead of unitig_off / unitig_bases */
 #define SNK_F_GLOBAL_GRAPH 4u   /* use the global graph stage (sort + HBM index + list ranking over all k-mers) instead
                                   of the bucket-local one; same results, kept as a cross-check */
 
@@ -300,6 +302,9 @@ typedef struct snk_result {
     uint32_t spectrum_bins;
     uint32_t reserved;
     float phase_ms[8];
+    uint8_t* bv_image;          /* SNK_F_BV_IMAGE: the .bv file ("BINWRITE", u64 count, per unitig u32 length + ceil(len/4)
+                                   bytes; lib/tada/src/debruijn.rs:895-929), unitigs in BVComp order; else NULL */
+    uint64_t bv_bytes;
 } snk_result;
 
 /* Replaces buildReadQGraph48(..., pPaths=nullptr) up to the unitigs for host-resident inputs
@@ -307,6 +312,11 @@ typedef struct snk_result {
  * Outputs are malloc'ed by the library and released by snk_free. */
 int snk_count_graph(snk_ctx* ctx, const snk_reads* in, const snk_params* p, snk_result* out, char* err, size_t errcap);
 void snk_free(snk_result* r);
+/* Page-locked host memory for the inputs of snk_count_graph (the reference keeps reads/quals in plain vectors, vecbvec /
+ * VecPQVec, BuildReadQGraph48.h:24-34; a host that fills pinned buffers instead saves the staging copy: the DMA engine
+ * reads them in place).  Pageable inputs are accepted just the same. */
+int snk_host_alloc_pinned(size_t bytes, void** out, char* err, size_t errcap);
+void snk_host_free_pinned(void* p);
 
 /* a13: the unitig hand-off file tada writes and DF reads through MSPEDGES= ("BINWRITE", u64 count, per entry u32
  * length + ceil(len/4) bytes, base j at bits 2*(j%4)): writer TempGraph::write_to_sn_format

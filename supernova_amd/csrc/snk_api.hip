@@ -130,6 +130,7 @@ extern "C" void snk_ctx_destroy(snk_ctx* ctx) {
     snk_ctx_release_scratch(ctx);
     snk_ctx_trim_cache(ctx);
     if (ctx->shard) snk_shard_state_free(ctx->shard);
+    if (ctx->host_io && ctx->host_io_free) ctx->host_io_free(ctx->host_io);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -25,6 +25,8 @@ struct snk_ctx {
     uint64_t last_n_kmers = 0, last_n_instances = 0;   // sizing hint from the previous call
     uint32_t last_extra = 0;                           // split sub-passes the previous call recorded
     void* shard = nullptr;      // snk_shard_state (snk_dist.hip)
+    void* host_io = nullptr;    // pinned staging + device input buffers of the host-pointer entry point (snk_host.hip)
+    void (*host_io_free)(void*) = nullptr;
 };
 
 void snk_set_error(char* err, size_t errcap, const char* fmt, ...);

@@ -7,65 +7,220 @@
 
 #include <algorithm>
 #include <numeric>
+#include <thread>
 #include <vector>
+
+#include <rocprim/rocprim.hpp>
 
 #include "snk_ctx.h"
 #include "snk_common.h"
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Host seam.  The first version of snk_count_graph hipMalloc'ed every input, copied pageable memory synchronously, ordered
+// the unitigs with std::sort on the host and repacked every key word by word: 0.9 Gk-mers/s at 5 M reads against 70+ on
+// the device.  Now: device inputs and pinned staging buffers live in the context (grow-only, no hipMalloc in steady state);
+// pageable host arrays go up in 64 MiB pieces through three pinned buffers filled by a few memcpy threads (pinned callers --
+// snk_host_alloc_pinned -- are copied from in place); the quality rows, three quarters of the bytes and dead after the
+// trim, never exist on the device in full: every piece is trimmed on the compute stream while the next is on the wire;
+// the BVComp order (HBVFromEdges.cc:106-111) is one stable radix sort on the device (unitigs leave the join ordered by their
+// first k-mer, which no two share), and the .bv file image is packed on the device.
 namespace {
 
-struct dev_buf {
-    void* p = nullptr;
-    ~dev_buf() { if (p) (void)hipFree(p); }
-};
+constexpr size_t STAGE_BYTES = 64ull << 20;
+constexpr int STAGE_BUFS = 3;
+constexpr int COPY_THREADS = 8;
 
-// BVComp, HBVFromEdges.cc:106-111: length descending, then lexicographic
-struct bv_less {
-    const uint64_t* off;
-    const uint8_t* b;
-    bool operator()(uint64_t x, uint64_t y) const {
-        uint64_t lx = off[x + 1] - off[x], ly = off[y + 1] - off[y];
-        if (lx != ly) return lx > ly;
-        int c = memcmp(b + off[x], b + off[y], lx);
-        return c < 0;
+struct host_io {
+    int device = 0;
+    hipStream_t copy = nullptr;
+    void* pin[STAGE_BUFS] = {nullptr, nullptr, nullptr};
+    hipEvent_t pin_free[STAGE_BUFS] = {nullptr, nullptr, nullptr};
+    int next = 0;
+    struct dbuf { void* p = nullptr; size_t cap = 0; };
+    dbuf rows, ascii, lens, gl, bc, qchunk[2];
+    hipEvent_t q_done[2] = {nullptr, nullptr}, q_up[2] = {nullptr, nullptr};
+    ~host_io() {
+        (void)hipSetDevice(device);
+        for (auto& q : pin) if (q) (void)hipHostFree(q);
+        for (auto& e : pin_free) if (e) (void)hipEventDestroy(e);
+        for (auto& e : q_done) if (e) (void)hipEventDestroy(e);
+        for (auto& e : q_up) if (e) (void)hipEventDestroy(e);
+        for (dbuf* b : {&rows, &ascii, &lens, &gl, &bc, &qchunk[0], &qchunk[1]}) if (b->p) (void)hipFree(b->p);
+        if (copy) (void)hipStreamDestroy(copy);
     }
 };
 
-}  // namespace
+int io_of(snk_ctx* ctx, host_io** out, char* err, size_t errcap) {
+    if (!ctx->host_io) {
+        host_io* io = new host_io();
+        io->device = ctx->device;
+        ctx->host_io = io;
+        ctx->host_io_free = [](void* p) { delete static_cast<host_io*>(p); };
+        SNK_HIP_TRY(hipStreamCreateWithFlags(&io->copy, hipStreamNonBlocking));
+        for (int b = 0; b < STAGE_BUFS; ++b) {
+            SNK_HIP_TRY(hipHostMalloc(&io->pin[b], STAGE_BYTES, hipHostMallocDefault));
+            SNK_HIP_TRY(hipEventCreateWithFlags(&io->pin_free[b], hipEventDisableTiming));
+        }
+        for (int b = 0; b < 2; ++b) {
+            SNK_HIP_TRY(hipEventCreateWithFlags(&io->q_done[b], hipEventDisableTiming));
+            SNK_HIP_TRY(hipEventCreateWithFlags(&io->q_up[b], hipEventDisableTiming));
+        }
+    }
+    *out = static_cast<host_io*>(ctx->host_io);
+    return SNK_OK;
+}
 
-extern "C" int snk_count_graph(snk_ctx* ctx, const snk_reads* in, const snk_params* p, snk_result* out, char* err, size_t errcap) {
+int grow(host_io::dbuf* b, size_t bytes, char* err, size_t errcap) {
+    bytes = std::max<size_t>(bytes, 256);
+    if (b->cap >= bytes) return SNK_OK;
+    if (b->p) { SNK_HIP_TRY(hipFree(b->p)); b->p = nullptr; b->cap = 0; }
+    SNK_HIP_TRY(hipMalloc(&b->p, bytes + bytes / 8));
+    b->cap = bytes + bytes / 8;
+    return SNK_OK;
+}
+
+bool is_pinned(const void* p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+
+void parallel_copy(void* dst, const void* src, size_t n) {
+    if (n < (4u << 20)) { memcpy(dst, src, n); return; }
+    std::thread th[COPY_THREADS];
+    const size_t per = (n / COPY_THREADS + 63) & ~(size_t)63;
+    for (int t = 0; t < COPY_THREADS; ++t) {
+        const size_t a = std::min(n, per * t), b = std::min(n, per * (t + 1));
+        th[t] = std::thread([=] { if (b > a) memcpy((char*)dst + a, (const char*)src + a, b - a); });
+    }
+    for (auto& t : th) t.join();
+}
+
+// host -> device on the copy stream; pageable sources go through the pinned ring
+int upload(host_io* io, void* d_dst, const void* h_src, size_t bytes, char* err, size_t errcap) {
+    if (!bytes) return SNK_OK;
+    if (is_pinned(h_src)) { SNK_HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, io->copy)); return SNK_OK; }
+    for (size_t off = 0; off < bytes; off += STAGE_BYTES) {
+        const size_t n = std::min(STAGE_BYTES, bytes - off);
+        const int b = io->next;
+        io->next = (io->next + 1) % STAGE_BUFS;
+        SNK_HIP_TRY(hipEventSynchronize(io->pin_free[b]));          // its previous DMA has drained (a fresh event is complete)
+        parallel_copy(io->pin[b], (const char*)h_src + off, n);
+        SNK_HIP_TRY(hipMemcpyAsync((char*)d_dst + off, io->pin[b], n, hipMemcpyHostToDevice, io->copy));
+        SNK_HIP_TRY(hipEventRecord(io->pin_free[b], io->copy));
+    }
+    return SNK_OK;
+}
+
+// ---- BVComp order + gathers on the device
+__global__ void __launch_bounds__(256) bv_lenkey_kernel(const uint64_t* __restrict__ off, uint64_t U, uint64_t* __restrict__ key, uint32_t* __restrict__ idx) {
+    const uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u >= U) return;
+    key[u] = ~(off[u + 1] - off[u]);            // ascending ~len = descending length; the sort is stable, ties keep first-k-mer order
+    idx[u] = (uint32_t)u;
+}
+// sizes of the ordered unitigs: bases (plain copy) or .bv bytes (u32 length + ceil(len/4))
+__global__ void __launch_bounds__(256) bv_sizes_kernel(const uint64_t* __restrict__ off, const uint32_t* __restrict__ order, uint64_t U, int image,
+                                                       uint64_t* __restrict__ sz) {
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r > U) return;
+    uint64_t v = 0;
+    if (r < U) { const uint64_t len = off[order[r] + 1] - off[order[r]]; v = image ? 4 + (len + 3) / 4 : len; }
+    sz[r] = v;
+}
+// one workgroup per 4096 output bytes: the owners of a block's bytes are found by binary search over the offsets
+__global__ void __launch_bounds__(256) bv_gather_kernel(const uint64_t* __restrict__ off, const uint8_t* __restrict__ bases, const uint32_t* __restrict__ order,
+                                                        const uint64_t* __restrict__ noff, uint64_t U, uint64_t total, int image, uint8_t* __restrict__ out) {
+    const uint64_t p0 = (uint64_t)blockIdx.x * 4096;
+    for (uint64_t p = p0 + threadIdx.x; p < p0 + 4096 && p < total; p += 256) {
+        uint64_t lo = 0, hi = U;                     // largest r with noff[r] <= p
+        while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (noff[mid] <= p) lo = mid; else hi = mid; }
+        const uint64_t src = off[order[lo]], len = off[order[lo] + 1] - src, q = p - noff[lo];
+        if (!image) { out[p] = bases[src + q]; continue; }
+        if (q < 4) { out[p] = (uint8_t)((uint32_t)len >> (8 * q)); continue; }
+        const uint64_t j = (q - 4) * 4;
+        uint32_t v = 0;
+        for (uint32_t t = 0; t < 4 && j + t < len; ++t) v |= (uint32_t)(bases[src + j + t] & 3u) << (2 * t);
+        out[p] = (uint8_t)v;
+    }
+}
+__global__ void __launch_bounds__(256) key_words_kernel(const snk_kmer* __restrict__ keys, uint64_t n, uint4* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t lo = reinterpret_cast<const uint64_t*>(keys)[2 * i], hi = reinterpret_cast<const uint64_t*>(keys)[2 * i + 1];
+    out[i] = make_uint4((uint32_t)(hi >> 32), (uint32_t)hi, (uint32_t)(lo >> 32), (uint32_t)lo);
+}
+
+template <typename T>
+int arena(snk_ctx* ctx, size_t n, T** out, char* err, size_t errcap) {
+    void* q = nullptr;
+    int rc = snk_ctx_alloc(ctx, std::max<size_t>(n * sizeof(T), 16), &q, err, errcap);
+    *out = (T*)q;
+    return rc;
+}
+
+int count_graph_impl(snk_ctx* ctx, const snk_reads* in, const snk_params* p, snk_result* out, char* err, size_t errcap) {
     if (!ctx || !in || !p || !out) return snk_fail(SNK_E_ARG, err, errcap, "snk_count_graph: NULL argument");
     if (!in->ascii && !in->rows) return snk_fail(SNK_E_ARG, err, errcap, "snk_count_graph: need ascii or rows");
     if (!in->quals && !in->good_len) return snk_fail(SNK_E_ARG, err, errcap, "snk_count_graph: need quals or good_len");
     if (in->read_len == 0 || in->read_len > 256) return snk_fail(SNK_E_ARG, err, errcap, "snk_count_graph: read_len must be 1..256");
+    if (p->K != 48 && p->K != 60) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "K=%u is not supported (48 or 60)", p->K);
     memset(out, 0, sizeof *out);
     SNK_HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    host_io* io = nullptr;
+    int rc = io_of(ctx, &io, err, errcap);
+    if (rc) return rc;
     const uint64_t n = in->n_reads;
     const uint32_t L = in->read_len, rw = (L + 15) / 16;
-    dev_buf d_rows, d_ascii, d_quals, d_lens, d_gl, d_bc;
-    SNK_HIP_TRY(hipMalloc(&d_rows.p, std::max<size_t>(n * rw * 4, 16)));
-    if (in->rows) SNK_HIP_TRY(hipMemcpyAsync(d_rows.p, in->rows, n * rw * 4, hipMemcpyHostToDevice, st));
+    hipEvent_t up_done;
+    SNK_HIP_TRY(hipEventCreateWithFlags(&up_done, hipEventDisableTiming));
+    struct ev_guard { hipEvent_t e; ~ev_guard() { (void)hipEventDestroy(e); } } eg{up_done};
+    // ---- uploads (copy stream), the quality rows piece by piece with the trim behind each piece (compute stream)
+    if ((rc = grow(&io->rows, n * rw * 4, err, errcap))) return rc;
+    if (in->rows) { if ((rc = upload(io, io->rows.p, in->rows, n * rw * 4, err, errcap))) return rc; }
     else {
-        SNK_HIP_TRY(hipMalloc(&d_ascii.p, std::max<size_t>(n * L, 16)));
-        SNK_HIP_TRY(hipMemcpyAsync(d_ascii.p, in->ascii, n * L, hipMemcpyHostToDevice, st));
-        int rc = snk_dev_pack_ascii(ctx, d_ascii.p, L, L, n, d_rows.p, rw, st);
+        if ((rc = grow(&io->ascii, n * L, err, errcap))) return rc;
+        if ((rc = upload(io, io->ascii.p, in->ascii, n * L, err, errcap))) return rc;
+    }
+    if (in->lens) { if ((rc = grow(&io->lens, n * 2, err, errcap)) || (rc = upload(io, io->lens.p, in->lens, n * 2, err, errcap))) return rc; }
+    if (in->bc) { if ((rc = grow(&io->bc, n * 4, err, errcap)) || (rc = upload(io, io->bc.p, in->bc, n * 4, err, errcap))) return rc; }
+    if ((rc = grow(&io->gl, n * 2 + 16, err, errcap))) return rc;
+    if (in->good_len) { if ((rc = upload(io, io->gl.p, in->good_len, n * 2, err, errcap))) return rc; }
+    SNK_HIP_TRY(hipEventRecord(up_done, io->copy));
+    if (!in->good_len) {
+        SNK_HIP_TRY(hipStreamWaitEvent(st, up_done, 0));            // the trim reads the lengths
+        const uint64_t rows_per = std::max<uint64_t>(1, (256ull << 20) / L) & ~255ull ? (std::max<uint64_t>(1, (256ull << 20) / L) & ~255ull) : 256;
+        for (int b = 0; b < 2; ++b) if ((rc = grow(&io->qchunk[b], std::min<uint64_t>(rows_per, std::max<uint64_t>(n, 1)) * L, err, errcap))) return rc;
+        int b = 0;
+        bool used[2] = {false, false};
+        for (uint64_t r0 = 0; r0 < n; r0 += rows_per, b ^= 1) {
+            const uint64_t nr = std::min(rows_per, n - r0);
+            if (used[b]) SNK_HIP_TRY(hipStreamWaitEvent(io->copy, io->q_done[b], 0));      // the trim of the piece before last has read this buffer
+            if ((rc = upload(io, io->qchunk[b].p, in->quals + r0 * L, nr * L, err, errcap))) return rc;
+            SNK_HIP_TRY(hipEventRecord(io->q_up[b], io->copy));
+            SNK_HIP_TRY(hipStreamWaitEvent(st, io->q_up[b], 0));
+            rc = snk_dev_trim(ctx, io->qchunk[b].p, L, in->lens ? (const char*)io->lens.p + r0 * 2 : nullptr, L, nr, p->K, p->min_qual,
+                              (char*)io->gl.p + r0 * 2, st);
+            if (rc) return snk_fail(rc, err, errcap, "%s", snk_last_error());
+            SNK_HIP_TRY(hipEventRecord(io->q_done[b], st));
+            used[b] = true;
+        }
+    } else SNK_HIP_TRY(hipStreamWaitEvent(st, up_done, 0));
+    if (!in->rows) {
+        rc = snk_dev_pack_ascii(ctx, io->ascii.p, L, L, n, io->rows.p, rw, st);
         if (rc) return snk_fail(rc, err, errcap, "%s", snk_last_error());
     }
-    if (in->quals) { SNK_HIP_TRY(hipMalloc(&d_quals.p, std::max<size_t>(n * L, 16))); SNK_HIP_TRY(hipMemcpyAsync(d_quals.p, in->quals, n * L, hipMemcpyHostToDevice, st)); }
-    if (in->lens) { SNK_HIP_TRY(hipMalloc(&d_lens.p, std::max<size_t>(n * 2, 16))); SNK_HIP_TRY(hipMemcpyAsync(d_lens.p, in->lens, n * 2, hipMemcpyHostToDevice, st)); }
-    if (in->good_len) { SNK_HIP_TRY(hipMalloc(&d_gl.p, std::max<size_t>(n * 2, 16))); SNK_HIP_TRY(hipMemcpyAsync(d_gl.p, in->good_len, n * 2, hipMemcpyHostToDevice, st)); }
-    if (in->bc) { SNK_HIP_TRY(hipMalloc(&d_bc.p, std::max<size_t>(n * 4, 16))); SNK_HIP_TRY(hipMemcpyAsync(d_bc.p, in->bc, n * 4, hipMemcpyHostToDevice, st)); }
     snk_dev_reads dr;
     memset(&dr, 0, sizeof dr);
-    dr.n_reads = n; dr.rows = d_rows.p; dr.row_words = rw; dr.read_len = L; dr.lens = d_lens.p;
-    dr.quals = d_quals.p; dr.qstride = L; dr.good_len = d_gl.p; dr.bc = d_bc.p; dr.ign_bc_below = in->ign_bc_below;
+    dr.n_reads = n; dr.rows = io->rows.p; dr.row_words = rw; dr.read_len = L; dr.lens = in->lens ? io->lens.p : nullptr;
+    dr.good_len = io->gl.p; dr.bc = in->bc ? io->bc.p : nullptr; dr.ign_bc_below = in->ign_bc_below;
     snk_dev_result r;
     snk_params pp = *p;
-    const bool want_table = !(p->flags & SNK_F_NO_TABLE);
+    const bool want_table = !(p->flags & SNK_F_NO_TABLE), want_image = (p->flags & SNK_F_BV_IMAGE) != 0;
+    pp.flags &= ~(uint32_t)(SNK_F_NO_TABLE | SNK_F_BV_IMAGE);
     if (!want_table) pp.flags |= SNK_F_UNSORTED_TABLE;          // nobody will look at the table: do not sort it
-    int rc = snk_dev_count_graph(ctx, &dr, &pp, &r, st, err, errcap);
-    if (rc) return rc;
+    if ((rc = snk_dev_count_graph(ctx, &dr, &pp, &r, st, err, errcap))) return rc;
     out->n_instances = r.n_instances;
     out->n_kmers = r.n_kmers;
     out->spectrum_bins = r.spectrum_bins;
@@ -77,53 +232,91 @@ extern "C" int snk_count_graph(snk_ctx* ctx, const snk_reads* in, const snk_para
         out->ctx = (uint8_t*)malloc(std::max<size_t>(nk, 16));
     }
     out->spectrum = (uint64_t*)malloc(std::max<size_t>((size_t)r.spectrum_bins * 8, 16));
-    std::vector<uint64_t> lohi(nk * 2);
     if ((want_table && (!out->kmers || !out->counts || !out->ctx)) || !out->spectrum) { snk_free(out); return snk_fail(SNK_E_NOMEM, err, errcap, "snk_count_graph: host allocation failed"); }
     if (nk) {
-        SNK_HIP_TRY(hipMemcpyAsync(lohi.data(), r.keys, nk * 16, hipMemcpyDeviceToHost, st));
+        uint4* kw;
+        if ((rc = arena(ctx, nk, &kw, err, errcap))) return rc;
+        hipLaunchKernelGGL(key_words_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, (const snk_kmer*)r.keys, nk, kw);
+        SNK_HIP_TRY(hipMemcpyAsync(out->kmers, kw, nk * 16, hipMemcpyDeviceToHost, st));
         SNK_HIP_TRY(hipMemcpyAsync(out->counts, r.counts, nk * 4, hipMemcpyDeviceToHost, st));
         SNK_HIP_TRY(hipMemcpyAsync(out->ctx, r.ctx, nk, hipMemcpyDeviceToHost, st));
     }
     if (r.spectrum_bins) SNK_HIP_TRY(hipMemcpyAsync(out->spectrum, r.spectrum, (size_t)r.spectrum_bins * 8, hipMemcpyDeviceToHost, st));
-    std::vector<uint64_t> off(r.n_unitigs + 1, 0);
-    std::vector<uint8_t> bases(r.unitig_total_bases);
-    if (r.n_unitigs) {
-        SNK_HIP_TRY(hipMemcpyAsync(off.data(), r.unitig_off, (r.n_unitigs + 1) * 8, hipMemcpyDeviceToHost, st));
-        SNK_HIP_TRY(hipMemcpyAsync(bases.data(), r.unitig_bases, r.unitig_total_bases, hipMemcpyDeviceToHost, st));
+    // ---- unitigs in the reference's deterministic order (BVComp), gathered on the device: plain bases, or the .bv image
+    const uint64_t U = r.n_unitigs;
+    out->n_unitigs = U;
+    const uint64_t* d_off = (const uint64_t*)r.unitig_off;
+    uint64_t *key, *key2, *sz, *noff;
+    uint32_t *idx, *order;
+    if ((rc = arena(ctx, U + 1, &key, err, errcap)) || (rc = arena(ctx, U + 1, &key2, err, errcap)) || (rc = arena(ctx, U + 1, &idx, err, errcap)) ||
+        (rc = arena(ctx, U + 1, &order, err, errcap)) || (rc = arena(ctx, U + 2, &sz, err, errcap)) || (rc = arena(ctx, U + 2, &noff, err, errcap)))
+        return rc;
+    uint64_t total = 0;
+    if (U) {
+        hipLaunchKernelGGL(bv_lenkey_kernel, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, st, d_off, U, key, idx);
+        size_t tb = 0, tb2 = 0;
+        SNK_HIP_TRY(rocprim::radix_sort_pairs((void*)nullptr, tb, key, key2, idx, order, (size_t)U, 0u, 64u, st));
+        SNK_HIP_TRY(rocprim::exclusive_scan((void*)nullptr, tb2, sz, noff, (uint64_t)0, (size_t)(U + 1), rocprim::plus<uint64_t>(), st));
+        uint8_t* tmp;
+        if ((rc = arena(ctx, std::max(tb, tb2), &tmp, err, errcap))) return rc;
+        SNK_HIP_TRY(rocprim::radix_sort_pairs(tmp, tb, key, key2, idx, order, (size_t)U, 0u, 64u, st));
+        hipLaunchKernelGGL(bv_sizes_kernel, dim3((unsigned)((U + 256) / 256)), dim3(256), 0, st, d_off, order, U, want_image ? 1 : 0, sz);
+        SNK_HIP_TRY(rocprim::exclusive_scan(tmp, tb2, sz, noff, (uint64_t)0, (size_t)(U + 1), rocprim::plus<uint64_t>(), st));
+        SNK_HIP_TRY(hipMemcpyAsync(&total, noff + U, 8, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(hipStreamSynchronize(st));
+    }
+    uint8_t* d_out;
+    if ((rc = arena(ctx, total + 16, &d_out, err, errcap))) return rc;
+    if (total) hipLaunchKernelGGL(bv_gather_kernel, dim3((unsigned)((total + 4095) / 4096)), dim3(256), 0, st, d_off, (const uint8_t*)r.unitig_bases, order, noff, U, total,
+                                  want_image ? 1 : 0, d_out);
+    SNK_HIP_TRY(hipGetLastError());
+    if (want_image) {
+        out->bv_bytes = 16 + total;
+        out->bv_image = (uint8_t*)malloc(out->bv_bytes);
+        if (!out->bv_image) { snk_free(out); return snk_fail(SNK_E_NOMEM, err, errcap, "snk_count_graph: host allocation failed"); }
+        memcpy(out->bv_image, "BINWRITE", 8);
+        memcpy(out->bv_image + 8, &U, 8);
+        if (total) SNK_HIP_TRY(hipMemcpyAsync(out->bv_image + 16, d_out, total, hipMemcpyDeviceToHost, st));
+    } else {
+        out->unitig_off = (uint64_t*)malloc((U + 1) * 8);
+        out->unitig_bases = (uint8_t*)malloc(std::max<size_t>(total, 16));
+        if (!out->unitig_off || !out->unitig_bases) { snk_free(out); return snk_fail(SNK_E_NOMEM, err, errcap, "snk_count_graph: host allocation failed"); }
+        out->unitig_off[0] = 0;
+        if (U) SNK_HIP_TRY(hipMemcpyAsync(out->unitig_off, noff, (U + 1) * 8, hipMemcpyDeviceToHost, st));
+        if (total) SNK_HIP_TRY(hipMemcpyAsync(out->unitig_bases, d_out, total, hipMemcpyDeviceToHost, st));
     }
     SNK_HIP_TRY(hipStreamSynchronize(st));
-    for (uint64_t i = 0; i < nk; ++i) {
-        uint64_t lo = lohi[2 * i], hi = lohi[2 * i + 1];
-        out->kmers[4 * i] = (uint32_t)(hi >> 32); out->kmers[4 * i + 1] = (uint32_t)hi;
-        out->kmers[4 * i + 2] = (uint32_t)(lo >> 32); out->kmers[4 * i + 3] = (uint32_t)lo;
-    }
-    // deterministic unitig order of the reference's graph builder (BVComp)
-    const uint64_t U = r.n_unitigs;
-    std::vector<uint64_t> order(U);
-    std::iota(order.begin(), order.end(), 0ull);
-    std::sort(order.begin(), order.end(), bv_less{off.data(), bases.data()});
-    out->n_unitigs = U;
-    out->unitig_off = (uint64_t*)malloc((U + 1) * 8);
-    out->unitig_bases = (uint8_t*)malloc(std::max<size_t>(bases.size(), 16));
-    if (!out->unitig_off || !out->unitig_bases) { snk_free(out); return snk_fail(SNK_E_NOMEM, err, errcap, "snk_count_graph: host allocation failed"); }
-    uint64_t w = 0;
-    for (uint64_t u = 0; u < U; ++u) {
-        uint64_t s = order[u], len = off[s + 1] - off[s];
-        out->unitig_off[u] = w;
-        memcpy(out->unitig_bases + w, bases.data() + off[s], len);
-        w += len;
-    }
-    out->unitig_off[U] = w;
     return SNK_OK;
 }
 
+}  // namespace
+
+// No C++ exception leaves an extern "C" entry point: a failed host allocation maps to SNK_E_NOMEM (the caller's exit code 99,
+// system/RunTime.cc:195-221), anything else to SNK_E_INTERNAL.
+#define SNK_GUARD(body)                                                                                       \
+    try { body } catch (const std::bad_alloc&) { return snk_fail(SNK_E_NOMEM, err, errcap, "host allocation failed"); } \
+    catch (const std::exception& ex) { return snk_fail(SNK_E_INTERNAL, err, errcap, "%s", ex.what()); }               \
+    catch (...) { return snk_fail(SNK_E_INTERNAL, err, errcap, "unexpected exception"); }
+
+extern "C" int snk_count_graph(snk_ctx* ctx, const snk_reads* in, const snk_params* p, snk_result* out, char* err, size_t errcap) {
+    SNK_GUARD(return count_graph_impl(ctx, in, p, out, err, errcap);)
+}
+
+extern "C" int snk_host_alloc_pinned(size_t bytes, void** out, char* err, size_t errcap) {
+    if (!out) return snk_fail(SNK_E_ARG, err, errcap, "snk_host_alloc_pinned: NULL argument");
+    *out = nullptr;
+    SNK_HIP_TRY(hipHostMalloc(out, std::max<size_t>(bytes, 16), hipHostMallocDefault));
+    return SNK_OK;
+}
+extern "C" void snk_host_free_pinned(void* p) { if (p) (void)hipHostFree(p); }
+
 extern "C" void snk_free(snk_result* r) {
     if (!r) return;
-    free(r->kmers); free(r->counts); free(r->ctx); free(r->unitig_off); free(r->unitig_bases); free(r->spectrum);
+    free(r->kmers); free(r->counts); free(r->ctx); free(r->unitig_off); free(r->unitig_bases); free(r->spectrum); free(r->bv_image);
     memset(r, 0, sizeof *r);
 }
 
-extern "C" int snk_write_bv(const char* path, uint64_t n_unitigs, const uint64_t* off, const uint8_t* bases, char* err, size_t errcap) {
+static int write_bv_impl(const char* path, uint64_t n_unitigs, const uint64_t* off, const uint8_t* bases, char* err, size_t errcap) {
     FILE* f = fopen(path, "wb");
     if (!f) return snk_fail(SNK_E_IO, err, errcap, "snk_write_bv: cannot open %s", path);
     bool ok = fwrite("BINWRITE", 1, 8, f) == 8 && fwrite(&n_unitigs, 8, 1, f) == 1;
@@ -140,31 +333,61 @@ extern "C" int snk_write_bv(const char* path, uint64_t n_unitigs, const uint64_t
     if (fclose(f) != 0) ok = false;
     return ok ? SNK_OK : snk_fail(SNK_E_IO, err, errcap, "snk_write_bv: short write to %s", path);
 }
+extern "C" int snk_write_bv(const char* path, uint64_t n_unitigs, const uint64_t* off, const uint8_t* bases, char* err, size_t errcap) {
+    SNK_GUARD(return write_bv_impl(path, n_unitigs, off, bases, err, errcap);)
+}
 
-extern "C" int snk_read_bv(const char* path, uint64_t* n_unitigs, uint64_t** off_out, uint8_t** bases_out, char* err, size_t errcap) {
+// The header is untrusted: the unitig count and every length are checked against the bytes that are really there before
+// anything is sized by them (a corrupt .bv must come back as SNK_E_IO, not as std::length_error through the C ABI).
+static int read_bv_impl(const char* path, uint64_t* n_unitigs, uint64_t** off_out, uint8_t** bases_out, char* err, size_t errcap) {
     FILE* f = fopen(path, "rb");
     if (!f) return snk_fail(SNK_E_IO, err, errcap, "snk_read_bv: cannot open %s", path);
+    struct closer { FILE* f; ~closer() { fclose(f); } } cl{f};
+    if (fseek(f, 0, SEEK_END) != 0) return snk_fail(SNK_E_IO, err, errcap, "snk_read_bv: cannot seek in %s", path);
+    const long fsz = ftell(f);
+    rewind(f);
     char magic[8];
     uint64_t n = 0;
-    if (fread(magic, 1, 8, f) != 8 || memcmp(magic, "BINWRITE", 8) || fread(&n, 8, 1, f) != 1) { fclose(f); return snk_fail(SNK_E_IO, err, errcap, "snk_read_bv: %s is not a BINWRITE file", path); }
-    std::vector<uint64_t> off(n + 1, 0);
-    std::vector<uint8_t> bases;
-    std::vector<uint8_t> buf;
+    if (fsz < 16 || fread(magic, 1, 8, f) != 8 || memcmp(magic, "BINWRITE", 8) || fread(&n, 8, 1, f) != 1)
+        return snk_fail(SNK_E_IO, err, errcap, "snk_read_bv: %s is not a BINWRITE file", path);
+    if (n > ((uint64_t)fsz - 16) / 4) return snk_fail(SNK_E_IO, err, errcap, "snk_read_bv: %s claims %llu unitigs in %ld bytes", path, (unsigned long long)n, fsz);
+    std::vector<uint8_t> raw((size_t)fsz - 16);
+    if (!raw.empty() && fread(raw.data(), 1, raw.size(), f) != raw.size()) return snk_fail(SNK_E_IO, err, errcap, "snk_read_bv: truncated file");
+    // pass 1: lengths and offsets
+    uint64_t* off = (uint64_t*)malloc((n + 1) * 8);
+    if (!off) return snk_fail(SNK_E_NOMEM, err, errcap, "snk_read_bv: host allocation failed");
+    size_t p = 0;
+    uint64_t tot = 0;
     for (uint64_t u = 0; u < n; ++u) {
         uint32_t len;
-        if (fread(&len, 4, 1, f) != 1) { fclose(f); return snk_fail(SNK_E_IO, err, errcap, "snk_read_bv: truncated file"); }
-        buf.resize((len + 3) / 4);
-        if (!buf.empty() && fread(buf.data(), 1, buf.size(), f) != buf.size()) { fclose(f); return snk_fail(SNK_E_IO, err, errcap, "snk_read_bv: truncated file"); }
-        off[u] = bases.size();
-        for (uint32_t j = 0; j < len; ++j) bases.push_back((uint8_t)((buf[j >> 2] >> (2 * (j & 3))) & 3u));
+        if (p + 4 > raw.size()) { free(off); return snk_fail(SNK_E_IO, err, errcap, "snk_read_bv: truncated file"); }
+        memcpy(&len, raw.data() + p, 4);
+        p += 4;
+        const size_t nb = ((size_t)len + 3) / 4;
+        if (nb > raw.size() - p) { free(off); return snk_fail(SNK_E_IO, err, errcap, "snk_read_bv: truncated file"); }
+        off[u] = tot;
+        tot += len;
+        p += nb;
     }
-    off[n] = bases.size();
-    fclose(f);
+    off[n] = tot;
+    uint8_t* bases = (uint8_t*)malloc(std::max<size_t>(tot, 16));
+    if (!bases) { free(off); return snk_fail(SNK_E_NOMEM, err, errcap, "snk_read_bv: host allocation failed"); }
+    // pass 2: four bases per byte
+    p = 0;
+    for (uint64_t u = 0; u < n; ++u) {
+        const uint64_t len = off[u + 1] - off[u];
+        const uint8_t* src = raw.data() + p + 4;
+        uint8_t* dst = bases + off[u];
+        for (uint64_t j = 0; j + 4 <= len; j += 4) { const uint8_t b = src[j >> 2]; dst[j] = b & 3u; dst[j + 1] = (b >> 2) & 3u; dst[j + 2] = (b >> 4) & 3u; dst[j + 3] = b >> 6; }
+        for (uint64_t j = len & ~3ull; j < len; ++j) dst[j] = (uint8_t)((src[j >> 2] >> (2 * (j & 3))) & 3u);
+        p += 4 + (len + 3) / 4;
+    }
     *n_unitigs = n;
-    *off_out = (uint64_t*)malloc((n + 1) * 8);
-    *bases_out = (uint8_t*)malloc(std::max<size_t>(bases.size(), 16));
-    if (!*off_out || !*bases_out) return snk_fail(SNK_E_NOMEM, err, errcap, "snk_read_bv: host allocation failed");
-    memcpy(*off_out, off.data(), (n + 1) * 8);
-    if (!bases.empty()) memcpy(*bases_out, bases.data(), bases.size());
+    *off_out = off;
+    *bases_out = bases;
     return SNK_OK;
+}
+extern "C" int snk_read_bv(const char* path, uint64_t* n_unitigs, uint64_t** off_out, uint8_t** bases_out, char* err, size_t errcap) {
+    if (!path || !n_unitigs || !off_out || !bases_out) return snk_fail(SNK_E_ARG, err, errcap, "snk_read_bv: NULL argument");
+    SNK_GUARD(return read_bv_impl(path, n_unitigs, off_out, bases_out, err, errcap);)
 }

@@ -79,7 +79,7 @@ class SnkResult(C.Structure):
                 ("counts", C.POINTER(C.c_uint32)), ("ctx", C.POINTER(C.c_uint8)), ("n_unitigs", C.c_uint64),
                 ("unitig_off", C.POINTER(C.c_uint64)), ("unitig_bases", C.POINTER(C.c_uint8)),
                 ("spectrum", C.POINTER(C.c_uint64)), ("spectrum_bins", C.c_uint32), ("reserved", C.c_uint32),
-                ("phase_ms", C.c_float * 8)]
+                ("phase_ms", C.c_float * 8), ("bv_image", C.POINTER(C.c_uint8)), ("bv_bytes", C.c_uint64)]
 
 
 class SnkHbv(C.Structure):
@@ -148,6 +148,8 @@ def _declare(lib: C.CDLL) -> None:
         "snk_dev_download": (C.c_int, [vp, vp, vp, sz, vp]),
         "snk_count_graph": (C.c_int, [vp, P(SnkReads), P(SnkParams), P(SnkResult), cp, sz]),
         "snk_free": (None, [P(SnkResult)]),
+        "snk_host_alloc_pinned": (C.c_int, [sz, P(vp), cp, sz]),
+        "snk_host_free_pinned": (None, [vp]),
         "snk_write_bv": (C.c_int, [cp, u64, vp, vp, cp, sz]),
         "snk_read_bv": (C.c_int, [cp, P(u64), P(P(u64)), P(P(C.c_uint8)), cp, sz]),
         "snk_hbv_from_unitigs": (C.c_int, [u32, u64, vp, vp, P(SnkHbv), cp, sz]),

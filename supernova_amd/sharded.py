@@ -448,6 +448,12 @@ class ShardedEngine:
 
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
         ev[0].record()
+        marks = []          # (name, event): finer breakdown of the join (compute sections vs exchanges), res.join_ms
+
+        def tick(name):
+            m_ev = torch.cuda.Event(enable_timing=True)
+            m_ev.record()
+            marks.append((name, m_ev))
         r = _lib.SnkDevReads()
         r.n_reads, r.rows, r.row_words, r.read_len = rows.shape[0], rows.data_ptr(), rows.shape[1], read_len
         if lens is not None:
@@ -567,6 +573,7 @@ class ShardedEngine:
             return t[:nbytes]
 
         # ---- links between fragments, decided on the owners: an end asks the rank that owns the state it points at
+        tick("start")
         all_F = comm.all_gather_int(F, dev)
         frag_off = [0]
         for x in all_F:
@@ -590,6 +597,7 @@ class ShardedEngine:
         flink_p = C.c_void_p()
         chk(lib.snk_shard_links_apply(e._ctx, lqbuf.data_ptr(), lans_back.data_ptr(), nlq, C.byref(flink_p), st, err, 512))
         res.n_link_queries = nlq
+        tick("links(x)")
         if self.join == "owner":
             # ---- owner-side join: every rank sees the job's LINK structure only (12 bytes per fragment), ranks the fragment
             # lists, places its own fragments and sends each to the rank that owns its unitig's head, which writes the unitig
@@ -597,6 +605,7 @@ class ShardedEngine:
             nk_all = comm.all_gather_v(dcopy("s_nk", fr.nk, F * 4), [x * 4 for x in all_F], alloc=lambda nb: pool.get("g_nk", max(nb, 8))[:nb])
             fl_all = comm.all_gather_v(dcopy("s_link", flink_p.value, F * 8), [x * 8 for x in all_F], alloc=lambda nb: pool.get("g_link", max(nb, 8))[:nb])
             d_frag_off = torch.tensor(frag_off, dtype=torch.int64, device=dev)
+            tick("gather_links(x)")
             fto, bto = (C.c_uint64 * W)(), (C.c_uint64 * W)()
             ranked = False
             if self.rank_mode == "partitioned":
@@ -605,8 +614,10 @@ class ShardedEngine:
                 m_spl, w1p = C.c_uint64(0), C.c_void_p()
                 chk(lib.snk_shard_prank_begin(e._ctx, Ft, nk_all.data_ptr(), fl_all.data_ptr(), frag_off[me], C.byref(m_spl), C.byref(w1p), st, err, 512))
                 m = int(m_spl.value)
+                tick("rank_setup+walk1")
                 shares = [(m * (q + 1) // W - m * q // W) * 16 for q in range(W)]
                 w1_all = comm.all_gather_v(dcopy("s_w1", w1p.value, shares[me]), shares, alloc=lambda nb: pool.get("g_w1", max(nb, 16))[:nb])
+                tick("gather_splitters(x)")
                 rto, circ = (C.c_uint64 * W)(), C.c_uint32(0)
                 chk(lib.snk_shard_prank_walk(e._ctx, w1_all.data_ptr(), d_frag_off.data_ptr(), rto, C.byref(circ), st, err, 512))
                 if not circ.value:
@@ -618,13 +629,16 @@ class ShardedEngine:
                     rsend = pool.get("s_rk", max(roff_[-1], 1) * 16)
                     chk(lib.snk_shard_prank_route(e._ctx, d_frag_off.data_ptr(), d_roff.data_ptr(), rsend.data_ptr(), st, err, 512))
                     torch.cuda.current_stream().synchronize()
+                    tick("jump+walk2+route")
                     rk_in, _ = comm.all_to_all_v(rsend[: roff_[-1] * 16], [c * 16 for c in rto], alloc=lambda nb: pool.get("g_rk", max(nb, 16))[:nb])
+                    tick("ranks_to_owners(x)")
                     chk(lib.snk_shard_place_ranked(e._ctx, K, rk_in.data_ptr(), rk_in.numel() // 16, d_frag_off.data_ptr(), fto, bto, st, err, 512))
                     ranked = True
                     res.exchange_bytes_rank = (m * 16, roff_[-1] * 16)
             if not ranked:      # a list is a circle (same verdict on every rank: it comes from replicated data), or rank_mode == "replicated"
                 chk(lib.snk_shard_place(e._ctx, K, Ft, nk_all.data_ptr(), fl_all.data_ptr(), d_frag_off.data_ptr(), frag_off[me], fto, bto, st, err, 512))
             res.join_ranking = "partitioned" if ranked else "replicated"
+            tick("place")
             fto, bto = [int(x) for x in fto], [int(x) for x in bto]
             hoff, boff_, bpad = route_offsets(fto, bto)
             d_hoff = torch.tensor(hoff[:W], dtype=torch.int64, device=dev)
@@ -633,13 +647,16 @@ class ShardedEngine:
             sb = pool.get("s_bases", max(boff_[-1], 16))
             chk(lib.snk_shard_route_fill(e._ctx, K, d_frag_off.data_ptr(), d_hoff.data_ptr(), d_boff.data_ptr(), hdr.data_ptr(), sb.data_ptr(), st, err, 512))
             torch.cuda.current_stream().synchronize()
+            tick("route_fill")
             hdr_in, hdr_bytes = comm.all_to_all_v(hdr[: hoff[-1] * 32], [c * 32 for c in fto], alloc=lambda nb: pool.get("g_hdr", max(nb, 8))[:nb])
             b_in, b_bytes = comm.all_to_all_v(sb[: boff_[-1]], bpad, alloc=lambda nb: pool.get("g_bases", max(nb, 16))[:nb])
             hseg, bseg = recv_segments(hdr_bytes, b_bytes)
+            tick("fragments_to_owners(x)")
             d_hseg = torch.tensor(hseg, dtype=torch.int64, device=dev)
             d_bseg = torch.tensor(bseg, dtype=torch.int64, device=dev)
             un = _lib.SnkShardUnitigs()
             chk(lib.snk_shard_emit(e._ctx, K, hseg[-1], hdr_in.data_ptr(), d_hseg.data_ptr(), d_bseg.data_ptr(), b_in.data_ptr(), C.byref(un), st, err, 512))
+            tick("emit")
             res.joined = un
             res.n_unitigs = int(un.n_unitigs)
             res.exchange_bytes_join = (Ft * 12, hoff[-1] * 32 + boff_[-1])
@@ -702,6 +719,8 @@ class ShardedEngine:
         names = ["partition", "compact", "exchange", "count", "prune", "fragments", "join"]
         res.phase_ms = {names[i]: ev[i].elapsed_time(ev[i + 1]) for i in range(7)}
         res.phase_ms["total"] = ev[0].elapsed_time(ev[7])
+        # sections of the join; "(x)" = an exchange (transport + the waits for the other ranks), the rest is this rank's compute
+        res.join_ms = {marks[i + 1][0]: marks[i][1].elapsed_time(marks[i + 1][1]) for i in range(len(marks) - 1)}
         res.kernel_ms = {"count": float(fr.count_kernel_ms)}
         res.buckets_split = int(fr.buckets_split)
         return res

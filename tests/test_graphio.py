@@ -51,3 +51,28 @@ def test_bv_roundtrip_and_layout(snk, tmp_path):
     p2 = tmp_path / "oracle.bv"
     assert lib.sno_write_bv(str(p2).encode(), C.byref(u)) == 0
     assert p2.read_bytes() == raw
+
+
+def test_read_bv_rejects_corrupt_headers(snk, tmp_path):
+    """The unitig count and every length come from the file: a header that claims more than the bytes hold is an I/O error
+    through the C ABI, never an exception or an abort (exit-code contract of the stage: 1, not SIGABRT)."""
+    import struct
+    from supernova_amd import graphio
+    from supernova_amd.lib import SnkError
+    good = tmp_path / "g.bv"
+    graphio.write_bv(str(good), np.array([0, 5, 9], dtype=np.uint64), np.array([0, 1, 2, 3, 0, 3, 2, 1, 0], dtype=np.uint8))
+    raw = good.read_bytes()
+    cases = {
+        "count": raw[:8] + struct.pack("<Q", 1 << 60) + raw[16:],            # absurd unitig count
+        "length": raw[:16] + struct.pack("<I", 0xFFFFFFF0) + raw[20:],       # first unitig claims 4 G bases
+        "cut": raw[:-1],                                                     # last payload byte missing
+        "magic": b"BINWRITX" + raw[8:],
+        "short": raw[:11],
+    }
+    for name, blob in cases.items():
+        f = tmp_path / f"{name}.bv"
+        f.write_bytes(blob)
+        with pytest.raises(SnkError):
+            graphio.read_bv(str(f))
+    off, bases = graphio.read_bv(str(good))
+    assert list(off) == [0, 5, 9] and list(bases) == [0, 1, 2, 3, 0, 3, 2, 1, 0]

@@ -31,6 +31,11 @@ def worker(r):
             c._end_section()
             torch.cuda.synchronize(); t1 = time.time()
             out[r] = (t1 - t0, res.phase_ms, res.n_kmers, res.n_frags, res.n_queries, res.n_unitigs, res.n_instances)
+            jm = getattr(res, "join_ms", {})
+            if r == 0 and jm:
+                comp = sum(v for k, v in jm.items() if not k.endswith("(x)"))
+                print(f"rep{rep} rank0 join sections (ms; (x) = exchange incl. waiting for the other ranks): "
+                      + " ".join(f"{k}={v:.1f}" for k, v in jm.items()) + f" | compute {comp:.1f}", flush=True)
             world.barrier_obj.wait()
             if r == 0:
                 for q in range(W):
