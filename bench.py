@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--error-free", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=float, default=1e6, help="reads of the workload timed on the host cores")
+    ap.add_argument("--cpu-threads", default="16,64,256", help="thread counts the CPU baseline is timed at (the best is reported)")
     ap.add_argument("--sharded", action="store_true", help="force the sharded (multi-GPU) code path even with one rank")
     ap.add_argument("--sorted-table", action="store_true",
                     help="also sort the retained k-mer table by key (+~40 ms; the reference's dictionary is an unordered hash set, "
@@ -61,7 +62,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(sp_full, K: int, sample_reads: int):
+def cpu_baseline(sp_full, K: int, sample_reads: int, threads=(16, 64, 256)):
     """Reference CPU path on a bounded sample (first `sample_reads` reads of a data set with the same coverage)."""
     import numpy as np
     from supernova_amd import synth
@@ -74,14 +75,24 @@ def cpu_baseline(sp_full, K: int, sample_reads: int):
         sys.path.insert(0, str(ROOT / "tests"))
         import refio
         asc = synth.codes_to_ascii(synth.unpack_rows(rows, sp.read_len))
+        # the reference's MapReduce engine does not scale with the core count (its best is a few dozen threads): the sample
+        # is timed at several thread counts and the best one is reported, with the whole sweep in `sample`
+        sweep = sorted({t for t in threads if 0 < t <= cores} or {cores})
+        best, runs = None, []
         with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as td:
             refio.write_snkrd(Path(td) / "in.snkrd", np.full(n, sp.read_len), asc, quals, bc)
-            out = refio.run_ref(Path(td) / "in.snkrd", Path(td) / "out", threads=cores, mode="time", timeout=1800)
-        m = re.search(r"SNREF_TIME seconds=([0-9.]+) threads=(\d+) reads=(\d+) kmer_instances=(\d+)", out)
-        secs, inst = float(m.group(1)), int(m.group(4))
-        return {"value": inst / secs / 1e9, "unit": "Gk-mers/s", "cores": cores, "kind": "reference",
+            for t in sweep:
+                out = refio.run_ref(Path(td) / "in.snkrd", Path(td) / f"out{t}", threads=t, mode="time", timeout=1800)
+                m = re.search(r"SNREF_TIME seconds=([0-9.]+) threads=(\d+) reads=(\d+) kmer_instances=(\d+)", out)
+                secs, inst = float(m.group(1)), int(m.group(4))
+                runs.append((t, secs))
+                if best is None or secs < best[1]:
+                    best = (t, secs, inst)
+        t, secs, inst = best
+        return {"value": inst / secs / 1e9, "unit": "Gk-mers/s", "cores": t, "kind": "reference",
                 "sample": f"{n} reads x {sp.read_len} bp of the same synthetic model ({inst} k-mer instances), "
-                          f"buildReadQGraph48 (count+unitigs+HBV, no read pathing), {secs:.2f} s on {cores} threads"}
+                          f"buildReadQGraph48 (count+unitigs+HBV, no read pathing); best of "
+                          + ", ".join(f"{tt} threads {ss:.2f} s" for tt, ss in runs) + f" on a {cores}-thread host"}
     sys.path.insert(0, str(ROOT / "tests"))
     import oracle_lib
     n = min(n, 200_000)
@@ -221,13 +232,14 @@ def main():
         count_ms = sum(k["count"] for k in kernel_ms) / len(kernel_ms)
         units = float(res.n_instances)
         achieved = units * ALG_BYTES_PER_KMER[K] / (count_ms * 1e-3) / 1e9
+        # HBM bytes of one count-kernel launch from the PMC passes (profiles/traffic.json, keyed by reads / K / mode)
         traffic = None
         tf = ROOT / "profiles" / "traffic.json"
+        mode = "grouped" if args.grouped else ("sharded" if use_dist else "single")
         if tf.exists():
             try:
-                tj = json.loads(tf.read_text())
-                if tj.get("reads_per_gpu") == per_gpu and tj.get("K") == K:
-                    traffic = tj.get("count_kernel_hbm_bytes_per_launch")
+                ent = json.loads(tf.read_text()).get("entries", {}).get(f"{per_gpu}_k{K}_{mode}")
+                traffic = ent["count_kernel_hbm_bytes_per_launch"] if ent else None
             except Exception:
                 traffic = None
         out = {
@@ -272,7 +284,7 @@ def main():
 
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(sp, K, args.cpu_sample)
+                out["cpu_baseline"] = cpu_baseline(sp, K, args.cpu_sample, tuple(int(x) for x in args.cpu_threads.split(",")))
             except Exception as ex:  # the baseline is a report, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "Gk-mers/s", "cores": os.cpu_count(), "kind": "reference",
                                        "sample": f"failed: {ex}"}

@@ -351,6 +351,13 @@ int snk_hbv_from_unitigs(uint32_t K, uint64_t n_unitigs, const uint64_t* unitig_
 int snk_dev_hbv(snk_ctx* ctx, uint32_t K, uint64_t n_unitigs, const void* d_unitig_off, const void* d_unitig_bases,
                 snk_hbv* out, float* device_ms, void* stream, char* err, size_t errcap);
 void snk_hbv_free(snk_hbv* h);
+/* f2: hbv.Involution (paths/HyperBasevector.cc:685-697; 10X/runstages/RunStages.cc:418): inv[e] = edge that is e's reverse
+ * complement -- and the files DF keeps the graph in: a.hbv = BinaryWriter::writeFile(HyperBasevector)
+ * (paths/HyperBasevector.cc:121-125, graph/DigraphTemplate.h:3092-3097) and a.inv (vec<int>), byte for byte.  The unitig arrays
+ * are the ones the snk_hbv was built from (BVComp order); path_inv may be NULL. */
+int snk_hbv_involution(const snk_hbv* h, uint64_t n_unitigs, int32_t* inv /* [n_edges] */, char* err, size_t errcap);
+int snk_write_hbv(const char* path_hbv, const char* path_inv, uint32_t K, uint64_t n_unitigs, const uint64_t* unitig_off,
+                  const uint8_t* unitig_bases, const snk_hbv* h, char* err, size_t errcap);
 
 /* ---- f3: barcode ids on the device --------------------------------------------------------------
  * BcIndexer, lib/tada/src/utils.rs:101-164: whitelist line -> index (identical lines: the last one wins); a read's

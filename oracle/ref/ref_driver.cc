@@ -10,6 +10,9 @@
 //   kmers.bin      sorted retained k-mers: 3xu32 key, u32 count, u8 ctx(+3 pad)
 //   unitigs.txt    canonical unitigs sorted by BVComp (HBVFromEdges.cc:106-111)
 //   hbv.txt        buildHBVFromEdges result on the *sorted* unitigs
+//   a.hbv, a.inv   that graph and its involution as DF writes them (BinaryWriter::writeFile; RunStages.cc:418, DF a.base files)
+//   paths.txt      (K=48, mode dump) read paths of pathReads(..., NEW_ALIGNER=True) (BuildReadQGraph48.cc:1441-1469,
+//                  HBVPather::algorithmTwo :1217-1336): per read "offset n e0 e1 ..." with HBV edge ids
 //   stats/histogram_kmer_count.json  (written by the reference itself)
 // Built only by oracle/ref/build_ref.sh from the sources where they lie in
 // /root/reference; the binary lands in oracle/_ref/ (git-ignored).
@@ -126,6 +129,7 @@ int main(int argc, char** argv) {
             pq.push_back(PQVec(q));
         }
     }
+    quals.store();          // the pathing stage reads the quality file back (VirtualMasterVec), as DF does
     vec<int32_t> bc;
     if (in.has_bc) bc.assign(in.bc.begin(), in.bc.end());
     vec<int32_t> const* bcp = in.has_bc ? &bc : nullptr;
@@ -218,6 +222,30 @@ int main(int argc, char** argv) {
     vecbvec edges;
     edges.reserve(pDict->size() / 100);
     buildEdges(*pDict, &edges);
+#ifndef SNK_REF_K60
+    // ---- read paths: the pPaths != nullptr branch of buildReadQGraph48 (:1749-1769) -- graph from the edges as built, then
+    //      pathReads with the new aligner (RunStages.cc:405-406 passes useNewAligner = True)
+    {
+        HyperBasevector hbvp;
+        vec<int> fwdp, revp;
+        buildHBVFromEdges(edges, K, &hbvp, &fwdp, &revp);
+        reads.WriteAll(work + "/data/frag_reads_orig.fastb");
+        {
+            VirtualMasterVec<PQVec> vquals(quals.filename());
+            VirtualMasterVec<BaseVec> vreads(work + "/data/frag_reads_orig.fastb");
+            pathReads(vreads, vquals, *pDict, edges, hbvp, fwdp, revp, work + "/tmp.paths", True, False);
+        }
+        ReadPathVec paths(work + "/tmp.paths");
+        FILE* f = fopen((outdir + "/paths.txt").c_str(), "w");
+        for (size_t r = 0; r < paths.size(); ++r) {
+            ReadPath const& rp = paths[r];
+            fprintf(f, "%d %lu", rp.getOffset(), (unsigned long)rp.size());
+            for (size_t i = 0; i < rp.size(); ++i) fprintf(f, " %d", rp[i]);
+            fprintf(f, "\n");
+        }
+        fclose(f);
+    }
+#endif
     delete pDict;
 
     std::vector<size_t> order(edges.size());
@@ -250,6 +278,12 @@ int main(int argc, char** argv) {
             fprintf(f, "E %d %d %d %s\n", e, to_left[e], to_right[e], bvstr(hbv.EdgeObject(e)).c_str());
         for (size_t u = 0; u < sorted.size(); ++u) fprintf(f, "X %lu %d %d\n", (unsigned long)u, fwd[u], rev[u]);
         fclose(f);
+    }
+    {
+        vec<int> inv;
+        hbv.Involution(inv);
+        BinaryWriter::writeFile(work + "/a.hbv", hbv);
+        BinaryWriter::writeFile(work + "/a.inv", inv);
     }
     printf("SNREF_DUMP reads=%lu kmer_instances=%lu unitigs=%lu hbv_edges=%d hbv_vertices=%d\n",
            (unsigned long)in.n, (unsigned long)nInst, (unsigned long)sorted.size(), hbv.EdgeObjectCount(), hbv.N());

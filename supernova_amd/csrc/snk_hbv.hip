@@ -136,6 +136,95 @@ extern "C" int snk_hbv_from_unitigs(uint32_t K, uint64_t U, const uint64_t* off,
     return hbv_flood(U, pal.data(), ee.data(), ee.size(), vtx_of.data(), run_beg.data(), nruns, out, err, errcap);
 }
 
+// ---- f2: the involution and the files DF keeps the graph in.
+// hbv.Involution(inv) (paths/HyperBasevector.cc:685-697, called at 10X/runstages/RunStages.cc:418): inv[e] = the edge whose
+// sequence is the reverse complement of edge e's.  The reference finds the pairs by sorting the edges and their reverse
+// complements; here they are known by construction: the two copies of a unitig (a palindrome is its own partner).
+extern "C" int snk_hbv_involution(const snk_hbv* h, uint64_t n_unitigs, int32_t* inv, char* err, size_t errcap) {
+    if (!h || (!inv && h->n_edges)) return snk_fail(SNK_E_ARG, err, errcap, "snk_hbv_involution: NULL argument");
+    for (int32_t e = 0; e < h->n_edges; ++e) inv[e] = -1;
+    for (uint64_t u = 0; u < n_unitigs; ++u) {
+        const int32_t f = h->fwd_xlat[u], r = h->rev_xlat[u];
+        if (f < 0 || r < 0 || f >= h->n_edges || r >= h->n_edges) return snk_fail(SNK_E_ARG, err, errcap, "snk_hbv_involution: inconsistent translation tables");
+        inv[f] = r;
+        inv[r] = f;
+    }
+    for (int32_t e = 0; e < h->n_edges; ++e) if (inv[e] < 0) return snk_fail(SNK_E_ARG, err, errcap, "snk_hbv_involution: edge %d has no partner", e);
+    return SNK_OK;
+}
+
+// a.hbv = BinaryWriter::writeFile(HyperBasevector): "BINWRITE", int K, from_ (vec<vec<int>>: u64 n, per vertex u64 m + m ints),
+// from_edge_obj_, to_edge_obj_ (same shape), edges_ (u64 E, per edge u32 bases + ceil(bases/4) bytes, base j at bits 2(j%4))
+// (paths/HyperBasevector.cc:121-125, graph/Digraph.h:381-382, graph/DigraphTemplate.h:3092-3097, feudal/BinaryStream.h:488-493).
+// Adjacency order is AddEdge's (DigraphTemplate.h:2572-2582): a vertex's out-edges ascending by target vertex, equal targets
+// in edge-id order (upper_bound insertion); in-edges likewise by source vertex.  a.inv = "BINWRITE", u64 E, E ints.
+static int write_hbv_impl(const char* path_hbv, const char* path_inv, uint32_t K, uint64_t U, const uint64_t* off, const uint8_t* bases,
+                          const snk_hbv* h, char* err, size_t errcap) {
+    const int32_t N = h->n_vertices, E = h->n_edges;
+    std::vector<std::vector<std::pair<int32_t, int32_t>>> from(N), to(N);      // (other vertex, edge)
+    for (int32_t e = 0; e < E; ++e) {
+        const int32_t v = h->v_left[e], w = h->v_right[e];
+        if (v < 0 || w < 0 || v >= N || w >= N || h->src_unitig[e] < 0 || (uint64_t)h->src_unitig[e] >= U)
+            return snk_fail(SNK_E_ARG, err, errcap, "snk_write_hbv: edge %d is out of range", e);
+        from[v].push_back({w, e});
+        to[w].push_back({v, e});
+    }
+    for (auto& l : from) std::stable_sort(l.begin(), l.end(), [](const std::pair<int32_t, int32_t>& a, const std::pair<int32_t, int32_t>& b) { return a.first < b.first; });
+    for (auto& l : to) std::stable_sort(l.begin(), l.end(), [](const std::pair<int32_t, int32_t>& a, const std::pair<int32_t, int32_t>& b) { return a.first < b.first; });
+    FILE* f = fopen(path_hbv, "wb");
+    if (!f) return snk_fail(SNK_E_IO, err, errcap, "snk_write_hbv: cannot open %s", path_hbv);
+    bool ok = fwrite("BINWRITE", 1, 8, f) == 8;
+    const int32_t k32 = (int32_t)K;
+    ok = ok && fwrite(&k32, 4, 1, f) == 1;
+    auto put_lists = [&](const std::vector<std::vector<std::pair<int32_t, int32_t>>>& ls, bool second) {
+        const uint64_t n = ls.size();
+        ok = ok && fwrite(&n, 8, 1, f) == 1;
+        std::vector<int32_t> tmp;
+        for (const auto& l : ls) {
+            const uint64_t m = l.size();
+            tmp.resize(m);
+            for (uint64_t i = 0; i < m; ++i) tmp[i] = second ? l[i].second : l[i].first;
+            ok = ok && fwrite(&m, 8, 1, f) == 1 && (m == 0 || fwrite(tmp.data(), 4, m, f) == m);
+        }
+    };
+    put_lists(from, false);
+    put_lists(from, true);
+    put_lists(to, true);
+    const uint64_t e64 = (uint64_t)E;
+    ok = ok && fwrite(&e64, 8, 1, f) == 1;
+    std::vector<uint8_t> buf;
+    for (int32_t e = 0; ok && e < E; ++e) {
+        const uint64_t u = (uint64_t)h->src_unitig[e], len64 = off[u + 1] - off[u];
+        if (len64 > 0xFFFFFFFFull) { fclose(f); return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_write_hbv: edge longer than 2^32 bases"); }
+        const uint32_t len = (uint32_t)len64;
+        const uint8_t* b = bases + off[u];
+        buf.assign((len + 3) / 4, 0);
+        if (!h->is_rc[e]) for (uint32_t j = 0; j < len; ++j) buf[j >> 2] |= (uint8_t)((b[j] & 3u) << (2 * (j & 3)));
+        else for (uint32_t j = 0; j < len; ++j) buf[j >> 2] |= (uint8_t)(((b[len - 1 - j] & 3u) ^ 3u) << (2 * (j & 3)));
+        ok = fwrite(&len, 4, 1, f) == 1 && (buf.empty() || fwrite(buf.data(), 1, buf.size(), f) == buf.size());
+    }
+    if (fclose(f) != 0) ok = false;
+    if (!ok) return snk_fail(SNK_E_IO, err, errcap, "snk_write_hbv: short write to %s", path_hbv);
+    if (path_inv) {
+        std::vector<int32_t> inv((size_t)E);
+        int rc = snk_hbv_involution(h, U, inv.data(), err, errcap);
+        if (rc) return rc;
+        f = fopen(path_inv, "wb");
+        if (!f) return snk_fail(SNK_E_IO, err, errcap, "snk_write_hbv: cannot open %s", path_inv);
+        ok = fwrite("BINWRITE", 1, 8, f) == 8 && fwrite(&e64, 8, 1, f) == 1 && (E == 0 || fwrite(inv.data(), 4, (size_t)E, f) == (size_t)E);
+        if (fclose(f) != 0) ok = false;
+        if (!ok) return snk_fail(SNK_E_IO, err, errcap, "snk_write_hbv: short write to %s", path_inv);
+    }
+    return SNK_OK;
+}
+extern "C" int snk_write_hbv(const char* path_hbv, const char* path_inv, uint32_t K, uint64_t n_unitigs, const uint64_t* unitig_off,
+                             const uint8_t* unitig_bases, const snk_hbv* h, char* err, size_t errcap) {
+    if (!path_hbv || !h || (n_unitigs && (!unitig_off || !unitig_bases))) return snk_fail(SNK_E_ARG, err, errcap, "snk_write_hbv: NULL argument");
+    try { return write_hbv_impl(path_hbv, path_inv, K, n_unitigs, unitig_off, unitig_bases, h, err, errcap); }
+    catch (const std::bad_alloc&) { return snk_fail(SNK_E_NOMEM, err, errcap, "snk_write_hbv: host allocation failed"); }
+    catch (...) { return snk_fail(SNK_E_INTERNAL, err, errcap, "snk_write_hbv: unexpected exception"); }
+}
+
 extern "C" void snk_hbv_free(snk_hbv* h) {
     if (!h) return;
     free(h->v_left); free(h->v_right); free(h->src_unitig); free(h->is_rc); free(h->fwd_xlat); free(h->rev_xlat); free(h->bvcomp_order);

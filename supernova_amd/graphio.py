@@ -79,6 +79,30 @@ def hbv_from_unitigs(K: int, off: np.ndarray, bases: np.ndarray) -> dict:
     return out
 
 
+def write_hbv(path_hbv, path_inv, K: int, off: np.ndarray, bases: np.ndarray) -> np.ndarray:
+    """Unitigs in BVComp order -> a.hbv (+ a.inv) as DF writes them; returns the involution."""
+    lib = _lib.load()
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    h = _lib.SnkHbv()
+    err = C.create_string_buffer(512)
+    nu = len(off) - 1
+    rc = lib.snk_hbv_from_unitigs(K, nu, off.ctypes.data, bases.ctypes.data, C.byref(h), err, 512)
+    if rc:
+        raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+    try:
+        inv = np.zeros(max(h.n_edges, 1), dtype=np.int32)
+        rc = lib.snk_hbv_involution(C.byref(h), nu, inv.ctypes.data, err, 512)
+        if not rc:
+            rc = lib.snk_write_hbv(str(path_hbv).encode(), str(path_inv).encode() if path_inv else None, K, nu, off.ctypes.data,
+                                   bases.ctypes.data, C.byref(h), err, 512)
+        if rc:
+            raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+        return inv[:h.n_edges].copy()
+    finally:
+        lib.snk_hbv_free(C.byref(h))
+
+
 def hbv_text(unitigs: list[str], h: dict) -> str:
     """Same text layout as oracle/ref/ref_driver.cc's hbv.txt (golden fixtures)."""
     comp = str.maketrans("ACGT", "TGCA")

@@ -155,6 +155,8 @@ def _declare(lib: C.CDLL) -> None:
         "snk_hbv_from_unitigs": (C.c_int, [u32, u64, vp, vp, P(SnkHbv), cp, sz]),
         "snk_dev_hbv": (C.c_int, [vp, u32, u64, vp, vp, P(SnkHbv), P(C.c_float), vp, cp, sz]),
         "snk_hbv_free": (None, [P(SnkHbv)]),
+        "snk_hbv_involution": (C.c_int, [P(SnkHbv), u64, vp, cp, sz]),
+        "snk_write_hbv": (C.c_int, [cp, cp, u32, u64, vp, vp, P(SnkHbv), cp, sz]),
         "snk_read_fastb": (C.c_int, [cp, P(u64), P(u32), P(P(C.c_uint16)), P(P(u32)), cp, sz]),
         "snk_read_qualp": (C.c_int, [cp, u64, u32, vp, cp, sz]),
         "snk_read_bci": (C.c_int, [cp, u64, vp, P(u64), cp, sz]),

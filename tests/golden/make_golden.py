@@ -159,6 +159,7 @@ def make(name: str) -> None:
                 exp_counts=d60["kmers"]["count"], exp_ctx=d60["kmers"]["ctx"],
                 exp_unitigs=np.frombuffer("\n".join(d60["unitigs"]).encode(), dtype=np.uint8),
                 exp_hbv=np.frombuffer(d60["hbv"].encode(), dtype=np.uint8),
+                exp_ahbv=d60["a.hbv"], exp_ainv=d60["a.inv"],
                 ref_summary=np.frombuffer(s60.encode(), dtype=np.uint8))
             print(f"{name}_k60: {s60}")
     summary = [l for l in log.splitlines() if l.startswith("SNREF_DUMP")][-1]
@@ -172,6 +173,8 @@ def make(name: str) -> None:
         exp_unitigs=np.frombuffer("\n".join(d["unitigs"]).encode(), dtype=np.uint8),
         exp_hbv=np.frombuffer(d["hbv"].encode(), dtype=np.uint8),
         exp_hist=np.asarray(d["hist"]["vals"] if d["hist"] else [], dtype=np.int64),
+        exp_path_off=d["path_off"], exp_path_n=d["path_n"], exp_path_edges=d["path_edges"],
+        exp_ahbv=d["a.hbv"], exp_ainv=d["a.inv"],
         meta=np.frombuffer(repr(case["meta"]).encode(), dtype=np.uint8),
         ref_summary=np.frombuffer(summary.encode(), dtype=np.uint8),
     )

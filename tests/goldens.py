@@ -29,6 +29,12 @@ class Case:
         self.exp_unitigs = bytes(z["exp_unitigs"]).decode().split("\n") if len(z["exp_unitigs"]) else []
         self.exp_hbv = bytes(z["exp_hbv"]).decode()
         self.exp_hist = z["exp_hist"]
+        # f1: read paths of pathReads (offset, HBV edge ids per read); f2: a.hbv / a.inv file bytes
+        self.exp_path_off = z["exp_path_off"]
+        self.exp_path_n = z["exp_path_n"]
+        self.exp_path_edges = z["exp_path_edges"]
+        self.exp_ahbv = bytes(z["exp_ahbv"])
+        self.exp_ainv = bytes(z["exp_ainv"])
 
 
 _cache: dict[str, Case] = {}
@@ -52,6 +58,8 @@ class Case60:
         self.exp_ctx = z["exp_ctx"]
         self.exp_unitigs = bytes(z["exp_unitigs"]).decode().split("\n") if len(z["exp_unitigs"]) else []
         self.exp_hbv = bytes(z["exp_hbv"]).decode()
+        self.exp_ahbv = bytes(z["exp_ahbv"])
+        self.exp_ainv = bytes(z["exp_ainv"])
 
 
 K60_CASES = ["adversarial", "synth_20k_err"]

@@ -52,4 +52,17 @@ def read_ref_dump(outdir, K=48):
     out["hbv"] = (outdir / "hbv.txt").read_text()
     hist = outdir / "stats" / "histogram_kmer_count.json"
     out["hist"] = json.loads(hist.read_text()) if hist.exists() else None
+    # f1/f2: read paths (K=48 dumps), the graph file and its involution as DF writes them
+    pp = outdir / "paths.txt"
+    if pp.exists():
+        offs, ns, edges = [], [], []
+        for line in pp.read_text().splitlines():
+            t = line.split()
+            offs.append(int(t[0])); ns.append(int(t[1])); edges.extend(int(x) for x in t[2:])
+        out["path_off"] = np.asarray(offs, dtype=np.int32)
+        out["path_n"] = np.asarray(ns, dtype=np.int32)
+        out["path_edges"] = np.asarray(edges, dtype=np.int32)
+    for nm in ("a.hbv", "a.inv"):
+        f = outdir / nm
+        out[nm] = np.frombuffer(f.read_bytes(), dtype=np.uint8) if f.exists() else None
     return out

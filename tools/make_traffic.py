@@ -1,0 +1,33 @@
+"""profiles/traffic.json from the FETCH_SIZE / WRITE_SIZE PMC passes of bench.py (one pass per counter, nothing else traced):
+HBM bytes of ONE launch of the count kernel, keyed by '<reads>_k<K>_<mode>' -- what bench.py reports as roofline.traffic.
+usage: python tools/make_traffic.py <key> <fetch counter_collection.csv> <write counter_collection.csv> [...more triples]
+gfx950 correction (MI355X_MICROARCH.md, HBM/rocprofv3): FETCH_SIZE counts the 128-B requests of a wide coalesced stream
+at 64 B -> x2 for the record stream the count kernel reads; WRITE_SIZE as reported (KB)."""
+import csv, json, sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+out = ROOT / "profiles" / "traffic.json"
+doc = json.loads(out.read_text()) if out.exists() else {}
+entries = doc.get("entries", {})
+
+
+def per_launch(path, counter):
+    tot, n, name = 0.0, 0, None
+    for r in csv.DictReader(open(path)):
+        if "snk_count_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            tot += float(r["Counter_Value"]); n += 1; name = r["Kernel_Name"].split("(")[1 if r["Kernel_Name"].startswith("void (") else 0]
+    return tot / max(n, 1), n, name
+
+
+a = sys.argv[1:]
+for i in range(0, len(a), 3):
+    key, f_csv, w_csv = a[i:i + 3]
+    f, nf, name = per_launch(f_csv, "FETCH_SIZE")
+    w, nw, _ = per_launch(w_csv, "WRITE_SIZE")
+    entries[key] = {"FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w, "launches_averaged": [nf, nw],
+                    "count_kernel_hbm_bytes_per_launch": (2 * f + w) * 1024, "source": [Path(f_csv).name, Path(w_csv).name]}
+    print(key, entries[key])
+doc = {"note": "HBM bytes per launch of snk_count_kernel = (2 x FETCH_SIZE + WRITE_SIZE) KB from separate rocprofv3 --pmc passes of "
+               "bench.py (--steps 1 --warmup 1); FETCH_SIZE x2 = the gfx950 correction for wide coalesced reads (MI355X_MICROARCH.md)",
+       "entries": entries}
+out.write_text(json.dumps(doc, indent=1) + "\n")
