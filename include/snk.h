@@ -351,6 +351,25 @@ int snk_hbv_from_unitigs(uint32_t K, uint64_t n_unitigs, const uint64_t* unitig_
 int snk_dev_hbv(snk_ctx* ctx, uint32_t K, uint64_t n_unitigs, const void* d_unitig_off, const void* d_unitig_bases,
                 snk_hbv* out, float* device_ms, void* stream, char* err, size_t errcap);
 void snk_hbv_free(snk_hbv* h);
+/* f1: read pathing on the device -- pathReads with the new aligner (paths/long/BuildReadQGraph48.cc:1441-1469):
+ * Pather::path (:705-748), HBVPather::algorithmTwo (:1217-1336), pathPartsToReadPath (:1393-1428) and
+ * ExtendReadPath::attemptLeftRightExtension (paths/long/ExtendReadPath.cc:108-358), over a k-mer -> (edge, offset) dictionary
+ * built from the unitigs (:1656-1664).  Reads are pathed untrimmed (packed rows + quality rows + lengths of snk_dev_reads;
+ * good_len / bc are not used).  The unitigs are the device arrays of snk_dev_count_graph, h their graph from snk_dev_hbv
+ * (bvcomp_order maps its unitig numbering to the device arrays; NULL = the arrays are already in BVComp order).
+ * Result (device memory of the context, valid until its next top-level call): per read the offset of the read on its first
+ * edge (ReadPath::mOffset, may be negative), its number of edges and their HBV edge ids (start[r] .. start[r] + n_edges[r]). */
+typedef struct snk_dev_paths {
+    uint64_t n_reads, n_edges_total;
+    const void* offset;        /* i32[n_reads] */
+    const void* n_edges;       /* u32[n_reads] */
+    const void* start;         /* u64[n_reads + 1] */
+    const void* edges;         /* i32[n_edges_total] */
+    uint64_t dict_slots;
+    float dict_ms, path_ms;    /* HIP events: graph tables + packed unitigs + dictionary; pathing + gather */
+} snk_dev_paths;
+int snk_dev_path_reads(snk_ctx* ctx, uint32_t K, const snk_dev_reads* in, uint64_t n_unitigs, const void* d_unitig_off, const void* d_unitig_bases,
+                       const snk_hbv* h, snk_dev_paths* out, void* stream, char* err, size_t errcap);
 /* f2: hbv.Involution (paths/HyperBasevector.cc:685-697; 10X/runstages/RunStages.cc:418): inv[e] = edge that is e's reverse
  * complement -- and the files DF keeps the graph in: a.hbv = BinaryWriter::writeFile(HyperBasevector)
  * (paths/HyperBasevector.cc:121-125, graph/DigraphTemplate.h:3092-3097) and a.inv (vec<int>), byte for byte.  The unitig arrays

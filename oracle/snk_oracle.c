@@ -651,3 +651,308 @@ void sno_hbv_free(sno_hbv* h) {
     free(h->v_left); free(h->v_right); free(h->src_unitig); free(h->is_rc); free(h->fwd_xlat); free(h->rev_xlat);
     memset(h, 0, sizeof *h);
 }
+
+/* ================================================================================================
+ * f1  read pathing: every read onto the unitig graph.
+ *   Pather::path                          paths/long/BuildReadQGraph48.cc:705-748   (seed by dictionary, extend by exact match)
+ *   HBVPather::algorithmTwo               :1217-1336   (hanging-edge seeds, captured gaps, short last seed, connectivity)
+ *   pathPartsToReadPath                   :1393-1428
+ *   ExtendReadPath::attemptLeft/RightwardExtension, scoreLeft/RightOverlap   paths/long/ExtendReadPath.cc:15-358
+ *   dictionary fill (k-mer -> edge, offset)   :1656-1664 (buildGraphFromMSP) == KDef::set in buildEdges
+ * Reads are pathed UNTRIMMED (mReads[readId]).  Edge ids in the result are HBV edge ids (fwd/rev translation of the unitig).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct { kmer_t k; uint32_t unitig, offset; int used; } pdict_ent;
+typedef struct { pdict_ent* e; uint64_t mask; } pdict;
+static uint64_t pd_hash(kmer_t k) { uint64_t x = k.hi * 0x9E3779B97F4A7C15ull ^ (k.lo + 0xD1B54A32D192ED03ull) * 0xC2B2AE3D27D4EB4Full; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; return x ^ (x >> 32); }
+static const pdict_ent* pd_find(const pdict* d, kmer_t k, uint32_t K) {       /* KmerDict::findEntry canonicalises, kmers/ReadPather.h:241-245 */
+    kmer_t r = kmer_rc(k, K);
+    if (kmer_lt(r, k)) k = r;
+    for (uint64_t s = pd_hash(k) & d->mask;; s = (s + 1) & d->mask) {
+        if (!d->e[s].used) return NULL;
+        if (kmer_eq(d->e[s].k, k)) return &d->e[s];
+    }
+}
+typedef struct { int gap; uint32_t unitig; int rc; uint32_t off, len, elen; } ppart;   /* PathPart :622-689 (len of a gap = its k-mers) */
+typedef struct {
+    uint32_t K;
+    const sno_unitigs* u;
+    const sno_hbv* h;
+    pdict d;
+    int32_t *to_off, *to_v, *to_e, *from_off, *from_v, *from_e;   /* To(v)/ToEdgeObj(v), From(v)/FromEdgeObj(v): AddEdge order, graph/DigraphTemplate.h:2572-2582 */
+} pctx;
+static inline uint32_t ulen(const pctx* c, uint32_t u) { return (uint32_t)(c->u->off[u + 1] - c->u->off[u]); }
+static inline uint32_t ubase(const pctx* c, uint32_t u, int rc, uint32_t i) {     /* base i of the unitig in the given orientation */
+    const uint8_t* b = c->u->bases + c->u->off[u];
+    return rc ? (uint32_t)(b[ulen(c, u) - 1 - i] ^ 3u) : b[i];
+}
+static inline uint32_t ebase(const pctx* c, int32_t e, uint32_t i) { return ubase(c, (uint32_t)c->h->src_unitig[e], c->h->is_rc[e], i); }
+static inline uint32_t elen_bases(const pctx* c, int32_t e) { return ulen(c, (uint32_t)c->h->src_unitig[e]); }
+static inline int to_size(const pctx* c, int32_t v) { return c->to_off[v + 1] - c->to_off[v]; }
+static inline int from_size(const pctx* c, int32_t v) { return c->from_off[v + 1] - c->from_off[v]; }
+static inline int32_t part_edge(const pctx* c, const ppart* p) { return p->rc ? c->h->rev_xlat[p->unitig] : c->h->fwd_xlat[p->unitig]; }
+
+static int pair_cmp(const void* a, const void* b) {
+    const int32_t* x = (const int32_t*)a; const int32_t* y = (const int32_t*)b;
+    if (x[0] != y[0]) return x[0] < y[0] ? -1 : 1;
+    return x[1] < y[1] ? -1 : (x[1] > y[1]);
+}
+static void build_adj(int32_t N, int32_t E, const int32_t* key_v, const int32_t* other_v, int32_t** off_o, int32_t** v_o, int32_t** e_o) {
+    int32_t* off = (int32_t*)calloc((size_t)N + 2, 4);
+    for (int32_t e = 0; e < E; ++e) off[key_v[e] + 1]++;
+    for (int32_t v = 0; v < N; ++v) off[v + 1] += off[v];
+    int32_t* tmp = (int32_t*)malloc(((size_t)E + 1) * 8);
+    int32_t* cur = (int32_t*)malloc(((size_t)N + 1) * 4);
+    memcpy(cur, off, ((size_t)N + 1) * 4);
+    for (int32_t e = 0; e < E; ++e) { int32_t p = cur[key_v[e]]++; tmp[2 * p] = other_v[e]; tmp[2 * p + 1] = e; }
+    for (int32_t v = 0; v < N; ++v) qsort(tmp + 2 * off[v], (size_t)(off[v + 1] - off[v]), 8, pair_cmp);    /* (other vertex, edge id) ascending */
+    int32_t* vv = (int32_t*)malloc(((size_t)E + 1) * 4);
+    int32_t* ee = (int32_t*)malloc(((size_t)E + 1) * 4);
+    for (int32_t i = 0; i < E; ++i) { vv[i] = tmp[2 * i]; ee[i] = tmp[2 * i + 1]; }
+    free(tmp); free(cur);
+    *off_o = off; *v_o = vv; *e_o = ee;
+}
+
+/* Pather::path :705-748 */
+static int path_parts(const pctx* c, const uint8_t* read, uint32_t n, ppart* parts, int cap) {
+    const uint32_t K = c->K;
+    int np = 0;
+    if (n < K) { parts[np].gap = 1; parts[np].len = n; parts[np].elen = 0; parts[np].off = 0; parts[np].rc = 0; parts[np].unitig = 0; return 1; }
+    uint32_t i = 0;
+    const uint32_t end = n - K + 1;
+    while (i != end) {
+        kmer_t km = kmer_from(read + i, K);
+        const pdict_ent* ent = pd_find(&c->d, km, K);
+        if (!ent) {
+            uint32_t gap_len = 1, i2 = i + K;
+            ++i;
+            while (i2 != n) {
+                km = kmer_succ(km, K, read[i2] & 3u);
+                ++i2;
+                if ((ent = pd_find(&c->d, km, K))) break;
+                ++gap_len; ++i;
+            }
+            if (np >= cap) return -1;
+            ppart g = {1, 0, 0, 0, gap_len, 0};
+            parts[np++] = g;
+        }
+        if (ent) {
+            const uint32_t u = ent->unitig, sz = ulen(c, u);
+            uint32_t off = ent->offset, len = 1;
+            int rc = 0;
+            for (uint32_t q = 0; q < K; ++q) if ((read[i + q] & 3u) != ubase(c, u, 0, off + q)) { rc = 1; break; }      /* CF<K>::isRC, dna/CanonicalForm.h:85-91 */
+            if (!rc) {
+                uint32_t a = i + K, b = off + K;
+                while (a < n && b < sz && (read[a] & 3u) == ubase(c, u, 0, b)) { ++len; ++a; ++b; }
+            } else {
+                off = sz - off;                                   /* :726-729 */
+                uint32_t a = i + K, b = off;
+                while (a < n && b < sz && (read[a] & 3u) == ubase(c, u, 1, b)) { ++len; ++a; ++b; }
+                off -= K;
+            }
+            if (np >= cap) return -1;
+            ppart p = {0, u, rc, off, len, sz - K + 1};
+            parts[np++] = p;
+            i += len;
+        }
+    }
+    return np;
+}
+static inline int same_edge(const ppart* a, const ppart* b) { return a->unitig == b->unitig && a->rc == b->rc; }     /* :656-657; gaps carry unitig 0, rc 0 */
+/* PathPart::isConformingCapturedGap :659-666 (unsigned arithmetic as written) */
+static int conforming_gap(const ppart* p, uint32_t max_jitter) {
+    const ppart *prev = p - 1, *next = p + 1;
+    uint32_t graph_dist = next->off - (prev->off + prev->len);
+    if (!same_edge(prev, next)) graph_dist += prev->elen;
+    int32_t d = (int32_t)(p->len - graph_dist);
+    return (uint32_t)(d < 0 ? -d : d) <= max_jitter;
+}
+/* Pather::isJoinable :808-814: the LAST K-1 bases of both edges, each in its part's orientation (as written in the reference) */
+static int joinable(const pctx* c, const ppart* a, const ppart* b) {
+    if (a->unitig == b->unitig) return 1;
+    const uint32_t K = c->K, la = ulen(c, a->unitig), lb = ulen(c, b->unitig);
+    for (uint32_t q = 0; q + 1 < K; ++q)
+        if (ubase(c, a->unitig, a->rc, la - (K - 1) + q) != ubase(c, b->unitig, b->rc, lb - (K - 1) + q)) return 0;
+    return 1;
+}
+/* scoreLeftOverlap / scoreRightOverlap, ExtendReadPath.cc:15-106: pDecay 0.2, Q2 counted as Q20, 10 per read base left over */
+static uint32_t score_overlap(const pctx* c, const uint8_t* bases, const uint8_t* quals, uint32_t n, uint32_t start, int32_t e, int left) {
+    const uint32_t K = c->K, esz = elen_bases(c, e);
+    uint32_t qsum = 0, penalty = 0, steps = 0;
+    /* right: read positions n-start.., edge positions K-1..;  left: read positions start-1 downwards, edge positions esz-K downwards */
+    for (;; ++steps) {
+        if (steps >= start) break;
+        uint32_t rp, ep;
+        if (!left) { rp = n - start + steps; ep = K - 1 + steps; if (ep >= esz) break; }
+        else { rp = start - 1 - steps; if (steps + K > esz) break; ep = esz - K - steps; }
+        if ((bases[rp] & 3u) != ebase(c, e, ep)) {
+            const uint32_t q = quals[rp] == 2 ? 20u : quals[rp];
+            penalty += q;
+            qsum += penalty;
+        } else if (penalty > 0) penalty = (uint32_t)((double)penalty - 0.2 * (double)penalty);      /* penalty -= (pDecay*penalty) */
+    }
+    qsum += 10u * (start - steps);
+    return qsum;
+}
+/* attemptLeftwardExtension :123-239 / attemptRightwardExtension :242-358 */
+static int extend_once(const pctx* c, int32_t* path, int* np, int cap, int32_t* offset, const uint8_t* bases, const uint8_t* quals, uint32_t n, int left) {
+    const uint32_t K = c->K;
+    if (!*np) return 0;
+    uint64_t last_gap;
+    if (left) {
+        if (*offset >= 0) return 0;
+        last_gap = (uint64_t)(-(int64_t)*offset);
+    } else {
+        int32_t g = (int32_t)n + *offset;
+        for (int i = 0; i < *np; ++i) g -= (int32_t)(elen_bases(c, path[i]) - K + 1);
+        g -= (int32_t)(K - 1);
+        if (g < 10) return 0;
+        last_gap = (uint64_t)g;
+    }
+    if (last_gap < 10) return 0;
+    const int32_t v = left ? c->h->v_left[path[0]] : c->h->v_right[path[*np - 1]];
+    const int32_t* off = left ? c->to_off : c->from_off;
+    const int32_t* ee = (left ? c->to_e : c->from_e) + off[v];
+    const int32_t* vd = (left ? c->to_v : c->from_v) + off[v];
+    const int ne = off[v + 1] - off[v];
+    int nlong = 0, nshort = 0, short_same = 1;
+    int32_t short_dest = -1;
+    for (int i = 0; i < ne; ++i) {
+        const int hanging = left ? (to_size(c, vd[i]) == 0 && from_size(c, vd[i]) == 1) : (from_size(c, vd[i]) == 0 && to_size(c, vd[i]) == 1);
+        const int lng = (uint64_t)elen_bases(c, ee[i]) - (K - 1) >= last_gap;
+        nlong += lng;
+        if (!lng && !hanging) { if (nshort && vd[i] != short_dest) short_same = 0; short_dest = vd[i]; ++nshort; }
+    }
+    if (ne != 1 && nshort > 0) {
+        if (nlong > 0) return 0;
+        if (!short_same) return 0;
+        if ((left ? to_size(c, short_dest) : from_size(c, short_dest)) != 1) return 0;
+    }
+    int32_t least_edge = -1;
+    uint32_t least = 0xFFFFFFFFu;
+    for (int i = 0; i < ne; ++i) {
+        const int hanging = left ? (to_size(c, vd[i]) == 0 && from_size(c, vd[i]) == 1) : (from_size(c, vd[i]) == 0 && to_size(c, vd[i]) == 1);
+        if (!hanging || ne == 1) {
+            const uint32_t sc = score_overlap(c, bases, quals, n, (uint32_t)last_gap, ee[i], left);
+            if (sc < least) { least_edge = ee[i]; least = sc; }
+        }
+    }
+    if (least_edge == -1 || (uint64_t)least > last_gap * 10) return 0;
+    if (*np >= cap) return 0;
+    if (left) {
+        memmove(path + 1, path, (size_t)*np * 4);
+        path[0] = least_edge;
+        *offset += (int32_t)(elen_bases(c, least_edge) - K + 1);
+    } else path[*np] = least_edge;
+    ++*np;
+    return 1;
+}
+
+#define SNO_PATH_CAP 512
+int sno_path_reads(const uint8_t* bases, const uint8_t* quals, uint32_t stride, const uint32_t* lens, uint64_t n_reads, uint32_t K,
+                   const sno_unitigs* u, const sno_hbv* h, int32_t* out_off, int32_t* out_n, int32_t** out_edges, uint64_t* out_total) {
+    pctx c;
+    memset(&c, 0, sizeof c);
+    c.K = K; c.u = u; c.h = h;
+    uint64_t nk = 0;
+    for (uint64_t i = 0; i < u->n; ++i) nk += u->off[i + 1] - u->off[i] - (K - 1);
+    uint64_t cap = 64;
+    while (cap < 2 * nk + 2) cap <<= 1;
+    c.d.e = (pdict_ent*)calloc(cap, sizeof(pdict_ent));
+    c.d.mask = cap - 1;
+    if (!c.d.e) return -2;
+    for (uint64_t i = 0; i < u->n; ++i) {                /* :1656-1664: every k-mer of every edge -> (edge, offset) */
+        const uint8_t* b = u->bases + u->off[i];
+        const uint32_t L = (uint32_t)(u->off[i + 1] - u->off[i]);
+        kmer_t km = kmer_from(b, K);
+        for (uint32_t o = 0; o + K <= L; ++o) {
+            if (o) km = kmer_succ(km, K, b[o + K - 1] & 3u);
+            kmer_t r = kmer_rc(km, K), ck = kmer_lt(r, km) ? r : km;
+            uint64_t s = pd_hash(ck) & c.d.mask;
+            while (c.d.e[s].used) s = (s + 1) & c.d.mask;
+            c.d.e[s].k = ck; c.d.e[s].unitig = (uint32_t)i; c.d.e[s].offset = o; c.d.e[s].used = 1;
+        }
+    }
+    build_adj(h->n_vertices, h->n_edges, h->v_right, h->v_left, &c.to_off, &c.to_v, &c.to_e);       /* in-edges of w keyed by source vertex */
+    build_adj(h->n_vertices, h->n_edges, h->v_left, h->v_right, &c.from_off, &c.from_v, &c.from_e);
+    uint64_t ecap = n_reads * 2 + 16, tot = 0;
+    int32_t* edges = (int32_t*)malloc(ecap * 4);
+    ppart* parts = (ppart*)malloc(sizeof(ppart) * SNO_PATH_CAP);
+    ppart* np_ = (ppart*)malloc(sizeof(ppart) * SNO_PATH_CAP);
+    int32_t path[SNO_PATH_CAP];
+    int rc = 0;
+    for (uint64_t r = 0; r < n_reads && !rc; ++r) {
+        const uint8_t* rb = bases + r * (uint64_t)stride;
+        const uint8_t* rq = quals + r * (uint64_t)stride;
+        const uint32_t n = lens[r];
+        int m = path_parts(&c, rb, n, parts, SNO_PATH_CAP);
+        if (m < 0) { rc = -3; break; }
+        /* seeds on hanging edges become gaps, adjacent gaps merge (:1235-1262) */
+        int m2 = 0;
+        for (int i = 0; i < m; ++i) {
+            ppart p = parts[i];
+            if (!p.gap) {
+                const int32_t e = part_edge(&c, &p), vl = h->v_left[e], vr = h->v_right[e];
+                if (to_size(&c, vl) == 0 && to_size(&c, vr) > 1 && from_size(&c, vr) > 0 && p.elen <= 100) { ppart g = {1, 0, 0, 0, p.len, 0}; p = g; }
+            }
+            if (p.gap && m2 && np_[m2 - 1].gap) np_[m2 - 1].len += p.len;
+            else np_[m2++] = p;
+        }
+        memcpy(parts, np_, sizeof(ppart) * (size_t)m2);
+        m = m2;
+        /* a captured gap that does not fit the graph (:1268-1292) */
+        if (m >= 3) {
+            uint32_t seeds = parts[0].gap ? 0u : 1u;
+            for (int p = 1; p < m - 1; ++p) {
+                if (!parts[p].gap) { ++seeds; continue; }
+                if (!conforming_gap(&parts[p], 3) || !joinable(&c, &parts[p - 1], &parts[p + 1])) {
+                    if (seeds > 1) {
+                        ppart t = {1, 0, 0, 0, parts[p - 1].len, 0};
+                        for (int q = p; q < m; ++q) t.len += parts[q].len;
+                        parts[p - 1] = t;
+                        m = p;
+                    } else {
+                        for (int q = p + 1; q < m; ++q) parts[p].len += parts[q].len;
+                        m = p + 1;
+                    }
+                    break;
+                }
+            }
+        }
+        /* a last seed of <= 5 k-mers at the very start of an edge is not trusted (:1298-1312) */
+        if (parts[m - 1].gap && m > 1) {
+            const ppart* l2 = &parts[m - 2];
+            if (l2->off == 0 && l2->len <= 5) { ppart last = parts[m - 1]; last.len += l2->len; m -= 2; parts[m++] = last; }
+        } else if (!parts[m - 1].gap) {
+            ppart* l = &parts[m - 1];
+            if (l->off == 0 && l->len <= 5) { ppart g = {1, 0, 0, 0, l->len, 0}; *l = g; }
+        }
+        /* pathPartsToReadPath :1393-1428 */
+        int np = 0;
+        int32_t offset = 0;
+        const ppart* plast = NULL;
+        for (int i = 0; i < m; ++i) {
+            if (parts[i].gap) continue;
+            if (plast && same_edge(plast, &parts[i])) continue;
+            if (np < SNO_PATH_CAP) path[np++] = part_edge(&c, &parts[i]);
+            plast = &parts[i];
+        }
+        if (np) offset = !parts[0].gap ? (int32_t)parts[0].off : (int32_t)parts[1].off - (int32_t)parts[0].len;
+        /* adjacent edges must share a vertex (:1316-1323) */
+        for (int i = 0; i + 1 < np; ++i) if (h->v_right[path[i]] != h->v_left[path[i + 1]]) { np = i + 1; break; }
+        /* ExtendReadPath::attemptLeftRightExtension :108-119 */
+        while (extend_once(&c, path, &np, SNO_PATH_CAP, &offset, rb, rq, n, 1)) {}
+        while (extend_once(&c, path, &np, SNO_PATH_CAP, &offset, rb, rq, n, 0)) {}
+        if (tot + (uint64_t)np > ecap) { ecap = ecap * 2 + (uint64_t)np; edges = (int32_t*)realloc(edges, ecap * 4); }
+        memcpy(edges + tot, path, (size_t)np * 4);
+        out_off[r] = offset;
+        out_n[r] = np;
+        tot += (uint64_t)np;
+    }
+    free(parts); free(np_);
+    free(c.d.e); free(c.to_off); free(c.to_v); free(c.to_e); free(c.from_off); free(c.from_v); free(c.from_e);
+    if (rc) { free(edges); return rc; }
+    *out_edges = edges;
+    *out_total = tot;
+    return 0;
+}
+void sno_free(void* p) { free(p); }

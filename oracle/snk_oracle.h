@@ -52,6 +52,12 @@ int sno_unitigs_build(const sno_table* t, uint32_t K, sno_unitigs* out);
 int sno_hbv_build(const sno_unitigs* u, uint32_t K, sno_hbv* out);
 int sno_write_bv(const char* path, const sno_unitigs* u);
 int sno_read_bv(const char* path, sno_unitigs* out);
+/* f1: read paths (offset of the read on its first edge, HBV edge ids) of pathReads with the new aligner,
+ * paths/long/BuildReadQGraph48.cc:705-748,1217-1336,1393-1469 + paths/long/ExtendReadPath.cc.  Untrimmed reads; unitigs in
+ * BVComp order with their HBV (sno_hbv_build).  *out_edges is malloc'ed (sno_free). */
+int sno_path_reads(const uint8_t* bases, const uint8_t* quals, uint32_t stride, const uint32_t* lens, uint64_t n_reads, uint32_t K,
+                   const sno_unitigs* u, const sno_hbv* h, int32_t* out_off, int32_t* out_n, int32_t** out_edges, uint64_t* out_total);
+void sno_free(void* p);
 void sno_table_free(sno_table* t);
 void sno_unitigs_free(sno_unitigs* u);
 void sno_hbv_free(sno_hbv* h);

@@ -1,0 +1,581 @@
+// snk_path.hip -- f1: every read onto the unitig graph, on the device.
+//
+// What it replaces:
+//   dictionary fill  k-mer -> (edge, offset)     lib/assembly/src/paths/long/BuildReadQGraph48.cc:1656-1664 (buildGraphFromMSP),
+//                                                == KDef::set in buildEdges (:327-512)
+//   Pather::path                                 :705-748    seed by dictionary look-up, extend by exact match, gaps in between
+//   HBVPather::algorithmTwo                      :1217-1336  seeds on hanging edges, captured gaps, short last seed, connectivity
+//   pathPartsToReadPath                          :1393-1428
+//   ExtendReadPath::attemptLeft/RightExtension   paths/long/ExtendReadPath.cc:108-358 (+ scoreLeft/RightOverlap :15-106)
+//   pathReads                                    :1441-1469  (the reference: one thread per 500 k reads, a hash-set look-up per k-mer)
+//
+// Layout.  The dictionary is an open-addressing table in HBM over all k-mers of all unitigs: u32 fingerprint + u64 (unitig, offset)
+// per slot, two slots per k-mer; a hit is verified against the unitig's 2-bit packed sequence (exact, and it tells the strand).
+// One wave per read: the 64 lanes look up 64 consecutive k-mer positions at once (a read with an error has K missing k-mers
+// in a row -- one round instead of 48 dependent look-ups), the first hit seeds, the exact-match extension compares 64 bases
+// per step with a ballot.  The bookkeeping that follows (a handful of parts per read) is the reference's sequential logic,
+// run by lane 0 over the parts in LDS; paths leave through a wave-level reservation and are put in read order by a gather.
+#include <string.h>
+
+#include <vector>
+
+#include <rocprim/rocprim.hpp>
+
+#include "snk_ctx.h"
+#include "snk_common.h"
+#include "snk_kernels.h"
+
+namespace {
+
+constexpr int PCAP = 112;      // path parts per read (a 150-base read has at most 103 k-mers)
+constexpr int PMAX = 128;      // edges per read path
+
+struct path_graph {            // device arrays
+    const uint64_t* uoff;      // [U+1] unitig offsets into ubases (device order)
+    const uint8_t* ubases;     // 1 byte per base
+    const uint64_t* woff;      // [U+1] offsets into upacked (32-bit words, 16 bases each, MSB first)
+    const uint32_t* upacked;
+    const int32_t *fwd, *rev;  // [U] HBV edge of the unitig read forward / reverse-complemented
+    const int32_t *vleft, *vright;         // [E]
+    const int32_t *e_unitig;               // [E] device index of the unitig the edge is a copy of
+    const uint8_t* e_rc;                   // [E]
+    const int32_t *to_off, *to_v, *to_e;   // [N+1], [E], [E]: in-edges of a vertex, AddEdge order (graph/DigraphTemplate.h:2572-2582)
+    const int32_t *from_off, *from_v, *from_e;
+    const uint32_t* dfp;       // dictionary: fingerprint | 1, 0 = empty
+    const unsigned long long* dval;        // unitig << 32 | offset
+    uint64_t dmask;
+};
+
+template <int K>
+__device__ __forceinline__ snk_kmer kmer_at(const uint32_t* words, uint32_t nwords, uint32_t pos) {
+    const uint32_t wi = pos >> 4, sh = 2u * (pos & 15u);
+    uint32_t W[5];
+#pragma unroll
+    for (uint32_t q = 0; q < 5; ++q) W[q] = wi + q < nwords ? words[wi + q] : 0u;
+    const uint64_t A = ((uint64_t)W[0] << 32) | W[1], B = ((uint64_t)W[2] << 32) | W[3], C = (uint64_t)W[4] << 32;
+    snk_kmer f;
+    f.hi = sh ? ((A << sh) | (B >> (64 - sh))) : A;
+    const uint64_t lo = sh ? ((B << sh) | (C >> (64 - sh))) : B;
+    f.lo = lo & ~((1ull << (128 - 2 * K)) - 1ull);
+    return f;
+}
+__device__ __forceinline__ uint64_t dict_slot(snk_kmer c, uint32_t* fp) {
+    uint32_t h1, h2;
+    snk_kmer_hash2(c, &h1, &h2);
+    *fp = h2 | 1u;
+    return ((uint64_t)h1 << 20) ^ h2;
+}
+
+// ---- dictionary build: one thread per base position of the concatenated unitigs
+template <int K>
+__global__ void __launch_bounds__(256) dict_build_kernel(const uint64_t* __restrict__ uoff, const uint8_t* __restrict__ ubases, uint64_t U, uint64_t total,
+                                                         uint32_t* __restrict__ dfp, unsigned long long* __restrict__ dval, uint64_t dmask) {
+    const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= total) return;
+    uint64_t lo = 0, hi = U;                     // largest u with uoff[u] <= p
+    while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (uoff[mid] <= p) lo = mid; else hi = mid; }
+    const uint64_t o = p - uoff[lo], len = uoff[lo + 1] - uoff[lo];
+    if (o + K > len) return;
+    snk_kmer f;
+    f.hi = 0; f.lo = 0;
+    for (int q = 0; q < K; ++q) f = snk_kmer_succ<K>(f, ubases[p + q] & 3u);
+    const snk_kmer r = snk_kmer_rc<K>(f);
+    const snk_kmer c = snk_kmer_lt(r, f) ? r : f;
+    uint32_t fp;
+    uint64_t s = dict_slot(c, &fp) & dmask;
+    for (;;) {
+        if (atomicCAS(&dfp[s], 0u, fp) == 0u) { dval[s] = ((unsigned long long)lo << 32) | (unsigned long long)o; break; }
+        s = (s + 1) & dmask;
+    }
+}
+__global__ void __launch_bounds__(256) words_kernel(const uint64_t* __restrict__ uoff, uint64_t U, uint64_t* __restrict__ nw) {
+    const uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u <= U) nw[u] = u < U ? (uoff[u + 1] - uoff[u] + 15) / 16 : 0ull;
+}
+__global__ void __launch_bounds__(256) upack_kernel(const uint64_t* __restrict__ uoff, const uint8_t* __restrict__ ubases, const uint64_t* __restrict__ woff,
+                                                    uint64_t U, uint64_t total_words, uint32_t* __restrict__ out) {
+    const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (w >= total_words) return;
+    uint64_t lo = 0, hi = U;
+    while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (woff[mid] <= w) lo = mid; else hi = mid; }
+    const uint64_t b0 = uoff[lo] + (w - woff[lo]) * 16, end = uoff[lo + 1];
+    uint32_t v = 0;
+    for (int j = 0; j < 16; ++j) v = (v << 2) | (b0 + j < end ? (uint32_t)(ubases[b0 + j] & 3u) : 0u);
+    out[w] = v;
+}
+
+// ---- the sequential part of a read's path, run by one lane (parts in LDS)
+struct ppart { uint32_t unitig; uint32_t off_rc; uint32_t len; uint32_t elen; };      // elen == 0: a gap (only len counts); off_rc = offset | rc << 31
+__device__ __forceinline__ bool p_gap(const ppart& p) { return p.elen == 0; }
+__device__ __forceinline__ uint32_t p_off(const ppart& p) { return p.off_rc & 0x7FFFFFFFu; }
+__device__ __forceinline__ uint32_t p_rc(const ppart& p) { return p.off_rc >> 31; }
+__device__ __forceinline__ bool p_same_edge(const ppart& a, const ppart& b) { return a.unitig == b.unitig && p_rc(a) == p_rc(b); }
+__device__ __forceinline__ ppart make_gap(uint32_t len) { ppart g; g.unitig = 0; g.off_rc = 0; g.len = len; g.elen = 0; return g; }
+
+__device__ __forceinline__ uint32_t u_len(const path_graph& G, uint32_t u) { return (uint32_t)(G.uoff[u + 1] - G.uoff[u]); }
+__device__ __forceinline__ uint32_t u_base(const path_graph& G, uint32_t u, uint32_t rc, uint32_t i) {
+    const uint8_t* b = G.ubases + G.uoff[u];
+    return rc ? (uint32_t)(b[u_len(G, u) - 1 - i] ^ 3u) & 3u : (uint32_t)b[i] & 3u;
+}
+__device__ __forceinline__ uint32_t e_len(const path_graph& G, int32_t e) { return u_len(G, (uint32_t)G.e_unitig[e]); }
+__device__ __forceinline__ int to_size(const path_graph& G, int32_t v) { return G.to_off[v + 1] - G.to_off[v]; }
+__device__ __forceinline__ int from_size(const path_graph& G, int32_t v) { return G.from_off[v + 1] - G.from_off[v]; }
+__device__ __forceinline__ int32_t part_edge(const path_graph& G, const ppart& p) { return p_rc(p) ? G.rev[p.unitig] : G.fwd[p.unitig]; }
+
+// PathPart::isConformingCapturedGap :659-666 (unsigned arithmetic as written)
+__device__ bool conforming_gap(const ppart* p, uint32_t max_jitter) {
+    const ppart &prev = p[-1], &next = p[1];
+    uint32_t graph_dist = p_off(next) - (p_off(prev) + prev.len);
+    if (!p_same_edge(prev, next)) graph_dist += prev.elen;
+    const int32_t d = (int32_t)(p->len - graph_dist);
+    return (uint32_t)(d < 0 ? -d : d) <= max_jitter;
+}
+// Pather::isJoinable :808-814: the last K-1 bases of both edges, each in its part's orientation (as written in the reference)
+template <int K>
+__device__ bool joinable(const path_graph& G, const ppart& a, const ppart& b) {
+    if (a.unitig == b.unitig) return true;
+    const uint32_t la = u_len(G, a.unitig), lb = u_len(G, b.unitig);
+    for (uint32_t q = 0; q + 1 < (uint32_t)K; ++q)
+        if (u_base(G, a.unitig, p_rc(a), la - (K - 1) + q) != u_base(G, b.unitig, p_rc(b), lb - (K - 1) + q)) return false;
+    return true;
+}
+__device__ __forceinline__ uint32_t read_base(const uint32_t* row, uint32_t p) { return (row[p >> 4] >> (30 - 2 * (p & 15))) & 3u; }
+// scoreLeftOverlap / scoreRightOverlap, ExtendReadPath.cc:15-106: decay 0.2, Q2 counted as Q20, 10 per read base left over
+template <int K>
+__device__ uint32_t score_overlap(const path_graph& G, const uint32_t* row, const uint8_t* quals, uint32_t n, uint32_t start, int32_t e, bool left) {
+    const uint32_t esz = e_len(G, e), u = (uint32_t)G.e_unitig[e], erc = G.e_rc[e];
+    uint32_t qsum = 0, penalty = 0, steps = 0;
+    for (;; ++steps) {
+        if (steps >= start) break;
+        uint32_t rp, ep;
+        if (!left) { rp = n - start + steps; ep = K - 1 + steps; if (ep >= esz) break; }
+        else { rp = start - 1 - steps; if (steps + K > esz) break; ep = esz - K - steps; }
+        if (read_base(row, rp) != u_base(G, u, erc, ep)) {
+            const uint32_t q = quals[rp] == 2 ? 20u : (uint32_t)quals[rp];
+            penalty += q;
+            qsum += penalty;
+        } else if (penalty > 0) penalty = (uint32_t)((double)penalty - 0.2 * (double)penalty);      // penalty -= (pDecay*penalty)
+    }
+    return qsum + 10u * (start - steps);
+}
+// attemptLeftwardExtension :123-239 / attemptRightwardExtension :242-358
+template <int K>
+__device__ bool extend_once(const path_graph& G, int32_t* path, int* np, int32_t* offset, const uint32_t* row, const uint8_t* quals, uint32_t n, bool left) {
+    if (!*np) return false;
+    uint64_t last_gap;
+    if (left) {
+        if (*offset >= 0) return false;
+        last_gap = (uint64_t)(-(int64_t)*offset);
+    } else {
+        int32_t g = (int32_t)n + *offset;
+        for (int i = 0; i < *np; ++i) g -= (int32_t)(e_len(G, path[i]) - K + 1);
+        g -= K - 1;
+        if (g < 10) return false;
+        last_gap = (uint64_t)g;
+    }
+    if (last_gap < 10) return false;
+    const int32_t v = left ? G.vleft[path[0]] : G.vright[path[*np - 1]];
+    const int32_t* off = left ? G.to_off : G.from_off;
+    const int32_t* ee = (left ? G.to_e : G.from_e) + off[v];
+    const int32_t* vd = (left ? G.to_v : G.from_v) + off[v];
+    const int ne = off[v + 1] - off[v];
+    int nlong = 0, nshort = 0;
+    bool short_same = true;
+    int32_t short_dest = -1;
+    for (int i = 0; i < ne; ++i) {
+        const bool hanging = left ? (to_size(G, vd[i]) == 0 && from_size(G, vd[i]) == 1) : (from_size(G, vd[i]) == 0 && to_size(G, vd[i]) == 1);
+        const bool lng = (uint64_t)e_len(G, ee[i]) - (K - 1) >= last_gap;
+        nlong += lng ? 1 : 0;
+        if (!lng && !hanging) { if (nshort && vd[i] != short_dest) short_same = false; short_dest = vd[i]; ++nshort; }
+    }
+    if (ne != 1 && nshort > 0) {
+        if (nlong > 0 || !short_same) return false;
+        if ((left ? to_size(G, short_dest) : from_size(G, short_dest)) != 1) return false;
+    }
+    int32_t least_edge = -1;
+    uint32_t least = 0xFFFFFFFFu;
+    for (int i = 0; i < ne; ++i) {
+        const bool hanging = left ? (to_size(G, vd[i]) == 0 && from_size(G, vd[i]) == 1) : (from_size(G, vd[i]) == 0 && to_size(G, vd[i]) == 1);
+        if (!hanging || ne == 1) {
+            const uint32_t sc = score_overlap<K>(G, row, quals, n, (uint32_t)last_gap, ee[i], left);
+            if (sc < least) { least_edge = ee[i]; least = sc; }
+        }
+    }
+    if (least_edge == -1 || (uint64_t)least > last_gap * 10) return false;
+    if (*np >= PMAX) return false;
+    if (left) {
+        for (int i = *np; i > 0; --i) path[i] = path[i - 1];
+        path[0] = least_edge;
+        *offset += (int32_t)(e_len(G, least_edge) - K + 1);
+    } else path[*np] = least_edge;
+    ++*np;
+    return true;
+}
+
+// algorithmTwo after Pather::path: m parts in LDS -> path[np], offset
+template <int K>
+__device__ void finish_path(const path_graph& G, ppart* parts, int m, const uint32_t* row, const uint8_t* quals, uint32_t n, int32_t* path, int* np_out,
+                            int32_t* off_out) {
+    // seeds on hanging edges become gaps, adjacent gaps merge (:1235-1262) -- in place: the write index never passes the read index
+    int m2 = 0;
+    for (int i = 0; i < m; ++i) {
+        ppart p = parts[i];
+        if (!p_gap(p)) {
+            const int32_t e = part_edge(G, p), vl = G.vleft[e], vr = G.vright[e];
+            if (to_size(G, vl) == 0 && to_size(G, vr) > 1 && from_size(G, vr) > 0 && p.elen <= 100) p = make_gap(p.len);
+        }
+        if (p_gap(p) && m2 && p_gap(parts[m2 - 1])) parts[m2 - 1].len += p.len;
+        else parts[m2++] = p;
+    }
+    m = m2;
+    // a captured gap that does not fit the graph (:1268-1292)
+    if (m >= 3) {
+        uint32_t seeds = p_gap(parts[0]) ? 0u : 1u;
+        for (int p = 1; p < m - 1; ++p) {
+            if (!p_gap(parts[p])) { ++seeds; continue; }
+            if (!conforming_gap(&parts[p], 3) || !joinable<K>(G, parts[p - 1], parts[p + 1])) {
+                if (seeds > 1) {
+                    ppart t = make_gap(parts[p - 1].len);
+                    for (int q = p; q < m; ++q) t.len += parts[q].len;
+                    parts[p - 1] = t;
+                    m = p;
+                } else {
+                    for (int q = p + 1; q < m; ++q) parts[p].len += parts[q].len;
+                    m = p + 1;
+                }
+                break;
+            }
+        }
+    }
+    // a last seed of <= 5 k-mers at the very start of an edge is not trusted (:1298-1312)
+    if (p_gap(parts[m - 1]) && m > 1) {
+        const ppart l2 = parts[m - 2];
+        if (p_off(l2) == 0 && l2.len <= 5) { ppart last = parts[m - 1]; last.len += l2.len; m -= 2; parts[m++] = last; }
+    } else if (!p_gap(parts[m - 1])) {
+        if (p_off(parts[m - 1]) == 0 && parts[m - 1].len <= 5) parts[m - 1] = make_gap(parts[m - 1].len);
+    }
+    // pathPartsToReadPath :1393-1428
+    int np = 0;
+    int32_t offset = 0;
+    int last = -1;
+    for (int i = 0; i < m; ++i) {
+        if (p_gap(parts[i])) continue;
+        if (last >= 0 && p_same_edge(parts[last], parts[i])) continue;
+        if (np < PMAX) path[np++] = part_edge(G, parts[i]);
+        last = i;
+    }
+    if (np) offset = !p_gap(parts[0]) ? (int32_t)p_off(parts[0]) : (int32_t)p_off(parts[1]) - (int32_t)parts[0].len;
+    // adjacent edges must share a vertex (:1316-1323)
+    for (int i = 0; i + 1 < np; ++i) if (G.vright[path[i]] != G.vleft[path[i + 1]]) { np = i + 1; break; }
+    // ExtendReadPath::attemptLeftRightExtension :108-119
+    while (extend_once<K>(G, path, &np, &offset, row, quals, n, true)) {}
+    while (extend_once<K>(G, path, &np, &offset, row, quals, n, false)) {}
+    *np_out = np;
+    *off_out = offset;
+}
+
+struct path_args {
+    path_graph G;
+    const uint32_t* rows; uint32_t row_words; uint32_t read_len;
+    const uint8_t* quals; uint32_t qstride;
+    const uint16_t* lens;
+    uint64_t n_reads;
+    int32_t* out_off;                 // [n] offset of the read on its first edge (ReadPath::mOffset)
+    uint32_t* out_n;                  // [n + 1] edges per read
+    unsigned long long* out_start;    // [n] position of the read's edges in the scratch list
+    int32_t* scratch;                 // edges in completion order
+    unsigned long long* cursor;       // [0] edges reserved, [1] error flags
+    uint64_t scratch_cap;
+};
+
+template <int K>
+__global__ void __launch_bounds__(256) path_kernel(path_args a) {
+    __shared__ uint32_t rowL[4][20];
+    __shared__ uint8_t qualL[4][256];
+    __shared__ ppart partsL[4][PCAP];
+    __shared__ int32_t pathL[4][PMAX];
+    __shared__ int32_t resL[4][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const path_graph& G = a.G;
+    uint32_t* row = rowL[wv];
+    uint8_t* ql = qualL[wv];
+    ppart* parts = partsL[wv];
+    const uint64_t nw = (uint64_t)gridDim.x * 4;
+    for (uint64_t r = (uint64_t)blockIdx.x * 4 + wv; r < a.n_reads; r += nw) {
+        uint32_t n = a.lens ? a.lens[r] : a.read_len;
+        if (n > a.read_len) n = a.read_len;
+        if (lane < 20) row[lane] = (uint32_t)lane < a.row_words ? a.rows[r * a.row_words + lane] : 0u;
+        for (uint32_t q = lane; q < 256; q += 64) ql[q] = q < n ? a.quals[r * a.qstride + q] : 0;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        // ---- Pather::path :705-748, 64 k-mer positions per round
+        int m = 0;
+        bool overflow = false;
+        if (n < (uint32_t)K) { if (lane == 0) parts[0] = make_gap(n); m = 1; }
+        else {
+            const uint32_t end = n - K + 1;
+            uint32_t i = 0, gap = 0;
+            while (i < end) {
+                const uint32_t pos = i + lane;
+                bool hit = false;
+                uint32_t hu = 0, ho = 0, hrc = 0;
+                if (pos < end) {
+                    const snk_kmer f = kmer_at<K>(row, 20, pos);
+                    const snk_kmer rk = snk_kmer_rc<K>(f);
+                    const snk_kmer c = snk_kmer_lt(rk, f) ? rk : f;
+                    uint32_t fp;
+                    uint64_t s = dict_slot(c, &fp) & G.dmask;
+                    for (;;) {
+                        const uint32_t t = G.dfp[s];
+                        if (t == 0u) break;
+                        if (t == fp) {
+                            const unsigned long long v = G.dval[s];
+                            const uint32_t u = (uint32_t)(v >> 32), o = (uint32_t)v;
+                            const uint64_t w0 = G.woff[u];
+                            const snk_kmer e = kmer_at<K>(G.upacked + w0, (uint32_t)(G.woff[u + 1] - w0), o);
+                            if (snk_kmer_eq(e, f)) { hit = true; hu = u; ho = o; hrc = 0; break; }
+                            if (snk_kmer_eq(e, rk)) { hit = true; hu = u; ho = o; hrc = 1; break; }     // CF<K>::isRC, dna/CanonicalForm.h:85-91
+                        }
+                        s = (s + 1) & G.dmask;
+                    }
+                }
+                const unsigned long long hm = __ballot(hit);
+                if (!hm) { const uint32_t step = end - i < 64u ? end - i : 64u; gap += step; i += step; continue; }
+                const int first = __ffsll((long long)hm) - 1;
+                gap += (uint32_t)first;
+                i += (uint32_t)first;
+                const uint32_t u = __shfl(hu, first), o0 = __shfl(ho, first), rc = __shfl(hrc, first);
+                const uint32_t sz = u_len(G, u);
+                // exact-match extension behind the seed (matchLen :549-558): 64 bases per step
+                uint32_t a0 = i + K, b0, off;
+                if (!rc) { off = o0; b0 = o0 + K; } else { off = sz - o0; b0 = off; off -= K; }      // :726-729
+                uint32_t len = 1;
+                for (;;) {
+                    const uint32_t ra = a0 + lane, eb = b0 + lane;
+                    const bool in = ra < n && eb < sz;
+                    const bool same = in && read_base(row, ra) == u_base(G, u, rc, eb);
+                    const unsigned long long mm = __ballot(!same);
+                    if (mm) { len += (uint32_t)(__ffsll((long long)mm) - 1); break; }
+                    len += 64; a0 += 64; b0 += 64;
+                }
+                if (lane == 0) {
+                    if (gap) { if (m < PCAP) parts[m] = make_gap(gap); }
+                    const int at = m + (gap ? 1 : 0);
+                    if (at < PCAP) { ppart p; p.unitig = u; p.off_rc = off | (rc << 31); p.len = len; p.elen = sz - K + 1; parts[at] = p; }
+                }
+                m += gap ? 2 : 1;
+                if (m > PCAP) { overflow = true; break; }
+                gap = 0;
+                i += len;
+            }
+            if (gap && !overflow) { if (m < PCAP) { if (lane == 0) parts[m] = make_gap(gap); ++m; } else overflow = true; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        // ---- the rest of algorithmTwo + the extension: sequential, lane 0
+        if (lane == 0) {
+            int np = 0;
+            int32_t off = 0;
+            if (!overflow) finish_path<K>(G, parts, m, row, ql, n, pathL[wv], &np, &off);
+            unsigned long long st = 0;
+            if (np) st = atomicAdd(&a.cursor[0], (unsigned long long)np);
+            if (overflow || st + (unsigned long long)np > a.scratch_cap) { atomicOr(&a.cursor[1], overflow ? 1ull : 2ull); np = 0; }
+            a.out_off[r] = off;
+            a.out_n[r] = (uint32_t)np;
+            a.out_start[r] = st;
+            resL[wv][0] = np;
+            resL[wv][1] = (int32_t)(st & 0xFFFFFFFFu);
+            resL[wv][2] = (int32_t)(st >> 32);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        const int np = resL[wv][0];
+        const unsigned long long st = ((unsigned long long)(uint32_t)resL[wv][2] << 32) | (uint32_t)resL[wv][1];
+        for (int q = lane; q < np; q += 64) a.scratch[st + q] = pathL[wv][q];
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+__global__ void __launch_bounds__(256) path_gather_kernel(const uint32_t* __restrict__ n, const unsigned long long* __restrict__ start, const uint64_t* __restrict__ pos,
+                                                          const int32_t* __restrict__ scratch, uint64_t n_reads, int32_t* __restrict__ out) {
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint32_t c = n[r];
+    for (uint32_t q = 0; q < c; ++q) out[pos[r] + q] = scratch[start[r] + q];
+}
+__global__ void __launch_bounds__(256) widen_kernel(const uint32_t* __restrict__ in, uint64_t n, uint64_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i <= n) out[i] = i < n ? in[i] : 0ull;
+}
+
+template <typename T>
+int dev(snk_ctx* ctx, size_t n, T** out, char* err, size_t errcap) {
+    void* q = nullptr;
+    int rc = snk_ctx_alloc(ctx, (n ? n : 1) * sizeof(T) + 16, &q, err, errcap);
+    *out = (T*)q;
+    return rc;
+}
+template <typename T>
+int up(snk_ctx* ctx, hipStream_t st, const std::vector<T>& h, const T** out, char* err, size_t errcap) {
+    T* d;
+    int rc = dev(ctx, h.size(), &d, err, errcap);
+    if (rc) return rc;
+    if (!h.empty()) SNK_HIP_TRY(hipMemcpyAsync(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    *out = d;
+    return SNK_OK;
+}
+int scan64(snk_ctx* ctx, hipStream_t st, const uint64_t* in, uint64_t* out, size_t count, char* err, size_t errcap) {
+    size_t tb = 0;
+    SNK_HIP_TRY(rocprim::exclusive_scan((void*)nullptr, tb, in, out, (uint64_t)0, count, rocprim::plus<uint64_t>(), st));
+    void* tmp;
+    int rc = snk_ctx_alloc(ctx, tb + 16, &tmp, err, errcap);
+    if (rc) return rc;
+    SNK_HIP_TRY(rocprim::exclusive_scan(tmp, tb, in, out, (uint64_t)0, count, rocprim::plus<uint64_t>(), st));
+    return SNK_OK;
+}
+
+// adjacency in AddEdge order: a vertex's edges ascending by the vertex at their other end, equal ones in edge-id order
+void adjacency(int32_t N, int32_t E, const int32_t* key_v, const int32_t* other_v, std::vector<int32_t>& off, std::vector<int32_t>& vv, std::vector<int32_t>& ee) {
+    off.assign((size_t)N + 2, 0);
+    for (int32_t e = 0; e < E; ++e) off[key_v[e] + 1]++;
+    for (int32_t v = 0; v < N; ++v) off[v + 1] += off[v];
+    std::vector<int32_t> cur(off.begin(), off.end() - 1);
+    std::vector<std::pair<int32_t, int32_t>> tmp((size_t)E);
+    for (int32_t e = 0; e < E; ++e) tmp[cur[key_v[e]]++] = {other_v[e], e};
+    for (int32_t v = 0; v < N; ++v) std::sort(tmp.begin() + off[v], tmp.begin() + off[v + 1]);
+    vv.resize((size_t)E);
+    ee.resize((size_t)E);
+    for (int32_t i = 0; i < E; ++i) { vv[i] = tmp[i].first; ee[i] = tmp[i].second; }
+}
+
+template <int K>
+int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U, const uint64_t* d_uoff, const uint8_t* d_ubases, const snk_hbv* h,
+              snk_dev_paths* out, char* err, size_t errcap) {
+    int rc;
+    const uint64_t n = in->n_reads;
+    hipEvent_t e0, e1, e2;
+    SNK_HIP_TRY(hipEventCreate(&e0)); SNK_HIP_TRY(hipEventCreate(&e1)); SNK_HIP_TRY(hipEventCreate(&e2));
+    struct evg { hipEvent_t a, b, c; ~evg() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipEventDestroy(c); } } g{e0, e1, e2};
+    SNK_HIP_TRY(hipEventRecord(e0, st));
+    // ---- graph tables (host: O(U + E)), in the device's unitig numbering
+    const int32_t N = h->n_vertices, E = h->n_edges;
+    std::vector<int32_t> fwd(U), rev(U), eu((size_t)E), off_to, v_to, e_to, off_from, v_from, e_from;
+    std::vector<uint8_t> erc((size_t)E);
+    for (uint64_t r = 0; r < U; ++r) {
+        const uint64_t d = h->bvcomp_order ? (uint64_t)h->bvcomp_order[r] : r;
+        fwd[d] = h->fwd_xlat[r];
+        rev[d] = h->rev_xlat[r];
+    }
+    for (int32_t e = 0; e < E; ++e) {
+        const uint64_t r = (uint64_t)h->src_unitig[e];
+        eu[e] = (int32_t)(h->bvcomp_order ? h->bvcomp_order[r] : (int32_t)r);
+        erc[e] = h->is_rc[e];
+    }
+    adjacency(N, E, h->v_right, h->v_left, off_to, v_to, e_to);
+    adjacency(N, E, h->v_left, h->v_right, off_from, v_from, e_from);
+    std::vector<int32_t> vl(h->v_left, h->v_left + E), vr(h->v_right, h->v_right + E);
+    path_args a;
+    memset(&a, 0, sizeof a);
+    path_graph& G = a.G;
+    G.uoff = d_uoff; G.ubases = d_ubases;
+    if ((rc = up(ctx, st, fwd, &G.fwd, err, errcap)) || (rc = up(ctx, st, rev, &G.rev, err, errcap)) || (rc = up(ctx, st, vl, &G.vleft, err, errcap)) ||
+        (rc = up(ctx, st, vr, &G.vright, err, errcap)) || (rc = up(ctx, st, eu, &G.e_unitig, err, errcap)) || (rc = up(ctx, st, erc, &G.e_rc, err, errcap)) ||
+        (rc = up(ctx, st, off_to, &G.to_off, err, errcap)) || (rc = up(ctx, st, v_to, &G.to_v, err, errcap)) || (rc = up(ctx, st, e_to, &G.to_e, err, errcap)) ||
+        (rc = up(ctx, st, off_from, &G.from_off, err, errcap)) || (rc = up(ctx, st, v_from, &G.from_v, err, errcap)) || (rc = up(ctx, st, e_from, &G.from_e, err, errcap)))
+        return rc;
+    // ---- packed unitigs + dictionary
+    uint64_t h_off_last = 0;
+    SNK_HIP_TRY(hipMemcpyAsync(&h_off_last, d_uoff + U, 8, hipMemcpyDeviceToHost, st));
+    uint64_t *nw, *woff;
+    if ((rc = dev(ctx, U + 2, &nw, err, errcap)) || (rc = dev(ctx, U + 2, &woff, err, errcap))) return rc;
+    hipLaunchKernelGGL(words_kernel, dim3((unsigned)((U + 256) / 256)), dim3(256), 0, st, d_uoff, U, nw);
+    if ((rc = scan64(ctx, st, nw, woff, U + 1, err, errcap))) return rc;
+    uint64_t total_words = 0;
+    SNK_HIP_TRY(hipMemcpyAsync(&total_words, woff + U, 8, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipStreamSynchronize(st));            // also: the host vectors above have been copied
+    const uint64_t total_bases = h_off_last;
+    uint32_t* upacked;
+    if ((rc = dev(ctx, total_words + 8, &upacked, err, errcap))) return rc;
+    SNK_HIP_TRY(hipMemsetAsync(upacked + total_words, 0, 32, st));
+    if (total_words) hipLaunchKernelGGL(upack_kernel, dim3((unsigned)((total_words + 255) / 256)), dim3(256), 0, st, d_uoff, d_ubases, woff, U, total_words, upacked);
+    G.woff = woff; G.upacked = upacked;
+    const uint64_t nk = total_bases >= U * (uint64_t)(K - 1) ? total_bases - U * (uint64_t)(K - 1) : 0;
+    uint64_t cap = 1024;
+    while (cap < 2 * nk + 2) cap <<= 1;
+    uint32_t* dfp;
+    unsigned long long* dval;
+    if ((rc = dev(ctx, cap, &dfp, err, errcap)) || (rc = dev(ctx, cap, &dval, err, errcap))) return rc;
+    SNK_HIP_TRY(hipMemsetAsync(dfp, 0, cap * 4, st));
+    if (total_bases) hipLaunchKernelGGL((dict_build_kernel<K>), dim3((unsigned)((total_bases + 255) / 256)), dim3(256), 0, st, d_uoff, d_ubases, U, total_bases, dfp, dval, cap - 1);
+    SNK_HIP_TRY(hipGetLastError());
+    G.dfp = dfp; G.dval = dval; G.dmask = cap - 1;
+    SNK_HIP_TRY(hipEventRecord(e1, st));
+    // ---- the reads
+    a.rows = (const uint32_t*)in->rows; a.row_words = in->row_words; a.read_len = in->read_len;
+    a.quals = (const uint8_t*)in->quals; a.qstride = in->qstride; a.lens = (const uint16_t*)in->lens; a.n_reads = n;
+    uint32_t* out_n;
+    unsigned long long *out_start, *cursor;
+    int32_t *out_off, *scratch = nullptr, *edges = nullptr;
+    uint64_t *n64, *pos;
+    if ((rc = dev(ctx, n + 1, &out_n, err, errcap)) || (rc = dev(ctx, n + 1, &out_start, err, errcap)) || (rc = dev(ctx, n + 1, &out_off, err, errcap)) ||
+        (rc = dev(ctx, 4, &cursor, err, errcap)) || (rc = dev(ctx, n + 2, &n64, err, errcap)) || (rc = dev(ctx, n + 2, &pos, err, errcap)))
+        return rc;
+    uint64_t scap = n + n / 2 + 1024;                 // most reads lie on one edge; a wrong guess costs one re-run
+    unsigned long long h_cur[2] = {0, 0};
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if ((rc = dev(ctx, scap, &scratch, err, errcap))) return rc;
+        SNK_HIP_TRY(hipMemsetAsync(cursor, 0, 16, st));
+        a.out_off = out_off; a.out_n = out_n; a.out_start = out_start; a.scratch = scratch; a.cursor = cursor; a.scratch_cap = scap;
+        if (n) {
+            uint64_t grid = (n + 3) / 4;
+            const uint64_t gmax = (uint64_t)ctx->n_cu * 64;
+            if (grid > gmax) grid = gmax;
+            hipLaunchKernelGGL((path_kernel<K>), dim3((unsigned)grid), dim3(256), 0, st, a);
+        }
+        SNK_HIP_TRY(hipGetLastError());
+        SNK_HIP_TRY(hipMemcpyAsync(h_cur, cursor, 16, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(hipStreamSynchronize(st));
+        if (h_cur[1] & 1ull) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_dev_path_reads: a read has more than %d path parts", PCAP);
+        if (!(h_cur[1] & 2ull)) break;
+        if (attempt == 1) return snk_fail(SNK_E_INTERNAL, err, errcap, "snk_dev_path_reads: path scratch overflow");
+        snk_ctx_release_block(ctx, scratch);
+        scap = h_cur[0] + 1024;
+    }
+    const uint64_t total = h_cur[0];
+    if ((rc = dev(ctx, total + 1, &edges, err, errcap))) return rc;
+    hipLaunchKernelGGL(widen_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, st, out_n, n, n64);
+    if ((rc = scan64(ctx, st, n64, pos, n + 1, err, errcap))) return rc;
+    if (n) hipLaunchKernelGGL(path_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out_n, out_start, pos, scratch, n, edges);
+    SNK_HIP_TRY(hipGetLastError());
+    SNK_HIP_TRY(hipEventRecord(e2, st));
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    snk_ctx_release_block(ctx, scratch);
+    out->n_reads = n;
+    out->n_edges_total = total;
+    out->offset = out_off;
+    out->n_edges = out_n;
+    out->start = pos;
+    out->edges = edges;
+    out->dict_slots = cap;
+    (void)hipEventElapsedTime(&out->dict_ms, e0, e1);
+    (void)hipEventElapsedTime(&out->path_ms, e1, e2);
+    return SNK_OK;
+}
+
+}  // namespace
+
+extern "C" int snk_dev_path_reads(snk_ctx* ctx, uint32_t K, const snk_dev_reads* in, uint64_t n_unitigs, const void* d_unitig_off, const void* d_unitig_bases,
+                                  const snk_hbv* h, snk_dev_paths* out, void* stream, char* err, size_t errcap) {
+    if (!ctx || !in || !h || !out) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_path_reads: NULL argument");
+    if (K != 48 && K != 60) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "K=%u is not supported (48 or 60)", K);
+    if (in->n_reads && (!in->rows || !in->quals || in->read_len == 0 || in->read_len > 256 || in->row_words * 16 < in->read_len || in->row_words > 16))
+        return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_path_reads: need packed rows and quality rows, reads of at most 256 bases");
+    if (n_unitigs && (!d_unitig_off || !d_unitig_bases)) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_path_reads: NULL unitig arrays");
+    if (n_unitigs >= (1ull << 31)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_dev_path_reads: too many unitigs");
+    memset(out, 0, sizeof *out);
+    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    try {
+        if (K == 48) return path_impl<48>(ctx, st, in, n_unitigs, (const uint64_t*)d_unitig_off, (const uint8_t*)d_unitig_bases, h, out, err, errcap);
+        return path_impl<60>(ctx, st, in, n_unitigs, (const uint64_t*)d_unitig_off, (const uint8_t*)d_unitig_bases, h, out, err, errcap);
+    } catch (const std::bad_alloc&) { return snk_fail(SNK_E_NOMEM, err, errcap, "snk_dev_path_reads: host allocation failed"); }
+}

@@ -115,6 +115,38 @@ class Result:
         self._e.lib.snk_hbv_free(C.byref(h))
         return out
 
+    def path_reads(self, rows, read_len: int, quals, lens=None):
+        """f1: the reads (untrimmed packed rows + quality rows on the device) onto the graph of this result's unitigs --
+        pathReads with the new aligner (BuildReadQGraph48.cc:1441-1469).  Returns (offset i32[n], n_edges u32[n], edges i32[sum],
+        info) on the host, HBV edge ids as numbered by buildHBVFromEdges.  Must be called before the engine's next count_graph."""
+        e = self._e
+        h = _lib.SnkHbv()
+        ms = C.c_float(0)
+        err = C.create_string_buffer(512)
+        rc = e.lib.snk_dev_hbv(e._ctx, int(self.K), self.n_unitigs, self.raw.unitig_off, self.raw.unitig_bases, C.byref(h), C.byref(ms),
+                               e._stream(), err, 512)
+        if rc:
+            raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+        try:
+            r = _lib.SnkDevReads()
+            r.n_reads, r.rows, r.row_words, r.read_len = rows.shape[0], rows.data_ptr(), rows.shape[1], read_len
+            r.quals, r.qstride = quals.data_ptr(), quals.shape[1]
+            if lens is not None:
+                r.lens = lens.data_ptr()
+            out = _lib.SnkDevPaths()
+            rc = e.lib.snk_dev_path_reads(e._ctx, int(self.K), C.byref(r), self.n_unitigs, self.raw.unitig_off, self.raw.unitig_bases,
+                                          C.byref(h), C.byref(out), e._stream(), err, 512)
+            if rc:
+                raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+        finally:
+            e.lib.snk_hbv_free(C.byref(h))
+        n, tot = int(out.n_reads), int(out.n_edges_total)
+        off = self._dl(out.offset, n * 4, np.int32, (n,))
+        ne = self._dl(out.n_edges, n * 4, np.uint32, (n,))
+        edges = self._dl(out.edges, tot * 4, np.int32, (tot,))
+        return off, ne, edges, dict(dict_ms=float(out.dict_ms), path_ms=float(out.path_ms), hbv_device_ms=float(ms.value),
+                                    dict_slots=int(out.dict_slots))
+
     def unitigs(self) -> list[str]:
         """Canonical unitigs sorted by (length desc, lexicographic) = BVComp, HBVFromEdges.cc:106-111."""
         off, bases = self.unitig_arrays()

@@ -89,6 +89,12 @@ class SnkHbv(C.Structure):
                 ("rev_xlat", C.POINTER(C.c_int32)), ("bvcomp_order", C.POINTER(C.c_int32))]
 
 
+class SnkDevPaths(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("n_edges_total", C.c_uint64), ("offset", C.c_void_p), ("n_edges", C.c_void_p),
+                ("start", C.c_void_p), ("edges", C.c_void_p), ("dict_slots", C.c_uint64), ("dict_ms", C.c_float),
+                ("path_ms", C.c_float)]
+
+
 RANGE_READY = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32)      # int ready(void* user, uint32_t range)
 
 _lib = None
@@ -155,6 +161,7 @@ def _declare(lib: C.CDLL) -> None:
         "snk_hbv_from_unitigs": (C.c_int, [u32, u64, vp, vp, P(SnkHbv), cp, sz]),
         "snk_dev_hbv": (C.c_int, [vp, u32, u64, vp, vp, P(SnkHbv), P(C.c_float), vp, cp, sz]),
         "snk_hbv_free": (None, [P(SnkHbv)]),
+        "snk_dev_path_reads": (C.c_int, [vp, u32, P(SnkDevReads), u64, vp, vp, P(SnkHbv), P(SnkDevPaths), vp, cp, sz]),
         "snk_hbv_involution": (C.c_int, [P(SnkHbv), u64, vp, cp, sz]),
         "snk_write_hbv": (C.c_int, [cp, cp, u32, u64, vp, vp, P(SnkHbv), cp, sz]),
         "snk_read_fastb": (C.c_int, [cp, P(u64), P(u32), P(P(C.c_uint16)), P(P(u32)), cp, sz]),

@@ -56,6 +56,11 @@ def load():
         lib.sno_write_bv.argtypes = [C.c_char_p, C.POINTER(Unitigs)]
         lib.sno_read_bv.restype = C.c_int
         lib.sno_read_bv.argtypes = [C.c_char_p, C.POINTER(Unitigs)]
+        lib.sno_path_reads.restype = C.c_int
+        lib.sno_path_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(Unitigs),
+                                       C.POINTER(Hbv), C.c_void_p, C.c_void_p, C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_uint64)]
+        lib.sno_free.restype = None
+        lib.sno_free.argtypes = [C.c_void_p]
         for f in ("sno_table_free", "sno_unitigs_free", "sno_hbv_free"):
             getattr(lib, f).restype = None
         _lib = lib
@@ -86,6 +91,40 @@ def msp_scan(k, p, seq_codes: np.ndarray, perm=None):
     if ns < 0:
         raise RuntimeError("sno_msp_scan failed")
     return [(buf[i].value, buf[i].min_pos, buf[i].start, buf[i].len) for i in range(ns)]
+
+
+def path_reads(codes: np.ndarray, quals: np.ndarray, lens, unitigs: list[str], K=48):
+    """f1: read paths of untrimmed reads on the graph of the given (BVComp-ordered) unitigs: (offset i32[n], n_edges i32[n],
+    edges i32[sum]) with HBV edge ids -- the restatement of pathReads / HBVPather::algorithmTwo / ExtendReadPath."""
+    lib = load()
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    quals = np.ascontiguousarray(quals, dtype=np.uint8)
+    n, stride = codes.shape
+    assert quals.shape == codes.shape
+    lens = np.ascontiguousarray(np.broadcast_to(np.asarray(lens), (n,)), dtype=np.uint32)
+    lut = np.zeros(256, dtype=np.uint8)
+    for i, ch in enumerate(b"ACGT"):
+        lut[ch] = i
+    off = np.zeros(len(unitigs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(u) for u in unitigs])
+    bases = lut[np.frombuffer("".join(unitigs).encode(), dtype=np.uint8)] if unitigs else np.zeros(1, np.uint8)
+    bases = np.ascontiguousarray(bases)
+    u = Unitigs(len(unitigs), off.ctypes.data_as(C.POINTER(C.c_uint64)), bases.ctypes.data_as(C.POINTER(C.c_uint8)))
+    h = Hbv()
+    if lib.sno_hbv_build(C.byref(u), K, C.byref(h)) != 0:
+        raise RuntimeError("sno_hbv_build failed")
+    o_off = np.zeros(n, dtype=np.int32)
+    o_n = np.zeros(n, dtype=np.int32)
+    pe = C.POINTER(C.c_int32)()
+    tot = C.c_uint64(0)
+    rc = lib.sno_path_reads(codes.ctypes.data, quals.ctypes.data, stride, lens.ctypes.data, n, K, C.byref(u), C.byref(h),
+                            o_off.ctypes.data, o_n.ctypes.data, C.byref(pe), C.byref(tot))
+    lib.sno_hbv_free(C.byref(h))
+    if rc != 0:
+        raise RuntimeError(f"sno_path_reads failed {rc}")
+    edges = np.ctypeslib.as_array(pe, shape=(max(tot.value, 1),))[:tot.value].copy()
+    lib.sno_free(pe)
+    return o_off, o_n, edges
 
 
 class OracleResult:

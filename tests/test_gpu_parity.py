@@ -586,3 +586,19 @@ def test_device_hbv_many_unitigs(engine):
     assert h["n_vertices"] == h2["n_vertices"] and h["n_edges"] == h2["n_edges"]
     for k in ("v_left", "v_right", "src", "is_rc", "fwd", "rev"):
         assert np.array_equal(h[k], h2[k]), k
+
+
+@pytest.mark.parametrize("name", goldens.CASES)
+def test_read_paths_match_reference(engine, graph_stage, name):
+    """f1: read pathing on the device (dictionary over the unitigs, wave-per-read seed and extend, algorithmTwo, quality-aware
+    extension) against the paths the reference binary dumped: offset and HBV edge ids of every read, bit for bit."""
+    if graph_stage == "global":
+        pytest.skip("pathing reads the unitigs; one graph stage is enough")
+    c = goldens.load(name)
+    rows, quals, bc, lens = _to_dev(c)
+    res = engine.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, ign_bc_below=c.ign_bc_below)
+    off, ne, edges, info = res.path_reads(rows, c.read_len, quals, lens=lens)
+    bad = np.nonzero(ne.astype(np.int64) != c.exp_path_n)[0]
+    assert len(bad) == 0, (len(bad), bad[:5], ne[bad[:5]], c.exp_path_n[bad[:5]])
+    assert np.array_equal(edges, c.exp_path_edges)
+    assert np.array_equal(off, c.exp_path_off)

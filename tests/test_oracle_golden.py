@@ -120,3 +120,15 @@ def test_oracle_k60_matches_reference(name):
     assert np.array_equal(o.ctx, g.exp_ctx)
     assert o.unitigs == g.exp_unitigs
     assert o.hbv_text() == g.exp_hbv
+
+
+@pytest.mark.parametrize("name", goldens.CASES)
+def test_read_paths_match_reference(name):
+    """f1: the restatement of pathReads (new aligner) against the read paths the reference binary dumped for the golden cases:
+    offset and HBV edge ids of every read, untrimmed reads, N bases as A."""
+    c = goldens.load(name)
+    off, n, edges = oracle_lib.path_reads(c.codes, c.quals, c.lens, c.exp_unitigs, K=48)
+    bad = np.nonzero((n != c.exp_path_n))[0]
+    assert len(bad) == 0, (len(bad), bad[:5], n[bad[:5]], c.exp_path_n[bad[:5]])
+    assert np.array_equal(edges, c.exp_path_edges)
+    assert np.array_equal(off, c.exp_path_off)
