@@ -9,12 +9,15 @@
 //   ExtendReadPath::attemptLeft/RightExtension   paths/long/ExtendReadPath.cc:108-358 (+ scoreLeft/RightOverlap :15-106)
 //   pathReads                                    :1441-1469  (the reference: one thread per 500 k reads, a hash-set look-up per k-mer)
 //
-// Layout.  The dictionary is an open-addressing table in HBM over all k-mers of all unitigs: u32 fingerprint + u64 (unitig, offset)
-// per slot, two slots per k-mer; a hit is verified against the unitig's 2-bit packed sequence (exact, and it tells the strand).
-// One wave per read: the 64 lanes look up 64 consecutive k-mer positions at once (a read with an error has K missing k-mers
-// in a row -- one round instead of 48 dependent look-ups), the first hit seeds, the exact-match extension compares 64 bases
-// per step with a ballot.  The bookkeeping that follows (a handful of parts per read) is the reference's sequential logic,
-// run by lane 0 over the parts in LDS; paths leave through a wave-level reservation and are put in read order by a gather.
+// Layout.  The dictionary is an open-addressing table in HBM over all k-mers of all unitigs, two slots per k-mer: the 128-bit
+// canonical key and a u64 (unitig, strand of the canonical form inside the unitig, offset) -- a look-up is exact with ONE
+// dependent load on a miss and two on a hit.  One wave per read, and the whole thing is latency bound (a read is a chain of
+// dependent random accesses), so the chain is kept short: the first k-mer is looked up by one lane (99 % of the reads of a
+// deep data set start on the graph); only after a miss do the 64 lanes look up 64 consecutive positions at once (a read with
+// an error has K missing k-mers in a row -- one round instead of 48 dependent look-ups); the exact-match extension compares
+// 128 bases per step with two ballots; per-unitig records (offset, length, both HBV edges, hanging-seed flags) come with one
+// 32-byte load.  The bookkeeping that follows (a handful of parts per read) is the reference's sequential logic, run by lane 0
+// over the parts in LDS; paths leave through a wave-level reservation and are put in read order by a gather.
 #include <string.h>
 
 #include <vector>
@@ -28,22 +31,23 @@
 namespace {
 
 constexpr int PCAP = 112;      // path parts per read (a 150-base read has at most 103 k-mers)
-constexpr int PMAX = 128;      // edges per read path
+constexpr int PMAX = 64;       // edges per read path
 
 struct path_graph {            // device arrays
     const uint64_t* uoff;      // [U+1] unitig offsets into ubases (device order)
     const uint8_t* ubases;     // 1 byte per base
-    const uint64_t* woff;      // [U+1] offsets into upacked (32-bit words, 16 bases each, MSB first)
-    const uint32_t* upacked;
+    const uint4* uinfo;        // [U] x 2: {offset lo, offset hi, bases, flags}, {fwd edge, rev edge, 0, 0}; flags bit 0 / 1: a seed on the
+                               //     forward / reverse-complement copy is dropped (hanging edge rule, BuildReadQGraph48.cc:1240-1247)
     const int32_t *fwd, *rev;  // [U] HBV edge of the unitig read forward / reverse-complemented
     const int32_t *vleft, *vright;         // [E]
     const int32_t *e_unitig;               // [E] device index of the unitig the edge is a copy of
     const uint8_t* e_rc;                   // [E]
     const int32_t *to_off, *to_v, *to_e;   // [N+1], [E], [E]: in-edges of a vertex, AddEdge order (graph/DigraphTemplate.h:2572-2582)
     const int32_t *from_off, *from_v, *from_e;
-    const uint32_t* dfp;       // dictionary: fingerprint | 1, 0 = empty
-    const unsigned long long* dval;        // unitig << 32 | offset
-    uint64_t dmask;
+    const uint4* dslot;        // dictionary, 32 bytes per slot: {key lo lo32, lo hi32, hi lo32, hi hi32} {offset | rev << 31, unitig, 0, 0};
+                               //   key hi == ~0: empty (no canonical k-mer starts with 32 T); rev: the unitig holds the reverse complement of the
+                               //   canonical form.  One random access (one TLB entry, one sector pair) per probe.
+    uint64_t dcap;             // slots: 2.5 per k-mer, not a power of two
 };
 
 template <int K>
@@ -59,17 +63,16 @@ __device__ __forceinline__ snk_kmer kmer_at(const uint32_t* words, uint32_t nwor
     f.lo = lo & ~((1ull << (128 - 2 * K)) - 1ull);
     return f;
 }
-__device__ __forceinline__ uint64_t dict_slot(snk_kmer c, uint32_t* fp) {
+__device__ __forceinline__ uint64_t dict_slot(snk_kmer c, uint64_t cap) {
     uint32_t h1, h2;
     snk_kmer_hash2(c, &h1, &h2);
-    *fp = h2 | 1u;
-    return ((uint64_t)h1 << 20) ^ h2;
+    return __umul64hi(((uint64_t)h1 << 32) | h2, cap);          // multiply-shift range reduction
 }
 
-// ---- dictionary build: one thread per base position of the concatenated unitigs
+// ---- dictionary build: one thread per base position of the concatenated unitigs; a slot is claimed on a u32 lock word
 template <int K>
 __global__ void __launch_bounds__(256) dict_build_kernel(const uint64_t* __restrict__ uoff, const uint8_t* __restrict__ ubases, uint64_t U, uint64_t total,
-                                                         uint32_t* __restrict__ dfp, unsigned long long* __restrict__ dval, uint64_t dmask) {
+                                                         uint32_t* __restrict__ lock, uint4* __restrict__ dslot, uint64_t dcap) {
     const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= total) return;
     uint64_t lo = 0, hi = U;                     // largest u with uoff[u] <= p
@@ -80,30 +83,29 @@ __global__ void __launch_bounds__(256) dict_build_kernel(const uint64_t* __restr
     f.hi = 0; f.lo = 0;
     for (int q = 0; q < K; ++q) f = snk_kmer_succ<K>(f, ubases[p + q] & 3u);
     const snk_kmer r = snk_kmer_rc<K>(f);
-    const snk_kmer c = snk_kmer_lt(r, f) ? r : f;
-    uint32_t fp;
-    uint64_t s = dict_slot(c, &fp) & dmask;
+    const bool rev = snk_kmer_lt(r, f);
+    const snk_kmer c = rev ? r : f;
+    uint64_t s = dict_slot(c, dcap);
     for (;;) {
-        if (atomicCAS(&dfp[s], 0u, fp) == 0u) { dval[s] = ((unsigned long long)lo << 32) | (unsigned long long)o; break; }
-        s = (s + 1) & dmask;
+        if (atomicCAS(&lock[s], 0u, 1u) == 0u) {
+            dslot[2 * s] = make_uint4((uint32_t)c.lo, (uint32_t)(c.lo >> 32), (uint32_t)c.hi, (uint32_t)(c.hi >> 32));
+            dslot[2 * s + 1] = make_uint4((uint32_t)o | (rev ? 0x80000000u : 0u), (uint32_t)lo, 0u, 0u);
+            break;
+        }
+        if (++s == dcap) s = 0;
     }
 }
-__global__ void __launch_bounds__(256) words_kernel(const uint64_t* __restrict__ uoff, uint64_t U, uint64_t* __restrict__ nw) {
+// per-unitig record for the pather
+__global__ void __launch_bounds__(256) uinfo_kernel(const uint64_t* __restrict__ uoff, uint64_t U, const int32_t* __restrict__ fwd, const int32_t* __restrict__ rev,
+                                                    const uint8_t* __restrict__ e_drop, uint4* __restrict__ uinfo) {
     const uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (u <= U) nw[u] = u < U ? (uoff[u + 1] - uoff[u] + 15) / 16 : 0ull;
+    if (u >= U) return;
+    const uint64_t o = uoff[u];
+    const uint32_t len = (uint32_t)(uoff[u + 1] - o);
+    const int32_t f = fwd[u], r = rev[u];
+    uinfo[2 * u] = make_uint4((uint32_t)o, (uint32_t)(o >> 32), len, (uint32_t)e_drop[f] | ((uint32_t)e_drop[r] << 1));
+    uinfo[2 * u + 1] = make_uint4((uint32_t)f, (uint32_t)r, 0u, 0u);
 }
-__global__ void __launch_bounds__(256) upack_kernel(const uint64_t* __restrict__ uoff, const uint8_t* __restrict__ ubases, const uint64_t* __restrict__ woff,
-                                                    uint64_t U, uint64_t total_words, uint32_t* __restrict__ out) {
-    const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (w >= total_words) return;
-    uint64_t lo = 0, hi = U;
-    while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (woff[mid] <= w) lo = mid; else hi = mid; }
-    const uint64_t b0 = uoff[lo] + (w - woff[lo]) * 16, end = uoff[lo + 1];
-    uint32_t v = 0;
-    for (int j = 0; j < 16; ++j) v = (v << 2) | (b0 + j < end ? (uint32_t)(ubases[b0 + j] & 3u) : 0u);
-    out[w] = v;
-}
-
 // ---- the sequential part of a read's path, run by one lane (parts in LDS)
 struct ppart { uint32_t unitig; uint32_t off_rc; uint32_t len; uint32_t elen; };      // elen == 0: a gap (only len counts); off_rc = offset | rc << 31
 __device__ __forceinline__ bool p_gap(const ppart& p) { return p.elen == 0; }
@@ -112,15 +114,16 @@ __device__ __forceinline__ uint32_t p_rc(const ppart& p) { return p.off_rc >> 31
 __device__ __forceinline__ bool p_same_edge(const ppart& a, const ppart& b) { return a.unitig == b.unitig && p_rc(a) == p_rc(b); }
 __device__ __forceinline__ ppart make_gap(uint32_t len) { ppart g; g.unitig = 0; g.off_rc = 0; g.len = len; g.elen = 0; return g; }
 
-__device__ __forceinline__ uint32_t u_len(const path_graph& G, uint32_t u) { return (uint32_t)(G.uoff[u + 1] - G.uoff[u]); }
+__device__ __forceinline__ uint32_t u_len(const path_graph& G, uint32_t u) { return G.uinfo[2 * (uint64_t)u].z; }
 __device__ __forceinline__ uint32_t u_base(const path_graph& G, uint32_t u, uint32_t rc, uint32_t i) {
-    const uint8_t* b = G.ubases + G.uoff[u];
-    return rc ? (uint32_t)(b[u_len(G, u) - 1 - i] ^ 3u) & 3u : (uint32_t)b[i] & 3u;
+    const uint4 q = G.uinfo[2 * (uint64_t)u];
+    const uint8_t* b = G.ubases + (((uint64_t)q.y << 32) | q.x);
+    return rc ? (uint32_t)(b[q.z - 1 - i] ^ 3u) & 3u : (uint32_t)b[i] & 3u;
 }
 __device__ __forceinline__ uint32_t e_len(const path_graph& G, int32_t e) { return u_len(G, (uint32_t)G.e_unitig[e]); }
 __device__ __forceinline__ int to_size(const path_graph& G, int32_t v) { return G.to_off[v + 1] - G.to_off[v]; }
 __device__ __forceinline__ int from_size(const path_graph& G, int32_t v) { return G.from_off[v + 1] - G.from_off[v]; }
-__device__ __forceinline__ int32_t part_edge(const path_graph& G, const ppart& p) { return p_rc(p) ? G.rev[p.unitig] : G.fwd[p.unitig]; }
+__device__ __forceinline__ int32_t part_edge(const path_graph& G, const ppart& p) { const uint4 q = G.uinfo[2 * (uint64_t)p.unitig + 1]; return (int32_t)(p_rc(p) ? q.y : q.x); }
 
 // PathPart::isConformingCapturedGap :659-666 (unsigned arithmetic as written)
 __device__ bool conforming_gap(const ppart* p, uint32_t max_jitter) {
@@ -142,7 +145,8 @@ __device__ bool joinable(const path_graph& G, const ppart& a, const ppart& b) {
 __device__ __forceinline__ uint32_t read_base(const uint32_t* row, uint32_t p) { return (row[p >> 4] >> (30 - 2 * (p & 15))) & 3u; }
 // scoreLeftOverlap / scoreRightOverlap, ExtendReadPath.cc:15-106: decay 0.2, Q2 counted as Q20, 10 per read base left over
 template <int K>
-__device__ uint32_t score_overlap(const path_graph& G, const uint32_t* row, const uint8_t* quals, uint32_t n, uint32_t start, int32_t e, bool left) {
+__device__ uint32_t score_overlap(const path_graph& G, const uint32_t* row, const uint8_t* __restrict__ quals /* the read's row in HBM */, uint32_t n, uint32_t start, int32_t e,
+                                  bool left) {
     const uint32_t esz = e_len(G, e), u = (uint32_t)G.e_unitig[e], erc = G.e_rc[e];
     uint32_t qsum = 0, penalty = 0, steps = 0;
     for (;; ++steps) {
@@ -202,7 +206,7 @@ __device__ bool extend_once(const path_graph& G, int32_t* path, int* np, int32_t
         }
     }
     if (least_edge == -1 || (uint64_t)least > last_gap * 10) return false;
-    if (*np >= PMAX) return false;
+    if (*np >= PMAX) { *offset = 0x7FFFFFFF; return false; }      // marks the path as too long (reported, never truncated silently)
     if (left) {
         for (int i = *np; i > 0; --i) path[i] = path[i - 1];
         path[0] = least_edge;
@@ -220,10 +224,7 @@ __device__ void finish_path(const path_graph& G, ppart* parts, int m, const uint
     int m2 = 0;
     for (int i = 0; i < m; ++i) {
         ppart p = parts[i];
-        if (!p_gap(p)) {
-            const int32_t e = part_edge(G, p), vl = G.vleft[e], vr = G.vright[e];
-            if (to_size(G, vl) == 0 && to_size(G, vr) > 1 && from_size(G, vr) > 0 && p.elen <= 100) p = make_gap(p.len);
-        }
+        if (!p_gap(p) && ((G.uinfo[2 * (uint64_t)p.unitig].w >> p_rc(p)) & 1u)) p = make_gap(p.len);      // precomputed per edge (host, drop_flags)
         if (p_gap(p) && m2 && p_gap(parts[m2 - 1])) parts[m2 - 1].len += p.len;
         else parts[m2++] = p;
     }
@@ -258,10 +259,11 @@ __device__ void finish_path(const path_graph& G, ppart* parts, int m, const uint
     int np = 0;
     int32_t offset = 0;
     int last = -1;
+    bool too_long = false;
     for (int i = 0; i < m; ++i) {
         if (p_gap(parts[i])) continue;
         if (last >= 0 && p_same_edge(parts[last], parts[i])) continue;
-        if (np < PMAX) path[np++] = part_edge(G, parts[i]);
+        if (np < PMAX) path[np++] = part_edge(G, parts[i]); else too_long = true;
         last = i;
     }
     if (np) offset = !p_gap(parts[0]) ? (int32_t)p_off(parts[0]) : (int32_t)p_off(parts[1]) - (int32_t)parts[0].len;
@@ -270,7 +272,7 @@ __device__ void finish_path(const path_graph& G, ppart* parts, int m, const uint
     // ExtendReadPath::attemptLeftRightExtension :108-119
     while (extend_once<K>(G, path, &np, &offset, row, quals, n, true)) {}
     while (extend_once<K>(G, path, &np, &offset, row, quals, n, false)) {}
-    *np_out = np;
+    *np_out = (too_long || offset == 0x7FFFFFFF) ? -1 : np;
     *off_out = offset;
 }
 
@@ -282,83 +284,111 @@ struct path_args {
     uint64_t n_reads;
     int32_t* out_off;                 // [n] offset of the read on its first edge (ReadPath::mOffset)
     uint32_t* out_n;                  // [n + 1] edges per read
-    unsigned long long* out_start;    // [n] position of the read's edges in the scratch list
-    int32_t* scratch;                 // edges in completion order
+    int32_t* out_e0;                  // [n] first edge of the path (-1: none)
+    unsigned long long* out_start;    // [n] position of the read's FURTHER edges in the scratch list
+    int32_t* scratch;                 // second and later edges in completion order
     unsigned long long* cursor;       // [0] edges reserved, [1] error flags
     uint64_t scratch_cap;
 };
 
+// one dictionary look-up: canonical form, probe, the strand the read is on relative to the unitig
 template <int K>
-__global__ void __launch_bounds__(256) path_kernel(path_args a) {
-    __shared__ uint32_t rowL[4][20];
-    __shared__ uint8_t qualL[4][256];
-    __shared__ ppart partsL[4][PCAP];
-    __shared__ int32_t pathL[4][PMAX];
-    __shared__ int32_t resL[4][4];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+__device__ __forceinline__ bool dict_find(const path_graph& G, const uint32_t* row, uint32_t pos, uint32_t* hu, uint32_t* ho, uint32_t* hrc) {
+    const snk_kmer f = kmer_at<K>(row, 20, pos);
+    const snk_kmer rk = snk_kmer_rc<K>(f);
+    const bool rrev = snk_kmer_lt(rk, f);
+    const snk_kmer c = rrev ? rk : f;
+    uint64_t s = dict_slot(c, G.dcap);
+    for (;;) {
+        const uint4 k = G.dslot[2 * s];
+        if (k.w == 0xFFFFFFFFu && k.z == 0xFFFFFFFFu) return false;
+        if ((((uint64_t)k.w << 32) | k.z) == c.hi && (((uint64_t)k.y << 32) | k.x) == c.lo) {
+            const uint4 v = G.dslot[2 * s + 1];
+            *hu = v.y;
+            *ho = v.x & 0x7FFFFFFFu;
+            *hrc = (v.x >> 31) ^ (rrev ? 1u : 0u);       // read k-mer vs the unitig's k-mer: CF<K>::isRC, dna/CanonicalForm.h:85-91
+            return true;
+        }
+        if (++s == G.dcap) s = 0;
+    }
+}
+
+// Sixteen lanes per read, four reads per wave: the kernel is bound by instruction issue (a read is ~1000 wave-level
+// instructions whatever the number of active lanes), so four reads share every instruction.  A group's control flow is
+// uniform inside the group; the groups of a wave diverge like threads do.
+template <int K>
+__global__ void __launch_bounds__(256, 8) path_kernel(path_args a) {
+    __shared__ uint32_t rowL[16][20];
+    __shared__ ppart partsL[16][PCAP];
+    __shared__ int32_t pathL[16][PMAX];
+    __shared__ int32_t resL[16][4];
+    const int lane = threadIdx.x & 63, sub = lane & 15, gsh = lane & 48;       // gsh: first lane of my group
+    const int gw = threadIdx.x >> 4;                                           // group inside the workgroup
     const path_graph& G = a.G;
-    uint32_t* row = rowL[wv];
-    uint8_t* ql = qualL[wv];
-    ppart* parts = partsL[wv];
-    const uint64_t nw = (uint64_t)gridDim.x * 4;
-    for (uint64_t r = (uint64_t)blockIdx.x * 4 + wv; r < a.n_reads; r += nw) {
-        uint32_t n = a.lens ? a.lens[r] : a.read_len;
-        if (n > a.read_len) n = a.read_len;
-        if (lane < 20) row[lane] = (uint32_t)lane < a.row_words ? a.rows[r * a.row_words + lane] : 0u;
-        for (uint32_t q = lane; q < 256; q += 64) ql[q] = q < n ? a.quals[r * a.qstride + q] : 0;
+    uint32_t* row = rowL[gw];
+    ppart* parts = partsL[gw];
+    const uint64_t ng = (uint64_t)gridDim.x * 16;
+    for (uint64_t r0 = (uint64_t)blockIdx.x * 16; r0 < a.n_reads; r0 += ng) {
+        const uint64_t r = r0 + gw;
+        const bool live = r < a.n_reads;
+        uint32_t n = 0;
+        if (live) {
+            n = a.lens ? a.lens[r] : a.read_len;
+            if (n > a.read_len) n = a.read_len;
+            row[sub] = (uint32_t)sub < a.row_words ? a.rows[r * a.row_words + sub] : 0u;
+            if (sub < 4) row[16 + sub] = 0u;
+        }
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
-        // ---- Pather::path :705-748, 64 k-mer positions per round
+        // ---- Pather::path :705-748
         int m = 0;
         bool overflow = false;
-        if (n < (uint32_t)K) { if (lane == 0) parts[0] = make_gap(n); m = 1; }
-        else {
+        if (live && n < (uint32_t)K) { if (sub == 0) parts[0] = make_gap(n); m = 1; }
+        else if (live) {
             const uint32_t end = n - K + 1;
             uint32_t i = 0, gap = 0;
+            bool wide = false;                // after a miss the next look-ups go 16 positions at a time
             while (i < end) {
-                const uint32_t pos = i + lane;
+                const uint32_t pos = i + sub;
                 bool hit = false;
                 uint32_t hu = 0, ho = 0, hrc = 0;
-                if (pos < end) {
-                    const snk_kmer f = kmer_at<K>(row, 20, pos);
-                    const snk_kmer rk = snk_kmer_rc<K>(f);
-                    const snk_kmer c = snk_kmer_lt(rk, f) ? rk : f;
-                    uint32_t fp;
-                    uint64_t s = dict_slot(c, &fp) & G.dmask;
-                    for (;;) {
-                        const uint32_t t = G.dfp[s];
-                        if (t == 0u) break;
-                        if (t == fp) {
-                            const unsigned long long v = G.dval[s];
-                            const uint32_t u = (uint32_t)(v >> 32), o = (uint32_t)v;
-                            const uint64_t w0 = G.woff[u];
-                            const snk_kmer e = kmer_at<K>(G.upacked + w0, (uint32_t)(G.woff[u + 1] - w0), o);
-                            if (snk_kmer_eq(e, f)) { hit = true; hu = u; ho = o; hrc = 0; break; }
-                            if (snk_kmer_eq(e, rk)) { hit = true; hu = u; ho = o; hrc = 1; break; }     // CF<K>::isRC, dna/CanonicalForm.h:85-91
-                        }
-                        s = (s + 1) & G.dmask;
-                    }
+                if (pos < end && (wide || sub == 0)) hit = dict_find<K>(G, row, pos, &hu, &ho, &hrc);
+                const uint32_t hm = (uint32_t)(__ballot(hit) >> gsh) & 0xFFFFu;
+                if (!hm) {
+                    const uint32_t step = !wide ? 1u : (end - i < 16u ? end - i : 16u);
+                    gap += step; i += step; wide = true;
+                    continue;
                 }
-                const unsigned long long hm = __ballot(hit);
-                if (!hm) { const uint32_t step = end - i < 64u ? end - i : 64u; gap += step; i += step; continue; }
-                const int first = __ffsll((long long)hm) - 1;
+                wide = false;
+                const int first = __ffs((int)hm) - 1;
                 gap += (uint32_t)first;
                 i += (uint32_t)first;
-                const uint32_t u = __shfl(hu, first), o0 = __shfl(ho, first), rc = __shfl(hrc, first);
-                const uint32_t sz = u_len(G, u);
-                // exact-match extension behind the seed (matchLen :549-558): 64 bases per step
+                const uint32_t u = __shfl(hu, gsh + first), o0 = __shfl(ho, gsh + first), rc = __shfl(hrc, gsh + first);
+                const uint4 ui = G.uinfo[2 * (uint64_t)u];
+                const uint32_t sz = ui.z;
+                const uint8_t* ub = G.ubases + (((uint64_t)ui.y << 32) | ui.x);
+                // exact-match extension behind the seed (matchLen :549-558): 128 bases per step, eight per lane
                 uint32_t a0 = i + K, b0, off;
                 if (!rc) { off = o0; b0 = o0 + K; } else { off = sz - o0; b0 = off; off -= K; }      // :726-729
                 uint32_t len = 1;
                 for (;;) {
-                    const uint32_t ra = a0 + lane, eb = b0 + lane;
-                    const bool in = ra < n && eb < sz;
-                    const bool same = in && read_base(row, ra) == u_base(G, u, rc, eb);
-                    const unsigned long long mm = __ballot(!same);
-                    if (mm) { len += (uint32_t)(__ffsll((long long)mm) - 1); break; }
-                    len += 64; a0 += 64; b0 += 64;
+                    uint32_t cnt = 0;
+                    bool stop = false;
+#pragma unroll
+                    for (uint32_t q = 0; q < 8; ++q) {
+                        const uint32_t ra = a0 + 8u * sub + q, eb = b0 + 8u * sub + q;
+                        bool same = false;
+                        if (ra < n && eb < sz) {
+                            const uint32_t e1 = rc ? (uint32_t)(ub[sz - 1 - eb] ^ 3u) & 3u : (uint32_t)ub[eb] & 3u;
+                            same = read_base(row, ra) == e1;
+                        }
+                        if (!stop) { if (same) ++cnt; else stop = true; }
+                    }
+                    const uint32_t mm = (uint32_t)(__ballot(stop) >> gsh) & 0xFFFFu;
+                    if (mm) { const int fl = __ffs((int)mm) - 1; len += 8u * (uint32_t)fl + __shfl(cnt, gsh + fl); break; }
+                    len += 128; a0 += 128; b0 += 128;
                 }
-                if (lane == 0) {
+                if (sub == 0) {
                     if (gap) { if (m < PCAP) parts[m] = make_gap(gap); }
                     const int at = m + (gap ? 1 : 0);
                     if (at < PCAP) { ppart p; p.unitig = u; p.off_rc = off | (rc << 31); p.len = len; p.elen = sz - K + 1; parts[at] = p; }
@@ -368,39 +398,47 @@ __global__ void __launch_bounds__(256) path_kernel(path_args a) {
                 gap = 0;
                 i += len;
             }
-            if (gap && !overflow) { if (m < PCAP) { if (lane == 0) parts[m] = make_gap(gap); ++m; } else overflow = true; }
+            if (gap && !overflow) { if (m < PCAP) { if (sub == 0) parts[m] = make_gap(gap); ++m; } else overflow = true; }
         }
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
-        // ---- the rest of algorithmTwo + the extension: sequential, lane 0
-        if (lane == 0) {
+        // ---- the rest of algorithmTwo + the extension: sequential, the group's first lane
+        if (live && sub == 0) {
             int np = 0;
             int32_t off = 0;
-            if (!overflow) finish_path<K>(G, parts, m, row, ql, n, pathL[wv], &np, &off);
+            if (!overflow) finish_path<K>(G, parts, m, row, a.quals + r * a.qstride, n, pathL[gw], &np, &off);
+            if (np < 0) { overflow = true; np = 0; off = 0; }
+            // a path's first edge travels with the read; only the rest (one read in a thousand has more than one edge on a deep
+            // data set) takes a reservation on the shared cursor -- 1e8 atomics on one address were a second of serialisation
             unsigned long long st = 0;
-            if (np) st = atomicAdd(&a.cursor[0], (unsigned long long)np);
-            if (overflow || st + (unsigned long long)np > a.scratch_cap) { atomicOr(&a.cursor[1], overflow ? 1ull : 2ull); np = 0; }
+            if (np > 1) st = atomicAdd(&a.cursor[0], (unsigned long long)(np - 1));
+            if (overflow || (np > 1 && st + (unsigned long long)(np - 1) > a.scratch_cap)) { atomicOr(&a.cursor[1], overflow ? 1ull : 2ull); np = 0; }
             a.out_off[r] = off;
             a.out_n[r] = (uint32_t)np;
+            a.out_e0[r] = np ? pathL[gw][0] : -1;
             a.out_start[r] = st;
-            resL[wv][0] = np;
-            resL[wv][1] = (int32_t)(st & 0xFFFFFFFFu);
-            resL[wv][2] = (int32_t)(st >> 32);
+            resL[gw][0] = np;
+            resL[gw][1] = (int32_t)(st & 0xFFFFFFFFu);
+            resL[gw][2] = (int32_t)(st >> 32);
         }
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
-        const int np = resL[wv][0];
-        const unsigned long long st = ((unsigned long long)(uint32_t)resL[wv][2] << 32) | (uint32_t)resL[wv][1];
-        for (int q = lane; q < np; q += 64) a.scratch[st + q] = pathL[wv][q];
+        if (live) {
+            const int np = resL[gw][0];
+            const unsigned long long st = ((unsigned long long)(uint32_t)resL[gw][2] << 32) | (uint32_t)resL[gw][1];
+            for (int q = 1 + sub; q < np; q += 16) a.scratch[st + q - 1] = pathL[gw][q];
+        }
         __builtin_amdgcn_wave_barrier();
     }
 }
-__global__ void __launch_bounds__(256) path_gather_kernel(const uint32_t* __restrict__ n, const unsigned long long* __restrict__ start, const uint64_t* __restrict__ pos,
-                                                          const int32_t* __restrict__ scratch, uint64_t n_reads, int32_t* __restrict__ out) {
+__global__ void __launch_bounds__(256) path_gather_kernel(const uint32_t* __restrict__ n, const int32_t* __restrict__ e0, const unsigned long long* __restrict__ start,
+                                                          const uint64_t* __restrict__ pos, const int32_t* __restrict__ scratch, uint64_t n_reads,
+                                                          int32_t* __restrict__ out) {
     const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= n_reads) return;
     const uint32_t c = n[r];
-    for (uint32_t q = 0; q < c; ++q) out[pos[r] + q] = scratch[start[r] + q];
+    if (c) out[pos[r]] = e0[r];
+    for (uint32_t q = 1; q < c; ++q) out[pos[r] + q] = scratch[start[r] + q - 1];
 }
 __global__ void __launch_bounds__(256) widen_kernel(const uint32_t* __restrict__ in, uint64_t n, uint64_t* __restrict__ out) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -482,51 +520,59 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
         (rc = up(ctx, st, off_to, &G.to_off, err, errcap)) || (rc = up(ctx, st, v_to, &G.to_v, err, errcap)) || (rc = up(ctx, st, e_to, &G.to_e, err, errcap)) ||
         (rc = up(ctx, st, off_from, &G.from_off, err, errcap)) || (rc = up(ctx, st, v_from, &G.from_v, err, errcap)) || (rc = up(ctx, st, e_from, &G.from_e, err, errcap)))
         return rc;
-    // ---- packed unitigs + dictionary
+    // ---- per-unitig records + dictionary
     uint64_t h_off_last = 0;
     SNK_HIP_TRY(hipMemcpyAsync(&h_off_last, d_uoff + U, 8, hipMemcpyDeviceToHost, st));
-    uint64_t *nw, *woff;
-    if ((rc = dev(ctx, U + 2, &nw, err, errcap)) || (rc = dev(ctx, U + 2, &woff, err, errcap))) return rc;
-    hipLaunchKernelGGL(words_kernel, dim3((unsigned)((U + 256) / 256)), dim3(256), 0, st, d_uoff, U, nw);
-    if ((rc = scan64(ctx, st, nw, woff, U + 1, err, errcap))) return rc;
-    uint64_t total_words = 0;
-    SNK_HIP_TRY(hipMemcpyAsync(&total_words, woff + U, 8, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));            // also: the host vectors above have been copied
+    // seeds on a short hanging edge are dropped (BuildReadQGraph48.cc:1240-1247): a property of the edge, decided here once
+    std::vector<uint8_t> drop((size_t)E + 1, 0);
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    {
+        std::vector<uint64_t> h_uoff(U + 1);
+        if (U) SNK_HIP_TRY(hipMemcpy(h_uoff.data(), d_uoff, (U + 1) * 8, hipMemcpyDeviceToHost));
+        for (int32_t e = 0; e < E; ++e) {
+            const int32_t vl_ = vl[e], vr_ = vr[e];
+            const uint64_t kmers = h_uoff[(size_t)eu[e] + 1] - h_uoff[(size_t)eu[e]] - (K - 1);
+            drop[e] = (off_to[vl_ + 1] - off_to[vl_] == 0 && off_to[vr_ + 1] - off_to[vr_] > 1 && off_from[vr_ + 1] - off_from[vr_] > 0 && kmers <= 100) ? 1 : 0;
+        }
+    }
+    const uint8_t* d_drop;
+    if ((rc = up(ctx, st, drop, &d_drop, err, errcap))) return rc;
+    uint4* uinfo;
+    if ((rc = dev(ctx, 2 * U + 2, &uinfo, err, errcap))) return rc;
+    if (U) hipLaunchKernelGGL(uinfo_kernel, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, st, d_uoff, U, G.fwd, G.rev, d_drop, uinfo);
+    G.uinfo = uinfo;
     const uint64_t total_bases = h_off_last;
-    uint32_t* upacked;
-    if ((rc = dev(ctx, total_words + 8, &upacked, err, errcap))) return rc;
-    SNK_HIP_TRY(hipMemsetAsync(upacked + total_words, 0, 32, st));
-    if (total_words) hipLaunchKernelGGL(upack_kernel, dim3((unsigned)((total_words + 255) / 256)), dim3(256), 0, st, d_uoff, d_ubases, woff, U, total_words, upacked);
-    G.woff = woff; G.upacked = upacked;
     const uint64_t nk = total_bases >= U * (uint64_t)(K - 1) ? total_bases - U * (uint64_t)(K - 1) : 0;
-    uint64_t cap = 1024;
-    while (cap < 2 * nk + 2) cap <<= 1;
-    uint32_t* dfp;
-    unsigned long long* dval;
-    if ((rc = dev(ctx, cap, &dfp, err, errcap)) || (rc = dev(ctx, cap, &dval, err, errcap))) return rc;
-    SNK_HIP_TRY(hipMemsetAsync(dfp, 0, cap * 4, st));
-    if (total_bases) hipLaunchKernelGGL((dict_build_kernel<K>), dim3((unsigned)((total_bases + 255) / 256)), dim3(256), 0, st, d_uoff, d_ubases, U, total_bases, dfp, dval, cap - 1);
+    const uint64_t cap = ((2 * nk + nk / 2 + 1024) + 63) & ~63ull;        // load 0.4: the chain of dependent probes is what a read waits for
+    uint32_t* lock;
+    uint4* dslot;
+    if ((rc = dev(ctx, cap, &lock, err, errcap)) || (rc = dev(ctx, 2 * cap, &dslot, err, errcap))) return rc;
+    SNK_HIP_TRY(hipMemsetAsync(lock, 0, cap * 4, st));
+    SNK_HIP_TRY(hipMemsetAsync(dslot, 0xFF, cap * 32, st));
+    if (total_bases) hipLaunchKernelGGL((dict_build_kernel<K>), dim3((unsigned)((total_bases + 255) / 256)), dim3(256), 0, st, d_uoff, d_ubases, U, total_bases, lock, dslot, cap);
     SNK_HIP_TRY(hipGetLastError());
-    G.dfp = dfp; G.dval = dval; G.dmask = cap - 1;
+    SNK_HIP_TRY(hipStreamSynchronize(st));            // drop[] has been copied; the lock words are dead
+    snk_ctx_release_block(ctx, lock);
+    G.dslot = dslot; G.dcap = cap;
     SNK_HIP_TRY(hipEventRecord(e1, st));
     // ---- the reads
     a.rows = (const uint32_t*)in->rows; a.row_words = in->row_words; a.read_len = in->read_len;
     a.quals = (const uint8_t*)in->quals; a.qstride = in->qstride; a.lens = (const uint16_t*)in->lens; a.n_reads = n;
     uint32_t* out_n;
     unsigned long long *out_start, *cursor;
-    int32_t *out_off, *scratch = nullptr, *edges = nullptr;
+    int32_t *out_off, *out_e0, *scratch = nullptr, *edges = nullptr;
     uint64_t *n64, *pos;
-    if ((rc = dev(ctx, n + 1, &out_n, err, errcap)) || (rc = dev(ctx, n + 1, &out_start, err, errcap)) || (rc = dev(ctx, n + 1, &out_off, err, errcap)) ||
+    if ((rc = dev(ctx, n + 1, &out_n, err, errcap)) || (rc = dev(ctx, n + 1, &out_start, err, errcap)) || (rc = dev(ctx, n + 1, &out_off, err, errcap)) || (rc = dev(ctx, n + 1, &out_e0, err, errcap)) ||
         (rc = dev(ctx, 4, &cursor, err, errcap)) || (rc = dev(ctx, n + 2, &n64, err, errcap)) || (rc = dev(ctx, n + 2, &pos, err, errcap)))
         return rc;
-    uint64_t scap = n + n / 2 + 1024;                 // most reads lie on one edge; a wrong guess costs one re-run
+    uint64_t scap = n / 4 + 65536;                    // second and later edges only; a wrong guess costs one re-run
     unsigned long long h_cur[2] = {0, 0};
     for (int attempt = 0; attempt < 2; ++attempt) {
         if ((rc = dev(ctx, scap, &scratch, err, errcap))) return rc;
         SNK_HIP_TRY(hipMemsetAsync(cursor, 0, 16, st));
-        a.out_off = out_off; a.out_n = out_n; a.out_start = out_start; a.scratch = scratch; a.cursor = cursor; a.scratch_cap = scap;
+        a.out_off = out_off; a.out_n = out_n; a.out_e0 = out_e0; a.out_start = out_start; a.scratch = scratch; a.cursor = cursor; a.scratch_cap = scap;
         if (n) {
-            uint64_t grid = (n + 3) / 4;
+            uint64_t grid = (n + 15) / 16;
             const uint64_t gmax = (uint64_t)ctx->n_cu * 64;
             if (grid > gmax) grid = gmax;
             hipLaunchKernelGGL((path_kernel<K>), dim3((unsigned)grid), dim3(256), 0, st, a);
@@ -534,17 +580,19 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
         SNK_HIP_TRY(hipGetLastError());
         SNK_HIP_TRY(hipMemcpyAsync(h_cur, cursor, 16, hipMemcpyDeviceToHost, st));
         SNK_HIP_TRY(hipStreamSynchronize(st));
-        if (h_cur[1] & 1ull) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_dev_path_reads: a read has more than %d path parts", PCAP);
+        if (h_cur[1] & 1ull) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_dev_path_reads: a read has more than %d path parts or %d edges", PCAP, PMAX);
         if (!(h_cur[1] & 2ull)) break;
         if (attempt == 1) return snk_fail(SNK_E_INTERNAL, err, errcap, "snk_dev_path_reads: path scratch overflow");
         snk_ctx_release_block(ctx, scratch);
         scap = h_cur[0] + 1024;
     }
-    const uint64_t total = h_cur[0];
-    if ((rc = dev(ctx, total + 1, &edges, err, errcap))) return rc;
     hipLaunchKernelGGL(widen_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, st, out_n, n, n64);
     if ((rc = scan64(ctx, st, n64, pos, n + 1, err, errcap))) return rc;
-    if (n) hipLaunchKernelGGL(path_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out_n, out_start, pos, scratch, n, edges);
+    uint64_t total = 0;
+    SNK_HIP_TRY(hipMemcpyAsync(&total, pos + n, 8, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipStreamSynchronize(st));
+    if ((rc = dev(ctx, total + 1, &edges, err, errcap))) return rc;
+    if (n) hipLaunchKernelGGL(path_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out_n, out_e0, out_start, pos, scratch, n, edges);
     SNK_HIP_TRY(hipGetLastError());
     SNK_HIP_TRY(hipEventRecord(e2, st));
     SNK_HIP_TRY(hipStreamSynchronize(st));

@@ -526,6 +526,11 @@ def test_vs_reference_binary_200k(engine, graph_stage, tmp_path):
                              bc=torch.from_numpy(bc).to(dev))
     hist = np.asarray(d["hist"]["vals"], dtype=np.int64)
     _check_against(res, d["kmers"]["k"], d["kmers"]["count"], d["kmers"]["ctx"], d["unitigs"], d["goodlens"], hist)
+    # f1: the same run's read paths (the reference's pathReads, new aligner) against the device pather
+    rows_d, quals_d = torch.from_numpy(rows.view(np.int32)).to(dev), torch.from_numpy(quals).to(dev)
+    off, ne, edges, _ = res.path_reads(rows_d, 150, quals_d)
+    assert np.array_equal(ne.astype(np.int32), d["path_n"]) and np.array_equal(edges, d["path_edges"]) and np.array_equal(off, d["path_off"])
+    assert int((ne > 1).sum()) > 100 and int((ne == 0).sum()) > 0          # multi-edge paths and unplaced reads both occur
 
 
 def test_circle_pool_retry(engine, monkeypatch):
