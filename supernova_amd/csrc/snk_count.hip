@@ -91,6 +91,11 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     uint16_t* cidx = lpre + BATCH + 2;                                              // [NCI] leader rank that owns instance 32*w
     uint32_t* segi = reinterpret_cast<uint32_t*>(smem_raw + (((size_t)(reinterpret_cast<unsigned char*>(cidx + NCI) - smem_raw) + 15) & ~(size_t)15));   // [3][MAXSEG] segment start (lo, hi), length
     uint16_t* olist = reinterpret_cast<uint16_t*>(segi + 3 * SNK_COUNT_MAXSEG);     // [LIMIT] claimed slots in claim order (the filter walks these, not the table)
+    // minBC > 2 (areEnoughBarcodes counts DISTINCT barcodes for any minBC, BuildReadQGraph48.cc:117-137): six more barcode ids
+    // per slot behind the one in bcs[] -- up to seven distinct ids are told apart exactly, an eighth turns the state into MULTI
+    // (so min_bc <= 8).  Only allocated for such runs (a.bc_mode > 2); they give up the second workgroup per CU.
+    uint32_t* bcx = reinterpret_cast<uint32_t*>(smem_raw + (((size_t)(reinterpret_cast<unsigned char*>(olist + (SLOTS - THREADS - 64)) - smem_raw) + 15) & ~(size_t)15));   // [SLOTS][6]
+    const bool bcset = a.bc_mode > 2;
     // ctl[0] unused, ctl[1] occupied slots, ctl[2] overflow flag, ctl[3] split log2, ctl[4] split id,
     // ctl[5] valid entries of the sub-pass, ctl[6..7] reserved base (lo,hi), ctl[8] placement counter,
     // ctl[16..16+2*MAX) split stack (MAX = 17 levels -> up to ctl[51]), ctl[52..59] wave totals of the batch scan
@@ -198,7 +203,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                         bool same = true;
 #pragma unroll
                         for (int q = 0; q < 7; ++q) same &= rec[q * BATCH + L] == w[q];
-                        if (GROUPED) same &= rec[7 * BATCH + L] == rec[7 * BATCH + tid];     // same bases in another group: not a copy
+                        if (GROUPED || bcset) same &= rec[7 * BATCH + L] == rec[7 * BATCH + tid];     // same bases in another group: not a copy; minBC > 2: a folded supermer could not say how many barcodes it stands for
                         if (same) {
                             atomicAdd(&wgt[L], 1u);
                             const uint32_t mine = GROUPED ? 0u : rec[7 * BATCH + tid];
@@ -299,6 +304,10 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                                         klo[slot] = clo;
                                         cnt[slot] = 0;
                                         bcs[slot] = 0;
+                                        if (bcset) {
+#pragma unroll
+                                            for (int j = 0; j < 6; ++j) bcx[slot * 6 + j] = 0;
+                                        }
                                         __hip_atomic_store(&tag[slot], mytag | 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                                         uint32_t occ = atomicAdd(&ctl[1], 1u);
                                         if (occ >= LIMIT) __hip_atomic_store(&ctl[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -319,7 +328,17 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                                 if (bst >= BC_MULTI) atomicMax(&bcs[slot], bst);
                                 else if (bst) {
                                     uint32_t ob = atomicCAS(&bcs[slot], 0u, bst);
-                                    if (ob != 0 && ob != bst && ob < BC_MULTI) atomicMax(&bcs[slot], BC_MULTI);
+                                    if (ob != 0 && ob != bst && ob < BC_MULTI) {
+                                        if (!bcset) atomicMax(&bcs[slot], BC_MULTI);
+                                        else {
+                                            bool stored = false;
+                                            for (int j = 0; j < 6 && !stored; ++j) {
+                                                const uint32_t o = atomicCAS(&bcx[slot * 6 + j], 0u, bst);
+                                                stored = o == 0u || o == bst;
+                                            }
+                                            if (!stored) atomicMax(&bcs[slot], BC_MULTI);       // an eighth distinct barcode
+                                        }
+                                    }
                                 }
                             }
                         }
@@ -365,7 +384,12 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                 ok = c >= a.min_freq && c != 0;
                 if (ok && a.bc_mode) {
                     const uint32_t b = bcs[s];
-                    ok = a.bc_mode == 1 ? (b != 0) : (b >= BC_MULTI);
+                    if (!bcset) ok = a.bc_mode == 1 ? (b != 0) : (b >= BC_MULTI);
+                    else {
+                        uint32_t distinct = b ? 1u : 0u;
+                        for (int j = 0; j < 6; ++j) distinct += bcx[s * 6 + j] ? 1u : 0u;
+                        ok = b >= BC_MULTI || distinct >= a.bc_mode;
+                    }
                 }
             }
             const unsigned long long m = __ballot(ok);
@@ -416,15 +440,15 @@ template <> struct cfg<48> { static constexpr int THREADS = SNK_COUNT_THREADS; s
 template <> struct cfg<60> { static constexpr int THREADS = SNK_COUNT_THREADS; static constexpr int SLOTS = SNK_COUNT_SLOTS; };
 
 template <int K, bool G>
-size_t lds_bytes() {
+size_t lds_bytes(uint32_t bc_mode = 0) {
     constexpr size_t S = cfg<K>::SLOTS, B = (K == 48 && !G && S >= 2048) ? 512 : 256, DD = 2 * B, NCI = B * (K - SNK_M + 1) / 32 + 2;
-    return S * (8 + sizeof(typename klo_t<K, G>::type) + 4 + 4 + 4) + S + 4 * (8 * B + 64 + DD + B) + 2 * (B + B + 2 + NCI) + 16 + 4 * 3 * SNK_COUNT_MAXSEG + 2 * (S - cfg<K>::THREADS - 64) + 16;
+    return S * (8 + sizeof(typename klo_t<K, G>::type) + 4 + 4 + 4) + S + 4 * (8 * B + 64 + DD + B) + 2 * (B + B + 2 + NCI) + 16 + 4 * 3 * SNK_COUNT_MAXSEG + 2 * (S - cfg<K>::THREADS - 64) + 16 + (bc_mode > 2 ? S * 24 + 16 : 0);
 }
 
 template <int K, bool G>
 int launch(hipStream_t st, const snk_count_args& a, char* err, size_t errcap) {
     auto kern = a.nseg > 1 ? snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G, true> : snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G, false>;
-    size_t lds = lds_bytes<K, G>();
+    size_t lds = lds_bytes<K, G>(a.bc_mode);
     SNK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (a.bucket0 >= a.NB) return SNK_OK;          // the launch covers buckets [bucket0, NB)
     // one workgroup per output region, every launch of a table (the ranged launches of the sharded path) with the same grid:
@@ -440,9 +464,9 @@ int launch(hipStream_t st, const snk_count_args& a, char* err, size_t errcap) {
 // reads); exactly one residency wave (grid = 2 x CUs) is no better (73.5: whoever finishes early idles to the end); 32-64
 // waves keep both the dispatch cost and the tail small (67.3 ms).  SNK_COUNT_PERSIST sets the number of residency waves.
 template <int K, bool G>
-int regions(uint32_t nseg, uint32_t NB, uint32_t* out, char* err, size_t errcap) {
+int regions(uint32_t nseg, uint32_t NB, uint32_t bc_mode, uint32_t* out, char* err, size_t errcap) {
     auto kern = nseg > 1 ? snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G, true> : snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G, false>;
-    size_t lds = lds_bytes<K, G>();
+    size_t lds = lds_bytes<K, G>(bc_mode);
     SNK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     uint32_t persist = snk_env_u32("SNK_COUNT_PERSIST", 32);
     if (persist == 0) persist = 1;
@@ -485,14 +509,15 @@ int snk_launch_compact_regions(hipStream_t st, const snk_u128* keys_in, const ui
 
 uint32_t snk_count_slots(uint32_t K) { return K == 60 ? cfg<60>::SLOTS : cfg<48>::SLOTS; }
 
-int snk_count_regions(uint32_t K, uint32_t grouped, uint32_t nseg, uint32_t NB, uint32_t* n_regions, char* err, size_t errcap) {
-    if (grouped) return regions<48, true>(nseg, NB, n_regions, err, errcap);
-    if (K == 60) return regions<60, false>(nseg, NB, n_regions, err, errcap);
-    return regions<48, false>(nseg, NB, n_regions, err, errcap);
+int snk_count_regions(uint32_t K, uint32_t grouped, uint32_t nseg, uint32_t NB, uint32_t bc_mode, uint32_t* n_regions, char* err, size_t errcap) {
+    if (grouped) return regions<48, true>(nseg, NB, bc_mode, n_regions, err, errcap);
+    if (K == 60) return regions<60, false>(nseg, NB, bc_mode, n_regions, err, errcap);
+    return regions<48, false>(nseg, NB, bc_mode, n_regions, err, errcap);
 }
 
 int snk_launch_count(uint32_t K, hipStream_t st, const snk_count_args& a, char* err, size_t errcap) {
     if (a.NB == 0) return SNK_OK;
+    if (a.bc_mode > 8) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "min_bc=%u: up to eight distinct barcodes are told apart per k-mer", a.bc_mode);
     if (a.nseg > SNK_COUNT_MAXSEG) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "more than %d record segments per bucket (nseg=%u)", SNK_COUNT_MAXSEG, a.nseg);
     if (a.grouped) {
         if (K != 48 || a.bc_mode) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "grouped counting needs K=48 and no barcode rule");

@@ -45,7 +45,7 @@ struct snk_count_args {
     uint32_t nseg;
     uint32_t NB;
     uint32_t min_freq;
-    uint32_t bc_mode;              // 0: no barcode rule, 1: >=1 barcode>0 (or ignore-rule read), 2: >=2 distinct
+    uint32_t bc_mode;              // = minBC: 0 no barcode rule, 1: >=1 barcode>0 (or ignore-rule read), 2: >=2 distinct (state machine), 3..8: id sets
     uint32_t bucket0;              // first bucket of this launch (set by the launcher)
     uint32_t bucket_stride;        // set by the launcher (= n_regions): workgroup w counts the buckets == w (mod stride)
     uint32_t grouped;              // record word 7 is a group id that becomes the low 32 bits of the key (K=48 only)
@@ -66,7 +66,7 @@ struct snk_count_args {
 int snk_launch_count(uint32_t K, hipStream_t st, const snk_count_args& a, char* err, size_t errcap);
 uint32_t snk_count_slots(uint32_t K);   // LDS table slots per workgroup
 // output regions (= workgroups of every launch) for a table over NB buckets
-int snk_count_regions(uint32_t K, uint32_t grouped, uint32_t nseg, uint32_t NB, uint32_t* n_regions, char* err, size_t errcap);
+int snk_count_regions(uint32_t K, uint32_t grouped, uint32_t nseg, uint32_t NB, uint32_t bc_mode, uint32_t* n_regions, char* err, size_t errcap);
 // gather the used prefix of every region into one dense table; region_off = exclusive scan of region_cursor
 int snk_launch_compact_regions(hipStream_t st, const snk_u128* keys_in, const uint64_t* vals_in, uint64_t region_cap,
                                uint32_t n_regions, const unsigned long long* region_cursor,

@@ -317,7 +317,7 @@ __device__ __forceinline__ bool dict_find(const path_graph& G, const uint32_t* r
 // instructions whatever the number of active lanes), so four reads share every instruction.  A group's control flow is
 // uniform inside the group; the groups of a wave diverge like threads do.
 template <int K>
-__global__ void __launch_bounds__(256, 8) path_kernel(path_args a) {
+__global__ void __launch_bounds__(256, 4) path_kernel(path_args a) {
     __shared__ uint32_t rowL[16][20];
     __shared__ ppart partsL[16][PCAP];
     __shared__ int32_t pathL[16][PMAX];

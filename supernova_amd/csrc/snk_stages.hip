@@ -31,7 +31,7 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
     // ---- K5-K8 count + filter into a region-partitioned table, then gather the regions densely.
     // Every retained k-mer has >= min_freq instances; deep coverage retains far fewer (56x: ~1/38 of them).
     uint32_t n_regions = 1;
-    if ((rc = snk_count_regions(K, grouped, nseg, NB, &n_regions, err, errcap))) return rc;
+    if ((rc = snk_count_regions(K, grouped, nseg, NB, bc_mode, &n_regions, err, errcap))) return rc;
     uint64_t est = n_inst_hint / (min_freq > 1 ? 12 : 1) + 4096;     // first call only; a wrong guess costs one re-run
     if (ctx->last_n_kmers && ctx->last_n_instances == n_inst_hint) est = ctx->last_n_kmers + ctx->last_n_kmers / 2 + 4096;
     uint64_t region_cap = est / n_regions + 64;

@@ -104,7 +104,8 @@ def test_no_barcodes_and_minbc_modes(engine):
     c = goldens.load("adversarial")
     rows, quals, bc, lens = _to_dev(c)
     gl = c.exp_goodlens
-    for min_bc, bcarg in [(2, None), (0, bc), (1, bc)]:
+    # min_bc > 2: areEnoughBarcodes counts distinct barcodes for any minBC (BuildReadQGraph48.cc:117-137) -- per-slot id sets
+    for min_bc, bcarg in [(2, None), (0, bc), (1, bc), (3, bc), (4, bc), (6, bc), (8, bc)]:
         res = engine.count_graph(rows, c.read_len, quals=quals, bc=bcarg, lens=lens, params=Params(K=48, min_bc=min_bc),
                                  ign_bc_below=c.ign_bc_below)
         o = oracle_lib.OracleResult(c.codes, gl, None if bcarg is None else c.bc, min_bc=min_bc,
@@ -607,3 +608,25 @@ def test_read_paths_match_reference(engine, graph_stage, name):
     assert len(bad) == 0, (len(bad), bad[:5], ne[bad[:5]], c.exp_path_n[bad[:5]])
     assert np.array_equal(edges, c.exp_path_edges)
     assert np.array_equal(off, c.exp_path_off)
+
+
+@pytest.mark.parametrize("min_bc", [3, 5])
+def test_minbc_above_two_synth(engine, graph_stage, min_bc):
+    """General minBC on a seeded workload with many barcodes per locus (40 barcodes over 60 k reads: every locus sees several),
+    one GPU and the count kernel's hash-split path (3 buckets), against the C oracle."""
+    from supernova_amd import synth
+    from supernova_amd.engine import Params
+    if graph_stage == "global":
+        pytest.skip("the barcode rule lives in the count kernel")
+    n = 60_000
+    sp = synth.synth_params(n, seed=0x5EED0B00 + min_bc, pairs_per_bc=750)
+    rows_h, quals_h, bc_h = synth.synth_host(sp, qstride=160)
+    rows_d, quals_d, bc_d = engine.synth(sp, qstride=160)
+    gl = oracle_lib.good_lens(quals_h, 150)
+    o = oracle_lib.OracleResult(synth.unpack_rows(rows_h, 150), gl, bc_h, min_bc=min_bc, hbv=False)
+    o2 = oracle_lib.OracleResult(synth.unpack_rows(rows_h, 150), gl, bc_h, min_bc=2, hbv=False)
+    assert 0 < o.keys.shape[0] < o2.keys.shape[0]                 # the stricter rule really drops k-mers
+    hist = np.bincount(np.minimum(o.counts, (1 << 24) - 1)).astype(np.int64)
+    for nb in (0, 3):
+        res = engine.count_graph(rows_d, 150, quals=quals_d, bc=bc_d, params=Params(K=48, min_bc=min_bc, n_buckets=nb))
+        _check_against(res, o.keys[:, :3], o.counts, o.ctx, o.unitigs, gl, hist)
