@@ -58,7 +58,7 @@ for case in range(n_cases):
     n = max(10, int(G * cov / L))
     err = float(rng.choice([0.0, 0.002, 0.01]))
     nbc = int(rng.choice([1, 3, 40]))
-    min_freq = int(rng.choice([1, 2, 3, 4])); min_bc = int(rng.choice([0, 1, 2]))
+    min_freq = int(rng.choice([1, 2, 3, 4])); min_bc = int(rng.choice([0, 1, 2, 2, 3, 4]))
     nb = int(rng.choice([0, 0, 1, 5, 97, 4099]))
     use_bc = rng.random() < 0.8
     if os.environ.get("FUZZ_PROFILE") == "deep":      # few huge buckets, nothing filtered: deep hash splits, big sparse chunks
