@@ -46,6 +46,15 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 #define PROF(n) do {} while (0)
 #endif
 
+// high word of (hi:lo) << sh, sh in 0..31
+__device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t sh) {
+#ifdef SNK_FUNNEL_ALIGNBIT
+    return sh ? __builtin_amdgcn_alignbit(hi, lo, 32u - sh) : hi;
+#else
+    return (uint32_t)(((((uint64_t)hi << 32) | lo) << sh) >> 32);
+#endif
+}
+
 template <int K> struct lo_t { typedef uint32_t type; };       // K<=48: only the top 32 bits of lo are used
 template <> struct lo_t<60> { typedef uint64_t type; };
 
@@ -81,11 +90,11 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     uint32_t* tag = reinterpret_cast<uint32_t*>(klo + SLOTS);                       // [SLOTS] 0 empty | fingerprint(31) | ready(1)
     uint32_t* cnt = tag + SLOTS;                                                    // [SLOTS] observations
     uint32_t* bcs = cnt + SLOTS;                                                    // [SLOTS] barcode state
-    uint32_t* ctxw = bcs + SLOTS;                                                   // [SLOTS/4] context bytes
+    uint32_t* ctxw = bcs + SLOTS;                                                   // [SLOTS/4] context bytes (a claimer stores its byte, later observations OR into the word)
     uint32_t* rec = ctxw + SLOTS / 4;                                               // [8][BATCH] staged supermer records
     uint32_t* ctl = rec + 8 * BATCH;                                                // [64] control words
     uint32_t* dd = ctl + 64;                                                        // [DD] supermer de-duplication table (leader index + 1)
-    uint32_t* wgt = dd + DD;                                                        // [BATCH] copies folded into each leader
+    uint32_t* wgt = dd + DD;                                                        // [BATCH] copies folded into each leader (low 16 bits) | k-mers, flank flags (the 9 meta bits of record word 6) << 16
     uint16_t* lead = reinterpret_cast<uint16_t*>(wgt + BATCH);                      // [BATCH] r-th leading (non-folded) supermer
     uint16_t* lpre = lead + BATCH;                                                  // [BATCH+2] its first k-mer instance (+ sentinel)
     uint16_t* cidx = lpre + BATCH + 2;                                              // [NCI] leader rank that owns instance 32*w
@@ -96,7 +105,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     // (so min_bc <= 8).  Only allocated for such runs (a.bc_mode > 2); they give up the second workgroup per CU.
     uint32_t* bcx = reinterpret_cast<uint32_t*>(smem_raw + (((size_t)(reinterpret_cast<unsigned char*>(olist + (SLOTS - THREADS - 64)) - smem_raw) + 15) & ~(size_t)15));   // [SLOTS][6]
     const bool bcset = a.bc_mode > 2;
-    // ctl[0] unused, ctl[1] occupied slots, ctl[2] overflow flag, ctl[3] split log2, ctl[4] split id,
+    // ctl[0] unused, ctl[1] occupied slots (more than LIMIT = the sub-pass overflows), ctl[2] unused, ctl[3] split log2, ctl[4] split id,
     // ctl[5] valid entries of the sub-pass, ctl[6..7] reserved base (lo,hi), ctl[8] placement counter,
     // ctl[16..16+2*MAX) split stack (MAX = 17 levels -> up to ctl[51]), ctl[52..59] wave totals of the batch scan
     static_assert(THREADS >= BATCH && THREADS % 64 == 0, "the first BATCH threads stage the records");
@@ -146,7 +155,6 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
         const uint32_t split_mask = (1u << split_lg) - 1u;
         if (tid == 0) { ctl[1] = 0; ctl[2] = 0; ctl[5] = 0; ctl[8] = 0; }
         for (int s = tid; s < SLOTS; s += THREADS) tag[s] = 0;      // cnt/bcs of a slot are initialised by the lane that claims it
-        for (int s = tid; s < SLOTS / 4; s += THREADS) ctxw[s] = 0;
         lds_barrier();
         PROF(1);
 
@@ -171,12 +179,12 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                     const uint4 r0 = use_pf ? pf0 : a.records[idx * 2], r1 = use_pf ? pf1 : a.records[idx * 2 + 1];
                     rec[0 * BATCH + tid] = r0.x; rec[1 * BATCH + tid] = r0.y; rec[2 * BATCH + tid] = r0.z;
                     rec[3 * BATCH + tid] = r0.w; rec[4 * BATCH + tid] = r1.x; rec[5 * BATCH + tid] = r1.y;
-                    rec[6 * BATCH + tid] = r1.z;
+                    rec[6 * BATCH + tid] = r1.z & 0xFFFFF000u;      // bases only: the insert phase reads the rows without looking at the word index
                     // word 7 becomes the barcode STATE of the (possibly merged) supermer: none / id / MULTI / IGN
                     const int32_t b = (int32_t)r1.w;
                     rec[7 * BATCH + tid] = GROUPED ? r1.w : (b > 0 ? (uint32_t)b : (b == -1 ? BC_IGN : 0u));
                     nkm = r1.z & 0x7Fu;
-                    wgt[tid] = 1;
+                    wgt[tid] = 1u | ((r1.z & 0x1FFu) << 16);
                 }
                 for (int q = tid; q < DD; q += THREADS) dd[q] = 0;
                 lds_barrier();
@@ -188,6 +196,8 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                     uint32_t w[7];
 #pragma unroll
                     for (int q = 0; q < 7; ++q) w[q] = rec[q * BATCH + tid];
+                    const uint32_t mymeta = wgt[tid] >> 16;     // nobody adds to my weight before I lead (and then only to the low half)
+                    w[6] |= mymeta;
                     uint32_t h = w[0] * 0x9E3779B1u;
 #pragma unroll
                     for (int q = 1; q < 7; ++q) h = (h ^ w[q]) * 0x85EBCA77u + (h >> 15);
@@ -202,7 +212,8 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                         const uint32_t L = v - 1u;
                         bool same = true;
 #pragma unroll
-                        for (int q = 0; q < 7; ++q) same &= rec[q * BATCH + L] == w[q];
+                        for (int q = 0; q < 6; ++q) same &= rec[q * BATCH + L] == w[q];
+                        same &= (rec[6 * BATCH + L] | (LDS_LOAD(&wgt[L]) >> 16)) == w[6];
                         if (GROUPED || bcset) same &= rec[7 * BATCH + L] == rec[7 * BATCH + tid];     // same bases in another group: not a copy; minBC > 2: a folded supermer could not say how many barcodes it stands for
                         if (same) {
                             atomicAdd(&wgt[L], 1u);
@@ -242,45 +253,52 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                 PROF(4);
                 // ---- one lane per k-mer instance: a wave inserts 64 different k-mers of consecutive supermers, so
                 //      copies of the same k-mer (identical supermers of other reads) are spread over time, not lanes
-                const bool ovf_seen = LDS_LOAD(&ctl[2]) != 0;
-                for (uint32_t g0 = 0; g0 < total && !ovf_seen; g0 += THREADS) {
+                // A sub-pass overflows when it holds more than LIMIT distinct k-mers.  Nobody polls a flag while probing: a wave
+                // looks at the occupancy before each round of 64 insertions and stops above LIMIT, so at most THREADS claims
+                // can follow the one that crossed the line -- LIMIT + THREADS < SLOTS, the probe loops always find a free slot.
+                for (uint32_t g0 = 0; g0 < total; g0 += THREADS) {
+                    if (LDS_LOAD(&ctl[1]) > LIMIT) break;
                     const uint32_t g = g0 + tid;
                     if (g < total) {
                         uint32_t lr = cidx[g >> 5];
                         while (lpre[lr + 1] <= g) ++lr;
                         const uint32_t i = lead[lr];
                         const uint32_t j = g - lpre[lr];
-                        const uint32_t m6 = rec[6 * BATCH + i];
-                        const uint32_t n_i = m6 & 0x7Fu, hasL = (m6 >> 7) & 1u, hasR = (m6 >> 8) & 1u;
+                        const uint32_t wm = wgt[i];
+                        const uint32_t wt = wm & 0xFFFFu;
+                        const uint32_t n_i = (wm >> 16) & 0x7Fu, hasL = (wm >> 23) & 1u, hasR = (wm >> 24) & 1u;
                         const uint32_t w7 = rec[7 * BATCH + i];
                         const uint32_t bst = GROUPED ? 0u : w7;                   // merged barcode state of the supermer
-                        const uint32_t wt = wgt[i];
                         const uint32_t o = hasL + j;                     // first base of the k-mer inside the record
-                        const uint32_t wi = (2u * o) >> 5, sh = (2u * o) & 31u;
-                        uint32_t W[5];
-#pragma unroll
-                        for (uint32_t q = 0; q < 5; ++q) {
-                            const uint32_t x = wi + q;
-                            uint32_t v = x < 7 ? rec[x * BATCH + i] : 0u;
-                            if (x == 6) v &= 0xFFFFF000u;
-                            W[q] = v;
+                        const uint32_t wi = o >> 4, sh = (2u * o) & 31u;
+                        // the k-mer's words: rows wi .. wi+3 (K=48; +4 at K=60) of the record -- always inside its seven rows
+                        // (o <= K-M+1, so wi <= 2) -- and the row before for the preceding base (row -1 of a record is other LDS
+                        // data; it is only looked at when o > 0, and then wi > 0 or sh > 0)
+                        const uint32_t* wp = rec + wi * BATCH + i;
+                        const uint32_t P = wp[-BATCH], W0 = wp[0], W1 = wp[BATCH], W2 = wp[2 * BATCH], W3 = wp[3 * BATCH];
+                        const uint32_t F0 = funnel(W0, W1, sh), F1 = funnel(W1, W2, sh), F2 = funnel(W2, W3, sh);
+                        const uint32_t pb = funnel(P, W0, sh) & 3u;       // base before the k-mer
+                        uint32_t F3 = 0, nb;                              // base after the k-mer
+                        if constexpr (K == 48) nb = (W3 >> (30u - sh)) & 3u;
+                        else {
+                            static_assert(K == 60, "K is 48 or 60");
+                            const uint32_t W4 = wp[4 * BATCH];
+                            const uint32_t f3 = funnel(W3, W4, sh);
+                            nb = (f3 >> 6) & 3u;
+                            F3 = f3 & 0xFFFFFF00u;
                         }
-                        const uint64_t A = ((uint64_t)W[0] << 32) | W[1], B = ((uint64_t)W[2] << 32) | W[3], C = (uint64_t)W[4] << 32;
+                        const bool havesucc = (j + 1 < n_i) || hasR, havepred = o != 0;
                         snk_kmer f;
-                        f.hi = sh ? ((A << sh) | (B >> (64 - sh))) : A;
-                        const uint64_t lo_un = sh ? ((B << sh) | (C >> (64 - sh))) : B;
-                        f.lo = lo_un & ~((1ull << (128 - 2 * K)) - 1ull);
-                        const uint32_t nb = (uint32_t)(lo_un >> (126 - 2 * K)) & 3u;       // base after the k-mer
-                        const uint32_t havesucc = (j + 1 < n_i) ? 1u : hasR;
-                        const uint32_t havepred = o ? 1u : 0u;
-                        uint32_t pb;
-                        if (sh) pb = (W[0] >> (32 - sh)) & 3u;
-                        else pb = (wi ? rec[(wi - 1) * BATCH + i] : 0u) & 3u;
-                        uint32_t ctx = (havepred ? (0x10u << pb) : 0u) | (havesucc ? (1u << nb) : 0u);
+                        f.hi = ((uint64_t)F0 << 32) | F1;
+                        f.lo = ((uint64_t)F2 << 32) | F3;
                         const snk_kmer r = snk_kmer_rc<K>(f);
                         const bool rev = snk_kmer_lt(r, f);          // isRev(): store the reverse complement (:164)
                         snk_kmer c = rev ? r : f;
-                        if (rev) ctx = snk_ctx_rc(ctx);
+                        // context of the stored orientation: the reverse complement's successor is the complement of the
+                        // base before, its predecessor the complement of the base after (KMerContext.cc:19)
+                        const uint32_t pa = rev ? 3u - nb : pb, sa = rev ? 3u - pb : nb;
+                        const bool hp = rev ? havesucc : havepred, hs = rev ? havepred : havesucc;
+                        const uint32_t ctx = (hp ? (0x10u << pa) : 0u) | (hs ? (1u << sa) : 0u);
                         if (GROUPED) c.lo |= (uint64_t)w7;           // (group, k-mer) is the counted entity
                         uint32_t h1, h2;
                         snk_kmer_hash_count<(K > 48) || GROUPED>(c, &h1, &h2);
@@ -291,38 +309,45 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                             uint32_t slot = h1 & (SLOTS - 1);
                             const uint32_t stride = ((h1 >> 16) ^ (h2 >> 20)) | 1u;
                             const lo_type clo = klo_pack<K, GROUPED>(c.lo);
-                            const uint32_t mytag = (h2 & ~1u) | 2u;     // never 0; bit 0 = key words are in place
-                            bool found = false;
-                            // find-or-claim: the loop body is one tag load; key words are only read on a fingerprint hit
+                            const uint32_t mytag = (h2 & ~1u) | 2u;     // never 0; bit 0 = the slot's fields are in place
+                            bool claimed = false;
+                            // find-or-claim.  The inner loop is the common case and nothing else: step over slots that hold
+                            // other fingerprints (one tag load each).  It stops at an empty slot or at my fingerprint.
                             for (;;) {
-                                uint32_t t = __hip_atomic_load(&tag[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                uint32_t t;
+                                for (;;) {
+                                    t = __hip_atomic_load(&tag[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    if (t == 0 || ((t ^ mytag) & ~1u) == 0) break;
+                                    slot = (slot + stride) & (SLOTS - 1);
+                                }
                                 if (t == 0) {
-                                    if (LDS_LOAD(&ctl[2])) break;        // sub-pass already declared overflowing: stop claiming
                                     t = atomicCAS(&tag[slot], 0u, mytag);
                                     if (t == 0) {
+                                        // mine: the first observation is stored, not added (no atomics; nobody touches the
+                                        // fields before the ready bit is up)
                                         khi[slot] = c.hi;
                                         klo[slot] = clo;
-                                        cnt[slot] = 0;
-                                        bcs[slot] = 0;
+                                        cnt[slot] = a.dbg == 2 ? 0u : wt;
+                                        bcs[slot] = bst;
+                                        reinterpret_cast<uint8_t*>(ctxw)[slot] = (uint8_t)ctx;
                                         if (bcset) {
 #pragma unroll
-                                            for (int j = 0; j < 6; ++j) bcx[slot * 6 + j] = 0;
+                                            for (int q = 0; q < 6; ++q) bcx[slot * 6 + q] = 0;
                                         }
                                         __hip_atomic_store(&tag[slot], mytag | 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                        uint32_t occ = atomicAdd(&ctl[1], 1u);
-                                        if (occ >= LIMIT) __hip_atomic_store(&ctl[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                        else olist[occ] = (uint16_t)slot;
-                                        found = true;
+                                        claimed = true;
                                         break;
                                     }
+                                    if (((t ^ mytag) & ~1u) != 0) { slot = (slot + stride) & (SLOTS - 1); continue; }   // lost it to another k-mer
                                 }
-                                if ((t & ~1u) == mytag) {
-                                    if (!(t & 1u)) continue;             // same fingerprint, key not written yet: look again
-                                    if (khi[slot] == c.hi && klo[slot] == clo) { found = true; break; }
-                                }
+                                if (!(t & 1u)) continue;                 // my fingerprint, fields not written yet: look again
+                                if (khi[slot] == c.hi && klo[slot] == clo) break;
                                 slot = (slot + stride) & (SLOTS - 1);
                             }
-                            if (found && a.dbg != 2) {
+                            if (claimed) {
+                                const uint32_t occ = atomicAdd(&ctl[1], 1u);
+                                if (occ < LIMIT) olist[occ] = (uint16_t)slot;
+                            } else if (a.dbg != 2) {
                                 atomicAdd(&cnt[slot], wt);
                                 if (ctx) atomicOr(&ctxw[slot >> 2], ctx << (8 * (slot & 3)));
                                 if (bst >= BC_MULTI) atomicMax(&bcs[slot], bst);
@@ -332,9 +357,9 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                                         if (!bcset) atomicMax(&bcs[slot], BC_MULTI);
                                         else {
                                             bool stored = false;
-                                            for (int j = 0; j < 6 && !stored; ++j) {
-                                                const uint32_t o = atomicCAS(&bcx[slot * 6 + j], 0u, bst);
-                                                stored = o == 0u || o == bst;
+                                            for (int q = 0; q < 6 && !stored; ++q) {
+                                                const uint32_t ov = atomicCAS(&bcx[slot * 6 + q], 0u, bst);
+                                                stored = ov == 0u || ov == bst;
                                             }
                                             if (!stored) atomicMax(&bcs[slot], BC_MULTI);       // an eighth distinct barcode
                                         }
@@ -349,7 +374,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
             }
         }
         // (every batch ends with a barrier: the overflow flag and the table are final here)
-        if (LDS_LOAD(&ctl[2])) {   // too many distinct k-mers for one table: split this sub-pass in two by one more hash bit
+        if (LDS_LOAD(&ctl[1]) > LIMIT) {   // too many distinct k-mers for one table: split this sub-pass in two by one more hash bit
             if (split_lg >= MAX_SPLIT_LOG2) { if (tid == 0) atomicExch(&a.status[1], 1u); }
             else {
                 if (tid == 0) {
@@ -371,7 +396,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
         // this one's survivors are written (the registers are free here; nothing waits for the loads before the next bucket
         // stages them -- the barriers order LDS only)
         if (sp == 0 && tid < BATCH && nbeg + tid < nend) { nf0 = a.records[(nbeg + tid) * 2]; nf1 = a.records[(nbeg + tid) * 2 + 1]; }
-        const uint32_t nocc = LDS_LOAD(&ctl[1]);          // < LIMIT here (the overflow case went the other way)
+        const uint32_t nocc = LDS_LOAD(&ctl[1]);          // <= LIMIT here (the overflow case went the other way)
         const uint64_t rbase = rcur;
         const uint64_t gbase = (uint64_t)blockIdx.x * a.region_cap + rbase;
         for (uint32_t e0 = 0; e0 < nocc; e0 += THREADS) {
