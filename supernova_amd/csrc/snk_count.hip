@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     // (so min_bc <= 8).  Only allocated for such runs (a.bc_mode > 2); they give up the second workgroup per CU.
     uint32_t* bcx = reinterpret_cast<uint32_t*>(smem_raw + (((size_t)(reinterpret_cast<unsigned char*>(olist + (SLOTS - THREADS - 64)) - smem_raw) + 15) & ~(size_t)15));   // [SLOTS][6]
     const bool bcset = a.bc_mode > 2;
-    // ctl[0] unused, ctl[1] occupied slots (more than LIMIT = the sub-pass overflows), ctl[2] unused, ctl[3] split log2, ctl[4] split id,
+    // ctl[0] unused, ctl[1] occupied slots (more than LIMIT = the sub-pass overflows), ctl[2] unused, ctl[3] most slots used so far, ctl[4] unused,
     // ctl[5] valid entries of the sub-pass, ctl[6..7] reserved base (lo,hi), ctl[8] placement counter,
     // ctl[16..16+2*MAX) split stack (MAX = 17 levels -> up to ctl[51]), ctl[52..59] wave totals of the batch scan
     static_assert(THREADS >= BATCH && THREADS % 64 == 0, "the first BATCH threads stage the records");
@@ -130,6 +130,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     if (bucket < a.NB) { beg0 = a.seg_beg[bucket]; end0 = a.seg_end[bucket]; }
     uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = make_uint4(0, 0, 0, 0);
     if (tid < BATCH && beg0 + tid < end0) { pf0 = a.records[(beg0 + tid) * 2]; pf1 = a.records[(beg0 + tid) * 2 + 1]; }
+    if (tid == 0) ctl[3] = 0;       // most slots any sub-pass used
     for (; bucket < a.NB; bucket += G) {
     // depth of the split stack: every thread keeps its own copy (the control flow is uniform), so the sub-pass loop needs
     // no barrier-protected LDS read to decide whether it is done
@@ -448,13 +449,13 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                 }
             }
         }
-        if (tid == 0) atomicMax(&a.status[3], LDS_LOAD(&ctl[1]));
+        if (tid == 0 && nocc > ctl[3]) ctl[3] = nocc;      // running maximum, reported once at the end (a device atomic per bucket: 2 M on one address are 20 ms)
         PROF(7);
     }
     if (tid == 0 && splits_done) atomicAdd(&a.status[2], 1u);
     beg0 = nbeg; end0 = nend; pf0 = nf0; pf1 = nf1;
     }
-    if (tid == 0) a.region_cursor[blockIdx.x] = rcur;
+    if (tid == 0) { a.region_cursor[blockIdx.x] = rcur; atomicMax(&a.status[3], ctl[3]); }
 #ifdef SNK_COUNT_PROF
     if (tid == 0) for (int q = 0; q < 8; ++q) atomicAdd(&a.prof[q], prof_acc[q]);
 #endif
