@@ -74,6 +74,8 @@ template <int K, bool G> __device__ __forceinline__ uint64_t klo_unpack(typename
     if constexpr (G) return v; else return lo_unpack<K>(v);
 }
 
+typedef __attribute__((address_space(3))) void* snk_lptr;
+
 template <int K, int THREADS, int SLOTS, bool GROUPED, bool MULTI>      // MULTI: more than one record segment per bucket
 __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a) {
     // supermers staged per batch.  A 4000-instance bucket holds ~270 (sigma ~100): with 512 slots nearly every bucket is
@@ -91,31 +93,69 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     uint32_t* cnt = tag + SLOTS;                                                    // [SLOTS] observations
     uint32_t* bcs = cnt + SLOTS;                                                    // [SLOTS] barcode state
     uint32_t* ctxw = bcs + SLOTS;                                                   // [SLOTS/4] context bytes (a claimer stores its byte, later observations OR into the word)
-    uint32_t* rec = ctxw + SLOTS / 4;                                               // [8][BATCH] staged supermer records
+    // [BATCH][8] the staged supermer records as they are in HBM (32 bytes each; word 6 = bases | k-mers, flank flags; word 7 =
+    // barcode state / group id).  They are not copied through registers: the LDS-DMA load of gfx950 (global_load_lds_dwordx4)
+    // puts the 16 bytes lane l asked for at (wave's LDS base) + 16 l -- two lanes per record, consecutive lanes = consecutive
+    // addresses on both sides.  16-byte aligned (every array before it is a multiple of 16 bytes).
+    uint32_t* rec = ctxw + SLOTS / 4;
     uint32_t* ctl = rec + 8 * BATCH;                                                // [64] control words
     uint32_t* dd = ctl + 64;                                                        // [DD] supermer de-duplication table (leader index + 1)
-    uint32_t* wgt = dd + DD;                                                        // [BATCH] copies folded into each leader (low 16 bits) | k-mers, flank flags (the 9 meta bits of record word 6) << 16
+    uint32_t* wgt = dd + DD;                                                        // [BATCH] copies folded into each leader
     uint16_t* lead = reinterpret_cast<uint16_t*>(wgt + BATCH);                      // [BATCH] r-th leading (non-folded) supermer
     uint16_t* lpre = lead + BATCH;                                                  // [BATCH+2] its first k-mer instance (+ sentinel)
     uint16_t* cidx = lpre + BATCH + 2;                                              // [NCI] leader rank that owns instance 32*w
-    uint32_t* segi = reinterpret_cast<uint32_t*>(smem_raw + (((size_t)(reinterpret_cast<unsigned char*>(cidx + NCI) - smem_raw) + 15) & ~(size_t)15));   // [3][MAXSEG] segment start (lo, hi), length
-    uint16_t* olist = reinterpret_cast<uint16_t*>(segi + 3 * SNK_COUNT_MAXSEG);     // [LIMIT] claimed slots in claim order (the filter walks these, not the table)
+    uint32_t* segi = reinterpret_cast<uint32_t*>(smem_raw + (((size_t)(reinterpret_cast<unsigned char*>(cidx + NCI) - smem_raw) + 15) & ~(size_t)15));   // [2][3][MAXSEG] segment start (lo, hi), end (lo; a segment holds < 2^32 records); one copy per bucket parity
+    uint16_t* olist = reinterpret_cast<uint16_t*>(segi + 2 * 3 * SNK_COUNT_MAXSEG);  // [LIMIT] claimed slots in claim order (the filter walks these, not the table)
     // minBC > 2 (areEnoughBarcodes counts DISTINCT barcodes for any minBC, BuildReadQGraph48.cc:117-137): six more barcode ids
     // per slot behind the one in bcs[] -- up to seven distinct ids are told apart exactly, an eighth turns the state into MULTI
     // (so min_bc <= 8).  Only allocated for such runs (a.bc_mode > 2); they give up the second workgroup per CU.
     uint32_t* bcx = reinterpret_cast<uint32_t*>(smem_raw + (((size_t)(reinterpret_cast<unsigned char*>(olist + (SLOTS - THREADS - 64)) - smem_raw) + 15) & ~(size_t)15));   // [SLOTS][6]
     const bool bcset = a.bc_mode > 2;
-    // ctl[0] unused, ctl[1] occupied slots (more than LIMIT = the sub-pass overflows), ctl[2] unused, ctl[3] most slots used so far, ctl[4] unused,
-    // ctl[5] valid entries of the sub-pass, ctl[6..7] reserved base (lo,hi), ctl[8] placement counter,
+    // ctl[1] occupied slots (more than LIMIT = the sub-pass overflows), ctl[3] most slots used so far,
+    // ctl[4..7] / ctl[12..15] record bounds of the bucket (segment 0; by bucket parity), ctl[8] placement counter,
     // ctl[16..16+2*MAX) split stack (MAX = 17 levels -> up to ctl[51]), ctl[52..59] wave totals of the batch scan
-    static_assert(THREADS >= BATCH && THREADS % 64 == 0, "the first BATCH threads stage the records");
+    static_assert(THREADS >= BATCH && THREADS % 64 == 0, "the first BATCH threads own the staged records");
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
-    constexpr uint32_t LIMIT = SLOTS - THREADS - 64;   // claims allowed before a sub-pass is declared overflowing
+    constexpr uint32_t LIMIT = SLOTS - THREADS - 64;   // distinct k-mers one sub-pass may hold
 #ifdef SNK_COUNT_PROF
     long long prof_t = clock64();
     unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+    // Fetch one batch of records (virtual indices base .. base+BATCH-1 of a bucket whose bounds are in LDS: bnd = segment 0's
+    // start and end, seg = all segments') into rec[] by LDS-DMA.  Nothing is waited for here.
+    auto dma_batch = [&](uint64_t base, uint64_t vend, const uint32_t* bnd, const uint32_t* seg) {
+        constexpr int CH = 2 * BATCH;                     // 16-byte chunks
+#pragma unroll
+        for (int r = 0; r * THREADS < CH; ++r) {
+            const int c = r * THREADS + tid;
+            const uint64_t v = base + (uint32_t)(c >> 1);
+            if (c < CH && v < vend) {
+                uint64_t gi;
+                if (MULTI) {
+                    // the segments are read as ONE concatenated record stream (batches stay full, identical supermers from
+                    // different sources fold): find the segment by a short prefix walk
+                    const uint32_t x = (uint32_t)v;
+                    uint32_t acc = 0, sg = 0;
+                    for (; sg + 1 < a.nseg; ++sg) { const uint32_t l = seg[2 * SNK_COUNT_MAXSEG + sg] - seg[sg]; if (x < acc + l) break; acc += l; }
+                    gi = (((uint64_t)seg[SNK_COUNT_MAXSEG + sg] << 32) | seg[sg]) + (x - acc);
+                } else gi = v;
+                (void)bnd;
+                // (inline assembly on purpose: behind the builtin the compiler drains vmcnt before the next LDS read, whatever
+                // it reads -- the fetch would be waited for right where it is issued)
+                const uint32_t lds_at = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(snk_lptr)(rec + 4 * (r * THREADS + (tid & ~63))));
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds_at), "v"(a.records + gi * 2 + (uint32_t)(c & 1)) : "memory");
+            }
+        }
+    };
+    // iteration space of a bucket: absolute record indices of its one segment, or offsets into the concatenation of all segments
+    auto bucket_range = [&](const uint32_t* bnd, const uint32_t* seg, uint64_t& vbeg, uint64_t& vend) {
+        if (MULTI) { vbeg = 0; vend = 0; for (uint32_t sg = 0; sg < a.nseg; ++sg) vend += LDS_LOAD(&seg[2 * SNK_COUNT_MAXSEG + sg]) - LDS_LOAD(&seg[sg]); }
+        else {
+            vbeg = ((uint64_t)LDS_LOAD(&bnd[1]) << 32) | LDS_LOAD(&bnd[0]);
+            vend = ((uint64_t)LDS_LOAD(&bnd[3]) << 32) | LDS_LOAD(&bnd[2]);
+        }
+    };
     // The grid is a few residency waves of workgroups; workgroup w counts the buckets b == w (mod grid) of [bucket0, NB)
     // (no dispatch gap between buckets) and OWNS output region w: its survivors go out behind each other at a cursor the
     // workgroup keeps itself.  The first version reserved every sub-pass's chunk with a device-scope atomic on one of 4096
@@ -124,13 +164,29 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     const uint32_t G = a.bucket_stride;
     unsigned long long rcur = a.region_cursor[blockIdx.x];          // uniform: every thread keeps the same value
     uint32_t bucket = a.bucket0 + (blockIdx.x + G - a.bucket0 % G) % G;
-    // bounds of the workgroup's first bucket; afterwards the NEXT bucket's bounds are fetched (scalar loads: the index is
-    // uniform) while the current one is counted, and its first batch of records right after the last insert phase
-    uint64_t beg0 = 0, end0 = 0;
-    if (bucket < a.NB) { beg0 = a.seg_beg[bucket]; end0 = a.seg_end[bucket]; }
-    uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = make_uint4(0, 0, 0, 0);
-    if (tid < BATCH && beg0 + tid < end0) { pf0 = a.records[(beg0 + tid) * 2]; pf1 = a.records[(beg0 + tid) * 2 + 1]; }
-    if (tid == 0) ctl[3] = 0;       // most slots any sub-pass used
+    // The bounds of a bucket travel through LDS, one bucket ahead: they are loaded at the top of the bucket before, put down
+    // (ctl[4..7] / ctl[12..15] and the two copies of segi, by bucket parity) once that bucket's first batch is staged, and read
+    // when its last insert phase is over -- which is where the next bucket's first batch is fetched, behind the survivors'
+    // stores, so that neither the bounds nor the records cost an HBM latency at the top of a bucket.
+    uint32_t par = 0;
+    {
+        uint64_t b0 = 0, e0 = 0;
+        if (tid == 0) {
+            if (bucket < a.NB) { b0 = a.seg_beg[bucket]; e0 = a.seg_end[bucket]; }
+            ctl[4] = (uint32_t)b0; ctl[5] = (uint32_t)(b0 >> 32); ctl[6] = (uint32_t)e0; ctl[7] = (uint32_t)(e0 >> 32);
+            ctl[3] = 0;
+        }
+        if (MULTI && tid < (int)a.nseg) {
+            uint64_t b = 0, e = 0;
+            if (bucket < a.NB) { b = a.seg_beg[(uint64_t)tid * a.seg_stride + bucket]; e = a.seg_end[(uint64_t)tid * a.seg_stride + bucket]; }
+            segi[tid] = (uint32_t)b; segi[SNK_COUNT_MAXSEG + tid] = (uint32_t)(b >> 32); segi[2 * SNK_COUNT_MAXSEG + tid] = (uint32_t)e;
+        }
+        lds_barrier();
+        uint64_t vb, ve;
+        bucket_range(ctl + 4, segi, vb, ve);
+        dma_batch(vb, ve, ctl + 4, segi);
+    }
+    bool prefetched = true;         // rec[] holds (or is about to hold) the first batch of the bucket at hand
     for (; bucket < a.NB; bucket += G) {
     // depth of the split stack: every thread keeps its own copy (the control flow is uniform), so the sub-pass loop needs
     // no barrier-protected LDS read to decide whether it is done
@@ -138,96 +194,100 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     if (tid == 0) { ctl[16] = 0; ctl[17] = 0; }
     uint32_t splits_done = 0;
     const uint32_t nbucket = bucket + G;
-    uint64_t nbeg = 0, nend = 0;
-    if (nbucket < a.NB) { nbeg = a.seg_beg[nbucket]; nend = a.seg_end[nbucket]; }
-    uint4 nf0 = make_uint4(0, 0, 0, 0), nf1 = make_uint4(0, 0, 0, 0);
-    // more than one segment (sharded runs: one per source rank): the segments are counted as ONE concatenated record
-    // stream -- batches stay full and identical supermers from different sources fold -- so every thread needs all bounds
-    if (MULTI && tid < (int)a.nseg) {
-        const uint64_t b = a.seg_beg[(uint64_t)tid * a.seg_stride + bucket], e = a.seg_end[(uint64_t)tid * a.seg_stride + bucket];
-        segi[tid] = (uint32_t)b; segi[SNK_COUNT_MAXSEG + tid] = (uint32_t)(b >> 32); segi[2 * SNK_COUNT_MAXSEG + tid] = (uint32_t)(e - b);
-    }
-    bool first_batch = true;
+    bool seg_pending = true;        // the next bucket's bounds are not in LDS yet
+    const uint32_t* bcur = ctl + 4 + 8 * par;
+    uint32_t* bnext = ctl + 4 + 8 * (par ^ 1u);
+    const uint32_t* segc = segi + par * (3 * SNK_COUNT_MAXSEG);          // this bucket's copy
+    uint32_t* segn = segi + (par ^ 1u) * (3 * SNK_COUNT_MAXSEG);        // the next bucket's
+    // Every lane loads them (the same address in all lanes is one transaction per wave) and every lane puts them down (the same
+    // value to the same word): no divergent branch around either side, so the one wait the compiler needs sits in front of the
+    // stores and nowhere else (a load that is consumed on some paths only is waited for at the next loop header).
+    const uint32_t sseg = MULTI ? min((uint32_t)tid, a.nseg - 1u) : 0u;
+    auto load_next = [&](uint64_t& nbeg, uint64_t& nend, uint64_t& nsb, uint32_t& nse) {
+        nbeg = 0; nend = 0; nsb = 0; nse = 0;
+        if (nbucket < a.NB) {
+            nbeg = a.seg_beg[nbucket]; nend = a.seg_end[nbucket];
+            if (MULTI) { nsb = a.seg_beg[(uint64_t)sseg * a.seg_stride + nbucket]; nse = (uint32_t)a.seg_end[(uint64_t)sseg * a.seg_stride + nbucket]; }
+        }
+    };
+    auto put_down = [&](uint64_t nbeg, uint64_t nend, uint64_t nsb, uint32_t nse) {
+        bnext[0] = (uint32_t)nbeg; bnext[1] = (uint32_t)(nbeg >> 32); bnext[2] = (uint32_t)nend; bnext[3] = (uint32_t)(nend >> 32);
+        if (MULTI) { segn[sseg] = (uint32_t)nsb; segn[SNK_COUNT_MAXSEG + sseg] = (uint32_t)(nsb >> 32); segn[2 * SNK_COUNT_MAXSEG + sseg] = nse; }
+        seg_pending = false;
+    };
     while (sp) {
         lds_barrier();          // the previous sub-pass / bucket is done with the table; stack entries are visible
         PROF(0);
         --sp;
         const uint32_t split_lg = LDS_LOAD(&ctl[16 + 2 * sp]), split_id = LDS_LOAD(&ctl[17 + 2 * sp]);
         const uint32_t split_mask = (1u << split_lg) - 1u;
-        if (tid == 0) { ctl[1] = 0; ctl[2] = 0; ctl[5] = 0; ctl[8] = 0; }
-        for (int s = tid; s < SLOTS; s += THREADS) tag[s] = 0;      // cnt/bcs of a slot are initialised by the lane that claims it
+        if (tid == 0) { ctl[1] = 0; ctl[8] = 0; }
+        for (int s = tid; s < SLOTS; s += THREADS) tag[s] = 0;      // the other fields of a slot are initialised by the lane that claims it
+        uint64_t vbeg, vend;
+        bucket_range(bcur, segc, vbeg, vend);
+        if (seg_pending && vbeg >= vend) {                  // a bucket without records: nothing will be staged
+            uint64_t nbeg, nend, nsb; uint32_t nse;
+            load_next(nbeg, nend, nsb, nse);
+            put_down(nbeg, nend, nsb, nse);
+        }
         lds_barrier();
         PROF(1);
-
-        // iteration space: absolute record indices of the one segment, or offsets into the concatenation of all segments
-        uint64_t vbeg = beg0, vend = end0;
-        if (MULTI) { vbeg = 0; vend = 0; for (uint32_t sg = 0; sg < a.nseg; ++sg) vend += LDS_LOAD(&segi[2 * SNK_COUNT_MAXSEG + sg]); }
         {
             for (uint64_t base = vbeg; base < vend; base += BATCH) {
-                // ---- stage one batch of supermer records (coalesced 32-byte loads) and scan their k-mer counts
-                uint64_t idx = base + tid;
-                uint32_t nkm = 0;
-                bool use_pf = first_batch && base == vbeg;      // the prefetch holds records beg0 + tid of segment 0
-                first_batch = false;
-                if (tid < BATCH && idx < vend) {
-                    if (MULTI) {
-                        const uint32_t v = (uint32_t)idx;
-                        uint32_t acc = 0, sg = 0;
-                        for (; sg + 1 < a.nseg; ++sg) { const uint32_t l = segi[2 * SNK_COUNT_MAXSEG + sg]; if (v < acc + l) break; acc += l; }
-                        idx = (((uint64_t)segi[SNK_COUNT_MAXSEG + sg] << 32) | segi[sg]) + (v - acc);
-                        use_pf = use_pf && sg == 0;
-                    }
-                    const uint4 r0 = use_pf ? pf0 : a.records[idx * 2], r1 = use_pf ? pf1 : a.records[idx * 2 + 1];
-                    rec[0 * BATCH + tid] = r0.x; rec[1 * BATCH + tid] = r0.y; rec[2 * BATCH + tid] = r0.z;
-                    rec[3 * BATCH + tid] = r0.w; rec[4 * BATCH + tid] = r1.x; rec[5 * BATCH + tid] = r1.y;
-                    rec[6 * BATCH + tid] = r1.z & 0xFFFFF000u;      // bases only: the insert phase reads the rows without looking at the word index
-                    // word 7 becomes the barcode STATE of the (possibly merged) supermer: none / id / MULTI / IGN
-                    const int32_t b = (int32_t)r1.w;
-                    rec[7 * BATCH + tid] = GROUPED ? r1.w : (b > 0 ? (uint32_t)b : (b == -1 ? BC_IGN : 0u));
-                    nkm = r1.z & 0x7Fu;
-                    wgt[tid] = 1u | ((r1.z & 0x1FFu) << 16);
-                }
+                // ---- stage one batch of supermer records
+                if (!prefetched) dma_batch(base, vend, bcur, segc);
+                prefetched = false;
+                if (tid < BATCH) wgt[tid] = 1;
                 for (int q = tid; q < DD; q += THREADS) dd[q] = 0;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my share of the batch is in LDS (and everything older has landed)
                 lds_barrier();
                 PROF(2);
+                // the next bucket's bounds: asked for here (behind the wait for the batch -- vmcnt counts in order), put down
+                // before the insert phase, read when it is over
+                const bool fetch_next = seg_pending;
+                uint64_t nbeg = 0, nend = 0, nsb = 0; uint32_t nse = 0;
+                if (fetch_next) load_next(nbeg, nend, nsb, nse);
                 // ---- fold identical supermers: at 56x coverage ~3 of 4 reads over a locus yield the SAME record (same
                 //      bases, same flanks); only their barcodes differ.  The first one becomes the leader and carries a
                 //      weight and a merged barcode state, the copies insert nothing (2.5x fewer k-mer insertions).
-                if (a.dbg != 4 && tid < BATCH && nkm) {
-                    uint32_t w[7];
-#pragma unroll
-                    for (int q = 0; q < 7; ++q) w[q] = rec[q * BATCH + tid];
-                    const uint32_t mymeta = wgt[tid] >> 16;     // nobody adds to my weight before I lead (and then only to the low half)
-                    w[6] |= mymeta;
-                    uint32_t h = w[0] * 0x9E3779B1u;
-#pragma unroll
-                    for (int q = 1; q < 7; ++q) h = (h ^ w[q]) * 0x85EBCA77u + (h >> 15);
-                    h ^= h >> 13;
-                    uint32_t s = h & (DD - 1);
-                    for (;;) {
-                        uint32_t v = LDS_LOAD(&dd[s]);
-                        if (v == 0) {
-                            v = atomicCAS(&dd[s], 0u, (uint32_t)tid + 1u);
-                            if (v == 0) break;                               // I lead this record
-                        }
-                        const uint32_t L = v - 1u;
-                        bool same = true;
-#pragma unroll
-                        for (int q = 0; q < 6; ++q) same &= rec[q * BATCH + L] == w[q];
-                        same &= (rec[6 * BATCH + L] | (LDS_LOAD(&wgt[L]) >> 16)) == w[6];
-                        if (GROUPED || bcset) same &= rec[7 * BATCH + L] == rec[7 * BATCH + tid];     // same bases in another group: not a copy; minBC > 2: a folded supermer could not say how many barcodes it stands for
-                        if (same) {
-                            atomicAdd(&wgt[L], 1u);
-                            const uint32_t mine = GROUPED ? 0u : rec[7 * BATCH + tid];
-                            if (mine >= BC_MULTI) atomicMax(&rec[7 * BATCH + L], mine);
-                            else if (mine) {
-                                uint32_t ob = atomicCAS(&rec[7 * BATCH + L], 0u, mine);
-                                if (ob != 0 && ob != mine && ob < BC_MULTI) atomicMax(&rec[7 * BATCH + L], BC_MULTI);
+                uint32_t nkm = 0;
+                if (tid < BATCH && base + tid < vend) {
+                    const uint4 ra = *reinterpret_cast<const uint4*>(rec + 8 * tid), rb = *reinterpret_cast<const uint4*>(rec + 8 * tid + 4);
+                    nkm = rb.z & 0x7Fu;
+                    if (a.dbg != 4 && nkm) {
+                        uint32_t h = ra.x * 0x9E3779B1u;
+                        h = (h ^ ra.y) * 0x85EBCA77u + (h >> 15);
+                        h = (h ^ ra.z) * 0x85EBCA77u + (h >> 15);
+                        h = (h ^ ra.w) * 0x85EBCA77u + (h >> 15);
+                        h = (h ^ rb.x) * 0x85EBCA77u + (h >> 15);
+                        h = (h ^ rb.y) * 0x85EBCA77u + (h >> 15);
+                        h = (h ^ rb.z) * 0x85EBCA77u + (h >> 15);
+                        h ^= h >> 13;
+                        uint32_t s = h & (DD - 1);
+                        for (;;) {
+                            uint32_t v = LDS_LOAD(&dd[s]);
+                            if (v == 0) {
+                                v = atomicCAS(&dd[s], 0u, (uint32_t)tid + 1u);
+                                if (v == 0) break;                               // I lead this record
                             }
-                            nkm = 0;
-                            break;
+                            const uint32_t L = v - 1u;
+                            const uint4 la = *reinterpret_cast<const uint4*>(rec + 8 * L);
+                            const uint32_t lb0 = rec[8 * L + 4], lb1 = rec[8 * L + 5], lb2 = rec[8 * L + 6];     // (word 7 of a leader changes under us)
+                            bool same = ((la.x ^ ra.x) | (la.y ^ ra.y) | (la.z ^ ra.z) | (la.w ^ ra.w) | (lb0 ^ rb.x) | (lb1 ^ rb.y) | (lb2 ^ rb.z)) == 0;
+                            if (GROUPED || bcset) same = same && LDS_LOAD(&rec[8 * L + 7]) == rb.w;     // same bases in another group: not a copy; minBC > 2: a folded supermer could not say how many barcodes it stands for
+                            if (same) {
+                                atomicAdd(&wgt[L], 1u);
+                                const uint32_t mine = GROUPED ? 0u : rb.w;
+                                if (mine >= BC_MULTI) atomicMax(&rec[8 * L + 7], mine);
+                                else if (mine) {
+                                    uint32_t ob = atomicCAS(&rec[8 * L + 7], 0u, mine);
+                                    if (ob != 0 && ob != mine && ob < BC_MULTI) atomicMax(&rec[8 * L + 7], BC_MULTI);
+                                }
+                                nkm = 0;
+                                break;
+                            }
+                            s = (s + 1) & (DD - 1);
                         }
-                        s = (s + 1) & (DD - 1);
                     }
                 }
                 // one packed scan over the supermers: k-mer instances (low 16 bits) and leaders (high 16 bits)
@@ -252,8 +312,9 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                 if (tid == 0) lpre[nlead] = (uint16_t)total;
                 lds_barrier();
                 PROF(4);
+                if (fetch_next) put_down(nbeg, nend, nsb, nse);
                 // ---- one lane per k-mer instance: a wave inserts 64 different k-mers of consecutive supermers, so
-                //      copies of the same k-mer (identical supermers of other reads) are spread over time, not lanes
+                //      copies of the same k-mer (identical supermers of other reads) are spread over time, not lanes.
                 // A sub-pass overflows when it holds more than LIMIT distinct k-mers.  Nobody polls a flag while probing: a wave
                 // looks at the occupancy before each round of 64 insertions and stops above LIMIT, so at most THREADS claims
                 // can follow the one that crossed the line -- LIMIT + THREADS < SLOTS, the probe loops always find a free slot.
@@ -265,25 +326,26 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                         while (lpre[lr + 1] <= g) ++lr;
                         const uint32_t i = lead[lr];
                         const uint32_t j = g - lpre[lr];
-                        const uint32_t wm = wgt[i];
-                        const uint32_t wt = wm & 0xFFFFu;
-                        const uint32_t n_i = (wm >> 16) & 0x7Fu, hasL = (wm >> 23) & 1u, hasR = (wm >> 24) & 1u;
-                        const uint32_t w7 = rec[7 * BATCH + i];
+                        const uint32_t* rp = rec + 8 * i;
+                        const uint32_t m6 = rp[6], w7 = rp[7];
+                        const uint32_t wt = wgt[i];
+                        const uint32_t n_i = m6 & 0x7Fu, hasL = (m6 >> 7) & 1u, hasR = (m6 >> 8) & 1u;
                         const uint32_t bst = GROUPED ? 0u : w7;                   // merged barcode state of the supermer
                         const uint32_t o = hasL + j;                     // first base of the k-mer inside the record
                         const uint32_t wi = o >> 4, sh = (2u * o) & 31u;
-                        // the k-mer's words: rows wi .. wi+3 (K=48; +4 at K=60) of the record -- always inside its seven rows
-                        // (o <= K-M+1, so wi <= 2) -- and the row before for the preceding base (row -1 of a record is other LDS
-                        // data; it is only looked at when o > 0, and then wi > 0 or sh > 0)
-                        const uint32_t* wp = rec + wi * BATCH + i;
-                        const uint32_t P = wp[-BATCH], W0 = wp[0], W1 = wp[BATCH], W2 = wp[2 * BATCH], W3 = wp[3 * BATCH];
+                        // the k-mer's words: words wi .. wi+3 (K=48; +4 at K=60) of the record -- always inside its eight words
+                        // (o <= K-M+1, so wi <= 2; the flag bits of word 6 and word 7 only reach the base after a k-mer that has
+                        // no successor, which is not looked at) -- and the word before for the preceding base (the word before a
+                        // record is other LDS data; it only matters when o > 0, and then wi > 0 or sh > 0)
+                        const uint32_t* wp = rp + wi;
+                        const uint32_t P = wp[-1], W0 = wp[0], W1 = wp[1], W2 = wp[2], W3 = wp[3];
                         const uint32_t F0 = funnel(W0, W1, sh), F1 = funnel(W1, W2, sh), F2 = funnel(W2, W3, sh);
                         const uint32_t pb = funnel(P, W0, sh) & 3u;       // base before the k-mer
                         uint32_t F3 = 0, nb;                              // base after the k-mer
                         if constexpr (K == 48) nb = (W3 >> (30u - sh)) & 3u;
                         else {
                             static_assert(K == 60, "K is 48 or 60");
-                            const uint32_t W4 = wp[4 * BATCH];
+                            const uint32_t W4 = wp[4];
                             const uint32_t f3 = funnel(W3, W4, sh);
                             nb = (f3 >> 6) & 3u;
                             F3 = f3 & 0xFFFFFF00u;
@@ -370,11 +432,11 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                         }
                     }
                 }
-                lds_barrier();   // rec/pre/owner are rewritten by the next batch
+                lds_barrier();   // rec and the map are rewritten by the next batch
                 PROF(5);
             }
         }
-        // (every batch ends with a barrier: the overflow flag and the table are final here)
+        // (every batch ends with a barrier: the occupancy and the table are final here)
         if (LDS_LOAD(&ctl[1]) > LIMIT) {   // too many distinct k-mers for one table: split this sub-pass in two by one more hash bit
             if (split_lg >= MAX_SPLIT_LOG2) { if (tid == 0) atomicExch(&a.status[1], 1u); }
             else {
@@ -393,10 +455,14 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
         // device-scope reservation and two barriers in between -- a quarter of the kernel.  A survivor's position is the
         // running cursor + its rank (one LDS atomic per wave); the cursor moves on after the one barrier that follows.
         PROF(6);
-        // the last sub-pass of the bucket is past its insert phase: the next bucket's first records can be on their way while
-        // this one's survivors are written (the registers are free here; nothing waits for the loads before the next bucket
-        // stages them -- the barriers order LDS only)
-        if (sp == 0 && tid < BATCH && nbeg + tid < nend) { nf0 = a.records[(nbeg + tid) * 2]; nf1 = a.records[(nbeg + tid) * 2 + 1]; }
+        // the last sub-pass of the bucket is past its insert phase: rec[] is free, the next bucket's first batch can be on its
+        // way while this one's survivors are written (no registers involved; the next bucket's stage waits for it)
+        if (sp == 0) {
+            uint64_t nvb, nve;
+            bucket_range(bnext, segn, nvb, nve);
+            dma_batch(nvb, nve, bnext, segn);
+            prefetched = true;
+        }
         const uint32_t nocc = LDS_LOAD(&ctl[1]);          // <= LIMIT here (the overflow case went the other way)
         const uint64_t rbase = rcur;
         const uint64_t gbase = (uint64_t)blockIdx.x * a.region_cap + rbase;
@@ -453,9 +519,10 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
         PROF(7);
     }
     if (tid == 0 && splits_done) atomicAdd(&a.status[2], 1u);
-    beg0 = nbeg; end0 = nend; pf0 = nf0; pf1 = nf1;
+    par ^= 1u;
     }
     if (tid == 0) { a.region_cursor[blockIdx.x] = rcur; atomicMax(&a.status[3], ctl[3]); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA in flight when the workgroup's LDS is handed back
 #ifdef SNK_COUNT_PROF
     if (tid == 0) for (int q = 0; q < 8; ++q) atomicAdd(&a.prof[q], prof_acc[q]);
 #endif
@@ -468,7 +535,7 @@ template <> struct cfg<60> { static constexpr int THREADS = SNK_COUNT_THREADS; s
 template <int K, bool G>
 size_t lds_bytes(uint32_t bc_mode = 0) {
     constexpr size_t S = cfg<K>::SLOTS, B = (K == 48 && !G && S >= 2048) ? 512 : 256, DD = 2 * B, NCI = B * (K - SNK_M + 1) / 32 + 2;
-    return S * (8 + sizeof(typename klo_t<K, G>::type) + 4 + 4 + 4) + S + 4 * (8 * B + 64 + DD + B) + 2 * (B + B + 2 + NCI) + 16 + 4 * 3 * SNK_COUNT_MAXSEG + 2 * (S - cfg<K>::THREADS - 64) + 16 + (bc_mode > 2 ? S * 24 + 16 : 0);
+    return S * (8 + sizeof(typename klo_t<K, G>::type) + 4 + 4 + 4) + S + 4 * (8 * B + 64 + DD + B) + 2 * (B + B + 2 + NCI) + 16 + 2 * 4 * 3 * SNK_COUNT_MAXSEG + 2 * (S - cfg<K>::THREADS - 64) + 16 + (bc_mode > 2 ? S * 24 + 16 : 0);
 }
 
 template <int K, bool G>

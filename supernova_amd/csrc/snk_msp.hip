@@ -114,7 +114,9 @@ __global__ void __launch_bounds__(BD, K == 48 ? 5 : 4) snk_msp_kernel(snk_msp_ar
     const int nk = g ? g - K + 1 : 0;
     const int npos = g ? g - M + 1 : 0;
     int32_t mybc = 0;
-    if (g) mybc = (a.bc && (int64_t)(a.read_index_base + r) >= a.ign_bc_below) ? a.bc[r] : -1;
+    // word 7 of a record is the barcode STATE the count kernel starts from: 0 none, id > 0, 0xFFFFFFFF (-1) a read under the
+    // ignore rule; other non-positive ids count as none (areEnoughBarcodes only looks at ids > 0, BuildReadQGraph48.cc:117-137)
+    if (g) { mybc = (a.bc && (int64_t)(a.read_index_base + r) >= a.ign_bc_below) ? a.bc[r] : -1; if (mybc < -1) mybc = 0; }
     uint32_t gmix = 0;                                   // grouped runs: word 7 of the record carries the group id
     if (a.group && g) { const uint32_t grp = a.group[r]; gmix = snk_group_mix(grp); mybc = (int32_t)grp; }
 

@@ -1,0 +1,7 @@
+cd /tmp && export TMPDIR=/tmp
+R=/root/repo; O=$R/gpurun_out
+cd $R && timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -3
+cd /tmp
+timeout 120 python $R/tools/count_probe.py 1e8 0,1 2>&1 | grep -E "^dbg" | tail -3
+SNK_MSP_DBG=3 timeout 120 python $R/tools/count_probe.py 1e8 0 2>&1 | grep -E "^dbg" | tail -3
+SNK_LIB_PATH=$R/supernova_amd/variants/libsnk_prof.so timeout 120 python $R/tools/count_probe.py 1e8 0 2>&1 | grep -E "prof|^dbg" | tail -2
