@@ -111,9 +111,9 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     // (so min_bc <= 8).  Only allocated for such runs (a.bc_mode > 2); they give up the second workgroup per CU.
     uint32_t* bcx = reinterpret_cast<uint32_t*>(smem_raw + (((size_t)(reinterpret_cast<unsigned char*>(olist + (SLOTS - THREADS - 64)) - smem_raw) + 15) & ~(size_t)15));   // [SLOTS][6]
     const bool bcset = a.bc_mode > 2;
-    // ctl[1] occupied slots (more than LIMIT = the sub-pass overflows), ctl[3] most slots used so far,
-    // ctl[4..7] / ctl[12..15] record bounds of the bucket (segment 0; by bucket parity), ctl[8] placement counter,
-    // ctl[16..16+2*MAX) split stack (MAX = 17 levels -> up to ctl[51]), ctl[52..59] wave totals of the batch scan
+    // ctl[1..2] occupied slots (by pass parity; more than LIMIT = the pass overflows), ctl[3] most slots used so far,
+    // ctl[4..7] / ctl[12..15] record bounds of the bucket (segment 0; by bucket parity), ctl[8..9] placement counter (by pass
+    // parity), ctl[10..11] instances | leaders << 16 of the batch (by batch parity), ctl[16..16+2*MAX) split stack (17 levels)
     static_assert(THREADS >= BATCH && THREADS % 64 == 0, "the first BATCH threads own the staged records");
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
@@ -175,7 +175,9 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
             if (bucket < a.NB) { b0 = a.seg_beg[bucket]; e0 = a.seg_end[bucket]; }
             ctl[4] = (uint32_t)b0; ctl[5] = (uint32_t)(b0 >> 32); ctl[6] = (uint32_t)e0; ctl[7] = (uint32_t)(e0 >> 32);
             ctl[3] = 0;
+            ctl[1] = 0; ctl[2] = 0; ctl[8] = 0; ctl[9] = 0; ctl[10] = 0; ctl[11] = 0;
         }
+        for (int s = tid; s < SLOTS; s += THREADS) tag[s] = 0;      // from here on a pass leaves the table empty behind it
         if (MULTI && tid < (int)a.nseg) {
             uint64_t b = 0, e = 0;
             if (bucket < a.NB) { b = a.seg_beg[(uint64_t)tid * a.seg_stride + bucket]; e = a.seg_end[(uint64_t)tid * a.seg_stride + bucket]; }
@@ -187,11 +189,16 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
         dma_batch(vb, ve, ctl + 4, segi);
     }
     bool prefetched = true;         // rec[] holds (or is about to hold) the first batch of the bucket at hand
+    // Four barriers per pass (staged / mapped / inserted / written), none between passes: the counters a pass uses (occupancy,
+    // placement; the batch's instance scan) exist twice and the copy the NEXT pass / batch will use is zeroed behind the
+    // 'staged' barrier of this one, when every wave is past its last look at it; the table is emptied by the lanes that write
+    // its entries out.
+    uint32_t q = 0, bq = 0;         // parity of the pass / of the batch
     for (; bucket < a.NB; bucket += G) {
     // depth of the split stack: every thread keeps its own copy (the control flow is uniform), so the sub-pass loop needs
     // no barrier-protected LDS read to decide whether it is done
     uint32_t sp = 1;
-    if (tid == 0) { ctl[16] = 0; ctl[17] = 0; }
+    bool fresh = true;              // the first pass of a bucket: nothing on the split stack
     uint32_t splits_done = 0;
     const uint32_t nbucket = bucket + G;
     bool seg_pending = true;        // the next bucket's bounds are not in LDS yet
@@ -216,21 +223,29 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
         seg_pending = false;
     };
     while (sp) {
-        lds_barrier();          // the previous sub-pass / bucket is done with the table; stack entries are visible
         PROF(0);
         --sp;
-        const uint32_t split_lg = LDS_LOAD(&ctl[16 + 2 * sp]), split_id = LDS_LOAD(&ctl[17 + 2 * sp]);
+        uint32_t split_lg = 0, split_id = 0;
+        if (!fresh) {
+            lds_barrier();      // the stack entries and the cleared table of the pass that overflowed are visible
+            split_lg = LDS_LOAD(&ctl[16 + 2 * sp]); split_id = LDS_LOAD(&ctl[17 + 2 * sp]);
+        }
+        fresh = false;
         const uint32_t split_mask = (1u << split_lg) - 1u;
-        if (tid == 0) { ctl[1] = 0; ctl[8] = 0; }
-        for (int s = tid; s < SLOTS; s += THREADS) tag[s] = 0;      // the other fields of a slot are initialised by the lane that claims it
+        uint32_t* occ = ctl + 1 + q;            // distinct k-mers of this pass
+        uint32_t* place = ctl + 8 + q;          // its survivors
         uint64_t vbeg, vend;
         bucket_range(bcur, segc, vbeg, vend);
-        if (seg_pending && vbeg >= vend) {                  // a bucket without records: nothing will be staged
-            uint64_t nbeg, nend, nsb; uint32_t nse;
-            load_next(nbeg, nend, nsb, nse);
-            put_down(nbeg, nend, nsb, nse);
+        if (vbeg >= vend) {                     // a bucket without records: nothing is staged, what happens behind 'staged' happens here
+            lds_barrier();
+            if (tid == 0) { ctl[1 + (q ^ 1u)] = 0; ctl[8 + (q ^ 1u)] = 0; }
+            if (seg_pending) {
+                uint64_t nbeg, nend, nsb; uint32_t nse;
+                load_next(nbeg, nend, nsb, nse);
+                put_down(nbeg, nend, nsb, nse);
+            }
+            lds_barrier();
         }
-        lds_barrier();
         PROF(1);
         {
             for (uint64_t base = vbeg; base < vend; base += BATCH) {
@@ -240,8 +255,9 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                 if (tid < BATCH) wgt[tid] = 1;
                 for (int q = tid; q < DD; q += THREADS) dd[q] = 0;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my share of the batch is in LDS (and everything older has landed)
-                lds_barrier();
+                lds_barrier();                                       // 'staged'
                 PROF(2);
+                if (tid == 0) { ctl[1 + (q ^ 1u)] = 0; ctl[8 + (q ^ 1u)] = 0; ctl[10 + (bq ^ 1u)] = 0; }
                 // the next bucket's bounds: asked for here (behind the wait for the batch -- vmcnt counts in order), put down
                 // before the insert phase, read when it is over
                 const bool fetch_next = seg_pending;
@@ -290,16 +306,15 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                         }
                     }
                 }
-                // one packed scan over the supermers: k-mer instances (low 16 bits) and leaders (high 16 bits)
+                // one packed scan over the supermers: k-mer instances (low 16 bits) and leaders (high 16 bits); a wave takes its
+                // base from a counter (no barrier, no wave order: an instance range and a leader rank come from the same atomic,
+                // so they are ordered alike)
                 const uint32_t sv = nkm | (nkm ? 0x10000u : 0u);
                 uint32_t incl = sv;
                 for (int o = 1; o < 64; o <<= 1) { uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-                if (lane == 63 && wv < BATCH / 64) ctl[52 + wv] = incl;
-                lds_barrier();
-                PROF(3);
-                uint32_t woff = 0, tot = 0;
-                for (int w = 0; w < BATCH / 64; ++w) { uint32_t t = ctl[52 + w]; if (w < wv) woff += t; tot += t; }
-                const uint32_t total = tot & 0xFFFFu, nlead = tot >> 16;
+                uint32_t woff = 0;
+                if (lane == 63 && incl) woff = atomicAdd(&ctl[10 + bq], incl);
+                woff = __shfl(woff, 63);
                 if (tid < BATCH && nkm) {
                     // instance -> supermer map without a byte per instance: leaders in order, their first instance, and
                     // for every 32nd instance the leader that owns it (a lane then walks 0-3 leaders forward)
@@ -309,9 +324,10 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                     lpre[r] = (uint16_t)off;
                     for (uint32_t w = (off + 31u) >> 5; (w << 5) < off + nkm; ++w) cidx[w] = (uint16_t)r;
                 }
-                if (tid == 0) lpre[nlead] = (uint16_t)total;
-                lds_barrier();
+                lds_barrier();                                       // 'mapped'
                 PROF(4);
+                const uint32_t tot = LDS_LOAD(&ctl[10 + bq]);
+                const uint32_t total = tot & 0xFFFFu, nlead = tot >> 16;
                 if (fetch_next) put_down(nbeg, nend, nsb, nse);
                 // ---- one lane per k-mer instance: a wave inserts 64 different k-mers of consecutive supermers, so
                 //      copies of the same k-mer (identical supermers of other reads) are spread over time, not lanes.
@@ -319,11 +335,11 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                 // looks at the occupancy before each round of 64 insertions and stops above LIMIT, so at most THREADS claims
                 // can follow the one that crossed the line -- LIMIT + THREADS < SLOTS, the probe loops always find a free slot.
                 for (uint32_t g0 = 0; g0 < total; g0 += THREADS) {
-                    if (LDS_LOAD(&ctl[1]) > LIMIT) break;
+                    if (LDS_LOAD(occ) > LIMIT) break;
                     const uint32_t g = g0 + tid;
                     if (g < total) {
                         uint32_t lr = cidx[g >> 5];
-                        while (lpre[lr + 1] <= g) ++lr;
+                        while (lr + 1 < nlead && lpre[lr + 1] <= g) ++lr;
                         const uint32_t i = lead[lr];
                         const uint32_t j = g - lpre[lr];
                         const uint32_t* rp = rec + 8 * i;
@@ -408,8 +424,8 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                                 slot = (slot + stride) & (SLOTS - 1);
                             }
                             if (claimed) {
-                                const uint32_t occ = atomicAdd(&ctl[1], 1u);
-                                if (occ < LIMIT) olist[occ] = (uint16_t)slot;
+                                const uint32_t at = atomicAdd(occ, 1u);
+                                if (at < LIMIT) olist[at] = (uint16_t)slot;
                             } else if (a.dbg != 2) {
                                 atomicAdd(&cnt[slot], wt);
                                 if (ctx) atomicOr(&ctxw[slot >> 2], ctx << (8 * (slot & 3)));
@@ -432,12 +448,13 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                         }
                     }
                 }
-                lds_barrier();   // rec and the map are rewritten by the next batch
+                lds_barrier();   // 'inserted': rec and the map are rewritten by the next batch
                 PROF(5);
+                bq ^= 1u;
             }
         }
         // (every batch ends with a barrier: the occupancy and the table are final here)
-        if (LDS_LOAD(&ctl[1]) > LIMIT) {   // too many distinct k-mers for one table: split this sub-pass in two by one more hash bit
+        if (LDS_LOAD(occ) > LIMIT) {   // too many distinct k-mers for one table: split this pass in two by one more hash bit
             if (split_lg >= MAX_SPLIT_LOG2) { if (tid == 0) atomicExch(&a.status[1], 1u); }
             else {
                 if (tid == 0) {
@@ -446,7 +463,9 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                 }
                 sp += 2;
             }
+            for (int s = tid; s < SLOTS; s += THREADS) tag[s] = 0;      // nothing is written out: the table is emptied wholesale
             ++splits_done;
+            q ^= 1u;
             continue;
         }
         // K8: filter + write the surviving entries behind the workgroup's cursor in its own output region, in ONE pass over the
@@ -463,7 +482,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
             dma_batch(nvb, nve, bnext, segn);
             prefetched = true;
         }
-        const uint32_t nocc = LDS_LOAD(&ctl[1]);          // <= LIMIT here (the overflow case went the other way)
+        const uint32_t nocc = LDS_LOAD(occ);              // <= LIMIT here (the overflow case went the other way)
         const uint64_t rbase = rcur;
         const uint64_t gbase = (uint64_t)blockIdx.x * a.region_cap + rbase;
         for (uint32_t e0 = 0; e0 < nocc; e0 += THREADS) {
@@ -473,6 +492,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
             if (e < nocc) {
                 s = olist[e];
                 c = cnt[s];
+                tag[s] = 0;                     // the slot is free for the next pass (nobody probes before the barrier below)
                 ok = c >= a.min_freq && c != 0;
                 if (ok && a.bc_mode) {
                     const uint32_t b = bcs[s];
@@ -488,7 +508,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
             if (m) {
                 const int leader = __ffsll((long long)m) - 1;
                 uint32_t b = 0;
-                if (lane == leader) b = atomicAdd(&ctl[8], (uint32_t)__popcll(m));
+                if (lane == leader) b = atomicAdd(place, (uint32_t)__popcll(m));
                 b = __shfl(b, leader);
                 const uint64_t pos = rbase + b + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                 if (ok && pos < a.region_cap) {
@@ -499,8 +519,8 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                 }
             }
         }
-        lds_barrier();
-        const uint32_t nvalid = LDS_LOAD(&ctl[8]);
+        lds_barrier();                                               // 'written'
+        const uint32_t nvalid = LDS_LOAD(place);
         if (nvalid) {
             rcur += nvalid;                       // keeps counting past the capacity: the host learns what the region needs
             if (tid == 0) {
@@ -516,6 +536,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
             }
         }
         if (tid == 0 && nocc > ctl[3]) ctl[3] = nocc;      // running maximum, reported once at the end (a device atomic per bucket: 2 M on one address are 20 ms)
+        q ^= 1u;
         PROF(7);
     }
     if (tid == 0 && splits_done) atomicAdd(&a.status[2], 1u);
