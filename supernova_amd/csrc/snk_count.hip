@@ -46,6 +46,17 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 #define PROF(n) do {} while (0)
 #endif
 
+// inclusive prefix sum over the 64 lanes of a wave without LDS traffic (six DPP adds: inside the rows of 16, then across them)
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);      // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);      // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);      // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);      // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 // high word of (hi:lo) << sh, sh in 0..31
 __device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t sh) {
 #ifdef SNK_FUNNEL_ALIGNBIT
@@ -102,7 +113,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     uint32_t* dd = ctl + 64;                                                        // [DD] supermer de-duplication table (leader index + 1)
     uint32_t* wgt = dd + DD;                                                        // [BATCH] copies folded into each leader
     uint16_t* lead = reinterpret_cast<uint16_t*>(wgt + BATCH);                      // [BATCH] r-th leading (non-folded) supermer
-    uint16_t* lpre = lead + BATCH;                                                  // [BATCH+2] its first k-mer instance (+ sentinel)
+    uint16_t* lpre = lead + BATCH;                                                  // [BATCH+2] one past its last k-mer instance
     uint16_t* cidx = lpre + BATCH + 2;                                              // [NCI] leader rank that owns instance 32*w
     uint32_t* segi = reinterpret_cast<uint32_t*>(smem_raw + (((size_t)(reinterpret_cast<unsigned char*>(cidx + NCI) - smem_raw) + 15) & ~(size_t)15));   // [2][3][MAXSEG] segment start (lo, hi), end (lo; a segment holds < 2^32 records); one copy per bucket parity
     uint16_t* olist = reinterpret_cast<uint16_t*>(segi + 2 * 3 * SNK_COUNT_MAXSEG);  // [LIMIT] claimed slots in claim order (the filter walks these, not the table)
@@ -271,14 +282,10 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                     const uint4 ra = *reinterpret_cast<const uint4*>(rec + 8 * tid), rb = *reinterpret_cast<const uint4*>(rec + 8 * tid + 4);
                     nkm = rb.z & 0x7Fu;
                     if (a.dbg != 4 && nkm) {
-                        uint32_t h = ra.x * 0x9E3779B1u;
-                        h = (h ^ ra.y) * 0x85EBCA77u + (h >> 15);
-                        h = (h ^ ra.z) * 0x85EBCA77u + (h >> 15);
-                        h = (h ^ ra.w) * 0x85EBCA77u + (h >> 15);
-                        h = (h ^ rb.x) * 0x85EBCA77u + (h >> 15);
-                        h = (h ^ rb.y) * 0x85EBCA77u + (h >> 15);
-                        h = (h ^ rb.z) * 0x85EBCA77u + (h >> 15);
-                        h ^= h >> 13;
+                        // (seven independent multiplies, one finaliser: this lane is on the critical path of the batch)
+                        uint32_t h = (ra.x * 0x9E3779B1u) ^ snk_rotl32(ra.y * 0x85EBCA77u, 7) ^ (ra.z * 0xC2B2AE3Du) ^ snk_rotl32(ra.w * 0x27D4EB2Fu, 13)
+                                   ^ (rb.x * 0x165667B1u) ^ snk_rotl32(rb.y * 0xcc9e2d51u, 19) ^ (rb.z * 0x1b873593u);
+                        h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 13;
                         uint32_t s = h & (DD - 1);
                         for (;;) {
                             uint32_t v = LDS_LOAD(&dd[s]);
@@ -311,23 +318,23 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                 // so they are ordered alike)
                 const uint32_t sv = nkm | (nkm ? 0x10000u : 0u);
                 uint32_t incl = sv;
-                for (int o = 1; o < 64; o <<= 1) { uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+                incl = wave_scan_incl(incl);
                 uint32_t woff = 0;
                 if (lane == 63 && incl) woff = atomicAdd(&ctl[10 + bq], incl);
-                woff = __shfl(woff, 63);
+                woff = __builtin_amdgcn_readlane(woff, 63);
                 if (tid < BATCH && nkm) {
                     // instance -> supermer map without a byte per instance: leaders in order, their first instance, and
                     // for every 32nd instance the leader that owns it (a lane then walks 0-3 leaders forward)
                     const uint32_t ex = woff + incl - sv;
                     const uint32_t off = ex & 0xFFFFu, r = ex >> 16;
                     lead[r] = (uint16_t)tid;
-                    lpre[r] = (uint16_t)off;
+                    lpre[r] = (uint16_t)(off + nkm);                 // one past its last instance
                     for (uint32_t w = (off + 31u) >> 5; (w << 5) < off + nkm; ++w) cidx[w] = (uint16_t)r;
                 }
                 lds_barrier();                                       // 'mapped'
                 PROF(4);
                 const uint32_t tot = LDS_LOAD(&ctl[10 + bq]);
-                const uint32_t total = tot & 0xFFFFu, nlead = tot >> 16;
+                const uint32_t total = tot & 0xFFFFu;
                 if (fetch_next) put_down(nbeg, nend, nsb, nse);
                 // ---- one lane per k-mer instance: a wave inserts 64 different k-mers of consecutive supermers, so
                 //      copies of the same k-mer (identical supermers of other reads) are spread over time, not lanes.
@@ -339,13 +346,14 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                     const uint32_t g = g0 + tid;
                     if (g < total) {
                         uint32_t lr = cidx[g >> 5];
-                        while (lr + 1 < nlead && lpre[lr + 1] <= g) ++lr;
+                        uint32_t lend = lpre[lr];
+                        while (lend <= g) lend = lpre[++lr];         // (the last leader ends at total > g)
                         const uint32_t i = lead[lr];
-                        const uint32_t j = g - lpre[lr];
                         const uint32_t* rp = rec + 8 * i;
                         const uint32_t m6 = rp[6], w7 = rp[7];
                         const uint32_t wt = wgt[i];
                         const uint32_t n_i = m6 & 0x7Fu, hasL = (m6 >> 7) & 1u, hasR = (m6 >> 8) & 1u;
+                        const uint32_t j = g + n_i - lend;
                         const uint32_t bst = GROUPED ? 0u : w7;                   // merged barcode state of the supermer
                         const uint32_t o = hasL + j;                     // first base of the k-mer inside the record
                         const uint32_t wi = o >> 4, sh = (2u * o) & 31u;
@@ -366,7 +374,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                             nb = (f3 >> 6) & 3u;
                             F3 = f3 & 0xFFFFFF00u;
                         }
-                        const bool havesucc = (j + 1 < n_i) || hasR, havepred = o != 0;
+                        const uint32_t havesucc = hasR | ((j + 1u - n_i) >> 31), havepred = min(o, 1u);      // 0 / 1
                         snk_kmer f;
                         f.hi = ((uint64_t)F0 << 32) | F1;
                         f.lo = ((uint64_t)F2 << 32) | F3;
@@ -375,9 +383,9 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                         snk_kmer c = rev ? r : f;
                         // context of the stored orientation: the reverse complement's successor is the complement of the
                         // base before, its predecessor the complement of the base after (KMerContext.cc:19)
-                        const uint32_t pa = rev ? 3u - nb : pb, sa = rev ? 3u - pb : nb;
-                        const bool hp = rev ? havesucc : havepred, hs = rev ? havepred : havesucc;
-                        const uint32_t ctx = (hp ? (0x10u << pa) : 0u) | (hs ? (1u << sa) : 0u);
+                        const uint32_t cfw = (havepred << (4u + pb)) | (havesucc << nb);
+                        const uint32_t crv = (havesucc << (7u - nb)) | (havepred << (3u - pb));
+                        const uint32_t ctx = rev ? crv : cfw;
                         if (GROUPED) c.lo |= (uint64_t)w7;           // (group, k-mer) is the counted entity
                         uint32_t h1, h2;
                         snk_kmer_hash_count<(K > 48) || GROUPED>(c, &h1, &h2);
@@ -509,7 +517,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                 const int leader = __ffsll((long long)m) - 1;
                 uint32_t b = 0;
                 if (lane == leader) b = atomicAdd(place, (uint32_t)__popcll(m));
-                b = __shfl(b, leader);
+                b = __builtin_amdgcn_readlane(b, leader);
                 const uint64_t pos = rbase + b + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                 if (ok && pos < a.region_cap) {
                     const uint64_t at = gbase - rbase + pos;
