@@ -378,6 +378,30 @@ int snk_hbv_involution(const snk_hbv* h, uint64_t n_unitigs, int32_t* inv /* [n_
 int snk_write_hbv(const char* path_hbv, const char* path_inv, uint32_t K, uint64_t n_unitigs, const uint64_t* unitig_off,
                   const uint8_t* unitig_bases, const snk_hbv* h, char* err, size_t errcap);
 
+/* ---- f4: duplicate marking over the read paths --------------------------------------------------
+ * MarkDups, lib/assembly/src/10X/SecretOps.cc:413-593 (10X/DF.cc:597-600 runs it on the paths just made and writes a.dup):
+ * placed reads that share (first edge, offset on it, first five bases of the mate) are duplicates of each other; the one with
+ * the largest quality sum over both mates -- the earliest read among equals -- survives, every other member flags its PAIR.
+ *   in     the reads the paths were made from (untrimmed rows, quality rows, lens, bc: the raw barcode ids; NULL = all 0);
+ *          reads 2q and 2q+1 are mates
+ *   dup    u8[n_reads / 2] on the device (owned by the context, valid until its next call): vec<Bool> dup of the reference
+ *   interdup_rate   duplicate reads whose group spans more than one barcode / duplicate reads (the reference's rule: a group's
+ *          barcode is its first member's, or while that is 0 the next member's)
+ *   n_art_pairs     pairs the reference counts as artifactual duplicates (identical bases AND qualities to another member of a
+ *          group with a quality-sum tie); it only logs their percentage */
+typedef struct snk_dev_dups {
+    uint64_t n_pairs;
+    const void* dup;
+    uint64_t n_placed;            /* reads with a path */
+    uint64_t n_dup_reads;         /* sum over groups of (size - 1) */
+    uint64_t n_interdup_reads;
+    uint64_t n_dup_pairs;         /* pairs flagged */
+    uint64_t n_art_pairs;
+    double interdup_rate;
+    float ms;                     /* HIP events around the whole call */
+} snk_dev_dups;
+int snk_dev_mark_dups(snk_ctx* ctx, const snk_dev_reads* in, const snk_dev_paths* paths, snk_dev_dups* out, void* stream, char* err, size_t errcap);
+
 /* ---- f3: barcode ids on the device --------------------------------------------------------------
  * BcIndexer, lib/tada/src/utils.rs:101-164: whitelist line -> index (identical lines: the last one wins); a read's
  * barcode field "SEQ[-gg][,raw]" (FASTH line 6, lib/tada/src/multifastq.rs:72-126) gets

@@ -43,11 +43,14 @@ sed '1134s/return \(.*\);/return (bool)(\1);/' "$S/system/System.cc" > "$OV/syst
 
 CXX=${CXX:-g++}
 OPT=${SNK_REF_OPT:--O3}
-FLAGS="-std=c++11 -fpermissive -fopenmp -fno-strict-aliasing -w $OPT -DNDEBUG -I$OV"
+# -ffunction-sections / --gc-sections: MarkDups (10X/SecretOps.cc, f4) logs through StatLogger (10X/DfTools.cc); the other
+# functions of those two files reach into parts of the reference that do not compile here (paths/long/large/GapToyTools4.cc),
+# but nothing the driver calls does -- the linker drops the unreachable functions and with them their open references
+FLAGS="-std=c++11 -fpermissive -fopenmp -fno-strict-aliasing -w $OPT -DNDEBUG -ffunction-sections -fdata-sections -I$OV"
 
 # link closure of BuildReadQGraph48.o, paths relative to $S, without .cc
 CLOSURE="
-10X/MakeHist 10X/Martian
+10X/MakeHist 10X/Martian 10X/SecretOps 10X/DfTools
 Basevector Charvector CompressedSequence Equiv FastIfstream FastaFileset FastaFilestream
 FastaConverter FastaFilestreamPreview FastaNameParser FastaVerifier TokenizeString Fastavector Intvector Qualvector Vec VecString
 dna/Bases
@@ -78,6 +81,6 @@ $CXX $FLAGS -c "$HERE/ref_driver.cc" -o "$W/obj/ref_driver.o"
 $CXX $FLAGS -DSNK_REF_K60 -c "$HERE/ref_driver.cc" -o "$W/obj/ref_driver60.o"
 # archive, so that only the members the driver really reaches are linked (the closure list is a superset)
 ar rcs "$W/libref.a" $(ls "$W"/obj/*.o | grep -v -e ref_driver.o -e ref_driver60.o -e LinkTimestamp.o)
-$CXX -fopenmp -o "$OUT/snref_driver" "$W/obj/ref_driver.o" "$W/obj/LinkTimestamp.o" "$W/libref.a" -lz -lpthread
-$CXX -fopenmp -o "$OUT/snref_driver60" "$W/obj/ref_driver60.o" "$W/obj/LinkTimestamp.o" "$W/libref.a" -lz -lpthread
+$CXX -fopenmp -Wl,--gc-sections -o "$OUT/snref_driver" "$W/obj/ref_driver.o" "$W/obj/LinkTimestamp.o" "$W/libref.a" -lz -lpthread
+$CXX -fopenmp -Wl,--gc-sections -o "$OUT/snref_driver60" "$W/obj/ref_driver60.o" "$W/obj/LinkTimestamp.o" "$W/libref.a" -lz -lpthread
 echo "build_ref: built $OUT/snref_driver and $OUT/snref_driver60"

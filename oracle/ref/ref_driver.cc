@@ -11,6 +11,8 @@
 //   unitigs.txt    canonical unitigs sorted by BVComp (HBVFromEdges.cc:106-111)
 //   hbv.txt        buildHBVFromEdges result on the *sorted* unitigs
 //   a.hbv, a.inv   that graph and its involution as DF writes them (BinaryWriter::writeFile; RunStages.cc:418, DF a.base files)
+//   markdups.txt   (K=48, mode dump, even read count) MarkDups (10X/SecretOps.cc:413-593) over those paths: inter-barcode
+//                  duplicate rate, logged artifactual-duplicate percentage, one flag per read pair
 //   paths.txt      (K=48, mode dump) read paths of pathReads(..., NEW_ALIGNER=True) (BuildReadQGraph48.cc:1441-1469,
 //                  HBVPather::algorithmTwo :1217-1336): per read "offset n e0 e1 ..." with HBV edge ids
 //   stats/histogram_kmer_count.json  (written by the reference itself)
@@ -33,6 +35,8 @@
 #define SNK_KW 4
 #else
 #include "paths/long/BuildReadQGraph48.cc"
+#include "10X/SecretOps.h"
+#include <sstream>
 #define SNK_KW 3
 #endif
 
@@ -244,6 +248,31 @@ int main(int argc, char** argv) {
             fprintf(f, "\n");
         }
         fclose(f);
+        // ---- duplicate marking: MarkDups over the read paths just made (10X/SecretOps.cc:413-593; DF.cc:597-600
+        //      runs it right after the pathing).  dup = one flag per read PAIR; the rate of duplicates that involve more than
+        //      one barcode; the artifactual-duplicate percentage only exists as a logged statistic, so it is taken from the log.
+        if (reads.size() % 2 == 0 && reads.size() > 0) {
+            VecPQVec pq2 = quals.load();
+            vec<int32_t> bcm(reads.size(), 0);
+            if (in.has_bc) bcm.assign(in.bc.begin(), in.bc.end());
+            vec<Bool> dup;
+            double interdup = 0;
+            std::stringstream log;
+            std::streambuf* old = std::cout.rdbuf(log.rdbuf());
+            MarkDups(reads, pq2, paths, bcm, dup, interdup, False);
+            std::cout.rdbuf(old);
+            std::string art = "0";
+            {
+                const std::string l = log.str();
+                size_t at = l.find("art_dup_perc=");
+                if (at != std::string::npos) { size_t e = l.find('\n', at); art = l.substr(at + 13, e - at - 13); }
+            }
+            FILE* g = fopen((outdir + "/markdups.txt").c_str(), "w");
+            fprintf(g, "%.17g %s %lu\n", interdup, art.c_str(), (unsigned long)dup.size());
+            for (size_t i = 0; i < dup.size(); ++i) fputc(dup[i] ? '1' : '0', g);
+            fputc('\n', g);
+            fclose(g);
+        }
     }
 #endif
     delete pDict;

@@ -956,3 +956,120 @@ int sno_path_reads(const uint8_t* bases, const uint8_t* quals, uint32_t stride, 
     return 0;
 }
 void sno_free(void* p) { free(p); }
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * f4: MarkDups, lib/assembly/src/10X/SecretOps.cc:413-593 (DF.cc:597-600).  Plain restatement: the records
+ * (first edge, offset, head of the mate, read id) as the reference builds them (:430-441), qsort in place of
+ * sortInPlaceParallel (:447), the marking walk (:449-474), the quality sums (:480-499), the finalising walk with
+ * its artifact check (:505-556).  first_edge[r] < 0 = read r has no path.  dup / art: one byte per PAIR. */
+typedef struct { int32_t e, off, head; int64_t id; } md_rec;
+static int md_cmp(const void* a, const void* b) {
+    const md_rec* x = (const md_rec*)a; const md_rec* y = (const md_rec*)b;
+    if (x->e != y->e) return x->e < y->e ? -1 : 1;
+    if (x->off != y->off) return x->off < y->off ? -1 : 1;
+    if (x->head != y->head) return x->head < y->head ? -1 : 1;
+    return x->id < y->id ? -1 : (x->id > y->id ? 1 : 0);
+}
+typedef struct { const uint8_t* b; const uint8_t* q; uint32_t len; int64_t pair; } md_qb;
+static int md_qb_cmp(const void* a, const void* b) {          /* Sort(qb): bases, then qualities, then the pair (:537) */
+    const md_qb* x = (const md_qb*)a; const md_qb* y = (const md_qb*)b;
+    uint32_t n = x->len < y->len ? x->len : y->len;
+    int c = memcmp(x->b, y->b, n);
+    if (c) return c;
+    if (x->len != y->len) return x->len < y->len ? -1 : 1;
+    c = memcmp(x->q, y->q, n);
+    if (c) return c;
+    return x->pair < y->pair ? -1 : (x->pair > y->pair ? 1 : 0);
+}
+int sno_mark_dups(const uint8_t* bases, const uint8_t* quals, uint32_t stride, const uint32_t* lens, uint64_t n_reads,
+                  const int32_t* first_edge, const int32_t* offset, const int32_t* bc, uint8_t* dup, uint8_t* art,
+                  double* interdup_rate, uint64_t* n_dups, uint64_t* n_interdups) {
+    const int BHEAD = 5;
+    if (n_reads & 1ull) return -1;
+    md_rec* X = (md_rec*)malloc((n_reads ? n_reads : 1) * sizeof(md_rec));
+    uint8_t* dup1 = (uint8_t*)calloc(n_reads ? n_reads : 1, 1);
+    int64_t* qsum = (int64_t*)calloc(n_reads ? n_reads : 1, sizeof(int64_t));
+    if (!X || !dup1 || !qsum) { free(X); free(dup1); free(qsum); return -2; }
+    memset(dup, 0, n_reads / 2);
+    memset(art, 0, n_reads / 2);
+    for (uint64_t id1 = 0; id1 < n_reads; ++id1) {
+        const uint64_t id2 = id1 ^ 1ull;
+        if (first_edge[id1] < 0) { X[id1].e = -1; X[id1].off = -1; X[id1].head = -1; X[id1].id = -1; }
+        else {
+            int n = 0;
+            for (int j = 0; j < BHEAD; ++j) n = n * 4 + bases[id2 * stride + j];
+            X[id1].e = first_edge[id1]; X[id1].off = offset[id1]; X[id1].head = n; X[id1].id = (int64_t)id1;
+        }
+    }
+    qsort(X, n_reads, sizeof(md_rec), md_cmp);
+    uint64_t ndups = 0, interdups = 0;
+    for (uint64_t j = 0; j < n_reads; ++j) {
+        if (X[j].e < 0) continue;
+        uint64_t k;
+        for (k = j + 1; k < n_reads; ++k) {
+            if (X[k].e != X[j].e || X[k].off != X[j].off) break;
+            if (X[k].head != X[j].head) break;
+        }
+        if (k - j > 1) {
+            for (uint64_t l = j; l < k; ++l) dup1[X[l].id] = 1;
+            ndups += k - j - 1;
+            int inter = 0;
+            int32_t b = bc ? bc[X[j].id] : 0;
+            for (uint64_t l = j + 1; l < k; ++l) {
+                const int32_t c = bc ? bc[X[l].id] : 0;
+                if (b == 0) b = c;
+                else if (c != b) inter = 1;
+            }
+            if (inter) interdups += k - j - 1;
+        }
+        j = k - 1;
+    }
+    *interdup_rate = ndups ? (double)interdups / (double)ndups : 0.0;
+    for (uint64_t id1 = 0; id1 < n_reads; ++id1) {
+        if (!dup1[id1]) continue;
+        const uint64_t id2 = id1 ^ 1ull;
+        for (uint32_t l = 0; l < lens[id1]; ++l) qsum[id1] += quals[id1 * stride + l];
+        for (uint32_t l = 0; l < lens[id2]; ++l) qsum[id1] += quals[id2 * stride + l];
+    }
+    md_qb* qb = NULL;
+    uint64_t qcap = 0;
+    for (uint64_t j = 0; j < n_reads; ++j) {
+        uint64_t k;
+        for (k = j + 1; k < n_reads; ++k) {
+            if (X[k].e != X[j].e || X[k].off != X[j].off) break;
+            if (X[k].head != X[j].head) break;
+        }
+        if (X[j].e < 0) { j = k - 1; continue; }
+        uint64_t best = j;
+        int64_t q = qsum[X[j].id];
+        int tie = 0;
+        for (uint64_t l = j + 1; l < k; ++l) {
+            if (qsum[X[l].id] == q) { tie = 1; if (X[l].id < X[best].id) best = l; }
+            else if (qsum[X[l].id] > q) { q = qsum[X[l].id]; best = l; }
+        }
+        if (tie) {
+            const uint64_t m = k - j;
+            if (m > qcap) { qcap = m * 2; qb = (md_qb*)realloc(qb, qcap * sizeof(md_qb)); }
+            for (uint64_t l = j; l < k; ++l) {
+                const uint64_t id = (uint64_t)X[l].id;
+                qb[l - j].b = bases + id * stride; qb[l - j].q = quals + id * stride; qb[l - j].len = lens[id]; qb[l - j].pair = (int64_t)(id / 2);
+            }
+            qsort(qb, m, sizeof(md_qb), md_qb_cmp);
+            for (uint64_t a = 0; a < m; ++a) {
+                uint64_t b2;
+                for (b2 = a + 1; b2 < m; ++b2) {
+                    if (qb[b2].len != qb[a].len || memcmp(qb[b2].b, qb[a].b, qb[a].len)) break;
+                    if (memcmp(qb[b2].q, qb[a].q, qb[a].len)) break;
+                }
+                for (uint64_t x = a + 1; x < b2; ++x) art[qb[x].pair] = 1;
+                a = b2 - 1;
+            }
+        }
+        for (uint64_t l = j; l < k; ++l) if (l != best) dup[X[l].id / 2] = 1;
+        j = k - 1;
+    }
+    *n_dups = ndups;
+    *n_interdups = interdups;
+    free(qb); free(X); free(dup1); free(qsum);
+    return 0;
+}

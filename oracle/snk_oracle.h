@@ -57,6 +57,11 @@ int sno_read_bv(const char* path, sno_unitigs* out);
  * BVComp order with their HBV (sno_hbv_build).  *out_edges is malloc'ed (sno_free). */
 int sno_path_reads(const uint8_t* bases, const uint8_t* quals, uint32_t stride, const uint32_t* lens, uint64_t n_reads, uint32_t K,
                    const sno_unitigs* u, const sno_hbv* h, int32_t* out_off, int32_t* out_n, int32_t** out_edges, uint64_t* out_total);
+/* f4: MarkDups (10X/SecretOps.cc:413-593) over read paths given as (first edge or -1, offset) per read; reads 2q, 2q+1 are
+ * mates; bc may be NULL (all 0).  dup / art: one byte per pair.  Pinned by the reference's own MarkDups on the golden cases. */
+int sno_mark_dups(const uint8_t* bases, const uint8_t* quals, uint32_t stride, const uint32_t* lens, uint64_t n_reads,
+                  const int32_t* first_edge, const int32_t* offset, const int32_t* bc, uint8_t* dup, uint8_t* art,
+                  double* interdup_rate, uint64_t* n_dups, uint64_t* n_interdups);
 void sno_free(void* p);
 void sno_table_free(sno_table* t);
 void sno_unitigs_free(sno_unitigs* u);

@@ -115,10 +115,12 @@ class Result:
         self._e.lib.snk_hbv_free(C.byref(h))
         return out
 
-    def path_reads(self, rows, read_len: int, quals, lens=None):
+    def path_reads(self, rows, read_len: int, quals, lens=None, mark_dups=False, bc=None):
         """f1: the reads (untrimmed packed rows + quality rows on the device) onto the graph of this result's unitigs --
         pathReads with the new aligner (BuildReadQGraph48.cc:1441-1469).  Returns (offset i32[n], n_edges u32[n], edges i32[sum],
-        info) on the host, HBV edge ids as numbered by buildHBVFromEdges.  Must be called before the engine's next count_graph."""
+        info) on the host, HBV edge ids as numbered by buildHBVFromEdges.  Must be called before the engine's next count_graph.
+        mark_dups: f4, MarkDups over these paths (10X/SecretOps.cc:413-593; bc = raw barcode ids on the device or None) ->
+        info['dups'] = dict(dup u8[n/2], interdup_rate, n_dup_pairs, n_dup_reads, n_art_pairs, n_placed, ms)."""
         e = self._e
         h = _lib.SnkHbv()
         ms = C.c_float(0)
@@ -138,14 +140,28 @@ class Result:
                                           C.byref(h), C.byref(out), e._stream(), err, 512)
             if rc:
                 raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+            dups = None
+            if mark_dups:
+                if bc is not None:
+                    r.bc = bc.data_ptr()
+                dd = _lib.SnkDevDups()
+                rc = e.lib.snk_dev_mark_dups(e._ctx, C.byref(r), C.byref(out), C.byref(dd), e._stream(), err, 512)
+                if rc:
+                    raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+                npairs = int(dd.n_pairs)
+                dups = dict(dup=self._dl(dd.dup, npairs, np.uint8, (npairs,)), interdup_rate=float(dd.interdup_rate),
+                            n_dup_pairs=int(dd.n_dup_pairs), n_dup_reads=int(dd.n_dup_reads), n_interdup_reads=int(dd.n_interdup_reads),
+                            n_art_pairs=int(dd.n_art_pairs), n_placed=int(dd.n_placed), ms=float(dd.ms))
         finally:
             e.lib.snk_hbv_free(C.byref(h))
         n, tot = int(out.n_reads), int(out.n_edges_total)
         off = self._dl(out.offset, n * 4, np.int32, (n,))
         ne = self._dl(out.n_edges, n * 4, np.uint32, (n,))
         edges = self._dl(out.edges, tot * 4, np.int32, (tot,))
-        return off, ne, edges, dict(dict_ms=float(out.dict_ms), path_ms=float(out.path_ms), hbv_device_ms=float(ms.value),
-                                    dict_slots=int(out.dict_slots))
+        info = dict(dict_ms=float(out.dict_ms), path_ms=float(out.path_ms), hbv_device_ms=float(ms.value), dict_slots=int(out.dict_slots))
+        if dups is not None:
+            info["dups"] = dups
+        return off, ne, edges, info
 
     def unitigs(self) -> list[str]:
         """Canonical unitigs sorted by (length desc, lexicographic) = BVComp, HBVFromEdges.cc:106-111."""

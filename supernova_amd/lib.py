@@ -95,6 +95,12 @@ class SnkDevPaths(C.Structure):
                 ("path_ms", C.c_float)]
 
 
+class SnkDevDups(C.Structure):
+    _fields_ = [("n_pairs", C.c_uint64), ("dup", C.c_void_p), ("n_placed", C.c_uint64), ("n_dup_reads", C.c_uint64),
+                ("n_interdup_reads", C.c_uint64), ("n_dup_pairs", C.c_uint64), ("n_art_pairs", C.c_uint64),
+                ("interdup_rate", C.c_double), ("ms", C.c_float)]
+
+
 RANGE_READY = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32)      # int ready(void* user, uint32_t range)
 
 _lib = None
@@ -162,6 +168,7 @@ def _declare(lib: C.CDLL) -> None:
         "snk_dev_hbv": (C.c_int, [vp, u32, u64, vp, vp, P(SnkHbv), P(C.c_float), vp, cp, sz]),
         "snk_hbv_free": (None, [P(SnkHbv)]),
         "snk_dev_path_reads": (C.c_int, [vp, u32, P(SnkDevReads), u64, vp, vp, P(SnkHbv), P(SnkDevPaths), vp, cp, sz]),
+        "snk_dev_mark_dups": (C.c_int, [vp, P(SnkDevReads), P(SnkDevPaths), P(SnkDevDups), vp, cp, sz]),
         "snk_hbv_involution": (C.c_int, [P(SnkHbv), u64, vp, cp, sz]),
         "snk_write_hbv": (C.c_int, [cp, cp, u32, u64, vp, vp, P(SnkHbv), cp, sz]),
         "snk_read_fastb": (C.c_int, [cp, P(u64), P(u32), P(P(C.c_uint16)), P(P(u32)), cp, sz]),

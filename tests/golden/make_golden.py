@@ -131,7 +131,34 @@ def adversarial_case(seed=20260928, K=48):
                 meta=dict(kind="adversarial", seed=seed))
 
 
+def dups_case(n_reads=4000, seed=0x5EED00D0):
+    """Synthetic pairs plus planted duplicate pairs (MarkDups): copies with the same qualities (ties ->
+    artifactual duplicates), with lowered / raised qualities (the best copy wins), in the same / another / no barcode
+    (inter-barcode rate), groups of two to four, one copy with a changed mate head (not a duplicate)."""
+    c = synth_case(n_reads, seed, False)
+    rng = np.random.default_rng(seed)
+    asc, qa, bc, lens = [c["ascii"]], [c["quals"]], [c["bc"]], [c["lens"]]
+    npairs = n_reads // 2
+    for p in rng.choice(npairs, 160, replace=False):
+        for _ in range(int(rng.integers(1, 4))):
+            a = c["ascii"][2 * p:2 * p + 2].copy()
+            q = c["quals"][2 * p:2 * p + 2].copy()
+            b = c["bc"][2 * p:2 * p + 2].copy()
+            kind = int(rng.integers(0, 6))
+            if kind == 1: q[:, 100:] = np.maximum(q[:, 100:], 3) - 1          # a worse copy
+            elif kind == 2: q[0, 50:60] = 40                                   # a better copy
+            elif kind == 3: b[:] = int(rng.integers(1, 1 << 20))               # another barcode
+            elif kind == 4: b[:] = 0                                           # no barcode
+            elif kind == 5: a[1, 2] = ord("ACGT"[("ACGT".index(chr(a[1, 2])) + 1) % 4])   # another mate head for read 0
+            asc.append(a); qa.append(q); bc.append(b); lens.append(c["lens"][2 * p:2 * p + 2])
+    out = dict(c)
+    out.update(ascii=np.concatenate(asc), quals=np.concatenate(qa), bc=np.concatenate(bc).astype(np.int32), lens=np.concatenate(lens),
+               meta=dict(kind="synth+dups", n_reads=n_reads, seed=seed))
+    return out
+
+
 CASES = {
+    "synth_4k_dups": lambda: dups_case(),
     "synth_2k_err": lambda: synth_case(2000, 0x5EED0001, False),
     "synth_6k_clean": lambda: synth_case(6000, 0x5EED0002, True),
     "synth_20k_err": lambda: synth_case(20000, 0x5EED0003, False),
@@ -175,6 +202,8 @@ def make(name: str) -> None:
         exp_hist=np.asarray(d["hist"]["vals"] if d["hist"] else [], dtype=np.int64),
         exp_path_off=d["path_off"], exp_path_n=d["path_n"], exp_path_edges=d["path_edges"],
         exp_ahbv=d["a.hbv"], exp_ainv=d["a.inv"],
+        exp_dup=d["dup"] if d["dup"] is not None else np.zeros(0, np.uint8),
+        exp_interdup=np.float64(d.get("interdup", 0.0)), exp_art_perc=np.float64(d.get("art_perc", 0.0)),
         meta=np.frombuffer(repr(case["meta"]).encode(), dtype=np.uint8),
         ref_summary=np.frombuffer(summary.encode(), dtype=np.uint8),
     )

@@ -8,7 +8,7 @@ import numpy as np
 from supernova_amd import synth
 
 GOLD = Path(__file__).resolve().parent / "golden"
-CASES = ["synth_2k_err", "synth_6k_clean", "synth_20k_err", "adversarial"]
+CASES = ["synth_2k_err", "synth_6k_clean", "synth_20k_err", "adversarial", "synth_4k_dups"]
 
 
 class Case:
@@ -35,6 +35,10 @@ class Case:
         self.exp_path_edges = z["exp_path_edges"]
         self.exp_ahbv = bytes(z["exp_ahbv"])
         self.exp_ainv = bytes(z["exp_ainv"])
+        # f4: MarkDups over those paths -- flag per pair, inter-barcode rate, the logged artifactual-duplicate percentage
+        self.exp_dup = z["exp_dup"]
+        self.exp_interdup = float(z["exp_interdup"])
+        self.exp_art_perc = float(z["exp_art_perc"])
 
 
 _cache: dict[str, Case] = {}

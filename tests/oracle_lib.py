@@ -194,3 +194,37 @@ class OracleResult:
         for u in range(len(self.unitigs)):
             lines.append(f"X {u} {h['fwd'][u]} {h['rev'][u]}")
         return "\n".join(lines) + "\n"
+
+
+def mark_dups(codes: np.ndarray, quals: np.ndarray, lens, path_off, path_n, path_edges, bc=None):
+    """f4: the restatement of MarkDups (10X/SecretOps.cc:413-593) over read paths in the dumped form (offset, edge count, edges
+    concatenated).  Returns (dup u8[n/2], art u8[n/2], interdup_rate, n_dups, n_interdups)."""
+    lib = load()
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    quals = np.ascontiguousarray(quals, dtype=np.uint8)
+    n, stride = codes.shape
+    lens = np.ascontiguousarray(np.broadcast_to(np.asarray(lens), (n,)), dtype=np.uint32)
+    path_n = np.asarray(path_n, dtype=np.int64)
+    start = np.zeros(n + 1, dtype=np.int64)
+    start[1:] = np.cumsum(path_n)
+    pe = np.asarray(path_edges, dtype=np.int32)
+    first = np.full(n, -1, dtype=np.int32)
+    has = path_n > 0
+    first[has] = pe[start[:-1][has]]
+    off = np.ascontiguousarray(path_off, dtype=np.int32)
+    bcp = None
+    if bc is not None:
+        bca = np.ascontiguousarray(bc, dtype=np.int32)
+        bcp = bca.ctypes.data
+    dup = np.zeros(n // 2, dtype=np.uint8)
+    art = np.zeros(n // 2, dtype=np.uint8)
+    rate = C.c_double(0)
+    nd, ni = C.c_uint64(0), C.c_uint64(0)
+    lib.sno_mark_dups.restype = C.c_int
+    lib.sno_mark_dups.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    rc = lib.sno_mark_dups(codes.ctypes.data, quals.ctypes.data, stride, lens.ctypes.data, n, first.ctypes.data, off.ctypes.data, bcp,
+                           dup.ctypes.data, art.ctypes.data, C.byref(rate), C.byref(nd), C.byref(ni))
+    if rc != 0:
+        raise RuntimeError(f"sno_mark_dups failed {rc}")
+    return dup, art, float(rate.value), int(nd.value), int(ni.value)

@@ -62,6 +62,16 @@ def read_ref_dump(outdir, K=48):
         out["path_off"] = np.asarray(offs, dtype=np.int32)
         out["path_n"] = np.asarray(ns, dtype=np.int32)
         out["path_edges"] = np.asarray(edges, dtype=np.int32)
+    # f4: MarkDups over those paths -- inter-barcode duplicate rate, logged artifactual-duplicate percentage, flag per pair
+    md = outdir / "markdups.txt"
+    out["dup"] = None
+    if md.exists():
+        head, bits = md.read_text().split("\n")[:2]
+        t = head.split()
+        out["interdup"] = float(t[0])
+        out["art_perc"] = float(t[1]) if t[1] not in ("nan", "-nan") else 0.0
+        out["dup"] = np.frombuffer(bits.encode(), dtype=np.uint8) - ord("0")
+        assert len(out["dup"]) == int(t[2])
     for nm in ("a.hbv", "a.inv"):
         f = outdir / nm
         out[nm] = np.frombuffer(f.read_bytes(), dtype=np.uint8) if f.exists() else None

@@ -610,6 +610,26 @@ def test_read_paths_match_reference(engine, graph_stage, name):
     assert np.array_equal(off, c.exp_path_off)
 
 
+@pytest.mark.parametrize("name", goldens.CASES)
+def test_mark_dups_match_reference(engine, graph_stage, name):
+    """f4: MarkDups on the device (radix sort of (first edge, offset, mate head), one thread per duplicate group) over the
+    device's own read paths, against the reference's MarkDups on the golden cases: the flag of every pair, the inter-barcode
+    rate exactly, the artifactual pairs against the C restatement (the reference only logs their percentage)."""
+    if graph_stage == "global":
+        pytest.skip("duplicates are marked on read paths; one graph stage is enough")
+    c = goldens.load(name)
+    rows, quals, bc, lens = _to_dev(c)
+    res = engine.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, ign_bc_below=c.ign_bc_below)
+    off, ne, edges, info = res.path_reads(rows, c.read_len, quals, lens=lens, mark_dups=True, bc=bc)
+    d = info["dups"]
+    assert np.array_equal(d["dup"], c.exp_dup), np.nonzero(d["dup"] != c.exp_dup)[0][:10]
+    assert d["interdup_rate"] == c.exp_interdup
+    o_dup, o_art, o_rate, o_nd, o_ni = oracle_lib.mark_dups(c.codes, c.quals, c.lens, c.exp_path_off, c.exp_path_n, c.exp_path_edges, bc=c.bc)
+    assert (d["n_dup_reads"], d["n_interdup_reads"], d["n_dup_pairs"], d["n_art_pairs"]) == (o_nd, o_ni, int(o_dup.sum()), int(o_art.sum()))
+    assert d["n_placed"] == int((c.exp_path_n > 0).sum())
+    assert float(f"{100.0 * d['n_art_pairs'] / len(o_dup):.2g}") == float(f"{c.exp_art_perc:.2g}")
+
+
 @pytest.mark.parametrize("min_bc", [3, 5])
 def test_minbc_above_two_synth(engine, graph_stage, min_bc):
     """General minBC on a seeded workload with many barcodes per locus (40 barcodes over 60 k reads: every locus sees several),

@@ -132,3 +132,23 @@ def test_read_paths_match_reference(name):
     assert len(bad) == 0, (len(bad), bad[:5], n[bad[:5]], c.exp_path_n[bad[:5]])
     assert np.array_equal(edges, c.exp_path_edges)
     assert np.array_equal(off, c.exp_path_off)
+
+
+def _art_matches_log(n_art, n_pairs, logged):
+    """The reference only LOGS the artifactual-duplicate percentage (two significant digits after its fixed/precision
+    manipulators): the count is checked through the same rounding."""
+    return float(f"{100.0 * n_art / n_pairs:.2g}") == float(f"{logged:.2g}")
+
+
+@pytest.mark.parametrize("name", goldens.CASES)
+def test_mark_dups_matches_reference(name):
+    """f4: the restatement of MarkDups against the reference's own MarkDups (10X/SecretOps.cc:413-593) run on the read paths
+    it made for the golden cases: the flag of every pair, the inter-barcode rate exactly, the artifact share as logged."""
+    c = goldens.load(name)
+    dup, art, rate, nd, ni = oracle_lib.mark_dups(c.codes, c.quals, c.lens, c.exp_path_off, c.exp_path_n, c.exp_path_edges, bc=c.bc)
+    assert len(dup) == len(c.exp_dup)
+    assert np.array_equal(dup, c.exp_dup), np.nonzero(dup != c.exp_dup)[0][:10]
+    assert rate == c.exp_interdup
+    assert _art_matches_log(int(art.sum()), len(dup), c.exp_art_perc), (int(art.sum()), len(dup), c.exp_art_perc)
+    if name == "synth_4k_dups":
+        assert dup.sum() > 300 and art.sum() > 100 and 0.0 < rate < 1.0
