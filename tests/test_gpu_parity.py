@@ -529,9 +529,12 @@ def test_vs_reference_binary_200k(engine, graph_stage, tmp_path):
     _check_against(res, d["kmers"]["k"], d["kmers"]["count"], d["kmers"]["ctx"], d["unitigs"], d["goodlens"], hist)
     # f1: the same run's read paths (the reference's pathReads, new aligner) against the device pather
     rows_d, quals_d = torch.from_numpy(rows.view(np.int32)).to(dev), torch.from_numpy(quals).to(dev)
-    off, ne, edges, _ = res.path_reads(rows_d, 150, quals_d)
+    off, ne, edges, info = res.path_reads(rows_d, 150, quals_d, mark_dups=True, bc=torch.from_numpy(bc).to(dev))
     assert np.array_equal(ne.astype(np.int32), d["path_n"]) and np.array_equal(edges, d["path_edges"]) and np.array_equal(off, d["path_off"])
     assert int((ne > 1).sum()) > 100 and int((ne == 0).sum()) > 0          # multi-edge paths and unplaced reads both occur
+    # f4: the same run's MarkDups (100 k pairs on a 0.5 Mb genome: chance duplicates by the hundred)
+    assert np.array_equal(info["dups"]["dup"], d["dup"]) and info["dups"]["interdup_rate"] == d["interdup"]
+    assert int(d["dup"].sum()) > 50
 
 
 def test_circle_pool_retry(engine, monkeypatch):
