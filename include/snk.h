@@ -367,9 +367,18 @@ typedef struct snk_dev_paths {
     const void* edges;         /* i32[n_edges_total] */
     uint64_t dict_slots;
     float dict_ms, path_ms;    /* HIP events: graph tables + packed unitigs + dictionary; pathing + gather */
+    /* SNK_PATH_UNITIG_BCS (snk_dev_path_reads2): per unitig (device numbering) the sorted distinct barcodes > 0 of the reads that
+     * have a k-mer on it -- the edge -> barcode sets of tada's MAIN_ASM_SN (lib/tada/src/cmd_main_asm.rs:91-151,
+     * debruijn.rs:115-131; the 20 000-entry cut of its shard-by-shard collection is not applied) */
+    const void* unitig_bc_off; /* u64[n_unitigs + 1] */
+    const void* unitig_bcs;    /* u32[n_unitig_bcs] */
+    uint64_t n_unitig_bcs;
 } snk_dev_paths;
+#define SNK_PATH_UNITIG_BCS 1u
 int snk_dev_path_reads(snk_ctx* ctx, uint32_t K, const snk_dev_reads* in, uint64_t n_unitigs, const void* d_unitig_off, const void* d_unitig_bases,
                        const snk_hbv* h, snk_dev_paths* out, void* stream, char* err, size_t errcap);
+int snk_dev_path_reads2(snk_ctx* ctx, uint32_t K, const snk_dev_reads* in, uint64_t n_unitigs, const void* d_unitig_off, const void* d_unitig_bases,
+                        const snk_hbv* h, uint32_t flags, snk_dev_paths* out, void* stream, char* err, size_t errcap);
 /* f2: hbv.Involution (paths/HyperBasevector.cc:685-697; 10X/runstages/RunStages.cc:418): inv[e] = edge that is e's reverse
  * complement -- and the files DF keeps the graph in: a.hbv = BinaryWriter::writeFile(HyperBasevector)
  * (paths/HyperBasevector.cc:121-125, graph/DigraphTemplate.h:3092-3097) and a.inv (vec<int>), byte for byte.  The unitig arrays

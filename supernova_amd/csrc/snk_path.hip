@@ -287,8 +287,15 @@ struct path_args {
     int32_t* out_e0;                  // [n] first edge of the path (-1: none)
     unsigned long long* out_start;    // [n] position of the read's FURTHER edges in the scratch list
     int32_t* scratch;                 // second and later edges in completion order
-    unsigned long long* cursor;       // [0] edges reserved, [1] error flags
+    unsigned long long* cursor;       // [0] edges reserved, [1] error flags, [2] (unitig, barcode) keys reserved
     uint64_t scratch_cap;
+    // per-unitig barcode lists (the rest of SURVEY f4; tada's edge -> barcode sets, lib/tada/src/cmd_main_asm.rs:91-151,
+    // debruijn.rs:115-131): a barcoded read contributes its barcode to every unitig one of its k-mers lies on -- exactly the
+    // unitigs of its non-gap path parts, since Pather::path looks every k-mer up that no exact-match run covers
+    const int32_t* bc;                // raw barcode ids, or NULL: no lists
+    unsigned long long* ub_first;     // [n] unitig << 32 | barcode of the read's first such unitig (~0: none)
+    unsigned long long* ub_more;      // further ones, through cursor[2]
+    uint64_t ub_cap;
 };
 
 // one dictionary look-up: canonical form, probe, the strand the read is on relative to the unitig
@@ -403,6 +410,25 @@ __global__ void __launch_bounds__(256, 4) path_kernel(path_args a) {
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
         // ---- the rest of algorithmTwo + the extension: sequential, the group's first lane
+        if (live && sub == 0 && a.bc) {
+            // (unitig, barcode) keys of this read -- from the parts as Pather::path left them (finish_path rewrites them)
+            unsigned long long first = ~0ull;
+            const int32_t b = a.bc[r];
+            if (b > 0 && !overflow) {
+                uint32_t fu = 0xFFFFFFFFu, lastu = 0xFFFFFFFFu;
+                for (int p = 0; p < m; ++p) {
+                    if (p_gap(parts[p])) continue;
+                    const uint32_t u = parts[p].unitig;
+                    if (fu == 0xFFFFFFFFu) { fu = u; first = ((unsigned long long)u << 32) | (uint32_t)b; }
+                    else if (u != fu && u != lastu) {
+                        const unsigned long long at = atomicAdd(&a.cursor[2], 1ull);
+                        if (at < a.ub_cap) a.ub_more[at] = ((unsigned long long)u << 32) | (uint32_t)b;
+                    }
+                    lastu = u;
+                }
+            }
+            a.ub_first[r] = first;
+        }
         if (live && sub == 0) {
             int np = 0;
             int32_t off = 0;
@@ -485,9 +511,23 @@ void adjacency(int32_t N, int32_t E, const int32_t* key_v, const int32_t* other_
     for (int32_t i = 0; i < E; ++i) { vv[i] = tmp[i].first; ee[i] = tmp[i].second; }
 }
 
+// sorted (unitig << 32 | barcode) keys -> the first of every run of equal keys (the all-ones filler excluded)
+__global__ void __launch_bounds__(256) ubc_flag_kernel(const unsigned long long* __restrict__ k, uint64_t n, uint64_t* __restrict__ flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) flag[i] = (k[i] != ~0ull && (i == 0 || k[i] != k[i - 1])) ? 1ull : 0ull;
+    else if (i == n) flag[i] = 0;
+}
+__global__ void __launch_bounds__(256) ubc_scatter_kernel(const unsigned long long* __restrict__ k, const uint64_t* __restrict__ flag, const uint64_t* __restrict__ pos,
+                                                          uint64_t n, uint32_t* __restrict__ bcs, uint64_t* __restrict__ per_unitig) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    bcs[pos[i]] = (uint32_t)k[i];
+    atomicAdd((unsigned long long*)&per_unitig[k[i] >> 32], 1ull);
+}
+
 template <int K>
 int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U, const uint64_t* d_uoff, const uint8_t* d_ubases, const snk_hbv* h,
-              snk_dev_paths* out, char* err, size_t errcap) {
+              uint32_t flags, snk_dev_paths* out, char* err, size_t errcap) {
     int rc;
     const uint64_t n = in->n_reads;
     hipEvent_t e0, e1, e2;
@@ -566,11 +606,16 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
         (rc = dev(ctx, 4, &cursor, err, errcap)) || (rc = dev(ctx, n + 2, &n64, err, errcap)) || (rc = dev(ctx, n + 2, &pos, err, errcap)))
         return rc;
     uint64_t scap = n / 4 + 65536;                    // second and later edges only; a wrong guess costs one re-run
-    unsigned long long h_cur[2] = {0, 0};
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        if ((rc = dev(ctx, scap, &scratch, err, errcap))) return rc;
-        SNK_HIP_TRY(hipMemsetAsync(cursor, 0, 16, st));
+    const bool want_bcs = (flags & SNK_PATH_UNITIG_BCS) && in->bc;
+    uint64_t ubcap = want_bcs ? n / 4 + 65536 : 0;    // (unitig, barcode) keys beyond a read's first
+    unsigned long long* ubk = nullptr;                // [n + ubcap]: the reads' first keys, then the further ones
+    unsigned long long h_cur[3] = {0, 0, 0};
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        if (!scratch && (rc = dev(ctx, scap, &scratch, err, errcap))) return rc;
+        if (want_bcs && !ubk && (rc = dev(ctx, n + ubcap, &ubk, err, errcap))) return rc;
+        SNK_HIP_TRY(hipMemsetAsync(cursor, 0, 32, st));
         a.out_off = out_off; a.out_n = out_n; a.out_e0 = out_e0; a.out_start = out_start; a.scratch = scratch; a.cursor = cursor; a.scratch_cap = scap;
+        a.bc = want_bcs ? (const int32_t*)in->bc : nullptr; a.ub_first = ubk; a.ub_more = ubk ? ubk + n : nullptr; a.ub_cap = ubcap;
         if (n) {
             uint64_t grid = (n + 15) / 16;
             const uint64_t gmax = (uint64_t)ctx->n_cu * 64;
@@ -578,13 +623,14 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
             hipLaunchKernelGGL((path_kernel<K>), dim3((unsigned)grid), dim3(256), 0, st, a);
         }
         SNK_HIP_TRY(hipGetLastError());
-        SNK_HIP_TRY(hipMemcpyAsync(h_cur, cursor, 16, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(hipMemcpyAsync(h_cur, cursor, 24, hipMemcpyDeviceToHost, st));
         SNK_HIP_TRY(hipStreamSynchronize(st));
         if (h_cur[1] & 1ull) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_dev_path_reads: a read has more than %d path parts or %d edges", PCAP, PMAX);
-        if (!(h_cur[1] & 2ull)) break;
-        if (attempt == 1) return snk_fail(SNK_E_INTERNAL, err, errcap, "snk_dev_path_reads: path scratch overflow");
-        snk_ctx_release_block(ctx, scratch);
-        scap = h_cur[0] + 1024;
+        const bool e_over = (h_cur[1] & 2ull) != 0, b_over = want_bcs && h_cur[2] > ubcap;
+        if (!e_over && !b_over) break;
+        if (attempt == 2) return snk_fail(SNK_E_INTERNAL, err, errcap, "snk_dev_path_reads: path scratch overflow");
+        if (e_over) { snk_ctx_release_block(ctx, scratch); scratch = nullptr; scap = h_cur[0] + 1024; }
+        if (b_over) { snk_ctx_release_block(ctx, ubk); ubk = nullptr; ubcap = h_cur[2] + 1024; }
     }
     hipLaunchKernelGGL(widen_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, st, out_n, n, n64);
     if ((rc = scan64(ctx, st, n64, pos, n + 1, err, errcap))) return rc;
@@ -606,6 +652,37 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
     out->dict_slots = cap;
     (void)hipEventElapsedTime(&out->dict_ms, e0, e1);
     (void)hipEventElapsedTime(&out->path_ms, e1, e2);
+    if (want_bcs) {
+        // sort the keys, keep the first of every run, count per unitig: sorted distinct barcodes per unitig
+        const uint64_t nkeys = n + h_cur[2];
+        unsigned long long* ks;
+        uint64_t *flag, *upos, *per_u, *uoff_out;
+        uint32_t* bcs = nullptr;
+        if ((rc = dev(ctx, nkeys + 1, &ks, err, errcap)) || (rc = dev(ctx, nkeys + 2, &flag, err, errcap)) || (rc = dev(ctx, nkeys + 2, &upos, err, errcap)) ||
+            (rc = dev(ctx, U + 2, &per_u, err, errcap)) || (rc = dev(ctx, U + 2, &uoff_out, err, errcap)))
+            return rc;
+        uint64_t n_unique = 0;
+        if (nkeys) {
+            size_t tb = 0;
+            SNK_HIP_TRY(rocprim::radix_sort_keys((void*)nullptr, tb, ubk, ks, (size_t)nkeys, 0u, 64u, st));
+            uint8_t* tmp;
+            if ((rc = dev(ctx, tb, &tmp, err, errcap))) return rc;
+            SNK_HIP_TRY(rocprim::radix_sort_keys(tmp, tb, ubk, ks, (size_t)nkeys, 0u, 64u, st));
+            hipLaunchKernelGGL(ubc_flag_kernel, dim3((unsigned)((nkeys + 256) / 256)), dim3(256), 0, st, ks, nkeys, flag);
+            if ((rc = scan64(ctx, st, flag, upos, nkeys + 1, err, errcap))) return rc;
+            SNK_HIP_TRY(hipMemcpyAsync(&n_unique, upos + nkeys, 8, hipMemcpyDeviceToHost, st));
+            SNK_HIP_TRY(hipStreamSynchronize(st));
+        }
+        if ((rc = dev(ctx, n_unique + 1, &bcs, err, errcap))) return rc;
+        SNK_HIP_TRY(hipMemsetAsync(per_u, 0, (U + 2) * 8, st));
+        if (nkeys) hipLaunchKernelGGL(ubc_scatter_kernel, dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, st, ks, flag, upos, nkeys, bcs, per_u);
+        if ((rc = scan64(ctx, st, per_u, uoff_out, U + 1, err, errcap))) return rc;
+        SNK_HIP_TRY(hipGetLastError());
+        SNK_HIP_TRY(hipStreamSynchronize(st));
+        out->unitig_bc_off = uoff_out;
+        out->unitig_bcs = bcs;
+        out->n_unitig_bcs = n_unique;
+    }
     return SNK_OK;
 }
 
@@ -613,6 +690,11 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
 
 extern "C" int snk_dev_path_reads(snk_ctx* ctx, uint32_t K, const snk_dev_reads* in, uint64_t n_unitigs, const void* d_unitig_off, const void* d_unitig_bases,
                                   const snk_hbv* h, snk_dev_paths* out, void* stream, char* err, size_t errcap) {
+    return snk_dev_path_reads2(ctx, K, in, n_unitigs, d_unitig_off, d_unitig_bases, h, 0u, out, stream, err, errcap);
+}
+
+extern "C" int snk_dev_path_reads2(snk_ctx* ctx, uint32_t K, const snk_dev_reads* in, uint64_t n_unitigs, const void* d_unitig_off, const void* d_unitig_bases,
+                                   const snk_hbv* h, uint32_t flags, snk_dev_paths* out, void* stream, char* err, size_t errcap) {
     if (!ctx || !in || !h || !out) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_path_reads: NULL argument");
     if (K != 48 && K != 60) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "K=%u is not supported (48 or 60)", K);
     if (in->n_reads && (!in->rows || !in->quals || in->read_len == 0 || in->read_len > 256 || in->row_words * 16 < in->read_len || in->row_words > 16))
@@ -623,7 +705,7 @@ extern "C" int snk_dev_path_reads(snk_ctx* ctx, uint32_t K, const snk_dev_reads*
     SNK_HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     try {
-        if (K == 48) return path_impl<48>(ctx, st, in, n_unitigs, (const uint64_t*)d_unitig_off, (const uint8_t*)d_unitig_bases, h, out, err, errcap);
-        return path_impl<60>(ctx, st, in, n_unitigs, (const uint64_t*)d_unitig_off, (const uint8_t*)d_unitig_bases, h, out, err, errcap);
+        if (K == 48) return path_impl<48>(ctx, st, in, n_unitigs, (const uint64_t*)d_unitig_off, (const uint8_t*)d_unitig_bases, h, flags, out, err, errcap);
+        return path_impl<60>(ctx, st, in, n_unitigs, (const uint64_t*)d_unitig_off, (const uint8_t*)d_unitig_bases, h, flags, out, err, errcap);
     } catch (const std::bad_alloc&) { return snk_fail(SNK_E_NOMEM, err, errcap, "snk_dev_path_reads: host allocation failed"); }
 }

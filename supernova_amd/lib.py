@@ -92,7 +92,7 @@ class SnkHbv(C.Structure):
 class SnkDevPaths(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_edges_total", C.c_uint64), ("offset", C.c_void_p), ("n_edges", C.c_void_p),
                 ("start", C.c_void_p), ("edges", C.c_void_p), ("dict_slots", C.c_uint64), ("dict_ms", C.c_float),
-                ("path_ms", C.c_float)]
+                ("path_ms", C.c_float), ("unitig_bc_off", C.c_void_p), ("unitig_bcs", C.c_void_p), ("n_unitig_bcs", C.c_uint64)]
 
 
 class SnkDevDups(C.Structure):
@@ -168,6 +168,7 @@ def _declare(lib: C.CDLL) -> None:
         "snk_dev_hbv": (C.c_int, [vp, u32, u64, vp, vp, P(SnkHbv), P(C.c_float), vp, cp, sz]),
         "snk_hbv_free": (None, [P(SnkHbv)]),
         "snk_dev_path_reads": (C.c_int, [vp, u32, P(SnkDevReads), u64, vp, vp, P(SnkHbv), P(SnkDevPaths), vp, cp, sz]),
+        "snk_dev_path_reads2": (C.c_int, [vp, u32, P(SnkDevReads), u64, vp, vp, P(SnkHbv), u32, P(SnkDevPaths), vp, cp, sz]),
         "snk_dev_mark_dups": (C.c_int, [vp, P(SnkDevReads), P(SnkDevPaths), P(SnkDevDups), vp, cp, sz]),
         "snk_hbv_involution": (C.c_int, [P(SnkHbv), u64, vp, cp, sz]),
         "snk_write_hbv": (C.c_int, [cp, cp, u32, u64, vp, vp, P(SnkHbv), cp, sz]),

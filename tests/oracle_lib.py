@@ -228,3 +228,33 @@ def mark_dups(codes: np.ndarray, quals: np.ndarray, lens, path_off, path_n, path
     if rc != 0:
         raise RuntimeError(f"sno_mark_dups failed {rc}")
     return dup, art, float(rate.value), int(nd.value), int(ni.value)
+
+
+def unitig_barcodes(codes: np.ndarray, lens, bc, unitigs: list[str], K=48):
+    """The rest of f4, restated in plain Python (PARITY UNPINNED: the reference side is Rust -- tada's MAIN_ASM_SN,
+    lib/tada/src/cmd_main_asm.rs:91-151 with barcodes_for_sedge, debruijn.rs:115-131 -- which cannot be built here): per unitig
+    the sorted distinct barcodes > 0 of the reads that have at least one k-mer of the unitig (either strand).  unitigs: strings,
+    the numbering the result refers to.  Returns a list of sorted lists."""
+    comp = str.maketrans("ACGT", "TGCA")
+    where = {}
+    for u, sq in enumerate(unitigs):
+        for i in range(len(sq) - K + 1):
+            k = sq[i:i + K]
+            r = k.translate(comp)[::-1]
+            where[k if k <= r else r] = u
+    n = codes.shape[0]
+    lens = np.broadcast_to(np.asarray(lens), (n,))
+    asc = np.frombuffer(b"ACGT", dtype=np.uint8)[codes]
+    out = [set() for _ in unitigs]
+    for r in range(n):
+        b = int(bc[r])
+        if b <= 0:
+            continue
+        sq = asc[r, :int(lens[r])].tobytes().decode()
+        for i in range(len(sq) - K + 1):
+            k = sq[i:i + K]
+            rk = k.translate(comp)[::-1]
+            u = where.get(k if k <= rk else rk)
+            if u is not None:
+                out[u].add(b)
+    return [sorted(x) for x in out]

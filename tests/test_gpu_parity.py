@@ -633,6 +633,29 @@ def test_mark_dups_match_reference(engine, graph_stage, name):
     assert float(f"{100.0 * d['n_art_pairs'] / len(o_dup):.2g}") == float(f"{c.exp_art_perc:.2g}")
 
 
+@pytest.mark.parametrize("name", ["synth_2k_err", "adversarial", "synth_4k_dups"])
+def test_unitig_barcode_lists(engine, graph_stage, name):
+    """The rest of f4: per-unitig barcode lists out of the pather's exact-match parts, against the plain-Python restatement of
+    tada's edge -> barcode sets (every k-mer of every barcoded read looked up).  Parity unpinned: the Rust reference cannot be
+    built here, the restatement follows lib/tada/src/cmd_main_asm.rs:91-151 / debruijn.rs:115-131."""
+    if graph_stage == "global":
+        pytest.skip("one graph stage is enough")
+    c = goldens.load(name)
+    rows, quals, bc, lens = _to_dev(c)
+    res = engine.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, ign_bc_below=c.ign_bc_below)
+    uoff, ubases = res.unitig_arrays()
+    asc = np.frombuffer(b"ACGT", dtype=np.uint8)[ubases].tobytes().decode()
+    us = [asc[int(uoff[i]):int(uoff[i + 1])] for i in range(res.n_unitigs)]
+    off, ne, edges, info = res.path_reads(rows, c.read_len, quals, lens=lens, bc=bc, unitig_bcs=True)
+    assert np.array_equal(ne.astype(np.int64), c.exp_path_n) and np.array_equal(edges, c.exp_path_edges)      # the paths are untouched by it
+    boff, bcs = info["unitig_bcs"]
+    exp = oracle_lib.unitig_barcodes(c.codes, c.lens, c.bc, us, K=48)
+    assert len(boff) == len(us) + 1 and int(boff[-1]) == len(bcs) == sum(len(x) for x in exp)
+    for u in range(len(us)):
+        assert bcs[int(boff[u]):int(boff[u + 1])].tolist() == exp[u], u
+    assert len(bcs) > 0
+
+
 @pytest.mark.parametrize("min_bc", [3, 5])
 def test_minbc_above_two_synth(engine, graph_stage, min_bc):
     """General minBC on a seeded workload with many barcodes per locus (40 barcodes over 60 k reads: every locus sees several),
