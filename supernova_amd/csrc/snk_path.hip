@@ -23,6 +23,7 @@
 #include <vector>
 
 #include <rocprim/rocprim.hpp>
+#include "snk_stages.h"
 
 #include "snk_ctx.h"
 #include "snk_common.h"
@@ -32,6 +33,11 @@ namespace {
 
 constexpr int PCAP = 112;      // path parts per read (a 150-base read has at most 103 k-mers)
 constexpr int PMAX = 64;       // edges per read path
+// The parts of sixteen reads sit in LDS.  At full capacity that is 29 KB per workgroup and four workgroups per CU; a read of a
+// deep data set has one to three parts, so the kernel runs with room for PCAP1 parts / PMAX1 edges (8 KB, occupancy limited
+// by registers) and the few reads that need more are listed and redone by the full-capacity variant.
+constexpr int PCAP1 = 20;
+constexpr int PMAX1 = 16;
 
 struct path_graph {            // device arrays
     const uint64_t* uoff;      // [U+1] unitig offsets into ubases (device order)
@@ -164,7 +170,7 @@ __device__ uint32_t score_overlap(const path_graph& G, const uint32_t* row, cons
 }
 // attemptLeftwardExtension :123-239 / attemptRightwardExtension :242-358
 template <int K>
-__device__ bool extend_once(const path_graph& G, int32_t* path, int* np, int32_t* offset, const uint32_t* row, const uint8_t* quals, uint32_t n, bool left) {
+__device__ bool extend_once(const path_graph& G, int32_t* path, int* np, int pmax, int32_t* offset, const uint32_t* row, const uint8_t* quals, uint32_t n, bool left) {
     if (!*np) return false;
     uint64_t last_gap;
     if (left) {
@@ -206,7 +212,7 @@ __device__ bool extend_once(const path_graph& G, int32_t* path, int* np, int32_t
         }
     }
     if (least_edge == -1 || (uint64_t)least > last_gap * 10) return false;
-    if (*np >= PMAX) { *offset = 0x7FFFFFFF; return false; }      // marks the path as too long (reported, never truncated silently)
+    if (*np >= pmax) { *offset = 0x7FFFFFFF; return false; }      // marks the path as too long (reported, never truncated silently)
     if (left) {
         for (int i = *np; i > 0; --i) path[i] = path[i - 1];
         path[0] = least_edge;
@@ -218,7 +224,7 @@ __device__ bool extend_once(const path_graph& G, int32_t* path, int* np, int32_t
 
 // algorithmTwo after Pather::path: m parts in LDS -> path[np], offset
 template <int K>
-__device__ void finish_path(const path_graph& G, ppart* parts, int m, const uint32_t* row, const uint8_t* quals, uint32_t n, int32_t* path, int* np_out,
+__device__ void finish_path(const path_graph& G, ppart* parts, int m, const uint32_t* row, const uint8_t* quals, uint32_t n, int32_t* path, int pmax, int* np_out,
                             int32_t* off_out) {
     // seeds on hanging edges become gaps, adjacent gaps merge (:1235-1262) -- in place: the write index never passes the read index
     int m2 = 0;
@@ -263,15 +269,15 @@ __device__ void finish_path(const path_graph& G, ppart* parts, int m, const uint
     for (int i = 0; i < m; ++i) {
         if (p_gap(parts[i])) continue;
         if (last >= 0 && p_same_edge(parts[last], parts[i])) continue;
-        if (np < PMAX) path[np++] = part_edge(G, parts[i]); else too_long = true;
+        if (np < pmax) path[np++] = part_edge(G, parts[i]); else too_long = true;
         last = i;
     }
     if (np) offset = !p_gap(parts[0]) ? (int32_t)p_off(parts[0]) : (int32_t)p_off(parts[1]) - (int32_t)parts[0].len;
     // adjacent edges must share a vertex (:1316-1323)
     for (int i = 0; i + 1 < np; ++i) if (G.vright[path[i]] != G.vleft[path[i + 1]]) { np = i + 1; break; }
     // ExtendReadPath::attemptLeftRightExtension :108-119
-    while (extend_once<K>(G, path, &np, &offset, row, quals, n, true)) {}
-    while (extend_once<K>(G, path, &np, &offset, row, quals, n, false)) {}
+    while (extend_once<K>(G, path, &np, pmax, &offset, row, quals, n, true)) {}
+    while (extend_once<K>(G, path, &np, pmax, &offset, row, quals, n, false)) {}
     *np_out = (too_long || offset == 0x7FFFFFFF) ? -1 : np;
     *off_out = offset;
 }
@@ -287,11 +293,14 @@ struct path_args {
     int32_t* out_e0;                  // [n] first edge of the path (-1: none)
     unsigned long long* out_start;    // [n] position of the read's FURTHER edges in the scratch list
     int32_t* scratch;                 // second and later edges in completion order
-    unsigned long long* cursor;       // [0] edges reserved, [1] error flags, [2] (unitig, barcode) keys reserved
+    unsigned long long* cursor;       // [0] edges reserved, [1] error flags, [2] (unitig, barcode) keys reserved, [3] reads to redo
     uint64_t scratch_cap;
     // per-unitig barcode lists (the rest of SURVEY f4; tada's edge -> barcode sets, lib/tada/src/cmd_main_asm.rs:91-151,
     // debruijn.rs:115-131): a barcoded read contributes its barcode to every unitig one of its k-mers lies on -- exactly the
     // unitigs of its non-gap path parts, since Pather::path looks every k-mer up that no exact-match run covers
+    uint32_t* redo;                   // reads that did not fit the small capacities (first pass: written through cursor[3]; second: read)
+    uint64_t redo_cap, n_redo;
+    uint32_t force_redo;              // SNK_PATH_REDO_ALL=1 (tests): the first pass hands every read to the second
     const int32_t* bc;                // raw barcode ids, or NULL: no lists
     unsigned long long* ub_first;     // [n] unitig << 32 | barcode of the read's first such unitig (~0: none)
     unsigned long long* ub_more;      // further ones, through cursor[2]
@@ -323,11 +332,14 @@ __device__ __forceinline__ bool dict_find(const path_graph& G, const uint32_t* r
 // Sixteen lanes per read, four reads per wave: the kernel is bound by instruction issue (a read is ~1000 wave-level
 // instructions whatever the number of active lanes), so four reads share every instruction.  A group's control flow is
 // uniform inside the group; the groups of a wave diverge like threads do.
-template <int K>
-__global__ void __launch_bounds__(256, 4) path_kernel(path_args a) {
+#ifndef SNK_PATH_OCC
+#define SNK_PATH_OCC 5
+#endif
+template <int K, int PC, int PM, bool SECOND>
+__global__ void __launch_bounds__(256, SECOND ? 4 : SNK_PATH_OCC) path_kernel(path_args a) {
     __shared__ uint32_t rowL[16][20];
-    __shared__ ppart partsL[16][PCAP];
-    __shared__ int32_t pathL[16][PMAX];
+    __shared__ ppart partsL[16][PC];
+    __shared__ int32_t pathL[16][PM];
     __shared__ int32_t resL[16][4];
     const int lane = threadIdx.x & 63, sub = lane & 15, gsh = lane & 48;       // gsh: first lane of my group
     const int gw = threadIdx.x >> 4;                                           // group inside the workgroup
@@ -335,9 +347,10 @@ __global__ void __launch_bounds__(256, 4) path_kernel(path_args a) {
     uint32_t* row = rowL[gw];
     ppart* parts = partsL[gw];
     const uint64_t ng = (uint64_t)gridDim.x * 16;
-    for (uint64_t r0 = (uint64_t)blockIdx.x * 16; r0 < a.n_reads; r0 += ng) {
-        const uint64_t r = r0 + gw;
-        const bool live = r < a.n_reads;
+    const uint64_t n_items = SECOND ? a.n_redo : a.n_reads;
+    for (uint64_t r0 = (uint64_t)blockIdx.x * 16; r0 < n_items; r0 += ng) {
+        const bool live = r0 + gw < n_items;
+        const uint64_t r = SECOND ? (live ? (uint64_t)a.redo[r0 + gw] : 0ull) : r0 + gw;
         uint32_t n = 0;
         if (live) {
             n = a.lens ? a.lens[r] : a.read_len;
@@ -396,16 +409,16 @@ __global__ void __launch_bounds__(256, 4) path_kernel(path_args a) {
                     len += 128; a0 += 128; b0 += 128;
                 }
                 if (sub == 0) {
-                    if (gap) { if (m < PCAP) parts[m] = make_gap(gap); }
+                    if (gap) { if (m < PC) parts[m] = make_gap(gap); }
                     const int at = m + (gap ? 1 : 0);
-                    if (at < PCAP) { ppart p; p.unitig = u; p.off_rc = off | (rc << 31); p.len = len; p.elen = sz - K + 1; parts[at] = p; }
+                    if (at < PC) { ppart p; p.unitig = u; p.off_rc = off | (rc << 31); p.len = len; p.elen = sz - K + 1; parts[at] = p; }
                 }
                 m += gap ? 2 : 1;
-                if (m > PCAP) { overflow = true; break; }
+                if (m > PC) { overflow = true; break; }
                 gap = 0;
                 i += len;
             }
-            if (gap && !overflow) { if (m < PCAP) { if (sub == 0) parts[m] = make_gap(gap); ++m; } else overflow = true; }
+            if (gap && !overflow) { if (m < PC) { if (sub == 0) parts[m] = make_gap(gap); ++m; } else overflow = true; }
         }
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
@@ -432,8 +445,14 @@ __global__ void __launch_bounds__(256, 4) path_kernel(path_args a) {
         if (live && sub == 0) {
             int np = 0;
             int32_t off = 0;
-            if (!overflow) finish_path<K>(G, parts, m, row, a.quals + r * a.qstride, n, pathL[gw], &np, &off);
+            if (!SECOND && a.force_redo) overflow = true;
+            if (!overflow) finish_path<K>(G, parts, m, row, a.quals + r * a.qstride, n, pathL[gw], PM, &np, &off);
             if (np < 0) { overflow = true; np = 0; off = 0; }
+            if (!SECOND && overflow) {          // not an error yet: the full-capacity pass takes this read
+                const unsigned long long at = atomicAdd(&a.cursor[3], 1ull);
+                if (at < a.redo_cap) a.redo[at] = (uint32_t)r;
+                overflow = false;
+            }
             // a path's first edge travels with the read; only the rest (one read in a thousand has more than one edge on a deep
             // data set) takes a reservation on the shared cursor -- 1e8 atomics on one address were a second of serialisation
             unsigned long long st = 0;
@@ -609,22 +628,41 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
     const bool want_bcs = (flags & SNK_PATH_UNITIG_BCS) && in->bc;
     uint64_t ubcap = want_bcs ? n / 4 + 65536 : 0;    // (unitig, barcode) keys beyond a read's first
     unsigned long long* ubk = nullptr;                // [n + ubcap]: the reads' first keys, then the further ones
-    unsigned long long h_cur[3] = {0, 0, 0};
+    unsigned long long h_cur[4] = {0, 0, 0, 0};
+    uint32_t* redo = nullptr;
+    uint64_t rcap = n / 64 + 65536;
     for (int attempt = 0; attempt < 3; ++attempt) {
         if (!scratch && (rc = dev(ctx, scap, &scratch, err, errcap))) return rc;
         if (want_bcs && !ubk && (rc = dev(ctx, n + ubcap, &ubk, err, errcap))) return rc;
         SNK_HIP_TRY(hipMemsetAsync(cursor, 0, 32, st));
         a.out_off = out_off; a.out_n = out_n; a.out_e0 = out_e0; a.out_start = out_start; a.scratch = scratch; a.cursor = cursor; a.scratch_cap = scap;
         a.bc = want_bcs ? (const int32_t*)in->bc : nullptr; a.ub_first = ubk; a.ub_more = ubk ? ubk + n : nullptr; a.ub_cap = ubcap;
+        if (!redo && (rc = dev(ctx, rcap, &redo, err, errcap))) return rc;
+        a.redo = redo; a.redo_cap = rcap; a.n_redo = 0; a.force_redo = snk_env_u32("SNK_PATH_REDO_ALL", 0);
         if (n) {
             uint64_t grid = (n + 15) / 16;
             const uint64_t gmax = (uint64_t)ctx->n_cu * 64;
             if (grid > gmax) grid = gmax;
-            hipLaunchKernelGGL((path_kernel<K>), dim3((unsigned)grid), dim3(256), 0, st, a);
+            hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, false>), dim3((unsigned)grid), dim3(256), 0, st, a);
         }
         SNK_HIP_TRY(hipGetLastError());
-        SNK_HIP_TRY(hipMemcpyAsync(h_cur, cursor, 24, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(hipMemcpyAsync(h_cur, cursor, 32, hipMemcpyDeviceToHost, st));
         SNK_HIP_TRY(hipStreamSynchronize(st));
+        if (h_cur[3] > rcap) {                       // more reads to redo than the list holds: once more with a longer list
+            if (attempt == 2) return snk_fail(SNK_E_INTERNAL, err, errcap, "snk_dev_path_reads: redo list overflow");
+            snk_ctx_release_block(ctx, redo); redo = nullptr; rcap = h_cur[3] + 1024;
+            continue;
+        }
+        if (h_cur[3]) {                              // the reads with many parts / edges, at full capacity
+            a.n_redo = h_cur[3];
+            uint64_t grid = (a.n_redo + 15) / 16;
+            const uint64_t gmax = (uint64_t)ctx->n_cu * 64;
+            if (grid > gmax) grid = gmax;
+            hipLaunchKernelGGL((path_kernel<K, PCAP, PMAX, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
+            SNK_HIP_TRY(hipGetLastError());
+            SNK_HIP_TRY(hipMemcpyAsync(h_cur, cursor, 32, hipMemcpyDeviceToHost, st));
+            SNK_HIP_TRY(hipStreamSynchronize(st));
+        }
         if (h_cur[1] & 1ull) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_dev_path_reads: a read has more than %d path parts or %d edges", PCAP, PMAX);
         const bool e_over = (h_cur[1] & 2ull) != 0, b_over = want_bcs && h_cur[2] > ubcap;
         if (!e_over && !b_over) break;

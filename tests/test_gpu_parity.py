@@ -633,6 +633,20 @@ def test_mark_dups_match_reference(engine, graph_stage, name):
     assert float(f"{100.0 * d['n_art_pairs'] / len(o_dup):.2g}") == float(f"{c.exp_art_perc:.2g}")
 
 
+def test_read_paths_full_capacity_pass(engine, monkeypatch):
+    """The pather keeps room for 20 parts / 16 edges per read in LDS and hands reads that need more to a full-capacity second
+    pass; SNK_PATH_REDO_ALL sends EVERY read through it: same paths, same duplicate flags, same barcode lists."""
+    c = goldens.load("adversarial")
+    rows, quals, bc, lens = _to_dev(c)
+    res = engine.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, ign_bc_below=c.ign_bc_below)
+    off0, ne0, edges0, info0 = res.path_reads(rows, c.read_len, quals, lens=lens, mark_dups=True, bc=bc, unitig_bcs=True)
+    monkeypatch.setenv("SNK_PATH_REDO_ALL", "1")
+    off, ne, edges, info = res.path_reads(rows, c.read_len, quals, lens=lens, mark_dups=True, bc=bc, unitig_bcs=True)
+    assert np.array_equal(ne.astype(np.int64), c.exp_path_n) and np.array_equal(edges, c.exp_path_edges) and np.array_equal(off, c.exp_path_off)
+    assert np.array_equal(info["dups"]["dup"], c.exp_dup)
+    assert np.array_equal(info["unitig_bcs"][0], info0["unitig_bcs"][0]) and np.array_equal(info["unitig_bcs"][1], info0["unitig_bcs"][1])
+
+
 @pytest.mark.parametrize("name", ["synth_2k_err", "adversarial", "synth_4k_dups"])
 def test_unitig_barcode_lists(engine, graph_stage, name):
     """The rest of f4: per-unitig barcode lists out of the pather's exact-match parts, against the plain-Python restatement of
