@@ -10,12 +10,14 @@
 //   == process_kmer_shard_opt, lib/tada/src/utils.rs:322-408 (sort + group_by per shard).
 //
 // The reference materialises one 24-byte record per k-mer instance and comparison-sorts them.  Here
-// the instances never leave the CU: a bucket's supermers (32 B per ~17 k-mers) are streamed from HBM
-// once, every k-mer is rolled in registers and inserted into an open-addressing hash table in LDS
-// (key 96/120 bit, count, barcode state, context byte) with LDS atomics.  A bucket whose distinct
-// k-mers do not fit is re-run split by a second hash (2, 4, ... sub-passes) -- correctness never
-// depends on the bucket sizing.  Barcode state machine (sufficient for minBC <= 2): 0 = none yet,
-// id = exactly one barcode id seen, MULTI = two different ids, IGN = a bc == -1 read contributed.
+// the instances never leave the CU: a bucket's supermers (32 B per ~15 k-mers) come from HBM once, by LDS-DMA and one bucket
+// ahead; identical supermers are folded; every remaining k-mer instance is extracted by its own lane, canonicalised, hashed
+// and inserted into an open-addressing hash table in LDS (key 96/120 bit, count, barcode state, context byte).  A workgroup
+// walks a strided list of buckets and writes the survivors of each behind a cursor in its own output region.  A bucket whose
+// distinct k-mers do not fit is re-run split by a second hash (2, 4, ... passes) -- correctness never depends on the bucket
+// sizing.  Barcode state machine (minBC <= 2): 0 = none yet, id = exactly one barcode id seen, MULTI = two different ids,
+// IGN = a bc == -1 read contributed; minBC 3..8: six more id words per slot.
+// The kernel is bound by VALU issue in its insert phase; DESIGN.md 4 ("round 2") says what was tried around that.
 #include "snk_ctx.h"
 #include "snk_common.h"
 #include "snk_kernels.h"
