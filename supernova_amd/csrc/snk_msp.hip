@@ -36,9 +36,9 @@ template <int M>
 __device__ __forceinline__ uint32_t mmer_key(const uint32_t* rowL, int tid, uint32_t row_words, int p) {
     uint32_t wi = (uint32_t)p >> 4;
     uint32_t w0 = rowL[wi * BD + tid];
-    uint32_t w1 = (wi + 1 < row_words) ? rowL[(wi + 1) * BD + tid] : 0u;
+    uint32_t w1 = rowL[(wi + 1) * BD + tid];                 // (row `row_words` of the staged rows is all zero)
     uint32_t s = 2u * ((uint32_t)p & 15u);
-    uint32_t x = s ? ((w0 << s) | (w1 >> (32u - s))) : w0;   // 16 bases starting at p, MSB first
+    uint32_t x = (uint32_t)(((((uint64_t)w0 << 32) | w1) << s) >> 32);   // 16 bases starting at p, MSB first
     uint32_t rx = snk_rev2_32(~x);                             // reverse complement of those 16 bases
     uint32_t code, rcode;
     if (M == 16) { code = x; rcode = rx; }
@@ -79,9 +79,9 @@ __global__ void __launch_bounds__(BD, K == 48 ? 5 : 4) snk_msp_kernel(snk_msp_ar
     const uint32_t row_words = a.row_words;
     const uint32_t NB = a.NB;
     const uint64_t n_reads = a.n_reads;
-    uint32_t* rowL = smem;                              // [row_words][BD]
+    uint32_t* rowL = smem;                              // [row_words + 1][BD]; the last row is zero: words behind a read's row are read there
     // Only the POSITION of every suffix minimum is kept in LDS (1 byte per entry); the keys live in registers.
-    uint16_t* lst = reinterpret_cast<uint16_t*>(rowL + (size_t)row_words * BD);   // [LCAP][BD] minimiser position << 8 | first k-mer
+    uint16_t* lst = reinterpret_cast<uint16_t*>(rowL + (size_t)(row_words + 1) * BD);   // [LCAP][BD] minimiser position << 8 | first k-mer
     uint8_t* sfxp = reinterpret_cast<uint8_t*>(lst + (size_t)LCAP * BD);  // [W][BD] position of the suffix minimum
     const int tid = threadIdx.x;
     const uint64_t r0 = (uint64_t)blockIdx.x * BD;
@@ -106,6 +106,7 @@ __global__ void __launch_bounds__(BD, K == 48 ? 5 : 4) snk_msp_kernel(snk_msp_ar
             }
         }
     }
+    rowL[row_words * BD + tid] = 0u;
     __syncthreads();
     const uint64_t r = r0 + tid;
     int g = (r < n_reads) ? (int)a.good_len[r] : 0;
@@ -160,14 +161,18 @@ __global__ void __launch_bounds__(BD, K == 48 ? 5 : 4) snk_msp_kernel(snk_msp_ar
                         uint32_t hasR = (en + (uint32_t)K < (uint32_t)g) ? 1u : 0u;
                         uint32_t a0 = s - hasL;
                         uint32_t bits = 2u * (n_kmers + (uint32_t)K - 1u + hasL + hasR);
-                        uint32_t w[8];
+                        // the record's seven base words: eight consecutive row words (behind the row: the zero row), one funnel shift
+                        // and one mask each -- no word-index tests (the first version compiled into seven exec-masked blocks)
+                        uint32_t w[8], rw[8];
+                        const uint32_t wi0 = a0 >> 4, fs = 2u * (a0 & 15u);
+#pragma unroll
+                        for (uint32_t q = 0; q < 8; ++q) rw[q] = rowL[min(wi0 + q, row_words) * BD + tid];
 #pragma unroll
                         for (uint32_t j = 0; j < 7; ++j) {
-                            uint32_t x = row_window(rowL, tid, row_words, a0, j);
-                            uint32_t lo = 32u * j;
-                            if (bits <= lo) x = 0u;
-                            else if (bits - lo < 32u) x &= ~(0xFFFFFFFFu >> (bits - lo));
-                            w[j] = x;
+                            const uint32_t x = (uint32_t)(((((uint64_t)rw[j] << 32) | rw[j + 1]) << fs) >> 32);
+                            int rbits = (int)bits - 32 * (int)j;
+                            rbits = rbits < 0 ? 0 : (rbits > 32 ? 32 : rbits);
+                            w[j] = x & (uint32_t)(0xFFFFFFFF00000000ull >> rbits);     // the top rbits bits
                         }
                         w[6] |= n_kmers | (hasL << 7) | (hasR << 8);
                         w[7] = (uint32_t)mybc;
@@ -315,7 +320,7 @@ __global__ void __launch_bounds__(256) snk_msp_plan_kernel(const uint16_t* __res
 }  // namespace
 
 size_t snk_msp_lds_bytes(uint32_t K, uint32_t M, uint32_t row_words) {
-    return (size_t)row_words * BD * 4 + (size_t)LCAP * BD * 2 + (size_t)(K - M + 1) * BD + 64;
+    return (size_t)(row_words + 1) * BD * 4 + (size_t)LCAP * BD * 2 + (size_t)(K - M + 1) * BD + 64;
 }
 
 template <int K, int M>
