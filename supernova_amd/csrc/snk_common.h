@@ -35,6 +35,34 @@ SNK_HD uint32_t snk_mix32(uint32_t x) {
     return x;
 }
 
+#if defined(__HIPCC__)
+// inclusive prefix sum over the 64 lanes of a wave without LDS traffic (six DPP adds: inside the rows of 16, then across them).
+// Lanes that are switched off contribute nothing and get nothing; the callers run it with the whole wave active.
+__device__ __forceinline__ uint32_t snk_wave_scan_incl(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);      // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);      // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);      // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);      // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
+// Every lane of a wave asks for v slots (0 allowed) behind an LDS counter: exclusive position of the lane.  One LDS atomic per
+// wave -- the compiler's own treatment of a divergent-valued atomicAdd is a scalar loop over the active lanes.
+__device__ __forceinline__ uint32_t snk_wave_alloc(uint32_t* counter, uint32_t v) {
+    const uint32_t incl = snk_wave_scan_incl(v);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    uint32_t base = 0;
+    if ((threadIdx.x & 63) == 63 && total) base = atomicAdd(counter, total);
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, 63);
+    return base + incl - v;
+}
+__device__ __forceinline__ void snk_wave_add(uint32_t* counter, uint32_t v) {
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)snk_wave_scan_incl(v), 63);
+    if ((threadIdx.x & 63) == 63 && total) atomicAdd(counter, total);
+}
+#endif
+
 // ---------------------------------------------------------------- 128-bit k-mer value
 struct snk_kmer {
     uint64_t hi, lo;

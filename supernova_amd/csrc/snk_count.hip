@@ -48,17 +48,6 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 #define PROF(n) do {} while (0)
 #endif
 
-// inclusive prefix sum over the 64 lanes of a wave without LDS traffic (six DPP adds: inside the rows of 16, then across them)
-__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);      // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);      // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);      // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);      // row_shr:8
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
-    return v;
-}
-
 // high word of (hi:lo) << sh, sh in 0..31
 __device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t sh) {
 #ifdef SNK_FUNNEL_ALIGNBIT
@@ -320,7 +309,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                 // so they are ordered alike)
                 const uint32_t sv = nkm | (nkm ? 0x10000u : 0u);
                 uint32_t incl = sv;
-                incl = wave_scan_incl(incl);
+                incl = snk_wave_scan_incl(incl);
                 uint32_t woff = 0;
                 if (lane == 63 && incl) woff = atomicAdd(&ctl[10 + bq], incl);
                 woff = __builtin_amdgcn_readlane(woff, 63);

@@ -203,8 +203,8 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
         if (tid == 0) mcnt = 0;
         resL[tid] = 0;
         __syncthreads();
+        uint32_t pos = snk_wave_alloc(&mcnt, (uint32_t)__popc(miss));
         if (miss) {
-            uint32_t pos = atomicAdd(&mcnt, (uint32_t)__popc(miss));
             for (uint32_t bit = 0; bit < 8; ++bit)
                 if (miss & (1u << bit)) mlist[pos++] = (uint16_t)((tid << 3) | bit);
         }
@@ -281,7 +281,7 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
         nbr_out[2 * gi + 1] = nb1;
         if (pm) ++mybnd;
     }
-    if (mybnd) atomicAdd(&bcnt, mybnd);
+    snk_wave_add(&bcnt, mybnd);
     __syncthreads();
     if (tid == 0) nbnd[c] = bcnt;
 }
@@ -505,7 +505,7 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
         else wr[s] = (wrec_t)(out ^ 1u) | ((wrec_t)1 << FB) | ((wrec_t)(out ^ 1u) << (2 * FB));
     }
     if (!EMIT) {      // sizing pass: a chunk has (terminal states / 2) open paths
-        if (myterm) atomicAdd(&fcnt, myterm);
+        snk_wave_add(&fcnt, myterm);
         __syncthreads();
         if (tid == 0) nfrag[c] = fcnt >> 1;
         return;
