@@ -38,6 +38,8 @@ constexpr int PMAX = 64;       // edges per read path
 // by registers) and the few reads that need more are listed and redone by the full-capacity variant.
 constexpr int PCAP1 = 20;
 constexpr int PMAX1 = 16;
+constexpr int GPARTS = 4;      // parts per read that travel to the finishing kernel
+constexpr int PMT = 8;         // edges per read there
 
 struct path_graph {            // device arrays
     const uint64_t* uoff;      // [U+1] unitig offsets into ubases (device order)
@@ -301,6 +303,10 @@ struct path_args {
     uint32_t* redo;                   // reads that did not fit the small capacities (first pass: written through cursor[3]; second: read)
     uint64_t redo_cap, n_redo;
     uint32_t force_redo;              // SNK_PATH_REDO_ALL=1 (tests): the first pass hands every read to the second
+    // split first pass: the group kernel stops after Pather::path and leaves the parts (at most GPARTS per read; more: redo list)
+    // in HBM; a one-thread-per-read kernel does the sequential rest (algorithmTwo, extension) at full lane occupancy
+    ppart* gparts;                    // [n][GPARTS]
+    uint8_t* gm;                      // [n] parts of the read, 0xFF: handed to the redo list
     const int32_t* bc;                // raw barcode ids, or NULL: no lists
     unsigned long long* ub_first;     // [n] unitig << 32 | barcode of the read's first such unitig (~0: none)
     unsigned long long* ub_more;      // further ones, through cursor[2]
@@ -442,6 +448,22 @@ __global__ void __launch_bounds__(256, SECOND ? 4 : SNK_PATH_OCC) path_kernel(pa
             }
             a.ub_first[r] = first;
         }
+        if (!SECOND && a.gparts) {
+            // split first pass: hand the parts over (or the read to the redo list) and go on to the next reads
+            if (live && sub == 0) {
+                if (a.force_redo || overflow || m > GPARTS) {
+                    const unsigned long long at = atomicAdd(&a.cursor[3], 1ull);
+                    if (at < a.redo_cap) a.redo[at] = (uint32_t)r;
+                    a.gm[r] = 0xFF;
+                    a.out_off[r] = 0; a.out_n[r] = 0; a.out_e0[r] = -1; a.out_start[r] = 0;
+                } else {
+                    for (int p = 0; p < m; ++p) a.gparts[r * GPARTS + p] = parts[p];
+                    a.gm[r] = (uint8_t)m;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
         if (live && sub == 0) {
             int np = 0;
             int32_t off = 0;
@@ -476,6 +498,42 @@ __global__ void __launch_bounds__(256, SECOND ? 4 : SNK_PATH_OCC) path_kernel(pa
         __builtin_amdgcn_wave_barrier();
     }
 }
+// the sequential rest of a read's pathing (algorithmTwo after Pather::path, the extension), one thread per read
+template <int K>
+__global__ void __launch_bounds__(256) path_finish_kernel(path_args a) {
+    const path_graph& G = a.G;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < a.n_reads; r += stride) {
+        const int m = a.gm[r];
+        if (m == 0xFF) continue;
+        uint32_t n = a.lens ? a.lens[r] : a.read_len;
+        if (n > a.read_len) n = a.read_len;
+        uint32_t row[20];
+#pragma unroll
+        for (uint32_t q = 0; q < 20; ++q) row[q] = q < a.row_words ? a.rows[r * a.row_words + q] : 0u;
+        ppart parts[GPARTS];
+#pragma unroll
+        for (int p = 0; p < GPARTS; ++p) if (p < m) parts[p] = a.gparts[r * GPARTS + p];
+        int32_t path[PMT];
+        int np = 0;
+        int32_t off = 0;
+        finish_path<K>(G, parts, m, row, a.quals + r * a.qstride, n, path, PMT, &np, &off);
+        if (np < 0) {                               // more edges than fit here: the full-capacity pass takes the read
+            const unsigned long long at = atomicAdd(&a.cursor[3], 1ull);
+            if (at < a.redo_cap) a.redo[at] = (uint32_t)r;
+            np = 0; off = 0;
+        }
+        unsigned long long st = 0;
+        if (np > 1) st = atomicAdd(&a.cursor[0], (unsigned long long)(np - 1));
+        if (np > 1 && st + (unsigned long long)(np - 1) > a.scratch_cap) { atomicOr(&a.cursor[1], 2ull); np = 0; }
+        a.out_off[r] = off;
+        a.out_n[r] = (uint32_t)np;
+        a.out_e0[r] = np ? path[0] : -1;
+        a.out_start[r] = st;
+        for (int q = 1; q < np; ++q) a.scratch[st + q - 1] = path[q];
+    }
+}
+
 __global__ void __launch_bounds__(256) path_gather_kernel(const uint32_t* __restrict__ n, const int32_t* __restrict__ e0, const unsigned long long* __restrict__ start,
                                                           const uint64_t* __restrict__ pos, const int32_t* __restrict__ scratch, uint64_t n_reads,
                                                           int32_t* __restrict__ out) {
@@ -629,6 +687,11 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
     uint64_t ubcap = want_bcs ? n / 4 + 65536 : 0;    // (unitig, barcode) keys beyond a read's first
     unsigned long long* ubk = nullptr;                // [n + ubcap]: the reads' first keys, then the further ones
     unsigned long long h_cur[4] = {0, 0, 0, 0};
+    ppart* gparts = nullptr;
+    uint8_t* gm = nullptr;
+    if (!snk_env_u32("SNK_PATH_FUSED", 0)) {          // default: split first pass (SNK_PATH_FUSED=1: the group kernel does it all)
+        if ((rc = dev(ctx, n * GPARTS + 1, &gparts, err, errcap)) || (rc = dev(ctx, n + 1, &gm, err, errcap))) return rc;
+    }
     uint32_t* redo = nullptr;
     uint64_t rcap = n / 64 + 65536;
     for (int attempt = 0; attempt < 3; ++attempt) {
@@ -639,11 +702,17 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
         a.bc = want_bcs ? (const int32_t*)in->bc : nullptr; a.ub_first = ubk; a.ub_more = ubk ? ubk + n : nullptr; a.ub_cap = ubcap;
         if (!redo && (rc = dev(ctx, rcap, &redo, err, errcap))) return rc;
         a.redo = redo; a.redo_cap = rcap; a.n_redo = 0; a.force_redo = snk_env_u32("SNK_PATH_REDO_ALL", 0);
+        a.gparts = gparts; a.gm = gm;
         if (n) {
             uint64_t grid = (n + 15) / 16;
             const uint64_t gmax = (uint64_t)ctx->n_cu * 64;
             if (grid > gmax) grid = gmax;
             hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, false>), dim3((unsigned)grid), dim3(256), 0, st, a);
+            if (gparts) {
+                uint64_t g2 = (n + 255) / 256;
+                if (g2 > gmax) g2 = gmax;
+                hipLaunchKernelGGL((path_finish_kernel<K>), dim3((unsigned)g2), dim3(256), 0, st, a);
+            }
         }
         SNK_HIP_TRY(hipGetLastError());
         SNK_HIP_TRY(hipMemcpyAsync(h_cur, cursor, 32, hipMemcpyDeviceToHost, st));
