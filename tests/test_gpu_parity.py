@@ -645,6 +645,12 @@ def test_read_paths_full_capacity_pass(engine, monkeypatch):
     assert np.array_equal(ne.astype(np.int64), c.exp_path_n) and np.array_equal(edges, c.exp_path_edges) and np.array_equal(off, c.exp_path_off)
     assert np.array_equal(info["dups"]["dup"], c.exp_dup)
     assert np.array_equal(info["unitig_bcs"][0], info0["unitig_bcs"][0]) and np.array_equal(info["unitig_bcs"][1], info0["unitig_bcs"][1])
+    # and the group kernel doing the sequential tail itself (SNK_PATH_FUSED) instead of the one-thread-per-read finishing kernel
+    monkeypatch.delenv("SNK_PATH_REDO_ALL")
+    monkeypatch.setenv("SNK_PATH_FUSED", "1")
+    off, ne, edges, info = res.path_reads(rows, c.read_len, quals, lens=lens, mark_dups=True, bc=bc, unitig_bcs=True)
+    assert np.array_equal(ne.astype(np.int64), c.exp_path_n) and np.array_equal(edges, c.exp_path_edges) and np.array_equal(off, c.exp_path_off)
+    assert np.array_equal(info["dups"]["dup"], c.exp_dup)
 
 
 @pytest.mark.parametrize("name", ["synth_2k_err", "adversarial", "synth_4k_dups"])
