@@ -152,3 +152,36 @@ def test_mark_dups_matches_reference(name):
     assert _art_matches_log(int(art.sum()), len(dup), c.exp_art_perc), (int(art.sum()), len(dup), c.exp_art_perc)
     if name == "synth_4k_dups":
         assert dup.sum() > 300 and art.sum() > 100 and 0.0 < rate < 1.0
+
+
+def test_mark_dups_hand_case():
+    """MarkDups by hand (10X/SecretOps.cc:413-593): four pairs of 10-base reads.  Reads 0 and 2 sit on (edge 5, offset 3) and
+    their mates start with the same five bases: one duplicate group; read 2's pair has the larger quality sum and survives, so
+    pair 0 is flagged; their barcodes differ (inter-barcode rate 1).  Read 4 shares the placement but its mate starts
+    differently: no duplicate.  Reads 6 and 7... are not placed.  Then the same with equal qualities: a tie, the earliest read
+    survives (pair 1 flagged) and pair 1 is an artifactual duplicate (identical bases and qualities)."""
+    n, L = 8, 10
+    codes = np.zeros((n, L), dtype=np.uint8)
+    codes[1] = [0, 1, 2, 3, 0, 1, 1, 1, 1, 1]
+    codes[3] = [0, 1, 2, 3, 0, 2, 2, 2, 2, 2]            # same first five bases as read 1
+    codes[5] = [3, 1, 2, 3, 0, 1, 1, 1, 1, 1]            # another head
+    quals = np.full((n, L), 5, dtype=np.uint8)
+    quals[2] = 7                                          # pair 1: sum 120 against pair 0's 100
+    path_off = np.array([3, 0, 3, 0, 3, 0, 0, 0], dtype=np.int32)
+    path_n = np.array([1, 0, 1, 0, 1, 0, 0, 0], dtype=np.int32)
+    path_edges = np.array([5, 5, 5], dtype=np.int32)
+    bc = np.array([7, 7, 9, 9, 7, 7, 0, 0], dtype=np.int32)
+    dup, art, rate, nd, ni = oracle_lib.mark_dups(codes, quals, L, path_off, path_n, path_edges, bc=bc)
+    assert dup.tolist() == [1, 0, 0, 0] and art.tolist() == [0, 0, 0, 0] and (rate, nd, ni) == (1.0, 1, 1)
+    quals[2] = 5                                          # a tie: the earliest read wins, the later identical one is an artifact
+    bc[2:4] = 7
+    dup, art, rate, nd, ni = oracle_lib.mark_dups(codes, quals, L, path_off, path_n, path_edges, bc=bc)
+    assert dup.tolist() == [0, 1, 0, 0] and art.tolist() == [0, 1, 0, 0] and (rate, nd, ni) == (0.0, 1, 0)
+    # barcode 0 adopts the next member's barcode without a comparison (:463-466)
+    bc[0:2] = 0
+    bc[2:4] = 9
+    _, _, rate, _, _ = oracle_lib.mark_dups(codes, quals, L, path_off, path_n, path_edges, bc=bc)
+    assert rate == 0.0
+    # no barcode vector at all, and nothing placed
+    dup, art, rate, nd, ni = oracle_lib.mark_dups(codes, quals, L, path_off, np.zeros(n, np.int32), np.zeros(0, np.int32))
+    assert dup.sum() == 0 and art.sum() == 0 and (rate, nd, ni) == (0.0, 0, 0)
