@@ -153,7 +153,7 @@ def main():
         sh = ShardedEngine(eng, dist)
 
         def step():
-            return sh.count_graph(rows, sp.read_len, quals=quals, bc=bc, params=params, read_index_base=rank * per_gpu)
+            return sh.count_graph(rows, sp.read_len, quals=quals, bc=bc, params=params, read_index_base=rank * per_gpu, total_reads=total_reads)
 
     def barrier():
         if use_dist:
@@ -170,7 +170,7 @@ def main():
         per_v = 2_000_000
         spv = synth.synth_params(per_v * world, seed=0x5EED0F00 + world, error_free=args.error_free)
         rv, qv, bv = eng.synth(spv, first=rank * per_v, n=per_v)
-        resv = sh.count_graph(rv, spv.read_len, quals=qv, bc=bv, params=params, read_index_base=rank * per_v)
+        resv = sh.count_graph(rv, spv.read_len, quals=qv, bc=bv, params=params, read_index_base=rank * per_v, total_reads=per_v * world)
         kv = resv.keys().astype(np.uint64)
         mixed = (kv[:, 0] * np.uint64(0x9E3779B97F4A7C15) + kv[:, 1] * np.uint64(0xC2B2AE3D27D4EB4F) + kv[:, 2] * np.uint64(0x165667B19E3779F9)
                  + resv.counts().astype(np.uint64) * np.uint64(0x27D4EB2F165667C5) + resv.ctx().astype(np.uint64) * np.uint64(0x85EBCA77C2B2AE63))
@@ -263,18 +263,13 @@ def main():
         }
         out["config"]["path"] = "grouped-replicas" if args.grouped else ("sharded" if use_dist else "single")
         if use_dist and not args.grouped:
-            # the multi-GPU breakdown of rank 0's last step: sections of the join ("(x)" = an exchange, incl. the wait for the
-            # slowest peer), bytes this rank put on the links per exchange, ranks of the RCCL group
-            rec_b = int(res.n_supermers) * 32 * (world - 1) // world
+            # the multi-GPU breakdown of rank 0's last step: sections of the join, bytes this rank put on the links per exchange,
+            # host read-backs of the step, ranks of the RCCL group
             out["config"]["multi_gpu"] = {
-                "rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "join": sh.join,
-                "join_ranking": getattr(res, "join_ranking", None),
-                "join_ms_rank0": {k: round(v, 3) for k, v in getattr(res, "join_ms", {}).items()},
-                "exchange_bytes_rank0": {"supermer_records": rec_b, "prune_queries": int(res.n_queries) * 28,
-                                         "link_queries": int(getattr(res, "n_link_queries", 0)) * 28,
-                                         "link_structure_allgather": int(getattr(res, "exchange_bytes_join", (0, 0))[0]),
-                                         "ranking": list(getattr(res, "exchange_bytes_rank", (0, 0))),
-                                         "fragments_to_owners": int(getattr(res, "exchange_bytes_join", (0, 0))[1])},
+                "rccl_ranks": dist.get_world_size(), "transport": sh.kind, "host": "snk_shard_step (C++ behind the C ABI)",
+                "host_syncs": int(res.host_syncs), "join": "owner", "join_ranking": res.join_ranking,
+                "join_ms_rank0": {k: round(v, 3) for k, v in res.join_ms.items()},
+                "exchange_bytes_rank0": res.exchange_bytes,
                 "fragments_rank0": int(res.n_frags), "unitigs_written_by_rank0": int(res.n_unitigs)}
         if verified is not None:
             out["config"]["sharded_self_check"] = "passed" if verified else "FAILED"

@@ -274,6 +274,62 @@ int snk_dev_pack2(snk_ctx* ctx, const void* d_bases, uint64_t n_bases, void* d_p
 int snk_dev_unpack2(snk_ctx* ctx, const void* d_packed, uint64_t n_bases, void* d_bases, void* stream);
 
 
+/* ---- the sharded step behind ONE call (round 3) ------------------------------------------------------------------------
+ * A communicator carries the exchanges; the step itself -- partition, histogram and record exchange (in bucket ranges,
+ * overlapped with the count), count, cross-rank prune, fragments, fragment links, owner-side join -- runs inside
+ * snk_shard_step, so a C++ host (supernova_amd/csrc/host/snk_asm_sn.cc) runs the N-GPU job without any scripting layer.
+ * Replaces tada's MSP -> SHARD_ASM -> MAIN_ASM_SN with its shard files (lib/tada/src/cmd_msp.rs:38-80, cmd_shard_asm.rs:37-94,
+ * cmd_main_asm.rs:25-89; lib/tada/external/rust-shardio/src/shard.rs:184-211,488-493) and MapReduceEngine.h:362-385.
+ *   snk_comm_unique_id      rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the other ranks (file, socket, ...)
+ *   snk_comm_create_rccl    every rank: ncclCommInitRank on the context's device; librccl is bound at run time
+ *                           (snk_comm_set_rccl_path / $SNK_RCCL_LIB / librccl.so.1 / $ROCM_PATH/lib)
+ *   snk_comm_from_nccl      adopt the caller's ncclComm_t (not destroyed by snk_comm_destroy)
+ *   snk_comm_create_local   `world` in-process ranks on ONE device (tests): out[r] is rank r's handle, every rank runs on its
+ *                           own host thread with its own context; the wire is a device copy */
+typedef struct snk_comm snk_comm;
+int snk_comm_set_rccl_path(const char* path);
+int snk_comm_unique_id(void* id128, char* err, size_t errcap);
+int snk_comm_create_rccl(snk_ctx* ctx, const void* id128, uint32_t rank, uint32_t world, snk_comm** out, char* err, size_t errcap);
+int snk_comm_from_nccl(snk_ctx* ctx, void* nccl_comm, uint32_t rank, uint32_t world, snk_comm** out, char* err, size_t errcap);
+int snk_comm_create_local(uint32_t world, snk_comm** out /* [world] */, char* err, size_t errcap);
+void snk_comm_destroy(snk_comm* c);
+void snk_comm_abort(snk_comm* c);          /* in-process ranks: release the others after a failure outside snk_shard_step */
+uint32_t snk_comm_rank(const snk_comm* c);
+uint32_t snk_comm_world(const snk_comm* c);
+const char* snk_comm_kind(const snk_comm* c);   /* "rccl" | "local" */
+
+/* Device pointers owned by the context, valid until its next top-level call.  The table share is in bucket order; the
+ * unitigs are the ones whose head fragment this rank owns, ordered by their first K bases (the union over the ranks is the
+ * job's unitig set; snk_shard_gather_unitigs brings it to one rank in BVComp order). */
+typedef struct snk_shard_result {
+    uint32_t rank, world;
+    uint64_t n_reads, n_instances, n_supermers, n_buckets_total;
+    uint64_t n_kmers;
+    const void* keys;
+    const void* counts;
+    const void* ctx;
+    const void* spectrum;
+    uint32_t spectrum_bins, n_circles;
+    uint64_t n_unitigs, unitig_total_bases;
+    const void* unitig_off;          /* u64[n_unitigs+1] */
+    const void* unitig_bases;
+    const void* unitig_circular;
+    uint64_t n_frags, n_frags_total, n_queries, n_link_queries;
+    uint64_t exchanged_bytes[8];     /* sent to OTHER ranks: records, prune queries+answers, link queries+answers, link structure,
+                                        splitters, ranks, fragments, everything the transport carried */
+    uint32_t host_syncs;             /* host waits for the stream during the step (the read-backs of sizes) */
+    uint32_t ranking;                /* 1 = the list ranking ran partitioned over the ranks, 0 = replicated */
+    uint32_t buckets_split, max_slots_used;
+    float phase_ms[8];               /* trim+partition, histograms+compaction, exchange issue, count, prune, fragments, join, total */
+    float join_ms[8];                /* links, link structure, rank+place, route, emit */
+    float count_kernel_ms;
+    float reserved_f;
+} snk_shard_result;
+/* total_reads: reads of the whole job (sizes the bucket count without an exchange; 0 = the ranks exchange their slab sizes,
+ * ignored when p->n_buckets is set).  in->read_index_base = global index of the slab's first read. */
+int snk_shard_step(snk_ctx* ctx, snk_comm* comm, const snk_dev_reads* in, const snk_params* p, uint64_t total_reads, uint32_t flags,
+                   snk_shard_result* out, void* stream, char* err, size_t errcap);
+
 /* ---- host-pointer convenience + graph hand-off -------------- */
 typedef struct snk_reads {
     uint64_t n_reads;

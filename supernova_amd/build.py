@@ -61,7 +61,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         # The HIP runtime is NOT a DT_NEEDED of libsnk.so: the host process supplies it (torch's bundled
         # libamdhip64 when the host is Python/torch, /opt/rocm's otherwise -- see supernova_amd/lib.py and
         # INTEGRATION.md).  Two HIP runtimes in one process do not work.
-        cmd = [os.environ.get("CXX", "g++"), "-shared", "-fPIC", "-o", str(LIB), *map(str, objs), "-lz"]
+        cmd = [os.environ.get("CXX", "g++"), "-shared", "-fPIC", "-o", str(LIB), *map(str, objs), "-lz", "-ldl", "-lpthread"]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -28,6 +28,10 @@ int snk_fail(int code, char* err, size_t errcap, const char* fmt, ...) {
     return code;
 }
 
+static thread_local uint64_t g_syncs = 0;
+hipError_t snk_sync(hipStream_t st) { ++g_syncs; return hipStreamSynchronize(st); }
+uint64_t snk_sync_count() { return g_syncs; }
+
 extern "C" const char* snk_version(void) { return "libsnk 0.1 (gfx950)"; }
 extern "C" const char* snk_last_error(void) { return g_last_error; }
 
@@ -131,6 +135,7 @@ extern "C" void snk_ctx_destroy(snk_ctx* ctx) {
     snk_ctx_trim_cache(ctx);
     if (ctx->shard) snk_shard_state_free(ctx->shard);
     if (ctx->host_io && ctx->host_io_free) ctx->host_io_free(ctx->host_io);
+    if (ctx->shard_host && ctx->shard_host_free) ctx->shard_host_free(ctx->shard_host);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -1,0 +1,296 @@
+// snk_comm.hip -- transports of the minimiser-sharded path behind the C ABI (snk_comm_* in include/snk.h).
+//
+//  * RCCL: one process per GPU.  librccl is bound at run time (dlopen) so that libsnk links no second HIP runtime: in a
+//    torch process the library torch ships is the one to use (supernova_amd/lib.py passes its path), in a plain C++ host
+//    /opt/rocm's.  Every exchange is ONE group of ncclSend / ncclRecv pairs on the caller's stream -- xGMI is point-to-point,
+//    an all-to-all is W-1 concurrent pair transfers, which is exactly what a send/recv group expresses -- in pieces of at
+//    most 256 MiB (RCCL 2.26 mis-delivers multi-GB messages, tools/dbg_a2a.py), the piece a rank owes itself is a device
+//    copy.  The communicator comes from a 128-byte unique id that rank 0 makes and the host hands round (file, socket,
+//    torch.distributed broadcast: the host's business), or is adopted from the caller (an ncclComm_t).
+//  * local: W in-process ranks on ONE device (every rank a host thread with its own context), the wire replaced by device
+//    copies between the ranks' buffers.  The SPMD code of the step is the same; this is how N > 1 is tested on one GPU.
+// Reference counterpart of the exchange: shard files written and gathered per shard id
+// (lib/tada/external/rust-shardio/src/shard.rs:184-211,488-493), MapReduceEngine.h:362-385.
+#include <dlfcn.h>
+#include <stdlib.h>
+
+#include <condition_variable>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include <rccl/rccl.h>      // types and enums only: the functions are bound with dlsym
+
+#include "snk_comm.h"
+
+namespace {
+
+constexpr size_t PIECE = 256ull << 20;
+
+struct rccl_api {
+    void* h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+rccl_api g_rccl;
+std::string g_rccl_path;
+std::mutex g_rccl_mu;
+
+int rccl_load(char* err, size_t errcap) {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.h) return SNK_OK;
+    std::vector<std::string> cands;
+    if (!g_rccl_path.empty()) cands.push_back(g_rccl_path);
+    if (const char* e = getenv("SNK_RCCL_LIB")) if (*e) cands.push_back(e);
+    cands.push_back("librccl.so.1");
+    cands.push_back("librccl.so");
+    cands.push_back(std::string(getenv("ROCM_PATH") ? getenv("ROCM_PATH") : "/opt/rocm") + "/lib/librccl.so");
+    void* h = nullptr;
+    std::string tried;
+    for (auto& c : cands) {
+        h = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (h) break;
+        tried += c + " ";
+    }
+    if (!h) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "librccl not found (tried: %s)", tried.c_str());
+    rccl_api a;
+    a.h = h;
+#define BIND(f, name) do { *(void**)(&a.f) = dlsym(h, name); if (!a.f) { dlclose(h); return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "librccl has no %s", name); } } while (0)
+    BIND(GetUniqueId, "ncclGetUniqueId");
+    BIND(CommInitRank, "ncclCommInitRank");
+    BIND(CommDestroy, "ncclCommDestroy");
+    BIND(Send, "ncclSend");
+    BIND(Recv, "ncclRecv");
+    BIND(AllGather, "ncclAllGather");
+    BIND(GroupStart, "ncclGroupStart");
+    BIND(GroupEnd, "ncclGroupEnd");
+    BIND(GetErrorString, "ncclGetErrorString");
+#undef BIND
+    g_rccl = a;
+    return SNK_OK;
+}
+
+#define NCCL_TRY(expr)                                                                                                       \
+    do {                                                                                                                     \
+        ncclResult_t _r = (expr);                                                                                            \
+        if (_r != ncclSuccess) return snk_fail(SNK_E_HIP, err, errcap, "%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(_r), __FILE__, __LINE__); \
+    } while (0)
+
+struct rccl_comm : snk_comm {
+    ncclComm_t comm = nullptr;
+    bool owned = false;
+    unsigned long long* h_pin = nullptr;    // pinned landing area of gather_counts
+    unsigned long long* d_all = nullptr;
+    size_t cap = 0;                          // u64 entries both hold
+    const char* kind() const override { return "rccl"; }
+    ~rccl_comm() override {
+        if (comm && owned && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comm);
+        if (h_pin) (void)hipHostFree(h_pin);
+        if (d_all) (void)hipFree(d_all);
+    }
+    int a2a(const void* send, const uint64_t* sbeg, const uint64_t* scnt, void* recv, const uint64_t* rbeg, const uint64_t* rcnt, hipStream_t st, char* err,
+            size_t errcap) override {
+        ++n_collectives;
+        const char* s = (const char*)send;
+        char* r = (char*)recv;
+        if (scnt[rank]) {
+            if (scnt[rank] != rcnt[rank]) return snk_fail(SNK_E_INTERNAL, err, errcap, "a2a: the piece for myself has two sizes");
+            SNK_HIP_TRY(hipMemcpyAsync(r + rbeg[rank], s + sbeg[rank], scnt[rank], hipMemcpyDeviceToDevice, st));
+        }
+        bool any = false;
+        for (uint32_t p = 0; p < world; ++p) if (p != rank && (scnt[p] || rcnt[p])) any = true;
+        if (!any) return SNK_OK;
+        NCCL_TRY(g_rccl.GroupStart());
+        for (uint32_t p = 0; p < world; ++p) {
+            if (p == rank) continue;
+            for (uint64_t o = 0; o < scnt[p]; o += PIECE) {
+                const size_t n = (size_t)(scnt[p] - o < PIECE ? scnt[p] - o : PIECE);
+                NCCL_TRY(g_rccl.Send(s + sbeg[p] + o, n, ncclUint8, (int)p, comm, st));
+            }
+            for (uint64_t o = 0; o < rcnt[p]; o += PIECE) {
+                const size_t n = (size_t)(rcnt[p] - o < PIECE ? rcnt[p] - o : PIECE);
+                NCCL_TRY(g_rccl.Recv(r + rbeg[p] + o, n, ncclUint8, (int)p, comm, st));
+            }
+            bytes_sent += scnt[p];
+        }
+        NCCL_TRY(g_rccl.GroupEnd());
+        return SNK_OK;
+    }
+    int allgatherv(const void* send, const uint64_t* counts, void* recv, hipStream_t st, char* err, size_t errcap) override {
+        std::vector<uint64_t> sbeg(world, 0), scnt(world, counts[rank]), rbeg(world), rcnt(world);
+        uint64_t acc = 0;
+        for (uint32_t p = 0; p < world; ++p) { rbeg[p] = acc; rcnt[p] = counts[p]; acc += counts[p]; }
+        return a2a(send, sbeg.data(), scnt.data(), recv, rbeg.data(), rcnt.data(), st, err, errcap);
+    }
+    int gather_counts(const unsigned long long* d_mine, uint32_t k, unsigned long long* h_all, hipStream_t st, char* err, size_t errcap) override {
+        ++n_collectives;
+        const size_t need = (size_t)world * k;
+        if (need > cap) {
+            if (h_pin) (void)hipHostFree(h_pin);
+            if (d_all) (void)hipFree(d_all);
+            h_pin = nullptr; d_all = nullptr;
+            cap = need + 256;
+            SNK_HIP_TRY(hipHostMalloc((void**)&h_pin, cap * 8, hipHostMallocDefault));
+            SNK_HIP_TRY(hipMalloc((void**)&d_all, cap * 8));
+        }
+        if (world == 1) SNK_HIP_TRY(hipMemcpyAsync(h_pin, d_mine, (size_t)k * 8, hipMemcpyDeviceToHost, st));
+        else {
+            NCCL_TRY(g_rccl.AllGather(d_mine, d_all, k, ncclUint64, comm, st));
+            SNK_HIP_TRY(hipMemcpyAsync(h_pin, d_all, need * 8, hipMemcpyDeviceToHost, st));
+            bytes_sent += (uint64_t)(world - 1) * k * 8;
+        }
+        SNK_HIP_TRY(snk_sync(st));
+        memcpy(h_all, h_pin, need * 8);
+        return SNK_OK;
+    }
+    int barrier(hipStream_t st, char* err, size_t errcap) override {
+        // a stream-ordered rendezvous: an all-gather of one word (nothing on this path needs a host-side barrier)
+        if (world == 1) return SNK_OK;
+        if (!d_all) { cap = 256 + world; SNK_HIP_TRY(hipHostMalloc((void**)&h_pin, cap * 8, hipHostMallocDefault)); SNK_HIP_TRY(hipMalloc((void**)&d_all, cap * 8)); }
+        NCCL_TRY(g_rccl.AllGather(d_all + world, d_all, 1, ncclUint64, comm, st));
+        return SNK_OK;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------- in-process ranks
+struct local_world {
+    uint32_t W;
+    std::mutex mu;
+    std::condition_variable cv;
+    uint32_t arrived = 0;
+    uint64_t gen = 0;
+    bool aborted = false;
+    uint32_t refs;
+    std::vector<const void*> sptr;
+    std::vector<const uint64_t*> sbeg, scnt;
+    std::vector<const unsigned long long*> dvals;
+    explicit local_world(uint32_t w) : W(w), refs(w), sptr(w), sbeg(w), scnt(w), dvals(w) {}
+    bool wait() {       // false: somebody aborted
+        std::unique_lock<std::mutex> lk(mu);
+        if (aborted) return false;
+        const uint64_t g = gen;
+        if (++arrived == W) { arrived = 0; ++gen; cv.notify_all(); return true; }
+        cv.wait(lk, [&] { return gen != g || aborted; });
+        return !aborted;
+    }
+};
+
+struct local_comm : snk_comm {
+    local_world* w = nullptr;
+    const char* kind() const override { return "local"; }
+    ~local_comm() override {
+        bool last;
+        { std::lock_guard<std::mutex> lk(w->mu); last = --w->refs == 0; }
+        if (last) delete w;
+    }
+    void abort() override {
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->aborted = true;
+        w->cv.notify_all();
+    }
+    int gone(char* err, size_t errcap) { return snk_fail(SNK_E_INTERNAL, err, errcap, "another in-process rank failed"); }
+    int a2a(const void* send, const uint64_t* sbeg, const uint64_t* scnt, void* recv, const uint64_t* rbeg, const uint64_t* rcnt, hipStream_t st, char* err,
+            size_t errcap) override {
+        ++n_collectives;
+        SNK_HIP_TRY(hipStreamSynchronize(st));        // what I send is complete (the wire's waits are not the step's read-backs: not counted)
+        w->sptr[rank] = send; w->sbeg[rank] = sbeg; w->scnt[rank] = scnt;
+        if (!w->wait()) return gone(err, errcap);
+        for (uint32_t s = 0; s < world; ++s) {
+            const uint64_t n = w->scnt[s][rank];
+            if (n != rcnt[s]) { abort(); return snk_fail(SNK_E_INTERNAL, err, errcap, "a2a: rank %u sends %llu bytes, rank %u expects %llu", s, (unsigned long long)n, rank, (unsigned long long)rcnt[s]); }
+            if (n) SNK_HIP_TRY(hipMemcpyAsync((char*)recv + rbeg[s], (const char*)w->sptr[s] + w->sbeg[s][rank], n, hipMemcpyDeviceToDevice, st));
+            if (s != rank) bytes_sent += scnt[s];
+        }
+        SNK_HIP_TRY(hipStreamSynchronize(st));
+        if (!w->wait()) return gone(err, errcap);     // nobody reuses its send buffer before everyone has copied
+        return SNK_OK;
+    }
+    int allgatherv(const void* send, const uint64_t* counts, void* recv, hipStream_t st, char* err, size_t errcap) override {
+        std::vector<uint64_t> sbeg(world, 0), scnt(world, counts[rank]), rbeg(world), rcnt(world);
+        uint64_t acc = 0;
+        for (uint32_t p = 0; p < world; ++p) { rbeg[p] = acc; rcnt[p] = counts[p]; acc += counts[p]; }
+        return a2a(send, sbeg.data(), scnt.data(), recv, rbeg.data(), rcnt.data(), st, err, errcap);
+    }
+    int gather_counts(const unsigned long long* d_mine, uint32_t k, unsigned long long* h_all, hipStream_t st, char* err, size_t errcap) override {
+        ++n_collectives;
+        SNK_HIP_TRY(snk_sync(st));                    // the step's read-back
+        w->dvals[rank] = d_mine;
+        if (!w->wait()) return gone(err, errcap);
+        for (uint32_t s = 0; s < world; ++s) SNK_HIP_TRY(hipMemcpy(h_all + (size_t)s * k, w->dvals[s], (size_t)k * 8, hipMemcpyDeviceToHost));
+        if (!w->wait()) return gone(err, errcap);
+        return SNK_OK;
+    }
+    int barrier(hipStream_t st, char* err, size_t errcap) override {
+        SNK_HIP_TRY(hipStreamSynchronize(st));
+        if (!w->wait()) return gone(err, errcap);
+        return SNK_OK;
+    }
+};
+
+}  // namespace
+
+extern "C" int snk_comm_set_rccl_path(const char* path) {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    g_rccl_path = path ? path : "";
+    return SNK_OK;
+}
+
+extern "C" int snk_comm_unique_id(void* id128, char* err, size_t errcap) {
+    if (!id128) return snk_fail(SNK_E_ARG, err, errcap, "snk_comm_unique_id: NULL");
+    int rc = rccl_load(err, errcap);
+    if (rc) return rc;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    NCCL_TRY(g_rccl.GetUniqueId(&id));
+    memcpy(id128, &id, 128);
+    return SNK_OK;
+}
+
+extern "C" int snk_comm_create_rccl(snk_ctx* ctx, const void* id128, uint32_t rank, uint32_t world, snk_comm** out, char* err, size_t errcap) {
+    if (!ctx || !id128 || !out || world == 0 || rank >= world) return snk_fail(SNK_E_ARG, err, errcap, "snk_comm_create_rccl: bad argument");
+    int rc = rccl_load(err, errcap);
+    if (rc) return rc;
+    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    rccl_comm* c = new rccl_comm();
+    c->rank = rank; c->world = world; c->owned = true;
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, (int)world, id, (int)rank);
+    if (r != ncclSuccess) { c->comm = nullptr; delete c; return snk_fail(SNK_E_HIP, err, errcap, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r)); }
+    *out = c;
+    return SNK_OK;
+}
+
+extern "C" int snk_comm_from_nccl(snk_ctx* ctx, void* nccl_comm, uint32_t rank, uint32_t world, snk_comm** out, char* err, size_t errcap) {
+    if (!ctx || !nccl_comm || !out || world == 0 || rank >= world) return snk_fail(SNK_E_ARG, err, errcap, "snk_comm_from_nccl: bad argument");
+    int rc = rccl_load(err, errcap);
+    if (rc) return rc;
+    rccl_comm* c = new rccl_comm();
+    c->rank = rank; c->world = world; c->owned = false; c->comm = (ncclComm_t)nccl_comm;
+    *out = c;
+    return SNK_OK;
+}
+
+extern "C" int snk_comm_create_local(uint32_t world, snk_comm** out /* [world] */, char* err, size_t errcap) {
+    if (!out || world == 0 || world > 0x7FFF) return snk_fail(SNK_E_ARG, err, errcap, "snk_comm_create_local: bad argument");
+    local_world* w = new local_world(world);
+    for (uint32_t r = 0; r < world; ++r) {
+        local_comm* c = new local_comm();
+        c->rank = r; c->world = world; c->w = w;
+        out[r] = c;
+    }
+    return SNK_OK;
+}
+
+extern "C" void snk_comm_destroy(snk_comm* c) { delete c; }
+extern "C" uint32_t snk_comm_rank(const snk_comm* c) { return c ? c->rank : 0; }
+extern "C" uint32_t snk_comm_world(const snk_comm* c) { return c ? c->world : 0; }
+extern "C" const char* snk_comm_kind(const snk_comm* c) { return c ? c->kind() : ""; }
+extern "C" void snk_comm_abort(snk_comm* c) { if (c) c->abort(); }

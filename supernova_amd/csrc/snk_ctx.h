@@ -27,9 +27,15 @@ struct snk_ctx {
     void* shard = nullptr;      // snk_shard_state (snk_dist.hip)
     void* host_io = nullptr;    // pinned staging + device input buffers of the host-pointer entry point (snk_host.hip)
     void (*host_io_free)(void*) = nullptr;
+    void* shard_host = nullptr; // pinned staging, exchange stream and events of snk_shard_step (snk_shard_step.hip)
+    void (*shard_host_free)(void*) = nullptr;
 };
 
 void snk_set_error(char* err, size_t errcap, const char* fmt, ...);
+// every host wait for a stream goes through here: the calling thread's count is what the sharded step reports as
+// host_syncs (a host thread = a rank)
+hipError_t snk_sync(hipStream_t st);
+uint64_t snk_sync_count();
 int snk_fail(int code, char* err, size_t errcap, const char* fmt, ...);
 
 #define SNK_HIP_TRY(expr)                                                                          \

@@ -17,50 +17,21 @@
 #include "snk_graph.h"
 #include "snk_kernels.h"
 #include "snk_stages.h"
+#include "snk_shard.h"
 
-struct snk_shard_state {
-    snk_dev_reads reads;
-    snk_params params;
-    uint32_t rank = 0, world = 1, NB_total = 0, NBl = 0;
-    const uint16_t* good_len = nullptr;
-    uint32_t* status = nullptr;
-    snk_partition part{};
-    snk_table tab{};
-    snk_dist_graph g{};
-    snk_bl_state bl{};
-    snk_frag_out frags{};              // this rank's fragments (valid from snk_shard_fragments on)
-    const unsigned long long* d_node_off = nullptr;
-    unsigned long long my_node_off = 0, my_end_base = 0;
-    unsigned long long *lq_count = nullptr, *lq_cursor = nullptr;
-    // owner-side join: placement of this rank's fragments, destination rank of each, route cursors
-    snk_placement pl{};
-    uint32_t* dest = nullptr;
-    unsigned long long *rt_count = nullptr, *rt_cursor = nullptr;      // [2][world]: fragments, base bytes
-    unsigned long long my_frag_off = 0;
-    uint64_t n_frags_total = 0;
-    uint32_t join_circles = 0, join_rounds = 0;
-    snk_prank pr{};
-    const uint32_t* nk_all = nullptr;
-    snk_phase_timer* tm = nullptr;
-};
-
-static snk_shard_state* state_of(snk_ctx* ctx) {
-    if (!ctx->shard) ctx->shard = new snk_shard_state();
-    return static_cast<snk_shard_state*>(ctx->shard);
-}
+static snk_shard_state* state_of(snk_ctx* ctx) { return snk_shard_state_of(ctx); }
 void snk_shard_state_free(void* p) { delete static_cast<snk_shard_state*>(p); }
 
-extern "C" int snk_shard_hist(snk_ctx* ctx, const snk_dev_reads* in, const snk_params* p, uint32_t rank, uint32_t world,
-                              uint32_t NB_total, void* d_hist, uint64_t* n_instances, void* stream, char* err, size_t errcap) {
-    if (!ctx || !in || !p || !d_hist) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_hist: NULL argument");
+int snk_shard_begin(snk_ctx* ctx, const snk_dev_reads* in, const snk_params* p, uint32_t rank, uint32_t world, uint32_t NB_total,
+                    uint64_t* n_instances, hipStream_t st, char* err, size_t errcap) {
+    if (!ctx || !in || !p) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_hist: NULL argument");
     if (p->K != 48 && p->K != 60) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "K=%u is not supported (48 or 60)", p->K);
     if (p->min_bc > 8) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "min_bc=%u: the device barcode rule tells up to eight distinct barcodes apart (min_bc <= 8)", p->min_bc);
     if (world == 0 || rank >= world || NB_total == 0 || NB_total % world) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_hist: NB_total must be a positive multiple of world");
     if (world > 0x7FFF) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "world > 32767");
-    if (!in->rows || in->row_words * 16 < in->read_len || in->read_len > 256 || (!in->quals && !in->good_len))
+    if (in->n_reads && (!in->rows || in->row_words * 16 < in->read_len || in->read_len > 256 || (!in->quals && !in->good_len)))
         return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_hist: bad reads");
     SNK_HIP_TRY(hipSetDevice(ctx->device));
-    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     snk_ctx_release_scratch(ctx);
     snk_shard_state* S = state_of(ctx);
     S->reads = *in;
@@ -71,22 +42,33 @@ extern "C" int snk_shard_hist(snk_ctx* ctx, const snk_dev_reads* in, const snk_p
     if (!good_len) {
         void* gl;
         if ((rc = snk_ctx_alloc(ctx, in->n_reads * 2 + 2, &gl, err, errcap))) return rc;
-        rc = snk_dev_trim(ctx, in->quals, in->qstride, in->lens, in->read_len, in->n_reads, p->K, p->min_qual, gl, st);
-        if (rc) return snk_fail(rc, err, errcap, "%s", snk_last_error());
+        if (in->n_reads) {
+            rc = snk_dev_trim(ctx, in->quals, in->qstride, in->lens, in->read_len, in->n_reads, p->K, p->min_qual, gl, st);
+            if (rc) return snk_fail(rc, err, errcap, "%s", snk_last_error());
+        }
         good_len = (const uint16_t*)gl;
     }
     S->good_len = good_len;
     void* q;
     if ((rc = snk_ctx_alloc(ctx, 64, &q, err, errcap))) return rc; S->status = (uint32_t*)q;
     SNK_HIP_TRY(hipMemsetAsync(S->status, 0, 64, st));
-    // one partition pass into fixed-capacity bucket slots (as on one GPU); the histogram is its cursor array, the
-    // "scatter" stage compacts the slots into the caller's exact, destination-contiguous send buffer
+    // one partition pass into fixed-capacity bucket slots (as on one GPU); the histogram is its cursor array
     unsigned long long h_plan[2] = {0, 0};
     if ((rc = snk_stage_partition_plan(ctx, st, p->K, good_len, in->n_reads, h_plan, err, errcap))) return rc;
     if ((rc = snk_stage_partition(ctx, st, p->K, in, good_len, NB_total, h_plan[0], h_plan[1], false, S->status, &S->part, err, errcap))) return rc;
-    SNK_HIP_TRY(hipMemcpyAsync(d_hist, S->part.cursor, (size_t)NB_total * 4, hipMemcpyDeviceToDevice, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
     if (n_instances) *n_instances = h_plan[0];
+    return SNK_OK;
+}
+
+extern "C" int snk_shard_hist(snk_ctx* ctx, const snk_dev_reads* in, const snk_params* p, uint32_t rank, uint32_t world,
+                              uint32_t NB_total, void* d_hist, uint64_t* n_instances, void* stream, char* err, size_t errcap) {
+    if (!ctx || !d_hist) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_hist: NULL argument");
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    int rc = snk_shard_begin(ctx, in, p, rank, world, NB_total, n_instances, st, err, errcap);
+    if (rc) return rc;
+    // the "scatter" stage compacts the slots into the caller's exact, destination-contiguous send buffer
+    SNK_HIP_TRY(hipMemcpyAsync(d_hist, state_of(ctx)->part.cursor, (size_t)NB_total * 4, hipMemcpyDeviceToDevice, st));
+    SNK_HIP_TRY(snk_sync(st));
     return SNK_OK;
 }
 
@@ -214,7 +196,7 @@ extern "C" int snk_shard_links_plan(snk_ctx* ctx, uint64_t my_frag_off, uint64_t
     if ((rc = snk_dist_links_query(ctx, st, false, &S->frags, S->d_node_off, S->world, S->my_end_base, S->lq_count, nullptr, err, errcap))) return rc;
     std::vector<unsigned long long> h(S->world);
     SNK_HIP_TRY(hipMemcpyAsync(h.data(), S->lq_count, S->world * 8ull, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     for (uint32_t r = 0; r < S->world; ++r) h_qcount[r] = h[r];
     return SNK_OK;
 }
@@ -389,7 +371,7 @@ static int place_and_count(snk_ctx* ctx, snk_shard_state* S, hipStream_t st, uin
     SNK_HIP_TRY(hipGetLastError());
     std::vector<unsigned long long> h(2 * S->world);
     SNK_HIP_TRY(hipMemcpyAsync(h.data(), S->rt_count, 2ull * S->world * 8, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     for (uint32_t r = 0; r < S->world; ++r) { h_frags_to[r] = h[r]; h_bases_to[r] = h[S->world + r]; }
     return SNK_OK;
 }
@@ -423,7 +405,7 @@ extern "C" int snk_shard_prank_begin(snk_ctx* ctx, uint64_t n_frags_total, const
     S->nk_all = (const uint32_t*)d_nk_all;
     int rc = snk_prank_begin(ctx, st, n_frags_total, (const uint32_t*)d_nk_all, (uint32_t*)d_flink_all, S->rank, S->world, &S->pr, err, errcap);
     if (rc) return rc;
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     *n_splitters = S->pr.m;
     *d_w1_share = S->pr.w1_share;
     return SNK_OK;
@@ -445,7 +427,7 @@ extern "C" int snk_shard_prank_walk(snk_ctx* ctx, const void* d_w1_all, const vo
     if ((rc = snk_prank_route(ctx, st, &S->pr, false, (const unsigned long long*)d_frag_off, S->world, cnt, nullptr, err, errcap))) return rc;
     std::vector<unsigned long long> h(S->world);
     SNK_HIP_TRY(hipMemcpyAsync(h.data(), cnt, S->world * 8ull, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     for (uint32_t r = 0; r < S->world; ++r) h_recs_to[r] = h[r];
     return SNK_OK;
 }

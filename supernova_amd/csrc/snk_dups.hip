@@ -219,7 +219,7 @@ extern "C" int snk_dev_mark_dups(snk_ctx* ctx, const snk_dev_reads* in, const sn
         t = tb;
         SNK_HIP_TRY(rocprim::radix_sort_pairs(tmp, t, key2, key, id2, id, (size_t)n, 0u, 64u, st));            // key / id = (edge, offset, head, id) order
         SNK_HIP_TRY(hipMemcpyAsync(h_stat + 4, stat + 4, 8, hipMemcpyDeviceToHost, st));
-        SNK_HIP_TRY(hipStreamSynchronize(st));
+        SNK_HIP_TRY(snk_sync(st));
         const uint64_t m = h_stat[4];                       // placed reads: the front of the sorted array
         if (m) {
             const unsigned gm = (unsigned)((m + 255) / 256);
@@ -232,7 +232,7 @@ extern "C" int snk_dev_mark_dups(snk_ctx* ctx, const snk_dev_reads* in, const sn
         SNK_HIP_TRY(hipMemcpyAsync(h_stat, stat, 64, hipMemcpyDeviceToHost, st));
     }
     SNK_HIP_TRY(hipEventRecord(e1, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     out->n_pairs = np;
     out->dup = dup;
     out->n_dup_reads = h_stat[0];

@@ -1,0 +1,361 @@
+// snk_fasth.hip -- f3 at rate: FASTH files -> batches of reads in page-locked host memory, many files in
+// flight, and from there into HBM (snk_dev_ingest_fasth) with the upload, the 2-bit pack and the barcode ids overlapped
+// with the decode.
+//
+// What it replaces: the reading half of tada's MSP stage -- one decode thread per two files
+// (lib/tada/src/cmd_msp.rs:55-69) over MultiFastqIter (lib/tada/src/multifastq.rs:69-127: gzip text, 9 lines per read pair:
+// header, R1, Q1, R2, Q2, barcode field, three ignored lines; R1 = read 2q, R2 = read 2q+1, cmd_msp.rs:160-181) and the
+// barcode lookup of BcIndexer (lib/tada/src/utils.rs:101-164, on the device: snk_ingest.hip).
+//
+// Design: a pool of worker threads takes whole files (a gzip stream is sequential; the parallelism of this format is across
+// files: a lane of a flowcell is bucketed into dozens of them).  A worker inflates with zlib's streaming API into a text
+// window and parses records in place -- no per-line strings, the bases and qualities of a read are copied once, from the
+// inflate window into their row of the batch -- and hands full batches to the consumer through a queue.  Batches live in
+// page-locked memory (when a GPU is there), so the DMA engine reads them where they are.
+#include <fcntl.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "snk_ctx.h"
+#include "snk_synth.h"
+
+struct snk_fasth_stream {
+    struct batch {
+        uint8_t *ascii = nullptr, *quals = nullptr, *bcf = nullptr;
+        uint16_t* lens = nullptr;
+        uint64_t n_pairs = 0, text_bytes = 0, first_pair = 0;
+        uint32_t file = 0, max_len = 0;
+        bool pinned = false;
+    };
+    std::vector<std::string> paths;
+    uint32_t stride = 0, batch_pairs = 0;
+    std::vector<batch> pool;
+    std::deque<int> free_q, ready_q;
+    std::mutex mu;
+    std::condition_variable cv_free, cv_ready;
+    std::vector<std::thread> workers;
+    std::atomic<uint32_t> next_file{0};
+    uint32_t live_workers = 0;
+    bool stop = false;
+    int rc = SNK_OK;
+    std::string errmsg;
+    std::vector<uint64_t> file_pairs;      // pairs of every file (known once it has been read to its end)
+};
+
+namespace {
+
+void fail(snk_fasth_stream* s, int rc, const std::string& msg) {
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (s->rc == SNK_OK) { s->rc = rc; s->errmsg = msg; }
+    s->stop = true;
+    s->cv_free.notify_all();
+    s->cv_ready.notify_all();
+}
+
+int take_free(snk_fasth_stream* s) {
+    std::unique_lock<std::mutex> lk(s->mu);
+    s->cv_free.wait(lk, [&] { return s->stop || !s->free_q.empty(); });
+    if (s->stop) return -1;
+    const int b = s->free_q.front();
+    s->free_q.pop_front();
+    return b;
+}
+void push_ready(snk_fasth_stream* s, int b) {
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->ready_q.push_back(b);
+    s->cv_ready.notify_one();
+}
+
+// one file, start to end.  Returns false after an error / stop.
+bool decode_file(snk_fasth_stream* s, uint32_t fi) {
+    const std::string& path = s->paths[fi];
+    const uint32_t stride = s->stride;
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) { fail(s, SNK_E_IO, "cannot open " + path); return false; }
+    (void)posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
+    constexpr size_t IN = 1 << 20, WIN = 4 << 20;
+    std::vector<unsigned char> in(IN), win(WIN);
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, 15 + 32) != Z_OK) { close(fd); fail(s, SNK_E_INTERNAL, "inflateInit2 failed"); return false; }
+    int cur = -1;                 // batch being filled
+    uint64_t pairs_in_file = 0, text_in_batch = 0;
+    size_t have = 0;              // bytes of text in the window
+    size_t line_beg = 0;          // start of the line being completed
+    size_t scan = 0;              // first byte not yet searched for a newline
+    uint32_t li = 0;              // line of the record, 0..8
+    uint32_t r_len[2] = {0, 0};
+    bool ok = true, eof_in = false, first_byte = true;
+    std::string what;
+    auto flush = [&](bool last) {
+        if (cur < 0) return;
+        snk_fasth_stream::batch& b = s->pool[cur];
+        if (b.n_pairs == 0 && !last) return;
+        b.text_bytes = text_in_batch;
+        text_in_batch = 0;
+        push_ready(s, cur);
+        cur = -1;
+    };
+    auto on_line = [&](const unsigned char* p, size_t n) -> bool {       // a complete line without its terminator
+        if (n && p[n - 1] == '\r') --n;
+        if (li == 0) {
+            if (cur < 0) {
+                cur = take_free(s);
+                if (cur < 0) return false;
+                snk_fasth_stream::batch& b = s->pool[cur];
+                b.n_pairs = 0; b.file = fi; b.first_pair = pairs_in_file; b.max_len = 0;
+            }
+        } else if (li == 1 || li == 3) {
+            snk_fasth_stream::batch& b = s->pool[cur];
+            if (n > stride) { what = path + ": a read of " + std::to_string(n) + " bases does not fit rows of " + std::to_string(stride); return false; }
+            uint8_t* row = b.ascii + (2 * b.n_pairs + (li >> 1)) * (size_t)stride;
+            memcpy(row, p, n);
+            memset(row + n, 'A', stride - n);
+            r_len[li >> 1] = (uint32_t)n;
+            b.lens[2 * b.n_pairs + (li >> 1)] = (uint16_t)n;
+            if (n > b.max_len) b.max_len = (uint32_t)n;
+        } else if (li == 2 || li == 4) {
+            snk_fasth_stream::batch& b = s->pool[cur];
+            const uint32_t m = (li >> 1) - 1;
+            if (n != r_len[m]) { what = path + ": record " + std::to_string(pairs_in_file) + ": " + std::to_string(r_len[m]) + " bases but " + std::to_string(n) + " qualities"; return false; }
+            uint8_t* row = b.quals + (2 * b.n_pairs + m) * (size_t)stride;
+            for (size_t i = 0; i < n; ++i) row[i] = (uint8_t)(p[i] - 33);
+            memset(row + n, 0, stride - n);
+        } else if (li == 5) {
+            snk_fasth_stream::batch& b = s->pool[cur];
+            const void* comma = memchr(p, ',', n);                      // only the part before the first ',' is the barcode
+            size_t nb = comma ? (size_t)((const unsigned char*)comma - p) : n;
+            if (nb > 64) nb = 64;
+            uint8_t* f = b.bcf + b.n_pairs * 64;
+            memcpy(f, p, nb);
+            memset(f + nb, 0, 64 - nb);
+        }
+        if (++li == 9) {
+            li = 0;
+            snk_fasth_stream::batch& b = s->pool[cur];
+            ++b.n_pairs;
+            ++pairs_in_file;
+            if (b.n_pairs == s->batch_pairs) flush(false);
+        }
+        return true;
+    };
+    while (ok) {
+        // refill the input
+        if (zs.avail_in == 0 && !eof_in) {
+            const ssize_t got = read(fd, in.data(), IN);
+            if (got < 0) { what = "read error on " + path; ok = false; break; }
+            if (got == 0) eof_in = true;
+            zs.next_in = in.data();
+            zs.avail_in = (uInt)got;
+            if (first_byte && got >= 2) { first_byte = false; if (in[0] != 0x1f || in[1] != 0x8b) { what = path + ": not a gz file"; ok = false; break; } }
+        }
+        if (eof_in && zs.avail_in == 0) break;
+        if (have == WIN) {
+            // the window is full: keep the incomplete line, drop the rest
+            if (line_beg == 0) { what = path + ": a line longer than " + std::to_string(WIN) + " bytes"; ok = false; break; }
+            memmove(win.data(), win.data() + line_beg, have - line_beg);
+            have -= line_beg; scan -= line_beg; line_beg = 0;
+        }
+        zs.next_out = win.data() + have;
+        zs.avail_out = (uInt)(WIN - have);
+        const int zr = inflate(&zs, Z_NO_FLUSH);
+        if (zr != Z_OK && zr != Z_STREAM_END && zr != Z_BUF_ERROR) { what = path + ": corrupt gzip stream (" + std::string(zs.msg ? zs.msg : "zlib error") + ")"; ok = false; break; }
+        const size_t now = WIN - zs.avail_out;
+        text_in_batch += now - have;
+        have = now;
+        // complete lines
+        while (scan < have) {
+            const unsigned char* nl = (const unsigned char*)memchr(win.data() + scan, '\n', have - scan);
+            if (!nl) { scan = have; break; }
+            const size_t e = (size_t)(nl - win.data());
+            if (!on_line(win.data() + line_beg, e - line_beg)) { ok = false; break; }
+            line_beg = scan = e + 1;
+        }
+        if (!ok) break;
+        if (zr == Z_STREAM_END) {
+            // a further gzip member may follow (concatenated members are one stream)
+            if (zs.avail_in == 0 && eof_in) break;
+            if (inflateReset(&zs) != Z_OK) { what = "inflateReset failed"; ok = false; break; }
+        }
+        if (zr == Z_BUF_ERROR && zs.avail_in == 0 && eof_in) break;
+    }
+    inflateEnd(&zs);
+    close(fd);
+    if (ok && line_beg < have) {          // a last line without a newline
+        if (!on_line(win.data() + line_beg, have - line_beg)) ok = false;
+    }
+    if (ok && li != 0) { what = path + ": truncated record " + std::to_string(pairs_in_file); ok = false; }
+    if (!ok) {
+        if (!what.empty()) fail(s, what.find("does not fit") != std::string::npos ? SNK_E_UNSUPPORTED : SNK_E_IO, what);
+        return false;
+    }
+    flush(true);
+    { std::lock_guard<std::mutex> lk(s->mu); s->file_pairs[fi] = pairs_in_file; }
+    return true;
+}
+
+void worker_main(snk_fasth_stream* s) {
+    for (;;) {
+        const uint32_t fi = s->next_file.fetch_add(1);
+        if (fi >= s->paths.size()) break;
+        if (!decode_file(s, fi)) break;
+    }
+    std::lock_guard<std::mutex> lk(s->mu);
+    --s->live_workers;
+    s->cv_ready.notify_all();
+}
+
+void free_batch(snk_fasth_stream::batch& b) {
+    auto rel = [&](void* p) { if (!p) return; if (b.pinned) (void)hipHostFree(p); else free(p); };
+    rel(b.ascii); rel(b.quals); rel(b.bcf); rel(b.lens);
+    b.ascii = b.quals = b.bcf = nullptr; b.lens = nullptr;
+}
+
+}  // namespace
+
+extern "C" int snk_fasth_open(const char* const* paths, uint32_t n_files, uint32_t stride, uint32_t batch_pairs, uint32_t threads, uint32_t flags,
+                              snk_fasth_stream** out, char* err, size_t errcap) {
+    if (!paths || !out || n_files == 0) return snk_fail(SNK_E_ARG, err, errcap, "snk_fasth_open: no files");
+    if (stride == 0 || stride > 65535) return snk_fail(SNK_E_ARG, err, errcap, "snk_fasth_open: bad row stride");
+    if (batch_pairs == 0) batch_pairs = 32768;
+    if (threads == 0) { threads = std::thread::hardware_concurrency(); if (threads == 0) threads = 8; }
+    if (threads > n_files) threads = n_files;
+    if (threads > 256) threads = 256;
+    snk_fasth_stream* s = new snk_fasth_stream();
+    for (uint32_t i = 0; i < n_files; ++i) s->paths.push_back(paths[i] ? paths[i] : "");
+    s->stride = stride;
+    s->batch_pairs = batch_pairs;
+    s->file_pairs.assign(n_files, 0);
+    const bool want_pinned = (flags & 1u) != 0;
+    const uint32_t n_batches = 2 * threads + 2;
+    s->pool.resize(n_batches);
+    for (uint32_t i = 0; i < n_batches; ++i) {
+        snk_fasth_stream::batch& b = s->pool[i];
+        const size_t rows = 2 * (size_t)batch_pairs * stride;
+        bool ok = true;
+        auto get = [&](size_t bytes) -> void* {
+            void* p = nullptr;
+            if (want_pinned) { if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p = nullptr; } }
+            else p = malloc(bytes);
+            if (!p) ok = false;
+            return p;
+        };
+        b.pinned = want_pinned;
+        b.ascii = (uint8_t*)get(rows);
+        b.quals = (uint8_t*)get(rows);
+        b.bcf = (uint8_t*)get((size_t)batch_pairs * 64);
+        b.lens = (uint16_t*)get((size_t)batch_pairs * 4);
+        if (!ok) {
+            for (auto& q : s->pool) free_batch(q);
+            delete s;
+            return snk_fail(SNK_E_NOMEM, err, errcap, "snk_fasth_open: %s host allocation failed (%u batches of %u pairs)", want_pinned ? "page-locked" : "", n_batches, batch_pairs);
+        }
+        s->free_q.push_back((int)i);
+    }
+    s->live_workers = threads;
+    for (uint32_t t = 0; t < threads; ++t) s->workers.emplace_back(worker_main, s);
+    *out = s;
+    return SNK_OK;
+}
+
+extern "C" int snk_fasth_next(snk_fasth_stream* s, snk_fasth_batch* out, char* err, size_t errcap) {
+    if (!s || !out) return snk_fail(SNK_E_ARG, err, errcap, "snk_fasth_next: NULL argument");
+    memset(out, 0, sizeof *out);
+    std::unique_lock<std::mutex> lk(s->mu);
+    s->cv_ready.wait(lk, [&] { return !s->ready_q.empty() || s->live_workers == 0 || s->rc != SNK_OK; });
+    if (s->rc != SNK_OK) return snk_fail(s->rc, err, errcap, "%s", s->errmsg.c_str());
+    if (s->ready_q.empty()) return SNK_OK;          // n_pairs == 0: every file has been read to its end
+    const int b = s->ready_q.front();
+    s->ready_q.pop_front();
+    const snk_fasth_stream::batch& B = s->pool[b];
+    out->n_pairs = B.n_pairs; out->file = B.file; out->first_pair = B.first_pair; out->max_len = B.max_len;
+    out->ascii = B.ascii; out->quals = B.quals; out->lens = B.lens; out->bc_fields = B.bcf; out->text_bytes = B.text_bytes;
+    out->token = b + 1;
+    return SNK_OK;
+}
+
+extern "C" void snk_fasth_release(snk_fasth_stream* s, snk_fasth_batch* b) {
+    if (!s || !b || b->token == 0) return;
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->free_q.push_back((int)b->token - 1);
+    b->token = 0;
+    s->cv_free.notify_one();
+}
+
+extern "C" uint64_t snk_fasth_file_pairs(snk_fasth_stream* s, uint32_t file) {
+    if (!s || file >= s->file_pairs.size()) return 0;
+    std::lock_guard<std::mutex> lk(s->mu);
+    return s->file_pairs[file];
+}
+
+extern "C" void snk_fasth_close(snk_fasth_stream* s) {
+    if (!s) return;
+    { std::lock_guard<std::mutex> lk(s->mu); s->stop = true; s->cv_free.notify_all(); s->cv_ready.notify_all(); }
+    for (auto& t : s->workers) t.join();
+    for (auto& b : s->pool) free_batch(b);
+    delete s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Synthetic FASTH (tests, bench.py --ingest): pairs [first_pair, first_pair + n_pairs) of the synthetic linked-read model
+// (snk_synth.h) as one gzip file in the layout MultiFastqIter reads.  Barcode field = a whitelist-style 16-mer derived from the
+// barcode id + "-1" (+ ",raw" on every third pair), or a sequence off the whitelist for bc 0.
+namespace {
+void bc_seq(uint32_t id, char* out16) {
+    // a fixed bijection id -> 16-mer (id < 2^32): 2 bits per base
+    uint32_t x = id * 2654435761u;
+    for (int i = 0; i < 16; ++i) { out16[i] = "ACGT"[x & 3u]; x >>= 2; }
+}
+}  // namespace
+
+extern "C" void snk_synth_bc_seq(uint32_t id, char* out16) { bc_seq(id, out16); }
+
+extern "C" int snk_synth_fasth_write(const char* path, const snk_synth_params* sp, uint64_t first_pair, uint64_t n_pairs, int level, uint64_t* text_bytes,
+                                     char* err, size_t errcap) {
+    if (!path || !sp) return snk_fail(SNK_E_ARG, err, errcap, "snk_synth_fasth_write: NULL argument");
+    const uint32_t L = sp->read_len, rw = (L + 15) / 16;
+    if (L == 0 || L > 4096) return snk_fail(SNK_E_ARG, err, errcap, "snk_synth_fasth_write: bad read length");
+    char mode[8];
+    snprintf(mode, sizeof mode, "wb%d", level < 0 ? 1 : (level > 9 ? 9 : level));
+    gzFile f = gzopen(path, mode);
+    if (!f) return snk_fail(SNK_E_IO, err, errcap, "snk_synth_fasth_write: cannot open %s", path);
+    gzbuffer(f, 1 << 20);
+    std::vector<uint32_t> rows(2 * rw);
+    std::vector<uint8_t> q(2 * (size_t)L);
+    std::string rec;
+    uint64_t total = 0;
+    int rc = SNK_OK;
+    for (uint64_t pq = first_pair; pq < first_pair + n_pairs; ++pq) {
+        int32_t bc[2] = {0, 0};
+        for (int m = 0; m < 2; ++m) snk_synth_read(*sp, 2 * pq + m, rows.data() + m * rw, rw, q.data() + (size_t)m * L, &bc[m]);
+        rec.clear();
+        rec += "@SYN:"; rec += std::to_string(pq); rec += '\n';
+        for (int m = 0; m < 2; ++m) {
+            for (uint32_t i = 0; i < L; ++i) rec += "ACGT"[(rows[m * rw + (i >> 4)] >> (30 - 2 * (i & 15))) & 3u];
+            rec += '\n';
+            for (uint32_t i = 0; i < L; ++i) rec += (char)(q[(size_t)m * L + i] + 33);
+            rec += '\n';
+        }
+        char b16[16];
+        if (bc[0] > 0) { bc_seq((uint32_t)bc[0], b16); rec.append(b16, 16); rec += "-1"; }
+        else rec += "NNNNNNNNNNNNNNNN-1";
+        if (pq % 3 == 0) rec += ",RAWRAWRAWRAWRAWR";
+        rec += '\n';
+        rec += "FFFFFFFFFFFFFFFF\nACGTACGT\nFFFFFFFF\n";
+        total += rec.size();
+        if (gzwrite(f, rec.data(), (unsigned)rec.size()) != (int)rec.size()) { rc = snk_fail(SNK_E_IO, err, errcap, "snk_synth_fasth_write: write error on %s", path); break; }
+    }
+    if (gzclose(f) != Z_OK && rc == SNK_OK) rc = snk_fail(SNK_E_IO, err, errcap, "snk_synth_fasth_write: close error on %s", path);
+    if (text_bytes) *text_bytes = total;
+    return rc;
+}

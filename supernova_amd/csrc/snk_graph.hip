@@ -361,7 +361,7 @@ int snk_graph_sort(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t n, snk_u12
         hipLaunchKernelGGL(sorted_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, keys_out, n, bad);
         uint32_t h_bad = 0;
         SNK_HIP_TRY(hipMemcpyAsync(&h_bad, bad, 4, hipMemcpyDeviceToHost, st));
-        SNK_HIP_TRY(hipStreamSynchronize(st));
+        SNK_HIP_TRY(snk_sync(st));
         if (!h_bad) return SNK_OK;
         if (begin_bit == 0) break;
     }
@@ -413,7 +413,7 @@ static int rank_lists_wyllie(snk_ctx* ctx, hipStream_t st, uint32_t* link, uint6
             cur ^= 1;
             ++rounds_total;
             SNK_HIP_TRY(hipMemcpyAsync(h_flags, flags, 4, hipMemcpyDeviceToHost, st));
-            SNK_HIP_TRY(hipStreamSynchronize(st));
+            SNK_HIP_TRY(snk_sync(st));
             if (h_flags[0] == 0) { converged = true; break; }
         }
         if (converged) break;
@@ -434,7 +434,7 @@ static int rank_lists_wyllie(snk_ctx* ctx, hipStream_t st, uint32_t* link, uint6
         SNK_HIP_TRY(hipGetLastError());
     }
     SNK_HIP_TRY(hipMemcpyAsync(h_flags, flags, 8, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     *n_circles = h_flags[1];
     *rounds = rounds_total;
     (void)hipHostFree(h_flags);
@@ -547,7 +547,7 @@ static int rank_lists(snk_ctx* ctx, hipStream_t st, uint32_t* link, uint64_t n, 
     }
     uint32_t m32 = 0;
     SNK_HIP_TRY(hipMemcpyAsync(&m32, sid + ns, 4, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     const uint64_t m = m32;
     uint32_t* spl_state = flag32;      // flag32 is dead after the scan: reuse it for the compacted splitter list
     if (m) hipLaunchKernelGGL(spl_collect_kernel, dim3(nblk(ns)), dim3(TB), 0, st, spl, sid, ns, spl_state);
@@ -573,7 +573,7 @@ static int rank_lists(snk_ctx* ctx, hipStream_t st, uint32_t* link, uint64_t n, 
         cur ^= 1;
         ++r_done;
         SNK_HIP_TRY(hipMemcpyAsync(&h_flag, flags, 4, hipMemcpyDeviceToHost, st));
-        SNK_HIP_TRY(hipStreamSynchronize(st));
+        SNK_HIP_TRY(snk_sync(st));
         if (h_flag == 0) converged = true;
     }
     if (!converged)      // a circle that contains splitters: let the general algorithm find, cut and rank it
@@ -585,7 +585,7 @@ static int rank_lists(snk_ctx* ctx, hipStream_t st, uint32_t* link, uint64_t n, 
     SNK_HIP_TRY(hipMemsetAsync(flags, 0, 4, st));
     hipLaunchKernelGGL(unranked_check_kernel, dim3(nblk(ns)), dim3(TB), 0, st, rk, ns, flags);
     SNK_HIP_TRY(hipMemcpyAsync(&h_flag, flags, 4, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     if (h_flag)          // states no walk reached: a circle without a splitter
         return rank_lists_wyllie(ctx, st, link, n, weights, circ, rk_out, n_circles, rounds, err, errcap);
     *rk_out = rk;
@@ -770,7 +770,7 @@ static int graph_impl(snk_ctx* ctx, hipStream_t st, const snk_u128* keys, const 
     uint32_t h_nu = 0;
     SNK_HIP_TRY(hipMemcpyAsync(&h_nu, hidx + n, 4, hipMemcpyDeviceToHost, st));
     SNK_HIP_TRY(hipMemcpyAsync(&h_tot, hoff + n, 8, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     uint64_t n_unitigs = h_nu, total_bases = h_tot;
     uint64_t *poff, *uoff;
     uint8_t* bases;
@@ -1192,7 +1192,7 @@ static int chunk_owners(snk_ctx* ctx, hipStream_t st, uint32_t* nch /*[count+1],
     if (rc) return rc;
     uint32_t total = 0;
     SNK_HIP_TRY(hipMemcpyAsync(&total, choff + count, 4, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     uint32_t* owner;
     G_ALLOC(owner, uint32_t, (uint64_t)total + 1);
     SNK_HIP_TRY(hipMemsetAsync(owner, 0, ((uint64_t)total + 1) * 4, st));
@@ -1318,7 +1318,7 @@ int snk_join_emit(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
     uint64_t h_tot = 0;
     SNK_HIP_TRY(hipMemcpyAsync(&h_nu, hidx + F, 4, hipMemcpyDeviceToHost, st));
     SNK_HIP_TRY(hipMemcpyAsync(&h_tot, hoff + F, 8, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     const uint64_t U = h_nu;
     uint64_t *poff, *uoff;
     uint8_t *ucirc, *prov, *final_bases, *urev;
@@ -1343,7 +1343,7 @@ int snk_join_emit(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
         hipLaunchKernelGGL(jcirc_list_kernel, dim3(nblk(U)), dim3(TB), 0, st, ucirc, U, clist, ccnt);
         uint32_t h_nc = 0;
         SNK_HIP_TRY(hipMemcpyAsync(&h_nc, ccnt, 4, hipMemcpyDeviceToHost, st));
-        SNK_HIP_TRY(hipStreamSynchronize(st));
+        SNK_HIP_TRY(snk_sync(st));
         if (h_nc) {
             if (K == 48) hipLaunchKernelGGL((jcircle_kernel<48>), dim3(h_nc), dim3(256), 0, st, clist, uoff, prov, final_bases);
             else hipLaunchKernelGGL((jcircle_kernel<60>), dim3(h_nc), dim3(256), 0, st, clist, uoff, prov, final_bases);
@@ -1395,7 +1395,7 @@ int snk_join_emit(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
         if (ototal) hipLaunchKernelGGL(jorder_copy_kernel, dim3(ototal), dim3(256), 0, st, oowner, ochoff, noff, uoff, oi_out, final_bases, ucirc, obases, ocirc, (const uint32_t*)ugroup, ogroup);
         SNK_HIP_TRY(hipGetLastError());
     }
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     out->n_unitigs = U;
     out->total_bases = h_tot;
     out->unitig_off = noff;
@@ -1420,7 +1420,7 @@ int snk_spectrum(snk_ctx* ctx, hipStream_t st, const uint32_t* counts, uint64_t 
         if (rc) return rc;
         SNK_HIP_TRY(rocprim::reduce(tmp, tb, counts, d_max, 0u, (size_t)n, rocprim::maximum<uint32_t>(), st));
         SNK_HIP_TRY(hipMemcpyAsync(&h_max, d_max, 4, hipMemcpyDeviceToHost, st));
-        SNK_HIP_TRY(hipStreamSynchronize(st));
+        SNK_HIP_TRY(snk_sync(st));
     }
     if (h_max > 0xFFFFFFu) h_max = 0xFFFFFFu;
     const uint32_t nbins = h_max + 1 > 65536u ? h_max + 1 : 65536u;
@@ -1465,7 +1465,7 @@ int snk_dist_links_apply(snk_ctx* ctx, hipStream_t st, const snk_frag_out* fr, c
     SNK_HIP_TRY(hipMemsetAsync(flink, 0xFF, (ne + 2) * 4, st));
     if (nq) hipLaunchKernelGGL(jlink_apply_kernel, dim3(nblk(nq)), dim3(TB), 0, st, (const unsigned long long*)d_qbuf, (const uint32_t*)d_ans, nq, flink);
     SNK_HIP_TRY(hipGetLastError());
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     *flink_out = flink;
     return SNK_OK;
 }
@@ -1494,7 +1494,7 @@ int snk_prank_begin(snk_ctx* ctx, hipStream_t st, uint64_t F, const uint32_t* nk
     }
     uint32_t m32 = 0;
     SNK_HIP_TRY(hipMemcpyAsync(&m32, sid + ns, 4, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     const uint64_t m = m32;
     P->m = m;
     P->spl_state = flag32;             // flag32 is dead after the scan: reuse it for the compacted splitter list
@@ -1527,7 +1527,7 @@ int snk_prank_walk(snk_ctx* ctx, hipStream_t st, snk_prank* P, const uint4* w1_a
     if (m) hipLaunchKernelGGL(prank_unzip_kernel, dim3(nblk(m)), dim3(TB), 0, st, w1_all, m, rn[0], rd[0], rt[0], tot);
     unsigned long long h_tot = 0;
     SNK_HIP_TRY(hipMemcpyAsync(&h_tot, tot, 8, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     if (h_tot != P->ns) { *circles = 1; return SNK_OK; }          // states no walk reached: a circle without a splitter
     uint32_t h_flag = 0;
     int max_rounds = 2;
@@ -1540,7 +1540,7 @@ int snk_prank_walk(snk_ctx* ctx, hipStream_t st, snk_prank* P, const uint4* w1_a
         cur ^= 1;
         ++*rounds;
         SNK_HIP_TRY(hipMemcpyAsync(&h_flag, flags, 4, hipMemcpyDeviceToHost, st));
-        SNK_HIP_TRY(hipStreamSynchronize(st));
+        SNK_HIP_TRY(snk_sync(st));
         if (h_flag == 0) converged = true;
     }
     if (!converged) { *circles = 1; return SNK_OK; }               // a circle that contains splitters
@@ -1553,7 +1553,7 @@ int snk_prank_walk(snk_ctx* ctx, hipStream_t st, snk_prank* P, const uint4* w1_a
     if (rc) return rc;
     uint64_t n_rec = 0;
     SNK_HIP_TRY(hipMemcpyAsync(&n_rec, pos + cnt, 8, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     G_ALLOC(P->rec, uint4, n_rec + 1);
     if (cnt) hipLaunchKernelGGL(spl_walk2p_kernel, dim3(nblk(cnt)), dim3(TB), 0, st, P->wrec, P->spl_state, P->w, rd[cur], rt[cur], P->k0, cnt, pos, P->rec);
     SNK_HIP_TRY(hipGetLastError());
@@ -1584,7 +1584,7 @@ int snk_prank_apply(snk_ctx* ctx, hipStream_t st, const void* d_rec, uint64_t n,
     if (n_local_states) hipLaunchKernelGGL(unranked_check_kernel, dim3(nblk(n_local_states)), dim3(TB), 0, st, (const uint2*)rk, n_local_states, flag + 1);
     uint32_t h[2] = {0, 0};
     SNK_HIP_TRY(hipMemcpyAsync(h, flag, 8, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     if (h[0] || h[1]) return snk_fail(SNK_E_INTERNAL, err, errcap, "partitioned ranking: %s", h[0] ? "a record for a foreign state arrived" : "a local state was not ranked");
     *rk_out = rk;
     return SNK_OK;

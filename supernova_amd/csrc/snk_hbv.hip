@@ -381,7 +381,7 @@ extern "C" int snk_dev_hbv(snk_ctx* ctx, uint32_t K, uint64_t U, const void* d_u
     SNK_HIP_TRY(rocprim::radix_sort_pairs(tmp, tbx, keys, keys2, codes, codes2, (size_t)n4, 0u, 128u, st));
     uint32_t h_flags[4] = {0, 0, 0, 0};
     SNK_HIP_TRY(hipMemcpyAsync(h_flags, flags, 16, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     if (h_flags[0]) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_hbv: a unitig is shorter than K");
     const uint64_t n_ee = n4 - 2ull * h_flags[1];            // the missing ends of palindromes sorted last
     const unsigned ge = (unsigned)((n_ee + HB - 1) / HB);
@@ -401,7 +401,7 @@ extern "C" int snk_dev_hbv(snk_ctx* ctx, uint32_t K, uint64_t U, const void* d_u
     SNK_HIP_TRY(hipMemcpyAsync(h_vtx.data(), vtx_of, n4 * 4, hipMemcpyDeviceToHost, st));
     SNK_HIP_TRY(hipMemcpyAsync(h_pal.data(), palr, U, hipMemcpyDeviceToHost, st));
     SNK_HIP_TRY(hipMemcpyAsync(h_order.data(), order, U * 4, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     std::vector<uint64_t> h_run(nruns + 1);
     SNK_HIP_TRY(hipMemcpy(h_run.data(), run_beg, (size_t)nruns * 8, hipMemcpyDeviceToHost));
     h_run[nruns] = n_ee;

@@ -263,7 +263,7 @@ int count_graph_impl(snk_ctx* ctx, const snk_reads* in, const snk_params* p, snk
         hipLaunchKernelGGL(bv_sizes_kernel, dim3((unsigned)((U + 256) / 256)), dim3(256), 0, st, d_off, order, U, want_image ? 1 : 0, sz);
         SNK_HIP_TRY(rocprim::exclusive_scan(tmp, tb2, sz, noff, (uint64_t)0, (size_t)(U + 1), rocprim::plus<uint64_t>(), st));
         SNK_HIP_TRY(hipMemcpyAsync(&total, noff + U, 8, hipMemcpyDeviceToHost, st));
-        SNK_HIP_TRY(hipStreamSynchronize(st));
+        SNK_HIP_TRY(snk_sync(st));
     }
     uint8_t* d_out;
     if ((rc = arena(ctx, total + 16, &d_out, err, errcap))) return rc;
@@ -285,7 +285,7 @@ int count_graph_impl(snk_ctx* ctx, const snk_reads* in, const snk_params* p, snk
         if (U) SNK_HIP_TRY(hipMemcpyAsync(out->unitig_off, noff, (U + 1) * 8, hipMemcpyDeviceToHost, st));
         if (total) SNK_HIP_TRY(hipMemcpyAsync(out->unitig_bases, d_out, total, hipMemcpyDeviceToHost, st));
     }
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     return SNK_OK;
 }
 

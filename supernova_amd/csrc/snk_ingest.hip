@@ -165,7 +165,7 @@ extern "C" int snk_dev_bc_ids(snk_ctx* ctx, const snk_bc_index* ix, const void* 
     SNK_HIP_TRY(hipGetLastError());
     uint32_t h_err[2] = {0, 0};
     SNK_HIP_TRY(hipMemcpyAsync(h_err, ix->d_err, 8, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     if (h_err[0]) return snk_fail(SNK_E_ARG, err, errcap, "invalid gem group string in %u barcode fields (utils.rs:138)", h_err[0]);
     if (h_err[1]) return snk_fail(SNK_E_ARG, err, errcap, "too many gem groups - BC id overflowed (%u fields, utils.rs:157)", h_err[1]);
     return SNK_OK;

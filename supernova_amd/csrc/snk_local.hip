@@ -846,7 +846,7 @@ static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* er
     SNK_HIP_TRY(hipGetLastError());
     uint32_t h_nbig = 0;
     SNK_HIP_TRY(hipMemcpyAsync(&h_nbig, ctr, 4, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     B->nbig = h_nbig;
     if (h_nbig)
         hipLaunchKernelGGL((bl_prune_kernel<K, BCAP, BT, true, GR>), dim3(h_nbig), dim3(BT), 0, st, (const uint4*)B->desc, NBh, sh,
@@ -866,7 +866,7 @@ static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* er
     }
     unsigned long long h_bnd = 0;
     SNK_HIP_TRY(hipMemcpyAsync(&h_bnd, d_sum, 8, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     B->n_boundary = h_bnd;
     uint64_t tg = 1024;
     while (tg < 2 * h_bnd) tg <<= 1;
@@ -917,7 +917,7 @@ static int bl_fragments_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, cons
     uint64_t h_B = 0;
     SNK_HIP_TRY(hipMemcpyAsync(&h_F, foff + nchunks, 4, hipMemcpyDeviceToHost, st));
     SNK_HIP_TRY(hipMemcpyAsync(&h_B, boff + nchunks, 8, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     // the open paths' bases: every node once + K-1 per path; circle nodes are not in any path, their bases come from the pool
     unsigned long long* xcur;
     G_ALLOC(xcur, unsigned long long, 2);
@@ -949,7 +949,7 @@ static int bl_fragments_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, cons
                                out->hl_self, out->hl_nb, out->boff, out->bases, out->fgroup, out->sfrag, xp);
         SNK_HIP_TRY(hipGetLastError());
         SNK_HIP_TRY(hipMemcpyAsync(h_x, xcur, 16, hipMemcpyDeviceToHost, st));
-        SNK_HIP_TRY(hipStreamSynchronize(st));
+        SNK_HIP_TRY(snk_sync(st));
         if (h_x[0] <= xf_cap && h_x[1] <= xb_cap) break;
         if (attempt == 1) return snk_fail(SNK_E_INTERNAL, err, errcap, "bucket-local graph: circle pool overflow");
         xf_cap = h_x[0] + 64;          // exact requirement (the counters keep counting past the capacity)
@@ -1080,7 +1080,7 @@ int snk_bl_dist_plan(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, unsigned lon
     else hipLaunchKernelGGL((bl_query_kernel<60, false>), dim3(grid), dim3(TB), lds, st, B->tab->keys, (const uint8_t*)B->premote, n, B->NB_total, B->NBl, B->world, B->qcount, (unsigned long long*)nullptr);
     SNK_HIP_TRY(hipGetLastError());
     SNK_HIP_TRY(hipMemcpyAsync(h_qcount, B->qcount, B->world * 8ull, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     return SNK_OK;
 }
 int snk_bl_dist_fill(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, const unsigned long long* d_qoff, void* d_qbuf, char* err, size_t errcap) {
@@ -1119,6 +1119,6 @@ int snk_bl_dist_fragments(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, const u
     da.my_node_off = my_node_off;
     int rc = B->K == 48 ? bl_fragments_impl<48, true, false>(ctx, st, B, da, out, err, errcap) : bl_fragments_impl<60, true, false>(ctx, st, B, da, out, err, errcap);
     if (rc) return rc;
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     return SNK_OK;
 }

@@ -642,7 +642,7 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
     SNK_HIP_TRY(hipMemcpyAsync(&h_off_last, d_uoff + U, 8, hipMemcpyDeviceToHost, st));
     // seeds on a short hanging edge are dropped (BuildReadQGraph48.cc:1240-1247): a property of the edge, decided here once
     std::vector<uint8_t> drop((size_t)E + 1, 0);
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     {
         std::vector<uint64_t> h_uoff(U + 1);
         if (U) SNK_HIP_TRY(hipMemcpy(h_uoff.data(), d_uoff, (U + 1) * 8, hipMemcpyDeviceToHost));
@@ -668,7 +668,7 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
     SNK_HIP_TRY(hipMemsetAsync(dslot, 0xFF, cap * 32, st));
     if (total_bases) hipLaunchKernelGGL((dict_build_kernel<K>), dim3((unsigned)((total_bases + 255) / 256)), dim3(256), 0, st, d_uoff, d_ubases, U, total_bases, lock, dslot, cap);
     SNK_HIP_TRY(hipGetLastError());
-    SNK_HIP_TRY(hipStreamSynchronize(st));            // drop[] has been copied; the lock words are dead
+    SNK_HIP_TRY(snk_sync(st));            // drop[] has been copied; the lock words are dead
     snk_ctx_release_block(ctx, lock);
     G.dslot = dslot; G.dcap = cap;
     SNK_HIP_TRY(hipEventRecord(e1, st));
@@ -716,7 +716,7 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
         }
         SNK_HIP_TRY(hipGetLastError());
         SNK_HIP_TRY(hipMemcpyAsync(h_cur, cursor, 32, hipMemcpyDeviceToHost, st));
-        SNK_HIP_TRY(hipStreamSynchronize(st));
+        SNK_HIP_TRY(snk_sync(st));
         if (h_cur[3] > rcap) {                       // more reads to redo than the list holds: once more with a longer list
             if (attempt == 2) return snk_fail(SNK_E_INTERNAL, err, errcap, "snk_dev_path_reads: redo list overflow");
             snk_ctx_release_block(ctx, redo); redo = nullptr; rcap = h_cur[3] + 1024;
@@ -730,7 +730,7 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
             hipLaunchKernelGGL((path_kernel<K, PCAP, PMAX, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
             SNK_HIP_TRY(hipGetLastError());
             SNK_HIP_TRY(hipMemcpyAsync(h_cur, cursor, 32, hipMemcpyDeviceToHost, st));
-            SNK_HIP_TRY(hipStreamSynchronize(st));
+            SNK_HIP_TRY(snk_sync(st));
         }
         if (h_cur[1] & 1ull) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_dev_path_reads: a read has more than %d path parts or %d edges", PCAP, PMAX);
         const bool e_over = (h_cur[1] & 2ull) != 0, b_over = want_bcs && h_cur[2] > ubcap;
@@ -743,12 +743,12 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
     if ((rc = scan64(ctx, st, n64, pos, n + 1, err, errcap))) return rc;
     uint64_t total = 0;
     SNK_HIP_TRY(hipMemcpyAsync(&total, pos + n, 8, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     if ((rc = dev(ctx, total + 1, &edges, err, errcap))) return rc;
     if (n) hipLaunchKernelGGL(path_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out_n, out_e0, out_start, pos, scratch, n, edges);
     SNK_HIP_TRY(hipGetLastError());
     SNK_HIP_TRY(hipEventRecord(e2, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     snk_ctx_release_block(ctx, scratch);
     out->n_reads = n;
     out->n_edges_total = total;
@@ -778,14 +778,14 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
             hipLaunchKernelGGL(ubc_flag_kernel, dim3((unsigned)((nkeys + 256) / 256)), dim3(256), 0, st, ks, nkeys, flag);
             if ((rc = scan64(ctx, st, flag, upos, nkeys + 1, err, errcap))) return rc;
             SNK_HIP_TRY(hipMemcpyAsync(&n_unique, upos + nkeys, 8, hipMemcpyDeviceToHost, st));
-            SNK_HIP_TRY(hipStreamSynchronize(st));
+            SNK_HIP_TRY(snk_sync(st));
         }
         if ((rc = dev(ctx, n_unique + 1, &bcs, err, errcap))) return rc;
         SNK_HIP_TRY(hipMemsetAsync(per_u, 0, (U + 2) * 8, st));
         if (nkeys) hipLaunchKernelGGL(ubc_scatter_kernel, dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, st, ks, flag, upos, nkeys, bcs, per_u);
         if ((rc = scan64(ctx, st, per_u, uoff_out, U + 1, err, errcap))) return rc;
         SNK_HIP_TRY(hipGetLastError());
-        SNK_HIP_TRY(hipStreamSynchronize(st));
+        SNK_HIP_TRY(snk_sync(st));
         out->unitig_bc_off = uoff_out;
         out->unitig_bcs = bcs;
         out->n_unitig_bcs = n_unique;

@@ -147,7 +147,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
         if (rc) return rc;
     }
     tm.mark();  // 6
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     out->counts = go.counts;
     out->ctx = go.ctx;
     out->spectrum = go.spectrum;
@@ -180,6 +180,6 @@ extern "C" int snk_dev_download(snk_ctx* ctx, const void* d_src, void* h_dst, si
     if (bytes == 0) return SNK_OK;
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     SNK_HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     return SNK_OK;
 }

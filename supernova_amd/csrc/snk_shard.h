@@ -1,0 +1,41 @@
+// snk_shard.h -- per-context session state of the minimiser-sharded path (snk_dist.hip, snk_shard_step.hip).
+#pragma once
+#include "snk_ctx.h"
+#include "snk_graph.h"
+#include "snk_kernels.h"
+#include "snk_stages.h"
+
+struct snk_shard_state {
+    snk_dev_reads reads;
+    snk_params params;
+    uint32_t rank = 0, world = 1, NB_total = 0, NBl = 0;
+    const uint16_t* good_len = nullptr;
+    uint32_t* status = nullptr;
+    snk_partition part{};
+    snk_table tab{};
+    snk_dist_graph g{};
+    snk_bl_state bl{};
+    snk_frag_out frags{};              // this rank's fragments (valid from snk_shard_fragments on)
+    const unsigned long long* d_node_off = nullptr;
+    unsigned long long my_node_off = 0, my_end_base = 0;
+    unsigned long long *lq_count = nullptr, *lq_cursor = nullptr;
+    // owner-side join: placement of this rank's fragments, destination rank of each, route cursors
+    snk_placement pl{};
+    uint32_t* dest = nullptr;
+    unsigned long long *rt_count = nullptr, *rt_cursor = nullptr;      // [2][world]: fragments, base bytes
+    unsigned long long my_frag_off = 0;
+    uint64_t n_frags_total = 0;
+    uint32_t join_circles = 0, join_rounds = 0;
+    snk_prank pr{};
+    const uint32_t* nk_all = nullptr;
+    snk_phase_timer* tm = nullptr;
+};
+
+
+inline snk_shard_state* snk_shard_state_of(snk_ctx* ctx) {
+    if (!ctx->shard) ctx->shard = new snk_shard_state();
+    return static_cast<snk_shard_state*>(ctx->shard);
+}
+// trim + one-pass minimiser partition over all NB_total buckets of the job (what snk_shard_hist does before it copies the histogram out)
+int snk_shard_begin(snk_ctx* ctx, const snk_dev_reads* in, const snk_params* p, uint32_t rank, uint32_t world, uint32_t NB_total,
+                    uint64_t* n_instances, hipStream_t st, char* err, size_t errcap);

@@ -1,0 +1,549 @@
+// snk_shard_step.hip -- one step of the minimiser-sharded (multi-GPU) count+graph path, entirely behind the C ABI:
+// a C++ host (supernova_amd/csrc/host/snk_asm_sn.cc) or any other caller hands in its slab of reads and a communicator
+// (snk_comm.hip: RCCL over xGMI, or in-process ranks for tests) and gets its share of the table and its unitigs back.
+//
+// What it replaces: tada's MSP -> SHARD_ASM -> MAIN_ASM_SN chain with its shard-file exchange
+// (lib/tada/src/cmd_msp.rs:38-80, cmd_shard_asm.rs:37-94, cmd_main_asm.rs:25-89;
+// lib/tada/external/rust-shardio/src/shard.rs:184-211,488-493) and the in-memory swizzle of MapReduceEngine.h:362-385.
+//
+//   partition (all NB_total buckets, one pass) -> [histograms] -> compaction of the buckets other ranks own
+//   -> [supermer records, in bucket ranges] -> count (range r while range r+1 is on the wire; the rank's own buckets are
+//   counted IN PLACE from the partition's slots: no copy, no compaction) -> bucket-local prune -> [membership queries /
+//   answers] -> fragments -> [link queries / answers] -> owner-side join: [link structure] -> ranking (partitioned:
+//   [splitters], [ranks to owners]) -> placement -> [fragments to the owners of their unitigs] -> unitigs.
+// [..] = an exchange.  The host learns sizes through snk_comm::gather_counts only (device counters of all ranks -> host).
+#include <string.h>
+
+#include <rocprim/rocprim.hpp>
+
+#include <vector>
+
+#include "snk_comm.h"
+#include "snk_common.h"
+#include "snk_shard.h"
+
+// the stage entry points of snk_dist.hip (declared in include/snk.h)
+
+namespace {
+
+typedef unsigned long long ull;
+
+__global__ void __launch_bounds__(256) range_sum_kernel(const uint32_t* __restrict__ h, uint32_t NBl, uint32_t R, ull* __restrict__ out) {
+    // block (row, r): sum of h[row*NBl + bounds(r) .. bounds(r+1)), bounds(q) = NBl*q/R
+    const uint32_t row = blockIdx.x / R, r = blockIdx.x % R;
+    const uint64_t lo = (uint64_t)NBl * r / R, hi = (uint64_t)NBl * (r + 1) / R;
+    ull v = 0;
+    for (uint64_t b = lo + threadIdx.x; b < hi; b += 256) v += h[(uint64_t)row * NBl + b];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    __shared__ ull part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+// segment tables of the count kernel on a rank of a W > 1 job: T[0..nseg) x NBl starts, then nseg x NBl ends (record indices
+// relative to the RECEIVE buffer; the rank's own records stay in the partition's slot array, `delta` records away -- the
+// arithmetic wraps, the kernel adds the index to the buffer's address)
+__global__ void __launch_bounds__(256) seg_table_kernel(const ull* __restrict__ roff /* [W*NBl] */, const uint32_t* __restrict__ hrecv /* [W][NBl], row me = 0 */,
+                                                        const uint32_t* __restrict__ cursor /* [NB_total] */, const uint64_t* __restrict__ pseg /* part.seg */,
+                                                        uint32_t W, uint32_t me, uint32_t NBl, uint32_t NB_total, uint32_t cap, uint32_t nseg, ull delta,
+                                                        uint64_t* __restrict__ T) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= NBl) return;
+    uint64_t* beg = T;
+    uint64_t* end = T + (uint64_t)nseg * NBl;
+    for (uint32_t s = 0; s < W; ++s) {
+        uint64_t x, y;
+        if (s == me) {
+            const uint32_t gb = me * NBl + b;
+            const uint32_t c = cursor[gb];
+            x = delta + (uint64_t)gb * cap;
+            y = x + (c < cap ? c : cap);
+        } else {
+            x = roff[(uint64_t)s * NBl + b];
+            y = x + hrecv[(uint64_t)s * NBl + b];
+        }
+        beg[(uint64_t)s * NBl + b] = x;
+        end[(uint64_t)s * NBl + b] = y;
+    }
+    if (nseg > W) {      // the partition's overflow segment of my own buckets
+        const uint32_t gb = me * NBl + b;
+        const uint64_t x = pseg[2ull * NB_total + gb], y = pseg[3ull * NB_total + gb];
+        beg[(uint64_t)W * NBl + b] = y > x ? delta + x : 0;
+        end[(uint64_t)W * NBl + b] = y > x ? delta + y : 0;
+    }
+}
+
+struct step_ctx {
+    snk_ctx* ctx;
+    snk_comm* comm;
+    hipStream_t st;
+    char* err;
+    size_t errcap;
+    uint32_t W, me;
+    // pinned staging for the small host -> device uploads of the step (offset tables): a bump allocator, reset per step
+    ull* pin = nullptr;
+    size_t pin_cap = 0, pin_used = 0;
+};
+
+struct shard_host {                 // per-context host resources of the step (kept across steps)
+    ull* pin = nullptr;
+    size_t pin_cap = 0;
+    hipStream_t cstream = nullptr;  // the exchange's stream (the count of range r runs while range r+1 is on the wire)
+    std::vector<hipEvent_t> ev;
+    ~shard_host() {
+        if (pin) (void)hipHostFree(pin);
+        if (cstream) (void)hipStreamDestroy(cstream);
+        for (auto e : ev) (void)hipEventDestroy(e);
+    }
+};
+
+#define TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+#define ALLOC(ptr, type, count) do { void* _p = nullptr; int _rc = snk_ctx_alloc(X.ctx, sizeof(type) * (size_t)(count), &_p, X.err, X.errcap); if (_rc) return _rc; ptr = (type*)_p; } while (0)
+
+// host values -> a device array (stream-ordered copy out of the pinned staging area)
+int upload(step_ctx& X, const ull* h, size_t n, ull** d_out) {
+    char* err = X.err; size_t errcap = X.errcap;
+    if (X.pin_used + n > X.pin_cap) return snk_fail(SNK_E_INTERNAL, err, errcap, "shard step: staging area exhausted");
+    ull* d;
+    ALLOC(d, ull, n + 1);
+    ull* p = X.pin + X.pin_used;
+    X.pin_used += n;
+    memcpy(p, h, n * 8);
+    SNK_HIP_TRY(hipMemcpyAsync(d, p, n * 8, hipMemcpyHostToDevice, X.st));
+    *d_out = d;
+    return SNK_OK;
+}
+
+// all-to-all of variable pieces whose per-destination counts (items) every rank holds in a DEVICE array: one read-back tells
+// every rank the whole matrix
+int exchange_counts(step_ctx& X, const ull* d_counts, uint32_t k, std::vector<ull>& all) {
+    all.assign((size_t)X.W * k, 0);
+    return X.comm->gather_counts(d_counts, k, all.data(), X.st, X.err, X.errcap);
+}
+
+int a2a_items(step_ctx& X, const void* send, const std::vector<ull>& send_items, void* recv, const std::vector<ull>& recv_items, size_t item_bytes) {
+    const uint32_t W = X.W;
+    std::vector<uint64_t> sbeg(W), scnt(W), rbeg(W), rcnt(W);
+    uint64_t a = 0, b = 0;
+    for (uint32_t p = 0; p < W; ++p) { sbeg[p] = a; scnt[p] = send_items[p] * item_bytes; a += scnt[p]; rbeg[p] = b; rcnt[p] = recv_items[p] * item_bytes; b += rcnt[p]; }
+    return X.comm->a2a(send, sbeg.data(), scnt.data(), recv, rbeg.data(), rcnt.data(), X.st, X.err, X.errcap);
+}
+
+struct range_wait { hipStream_t st; hipEvent_t* ev; uint32_t n; };
+int range_ready(void* user, uint32_t r) {
+    range_wait* w = (range_wait*)user;
+    if (r >= w->n) return 1;
+    return hipStreamWaitEvent(w->st, w->ev[r], 0) == hipSuccess ? 0 : 1;
+}
+
+uint32_t plan_buckets(uint64_t inst_ub, uint32_t world, uint32_t K, uint32_t forced) {
+    uint64_t nb = forced;
+    if (!nb) {
+        const uint64_t target = snk_env_u32("SNK_TARGET_INST", K == 48 ? 5000u : 3500u);
+        nb = (inst_ub + target - 1) / target;
+        if (nb < 1) nb = 1;
+        if (nb > (1ull << 26)) nb = 1ull << 26;
+    }
+    const uint64_t floor_ = (inst_ub >> 20) + 1;       // at most ~1 M instances per bucket (one workgroup counts a bucket)
+    if (nb < floor_) nb = floor_;
+    nb = (nb + world - 1) / world * world;
+    return (uint32_t)nb;
+}
+
+template <typename In, typename Out>
+int excl_scan(step_ctx& X, In in, Out* out, size_t n, Out init) {
+    char* err = X.err; size_t errcap = X.errcap;
+    size_t tb = 0;
+    SNK_HIP_TRY(rocprim::exclusive_scan((void*)nullptr, tb, in, out, init, n, rocprim::plus<Out>(), X.st));
+    void* tmp;
+    TRY(snk_ctx_alloc(X.ctx, tb, &tmp, err, errcap));
+    SNK_HIP_TRY(rocprim::exclusive_scan(tmp, tb, in, out, init, n, rocprim::plus<Out>(), X.st));
+    return SNK_OK;
+}
+
+int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_params* p, uint64_t total_reads, uint32_t flags, snk_shard_result* out) {
+    snk_ctx* ctx = X.ctx;
+    snk_comm* comm = X.comm;
+    hipStream_t st = X.st;
+    char* err = X.err;
+    size_t errcap = X.errcap;
+    const uint32_t W = X.W, me = X.me, K = p->K;
+    const uint64_t syncs0 = snk_sync_count();
+    comm->bytes_sent = 0;
+    snk_phase_timer tm(st);
+    tm.mark();   // 0
+    // ---- the job's bucket count: from the caller's read total, or from an exchange of the slabs' sizes
+    uint64_t inst_ub = 0;
+    const uint64_t kpr = in->read_len >= K ? in->read_len - K + 1 : 0;
+    if (p->n_buckets == 0) {
+        if (total_reads) inst_ub = total_reads * kpr;
+        else if (W == 1) inst_ub = in->n_reads * kpr;
+        else {
+            ull mine = in->n_reads, *d_mine;
+            // (a scratch block next to what the previous step still holds; snk_shard_begin hands everything back)
+            TRY(upload(X, &mine, 1, &d_mine));
+            std::vector<ull> all;
+            TRY(exchange_counts(X, d_mine, 1, all));
+            for (ull v : all) inst_ub += v * kpr;
+        }
+    }
+    const uint32_t NB_total = plan_buckets(inst_ub, W, K, p->n_buckets);
+    const uint32_t NBl = NB_total / W;
+    // ---- trim + one-pass partition over all buckets of the job
+    uint64_t n_inst = 0;
+    TRY(snk_shard_begin(ctx, in, p, me, W, NB_total, &n_inst, st, err, errcap));
+    snk_shard_state* S = snk_shard_state_of(ctx);
+    const snk_partition& part = S->part;
+    if (part.n_supermers >= (1ull << 32)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "more than 2^32 supermers on one rank");
+    tm.mark();   // 1
+    const int has_bc = in->bc ? 1 : 0;
+    const uint64_t inst_hint = total_reads ? total_reads * kpr / W : (inst_ub ? inst_ub / W : n_inst);
+    uint64_t exch_records = 0;
+    if (W == 1) {
+        // one rank owns every bucket: the slots are counted where they are (exactly the one-GPU path)
+        tm.mark();   // 2
+        tm.mark();   // 3
+        TRY(snk_stage_count_table(ctx, st, K, part.records, part.seg, part.seg + NB_total, 2 * NB_total, part.nseg, NB_total, p->min_freq,
+                                  has_bc ? p->min_bc : 0u, 0u, inst_hint, S->status, false, &S->tab, err, errcap));
+        snk_ctx_release_block(ctx, part.records);
+    } else {
+        // ---- histograms: row p of my cursor array goes to rank p
+        uint32_t *hrecv, *hsend_x;
+        ALLOC(hrecv, uint32_t, (uint64_t)NB_total + 4);
+        ALLOC(hsend_x, uint32_t, (uint64_t)NB_total + 4);
+        {
+            std::vector<uint64_t> beg(W), cnt(W, (uint64_t)NBl * 4);
+            for (uint32_t q = 0; q < W; ++q) beg[q] = (uint64_t)q * NBl * 4;
+            TRY(comm->a2a(part.cursor, beg.data(), cnt.data(), hrecv, beg.data(), cnt.data(), st, err, errcap));
+        }
+        // my own buckets take no part in the exchange: zero rows in both directions
+        SNK_HIP_TRY(hipMemcpyAsync(hsend_x, part.cursor, (size_t)NB_total * 4, hipMemcpyDeviceToDevice, st));
+        SNK_HIP_TRY(hipMemsetAsync(hsend_x + (uint64_t)me * NBl, 0, (size_t)NBl * 4, st));
+        SNK_HIP_TRY(hipMemsetAsync(hrecv + (uint64_t)me * NBl, 0, (size_t)NBl * 4, st));
+        uint32_t R = snk_env_u32("SNK_EXCHANGE_RANGES", 4);
+        if (R < 1) R = 1;
+        if (R > NBl) R = NBl;
+        if (R > 64) R = 64;
+        ull* d_rs;      // [2][W][R] records per (destination, range) and per (source, range)
+        ALLOC(d_rs, ull, 2ull * W * R + 1);
+        hipLaunchKernelGGL(range_sum_kernel, dim3(W * R), dim3(256), 0, st, hsend_x, NBl, R, d_rs);
+        hipLaunchKernelGGL(range_sum_kernel, dim3(W * R), dim3(256), 0, st, hrecv, NBl, R, d_rs + (size_t)W * R);
+        uint32_t* soff32;
+        ull* roff;
+        ALLOC(soff32, uint32_t, (uint64_t)NB_total + 4);
+        ALLOC(roff, ull, (uint64_t)NB_total + 4);
+        TRY((excl_scan<const uint32_t*, uint32_t>(X, hsend_x, soff32, (size_t)NB_total + 1, 0u)));
+        {
+            auto it = rocprim::make_transform_iterator(hrecv, [] __device__(uint32_t v) { return (ull)v; });
+            TRY((excl_scan<decltype(it), ull>(X, it, roff, (size_t)NB_total + 1, 0ull)));
+        }
+        std::vector<ull> h_rs(2ull * W * R);
+        SNK_HIP_TRY(hipMemcpyAsync(h_rs.data(), d_rs, h_rs.size() * 8, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(snk_sync(st));          // read-back: piece sizes of the record exchange (both directions)
+        uint64_t n_send = 0, n_recv = 0;
+        for (size_t q = 0; q < (size_t)W * R; ++q) { n_send += h_rs[q]; n_recv += h_rs[(size_t)W * R + q]; }
+        uint4 *sendb, *recvb;
+        ALLOC(sendb, uint4, 2 * n_send + 2);
+        ALLOC(recvb, uint4, 2 * n_recv + 2);
+        TRY(snk_stage_partition_compact_remote(ctx, st, &part, soff32, sendb, me * NBl, (me + 1) * NBl, err, errcap));
+        tm.mark();   // 2
+        // ---- the records, range by range on the exchange's stream
+        if (H.ev.size() < R + 1) { const size_t o = H.ev.size(); H.ev.resize(R + 1); for (size_t q = o; q < H.ev.size(); ++q) SNK_HIP_TRY(hipEventCreateWithFlags(&H.ev[q], hipEventDisableTiming)); }
+        if (!H.cstream) SNK_HIP_TRY(hipStreamCreateWithFlags(&H.cstream, hipStreamNonBlocking));
+        SNK_HIP_TRY(hipEventRecord(H.ev[R], st));
+        SNK_HIP_TRY(hipStreamWaitEvent(H.cstream, H.ev[R], 0));
+        {
+            // offsets of piece (q, r): the ranges of one peer follow each other
+            std::vector<uint64_t> sbeg(W), scnt(W), rbeg(W), rcnt(W), sacc(W + 1, 0), racc(W + 1, 0);
+            for (uint32_t q = 0; q < W; ++q) {
+                uint64_t a = 0, b = 0;
+                for (uint32_t r = 0; r < R; ++r) { a += h_rs[(size_t)q * R + r]; b += h_rs[(size_t)W * R + (size_t)q * R + r]; }
+                sacc[q + 1] = sacc[q] + a; racc[q + 1] = racc[q] + b;
+            }
+            std::vector<uint64_t> sdone(W, 0), rdone(W, 0);
+            for (uint32_t r = 0; r < R; ++r) {
+                for (uint32_t q = 0; q < W; ++q) {
+                    sbeg[q] = (sacc[q] + sdone[q]) * 32; scnt[q] = h_rs[(size_t)q * R + r] * 32;
+                    rbeg[q] = (racc[q] + rdone[q]) * 32; rcnt[q] = h_rs[(size_t)W * R + (size_t)q * R + r] * 32;
+                    sdone[q] += h_rs[(size_t)q * R + r]; rdone[q] += h_rs[(size_t)W * R + (size_t)q * R + r];
+                }
+                TRY(comm->a2a(sendb, sbeg.data(), scnt.data(), recvb, rbeg.data(), rcnt.data(), H.cstream, err, errcap));
+                SNK_HIP_TRY(hipEventRecord(H.ev[r], H.cstream));
+            }
+        }
+        exch_records = n_send * 32;
+        // ---- segment tables: W sources (mine = the slots, in place) + my overflow segment
+        const uint32_t nseg = W + (part.n_overflow ? 1u : 0u);
+        uint64_t* T;
+        ALLOC(T, uint64_t, 2ull * nseg * NBl + 2);
+        const ull delta = (ull)(((intptr_t)part.records - (intptr_t)recvb) / 32);
+        hipLaunchKernelGGL(seg_table_kernel, dim3((NBl + 255) / 256), dim3(256), 0, st, roff, hrecv, part.cursor, part.seg, W, me, NBl, NB_total, part.cap,
+                           nseg, delta, T);
+        SNK_HIP_TRY(hipGetLastError());
+        tm.mark();   // 3
+        std::vector<uint32_t> bounds(R + 1);
+        for (uint32_t r = 0; r <= R; ++r) bounds[r] = (uint32_t)((uint64_t)NBl * r / R);
+        range_wait rw{st, H.ev.data(), R};
+        snk_count_ranges rg{R, bounds.data(), range_ready, &rw};
+        TRY(snk_stage_count_table(ctx, st, K, recvb, T, T + (uint64_t)nseg * NBl, NBl, nseg, NBl, p->min_freq, has_bc ? p->min_bc : 0u, 0u, inst_hint,
+                                  S->status, false, &S->tab, err, errcap, &rg));
+        snk_ctx_release_block(ctx, part.records);
+        snk_ctx_release_block(ctx, sendb);
+        snk_ctx_release_block(ctx, recvb);
+    }
+    tm.mark();   // 4
+    const uint64_t n_kmers = S->tab.n;
+
+    // ---- bucket-local prune with membership queries for neighbours owned by other ranks
+    std::vector<uint64_t> h_q(W);
+    TRY(snk_shard_prune_plan(ctx, h_q.data(), st, err, errcap));
+    // one read-back: every rank's query counts and retained k-mers
+    ull* d_cnt;
+    ALLOC(d_cnt, ull, W + 2);
+    {
+        std::vector<ull> mine(W + 1);
+        for (uint32_t q = 0; q < W; ++q) mine[q] = h_q[q];
+        mine[W] = n_kmers;
+        ull* up;
+        TRY(upload(X, mine.data(), W + 1, &up));
+        d_cnt = up;
+    }
+    std::vector<ull> qall;
+    TRY(exchange_counts(X, d_cnt, W + 1, qall));
+    std::vector<ull> q_send(W), q_recv(W), all_n(W);
+    for (uint32_t q = 0; q < W; ++q) { q_send[q] = qall[(size_t)me * (W + 1) + q]; q_recv[q] = qall[(size_t)q * (W + 1) + me]; all_n[q] = qall[(size_t)q * (W + 1) + W]; }
+    uint64_t nq = 0, nq_in = 0;
+    for (uint32_t q = 0; q < W; ++q) { nq += q_send[q]; nq_in += q_recv[q]; }
+    ull* d_qoff;
+    {
+        std::vector<ull> qoff(W + 1, 0);
+        for (uint32_t q = 0; q < W; ++q) qoff[q + 1] = qoff[q] + q_send[q];
+        TRY(upload(X, qoff.data(), W + 1, &d_qoff));
+    }
+    uint8_t *qbuf, *qin, *ans, *ans_back;
+    ALLOC(qbuf, uint8_t, nq * 24 + 32);
+    ALLOC(qin, uint8_t, nq_in * 24 + 32);
+    ALLOC(ans, uint8_t, nq_in * 4 + 32);
+    ALLOC(ans_back, uint8_t, nq * 4 + 32);
+    TRY(snk_shard_prune_fill(ctx, d_qoff, qbuf, st, err, errcap));
+    TRY(a2a_items(X, qbuf, q_send, qin, q_recv, 24));
+    TRY(snk_shard_prune_answer(ctx, qin, nq_in, ans, st, err, errcap));
+    TRY(a2a_items(X, ans, q_recv, ans_back, q_send, 4));
+    TRY(snk_shard_prune_apply(ctx, qbuf, ans_back, nq, d_qoff, st, err, errcap));
+    tm.mark();   // 5
+
+    // ---- fragments of my chunks (global node numbering = the ranks' tables behind each other)
+    std::vector<ull> node_off(W + 1, 0);
+    for (uint32_t q = 0; q < W; ++q) node_off[q + 1] = node_off[q] + all_n[q];
+    ull* d_node_off;
+    TRY(upload(X, node_off.data(), W + 1, &d_node_off));
+    snk_shard_frags fr;
+    TRY(snk_shard_fragments(ctx, d_node_off, node_off[me], &fr, st, err, errcap));
+    const uint64_t F = fr.n_frags;
+    tm.mark();   // 6
+
+    // ---- links between fragments, decided on the owners: an end asks the rank that owns the state it points at.
+    // One read-back: everybody's fragment count and link-query counts (counting needs no global fragment numbering).
+    snk_phase_timer jt(st);
+    jt.mark();   // j0
+    ALLOC(S->lq_count, ull, W + 2);
+    ALLOC(S->lq_cursor, ull, W + 2);
+    SNK_HIP_TRY(hipMemsetAsync(S->lq_count, 0, (W + 2) * 8ull, st));
+    TRY(snk_dist_links_query(ctx, st, false, &S->frags, S->d_node_off, W, 0ull, S->lq_count, nullptr, err, errcap));
+    {
+        ull hf = F, *up;
+        TRY(upload(X, &hf, 1, &up));
+        SNK_HIP_TRY(hipMemcpyAsync(S->lq_count + W, up, 8, hipMemcpyDeviceToDevice, st));
+    }
+    std::vector<ull> lall;
+    TRY(exchange_counts(X, S->lq_count, W + 1, lall));
+    std::vector<ull> l_send(W), l_recv(W), all_F(W), frag_off(W + 1, 0);
+    for (uint32_t q = 0; q < W; ++q) { l_send[q] = lall[(size_t)me * (W + 1) + q]; l_recv[q] = lall[(size_t)q * (W + 1) + me]; all_F[q] = lall[(size_t)q * (W + 1) + W]; }
+    for (uint32_t q = 0; q < W; ++q) frag_off[q + 1] = frag_off[q] + all_F[q];
+    const uint64_t Ft = frag_off[W];
+    if (2 * Ft >= (1ull << 32)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "more than 2^31 fragments in the job");
+    S->my_end_base = 2ull * frag_off[me];
+    uint64_t nlq = 0, nlq_in = 0;
+    for (uint32_t q = 0; q < W; ++q) { nlq += l_send[q]; nlq_in += l_recv[q]; }
+    uint8_t *lqbuf, *lqin, *lans, *lans_back;
+    ALLOC(lqbuf, uint8_t, nlq * 24 + 32);
+    ALLOC(lqin, uint8_t, nlq_in * 24 + 32);
+    ALLOC(lans, uint8_t, nlq_in * 4 + 32);
+    ALLOC(lans_back, uint8_t, nlq * 4 + 32);
+    {
+        std::vector<ull> lqoff(W + 1, 0);
+        for (uint32_t q = 0; q < W; ++q) lqoff[q + 1] = lqoff[q] + l_send[q];
+        ull* d_lqoff;
+        TRY(upload(X, lqoff.data(), W + 1, &d_lqoff));
+        TRY(snk_shard_links_fill(ctx, d_lqoff, lqbuf, st, err, errcap));
+    }
+    TRY(a2a_items(X, lqbuf, l_send, lqin, l_recv, 24));
+    TRY(snk_shard_links_answer(ctx, lqin, nlq_in, lans, st, err, errcap));
+    TRY(a2a_items(X, lans, l_recv, lans_back, l_send, 4));
+    const void* flink = nullptr;
+    TRY(snk_shard_links_apply(ctx, lqbuf, lans_back, nlq, &flink, st, err, errcap));
+    jt.mark();   // j1 links
+
+    // ---- owner-side join: every rank sees the job's LINK structure only (12 bytes per fragment), ranks the fragment lists,
+    // places its own fragments and sends each to the rank that owns its unitig's head, which writes the unitig
+    uint32_t* nk_all;
+    uint32_t* fl_all;
+    ALLOC(nk_all, uint32_t, Ft + 4);
+    ALLOC(fl_all, uint32_t, 2 * Ft + 4);
+    {
+        std::vector<uint64_t> c4(W), c8(W);
+        for (uint32_t q = 0; q < W; ++q) { c4[q] = all_F[q] * 4; c8[q] = all_F[q] * 8; }
+        TRY(comm->allgatherv(fr.nk, c4.data(), nk_all, st, err, errcap));
+        TRY(comm->allgatherv(flink, c8.data(), fl_all, st, err, errcap));
+    }
+    ull* d_frag_off;
+    TRY(upload(X, frag_off.data(), W + 1, &d_frag_off));
+    jt.mark();   // j2 gather links
+    std::vector<uint64_t> fto(W, 0), bto(W, 0);
+    bool ranked = false;
+    uint64_t exch_spl = 0, exch_rank = 0;
+    const bool want_partitioned = snk_env_u32("SNK_JOIN_REPLICATED", 0) == 0;
+    if (want_partitioned) {
+        uint64_t m_spl = 0;
+        const void* w1p = nullptr;
+        TRY(snk_shard_prank_begin(ctx, Ft, nk_all, fl_all, frag_off[me], &m_spl, &w1p, st, err, errcap));
+        std::vector<uint64_t> shares(W);
+        uint64_t tot16 = 0;
+        for (uint32_t q = 0; q < W; ++q) { shares[q] = (m_spl * (q + 1) / W - m_spl * q / W) * 16; tot16 += shares[q]; }
+        uint8_t* w1_all;
+        ALLOC(w1_all, uint8_t, tot16 + 32);
+        TRY(comm->allgatherv(w1p, shares.data(), w1_all, st, err, errcap));
+        exch_spl = m_spl * 16;
+        std::vector<uint64_t> rto(W, 0);
+        uint32_t circ = 0;
+        TRY(snk_shard_prank_walk(ctx, w1_all, d_frag_off, rto.data(), &circ, st, err, errcap));
+        if (!circ) {
+            // everybody's record counts: one read-back
+            ull* d_rto;
+            {
+                std::vector<ull> v(rto.begin(), rto.end());
+                TRY(upload(X, v.data(), W, &d_rto));
+            }
+            std::vector<ull> rall;
+            TRY(exchange_counts(X, d_rto, W, rall));
+            std::vector<ull> r_send(W), r_recv(W), roff_(W + 1, 0);
+            uint64_t n_in = 0;
+            for (uint32_t q = 0; q < W; ++q) { r_send[q] = rall[(size_t)me * W + q]; r_recv[q] = rall[(size_t)q * W + me]; roff_[q + 1] = roff_[q] + r_send[q]; n_in += r_recv[q]; }
+            ull* d_roff;
+            TRY(upload(X, roff_.data(), W, &d_roff));
+            uint8_t *rsend, *rk_in;
+            ALLOC(rsend, uint8_t, roff_[W] * 16 + 32);
+            ALLOC(rk_in, uint8_t, n_in * 16 + 32);
+            TRY(snk_shard_prank_route(ctx, d_frag_off, d_roff, rsend, st, err, errcap));
+            TRY(a2a_items(X, rsend, r_send, rk_in, r_recv, 16));
+            TRY(snk_shard_place_ranked(ctx, K, rk_in, n_in, d_frag_off, fto.data(), bto.data(), st, err, errcap));
+            ranked = true;
+            exch_rank = roff_[W] * 16;
+        }
+    }
+    if (!ranked)      // a list is a circle (same verdict on every rank: it comes from replicated data), or the replicated mode was asked for
+        TRY(snk_shard_place(ctx, K, Ft, nk_all, fl_all, d_frag_off, frag_off[me], fto.data(), bto.data(), st, err, errcap));
+    jt.mark();   // j3 rank + place
+    // headers + bases grouped by owner; every owner's bases start 16-byte aligned in the send buffer
+    std::vector<ull> hoff(W + 1, 0), boff(W + 1, 0), bpad(W);
+    for (uint32_t q = 0; q < W; ++q) { bpad[q] = (bto[q] + 15) / 16 * 16; hoff[q + 1] = hoff[q] + fto[q]; boff[q + 1] = boff[q] + bpad[q]; }
+    ull *d_hoff, *d_boff;
+    TRY(upload(X, hoff.data(), W, &d_hoff));
+    TRY(upload(X, boff.data(), W, &d_boff));
+    uint8_t *hdr, *sb;
+    ALLOC(hdr, uint8_t, hoff[W] * 32 + 32);
+    ALLOC(sb, uint8_t, boff[W] + 32);
+    TRY(snk_shard_route_fill(ctx, K, d_frag_off, d_hoff, d_boff, hdr, sb, st, err, errcap));
+    // what arrives: everybody's (fragments, padded base bytes) per owner -- one read-back
+    std::vector<ull> fall;
+    {
+        std::vector<ull> v(2 * W);
+        for (uint32_t q = 0; q < W; ++q) { v[q] = fto[q]; v[W + q] = bpad[q]; }
+        ull* d_v;
+        TRY(upload(X, v.data(), 2 * W, &d_v));
+        TRY(exchange_counts(X, d_v, 2 * W, fall));
+    }
+    std::vector<ull> f_send(W), f_recv(W), b_send(W), b_recv(W), hseg(W + 1, 0), bseg(W + 1, 0);
+    for (uint32_t q = 0; q < W; ++q) {
+        f_send[q] = fto[q]; b_send[q] = bpad[q];
+        f_recv[q] = fall[(size_t)q * 2 * W + me]; b_recv[q] = fall[(size_t)q * 2 * W + W + me];
+        hseg[q + 1] = hseg[q] + f_recv[q]; bseg[q + 1] = bseg[q] + b_recv[q];
+    }
+    uint8_t *hdr_in, *b_in;
+    ALLOC(hdr_in, uint8_t, hseg[W] * 32 + 32);
+    ALLOC(b_in, uint8_t, bseg[W] + 32);
+    TRY(a2a_items(X, hdr, f_send, hdr_in, f_recv, 32));
+    TRY(a2a_items(X, sb, b_send, b_in, b_recv, 1));
+    jt.mark();   // j4 route
+    ull *d_hseg, *d_bseg;
+    TRY(upload(X, hseg.data(), W + 1, &d_hseg));
+    TRY(upload(X, bseg.data(), W + 1, &d_bseg));
+    snk_shard_unitigs un;
+    TRY(snk_shard_emit(ctx, K, hseg[W], hdr_in, d_hseg, d_bseg, b_in, &un, st, err, errcap));
+    jt.mark();   // j5 emit
+    tm.mark();   // 7
+    SNK_HIP_TRY(snk_sync(st));
+
+    memset(out, 0, sizeof *out);
+    out->n_reads = in->n_reads;
+    out->n_instances = n_inst;
+    out->n_supermers = part.n_supermers;
+    out->n_buckets_total = NB_total;
+    out->n_kmers = n_kmers;
+    out->keys = fr.keys; out->counts = fr.counts; out->ctx = fr.ctx;
+    out->spectrum = fr.spectrum; out->spectrum_bins = fr.spectrum_bins;
+    out->n_unitigs = un.n_unitigs; out->unitig_total_bases = un.total_bases;
+    out->unitig_off = un.unitig_off; out->unitig_bases = un.unitig_bases; out->unitig_circular = un.unitig_circular;
+    out->n_circles = un.n_circles;
+    out->n_frags = F; out->n_frags_total = Ft; out->n_queries = nq; out->n_link_queries = nlq;
+    out->ranking = ranked ? 1u : 0u;
+    out->buckets_split = fr.buckets_split; out->max_slots_used = fr.max_slots_used;
+    out->exchanged_bytes[0] = exch_records;
+    out->exchanged_bytes[1] = 0; for (uint32_t q = 0; q < W; ++q) if (q != me) out->exchanged_bytes[1] += q_send[q] * 24 + q_recv[q] * 4;
+    out->exchanged_bytes[2] = 0; for (uint32_t q = 0; q < W; ++q) if (q != me) out->exchanged_bytes[2] += l_send[q] * 24 + l_recv[q] * 4;
+    out->exchanged_bytes[3] = (W - 1) * F * 12;
+    out->exchanged_bytes[4] = exch_spl;
+    out->exchanged_bytes[5] = exch_rank;
+    out->exchanged_bytes[6] = 0; for (uint32_t q = 0; q < W; ++q) if (q != me) out->exchanged_bytes[6] += f_send[q] * 32 + b_send[q];
+    out->exchanged_bytes[7] = comm->bytes_sent;
+    for (int q = 0; q < 7; ++q) out->phase_ms[q] = tm.ms(q, q + 1);
+    out->phase_ms[7] = tm.ms(0, 7);
+    for (int q = 0; q < 5; ++q) out->join_ms[q] = jt.ms(q, q + 1);
+    out->count_kernel_ms = fr.count_kernel_ms;
+    out->host_syncs = (uint32_t)(snk_sync_count() - syncs0);
+    out->world = W; out->rank = me;
+    (void)flags;
+    return SNK_OK;
+}
+
+void shard_host_free(void* p) { delete static_cast<shard_host*>(p); }
+
+}  // namespace
+
+extern "C" int snk_shard_step(snk_ctx* ctx, snk_comm* comm, const snk_dev_reads* in, const snk_params* p, uint64_t total_reads, uint32_t flags,
+                              snk_shard_result* out, void* stream, char* err, size_t errcap) {
+    if (!ctx || !comm || !in || !p || !out) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_step: NULL argument");
+    if (p->flags & SNK_F_GROUPED) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_shard_step: per-group graphs shard by group (replicas), not by minimiser");
+    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    if (!ctx->shard_host) { ctx->shard_host = new shard_host(); ctx->shard_host_free = shard_host_free; }
+    shard_host& H = *static_cast<shard_host*>(ctx->shard_host);
+    step_ctx X;
+    X.ctx = ctx; X.comm = comm; X.st = stream ? (hipStream_t)stream : ctx->stream; X.err = err; X.errcap = errcap;
+    X.W = comm->world; X.me = comm->rank;
+    const size_t need = 64ull * (X.W + 2) + 4096;
+    if (H.pin_cap < need) {
+        if (H.pin) (void)hipHostFree(H.pin);
+        H.pin = nullptr; H.pin_cap = 0;
+        SNK_HIP_TRY(hipHostMalloc((void**)&H.pin, need * 8, hipHostMallocDefault));
+        H.pin_cap = need;
+    }
+    X.pin = H.pin; X.pin_cap = H.pin_cap; X.pin_used = 0;
+    int rc = step_impl(X, H, in, p, total_reads, flags, out);
+    if (rc) {
+        comm->abort();
+        (void)hipStreamSynchronize(X.st);
+        if (H.cstream) (void)hipStreamSynchronize(H.cstream);
+    }
+    return rc;
+}

@@ -69,3 +69,5 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
                         char* err, size_t errcap);
 // sharded runs: the buckets' records copied to exact offsets (u32 record index per bucket) of a compact buffer
 int snk_stage_partition_compact(snk_ctx* ctx, hipStream_t st, const snk_partition* part, const uint32_t* d_offsets, void* d_out, char* err, size_t errcap);
+int snk_stage_partition_compact_remote(snk_ctx* ctx, hipStream_t st, const snk_partition* part, const uint32_t* d_offsets, void* d_out,
+                                       uint32_t skip_lo, uint32_t skip_hi, char* err, size_t errcap);

@@ -114,7 +114,7 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
         kt.mark();
         SNK_HIP_TRY(hipMemcpyAsync(h_rcur.data(), rcur, n_regions * 8ull, hipMemcpyDeviceToHost, st));
         SNK_HIP_TRY(hipMemcpyAsync(h_status, status, 32, hipMemcpyDeviceToHost, st));
-        SNK_HIP_TRY(hipStreamSynchronize(st));
+        SNK_HIP_TRY(snk_sync(st));
 #ifdef SNK_COUNT_PROF
         {
             unsigned long long hp[8];
@@ -153,7 +153,7 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
         if ((rc = snk_ctx_alloc(ctx, (n_kmers + 1) * 16, &q, err, errcap))) return rc; keys_a = (snk_u128*)q;
         if ((rc = snk_ctx_alloc(ctx, (n_kmers + 1) * 8, &q, err, errcap))) return rc; vals_a = (uint64_t*)q;
         if ((rc = snk_launch_compact_regions(st, keys_r, vals_r, region_cap, n_regions, rcur, roff, keys_a, vals_a, err, errcap))) return rc;
-        SNK_HIP_TRY(hipStreamSynchronize(st));   // h_off is a stack vector: the upload must finish before it goes away
+        SNK_HIP_TRY(snk_sync(st));   // h_off is a stack vector: the upload must finish before it goes away
         snk_ctx_release_block(ctx, keys_r);      // the region-partitioned copy is dead: later stages may reuse it
         snk_ctx_release_block(ctx, vals_r);
     }
@@ -231,9 +231,9 @@ __global__ void __launch_bounds__(256) ovf_gather_kernel(const uint4* rec, uint6
 
 // sharded runs: copy the used slots (+ overflow records) of every bucket to exact offsets of a compact send buffer
 __global__ void __launch_bounds__(256) compact_buckets_kernel(const uint4* __restrict__ rec, const uint64_t* __restrict__ seg, uint32_t NB,
-                                                              const uint32_t* __restrict__ offsets, uint4* __restrict__ out) {
+                                                              const uint32_t* __restrict__ offsets, uint4* __restrict__ out, uint32_t skip_lo, uint32_t skip_hi) {
     const uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= NB) return;
+    if (b >= NB || (b >= skip_lo && b < skip_hi)) return;
     const uint32_t lane = threadIdx.x & 63;
     uint64_t dst = (uint64_t)offsets[b] * 2;
     for (int sgm = 0; sgm < 2; ++sgm) {
@@ -278,7 +278,7 @@ int snk_stage_partition_plan(snk_ctx* ctx, hipStream_t st, uint32_t K, const uin
     counters = (unsigned long long*)q;
     if ((rc = snk_launch_msp_plan(st, good_len, n_reads, K, counters, err, errcap))) return rc;
     SNK_HIP_TRY(hipMemcpyAsync(h_plan, counters, 16, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     return SNK_OK;
 }
 
@@ -337,7 +337,7 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
         if ((rc = snk_launch_msp(K, st, ma, err, errcap))) return rc;
         kt.mark();  // 1
         SNK_HIP_TRY(hipMemcpyAsync(&h_novf, status + 8, 4, hipMemcpyDeviceToHost, st));
-        SNK_HIP_TRY(hipStreamSynchronize(st));
+        SNK_HIP_TRY(snk_sync(st));
         if (h_novf <= ovf_cap) break;
         if (attempt == 2) return snk_fail(SNK_E_INTERNAL, err, errcap, "supermer overflow list too small (%u > %llu)", h_novf, (unsigned long long)ovf_cap);
         snk_ctx_release_block(ctx, records);
@@ -348,7 +348,7 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
     if ((rc = snk_msp_segments(ctx, st, NB, cap, cursor, (uint4*)records, (uint64_t)NB * cap, ovf_cap, ovf_bucket, h_novf, seg, d_total, err, errcap))) return rc;
     unsigned long long h_total = 0;
     SNK_HIP_TRY(hipMemcpyAsync(&h_total, d_total, 8, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     out->NB = NB;
     out->cap = cap;
     out->nseg = h_novf ? 2u : 1u;
@@ -365,9 +365,20 @@ int snk_stage_partition_compact(snk_ctx* ctx, hipStream_t st, const snk_partitio
                                 size_t errcap) {
     if (part->NB == 0) return SNK_OK;
     hipLaunchKernelGGL(compact_buckets_kernel, dim3((part->NB + 3) / 4), dim3(256), 0, st, (const uint4*)part->records, part->seg, part->NB,
-                       d_offsets, (uint4*)d_out);
+                       d_offsets, (uint4*)d_out, 0u, 0u);
     SNK_HIP_TRY(hipGetLastError());
-    SNK_HIP_TRY(hipStreamSynchronize(st));
+    SNK_HIP_TRY(snk_sync(st));
     snk_ctx_release_block(ctx, part->records);      // the slot layout is dead once the send buffer is filled
+    return SNK_OK;
+}
+
+// the same for the buckets OUTSIDE [skip_lo, skip_hi): the rank's own buckets stay where they are and are counted in place
+// (snk_shard_step.hip); nothing is waited for, the slot layout stays alive
+int snk_stage_partition_compact_remote(snk_ctx* ctx, hipStream_t st, const snk_partition* part, const uint32_t* d_offsets, void* d_out,
+                                       uint32_t skip_lo, uint32_t skip_hi, char* err, size_t errcap) {
+    if (part->NB == 0) return SNK_OK;
+    hipLaunchKernelGGL(compact_buckets_kernel, dim3((part->NB + 3) / 4), dim3(256), 0, st, (const uint4*)part->records, part->seg, part->NB,
+                       d_offsets, (uint4*)d_out, skip_lo, skip_hi);
+    SNK_HIP_TRY(hipGetLastError());
     return SNK_OK;
 }

@@ -101,6 +101,18 @@ class SnkDevDups(C.Structure):
                 ("interdup_rate", C.c_double), ("ms", C.c_float)]
 
 
+class SnkShardResult(C.Structure):
+    _fields_ = [("rank", C.c_uint32), ("world", C.c_uint32), ("n_reads", C.c_uint64), ("n_instances", C.c_uint64),
+                ("n_supermers", C.c_uint64), ("n_buckets_total", C.c_uint64), ("n_kmers", C.c_uint64), ("keys", C.c_void_p),
+                ("counts", C.c_void_p), ("ctx", C.c_void_p), ("spectrum", C.c_void_p), ("spectrum_bins", C.c_uint32),
+                ("n_circles", C.c_uint32), ("n_unitigs", C.c_uint64), ("unitig_total_bases", C.c_uint64),
+                ("unitig_off", C.c_void_p), ("unitig_bases", C.c_void_p), ("unitig_circular", C.c_void_p),
+                ("n_frags", C.c_uint64), ("n_frags_total", C.c_uint64), ("n_queries", C.c_uint64), ("n_link_queries", C.c_uint64),
+                ("exchanged_bytes", C.c_uint64 * 8), ("host_syncs", C.c_uint32), ("ranking", C.c_uint32),
+                ("buckets_split", C.c_uint32), ("max_slots_used", C.c_uint32), ("phase_ms", C.c_float * 8),
+                ("join_ms", C.c_float * 8), ("count_kernel_ms", C.c_float), ("reserved_f", C.c_float)]
+
+
 RANGE_READY = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32)      # int ready(void* user, uint32_t range)
 
 _lib = None
@@ -206,6 +218,17 @@ def _declare(lib: C.CDLL) -> None:
         "snk_shard_place_ranked": (C.c_int, [vp, u32, vp, u64, vp, P(u64), P(u64), vp, cp, sz]),
         "snk_shard_route_fill": (C.c_int, [vp, u32, vp, vp, vp, vp, vp, vp, cp, sz]),
         "snk_shard_emit": (C.c_int, [vp, u32, u64, vp, vp, vp, vp, P(SnkShardUnitigs), vp, cp, sz]),
+        "snk_comm_set_rccl_path": (C.c_int, [cp]),
+        "snk_comm_unique_id": (C.c_int, [vp, cp, sz]),
+        "snk_comm_create_rccl": (C.c_int, [vp, vp, u32, u32, P(vp), cp, sz]),
+        "snk_comm_from_nccl": (C.c_int, [vp, vp, u32, u32, P(vp), cp, sz]),
+        "snk_comm_create_local": (C.c_int, [u32, P(vp), cp, sz]),
+        "snk_comm_destroy": (None, [vp]),
+        "snk_comm_abort": (None, [vp]),
+        "snk_comm_rank": (u32, [vp]),
+        "snk_comm_world": (u32, [vp]),
+        "snk_comm_kind": (cp, [vp]),
+        "snk_shard_step": (C.c_int, [vp, vp, P(SnkDevReads), P(SnkParams), u64, u32, P(SnkShardResult), vp, cp, sz]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -1,15 +1,19 @@
-"""Minimiser-sharded multi-GPU host logic: one process per GPU, torch.distributed for the
-exchanges (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests of the plumbing).
+"""Minimiser-sharded multi-GPU path: the Python face of `snk_shard_step` (include/snk.h).
 
-The k-mer space is cut into NB_total minimiser buckets, rank r owns a contiguous range.  Per step:
-  all-to-all #1  bucket histograms (u32 per bucket)            -> segment offsets on the owner
-  all-to-all #2  supermer records (32 B each)                  -> every k-mer instance meets its owner
-  all-to-all #3  membership queries for cross-rank neighbours  (24 B each, ~0.15 per retained k-mer)
-  all-to-all #4  answers (4 B each)
-  all-to-all #5/#6  fragment-link queries (24 B per fragment end with a remote neighbour) and answers (4 B)
-  gather         fragments (k-mers, links, bases) -> rank 0, which ranks and writes them (tada's MAIN_ASM_SN)
+The step itself -- partition, histogram + record exchange (in bucket ranges, overlapped with the count), count,
+cross-rank prune, fragments, fragment links, owner-side join -- runs in C++ behind the C ABI
+(supernova_amd/csrc/snk_shard_step.hip) over a communicator (supernova_amd/csrc/snk_comm.hip):
+  * RCCL over xGMI, one process per GPU: `ShardedEngine(engine, torch.distributed)` creates the communicator from a
+    unique id that rank 0 makes and torch.distributed broadcasts (the only thing torch.distributed does here);
+  * in-process ranks on ONE device (`local_world(W)`): the same SPMD code with device copies as the wire -- how N > 1 is
+    tested on one GPU.
 Reference counterpart: the shardio exchange files + SHARD_ASM chunks + MAIN_ASM_SN of lib/tada
-(rust-shardio/src/shard.rs:184-211,488-493; cmd_shard_asm.rs:37-94; cmd_main_asm.rs:25-89).
+(rust-shardio/src/shard.rs:184-211,488-493; cmd_shard_asm.rs:37-94; cmd_main_asm.rs:25-89).  The C++ host program that
+runs the same step without Python is supernova_amd/csrc/host/snk_asm_sn.cc.
+
+`TorchComm` and the planning helpers below are the host-side arithmetic of the exchanges in plain torch; the CPU tests
+drive them over gloo with world_size 2 (tests/test_sharded_plumbing.py), and `TorchComm` is the transport behind
+`snk_comm_create_callbacks` there.
 """
 from __future__ import annotations
 
@@ -171,109 +175,6 @@ class TorchComm:
         self.dist.barrier()
 
 
-class SimWorld:
-    """W in-process ranks (threads) that exchange through shared lists -- the SPMD code path of the real
-    multi-GPU run on ONE GPU (tests), with the transport replaced by tensor copies."""
-
-    def __init__(self, world: int, serial: bool = False):
-        """serial=True: between two exchanges the ranks compute one after the other (rank 0 first), so the per-rank phase
-        timings are those of a rank that has the GPU to itself (tools/sim_scale.py)."""
-        self.world = world
-        self.barrier_obj = threading.Barrier(world)
-        self.slots = [None] * world
-        self.serial = serial
-        self.turn = threading.Condition()
-        self.turn_of = 0
-
-    def comm(self, rank: int) -> "SimComm":
-        return SimComm(self, rank)
-
-
-class SimComm:
-    def __init__(self, w: SimWorld, rank: int):
-        self.w, self.rank, self.world = w, rank, w.world
-
-    def _end_section(self):       # my compute section is over: the next rank may start its own
-        if self.w.serial:
-            torch.cuda.synchronize()
-            with self.w.turn:
-                while self.w.turn_of != self.rank:
-                    self.w.turn.wait()
-                self.w.turn_of = self.rank + 1
-                self.w.turn.notify_all()
-
-    def _begin_section(self):     # after an exchange: wait until every lower rank has finished its section
-        if self.w.serial:
-            with self.w.turn:
-                while self.w.turn_of != self.rank:
-                    self.w.turn.wait()
-
-    def _exchange(self, obj):
-        self._end_section()
-        self.w.slots[self.rank] = obj
-        self.w.barrier_obj.wait()
-        allv = list(self.w.slots)
-        if self.w.serial and self.rank == 0:
-            self.w.turn_of = 0
-        self.w.barrier_obj.wait()
-        return allv
-
-    def allreduce_sum_int(self, v, device):
-        r = sum(self._exchange(int(v)))
-        self._begin_section()
-        return r
-
-    def all_gather_int(self, v, device):
-        r = [int(x) for x in self._exchange(int(v))]
-        self._begin_section()
-        return r
-
-    def all_to_all_v(self, send, send_counts, alloc=None):
-        torch.cuda.synchronize()
-        allv = self._exchange((send, list(send_counts)))
-        parts, counts = [], []
-        for (t, sc) in allv:
-            off = sum(sc[: self.rank])
-            parts.append(t[off: off + sc[self.rank]])
-            counts.append(sc[self.rank])
-        recv = torch.cat(parts) if parts else send[:0]
-        torch.cuda.synchronize()
-        self.w.barrier_obj.wait()     # nobody reuses its send buffer before everyone has copied
-        self._begin_section()
-        return recv, counts
-
-    def exchange_ranged(self, send, recv, soff, roff, n_ranges):
-        torch.cuda.synchronize()
-        allv = self._exchange((send, soff))
-        for src, (t, so) in enumerate(allv):
-            a, b = so[self.rank][0], so[self.rank][n_ranges]
-            if b > a:
-                recv[roff[src][0]: roff[src][n_ranges]].copy_(t[a:b])
-        torch.cuda.synchronize()
-        self.w.barrier_obj.wait()     # nobody reuses its send buffer before everyone has copied
-        self._begin_section()
-        return [[] for _ in range(n_ranges)]
-
-    def all_gather_v(self, send, counts, alloc=None):
-        torch.cuda.synchronize()
-        allv = self._exchange(send[:counts[self.rank]])
-        out = torch.cat(list(allv)) if allv else send[:0]
-        torch.cuda.synchronize()
-        self.w.barrier_obj.wait()
-        self._begin_section()
-        return out
-
-    def all_to_all_equal(self, send):
-        m = send.shape[1]
-        recv, _ = self.all_to_all_v(send.contiguous().view(-1).view(torch.uint8),
-                                    [m * send.element_size()] * self.world)
-        return recv.view(send.dtype).view(self.world, m)
-
-    def barrier(self):
-        self._exchange(None)
-        self._begin_section()
-
-
 # ------------------------------------------------------------------------------------------------ planning helpers
 def plan_buckets(total_inst_upper: int, world: int, K: int) -> int:
     target = int(os.environ.get("SNK_TARGET_INST", "5000" if K == 48 else "3500"))
@@ -353,12 +254,27 @@ def canonicalize_circle(codes: np.ndarray, K: int) -> np.ndarray:
 
 
 # ------------------------------------------------------------------------------------------------ the SPMD step
+JOIN_NAMES = ("links", "link_structure", "rank+place", "route", "emit")
+PHASE_NAMES = ("partition", "compact", "exchange", "count", "prune", "fragments", "join", "total")
+EXCH_NAMES = ("records", "prune_queries", "link_queries", "link_structure", "splitters", "ranks", "fragments", "total")
+
+
 class ShardedResult:
-    def __init__(self, eng: Engine, K: int):
+    """One rank's share of a sharded step (device pointers owned by the engine's context, valid until its next call)."""
+
+    def __init__(self, eng: Engine, K: int, raw: "_lib.SnkShardResult"):
         self._e = eng
         self.K = K
-        self.phase_ms = {}
-        self.kernel_ms = {}
+        self.raw = raw
+        for f in ("n_reads", "n_instances", "n_supermers", "n_kmers", "n_unitigs", "n_frags", "n_frags_total", "n_queries",
+                  "n_link_queries", "host_syncs", "buckets_split", "max_slots_used", "n_circles"):
+            setattr(self, f, int(getattr(raw, f)))
+        self.n_buckets = int(raw.n_buckets_total)
+        self.join_ranking = "partitioned" if raw.ranking else "replicated"
+        self.phase_ms = {PHASE_NAMES[i]: float(raw.phase_ms[i]) for i in range(8)}
+        self.join_ms = {JOIN_NAMES[i]: float(raw.join_ms[i]) for i in range(5)}
+        self.kernel_ms = {"count": float(raw.count_kernel_ms)}
+        self.exchange_bytes = {EXCH_NAMES[i]: int(raw.exchanged_bytes[i]) for i in range(8)}
 
     def _dl(self, ptr, nbytes, dtype, shape):
         out = np.empty(shape, dtype=dtype)
@@ -367,7 +283,7 @@ class ShardedResult:
         return out
 
     def keys(self):
-        lohi = self._dl(self.frags.keys, self.n_kmers * 16, np.uint64, (self.n_kmers, 2))
+        lohi = self._dl(self.raw.keys, self.n_kmers * 16, np.uint64, (self.n_kmers, 2))
         lo, hi = lohi[:, 0], lohi[:, 1]
         w = np.empty((self.n_kmers, 4), dtype=np.uint32)
         w[:, 0] = hi >> np.uint64(32); w[:, 1] = hi & np.uint64(0xFFFFFFFF)
@@ -375,85 +291,125 @@ class ShardedResult:
         return w
 
     def counts(self):
-        return self._dl(self.frags.counts, self.n_kmers * 4, np.uint32, (self.n_kmers,))
+        return self._dl(self.raw.counts, self.n_kmers * 4, np.uint32, (self.n_kmers,))
 
     def ctx(self):
-        return self._dl(self.frags.ctx, self.n_kmers, np.uint8, (self.n_kmers,))
+        return self._dl(self.raw.ctx, self.n_kmers, np.uint8, (self.n_kmers,))
 
     def spectrum(self):
-        nb = int(self.frags.spectrum_bins)
-        return self._dl(self.frags.spectrum, nb * 8, np.uint64, (nb,))
+        nb = int(self.raw.spectrum_bins)
+        return self._dl(self.raw.spectrum, nb * 8, np.uint64, (nb,))
+
+    def unitig_arrays(self):
+        n, tb = self.n_unitigs, int(self.raw.unitig_total_bases)
+        return (self._dl(self.raw.unitig_off, (n + 1) * 8, np.uint64, (n + 1,)), self._dl(self.raw.unitig_bases, tb, np.uint8, (tb,)))
 
     def unitigs(self) -> list[str]:
-        """Canonical unitigs this rank wrote, sorted by BVComp: with the owner-side join every rank holds the unitigs whose
-        head fragment it owns (their union over the ranks is the data set's unitig set); with join="rank0" rank 0 holds all."""
-        u = self.joined
-        if u is None:
-            return []
-        off = self._dl(u.unitig_off, (u.n_unitigs + 1) * 8, np.uint64, (u.n_unitigs + 1,))
-        bases = self._dl(u.unitig_bases, u.total_bases, np.uint8, (u.total_bases,))
+        """Canonical unitigs this rank wrote (the ones whose head fragment it owns), sorted by BVComp; the union over the ranks
+        is the data set's unitig set."""
+        off, bases = self.unitig_arrays()
         lut = np.frombuffer(b"ACGT", dtype=np.uint8)
-        out = [lut[bases[int(off[i]):int(off[i + 1])]].tobytes().decode() for i in range(u.n_unitigs)]
+        out = [lut[bases[int(off[i]):int(off[i + 1])]].tobytes().decode() for i in range(self.n_unitigs)]
         out.sort(key=lambda s: (-len(s), s))
         return out
 
 
-class _BufferPool:
-    """Grow-only named byte buffers reused across steps: the send / receive / query buffers are tens of GB, and a fresh
-    torch.empty of that size is a device allocation (milliseconds each) whenever the caching allocator has no block of
-    the right size left."""
+def local_world(world: int) -> list[int]:
+    """`world` in-process ranks on one device: handles for ShardedEngine(engine, handle), one per rank / host thread."""
+    lib = _lib.load()
+    arr = (C.c_void_p * world)()
+    err = C.create_string_buffer(512)
+    rc = lib.snk_comm_create_local(world, arr, err, 512)
+    if rc:
+        raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+    return [int(arr[r]) for r in range(world)]
 
-    def __init__(self, device):
-        self.device = device
-        self.bufs: dict[str, torch.Tensor] = {}
 
-    def get(self, name: str, nbytes: int) -> torch.Tensor:
-        b = self.bufs.get(name)
-        if b is None or b.numel() < nbytes:
-            self.bufs.pop(name, None)
-            b = torch.empty(int(nbytes * 1.1) + 4096, dtype=torch.uint8, device=self.device)
-            self.bufs[name] = b
-        return b[:nbytes]
+class SimWorld:
+    """W in-process ranks on one GPU (tests, tools): `comm(r)` is rank r's communicator handle for ShardedEngine; every rank
+    runs on its own host thread with its own Engine.  barrier_obj.abort() releases the ranks that wait in an exchange after
+    another one failed outside the step."""
+
+    class _Abort:
+        def __init__(self, w):
+            self.w = w
+
+        def abort(self):
+            lib = _lib.load()
+            for h in self.w.handles:
+                lib.snk_comm_abort(h)
+
+    def __init__(self, world: int, serial: bool = False):
+        self.world = world
+        self.handles = local_world(world)
+        self.barrier_obj = SimWorld._Abort(self)
+
+    def comm(self, rank: int) -> int:
+        return self.handles[rank]
+
+
+def rccl_comm(engine: Engine, dist) -> int:
+    """An RCCL communicator for libsnk on the engine's device: rank 0 makes the 128-byte unique id, torch.distributed carries
+    it to the other ranks (a broadcast of 128 bytes -- everything else of the step runs behind the C ABI)."""
+    lib = engine.lib
+    err = C.create_string_buffer(512)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    from pathlib import Path
+    cand = Path(torch.__file__).parent / "lib" / "librccl.so"      # the RCCL of this process: the one torch ships
+    if cand.exists():
+        lib.snk_comm_set_rccl_path(str(cand).encode())
+    idb = (C.c_uint8 * 128)()
+    if rank == 0:
+        rc = lib.snk_comm_unique_id(idb, err, 512)
+        if rc:
+            raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+    if world > 1:
+        dev = torch.device("cuda", engine.device) if dist.get_backend() == "nccl" else torch.device("cpu")
+        t = torch.tensor(list(idb), dtype=torch.uint8, device=dev)
+        dist.broadcast(t, 0)
+        for i, v in enumerate(t.cpu().tolist()):
+            idb[i] = v
+    h = C.c_void_p()
+    rc = lib.snk_comm_create_rccl(engine._ctx, idb, rank, world, C.byref(h), err, 512)
+    if rc:
+        raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+    return int(h.value)
 
 
 class ShardedEngine:
     def __init__(self, engine: Engine, dist_or_comm, join: str | None = None):
-        """join = "owner" (default): every rank writes the unitigs whose head fragment it owns -- no rank holds the whole job;
-        "rank0": the first version, every fragment travels to rank 0 (tada's single-process MAIN_ASM_SN); SNK_JOIN overrides."""
+        """dist_or_comm: torch.distributed (an initialised process group: one process per GPU, RCCL) or a communicator handle
+        (local_world).  The join is owner-side: every rank writes the unitigs whose head fragment it owns."""
         self.eng = engine
-        self.comm = dist_or_comm if hasattr(dist_or_comm, "all_to_all_v") else TorchComm(dist_or_comm)
-        self.pool = None
-        self.join = join or os.environ.get("SNK_JOIN", "owner")
-        assert self.join in ("owner", "rank0")
-        # owner-side join: "partitioned" = every rank walks 1/W of the ranking (lists that are circles fall back to "replicated")
-        self.rank_mode = os.environ.get("SNK_JOIN_RANK", "partitioned")
-        assert self.rank_mode in ("partitioned", "replicated")
+        self.lib = engine.lib
+        if isinstance(dist_or_comm, int):
+            self.comm = dist_or_comm
+        else:
+            self.comm = rccl_comm(engine, dist_or_comm)
+        self.rank = int(self.lib.snk_comm_rank(self.comm))
+        self.world = int(self.lib.snk_comm_world(self.comm))
+        self.kind = self.lib.snk_comm_kind(self.comm).decode()
+
+    def close(self):
+        if getattr(self, "comm", None):
+            self.lib.snk_comm_destroy(self.comm)
+            self.comm = None
+
+    def abort(self):
+        if getattr(self, "comm", None):
+            self.lib.snk_comm_abort(self.comm)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def count_graph(self, rows, read_len, quals=None, bc=None, lens=None, good_len=None, params: Params | None = None,
-                    ign_bc_below: int = 0, read_index_base: int = 0) -> ShardedResult:
-        e, comm, lib = self.eng, self.comm, self.eng.lib
-        W, me = comm.world, comm.rank
+                    ign_bc_below: int = 0, read_index_base: int = 0, total_reads: int = 0) -> ShardedResult:
+        e, lib = self.eng, self.lib
         params = params or Params()
-        K = params.K
-        dev = rows.device
-        st = e._stream()
         err = C.create_string_buffer(512)
-        if self.pool is None or self.pool.device != dev:
-            self.pool = _BufferPool(dev)
-        pool = self.pool
-
-        def chk(rc):
-            if rc != 0:
-                raise _lib.SnkError(rc, err.value.decode(errors="replace"))
-
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
-        ev[0].record()
-        marks = []          # (name, event): finer breakdown of the join (compute sections vs exchanges), res.join_ms
-
-        def tick(name):
-            m_ev = torch.cuda.Event(enable_timing=True)
-            m_ev.record()
-            marks.append((name, m_ev))
         r = _lib.SnkDevReads()
         r.n_reads, r.rows, r.row_words, r.read_len = rows.shape[0], rows.data_ptr(), rows.shape[1], read_len
         if lens is not None:
@@ -466,283 +422,8 @@ class ShardedEngine:
             r.bc = bc.data_ptr()
         r.ign_bc_below, r.read_index_base = ign_bc_below, read_index_base
         p = params.to_c()
-
-        inst_ub = comm.allreduce_sum_int(rows.shape[0] * max(0, read_len - K + 1), dev)
-        NB_total = params.n_buckets if params.n_buckets else plan_buckets(inst_ub, W, K)
-        NB_total = max(NB_total, (inst_ub >> 20) + 1)      # at most ~1 M instances per bucket (one workgroup counts a bucket)
-        NB_total = -(-NB_total // W) * W
-        NBl = NB_total // W
-        # ---- stage 1: trim + histogram
-        hist = torch.empty(NB_total, dtype=torch.int32, device=dev)
-        ninst = C.c_uint64(0)
-        chk(lib.snk_shard_hist(e._ctx, C.byref(r), C.byref(p), me, W, NB_total, hist.data_ptr(), C.byref(ninst), st, err, 512))
-        ev[1].record()
-        off64 = torch.zeros(NB_total + 1, dtype=torch.int64, device=dev)
-        off64[1:] = torch.cumsum(hist.to(torch.int64), 0)
-        n_super = int(off64[-1].item())
-        if n_super >= (1 << 32):
-            raise _lib.SnkError(-6, "more than 2^32 supermers on one rank")
-        # the kernel reads u32; int32 storage holds the same bit patterns (values >= 2^31 wrap)
-        offsets = torch.where(off64 >= (1 << 31), off64 - (1 << 32), off64).to(torch.int32)
-        send = pool.get("send", max(n_super, 1) * 32)
-        chk(lib.snk_shard_scatter(e._ctx, offsets.data_ptr(), send.data_ptr(), st, err, 512))
-        ev[2].record()
-        # ---- exchange #1/#2: histograms and records
-        send_counts = owner_record_counts(off64, W)
-        hist_recv = comm.all_to_all_equal(hist.view(W, NBl))
-        nk = C.c_uint64(0)
-        R = int(os.environ.get("SNK_EXCHANGE_RANGES", "4" if W > 1 else "1"))
-        if R > 1 and hasattr(comm, "exchange_ranged"):
-            # the records travel in R bucket ranges and range r is counted while range r+1 is still on the wire: both
-            # sides know every piece size from the histograms, so nothing but the records is exchanged
-            recv_counts = [int(x) for x in hist_recv.to(torch.int64).sum(dim=1).tolist()]
-            seg_off = segment_offsets(hist_recv, recv_counts)
-            recv = pool.get("recv", max(sum(recv_counts), 1) * 32)
-            bounds = [NBl * q // R for q in range(R + 1)]
-            bidx = torch.tensor(bounds, dtype=torch.int64, device=dev)
-            soff = (off64[(torch.arange(W, device=dev, dtype=torch.int64) * NBl)[:, None] + bidx[None, :]] * 32).tolist()
-            roff = (seg_off[:, bidx] * 32).tolist()
-            works = comm.exchange_ranged(send, recv, soff, roff, R)
-            ev[3].record()
-            failure = []
-
-            def ready(_user, q):
-                try:
-                    for wk in works[q]:
-                        wk.wait()
-                    return 0
-                except BaseException as ex:          # a ctypes callback must not raise
-                    failure.append(ex)
-                    return 1
-            cb = _lib.RANGE_READY(ready)
-            barr = (C.c_uint32 * (R + 1))(*bounds)
-            rc = lib.snk_shard_count_ranged(e._ctx, recv.data_ptr(), seg_off.data_ptr(), inst_ub // W, 1 if bc is not None else 0,
-                                            R, barr, cb, None, C.byref(nk), st, err, 512)
-            if failure:
-                raise failure[0]
-            chk(rc)
-        else:
-            recv, recv_bytes = comm.all_to_all_v(send[: n_super * 32], [c * 32 for c in send_counts], alloc=lambda nb: pool.get("recv", nb))
-            seg_off = segment_offsets(hist_recv, [b // 32 for b in recv_bytes])
-            ev[3].record()
-            # ---- stage 3: count
-            chk(lib.snk_shard_count(e._ctx, recv.data_ptr(), seg_off.data_ptr(), inst_ub // W, 1 if bc is not None else 0,
-                                    C.byref(nk), st, err, 512))
-        ev[4].record()
-        # ---- stage 4: prune with remote queries
-        qcount = (C.c_uint64 * W)()
-        chk(lib.snk_shard_prune_plan(e._ctx, qcount, st, err, 512))
-        qc = [int(x) for x in qcount]
-        qoff = torch.zeros(W + 1, dtype=torch.int64, device=dev)
-        qoff[1:] = torch.cumsum(torch.tensor(qc, dtype=torch.int64, device=dev), 0)
-        nq = sum(qc)
-        qbuf = pool.get("qbuf", max(nq, 1) * 24)
-        chk(lib.snk_shard_prune_fill(e._ctx, qoff.data_ptr(), qbuf.data_ptr(), st, err, 512))
-        qin, qin_bytes = comm.all_to_all_v(qbuf[: nq * 24], [c * 24 for c in qc], alloc=lambda nb: pool.get("qin", nb))
-        nq_in = qin.numel() // 24
-        ans = pool.get("ans", max(nq_in, 1) * 4)
-        chk(lib.snk_shard_prune_answer(e._ctx, qin.data_ptr(), nq_in, ans.data_ptr(), st, err, 512))
-        ans_back, _ = comm.all_to_all_v(ans[: nq_in * 4], [b // 24 * 4 for b in qin_bytes], alloc=lambda nb: pool.get("ans_back", nb))
-        assert ans_back.numel() == nq * 4
-        chk(lib.snk_shard_prune_apply(e._ctx, qbuf.data_ptr(), ans_back.data_ptr(), nq, qoff.data_ptr(), st, err, 512))
-        ev[5].record()
-        # ---- stage 5: local fragments
-        all_n = comm.all_gather_int(int(nk.value), dev)
-        node_off = torch.zeros(W + 1, dtype=torch.int64, device=dev)
-        node_off[1:] = torch.cumsum(torch.tensor(all_n, dtype=torch.int64, device=dev), 0)
-        fr = _lib.SnkShardFrags()
-        chk(lib.snk_shard_fragments(e._ctx, node_off.data_ptr(), int(node_off[me].item()), C.byref(fr), st, err, 512))
-        ev[6].record()
-        # ---- gather fragments on rank 0 and join
-        res = ShardedResult(e, K)
-        res.frags = fr
-        res.n_kmers = int(fr.n_kmers)
-        res.n_instances = int(ninst.value)
-        res.n_supermers = n_super
-        res.n_buckets = NB_total
-        res.n_queries = nq
-        res.n_frags = int(fr.n_frags)
-        F = int(fr.n_frags)
-
-        def dcopy(name, ptr, nbytes):
-            """device-to-device copy of a library-owned buffer into a pooled torch tensor (send buffer)."""
-            t = pool.get(name, max(nbytes, 8))
-            if nbytes:
-                torch.cuda.current_stream().synchronize()
-                _copy_d2d(t.data_ptr(), ptr, nbytes)
-            return t[:nbytes]
-
-        # ---- links between fragments, decided on the owners: an end asks the rank that owns the state it points at
-        tick("start")
-        all_F = comm.all_gather_int(F, dev)
-        frag_off = [0]
-        for x in all_F:
-            frag_off.append(frag_off[-1] + x)
-        if 2 * frag_off[-1] >= (1 << 32):
-            raise _lib.SnkError(-6, "more than 2^31 fragments in the job")
-        lq = (C.c_uint64 * W)()
-        chk(lib.snk_shard_links_plan(e._ctx, frag_off[me], lq, st, err, 512))
-        lqc = [int(x) for x in lq]
-        lqoff = torch.zeros(W + 1, dtype=torch.int64, device=dev)
-        lqoff[1:] = torch.cumsum(torch.tensor(lqc, dtype=torch.int64, device=dev), 0)
-        nlq = sum(lqc)
-        lqbuf = pool.get("lqbuf", max(nlq, 1) * 24)
-        chk(lib.snk_shard_links_fill(e._ctx, lqoff.data_ptr(), lqbuf.data_ptr(), st, err, 512))
-        lqin, lqin_bytes = comm.all_to_all_v(lqbuf[: nlq * 24], [c * 24 for c in lqc], alloc=lambda nb: pool.get("lqin", nb))
-        nlq_in = lqin.numel() // 24
-        lans = pool.get("lans", max(nlq_in, 1) * 4)
-        chk(lib.snk_shard_links_answer(e._ctx, lqin.data_ptr(), nlq_in, lans.data_ptr(), st, err, 512))
-        lans_back, _ = comm.all_to_all_v(lans[: nlq_in * 4], [b // 24 * 4 for b in lqin_bytes], alloc=lambda nb: pool.get("lans_back", nb))
-        assert lans_back.numel() == nlq * 4
-        flink_p = C.c_void_p()
-        chk(lib.snk_shard_links_apply(e._ctx, lqbuf.data_ptr(), lans_back.data_ptr(), nlq, C.byref(flink_p), st, err, 512))
-        res.n_link_queries = nlq
-        tick("links(x)")
-        if self.join == "owner":
-            # ---- owner-side join: every rank sees the job's LINK structure only (12 bytes per fragment), ranks the fragment
-            # lists, places its own fragments and sends each to the rank that owns its unitig's head, which writes the unitig
-            Ft = frag_off[-1]
-            nk_all = comm.all_gather_v(dcopy("s_nk", fr.nk, F * 4), [x * 4 for x in all_F], alloc=lambda nb: pool.get("g_nk", max(nb, 8))[:nb])
-            fl_all = comm.all_gather_v(dcopy("s_link", flink_p.value, F * 8), [x * 8 for x in all_F], alloc=lambda nb: pool.get("g_link", max(nb, 8))[:nb])
-            d_frag_off = torch.tensor(frag_off, dtype=torch.int64, device=dev)
-            tick("gather_links(x)")
-            fto, bto = (C.c_uint64 * W)(), (C.c_uint64 * W)()
-            ranked = False
-            if self.rank_mode == "partitioned":
-                # the two walks of the ruling-set ranking for a 1/W share of the splitters on every rank; 16 B per splitter
-                # (all-gather) and 16 B per state (to its owner) cross the links
-                m_spl, w1p = C.c_uint64(0), C.c_void_p()
-                chk(lib.snk_shard_prank_begin(e._ctx, Ft, nk_all.data_ptr(), fl_all.data_ptr(), frag_off[me], C.byref(m_spl), C.byref(w1p), st, err, 512))
-                m = int(m_spl.value)
-                tick("rank_setup+walk1")
-                shares = [(m * (q + 1) // W - m * q // W) * 16 for q in range(W)]
-                w1_all = comm.all_gather_v(dcopy("s_w1", w1p.value, shares[me]), shares, alloc=lambda nb: pool.get("g_w1", max(nb, 16))[:nb])
-                tick("gather_splitters(x)")
-                rto, circ = (C.c_uint64 * W)(), C.c_uint32(0)
-                chk(lib.snk_shard_prank_walk(e._ctx, w1_all.data_ptr(), d_frag_off.data_ptr(), rto, C.byref(circ), st, err, 512))
-                if not circ.value:
-                    rto = [int(x) for x in rto]
-                    roff_ = [0]
-                    for q in range(W):
-                        roff_.append(roff_[-1] + rto[q])
-                    d_roff = torch.tensor(roff_[:W], dtype=torch.int64, device=dev)
-                    rsend = pool.get("s_rk", max(roff_[-1], 1) * 16)
-                    chk(lib.snk_shard_prank_route(e._ctx, d_frag_off.data_ptr(), d_roff.data_ptr(), rsend.data_ptr(), st, err, 512))
-                    torch.cuda.current_stream().synchronize()
-                    tick("jump+walk2+route")
-                    rk_in, _ = comm.all_to_all_v(rsend[: roff_[-1] * 16], [c * 16 for c in rto], alloc=lambda nb: pool.get("g_rk", max(nb, 16))[:nb])
-                    tick("ranks_to_owners(x)")
-                    chk(lib.snk_shard_place_ranked(e._ctx, K, rk_in.data_ptr(), rk_in.numel() // 16, d_frag_off.data_ptr(), fto, bto, st, err, 512))
-                    ranked = True
-                    res.exchange_bytes_rank = (m * 16, roff_[-1] * 16)
-            if not ranked:      # a list is a circle (same verdict on every rank: it comes from replicated data), or rank_mode == "replicated"
-                chk(lib.snk_shard_place(e._ctx, K, Ft, nk_all.data_ptr(), fl_all.data_ptr(), d_frag_off.data_ptr(), frag_off[me], fto, bto, st, err, 512))
-            res.join_ranking = "partitioned" if ranked else "replicated"
-            tick("place")
-            fto, bto = [int(x) for x in fto], [int(x) for x in bto]
-            hoff, boff_, bpad = route_offsets(fto, bto)
-            d_hoff = torch.tensor(hoff[:W], dtype=torch.int64, device=dev)
-            d_boff = torch.tensor(boff_[:W], dtype=torch.int64, device=dev)
-            hdr = pool.get("s_hdr", max(hoff[-1], 1) * 32)
-            sb = pool.get("s_bases", max(boff_[-1], 16))
-            chk(lib.snk_shard_route_fill(e._ctx, K, d_frag_off.data_ptr(), d_hoff.data_ptr(), d_boff.data_ptr(), hdr.data_ptr(), sb.data_ptr(), st, err, 512))
-            torch.cuda.current_stream().synchronize()
-            tick("route_fill")
-            hdr_in, hdr_bytes = comm.all_to_all_v(hdr[: hoff[-1] * 32], [c * 32 for c in fto], alloc=lambda nb: pool.get("g_hdr", max(nb, 8))[:nb])
-            b_in, b_bytes = comm.all_to_all_v(sb[: boff_[-1]], bpad, alloc=lambda nb: pool.get("g_bases", max(nb, 16))[:nb])
-            hseg, bseg = recv_segments(hdr_bytes, b_bytes)
-            tick("fragments_to_owners(x)")
-            d_hseg = torch.tensor(hseg, dtype=torch.int64, device=dev)
-            d_bseg = torch.tensor(bseg, dtype=torch.int64, device=dev)
-            un = _lib.SnkShardUnitigs()
-            chk(lib.snk_shard_emit(e._ctx, K, hseg[-1], hdr_in.data_ptr(), d_hseg.data_ptr(), d_bseg.data_ptr(), b_in.data_ptr(), C.byref(un), st, err, 512))
-            tick("emit")
-            res.joined = un
-            res.n_unitigs = int(un.n_unitigs)
-            res.exchange_bytes_join = (Ft * 12, hoff[-1] * 32 + boff_[-1])
-            res._keep = (nk_all, fl_all, hdr_in, b_in, d_hseg, d_bseg, d_frag_off)
-        else:
-            # ---- gather on rank 0: k-mers per fragment, links, starts, bases
-            to0 = lambda n: [n if q == 0 else 0 for q in range(W)]
-            TB = int(fr.total_bases)
-            t_nk, _ = comm.all_to_all_v(dcopy("s_nk", fr.nk, F * 4), to0(F * 4), alloc=lambda nb: pool.get("g_nk", nb))
-            t_link, _ = comm.all_to_all_v(dcopy("s_link", flink_p.value, F * 8), to0(F * 8), alloc=lambda nb: pool.get("g_link", nb))
-            t_start, start_bytes = comm.all_to_all_v(dcopy("s_start", fr.boff, F * 8), to0(F * 8), alloc=lambda nb: pool.get("g_start", nb))
-            if W == 1:
-                t_bases, base_bytes = comm.all_to_all_v(dcopy("s_bases", fr.bases, TB), to0(TB), alloc=lambda nb: pool.get("g_bases", nb))
-            else:
-                # the bases are the bulk of the gather (1 byte per k-mer + 47 per fragment): they cross xGMI at 2 bits each
-                all_TB = comm.all_gather_int(TB, dev)
-                pb = int(lib.snk_pack2_bytes(TB))
-                t_pk = pool.get("s_bases2", max(pb, 8))
-                if TB:
-                    chk(lib.snk_dev_pack2(e._ctx, fr.bases, TB, t_pk.data_ptr(), st))
-                    torch.cuda.current_stream().synchronize()
-                t_pk_all, pk_bytes = comm.all_to_all_v(t_pk[:pb], to0(pb), alloc=lambda nb: pool.get("g_bases2", nb))
-                base_bytes = [0] * W
-                t_bases = t_pk_all[:0]
-                if me == 0:
-                    base_bytes = [((x + 15) // 16) * 16 for x in all_TB]          # every rank's bases start 16-byte aligned
-                    t_bases = pool.get("g_bases", max(sum(base_bytes), 16))[:sum(base_bytes)]
-                    a = b = 0
-                    for q in range(W):
-                        if all_TB[q]:
-                            chk(lib.snk_dev_unpack2(e._ctx, t_pk_all.data_ptr() + a, all_TB[q], t_bases.data_ptr() + b, st))
-                        a += pk_bytes[q]
-                        b += base_bytes[q]
-            res.joined = None
-            res.n_unitigs = 0
-            if me == 0:
-                Ft = t_nk.numel() // 4
-                # fragment starts are offsets into their rank's base buffer: shift by the buffers in front
-                # (in place, one slice per source rank: torch.repeat_interleave over the fragments took 6.8 ms per 17.5 M)
-                starts_all = t_start.view(torch.int64)
-                a, shift = 0, 0
-                for q in range(W):
-                    nq = start_bytes[q] // 8
-                    if shift and nq:
-                        starts_all[a:a + nq] += shift
-                    a += nq
-                    shift += base_bytes[q]
-                if starts_all.numel() == 0:
-                    starts_all = torch.zeros(1, dtype=torch.int64, device=dev)
-                if t_link.numel() == 0:
-                    t_link = torch.zeros(8, dtype=torch.uint8, device=dev)
-                un = _lib.SnkShardUnitigs()
-                chk(lib.snk_shard_join_linked(e._ctx, K, Ft, t_nk.data_ptr(), None, None, t_link.data_ptr(), starts_all.data_ptr(),
-                                              t_bases.data_ptr(), t_bases.numel(), C.byref(un), st, err, 512))
-                res.joined = un
-                res.n_unitigs = int(un.n_unitigs)
-                res._keep = (t_nk, t_link, starts_all, t_bases)
-        ev[7].record()
-        torch.cuda.synchronize()
-        names = ["partition", "compact", "exchange", "count", "prune", "fragments", "join"]
-        res.phase_ms = {names[i]: ev[i].elapsed_time(ev[i + 1]) for i in range(7)}
-        res.phase_ms["total"] = ev[0].elapsed_time(ev[7])
-        # sections of the join; "(x)" = an exchange (transport + the waits for the other ranks), the rest is this rank's compute
-        res.join_ms = {marks[i + 1][0]: marks[i][1].elapsed_time(marks[i + 1][1]) for i in range(len(marks) - 1)}
-        res.kernel_ms = {"count": float(fr.count_kernel_ms)}
-        res.buckets_split = int(fr.buckets_split)
-        return res
-
-
-def _copy_d2d(dst_ptr: int, src_ptr: int, nbytes: int) -> None:
-    """hipMemcpy device-to-device through the process's HIP runtime (the one torch uses)."""
-    hip = _hip()
-    rc = hip.hipMemcpy(C.c_void_p(dst_ptr), C.c_void_p(src_ptr), C.c_size_t(nbytes), 3)  # hipMemcpyDeviceToDevice = 3
-    if rc != 0:
-        raise RuntimeError(f"hipMemcpy D2D failed ({rc})")
-
-
-_hip_handle = None
-
-
-def _hip():
-    global _hip_handle
-    if _hip_handle is None:
-        from pathlib import Path
-        cand = Path(torch.__file__).parent / "lib" / "libamdhip64.so"
-        _hip_handle = C.CDLL(str(cand if cand.exists() else "libamdhip64.so"), mode=C.RTLD_GLOBAL)
-        _hip_handle.hipMemcpy.restype = C.c_int
-        _hip_handle.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    return _hip_handle
+        raw = _lib.SnkShardResult()
+        rc = lib.snk_shard_step(e._ctx, self.comm, C.byref(r), C.byref(p), int(total_reads), 0, C.byref(raw), e._stream(), err, 512)
+        if rc != 0:
+            raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+        return ShardedResult(e, params.K, raw)
