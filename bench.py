@@ -59,6 +59,11 @@ def parse():
                          "replicas only for N>1 (every rank owns whole barcodes, no collective)")
     ap.add_argument("--min-freq", type=int, default=3)
     ap.add_argument("--no-verify", action="store_true", help="skip the untimed self-check of the sharded path")
+    ap.add_argument("--no-next-rows", action="store_true", help="N=1: skip the untimed f1/f4 rows (read pathing, MarkDups, barcode lists) on the bench workload")
+    ap.add_argument("--no-ingest", action="store_true", help="N=1: skip the untimed f3 row (FASTH files -> HBM)")
+    ap.add_argument("--ingest-files", type=int, default=64)
+    ap.add_argument("--ingest-pairs", type=int, default=100_000, help="read pairs per FASTH file of the f3 row")
+    ap.add_argument("--ingest-threads", type=int, default=0, help="decode threads (0 = one per file up to the host's hardware threads)")
     return ap.parse_args()
 
 
@@ -102,6 +107,67 @@ def cpu_baseline(sp_full, K: int, sample_reads: int, threads=(16, 64, 256)):
     secs = time.time() - t0
     return {"value": o.n_instances / secs / 1e9, "unit": "Gk-mers/s", "cores": 1, "kind": "port",
             "sample": f"{n} reads x {sp.read_len} bp, oracle/snk_oracle.c count+unitigs, {secs:.2f} s single thread"}
+
+
+def next_rows(eng, res, rows, quals, bc, read_len, K):
+    """f1 / f4 on the bench workload, untimed rows next to the contract line: HIP-event times of the library's own
+    phases, each with the bytes its data model moves once and the fraction of the HBM peak that is."""
+    n = int(rows.shape[0])
+    _, _, _, info = res.path_reads(rows, read_len, quals, mark_dups=True, bc=bc, unitig_bcs=True, download=False)
+    rw, qs = int(rows.shape[1]) * 4, int(quals.shape[1])
+    frac = lambda nbytes, ms: (nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms > 0 else None
+    path_bytes = n * (rw + qs + 16) + info["n_edges_total"] * 4
+    dict_bytes = info["dict_slots"] * 32 + int(res.unitig_total_bases)
+    dup_bytes = n * (16 + rw + 2 * 12)          # path head (edge, offset), mate head row, two sort passes over 12-byte (key, id) records
+    bcs_bytes = n * 8 * 4                       # one 8-byte (unitig, barcode) key per barcoded read through a 64-bit radix sort (write + read, twice)
+    d = info["dups"]
+    return {
+        "reads": n,
+        "f1_dictionary_build": {"ms": round(info["dict_ms"], 3), "slots": info["dict_slots"], "alg_bytes": dict_bytes, "hbm_frac": frac(dict_bytes, info["dict_ms"])},
+        "f1_read_pathing": {"ms": round(info["path_ms"], 3), "reads_per_s": n / (info["path_ms"] * 1e-3), "edges": info["n_edges_total"],
+                            "alg_bytes": path_bytes, "hbm_frac": frac(path_bytes, info["path_ms"])},
+        "f2_hbv_device_ms": round(info["hbv_device_ms"], 3),
+        "f4_mark_dups": {"ms": round(d["ms"], 3), "dup_pairs": d["n_dup_pairs"], "interdup_rate": d["interdup_rate"], "alg_bytes": dup_bytes,
+                         "hbm_frac": frac(dup_bytes, d["ms"])},
+        "f4_unitig_barcode_lists": {"ms": round(info["bcs_ms"], 3), "entries": info["n_unitig_bcs"], "alg_bytes": bcs_bytes, "hbm_frac": frac(bcs_bytes, info["bcs_ms"])},
+    }
+
+
+def ingest_row(eng, args, K, step_ms_per_read):
+    """f3: synthetic FASTH files -> reads resident in HBM (parallel inflate, uploads / pack / barcode ids overlapped),
+    then the same count+graph step on what arrived."""
+    import shutil
+    from supernova_amd import ingest, synth
+    from supernova_amd.engine import Params
+    nf, ppf = args.ingest_files, args.ingest_pairs
+    n = 2 * nf * ppf
+    sp = synth.synth_params(n, seed=0x5EED0F33)
+    td = Path(tempfile.mkdtemp(prefix="snk_fasth_", dir=os.environ.get("TMPDIR", "/tmp")))
+    try:
+        t0 = time.perf_counter()
+        paths, text = ingest.write_synth_fasth(td, sp, nf, ppf, workers=os.cpu_count() or 8)
+        t_write = time.perf_counter() - t0
+        nbc = n // (2 * sp.pairs_per_bc) + 8
+        wl = ingest.synth_whitelist(nbc)
+        best = None
+        for _ in range(2):                      # the second pass has the files in the page cache for certain
+            dr = ingest.ingest_fasth(eng, paths, sp.read_len, wl, threads=args.ingest_threads)
+            st = dr.stats
+            if best is None or st["seconds"] < best["seconds"]:
+                best = dict(st)
+            res = eng.count_graph_reads(dr.dev_reads(), Params(K=K, sorted_table=False))
+            n_k, n_u = int(res.n_kmers), int(res.n_unitigs)
+            dr.close()
+        secs = best["seconds"]
+        return {"files": nf, "reads": n, "text_GB": text / 1e9, "compressed_GB": best["compressed_bytes"] / 1e9, "seconds": secs,
+                "text_GB_per_s": text / secs / 1e9, "reads_per_s": n / secs, "decode_wait_share": best["decode_wait_seconds"] / secs,
+                "setup_seconds": best["setup_seconds"], "text_GB_per_s_after_setup": text / max(secs - best["setup_seconds"], 1e-9) / 1e9,
+                "decode_threads": args.ingest_threads or min(nf, os.cpu_count() or 1), "host_threads": os.cpu_count(),
+                "count_graph_on_ingested": {"retained_kmers": n_k, "unitigs": n_u},
+                # how long the device step of the same reads is against their ingest: the share of the ingest the step hides behind
+                "step_over_ingest": (step_ms_per_read * n * 1e-3) / secs, "synth_files_written_in_s": t_write}
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
 
 
 def main():
@@ -277,6 +343,18 @@ def main():
                 out["value"] = None
                 out["invalid"] = "the sharded path's self-check against the one-GPU path failed"
 
+        if world == 1 and not use_dist and not args.grouped:
+            out["config"]["excludes"] = "a13/a14 (BVComp order, .bv image, HBV) and the key-sorted table are outside the timed step; see next_rows / hbv"
+            if not args.no_next_rows:
+                try:
+                    out["config"]["next_rows"] = next_rows(eng, step(), rows, quals, bc, sp.read_len, K)
+                except Exception as ex:
+                    out["config"]["next_rows"] = {"failed": str(ex)}
+            if not args.no_ingest:
+                try:
+                    out["config"]["f3_ingest"] = ingest_row(eng, args, K, ms_per_step / per_gpu)
+                except Exception as ex:
+                    out["config"]["f3_ingest"] = {"failed": str(ex)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(sp, K, args.cpu_sample, tuple(int(x) for x in args.cpu_threads.split(",")))

@@ -429,6 +429,7 @@ typedef struct snk_dev_paths {
     const void* unitig_bc_off; /* u64[n_unitigs + 1] */
     const void* unitig_bcs;    /* u32[n_unitig_bcs] */
     uint64_t n_unitig_bcs;
+    float bcs_ms, reserved_f;  /* HIP events: key sort + run heads + per-unitig lists (SNK_PATH_UNITIG_BCS) */
 } snk_dev_paths;
 #define SNK_PATH_UNITIG_BCS 1u
 int snk_dev_path_reads(snk_ctx* ctx, uint32_t K, const snk_dev_reads* in, uint64_t n_unitigs, const void* d_unitig_off, const void* d_unitig_bases,
@@ -502,6 +503,54 @@ int snk_read_bci(const char* path, uint64_t n_reads, int32_t* bc_per_read, uint6
 int snk_read_fasth(const char* path, uint32_t stride, uint64_t* n_reads, uint32_t* max_len, uint8_t** ascii, uint8_t** quals,
                    uint16_t** lens, uint8_t** bc_fields, char* err, size_t errcap);
 void snk_host_free(void* p);
+
+/* f3 at rate: many FASTH files decoded concurrently (the reference: one decode thread per two files, lib/tada/src/cmd_msp.rs:55-69,
+ * over MultiFastqIter, multifastq.rs:69-127; like it, a file that is not gzip is refused).  A pool of `threads` workers
+ * (0 = one per file up to the host's hardware threads) takes whole files, inflates with zlib's streaming API and parses the
+ * records in place into batches of `batch_pairs` read pairs (0 = 32768); snk_fasth_next hands out full batches in any order
+ * (file / first_pair say where a batch belongs), n_pairs == 0 = every file has been read to its end.  flags bit 0: the batches
+ * live in page-locked memory (needs a GPU).  Rows of `stride` bytes: bases 'A'-padded, raw phred 0-padded. */
+typedef struct snk_fasth_stream snk_fasth_stream;
+typedef struct snk_fasth_batch {
+    uint64_t n_pairs;           /* reads 2q, 2q+1 of the batch = R1, R2 of its pair q (cmd_msp.rs:160-181) */
+    uint64_t first_pair;        /* index of the batch's first pair inside its file */
+    uint32_t file, max_len;
+    const uint8_t* ascii;       /* 2*n_pairs rows */
+    const uint8_t* quals;
+    const uint16_t* lens;       /* 2*n_pairs */
+    const uint8_t* bc_fields;   /* n_pairs x 64 bytes, zero padded: the barcode field up to its first ',' */
+    uint64_t text_bytes;        /* inflated bytes this batch was parsed from */
+    uint64_t token;
+} snk_fasth_batch;
+int snk_fasth_open(const char* const* paths, uint32_t n_files, uint32_t stride, uint32_t batch_pairs, uint32_t threads, uint32_t flags,
+                   snk_fasth_stream** out, char* err, size_t errcap);
+int snk_fasth_next(snk_fasth_stream* s, snk_fasth_batch* out, char* err, size_t errcap);
+void snk_fasth_release(snk_fasth_stream* s, snk_fasth_batch* b);      /* the batch's buffers go back to the workers */
+uint64_t snk_fasth_file_pairs(snk_fasth_stream* s, uint32_t file);   /* known once the file has been read to its end */
+void snk_fasth_close(snk_fasth_stream* s);
+/* ... and into HBM: packed rows (snk_dev_pack_ascii), quality rows, lengths and -- with a whitelist index -- barcode ids
+ * (snk_dev_bc_ids, one per read), in file-major order; uploads, pack and id lookup overlap the decode.  The arrays are plain
+ * device allocations (not the context's arena: they are the INPUT of snk_dev_count_graph); snk_dev_ingest_free releases them. */
+typedef struct snk_dev_ingest {
+    uint64_t n_reads;
+    uint32_t read_len, row_words, qstride, max_len;
+    const void* rows;
+    const void* quals;
+    const void* lens;
+    const void* bc;             /* NULL without an index */
+    uint64_t text_bytes, compressed_bytes;
+    double seconds, decode_wait_seconds;   /* whole call; of it, time the consumer waited for a decoded batch */
+    uint32_t n_files, n_batches;
+    double setup_seconds;                  /* of `seconds`: page-locked batch pool + device arrays allocated, workers started */
+} snk_dev_ingest;
+int snk_dev_ingest_fasth(snk_ctx* ctx, const char* const* paths, uint32_t n_files, uint32_t read_len, const snk_bc_index* ix, uint32_t threads,
+                         uint32_t batch_pairs, snk_dev_ingest* out, char* err, size_t errcap);
+void snk_dev_ingest_free(snk_dev_ingest* r);
+/* synthetic FASTH (tests, bench.py --ingest): pairs [first_pair, first_pair + n_pairs) of the synthetic read model as one gzip
+ * file; barcode field = snk_synth_bc_seq(id) + "-1" (",raw" appended on every third pair), an off-whitelist sequence for id 0 */
+int snk_synth_fasth_write(const char* path, const snk_synth_params* sp, uint64_t first_pair, uint64_t n_pairs, int level, uint64_t* text_bytes,
+                          char* err, size_t errcap);
+void snk_synth_bc_seq(uint32_t id, char* out16);
 
 #ifdef __cplusplus
 }

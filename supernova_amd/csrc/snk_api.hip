@@ -1,5 +1,6 @@
 // snk_api.hip -- context, error plumbing, synthetic read generator entry points of libsnk.
 #include <math.h>
+#include <stdlib.h>
 
 #include "snk_ctx.h"
 #include "snk_synth.h"
@@ -29,7 +30,12 @@ int snk_fail(int code, char* err, size_t errcap, const char* fmt, ...) {
 }
 
 static thread_local uint64_t g_syncs = 0;
-hipError_t snk_sync(hipStream_t st) { ++g_syncs; return hipStreamSynchronize(st); }
+hipError_t snk_sync_at(hipStream_t st, const char* file, int line) {
+    static const bool trace = getenv("SNK_SYNC_TRACE") && *getenv("SNK_SYNC_TRACE") == '1';
+    ++g_syncs;
+    if (trace) { const char* b = strrchr(file, '/'); fprintf(stderr, "[snk sync %llu] %s:%d\n", (unsigned long long)g_syncs, b ? b + 1 : file, line); }
+    return hipStreamSynchronize(st);
+}
 uint64_t snk_sync_count() { return g_syncs; }
 
 extern "C" const char* snk_version(void) { return "libsnk 0.1 (gfx950)"; }

@@ -24,6 +24,7 @@ struct snk_ctx {
     size_t cached_bytes = 0;    // bytes held by the arena
     uint64_t last_n_kmers = 0, last_n_instances = 0;   // sizing hint from the previous call
     uint32_t last_extra = 0;                           // split sub-passes the previous call recorded
+    std::vector<unsigned long long> h_region_off;      // host copy of the count regions' dense offsets (source of an async upload)
     void* shard = nullptr;      // snk_shard_state (snk_dist.hip)
     void* host_io = nullptr;    // pinned staging + device input buffers of the host-pointer entry point (snk_host.hip)
     void (*host_io_free)(void*) = nullptr;
@@ -34,8 +35,9 @@ struct snk_ctx {
 void snk_set_error(char* err, size_t errcap, const char* fmt, ...);
 // every host wait for a stream goes through here: the calling thread's count is what the sharded step reports as
 // host_syncs (a host thread = a rank)
-hipError_t snk_sync(hipStream_t st);
+hipError_t snk_sync_at(hipStream_t st, const char* file, int line);     // SNK_SYNC_TRACE=1: every wait is logged with its site
 uint64_t snk_sync_count();
+#define snk_sync(st) snk_sync_at((st), __FILE__, __LINE__)
 int snk_fail(int code, char* err, size_t errcap, const char* fmt, ...);
 
 #define SNK_HIP_TRY(expr)                                                                          \

@@ -53,9 +53,13 @@ int snk_shard_begin(snk_ctx* ctx, const snk_dev_reads* in, const snk_params* p, 
     if ((rc = snk_ctx_alloc(ctx, 64, &q, err, errcap))) return rc; S->status = (uint32_t*)q;
     SNK_HIP_TRY(hipMemsetAsync(S->status, 0, 64, st));
     // one partition pass into fixed-capacity bucket slots (as on one GPU); the histogram is its cursor array
+    // the slots are sized from what the untrimmed reads could hold at most (a few per cent above what the trim leaves: the
+    // capacity is 2.5 x the mean anyway); the exact instance count comes back with the partition's own read-back
     unsigned long long h_plan[2] = {0, 0};
-    if ((rc = snk_stage_partition_plan(ctx, st, p->K, good_len, in->n_reads, h_plan, err, errcap))) return rc;
-    if ((rc = snk_stage_partition(ctx, st, p->K, in, good_len, NB_total, h_plan[0], h_plan[1], false, S->status, &S->part, err, errcap))) return rc;
+    unsigned long long* d_plan = nullptr;
+    if ((rc = snk_stage_partition_plan(ctx, st, p->K, good_len, in->n_reads, h_plan, err, errcap, &d_plan))) return rc;
+    const unsigned long long kpr = in->read_len >= p->K ? in->read_len - p->K + 1 : 0;
+    if ((rc = snk_stage_partition(ctx, st, p->K, in, good_len, NB_total, in->n_reads * kpr, in->n_reads, false, S->status, &S->part, err, errcap, d_plan, h_plan))) return rc;
     if (n_instances) *n_instances = h_plan[0];
     return SNK_OK;
 }
@@ -108,7 +112,7 @@ extern "C" int snk_shard_count_ranged(snk_ctx* ctx, const void* d_records, const
 }
 
 extern "C" int snk_shard_prune_plan(snk_ctx* ctx, uint64_t* h_qcount, void* stream, char* err, size_t errcap) {
-    if (!ctx || !ctx->shard || !h_qcount) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_prune_plan: NULL argument / no session");
+    if (!ctx || !ctx->shard) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_prune_plan: NULL argument / no session");
     snk_shard_state* S = state_of(ctx);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     // bucket-local prune (snk_local.hip); only neighbours owned by another rank become queries
@@ -118,9 +122,9 @@ extern "C" int snk_shard_prune_plan(snk_ctx* ctx, uint64_t* h_qcount, void* stre
     B.K = S->params.K; B.rank = S->rank; B.world = S->world; B.NB_total = S->NB_total; B.NBl = S->NBl;
     B.do_prune = S->params.min_freq > 1 ? 1u : 0u;
     std::vector<unsigned long long> h(S->world);
-    int rc = snk_bl_dist_plan(ctx, st, &B, h.data(), err, errcap);
+    int rc = snk_bl_dist_plan(ctx, st, &B, h_qcount ? h.data() : nullptr, err, errcap);      // NULL: the counts stay on the device (B.qcount)
     if (rc) return rc;
-    for (uint32_t r = 0; r < S->world; ++r) h_qcount[r] = h[r];
+    if (h_qcount) for (uint32_t r = 0; r < S->world; ++r) h_qcount[r] = h[r];
     // the answering / applying kernels of the global sharded stage work on the same arrays
     snk_dist_graph& g = S->g;
     memset(&g, 0, sizeof g);
@@ -363,6 +367,10 @@ static int place_and_count(snk_ctx* ctx, snk_shard_state* S, hipStream_t st, uin
     int rc;
     if ((rc = snk_join_place(ctx, st, rk, nk_all, circ, S->my_frag_off, Fl, &S->pl, err, errcap, rk_f0))) return rc;
     void* q;
+    if (!h_frags_to) {          // the caller routes in one pass into per-owner regions (snk_shard_step.hip): nothing to count
+        if ((rc = snk_ctx_alloc(ctx, 2ull * (S->world + 1) * 8, &q, err, errcap))) return rc; S->rt_cursor = (unsigned long long*)q;
+        return SNK_OK;
+    }
     if ((rc = snk_ctx_alloc(ctx, 2ull * (S->world + 1) * 8, &q, err, errcap))) return rc; S->rt_count = (unsigned long long*)q;
     if ((rc = snk_ctx_alloc(ctx, 2ull * (S->world + 1) * 8, &q, err, errcap))) return rc; S->rt_cursor = (unsigned long long*)q;
     SNK_HIP_TRY(hipMemsetAsync(S->rt_count, 0, 2ull * (S->world + 1) * 8, st));
@@ -379,7 +387,7 @@ static int place_and_count(snk_ctx* ctx, snk_shard_state* S, hipStream_t st, uin
 extern "C" int snk_shard_place(snk_ctx* ctx, uint32_t K, uint64_t n_frags_total, const void* d_nk_all, void* d_flink_all, const void* d_frag_off,
                                uint64_t my_frag_off, uint64_t* h_frags_to /* [world] */, uint64_t* h_bases_to /* [world] */, void* stream, char* err,
                                size_t errcap) {
-    if (!ctx || !ctx->shard || !d_frag_off || !h_frags_to || !h_bases_to) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_place: NULL argument / no session");
+    if (!ctx || !ctx->shard || !d_frag_off || (!h_frags_to) != (!h_bases_to)) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_place: NULL argument / no session");
     snk_shard_state* S = state_of(ctx);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     if (2 * n_frags_total >= (1ull << 32)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "more than 2^31 fragments in the job");
@@ -405,19 +413,19 @@ extern "C" int snk_shard_prank_begin(snk_ctx* ctx, uint64_t n_frags_total, const
     S->nk_all = (const uint32_t*)d_nk_all;
     int rc = snk_prank_begin(ctx, st, n_frags_total, (const uint32_t*)d_nk_all, (uint32_t*)d_flink_all, S->rank, S->world, &S->pr, err, errcap);
     if (rc) return rc;
-    SNK_HIP_TRY(snk_sync(st));
-    *n_splitters = S->pr.m;
+    *n_splitters = S->pr.m;       // (the share is consumed by a collective on the same stream: nothing to wait for here)
     *d_w1_share = S->pr.w1_share;
     return SNK_OK;
 }
 extern "C" int snk_shard_prank_walk(snk_ctx* ctx, const void* d_w1_all, const void* d_frag_off, uint64_t* h_recs_to /* [world] */, uint32_t* circles,
                                     void* stream, char* err, size_t errcap) {
-    if (!ctx || !ctx->shard || !h_recs_to || !circles) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_prank_walk: NULL argument / no session");
+    if (!ctx || !ctx->shard || !circles) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_prank_walk: NULL argument / no session");
     snk_shard_state* S = state_of(ctx);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     S->join_circles = 0;
     int rc = snk_prank_walk(ctx, st, &S->pr, (const uint4*)d_w1_all, circles, &S->join_rounds, err, errcap);
     if (rc) return rc;
+    if (!h_recs_to) return SNK_OK;       // one-pass routing into per-owner regions: S->pr.n_rec records, no count pass
     for (uint32_t r = 0; r < S->world; ++r) h_recs_to[r] = 0;
     if (*circles) return SNK_OK;
     void* q;
@@ -440,11 +448,12 @@ extern "C" int snk_shard_prank_route(snk_ctx* ctx, const void* d_frag_off, const
     int rc;
     if ((rc = snk_ctx_alloc(ctx, (S->world + 1) * 8ull, &q, err, errcap))) return rc;
     SNK_HIP_TRY(hipMemcpyAsync(q, d_rec_off, S->world * 8ull, hipMemcpyDeviceToDevice, st));
+    S->pr_cursor = (unsigned long long*)q;
     return snk_prank_route(ctx, st, &S->pr, true, (const unsigned long long*)d_frag_off, S->world, (unsigned long long*)q, d_out, err, errcap);
 }
 extern "C" int snk_shard_place_ranked(snk_ctx* ctx, uint32_t K, const void* d_recs, uint64_t n_recs, const void* d_frag_off, uint64_t* h_frags_to,
                                       uint64_t* h_bases_to, void* stream, char* err, size_t errcap) {
-    if (!ctx || !ctx->shard || !d_frag_off || !h_frags_to || !h_bases_to) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_place_ranked: NULL argument / no session");
+    if (!ctx || !ctx->shard || !d_frag_off || (!h_frags_to) != (!h_bases_to)) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_place_ranked: NULL argument / no session");
     snk_shard_state* S = state_of(ctx);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     const uint2* rk = nullptr;

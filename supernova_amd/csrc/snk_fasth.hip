@@ -160,8 +160,8 @@ bool decode_file(snk_fasth_stream* s, uint32_t fi) {
             if (first_byte && got >= 2) { first_byte = false; if (in[0] != 0x1f || in[1] != 0x8b) { what = path + ": not a gz file"; ok = false; break; } }
         }
         if (eof_in && zs.avail_in == 0) break;
-        if (have == WIN) {
-            // the window is full: keep the incomplete line, drop the rest
+        if (have == WIN || line_beg > WIN / 2) {
+            // keep the incomplete line, drop what has been parsed
             if (line_beg == 0) { what = path + ": a line longer than " + std::to_string(WIN) + " bytes"; ok = false; break; }
             memmove(win.data(), win.data() + line_beg, have - line_beg);
             have -= line_beg; scan -= line_beg; line_beg = 0;
@@ -358,4 +358,169 @@ extern "C" int snk_synth_fasth_write(const char* path, const snk_synth_params* s
     if (gzclose(f) != Z_OK && rc == SNK_OK) rc = snk_fail(SNK_E_IO, err, errcap, "snk_synth_fasth_write: close error on %s", path);
     if (text_bytes) *text_bytes = total;
     return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// FASTH files -> reads resident in HBM (packed 2-bit rows, quality rows, lengths, barcode ids), file-major order.
+// The caller's thread is the consumer of the decode workers: every batch goes up with asynchronous copies out of its
+// page-locked buffers -- quality rows and lengths straight to their place, the ASCII rows and barcode fields through a small
+// staging ring from which snk_dev_pack_ascii / snk_dev_bc_ids take them -- while the workers inflate the next batches.
+// Batches arrive in any order; the arrays are put into file-major order at the end (one device copy per batch and array).
+namespace {
+__global__ void __launch_bounds__(256) pair_ids_kernel(const int32_t* __restrict__ pair_ids, uint64_t n_pairs, int32_t* __restrict__ read_ids) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < 2 * n_pairs) read_ids[i] = pair_ids[i >> 1];
+}
+struct ingest_arrays {
+    uint32_t* rows = nullptr; uint8_t* quals = nullptr; uint16_t* lens = nullptr; int32_t* bc = nullptr;
+    uint64_t cap = 0;
+    void release() { (void)hipFree(rows); (void)hipFree(quals); (void)hipFree(lens); (void)hipFree(bc); rows = nullptr; quals = nullptr; lens = nullptr; bc = nullptr; cap = 0; }
+};
+int alloc_arrays(ingest_arrays& a, uint64_t cap, uint32_t row_words, uint32_t qstride, bool want_bc, char* err, size_t errcap) {
+    a.cap = cap;
+    SNK_HIP_TRY(hipMalloc((void**)&a.rows, (cap + 1) * row_words * 4ull));
+    SNK_HIP_TRY(hipMalloc((void**)&a.quals, (cap + 1) * (uint64_t)qstride));
+    SNK_HIP_TRY(hipMalloc((void**)&a.lens, (cap + 8) * 2ull));
+    if (want_bc) SNK_HIP_TRY(hipMalloc((void**)&a.bc, (cap + 2) * 4ull));
+    return SNK_OK;
+}
+double now_s() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+}  // namespace
+
+extern "C" int snk_dev_ingest_fasth(snk_ctx* ctx, const char* const* paths, uint32_t n_files, uint32_t read_len, const snk_bc_index* ix, uint32_t threads,
+                                    uint32_t batch_pairs, snk_dev_ingest* out, char* err, size_t errcap) {
+    if (!ctx || !paths || !out || n_files == 0) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_ingest_fasth: NULL argument");
+    if (read_len == 0 || read_len > 256) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_ingest_fasth: read_len must be 1..256");
+    memset(out, 0, sizeof *out);
+    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    const uint32_t stride = (read_len + 15) / 16 * 16, row_words = (read_len + 15) / 16, qstride = stride;
+    if (batch_pairs == 0) batch_pairs = 32768;
+    const double t0 = now_s();
+    // capacity guess from the compressed sizes (a read is ~330 bytes of text, FASTH deflates ~4x); the arrays grow if it is wrong
+    uint64_t comp = 0;
+    for (uint32_t i = 0; i < n_files; ++i) { FILE* f = fopen(paths[i], "rb"); if (f) { fseek(f, 0, SEEK_END); const long n = ftell(f); if (n > 0) comp += (uint64_t)n; fclose(f); } }
+    uint64_t cap = comp / 70 + 4ull * batch_pairs;
+    snk_fasth_stream* fs = nullptr;
+    int rc = snk_fasth_open(paths, n_files, stride, batch_pairs, threads, 1u, &fs, err, errcap);
+    if (rc) return rc;
+    hipStream_t cs = nullptr;
+    constexpr int NST = 4;
+    uint8_t* st_ascii[NST] = {nullptr, nullptr, nullptr, nullptr};
+    uint8_t* st_bcf[NST] = {nullptr, nullptr, nullptr, nullptr};
+    int32_t* st_ids[NST] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t st_ev[NST] = {nullptr, nullptr, nullptr, nullptr};
+    bool st_busy[NST] = {false, false, false, false};
+    ingest_arrays A, Bf;
+    struct piece { uint32_t file; uint64_t first_pair, n_pairs, at; };
+    std::vector<piece> pieces;
+    struct pend { hipEvent_t ev; snk_fasth_batch b; };
+    std::deque<pend> pending;
+    uint64_t n_reads = 0, text = 0;
+    uint32_t max_len = 0;
+    auto cleanup = [&]() {
+        if (cs) (void)hipStreamSynchronize(cs);
+        for (auto& p : pending) { (void)hipEventDestroy(p.ev); snk_fasth_release(fs, &p.b); }
+        pending.clear();
+        for (int q = 0; q < NST; ++q) { (void)hipFree(st_ascii[q]); (void)hipFree(st_bcf[q]); (void)hipFree(st_ids[q]); if (st_ev[q]) (void)hipEventDestroy(st_ev[q]); }
+        if (cs) (void)hipStreamDestroy(cs);
+        if (fs) snk_fasth_close(fs);
+    };
+#define ING_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); A.release(); Bf.release(); return snk_fail(_e == hipErrorOutOfMemory ? SNK_E_NOMEM : SNK_E_HIP, err, errcap, "%s failed: %s", #expr, hipGetErrorString(_e)); } } while (0)
+#define ING_RC(expr) do { int _r = (expr); if (_r) { cleanup(); A.release(); Bf.release(); return _r; } } while (0)
+    ING_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    for (int q = 0; q < NST; ++q) {
+        ING_TRY(hipMalloc((void**)&st_ascii[q], 2ull * batch_pairs * stride));
+        ING_TRY(hipMalloc((void**)&st_bcf[q], (size_t)batch_pairs * 64));
+        ING_TRY(hipMalloc((void**)&st_ids[q], (size_t)batch_pairs * 4));
+        ING_TRY(hipEventCreateWithFlags(&st_ev[q], hipEventDisableTiming));
+    }
+    ING_RC(alloc_arrays(A, cap, row_words, qstride, ix != nullptr, err, errcap));
+    int slot = 0;
+    double wait_s = 0;
+    const double t_ready = now_s();          // decode threads running, page-locked batches and device arrays allocated
+    for (;;) {
+        // hand back the batches whose copies are done (never more than two outstanding: the workers need them)
+        while (!pending.empty() && (pending.size() > 2 || hipEventQuery(pending.front().ev) == hipSuccess)) {
+            ING_TRY(hipEventSynchronize(pending.front().ev));
+            (void)hipEventDestroy(pending.front().ev);
+            snk_fasth_release(fs, &pending.front().b);
+            pending.pop_front();
+        }
+        snk_fasth_batch b;
+        const double w0 = now_s();
+        ING_RC(snk_fasth_next(fs, &b, err, errcap));
+        wait_s += now_s() - w0;
+        if (b.n_pairs == 0) break;
+        const uint64_t nr = 2 * b.n_pairs;
+        if (n_reads + nr > A.cap) {
+            ingest_arrays N;
+            const uint64_t ncap = A.cap + A.cap / 2 + nr;
+            int r2 = alloc_arrays(N, ncap, row_words, qstride, ix != nullptr, err, errcap);
+            if (r2) { N.release(); snk_fasth_release(fs, &b); cleanup(); A.release(); return r2; }
+            ING_TRY(hipMemcpyAsync(N.rows, A.rows, n_reads * row_words * 4ull, hipMemcpyDeviceToDevice, cs));
+            ING_TRY(hipMemcpyAsync(N.quals, A.quals, n_reads * (uint64_t)qstride, hipMemcpyDeviceToDevice, cs));
+            ING_TRY(hipMemcpyAsync(N.lens, A.lens, n_reads * 2ull, hipMemcpyDeviceToDevice, cs));
+            if (ix) ING_TRY(hipMemcpyAsync(N.bc, A.bc, n_reads * 4ull, hipMemcpyDeviceToDevice, cs));
+            ING_TRY(hipStreamSynchronize(cs));
+            A.release();
+            A = N;
+        }
+        if (st_busy[slot]) { ING_TRY(hipEventSynchronize(st_ev[slot])); st_busy[slot] = false; }
+        ING_TRY(hipMemcpyAsync(st_ascii[slot], b.ascii, nr * (uint64_t)stride, hipMemcpyHostToDevice, cs));
+        ING_TRY(hipMemcpyAsync(A.quals + n_reads * (uint64_t)qstride, b.quals, nr * (uint64_t)stride, hipMemcpyHostToDevice, cs));
+        ING_TRY(hipMemcpyAsync(A.lens + n_reads, b.lens, nr * 2ull, hipMemcpyHostToDevice, cs));
+        if (ix) ING_TRY(hipMemcpyAsync(st_bcf[slot], b.bc_fields, b.n_pairs * 64ull, hipMemcpyHostToDevice, cs));
+        pend pe;
+        ING_TRY(hipEventCreateWithFlags(&pe.ev, hipEventDisableTiming));
+        ING_TRY(hipEventRecord(pe.ev, cs));
+        pe.b = b;
+        pending.push_back(pe);
+        ING_RC(snk_dev_pack_ascii(ctx, st_ascii[slot], stride, read_len, nr, A.rows + n_reads * row_words, row_words, cs));
+        if (ix) {
+            ING_RC(snk_dev_bc_ids(ctx, ix, st_bcf[slot], 64, b.n_pairs, st_ids[slot], cs, err, errcap));
+            hipLaunchKernelGGL(pair_ids_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, cs, st_ids[slot], b.n_pairs, A.bc + n_reads);
+        }
+        ING_TRY(hipEventRecord(st_ev[slot], cs));
+        st_busy[slot] = true;
+        slot = (slot + 1) % NST;
+        pieces.push_back({b.file, b.first_pair, b.n_pairs, n_reads});
+        n_reads += nr;
+        text += b.text_bytes;
+        if (b.max_len > max_len) max_len = b.max_len;
+    }
+    ING_TRY(hipStreamSynchronize(cs));
+    while (!pending.empty()) { (void)hipEventDestroy(pending.front().ev); snk_fasth_release(fs, &pending.front().b); pending.pop_front(); }
+    // ---- file-major order
+    std::vector<uint64_t> fbase(n_files + 1, 0);
+    for (uint32_t i = 0; i < n_files; ++i) fbase[i + 1] = fbase[i] + 2 * snk_fasth_file_pairs(fs, i);
+    bool in_order = true;
+    for (auto& p : pieces) if (fbase[p.file] + 2 * p.first_pair != p.at) { in_order = false; break; }
+    if (!in_order) {
+        ING_RC(alloc_arrays(Bf, n_reads, row_words, qstride, ix != nullptr, err, errcap));
+        for (auto& p : pieces) {
+            const uint64_t d = fbase[p.file] + 2 * p.first_pair, s = p.at, nr = 2 * p.n_pairs;
+            ING_TRY(hipMemcpyAsync(Bf.rows + d * row_words, A.rows + s * row_words, nr * row_words * 4ull, hipMemcpyDeviceToDevice, cs));
+            ING_TRY(hipMemcpyAsync(Bf.quals + d * qstride, A.quals + s * qstride, nr * (uint64_t)qstride, hipMemcpyDeviceToDevice, cs));
+            ING_TRY(hipMemcpyAsync(Bf.lens + d, A.lens + s, nr * 2ull, hipMemcpyDeviceToDevice, cs));
+            if (ix) ING_TRY(hipMemcpyAsync(Bf.bc + d, A.bc + s, nr * 4ull, hipMemcpyDeviceToDevice, cs));
+        }
+        ING_TRY(hipStreamSynchronize(cs));
+        A.release();
+        A = Bf;
+        Bf = ingest_arrays();
+    }
+    cleanup();
+    out->n_reads = n_reads; out->read_len = read_len; out->row_words = row_words; out->qstride = qstride; out->max_len = max_len;
+    out->rows = A.rows; out->quals = A.quals; out->lens = A.lens; out->bc = A.bc;
+    out->text_bytes = text; out->compressed_bytes = comp; out->n_files = n_files;
+    out->seconds = now_s() - t0; out->decode_wait_seconds = wait_s; out->setup_seconds = t_ready - t0; out->n_batches = (uint32_t)pieces.size();
+    return SNK_OK;
+#undef ING_TRY
+#undef ING_RC
+}
+
+extern "C" void snk_dev_ingest_free(snk_dev_ingest* r) {
+    if (!r) return;
+    (void)hipFree((void*)r->rows); (void)hipFree((void*)r->quals); (void)hipFree((void*)r->lens); (void)hipFree((void*)r->bc);
+    r->rows = r->quals = r->lens = r->bc = nullptr;
 }

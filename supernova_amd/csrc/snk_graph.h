@@ -104,6 +104,9 @@ int snk_dist_links_answer(snk_ctx* ctx, hipStream_t st, const snk_frag_out* fr, 
 int snk_dist_links_apply(snk_ctx* ctx, hipStream_t st, const snk_frag_out* fr, const void* d_qbuf, const void* d_ans, uint64_t nq, uint32_t** flink_out,
                          char* err, size_t errcap);
 
+int snk_dist_links_apply_regions(snk_ctx* ctx, hipStream_t st, const snk_frag_out* fr, const void* d_qbuf, const void* d_ans, uint32_t world, uint64_t cap,
+                                 const unsigned long long* counts, uint32_t** flink_out, char* err, size_t errcap);
+
 // ---- bucket-local graph stage (snk_local.hip): table in chunk order -> pruned contexts + canonical unitigs
 struct snk_table;
 struct snk_bl_state {          // device arrays of the bucket-local stage (indexed by table position / chunk)

@@ -1465,7 +1465,20 @@ int snk_dist_links_apply(snk_ctx* ctx, hipStream_t st, const snk_frag_out* fr, c
     SNK_HIP_TRY(hipMemsetAsync(flink, 0xFF, (ne + 2) * 4, st));
     if (nq) hipLaunchKernelGGL(jlink_apply_kernel, dim3(nblk(nq)), dim3(TB), 0, st, (const unsigned long long*)d_qbuf, (const uint32_t*)d_ans, nq, flink);
     SNK_HIP_TRY(hipGetLastError());
-    SNK_HIP_TRY(snk_sync(st));
+    *flink_out = flink;
+    return SNK_OK;
+}
+// the same for queries / answers that sit in per-destination regions of `cap` items (one-pass routing, snk_shard_step.hip)
+int snk_dist_links_apply_regions(snk_ctx* ctx, hipStream_t st, const snk_frag_out* fr, const void* d_qbuf, const void* d_ans, uint32_t world, uint64_t cap,
+                                 const unsigned long long* counts, uint32_t** flink_out, char* err, size_t errcap) {
+    const uint64_t ne = 2 * fr->n_frags;
+    uint32_t* flink;
+    G_ALLOC(flink, uint32_t, ne + 2);
+    SNK_HIP_TRY(hipMemsetAsync(flink, 0xFF, (ne + 2) * 4, st));
+    for (uint32_t p = 0; p < world; ++p)
+        if (counts[p]) hipLaunchKernelGGL(jlink_apply_kernel, dim3(nblk(counts[p])), dim3(TB), 0, st, (const unsigned long long*)d_qbuf + 3 * cap * p,
+                                          (const uint32_t*)d_ans + cap * p, (uint64_t)counts[p], flink);
+    SNK_HIP_TRY(hipGetLastError());
     *flink_out = flink;
     return SNK_OK;
 }
@@ -1525,23 +1538,30 @@ int snk_prank_walk(snk_ctx* ctx, hipStream_t st, snk_prank* P, const uint4* w1_a
     G_ALLOC(flags, uint32_t, 4);
     SNK_HIP_TRY(hipMemsetAsync(tot, 0, 8, st));
     if (m) hipLaunchKernelGGL(prank_unzip_kernel, dim3(nblk(m)), dim3(TB), 0, st, w1_all, m, rn[0], rd[0], rt[0], tot);
+    // pointer jumping over the splitter list in batches of rounds: one read-back per batch (flag of the batch's last round +,
+    // the first time, the total the first walk reached), not per round; rounds past convergence change nothing
     unsigned long long h_tot = 0;
-    SNK_HIP_TRY(hipMemcpyAsync(&h_tot, tot, 8, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(snk_sync(st));
-    if (h_tot != P->ns) { *circles = 1; return SNK_OK; }          // states no walk reached: a circle without a splitter
     uint32_t h_flag = 0;
     int max_rounds = 2;
     while ((1ull << (max_rounds - 1)) < m + 1) ++max_rounds;
     int cur = 0;
-    bool converged = (m == 0);
-    for (int r = 0; r < max_rounds && !converged; ++r) {
-        SNK_HIP_TRY(hipMemsetAsync(flags, 0, 4, st));
-        hipLaunchKernelGGL(rank_round_kernel, dim3(nblk(m)), dim3(TB), 0, st, rn[cur], rd[cur], rt[cur], m, rn[cur ^ 1], rd[cur ^ 1], rt[cur ^ 1], flags);
-        cur ^= 1;
-        ++*rounds;
-        SNK_HIP_TRY(hipMemcpyAsync(&h_flag, flags, 4, hipMemcpyDeviceToHost, st));
+    bool converged = false, first = true;
+    const int BATCH_R = (int)snk_env_u32("SNK_RANK_ROUND_BATCH", 8);
+    for (int r = 0; r < max_rounds && !converged;) {
+        int did = 0;
+        for (; did < BATCH_R && r < max_rounds && m; ++did, ++r) {
+            SNK_HIP_TRY(hipMemsetAsync(flags, 0, 4, st));
+            hipLaunchKernelGGL(rank_round_kernel, dim3(nblk(m)), dim3(TB), 0, st, rn[cur], rd[cur], rt[cur], m, rn[cur ^ 1], rd[cur ^ 1], rt[cur ^ 1], flags);
+            cur ^= 1;
+            ++*rounds;
+        }
+        if (first) SNK_HIP_TRY(hipMemcpyAsync(&h_tot, tot, 8, hipMemcpyDeviceToHost, st));
+        if (m) SNK_HIP_TRY(hipMemcpyAsync(&h_flag, flags, 4, hipMemcpyDeviceToHost, st));
         SNK_HIP_TRY(snk_sync(st));
-        if (h_flag == 0) converged = true;
+        if (first && h_tot != P->ns) { *circles = 1; return SNK_OK; }          // states no walk reached: a circle without a splitter
+        first = false;
+        if (m == 0 || h_flag == 0) converged = true;
+        if (m == 0) break;
     }
     if (!converged) { *circles = 1; return SNK_OK; }               // a circle that contains splitters
     const uint64_t cnt = P->k1 - P->k0;

@@ -292,7 +292,14 @@ __global__ void __launch_bounds__(T) bl_prune_kernel(const uint4* __restrict__ d
                                                      uint32_t do_prune, uint8_t* __restrict__ ctx_out,
                                                      uint32_t* __restrict__ count_out, uint8_t* __restrict__ pend_out,
                                                      uint32_t* __restrict__ nbr_out, uint32_t* __restrict__ nbnd,
-                                                     uint32_t* __restrict__ biglist, uint32_t* __restrict__ nbig) {
+                                                     uint32_t* __restrict__ biglist, uint32_t* __restrict__ nbig, const uint32_t* __restrict__ n_dev) {
+    if (BIG && n_dev) {
+        // the list's length is still on the device (no read-back between the two prune launches): a fixed grid strides over it
+        const uint32_t nb = *n_dev;
+        for (uint32_t w = blockIdx.x; w < nb; w += gridDim.x)
+            bl_prune_chunk<K, CAP, T, BIG, GR>(biglist_in[w], desc, NB, sh, keys, vals, do_prune, ctx_out, count_out, pend_out, nbr_out, nbnd, biglist, nbig);
+        return;
+    }
     for (uint32_t r = 0; r < cpw; ++r) {
         const uint32_t w = blockIdx.x * cpw + r;
         if (w >= nchunks) return;
@@ -842,16 +849,15 @@ static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* er
     const uint32_t cpw = 1;
     hipLaunchKernelGGL((bl_prune_kernel<K, SCAP, ST, false, GR>), dim3((nchunks + cpw - 1) / cpw), dim3(ST), 0, st, (const uint4*)B->desc, NBh, sh,
                        (const uint32_t*)nullptr, nchunks, cpw, tab->keys, tab->vals, B->do_prune, B->ctx, B->counts, B->pend, B->nbr, nbnd,
-                       B->biglist, ctr);
+                       B->biglist, ctr, (const uint32_t*)nullptr);
     SNK_HIP_TRY(hipGetLastError());
+    // the chunks that did not fit the one-wave variant (split sub-passes near the table's capacity): their number stays on the
+    // device until the read-back below -- the big variant runs a fixed grid that strides over the list
     uint32_t h_nbig = 0;
-    SNK_HIP_TRY(hipMemcpyAsync(&h_nbig, ctr, 4, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(snk_sync(st));
-    B->nbig = h_nbig;
-    if (h_nbig)
-        hipLaunchKernelGGL((bl_prune_kernel<K, BCAP, BT, true, GR>), dim3(h_nbig), dim3(BT), 0, st, (const uint4*)B->desc, NBh, sh,
-                           (const uint32_t*)B->biglist, h_nbig, 1u, tab->keys, tab->vals, B->do_prune, B->ctx, B->counts, B->pend, B->nbr,
-                           nbnd, B->biglist, ctr);
+    SNK_HIP_TRY(hipMemcpyAsync(ctr + 1, ctr, 4, hipMemcpyDeviceToDevice, st));       // (ctr[0] is the small kernel's list cursor)
+    hipLaunchKernelGGL((bl_prune_kernel<K, BCAP, BT, true, GR>), dim3(2048), dim3(BT), 0, st, (const uint4*)B->desc, NBh, sh,
+                       (const uint32_t*)B->biglist, 0u, 1u, tab->keys, tab->vals, B->do_prune, B->ctx, B->counts, B->pend, B->nbr,
+                       nbnd, B->biglist, ctr + 2, (const uint32_t*)(ctr + 1));
     SNK_HIP_TRY(hipGetLastError());
     unsigned long long* d_sum;
     G_ALLOC(d_sum, unsigned long long, 2);
@@ -866,7 +872,9 @@ static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* er
     }
     unsigned long long h_bnd = 0;
     SNK_HIP_TRY(hipMemcpyAsync(&h_bnd, d_sum, 8, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipMemcpyAsync(&h_nbig, ctr + 1, 4, hipMemcpyDeviceToHost, st));
     SNK_HIP_TRY(snk_sync(st));
+    B->nbig = h_nbig;
     B->n_boundary = h_bnd;
     uint64_t tg = 1024;
     while (tg < 2 * h_bnd) tg <<= 1;
@@ -1062,7 +1070,7 @@ int snk_bl_dist_plan(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, unsigned lon
     G_ALLOC(B->rq_meta, uint16_t, 2 * n + 2);
     SNK_HIP_TRY(hipMemsetAsync(B->qcount, 0, (B->world + 1) * 8ull, st));
     SNK_HIP_TRY(hipMemsetAsync(B->rq_idx, 0xFF, (2 * n + 2) * 4, st));
-    for (uint32_t r = 0; r < B->world; ++r) h_qcount[r] = 0;
+    if (h_qcount) for (uint32_t r = 0; r < B->world; ++r) h_qcount[r] = 0;
     if (n == 0) {
         G_ALLOC(B->ctx, uint8_t, 16);
         G_ALLOC(B->counts, uint32_t, 4);
@@ -1079,8 +1087,10 @@ int snk_bl_dist_plan(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, unsigned lon
     if (B->K == 48) hipLaunchKernelGGL((bl_query_kernel<48, false>), dim3(grid), dim3(TB), lds, st, B->tab->keys, (const uint8_t*)B->premote, n, B->NB_total, B->NBl, B->world, B->qcount, (unsigned long long*)nullptr);
     else hipLaunchKernelGGL((bl_query_kernel<60, false>), dim3(grid), dim3(TB), lds, st, B->tab->keys, (const uint8_t*)B->premote, n, B->NB_total, B->NBl, B->world, B->qcount, (unsigned long long*)nullptr);
     SNK_HIP_TRY(hipGetLastError());
-    SNK_HIP_TRY(hipMemcpyAsync(h_qcount, B->qcount, B->world * 8ull, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(snk_sync(st));
+    if (h_qcount) {
+        SNK_HIP_TRY(hipMemcpyAsync(h_qcount, B->qcount, B->world * 8ull, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(snk_sync(st));
+    }
     return SNK_OK;
 }
 int snk_bl_dist_fill(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, const unsigned long long* d_qoff, void* d_qbuf, char* err, size_t errcap) {
@@ -1117,8 +1127,5 @@ int snk_bl_dist_fragments(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, const u
     da.rq_meta = B->rq_meta;
     da.node_off = d_node_off;
     da.my_node_off = my_node_off;
-    int rc = B->K == 48 ? bl_fragments_impl<48, true, false>(ctx, st, B, da, out, err, errcap) : bl_fragments_impl<60, true, false>(ctx, st, B, da, out, err, errcap);
-    if (rc) return rc;
-    SNK_HIP_TRY(snk_sync(st));
-    return SNK_OK;
+    return B->K == 48 ? bl_fragments_impl<48, true, false>(ctx, st, B, da, out, err, errcap) : bl_fragments_impl<60, true, false>(ctx, st, B, da, out, err, errcap);
 }

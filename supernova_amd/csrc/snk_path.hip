@@ -607,9 +607,9 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
               uint32_t flags, snk_dev_paths* out, char* err, size_t errcap) {
     int rc;
     const uint64_t n = in->n_reads;
-    hipEvent_t e0, e1, e2;
-    SNK_HIP_TRY(hipEventCreate(&e0)); SNK_HIP_TRY(hipEventCreate(&e1)); SNK_HIP_TRY(hipEventCreate(&e2));
-    struct evg { hipEvent_t a, b, c; ~evg() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipEventDestroy(c); } } g{e0, e1, e2};
+    hipEvent_t e0, e1, e2, e3;
+    SNK_HIP_TRY(hipEventCreate(&e0)); SNK_HIP_TRY(hipEventCreate(&e1)); SNK_HIP_TRY(hipEventCreate(&e2)); SNK_HIP_TRY(hipEventCreate(&e3));
+    struct evg { hipEvent_t a, b, c, d; ~evg() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipEventDestroy(c); (void)hipEventDestroy(d); } } g{e0, e1, e2, e3};
     SNK_HIP_TRY(hipEventRecord(e0, st));
     // ---- graph tables (host: O(U + E)), in the device's unitig numbering
     const int32_t N = h->n_vertices, E = h->n_edges;
@@ -661,6 +661,20 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
     const uint64_t total_bases = h_off_last;
     const uint64_t nk = total_bases >= U * (uint64_t)(K - 1) ? total_bases - U * (uint64_t)(K - 1) : 0;
     const uint64_t cap = ((2 * nk + nk / 2 + 1024) + 63) & ~63ull;        // load 0.4: the chain of dependent probes is what a read waits for
+    {
+        // the dictionary is the one allocation of this path that grows with the GRAPH, not with the reads: 2.5 slots of 32 bytes
+        // per unitig k-mer (+ 4 transient bytes per slot).  Say so before asking for it: a human-size graph (3-4 G k-mers) wants
+        // ~300 GB and does not fit one device -- path such a graph per unitig range, in passes.
+        size_t fr = 0, tot = 0;
+        const uint64_t want = cap * 36ull;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+            uint64_t cached = 0;
+            for (auto& b : ctx->blocks) if (!b.used) cached += b.bytes;     // the arena's idle blocks can be handed back to the driver
+            if (want > (uint64_t)fr + cached)
+                return snk_fail(SNK_E_NOMEM, err, errcap, "snk_dev_path_reads: the k-mer dictionary of this graph (%llu unitig k-mers, 2.5 slots of 32 B each) needs %.1f GB, "
+                                "%.1f GB of HBM are free; path the reads against ranges of the unitigs instead", (unsigned long long)nk, want / 1e9, (fr + cached) / 1e9);
+        }
+    }
     uint32_t* lock;
     uint4* dslot;
     if ((rc = dev(ctx, cap, &lock, err, errcap)) || (rc = dev(ctx, 2 * cap, &dslot, err, errcap))) return rc;
@@ -789,6 +803,9 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
         out->unitig_bc_off = uoff_out;
         out->unitig_bcs = bcs;
         out->n_unitig_bcs = n_unique;
+        SNK_HIP_TRY(hipEventRecord(e3, st));
+        SNK_HIP_TRY(snk_sync(st));
+        (void)hipEventElapsedTime(&out->bcs_ms, e2, e3);
     }
     return SNK_OK;
 }

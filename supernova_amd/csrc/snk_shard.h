@@ -27,6 +27,7 @@ struct snk_shard_state {
     uint64_t n_frags_total = 0;
     uint32_t join_circles = 0, join_rounds = 0;
     snk_prank pr{};
+    unsigned long long* pr_cursor = nullptr;   // [world] cursors of the rank-record routing (end positions after the fill)
     const uint32_t* nk_all = nullptr;
     snk_phase_timer* tm = nullptr;
 };

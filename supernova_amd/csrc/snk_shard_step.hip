@@ -296,18 +296,13 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
     const uint64_t n_kmers = S->tab.n;
 
     // ---- bucket-local prune with membership queries for neighbours owned by other ranks
-    std::vector<uint64_t> h_q(W);
-    TRY(snk_shard_prune_plan(ctx, h_q.data(), st, err, errcap));
-    // one read-back: every rank's query counts and retained k-mers
-    ull* d_cnt;
-    ALLOC(d_cnt, ull, W + 2);
+    TRY(snk_shard_prune_plan(ctx, nullptr, st, err, errcap));
+    // one read-back: every rank's query counts (still on the device: bl.qcount) and retained k-mers
+    ull* d_cnt = S->bl.qcount;
     {
-        std::vector<ull> mine(W + 1);
-        for (uint32_t q = 0; q < W; ++q) mine[q] = h_q[q];
-        mine[W] = n_kmers;
-        ull* up;
-        TRY(upload(X, mine.data(), W + 1, &up));
-        d_cnt = up;
+        ull hn = n_kmers, *up;
+        TRY(upload(X, &hn, 1, &up));
+        SNK_HIP_TRY(hipMemcpyAsync(d_cnt + W, up, 8, hipMemcpyDeviceToDevice, st));
     }
     std::vector<ull> qall;
     TRY(exchange_counts(X, d_cnt, W + 1, qall));
@@ -347,42 +342,51 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
     // One read-back: everybody's fragment count and link-query counts (counting needs no global fragment numbering).
     snk_phase_timer jt(st);
     jt.mark();   // j0
+    // One pass: destination q's queries go to region q of the buffer (capacity = every end I have), the cursors come back
+    // with the fragment count in ONE read-back, the answers return into the same regions.
     ALLOC(S->lq_count, ull, W + 2);
     ALLOC(S->lq_cursor, ull, W + 2);
-    SNK_HIP_TRY(hipMemsetAsync(S->lq_count, 0, (W + 2) * 8ull, st));
-    TRY(snk_dist_links_query(ctx, st, false, &S->frags, S->d_node_off, W, 0ull, S->lq_count, nullptr, err, errcap));
+    const uint64_t lcap = 2 * F + 1;
+    uint8_t *lqbuf, *lans_back;
+    ALLOC(lqbuf, uint8_t, (uint64_t)W * lcap * 24 + 32);
+    ALLOC(lans_back, uint8_t, (uint64_t)W * lcap * 4 + 32);
     {
-        ull hf = F, *up;
-        TRY(upload(X, &hf, 1, &up));
-        SNK_HIP_TRY(hipMemcpyAsync(S->lq_count + W, up, 8, hipMemcpyDeviceToDevice, st));
+        std::vector<ull> init(W + 1);
+        for (uint32_t q = 0; q < W; ++q) init[q] = (ull)q * lcap;
+        init[W] = F;
+        ull* d_init;
+        TRY(upload(X, init.data(), W + 1, &d_init));
+        TRY(snk_shard_links_fill(ctx, d_init, lqbuf, st, err, errcap));      // copies W+1 words: the cursors and, behind them, F
     }
     std::vector<ull> lall;
-    TRY(exchange_counts(X, S->lq_count, W + 1, lall));
+    TRY(exchange_counts(X, S->lq_cursor, W + 1, lall));
     std::vector<ull> l_send(W), l_recv(W), all_F(W), frag_off(W + 1, 0);
-    for (uint32_t q = 0; q < W; ++q) { l_send[q] = lall[(size_t)me * (W + 1) + q]; l_recv[q] = lall[(size_t)q * (W + 1) + me]; all_F[q] = lall[(size_t)q * (W + 1) + W]; }
+    for (uint32_t q = 0; q < W; ++q) {
+        l_send[q] = lall[(size_t)me * (W + 1) + q] - (ull)q * lcap;
+        l_recv[q] = lall[(size_t)q * (W + 1) + me] - (ull)me * (2 * lall[(size_t)q * (W + 1) + W] + 1);
+        all_F[q] = lall[(size_t)q * (W + 1) + W];
+    }
     for (uint32_t q = 0; q < W; ++q) frag_off[q + 1] = frag_off[q] + all_F[q];
     const uint64_t Ft = frag_off[W];
     if (2 * Ft >= (1ull << 32)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "more than 2^31 fragments in the job");
     S->my_end_base = 2ull * frag_off[me];
     uint64_t nlq = 0, nlq_in = 0;
     for (uint32_t q = 0; q < W; ++q) { nlq += l_send[q]; nlq_in += l_recv[q]; }
-    uint8_t *lqbuf, *lqin, *lans, *lans_back;
-    ALLOC(lqbuf, uint8_t, nlq * 24 + 32);
+    uint8_t *lqin, *lans;
     ALLOC(lqin, uint8_t, nlq_in * 24 + 32);
     ALLOC(lans, uint8_t, nlq_in * 4 + 32);
-    ALLOC(lans_back, uint8_t, nlq * 4 + 32);
     {
-        std::vector<ull> lqoff(W + 1, 0);
-        for (uint32_t q = 0; q < W; ++q) lqoff[q + 1] = lqoff[q] + l_send[q];
-        ull* d_lqoff;
-        TRY(upload(X, lqoff.data(), W + 1, &d_lqoff));
-        TRY(snk_shard_links_fill(ctx, d_lqoff, lqbuf, st, err, errcap));
+        std::vector<uint64_t> sbeg(W), scnt(W), rbeg(W), rcnt(W);
+        uint64_t acc = 0;
+        for (uint32_t q = 0; q < W; ++q) { sbeg[q] = (uint64_t)q * lcap * 24; scnt[q] = l_send[q] * 24; rbeg[q] = acc * 24; rcnt[q] = l_recv[q] * 24; acc += l_recv[q]; }
+        TRY(comm->a2a(lqbuf, sbeg.data(), scnt.data(), lqin, rbeg.data(), rcnt.data(), st, err, errcap));
+        TRY(snk_shard_links_answer(ctx, lqin, nlq_in, lans, st, err, errcap));
+        for (uint32_t q = 0; q < W; ++q) { std::swap(sbeg[q], rbeg[q]); std::swap(scnt[q], rcnt[q]); sbeg[q] /= 6; scnt[q] /= 6; rbeg[q] /= 6; rcnt[q] /= 6; }
+        TRY(comm->a2a(lans, sbeg.data(), scnt.data(), lans_back, rbeg.data(), rcnt.data(), st, err, errcap));
     }
-    TRY(a2a_items(X, lqbuf, l_send, lqin, l_recv, 24));
-    TRY(snk_shard_links_answer(ctx, lqin, nlq_in, lans, st, err, errcap));
-    TRY(a2a_items(X, lans, l_recv, lans_back, l_send, 4));
-    const void* flink = nullptr;
-    TRY(snk_shard_links_apply(ctx, lqbuf, lans_back, nlq, &flink, st, err, errcap));
+    uint32_t* flink_w = nullptr;
+    TRY(snk_dist_links_apply_regions(ctx, st, &S->frags, lqbuf, lans_back, W, lcap, l_send.data(), &flink_w, err, errcap));
+    const void* flink = flink_w;
     jt.mark();   // j1 links
 
     // ---- owner-side join: every rank sees the job's LINK structure only (12 bytes per fragment), ranks the fragment lists,
@@ -400,7 +404,6 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
     ull* d_frag_off;
     TRY(upload(X, frag_off.data(), W + 1, &d_frag_off));
     jt.mark();   // j2 gather links
-    std::vector<uint64_t> fto(W, 0), bto(W, 0);
     bool ranked = false;
     uint64_t exch_spl = 0, exch_rank = 0;
     const bool want_partitioned = snk_env_u32("SNK_JOIN_REPLICATED", 0) == 0;
@@ -415,66 +418,94 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
         ALLOC(w1_all, uint8_t, tot16 + 32);
         TRY(comm->allgatherv(w1p, shares.data(), w1_all, st, err, errcap));
         exch_spl = m_spl * 16;
-        std::vector<uint64_t> rto(W, 0);
         uint32_t circ = 0;
-        TRY(snk_shard_prank_walk(ctx, w1_all, d_frag_off, rto.data(), &circ, st, err, errcap));
+        TRY(snk_shard_prank_walk(ctx, w1_all, d_frag_off, nullptr, &circ, st, err, errcap));
         if (!circ) {
-            // everybody's record counts: one read-back
-            ull* d_rto;
+            // the (state, distance, terminal) records of my walks, routed to the states' owners in one pass (regions of n_rec)
+            const uint64_t n_rec = S->pr.n_rec, rcap = n_rec + 1;
+            std::vector<ull> init(W);
+            for (uint32_t q = 0; q < W; ++q) init[q] = (ull)q * rcap;
+            ull* d_init;
+            TRY(upload(X, init.data(), W, &d_init));
+            uint8_t* rsend;
+            ALLOC(rsend, uint8_t, (uint64_t)W * rcap * 16 + 32);
+            TRY(snk_shard_prank_route(ctx, d_frag_off, d_init, rsend, st, err, errcap));
+            ull* d_cur = S->pr_cursor;
+            ull* d_cur2;
+            ALLOC(d_cur2, ull, W + 2);
+            if (n_rec) SNK_HIP_TRY(hipMemcpyAsync(d_cur2, d_cur, W * 8ull, hipMemcpyDeviceToDevice, st));
+            else SNK_HIP_TRY(hipMemcpyAsync(d_cur2, d_init, W * 8ull, hipMemcpyDeviceToDevice, st));      // (no records: the fill was not launched)
             {
-                std::vector<ull> v(rto.begin(), rto.end());
-                TRY(upload(X, v.data(), W, &d_rto));
+                ull hr = rcap, *up;
+                TRY(upload(X, &hr, 1, &up));
+                SNK_HIP_TRY(hipMemcpyAsync(d_cur2 + W, up, 8, hipMemcpyDeviceToDevice, st));
             }
             std::vector<ull> rall;
-            TRY(exchange_counts(X, d_rto, W, rall));
-            std::vector<ull> r_send(W), r_recv(W), roff_(W + 1, 0);
-            uint64_t n_in = 0;
-            for (uint32_t q = 0; q < W; ++q) { r_send[q] = rall[(size_t)me * W + q]; r_recv[q] = rall[(size_t)q * W + me]; roff_[q + 1] = roff_[q] + r_send[q]; n_in += r_recv[q]; }
-            ull* d_roff;
-            TRY(upload(X, roff_.data(), W, &d_roff));
-            uint8_t *rsend, *rk_in;
-            ALLOC(rsend, uint8_t, roff_[W] * 16 + 32);
+            TRY(exchange_counts(X, d_cur2, W + 1, rall));
+            std::vector<uint64_t> sbeg(W), scnt(W), rbeg(W), rcnt(W);
+            uint64_t n_in = 0, n_out = 0;
+            for (uint32_t q = 0; q < W; ++q) {
+                const ull cap_q = rall[(size_t)q * (W + 1) + W];
+                sbeg[q] = (uint64_t)q * rcap * 16; scnt[q] = (rall[(size_t)me * (W + 1) + q] - (ull)q * rcap) * 16;
+                rbeg[q] = n_in * 16; rcnt[q] = (rall[(size_t)q * (W + 1) + me] - (ull)me * cap_q) * 16;
+                n_in += rcnt[q] / 16; n_out += scnt[q] / 16;
+            }
+            uint8_t* rk_in;
             ALLOC(rk_in, uint8_t, n_in * 16 + 32);
-            TRY(snk_shard_prank_route(ctx, d_frag_off, d_roff, rsend, st, err, errcap));
-            TRY(a2a_items(X, rsend, r_send, rk_in, r_recv, 16));
-            TRY(snk_shard_place_ranked(ctx, K, rk_in, n_in, d_frag_off, fto.data(), bto.data(), st, err, errcap));
+            TRY(comm->a2a(rsend, sbeg.data(), scnt.data(), rk_in, rbeg.data(), rcnt.data(), st, err, errcap));
+            TRY(snk_shard_place_ranked(ctx, K, rk_in, n_in, d_frag_off, nullptr, nullptr, st, err, errcap));
+            snk_ctx_release_block(ctx, rsend);
             ranked = true;
-            exch_rank = roff_[W] * 16;
+            exch_rank = n_out * 16;
         }
     }
     if (!ranked)      // a list is a circle (same verdict on every rank: it comes from replicated data), or the replicated mode was asked for
-        TRY(snk_shard_place(ctx, K, Ft, nk_all, fl_all, d_frag_off, frag_off[me], fto.data(), bto.data(), st, err, errcap));
+        TRY(snk_shard_place(ctx, K, Ft, nk_all, fl_all, d_frag_off, frag_off[me], nullptr, nullptr, st, err, errcap));
     jt.mark();   // j3 rank + place
-    // headers + bases grouped by owner; every owner's bases start 16-byte aligned in the send buffer
-    std::vector<ull> hoff(W + 1, 0), boff(W + 1, 0), bpad(W);
-    for (uint32_t q = 0; q < W; ++q) { bpad[q] = (bto[q] + 15) / 16 * 16; hoff[q + 1] = hoff[q] + fto[q]; boff[q + 1] = boff[q] + bpad[q]; }
-    ull *d_hoff, *d_boff;
-    TRY(upload(X, hoff.data(), W, &d_hoff));
-    TRY(upload(X, boff.data(), W, &d_boff));
+    // headers + bases to the owners of the unitigs, one pass into per-owner regions (capacity: all my fragments / all my bases;
+    // every region of bases starts 16-byte aligned); the cursors come back in one read-back
+    const uint64_t fcap = F + 1, bcap = (S->frags.total_bases + 15) / 16 * 16 + 16;
     uint8_t *hdr, *sb;
-    ALLOC(hdr, uint8_t, hoff[W] * 32 + 32);
-    ALLOC(sb, uint8_t, boff[W] + 32);
-    TRY(snk_shard_route_fill(ctx, K, d_frag_off, d_hoff, d_boff, hdr, sb, st, err, errcap));
-    // what arrives: everybody's (fragments, padded base bytes) per owner -- one read-back
+    ALLOC(hdr, uint8_t, (uint64_t)W * fcap * 32 + 32);
+    ALLOC(sb, uint8_t, (uint64_t)W * bcap + 32);
+    {
+        std::vector<ull> hb(W), bb(W);
+        for (uint32_t q = 0; q < W; ++q) { hb[q] = (ull)q * fcap; bb[q] = (ull)q * bcap; }
+        ull *d_hoff, *d_boff;
+        TRY(upload(X, hb.data(), W, &d_hoff));
+        TRY(upload(X, bb.data(), W, &d_boff));
+        TRY(snk_shard_route_fill(ctx, K, d_frag_off, d_hoff, d_boff, hdr, sb, st, err, errcap));
+    }
     std::vector<ull> fall;
     {
-        std::vector<ull> v(2 * W);
-        for (uint32_t q = 0; q < W; ++q) { v[q] = fto[q]; v[W + q] = bpad[q]; }
         ull* d_v;
-        TRY(upload(X, v.data(), 2 * W, &d_v));
-        TRY(exchange_counts(X, d_v, 2 * W, fall));
+        ALLOC(d_v, ull, 2 * W + 4);
+        SNK_HIP_TRY(hipMemcpyAsync(d_v, S->rt_cursor, 2ull * W * 8, hipMemcpyDeviceToDevice, st));
+        ull caps[2] = {fcap, bcap}, *up;
+        TRY(upload(X, caps, 2, &up));
+        SNK_HIP_TRY(hipMemcpyAsync(d_v + 2 * W, up, 16, hipMemcpyDeviceToDevice, st));
+        TRY(exchange_counts(X, d_v, 2 * W + 2, fall));
     }
+    const size_t FS = 2 * (size_t)W + 2;
     std::vector<ull> f_send(W), f_recv(W), b_send(W), b_recv(W), hseg(W + 1, 0), bseg(W + 1, 0);
     for (uint32_t q = 0; q < W; ++q) {
-        f_send[q] = fto[q]; b_send[q] = bpad[q];
-        f_recv[q] = fall[(size_t)q * 2 * W + me]; b_recv[q] = fall[(size_t)q * 2 * W + W + me];
+        const ull fcap_q = fall[q * FS + 2 * W], bcap_q = fall[q * FS + 2 * W + 1];
+        f_send[q] = F ? fall[me * FS + q] - (ull)q * fcap : 0;
+        b_send[q] = F ? (fall[me * FS + W + q] - (ull)q * bcap + 15) / 16 * 16 : 0;
+        f_recv[q] = fcap_q > 1 ? fall[q * FS + me] - (ull)me * fcap_q : 0;
+        b_recv[q] = fcap_q > 1 ? (fall[q * FS + W + me] - (ull)me * bcap_q + 15) / 16 * 16 : 0;
         hseg[q + 1] = hseg[q] + f_recv[q]; bseg[q + 1] = bseg[q] + b_recv[q];
     }
     uint8_t *hdr_in, *b_in;
     ALLOC(hdr_in, uint8_t, hseg[W] * 32 + 32);
     ALLOC(b_in, uint8_t, bseg[W] + 32);
-    TRY(a2a_items(X, hdr, f_send, hdr_in, f_recv, 32));
-    TRY(a2a_items(X, sb, b_send, b_in, b_recv, 1));
+    {
+        std::vector<uint64_t> sbeg(W), scnt(W), rbeg(W), rcnt(W);
+        for (uint32_t q = 0; q < W; ++q) { sbeg[q] = (uint64_t)q * fcap * 32; scnt[q] = f_send[q] * 32; rbeg[q] = hseg[q] * 32; rcnt[q] = f_recv[q] * 32; }
+        TRY(comm->a2a(hdr, sbeg.data(), scnt.data(), hdr_in, rbeg.data(), rcnt.data(), st, err, errcap));
+        for (uint32_t q = 0; q < W; ++q) { sbeg[q] = (uint64_t)q * bcap; scnt[q] = b_send[q]; rbeg[q] = bseg[q]; rcnt[q] = b_recv[q]; }
+        TRY(comm->a2a(sb, sbeg.data(), scnt.data(), b_in, rbeg.data(), rcnt.data(), st, err, errcap));
+    }
     jt.mark();   // j4 route
     ull *d_hseg, *d_bseg;
     TRY(upload(X, hseg.data(), W + 1, &d_hseg));

@@ -144,7 +144,8 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
     }
     {
         // exclusive offsets of the regions (host: one region per count workgroup, ~16 k) and the dense gather
-        std::vector<unsigned long long> h_off(n_regions + 1);
+        std::vector<unsigned long long>& h_off = ctx->h_region_off;      // lives in the context: the upload below is not waited for
+        h_off.resize(n_regions + 1);
         unsigned long long acc = 0;
         for (uint32_t r = 0; r < n_regions; ++r) { h_off[r] = acc; acc += h_rcur[r]; }
         h_off[n_regions] = acc;
@@ -153,7 +154,6 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
         if ((rc = snk_ctx_alloc(ctx, (n_kmers + 1) * 16, &q, err, errcap))) return rc; keys_a = (snk_u128*)q;
         if ((rc = snk_ctx_alloc(ctx, (n_kmers + 1) * 8, &q, err, errcap))) return rc; vals_a = (uint64_t*)q;
         if ((rc = snk_launch_compact_regions(st, keys_r, vals_r, region_cap, n_regions, rcur, roff, keys_a, vals_a, err, errcap))) return rc;
-        SNK_HIP_TRY(snk_sync(st));   // h_off is a stack vector: the upload must finish before it goes away
         snk_ctx_release_block(ctx, keys_r);      // the region-partitioned copy is dead: later stages may reuse it
         snk_ctx_release_block(ctx, vals_r);
     }
@@ -245,10 +245,8 @@ __global__ void __launch_bounds__(256) compact_buckets_kernel(const uint4* __res
 }  // namespace
 
 static int snk_msp_segments(snk_ctx* ctx, hipStream_t st, uint32_t NB, uint32_t cap, const uint32_t* cursor, uint4* records, uint64_t ovf_base,
-                     uint64_t ovf_cap, const uint32_t* ovf_bucket, uint32_t n_ovf, uint64_t* seg, unsigned long long* d_total, char* err,
+                     uint64_t ovf_cap, const uint32_t* ovf_bucket, uint32_t n_ovf, uint64_t* seg, char* err,
                      size_t errcap) {
-    SNK_HIP_TRY(hipMemsetAsync(d_total, 0, 8, st));
-    hipLaunchKernelGGL(seg0_kernel, dim3((NB + 255) / 256), dim3(256), 0, st, cursor, NB, cap, seg, d_total);
     if (n_ovf) {
         uint32_t *idx_in, *idx_out, *key_out;
         void* q;
@@ -270,13 +268,14 @@ static int snk_msp_segments(snk_ctx* ctx, hipStream_t st, uint32_t NB, uint32_t 
 
 
 int snk_stage_partition_plan(snk_ctx* ctx, hipStream_t st, uint32_t K, const uint16_t* good_len, uint64_t n_reads,
-                             unsigned long long h_plan[2], char* err, size_t errcap) {
+                             unsigned long long h_plan[2], char* err, size_t errcap, unsigned long long** d_plan_out) {
     unsigned long long* counters;
     void* q;
     int rc;
     if ((rc = snk_ctx_alloc(ctx, 64, &q, err, errcap))) return rc;
     counters = (unsigned long long*)q;
     if ((rc = snk_launch_msp_plan(st, good_len, n_reads, K, counters, err, errcap))) return rc;
+    if (d_plan_out) { *d_plan_out = counters; return SNK_OK; }      // the caller reads the counters with a later read-back
     SNK_HIP_TRY(hipMemcpyAsync(h_plan, counters, 16, hipMemcpyDeviceToHost, st));
     SNK_HIP_TRY(snk_sync(st));
     return SNK_OK;
@@ -284,7 +283,7 @@ int snk_stage_partition_plan(snk_ctx* ctx, hipStream_t st, uint32_t K, const uin
 
 int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_reads* in, const uint16_t* good_len, uint32_t NB,
                         unsigned long long n_inst, unsigned long long n_live, bool grouped, uint32_t* status, snk_partition* out,
-                        char* err, size_t errcap) {
+                        char* err, size_t errcap, const unsigned long long* d_plan, unsigned long long* h_plan) {
     memset(out, 0, sizeof *out);
     const uint64_t n_reads = in->n_reads;
     const uint32_t Wm = K - SNK_M + 1;
@@ -317,6 +316,7 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
     void* records = nullptr;
     uint32_t* ovf_bucket = nullptr;
     uint32_t h_novf = 0;
+    unsigned long long h_total = 0;
     for (int attempt = 0; attempt < 3; ++attempt) {
         if (ovf_cap >= (1ull << 31)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "supermer overflow list too large");
         void* q;
@@ -336,7 +336,13 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
         kt.mark();  // 0
         if ((rc = snk_launch_msp(K, st, ma, err, errcap))) return rc;
         kt.mark();  // 1
+        // segment 0 (the fixed-capacity slots) and the supermer total need the cursors only: one read-back for everything the
+        // host wants to know about this pass (overflow count, supermers, and the caller's trim statistics if asked for)
+        SNK_HIP_TRY(hipMemsetAsync(d_total, 0, 8, st));
+        hipLaunchKernelGGL(seg0_kernel, dim3((NB + 255) / 256), dim3(256), 0, st, cursor, NB, cap, seg, d_total);
         SNK_HIP_TRY(hipMemcpyAsync(&h_novf, status + 8, 4, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(hipMemcpyAsync(&h_total, d_total, 8, hipMemcpyDeviceToHost, st));
+        if (d_plan && h_plan) SNK_HIP_TRY(hipMemcpyAsync(h_plan, d_plan, 16, hipMemcpyDeviceToHost, st));
         SNK_HIP_TRY(snk_sync(st));
         if (h_novf <= ovf_cap) break;
         if (attempt == 2) return snk_fail(SNK_E_INTERNAL, err, errcap, "supermer overflow list too small (%u > %llu)", h_novf, (unsigned long long)ovf_cap);
@@ -344,11 +350,8 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
         snk_ctx_release_block(ctx, ovf_bucket);
         ovf_cap = (uint64_t)h_novf + 65536;
     }
-    // segment 0: the fixed-capacity slots; segment 1: the overflow records grouped by bucket
-    if ((rc = snk_msp_segments(ctx, st, NB, cap, cursor, (uint4*)records, (uint64_t)NB * cap, ovf_cap, ovf_bucket, h_novf, seg, d_total, err, errcap))) return rc;
-    unsigned long long h_total = 0;
-    SNK_HIP_TRY(hipMemcpyAsync(&h_total, d_total, 8, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(snk_sync(st));
+    // segment 1: the overflow records grouped by bucket
+    if ((rc = snk_msp_segments(ctx, st, NB, cap, cursor, (uint4*)records, (uint64_t)NB * cap, ovf_cap, ovf_bucket, h_novf, seg, err, errcap))) return rc;
     out->NB = NB;
     out->cap = cap;
     out->nseg = h_novf ? 2u : 1u;

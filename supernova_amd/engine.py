@@ -115,7 +115,7 @@ class Result:
         self._e.lib.snk_hbv_free(C.byref(h))
         return out
 
-    def path_reads(self, rows, read_len: int, quals, lens=None, mark_dups=False, bc=None, unitig_bcs=False):
+    def path_reads(self, rows, read_len: int, quals, lens=None, mark_dups=False, bc=None, unitig_bcs=False, download=True):
         """f1: the reads (untrimmed packed rows + quality rows on the device) onto the graph of this result's unitigs --
         pathReads with the new aligner (BuildReadQGraph48.cc:1441-1469).  Returns (offset i32[n], n_edges u32[n], edges i32[sum],
         info) on the host, HBV edge ids as numbered by buildHBVFromEdges.  Must be called before the engine's next count_graph.
@@ -153,16 +153,22 @@ class Result:
                 if rc:
                     raise _lib.SnkError(rc, err.value.decode(errors="replace"))
                 npairs = int(dd.n_pairs)
-                dups = dict(dup=self._dl(dd.dup, npairs, np.uint8, (npairs,)), interdup_rate=float(dd.interdup_rate),
+                dups = dict(dup=self._dl(dd.dup, npairs, np.uint8, (npairs,)) if download else None, interdup_rate=float(dd.interdup_rate),
                             n_dup_pairs=int(dd.n_dup_pairs), n_dup_reads=int(dd.n_dup_reads), n_interdup_reads=int(dd.n_interdup_reads),
                             n_art_pairs=int(dd.n_art_pairs), n_placed=int(dd.n_placed), ms=float(dd.ms))
         finally:
             e.lib.snk_hbv_free(C.byref(h))
         n, tot = int(out.n_reads), int(out.n_edges_total)
+        if not download:          # timings only (bench.py: the results stay on the device)
+            info = dict(dict_ms=float(out.dict_ms), path_ms=float(out.path_ms), bcs_ms=float(out.bcs_ms), hbv_device_ms=float(ms.value),
+                        dict_slots=int(out.dict_slots), n_edges_total=tot, n_unitig_bcs=int(out.n_unitig_bcs))
+            if dups is not None:
+                info["dups"] = {k: v for k, v in dups.items() if k != "dup"}
+            return None, None, None, info
         off = self._dl(out.offset, n * 4, np.int32, (n,))
         ne = self._dl(out.n_edges, n * 4, np.uint32, (n,))
         edges = self._dl(out.edges, tot * 4, np.int32, (tot,))
-        info = dict(dict_ms=float(out.dict_ms), path_ms=float(out.path_ms), hbv_device_ms=float(ms.value), dict_slots=int(out.dict_slots))
+        info = dict(dict_ms=float(out.dict_ms), path_ms=float(out.path_ms), bcs_ms=float(out.bcs_ms), hbv_device_ms=float(ms.value), dict_slots=int(out.dict_slots))
         if dups is not None:
             info["dups"] = dups
         if unitig_bcs and out.unitig_bc_off:
@@ -268,6 +274,11 @@ class Engine:
         if group is not None:
             assert group.dtype == torch.int32 and group.is_cuda and group.is_contiguous()
             r.group = group.data_ptr()
+        return self.count_graph_reads(r, params)
+
+    def count_graph_reads(self, r: "_lib.SnkDevReads", params: Params | None = None) -> Result:
+        """The same for reads described by plain device pointers (e.g. the arrays of snk_dev_ingest_fasth)."""
+        params = params or Params()
         p = params.to_c()
         raw = _lib.SnkDevResult()
         err = C.create_string_buffer(512)

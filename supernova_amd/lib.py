@@ -92,13 +92,27 @@ class SnkHbv(C.Structure):
 class SnkDevPaths(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_edges_total", C.c_uint64), ("offset", C.c_void_p), ("n_edges", C.c_void_p),
                 ("start", C.c_void_p), ("edges", C.c_void_p), ("dict_slots", C.c_uint64), ("dict_ms", C.c_float),
-                ("path_ms", C.c_float), ("unitig_bc_off", C.c_void_p), ("unitig_bcs", C.c_void_p), ("n_unitig_bcs", C.c_uint64)]
+                ("path_ms", C.c_float), ("unitig_bc_off", C.c_void_p), ("unitig_bcs", C.c_void_p), ("n_unitig_bcs", C.c_uint64),
+                ("bcs_ms", C.c_float), ("reserved_f", C.c_float)]
 
 
 class SnkDevDups(C.Structure):
     _fields_ = [("n_pairs", C.c_uint64), ("dup", C.c_void_p), ("n_placed", C.c_uint64), ("n_dup_reads", C.c_uint64),
                 ("n_interdup_reads", C.c_uint64), ("n_dup_pairs", C.c_uint64), ("n_art_pairs", C.c_uint64),
                 ("interdup_rate", C.c_double), ("ms", C.c_float)]
+
+
+class SnkFasthBatch(C.Structure):
+    _fields_ = [("n_pairs", C.c_uint64), ("first_pair", C.c_uint64), ("file", C.c_uint32), ("max_len", C.c_uint32),
+                ("ascii", C.c_void_p), ("quals", C.c_void_p), ("lens", C.c_void_p), ("bc_fields", C.c_void_p),
+                ("text_bytes", C.c_uint64), ("token", C.c_uint64)]
+
+
+class SnkDevIngest(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("read_len", C.c_uint32), ("row_words", C.c_uint32), ("qstride", C.c_uint32),
+                ("max_len", C.c_uint32), ("rows", C.c_void_p), ("quals", C.c_void_p), ("lens", C.c_void_p), ("bc", C.c_void_p),
+                ("text_bytes", C.c_uint64), ("compressed_bytes", C.c_uint64), ("seconds", C.c_double),
+                ("decode_wait_seconds", C.c_double), ("n_files", C.c_uint32), ("n_batches", C.c_uint32), ("setup_seconds", C.c_double)]
 
 
 class SnkShardResult(C.Structure):
@@ -218,6 +232,15 @@ def _declare(lib: C.CDLL) -> None:
         "snk_shard_place_ranked": (C.c_int, [vp, u32, vp, u64, vp, P(u64), P(u64), vp, cp, sz]),
         "snk_shard_route_fill": (C.c_int, [vp, u32, vp, vp, vp, vp, vp, vp, cp, sz]),
         "snk_shard_emit": (C.c_int, [vp, u32, u64, vp, vp, vp, vp, P(SnkShardUnitigs), vp, cp, sz]),
+        "snk_fasth_open": (C.c_int, [P(cp), u32, u32, u32, u32, u32, P(vp), cp, sz]),
+        "snk_fasth_next": (C.c_int, [vp, P(SnkFasthBatch), cp, sz]),
+        "snk_fasth_release": (None, [vp, P(SnkFasthBatch)]),
+        "snk_fasth_file_pairs": (u64, [vp, u32]),
+        "snk_fasth_close": (None, [vp]),
+        "snk_dev_ingest_fasth": (C.c_int, [vp, P(cp), u32, u32, vp, u32, u32, P(SnkDevIngest), cp, sz]),
+        "snk_dev_ingest_free": (None, [P(SnkDevIngest)]),
+        "snk_synth_fasth_write": (C.c_int, [cp, P(SnkSynthParams), u64, u64, C.c_int, P(u64), cp, sz]),
+        "snk_synth_bc_seq": (None, [u32, vp]),
         "snk_comm_set_rccl_path": (C.c_int, [cp]),
         "snk_comm_unique_id": (C.c_int, [vp, cp, sz]),
         "snk_comm_create_rccl": (C.c_int, [vp, vp, u32, u32, P(vp), cp, sz]),

@@ -137,6 +137,52 @@ def read_fasth_native(paths):
     return cat(0)[:, :L].copy(), cat(1)[:, :L].copy(), cat(2), cat(3)
 
 
+def read_fasth_stream(paths, threads=0, batch_pairs=0, stride=256):
+    """The streaming reader of libsnk (snk_fasth_open / _next: `threads` files decoded concurrently, batches in any order) put back
+    into file-major order: -> (ascii u8[n,L], quals u8[n,L], lens u16[n], fields u8[n/2,64], stats)."""
+    import ctypes as C
+    from . import lib as _lib
+    lib = _lib.load()
+    arr = (C.c_char_p * len(paths))(*[str(p).encode() for p in paths])
+    h = C.c_void_p()
+    err = C.create_string_buffer(512)
+    rc = lib.snk_fasth_open(arr, len(paths), stride, batch_pairs, threads, 0, C.byref(h), err, 512)
+    if rc:
+        raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+    got, text, nb = [], 0, 0
+    try:
+        while True:
+            b = _lib.SnkFasthBatch()
+            rc = lib.snk_fasth_next(h, C.byref(b), err, 512)
+            if rc:
+                raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+            if b.n_pairs == 0:
+                break
+            npair = int(b.n_pairs)
+            view = lambda ptr, shape, dt: np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(int(np.prod(shape)) * np.dtype(dt).itemsize,)).view(dt).reshape(shape).copy()
+            got.append((int(b.file), int(b.first_pair), view(b.ascii, (2 * npair, stride), np.uint8), view(b.quals, (2 * npair, stride), np.uint8),
+                        view(b.lens, (2 * npair,), np.uint16), view(b.bc_fields, (npair, 64), np.uint8)))
+            text += int(b.text_bytes)
+            nb += 1
+            lib.snk_fasth_release(h, C.byref(b))
+        pairs = [int(lib.snk_fasth_file_pairs(h, i)) for i in range(len(paths))]
+    finally:
+        lib.snk_fasth_close(h)
+    got.sort(key=lambda t: (t[0], t[1]))
+    for fi in range(len(paths)):          # the batches of a file tile it exactly
+        at = 0
+        for t in got:
+            if t[0] == fi:
+                assert t[1] == at
+                at += t[5].shape[0]
+        assert at == pairs[fi]
+    cat = lambda i, shape, dt: np.concatenate([t[i] for t in got]) if got else np.zeros(shape, dt)
+    lens = cat(4, (0,), np.uint16)
+    L = max(int(lens.max()) if lens.size else 1, 1)
+    return (cat(2, (0, stride), np.uint8)[:, :L].copy(), cat(3, (0, stride), np.uint8)[:, :L].copy(), lens, cat(5, (0, 64), np.uint8),
+            dict(text_bytes=text, batches=nb, file_pairs=pairs))
+
+
 def read_fasth(paths, indexer):
     """FASTH records -> (ascii u8[n,L], quals u8[n,L] raw phred, lens u16[n], bc i32[n]); R1 = read 2q, R2 = 2q+1
     (cmd_msp.rs:160-181).  With a device indexer the files are parsed by the library's C++ reader and the barcode ids

@@ -158,6 +158,83 @@ def test_native_fasth_reader_matches_python(snk, tmp_path):
         read_fasth_native([str(bad)])
 
 
+def test_fasth_stream_multi_file(snk, tmp_path):
+    """f3: snk_fasth_open/_next -- many files decoded concurrently by a worker pool, batches in any order -- gives, put back into
+    file-major order, exactly what the Python restatement of MultiFastqIter reads from the same files; small batches so that every
+    file is cut into several; ragged lengths, CRLF, multi-member gzip; plain text is refused like the reference does
+    (multifastq.rs "Not a gz file"); a truncated record is an error."""
+    from supernova_amd.lib import SnkError
+    from supernova_amd.martian import BcIndexer, read_fasth, read_fasth_stream
+    c = goldens.load("synth_2k_err")
+    files, wl = make_fasth(c, tmp_path, n_files=7)
+    rag = tmp_path / "ragged.fasth.gz"
+    rng = np.random.default_rng(12)
+    with gzip.open(rag, "wt", newline="") as f:
+        for q in range(500):
+            eol = "\r\n" if q % 3 == 0 else "\n"
+            f.write(f"@rag{q}" + eol)
+            for _ in range(2):
+                L = int(rng.integers(0, 200)) if q else 0
+                f.write("".join("ACGTN"[i] for i in rng.integers(0, 5, L)) + eol)
+                f.write("".join(chr(33 + int(v)) for v in rng.integers(0, 42, L)) + eol)
+            f.write(("ACGTACGTACGTACGT" if q % 2 else "TTTTACGTACGTACGT-2,RAW") + eol + "FFFF" + eol + "ACGT" + eol + "FFFF" + eol)
+    # two gzip members in one file (cat a.gz b.gz): one stream for the reader
+    multi = tmp_path / "multi.fasth.gz"
+    multi.write_bytes(open(files[0], "rb").read() + open(files[1], "rb").read())
+    ix = BcIndexer.from_file(wl)
+    for fl, threads, bp in ((files, 0, 37), (files + [str(rag)], 3, 64), ([str(multi)] + files[2:], 2, 0), ([str(rag)], 1, 1)):
+        asc, qa, lens, fields, st = read_fasth_stream(fl, threads=threads, batch_pairs=bp)
+        asc_p, qa_p, lens_p, bc_p = read_fasth(fl, ix)
+        assert np.array_equal(lens, lens_p) and asc.shape == asc_p.shape
+        assert np.array_equal(asc, asc_p) and np.array_equal(qa, qa_p)
+        ids = np.array([ix.get_bc_id(bytes(f[:int(np.argmax(f == 0)) if (f == 0).any() else 64]).decode()) or 0 for f in fields], dtype=np.int32)
+        assert np.array_equal(np.repeat(ids, 2), bc_p)
+        assert st["text_bytes"] == sum(len(gzip.open(p, "rb").read()) for p in fl)
+        if bp:
+            assert st["batches"] >= sum(-(-n // bp) for n in st["file_pairs"])
+    plain = tmp_path / "plain.fasth"
+    plain.write_bytes(gzip.open(files[0], "rb").read())
+    with pytest.raises(SnkError, match="not a gz file"):
+        read_fasth_stream([files[1], str(plain)])
+    bad = tmp_path / "trunc.fasth.gz"
+    with gzip.open(bad, "wt") as f:
+        f.write("@h\nACGT\nIIII\nACGT\n")
+    with pytest.raises(SnkError, match="truncated"):
+        read_fasth_stream([str(bad)])
+
+
+def test_synth_fasth_writer_round_trip(snk, tmp_path):
+    """snk_synth_fasth_write (the generator behind bench.py --ingest) -> the stream reader gives back the synthetic model's reads,
+    and the barcode fields are snk_synth_bc_seq(id) + "-1" for barcoded pairs."""
+    import ctypes as C
+    from supernova_amd import lib as _lib, synth
+    from supernova_amd.martian import read_fasth_stream
+    lib = _lib.load()
+    sp = synth.synth_params(6000, seed=77)
+    rows, quals, bc = synth.synth_host(sp)
+    err = C.create_string_buffer(512)
+    paths, tot = [], 0
+    for fi, (a, n) in enumerate(((0, 1000), (1000, 1500), (2500, 500))):
+        p = tmp_path / f"s{fi}.fasth.gz"
+        tb = C.c_uint64(0)
+        assert lib.snk_synth_fasth_write(str(p).encode(), C.byref(sp), a, n, 1, C.byref(tb), err, 512) == 0, err.value
+        tot += tb.value
+        paths.append(str(p))
+    asc, qa, lens, fields, st = read_fasth_stream(paths, threads=3, batch_pairs=400)
+    assert st["text_bytes"] == tot and asc.shape[0] == 6000
+    assert np.array_equal(synth.ascii_to_codes(asc), synth.unpack_rows(rows, sp.read_len))
+    assert np.array_equal(qa, quals[:, :sp.read_len]) and np.all(lens == sp.read_len)
+    for q in (0, 1, 17, 2999):
+        b = int(bc[2 * q])
+        f = bytes(fields[q]).rstrip(b"\0").decode()
+        if b > 0:
+            buf = C.create_string_buffer(16)
+            lib.snk_synth_bc_seq(b, buf)
+            assert f == buf.raw.decode() + "-1"
+        else:
+            assert f == "NNNNNNNNNNNNNNNN-1"
+
+
 def _run_stage(tmp_path, stage_type, args=None, outs=None, extra=None, env=None):
     md = tmp_path / f"md_{stage_type}"
     md.mkdir()
