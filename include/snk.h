@@ -329,7 +329,6 @@ typedef struct snk_shard_result {
  * ignored when p->n_buckets is set).  in->read_index_base = global index of the slab's first read. */
 int snk_shard_step(snk_ctx* ctx, snk_comm* comm, const snk_dev_reads* in, const snk_params* p, uint64_t total_reads, uint32_t flags,
                    snk_shard_result* out, void* stream, char* err, size_t errcap);
-
 /* ---- host-pointer convenience + graph hand-off -------------- */
 typedef struct snk_reads {
     uint64_t n_reads;
@@ -368,6 +367,15 @@ typedef struct snk_result {
  * Outputs are malloc'ed by the library and released by snk_free. */
 int snk_count_graph(snk_ctx* ctx, const snk_reads* in, const snk_params* p, snk_result* out, char* err, size_t errcap);
 void snk_free(snk_result* r);
+
+/* The job's unitig set on ONE rank in the reference's order -- what MAIN_ASM_SN writes to asm_graph.bv
+ * (lib/tada/src/cmd_main_asm.rs:184-193, debruijn.rs:895-929): every rank (all must call) ships the unitigs it wrote at 2 bits
+ * per base to `root`, which orders the union by BVComp (HBVFromEdges.cc:106-111) on its device.  On root, out holds n_unitigs +
+ * unitig_off / unitig_bases, or with flags & SNK_F_BV_IMAGE the file's bytes (bv_image / bv_bytes); release with snk_free.
+ * Other ranks get an empty result. */
+int snk_shard_gather_unitigs(snk_ctx* ctx, snk_comm* comm, const snk_shard_result* res, uint32_t K, uint32_t root, uint32_t flags,
+                             snk_result* out, void* stream, char* err, size_t errcap);
+
 /* Page-locked host memory for the inputs of snk_count_graph (the reference keeps reads/quals in plain vectors, vecbvec /
  * VecPQVec, BuildReadQGraph48.h:24-34; a host that fills pinned buffers instead saves the staging copy: the DMA engine
  * reads them in place).  Pageable inputs are accepted just the same. */

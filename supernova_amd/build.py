@@ -82,7 +82,7 @@ def _build_host(verbose: bool) -> None:
         exe = BIN / src.stem
         if exe.exists() and exe.stat().st_mtime >= max(src.stat().st_mtime, LIB.stat().st_mtime):
             continue
-        cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", str(src), "-o", str(exe), f"-L{HERE}", "-lsnk",
+        cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", f"-I{rocm_lib.parent / 'include'}", str(src), "-o", str(exe), f"-L{HERE}", "-lsnk",
                f"-L{rocm_lib}", "-lamdhip64", f"-Wl,-rpath,{HERE}", f"-Wl,-rpath,{rocm_lib}", "-Wl,-rpath,$ORIGIN/.."]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)

@@ -14,6 +14,7 @@
 
 #include "snk_ctx.h"
 #include "snk_common.h"
+#include "snk_kernels.h"
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Host seam.  The first version of snk_count_graph hipMalloc'ed every input, copied pageable memory synchronously, ordered
@@ -159,6 +160,83 @@ int arena(snk_ctx* ctx, size_t n, T** out, char* err, size_t errcap) {
     return rc;
 }
 
+// unitigs resident on the device -> the reference's deterministic order (BVComp, HBVFromEdges.cc:106-111: length descending,
+// then lexicographic), gathered on the device and downloaded: plain bases + offsets, or the bytes of the .bv hand-off file.
+// by_first_kmer: the input is already ordered by its first K bases (how the join leaves it): one stable sort by length does;
+// else (the union of several ranks' sets) the first k-mers are sorted first -- two unitigs never share theirs.
+__global__ void __launch_bounds__(256) bv_headkey_kernel(const uint64_t* __restrict__ off, const uint8_t* __restrict__ bases, uint64_t U, uint32_t K,
+                                                         snk_u128* __restrict__ key, uint32_t* __restrict__ idx) {
+    const uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u >= U) return;
+    const uint8_t* b = bases + off[u];
+    const uint64_t len = off[u + 1] - off[u];
+    snk_u128 k = 0;
+    for (uint32_t j = 0; j < K; ++j) k = (k << 2) | (snk_u128)(j < len ? (b[j] & 3u) : 0u);
+    key[u] = k;
+    idx[u] = (uint32_t)u;
+}
+__global__ void __launch_bounds__(256) bv_lenkey_of_kernel(const uint64_t* __restrict__ off, const uint32_t* __restrict__ idx1, uint64_t U, uint64_t* __restrict__ key) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < U) key[i] = ~(off[idx1[i] + 1] - off[idx1[i]]);
+}
+int unitigs_to_host(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t U, const uint64_t* d_off, const uint8_t* d_bases, bool by_first_kmer, bool want_image,
+                    snk_result* out, char* err, size_t errcap) {
+    int rc;
+    out->n_unitigs = U;
+    uint64_t *key, *key2, *sz, *noff;
+    uint32_t *idx, *order;
+    if ((rc = arena(ctx, U + 1, &key, err, errcap)) || (rc = arena(ctx, U + 1, &key2, err, errcap)) || (rc = arena(ctx, U + 1, &idx, err, errcap)) ||
+        (rc = arena(ctx, U + 1, &order, err, errcap)) || (rc = arena(ctx, U + 2, &sz, err, errcap)) || (rc = arena(ctx, U + 2, &noff, err, errcap)))
+        return rc;
+    uint64_t total = 0;
+    if (U) {
+        size_t tb = 0, tb2 = 0, tb3 = 0;
+        snk_u128 *hk = nullptr, *hk2 = nullptr;
+        uint32_t* idx1 = nullptr;
+        SNK_HIP_TRY(rocprim::radix_sort_pairs((void*)nullptr, tb, key, key2, idx, order, (size_t)U, 0u, 64u, st));
+        SNK_HIP_TRY(rocprim::exclusive_scan((void*)nullptr, tb2, sz, noff, (uint64_t)0, (size_t)(U + 1), rocprim::plus<uint64_t>(), st));
+        if (!by_first_kmer) {
+            if ((rc = arena(ctx, U + 1, &hk, err, errcap)) || (rc = arena(ctx, U + 1, &hk2, err, errcap)) || (rc = arena(ctx, U + 1, &idx1, err, errcap))) return rc;
+            SNK_HIP_TRY(rocprim::radix_sort_pairs((void*)nullptr, tb3, hk, hk2, idx, idx1, (size_t)U, 0u, 128u, st));
+        }
+        uint8_t* tmp;
+        if ((rc = arena(ctx, std::max(tb, std::max(tb2, tb3)), &tmp, err, errcap))) return rc;
+        if (by_first_kmer) hipLaunchKernelGGL(bv_lenkey_kernel, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, st, d_off, U, key, idx);
+        else {
+            hipLaunchKernelGGL(bv_headkey_kernel, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, st, d_off, d_bases, U, K, hk, idx);
+            SNK_HIP_TRY(rocprim::radix_sort_pairs(tmp, tb3, hk, hk2, idx, idx1, (size_t)U, 0u, 128u, st));
+            hipLaunchKernelGGL(bv_lenkey_of_kernel, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, st, d_off, idx1, U, key);
+            idx = idx1;
+        }
+        SNK_HIP_TRY(rocprim::radix_sort_pairs(tmp, tb, key, key2, idx, order, (size_t)U, 0u, 64u, st));
+        hipLaunchKernelGGL(bv_sizes_kernel, dim3((unsigned)((U + 256) / 256)), dim3(256), 0, st, d_off, order, U, want_image ? 1 : 0, sz);
+        SNK_HIP_TRY(rocprim::exclusive_scan(tmp, tb2, sz, noff, (uint64_t)0, (size_t)(U + 1), rocprim::plus<uint64_t>(), st));
+        SNK_HIP_TRY(hipMemcpyAsync(&total, noff + U, 8, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(snk_sync(st));
+    }
+    uint8_t* d_out;
+    if ((rc = arena(ctx, total + 16, &d_out, err, errcap))) return rc;
+    if (total) hipLaunchKernelGGL(bv_gather_kernel, dim3((unsigned)((total + 4095) / 4096)), dim3(256), 0, st, d_off, d_bases, order, noff, U, total,
+                                  want_image ? 1 : 0, d_out);
+    SNK_HIP_TRY(hipGetLastError());
+    if (want_image) {
+        out->bv_bytes = 16 + total;
+        out->bv_image = (uint8_t*)malloc(out->bv_bytes);
+        if (!out->bv_image) { snk_free(out); return snk_fail(SNK_E_NOMEM, err, errcap, "host allocation failed"); }
+        memcpy(out->bv_image, "BINWRITE", 8);
+        memcpy(out->bv_image + 8, &U, 8);
+        if (total) SNK_HIP_TRY(hipMemcpyAsync(out->bv_image + 16, d_out, total, hipMemcpyDeviceToHost, st));
+    } else {
+        out->unitig_off = (uint64_t*)malloc((U + 1) * 8);
+        out->unitig_bases = (uint8_t*)malloc(std::max<size_t>(total, 16));
+        if (!out->unitig_off || !out->unitig_bases) { snk_free(out); return snk_fail(SNK_E_NOMEM, err, errcap, "host allocation failed"); }
+        out->unitig_off[0] = 0;
+        if (U) SNK_HIP_TRY(hipMemcpyAsync(out->unitig_off, noff, (U + 1) * 8, hipMemcpyDeviceToHost, st));
+        if (total) SNK_HIP_TRY(hipMemcpyAsync(out->unitig_bases, d_out, total, hipMemcpyDeviceToHost, st));
+    }
+    return SNK_OK;
+}
+
 int count_graph_impl(snk_ctx* ctx, const snk_reads* in, const snk_params* p, snk_result* out, char* err, size_t errcap) {
     if (!ctx || !in || !p || !out) return snk_fail(SNK_E_ARG, err, errcap, "snk_count_graph: NULL argument");
     if (!in->ascii && !in->rows) return snk_fail(SNK_E_ARG, err, errcap, "snk_count_graph: need ascii or rows");
@@ -242,54 +320,21 @@ int count_graph_impl(snk_ctx* ctx, const snk_reads* in, const snk_params* p, snk
         SNK_HIP_TRY(hipMemcpyAsync(out->ctx, r.ctx, nk, hipMemcpyDeviceToHost, st));
     }
     if (r.spectrum_bins) SNK_HIP_TRY(hipMemcpyAsync(out->spectrum, r.spectrum, (size_t)r.spectrum_bins * 8, hipMemcpyDeviceToHost, st));
-    // ---- unitigs in the reference's deterministic order (BVComp), gathered on the device: plain bases, or the .bv image
-    const uint64_t U = r.n_unitigs;
-    out->n_unitigs = U;
-    const uint64_t* d_off = (const uint64_t*)r.unitig_off;
-    uint64_t *key, *key2, *sz, *noff;
-    uint32_t *idx, *order;
-    if ((rc = arena(ctx, U + 1, &key, err, errcap)) || (rc = arena(ctx, U + 1, &key2, err, errcap)) || (rc = arena(ctx, U + 1, &idx, err, errcap)) ||
-        (rc = arena(ctx, U + 1, &order, err, errcap)) || (rc = arena(ctx, U + 2, &sz, err, errcap)) || (rc = arena(ctx, U + 2, &noff, err, errcap)))
-        return rc;
-    uint64_t total = 0;
-    if (U) {
-        hipLaunchKernelGGL(bv_lenkey_kernel, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, st, d_off, U, key, idx);
-        size_t tb = 0, tb2 = 0;
-        SNK_HIP_TRY(rocprim::radix_sort_pairs((void*)nullptr, tb, key, key2, idx, order, (size_t)U, 0u, 64u, st));
-        SNK_HIP_TRY(rocprim::exclusive_scan((void*)nullptr, tb2, sz, noff, (uint64_t)0, (size_t)(U + 1), rocprim::plus<uint64_t>(), st));
-        uint8_t* tmp;
-        if ((rc = arena(ctx, std::max(tb, tb2), &tmp, err, errcap))) return rc;
-        SNK_HIP_TRY(rocprim::radix_sort_pairs(tmp, tb, key, key2, idx, order, (size_t)U, 0u, 64u, st));
-        hipLaunchKernelGGL(bv_sizes_kernel, dim3((unsigned)((U + 256) / 256)), dim3(256), 0, st, d_off, order, U, want_image ? 1 : 0, sz);
-        SNK_HIP_TRY(rocprim::exclusive_scan(tmp, tb2, sz, noff, (uint64_t)0, (size_t)(U + 1), rocprim::plus<uint64_t>(), st));
-        SNK_HIP_TRY(hipMemcpyAsync(&total, noff + U, 8, hipMemcpyDeviceToHost, st));
-        SNK_HIP_TRY(snk_sync(st));
-    }
-    uint8_t* d_out;
-    if ((rc = arena(ctx, total + 16, &d_out, err, errcap))) return rc;
-    if (total) hipLaunchKernelGGL(bv_gather_kernel, dim3((unsigned)((total + 4095) / 4096)), dim3(256), 0, st, d_off, (const uint8_t*)r.unitig_bases, order, noff, U, total,
-                                  want_image ? 1 : 0, d_out);
-    SNK_HIP_TRY(hipGetLastError());
-    if (want_image) {
-        out->bv_bytes = 16 + total;
-        out->bv_image = (uint8_t*)malloc(out->bv_bytes);
-        if (!out->bv_image) { snk_free(out); return snk_fail(SNK_E_NOMEM, err, errcap, "snk_count_graph: host allocation failed"); }
-        memcpy(out->bv_image, "BINWRITE", 8);
-        memcpy(out->bv_image + 8, &U, 8);
-        if (total) SNK_HIP_TRY(hipMemcpyAsync(out->bv_image + 16, d_out, total, hipMemcpyDeviceToHost, st));
-    } else {
-        out->unitig_off = (uint64_t*)malloc((U + 1) * 8);
-        out->unitig_bases = (uint8_t*)malloc(std::max<size_t>(total, 16));
-        if (!out->unitig_off || !out->unitig_bases) { snk_free(out); return snk_fail(SNK_E_NOMEM, err, errcap, "snk_count_graph: host allocation failed"); }
-        out->unitig_off[0] = 0;
-        if (U) SNK_HIP_TRY(hipMemcpyAsync(out->unitig_off, noff, (U + 1) * 8, hipMemcpyDeviceToHost, st));
-        if (total) SNK_HIP_TRY(hipMemcpyAsync(out->unitig_bases, d_out, total, hipMemcpyDeviceToHost, st));
-    }
+    if ((rc = unitigs_to_host(ctx, st, p->K, r.n_unitigs, (const uint64_t*)r.unitig_off, (const uint8_t*)r.unitig_bases, true, want_image, out, err, errcap))) return rc;
     SNK_HIP_TRY(snk_sync(st));
     return SNK_OK;
 }
 
 }  // namespace
+
+// (library-internal: the gather of the sharded path ends here, snk_shard_step.hip)
+int snk_unitigs_to_host(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t U, const uint64_t* d_off, const uint8_t* d_bases, bool by_first_kmer,
+                        bool want_image, snk_result* out, char* err, size_t errcap) {
+    int rc = unitigs_to_host(ctx, st, K, U, d_off, d_bases, by_first_kmer, want_image, out, err, errcap);
+    if (rc) return rc;
+    SNK_HIP_TRY(snk_sync(st));
+    return SNK_OK;
+}
 
 // No C++ exception leaves an extern "C" entry point: a failed host allocation maps to SNK_E_NOMEM (the caller's exit code 99,
 // system/RunTime.cc:195-221), anything else to SNK_E_INTERNAL.

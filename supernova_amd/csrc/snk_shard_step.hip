@@ -552,6 +552,90 @@ void shard_host_free(void* p) { delete static_cast<shard_host*>(p); }
 
 }  // namespace
 
+int snk_unitigs_to_host(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t U, const uint64_t* d_off, const uint8_t* d_bases, bool by_first_kmer,
+                        bool want_image, snk_result* out, char* err, size_t errcap);
+
+namespace {
+__global__ void __launch_bounds__(256) shift_offsets_kernel(const uint64_t* __restrict__ in, uint64_t n, uint64_t add, uint64_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = in[i] + add;
+}
+}  // namespace
+
+// The job's unitig set on ONE rank, in the reference's order: every rank packs the unitigs it wrote to 2 bits per base
+// (what crosses xGMI), `root` receives them, orders the union by BVComp on its device and gets host arrays -- or the bytes of the
+// .bv hand-off file (SNK_F_BV_IMAGE) that MAIN_ASM_SN writes (lib/tada/src/cmd_main_asm.rs:184-193, debruijn.rs:895-929).
+extern "C" int snk_shard_gather_unitigs(snk_ctx* ctx, snk_comm* comm, const snk_shard_result* res, uint32_t K, uint32_t root, uint32_t flags,
+                                        snk_result* out, void* stream, char* err, size_t errcap) {
+    if (!ctx || !comm || !res || !out || root >= comm->world) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_gather_unitigs: bad argument");
+    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    memset(out, 0, sizeof *out);
+    if (!ctx->shard_host) { ctx->shard_host = new shard_host(); ctx->shard_host_free = shard_host_free; }
+    shard_host& H = *static_cast<shard_host*>(ctx->shard_host);
+    step_ctx X;
+    X.ctx = ctx; X.comm = comm; X.st = stream ? (hipStream_t)stream : ctx->stream; X.err = err; X.errcap = errcap;
+    X.W = comm->world; X.me = comm->rank;
+    const size_t need = 64ull * (X.W + 2) + 4096;
+    if (H.pin_cap < need) {
+        if (H.pin) (void)hipHostFree(H.pin);
+        H.pin = nullptr; H.pin_cap = 0;
+        SNK_HIP_TRY(hipHostMalloc((void**)&H.pin, need * 8, hipHostMallocDefault));
+        H.pin_cap = need;
+    }
+    X.pin = H.pin; X.pin_cap = H.pin_cap; X.pin_used = 0;
+    hipStream_t st = X.st;
+    const uint32_t W = X.W, me = X.me;
+    auto body = [&]() -> int {
+        const uint64_t U = res->n_unitigs, TB = res->unitig_total_bases;
+        const uint64_t pb = ((TB + 15) / 16) * 4;
+        uint8_t* packed;
+        ALLOC(packed, uint8_t, pb + 32);
+        if (TB) TRY(snk_dev_pack2(ctx, res->unitig_bases, TB, packed, st));
+        ull mine[2] = {U, TB}, *d_mine;
+        TRY(upload(X, mine, 2, &d_mine));
+        std::vector<ull> all;
+        TRY(exchange_counts(X, d_mine, 2, all));
+        std::vector<uint64_t> sbeg(W, 0), scnt(W, 0), rbeg(W, 0), rcnt(W, 0);
+        uint64_t Ut = 0, TBt = 0, pbt = 0;
+        std::vector<uint64_t> ubase(W + 1, 0), bbase(W + 1, 0), pbase(W + 1, 0);
+        for (uint32_t q = 0; q < W; ++q) {
+            ubase[q + 1] = ubase[q] + all[2 * q] + 1;                       // every source ships its U+1 offsets
+            bbase[q + 1] = bbase[q] + all[2 * q + 1];
+            pbase[q + 1] = pbase[q] + ((all[2 * q + 1] + 15) / 16) * 4;
+        }
+        Ut = ubase[W] - W; TBt = bbase[W]; pbt = pbase[W];
+        uint64_t* off_in = nullptr;
+        uint8_t* pk_in = nullptr;
+        if (me == root) { ALLOC(off_in, uint64_t, ubase[W] + 2); ALLOC(pk_in, uint8_t, pbt + 32); }
+        // offsets, then packed bases: everything flows to `root`
+        scnt[root] = (U + 1) * 8;
+        if (me == root) for (uint32_t q = 0; q < W; ++q) { rbeg[q] = ubase[q] * 8; rcnt[q] = (all[2 * q] + 1) * 8; }
+        TRY(comm->a2a(res->unitig_off, sbeg.data(), scnt.data(), off_in, rbeg.data(), rcnt.data(), st, err, errcap));
+        scnt[root] = pb;
+        if (me == root) for (uint32_t q = 0; q < W; ++q) { rbeg[q] = pbase[q]; rcnt[q] = ((all[2 * q + 1] + 15) / 16) * 4; }
+        TRY(comm->a2a(packed, sbeg.data(), scnt.data(), pk_in, rbeg.data(), rcnt.data(), st, err, errcap));
+        if (me != root) { SNK_HIP_TRY(snk_sync(st)); return SNK_OK; }
+        uint8_t* bases;
+        uint64_t* off;
+        ALLOC(bases, uint8_t, TBt + 32);
+        ALLOC(off, uint64_t, Ut + 2);
+        uint64_t uacc = 0;
+        for (uint32_t q = 0; q < W; ++q) {
+            const uint64_t uq = all[2 * q], tq = all[2 * q + 1];
+            if (tq) TRY(snk_dev_unpack2(ctx, pk_in + pbase[q], tq, bases + bbase[q], st));
+            // a source's offsets start at 0: shift them to where its bases landed (the last source also writes the closing offset)
+            hipLaunchKernelGGL(shift_offsets_kernel, dim3((unsigned)((uq + 1 + 255) / 256)), dim3(256), 0, st, off_in + ubase[q], uq + (q + 1 == W ? 1 : 0), bbase[q],
+                               off + uacc);
+            uacc += uq;
+        }
+        SNK_HIP_TRY(hipGetLastError());
+        return snk_unitigs_to_host(ctx, st, K, Ut, off, bases, false, (flags & SNK_F_BV_IMAGE) != 0, out, err, errcap);
+    };
+    int rc = body();
+    if (rc) comm->abort();
+    return rc;
+}
+
 extern "C" int snk_shard_step(snk_ctx* ctx, snk_comm* comm, const snk_dev_reads* in, const snk_params* p, uint64_t total_reads, uint32_t flags,
                               snk_shard_result* out, void* stream, char* err, size_t errcap) {
     if (!ctx || !comm || !in || !p || !out) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_step: NULL argument");

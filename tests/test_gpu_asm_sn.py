@@ -1,0 +1,119 @@
+"""The N-GPU job without a scripting layer: supernova_amd/bin/snk_asm_sn (C++ over the C ABI: snk_shard_step on an RCCL
+communicator + snk_shard_gather_unitigs) against the reference's unitigs, and the gather through in-process ranks."""
+import hashlib
+import json
+import subprocess
+import threading
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import goldens
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+EXE = ROOT / "supernova_amd" / "bin" / "snk_asm_sn"
+
+
+def _run(args, timeout=900):
+    r = subprocess.run([str(EXE)] + args, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stderr
+
+
+def test_asm_sn_fasth_to_bv(snk, tmp_path):
+    """FASTH files + whitelist -> asm_graph.bv on a one-rank RCCL communicator == the reference's unitigs in BVComp order."""
+    from test_martian import make_fasth
+    from supernova_amd import graphio
+    c = goldens.load("synth_20k_err")
+    files, wl = make_fasth(c, tmp_path, n_files=5)
+    out = tmp_path / "asm_graph.bv"
+    log = _run([f"FASTH={','.join(files)}", f"WHITELIST={wl}", f"OUT={out}", "WORLD=1", "RANK=0", f"STATS={tmp_path / 'stats.jsonl'}"])
+    assert "host read-backs" in log
+    off, bases = graphio.read_bv(str(out))
+    assert graphio.arrays_to_unitigs(off, bases) == c.exp_unitigs
+    st = json.loads((tmp_path / "stats.jsonl").read_text().splitlines()[-1])
+    assert st["world"] == 1 and st["reads_rank0"] == c.rows.shape[0]
+
+
+def test_asm_sn_10m_reference_digest(snk, tmp_path):
+    """BASELINE config 1 (10 M x 150 bp, seed 0x5EED0001) through the C++ host on a one-rank RCCL communicator: the unitig file's
+    content hashes to the reference's own digest (tests/golden/big_hashes.json)."""
+    from supernova_amd import graphio
+    fix = ROOT / "tests" / "golden" / "big_hashes.json"
+    exp = json.loads(fix.read_text())["c1_10m"]
+    out = tmp_path / "asm_graph.bv"
+    _run([f"SYNTH={exp['n_reads']}", f"SEED={exp['seed']}", f"OUT={out}", "STEPS=2"])
+    off, bases = graphio.read_bv(str(out))
+    us = graphio.arrays_to_unitigs(off, bases)
+    assert len(us) == exp["n_unitigs"] and sum(len(u) for u in us) == exp["unitig_bases"]
+    assert us == sorted(us, key=lambda s: (-len(s), s))                # BVComp order in the file
+    h = hashlib.sha256()
+    for u in sorted(u.encode() for u in us):
+        h.update(u)
+        h.update(b"\n")
+    assert h.hexdigest() == exp["unitigs"]
+
+
+@pytest.mark.parametrize("W", [1, 3])
+def test_gather_unitigs_in_process_ranks(snk, W):
+    """snk_shard_gather_unitigs over in-process ranks: root's arrays are the reference's unitigs in BVComp order (the adversarial
+    case: circles, a palindrome, unitigs of equal length)."""
+    import ctypes as C
+    import torch
+    from supernova_amd import graphio, lib as _lib
+    from supernova_amd.engine import Engine, Params
+    from supernova_amd.sharded import ShardedEngine, SimWorld
+    c = goldens.load("adversarial")
+    world = SimWorld(W)
+    dev = torch.device("cuda", 0)
+    n = c.rows.shape[0]
+    bounds = [(n // 2 * r // W) * 2 for r in range(W)] + [n]
+    got, errs = {}, []
+
+    def worker(r):
+        try:
+            e = Engine(0)
+            lo, hi = bounds[r], bounds[r + 1]
+            sh = ShardedEngine(e, world.comm(r))
+            res = sh.count_graph(torch.from_numpy(c.rows[lo:hi].view(np.int32).copy()).to(dev), c.read_len,
+                                 quals=torch.from_numpy(np.ascontiguousarray(c.quals[lo:hi])).to(dev),
+                                 bc=torch.from_numpy(c.bc[lo:hi].astype(np.int32)).to(dev),
+                                 lens=torch.from_numpy(c.lens[lo:hi].astype(np.uint16).view(np.int16)).to(dev),
+                                 params=Params(K=48), ign_bc_below=c.ign_bc_below, read_index_base=lo, total_reads=n)
+            for root, image in ((0, 0), (W - 1, 32)):
+                out = _lib.SnkResult()
+                err = C.create_string_buffer(512)
+                rc = e.lib.snk_shard_gather_unitigs(e._ctx, sh.comm, C.byref(res.raw), 48, root, image, C.byref(out), e._stream(), err, 512)
+                assert rc == 0, err.value
+                if r == root:
+                    if image:
+                        got["image"] = bytes(np.ctypeslib.as_array(out.bv_image, shape=(int(out.bv_bytes),)))
+                    else:
+                        nu = int(out.n_unitigs)
+                        off = np.ctypeslib.as_array(out.unitig_off, shape=(nu + 1,)).copy()
+                        bases = np.ctypeslib.as_array(out.unitig_bases, shape=(max(int(off[-1]), 1),))[:int(off[-1])].copy()
+                        got["plain"] = graphio.arrays_to_unitigs(off, bases)
+                else:
+                    assert int(out.n_unitigs) == 0
+                e.lib.snk_free(C.byref(out))
+            sh.close()
+            e.close()
+        except BaseException as ex:  # noqa: BLE001
+            errs.append(ex)
+            world.barrier_obj.abort()
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(W)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    if errs:
+        raise errs[0]
+    assert got["plain"] == c.exp_unitigs
+
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        p = Path(td) / "x.bv"
+        p.write_bytes(got["image"])
+        off, bases = graphio.read_bv(str(p))
+        assert graphio.arrays_to_unitigs(off, bases) == c.exp_unitigs
