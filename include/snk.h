@@ -292,6 +292,17 @@ int snk_comm_unique_id(void* id128, char* err, size_t errcap);
 int snk_comm_create_rccl(snk_ctx* ctx, const void* id128, uint32_t rank, uint32_t world, snk_comm** out, char* err, size_t errcap);
 int snk_comm_from_nccl(snk_ctx* ctx, void* nccl_comm, uint32_t rank, uint32_t world, snk_comm** out, char* err, size_t errcap);
 int snk_comm_create_local(uint32_t world, snk_comm** out /* [world] */, char* err, size_t errcap);
+/* the exchanges through callbacks of the host (its own transport: MPI, sockets, torch.distributed, ...): a2a moves scnt[p] bytes
+ * at send + sbeg[p] to rank p and delivers rcnt[s] bytes from rank s at recv + rbeg[s]; gather collects k u64 of every rank
+ * (mine: whatever memory the step hands over -- device memory inside snk_shard_step) into all[world * k] on the host.
+ * Both return 0 or an error code.  snk_comm_selftest runs the step's exchange patterns on HOST memory with synthetic contents
+ * over any communicator whose buffers may be host memory (the CPU tests use it over gloo, world_size 2). */
+typedef int (*snk_comm_a2a_fn)(void* user, const void* send, const uint64_t* sbeg, const uint64_t* scnt, void* recv, const uint64_t* rbeg,
+                               const uint64_t* rcnt, uint32_t world);
+typedef int (*snk_comm_gather_fn)(void* user, const void* mine, uint32_t k, unsigned long long* all, uint32_t world);
+int snk_comm_create_callbacks(uint32_t rank, uint32_t world, snk_comm_a2a_fn a2a, snk_comm_gather_fn gather, void* user, snk_comm** out,
+                              char* err, size_t errcap);
+int snk_comm_selftest(snk_comm* c, uint64_t seed, uint32_t buckets_per_rank, uint32_t ranges, char* err, size_t errcap);
 void snk_comm_destroy(snk_comm* c);
 void snk_comm_abort(snk_comm* c);          /* in-process ranks: release the others after a failure outside snk_shard_step */
 uint32_t snk_comm_rank(const snk_comm* c);

@@ -24,3 +24,6 @@ struct snk_comm {
     virtual int barrier(hipStream_t st, char* err, size_t errcap) = 0;
     virtual void abort() {}            // a rank failed: release the others (in-process ranks only)
 };
+
+void snk_plan_range_pieces(const unsigned long long* h_rs, uint32_t W, uint32_t R, uint32_t r, uint64_t item_bytes, uint64_t* sbeg, uint64_t* scnt,
+                           uint64_t* rbeg, uint64_t* rcnt);

@@ -294,3 +294,145 @@ extern "C" uint32_t snk_comm_rank(const snk_comm* c) { return c ? c->rank : 0; }
 extern "C" uint32_t snk_comm_world(const snk_comm* c) { return c ? c->world : 0; }
 extern "C" const char* snk_comm_kind(const snk_comm* c) { return c ? c->kind() : ""; }
 extern "C" void snk_comm_abort(snk_comm* c) { if (c) c->abort(); }
+
+// ---------------------------------------------------------------------------------------------------- caller's transport
+// The exchanges handed to callbacks of the host (any transport it has: MPI, sockets, torch.distributed).  The CPU tests drive
+// the library's exchange planning over gloo with world_size 2 through this (tests/test_sharded_plumbing.py); buffers are
+// whatever the caller's transport understands -- host memory there.
+namespace {
+struct cb_comm : snk_comm {
+    snk_comm_a2a_fn a2a_fn = nullptr;
+    snk_comm_gather_fn gather_fn = nullptr;
+    void* user = nullptr;
+    const char* kind() const override { return "callbacks"; }
+    int a2a(const void* send, const uint64_t* sbeg, const uint64_t* scnt, void* recv, const uint64_t* rbeg, const uint64_t* rcnt, hipStream_t, char* err,
+            size_t errcap) override {
+        ++n_collectives;
+        for (uint32_t p = 0; p < world; ++p) if (p != rank) bytes_sent += scnt[p];
+        const int rc = a2a_fn(user, send, sbeg, scnt, recv, rbeg, rcnt, world);
+        return rc ? snk_fail(SNK_E_INTERNAL, err, errcap, "the caller's all-to-all failed (%d)", rc) : SNK_OK;
+    }
+    int allgatherv(const void* send, const uint64_t* counts, void* recv, hipStream_t st, char* err, size_t errcap) override {
+        std::vector<uint64_t> sbeg(world, 0), scnt(world, counts[rank]), rbeg(world), rcnt(world);
+        uint64_t acc = 0;
+        for (uint32_t p = 0; p < world; ++p) { rbeg[p] = acc; rcnt[p] = counts[p]; acc += counts[p]; }
+        return a2a(send, sbeg.data(), scnt.data(), recv, rbeg.data(), rcnt.data(), st, err, errcap);
+    }
+    int gather_counts(const unsigned long long* d_mine, uint32_t k, unsigned long long* h_all, hipStream_t, char* err, size_t errcap) override {
+        ++n_collectives;
+        const int rc = gather_fn(user, d_mine, k, h_all, world);
+        return rc ? snk_fail(SNK_E_INTERNAL, err, errcap, "the caller's gather failed (%d)", rc) : SNK_OK;
+    }
+    int barrier(hipStream_t, char* err, size_t errcap) override {
+        unsigned long long one = 1;
+        std::vector<unsigned long long> all(world);
+        return gather_counts(&one, 1, all.data(), nullptr, err, errcap);
+    }
+};
+uint64_t mix64(uint64_t x) { x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; return x ^ (x >> 31); }
+}  // namespace
+
+extern "C" int snk_comm_create_callbacks(uint32_t rank, uint32_t world, snk_comm_a2a_fn a2a, snk_comm_gather_fn gather, void* user, snk_comm** out,
+                                         char* err, size_t errcap) {
+    if (!out || !a2a || !gather || world == 0 || rank >= world) return snk_fail(SNK_E_ARG, err, errcap, "snk_comm_create_callbacks: bad argument");
+    cb_comm* c = new cb_comm();
+    c->rank = rank; c->world = world; c->a2a_fn = a2a; c->gather_fn = gather; c->user = user;
+    *out = c;
+    return SNK_OK;
+}
+
+// Exchange patterns of the sharded step on HOST memory with synthetic contents, checked on every rank: (1) bucket histograms
+// (equal pieces), (2) the supermer records in R bucket ranges with the step's own piece planner -- every record names its
+// (source, destination, bucket, serial) and must land in its (source, bucket) segment in order --, (3) a query / answer round
+// trip through per-destination regions with the counts learnt from a gather, (4) a ragged all-gather.  Works over any
+// communicator whose buffers may be host memory (callbacks); returns 0 or the number of the check that failed.
+extern "C" int snk_comm_selftest(snk_comm* c, uint64_t seed, uint32_t NBl, uint32_t R, char* err, size_t errcap) {
+    if (!c || NBl == 0 || R == 0) return snk_fail(SNK_E_ARG, err, errcap, "snk_comm_selftest: bad argument");
+    const uint32_t W = c->world, me = c->rank;
+    if (R > NBl) R = NBl;
+    auto hist_of = [&](uint32_t src, uint32_t dst, uint32_t b) -> uint32_t { return (uint32_t)(mix64(seed ^ ((uint64_t)src << 40) ^ ((uint64_t)dst << 20) ^ b) % 7); };
+    // (1) histograms
+    std::vector<uint32_t> hist((size_t)W * NBl), hrecv((size_t)W * NBl);
+    for (uint32_t p = 0; p < W; ++p) for (uint32_t b = 0; b < NBl; ++b) hist[(size_t)p * NBl + b] = hist_of(me, p, b);
+    {
+        std::vector<uint64_t> beg(W), cnt(W, (uint64_t)NBl * 4);
+        for (uint32_t q = 0; q < W; ++q) beg[q] = (uint64_t)q * NBl * 4;
+        int rc = c->a2a(hist.data(), beg.data(), cnt.data(), hrecv.data(), beg.data(), cnt.data(), nullptr, err, errcap);
+        if (rc) return rc;
+    }
+    for (uint32_t s = 0; s < W; ++s) for (uint32_t b = 0; b < NBl; ++b) if (hrecv[(size_t)s * NBl + b] != hist_of(s, me, b)) return snk_fail(1, err, errcap, "selftest: histogram of rank %u, bucket %u", s, b);
+    // (2) records in ranges: 32-byte records (src, dst, bucket, serial)
+    std::vector<unsigned long long> h_rs(2ull * W * R, 0);
+    for (uint32_t p = 0; p < W; ++p) for (uint32_t b = 0; b < NBl; ++b) {
+        const uint32_t r = (uint32_t)(((uint64_t)(b + 1) * R - 1) / NBl);        // the range whose bounds NBl*r/R .. NBl*(r+1)/R hold b
+        uint32_t rr = r;
+        while ((uint64_t)NBl * rr / R > b) --rr;
+        while ((uint64_t)NBl * (rr + 1) / R <= b) ++rr;
+        h_rs[(size_t)p * R + rr] += hist[(size_t)p * NBl + b];
+        h_rs[(size_t)W * R + (size_t)p * R + rr] += hrecv[(size_t)p * NBl + b];
+    }
+    uint64_t n_send = 0, n_recv = 0;
+    for (size_t q = 0; q < (size_t)W * R; ++q) { n_send += h_rs[q]; n_recv += h_rs[(size_t)W * R + q]; }
+    std::vector<uint64_t> sendb(4 * n_send + 4), recvb(4 * n_recv + 4, ~0ull);
+    {
+        uint64_t at = 0;
+        for (uint32_t p = 0; p < W; ++p) for (uint32_t b = 0; b < NBl; ++b) for (uint32_t k = 0; k < hist[(size_t)p * NBl + b]; ++k) {
+            sendb[4 * at] = me; sendb[4 * at + 1] = p; sendb[4 * at + 2] = b; sendb[4 * at + 3] = k; ++at;
+        }
+    }
+    std::vector<uint64_t> sbeg(W), scnt(W), rbeg(W), rcnt(W);
+    for (uint32_t r = 0; r < R; ++r) {
+        snk_plan_range_pieces(h_rs.data(), W, R, r, 32, sbeg.data(), scnt.data(), rbeg.data(), rcnt.data());
+        int rc = c->a2a(sendb.data(), sbeg.data(), scnt.data(), recvb.data(), rbeg.data(), rcnt.data(), nullptr, err, errcap);
+        if (rc) return rc;
+    }
+    {
+        uint64_t at = 0;       // the receive buffer is source-major, buckets ascending: exactly the segment table of the count
+        for (uint32_t s = 0; s < W; ++s) for (uint32_t b = 0; b < NBl; ++b) for (uint32_t k = 0; k < hrecv[(size_t)s * NBl + b]; ++k) {
+            if (recvb[4 * at] != s || recvb[4 * at + 1] != me || recvb[4 * at + 2] != b || recvb[4 * at + 3] != k)
+                return snk_fail(2, err, errcap, "selftest: record %llu of segment (source %u, bucket %u)", (unsigned long long)k, s, b);
+            ++at;
+        }
+        if (at != n_recv) return snk_fail(2, err, errcap, "selftest: record count");
+    }
+    // (3) queries through per-destination regions, answers back into the same regions
+    const uint64_t cap = 64 + mix64(seed ^ me) % 64;
+    std::vector<unsigned long long> cur(W + 1), all((size_t)W * (W + 1));
+    std::vector<uint64_t> qbuf((size_t)W * cap, 0), ans_back((size_t)W * cap, 0);
+    for (uint32_t p = 0; p < W; ++p) {
+        const uint64_t n = mix64(seed ^ ((uint64_t)me << 8) ^ p ^ 0x51) % cap;
+        for (uint64_t i = 0; i < n; ++i) qbuf[(size_t)p * cap + i] = ((uint64_t)me << 48) | ((uint64_t)p << 32) | i;
+        cur[p] = (uint64_t)p * cap + n;
+    }
+    cur[W] = cap;
+    { int rc = c->gather_counts(cur.data(), W + 1, all.data(), nullptr, err, errcap); if (rc) return rc; }
+    uint64_t n_in = 0;
+    for (uint32_t q = 0; q < W; ++q) {
+        const uint64_t cap_q = all[(size_t)q * (W + 1) + W];
+        sbeg[q] = (uint64_t)q * cap * 8; scnt[q] = (all[(size_t)me * (W + 1) + q] - (uint64_t)q * cap) * 8;
+        rbeg[q] = n_in * 8; rcnt[q] = (all[(size_t)q * (W + 1) + me] - (uint64_t)me * cap_q) * 8;
+        n_in += rcnt[q] / 8;
+    }
+    std::vector<uint64_t> qin(n_in + 1), ans(n_in + 1);
+    { int rc = c->a2a(qbuf.data(), sbeg.data(), scnt.data(), qin.data(), rbeg.data(), rcnt.data(), nullptr, err, errcap); if (rc) return rc; }
+    for (uint64_t i = 0; i < n_in; ++i) {
+        if (((qin[i] >> 32) & 0xFFFF) != me) return snk_fail(3, err, errcap, "selftest: a query for rank %llu arrived here", (unsigned long long)((qin[i] >> 32) & 0xFFFF));
+        ans[i] = mix64(qin[i]);
+    }
+    { int rc = c->a2a(ans.data(), rbeg.data(), rcnt.data(), ans_back.data(), sbeg.data(), scnt.data(), nullptr, err, errcap); if (rc) return rc; }
+    for (uint32_t p = 0; p < W; ++p) for (uint64_t i = 0; i < scnt[p] / 8; ++i)
+        if (ans_back[(size_t)p * cap + i] != mix64(qbuf[(size_t)p * cap + i])) return snk_fail(3, err, errcap, "selftest: answer %llu from rank %u", (unsigned long long)i, p);
+    // (4) ragged all-gather
+    std::vector<uint64_t> counts(W);
+    uint64_t tot = 0;
+    for (uint32_t q = 0; q < W; ++q) { counts[q] = (100 + 37 * q + mix64(seed) % 50) * 8; tot += counts[q]; }
+    std::vector<uint64_t> mine(counts[me] / 8), gathered(tot / 8 + 1);
+    for (size_t i = 0; i < mine.size(); ++i) mine[i] = mix64(seed ^ ((uint64_t)me << 32) ^ i);
+    { int rc = c->allgatherv(mine.data(), counts.data(), gathered.data(), nullptr, err, errcap); if (rc) return rc; }
+    {
+        size_t at = 0;
+        for (uint32_t q = 0; q < W; ++q) for (size_t i = 0; i < counts[q] / 8; ++i, ++at)
+            if (gathered[at] != mix64(seed ^ ((uint64_t)q << 32) ^ i)) return snk_fail(4, err, errcap, "selftest: all-gather, rank %u word %zu", q, i);
+    }
+    return SNK_OK;
+}

@@ -74,6 +74,29 @@ __global__ void __launch_bounds__(256) seg_table_kernel(const ull* __restrict__ 
     }
 }
 
+}  // namespace
+
+// Piece (q, r) of the ranged record exchange: h_rs = [2][W][R] items per (destination, range) and per (source, range); the
+// ranges of one peer follow each other in both buffers, the peers follow each other in rank order.  Byte offsets / counts of
+// range r for every peer (host arithmetic shared by the step and by snk_comm_selftest).
+void snk_plan_range_pieces(const unsigned long long* h_rs, uint32_t W, uint32_t R, uint32_t r, uint64_t item_bytes, uint64_t* sbeg, uint64_t* scnt,
+                           uint64_t* rbeg, uint64_t* rcnt) {
+    uint64_t sacc = 0, racc = 0;
+    for (uint32_t q = 0; q < W; ++q) {
+        uint64_t sd = 0, rd = 0, stot = 0, rtot = 0;
+        for (uint32_t x = 0; x < R; ++x) {
+            const uint64_t a = h_rs[(size_t)q * R + x], b = h_rs[(size_t)W * R + (size_t)q * R + x];
+            if (x < r) { sd += a; rd += b; }
+            stot += a; rtot += b;
+        }
+        sbeg[q] = (sacc + sd) * item_bytes; scnt[q] = h_rs[(size_t)q * R + r] * item_bytes;
+        rbeg[q] = (racc + rd) * item_bytes; rcnt[q] = h_rs[(size_t)W * R + (size_t)q * R + r] * item_bytes;
+        sacc += stot; racc += rtot;
+    }
+}
+
+namespace {
+
 struct step_ctx {
     snk_ctx* ctx;
     snk_comm* comm;
@@ -255,19 +278,9 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
         SNK_HIP_TRY(hipStreamWaitEvent(H.cstream, H.ev[R], 0));
         {
             // offsets of piece (q, r): the ranges of one peer follow each other
-            std::vector<uint64_t> sbeg(W), scnt(W), rbeg(W), rcnt(W), sacc(W + 1, 0), racc(W + 1, 0);
-            for (uint32_t q = 0; q < W; ++q) {
-                uint64_t a = 0, b = 0;
-                for (uint32_t r = 0; r < R; ++r) { a += h_rs[(size_t)q * R + r]; b += h_rs[(size_t)W * R + (size_t)q * R + r]; }
-                sacc[q + 1] = sacc[q] + a; racc[q + 1] = racc[q] + b;
-            }
-            std::vector<uint64_t> sdone(W, 0), rdone(W, 0);
+            std::vector<uint64_t> sbeg(W), scnt(W), rbeg(W), rcnt(W);
             for (uint32_t r = 0; r < R; ++r) {
-                for (uint32_t q = 0; q < W; ++q) {
-                    sbeg[q] = (sacc[q] + sdone[q]) * 32; scnt[q] = h_rs[(size_t)q * R + r] * 32;
-                    rbeg[q] = (racc[q] + rdone[q]) * 32; rcnt[q] = h_rs[(size_t)W * R + (size_t)q * R + r] * 32;
-                    sdone[q] += h_rs[(size_t)q * R + r]; rdone[q] += h_rs[(size_t)W * R + (size_t)q * R + r];
-                }
+                snk_plan_range_pieces(h_rs.data(), W, R, r, 32, sbeg.data(), scnt.data(), rbeg.data(), rcnt.data());
                 TRY(comm->a2a(sendb, sbeg.data(), scnt.data(), recvb, rbeg.data(), rcnt.data(), H.cstream, err, errcap));
                 SNK_HIP_TRY(hipEventRecord(H.ev[r], H.cstream));
             }

@@ -127,6 +127,9 @@ class SnkShardResult(C.Structure):
                 ("join_ms", C.c_float * 8), ("count_kernel_ms", C.c_float), ("reserved_f", C.c_float)]
 
 
+COMM_A2A = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64),
+                       C.POINTER(C.c_uint64), C.c_uint32)
+COMM_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64), C.c_uint32)
 RANGE_READY = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32)      # int ready(void* user, uint32_t range)
 
 _lib = None
@@ -246,6 +249,8 @@ def _declare(lib: C.CDLL) -> None:
         "snk_comm_create_rccl": (C.c_int, [vp, vp, u32, u32, P(vp), cp, sz]),
         "snk_comm_from_nccl": (C.c_int, [vp, vp, u32, u32, P(vp), cp, sz]),
         "snk_comm_create_local": (C.c_int, [u32, P(vp), cp, sz]),
+        "snk_comm_create_callbacks": (C.c_int, [u32, u32, COMM_A2A, COMM_GATHER, vp, P(vp), cp, sz]),
+        "snk_comm_selftest": (C.c_int, [vp, u64, u32, u32, cp, sz]),
         "snk_comm_destroy": (None, [vp]),
         "snk_comm_abort": (None, [vp]),
         "snk_comm_rank": (u32, [vp]),

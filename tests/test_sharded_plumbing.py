@@ -195,6 +195,93 @@ def test_gloo_world2_exchange():
     assert all(ok for (_r, ok, _n) in res), res
 
 
+def _cb_worker(rank, world, port, q):
+    """The library's own exchange planning (snk_comm_selftest: histograms, ranged record exchange with the step's piece planner,
+    region-routed queries and answers, ragged all-gather) over gloo: the C++ code asks for its exchanges through callbacks."""
+    import ctypes as C
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from supernova_amd import lib as _lib
+    lib = _lib.load()
+
+    def view(ptr, nbytes):
+        return torch.from_numpy(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(max(int(nbytes), 1),)))[:int(nbytes)]
+
+    calls = {"a2a": 0, "gather": 0}
+
+    def a2a(_user, send, sbeg, scnt, recv, rbeg, rcnt, W):
+        try:
+            calls["a2a"] += 1
+            s_hi = max([sbeg[p] + scnt[p] for p in range(W)] + [0])
+            r_hi = max([rbeg[p] + rcnt[p] for p in range(W)] + [0])
+            s_t, r_t = view(send, s_hi), view(recv, r_hi)
+            if scnt[rank]:
+                r_t[rbeg[rank]:rbeg[rank] + rcnt[rank]].copy_(s_t[sbeg[rank]:sbeg[rank] + scnt[rank]])
+            ops = []
+            for p in range(W):
+                if p == rank:
+                    continue
+                if scnt[p]:
+                    ops.append(dist.P2POp(dist.isend, s_t[sbeg[p]:sbeg[p] + scnt[p]].clone(), p))
+                if rcnt[p]:
+                    ops.append(dist.P2POp(dist.irecv, r_t[rbeg[p]:rbeg[p] + rcnt[p]], p))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            return 0
+        except BaseException:      # a ctypes callback must not raise
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def gather(_user, mine, k, allp, W):
+        try:
+            calls["gather"] += 1
+            m = view(mine, 8 * k).view(torch.int64).clone()
+            outs = [torch.empty_like(m) for _ in range(W)]
+            dist.all_gather(outs, m)
+            dst = view(allp, 8 * k * W).view(torch.int64)
+            for p in range(W):
+                dst[p * k:(p + 1) * k].copy_(outs[p])
+            return 0
+        except BaseException:
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    cb_a, cb_g = _lib.COMM_A2A(a2a), _lib.COMM_GATHER(gather)
+    h = C.c_void_p()
+    err = C.create_string_buffer(512)
+    ok = lib.snk_comm_create_callbacks(rank, world, cb_a, cb_g, None, C.byref(h), err, 512) == 0
+    ok = ok and lib.snk_comm_kind(h) == b"callbacks" and lib.snk_comm_world(h) == world and lib.snk_comm_rank(h) == rank
+    detail = ""
+    for seed, nbl, R in ((1, 12, 4), (2, 7, 3), (3, 1, 1), (4, 64, 8)):
+        rc = lib.snk_comm_selftest(h, seed, nbl, R, err, 512)
+        if rc:
+            ok = False
+            detail = f"seed {seed}: check {rc}: {err.value.decode(errors='replace')}"
+            break
+    lib.snk_comm_destroy(h)
+    q.put((rank, ok and calls["a2a"] > 10 and calls["gather"] >= 4, detail))
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_library_exchange_planning():
+    """world_size 2 on CPU: libsnk's exchange patterns through a callbacks communicator carried by gloo."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_cb_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in ps:
+        p.join(timeout=60)
+    assert all(ok for (_r, ok, _d) in res), res
+
+
 def test_group_partition_balanced_and_contiguous():
     """C5 (per-barcode graphs) shards without a collective: contiguous group ranges balanced by read count."""
     from supernova_amd.grouped import partition_groups, read_slab
