@@ -177,8 +177,14 @@ __global__ void __launch_bounds__(BD, K == 48 ? 5 : 4) snk_msp_kernel(snk_msp_ar
                         w[6] |= n_kmers | (hasL << 7) | (hasR << 8);
                         w[7] = (uint32_t)mybc;
                         uint4* dst = a.records + at * 2;
+#ifdef SNK_MSP_NT
+                        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+                        __builtin_nontemporal_store((v4u){w[0], w[1], w[2], w[3]}, reinterpret_cast<v4u*>(dst));
+                        __builtin_nontemporal_store((v4u){w[4], w[5], w[6], w[7]}, reinterpret_cast<v4u*>(dst) + 1);
+#else
                         dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
                         dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+#endif
                     }
                 }
             }
