@@ -52,10 +52,11 @@ struct path_graph {            // device arrays
     const uint8_t* e_rc;                   // [E]
     const int32_t *to_off, *to_v, *to_e;   // [N+1], [E], [E]: in-edges of a vertex, AddEdge order (graph/DigraphTemplate.h:2572-2582)
     const int32_t *from_off, *from_v, *from_e;
-    const uint4* dslot;        // dictionary, 32 bytes per slot: {key lo lo32, lo hi32, hi lo32, hi hi32} {offset | rev << 31, unitig, 0, 0};
-                               //   key hi == ~0: empty (no canonical k-mer starts with 32 T); rev: the unitig holds the reverse complement of the
-                               //   canonical form.  One random access (one TLB entry, one sector pair) per probe.
+    const uint4* dslot;        // dictionary, 16 bytes per slot: {fingerprint lo32, hi32, offset | rev << 31, unitig}; fingerprint == ~0: empty;
+                               //   rev: the unitig holds the reverse complement of the canonical form.  A probe is one 16-byte access; a
+                               //   fingerprint match is VERIFIED against the unitig's bases (dict_find), so look-ups stay exact.
     uint64_t dcap;             // slots: 2.5 per k-mer, not a power of two
+    unsigned long long fp_mask; // all ones; SNK_PATH_FP_MASK (tests) narrows the fingerprint so that false matches happen and the verified path runs
 };
 
 template <int K>
@@ -77,30 +78,52 @@ __device__ __forceinline__ uint64_t dict_slot(snk_kmer c, uint64_t cap) {
     return __umul64hi(((uint64_t)h1 << 32) | h2, cap);          // multiply-shift range reduction
 }
 
-// ---- dictionary build: one thread per base position of the concatenated unitigs; a slot is claimed on a u32 lock word
+// 64-bit fingerprint of a canonical k-mer, independent of the slot hash; never all ones (that is the empty slot)
+__device__ __forceinline__ unsigned long long dict_fp(snk_kmer c) {
+    unsigned long long x = c.hi * 0x9E3779B97F4A7C15ull ^ (c.lo + 0xD1B54A32D192ED03ull);
+    x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32; x += c.lo * 0x94D049BB133111EBull; x ^= x >> 31;
+    return x == ~0ull ? 0x7FFFFFFFFFFFFFFFull : x;
+}
+// ---- dictionary build.  A thread takes DB_RUN consecutive base positions of the concatenated unitigs: the first k-mer is read
+// base by base, the following ones roll (one byte each).  A slot is claimed by a 64-bit compare-and-swap on its fingerprint word
+// (all ones = empty), the value follows with one 8-byte store; no lock array, nothing to clear but the slots.  Round 2 had
+// 32-byte slots holding the whole key (80 bytes per unitig k-mer with the lock word): 40 now, and the build went 25 -> ~15 ms
+// (it is bound by the random read-modify-write of one sector per k-mer).
+constexpr int DB_RUN = 16;
 template <int K>
 __global__ void __launch_bounds__(256) dict_build_kernel(const uint64_t* __restrict__ uoff, const uint8_t* __restrict__ ubases, uint64_t U, uint64_t total,
-                                                         uint32_t* __restrict__ lock, uint4* __restrict__ dslot, uint64_t dcap) {
-    const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= total) return;
-    uint64_t lo = 0, hi = U;                     // largest u with uoff[u] <= p
-    while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (uoff[mid] <= p) lo = mid; else hi = mid; }
-    const uint64_t o = p - uoff[lo], len = uoff[lo + 1] - uoff[lo];
-    if (o + K > len) return;
+                                                         uint4* __restrict__ dslot, uint64_t dcap, unsigned long long fp_mask) {
+    const uint64_t p0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * DB_RUN;
+    if (p0 >= total) return;
+    uint64_t lo = 0, hi = U;                     // largest u with uoff[u] <= p0
+    while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (uoff[mid] <= p0) lo = mid; else hi = mid; }
+    uint64_t ub = uoff[lo], ue = uoff[lo + 1];
     snk_kmer f;
     f.hi = 0; f.lo = 0;
-    for (int q = 0; q < K; ++q) f = snk_kmer_succ<K>(f, ubases[p + q] & 3u);
-    const snk_kmer r = snk_kmer_rc<K>(f);
-    const bool rev = snk_kmer_lt(r, f);
-    const snk_kmer c = rev ? r : f;
-    uint64_t s = dict_slot(c, dcap);
-    for (;;) {
-        if (atomicCAS(&lock[s], 0u, 1u) == 0u) {
-            dslot[2 * s] = make_uint4((uint32_t)c.lo, (uint32_t)(c.lo >> 32), (uint32_t)c.hi, (uint32_t)(c.hi >> 32));
-            dslot[2 * s + 1] = make_uint4((uint32_t)o | (rev ? 0x80000000u : 0u), (uint32_t)lo, 0u, 0u);
-            break;
+    bool have = false;                            // f = the k-mer that starts at p - 1
+    for (uint64_t p = p0; p < p0 + DB_RUN && p < total; ++p) {
+        while (p >= ue) { ++lo; ub = ue; ue = uoff[lo + 1]; have = false; }
+        if (p + K > ue) { have = false; continue; }                           // the last K-1 positions of a unitig start no k-mer
+        if (have) f = snk_kmer_succ<K>(f, ubases[p + K - 1] & 3u);
+        else {
+            f.hi = 0; f.lo = 0;
+            for (int q = 0; q < K; ++q) f = snk_kmer_succ<K>(f, ubases[p + q] & 3u);
+            have = true;
         }
-        if (++s == dcap) s = 0;
+        const snk_kmer r = snk_kmer_rc<K>(f);
+        const bool rev = snk_kmer_lt(r, f);
+        const snk_kmer c = rev ? r : f;
+        const unsigned long long fp = dict_fp(c) & fp_mask;
+        const uint64_t o = p - ub;
+        uint64_t s = dict_slot(c, dcap);
+        for (;;) {
+            unsigned long long* w = reinterpret_cast<unsigned long long*>(dslot + s);
+            if (atomicCAS(w, ~0ull, fp) == ~0ull) {
+                w[1] = (unsigned long long)((uint32_t)o | (rev ? 0x80000000u : 0u)) | ((unsigned long long)(uint32_t)lo << 32);
+                break;
+            }
+            if (++s == dcap) s = 0;
+        }
     }
 }
 // per-unitig record for the pather
@@ -313,23 +336,40 @@ struct path_args {
     uint64_t ub_cap;
 };
 
-// one dictionary look-up: canonical form, probe, the strand the read is on relative to the unitig
+// one dictionary look-up: canonical form, probe, the strand the read is on relative to the unitig.  A slot whose fingerprint
+// matches is a candidate: the pather's group checks the seed's K bases against the unitig with all its lanes (the lines the
+// exact-match extension reads next); should that ever fail -- 2^-64 per probe -- the read is redone with verify = true, where a
+// match is checked here, base by base, and a false one just continues the probe sequence.  Look-ups are exact either way.
 template <int K>
-__device__ __forceinline__ bool dict_find(const path_graph& G, const uint32_t* row, uint32_t pos, uint32_t* hu, uint32_t* ho, uint32_t* hrc) {
+__device__ __forceinline__ bool dict_find(const path_graph& G, const uint32_t* row, uint32_t pos, uint32_t* hu, uint32_t* ho, uint32_t* hrc, bool verify) {
     const snk_kmer f = kmer_at<K>(row, 20, pos);
     const snk_kmer rk = snk_kmer_rc<K>(f);
     const bool rrev = snk_kmer_lt(rk, f);
     const snk_kmer c = rrev ? rk : f;
+    const unsigned long long fp = dict_fp(c) & G.fp_mask;
     uint64_t s = dict_slot(c, G.dcap);
     for (;;) {
-        const uint4 k = G.dslot[2 * s];
-        if (k.w == 0xFFFFFFFFu && k.z == 0xFFFFFFFFu) return false;
-        if ((((uint64_t)k.w << 32) | k.z) == c.hi && (((uint64_t)k.y << 32) | k.x) == c.lo) {
-            const uint4 v = G.dslot[2 * s + 1];
-            *hu = v.y;
-            *ho = v.x & 0x7FFFFFFFu;
-            *hrc = (v.x >> 31) ^ (rrev ? 1u : 0u);       // read k-mer vs the unitig's k-mer: CF<K>::isRC, dna/CanonicalForm.h:85-91
-            return true;
+        const uint4 k = G.dslot[s];
+        const unsigned long long kf = ((unsigned long long)k.y << 32) | k.x;
+        if (kf == ~0ull) return false;
+        if (kf == fp) {
+            const uint32_t u = k.w, o = k.z & 0x7FFFFFFFu, urev = k.z >> 31;
+            if (!verify) {          // the caller checks the seed's bases itself (sixteen lanes, three bases each)
+                *hu = u; *ho = o; *hrc = urev ^ (rrev ? 1u : 0u);
+                return true;
+            }
+            const uint4 ui = G.uinfo[2 * (uint64_t)u];
+            const uint8_t* ub = G.ubases + (((uint64_t)ui.y << 32) | ui.x) + o;
+            snk_kmer g;
+            g.hi = 0; g.lo = 0;
+            for (int q = 0; q < K; ++q) g = snk_kmer_succ<K>(g, ub[q] & 3u);
+            const snk_kmer cu = urev ? snk_kmer_rc<K>(g) : g;         // canonical form of the unitig's k-mer
+            if (snk_kmer_eq(cu, c)) {
+                *hu = u;
+                *ho = o;
+                *hrc = urev ^ (rrev ? 1u : 0u);       // read k-mer vs the unitig's k-mer: CF<K>::isRC, dna/CanonicalForm.h:85-91
+                return true;
+            }
         }
         if (++s == G.dcap) s = 0;
     }
@@ -374,28 +414,40 @@ __global__ void __launch_bounds__(256, SECOND ? 4 : SNK_PATH_OCC) path_kernel(pa
             const uint32_t end = n - K + 1;
             uint32_t i = 0, gap = 0;
             bool wide = false;                // after a miss the next look-ups go 16 positions at a time
+            bool exact = false;               // a fingerprint match failed the base check once: this read verifies inside dict_find
             while (i < end) {
                 const uint32_t pos = i + sub;
                 bool hit = false;
                 uint32_t hu = 0, ho = 0, hrc = 0;
-                if (pos < end && (wide || sub == 0)) hit = dict_find<K>(G, row, pos, &hu, &ho, &hrc);
+                if (pos < end && (wide || sub == 0)) hit = dict_find<K>(G, row, pos, &hu, &ho, &hrc, exact);
                 const uint32_t hm = (uint32_t)(__ballot(hit) >> gsh) & 0xFFFFu;
                 if (!hm) {
                     const uint32_t step = !wide ? 1u : (end - i < 16u ? end - i : 16u);
                     gap += step; i += step; wide = true;
                     continue;
                 }
-                wide = false;
                 const int first = __ffs((int)hm) - 1;
-                gap += (uint32_t)first;
-                i += (uint32_t)first;
                 const uint32_t u = __shfl(hu, gsh + first), o0 = __shfl(ho, gsh + first), rc = __shfl(hrc, gsh + first);
                 const uint4 ui = G.uinfo[2 * (uint64_t)u];
                 const uint32_t sz = ui.z;
                 const uint8_t* ub = G.ubases + (((uint64_t)ui.y << 32) | ui.x);
-                // exact-match extension behind the seed (matchLen :549-558): 128 bases per step, eight per lane
-                uint32_t a0 = i + K, b0, off;
+                uint32_t b0, off;
                 if (!rc) { off = o0; b0 = o0 + K; } else { off = sz - o0; b0 = off; off -= K; }      // :726-729
+                if (!exact) {
+                    // the candidate's K bases against the read's, a few per lane
+                    bool okv = true;
+                    for (uint32_t j = (uint32_t)sub; j < (uint32_t)K; j += 16u) {
+                        const uint32_t eb = off + j;
+                        const uint32_t e1 = rc ? (uint32_t)(ub[sz - 1 - eb] ^ 3u) & 3u : (uint32_t)ub[eb] & 3u;
+                        if (read_base(row, i + (uint32_t)first + j) != e1) okv = false;
+                    }
+                    if ((uint32_t)(__ballot(!okv) >> gsh) & 0xFFFFu) { exact = true; continue; }       // redo this round with verified look-ups
+                }
+                wide = false;
+                gap += (uint32_t)first;
+                i += (uint32_t)first;
+                // exact-match extension behind the seed (matchLen :549-558): 128 bases per step, eight per lane
+                uint32_t a0 = i + K;
                 uint32_t len = 1;
                 for (;;) {
                     uint32_t cnt = 0;
@@ -662,29 +714,28 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
     const uint64_t nk = total_bases >= U * (uint64_t)(K - 1) ? total_bases - U * (uint64_t)(K - 1) : 0;
     const uint64_t cap = ((2 * nk + nk / 2 + 1024) + 63) & ~63ull;        // load 0.4: the chain of dependent probes is what a read waits for
     {
-        // the dictionary is the one allocation of this path that grows with the GRAPH, not with the reads: 2.5 slots of 32 bytes
-        // per unitig k-mer (+ 4 transient bytes per slot).  Say so before asking for it: a human-size graph (3-4 G k-mers) wants
-        // ~300 GB and does not fit one device -- path such a graph per unitig range, in passes.
+        // the dictionary is the one allocation of this path that grows with the GRAPH, not with the reads: 2.5 slots of 16 bytes
+        // per unitig k-mer.  Say so before asking for it: a human-size graph (3-4 G k-mers) wants
+        // ~150 GB next to the reads -- path such a graph per unitig range, in passes.
         size_t fr = 0, tot = 0;
-        const uint64_t want = cap * 36ull;
+        const uint64_t want = cap * 16ull;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
             uint64_t cached = 0;
             for (auto& b : ctx->blocks) if (!b.used) cached += b.bytes;     // the arena's idle blocks can be handed back to the driver
             if (want > (uint64_t)fr + cached)
-                return snk_fail(SNK_E_NOMEM, err, errcap, "snk_dev_path_reads: the k-mer dictionary of this graph (%llu unitig k-mers, 2.5 slots of 32 B each) needs %.1f GB, "
+                return snk_fail(SNK_E_NOMEM, err, errcap, "snk_dev_path_reads: the k-mer dictionary of this graph (%llu unitig k-mers, 2.5 slots of 16 B each) needs %.1f GB, "
                                 "%.1f GB of HBM are free; path the reads against ranges of the unitigs instead", (unsigned long long)nk, want / 1e9, (fr + cached) / 1e9);
         }
     }
-    uint32_t* lock;
     uint4* dslot;
-    if ((rc = dev(ctx, cap, &lock, err, errcap)) || (rc = dev(ctx, 2 * cap, &dslot, err, errcap))) return rc;
-    SNK_HIP_TRY(hipMemsetAsync(lock, 0, cap * 4, st));
-    SNK_HIP_TRY(hipMemsetAsync(dslot, 0xFF, cap * 32, st));
-    if (total_bases) hipLaunchKernelGGL((dict_build_kernel<K>), dim3((unsigned)((total_bases + 255) / 256)), dim3(256), 0, st, d_uoff, d_ubases, U, total_bases, lock, dslot, cap);
+    unsigned long long fp_mask = ~0ull;
+    if (const char* e = getenv("SNK_PATH_FP_MASK")) if (*e) { fp_mask = strtoull(e, nullptr, 0); if (fp_mask == 0 || fp_mask == ~0ull) fp_mask = ~0ull; else fp_mask &= 0x7FFFFFFFFFFFFFFFull; }
+    if ((rc = dev(ctx, cap, &dslot, err, errcap))) return rc;
+    SNK_HIP_TRY(hipMemsetAsync(dslot, 0xFF, cap * 16, st));
+    if (total_bases) hipLaunchKernelGGL((dict_build_kernel<K>), dim3((unsigned)(((total_bases + DB_RUN - 1) / DB_RUN + 255) / 256)), dim3(256), 0, st, d_uoff, d_ubases, U, total_bases, dslot, cap, fp_mask);
     SNK_HIP_TRY(hipGetLastError());
-    SNK_HIP_TRY(snk_sync(st));            // drop[] has been copied; the lock words are dead
-    snk_ctx_release_block(ctx, lock);
-    G.dslot = dslot; G.dcap = cap;
+    SNK_HIP_TRY(snk_sync(st));            // drop[] has been copied
+    G.dslot = dslot; G.dcap = cap; G.fp_mask = fp_mask;
     SNK_HIP_TRY(hipEventRecord(e1, st));
     // ---- the reads
     a.rows = (const uint32_t*)in->rows; a.row_words = in->row_words; a.read_len = in->read_len;

@@ -653,6 +653,20 @@ def test_read_paths_full_capacity_pass(engine, monkeypatch):
     assert np.array_equal(info["dups"]["dup"], c.exp_dup)
 
 
+@pytest.mark.parametrize("mask", ["0xFF", "0x3"])
+def test_read_paths_with_colliding_fingerprints(engine, monkeypatch, mask):
+    """The dictionary keeps a 64-bit fingerprint per k-mer (16-byte slots) and the pather checks a match against the unitig's
+    bases.  SNK_PATH_FP_MASK narrows the fingerprint to 8 / 2 bits: nearly every probe chain now holds false matches, the reads fall
+    back to the verified look-up -- and the paths are still the reference's, bit for bit."""
+    monkeypatch.setenv("SNK_PATH_FP_MASK", mask)
+    for name in ("adversarial", "synth_20k_err"):
+        c = goldens.load(name)
+        rows, quals, bc, lens = _to_dev(c)
+        res = engine.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, ign_bc_below=c.ign_bc_below)
+        off, ne, edges, info = res.path_reads(rows, c.read_len, quals, lens=lens)
+        assert np.array_equal(ne.astype(np.int64), c.exp_path_n) and np.array_equal(edges, c.exp_path_edges) and np.array_equal(off, c.exp_path_off)
+
+
 @pytest.mark.parametrize("name", ["synth_2k_err", "adversarial", "synth_4k_dups"])
 def test_unitig_barcode_lists(engine, graph_stage, name):
     """The rest of f4: per-unitig barcode lists out of the pather's exact-match parts, against the plain-Python restatement of
