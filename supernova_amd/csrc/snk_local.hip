@@ -102,7 +102,8 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
                                                      uint32_t do_prune, uint8_t* __restrict__ ctx_out,
                                                      uint32_t* __restrict__ count_out, uint8_t* __restrict__ pend_out,
                                                      uint32_t* __restrict__ nbr_out, uint32_t* __restrict__ nbnd,
-                                                     uint32_t* __restrict__ biglist, uint32_t* __restrict__ nbig) {
+                                                     uint32_t* __restrict__ biglist, uint32_t* __restrict__ nbig,
+                                                     unsigned long long* __restrict__ gindex, uint64_t gmask) {
     constexpr int HT = CAP <= 256 ? 512 : 4096;
     // at K=48 without groups only the top 32 bits of the low key word are sequence (LDS per chunk = waves per CU)
     typedef typename std::conditional<(K <= 48 && !GR), uint32_t, uint64_t>::type klo_w;
@@ -279,7 +280,25 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
         count_out[gi] = (uint32_t)(v >> 8);
         nbr_out[2 * gi + 0] = nb0;
         nbr_out[2 * gi + 1] = nb1;
-        if (pm) ++mybnd;
+        if (pm) {
+            ++mybnd;
+            if (gindex) {
+                // boundary k-mers enter the HBM index right here (round 2: a separate pass over all pend bytes and keys, 2.2 ms);
+                // the index was sized from the previous call's boundary count -- the host falls back to the separate pass if it is too full
+                snk_kmer kk;
+                kk.hi = khi[i];
+                kk.lo = (uint64_t)klo[i] << KLS;
+                uint32_t h1, h2;
+                snk_kmer_hash2(kk, &h1, &h2);
+                uint64_t slot = (((uint64_t)h1 << 32) | h2) & gmask;
+                const unsigned long long ent = ((unsigned long long)h1 << 32) | (unsigned long long)(gi + 1);
+                for (uint32_t tries = 0; tries < 4096; ++tries) {
+                    const unsigned long long old = atomicCAS(&gindex[slot], 0ull, ent);
+                    if (old == 0ull) break;
+                    slot = (slot + 1) & gmask;
+                }
+            }
+        }
     }
     snk_wave_add(&bcnt, mybnd);
     __syncthreads();
@@ -292,19 +311,20 @@ __global__ void __launch_bounds__(T) bl_prune_kernel(const uint4* __restrict__ d
                                                      uint32_t do_prune, uint8_t* __restrict__ ctx_out,
                                                      uint32_t* __restrict__ count_out, uint8_t* __restrict__ pend_out,
                                                      uint32_t* __restrict__ nbr_out, uint32_t* __restrict__ nbnd,
-                                                     uint32_t* __restrict__ biglist, uint32_t* __restrict__ nbig, const uint32_t* __restrict__ n_dev) {
+                                                     uint32_t* __restrict__ biglist, uint32_t* __restrict__ nbig, const uint32_t* __restrict__ n_dev,
+                                                     unsigned long long* __restrict__ gindex, uint64_t gmask) {
     if (BIG && n_dev) {
         // the list's length is still on the device (no read-back between the two prune launches): a fixed grid strides over it
         const uint32_t nb = *n_dev;
         for (uint32_t w = blockIdx.x; w < nb; w += gridDim.x)
-            bl_prune_chunk<K, CAP, T, BIG, GR>(biglist_in[w], desc, NB, sh, keys, vals, do_prune, ctx_out, count_out, pend_out, nbr_out, nbnd, biglist, nbig);
+            bl_prune_chunk<K, CAP, T, BIG, GR>(biglist_in[w], desc, NB, sh, keys, vals, do_prune, ctx_out, count_out, pend_out, nbr_out, nbnd, biglist, nbig, gindex, gmask);
         return;
     }
     for (uint32_t r = 0; r < cpw; ++r) {
         const uint32_t w = blockIdx.x * cpw + r;
         if (w >= nchunks) return;
         bl_prune_chunk<K, CAP, T, BIG, GR>(BIG ? biglist_in[w] : w, desc, NB, sh, keys, vals, do_prune, ctx_out, count_out, pend_out, nbr_out,
-                                       nbnd, biglist, nbig);
+                                       nbnd, biglist, nbig, gindex, gmask);
     }
 }
 
@@ -847,9 +867,20 @@ static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* er
     sh.premote = B->premote;
     const uint32_t NBh = B->premote ? B->NB_total : tab->NB;      // bucket count of the minimiser hash
     const uint32_t cpw = 1;
+    // boundary index, filled by the prune kernel itself: sized from what the previous call of this context found for a table of
+    // this size (first call: n / 5); too small = too full -> the separate build pass below redoes it with the exact size
+    uint64_t tg0 = 0;
+    unsigned long long* index0 = nullptr;
+    if (snk_env_u32("SNK_BL_INDEX_FUSED", 1)) {
+        const uint64_t guess = (ctx->last_bnd_n == n && ctx->last_bnd) ? ctx->last_bnd + ctx->last_bnd / 8 : n / 5;
+        tg0 = 1024;
+        while (tg0 < 2 * guess) tg0 <<= 1;
+        G_ALLOC(index0, unsigned long long, tg0);
+        SNK_HIP_TRY(hipMemsetAsync(index0, 0, tg0 * 8, st));
+    }
     hipLaunchKernelGGL((bl_prune_kernel<K, SCAP, ST, false, GR>), dim3((nchunks + cpw - 1) / cpw), dim3(ST), 0, st, (const uint4*)B->desc, NBh, sh,
                        (const uint32_t*)nullptr, nchunks, cpw, tab->keys, tab->vals, B->do_prune, B->ctx, B->counts, B->pend, B->nbr, nbnd,
-                       B->biglist, ctr, (const uint32_t*)nullptr);
+                       B->biglist, ctr, (const uint32_t*)nullptr, index0, tg0 - 1);
     SNK_HIP_TRY(hipGetLastError());
     // the chunks that did not fit the one-wave variant (split sub-passes near the table's capacity): their number stays on the
     // device until the read-back below -- the big variant runs a fixed grid that strides over the list
@@ -857,7 +888,7 @@ static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* er
     SNK_HIP_TRY(hipMemcpyAsync(ctr + 1, ctr, 4, hipMemcpyDeviceToDevice, st));       // (ctr[0] is the small kernel's list cursor)
     hipLaunchKernelGGL((bl_prune_kernel<K, BCAP, BT, true, GR>), dim3(2048), dim3(BT), 0, st, (const uint4*)B->desc, NBh, sh,
                        (const uint32_t*)B->biglist, 0u, 1u, tab->keys, tab->vals, B->do_prune, B->ctx, B->counts, B->pend, B->nbr,
-                       nbnd, B->biglist, ctr + 2, (const uint32_t*)(ctr + 1));
+                       nbnd, B->biglist, ctr + 2, (const uint32_t*)(ctr + 1), index0, tg0 - 1);
     SNK_HIP_TRY(hipGetLastError());
     unsigned long long* d_sum;
     G_ALLOC(d_sum, unsigned long long, 2);
@@ -876,13 +907,19 @@ static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* er
     SNK_HIP_TRY(snk_sync(st));
     B->nbig = h_nbig;
     B->n_boundary = h_bnd;
+    ctx->last_bnd = h_bnd; ctx->last_bnd_n = n;
     uint64_t tg = 1024;
     while (tg < 2 * h_bnd) tg <<= 1;
-    G_ALLOC(B->index, unsigned long long, tg);
+    const bool fused_ok = index0 && h_bnd * 4 <= tg0 * 3;          // load <= 0.75: every insert found a slot long before its probe limit
+    if (fused_ok) { B->index = index0; tg = tg0; }
+    else {
+        if (index0) snk_ctx_release_block(ctx, index0);
+        G_ALLOC(B->index, unsigned long long, tg);
+        SNK_HIP_TRY(hipMemsetAsync(B->index, 0, tg * 8, st));
+    }
     B->index_mask = tg - 1;
-    SNK_HIP_TRY(hipMemsetAsync(B->index, 0, tg * 8, st));
     if (h_bnd) {
-        hipLaunchKernelGGL(bl_index_build_kernel, dim3(nblk(n)), dim3(TB), 0, st, tab->keys, B->pend, n, B->index, tg - 1);
+        if (!fused_ok) hipLaunchKernelGGL(bl_index_build_kernel, dim3(nblk(n)), dim3(TB), 0, st, tab->keys, B->pend, n, B->index, tg - 1);
         hipLaunchKernelGGL((bl_resolve_kernel<K, GR>), dim3((unsigned)((n + 8 * TB - 1) / (8 * TB))), dim3(TB), 0, st, tab->keys, B->pend, n,
                            B->index, tg - 1, B->do_prune, B->ctx, B->rq, (const uint8_t*)B->premote);
     }
