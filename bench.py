@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=float, default=1e6, help="reads of the workload timed on the host cores")
     ap.add_argument("--cpu-threads", default="16,64,256", help="thread counts the CPU baseline is timed at (the best is reported)")
+    ap.add_argument("--cpu-sample-10m", action="store_true",
+                    help="also time the reference on BASELINE config 1 (10 M reads, SURVEY 8(d)(i)) at the best thread count of the sweep: "
+                         "minutes of host time, so not part of the default run (cpu_baseline.sample_10m)")
     ap.add_argument("--sharded", action="store_true", help="force the sharded (multi-GPU) code path even with one rank")
     ap.add_argument("--sorted-table", action="store_true",
                     help="also sort the retained k-mer table by key (+~40 ms; the reference's dictionary is an unordered hash set, "
@@ -67,7 +70,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(sp_full, K: int, sample_reads: int, threads=(16, 64, 256)):
+def cpu_baseline(sp_full, K: int, sample_reads: int, threads=(16, 64, 256), big: bool = False):
     """Reference CPU path on a bounded sample (first `sample_reads` reads of a data set with the same coverage)."""
     import numpy as np
     from supernova_amd import synth
@@ -94,10 +97,23 @@ def cpu_baseline(sp_full, K: int, sample_reads: int, threads=(16, 64, 256)):
                 if best is None or secs < best[1]:
                     best = (t, secs, inst)
         t, secs, inst = best
-        return {"value": inst / secs / 1e9, "unit": "Gk-mers/s", "cores": t, "kind": "reference",
-                "sample": f"{n} reads x {sp.read_len} bp of the same synthetic model ({inst} k-mer instances), "
-                          f"buildReadQGraph48 (count+unitigs+HBV, no read pathing); best of "
-                          + ", ".join(f"{tt} threads {ss:.2f} s" for tt, ss in runs) + f" on a {cores}-thread host"}
+        out = {"value": inst / secs / 1e9, "unit": "Gk-mers/s", "cores": t, "kind": "reference",
+               "sample": f"{n} reads x {sp.read_len} bp of the same synthetic model ({inst} k-mer instances), "
+                         f"buildReadQGraph48 (count+unitigs+HBV, no read pathing); best of "
+                         + ", ".join(f"{tt} threads {ss:.2f} s" for tt, ss in runs) + f" on a {cores}-thread host"}
+        if big:
+            # BASELINE config 1 in time mode at the sweep's best thread count (the MapReduce engine's passes grow with the input)
+            nb = 10_000_000
+            spb = synth.synth_params(nb, seed=0x5EED0001, error_free=(sp_full.sub_ppm == 0))
+            rb, qb, bb = synth.synth_host(spb)
+            ab = synth.codes_to_ascii(synth.unpack_rows(rb, spb.read_len))
+            with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as td:
+                refio.write_snkrd(Path(td) / "in.snkrd", np.full(nb, spb.read_len), ab, qb, bb)
+                o = refio.run_ref(Path(td) / "in.snkrd", Path(td) / "out", threads=t, mode="time", timeout=7200)
+                m = re.search(r"SNREF_TIME seconds=([0-9.]+) threads=(\d+) reads=(\d+) kmer_instances=(\d+)", o)
+                out["sample_10m"] = {"reads": nb, "seconds": float(m.group(1)), "threads": t, "kmer_instances": int(m.group(4)),
+                                     "value": int(m.group(4)) / float(m.group(1)) / 1e9, "unit": "Gk-mers/s"}
+        return out
     sys.path.insert(0, str(ROOT / "tests"))
     import oracle_lib
     n = min(n, 200_000)
@@ -357,7 +373,7 @@ def main():
                     out["config"]["f3_ingest"] = {"failed": str(ex)}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(sp, K, args.cpu_sample, tuple(int(x) for x in args.cpu_threads.split(",")))
+                out["cpu_baseline"] = cpu_baseline(sp, K, args.cpu_sample, tuple(int(x) for x in args.cpu_threads.split(",")), big=args.cpu_sample_10m)
             except Exception as ex:  # the baseline is a report, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "Gk-mers/s", "cores": os.cpu_count(), "kind": "reference",
                                        "sample": f"failed: {ex}"}

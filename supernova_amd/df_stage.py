@@ -1,10 +1,12 @@
 """ASSEMBLER_DF stage adapter (mro/_assembler_stages.mro:24-39) with the graph built on the MI355X.
 
 Mirror of the reference's stage code mro/stages/denovo/df/__init__.py (Python 2; not importable here):
-  split   :8-12     one chunk; the reference reserves 2048 GB / 28 threads for the CPU dictionary -- the GPU path
-                    needs host memory only for the stage inputs
-  main    :81-173   filename-head check (:84-88), DF argv (:123-139), exit-code -> message mapping (:63-79),
-                    *.mm files moved into stats/ (:172-173)
+  split   :8-12     one chunk; the reference reserves 2048 GB / 28 threads for the CPU dictionary -- here 256 GB
+                    (deliberate: the stage inputs in host memory; the dictionary lives in HBM).  $SNK_DF_MEM_GB overrides it,
+                    e.g. 2048 when the stock DF that follows needs its usual reservation
+  main    :81-173   filename-head check (:84-88), DF argv (:123-139), alerts.list + the alarm / Martian::exit (code 185)
+                    relay (:139-166, tenkit/supernova/alerts.py), exit-code -> message mapping (:63-79), *.mm files moved
+                    into stats/ (:172-173)
   join    :14-15
 What changes: when `mspedges` is not supplied by an upstream `_ASM_SN`, this stage computes the unitigs itself
 (reads.fastb/.qualp/.bci -> libsnk -> asm_graph.bv) and hands them to the stock `DF` binary through `MSPEDGES=`
@@ -39,7 +41,7 @@ def _set(rec, name, value):
 
 
 def split(args):
-    return {"chunks": [{"__mem_gb": 256, "__threads": 28, "__special": "asmlarge"}]}
+    return {"chunks": [{"__mem_gb": int(os.environ.get("SNK_DF_MEM_GB", "256")), "__threads": 28, "__special": "asmlarge"}]}
 
 
 def join(args, outs, chunk_defs, chunk_outs):
@@ -63,6 +65,135 @@ def process_return_code(returncode: int):
         msg = ("Supernova terminated because of insufficient memory. The stage _stdout file may contain additional "
                "useful information, e.g., whether any competing processes were running.")
     return msg
+
+
+# ---- alerts: the C++ side of DF reports through files, the stage code turns them into Martian calls
+# (tenkit/lib/python/tenkit/supernova/alerts.py; C++: lib/assembly/src/10X/Martian.h:12-111).  Martian::exit(msg) writes
+# {"exit": [msg], ...} to <out>/martian_alerts.json and leaves with code 185 (cMagic); alarms go to the same file and to
+# <out>/alerts_rollup.txt.  The stage writes <out>/alerts.list first (thresholds DF checks its metrics against).
+class StageExit(Exception):
+    """martian.exit(msg): the stage ends with a message for the user (not a stack trace)."""
+
+
+class _PrintHandlers:
+    """What `import martian` offers inside a Martian py stage; used when that module is not there (tests, plain runs)."""
+
+    def __init__(self):
+        self.posted = []
+
+    def alarm(self, m):
+        self.posted.append(("alarm", m)); print("[alarm]", m)
+
+    def log_info(self, m):
+        self.posted.append(("log_info", m)); print("[log_info]", m)
+
+    def log_warn(self, m):
+        self.posted.append(("log_warn", m)); print("[log_warn]", m)
+
+    def throw(self, m):
+        raise Exception(m)
+
+    def exit(self, m):
+        raise StageExit(m)
+
+
+def _martian_handlers():
+    try:
+        import martian  # the real adapter, inside a Martian run
+        if hasattr(martian, "exit") and hasattr(martian, "alarm"):
+            return martian
+    except Exception:
+        pass
+    return _PrintHandlers()
+
+
+def load_alerts(alarms_json: str) -> dict:
+    """alerts.py:31-42 (check_alert :17-29): {stage: [{action, metric, compare, threshold, message}, ...]}."""
+    import json
+    alerts = json.loads(Path(alarms_json).read_text())
+    for stage, lst in alerts.items():
+        for a in lst:
+            for key in ("action", "metric", "compare", "threshold", "message"):
+                if key not in a:
+                    raise Exception("incorrectly formatted alert, see stdout.")
+            if a["compare"] not in ("<", ">"):
+                raise Exception("invalid value for compare in alert")
+            if type(a["threshold"]) not in (int, float):
+                raise Exception("%s: invalid type for threshold" % type(a["threshold"]))
+    return alerts
+
+
+def write_stage_alerts(stage: str, path: str, alarms_json: str, alerts_file: str = "alerts.list") -> str:
+    """alerts.py:44-61: the stage's alerts as the line-oriented list the C++ side reads."""
+    alerts = load_alerts(alarms_json)
+    os.makedirs(path, exist_ok=True)
+    if stage not in alerts:
+        raise Exception("No alerts found for stage %s" % stage)
+    out = os.path.join(path, alerts_file)
+    with open(out, "w") as f:
+        for a in alerts[stage]:
+            f.write("#\n" + a["metric"] + "\n" + str(a["threshold"]) + "\n" + a["compare"] + "\n" + a["action"] + "\n" + a["message"] + "\n")
+    return out
+
+
+def find_alarms_json():
+    """$SNK_ALARMS_JSON, or the pipeline's own tenkit/alarms/alarms-supernova.json when tenkit is importable."""
+    p = os.environ.get("SNK_ALARMS_JSON")
+    if p:
+        return p
+    try:
+        import tenkit.constants as tc
+        q = os.path.join(tc.ALARMS_LOCATION, "alarms-supernova.json")
+        return q if os.path.exists(q) else None
+    except Exception:
+        return None
+
+
+class SupernovaAlarms:
+    """alerts.py:82-161."""
+    SN_STAGE_ALARMS, SN_ROLLUP_ALARMS = "martian_alerts.json", "alerts_rollup.txt"
+    SN_ALARM_HEAD = "The following warning(s) were issued prior to encountering an error:"
+    SN_UNEXPECTED_TEXT = "An unexpected error has occurred."
+
+    def __init__(self, base_dir, handlers=None, delete=True):
+        self._alarms_file = os.path.join(base_dir, self.SN_STAGE_ALARMS)
+        self._rollup_file = os.path.join(base_dir, self.SN_ROLLUP_ALARMS)
+        self.h = handlers or _martian_handlers()
+        self._posted = False
+        if delete:
+            self.check_delete()
+
+    def exit(self, msg=None):
+        full = self.SN_UNEXPECTED_TEXT if msg is None else msg
+        if os.path.exists(self._rollup_file):
+            issued = list(set(open(self._rollup_file).read().split("\n")))      # a restarted stage repeats its alarms
+            full += "\n\n" + self.SN_ALARM_HEAD + "\n\n" + "\n".join(issued) + "\n"
+        self.h.exit(full)
+
+    def post(self):
+        import json
+        self._posted = True
+        if not os.path.exists(self._alarms_file):
+            return
+        alerts = json.loads(open(self._alarms_file).read())
+        handlers = {"alarm": self.h.alarm, "log_info": self.h.log_info, "log_warn": self.h.log_warn, "throw": self.h.throw}
+        meta, exit_str = [], ""
+        for k, v in alerts.items():
+            if k == "exit":
+                exit_str = ";".join(v)
+            elif k not in handlers:
+                meta.append("unknown key {} in {} (BUG)".format(k, self._alarms_file))
+            else:
+                for post in v:
+                    handlers[k](post)
+        for m in meta:
+            self.h.alarm(m)
+        if exit_str:
+            self.exit(exit_str)
+
+    def check_delete(self):
+        if os.path.isfile(self._alarms_file):
+            os.unlink(self._alarms_file)
 
 
 def build_df_command(args, out_dir: str, mspedges: str | None) -> list[str]:
@@ -176,7 +307,7 @@ def compute_mspedges(args, out_dir: str, device: int = 0, bc_start: int | None =
     return path
 
 
-def main(args, outs, run_df: bool = True):
+def main(args, outs, run_df: bool = True, handlers=None):
     print("__threads=", _get(args, "__threads"))
     print("__mem_gb=", _get(args, "__mem_gb"))
     h1 = check_exclude(_get(args, "reads"), ".fastb")
@@ -194,10 +325,18 @@ def main(args, outs, run_df: bool = True):
         df_bin = os.environ.get("SNK_DF_BIN") or shutil.which("DF")
         if df_bin is None:
             raise RuntimeError("the stock DF binary is not on PATH (set SNK_DF_BIN); unitigs are in " + mspedges)
+        # alerts.list for the C++ side, then DF; its alarms / Martian::exit (exit code 185) come back through files
+        # (df/__init__.py:139-166)
+        aj = find_alarms_json()
+        if aj:
+            write_stage_alerts("df", out_dir, aj)
+        bell = SupernovaAlarms(out_dir, handlers=handlers)
         try:
             subprocess.check_call([df_bin] + cmd[1:])
         except subprocess.CalledProcessError as e:
-            raise RuntimeError(process_return_code(e.returncode) or f"DF failed with exit code {e.returncode}")
+            bell.post()                                          # a Martian::exit of the C++ code leaves from here
+            bell.exit(process_return_code(e.returncode))         # anything else: signal / out of memory / unexpected
+        bell.post()
         for f in glob.glob("*.mm"):
             shutil.move(f, os.path.join(out_dir, "stats"))
     return cmd
