@@ -444,13 +444,18 @@ typedef struct snk_dev_paths {
     float dict_ms, path_ms;    /* HIP events: graph tables + packed unitigs + dictionary; pathing + gather */
     /* SNK_PATH_UNITIG_BCS (snk_dev_path_reads2): per unitig (device numbering) the sorted distinct barcodes > 0 of the reads that
      * have a k-mer on it -- the edge -> barcode sets of tada's MAIN_ASM_SN (lib/tada/src/cmd_main_asm.rs:91-151,
-     * debruijn.rs:115-131; the 20 000-entry cut of its shard-by-shard collection is not applied) */
+     * debruijn.rs:115-131), cut at 20 000 entries per unitig like cmd_main_asm.rs:115 -- the smallest ids are kept; the reference keeps
+     * what its shard order delivers first, which needs its shard layout: parity unpinned (Rust) */
     const void* unitig_bc_off; /* u64[n_unitigs + 1] */
     const void* unitig_bcs;    /* u32[n_unitig_bcs] */
     uint64_t n_unitig_bcs;
     float bcs_ms, reserved_f;  /* HIP events: key sort + run heads + per-unitig lists (SNK_PATH_UNITIG_BCS) */
 } snk_dev_paths;
 #define SNK_PATH_UNITIG_BCS 1u
+#define SNK_PATH_UNITIG_BCS_EXHAUSTIVE 2u   /* (with SNK_PATH_UNITIG_BCS) derive the lists the slow, literal way -- every k-mer of every barcoded
+                                               read looked up, barcodes_for_sedge (debruijn.rs:115-131) -- instead of from the path parts: a
+                                               second, independent derivation the tests compare the fast one with */
+#define SNK_PATH_UNITIG_BCS_NOCUT 4u        /* do not apply the 20 000-entry cut (cmd_main_asm.rs:115; here: a unitig keeps its 20 000 smallest ids) */
 int snk_dev_path_reads(snk_ctx* ctx, uint32_t K, const snk_dev_reads* in, uint64_t n_unitigs, const void* d_unitig_off, const void* d_unitig_bases,
                        const snk_hbv* h, snk_dev_paths* out, void* stream, char* err, size_t errcap);
 int snk_dev_path_reads2(snk_ctx* ctx, uint32_t K, const snk_dev_reads* in, uint64_t n_unitigs, const void* d_unitig_off, const void* d_unitig_bases,

@@ -92,6 +92,7 @@ int snk_ctx_alloc(snk_ctx* ctx, size_t bytes, void** out, char* err, size_t errc
     }
     if (best >= 0) {
         ctx->blocks[best].used = true;
+        ctx->blocks[best].serial = ++ctx->alloc_serial;
         ctx->total_alloc += ctx->blocks[best].bytes;
         if (ctx->total_alloc > ctx->peak_alloc) ctx->peak_alloc = ctx->total_alloc;
         *out = ctx->blocks[best].p;
@@ -106,7 +107,7 @@ int snk_ctx_alloc(snk_ctx* ctx, size_t bytes, void** out, char* err, size_t errc
     }
     if (e != hipSuccess)
         return snk_fail(SNK_E_NOMEM, err, errcap, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-    ctx->blocks.push_back({p, bytes, true});
+    ctx->blocks.push_back({p, bytes, true, ++ctx->alloc_serial});
     ctx->total_alloc += bytes;
     if (ctx->total_alloc > ctx->peak_alloc) ctx->peak_alloc = ctx->total_alloc;
     ctx->cached_bytes += bytes;
@@ -119,6 +120,14 @@ void snk_ctx_release_block(snk_ctx* ctx, const void* p) {
     if (!p) return;
     for (auto& b : ctx->blocks)
         if (b.p == p && b.used) { b.used = false; ctx->total_alloc -= b.bytes; return; }
+}
+void snk_ctx_release_since(snk_ctx* ctx, uint64_t mark, const void* const* keep, size_t n_keep) {
+    for (auto& b : ctx->blocks) {
+        if (!b.used || b.serial <= mark) continue;
+        bool kept = false;
+        for (size_t i = 0; i < n_keep; ++i) if (keep[i] == b.p) kept = true;
+        if (!kept) { b.used = false; ctx->total_alloc -= b.bytes; }
+    }
 }
 void snk_ctx_release_scratch(snk_ctx* ctx) {
     for (auto& b : ctx->blocks) b.used = false;

@@ -17,7 +17,8 @@ struct snk_ctx {
     size_t lds_per_block = 65536;
     // caching arena for call-scoped scratch: blocks are handed out by best fit, returned to the cache at the
     // start of the next top-level call (no hipFree/hipMalloc in steady state), released on destroy or OOM
-    struct block { void* p; size_t bytes; bool used; };
+    struct block { void* p; size_t bytes; bool used; uint64_t serial = 0; };
+    uint64_t alloc_serial = 0;   // blocks handed out so far (a call's internal scratch = the blocks with a larger serial than at its entry)
     std::vector<block> blocks;
     size_t total_alloc = 0;     // bytes handed out in the current call (minus blocks returned mid-call)
     size_t peak_alloc = 0;      // its maximum during the call
@@ -53,5 +54,7 @@ int snk_fail(int code, char* err, size_t errcap, const char* fmt, ...);
 int snk_ctx_alloc(snk_ctx* ctx, size_t bytes, void** out, char* err, size_t errcap);
 void snk_ctx_release_scratch(snk_ctx* ctx);   // return every block to the cache
 void snk_ctx_release_block(snk_ctx* ctx, const void* p);   // return one block to the cache (no-op for unknown pointers)
+// return every block handed out after `mark` (= ctx->alloc_serial at the call's entry) except the ones in keep[0..n_keep)
+void snk_ctx_release_since(snk_ctx* ctx, uint64_t mark, const void* const* keep, size_t n_keep);
 void snk_ctx_trim_cache(snk_ctx* ctx);        // hipFree every unused cached block
 void snk_shard_state_free(void* p);

@@ -171,8 +171,22 @@ __global__ void __launch_bounds__(256) dup_count_kernel(const uint8_t* __restric
 
 }  // namespace
 
+static int mark_dups_impl(snk_ctx* ctx, const snk_dev_reads* in, const snk_dev_paths* paths, snk_dev_dups* out, void* stream, char* err, size_t errcap);
+
 extern "C" int snk_dev_mark_dups(snk_ctx* ctx, const snk_dev_reads* in, const snk_dev_paths* paths, snk_dev_dups* out, void* stream, char* err, size_t errcap) {
     if (!ctx || !in || !paths || !out) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_mark_dups: NULL argument");
+    // sort keys, group heads, quality sums (~35 B per read + the sort's own scratch) go back to the arena with the call; the
+    // duplicate flags stay until the context's next snk_dev_count_graph / snk_shard_step
+    const uint64_t mark = ctx->alloc_serial;
+    const int rc = mark_dups_impl(ctx, in, paths, out, stream, err, errcap);
+    (void)hipStreamSynchronize(stream ? (hipStream_t)stream : ctx->stream);
+    const void* keep[1] = {out->dup};
+    snk_ctx_release_since(ctx, mark, keep, rc ? 0 : 1);
+    if (rc) memset(out, 0, sizeof *out);
+    return rc;
+}
+
+static int mark_dups_impl(snk_ctx* ctx, const snk_dev_reads* in, const snk_dev_paths* paths, snk_dev_dups* out, void* stream, char* err, size_t errcap) {
     const uint64_t n = in->n_reads;
     if (n != paths->n_reads) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_mark_dups: %llu reads, paths of %llu", (unsigned long long)n, (unsigned long long)paths->n_reads);
     if (n & 1ull) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_mark_dups: reads come in pairs (2q, 2q+1); got an odd number");

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <memory>
 #include <numeric>
 #include <thread>
 #include <vector>
@@ -53,10 +54,11 @@ struct host_io {
 
 int io_of(snk_ctx* ctx, host_io** out, char* err, size_t errcap) {
     if (!ctx->host_io) {
-        host_io* io = new host_io();
+        // built in a local owner and published only when every resource exists: a failed hipHostMalloc (192 MiB of page-locked
+        // memory) leaves the context without a half-made object (whose destructor frees what was made) and the next call retries
+        std::unique_ptr<host_io> own(new host_io());
+        host_io* io = own.get();
         io->device = ctx->device;
-        ctx->host_io = io;
-        ctx->host_io_free = [](void* p) { delete static_cast<host_io*>(p); };
         SNK_HIP_TRY(hipStreamCreateWithFlags(&io->copy, hipStreamNonBlocking));
         for (int b = 0; b < STAGE_BUFS; ++b) {
             SNK_HIP_TRY(hipHostMalloc(&io->pin[b], STAGE_BYTES, hipHostMallocDefault));
@@ -66,6 +68,8 @@ int io_of(snk_ctx* ctx, host_io** out, char* err, size_t errcap) {
             SNK_HIP_TRY(hipEventCreateWithFlags(&io->q_done[b], hipEventDisableTiming));
             SNK_HIP_TRY(hipEventCreateWithFlags(&io->q_up[b], hipEventDisableTiming));
         }
+        ctx->host_io = own.release();
+        ctx->host_io_free = [](void* p) { delete static_cast<host_io*>(p); };
     }
     *out = static_cast<host_io*>(ctx->host_io);
     return SNK_OK;
@@ -344,7 +348,19 @@ int snk_unitigs_to_host(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t U, co
     catch (...) { return snk_fail(SNK_E_INTERNAL, err, errcap, "unexpected exception"); }
 
 extern "C" int snk_count_graph(snk_ctx* ctx, const snk_reads* in, const snk_params* p, snk_result* out, char* err, size_t errcap) {
-    SNK_GUARD(return count_graph_impl(ctx, in, p, out, err, errcap);)
+    // every error exit of the implementation leaves through here: uploads / kernels it queued are waited for (the caller may free
+    // its input right after, and the next call reuses the context's staging buffers) and what it malloc'ed into *out is released
+    int rc;
+    try { rc = count_graph_impl(ctx, in, p, out, err, errcap); }
+    catch (const std::bad_alloc&) { rc = snk_fail(SNK_E_NOMEM, err, errcap, "host allocation failed"); }
+    catch (const std::exception& ex) { rc = snk_fail(SNK_E_INTERNAL, err, errcap, "%s", ex.what()); }
+    catch (...) { rc = snk_fail(SNK_E_INTERNAL, err, errcap, "unexpected exception"); }
+    if (rc && ctx) {
+        (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->host_io) (void)hipStreamSynchronize(static_cast<host_io*>(ctx->host_io)->copy);
+        if (out) snk_free(out);
+    }
+    return rc;
 }
 
 extern "C" int snk_host_alloc_pinned(size_t bytes, void** out, char* err, size_t errcap) {

@@ -59,7 +59,9 @@ __global__ void __launch_bounds__(256) bc_ids_kernel(const uint8_t* __restrict__
     if (p < stride && f[p] == '-') {            // gem group: decimal u8 up to the next '-', ',' or the end
         uint32_t v = 0, nd = 0;
         bool bad = false;
-        for (++p; p < stride; ++p) {
+        ++p;
+        if (p < stride && f[p] == '+') ++p;        // u8::from_str takes one leading '+' (core::num: "+1" parses, "-1" and " 1" do not)
+        for (; p < stride; ++p) {
             const uint8_t c = f[p];
             if (c == 0 || c == ',' || c == '-' || c == '\n') break;
             if (c < '0' || c > '9') bad = true;

@@ -654,6 +654,50 @@ __global__ void __launch_bounds__(256) ubc_scatter_kernel(const unsigned long lo
     atomicAdd((unsigned long long*)&per_unitig[k[i] >> 32], 1ull);
 }
 
+// ---- second, independent derivation of the (unitig, barcode) keys (SNK_PATH_UNITIG_BCS_EXHAUSTIVE; a cross-check, ~50x the
+// work): EVERY k-mer of every barcoded read is looked up (verified look-ups), which is literally what tada's per-shard code does
+// before MAIN_ASM_SN unions the lists (barcodes_for_sedge, lib/tada/src/debruijn.rs:115-131).  One thread per read; a key is
+// emitted whenever the unitig differs from the read's previous hit.
+template <int K>
+__global__ void __launch_bounds__(256) ubc_exhaustive_kernel(path_graph G, const uint32_t* __restrict__ rows, uint32_t row_words, uint32_t read_len,
+                                                             const uint16_t* __restrict__ lens, const int32_t* __restrict__ bc, uint64_t n,
+                                                             unsigned long long* __restrict__ keys, uint64_t cap, unsigned long long* __restrict__ cursor) {
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const int32_t b = bc[r];
+    if (b <= 0) return;
+    uint32_t row[20];
+    for (uint32_t q = 0; q < 20; ++q) row[q] = q < row_words ? rows[r * row_words + q] : 0u;
+    uint32_t len = lens ? lens[r] : read_len;
+    if (len > read_len) len = read_len;
+    if (len < (uint32_t)K) return;
+    uint32_t last = 0xFFFFFFFFu;
+    for (uint32_t pos = 0; pos + K <= len; ++pos) {
+        uint32_t hu, ho, hrc;
+        if (!dict_find<K>(G, row, pos, &hu, &ho, &hrc, true)) continue;
+        if (hu == last) continue;
+        last = hu;
+        const unsigned long long at = atomicAdd(cursor, 1ull);
+        if (at < cap) keys[at] = ((unsigned long long)hu << 32) | (uint32_t)b;
+    }
+}
+// the reference stops adding barcodes to an edge once its list holds 20 000 entries (cmd_main_asm.rs:115): lengths under the cut
+__global__ void __launch_bounds__(256) ubc_cut_len_kernel(const uint64_t* __restrict__ off, uint64_t U, uint64_t cut, uint64_t* __restrict__ len_out, uint32_t* __restrict__ any) {
+    const uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u > U) return;
+    if (u == U) { len_out[u] = 0; return; }
+    const uint64_t l = off[u + 1] - off[u];
+    len_out[u] = l < cut ? l : cut;
+    if (l > cut) atomicOr(any, 1u);
+}
+__global__ void __launch_bounds__(64) ubc_cut_copy_kernel(const uint64_t* __restrict__ off, const uint64_t* __restrict__ noff, uint64_t U, const uint32_t* __restrict__ in,
+                                                          uint32_t* __restrict__ out) {
+    const uint64_t u = blockIdx.x;
+    if (u >= U) return;
+    const uint64_t n = noff[u + 1] - noff[u];
+    for (uint64_t i = threadIdx.x; i < n; i += 64) out[noff[u] + i] = in[off[u] + i];
+}
+
 template <int K>
 int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U, const uint64_t* d_uoff, const uint8_t* d_ubases, const snk_hbv* h,
               uint32_t flags, snk_dev_paths* out, char* err, size_t errcap) {
@@ -826,7 +870,21 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
     (void)hipEventElapsedTime(&out->path_ms, e1, e2);
     if (want_bcs) {
         // sort the keys, keep the first of every run, count per unitig: sorted distinct barcodes per unitig
-        const uint64_t nkeys = n + h_cur[2];
+        uint64_t nkeys = n + h_cur[2];
+        if (flags & SNK_PATH_UNITIG_BCS_EXHAUSTIVE) {
+            const uint64_t xcap = n * 16 + 1024;
+            unsigned long long* xk;
+            if ((rc = dev(ctx, xcap, &xk, err, errcap))) return rc;
+            SNK_HIP_TRY(hipMemsetAsync(cursor, 0, 8, st));
+            if (n) hipLaunchKernelGGL((ubc_exhaustive_kernel<K>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, G, a.rows, a.row_words, a.read_len, a.lens,
+                                      (const int32_t*)in->bc, n, xk, xcap, cursor);
+            unsigned long long hx = 0;
+            SNK_HIP_TRY(hipMemcpyAsync(&hx, cursor, 8, hipMemcpyDeviceToHost, st));
+            SNK_HIP_TRY(snk_sync(st));
+            if (hx > xcap) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_dev_path_reads: the exhaustive barcode derivation found more than 16 unitigs per read on average");
+            ubk = xk;
+            nkeys = hx;
+        }
         unsigned long long* ks;
         uint64_t *flag, *upos, *per_u, *uoff_out;
         uint32_t* bcs = nullptr;
@@ -851,6 +909,31 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
         if ((rc = scan64(ctx, st, per_u, uoff_out, U + 1, err, errcap))) return rc;
         SNK_HIP_TRY(hipGetLastError());
         SNK_HIP_TRY(snk_sync(st));
+        if (!(flags & SNK_PATH_UNITIG_BCS_NOCUT) && U) {
+            // the reference's cut (cmd_main_asm.rs:115 stops extending an edge's list at 20 000 entries, in the order its shards
+            // are visited and with duplicates counted between compactions -- not reproducible without its shard layout); here:
+            // a unitig keeps its 20 000 SMALLEST barcode ids.  Lists under the cut -- all but high-copy repeats -- are unaffected.
+            const uint64_t cut = snk_env_u32("SNK_UNITIG_BC_CUT", 20000);
+            uint64_t *clen, *noff2;
+            uint32_t* any;
+            if ((rc = dev(ctx, U + 2, &clen, err, errcap)) || (rc = dev(ctx, U + 2, &noff2, err, errcap)) || (rc = dev(ctx, 4, &any, err, errcap))) return rc;
+            SNK_HIP_TRY(hipMemsetAsync(any, 0, 4, st));
+            hipLaunchKernelGGL(ubc_cut_len_kernel, dim3((unsigned)((U + 256) / 256)), dim3(256), 0, st, uoff_out, U, cut, clen, any);
+            uint32_t h_any = 0;
+            SNK_HIP_TRY(hipMemcpyAsync(&h_any, any, 4, hipMemcpyDeviceToHost, st));
+            SNK_HIP_TRY(snk_sync(st));
+            if (h_any) {
+                if ((rc = scan64(ctx, st, clen, noff2, U + 1, err, errcap))) return rc;
+                uint64_t n_cut = 0;
+                SNK_HIP_TRY(hipMemcpyAsync(&n_cut, noff2 + U, 8, hipMemcpyDeviceToHost, st));
+                SNK_HIP_TRY(snk_sync(st));
+                uint32_t* bcs2;
+                if ((rc = dev(ctx, n_cut + 1, &bcs2, err, errcap))) return rc;
+                hipLaunchKernelGGL(ubc_cut_copy_kernel, dim3((unsigned)U), dim3(64), 0, st, uoff_out, noff2, U, bcs, bcs2);
+                SNK_HIP_TRY(hipGetLastError());
+                uoff_out = noff2; bcs = bcs2; n_unique = n_cut;
+            }
+        }
         out->unitig_bc_off = uoff_out;
         out->unitig_bcs = bcs;
         out->n_unitig_bcs = n_unique;
@@ -879,8 +962,17 @@ extern "C" int snk_dev_path_reads2(snk_ctx* ctx, uint32_t K, const snk_dev_reads
     memset(out, 0, sizeof *out);
     SNK_HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    // the call's scratch (graph tables, dictionary, parts, sort buffers: ~0.3 KB per read + 40 B per unitig k-mer) goes back to the
+    // arena when it returns; only the paths (and barcode lists) stay, until the context's next snk_dev_count_graph / snk_shard_step
+    const uint64_t mark = ctx->alloc_serial;
+    int rc;
     try {
-        if (K == 48) return path_impl<48>(ctx, st, in, n_unitigs, (const uint64_t*)d_unitig_off, (const uint8_t*)d_unitig_bases, h, flags, out, err, errcap);
-        return path_impl<60>(ctx, st, in, n_unitigs, (const uint64_t*)d_unitig_off, (const uint8_t*)d_unitig_bases, h, flags, out, err, errcap);
-    } catch (const std::bad_alloc&) { return snk_fail(SNK_E_NOMEM, err, errcap, "snk_dev_path_reads: host allocation failed"); }
+        if (K == 48) rc = path_impl<48>(ctx, st, in, n_unitigs, (const uint64_t*)d_unitig_off, (const uint8_t*)d_unitig_bases, h, flags, out, err, errcap);
+        else rc = path_impl<60>(ctx, st, in, n_unitigs, (const uint64_t*)d_unitig_off, (const uint8_t*)d_unitig_bases, h, flags, out, err, errcap);
+    } catch (const std::bad_alloc&) { rc = snk_fail(SNK_E_NOMEM, err, errcap, "snk_dev_path_reads: host allocation failed"); }
+    (void)hipStreamSynchronize(st);          // also on the error paths: nothing of this call is still running when its scratch is handed back
+    const void* keep[6] = {out->offset, out->n_edges, out->start, out->edges, out->unitig_bc_off, out->unitig_bcs};
+    snk_ctx_release_since(ctx, mark, keep, rc ? 0 : 6);
+    if (rc) memset(out, 0, sizeof *out);
+    return rc;
 }

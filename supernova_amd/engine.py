@@ -115,14 +115,15 @@ class Result:
         self._e.lib.snk_hbv_free(C.byref(h))
         return out
 
-    def path_reads(self, rows, read_len: int, quals, lens=None, mark_dups=False, bc=None, unitig_bcs=False, download=True):
+    def path_reads(self, rows, read_len: int, quals, lens=None, mark_dups=False, bc=None, unitig_bcs=False, download=True, bcs_nocut=False):
         """f1: the reads (untrimmed packed rows + quality rows on the device) onto the graph of this result's unitigs --
         pathReads with the new aligner (BuildReadQGraph48.cc:1441-1469).  Returns (offset i32[n], n_edges u32[n], edges i32[sum],
         info) on the host, HBV edge ids as numbered by buildHBVFromEdges.  Must be called before the engine's next count_graph.
         mark_dups: f4, MarkDups over these paths (10X/SecretOps.cc:413-593; bc = raw barcode ids on the device or None) ->
         info['dups'] = dict(dup u8[n/2], interdup_rate, n_dup_pairs, n_dup_reads, n_art_pairs, n_placed, ms).
         unitig_bcs: the rest of f4 -- per unitig (numbering of unitig_arrays()) the sorted distinct barcodes > 0 of the reads with a
-        k-mer on it (tada's edge -> barcode sets) -> info['unitig_bcs'] = (off u64[U+1], bcs u32[...])."""
+        k-mer on it (tada's edge -> barcode sets) -> info['unitig_bcs'] = (off u64[U+1], bcs u32[...]); unitig_bcs="exhaustive" derives them
+        the slow, literal way (every k-mer of every barcoded read looked up); bcs_nocut: without the 20 000-entry cut."""
         e = self._e
         h = _lib.SnkHbv()
         ms = C.c_float(0)
@@ -141,7 +142,7 @@ class Result:
             if unitig_bcs and bc is not None:
                 r.bc = bc.data_ptr()
             rc = e.lib.snk_dev_path_reads2(e._ctx, int(self.K), C.byref(r), self.n_unitigs, self.raw.unitig_off, self.raw.unitig_bases,
-                                           C.byref(h), 1 if unitig_bcs else 0, C.byref(out), e._stream(), err, 512)
+                                           C.byref(h), (0 if not unitig_bcs else 1 | (2 if unitig_bcs == "exhaustive" else 0) | (4 if bcs_nocut else 0)), C.byref(out), e._stream(), err, 512)
             if rc:
                 raise _lib.SnkError(rc, err.value.decode(errors="replace"))
             dups = None

@@ -36,7 +36,8 @@ class BcIndexer:
         self.bc_map = {}
         i = 0
         for l in lines:
-            self.bc_map[l.rstrip("\n")] = i
+            l = l[:-1] if l.endswith("\n") else l
+            self.bc_map[l[:-1] if l.endswith("\r") else l] = i       # BufRead::lines strips "\n" or "\r\n"
             i += 1
         self.num_bcs = i
 
@@ -49,12 +50,17 @@ class BcIndexer:
         if "-" in bc:
             seq, gg = bc.split("-")[:2]
             idx = self.bc_map.get(seq)
+            # u8::from_str: decimal digits with an optional leading '+', 0..255, anything else panics ("invalid gem group string")
+            if not (gg[1:] if gg[:1] == "+" else gg).isdigit() or not gg.isascii() or int(gg) > 255:
+                raise ValueError("invalid gem group string")
             g = int(gg)
         else:
             idx = self.bc_map.get(bc)
             g = 1
         if idx is None:
             return None
+        if g == 0 or (g - 1) * self.num_bcs >= 1 << 32:
+            raise OverflowError("too many gem groups - BC id overflowed")      # (g - 1) underflows / checked_mul fails, utils.rs:157
         return (g - 1) * self.num_bcs + idx + 1
 
 

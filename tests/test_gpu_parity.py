@@ -653,6 +653,32 @@ def test_read_paths_full_capacity_pass(engine, monkeypatch):
     assert np.array_equal(info["dups"]["dup"], c.exp_dup)
 
 
+def test_unitig_barcode_lists_two_derivations_200k_parity_unpinned_rust(engine, monkeypatch):
+    """f4, parity unpinned (the reference side is Rust): the per-unitig barcode lists out of the pather's parts against a second,
+    independent derivation ON THE DEVICE -- every k-mer of every barcoded read looked up in the f1 dictionary, which is literally
+    barcodes_for_sedge (debruijn.rs:115-131) + the union of cmd_main_asm.rs:91-151 -- on 200 k synthetic reads; and the 20 000-entry
+    cut (cmd_main_asm.rs:115; here: the smallest ids are kept) with the cut lowered to 3."""
+    import torch
+    from supernova_amd import synth
+    sp = synth.synth_params(200_000, seed=0x5EED0B0C)
+    rows, quals, bc = engine.synth(sp)
+    res = engine.count_graph(rows, sp.read_len, quals=quals, bc=bc)
+    _, _, _, fast = res.path_reads(rows, sp.read_len, quals, bc=bc, unitig_bcs=True)
+    _, _, _, slow = res.path_reads(rows, sp.read_len, quals, bc=bc, unitig_bcs="exhaustive")
+    assert len(fast["unitig_bcs"][1]) > 1000
+    assert np.array_equal(fast["unitig_bcs"][0], slow["unitig_bcs"][0]) and np.array_equal(fast["unitig_bcs"][1], slow["unitig_bcs"][1])
+    monkeypatch.setenv("SNK_UNITIG_BC_CUT", "3")
+    _, _, _, cut = res.path_reads(rows, sp.read_len, quals, bc=bc, unitig_bcs=True)
+    _, _, _, nocut = res.path_reads(rows, sp.read_len, quals, bc=bc, unitig_bcs=True, bcs_nocut=True)
+    assert np.array_equal(nocut["unitig_bcs"][0], fast["unitig_bcs"][0]) and np.array_equal(nocut["unitig_bcs"][1], fast["unitig_bcs"][1])
+    off, b = fast["unitig_bcs"]
+    coff, cb = cut["unitig_bcs"]
+    assert int(np.diff(off.astype(np.int64)).max()) > 3 and int(np.diff(coff.astype(np.int64)).max()) == 3
+    for u in range(len(off) - 1):
+        want = b[int(off[u]):int(off[u + 1])][:3]
+        assert np.array_equal(cb[int(coff[u]):int(coff[u + 1])], want)
+
+
 @pytest.mark.parametrize("mask", ["0xFF", "0x3"])
 def test_read_paths_with_colliding_fingerprints(engine, monkeypatch, mask):
     """The dictionary keeps a 64-bit fingerprint per k-mer (16-byte slots) and the pather checks a match against the unitig's

@@ -23,6 +23,60 @@ def test_bc_indexer_kat():
     assert ix.get_bc_id("AACG-1") is None and ix.get_bc_id("AACG") is None
 
 
+def _bc_vectors():
+    return json.loads((ROOT / "tests" / "golden" / "bc_indexer_vectors.json").read_text())
+
+
+def test_bc_indexer_literal_vectors():
+    """Parity unpinned (Rust): the restated BcIndexer against literal vectors derived by hand from utils.rs:101-164 -- the reference's
+    KAT, gem groups up to 255, a duplicated / empty / blank-holding whitelist line, the integer syntax u8::from_str takes, and
+    every input the reference panics on."""
+    from supernova_amd.martian import BcIndexer
+    v = _bc_vectors()
+    kat = BcIndexer([l + "\n" for l in v["kat_whitelist"]])
+    for q, exp in v["kat"]:
+        assert kat.get_bc_id(q) == exp, q
+    ix = BcIndexer([l + "\n" for l in v["whitelist"][:-1]] + [v["whitelist"][-1]])        # (the last line has no newline)
+    assert ix.num_bcs == len(v["whitelist"])
+    for q, exp in v["cases"]:
+        if exp == "panic":
+            with pytest.raises((ValueError, OverflowError)):
+                ix.get_bc_id(q)
+        else:
+            assert ix.get_bc_id(q) == exp, q
+    for f, exp in v["fastq_fields"]:
+        assert ix.get_bc_id(f.split(",")[0] if "," in f else f) == exp, f
+
+
+@pytest.mark.gpu
+def test_device_bc_indexer_literal_vectors():
+    """The same vectors through snk_dev_bc_ids (whitelist in HBM, one thread per field): ids equal, every reference panic is an error."""
+    from supernova_amd.lib import SnkError
+    from supernova_amd.martian import DeviceBcIndexer
+    v = _bc_vectors()
+
+    def fields_of(strs, F=64):
+        a = np.zeros((len(strs), F), dtype=np.uint8)
+        for i, s in enumerate(strs):
+            b = s.encode()[:F]
+            a[i, :len(b)] = np.frombuffer(b, dtype=np.uint8)
+        return a
+
+    dev = DeviceBcIndexer(("\n".join(v["whitelist"])).encode())
+    assert dev.num_bcs == len(v["whitelist"])
+    good = [(q, e) for q, e in v["cases"] + v["fastq_fields"] if e != "panic"]
+    got = dev.ids_of_fields(fields_of([q for q, _ in good])).tolist()
+    assert got == [e or 0 for _, e in good], [(q, e, g) for (q, e), g in zip(good, got) if (e or 0) != g]
+    for q, e in v["cases"]:
+        if e == "panic":
+            with pytest.raises(SnkError):
+                dev.ids_of_fields(fields_of([q]))
+    dev.close()
+    kat = DeviceBcIndexer(("\n".join(v["kat_whitelist"])).encode())
+    assert kat.ids_of_fields(fields_of([q for q, _ in v["kat"]])).tolist() == [e or 0 for _, e in v["kat"]]
+    kat.close()
+
+
 @pytest.mark.gpu
 def test_device_bc_indexer_matches_host_and_kat():
     """f3: barcode ids on the device == BcIndexer (utils.rs:101-164): the reference's KAT (:435-448), duplicate whitelist
