@@ -37,6 +37,7 @@ int snk_shard_begin(snk_ctx* ctx, const snk_dev_reads* in, const snk_params* p, 
     S->reads = *in;
     S->params = *p;
     S->rank = rank; S->world = world; S->NB_total = NB_total; S->NBl = NB_total / world;
+    S->circ_all = nullptr; S->join_circles = 0;
     const uint16_t* good_len = (const uint16_t*)in->good_len;
     int rc;
     if (!good_len) {
@@ -395,8 +396,10 @@ extern "C" int snk_shard_place(snk_ctx* ctx, uint32_t K, uint64_t n_frags_total,
     S->n_frags_total = n_frags_total;
     const uint2* rk = nullptr;
     uint8_t* circ = nullptr;
-    int rc = snk_join_rank(ctx, st, n_frags_total, (const uint32_t*)d_nk_all, (uint32_t*)d_flink_all, &rk, &circ, &S->join_circles, &S->join_rounds, err, errcap);
+    uint32_t nc = 0;
+    int rc = snk_join_rank(ctx, st, n_frags_total, (const uint32_t*)d_nk_all, (uint32_t*)d_flink_all, &rk, &circ, &nc, &S->join_rounds, err, errcap, S->circ_all);
     if (rc) return rc;
+    S->join_circles += nc;
     return place_and_count(ctx, S, st, K, rk, 0, circ, (const uint32_t*)d_nk_all, d_frag_off, h_frags_to, h_bases_to, err, errcap);
 }
 
@@ -411,6 +414,13 @@ extern "C" int snk_shard_prank_begin(snk_ctx* ctx, uint64_t n_frags_total, const
     S->my_frag_off = my_frag_off;
     S->n_frags_total = n_frags_total;
     S->nk_all = (const uint32_t*)d_nk_all;
+    if (!S->circ_all) {          // first ranking attempt of this step (a second one follows a circle cut and keeps the marks)
+        void* q;
+        int rc0 = snk_ctx_alloc(ctx, 2 * n_frags_total + 16, &q, err, errcap);
+        if (rc0) return rc0;
+        S->circ_all = (uint8_t*)q;
+        SNK_HIP_TRY(hipMemsetAsync(S->circ_all, 0, 2 * n_frags_total + 16, st));
+    }
     int rc = snk_prank_begin(ctx, st, n_frags_total, (const uint32_t*)d_nk_all, (uint32_t*)d_flink_all, S->rank, S->world, &S->pr, err, errcap);
     if (rc) return rc;
     *n_splitters = S->pr.m;       // (the share is consumed by a collective on the same stream: nothing to wait for here)
@@ -422,12 +432,13 @@ extern "C" int snk_shard_prank_walk(snk_ctx* ctx, const void* d_w1_all, const vo
     if (!ctx || !ctx->shard || !circles) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_prank_walk: NULL argument / no session");
     snk_shard_state* S = state_of(ctx);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-    S->join_circles = 0;
-    int rc = snk_prank_walk(ctx, st, &S->pr, (const uint4*)d_w1_all, circles, &S->join_rounds, err, errcap);
+    uint32_t n_cut = 0;
+    int rc = snk_prank_walk(ctx, st, &S->pr, (const uint4*)d_w1_all, circles, &S->join_rounds, err, errcap, S->circ_all, &n_cut);
     if (rc) return rc;
+    S->join_circles += n_cut;
+    if (h_recs_to) for (uint32_t r = 0; r < S->world; ++r) h_recs_to[r] = 0;
+    if (*circles) return SNK_OK;       // 2: circles were cut in the replicated links, call snk_shard_prank_begin again; 1: use snk_shard_place
     if (!h_recs_to) return SNK_OK;       // one-pass routing into per-owner regions: S->pr.n_rec records, no count pass
-    for (uint32_t r = 0; r < S->world; ++r) h_recs_to[r] = 0;
-    if (*circles) return SNK_OK;
     void* q;
     if ((rc = snk_ctx_alloc(ctx, (S->world + 1) * 8ull, &q, err, errcap))) return rc;
     unsigned long long* cnt = (unsigned long long*)q;
@@ -459,7 +470,7 @@ extern "C" int snk_shard_place_ranked(snk_ctx* ctx, uint32_t K, const void* d_re
     const uint2* rk = nullptr;
     int rc = snk_prank_apply(ctx, st, d_recs, n_recs, 2ull * S->my_frag_off, 2ull * S->frags.n_frags, &rk, err, errcap);
     if (rc) return rc;
-    return place_and_count(ctx, S, st, K, rk, S->my_frag_off, nullptr, S->nk_all, d_frag_off, h_frags_to, h_bases_to, err, errcap);
+    return place_and_count(ctx, S, st, K, rk, S->my_frag_off, S->join_circles ? S->circ_all : nullptr, S->nk_all, d_frag_off, h_frags_to, h_bases_to, err, errcap);
 }
 
 extern "C" int snk_shard_route_fill(snk_ctx* ctx, uint32_t K, const void* d_frag_off, const void* d_hdr_off /* u64[world]: first header of every owner */,

@@ -66,7 +66,7 @@ struct snk_placement {
     uint8_t* circ;               // the unitig is a circle that was cut at an arbitrary fragment
 };
 int snk_join_rank(snk_ctx* ctx, hipStream_t st, uint64_t F, const uint32_t* nk, uint32_t* flink, const uint2** rk_out, uint8_t** circ_out,
-                  uint32_t* n_circles, uint32_t* rounds, char* err, size_t errcap);
+                  uint32_t* n_circles, uint32_t* rounds, char* err, size_t errcap, uint8_t* circ_given = nullptr);
 int snk_join_place(snk_ctx* ctx, hipStream_t st, const uint2* rk, const uint32_t* nk, const uint8_t* circ, uint64_t f0, uint64_t Fl,
                    snk_placement* pl, char* err, size_t errcap, uint64_t rk_f0 = 0);
 // partitioned ranking of the job's fragment lists (sharded runs): replicated streaming setup, walks for a 1/world share
@@ -81,7 +81,8 @@ struct snk_prank {
 };
 int snk_prank_begin(snk_ctx* ctx, hipStream_t st, uint64_t F, const uint32_t* nk, uint32_t* link, uint32_t rank, uint32_t world, snk_prank* P, char* err,
                     size_t errcap);
-int snk_prank_walk(snk_ctx* ctx, hipStream_t st, snk_prank* P, const uint4* w1_all, uint32_t* circles, uint32_t* rounds, char* err, size_t errcap);
+int snk_prank_walk(snk_ctx* ctx, hipStream_t st, snk_prank* P, const uint4* w1_all, uint32_t* circles, uint32_t* rounds, char* err, size_t errcap,
+                   uint8_t* circ = nullptr /* [ns]: given = circles are cut here (*circles = 2: begin again) */, uint32_t* n_cut = nullptr);
 int snk_prank_route(snk_ctx* ctx, hipStream_t st, snk_prank* P, bool fill, const unsigned long long* d_frag_off, uint32_t world,
                     unsigned long long* d_cnt_or_cur, void* d_out, char* err, size_t errcap);
 int snk_prank_apply(snk_ctx* ctx, hipStream_t st, const void* d_rec, uint64_t n, unsigned long long state_base, uint64_t n_local_states,

@@ -523,12 +523,129 @@ __global__ void __launch_bounds__(TB) unranked_check_kernel(const uint2* __restr
     if (s < ns && rk[s].y == NONE) *flag = 1u;
 }
 
+// ---- circles, cut without the general algorithm.  The ruling-set ranking sees a circle in one of two ways: its splitters form a
+// cycle in the splitter list (the jumping does not converge), or it holds no splitter at all and no walk reaches it.  Round 2
+// answered both with Wyllie's pointer jumping over ALL states (ceil(log2 ns) rounds of random gathers: ~50 ms at 35 M states,
+// a second at 280 M -- for ONE plasmid in the data set).  Here: the minimum sampled FRAGMENT of every splitter cycle by
+// pointer jumping on the splitter list only (1/64 of the states; both states of a fragment are sampled together, so the two
+// directed cycles of a circle agree on it), and the minimum fragment of a splitter-free circle (a few hundred states at most)
+// by walking it from every unreached odd state; the circle is cut at the odd state of that fragment -- one cut per circle --
+// and the caller ranks again.  Where a circle is cut does not matter in the join: jcircle_kernel rotates it to the
+// reference's cut (canonicalizeCircle, BuildReadQGraph48.cc:375-397).
+__global__ void __launch_bounds__(TB) spl_reach_kernel(const unsigned long long* __restrict__ wrec, const uint32_t* __restrict__ spl_state, uint64_t m,
+                                                       uint8_t* __restrict__ reach) {
+    const uint64_t k = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (k >= m) return;
+    uint32_t cur = spl_state[k];
+    unsigned long long rec = wrec[cur];
+    for (;;) {
+        reach[cur] = 1;
+        const uint32_t l = (uint32_t)rec;
+        if (l == NONE) break;
+        cur = l ^ 1u;
+        rec = wrec[cur];
+        if (rec >> 63) break;
+    }
+}
+__global__ void __launch_bounds__(TB) scyc_init_kernel(const uint32_t* __restrict__ rn_final, const uint32_t* __restrict__ rn_orig,
+                                                       const uint32_t* __restrict__ spl_state, uint64_t m, uint32_t* __restrict__ jump, uint32_t* __restrict__ mn) {
+    const uint64_t k = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (k >= m) return;
+    const bool on = rn_final[k] != NONE;          // still has a successor after ceil(log2 m) + 1 doublings: on a cycle
+    jump[k] = on ? rn_orig[k] : NONE;
+    mn[k] = on ? spl_state[k] >> 1 : NONE;
+}
+__device__ __forceinline__ void cut_at(uint32_t* link, uint32_t s, uint8_t* circ, uint32_t* n_cut) {
+    const uint32_t partner = link[s];
+    link[s] = NONE;
+    if (partner != NONE) link[partner] = NONE;
+    circ[s] = 1;
+    if (partner != NONE) circ[partner] = 1;       // both new terminals
+    atomicAdd(n_cut, 1u);
+}
+__global__ void __launch_bounds__(TB) scyc_cut_kernel(const uint32_t* __restrict__ mn, const uint32_t* __restrict__ spl_state, uint64_t m,
+                                                      uint32_t* __restrict__ link, uint32_t* __restrict__ n_cut, uint8_t* __restrict__ circ) {
+    const uint64_t k = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (k >= m) return;
+    const uint32_t s = spl_state[k];
+    if (mn[k] != NONE && (s & 1u) && mn[k] == (s >> 1)) cut_at(link, s, circ, n_cut);
+}
+__global__ void __launch_bounds__(TB) free_circle_find_kernel(const uint8_t* __restrict__ reach, uint64_t ns, const uint32_t* __restrict__ link,
+                                                              uint32_t* __restrict__ list, uint32_t cap, uint32_t* __restrict__ n_list, uint32_t* __restrict__ bad) {
+    const uint64_t s0 = (uint64_t)blockIdx.x * TB + threadIdx.x;
+    if (s0 >= ns || !(s0 & 1ull) || reach[s0]) return;
+    // an unreached state lies on a circle without a splitter; every odd state of that circle walks it, the one of the minimum
+    // fragment is where it will be cut.  Nothing is cut here: a cut also breaks the circle's OTHER direction, which other threads
+    // are walking at this moment -- the states are listed and cut by the next kernel.
+    const uint32_t s = (uint32_t)s0;
+    uint32_t cur = s, mn = s >> 1;
+    for (uint32_t steps = 0;; ++steps) {
+        const uint32_t l = link[cur];
+        if (l == NONE || steps > (1u << 22)) { atomicOr(bad, 1u); return; }      // not a circle / absurdly long: leave it to the general algorithm
+        cur = l ^ 1u;
+        if (cur == s) break;
+        const uint32_t f = cur >> 1;
+        mn = f < mn ? f : mn;
+    }
+    if (mn == (s >> 1)) { const uint32_t at = atomicAdd(n_list, 1u); if (at < cap) list[at] = s; else atomicOr(bad, 1u); }
+}
+__global__ void __launch_bounds__(TB) cut_list_kernel(const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list, uint32_t cap, uint32_t* __restrict__ link,
+                                                      uint32_t* __restrict__ n_cut, uint8_t* __restrict__ circ) {
+    const uint32_t i = blockIdx.x * TB + threadIdx.x;
+    const uint32_t n = *n_list < cap ? *n_list : cap;
+    if (i < n) cut_at(link, list[i], circ, n_cut);
+}
+
+// rn_orig: next splitter of every splitter after the first walk; rn_final: the same after the jumping (NONE unless on a cycle).
+// *n_cut = circles cut, *bad = 1: something the fast path does not understand (the caller uses the general algorithm).
+static int cut_circles_sparse(snk_ctx* ctx, hipStream_t st, uint32_t* link, uint64_t ns, uint64_t m, const uint32_t* spl_state,
+                              const unsigned long long* wrec, const uint32_t* rn_orig, const uint32_t* rn_final, bool jump_converged, uint8_t* circ,
+                              uint32_t* n_cut, uint32_t* bad, char* err, size_t errcap) {
+    uint32_t* d_flags;
+    G_ALLOC(d_flags, uint32_t, 4);
+    SNK_HIP_TRY(hipMemsetAsync(d_flags, 0, 16, st));
+    // (the reach marks come from the links as they are BEFORE any cut)
+    uint8_t* reach;
+    G_ALLOC(reach, uint8_t, ns + 1);
+    SNK_HIP_TRY(hipMemsetAsync(reach, 0, ns + 1, st));
+    if (m) hipLaunchKernelGGL(spl_reach_kernel, dim3(nblk(m)), dim3(TB), 0, st, wrec, spl_state, m, reach);
+    if (!jump_converged && m) {
+        uint32_t *jump[2], *mn[2];
+        for (int b = 0; b < 2; ++b) { G_ALLOC(jump[b], uint32_t, m + 1); G_ALLOC(mn[b], uint32_t, m + 1); }
+        hipLaunchKernelGGL(scyc_init_kernel, dim3(nblk(m)), dim3(TB), 0, st, rn_final, rn_orig, spl_state, m, jump[0], mn[0]);
+        int max_rounds = 2;
+        while ((1ull << (max_rounds - 1)) < m + 1) ++max_rounds;
+        int c2 = 0;
+        for (int r = 0; r < max_rounds; ++r) {
+            hipLaunchKernelGGL(cyc_round_kernel, dim3(nblk(m)), dim3(TB), 0, st, jump[c2], mn[c2], m, jump[c2 ^ 1], mn[c2 ^ 1]);
+            c2 ^= 1;
+        }
+        hipLaunchKernelGGL(scyc_cut_kernel, dim3(nblk(m)), dim3(TB), 0, st, mn[c2], spl_state, m, link, d_flags, circ);
+    }
+    {
+        const uint32_t cap = 1u << 18;
+        uint32_t* list;
+        G_ALLOC(list, uint32_t, cap);
+        hipLaunchKernelGGL(free_circle_find_kernel, dim3(nblk(ns)), dim3(TB), 0, st, reach, ns, (const uint32_t*)link, list, cap, d_flags + 2, d_flags + 1);
+        hipLaunchKernelGGL(cut_list_kernel, dim3(cap / TB), dim3(TB), 0, st, (const uint32_t*)list, (const uint32_t*)(d_flags + 2), cap, link, d_flags, circ);
+    }
+    SNK_HIP_TRY(hipGetLastError());
+    uint32_t h[2] = {0, 0};
+    SNK_HIP_TRY(hipMemcpyAsync(h, d_flags, 8, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(snk_sync(st));
+    *n_cut = h[0];
+    *bad = h[1];
+    return SNK_OK;
+}
+
 static int rank_lists(snk_ctx* ctx, hipStream_t st, uint32_t* link, uint64_t n, const uint32_t* weights, uint8_t* circ /* per state, nullable */,
                       const uint2** rk_out, uint32_t* n_circles, uint32_t* rounds,
                       char* err, size_t errcap) {
     const uint64_t ns = 2 * n;
     if (ns < 4096 || snk_env_u32("SNK_RANK_WYLLIE", 0))
         return rank_lists_wyllie(ctx, st, link, n, weights, circ, rk_out, n_circles, rounds, err, errcap);
+    uint32_t cut_total = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
     uint8_t* spl;
     uint32_t *flag32, *sid;
     G_ALLOC(spl, uint8_t, ns + 1);
@@ -558,6 +675,9 @@ static int rank_lists(snk_ctx* ctx, hipStream_t st, uint32_t* link, uint64_t n, 
     hipLaunchKernelGGL(spl_pack_kernel, dim3(nblk(ns)), dim3(TB), 0, st, link, spl, sid, ns, wrec);
     if (m) hipLaunchKernelGGL(spl_walk1_kernel, dim3(nblk(m)), dim3(TB), 0, st, wrec, spl_state, weights, m, rn[0], rd[0], rt[0]);
     SNK_HIP_TRY(hipGetLastError());
+    uint32_t* rn_orig;
+    G_ALLOC(rn_orig, uint32_t, m + 1);
+    if (m) SNK_HIP_TRY(hipMemcpyAsync(rn_orig, rn[0], m * 4, hipMemcpyDeviceToDevice, st));
     // pointer jumping on the splitter list
     uint32_t* flags;
     G_ALLOC(flags, uint32_t, 4);
@@ -576,22 +696,39 @@ static int rank_lists(snk_ctx* ctx, hipStream_t st, uint32_t* link, uint64_t n, 
         SNK_HIP_TRY(snk_sync(st));
         if (h_flag == 0) converged = true;
     }
-    if (!converged)      // a circle that contains splitters: let the general algorithm find, cut and rank it
-        return rank_lists_wyllie(ctx, st, link, n, weights, circ, rk_out, n_circles, rounds, err, errcap);
-    uint2* rk;
-    G_ALLOC(rk, uint2, ns);
-    SNK_HIP_TRY(hipMemsetAsync(rk, 0xFF, ns * 8, st));
-    if (m) hipLaunchKernelGGL(spl_walk2_kernel, dim3(nblk(m)), dim3(TB), 0, st, wrec, spl_state, weights, rd[cur], rt[cur], m, rk);
-    SNK_HIP_TRY(hipMemsetAsync(flags, 0, 4, st));
-    hipLaunchKernelGGL(unranked_check_kernel, dim3(nblk(ns)), dim3(TB), 0, st, rk, ns, flags);
-    SNK_HIP_TRY(hipMemcpyAsync(&h_flag, flags, 4, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(snk_sync(st));
-    if (h_flag)          // states no walk reached: a circle without a splitter
-        return rank_lists_wyllie(ctx, st, link, n, weights, circ, rk_out, n_circles, rounds, err, errcap);
-    *rk_out = rk;
-    *n_circles = 0;
-    *rounds = r_done;
-    return SNK_OK;
+    uint2* rk = nullptr;
+    bool unranked = false;
+    if (converged) {
+        G_ALLOC(rk, uint2, ns);
+        SNK_HIP_TRY(hipMemsetAsync(rk, 0xFF, ns * 8, st));
+        if (m) hipLaunchKernelGGL(spl_walk2_kernel, dim3(nblk(m)), dim3(TB), 0, st, wrec, spl_state, weights, rd[cur], rt[cur], m, rk);
+        SNK_HIP_TRY(hipMemsetAsync(flags, 0, 4, st));
+        hipLaunchKernelGGL(unranked_check_kernel, dim3(nblk(ns)), dim3(TB), 0, st, rk, ns, flags);
+        SNK_HIP_TRY(hipMemcpyAsync(&h_flag, flags, 4, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(snk_sync(st));
+        unranked = h_flag != 0;          // states no walk reached: a circle without a splitter
+        if (!unranked) {
+            *rk_out = rk;
+            *n_circles = cut_total;
+            *rounds = r_done;
+            return SNK_OK;
+        }
+    }
+    // circles.  In the join (circ given) they are cut here and the lists ranked once more; the k-mer level ranking of the global
+    // graph stage needs the cut AT the minimum k-mer (it is the reference's cut there): the general algorithm does that.
+    if (!circ || attempt == 1) break;
+    uint32_t n_cut = 0, bad = 0;
+    int rcc = cut_circles_sparse(ctx, st, link, ns, m, spl_state, wrec, rn_orig, rn[cur], converged, circ, &n_cut, &bad, err, errcap);
+    if (rcc) return rcc;
+    if (bad || n_cut == 0) break;
+    cut_total += n_cut;
+    }
+    {
+        uint32_t nc2 = 0;
+        int rcw = rank_lists_wyllie(ctx, st, link, n, weights, circ, rk_out, &nc2, rounds, err, errcap);
+        *n_circles = cut_total + nc2;
+        return rcw;
+    }
 }
 
 namespace {
@@ -1266,11 +1403,13 @@ int snk_dist_join(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
 
 // ranking of a whole fragment list (sharded runs: every rank holds the job's links and k-mer counts) -- rk[2F], circ[2F]
 int snk_join_rank(snk_ctx* ctx, hipStream_t st, uint64_t F, const uint32_t* nk, uint32_t* flink, const uint2** rk_out, uint8_t** circ_out,
-                  uint32_t* n_circles, uint32_t* rounds, char* err, size_t errcap) {
+                  uint32_t* n_circles, uint32_t* rounds, char* err, size_t errcap, uint8_t* circ_given) {
     if (F >= (1ull << 31)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "more than 2^31 fragments at the join (%llu)", (unsigned long long)F);
-    uint8_t* circ;
-    G_ALLOC(circ, uint8_t, 2 * F + 1);
-    SNK_HIP_TRY(hipMemsetAsync(circ, 0, 2 * F + 1, st));
+    uint8_t* circ = circ_given;          // given: the marks of circles an earlier (partitioned) attempt already cut in these links
+    if (!circ) {
+        G_ALLOC(circ, uint8_t, 2 * F + 1);
+        SNK_HIP_TRY(hipMemsetAsync(circ, 0, 2 * F + 1, st));
+    }
     *circ_out = circ;
     *n_circles = 0;
     *rounds = 0;
@@ -1525,7 +1664,8 @@ int snk_prank_begin(snk_ctx* ctx, hipStream_t st, uint64_t F, const uint32_t* nk
 
 // w1_all: the first walk's results of all ranks in splitter order.  *circles = 1: some list is a circle (the caller ranks the
 // replicated way); else rec_out / n_rec = this rank's share of (state, distance, terminal) records.
-int snk_prank_walk(snk_ctx* ctx, hipStream_t st, snk_prank* P, const uint4* w1_all, uint32_t* circles, uint32_t* rounds, char* err, size_t errcap) {
+int snk_prank_walk(snk_ctx* ctx, hipStream_t st, snk_prank* P, const uint4* w1_all, uint32_t* circles, uint32_t* rounds, char* err, size_t errcap,
+                   uint8_t* circ, uint32_t* n_cut_out) {
     const uint64_t m = P->m;
     *circles = 0;
     *rounds = 0;
@@ -1538,6 +1678,9 @@ int snk_prank_walk(snk_ctx* ctx, hipStream_t st, snk_prank* P, const uint4* w1_a
     G_ALLOC(flags, uint32_t, 4);
     SNK_HIP_TRY(hipMemsetAsync(tot, 0, 8, st));
     if (m) hipLaunchKernelGGL(prank_unzip_kernel, dim3(nblk(m)), dim3(TB), 0, st, w1_all, m, rn[0], rd[0], rt[0], tot);
+    uint32_t* rn_orig;
+    G_ALLOC(rn_orig, uint32_t, m + 1);
+    if (m) SNK_HIP_TRY(hipMemcpyAsync(rn_orig, rn[0], m * 4, hipMemcpyDeviceToDevice, st));
     // pointer jumping over the splitter list in batches of rounds: one read-back per batch (flag of the batch's last round +,
     // the first time, the total the first walk reached), not per round; rounds past convergence change nothing
     unsigned long long h_tot = 0;
@@ -1558,12 +1701,24 @@ int snk_prank_walk(snk_ctx* ctx, hipStream_t st, snk_prank* P, const uint4* w1_a
         if (first) SNK_HIP_TRY(hipMemcpyAsync(&h_tot, tot, 8, hipMemcpyDeviceToHost, st));
         if (m) SNK_HIP_TRY(hipMemcpyAsync(&h_flag, flags, 4, hipMemcpyDeviceToHost, st));
         SNK_HIP_TRY(snk_sync(st));
-        if (first && h_tot != P->ns) { *circles = 1; return SNK_OK; }          // states no walk reached: a circle without a splitter
         first = false;
         if (m == 0 || h_flag == 0) converged = true;
         if (m == 0) break;
     }
-    if (!converged) { *circles = 1; return SNK_OK; }               // a circle that contains splitters
+    if (!converged || h_tot != P->ns) {
+        // circles: splitters that form a cycle (the jumping did not converge) and / or states no walk reached (a circle without a
+        // splitter).  Everything needed to cut them is replicated -- links, splitter list, the first walk of ALL ranks -- so every
+        // rank makes the same cuts (cut_circles_sparse) and the caller starts the ranking again: *circles = 2.  1: fall back to the
+        // replicated general algorithm (no circ array, or something the fast path does not understand).
+        if (n_cut_out) *n_cut_out = 0;
+        if (!circ) { *circles = 1; return SNK_OK; }
+        uint32_t n_cut = 0, bad = 0;
+        int rcc = cut_circles_sparse(ctx, st, P->link, P->ns, m, P->spl_state, P->wrec, rn_orig, rn[cur], converged, circ, &n_cut, &bad, err, errcap);
+        if (rcc) return rcc;
+        if (n_cut_out) *n_cut_out = n_cut;
+        *circles = (bad || n_cut == 0) ? 1u : 2u;
+        return SNK_OK;
+    }
     const uint64_t cnt = P->k1 - P->k0;
     uint64_t *steps, *pos;
     G_ALLOC(steps, uint64_t, cnt + 1);

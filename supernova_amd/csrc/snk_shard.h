@@ -27,6 +27,7 @@ struct snk_shard_state {
     uint64_t n_frags_total = 0;
     uint32_t join_circles = 0, join_rounds = 0;
     snk_prank pr{};
+    uint8_t* circ_all = nullptr;               // [2 * fragments of the job] terminals made by cutting circles (replicated; reset per step)
     unsigned long long* pr_cursor = nullptr;   // [world] cursors of the rank-record routing (end positions after the fill)
     const uint32_t* nk_all = nullptr;
     snk_phase_timer* tm = nullptr;

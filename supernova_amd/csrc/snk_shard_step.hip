@@ -420,7 +420,8 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
     bool ranked = false;
     uint64_t exch_spl = 0, exch_rank = 0;
     const bool want_partitioned = snk_env_u32("SNK_JOIN_REPLICATED", 0) == 0;
-    if (want_partitioned) {
+    for (int attempt = 0; want_partitioned && !ranked && attempt < 3; ++attempt) {
+        // (a second attempt follows a circle cut: the links changed, everything derived from them is made again)
         uint64_t m_spl = 0;
         const void* w1p = nullptr;
         TRY(snk_shard_prank_begin(ctx, Ft, nk_all, fl_all, frag_off[me], &m_spl, &w1p, st, err, errcap));
@@ -433,7 +434,9 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
         exch_spl = m_spl * 16;
         uint32_t circ = 0;
         TRY(snk_shard_prank_walk(ctx, w1_all, d_frag_off, nullptr, &circ, st, err, errcap));
-        if (!circ) {
+        if (circ == 1) break;            // something the partitioned ranking does not handle: every rank ranks the replicated way
+        if (circ == 2) continue;         // circles were cut (the same cuts on every rank: the data is replicated): rank again
+        {
             // the (state, distance, terminal) records of my walks, routed to the states' owners in one pass (regions of n_rec)
             const uint64_t n_rec = S->pr.n_rec, rcap = n_rec + 1;
             std::vector<ull> init(W);

@@ -85,9 +85,19 @@ def test_sharded_matches_reference(snk, W, name):
     check(out, c)
     if W > 1:
         assert sum(o["n_queries"] for o in out) > 0      # the cross-rank prune really ran
-    # the ranking is partitioned over the ranks unless some fragment list is a circle (the plasmids of the adversarial case):
-    # then every rank ranks the replicated way -- both routes are exercised, every rank takes the same one
-    assert {o["ranking"] for o in out} == ({"replicated"} if name == "adversarial" else {"partitioned"})
+    # the ranking is partitioned over the ranks -- also when fragment lists are circles (the plasmids of the adversarial case,
+    # one of them without any splitter): every rank cuts them the same way in the replicated links and ranks again
+    assert {o["ranking"] for o in out} == {"partitioned"}
+
+
+@pytest.mark.parametrize("W", [1, 3])
+def test_sharded_replicated_ranking_with_circles(snk, W, monkeypatch):
+    """SNK_JOIN_REPLICATED=1: every rank ranks the whole link structure itself; the circles are cut by the same sparse pass."""
+    monkeypatch.setenv("SNK_JOIN_REPLICATED", "1")
+    c = goldens.load("adversarial")
+    out = run_world(W, c)
+    check(out, c)
+    assert {o["ranking"] for o in out} == {"replicated"}
 
 
 def test_sharded_many_small_buckets(snk):
@@ -218,3 +228,87 @@ def test_rccl_world1_exchange_multi_gib(snk):
         assert rb == [n] and torch.equal(recv, src)
     finally:
         dist.destroy_process_group()
+
+
+def _plasmid_case(seed=5):
+    """A 600 kb linear genome + six circular replicons from 150 bp to 20 kb at 30x, error-free, two barcodes per locus:
+    thousands of fragments (the sparse-ruling-set ranking runs, not the small-input fallback) with circles that hold splitters
+    and circles that hold none."""
+    rng = np.random.default_rng(seed)
+    L = 150
+    reps = [(rng.integers(0, 4, 600_000, dtype=np.uint8), False)] + [(rng.integers(0, 4, n, dtype=np.uint8), True) for n in (150, 400, 1000, 3000, 8000, 20000)]
+    rows = []
+    for g, circular in reps:
+        G = len(g)
+        n = max(40, G * 30 // L)
+        ext = np.concatenate([g, g[:L]]) if circular else g
+        starts = rng.integers(0, G if circular else G - L + 1, n)
+        idx = starts[:, None] + np.arange(L)[None, :]
+        r = ext[idx]
+        flip = rng.random(n) < 0.5
+        r[flip] = (3 - r[flip][:, ::-1])
+        rows.append(r)
+    codes = np.concatenate(rows).astype(np.uint8)
+    perm = rng.permutation(codes.shape[0])
+    codes = codes[perm]
+    if codes.shape[0] & 1:
+        codes = codes[:-1]
+    n = codes.shape[0]
+    quals = np.full((n, L), 30, dtype=np.uint8)
+    bc = rng.integers(1, 50, n).astype(np.int32)
+    return codes, quals, bc, L
+
+
+@pytest.mark.parametrize("W", [1, 2, 3])
+def test_sharded_circles_at_scale_against_the_oracle(snk, W):
+    """Circular replicons among tens of thousands of fragments: the partitioned ranking cuts them (splitter cycles by pointer
+    jumping on the splitter list, splitter-free circles by walking them) and still ranks partitioned; table and unitigs equal
+    the C oracle's, so does the one-GPU path (whose join uses the same cut instead of Wyllie's jumping over all states)."""
+    import oracle_lib
+    import torch
+    from supernova_amd import synth
+    from supernova_amd.engine import Engine, Params
+    from supernova_amd.sharded import ShardedEngine, SimWorld
+    codes, quals, bc, L = _plasmid_case()
+    n = codes.shape[0]
+    o = oracle_lib.OracleResult(codes, np.full(n, L, np.uint32), bc, hbv=False)
+    assert sum(1 for u in o.unitigs if len(u) >= 95 and u[:47] == u[-47:]) >= 6
+    rows = synth.pack_rows(codes)
+    dev = torch.device("cuda", 0)
+    world = SimWorld(W)
+    bounds = [(n // 2 * r // W) * 2 for r in range(W)] + [n]
+    out, errs = [None] * W, []
+
+    def worker(r):
+        try:
+            e = Engine(0)
+            lo, hi = bounds[r], bounds[r + 1]
+            res = ShardedEngine(e, world.comm(r)).count_graph(
+                torch.from_numpy(rows[lo:hi].view(np.int32).copy()).to(dev), L, quals=torch.from_numpy(quals[lo:hi].copy()).to(dev),
+                bc=torch.from_numpy(bc[lo:hi].copy()).to(dev), params=Params(K=48), read_index_base=lo, total_reads=n)
+            out[r] = dict(keys=res.keys(), counts=res.counts(), ctx=res.ctx(), unitigs=res.unitigs(), ranking=res.join_ranking, n_circles=res.n_circles,
+                          n_frags=res.n_frags)
+            e.close()
+        except BaseException as ex:  # noqa: BLE001
+            errs.append(ex)
+            world.barrier_obj.abort()
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(W)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    if errs:
+        raise errs[0]
+    assert sum(x["n_frags"] for x in out) > 4096
+    keys = np.concatenate([x["keys"] for x in out])
+    order = np.lexsort((keys[:, 2], keys[:, 1], keys[:, 0]))
+    assert np.array_equal(keys[order][:, :3], o.keys[:, :3])
+    assert np.array_equal(np.concatenate([x["counts"] for x in out])[order], o.counts)
+    assert np.array_equal(np.concatenate([x["ctx"] for x in out])[order], o.ctx)
+    assert all_unitigs(out) == o.unitigs
+    assert {x["ranking"] for x in out} == {"partitioned"} and all(x["n_circles"] >= 6 for x in out)
+    if W == 1:
+        e = Engine(0)
+        res = e.count_graph(torch.from_numpy(rows.view(np.int32).copy()).to(dev), L, quals=torch.from_numpy(quals).to(dev), bc=torch.from_numpy(bc).to(dev),
+                            params=Params(K=48))
+        assert res.unitigs() == o.unitigs and res.n_circles >= 6
+        e.close()
