@@ -450,6 +450,7 @@ typedef struct snk_dev_paths {
     const void* unitig_bcs;    /* u32[n_unitig_bcs] */
     uint64_t n_unitig_bcs;
     float bcs_ms, reserved_f;  /* HIP events: key sort + run heads + per-unitig lists (SNK_PATH_UNITIG_BCS) */
+    uint64_t n_slow;           /* reads the fast pass left to the full algorithm (a miss, or an exact-match run that ended inside the read) */
 } snk_dev_paths;
 #define SNK_PATH_UNITIG_BCS 1u
 #define SNK_PATH_UNITIG_BCS_EXHAUSTIVE 2u   /* (with SNK_PATH_UNITIG_BCS) derive the lists the slow, literal way -- every k-mer of every barcoded

@@ -323,6 +323,8 @@ struct path_args {
     // per-unitig barcode lists (the rest of SURVEY f4; tada's edge -> barcode sets, lib/tada/src/cmd_main_asm.rs:91-151,
     // debruijn.rs:115-131): a barcoded read contributes its barcode to every unitig one of its k-mers lies on -- exactly the
     // unitigs of its non-gap path parts, since Pather::path looks every k-mer up that no exact-match run covers
+    const uint32_t* slow;             // MODE 1: the reads the fast pass left (gm == 0xFE), ascending
+    uint64_t n_slow;
     uint32_t* redo;                   // reads that did not fit the small capacities (first pass: written through cursor[3]; second: read)
     uint64_t redo_cap, n_redo;
     uint32_t force_redo;              // SNK_PATH_REDO_ALL=1 (tests): the first pass hands every read to the second
@@ -381,48 +383,71 @@ __device__ __forceinline__ bool dict_find(const path_graph& G, const uint32_t* r
 #ifndef SNK_PATH_OCC
 #define SNK_PATH_OCC 5
 #endif
-template <int K, int PC, int PM, bool SECOND>
-__global__ void __launch_bounds__(256, SECOND ? 4 : SNK_PATH_OCC) path_kernel(path_args a) {
-    __shared__ uint32_t rowL[16][20];
-    __shared__ ppart partsL[16][PC];
-    __shared__ int32_t pathL[16][PM];
-    __shared__ int32_t resL[16][4];
-    const int lane = threadIdx.x & 63, sub = lane & 15, gsh = lane & 48;       // gsh: first lane of my group
-    const int gw = threadIdx.x >> 4;                                           // group inside the workgroup
+// GS lanes per read (16 or 8): the kernel is latency bound -- a clean read is a chain of ~6 dependent HBM round trips whatever the
+// number of lanes that wait for them -- so eight lanes per read put twice as many reads in flight per wave (round 3: 134 -> see DESIGN);
+// the full-capacity second pass keeps sixteen (its parts take 29 KB of LDS per sixteen reads).
+// MODE 0 "fast": every read, but only as far as a clean read goes -- first k-mer found, exact-match run to the end of the read;
+//        anything else (a miss, a run that ends early) marks the read (gm = 0xFE) and moves on.  Four reads share a wave and the
+//        wave takes the time of its slowest: with one read in four carrying an error, 70 % of the waves paid an error read's
+//        ~2000 instructions for all four (profiles/r02_pmc_path_instmix.csv); now the clean three quarters cost ~500 each wave
+//        and the rest are pathed together, where every group of a wave has the same kind of work.
+// MODE 1 "slow": the reads of a list (a.slow), the whole algorithm, small capacities.   MODE 2: the full-capacity pass over the
+// redo list.   MODE 3: every read, the whole algorithm (SNK_PATH_TWO_PASS=0 / the fused variant).
+template <int K, int PC, int PM, int MODE, int GS>
+__global__ void __launch_bounds__(256, MODE == 2 ? 4 : SNK_PATH_OCC) path_kernel(path_args a) {
+    constexpr bool SECOND = MODE == 2;
+    constexpr int NG = 256 / GS;                      // reads per workgroup
+    constexpr uint32_t GM = GS == 16 ? 0xFFFFu : 0xFFu;
+    constexpr uint32_t EPL = 128 / GS;                // bases per lane and extension step
+    __shared__ uint32_t rowL[NG][20];
+    __shared__ ppart partsL[NG][PC];
+    __shared__ int32_t pathL[NG][PM];
+    __shared__ int32_t resL[NG][4];
+    const int lane = threadIdx.x & 63, sub = lane & (GS - 1), gsh = lane & (64 - GS);       // gsh: first lane of my group
+    const int gw = threadIdx.x / GS;                                           // group inside the workgroup
     const path_graph& G = a.G;
     uint32_t* row = rowL[gw];
     ppart* parts = partsL[gw];
-    const uint64_t ng = (uint64_t)gridDim.x * 16;
-    const uint64_t n_items = SECOND ? a.n_redo : a.n_reads;
-    for (uint64_t r0 = (uint64_t)blockIdx.x * 16; r0 < n_items; r0 += ng) {
+    const uint64_t ng = (uint64_t)gridDim.x * NG;
+    const uint64_t n_items = SECOND ? a.n_redo : (MODE == 1 ? a.n_slow : a.n_reads);
+    for (uint64_t r0 = (uint64_t)blockIdx.x * NG; r0 < n_items; r0 += ng) {
         const bool live = r0 + gw < n_items;
-        const uint64_t r = SECOND ? (live ? (uint64_t)a.redo[r0 + gw] : 0ull) : r0 + gw;
+        const uint64_t r = SECOND ? (live ? (uint64_t)a.redo[r0 + gw] : 0ull) : (MODE == 1 ? (live ? (uint64_t)a.slow[r0 + gw] : 0ull) : r0 + gw);
         uint32_t n = 0;
         if (live) {
             n = a.lens ? a.lens[r] : a.read_len;
             if (n > a.read_len) n = a.read_len;
-            row[sub] = (uint32_t)sub < a.row_words ? a.rows[r * a.row_words + sub] : 0u;
-            if (sub < 4) row[16 + sub] = 0u;
+            for (uint32_t w = (uint32_t)sub; w < 20u; w += GS) row[w] = w < a.row_words ? a.rows[r * a.row_words + w] : 0u;
         }
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
         // ---- Pather::path :705-748
         int m = 0;
-        bool overflow = false;
+        bool overflow = false, deferred = false;
+        uint32_t resume_i = 0;
+        if (MODE == 1 && live) {              // continue where the fast pass stopped
+            const ppart res = a.gparts[r * GPARTS + 1];
+            resume_i = res.unitig;
+            m = (int)res.off_rc;
+            if (m && sub == 0) parts[0] = a.gparts[r * GPARTS];
+        }
         if (live && n < (uint32_t)K) { if (sub == 0) parts[0] = make_gap(n); m = 1; }
         else if (live) {
             const uint32_t end = n - K + 1;
-            uint32_t i = 0, gap = 0;
-            bool wide = false;                // after a miss the next look-ups go 16 positions at a time
+            uint32_t i = resume_i, gap = 0;
+            // after a miss the next look-ups go 16 positions at a time.  (The slow pass starts that way: where the fast pass stopped,
+            // the k-mer that follows a mismatch ends on the mismatching base; 16 look-ups at once are the same 16 sequential ones.)
+            bool wide = MODE == 1;
             bool exact = false;               // a fingerprint match failed the base check once: this read verifies inside dict_find
             while (i < end) {
                 const uint32_t pos = i + sub;
                 bool hit = false;
                 uint32_t hu = 0, ho = 0, hrc = 0;
                 if (pos < end && (wide || sub == 0)) hit = dict_find<K>(G, row, pos, &hu, &ho, &hrc, exact);
-                const uint32_t hm = (uint32_t)(__ballot(hit) >> gsh) & 0xFFFFu;
+                const uint32_t hm = (uint32_t)(__ballot(hit) >> gsh) & GM;
                 if (!hm) {
-                    const uint32_t step = !wide ? 1u : (end - i < 16u ? end - i : 16u);
+                    if (MODE == 0) { deferred = true; resume_i = i; break; }          // the first k-mer is not on the graph: the slow pass takes the read
+                    const uint32_t step = !wide ? 1u : (end - i < (uint32_t)GS ? end - i : (uint32_t)GS);
                     gap += step; i += step; wide = true;
                     continue;
                 }
@@ -436,12 +461,12 @@ __global__ void __launch_bounds__(256, SECOND ? 4 : SNK_PATH_OCC) path_kernel(pa
                 if (!exact) {
                     // the candidate's K bases against the read's, a few per lane
                     bool okv = true;
-                    for (uint32_t j = (uint32_t)sub; j < (uint32_t)K; j += 16u) {
+                    for (uint32_t j = (uint32_t)sub; j < (uint32_t)K; j += (uint32_t)GS) {
                         const uint32_t eb = off + j;
                         const uint32_t e1 = rc ? (uint32_t)(ub[sz - 1 - eb] ^ 3u) & 3u : (uint32_t)ub[eb] & 3u;
                         if (read_base(row, i + (uint32_t)first + j) != e1) okv = false;
                     }
-                    if ((uint32_t)(__ballot(!okv) >> gsh) & 0xFFFFu) { exact = true; continue; }       // redo this round with verified look-ups
+                    if ((uint32_t)(__ballot(!okv) >> gsh) & GM) { exact = true; continue; }       // redo this round with verified look-ups
                 }
                 wide = false;
                 gap += (uint32_t)first;
@@ -453,8 +478,8 @@ __global__ void __launch_bounds__(256, SECOND ? 4 : SNK_PATH_OCC) path_kernel(pa
                     uint32_t cnt = 0;
                     bool stop = false;
 #pragma unroll
-                    for (uint32_t q = 0; q < 8; ++q) {
-                        const uint32_t ra = a0 + 8u * sub + q, eb = b0 + 8u * sub + q;
+                    for (uint32_t q = 0; q < EPL; ++q) {
+                        const uint32_t ra = a0 + EPL * sub + q, eb = b0 + EPL * sub + q;
                         bool same = false;
                         if (ra < n && eb < sz) {
                             const uint32_t e1 = rc ? (uint32_t)(ub[sz - 1 - eb] ^ 3u) & 3u : (uint32_t)ub[eb] & 3u;
@@ -462,8 +487,8 @@ __global__ void __launch_bounds__(256, SECOND ? 4 : SNK_PATH_OCC) path_kernel(pa
                         }
                         if (!stop) { if (same) ++cnt; else stop = true; }
                     }
-                    const uint32_t mm = (uint32_t)(__ballot(stop) >> gsh) & 0xFFFFu;
-                    if (mm) { const int fl = __ffs((int)mm) - 1; len += 8u * (uint32_t)fl + __shfl(cnt, gsh + fl); break; }
+                    const uint32_t mm = (uint32_t)(__ballot(stop) >> gsh) & GM;
+                    if (mm) { const int fl = __ffs((int)mm) - 1; len += EPL * (uint32_t)fl + __shfl(cnt, gsh + fl); break; }
                     len += 128; a0 += 128; b0 += 128;
                 }
                 if (sub == 0) {
@@ -475,11 +500,23 @@ __global__ void __launch_bounds__(256, SECOND ? 4 : SNK_PATH_OCC) path_kernel(pa
                 if (m > PC) { overflow = true; break; }
                 gap = 0;
                 i += len;
+                if (MODE == 0 && i < end) { deferred = true; resume_i = i; break; }  // the run ended inside the read
             }
             if (gap && !overflow) { if (m < PC) { if (sub == 0) parts[m] = make_gap(gap); ++m; } else overflow = true; }
         }
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
+        if (MODE == 0 && deferred) {
+            // what was found so far travels with the read: the first part (if the first k-mer was on the graph) and where to go on
+            if (sub == 0) {
+                a.gm[r] = 0xFE;
+                if (m) a.gparts[r * GPARTS] = parts[0];
+                ppart res; res.unitig = resume_i; res.off_rc = (uint32_t)m; res.len = 0; res.elen = 0;
+                a.gparts[r * GPARTS + 1] = res;
+            }
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
         // ---- the rest of algorithmTwo + the extension: sequential, the group's first lane
         if (live && sub == 0 && a.bc) {
             // (unitig, barcode) keys of this read -- from the parts as Pather::path left them (finish_path rewrites them)
@@ -545,10 +582,18 @@ __global__ void __launch_bounds__(256, SECOND ? 4 : SNK_PATH_OCC) path_kernel(pa
         if (live) {
             const int np = resL[gw][0];
             const unsigned long long st = ((unsigned long long)(uint32_t)resL[gw][2] << 32) | (uint32_t)resL[gw][1];
-            for (int q = 1 + sub; q < np; q += 16) a.scratch[st + q - 1] = pathL[gw][q];
+            for (int q = 1 + sub; q < np; q += GS) a.scratch[st + q - 1] = pathL[gw][q];
         }
         __builtin_amdgcn_wave_barrier();
     }
+}
+__global__ void __launch_bounds__(256) slow_flag_kernel(const uint8_t* __restrict__ gm, uint64_t n, uint64_t* __restrict__ flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i <= n) flag[i] = (i < n && gm[i] == 0xFE) ? 1ull : 0ull;
+}
+__global__ void __launch_bounds__(256) slow_fill_kernel(const uint8_t* __restrict__ gm, const uint64_t* __restrict__ pos, uint64_t n, uint32_t* __restrict__ list) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && gm[i] == 0xFE) list[pos[i]] = (uint32_t)i;
 }
 // the sequential rest of a read's pathing (algorithmTwo after Pather::path, the extension), one thread per read
 template <int K>
@@ -802,6 +847,7 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
         if ((rc = dev(ctx, n * GPARTS + 1, &gparts, err, errcap)) || (rc = dev(ctx, n + 1, &gm, err, errcap))) return rc;
     }
     uint32_t* redo = nullptr;
+    uint64_t *slow_flag = nullptr, *slow_pos = nullptr;
     uint64_t rcap = n / 64 + 65536;
     for (int attempt = 0; attempt < 3; ++attempt) {
         if (!scratch && (rc = dev(ctx, scap, &scratch, err, errcap))) return rc;
@@ -813,10 +859,34 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
         a.redo = redo; a.redo_cap = rcap; a.n_redo = 0; a.force_redo = snk_env_u32("SNK_PATH_REDO_ALL", 0);
         a.gparts = gparts; a.gm = gm;
         if (n) {
+            // sixteen lanes per read (eight put twice the reads in flight but the kernel is issue bound: 145.6 ms against 134.5)
             uint64_t grid = (n + 15) / 16;
             const uint64_t gmax = (uint64_t)ctx->n_cu * 64;
             if (grid > gmax) grid = gmax;
-            hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, false>), dim3((unsigned)grid), dim3(256), 0, st, a);
+            if (gparts && snk_env_u32("SNK_PATH_TWO_PASS", 1)) {
+                if (snk_env_u32("SNK_PATH_FAST_GS", 8) == 8) {
+                    uint64_t g0 = (n + 31) / 32;
+                    if (g0 > gmax) g0 = gmax;
+                    hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, 0, 8>), dim3((unsigned)g0), dim3(256), 0, st, a);
+                } else hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, 0, 16>), dim3((unsigned)grid), dim3(256), 0, st, a);
+                // the reads it left, in read order
+                if (!slow_flag && ((rc = dev(ctx, n + 2, &slow_flag, err, errcap)) || (rc = dev(ctx, n + 2, &slow_pos, err, errcap)))) return rc;
+                hipLaunchKernelGGL(slow_flag_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, st, gm, n, slow_flag);
+                if ((rc = scan64(ctx, st, slow_flag, slow_pos, n + 1, err, errcap))) return rc;
+                uint64_t n_slow = 0;
+                SNK_HIP_TRY(hipMemcpyAsync(&n_slow, slow_pos + n, 8, hipMemcpyDeviceToHost, st));
+                SNK_HIP_TRY(snk_sync(st));
+                if (n_slow) {
+                    uint32_t* slow;
+                    if ((rc = dev(ctx, n_slow + 1, &slow, err, errcap))) return rc;
+                    hipLaunchKernelGGL(slow_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, gm, slow_pos, n, slow);
+                    a.slow = slow; a.n_slow = n_slow;
+                    uint64_t g1 = (n_slow + 15) / 16;
+                    if (g1 > gmax) g1 = gmax;
+                    hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, 1, 16>), dim3((unsigned)g1), dim3(256), 0, st, a);
+                }
+                out->n_slow = n_slow;
+            } else hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, 3, 16>), dim3((unsigned)grid), dim3(256), 0, st, a);
             if (gparts) {
                 uint64_t g2 = (n + 255) / 256;
                 if (g2 > gmax) g2 = gmax;
@@ -836,7 +906,7 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
             uint64_t grid = (a.n_redo + 15) / 16;
             const uint64_t gmax = (uint64_t)ctx->n_cu * 64;
             if (grid > gmax) grid = gmax;
-            hipLaunchKernelGGL((path_kernel<K, PCAP, PMAX, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
+            hipLaunchKernelGGL((path_kernel<K, PCAP, PMAX, 2, 16>), dim3((unsigned)grid), dim3(256), 0, st, a);
             SNK_HIP_TRY(hipGetLastError());
             SNK_HIP_TRY(hipMemcpyAsync(h_cur, cursor, 32, hipMemcpyDeviceToHost, st));
             SNK_HIP_TRY(snk_sync(st));
