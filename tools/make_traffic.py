@@ -11,10 +11,10 @@ doc = json.loads(out.read_text()) if out.exists() else {}
 entries = doc.get("entries", {})
 
 
-def per_launch(path, counter):
+def per_launch(path, counter, kernel="snk_count_kernel"):
     tot, n, name = 0.0, 0, None
     for r in csv.DictReader(open(path)):
-        if "snk_count_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+        if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter:
             tot += float(r["Counter_Value"]); n += 1; name = r["Kernel_Name"].split("(")[1 if r["Kernel_Name"].startswith("void (") else 0]
     return tot / max(n, 1), n, name
 
@@ -24,8 +24,15 @@ for i in range(0, len(a), 3):
     key, f_csv, w_csv = a[i:i + 3]
     f, nf, name = per_launch(f_csv, "FETCH_SIZE")
     w, nw, _ = per_launch(w_csv, "WRITE_SIZE")
+    pf, _, _ = per_launch(f_csv, "FETCH_SIZE", "snk_msp_kernel")
+    pw, _, _ = per_launch(w_csv, "WRITE_SIZE", "snk_msp_kernel")
     entries[key] = {"FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w, "launches_averaged": [nf, nw],
-                    "count_kernel_hbm_bytes_per_launch": (2 * f + w) * 1024, "source": [Path(f_csv).name, Path(w_csv).name]}
+                    "count_kernel_hbm_bytes_per_launch": (2 * f + w) * 1024,
+                    # the minimiser partition: packed rows streamed in (x2 as above), 32-byte records scattered out (WRITE_SIZE counts the
+                    # half-filled 64-byte sectors in full: 2.1x the payload)
+                    "partition_FETCH_SIZE_KB_per_launch": pf, "partition_WRITE_SIZE_KB_per_launch": pw,
+                    "partition_kernel_hbm_bytes_per_launch": (2 * pf + pw) * 1024,
+                    "source": [Path(f_csv).name, Path(w_csv).name]}
     print(key, entries[key])
 doc = {"note": "HBM bytes per launch of snk_count_kernel = (2 x FETCH_SIZE + WRITE_SIZE) KB from separate rocprofv3 --pmc passes of "
                "bench.py (--steps 1 --warmup 1); FETCH_SIZE x2 = the gfx950 correction for wide coalesced reads (MI355X_MICROARCH.md)",
