@@ -99,14 +99,15 @@ def test_rank_share_sharded_equals_single(rccl_group, K):
 
         e = Engine(0)
         sh = ShardedEngine(e, rccl_group)
+        assert sh.kind == "rccl" and sh.world == 1
         s = sh.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=K))
         assert (s.n_instances, s.n_kmers) == (single["n_inst"], single["nk"])
-        chk2 = _table_props(s.frags.keys, s.frags.counts, s.frags.ctx, s.n_kmers, 3, sorted_keys=False)
+        chk2 = _table_props(s.raw.keys, s.raw.counts, s.raw.ctx, s.n_kmers, 3, sorted_keys=False)
         assert chk2 == chk1
-        u = s.joined
+        u = s.raw
         assert int(u.n_unitigs) == single["nu"]
         off2 = _view(u.unitig_off, int(u.n_unitigs) + 1, "<i8")
-        bases2 = _view(u.unitig_bases, int(u.total_bases), "|u1")
+        bases2 = _view(u.unitig_bases, int(u.unitig_total_bases), "|u1")
         assert torch.equal(off1, off2) and torch.equal(bases1, bases2)
     finally:
         e.close()
