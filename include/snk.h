@@ -76,6 +76,10 @@ void snk_params_default(snk_params* p);
 /* ---- context ------------------------------------------------------------------------------------ */
 int snk_ctx_create(int device, snk_ctx** out, char* err, size_t errcap);
 void snk_ctx_destroy(snk_ctx* ctx);
+/* Give the context's cached, currently unused device memory back to the device (results of the last call stay valid).  The
+ * context keeps its scratch between calls so that a steady stream of equal-sized calls never allocates; a caller that shares
+ * the GPU with another allocator calls this when it changes problem size.  Blocks unused for two calls are dropped anyway. */
+void snk_ctx_trim(snk_ctx* ctx);
 
 /* ---- synthetic linked reads; counter-based, bit-identical host vs device ---------- */
 typedef struct snk_synth_params {

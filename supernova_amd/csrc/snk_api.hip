@@ -93,6 +93,7 @@ int snk_ctx_alloc(snk_ctx* ctx, size_t bytes, void** out, char* err, size_t errc
     if (best >= 0) {
         ctx->blocks[best].used = true;
         ctx->blocks[best].serial = ++ctx->alloc_serial;
+        ctx->blocks[best].epoch = ctx->call_epoch;
         ctx->total_alloc += ctx->blocks[best].bytes;
         if (ctx->total_alloc > ctx->peak_alloc) ctx->peak_alloc = ctx->total_alloc;
         *out = ctx->blocks[best].p;
@@ -107,7 +108,7 @@ int snk_ctx_alloc(snk_ctx* ctx, size_t bytes, void** out, char* err, size_t errc
     }
     if (e != hipSuccess)
         return snk_fail(SNK_E_NOMEM, err, errcap, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-    ctx->blocks.push_back({p, bytes, true, ++ctx->alloc_serial});
+    ctx->blocks.push_back({p, bytes, true, ++ctx->alloc_serial, ctx->call_epoch});
     ctx->total_alloc += bytes;
     if (ctx->total_alloc > ctx->peak_alloc) ctx->peak_alloc = ctx->total_alloc;
     ctx->cached_bytes += bytes;
@@ -133,6 +134,26 @@ void snk_ctx_release_scratch(snk_ctx* ctx) {
     for (auto& b : ctx->blocks) b.used = false;
     ctx->total_alloc = 0;
     ctx->peak_alloc = 0;
+    // A new top-level call.  Blocks that neither of the last two calls took are sizes the caller has moved away from (a
+    // 150 M-read run followed by 15 M-read runs): they go back to the device, where the caller's own allocator may need them.
+    // Steady state (the same sizes call after call) frees nothing.
+    ++ctx->call_epoch;
+    bool stale = false;
+    for (auto& b : ctx->blocks) if (b.epoch + 2 < ctx->call_epoch) stale = true;
+    if (stale) {
+        std::vector<snk_ctx::block> keep;
+        for (auto& b : ctx->blocks) {
+            if (b.epoch + 2 < ctx->call_epoch) { (void)hipFree(b.p); ctx->cached_bytes -= b.bytes; }
+            else keep.push_back(b);
+        }
+        ctx->blocks.swap(keep);
+    }
+}
+extern "C" void snk_ctx_trim(snk_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    snk_ctx_trim_cache(ctx);
 }
 void snk_ctx_trim_cache(snk_ctx* ctx) {
     std::vector<snk_ctx::block> keep;

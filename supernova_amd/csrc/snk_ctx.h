@@ -17,7 +17,8 @@ struct snk_ctx {
     size_t lds_per_block = 65536;
     // caching arena for call-scoped scratch: blocks are handed out by best fit, returned to the cache at the
     // start of the next top-level call (no hipFree/hipMalloc in steady state), released on destroy or OOM
-    struct block { void* p; size_t bytes; bool used; uint64_t serial = 0; };
+    struct block { void* p; size_t bytes; bool used; uint64_t serial = 0; uint64_t epoch = 0; };
+    uint64_t call_epoch = 0;     // top-level calls so far; a cached block no call has taken for two of them is given back to the device
     uint64_t alloc_serial = 0;   // blocks handed out so far (a call's internal scratch = the blocks with a larger serial than at its entry)
     std::vector<block> blocks;
     size_t total_alloc = 0;     // bytes handed out in the current call (minus blocks returned mid-call)

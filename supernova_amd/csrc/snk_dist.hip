@@ -40,10 +40,13 @@ int snk_shard_begin(snk_ctx* ctx, const snk_dev_reads* in, const snk_params* p, 
     S->circ_all = nullptr; S->join_circles = 0;
     const uint16_t* good_len = (const uint16_t*)in->good_len;
     int rc;
+    const bool fused = in->n_reads && snk_fused_trim_ok(in);      // the trim inside the partition kernel (snk_msp.hip)
+    snk_fused_trim ft;
     if (!good_len) {
         void* gl;
         if ((rc = snk_ctx_alloc(ctx, in->n_reads * 2 + 2, &gl, err, errcap))) return rc;
-        if (in->n_reads) {
+        if (fused) { ft.quals = in->quals; ft.qstride = in->qstride; ft.lens = in->lens; ft.min_qual = p->min_qual; ft.good_out = (uint16_t*)gl; }
+        else if (in->n_reads) {
             rc = snk_dev_trim(ctx, in->quals, in->qstride, in->lens, in->read_len, in->n_reads, p->K, p->min_qual, gl, st);
             if (rc) return snk_fail(rc, err, errcap, "%s", snk_last_error());
         }
@@ -58,9 +61,10 @@ int snk_shard_begin(snk_ctx* ctx, const snk_dev_reads* in, const snk_params* p, 
     // capacity is 2.5 x the mean anyway); the exact instance count comes back with the partition's own read-back
     unsigned long long h_plan[2] = {0, 0};
     unsigned long long* d_plan = nullptr;
-    if ((rc = snk_stage_partition_plan(ctx, st, p->K, good_len, in->n_reads, h_plan, err, errcap, &d_plan))) return rc;
+    if (!fused && (rc = snk_stage_partition_plan(ctx, st, p->K, good_len, in->n_reads, h_plan, err, errcap, &d_plan))) return rc;
     const unsigned long long kpr = in->read_len >= p->K ? in->read_len - p->K + 1 : 0;
-    if ((rc = snk_stage_partition(ctx, st, p->K, in, good_len, NB_total, in->n_reads * kpr, in->n_reads, false, S->status, &S->part, err, errcap, d_plan, h_plan))) return rc;
+    if ((rc = snk_stage_partition(ctx, st, p->K, in, good_len, NB_total, in->n_reads * kpr, in->n_reads, false, S->status, &S->part, err, errcap, d_plan, h_plan,
+                                  fused ? &ft : nullptr))) return rc;
     if (n_instances) *n_instances = h_plan[0];
     return SNK_OK;
 }

@@ -31,7 +31,15 @@ struct snk_msp_args {
     uint32_t* ovf_bucket;          // [ovf_cap] bucket of every overflow record
     uint32_t* ovf_cursor;          // [1] overflow records wanted (keeps counting past ovf_cap)
     uint32_t dbg;                  // profiling aid (results invalid): 1 = no record stores, 2 = no slot atomics
+    // fused quality trim (quals != NULL): the kernel derives every read's good length itself (the rule of snk_trim.hip), writes
+    // it to good_out and adds the k-mer instances / contributing reads of its waves to plan[2 * (wave % 256) + {0, 1}]
+    const uint8_t* quals;
+    uint32_t qstride, min_qual;
+    const uint16_t* lens;
+    uint16_t* good_out;
+    unsigned long long* plan;
 };
+constexpr int SNK_MSP_PLAN_SLOTS = 256;
 int snk_launch_msp(uint32_t K, hipStream_t st, const snk_msp_args& a, char* err, size_t errcap);
 int snk_launch_msp_plan(hipStream_t st, const uint16_t* good_len, uint64_t n_reads, uint32_t K, unsigned long long* out2,
                         char* err, size_t errcap);

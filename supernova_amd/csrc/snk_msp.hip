@@ -67,12 +67,138 @@ __device__ __forceinline__ uint32_t row_window(const uint32_t* rowL, int tid, ui
     return s ? ((w0 << s) | (w1 >> (32u - s))) : w0;
 }
 
+
+// ---- fused quality trim (K1 inside the partition kernel) ----------------------------------------------------------
+// The rule is snk_trim.hip's (GoodLenTailFinder, BuildReadQGraph48.cc:65-89): from the 3' end, the first run of K
+// quals >= min_qual ends the scan, good length = run start + K.  A read whose last K quals are all good -- nearly all --
+// is decided by K/4 + 1 words of its row.  The row of any other lane is read by its wave, a lane per word (one coalesced
+// load), the good-qual bits of the four byte positions are collected by ballots, and the highest run of K good bases falls
+// out of a few 64-bit shift-ands in scalar registers.  No workgroup barrier, no LDS.
+// The separate trim kernel streamed 15 GB in 3 ms with nothing else to do; here the loads ride under the slot atomics.
+__device__ __forceinline__ uint32_t qual_ge4(uint32_t x, uint32_t y4) {       // bit 7 of every byte: x.byte >= y.byte (unsigned)
+    const uint32_t H = 0x80808080u;
+    const uint32_t t = (x | H) - (y4 & ~H);
+    return ((x & ~y4) | (~(x ^ y4) & t)) & H;
+}
+// Good length from the four byte planes of a quality row (bit j of P[b]: base 4j + b has a good qual), all wave-uniform:
+// a run of K = 4q good bases from base 4 j0 + b0 is q good words from j0 in the planes b >= b0 and from j0 + 1 in the others.
+template <int K>
+__device__ __forceinline__ int trim_from_planes(uint64_t P0, uint64_t P1, uint64_t P2, uint64_t P3, int len) {
+    constexpr int q = K / 4;
+    static_assert(q >= 8 && q <= 16, "run ladder below");
+    uint64_t R[4] = {P0, P1, P2, P3};
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int n = (len - b + 3) >> 2;                 // words whose byte b lies inside the read
+        uint64_t r = n <= 0 ? 0ull : (n >= 64 ? R[b] : (R[b] & ((1ull << n) - 1ull)));
+        r &= r >> 1; r &= r >> 2; r &= r >> 4;             // runs of 8 words
+        r &= r >> (q - 8);                                 // runs of q
+        R[b] = r;
+    }
+    int best = -1;
+#pragma unroll
+    for (int b0 = 0; b0 < 4; ++b0) {
+        uint64_t c = ~0ull;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) c &= (b >= b0) ? R[b] : (R[b] >> 1);
+        if (c) { const int p = 4 * (63 - __clzll((long long)c)) + b0; best = p > best ? p : best; }
+    }
+    return best < 0 ? 0 : best + K;
+}
+
+// One call per thread at the top of the partition kernel; NOT inlined: the kernel's own register allocation (96 VGPRs, tuned
+// spills) stays what it is without the trim.
+template <int K>
+__device__ __forceinline__ int fused_trim(const snk_msp_args& a, int tid0, uint64_t r0) {
+    int g_trim = 0;
+        const uint64_t rq = r0 + tid0;
+        int qlen = 0;
+        const uint32_t* qrow = nullptr;
+        if (rq < a.n_reads) {
+            qlen = a.lens ? (int)a.lens[rq] : (int)a.read_len;
+            if (qlen > (int)a.read_len) qlen = (int)a.read_len;
+            qrow = reinterpret_cast<const uint32_t*>(a.quals + rq * (uint64_t)a.qstride);
+        }
+        const uint32_t mq4 = (a.min_qual > 255u ? 255u : a.min_qual) * 0x01010101u;
+        // step 1: the last K quals of every row of the wave, 16 bytes per lane: four lanes cover a row's window (64 contiguous
+        // bytes), a wave instruction covers 16 rows.  (A lane reading its own row's 13 words cost the kernel 5.5 ms: it pays per
+        // memory request.)  A window without a low qual decides the read.
+        const int lane = tid0 & 63;
+        const uint8_t* wave_rows = a.quals + (r0 + (uint64_t)(tid0 & ~63)) * a.qstride;
+        const int rw_all = (int)(a.qstride >> 2);
+        uint32_t mybad = 0;
+        {
+            struct __attribute__((packed, aligned(4))) q16 { uint32_t w[4]; };
+            q16 xv[4];
+            int st[4], lo_[4], ql_[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int R = 16 * it + (lane >> 2);
+                ql_[it] = __builtin_amdgcn_ds_bpermute(4 * R, qlen);      // (explicit addresses off tid0: nothing here is shared with the code behind the trim)
+                lo_[it] = ql_[it] - K;
+                int start = (lo_[it] >> 2) + 4 * (lane & 3);
+                if (start + 4 > rw_all) start = rw_all - 4;
+                st[it] = start;
+                xv[it].w[0] = xv[it].w[1] = xv[it].w[2] = xv[it].w[3] = 0xFFFFFFFFu;
+                if (lo_[it] >= 0) xv[it] = *reinterpret_cast<const q16*>(wave_rows + (uint64_t)R * a.qstride + 4 * start);
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                uint32_t bad = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int j4 = 4 * (st[it] + k);
+                    int lb = lo_[it] - j4, hb = ql_[it] - j4;                 // bytes [lb, hb) of this word lie inside the window
+                    lb = lb < 0 ? 0 : (lb > 4 ? 4 : lb);
+                    hb = hb < 0 ? 0 : (hb > 4 ? 4 : hb);
+                    const uint32_t below_h = hb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * hb)) - 1u);
+                    const uint32_t below_l = lb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * lb)) - 1u);
+                    bad |= ~qual_ge4(xv[it].w[k], mq4) & 0x80808080u & below_h & ~below_l;
+                }
+                if (lo_[it] < 0) bad = 0;
+                bad |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bad, 0xB1, 0xF, 0xF, false);     // quad_perm [1,0,3,2]
+                bad |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bad, 0x4E, 0xF, 0xF, false);     // quad_perm [2,3,0,1]
+                const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute(16 * (lane & 15), (int)bad);
+                if ((lane >> 4) == it) mybad = v;
+            }
+        }
+        bool scan = false;
+        if (qlen >= K && a.min_qual <= 255u) { g_trim = qlen; scan = mybad != 0u; }
+#ifndef SNK_FT_NOSLOW
+        // step 2: the rows that need the scan, one after the other, by the whole wave (four rows' loads in flight)
+        unsigned long long todo = __ballot(scan);
+        const uint32_t rw = (a.qstride >> 2) < 40u ? (a.qstride >> 2) : 40u;     // words of a row that can matter (read_len <= 160)
+        while (todo) {
+            int own[4];
+            uint32_t x[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                own[i] = todo ? __ffsll((long long)todo) - 1 : -1;
+                if (own[i] >= 0) todo &= todo - 1ull;
+                x[i] = 0u;
+                if (own[i] >= 0 && (uint32_t)lane < rw) x[i] = reinterpret_cast<const uint32_t*>(wave_rows + (uint64_t)own[i] * a.qstride)[lane];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (own[i] < 0) break;
+                const uint32_t gq = ((uint32_t)lane < rw) ? qual_ge4(x[i], mq4) : 0u;
+                const uint64_t P0 = __ballot((gq >> 7) & 1u), P1 = __ballot((gq >> 15) & 1u), P2 = __ballot((gq >> 23) & 1u), P3 = __ballot((gq >> 31) & 1u);
+                const int len_o = __builtin_amdgcn_readlane(qlen, own[i]);
+                const int g_o = trim_from_planes<K>(P0, P1, P2, P3, len_o);
+                if (lane == own[i]) g_trim = g_o;
+            }
+        }
+#endif
+        if (rq < a.n_reads) a.good_out[rq] = (uint16_t)g_trim;
+    return g_trim;
+}
+
 // Occupancy is what overlaps one wave's emit loop (slot atomics, scattered stores: device throughput limits) with other
 // waves' scans: 26.8 KB of LDS admit five workgroups per CU, and at K=48 the kernel fits 96 VGPRs with two spills
 // (36.0 -> 33.0 ms at 1e8 reads against the 105 registers / four waves per SIMD the compiler picks on its own).  Keeping
 // the minimisers' keys in a second LDS list to save their re-derivation in the emit loop costs the fifth workgroup and
 // was dropped again; six waves per SIMD (80 VGPRs) spill 28 registers.  K=60 (45 keys in registers) stays at four.
-template <int K, int M>
+template <int K, int M, bool TRIM>
 __global__ void __launch_bounds__(BD, K == 48 ? 5 : 4) snk_msp_kernel(snk_msp_args a) {
     constexpr int W = K - M + 1;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -83,8 +209,19 @@ __global__ void __launch_bounds__(BD, K == 48 ? 5 : 4) snk_msp_kernel(snk_msp_ar
     // Only the POSITION of every suffix minimum is kept in LDS (1 byte per entry); the keys live in registers.
     uint16_t* lst = reinterpret_cast<uint16_t*>(rowL + (size_t)(row_words + 1) * BD);   // [LCAP][BD] minimiser position << 8 | first k-mer
     uint8_t* sfxp = reinterpret_cast<uint8_t*>(lst + (size_t)LCAP * BD);  // [W][BD] position of the suffix minimum
-    const int tid = threadIdx.x;
+    const int tid0 = threadIdx.x;
     const uint64_t r0 = (uint64_t)blockIdx.x * BD;
+    // fused trim: finished before the rows are staged (its registers are free again when the staging loads go out; live
+    // across them they cost spills whose reloads serialise those loads)
+    static_assert(K % 4 == 0 && K >= 32 && K < 96, "the window below is K/4 + 1 aligned words");
+    // (the length goes through good_out and is read back below where the kernel without the trim reads good_len: everything
+    // of the trim is dead before the staging, and the body behind it compiles as it does without -- carried in a register it
+    // is spilled, and reloaded from scratch in every turn of the emit loop: +5 ms)
+    if (TRIM) (void)fused_trim<K>(a, tid0, r0);
+    // (a fresh value behind the trim: the register allocator would otherwise carry the thread id through it in scratch and reload
+    // it before every staging load below, one load in flight at a time)
+    int tid = tid0;
+    if (TRIM) asm volatile("" : "+v"(tid) :: "memory");
     // coalesced stage of the workgroup's rows
     {
         uint64_t nrows = n_reads - r0 < (uint64_t)BD ? n_reads - r0 : (uint64_t)BD;
@@ -109,11 +246,22 @@ __global__ void __launch_bounds__(BD, K == 48 ? 5 : 4) snk_msp_kernel(snk_msp_ar
     rowL[row_words * BD + tid] = 0u;
     __syncthreads();
     const uint64_t r = r0 + tid;
-    int g = (r < n_reads) ? (int)a.good_len[r] : 0;
+    int g;
+    g = (r < n_reads) ? (int)a.good_len[r] : 0;        // (fused trim: good_len == good_out, written above by this thread)
     if (g > (int)a.read_len) g = (int)a.read_len;     // a caller-supplied good length never reaches past the packed row
     if (g < K + 1) g = 0;                               // reads with fewer than 2 k-mers are skipped (:160)
     const int nk = g ? g - K + 1 : 0;
     const int npos = g ? g - M + 1 : 0;
+    if (TRIM) {
+        // the sizing figures of snk_msp_plan_kernel, per wave, spread over SNK_MSP_PLAN_SLOTS counters (same-address atomics queue)
+        unsigned long long inst = (unsigned long long)nk, live = g ? 1ull : 0ull;
+        for (int off = 32; off > 0; off >>= 1) { inst += __shfl_xor(inst, off); live += __shfl_xor(live, off); }
+        if ((tid & 63) == 0 && live) {
+            const uint32_t slot = (blockIdx.x * (BD / 64) + (tid >> 6)) % SNK_MSP_PLAN_SLOTS;
+            atomicAdd(&a.plan[2 * slot], inst);
+            atomicAdd(&a.plan[2 * slot + 1], live);
+        }
+    }
     int32_t mybc = 0;
     // word 7 of a record is the barcode STATE the count kernel starts from: 0 none, id > 0, 0xFFFFFFFF (-1) a read under the
     // ignore rule; other non-positive ids count as none (areEnoughBarcodes only looks at ids > 0, BuildReadQGraph48.cc:117-137)
@@ -329,14 +477,23 @@ size_t snk_msp_lds_bytes(uint32_t K, uint32_t M, uint32_t row_words) {
     return (size_t)(row_words + 1) * BD * 4 + (size_t)LCAP * BD * 2 + (size_t)(K - M + 1) * BD + 64;
 }
 
-template <int K, int M>
-static int launch_msp_k(hipStream_t st, const snk_msp_args& a, char* err, size_t errcap) {
+template <int K, int M, bool TRIM>
+static int launch_msp_kt(hipStream_t st, const snk_msp_args& a, char* err, size_t errcap) {
     size_t lds = snk_msp_lds_bytes(K, M, a.row_words);
     unsigned nb = (unsigned)((a.n_reads + BD - 1) / BD);
-    SNK_HIP_TRY(hipFuncSetAttribute((const void*)snk_msp_kernel<K, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((snk_msp_kernel<K, M>), dim3(nb), dim3(BD), lds, st, a);
+    SNK_HIP_TRY(hipFuncSetAttribute((const void*)snk_msp_kernel<K, M, TRIM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((snk_msp_kernel<K, M, TRIM>), dim3(nb), dim3(BD), lds, st, a);
     SNK_HIP_TRY(hipGetLastError());
     return SNK_OK;
+}
+template <int K, int M>
+static int launch_msp_k(hipStream_t st, const snk_msp_args& a, char* err, size_t errcap) {
+    if (a.quals) {
+        if (!a.good_out || !a.plan || (a.qstride & 3u) || (((uintptr_t)a.quals) & 3u) || a.read_len > 160)
+            return snk_fail(SNK_E_ARG, err, errcap, "fused trim: needs good_out, plan, 4-byte aligned quality rows and read_len <= 160");
+        return launch_msp_kt<K, M, true>(st, a, err, errcap);
+    }
+    return launch_msp_kt<K, M, false>(st, a, err, errcap);
 }
 
 int snk_launch_msp(uint32_t K, hipStream_t st, const snk_msp_args& a, char* err, size_t errcap) {

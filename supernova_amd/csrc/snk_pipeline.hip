@@ -59,20 +59,27 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     phase_timer tm(st);
     tm.mark();  // 0
 
-    // ---- K1 trim
+    // ---- K1 trim: inside the partition kernel when the quality rows allow it (its loads ride under the slot reservations),
+    // else its own streaming kernel
     const uint16_t* good_len = (const uint16_t*)in->good_len;
+    const bool fused = n_reads && snk_fused_trim_ok(in);
+    snk_fused_trim ft;
     if (!good_len && n_reads) {
         void* gl = nullptr;
         int rc = snk_ctx_alloc(ctx, n_reads * 2 + 2, &gl, err, errcap);
         if (rc) return rc;
-        rc = snk_dev_trim(ctx, in->quals, in->qstride, in->lens, in->read_len, n_reads, K, p->min_qual, gl, st);
-        if (rc) return snk_fail(rc, err, errcap, "%s", snk_last_error());
+        if (fused) { ft.quals = in->quals; ft.qstride = in->qstride; ft.lens = in->lens; ft.min_qual = p->min_qual; ft.good_out = (uint16_t*)gl; }
+        else {
+            rc = snk_dev_trim(ctx, in->quals, in->qstride, in->lens, in->read_len, n_reads, K, p->min_qual, gl, st);
+            if (rc) return snk_fail(rc, err, errcap, "%s", snk_last_error());
+        }
         good_len = (const uint16_t*)gl;
     }
     out->good_len = good_len;
     tm.mark();  // 1
 
     // ---- K3/K4 minimiser partition in ONE pass: exact k-mer instance count -> expected supermers -> fixed bucket capacity
+    // (fused trim: the count is not known yet; every base of every read is the bound, a few per cent above what the trim leaves)
     uint32_t* status = nullptr;
     {
         void* q;
@@ -81,9 +88,15 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     }
     SNK_HIP_TRY(hipMemsetAsync(status, 0, 64, st));
     unsigned long long h_plan[2] = {0, 0};
-    int rc = snk_stage_partition_plan(ctx, st, K, good_len, n_reads, h_plan, err, errcap);
+    int rc = SNK_OK;
+    if (fused) {
+        const unsigned long long kpr = in->read_len >= K ? in->read_len - K + 1 : 0;
+        h_plan[0] = n_reads * kpr;
+        h_plan[1] = n_reads;
+    } else
+        rc = snk_stage_partition_plan(ctx, st, K, good_len, n_reads, h_plan, err, errcap);
     if (rc) return rc;
-    const unsigned long long h_ninst = h_plan[0];
+    unsigned long long h_ninst = h_plan[0];
     out->n_instances = h_ninst;
     uint32_t NB = p->n_buckets;
     if (NB == 0) {
@@ -107,8 +120,11 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     out->n_buckets = NB;
     tm.mark();  // 2
     snk_partition part;
-    rc = snk_stage_partition(ctx, st, K, in, good_len, NB, h_plan[0], h_plan[1], grouped, status, &part, err, errcap);
+    rc = snk_stage_partition(ctx, st, K, in, good_len, NB, h_plan[0], h_plan[1], grouped, status, &part, err, errcap, nullptr, fused ? h_plan : nullptr,
+                             fused ? &ft : nullptr);
     if (rc) return rc;
+    h_ninst = h_plan[0];               // (fused trim: now the exact count)
+    out->n_instances = h_ninst;
     void* records = part.records;
     uint64_t* seg = part.seg;
     const uint32_t nseg = part.nseg;

@@ -65,9 +65,17 @@ struct snk_partition {
 int snk_stage_partition_plan(snk_ctx* ctx, hipStream_t st, uint32_t K, const uint16_t* good_len, uint64_t n_reads,
                              unsigned long long h_plan[2] /* instances, contributing reads */, char* err, size_t errcap,
                              unsigned long long** d_plan_out = nullptr /* given: no read-back, the device counters are returned */);
+// The quality trim inside the partition kernel: no trim kernel, no plan kernel; n_inst / n_live are then the caller's upper bounds
+// (all bases of all reads) and the exact figures come back in h_plan with the pass's read-back.
+struct snk_fused_trim {
+    const void* quals; uint32_t qstride; const void* lens; uint32_t min_qual;
+    uint16_t* good_out;            // [n_reads] the good lengths, as snk_dev_trim writes them
+};
+bool snk_fused_trim_ok(const snk_dev_reads* in);
 int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_reads* in, const uint16_t* good_len, uint32_t NB,
                         unsigned long long n_inst, unsigned long long n_live, bool grouped, uint32_t* status, snk_partition* out,
-                        char* err, size_t errcap, const unsigned long long* d_plan = nullptr, unsigned long long* h_plan = nullptr);
+                        char* err, size_t errcap, const unsigned long long* d_plan = nullptr, unsigned long long* h_plan = nullptr,
+                        const snk_fused_trim* ft = nullptr);
 // sharded runs: the buckets' records copied to exact offsets (u32 record index per bucket) of a compact buffer
 int snk_stage_partition_compact(snk_ctx* ctx, hipStream_t st, const snk_partition* part, const uint32_t* d_offsets, void* d_out, char* err, size_t errcap);
 int snk_stage_partition_compact_remote(snk_ctx* ctx, hipStream_t st, const snk_partition* part, const uint32_t* d_offsets, void* d_out,

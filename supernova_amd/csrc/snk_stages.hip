@@ -281,9 +281,14 @@ int snk_stage_partition_plan(snk_ctx* ctx, hipStream_t st, uint32_t K, const uin
     return SNK_OK;
 }
 
+bool snk_fused_trim_ok(const snk_dev_reads* in) {
+    return in->quals && !in->good_len && (in->qstride & 3u) == 0 && (((uintptr_t)in->quals) & 3u) == 0 && in->read_len <= 160 && in->qstride >= in->read_len &&
+           (!in->lens || (((uintptr_t)in->lens) & 1u) == 0) && env_u32("SNK_TRIM_FUSED", 1) != 0;
+}
+
 int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_reads* in, const uint16_t* good_len, uint32_t NB,
                         unsigned long long n_inst, unsigned long long n_live, bool grouped, uint32_t* status, snk_partition* out,
-                        char* err, size_t errcap, const unsigned long long* d_plan, unsigned long long* h_plan) {
+                        char* err, size_t errcap, const unsigned long long* d_plan, unsigned long long* h_plan, const snk_fused_trim* ft) {
     memset(out, 0, sizeof *out);
     const uint64_t n_reads = in->n_reads;
     const uint32_t Wm = K - SNK_M + 1;
@@ -312,6 +317,15 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
         if ((rc = snk_ctx_alloc(ctx, 4ull * NB * 8 + 64, &q, err, errcap))) return rc; seg = (uint64_t*)q;
         if ((rc = snk_ctx_alloc(ctx, 64, &q, err, errcap))) return rc; d_total = (unsigned long long*)q;
     }
+    // fused trim: the kernel's own sizing counters (the exact instance count comes back with the pass's read-back)
+    unsigned long long* d_fplan = nullptr;
+    std::vector<unsigned long long> h_fplan;
+    if (ft) {
+        void* q;
+        if (!h_plan) return snk_fail(SNK_E_ARG, err, errcap, "fused trim: the caller takes the instance count from h_plan");
+        if ((rc = snk_ctx_alloc(ctx, 2ull * SNK_MSP_PLAN_SLOTS * 8, &q, err, errcap))) return rc; d_fplan = (unsigned long long*)q;
+        h_fplan.resize(2 * SNK_MSP_PLAN_SLOTS);
+    }
     snk_phase_timer kt(st);
     void* records = nullptr;
     uint32_t* ovf_bucket = nullptr;
@@ -332,6 +346,11 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
         ma.cursor = cursor; ma.records = (uint4*)records; ma.cap = cap; ma.ovf_cap = (uint32_t)ovf_cap;
         ma.ovf_base = (uint64_t)NB * cap; ma.ovf_bucket = ovf_bucket; ma.ovf_cursor = status + 8;
         ma.dbg = env_u32("SNK_MSP_DBG", 0);
+        if (ft) {
+            ma.good_len = ft->good_out; ma.quals = (const uint8_t*)ft->quals; ma.qstride = ft->qstride; ma.min_qual = ft->min_qual;
+            ma.lens = (const uint16_t*)ft->lens; ma.good_out = ft->good_out; ma.plan = d_fplan;
+            SNK_HIP_TRY(hipMemsetAsync(d_fplan, 0, 2ull * SNK_MSP_PLAN_SLOTS * 8, st));
+        }
         kt.n = 0;
         kt.mark();  // 0
         if ((rc = snk_launch_msp(K, st, ma, err, errcap))) return rc;
@@ -342,8 +361,13 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
         hipLaunchKernelGGL(seg0_kernel, dim3((NB + 255) / 256), dim3(256), 0, st, cursor, NB, cap, seg, d_total);
         SNK_HIP_TRY(hipMemcpyAsync(&h_novf, status + 8, 4, hipMemcpyDeviceToHost, st));
         SNK_HIP_TRY(hipMemcpyAsync(&h_total, d_total, 8, hipMemcpyDeviceToHost, st));
-        if (d_plan && h_plan) SNK_HIP_TRY(hipMemcpyAsync(h_plan, d_plan, 16, hipMemcpyDeviceToHost, st));
+        if (d_plan && h_plan && !ft) SNK_HIP_TRY(hipMemcpyAsync(h_plan, d_plan, 16, hipMemcpyDeviceToHost, st));
+        if (ft) SNK_HIP_TRY(hipMemcpyAsync(h_fplan.data(), d_fplan, h_fplan.size() * 8, hipMemcpyDeviceToHost, st));
         SNK_HIP_TRY(snk_sync(st));
+        if (ft) {
+            h_plan[0] = h_plan[1] = 0;
+            for (int q = 0; q < SNK_MSP_PLAN_SLOTS; ++q) { h_plan[0] += h_fplan[2 * q]; h_plan[1] += h_fplan[2 * q + 1]; }
+        }
         if (h_novf <= ovf_cap) break;
         if (attempt == 2) return snk_fail(SNK_E_INTERNAL, err, errcap, "supermer overflow list too small (%u > %llu)", h_novf, (unsigned long long)ovf_cap);
         snk_ctx_release_block(ctx, records);

@@ -201,6 +201,10 @@ class Engine:
             raise _lib.SnkError(rc, err.value.decode(errors="replace"))
         self._ctx = h
 
+    def release_cache(self):
+        """Hand the context's cached, unused device memory back (snk_ctx_trim): for callers that change problem size and share the GPU."""
+        self.lib.snk_ctx_trim(self._ctx)
+
     def close(self):
         if getattr(self, "_ctx", None):
             self.lib.snk_ctx_destroy(self._ctx)

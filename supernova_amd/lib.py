@@ -180,6 +180,7 @@ def _declare(lib: C.CDLL) -> None:
         "snk_params_default": (None, [P(SnkParams)]),
         "snk_ctx_create": (C.c_int, [C.c_int, P(vp), cp, sz]),
         "snk_ctx_destroy": (None, [vp]),
+        "snk_ctx_trim": (None, [vp]),
         "snk_synth_default": (None, [P(SnkSynthParams), u64, u64, C.c_int]),
         "snk_synth_host": (C.c_int, [P(SnkSynthParams), u64, u64, vp, u32, vp, u32, vp]),
         "snk_synth_dev": (C.c_int, [vp, P(SnkSynthParams), u64, u64, vp, u32, vp, u32, vp, vp]),

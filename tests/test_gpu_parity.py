@@ -143,6 +143,53 @@ def test_pack_ascii_and_trim_kernels(engine):
             assert np.array_equal(g.astype(np.uint32), oracle_lib.good_lens(c.quals[:n], c.lens[:n], K=K, min_qual=mq))
 
 
+@pytest.mark.parametrize("K", [48, 60])
+def test_trim_inside_the_partition_kernel(engine, K, monkeypatch):
+    """Quality rows padded to 4 bytes are trimmed by the partition kernel itself (snk_msp.hip, fused trim): the good lengths
+    and the instance count it reports must be the trim kernel's / the oracle's (GoodLenTailFinder, BuildReadQGraph48.cc:65-89)
+    on clean reads (decided by their last K quals), on reads with low-quality tails and on rows of noise (the bit-mask scan),
+    with ragged lengths, and the counted table must not depend on where the trim ran."""
+    import torch
+    from supernova_amd import synth
+    from supernova_amd.engine import Params
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(17 + K)
+    n, L = 3001, 150
+    codes = rng.integers(0, 4, (n, L), dtype=np.uint8)
+    codes[1000:] = codes[rng.integers(0, 1000, n - 1000)]           # repeated reads: something survives min_freq
+    rows = torch.from_numpy(synth.pack_rows(codes).view(np.int32)).to(dev)
+    quals = np.full((n, 152), 30, dtype=np.uint8)
+    quals[:, 150:] = rng.integers(0, 3, (n, 2))                      # padding: garbage below every threshold
+    kind = rng.integers(0, 6, n)
+    for i in range(n):
+        if kind[i] == 1: quals[i, L - rng.integers(1, 120):L] = 2                       # a low-quality tail
+        elif kind[i] == 2: quals[i, :L] = rng.integers(0, 41, L)                        # noise
+        elif kind[i] == 3: quals[i, rng.integers(0, L, 3)] = rng.integers(0, 12, 3)     # a few dips
+        elif kind[i] == 4: quals[i, L - K - rng.integers(0, 4)] = 0                     # a dip right at the window's edge
+    lens = np.full(n, L, dtype=np.uint16)
+    ragged = rng.random(n) < 0.3
+    lens[ragged] = rng.integers(0, L + 1, int(ragged.sum()))
+    lens[:4] = (0, K - 1, K, K + 1)
+    qd = torch.from_numpy(quals).to(dev)
+    ld = torch.from_numpy(lens.view(np.int16)).to(dev)
+    for mq in (0, 7, 20, 31, 255):
+        want = oracle_lib.good_lens(quals[:, :L], lens, K=K, min_qual=mq)
+        params = Params(K=K, min_freq=2, min_qual=mq)
+        got = {}
+        for fused in ("1", "0"):
+            monkeypatch.setenv("SNK_TRIM_FUSED", fused)
+            res = engine.count_graph(rows, L, quals=qd, lens=ld, params=params)
+            gl = res.good_len().astype(np.uint32)
+            assert np.array_equal(gl, want), (mq, fused, np.flatnonzero(gl != want)[:8])
+            assert res.n_instances == int(np.where(want >= K + 1, want - K + 1, 0).sum())
+            keys, counts = res.keys(), res.counts()
+            order = np.lexsort(tuple(keys[:, j] for j in range(keys.shape[1])))
+            got[fused] = (keys[order], counts[order], res.n_unitigs)
+        assert np.array_equal(got["1"][0], got["0"][0]) and np.array_equal(got["1"][1], got["0"][1]) and got["1"][2] == got["0"][2]
+        g2 = engine.trim(qd, L, K=K, min_qual=mq, lens=ld).cpu().numpy().view(np.uint16)
+        assert np.array_equal(g2.astype(np.uint32), want)
+
+
 @pytest.mark.parametrize("name,use_bc", [("adversarial", True), ("synth_20k_err", False)])
 def test_k60_vs_oracle(engine, name, use_bc):
     """K=60 (long-k config): key 120 bit, supermers up to 106 bases.  The reference's BuildReadQGraph60 has no barcode
