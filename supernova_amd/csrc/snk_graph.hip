@@ -681,38 +681,41 @@ static int rank_lists(snk_ctx* ctx, hipStream_t st, uint32_t* link, uint64_t n, 
     // pointer jumping on the splitter list
     uint32_t* flags;
     G_ALLOC(flags, uint32_t, 4);
-    uint32_t h_flag = 0;
     int max_rounds = 2;
     while ((1ull << (max_rounds - 1)) < m + 1) ++max_rounds;
     int cur = 0;
     uint32_t r_done = 0;
-    bool converged = (m == 0);
-    for (int r = 0; r < max_rounds && !converged; ++r) {
-        SNK_HIP_TRY(hipMemsetAsync(flags, 0, 4, st));
-        hipLaunchKernelGGL(rank_round_kernel, dim3(nblk(m)), dim3(TB), 0, st, rn[cur], rd[cur], rt[cur], m, rn[cur ^ 1], rd[cur ^ 1], rt[cur ^ 1], flags);
-        cur ^= 1;
-        ++r_done;
-        SNK_HIP_TRY(hipMemcpyAsync(&h_flag, flags, 4, hipMemcpyDeviceToHost, st));
-        SNK_HIP_TRY(snk_sync(st));
-        if (h_flag == 0) converged = true;
-    }
+    // Rounds are issued in batches without asking the device whether the last one still changed anything (a round over the
+    // ~n/64 splitters takes 10-15 us, a read-back 25-30 us of idle device): the first batch covers lists of 2^12 splitters
+    // (256 k fragments), and its verdict comes back together with the walk's "every state ranked" check.
     uint2* rk = nullptr;
-    bool unranked = false;
-    if (converged) {
-        G_ALLOC(rk, uint2, ns);
+    bool converged = false, unranked = false;
+    G_ALLOC(rk, uint2, ns);
+    const int batch0 = (int)snk_env_u32("SNK_RANK_ROUND_BATCH0", 12);
+    for (int r = 0; r < max_rounds && !converged;) {
+        const int upto = r == 0 ? (batch0 < max_rounds ? batch0 : max_rounds) : max_rounds;
+        SNK_HIP_TRY(hipMemsetAsync(flags, 0, 8, st));
+        for (; r < upto; ++r) {
+            if (m) hipLaunchKernelGGL(rank_round_kernel, dim3(nblk(m)), dim3(TB), 0, st, rn[cur], rd[cur], rt[cur], m, rn[cur ^ 1], rd[cur ^ 1], rt[cur ^ 1],
+                                      r + 1 == upto ? flags : flags + 2);      // only the batch's last round reports
+            cur ^= 1;
+            ++r_done;
+        }
+        // optimistic: rank the states from what the rounds left (harmless if they had not converged: it is redone)
         SNK_HIP_TRY(hipMemsetAsync(rk, 0xFF, ns * 8, st));
         if (m) hipLaunchKernelGGL(spl_walk2_kernel, dim3(nblk(m)), dim3(TB), 0, st, wrec, spl_state, weights, rd[cur], rt[cur], m, rk);
-        SNK_HIP_TRY(hipMemsetAsync(flags, 0, 4, st));
-        hipLaunchKernelGGL(unranked_check_kernel, dim3(nblk(ns)), dim3(TB), 0, st, rk, ns, flags);
-        SNK_HIP_TRY(hipMemcpyAsync(&h_flag, flags, 4, hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(unranked_check_kernel, dim3(nblk(ns)), dim3(TB), 0, st, rk, ns, flags + 1);
+        uint32_t h2[2] = {0, 0};
+        SNK_HIP_TRY(hipMemcpyAsync(h2, flags, 8, hipMemcpyDeviceToHost, st));
         SNK_HIP_TRY(snk_sync(st));
-        unranked = h_flag != 0;          // states no walk reached: a circle without a splitter
-        if (!unranked) {
-            *rk_out = rk;
-            *n_circles = cut_total;
-            *rounds = r_done;
-            return SNK_OK;
-        }
+        converged = h2[0] == 0;
+        unranked = h2[1] != 0;          // states no walk reached: a circle without a splitter
+    }
+    if (converged && !unranked) {
+        *rk_out = rk;
+        *n_circles = cut_total;
+        *rounds = r_done;
+        return SNK_OK;
     }
     // circles.  In the join (circ given) they are cut here and the lists ranked once more; the k-mer level ranking of the global
     // graph stage needs the cut AT the minimum k-mer (it is the reference's cut there): the general algorithm does that.
