@@ -449,7 +449,7 @@ static int rank_lists_wyllie(snk_ctx* ctx, hipStream_t st, uint32_t* link, uint6
 
 // ---- work-efficient ranking: sparse ruling set.  Wyllie's pointer jumping touches every state log2(len) times
 // (21-28 rounds of random 12-byte gathers on the benchmark, 60% of the whole step); here every state is touched
-// twice: list heads and a hashed 1/64 sample of the states are "splitters", each walks to the next splitter, the
+// twice: list heads and a hashed 1/32 sample of the states are "splitters", each walks to the next splitter, the
 // short splitter list is ranked by pointer jumping, and a second walk hands the ranks to the states in between.
 __device__ __forceinline__ bool sampled_state(uint32_t s, uint32_t split_mask) { return ((snk_mix32(s >> 1) >> 7) & split_mask) == 0; }
 
@@ -527,7 +527,7 @@ __global__ void __launch_bounds__(TB) unranked_check_kernel(const uint2* __restr
 // cycle in the splitter list (the jumping does not converge), or it holds no splitter at all and no walk reaches it.  Round 2
 // answered both with Wyllie's pointer jumping over ALL states (ceil(log2 ns) rounds of random gathers: ~50 ms at 35 M states,
 // a second at 280 M -- for ONE plasmid in the data set).  Here: the minimum sampled FRAGMENT of every splitter cycle by
-// pointer jumping on the splitter list only (1/64 of the states; both states of a fragment are sampled together, so the two
+// pointer jumping on the splitter list only (1/32 of the states; both states of a fragment are sampled together, so the two
 // directed cycles of a circle agree on it), and the minimum fragment of a splitter-free circle (a few hundred states at most)
 // by walking it from every unreached odd state; the circle is cut at the odd state of that fragment -- one cut per circle --
 // and the caller ranks again.  Where a circle is cut does not matter in the join: jcircle_kernel rotates it to the
@@ -652,7 +652,7 @@ static int rank_lists(snk_ctx* ctx, hipStream_t st, uint32_t* link, uint64_t n, 
     G_ALLOC(flag32, uint32_t, ns + 1);
     G_ALLOC(sid, uint32_t, ns + 1);
     SNK_HIP_TRY(hipMemsetAsync(flag32 + ns, 0, 4, st));
-    const uint32_t split_mask = (1u << snk_env_u32("SNK_SPLIT_LOG2", 6)) - 1u;
+    const uint32_t split_mask = (1u << snk_env_u32("SNK_SPLIT_LOG2", 5)) - 1u;
     hipLaunchKernelGGL(spl_mark_kernel, dim3(nblk(ns)), dim3(TB), 0, st, link, ns, split_mask, spl, flag32);
     {
         size_t tb = 0;
@@ -686,8 +686,8 @@ static int rank_lists(snk_ctx* ctx, hipStream_t st, uint32_t* link, uint64_t n, 
     int cur = 0;
     uint32_t r_done = 0;
     // Rounds are issued in batches without asking the device whether the last one still changed anything (a round over the
-    // ~n/64 splitters takes 10-15 us, a read-back 25-30 us of idle device): the first batch covers lists of 2^12 splitters
-    // (256 k fragments), and its verdict comes back together with the walk's "every state ranked" check.
+    // ~n/32 splitters takes 10-15 us, a read-back 25-30 us of idle device): the first batch covers lists of 2^12 splitters
+    // (128 k fragments), and its verdict comes back together with the walk's "every state ranked" check.
     uint2* rk = nullptr;
     bool converged = false, unranked = false;
     G_ALLOC(rk, uint2, ns);
@@ -739,7 +739,7 @@ namespace {
 // but ranking it in full on every rank would cost each of them what the rank-0 funnel cost one.  The ruling-set scheme
 // splits naturally: marking and packing are streaming passes (replicated, ~30 B per state); the two walks -- the random
 // access part -- are done for a 1/world share of the splitters per rank; what leaves a rank is 16 B per splitter after
-// walk 1 (all-gather) and 16 B per visited state after walk 2 (to the state's owner).  The splitter list itself (1/64 of
+// walk 1 (all-gather) and 16 B per visited state after walk 2 (to the state's owner).  The splitter list itself (1/32 of
 // the states) is jumped on every rank.  Lists that are circles are not handled here: the caller falls back to the
 // replicated ranking (snk_join_rank) when it is told so -- the decision is the same on every rank because it is taken
 // from replicated data.
@@ -1637,7 +1637,7 @@ int snk_prank_begin(snk_ctx* ctx, hipStream_t st, uint64_t F, const uint32_t* nk
     G_ALLOC(flag32, uint32_t, ns + 1);
     G_ALLOC(sid, uint32_t, ns + 1);
     SNK_HIP_TRY(hipMemsetAsync(flag32 + ns, 0, 4, st));
-    const uint32_t split_mask = (1u << snk_env_u32("SNK_SPLIT_LOG2", 6)) - 1u;
+    const uint32_t split_mask = (1u << snk_env_u32("SNK_SPLIT_LOG2", 5)) - 1u;
     if (ns) hipLaunchKernelGGL(spl_mark_kernel, dim3(nblk(ns)), dim3(TB), 0, st, link, ns, split_mask, spl, flag32);
     {
         size_t tb = 0;
