@@ -141,6 +141,7 @@ def next_rows(eng, res, rows, quals, bc, read_len, K):
         "reads": n,
         "f1_dictionary_build": {"ms": round(info["dict_ms"], 3), "slots": info["dict_slots"], "alg_bytes": dict_bytes, "hbm_frac": frac(dict_bytes, info["dict_ms"])},
         "f1_read_pathing": {"ms": round(info["path_ms"], 3), "reads_per_s": n / (info["path_ms"] * 1e-3), "edges": info["n_edges_total"],
+                            "reads_in_second_pass": info["n_slow"],
                             "alg_bytes": path_bytes, "hbm_frac": frac(path_bytes, info["path_ms"])},
         "f2_hbv_device_ms": round(info["hbv_device_ms"], 3),
         "f4_mark_dups": {"ms": round(d["ms"], 3), "dup_pairs": d["n_dup_pairs"], "interdup_rate": d["interdup_rate"], "alg_bytes": dup_bytes,

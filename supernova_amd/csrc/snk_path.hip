@@ -44,6 +44,8 @@ constexpr int PMT = 8;         // edges per read there
 struct path_graph {            // device arrays
     const uint64_t* uoff;      // [U+1] unitig offsets into ubases (device order)
     const uint8_t* ubases;     // 1 byte per base
+    const uint32_t* upack;     // the same bases, 2 bits each, 16 per word, first base in the top bits (one word of slack at either end): what the
+                               //     seed check and the exact-match extension read (a read's whole window is 40 bytes instead of 150 byte loads)
     const uint4* uinfo;        // [U] x 2: {offset lo, offset hi, bases, flags}, {fwd edge, rev edge, 0, 0}; flags bit 0 / 1: a seed on the
                                //     forward / reverse-complement copy is dropped (hanging edge rule, BuildReadQGraph48.cc:1240-1247)
     const int32_t *fwd, *rev;  // [U] HBV edge of the unitig read forward / reverse-complemented
@@ -90,6 +92,34 @@ __device__ __forceinline__ unsigned long long dict_fp(snk_kmer c) {
 // 32-byte slots holding the whole key (80 bytes per unitig k-mer with the lock word): 40 now, and the build went 25 -> ~15 ms
 // (it is bound by the random read-modify-write of one sector per k-mer).
 constexpr int DB_RUN = 16;
+// 16 bases of the byte array -> one word (the same bit order as the packed read rows)
+__global__ void __launch_bounds__(256) upack_kernel(const uint8_t* __restrict__ ubases, uint64_t total, uint32_t* __restrict__ out, uint64_t n_words) {
+    const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (w >= n_words) return;
+    uint32_t v = 0;
+    const uint64_t b0 = w * 16;
+    if (b0 + 16 <= total && ((uintptr_t)(ubases + b0) & 15u) == 0) {
+        const uint4 q = *reinterpret_cast<const uint4*>(ubases + b0);
+        const uint32_t x[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t y = x[j] & 0x03030303u;               // bytes b0..b3 = bases 4j..4j+3 (little endian: base 4j in the low byte)
+            const uint32_t four = ((y & 3u) << 6) | (((y >> 8) & 3u) << 4) | (((y >> 16) & 3u) << 2) | ((y >> 24) & 3u);
+            v |= four << (24 - 8 * j);
+        }
+    } else {
+        for (int j = 0; j < 16; ++j) { const uint64_t b = b0 + j; v = (v << 2) | (b < total ? (uint32_t)ubases[b] & 3u : 0u); }
+    }
+    out[w] = v;
+}
+// 16 bases starting at base p of a packed array (two words, one funnel shift)
+__device__ __forceinline__ uint32_t packed16(const uint32_t* P, uint64_t p) {
+    const uint64_t wi = p >> 4;
+    const uint32_t sh = 2u * ((uint32_t)p & 15u);
+    const uint32_t w0 = P[wi], w1 = P[wi + 1];
+    return (uint32_t)(((((uint64_t)w0 << 32) | w1) << sh) >> 32);
+}
+
 template <int K>
 __global__ void __launch_bounds__(256) dict_build_kernel(const uint64_t* __restrict__ uoff, const uint8_t* __restrict__ ubases, uint64_t U, uint64_t total,
                                                          uint4* __restrict__ dslot, uint64_t dcap, unsigned long long fp_mask) {
@@ -398,7 +428,6 @@ __global__ void __launch_bounds__(256, MODE == 2 ? 4 : SNK_PATH_OCC) path_kernel
     constexpr bool SECOND = MODE == 2;
     constexpr int NG = 256 / GS;                      // reads per workgroup
     constexpr uint32_t GM = GS == 16 ? 0xFFFFu : 0xFFu;
-    constexpr uint32_t EPL = 128 / GS;                // bases per lane and extension step
     __shared__ uint32_t rowL[NG][20];
     __shared__ ppart partsL[NG][PC];
     __shared__ int32_t pathL[NG][PM];
@@ -455,42 +484,42 @@ __global__ void __launch_bounds__(256, MODE == 2 ? 4 : SNK_PATH_OCC) path_kernel
                 const uint32_t u = __shfl(hu, gsh + first), o0 = __shfl(ho, gsh + first), rc = __shfl(hrc, gsh + first);
                 const uint4 ui = G.uinfo[2 * (uint64_t)u];
                 const uint32_t sz = ui.z;
-                const uint8_t* ub = G.ubases + (((uint64_t)ui.y << 32) | ui.x);
-                uint32_t b0, off;
-                if (!rc) { off = o0; b0 = o0 + K; } else { off = sz - o0; b0 = off; off -= K; }      // :726-729
-                if (!exact) {
-                    // the candidate's K bases against the read's, a few per lane
-                    bool okv = true;
-                    for (uint32_t j = (uint32_t)sub; j < (uint32_t)K; j += (uint32_t)GS) {
-                        const uint32_t eb = off + j;
-                        const uint32_t e1 = rc ? (uint32_t)(ub[sz - 1 - eb] ^ 3u) & 3u : (uint32_t)ub[eb] & 3u;
-                        if (read_base(row, i + (uint32_t)first + j) != e1) okv = false;
+                const uint64_t gb = (((uint64_t)ui.y << 32) | ui.x) + 16u;       // first base of the unitig in upack (one word of slack in front)
+                const uint32_t off = !rc ? o0 : sz - o0 - (uint32_t)K;           // :726-729
+                // The read from the seed on against the unitig (or its reverse complement), 2-bit words on both sides, the whole
+                // window in ONE step: CPL bases per lane, 256 per group.  L = bases that agree from the seed's first base on; fewer
+                // than K is a false fingerprint match (the seed check), the rest is matchLen's exact-match extension (:549-558).
+                constexpr uint32_t CPL = 256 / GS;
+                const uint32_t rs = i + (uint32_t)first;
+                const uint32_t Lmax = (n - rs) < (sz - off) ? (n - rs) : (sz - off);
+                uint32_t mt = 0;
+                bool stop = false;
+#pragma unroll
+                for (uint32_t c = 0; c < CPL / 16; ++c) {
+                    const uint32_t j = CPL * (uint32_t)sub + 16u * c;
+                    if (!stop) {
+                        if (j >= Lmax) stop = true;
+                        else {
+                            const uint32_t vl = Lmax - j < 16u ? Lmax - j : 16u;
+                            const uint32_t xr = packed16(row, rs + j);
+                            uint32_t xu;
+                            if (!rc) xu = packed16(G.upack, gb + off + j);
+                            else xu = snk_rev2_32(~packed16(G.upack, gb + (sz - 1u - off - j) - 15u));      // the 16 bases that END at the mirrored position, reverse-complemented
+                            const uint32_t d = xr ^ xu;
+                            const uint32_t mm = d ? (uint32_t)__clz((int)d) >> 1 : 16u;
+                            if (mm >= vl) { mt += vl; stop = vl < 16u; }
+                            else { mt += mm; stop = true; }
+                        }
                     }
-                    if ((uint32_t)(__ballot(!okv) >> gsh) & GM) { exact = true; continue; }       // redo this round with verified look-ups
                 }
+                const uint32_t smask = (uint32_t)(__ballot(stop) >> gsh) & GM;
+                uint32_t L = 256u;
+                if (smask) { const int fl = __ffs((int)smask) - 1; L = CPL * (uint32_t)fl + __shfl(mt, gsh + fl); }
+                if (L < (uint32_t)K) { exact = true; continue; }       // (never with verified look-ups) redo this round with them
                 wide = false;
                 gap += (uint32_t)first;
                 i += (uint32_t)first;
-                // exact-match extension behind the seed (matchLen :549-558): 128 bases per step, eight per lane
-                uint32_t a0 = i + K;
-                uint32_t len = 1;
-                for (;;) {
-                    uint32_t cnt = 0;
-                    bool stop = false;
-#pragma unroll
-                    for (uint32_t q = 0; q < EPL; ++q) {
-                        const uint32_t ra = a0 + EPL * sub + q, eb = b0 + EPL * sub + q;
-                        bool same = false;
-                        if (ra < n && eb < sz) {
-                            const uint32_t e1 = rc ? (uint32_t)(ub[sz - 1 - eb] ^ 3u) & 3u : (uint32_t)ub[eb] & 3u;
-                            same = read_base(row, ra) == e1;
-                        }
-                        if (!stop) { if (same) ++cnt; else stop = true; }
-                    }
-                    const uint32_t mm = (uint32_t)(__ballot(stop) >> gsh) & GM;
-                    if (mm) { const int fl = __ffs((int)mm) - 1; len += EPL * (uint32_t)fl + __shfl(cnt, gsh + fl); break; }
-                    len += 128; a0 += 128; b0 += 128;
-                }
+                const uint32_t len = L - (uint32_t)K + 1u;
                 if (sub == 0) {
                     if (gap) { if (m < PC) parts[m] = make_gap(gap); }
                     const int at = m + (gap ? 1 : 0);
@@ -800,6 +829,15 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
     if (U) hipLaunchKernelGGL(uinfo_kernel, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, st, d_uoff, U, G.fwd, G.rev, d_drop, uinfo);
     G.uinfo = uinfo;
     const uint64_t total_bases = h_off_last;
+    {
+        // the unitigs once more, 2 bits per base (a quarter of the byte array): word 0 is slack, the bases start at word 1
+        const uint64_t n_words = (total_bases + 15) / 16 + 3;
+        uint32_t* upack;
+        if ((rc = dev(ctx, n_words + 1, &upack, err, errcap))) return rc;
+        SNK_HIP_TRY(hipMemsetAsync(upack, 0, 4, st));
+        hipLaunchKernelGGL(upack_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, d_ubases, total_bases, upack + 1, n_words);
+        G.upack = upack;
+    }
     const uint64_t nk = total_bases >= U * (uint64_t)(K - 1) ? total_bases - U * (uint64_t)(K - 1) : 0;
     const uint64_t cap = ((2 * nk + nk / 2 + 1024) + 63) & ~63ull;        // load 0.4: the chain of dependent probes is what a read waits for
     {

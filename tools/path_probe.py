@@ -17,7 +17,7 @@ for rep in range(reps):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     off, ne, edges, info = res.path_reads(rows, 150, quals, mark_dups=True, bc=bc, unitig_bcs=True)
     t1 = time.perf_counter()
-    print(f"rep {rep}: {n} reads on {res.n_unitigs} unitigs ({res.n_kmers} k-mers): dictionary+tables {info['dict_ms']:.1f} ms, pathing {info['path_ms']:.1f} ms "
+    print(f"rep {rep}: {n} reads on {res.n_unitigs} unitigs ({res.n_kmers} k-mers): dictionary+tables {info['dict_ms']:.1f} ms, pathing {info['path_ms']:.1f} ms (second pass: {info['n_slow']} reads) "
           f"({n / info['path_ms'] / 1e3:.1f} M reads/s), HBV device part {info['hbv_device_ms']:.1f} ms, whole call incl. host flood and download {1e3 * (t1 - t0):.0f} ms; "
           f"paths: empty {int((ne == 0).sum())}, one edge {int((ne == 1).sum())}, more {int((ne > 1).sum())}, max {int(ne.max())}; "
           f"MarkDups {info['dups']['ms']:.1f} ms: {info['dups']['n_dup_pairs']} duplicate pairs, inter-barcode rate {info['dups']['interdup_rate']:.3f}; "
