@@ -1154,11 +1154,29 @@ __global__ void __launch_bounds__(TB) jhead_place_kernel(const uint32_t* __restr
     ucirc[hidx[f]] = pl_circ[f];
     if (fgroup) ugroup[hidx[f]] = fgroup[f];
 }
-// number of 256-base chunks of every fragment (work items of the copy kernel)
+// Base arrays are bytes (one per base) at arbitrary byte offsets.  A lane that moves one byte per instruction makes the copy
+// kernels instruction-bound (a wave instruction moves 64 bytes); these move 4 / 16 bytes per lane with dword accesses at byte
+// alignment (the device runs in unaligned-access mode; the packed struct tells the compiler so).
+struct __attribute__((packed)) u32_any { uint32_t v; };
+__device__ __forceinline__ uint32_t ld_u32_any(const uint8_t* p) { return reinterpret_cast<const u32_any*>(p)->v; }
+__device__ __forceinline__ void st_u32_any(uint8_t* p, uint32_t v) { reinterpret_cast<u32_any*>(p)->v = v; }
+// 16 bytes dst[0..16) = src[0..16), or (rev) the reverse complement of the 16 bytes that END at src_end: dst[j] = src_end[-1-j] ^ 3
+__device__ __forceinline__ void copy16(uint8_t* dst, const uint8_t* src, bool rev) {
+    if (!rev) {
+        const uint32_t a = ld_u32_any(src), b = ld_u32_any(src + 4), c = ld_u32_any(src + 8), d = ld_u32_any(src + 12);
+        st_u32_any(dst, a); st_u32_any(dst + 4, b); st_u32_any(dst + 8, c); st_u32_any(dst + 12, d);
+    } else {
+        const uint32_t a = ld_u32_any(src - 4), b = ld_u32_any(src - 8), c = ld_u32_any(src - 12), d = ld_u32_any(src - 16);
+        st_u32_any(dst, __builtin_bswap32(a) ^ 0x03030303u); st_u32_any(dst + 4, __builtin_bswap32(b) ^ 0x03030303u);
+        st_u32_any(dst + 8, __builtin_bswap32(c) ^ 0x03030303u); st_u32_any(dst + 12, __builtin_bswap32(d) ^ 0x03030303u);
+    }
+}
+constexpr uint32_t JCH = 4096;            // bases per work item of the unitig copy kernels: 256 lanes x 16
+// number of JCH-base chunks of every unitig (work items of the copy kernels)
 __global__ void __launch_bounds__(TB) jchunks_kernel(const uint64_t* __restrict__ boff, uint64_t F, uint32_t* __restrict__ nch) {
     uint64_t f = (uint64_t)blockIdx.x * TB + threadIdx.x;
     if (f >= F) return;
-    nch[f] = (uint32_t)((boff[f + 1] - boff[f] + 255) / 256);
+    nch[f] = (uint32_t)((boff[f + 1] - boff[f] + JCH - 1) / JCH);
 }
 __global__ void __launch_bounds__(TB) jchunk_owner_kernel(const uint32_t* __restrict__ choff, uint64_t F, uint32_t* __restrict__ owner) {
     uint64_t f = (uint64_t)blockIdx.x * TB + threadIdx.x;
@@ -1174,12 +1192,23 @@ __global__ void __launch_bounds__(256) jemit_kernel(uint64_t F, const uint64_t* 
     const uint64_t f = (uint64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
     if (f >= F) return;
     const uint32_t sub = threadIdx.x & 7u;
-    const uint64_t len = (uint64_t)nk[f] + K - 1;
+    const uint32_t len = nk[f] + K - 1;
     const unsigned long long ko = pl_koff[f];
     const uint8_t* src = fbases + boff[f];
     uint8_t* dst = prov + poff[pl_pid[f] - pid_base] + (ko & ~PL_RC);
-    if (!(ko & PL_RC)) for (uint64_t q = sub; q < len; q += 8) dst[q] = src[q];
-    else for (uint64_t q = sub; q < len; q += 8) dst[len - 1 - q] = (uint8_t)(src[q] ^ 3u);
+    const bool rc = (ko & PL_RC) != 0;                  // dst[p] = src[len - 1 - p] ^ 3
+    // bytes up to the first 4-byte boundary of dst, dwords, the last bytes
+    uint32_t head = (4u - (uint32_t)((uintptr_t)dst & 3u)) & 3u;
+    if (head > len) head = len;
+    if (sub < head) dst[sub] = rc ? (uint8_t)(src[len - 1 - sub] ^ 3u) : src[sub];
+    const uint32_t ndw = (len - head) >> 2;
+    for (uint32_t j = sub; j < ndw; j += 8) {
+        const uint32_t o = head + 4 * j;
+        const uint32_t v = rc ? (__builtin_bswap32(ld_u32_any(src + len - 4 - o)) ^ 0x03030303u) : ld_u32_any(src + o);
+        *reinterpret_cast<uint32_t*>(dst + o) = v;
+    }
+    const uint32_t t0 = head + 4 * ndw;
+    if (sub < len - t0) { const uint32_t q = t0 + sub; dst[q] = rc ? (uint8_t)(src[len - 1 - q] ^ 3u) : src[q]; }
 }
 // canonical form of every unitig (dna/CanonicalForm.h:35-48) decided on the provisional sequence
 __global__ void __launch_bounds__(TB) jform_kernel(const uint64_t* __restrict__ uoff, uint64_t U, const uint8_t* __restrict__ prov,
@@ -1205,10 +1234,12 @@ __global__ void __launch_bounds__(TB) jfinal_kernel(const uint64_t* __restrict__
     const uint32_t item = blockIdx.x;
     const uint32_t u = uowner_of_chunk[item];
     const uint64_t len = uoff[u + 1] - uoff[u];
-    const uint64_t p0 = (uint64_t)(item - uchoff[u]) * 256 + threadIdx.x;
+    const uint64_t p0 = (uint64_t)(item - uchoff[u]) * JCH + 16u * threadIdx.x;
     if (p0 >= len) return;
     const uint64_t o = uoff[u];
-    out[o + p0] = urev[u] ? (uint8_t)(prov[o + len - 1 - p0] ^ 3u) : prov[o + p0];
+    const bool rev = urev[u] != 0;
+    if (p0 + 16 <= len) copy16(out + o + p0, rev ? prov + o + len - p0 : prov + o + p0, rev);
+    else for (uint64_t p = p0; p < len; ++p) out[o + p] = rev ? (uint8_t)(prov[o + len - 1 - p] ^ 3u) : prov[o + p];
 }
 
 __global__ void __launch_bounds__(TB) jcirc_list_kernel(const uint8_t* __restrict__ ucirc, uint64_t U, uint32_t* __restrict__ clist,
@@ -1304,10 +1335,13 @@ __global__ void __launch_bounds__(256) jorder_copy_kernel(const uint32_t* __rest
     const uint32_t item = blockIdx.x;
     const uint32_t r = owner[item];
     const uint64_t len = noff[r + 1] - noff[r];
-    const uint64_t p0 = (uint64_t)(item - choff[r]) * 256 + threadIdx.x;
+    const uint64_t p0 = (uint64_t)(item - choff[r]) * JCH + 16u * threadIdx.x;
     if (p0 == 0) { circ_out[r] = circ_in[idx[r]]; if (grp_in) grp_out[r] = grp_in[idx[r]]; }
     if (p0 >= len) return;
-    out[noff[r] + p0] = in[uoff[idx[r]] + p0];
+    const uint8_t* src = in + uoff[idx[r]] + p0;
+    uint8_t* dst = out + noff[r] + p0;
+    if (p0 + 16 <= len) copy16(dst, src, false);
+    else for (uint64_t p = 0; p0 + p < len; ++p) dst[p] = src[p];
 }
 
 }  // namespace
