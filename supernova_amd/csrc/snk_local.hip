@@ -693,13 +693,16 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
         const uint32_t fo = foffL[fwd ? tL : tR];
         fbases[c_boff + (WIDE ? frel[fo] : fo) + (K - 1) + pos] = (uint8_t)oriented_base<K>(k, !fwd, K - 1);
     }
-    // head k-mers: K lanes per head
+    // head k-mers: K / 4 lanes per head, four bases (one dword store at byte alignment) per lane, four heads per wave
+    // instruction (K lanes writing a byte each made this the kernel's largest block of memory instructions: one per head)
+    struct __attribute__((packed)) u32_any { uint32_t v; };
     const uint32_t nheads = fcnt;
-    constexpr int HPI = T / 64;                            // heads per iteration: one wave each
+    constexpr int HPI = T / 16;                            // heads per iteration: sixteen lanes each
+    static_assert(K % 4 == 0 && K / 4 <= 16, "a head is K / 4 dwords, one per lane of its group");
     for (uint32_t h0 = 0; h0 < nheads; h0 += HPI) {
-        const uint32_t h = h0 + (tid >> 6);
-        const int q = tid & 63;
-        if (h < nheads && q < K) {
+        const uint32_t h = h0 + (tid >> 4);
+        const int q = tid & 15;
+        if (h < nheads && q < K / 4) {
             const uint32_t hn = hnode[h];
             const uint32_t i = hn >> 1;
             const bool rc = hn & 1u;
@@ -709,7 +712,9 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
             snk_kmer k;
             k.hi = khi[i];
             k.lo = (uint64_t)klo[i] << KLS;
-            fbases[c_boff + fo + q] = (uint8_t)oriented_base<K>(k, rc, q);
+            const uint32_t v = oriented_base<K>(k, rc, 4 * q) | (oriented_base<K>(k, rc, 4 * q + 1) << 8) | (oriented_base<K>(k, rc, 4 * q + 2) << 16) |
+                               (oriented_base<K>(k, rc, 4 * q + 3) << 24);
+            reinterpret_cast<u32_any*>(fbases + c_boff + fo + 4 * q)->v = v;
         }
     }
 }
