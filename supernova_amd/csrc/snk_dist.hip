@@ -339,7 +339,16 @@ __global__ void __launch_bounds__(256) route_kernel(uint64_t Fl, unsigned long l
         const uint32_t n = c_len[i];
         const uint8_t* src = bases + c_src[i];
         uint8_t* dst = bout + c_dst[i];
-        for (uint32_t q = sub; q < n; q += 8) dst[q] = src[q];
+        // bytes up to dst's first 4-byte boundary, dwords (read at byte alignment), the last bytes -- a byte per lane and instruction
+        // made the copy instruction-bound (snk_graph.hip, jemit_kernel)
+        struct __attribute__((packed)) u32_any { uint32_t v; };
+        uint32_t head = (4u - (uint32_t)((uintptr_t)dst & 3u)) & 3u;
+        if (head > n) head = n;
+        if (sub < head) dst[sub] = src[sub];
+        const uint32_t ndw = (n - head) >> 2;
+        for (uint32_t j = sub; j < ndw; j += 8) *reinterpret_cast<uint32_t*>(dst + head + 4 * j) = reinterpret_cast<const u32_any*>(src + head + 4 * j)->v;
+        const uint32_t t0 = head + 4 * ndw;
+        if (sub < n - t0) dst[t0 + sub] = src[t0 + sub];
     }
 }
 // received headers -> the arrays snk_join_emit wants; hdr_seg / base_seg: first header / first base byte of every source rank
