@@ -82,7 +82,14 @@ for case in range(n_cases):
         print(f"skip case {case}: the oracle rejects it ({ex})", flush=True)
         continue
     rows = torch.from_numpy(synth.pack_rows(codes).view(np.int32)).to(dev)
-    dq = torch.from_numpy(quals).to(dev); dbc = torch.from_numpy(bc).to(dev) if use_bc else None
+    # two cases in three: quality rows padded to 4 bytes with garbage behind the read (the layout the readers produce): the trim
+    # then runs inside the partition kernel; the others keep the bare rows (the separate trim kernel)
+    quals_dev = quals
+    if case % 3 != 0:
+        prng = np.random.default_rng(1000 + case)
+        quals_dev = prng.integers(0, 42, (quals.shape[0], (L + 3) // 4 * 4 + 4 * int(prng.integers(0, 2))), dtype=np.uint8)
+        quals_dev[:, :L] = quals
+    dq = torch.from_numpy(np.ascontiguousarray(quals_dev)).to(dev); dbc = torch.from_numpy(bc).to(dev) if use_bc else None
     dl = torch.from_numpy(lens.view(np.int16)).to(dev)
     tag = f"case {case}: K={K} L={L} G={G} n={n} err={err} nbc={nbc} min_freq={min_freq} min_bc={min_bc} nb={nb} bc={use_bc} cap%={cap_pct} -> {o.keys.shape[0]} k-mers, {len(o.unitigs)} unitigs"
     ok = True
