@@ -298,7 +298,9 @@ int snk_comm_from_nccl(snk_ctx* ctx, void* nccl_comm, uint32_t rank, uint32_t wo
 int snk_comm_create_local(uint32_t world, snk_comm** out /* [world] */, char* err, size_t errcap);
 /* the exchanges through callbacks of the host (its own transport: MPI, sockets, torch.distributed, ...): a2a moves scnt[p] bytes
  * at send + sbeg[p] to rank p and delivers rcnt[s] bytes from rank s at recv + rbeg[s]; gather collects k u64 of every rank
- * (mine: whatever memory the step hands over -- device memory inside snk_shard_step) into all[world * k] on the host.
+ * (mine and all are HOST memory: device counters are read back by the library first) into all[world * k].  a2a's buffers are
+ * whatever memory the step hands over -- DEVICE memory inside snk_shard_step, not ordered with any stream: the callback
+ * synchronises the device before it reads and after it writes.
  * Both return 0 or an error code.  snk_comm_selftest runs the step's exchange patterns on HOST memory with synthetic contents
  * over any communicator whose buffers may be host memory (the CPU tests use it over gloo, world_size 2). */
 typedef int (*snk_comm_a2a_fn)(void* user, const void* send, const uint64_t* sbeg, const uint64_t* scnt, void* recv, const uint64_t* rbeg,

@@ -318,15 +318,23 @@ struct cb_comm : snk_comm {
         for (uint32_t p = 0; p < world; ++p) { rbeg[p] = acc; rcnt[p] = counts[p]; acc += counts[p]; }
         return a2a(send, sbeg.data(), scnt.data(), recv, rbeg.data(), rcnt.data(), st, err, errcap);
     }
-    int gather_counts(const unsigned long long* d_mine, uint32_t k, unsigned long long* h_all, hipStream_t, char* err, size_t errcap) override {
+    int gather_counts(const unsigned long long* d_mine, uint32_t k, unsigned long long* h_all, hipStream_t st, char* err, size_t errcap) override {
         ++n_collectives;
+        // the callback always sees HOST memory: counters that live on the device (inside snk_shard_step) are read back here
+        std::vector<unsigned long long> mine(k);
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, d_mine) == hipSuccess && at.type == hipMemoryTypeDevice) {
+            SNK_HIP_TRY(hipMemcpyAsync(mine.data(), d_mine, (size_t)k * 8, hipMemcpyDeviceToHost, st));
+            SNK_HIP_TRY(snk_sync(st));
+            d_mine = mine.data();
+        } else (void)hipGetLastError();
         const int rc = gather_fn(user, d_mine, k, h_all, world);
         return rc ? snk_fail(SNK_E_INTERNAL, err, errcap, "the caller's gather failed (%d)", rc) : SNK_OK;
     }
-    int barrier(hipStream_t, char* err, size_t errcap) override {
+    int barrier(hipStream_t st, char* err, size_t errcap) override {
         unsigned long long one = 1;
         std::vector<unsigned long long> all(world);
-        return gather_counts(&one, 1, all.data(), nullptr, err, errcap);
+        return gather_counts(&one, 1, all.data(), st, err, errcap);
     }
 };
 uint64_t mix64(uint64_t x) { x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; return x ^ (x >> 31); }

@@ -106,18 +106,16 @@ __device__ __forceinline__ int trim_from_planes(uint64_t P0, uint64_t P1, uint64
     return best < 0 ? 0 : best + K;
 }
 
-// One call per thread at the top of the partition kernel; NOT inlined: the kernel's own register allocation (96 VGPRs, tuned
-// spills) stays what it is without the trim.
+// One call per thread at the top of the partition kernel (inlined; what keeps it from disturbing the kernel's register allocation is
+// described at the call).
 template <int K>
 __device__ __forceinline__ int fused_trim(const snk_msp_args& a, int tid0, uint64_t r0) {
     int g_trim = 0;
         const uint64_t rq = r0 + tid0;
         int qlen = 0;
-        const uint32_t* qrow = nullptr;
         if (rq < a.n_reads) {
             qlen = a.lens ? (int)a.lens[rq] : (int)a.read_len;
             if (qlen > (int)a.read_len) qlen = (int)a.read_len;
-            qrow = reinterpret_cast<const uint32_t*>(a.quals + rq * (uint64_t)a.qstride);
         }
         const uint32_t mq4 = (a.min_qual > 255u ? 255u : a.min_qual) * 0x01010101u;
         // step 1: the last K quals of every row of the wave, 16 bytes per lane: four lanes cover a row's window (64 contiguous

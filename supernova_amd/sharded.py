@@ -376,14 +376,90 @@ def rccl_comm(engine: Engine, dist) -> int:
     return int(h.value)
 
 
+class _DevBytes:
+    """A device array of the library seen by torch without a copy (__cuda_array_interface__ over the raw pointer)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def gloo_comm(engine: Engine, dist):
+    """A communicator for libsnk over a gloo process group: the step's exchanges leave the device through the host
+    (`snk_comm_create_callbacks`; the callbacks get the step's DEVICE pointers).  Not a production transport -- it is how the
+    multi-process step (separate processes, separate contexts, real message passing) is run where RCCL cannot be: several ranks
+    sharing ONE GPU in the tests and `bench.py --transport gloo`.  Returns (handle, keepalive)."""
+    lib = engine.lib
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = torch.device("cuda", engine.device)
+
+    def dview(ptr, nbytes):
+        return torch.as_tensor(_DevBytes(ptr, nbytes), device=dev)
+
+    def a2a(_user, send, sbeg, scnt, recv, rbeg, rcnt, W):
+        try:
+            torch.cuda.synchronize(dev)                        # the step's kernels wrote `send` on its own streams
+            s_hi = max([sbeg[p] + scnt[p] for p in range(W)] + [0])
+            r_hi = max([rbeg[p] + rcnt[p] for p in range(W)] + [0])
+            s_t = dview(send, s_hi) if s_hi else None
+            r_t = dview(recv, r_hi) if r_hi else None
+            if scnt[rank]:
+                r_t[rbeg[rank]:rbeg[rank] + rcnt[rank]].copy_(s_t[sbeg[rank]:sbeg[rank] + scnt[rank]])
+            ops, landing = [], []
+            for q in range(W):
+                if q == rank:
+                    continue
+                if scnt[q]:
+                    ops.append(dist.P2POp(dist.isend, s_t[sbeg[q]:sbeg[q] + scnt[q]].cpu(), q))
+                if rcnt[q]:
+                    h = torch.empty(int(rcnt[q]), dtype=torch.uint8)
+                    landing.append((q, h))
+                    ops.append(dist.P2POp(dist.irecv, h, q))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            for q, h in landing:
+                r_t[rbeg[q]:rbeg[q] + rcnt[q]].copy_(h)
+            torch.cuda.synchronize(dev)
+            return 0
+        except BaseException:      # a ctypes callback must not raise
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def gather(_user, mine, k, allp, W):
+        try:
+            m = torch.from_numpy(np.ctypeslib.as_array(C.cast(mine, C.POINTER(C.c_int64)), shape=(int(k),))).clone()      # host memory
+            outs = [torch.empty_like(m) for _ in range(W)]
+            dist.all_gather(outs, m)
+            dst = torch.from_numpy(np.ctypeslib.as_array(C.cast(allp, C.POINTER(C.c_int64)), shape=(int(k) * int(W),)))
+            for q in range(W):
+                dst[q * k:(q + 1) * k].copy_(outs[q])
+            return 0
+        except BaseException:
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    cb_a, cb_g = _lib.COMM_A2A(a2a), _lib.COMM_GATHER(gather)
+    h = C.c_void_p()
+    err = C.create_string_buffer(512)
+    rc = lib.snk_comm_create_callbacks(rank, world, cb_a, cb_g, None, C.byref(h), err, 512)
+    if rc:
+        raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+    return int(h.value), (cb_a, cb_g)
+
+
 class ShardedEngine:
     def __init__(self, engine: Engine, dist_or_comm, join: str | None = None):
         """dist_or_comm: torch.distributed (an initialised process group: one process per GPU, RCCL) or a communicator handle
         (local_world).  The join is owner-side: every rank writes the unitigs whose head fragment it owns."""
         self.eng = engine
         self.lib = engine.lib
+        self._keep = None
         if isinstance(dist_or_comm, int):
             self.comm = dist_or_comm
+        elif dist_or_comm.get_backend() == "gloo":
+            self.comm, self._keep = gloo_comm(engine, dist_or_comm)      # ranks that share a GPU (tests, bench.py --transport gloo)
         else:
             self.comm = rccl_comm(engine, dist_or_comm)
         self.rank = int(self.lib.snk_comm_rank(self.comm))

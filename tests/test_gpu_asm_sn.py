@@ -117,3 +117,28 @@ def test_gather_unitigs_in_process_ranks(snk, W):
         p.write_bytes(got["image"])
         off, bases = graphio.read_bv(str(p))
         assert graphio.arrays_to_unitigs(off, bases) == c.exp_unitigs
+
+
+def test_bench_two_processes_over_gloo_one_gpu(tmp_path):
+    """bench.py's N > 1 plumbing and the multi-process step with real message passing between two PROCESSES (two contexts, rank
+    slabs, the library's exchange planning, the owner-side join, the self-check against the one-GPU path, max-over-ranks timing,
+    one JSON line from rank 0) on a box with one GPU: both ranks share it, the exchanges go through the host over gloo
+    (`--transport gloo`).  What it cannot show is RCCL between two devices."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           str(root / "bench.py"), "--gpus", "2", "--transport", "gloo", "--reads", "3e6", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(root))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] and d["value"] > 0
+    mg = d["config"]["multi_gpu"]
+    assert d["config"]["sharded_self_check"] == "passed" and mg["transport"] == "callbacks" and mg["rccl_ranks"] == 2
+    assert mg["exchange_bytes_rank0"]["records"] > 0 and mg["join_ranking"] == "partitioned"
