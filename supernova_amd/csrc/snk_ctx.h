@@ -26,6 +26,8 @@ struct snk_ctx {
     size_t cached_bytes = 0;    // bytes held by the arena
     uint64_t last_n_kmers = 0, last_n_instances = 0;   // sizing hint from the previous call
     uint64_t last_bnd = 0, last_bnd_n = 0;              // boundary k-mers the bucket-local prune found for a table of last_bnd_n k-mers
+    uint32_t last_ovf = 0, last_ovf_nb = 0;             // overflow supermers of the last partition pass and its bucket count
+    uint64_t last_ovf_reads = 0;
     uint32_t last_extra = 0;                           // split sub-passes the previous call recorded
     std::vector<unsigned long long> h_region_off;      // host copy of the count regions' dense offsets (source of an async upload)
     void* shard = nullptr;      // snk_shard_state (snk_dist.hip)

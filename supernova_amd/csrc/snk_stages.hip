@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <math.h>
 
+#include <cmath>
 #include <vector>
 
 #include "snk_ctx.h"
@@ -296,18 +297,36 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
     // a random-order minimiser starts a new supermer every (W+1)/2 k-mers, and every contributing read starts one
     const double est_super = (double)n_inst * 2.0 / (Wm + 1) + (double)n_live;
     const double mean = est_super / NB;
-    // Bucket occupancy is NOT Poisson in the supermers: a minimiser site of the genome contributes one supermer per
-    // read that covers it (~38 at 56x), so a 4000-instance bucket holds only ~7 sites and its supermer count has a
-    // relative sigma of ~37 %.  With 1.25 x mean + 4 sqrt(mean) 1.7 % of the supermers overflowed and their
-    // reservations on the single overflow cursor cost 30 ms (tools/msp_probe2.py).  2.5 x mean is > 5 sigma of the site
-    // count at 56x and generous below; the slots that stay empty are never touched.
-    uint64_t cap64 = (uint64_t)(mean * 2.5 + 32.0);
+    // Bucket occupancy is NOT Poisson in the supermers: a minimiser site of the genome contributes one supermer per read that
+    // covers it (c ~ 38 at 56x), so a bucket of `mean` supermers holds mean / c sites and its count has sigma = sqrt(mean c).
+    // capacity = mean + 5 sigma.  At 4000-instance buckets on one GPU (mean 340, 9 sites) that is 2.7 x mean -- the 2.5 x mean + 32
+    // this code used before; the sharded path partitions the same reads into world x as many buckets (mean 42 at eight ranks:
+    // ONE site), where 2.5 x mean lost a tenth of the supermers to the overflow list, overran it, and ran the pass twice
+    // (78 instead of 34 ms).  c is a property of the data set: 48 covers 70x; per-barcode groups see a site once or twice.
+    // Overflowing supermers are correct (segment 1), only slower; the slots that stay empty are never touched.
+    const double site_records = (double)env_u32("SNK_MSP_SITE_RECORDS", grouped ? 3u : 48u);
+    uint64_t cap64 = (uint64_t)(mean + 5.0 * std::sqrt(mean * site_records) + 16.0);
     cap64 = cap64 * env_u32("SNK_MSP_CAP_PCT", 100) / 100;
     if (cap64 < 2) cap64 = 2;
     cap64 = (cap64 + 1) & ~1ull;
+    {
+        // not more than ~45 % of the device for the slots: beyond that the capacity shrinks and the overflow list takes the rest
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot) {
+            const uint64_t budget = (uint64_t)((double)tot * 0.45);
+            if (cap64 * NB * 32ull > budget) {
+                uint64_t c2 = budget / (NB * 32ull);
+                const uint64_t floor_ = (uint64_t)(mean * 1.25 + 8.0);
+                if (c2 < floor_) c2 = floor_;
+                if (c2 < cap64) cap64 = c2 & ~1ull;
+            }
+        } else (void)hipGetLastError();
+    }
     if (cap64 * NB >= (1ull << 40) || cap64 >= (1ull << 31)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "bucket capacity out of range");
     const uint32_t cap = (uint32_t)cap64;
     uint64_t ovf_cap = (uint64_t)(est_super / 16) + 65536;
+    // (the same job geometry as the last call: what that one needed, so that a steady stream of calls never runs the pass twice)
+    if (ctx->last_ovf_nb == NB && ctx->last_ovf_reads == n_reads && (uint64_t)ctx->last_ovf * 5 / 4 + 65536 > ovf_cap) ovf_cap = (uint64_t)ctx->last_ovf * 5 / 4 + 65536;
     int rc;
     uint32_t* cursor = nullptr;
     uint64_t* seg = nullptr;           // [2 segments][beg NB | end NB]
@@ -372,6 +391,7 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
             h_plan[0] = h_plan[1] = 0;
             for (int q = 0; q < SNK_MSP_PLAN_SLOTS; ++q) { h_plan[0] += h_fplan[2 * q]; h_plan[1] += h_fplan[2 * q + 1]; }
         }
+        ctx->last_ovf = h_novf; ctx->last_ovf_nb = NB; ctx->last_ovf_reads = n_reads;
         if (h_novf <= ovf_cap) break;
         if (attempt == 2) return snk_fail(SNK_E_INTERNAL, err, errcap, "supermer overflow list too small (%u > %llu)", h_novf, (unsigned long long)ovf_cap);
         snk_ctx_release_block(ctx, records);
