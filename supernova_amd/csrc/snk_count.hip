@@ -128,6 +128,11 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     // start and end, seg = all segments') into rec[] by LDS-DMA.  Nothing is waited for here.
     auto dma_batch = [&](uint64_t base, uint64_t vend, const uint32_t* bnd, const uint32_t* seg) {
         constexpr int CH = 2 * BATCH;                     // 16-byte chunks
+        uint32_t seg_incl = 0;
+        if (MULTI) {
+            const uint32_t mylen = (uint32_t)lane < a.nseg ? LDS_LOAD(&seg[2 * SNK_COUNT_MAXSEG + lane]) - LDS_LOAD(&seg[lane]) : 0u;
+            seg_incl = snk_wave_scan_incl(mylen);
+        }
 #pragma unroll
         for (int r = 0; r * THREADS < CH; ++r) {
             const int c = r * THREADS + tid;
@@ -137,9 +142,12 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                 if (MULTI) {
                     // the segments are read as ONE concatenated record stream (batches stay full, identical supermers from
                     // different sources fold): find the segment by a short prefix walk
+                    // the segment of virtual record x: the inclusive prefix of the segment lengths sits in the wave's first lanes
+                    // (seg_incl, below) -- one scalar read per segment and a compare, no chain of dependent LDS reads (the walk
+                    // over eight segments was +5 ms on the kernel: its latency delays every batch's fetch)
                     const uint32_t x = (uint32_t)v;
                     uint32_t acc = 0, sg = 0;
-                    for (; sg + 1 < a.nseg; ++sg) { const uint32_t l = seg[2 * SNK_COUNT_MAXSEG + sg] - seg[sg]; if (x < acc + l) break; acc += l; }
+                    for (uint32_t q = 0; q + 1 < a.nseg; ++q) { const uint32_t e = __builtin_amdgcn_readlane(seg_incl, q); if (x >= e) { sg = q + 1; acc = e; } }
                     gi = (((uint64_t)seg[SNK_COUNT_MAXSEG + sg] << 32) | seg[sg]) + (x - acc);
                 } else gi = v;
                 (void)bnd;
@@ -152,7 +160,12 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     };
     // iteration space of a bucket: absolute record indices of its one segment, or offsets into the concatenation of all segments
     auto bucket_range = [&](const uint32_t* bnd, const uint32_t* seg, uint64_t& vbeg, uint64_t& vend) {
-        if (MULTI) { vbeg = 0; vend = 0; for (uint32_t sg = 0; sg < a.nseg; ++sg) vend += LDS_LOAD(&seg[2 * SNK_COUNT_MAXSEG + sg]) - LDS_LOAD(&seg[sg]); }
+        if (MULTI) {
+            // (sum of the segment lengths: one segment per lane and a wave scan, not a loop of 2 nseg LDS reads in every thread)
+            const uint32_t mylen = (uint32_t)lane < a.nseg ? LDS_LOAD(&seg[2 * SNK_COUNT_MAXSEG + lane]) - LDS_LOAD(&seg[lane]) : 0u;
+            vbeg = 0;
+            vend = (uint32_t)__builtin_amdgcn_readlane((int)snk_wave_scan_incl(mylen), 63);
+        }
         else {
             vbeg = ((uint64_t)LDS_LOAD(&bnd[1]) << 32) | LDS_LOAD(&bnd[0]);
             vend = ((uint64_t)LDS_LOAD(&bnd[3]) << 32) | LDS_LOAD(&bnd[2]);

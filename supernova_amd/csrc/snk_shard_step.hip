@@ -74,6 +74,18 @@ __global__ void __launch_bounds__(256) seg_table_kernel(const ull* __restrict__ 
     }
 }
 
+// Measurement aid (SNK_DBG_FAKE_SEGS = n on one rank): every bucket's slots seen as n segments of equal parts -- the record layout a
+// rank of an n-GPU job counts (one segment per source), same records, same result
+__global__ void __launch_bounds__(256) fake_seg_kernel(const uint32_t* __restrict__ cursor, uint32_t NB, uint32_t cap, uint32_t nseg, uint64_t* __restrict__ T) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= NB) return;
+    const uint32_t c = cursor[b] < cap ? cursor[b] : cap;
+    for (uint32_t s = 0; s < nseg; ++s) {
+        T[(uint64_t)s * NB + b] = (uint64_t)b * cap + (uint64_t)c * s / nseg;
+        T[(uint64_t)(nseg + s) * NB + b] = (uint64_t)b * cap + (uint64_t)c * (s + 1) / nseg;
+    }
+}
+
 }  // namespace
 
 // Piece (q, r) of the ranged record exchange: h_rs = [2][W][R] items per (destination, range) and per (source, range); the
@@ -227,6 +239,14 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
         // one rank owns every bucket: the slots are counted where they are (exactly the one-GPU path)
         tm.mark();   // 2
         tm.mark();   // 3
+        const uint32_t fake = snk_env_u32("SNK_DBG_FAKE_SEGS", 0);
+        if (fake > 1 && fake <= 32 && part.n_overflow == 0) {
+            uint64_t* T;
+            ALLOC(T, uint64_t, 2ull * fake * NB_total + 2);
+            hipLaunchKernelGGL(fake_seg_kernel, dim3((NB_total + 255) / 256), dim3(256), 0, st, part.cursor, NB_total, part.cap, fake, T);
+            TRY(snk_stage_count_table(ctx, st, K, part.records, T, T + (uint64_t)fake * NB_total, NB_total, fake, NB_total, p->min_freq,
+                                      has_bc ? p->min_bc : 0u, 0u, inst_hint, S->status, false, &S->tab, err, errcap));
+        } else
         TRY(snk_stage_count_table(ctx, st, K, part.records, part.seg, part.seg + NB_total, 2 * NB_total, part.nseg, NB_total, p->min_freq,
                                   has_bc ? p->min_bc : 0u, 0u, inst_hint, S->status, false, &S->tab, err, errcap));
         snk_ctx_release_block(ctx, part.records);
