@@ -67,6 +67,7 @@ extern "C" int snk_ctx_create(int device, snk_ctx** out, char* err, size_t errca
     snk_ctx* c = new snk_ctx();
     c->device = device;
     c->n_cu = prop.multiProcessorCount;
+    c->device_mem_total = (uint64_t)prop.totalGlobalMem;
     hipError_t se = hipStreamCreate(&c->stream);   // blocking stream: ordered after work on the legacy default stream
     if (se != hipSuccess) {
         delete c;

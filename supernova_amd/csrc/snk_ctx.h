@@ -15,6 +15,7 @@ struct snk_ctx {
     hipStream_t stream = nullptr;   // library-owned default stream
     int n_cu = 256;
     size_t lds_per_block = 65536;
+    uint64_t device_mem_total = 0;   // HBM of the device (sizing decisions that must not depend on what happens to be free)
     // caching arena for call-scoped scratch: blocks are handed out by best fit, returned to the cache at the
     // start of the next top-level call (no hipFree/hipMalloc in steady state), released on destroy or OOM
     struct block { void* p; size_t bytes; bool used; uint64_t serial = 0; uint64_t epoch = 0; };

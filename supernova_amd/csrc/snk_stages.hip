@@ -311,8 +311,8 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
     cap64 = (cap64 + 1) & ~1ull;
     {
         // not more than ~45 % of the device for the slots: beyond that the capacity shrinks and the overflow list takes the rest
-        size_t fr = 0, tot = 0;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot) {
+        const uint64_t tot = ctx->device_mem_total;
+        if (tot) {
             const uint64_t budget = (uint64_t)((double)tot * 0.45);
             if (cap64 * NB * 32ull > budget) {
                 uint64_t c2 = budget / (NB * 32ull);
@@ -320,7 +320,7 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
                 if (c2 < floor_) c2 = floor_;
                 if (c2 < cap64) cap64 = c2 & ~1ull;
             }
-        } else (void)hipGetLastError();
+        }
     }
     if (cap64 * NB >= (1ull << 40) || cap64 >= (1ull << 31)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "bucket capacity out of range");
     const uint32_t cap = (uint32_t)cap64;
