@@ -197,7 +197,10 @@ __device__ __forceinline__ int fused_trim(const snk_msp_args& a, int tid0, uint6
 // the minimisers' keys in a second LDS list to save their re-derivation in the emit loop costs the fifth workgroup and
 // was dropped again; six waves per SIMD (80 VGPRs) spill 28 registers.  K=60 (45 keys in registers) stays at four.
 template <int K, int M, bool TRIM>
-__global__ void __launch_bounds__(BD, K == 48 ? 5 : 4) snk_msp_kernel(snk_msp_args a) {
+#ifndef SNK_MSP_OCC48
+#define SNK_MSP_OCC48 5
+#endif
+__global__ void __launch_bounds__(BD, K == 48 ? SNK_MSP_OCC48 : 4) snk_msp_kernel(snk_msp_args a) {
     constexpr int W = K - M + 1;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t row_words = a.row_words;
