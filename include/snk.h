@@ -165,6 +165,9 @@ typedef struct snk_dev_result {
     const void* unitig_group;    /* u32[n_unitigs] group of every unitig (SNK_F_GROUPED; unitigs ordered by group, then by
                                     their first K bases), else NULL */
     float graph_ms[8];           /* bucket-local graph: local prune, boundary resolve, fragments, join, table sort+spectrum */
+    uint32_t repartitioned;      /* 1: the first buckets overflowed their tables (error-rich / shallow data) and the reads were
+                                    partitioned a second time into smaller buckets; later calls on the context start there */
+    uint32_t reserved0;
 } snk_dev_result;
 
 /* Replaces the body of buildReadQGraph48 (BuildReadQGraph48.cc:1688-1774, pPaths==nullptr) up to and

@@ -209,6 +209,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     // 'staged' barrier of this one, when every wave is past its last look at it; the table is emptied by the lanes that write
     // its entries out.
     uint32_t q = 0, bq = 0;         // parity of the pass / of the batch
+    unsigned long long claims_sum = 0;
     for (; bucket < a.NB; bucket += G) {
     // depth of the split stack: every thread keeps its own copy (the control flow is uniform), so the sub-pass loop needs
     // no barrier-protected LDS read to decide whether it is done
@@ -547,6 +548,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                 }
             }
         }
+        claims_sum += nocc;                                  // (uniform) distinct k-mers this workgroup has held in its table
         if (tid == 0 && nocc > ctl[3]) ctl[3] = nocc;      // running maximum, reported once at the end (a device atomic per bucket: 2 M on one address are 20 ms)
         q ^= 1u;
         PROF(7);
@@ -554,7 +556,9 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     if (tid == 0 && splits_done) atomicAdd(&a.status[2], 1u);
     par ^= 1u;
     }
-    if (tid == 0) { a.region_cursor[blockIdx.x] = rcur; atomicMax(&a.status[3], ctl[3]); }
+    // status[5]: distinct k-mers over all buckets, in units of 16 -- with the instance count it tells the host how full the
+    // tables run (the bucket size of the next call, snk_pipeline.hip)
+    if (tid == 0) { a.region_cursor[blockIdx.x] = rcur; atomicMax(&a.status[3], ctl[3]); atomicAdd(&a.status[5], (uint32_t)(claims_sum >> 4)); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA in flight when the workgroup's LDS is handed back
 #ifdef SNK_COUNT_PROF
     if (tid == 0) for (int q = 0; q < 8; ++q) atomicAdd(&a.prof[q], prof_acc[q]);
@@ -635,6 +639,7 @@ int snk_launch_compact_regions(hipStream_t st, const snk_u128* keys_in, const ui
 
 uint32_t snk_count_slots(uint32_t K) { return K == 60 ? cfg<60>::SLOTS : cfg<48>::SLOTS; }
 
+uint32_t snk_count_limit(uint32_t K, uint32_t grouped) { (void)grouped; return K == 48 ? cfg<48>::SLOTS - cfg<48>::THREADS - 64 : cfg<60>::SLOTS - cfg<60>::THREADS - 64; }
 int snk_count_regions(uint32_t K, uint32_t grouped, uint32_t nseg, uint32_t NB, uint32_t bc_mode, uint32_t* n_regions, char* err, size_t errcap) {
     if (grouped) return regions<48, true>(nseg, NB, bc_mode, n_regions, err, errcap);
     if (K == 60) return regions<60, false>(nseg, NB, bc_mode, n_regions, err, errcap);

@@ -1106,7 +1106,7 @@ int snk_local_graph(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_table* t
 int snk_bl_dist_plan(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, unsigned long long* h_qcount, char* err, size_t errcap) {
     B->force_dist = 1;
     const uint64_t n = B->tab->n;
-    G_ALLOC(B->qcount, unsigned long long, B->world + 1);
+    G_ALLOC(B->qcount, unsigned long long, B->world + 4);      // (+ the words the step appends to the exchange of these counts)
     G_ALLOC(B->qcursor, unsigned long long, B->world + 1);
     G_ALLOC(B->rq_idx, uint32_t, 2 * n + 2);
     G_ALLOC(B->rq_meta, uint16_t, 2 * n + 2);

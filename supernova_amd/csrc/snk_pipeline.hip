@@ -98,46 +98,81 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     if (rc) return rc;
     unsigned long long h_ninst = h_plan[0];
     out->n_instances = h_ninst;
-    uint32_t NB = p->n_buckets;
-    if (NB == 0) {
-        // instances per bucket: sized so that the DISTINCT k-mers of a bucket fit the LDS table (1216 claims).  At 56x
-        // coverage 4000 instances hold ~500 distinct k-mers; per-barcode groups see every locus once or twice, so
-        // nearly every instance is distinct there
-        uint32_t target = env_u32("SNK_TARGET_INST", grouped ? 900u : (K == 48 ? 5000u : 3500u));
-        uint64_t nb = (h_ninst + target - 1) / target;
-        const uint64_t nb_max = grouped ? (1ull << 24) : (1ull << 22);
-        if (nb < 1) nb = 1;
-        if (nb > nb_max) nb = nb_max;
-        NB = (uint32_t)nb;
-    }
-    {
-        // a caller's bucket count is honoured down to ~1 M k-mer instances per bucket: a bucket is counted by ONE
-        // workgroup that re-reads all its records in every hash-split sub-pass, so 20 M instances in one bucket would be
-        // thousands of passes over a million records (finite, but minutes)
-        const uint64_t nb_floor = (h_ninst >> 20) + 1;
-        if (NB < nb_floor) NB = (uint32_t)nb_floor;
-    }
-    out->n_buckets = NB;
-    tm.mark();  // 2
+    // instances per bucket: sized so that the DISTINCT k-mers of a bucket fit the LDS table (1216 claims).  At 56x coverage and
+    // 0.2 % errors 5000 instances hold ~800 distinct k-mers; per-barcode groups see every locus once or twice, so nearly every
+    // instance is distinct there.  Error-rich or shallow data have more distinct k-mers per instance: with the default size
+    // nearly every bucket would overflow its table and be counted in two to four hash-split sub-passes (0.6 % errors: count
+    // 46 -> 133 ms).  The ratio is a property of the data set: the previous call's is used if there is one, else the count stage
+    // looks at its first 1/64 of the buckets and asks for a second partition when they overflow as a rule.
+    const uint32_t default_target = grouped ? 900u : (K == 48 ? 5000u : 3500u);
+    const bool target_forced = getenv("SNK_TARGET_INST") && *getenv("SNK_TARGET_INST");
+    auto target_for = [&](double ratio) -> uint32_t {
+        if (target_forced) return env_u32("SNK_TARGET_INST", default_target);
+        if (!(ratio > 0.0)) return default_target;
+        // measured: the default size is right while the tables run up to ~65 % full on average (the bench model: 800 of 1216); data
+        // that would fill them further do best at ~50 % (0.6 % errors: 239 ms with the default size, 186 at 80 %, 154 at 50 %)
+        const double lim = (double)snk_count_limit(K, grouped ? 1u : 0u);
+        if (0.65 * lim / ratio >= (double)default_target) return default_target;
+        const double t = 0.01 * env_u32("SNK_BUCKET_FILL_PCT", 50) * lim / ratio;
+        return t >= (double)default_target ? default_target : (t < 600.0 ? 600u : (uint32_t)t);
+    };
+    const bool have_hint = ctx->claim_ratio > 0.0 && ctx->claim_ratio_reads == n_reads && ctx->claim_ratio_k == K * 2 + (grouped ? 1u : 0u);
+    double ratio = have_hint ? ctx->claim_ratio : 0.0;
+    const bool adaptive = p->n_buckets == 0 && !target_forced && !grouped && env_u32("SNK_ADAPTIVE_BUCKETS", 1) != 0;      // (the per-barcode default is tuned at ratio ~1)
+    uint32_t NB = 0;
     snk_partition part;
-    rc = snk_stage_partition(ctx, st, K, in, good_len, NB, h_plan[0], h_plan[1], grouped, status, &part, err, errcap, nullptr, fused ? h_plan : nullptr,
-                             fused ? &ft : nullptr);
-    if (rc) return rc;
-    h_ninst = h_plan[0];               // (fused trim: now the exact count)
-    out->n_instances = h_ninst;
-    void* records = part.records;
-    uint64_t* seg = part.seg;
-    const uint32_t nseg = part.nseg;
-    out->n_supermers = part.n_supermers;
-    out->n_overflow = part.n_overflow;
-    tm.mark();  // 3
-
-    // ---- K5-K8 count + filter + gather (+ sort for the global graph stage)
-    const bool local_graph = !(p->flags & SNK_F_GLOBAL_GRAPH) && !env_u32("SNK_GLOBAL_GRAPH", 0);
     snk_table tab;
-    rc = snk_stage_count_table(ctx, st, K, records, seg, seg + NB, 2 * NB, nseg, NB, p->min_freq, (in->bc && !grouped) ? p->min_bc : 0u, grouped ? 1u : 0u, h_ninst, status,
-                               !local_graph, &tab, err, errcap);
-    if (rc) return rc;
+    void* records = nullptr;
+    const bool local_graph = !(p->flags & SNK_F_GLOBAL_GRAPH) && !env_u32("SNK_GLOBAL_GRAPH", 0);
+    const uint64_t mark = ctx->alloc_serial;
+    const unsigned long long ub_inst = h_plan[0], ub_live = h_plan[1];
+    for (int pass = 0; pass < 2; ++pass) {
+        NB = p->n_buckets;
+        if (NB == 0) {
+            const uint32_t target = target_for(adaptive ? ratio : 0.0);
+            uint64_t nb = (ub_inst + target - 1) / target;
+            const uint64_t nb_max = grouped ? (1ull << 24) : (1ull << 23);
+            if (nb < 1) nb = 1;
+            if (nb > nb_max) nb = nb_max;
+            NB = (uint32_t)nb;
+        }
+        {
+            // a caller's bucket count is honoured down to ~1 M k-mer instances per bucket: a bucket is counted by ONE
+            // workgroup that re-reads all its records in every hash-split sub-pass, so 20 M instances in one bucket would be
+            // thousands of passes over a million records (finite, but minutes)
+            const uint64_t nb_floor = (ub_inst >> 20) + 1;
+            if (NB < nb_floor) NB = (uint32_t)nb_floor;
+        }
+        out->n_buckets = NB;
+        if (pass == 0) tm.mark();  // 2
+        h_plan[0] = ub_inst; h_plan[1] = ub_live;
+        rc = snk_stage_partition(ctx, st, K, in, good_len, NB, h_plan[0], h_plan[1], grouped, status, &part, err, errcap, nullptr, fused ? h_plan : nullptr,
+                                 fused ? &ft : nullptr);
+        if (rc) return rc;
+        h_ninst = h_plan[0];               // (fused trim: now the exact count)
+        out->n_instances = h_ninst;
+        records = part.records;
+        out->n_supermers = part.n_supermers;
+        out->n_overflow = part.n_overflow;
+        if (pass == 0) tm.mark();  // 3
+
+        // ---- K5-K8 count + filter + gather (+ sort for the global graph stage)
+        double pilot = 0.0;
+        const bool want_pilot = adaptive && pass == 0 && !have_hint;
+        rc = snk_stage_count_table(ctx, st, K, records, part.seg, part.seg + NB, 2 * NB, part.nseg, NB, p->min_freq, (in->bc && !grouped) ? p->min_bc : 0u, grouped ? 1u : 0u,
+                                   h_ninst, status, !local_graph, &tab, err, errcap, nullptr, want_pilot ? &pilot : nullptr);
+        if (rc == SNK_RETARGET) {
+            // everything since the partition goes back to the arena; the good lengths and the status words stay
+            snk_ctx_release_since(ctx, mark, nullptr, 0);
+            SNK_HIP_TRY(hipMemsetAsync(status, 0, 64, st));
+            ratio = pilot;
+            out->repartitioned = 1;
+            continue;
+        }
+        if (rc) return rc;
+        break;
+    }
+    if (h_ninst) { ctx->claim_ratio = (double)tab.distinct / (double)h_ninst; ctx->claim_ratio_reads = n_reads; ctx->claim_ratio_k = K * 2 + (grouped ? 1u : 0u); }
     snk_ctx_release_block(ctx, records);       // 2.5x-capacity supermer slots: the graph stage may reuse the memory
     const uint64_t n_kmers = tab.n;
     out->buckets_split = tab.buckets_split;

@@ -172,10 +172,17 @@ int range_ready(void* user, uint32_t r) {
     return hipStreamWaitEvent(w->st, w->ev[r], 0) == hipSuccess ? 0 : 1;
 }
 
-uint32_t plan_buckets(uint64_t inst_ub, uint32_t world, uint32_t K, uint32_t forced) {
+uint32_t plan_buckets(uint64_t inst_ub, uint32_t world, uint32_t K, uint32_t forced, double ratio) {
     uint64_t nb = forced;
     if (!nb) {
-        const uint64_t target = snk_env_u32("SNK_TARGET_INST", K == 48 ? 5000u : 3500u);
+        const uint32_t dflt = K == 48 ? 5000u : 3500u;
+        uint64_t target = snk_env_u32("SNK_TARGET_INST", dflt);
+        const char* e = getenv("SNK_TARGET_INST");
+        if (!(e && *e) && ratio > 0.0 && snk_env_u32("SNK_ADAPTIVE_BUCKETS", 1)) {
+            // (the rule of the one-GPU path, snk_pipeline.hip: smaller buckets when the tables would run more than ~65 % full)
+            const double lim = (double)snk_count_limit(K, 0);
+            if (0.65 * lim / ratio < (double)dflt) { const double t = 0.01 * snk_env_u32("SNK_BUCKET_FILL_PCT", 50) * lim / ratio; target = t < 600.0 ? 600u : (uint64_t)t; if (target > dflt) target = dflt; }
+        }
         nb = (inst_ub + target - 1) / target;
         if (nb < 1) nb = 1;
         if (nb > (1ull << 26)) nb = 1ull << 26;
@@ -223,7 +230,8 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
             for (ull v : all) inst_ub += v * kpr;
         }
     }
-    const uint32_t NB_total = plan_buckets(inst_ub, W, K, p->n_buckets);
+    const bool have_ratio = inst_ub && ctx->claim_ratio > 0.0 && ctx->claim_ratio_reads == inst_ub && ctx->claim_ratio_k == ((K * 2) | 0x80000000u);
+    const uint32_t NB_total = plan_buckets(inst_ub, W, K, p->n_buckets, have_ratio ? ctx->claim_ratio : 0.0);
     const uint32_t NBl = NB_total / W;
     // ---- trim + one-pass partition over all buckets of the job
     uint64_t n_inst = 0;
@@ -332,15 +340,25 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
     TRY(snk_shard_prune_plan(ctx, nullptr, st, err, errcap));
     // one read-back: every rank's query counts (still on the device: bl.qcount) and retained k-mers
     ull* d_cnt = S->bl.qcount;
+    // ... and, riding along, what the tables of my count kernel held (distinct k-mers) over how many instances: the job-wide ratio
+    // sizes the buckets of the NEXT step, the same on every rank because it is computed from the same exchanged words
+    constexpr uint32_t QX = 3;
     {
-        ull hn = n_kmers, *up;
-        TRY(upload(X, &hn, 1, &up));
-        SNK_HIP_TRY(hipMemcpyAsync(d_cnt + W, up, 8, hipMemcpyDeviceToDevice, st));
+        ull hn[QX] = {n_kmers, S->tab.distinct, n_inst}, *up;
+        TRY(upload(X, hn, QX, &up));
+        SNK_HIP_TRY(hipMemcpyAsync(d_cnt + W, up, QX * 8, hipMemcpyDeviceToDevice, st));
     }
     std::vector<ull> qall;
-    TRY(exchange_counts(X, d_cnt, W + 1, qall));
+    TRY(exchange_counts(X, d_cnt, W + QX, qall));
     std::vector<ull> q_send(W), q_recv(W), all_n(W);
-    for (uint32_t q = 0; q < W; ++q) { q_send[q] = qall[(size_t)me * (W + 1) + q]; q_recv[q] = qall[(size_t)q * (W + 1) + me]; all_n[q] = qall[(size_t)q * (W + 1) + W]; }
+    {
+        ull dsum = 0, isum = 0;
+        for (uint32_t q = 0; q < W; ++q) {
+            q_send[q] = qall[(size_t)me * (W + QX) + q]; q_recv[q] = qall[(size_t)q * (W + QX) + me]; all_n[q] = qall[(size_t)q * (W + QX) + W];
+            dsum += qall[(size_t)q * (W + QX) + W + 1]; isum += qall[(size_t)q * (W + QX) + W + 2];
+        }
+        if (isum) { ctx->claim_ratio = (double)dsum / (double)isum; ctx->claim_ratio_reads = inst_ub; ctx->claim_ratio_k = (K * 2) | 0x80000000u; }      // (keyed by a job-wide figure: every rank must take the same decision)
+    }
     uint64_t nq = 0, nq_in = 0;
     for (uint32_t q = 0; q < W; ++q) { nq += q_send[q]; nq_in += q_recv[q]; }
     ull* d_qoff;

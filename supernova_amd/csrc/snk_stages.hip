@@ -25,7 +25,7 @@ uint32_t snk_env_u32(const char* name, uint32_t dflt) {
 // status: device u32[16] scratch words.
 int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* records, const uint64_t* seg_beg,
                           const uint64_t* seg_end, uint32_t seg_stride, uint32_t nseg, uint32_t NB, uint32_t min_freq, uint32_t bc_mode, uint32_t grouped, uint64_t n_inst_hint,
-                          uint32_t* status, bool want_sort, snk_table* out, char* err, size_t errcap, const snk_count_ranges* ranges) {
+                          uint32_t* status, bool want_sort, snk_table* out, char* err, size_t errcap, const snk_count_ranges* ranges, double* pilot_ratio) {
     int rc;
     snk_phase_timer tm(st), kt(st);
     tm.mark();
@@ -111,6 +111,23 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
                 cr.NB = ranges->bounds[r + 1];
                 if ((rc = snk_launch_count(K, st, cr, err, errcap))) return rc;
             }
+        } else if (attempt == 0 && pilot_ratio && NB >= 16384 && n_inst_hint) {
+            // the pilot: 1/64 of the buckets, then a look at how full their tables ran
+            const uint32_t NBp = NB / 64;
+            snk_count_args cp = ca;
+            cp.NB = NBp;
+            if ((rc = snk_launch_count(K, st, cp, err, errcap))) return rc;
+            uint32_t h_p[8];
+            SNK_HIP_TRY(hipMemcpyAsync(h_p, status, 32, hipMemcpyDeviceToHost, st));
+            SNK_HIP_TRY(snk_sync(st));
+            const double per_bucket = (double)h_p[5] * 16.0 / NBp;
+            if (per_bucket > 0.85 * snk_count_limit(K, grouped) && !h_p[1]) {
+                *pilot_ratio = per_bucket * (double)NB / (double)n_inst_hint;
+                return SNK_RETARGET;
+            }
+            snk_count_args cr = ca;
+            cr.bucket0 = NBp;
+            if ((rc = snk_launch_count(K, st, cr, err, errcap))) return rc;
         } else if ((rc = snk_launch_count(K, st, ca, err, errcap))) return rc;
         kt.mark();
         SNK_HIP_TRY(hipMemcpyAsync(h_rcur.data(), rcur, n_regions * 8ull, hipMemcpyDeviceToHost, st));
@@ -160,6 +177,7 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
     }
     out->buckets_split = h_status[2];
     out->max_slots_used = h_status[3];
+    out->distinct = (uint64_t)h_status[5] * 16;
     out->n = n_kmers;
     ctx->last_n_kmers = n_kmers;
     ctx->last_n_instances = n_inst_hint;

@@ -50,7 +50,7 @@ class SnkDevResult(C.Structure):
                 ("buckets_split", C.c_uint32), ("max_slots_used", C.c_uint32), ("n_overflow", C.c_uint32),
                 ("scratch_bytes", C.c_uint64), ("phase_ms", C.c_float * 8), ("kernel_ms", C.c_float * 4),
                 ("n_boundary", C.c_uint64), ("n_fragments", C.c_uint64), ("unitig_group", C.c_void_p),
-                ("graph_ms", C.c_float * 8)]
+                ("graph_ms", C.c_float * 8), ("repartitioned", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 class SnkShardFrags(C.Structure):

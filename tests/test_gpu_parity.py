@@ -190,6 +190,54 @@ def test_trim_inside_the_partition_kernel(engine, K, monkeypatch):
         assert np.array_equal(g2.astype(np.uint32), want)
 
 
+def test_error_rich_reads_are_repartitioned_into_smaller_buckets(engine, monkeypatch):
+    """Bucket size follows the data: when the first buckets hold more distinct k-mers than the count kernel's LDS table takes
+    (1.5 % errors here), the one-GPU path partitions a second time into smaller buckets instead of hash-splitting nearly every
+    bucket, and later calls on the context start there.  The result does not depend on the bucket count: the same table and the
+    same unitigs as with the fixed default size."""
+    import math
+    import torch
+    from supernova_amd import synth
+    from supernova_amd.engine import Engine, Params
+    n = 1_200_000
+    sp = synth.synth_params(n, seed=0x5EED0E77, sub_ppm=15000, lowq_tail_ppm=200000)
+    lam, term, cum = 150 * 15000 / 1e6, math.exp(-150 * 15000 / 1e6), 0.0
+    for j in range(4):
+        cum += term
+        sp.err_cdf[j] = min(0xFFFFFFFF, int(cum * 4294967296.0))
+        term *= lam / (j + 1)
+    e = Engine(0)               # a fresh context: no bucket-size hint from earlier calls
+    try:
+        rows, quals, bc = e.synth(sp)
+
+        def table(r):
+            k, c, x = r.keys(), r.counts(), r.ctx()
+            o = np.lexsort(tuple(k[:, j] for j in range(k.shape[1] - 1, -1, -1)))
+            return k[o], c[o], x[o], sorted(r.unitigs())
+
+        monkeypatch.setenv("SNK_ADAPTIVE_BUCKETS", "0")
+        r0 = e.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48, sorted_table=False))
+        assert r0.repartitioned == 0 and r0.buckets_split > r0.n_buckets // 2
+        ref = table(r0)
+        nb0 = r0.n_buckets
+        monkeypatch.setenv("SNK_ADAPTIVE_BUCKETS", "1")
+        e2 = Engine(0)
+        try:
+            r1 = e2.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48, sorted_table=False))
+            assert r1.repartitioned == 1 and r1.n_buckets > 1.5 * nb0 and r1.buckets_split < r1.n_buckets // 4
+            got = table(r1)
+            assert all(np.array_equal(a, b) for a, b in zip(ref[:3], got[:3])) and ref[3] == got[3]
+            r2 = e2.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48, sorted_table=False))      # the hint: no second partition
+            assert r2.repartitioned == 0 and r2.n_buckets > 1.5 * nb0
+            got2 = table(r2)
+            assert all(np.array_equal(a, b) for a, b in zip(ref[:3], got2[:3])) and ref[3] == got2[3]
+        finally:
+            e2.close()
+    finally:
+        e.close()
+        torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("name,use_bc", [("adversarial", True), ("synth_20k_err", False)])
 def test_k60_vs_oracle(engine, name, use_bc):
     """K=60 (long-k config): key 120 bit, supermers up to 106 bases.  The reference's BuildReadQGraph60 has no barcode
