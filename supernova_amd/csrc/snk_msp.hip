@@ -17,7 +17,7 @@
 // register), so a wave never serialises on "rescan on expiry".  Supermer starts are appended to a
 // short per-thread LDS list and emitted in a second, short loop.
 //
-// ONE pass: every bucket owns `cap` record slots (cap = 2.5 x the expected supermers per bucket; the expectation is
+// ONE pass: every bucket owns `cap` record slots (cap = expected supermers per bucket + 5 sigma of the occupancy model in snk_stages.hip; the expectation is
 // exact bookkeeping: k-mer instances are known after the trim, a random-order minimiser starts a supermer every
 // (W+1)/2 k-mers); a supermer takes slot atomicAdd(cursor) of its bucket, the few that do not fit go to an overflow
 // list that is grouped by bucket afterwards and read by the count kernel as a second segment.  Correctness never

@@ -173,7 +173,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
         break;
     }
     if (h_ninst) { ctx->claim_ratio = (double)tab.distinct / (double)h_ninst; ctx->claim_ratio_reads = n_reads; ctx->claim_ratio_k = K * 2 + (grouped ? 1u : 0u); }
-    snk_ctx_release_block(ctx, records);       // 2.5x-capacity supermer slots: the graph stage may reuse the memory
+    snk_ctx_release_block(ctx, records);       // the fixed-capacity supermer slots: the graph stage may reuse the memory
     const uint64_t n_kmers = tab.n;
     out->buckets_split = tab.buckets_split;
     out->max_slots_used = tab.max_slots_used;
