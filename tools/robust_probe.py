@@ -29,13 +29,18 @@ cases = [("bench model (0.2 % errors, 5 % tails, 56x)", {}),
          ("0.6 % errors", dict(sub_ppm=6000)),
          ("1.5 % errors, 50 % tails", dict(sub_ppm=15000, lowq_tail_ppm=500000)),
          ("28x coverage", dict(genome_len=n * 150 // 28)),
-         ("112x coverage", dict(genome_len=n * 150 // 112))]
+         ("112x coverage", dict(genome_len=n * 150 // 112)),
+         ("100-base reads", dict(read_len=100, genome_len=n * 100 // 56)),
+         ("250-base reads", dict(read_len=250, genome_len=n * 250 // 56, insert_min=500)),
+         ("K=60, 0.6 % errors", dict(sub_ppm=6000, K=60))]
 for name, ov in cases:
     if only and only not in name:
         continue
+    K = ov.pop("K", 48)
     sp = synth.synth_params(n, seed=0x5EED0042, **ov)
+    L = sp.read_len
     if "sub_ppm" in ov:
-        for j, v in enumerate(cdf(150 * ov["sub_ppm"] / 1e6)):
+        for j, v in enumerate(cdf(L * ov["sub_ppm"] / 1e6)):
             sp.err_cdf[j] = v
     rows, quals, bc = eng.synth(sp)
     torch.cuda.synchronize()
@@ -43,7 +48,7 @@ for name, ov in cases:
     eng2 = Engine(0)          # a fresh context per case: no hint from the case before
     for rep in range(3):
         t0 = time.perf_counter()
-        r = eng2.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48, sorted_table=False))
+        r = eng2.count_graph(rows, L, quals=quals, bc=bc, params=Params(K=K, sorted_table=False))
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) * 1e3
         if rep == 0: first = (dt, r.repartitioned, r.n_buckets)
