@@ -312,3 +312,60 @@ def test_sharded_circles_at_scale_against_the_oracle(snk, W):
                             params=Params(K=48))
         assert res.unitigs() == o.unitigs and res.n_circles >= 6
         e.close()
+
+
+def test_sharded_bucket_size_follows_the_data(snk):
+    """Error-rich reads: the second step of a sharded job sizes its buckets from the job-wide ratio of distinct k-mers per instance
+    the first step exchanged (the same decision on every rank), and gives the same table and unitigs as the first step and as
+    the one-GPU path."""
+    import math
+    import threading
+    import torch
+    from supernova_amd import synth
+    from supernova_amd.engine import Engine, Params
+    from supernova_amd.sharded import ShardedEngine, SimWorld
+    W, n = 2, 1_200_000
+    sp = synth.synth_params(n, seed=0x5EED0E78, sub_ppm=15000)
+    lam, term, cum = 150 * 15000 / 1e6, math.exp(-150 * 15000 / 1e6), 0.0
+    for j in range(4):
+        cum += term
+        sp.err_cdf[j] = min(0xFFFFFFFF, int(cum * 4294967296.0))
+        term *= lam / (j + 1)
+    e0 = Engine(0)
+    rows, quals, bc = e0.synth(sp)
+    ref = e0.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48))
+    ref_keys, ref_counts, ref_unitigs = ref.keys(), ref.counts(), sorted(ref.unitigs())
+    world = SimWorld(W)
+    outs, errs = [[None] * W for _ in range(2)], []
+
+    def worker(r):
+        try:
+            torch.cuda.set_device(0)
+            e = Engine(0)
+            sh = ShardedEngine(e, world.comm(r))
+            lo, hi = n * r // W, n * (r + 1) // W
+            for step in range(2):
+                res = sh.count_graph(rows[lo:hi].contiguous(), 150, quals=quals[lo:hi].contiguous(), bc=bc[lo:hi].contiguous(), params=Params(K=48),
+                                     read_index_base=lo, total_reads=n)
+                outs[step][r] = dict(keys=res.keys(), counts=res.counts(), unitigs=res.unitigs(), nb=int(res.raw.n_buckets_total))
+            e.close()
+        except BaseException as ex:  # noqa: BLE001
+            errs.append(ex)
+            world.barrier_obj.abort()
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(W)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if errs:
+        raise errs[0]
+    for step in range(2):
+        keys = np.concatenate([o["keys"] for o in outs[step]])
+        counts = np.concatenate([o["counts"] for o in outs[step]])
+        order = np.lexsort((keys[:, 3], keys[:, 2], keys[:, 1], keys[:, 0]))
+        assert np.array_equal(keys[order], ref_keys) and np.array_equal(counts[order], ref_counts)
+        assert sorted(u for o in outs[step] for u in o["unitigs"]) == ref_unitigs
+        assert outs[step][0]["nb"] == outs[step][1]["nb"]
+    assert outs[1][0]["nb"] > 1.5 * outs[0][0]["nb"]
+    e0.close()
