@@ -343,7 +343,8 @@ typedef struct snk_shard_result {
     float phase_ms[8];               /* trim+partition, histograms+compaction, exchange issue, count, prune, fragments, join, total */
     float join_ms[8];                /* links, link structure, rank+place, route, emit */
     float count_kernel_ms;
-    float reserved_f;
+    uint32_t repartitioned;          /* 1: the first buckets overflowed the count kernel's tables and the step partitioned and exchanged a
+                                        second time into smaller buckets (a job-wide decision); later steps on the context start there */
 } snk_shard_result;
 /* total_reads: reads of the whole job (sizes the bucket count without an exchange; 0 = the ranks exchange their slab sizes,
  * ignored when p->n_buckets is set).  in->read_index_base = global index of the slab's first read. */

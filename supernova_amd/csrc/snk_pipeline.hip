@@ -157,7 +157,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
         if (pass == 0) tm.mark();  // 3
 
         // ---- K5-K8 count + filter + gather (+ sort for the global graph stage)
-        double pilot = 0.0;
+        snk_count_pilot pilot{0.0, nullptr, nullptr};
         const bool want_pilot = adaptive && pass == 0 && !have_hint;
         rc = snk_stage_count_table(ctx, st, K, records, part.seg, part.seg + NB, 2 * NB, part.nseg, NB, p->min_freq, (in->bc && !grouped) ? p->min_bc : 0u, grouped ? 1u : 0u,
                                    h_ninst, status, !local_graph, &tab, err, errcap, nullptr, want_pilot ? &pilot : nullptr);
@@ -165,7 +165,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
             // everything since the partition goes back to the arena; the good lengths and the status words stay
             snk_ctx_release_since(ctx, mark, nullptr, 0);
             SNK_HIP_TRY(hipMemsetAsync(status, 0, 64, st));
-            ratio = pilot;
+            ratio = h_ninst ? pilot.per_bucket * (double)NB / (double)h_ninst : 0.0;
             out->repartitioned = 1;
             continue;
         }

@@ -231,108 +231,149 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
         }
     }
     const bool have_ratio = inst_ub && ctx->claim_ratio > 0.0 && ctx->claim_ratio_reads == inst_ub && ctx->claim_ratio_k == ((K * 2) | 0x80000000u);
-    const uint32_t NB_total = plan_buckets(inst_ub, W, K, p->n_buckets, have_ratio ? ctx->claim_ratio : 0.0);
-    const uint32_t NBl = NB_total / W;
-    // ---- trim + one-pass partition over all buckets of the job
-    uint64_t n_inst = 0;
-    TRY(snk_shard_begin(ctx, in, p, me, W, NB_total, &n_inst, st, err, errcap));
-    snk_shard_state* S = snk_shard_state_of(ctx);
-    const snk_partition& part = S->part;
-    if (part.n_supermers >= (1ull << 32)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "more than 2^32 supermers on one rank");
-    tm.mark();   // 1
+    // Bucket size: from the job-wide ratio of distinct k-mers per instance the previous step exchanged; without that history the
+    // count stage looks at its first buckets, the ranks agree on what they saw (one more exchange), and if the tables overflow as
+    // a rule the reads are partitioned and exchanged once more into smaller buckets (error-rich reads: see snk_pipeline.hip).
+    const char* forced_target = getenv("SNK_TARGET_INST");
+    const bool adaptive = inst_ub && !(forced_target && *forced_target) && snk_env_u32("SNK_ADAPTIVE_BUCKETS", 1) != 0;
+    double ratio = have_ratio ? ctx->claim_ratio : 0.0;
+    uint32_t NB_total = 0, NBl = 0;
+    uint64_t n_inst = 0, inst_hint = 0, exch_records = 0;
+    snk_shard_state* S = nullptr;
     const int has_bc = in->bc ? 1 : 0;
-    const uint64_t inst_hint = total_reads ? total_reads * kpr / W : (inst_ub ? inst_ub / W : n_inst);
-    uint64_t exch_records = 0;
-    if (W == 1) {
-        // one rank owns every bucket: the slots are counted where they are (exactly the one-GPU path)
-        tm.mark();   // 2
-        tm.mark();   // 3
-        const uint32_t fake = snk_env_u32("SNK_DBG_FAKE_SEGS", 0);
-        if (fake > 1 && fake <= 32 && part.n_overflow == 0) {
-            uint64_t* T;
-            ALLOC(T, uint64_t, 2ull * fake * NB_total + 2);
-            hipLaunchKernelGGL(fake_seg_kernel, dim3((NB_total + 255) / 256), dim3(256), 0, st, part.cursor, NB_total, part.cap, fake, T);
-            TRY(snk_stage_count_table(ctx, st, K, part.records, T, T + (uint64_t)fake * NB_total, NB_total, fake, NB_total, p->min_freq,
-                                      has_bc ? p->min_bc : 0u, 0u, inst_hint, S->status, false, &S->tab, err, errcap));
-        } else
-        TRY(snk_stage_count_table(ctx, st, K, part.records, part.seg, part.seg + NB_total, 2 * NB_total, part.nseg, NB_total, p->min_freq,
-                                  has_bc ? p->min_bc : 0u, 0u, inst_hint, S->status, false, &S->tab, err, errcap));
-        snk_ctx_release_block(ctx, part.records);
-    } else {
-        // ---- histograms: row p of my cursor array goes to rank p
-        uint32_t *hrecv, *hsend_x;
-        ALLOC(hrecv, uint32_t, (uint64_t)NB_total + 4);
-        ALLOC(hsend_x, uint32_t, (uint64_t)NB_total + 4);
-        {
-            std::vector<uint64_t> beg(W), cnt(W, (uint64_t)NBl * 4);
-            for (uint32_t q = 0; q < W; ++q) beg[q] = (uint64_t)q * NBl * 4;
-            TRY(comm->a2a(part.cursor, beg.data(), cnt.data(), hrecv, beg.data(), cnt.data(), st, err, errcap));
-        }
-        // my own buckets take no part in the exchange: zero rows in both directions
-        SNK_HIP_TRY(hipMemcpyAsync(hsend_x, part.cursor, (size_t)NB_total * 4, hipMemcpyDeviceToDevice, st));
-        SNK_HIP_TRY(hipMemsetAsync(hsend_x + (uint64_t)me * NBl, 0, (size_t)NBl * 4, st));
-        SNK_HIP_TRY(hipMemsetAsync(hrecv + (uint64_t)me * NBl, 0, (size_t)NBl * 4, st));
-        uint32_t R = snk_env_u32("SNK_EXCHANGE_RANGES", 4);
-        if (R < 1) R = 1;
-        if (R > NBl) R = NBl;
-        if (R > 64) R = 64;
-        ull* d_rs;      // [2][W][R] records per (destination, range) and per (source, range)
-        ALLOC(d_rs, ull, 2ull * W * R + 1);
-        hipLaunchKernelGGL(range_sum_kernel, dim3(W * R), dim3(256), 0, st, hsend_x, NBl, R, d_rs);
-        hipLaunchKernelGGL(range_sum_kernel, dim3(W * R), dim3(256), 0, st, hrecv, NBl, R, d_rs + (size_t)W * R);
-        uint32_t* soff32;
-        ull* roff;
-        ALLOC(soff32, uint32_t, (uint64_t)NB_total + 4);
-        ALLOC(roff, ull, (uint64_t)NB_total + 4);
-        TRY((excl_scan<const uint32_t*, uint32_t>(X, hsend_x, soff32, (size_t)NB_total + 1, 0u)));
-        {
-            auto it = rocprim::make_transform_iterator(hrecv, [] __device__(uint32_t v) { return (ull)v; });
-            TRY((excl_scan<decltype(it), ull>(X, it, roff, (size_t)NB_total + 1, 0ull)));
-        }
-        std::vector<ull> h_rs(2ull * W * R);
-        SNK_HIP_TRY(hipMemcpyAsync(h_rs.data(), d_rs, h_rs.size() * 8, hipMemcpyDeviceToHost, st));
-        SNK_HIP_TRY(snk_sync(st));          // read-back: piece sizes of the record exchange (both directions)
-        uint64_t n_send = 0, n_recv = 0;
-        for (size_t q = 0; q < (size_t)W * R; ++q) { n_send += h_rs[q]; n_recv += h_rs[(size_t)W * R + q]; }
-        uint4 *sendb, *recvb;
-        ALLOC(sendb, uint4, 2 * n_send + 2);
-        ALLOC(recvb, uint4, 2 * n_recv + 2);
-        TRY(snk_stage_partition_compact_remote(ctx, st, &part, soff32, sendb, me * NBl, (me + 1) * NBl, err, errcap));
-        tm.mark();   // 2
-        // ---- the records, range by range on the exchange's stream
-        if (H.ev.size() < R + 1) { const size_t o = H.ev.size(); H.ev.resize(R + 1); for (size_t q = o; q < H.ev.size(); ++q) SNK_HIP_TRY(hipEventCreateWithFlags(&H.ev[q], hipEventDisableTiming)); }
-        if (!H.cstream) SNK_HIP_TRY(hipStreamCreateWithFlags(&H.cstream, hipStreamNonBlocking));
-        SNK_HIP_TRY(hipEventRecord(H.ev[R], st));
-        SNK_HIP_TRY(hipStreamWaitEvent(H.cstream, H.ev[R], 0));
-        {
-            // offsets of piece (q, r): the ranges of one peer follow each other
-            std::vector<uint64_t> sbeg(W), scnt(W), rbeg(W), rcnt(W);
-            for (uint32_t r = 0; r < R; ++r) {
-                snk_plan_range_pieces(h_rs.data(), W, R, r, 32, sbeg.data(), scnt.data(), rbeg.data(), rcnt.data());
-                TRY(comm->a2a(sendb, sbeg.data(), scnt.data(), recvb, rbeg.data(), rcnt.data(), H.cstream, err, errcap));
-                SNK_HIP_TRY(hipEventRecord(H.ev[r], H.cstream));
+    struct agree_ctx { step_ctx* X; } ag{&X};
+    snk_count_pilot pilot{0.0, [](void* u, double* pb) -> int {
+        step_ctx& Xc = *static_cast<agree_ctx*>(u)->X;
+        ull mine = (ull)(*pb * 1024.0), *d_mine;
+        int r2 = upload(Xc, &mine, 1, &d_mine);
+        if (r2) return r2;
+        std::vector<ull> all;
+        if ((r2 = exchange_counts(Xc, d_mine, 1, all))) return r2;
+        ull sum = 0;
+        for (ull v : all) sum += v;
+        *pb = (double)sum / 1024.0 / (double)all.size();
+        return 0;
+    }, &ag};
+    auto count_pass = [&](bool with_pilot) -> int {
+        // ---- trim + one-pass partition over all buckets of the job
+        n_inst = 0;
+        TRY(snk_shard_begin(ctx, in, p, me, W, NB_total, &n_inst, st, err, errcap));
+        S = snk_shard_state_of(ctx);
+        const snk_partition& part = S->part;
+        if (part.n_supermers >= (1ull << 32)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "more than 2^32 supermers on one rank");
+        tm.mark();   // 1
+        inst_hint = total_reads ? total_reads * kpr / W : (inst_ub ? inst_ub / W : n_inst);
+        exch_records = 0;
+        if (W == 1) {
+            // one rank owns every bucket: the slots are counted where they are (exactly the one-GPU path)
+            tm.mark();   // 2
+            tm.mark();   // 3
+            const uint32_t fake = snk_env_u32("SNK_DBG_FAKE_SEGS", 0);
+            if (fake > 1 && fake <= 32 && part.n_overflow == 0) {
+                uint64_t* T;
+                ALLOC(T, uint64_t, 2ull * fake * NB_total + 2);
+                hipLaunchKernelGGL(fake_seg_kernel, dim3((NB_total + 255) / 256), dim3(256), 0, st, part.cursor, NB_total, part.cap, fake, T);
+                TRY(snk_stage_count_table(ctx, st, K, part.records, T, T + (uint64_t)fake * NB_total, NB_total, fake, NB_total, p->min_freq,
+                                          has_bc ? p->min_bc : 0u, 0u, inst_hint, S->status, false, &S->tab, err, errcap));
+            } else
+            TRY(snk_stage_count_table(ctx, st, K, part.records, part.seg, part.seg + NB_total, 2 * NB_total, part.nseg, NB_total, p->min_freq,
+                                      has_bc ? p->min_bc : 0u, 0u, inst_hint, S->status, false, &S->tab, err, errcap, nullptr, with_pilot ? &pilot : nullptr));
+            snk_ctx_release_block(ctx, part.records);
+        } else {
+            // ---- histograms: row p of my cursor array goes to rank p
+            uint32_t *hrecv, *hsend_x;
+            ALLOC(hrecv, uint32_t, (uint64_t)NB_total + 4);
+            ALLOC(hsend_x, uint32_t, (uint64_t)NB_total + 4);
+            {
+                std::vector<uint64_t> beg(W), cnt(W, (uint64_t)NBl * 4);
+                for (uint32_t q = 0; q < W; ++q) beg[q] = (uint64_t)q * NBl * 4;
+                TRY(comm->a2a(part.cursor, beg.data(), cnt.data(), hrecv, beg.data(), cnt.data(), st, err, errcap));
             }
+            // my own buckets take no part in the exchange: zero rows in both directions
+            SNK_HIP_TRY(hipMemcpyAsync(hsend_x, part.cursor, (size_t)NB_total * 4, hipMemcpyDeviceToDevice, st));
+            SNK_HIP_TRY(hipMemsetAsync(hsend_x + (uint64_t)me * NBl, 0, (size_t)NBl * 4, st));
+            SNK_HIP_TRY(hipMemsetAsync(hrecv + (uint64_t)me * NBl, 0, (size_t)NBl * 4, st));
+            uint32_t R = snk_env_u32("SNK_EXCHANGE_RANGES", 4);
+            if (R < 1) R = 1;
+            if (R > NBl) R = NBl;
+            if (R > 64) R = 64;
+            ull* d_rs;      // [2][W][R] records per (destination, range) and per (source, range)
+            ALLOC(d_rs, ull, 2ull * W * R + 1);
+            hipLaunchKernelGGL(range_sum_kernel, dim3(W * R), dim3(256), 0, st, hsend_x, NBl, R, d_rs);
+            hipLaunchKernelGGL(range_sum_kernel, dim3(W * R), dim3(256), 0, st, hrecv, NBl, R, d_rs + (size_t)W * R);
+            uint32_t* soff32;
+            ull* roff;
+            ALLOC(soff32, uint32_t, (uint64_t)NB_total + 4);
+            ALLOC(roff, ull, (uint64_t)NB_total + 4);
+            TRY((excl_scan<const uint32_t*, uint32_t>(X, hsend_x, soff32, (size_t)NB_total + 1, 0u)));
+            {
+                auto it = rocprim::make_transform_iterator(hrecv, [] __device__(uint32_t v) { return (ull)v; });
+                TRY((excl_scan<decltype(it), ull>(X, it, roff, (size_t)NB_total + 1, 0ull)));
+            }
+            std::vector<ull> h_rs(2ull * W * R);
+            SNK_HIP_TRY(hipMemcpyAsync(h_rs.data(), d_rs, h_rs.size() * 8, hipMemcpyDeviceToHost, st));
+            SNK_HIP_TRY(snk_sync(st));          // read-back: piece sizes of the record exchange (both directions)
+            uint64_t n_send = 0, n_recv = 0;
+            for (size_t q = 0; q < (size_t)W * R; ++q) { n_send += h_rs[q]; n_recv += h_rs[(size_t)W * R + q]; }
+            uint4 *sendb, *recvb;
+            ALLOC(sendb, uint4, 2 * n_send + 2);
+            ALLOC(recvb, uint4, 2 * n_recv + 2);
+            TRY(snk_stage_partition_compact_remote(ctx, st, &part, soff32, sendb, me * NBl, (me + 1) * NBl, err, errcap));
+            tm.mark();   // 2
+            // ---- the records, range by range on the exchange's stream
+            if (H.ev.size() < R + 1) { const size_t o = H.ev.size(); H.ev.resize(R + 1); for (size_t q = o; q < H.ev.size(); ++q) SNK_HIP_TRY(hipEventCreateWithFlags(&H.ev[q], hipEventDisableTiming)); }
+            if (!H.cstream) SNK_HIP_TRY(hipStreamCreateWithFlags(&H.cstream, hipStreamNonBlocking));
+            SNK_HIP_TRY(hipEventRecord(H.ev[R], st));
+            SNK_HIP_TRY(hipStreamWaitEvent(H.cstream, H.ev[R], 0));
+            {
+                // offsets of piece (q, r): the ranges of one peer follow each other
+                std::vector<uint64_t> sbeg(W), scnt(W), rbeg(W), rcnt(W);
+                for (uint32_t r = 0; r < R; ++r) {
+                    snk_plan_range_pieces(h_rs.data(), W, R, r, 32, sbeg.data(), scnt.data(), rbeg.data(), rcnt.data());
+                    TRY(comm->a2a(sendb, sbeg.data(), scnt.data(), recvb, rbeg.data(), rcnt.data(), H.cstream, err, errcap));
+                    SNK_HIP_TRY(hipEventRecord(H.ev[r], H.cstream));
+                }
+            }
+            exch_records = n_send * 32;
+            // ---- segment tables: W sources (mine = the slots, in place) + my overflow segment
+            const uint32_t nseg = W + (part.n_overflow ? 1u : 0u);
+            uint64_t* T;
+            ALLOC(T, uint64_t, 2ull * nseg * NBl + 2);
+            const ull delta = (ull)(((intptr_t)part.records - (intptr_t)recvb) / 32);
+            hipLaunchKernelGGL(seg_table_kernel, dim3((NBl + 255) / 256), dim3(256), 0, st, roff, hrecv, part.cursor, part.seg, W, me, NBl, NB_total, part.cap,
+                               nseg, delta, T);
+            SNK_HIP_TRY(hipGetLastError());
+            tm.mark();   // 3
+            std::vector<uint32_t> bounds(R + 1);
+            for (uint32_t r = 0; r <= R; ++r) bounds[r] = (uint32_t)((uint64_t)NBl * r / R);
+            range_wait rw{st, H.ev.data(), R};
+            snk_count_ranges rg{R, bounds.data(), range_ready, &rw};
+            TRY(snk_stage_count_table(ctx, st, K, recvb, T, T + (uint64_t)nseg * NBl, NBl, nseg, NBl, p->min_freq, has_bc ? p->min_bc : 0u, 0u, inst_hint,
+                                      S->status, false, &S->tab, err, errcap, &rg, with_pilot ? &pilot : nullptr));
+            snk_ctx_release_block(ctx, part.records);
+            snk_ctx_release_block(ctx, sendb);
+            snk_ctx_release_block(ctx, recvb);
         }
-        exch_records = n_send * 32;
-        // ---- segment tables: W sources (mine = the slots, in place) + my overflow segment
-        const uint32_t nseg = W + (part.n_overflow ? 1u : 0u);
-        uint64_t* T;
-        ALLOC(T, uint64_t, 2ull * nseg * NBl + 2);
-        const ull delta = (ull)(((intptr_t)part.records - (intptr_t)recvb) / 32);
-        hipLaunchKernelGGL(seg_table_kernel, dim3((NBl + 255) / 256), dim3(256), 0, st, roff, hrecv, part.cursor, part.seg, W, me, NBl, NB_total, part.cap,
-                           nseg, delta, T);
-        SNK_HIP_TRY(hipGetLastError());
-        tm.mark();   // 3
-        std::vector<uint32_t> bounds(R + 1);
-        for (uint32_t r = 0; r <= R; ++r) bounds[r] = (uint32_t)((uint64_t)NBl * r / R);
-        range_wait rw{st, H.ev.data(), R};
-        snk_count_ranges rg{R, bounds.data(), range_ready, &rw};
-        TRY(snk_stage_count_table(ctx, st, K, recvb, T, T + (uint64_t)nseg * NBl, NBl, nseg, NBl, p->min_freq, has_bc ? p->min_bc : 0u, 0u, inst_hint,
-                                  S->status, false, &S->tab, err, errcap, &rg));
-        snk_ctx_release_block(ctx, part.records);
-        snk_ctx_release_block(ctx, sendb);
-        snk_ctx_release_block(ctx, recvb);
+        return SNK_OK;
+    };
+    uint32_t repartitioned = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        NB_total = plan_buckets(inst_ub, W, K, p->n_buckets, adaptive ? ratio : 0.0);
+        NBl = NB_total / W;
+        tm.n = 1;
+        const int rcp = count_pass(adaptive && !have_ratio && pass == 0 && p->n_buckets == 0);
+        if (rcp == SNK_RETARGET) {
+            // every rank took this turn (the figure is job-wide); what the exchange still has in flight lands first
+            if (H.cstream) SNK_HIP_TRY(hipStreamSynchronize(H.cstream));
+            SNK_HIP_TRY(snk_sync(st));
+            ratio = pilot.per_bucket * (double)NB_total / (double)inst_ub;
+            repartitioned = 1;
+            continue;
+        }
+        if (rcp) return rcp;
+        break;
     }
+    const snk_partition& part = S->part;
     tm.mark();   // 4
     const uint64_t n_kmers = S->tab.n;
 
@@ -583,6 +624,7 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
     out->n_circles = un.n_circles;
     out->n_frags = F; out->n_frags_total = Ft; out->n_queries = nq; out->n_link_queries = nlq;
     out->ranking = ranked ? 1u : 0u;
+    out->repartitioned = repartitioned;
     out->buckets_split = fr.buckets_split; out->max_slots_used = fr.max_slots_used;
     out->exchanged_bytes[0] = exch_records;
     out->exchanged_bytes[1] = 0; for (uint32_t q = 0; q < W; ++q) if (q != me) out->exchanged_bytes[1] += q_send[q] * 24 + q_recv[q] * 4;

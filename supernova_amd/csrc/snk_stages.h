@@ -49,15 +49,21 @@ struct snk_count_ranges {
     int (*ready)(void* user, uint32_t r);
     void* user;
 };
-// pilot_ratio (one-GPU path): the first 1/64 of the buckets is counted first; if their tables overflow as a rule (more distinct k-mers
-// than the LDS table holds: error-rich reads, shallow coverage) the stage stops there, stores distinct k-mers per instance and returns
-// SNK_RETARGET -- the caller partitions again into smaller buckets instead of hash-splitting nearly every bucket.
+// pilot: the first 1/64 of the buckets is counted first; if their tables overflow as a rule (more distinct k-mers than the LDS
+// table holds: error-rich reads, shallow coverage) the stage stops there, leaves the distinct k-mers per bucket it saw in
+// pilot->per_bucket and returns SNK_RETARGET -- the caller partitions again into smaller buckets instead of hash-splitting nearly
+// every bucket.  agree (sharded step): makes per_bucket the job-wide figure (a collective), so that every rank decides alike.
 constexpr int SNK_RETARGET = 1000;
+struct snk_count_pilot {
+    double per_bucket;
+    int (*agree)(void* user, double* per_bucket);
+    void* user;
+};
 uint32_t snk_count_limit(uint32_t K, uint32_t grouped);      // distinct k-mers one pass over a bucket may hold
 int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* records, const uint64_t* seg_beg,
                           const uint64_t* seg_end, uint32_t seg_stride, uint32_t nseg, uint32_t NB, uint32_t min_freq, uint32_t bc_mode, uint32_t grouped, uint64_t n_inst_hint,
                           uint32_t* status, bool want_sort, snk_table* out, char* err, size_t errcap,
-                          const snk_count_ranges* ranges = nullptr, double* pilot_ratio = nullptr);
+                          const snk_count_ranges* ranges = nullptr, snk_count_pilot* pilot = nullptr);
 
 // ---- minimiser partition in one pass (fixed bucket capacity + overflow segment)
 struct snk_partition {

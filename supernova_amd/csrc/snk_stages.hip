@@ -25,7 +25,7 @@ uint32_t snk_env_u32(const char* name, uint32_t dflt) {
 // status: device u32[16] scratch words.
 int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* records, const uint64_t* seg_beg,
                           const uint64_t* seg_end, uint32_t seg_stride, uint32_t nseg, uint32_t NB, uint32_t min_freq, uint32_t bc_mode, uint32_t grouped, uint64_t n_inst_hint,
-                          uint32_t* status, bool want_sort, snk_table* out, char* err, size_t errcap, const snk_count_ranges* ranges, double* pilot_ratio) {
+                          uint32_t* status, bool want_sort, snk_table* out, char* err, size_t errcap, const snk_count_ranges* ranges, snk_count_pilot* pilot) {
     int rc;
     snk_phase_timer tm(st), kt(st);
     tm.mark();
@@ -101,6 +101,21 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
 #endif
         kt.n = 0;
         kt.mark();
+        // the pilot: 1/64 of the buckets, then a look at how full their tables ran
+        auto run_pilot = [&](uint32_t b0, uint32_t NBp, bool* retarget) -> int {
+            snk_count_args cp = ca;
+            cp.bucket0 = b0;
+            cp.NB = b0 + NBp;
+            int r2;
+            if ((r2 = snk_launch_count(K, st, cp, err, errcap))) return r2;
+            uint32_t h_p[8];
+            SNK_HIP_TRY(hipMemcpyAsync(h_p, status, 32, hipMemcpyDeviceToHost, st));
+            SNK_HIP_TRY(snk_sync(st));
+            pilot->per_bucket = (double)h_p[5] * 16.0 / NBp;
+            if (pilot->agree && (r2 = pilot->agree(pilot->user, &pilot->per_bucket))) return snk_fail(SNK_E_INTERNAL, err, errcap, "count: the pilot's exchange failed (%d)", r2);
+            *retarget = pilot->per_bucket > 0.85 * snk_count_limit(K, grouped) && !h_p[1];
+            return SNK_OK;
+        };
         if (attempt == 0 && ranges && ranges->n) {
             // the records of bucket range r may still be on their way: the caller's hook makes the stream wait for
             // them, the ranges before it are being counted meanwhile
@@ -109,22 +124,20 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
                 snk_count_args cr = ca;
                 cr.bucket0 = ranges->bounds[r];
                 cr.NB = ranges->bounds[r + 1];
-                if ((rc = snk_launch_count(K, st, cr, err, errcap))) return rc;
+                if (r == 0 && pilot && NB >= 16384 && n_inst_hint) {
+                    const uint32_t NBp = NB / 64 < cr.NB - cr.bucket0 ? NB / 64 : cr.NB - cr.bucket0;
+                    bool retarget = false;
+                    if ((rc = run_pilot(cr.bucket0, NBp, &retarget))) return rc;
+                    if (retarget) return SNK_RETARGET;
+                    cr.bucket0 += NBp;
+                }
+                if (cr.bucket0 < cr.NB && (rc = snk_launch_count(K, st, cr, err, errcap))) return rc;
             }
-        } else if (attempt == 0 && pilot_ratio && NB >= 16384 && n_inst_hint) {
-            // the pilot: 1/64 of the buckets, then a look at how full their tables ran
+        } else if (attempt == 0 && pilot && NB >= 16384 && n_inst_hint) {
             const uint32_t NBp = NB / 64;
-            snk_count_args cp = ca;
-            cp.NB = NBp;
-            if ((rc = snk_launch_count(K, st, cp, err, errcap))) return rc;
-            uint32_t h_p[8];
-            SNK_HIP_TRY(hipMemcpyAsync(h_p, status, 32, hipMemcpyDeviceToHost, st));
-            SNK_HIP_TRY(snk_sync(st));
-            const double per_bucket = (double)h_p[5] * 16.0 / NBp;
-            if (per_bucket > 0.85 * snk_count_limit(K, grouped) && !h_p[1]) {
-                *pilot_ratio = per_bucket * (double)NB / (double)n_inst_hint;
-                return SNK_RETARGET;
-            }
+            bool retarget = false;
+            if ((rc = run_pilot(0, NBp, &retarget))) return rc;
+            if (retarget) return SNK_RETARGET;
             snk_count_args cr = ca;
             cr.bucket0 = NBp;
             if ((rc = snk_launch_count(K, st, cr, err, errcap))) return rc;

@@ -314,17 +314,19 @@ def test_sharded_circles_at_scale_against_the_oracle(snk, W):
         e.close()
 
 
-def test_sharded_bucket_size_follows_the_data(snk):
+@pytest.mark.parametrize("n", [1_200_000, 3_400_000])
+def test_sharded_bucket_size_follows_the_data(snk, n):
     """Error-rich reads: the second step of a sharded job sizes its buckets from the job-wide ratio of distinct k-mers per instance
-    the first step exchanged (the same decision on every rank), and gives the same table and unitigs as the first step and as
-    the one-GPU path."""
+    the first step exchanged (the same decision on every rank); a first step with enough buckets to look at (the larger case)
+    sees its first buckets overflow, the ranks agree, and it partitions and exchanges a second time itself.  Either way the same
+    table and unitigs as the one-GPU path."""
     import math
     import threading
     import torch
     from supernova_amd import synth
     from supernova_amd.engine import Engine, Params
     from supernova_amd.sharded import ShardedEngine, SimWorld
-    W, n = 2, 1_200_000
+    W = 2
     sp = synth.synth_params(n, seed=0x5EED0E78, sub_ppm=15000)
     lam, term, cum = 150 * 15000 / 1e6, math.exp(-150 * 15000 / 1e6), 0.0
     for j in range(4):
@@ -347,7 +349,7 @@ def test_sharded_bucket_size_follows_the_data(snk):
             for step in range(2):
                 res = sh.count_graph(rows[lo:hi].contiguous(), 150, quals=quals[lo:hi].contiguous(), bc=bc[lo:hi].contiguous(), params=Params(K=48),
                                      read_index_base=lo, total_reads=n)
-                outs[step][r] = dict(keys=res.keys(), counts=res.counts(), unitigs=res.unitigs(), nb=int(res.raw.n_buckets_total))
+                outs[step][r] = dict(keys=res.keys(), counts=res.counts(), unitigs=res.unitigs(), nb=int(res.raw.n_buckets_total), rep=int(res.raw.repartitioned))
             e.close()
         except BaseException as ex:  # noqa: BLE001
             errs.append(ex)
@@ -367,5 +369,9 @@ def test_sharded_bucket_size_follows_the_data(snk):
         assert np.array_equal(keys[order], ref_keys) and np.array_equal(counts[order], ref_counts)
         assert sorted(u for o in outs[step] for u in o["unitigs"]) == ref_unitigs
         assert outs[step][0]["nb"] == outs[step][1]["nb"]
-    assert outs[1][0]["nb"] > 1.5 * outs[0][0]["nb"]
+    if n < 2_000_000:
+        assert outs[0][0]["rep"] == 0 and outs[1][0]["nb"] > 1.5 * outs[0][0]["nb"]
+    else:
+        assert outs[0][0]["rep"] == 1 and outs[0][1]["rep"] == 1 and outs[1][0]["rep"] == 0
+        assert outs[0][0]["nb"] * W * 5000 > 1.5 * n * 103 and abs(outs[1][0]["nb"] - outs[0][0]["nb"]) < 0.2 * outs[0][0]["nb"]
     e0.close()
