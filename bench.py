@@ -137,7 +137,7 @@ def next_rows(eng, res, rows, quals, bc, read_len, K):
     rw, qs = int(rows.shape[1]) * 4, int(quals.shape[1])
     frac = lambda nbytes, ms: (nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms > 0 else None
     path_bytes = n * (rw + qs + 16) + info["n_edges_total"] * 4
-    dict_bytes = info["dict_slots"] * 32 + int(res.unitig_total_bases)
+    dict_bytes = info["dict_slots"] * 16 + int(res.unitig_total_bases)      # the slots cleared and written (8 B each) + the unitig bases read
     dup_bytes = n * (16 + rw + 2 * 12)          # path head (edge, offset), mate head row, two sort passes over 12-byte (key, id) records
     bcs_bytes = n * 8 * 4                       # one 8-byte (unitig, barcode) key per barcoded read through a 64-bit radix sort (write + read, twice)
     d = info["dups"]

@@ -54,11 +54,14 @@ struct path_graph {            // device arrays
     const uint8_t* e_rc;                   // [E]
     const int32_t *to_off, *to_v, *to_e;   // [N+1], [E], [E]: in-edges of a vertex, AddEdge order (graph/DigraphTemplate.h:2572-2582)
     const int32_t *from_off, *from_v, *from_e;
-    const uint4* dslot;        // dictionary, 16 bytes per slot: {fingerprint lo32, hi32, offset | rev << 31, unitig}; fingerprint == ~0: empty;
-                               //   rev: the unitig holds the reverse complement of the canonical form.  A probe is one 16-byte access; a
-                               //   fingerprint match is VERIFIED against the unitig's bases (dict_find), so look-ups stay exact.
-    uint64_t dcap;             // slots: 2.5 per k-mer, not a power of two
-    unsigned long long fp_mask; // all ones; SNK_PATH_FP_MASK (tests) narrows the fingerprint so that false matches happen and the verified path runs
+    const unsigned long long* dslot;   // dictionary, 8 bytes per slot: fingerprint (30 bits) | strand (1) | position (33 bits: first base of
+                               //   the k-mer in the concatenated unitigs); all ones: empty.  strand: the unitig holds the reverse complement
+                               //   of the canonical form.  A probe is one 8-byte access, a claim ONE 64-bit compare-and-swap; a fingerprint
+                               //   match is VERIFIED against the unitig's bases, so look-ups stay exact (2^-30 false candidates per probe of
+                               //   an occupied slot: a few reads per 10^8 take the verified path).  24 bytes per unitig k-mer.
+    const uint32_t* ublk;      // unitig that holds base 256 b of the concatenation (position -> unitig: this entry, then a step or two along uoff)
+    uint64_t dcap;             // slots: 3 per k-mer, not a power of two
+    unsigned long long fp_mask; // 30 ones; SNK_PATH_FP_MASK (tests) narrows the fingerprint so that false matches happen and the verified path runs
 };
 
 template <int K>
@@ -87,10 +90,11 @@ __device__ __forceinline__ unsigned long long dict_fp(snk_kmer c) {
     return x == ~0ull ? 0x7FFFFFFFFFFFFFFFull : x;
 }
 // ---- dictionary build.  A thread takes DB_RUN consecutive base positions of the concatenated unitigs: the first k-mer is read
-// base by base, the following ones roll (one byte each).  A slot is claimed by a 64-bit compare-and-swap on its fingerprint word
-// (all ones = empty), the value follows with one 8-byte store; no lock array, nothing to clear but the slots.  Round 2 had
-// 32-byte slots holding the whole key (80 bytes per unitig k-mer with the lock word): 40 now, and the build went 25 -> ~15 ms
-// (it is bound by the random read-modify-write of one sector per k-mer).
+// base by base, the following ones roll (one byte each).  A slot IS one 64-bit word (fingerprint | strand | position): it is
+// claimed and filled by ONE compare-and-swap on all ones; no lock array, no second store, nothing to clear but the slots.
+// Round 2 had 32-byte slots holding the whole key (80 bytes per unitig k-mer with the lock word), early round 3 16-byte slots
+// (fingerprint word + value word, 40 bytes per k-mer, 30 ms: a CAS and a store to a random sector each); 24 bytes and 17 ms now
+// (bound by the device's random atomics).
 constexpr int DB_RUN = 16;
 // 16 bases of the byte array -> one word (the same bit order as the packed read rows)
 __global__ void __launch_bounds__(256) upack_kernel(const uint8_t* __restrict__ ubases, uint64_t total, uint32_t* __restrict__ out, uint64_t n_words) {
@@ -112,6 +116,16 @@ __global__ void __launch_bounds__(256) upack_kernel(const uint8_t* __restrict__ 
     }
     out[w] = v;
 }
+// unitig of every 256th base of the concatenation (largest u with uoff[u] <= 256 b)
+__global__ void __launch_bounds__(256) ublk_kernel(const uint64_t* __restrict__ uoff, uint64_t U, uint64_t n_blk, uint32_t* __restrict__ ublk) {
+    const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= n_blk) return;
+    const uint64_t p = b << 8;
+    uint64_t lo = 0, hi = U;
+    while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (uoff[mid] <= p) lo = mid; else hi = mid; }
+    ublk[b] = (uint32_t)lo;
+}
+constexpr uint64_t UPAD = 512;      // bases of slack in front of (and behind) the packed unitigs: a window may start 270 bases before a hit or run 270 past it
 // 16 bases starting at base p of a packed array (two words, one funnel shift)
 __device__ __forceinline__ uint32_t packed16(const uint32_t* P, uint64_t p) {
     const uint64_t wi = p >> 4;
@@ -122,7 +136,7 @@ __device__ __forceinline__ uint32_t packed16(const uint32_t* P, uint64_t p) {
 
 template <int K>
 __global__ void __launch_bounds__(256) dict_build_kernel(const uint64_t* __restrict__ uoff, const uint8_t* __restrict__ ubases, uint64_t U, uint64_t total,
-                                                         uint4* __restrict__ dslot, uint64_t dcap, unsigned long long fp_mask) {
+                                                         unsigned long long* __restrict__ dslot, uint64_t dcap, unsigned long long fp_mask) {
     const uint64_t p0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * DB_RUN;
     if (p0 >= total) return;
     uint64_t lo = 0, hi = U;                     // largest u with uoff[u] <= p0
@@ -143,15 +157,10 @@ __global__ void __launch_bounds__(256) dict_build_kernel(const uint64_t* __restr
         const snk_kmer r = snk_kmer_rc<K>(f);
         const bool rev = snk_kmer_lt(r, f);
         const snk_kmer c = rev ? r : f;
-        const unsigned long long fp = dict_fp(c) & fp_mask;
-        const uint64_t o = p - ub;
+        const unsigned long long val = ((dict_fp(c) >> 34 & fp_mask) << 34) | ((unsigned long long)(rev ? 1u : 0u) << 33) | p;
         uint64_t s = dict_slot(c, dcap);
         for (;;) {
-            unsigned long long* w = reinterpret_cast<unsigned long long*>(dslot + s);
-            if (atomicCAS(w, ~0ull, fp) == ~0ull) {
-                w[1] = (unsigned long long)((uint32_t)o | (rev ? 0x80000000u : 0u)) | ((unsigned long long)(uint32_t)lo << 32);
-                break;
-            }
+            if (atomicCAS(dslot + s, ~0ull, val) == ~0ull) break;
             if (++s == dcap) s = 0;
         }
     }
@@ -373,33 +382,37 @@ struct path_args {
 // exact-match extension reads next); should that ever fail -- 2^-64 per probe -- the read is redone with verify = true, where a
 // match is checked here, base by base, and a false one just continues the probe sequence.  Look-ups are exact either way.
 template <int K>
-__device__ __forceinline__ bool dict_find(const path_graph& G, const uint32_t* row, uint32_t pos, uint32_t* hu, uint32_t* ho, uint32_t* hrc, bool verify) {
+__device__ __forceinline__ bool dict_find(const path_graph& G, const uint32_t* row, uint32_t pos, uint32_t* hu, uint32_t* ho, uint32_t* hrc, bool verify,
+                                          uint64_t* hpos = nullptr /* given: the hit's position in the concatenation instead of (unitig, offset) */) {
     const snk_kmer f = kmer_at<K>(row, 20, pos);
     const snk_kmer rk = snk_kmer_rc<K>(f);
     const bool rrev = snk_kmer_lt(rk, f);
     const snk_kmer c = rrev ? rk : f;
-    const unsigned long long fp = dict_fp(c) & G.fp_mask;
+    const unsigned long long fp = dict_fp(c) >> 34 & G.fp_mask;
     uint64_t s = dict_slot(c, G.dcap);
     for (;;) {
-        const uint4 k = G.dslot[s];
-        const unsigned long long kf = ((unsigned long long)k.y << 32) | k.x;
-        if (kf == ~0ull) return false;
-        if (kf == fp) {
-            const uint32_t u = k.w, o = k.z & 0x7FFFFFFFu, urev = k.z >> 31;
-            if (!verify) {          // the caller checks the seed's bases itself (sixteen lanes, three bases each)
-                *hu = u; *ho = o; *hrc = urev ^ (rrev ? 1u : 0u);
-                return true;
+        const unsigned long long k = G.dslot[s];
+        if (k == ~0ull) return false;
+        if ((k >> 34) == fp) {
+            const uint64_t pos = k & 0x1FFFFFFFFull;
+            const uint32_t urev = (uint32_t)(k >> 33) & 1u;
+            bool ok = true;
+            if (verify) {
+                const uint8_t* ub = G.ubases + pos;
+                snk_kmer g;
+                g.hi = 0; g.lo = 0;
+                for (int q = 0; q < K; ++q) g = snk_kmer_succ<K>(g, ub[q] & 3u);
+                const snk_kmer cu = urev ? snk_kmer_rc<K>(g) : g;         // canonical form of the unitig's k-mer
+                ok = snk_kmer_eq(cu, c);
             }
-            const uint4 ui = G.uinfo[2 * (uint64_t)u];
-            const uint8_t* ub = G.ubases + (((uint64_t)ui.y << 32) | ui.x) + o;
-            snk_kmer g;
-            g.hi = 0; g.lo = 0;
-            for (int q = 0; q < K; ++q) g = snk_kmer_succ<K>(g, ub[q] & 3u);
-            const snk_kmer cu = urev ? snk_kmer_rc<K>(g) : g;         // canonical form of the unitig's k-mer
-            if (snk_kmer_eq(cu, c)) {
+            if (ok) {
+                *hrc = urev ^ (rrev ? 1u : 0u);           // read k-mer vs the unitig's k-mer: CF<K>::isRC, dna/CanonicalForm.h:85-91
+                if (hpos) { *hpos = pos; return true; }
+                // position -> unitig and offset (a k-mer never crosses a unitig boundary)
+                uint32_t u = G.ublk[pos >> 8];
+                while (G.uoff[u + 1] <= pos) ++u;
                 *hu = u;
-                *ho = o;
-                *hrc = urev ^ (rrev ? 1u : 0u);       // read k-mer vs the unitig's k-mer: CF<K>::isRC, dna/CanonicalForm.h:85-91
+                *ho = (uint32_t)(pos - G.uoff[u]);
                 return true;
             }
         }
@@ -472,7 +485,8 @@ __global__ void __launch_bounds__(256, MODE == 2 ? 4 : SNK_PATH_OCC) path_kernel
                 const uint32_t pos = i + sub;
                 bool hit = false;
                 uint32_t hu = 0, ho = 0, hrc = 0;
-                if (pos < end && (wide || sub == 0)) hit = dict_find<K>(G, row, pos, &hu, &ho, &hrc, exact);
+                uint64_t hpos = 0;
+                if (pos < end && (wide || sub == 0)) hit = dict_find<K>(G, row, pos, &hu, &ho, &hrc, exact, &hpos);
                 const uint32_t hm = (uint32_t)(__ballot(hit) >> gsh) & GM;
                 if (!hm) {
                     if (MODE == 0) { deferred = true; resume_i = i; break; }          // the first k-mer is not on the graph: the slow pass takes the read
@@ -481,17 +495,34 @@ __global__ void __launch_bounds__(256, MODE == 2 ? 4 : SNK_PATH_OCC) path_kernel
                     continue;
                 }
                 const int first = __ffs((int)hm) - 1;
-                const uint32_t u = __shfl(hu, gsh + first), o0 = __shfl(ho, gsh + first), rc = __shfl(hrc, gsh + first);
-                const uint4 ui = G.uinfo[2 * (uint64_t)u];
-                const uint32_t sz = ui.z;
-                const uint64_t gb = (((uint64_t)ui.y << 32) | ui.x) + 16u;       // first base of the unitig in upack (one word of slack in front)
-                const uint32_t off = !rc ? o0 : sz - o0 - (uint32_t)K;           // :726-729
+                const uint32_t rc = __shfl(hrc, gsh + first);
+                const uint64_t hp = ((uint64_t)__shfl((uint32_t)(hpos >> 32), gsh + first) << 32) | __shfl((uint32_t)hpos, gsh + first);
                 // The read from the seed on against the unitig (or its reverse complement), 2-bit words on both sides, the whole
                 // window in ONE step: CPL bases per lane, 256 per group.  L = bases that agree from the seed's first base on; fewer
                 // than K is a false fingerprint match (the seed check), the rest is matchLen's exact-match extension (:549-558).
+                // The window is addressed by the hit's POSITION in the concatenated unitigs, so its loads go out before the unitig
+                // is known (position -> block table -> a step or two along uoff -> uinfo: three dependent loads that now run beside
+                // the window's); what lies behind the unitig's end is cut off afterwards.
                 constexpr uint32_t CPL = 256 / GS;
                 const uint32_t rs = i + (uint32_t)first;
-                const uint32_t Lmax = (n - rs) < (sz - off) ? (n - rs) : (sz - off);
+                const uint32_t Rmax = n - rs;
+                uint32_t w0[CPL / 16], w1[CPL / 16], wsh[CPL / 16];
+#pragma unroll
+                for (uint32_t c = 0; c < CPL / 16; ++c) {
+                    const uint32_t j = CPL * (uint32_t)sub + 16u * c;
+                    w0[c] = w1[c] = 0; wsh[c] = 0;
+                    if (j < Rmax) {
+                        const uint64_t q = !rc ? UPAD + hp + j : UPAD + hp + (uint64_t)(K - 1) - j - 15u;      // rc: the 16 bases that END at the mirrored position
+                        w0[c] = G.upack[q >> 4]; w1[c] = G.upack[(q >> 4) + 1]; wsh[c] = 2u * ((uint32_t)q & 15u);
+                    }
+                }
+                uint32_t u = G.ublk[hp >> 8];
+                while (G.uoff[u + 1] <= hp) ++u;
+                const uint4 ui = G.uinfo[2 * (uint64_t)u];
+                const uint32_t sz = ui.z;
+                const uint32_t o0 = (uint32_t)(hp - (((uint64_t)ui.y << 32) | ui.x));
+                const uint32_t off = !rc ? o0 : sz - o0 - (uint32_t)K;           // :726-729
+                const uint32_t Lmax = Rmax < (sz - off) ? Rmax : (sz - off);
                 uint32_t mt = 0;
                 bool stop = false;
 #pragma unroll
@@ -502,9 +533,8 @@ __global__ void __launch_bounds__(256, MODE == 2 ? 4 : SNK_PATH_OCC) path_kernel
                         else {
                             const uint32_t vl = Lmax - j < 16u ? Lmax - j : 16u;
                             const uint32_t xr = packed16(row, rs + j);
-                            uint32_t xu;
-                            if (!rc) xu = packed16(G.upack, gb + off + j);
-                            else xu = snk_rev2_32(~packed16(G.upack, gb + (sz - 1u - off - j) - 15u));      // the 16 bases that END at the mirrored position, reverse-complemented
+                            uint32_t xu = (uint32_t)(((((uint64_t)w0[c] << 32) | w1[c]) << wsh[c]) >> 32);
+                            if (rc) xu = snk_rev2_32(~xu);
                             const uint32_t d = xr ^ xu;
                             const uint32_t mm = d ? (uint32_t)__clz((int)d) >> 1 : 16u;
                             if (mm >= vl) { mt += vl; stop = vl < 16u; }
@@ -830,36 +860,47 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
     G.uinfo = uinfo;
     const uint64_t total_bases = h_off_last;
     {
-        // the unitigs once more, 2 bits per base (a quarter of the byte array): word 0 is slack, the bases start at word 1
-        const uint64_t n_words = (total_bases + 15) / 16 + 3;
+        // the unitigs once more, 2 bits per base (a quarter of the byte array), UPAD bases of slack at either end
+        const uint64_t n_words = (total_bases + 15) / 16 + 1;
         uint32_t* upack;
-        if ((rc = dev(ctx, n_words + 1, &upack, err, errcap))) return rc;
-        SNK_HIP_TRY(hipMemsetAsync(upack, 0, 4, st));
-        hipLaunchKernelGGL(upack_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, d_ubases, total_bases, upack + 1, n_words);
+        if ((rc = dev(ctx, n_words + 2 * (UPAD / 16) + 2, &upack, err, errcap))) return rc;
+        SNK_HIP_TRY(hipMemsetAsync(upack, 0, (UPAD / 16) * 4, st));
+        SNK_HIP_TRY(hipMemsetAsync(upack + UPAD / 16 + n_words, 0, (UPAD / 16 + 2) * 4, st));
+        hipLaunchKernelGGL(upack_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, d_ubases, total_bases, upack + UPAD / 16, n_words);
         G.upack = upack;
     }
     const uint64_t nk = total_bases >= U * (uint64_t)(K - 1) ? total_bases - U * (uint64_t)(K - 1) : 0;
-    const uint64_t cap = ((2 * nk + nk / 2 + 1024) + 63) & ~63ull;        // load 0.4: the chain of dependent probes is what a read waits for
+    const uint64_t spk10 = snk_env_u32("SNK_PATH_SLOTS_X10", 30);         // slots per unitig k-mer x 10 (measured: 2.5 -> 67.2 ms pathing, 3 -> 63.5, 4 -> 61.8)
+    const uint64_t cap = ((nk * spk10 / 10 + 1024) + 63) & ~63ull;        // load 1/3: the chain of dependent probes is what a read waits for
     {
-        // the dictionary is the one allocation of this path that grows with the GRAPH, not with the reads: 2.5 slots of 16 bytes
+        // the dictionary is the one allocation of this path that grows with the GRAPH, not with the reads: 3 slots of 8 bytes
         // per unitig k-mer.  Say so before asking for it: a human-size graph (3-4 G k-mers) wants
-        // ~150 GB next to the reads -- path such a graph per unitig range, in passes.
+        // ~85 GB next to the reads -- path such a graph per unitig range, in passes.
         size_t fr = 0, tot = 0;
-        const uint64_t want = cap * 16ull;
+        const uint64_t want = cap * 8ull;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
             uint64_t cached = 0;
             for (auto& b : ctx->blocks) if (!b.used) cached += b.bytes;     // the arena's idle blocks can be handed back to the driver
             if (want > (uint64_t)fr + cached)
-                return snk_fail(SNK_E_NOMEM, err, errcap, "snk_dev_path_reads: the k-mer dictionary of this graph (%llu unitig k-mers, 2.5 slots of 16 B each) needs %.1f GB, "
+                return snk_fail(SNK_E_NOMEM, err, errcap, "snk_dev_path_reads: the k-mer dictionary of this graph (%llu unitig k-mers, 3 slots of 8 B each) needs %.1f GB, "
                                 "%.1f GB of HBM are free; path the reads against ranges of the unitigs instead", (unsigned long long)nk, want / 1e9, (fr + cached) / 1e9);
         }
     }
-    uint4* dslot;
-    unsigned long long fp_mask = ~0ull;
-    if (const char* e = getenv("SNK_PATH_FP_MASK")) if (*e) { fp_mask = strtoull(e, nullptr, 0); if (fp_mask == 0 || fp_mask == ~0ull) fp_mask = ~0ull; else fp_mask &= 0x7FFFFFFFFFFFFFFFull; }
+    unsigned long long* dslot;
+    unsigned long long fp_mask = 0x3FFFFFFFull;
+    if (const char* e = getenv("SNK_PATH_FP_MASK")) if (*e) { const unsigned long long m = strtoull(e, nullptr, 0) & 0x3FFFFFFFull; if (m) fp_mask = m; }
+    if (total_bases >= (1ull << 33) - 1) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_dev_path_reads: more than 2^33 unitig bases (the dictionary keeps 33-bit positions)");
     if ((rc = dev(ctx, cap, &dslot, err, errcap))) return rc;
-    SNK_HIP_TRY(hipMemsetAsync(dslot, 0xFF, cap * 16, st));
+    SNK_HIP_TRY(hipMemsetAsync(dslot, 0xFF, cap * 8, st));
     if (total_bases) hipLaunchKernelGGL((dict_build_kernel<K>), dim3((unsigned)(((total_bases + DB_RUN - 1) / DB_RUN + 255) / 256)), dim3(256), 0, st, d_uoff, d_ubases, U, total_bases, dslot, cap, fp_mask);
+    {
+        const uint64_t n_blk = (total_bases >> 8) + 2;
+        uint32_t* ublk;
+        if ((rc = dev(ctx, n_blk, &ublk, err, errcap))) return rc;
+        if (U) hipLaunchKernelGGL(ublk_kernel, dim3((unsigned)((n_blk + 255) / 256)), dim3(256), 0, st, d_uoff, U, n_blk, ublk);
+        else SNK_HIP_TRY(hipMemsetAsync(ublk, 0, n_blk * 4, st));
+        G.ublk = ublk;
+    }
     SNK_HIP_TRY(hipGetLastError());
     SNK_HIP_TRY(snk_sync(st));            // drop[] has been copied
     G.dslot = dslot; G.dcap = cap; G.fp_mask = fp_mask;
