@@ -133,7 +133,9 @@ def next_rows(eng, res, rows, quals, bc, read_len, K):
     """f1 / f4 on the bench workload, untimed rows next to the contract line: HIP-event times of the library's own
     phases, each with the bytes its data model moves once and the fraction of the HBM peak that is."""
     n = int(rows.shape[0])
-    _, _, _, info = res.path_reads(rows, read_len, quals, mark_dups=True, bc=bc, unitig_bcs=True, download=False)
+    # (like the timed step: one call to size the arena, the second is reported)
+    for _ in range(2):
+        _, _, _, info = res.path_reads(rows, read_len, quals, mark_dups=True, bc=bc, unitig_bcs=True, download=False)
     rw, qs = int(rows.shape[1]) * 4, int(quals.shape[1])
     frac = lambda nbytes, ms: (nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms > 0 else None
     path_bytes = n * (rw + qs + 16) + info["n_edges_total"] * 4
@@ -142,7 +144,7 @@ def next_rows(eng, res, rows, quals, bc, read_len, K):
     bcs_bytes = n * 8 * 4                       # one 8-byte (unitig, barcode) key per barcoded read through a 64-bit radix sort (write + read, twice)
     d = info["dups"]
     return {
-        "reads": n,
+        "reads": n, "calls": "second of two (arena warm, like the timed step)",
         "f1_dictionary_build": {"ms": round(info["dict_ms"], 3), "slots": info["dict_slots"], "alg_bytes": dict_bytes, "hbm_frac": frac(dict_bytes, info["dict_ms"])},
         "f1_read_pathing": {"ms": round(info["path_ms"], 3), "reads_per_s": n / (info["path_ms"] * 1e-3), "edges": info["n_edges_total"],
                             "reads_in_second_pass": info["n_slow"],
