@@ -18,6 +18,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "snk_ctx.h"
+#include "snk_stages.h"
 #include "snk_common.h"
 
 
@@ -44,9 +45,10 @@ __device__ __forceinline__ uint32_t read_len_of(const dup_in& a, uint64_t r) { r
 
 // (e, offset, head of the mate): SecretOps.cc:430-441.  Reads without a path get the largest key and sort behind everything.
 __global__ void __launch_bounds__(256) dup_key_kernel(dup_in a, unsigned long long* __restrict__ key, uint32_t* __restrict__ head, uint32_t* __restrict__ id,
-                                                      unsigned long long* __restrict__ n_placed) {
+                                                      unsigned long long* __restrict__ n_placed, uint32_t* __restrict__ range /* [3][256] max edge, max / min biased offset */) {
     const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     bool placed = false;
+    uint32_t ke = 0, ko = 0;
     if (r < a.n) {
         id[r] = (uint32_t)r;
         unsigned long long k = ~0ull;
@@ -55,6 +57,7 @@ __global__ void __launch_bounds__(256) dup_key_kernel(dup_in a, unsigned long lo
             const uint32_t e = (uint32_t)a.p_edges[a.p_start[r]];
             const uint32_t off = (uint32_t)a.p_off[r] ^ 0x80000000u;          // signed order
             k = ((unsigned long long)e << 32) | off;
+            ke = e; ko = off;
             h = a.rows[(r ^ 1ull) * a.row_words] >> 22;                        // five bases, MSB first = n*4 + base
             placed = true;
         }
@@ -63,13 +66,38 @@ __global__ void __launch_bounds__(256) dup_key_kernel(dup_in a, unsigned long lo
     }
     // (one counter for every wave of the grid is 1.6 M atomics on ONE address, ~10 ns each: 16 of this kernel's 19 ms.  256 counters.)
     const unsigned long long m = __ballot(placed);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&n_placed[(blockIdx.x * 4u + (threadIdx.x >> 6)) & 255u], (unsigned long long)__popcll(m));
+    const uint32_t slot = (blockIdx.x * 4u + (threadIdx.x >> 6)) & 255u;
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&n_placed[slot], (unsigned long long)__popcll(m));
+    // ranges of the placed reads' edges and offsets (they decide how many key bits the sort has to look at)
+    uint32_t emax = placed ? ke : 0u, omax = placed ? ko : 0u, omin = placed ? ko : 0xFFFFFFFFu;
+    for (int o = 32; o > 0; o >>= 1) {
+        emax = max(emax, (uint32_t)__shfl_xor((int)emax, o)); omax = max(omax, (uint32_t)__shfl_xor((int)omax, o)); omin = min(omin, (uint32_t)__shfl_xor((int)omin, o));
+    }
+    if ((threadIdx.x & 63) == 0 && m) { atomicMax(&range[slot], emax); atomicMax(&range[256 + slot], omax); atomicMin(&range[512 + slot], omin); }
 }
 
 __global__ void __launch_bounds__(256) dup_gather_key_kernel(const uint32_t* __restrict__ id, const unsigned long long* __restrict__ key, uint64_t n,
                                                              unsigned long long* __restrict__ out) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = key[id[i]];
+}
+
+// (edge, offset, head) in as few bits as the data need: edge << (ob + 10) | (offset - smallest offset) << 10 | head; unplaced reads
+// get the one bit above -- ONE radix sort over those bits then orders the reads as the reference's records are ordered
+__global__ void __launch_bounds__(256) dup_composite_kernel(unsigned long long* __restrict__ key, const uint32_t* __restrict__ head, uint64_t n, uint32_t omin,
+                                                            uint32_t obits, uint32_t total_bits) {
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const unsigned long long k = key[r];
+    key[r] = k == ~0ull ? (1ull << total_bits) : (((k >> 32) << (obits + 10u)) | ((unsigned long long)((uint32_t)k - omin) << 10) | head[r]);
+}
+__global__ void __launch_bounds__(256) dup_flag1_kernel(const unsigned long long* __restrict__ skey, uint64_t m, uint8_t* __restrict__ gstart, uint8_t* __restrict__ multi) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const unsigned long long k = skey[i];
+    const bool same_prev = i > 0 && skey[i - 1] == k, same_next = i + 1 < m && skey[i + 1] == k;
+    gstart[i] = same_prev ? 0 : 1;
+    multi[i] = (same_prev || same_next) ? 1 : 0;
 }
 
 // group structure of the sorted array: gstart[i] = 1 iff position i opens a group; members of groups with more than one read
@@ -222,29 +250,54 @@ static int mark_dups_impl(snk_ctx* ctx, const snk_dev_reads* in, const snk_dev_p
     uint64_t n_placed_total = 0;
     if (n) {
         const unsigned gn = (unsigned)((n + 255) / 256);
-        hipLaunchKernelGGL(dup_key_kernel, dim3(gn), dim3(256), 0, st, a, key, head, id, stat + 8);
-        size_t tb1 = 0, tb2 = 0;
-        SNK_HIP_TRY(rocprim::radix_sort_pairs((void*)nullptr, tb1, head, head2, id, id2, (size_t)n, 0u, 10u, st));
-        SNK_HIP_TRY(rocprim::radix_sort_pairs((void*)nullptr, tb2, key, key2, id, id2, (size_t)n, 0u, 64u, st));
-        size_t tb = tb1 > tb2 ? tb1 : tb2;
-        uint8_t* tmp;
-        if ((rc = dev(ctx, tb, &tmp, err, errcap))) return rc;
-        size_t t = tb;
-        SNK_HIP_TRY(rocprim::radix_sort_pairs(tmp, t, head, head2, id, id2, (size_t)n, 0u, 10u, st));          // id2 = ids by (head, id)
-        hipLaunchKernelGGL(dup_gather_key_kernel, dim3(gn), dim3(256), 0, st, id2, key, n, key2);
-        t = tb;
-        SNK_HIP_TRY(rocprim::radix_sort_pairs(tmp, t, key2, key, id2, id, (size_t)n, 0u, 64u, st));            // key / id = (edge, offset, head, id) order
+        uint32_t* range;
+        if ((rc = dev(ctx, 768, &range, err, errcap))) return rc;
+        SNK_HIP_TRY(hipMemsetAsync(range, 0, 512 * 4, st));
+        SNK_HIP_TRY(hipMemsetAsync(range + 512, 0xFF, 256 * 4, st));
+        hipLaunchKernelGGL(dup_key_kernel, dim3(gn), dim3(256), 0, st, a, key, head, id, stat + 8, range);
         unsigned long long h_placed[256];
+        uint32_t h_range[768];
         SNK_HIP_TRY(hipMemcpyAsync(h_placed, stat + 8, sizeof h_placed, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(hipMemcpyAsync(h_range, range, sizeof h_range, hipMemcpyDeviceToHost, st));
         SNK_HIP_TRY(snk_sync(st));
         uint64_t m = 0;                                     // placed reads: the front of the sorted array
-        for (int q = 0; q < 256; ++q) m += h_placed[q];
+        uint32_t emax = 0, omax = 0, omin = 0xFFFFFFFFu;
+        for (int q = 0; q < 256; ++q) { m += h_placed[q]; emax = std::max(emax, h_range[q]); omax = std::max(omax, h_range[256 + q]); omin = std::min(omin, h_range[512 + q]); }
         n_placed_total = m;
+        auto bits_of = [](uint64_t v) { uint32_t b = 0; while (v) { ++b; v >>= 1; } return b; };
+        const uint32_t ebits = bits_of(emax), obits = m ? bits_of((uint64_t)omax - omin) : 0u, total_bits = ebits + obits + 10u;
+        const unsigned long long* skey;
+        const uint32_t* sid;
+        const bool one_sort = total_bits <= 62 && !snk_env_u32("SNK_DUPS_TWO_SORTS", 0);
+        if (one_sort) {
+            // the reference's record order (edge, offset, mate head, read id) in ONE stable sort over total_bits + 1 bits (the bench graph: 42)
+            hipLaunchKernelGGL(dup_composite_kernel, dim3(gn), dim3(256), 0, st, key, head, n, m ? omin : 0u, obits, total_bits);
+            size_t tb = 0;
+            SNK_HIP_TRY(rocprim::radix_sort_pairs((void*)nullptr, tb, key, key2, id, id2, (size_t)n, 0u, total_bits + 1u, st));
+            uint8_t* tmp;
+            if ((rc = dev(ctx, tb, &tmp, err, errcap))) return rc;
+            SNK_HIP_TRY(rocprim::radix_sort_pairs(tmp, tb, key, key2, id, id2, (size_t)n, 0u, total_bits + 1u, st));
+            skey = key2; sid = id2;
+        } else {
+            size_t tb1 = 0, tb2 = 0;
+            SNK_HIP_TRY(rocprim::radix_sort_pairs((void*)nullptr, tb1, head, head2, id, id2, (size_t)n, 0u, 10u, st));
+            SNK_HIP_TRY(rocprim::radix_sort_pairs((void*)nullptr, tb2, key, key2, id, id2, (size_t)n, 0u, 64u, st));
+            size_t tb = tb1 > tb2 ? tb1 : tb2;
+            uint8_t* tmp;
+            if ((rc = dev(ctx, tb, &tmp, err, errcap))) return rc;
+            size_t t = tb;
+            SNK_HIP_TRY(rocprim::radix_sort_pairs(tmp, t, head, head2, id, id2, (size_t)n, 0u, 10u, st));          // id2 = ids by (head, id)
+            hipLaunchKernelGGL(dup_gather_key_kernel, dim3(gn), dim3(256), 0, st, id2, key, n, key2);
+            t = tb;
+            SNK_HIP_TRY(rocprim::radix_sort_pairs(tmp, t, key2, key, id2, id, (size_t)n, 0u, 64u, st));            // key / id = (edge, offset, head, id) order
+            skey = key; sid = id;
+        }
         if (m) {
             const unsigned gm = (unsigned)((m + 255) / 256);
-            hipLaunchKernelGGL(dup_flag_kernel, dim3(gm), dim3(256), 0, st, key, id, head, m, gstart, multi);
-            hipLaunchKernelGGL(dup_qsum_kernel, dim3(gm), dim3(256), 0, st, a, id, multi, m, qsum);
-            hipLaunchKernelGGL(dup_group_kernel, dim3(gm), dim3(256), 0, st, a, key, id, head, gstart, qsum, m, dup, art, stat);
+            if (one_sort) hipLaunchKernelGGL(dup_flag1_kernel, dim3(gm), dim3(256), 0, st, skey, m, gstart, multi);
+            else hipLaunchKernelGGL(dup_flag_kernel, dim3(gm), dim3(256), 0, st, skey, sid, head, m, gstart, multi);
+            hipLaunchKernelGGL(dup_qsum_kernel, dim3(gm), dim3(256), 0, st, a, sid, multi, m, qsum);
+            hipLaunchKernelGGL(dup_group_kernel, dim3(gm), dim3(256), 0, st, a, skey, sid, head, gstart, qsum, m, dup, art, stat);
         }
         if (np) hipLaunchKernelGGL(dup_count_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, dup, art, np, stat);
         SNK_HIP_TRY(hipGetLastError());
