@@ -30,6 +30,7 @@ cases = [("bench model (0.2 % errors, 5 % tails, 56x)", {}),
          ("1.5 % errors, 50 % tails", dict(sub_ppm=15000, lowq_tail_ppm=500000)),
          ("28x coverage", dict(genome_len=n * 150 // 28)),
          ("112x coverage", dict(genome_len=n * 150 // 112)),
+         ("1000x coverage (a 15 Mb genome)", dict(genome_len=n * 150 // 1000)),
          ("100-base reads", dict(read_len=100, genome_len=n * 100 // 56)),
          ("250-base reads", dict(read_len=250, genome_len=n * 250 // 56, insert_min=500)),
          ("K=60, 0.6 % errors", dict(sub_ppm=6000, K=60))]
