@@ -58,6 +58,7 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
         extra_cap = NB / 8 > (1u << 16) ? NB / 8 : (1u << 16);
         if (ctx->last_extra > extra_cap) extra_cap = ctx->last_extra + ctx->last_extra / 4;
     }
+    bool pilot_regrown = false;
     for (int attempt = 0; attempt < 4; ++attempt) {
         void* q;
         if (!want_sort) {
@@ -101,8 +102,9 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
 #endif
         kt.n = 0;
         kt.mark();
+        bool pilot_regrow = false;
         // the pilot: 1/64 of the buckets, then a look at how full their tables ran
-        auto run_pilot = [&](uint32_t b0, uint32_t NBp, bool* retarget) -> int {
+        auto run_pilot = [&](uint32_t b0, uint32_t NBp, bool* retarget, bool* regrow) -> int {
             snk_count_args cp = ca;
             cp.bucket0 = b0;
             cp.NB = b0 + NBp;
@@ -112,6 +114,16 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
             SNK_HIP_TRY(hipMemcpyAsync(h_p, status, 32, hipMemcpyDeviceToHost, st));
             SNK_HIP_TRY(snk_sync(st));
             pilot->per_bucket = (double)h_p[5] * 16.0 / NBp;
+            {
+                // the pilot also says how many k-mers survive: a first call whose guess (instances / 12) is too small for this data
+                // (min_freq 1 or 2, shallow coverage) learns it here instead of from a full count run whose regions overflowed
+                std::vector<unsigned long long> h_rc(n_regions);
+                SNK_HIP_TRY(hipMemcpy(h_rc.data(), rcur, n_regions * 8ull, hipMemcpyDeviceToHost));
+                unsigned long long sum = 0;
+                for (uint32_t r = 0; r < n_regions; ++r) sum += h_rc[r];
+                const uint64_t need = (uint64_t)((double)sum * ((double)(NB - b0) / NBp) * 1.25 / n_regions) + 64;
+                if (need > region_cap && b0 == 0 && !pilot_regrown) { region_cap = need; *regrow = true; return SNK_OK; }
+            }
             if (pilot->agree && (r2 = pilot->agree(pilot->user, &pilot->per_bucket))) return snk_fail(SNK_E_INTERNAL, err, errcap, "count: the pilot's exchange failed (%d)", r2);
             *retarget = pilot->per_bucket > 0.85 * snk_count_limit(K, grouped) && !h_p[1];
             return SNK_OK;
@@ -126,23 +138,35 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
                 cr.NB = ranges->bounds[r + 1];
                 if (r == 0 && pilot && NB >= 16384 && n_inst_hint) {
                     const uint32_t NBp = NB / 64 < cr.NB - cr.bucket0 ? NB / 64 : cr.NB - cr.bucket0;
-                    bool retarget = false;
-                    if ((rc = run_pilot(cr.bucket0, NBp, &retarget))) return rc;
+                    bool retarget = false, regrow = false;
+                    if ((rc = run_pilot(cr.bucket0, NBp, &retarget, &regrow))) return rc;
                     if (retarget) return SNK_RETARGET;
+                    if (regrow) { pilot_regrow = true; break; }
                     cr.bucket0 += NBp;
                 }
                 if (cr.bucket0 < cr.NB && (rc = snk_launch_count(K, st, cr, err, errcap))) return rc;
             }
         } else if (attempt == 0 && pilot && NB >= 16384 && n_inst_hint) {
             const uint32_t NBp = NB / 64;
-            bool retarget = false;
-            if ((rc = run_pilot(0, NBp, &retarget))) return rc;
+            bool retarget = false, regrow = false;
+            if ((rc = run_pilot(0, NBp, &retarget, &regrow))) return rc;
             if (retarget) return SNK_RETARGET;
-            snk_count_args cr = ca;
-            cr.bucket0 = NBp;
-            if ((rc = snk_launch_count(K, st, cr, err, errcap))) return rc;
+            if (regrow) pilot_regrow = true;
+            else {
+                snk_count_args cr = ca;
+                cr.bucket0 = NBp;
+                if ((rc = snk_launch_count(K, st, cr, err, errcap))) return rc;
+            }
         } else if ((rc = snk_launch_count(K, st, ca, err, errcap))) return rc;
         kt.mark();
+        if (pilot_regrow) {           // larger regions, the pilot once more (nothing else has run)
+            snk_ctx_release_block(ctx, keys_r);
+            snk_ctx_release_block(ctx, vals_r);
+            if (extra) snk_ctx_release_block(ctx, extra);
+            pilot_regrown = true;
+            --attempt;
+            continue;
+        }
         SNK_HIP_TRY(hipMemcpyAsync(h_rcur.data(), rcur, n_regions * 8ull, hipMemcpyDeviceToHost, st));
         SNK_HIP_TRY(hipMemcpyAsync(h_status, status, 32, hipMemcpyDeviceToHost, st));
         SNK_HIP_TRY(snk_sync(st));
