@@ -238,6 +238,28 @@ def test_error_rich_reads_are_repartitioned_into_smaller_buckets(engine, monkeyp
         torch.cuda.empty_cache()
 
 
+def test_ctx_trim_gives_memory_back_and_the_context_still_works(engine):
+    """snk_ctx_trim: the arena's idle blocks go back to the device (another allocator on the GPU can have them), the last result stays
+    valid, and the next call allocates again and gives the same answer."""
+    import torch
+    c = goldens.load("synth_20k_err")
+    dev = torch.device("cuda", 0)
+    rows = torch.from_numpy(c.rows.view(np.int32).copy()).to(dev)
+    quals = torch.from_numpy(np.ascontiguousarray(c.quals)).to(dev)
+    bc = torch.from_numpy(c.bc.astype(np.int32)).to(dev)
+    lens = torch.from_numpy(c.lens.astype(np.uint16).view(np.int16)).to(dev)
+    from supernova_amd.engine import Params
+    r1 = engine.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, params=Params(K=48), ign_bc_below=c.ign_bc_below)
+    free0 = torch.cuda.mem_get_info()[0]
+    engine.release_cache()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free1 >= free0
+    k1, c1, u1 = r1.keys(), r1.counts(), r1.unitigs()            # still readable after the trim
+    r2 = engine.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, params=Params(K=48), ign_bc_below=c.ign_bc_below)
+    assert np.array_equal(k1, r2.keys()) and np.array_equal(c1, r2.counts()) and u1 == r2.unitigs()
+    assert np.array_equal(k1[:, :3], c.exp_keys)
+
+
 @pytest.mark.parametrize("name,use_bc", [("adversarial", True), ("synth_20k_err", False)])
 def test_k60_vs_oracle(engine, name, use_bc):
     """K=60 (long-k config): key 120 bit, supermers up to 106 bases.  The reference's BuildReadQGraph60 has no barcode
