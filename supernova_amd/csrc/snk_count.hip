@@ -286,7 +286,9 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                 if (tid < BATCH && base + tid < vend) {
                     const uint4 ra = *reinterpret_cast<const uint4*>(rec + 8 * tid), rb = *reinterpret_cast<const uint4*>(rec + 8 * tid + 4);
                     nkm = rb.z & 0x7Fu;
-                    if (a.dbg != 4 && nkm) {
+                    // (per-barcode groups: a group sees a locus once or twice, identical supermers inside one group are rare -- looking for
+                    // them cost 11 of the grouped bench's 160 ms and found next to nothing)
+                    if (!GROUPED && a.dbg != 4 && nkm) {
                         // (seven independent multiplies, one finaliser: this lane is on the critical path of the batch)
                         uint32_t h = (ra.x * 0x9E3779B1u) ^ snk_rotl32(ra.y * 0x85EBCA77u, 7) ^ (ra.z * 0xC2B2AE3Du) ^ snk_rotl32(ra.w * 0x27D4EB2Fu, 13)
                                    ^ (rb.x * 0x165667B1u) ^ snk_rotl32(rb.y * 0xcc9e2d51u, 19) ^ (rb.z * 0x1b873593u);
