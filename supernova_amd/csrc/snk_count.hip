@@ -26,7 +26,8 @@
 namespace {
 
 constexpr uint32_t BC_MULTI = 0xFFFFFFFEu;
-constexpr uint32_t BC_IGN = 0xFFFFFFFFu;
+constexpr uint32_t BC_IGN = 0xFFFFFFFFu;      // (a read under the ignore rule: larger than BC_MULTI, so the atomicMax of the merges keeps it)
+static_assert(BC_IGN > BC_MULTI, "barcode states are merged with atomicMax");
 constexpr int MAX_SPLIT_LOG2 = 16;
 #define SNK_COUNT_MAXSEG 32      // record segments per bucket (sharded runs: one per source rank)
 #ifndef SNK_COUNT_THREADS
@@ -118,7 +119,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     // parity), ctl[10..11] instances | leaders << 16 of the batch (by batch parity), ctl[16..16+2*MAX) split stack (17 levels)
     static_assert(THREADS >= BATCH && THREADS % 64 == 0, "the first BATCH threads own the staged records");
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wv = tid >> 6;
+    const int lane = tid & 63;
     constexpr uint32_t LIMIT = SLOTS - THREADS - 64;   // distinct k-mers one sub-pass may hold
 #ifdef SNK_COUNT_PROF
     long long prof_t = clock64();

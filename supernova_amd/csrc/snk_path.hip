@@ -141,12 +141,12 @@ __global__ void __launch_bounds__(256) dict_build_kernel(const uint64_t* __restr
     if (p0 >= total) return;
     uint64_t lo = 0, hi = U;                     // largest u with uoff[u] <= p0
     while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (uoff[mid] <= p0) lo = mid; else hi = mid; }
-    uint64_t ub = uoff[lo], ue = uoff[lo + 1];
+    uint64_t ue = uoff[lo + 1];
     snk_kmer f;
     f.hi = 0; f.lo = 0;
     bool have = false;                            // f = the k-mer that starts at p - 1
     for (uint64_t p = p0; p < p0 + DB_RUN && p < total; ++p) {
-        while (p >= ue) { ++lo; ub = ue; ue = uoff[lo + 1]; have = false; }
+        while (p >= ue) { ++lo; ue = uoff[lo + 1]; have = false; }
         if (p + K > ue) { have = false; continue; }                           // the last K-1 positions of a unitig start no k-mer
         if (have) f = snk_kmer_succ<K>(f, ubases[p + K - 1] & 3u);
         else {
