@@ -12,11 +12,17 @@ entries = doc.get("entries", {})
 
 
 def per_launch(path, counter, kernel="snk_count_kernel"):
-    tot, n, name = 0.0, 0, None
+    """Average counter value of the kernel's FULL launches (a first call also has the short pilot launch over 1/64 of the buckets and
+    the launch that finishes it: anything under a quarter of the largest value is left out, the finishing launch counts as full)."""
+    vals, name = [], None
     for r in csv.DictReader(open(path)):
         if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter:
-            tot += float(r["Counter_Value"]); n += 1; name = r["Kernel_Name"].split("(")[1 if r["Kernel_Name"].startswith("void (") else 0]
-    return tot / max(n, 1), n, name
+            vals.append(float(r["Counter_Value"])); name = r["Kernel_Name"].split("(")[1 if r["Kernel_Name"].startswith("void (") else 0]
+    if not vals:
+        return 0.0, 0, name
+    mx = max(vals)
+    full = [v for v in vals if v >= 0.9 * mx] or vals
+    return sum(full) / len(full), len(full), name
 
 
 a = sys.argv[1:]
