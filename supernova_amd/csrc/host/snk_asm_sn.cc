@@ -64,26 +64,39 @@ std::vector<std::string> split_list(const std::string& v) {
     return out;
 }
 
-void rendezvous(const std::string& path, int rank, int world, unsigned char id[128]) {
+// The file is the 128-byte unique id followed by a 64-byte job nonce (JOB_ID=..., default: MASTER_PORT of the launcher, else empty).
+// Rank 0 removes whatever a crashed run left behind BEFORE it makes the id; the other ranks only take a file that carries this job's
+// nonce -- a stale id from another job would send them into ncclCommInitRank with nobody on the other side.
+void rendezvous(const std::string& path, const std::string& job, int rank, int world, unsigned char id[128]) {
     char err[512] = "";
+    char nonce[64];
+    memset(nonce, 0, sizeof nonce);
+    memcpy(nonce, job.data(), job.size() < 63 ? job.size() : 63);
     if (rank == 0) {
+        if (world > 1 && !path.empty()) (void)unlink(path.c_str());
         int rc = snk_comm_unique_id(id, err, sizeof err);
         if (rc) fatal(rc, "RCCL unique id", err);
         if (world > 1) {
             if (path.empty()) fatal(SNK_E_ARG, "WORLD > 1", "ID_FILE=<path> is needed for the rendezvous");
             const std::string tmp = path + ".tmp";
             FILE* f = fopen(tmp.c_str(), "wb");
-            if (!f || fwrite(id, 1, 128, f) != 128 || fclose(f) != 0 || rename(tmp.c_str(), path.c_str()) != 0) fatal(SNK_E_IO, "ID_FILE", "cannot write the unique id");
+            if (!f || fwrite(id, 1, 128, f) != 128 || fwrite(nonce, 1, 64, f) != 64 || fclose(f) != 0 || rename(tmp.c_str(), path.c_str()) != 0)
+                fatal(SNK_E_IO, "ID_FILE", "cannot write the unique id");
         }
         return;
     }
     if (path.empty()) fatal(SNK_E_ARG, "WORLD > 1", "ID_FILE=<path> is needed for the rendezvous");
     for (int tries = 0; tries < 6000; ++tries) {         // ten minutes
         FILE* f = fopen(path.c_str(), "rb");
-        if (f) { const size_t n = fread(id, 1, 128, f); fclose(f); if (n == 128) return; }
+        if (f) {
+            unsigned char buf[192];
+            const size_t n = fread(buf, 1, 192, f);
+            fclose(f);
+            if (n == 192 && memcmp(buf + 128, nonce, 64) == 0) { memcpy(id, buf, 128); return; }
+        }
         usleep(100000);
     }
-    fatal(SNK_E_IO, "ID_FILE", "rank 0's unique id did not appear");
+    fatal(SNK_E_IO, "ID_FILE", "rank 0's unique id (with this job's JOB_ID) did not appear");
 }
 
 }  // namespace
@@ -103,7 +116,7 @@ int main(int argc, char** argv) {
     if (world < 1 || rank < 0 || rank >= world) fatal(SNK_E_ARG, "WORLD / RANK", "out of range");
     const int n_in = (int)kv.count("FASTH") + (int)kv.count("LR") + (int)kv.count("SYNTH");
     if (n_in != 1 || (rank == 0 && !kv.count("OUT"))) {
-        fprintf(stderr, "usage: snk_asm_sn [WORLD=n RANK=r ID_FILE=<path>] (FASTH=<files> WHITELIST=<txt> | LR=<reads.fastb> | SYNTH=<reads> [SEED=s]) OUT=<asm_graph.bv> "
+        fprintf(stderr, "usage: snk_asm_sn [WORLD=n RANK=r ID_FILE=<path> JOB_ID=<nonce>] (FASTH=<files> WHITELIST=<txt> | LR=<reads.fastb> | SYNTH=<reads> [SEED=s]) OUT=<asm_graph.bv> "
                         "[K=48] [MIN_QUAL=7] [MIN_FREQ=3] [MIN_BC=2] [BC_START=n] [DEVICE=d] [STEPS=k] [STATS=<file>]\n");
         return 1;
     }
@@ -199,7 +212,8 @@ int main(int argc, char** argv) {
 
     // ---- the communicator
     unsigned char id[128];
-    rendezvous(kv.count("ID_FILE") ? kv["ID_FILE"] : std::string(), rank, world, id);
+    const std::string job = kv.count("JOB_ID") ? kv["JOB_ID"] : std::string(getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "");
+    rendezvous(kv.count("ID_FILE") ? kv["ID_FILE"] : std::string(), job, rank, world, id);
     snk_comm* comm = nullptr;
     if ((rc = snk_comm_create_rccl(ctx, id, (uint32_t)rank, (uint32_t)world, &comm, err, sizeof err))) fatal(rc, "RCCL communicator", err);
 

@@ -9,6 +9,13 @@ struct snk_comm {
     uint32_t rank = 0, world = 1;
     uint64_t bytes_sent = 0;          // payload handed to the transport for OTHER ranks since the last reset
     uint64_t n_collectives = 0;
+    // Sizing history of the step, kept with the GROUP and not with a rank's context: distinct k-mers per instance the last step over
+    // this communicator saw (job-wide, computed by every rank from the same exchanged words).  Every rank of a group has been through
+    // the same steps over it, so the decision "partition with the ratio / run a pilot first" -- which decides whether a collective is
+    // issued -- is the same everywhere by construction; a context's own history (a one-rank step, a re-created engine) cannot split it.
+    double claim_ratio = 0.0;
+    uint64_t claim_ratio_reads = 0;
+    uint32_t claim_ratio_k = 0;
     virtual ~snk_comm() {}
     virtual const char* kind() const = 0;
     // Variable all-to-all of bytes: scnt[p] bytes at send + sbeg[p] go to rank p, rcnt[s] bytes from rank s land at

@@ -38,6 +38,7 @@ struct rccl_api {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
 };
 rccl_api g_rccl;
 std::string g_rccl_path;
@@ -73,6 +74,7 @@ int rccl_load(char* err, size_t errcap) {
     BIND(GroupEnd, "ncclGroupEnd");
     BIND(GetErrorString, "ncclGetErrorString");
 #undef BIND
+    *(void**)(&a.CommAbort) = dlsym(h, "ncclCommAbort");      // optional
     g_rccl = a;
     return SNK_OK;
 }
@@ -100,28 +102,39 @@ struct rccl_comm : snk_comm {
         ++n_collectives;
         const char* s = (const char*)send;
         char* r = (char*)recv;
-        if (scnt[rank]) {
-            if (scnt[rank] != rcnt[rank]) return snk_fail(SNK_E_INTERNAL, err, errcap, "a2a: the piece for myself has two sizes");
-            SNK_HIP_TRY(hipMemcpyAsync(r + rbeg[rank], s + sbeg[rank], scnt[rank], hipMemcpyDeviceToDevice, st));
-        }
+        if (scnt[rank] != rcnt[rank]) return snk_fail(SNK_E_INTERNAL, err, errcap, "a2a: the piece for myself has two sizes");
+        if (scnt[rank]) SNK_HIP_TRY(hipMemcpyAsync(r + rbeg[rank], s + sbeg[rank], scnt[rank], hipMemcpyDeviceToDevice, st));
         bool any = false;
         for (uint32_t p = 0; p < world; ++p) if (p != rank && (scnt[p] || rcnt[p])) any = true;
         if (!any) return SNK_OK;
         NCCL_TRY(g_rccl.GroupStart());
-        for (uint32_t p = 0; p < world; ++p) {
+        // a group that was opened is closed on every path: a communicator left in group mode would swallow the next collective of
+        // this rank while the peers wait in theirs
+        ncclResult_t bad = ncclSuccess;
+        const char* what = "";
+        for (uint32_t p = 0; p < world && bad == ncclSuccess; ++p) {
             if (p == rank) continue;
-            for (uint64_t o = 0; o < scnt[p]; o += PIECE) {
+            for (uint64_t o = 0; o < scnt[p] && bad == ncclSuccess; o += PIECE) {
                 const size_t n = (size_t)(scnt[p] - o < PIECE ? scnt[p] - o : PIECE);
-                NCCL_TRY(g_rccl.Send(s + sbeg[p] + o, n, ncclUint8, (int)p, comm, st));
+                bad = g_rccl.Send(s + sbeg[p] + o, n, ncclUint8, (int)p, comm, st);
+                what = "ncclSend";
             }
-            for (uint64_t o = 0; o < rcnt[p]; o += PIECE) {
+            for (uint64_t o = 0; o < rcnt[p] && bad == ncclSuccess; o += PIECE) {
                 const size_t n = (size_t)(rcnt[p] - o < PIECE ? rcnt[p] - o : PIECE);
-                NCCL_TRY(g_rccl.Recv(r + rbeg[p] + o, n, ncclUint8, (int)p, comm, st));
+                bad = g_rccl.Recv(r + rbeg[p] + o, n, ncclUint8, (int)p, comm, st);
+                what = "ncclRecv";
             }
             bytes_sent += scnt[p];
         }
-        NCCL_TRY(g_rccl.GroupEnd());
+        const ncclResult_t ge = g_rccl.GroupEnd();
+        if (bad != ncclSuccess) return snk_fail(SNK_E_HIP, err, errcap, "%s failed inside an exchange: %s", what, g_rccl.GetErrorString(bad));
+        if (ge != ncclSuccess) return snk_fail(SNK_E_HIP, err, errcap, "ncclGroupEnd failed: %s", g_rccl.GetErrorString(ge));
         return SNK_OK;
+    }
+    // a rank that fails between collectives cannot release peers that already wait inside one: ncclCommAbort tears the
+    // communicator down on THIS rank (its queued operations fail instead of waiting), the launcher has to end the job
+    void abort() override {
+        if (comm && g_rccl.CommAbort) { (void)g_rccl.CommAbort(comm); comm = nullptr; }
     }
     int allgatherv(const void* send, const uint64_t* counts, void* recv, hipStream_t st, char* err, size_t errcap) override {
         std::vector<uint64_t> sbeg(world, 0), scnt(world, counts[rank]), rbeg(world), rcnt(world);

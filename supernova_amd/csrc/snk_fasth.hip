@@ -95,7 +95,7 @@ bool decode_file(snk_fasth_stream* s, uint32_t fi) {
     size_t scan = 0;              // first byte not yet searched for a newline
     uint32_t li = 0;              // line of the record, 0..8
     uint32_t r_len[2] = {0, 0};
-    bool ok = true, eof_in = false, first_byte = true;
+    bool ok = true, eof_in = false, first_byte = true, mid_member = false;
     std::string what;
     auto flush = [&](bool last) {
         if (cur < 0) return;
@@ -168,7 +168,12 @@ bool decode_file(snk_fasth_stream* s, uint32_t fi) {
         }
         zs.next_out = win.data() + have;
         zs.avail_out = (uInt)(WIN - have);
+        const uInt in_before = zs.avail_in;
         const int zr = inflate(&zs, Z_NO_FLUSH);
+        // a member is open from its first consumed byte to its Z_STREAM_END: the end of the input inside one is a truncated file
+        // (the reference's MultiGzDecoder + unwrap() panics on it, multifastq.rs:69-127)
+        if (zr == Z_STREAM_END) mid_member = false;
+        else if (zs.avail_in < in_before || zs.avail_out < (uInt)(WIN - have)) mid_member = true;
         if (zr != Z_OK && zr != Z_STREAM_END && zr != Z_BUF_ERROR) { what = path + ": corrupt gzip stream (" + std::string(zs.msg ? zs.msg : "zlib error") + ")"; ok = false; break; }
         const size_t now = WIN - zs.avail_out;
         text_in_batch += now - have;
@@ -191,6 +196,7 @@ bool decode_file(snk_fasth_stream* s, uint32_t fi) {
     }
     inflateEnd(&zs);
     close(fd);
+    if (ok && mid_member) { what = path + ": truncated gzip stream (the input ends inside a member)"; ok = false; }
     if (ok && line_beg < have) {          // a last line without a newline
         if (!on_line(win.data() + line_beg, have - line_beg)) ok = false;
     }

@@ -228,6 +228,13 @@ extern "C" int snk_read_fasth(const char* path, uint32_t stride, uint64_t* n_rea
         memcpy(&B[ob], bc.data(), nb);
         ++pairs;
     }
+    if (rc == SNK_OK) {
+        // the end of the file inside a gzip member (an interrupted copy) reads as a clean end of data through gzgets; zlib knows
+        // (Z_BUF_ERROR at EOF).  The reference panics on it (MultiGzDecoder + unwrap(), multifastq.rs:69-127)
+        int zerr = Z_OK;
+        (void)gzerror(f, &zerr);
+        if (zerr != Z_OK && zerr != Z_STREAM_END) rc = snk_fail(SNK_E_IO, err, errcap, "%s: truncated or corrupt gzip stream (zlib %d)", path, zerr);
+    }
     gzclose(f);
     if (rc != SNK_OK) return rc;
     auto dup = [](const void* src, size_t bytes) -> void* { void* p = malloc(bytes ? bytes : 16); if (p && bytes) memcpy(p, src, bytes); return p; };

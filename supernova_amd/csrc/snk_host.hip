@@ -351,6 +351,7 @@ extern "C" int snk_count_graph(snk_ctx* ctx, const snk_reads* in, const snk_para
     // every error exit of the implementation leaves through here: uploads / kernels it queued are waited for (the caller may free
     // its input right after, and the next call reuses the context's staging buffers) and what it malloc'ed into *out is released
     int rc;
+    if (out) memset(out, 0, sizeof *out);      // before any validation return: the error exit below frees what *out points at
     try { rc = count_graph_impl(ctx, in, p, out, err, errcap); }
     catch (const std::bad_alloc&) { rc = snk_fail(SNK_E_NOMEM, err, errcap, "host allocation failed"); }
     catch (const std::exception& ex) { rc = snk_fail(SNK_E_INTERNAL, err, errcap, "%s", ex.what()); }

@@ -230,13 +230,13 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
             for (ull v : all) inst_ub += v * kpr;
         }
     }
-    const bool have_ratio = inst_ub && ctx->claim_ratio > 0.0 && ctx->claim_ratio_reads == inst_ub && ctx->claim_ratio_k == ((K * 2) | 0x80000000u);
+    const bool have_ratio = inst_ub && comm->claim_ratio > 0.0 && comm->claim_ratio_reads == inst_ub && comm->claim_ratio_k == K * 2;      // (the group's history: snk_comm.h)
     // Bucket size: from the job-wide ratio of distinct k-mers per instance the previous step exchanged; without that history the
     // count stage looks at its first buckets, the ranks agree on what they saw (one more exchange), and if the tables overflow as
     // a rule the reads are partitioned and exchanged once more into smaller buckets (error-rich reads: see snk_pipeline.hip).
     const char* forced_target = getenv("SNK_TARGET_INST");
     const bool adaptive = inst_ub && !(forced_target && *forced_target) && snk_env_u32("SNK_ADAPTIVE_BUCKETS", 1) != 0;
-    double ratio = have_ratio ? ctx->claim_ratio : 0.0;
+    double ratio = have_ratio ? comm->claim_ratio : 0.0;
     uint32_t NB_total = 0, NBl = 0;
     uint64_t n_inst = 0, inst_hint = 0, exch_records = 0;
     snk_shard_state* S = nullptr;
@@ -398,7 +398,7 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
             q_send[q] = qall[(size_t)me * (W + QX) + q]; q_recv[q] = qall[(size_t)q * (W + QX) + me]; all_n[q] = qall[(size_t)q * (W + QX) + W];
             dsum += qall[(size_t)q * (W + QX) + W + 1]; isum += qall[(size_t)q * (W + QX) + W + 2];
         }
-        if (isum) { ctx->claim_ratio = (double)dsum / (double)isum; ctx->claim_ratio_reads = inst_ub; ctx->claim_ratio_k = (K * 2) | 0x80000000u; }      // (keyed by a job-wide figure: every rank must take the same decision)
+        if (isum) { comm->claim_ratio = (double)dsum / (double)isum; comm->claim_ratio_reads = inst_ub; comm->claim_ratio_k = K * 2; }      // (job-wide figures, kept with the group: every rank takes the same decision next time)
     }
     uint64_t nq = 0, nq_in = 0;
     for (uint32_t q = 0; q < W; ++q) { nq += q_send[q]; nq_in += q_recv[q]; }

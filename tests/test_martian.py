@@ -210,6 +210,12 @@ def test_native_fasth_reader_matches_python(snk, tmp_path):
     from supernova_amd.lib import SnkError
     with pytest.raises(SnkError):
         read_fasth_native([str(bad)])
+    whole = open(files[0], "rb").read()
+    for cut in (len(whole) - 4, len(whole) // 2):
+        cutf = tmp_path / f"ncut{cut}.fasth.gz"
+        cutf.write_bytes(whole[:cut])
+        with pytest.raises(SnkError, match="truncated"):
+            read_fasth_native([str(cutf)])
 
 
 def test_fasth_stream_multi_file(snk, tmp_path):
@@ -255,6 +261,14 @@ def test_fasth_stream_multi_file(snk, tmp_path):
         f.write("@h\nACGT\nIIII\nACGT\n")
     with pytest.raises(SnkError, match="truncated"):
         read_fasth_stream([str(bad)])
+    # an interrupted copy: the compressed stream stops before its end.  Even when every record decoded so far is whole (the cut
+    # falls inside the gzip trailer, or anywhere at all) the reference's MultiGzDecoder + unwrap() panics; so does the reader
+    whole = open(files[0], "rb").read()
+    for cut in (len(whole) - 4, len(whole) - 9, len(whole) // 2):
+        cutf = tmp_path / f"cut{cut}.fasth.gz"
+        cutf.write_bytes(whole[:cut])
+        with pytest.raises(SnkError, match="truncated"):
+            read_fasth_stream([files[1], str(cutf)])
 
 
 def test_synth_fasth_writer_round_trip(snk, tmp_path):
