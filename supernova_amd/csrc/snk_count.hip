@@ -79,7 +79,10 @@ template <int K, bool G> __device__ __forceinline__ uint64_t klo_unpack(typename
 
 typedef __attribute__((address_space(3))) void* snk_lptr;
 
-template <int K, int THREADS, int SLOTS, bool GROUPED, bool MULTI>      // MULTI: more than one record segment per bucket
+// MULTI: more than one record segment per bucket.  GATHER (dense partition, snk_stages.hip): a bucket is a range of an index list, record v of
+// the bucket is records[gidx[v]] -- the LDS-DMA fetch takes a per-lane address, so a gathered batch costs what a contiguous one does
+// plus the (coalesced) read of its indices.
+template <int K, int THREADS, int SLOTS, bool GROUPED, bool MULTI, bool GATHER = false>
 __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a) {
     // supermers staged per batch.  A 4000-instance bucket holds ~270 (sigma ~100): with 512 slots nearly every bucket is
     // ONE batch (with 256, 55 % of the buckets ran a second, mostly empty batch through all the phases below).  K=60 and
@@ -134,13 +137,26 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
             const uint32_t mylen = (uint32_t)lane < a.nseg ? LDS_LOAD(&seg[2 * SNK_COUNT_MAXSEG + lane]) - LDS_LOAD(&seg[lane]) : 0u;
             seg_incl = snk_wave_scan_incl(mylen);
         }
+        // GATHER: every index of the batch is asked for before the first fetch goes out (vmcnt counts in order: an index load behind
+        // a fetch would wait for that fetch to land)
+        constexpr int NR = (CH + THREADS - 1) / THREADS;
+        uint32_t gx[NR];
+        if (GATHER) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int c = r * THREADS + tid;
+                const uint64_t v = base + (uint32_t)(c >> 1);
+                gx[r] = (c < CH && v < vend) ? a.gidx[v] : 0u;
+            }
+        }
 #pragma unroll
         for (int r = 0; r * THREADS < CH; ++r) {
             const int c = r * THREADS + tid;
             const uint64_t v = base + (uint32_t)(c >> 1);
             if (c < CH && v < vend) {
                 uint64_t gi;
-                if (MULTI) {
+                if (GATHER) gi = gx[r];
+                else if (MULTI) {
                     // the segments are read as ONE concatenated record stream (batches stay full, identical supermers from
                     // different sources fold): find the segment by a short prefix walk
                     // the segment of virtual record x: the inclusive prefix of the segment lengths sits in the wave's first lanes
@@ -586,6 +602,10 @@ size_t lds_bytes(uint32_t bc_mode = 0) {
 template <int K, bool G>
 int launch(hipStream_t st, const snk_count_args& a, char* err, size_t errcap) {
     auto kern = a.nseg > 1 ? snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G, true> : snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G, false>;
+    if (a.gidx) {
+        if (a.nseg != 1) return snk_fail(SNK_E_INTERNAL, err, errcap, "count: an index list comes with one segment per bucket");
+        kern = snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G, false, true>;
+    }
     size_t lds = lds_bytes<K, G>(a.bc_mode);
     SNK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (a.bucket0 >= a.NB) return SNK_OK;          // the launch covers buckets [bucket0, NB)

@@ -29,6 +29,7 @@ struct snk_ctx {
     uint64_t last_bnd = 0, last_bnd_n = 0;              // boundary k-mers the bucket-local prune found for a table of last_bnd_n k-mers
     uint32_t last_ovf = 0, last_ovf_nb = 0;             // overflow supermers of the last partition pass and its bucket count
     uint64_t last_ovf_reads = 0;
+    uint64_t last_dense = 0;                            // supermer records of the last dense partition pass (last_ovf_nb == 0xD0000000)
     double claim_ratio = 0.0;                          // distinct k-mers per k-mer instance the count kernel saw in the last call ...
     uint64_t claim_ratio_reads = 0;                    // ... over this many reads ...
     uint32_t claim_ratio_k = 0;                        // ... in this mode (2 K + grouped)

@@ -38,6 +38,11 @@ struct snk_msp_args {
     const uint16_t* lens;
     uint16_t* good_out;
     unsigned long long* plan;
+    // dense partition (dense_bkt != NULL): no per-bucket slots and no slot reservation -- record p of the pass goes to records[p]
+    // (a workgroup reserves its block with one atomic on dense_cursor), its bucket to dense_bkt[p]; cursor / cap / ovf_* are unused
+    uint32_t* dense_bkt;
+    unsigned long long* dense_cursor;   // [1] records wanted (keeps counting past dense_cap)
+    uint64_t dense_cap;
 };
 constexpr int SNK_MSP_PLAN_SLOTS = 256;
 int snk_launch_msp(uint32_t K, hipStream_t st, const snk_msp_args& a, char* err, size_t errcap);
@@ -51,6 +56,7 @@ struct snk_count_args {
     const uint64_t* seg_end;       // [nseg][seg_stride] one past its last record (offset tables: seg_end = seg_beg + 1)
     uint32_t seg_stride;
     uint32_t nseg;
+    const uint32_t* gidx;          // dense partition: the segment bounds index this list, record v of a bucket is records[gidx[v]]; else NULL
     uint32_t NB;
     uint32_t min_freq;
     uint32_t bc_mode;              // = minBC: 0 no barcode rule, 1: >=1 barcode>0 (or ignore-rule read), 2: >=2 distinct (state machine), 3..8: id sets

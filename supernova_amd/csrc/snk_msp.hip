@@ -196,7 +196,7 @@ __device__ __forceinline__ int fused_trim(const snk_msp_args& a, int tid0, uint6
 // (36.0 -> 33.0 ms at 1e8 reads against the 105 registers / four waves per SIMD the compiler picks on its own).  Keeping
 // the minimisers' keys in a second LDS list to save their re-derivation in the emit loop costs the fifth workgroup and
 // was dropped again; six waves per SIMD (80 VGPRs) spill 28 registers.  K=60 (45 keys in registers) stays at four.
-template <int K, int M, bool TRIM>
+template <int K, int M, bool TRIM, bool DENSE>
 #ifndef SNK_MSP_OCC48
 #define SNK_MSP_OCC48 5
 #endif
@@ -279,20 +279,40 @@ __global__ void __launch_bounds__(BD, K == 48 ? SNK_MSP_OCC48 : 4) snk_msp_kerne
     // other waves' scans).  What made this kernel take 65 ms for a while was the OVERFLOW path: with a capacity of
     // mean + 4 sqrt(mean), 1.7 % of the supermers overflowed (bucket occupancy is far from Poisson, see the sizing in
     // snk_pipeline.hip) and each took a returning atomic on the ONE overflow cursor (tools/msp_probe2.py).
-    auto flush = [&](int upto, int last_end) {
+    uint32_t dense_base = 0;          // DENSE: position of this thread's first record of the final flush
+    auto flush = [&](int upto, int last_end, bool last) {
         if (a.dbg == 3) { if (upto == 0x7FFF && last_end == 0x7FFF) a.cursor[0] = 1; return; }      // probe: the scan alone
         int maxn = upto;
         for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(maxn, off); maxn = o > maxn ? o : maxn; }
         for (int e = 0; e < maxn; ++e) {
+            uint32_t w[8];
+            uint64_t at = 0;
             if (e < upto) {
                 uint32_t ent = lst[e * BD + tid];
                 uint32_t s = ent & 0xFFu;
                 uint32_t en = (e + 1 < upto) ? (((uint32_t)lst[(e + 1) * BD + tid] & 0xFFu) - 1u) : (uint32_t)last_end;
                 uint32_t bucket = mmer_bucket<M>(rowL, tid, row_words, (int)(ent >> 8), NB, gmix);
                 {
-                    const uint32_t slot = a.dbg == 2 ? ((ent * 2654435761u) % (a.cap ? a.cap : 1u)) : atomicAdd(&a.cursor[bucket], 1u);
-                    uint64_t at = 0;
                     bool ok = true;
+                    uint32_t slot = 0;
+                    if (DENSE) {
+                        // no slot reservation: records go out densely in read order (a workgroup's block was reserved with ONE atomic,
+                        // a thread's records follow each other inside it); which bucket a record belongs to is written next to it and
+                        // the count kernel finds a bucket's records through a sorted index list (snk_stages.hip)
+                        uint64_t pos;
+                        if (last) pos = (uint64_t)dense_base + (uint32_t)e;
+                        else {
+                            // a list drained in mid-read (more than LCAP supermers in one read): one reservation per wave and turn
+                            const unsigned long long m = __ballot(1);
+                            const int lane = tid & 63, leader = __ffsll((long long)m) - 1;
+                            unsigned long long o = 0;
+                            if (lane == leader) o = atomicAdd(a.dense_cursor, (unsigned long long)__popcll(m));
+                            pos = __shfl(o, leader) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                        }
+                        if (pos < a.dense_cap) { at = pos; a.dense_bkt[pos] = bucket; }
+                        else ok = false;                                   // the host sees the cursor beyond the capacity and re-runs
+                    } else {
+                    slot = a.dbg == 2 ? ((ent * 2654435761u) % (a.cap ? a.cap : 1u)) : atomicAdd(&a.cursor[bucket], 1u);
                     if (slot < a.cap) at = (uint64_t)bucket * a.cap + slot;
                     else {
                         // overflow list: ONE reservation per wave (same-address atomics are served one at a time)
@@ -304,6 +324,7 @@ __global__ void __launch_bounds__(BD, K == 48 ? SNK_MSP_OCC48 : 4) snk_msp_kerne
                         if (o < a.ovf_cap) { at = a.ovf_base + o; a.ovf_bucket[o] = bucket; }
                         else ok = false;                               // the host sees ovf_cursor > ovf_cap and re-runs
                     }
+                    }
                     if (ok && a.dbg != 1) {
                         uint32_t n_kmers = en - s + 1u;
                         uint32_t hasL = s > 0 ? 1u : 0u;
@@ -312,7 +333,7 @@ __global__ void __launch_bounds__(BD, K == 48 ? SNK_MSP_OCC48 : 4) snk_msp_kerne
                         uint32_t bits = 2u * (n_kmers + (uint32_t)K - 1u + hasL + hasR);
                         // the record's seven base words: eight consecutive row words (behind the row: the zero row), one funnel shift
                         // and one mask each -- no word-index tests (the first version compiled into seven exec-masked blocks)
-                        uint32_t w[8], rw[8];
+                        uint32_t rw[8];
                         const uint32_t wi0 = a0 >> 4, fs = 2u * (a0 & 15u);
 #pragma unroll
                         for (uint32_t q = 0; q < 8; ++q) rw[q] = rowL[min(wi0 + q, row_words) * BD + tid];
@@ -427,7 +448,7 @@ __global__ void __launch_bounds__(BD, K == 48 ? SNK_MSP_OCC48 : 4) snk_msp_kerne
                 if (__any(isnew && cnt == LCAP)) {     // every lane of the wave drains its list; the open supermer stays
                     const int upto = cnt > 0 ? cnt - 1 : 0;
                     const int last_end = cnt > 0 ? (int)(lst[(cnt - 1) * BD + tid] & 0xFFu) - 1 : 0;
-                    flush(upto, last_end);
+                    flush(upto, last_end, false);
                     if (cnt > 0) { lst[tid] = lst[(cnt - 1) * BD + tid]; cnt = 1; }
                 }
                 if (isnew) {
@@ -443,7 +464,25 @@ __global__ void __launch_bounds__(BD, K == 48 ? SNK_MSP_OCC48 : 4) snk_msp_kerne
             }
         }
     }
-    flush(cnt, nk - 1);
+    if (DENSE) {
+        // the workgroup's block of the dense record array: exclusive scan of the threads' supermer counts, one atomic per workgroup
+        uint32_t* wtot = reinterpret_cast<uint32_t*>(sfxp);        // (the suffix-minimum positions are dead: every wave is past its scan at the barrier)
+        __syncthreads();
+        const uint32_t incl = snk_wave_scan_incl((uint32_t)cnt);
+        if ((tid & 63) == 63) wtot[tid >> 6] = incl;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t tot = 0;
+            for (int w = 0; w < BD / 64; ++w) { const uint32_t v = wtot[w]; wtot[w] = tot; tot += v; }
+            const unsigned long long b = tot ? atomicAdd(a.dense_cursor, (unsigned long long)tot) : 0ull;
+            wtot[BD / 64] = (uint32_t)b; wtot[BD / 64 + 1] = (uint32_t)(b >> 32);
+        }
+        __syncthreads();
+        const uint64_t wgb = ((uint64_t)wtot[BD / 64 + 1] << 32) | wtot[BD / 64];
+        // (positions are 32-bit inside the kernel: the host never launches the dense path on more than 2^32 records)
+        dense_base = (uint32_t)wgb + wtot[tid >> 6] + incl - (uint32_t)cnt;
+    }
+    flush(cnt, nk - 1, true);
 
 }
 
@@ -478,14 +517,22 @@ size_t snk_msp_lds_bytes(uint32_t K, uint32_t M, uint32_t row_words) {
     return (size_t)(row_words + 1) * BD * 4 + (size_t)LCAP * BD * 2 + (size_t)(K - M + 1) * BD + 64;
 }
 
-template <int K, int M, bool TRIM>
-static int launch_msp_kt(hipStream_t st, const snk_msp_args& a, char* err, size_t errcap) {
+template <int K, int M, bool TRIM, bool DENSE>
+static int launch_msp_ktd(hipStream_t st, const snk_msp_args& a, char* err, size_t errcap) {
     size_t lds = snk_msp_lds_bytes(K, M, a.row_words);
     unsigned nb = (unsigned)((a.n_reads + BD - 1) / BD);
-    SNK_HIP_TRY(hipFuncSetAttribute((const void*)snk_msp_kernel<K, M, TRIM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((snk_msp_kernel<K, M, TRIM>), dim3(nb), dim3(BD), lds, st, a);
+    SNK_HIP_TRY(hipFuncSetAttribute((const void*)snk_msp_kernel<K, M, TRIM, DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((snk_msp_kernel<K, M, TRIM, DENSE>), dim3(nb), dim3(BD), lds, st, a);
     SNK_HIP_TRY(hipGetLastError());
     return SNK_OK;
+}
+template <int K, int M, bool TRIM>
+static int launch_msp_kt(hipStream_t st, const snk_msp_args& a, char* err, size_t errcap) {
+    if (a.dense_bkt) {
+        if (!a.dense_cursor || a.dense_cap >= (1ull << 32)) return snk_fail(SNK_E_ARG, err, errcap, "dense partition: needs its cursor and fewer than 2^32 record positions");
+        return launch_msp_ktd<K, M, TRIM, true>(st, a, err, errcap);
+    }
+    return launch_msp_ktd<K, M, TRIM, false>(st, a, err, errcap);
 }
 template <int K, int M>
 static int launch_msp_k(hipStream_t st, const snk_msp_args& a, char* err, size_t errcap) {

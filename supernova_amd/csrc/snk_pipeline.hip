@@ -147,7 +147,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
         if (pass == 0) tm.mark();  // 2
         h_plan[0] = ub_inst; h_plan[1] = ub_live;
         rc = snk_stage_partition(ctx, st, K, in, good_len, NB, h_plan[0], h_plan[1], grouped, status, &part, err, errcap, nullptr, fused ? h_plan : nullptr,
-                                 fused ? &ft : nullptr);
+                                 fused ? &ft : nullptr, true);
         if (rc) return rc;
         h_ninst = h_plan[0];               // (fused trim: now the exact count)
         out->n_instances = h_ninst;
@@ -160,7 +160,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
         snk_count_pilot pilot{0.0, nullptr, nullptr};
         const bool want_pilot = adaptive && pass == 0 && !have_hint;
         rc = snk_stage_count_table(ctx, st, K, records, part.seg, part.seg + NB, 2 * NB, part.nseg, NB, p->min_freq, (in->bc && !grouped) ? p->min_bc : 0u, grouped ? 1u : 0u,
-                                   h_ninst, status, !local_graph, &tab, err, errcap, nullptr, want_pilot ? &pilot : nullptr);
+                                   h_ninst, status, !local_graph, &tab, err, errcap, nullptr, want_pilot ? &pilot : nullptr, part.gidx);
         if (rc == SNK_RETARGET) {
             // everything since the partition goes back to the arena; the good lengths and the status words stay
             snk_ctx_release_since(ctx, mark, nullptr, 0);

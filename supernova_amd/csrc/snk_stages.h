@@ -63,7 +63,7 @@ uint32_t snk_count_limit(uint32_t K, uint32_t grouped);      // distinct k-mers 
 int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* records, const uint64_t* seg_beg,
                           const uint64_t* seg_end, uint32_t seg_stride, uint32_t nseg, uint32_t NB, uint32_t min_freq, uint32_t bc_mode, uint32_t grouped, uint64_t n_inst_hint,
                           uint32_t* status, bool want_sort, snk_table* out, char* err, size_t errcap,
-                          const snk_count_ranges* ranges = nullptr, snk_count_pilot* pilot = nullptr);
+                          const snk_count_ranges* ranges = nullptr, snk_count_pilot* pilot = nullptr, const uint32_t* gidx = nullptr);
 
 // ---- minimiser partition in one pass (fixed bucket capacity + overflow segment)
 struct snk_partition {
@@ -73,6 +73,10 @@ struct snk_partition {
     uint32_t* cursor;     // [NB] supermers of every bucket (including the overflowed ones)
     uint64_t* seg;        // [begin seg 0 | end seg 0 | begin seg 1 | end seg 1] x NB absolute record offsets
     float kernel_ms;
+    // dense partition (snk_stage_partition with allow_dense): records in read order, gidx = their positions sorted by bucket; seg then
+    // bounds ranges of gidx, cap / cursor / the overflow segment do not exist
+    const uint32_t* gidx;
+    float sort_ms;
 };
 int snk_stage_partition_plan(snk_ctx* ctx, hipStream_t st, uint32_t K, const uint16_t* good_len, uint64_t n_reads,
                              unsigned long long h_plan[2] /* instances, contributing reads */, char* err, size_t errcap,
@@ -87,7 +91,7 @@ bool snk_fused_trim_ok(const snk_dev_reads* in);
 int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_reads* in, const uint16_t* good_len, uint32_t NB,
                         unsigned long long n_inst, unsigned long long n_live, bool grouped, uint32_t* status, snk_partition* out,
                         char* err, size_t errcap, const unsigned long long* d_plan = nullptr, unsigned long long* h_plan = nullptr,
-                        const snk_fused_trim* ft = nullptr);
+                        const snk_fused_trim* ft = nullptr, bool allow_dense = false);
 // sharded runs: the buckets' records copied to exact offsets (u32 record index per bucket) of a compact buffer
 int snk_stage_partition_compact(snk_ctx* ctx, hipStream_t st, const snk_partition* part, const uint32_t* d_offsets, void* d_out, char* err, size_t errcap);
 int snk_stage_partition_compact_remote(snk_ctx* ctx, hipStream_t st, const snk_partition* part, const uint32_t* d_offsets, void* d_out,

@@ -25,7 +25,8 @@ uint32_t snk_env_u32(const char* name, uint32_t dflt) {
 // status: device u32[16] scratch words.
 int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* records, const uint64_t* seg_beg,
                           const uint64_t* seg_end, uint32_t seg_stride, uint32_t nseg, uint32_t NB, uint32_t min_freq, uint32_t bc_mode, uint32_t grouped, uint64_t n_inst_hint,
-                          uint32_t* status, bool want_sort, snk_table* out, char* err, size_t errcap, const snk_count_ranges* ranges, snk_count_pilot* pilot) {
+                          uint32_t* status, bool want_sort, snk_table* out, char* err, size_t errcap, const snk_count_ranges* ranges, snk_count_pilot* pilot,
+                          const uint32_t* gidx) {
     int rc;
     snk_phase_timer tm(st), kt(st);
     tm.mark();
@@ -75,6 +76,7 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
         ca.seg_end = seg_end;
         ca.seg_stride = seg_stride;
         ca.nseg = nseg;
+        ca.gidx = gidx;
         ca.NB = NB;
         ca.min_freq = min_freq;
         ca.bc_mode = bc_mode;
@@ -343,9 +345,127 @@ bool snk_fused_trim_ok(const snk_dev_reads* in) {
            (!in->lens || (((uintptr_t)in->lens) & 1u) == 0) && env_u32("SNK_TRIM_FUSED", 1) != 0;
 }
 
+// ---- dense partition: no slots, no slot reservations.  The 0.69 G returning atomics of the one-pass partition are what its kernel
+// waits for (27 G/s device-wide whatever their flavour: tools/probe/atomics.hip; the emission alone takes the kernel's whole time:
+// tools/probe/partition2.hip).  Here the records leave the scan kernel in read order -- a workgroup reserves its block with one atomic --
+// next to a u32 bucket id each; what is sorted is (bucket, position): 8 bytes instead of 32 per record, by a radix sort over the
+// ceil(log2 NB) key bits; the count kernel fetches a bucket's records through the sorted positions (LDS-DMA takes per-lane addresses).
+namespace {
+__global__ void __launch_bounds__(256) seg_from_sorted_kernel(const uint32_t* __restrict__ key, uint32_t n, uint32_t NB, uint64_t* __restrict__ seg) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k = key[i];
+    if (k >= NB) return;
+    if (i == 0 || key[i - 1] != k) seg[k] = i;
+    if (i + 1 == n || key[i + 1] != k) seg[(uint64_t)NB + k] = (uint64_t)i + 1;
+}
+int partition_dense(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_reads* in, const uint16_t* good_len, uint32_t NB, double est_super, bool grouped,
+                    uint32_t* status, snk_partition* out, char* err, size_t errcap, const unsigned long long* d_plan, unsigned long long* h_plan,
+                    const snk_fused_trim* ft) {
+    int rc;
+    const uint64_t n_reads = in->n_reads;
+    uint64_t dcap = (uint64_t)(est_super * 1.12) + (1u << 20);
+    if (ctx->last_ovf_nb == 0xD0000000u && ctx->last_ovf_reads == n_reads && ctx->last_dense) dcap = ctx->last_dense + ctx->last_dense / 64 + 65536;   // what the last call on these reads needed
+    uint64_t* seg = nullptr;
+    unsigned long long* d_cur = nullptr;
+    unsigned long long* d_fplan = nullptr;
+    std::vector<unsigned long long> h_fplan;
+    {
+        void* q;
+        if ((rc = snk_ctx_alloc(ctx, 4ull * NB * 8 + 64, &q, err, errcap))) return rc; seg = (uint64_t*)q;
+        if ((rc = snk_ctx_alloc(ctx, 64, &q, err, errcap))) return rc; d_cur = (unsigned long long*)q;
+        if (ft) {
+            if (!h_plan) return snk_fail(SNK_E_ARG, err, errcap, "fused trim: the caller takes the instance count from h_plan");
+            if ((rc = snk_ctx_alloc(ctx, 2ull * SNK_MSP_PLAN_SLOTS * 8, &q, err, errcap))) return rc; d_fplan = (unsigned long long*)q;
+            h_fplan.resize(2 * SNK_MSP_PLAN_SLOTS);
+        }
+    }
+    snk_phase_timer kt(st);
+    void* records = nullptr;
+    uint32_t* bkt = nullptr;
+    unsigned long long h_n = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (dcap >= (1ull << 32)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "dense partition: more than 2^32 supermer records");
+        void* q;
+        if ((rc = snk_ctx_alloc(ctx, dcap * 32 + 64, &records, err, errcap))) return rc;
+        if ((rc = snk_ctx_alloc(ctx, dcap * 4 + 64, &q, err, errcap))) return rc; bkt = (uint32_t*)q;
+        SNK_HIP_TRY(hipMemsetAsync(d_cur, 0, 8, st));
+        snk_msp_args ma;
+        memset(&ma, 0, sizeof ma);
+        ma.rows = (const uint32_t*)in->rows; ma.row_words = in->row_words; ma.read_len = in->read_len; ma.good_len = good_len; ma.bc = (const int32_t*)in->bc;
+        ma.ign_bc_below = in->ign_bc_below; ma.read_index_base = in->read_index_base; ma.n_reads = n_reads; ma.NB = NB;
+        ma.group = grouped ? (const uint32_t*)in->group : nullptr;
+        ma.records = (uint4*)records;
+        ma.dense_bkt = bkt; ma.dense_cursor = d_cur; ma.dense_cap = dcap;
+        ma.dbg = env_u32("SNK_MSP_DBG", 0);
+        if (ft) {
+            ma.good_len = ft->good_out; ma.quals = (const uint8_t*)ft->quals; ma.qstride = ft->qstride; ma.min_qual = ft->min_qual;
+            ma.lens = (const uint16_t*)ft->lens; ma.good_out = ft->good_out; ma.plan = d_fplan;
+            SNK_HIP_TRY(hipMemsetAsync(d_fplan, 0, 2ull * SNK_MSP_PLAN_SLOTS * 8, st));
+        }
+        kt.n = 0;
+        kt.mark();  // 0
+        if ((rc = snk_launch_msp(K, st, ma, err, errcap))) return rc;
+        kt.mark();  // 1
+        SNK_HIP_TRY(hipMemcpyAsync(&h_n, d_cur, 8, hipMemcpyDeviceToHost, st));
+        if (d_plan && h_plan && !ft) SNK_HIP_TRY(hipMemcpyAsync(h_plan, d_plan, 16, hipMemcpyDeviceToHost, st));
+        if (ft) SNK_HIP_TRY(hipMemcpyAsync(h_fplan.data(), d_fplan, h_fplan.size() * 8, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(snk_sync(st));
+        if (ft) {
+            h_plan[0] = h_plan[1] = 0;
+            for (int q2 = 0; q2 < SNK_MSP_PLAN_SLOTS; ++q2) { h_plan[0] += h_fplan[2 * q2]; h_plan[1] += h_fplan[2 * q2 + 1]; }
+        }
+        ctx->last_ovf_nb = 0xD0000000u; ctx->last_ovf_reads = n_reads; ctx->last_dense = h_n;
+        if (h_n <= dcap) break;
+        if (attempt == 1) return snk_fail(SNK_E_INTERNAL, err, errcap, "dense partition: record array too small (%llu > %llu)", h_n, (unsigned long long)dcap);
+        snk_ctx_release_block(ctx, records);
+        snk_ctx_release_block(ctx, bkt);
+        dcap = h_n + 65536;
+    }
+    // ---- (bucket, position) sorted by bucket; the bounds of every bucket in the sorted list
+    uint32_t *bkt2 = nullptr, *gidx = nullptr;
+    const size_t n = (size_t)h_n;
+    {
+        void* q;
+        if ((rc = snk_ctx_alloc(ctx, n * 4 + 64, &q, err, errcap))) return rc; bkt2 = (uint32_t*)q;
+        if ((rc = snk_ctx_alloc(ctx, n * 4 + 64, &q, err, errcap))) return rc; gidx = (uint32_t*)q;
+    }
+    SNK_HIP_TRY(hipMemsetAsync(seg, 0, 4ull * NB * 8, st));
+    if (n) {
+        unsigned bits = 1;
+        while (bits < 32 && (1ull << bits) < NB) ++bits;
+        rocprim::counting_iterator<uint32_t> pos(0);
+        size_t tb = 0;
+        SNK_HIP_TRY(rocprim::radix_sort_pairs((void*)nullptr, tb, bkt, bkt2, pos, gidx, n, 0u, bits, st));
+        void* tmp;
+        if ((rc = snk_ctx_alloc(ctx, tb + 64, &tmp, err, errcap))) return rc;
+        SNK_HIP_TRY(rocprim::radix_sort_pairs(tmp, tb, bkt, bkt2, pos, gidx, n, 0u, bits, st));
+        hipLaunchKernelGGL(seg_from_sorted_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bkt2, (uint32_t)n, NB, seg);
+        SNK_HIP_TRY(hipGetLastError());
+        snk_ctx_release_block(ctx, tmp);
+    }
+    kt.mark();  // 2
+    snk_ctx_release_block(ctx, bkt);
+    snk_ctx_release_block(ctx, bkt2);
+    (void)status;
+    out->NB = NB;
+    out->cap = 0;
+    out->nseg = 1;
+    out->n_overflow = 0;
+    out->n_supermers = h_n;
+    out->records = records;
+    out->cursor = nullptr;
+    out->seg = seg;
+    out->gidx = gidx;
+    out->kernel_ms = kt.ms(0, 1);
+    out->sort_ms = kt.ms(1, 2);
+    return SNK_OK;
+}
+}  // namespace
+
 int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_reads* in, const uint16_t* good_len, uint32_t NB,
                         unsigned long long n_inst, unsigned long long n_live, bool grouped, uint32_t* status, snk_partition* out,
-                        char* err, size_t errcap, const unsigned long long* d_plan, unsigned long long* h_plan, const snk_fused_trim* ft) {
+                        char* err, size_t errcap, const unsigned long long* d_plan, unsigned long long* h_plan, const snk_fused_trim* ft, bool allow_dense) {
     memset(out, 0, sizeof *out);
     const uint64_t n_reads = in->n_reads;
     const uint32_t Wm = K - SNK_M + 1;
@@ -377,6 +497,8 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
             }
         }
     }
+    if (allow_dense && est_super * 1.25 + 2e6 < 4.0e9 && env_u32("SNK_MSP_DENSE", 0))
+        return partition_dense(ctx, st, K, in, good_len, NB, est_super, grouped, status, out, err, errcap, d_plan, h_plan, ft);
     if (cap64 * NB >= (1ull << 40) || cap64 >= (1ull << 31)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "bucket capacity out of range");
     const uint32_t cap = (uint32_t)cap64;
     uint64_t ovf_cap = (uint64_t)(est_super / 16) + 65536;
