@@ -96,8 +96,16 @@ typedef struct snk_synth_params {
     uint32_t unbarcoded_ppm;   /* pairs with bc=0 (20000) */
     uint32_t lowq_tail_ppm;    /* reads with a Q2 tail (50000) */
     uint32_t tail_max;         /* tail length uniform in [0,tail_max] (40) */
-    uint32_t err_cdf[4];       /* filled by snk_synth_default: P(#errors<=j)*2^32 for j=0..3 */
+    uint32_t err_cdf[4];       /* filled by snk_synth_default: P(#errors<=j)*2^32 for j=0..3 (snk_synth_set_errors refills it) */
+    uint32_t repeat_mode;      /* 0: i.i.d. uniform genome.  Bit mask (15 = all) of a repeat-rich genome, every structure a pure function of the
+                                  position (csrc/snk_synth.h): bit 0 four interspersed families (a 300-bp element in 60 % of the 4-kb
+                                  blocks, 1-3 % divergence from its consensus: ~10^4 copies each at the bench's genome size), bit 1 5-kb
+                                  segmental duplications (exact copies, one in four odd 64-kb superblocks), bit 2 short tandem repeats
+                                  (unit 1-6 bp, 40-200 bp, 3 % of the blocks), bit 3 poly-A runs (20-80 bp, 2 %) */
+    uint32_t reserved[3];
 } snk_synth_params;
+/* substitution rate of the model: sub_ppm and the error-count table that goes with it */
+void snk_synth_set_errors(snk_synth_params* sp, uint32_t sub_ppm);
 void snk_synth_default(snk_synth_params* sp, uint64_t n_reads, uint64_t seed, int error_free);
 /* host generator: reads [first, first+n).  rows: n*row_words u32; quals: n*qstride bytes (raw phred);
  * bc: n int32.  Any output pointer may be NULL. */
@@ -175,6 +183,22 @@ typedef struct snk_dev_result {
 int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const snk_params* p, snk_dev_result* out, void* stream,
                         char* err, size_t errcap);
 int snk_dev_download(snk_ctx* ctx, const void* d_src, void* h_dst, size_t bytes, void* stream);
+
+/* Streamed input: the same job with its reads arriving slab by slab (as a FASTH decoder delivers them).  The reference streams its
+ * FASTQ chunks through the partitioner (lib/tada/src/cmd_msp.rs:55-69) and re-scans in passes when the keys do not fit
+ * (MapReduceEngine.h:452-468); here every slab is partitioned into the job's minimiser buckets as it arrives -- the launch is
+ * asynchronous, so the decode / upload of the next slab overlaps it -- and the slab's buffers may be reused once the stream has passed
+ * the call (an event, or a synchronise).  The job's reads are never resident as a whole.
+ *   begin : total_reads_ub = an upper bound of the job's reads (it sizes the bucket slots; reads beyond it are refused),
+ *           has_bc = the slabs carry barcode ids (all of them or none).  Per-group graphs (SNK_F_GROUPED) are not streamed.
+ *   append: slab->read_index_base = global index of its first read (ign_bc_below); 0 = numbered in arrival order.
+ *   finish: count + graph over everything appended; result as snk_dev_count_graph's (good_len covers the reads in arrival order),
+ *           bit-identical to one resident call on the concatenated slabs.
+ * A job that cannot look at its first buckets and partition again (its slabs are gone): error-rich data without the context's
+ * history of an earlier job of the same size are counted in hash-split sub-passes -- slower, same result. */
+int snk_dev_stream_begin(snk_ctx* ctx, const snk_params* p, uint32_t read_len, uint64_t total_reads_ub, int has_bc, void* stream, char* err, size_t errcap);
+int snk_dev_stream_append(snk_ctx* ctx, const snk_dev_reads* slab, void* stream, char* err, size_t errcap);
+int snk_dev_stream_finish(snk_ctx* ctx, snk_dev_result* out, void* stream, char* err, size_t errcap);
 
 /* ---- minimiser-sharded multi-GPU path ------------------------------------------------
  * One process per GPU.  The k-mer space is cut into NB_total minimiser buckets; rank r owns buckets
@@ -410,6 +434,13 @@ int snk_write_bv(const char* path, uint64_t n_unitigs, const uint64_t* unitig_of
                  char* err, size_t errcap);
 int snk_read_bv(const char* path, uint64_t* n_unitigs, uint64_t** unitig_off, uint8_t** unitig_bases, char* err,
                 size_t errcap);   /* outputs malloc'ed; free() them */
+
+/* a13 on the device: the bytes of that file from the device-resident unitigs of snk_dev_count_graph -- BVComp order (length
+ * descending, then lexicographic: HBVFromEdges.cc:106-111), 2-bit packing and the "BINWRITE" header all in HBM; *d_image is context
+ * memory (valid until the next top-level call), ready for one download or a GPU-direct write.  by_first_kmer: the unitigs are ordered
+ * by their first K bases (how snk_dev_count_graph leaves them): one stable sort by length does. */
+int snk_dev_bv_image(snk_ctx* ctx, uint32_t K, uint64_t n_unitigs, const void* d_unitig_off, const void* d_unitig_bases, int by_first_kmer,
+                     const void** d_image, uint64_t* image_bytes, void* stream, char* err, size_t errcap);
 
 /* a14: buildHBVFromEdges (lib/assembly/src/paths/long/HBVFromEdges.cc:244-296): vertices = distinct (K-1)-mer
  * unitig ends, HBV edges = every unitig and its reverse complement (palindromes once), ids assigned by the

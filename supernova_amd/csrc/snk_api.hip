@@ -173,6 +173,7 @@ extern "C" void snk_ctx_destroy(snk_ctx* ctx) {
     if (ctx->shard) snk_shard_state_free(ctx->shard);
     if (ctx->host_io && ctx->host_io_free) ctx->host_io_free(ctx->host_io);
     if (ctx->shard_host && ctx->shard_host_free) ctx->shard_host_free(ctx->shard_host);
+    if (ctx->stream_job && ctx->stream_job_free) ctx->stream_job_free(ctx->stream_job);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -194,7 +195,11 @@ extern "C" void snk_synth_default(snk_synth_params* sp, uint64_t n_reads, uint64
     sp->unbarcoded_ppm = 20000;
     sp->lowq_tail_ppm = error_free ? 0 : 50000;
     sp->tail_max = 40;
-    // Poisson(lambda = read_len*sub_ppm/1e6) cumulative, scaled to 2^32
+    snk_synth_set_errors(sp, sp->sub_ppm);
+}
+extern "C" void snk_synth_set_errors(snk_synth_params* sp, uint32_t sub_ppm) {
+    // Poisson(lambda = read_len*sub_ppm/1e6) cumulative, scaled to 2^32 (a read carries at most four substitutions)
+    sp->sub_ppm = sub_ppm;
     double lam = sp->read_len * (double)sp->sub_ppm / 1e6, term = exp(-lam), cum = 0;
     for (int j = 0; j < 4; ++j) {
         cum += term;

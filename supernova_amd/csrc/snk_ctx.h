@@ -38,6 +38,8 @@ struct snk_ctx {
     void* shard = nullptr;      // snk_shard_state (snk_dist.hip)
     void* host_io = nullptr;    // pinned staging + device input buffers of the host-pointer entry point (snk_host.hip)
     void (*host_io_free)(void*) = nullptr;
+    void* stream_job = nullptr; // the open streamed job of snk_dev_stream_* (snk_pipeline.hip)
+    void (*stream_job_free)(void*) = nullptr;
     void* shard_host = nullptr; // pinned staging, exchange stream and events of snk_shard_step (snk_shard_step.hip)
     void (*shard_host_free)(void*) = nullptr;
 };

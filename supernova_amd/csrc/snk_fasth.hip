@@ -442,10 +442,12 @@ extern "C" int snk_dev_ingest_fasth(snk_ctx* ctx, const char* const* paths, uint
     }
     ING_RC(alloc_arrays(A, cap, row_words, qstride, ix != nullptr, err, errcap));
     int slot = 0;
-    double wait_s = 0;
+    double wait_s = 0, t_pend = 0, t_slot = 0, t_issue = 0;      // SNK_INGEST_TRACE=1: where the consumer thread's time goes
+    const bool trace = getenv("SNK_INGEST_TRACE") && *getenv("SNK_INGEST_TRACE") == '1';
     const double t_ready = now_s();          // decode threads running, page-locked batches and device arrays allocated
     for (;;) {
         // hand back the batches whose copies are done (never more than two outstanding: the workers need them)
+        const double p0 = now_s();
         while (!pending.empty() && (pending.size() > 2 || hipEventQuery(pending.front().ev) == hipSuccess)) {
             ING_TRY(hipEventSynchronize(pending.front().ev));
             (void)hipEventDestroy(pending.front().ev);
@@ -454,6 +456,7 @@ extern "C" int snk_dev_ingest_fasth(snk_ctx* ctx, const char* const* paths, uint
         }
         snk_fasth_batch b;
         const double w0 = now_s();
+        t_pend += w0 - p0;
         ING_RC(snk_fasth_next(fs, &b, err, errcap));
         wait_s += now_s() - w0;
         if (b.n_pairs == 0) break;
@@ -471,7 +474,10 @@ extern "C" int snk_dev_ingest_fasth(snk_ctx* ctx, const char* const* paths, uint
             A.release();
             A = N;
         }
+        const double s0 = now_s();
         if (st_busy[slot]) { ING_TRY(hipEventSynchronize(st_ev[slot])); st_busy[slot] = false; }
+        const double s1 = now_s();
+        t_slot += s1 - s0;
         ING_TRY(hipMemcpyAsync(st_ascii[slot], b.ascii, nr * (uint64_t)stride, hipMemcpyHostToDevice, cs));
         ING_TRY(hipMemcpyAsync(A.quals + n_reads * (uint64_t)qstride, b.quals, nr * (uint64_t)stride, hipMemcpyHostToDevice, cs));
         ING_TRY(hipMemcpyAsync(A.lens + n_reads, b.lens, nr * 2ull, hipMemcpyHostToDevice, cs));
@@ -493,8 +499,12 @@ extern "C" int snk_dev_ingest_fasth(snk_ctx* ctx, const char* const* paths, uint
         n_reads += nr;
         text += b.text_bytes;
         if (b.max_len > max_len) max_len = b.max_len;
+        t_issue += now_s() - s1;
     }
+    const double t_loop = now_s();
     ING_TRY(hipStreamSynchronize(cs));
+    if (trace) fprintf(stderr, "[snk ingest] setup %.3f s | loop %.3f s: wait for decode %.3f, wait for copies (batch hand-back) %.3f, wait for a staging slot %.3f, issue %.3f | drain %.3f s | %zu batches\n",
+                       t_ready - t0, t_loop - t_ready, wait_s, t_pend, t_slot, t_issue, now_s() - t_loop, pieces.size());
     while (!pending.empty()) { (void)hipEventDestroy(pending.front().ev); snk_fasth_release(fs, &pending.front().b); pending.pop_front(); }
     // ---- file-major order
     std::vector<uint64_t> fbase(n_files + 1, 0);

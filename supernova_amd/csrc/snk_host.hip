@@ -183,10 +183,11 @@ __global__ void __launch_bounds__(256) bv_lenkey_of_kernel(const uint64_t* __res
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < U) key[i] = ~(off[idx1[i] + 1] - off[idx1[i]]);
 }
-int unitigs_to_host(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t U, const uint64_t* d_off, const uint8_t* d_bases, bool by_first_kmer, bool want_image,
-                    snk_result* out, char* err, size_t errcap) {
+// device part: BVComp order (HBVFromEdges.cc:106-111), sizes, offsets and the gathered bytes -- plain bases, or the .bv payload
+// (u32 length + ceil(len/4) bytes per unitig; header_bytes are left free in front of it for the file header)
+int unitigs_bv_device(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t U, const uint64_t* d_off, const uint8_t* d_bases, bool by_first_kmer, bool want_image,
+                      uint32_t header_bytes, uint8_t** d_out_p, uint64_t** d_noff_p, uint64_t* total_p, char* err, size_t errcap) {
     int rc;
-    out->n_unitigs = U;
     uint64_t *key, *key2, *sz, *noff;
     uint32_t *idx, *order;
     if ((rc = arena(ctx, U + 1, &key, err, errcap)) || (rc = arena(ctx, U + 1, &key2, err, errcap)) || (rc = arena(ctx, U + 1, &idx, err, errcap)) ||
@@ -219,10 +220,24 @@ int unitigs_to_host(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t U, const 
         SNK_HIP_TRY(snk_sync(st));
     }
     uint8_t* d_out;
-    if ((rc = arena(ctx, total + 16, &d_out, err, errcap))) return rc;
+    if ((rc = arena(ctx, header_bytes + total + 16, &d_out, err, errcap))) return rc;
     if (total) hipLaunchKernelGGL(bv_gather_kernel, dim3((unsigned)((total + 4095) / 4096)), dim3(256), 0, st, d_off, d_bases, order, noff, U, total,
-                                  want_image ? 1 : 0, d_out);
+                                  want_image ? 1 : 0, d_out + header_bytes);
     SNK_HIP_TRY(hipGetLastError());
+    *d_out_p = d_out;
+    *d_noff_p = noff;
+    *total_p = total;
+    return SNK_OK;
+}
+
+int unitigs_to_host(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t U, const uint64_t* d_off, const uint8_t* d_bases, bool by_first_kmer, bool want_image,
+                    snk_result* out, char* err, size_t errcap) {
+    int rc;
+    out->n_unitigs = U;
+    uint8_t* d_out = nullptr;
+    uint64_t* noff = nullptr;
+    uint64_t total = 0;
+    if ((rc = unitigs_bv_device(ctx, st, K, U, d_off, d_bases, by_first_kmer, want_image, 0, &d_out, &noff, &total, err, errcap))) return rc;
     if (want_image) {
         out->bv_bytes = 16 + total;
         out->bv_image = (uint8_t*)malloc(out->bv_bytes);
@@ -239,6 +254,12 @@ int unitigs_to_host(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t U, const 
         if (total) SNK_HIP_TRY(hipMemcpyAsync(out->unitig_bases, d_out, total, hipMemcpyDeviceToHost, st));
     }
     return SNK_OK;
+}
+
+__global__ void bv_header_kernel(uint8_t* out, uint64_t U) {
+    const char m[8] = {'B', 'I', 'N', 'W', 'R', 'I', 'T', 'E'};
+    if (threadIdx.x < 8) out[threadIdx.x] = (uint8_t)m[threadIdx.x];
+    else if (threadIdx.x < 16) out[threadIdx.x] = (uint8_t)(U >> (8 * (threadIdx.x - 8)));
 }
 
 int count_graph_impl(snk_ctx* ctx, const snk_reads* in, const snk_params* p, snk_result* out, char* err, size_t errcap) {
@@ -362,6 +383,26 @@ extern "C" int snk_count_graph(snk_ctx* ctx, const snk_reads* in, const snk_para
         if (out) snk_free(out);
     }
     return rc;
+}
+
+extern "C" int snk_dev_bv_image(snk_ctx* ctx, uint32_t K, uint64_t n_unitigs, const void* d_unitig_off, const void* d_unitig_bases, int by_first_kmer,
+                                const void** d_image, uint64_t* image_bytes, void* stream, char* err, size_t errcap) {
+    if (!ctx || !d_image || !image_bytes || (n_unitigs && (!d_unitig_off || !d_unitig_bases))) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_bv_image: NULL argument");
+    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    SNK_GUARD(
+        uint8_t* d_out = nullptr;
+        uint64_t* noff = nullptr;
+        uint64_t total = 0;
+        int rc = unitigs_bv_device(ctx, st, K, n_unitigs, (const uint64_t*)d_unitig_off, (const uint8_t*)d_unitig_bases, by_first_kmer != 0, true, 16, &d_out, &noff, &total,
+                                   err, errcap);
+        if (rc) return rc;
+        hipLaunchKernelGGL(bv_header_kernel, dim3(1), dim3(64), 0, st, d_out, n_unitigs);
+        SNK_HIP_TRY(hipGetLastError());
+        *d_image = d_out;
+        *image_bytes = 16 + total;
+        return SNK_OK;
+    )
 }
 
 extern "C" int snk_host_alloc_pinned(size_t bytes, void** out, char* err, size_t errcap) {

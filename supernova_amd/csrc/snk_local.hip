@@ -50,6 +50,18 @@ struct chunk_t {
     uint32_t bucket, n, lg, id;
     uint64_t base;
 };
+// The count kernel leaves its survivors in per-workgroup regions (region r = bucket % n_regions holds region_cursor[r] entries at
+// r * region_cap).  The prune reads every chunk exactly once anyway: it takes the chunk from region space and writes the keys to their
+// dense positions itself -- the separate region compaction (24 B read + 24 B written per k-mer, 2.9 ms at the bench) is gone, the
+// (count << 8 | context) words never exist densely (they leave the prune as counts[] and ctx[]).  keys_r == NULL: the table is dense.
+struct bl_regions {
+    const snk_u128* keys_r;
+    const uint64_t* vals_r;
+    uint64_t region_cap;
+    const unsigned long long* region_off;
+    uint32_t n_regions;
+    snk_u128* keys_dense;
+};
 // sharded runs: this rank owns global buckets [bucket_base, bucket_base + NBl); NBl == 0 -> one GPU owns everything
 struct bl_shard {
     uint32_t bucket_base, NBl, me;
@@ -97,7 +109,7 @@ __device__ __forceinline__ uint32_t oriented_base(snk_kmer k, bool rc, int idx) 
 
 // ---------------------------------------------------------------------------------------------- L1: local prune
 template <int K, int CAP, int T, bool BIG, bool GR>
-__device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __restrict__ desc, uint32_t NB, bl_shard sh,
+__device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __restrict__ desc, uint32_t NB, bl_shard sh, const bl_regions& rg,
                                                      const snk_u128* __restrict__ keys, const uint64_t* __restrict__ vals,
                                                      uint32_t do_prune, uint8_t* __restrict__ ctx_out,
                                                      uint32_t* __restrict__ count_out, uint8_t* __restrict__ pend_out,
@@ -120,6 +132,13 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
         return;
     }
     const uint32_t n = ch.n;
+    // where the chunk lies: dense, or still in its count region (then this kernel is what compacts it)
+    uint64_t src = ch.base;
+    if (rg.keys_r) {
+        const uint32_t r = ch.bucket % rg.n_regions;
+        src = (uint64_t)r * rg.region_cap + (ch.base - rg.region_off[r]);
+        keys = rg.keys_r; vals = rg.vals_r;
+    }
     __syncthreads();      // the previous chunk of this workgroup is done with the LDS arrays
     for (int s = tid; s < HT; s += T) ht[s] = 0;
     if (tid == 0) bcnt = 0;
@@ -131,8 +150,8 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
         const uint32_t i = tid + q * T;
         myv[q] = 0;
         if (i < n) {
-            kq[q] = load_key(keys, ch.base + i);
-            myv[q] = vals[ch.base + i];
+            kq[q] = load_key(keys, src + i);
+            myv[q] = vals[src + i];
         }
     }
 #pragma unroll
@@ -141,6 +160,7 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
         if (i < n) {
             khi[i] = kq[q].hi;
             klo[i] = (klo_w)(kq[q].lo >> KLS);
+            if (rg.keys_r) { uint64_t* d = reinterpret_cast<uint64_t*>(rg.keys_dense + ch.base + i); d[0] = kq[q].lo; d[1] = kq[q].hi; }
         }
     }
     __syncthreads();
@@ -305,7 +325,7 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
     if (tid == 0) nbnd[c] = bcnt;
 }
 template <int K, int CAP, int T, bool BIG, bool GR>
-__global__ void __launch_bounds__(T) bl_prune_kernel(const uint4* __restrict__ desc, uint32_t NB, bl_shard sh, const uint32_t* __restrict__ biglist_in,
+__global__ void __launch_bounds__(T) bl_prune_kernel(const uint4* __restrict__ desc, uint32_t NB, bl_shard sh, bl_regions rg, const uint32_t* __restrict__ biglist_in,
                                                      uint32_t nchunks, uint32_t cpw,
                                                      const snk_u128* __restrict__ keys, const uint64_t* __restrict__ vals,
                                                      uint32_t do_prune, uint8_t* __restrict__ ctx_out,
@@ -317,13 +337,13 @@ __global__ void __launch_bounds__(T) bl_prune_kernel(const uint4* __restrict__ d
         // the list's length is still on the device (no read-back between the two prune launches): a fixed grid strides over it
         const uint32_t nb = *n_dev;
         for (uint32_t w = blockIdx.x; w < nb; w += gridDim.x)
-            bl_prune_chunk<K, CAP, T, BIG, GR>(biglist_in[w], desc, NB, sh, keys, vals, do_prune, ctx_out, count_out, pend_out, nbr_out, nbnd, biglist, nbig, gindex, gmask);
+            bl_prune_chunk<K, CAP, T, BIG, GR>(biglist_in[w], desc, NB, sh, rg, keys, vals, do_prune, ctx_out, count_out, pend_out, nbr_out, nbnd, biglist, nbig, gindex, gmask);
         return;
     }
     for (uint32_t r = 0; r < cpw; ++r) {
         const uint32_t w = blockIdx.x * cpw + r;
         if (w >= nchunks) return;
-        bl_prune_chunk<K, CAP, T, BIG, GR>(BIG ? biglist_in[w] : w, desc, NB, sh, keys, vals, do_prune, ctx_out, count_out, pend_out, nbr_out,
+        bl_prune_chunk<K, CAP, T, BIG, GR>(BIG ? biglist_in[w] : w, desc, NB, sh, rg, keys, vals, do_prune, ctx_out, count_out, pend_out, nbr_out,
                                        nbnd, biglist, nbig, gindex, gmask);
     }
 }
@@ -883,7 +903,10 @@ static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* er
         G_ALLOC(index0, unsigned long long, tg0);
         SNK_HIP_TRY(hipMemsetAsync(index0, 0, tg0 * 8, st));
     }
-    hipLaunchKernelGGL((bl_prune_kernel<K, SCAP, ST, false, GR>), dim3((nchunks + cpw - 1) / cpw), dim3(ST), 0, st, (const uint4*)B->desc, NBh, sh,
+    bl_regions rg;
+    rg.keys_r = tab->keys_r; rg.vals_r = tab->vals_r; rg.region_cap = tab->region_cap; rg.region_off = tab->region_off; rg.n_regions = tab->n_regions;
+    rg.keys_dense = const_cast<snk_u128*>(tab->keys);
+    hipLaunchKernelGGL((bl_prune_kernel<K, SCAP, ST, false, GR>), dim3((nchunks + cpw - 1) / cpw), dim3(ST), 0, st, (const uint4*)B->desc, NBh, sh, rg,
                        (const uint32_t*)nullptr, nchunks, cpw, tab->keys, tab->vals, B->do_prune, B->ctx, B->counts, B->pend, B->nbr, nbnd,
                        B->biglist, ctr, (const uint32_t*)nullptr, index0, tg0 - 1);
     SNK_HIP_TRY(hipGetLastError());
@@ -891,10 +914,14 @@ static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* er
     // device until the read-back below -- the big variant runs a fixed grid that strides over the list
     uint32_t h_nbig = 0;
     SNK_HIP_TRY(hipMemcpyAsync(ctr + 1, ctr, 4, hipMemcpyDeviceToDevice, st));       // (ctr[0] is the small kernel's list cursor)
-    hipLaunchKernelGGL((bl_prune_kernel<K, BCAP, BT, true, GR>), dim3(2048), dim3(BT), 0, st, (const uint4*)B->desc, NBh, sh,
+    hipLaunchKernelGGL((bl_prune_kernel<K, BCAP, BT, true, GR>), dim3(2048), dim3(BT), 0, st, (const uint4*)B->desc, NBh, sh, rg,
                        (const uint32_t*)B->biglist, 0u, 1u, tab->keys, tab->vals, B->do_prune, B->ctx, B->counts, B->pend, B->nbr,
                        nbnd, B->biglist, ctr + 2, (const uint32_t*)(ctr + 1), index0, tg0 - 1);
     SNK_HIP_TRY(hipGetLastError());
+    if (tab->keys_r) {       // the region-partitioned copy is dead (stream order): later stages may reuse it
+        snk_ctx_release_block(ctx, tab->keys_r);
+        snk_ctx_release_block(ctx, tab->vals_r);
+    }
     unsigned long long* d_sum;
     G_ALLOC(d_sum, unsigned long long, 2);
     {

@@ -38,6 +38,12 @@ struct snk_table {
     const uint32_t* chunk_base;
     const uint4* extra;
     const unsigned long long* region_off;
+    // deferred compaction (chunk order only): keys points at dense, still UNWRITTEN memory and vals is NULL; the survivors are where the
+    // count kernel put them -- region r at [r * region_cap, + region_cursor[r]) of keys_r / vals_r -- until the bucket-local prune,
+    // which reads every chunk once anyway, writes the keys densely (snk_local.hip).  keys_r == NULL: the table is dense.
+    const snk_u128* keys_r;
+    const uint64_t* vals_r;
+    uint64_t region_cap;
 };
 
 uint32_t snk_env_u32(const char* name, uint32_t dflt);
@@ -63,7 +69,8 @@ uint32_t snk_count_limit(uint32_t K, uint32_t grouped);      // distinct k-mers 
 int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* records, const uint64_t* seg_beg,
                           const uint64_t* seg_end, uint32_t seg_stride, uint32_t nseg, uint32_t NB, uint32_t min_freq, uint32_t bc_mode, uint32_t grouped, uint64_t n_inst_hint,
                           uint32_t* status, bool want_sort, snk_table* out, char* err, size_t errcap,
-                          const snk_count_ranges* ranges = nullptr, snk_count_pilot* pilot = nullptr, const uint32_t* gidx = nullptr);
+                          const snk_count_ranges* ranges = nullptr, snk_count_pilot* pilot = nullptr, const uint32_t* gidx = nullptr,
+                          bool defer_compact = false);
 
 // ---- minimiser partition in one pass (fixed bucket capacity + overflow segment)
 struct snk_partition {
@@ -92,6 +99,23 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
                         unsigned long long n_inst, unsigned long long n_live, bool grouped, uint32_t* status, snk_partition* out,
                         char* err, size_t errcap, const unsigned long long* d_plan = nullptr, unsigned long long* h_plan = nullptr,
                         const snk_fused_trim* ft = nullptr, bool allow_dense = false);
+// the same pass as a job that takes its reads slab by slab (snk_dev_stream_*)
+struct snk_partition_job {
+    uint32_t K, NB, cap, n_slabs;
+    uint64_t ovf_cap, n_reads;
+    bool grouped;
+    uint32_t* cursor;
+    uint64_t* seg;
+    unsigned long long *d_total, *d_plan;     // d_plan: SNK_MSP_PLAN_SLOTS x (instances, contributing reads), summed at close
+    void* records;
+    uint32_t* ovf_bucket;
+    uint32_t* status;
+};
+int snk_partition_open(snk_ctx* ctx, hipStream_t st, uint32_t K, uint32_t NB, unsigned long long n_inst_ub, unsigned long long n_live_ub, bool grouped,
+                       uint32_t* status, snk_partition_job* J, char* err, size_t errcap);
+int snk_partition_add(snk_ctx* ctx, hipStream_t st, snk_partition_job* J, const snk_dev_reads* in, const uint16_t* good_len, const snk_fused_trim* ft, char* err,
+                      size_t errcap);
+int snk_partition_close(snk_ctx* ctx, hipStream_t st, snk_partition_job* J, snk_partition* out, unsigned long long h_plan[2], char* err, size_t errcap);
 // sharded runs: the buckets' records copied to exact offsets (u32 record index per bucket) of a compact buffer
 int snk_stage_partition_compact(snk_ctx* ctx, hipStream_t st, const snk_partition* part, const uint32_t* d_offsets, void* d_out, char* err, size_t errcap);
 int snk_stage_partition_compact_remote(snk_ctx* ctx, hipStream_t st, const snk_partition* part, const uint32_t* d_offsets, void* d_out,

@@ -26,7 +26,8 @@ uint32_t snk_env_u32(const char* name, uint32_t dflt) {
 int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* records, const uint64_t* seg_beg,
                           const uint64_t* seg_end, uint32_t seg_stride, uint32_t nseg, uint32_t NB, uint32_t min_freq, uint32_t bc_mode, uint32_t grouped, uint64_t n_inst_hint,
                           uint32_t* status, bool want_sort, snk_table* out, char* err, size_t errcap, const snk_count_ranges* ranges, snk_count_pilot* pilot,
-                          const uint32_t* gidx) {
+                          const uint32_t* gidx, bool defer_compact) {
+    defer_compact = defer_compact && !want_sort && env_u32("SNK_DEFER_COMPACT", 1) != 0;
     int rc;
     snk_phase_timer tm(st), kt(st);
     tm.mark();
@@ -210,9 +211,17 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
         void* q;
         if ((rc = snk_ctx_alloc(ctx, (n_kmers + 1) * 16, &q, err, errcap))) return rc; keys_a = (snk_u128*)q;
         if ((rc = snk_ctx_alloc(ctx, (n_kmers + 1) * 8, &q, err, errcap))) return rc; vals_a = (uint64_t*)q;
-        if ((rc = snk_launch_compact_regions(st, keys_r, vals_r, region_cap, n_regions, rcur, roff, keys_a, vals_a, err, errcap))) return rc;
-        snk_ctx_release_block(ctx, keys_r);      // the region-partitioned copy is dead: later stages may reuse it
-        snk_ctx_release_block(ctx, vals_r);
+        out->keys_r = nullptr; out->vals_r = nullptr; out->region_cap = region_cap;
+        if (defer_compact) {
+            // the bucket-local prune compacts while it reads (snk_local.hip); the dense value words are never made
+            snk_ctx_release_block(ctx, vals_a);
+            vals_a = nullptr;
+            out->keys_r = keys_r; out->vals_r = vals_r;
+        } else {
+            if ((rc = snk_launch_compact_regions(st, keys_r, vals_r, region_cap, n_regions, rcur, roff, keys_a, vals_a, err, errcap))) return rc;
+            snk_ctx_release_block(ctx, keys_r);      // the region-partitioned copy is dead: later stages may reuse it
+            snk_ctx_release_block(ctx, vals_r);
+        }
     }
     out->buckets_split = h_status[2];
     out->max_slots_used = h_status[3];
@@ -269,6 +278,10 @@ __global__ void __launch_bounds__(256) seg0_kernel(const uint32_t* __restrict__ 
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
     // (64 counters: the grid's 32 k waves on ONE address were 0.3 of this kernel's 0.4 ms)
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(&total[(blockIdx.x * 4u + (threadIdx.x >> 6)) & 63u], v);
+}
+// (instances, contributing reads) of one slab added to the streamed job's counters
+__global__ void plan_add_kernel(const unsigned long long* __restrict__ two, unsigned long long* __restrict__ plan) {
+    if (threadIdx.x < 2) atomicAdd(&plan[threadIdx.x], two[threadIdx.x]);
 }
 __global__ void __launch_bounds__(256) iota_kernel(uint32_t* __restrict__ v, uint32_t n) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -343,6 +356,42 @@ int snk_stage_partition_plan(snk_ctx* ctx, hipStream_t st, uint32_t K, const uin
 bool snk_fused_trim_ok(const snk_dev_reads* in) {
     return in->quals && !in->good_len && (in->qstride & 3u) == 0 && (((uintptr_t)in->quals) & 3u) == 0 && in->read_len <= 160 && in->qstride >= in->read_len &&
            (!in->lens || (((uintptr_t)in->lens) & 1u) == 0) && env_u32("SNK_TRIM_FUSED", 1) != 0;
+}
+
+// expected supermers of a pass and the record slots a bucket gets
+static void partition_capacity(snk_ctx* ctx, uint32_t K, uint32_t NB, unsigned long long n_inst, unsigned long long n_live, bool grouped, double* est_super_out,
+                               uint64_t* cap_out) {
+    const uint32_t Wm = K - SNK_M + 1;
+    // a random-order minimiser starts a new supermer every (W+1)/2 k-mers, and every contributing read starts one
+    const double est_super = (double)n_inst * 2.0 / (Wm + 1) + (double)n_live;
+    const double mean = est_super / NB;
+    // Bucket occupancy is NOT Poisson in the supermers: a minimiser site of the genome contributes one supermer per read that
+    // covers it (c ~ 38 at 56x), so a bucket of `mean` supermers holds mean / c sites and its count has sigma = sqrt(mean c).
+    // capacity = mean + 5 sigma.  At 4000-instance buckets on one GPU (mean 340, 9 sites) that is 2.7 x mean -- the 2.5 x mean + 32
+    // this code used before; the sharded path partitions the same reads into world x as many buckets (mean 42 at eight ranks:
+    // ONE site), where 2.5 x mean lost a tenth of the supermers to the overflow list, overran it, and ran the pass twice
+    // (78 instead of 34 ms).  c is a property of the data set: 48 covers 70x; per-barcode groups see a site once or twice.
+    // Overflowing supermers are correct (segment 1), only slower; the slots that stay empty are never touched.
+    const double site_records = (double)env_u32("SNK_MSP_SITE_RECORDS", grouped ? 3u : 48u);
+    uint64_t cap64 = (uint64_t)(mean + 5.0 * std::sqrt(mean * site_records) + 16.0);
+    cap64 = cap64 * env_u32("SNK_MSP_CAP_PCT", 100) / 100;
+    if (cap64 < 2) cap64 = 2;
+    cap64 = (cap64 + 1) & ~1ull;
+    {
+        // not more than ~45 % of the device for the slots: beyond that the capacity shrinks and the overflow list takes the rest
+        const uint64_t tot = ctx->device_mem_total;
+        if (tot) {
+            const uint64_t budget = (uint64_t)((double)tot * 0.45);
+            if (cap64 * NB * 32ull > budget) {
+                uint64_t c2 = budget / (NB * 32ull);
+                const uint64_t floor_ = (uint64_t)(mean * 1.25 + 8.0);
+                if (c2 < floor_) c2 = floor_;
+                if (c2 < cap64) cap64 = c2 & ~1ull;
+            }
+        }
+    }
+    *est_super_out = est_super;
+    *cap_out = cap64;
 }
 
 // ---- dense partition: no slots, no slot reservations.  The 0.69 G returning atomics of the one-pass partition are what its kernel
@@ -468,35 +517,9 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
                         char* err, size_t errcap, const unsigned long long* d_plan, unsigned long long* h_plan, const snk_fused_trim* ft, bool allow_dense) {
     memset(out, 0, sizeof *out);
     const uint64_t n_reads = in->n_reads;
-    const uint32_t Wm = K - SNK_M + 1;
-    // a random-order minimiser starts a new supermer every (W+1)/2 k-mers, and every contributing read starts one
-    const double est_super = (double)n_inst * 2.0 / (Wm + 1) + (double)n_live;
-    const double mean = est_super / NB;
-    // Bucket occupancy is NOT Poisson in the supermers: a minimiser site of the genome contributes one supermer per read that
-    // covers it (c ~ 38 at 56x), so a bucket of `mean` supermers holds mean / c sites and its count has sigma = sqrt(mean c).
-    // capacity = mean + 5 sigma.  At 4000-instance buckets on one GPU (mean 340, 9 sites) that is 2.7 x mean -- the 2.5 x mean + 32
-    // this code used before; the sharded path partitions the same reads into world x as many buckets (mean 42 at eight ranks:
-    // ONE site), where 2.5 x mean lost a tenth of the supermers to the overflow list, overran it, and ran the pass twice
-    // (78 instead of 34 ms).  c is a property of the data set: 48 covers 70x; per-barcode groups see a site once or twice.
-    // Overflowing supermers are correct (segment 1), only slower; the slots that stay empty are never touched.
-    const double site_records = (double)env_u32("SNK_MSP_SITE_RECORDS", grouped ? 3u : 48u);
-    uint64_t cap64 = (uint64_t)(mean + 5.0 * std::sqrt(mean * site_records) + 16.0);
-    cap64 = cap64 * env_u32("SNK_MSP_CAP_PCT", 100) / 100;
-    if (cap64 < 2) cap64 = 2;
-    cap64 = (cap64 + 1) & ~1ull;
-    {
-        // not more than ~45 % of the device for the slots: beyond that the capacity shrinks and the overflow list takes the rest
-        const uint64_t tot = ctx->device_mem_total;
-        if (tot) {
-            const uint64_t budget = (uint64_t)((double)tot * 0.45);
-            if (cap64 * NB * 32ull > budget) {
-                uint64_t c2 = budget / (NB * 32ull);
-                const uint64_t floor_ = (uint64_t)(mean * 1.25 + 8.0);
-                if (c2 < floor_) c2 = floor_;
-                if (c2 < cap64) cap64 = c2 & ~1ull;
-            }
-        }
-    }
+    double est_super = 0;
+    uint64_t cap64 = 0;
+    partition_capacity(ctx, K, NB, n_inst, n_live, grouped, &est_super, &cap64);
     if (allow_dense && est_super * 1.25 + 2e6 < 4.0e9 && env_u32("SNK_MSP_DENSE", 0))
         return partition_dense(ctx, st, K, in, good_len, NB, est_super, grouped, status, out, err, errcap, d_plan, h_plan, ft);
     if (cap64 * NB >= (1ull << 40) || cap64 >= (1ull << 31)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "bucket capacity out of range");
@@ -608,5 +631,103 @@ int snk_stage_partition_compact_remote(snk_ctx* ctx, hipStream_t st, const snk_p
     hipLaunchKernelGGL(compact_buckets_kernel, dim3((part->NB + 3) / 4), dim3(256), 0, st, (const uint4*)part->records, part->seg, part->NB,
                        d_offsets, (uint4*)d_out, skip_lo, skip_hi);
     SNK_HIP_TRY(hipGetLastError());
+    return SNK_OK;
+}
+
+
+// ===================================================================================================================
+// The one-pass partition as a JOB that takes its reads slab by slab (snk_dev_stream_*: the reads of a job need not be resident;
+// a slab is partitioned while the next one is being decoded / uploaded -- what the reference does when it streams the FASTQ
+// chunks through its partitioner, lib/tada/src/cmd_msp.rs:55-69, and re-scans in passes when memory is short,
+// MapReduceEngine.h:452-468).  Sized from the caller's upper bound of the job's reads; every slab's launch appends to the same
+// bucket slots (the cursors persist), close() builds the segment tables.  Nothing can be run twice here -- the slabs are gone --
+// so the overflow list is generous and exceeding it is an error, not a retry.
+int snk_partition_open(snk_ctx* ctx, hipStream_t st, uint32_t K, uint32_t NB, unsigned long long n_inst_ub, unsigned long long n_live_ub, bool grouped,
+                       uint32_t* status, snk_partition_job* J, char* err, size_t errcap) {
+    memset(J, 0, sizeof *J);
+    double est_super = 0;
+    uint64_t cap64 = 0;
+    partition_capacity(ctx, K, NB, n_inst_ub, n_live_ub, grouped, &est_super, &cap64);
+    if (cap64 * NB >= (1ull << 40) || cap64 >= (1ull << 31)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "bucket capacity out of range");
+    J->K = K; J->NB = NB; J->cap = (uint32_t)cap64; J->grouped = grouped; J->status = status;
+    J->ovf_cap = (uint64_t)(est_super / 6) + (1u << 20);
+    if (J->ovf_cap >= (1ull << 31)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "supermer overflow list too large");
+    int rc;
+    void* q;
+    if ((rc = snk_ctx_alloc(ctx, (NB + 1) * 4ull, &q, err, errcap))) return rc; J->cursor = (uint32_t*)q;
+    if ((rc = snk_ctx_alloc(ctx, 4ull * NB * 8 + 64, &q, err, errcap))) return rc; J->seg = (uint64_t*)q;
+    if ((rc = snk_ctx_alloc(ctx, 64 * 8, &q, err, errcap))) return rc; J->d_total = (unsigned long long*)q;
+    if ((rc = snk_ctx_alloc(ctx, 2ull * SNK_MSP_PLAN_SLOTS * 8, &q, err, errcap))) return rc; J->d_plan = (unsigned long long*)q;
+    if ((rc = snk_ctx_alloc(ctx, ((size_t)NB * J->cap + 2 * J->ovf_cap) * 32 + 64, &J->records, err, errcap))) return rc;
+    if ((rc = snk_ctx_alloc(ctx, J->ovf_cap * 4 + 64, &q, err, errcap))) return rc; J->ovf_bucket = (uint32_t*)q;
+    SNK_HIP_TRY(hipMemsetAsync(J->cursor, 0, (NB + 1) * 4ull, st));
+    SNK_HIP_TRY(hipMemsetAsync(status + 8, 0, 4, st));
+    SNK_HIP_TRY(hipMemsetAsync(J->d_plan, 0, 2ull * SNK_MSP_PLAN_SLOTS * 8, st));
+    return SNK_OK;
+}
+
+// one slab: good_len = its good lengths (u16 per read, already computed), or ft = the fused trim's inputs (then the lengths are written
+// to ft->good_out by the kernel).  Nothing is waited for.
+int snk_partition_add(snk_ctx* ctx, hipStream_t st, snk_partition_job* J, const snk_dev_reads* in, const uint16_t* good_len, const snk_fused_trim* ft, char* err,
+                      size_t errcap) {
+    (void)ctx;
+    if (in->n_reads == 0) return SNK_OK;
+    snk_msp_args ma;
+    memset(&ma, 0, sizeof ma);
+    ma.rows = (const uint32_t*)in->rows; ma.row_words = in->row_words; ma.read_len = in->read_len; ma.good_len = good_len; ma.bc = (const int32_t*)in->bc;
+    ma.ign_bc_below = in->ign_bc_below; ma.read_index_base = in->read_index_base; ma.n_reads = in->n_reads; ma.NB = J->NB;
+    ma.group = J->grouped ? (const uint32_t*)in->group : nullptr;
+    ma.cursor = J->cursor; ma.records = (uint4*)J->records; ma.cap = J->cap; ma.ovf_cap = (uint32_t)J->ovf_cap;
+    ma.ovf_base = (uint64_t)J->NB * J->cap; ma.ovf_bucket = J->ovf_bucket; ma.ovf_cursor = J->status + 8;
+    if (ft) {
+        ma.good_len = ft->good_out; ma.quals = (const uint8_t*)ft->quals; ma.qstride = ft->qstride; ma.min_qual = ft->min_qual;
+        ma.lens = (const uint16_t*)ft->lens; ma.good_out = ft->good_out; ma.plan = J->d_plan;
+    }
+    int rc = snk_launch_msp(J->K, st, ma, err, errcap);
+    if (rc) return rc;
+    if (!ft) {
+        // the sizing figures the fused kernel adds up itself: instances and contributing reads of this slab
+        unsigned long long* two;
+        void* q;
+        if ((rc = snk_ctx_alloc(ctx, 64, &q, err, errcap))) return rc; two = (unsigned long long*)q;
+        if ((rc = snk_launch_msp_plan(st, good_len, in->n_reads, J->K, two, err, errcap))) return rc;
+        hipLaunchKernelGGL(plan_add_kernel, dim3(1), dim3(64), 0, st, two, J->d_plan);
+        SNK_HIP_TRY(hipGetLastError());
+    }
+    J->n_reads += in->n_reads;
+    ++J->n_slabs;
+    return SNK_OK;
+}
+
+int snk_partition_close(snk_ctx* ctx, hipStream_t st, snk_partition_job* J, snk_partition* out, unsigned long long h_plan[2], char* err, size_t errcap) {
+    memset(out, 0, sizeof *out);
+    const uint32_t NB = J->NB;
+    SNK_HIP_TRY(hipMemsetAsync(J->d_total, 0, 64 * 8, st));
+    hipLaunchKernelGGL(seg0_kernel, dim3((NB + 255) / 256), dim3(256), 0, st, J->cursor, NB, J->cap, J->seg, J->d_total);
+    uint32_t h_novf = 0;
+    unsigned long long h_tot64[64];
+    std::vector<unsigned long long> h_fplan(2 * SNK_MSP_PLAN_SLOTS);
+    SNK_HIP_TRY(hipMemcpyAsync(&h_novf, J->status + 8, 4, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipMemcpyAsync(h_tot64, J->d_total, sizeof h_tot64, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipMemcpyAsync(h_fplan.data(), J->d_plan, h_fplan.size() * 8, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(snk_sync(st));
+    unsigned long long h_total = 0;
+    for (int q = 0; q < 64; ++q) h_total += h_tot64[q];
+    h_plan[0] = h_plan[1] = 0;
+    for (int q = 0; q < SNK_MSP_PLAN_SLOTS; ++q) { h_plan[0] += h_fplan[2 * q]; h_plan[1] += h_fplan[2 * q + 1]; }
+    if (h_novf > J->ovf_cap)
+        return snk_fail(SNK_E_NOMEM, err, errcap, "streamed partition: %u supermers beyond their buckets' capacity, the overflow list holds %llu (the job's read total was "
+                        "underestimated, or one minimiser carries a large share of the data): run it resident or with a larger total", h_novf, (unsigned long long)J->ovf_cap);
+    int rc;
+    if ((rc = snk_msp_segments(ctx, st, NB, J->cap, J->cursor, (uint4*)J->records, (uint64_t)NB * J->cap, J->ovf_cap, J->ovf_bucket, h_novf, J->seg, err, errcap))) return rc;
+    out->NB = NB;
+    out->cap = J->cap;
+    out->nseg = h_novf ? 2u : 1u;
+    out->n_overflow = h_novf;
+    out->n_supermers = h_total;
+    out->records = J->records;
+    out->cursor = J->cursor;
+    out->seg = J->seg;
+    out->kernel_ms = 0.f;
     return SNK_OK;
 }

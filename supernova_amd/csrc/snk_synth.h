@@ -8,11 +8,60 @@
 #include "../../include/snk.h"
 #include "snk_common.h"
 
-enum { SNK_ST_GENOME = 1, SNK_ST_PAIR = 2, SNK_ST_PAIR2 = 3, SNK_ST_MOL = 4, SNK_ST_ERR = 5, SNK_ST_ERRPOS = 6, SNK_ST_TAIL = 7 };
+enum { SNK_ST_GENOME = 1, SNK_ST_PAIR = 2, SNK_ST_PAIR2 = 3, SNK_ST_MOL = 4, SNK_ST_ERR = 5, SNK_ST_ERRPOS = 6, SNK_ST_TAIL = 7,
+       SNK_ST_BLOCK = 8, SNK_ST_FAMILY = 9, SNK_ST_FAMMUT = 10, SNK_ST_STR = 11, SNK_ST_SEGDUP = 12 };
 
-SNK_HD uint32_t snk_genome_base(uint64_t seed, uint64_t p) {
+SNK_HD uint32_t snk_genome_raw(uint64_t seed, uint64_t p) {
     uint64_t w = snk_rng(seed, SNK_ST_GENOME, p >> 5);
     return (uint32_t)(w >> (2 * (p & 31))) & 3u;
+}
+// Repeat-rich genome (snk_synth_params.repeat_mode: bit 0 families, bit 1 segmental duplications, bit 2 tandem repeats, bit 3 poly-A; 15 = all): what real linked-read data have and an i.i.d. genome has not -- minimiser
+// sites shared by thousands of loci, k-mers far above the coverage depth, branching graphs.  Everything is a pure function of the
+// position, so host and device agree without a stored genome:
+//   * segmental duplications: the odd 64-kb superblocks S with hash(S) % 4 == 0 carry, at offset 8192, an exact copy of the 5000
+//     bases at the same offset of an EVEN superblock (even ones never redirect, so the copy is a copy of what is really there);
+//   * per 4-kb block B (after the redirect), from hash(B):
+//       60 %: bases [256, 556) are an element of one of four families: the family's consensus with 1, 2 or 3 % substitutions;
+//        3 %: bases [1024, 1024 + 40..200) are a tandem repeat of a 1..6-base unit;
+//        2 %: bases [2048, 2048 + 20..80) are a poly-A run;
+//     everything else is the i.i.d. background.
+SNK_HD uint32_t snk_genome_base(const snk_synth_params& sp, uint64_t p) {
+    const uint64_t seed = sp.seed;
+    if (!sp.repeat_mode) return snk_genome_raw(seed, p);
+    const uint64_t S = p >> 16;
+    const uint32_t so = (uint32_t)(p & 0xFFFF);
+    if ((sp.repeat_mode & 2u) && (S & 1) && so >= 8192 && so < 8192 + 5000) {
+        const uint64_t hs = snk_rng(seed, SNK_ST_SEGDUP, S);
+        const uint64_t n_even = ((sp.genome_len >> 16) + 1) >> 1;        // even superblocks that lie inside the genome
+        if ((hs & 3) == 0 && n_even) p = (((hs >> 8) % n_even) << 17) + so;
+    }
+    const uint64_t B = p >> 12;
+    const uint32_t o = (uint32_t)(p & 4095);
+    const uint64_t hb = snk_rng(seed, SNK_ST_BLOCK, B);
+    if (o >= 256 && o < 556) {
+        if ((sp.repeat_mode & 1u) && (hb & 0xFF) < 154) {
+            const uint32_t fam = (uint32_t)(hb >> 8) & 3u, div_pct = 1u + (uint32_t)((hb >> 10) % 3);
+            const uint32_t i = o - 256;
+            uint32_t c = snk_genome_raw(snk_mix64(seed ^ (0xFA11ull + fam)), i);
+            const uint64_t hm = snk_rng(seed, SNK_ST_FAMMUT, B * 512 + i);
+            if ((uint32_t)(hm % 100) < div_pct) c = (c + 1u + (uint32_t)((hm >> 32) % 3)) & 3u;
+            return c;
+        }
+    } else if (o >= 1024 && o < 1024 + 200) {
+        if ((sp.repeat_mode & 4u) && ((hb >> 16) & 0xFF) < 8) {
+            const uint32_t len = 40u + (uint32_t)((hb >> 24) & 0xFF) % 161u, unit = 1u + (uint32_t)((hb >> 32) & 0xFF) % 6u;
+            if (o - 1024 < len) {
+                const uint64_t hu = snk_rng(seed, SNK_ST_STR, B);
+                return (uint32_t)(hu >> (2 * ((o - 1024) % unit))) & 3u;
+            }
+        }
+    } else if (o >= 2048 && o < 2048 + 80) {
+        if ((sp.repeat_mode & 8u) && ((hb >> 40) & 0xFF) < 5) {
+            const uint32_t len = 20u + (uint32_t)((hb >> 48) & 0xFF) % 61u;
+            if (o - 2048 < len) return 0u;
+        }
+    }
+    return snk_genome_raw(seed, p);
 }
 
 struct snk_read_plan {
@@ -64,8 +113,8 @@ SNK_HD snk_read_plan snk_synth_plan(const snk_synth_params& sp, uint64_t r) {
 
 // base i (read orientation) before substitutions
 SNK_HD uint32_t snk_synth_clean_base(const snk_synth_params& sp, const snk_read_plan& pl, uint32_t i) {
-    if (!pl.rc) return snk_genome_base(sp.seed, pl.start + i);
-    return snk_genome_base(sp.seed, pl.start + (sp.read_len - 1 - i)) ^ 3u;
+    if (!pl.rc) return snk_genome_base(sp, pl.start + i);
+    return snk_genome_base(sp, pl.start + (sp.read_len - 1 - i)) ^ 3u;
 }
 
 // generate one read: rows/quals may be null

@@ -96,6 +96,21 @@ class Result:
         """Grouped runs: group id of every unitig (same order as unitig_arrays())."""
         return self._dl(self.raw.unitig_group, self.n_unitigs * 4, np.uint32, (self.n_unitigs,))
 
+    def bv_image_device(self):
+        """a13 on the device: (device pointer, bytes) of the .bv hand-off file -- "BINWRITE", count, per unitig u32 length + 2-bit bases in
+        BVComp order (snk_dev_bv_image).  Context memory: valid until the engine's next top-level call."""
+        ptr, nb = C.c_void_p(0), C.c_uint64(0)
+        err = C.create_string_buffer(512)
+        rc = self._e.lib.snk_dev_bv_image(self._e._ctx, int(self.K), self.n_unitigs, self.raw.unitig_off, self.raw.unitig_bases, 1,
+                                          C.byref(ptr), C.byref(nb), self._e._stream(), err, 512)
+        if rc:
+            raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+        return ptr.value, int(nb.value)
+
+    def bv_image(self) -> bytes:
+        ptr, nb = self.bv_image_device()
+        return self._dl(ptr, nb, np.uint8, (nb,)).tobytes()
+
     def hbv(self) -> dict:
         """The graph from the device-resident unitigs (buildHBVFromEdges, HBVFromEdges.cc:244-296; snk_dev_hbv):
         vertex ids per HBV edge, fwd/rev translation per unitig, numbered in BVComp order; 'order'[r] = index of the
@@ -281,6 +296,47 @@ class Engine:
             assert group.dtype == torch.int32 and group.is_cuda and group.is_contiguous()
             r.group = group.data_ptr()
         return self.count_graph_reads(r, params)
+
+    # ---- streamed input: the job's reads arrive slab by slab (snk_dev_stream_begin / _append / _finish)
+    def stream_begin(self, read_len: int, total_reads_ub: int, has_bc: bool = True, params: Params | None = None):
+        self._stream_params = params or Params()
+        p = self._stream_params.to_c()
+        err = C.create_string_buffer(512)
+        rc = self.lib.snk_dev_stream_begin(self._ctx, C.byref(p), int(read_len), int(total_reads_ub), 1 if has_bc else 0, self._stream(), err, 512)
+        if rc != 0:
+            raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+
+    def stream_append(self, rows: torch.Tensor, read_len: int, quals: torch.Tensor | None = None, bc: torch.Tensor | None = None,
+                      lens: torch.Tensor | None = None, good_len: torch.Tensor | None = None, ign_bc_below: int = 0, read_index_base: int = 0):
+        """One slab (asynchronous: its tensors must stay alive until the engine's stream has passed the call)."""
+        assert rows.is_cuda and rows.dtype == torch.int32 and rows.is_contiguous()
+        r = _lib.SnkDevReads()
+        r.n_reads, r.rows, r.row_words, r.read_len = rows.shape[0], rows.data_ptr(), rows.shape[1], read_len
+        if lens is not None:
+            r.lens = lens.data_ptr()
+        if quals is not None:
+            assert quals.dtype == torch.uint8 and quals.is_cuda and quals.is_contiguous()
+            r.quals, r.qstride = quals.data_ptr(), quals.shape[1]
+        if good_len is not None:
+            r.good_len = good_len.data_ptr()
+        if bc is not None:
+            r.bc = bc.data_ptr()
+        r.ign_bc_below, r.read_index_base = ign_bc_below, read_index_base
+        self.stream_append_reads(r)
+
+    def stream_append_reads(self, r: "_lib.SnkDevReads"):
+        err = C.create_string_buffer(512)
+        rc = self.lib.snk_dev_stream_append(self._ctx, C.byref(r), self._stream(), err, 512)
+        if rc != 0:
+            raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+
+    def stream_finish(self) -> Result:
+        raw = _lib.SnkDevResult()
+        err = C.create_string_buffer(512)
+        rc = self.lib.snk_dev_stream_finish(self._ctx, C.byref(raw), self._stream(), err, 512)
+        if rc != 0:
+            raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+        return Result(self, raw, self._stream_params.K)
 
     def count_graph_reads(self, r: "_lib.SnkDevReads", params: Params | None = None) -> Result:
         """The same for reads described by plain device pointers (e.g. the arrays of snk_dev_ingest_fasth)."""

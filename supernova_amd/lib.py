@@ -31,7 +31,7 @@ class SnkSynthParams(C.Structure):
                 ("mol_len", C.c_uint32), ("mols_per_bc", C.c_uint32), ("pairs_per_bc", C.c_uint32),
                 ("insert_min", C.c_uint32), ("insert_span", C.c_uint32), ("sub_ppm", C.c_uint32),
                 ("unbarcoded_ppm", C.c_uint32), ("lowq_tail_ppm", C.c_uint32), ("tail_max", C.c_uint32),
-                ("err_cdf", C.c_uint32 * 4)]
+                ("err_cdf", C.c_uint32 * 4), ("repeat_mode", C.c_uint32), ("reserved", C.c_uint32 * 3)]
 
 
 class SnkDevReads(C.Structure):
@@ -182,11 +182,15 @@ def _declare(lib: C.CDLL) -> None:
         "snk_ctx_destroy": (None, [vp]),
         "snk_ctx_trim": (None, [vp]),
         "snk_synth_default": (None, [P(SnkSynthParams), u64, u64, C.c_int]),
+        "snk_synth_set_errors": (None, [P(SnkSynthParams), u32]),
         "snk_synth_host": (C.c_int, [P(SnkSynthParams), u64, u64, vp, u32, vp, u32, vp]),
         "snk_synth_dev": (C.c_int, [vp, P(SnkSynthParams), u64, u64, vp, u32, vp, u32, vp, vp]),
         "snk_dev_trim": (C.c_int, [vp, vp, u32, vp, u32, u64, u32, u32, vp, vp]),
         "snk_dev_pack_ascii": (C.c_int, [vp, vp, u32, u32, u64, vp, u32, vp]),
         "snk_dev_count_graph": (C.c_int, [vp, P(SnkDevReads), P(SnkParams), P(SnkDevResult), vp, cp, sz]),
+        "snk_dev_stream_begin": (C.c_int, [vp, P(SnkParams), u32, u64, C.c_int, vp, cp, sz]),
+        "snk_dev_stream_append": (C.c_int, [vp, P(SnkDevReads), vp, cp, sz]),
+        "snk_dev_stream_finish": (C.c_int, [vp, P(SnkDevResult), vp, cp, sz]),
         "snk_dev_download": (C.c_int, [vp, vp, vp, sz, vp]),
         "snk_count_graph": (C.c_int, [vp, P(SnkReads), P(SnkParams), P(SnkResult), cp, sz]),
         "snk_free": (None, [P(SnkResult)]),
@@ -196,6 +200,7 @@ def _declare(lib: C.CDLL) -> None:
         "snk_read_bv": (C.c_int, [cp, P(u64), P(P(u64)), P(P(C.c_uint8)), cp, sz]),
         "snk_hbv_from_unitigs": (C.c_int, [u32, u64, vp, vp, P(SnkHbv), cp, sz]),
         "snk_dev_hbv": (C.c_int, [vp, u32, u64, vp, vp, P(SnkHbv), P(C.c_float), vp, cp, sz]),
+        "snk_dev_bv_image": (C.c_int, [vp, u32, u64, vp, vp, C.c_int, P(C.c_void_p), P(u64), vp, cp, sz]),
         "snk_hbv_free": (None, [P(SnkHbv)]),
         "snk_dev_path_reads": (C.c_int, [vp, u32, P(SnkDevReads), u64, vp, vp, P(SnkHbv), P(SnkDevPaths), vp, cp, sz]),
         "snk_dev_path_reads2": (C.c_int, [vp, u32, P(SnkDevReads), u64, vp, vp, P(SnkHbv), u32, P(SnkDevPaths), vp, cp, sz]),

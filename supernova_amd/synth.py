@@ -15,6 +15,8 @@ def synth_params(n_reads: int, seed: int = 0x5EED0001, error_free: bool = False,
         if not hasattr(sp, k):
             raise AttributeError(k)
         setattr(sp, k, v)
+    if "sub_ppm" in overrides or "read_len" in overrides:      # the error-count table follows the rate (and the read length)
+        _lib.load().snk_synth_set_errors(C.byref(sp), int(sp.sub_ppm))
     return sp
 
 

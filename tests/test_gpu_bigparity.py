@@ -33,7 +33,8 @@ def _compare(dg, exp, fields=FIELDS):
     assert not bad, {f: (dg[f], exp[f]) for f in bad}
 
 
-@pytest.mark.parametrize("name", ["c1_2m", "c1_10m", "c1_2m_k60", "c1_10m_k60"])
+@pytest.mark.parametrize("name", ["c1_2m", "c1_10m", "c1_2m_k60", "c1_10m_k60", "robust_err06_200k", "robust_err15_200k", "robust_cov28_200k",
+                                  "robust_repeats_200k", "robust_repeats_1m", "robust_repeats_200k_k60"])
 def test_one_gpu_vs_reference_digest(snk, name):
     import torch
     from supernova_amd import synth
@@ -42,7 +43,7 @@ def test_one_gpu_vs_reference_digest(snk, name):
     K = exp["K"]
     e = Engine(0)
     try:
-        sp = synth.synth_params(exp["n_reads"], seed=exp["seed"])
+        sp = synth.synth_params(exp["n_reads"], seed=exp["seed"], **exp.get("overrides", {}))
         rows, quals, bc = e.synth(sp)
         # the reference's K=60 variant has no barcode rule: run without a barcode vector there
         res = e.count_graph(rows, sp.read_len, quals=quals, bc=bc if K == 48 else None, params=Params(K=K))

@@ -677,6 +677,59 @@ def test_vs_reference_binary_200k(engine, graph_stage, tmp_path):
     assert int(d["dup"].sum()) > 50
 
 
+@pytest.mark.parametrize("name", ["adversarial", "synth_20k_err"])
+def test_device_bv_image(engine, graph_stage, tmp_path, name):
+    """a13 on the device (snk_dev_bv_image): BVComp order (length descending, then lexicographic: HBVFromEdges.cc:106-111), 2-bit packing
+    and the header in HBM -- the bytes of the file the host writer (and the oracle's independent writer, tests/test_graphio.py) produce
+    from the reference's unitigs put into that order."""
+    from supernova_amd import graphio
+    if graph_stage == "global":
+        pytest.skip("one stage is enough for this one")
+    c = goldens.load(name)
+    rows, quals, bc, lens = _to_dev(c)
+    res = engine.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, ign_bc_below=c.ign_bc_below)
+    img = res.bv_image()
+    us = sorted(c.exp_unitigs, key=lambda u: (-len(u), u))
+    off, bases = graphio.unitigs_to_arrays(us)
+    p = tmp_path / "host.bv"
+    graphio.write_bv(p, off, bases)
+    assert img == p.read_bytes()
+
+
+@pytest.mark.parametrize("name,cuts", [("adversarial", (0.0, 0.31, 0.32, 0.9, 1.0)), ("synth_20k_err", (0.0, 0.5, 1.0)), ("synth_2k_err", (0.0, 1.0))])
+def test_streamed_slabs_equal_the_resident_call(engine, graph_stage, name, cuts):
+    """snk_dev_stream_begin / _append / _finish: the reads arrive in slabs (ragged cuts, an empty slab, slabs with and without the fused
+    trim's alignment), every slab is partitioned as it arrives and may be freed afterwards -- the reads are never resident as a whole.
+    Result == the golden (= the resident call) bit for bit; reads beyond the job's bound and calls without a job are refused."""
+    import torch
+    from supernova_amd.engine import Params
+    from supernova_amd.lib import SnkError
+    c = goldens.load(name)
+    rows, quals, bc, lens = _to_dev(c)
+    if name != "adversarial":          # quality rows padded to a multiple of four bytes: the trim runs inside the partition kernel
+        quals = torch.nn.functional.pad(quals, (0, 160 - quals.shape[1])).contiguous()
+    n = rows.shape[0]
+    bounds = [int(round(f * n)) & ~1 for f in cuts]
+    bounds[-1] = n
+    engine.stream_begin(c.read_len, n + 10, has_bc=True, params=Params(K=48))
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        # every slab in memory of its own that is dropped right after the call (stream order keeps it alive long enough: torch's caching
+        # allocator does not hand a freed block to another stream)
+        r, q, bcs, ln = rows[a:b].clone(), quals[a:b].clone(), bc[a:b].clone(), lens[a:b].clone()
+        engine.stream_append(r, c.read_len, quals=q, bc=bcs, lens=ln, ign_bc_below=c.ign_bc_below, read_index_base=a)
+        torch.cuda.synchronize()
+        del r, q, bcs, ln
+    engine.stream_append(rows[:0].clone(), c.read_len, quals=quals[:0].clone(), bc=bc[:0].clone(), lens=lens[:0].clone())       # an empty slab
+    res = engine.stream_finish()
+    assert res.n_reads == n
+    _check_against(res, c.exp_keys, c.exp_counts, c.exp_ctx, c.exp_unitigs, c.exp_goodlens, c.exp_hist)
+    with pytest.raises(SnkError):
+        engine.stream_finish()                                  # no open job
+    engine.stream_begin(c.read_len, n // 2, has_bc=True, params=Params(K=48))
+    with pytest.raises(SnkError, match="upper bound"):
+        engine.stream_append(rows, c.read_len, quals=quals, bc=bc, lens=lens)
+
+
 def test_circle_pool_retry(engine, monkeypatch):
     """Circles inside one chunk take their fragment slots from a small pool; an empty pool must trigger the exact re-run."""
     monkeypatch.setenv("SNK_BL_POOL", "0")

@@ -185,3 +185,26 @@ def test_mark_dups_hand_case():
     # no barcode vector at all, and nothing placed
     dup, art, rate, nd, ni = oracle_lib.mark_dups(codes, quals, L, path_off, np.zeros(n, np.int32), np.zeros(0, np.int32))
     assert dup.sum() == 0 and art.sum() == 0 and (rate, nd, ni) == (0.0, 0, 0)
+
+
+@pytest.mark.parametrize("name", ["robust_repeats_200k", "robust_err15_200k"])
+def test_oracle_matches_reference_digest_off_the_operating_point(name):
+    """The C restatement against the REFERENCE's digests (tests/golden/big_hashes.json, made by make_big_hashes.py from
+    oracle/_ref/snref_driver) on 200 k reads of the models bench.py's config.robust runs: a repeat-rich genome (interspersed families at
+    1-3 % divergence, exact 5-kb duplications, STRs, poly-A) and 1.5 % sequencing errors."""
+    import json
+    from pathlib import Path
+    import bighash
+    from supernova_amd import synth
+    fix = Path(__file__).resolve().parent / "golden" / "big_hashes.json"
+    exp = json.loads(fix.read_text()).get(name)
+    if exp is None:
+        pytest.skip("no fixture")
+    sp = synth.synth_params(exp["n_reads"], seed=exp["seed"], **exp.get("overrides", {}))
+    rows, quals, bc = synth.synth_host(sp)
+    gl = oracle_lib.good_lens(quals, sp.read_len)
+    o = oracle_lib.OracleResult(synth.unpack_rows(rows, sp.read_len), gl, bc, hbv=False)
+    hist = np.bincount(np.minimum(o.counts, (1 << 24) - 1)).astype(np.int64)
+    dg = bighash.digest(gl.astype(np.uint32), o.keys, np.minimum(o.counts, (1 << 24) - 1), o.ctx, o.unitigs, hist, kw=3)
+    bad = [f for f in ("n_reads", "n_kmers", "n_unitigs", "unitig_bases", "goodlens", "keys", "counts", "ctx", "hist", "unitigs") if dg[f] != exp[f]]
+    assert not bad, {f: (dg[f], exp[f]) for f in bad}

@@ -26,13 +26,31 @@ def per_launch(path, counter, kernel="snk_count_kernel"):
 
 
 a = sys.argv[1:]
+if a and a[0] == "--instmix":
+    # python tools/make_traffic.py --instmix <key> <SQ counter_collection.csv>: wave-instruction counts per full launch of the two big
+    # kernels (SQ_INSTS_VALU / _SALU / _LDS ..., SQ_WAVE_CYCLES, SQ_BUSY_CYCLES as collected by tools/prof_round.sh) -- what bench.py
+    # prices the count kernel's VALU-issue roofline with
+    key, path = a[1], a[2]
+    names = sorted({r["Counter_Name"] for r in csv.DictReader(open(path))})
+    e = entries.setdefault(key, {})
+    for kern, tag in (("snk_count_kernel", "count_kernel"), ("snk_msp_kernel", "partition_kernel")):
+        for cn in names:
+            v, n, _ = per_launch(path, cn, kern)
+            if n:
+                e[f"{tag}_{cn}_per_launch"] = v
+    e["instmix_source"] = Path(path).name
+    print(key, {k: v for k, v in e.items() if "SQ_" in k or "GRBM" in k})
+    doc["entries"] = entries
+    out.write_text(json.dumps(doc, indent=1) + "\n")
+    sys.exit(0)
 for i in range(0, len(a), 3):
     key, f_csv, w_csv = a[i:i + 3]
     f, nf, name = per_launch(f_csv, "FETCH_SIZE")
     w, nw, _ = per_launch(w_csv, "WRITE_SIZE")
     pf, _, _ = per_launch(f_csv, "FETCH_SIZE", "snk_msp_kernel")
     pw, _, _ = per_launch(w_csv, "WRITE_SIZE", "snk_msp_kernel")
-    entries[key] = {"FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w, "launches_averaged": [nf, nw],
+    keep = {k: v for k, v in entries.get(key, {}).items() if "SQ_" in k or "GRBM" in k or k == "instmix_source"}
+    entries[key] = {**keep, "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w, "launches_averaged": [nf, nw],
                     "count_kernel_hbm_bytes_per_launch": (2 * f + w) * 1024,
                     # the minimiser partition: packed rows streamed in (x2 as above), 32-byte records scattered out (WRITE_SIZE counts the
                     # half-filled 64-byte sectors in full: 2.1x the payload)

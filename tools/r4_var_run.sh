@@ -6,7 +6,7 @@ if [ "$what" != "bench" ]; then
   timeout 600 tools/probe/_bin/partition2 2>&1 | tee gpurun_out/r04_partition2_probe.log
 fi
 if [ "$what" != "probe" ]; then
-  B="python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-next-rows --no-ingest"
+  B="python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-next-rows --no-ingest --no-robust"
   ex() { python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print(sys.argv[1], round(d['ms_per_step'],2), d['config']['phase_ms_rank0'], d['roofline'].get('launch_ms'))" "$1"; }
   $B 2>/dev/null | ex base
   for v in $(ls supernova_amd/variants/libsnk_*.so 2>/dev/null); do
