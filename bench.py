@@ -185,8 +185,19 @@ def ingest_row(eng, args, K, step_ms_per_read):
             res = eng.count_graph_reads(dr.dev_reads(), Params(K=K, sorted_table=False))
             n_k, n_u = int(res.n_kmers), int(res.n_unitigs)
             dr.close()
+        # end to end with the reads never resident: batches are partitioned as they arrive (snk_dev_ingest_count_graph); the wall is
+        # max(ingest, partition) + count + graph, not ingest + step
+        e2e = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            r2, st2 = ingest.ingest_count_graph(eng, paths, sp.read_len, wl, params=Params(K=K, sorted_table=False), threads=args.ingest_threads, total_reads_hint=n)
+            wall = time.perf_counter() - t0
+            if e2e is None or wall < e2e["wall_seconds"]:
+                e2e = {"wall_seconds": wall, "text_GB_per_s": text / wall / 1e9, "reads_per_s": n / wall, "decode_wait_share": st2["decode_wait_seconds"] / st2["seconds"],
+                       "retained_kmers": int(r2.n_kmers), "unitigs": int(r2.n_unitigs), "same_result_as_resident": bool(int(r2.n_kmers) == n_k and int(r2.n_unitigs) == n_u),
+                       "count_graph_ms_after_last_batch": round(r2.phase_ms["count"] + r2.phase_ms["graph"], 2)}
         secs = best["seconds"]
-        return {"files": nf, "reads": n, "text_GB": text / 1e9, "compressed_GB": best["compressed_bytes"] / 1e9, "seconds": secs,
+        return {"files": nf, "reads": n, "text_GB": text / 1e9, "compressed_GB": best["compressed_bytes"] / 1e9, "seconds": secs, "fasth_to_unitigs_streamed": e2e,
                 "text_GB_per_s": text / secs / 1e9, "reads_per_s": n / secs, "decode_wait_share": best["decode_wait_seconds"] / secs,
                 "setup_seconds": best["setup_seconds"], "text_GB_per_s_after_setup": text / max(secs - best["setup_seconds"], 1e-9) / 1e9,
                 "decode_threads": args.ingest_threads or min(nf, os.cpu_count() or 1), "host_threads": os.cpu_count(),
@@ -205,8 +216,8 @@ ROBUST = (("errors_0.6pct", dict(sub_ppm=6000)),
 
 def robust_rows(eng, per_gpu, K, headline_ms):
     """The same step off the bench's operating point, 100 M reads each, on the SAME engine (arena warm, like the timed
-    steps): the first call on the new data (it may look at the first buckets and partition a second time) and the second call, which is
-    the figure.  Every model also exists as a 200 k-read digest of the REFERENCE's result (tests/golden/big_hashes.json robust_*) that
+    steps): the first call on the new data (it may look at the first buckets and partition a second time) and the better of the next two
+    (the figure: the second call still sizes the arena for the new bucket count).  Every model also exists as a 200 k-read digest of the REFERENCE's result (tests/golden/big_hashes.json robust_*) that
     tests/test_gpu_bigparity.py compares the HIP path with."""
     import torch
     from supernova_amd import synth
@@ -218,14 +229,16 @@ def robust_rows(eng, per_gpu, K, headline_ms):
         rows, quals, bc = eng.synth(sp)
         torch.cuda.synchronize()
         calls = []
-        for rep in range(2):
+        for rep in range(3):        # the first call meets new data (it may partition twice), the second sizes the arena for it, the third is steady state
             t0 = time.perf_counter()
             r = eng.count_graph(rows, sp.read_len, quals=quals, bc=bc, params=Params(K=K, sorted_table=False))
             torch.cuda.synchronize()
             calls.append(((time.perf_counter() - t0) * 1e3, int(r.repartitioned)))
-        ms = calls[1][0]
+            if calls[-1][0] > 20000:       # a pathological case is reported, not repeated
+                break
+        ms = min(c[0] for c in calls[1:]) if len(calls) > 1 else calls[0][0]
         out[name] = {"ms": round(ms, 2), "Gkmers_per_s": round(r.n_instances / ms / 1e6, 2), "vs_headline_ms": round(ms / headline_ms, 3),
-                     "first_call_ms": round(calls[0][0], 2), "first_call_repartitioned": calls[0][1],
+                     "first_call_ms": round(calls[0][0], 2), "first_call_repartitioned": calls[0][1], "calls_ms": [round(c[0], 1) for c in calls],
                      "phase_ms": {k: round(v, 2) for k, v in r.phase_ms.items() if k in ("partition", "count", "graph")},
                      "buckets": int(r.n_buckets), "buckets_split": int(r.buckets_split), "overflow_supermers": int(r.n_overflow),
                      "retained_kmers": int(r.n_kmers), "unitigs": int(r.n_unitigs)}

@@ -175,7 +175,8 @@ typedef struct snk_dev_result {
     float graph_ms[8];           /* bucket-local graph: local prune, boundary resolve, fragments, join, table sort+spectrum */
     uint32_t repartitioned;      /* 1: the first buckets overflowed their tables (error-rich / shallow data) and the reads were
                                     partitioned a second time into smaller buckets; later calls on the context start there */
-    uint32_t reserved0;
+    uint32_t n_hot_buckets;      /* minimiser buckets far above their capacity (repeat families, homopolymer runs) whose k-mer instances
+                                    were re-partitioned by k-mer hash and counted class by class */
 } snk_dev_result;
 
 /* Replaces the body of buildReadQGraph48 (BuildReadQGraph48.cc:1688-1774, pPaths==nullptr) up to and
@@ -612,6 +613,14 @@ typedef struct snk_dev_ingest {
 int snk_dev_ingest_fasth(snk_ctx* ctx, const char* const* paths, uint32_t n_files, uint32_t read_len, const snk_bc_index* ix, uint32_t threads,
                          uint32_t batch_pairs, snk_dev_ingest* out, char* err, size_t errcap);
 void snk_dev_ingest_free(snk_dev_ingest* r);
+/* FASTH files -> unitigs with the reads never resident as a whole: every decoded batch is uploaded, packed, given its barcode ids and
+ * appended to a streamed job (snk_dev_stream_*) -- partitioned while the next batches are being inflated; the wall time is
+ * max(ingest, partition) + count + graph.  res: as snk_dev_count_graph's (good_len in arrival order: batches arrive in any order).
+ * total_reads_hint: an upper bound of the job's reads (sizes the bucket slots), 0 = from the compressed sizes.  stats: rows / quals /
+ * lens / bc stay NULL.  The reading half + MSP of tada in one pass (lib/tada/src/cmd_msp.rs:55-69,100-190). */
+int snk_dev_ingest_count_graph(snk_ctx* ctx, const char* const* paths, uint32_t n_files, uint32_t read_len, const snk_bc_index* ix, uint32_t threads,
+                               uint32_t batch_pairs, uint64_t total_reads_hint, const snk_params* p, snk_dev_result* res, snk_dev_ingest* stats, char* err,
+                               size_t errcap);
 /* synthetic FASTH (tests, bench.py --ingest): pairs [first_pair, first_pair + n_pairs) of the synthetic read model as one gzip
  * file; barcode field = snk_synth_bc_seq(id) + "-1" (",raw" appended on every third pair), an off-whitelist sequence for id 0 */
 int snk_synth_fasth_write(const char* path, const snk_synth_params* sp, uint64_t first_pair, uint64_t n_pairs, int level, uint64_t* text_bytes,

@@ -28,7 +28,7 @@ namespace {
 constexpr uint32_t BC_MULTI = 0xFFFFFFFEu;
 constexpr uint32_t BC_IGN = 0xFFFFFFFFu;      // (a read under the ignore rule: larger than BC_MULTI, so the atomicMax of the merges keeps it)
 static_assert(BC_IGN > BC_MULTI, "barcode states are merged with atomicMax");
-constexpr int MAX_SPLIT_LOG2 = 16;
+constexpr int MAX_SPLIT_LOG2 = 20;      // (split ids are 24-bit fields; the split stack in ctl[] holds 24 entries)
 #define SNK_COUNT_MAXSEG 32      // record segments per bucket (sharded runs: one per source rank)
 #ifndef SNK_COUNT_THREADS
 #define SNK_COUNT_THREADS 768
@@ -255,10 +255,19 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
         if (MULTI) { segn[sseg] = (uint32_t)nsb; segn[SNK_COUNT_MAXSEG + sseg] = (uint32_t)(nsb >> 32); segn[2 * SNK_COUNT_MAXSEG + sseg] = nse; }
         seg_pending = false;
     };
+    // virtual buckets (snk_hot.hip): the k-mer instances of one hash class of a hot minimiser bucket -- the pass starts in that class
+    // (further splits add hash bits above it) and its chunks are reported under the real bucket
+    uint32_t lg0 = 0, id0 = 0, real_bucket = bucket;
+    if (a.vmeta) {
+        const uint2 vm = a.vmeta[bucket];
+        real_bucket = __builtin_amdgcn_readfirstlane(vm.x);
+        lg0 = __builtin_amdgcn_readfirstlane(vm.y >> 24);
+        id0 = __builtin_amdgcn_readfirstlane(vm.y & 0xFFFFFFu);
+    }
     while (sp) {
         PROF(0);
         --sp;
-        uint32_t split_lg = 0, split_id = 0;
+        uint32_t split_lg = lg0, split_id = id0;
         if (!fresh) {
             lds_barrier();      // the stack entries and the cleared table of the pass that overflowed are visible
             split_lg = LDS_LOAD(&ctl[16 + 2 * sp]); split_id = LDS_LOAD(&ctl[17 + 2 * sp]);
@@ -566,8 +575,9 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                     // chunk descriptor for the bucket-local graph stage: the survivors of one sub-pass are contiguous
                     if (split_lg == 0) { a.chunk_n[bucket] = nvalid; a.chunk_base[bucket] = (uint32_t)rbase; }
                     else {
+                        // (the region travels with the descriptor: a virtual bucket's region is not its real bucket's)
                         const uint32_t e = atomicAdd(&a.status[4], 1u);
-                        if (e < a.extra_cap) a.extra[e] = make_uint4(bucket, (uint32_t)rbase, nvalid, (split_lg << 24) | split_id);
+                        if (e < a.extra_cap) a.extra[e] = make_uint4(real_bucket, (uint32_t)rbase, nvalid | (blockIdx.x << 12), (split_lg << 24) | split_id);
                     }
                 }
             }

@@ -12,9 +12,11 @@
 // window and parses records in place -- no per-line strings, the bases and qualities of a read are copied once, from the
 // inflate window into their row of the batch -- and hands full batches to the consumer through a queue.  Batches live in
 // page-locked memory (when a GPU is there), so the DMA engine reads them where they are.
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -53,6 +55,38 @@ struct snk_fasth_stream {
 };
 
 namespace {
+
+// libdeflate, when the host has it (bound with dlopen like librccl: libsnk links nothing it can do without): whole-buffer inflate,
+// three times zlib's rate (0.64 against 0.21 GB/s of text per thread on the build host).  It cannot stream, so it takes the files
+// whose compressed size is under SNK_FASTH_WHOLE_MAX_MB (default 128) -- a lane bucketed into dozens of files gives files of that
+// size -- and zlib's streaming inflate takes the rest.  SNK_FASTH_LIBDEFLATE=0 switches it off.
+struct deflate_api {
+    void* h = nullptr;
+    void* (*alloc)() = nullptr;
+    void (*release)(void*) = nullptr;
+    int (*gzip_ex)(void*, const void*, size_t, void*, size_t, size_t*, size_t*) = nullptr;
+    bool tried = false;
+};
+deflate_api g_defl;
+std::mutex g_defl_mu;
+const deflate_api* libdeflate() {
+    std::lock_guard<std::mutex> lk(g_defl_mu);
+    if (g_defl.tried) return g_defl.gzip_ex ? &g_defl : nullptr;
+    g_defl.tried = true;
+    const char* off = getenv("SNK_FASTH_LIBDEFLATE");
+    if (off && *off == '0') return nullptr;
+    for (const char* name : {"libdeflate.so.0", "libdeflate.so"}) {
+        void* h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (!h) continue;
+        *(void**)(&g_defl.alloc) = dlsym(h, "libdeflate_alloc_decompressor");
+        *(void**)(&g_defl.release) = dlsym(h, "libdeflate_free_decompressor");
+        *(void**)(&g_defl.gzip_ex) = dlsym(h, "libdeflate_gzip_decompress_ex");
+        if (g_defl.alloc && g_defl.release && g_defl.gzip_ex) { g_defl.h = h; return &g_defl; }
+        g_defl.gzip_ex = nullptr;
+        dlclose(h);
+    }
+    return nullptr;
+}
 
 void fail(snk_fasth_stream* s, int rc, const std::string& msg) {
     std::lock_guard<std::mutex> lk(s->mu);
@@ -149,7 +183,54 @@ bool decode_file(snk_fasth_stream* s, uint32_t fi) {
         }
         return true;
     };
-    while (ok) {
+    // ---- whole-file inflate (libdeflate) for files of modest size: every gzip member in turn into one text buffer, lines parsed from it
+    bool whole_done = false;
+    if (const deflate_api* D = libdeflate()) {
+        struct stat sb;
+        const char* mx = getenv("SNK_FASTH_WHOLE_MAX_MB");
+        const uint64_t max_comp = (uint64_t)(mx && *mx ? strtoull(mx, nullptr, 10) : 128) << 20;
+        if (fstat(fd, &sb) == 0 && sb.st_size >= 18 && (uint64_t)sb.st_size <= max_comp) {
+            const size_t csz = (size_t)sb.st_size;
+            std::vector<unsigned char> comp(csz);
+            size_t got = 0;
+            while (got < csz) { const ssize_t r = pread(fd, comp.data() + got, csz - got, (off_t)got); if (r <= 0) break; got += (size_t)r; }
+            if (got == csz && comp[0] == 0x1f && comp[1] == 0x8b) {
+                // the last member's ISIZE says how large its text is (mod 2^32): a first guess for the buffer, doubled while it is too small
+                uint32_t isize;
+                memcpy(&isize, comp.data() + csz - 4, 4);
+                const size_t cap_max = (size_t)24 * csz + (64u << 20);
+                size_t cap = (size_t)isize + 64;
+                if (cap < 4 * csz) cap = 4 * csz;
+                if (cap > cap_max) cap = cap_max;          // (a cut file's last four bytes are not a size)
+                void* dc = D->alloc();
+                std::vector<unsigned char> text;
+                bool bad = !dc, too_big = false;
+                size_t ipos = 0, opos = 0;
+                while (!bad && !too_big && ipos < csz) {
+                    if (text.size() < cap) text.resize(cap);
+                    size_t ain = 0, aout = 0;
+                    const int r = D->gzip_ex(dc, comp.data() + ipos, csz - ipos, text.data() + opos, text.size() - opos, &ain, &aout);
+                    if (r == 0) { ipos += ain; opos += aout; if (ain == 0) bad = true; }
+                    else if (r == 3) { if (cap >= cap_max) too_big = true; else cap = cap * 2 < cap_max ? cap * 2 : cap_max; }      // LIBDEFLATE_INSUFFICIENT_SPACE
+                    else bad = true;
+                }
+                if (dc) D->release(dc);
+                if (bad) { what = path + ": truncated or corrupt gzip stream"; ok = false; whole_done = true; }
+                else if (!too_big) {
+                    whole_done = true;
+                    size_t lb = 0;
+                    while (lb < opos && ok) {
+                        const unsigned char* nl = (const unsigned char*)memchr(text.data() + lb, '\n', opos - lb);
+                        const size_t e = nl ? (size_t)(nl - text.data()) : opos;
+                        text_in_batch += e + (nl ? 1 : 0) - lb;
+                        if (!on_line(text.data() + lb, e - lb)) { ok = false; break; }
+                        lb = e + 1;
+                    }
+                }
+            } else if (got == csz && csz >= 2) { what = path + ": not a gz file"; ok = false; whole_done = true; }
+        }
+    }
+    while (ok && !whole_done) {
         // refill the input
         if (zs.avail_in == 0 && !eof_in) {
             const ssize_t got = read(fd, in.data(), IN);
@@ -197,7 +278,7 @@ bool decode_file(snk_fasth_stream* s, uint32_t fi) {
     inflateEnd(&zs);
     close(fd);
     if (ok && mid_member) { what = path + ": truncated gzip stream (the input ends inside a member)"; ok = false; }
-    if (ok && line_beg < have) {          // a last line without a newline
+    if (ok && !whole_done && line_beg < have) {          // a last line without a newline
         if (!on_line(win.data() + line_beg, have - line_beg)) ok = false;
     }
     if (ok && li != 0) { what = path + ": truncated record " + std::to_string(pairs_in_file); ok = false; }
@@ -243,7 +324,7 @@ extern "C" int snk_fasth_open(const char* const* paths, uint32_t n_files, uint32
     s->batch_pairs = batch_pairs;
     s->file_pairs.assign(n_files, 0);
     const bool want_pinned = (flags & 1u) != 0;
-    const uint32_t n_batches = 2 * threads + 2;
+    const uint32_t n_batches = threads + (threads < 14 ? threads + 2 : 16);      // one per worker being filled + what waits for / is with the consumer
     s->pool.resize(n_batches);
     for (uint32_t i = 0; i < n_batches; ++i) {
         snk_fasth_stream::batch& b = s->pool[i];
@@ -400,7 +481,7 @@ extern "C" int snk_dev_ingest_fasth(snk_ctx* ctx, const char* const* paths, uint
     memset(out, 0, sizeof *out);
     SNK_HIP_TRY(hipSetDevice(ctx->device));
     const uint32_t stride = (read_len + 15) / 16 * 16, row_words = (read_len + 15) / 16, qstride = stride;
-    if (batch_pairs == 0) batch_pairs = 32768;
+    if (batch_pairs == 0) batch_pairs = 65536;       // (the consumer's per-batch cost -- a dozen runtime calls -- is what limits it once the decode is fast)
     const double t0 = now_s();
     // capacity guess from the compressed sizes (a read is ~330 bytes of text, FASTH deflates ~4x); the arrays grow if it is wrong
     uint64_t comp = 0;
@@ -421,12 +502,15 @@ extern "C" int snk_dev_ingest_fasth(snk_ctx* ctx, const char* const* paths, uint
     std::vector<piece> pieces;
     struct pend { hipEvent_t ev; snk_fasth_batch b; };
     std::deque<pend> pending;
+    std::vector<hipEvent_t> ev_pool;
     uint64_t n_reads = 0, text = 0;
     uint32_t max_len = 0;
     auto cleanup = [&]() {
         if (cs) (void)hipStreamSynchronize(cs);
         for (auto& p : pending) { (void)hipEventDestroy(p.ev); snk_fasth_release(fs, &p.b); }
         pending.clear();
+        for (auto e : ev_pool) (void)hipEventDestroy(e);
+        ev_pool.clear();
         for (int q = 0; q < NST; ++q) { (void)hipFree(st_ascii[q]); (void)hipFree(st_bcf[q]); (void)hipFree(st_ids[q]); if (st_ev[q]) (void)hipEventDestroy(st_ev[q]); }
         if (cs) (void)hipStreamDestroy(cs);
         if (fs) snk_fasth_close(fs);
@@ -450,7 +534,7 @@ extern "C" int snk_dev_ingest_fasth(snk_ctx* ctx, const char* const* paths, uint
         const double p0 = now_s();
         while (!pending.empty() && (pending.size() > 2 || hipEventQuery(pending.front().ev) == hipSuccess)) {
             ING_TRY(hipEventSynchronize(pending.front().ev));
-            (void)hipEventDestroy(pending.front().ev);
+            ev_pool.push_back(pending.front().ev);
             snk_fasth_release(fs, &pending.front().b);
             pending.pop_front();
         }
@@ -483,7 +567,8 @@ extern "C" int snk_dev_ingest_fasth(snk_ctx* ctx, const char* const* paths, uint
         ING_TRY(hipMemcpyAsync(A.lens + n_reads, b.lens, nr * 2ull, hipMemcpyHostToDevice, cs));
         if (ix) ING_TRY(hipMemcpyAsync(st_bcf[slot], b.bc_fields, b.n_pairs * 64ull, hipMemcpyHostToDevice, cs));
         pend pe;
-        ING_TRY(hipEventCreateWithFlags(&pe.ev, hipEventDisableTiming));
+        if (!ev_pool.empty()) { pe.ev = ev_pool.back(); ev_pool.pop_back(); }
+        else ING_TRY(hipEventCreateWithFlags(&pe.ev, hipEventDisableTiming));
         ING_TRY(hipEventRecord(pe.ev, cs));
         pe.b = b;
         pending.push_back(pe);
@@ -530,6 +615,121 @@ extern "C" int snk_dev_ingest_fasth(snk_ctx* ctx, const char* const* paths, uint
     out->rows = A.rows; out->quals = A.quals; out->lens = A.lens; out->bc = A.bc;
     out->text_bytes = text; out->compressed_bytes = comp; out->n_files = n_files;
     out->seconds = now_s() - t0; out->decode_wait_seconds = wait_s; out->setup_seconds = t_ready - t0; out->n_batches = (uint32_t)pieces.size();
+    return SNK_OK;
+#undef ING_TRY
+#undef ING_RC
+}
+
+// FASTH files -> count + graph with the reads never resident as a whole: every decoded batch goes up, is packed, gets its barcode ids
+// and is appended to a streamed job (snk_dev_stream_*, snk_pipeline.hip) -- partitioned into the job's minimiser buckets while the
+// workers inflate the next batches; finish() counts and builds the graph.  Wall time = max(ingest, partition) + count + graph, not
+// their sum; the device holds the supermer records, not the reads.  total_reads_hint: an upper bound of the job's reads (it sizes the
+// bucket slots); 0 = derived from the compressed sizes.
+extern "C" int snk_dev_ingest_count_graph(snk_ctx* ctx, const char* const* paths, uint32_t n_files, uint32_t read_len, const snk_bc_index* ix, uint32_t threads,
+                                          uint32_t batch_pairs, uint64_t total_reads_hint, const snk_params* p, snk_dev_result* res, snk_dev_ingest* out, char* err,
+                                          size_t errcap) {
+    if (!ctx || !paths || !out || !p || !res || n_files == 0) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_ingest_count_graph: NULL argument");
+    if (read_len == 0 || read_len > 256) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_ingest_count_graph: read_len must be 1..256");
+    memset(out, 0, sizeof *out);
+    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    const uint32_t stride = (read_len + 15) / 16 * 16, row_words = (read_len + 15) / 16, qstride = stride;
+    if (batch_pairs == 0) batch_pairs = 65536;
+    const double t0 = now_s();
+    uint64_t comp = 0;
+    for (uint32_t i = 0; i < n_files; ++i) { struct stat sb; if (stat(paths[i], &sb) == 0 && sb.st_size > 0) comp += (uint64_t)sb.st_size; }
+    // a read pair is ~650 bytes of text that deflate to ~130; 45 compressed bytes per read is a bound with a margin of a third
+    const uint64_t ub = total_reads_hint ? total_reads_hint : comp / 45 + 8ull * batch_pairs;
+    snk_fasth_stream* fs = nullptr;
+    int rc = snk_fasth_open(paths, n_files, stride, batch_pairs, threads, 1u, &fs, err, errcap);
+    if (rc) return rc;
+    hipStream_t cs = nullptr;
+    constexpr int NST = 4;
+    struct slot_t { uint8_t *ascii = nullptr, *bcf = nullptr, *quals = nullptr; int32_t *ids = nullptr, *bc = nullptr; uint32_t* rows = nullptr; uint16_t* lens = nullptr; hipEvent_t ev = nullptr; bool busy = false; };
+    slot_t S[NST];
+    struct pend { hipEvent_t ev; snk_fasth_batch b; };
+    std::deque<pend> pending;
+    std::vector<hipEvent_t> ev_pool;
+    auto cleanup = [&]() {
+        if (cs) (void)hipStreamSynchronize(cs);
+        for (auto& q : pending) { (void)hipEventDestroy(q.ev); snk_fasth_release(fs, &q.b); }
+        pending.clear();
+        for (auto e : ev_pool) (void)hipEventDestroy(e);
+        for (auto& q : S) { (void)hipFree(q.ascii); (void)hipFree(q.bcf); (void)hipFree(q.quals); (void)hipFree(q.ids); (void)hipFree(q.bc); (void)hipFree(q.rows); (void)hipFree(q.lens); if (q.ev) (void)hipEventDestroy(q.ev); }
+        if (cs) (void)hipStreamDestroy(cs);
+        if (fs) snk_fasth_close(fs);
+    };
+#define ING_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return snk_fail(_e == hipErrorOutOfMemory ? SNK_E_NOMEM : SNK_E_HIP, err, errcap, "%s failed: %s", #expr, hipGetErrorString(_e)); } } while (0)
+#define ING_RC(expr) do { int _r = (expr); if (_r) { cleanup(); return _r; } } while (0)
+    ING_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    const uint64_t nrb = 2ull * batch_pairs;
+    for (auto& q : S) {
+        ING_TRY(hipMalloc((void**)&q.ascii, nrb * stride));
+        ING_TRY(hipMalloc((void**)&q.quals, nrb * qstride));
+        ING_TRY(hipMalloc((void**)&q.rows, nrb * row_words * 4ull));
+        ING_TRY(hipMalloc((void**)&q.lens, nrb * 2 + 16));
+        ING_TRY(hipMalloc((void**)&q.bcf, (size_t)batch_pairs * 64));
+        ING_TRY(hipMalloc((void**)&q.ids, (size_t)batch_pairs * 4));
+        ING_TRY(hipMalloc((void**)&q.bc, nrb * 4));
+        ING_TRY(hipEventCreateWithFlags(&q.ev, hipEventDisableTiming));
+    }
+    ING_RC(snk_dev_stream_begin(ctx, p, read_len, ub, ix ? 1 : 0, cs, err, errcap));
+    int slot = 0;
+    double wait_s = 0;
+    uint64_t n_reads = 0, text = 0;
+    uint32_t max_len = 0, n_batches = 0;
+    const double t_ready = now_s();
+    for (;;) {
+        while (!pending.empty() && (pending.size() > 2 || hipEventQuery(pending.front().ev) == hipSuccess)) {
+            ING_TRY(hipEventSynchronize(pending.front().ev));
+            ev_pool.push_back(pending.front().ev);
+            snk_fasth_release(fs, &pending.front().b);
+            pending.pop_front();
+        }
+        snk_fasth_batch b;
+        const double w0 = now_s();
+        ING_RC(snk_fasth_next(fs, &b, err, errcap));
+        wait_s += now_s() - w0;
+        if (b.n_pairs == 0) break;
+        const uint64_t nr = 2 * b.n_pairs;
+        slot_t& q = S[slot];
+        if (q.busy) { ING_TRY(hipEventSynchronize(q.ev)); q.busy = false; }        // the partition launch that read this slot is done
+        ING_TRY(hipMemcpyAsync(q.ascii, b.ascii, nr * (uint64_t)stride, hipMemcpyHostToDevice, cs));
+        ING_TRY(hipMemcpyAsync(q.quals, b.quals, nr * (uint64_t)stride, hipMemcpyHostToDevice, cs));
+        ING_TRY(hipMemcpyAsync(q.lens, b.lens, nr * 2ull, hipMemcpyHostToDevice, cs));
+        if (ix) ING_TRY(hipMemcpyAsync(q.bcf, b.bc_fields, b.n_pairs * 64ull, hipMemcpyHostToDevice, cs));
+        pend pe;
+        if (!ev_pool.empty()) { pe.ev = ev_pool.back(); ev_pool.pop_back(); }
+        else ING_TRY(hipEventCreateWithFlags(&pe.ev, hipEventDisableTiming));
+        ING_TRY(hipEventRecord(pe.ev, cs));
+        pe.b = b;
+        pending.push_back(pe);
+        ING_RC(snk_dev_pack_ascii(ctx, q.ascii, stride, read_len, nr, q.rows, row_words, cs));
+        if (ix) {
+            ING_RC(snk_dev_bc_ids(ctx, ix, q.bcf, 64, b.n_pairs, q.ids, cs, err, errcap));
+            hipLaunchKernelGGL(pair_ids_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, cs, q.ids, b.n_pairs, q.bc);
+        }
+        snk_dev_reads slab;
+        memset(&slab, 0, sizeof slab);
+        slab.n_reads = nr; slab.rows = q.rows; slab.row_words = row_words; slab.read_len = read_len; slab.lens = q.lens; slab.quals = q.quals; slab.qstride = qstride;
+        slab.bc = ix ? q.bc : nullptr;
+        ING_RC(snk_dev_stream_append(ctx, &slab, cs, err, errcap));
+        ING_TRY(hipEventRecord(q.ev, cs));
+        q.busy = true;
+        slot = (slot + 1) % NST;
+        n_reads += nr;
+        text += b.text_bytes;
+        ++n_batches;
+        if (b.max_len > max_len) max_len = b.max_len;
+    }
+    const double t_decoded = now_s();
+    ING_RC(snk_dev_stream_finish(ctx, res, cs, err, errcap));
+    ING_TRY(hipStreamSynchronize(cs));
+    while (!pending.empty()) { (void)hipEventDestroy(pending.front().ev); snk_fasth_release(fs, &pending.front().b); pending.pop_front(); }
+    cleanup();
+    out->n_reads = n_reads; out->read_len = read_len; out->row_words = row_words; out->qstride = qstride; out->max_len = max_len;
+    out->text_bytes = text; out->compressed_bytes = comp; out->n_files = n_files; out->n_batches = n_batches;
+    out->seconds = now_s() - t0; out->decode_wait_seconds = wait_s; out->setup_seconds = t_ready - t0;
+    (void)t_decoded;
     return SNK_OK;
 #undef ING_TRY
 #undef ING_RC

@@ -1,0 +1,267 @@
+// snk_hot.hip -- hot minimiser buckets: a bucket that holds far more supermers than its capacity is re-partitioned by K-MER HASH.
+//
+// A minimiser bucket is counted by ONE workgroup in an LDS table of ~1200 distinct k-mers; a bucket with more is counted in hash-split
+// sub-passes, each of which reads ALL records of the bucket.  That is fine for the odd bucket that is twice too large -- and quadratic
+// for a minimiser site that thousands of loci share: an interspersed repeat family (10^4 copies of a 300-bp element at 1-3 %
+// divergence) puts ~4 x 10^5 supermers with ~2 x 10^5 distinct k-mers behind ONE minimiser, i.e. hundreds of sub-passes over
+// hundreds of thousands of records, serial in one workgroup (round 4, bench.py config.robust: 48 s on a step that takes 0.1 s).
+// Real genomes are made of such families; the reference's sort-based reduce does not care (MapReduceEngine.h:574-584 sorts k-mer
+// records, a k-mer's multiplicity changes nothing), so neither may this.
+//
+// What is done about it: the records of a hot bucket are expanded into single-k-mer records (the same 32-byte layout with n_kmers = 1:
+// the k-mer, its two flank bases, the barcode word), each of which goes to the VIRTUAL bucket (hot bucket, class), class = the low
+// bits of the count kernel's own split hash of the canonical k-mer -- all instances of a k-mer meet in one class, the classes of a
+// bucket are counted by different workgroups in parallel, and a class holds about what a normal bucket holds.  The count kernel runs
+// a second launch over the virtual buckets; a pass over virtual bucket (b, lg, id) starts where a hash-split sub-pass (lg, id) of
+// bucket b would (further splits add hash bits above lg) and reports its chunk under the real bucket, so the bucket-local graph stage
+// sees nothing new.  Exact sizing (count pass, scan, scatter pass): nothing is guessed, nothing can overflow.
+#include <string.h>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+#include <vector>
+
+#include "snk_ctx.h"
+#include "snk_common.h"
+#include "snk_kernels.h"
+#include "snk_stages.h"
+
+namespace {
+
+constexpr int HT = 256;               // threads per workgroup of the expansion kernels = records staged per workgroup
+
+struct hot_tab {
+    const uint32_t* bucket;           // [n_hot]
+    const uint32_t* lg;               // [n_hot] classes = 1 << lg
+    const uint64_t* rbase;            // [n_hot + 1] records of the hot buckets before this one
+    const uint32_t* vbase;            // [n_hot + 1] virtual buckets before this one
+    uint32_t n_hot;
+};
+
+// ---- which buckets are hot
+__global__ void __launch_bounds__(256) hot_scan_kernel(const uint64_t* __restrict__ seg, uint32_t NB, uint32_t thresh, uint32_t hot_cap, uint32_t* __restrict__ hot_b,
+                                                       uint32_t* __restrict__ hot_r, unsigned long long* __restrict__ ctr) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= NB) return;
+    const uint64_t r = (seg[(uint64_t)NB + b] - seg[b]) + (seg[3ull * NB + b] - seg[2ull * NB + b]);
+    if (r >= thresh) {
+        const unsigned long long i = atomicAdd(&ctr[0], 1ull);
+        if (i < hot_cap) { hot_b[i] = b; hot_r[i] = (uint32_t)(r > 0xFFFFFFFFull ? 0xFFFFFFFFull : r); }
+    }
+}
+// one thread: class counts and the two running sums (a few thousand hot buckets at most)
+__global__ void hot_plan_kernel(const uint32_t* __restrict__ hot_r, uint32_t hot_cap, uint32_t inst_per_class, uint32_t* __restrict__ lg, uint64_t* __restrict__ rbase,
+                                uint32_t* __restrict__ vbase, unsigned long long* __restrict__ ctr) {
+    if (threadIdx.x || blockIdx.x) return;
+    unsigned long long n = ctr[0];
+    if (n > hot_cap) n = hot_cap;
+    unsigned long long racc = 0, vacc = 0;
+    for (uint32_t i = 0; i < (uint32_t)n; ++i) {
+        // a record holds up to K - M + 1 k-mers, ~16 on average: classes of ~inst_per_class instances
+        const unsigned long long inst = (unsigned long long)hot_r[i] * 16ull;
+        uint32_t l = 1;
+        while (l < 12 && (inst >> l) > inst_per_class) ++l;
+        lg[i] = l;
+        rbase[i] = racc; racc += hot_r[i];
+        vbase[i] = (uint32_t)vacc; vacc += 1ull << l;
+    }
+    rbase[n] = racc;
+    vbase[n] = (uint32_t)vacc;
+    ctr[1] = racc;
+    ctr[2] = vacc;
+}
+// the hot buckets leave the main launch; every virtual bucket learns who it is
+__global__ void __launch_bounds__(256) hot_meta_kernel(hot_tab h, uint32_t NB, uint64_t* __restrict__ seg, uint2* __restrict__ vmeta) {
+    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t NBv = h.vbase[h.n_hot];
+    if (v >= NBv) return;
+    uint32_t lo = 0, hi = h.n_hot;                    // largest i with vbase[i] <= v
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (h.vbase[mid] <= v) lo = mid; else hi = mid; }
+    const uint32_t cls = v - h.vbase[lo];
+    vmeta[v] = make_uint2(h.bucket[lo], (h.lg[lo] << 24) | cls);
+}
+__global__ void __launch_bounds__(256) hot_mask_kernel(hot_tab h, uint32_t NB, uint64_t* __restrict__ seg_main) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= h.n_hot) return;
+    const uint32_t b = h.bucket[i];
+    seg_main[(uint64_t)NB + b] = seg_main[b];                       // empty in both segments
+    seg_main[3ull * NB + b] = seg_main[2ull * NB + b];
+}
+
+// ---- expansion: one thread per hot record, its k-mers one after the other.  SCATTER = false: count the instances per virtual bucket;
+// true: write the single-k-mer records behind the virtual buckets' cursors.
+template <int K, bool GROUPED, bool SCATTER>
+__global__ void __launch_bounds__(HT) hot_expand_kernel(hot_tab h, const uint4* __restrict__ records, const uint64_t* __restrict__ seg_saved, uint32_t NB, uint32_t cap,
+                                                        uint32_t* __restrict__ vcount, const uint64_t* __restrict__ voff, uint4* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint32_t rec[(HT + 1) * 9];        // staged records, nine words each (the ninth is zero: reads behind word 7), one zero record in front
+    const int tid = threadIdx.x;
+    const uint64_t t = (uint64_t)blockIdx.x * HT + tid;
+    const uint64_t total = h.rbase[h.n_hot];
+    const bool live = t < total;
+    uint32_t i = 0;
+    uint4 ra = make_uint4(0, 0, 0, 0), rb = ra;
+    if (live) {
+        uint32_t lo = 0, hi = h.n_hot;                // largest i with rbase[i] <= t
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (h.rbase[mid] <= t) lo = mid; else hi = mid; }
+        i = lo;
+        const uint32_t b = h.bucket[i];
+        const uint64_t r = t - h.rbase[i];
+        // the bucket's records: its slots, then its part of the overflow segment (seg_saved: the bounds before the bucket was masked out)
+        const uint64_t n0 = seg_saved[(uint64_t)NB + b] - seg_saved[b];
+        const uint64_t at = r < n0 ? seg_saved[b] + r : seg_saved[2ull * NB + b] + (r - n0);
+        ra = records[2 * at];
+        rb = records[2 * at + 1];
+    }
+    (void)cap;
+    uint32_t* my = rec + (tid + 1) * 9;
+    my[0] = ra.x; my[1] = ra.y; my[2] = ra.z; my[3] = ra.w; my[4] = rb.x; my[5] = rb.y; my[6] = rb.z; my[7] = rb.w; my[8] = 0u;
+    if (tid < 9) rec[tid] = 0u;
+    __syncthreads();
+    if (!live) return;
+    const uint32_t m6 = rb.z, w7 = rb.w;
+    const uint32_t n_i = m6 & 0x7Fu, hasL = (m6 >> 7) & 1u, hasR = (m6 >> 8) & 1u;
+    const uint32_t lg = h.lg[i], vb0 = h.vbase[i];
+    for (uint32_t j = 0; j < n_i; ++j) {
+        // (the extraction of snk_count.hip's insert phase: words wi .. wi+4 of the record, the word before it for the preceding base)
+        const uint32_t o = hasL + j;
+        const uint32_t wi = o >> 4, sh = (2u * o) & 31u;
+        const uint32_t* wp = my + wi;
+        auto funnel = [](uint32_t hi_, uint32_t lo_, uint32_t s) { return (uint32_t)(((((uint64_t)hi_ << 32) | lo_) << s) >> 32); };
+        const uint32_t W0 = wp[0], W1 = wp[1], W2 = wp[2], W3 = wp[3];
+        const uint32_t F0 = funnel(W0, W1, sh), F1 = funnel(W1, W2, sh), F2 = funnel(W2, W3, sh);
+        uint32_t F3 = 0;
+        if (K == 60) { const uint32_t W4 = wp[4]; F3 = funnel(W3, W4, sh) & 0xFFFFFF00u; }
+        snk_kmer f;
+        f.hi = ((uint64_t)F0 << 32) | F1;
+        f.lo = ((uint64_t)F2 << 32) | F3;
+        if (K == 48) f.lo &= 0xFFFFFFFF00000000ull;
+        const snk_kmer r = snk_kmer_rc<K>(f);
+        snk_kmer c = snk_kmer_lt(r, f) ? r : f;
+        if (GROUPED) c.lo |= (uint64_t)w7;
+        uint32_t h1, h2;
+        snk_kmer_hash_count<(K > 48) || GROUPED>(c, &h1, &h2);
+        const uint32_t v = vb0 + (h2 & ((1u << lg) - 1u));
+        if (!SCATTER) { atomicAdd(&vcount[v], 1u); continue; }
+        const uint32_t slot = atomicAdd(&vcount[v], 1u);
+        const uint64_t dst = voff[v] + slot;
+        // the single-k-mer record: bases o - hasL' .. o + K - 1 + hasR' of the supermer's base stream
+        const uint32_t nhasL = o > 0 ? 1u : 0u, nhasR = (j + 1u < n_i) ? 1u : hasR;
+        const uint32_t a0 = o - nhasL, bits = 2u * ((uint32_t)K + nhasL + nhasR);
+        const uint32_t wj = a0 >> 4, fs = (2u * a0) & 31u;
+        const uint32_t* wq = my + wj;
+        uint32_t nw[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const uint32_t x = funnel(wq[q], (wj + q + 1 <= 8) ? wq[q + 1] : 0u, fs);
+            int rbits = (int)bits - 32 * q;
+            rbits = rbits < 0 ? 0 : (rbits > 32 ? 32 : rbits);
+            nw[q] = x & (uint32_t)(0xFFFFFFFF00000000ull >> rbits);
+        }
+        // (word 6 of the source record carries flag bits in its low nine bits: they are never inside the K + 2 bases taken here -- a
+        // supermer's bases end above them -- but the funnel shift may drag them into a word that the mask above cuts to nothing)
+        out[2 * dst] = make_uint4(nw[0], nw[1], nw[2], nw[3]);
+        out[2 * dst + 1] = make_uint4(nw[4], 0u, 1u | (nhasL << 7) | (nhasR << 8), w7);
+    }
+}
+
+__global__ void __launch_bounds__(256) hot_seg_kernel(const uint64_t* __restrict__ voff, uint32_t NBv, uint64_t* __restrict__ seg) {
+    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= NBv) return;
+    seg[v] = voff[v];
+    seg[(uint64_t)NBv + v] = voff[v + 1];
+}
+
+template <typename T>
+int alloc(snk_ctx* ctx, size_t n, T** out, char* err, size_t errcap) {
+    void* q = nullptr;
+    int rc = snk_ctx_alloc(ctx, (n ? n : 1) * sizeof(T) + 64, &q, err, errcap);
+    *out = (T*)q;
+    return rc;
+}
+
+template <int K, bool GROUPED>
+int expand(hipStream_t st, const hot_tab& h, uint64_t total_records, const uint4* records, const uint64_t* seg_saved, uint32_t NB, uint32_t cap, uint32_t* vcount,
+           const uint64_t* voff, uint4* out, bool scatter, char* err, size_t errcap) {
+    const unsigned grid = (unsigned)((total_records + HT - 1) / HT);
+    if (!scatter) hipLaunchKernelGGL((hot_expand_kernel<K, GROUPED, false>), dim3(grid), dim3(HT), 0, st, h, records, seg_saved, NB, cap, vcount, voff, out);
+    else hipLaunchKernelGGL((hot_expand_kernel<K, GROUPED, true>), dim3(grid), dim3(HT), 0, st, h, records, seg_saved, NB, cap, vcount, voff, out);
+    SNK_HIP_TRY(hipGetLastError());
+    return SNK_OK;
+}
+
+}  // namespace
+
+int snk_stage_hot(snk_ctx* ctx, hipStream_t st, uint32_t K, bool grouped, snk_partition* part, snk_hot* hot, char* err, size_t errcap) {
+    memset(hot, 0, sizeof *hot);
+    if (part->gidx || part->NB == 0 || part->n_overflow == 0) return SNK_OK;        // a bucket far above its capacity has records on the overflow list
+    const uint32_t NB = part->NB;
+    // hot = more records than eight times the slots of a bucket (and never fewer than SNK_HOT_MIN: a normal hash-split pass or two
+    // over a few thousand records is cheaper than the expansion)
+    const uint32_t floor_ = snk_env_u32("SNK_HOT_MIN", 8192);
+    uint64_t thr = (uint64_t)part->cap * snk_env_u32("SNK_HOT_FACTOR", 8);
+    if (thr < floor_) thr = floor_;
+    if (thr > 0xFFFFFFFFull || snk_env_u32("SNK_HOT", 1) == 0) return SNK_OK;
+    const uint32_t hot_cap = 1u << 16;
+    int rc;
+    uint32_t *hot_b, *hot_r, *lg, *vbase;
+    uint64_t* rbase;
+    unsigned long long* ctr;
+    if ((rc = alloc(ctx, hot_cap, &hot_b, err, errcap)) || (rc = alloc(ctx, hot_cap, &hot_r, err, errcap)) || (rc = alloc(ctx, hot_cap + 1, &lg, err, errcap)) ||
+        (rc = alloc(ctx, hot_cap + 1, &vbase, err, errcap)) || (rc = alloc(ctx, hot_cap + 1, &rbase, err, errcap)) || (rc = alloc(ctx, 8, &ctr, err, errcap)))
+        return rc;
+    SNK_HIP_TRY(hipMemsetAsync(ctr, 0, 64, st));
+    hipLaunchKernelGGL(hot_scan_kernel, dim3((NB + 255) / 256), dim3(256), 0, st, part->seg, NB, (uint32_t)thr, hot_cap, hot_b, hot_r, ctr);
+    hipLaunchKernelGGL(hot_plan_kernel, dim3(1), dim3(64), 0, st, hot_r, hot_cap, snk_env_u32("SNK_HOT_CLASS_INST", 6000), lg, rbase, vbase, ctr);
+    unsigned long long h_ctr[3] = {0, 0, 0};
+    SNK_HIP_TRY(hipMemcpyAsync(h_ctr, ctr, 24, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(snk_sync(st));
+    if (h_ctr[0] == 0) return SNK_OK;
+    if (h_ctr[0] > hot_cap) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "more than %u hot minimiser buckets", hot_cap);
+    const uint32_t n_hot = (uint32_t)h_ctr[0], NBv = (uint32_t)h_ctr[2];
+    const uint64_t n_rec = h_ctr[1];
+    hot_tab h{hot_b, lg, rbase, vbase, n_hot};
+    // the main segment table keeps the hot buckets' bounds in a copy (the expansion reads them), the live one shows them empty
+    uint64_t* seg_saved;
+    if ((rc = alloc(ctx, 4ull * NB, &seg_saved, err, errcap))) return rc;
+    SNK_HIP_TRY(hipMemcpyAsync(seg_saved, part->seg, 4ull * NB * 8, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(hot_mask_kernel, dim3((n_hot + 255) / 256), dim3(256), 0, st, h, NB, part->seg);
+    uint2* vmeta;
+    uint32_t* vcount;
+    uint64_t *voff, *vseg;
+    if ((rc = alloc(ctx, NBv, &vmeta, err, errcap)) || (rc = alloc(ctx, (size_t)NBv + 1, &vcount, err, errcap)) || (rc = alloc(ctx, (size_t)NBv + 2, &voff, err, errcap)) ||
+        (rc = alloc(ctx, 2ull * NBv, &vseg, err, errcap)))
+        return rc;
+    hipLaunchKernelGGL(hot_meta_kernel, dim3((NBv + 255) / 256), dim3(256), 0, st, h, NB, part->seg, vmeta);
+    SNK_HIP_TRY(hipMemsetAsync(vcount, 0, ((size_t)NBv + 1) * 4, st));
+    auto run = [&](bool scatter, uint4* out) -> int {
+        if (grouped) return expand<48, true>(st, h, n_rec, (const uint4*)part->records, seg_saved, NB, part->cap, vcount, voff, out, scatter, err, errcap);
+        if (K == 48) return expand<48, false>(st, h, n_rec, (const uint4*)part->records, seg_saved, NB, part->cap, vcount, voff, out, scatter, err, errcap);
+        return expand<60, false>(st, h, n_rec, (const uint4*)part->records, seg_saved, NB, part->cap, vcount, voff, out, scatter, err, errcap);
+    };
+    if ((rc = run(false, nullptr))) return rc;
+    {
+        auto in = rocprim::make_transform_iterator(vcount, [] __device__(uint32_t v) { return (uint64_t)v; });
+        size_t tb = 0;
+        SNK_HIP_TRY(rocprim::exclusive_scan((void*)nullptr, tb, in, voff, (uint64_t)0, (size_t)NBv + 1, rocprim::plus<uint64_t>(), st));
+        void* tmp;
+        if ((rc = snk_ctx_alloc(ctx, tb + 64, &tmp, err, errcap))) return rc;
+        SNK_HIP_TRY(rocprim::exclusive_scan(tmp, tb, in, voff, (uint64_t)0, (size_t)NBv + 1, rocprim::plus<uint64_t>(), st));
+    }
+    uint64_t n_inst = 0;
+    SNK_HIP_TRY(hipMemcpyAsync(&n_inst, voff + NBv, 8, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(snk_sync(st));
+    uint4* vrec;
+    if ((rc = alloc(ctx, 2 * (size_t)n_inst + 2, &vrec, err, errcap))) return rc;
+    SNK_HIP_TRY(hipMemsetAsync(vcount, 0, ((size_t)NBv + 1) * 4, st));
+    if ((rc = run(true, vrec))) return rc;
+    hipLaunchKernelGGL(hot_seg_kernel, dim3((NBv + 255) / 256), dim3(256), 0, st, voff, NBv, vseg);
+    SNK_HIP_TRY(hipGetLastError());
+    hot->n_hot = n_hot;
+    hot->NBv = NBv;
+    hot->n_records = n_rec;
+    hot->n_instances = n_inst;
+    hot->records = vrec;
+    hot->seg = vseg;
+    hot->vmeta = vmeta;
+    return SNK_OK;
+}

@@ -26,10 +26,10 @@ struct snk_msp_args {
     uint4* records;
     // bucket b owns records [b*cap, (b+1)*cap); what does not fit goes to [ovf_base, ovf_base+ovf_cap)
     uint32_t cap;
-    uint32_t ovf_cap;
+    uint32_t ovf_cap;              // slots of ONE overflow sub-list (there are SNK_OVF_SUBLISTS, chosen by wave)
     uint64_t ovf_base;
-    uint32_t* ovf_bucket;          // [ovf_cap] bucket of every overflow record
-    uint32_t* ovf_cursor;          // [1] overflow records wanted (keeps counting past ovf_cap)
+    uint32_t* ovf_bucket;          // [SNK_OVF_SUBLISTS * ovf_cap] bucket of every overflow record
+    uint32_t* ovf_cursor;          // [SNK_OVF_SUBLISTS] overflow records wanted per sub-list (keep counting past ovf_cap)
     uint32_t dbg;                  // profiling aid (results invalid): 1 = no record stores, 2 = no slot atomics
     // fused quality trim (quals != NULL): the kernel derives every read's good length itself (the rule of snk_trim.hip), writes
     // it to good_out and adds the k-mer instances / contributing reads of its waves to plan[2 * (wave % 256) + {0, 1}]
@@ -45,6 +45,7 @@ struct snk_msp_args {
     uint64_t dense_cap;
 };
 constexpr int SNK_MSP_PLAN_SLOTS = 256;
+constexpr uint32_t SNK_OVF_SUBLISTS = 64;
 int snk_launch_msp(uint32_t K, hipStream_t st, const snk_msp_args& a, char* err, size_t errcap);
 int snk_launch_msp_plan(hipStream_t st, const uint16_t* good_len, uint64_t n_reads, uint32_t K, unsigned long long* out2,
                         char* err, size_t errcap);
@@ -56,6 +57,7 @@ struct snk_count_args {
     const uint64_t* seg_end;       // [nseg][seg_stride] one past its last record (offset tables: seg_end = seg_beg + 1)
     uint32_t seg_stride;
     uint32_t nseg;
+    const uint2* vmeta;            // virtual buckets (snk_hot.hip): per bucket (real bucket, split_lg << 24 | split_id) the pass starts from; else NULL
     const uint32_t* gidx;          // dense partition: the segment bounds index this list, record v of a bucket is records[gidx[v]]; else NULL
     uint32_t NB;
     uint32_t min_freq;
@@ -71,7 +73,7 @@ struct snk_count_args {
     unsigned long long* region_cursor;   // [n_regions] entries used per region
     uint32_t* chunk_n;             // [NB] survivors of an unsplit bucket (0 when it split or has none), or NULL
     uint32_t* chunk_base;          // [NB] their offset inside region (bucket % n_regions)
-    uint4* extra;                  // sub-passes of split buckets: (bucket, offset, n, split_lg << 24 | split_id); count in status[4]
+    uint4* extra;                  // sub-passes of split buckets: (bucket, offset, n | region << 12, split_lg << 24 | split_id); count in status[4]
     uint32_t extra_cap;
     unsigned long long* prof;      // SNK_COUNT_PROF builds: [8] clock cycles of thread 0 per phase, summed over workgroups
     uint32_t dbg;                  // profiling aid: 1 = roll+hash only, 2 = no updates after the probe (results invalid)

@@ -57,9 +57,7 @@ struct chunk_t {
 struct bl_regions {
     const snk_u128* keys_r;
     const uint64_t* vals_r;
-    uint64_t region_cap;
-    const unsigned long long* region_off;
-    uint32_t n_regions;
+    const uint64_t* desc_src;      // [nchunks] region-space position of every chunk
     snk_u128* keys_dense;
 };
 // sharded runs: this rank owns global buckets [bucket_base, bucket_base + NBl); NBl == 0 -> one GPU owns everything
@@ -69,19 +67,21 @@ struct bl_shard {
 };
 // one 16-byte record per chunk (dense position, k-mers, bucket, split_lg << 24 | split_id): every chunk kernel starts
 // with ONE load instead of a chain of three dependent ones
-__global__ void __launch_bounds__(256) bl_chunk_desc_kernel(chunk_src cs, uint32_t nchunks, uint4* __restrict__ desc) {
+__global__ void __launch_bounds__(256) bl_chunk_desc_kernel(chunk_src cs, uint32_t nchunks, uint4* __restrict__ desc, uint64_t region_cap, uint64_t* __restrict__ desc_src) {
     const uint32_t c = blockIdx.x * 256 + threadIdx.x;
     if (c >= nchunks) return;
-    uint32_t bucket, n, off = 0, meta = 0;
+    uint32_t bucket, n, off = 0, meta = 0, region;
     if (c < cs.NB) {
         bucket = c; n = cs.chunk_n[c];
         if (n) off = cs.chunk_base[c];
+        region = bucket % cs.n_regions;
     } else {
         const uint4 e = cs.extra[c - cs.NB];
-        bucket = e.x; off = e.y; n = e.z; meta = e.w;
+        bucket = e.x; off = e.y; n = e.z & 0xFFFu; region = e.z >> 12; meta = e.w;      // (a hot bucket's classes are counted by other workgroups than the bucket's own: snk_hot.hip)
     }
-    const uint64_t base = cs.region_off[bucket % cs.n_regions] + off;
+    const uint64_t base = cs.region_off[region] + off;
     desc[c] = make_uint4((uint32_t)base, n, bucket, meta);
+    if (desc_src) desc_src[c] = (uint64_t)region * region_cap + off;      // where the chunk lies in region space (deferred compaction)
 }
 __device__ __forceinline__ chunk_t chunk_get(const uint4* __restrict__ desc, uint32_t c) {
     const uint4 d = desc[c];
@@ -134,11 +134,7 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
     const uint32_t n = ch.n;
     // where the chunk lies: dense, or still in its count region (then this kernel is what compacts it)
     uint64_t src = ch.base;
-    if (rg.keys_r) {
-        const uint32_t r = ch.bucket % rg.n_regions;
-        src = (uint64_t)r * rg.region_cap + (ch.base - rg.region_off[r]);
-        keys = rg.keys_r; vals = rg.vals_r;
-    }
+    if (rg.keys_r) { src = rg.desc_src[c]; keys = rg.keys_r; vals = rg.vals_r; }
     __syncthreads();      // the previous chunk of this workgroup is done with the LDS arrays
     for (int s = tid; s < HT; s += T) ht[s] = 0;
     if (tid == 0) bcnt = 0;
@@ -868,7 +864,9 @@ static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* er
     const uint32_t nchunks = tab->NB + tab->n_extra;
     B->nchunks = nchunks;
     G_ALLOC(B->desc, uint4, (uint64_t)nchunks + 1);
-    hipLaunchKernelGGL(bl_chunk_desc_kernel, dim3((nchunks + 255) / 256), dim3(256), 0, st, cs, nchunks, B->desc);
+    uint64_t* desc_src = nullptr;
+    if (tab->keys_r) G_ALLOC(desc_src, uint64_t, (uint64_t)nchunks + 1);
+    hipLaunchKernelGGL(bl_chunk_desc_kernel, dim3((nchunks + 255) / 256), dim3(256), 0, st, cs, nchunks, B->desc, tab->region_cap, desc_src);
     uint32_t *nbnd, *ctr;
     G_ALLOC(B->ctx, uint8_t, n + 16);
     G_ALLOC(B->pend, uint8_t, n + 16);
@@ -904,7 +902,7 @@ static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* er
         SNK_HIP_TRY(hipMemsetAsync(index0, 0, tg0 * 8, st));
     }
     bl_regions rg;
-    rg.keys_r = tab->keys_r; rg.vals_r = tab->vals_r; rg.region_cap = tab->region_cap; rg.region_off = tab->region_off; rg.n_regions = tab->n_regions;
+    rg.keys_r = tab->keys_r; rg.vals_r = tab->vals_r; rg.desc_src = desc_src;
     rg.keys_dense = const_cast<snk_u128*>(tab->keys);
     hipLaunchKernelGGL((bl_prune_kernel<K, SCAP, ST, false, GR>), dim3((nchunks + cpw - 1) / cpw), dim3(ST), 0, st, (const uint4*)B->desc, NBh, sh, rg,
                        (const uint32_t*)nullptr, nchunks, cpw, tab->keys, tab->vals, B->do_prune, B->ctx, B->counts, B->pend, B->nbr, nbnd,

@@ -318,11 +318,14 @@ __global__ void __launch_bounds__(BD, K == 48 ? SNK_MSP_OCC48 : 4) snk_msp_kerne
                         // overflow list: ONE reservation per wave (same-address atomics are served one at a time)
                         const unsigned long long m = __ballot(1);
                         const int lane = tid & 63, leader = __ffsll((long long)m) - 1;
+                        // ... on one of SNK_OVF_SUBLISTS cursors, by wave: with a repeat-rich genome a few per cent of all supermers
+                        // overflow, nearly every wave has one in every turn, and ten million reservations on ONE address were 108 ms
+                        const uint32_t sub = (blockIdx.x * (BD / 64) + ((uint32_t)tid >> 6)) & (SNK_OVF_SUBLISTS - 1u);
                         uint32_t o = 0;
-                        if (lane == leader) o = atomicAdd(a.ovf_cursor, (uint32_t)__popcll(m));
+                        if (lane == leader) o = atomicAdd(&a.ovf_cursor[sub], (uint32_t)__popcll(m));
                         o = __shfl(o, leader) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                        if (o < a.ovf_cap) { at = a.ovf_base + o; a.ovf_bucket[o] = bucket; }
-                        else ok = false;                               // the host sees ovf_cursor > ovf_cap and re-runs
+                        if (o < a.ovf_cap) { const uint32_t g = sub * a.ovf_cap + o; at = a.ovf_base + g; a.ovf_bucket[g] = bucket; }
+                        else ok = false;                               // the host sees a cursor beyond its sub-list and re-runs
                     }
                     }
                     if (ok && a.dbg != 1) {

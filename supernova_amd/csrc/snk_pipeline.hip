@@ -214,11 +214,15 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
         out->n_overflow = part.n_overflow;
         if (pass == 0) tm.mark();  // 3
 
+        // ---- hot minimiser buckets (repeat families, homopolymer runs): re-partitioned by k-mer hash (snk_hot.hip)
+        snk_hot hot;
+        if ((rc = snk_stage_hot(ctx, st, K, grouped, &part, &hot, err, errcap))) return rc;
+        out->n_hot_buckets = hot.n_hot;
         // ---- K5-K8 count + filter + gather (+ sort for the global graph stage)
         snk_count_pilot pilot{0.0, nullptr, nullptr};
         const bool want_pilot = adaptive && pass == 0 && !have_hint;
         rc = snk_stage_count_table(ctx, st, K, records, part.seg, part.seg + NB, 2 * NB, part.nseg, NB, p->min_freq, (in->bc && !grouped) ? p->min_bc : 0u, grouped ? 1u : 0u,
-                                   h_ninst, status, !local_graph, &tab, err, errcap, nullptr, want_pilot ? &pilot : nullptr, part.gidx, local_graph);
+                                   h_ninst, status, !local_graph, &tab, err, errcap, nullptr, want_pilot ? &pilot : nullptr, part.gidx, local_graph, &hot);
         if (rc == SNK_RETARGET) {
             // everything since the partition goes back to the arena; the good lengths and the status words stay
             snk_ctx_release_since(ctx, mark, nullptr, 0);
@@ -373,9 +377,12 @@ extern "C" int snk_dev_stream_finish(snk_ctx* ctx, snk_dev_result* out, void* st
     out->n_supermers = part.n_supermers;
     out->n_overflow = part.n_overflow;
     const bool local_graph = !(p->flags & SNK_F_GLOBAL_GRAPH) && !env_u32("SNK_GLOBAL_GRAPH", 0);
+    snk_hot hot;
+    if ((rc = snk_stage_hot(ctx, st, K, false, &part, &hot, err, errcap))) return rc;
+    out->n_hot_buckets = hot.n_hot;
     snk_table tab;
     rc = snk_stage_count_table(ctx, st, K, part.records, part.seg, part.seg + j->NB, 2 * j->NB, part.nseg, j->NB, p->min_freq, j->has_bc ? p->min_bc : 0u, 0u, h_ninst, j->status,
-                               !local_graph, &tab, err, errcap, nullptr, nullptr, nullptr, local_graph);
+                               !local_graph, &tab, err, errcap, nullptr, nullptr, nullptr, local_graph, &hot);
     if (rc) return rc;
     // (the ratio is keyed by the job's read bound: the next job of the same size starts from it)
     rc = graph_tail(ctx, st, p, K, false, local_graph, j->total_ub, h_ninst, tab, part, out, tm, err, errcap);

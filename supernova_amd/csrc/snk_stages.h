@@ -46,6 +46,7 @@ struct snk_table {
     uint64_t region_cap;
 };
 
+struct snk_hot;
 uint32_t snk_env_u32(const char* name, uint32_t dflt);
 // optional: the first count launch goes out in bucket ranges [bounds[r], bounds[r+1]); ready(user, r) is called before
 // range r is launched (the sharded path makes the stream wait for that range's records there)
@@ -70,7 +71,7 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
                           const uint64_t* seg_end, uint32_t seg_stride, uint32_t nseg, uint32_t NB, uint32_t min_freq, uint32_t bc_mode, uint32_t grouped, uint64_t n_inst_hint,
                           uint32_t* status, bool want_sort, snk_table* out, char* err, size_t errcap,
                           const snk_count_ranges* ranges = nullptr, snk_count_pilot* pilot = nullptr, const uint32_t* gidx = nullptr,
-                          bool defer_compact = false);
+                          bool defer_compact = false, const snk_hot* hot = nullptr);
 
 // ---- minimiser partition in one pass (fixed bucket capacity + overflow segment)
 struct snk_partition {
@@ -99,6 +100,17 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
                         unsigned long long n_inst, unsigned long long n_live, bool grouped, uint32_t* status, snk_partition* out,
                         char* err, size_t errcap, const unsigned long long* d_plan = nullptr, unsigned long long* h_plan = nullptr,
                         const snk_fused_trim* ft = nullptr, bool allow_dense = false);
+// hot minimiser buckets (snk_hot.hip): their records expanded into single-k-mer records, one virtual bucket per (bucket, hash class)
+struct snk_hot {
+    uint32_t n_hot, NBv;           // hot buckets, virtual buckets (0: nothing is hot)
+    uint64_t n_records, n_instances;
+    const void* records;           // n_instances single-k-mer records, virtual-bucket-major
+    const uint64_t* seg;           // [begin NBv | end NBv]
+    const uint2* vmeta;            // [NBv] (real bucket, split_lg << 24 | split_id)
+};
+// after snk_stage_partition: finds the buckets far above their capacity, takes them out of the partition's segment table and builds
+// their virtual buckets; snk_stage_count_table counts those in a second launch
+int snk_stage_hot(snk_ctx* ctx, hipStream_t st, uint32_t K, bool grouped, snk_partition* part, snk_hot* hot, char* err, size_t errcap);
 // the same pass as a job that takes its reads slab by slab (snk_dev_stream_*)
 struct snk_partition_job {
     uint32_t K, NB, cap, n_slabs;
@@ -109,6 +121,7 @@ struct snk_partition_job {
     unsigned long long *d_total, *d_plan;     // d_plan: SNK_MSP_PLAN_SLOTS x (instances, contributing reads), summed at close
     void* records;
     uint32_t* ovf_bucket;
+    uint32_t* ovf_cur;        // [SNK_OVF_SUBLISTS] cursors of the overflow sub-lists
     uint32_t* status;
 };
 int snk_partition_open(snk_ctx* ctx, hipStream_t st, uint32_t K, uint32_t NB, unsigned long long n_inst_ub, unsigned long long n_live_ub, bool grouped,

@@ -26,7 +26,8 @@ uint32_t snk_env_u32(const char* name, uint32_t dflt) {
 int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* records, const uint64_t* seg_beg,
                           const uint64_t* seg_end, uint32_t seg_stride, uint32_t nseg, uint32_t NB, uint32_t min_freq, uint32_t bc_mode, uint32_t grouped, uint64_t n_inst_hint,
                           uint32_t* status, bool want_sort, snk_table* out, char* err, size_t errcap, const snk_count_ranges* ranges, snk_count_pilot* pilot,
-                          const uint32_t* gidx, bool defer_compact) {
+                          const uint32_t* gidx, bool defer_compact, const snk_hot* hot) {
+    if (hot && hot->NBv == 0) hot = nullptr;
     defer_compact = defer_compact && !want_sort && env_u32("SNK_DEFER_COMPACT", 1) != 0;
     int rc;
     snk_phase_timer tm(st), kt(st);
@@ -59,6 +60,7 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
         // sub-passes of split buckets: a few per cent of the buckets split once; remember what the last call needed
         extra_cap = NB / 8 > (1u << 16) ? NB / 8 : (1u << 16);
         if (ctx->last_extra > extra_cap) extra_cap = ctx->last_extra + ctx->last_extra / 4;
+        if (hot) extra_cap += hot->NBv + hot->NBv / 2;          // every virtual bucket reports its chunk through this list
     }
     bool pilot_regrown = false;
     for (int attempt = 0; attempt < 4; ++attempt) {
@@ -78,6 +80,7 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
         ca.seg_stride = seg_stride;
         ca.nseg = nseg;
         ca.gidx = gidx;
+        ca.vmeta = nullptr;
         ca.NB = NB;
         ca.min_freq = min_freq;
         ca.bc_mode = bc_mode;
@@ -162,6 +165,20 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
             }
         } else if ((rc = snk_launch_count(K, st, ca, err, errcap))) return rc;
         kt.mark();
+        if (hot && !pilot_regrow) {
+            // the hot buckets' hash classes: the same kernel over the virtual buckets, appending to the same regions and chunk list
+            snk_count_args cv = ca;
+            cv.records = (const uint4*)hot->records;
+            cv.seg_beg = hot->seg;
+            cv.seg_end = hot->seg + hot->NBv;
+            cv.seg_stride = hot->NBv;
+            cv.nseg = 1;
+            cv.gidx = nullptr;
+            cv.vmeta = hot->vmeta;
+            cv.NB = hot->NBv;
+            cv.bucket0 = 0;
+            if ((rc = snk_launch_count(K, st, cv, err, errcap))) return rc;
+        }
         if (pilot_regrow) {           // larger regions, the pilot once more (nothing else has run)
             snk_ctx_release_block(ctx, keys_r);
             snk_ctx_release_block(ctx, vals_r);
@@ -287,6 +304,18 @@ __global__ void __launch_bounds__(256) iota_kernel(uint32_t* __restrict__ v, uin
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) v[i] = i;
 }
+// the used prefixes of the overflow sub-lists as ONE list: position j -> slot idx[j] and its bucket key[j]
+struct ovf_pre { uint32_t pre[SNK_OVF_SUBLISTS + 1]; };
+__global__ void __launch_bounds__(256) ovf_index_kernel(ovf_pre P, uint32_t sub_cap, const uint32_t* __restrict__ ovf_bucket, uint32_t n, uint32_t* __restrict__ idx,
+                                                        uint32_t* __restrict__ key) {
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    uint32_t lo = 0, hi = SNK_OVF_SUBLISTS;                 // largest s with pre[s] <= j
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (P.pre[mid] <= j) lo = mid; else hi = mid; }
+    const uint32_t g = lo * sub_cap + (j - P.pre[lo]);
+    idx[j] = g;
+    key[j] = ovf_bucket[g];
+}
 __global__ void __launch_bounds__(256) ovf_gather_kernel(const uint4* rec, uint64_t src_base, uint64_t dst_base,
                                                          const uint32_t* __restrict__ idx, const uint32_t* __restrict__ key, uint32_t n,
                                                          uint32_t NB, uint4* out, uint64_t* __restrict__ seg) {
@@ -317,21 +346,29 @@ __global__ void __launch_bounds__(256) compact_buckets_kernel(const uint4* __res
 }  // namespace
 
 static int snk_msp_segments(snk_ctx* ctx, hipStream_t st, uint32_t NB, uint32_t cap, const uint32_t* cursor, uint4* records, uint64_t ovf_base,
-                     uint64_t ovf_cap, const uint32_t* ovf_bucket, uint32_t n_ovf, uint64_t* seg, char* err,
+                     uint64_t sub_cap, const uint32_t* ovf_bucket, const uint32_t* h_sub /* [SNK_OVF_SUBLISTS] used slots of every sub-list */, uint64_t* seg, char* err,
                      size_t errcap) {
+    (void)cap; (void)cursor;
+    ovf_pre P;
+    uint64_t acc = 0;
+    for (uint32_t q = 0; q < SNK_OVF_SUBLISTS; ++q) { P.pre[q] = (uint32_t)acc; acc += h_sub[q]; }
+    P.pre[SNK_OVF_SUBLISTS] = (uint32_t)acc;
+    const uint32_t n_ovf = (uint32_t)acc;
     if (n_ovf) {
-        uint32_t *idx_in, *idx_out, *key_out;
+        uint32_t *idx_in, *idx_out, *key_in, *key_out;
         void* q;
         int rc;
         if ((rc = snk_ctx_alloc(ctx, (size_t)n_ovf * 4 + 16, &q, err, errcap))) return rc; idx_in = (uint32_t*)q;
         if ((rc = snk_ctx_alloc(ctx, (size_t)n_ovf * 4 + 16, &q, err, errcap))) return rc; idx_out = (uint32_t*)q;
+        if ((rc = snk_ctx_alloc(ctx, (size_t)n_ovf * 4 + 16, &q, err, errcap))) return rc; key_in = (uint32_t*)q;
         if ((rc = snk_ctx_alloc(ctx, (size_t)n_ovf * 4 + 16, &q, err, errcap))) return rc; key_out = (uint32_t*)q;
-        hipLaunchKernelGGL(iota_kernel, dim3((n_ovf + 255) / 256), dim3(256), 0, st, idx_in, n_ovf);
+        hipLaunchKernelGGL(ovf_index_kernel, dim3((n_ovf + 255) / 256), dim3(256), 0, st, P, (uint32_t)sub_cap, ovf_bucket, n_ovf, idx_in, key_in);
         size_t tb = 0;
-        SNK_HIP_TRY(rocprim::radix_sort_pairs((void*)nullptr, tb, ovf_bucket, key_out, idx_in, idx_out, (size_t)n_ovf, 0u, 32u, st));
+        SNK_HIP_TRY(rocprim::radix_sort_pairs((void*)nullptr, tb, key_in, key_out, idx_in, idx_out, (size_t)n_ovf, 0u, 32u, st));
         if ((rc = snk_ctx_alloc(ctx, tb, &q, err, errcap))) return rc;
-        SNK_HIP_TRY(rocprim::radix_sort_pairs(q, tb, ovf_bucket, key_out, idx_in, idx_out, (size_t)n_ovf, 0u, 32u, st));
-        hipLaunchKernelGGL(ovf_gather_kernel, dim3((n_ovf + 255) / 256), dim3(256), 0, st, records, ovf_base, ovf_base + ovf_cap, idx_out,
+        SNK_HIP_TRY(rocprim::radix_sort_pairs(q, tb, key_in, key_out, idx_in, idx_out, (size_t)n_ovf, 0u, 32u, st));
+        // the grouped copy goes behind all the sub-lists
+        hipLaunchKernelGGL(ovf_gather_kernel, dim3((n_ovf + 255) / 256), dim3(256), 0, st, records, ovf_base, ovf_base + sub_cap * SNK_OVF_SUBLISTS, idx_out,
                            key_out, n_ovf, NB, records, seg);
     }
     SNK_HIP_TRY(hipGetLastError());
@@ -549,22 +586,27 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
     snk_phase_timer kt(st);
     void* records = nullptr;
     uint32_t* ovf_bucket = nullptr;
+    uint32_t* ovf_cur = nullptr;        // [SNK_OVF_SUBLISTS] the sub-lists' cursors
+    { void* q; if ((rc = snk_ctx_alloc(ctx, SNK_OVF_SUBLISTS * 4 + 64, &q, err, errcap))) return rc; ovf_cur = (uint32_t*)q; }
     uint32_t h_novf = 0;
+    uint32_t h_sub[SNK_OVF_SUBLISTS];
     unsigned long long h_total = 0;
     for (int attempt = 0; attempt < 3; ++attempt) {
+        ovf_cap = (ovf_cap + SNK_OVF_SUBLISTS - 1) / SNK_OVF_SUBLISTS * SNK_OVF_SUBLISTS;
         if (ovf_cap >= (1ull << 31)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "supermer overflow list too large");
+        const uint64_t sub_cap = ovf_cap / SNK_OVF_SUBLISTS;
         void* q;
         if ((rc = snk_ctx_alloc(ctx, ((size_t)NB * cap + 2 * ovf_cap) * 32 + 64, &records, err, errcap))) return rc;
         if ((rc = snk_ctx_alloc(ctx, ovf_cap * 4 + 64, &q, err, errcap))) return rc; ovf_bucket = (uint32_t*)q;
         SNK_HIP_TRY(hipMemsetAsync(cursor, 0, (NB + 1) * 4ull, st));
-        SNK_HIP_TRY(hipMemsetAsync(status + 8, 0, 4, st));
+        SNK_HIP_TRY(hipMemsetAsync(ovf_cur, 0, SNK_OVF_SUBLISTS * 4, st));
         snk_msp_args ma;
         memset(&ma, 0, sizeof ma);
         ma.rows = (const uint32_t*)in->rows; ma.row_words = in->row_words; ma.read_len = in->read_len; ma.good_len = good_len; ma.bc = (const int32_t*)in->bc;
         ma.ign_bc_below = in->ign_bc_below; ma.read_index_base = in->read_index_base; ma.n_reads = n_reads; ma.NB = NB;
         ma.group = grouped ? (const uint32_t*)in->group : nullptr;
-        ma.cursor = cursor; ma.records = (uint4*)records; ma.cap = cap; ma.ovf_cap = (uint32_t)ovf_cap;
-        ma.ovf_base = (uint64_t)NB * cap; ma.ovf_bucket = ovf_bucket; ma.ovf_cursor = status + 8;
+        ma.cursor = cursor; ma.records = (uint4*)records; ma.cap = cap; ma.ovf_cap = (uint32_t)sub_cap;
+        ma.ovf_base = (uint64_t)NB * cap; ma.ovf_bucket = ovf_bucket; ma.ovf_cursor = ovf_cur;
         ma.dbg = env_u32("SNK_MSP_DBG", 0);
         if (ft) {
             ma.good_len = ft->good_out; ma.quals = (const uint8_t*)ft->quals; ma.qstride = ft->qstride; ma.min_qual = ft->min_qual;
@@ -579,7 +621,7 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
         // host wants to know about this pass (overflow count, supermers, and the caller's trim statistics if asked for)
         SNK_HIP_TRY(hipMemsetAsync(d_total, 0, 64 * 8, st));
         hipLaunchKernelGGL(seg0_kernel, dim3((NB + 255) / 256), dim3(256), 0, st, cursor, NB, cap, seg, d_total);
-        SNK_HIP_TRY(hipMemcpyAsync(&h_novf, status + 8, 4, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(hipMemcpyAsync(h_sub, ovf_cur, sizeof h_sub, hipMemcpyDeviceToHost, st));
         unsigned long long h_tot64[64];
         SNK_HIP_TRY(hipMemcpyAsync(h_tot64, d_total, sizeof h_tot64, hipMemcpyDeviceToHost, st));
         if (d_plan && h_plan && !ft) SNK_HIP_TRY(hipMemcpyAsync(h_plan, d_plan, 16, hipMemcpyDeviceToHost, st));
@@ -591,15 +633,19 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
             h_plan[0] = h_plan[1] = 0;
             for (int q = 0; q < SNK_MSP_PLAN_SLOTS; ++q) { h_plan[0] += h_fplan[2 * q]; h_plan[1] += h_fplan[2 * q + 1]; }
         }
-        ctx->last_ovf = h_novf; ctx->last_ovf_nb = NB; ctx->last_ovf_reads = n_reads;
-        if (h_novf <= ovf_cap) break;
-        if (attempt == 2) return snk_fail(SNK_E_INTERNAL, err, errcap, "supermer overflow list too small (%u > %llu)", h_novf, (unsigned long long)ovf_cap);
+        // every sub-list within its slots?  (the wanted total sizes the next call's list, the largest sub-list a re-run's)
+        uint64_t want = 0, mx = 0;
+        for (uint32_t q2 = 0; q2 < SNK_OVF_SUBLISTS; ++q2) { want += h_sub[q2]; if (h_sub[q2] > mx) mx = h_sub[q2]; }
+        h_novf = (uint32_t)(want > 0xFFFFFFFFull ? 0xFFFFFFFFull : want);
+        ctx->last_ovf = (uint32_t)(mx * SNK_OVF_SUBLISTS > 0xFFFFFFFFull ? 0xFFFFFFFFull : mx * SNK_OVF_SUBLISTS); ctx->last_ovf_nb = NB; ctx->last_ovf_reads = n_reads;
+        if (mx <= sub_cap) break;
+        if (attempt == 2) return snk_fail(SNK_E_INTERNAL, err, errcap, "supermer overflow list too small (%llu > %llu)", (unsigned long long)mx, (unsigned long long)sub_cap);
         snk_ctx_release_block(ctx, records);
         snk_ctx_release_block(ctx, ovf_bucket);
-        ovf_cap = (uint64_t)h_novf + 65536;
+        ovf_cap = (mx + mx / 8 + 1024) * SNK_OVF_SUBLISTS;
     }
     // segment 1: the overflow records grouped by bucket
-    if ((rc = snk_msp_segments(ctx, st, NB, cap, cursor, (uint4*)records, (uint64_t)NB * cap, ovf_cap, ovf_bucket, h_novf, seg, err, errcap))) return rc;
+    if ((rc = snk_msp_segments(ctx, st, NB, cap, cursor, (uint4*)records, (uint64_t)NB * cap, ovf_cap / SNK_OVF_SUBLISTS, ovf_bucket, h_sub, seg, err, errcap))) return rc;
     out->NB = NB;
     out->cap = cap;
     out->nseg = h_novf ? 2u : 1u;
@@ -650,7 +696,7 @@ int snk_partition_open(snk_ctx* ctx, hipStream_t st, uint32_t K, uint32_t NB, un
     partition_capacity(ctx, K, NB, n_inst_ub, n_live_ub, grouped, &est_super, &cap64);
     if (cap64 * NB >= (1ull << 40) || cap64 >= (1ull << 31)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "bucket capacity out of range");
     J->K = K; J->NB = NB; J->cap = (uint32_t)cap64; J->grouped = grouped; J->status = status;
-    J->ovf_cap = (uint64_t)(est_super / 6) + (1u << 20);
+    J->ovf_cap = ((uint64_t)(est_super / 6) + (1u << 20) + SNK_OVF_SUBLISTS - 1) / SNK_OVF_SUBLISTS * SNK_OVF_SUBLISTS;
     if (J->ovf_cap >= (1ull << 31)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "supermer overflow list too large");
     int rc;
     void* q;
@@ -660,8 +706,9 @@ int snk_partition_open(snk_ctx* ctx, hipStream_t st, uint32_t K, uint32_t NB, un
     if ((rc = snk_ctx_alloc(ctx, 2ull * SNK_MSP_PLAN_SLOTS * 8, &q, err, errcap))) return rc; J->d_plan = (unsigned long long*)q;
     if ((rc = snk_ctx_alloc(ctx, ((size_t)NB * J->cap + 2 * J->ovf_cap) * 32 + 64, &J->records, err, errcap))) return rc;
     if ((rc = snk_ctx_alloc(ctx, J->ovf_cap * 4 + 64, &q, err, errcap))) return rc; J->ovf_bucket = (uint32_t*)q;
+    if ((rc = snk_ctx_alloc(ctx, SNK_OVF_SUBLISTS * 4 + 64, &q, err, errcap))) return rc; J->ovf_cur = (uint32_t*)q;
     SNK_HIP_TRY(hipMemsetAsync(J->cursor, 0, (NB + 1) * 4ull, st));
-    SNK_HIP_TRY(hipMemsetAsync(status + 8, 0, 4, st));
+    SNK_HIP_TRY(hipMemsetAsync(J->ovf_cur, 0, SNK_OVF_SUBLISTS * 4, st));
     SNK_HIP_TRY(hipMemsetAsync(J->d_plan, 0, 2ull * SNK_MSP_PLAN_SLOTS * 8, st));
     return SNK_OK;
 }
@@ -677,8 +724,8 @@ int snk_partition_add(snk_ctx* ctx, hipStream_t st, snk_partition_job* J, const 
     ma.rows = (const uint32_t*)in->rows; ma.row_words = in->row_words; ma.read_len = in->read_len; ma.good_len = good_len; ma.bc = (const int32_t*)in->bc;
     ma.ign_bc_below = in->ign_bc_below; ma.read_index_base = in->read_index_base; ma.n_reads = in->n_reads; ma.NB = J->NB;
     ma.group = J->grouped ? (const uint32_t*)in->group : nullptr;
-    ma.cursor = J->cursor; ma.records = (uint4*)J->records; ma.cap = J->cap; ma.ovf_cap = (uint32_t)J->ovf_cap;
-    ma.ovf_base = (uint64_t)J->NB * J->cap; ma.ovf_bucket = J->ovf_bucket; ma.ovf_cursor = J->status + 8;
+    ma.cursor = J->cursor; ma.records = (uint4*)J->records; ma.cap = J->cap; ma.ovf_cap = (uint32_t)(J->ovf_cap / SNK_OVF_SUBLISTS);
+    ma.ovf_base = (uint64_t)J->NB * J->cap; ma.ovf_bucket = J->ovf_bucket; ma.ovf_cursor = J->ovf_cur;
     if (ft) {
         ma.good_len = ft->good_out; ma.quals = (const uint8_t*)ft->quals; ma.qstride = ft->qstride; ma.min_qual = ft->min_qual;
         ma.lens = (const uint16_t*)ft->lens; ma.good_out = ft->good_out; ma.plan = J->d_plan;
@@ -705,9 +752,10 @@ int snk_partition_close(snk_ctx* ctx, hipStream_t st, snk_partition_job* J, snk_
     SNK_HIP_TRY(hipMemsetAsync(J->d_total, 0, 64 * 8, st));
     hipLaunchKernelGGL(seg0_kernel, dim3((NB + 255) / 256), dim3(256), 0, st, J->cursor, NB, J->cap, J->seg, J->d_total);
     uint32_t h_novf = 0;
+    uint32_t h_sub[SNK_OVF_SUBLISTS];
     unsigned long long h_tot64[64];
     std::vector<unsigned long long> h_fplan(2 * SNK_MSP_PLAN_SLOTS);
-    SNK_HIP_TRY(hipMemcpyAsync(&h_novf, J->status + 8, 4, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipMemcpyAsync(h_sub, J->ovf_cur, sizeof h_sub, hipMemcpyDeviceToHost, st));
     SNK_HIP_TRY(hipMemcpyAsync(h_tot64, J->d_total, sizeof h_tot64, hipMemcpyDeviceToHost, st));
     SNK_HIP_TRY(hipMemcpyAsync(h_fplan.data(), J->d_plan, h_fplan.size() * 8, hipMemcpyDeviceToHost, st));
     SNK_HIP_TRY(snk_sync(st));
@@ -715,11 +763,14 @@ int snk_partition_close(snk_ctx* ctx, hipStream_t st, snk_partition_job* J, snk_
     for (int q = 0; q < 64; ++q) h_total += h_tot64[q];
     h_plan[0] = h_plan[1] = 0;
     for (int q = 0; q < SNK_MSP_PLAN_SLOTS; ++q) { h_plan[0] += h_fplan[2 * q]; h_plan[1] += h_fplan[2 * q + 1]; }
-    if (h_novf > J->ovf_cap)
+    uint64_t want = 0, mx = 0;
+    for (uint32_t q = 0; q < SNK_OVF_SUBLISTS; ++q) { want += h_sub[q]; if (h_sub[q] > mx) mx = h_sub[q]; }
+    h_novf = (uint32_t)(want > 0xFFFFFFFFull ? 0xFFFFFFFFull : want);
+    if (mx > J->ovf_cap / SNK_OVF_SUBLISTS)
         return snk_fail(SNK_E_NOMEM, err, errcap, "streamed partition: %u supermers beyond their buckets' capacity, the overflow list holds %llu (the job's read total was "
-                        "underestimated, or one minimiser carries a large share of the data): run it resident or with a larger total", h_novf, (unsigned long long)J->ovf_cap);
+                        "underestimated, or a few minimisers carry a large share of the data): run it resident or with a larger total", h_novf, (unsigned long long)J->ovf_cap);
     int rc;
-    if ((rc = snk_msp_segments(ctx, st, NB, J->cap, J->cursor, (uint4*)J->records, (uint64_t)NB * J->cap, J->ovf_cap, J->ovf_bucket, h_novf, J->seg, err, errcap))) return rc;
+    if ((rc = snk_msp_segments(ctx, st, NB, J->cap, J->cursor, (uint4*)J->records, (uint64_t)NB * J->cap, J->ovf_cap / SNK_OVF_SUBLISTS, J->ovf_bucket, h_sub, J->seg, err, errcap))) return rc;
     out->NB = NB;
     out->cap = J->cap;
     out->nseg = h_novf ? 2u : 1u;

@@ -49,7 +49,7 @@ class Result:
         self.K = K
         for f in ("n_reads", "n_instances", "n_supermers", "n_buckets", "n_kmers", "n_unitigs", "unitig_total_bases",
                   "n_circles", "rank_rounds", "buckets_split", "max_slots_used", "scratch_bytes", "n_boundary", "n_overflow",
-                  "n_fragments", "repartitioned"):
+                  "n_fragments", "repartitioned", "n_hot_buckets"):
             setattr(self, f, int(getattr(raw, f)))
         self.phase_ms = {PHASES[i]: float(raw.phase_ms[i]) for i in range(8) if PHASES[i] != "-"}
         self.kernel_ms = {"partition": float(raw.kernel_ms[1]),

@@ -95,3 +95,32 @@ def ingest_fasth(engine, paths, read_len: int, whitelist: bytes | None = None, t
         if ix:
             lib.snk_bc_index_destroy(ix)
     return DeviceReads(lib, raw)
+
+
+def ingest_count_graph(engine, paths, read_len: int, whitelist: bytes | None = None, params=None, threads: int = 0, batch_pairs: int = 0,
+                       total_reads_hint: int = 0):
+    """FASTH files -> (Result, stats) with the reads never resident as a whole (snk_dev_ingest_count_graph): every decoded batch is
+    partitioned into the job's minimiser buckets while the next ones are being inflated."""
+    from .engine import Params, Result
+    lib = engine.lib
+    params = params or Params()
+    err = C.create_string_buffer(512)
+    ix = C.c_void_p()
+    if whitelist is not None:
+        rc = lib.snk_bc_index_create(engine._ctx, whitelist, len(whitelist), C.byref(ix), err, 512)
+        if rc:
+            raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+    try:
+        arr = (C.c_char_p * len(paths))(*[str(p).encode() for p in paths])
+        raw, res, p = _lib.SnkDevIngest(), _lib.SnkDevResult(), params.to_c()
+        rc = lib.snk_dev_ingest_count_graph(engine._ctx, arr, len(paths), read_len, ix, threads, batch_pairs, int(total_reads_hint), C.byref(p), C.byref(res),
+                                            C.byref(raw), err, 512)
+        if rc:
+            raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+    finally:
+        if ix:
+            lib.snk_bc_index_destroy(ix)
+    stats = dict(n_reads=int(raw.n_reads), text_bytes=int(raw.text_bytes), compressed_bytes=int(raw.compressed_bytes), seconds=float(raw.seconds),
+                 decode_wait_seconds=float(raw.decode_wait_seconds), n_files=int(raw.n_files), n_batches=int(raw.n_batches), max_len=int(raw.max_len),
+                 setup_seconds=float(raw.setup_seconds))
+    return Result(engine, res, params.K), stats

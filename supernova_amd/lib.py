@@ -50,7 +50,7 @@ class SnkDevResult(C.Structure):
                 ("buckets_split", C.c_uint32), ("max_slots_used", C.c_uint32), ("n_overflow", C.c_uint32),
                 ("scratch_bytes", C.c_uint64), ("phase_ms", C.c_float * 8), ("kernel_ms", C.c_float * 4),
                 ("n_boundary", C.c_uint64), ("n_fragments", C.c_uint64), ("unitig_group", C.c_void_p),
-                ("graph_ms", C.c_float * 8), ("repartitioned", C.c_uint32), ("reserved0", C.c_uint32)]
+                ("graph_ms", C.c_float * 8), ("repartitioned", C.c_uint32), ("n_hot_buckets", C.c_uint32)]
 
 
 class SnkShardFrags(C.Structure):
@@ -248,6 +248,7 @@ def _declare(lib: C.CDLL) -> None:
         "snk_fasth_close": (None, [vp]),
         "snk_dev_ingest_fasth": (C.c_int, [vp, P(cp), u32, u32, vp, u32, u32, P(SnkDevIngest), cp, sz]),
         "snk_dev_ingest_free": (None, [P(SnkDevIngest)]),
+        "snk_dev_ingest_count_graph": (C.c_int, [vp, P(cp), u32, u32, vp, u32, u32, u64, P(SnkParams), P(SnkDevResult), P(SnkDevIngest), cp, sz]),
         "snk_synth_fasth_write": (C.c_int, [cp, P(SnkSynthParams), u64, u64, C.c_int, P(u64), cp, sz]),
         "snk_synth_bc_seq": (None, [u32, vp]),
         "snk_comm_set_rccl_path": (C.c_int, [cp]),

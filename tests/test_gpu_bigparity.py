@@ -35,7 +35,7 @@ def _compare(dg, exp, fields=FIELDS):
 
 @pytest.mark.parametrize("name", ["c1_2m", "c1_10m", "c1_2m_k60", "c1_10m_k60", "robust_err06_200k", "robust_err15_200k", "robust_cov28_200k",
                                   "robust_repeats_200k", "robust_repeats_1m", "robust_repeats_200k_k60"])
-def test_one_gpu_vs_reference_digest(snk, name):
+def test_one_gpu_vs_reference_digest(snk, name, monkeypatch):
     import torch
     from supernova_amd import synth
     from supernova_amd.engine import Engine, Params
@@ -43,6 +43,11 @@ def test_one_gpu_vs_reference_digest(snk, name):
     K = exp["K"]
     e = Engine(0)
     try:
+        if name == "robust_repeats_1m":
+            # at this size the repeat families are 100 copies deep: with the threshold down, their minimiser buckets take the hot path
+            # (snk_hot.hip) the 100 M-read runs of bench.py config.robust take on their own
+            monkeypatch.setenv("SNK_HOT_MIN", "1000")
+            monkeypatch.setenv("SNK_HOT_FACTOR", "1")
         sp = synth.synth_params(exp["n_reads"], seed=exp["seed"], **exp.get("overrides", {}))
         rows, quals, bc = e.synth(sp)
         # the reference's K=60 variant has no barcode rule: run without a barcode vector there
@@ -55,6 +60,8 @@ def test_one_gpu_vs_reference_digest(snk, name):
             hist = np.bincount(np.minimum(res.counts(), (1 << 24) - 1)).astype(np.int64)
             dg["hist"] = bighash.digest(np.zeros(0), np.zeros((0, 4)), [], [], [], hist)["hist"]
         _compare(dg, exp)
+        if name == "robust_repeats_1m":
+            assert res.n_hot_buckets > 0
     finally:
         e.close()
         torch.cuda.empty_cache()
