@@ -200,7 +200,8 @@ def ingest_row(eng, args, K, step_ms_per_read):
         return {"files": nf, "reads": n, "text_GB": text / 1e9, "compressed_GB": best["compressed_bytes"] / 1e9, "seconds": secs, "fasth_to_unitigs_streamed": e2e,
                 "text_GB_per_s": text / secs / 1e9, "reads_per_s": n / secs, "decode_wait_share": best["decode_wait_seconds"] / secs,
                 "setup_seconds": best["setup_seconds"], "text_GB_per_s_after_setup": text / max(secs - best["setup_seconds"], 1e-9) / 1e9,
-                "decode_threads": args.ingest_threads or min(nf, os.cpu_count() or 1), "host_threads": os.cpu_count(),
+                "decode_threads": args.ingest_threads or min(nf, max(1, int(eng.lib.snk_host_cpu_budget()) - 2)), "host_threads": os.cpu_count(),
+                "host_cpu_budget": int(eng.lib.snk_host_cpu_budget()),      # the cgroup's CPU quota when there is one: what host-side inflate can use at all
                 "count_graph_on_ingested": {"retained_kmers": n_k, "unitigs": n_u},
                 # how long the device step of the same reads is against their ingest: the share of the ingest the step hides behind
                 "step_over_ingest": (step_ms_per_read * n * 1e-3) / secs, "synth_files_written_in_s": t_write}
@@ -240,6 +241,7 @@ def robust_rows(eng, per_gpu, K, headline_ms):
         out[name] = {"ms": round(ms, 2), "Gkmers_per_s": round(r.n_instances / ms / 1e6, 2), "vs_headline_ms": round(ms / headline_ms, 3),
                      "first_call_ms": round(calls[0][0], 2), "first_call_repartitioned": calls[0][1], "calls_ms": [round(c[0], 1) for c in calls],
                      "phase_ms": {k: round(v, 2) for k, v in r.phase_ms.items() if k in ("partition", "count", "graph")},
+                     "graph_ms": {k: round(v, 2) for k, v in r.graph_ms.items()}, "hot_buckets": int(r.n_hot_buckets),
                      "buckets": int(r.n_buckets), "buckets_split": int(r.buckets_split), "overflow_supermers": int(r.n_overflow),
                      "retained_kmers": int(r.n_kmers), "unitigs": int(r.n_unitigs)}
         del rows, quals, bc, r

@@ -30,6 +30,7 @@ struct snk_ctx {
     uint32_t last_ovf = 0, last_ovf_nb = 0;             // overflow supermers of the last partition pass and its bucket count
     uint64_t last_ovf_reads = 0;
     uint64_t last_dense = 0;                            // supermer records of the last dense partition pass (last_ovf_nb == 0xD0000000)
+    double retain_ratio = 0.0;                         // retained k-mers per k-mer instance of the last call (same key as claim_ratio)
     double claim_ratio = 0.0;                          // distinct k-mers per k-mer instance the count kernel saw in the last call ...
     uint64_t claim_ratio_reads = 0;                    // ... over this many reads ...
     uint32_t claim_ratio_k = 0;                        // ... in this mode (2 K + grouped)

@@ -807,9 +807,9 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
               uint32_t flags, snk_dev_paths* out, char* err, size_t errcap) {
     int rc;
     const uint64_t n = in->n_reads;
-    hipEvent_t e0, e1, e2, e3;
-    SNK_HIP_TRY(hipEventCreate(&e0)); SNK_HIP_TRY(hipEventCreate(&e1)); SNK_HIP_TRY(hipEventCreate(&e2)); SNK_HIP_TRY(hipEventCreate(&e3));
-    struct evg { hipEvent_t a, b, c, d; ~evg() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipEventDestroy(c); (void)hipEventDestroy(d); } } g{e0, e1, e2, e3};
+    hipEvent_t e0, e1, e2, e3, e2b;
+    SNK_HIP_TRY(hipEventCreate(&e0)); SNK_HIP_TRY(hipEventCreate(&e1)); SNK_HIP_TRY(hipEventCreate(&e2)); SNK_HIP_TRY(hipEventCreate(&e3)); SNK_HIP_TRY(hipEventCreate(&e2b));
+    struct evg { hipEvent_t a, b, c, d, e; ~evg() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipEventDestroy(c); (void)hipEventDestroy(d); (void)hipEventDestroy(e); } } g{e0, e1, e2, e3, e2b};
     SNK_HIP_TRY(hipEventRecord(e0, st));
     // ---- graph tables (host: O(U + E)), in the device's unitig numbering
     const int32_t N = h->n_vertices, E = h->n_edges;
@@ -1034,25 +1034,35 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
             ubk = xk;
             nkeys = hx;
         }
+        // Everything this stage allocates is allocated HERE, in front of its timed interval (seven arena allocations, one
+        // of which could land on a hipMalloc, and a temp-size query sat inside it -- 76 ms on the driver's box against 7 ms here): the
+        // barcode array gets its upper bound (one entry per key) instead of waiting for the distinct count.
         unsigned long long* ks;
         uint64_t *flag, *upos, *per_u, *uoff_out;
         uint32_t* bcs = nullptr;
+        // the key is unitig << 32 | barcode: only the bits that can differ are sorted (the unitig field's all-ones pattern is above every
+        // unitig id, so the unused first-key slots -- all ones -- still sort behind everything)
+        unsigned ubits = 1;
+        while (ubits < 32 && (1ull << ubits) < U + 2) ++ubits;
+        const unsigned end_bit = 32 + ubits;
+        size_t tb = 0;
+        uint8_t* tmp = nullptr;
         if ((rc = dev(ctx, nkeys + 1, &ks, err, errcap)) || (rc = dev(ctx, nkeys + 2, &flag, err, errcap)) || (rc = dev(ctx, nkeys + 2, &upos, err, errcap)) ||
-            (rc = dev(ctx, U + 2, &per_u, err, errcap)) || (rc = dev(ctx, U + 2, &uoff_out, err, errcap)))
+            (rc = dev(ctx, U + 2, &per_u, err, errcap)) || (rc = dev(ctx, U + 2, &uoff_out, err, errcap)) || (rc = dev(ctx, nkeys + 1, &bcs, err, errcap)))
             return rc;
+        if (nkeys) {
+            SNK_HIP_TRY(rocprim::radix_sort_keys((void*)nullptr, tb, ubk, ks, (size_t)nkeys, 0u, end_bit, st));
+            if ((rc = dev(ctx, tb, &tmp, err, errcap))) return rc;
+        }
+        SNK_HIP_TRY(hipEventRecord(e2b, st));
         uint64_t n_unique = 0;
         if (nkeys) {
-            size_t tb = 0;
-            SNK_HIP_TRY(rocprim::radix_sort_keys((void*)nullptr, tb, ubk, ks, (size_t)nkeys, 0u, 64u, st));
-            uint8_t* tmp;
-            if ((rc = dev(ctx, tb, &tmp, err, errcap))) return rc;
-            SNK_HIP_TRY(rocprim::radix_sort_keys(tmp, tb, ubk, ks, (size_t)nkeys, 0u, 64u, st));
+            SNK_HIP_TRY(rocprim::radix_sort_keys(tmp, tb, ubk, ks, (size_t)nkeys, 0u, end_bit, st));
             hipLaunchKernelGGL(ubc_flag_kernel, dim3((unsigned)((nkeys + 256) / 256)), dim3(256), 0, st, ks, nkeys, flag);
             if ((rc = scan64(ctx, st, flag, upos, nkeys + 1, err, errcap))) return rc;
             SNK_HIP_TRY(hipMemcpyAsync(&n_unique, upos + nkeys, 8, hipMemcpyDeviceToHost, st));
             SNK_HIP_TRY(snk_sync(st));
         }
-        if ((rc = dev(ctx, n_unique + 1, &bcs, err, errcap))) return rc;
         SNK_HIP_TRY(hipMemsetAsync(per_u, 0, (U + 2) * 8, st));
         if (nkeys) hipLaunchKernelGGL(ubc_scatter_kernel, dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, st, ks, flag, upos, nkeys, bcs, per_u);
         if ((rc = scan64(ctx, st, per_u, uoff_out, U + 1, err, errcap))) return rc;
@@ -1088,7 +1098,7 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
         out->n_unitig_bcs = n_unique;
         SNK_HIP_TRY(hipEventRecord(e3, st));
         SNK_HIP_TRY(snk_sync(st));
-        (void)hipEventElapsedTime(&out->bcs_ms, e2, e3);
+        (void)hipEventElapsedTime(&out->bcs_ms, e2b, e3);
     }
     return SNK_OK;
 }

@@ -40,7 +40,8 @@ static int graph_tail(snk_ctx* ctx, hipStream_t st, const snk_params* p, uint32_
                       snk_table& tab, const snk_partition& part, snk_dev_result* out, phase_timer& tm, char* err, size_t errcap) {
     int rc;
     void* records = part.records;
-    if (h_ninst) { ctx->claim_ratio = (double)tab.distinct / (double)h_ninst; ctx->claim_ratio_reads = n_reads; ctx->claim_ratio_k = K * 2 + (grouped ? 1u : 0u); }
+    if (h_ninst) { ctx->claim_ratio = (double)tab.distinct / (double)h_ninst; ctx->claim_ratio_reads = n_reads; ctx->claim_ratio_k = K * 2 + (grouped ? 1u : 0u);
+                   ctx->retain_ratio = (double)tab.n / (double)h_ninst; }
     snk_ctx_release_block(ctx, records);       // the fixed-capacity supermer slots: the graph stage may reuse the memory
     const uint64_t n_kmers = tab.n;
     out->buckets_split = tab.buckets_split;
@@ -164,8 +165,26 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     // looks at its first 1/64 of the buckets and asks for a second partition when they overflow as a rule.
     const uint32_t default_target = grouped ? 900u : (K == 48 ? 5000u : 3500u);
     const bool target_forced = getenv("SNK_TARGET_INST") && *getenv("SNK_TARGET_INST");
+    // ... and the RETAINED k-mers of a bucket are one chunk of the bucket-local graph stage, whose one-wave kernels hold 256 of them
+    // (larger chunks take the slower big-chunk variants): at half the coverage twice as many k-mers survive per instance, every other
+    // chunk was over the line and the graph stage took 81 instead of ~58 ms.  From the previous call's retained share: chunks of ~150.
+    const double retain = (ctx->retain_ratio > 0.0 && ctx->claim_ratio_reads == n_reads && ctx->claim_ratio_k == K * 2 + (grouped ? 1u : 0u)) ? ctx->retain_ratio : 0.0;
     auto target_for = [&](double ratio) -> uint32_t {
         if (target_forced) return env_u32("SNK_TARGET_INST", default_target);
+        if (retain > 0.0 && !grouped) {
+            const double t = (double)env_u32("SNK_CHUNK_KMERS", 150) / retain;
+            if (t < (double)default_target) {
+                uint32_t tt = t < 600.0 ? 600u : (uint32_t)t;
+                if (ratio > 0.0) {           // the tighter of the two limits
+                    const double lim = (double)snk_count_limit(K, 0u);
+                    if (0.65 * lim / ratio < (double)default_target) {
+                        const double t2 = 0.01 * env_u32("SNK_BUCKET_FILL_PCT", 50) * lim / ratio;
+                        if (t2 < (double)tt) tt = t2 < 600.0 ? 600u : (uint32_t)t2;
+                    }
+                }
+                return tt;
+            }
+        }
         if (!(ratio > 0.0)) return default_target;
         // measured: the default size is right while the tables run up to ~65 % full on average (the bench model: 800 of 1216); data
         // that would fill them further do best at ~50 % (0.6 % errors: 239 ms with the default size, 186 at 80 %, 154 at 50 %)

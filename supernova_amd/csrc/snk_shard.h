@@ -4,6 +4,7 @@
 #include "snk_graph.h"
 #include "snk_kernels.h"
 #include "snk_stages.h"
+#include "snk_shard_phases.h"
 
 struct snk_shard_state {
     snk_dev_reads reads;

@@ -53,21 +53,6 @@ class SnkDevResult(C.Structure):
                 ("graph_ms", C.c_float * 8), ("repartitioned", C.c_uint32), ("n_hot_buckets", C.c_uint32)]
 
 
-class SnkShardFrags(C.Structure):
-    _fields_ = [("n_kmers", C.c_uint64), ("keys", C.c_void_p), ("counts", C.c_void_p), ("ctx", C.c_void_p),
-                ("spectrum", C.c_void_p), ("spectrum_bins", C.c_uint32), ("n_circles", C.c_uint32),
-                ("n_frags", C.c_uint64), ("total_bases", C.c_uint64), ("nk", C.c_void_p), ("hl_self", C.c_void_p),
-                ("hl_nb", C.c_void_p), ("boff", C.c_void_p), ("bases", C.c_void_p), ("rank_rounds", C.c_uint32),
-                ("buckets_split", C.c_uint32), ("max_slots_used", C.c_uint32), ("reserved", C.c_uint32),
-                ("count_ms", C.c_float), ("sort_ms", C.c_float), ("count_kernel_ms", C.c_float), ("reserved_f", C.c_float)]
-
-
-class SnkShardUnitigs(C.Structure):
-    _fields_ = [("n_unitigs", C.c_uint64), ("total_bases", C.c_uint64), ("unitig_off", C.c_void_p),
-                ("unitig_bases", C.c_void_p), ("unitig_circular", C.c_void_p), ("n_circles", C.c_uint32),
-                ("rank_rounds", C.c_uint32)]
-
-
 class SnkReads(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("read_len", C.c_uint32), ("reserved", C.c_uint32), ("ascii", C.c_void_p),
                 ("rows", C.c_void_p), ("lens", C.c_void_p), ("quals", C.c_void_p), ("good_len", C.c_void_p),
@@ -219,28 +204,7 @@ def _declare(lib: C.CDLL) -> None:
         "snk_pack2_bytes": (u64, [u64]),
         "snk_dev_pack2": (C.c_int, [vp, vp, u64, vp, vp]),
         "snk_dev_unpack2": (C.c_int, [vp, vp, u64, vp, vp]),
-        "snk_shard_hist": (C.c_int, [vp, P(SnkDevReads), P(SnkParams), u32, u32, u32, vp, P(u64), vp, cp, sz]),
-        "snk_shard_scatter": (C.c_int, [vp, vp, vp, vp, cp, sz]),
-        "snk_shard_count": (C.c_int, [vp, vp, vp, u64, C.c_int, P(u64), vp, cp, sz]),
-        "snk_shard_count_ranged": (C.c_int, [vp, vp, vp, u64, C.c_int, u32, P(u32), RANGE_READY, vp, P(u64), vp, cp, sz]),
-        "snk_shard_prune_plan": (C.c_int, [vp, P(u64), vp, cp, sz]),
-        "snk_shard_prune_fill": (C.c_int, [vp, vp, vp, vp, cp, sz]),
-        "snk_shard_prune_answer": (C.c_int, [vp, vp, u64, vp, vp, cp, sz]),
-        "snk_shard_prune_apply": (C.c_int, [vp, vp, vp, u64, vp, vp, cp, sz]),
-        "snk_shard_fragments": (C.c_int, [vp, vp, u64, P(SnkShardFrags), vp, cp, sz]),
-        "snk_shard_join": (C.c_int, [vp, u32, u64, vp, vp, vp, vp, vp, u64, P(SnkShardUnitigs), vp, cp, sz]),
-        "snk_shard_join_linked": (C.c_int, [vp, u32, u64, vp, vp, vp, vp, vp, vp, u64, P(SnkShardUnitigs), vp, cp, sz]),
-        "snk_shard_links_plan": (C.c_int, [vp, u64, P(u64), vp, cp, sz]),
-        "snk_shard_links_fill": (C.c_int, [vp, vp, vp, vp, cp, sz]),
-        "snk_shard_links_answer": (C.c_int, [vp, vp, u64, vp, vp, cp, sz]),
-        "snk_shard_links_apply": (C.c_int, [vp, vp, vp, u64, P(vp), vp, cp, sz]),
-        "snk_shard_place": (C.c_int, [vp, u32, u64, vp, vp, vp, u64, P(u64), P(u64), vp, cp, sz]),
-        "snk_shard_prank_begin": (C.c_int, [vp, u64, vp, vp, u64, P(u64), P(vp), vp, cp, sz]),
-        "snk_shard_prank_walk": (C.c_int, [vp, vp, vp, P(u64), P(u32), vp, cp, sz]),
-        "snk_shard_prank_route": (C.c_int, [vp, vp, vp, vp, vp, cp, sz]),
-        "snk_shard_place_ranked": (C.c_int, [vp, u32, vp, u64, vp, P(u64), P(u64), vp, cp, sz]),
-        "snk_shard_route_fill": (C.c_int, [vp, u32, vp, vp, vp, vp, vp, vp, cp, sz]),
-        "snk_shard_emit": (C.c_int, [vp, u32, u64, vp, vp, vp, vp, P(SnkShardUnitigs), vp, cp, sz]),
+        "snk_host_cpu_budget": (u32, []),
         "snk_fasth_open": (C.c_int, [P(cp), u32, u32, u32, u32, u32, P(vp), cp, sz]),
         "snk_fasth_next": (C.c_int, [vp, P(SnkFasthBatch), cp, sz]),
         "snk_fasth_release": (None, [vp, P(SnkFasthBatch)]),
