@@ -24,7 +24,9 @@ if [ ! -d "$S" ]; then
   echo "build_ref: $S not present (GPU box?) -- keeping prebuilt oracle/_ref as is"; exit 0
 fi
 mkdir -p "$OUT"
-if [ -x "$OUT/snref_driver" ] && [ "$OUT/snref_driver" -nt "$HERE/ref_driver.cc" ] && [ "$OUT/snref_driver" -nt "$0" ]; then
+LIBSNK=$HERE/../../supernova_amd/libsnk.so
+if [ -x "$OUT/snref_driver" ] && [ "$OUT/snref_driver" -nt "$HERE/ref_driver.cc" ] && [ "$OUT/snref_driver" -nt "$0" ] &&
+   { [ ! -f "$LIBSNK" ] || { [ -x "$OUT/snref_seam" ] && [ "$OUT/snref_seam" -nt "$HERE/seam_driver.cc" ]; }; }; then
   echo "build_ref: oracle/_ref/snref_driver up to date"; exit 0
 fi
 W=${SNK_REF_WORK:-${TMPDIR:-/tmp}/snk_refbuild.$$}
@@ -83,4 +85,13 @@ $CXX $FLAGS -DSNK_REF_K60 -c "$HERE/ref_driver.cc" -o "$W/obj/ref_driver60.o"
 ar rcs "$W/libref.a" $(ls "$W"/obj/*.o | grep -v -e ref_driver.o -e ref_driver60.o -e LinkTimestamp.o)
 $CXX -fopenmp -Wl,--gc-sections -o "$OUT/snref_driver" "$W/obj/ref_driver.o" "$W/obj/LinkTimestamp.o" "$W/libref.a" -lz -lpthread
 $CXX -fopenmp -Wl,--gc-sections -o "$OUT/snref_driver60" "$W/obj/ref_driver60.o" "$W/obj/LinkTimestamp.o" "$W/libref.a" -lz -lpthread
+# SURVEY 8 row b4 as code: the StageBuildGraph binding of INTEGRATION.md section 1 (seam_driver.cc) compiled against the reference's
+# headers and linked with the reference's objects + libsnk.so + the HIP runtime; it needs a GPU to RUN (tests/test_gpu_seam.py)
+ROCM=${ROCM_PATH:-/opt/rocm}
+if [ -f "$LIBSNK" ] && [ -d "$ROCM/include/hip" ]; then
+  $CXX $FLAGS -D__HIP_PLATFORM_AMD__ -I"$ROCM/include" -c "$HERE/seam_driver.cc" -o "$W/obj/seam_driver.o"
+  $CXX -fopenmp -Wl,--gc-sections -o "$OUT/snref_seam" "$W/obj/seam_driver.o" "$W/obj/LinkTimestamp.o" "$W/libref.a" -lz -lpthread \
+       -L"$(dirname "$LIBSNK")" -lsnk -L"$ROCM/lib" -lamdhip64 -Wl,-rpath,'$ORIGIN/../../supernova_amd' -Wl,-rpath,"$ROCM/lib"
+  echo "build_ref: built $OUT/snref_seam (the DF seam stub against the reference's headers)"
+fi
 echo "build_ref: built $OUT/snref_driver and $OUT/snref_driver60"
