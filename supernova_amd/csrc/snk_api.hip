@@ -1,6 +1,9 @@
 // snk_api.hip -- context, error plumbing, synthetic read generator entry points of libsnk.
 #include <math.h>
 #include <stdlib.h>
+#include <time.h>
+
+#include <algorithm>
 
 #include "snk_ctx.h"
 #include "snk_synth.h"
@@ -77,9 +80,140 @@ extern "C" int snk_ctx_create(int device, snk_ctx** out, char* err, size_t errca
     return SNK_OK;
 }
 
+// ---- the growing arena (snk_ctx.h)
+namespace {
+bool va_init(snk_ctx* ctx) {
+    if (ctx->va_state) return ctx->va_state > 0;
+    ctx->va_state = -1;
+    // opt-in (SNK_ARENA_VMM=1) for now: the one-GPU bench and parity tests run on it, but a full run of the GPU suite aborted inside the
+    // 150 M-read rank-share test of the sharded path with it (not reproduced in isolation), so the default stays the cached blocks
+    const char* on = getenv("SNK_ARENA_VMM");
+    if (!on || *on != '1') return false;
+    size_t sz = (size_t)ctx->device_mem_total;
+    sz = (sz + ((size_t)1 << 30) - 1) & ~(((size_t)1 << 30) - 1);
+    void* base = nullptr;
+    if (hipMemAddressReserve(&base, sz, 0, nullptr, 0) != hipSuccess || !base) { (void)hipGetLastError(); return false; }
+    ctx->va_base = (char*)base;
+    ctx->va_size = sz;
+    ctx->va_state = 1;
+    return true;
+}
+void va_insert_free(std::vector<snk_ctx::vrange>& fr, size_t off, size_t bytes) {
+    size_t i = 0;
+    while (i < fr.size() && fr[i].off < off) ++i;
+    fr.insert(fr.begin() + (long)i, snk_ctx::vrange{off, bytes});
+    if (i + 1 < fr.size() && fr[i].off + fr[i].bytes == fr[i + 1].off) { fr[i].bytes += fr[i + 1].bytes; fr.erase(fr.begin() + (long)i + 1); }
+    if (i > 0 && fr[i - 1].off + fr[i - 1].bytes == fr[i].off) { fr[i - 1].bytes += fr[i].bytes; fr.erase(fr.begin() + (long)i); }
+}
+bool va_trace() { static const bool t = getenv("SNK_ARENA_TRACE") && *getenv("SNK_ARENA_TRACE") == '1'; return t; }
+double va_now() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + 1e-6 * t.tv_nsec; }
+bool va_grow(snk_ctx* ctx, size_t need) {
+    const double t0 = va_now();
+    struct tr { snk_ctx* c; size_t need; double t0; ~tr() { if (va_trace()) fprintf(stderr, "[snk arena] grow by >= %.2f GB -> mapped %.2f GB (%.2f ms)\n", need / 1073741824.0, c->va_mapped / 1073741824.0, va_now() - t0); } } _t{ctx, need, t0};
+    // map `need` more bytes behind what is mapped, in uniform 1-GB chunks at 1-GB aligned addresses (chunks of odd sizes at odd offsets
+    // were refused by hipMemMap now and then: round 4's trace)
+    constexpr size_t CH = (size_t)1 << 30;
+    const size_t n_ch = (need + CH - 1) / CH ? (need + CH - 1) / CH : 1;
+    if (ctx->va_mapped + n_ch * CH > ctx->va_size) return false;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = ctx->device;
+    hipMemAccessDesc acc = {};
+    acc.location.type = hipMemLocationTypeDevice;
+    acc.location.id = ctx->device;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    const size_t mapped0 = ctx->va_mapped;
+    for (size_t q = 0; q < n_ch; ++q) {
+        hipMemGenericAllocationHandle_t h;
+        char* at = ctx->va_base + ctx->va_mapped;
+        bool ok = hipMemCreate(&h, CH, &prop, 0) == hipSuccess;
+        if (ok && hipMemMap(at, CH, 0, h, 0) != hipSuccess) { (void)hipMemRelease(h); ok = false; }
+        if (ok && hipMemSetAccess(at, CH, &acc, 1) != hipSuccess) { (void)hipMemUnmap(at, CH); (void)hipMemRelease(h); ok = false; }
+        if (!ok) {
+            (void)hipGetLastError();
+            if (ctx->va_mapped > mapped0) va_insert_free(ctx->va_free, mapped0, ctx->va_mapped - mapped0);      // what did get mapped is usable
+            return false;
+        }
+        ctx->va_handles.push_back(h);
+        ctx->va_chunk.push_back(CH);
+        ctx->va_mapped += CH;
+        ctx->cached_bytes += CH;
+    }
+    va_insert_free(ctx->va_free, mapped0, ctx->va_mapped - mapped0);
+    return true;
+}
+// unmap the chunks that lie wholly behind `keep` bytes (only called when nothing behind `keep` is in use)
+void va_shrink(snk_ctx* ctx, size_t keep) {
+    const double t0 = va_now();
+    const size_t before = ctx->va_mapped;
+    struct tr { snk_ctx* c; size_t before; double t0; ~tr() { if (va_trace() && c->va_mapped != before) fprintf(stderr, "[snk arena] shrink %.2f -> %.2f GB (%.2f ms)\n", before / 1073741824.0, c->va_mapped / 1073741824.0, va_now() - t0); } } _t{ctx, before, t0};
+    while (!ctx->va_chunk.empty() && ctx->va_mapped - ctx->va_chunk.back() >= keep) {
+        const size_t c = ctx->va_chunk.back();
+        char* at = ctx->va_base + ctx->va_mapped - c;
+        (void)hipMemUnmap(at, c);
+        (void)hipMemRelease(ctx->va_handles.back());
+        ctx->va_handles.pop_back();
+        ctx->va_chunk.pop_back();
+        ctx->va_mapped -= c;
+        ctx->cached_bytes -= c;
+        // the free list loses the tail
+        if (!ctx->va_free.empty()) {
+            snk_ctx::vrange& t = ctx->va_free.back();
+            if (t.off >= ctx->va_mapped) ctx->va_free.pop_back();
+            else if (t.off + t.bytes > ctx->va_mapped) t.bytes = ctx->va_mapped - t.off;
+        }
+    }
+}
+void* va_alloc(snk_ctx* ctx, size_t bytes) {
+    if (!va_init(ctx)) return nullptr;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        for (size_t i = 0; i < ctx->va_free.size(); ++i) {
+            snk_ctx::vrange& f = ctx->va_free[i];
+            if (f.bytes < bytes) continue;
+            const size_t off = f.off;
+            if (f.bytes == bytes) ctx->va_free.erase(ctx->va_free.begin() + (long)i);
+            else { f.off += bytes; f.bytes -= bytes; }
+            ctx->va_used.push_back(snk_ctx::vrange{off, bytes});
+            if (off + bytes > ctx->va_high) ctx->va_high = off + bytes;
+            return ctx->va_base + off;
+        }
+        // nothing fits: grow by what is missing behind a free tail
+        size_t tail = 0;
+        if (!ctx->va_free.empty() && ctx->va_free.back().off + ctx->va_free.back().bytes == ctx->va_mapped) tail = ctx->va_free.back().bytes;
+        if (attempt || !va_grow(ctx, bytes - (tail < bytes ? tail : 0))) return nullptr;
+    }
+    return nullptr;
+}
+bool va_release(snk_ctx* ctx, const void* p) {
+    if (ctx->va_state <= 0 || (const char*)p < ctx->va_base || (const char*)p >= ctx->va_base + ctx->va_size) return false;
+    const size_t off = (size_t)((const char*)p - ctx->va_base);
+    for (size_t i = 0; i < ctx->va_used.size(); ++i)
+        if (ctx->va_used[i].off == off) {
+            const size_t b = ctx->va_used[i].bytes;
+            ctx->va_used[i] = ctx->va_used.back();
+            ctx->va_used.pop_back();
+            va_insert_free(ctx->va_free, off, b);
+            ctx->total_alloc -= b;
+            return true;
+        }
+    return true;      // inside the range but not live: already released
+}
+}  // namespace
+
 int snk_ctx_alloc(snk_ctx* ctx, size_t bytes, void** out, char* err, size_t errcap) {
     if (bytes == 0) bytes = 256;
     bytes = (bytes + 255) & ~(size_t)255;
+    if (ctx->va_state >= 0 && !ctx->arena_legacy) {
+        if (void* q = va_alloc(ctx, bytes)) {
+            ++ctx->alloc_serial;
+            ctx->va_serial.push_back({(size_t)((char*)q - ctx->va_base), ctx->alloc_serial});
+            ctx->total_alloc += bytes;
+            if (ctx->total_alloc > ctx->peak_alloc) ctx->peak_alloc = ctx->total_alloc;
+            *out = q;
+            return SNK_OK;
+        }
+    }
     // best fit among the free cached blocks.  A block may be up to 4x the request: the first call of a context sizes its
     // count regions from a guess (instances / 12), later calls from what the first one retained, and a cached block that
     // no request is allowed to take is memory wasted twice (it stays idle AND a new one is allocated -- a 100+ ms
@@ -120,10 +254,22 @@ int snk_ctx_alloc(snk_ctx* ctx, size_t bytes, void** out, char* err, size_t errc
 // after the gather) so that later stages of the same call can reuse the memory
 void snk_ctx_release_block(snk_ctx* ctx, const void* p) {
     if (!p) return;
+    if (va_release(ctx, p)) return;
     for (auto& b : ctx->blocks)
         if (b.p == p && b.used) { b.used = false; ctx->total_alloc -= b.bytes; return; }
 }
 void snk_ctx_release_since(snk_ctx* ctx, uint64_t mark, const void* const* keep, size_t n_keep) {
+    if (ctx->va_state > 0) {
+        std::vector<size_t> drop;
+        for (auto& e : ctx->va_serial) {
+            if (e.serial <= mark) continue;
+            bool kept = false, live = false;
+            for (size_t i = 0; i < n_keep; ++i) if (keep[i] == ctx->va_base + e.off) kept = true;
+            for (auto& u : ctx->va_used) if (u.off == e.off) live = true;
+            if (!kept && live) drop.push_back(e.off);
+        }
+        for (size_t off : drop) (void)va_release(ctx, ctx->va_base + off);
+    }
     for (auto& b : ctx->blocks) {
         if (!b.used || b.serial <= mark) continue;
         bool kept = false;
@@ -135,6 +281,21 @@ void snk_ctx_release_scratch(snk_ctx* ctx) {
     for (auto& b : ctx->blocks) b.used = false;
     ctx->total_alloc = 0;
     ctx->peak_alloc = 0;
+    if (ctx->va_state > 0) {
+        if (va_trace()) fprintf(stderr, "[snk arena] call done: mapped %.2f GB, high water %.2f GB, live ranges %zu, free ranges %zu\n", ctx->va_mapped / 1073741824.0,
+                                ctx->va_high / 1073741824.0, ctx->va_used.size(), ctx->va_free.size());
+        // everything is free again; what the last two calls never reached (a 150 M-read run followed by 15 M-read runs) goes back to
+        // the device -- only when the range is more than twice what they used: mapping it again would cost ~30 ms per GB
+        ctx->va_used.clear();
+        ctx->va_serial.clear();
+        ctx->va_free.clear();
+        if (ctx->va_mapped) ctx->va_free.push_back(snk_ctx::vrange{0, ctx->va_mapped});
+        const size_t recent = std::max(ctx->va_high, std::max(ctx->va_high_prev[0], ctx->va_high_prev[1]));
+        ctx->va_high_prev[1] = ctx->va_high_prev[0];
+        ctx->va_high_prev[0] = ctx->va_high;
+        ctx->va_high = 0;
+        if (recent && ctx->va_mapped > 2 * recent + ((size_t)1 << 30)) va_shrink(ctx, recent + recent / 4);
+    }
     // A new top-level call.  Blocks that neither of the last two calls took are sizes the caller has moved away from (a
     // 150 M-read run followed by 15 M-read runs): they go back to the device, where the caller's own allocator may need them.
     // Steady state (the same sizes call after call) frees nothing.
@@ -157,6 +318,12 @@ extern "C" void snk_ctx_trim(snk_ctx* ctx) {
     snk_ctx_trim_cache(ctx);
 }
 void snk_ctx_trim_cache(snk_ctx* ctx) {
+    if (ctx->va_state > 0) {
+        // unmap everything behind the highest live range
+        size_t live_end = 0;
+        for (auto& u : ctx->va_used) if (u.off + u.bytes > live_end) live_end = u.off + u.bytes;
+        va_shrink(ctx, live_end);
+    }
     std::vector<snk_ctx::block> keep;
     for (auto& b : ctx->blocks) {
         if (b.used) keep.push_back(b);
@@ -170,6 +337,7 @@ extern "C" void snk_ctx_destroy(snk_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     snk_ctx_release_scratch(ctx);
     snk_ctx_trim_cache(ctx);
+    if (ctx->va_base) { va_shrink(ctx, 0); (void)hipMemAddressFree(ctx->va_base, ctx->va_size); ctx->va_base = nullptr; }
     if (ctx->shard) snk_shard_state_free(ctx->shard);
     if (ctx->host_io && ctx->host_io_free) ctx->host_io_free(ctx->host_io);
     if (ctx->shard_host && ctx->shard_host_free) ctx->shard_host_free(ctx->shard_host);

@@ -22,6 +22,23 @@ struct snk_ctx {
     uint64_t call_epoch = 0;     // top-level calls so far; a cached block no call has taken for two of them is given back to the device
     uint64_t alloc_serial = 0;   // blocks handed out so far (a call's internal scratch = the blocks with a larger serial than at its entry)
     std::vector<block> blocks;
+    // Round 4, opt-in (SNK_ARENA_VMM=1; see va_init in snk_api.hip for why not yet the default): the arena as ONE growing range of virtual addresses (hipMemAddressReserve) that physical memory is mapped behind
+    // on demand (hipMemCreate / hipMemMap): a request that does not fit maps more at the end -- no hipFree, no hipMalloc of a block of
+    // another size when the bucket count changes (re-allocating memory the process has freed costs ~30 ms per GB on this stack:
+    // tools/probe/vmm.hip; a call that changed its block sizes took 2.7-6.8 s).  Ranges are handed out first-fit and coalesce when
+    // they come back; everything is free again at the start of a top-level call.  `blocks` stays as the fallback (VMM refused, the
+    // range exhausted, SNK_ARENA_VMM=0, or a multi-rank RCCL step, whose buffers stay plain hipMalloc memory).
+    struct vrange { size_t off, bytes; };
+    char* va_base = nullptr;
+    size_t va_size = 0, va_mapped = 0, va_high = 0, va_high_prev[2] = {0, 0};
+    std::vector<hipMemGenericAllocationHandle_t> va_handles;
+    std::vector<size_t> va_chunk;           // bytes of every mapped chunk (they follow each other from va_base)
+    std::vector<vrange> va_free;            // sorted by offset, coalesced
+    std::vector<vrange> va_used;
+    int va_state = 0;                       // 0 untried, 1 in use, -1 off
+    struct vser { size_t off; uint64_t serial; };
+    std::vector<vser> va_serial;            // allocation order of the live ranges (snk_ctx_release_since)
+    bool arena_legacy = false;              // this call's scratch comes from plain hipMalloc blocks (multi-rank RCCL steps)
     size_t total_alloc = 0;     // bytes handed out in the current call (minus blocks returned mid-call)
     size_t peak_alloc = 0;      // its maximum during the call
     size_t cached_bytes = 0;    // bytes held by the arena

@@ -707,6 +707,8 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
         k.hi = khi[i];
         k.lo = (uint64_t)klo[i] << KLS;
         const uint32_t fo = foffL[fwd ? tL : tR];
+        // (round 4, measured with these stores compiled out: 8.55 -> 8.23 ms -- the one-byte-per-node stores are NOT what the kernel
+        // spends its time on, so packing the fragments' bases to 2 bits, DESIGN 8 item 6 of round 3, would not buy the 2 ms hoped for)
         fbases[c_boff + (WIDE ? frel[fo] : fo) + (K - 1) + pos] = (uint8_t)oriented_base<K>(k, !fwd, K - 1);
     }
     // head k-mers: K / 4 lanes per head, four bases (one dword store at byte alignment) per lane, four heads per wave

@@ -110,6 +110,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     }
     SNK_HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->arena_legacy = false;
     snk_ctx_release_scratch(ctx);
     memset(out, 0, sizeof *out);
     const uint32_t K = p->K;

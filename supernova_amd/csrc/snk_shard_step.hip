@@ -211,6 +211,9 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
     char* err = X.err;
     size_t errcap = X.errcap;
     const uint32_t W = X.W, me = X.me, K = p->K;
+    // buffers that cross xGMI stay plain hipMalloc memory (the growing arena of snk_ctx.h is mapped through the VMM API; RCCL over several
+    // devices on such ranges is not something this build environment can test): a multi-rank RCCL step takes its scratch the old way
+    ctx->arena_legacy = W > 1 && strcmp(comm->kind(), "rccl") == 0;
     const uint64_t syncs0 = snk_sync_count();
     comm->bytes_sent = 0;
     snk_phase_timer tm(st);
@@ -275,9 +278,14 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
                 hipLaunchKernelGGL(fake_seg_kernel, dim3((NB_total + 255) / 256), dim3(256), 0, st, part.cursor, NB_total, part.cap, fake, T);
                 TRY(snk_stage_count_table(ctx, st, K, part.records, T, T + (uint64_t)fake * NB_total, NB_total, fake, NB_total, p->min_freq,
                                           has_bc ? p->min_bc : 0u, 0u, inst_hint, S->status, false, &S->tab, err, errcap));
-            } else
+            } else {
+            // (hot minimiser buckets -- repeat families -- are re-partitioned by k-mer hash on the one-rank path as on the one-GPU path;
+            // with W > 1 a bucket's records arrive as W + 1 segments and the expansion is not wired up yet: DESIGN 8)
+            snk_hot hot;
+            TRY(snk_stage_hot(ctx, st, K, false, &S->part, &hot, err, errcap));
             TRY(snk_stage_count_table(ctx, st, K, part.records, part.seg, part.seg + NB_total, 2 * NB_total, part.nseg, NB_total, p->min_freq,
-                                      has_bc ? p->min_bc : 0u, 0u, inst_hint, S->status, false, &S->tab, err, errcap, nullptr, with_pilot ? &pilot : nullptr));
+                                      has_bc ? p->min_bc : 0u, 0u, inst_hint, S->status, false, &S->tab, err, errcap, nullptr, with_pilot ? &pilot : nullptr, nullptr, false, &hot));
+            }
             snk_ctx_release_block(ctx, part.records);
         } else {
             // ---- histograms: row p of my cursor array goes to rank p
