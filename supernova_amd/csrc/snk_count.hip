@@ -312,6 +312,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                 if (tid < BATCH && base + tid < vend) {
                     const uint4 ra = *reinterpret_cast<const uint4*>(rec + 8 * tid), rb = *reinterpret_cast<const uint4*>(rec + 8 * tid + 4);
                     nkm = rb.z & 0x7Fu;
+                    if (a.dbg == 5 && ((rb.z >> 7) & 3u) != 3u) nkm = 0;      // probe (results invalid): what the records of read starts / ends cost (DESIGN 4 "round 4")
                     // (per-barcode groups: a group sees a locus once or twice, identical supermers inside one group are rare -- looking for
                     // them cost 11 of the grouped bench's 160 ms and found next to nothing)
                     if (!GROUPED && a.dbg != 4 && nkm) {

@@ -308,10 +308,18 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
                 snk_kmer_hash2(kk, &h1, &h2);
                 uint64_t slot = (((uint64_t)h1 << 32) | h2) & gmask;
                 const unsigned long long ent = ((unsigned long long)h1 << 32) | (unsigned long long)(gi + 1);
-                for (uint32_t tries = 0; tries < 4096; ++tries) {
-                    const unsigned long long old = atomicCAS(&gindex[slot], 0ull, ent);
-                    if (old == 0ull) break;
-                    slot = (slot + 1) & gmask;
+                // gindex[gmask + 1] = "give up" flag: the table was sized from the PREVIOUS call's boundary count; on other data (a first
+                // call with many split chunks: most neighbours lie in another hash class) it can be several times too small, and 10^8
+                // inserts probing 4096 slots each into a full table took 6.4 s (round 4, config.robust first_call_phases).  An insert
+                // that finds no slot within 64 probes raises the flag, everybody stops inserting, the host runs the exact-size build pass.
+                if (gindex[gmask + 1] == 0ull) {
+                    bool placed = false;
+                    for (uint32_t tries = 0; tries < 64; ++tries) {
+                        const unsigned long long old = atomicCAS(&gindex[slot], 0ull, ent);
+                        if (old == 0ull) { placed = true; break; }
+                        slot = (slot + 1) & gmask;
+                    }
+                    if (!placed) gindex[gmask + 1] = 1ull;
                 }
             }
         }
@@ -900,8 +908,8 @@ static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* er
         const uint64_t guess = (ctx->last_bnd_n == n && ctx->last_bnd) ? ctx->last_bnd + ctx->last_bnd / 8 : n / 5;
         tg0 = 1024;
         while (tg0 < 2 * guess) tg0 <<= 1;
-        G_ALLOC(index0, unsigned long long, tg0);
-        SNK_HIP_TRY(hipMemsetAsync(index0, 0, tg0 * 8, st));
+        G_ALLOC(index0, unsigned long long, tg0 + 1);
+        SNK_HIP_TRY(hipMemsetAsync(index0, 0, (tg0 + 1) * 8, st));
     }
     bl_regions rg;
     rg.keys_r = tab->keys_r; rg.vals_r = tab->vals_r; rg.desc_src = desc_src;
@@ -933,7 +941,8 @@ static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* er
         if (rc) return rc;
         SNK_HIP_TRY(rocprim::reduce(tmp, tb, in, d_sum, 0ull, (size_t)nchunks, rocprim::plus<unsigned long long>(), st));
     }
-    unsigned long long h_bnd = 0;
+    unsigned long long h_bnd = 0, h_gaveup = 0;
+    if (index0) SNK_HIP_TRY(hipMemcpyAsync(&h_gaveup, index0 + tg0, 8, hipMemcpyDeviceToHost, st));
     SNK_HIP_TRY(hipMemcpyAsync(&h_bnd, d_sum, 8, hipMemcpyDeviceToHost, st));
     SNK_HIP_TRY(hipMemcpyAsync(&h_nbig, ctr + 1, 4, hipMemcpyDeviceToHost, st));
     SNK_HIP_TRY(snk_sync(st));
@@ -942,7 +951,7 @@ static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* er
     ctx->last_bnd = h_bnd; ctx->last_bnd_n = n;
     uint64_t tg = 1024;
     while (tg < 2 * h_bnd) tg <<= 1;
-    const bool fused_ok = index0 && h_bnd * 4 <= tg0 * 3;          // load <= 0.75: every insert found a slot long before its probe limit
+    const bool fused_ok = index0 && !h_gaveup && h_bnd * 4 <= tg0 * 3;          // load <= 0.75: every insert found a slot long before its probe limit
     if (fused_ok) { B->index = index0; tg = tg0; }
     else {
         if (index0) snk_ctx_release_block(ctx, index0);
