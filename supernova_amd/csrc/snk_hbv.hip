@@ -12,8 +12,11 @@
 //        BVComp rank of every unitig (radix sort by first k-mer -- two unitigs never share it, so it decides the
 //        lexicographic comparison -- then a stable one by length), the palindrome test, the 4U (K-1)-mer end keys
 //        (128-bit, MSB first), their stable radix sort (EEComp == generation order), vertex classes by a flag scan.
-//        Only the id hand-out, a breadth-first flood that is sequential by definition (ids are visiting order), runs
-//        on the host over the downloaded classes: 4U + U + #vertices words.
+//        The id hand-out is a breadth-first flood whose ids are the visiting order -- sequential inside a connected
+//        component, independent between components: components by union-find on the device, one thread floods one
+//        component into its own id block, and only components above SNK_HBV_BIG nodes (the connected bulk of a genome
+//        graph) are flooded on the host.  Graphs below SNK_HBV_DEV_MIN unitigs take the host flood directly (the hot
+//        path's few thousand: faster than the launches); the default is "all" -- the device flood is opt-in.
 #include <stdlib.h>
 #include <string.h>
 
@@ -29,9 +32,15 @@
 namespace {
 
 // ee[]: edge ends in vertex-major order, code = rank*4 + rc*2 + distal; run_beg[v..v+1] delimits vertex class v;
-// vtx_of[code] = class (or -1).  Fills every array of `out`.
-int hbv_flood(uint64_t U, const uint8_t* pal, const uint32_t* ee, uint64_t n_ee, const int32_t* vtx_of, const uint64_t* run_beg,
-              uint64_t nruns, snk_hbv* out, char* err, size_t errcap) {
+// vtx_of[code] = class (or -1).
+struct hbv_tables {
+    uint64_t U;
+    const uint8_t* pal;
+    const uint32_t* ee;
+    const int32_t* vtx_of;
+    const uint64_t* run_beg;
+};
+int hbv_alloc_out(uint64_t U, uint64_t nruns, snk_hbv* out, char* err, size_t errcap) {
     out->n_vertices = (int32_t)nruns;
     out->fwd_xlat = (int32_t*)malloc(U * 4);
     out->rev_xlat = (int32_t*)malloc(U * 4);
@@ -43,43 +52,53 @@ int hbv_flood(uint64_t U, const uint8_t* pal, const uint32_t* ee, uint64_t n_ee,
         snk_hbv_free(out);
         return snk_fail(SNK_E_NOMEM, err, errcap, "snk_hbv: host allocation failed");
     }
+    return SNK_OK;
+}
+// the flood of one component from its seed (HBVBuilder::processQueue); ids continue from next_e / next_v
+void hbv_flood_component(const hbv_tables& t, uint64_t e0, int rc0, std::vector<int32_t>& vid, std::vector<uint64_t>& q, int32_t& next_e,
+                         int32_t& next_v, snk_hbv* out) {
+    auto done = [&](uint64_t e, int rc) { return (rc ? out->rev_xlat : out->fwd_xlat)[e] != -1; };
+    q.clear();            // FIFO: [head, size); emptied whenever a component is finished
+    size_t head = 0;
+    q.push_back(e0 * 2 + rc0);
+    while (head < q.size()) {
+        const uint64_t x = q[head++];
+        const uint64_t e = x >> 1;
+        const int rc = (int)(x & 1);
+        if (done(e, rc)) continue;
+        int32_t r1 = t.vtx_of[e * 4 + rc * 2 + 0], r2 = t.vtx_of[e * 4 + rc * 2 + 1];
+        if (t.pal[e] && rc) { r1 = t.vtx_of[e * 4 + 0]; r2 = t.vtx_of[e * 4 + 1]; }
+        if (vid[r1] == -1) vid[r1] = next_v++;
+        if (vid[r2] == -1) vid[r2] = next_v++;
+        const int32_t id = next_e++;
+        out->v_left[id] = vid[r1]; out->v_right[id] = vid[r2];
+        out->src_unitig[id] = (int32_t)e; out->is_rc[id] = (uint8_t)rc;
+        if (!rc || t.pal[e]) out->fwd_xlat[e] = id;
+        if (rc || t.pal[e]) out->rev_xlat[e] = id;
+        for (int side = 0; side < 2; ++side) {
+            const int32_t r = side ? r2 : r1;
+            for (uint64_t j = t.run_beg[r]; j < t.run_beg[r + 1]; ++j) {
+                const uint64_t ed = t.ee[j] >> 2;
+                const int erc = (int)((t.ee[j] >> 1) & 1u);
+                if (!done(ed, erc)) q.push_back(ed * 2 + erc);
+            }
+        }
+    }
+}
+// Fills every array of `out`: every component in seed order.
+int hbv_flood(uint64_t U, const uint8_t* pal, const uint32_t* ee, uint64_t n_ee, const int32_t* vtx_of, const uint64_t* run_beg,
+              uint64_t nruns, snk_hbv* out, char* err, size_t errcap) {
+    int rc = hbv_alloc_out(U, nruns, out, err, errcap);
+    if (rc) return rc;
     for (uint64_t i = 0; i < U; ++i) out->fwd_xlat[i] = out->rev_xlat[i] = -1;
     std::vector<int32_t> vid(nruns, -1);
     int32_t next_v = 0, next_e = 0;
-    std::vector<uint64_t> q;          // FIFO: [head, size); emptied whenever a component is finished
-    size_t head = 0;
-    auto done = [&](uint64_t e, int rc) { return (rc ? out->rev_xlat : out->fwd_xlat)[e] != -1; };
+    std::vector<uint64_t> q;
+    const hbv_tables t{U, pal, ee, vtx_of, run_beg};
     (void)n_ee;
     for (int pass = 0; pass < 2; ++pass)
-        for (uint64_t e0 = 0; e0 < U; ++e0) {
-            if (done(e0, pass)) continue;
-            q.clear();
-            head = 0;
-            q.push_back(e0 * 2 + pass);
-            while (head < q.size()) {
-                const uint64_t x = q[head++];
-                const uint64_t e = x >> 1;
-                const int rc = (int)(x & 1);
-                if (done(e, rc)) continue;
-                int32_t r1 = vtx_of[e * 4 + rc * 2 + 0], r2 = vtx_of[e * 4 + rc * 2 + 1];
-                if (pal[e] && rc) { r1 = vtx_of[e * 4 + 0]; r2 = vtx_of[e * 4 + 1]; }
-                if (vid[r1] == -1) vid[r1] = next_v++;
-                if (vid[r2] == -1) vid[r2] = next_v++;
-                const int32_t id = next_e++;
-                out->v_left[id] = vid[r1]; out->v_right[id] = vid[r2];
-                out->src_unitig[id] = (int32_t)e; out->is_rc[id] = (uint8_t)rc;
-                if (!rc || pal[e]) out->fwd_xlat[e] = id;
-                if (rc || pal[e]) out->rev_xlat[e] = id;
-                for (int side = 0; side < 2; ++side) {
-                    const int32_t r = side ? r2 : r1;
-                    for (uint64_t j = run_beg[r]; j < run_beg[r + 1]; ++j) {
-                        const uint64_t ed = ee[j] >> 2;
-                        const int erc = (int)((ee[j] >> 1) & 1u);
-                        if (!done(ed, erc)) q.push_back(ed * 2 + erc);
-                    }
-                }
-            }
-        }
+        for (uint64_t e0 = 0; e0 < U; ++e0)
+            if ((pass ? out->rev_xlat : out->fwd_xlat)[e0] == -1) hbv_flood_component(t, e0, pass, vid, q, next_e, next_v, out);
     out->n_edges = next_e;
     return SNK_OK;
 }
@@ -308,6 +327,115 @@ __global__ void __launch_bounds__(HB) hbv_class_kernel(const uint32_t* __restric
     if (flag[i]) run_beg[c] = i;
 }
 
+// ---- id hand-out on the device.  HBVBuilder (HBVFromEdges.cc:170-238) floods one connected component of the (edge, strand)
+// graph after the other -- components in the order of their smallest seed (forward copies in BVComp order, then reverse
+// copies), inside a component in first-push order of a FIFO -- so a component's ids are a block [first edge id, +size) x
+// [first vertex id, +classes) that depends on nothing but the components in front of it.  Components: lock-free union-find
+// over the 2U nodes (node = rc * U + rank, the seed order; larger roots hook under smaller ones, so a root IS its
+// component's seed), sizes by wave-aggregated atomics, block starts by two scans over the node space.  Then one thread
+// floods one component, its queue being its block of the output arrays (an id is handed out at the first push: visiting
+// order == first-push order in a FIFO that skips what is done).  Components above a size limit (the connected bulk of
+// a genome graph: sequential by definition) are left to the host, which floods them into their blocks.
+__device__ __forceinline__ uint32_t uf_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t uf_find(uint32_t* par, uint32_t x) {
+    for (;;) {
+        const uint32_t p = uf_ld(par + x);
+        if (p == x) return x;
+        const uint32_t gp = uf_ld(par + p);
+        if (gp != p) __hip_atomic_store(par + x, gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // path halving: any ancestor will do
+        x = gp;
+    }
+}
+__device__ __forceinline__ uint32_t hbv_node(uint32_t code, uint32_t U) { return ((code >> 1) & 1u) * U + (code >> 2); }
+
+__global__ void __launch_bounds__(HB) hbv_cc_init_kernel(uint32_t* __restrict__ par, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * HB + threadIdx.x;
+    if (i < n) par[i] = (uint32_t)i;
+}
+// the ends of one vertex class are mutually adjacent: every entry joins the class's first
+__global__ void __launch_bounds__(HB) hbv_cc_union_kernel(const uint32_t* __restrict__ ee, const uint32_t* __restrict__ cls,
+                                                          const uint64_t* __restrict__ run_beg, uint64_t n_ee, uint32_t U, uint32_t* par) {
+    const uint64_t i = (uint64_t)blockIdx.x * HB + threadIdx.x;
+    if (i >= n_ee) return;
+    const uint64_t first = run_beg[cls[i] - 1u];
+    if (first == i) return;
+    uint32_t a = hbv_node(ee[i], U), b = hbv_node(ee[first], U);
+    for (;;) {
+        a = uf_find(par, a);
+        b = uf_find(par, b);
+        if (a == b) return;
+        if (a < b) { const uint32_t t = a; a = b; b = t; }
+        if (atomicCAS(par + a, a, b) == a) return;
+    }
+}
+// counter[root] += 1 for every valid lane, one atomic per distinct root of a wave (a genome graph's bulk is ONE root)
+__device__ __forceinline__ void hbv_count_root(uint32_t* counter, bool valid, uint32_t root) {
+    unsigned long long act = __ballot(valid);
+    const uint32_t lane = __lane_id();
+    while (act) {
+        const int lead = __ffsll((long long)act) - 1;
+        const uint32_t r0 = (uint32_t)__shfl((int)root, lead);
+        const unsigned long long same = __ballot(valid && root == r0);
+        if ((int)lane == lead) atomicAdd(counter + r0, (uint32_t)__popcll(same));
+        act &= ~same;
+    }
+}
+__global__ void __launch_bounds__(HB) hbv_cc_nodes_kernel(uint32_t* par, const uint8_t* __restrict__ palr, uint32_t U, uint32_t* ce) {
+    const uint64_t n = (uint64_t)blockIdx.x * HB + threadIdx.x;
+    const bool valid = n < 2ull * U && !(n >= U && palr[n - U]);
+    hbv_count_root(ce, valid, valid ? uf_find(par, (uint32_t)n) : 0u);
+}
+__global__ void __launch_bounds__(HB) hbv_cc_classes_kernel(uint32_t* par, const uint32_t* __restrict__ ee, const uint64_t* __restrict__ run_beg,
+                                                            uint64_t nruns, uint32_t U, uint32_t* cv) {
+    const uint64_t r = (uint64_t)blockIdx.x * HB + threadIdx.x;
+    const bool valid = r < nruns;
+    hbv_count_root(cv, valid, valid ? uf_find(par, hbv_node(ee[run_beg[r]], U)) : 0u);
+}
+struct hbv_big { uint32_t root, be, bv, ce; };
+// one thread per root: floods its component when that is small, lists it for the host otherwise
+__global__ void __launch_bounds__(HB) hbv_flood_kernel(const uint32_t* __restrict__ par, const uint8_t* __restrict__ palr, uint32_t U,
+                                                       const uint32_t* __restrict__ ce, const uint32_t* __restrict__ be,
+                                                       const uint32_t* __restrict__ bv, const uint32_t* __restrict__ ee,
+                                                       const int32_t* __restrict__ vtx_of, const uint64_t* __restrict__ run_beg,
+                                                       uint32_t big_limit, int32_t* fwd, int32_t* rev, int32_t* vid, int32_t* v_left,
+                                                       int32_t* v_right, int32_t* src, uint8_t* isrc, hbv_big* big, uint32_t big_cap,
+                                                       uint32_t* n_big) {
+    const uint64_t n = (uint64_t)blockIdx.x * HB + threadIdx.x;
+    if (n >= 2ull * U || par[n] != (uint32_t)n || (n >= U && palr[n - U])) return;
+    const uint32_t size = ce[n], e_base = be[n], v_base = bv[n];
+    if (size > big_limit) {
+        const uint32_t q = atomicAdd(n_big, 1u);
+        if (q < big_cap) big[q] = hbv_big{(uint32_t)n, e_base, v_base, size};
+        return;
+    }
+    uint32_t head = 0, tail = 0, nv = 0;
+    auto push = [&](uint32_t e, uint32_t rc) {
+        const bool p = palr[e] != 0;
+        int32_t* x = (rc && !p) ? rev : fwd;
+        if (x[e] != -1) return;
+        const int32_t id = (int32_t)(e_base + tail++);
+        x[e] = id;
+        if (p) rev[e] = id;
+        src[id] = (int32_t)e;
+        isrc[id] = (uint8_t)rc;
+    };
+    push(n >= U ? (uint32_t)(n - U) : (uint32_t)n, n >= U ? 1u : 0u);
+    while (head < tail) {
+        const uint32_t id = e_base + head++;
+        const uint32_t e = (uint32_t)src[id], rc = isrc[id];
+        const int32_t r1 = vtx_of[4ull * e + 2 * rc], r2 = vtx_of[4ull * e + 2 * rc + 1];
+        if (vid[r1] == -1) vid[r1] = (int32_t)(v_base + nv++);
+        if (vid[r2] == -1) vid[r2] = (int32_t)(v_base + nv++);
+        v_left[id] = vid[r1];
+        v_right[id] = vid[r2];
+        for (int side = 0; side < 2; ++side) {
+            const int32_t r = side ? r2 : r1;
+            const uint64_t j1 = run_beg[r + 1];
+            for (uint64_t j = run_beg[r]; j < j1; ++j) { const uint32_t c = ee[j]; push(c >> 2, (c >> 1) & 1u); }
+        }
+    }
+}
+
 // scratch of one call: handed back to the arena when the call returns (the unitigs it reads are scratch of the
 // preceding snk_dev_count_graph and must stay)
 struct scratch_list {
@@ -315,6 +443,11 @@ struct scratch_list {
     std::vector<void*> p;
     ~scratch_list() { for (void* q : p) snk_ctx_release_block(ctx, q); }
 };
+
+uint64_t env_u64(const char* name, uint64_t dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? strtoull(v, nullptr, 0) : dflt;
+}
 
 template <typename T>
 int dalloc(scratch_list& sl, size_t n, T** out, char* err, size_t errcap) {
@@ -366,7 +499,9 @@ extern "C" int snk_dev_hbv(snk_ctx* ctx, uint32_t K, uint64_t U, const void* d_u
     SNK_HIP_TRY(rocprim::radix_sort_pairs((void*)nullptr, tmp_bytes, lkey, lkey2, idx, order, (size_t)U, 0u, 64u, st));
     SNK_HIP_TRY(rocprim::radix_sort_pairs((void*)nullptr, tb2, keys, keys2, codes, codes2, (size_t)n4, 0u, 128u, st));
     SNK_HIP_TRY(rocprim::inclusive_scan((void*)nullptr, tb3, flag, cls, (size_t)n4, rocprim::plus<uint32_t>(), st));
-    tmp_bytes = std::max(tmp_bytes, std::max(tb2, tb3));
+    size_t tb4 = 0;
+    SNK_HIP_TRY(rocprim::exclusive_scan((void*)nullptr, tb4, flag, cls, 0u, (size_t)(2 * U), rocprim::plus<uint32_t>(), st));
+    tmp_bytes = std::max(std::max(tmp_bytes, tb4), std::max(tb2, tb3));
     uint8_t* tmp = nullptr;
     if ((rc = dalloc(sl, tmp_bytes, &tmp, err, errcap))) return rc;
     size_t tbx = tmp_bytes;
@@ -391,25 +526,100 @@ extern "C" int snk_dev_hbv(snk_ctx* ctx, uint32_t K, uint64_t U, const void* d_u
     SNK_HIP_TRY(hipMemsetAsync(vtx_of, 0xFF, n4 * 4, st));
     hipLaunchKernelGGL(hbv_class_kernel, dim3(ge), dim3(HB), 0, st, cls, flag, codes2, n_ee, vtx_of, run_beg);
     SNK_HIP_TRY(hipGetLastError());
-    SNK_HIP_TRY(hipEventRecord(e1, st));
     uint32_t nruns = 0;
     SNK_HIP_TRY(hipMemcpyAsync(&nruns, cls + (n_ee - 1), 4, hipMemcpyDeviceToHost, st));
-    std::vector<uint32_t> h_ee(n_ee), h_order(U);
-    std::vector<int32_t> h_vtx(n4);
-    std::vector<uint8_t> h_pal(U);
-    SNK_HIP_TRY(hipMemcpyAsync(h_ee.data(), codes2, n_ee * 4, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipMemcpyAsync(h_vtx.data(), vtx_of, n4 * 4, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipMemcpyAsync(h_pal.data(), palr, U, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(hipMemcpyAsync(h_order.data(), order, U * 4, hipMemcpyDeviceToHost, st));
     SNK_HIP_TRY(snk_sync(st));
-    std::vector<uint64_t> h_run(nruns + 1);
-    SNK_HIP_TRY(hipMemcpy(h_run.data(), run_beg, (size_t)nruns * 8, hipMemcpyDeviceToHost));
-    h_run[nruns] = n_ee;
-    if (device_ms) (void)hipEventElapsedTime(device_ms, e0, e1);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    rc = hbv_flood(U, h_pal.data(), h_ee.data(), n_ee, h_vtx.data(), h_run.data(), nruns, out, err, errcap);
-    if (rc) return rc;
+    std::vector<uint32_t> h_ee, h_order(U);
+    std::vector<int32_t> h_vtx;
+    std::vector<uint8_t> h_pal;
+    std::vector<uint64_t> h_run;
+    auto fetch_tables = [&]() -> hipError_t {       // what a flood on the host reads
+        h_ee.resize(n_ee); h_vtx.resize(n4); h_pal.resize(U); h_run.resize((size_t)nruns + 1);
+        hipError_t e;
+        if ((e = hipMemcpyAsync(h_ee.data(), codes2, n_ee * 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(h_vtx.data(), vtx_of, n4 * 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(h_pal.data(), palr, U, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(h_run.data(), run_beg, (size_t)nruns * 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+        h_run[nruns] = n_ee;
+        return hipSuccess;
+    };
+    // small graphs (the hot path's few thousand unitigs) are flooded on the host in less time than the launches below take.
+    // The device flood is opt-in (SNK_HBV_DEV_MIN=<unitigs>) until it has been measured on graphs of millions of unitigs.
+    const uint64_t dev_min = env_u64("SNK_HBV_DEV_MIN", ~0ull);
+    if (U < dev_min) {
+        SNK_HIP_TRY(hipEventRecord(e1, st));
+        SNK_HIP_TRY(fetch_tables());
+        SNK_HIP_TRY(hipMemcpyAsync(h_order.data(), order, U * 4, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(snk_sync(st));
+        if (device_ms) (void)hipEventElapsedTime(device_ms, e0, e1);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        rc = hbv_flood(U, h_pal.data(), h_ee.data(), n_ee, h_vtx.data(), h_run.data(), nruns, out, err, errcap);
+        if (rc) return rc;
+    } else {
+        // the sort buffers are dead: node arrays live in `keys` (64 U bytes), the outputs in `keys2`, the vertex ids in `flag`
+        const uint64_t n2 = 2 * U;
+        uint32_t* par = (uint32_t*)keys;
+        uint32_t *ce = par + n2, *cv = ce + n2, *be = cv + n2, *bv = be + n2;
+        int32_t* d_fwd = (int32_t*)keys2;
+        int32_t *d_rev = d_fwd + U, *d_vl = d_rev + U, *d_vr = d_vl + n2, *d_src = d_vr + n2;
+        uint8_t* d_isrc = (uint8_t*)(d_src + n2);
+        int32_t* d_vid = (int32_t*)flag;
+        const uint32_t big_limit = (uint32_t)env_u64("SNK_HBV_BIG", 1024);
+        const uint32_t big_cap = (uint32_t)(n2 / ((uint64_t)big_limit + 1) + 1);
+        hbv_big* d_big;
+        uint32_t* d_nbig;
+        if ((rc = dalloc(sl, big_cap, &d_big, err, errcap)) || (rc = dalloc(sl, 4, &d_nbig, err, errcap))) return rc;
+        const uint64_t h_nee = n_ee;
+        SNK_HIP_TRY(hipMemcpyAsync(run_beg + nruns, &h_nee, 8, hipMemcpyHostToDevice, st));
+        SNK_HIP_TRY(hipMemsetAsync(ce, 0, n2 * 8, st));                       // ce, cv
+        SNK_HIP_TRY(hipMemsetAsync(d_fwd, 0xFF, U * 8, st));                  // fwd, rev
+        SNK_HIP_TRY(hipMemsetAsync(d_vid, 0xFF, (size_t)nruns * 4, st));
+        SNK_HIP_TRY(hipMemsetAsync(d_nbig, 0, 4, st));
+        const unsigned g2 = (unsigned)((n2 + HB - 1) / HB), gr = (unsigned)(((uint64_t)nruns + HB - 1) / HB);
+        hipLaunchKernelGGL(hbv_cc_init_kernel, dim3(g2), dim3(HB), 0, st, par, n2);
+        hipLaunchKernelGGL(hbv_cc_union_kernel, dim3(ge), dim3(HB), 0, st, codes2, cls, run_beg, n_ee, (uint32_t)U, par);
+        hipLaunchKernelGGL(hbv_cc_nodes_kernel, dim3(g2), dim3(HB), 0, st, par, palr, (uint32_t)U, ce);
+        hipLaunchKernelGGL(hbv_cc_classes_kernel, dim3(gr), dim3(HB), 0, st, par, codes2, run_beg, (uint64_t)nruns, (uint32_t)U, cv);
+        tbx = tmp_bytes;
+        SNK_HIP_TRY(rocprim::exclusive_scan(tmp, tbx, ce, be, 0u, (size_t)n2, rocprim::plus<uint32_t>(), st));
+        tbx = tmp_bytes;
+        SNK_HIP_TRY(rocprim::exclusive_scan(tmp, tbx, cv, bv, 0u, (size_t)n2, rocprim::plus<uint32_t>(), st));
+        hipLaunchKernelGGL(hbv_flood_kernel, dim3(g2), dim3(HB), 0, st, par, palr, (uint32_t)U, ce, be, bv, codes2, vtx_of, run_beg, big_limit,
+                           d_fwd, d_rev, d_vid, d_vl, d_vr, d_src, d_isrc, d_big, big_cap, d_nbig);
+        SNK_HIP_TRY(hipGetLastError());
+        SNK_HIP_TRY(hipEventRecord(e1, st));
+        uint32_t n_big = 0;
+        SNK_HIP_TRY(hipMemcpyAsync(&n_big, d_nbig, 4, hipMemcpyDeviceToHost, st));
+        if ((rc = hbv_alloc_out(U, nruns, out, err, errcap))) return rc;
+        SNK_HIP_TRY(hipMemcpyAsync(out->fwd_xlat, d_fwd, U * 4, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(hipMemcpyAsync(out->rev_xlat, d_rev, U * 4, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(hipMemcpyAsync(out->v_left, d_vl, n2 * 4, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(hipMemcpyAsync(out->v_right, d_vr, n2 * 4, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(hipMemcpyAsync(out->src_unitig, d_src, n2 * 4, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(hipMemcpyAsync(out->is_rc, d_isrc, n2, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(hipMemcpyAsync(h_order.data(), order, U * 4, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(snk_sync(st));
+        if (device_ms) (void)hipEventElapsedTime(device_ms, e0, e1);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        out->n_edges = (int32_t)(n2 - h_flags[1]);
+        if (n_big) {               // the connected bulk: flooded here into the blocks the scans gave it
+            if (n_big > big_cap) { snk_hbv_free(out); return snk_fail(SNK_E_INTERNAL, err, errcap, "snk_dev_hbv: component list overflow"); }
+            std::vector<hbv_big> h_big(n_big);
+            SNK_HIP_TRY(hipMemcpyAsync(h_big.data(), d_big, (size_t)n_big * sizeof(hbv_big), hipMemcpyDeviceToHost, st));
+            SNK_HIP_TRY(fetch_tables());
+            SNK_HIP_TRY(snk_sync(st));
+            std::vector<int32_t> vid(nruns, -1);
+            std::vector<uint64_t> q;
+            const hbv_tables t{U, h_pal.data(), h_ee.data(), h_vtx.data(), h_run.data()};
+            for (const hbv_big& b : h_big) {
+                int32_t next_e = (int32_t)b.be, next_v = (int32_t)b.bv;
+                hbv_flood_component(t, b.root >= U ? b.root - U : b.root, b.root >= U ? 1 : 0, vid, q, next_e, next_v, out);
+                if ((uint32_t)next_e != b.be + b.ce) { snk_hbv_free(out); return snk_fail(SNK_E_INTERNAL, err, errcap, "snk_dev_hbv: a component's flood left its block"); }
+            }
+        }
+    }
     out->bvcomp_order = (int32_t*)malloc(U * 4);
     if (!out->bvcomp_order) { snk_hbv_free(out); return snk_fail(SNK_E_NOMEM, err, errcap, "snk_dev_hbv: host allocation failed"); }
     for (uint64_t i = 0; i < U; ++i) out->bvcomp_order[i] = (int32_t)h_order[i];

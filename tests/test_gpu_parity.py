@@ -765,12 +765,24 @@ def test_circle_pool_retry(engine, monkeypatch):
     _check_against(res, c.exp_keys, c.exp_counts, c.exp_ctx, c.exp_unitigs, c.exp_goodlens, c.exp_hist)
 
 
+HBV_FLOODS = {"host": {"SNK_HBV_DEV_MIN": "1000000000"},            # the sequential flood over the downloaded classes
+              "device": {"SNK_HBV_DEV_MIN": "0"},                    # components on the device, one thread floods one component
+              "device_big4": {"SNK_HBV_DEV_MIN": "0", "SNK_HBV_BIG": "4"},   # components above 4 nodes go to the host's flood
+              "device_big0": {"SNK_HBV_DEV_MIN": "0", "SNK_HBV_BIG": "0"}}   # every component does
+
+
+@pytest.mark.parametrize("flood", list(HBV_FLOODS))
 @pytest.mark.parametrize("name,K", [(n, 48) for n in goldens.CASES] + [(n, 60) for n in goldens.K60_CASES])
-def test_device_hbv_matches_reference(engine, graph_stage, name, K):
-    """a14 on the device (snk_dev_hbv): BVComp ranking, (K-1)-mer end keys, vertex classes in HBM, id flood on the host
-    -- the text dump equals the reference's buildHBVFromEdges output (golden), and the host-array entry point."""
+def test_device_hbv_matches_reference(engine, graph_stage, name, K, flood, monkeypatch):
+    """a14 on the device (snk_dev_hbv): BVComp ranking, (K-1)-mer end keys, vertex classes, connected components and the id
+    flood per component in HBM (or, `host`, the flood on the host) -- the text dump equals the reference's buildHBVFromEdges
+    output (golden), and the host-array entry point."""
     from supernova_amd import graphio
     from supernova_amd.engine import Params
+    if graph_stage == "global" and flood != "device":
+        pytest.skip("the flood does not depend on the graph stage")
+    for k, v in HBV_FLOODS[flood].items():
+        monkeypatch.setenv(k, v)
     c = goldens.load(name)
     rows, quals, bc, lens = _to_dev(c)
     exp = c if K == 48 else goldens.Case60(name)
@@ -791,11 +803,14 @@ def test_device_hbv_matches_reference(engine, graph_stage, name, K):
     assert np.array_equal(res.hbv()["v_left"], h["v_left"])
 
 
-def test_device_hbv_many_unitigs(engine):
+@pytest.mark.parametrize("flood", ["host", "device", "device_big4"])
+def test_device_hbv_many_unitigs(engine, flood, monkeypatch):
     """Error-rich reads at low coverage: hundreds of thousands of short unitigs, equal lengths everywhere (the BVComp
     tie-break) -- device result == host-array entry point on the BVComp-sorted unitigs."""
     from supernova_amd import graphio, synth
     from supernova_amd.engine import Params
+    for k, v in HBV_FLOODS[flood].items():
+        monkeypatch.setenv(k, v)
     sp = synth.synth_params(400_000, seed=0x5EED0042)
     rows, quals, bc = engine.synth(sp)
     res = engine.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48, min_freq=1, min_bc=0))
