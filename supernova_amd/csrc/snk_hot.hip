@@ -90,10 +90,18 @@ __global__ void __launch_bounds__(256) hot_mask_kernel(hot_tab h, uint32_t NB, u
 
 // ---- expansion: one thread per hot record, its k-mers one after the other.  SCATTER = false: count the instances per virtual bucket;
 // true: write the single-k-mer records behind the virtual buckets' cursors.
+// The instances of a workgroup are counted in LDS first (a workgroup's 256 records are -- but for a boundary -- records of ONE hot bucket,
+// so an LDS counter per class of that bucket does): ONE global atomic per class and workgroup instead of one per instance.  The buckets
+// this is for are the ones where instances repeat: a homopolymer's bucket holds a handful of distinct k-mers, and one global counter
+// took every instance of the bucket, one at a time (same-address atomics queue, ~10 ns each).
+constexpr int HOT_LG_MAX = 12;
 template <int K, bool GROUPED, bool SCATTER>
 __global__ void __launch_bounds__(HT) hot_expand_kernel(hot_tab h, const uint4* __restrict__ records, const uint64_t* __restrict__ seg_saved, uint32_t NB, uint32_t cap,
                                                         uint32_t* __restrict__ vcount, const uint64_t* __restrict__ voff, uint4* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) uint32_t rec[(HT + 1) * 9];        // staged records, nine words each (the ninth is zero: reads behind word 7), one zero record in front
+    __shared__ uint32_t hist[1 << HOT_LG_MAX];                                  // instances of this workgroup per class of its first bucket; then the running slot inside the class
+    __shared__ uint32_t cbase[SCATTER ? (1 << HOT_LG_MAX) : 1];                 // SCATTER: the workgroup's first slot in every class
+    __shared__ uint32_t i0_s;
     const int tid = threadIdx.x;
     const uint64_t t = (uint64_t)blockIdx.x * HT + tid;
     const uint64_t total = h.rbase[h.n_hot];
@@ -116,17 +124,22 @@ __global__ void __launch_bounds__(HT) hot_expand_kernel(hot_tab h, const uint4* 
     uint32_t* my = rec + (tid + 1) * 9;
     my[0] = ra.x; my[1] = ra.y; my[2] = ra.z; my[3] = ra.w; my[4] = rb.x; my[5] = rb.y; my[6] = rb.z; my[7] = rb.w; my[8] = 0u;
     if (tid < 9) rec[tid] = 0u;
+    if (tid == 0) i0_s = i;                            // thread 0 is live whenever the workgroup has a record
     __syncthreads();
-    if (!live) return;
+    const uint32_t i0 = i0_s;
+    const uint32_t ncls0 = 1u << h.lg[i0], vb00 = h.vbase[i0];
+    for (uint32_t c = tid; c < ncls0; c += HT) hist[c] = 0u;
+    __syncthreads();
     const uint32_t m6 = rb.z, w7 = rb.w;
-    const uint32_t n_i = m6 & 0x7Fu, hasL = (m6 >> 7) & 1u, hasR = (m6 >> 8) & 1u;
-    const uint32_t lg = h.lg[i], vb0 = h.vbase[i];
-    for (uint32_t j = 0; j < n_i; ++j) {
-        // (the extraction of snk_count.hip's insert phase: words wi .. wi+4 of the record, the word before it for the preceding base)
+    const uint32_t n_i = live ? (m6 & 0x7Fu) : 0u, hasL = (m6 >> 7) & 1u, hasR = (m6 >> 8) & 1u;
+    const uint32_t lg = h.lg[live ? i : i0], vb0 = h.vbase[live ? i : i0];
+    const bool mine = i == i0;                         // counted in LDS
+    auto funnel = [](uint32_t hi_, uint32_t lo_, uint32_t s) { return (uint32_t)(((((uint64_t)hi_ << 32) | lo_) << s) >> 32); };
+    // class of k-mer j of this thread's record (the extraction of snk_count.hip's insert phase: words wi .. wi+4 of the record)
+    auto class_of = [&](uint32_t j) -> uint32_t {
         const uint32_t o = hasL + j;
         const uint32_t wi = o >> 4, sh = (2u * o) & 31u;
         const uint32_t* wp = my + wi;
-        auto funnel = [](uint32_t hi_, uint32_t lo_, uint32_t s) { return (uint32_t)(((((uint64_t)hi_ << 32) | lo_) << s) >> 32); };
         const uint32_t W0 = wp[0], W1 = wp[1], W2 = wp[2], W3 = wp[3];
         const uint32_t F0 = funnel(W0, W1, sh), F1 = funnel(W1, W2, sh), F2 = funnel(W2, W3, sh);
         uint32_t F3 = 0;
@@ -140,11 +153,29 @@ __global__ void __launch_bounds__(HT) hot_expand_kernel(hot_tab h, const uint4* 
         if (GROUPED) c.lo |= (uint64_t)w7;
         uint32_t h1, h2;
         snk_kmer_hash_count<(K > 48) || GROUPED>(c, &h1, &h2);
-        const uint32_t v = vb0 + (h2 & ((1u << lg) - 1u));
-        if (!SCATTER) { atomicAdd(&vcount[v], 1u); continue; }
-        const uint32_t slot = atomicAdd(&vcount[v], 1u);
-        const uint64_t dst = voff[v] + slot;
+        return h2 & ((1u << lg) - 1u);
+    };
+    for (uint32_t j = 0; j < n_i; ++j) {
+        const uint32_t c = class_of(j);
+        if (mine) atomicAdd(&hist[c], 1u);
+        else if (!SCATTER) atomicAdd(&vcount[vb0 + c], 1u);
+    }
+    __syncthreads();
+    for (uint32_t c = tid; c < ncls0; c += HT) {
+        const uint32_t n = hist[c];
+        if (n) {
+            const uint32_t first = atomicAdd(&vcount[vb00 + c], n);
+            if (SCATTER) { cbase[c] = first; hist[c] = 0u; }
+        }
+    }
+    if (!SCATTER) return;
+    __syncthreads();
+    for (uint32_t j = 0; j < n_i; ++j) {
+        const uint32_t c = class_of(j);
+        const uint32_t slot = mine ? cbase[c] + atomicAdd(&hist[c], 1u) : atomicAdd(&vcount[vb0 + c], 1u);
+        const uint64_t dst = voff[vb0 + c] + slot;
         // the single-k-mer record: bases o - hasL' .. o + K - 1 + hasR' of the supermer's base stream
+        const uint32_t o = hasL + j;
         const uint32_t nhasL = o > 0 ? 1u : 0u, nhasR = (j + 1u < n_i) ? 1u : hasR;
         const uint32_t a0 = o - nhasL, bits = 2u * ((uint32_t)K + nhasL + nhasR);
         const uint32_t wj = a0 >> 4, fs = (2u * a0) & 31u;

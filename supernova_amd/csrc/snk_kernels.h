@@ -30,6 +30,12 @@ struct snk_msp_args {
     uint64_t ovf_base;
     uint32_t* ovf_bucket;          // [SNK_OVF_SUBLISTS * ovf_cap] bucket of every overflow record
     uint32_t* ovf_cursor;          // [SNK_OVF_SUBLISTS] overflow records wanted per sub-list (keep counting past ovf_cap)
+    // buckets far beyond their capacity (a repeat family's or a homopolymer's minimiser: millions of supermers) stop reserving slots:
+    // a lane that is handed slot >= hot_thr notes the bucket in hot_tab[bucket % SNK_MSP_HOT_TAB] (bucket + 1), workgroups copy the
+    // table into LDS when they start, and a supermer of a noted bucket goes to the overflow list without touching the cursor --
+    // same-address atomics are served one at a time, ~10 ns each.  cursor[b] is exact up to cap and a lower bound beyond.
+    uint32_t* hot_tab;             // [SNK_MSP_HOT_TAB], zeroed; NULL = every supermer takes its reservation
+    uint32_t hot_thr;
     uint32_t dbg;                  // profiling aid (results invalid): 1 = no record stores, 2 = no slot atomics
     // fused quality trim (quals != NULL): the kernel derives every read's good length itself (the rule of snk_trim.hip), writes
     // it to good_out and adds the k-mer instances / contributing reads of its waves to plan[2 * (wave % 256) + {0, 1}]
@@ -46,6 +52,7 @@ struct snk_msp_args {
 };
 constexpr int SNK_MSP_PLAN_SLOTS = 256;
 constexpr uint32_t SNK_OVF_SUBLISTS = 64;
+constexpr uint32_t SNK_MSP_HOT_TAB = 256;
 int snk_launch_msp(uint32_t K, hipStream_t st, const snk_msp_args& a, char* err, size_t errcap);
 int snk_launch_msp_plan(hipStream_t st, const uint16_t* good_len, uint64_t n_reads, uint32_t K, unsigned long long* out2,
                         char* err, size_t errcap);

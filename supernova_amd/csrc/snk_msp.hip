@@ -210,6 +210,8 @@ __global__ void __launch_bounds__(BD, K == 48 ? SNK_MSP_OCC48 : 4) snk_msp_kerne
     // Only the POSITION of every suffix minimum is kept in LDS (1 byte per entry); the keys live in registers.
     uint16_t* lst = reinterpret_cast<uint16_t*>(rowL + (size_t)(row_words + 1) * BD);   // [LCAP][BD] minimiser position << 8 | first k-mer
     uint8_t* sfxp = reinterpret_cast<uint8_t*>(lst + (size_t)LCAP * BD);  // [W][BD] position of the suffix minimum
+    uint32_t* hotL = reinterpret_cast<uint32_t*>(sfxp + (size_t)W * BD);  // [SNK_MSP_HOT_TAB] buckets that stopped reserving slots (bucket + 1)
+    static_assert(SNK_MSP_HOT_TAB == BD && (W * BD) % 4 == 0, "one table entry per thread");
     const int tid0 = threadIdx.x;
     const uint64_t r0 = (uint64_t)blockIdx.x * BD;
     // fused trim: finished before the rows are staged (its registers are free again when the staging loads go out; live
@@ -245,6 +247,8 @@ __global__ void __launch_bounds__(BD, K == 48 ? SNK_MSP_OCC48 : 4) snk_msp_kerne
         }
     }
     rowL[row_words * BD + tid] = 0u;
+    // (an agent-scope load: the table is written by other workgroups of this launch, a plain load may be served from a stale line for good)
+    if (!DENSE) hotL[tid] = a.hot_tab ? __hip_atomic_load(&a.hot_tab[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     __syncthreads();
     const uint64_t r = r0 + tid;
     int g;
@@ -312,7 +316,13 @@ __global__ void __launch_bounds__(BD, K == 48 ? SNK_MSP_OCC48 : 4) snk_msp_kerne
                         if (pos < a.dense_cap) { at = pos; a.dense_bkt[pos] = bucket; }
                         else ok = false;                                   // the host sees the cursor beyond the capacity and re-runs
                     } else {
-                    slot = a.dbg == 2 ? ((ent * 2654435761u) % (a.cap ? a.cap : 1u)) : atomicAdd(&a.cursor[bucket], 1u);
+                    if (hotL[bucket % SNK_MSP_HOT_TAB] == bucket + 1u) slot = 0xFFFFFFFFu;
+                    else {
+                        slot = a.dbg == 2 ? ((ent * 2654435761u) % (a.cap ? a.cap : 1u)) : atomicAdd(&a.cursor[bucket], 1u);
+                        // (noted again every 1024 reservations: two hot buckets may share an entry)
+                        if (slot >= a.hot_thr && ((slot - a.hot_thr) & 1023u) == 0u && a.hot_tab)
+                            __hip_atomic_store(&a.hot_tab[bucket % SNK_MSP_HOT_TAB], bucket + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                     if (slot < a.cap) at = (uint64_t)bucket * a.cap + slot;
                     else {
                         // overflow list: ONE reservation per wave (same-address atomics are served one at a time)
@@ -517,7 +527,7 @@ __global__ void __launch_bounds__(256) snk_msp_plan_kernel(const uint16_t* __res
 }  // namespace
 
 size_t snk_msp_lds_bytes(uint32_t K, uint32_t M, uint32_t row_words) {
-    return (size_t)(row_words + 1) * BD * 4 + (size_t)LCAP * BD * 2 + (size_t)(K - M + 1) * BD + 64;
+    return (size_t)(row_words + 1) * BD * 4 + (size_t)LCAP * BD * 2 + (size_t)(K - M + 1) * BD + SNK_MSP_HOT_TAB * 4 + 64;
 }
 
 template <int K, int M, bool TRIM, bool DENSE>

@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(256) seg0_kernel(const uint32_t* __restrict__ 
     unsigned long long v = 0;
     if (b < NB) {
         const uint32_t c = cursor[b];
-        v = c;
+        v = c < cap ? c : cap;                 // (beyond the capacity the cursor is a lower bound: hot buckets stop counting, snk_msp.hip; the host adds the overflow lists)
         seg[b] = (uint64_t)b * cap;
         seg[NB + b] = (uint64_t)b * cap + (c < cap ? c : cap);
         seg[2ull * NB + b] = 0;
@@ -295,6 +295,18 @@ __global__ void __launch_bounds__(256) seg0_kernel(const uint32_t* __restrict__ 
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
     // (64 counters: the grid's 32 k waves on ONE address were 0.3 of this kernel's 0.4 ms)
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(&total[(blockIdx.x * 4u + (threadIdx.x >> 6)) & 63u], v);
+}
+// cursor[b] = supermers of bucket b, the overflowed ones included -- exact again once the overflow list is grouped by bucket
+__global__ void __launch_bounds__(256) cursor_exact_kernel(const uint64_t* __restrict__ seg, uint32_t NB, uint32_t* __restrict__ cursor) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b < NB) cursor[b] = (uint32_t)((seg[(uint64_t)NB + b] - seg[b]) + (seg[3ull * NB + b] - seg[2ull * NB + b]));
+}
+// slot reservations stop for a bucket that was handed slot hot_thr (SNK_MSP_HOT_FACTOR x capacity, 0 = never)
+static uint32_t msp_hot_thr(uint32_t cap) {
+    const uint64_t f = env_u32("SNK_MSP_HOT_FACTOR", 32);
+    const uint64_t t = f * cap;
+    const uint64_t lo = env_u32("SNK_MSP_HOT_MIN", 4096);
+    return f == 0 ? 0xFFFFFFFFu : (uint32_t)(t < lo ? lo : (t > 0x7FFFFFFFull ? 0x7FFFFFFFull : t));
 }
 // (instances, contributing reads) of one slab added to the streamed job's counters
 __global__ void plan_add_kernel(const unsigned long long* __restrict__ two, unsigned long long* __restrict__ plan) {
@@ -570,7 +582,7 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
     unsigned long long* d_total = nullptr;
     {
         void* q;
-        if ((rc = snk_ctx_alloc(ctx, (NB + 1) * 4ull, &q, err, errcap))) return rc; cursor = (uint32_t*)q;
+        if ((rc = snk_ctx_alloc(ctx, (NB + 1 + SNK_MSP_HOT_TAB) * 4ull, &q, err, errcap))) return rc; cursor = (uint32_t*)q;     // the hot table behind the cursors
         if ((rc = snk_ctx_alloc(ctx, 4ull * NB * 8 + 64, &q, err, errcap))) return rc; seg = (uint64_t*)q;
         if ((rc = snk_ctx_alloc(ctx, 64 * 8, &q, err, errcap))) return rc; d_total = (unsigned long long*)q;
     }
@@ -598,7 +610,7 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
         void* q;
         if ((rc = snk_ctx_alloc(ctx, ((size_t)NB * cap + 2 * ovf_cap) * 32 + 64, &records, err, errcap))) return rc;
         if ((rc = snk_ctx_alloc(ctx, ovf_cap * 4 + 64, &q, err, errcap))) return rc; ovf_bucket = (uint32_t*)q;
-        SNK_HIP_TRY(hipMemsetAsync(cursor, 0, (NB + 1) * 4ull, st));
+        SNK_HIP_TRY(hipMemsetAsync(cursor, 0, (NB + 1 + SNK_MSP_HOT_TAB) * 4ull, st));
         SNK_HIP_TRY(hipMemsetAsync(ovf_cur, 0, SNK_OVF_SUBLISTS * 4, st));
         snk_msp_args ma;
         memset(&ma, 0, sizeof ma);
@@ -607,6 +619,7 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
         ma.group = grouped ? (const uint32_t*)in->group : nullptr;
         ma.cursor = cursor; ma.records = (uint4*)records; ma.cap = cap; ma.ovf_cap = (uint32_t)sub_cap;
         ma.ovf_base = (uint64_t)NB * cap; ma.ovf_bucket = ovf_bucket; ma.ovf_cursor = ovf_cur;
+        ma.hot_tab = cursor + NB + 1; ma.hot_thr = msp_hot_thr(cap);
         ma.dbg = env_u32("SNK_MSP_DBG", 0);
         if (ft) {
             ma.good_len = ft->good_out; ma.quals = (const uint8_t*)ft->quals; ma.qstride = ft->qstride; ma.min_qual = ft->min_qual;
@@ -637,6 +650,7 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
         uint64_t want = 0, mx = 0;
         for (uint32_t q2 = 0; q2 < SNK_OVF_SUBLISTS; ++q2) { want += h_sub[q2]; if (h_sub[q2] > mx) mx = h_sub[q2]; }
         h_novf = (uint32_t)(want > 0xFFFFFFFFull ? 0xFFFFFFFFull : want);
+        h_total += want;
         ctx->last_ovf = (uint32_t)(mx * SNK_OVF_SUBLISTS > 0xFFFFFFFFull ? 0xFFFFFFFFull : mx * SNK_OVF_SUBLISTS); ctx->last_ovf_nb = NB; ctx->last_ovf_reads = n_reads;
         if (mx <= sub_cap) break;
         if (attempt == 2) return snk_fail(SNK_E_INTERNAL, err, errcap, "supermer overflow list too small (%llu > %llu)", (unsigned long long)mx, (unsigned long long)sub_cap);
@@ -646,6 +660,7 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
     }
     // segment 1: the overflow records grouped by bucket
     if ((rc = snk_msp_segments(ctx, st, NB, cap, cursor, (uint4*)records, (uint64_t)NB * cap, ovf_cap / SNK_OVF_SUBLISTS, ovf_bucket, h_sub, seg, err, errcap))) return rc;
+    if (h_novf) hipLaunchKernelGGL(cursor_exact_kernel, dim3((NB + 255) / 256), dim3(256), 0, st, seg, NB, cursor);
     out->NB = NB;
     out->cap = cap;
     out->nseg = h_novf ? 2u : 1u;
@@ -700,14 +715,14 @@ int snk_partition_open(snk_ctx* ctx, hipStream_t st, uint32_t K, uint32_t NB, un
     if (J->ovf_cap >= (1ull << 31)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "supermer overflow list too large");
     int rc;
     void* q;
-    if ((rc = snk_ctx_alloc(ctx, (NB + 1) * 4ull, &q, err, errcap))) return rc; J->cursor = (uint32_t*)q;
+    if ((rc = snk_ctx_alloc(ctx, (NB + 1 + SNK_MSP_HOT_TAB) * 4ull, &q, err, errcap))) return rc; J->cursor = (uint32_t*)q;
     if ((rc = snk_ctx_alloc(ctx, 4ull * NB * 8 + 64, &q, err, errcap))) return rc; J->seg = (uint64_t*)q;
     if ((rc = snk_ctx_alloc(ctx, 64 * 8, &q, err, errcap))) return rc; J->d_total = (unsigned long long*)q;
     if ((rc = snk_ctx_alloc(ctx, 2ull * SNK_MSP_PLAN_SLOTS * 8, &q, err, errcap))) return rc; J->d_plan = (unsigned long long*)q;
     if ((rc = snk_ctx_alloc(ctx, ((size_t)NB * J->cap + 2 * J->ovf_cap) * 32 + 64, &J->records, err, errcap))) return rc;
     if ((rc = snk_ctx_alloc(ctx, J->ovf_cap * 4 + 64, &q, err, errcap))) return rc; J->ovf_bucket = (uint32_t*)q;
     if ((rc = snk_ctx_alloc(ctx, SNK_OVF_SUBLISTS * 4 + 64, &q, err, errcap))) return rc; J->ovf_cur = (uint32_t*)q;
-    SNK_HIP_TRY(hipMemsetAsync(J->cursor, 0, (NB + 1) * 4ull, st));
+    SNK_HIP_TRY(hipMemsetAsync(J->cursor, 0, (NB + 1 + SNK_MSP_HOT_TAB) * 4ull, st));
     SNK_HIP_TRY(hipMemsetAsync(J->ovf_cur, 0, SNK_OVF_SUBLISTS * 4, st));
     SNK_HIP_TRY(hipMemsetAsync(J->d_plan, 0, 2ull * SNK_MSP_PLAN_SLOTS * 8, st));
     return SNK_OK;
@@ -726,6 +741,7 @@ int snk_partition_add(snk_ctx* ctx, hipStream_t st, snk_partition_job* J, const 
     ma.group = J->grouped ? (const uint32_t*)in->group : nullptr;
     ma.cursor = J->cursor; ma.records = (uint4*)J->records; ma.cap = J->cap; ma.ovf_cap = (uint32_t)(J->ovf_cap / SNK_OVF_SUBLISTS);
     ma.ovf_base = (uint64_t)J->NB * J->cap; ma.ovf_bucket = J->ovf_bucket; ma.ovf_cursor = J->ovf_cur;
+    ma.hot_tab = J->cursor + J->NB + 1; ma.hot_thr = msp_hot_thr(J->cap);
     if (ft) {
         ma.good_len = ft->good_out; ma.quals = (const uint8_t*)ft->quals; ma.qstride = ft->qstride; ma.min_qual = ft->min_qual;
         ma.lens = (const uint16_t*)ft->lens; ma.good_out = ft->good_out; ma.plan = J->d_plan;
@@ -766,11 +782,13 @@ int snk_partition_close(snk_ctx* ctx, hipStream_t st, snk_partition_job* J, snk_
     uint64_t want = 0, mx = 0;
     for (uint32_t q = 0; q < SNK_OVF_SUBLISTS; ++q) { want += h_sub[q]; if (h_sub[q] > mx) mx = h_sub[q]; }
     h_novf = (uint32_t)(want > 0xFFFFFFFFull ? 0xFFFFFFFFull : want);
+    h_total += want;
     if (mx > J->ovf_cap / SNK_OVF_SUBLISTS)
         return snk_fail(SNK_E_NOMEM, err, errcap, "streamed partition: %u supermers beyond their buckets' capacity, the overflow list holds %llu (the job's read total was "
                         "underestimated, or a few minimisers carry a large share of the data): run it resident or with a larger total", h_novf, (unsigned long long)J->ovf_cap);
     int rc;
     if ((rc = snk_msp_segments(ctx, st, NB, J->cap, J->cursor, (uint4*)J->records, (uint64_t)NB * J->cap, J->ovf_cap / SNK_OVF_SUBLISTS, J->ovf_bucket, h_sub, J->seg, err, errcap))) return rc;
+    if (h_novf) hipLaunchKernelGGL(cursor_exact_kernel, dim3((NB + 255) / 256), dim3(256), 0, st, J->seg, NB, J->cursor);
     out->NB = NB;
     out->cap = J->cap;
     out->nseg = h_novf ? 2u : 1u;

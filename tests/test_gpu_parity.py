@@ -513,6 +513,30 @@ def test_partition_overflow_segment(engine, monkeypatch, pct):
         assert res.n_overflow > 0
 
 
+@pytest.mark.parametrize("name", ["adversarial", "synth_20k_err"])
+@pytest.mark.parametrize("hot_buckets", [False, True])
+def test_partition_stops_reserving_slots_for_hot_buckets(engine, monkeypatch, name, hot_buckets):
+    """snk_msp.hip: a bucket that was handed a slot far beyond its capacity is noted in a small table; workgroups that start later send its
+    supermers to the overflow list without touching its cursor (same-address atomics queue: a homopolymer's bucket held the partition
+    for 60 ms).  Forced on the goldens: tiny capacity, noted at the first overflowing slot -- same results, with and without the
+    k-mer-hash re-partition of the buckets that end up hot."""
+    monkeypatch.setenv("SNK_MSP_CAP_PCT", "10")
+    monkeypatch.setenv("SNK_MSP_HOT_FACTOR", "1")
+    monkeypatch.setenv("SNK_MSP_HOT_MIN", "1")
+    if hot_buckets:
+        monkeypatch.setenv("SNK_HOT_MIN", "8")
+        monkeypatch.setenv("SNK_HOT_FACTOR", "1")
+        monkeypatch.setenv("SNK_HOT_CLASS_INST", "300")
+    c = goldens.load(name)
+    rows, quals, bc, lens = _to_dev(c)
+    res = engine.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, ign_bc_below=c.ign_bc_below)
+    _check_against(res, c.exp_keys, c.exp_counts, c.exp_ctx, c.exp_unitigs, c.exp_goodlens, c.exp_hist)
+    assert res.n_overflow > 0
+    assert res.n_supermers == engine.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, ign_bc_below=c.ign_bc_below).n_supermers
+    monkeypatch.setenv("SNK_MSP_HOT_FACTOR", "0")          # never noted: every supermer takes its reservation
+    assert res.n_supermers == engine.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, ign_bc_below=c.ign_bc_below).n_supermers
+
+
 @pytest.mark.parametrize("name,K", [("adversarial", 48), ("synth_20k_err", 48), ("adversarial", 60)])
 def test_dense_partition_mode(engine, monkeypatch, name, K):
     """SNK_MSP_DENSE=1 (round 4's measured alternative to the slot reservations, DESIGN 4 "round 4"): records leave the scan kernel in

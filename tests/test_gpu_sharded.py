@@ -100,6 +100,17 @@ def test_sharded_replicated_ranking_with_circles(snk, W, monkeypatch):
     assert {o["ranking"] for o in out} == {"replicated"}
 
 
+@pytest.mark.parametrize("W", [1, 3])
+def test_sharded_overflowing_buckets_and_the_hot_table(snk, W, monkeypatch):
+    """Tiny bucket capacity: most supermers travel through the overflow list, and buckets noted as hot stop counting in their cursors
+    (snk_msp.hip) -- the per-bucket histogram the exchange is planned from is rebuilt from the grouped overflow list."""
+    monkeypatch.setenv("SNK_MSP_CAP_PCT", "10")
+    monkeypatch.setenv("SNK_MSP_HOT_FACTOR", "1")
+    monkeypatch.setenv("SNK_MSP_HOT_MIN", "1")
+    c = goldens.load("synth_20k_err")
+    check(run_world(W, c), c)
+
+
 def test_sharded_many_small_buckets(snk):
     c = goldens.load("adversarial")
     check(run_world(4, c, n_buckets=4 * 997), c)
