@@ -29,7 +29,7 @@ struct snk_msp_args {
     uint32_t ovf_cap;              // slots of ONE overflow sub-list (there are SNK_OVF_SUBLISTS, chosen by wave)
     uint64_t ovf_base;
     uint32_t* ovf_bucket;          // [SNK_OVF_SUBLISTS * ovf_cap] bucket of every overflow record
-    uint32_t* ovf_cursor;          // [SNK_OVF_SUBLISTS] overflow records wanted per sub-list (keep counting past ovf_cap)
+    uint32_t* ovf_cursor;          // [SNK_OVF_SUBLISTS x SNK_OVF_CUR_STRIDE] overflow records wanted per sub-list (keep counting past ovf_cap)
     // buckets far beyond their capacity (a repeat family's or a homopolymer's minimiser: millions of supermers) stop reserving slots:
     // a lane that is handed slot >= hot_thr notes the bucket in hot_tab[bucket % SNK_MSP_HOT_TAB] (bucket + 1), workgroups copy the
     // table into LDS when they start, and a supermer of a noted bucket goes to the overflow list without touching the cursor --
@@ -52,6 +52,9 @@ struct snk_msp_args {
 };
 constexpr int SNK_MSP_PLAN_SLOTS = 256;
 constexpr uint32_t SNK_OVF_SUBLISTS = 64;
+// the sub-lists' cursors lie 128 bytes apart: atomics on one 64-byte line are served one at a time whatever word they address (64 cursors in
+// four lines: 25 M reservations of a repeat-rich genome took 63 ms, a quarter of what ONE cursor took)
+constexpr uint32_t SNK_OVF_CUR_STRIDE = 32;
 constexpr uint32_t SNK_MSP_HOT_TAB = 256;
 int snk_launch_msp(uint32_t K, hipStream_t st, const snk_msp_args& a, char* err, size_t errcap);
 int snk_launch_msp_plan(hipStream_t st, const uint16_t* good_len, uint64_t n_reads, uint32_t K, unsigned long long* out2,

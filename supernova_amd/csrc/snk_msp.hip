@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(BD, K == 48 ? SNK_MSP_OCC48 : 4) snk_msp_kerne
                         // overflow, nearly every wave has one in every turn, and ten million reservations on ONE address were 108 ms
                         const uint32_t sub = (blockIdx.x * (BD / 64) + ((uint32_t)tid >> 6)) & (SNK_OVF_SUBLISTS - 1u);
                         uint32_t o = 0;
-                        if (lane == leader) o = atomicAdd(&a.ovf_cursor[sub], (uint32_t)__popcll(m));
+                        if (lane == leader) o = atomicAdd(&a.ovf_cursor[sub * SNK_OVF_CUR_STRIDE], (uint32_t)__popcll(m));
                         o = __shfl(o, leader) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                         if (o < a.ovf_cap) { const uint32_t g = sub * a.ovf_cap + o; at = a.ovf_base + g; a.ovf_bucket[g] = bucket; }
                         else ok = false;                               // the host sees a cursor beyond its sub-list and re-runs

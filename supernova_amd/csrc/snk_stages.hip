@@ -599,9 +599,10 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
     void* records = nullptr;
     uint32_t* ovf_bucket = nullptr;
     uint32_t* ovf_cur = nullptr;        // [SNK_OVF_SUBLISTS] the sub-lists' cursors
-    { void* q; if ((rc = snk_ctx_alloc(ctx, SNK_OVF_SUBLISTS * 4 + 64, &q, err, errcap))) return rc; ovf_cur = (uint32_t*)q; }
+    { void* q; if ((rc = snk_ctx_alloc(ctx, SNK_OVF_SUBLISTS * SNK_OVF_CUR_STRIDE * 4 + 64, &q, err, errcap))) return rc; ovf_cur = (uint32_t*)q; }
     uint32_t h_novf = 0;
     uint32_t h_sub[SNK_OVF_SUBLISTS];
+    uint32_t h_cur[SNK_OVF_SUBLISTS * SNK_OVF_CUR_STRIDE];      // the cursors as they lie on the device, one per 128 bytes
     unsigned long long h_total = 0;
     for (int attempt = 0; attempt < 3; ++attempt) {
         ovf_cap = (ovf_cap + SNK_OVF_SUBLISTS - 1) / SNK_OVF_SUBLISTS * SNK_OVF_SUBLISTS;
@@ -611,7 +612,7 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
         if ((rc = snk_ctx_alloc(ctx, ((size_t)NB * cap + 2 * ovf_cap) * 32 + 64, &records, err, errcap))) return rc;
         if ((rc = snk_ctx_alloc(ctx, ovf_cap * 4 + 64, &q, err, errcap))) return rc; ovf_bucket = (uint32_t*)q;
         SNK_HIP_TRY(hipMemsetAsync(cursor, 0, (NB + 1 + SNK_MSP_HOT_TAB) * 4ull, st));
-        SNK_HIP_TRY(hipMemsetAsync(ovf_cur, 0, SNK_OVF_SUBLISTS * 4, st));
+        SNK_HIP_TRY(hipMemsetAsync(ovf_cur, 0, SNK_OVF_SUBLISTS * SNK_OVF_CUR_STRIDE * 4, st));
         snk_msp_args ma;
         memset(&ma, 0, sizeof ma);
         ma.rows = (const uint32_t*)in->rows; ma.row_words = in->row_words; ma.read_len = in->read_len; ma.good_len = good_len; ma.bc = (const int32_t*)in->bc;
@@ -634,12 +635,13 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
         // host wants to know about this pass (overflow count, supermers, and the caller's trim statistics if asked for)
         SNK_HIP_TRY(hipMemsetAsync(d_total, 0, 64 * 8, st));
         hipLaunchKernelGGL(seg0_kernel, dim3((NB + 255) / 256), dim3(256), 0, st, cursor, NB, cap, seg, d_total);
-        SNK_HIP_TRY(hipMemcpyAsync(h_sub, ovf_cur, sizeof h_sub, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(hipMemcpyAsync(h_cur, ovf_cur, sizeof h_cur, hipMemcpyDeviceToHost, st));
         unsigned long long h_tot64[64];
         SNK_HIP_TRY(hipMemcpyAsync(h_tot64, d_total, sizeof h_tot64, hipMemcpyDeviceToHost, st));
         if (d_plan && h_plan && !ft) SNK_HIP_TRY(hipMemcpyAsync(h_plan, d_plan, 16, hipMemcpyDeviceToHost, st));
         if (ft) SNK_HIP_TRY(hipMemcpyAsync(h_fplan.data(), d_fplan, h_fplan.size() * 8, hipMemcpyDeviceToHost, st));
         SNK_HIP_TRY(snk_sync(st));
+        for (uint32_t q2 = 0; q2 < SNK_OVF_SUBLISTS; ++q2) h_sub[q2] = h_cur[q2 * SNK_OVF_CUR_STRIDE];
         h_total = 0;
         for (int q = 0; q < 64; ++q) h_total += h_tot64[q];
         if (ft) {
@@ -721,9 +723,9 @@ int snk_partition_open(snk_ctx* ctx, hipStream_t st, uint32_t K, uint32_t NB, un
     if ((rc = snk_ctx_alloc(ctx, 2ull * SNK_MSP_PLAN_SLOTS * 8, &q, err, errcap))) return rc; J->d_plan = (unsigned long long*)q;
     if ((rc = snk_ctx_alloc(ctx, ((size_t)NB * J->cap + 2 * J->ovf_cap) * 32 + 64, &J->records, err, errcap))) return rc;
     if ((rc = snk_ctx_alloc(ctx, J->ovf_cap * 4 + 64, &q, err, errcap))) return rc; J->ovf_bucket = (uint32_t*)q;
-    if ((rc = snk_ctx_alloc(ctx, SNK_OVF_SUBLISTS * 4 + 64, &q, err, errcap))) return rc; J->ovf_cur = (uint32_t*)q;
+    if ((rc = snk_ctx_alloc(ctx, SNK_OVF_SUBLISTS * SNK_OVF_CUR_STRIDE * 4 + 64, &q, err, errcap))) return rc; J->ovf_cur = (uint32_t*)q;
     SNK_HIP_TRY(hipMemsetAsync(J->cursor, 0, (NB + 1 + SNK_MSP_HOT_TAB) * 4ull, st));
-    SNK_HIP_TRY(hipMemsetAsync(J->ovf_cur, 0, SNK_OVF_SUBLISTS * 4, st));
+    SNK_HIP_TRY(hipMemsetAsync(J->ovf_cur, 0, SNK_OVF_SUBLISTS * SNK_OVF_CUR_STRIDE * 4, st));
     SNK_HIP_TRY(hipMemsetAsync(J->d_plan, 0, 2ull * SNK_MSP_PLAN_SLOTS * 8, st));
     return SNK_OK;
 }
@@ -769,12 +771,14 @@ int snk_partition_close(snk_ctx* ctx, hipStream_t st, snk_partition_job* J, snk_
     hipLaunchKernelGGL(seg0_kernel, dim3((NB + 255) / 256), dim3(256), 0, st, J->cursor, NB, J->cap, J->seg, J->d_total);
     uint32_t h_novf = 0;
     uint32_t h_sub[SNK_OVF_SUBLISTS];
+    uint32_t h_cur[SNK_OVF_SUBLISTS * SNK_OVF_CUR_STRIDE];      // the cursors as they lie on the device, one per 128 bytes
     unsigned long long h_tot64[64];
     std::vector<unsigned long long> h_fplan(2 * SNK_MSP_PLAN_SLOTS);
-    SNK_HIP_TRY(hipMemcpyAsync(h_sub, J->ovf_cur, sizeof h_sub, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipMemcpyAsync(h_cur, J->ovf_cur, sizeof h_cur, hipMemcpyDeviceToHost, st));
     SNK_HIP_TRY(hipMemcpyAsync(h_tot64, J->d_total, sizeof h_tot64, hipMemcpyDeviceToHost, st));
     SNK_HIP_TRY(hipMemcpyAsync(h_fplan.data(), J->d_plan, h_fplan.size() * 8, hipMemcpyDeviceToHost, st));
     SNK_HIP_TRY(snk_sync(st));
+    for (uint32_t q = 0; q < SNK_OVF_SUBLISTS; ++q) h_sub[q] = h_cur[q * SNK_OVF_CUR_STRIDE];
     unsigned long long h_total = 0;
     for (int q = 0; q < 64; ++q) h_total += h_tot64[q];
     h_plan[0] = h_plan[1] = 0;
