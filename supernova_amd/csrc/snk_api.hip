@@ -1,6 +1,8 @@
 // snk_api.hip -- context, error plumbing, synthetic read generator entry points of libsnk.
 #include <math.h>
 #include <stdlib.h>
+#include <execinfo.h>
+#include <dlfcn.h>
 #include <time.h>
 
 #include <algorithm>
@@ -105,7 +107,8 @@ void va_insert_free(std::vector<snk_ctx::vrange>& fr, size_t off, size_t bytes) 
     if (i + 1 < fr.size() && fr[i].off + fr[i].bytes == fr[i + 1].off) { fr[i].bytes += fr[i + 1].bytes; fr.erase(fr.begin() + (long)i + 1); }
     if (i > 0 && fr[i - 1].off + fr[i - 1].bytes == fr[i].off) { fr[i - 1].bytes += fr[i].bytes; fr.erase(fr.begin() + (long)i); }
 }
-bool va_trace() { static const bool t = getenv("SNK_ARENA_TRACE") && *getenv("SNK_ARENA_TRACE") == '1'; return t; }
+bool va_trace() { static const bool t = getenv("SNK_ARENA_TRACE") && *getenv("SNK_ARENA_TRACE") >= '1'; return t; }
+bool va_trace2() { static const bool t = getenv("SNK_ARENA_TRACE") && *getenv("SNK_ARENA_TRACE") >= '2'; return t; }      // every range handed out / taken back
 double va_now() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + 1e-6 * t.tv_nsec; }
 bool va_grow(snk_ctx* ctx, size_t need) {
     const double t0 = va_now();
@@ -176,6 +179,7 @@ void* va_alloc(snk_ctx* ctx, size_t bytes) {
             else { f.off += bytes; f.bytes -= bytes; }
             ctx->va_used.push_back(snk_ctx::vrange{off, bytes});
             if (off + bytes > ctx->va_high) ctx->va_high = off + bytes;
+            if (va_trace2()) fprintf(stderr, "[snk arena] A %zu %zu\n", off, bytes);
             return ctx->va_base + off;
         }
         // nothing fits: grow by what is missing behind a free tail
@@ -194,16 +198,40 @@ bool va_release(snk_ctx* ctx, const void* p) {
             ctx->va_used[i] = ctx->va_used.back();
             ctx->va_used.pop_back();
             va_insert_free(ctx->va_free, off, b);
+            if (va_trace2()) fprintf(stderr, "[snk arena] R %zu %zu\n", off, b);
             ctx->total_alloc -= b;
             return true;
         }
+    if (va_trace2()) fprintf(stderr, "[snk arena] R? %zu (not live)\n", off);
     return true;      // inside the range but not live: already released
 }
 }  // namespace
 
+// SNK_ARENA_POISON=1 (tests): every block handed out is filled with 0xCD first -- scratch is not zero (a cached block holds the last
+// call's data, a fresh mapping whatever the device held), and code that reads a word it never wrote shows up at golden size this way
+// instead of at 150 M reads in the third test of a process
+static void arena_poison(void* p, size_t bytes) {
+    static const bool on = getenv("SNK_ARENA_POISON") && *getenv("SNK_ARENA_POISON") == '1';
+    // (waited for: the caller may initialise the block on a non-blocking stream, which the null stream's memset is not ordered with)
+    if (on) { (void)hipMemset(p, 0xCD, bytes); (void)hipStreamSynchronize(nullptr); }
+}
+
 int snk_ctx_alloc(snk_ctx* ctx, size_t bytes, void** out, char* err, size_t errcap) {
     if (bytes == 0) bytes = 256;
     bytes = (bytes + 255) & ~(size_t)255;
+    if (ctx->device_mem_total && bytes > 2 * ctx->device_mem_total) {
+        // a size no device holds is a sizing bug upstream (an unset counter, an underflow): say where it came from -- return addresses
+        // relative to the library's load address, for llvm-symbolizer / objdump on the same build
+        void* fr[12];
+        const int n = backtrace(fr, 12);
+        Dl_info di;
+        uintptr_t base = 0;
+        if (dladdr((void*)&snk_ctx_alloc, &di) && di.dli_fbase) base = (uintptr_t)di.dli_fbase;
+        char where[256];
+        size_t w = 0;
+        for (int i = 1; i < n && w + 20 < sizeof where; ++i) w += (size_t)snprintf(where + w, sizeof where - w, " +0x%zx", (size_t)((uintptr_t)fr[i] - base));
+        return snk_fail(SNK_E_INTERNAL, err, errcap, "scratch request of %zu bytes (device: %zu) from libsnk%s", bytes, (size_t)ctx->device_mem_total, where);
+    }
     if (ctx->va_state >= 0 && !ctx->arena_legacy) {
         if (void* q = va_alloc(ctx, bytes)) {
             ++ctx->alloc_serial;
@@ -211,6 +239,7 @@ int snk_ctx_alloc(snk_ctx* ctx, size_t bytes, void** out, char* err, size_t errc
             ctx->total_alloc += bytes;
             if (ctx->total_alloc > ctx->peak_alloc) ctx->peak_alloc = ctx->total_alloc;
             *out = q;
+            arena_poison(q, bytes);
             return SNK_OK;
         }
     }
@@ -232,6 +261,7 @@ int snk_ctx_alloc(snk_ctx* ctx, size_t bytes, void** out, char* err, size_t errc
         ctx->total_alloc += ctx->blocks[best].bytes;
         if (ctx->total_alloc > ctx->peak_alloc) ctx->peak_alloc = ctx->total_alloc;
         *out = ctx->blocks[best].p;
+        arena_poison(*out, bytes);
         return SNK_OK;
     }
     void* p = nullptr;
@@ -248,6 +278,7 @@ int snk_ctx_alloc(snk_ctx* ctx, size_t bytes, void** out, char* err, size_t errc
     if (ctx->total_alloc > ctx->peak_alloc) ctx->peak_alloc = ctx->total_alloc;
     ctx->cached_bytes += bytes;
     *out = p;
+    arena_poison(p, bytes);
     return SNK_OK;
 }
 // hand one block back to the cache in the middle of a call (the big ones: supermer slots after the count, count regions
