@@ -397,7 +397,8 @@ typedef struct snk_dev_paths {
     const void* unitig_bc_off; /* u64[n_unitigs + 1] */
     const void* unitig_bcs;    /* u32[n_unitig_bcs] */
     uint64_t n_unitig_bcs;
-    float bcs_ms, reserved_f;  /* HIP events: key sort + run heads + per-unitig lists (SNK_PATH_UNITIG_BCS) */
+    float bcs_ms;              /* HIP events: key sort + run heads + per-unitig lists (SNK_PATH_UNITIG_BCS) */
+    uint32_t lookup_index;     /* 1: the look-ups went through the minimiser index (the k-mer dictionary did not fit, or SNK_PATH_INDEX=1); dict_slots then counts its places */
     uint64_t n_slow;           /* reads the fast pass left to the full algorithm (a miss, or an exact-match run that ended inside the read) */
 } snk_dev_paths;
 #define SNK_PATH_UNITIG_BCS 1u

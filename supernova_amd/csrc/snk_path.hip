@@ -62,6 +62,15 @@ struct path_graph {            // device arrays
     const uint32_t* ublk;      // unitig that holds base 256 b of the concatenation (position -> unitig: this entry, then a step or two along uoff)
     uint64_t dcap;             // slots: 3 per k-mer, not a power of two
     unsigned long long fp_mask; // 30 ones; SNK_PATH_FP_MASK (tests) narrows the fingerprint so that false matches happen and the verified path runs
+    // Minimiser index (round 4; ment != NULL: the look-ups go through it and dslot is not built).  A k-mer lies on the graph iff its
+    // minimiser -- the 16-mer with the smallest ordering key among its K-15, the leftmost on ties -- occurs in a unitig at the matching
+    // place and the K bases around it agree.  The index lists the places a unitig k-mer's window picks (its leftmost AND its rightmost
+    // minimum: a read may run against the unitig's strand), ~2 / (K-14) of the unitig bases: 8 bytes each, sorted by key behind a
+    // directory over the key's top bits -- 0.14 GB for the bench graph's 0.27 G k-mers where the k-mer dictionary takes 6.4 GB, small
+    // enough to live in the 256 MB Infinity Cache together with the packed unitigs the candidates are verified against.
+    const unsigned long long* ment;    // [n_ment] key low 30 bits << 34 | the unitig's 16-mer is the reverse complement of the canonical one << 33 | position
+    const uint32_t* mdir;      // [(1 << mdir_bits) + 1] first entry of every key prefix
+    uint32_t mdir_bits;
 };
 
 template <int K>
@@ -71,6 +80,18 @@ __device__ __forceinline__ snk_kmer kmer_at(const uint32_t* words, uint32_t nwor
 #pragma unroll
     for (uint32_t q = 0; q < 5; ++q) W[q] = wi + q < nwords ? words[wi + q] : 0u;
     const uint64_t A = ((uint64_t)W[0] << 32) | W[1], B = ((uint64_t)W[2] << 32) | W[3], C = (uint64_t)W[4] << 32;
+    snk_kmer f;
+    f.hi = sh ? ((A << sh) | (B >> (64 - sh))) : A;
+    const uint64_t lo = sh ? ((B << sh) | (C >> (64 - sh))) : B;
+    f.lo = lo & ~((1ull << (128 - 2 * K)) - 1ull);
+    return f;
+}
+// the same from a long packed array (no bound: the caller's array has slack behind its last base)
+template <int K>
+__device__ __forceinline__ snk_kmer kmer_at64(const uint32_t* words, uint64_t pos) {
+    const uint64_t wi = pos >> 4;
+    const uint32_t sh = 2u * ((uint32_t)pos & 15u);
+    const uint64_t A = ((uint64_t)words[wi] << 32) | words[wi + 1], B = ((uint64_t)words[wi + 2] << 32) | words[wi + 3], C = (uint64_t)words[wi + 4] << 32;
     snk_kmer f;
     f.hi = sh ? ((A << sh) | (B >> (64 - sh))) : A;
     const uint64_t lo = sh ? ((B << sh) | (C >> (64 - sh))) : B;
@@ -164,6 +185,135 @@ __global__ void __launch_bounds__(256) dict_build_kernel(const uint64_t* __restr
             if (++s == dcap) s = 0;
         }
     }
+}
+// ---- minimiser index build.  A thread takes MM_RUN consecutive windows (k-mer start positions) of the concatenated unitigs: the
+// ordering keys of the MM_RUN + W 16-mers they cover are computed once (registers, static indices), every window's leftmost and
+// rightmost minimum falls out of W compares.  A place is listed when the window's choice moves (L and R only move right along a
+// unitig), so every chosen place is listed once per role.  COUNT pass: places per workgroup; FILL pass: the same scan writes them
+// at the workgroup's offset -- no atomics, no guessed capacity.
+constexpr int MM_RUN = 16;
+__device__ __forceinline__ uint32_t mm_key(uint32_t x, uint32_t* orient) {
+    const uint32_t rx = snk_rev2_32(~x);
+    *orient = rx < x ? 1u : 0u;
+    return snk_minimizer_key(x, rx);
+}
+template <int K, bool FILL>
+__global__ void __launch_bounds__(256) mm_scan_kernel(const uint64_t* __restrict__ uoff, const uint32_t* __restrict__ upack, uint64_t U, uint64_t total,
+                                                      uint32_t* __restrict__ wg_count, const uint64_t* __restrict__ wg_off, uint32_t* __restrict__ okey,
+                                                      unsigned long long* __restrict__ oval) {
+    constexpr int W = K - 15;                      // 16-mers per k-mer
+    constexpr int NK = MM_RUN + W;                 // keys of windows t0 - 1 .. t0 + MM_RUN - 1
+    constexpr int NWD = (NK + 15 + 15) / 16 + 1;   // aligned words that hold their bases
+    __shared__ uint32_t lcur;                      // places of this workgroup so far
+    if (threadIdx.x == 0) lcur = 0;
+    __syncthreads();
+    const uint64_t t0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * MM_RUN;
+    const uint64_t out0 = FILL ? wg_off[blockIdx.x] : 0ull;
+    uint32_t mine = 0;
+    auto emit = [&](uint32_t bk, unsigned long long orib, int at, uint64_t tbase) {
+        if (FILL) {
+            const uint32_t s = atomicAdd(&lcur, 1u);     // (the order inside a workgroup does not matter: the places are sorted by key afterwards)
+            okey[out0 + s] = bk;
+            oval[out0 + s] = ((unsigned long long)(bk & 0x3FFFFFFFu) << 34) | (((orib >> at) & 1ull) << 33) | (tbase + (uint64_t)at);
+        } else ++mine;
+    };
+    if (t0 < total) {
+        // bases from t0 - 1 on, aligned to a word boundary (the slack in front of the packed unitigs covers t0 = 0)
+        const uint64_t b0 = UPAD + t0 - 1;
+        const uint32_t* wp = upack + (b0 >> 4);
+        const uint32_t sh = 2u * ((uint32_t)b0 & 15u);
+        uint32_t A[NWD];
+#pragma unroll
+        for (int q = 0; q < NWD; ++q) A[q] = (uint32_t)(((((uint64_t)wp[q] << 32) | wp[q + 1]) << sh) >> 32);
+        uint32_t key[NK], ori = 0;                 // key j: the 16-mer at t0 - 1 + j
+        unsigned long long orib = 0;
+#pragma unroll
+        for (int j = 0; j < NK; ++j) {
+            const uint32_t x = (uint32_t)(((((uint64_t)A[j >> 4] << 32) | A[(j >> 4) + 1]) << (2 * (j & 15))) >> 32);
+            key[j] = mm_key(x, &ori);
+            orib |= (unsigned long long)ori << j;
+        }
+        uint64_t lo = 0, hi = U;                   // unitig of t0 (largest u with uoff[u] <= t0)
+        while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (uoff[mid] <= t0) lo = mid; else hi = mid; }
+        uint64_t us = uoff[lo], ue = uoff[lo + 1];
+        int pl = -1, pr = -1;                      // the choices of the window before (relative to t0 - 1), -1: none in this unitig
+        {   // window t0 - 1, if it is a window of the same unitig
+            if (t0 > us) {
+                uint32_t bk = key[0]; int bl = 0, br = 0;
+#pragma unroll
+                for (int j = 1; j < W; ++j) { if (key[j] < bk) { bk = key[j]; bl = j; br = j; } else if (key[j] == bk) br = j; }
+                if (t0 - 1 + K <= ue) { pl = bl; pr = br; }
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < MM_RUN; ++w) {
+            const uint64_t t = t0 + w;
+            if (t >= ue && t < total) { ++lo; us = ue; ue = uoff[lo + 1]; pl = -1; pr = -1; while (t >= ue) { ++lo; us = ue; ue = uoff[lo + 1]; } }
+            if (t < total && t + K <= ue) {
+                uint32_t bk = key[w + 1]; int bl = w + 1, br = w + 1;
+#pragma unroll
+                for (int j = 1; j < W; ++j) { const uint32_t kj = key[w + 1 + j]; if (kj < bk) { bk = kj; bl = w + 1 + j; br = bl; } else if (kj == bk) br = w + 1 + j; }
+                if (bl != pl) emit(bk, orib, bl, t0 - 1);
+                if (br != bl && br != pr) emit(bk, orib, br, t0 - 1);
+                pl = bl; pr = br;
+            } else { pl = -1; pr = -1; }
+        }
+    }
+    if (!FILL) {
+        snk_wave_add(&lcur, mine);
+        __syncthreads();
+        if (threadIdx.x == 0) wg_count[blockIdx.x] = lcur;
+    }
+}
+__global__ void __launch_bounds__(256) mm_widen_kernel(const uint32_t* __restrict__ in, uint64_t n, uint64_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i <= n) out[i] = i < n ? in[i] : 0ull;
+}
+__global__ void __launch_bounds__(256) mm_hist_kernel(const uint32_t* __restrict__ key, uint64_t n, uint32_t shift, uint32_t* __restrict__ hist) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) atomicAdd(&hist[key[i] >> shift], 1u);
+}
+
+// the ordering keys of a read's 16-mers, by the lanes of its group (keys[i]: the 16-mer at base i)
+__device__ __forceinline__ void mm_read_keys(const uint32_t* row, uint32_t n, uint32_t cap, int sub, int gs, uint32_t* keys) {
+    const uint32_t nk = n >= 16u ? (n - 15u < cap ? n - 15u : cap) : 0u;
+    for (uint32_t i = (uint32_t)sub; i < nk; i += (uint32_t)gs) { uint32_t o; keys[i] = mm_key(packed16(row, i), &o); }
+}
+// dict_find through the minimiser index: the k-mer at base `pos` of the read (keys: mm_read_keys of that read).  Always exact.
+template <int K>
+__device__ __forceinline__ bool mm_find(const path_graph& G, const uint32_t* row, const uint32_t* keys, uint32_t pos, uint32_t* hrc, uint64_t* hpos) {
+    constexpr uint32_t W = K - 15;
+    uint32_t best = keys[pos], bq = 0;
+    for (uint32_t j = 1; j < W; ++j) { const uint32_t k = keys[pos + j]; if (k < best) { best = k; bq = j; } }
+    const uint32_t x = packed16(row, pos + bq), rx = snk_rev2_32(~x);
+    const uint32_t orient_r = rx < x ? 1u : 0u;
+    const uint32_t b = best >> (32u - G.mdir_bits);
+    const uint32_t lo = G.mdir[b], hi = G.mdir[b + 1];
+    const unsigned long long want = (unsigned long long)(best & 0x3FFFFFFFu);
+    const snk_kmer f = kmer_at<K>(row, 20, pos);
+    const snk_kmer fr = snk_kmer_rc<K>(f);
+    for (uint32_t c = lo; c < hi; ++c) {
+        const unsigned long long e = G.ment[c];
+        if ((e >> 34) != want) continue;
+        const uint64_t P = e & 0x1FFFFFFFFull;
+        const uint32_t orient_u = (uint32_t)(e >> 33) & 1u;
+        // same strand: the k-mer starts bq bases before the place; opposite strand: its reverse complement starts K - 16 - bq before it
+        for (uint32_t rc = 0; rc < 2; ++rc) {
+            if (x != rx && (orient_u ^ orient_r) != rc) continue;         // (a 16-mer that is its own reverse complement fits both ways)
+            const uint32_t back = rc ? (uint32_t)K - 16u - bq : bq;
+            if (P < back) continue;
+            const uint64_t t = P - back;
+            const snk_kmer g = kmer_at64<K>(G.upack, UPAD + t);      // (the packed array has UPAD bases of slack at either end)
+            if (!snk_kmer_eq(g, rc ? fr : f)) continue;
+            uint32_t u = G.ublk[t >> 8];                                  // the K bases lie inside ONE unitig?
+            while (G.uoff[u + 1] <= t) ++u;
+            if (t + K > G.uoff[u + 1]) continue;
+            *hrc = rc;
+            *hpos = t;
+            return true;
+        }
+    }
+    return false;
 }
 // per-unitig record for the pather
 __global__ void __launch_bounds__(256) uinfo_kernel(const uint64_t* __restrict__ uoff, uint64_t U, const int32_t* __restrict__ fwd, const int32_t* __restrict__ rev,
@@ -442,6 +592,9 @@ __global__ void __launch_bounds__(256, MODE == 2 ? 4 : SNK_PATH_OCC) path_kernel
     constexpr int NG = 256 / GS;                      // reads per workgroup
     constexpr uint32_t GM = GS == 16 ? 0xFFFFu : 0xFFu;
     __shared__ uint32_t rowL[NG][20];
+    // ordering keys of the read's 16-mers (minimiser index): the fast pass looks the first k-mer up and nothing else
+    constexpr uint32_t KEYCAP = MODE == 0 ? 64u : 20u * 16u - 15u;
+    __shared__ uint32_t keysL[NG][KEYCAP];
     __shared__ ppart partsL[NG][PC];
     __shared__ int32_t pathL[NG][PM];
     __shared__ int32_t resL[NG][4];
@@ -463,6 +616,11 @@ __global__ void __launch_bounds__(256, MODE == 2 ? 4 : SNK_PATH_OCC) path_kernel
         }
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
+        if (G.ment) {
+            if (live) mm_read_keys(row, n, KEYCAP, sub, GS, keysL[gw]);
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+        }
         // ---- Pather::path :705-748
         int m = 0;
         bool overflow = false, deferred = false;
@@ -486,7 +644,7 @@ __global__ void __launch_bounds__(256, MODE == 2 ? 4 : SNK_PATH_OCC) path_kernel
                 bool hit = false;
                 uint32_t hu = 0, ho = 0, hrc = 0;
                 uint64_t hpos = 0;
-                if (pos < end && (wide || sub == 0)) hit = dict_find<K>(G, row, pos, &hu, &ho, &hrc, exact, &hpos);
+                if (pos < end && (wide || sub == 0)) hit = G.ment ? mm_find<K>(G, row, keysL[gw], pos, &hrc, &hpos) : dict_find<K>(G, row, pos, &hu, &ho, &hrc, exact, &hpos);
                 const uint32_t hm = (uint32_t)(__ballot(hit) >> gsh) & GM;
                 if (!hm) {
                     if (MODE == 0) { deferred = true; resume_i = i; break; }          // the first k-mer is not on the graph: the slow pass takes the read
@@ -870,29 +1028,85 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
         G.upack = upack;
     }
     const uint64_t nk = total_bases >= U * (uint64_t)(K - 1) ? total_bases - U * (uint64_t)(K - 1) : 0;
+    if (total_bases >= (1ull << 33) - 1) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_dev_path_reads: more than 2^33 unitig bases (the dictionary keeps 33-bit positions)");
+    // Look-ups: the k-mer dictionary (a slot per unitig k-mer: 24 bytes each, one probe or two per look-up) or the minimiser index
+    // (8 bytes per ~17 unitig k-mers, every look-up verified against the packed unitigs: measured 2.6 x slower at bench size --
+    // 182 against 71 ms per 100 M reads, the chain of dependent loads per look-up is three long instead of one or two -- but 0.14 GB
+    // where the dictionary takes 6.4 GB).  The dictionary while it fits, the index when it does not (a human-size graph's dictionary
+    // is ~85 GB next to the reads: rounds 1-3 refused such a graph); SNK_PATH_INDEX=1 / 0 forces one or the other.  The exhaustive
+    // cross-check of the unitig barcode lists reads the dictionary.
     const uint64_t spk10 = snk_env_u32("SNK_PATH_SLOTS_X10", 30);         // slots per unitig k-mer x 10 (measured: 2.5 -> 67.2 ms pathing, 3 -> 63.5, 4 -> 61.8)
-    const uint64_t cap = ((nk * spk10 / 10 + 1024) + 63) & ~63ull;        // load 1/3: the chain of dependent probes is what a read waits for
+    uint64_t cap = ((nk * spk10 / 10 + 1024) + 63) & ~63ull;              // load 1/3: the chain of dependent probes is what a read waits for
+    bool dict_fits = true;
+    uint64_t free_b = 0;
     {
-        // the dictionary is the one allocation of this path that grows with the GRAPH, not with the reads: 3 slots of 8 bytes
-        // per unitig k-mer.  Say so before asking for it: a human-size graph (3-4 G k-mers) wants
-        // ~85 GB next to the reads -- path such a graph per unitig range, in passes.
         size_t fr = 0, tot = 0;
-        const uint64_t want = cap * 8ull;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
             uint64_t cached = 0;
             for (auto& b : ctx->blocks) if (!b.used) cached += b.bytes;     // the arena's idle blocks can be handed back to the driver
-            if (want > (uint64_t)fr + cached)
-                return snk_fail(SNK_E_NOMEM, err, errcap, "snk_dev_path_reads: the k-mer dictionary of this graph (%llu unitig k-mers, 3 slots of 8 B each) needs %.1f GB, "
-                                "%.1f GB of HBM are free; path the reads against ranges of the unitigs instead", (unsigned long long)nk, want / 1e9, (fr + cached) / 1e9);
+            free_b = (uint64_t)fr + cached;
+            dict_fits = cap * 8ull <= free_b;
         }
+        const uint64_t max_mb = snk_env_u32("SNK_PATH_DICT_MAX_KB", 0);     // (tests: a dictionary above this size "does not fit")
+        if (max_mb && cap * 8ull > (max_mb << 10)) dict_fits = false;
     }
-    unsigned long long* dslot;
+    const char* ix_env = getenv("SNK_PATH_INDEX");
+    const bool use_index = (ix_env && *ix_env) ? *ix_env == '1' : !dict_fits;
+    const bool need_kdict = !use_index || (flags & SNK_PATH_UNITIG_BCS_EXHAUSTIVE);
+    unsigned long long* dslot = nullptr;
     unsigned long long fp_mask = 0x3FFFFFFFull;
+    if (need_kdict) {
+    if (!dict_fits && !snk_env_u32("SNK_PATH_DICT_MAX_KB", 0))
+        return snk_fail(SNK_E_NOMEM, err, errcap, "snk_dev_path_reads: the k-mer dictionary of this graph (%llu unitig k-mers, 3 slots of 8 B each) needs %.1f GB, "
+                        "%.1f GB of HBM are free; let the minimiser index take the look-ups (SNK_PATH_INDEX unset or 1)", (unsigned long long)nk, cap * 8ull / 1e9, free_b / 1e9);
     if (const char* e = getenv("SNK_PATH_FP_MASK")) if (*e) { const unsigned long long m = strtoull(e, nullptr, 0) & 0x3FFFFFFFull; if (m) fp_mask = m; }
-    if (total_bases >= (1ull << 33) - 1) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_dev_path_reads: more than 2^33 unitig bases (the dictionary keeps 33-bit positions)");
     if ((rc = dev(ctx, cap, &dslot, err, errcap))) return rc;
     SNK_HIP_TRY(hipMemsetAsync(dslot, 0xFF, cap * 8, st));
     if (total_bases) hipLaunchKernelGGL((dict_build_kernel<K>), dim3((unsigned)(((total_bases + DB_RUN - 1) / DB_RUN + 255) / 256)), dim3(256), 0, st, d_uoff, d_ubases, U, total_bases, dslot, cap, fp_mask);
+    }
+    uint64_t n_ment = 0;
+    if (use_index) {
+        // places per workgroup, their offsets, the places, sorted by key, the directory over the key's top bits
+        const uint64_t n_wg = total_bases ? ((total_bases + MM_RUN - 1) / MM_RUN + 255) / 256 : 0;
+        uint32_t *wgc, *okey, *okey2, *mdir, *mhist;
+        uint64_t *wg64, *wgo;
+        unsigned long long *oval, *oval2;
+        if ((rc = dev(ctx, n_wg + 2, &wgc, err, errcap)) || (rc = dev(ctx, n_wg + 2, &wg64, err, errcap)) || (rc = dev(ctx, n_wg + 2, &wgo, err, errcap))) return rc;
+        if (n_wg) {
+            hipLaunchKernelGGL((mm_scan_kernel<K, false>), dim3((unsigned)n_wg), dim3(256), 0, st, d_uoff, G.upack, U, total_bases, wgc, (const uint64_t*)nullptr, (uint32_t*)nullptr,
+                               (unsigned long long*)nullptr);
+            hipLaunchKernelGGL(mm_widen_kernel, dim3((unsigned)((n_wg + 256) / 256)), dim3(256), 0, st, wgc, n_wg, wg64);
+            if ((rc = scan64(ctx, st, wg64, wgo, n_wg + 1, err, errcap))) return rc;
+            SNK_HIP_TRY(hipMemcpyAsync(&n_ment, wgo + n_wg, 8, hipMemcpyDeviceToHost, st));
+            SNK_HIP_TRY(snk_sync(st));
+        }
+        if (n_ment >= (1ull << 32) - 2) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_dev_path_reads: more than 2^32 minimiser places");
+        if ((rc = dev(ctx, n_ment + 1, &okey, err, errcap)) || (rc = dev(ctx, n_ment + 1, &okey2, err, errcap)) || (rc = dev(ctx, n_ment + 1, &oval, err, errcap)) ||
+            (rc = dev(ctx, n_ment + 1, &oval2, err, errcap)))
+            return rc;
+        uint32_t bits = 8;
+        while (bits < 26 && (2ull << bits) < n_ment) ++bits;             // ~2-4 places per directory entry
+        if ((rc = dev(ctx, (1ull << bits) + 2, &mdir, err, errcap)) || (rc = dev(ctx, (1ull << bits) + 2, &mhist, err, errcap))) return rc;
+        SNK_HIP_TRY(hipMemsetAsync(mdir, 0, ((1ull << bits) + 2) * 4, st));
+        SNK_HIP_TRY(hipMemsetAsync(mhist, 0, ((1ull << bits) + 2) * 4, st));
+        if (n_ment) {
+            hipLaunchKernelGGL((mm_scan_kernel<K, true>), dim3((unsigned)n_wg), dim3(256), 0, st, d_uoff, G.upack, U, total_bases, wgc, (const uint64_t*)wgo, okey, oval);
+            size_t tb = 0;
+            SNK_HIP_TRY(rocprim::radix_sort_pairs((void*)nullptr, tb, okey, okey2, oval, oval2, (size_t)n_ment, 0u, 32u, st));
+            void* tmp;
+            if ((rc = snk_ctx_alloc(ctx, tb + 64, &tmp, err, errcap))) return rc;
+            SNK_HIP_TRY(rocprim::radix_sort_pairs(tmp, tb, okey, okey2, oval, oval2, (size_t)n_ment, 0u, 32u, st));
+            hipLaunchKernelGGL(mm_hist_kernel, dim3((unsigned)((n_ment + 255) / 256)), dim3(256), 0, st, okey2, n_ment, 32u - bits, mhist);
+            size_t tb2 = 0;
+            SNK_HIP_TRY(rocprim::exclusive_scan((void*)nullptr, tb2, mhist, mdir, 0u, ((size_t)1 << bits) + 1, rocprim::plus<uint32_t>(), st));
+            void* tmp2;
+            if ((rc = snk_ctx_alloc(ctx, tb2 + 64, &tmp2, err, errcap))) return rc;
+            SNK_HIP_TRY(rocprim::exclusive_scan(tmp2, tb2, mhist, mdir, 0u, ((size_t)1 << bits) + 1, rocprim::plus<uint32_t>(), st));
+        }
+        G.ment = oval2; G.mdir = mdir; G.mdir_bits = bits;
+        if (!need_kdict) cap = n_ment;
+        out->lookup_index = 1;
+    }
     {
         const uint64_t n_blk = (total_bases >> 8) + 2;
         uint32_t* ublk;

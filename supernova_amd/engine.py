@@ -177,14 +177,15 @@ class Result:
         n, tot = int(out.n_reads), int(out.n_edges_total)
         if not download:          # timings only (bench.py: the results stay on the device)
             info = dict(dict_ms=float(out.dict_ms), path_ms=float(out.path_ms), bcs_ms=float(out.bcs_ms), hbv_device_ms=float(ms.value),
-                        dict_slots=int(out.dict_slots), n_edges_total=tot, n_unitig_bcs=int(out.n_unitig_bcs), n_slow=int(out.n_slow))
+                        dict_slots=int(out.dict_slots), n_edges_total=tot, n_unitig_bcs=int(out.n_unitig_bcs), n_slow=int(out.n_slow),
+                        lookup=("index" if out.lookup_index else "kmer_dictionary"))
             if dups is not None:
                 info["dups"] = {k: v for k, v in dups.items() if k != "dup"}
             return None, None, None, info
         off = self._dl(out.offset, n * 4, np.int32, (n,))
         ne = self._dl(out.n_edges, n * 4, np.uint32, (n,))
         edges = self._dl(out.edges, tot * 4, np.int32, (tot,))
-        info = dict(dict_ms=float(out.dict_ms), path_ms=float(out.path_ms), bcs_ms=float(out.bcs_ms), hbv_device_ms=float(ms.value), dict_slots=int(out.dict_slots),
+        info = dict(dict_ms=float(out.dict_ms), path_ms=float(out.path_ms), bcs_ms=float(out.bcs_ms), hbv_device_ms=float(ms.value), dict_slots=int(out.dict_slots), lookup=("index" if out.lookup_index else "kmer_dictionary"),
                     n_slow=int(out.n_slow))
         if dups is not None:
             info["dups"] = dups

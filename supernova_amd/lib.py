@@ -78,7 +78,7 @@ class SnkDevPaths(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_edges_total", C.c_uint64), ("offset", C.c_void_p), ("n_edges", C.c_void_p),
                 ("start", C.c_void_p), ("edges", C.c_void_p), ("dict_slots", C.c_uint64), ("dict_ms", C.c_float),
                 ("path_ms", C.c_float), ("unitig_bc_off", C.c_void_p), ("unitig_bcs", C.c_void_p), ("n_unitig_bcs", C.c_uint64),
-                ("bcs_ms", C.c_float), ("reserved_f", C.c_float), ("n_slow", C.c_uint64)]
+                ("bcs_ms", C.c_float), ("lookup_index", C.c_uint32), ("n_slow", C.c_uint64)]
 
 
 class SnkDevDups(C.Structure):

@@ -855,16 +855,23 @@ def test_device_hbv_many_unitigs(engine, flood, monkeypatch):
         assert np.array_equal(h[k], h2[k]), k
 
 
+@pytest.mark.parametrize("lookup", ["index", "kmer_dictionary"])
 @pytest.mark.parametrize("name", goldens.CASES)
-def test_read_paths_match_reference(engine, graph_stage, name):
-    """f1: read pathing on the device (dictionary over the unitigs, wave-per-read seed and extend, algorithmTwo, quality-aware
-    extension) against the paths the reference binary dumped: offset and HBV edge ids of every read, bit for bit."""
+def test_read_paths_match_reference(engine, graph_stage, name, lookup, monkeypatch):
+    """f1: read pathing on the device (look-ups through the minimiser index over the unitigs -- or, SNK_PATH_INDEX=0, the k-mer
+    dictionary of rounds 1-3 --, wave-per-read seed and extend, algorithmTwo, quality-aware extension) against the paths the
+    reference binary dumped: offset and HBV edge ids of every read, bit for bit."""
     if graph_stage == "global":
         pytest.skip("pathing reads the unitigs; one graph stage is enough")
+    if lookup == "index":       # the k-mer dictionary "does not fit": the call falls back to the index by itself
+        monkeypatch.setenv("SNK_PATH_DICT_MAX_KB", "1")
+    else:
+        monkeypatch.setenv("SNK_PATH_INDEX", "0")
     c = goldens.load(name)
     rows, quals, bc, lens = _to_dev(c)
     res = engine.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, ign_bc_below=c.ign_bc_below)
     off, ne, edges, info = res.path_reads(rows, c.read_len, quals, lens=lens)
+    assert info["lookup"] == lookup
     bad = np.nonzero(ne.astype(np.int64) != c.exp_path_n)[0]
     assert len(bad) == 0, (len(bad), bad[:5], ne[bad[:5]], c.exp_path_n[bad[:5]])
     assert np.array_equal(edges, c.exp_path_edges)
@@ -937,12 +944,43 @@ def test_unitig_barcode_lists_two_derivations_200k_parity_unpinned_rust(engine, 
         assert np.array_equal(cb[int(coff[u]):int(coff[u + 1])], want)
 
 
+def test_read_paths_index_equals_kmer_dictionary_200k_k60(engine, monkeypatch):
+    """The two look-up structures of the pather -- minimiser index (places a unitig k-mer's window picks, verified against the packed
+    unitigs) and k-mer dictionary (a slot per unitig k-mer) -- give the same paths, duplicate flags and barcode lists on 200 k reads with
+    0.6 % errors at K=48 and on the K=60 golden graph."""
+    from supernova_amd import synth
+    from supernova_amd.engine import Params
+    sp = synth.synth_params(200_000, seed=0x5EED0B1D, sub_ppm=6000)
+    rows, quals, bc = engine.synth(sp)
+    res = engine.count_graph(rows, sp.read_len, quals=quals, bc=bc)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SNK_PATH_INDEX", mode)
+        off, ne, edges, info = res.path_reads(rows, sp.read_len, quals, bc=bc, mark_dups=True, unitig_bcs=True)
+        out[mode] = (off, ne, edges, info["dups"]["dup"], info["unitig_bcs"][0], info["unitig_bcs"][1])
+    assert int((out["1"][1] > 0).sum()) > 150_000
+    for a, b in zip(out["1"], out["0"]):
+        assert np.array_equal(a, b)
+    c = goldens.load("adversarial")
+    rows, quals, bc, lens = _to_dev(c)
+    res = engine.count_graph(rows, c.read_len, quals=quals, bc=None, lens=lens, params=Params(K=60))
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SNK_PATH_INDEX", mode)
+        off, ne, edges, info = res.path_reads(rows, c.read_len, quals, lens=lens)
+        out[mode] = (off, ne, edges)
+    assert int((out["1"][1] > 0).sum()) > 0
+    for a, b in zip(out["1"], out["0"]):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("mask", ["0xFF", "0x3"])
 def test_read_paths_with_colliding_fingerprints(engine, monkeypatch, mask):
     """The dictionary keeps a 64-bit fingerprint per k-mer (16-byte slots) and the pather checks a match against the unitig's
     bases.  SNK_PATH_FP_MASK narrows the fingerprint to 8 / 2 bits: nearly every probe chain now holds false matches, the reads fall
     back to the verified look-up -- and the paths are still the reference's, bit for bit."""
     monkeypatch.setenv("SNK_PATH_FP_MASK", mask)
+    monkeypatch.setenv("SNK_PATH_INDEX", "0")          # (the minimiser index compares bases on every look-up: it has no fingerprints)
     for name in ("adversarial", "synth_20k_err"):
         c = goldens.load(name)
         rows, quals, bc, lens = _to_dev(c)
