@@ -355,8 +355,7 @@ int snk_dev_bv_image(snk_ctx* ctx, uint32_t K, uint64_t n_unitigs, const void* d
  * (K-1)-mer end keys, their sort and the vertex classes are computed on the device (what the reference runs through
  * its MapReduce engine, HBVFromEdges.cc:136-168,257-262); the id hand-out, a breadth-first flood whose ids ARE the
  * visiting order (:170-238), runs per connected component: components and their id blocks on the device, one thread per
- * component; a component above SNK_HBV_BIG (1024) nodes, and any graph below SNK_HBV_DEV_MIN unitigs (default: every graph --
- * the device flood is opt-in), on the host. */
+ * component; a component above SNK_HBV_BIG (1024) nodes, and any graph below SNK_HBV_DEV_MIN (65536) unitigs, on the host. */
 typedef struct snk_hbv {
     int32_t n_vertices, n_edges;
     int32_t* v_left;            /* per HBV edge */

@@ -15,8 +15,9 @@
 //        The id hand-out is a breadth-first flood whose ids are the visiting order -- sequential inside a connected
 //        component, independent between components: components by union-find on the device, one thread floods one
 //        component into its own id block, and only components above SNK_HBV_BIG nodes (the connected bulk of a genome
-//        graph) are flooded on the host.  Graphs below SNK_HBV_DEV_MIN unitigs take the host flood directly (the hot
-//        path's few thousand: faster than the launches); the default is "all" -- the device flood is opt-in.
+//        graph) are flooded on the host.  Graphs below SNK_HBV_DEV_MIN (65536) unitigs take the host flood directly (the
+//        hot path's few thousand: faster than the launches).  Every loop of the device flood is bounded; one that runs out
+//        hands the graph to the host flood.
 #include <stdlib.h>
 #include <string.h>
 
@@ -337,14 +338,18 @@ __global__ void __launch_bounds__(HB) hbv_class_kernel(const uint32_t* __restric
 // order == first-push order in a FIFO that skips what is done).  Components above a size limit (the connected bulk of
 // a genome graph: sequential by definition) are left to the host, which floods them into their blocks.
 __device__ __forceinline__ uint32_t uf_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint32_t uf_find(uint32_t* par, uint32_t x) {
-    for (;;) {
+// (every loop of the device flood is bounded: a logic error must end in the error flag and the host's flood, never in a kernel that
+// runs for minutes)
+__device__ __forceinline__ uint32_t uf_find(uint32_t* par, uint32_t x, uint32_t* errflag) {
+    for (uint32_t it = 0; it < (1u << 24); ++it) {
         const uint32_t p = uf_ld(par + x);
         if (p == x) return x;
         const uint32_t gp = uf_ld(par + p);
         if (gp != p) __hip_atomic_store(par + x, gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // path halving: any ancestor will do
         x = gp;
     }
+    atomicOr(errflag, 1u);
+    return x;
 }
 __device__ __forceinline__ uint32_t hbv_node(uint32_t code, uint32_t U) { return ((code >> 1) & 1u) * U + (code >> 2); }
 
@@ -354,19 +359,20 @@ __global__ void __launch_bounds__(HB) hbv_cc_init_kernel(uint32_t* __restrict__ 
 }
 // the ends of one vertex class are mutually adjacent: every entry joins the class's first
 __global__ void __launch_bounds__(HB) hbv_cc_union_kernel(const uint32_t* __restrict__ ee, const uint32_t* __restrict__ cls,
-                                                          const uint64_t* __restrict__ run_beg, uint64_t n_ee, uint32_t U, uint32_t* par) {
+                                                          const uint64_t* __restrict__ run_beg, uint64_t n_ee, uint32_t U, uint32_t* par, uint32_t* errflag) {
     const uint64_t i = (uint64_t)blockIdx.x * HB + threadIdx.x;
     if (i >= n_ee) return;
     const uint64_t first = run_beg[cls[i] - 1u];
     if (first == i) return;
     uint32_t a = hbv_node(ee[i], U), b = hbv_node(ee[first], U);
-    for (;;) {
-        a = uf_find(par, a);
-        b = uf_find(par, b);
+    for (uint32_t it = 0; it < (1u << 16); ++it) {
+        a = uf_find(par, a, errflag);
+        b = uf_find(par, b, errflag);
         if (a == b) return;
         if (a < b) { const uint32_t t = a; a = b; b = t; }
         if (atomicCAS(par + a, a, b) == a) return;
     }
+    atomicOr(errflag, 2u);
 }
 // counter[root] += 1 for every valid lane, one atomic per distinct root of a wave (a genome graph's bulk is ONE root)
 __device__ __forceinline__ void hbv_count_root(uint32_t* counter, bool valid, uint32_t root) {
@@ -380,16 +386,16 @@ __device__ __forceinline__ void hbv_count_root(uint32_t* counter, bool valid, ui
         act &= ~same;
     }
 }
-__global__ void __launch_bounds__(HB) hbv_cc_nodes_kernel(uint32_t* par, const uint8_t* __restrict__ palr, uint32_t U, uint32_t* ce) {
+__global__ void __launch_bounds__(HB) hbv_cc_nodes_kernel(uint32_t* par, const uint8_t* __restrict__ palr, uint32_t U, uint32_t* ce, uint32_t* errflag) {
     const uint64_t n = (uint64_t)blockIdx.x * HB + threadIdx.x;
     const bool valid = n < 2ull * U && !(n >= U && palr[n - U]);
-    hbv_count_root(ce, valid, valid ? uf_find(par, (uint32_t)n) : 0u);
+    hbv_count_root(ce, valid, valid ? uf_find(par, (uint32_t)n, errflag) : 0u);
 }
 __global__ void __launch_bounds__(HB) hbv_cc_classes_kernel(uint32_t* par, const uint32_t* __restrict__ ee, const uint64_t* __restrict__ run_beg,
-                                                            uint64_t nruns, uint32_t U, uint32_t* cv) {
+                                                            uint64_t nruns, uint32_t U, uint32_t* cv, uint32_t* errflag) {
     const uint64_t r = (uint64_t)blockIdx.x * HB + threadIdx.x;
     const bool valid = r < nruns;
-    hbv_count_root(cv, valid, valid ? uf_find(par, hbv_node(ee[run_beg[r]], U)) : 0u);
+    hbv_count_root(cv, valid, valid ? uf_find(par, hbv_node(ee[run_beg[r]], U), errflag) : 0u);
 }
 struct hbv_big { uint32_t root, be, bv, ce; };
 // one thread per root: floods its component when that is small, lists it for the host otherwise
@@ -399,7 +405,7 @@ __global__ void __launch_bounds__(HB) hbv_flood_kernel(const uint32_t* __restric
                                                        const int32_t* __restrict__ vtx_of, const uint64_t* __restrict__ run_beg,
                                                        uint32_t big_limit, int32_t* fwd, int32_t* rev, int32_t* vid, int32_t* v_left,
                                                        int32_t* v_right, int32_t* src, uint8_t* isrc, hbv_big* big, uint32_t big_cap,
-                                                       uint32_t* n_big) {
+                                                       uint32_t* n_big, uint32_t nruns, uint32_t* errflag) {
     const uint64_t n = (uint64_t)blockIdx.x * HB + threadIdx.x;
     if (n >= 2ull * U || par[n] != (uint32_t)n || (n >= U && palr[n - U])) return;
     const uint32_t size = ce[n], e_base = be[n], v_base = bv[n];
@@ -409,10 +415,12 @@ __global__ void __launch_bounds__(HB) hbv_flood_kernel(const uint32_t* __restric
         return;
     }
     uint32_t head = 0, tail = 0, nv = 0;
+    bool bad = false;
     auto push = [&](uint32_t e, uint32_t rc) {
         const bool p = palr[e] != 0;
         int32_t* x = (rc && !p) ? rev : fwd;
         if (x[e] != -1) return;
+        if (tail >= size) { bad = true; return; }         // more nodes than the component was counted to hold: never outside its block
         const int32_t id = (int32_t)(e_base + tail++);
         x[e] = id;
         if (p) rev[e] = id;
@@ -420,20 +428,23 @@ __global__ void __launch_bounds__(HB) hbv_flood_kernel(const uint32_t* __restric
         isrc[id] = (uint8_t)rc;
     };
     push(n >= U ? (uint32_t)(n - U) : (uint32_t)n, n >= U ? 1u : 0u);
-    while (head < tail) {
+    while (head < tail && !bad) {
         const uint32_t id = e_base + head++;
         const uint32_t e = (uint32_t)src[id], rc = isrc[id];
         const int32_t r1 = vtx_of[4ull * e + 2 * rc], r2 = vtx_of[4ull * e + 2 * rc + 1];
+        if ((uint32_t)r1 >= nruns || (uint32_t)r2 >= nruns) { bad = true; break; }
         if (vid[r1] == -1) vid[r1] = (int32_t)(v_base + nv++);
         if (vid[r2] == -1) vid[r2] = (int32_t)(v_base + nv++);
         v_left[id] = vid[r1];
         v_right[id] = vid[r2];
         for (int side = 0; side < 2; ++side) {
             const int32_t r = side ? r2 : r1;
-            const uint64_t j1 = run_beg[r + 1];
-            for (uint64_t j = run_beg[r]; j < j1; ++j) { const uint32_t c = ee[j]; push(c >> 2, (c >> 1) & 1u); }
+            const uint64_t j0 = run_beg[r], j1 = run_beg[r + 1];
+            if (j1 - j0 > 4096) { bad = true; break; }         // (a (K-1)-mer has at most eight edge ends)
+            for (uint64_t j = j0; j < j1; ++j) { const uint32_t c = ee[j]; push(c >> 2, (c >> 1) & 1u); }
         }
     }
+    if (bad || tail != size) atomicOr(errflag, 4u);
 }
 
 // scratch of one call: handed back to the arena when the call returns (the unitigs it reads are scratch of the
@@ -544,8 +555,10 @@ extern "C" int snk_dev_hbv(snk_ctx* ctx, uint32_t K, uint64_t U, const void* d_u
         return hipSuccess;
     };
     // small graphs (the hot path's few thousand unitigs) are flooded on the host in less time than the launches below take.
-    // The device flood is opt-in (SNK_HBV_DEV_MIN=<unitigs>) until it has been measured on graphs of millions of unitigs.
-    const uint64_t dev_min = env_u64("SNK_HBV_DEV_MIN", ~0ull);
+    // Measured (tools/hbv_scale_probe.py, profiles/r04_hbv_scale.log): 9.5 M unitigs of per-barcode graphs (every component small) 4.8 s
+    // -> 0.19 s per call, the flood itself ~5 ms behind the 30 ms of sorts; 6.1 M unitigs of ONE genome (the connected bulk goes to
+    // the host either way) 3.15 -> 2.82 s.
+    const uint64_t dev_min = env_u64("SNK_HBV_DEV_MIN", 1ull << 16);
     if (U < dev_min) {
         SNK_HIP_TRY(hipEventRecord(e1, st));
         SNK_HIP_TRY(fetch_tables());
@@ -568,29 +581,29 @@ extern "C" int snk_dev_hbv(snk_ctx* ctx, uint32_t K, uint64_t U, const void* d_u
         const uint32_t big_limit = (uint32_t)env_u64("SNK_HBV_BIG", 1024);
         const uint32_t big_cap = (uint32_t)(n2 / ((uint64_t)big_limit + 1) + 1);
         hbv_big* d_big;
-        uint32_t* d_nbig;
+        uint32_t* d_nbig;                      // [0] components for the host, [1] error flag
         if ((rc = dalloc(sl, big_cap, &d_big, err, errcap)) || (rc = dalloc(sl, 4, &d_nbig, err, errcap))) return rc;
         const uint64_t h_nee = n_ee;
         SNK_HIP_TRY(hipMemcpyAsync(run_beg + nruns, &h_nee, 8, hipMemcpyHostToDevice, st));
         SNK_HIP_TRY(hipMemsetAsync(ce, 0, n2 * 8, st));                       // ce, cv
         SNK_HIP_TRY(hipMemsetAsync(d_fwd, 0xFF, U * 8, st));                  // fwd, rev
         SNK_HIP_TRY(hipMemsetAsync(d_vid, 0xFF, (size_t)nruns * 4, st));
-        SNK_HIP_TRY(hipMemsetAsync(d_nbig, 0, 4, st));
+        SNK_HIP_TRY(hipMemsetAsync(d_nbig, 0, 8, st));
         const unsigned g2 = (unsigned)((n2 + HB - 1) / HB), gr = (unsigned)(((uint64_t)nruns + HB - 1) / HB);
         hipLaunchKernelGGL(hbv_cc_init_kernel, dim3(g2), dim3(HB), 0, st, par, n2);
-        hipLaunchKernelGGL(hbv_cc_union_kernel, dim3(ge), dim3(HB), 0, st, codes2, cls, run_beg, n_ee, (uint32_t)U, par);
-        hipLaunchKernelGGL(hbv_cc_nodes_kernel, dim3(g2), dim3(HB), 0, st, par, palr, (uint32_t)U, ce);
-        hipLaunchKernelGGL(hbv_cc_classes_kernel, dim3(gr), dim3(HB), 0, st, par, codes2, run_beg, (uint64_t)nruns, (uint32_t)U, cv);
+        hipLaunchKernelGGL(hbv_cc_union_kernel, dim3(ge), dim3(HB), 0, st, codes2, cls, run_beg, n_ee, (uint32_t)U, par, d_nbig + 1);
+        hipLaunchKernelGGL(hbv_cc_nodes_kernel, dim3(g2), dim3(HB), 0, st, par, palr, (uint32_t)U, ce, d_nbig + 1);
+        hipLaunchKernelGGL(hbv_cc_classes_kernel, dim3(gr), dim3(HB), 0, st, par, codes2, run_beg, (uint64_t)nruns, (uint32_t)U, cv, d_nbig + 1);
         tbx = tmp_bytes;
         SNK_HIP_TRY(rocprim::exclusive_scan(tmp, tbx, ce, be, 0u, (size_t)n2, rocprim::plus<uint32_t>(), st));
         tbx = tmp_bytes;
         SNK_HIP_TRY(rocprim::exclusive_scan(tmp, tbx, cv, bv, 0u, (size_t)n2, rocprim::plus<uint32_t>(), st));
         hipLaunchKernelGGL(hbv_flood_kernel, dim3(g2), dim3(HB), 0, st, par, palr, (uint32_t)U, ce, be, bv, codes2, vtx_of, run_beg, big_limit,
-                           d_fwd, d_rev, d_vid, d_vl, d_vr, d_src, d_isrc, d_big, big_cap, d_nbig);
+                           d_fwd, d_rev, d_vid, d_vl, d_vr, d_src, d_isrc, d_big, big_cap, d_nbig, nruns, d_nbig + 1);
         SNK_HIP_TRY(hipGetLastError());
         SNK_HIP_TRY(hipEventRecord(e1, st));
-        uint32_t n_big = 0;
-        SNK_HIP_TRY(hipMemcpyAsync(&n_big, d_nbig, 4, hipMemcpyDeviceToHost, st));
+        uint32_t h_nb[2] = {0, 0};
+        SNK_HIP_TRY(hipMemcpyAsync(h_nb, d_nbig, 8, hipMemcpyDeviceToHost, st));
         if ((rc = hbv_alloc_out(U, nruns, out, err, errcap))) return rc;
         SNK_HIP_TRY(hipMemcpyAsync(out->fwd_xlat, d_fwd, U * 4, hipMemcpyDeviceToHost, st));
         SNK_HIP_TRY(hipMemcpyAsync(out->rev_xlat, d_rev, U * 4, hipMemcpyDeviceToHost, st));
@@ -603,6 +616,15 @@ extern "C" int snk_dev_hbv(snk_ctx* ctx, uint32_t K, uint64_t U, const void* d_u
         if (device_ms) (void)hipEventElapsedTime(device_ms, e0, e1);
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
+        const uint32_t n_big = h_nb[0];
+        if (h_nb[1]) {              // a bounded loop of the device flood ran out (never seen; the flood on the host does not depend on it)
+            snk_hbv_free(out);
+            if (getenv("SNK_HBV_STRICT")) return snk_fail(SNK_E_INTERNAL, err, errcap, "snk_dev_hbv: the device flood gave up (flag %u)", h_nb[1]);
+            SNK_HIP_TRY(fetch_tables());
+            SNK_HIP_TRY(snk_sync(st));
+            if ((rc = hbv_flood(U, h_pal.data(), h_ee.data(), n_ee, h_vtx.data(), h_run.data(), nruns, out, err, errcap))) return rc;
+            goto flooded;
+        }
         out->n_edges = (int32_t)(n2 - h_flags[1]);
         if (n_big) {               // the connected bulk: flooded here into the blocks the scans gave it
             if (n_big > big_cap) { snk_hbv_free(out); return snk_fail(SNK_E_INTERNAL, err, errcap, "snk_dev_hbv: component list overflow"); }
@@ -620,6 +642,7 @@ extern "C" int snk_dev_hbv(snk_ctx* ctx, uint32_t K, uint64_t U, const void* d_u
             }
         }
     }
+flooded:
     out->bvcomp_order = (int32_t*)malloc(U * 4);
     if (!out->bvcomp_order) { snk_hbv_free(out); return snk_fail(SNK_E_NOMEM, err, errcap, "snk_dev_hbv: host allocation failed"); }
     for (uint64_t i = 0; i < U; ++i) out->bvcomp_order[i] = (int32_t)h_order[i];
