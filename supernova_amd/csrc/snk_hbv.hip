@@ -63,6 +63,24 @@ void hbv_flood_component(const hbv_tables& t, uint64_t e0, int rc0, std::vector<
     size_t head = 0;
     q.push_back(e0 * 2 + rc0);
     while (head < q.size()) {
+        // The flood is a chain of cache misses (4U + U + V words touched at random: 250 ns per edge on a 6 M-unitig graph); the queue
+        // says what will be touched next, so the lines of the entries 16, 8 and 4 places ahead are asked for now, one level of
+        // indirection each (classes of an entry; runs and ids of its classes; the ends behind the runs).
+        if (head + 16 < q.size()) __builtin_prefetch(&t.vtx_of[(q[head + 16] >> 1) * 4 + (q[head + 16] & 1) * 2]);
+        if (head + 8 < q.size()) {
+            const uint64_t y = q[head + 8];
+            const uint64_t ye = y >> 1, yrc = (t.pal[ye] && (y & 1)) ? 0 : (y & 1);
+            const int32_t a = t.vtx_of[ye * 4 + yrc * 2], b = t.vtx_of[ye * 4 + yrc * 2 + 1];
+            __builtin_prefetch(&t.run_beg[a]); __builtin_prefetch(&t.run_beg[b]);
+            __builtin_prefetch(&vid[a]); __builtin_prefetch(&vid[b]);
+            __builtin_prefetch(&(y & 1 ? out->rev_xlat : out->fwd_xlat)[ye]);
+        }
+        if (head + 4 < q.size()) {
+            const uint64_t y = q[head + 4];
+            const uint64_t ye = y >> 1, yrc = (t.pal[ye] && (y & 1)) ? 0 : (y & 1);
+            __builtin_prefetch(&t.ee[t.run_beg[t.vtx_of[ye * 4 + yrc * 2]]]);
+            __builtin_prefetch(&t.ee[t.run_beg[t.vtx_of[ye * 4 + yrc * 2 + 1]]]);
+        }
         const uint64_t x = q[head++];
         const uint64_t e = x >> 1;
         const int rc = (int)(x & 1);
