@@ -13,6 +13,7 @@
 struct snk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;   // library-owned default stream
+    hipStream_t cur_stream = nullptr;   // the stream of the top-level call at hand (SNK_ARENA_POISON=2 fills handed-back blocks in its order)
     int n_cu = 256;
     size_t lds_per_block = 65536;
     uint64_t device_mem_total = 0;   // HBM of the device (sizing decisions that must not depend on what happens to be free)
@@ -22,7 +23,7 @@ struct snk_ctx {
     uint64_t call_epoch = 0;     // top-level calls so far; a cached block no call has taken for two of them is given back to the device
     uint64_t alloc_serial = 0;   // blocks handed out so far (a call's internal scratch = the blocks with a larger serial than at its entry)
     std::vector<block> blocks;
-    // Round 4, opt-in (SNK_ARENA_VMM=1; see va_init in snk_api.hip for why not yet the default): the arena as ONE growing range of virtual addresses (hipMemAddressReserve) that physical memory is mapped behind
+    // Round 4 (SNK_ARENA_VMM=0 switches it off): the arena as ONE growing range of virtual addresses (hipMemAddressReserve) that physical memory is mapped behind
     // on demand (hipMemCreate / hipMemMap): a request that does not fit maps more at the end -- no hipFree, no hipMalloc of a block of
     // another size when the bucket count changes (re-allocating memory the process has freed costs ~30 ms per GB on this stack:
     // tools/probe/vmm.hip; a call that changed its block sizes took 2.7-6.8 s).  Ranges are handed out first-fit and coalesce when
@@ -36,6 +37,7 @@ struct snk_ctx {
     std::vector<vrange> va_free;            // sorted by offset, coalesced
     std::vector<vrange> va_used;
     int va_state = 0;                       // 0 untried, 1 in use, -1 off
+    bool va_sealed = false;                 // chunks were unmapped behind live ranges: no growth until the reservation is replaced
     struct vser { size_t off; uint64_t serial; };
     std::vector<vser> va_serial;            // allocation order of the live ranges (snk_ctx_release_since)
     bool arena_legacy = false;              // this call's scratch comes from plain hipMalloc blocks (multi-rank RCCL steps)

@@ -73,6 +73,7 @@ extern "C" int snk_shard_hist(snk_ctx* ctx, const snk_dev_reads* in, const snk_p
                               uint32_t NB_total, void* d_hist, uint64_t* n_instances, void* stream, char* err, size_t errcap) {
     if (!ctx || !d_hist) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_hist: NULL argument");
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->cur_stream = st;
     int rc = snk_shard_begin(ctx, in, p, rank, world, NB_total, n_instances, st, err, errcap);
     if (rc) return rc;
     // the "scatter" stage compacts the slots into the caller's exact, destination-contiguous send buffer
@@ -85,6 +86,7 @@ extern "C" int snk_shard_scatter(snk_ctx* ctx, const void* d_offsets, void* d_re
     if (!ctx || !ctx->shard || !d_offsets || !d_records) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_scatter: NULL argument / no session");
     snk_shard_state* S = state_of(ctx);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->cur_stream = st;
     return snk_stage_partition_compact(ctx, st, &S->part, (const uint32_t*)d_offsets, d_records, err, errcap);
 }
 
@@ -93,6 +95,7 @@ extern "C" int snk_shard_count(snk_ctx* ctx, const void* d_records, const void* 
     if (!ctx || !ctx->shard || !d_seg_off) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_count: NULL argument / no session");
     snk_shard_state* S = state_of(ctx);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->cur_stream = st;
     int rc = snk_stage_count_table(ctx, st, S->params.K, d_records, (const uint64_t*)d_seg_off, (const uint64_t*)d_seg_off + 1, S->NBl + 1, S->world, S->NBl, S->params.min_freq,
                                    has_bc ? S->params.min_bc : 0u, 0u, n_inst_hint, S->status, false, &S->tab, err, errcap);
     if (rc) return rc;
@@ -108,6 +111,7 @@ extern "C" int snk_shard_count_ranged(snk_ctx* ctx, const void* d_records, const
     if (n_ranges && (bounds[0] != 0 || bounds[n_ranges] != S->NBl)) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_count_ranged: the ranges must cover the local buckets");
     for (uint32_t r = 0; r < n_ranges; ++r) if (bounds[r] > bounds[r + 1]) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_count_ranged: descending range bounds");
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->cur_stream = st;
     snk_count_ranges rg{n_ranges, bounds, ready, user};
     int rc = snk_stage_count_table(ctx, st, S->params.K, d_records, (const uint64_t*)d_seg_off, (const uint64_t*)d_seg_off + 1, S->NBl + 1, S->world, S->NBl, S->params.min_freq,
                                    has_bc ? S->params.min_bc : 0u, 0u, n_inst_hint, S->status, false, &S->tab, err, errcap, n_ranges ? &rg : nullptr);
@@ -120,6 +124,7 @@ extern "C" int snk_shard_prune_plan(snk_ctx* ctx, uint64_t* h_qcount, void* stre
     if (!ctx || !ctx->shard) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_prune_plan: NULL argument / no session");
     snk_shard_state* S = state_of(ctx);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->cur_stream = st;
     // bucket-local prune (snk_local.hip); only neighbours owned by another rank become queries
     snk_bl_state& B = S->bl;
     memset(&B, 0, sizeof B);
@@ -161,6 +166,7 @@ extern "C" int snk_shard_fragments(snk_ctx* ctx, const void* d_node_off, uint64_
     if (!ctx || !ctx->shard || !out || !d_node_off) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_fragments: NULL argument / no session");
     snk_shard_state* S = state_of(ctx);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->cur_stream = st;
     snk_frag_out fo;
     int rc = snk_bl_dist_fragments(ctx, st, &S->bl, (const unsigned long long*)d_node_off, my_node_off, &fo, err, errcap);
     if (rc) return rc;
@@ -196,6 +202,7 @@ extern "C" int snk_shard_links_plan(snk_ctx* ctx, uint64_t my_frag_off, uint64_t
     if (!ctx || !ctx->shard || !h_qcount) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_links_plan: NULL argument / no session");
     snk_shard_state* S = state_of(ctx);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->cur_stream = st;
     S->my_end_base = 2ull * my_frag_off;
     void* q;
     int rc;
@@ -213,6 +220,7 @@ extern "C" int snk_shard_links_fill(snk_ctx* ctx, const void* d_qoff, void* d_qb
     if (!ctx || !ctx->shard || !d_qoff) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_links_fill: NULL argument / no session");
     snk_shard_state* S = state_of(ctx);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->cur_stream = st;
     SNK_HIP_TRY(hipMemcpyAsync(S->lq_cursor, d_qoff, (S->world + 1) * 8ull, hipMemcpyDeviceToDevice, st));
     return snk_dist_links_query(ctx, st, true, &S->frags, S->d_node_off, S->world, S->my_end_base, S->lq_cursor, d_qbuf, err, errcap);
 }
@@ -246,6 +254,7 @@ extern "C" int snk_shard_join_linked(snk_ctx* ctx, uint32_t K, uint64_t n_frags,
     if (!d_flink && (!d_hl_self || !d_hl_nb)) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_join: need half links or links");
     if (K != 48 && K != 60) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "K=%u is not supported (48 or 60)", K);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->cur_stream = st;
     snk_join_out jo;
     int rc = snk_dist_join(ctx, st, K, n_frags, (const uint32_t*)d_nk, (const unsigned long long*)d_hl_self,
                            (const unsigned long long*)d_hl_nb, (const uint64_t*)d_boff, (const uint8_t*)d_bases, total_bases, &jo, err, errcap, nullptr, nullptr, 0,
@@ -404,6 +413,7 @@ extern "C" int snk_shard_place(snk_ctx* ctx, uint32_t K, uint64_t n_frags_total,
     if (!ctx || !ctx->shard || !d_frag_off || (!h_frags_to) != (!h_bases_to)) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_place: NULL argument / no session");
     snk_shard_state* S = state_of(ctx);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->cur_stream = st;
     if (2 * n_frags_total >= (1ull << 32)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "more than 2^31 fragments in the job");
     S->my_frag_off = my_frag_off;
     S->n_frags_total = n_frags_total;
@@ -423,6 +433,7 @@ extern "C" int snk_shard_prank_begin(snk_ctx* ctx, uint64_t n_frags_total, const
     if (!ctx || !ctx->shard || !n_splitters || !d_w1_share) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_prank_begin: NULL argument / no session");
     snk_shard_state* S = state_of(ctx);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->cur_stream = st;
     if (2 * n_frags_total >= (1ull << 32)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "more than 2^31 fragments in the job");
     S->my_frag_off = my_frag_off;
     S->n_frags_total = n_frags_total;
@@ -445,6 +456,7 @@ extern "C" int snk_shard_prank_walk(snk_ctx* ctx, const void* d_w1_all, const vo
     if (!ctx || !ctx->shard || !circles) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_prank_walk: NULL argument / no session");
     snk_shard_state* S = state_of(ctx);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->cur_stream = st;
     uint32_t n_cut = 0;
     int rc = snk_prank_walk(ctx, st, &S->pr, (const uint4*)d_w1_all, circles, &S->join_rounds, err, errcap, S->circ_all, &n_cut);
     if (rc) return rc;
@@ -468,6 +480,7 @@ extern "C" int snk_shard_prank_route(snk_ctx* ctx, const void* d_frag_off, const
     if (!ctx || !ctx->shard || !d_rec_off) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_prank_route: NULL argument / no session");
     snk_shard_state* S = state_of(ctx);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->cur_stream = st;
     void* q;
     int rc;
     if ((rc = snk_ctx_alloc(ctx, (S->world + 1) * 8ull, &q, err, errcap))) return rc;
@@ -480,6 +493,7 @@ extern "C" int snk_shard_place_ranked(snk_ctx* ctx, uint32_t K, const void* d_re
     if (!ctx || !ctx->shard || !d_frag_off || (!h_frags_to) != (!h_bases_to)) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_place_ranked: NULL argument / no session");
     snk_shard_state* S = state_of(ctx);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->cur_stream = st;
     const uint2* rk = nullptr;
     int rc = snk_prank_apply(ctx, st, d_recs, n_recs, 2ull * S->my_frag_off, 2ull * S->frags.n_frags, &rk, err, errcap);
     if (rc) return rc;
@@ -492,6 +506,7 @@ extern "C" int snk_shard_route_fill(snk_ctx* ctx, uint32_t K, const void* d_frag
     if (!ctx || !ctx->shard || !d_frag_off || !d_hdr_off || !d_base_off) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_route_fill: NULL argument / no session");
     snk_shard_state* S = state_of(ctx);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->cur_stream = st;
     const uint64_t Fl = S->frags.n_frags;
     SNK_HIP_TRY(hipMemcpyAsync(S->rt_cursor, d_hdr_off, S->world * 8ull, hipMemcpyDeviceToDevice, st));
     SNK_HIP_TRY(hipMemcpyAsync(S->rt_cursor + S->world, d_base_off, S->world * 8ull, hipMemcpyDeviceToDevice, st));
@@ -508,6 +523,7 @@ extern "C" int snk_shard_emit(snk_ctx* ctx, uint32_t K, uint64_t n_recv, const v
     if (K != 48 && K != 60) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "K=%u is not supported (48 or 60)", K);
     snk_shard_state* S = state_of(ctx);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->cur_stream = st;
     uint32_t *nk, *gfid, *pid;
     unsigned long long *koff, *N;
     uint8_t* circ;
@@ -588,6 +604,7 @@ extern "C" int snk_dev_pack2(snk_ctx* ctx, const void* d_bases, uint64_t n_bases
     if (((uintptr_t)d_bases & 15u) || ((uintptr_t)d_packed & 3u)) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_pack2: bases must be 16-byte, packed 4-byte aligned");
     if (n_bases == 0) return SNK_OK;
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->cur_stream = st;
     const uint64_t nt = (n_bases + 15) / 16;
     hipLaunchKernelGGL(pack2_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, (const uint8_t*)d_bases, n_bases, (uint8_t*)d_packed);
     SNK_HIP_TRY(hipGetLastError());
@@ -601,6 +618,7 @@ extern "C" int snk_dev_unpack2(snk_ctx* ctx, const void* d_packed, uint64_t n_ba
     if ((uintptr_t)d_packed & 3u) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_unpack2: packed input must be 4-byte aligned");
     if (n_bases == 0) return SNK_OK;
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->cur_stream = st;
     const uint64_t nt = (n_bases + 15) / 16;
     hipLaunchKernelGGL(unpack2_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, (const uint8_t*)d_packed, n_bases, (uint8_t*)d_bases);
     SNK_HIP_TRY(hipGetLastError());

@@ -225,6 +225,7 @@ static int mark_dups_impl(snk_ctx* ctx, const snk_dev_reads* in, const snk_dev_p
     memset(out, 0, sizeof *out);
     SNK_HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->cur_stream = st;
     hipEvent_t e0, e1;
     SNK_HIP_TRY(hipEventCreate(&e0)); SNK_HIP_TRY(hipEventCreate(&e1));
     struct evg { hipEvent_t a, b; ~evg() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } g{e0, e1};

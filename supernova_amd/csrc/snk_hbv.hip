@@ -500,6 +500,7 @@ extern "C" int snk_dev_hbv(snk_ctx* ctx, uint32_t K, uint64_t U, const void* d_u
     if (U >= (1ull << 30)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_dev_hbv: too many unitigs");
     SNK_HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->cur_stream = st;
     const uint64_t* off = (const uint64_t*)d_unitig_off;
     const uint8_t* bases = (const uint8_t*)d_unitig_bases;
     const uint64_t n4 = 4 * U;

@@ -390,6 +390,7 @@ extern "C" int snk_dev_bv_image(snk_ctx* ctx, uint32_t K, uint64_t n_unitigs, co
     if (!ctx || !d_image || !image_bytes || (n_unitigs && (!d_unitig_off || !d_unitig_bases))) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_bv_image: NULL argument");
     SNK_HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->cur_stream = st;
     SNK_GUARD(
         uint8_t* d_out = nullptr;
         uint64_t* noff = nullptr;

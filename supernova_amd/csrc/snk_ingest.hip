@@ -161,6 +161,7 @@ extern "C" int snk_dev_bc_ids(snk_ctx* ctx, const snk_bc_index* ix, const void* 
     if (n_reads == 0) return SNK_OK;
     SNK_HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->cur_stream = st;
     SNK_HIP_TRY(hipMemsetAsync(ix->d_err, 0, 16, st));
     hipLaunchKernelGGL(bc_ids_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, st, (const uint8_t*)d_fields, stride, n_reads,
                        ix->d_hash, ix->d_line, ix->d_text, ix->n, ix->num_bcs, (int32_t*)d_ids, ix->d_err);

@@ -586,15 +586,17 @@ __device__ __forceinline__ bool dict_find(const path_graph& G, const uint32_t* r
 //        and the rest are pathed together, where every group of a wave has the same kind of work.
 // MODE 1 "slow": the reads of a list (a.slow), the whole algorithm, small capacities.   MODE 2: the full-capacity pass over the
 // redo list.   MODE 3: every read, the whole algorithm (SNK_PATH_TWO_PASS=0 / the fused variant).
-template <int K, int PC, int PM, int MODE, int GS>
+// IDX: the look-ups go through the minimiser index (its own instantiation: the key array in LDS and the second look-up path cost the
+// dictionary variant 9 % when they were a run-time switch)
+template <int K, int PC, int PM, int MODE, int GS, bool IDX>
 __global__ void __launch_bounds__(256, MODE == 2 ? 4 : SNK_PATH_OCC) path_kernel(path_args a) {
     constexpr bool SECOND = MODE == 2;
     constexpr int NG = 256 / GS;                      // reads per workgroup
     constexpr uint32_t GM = GS == 16 ? 0xFFFFu : 0xFFu;
     __shared__ uint32_t rowL[NG][20];
     // ordering keys of the read's 16-mers (minimiser index): the fast pass looks the first k-mer up and nothing else
-    constexpr uint32_t KEYCAP = MODE == 0 ? 64u : 20u * 16u - 15u;
-    __shared__ uint32_t keysL[NG][KEYCAP];
+    constexpr uint32_t KEYCAP = !IDX ? 1u : (MODE == 0 ? 64u : 20u * 16u - 15u);
+    __shared__ uint32_t keysL[IDX ? NG : 1][KEYCAP];
     __shared__ ppart partsL[NG][PC];
     __shared__ int32_t pathL[NG][PM];
     __shared__ int32_t resL[NG][4];
@@ -616,8 +618,8 @@ __global__ void __launch_bounds__(256, MODE == 2 ? 4 : SNK_PATH_OCC) path_kernel
         }
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
-        if (G.ment) {
-            if (live) mm_read_keys(row, n, KEYCAP, sub, GS, keysL[gw]);
+        if (IDX) {
+            if (live) mm_read_keys(row, n, KEYCAP, sub, GS, keysL[IDX ? gw : 0]);
             __builtin_amdgcn_wave_barrier();
             __threadfence_block();
         }
@@ -644,7 +646,7 @@ __global__ void __launch_bounds__(256, MODE == 2 ? 4 : SNK_PATH_OCC) path_kernel
                 bool hit = false;
                 uint32_t hu = 0, ho = 0, hrc = 0;
                 uint64_t hpos = 0;
-                if (pos < end && (wide || sub == 0)) hit = G.ment ? mm_find<K>(G, row, keysL[gw], pos, &hrc, &hpos) : dict_find<K>(G, row, pos, &hu, &ho, &hrc, exact, &hpos);
+                if (pos < end && (wide || sub == 0)) hit = IDX ? mm_find<K>(G, row, keysL[IDX ? gw : 0], pos, &hrc, &hpos) : dict_find<K>(G, row, pos, &hu, &ho, &hrc, exact, &hpos);
                 const uint32_t hm = (uint32_t)(__ballot(hit) >> gsh) & GM;
                 if (!hm) {
                     if (MODE == 0) { deferred = true; resume_i = i; break; }          // the first k-mer is not on the graph: the slow pass takes the read
@@ -1044,6 +1046,7 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
         if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
             uint64_t cached = 0;
             for (auto& b : ctx->blocks) if (!b.used) cached += b.bytes;     // the arena's idle blocks can be handed back to the driver
+            for (auto& f : ctx->va_free) cached += f.bytes;                 // (growing arena: mapped and free)
             free_b = (uint64_t)fr + cached;
             dict_fits = cap * 8ull <= free_b;
         }
@@ -1160,8 +1163,10 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
                 if (snk_env_u32("SNK_PATH_FAST_GS", 8) == 8) {
                     uint64_t g0 = (n + 31) / 32;
                     if (g0 > gmax) g0 = gmax;
-                    hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, 0, 8>), dim3((unsigned)g0), dim3(256), 0, st, a);
-                } else hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, 0, 16>), dim3((unsigned)grid), dim3(256), 0, st, a);
+                    if (use_index) hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, 0, 8, true>), dim3((unsigned)g0), dim3(256), 0, st, a);
+                    else hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, 0, 8, false>), dim3((unsigned)g0), dim3(256), 0, st, a);
+                } else if (use_index) hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, 0, 16, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, 0, 16, false>), dim3((unsigned)grid), dim3(256), 0, st, a);
                 // the reads it left, in read order
                 if (!slow_flag && ((rc = dev(ctx, n + 2, &slow_flag, err, errcap)) || (rc = dev(ctx, n + 2, &slow_pos, err, errcap)))) return rc;
                 hipLaunchKernelGGL(slow_flag_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, st, gm, n, slow_flag);
@@ -1176,10 +1181,12 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
                     a.slow = slow; a.n_slow = n_slow;
                     uint64_t g1 = (n_slow + 15) / 16;
                     if (g1 > gmax) g1 = gmax;
-                    hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, 1, 16>), dim3((unsigned)g1), dim3(256), 0, st, a);
+                    if (use_index) hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, 1, 16, true>), dim3((unsigned)g1), dim3(256), 0, st, a);
+                    else hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, 1, 16, false>), dim3((unsigned)g1), dim3(256), 0, st, a);
                 }
                 out->n_slow = n_slow;
-            } else hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, 3, 16>), dim3((unsigned)grid), dim3(256), 0, st, a);
+            } else if (use_index) hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, 3, 16, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, 3, 16, false>), dim3((unsigned)grid), dim3(256), 0, st, a);
             if (gparts) {
                 uint64_t g2 = (n + 255) / 256;
                 if (g2 > gmax) g2 = gmax;
@@ -1199,7 +1206,8 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
             uint64_t grid = (a.n_redo + 15) / 16;
             const uint64_t gmax = (uint64_t)ctx->n_cu * 64;
             if (grid > gmax) grid = gmax;
-            hipLaunchKernelGGL((path_kernel<K, PCAP, PMAX, 2, 16>), dim3((unsigned)grid), dim3(256), 0, st, a);
+            if (use_index) hipLaunchKernelGGL((path_kernel<K, PCAP, PMAX, 2, 16, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((path_kernel<K, PCAP, PMAX, 2, 16, false>), dim3((unsigned)grid), dim3(256), 0, st, a);
             SNK_HIP_TRY(hipGetLastError());
             SNK_HIP_TRY(hipMemcpyAsync(h_cur, cursor, 32, hipMemcpyDeviceToHost, st));
             SNK_HIP_TRY(snk_sync(st));
@@ -1335,6 +1343,7 @@ extern "C" int snk_dev_path_reads2(snk_ctx* ctx, uint32_t K, const snk_dev_reads
     memset(out, 0, sizeof *out);
     SNK_HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->cur_stream = st;
     // the call's scratch (graph tables, dictionary, parts, sort buffers: ~0.3 KB per read + 40 B per unitig k-mer) goes back to the
     // arena when it returns; only the paths (and barcode lists) stay, until the context's next snk_dev_count_graph / snk_shard_step
     const uint64_t mark = ctx->alloc_serial;

@@ -110,6 +110,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     }
     SNK_HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->cur_stream = st;
     ctx->arena_legacy = false;
     snk_ctx_release_scratch(ctx);
     memset(out, 0, sizeof *out);
@@ -290,6 +291,7 @@ extern "C" int snk_dev_stream_begin(snk_ctx* ctx, const snk_params* p, uint32_t 
     if ((p->flags & SNK_F_GROUPED)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_dev_stream_begin: per-group graphs take their reads resident (snk_dev_count_graph)");
     SNK_HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->cur_stream = st;
     snk_ctx_release_scratch(ctx);
     if (ctx->stream_job) { stream_job_free(ctx->stream_job); ctx->stream_job = nullptr; }
     stream_job* j = new stream_job();
@@ -343,6 +345,7 @@ extern "C" int snk_dev_stream_append(snk_ctx* ctx, const snk_dev_reads* slab, vo
                         (unsigned long long)slab->n_reads, (unsigned long long)j->total_ub);
     SNK_HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->cur_stream = st;
     snk_dev_reads r = *slab;
     if (r.read_index_base == 0) r.read_index_base = j->J.n_reads;           // reads are numbered in arrival order unless the caller numbers them
     uint16_t* gl = j->good_len + j->J.n_reads;
@@ -375,6 +378,7 @@ extern "C" int snk_dev_stream_finish(snk_ctx* ctx, snk_dev_result* out, void* st
     if (!j || !j->open) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_stream_finish: no open job (snk_dev_stream_begin)");
     SNK_HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->cur_stream = st;
     j->open = false;
     memset(out, 0, sizeof *out);
     const snk_params* p = &j->p;
@@ -417,6 +421,7 @@ extern "C" int snk_dev_download(snk_ctx* ctx, const void* d_src, void* h_dst, si
     if (!ctx) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_download: NULL ctx");
     if (bytes == 0) return SNK_OK;
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->cur_stream = st;
     SNK_HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st));
     SNK_HIP_TRY(snk_sync(st));
     return SNK_OK;

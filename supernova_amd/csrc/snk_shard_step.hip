@@ -211,9 +211,11 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
     char* err = X.err;
     size_t errcap = X.errcap;
     const uint32_t W = X.W, me = X.me, K = p->K;
-    // buffers that cross xGMI stay plain hipMalloc memory (the growing arena of snk_ctx.h is mapped through the VMM API; RCCL over several
-    // devices on such ranges is not something this build environment can test): a multi-rank RCCL step takes its scratch the old way
-    ctx->arena_legacy = W > 1 && strcmp(comm->kind(), "rccl") == 0;
+    // A multi-rank step takes its scratch from plain hipMalloc blocks, not from the growing arena (snk_ctx.h: mapped through the VMM API):
+    // buffers that cross xGMI stay ordinary device memory (RCCL over several devices on VMM ranges is not something this build
+    // environment can test), and in-process ranks -- one host thread and one context each -- crashed inside the runtime when one thread
+    // unmapped its arena while another copied out of its own (round 4: the suite's in-process worlds with the arena on by default).
+    ctx->arena_legacy = W > 1;
     const uint64_t syncs0 = snk_sync_count();
     comm->bytes_sent = 0;
     snk_phase_timer tm(st);

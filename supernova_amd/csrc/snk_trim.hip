@@ -102,6 +102,7 @@ extern "C" int snk_dev_trim(snk_ctx* ctx, const void* d_quals, uint32_t qstride,
     if (read_len > 65535 || qstride < read_len) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_trim: bad read_len/qstride");
     if (n_reads == 0) return SNK_OK;
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->cur_stream = st;
     uint64_t nb = (n_reads + 255) / 256;
     const bool tiled = (qstride & 3u) == 0 && qstride <= 160 && (((uintptr_t)d_quals) & 15u) == 0 && !snk_env_u32("SNK_TRIM_ROWWISE", 0);
     if (tiled)
@@ -147,6 +148,7 @@ extern "C" int snk_dev_pack_ascii(snk_ctx* ctx, const void* d_ascii, uint32_t as
         return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_pack_ascii: stride too small");
     if (n_reads == 0) return SNK_OK;
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->cur_stream = st;
     uint64_t total = n_reads * row_words;
     uint64_t nb = (total + 255) / 256;
     hipLaunchKernelGGL(snk_pack_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const uint8_t*)d_ascii, astride, read_len,
