@@ -491,6 +491,20 @@ def main():
                     out["config"]["robust"] = robust_rows(eng, per_gpu, K, ms_per_step)
                 except Exception as ex:
                     out["config"]["robust"] = {"failed": str(ex)}
+                try:
+                    # the first call on a FRESH context (5.2-5.9 s while the arena was cached hipMalloc blocks), same reads
+                    from supernova_amd.engine import Engine, Params
+                    e2 = Engine(local_rank)
+                    ts = []
+                    for rep in range(2):
+                        torch.cuda.synchronize(); t0 = time.perf_counter()
+                        r2 = e2.count_graph(rows, sp.read_len, quals=quals, bc=bc, params=Params(K=K, sorted_table=False))
+                        torch.cuda.synchronize(); ts.append(round((time.perf_counter() - t0) * 1e3, 1))
+                    out["config"]["robust"]["fresh_context_calls_ms"] = ts
+                    del r2
+                    e2.close()
+                except Exception as ex:
+                    out["config"]["robust"]["fresh_context_calls_ms"] = {"failed": str(ex)}
             if not args.no_next_rows:
                 try:
                     out["config"]["next_rows"] = next_rows(eng, step(), rows, quals, bc, sp.read_len, K)
