@@ -491,9 +491,25 @@ def main():
                     out["config"]["robust"] = robust_rows(eng, per_gpu, K, ms_per_step)
                 except Exception as ex:
                     out["config"]["robust"] = {"failed": str(ex)}
+            if not args.no_next_rows:
                 try:
-                    # the first call on a FRESH context (5.2-5.9 s while the arena was cached hipMalloc blocks), same reads
+                    out["config"]["next_rows"] = next_rows(eng, step(), rows, quals, bc, sp.read_len, K)
+                except Exception as ex:
+                    out["config"]["next_rows"] = {"failed": str(ex)}
+            if not args.no_ingest:
+                try:
+                    out["config"]["f3_ingest"] = ingest_row(eng, args, K, ms_per_step / per_gpu)
+                except Exception as ex:
+                    out["config"]["f3_ingest"] = {"failed": str(ex)}
+            if not args.no_robust and not args.error_free and per_gpu >= 10_000_000 and isinstance(out["config"].get("robust"), dict):
+                try:
+                    # the first call on a NEW context, same reads, right after the bench's own engine was closed: what it pays for is
+                    # mostly the driver clearing the ~150 GB that engine has just handed back (~30 ms per GB; 0.19 s on a clean device:
+                    # tools/first_call_probe.py, DESIGN 4 "round 4")
                     from supernova_amd.engine import Engine, Params
+                    del res
+                    eng.close()
+                    torch.cuda.empty_cache()
                     e2 = Engine(local_rank)
                     ts = []
                     for rep in range(2):
@@ -505,16 +521,6 @@ def main():
                     e2.close()
                 except Exception as ex:
                     out["config"]["robust"]["fresh_context_calls_ms"] = {"failed": str(ex)}
-            if not args.no_next_rows:
-                try:
-                    out["config"]["next_rows"] = next_rows(eng, step(), rows, quals, bc, sp.read_len, K)
-                except Exception as ex:
-                    out["config"]["next_rows"] = {"failed": str(ex)}
-            if not args.no_ingest:
-                try:
-                    out["config"]["f3_ingest"] = ingest_row(eng, args, K, ms_per_step / per_gpu)
-                except Exception as ex:
-                    out["config"]["f3_ingest"] = {"failed": str(ex)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(sp, K, args.cpu_sample, tuple(int(x) for x in args.cpu_threads.split(",")), big=args.cpu_sample_10m)

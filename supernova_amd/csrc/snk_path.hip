@@ -71,6 +71,7 @@ struct path_graph {            // device arrays
     const unsigned long long* ment;    // [n_ment] key low 30 bits << 34 | the unitig's 16-mer is the reverse complement of the canonical one << 33 | position
     const uint32_t* mdir;      // [(1 << mdir_bits) + 1] first entry of every key prefix
     uint32_t mdir_bits;
+    uint32_t idx_dbg;          // SNK_PATH_IDX_DBG (timing aid, results invalid): 1 = window minimum only, 2 = + directory and entries, 3 = + base comparison (no unitig-bounds check)
 };
 
 template <int K>
@@ -285,6 +286,7 @@ __device__ __forceinline__ bool mm_find(const path_graph& G, const uint32_t* row
     constexpr uint32_t W = K - 15;
     uint32_t best = keys[pos], bq = 0;
     for (uint32_t j = 1; j < W; ++j) { const uint32_t k = keys[pos + j]; if (k < best) { best = k; bq = j; } }
+    if (G.idx_dbg == 1) return best == 0x12345u && bq == 99u;
     const uint32_t x = packed16(row, pos + bq), rx = snk_rev2_32(~x);
     const uint32_t orient_r = rx < x ? 1u : 0u;
     const uint32_t b = best >> (32u - G.mdir_bits);
@@ -295,6 +297,7 @@ __device__ __forceinline__ bool mm_find(const path_graph& G, const uint32_t* row
     for (uint32_t c = lo; c < hi; ++c) {
         const unsigned long long e = G.ment[c];
         if ((e >> 34) != want) continue;
+        if (G.idx_dbg == 2) { if (e == 0x123456789ull) *hrc = 1; continue; }
         const uint64_t P = e & 0x1FFFFFFFFull;
         const uint32_t orient_u = (uint32_t)(e >> 33) & 1u;
         // same strand: the k-mer starts bq bases before the place; opposite strand: its reverse complement starts K - 16 - bq before it
@@ -305,6 +308,7 @@ __device__ __forceinline__ bool mm_find(const path_graph& G, const uint32_t* row
             const uint64_t t = P - back;
             const snk_kmer g = kmer_at64<K>(G.upack, UPAD + t);      // (the packed array has UPAD bases of slack at either end)
             if (!snk_kmer_eq(g, rc ? fr : f)) continue;
+            if (G.idx_dbg == 3) { *hrc = rc; *hpos = t; return true; }
             uint32_t u = G.ublk[t >> 8];                                  // the K bases lie inside ONE unitig?
             while (G.uoff[u + 1] <= t) ++u;
             if (t + K > G.uoff[u + 1]) continue;
@@ -1106,7 +1110,7 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
             if ((rc = snk_ctx_alloc(ctx, tb2 + 64, &tmp2, err, errcap))) return rc;
             SNK_HIP_TRY(rocprim::exclusive_scan(tmp2, tb2, mhist, mdir, 0u, ((size_t)1 << bits) + 1, rocprim::plus<uint32_t>(), st));
         }
-        G.ment = oval2; G.mdir = mdir; G.mdir_bits = bits;
+        G.ment = oval2; G.mdir = mdir; G.mdir_bits = bits; G.idx_dbg = snk_env_u32("SNK_PATH_IDX_DBG", 0);
         if (!need_kdict) cap = n_ment;
         out->lookup_index = 1;
     }

@@ -1,6 +1,6 @@
 """What the first call on a fresh context costs (5.2-5.9 s with the cached blocks): a new engine, the bench workload,
 three calls; then the same with the cached blocks (SNK_ARENA_VMM=0 is read when the context first allocates).
-usage: python tools/first_call_probe.py [n_reads=1e8]"""
+usage: python tools/first_call_probe.py [n_reads=1e8] [1|0]"""
 import os, sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -8,7 +8,8 @@ import torch
 from supernova_amd import synth
 from supernova_amd.engine import Engine, Params
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100_000_000
-for vmm in ("1", "0"):
+# one mode per process (memory a process has freed is slow to get again -- ~30 ms per GB on this stack -- whoever asks for it)
+for vmm in ((sys.argv[2],) if len(sys.argv) > 2 else ("1", "0")):
     os.environ["SNK_ARENA_VMM"] = vmm
     e = Engine(0)
     sp = synth.synth_params(n, seed=0x5EED0001)
