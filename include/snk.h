@@ -274,6 +274,9 @@ typedef struct snk_shard_result {
     float count_kernel_ms;
     uint32_t repartitioned;          /* 1: the first buckets overflowed the count kernel's tables and the step partitioned and exchanged a
                                         second time into smaller buckets (a job-wide decision); later steps on the context start there */
+    uint32_t n_hot_buckets;          /* this rank's minimiser buckets far above their capacity (repeat families, homopolymer runs): re-partitioned
+                                        by k-mer hash and counted by a launch of their own, like snk_dev_result.n_hot_buckets */
+    uint32_t reserved_u;
 } snk_shard_result;
 /* total_reads: reads of the whole job (sizes the bucket count without an exchange; 0 = the ranks exchange their slab sizes,
  * ignored when p->n_buckets is set).  in->read_index_base = global index of the slab's first read. */

@@ -30,6 +30,11 @@ namespace {
 
 constexpr int HT = 256;               // threads per workgroup of the expansion kernels = records staged per workgroup
 
+struct seg_tab {                      // a bucket's records: segment s holds [beg[s * stride + b], end[s * stride + b]) of the record array
+    const uint64_t* beg;
+    const uint64_t* end;
+    uint32_t stride, nseg;
+};
 struct hot_tab {
     const uint32_t* bucket;           // [n_hot]
     const uint32_t* lg;               // [n_hot] classes = 1 << lg
@@ -39,11 +44,12 @@ struct hot_tab {
 };
 
 // ---- which buckets are hot
-__global__ void __launch_bounds__(256) hot_scan_kernel(const uint64_t* __restrict__ seg, uint32_t NB, uint32_t thresh, uint32_t hot_cap, uint32_t* __restrict__ hot_b,
+__global__ void __launch_bounds__(256) hot_scan_kernel(seg_tab sg, uint32_t NB, uint32_t thresh, uint32_t hot_cap, uint32_t* __restrict__ hot_b,
                                                        uint32_t* __restrict__ hot_r, unsigned long long* __restrict__ ctr) {
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
     if (b >= NB) return;
-    const uint64_t r = (seg[(uint64_t)NB + b] - seg[b]) + (seg[3ull * NB + b] - seg[2ull * NB + b]);
+    uint64_t r = 0;
+    for (uint32_t q = 0; q < sg.nseg; ++q) r += sg.end[(uint64_t)q * sg.stride + b] - sg.beg[(uint64_t)q * sg.stride + b];
     if (r >= thresh) {
         const unsigned long long i = atomicAdd(&ctr[0], 1ull);
         if (i < hot_cap) { hot_b[i] = b; hot_r[i] = (uint32_t)(r > 0xFFFFFFFFull ? 0xFFFFFFFFull : r); }
@@ -71,7 +77,7 @@ __global__ void hot_plan_kernel(const uint32_t* __restrict__ hot_r, uint32_t hot
     ctr[2] = vacc;
 }
 // the hot buckets leave the main launch; every virtual bucket learns who it is
-__global__ void __launch_bounds__(256) hot_meta_kernel(hot_tab h, uint32_t NB, uint64_t* __restrict__ seg, uint2* __restrict__ vmeta) {
+__global__ void __launch_bounds__(256) hot_meta_kernel(hot_tab h, uint2* __restrict__ vmeta) {
     const uint32_t v = blockIdx.x * 256 + threadIdx.x;
     const uint32_t NBv = h.vbase[h.n_hot];
     if (v >= NBv) return;
@@ -80,12 +86,18 @@ __global__ void __launch_bounds__(256) hot_meta_kernel(hot_tab h, uint32_t NB, u
     const uint32_t cls = v - h.vbase[lo];
     vmeta[v] = make_uint2(h.bucket[lo], (h.lg[lo] << 24) | cls);
 }
-__global__ void __launch_bounds__(256) hot_mask_kernel(hot_tab h, uint32_t NB, uint64_t* __restrict__ seg_main) {
+// the hot buckets leave the main launch (empty in every segment); their bounds stay in saved[(2 s) * n_hot + i] / [(2 s + 1) * n_hot + i]
+__global__ void __launch_bounds__(256) hot_mask_kernel(hot_tab h, const uint64_t* __restrict__ sbeg, uint64_t* __restrict__ send, uint32_t stride, uint32_t nseg,
+                                                       uint64_t* __restrict__ saved) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= h.n_hot) return;
     const uint32_t b = h.bucket[i];
-    seg_main[(uint64_t)NB + b] = seg_main[b];                       // empty in both segments
-    seg_main[3ull * NB + b] = seg_main[2ull * NB + b];
+    for (uint32_t q = 0; q < nseg; ++q) {
+        const uint64_t x = sbeg[(uint64_t)q * stride + b], y = send[(uint64_t)q * stride + b];
+        saved[(2ull * q) * h.n_hot + i] = x;
+        saved[(2ull * q + 1) * h.n_hot + i] = y;
+        send[(uint64_t)q * stride + b] = x;
+    }
 }
 
 // ---- expansion: one thread per hot record, its k-mers one after the other.  SCATTER = false: count the instances per virtual bucket;
@@ -96,7 +108,7 @@ __global__ void __launch_bounds__(256) hot_mask_kernel(hot_tab h, uint32_t NB, u
 // took every instance of the bucket, one at a time (same-address atomics queue, ~10 ns each).
 constexpr int HOT_LG_MAX = 12;
 template <int K, bool GROUPED, bool SCATTER>
-__global__ void __launch_bounds__(HT) hot_expand_kernel(hot_tab h, const uint4* __restrict__ records, const uint64_t* __restrict__ seg_saved, uint32_t NB, uint32_t cap,
+__global__ void __launch_bounds__(HT) hot_expand_kernel(hot_tab h, const uint4* __restrict__ records, const uint64_t* __restrict__ saved, uint32_t nseg,
                                                         uint32_t* __restrict__ vcount, const uint64_t* __restrict__ voff, uint4* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) uint32_t rec[(HT + 1) * 9];        // staged records, nine words each (the ninth is zero: reads behind word 7), one zero record in front
     __shared__ uint32_t hist[1 << HOT_LG_MAX];                                  // instances of this workgroup per class of its first bucket; then the running slot inside the class
@@ -112,15 +124,20 @@ __global__ void __launch_bounds__(HT) hot_expand_kernel(hot_tab h, const uint4* 
         uint32_t lo = 0, hi = h.n_hot;                // largest i with rbase[i] <= t
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (h.rbase[mid] <= t) lo = mid; else hi = mid; }
         i = lo;
-        const uint32_t b = h.bucket[i];
-        const uint64_t r = t - h.rbase[i];
-        // the bucket's records: its slots, then its part of the overflow segment (seg_saved: the bounds before the bucket was masked out)
-        const uint64_t n0 = seg_saved[(uint64_t)NB + b] - seg_saved[b];
-        const uint64_t at = r < n0 ? seg_saved[b] + r : seg_saved[2ull * NB + b] + (r - n0);
-        ra = records[2 * at];
-        rb = records[2 * at + 1];
+        uint64_t r = t - h.rbase[i];
+        // the bucket's records: its segments one after the other (saved: the bounds before the bucket was masked out).  An index is an
+        // offset from `records` that may wrap (the sharded step keeps a rank's own records outside its receive buffer): address arithmetic
+        // on integers
+        uint64_t at = 0;
+        for (uint32_t q = 0; q < nseg; ++q) {
+            const uint64_t x = saved[(2ull * q) * h.n_hot + i], n = saved[(2ull * q + 1) * h.n_hot + i] - x;
+            if (r < n) { at = x + r; break; }
+            r -= n;
+        }
+        const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<uintptr_t>(records) + at * 32ull);
+        ra = src[0];
+        rb = src[1];
     }
-    (void)cap;
     uint32_t* my = rec + (tid + 1) * 9;
     my[0] = ra.x; my[1] = ra.y; my[2] = ra.z; my[3] = ra.w; my[4] = rb.x; my[5] = rb.y; my[6] = rb.z; my[7] = rb.w; my[8] = 0u;
     if (tid < 9) rec[tid] = 0u;
@@ -211,25 +228,81 @@ int alloc(snk_ctx* ctx, size_t n, T** out, char* err, size_t errcap) {
 }
 
 template <int K, bool GROUPED>
-int expand(hipStream_t st, const hot_tab& h, uint64_t total_records, const uint4* records, const uint64_t* seg_saved, uint32_t NB, uint32_t cap, uint32_t* vcount,
+int expand(hipStream_t st, const hot_tab& h, uint64_t total_records, const uint4* records, const uint64_t* saved, uint32_t nseg, uint32_t* vcount,
            const uint64_t* voff, uint4* out, bool scatter, char* err, size_t errcap) {
     const unsigned grid = (unsigned)((total_records + HT - 1) / HT);
-    if (!scatter) hipLaunchKernelGGL((hot_expand_kernel<K, GROUPED, false>), dim3(grid), dim3(HT), 0, st, h, records, seg_saved, NB, cap, vcount, voff, out);
-    else hipLaunchKernelGGL((hot_expand_kernel<K, GROUPED, true>), dim3(grid), dim3(HT), 0, st, h, records, seg_saved, NB, cap, vcount, voff, out);
+    if (!scatter) hipLaunchKernelGGL((hot_expand_kernel<K, GROUPED, false>), dim3(grid), dim3(HT), 0, st, h, records, saved, nseg, vcount, voff, out);
+    else hipLaunchKernelGGL((hot_expand_kernel<K, GROUPED, true>), dim3(grid), dim3(HT), 0, st, h, records, saved, nseg, vcount, voff, out);
     SNK_HIP_TRY(hipGetLastError());
     return SNK_OK;
 }
 
 }  // namespace
 
-int snk_stage_hot(snk_ctx* ctx, hipStream_t st, uint32_t K, bool grouped, snk_partition* part, snk_hot* hot, char* err, size_t errcap) {
+// Two steps: the PLAN needs the buckets' sizes only (which buckets are hot, their classes, the virtual buckets; the hot buckets leave
+// the main launch's segment table), the EXPANSION reads their records.  On one rank they follow each other; a rank of the N-GPU job
+// plans from the exchanged histograms and expands when the records have arrived (snk_shard_step.hip).
+struct hot_plan_state {
+    hot_tab h;
+    uint64_t* saved;
+    uint32_t nseg, K;
+    bool grouped;
+    uint64_t n_rec;
+    uint32_t *vcount;
+    uint64_t *voff, *vseg;
+};
+static int hot_expand_run(snk_ctx* ctx, hipStream_t st, const void* records, snk_hot* hot, char* err, size_t errcap) {
+    hot_plan_state* P = static_cast<hot_plan_state*>(hot->plan);
+    const uint32_t NBv = hot->NBv;
+    int rc;
+    auto run = [&](bool scatter, uint4* out) -> int {
+        if (P->grouped) return expand<48, true>(st, P->h, P->n_rec, (const uint4*)records, P->saved, P->nseg, P->vcount, P->voff, out, scatter, err, errcap);
+        if (P->K == 48) return expand<48, false>(st, P->h, P->n_rec, (const uint4*)records, P->saved, P->nseg, P->vcount, P->voff, out, scatter, err, errcap);
+        return expand<60, false>(st, P->h, P->n_rec, (const uint4*)records, P->saved, P->nseg, P->vcount, P->voff, out, scatter, err, errcap);
+    };
+    SNK_HIP_TRY(hipMemsetAsync(P->vcount, 0, ((size_t)NBv + 1) * 4, st));
+    if ((rc = run(false, nullptr))) return rc;
+    {
+        auto in = rocprim::make_transform_iterator(P->vcount, [] __device__(uint32_t v) { return (uint64_t)v; });
+        size_t tb = 0;
+        SNK_HIP_TRY(rocprim::exclusive_scan((void*)nullptr, tb, in, P->voff, (uint64_t)0, (size_t)NBv + 1, rocprim::plus<uint64_t>(), st));
+        void* tmp;
+        if ((rc = snk_ctx_alloc(ctx, tb + 64, &tmp, err, errcap))) return rc;
+        SNK_HIP_TRY(rocprim::exclusive_scan(tmp, tb, in, P->voff, (uint64_t)0, (size_t)NBv + 1, rocprim::plus<uint64_t>(), st));
+    }
+    uint64_t n_inst = 0;
+    SNK_HIP_TRY(hipMemcpyAsync(&n_inst, P->voff + NBv, 8, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(snk_sync(st));
+    uint4* vrec;
+    if ((rc = alloc(ctx, 2 * (size_t)n_inst + 2, &vrec, err, errcap))) return rc;
+    SNK_HIP_TRY(hipMemsetAsync(P->vcount, 0, ((size_t)NBv + 1) * 4, st));
+    if ((rc = run(true, vrec))) return rc;
+    hipLaunchKernelGGL(hot_seg_kernel, dim3((NBv + 255) / 256), dim3(256), 0, st, P->voff, NBv, P->vseg);
+    SNK_HIP_TRY(hipGetLastError());
+    hot->n_instances = n_inst;
+    hot->records = vrec;
+    hot->seg = P->vseg;
+    return SNK_OK;
+}
+int snk_stage_hot_expand(snk_ctx* ctx, hipStream_t st, const void* records, snk_hot* hot, char* err, size_t errcap) {
+    if (!hot || hot->NBv == 0 || hot->records) return SNK_OK;
+    int rc = hot_expand_run(ctx, st, records, hot, err, errcap);
+    delete static_cast<hot_plan_state*>(hot->plan);
+    hot->plan = nullptr;
+    return rc;
+}
+void snk_stage_hot_drop(snk_hot* hot) {
+    if (hot && hot->plan) { delete static_cast<hot_plan_state*>(hot->plan); hot->plan = nullptr; }
+}
+
+int snk_stage_hot_plan(snk_ctx* ctx, hipStream_t st, uint32_t K, bool grouped, uint64_t* seg_beg, uint64_t* seg_end, uint32_t stride, uint32_t nseg, uint32_t NB,
+                       uint32_t cap, snk_hot* hot, char* err, size_t errcap) {
     memset(hot, 0, sizeof *hot);
-    if (part->gidx || part->NB == 0 || part->n_overflow == 0) return SNK_OK;        // a bucket far above its capacity has records on the overflow list
-    const uint32_t NB = part->NB;
+    if (NB == 0 || nseg == 0) return SNK_OK;
     // hot = more records than eight times the slots of a bucket (and never fewer than SNK_HOT_MIN: a normal hash-split pass or two
     // over a few thousand records is cheaper than the expansion)
     const uint32_t floor_ = snk_env_u32("SNK_HOT_MIN", 8192);
-    uint64_t thr = (uint64_t)part->cap * snk_env_u32("SNK_HOT_FACTOR", 8);
+    uint64_t thr = (uint64_t)cap * snk_env_u32("SNK_HOT_FACTOR", 8);
     if (thr < floor_) thr = floor_;
     if (thr > 0xFFFFFFFFull || snk_env_u32("SNK_HOT", 1) == 0) return SNK_OK;
     const uint32_t hot_cap = 1u << 16;
@@ -241,7 +314,8 @@ int snk_stage_hot(snk_ctx* ctx, hipStream_t st, uint32_t K, bool grouped, snk_pa
         (rc = alloc(ctx, hot_cap + 1, &vbase, err, errcap)) || (rc = alloc(ctx, hot_cap + 1, &rbase, err, errcap)) || (rc = alloc(ctx, 8, &ctr, err, errcap)))
         return rc;
     SNK_HIP_TRY(hipMemsetAsync(ctr, 0, 64, st));
-    hipLaunchKernelGGL(hot_scan_kernel, dim3((NB + 255) / 256), dim3(256), 0, st, part->seg, NB, (uint32_t)thr, hot_cap, hot_b, hot_r, ctr);
+    const seg_tab sg{seg_beg, seg_end, stride, nseg};
+    hipLaunchKernelGGL(hot_scan_kernel, dim3((NB + 255) / 256), dim3(256), 0, st, sg, NB, (uint32_t)thr, hot_cap, hot_b, hot_r, ctr);
     hipLaunchKernelGGL(hot_plan_kernel, dim3(1), dim3(64), 0, st, hot_r, hot_cap, snk_env_u32("SNK_HOT_CLASS_INST", 6000), lg, rbase, vbase, ctr);
     unsigned long long h_ctr[3] = {0, 0, 0};
     SNK_HIP_TRY(hipMemcpyAsync(h_ctr, ctr, 24, hipMemcpyDeviceToHost, st));
@@ -249,50 +323,33 @@ int snk_stage_hot(snk_ctx* ctx, hipStream_t st, uint32_t K, bool grouped, snk_pa
     if (h_ctr[0] == 0) return SNK_OK;
     if (h_ctr[0] > hot_cap) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "more than %u hot minimiser buckets", hot_cap);
     const uint32_t n_hot = (uint32_t)h_ctr[0], NBv = (uint32_t)h_ctr[2];
-    const uint64_t n_rec = h_ctr[1];
-    hot_tab h{hot_b, lg, rbase, vbase, n_hot};
-    // the main segment table keeps the hot buckets' bounds in a copy (the expansion reads them), the live one shows them empty
-    uint64_t* seg_saved;
-    if ((rc = alloc(ctx, 4ull * NB, &seg_saved, err, errcap))) return rc;
-    SNK_HIP_TRY(hipMemcpyAsync(seg_saved, part->seg, 4ull * NB * 8, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(hot_mask_kernel, dim3((n_hot + 255) / 256), dim3(256), 0, st, h, NB, part->seg);
+    hot_plan_state* P = new hot_plan_state();
+    P->h = hot_tab{hot_b, lg, rbase, vbase, n_hot};
+    P->nseg = nseg; P->K = K; P->grouped = grouped; P->n_rec = h_ctr[1];
+    hot->plan = P;
+    // the main segment table shows the hot buckets empty; their bounds are kept for the expansion
     uint2* vmeta;
-    uint32_t* vcount;
-    uint64_t *voff, *vseg;
-    if ((rc = alloc(ctx, NBv, &vmeta, err, errcap)) || (rc = alloc(ctx, (size_t)NBv + 1, &vcount, err, errcap)) || (rc = alloc(ctx, (size_t)NBv + 2, &voff, err, errcap)) ||
-        (rc = alloc(ctx, 2ull * NBv, &vseg, err, errcap)))
+    if ((rc = alloc(ctx, 2ull * nseg * n_hot, &P->saved, err, errcap)) || (rc = alloc(ctx, NBv, &vmeta, err, errcap)) || (rc = alloc(ctx, (size_t)NBv + 1, &P->vcount, err, errcap)) ||
+        (rc = alloc(ctx, (size_t)NBv + 2, &P->voff, err, errcap)) || (rc = alloc(ctx, 2ull * NBv, &P->vseg, err, errcap))) {
+        snk_stage_hot_drop(hot);
         return rc;
-    hipLaunchKernelGGL(hot_meta_kernel, dim3((NBv + 255) / 256), dim3(256), 0, st, h, NB, part->seg, vmeta);
-    SNK_HIP_TRY(hipMemsetAsync(vcount, 0, ((size_t)NBv + 1) * 4, st));
-    auto run = [&](bool scatter, uint4* out) -> int {
-        if (grouped) return expand<48, true>(st, h, n_rec, (const uint4*)part->records, seg_saved, NB, part->cap, vcount, voff, out, scatter, err, errcap);
-        if (K == 48) return expand<48, false>(st, h, n_rec, (const uint4*)part->records, seg_saved, NB, part->cap, vcount, voff, out, scatter, err, errcap);
-        return expand<60, false>(st, h, n_rec, (const uint4*)part->records, seg_saved, NB, part->cap, vcount, voff, out, scatter, err, errcap);
-    };
-    if ((rc = run(false, nullptr))) return rc;
-    {
-        auto in = rocprim::make_transform_iterator(vcount, [] __device__(uint32_t v) { return (uint64_t)v; });
-        size_t tb = 0;
-        SNK_HIP_TRY(rocprim::exclusive_scan((void*)nullptr, tb, in, voff, (uint64_t)0, (size_t)NBv + 1, rocprim::plus<uint64_t>(), st));
-        void* tmp;
-        if ((rc = snk_ctx_alloc(ctx, tb + 64, &tmp, err, errcap))) return rc;
-        SNK_HIP_TRY(rocprim::exclusive_scan(tmp, tb, in, voff, (uint64_t)0, (size_t)NBv + 1, rocprim::plus<uint64_t>(), st));
     }
-    uint64_t n_inst = 0;
-    SNK_HIP_TRY(hipMemcpyAsync(&n_inst, voff + NBv, 8, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(snk_sync(st));
-    uint4* vrec;
-    if ((rc = alloc(ctx, 2 * (size_t)n_inst + 2, &vrec, err, errcap))) return rc;
-    SNK_HIP_TRY(hipMemsetAsync(vcount, 0, ((size_t)NBv + 1) * 4, st));
-    if ((rc = run(true, vrec))) return rc;
-    hipLaunchKernelGGL(hot_seg_kernel, dim3((NBv + 255) / 256), dim3(256), 0, st, voff, NBv, vseg);
+    hipLaunchKernelGGL(hot_mask_kernel, dim3((n_hot + 255) / 256), dim3(256), 0, st, P->h, seg_beg, seg_end, stride, nseg, P->saved);
+    hipLaunchKernelGGL(hot_meta_kernel, dim3((NBv + 255) / 256), dim3(256), 0, st, P->h, vmeta);
     SNK_HIP_TRY(hipGetLastError());
     hot->n_hot = n_hot;
     hot->NBv = NBv;
-    hot->n_records = n_rec;
-    hot->n_instances = n_inst;
-    hot->records = vrec;
-    hot->seg = vseg;
+    hot->n_records = P->n_rec;
     hot->vmeta = vmeta;
     return SNK_OK;
+}
+
+// one rank, records resident: plan and expand
+int snk_stage_hot(snk_ctx* ctx, hipStream_t st, uint32_t K, bool grouped, snk_partition* part, snk_hot* hot, char* err, size_t errcap) {
+    memset(hot, 0, sizeof *hot);
+    if (part->gidx || part->NB == 0 || part->n_overflow == 0) return SNK_OK;        // a bucket far above its capacity has records on the overflow list
+    const uint32_t NB = part->NB;
+    int rc = snk_stage_hot_plan(ctx, st, K, grouped, part->seg, part->seg + NB, 2 * NB, 2, NB, part->cap, hot, err, errcap);
+    if (rc || hot->NBv == 0) return rc;
+    return snk_stage_hot_expand(ctx, st, part->records, hot, err, errcap);
 }

@@ -172,6 +172,12 @@ int range_ready(void* user, uint32_t r) {
     return hipStreamWaitEvent(w->st, w->ev[r], 0) == hipSuccess ? 0 : 1;
 }
 
+int all_ranges_ready(void* user) {       // the whole exchange has landed (the hot buckets' expansion reads records of every range)
+    range_wait* w = (range_wait*)user;
+    for (uint32_t r = 0; r < w->n; ++r) if (hipStreamWaitEvent(w->st, w->ev[r], 0) != hipSuccess) return 1;
+    return 0;
+}
+
 uint32_t plan_buckets(uint64_t inst_ub, uint32_t world, uint32_t K, uint32_t forced, double ratio) {
     uint64_t nb = forced;
     if (!nb) {
@@ -259,6 +265,7 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
         *pb = (double)sum / 1024.0 / (double)all.size();
         return 0;
     }, &ag};
+    uint32_t n_hot_buckets = 0;
     auto count_pass = [&](bool with_pilot) -> int {
         // ---- trim + one-pass partition over all buckets of the job
         n_inst = 0;
@@ -281,12 +288,12 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
                 TRY(snk_stage_count_table(ctx, st, K, part.records, T, T + (uint64_t)fake * NB_total, NB_total, fake, NB_total, p->min_freq,
                                           has_bc ? p->min_bc : 0u, 0u, inst_hint, S->status, false, &S->tab, err, errcap));
             } else {
-            // (hot minimiser buckets -- repeat families -- are re-partitioned by k-mer hash on the one-rank path as on the one-GPU path;
-            // with W > 1 a bucket's records arrive as W + 1 segments and the expansion is not wired up yet: DESIGN 8)
+            // (hot minimiser buckets -- repeat families -- are re-partitioned by k-mer hash as on the one-GPU path)
             snk_hot hot;
             TRY(snk_stage_hot(ctx, st, K, false, &S->part, &hot, err, errcap));
+            n_hot_buckets = hot.n_hot;
             TRY(snk_stage_count_table(ctx, st, K, part.records, part.seg, part.seg + NB_total, 2 * NB_total, part.nseg, NB_total, p->min_freq,
-                                      has_bc ? p->min_bc : 0u, 0u, inst_hint, S->status, false, &S->tab, err, errcap, nullptr, with_pilot ? &pilot : nullptr, nullptr, false, &hot));
+                                      has_bc ? p->min_bc : 0u, 0u, inst_hint, S->status, false, &S->tab, err, errcap, nullptr, with_pilot ? &pilot : nullptr, nullptr, true, &hot));
             }
             snk_ctx_release_block(ctx, part.records);
         } else {
@@ -358,8 +365,17 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
             for (uint32_t r = 0; r <= R; ++r) bounds[r] = (uint32_t)((uint64_t)NBl * r / R);
             range_wait rw{st, H.ev.data(), R};
             snk_count_ranges rg{R, bounds.data(), range_ready, &rw};
-            TRY(snk_stage_count_table(ctx, st, K, recvb, T, T + (uint64_t)nseg * NBl, NBl, nseg, NBl, p->min_freq, has_bc ? p->min_bc : 0u, 0u, inst_hint,
-                                      S->status, false, &S->tab, err, errcap, &rg, with_pilot ? &pilot : nullptr));
+            // hot minimiser buckets (a repeat family's, a homopolymer's: all of their records meet on ONE rank, and one workgroup would count
+            // them in hundreds of passes): planned here from the segment table -- the histograms say how large every bucket is before a record
+            // has arrived --, expanded by the count stage behind its ranged launches, when the exchange is through
+            snk_hot hot;
+            TRY(snk_stage_hot_plan(ctx, st, K, false, T, T + (uint64_t)nseg * NBl, NBl, nseg, NBl, part.cap, &hot, err, errcap));
+            hot.before_expand = all_ranges_ready; hot.user = &rw; hot.src_records = recvb;
+            const int rcc = snk_stage_count_table(ctx, st, K, recvb, T, T + (uint64_t)nseg * NBl, NBl, nseg, NBl, p->min_freq, has_bc ? p->min_bc : 0u, 0u, inst_hint,
+                                                  S->status, false, &S->tab, err, errcap, &rg, with_pilot ? &pilot : nullptr, nullptr, true, &hot);      // (the region compaction rides in the prune, as on the one-GPU path)
+            snk_stage_hot_drop(&hot);
+            if (rcc) return rcc;
+            n_hot_buckets = hot.n_hot;
             snk_ctx_release_block(ctx, part.records);
             snk_ctx_release_block(ctx, sendb);
             snk_ctx_release_block(ctx, recvb);
@@ -635,6 +651,7 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
     out->n_frags = F; out->n_frags_total = Ft; out->n_queries = nq; out->n_link_queries = nlq;
     out->ranking = ranked ? 1u : 0u;
     out->repartitioned = repartitioned;
+    out->n_hot_buckets = n_hot_buckets;
     out->buckets_split = fr.buckets_split; out->max_slots_used = fr.max_slots_used;
     out->exchanged_bytes[0] = exch_records;
     out->exchanged_bytes[1] = 0; for (uint32_t q = 0; q < W; ++q) if (q != me) out->exchanged_bytes[1] += q_send[q] * 24 + q_recv[q] * 4;

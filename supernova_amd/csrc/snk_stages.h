@@ -107,10 +107,22 @@ struct snk_hot {
     const void* records;           // n_instances single-k-mer records, virtual-bucket-major
     const uint64_t* seg;           // [begin NBv | end NBv]
     const uint2* vmeta;            // [NBv] (real bucket, split_lg << 24 | split_id)
+    void* plan;                    // between snk_stage_hot_plan and snk_stage_hot_expand: what the expansion needs (host object)
+    // the records are expanded when the count stage gets to them (records == NULL until then): the hook makes the stream wait for what
+    // the expansion reads -- a rank of the N-GPU job plans from the exchanged histograms while the records are still on their way
+    int (*before_expand)(void* user);
+    void* user;
+    const void* src_records;       // base of the record array the segment table indexes
 };
 // after snk_stage_partition: finds the buckets far above their capacity, takes them out of the partition's segment table and builds
 // their virtual buckets; snk_stage_count_table counts those in a second launch
 int snk_stage_hot(snk_ctx* ctx, hipStream_t st, uint32_t K, bool grouped, snk_partition* part, snk_hot* hot, char* err, size_t errcap);
+// the two halves: the plan from a segment table (beg/end [s * stride + b], nseg segments per bucket; the hot buckets are emptied in
+// it), the expansion from the records it indexes
+int snk_stage_hot_plan(snk_ctx* ctx, hipStream_t st, uint32_t K, bool grouped, uint64_t* seg_beg, uint64_t* seg_end, uint32_t stride, uint32_t nseg, uint32_t NB,
+                       uint32_t cap, snk_hot* hot, char* err, size_t errcap);
+int snk_stage_hot_expand(snk_ctx* ctx, hipStream_t st, const void* records, snk_hot* hot, char* err, size_t errcap);
+void snk_stage_hot_drop(snk_hot* hot);
 // the same pass as a job that takes its reads slab by slab (snk_dev_stream_*)
 struct snk_partition_job {
     uint32_t K, NB, cap, n_slabs;

@@ -167,6 +167,11 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
         kt.mark();
         if (hot && !pilot_regrow) {
             // the hot buckets' hash classes: the same kernel over the virtual buckets, appending to the same regions and chunk list
+            if (!hot->records) {        // planned, not expanded yet (sharded step): everything the expansion reads has to be there first
+                snk_hot* hm = const_cast<snk_hot*>(hot);
+                if (hm->before_expand && (rc = hm->before_expand(hm->user))) return snk_fail(SNK_E_ARG, err, errcap, "count: the hot buckets' hook failed (%d)", rc);
+                if ((rc = snk_stage_hot_expand(ctx, st, hm->src_records, hm, err, errcap))) return rc;
+            }
             snk_count_args cv = ca;
             cv.records = (const uint4*)hot->records;
             cv.seg_beg = hot->seg;

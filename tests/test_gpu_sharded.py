@@ -36,7 +36,7 @@ def run_world(W, case, n_buckets=0):
                                  ign_bc_below=case.ign_bc_below, read_index_base=lo)
             out[r] = dict(keys=res.keys(), counts=res.counts(), ctx=res.ctx(), spectrum=res.spectrum(),
                           n_instances=res.n_instances, n_frags=res.n_frags, n_queries=res.n_queries,
-                          unitigs=res.unitigs(), ranking=getattr(res, "join_ranking", None))
+                          unitigs=res.unitigs(), ranking=getattr(res, "join_ranking", None), n_hot=int(res.raw.n_hot_buckets))
             e.close()
         except BaseException as ex:  # noqa: BLE001
             errs.append(ex)
@@ -109,6 +109,22 @@ def test_sharded_overflowing_buckets_and_the_hot_table(snk, W, monkeypatch):
     monkeypatch.setenv("SNK_MSP_HOT_MIN", "1")
     c = goldens.load("synth_20k_err")
     check(run_world(W, c), c)
+
+
+@pytest.mark.parametrize("W", [1, 2, 3])
+@pytest.mark.parametrize("name", ["adversarial", "synth_20k_err"])
+def test_sharded_hot_buckets_are_repartitioned_on_their_owner(snk, W, name, monkeypatch):
+    """snk_hot.hip on a rank of the N-GPU job: a minimiser bucket's records arrive as one segment per source rank (+ the owner's own slots
+    and overflow); a bucket far above its capacity is planned from the exchanged histograms, its records are expanded into hash classes
+    when the exchange is through, and the classes are counted by a launch of their own.  Forced on the goldens by a tiny threshold."""
+    monkeypatch.setenv("SNK_MSP_CAP_PCT", "20")
+    monkeypatch.setenv("SNK_HOT_MIN", "8")
+    monkeypatch.setenv("SNK_HOT_FACTOR", "1")
+    monkeypatch.setenv("SNK_HOT_CLASS_INST", "300")
+    c = goldens.load(name)
+    out = run_world(W, c)
+    check(out, c)
+    assert sum(o["n_hot"] for o in out) > 0
 
 
 def test_sharded_many_small_buckets(snk):

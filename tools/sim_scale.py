@@ -1,6 +1,6 @@
 """W in-process ranks on ONE GPU at bench-like sizes: per-rank phase timings of snk_shard_step (the ranks share the GPU, so the
 phase times are upper bounds of what a rank alone would take; the exchanges are device copies).
-usage: python tools/sim_scale.py W reads_per_rank [reps]"""
+usage: python tools/sim_scale.py W reads_per_rank [reps] [repeat_mode]      (repeat_mode 15: the repeat-rich genome of config.robust -- hot buckets on their owners)"""
 import sys, threading, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -13,7 +13,8 @@ from supernova_amd.sharded import ShardedEngine, SimWorld
 W = int(sys.argv[1]); per = int(float(sys.argv[2])); reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 world = SimWorld(W)
 bar = threading.Barrier(W)
-sp = synth.synth_params(W * per, seed=0x5EED0002)
+rmode = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+sp = synth.synth_params(W * per, seed=0x5EED0002, **({'repeat_mode': rmode} if rmode else {}))
 out = [None] * W
 errs = []
 
@@ -27,12 +28,12 @@ def worker(r):
             torch.cuda.synchronize(); bar.wait(); t0 = time.time()
             res = sh.count_graph(rows, sp.read_len, quals=quals, bc=bc, params=Params(K=48), read_index_base=r * per, total_reads=W * per)
             torch.cuda.synchronize(); t1 = time.time()
-            out[r] = (t1 - t0, res.phase_ms, res.join_ms, res.n_kmers, res.n_frags, res.n_queries, res.n_unitigs, res.n_instances, res.host_syncs, res.exchange_bytes)
+            out[r] = (t1 - t0, res.phase_ms, res.join_ms, res.n_kmers, res.n_frags, res.n_queries, res.n_unitigs, res.n_instances, res.host_syncs, res.exchange_bytes, int(res.raw.n_hot_buckets))
             bar.wait()
             if r == 0:
                 for q in range(W):
-                    w, ph, jm, nk, nf, nq, nu, ni, hs, xb = out[q]
-                    print(f"rep{rep} rank{q} wall={w*1e3:.0f}ms inst={ni} kmers={nk} frags={nf} queries={nq} unitigs={nu} read-backs={hs} "
+                    w, ph, jm, nk, nf, nq, nu, ni, hs, xb, nh = out[q]
+                    print(f"rep{rep} rank{q} wall={w*1e3:.0f}ms hot_buckets={nh} inst={ni} kmers={nk} frags={nf} queries={nq} unitigs={nu} read-backs={hs} "
                           + " ".join(f"{k}={v:.0f}" for k, v in ph.items()) + " | join: " + " ".join(f"{k}={v:.1f}" for k, v in jm.items())
                           + f" | sent MB: " + " ".join(f"{k}={v/1e6:.0f}" for k, v in xb.items()), flush=True)
             bar.wait()
