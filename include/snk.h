@@ -282,6 +282,15 @@ typedef struct snk_shard_result {
  * ignored when p->n_buckets is set).  in->read_index_base = global index of the slab's first read. */
 int snk_shard_step(snk_ctx* ctx, snk_comm* comm, const snk_dev_reads* in, const snk_params* p, uint64_t total_reads, uint32_t flags,
                    snk_shard_result* out, void* stream, char* err, size_t errcap);
+/* The same step with the rank's reads arriving slab by slab (what snk_dev_stream_* is to snk_dev_count_graph; tada streams its FASTQ
+ * chunks into the partitioner, lib/tada/src/cmd_msp.rs:55-69): begin sizes the job's buckets -- total_reads = reads of the whole job, the
+ * same on every rank -- and this rank's slots (rank_reads_ub: an upper bound of what it will append); append partitions one slab (nothing
+ * is waited for; slab->read_index_base = global index of its first read); finish runs the rest of the step.  A streamed step cannot
+ * partition twice: without the group's history of a previous step, error-rich data are counted in hash-split sub-passes. */
+int snk_shard_stream_begin(snk_ctx* ctx, snk_comm* comm, const snk_params* p, uint32_t read_len, uint64_t rank_reads_ub, uint64_t total_reads,
+                           int has_bc, void* stream, char* err, size_t errcap);
+int snk_shard_stream_append(snk_ctx* ctx, const snk_dev_reads* slab, void* stream, char* err, size_t errcap);
+int snk_shard_stream_finish(snk_ctx* ctx, snk_comm* comm, uint32_t flags, snk_shard_result* out, void* stream, char* err, size_t errcap);
 /* ---- host-pointer convenience + graph hand-off -------------- */
 typedef struct snk_reads {
     uint64_t n_reads;

@@ -69,6 +69,76 @@ int snk_shard_begin(snk_ctx* ctx, const snk_dev_reads* in, const snk_params* p, 
     return SNK_OK;
 }
 
+// ---- streamed step: the partition runs slab by slab while the next slab is decoded / uploaded (lib/tada/src/cmd_msp.rs:55-69 streams its
+// FASTQ chunks into the partitioner the same way); everything behind the partition is the resident step's
+int snk_shard_job_open(snk_ctx* ctx, const snk_params* p, uint32_t rank, uint32_t world, uint32_t NB_total, uint32_t read_len, uint64_t reads_ub,
+                       uint64_t total_reads, int has_bc, hipStream_t st, char* err, size_t errcap) {
+    if (!ctx || !p) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_stream_begin: NULL argument");
+    if (p->K != 48 && p->K != 60) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "K=%u is not supported (48 or 60)", p->K);
+    if (p->min_bc > 8) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "min_bc=%u: the device barcode rule tells up to eight distinct barcodes apart (min_bc <= 8)", p->min_bc);
+    if (world == 0 || rank >= world || NB_total == 0 || NB_total % world) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_stream_begin: NB_total must be a positive multiple of world");
+    if (read_len == 0 || read_len > 256 || reads_ub == 0) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_stream_begin: read_len 1..256 and an upper bound of this rank's reads are needed");
+    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    snk_ctx_release_scratch(ctx);
+    snk_shard_state* S = state_of(ctx);
+    memset(&S->reads, 0, sizeof S->reads);
+    S->params = *p;
+    S->rank = rank; S->world = world; S->NB_total = NB_total; S->NBl = NB_total / world;
+    S->circ_all = nullptr; S->join_circles = 0;
+    S->job_open = false; S->job_read_len = read_len; S->job_has_bc = has_bc; S->job_reads_ub = reads_ub; S->job_total_reads = total_reads;
+    void* q;
+    int rc;
+    if ((rc = snk_ctx_alloc(ctx, 64, &q, err, errcap))) return rc; S->status = (uint32_t*)q;
+    SNK_HIP_TRY(hipMemsetAsync(S->status, 0, 64, st));
+    if ((rc = snk_ctx_alloc(ctx, reads_ub * 2 + 64, &q, err, errcap))) return rc; S->job_good_len = (uint16_t*)q;
+    const unsigned long long kpr = read_len >= p->K ? read_len - p->K + 1 : 0;
+    if ((rc = snk_partition_open(ctx, st, p->K, NB_total, reads_ub * kpr, reads_ub, false, S->status, &S->job, err, errcap))) return rc;
+    S->job_open = true;
+    return SNK_OK;
+}
+int snk_shard_job_add(snk_ctx* ctx, const snk_dev_reads* slab, hipStream_t st, char* err, size_t errcap) {
+    if (!ctx || !ctx->shard || !slab) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_stream_append: NULL argument / no open step");
+    snk_shard_state* S = state_of(ctx);
+    if (!S->job_open) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_stream_append: no open step (snk_shard_stream_begin)");
+    if (slab->n_reads == 0) return SNK_OK;
+    if (!slab->rows || slab->read_len != S->job_read_len || slab->row_words * 16 < slab->read_len) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_stream_append: bad rows / read_len (the step's is %u)", S->job_read_len);
+    if (!slab->good_len && !slab->quals) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_stream_append: need quals or good_len");
+    if ((slab->bc != nullptr) != (S->job_has_bc != 0)) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_stream_append: every slab carries barcodes, or none does");
+    if (S->job.n_reads + slab->n_reads > S->job_reads_ub)
+        return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_stream_append: more reads than the rank's upper bound (%llu + %llu > %llu)", (unsigned long long)S->job.n_reads,
+                        (unsigned long long)slab->n_reads, (unsigned long long)S->job_reads_ub);
+    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    snk_dev_reads r = *slab;
+    uint16_t* gl = S->job_good_len + S->job.n_reads;
+    int rc;
+    if (slab->good_len) {
+        SNK_HIP_TRY(hipMemcpyAsync(gl, slab->good_len, slab->n_reads * 2, hipMemcpyDeviceToDevice, st));
+        rc = snk_partition_add(ctx, st, &S->job, &r, gl, nullptr, err, errcap);
+    } else if (snk_fused_trim_ok(&r)) {
+        snk_fused_trim ft;
+        ft.quals = r.quals; ft.qstride = r.qstride; ft.lens = r.lens; ft.min_qual = S->params.min_qual; ft.good_out = gl;
+        rc = snk_partition_add(ctx, st, &S->job, &r, gl, &ft, err, errcap);
+    } else {
+        rc = snk_dev_trim(ctx, r.quals, r.qstride, r.lens, r.read_len, r.n_reads, S->params.K, S->params.min_qual, gl, st);
+        if (rc) return snk_fail(rc, err, errcap, "%s", snk_last_error());
+        rc = snk_partition_add(ctx, st, &S->job, &r, gl, nullptr, err, errcap);
+    }
+    return rc;
+}
+int snk_shard_job_adopt(snk_ctx* ctx, uint64_t* n_instances, hipStream_t st, char* err, size_t errcap) {
+    snk_shard_state* S = state_of(ctx);
+    if (!S->job_open) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_stream_finish: no open step");
+    S->job_open = false;
+    S->good_len = S->job_good_len;
+    S->reads.n_reads = S->job.n_reads;
+    S->reads.read_len = S->job_read_len;
+    unsigned long long h_plan[2] = {0, 0};
+    int rc = snk_partition_close(ctx, st, &S->job, &S->part, h_plan, err, errcap);
+    if (rc) return rc;
+    if (n_instances) *n_instances = h_plan[0];
+    return SNK_OK;
+}
+
 extern "C" int snk_shard_hist(snk_ctx* ctx, const snk_dev_reads* in, const snk_params* p, uint32_t rank, uint32_t world,
                               uint32_t NB_total, void* d_hist, uint64_t* n_instances, void* stream, char* err, size_t errcap) {
     if (!ctx || !d_hist) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_hist: NULL argument");

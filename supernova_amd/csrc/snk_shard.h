@@ -32,6 +32,13 @@ struct snk_shard_state {
     unsigned long long* pr_cursor = nullptr;   // [world] cursors of the rank-record routing (end positions after the fill)
     const uint32_t* nk_all = nullptr;
     snk_phase_timer* tm = nullptr;
+    // a streamed step (snk_shard_stream_*): the rank's reads arrive slab by slab and are partitioned as they come
+    snk_partition_job job{};
+    bool job_open = false;
+    uint32_t job_read_len = 0;
+    int job_has_bc = 0;
+    uint64_t job_reads_ub = 0, job_total_reads = 0;
+    uint16_t* job_good_len = nullptr;
 };
 
 
@@ -40,5 +47,10 @@ inline snk_shard_state* snk_shard_state_of(snk_ctx* ctx) {
     return static_cast<snk_shard_state*>(ctx->shard);
 }
 // trim + one-pass minimiser partition over all NB_total buckets of the job (what snk_shard_hist does before it copies the histogram out)
+// the streamed variant of snk_shard_begin: open (sizes the job's slots), add a slab, adopt (closes the job: S->part as snk_shard_begin leaves it)
+int snk_shard_job_open(snk_ctx* ctx, const snk_params* p, uint32_t rank, uint32_t world, uint32_t NB_total, uint32_t read_len, uint64_t reads_ub,
+                       uint64_t total_reads, int has_bc, hipStream_t st, char* err, size_t errcap);
+int snk_shard_job_add(snk_ctx* ctx, const snk_dev_reads* slab, hipStream_t st, char* err, size_t errcap);
+int snk_shard_job_adopt(snk_ctx* ctx, uint64_t* n_instances, hipStream_t st, char* err, size_t errcap);
 int snk_shard_begin(snk_ctx* ctx, const snk_dev_reads* in, const snk_params* p, uint32_t rank, uint32_t world, uint32_t NB_total,
                     uint64_t* n_instances, hipStream_t st, char* err, size_t errcap);

@@ -119,6 +119,7 @@ struct step_ctx {
     // pinned staging for the small host -> device uploads of the step (offset tables): a bump allocator, reset per step
     ull* pin = nullptr;
     size_t pin_cap = 0, pin_used = 0;
+    bool streamed = false;         // the partition is the context's open streamed job (snk_shard_stream_*), not a pass over resident reads
 };
 
 struct shard_host {                 // per-context host resources of the step (kept across steps)
@@ -269,7 +270,8 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
     auto count_pass = [&](bool with_pilot) -> int {
         // ---- trim + one-pass partition over all buckets of the job
         n_inst = 0;
-        TRY(snk_shard_begin(ctx, in, p, me, W, NB_total, &n_inst, st, err, errcap));
+        if (X.streamed) TRY(snk_shard_job_adopt(ctx, &n_inst, st, err, errcap));
+        else TRY(snk_shard_begin(ctx, in, p, me, W, NB_total, &n_inst, st, err, errcap));
         S = snk_shard_state_of(ctx);
         const snk_partition& part = S->part;
         if (part.n_supermers >= (1ull << 32)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "more than 2^32 supermers on one rank");
@@ -384,10 +386,12 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
     };
     uint32_t repartitioned = 0;
     for (int pass = 0; pass < 2; ++pass) {
-        NB_total = plan_buckets(inst_ub, W, K, p->n_buckets, adaptive ? ratio : 0.0);
+        // (a streamed step sized its buckets when it was opened -- the same rule on the same job-wide figures -- and cannot partition twice: its
+        // slabs are gone; error-rich data without the group's history are counted in hash-split sub-passes then)
+        NB_total = X.streamed ? snk_shard_state_of(ctx)->NB_total : plan_buckets(inst_ub, W, K, p->n_buckets, adaptive ? ratio : 0.0);
         NBl = NB_total / W;
         tm.n = 1;
-        const int rcp = count_pass(adaptive && !have_ratio && pass == 0 && p->n_buckets == 0);
+        const int rcp = count_pass(adaptive && !have_ratio && pass == 0 && p->n_buckets == 0 && !X.streamed);
         if (rcp == SNK_RETARGET) {
             // every rank took this turn (the figure is job-wide); what the exchange still has in flight lands first
             if (H.cstream) SNK_HIP_TRY(hipStreamSynchronize(H.cstream));
@@ -759,16 +763,63 @@ extern "C" int snk_shard_gather_unitigs(snk_ctx* ctx, snk_comm* comm, const snk_
     return rc;
 }
 
+static int shard_step_run(snk_ctx* ctx, snk_comm* comm, const snk_dev_reads* in, const snk_params* p, uint64_t total_reads, uint32_t flags, snk_shard_result* out,
+                          void* stream, bool streamed, char* err, size_t errcap);
 extern "C" int snk_shard_step(snk_ctx* ctx, snk_comm* comm, const snk_dev_reads* in, const snk_params* p, uint64_t total_reads, uint32_t flags,
                               snk_shard_result* out, void* stream, char* err, size_t errcap) {
     if (!ctx || !comm || !in || !p || !out) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_step: NULL argument");
+    return shard_step_run(ctx, comm, in, p, total_reads, flags, out, stream, false, err, errcap);
+}
+
+// ---- the same step with the rank's reads arriving slab by slab (snk_dev_stream_* of the one-GPU path, under the N-GPU step): begin sizes
+// the job's buckets from the job-wide read total (every rank computes the same count: same rule, same figures, same group history) and
+// this rank's slots from its own upper bound; append partitions a slab (nothing is waited for: the slab's buffers are free when the
+// stream has passed the launch); finish runs the rest of the step -- histograms, exchange, count, prune, fragments, join.
+extern "C" int snk_shard_stream_begin(snk_ctx* ctx, snk_comm* comm, const snk_params* p, uint32_t read_len, uint64_t rank_reads_ub, uint64_t total_reads, int has_bc,
+                                      void* stream, char* err, size_t errcap) {
+    if (!ctx || !comm || !p) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_stream_begin: NULL argument");
+    if (p->flags & SNK_F_GROUPED) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_shard_stream_begin: per-group graphs shard by group (replicas), not by minimiser");
+    if (total_reads == 0 && p->n_buckets == 0) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_stream_begin: the job's read total (or n_buckets) is needed: the ranks size the buckets alike from it");
+    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->cur_stream = st;
+    const uint32_t W = comm->world, K = p->K;
+    ctx->arena_legacy = W > 1;
+    const uint64_t kpr = read_len >= K ? read_len - K + 1 : 0;
+    const uint64_t inst_ub = total_reads * kpr;
+    const char* forced_target = getenv("SNK_TARGET_INST");
+    const bool adaptive = inst_ub && !(forced_target && *forced_target) && snk_env_u32("SNK_ADAPTIVE_BUCKETS", 1) != 0;
+    const bool have_ratio = inst_ub && comm->claim_ratio > 0.0 && comm->claim_ratio_reads == inst_ub && comm->claim_ratio_k == K * 2;
+    const uint32_t NB_total = plan_buckets(inst_ub, W, K, p->n_buckets, adaptive && have_ratio ? comm->claim_ratio : 0.0);
+    return snk_shard_job_open(ctx, p, comm->rank, W, NB_total, read_len, rank_reads_ub, total_reads, has_bc, st, err, errcap);
+}
+extern "C" int snk_shard_stream_append(snk_ctx* ctx, const snk_dev_reads* slab, void* stream, char* err, size_t errcap) {
+    if (!ctx || !slab) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_stream_append: NULL argument");
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->cur_stream = st;
+    return snk_shard_job_add(ctx, slab, st, err, errcap);
+}
+extern "C" int snk_shard_stream_finish(snk_ctx* ctx, snk_comm* comm, uint32_t flags, snk_shard_result* out, void* stream, char* err, size_t errcap) {
+    if (!ctx || !comm || !out || !ctx->shard) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_stream_finish: NULL argument / no open step");
+    snk_shard_state* S = snk_shard_state_of(ctx);
+    if (!S->job_open) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_stream_finish: no open step (snk_shard_stream_begin)");
+    snk_dev_reads in;
+    memset(&in, 0, sizeof in);
+    in.n_reads = S->job.n_reads; in.read_len = S->job_read_len; in.row_words = (S->job_read_len + 15) / 16;
+    in.bc = S->job_has_bc ? (const void*)S->job_good_len : nullptr;       // (only asked whether there are barcodes)
+    const snk_params p = S->params;
+    return shard_step_run(ctx, comm, &in, &p, S->job_total_reads, flags, out, stream, true, err, errcap);
+}
+
+static int shard_step_run(snk_ctx* ctx, snk_comm* comm, const snk_dev_reads* in, const snk_params* p, uint64_t total_reads, uint32_t flags, snk_shard_result* out,
+                          void* stream, bool streamed, char* err, size_t errcap) {
     if (p->flags & SNK_F_GROUPED) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_shard_step: per-group graphs shard by group (replicas), not by minimiser");
     SNK_HIP_TRY(hipSetDevice(ctx->device));
     if (!ctx->shard_host) { ctx->shard_host = new shard_host(); ctx->shard_host_free = shard_host_free; }
     shard_host& H = *static_cast<shard_host*>(ctx->shard_host);
     step_ctx X;
     X.ctx = ctx; X.comm = comm; X.st = stream ? (hipStream_t)stream : ctx->stream; X.err = err; X.errcap = errcap;
-    X.W = comm->world; X.me = comm->rank;
+    X.W = comm->world; X.me = comm->rank; X.streamed = streamed;
     const size_t need = 64ull * (X.W + 2) + 4096;
     if (H.pin_cap < need) {
         if (H.pin) (void)hipHostFree(H.pin);

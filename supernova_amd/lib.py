@@ -229,6 +229,9 @@ def _declare(lib: C.CDLL) -> None:
         "snk_comm_world": (u32, [vp]),
         "snk_comm_kind": (cp, [vp]),
         "snk_shard_step": (C.c_int, [vp, vp, P(SnkDevReads), P(SnkParams), u64, u32, P(SnkShardResult), vp, cp, sz]),
+        "snk_shard_stream_begin": (C.c_int, [vp, vp, P(SnkParams), u32, u64, u64, C.c_int, vp, cp, sz]),
+        "snk_shard_stream_append": (C.c_int, [vp, P(SnkDevReads), vp, cp, sz]),
+        "snk_shard_stream_finish": (C.c_int, [vp, vp, u32, P(SnkShardResult), vp, cp, sz]),
         "snk_shard_gather_unitigs": (C.c_int, [vp, vp, P(SnkShardResult), u32, u32, u32, P(SnkResult), vp, cp, sz]),
     }
     for name, (res, args) in sig.items():

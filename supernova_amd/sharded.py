@@ -503,3 +503,42 @@ class ShardedEngine:
         if rc != 0:
             raise _lib.SnkError(rc, err.value.decode(errors="replace"))
         return ShardedResult(e, params.K, raw)
+
+    def count_graph_streamed(self, slabs, read_len, total_reads: int, rank_reads_ub: int, params: Params | None = None, ign_bc_below: int = 0) -> ShardedResult:
+        """The same step with this rank's reads arriving slab by slab (snk_shard_stream_*): `slabs` yields dicts with rows, quals / good_len,
+        optional lens, bc, and read_index_base (global index of the slab's first read); total_reads = reads of the whole job (every rank
+        passes the same figure), rank_reads_ub = an upper bound of what this rank appends."""
+        e, lib = self.eng, self.lib
+        params = params or Params()
+        err = C.create_string_buffer(512)
+        p = params.to_c()
+        it = iter(slabs)
+        first = next(it)
+        has_bc = 1 if first.get("bc") is not None else 0
+        rc = lib.snk_shard_stream_begin(e._ctx, self.comm, C.byref(p), int(read_len), int(rank_reads_ub), int(total_reads), has_bc, e._stream(), err, 512)
+        if rc != 0:
+            raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+        import itertools
+        keep = []
+        for sl in itertools.chain([first], it):
+            r = _lib.SnkDevReads()
+            rows = sl["rows"]
+            r.n_reads, r.rows, r.row_words, r.read_len = rows.shape[0], rows.data_ptr(), rows.shape[1], read_len
+            if sl.get("lens") is not None:
+                r.lens = sl["lens"].data_ptr()
+            if sl.get("quals") is not None:
+                r.quals, r.qstride = sl["quals"].data_ptr(), sl["quals"].shape[1]
+            if sl.get("good_len") is not None:
+                r.good_len = sl["good_len"].data_ptr()
+            if sl.get("bc") is not None:
+                r.bc = sl["bc"].data_ptr()
+            r.ign_bc_below, r.read_index_base = ign_bc_below, int(sl.get("read_index_base", 0))
+            rc = lib.snk_shard_stream_append(e._ctx, C.byref(r), e._stream(), err, 512)
+            if rc != 0:
+                raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+            keep.append(sl)          # (the launches read the slab's tensors: they stay alive until the step is through)
+        raw = _lib.SnkShardResult()
+        rc = lib.snk_shard_stream_finish(e._ctx, self.comm, 0, C.byref(raw), e._stream(), err, 512)
+        if rc != 0:
+            raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+        return ShardedResult(e, params.K, raw)

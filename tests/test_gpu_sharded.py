@@ -127,6 +127,52 @@ def test_sharded_hot_buckets_are_repartitioned_on_their_owner(snk, W, name, monk
     assert sum(o["n_hot"] for o in out) > 0
 
 
+@pytest.mark.parametrize("W", [1, 2, 3])
+def test_sharded_streamed_slabs_equal_the_resident_step(snk, W):
+    """snk_shard_stream_begin / _append / _finish: a rank's reads arrive in slabs of uneven size and are partitioned as they come; everything
+    behind the partition is the resident step's.  Same table, contexts, spectrum and unitigs as the reference's (the golden), i.e. as the
+    resident step gives."""
+    import threading
+    import torch
+    from supernova_amd.engine import Engine, Params
+    from supernova_amd.sharded import ShardedEngine, SimWorld
+    c = goldens.load("synth_20k_err")
+    dev = torch.device("cuda", 0)
+    world = SimWorld(W)
+    n = c.rows.shape[0]
+    bounds = [n * r // W for r in range(W + 1)]
+    out, errs = [None] * W, []
+
+    def worker(r):
+        try:
+            torch.cuda.set_device(0)
+            e = Engine(0)
+            lo, hi = bounds[r], bounds[r + 1]
+            cuts = [lo, lo + (hi - lo) // 7, lo + (hi - lo) // 7, lo + (hi - lo) // 2, hi]        # (one empty slab among them)
+            def slabs():
+                for a, b in zip(cuts[:-1], cuts[1:]):
+                    yield dict(rows=torch.from_numpy(c.rows[a:b].view(np.int32).copy()).to(dev), quals=torch.from_numpy(np.ascontiguousarray(c.quals[a:b])).to(dev),
+                               bc=torch.from_numpy(c.bc[a:b].astype(np.int32)).to(dev), lens=torch.from_numpy(c.lens[a:b].astype(np.uint16).view(np.int16)).to(dev),
+                               read_index_base=a)
+            sh = ShardedEngine(e, world.comm(r))
+            res = sh.count_graph_streamed(slabs(), c.read_len, total_reads=n, rank_reads_ub=hi - lo + 5, params=Params(K=48), ign_bc_below=c.ign_bc_below)
+            out[r] = dict(keys=res.keys(), counts=res.counts(), ctx=res.ctx(), spectrum=res.spectrum(), n_instances=res.n_instances, n_frags=res.n_frags,
+                          n_queries=res.n_queries, unitigs=res.unitigs())
+            e.close()
+        except BaseException as ex:  # noqa: BLE001
+            errs.append(ex)
+            world.barrier_obj.abort()
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(W)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if errs:
+        raise errs[0]
+    check(out, c)
+
+
 def test_sharded_many_small_buckets(snk):
     c = goldens.load("adversarial")
     check(run_world(4, c, n_buckets=4 * 997), c)
