@@ -362,6 +362,7 @@ __device__ __forceinline__ uint32_t owner_of_frag(const unsigned long long* __re
 // One fragment per thread for the bookkeeping: the workgroup adds up its fragments and bytes per owner in LDS and goes to
 // the `world` device counters once per owner (2 M fragments on the same few addresses, one device atomic each, took 100 ms);
 // then the bases are copied by 8 lanes per fragment.
+constexpr int ROUTE_TILES = 16;      // tiles of 256 fragments per workgroup: ONE reservation per owner for all of them (see jlink_query_kernel, snk_graph.hip)
 template <bool FILL>
 __global__ void __launch_bounds__(256) route_kernel(uint64_t Fl, unsigned long long f0, const uint32_t* __restrict__ nk, const uint32_t* __restrict__ pl_pid,
                                                     const unsigned long long* __restrict__ pl_koff, const unsigned long long* __restrict__ pl_N,
@@ -369,23 +370,23 @@ __global__ void __launch_bounds__(256) route_kernel(uint64_t Fl, unsigned long l
                                                     uint32_t K, const uint64_t* __restrict__ boff, const uint8_t* __restrict__ bases,
                                                     unsigned long long* __restrict__ cnt_or_cur /* [2][world] */, unsigned long long* __restrict__ hdr,
                                                     uint8_t* __restrict__ bout, const unsigned long long* __restrict__ base_seg /* [world] byte offset of every owner's segment */) {
-    extern __shared__ unsigned long long dynr[];          // [world] fragments -> reserved first header, [world] bytes -> reserved first byte
+    extern __shared__ unsigned long long dynr[];          // [world] fragments -> reserved first header, [world] bytes -> reserved first byte, [2][world] running cursors
     __shared__ unsigned long long c_src[256], c_dst[256];
     __shared__ uint32_t c_len[256];
     unsigned long long* lfr = dynr;
     unsigned long long* lby = dynr + world;
-    for (uint32_t r = threadIdx.x; r < 2 * world; r += 256) dynr[r] = 0;
+    unsigned long long* cfr = dynr + 2 * world;
+    unsigned long long* cby = dynr + 3 * world;
+    for (uint32_t r = threadIdx.x; r < 4 * world; r += 256) dynr[r] = 0;
     __syncthreads();
-    const uint64_t f = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    uint32_t pid = 0, owner = 0;
-    uint64_t len = 0;
-    unsigned long long lslot = 0, lbo = 0;
-    if (f < Fl) {
-        pid = pl_pid[f];
-        owner = owner_of_frag(frag_off, world, pid >> 1);
-        len = (uint64_t)nk[f] + K - 1;
-        lslot = atomicAdd(&lfr[owner], 1ull);
-        lbo = atomicAdd(&lby[owner], (unsigned long long)len);
+    const uint64_t fbase = (uint64_t)blockIdx.x * 256 * ROUTE_TILES + threadIdx.x;
+    for (int t = 0; t < ROUTE_TILES; ++t) {
+        const uint64_t f = fbase + (uint64_t)t * 256;
+        if (f < Fl) {
+            const uint32_t owner = owner_of_frag(frag_off, world, pl_pid[f] >> 1);
+            atomicAdd(&lfr[owner], 1ull);
+            atomicAdd(&lby[owner], (unsigned long long)((uint64_t)nk[f] + K - 1));
+        }
     }
     __syncthreads();
     for (uint32_t r = threadIdx.x; r < world; r += 256) {
@@ -396,38 +397,44 @@ __global__ void __launch_bounds__(256) route_kernel(uint64_t Fl, unsigned long l
         }
     }
     if (!FILL) return;
-    __syncthreads();
-    c_len[threadIdx.x] = 0;
-    if (f < Fl) {
-        const unsigned long long slot = lfr[owner] + lslot, bo = lby[owner] + lbo;
-        const unsigned long long ko = pl_koff[f];
-        const unsigned long long g = f0 + f;
-        const bool head = (ko & ~(1ull << 63)) == 0 && (pid >> 1) == (uint32_t)g;
-        const unsigned long long flags = ((ko >> 63) ? RT_RC : 0ull) | (pl_circ[f] ? RT_CIRC : 0ull) | (head ? RT_HEAD : 0ull);
-        hdr[4 * slot + 0] = (unsigned long long)pid | (g << 32);
-        hdr[4 * slot + 1] = (unsigned long long)nk[f] | (flags << 32);
-        hdr[4 * slot + 2] = head ? pl_N[f] : (ko & ~(1ull << 63));
-        hdr[4 * slot + 3] = bo - base_seg[owner];
-        c_src[threadIdx.x] = boff[f];
-        c_dst[threadIdx.x] = bo;
-        c_len[threadIdx.x] = (uint32_t)len;
-    }
-    __syncthreads();
-    const uint32_t sub = threadIdx.x & 7u;
-    for (uint32_t i = threadIdx.x >> 3; i < 256; i += 32) {
-        const uint32_t n = c_len[i];
-        const uint8_t* src = bases + c_src[i];
-        uint8_t* dst = bout + c_dst[i];
-        // bytes up to dst's first 4-byte boundary, dwords (read at byte alignment), the last bytes -- a byte per lane and instruction
-        // made the copy instruction-bound (snk_graph.hip, jemit_kernel)
-        struct __attribute__((packed)) u32_any { uint32_t v; };
-        uint32_t head = (4u - (uint32_t)((uintptr_t)dst & 3u)) & 3u;
-        if (head > n) head = n;
-        if (sub < head) dst[sub] = src[sub];
-        const uint32_t ndw = (n - head) >> 2;
-        for (uint32_t j = sub; j < ndw; j += 8) *reinterpret_cast<uint32_t*>(dst + head + 4 * j) = reinterpret_cast<const u32_any*>(src + head + 4 * j)->v;
-        const uint32_t t0 = head + 4 * ndw;
-        if (sub < n - t0) dst[t0 + sub] = src[t0 + sub];
+    for (int t = 0; t < ROUTE_TILES; ++t) {
+        __syncthreads();       // the reservations are in LDS / the copy of the tile before is through with c_src, c_dst, c_len
+        const uint64_t f = fbase + (uint64_t)t * 256;
+        c_len[threadIdx.x] = 0;
+        if (f < Fl) {
+            const uint32_t pid = pl_pid[f];
+            const uint32_t owner = owner_of_frag(frag_off, world, pid >> 1);
+            const uint64_t len = (uint64_t)nk[f] + K - 1;
+            const unsigned long long slot = lfr[owner] + atomicAdd(&cfr[owner], 1ull), bo = lby[owner] + atomicAdd(&cby[owner], (unsigned long long)len);
+            const unsigned long long ko = pl_koff[f];
+            const unsigned long long g = f0 + f;
+            const bool head = (ko & ~(1ull << 63)) == 0 && (pid >> 1) == (uint32_t)g;
+            const unsigned long long flags = ((ko >> 63) ? RT_RC : 0ull) | (pl_circ[f] ? RT_CIRC : 0ull) | (head ? RT_HEAD : 0ull);
+            hdr[4 * slot + 0] = (unsigned long long)pid | (g << 32);
+            hdr[4 * slot + 1] = (unsigned long long)nk[f] | (flags << 32);
+            hdr[4 * slot + 2] = head ? pl_N[f] : (ko & ~(1ull << 63));
+            hdr[4 * slot + 3] = bo - base_seg[owner];
+            c_src[threadIdx.x] = boff[f];
+            c_dst[threadIdx.x] = bo;
+            c_len[threadIdx.x] = (uint32_t)len;
+        }
+        __syncthreads();
+        const uint32_t sub = threadIdx.x & 7u;
+        for (uint32_t i = threadIdx.x >> 3; i < 256; i += 32) {
+            const uint32_t n = c_len[i];
+            const uint8_t* src = bases + c_src[i];
+            uint8_t* dst = bout + c_dst[i];
+            // bytes up to dst's first 4-byte boundary, dwords (read at byte alignment), the last bytes -- a byte per lane and instruction
+            // made the copy instruction-bound (snk_graph.hip, jemit_kernel)
+            struct __attribute__((packed)) u32_any { uint32_t v; };
+            uint32_t head = (4u - (uint32_t)((uintptr_t)dst & 3u)) & 3u;
+            if (head > n) head = n;
+            if (sub < head) dst[sub] = src[sub];
+            const uint32_t ndw = (n - head) >> 2;
+            for (uint32_t j = sub; j < ndw; j += 8) *reinterpret_cast<uint32_t*>(dst + head + 4 * j) = reinterpret_cast<const u32_any*>(src + head + 4 * j)->v;
+            const uint32_t t0 = head + 4 * ndw;
+            if (sub < n - t0) dst[t0 + sub] = src[t0 + sub];
+        }
     }
 }
 // received headers -> the arrays snk_join_emit wants; hdr_seg / base_seg: first header / first base byte of every source rank
@@ -467,7 +474,7 @@ static int place_and_count(snk_ctx* ctx, snk_shard_state* S, hipStream_t st, uin
     if ((rc = snk_ctx_alloc(ctx, 2ull * (S->world + 1) * 8, &q, err, errcap))) return rc; S->rt_count = (unsigned long long*)q;
     if ((rc = snk_ctx_alloc(ctx, 2ull * (S->world + 1) * 8, &q, err, errcap))) return rc; S->rt_cursor = (unsigned long long*)q;
     SNK_HIP_TRY(hipMemsetAsync(S->rt_count, 0, 2ull * (S->world + 1) * 8, st));
-    if (Fl) hipLaunchKernelGGL((route_kernel<false>), dim3((unsigned)((Fl + 255) / 256)), dim3(256), 2ull * S->world * 8, st, Fl, (unsigned long long)S->my_frag_off, S->frags.nk, S->pl.pid, S->pl.koff,
+    if (Fl) hipLaunchKernelGGL((route_kernel<false>), dim3((unsigned)((Fl + 256 * ROUTE_TILES - 1) / (256 * ROUTE_TILES))), dim3(256), 4ull * S->world * 8, st, Fl, (unsigned long long)S->my_frag_off, S->frags.nk, S->pl.pid, S->pl.koff,
                                S->pl.N, S->pl.circ, (const unsigned long long*)d_frag_off, S->world, K, S->frags.boff, S->frags.bases, S->rt_count, nullptr, nullptr, nullptr);
     SNK_HIP_TRY(hipGetLastError());
     std::vector<unsigned long long> h(2 * S->world);
@@ -580,7 +587,7 @@ extern "C" int snk_shard_route_fill(snk_ctx* ctx, uint32_t K, const void* d_frag
     const uint64_t Fl = S->frags.n_frags;
     SNK_HIP_TRY(hipMemcpyAsync(S->rt_cursor, d_hdr_off, S->world * 8ull, hipMemcpyDeviceToDevice, st));
     SNK_HIP_TRY(hipMemcpyAsync(S->rt_cursor + S->world, d_base_off, S->world * 8ull, hipMemcpyDeviceToDevice, st));
-    if (Fl) hipLaunchKernelGGL((route_kernel<true>), dim3((unsigned)((Fl + 255) / 256)), dim3(256), 2ull * S->world * 8, st, Fl, (unsigned long long)S->my_frag_off, S->frags.nk, S->pl.pid, S->pl.koff,
+    if (Fl) hipLaunchKernelGGL((route_kernel<true>), dim3((unsigned)((Fl + 256 * ROUTE_TILES - 1) / (256 * ROUTE_TILES))), dim3(256), 4ull * S->world * 8, st, Fl, (unsigned long long)S->my_frag_off, S->frags.nk, S->pl.pid, S->pl.koff,
                                S->pl.N, S->pl.circ, (const unsigned long long*)d_frag_off, S->world, K, S->frags.boff, S->frags.bases, S->rt_cursor,
                                (unsigned long long*)d_hdr, (uint8_t*)d_bases, (const unsigned long long*)d_base_off);
     SNK_HIP_TRY(hipGetLastError());

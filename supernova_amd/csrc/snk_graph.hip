@@ -795,28 +795,33 @@ __global__ void __launch_bounds__(TB) spl_walk2p_kernel(const unsigned long long
         d -= w[cur >> 1];
     }
 }
-// records to the owners of their states: count / fill with the per-owner sums taken in LDS first
+// records to the owners of their states: count / fill with the per-owner sums taken in LDS first, one reservation per owner and PR_TILES tiles
+constexpr int PR_TILES = 16;
 template <bool FILL>
 __global__ void __launch_bounds__(256) prank_route_kernel(const uint4* __restrict__ rec, uint64_t n, const unsigned long long* __restrict__ frag_off, uint32_t world,
                                                           unsigned long long* __restrict__ cnt_or_cur, uint4* __restrict__ out) {
-    extern __shared__ unsigned long long dynp[];
-    for (uint32_t r = threadIdx.x; r < world; r += 256) dynp[r] = 0;
+    extern __shared__ unsigned long long dynp[];          // [world] counts -> reserved bases, then [world] u32 local cursors
+    uint32_t* lcur = reinterpret_cast<uint32_t*>(dynp + world);
+    for (uint32_t r = threadIdx.x; r < world; r += 256) { dynp[r] = 0; lcur[r] = 0; }
     __syncthreads();
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    uint32_t owner = 0;
-    unsigned long long ls = 0;
-    if (i < n) {
-        v = rec[i];
-        const unsigned long long g = v.x >> 1;
-        while (owner + 1 < world && g >= frag_off[owner + 1]) ++owner;
-        ls = atomicAdd(&dynp[owner], 1ull);
+    const uint64_t i0 = (uint64_t)blockIdx.x * 256 * PR_TILES + threadIdx.x;
+    auto owner_of = [&](unsigned long long g) { uint32_t o = 0; while (o + 1 < world && g >= frag_off[o + 1]) ++o; return o; };
+    for (int t = 0; t < PR_TILES; ++t) {
+        const uint64_t i = i0 + (uint64_t)t * 256;
+        if (i < n) atomicAdd(&dynp[owner_of(rec[i].x >> 1)], 1ull);
     }
     __syncthreads();
     for (uint32_t r = threadIdx.x; r < world; r += 256) { const unsigned long long c = dynp[r]; if (c) dynp[r] = atomicAdd(&cnt_or_cur[r], c); }
     if (!FILL) return;
     __syncthreads();
-    if (i < n) out[dynp[owner] + ls] = v;
+    for (int t = 0; t < PR_TILES; ++t) {
+        const uint64_t i = i0 + (uint64_t)t * 256;
+        if (i < n) {
+            const uint4 v = rec[i];
+            const uint32_t owner = owner_of(v.x >> 1);
+            out[dynp[owner] + atomicAdd(&lcur[owner], 1u)] = v;
+        }
+    }
 }
 __global__ void __launch_bounds__(TB) prank_apply_kernel(const uint4* __restrict__ rec, uint64_t n, unsigned long long state_base, uint64_t n_local_states,
                                                          uint2* __restrict__ rk, uint32_t* __restrict__ bad) {
@@ -1040,6 +1045,11 @@ __global__ void __launch_bounds__(TB) jmatch_direct_kernel(const unsigned long l
 // ---- sharded runs: fragment links decided on the owners.  An end whose half link names a state of rank q asks q (24 bytes:
 // target state, my state, my global end id | my local end << 32); q looks the state up in its terminal-state table and
 // answers with the global id of the end that sits there and points back, or NONE.
+// A workgroup takes RT_TILES tiles of TB items and goes to the per-owner device counters ONCE (count the tiles, reserve, then fill them):
+// these cursors are a handful of words on one 64-byte line, atomics on one line are served one at a time (~10 ns each), and with a
+// reservation per 256 items the 136 k workgroups of a 17 M-fragment rank WERE these kernels' time (1.65-1.76 ms each on one rank;
+// times the number of owners on eight).
+constexpr int RT_TILES = 16;
 template <bool FILL>
 __global__ void __launch_bounds__(TB) jlink_query_kernel(const unsigned long long* __restrict__ hl_self, const unsigned long long* __restrict__ hl_nb,
                                                          uint64_t ne, const unsigned long long* __restrict__ node_off, uint32_t world,
@@ -1049,14 +1059,12 @@ __global__ void __launch_bounds__(TB) jlink_query_kernel(const unsigned long lon
     uint32_t* lcur = reinterpret_cast<uint32_t*>(dynl + world);
     for (uint32_t r = threadIdx.x; r < world; r += TB) { dynl[r] = 0; lcur[r] = 0; }
     __syncthreads();
-    const uint64_t e = (uint64_t)blockIdx.x * TB + threadIdx.x;
-    unsigned long long nb = NONE64;
-    uint32_t owner = 0;
-    if (e < ne) nb = hl_nb[e];
-    if (nb != NONE64) {
-        const unsigned long long node = nb >> 1;
-        while (owner + 1 < world && node >= node_off[owner + 1]) ++owner;
-        atomicAdd(&dynl[owner], 1ull);
+    const uint64_t e0 = (uint64_t)blockIdx.x * TB * RT_TILES + threadIdx.x;
+    auto owner_of = [&](unsigned long long nb) { uint32_t o = 0; const unsigned long long node = nb >> 1; while (o + 1 < world && node >= node_off[o + 1]) ++o; return o; };
+    for (int t = 0; t < RT_TILES; ++t) {
+        const uint64_t e = e0 + (uint64_t)t * TB;
+        const unsigned long long nb = e < ne ? hl_nb[e] : NONE64;
+        if (nb != NONE64) atomicAdd(&dynl[owner_of(nb)], 1ull);
     }
     __syncthreads();
     for (uint32_t r = threadIdx.x; r < world; r += TB) {
@@ -1065,11 +1073,16 @@ __global__ void __launch_bounds__(TB) jlink_query_kernel(const unsigned long lon
     }
     if (!FILL) return;
     __syncthreads();
-    if (nb != NONE64) {
-        const unsigned long long slot = dynl[owner] + atomicAdd(&lcur[owner], 1u);
-        qbuf[3 * slot + 0] = nb;
-        qbuf[3 * slot + 1] = hl_self[e];
-        qbuf[3 * slot + 2] = (my_end_base + e) | ((unsigned long long)e << 32);
+    for (int t = 0; t < RT_TILES; ++t) {
+        const uint64_t e = e0 + (uint64_t)t * TB;
+        const unsigned long long nb = e < ne ? hl_nb[e] : NONE64;
+        if (nb != NONE64) {
+            const uint32_t owner = owner_of(nb);
+            const unsigned long long slot = dynl[owner] + atomicAdd(&lcur[owner], 1u);
+            qbuf[3 * slot + 0] = nb;
+            qbuf[3 * slot + 1] = hl_self[e];
+            qbuf[3 * slot + 2] = (my_end_base + e) | ((unsigned long long)e << 32);
+        }
     }
 }
 __global__ void __launch_bounds__(TB) jlink_answer_kernel(const unsigned long long* __restrict__ q, uint64_t nq,
@@ -1621,8 +1634,8 @@ int snk_dist_links_query(snk_ctx* ctx, hipStream_t st, bool fill, const snk_frag
     if (ne == 0) return SNK_OK;
     if (ne >= (1ull << 32)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "more than 2^31 fragments on one rank");
     const size_t lds = (size_t)world * 12 + 16;
-    if (fill) hipLaunchKernelGGL((jlink_query_kernel<true>), dim3(nblk(ne)), dim3(TB), lds, st, fr->hl_self, fr->hl_nb, ne, d_node_off, world, my_end_base, d_count_or_cursor, (unsigned long long*)d_qbuf);
-    else hipLaunchKernelGGL((jlink_query_kernel<false>), dim3(nblk(ne)), dim3(TB), lds, st, fr->hl_self, fr->hl_nb, ne, d_node_off, world, my_end_base, d_count_or_cursor, (unsigned long long*)nullptr);
+    if (fill) hipLaunchKernelGGL((jlink_query_kernel<true>), dim3(nblk((ne + RT_TILES - 1) / RT_TILES)), dim3(TB), lds, st, fr->hl_self, fr->hl_nb, ne, d_node_off, world, my_end_base, d_count_or_cursor, (unsigned long long*)d_qbuf);
+    else hipLaunchKernelGGL((jlink_query_kernel<false>), dim3(nblk((ne + RT_TILES - 1) / RT_TILES)), dim3(TB), lds, st, fr->hl_self, fr->hl_nb, ne, d_node_off, world, my_end_base, d_count_or_cursor, (unsigned long long*)nullptr);
     SNK_HIP_TRY(hipGetLastError());
     return SNK_OK;
 }
@@ -1776,9 +1789,9 @@ int snk_prank_walk(snk_ctx* ctx, hipStream_t st, snk_prank* P, const uint4* w1_a
 int snk_prank_route(snk_ctx* ctx, hipStream_t st, snk_prank* P, bool fill, const unsigned long long* d_frag_off, uint32_t world,
                     unsigned long long* d_cnt_or_cur, void* d_out, char* err, size_t errcap) {
     if (!P->n_rec) return SNK_OK;
-    const unsigned nb = (unsigned)((P->n_rec + 255) / 256);
-    if (fill) hipLaunchKernelGGL((prank_route_kernel<true>), dim3(nb), dim3(256), world * 8ull, st, P->rec, P->n_rec, d_frag_off, world, d_cnt_or_cur, (uint4*)d_out);
-    else hipLaunchKernelGGL((prank_route_kernel<false>), dim3(nb), dim3(256), world * 8ull, st, P->rec, P->n_rec, d_frag_off, world, d_cnt_or_cur, (uint4*)nullptr);
+    const unsigned nb = (unsigned)((P->n_rec + 256 * PR_TILES - 1) / (256 * PR_TILES));
+    if (fill) hipLaunchKernelGGL((prank_route_kernel<true>), dim3(nb), dim3(256), world * 12ull + 16, st, P->rec, P->n_rec, d_frag_off, world, d_cnt_or_cur, (uint4*)d_out);
+    else hipLaunchKernelGGL((prank_route_kernel<false>), dim3(nb), dim3(256), world * 12ull + 16, st, P->rec, P->n_rec, d_frag_off, world, d_cnt_or_cur, (uint4*)nullptr);
     SNK_HIP_TRY(hipGetLastError());
     return SNK_OK;
 }

@@ -792,7 +792,9 @@ constexpr int BCAP = 1280, BT = 256;    // big chunks (a count sub-pass retains 
 namespace {
 // ---- sharded runs: membership queries for pending neighbours that belong to another rank
 // query record: 3 x u64 = key lo, key hi, (node | bit << 32 | rev << 40)   (same as snk_graph.hip's sharded stage)
-constexpr int QSPAN = 8 * TB;
+constexpr int QWORDS = 4;               // 8-byte words of pending flags per thread
+constexpr int QSPAN = 8 * QWORDS * TB;      // k-mers per workgroup: ONE reservation per destination rank for all of them (the per-rank cursors are a few words on
+                                            // one 64-byte line: atomics on a line are served one at a time; 131 k workgroups x 8 ranks were ~10 ms per pass)
 template <int K, bool FILL>
 __global__ void __launch_bounds__(TB) bl_query_kernel(const snk_u128* __restrict__ keys, const uint8_t* __restrict__ premote, uint64_t n,
                                                       uint32_t NB_total, uint32_t NBl, uint32_t world,
@@ -806,8 +808,9 @@ __global__ void __launch_bounds__(TB) bl_query_kernel(const snk_u128* __restrict
     if (threadIdx.x == 0) cnt = 0;
     for (uint32_t r = threadIdx.x; r < world; r += TB) { dynq[r] = 0; lcur[r] = 0; }
     __syncthreads();
-    {
-        const uint64_t i8 = base + 8ull * threadIdx.x;
+    for (int t = 0; t < QWORDS; ++t) {
+        const uint32_t w0 = 8u * ((uint32_t)t * TB + threadIdx.x);        // first item of this thread's word inside the span
+        const uint64_t i8 = base + w0;
         unsigned long long w = 0;
         if (i8 + 8 <= n) w = *reinterpret_cast<const unsigned long long*>(premote + i8);
         else for (uint64_t q = i8; q < n; ++q) w |= (unsigned long long)premote[q] << (8 * (q - i8));
@@ -815,7 +818,7 @@ __global__ void __launch_bounds__(TB) bl_query_kernel(const snk_u128* __restrict
             uint32_t m = 0;
             for (int q = 0; q < 8; ++q) if ((w >> (8 * q)) & 0xFFull) ++m;
             uint32_t pos = atomicAdd(&cnt, m);
-            for (int q = 0; q < 8; ++q) if ((w >> (8 * q)) & 0xFFull) list[pos++] = (uint16_t)(8 * threadIdx.x + q);
+            for (int q = 0; q < 8; ++q) if ((w >> (8 * q)) & 0xFFull) list[pos++] = (uint16_t)(w0 + q);
         }
     }
     __syncthreads();
