@@ -917,9 +917,21 @@ __global__ void __launch_bounds__(256) ubc_flag_kernel(const unsigned long long*
 __global__ void __launch_bounds__(256) ubc_scatter_kernel(const unsigned long long* __restrict__ k, const uint64_t* __restrict__ flag, const uint64_t* __restrict__ pos,
                                                           uint64_t n, uint32_t* __restrict__ bcs, uint64_t* __restrict__ per_unitig) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n || !flag[i]) return;
-    bcs[pos[i]] = (uint32_t)k[i];
-    atomicAdd((unsigned long long*)&per_unitig[k[i] >> 32], 1ull);
+    const bool on = i < n && flag[i];
+    unsigned long long key = 0;
+    if (on) { key = k[i]; bcs[pos[i]] = (uint32_t)key; }
+    // the keys are sorted: a wave's keys belong to one unitig or a few -- one addition per unitig and wave (lane by lane, 64 additions
+    // to ONE counter were served one at a time)
+    const uint32_t u = (uint32_t)(key >> 32);
+    unsigned long long act = __ballot(on);
+    const uint32_t lane = threadIdx.x & 63u;
+    while (act) {
+        const int lead = __ffsll((long long)act) - 1;
+        const uint32_t u0 = (uint32_t)__shfl((int)u, lead);
+        const unsigned long long same = __ballot(on && u == u0);
+        if ((int)lane == lead) atomicAdd((unsigned long long*)&per_unitig[u0], (unsigned long long)__popcll(same));
+        act &= ~same;
+    }
 }
 
 // ---- second, independent derivation of the (unitig, barcode) keys (SNK_PATH_UNITIG_BCS_EXHAUSTIVE; a cross-check, ~50x the
