@@ -65,15 +65,28 @@ __global__ void __launch_bounds__(256) dup_key_kernel(dup_in a, unsigned long lo
         head[r] = h;
     }
     // (one counter for every wave of the grid is 1.6 M atomics on ONE address, ~10 ns each: 16 of this kernel's 19 ms.  256 counters.)
+    // (round 4: the 256 counters are 2 KB = 32 lines, and atomics on one 64-byte line are served one at a time whatever word they address:
+    // 1.56 M waves x four atomics were still half of this kernel's 1.9 ms.  One addition per workgroup now, and the three range words
+    // are looked at before they are touched -- they stop moving after the first few thousand reads.)
+    __shared__ uint32_t wg_placed;
+    if (threadIdx.x == 0) wg_placed = 0;
+    __syncthreads();
     const unsigned long long m = __ballot(placed);
-    const uint32_t slot = (blockIdx.x * 4u + (threadIdx.x >> 6)) & 255u;
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&n_placed[slot], (unsigned long long)__popcll(m));
+    const uint32_t slot = blockIdx.x & 255u;
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&wg_placed, (uint32_t)__popcll(m));
+    __syncthreads();
+    if (threadIdx.x == 0 && wg_placed) atomicAdd(&n_placed[slot], (unsigned long long)wg_placed);
     // ranges of the placed reads' edges and offsets (they decide how many key bits the sort has to look at)
     uint32_t emax = placed ? ke : 0u, omax = placed ? ko : 0u, omin = placed ? ko : 0xFFFFFFFFu;
     for (int o = 32; o > 0; o >>= 1) {
         emax = max(emax, (uint32_t)__shfl_xor((int)emax, o)); omax = max(omax, (uint32_t)__shfl_xor((int)omax, o)); omin = min(omin, (uint32_t)__shfl_xor((int)omin, o));
     }
-    if ((threadIdx.x & 63) == 0 && m) { atomicMax(&range[slot], emax); atomicMax(&range[256 + slot], omax); atomicMin(&range[512 + slot], omin); }
+    if ((threadIdx.x & 63) == 0 && m) {
+        // (a plain load may be stale -- then the atomic runs, as before; what it can never do is hide a value that still has to go in)
+        if (emax > range[slot]) atomicMax(&range[slot], emax);
+        if (omax > range[256 + slot]) atomicMax(&range[256 + slot], omax);
+        if (omin < range[512 + slot]) atomicMin(&range[512 + slot], omin);
+    }
 }
 
 __global__ void __launch_bounds__(256) dup_gather_key_kernel(const uint32_t* __restrict__ id, const unsigned long long* __restrict__ key, uint64_t n,
