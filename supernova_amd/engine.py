@@ -123,7 +123,7 @@ class Result:
         if rc:
             raise _lib.SnkError(rc, err.value.decode(errors="replace"))
         ne, nu = h.n_edges, self.n_unitigs
-        arr = lambda p, m, dt: (np.ctypeslib.as_array(p, shape=(m,)).astype(dt).copy() if m else np.zeros(0, dt))
+        arr = lambda p, m, dt: (np.array(np.ctypeslib.as_array(p, shape=(m,)), dtype=dt, copy=True) if m else np.zeros(0, dt))      # (one copy: the C arrays are freed below)
         out = dict(n_vertices=h.n_vertices, n_edges=ne, v_left=arr(h.v_left, ne, np.int32), v_right=arr(h.v_right, ne, np.int32),
                    src=arr(h.src_unitig, ne, np.int32), is_rc=arr(h.is_rc, ne, np.uint8), fwd=arr(h.fwd_xlat, nu, np.int32),
                    rev=arr(h.rev_xlat, nu, np.int32), order=arr(h.bvcomp_order, nu, np.int32), device_ms=float(ms.value))
