@@ -133,20 +133,46 @@ __global__ void __launch_bounds__(256) bv_sizes_kernel(const uint64_t* __restric
     if (r < U) { const uint64_t len = off[order[r] + 1] - off[order[r]]; v = image ? 4 + (len + 3) / 4 : len; }
     sz[r] = v;
 }
-// one workgroup per 4096 output bytes: the owners of a block's bytes are found by binary search over the offsets
+// One thread per FOUR output bytes (a byte per lane and store made this kernel instruction-bound: 0.98 ms for the bench graph's 67 MB
+// image, 350 GB/s): the owner of the group is found by binary search over the offsets; a group that lies inside one unitig's packed
+// bases -- all but the few at a record's head or tail -- is 16 source bytes (four unaligned dword loads) and one dword store.
+__device__ __forceinline__ uint8_t bv_byte(const uint64_t* __restrict__ off, const uint8_t* __restrict__ bases, const uint32_t* __restrict__ order,
+                                           const uint64_t* __restrict__ noff, uint64_t lo, uint64_t p, int image) {
+    const uint64_t src = off[order[lo]], len = off[order[lo] + 1] - src, q = p - noff[lo];
+    if (!image) return bases[src + q];
+    if (q < 4) return (uint8_t)((uint32_t)len >> (8 * q));
+    const uint64_t j = (q - 4) * 4;
+    uint32_t v = 0;
+    for (uint32_t t = 0; t < 4 && j + t < len; ++t) v |= (uint32_t)(bases[src + j + t] & 3u) << (2 * t);
+    return (uint8_t)v;
+}
 __global__ void __launch_bounds__(256) bv_gather_kernel(const uint64_t* __restrict__ off, const uint8_t* __restrict__ bases, const uint32_t* __restrict__ order,
                                                         const uint64_t* __restrict__ noff, uint64_t U, uint64_t total, int image, uint8_t* __restrict__ out) {
-    const uint64_t p0 = (uint64_t)blockIdx.x * 4096;
-    for (uint64_t p = p0 + threadIdx.x; p < p0 + 4096 && p < total; p += 256) {
-        uint64_t lo = 0, hi = U;                     // largest r with noff[r] <= p
-        while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (noff[mid] <= p) lo = mid; else hi = mid; }
-        const uint64_t src = off[order[lo]], len = off[order[lo] + 1] - src, q = p - noff[lo];
-        if (!image) { out[p] = bases[src + q]; continue; }
-        if (q < 4) { out[p] = (uint8_t)((uint32_t)len >> (8 * q)); continue; }
+    const uint64_t p = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (p >= total) return;
+    uint64_t lo = 0, hi = U;                     // largest r with noff[r] <= p
+    while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (noff[mid] <= p) lo = mid; else hi = mid; }
+    struct __attribute__((packed)) u32_any { uint32_t v; };
+    const uint64_t nend = noff[lo + 1];
+    const uint64_t src = off[order[lo]], len = off[order[lo] + 1] - src, q = p - noff[lo];
+    if (p + 4 <= total && p + 4 <= nend && (((uintptr_t)(out + p)) & 3u) == 0) {
+        if (!image) { *reinterpret_cast<uint32_t*>(out + p) = reinterpret_cast<const u32_any*>(bases + src + q)->v; return; }
         const uint64_t j = (q - 4) * 4;
-        uint32_t v = 0;
-        for (uint32_t t = 0; t < 4 && j + t < len; ++t) v |= (uint32_t)(bases[src + j + t] & 3u) << (2 * t);
-        out[p] = (uint8_t)v;
+        if (q >= 4 && j + 16 <= len) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint32_t x = reinterpret_cast<const u32_any*>(bases + src + j + 4 * t)->v & 0x03030303u;     // four bases, one per byte
+                v |= ((x | (x >> 6) | (x >> 12) | (x >> 18)) & 0xFFu) << (8 * t);
+            }
+            *reinterpret_cast<uint32_t*>(out + p) = v;
+            return;
+        }
+    }
+    // a record's length word, its last bytes, a group across two records, the image's tail: byte by byte
+    for (uint64_t pp = p; pp < p + 4 && pp < total; ++pp) {
+        while (pp >= noff[lo + 1]) ++lo;
+        out[pp] = bv_byte(off, bases, order, noff, lo, pp, image);
     }
 }
 __global__ void __launch_bounds__(256) key_words_kernel(const snk_kmer* __restrict__ keys, uint64_t n, uint4* __restrict__ out) {
@@ -221,7 +247,7 @@ int unitigs_bv_device(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t U, cons
     }
     uint8_t* d_out;
     if ((rc = arena(ctx, header_bytes + total + 16, &d_out, err, errcap))) return rc;
-    if (total) hipLaunchKernelGGL(bv_gather_kernel, dim3((unsigned)((total + 4095) / 4096)), dim3(256), 0, st, d_off, d_bases, order, noff, U, total,
+    if (total) hipLaunchKernelGGL(bv_gather_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, st, d_off, d_bases, order, noff, U, total,
                                   want_image ? 1 : 0, d_out + header_bytes);
     SNK_HIP_TRY(hipGetLastError());
     *d_out_p = d_out;
