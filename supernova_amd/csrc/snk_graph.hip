@@ -1196,7 +1196,7 @@ __global__ void __launch_bounds__(TB) jchunk_owner_kernel(const uint32_t* __rest
     if (f >= F) return;
     if (choff[f + 1] > choff[f]) owner[choff[f]] = (uint32_t)f;
 }
-// provisional unitig sequences: every fragment copies all of its bases (the K-1 overlaps write equal values).
+// provisional unitig sequences: every fragment copies the bases it alone stands for.
 // Fragments are short (K-1 + ~17 bases): 8 lanes per fragment, 32 fragments per workgroup, no per-chunk owner tables.
 __global__ void __launch_bounds__(256) jemit_kernel(uint64_t F, const uint64_t* __restrict__ boff, const uint8_t* __restrict__ fbases,
                                                     const uint32_t* __restrict__ pl_pid, const unsigned long long* __restrict__ pl_koff,
@@ -1205,11 +1205,15 @@ __global__ void __launch_bounds__(256) jemit_kernel(uint64_t F, const uint64_t* 
     const uint64_t f = (uint64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
     if (f >= F) return;
     const uint32_t sub = threadIdx.x & 7u;
-    const uint32_t len = nk[f] + K - 1;
     const unsigned long long ko = pl_koff[f];
-    const uint8_t* src = fbases + boff[f];
-    uint8_t* dst = prov + poff[pl_pid[f] - pid_base] + (ko & ~PL_RC);
     const bool rc = (ko & PL_RC) != 0;                  // dst[p] = src[len - 1 - p] ^ 3
+    // A fragment's first K-1 bases are the last K-1 of the fragment before it in the unitig: only the unitig's first fragment writes
+    // them (round 4: every fragment copied all K-1 + ~15 of its bases -- 1.1 GB for 0.27 GB of unitigs).  In destination order the bases
+    // that are left are [K-1, len): read forward from src + K-1, or backward from src + len - K (the same first `len` bytes of the code below).
+    const uint32_t skip = (ko & ~PL_RC) == 0 ? 0u : K - 1;
+    const uint32_t len = nk[f] + K - 1 - skip;
+    const uint8_t* src = fbases + boff[f] + (rc ? 0u : skip);
+    uint8_t* dst = prov + poff[pl_pid[f] - pid_base] + (ko & ~PL_RC) + skip;
     // bytes up to the first 4-byte boundary of dst, dwords, the last bytes
     uint32_t head = (4u - (uint32_t)((uintptr_t)dst & 3u)) & 3u;
     if (head > len) head = len;
