@@ -294,8 +294,8 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
         pend_out[gi] = (uint8_t)pm;
         if (sh.premote) sh.premote[gi] = (uint8_t)(res >> 16);
         count_out[gi] = (uint32_t)(v >> 8);
-        nbr_out[2 * gi + 0] = nb0;
-        nbr_out[2 * gi + 1] = nb1;
+        // (chunk-local index << 1 | rev fits 16 bits -- a chunk holds at most 1280 k-mers --: one word per k-mer for both sides, 0xFFFF = none)
+        nbr_out[gi] = (nb0 == NONE ? 0xFFFFu : nb0) | ((nb1 == NONE ? 0xFFFFu : nb1) << 16);
         if (pm) {
             ++mybnd;
             if (gindex) {
@@ -500,7 +500,7 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
         constexpr int NPT = (CAP + T - 1) / T;
         snk_kmer kq[NPT];
         uint32_t cq[NPT], pq[NPT];
-        uint2 nq[NPT];
+        uint32_t nq[NPT];
 #pragma unroll
         for (int q = 0; q < NPT; ++q) {
             const uint32_t i = tid + q * T;
@@ -509,7 +509,7 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
                 kq[q] = load_key(keys, gi);
                 cq[q] = ctx[gi];
                 pq[q] = pend[gi];
-                nq[q] = *reinterpret_cast<const uint2*>(nbr + 2 * gi);
+                nq[q] = nbr[gi];
             }
         }
 #pragma unroll
@@ -524,8 +524,8 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
                 palL[i] = snk_kmer_eq(kb, snk_kmer_rc<K>(kb)) ? 1 : 0;
                 ctxL[i] = (uint8_t)cq[q];
                 pendL[i] = (uint8_t)pq[q];
-                nbL[2 * i] = nq[q].x == NONE ? NONE16 : (uint16_t)nq[q].x;
-                nbL[2 * i + 1] = nq[q].y == NONE ? NONE16 : (uint16_t)nq[q].y;
+                nbL[2 * i] = (uint16_t)nq[q];                     // (0xFFFF == NONE16)
+                nbL[2 * i + 1] = (uint16_t)(nq[q] >> 16);
             }
         }
     }
@@ -884,7 +884,7 @@ static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* er
     G_ALLOC(B->ctx, uint8_t, n + 16);
     G_ALLOC(B->pend, uint8_t, n + 16);
     G_ALLOC(B->counts, uint32_t, n + 4);
-    G_ALLOC(B->nbr, uint32_t, 2 * n + 2);
+    G_ALLOC(B->nbr, uint32_t, n + 2);
     G_ALLOC(B->rq, uint32_t, 2 * n + 2);
     G_ALLOC(nbnd, uint32_t, (uint64_t)nchunks + 1);
     G_ALLOC(B->biglist, uint32_t, n / SCAP + 2);
