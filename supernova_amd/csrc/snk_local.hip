@@ -294,8 +294,9 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
         pend_out[gi] = (uint8_t)pm;
         if (sh.premote) sh.premote[gi] = (uint8_t)(res >> 16);
         count_out[gi] = (uint32_t)(v >> 8);
-        // (chunk-local index << 1 | rev fits 16 bits -- a chunk holds at most 1280 k-mers --: one word per k-mer for both sides, 0xFFFF = none)
-        nbr_out[gi] = (nb0 == NONE ? 0xFFFFu : nb0) | ((nb1 == NONE ? 0xFFFFu : nb1) << 16);
+        // (chunk-local index << 1 | rev fits 12 bits -- a chunk holds at most 1280 k-mers --: one word per k-mer for both sides, 0xFFF = none;
+        // bit 15: the k-mer is its own reverse complement -- the fragment kernel's sizing pass then needs no keys at all)
+        nbr_out[gi] = (nb0 == NONE ? 0x0FFFu : nb0) | (snk_kmer_eq(k, kr) ? 0x8000u : 0u) | ((nb1 == NONE ? 0x0FFFu : nb1) << 16);
         if (pm) {
             ++mybnd;
             if (gindex) {
@@ -506,7 +507,7 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
             const uint32_t i = tid + q * T;
             if (i < n) {
                 const uint64_t gi = ch.base + i;
-                kq[q] = load_key(keys, gi);
+                if (EMIT) kq[q] = load_key(keys, gi);          // (the sizing pass decides links from contexts, pending bits and the neighbour word alone)
                 cq[q] = ctx[gi];
                 pq[q] = pend[gi];
                 nq[q] = nbr[gi];
@@ -516,16 +517,17 @@ __global__ void __launch_bounds__(T) bl_frag_kernel(const uint4* __restrict__ de
         for (int q = 0; q < NPT; ++q) {
             const uint32_t i = tid + q * T;
             if (i < n) {
-                const snk_kmer k = kq[q];
-                khi[i] = k.hi;
-                klo[i] = (klo_w)(k.lo >> KLS);
-                snk_kmer kb = k;
-                if (GR) kb.lo &= ~0xFFFFFFFFull;               // the group id is not part of the sequence
-                palL[i] = snk_kmer_eq(kb, snk_kmer_rc<K>(kb)) ? 1 : 0;
+                if (EMIT) {
+                    const snk_kmer k = kq[q];
+                    khi[i] = k.hi;
+                    klo[i] = (klo_w)(k.lo >> KLS);
+                }
+                palL[i] = (uint8_t)((nq[q] >> 15) & 1u);          // (noted by the prune, which has the reverse complement at hand)
                 ctxL[i] = (uint8_t)cq[q];
                 pendL[i] = (uint8_t)pq[q];
-                nbL[2 * i] = (uint16_t)nq[q];                     // (0xFFFF == NONE16)
-                nbL[2 * i + 1] = (uint16_t)(nq[q] >> 16);
+                const uint32_t a0 = nq[q] & 0x0FFFu, a1 = (nq[q] >> 16) & 0x0FFFu;
+                nbL[2 * i] = a0 == 0x0FFFu ? NONE16 : (uint16_t)a0;
+                nbL[2 * i + 1] = a1 == 0x0FFFu ? NONE16 : (uint16_t)a1;
             }
         }
     }
