@@ -51,7 +51,8 @@ typedef struct snk_params {
     uint32_t K;            /* 48 or 60 */
     uint32_t min_qual;     /* 7 */
     uint32_t min_freq;     /* 3 */
-    uint32_t min_bc;       /* 0,1,2 (2 = reference default; >2 is SNK_E_UNSUPPORTED on device) */
+    uint32_t min_bc;       /* 0..8 distinct barcodes a k-mer needs (2 = reference default; the count kernel tells up to eight apart
+                              per k-mer in LDS: > 8 is SNK_E_UNSUPPORTED) */
     uint32_t n_buckets;    /* 0 = choose from the k-mer instance count */
     uint32_t flags;        /* SNK_F_* */
 } snk_params;
