@@ -1269,12 +1269,14 @@ __global__ void __launch_bounds__(TB) jcirc_list_kernel(const uint8_t* __restric
 // starts at its minimum canonical k-mer read forward.  Candidates: the k-mer at ring position j on strand 0, and its
 // reverse complement, which sits at position (N-K-j) mod N of the reverse-complemented ring.
 template <int K>
-__global__ void __launch_bounds__(256) jcircle_kernel(const uint32_t* __restrict__ clist, const uint64_t* __restrict__ uoff,
-                                                      uint8_t* __restrict__ prov, uint8_t* __restrict__ tmp) {
+__global__ void __launch_bounds__(256) jcircle_kernel(const uint32_t* __restrict__ clist, const uint32_t* __restrict__ ccnt,
+                                                      const uint64_t* __restrict__ uoff, uint8_t* __restrict__ prov, uint8_t* __restrict__ tmp) {
     __shared__ uint64_t bhi[256], blo[256];
     __shared__ uint32_t bpos[256];      // rotation << 1 | strand
     __shared__ uint32_t win;
-    const uint32_t u = clist[blockIdx.x];
+    const uint32_t n_circ = *ccnt;      // the list's length stays on the device: the workgroups stride over it (no read-back for the grid)
+    for (uint32_t c = blockIdx.x; c < n_circ; c += gridDim.x) {
+    const uint32_t u = clist[c];
     const uint64_t o = uoff[u];
     const uint64_t len = uoff[u + 1] - o;
     const uint64_t N = len - (K - 1);
@@ -1319,6 +1321,8 @@ __global__ void __launch_bounds__(256) jcircle_kernel(const uint32_t* __restrict
     __threadfence_block();
     __syncthreads();
     for (uint64_t p = tid; p < len; p += 256) ring[p] = t[p];
+    __syncthreads();
+    }
 }
 
 // deterministic output order: unitigs sorted by their first K bases (every k-mer belongs to exactly one unitig)
@@ -1375,15 +1379,23 @@ static int excl_scan(snk_ctx* ctx, hipStream_t st, const T* in, T* out, size_t c
     return SNK_OK;
 }
 // owner of every chunk from per-owner chunk counts: scatter the owner id at its first chunk, then max-scan
+// total_ub != 0: an upper bound of the chunk count the caller knows without asking the device (sum of ceil(len / JCH) <= sum(len) / JCH
+// + count): the tables are sized and the copy kernels launched for it -- no read-back; the owner of an item past the true total is the
+// last owner, whose item then lies past its length, so the copy kernels' bound check drops it.
 static int chunk_owners(snk_ctx* ctx, hipStream_t st, uint32_t* nch /*[count+1], last = 0*/, uint64_t count, uint32_t** choff_out,
-                        uint32_t** owner_out, uint32_t* total_out, char* err, size_t errcap) {
+                        uint32_t** owner_out, uint32_t* total_out, char* err, size_t errcap, uint64_t total_ub = 0) {
     uint32_t* choff;
     G_ALLOC(choff, uint32_t, count + 1);
     int rc = excl_scan<uint32_t>(ctx, st, nch, choff, count + 1, err, errcap);
     if (rc) return rc;
     uint32_t total = 0;
-    SNK_HIP_TRY(hipMemcpyAsync(&total, choff + count, 4, hipMemcpyDeviceToHost, st));
-    SNK_HIP_TRY(snk_sync(st));
+    if (total_ub) {
+        if (total_ub > 0xFFFFFFF0ull) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "join: %llu copy chunks", (unsigned long long)total_ub);
+        total = (uint32_t)total_ub;
+    } else {
+        SNK_HIP_TRY(hipMemcpyAsync(&total, choff + count, 4, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(snk_sync(st));
+    }
     uint32_t* owner;
     G_ALLOC(owner, uint32_t, (uint64_t)total + 1);
     SNK_HIP_TRY(hipMemsetAsync(owner, 0, ((uint64_t)total + 1) * 4, st));
@@ -1513,6 +1525,8 @@ int snk_join_emit(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
     SNK_HIP_TRY(hipMemcpyAsync(&h_tot, hoff + F, 8, hipMemcpyDeviceToHost, st));
     SNK_HIP_TRY(snk_sync(st));
     const uint64_t U = h_nu;
+    const uint64_t chunks_ub = U ? h_tot / JCH + U : 0;      // both copy passes: every unitig's ceil(len / JCH), in either order
+    uint32_t h_nc = 0;
     uint64_t *poff, *uoff;
     uint8_t *ucirc, *prov, *final_bases, *urev;
     G_ALLOC(poff, uint64_t, n_pid + 1);
@@ -1534,21 +1548,19 @@ int snk_join_emit(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
         G_ALLOC(ccnt, uint32_t, 4);
         SNK_HIP_TRY(hipMemsetAsync(ccnt, 0, 4, st));
         hipLaunchKernelGGL(jcirc_list_kernel, dim3(nblk(U)), dim3(TB), 0, st, ucirc, U, clist, ccnt);
-        uint32_t h_nc = 0;
-        SNK_HIP_TRY(hipMemcpyAsync(&h_nc, ccnt, 4, hipMemcpyDeviceToHost, st));
-        SNK_HIP_TRY(snk_sync(st));
-        if (h_nc) {
-            if (K == 48) hipLaunchKernelGGL((jcircle_kernel<48>), dim3(h_nc), dim3(256), 0, st, clist, uoff, prov, final_bases);
-            else hipLaunchKernelGGL((jcircle_kernel<60>), dim3(h_nc), dim3(256), 0, st, clist, uoff, prov, final_bases);
+        SNK_HIP_TRY(hipMemcpyAsync(&h_nc, ccnt, 4, hipMemcpyDeviceToHost, st));      // read at the function's one closing wait
+        if (U) {
+            const unsigned cg = (unsigned)(U < 1024 ? U : 1024);
+            if (K == 48) hipLaunchKernelGGL((jcircle_kernel<48>), dim3(cg), dim3(256), 0, st, clist, ccnt, uoff, prov, final_bases);
+            else hipLaunchKernelGGL((jcircle_kernel<60>), dim3(cg), dim3(256), 0, st, clist, ccnt, uoff, prov, final_bases);
         }
-        out->n_circles_rotated = h_nc;
     }
     hipLaunchKernelGGL(jform_kernel, dim3(nblk(U)), dim3(TB), 0, st, uoff, U, prov, urev);
     uint32_t *unch, *uchoff, *uowner, utotal = 0;
     G_ALLOC(unch, uint32_t, U + 1);
     SNK_HIP_TRY(hipMemsetAsync(unch + U, 0, 4, st));
     hipLaunchKernelGGL(jchunks_kernel, dim3(nblk(U)), dim3(TB), 0, st, uoff, U, unch);
-    if ((rc = chunk_owners(ctx, st, unch, U, &uchoff, &uowner, &utotal, err, errcap))) return rc;
+    if ((rc = chunk_owners(ctx, st, unch, U, &uchoff, &uowner, &utotal, err, errcap, chunks_ub))) return rc;
     if (utotal) hipLaunchKernelGGL(jfinal_kernel, dim3(utotal), dim3(256), 0, st, uoff, uowner, uchoff, urev, prov, final_bases);
     SNK_HIP_TRY(hipGetLastError());
     // deterministic order (fragment ids depend on the order in which workgroups reserved their output)
@@ -1584,11 +1596,12 @@ int snk_join_emit(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
         G_ALLOC(onch, uint32_t, U + 1);
         SNK_HIP_TRY(hipMemsetAsync(onch + U, 0, 4, st));
         hipLaunchKernelGGL(jchunks_kernel, dim3(nblk(U)), dim3(TB), 0, st, noff, U, onch);
-        if ((rc = chunk_owners(ctx, st, onch, U, &ochoff, &oowner, &ototal, err, errcap))) return rc;
+        if ((rc = chunk_owners(ctx, st, onch, U, &ochoff, &oowner, &ototal, err, errcap, chunks_ub))) return rc;
         if (ototal) hipLaunchKernelGGL(jorder_copy_kernel, dim3(ototal), dim3(256), 0, st, oowner, ochoff, noff, uoff, oi_out, final_bases, ucirc, obases, ocirc, (const uint32_t*)ugroup, ogroup);
         SNK_HIP_TRY(hipGetLastError());
     }
     SNK_HIP_TRY(snk_sync(st));
+    out->n_circles_rotated = h_nc;
     out->n_unitigs = U;
     out->total_bases = h_tot;
     out->unitig_off = noff;
