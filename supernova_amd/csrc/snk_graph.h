@@ -56,7 +56,7 @@ struct snk_join_out {
     uint8_t* unitig_bases;
     uint8_t* unitig_circular;   // 1: a circle that spanned fragments (already rotated to the reference's cut)
     uint32_t* unitig_group;     // grouped runs (fgroup given): group of every unitig; unitigs ordered by (group, first K bases)
-    uint32_t n_circles, rank_rounds, n_circles_rotated;
+    uint32_t n_circles, rank_rounds;
 };
 // placement of fragments inside their unitigs (snk_graph.hip: jplace_kernel), device arrays
 struct snk_placement {

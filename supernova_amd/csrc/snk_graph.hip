@@ -1526,7 +1526,6 @@ int snk_join_emit(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
     SNK_HIP_TRY(snk_sync(st));
     const uint64_t U = h_nu;
     const uint64_t chunks_ub = U ? h_tot / JCH + U : 0;      // both copy passes: every unitig's ceil(len / JCH), in either order
-    uint32_t h_nc = 0;
     uint64_t *poff, *uoff;
     uint8_t *ucirc, *prov, *final_bases, *urev;
     G_ALLOC(poff, uint64_t, n_pid + 1);
@@ -1548,7 +1547,6 @@ int snk_join_emit(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
         G_ALLOC(ccnt, uint32_t, 4);
         SNK_HIP_TRY(hipMemsetAsync(ccnt, 0, 4, st));
         hipLaunchKernelGGL(jcirc_list_kernel, dim3(nblk(U)), dim3(TB), 0, st, ucirc, U, clist, ccnt);
-        SNK_HIP_TRY(hipMemcpyAsync(&h_nc, ccnt, 4, hipMemcpyDeviceToHost, st));      // read at the function's one closing wait
         if (U) {
             const unsigned cg = (unsigned)(U < 1024 ? U : 1024);
             if (K == 48) hipLaunchKernelGGL((jcircle_kernel<48>), dim3(cg), dim3(256), 0, st, clist, ccnt, uoff, prov, final_bases);
@@ -1600,8 +1598,7 @@ int snk_join_emit(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
         if (ototal) hipLaunchKernelGGL(jorder_copy_kernel, dim3(ototal), dim3(256), 0, st, oowner, ochoff, noff, uoff, oi_out, final_bases, ucirc, obases, ocirc, (const uint32_t*)ugroup, ogroup);
         SNK_HIP_TRY(hipGetLastError());
     }
-    SNK_HIP_TRY(snk_sync(st));
-    out->n_circles_rotated = h_nc;
+    // nothing is waited for here: the unitigs are stream-ordered results, the step's closing wait is the caller's
     out->n_unitigs = U;
     out->total_bases = h_tot;
     out->unitig_off = noff;
