@@ -21,7 +21,7 @@ for name in want:
         r = eng.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48, sorted_table=False, graph=graph))
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) * 1e3
-        if rep in (0, 3):
+        if rep in (0, 1, 3):
             print(f"{name} call {rep}: {dt:.1f} ms | " + " ".join(f"{k} {v:.1f}" for k, v in r.phase_ms.items() if k in ("partition", "count", "graph")) +
-                  f" | buckets {r.n_buckets} split {r.buckets_split} kmers {r.n_kmers} unitigs {r.n_unitigs} max_slots {r.max_slots_used}", flush=True)
+                  f" | supermers {r.n_supermers} repartitioned {r.repartitioned} buckets {r.n_buckets} split {r.buckets_split} kmers {r.n_kmers} unitigs {r.n_unitigs} max_slots {r.max_slots_used}", flush=True)
     del rows, quals, bc, r
