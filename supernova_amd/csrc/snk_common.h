@@ -177,17 +177,23 @@ SNK_HD uint32_t snk_bucket_of_key(uint32_t key, uint32_t NB) {
 // the 32 low bits of the 128-bit key (free at K=48) and is folded into the bucket choice
 SNK_HD uint32_t snk_group_mix(uint32_t group) { return snk_mix32(group * 0x9E3779B1u + 0x7F4A7C15u); }
 // bucket of a k-mer = bucket of the minimum ordering key over its K-15 16-mers (strand symmetric)
-template <int K>
+// ordering key of the M-mer in the top 2M bits of v (the bases from some position of a k-mer on, left-aligned)
+template <int M>
+SNK_HD uint32_t snk_mmer_key_top(uint64_t v) {
+    const uint32_t x = (uint32_t)(v >> (64 - 2 * M));                  // the M bases as a number
+    const uint32_t rx = snk_rev2_32(~(x << (32 - 2 * M))) & (M == 16 ? 0xFFFFFFFFu : ((1u << (2 * (M & 15))) - 1u));   // ... and their reverse complement
+    return snk_minimizer_key(x, rx);
+}
+template <int K, int M>
 SNK_HD uint32_t snk_bucket_of_kmer(snk_kmer k, uint32_t NB) {
     uint32_t best = 0xFFFFFFFFu;
-    for (int p = 0; p + 16 <= K; ++p) {
+    for (int p = 0; p + M <= K; ++p) {
         uint64_t v;
         if (p == 0) v = k.hi;
         else if (p < 32) v = (k.hi << (2 * p)) | (k.lo >> (64 - 2 * p));
         else if (p == 32) v = k.lo;
         else v = k.lo << (2 * p - 64);
-        uint32_t x = (uint32_t)(v >> 32);
-        uint32_t key = snk_minimizer_key(x, snk_rev2_32(~x));
+        uint32_t key = snk_mmer_key_top<M>(v);
         best = key < best ? key : best;
     }
     return snk_bucket_of_key(best, NB);

@@ -5,7 +5,14 @@
 
 #include "snk_common.h"
 
-#define SNK_M 16  // minimiser length (bases)
+// minimiser length (bases), by K.  A random-order minimiser starts a supermer every (K - M + 2) / 2 k-mers: the shorter the M-mer the fewer
+// supermers -- slot reservations, records -- a read is cut into.  A record holds 107 bases (6 words + 23 bits): K=60 (two flanks + 59 + the
+// k-mers of a supermer) has room for M=16 only.  SNK_M48: tuning builds (tools/build_variant.sh).
+#ifndef SNK_M48
+#define SNK_M48 16
+#endif
+#define SNK_M_OF(K) ((K) == 48 ? SNK_M48 : 16)
+static_assert(SNK_M48 >= 11 && SNK_M48 <= 16, "the M-mer is rolled in one 32-bit word; 4^M values must cover the buckets");
 
 typedef unsigned __int128 snk_u128;
 

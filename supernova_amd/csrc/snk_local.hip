@@ -227,7 +227,8 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
         }
         __syncthreads();
         const uint32_t nm = mcnt;
-        constexpr int SH = K - SNK_M;            // shared M-mers of a k-mer and its neighbour
+        constexpr int MM = SNK_M_OF(K);
+        constexpr int SH = K - MM;               // shared M-mers of a k-mer and its neighbour
         constexpr int PER = (SH + 3) / 4;
         for (uint32_t it0 = 0; it0 < nm; it0 += T / 4) {
             const uint32_t item = it0 + (tid >> 2), sub = tid & 3u;
@@ -251,8 +252,7 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
                     else if (pp < 32) w = (kk.hi << (2 * pp)) | (kk.lo >> (64 - 2 * pp));
                     else if (pp == 32) w = kk.lo;
                     else w = kk.lo << (2 * pp - 64);
-                    const uint32_t x = (uint32_t)(w >> 32);
-                    const uint32_t key = snk_minimizer_key(x, snk_rev2_32(~x));
+                    const uint32_t key = snk_mmer_key_top<MM>(w);
                     mk = key < mk ? key : mk;
                 }
             }
@@ -260,13 +260,12 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
             { const uint32_t o = __shfl_xor(mk, 2); mk = o < mk ? o : mk; }
             if (on && sub == 0) {
                 const snk_kmer y = bit < 4 ? snk_kmer_succ<K>(kk, bit) : snk_kmer_pred<K>(kk, bit - 4);
-                uint32_t x;      // the one M-mer of the neighbour that k does not have
+                uint64_t wn;     // the one M-mer of the neighbour that k does not have (left-aligned)
                 if (bit < 4) {
-                    constexpr int pl = K - SNK_M;
-                    const uint64_t w = pl < 32 ? ((y.hi << (2 * pl)) | (y.lo >> (64 - 2 * pl))) : (pl == 32 ? y.lo : (y.lo << (2 * pl - 64)));
-                    x = (uint32_t)(w >> 32);
-                } else x = (uint32_t)(y.hi >> 32);
-                const uint32_t nkey = snk_minimizer_key(x, snk_rev2_32(~x));
+                    constexpr int pl = K - MM;
+                    wn = pl < 32 ? ((y.hi << (2 * pl)) | (y.lo >> (64 - 2 * pl))) : (pl == 32 ? y.lo : (y.lo << (2 * pl - 64)));
+                } else wn = y.hi;
+                const uint32_t nkey = snk_mmer_key_top<MM>(wn);
                 if (nkey < mk) mk = nkey;
                 const uint32_t gb = snk_bucket_of_key(mk ^ (GR ? snk_group_mix((uint32_t)ktag) : 0u), NB);   // (global) bucket of the neighbour
                 bool here = gb == sh.bucket_base + ch.bucket;
@@ -832,7 +831,7 @@ __global__ void __launch_bounds__(TB) bl_query_kernel(const snk_u128* __restrict
         for (uint32_t rem = premote[i]; rem; rem &= rem - 1) {
             const uint32_t bit = __ffs(rem) - 1;
             const snk_kmer y = bit < 4 ? snk_kmer_succ<K>(k, bit) : snk_kmer_pred<K>(k, bit - 4);
-            const uint32_t owner = snk_bucket_of_kmer<K>(y, NB_total) / NBl;
+            const uint32_t owner = snk_bucket_of_kmer<K, SNK_M_OF(K)>(y, NB_total) / NBl;
             atomicAdd(&dynq[owner], 1ull);
         }
     }
@@ -850,7 +849,7 @@ __global__ void __launch_bounds__(TB) bl_query_kernel(const snk_u128* __restrict
         for (uint32_t rem = premote[i]; rem; rem &= rem - 1) {
             const uint32_t bit = __ffs(rem) - 1;
             const snk_kmer y = bit < 4 ? snk_kmer_succ<K>(k, bit) : snk_kmer_pred<K>(k, bit - 4);
-            const uint32_t owner = snk_bucket_of_kmer<K>(y, NB_total) / NBl;
+            const uint32_t owner = snk_bucket_of_kmer<K, SNK_M_OF(K)>(y, NB_total) / NBl;
             const snk_kmer r = snk_kmer_rc<K>(y);
             const bool rev = snk_kmer_lt(r, y);
             const snk_kmer c = rev ? r : y;

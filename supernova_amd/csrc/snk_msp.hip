@@ -6,7 +6,7 @@
 //   shardio write path          lib/tada/external/rust-shardio/src/shard.rs:184-211 (group by shard)
 //   and, for path B, the hash->(pass,bin) map of MapReduceEngine.h:315-326.
 // Shard assignment is internal to the reference (App. A.10): counts and unitigs do not depend on it.
-// This build uses M=16-mers ordered by a 32-bit hash of the canonical M-mer (strand symmetric, so a
+// This build uses M-mers (SNK_M_OF(K), snk_kernels.h) ordered by a 32-bit hash of the canonical M-mer (strand symmetric, so a
 // k-mer and its reverse complement always land in the same bucket -- the invariant of
 // check_consistent_shard, lib/tada/src/kmer/mod.rs:1102-1150).
 //
@@ -382,7 +382,8 @@ __global__ void __launch_bounds__(BD, K == 48 ? SNK_MSP_OCC48 : 4) snk_msp_kerne
     // at a time; all lanes are at the same position, so the refill is a uniform branch).  kk[t] (registers, static
     // indices -- both passes are fully unrolled) holds the raw keys of the next block after a forward pass and that
     // block's suffix-minimum keys after its suffix pass.
-    static_assert(M == 16, "the rolling window below is one 32-bit word");
+    static_assert(M >= 8 && M <= 16, "the rolling window below is one 32-bit word");
+    constexpr uint32_t MMASK = M == 16 ? 0xFFFFFFFFu : ((1u << (2 * (M & 15))) - 1u);
     uint32_t kk[W];
     uint32_t x = 0, rx = 0, cw = 0;
     int rp = 0;                                  // position of x
@@ -391,14 +392,15 @@ __global__ void __launch_bounds__(BD, K == 48 ? SNK_MSP_OCC48 : 4) snk_msp_kerne
         if ((nb & 15) == 0) { const uint32_t wi = (uint32_t)nb >> 4; cw = wi < row_words ? rowL[wi * BD + tid] : 0u; }
         const uint32_t base = cw >> 30;
         cw <<= 2;
-        x = (x << 2) | base;
-        rx = (rx >> 2) | ((base ^ 3u) << 30);
+        x = ((x << 2) | base) & MMASK;
+        rx = (rx >> 2) | ((base ^ 3u) << (2 * M - 2));
         ++rp;
     };
     if (maxblocks > 0) {
-        x = rowL[tid];
-        rx = snk_rev2_32(~x);
-        cw = row_words > 1 ? rowL[BD + tid] : 0u;
+        const uint32_t w0 = rowL[tid];
+        x = w0 >> (32 - 2 * M);                  // the first M bases as a number,
+        rx = snk_rev2_32(~w0) & MMASK;           // their reverse complement,
+        cw = M == 16 ? (row_words > 1 ? rowL[BD + tid] : 0u) : (w0 << (2 * (M & 15)));      // and the bases that follow, next one on top
 #pragma unroll
         for (int t = 0; t < W; ++t) {            // raw keys of block 0
             kk[t] = (t < npos) ? snk_minimizer_key(x, rx) : 0xFFFFFFFFu;
@@ -560,8 +562,8 @@ static int launch_msp_k(hipStream_t st, const snk_msp_args& a, char* err, size_t
 int snk_launch_msp(uint32_t K, hipStream_t st, const snk_msp_args& a, char* err, size_t errcap) {
     if (a.n_reads == 0) return SNK_OK;
     if (a.row_words > 16) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "reads longer than 256 bases are not supported (row_words=%u)", a.row_words);
-    if (K == 48) return launch_msp_k<48, SNK_M>(st, a, err, errcap);
-    if (K == 60) return launch_msp_k<60, SNK_M>(st, a, err, errcap);
+    if (K == 48) return launch_msp_k<48, SNK_M_OF(48)>(st, a, err, errcap);
+    if (K == 60) return launch_msp_k<60, SNK_M_OF(60)>(st, a, err, errcap);
     return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "K=%u is not supported (48 or 60)", K);
 }
 

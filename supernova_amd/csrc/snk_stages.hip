@@ -415,7 +415,7 @@ bool snk_fused_trim_ok(const snk_dev_reads* in) {
 // expected supermers of a pass and the record slots a bucket gets
 static void partition_capacity(snk_ctx* ctx, uint32_t K, uint32_t NB, unsigned long long n_inst, unsigned long long n_live, bool grouped, double* est_super_out,
                                uint64_t* cap_out) {
-    const uint32_t Wm = K - SNK_M + 1;
+    const uint32_t Wm = K - SNK_M_OF(K) + 1;
     // a random-order minimiser starts a new supermer every (W+1)/2 k-mers, and every contributing read starts one
     const double est_super = (double)n_inst * 2.0 / (Wm + 1) + (double)n_live;
     const double mean = est_super / NB;
