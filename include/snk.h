@@ -67,6 +67,9 @@ typedef struct snk_params {
                                   NULL, n_kmers is still reported) -- callers at the .bv seam only need the unitigs */
 #define SNK_F_BV_IMAGE 32u      /* snk_count_graph (host pointers): return the unitigs as the bytes of the .bv hand-off file
                                    (snk_result.bv_image, packed on the device) instead of unitig_off / unitig_bases */
+#define SNK_F_LONG_MINIMISER 64u /* minimisers of 20 bases instead of 16: for genomes whose minimiser sites outnumber the 2.1 G canonical 16-mers
+                                   (human: 3.1 G) -- sites that share a minimiser share a bucket, and at 1-2 sites per value the step loses
+                                   5-25 %.  11 % more supermers: slower on small genomes.  Same results, bit for bit. */
 #define SNK_F_GLOBAL_GRAPH 4u   /* use the global graph stage (sort + HBM index + list ranking over all k-mers) instead
                                   of the bucket-local one; same results, kept as a cross-check */
 

@@ -117,7 +117,7 @@ int main(int argc, char** argv) {
     const int n_in = (int)kv.count("FASTH") + (int)kv.count("LR") + (int)kv.count("SYNTH");
     if (n_in != 1 || (rank == 0 && !kv.count("OUT"))) {
         fprintf(stderr, "usage: snk_asm_sn [WORLD=n RANK=r ID_FILE=<path> JOB_ID=<nonce>] (FASTH=<files> WHITELIST=<txt> | LR=<reads.fastb> | SYNTH=<reads> [SEED=s]) OUT=<asm_graph.bv> "
-                        "[K=48] [MIN_QUAL=7] [MIN_FREQ=3] [MIN_BC=2] [BC_START=n] [DEVICE=d] [STEPS=k] [STATS=<file>]\n");
+                        "[K=48] [MIN_QUAL=7] [MIN_FREQ=3] [MIN_BC=2] [LONG_MINIMISER=1] [BC_START=n] [DEVICE=d] [STEPS=k] [STATS=<file>]\n");
         return 1;
     }
     char err[512] = "";
@@ -134,6 +134,7 @@ int main(int argc, char** argv) {
     p.K = (uint32_t)atoi(kv["K"].c_str());
     p.min_qual = (uint32_t)atoi(kv["MIN_QUAL"].c_str());
     p.min_freq = (uint32_t)atoi(kv["MIN_FREQ"].c_str());
+    if (kv.count("LONG_MINIMISER") && atoi(kv["LONG_MINIMISER"].c_str())) p.flags |= SNK_F_LONG_MINIMISER;      // genomes of human size (snk.h)
     p.min_bc = (uint32_t)atoi(kv["MIN_BC"].c_str());
 
     // ---- this rank's slab of reads, resident in HBM

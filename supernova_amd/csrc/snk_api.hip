@@ -8,9 +8,17 @@
 #include <algorithm>
 
 #include "snk_ctx.h"
+#include "snk_kernels.h"
 #include "snk_synth.h"
 
 static thread_local char g_last_error[512] = "";
+
+void snk_set_mlen(snk_ctx* ctx, const snk_params* p) {
+    uint32_t m = (p->flags & SNK_F_LONG_MINIMISER) ? (uint32_t)SNK_M_LONG : (uint32_t)SNK_M_OF(p->K);
+    const char* e = getenv("SNK_MINIMISER_LEN");
+    if (e && *e) { const long v = strtol(e, nullptr, 10); if (v == SNK_M_LONG || v == SNK_M_OF(p->K)) m = (uint32_t)v; }
+    ctx->mlen = m;
+}
 
 void snk_set_error(char* err, size_t errcap, const char* fmt, ...) {
     va_list ap;

@@ -177,12 +177,26 @@ SNK_HD uint32_t snk_bucket_of_key(uint32_t key, uint32_t NB) {
 // the 32 low bits of the 128-bit key (free at K=48) and is folded into the bucket choice
 SNK_HD uint32_t snk_group_mix(uint32_t group) { return snk_mix32(group * 0x9E3779B1u + 0x7F4A7C15u); }
 // bucket of a k-mer = bucket of the minimum ordering key over its K-15 16-mers (strand symmetric)
+// M-mers longer than 16 bases: codes are 64-bit, the ordering key stays a 32-bit hash of the canonical one
+SNK_HD uint64_t snk_rev2_64(uint64_t x) { return ((uint64_t)snk_rev2_32((uint32_t)x) << 32) | snk_rev2_32((uint32_t)(x >> 32)); }
+SNK_HD uint32_t snk_minimizer_key64(uint64_t code, uint64_t rcode) {
+    const uint64_t c = code < rcode ? code : rcode;
+    return snk_mix32((uint32_t)c ^ ((uint32_t)(c >> 32) * 0x9E3779B1u + 0x7F4A7C15u));
+}
 // ordering key of the M-mer in the top 2M bits of v (the bases from some position of a k-mer on, left-aligned)
 template <int M>
 SNK_HD uint32_t snk_mmer_key_top(uint64_t v) {
-    const uint32_t x = (uint32_t)(v >> (64 - 2 * M));                  // the M bases as a number
-    const uint32_t rx = snk_rev2_32(~(x << (32 - 2 * M))) & (M == 16 ? 0xFFFFFFFFu : ((1u << (2 * (M & 15))) - 1u));   // ... and their reverse complement
-    return snk_minimizer_key(x, rx);
+    if constexpr (M <= 16) {
+        const uint32_t x = (uint32_t)(v >> (64 - 2 * M));                  // the M bases as a number
+        const uint32_t rx = snk_rev2_32(~(x << (32 - 2 * M))) & (M == 16 ? 0xFFFFFFFFu : ((1u << (2 * (M & 15))) - 1u));   // ... and their reverse complement
+        return snk_minimizer_key(x, rx);
+    } else {
+        static_assert(M <= 32, "the M-mer is held in one 64-bit word");
+        const uint64_t top = v & ~((1ull << (64 - 2 * M)) - 1ull);
+        const uint64_t x = top >> (64 - 2 * M);
+        const uint64_t rx = snk_rev2_64(~top) & ((1ull << (2 * M)) - 1ull);
+        return snk_minimizer_key64(x, rx);
+    }
 }
 template <int K, int M>
 SNK_HD uint32_t snk_bucket_of_kmer(snk_kmer k, uint32_t NB) {

@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     constexpr int BATCH = (K == 48 && !GROUPED && SLOTS >= 2048) ? 512 : 256;
     constexpr int DD = 2 * BATCH;                        // de-duplication table slots
     typedef typename klo_t<K, GROUPED>::type lo_type;
-    constexpr int WMAX = K - SNK_M_OF(K) + 1;                  // k-mers per supermer, at most
+    constexpr int WMAX = K - SNK_M_MIN_OF(K) + 1;                  // k-mers per supermer, at most
     constexpr int NCI = BATCH * WMAX / 32 + 2;           // coarse instance index: one entry per 32 k-mer instances
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint64_t* khi = reinterpret_cast<uint64_t*>(smem_raw);                         // [SLOTS]
@@ -606,7 +606,7 @@ template <> struct cfg<60> { static constexpr int THREADS = SNK_COUNT_THREADS; s
 
 template <int K, bool G>
 size_t lds_bytes(uint32_t bc_mode = 0) {
-    constexpr size_t S = cfg<K>::SLOTS, B = (K == 48 && !G && S >= 2048) ? 512 : 256, DD = 2 * B, NCI = B * (K - SNK_M_OF(K) + 1) / 32 + 2;
+    constexpr size_t S = cfg<K>::SLOTS, B = (K == 48 && !G && S >= 2048) ? 512 : 256, DD = 2 * B, NCI = B * (K - SNK_M_MIN_OF(K) + 1) / 32 + 2;
     return S * (8 + sizeof(typename klo_t<K, G>::type) + 4 + 4 + 4) + S + 4 * (8 * B + 64 + DD + B) + 2 * (B + B + 2 + NCI) + 16 + 2 * 4 * 3 * SNK_COUNT_MAXSEG + 2 * (S - cfg<K>::THREADS - 64) + 16 + (bc_mode > 2 ? S * 24 + 16 : 0);
 }
 

@@ -52,7 +52,8 @@ struct snk_ctx {
     double retain_ratio = 0.0;                         // retained k-mers per k-mer instance of the last call (same key as claim_ratio)
     double claim_ratio = 0.0;                          // distinct k-mers per k-mer instance the count kernel saw in the last call ...
     uint64_t claim_ratio_reads = 0;                    // ... over this many reads ...
-    uint32_t claim_ratio_k = 0;                        // ... in this mode (2 K + grouped)
+    uint32_t claim_ratio_k = 0;                        // ... in this mode (2 K + grouped + 256 x minimiser length)
+    uint32_t mlen = 16;                                // minimiser length of the top-level call at hand (snk_set_mlen)
     uint32_t last_extra = 0;                           // split sub-passes the previous call recorded
     std::vector<unsigned long long> h_region_off;      // host copy of the count regions' dense offsets (source of an async upload)
     void* shard = nullptr;      // snk_shard_state (snk_dist.hip)
@@ -65,6 +66,7 @@ struct snk_ctx {
 };
 
 void snk_set_error(char* err, size_t errcap, const char* fmt, ...);
+void snk_set_mlen(snk_ctx* ctx, const snk_params* p);      // ctx->mlen from the call's K and flags (SNK_MINIMISER_LEN=16|20 overrides: tests)
 // every host wait for a stream goes through here: the calling thread's count is what the sharded step reports as
 // host_syncs (a host thread = a rank)
 hipError_t snk_sync_at(hipStream_t st, const char* file, int line);     // SNK_SYNC_TRACE=1: every wait is logged with its site

@@ -12,7 +12,9 @@
 #define SNK_M48 16
 #endif
 #define SNK_M_OF(K) ((K) == 48 ? SNK_M48 : 16)
-static_assert(SNK_M48 >= 11 && SNK_M48 <= 16, "the M-mer is rolled in one 32-bit word; 4^M values must cover the buckets");
+#define SNK_M_LONG 20                    // SNK_F_LONG_MINIMISER (64-bit rolling window)
+#define SNK_M_MIN_OF(K) (SNK_M_OF(K) < SNK_M_LONG ? SNK_M_OF(K) : SNK_M_LONG)
+static_assert(SNK_M48 >= 11 && SNK_M48 <= 24, "the M-mer is rolled in one 32-bit (M <= 16) or 64-bit word; 4^M values must cover the buckets");
 
 typedef unsigned __int128 snk_u128;
 
@@ -63,7 +65,7 @@ constexpr uint32_t SNK_OVF_SUBLISTS = 64;
 // four lines: 25 M reservations of a repeat-rich genome took 63 ms, a quarter of what ONE cursor took)
 constexpr uint32_t SNK_OVF_CUR_STRIDE = 32;
 constexpr uint32_t SNK_MSP_HOT_TAB = 256;
-int snk_launch_msp(uint32_t K, hipStream_t st, const snk_msp_args& a, char* err, size_t errcap);
+int snk_launch_msp(uint32_t K, uint32_t mlen, hipStream_t st, const snk_msp_args& a, char* err, size_t errcap);
 int snk_launch_msp_plan(hipStream_t st, const uint16_t* good_len, uint64_t n_reads, uint32_t K, unsigned long long* out2,
                         char* err, size_t errcap);
 

@@ -108,7 +108,7 @@ __device__ __forceinline__ uint32_t oriented_base(snk_kmer k, bool rc, int idx) 
 }
 
 // ---------------------------------------------------------------------------------------------- L1: local prune
-template <int K, int CAP, int T, bool BIG, bool GR>
+template <int K, int CAP, int T, bool BIG, bool GR, int MM>
 __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __restrict__ desc, uint32_t NB, bl_shard sh, const bl_regions& rg,
                                                      const snk_u128* __restrict__ keys, const uint64_t* __restrict__ vals,
                                                      uint32_t do_prune, uint8_t* __restrict__ ctx_out,
@@ -227,7 +227,6 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
         }
         __syncthreads();
         const uint32_t nm = mcnt;
-        constexpr int MM = SNK_M_OF(K);
         constexpr int SH = K - MM;               // shared M-mers of a k-mer and its neighbour
         constexpr int PER = (SH + 3) / 4;
         for (uint32_t it0 = 0; it0 < nm; it0 += T / 4) {
@@ -328,7 +327,7 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
     __syncthreads();
     if (tid == 0) nbnd[c] = bcnt;
 }
-template <int K, int CAP, int T, bool BIG, bool GR>
+template <int K, int CAP, int T, bool BIG, bool GR, int MM>
 __global__ void __launch_bounds__(T) bl_prune_kernel(const uint4* __restrict__ desc, uint32_t NB, bl_shard sh, bl_regions rg, const uint32_t* __restrict__ biglist_in,
                                                      uint32_t nchunks, uint32_t cpw,
                                                      const snk_u128* __restrict__ keys, const uint64_t* __restrict__ vals,
@@ -341,13 +340,13 @@ __global__ void __launch_bounds__(T) bl_prune_kernel(const uint4* __restrict__ d
         // the list's length is still on the device (no read-back between the two prune launches): a fixed grid strides over it
         const uint32_t nb = *n_dev;
         for (uint32_t w = blockIdx.x; w < nb; w += gridDim.x)
-            bl_prune_chunk<K, CAP, T, BIG, GR>(biglist_in[w], desc, NB, sh, rg, keys, vals, do_prune, ctx_out, count_out, pend_out, nbr_out, nbnd, biglist, nbig, gindex, gmask);
+            bl_prune_chunk<K, CAP, T, BIG, GR, MM>(biglist_in[w], desc, NB, sh, rg, keys, vals, do_prune, ctx_out, count_out, pend_out, nbr_out, nbnd, biglist, nbig, gindex, gmask);
         return;
     }
     for (uint32_t r = 0; r < cpw; ++r) {
         const uint32_t w = blockIdx.x * cpw + r;
         if (w >= nchunks) return;
-        bl_prune_chunk<K, CAP, T, BIG, GR>(BIG ? biglist_in[w] : w, desc, NB, sh, rg, keys, vals, do_prune, ctx_out, count_out, pend_out, nbr_out,
+        bl_prune_chunk<K, CAP, T, BIG, GR, MM>(BIG ? biglist_in[w] : w, desc, NB, sh, rg, keys, vals, do_prune, ctx_out, count_out, pend_out, nbr_out,
                                        nbnd, biglist, nbig, gindex, gmask);
     }
 }
@@ -798,7 +797,7 @@ constexpr int QSPAN = 8 * QWORDS * TB;      // k-mers per workgroup: ONE reserva
                                             // one 64-byte line: atomics on a line are served one at a time; 131 k workgroups x 8 ranks were ~10 ms per pass)
 template <int K, bool FILL>
 __global__ void __launch_bounds__(TB) bl_query_kernel(const snk_u128* __restrict__ keys, const uint8_t* __restrict__ premote, uint64_t n,
-                                                      uint32_t NB_total, uint32_t NBl, uint32_t world,
+                                                      uint32_t NB_total, uint32_t NBl, uint32_t world, uint32_t mlen,
                                                       unsigned long long* __restrict__ qcount_or_cursor,
                                                       unsigned long long* __restrict__ qbuf) {
     extern __shared__ unsigned long long dynq[];          // [world] counts, then reserved bases
@@ -831,7 +830,7 @@ __global__ void __launch_bounds__(TB) bl_query_kernel(const snk_u128* __restrict
         for (uint32_t rem = premote[i]; rem; rem &= rem - 1) {
             const uint32_t bit = __ffs(rem) - 1;
             const snk_kmer y = bit < 4 ? snk_kmer_succ<K>(k, bit) : snk_kmer_pred<K>(k, bit - 4);
-            const uint32_t owner = snk_bucket_of_kmer<K, SNK_M_OF(K)>(y, NB_total) / NBl;
+            const uint32_t owner = (mlen == (uint32_t)SNK_M_LONG ? snk_bucket_of_kmer<K, SNK_M_LONG>(y, NB_total) : snk_bucket_of_kmer<K, SNK_M_OF(K)>(y, NB_total)) / NBl;
             atomicAdd(&dynq[owner], 1ull);
         }
     }
@@ -849,7 +848,7 @@ __global__ void __launch_bounds__(TB) bl_query_kernel(const snk_u128* __restrict
         for (uint32_t rem = premote[i]; rem; rem &= rem - 1) {
             const uint32_t bit = __ffs(rem) - 1;
             const snk_kmer y = bit < 4 ? snk_kmer_succ<K>(k, bit) : snk_kmer_pred<K>(k, bit - 4);
-            const uint32_t owner = snk_bucket_of_kmer<K, SNK_M_OF(K)>(y, NB_total) / NBl;
+            const uint32_t owner = (mlen == (uint32_t)SNK_M_LONG ? snk_bucket_of_kmer<K, SNK_M_LONG>(y, NB_total) : snk_bucket_of_kmer<K, SNK_M_OF(K)>(y, NB_total)) / NBl;
             const snk_kmer r = snk_kmer_rc<K>(y);
             const bool rev = snk_kmer_lt(r, y);
             const snk_kmer c = rev ? r : y;
@@ -918,7 +917,8 @@ static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* er
     bl_regions rg;
     rg.keys_r = tab->keys_r; rg.vals_r = tab->vals_r; rg.desc_src = desc_src;
     rg.keys_dense = const_cast<snk_u128*>(tab->keys);
-    hipLaunchKernelGGL((bl_prune_kernel<K, SCAP, ST, false, GR>), dim3((nchunks + cpw - 1) / cpw), dim3(ST), 0, st, (const uint4*)B->desc, NBh, sh, rg,
+    const bool long_m = ctx->mlen == (uint32_t)SNK_M_LONG;
+    hipLaunchKernelGGL((long_m ? bl_prune_kernel<K, SCAP, ST, false, GR, SNK_M_LONG> : bl_prune_kernel<K, SCAP, ST, false, GR, SNK_M_OF(K)>), dim3((nchunks + cpw - 1) / cpw), dim3(ST), 0, st, (const uint4*)B->desc, NBh, sh, rg,
                        (const uint32_t*)nullptr, nchunks, cpw, tab->keys, tab->vals, B->do_prune, B->ctx, B->counts, B->pend, B->nbr, nbnd,
                        B->biglist, ctr, (const uint32_t*)nullptr, index0, tg0 - 1);
     SNK_HIP_TRY(hipGetLastError());
@@ -926,7 +926,7 @@ static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* er
     // device until the read-back below -- the big variant runs a fixed grid that strides over the list
     uint32_t h_nbig = 0;
     SNK_HIP_TRY(hipMemcpyAsync(ctr + 1, ctr, 4, hipMemcpyDeviceToDevice, st));       // (ctr[0] is the small kernel's list cursor)
-    hipLaunchKernelGGL((bl_prune_kernel<K, BCAP, BT, true, GR>), dim3(2048), dim3(BT), 0, st, (const uint4*)B->desc, NBh, sh, rg,
+    hipLaunchKernelGGL((long_m ? bl_prune_kernel<K, BCAP, BT, true, GR, SNK_M_LONG> : bl_prune_kernel<K, BCAP, BT, true, GR, SNK_M_OF(K)>), dim3(2048), dim3(BT), 0, st, (const uint4*)B->desc, NBh, sh, rg,
                        (const uint32_t*)B->biglist, 0u, 1u, tab->keys, tab->vals, B->do_prune, B->ctx, B->counts, B->pend, B->nbr,
                        nbnd, B->biglist, ctr + 2, (const uint32_t*)(ctr + 1), index0, tg0 - 1);
     SNK_HIP_TRY(hipGetLastError());
@@ -1170,8 +1170,8 @@ int snk_bl_dist_plan(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, unsigned lon
     if (rc) return rc;
     const size_t lds = (size_t)B->world * 12 + 16;
     const unsigned grid = (unsigned)((n + QSPAN - 1) / QSPAN);
-    if (B->K == 48) hipLaunchKernelGGL((bl_query_kernel<48, false>), dim3(grid), dim3(TB), lds, st, B->tab->keys, (const uint8_t*)B->premote, n, B->NB_total, B->NBl, B->world, B->qcount, (unsigned long long*)nullptr);
-    else hipLaunchKernelGGL((bl_query_kernel<60, false>), dim3(grid), dim3(TB), lds, st, B->tab->keys, (const uint8_t*)B->premote, n, B->NB_total, B->NBl, B->world, B->qcount, (unsigned long long*)nullptr);
+    if (B->K == 48) hipLaunchKernelGGL((bl_query_kernel<48, false>), dim3(grid), dim3(TB), lds, st, B->tab->keys, (const uint8_t*)B->premote, n, B->NB_total, B->NBl, B->world, ctx->mlen, B->qcount, (unsigned long long*)nullptr);
+    else hipLaunchKernelGGL((bl_query_kernel<60, false>), dim3(grid), dim3(TB), lds, st, B->tab->keys, (const uint8_t*)B->premote, n, B->NB_total, B->NBl, B->world, ctx->mlen, B->qcount, (unsigned long long*)nullptr);
     SNK_HIP_TRY(hipGetLastError());
     if (h_qcount) {
         SNK_HIP_TRY(hipMemcpyAsync(h_qcount, B->qcount, B->world * 8ull, hipMemcpyDeviceToHost, st));
@@ -1185,8 +1185,8 @@ int snk_bl_dist_fill(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, const unsign
     SNK_HIP_TRY(hipMemcpyAsync(B->qcursor, d_qoff, (B->world + 1) * 8ull, hipMemcpyDeviceToDevice, st));
     const size_t lds = (size_t)B->world * 12 + 16;
     const unsigned grid = (unsigned)((n + QSPAN - 1) / QSPAN);
-    if (B->K == 48) hipLaunchKernelGGL((bl_query_kernel<48, true>), dim3(grid), dim3(TB), lds, st, B->tab->keys, (const uint8_t*)B->premote, n, B->NB_total, B->NBl, B->world, B->qcursor, (unsigned long long*)d_qbuf);
-    else hipLaunchKernelGGL((bl_query_kernel<60, true>), dim3(grid), dim3(TB), lds, st, B->tab->keys, (const uint8_t*)B->premote, n, B->NB_total, B->NBl, B->world, B->qcursor, (unsigned long long*)d_qbuf);
+    if (B->K == 48) hipLaunchKernelGGL((bl_query_kernel<48, true>), dim3(grid), dim3(TB), lds, st, B->tab->keys, (const uint8_t*)B->premote, n, B->NB_total, B->NBl, B->world, ctx->mlen, B->qcursor, (unsigned long long*)d_qbuf);
+    else hipLaunchKernelGGL((bl_query_kernel<60, true>), dim3(grid), dim3(TB), lds, st, B->tab->keys, (const uint8_t*)B->premote, n, B->NB_total, B->NBl, B->world, ctx->mlen, B->qcursor, (unsigned long long*)d_qbuf);
     SNK_HIP_TRY(hipGetLastError());
     return SNK_OK;
 }

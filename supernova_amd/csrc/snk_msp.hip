@@ -23,6 +23,8 @@
 // list that is grouped by bucket afterwards and read by the count kernel as a second segment.  Correctness never
 // depends on the estimate.  The sharded path runs the same pass and then compacts the used slots into its exact,
 // destination-contiguous send buffer (snk_stages.hip).
+#include <type_traits>
+
 #include "snk_ctx.h"
 #include "snk_common.h"
 #include "snk_kernels.h"
@@ -38,12 +40,19 @@ __device__ __forceinline__ uint32_t mmer_key(const uint32_t* rowL, int tid, uint
     uint32_t w0 = rowL[wi * BD + tid];
     uint32_t w1 = rowL[(wi + 1) * BD + tid];                 // (row `row_words` of the staged rows is all zero)
     uint32_t s = 2u * ((uint32_t)p & 15u);
+    if constexpr (M > 16) {
+        const uint32_t wj = wi + 2 < row_words ? wi + 2 : row_words;
+        const uint32_t w2 = rowL[wj * BD + tid];
+        const uint64_t v = ((((uint64_t)w0 << 32) | w1) << s) | (s ? (uint64_t)(w2 >> (32u - s)) : 0ull);      // 32 bases from p on
+        return snk_mmer_key_top<M>(v);
+    } else {
     uint32_t x = (uint32_t)(((((uint64_t)w0 << 32) | w1) << s) >> 32);   // 16 bases starting at p, MSB first
     uint32_t rx = snk_rev2_32(~x);                             // reverse complement of those 16 bases
     uint32_t code, rcode;
     if (M == 16) { code = x; rcode = rx; }
     else { code = x >> (32 - 2 * M); rcode = rx & ((1u << (2 * M)) - 1u); }
     return snk_minimizer_key(code, rcode);
+    }
 }
 
 // Bucket of the supermer whose minimiser sits at position p.  Two rules make this safe:
@@ -382,28 +391,42 @@ __global__ void __launch_bounds__(BD, K == 48 ? SNK_MSP_OCC48 : 4) snk_msp_kerne
     // at a time; all lanes are at the same position, so the refill is a uniform branch).  kk[t] (registers, static
     // indices -- both passes are fully unrolled) holds the raw keys of the next block after a forward pass and that
     // block's suffix-minimum keys after its suffix pass.
-    static_assert(M >= 8 && M <= 16, "the rolling window below is one 32-bit word");
-    constexpr uint32_t MMASK = M == 16 ? 0xFFFFFFFFu : ((1u << (2 * (M & 15))) - 1u);
+    static_assert(M >= 8 && M <= 31, "the rolling window below is one 32-bit word, or one 64-bit word for M > 16");
+    typedef typename std::conditional<(M > 16), uint64_t, uint32_t>::type mm_t;
+    constexpr mm_t MMASK = (M == 16 || M == 32) ? ~(mm_t)0 : (((mm_t)1 << (2 * (M & 31))) - (mm_t)1);
     uint32_t kk[W];
-    uint32_t x = 0, rx = 0, cw = 0;
+    mm_t x = 0, rx = 0;
+    uint32_t cw = 0;
     int rp = 0;                                  // position of x
     auto roll = [&]() {                          // advance x/rx to position rp+1
         const int nb = rp + M;                   // index of the incoming base
         if ((nb & 15) == 0) { const uint32_t wi = (uint32_t)nb >> 4; cw = wi < row_words ? rowL[wi * BD + tid] : 0u; }
         const uint32_t base = cw >> 30;
         cw <<= 2;
-        x = ((x << 2) | base) & MMASK;
-        rx = (rx >> 2) | ((base ^ 3u) << (2 * M - 2));
+        x = ((x << 2) | (mm_t)base) & MMASK;
+        rx = (rx >> 2) | ((mm_t)(base ^ 3u) << (2 * M - 2));
         ++rp;
+    };
+    auto key_now = [&]() -> uint32_t {
+        if constexpr (M > 16) return snk_minimizer_key64(x, rx);
+        else return snk_minimizer_key(x, rx);
     };
     if (maxblocks > 0) {
         const uint32_t w0 = rowL[tid];
-        x = w0 >> (32 - 2 * M);                  // the first M bases as a number,
-        rx = snk_rev2_32(~w0) & MMASK;           // their reverse complement,
-        cw = M == 16 ? (row_words > 1 ? rowL[BD + tid] : 0u) : (w0 << (2 * (M & 15)));      // and the bases that follow, next one on top
+        if constexpr (M > 16) {
+            const uint32_t w1 = rowL[BD + tid];                  // (a one-word row: the zero row)
+            const uint64_t v0 = ((uint64_t)w0 << 32) | w1;
+            x = v0 >> (64 - 2 * M);                              // the first M bases as a number,
+            rx = snk_rev2_64(~(v0 & ~((1ull << (64 - 2 * M)) - 1ull))) & MMASK;      // their reverse complement,
+            cw = w1 << (2 * (M - 16));                           // and the bases that follow, next one on top
+        } else {
+            x = w0 >> (32 - 2 * (M & 31));           // the first M bases as a number,
+            rx = snk_rev2_32(~w0) & MMASK;           // their reverse complement,
+            cw = M == 16 ? (row_words > 1 ? rowL[BD + tid] : 0u) : (w0 << (2 * (M & 15)));      // and the bases that follow, next one on top
+        }
 #pragma unroll
         for (int t = 0; t < W; ++t) {            // raw keys of block 0
-            kk[t] = (t < npos) ? snk_minimizer_key(x, rx) : 0xFFFFFFFFu;
+            kk[t] = (t < npos) ? key_now() : 0xFFFFFFFFu;
             roll();
         }
     }
@@ -439,7 +462,7 @@ __global__ void __launch_bounds__(BD, K == 48 ? SNK_MSP_OCC48 : 4) snk_msp_kerne
                 }
                 const int p2 = (b + 1) * W + t;          // == rp: the roll is exactly one block ahead
                 const bool v2 = p2 < npos;
-                const uint32_t k2 = v2 ? snk_minimizer_key(x, rx) : 0xFFFFFFFFu;
+                const uint32_t k2 = v2 ? key_now() : 0xFFFFFFFFu;
                 kk[t] = k2;
                 if (v2 && k2 < pfx) { pfx = k2; pfxp = p2; }
                 roll();
@@ -559,11 +582,12 @@ static int launch_msp_k(hipStream_t st, const snk_msp_args& a, char* err, size_t
     return launch_msp_kt<K, M, false>(st, a, err, errcap);
 }
 
-int snk_launch_msp(uint32_t K, hipStream_t st, const snk_msp_args& a, char* err, size_t errcap) {
+int snk_launch_msp(uint32_t K, uint32_t mlen, hipStream_t st, const snk_msp_args& a, char* err, size_t errcap) {
     if (a.n_reads == 0) return SNK_OK;
     if (a.row_words > 16) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "reads longer than 256 bases are not supported (row_words=%u)", a.row_words);
-    if (K == 48) return launch_msp_k<48, SNK_M_OF(48)>(st, a, err, errcap);
-    if (K == 60) return launch_msp_k<60, SNK_M_OF(60)>(st, a, err, errcap);
+    if (mlen != SNK_M_LONG && mlen != (uint32_t)SNK_M_OF(K)) return snk_fail(SNK_E_INTERNAL, err, errcap, "partition: minimiser length %u", mlen);
+    if (K == 48) return mlen == SNK_M_LONG ? launch_msp_k<48, SNK_M_LONG>(st, a, err, errcap) : launch_msp_k<48, SNK_M_OF(48)>(st, a, err, errcap);
+    if (K == 60) return mlen == SNK_M_LONG ? launch_msp_k<60, SNK_M_LONG>(st, a, err, errcap) : launch_msp_k<60, SNK_M_OF(60)>(st, a, err, errcap);
     return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "K=%u is not supported (48 or 60)", K);
 }
 

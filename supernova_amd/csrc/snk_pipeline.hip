@@ -40,7 +40,7 @@ static int graph_tail(snk_ctx* ctx, hipStream_t st, const snk_params* p, uint32_
                       snk_table& tab, const snk_partition& part, snk_dev_result* out, phase_timer& tm, char* err, size_t errcap) {
     int rc;
     void* records = part.records;
-    if (h_ninst) { ctx->claim_ratio = (double)tab.distinct / (double)h_ninst; ctx->claim_ratio_reads = n_reads; ctx->claim_ratio_k = K * 2 + (grouped ? 1u : 0u);
+    if (h_ninst) { ctx->claim_ratio = (double)tab.distinct / (double)h_ninst; ctx->claim_ratio_reads = n_reads; ctx->claim_ratio_k = K * 2 + (grouped ? 1u : 0u) + 256u * ctx->mlen;
                    ctx->retain_ratio = (double)tab.n / (double)h_ninst; }
     snk_ctx_release_block(ctx, records);       // the fixed-capacity supermer slots: the graph stage may reuse the memory
     const uint64_t n_kmers = tab.n;
@@ -98,6 +98,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     if (!ctx || !in || !p || !out) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_count_graph: NULL argument");
     if (p->K != 48 && p->K != 60) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "K=%u is not supported (48 or 60)", p->K);
     if (p->min_bc > 8) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "min_bc=%u: the device barcode rule tells up to eight distinct barcodes apart (min_bc <= 8)", p->min_bc);
+    snk_set_mlen(ctx, p);
     if (in->n_reads && (!in->rows || in->row_words * 16 < in->read_len || in->read_len > 256))
         return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_count_graph: bad rows/read_len (read_len <= 256)");
     if (in->n_reads && !in->good_len && !in->quals) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_count_graph: need quals or good_len");
@@ -170,7 +171,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     // ... and the RETAINED k-mers of a bucket are one chunk of the bucket-local graph stage, whose one-wave kernels hold 256 of them
     // (larger chunks take the slower big-chunk variants): at half the coverage twice as many k-mers survive per instance, every other
     // chunk was over the line and the graph stage took 81 instead of ~58 ms.  From the previous call's retained share: chunks of ~150.
-    const double retain = (ctx->retain_ratio > 0.0 && ctx->claim_ratio_reads == n_reads && ctx->claim_ratio_k == K * 2 + (grouped ? 1u : 0u)) ? ctx->retain_ratio : 0.0;
+    const double retain = (ctx->retain_ratio > 0.0 && ctx->claim_ratio_reads == n_reads && ctx->claim_ratio_k == K * 2 + (grouped ? 1u : 0u) + 256u * ctx->mlen) ? ctx->retain_ratio : 0.0;
     auto target_for = [&](double ratio) -> uint32_t {
         if (target_forced) return env_u32("SNK_TARGET_INST", default_target);
         if (retain > 0.0 && !grouped) {
@@ -195,7 +196,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
         const double t = 0.01 * env_u32("SNK_BUCKET_FILL_PCT", 50) * lim / ratio;
         return t >= (double)default_target ? default_target : (t < 600.0 ? 600u : (uint32_t)t);
     };
-    const bool have_hint = ctx->claim_ratio > 0.0 && ctx->claim_ratio_reads == n_reads && ctx->claim_ratio_k == K * 2 + (grouped ? 1u : 0u);
+    const bool have_hint = ctx->claim_ratio > 0.0 && ctx->claim_ratio_reads == n_reads && ctx->claim_ratio_k == K * 2 + (grouped ? 1u : 0u) + 256u * ctx->mlen;
     double ratio = have_hint ? ctx->claim_ratio : 0.0;
     const bool adaptive = p->n_buckets == 0 && !target_forced && !grouped && env_u32("SNK_ADAPTIVE_BUCKETS", 1) != 0;      // (the per-barcode default is tuned at ratio ~1)
     uint32_t NB = 0;
@@ -287,6 +288,7 @@ extern "C" int snk_dev_stream_begin(snk_ctx* ctx, const snk_params* p, uint32_t 
     if (!ctx || !p) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_stream_begin: NULL argument");
     if (p->K != 48 && p->K != 60) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "K=%u is not supported (48 or 60)", p->K);
     if (p->min_bc > 8) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "min_bc=%u: the device barcode rule tells up to eight distinct barcodes apart (min_bc <= 8)", p->min_bc);
+    snk_set_mlen(ctx, p);
     if (read_len == 0 || read_len > 256 || total_reads_ub == 0) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_stream_begin: read_len 1..256 and an upper bound of the job's reads are needed");
     if ((p->flags & SNK_F_GROUPED)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_dev_stream_begin: per-group graphs take their reads resident (snk_dev_count_graph)");
     SNK_HIP_TRY(hipSetDevice(ctx->device));
@@ -308,7 +310,7 @@ extern "C" int snk_dev_stream_begin(snk_ctx* ctx, const snk_params* p, uint32_t 
     if (NB == 0) {
         uint32_t target = K == 48 ? 5000u : 3500u;
         if (getenv("SNK_TARGET_INST") && *getenv("SNK_TARGET_INST")) target = env_u32("SNK_TARGET_INST", target);
-        else if (ctx->claim_ratio > 0.0 && ctx->claim_ratio_reads == total_reads_ub && ctx->claim_ratio_k == K * 2) {
+        else if (ctx->claim_ratio > 0.0 && ctx->claim_ratio_reads == total_reads_ub && ctx->claim_ratio_k == K * 2 + 256u * ctx->mlen) {
             const double lim = (double)snk_count_limit(K, 0u);
             if (0.65 * lim / ctx->claim_ratio < (double)target) {
                 const double t = 0.01 * env_u32("SNK_BUCKET_FILL_PCT", 50) * lim / ctx->claim_ratio;
@@ -336,6 +338,7 @@ extern "C" int snk_dev_stream_append(snk_ctx* ctx, const snk_dev_reads* slab, vo
     if (!ctx || !slab) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_stream_append: NULL argument");
     stream_job* j = static_cast<stream_job*>(ctx->stream_job);
     if (!j || !j->open) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_stream_append: no open job (snk_dev_stream_begin)");
+    snk_set_mlen(ctx, &j->p);
     if (slab->n_reads == 0) return SNK_OK;
     if (!slab->rows || slab->read_len != j->read_len || slab->row_words * 16 < slab->read_len) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_stream_append: bad rows / read_len (the job's is %u)", j->read_len);
     if (!slab->good_len && !slab->quals) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_stream_append: need quals or good_len");
@@ -382,6 +385,7 @@ extern "C" int snk_dev_stream_finish(snk_ctx* ctx, snk_dev_result* out, void* st
     j->open = false;
     memset(out, 0, sizeof *out);
     const snk_params* p = &j->p;
+    snk_set_mlen(ctx, p);
     const uint32_t K = j->K;
     phase_timer tm(st);
     tm.mark(); tm.mark(); tm.mark();   // 0, 1, 2 (no trim / plan phase of their own)

@@ -223,6 +223,7 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
     // environment can test), and in-process ranks -- one host thread and one context each -- crashed inside the runtime when one thread
     // unmapped its arena while another copied out of its own (round 4: the suite's in-process worlds with the arena on by default).
     ctx->arena_legacy = W > 1;
+    snk_set_mlen(ctx, p);
     const uint64_t syncs0 = snk_sync_count();
     comm->bytes_sent = 0;
     snk_phase_timer tm(st);
@@ -242,7 +243,7 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
             for (ull v : all) inst_ub += v * kpr;
         }
     }
-    const bool have_ratio = inst_ub && comm->claim_ratio > 0.0 && comm->claim_ratio_reads == inst_ub && comm->claim_ratio_k == K * 2;      // (the group's history: snk_comm.h)
+    const bool have_ratio = inst_ub && comm->claim_ratio > 0.0 && comm->claim_ratio_reads == inst_ub && comm->claim_ratio_k == K * 2 + 256u * ctx->mlen;      // (the group's history: snk_comm.h)
     // Bucket size: from the job-wide ratio of distinct k-mers per instance the previous step exchanged; without that history the
     // count stage looks at its first buckets, the ranks agree on what they saw (one more exchange), and if the tables overflow as
     // a rule the reads are partitioned and exchanged once more into smaller buckets (error-rich reads: see snk_pipeline.hip).
@@ -428,7 +429,7 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
             q_send[q] = qall[(size_t)me * (W + QX) + q]; q_recv[q] = qall[(size_t)q * (W + QX) + me]; all_n[q] = qall[(size_t)q * (W + QX) + W];
             dsum += qall[(size_t)q * (W + QX) + W + 1]; isum += qall[(size_t)q * (W + QX) + W + 2];
         }
-        if (isum) { comm->claim_ratio = (double)dsum / (double)isum; comm->claim_ratio_reads = inst_ub; comm->claim_ratio_k = K * 2; }      // (job-wide figures, kept with the group: every rank takes the same decision next time)
+        if (isum) { comm->claim_ratio = (double)dsum / (double)isum; comm->claim_ratio_reads = inst_ub; comm->claim_ratio_k = K * 2 + 256u * ctx->mlen; }      // (job-wide figures, kept with the group: every rank takes the same decision next time)
     }
     uint64_t nq = 0, nq_in = 0;
     for (uint32_t q = 0; q < W; ++q) { nq += q_send[q]; nq_in += q_recv[q]; }
@@ -785,11 +786,12 @@ extern "C" int snk_shard_stream_begin(snk_ctx* ctx, snk_comm* comm, const snk_pa
     ctx->cur_stream = st;
     const uint32_t W = comm->world, K = p->K;
     ctx->arena_legacy = W > 1;
+    snk_set_mlen(ctx, p);
     const uint64_t kpr = read_len >= K ? read_len - K + 1 : 0;
     const uint64_t inst_ub = total_reads * kpr;
     const char* forced_target = getenv("SNK_TARGET_INST");
     const bool adaptive = inst_ub && !(forced_target && *forced_target) && snk_env_u32("SNK_ADAPTIVE_BUCKETS", 1) != 0;
-    const bool have_ratio = inst_ub && comm->claim_ratio > 0.0 && comm->claim_ratio_reads == inst_ub && comm->claim_ratio_k == K * 2;
+    const bool have_ratio = inst_ub && comm->claim_ratio > 0.0 && comm->claim_ratio_reads == inst_ub && comm->claim_ratio_k == K * 2 + 256u * ctx->mlen;
     const uint32_t NB_total = plan_buckets(inst_ub, W, K, p->n_buckets, adaptive && have_ratio ? comm->claim_ratio : 0.0);
     return snk_shard_job_open(ctx, p, comm->rank, W, NB_total, read_len, rank_reads_ub, total_reads, has_bc, st, err, errcap);
 }

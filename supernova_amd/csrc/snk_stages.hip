@@ -415,7 +415,7 @@ bool snk_fused_trim_ok(const snk_dev_reads* in) {
 // expected supermers of a pass and the record slots a bucket gets
 static void partition_capacity(snk_ctx* ctx, uint32_t K, uint32_t NB, unsigned long long n_inst, unsigned long long n_live, bool grouped, double* est_super_out,
                                uint64_t* cap_out) {
-    const uint32_t Wm = K - SNK_M_OF(K) + 1;
+    const uint32_t Wm = K - ctx->mlen + 1;
     // a random-order minimiser starts a new supermer every (W+1)/2 k-mers, and every contributing read starts one
     const double est_super = (double)n_inst * 2.0 / (Wm + 1) + (double)n_live;
     const double mean = est_super / NB;
@@ -508,7 +508,7 @@ int partition_dense(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_read
         }
         kt.n = 0;
         kt.mark();  // 0
-        if ((rc = snk_launch_msp(K, st, ma, err, errcap))) return rc;
+        if ((rc = snk_launch_msp(K, ctx->mlen, st, ma, err, errcap))) return rc;
         kt.mark();  // 1
         SNK_HIP_TRY(hipMemcpyAsync(&h_n, d_cur, 8, hipMemcpyDeviceToHost, st));
         if (d_plan && h_plan && !ft) SNK_HIP_TRY(hipMemcpyAsync(h_plan, d_plan, 16, hipMemcpyDeviceToHost, st));
@@ -634,7 +634,7 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
         }
         kt.n = 0;
         kt.mark();  // 0
-        if ((rc = snk_launch_msp(K, st, ma, err, errcap))) return rc;
+        if ((rc = snk_launch_msp(K, ctx->mlen, st, ma, err, errcap))) return rc;
         kt.mark();  // 1
         // segment 0 (the fixed-capacity slots) and the supermer total need the cursors only: one read-back for everything the
         // host wants to know about this pass (overflow count, supermers, and the caller's trim statistics if asked for)
@@ -753,7 +753,7 @@ int snk_partition_add(snk_ctx* ctx, hipStream_t st, snk_partition_job* J, const 
         ma.good_len = ft->good_out; ma.quals = (const uint8_t*)ft->quals; ma.qstride = ft->qstride; ma.min_qual = ft->min_qual;
         ma.lens = (const uint16_t*)ft->lens; ma.good_out = ft->good_out; ma.plan = J->d_plan;
     }
-    int rc = snk_launch_msp(J->K, st, ma, err, errcap);
+    int rc = snk_launch_msp(J->K, ctx->mlen, st, ma, err, errcap);
     if (rc) return rc;
     if (!ft) {
         // the sizing figures the fused kernel adds up itself: instances and contributing reads of this slab

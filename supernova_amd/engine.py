@@ -30,13 +30,14 @@ class Params:
     sorted_table: bool = True     # False: leave the retained table in bucket order (SNK_F_UNSORTED_TABLE)
     global_graph: bool = False    # True: the global graph stage (SNK_F_GLOBAL_GRAPH), a cross-check of the bucket-local one
     grouped: bool = False         # True: per-group graphs (SNK_F_GROUPED); count_graph(group=...) gives the group of every read
+    long_minimiser: bool = False  # True: 20-base minimisers (SNK_F_LONG_MINIMISER): genomes of human size; same results
 
     def to_c(self) -> _lib.SnkParams:
         p = _lib.SnkParams()
         p.K, p.min_qual, p.min_freq, p.min_bc = self.K, self.min_qual, self.min_freq, self.min_bc
         p.n_buckets = self.n_buckets
         p.flags = ((0 if self.graph else 1) | (0 if self.sorted_table else 2) | (4 if self.global_graph else 0)
-                   | (8 if self.grouped else 0))
+                   | (8 if self.grouped else 0) | (64 if self.long_minimiser else 0))
         return p
 
 

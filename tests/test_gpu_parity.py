@@ -54,12 +54,15 @@ def _check_against(res, keys3, counts, ctx, unitigs, goodlens, hist):
     assert res.unitigs() == unitigs
 
 
+@pytest.mark.parametrize("long_minimiser", [False, True])
 @pytest.mark.parametrize("name", goldens.CASES)
-def test_golden_case(engine, name):
+def test_golden_case(engine, name, long_minimiser):
+    """long_minimiser: SNK_F_LONG_MINIMISER -- 20-base minimisers in a 64-bit rolling window (genomes of human size); which minimiser cuts the
+    reads is internal: same table, contexts, spectrum and unitigs."""
     from supernova_amd.engine import Params
     c = goldens.load(name)
     rows, quals, bc, lens = _to_dev(c)
-    res = engine.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, params=Params(K=48),
+    res = engine.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, params=Params(K=48, long_minimiser=long_minimiser),
                              ign_bc_below=c.ign_bc_below)
     _check_against(res, c.exp_keys, c.exp_counts, c.exp_ctx, c.exp_unitigs, c.exp_goodlens, c.exp_hist)
 
@@ -280,14 +283,15 @@ def test_k60_vs_oracle(engine, name, use_bc):
     assert res.unitigs() == o.unitigs
 
 
+@pytest.mark.parametrize("long_minimiser", [False, True])
 @pytest.mark.parametrize("name", goldens.K60_CASES)
-def test_k60_golden(engine, name):
+def test_k60_golden(engine, name, long_minimiser):
     """K=60 against golden vectors dumped from the reference's BuildReadQGraph60 (no barcode rule => bc=None)."""
     from supernova_amd.engine import Params
     g = goldens.Case60(name)
     c = g.base
     rows, quals, bc, lens = _to_dev(c)
-    res = engine.count_graph(rows, c.read_len, quals=quals, bc=None, lens=lens, params=Params(K=60))
+    res = engine.count_graph(rows, c.read_len, quals=quals, bc=None, lens=lens, params=Params(K=60, long_minimiser=long_minimiser))
     assert np.array_equal(res.good_len().astype(np.uint32), g.exp_goodlens)
     assert np.array_equal(res.keys(), g.exp_keys)
     assert np.array_equal(np.minimum(res.counts(), (1 << 24) - 1), g.exp_counts)

@@ -11,7 +11,7 @@ import goldens
 pytestmark = pytest.mark.gpu
 
 
-def run_world(W, case, n_buckets=0):
+def run_world(W, case, n_buckets=0, long_minimiser=False):
     import torch
     from supernova_amd.engine import Engine, Params
     from supernova_amd.sharded import ShardedEngine, SimWorld
@@ -32,7 +32,7 @@ def run_world(W, case, n_buckets=0):
             bc = torch.from_numpy(case.bc[lo:hi].astype(np.int32)).to(dev)
             lens = torch.from_numpy(case.lens[lo:hi].astype(np.uint16).view(np.int16)).to(dev)
             sh = ShardedEngine(e, world.comm(r))
-            res = sh.count_graph(rows, case.read_len, quals=quals, bc=bc, lens=lens, params=Params(K=48, n_buckets=n_buckets),
+            res = sh.count_graph(rows, case.read_len, quals=quals, bc=bc, lens=lens, params=Params(K=48, n_buckets=n_buckets, long_minimiser=long_minimiser),
                                  ign_bc_below=case.ign_bc_below, read_index_base=lo)
             out[r] = dict(keys=res.keys(), counts=res.counts(), ctx=res.ctx(), spectrum=res.spectrum(),
                           n_instances=res.n_instances, n_frags=res.n_frags, n_queries=res.n_queries,
@@ -88,6 +88,18 @@ def test_sharded_matches_reference(snk, W, name):
     # the ranking is partitioned over the ranks -- also when fragment lists are circles (the plasmids of the adversarial case,
     # one of them without any splitter): every rank cuts them the same way in the replicated links and ranks again
     assert {o["ranking"] for o in out} == {"partitioned"}
+
+
+@pytest.mark.parametrize("W", [1, 2, 3])
+@pytest.mark.parametrize("name", ["adversarial", "synth_20k_err"])
+def test_sharded_long_minimisers(snk, W, name):
+    """SNK_F_LONG_MINIMISER through the N-rank step: the partition, the neighbour classification of the prune and the owner of a remote
+    k-mer (the cross-rank queries) all use the 20-base minimiser; same results as the reference."""
+    c = goldens.load(name)
+    out = run_world(W, c, long_minimiser=True)
+    check(out, c)
+    if W > 1:
+        assert sum(o["n_queries"] for o in out) > 0
 
 
 @pytest.mark.parametrize("W", [1, 3])
