@@ -212,7 +212,10 @@ def ingest_row(eng, args, K, step_ms_per_read):
 ROBUST = (("errors_0.6pct", dict(sub_ppm=6000)),
           ("errors_1.5pct_tails_50pct", dict(sub_ppm=15000, lowq_tail_ppm=500000)),
           ("coverage_28x", None),                # genome_len = reads * read_len / 28
-          ("repeat_rich_genome", dict(repeat_mode=15)))
+          ("repeat_rich_genome", dict(repeat_mode=15)),
+          # every fifth base of the genome an A: ~1 site per canonical 16-mer value, the minimiser-sharing regime of a human genome at the
+          # bench's size; the row also times the step with SNK_F_LONG_MINIMISER (20-base minimisers)
+          ("crowded_minimiser_space", dict(repeat_mode=16)))
 
 
 def robust_rows(eng, per_gpu, K, headline_ms):
@@ -247,6 +250,15 @@ def robust_rows(eng, per_gpu, K, headline_ms):
                      "graph_ms": {k: round(v, 2) for k, v in r.graph_ms.items()}, "hot_buckets": int(r.n_hot_buckets),
                      "buckets": int(r.n_buckets), "buckets_split": int(r.buckets_split), "overflow_supermers": int(r.n_overflow),
                      "retained_kmers": int(r.n_kmers), "unitigs": int(r.n_unitigs)}
+        if name == "crowded_minimiser_space":
+            lm = []
+            for rep in range(3):
+                t0 = time.perf_counter()
+                r = eng.count_graph(rows, sp.read_len, quals=quals, bc=bc, params=Params(K=K, sorted_table=False, long_minimiser=True))
+                torch.cuda.synchronize()
+                lm.append((time.perf_counter() - t0) * 1e3)
+            out[name]["long_minimiser_ms"] = round(min(lm[1:]), 2)
+            out[name]["long_minimiser_phase_ms"] = {k: round(v, 2) for k, v in r.phase_ms.items() if k in ("partition", "count", "graph")}
         del rows, quals, bc, r
     return out
 

@@ -105,7 +105,8 @@ typedef struct snk_synth_params {
                                   position (csrc/snk_synth.h): bit 0 four interspersed families (a 300-bp element in 60 % of the 4-kb
                                   blocks, 1-3 % divergence from its consensus: ~10^4 copies each at the bench's genome size), bit 1 5-kb
                                   segmental duplications (exact copies, one in four odd 64-kb superblocks), bit 2 short tandem repeats
-                                  (unit 1-6 bp, 40-200 bp, 3 % of the blocks), bit 3 poly-A runs (20-80 bp, 2 %) */
+                                  (unit 1-6 bp, 40-200 bp, 3 % of the blocks), bit 3 poly-A runs (20-80 bp, 2 %); bit 4 (16, not part of 15): every
+                                  fifth base is A -- a minimiser space as crowded as a human genome's at a fraction of its size */
     uint32_t reserved[3];
 } snk_synth_params;
 /* substitution rate of the model: sub_ppm and the error-count table that goes with it */

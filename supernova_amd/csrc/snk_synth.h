@@ -28,6 +28,10 @@ SNK_HD uint32_t snk_genome_raw(uint64_t seed, uint64_t p) {
 SNK_HD uint32_t snk_genome_base(const snk_synth_params& sp, uint64_t p) {
     const uint64_t seed = sp.seed;
     if (!sp.repeat_mode) return snk_genome_raw(seed, p);
+    // bit 4: a CROWDED minimiser space -- every fifth base is A, so a 16-mer takes one of 4^12 + 4 x 4^13 = 285 M values instead of 4.3 G
+    // while every 48-mer stays unique (76 free bits): a 268 Mb genome then has ~1 site per canonical 16-mer value, as a human genome has
+    // (3.1 G sites over 2.1 G values) -- the minimiser-sharing regime of configs 3-5 at a size one GPU holds at 56x
+    if ((sp.repeat_mode & 16u) && p % 5 == 0) return 0u;
     const uint64_t S = p >> 16;
     const uint32_t so = (uint32_t)(p & 0xFFFF);
     if ((sp.repeat_mode & 2u) && (S & 1) && so >= 8192 && so < 8192 + 5000) {

@@ -100,6 +100,25 @@ def test_synth_vs_oracle(engine, n_reads, error_free):
     _check_against(res, o.keys[:, :3], np.minimum(o.counts, (1 << 24) - 1), o.ctx, o.unitigs, gl, hist)
 
 
+@pytest.mark.parametrize("long_minimiser", [False, True])
+def test_crowded_minimiser_space_vs_oracle(engine, long_minimiser):
+    """repeat_mode bit 4: every fifth base of the genome is A -- ~1 site per canonical 16-mer value at the bench's size, the minimiser-sharing
+    regime of a human genome.  Both minimiser lengths give the oracle's table and unitigs."""
+    from supernova_amd import synth
+    from supernova_amd.engine import Params
+    sp = synth.synth_params(120_000, seed=77, repeat_mode=16)
+    rows_h, quals_h, bc_h = synth.synth_host(sp, qstride=160)
+    rows_d, quals_d, bc_d = engine.synth(sp, qstride=160)
+    assert np.array_equal(rows_d.cpu().numpy().view(np.uint32), rows_h)          # the mode is the shared generator's: device == host
+    codes = synth.unpack_rows(rows_h, 150)
+    assert all(any((r[p::5] == 0).mean() > 0.9 for p in range(5)) or any((r[p::5] == 3).mean() > 0.9 for p in range(5)) for r in codes[:200])
+    res = engine.count_graph(rows_d, 150, quals=quals_d, bc=bc_d, params=Params(K=48, long_minimiser=long_minimiser))
+    gl = oracle_lib.good_lens(quals_h, 150)
+    o = oracle_lib.OracleResult(codes, gl, bc_h, hbv=False)
+    hist = np.bincount(np.minimum(o.counts, (1 << 24) - 1)).astype(np.int64)
+    _check_against(res, o.keys[:, :3], np.minimum(o.counts, (1 << 24) - 1), o.ctx, o.unitigs, gl, hist)
+
+
 def test_no_barcodes_and_minbc_modes(engine):
     """bc == NULL disables the barcode rule (BuildReadQGraph48.cc:176-178); min_bc 0/1 follow areEnoughBarcodes."""
     import torch

@@ -1,6 +1,6 @@
 """The step on the bench's data and on the two error-rich models (bench.py's robust rows), phases and bucket counts: what a tuning
 build of the count kernel (tools/build_variant.sh, SNK_LIB_PATH=...) does off the operating point.
-usage: python tools/err_probe.py [n_reads] [rows: comma list of headline,e06,e15,cov28,human] [count]"""
+usage: python tools/err_probe.py [n_reads] [rows: comma list of headline,e06,e15,cov28,crowded,human] [count]"""
 import sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -11,6 +11,7 @@ n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100_000_000
 want = sys.argv[2].split(",") if len(sys.argv) > 2 else ["headline", "e06", "e15"]
 graph = not (len(sys.argv) > 3 and sys.argv[3] == "count")      # "count": stop after the table (a variant whose table outgrows the graph stage's chunks)
 MODELS = {"headline": {}, "e06": dict(sub_ppm=6000), "e15": dict(sub_ppm=15000, lowq_tail_ppm=500000), "cov28": dict(genome_len=n * 150 // 28),
+          "crowded": dict(repeat_mode=16),      # the bench's reads over a genome with ~1 site per canonical 16-mer value (human: 1.4), at 56x
           "human": dict(genome_len=3_100_000_000)}      # a genome of human size under these reads (4.8x at 1e8 reads: what the minimiser space of configs 3-5 looks like)
 eng = Engine(0)
 for name in want:
