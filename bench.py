@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--grouped", action="store_true",
                     help="BASELINE config 5: per-barcode local graphs (group = barcode, frequency rule only, --min-freq); "
                          "replicas only for N>1 (every rank owns whole barcodes, no collective)")
+    ap.add_argument("--minimiser", choices=["auto", "16", "20"], default="auto",
+                    help="minimiser length of the partition: 20 = SNK_F_LONG_MINIMISER; auto = 20 when the job's genome has more minimiser sites than "
+                         "~0.7 per canonical 16-mer (genome >= 1.5 Gb: the 6..8-GPU lines of this bench, whose genome grows with the reads), else 16")
     ap.add_argument("--min-freq", type=int, default=3)
     ap.add_argument("--no-verify", action="store_true", help="skip the untimed self-check of the sharded path")
     ap.add_argument("--no-next-rows", action="store_true", help="N=1: skip the untimed f1/f4 rows (read pathing, MarkDups, barcode lists) on the bench workload")
@@ -300,7 +303,8 @@ def main():
     sp = synth.synth_params(total_reads, seed=0x5EED0000 + (1 if world == 1 else 2), error_free=args.error_free)
     rows, quals, bc = eng.synth(sp, first=rank * per_gpu, n=per_gpu)
     torch.cuda.synchronize()
-    params = Params(K=K, sorted_table=args.sorted_table, global_graph=args.global_graph, min_freq=args.min_freq)
+    long_min = args.minimiser == "20" or (args.minimiser == "auto" and int(sp.genome_len) >= 1_500_000_000)      # sites that share a minimiser share a bucket
+    params = Params(K=K, sorted_table=args.sorted_table, global_graph=args.global_graph, min_freq=args.min_freq, long_minimiser=long_min)
     if args.grouped:
         assert per_gpu % (2 * sp.pairs_per_bc) == 0, "--grouped: reads per GPU must be a multiple of the reads per barcode"
         params = Params(K=K, sorted_table=False, grouped=True, min_bc=0, min_freq=args.min_freq)
@@ -455,7 +459,7 @@ def main():
                        "retained_kmers_rank0": int(res.n_kmers), "unitigs_rank0": int(res.n_unitigs),
                        "phase_ms_rank0": {k: round(v, 3) for k, v in res.phase_ms.items()},
                        "graph_ms_rank0": {k: round(v, 3) for k, v in getattr(res, "graph_ms", {}).items()},
-                       "table_order": "key" if args.sorted_table else "bucket",
+                       "table_order": "key" if args.sorted_table else "bucket", "minimiser_len": 20 if (long_min and not args.grouped) else 16, "genome_len": int(sp.genome_len),
                        "fragments_rank0": int(getattr(res, "n_fragments", 0) or getattr(res, "n_frags", 0))},
             # THE figure is pipeline_frac: the whole step (value x SURVEY 8(d)'s algorithmic bytes) against the chips' HBM peak.  The
             # dominant kernel (the LDS count kernel, ~40 % of the step) is NOT bound by HBM -- its real traffic (`traffic`, PMC) is a tenth
