@@ -39,7 +39,7 @@ done
 rm -rf $O/prof_${T}_path
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${T}_path -- python $R/tools/path_probe.py 1e8 2 > $O/prof_${T}_path.log 2>&1
 cp $(ls $O/prof_${T}_path/*/*kernel_stats.csv | head -1) $O/${T}_path_1e8_kernel_stats.csv; tail -1 $O/prof_${T}_path.log | cut -c1-200
-for x in "--k 60" "--grouped" "--error-free" "--reads 2e8" "--sorted-table" "--sharded"; do
+for x in "--k 60" "--grouped" "--error-free" "--reads 2e8" "--sorted-table" "--sharded" "--minimiser 20" "--sharded --minimiser 20"; do
   timeout 600 python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-next-rows --no-ingest --no-robust $x 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('$x', round(d['ms_per_step'],2), round(d['value'],2))"
 done > $O/bench_modes_$T.log 2>&1
 cat $O/bench_modes_$T.log
