@@ -12,7 +12,9 @@
 #define SNK_M48 16
 #endif
 #define SNK_M_OF(K) ((K) == 48 ? SNK_M48 : 16)
+#ifndef SNK_M_LONG
 #define SNK_M_LONG 20                    // SNK_F_LONG_MINIMISER (64-bit rolling window)
+#endif
 #define SNK_M_MIN_OF(K) (SNK_M_OF(K) < SNK_M_LONG ? SNK_M_OF(K) : SNK_M_LONG)
 static_assert(SNK_M48 >= 11 && SNK_M48 <= 24, "the M-mer is rolled in one 32-bit (M <= 16) or 64-bit word; 4^M values must cover the buckets");
 
