@@ -266,6 +266,21 @@ def robust_rows(eng, per_gpu, K, headline_ms):
     return out
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` with no launcher around it: run the N ranks under torch.distributed.run on this node (127.0.0.1, a free
+    port), exactly as the driver's own N > 1 command does, and return their exit code.  Rank 0's JSON line is the children's stdout."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
     import torch
@@ -275,8 +290,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the driver's own command
+            # line), hand their stdout through -- rank 0 prints the one JSON line -- and leave with their exit code
+            if args.transport == "rccl" and torch.cuda.device_count() < args.gpus:
+                raise SystemExit(f"--gpus {args.gpus} over RCCL needs {args.gpus} visible GPUs, this node shows {torch.cuda.device_count()} "
+                                 "(--transport gloo runs the same N-process job on fewer GPUs as a functional check)")
+            raise SystemExit(self_launch(args.gpus))
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
     if args.transport == "gloo":

@@ -356,6 +356,11 @@ void snk_ctx_release_since(snk_ctx* ctx, uint64_t mark, const void* const* keep,
     }
 }
 void snk_ctx_release_scratch(snk_ctx* ctx) {
+    // a streamed job (snk_dev_stream_* / snk_shard_stream_*) keeps its slots, cursors, good lengths and status in this arena: once the
+    // arena is recycled by ANOTHER top-level call the job is gone, and its append / finish must say so instead of writing into memory
+    // that now belongs to someone else
+    if (ctx->stream_job && ctx->stream_job_invalidate) ctx->stream_job_invalidate(ctx->stream_job);
+    if (ctx->shard) snk_shard_state_invalidate_job(ctx->shard);
     for (auto& b : ctx->blocks) b.used = false;
     ctx->total_alloc = 0;
     ctx->peak_alloc = 0;

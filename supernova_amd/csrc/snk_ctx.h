@@ -61,6 +61,7 @@ struct snk_ctx {
     void (*host_io_free)(void*) = nullptr;
     void* stream_job = nullptr; // the open streamed job of snk_dev_stream_* (snk_pipeline.hip)
     void (*stream_job_free)(void*) = nullptr;
+    void (*stream_job_invalidate)(void*) = nullptr;   // the arena the open job lives in is being recycled: append / finish must fail from now on
     void* shard_host = nullptr; // pinned staging, exchange stream and events of snk_shard_step (snk_shard_step.hip)
     void (*shard_host_free)(void*) = nullptr;
 };
@@ -90,3 +91,4 @@ void snk_ctx_release_block(snk_ctx* ctx, const void* p);   // return one block t
 void snk_ctx_release_since(snk_ctx* ctx, uint64_t mark, const void* const* keep, size_t n_keep);
 void snk_ctx_trim_cache(snk_ctx* ctx);        // hipFree every unused cached block
 void snk_shard_state_free(void* p);
+void snk_shard_state_invalidate_job(void* p);   // an open streamed step dies with the arena it lives in (snk_ctx_release_scratch)

@@ -21,6 +21,7 @@
 
 static snk_shard_state* state_of(snk_ctx* ctx) { return snk_shard_state_of(ctx); }
 void snk_shard_state_free(void* p) { delete static_cast<snk_shard_state*>(p); }
+void snk_shard_state_invalidate_job(void* p) { if (p) static_cast<snk_shard_state*>(p)->job_open = false; }
 
 int snk_shard_begin(snk_ctx* ctx, const snk_dev_reads* in, const snk_params* p, uint32_t rank, uint32_t world, uint32_t NB_total,
                     uint64_t* n_instances, hipStream_t st, char* err, size_t errcap) {

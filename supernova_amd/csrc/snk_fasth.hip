@@ -545,7 +545,7 @@ extern "C" int snk_dev_ingest_fasth(snk_ctx* ctx, const char* const* paths, uint
         for (auto e : ev_pool) (void)hipEventDestroy(e);
         ev_pool.clear();
         for (int q = 0; q < NST; ++q) { (void)hipFree(st_ascii[q]); (void)hipFree(st_bcf[q]); (void)hipFree(st_ids[q]); if (st_ev[q]) (void)hipEventDestroy(st_ev[q]); }
-        if (cs) (void)hipStreamDestroy(cs);
+        if (cs) { if (ctx->cur_stream == cs) ctx->cur_stream = nullptr; (void)hipStreamDestroy(cs); }
         if (fs) snk_fasth_close(fs);
     };
 #define ING_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); A.release(); Bf.release(); return snk_fail(_e == hipErrorOutOfMemory ? SNK_E_NOMEM : SNK_E_HIP, err, errcap, "%s failed: %s", #expr, hipGetErrorString(_e)); } } while (0)
@@ -688,7 +688,7 @@ extern "C" int snk_dev_ingest_count_graph(snk_ctx* ctx, const char* const* paths
         pending.clear();
         for (auto e : ev_pool) (void)hipEventDestroy(e);
         for (auto& q : S) { (void)hipFree(q.ascii); (void)hipFree(q.bcf); (void)hipFree(q.quals); (void)hipFree(q.ids); (void)hipFree(q.bc); (void)hipFree(q.rows); (void)hipFree(q.lens); if (q.ev) (void)hipEventDestroy(q.ev); }
-        if (cs) (void)hipStreamDestroy(cs);
+        if (cs) { if (ctx->cur_stream == cs) ctx->cur_stream = nullptr; (void)hipStreamDestroy(cs); }
         if (fs) snk_fasth_close(fs);
     };
 #define ING_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return snk_fail(_e == hipErrorOutOfMemory ? SNK_E_NOMEM : SNK_E_HIP, err, errcap, "%s failed: %s", #expr, hipGetErrorString(_e)); } } while (0)

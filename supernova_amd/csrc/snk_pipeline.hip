@@ -282,6 +282,9 @@ void stream_job_free(void* q) {
     for (auto& e : j->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete j;
 }
+void stream_job_invalidate(void* q) {
+    if (q) static_cast<stream_job*>(q)->open = false;
+}
 }  // namespace
 
 extern "C" int snk_dev_stream_begin(snk_ctx* ctx, const snk_params* p, uint32_t read_len, uint64_t total_reads_ub, int has_bc, void* stream, char* err, size_t errcap) {
@@ -294,11 +297,13 @@ extern "C" int snk_dev_stream_begin(snk_ctx* ctx, const snk_params* p, uint32_t 
     SNK_HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     ctx->cur_stream = st;
+    ctx->arena_legacy = false;
     snk_ctx_release_scratch(ctx);
     if (ctx->stream_job) { stream_job_free(ctx->stream_job); ctx->stream_job = nullptr; }
     stream_job* j = new stream_job();
     ctx->stream_job = j;
     ctx->stream_job_free = stream_job_free;
+    ctx->stream_job_invalidate = stream_job_invalidate;
     j->p = *p; j->K = p->K; j->read_len = read_len; j->row_words = (read_len + 15) / 16; j->has_bc = has_bc != 0; j->total_ub = total_reads_ub;
     const uint32_t K = p->K;
     const unsigned long long kpr = read_len >= K ? read_len - K + 1 : 0;
@@ -396,6 +401,8 @@ extern "C" int snk_dev_stream_finish(snk_ctx* ctx, snk_dev_result* out, void* st
     tm.mark();  // 3
     float part_ms = 0.f;
     for (auto& e : j->ev) { float t = 0.f; if (hipEventElapsedTime(&t, e.first, e.second) == hipSuccess) part_ms += t; }
+    for (auto& e : j->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    j->ev.clear();
     part.kernel_ms = part_ms;
     const unsigned long long h_ninst = h_plan[0];
     out->n_reads = j->J.n_reads;

@@ -142,3 +142,30 @@ def test_bench_two_processes_over_gloo_one_gpu(tmp_path):
     mg = d["config"]["multi_gpu"]
     assert d["config"]["sharded_self_check"] == "passed" and mg["transport"] == "callbacks" and mg["rccl_ranks"] == 2
     assert mg["exchange_bytes_rank0"]["records"] > 0 and mg["join_ranking"] == "partitioned"
+
+
+@pytest.mark.parametrize("extra", [[], ["--k", "60"], ["--grouped"]], ids=["c3_k48", "c4_k60", "c5_grouped"])
+def test_bench_self_launches_its_ranks(extra):
+    """The driver's N = 1 command shape with --gpus 2 and NO launcher around it (WORLD_SIZE unset): bench.py starts its two ranks itself
+    (bench.py::self_launch), rank 0 prints the one JSON line, exit code 0.  One line each for the job shapes of BASELINE configs 3, 4 and 5
+    (k=48 sharded, k=60 sharded, per-barcode replicas), over `--transport gloo` because this box has one GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "2", "--transport", "gloo", "--reads", "2e6", "--steps", "1", "--warmup", "0",
+           "--no-cpu-baseline", *extra]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(root), env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] and d["value"] > 0
+    assert d["config"]["k"] == (60 if "--k" in extra else 48)
+    if "--grouped" in extra:
+        assert d["config"]["path"] == "grouped-replicas"
+    else:
+        assert d["config"]["sharded_self_check"] == "passed" and d["config"]["multi_gpu"]["rccl_ranks"] == 2

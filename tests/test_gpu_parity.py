@@ -803,6 +803,25 @@ def test_streamed_slabs_equal_the_resident_call(engine, graph_stage, name, cuts)
         engine.stream_append(rows, c.read_len, quals=quals, bc=bc, lens=lens)
 
 
+def test_open_streamed_job_dies_with_its_arena(engine):
+    """A streamed job keeps its slots, cursors and good lengths in the context's arena.  A resident call in between recycles that arena
+    (snk_ctx_release_scratch): append / finish must then be refused instead of writing into memory that belongs to the new call
+    (snk_pipeline.hip)."""
+    from supernova_amd.engine import Params
+    from supernova_amd.lib import SnkError
+    c = goldens.load("synth_2k_err")
+    rows, quals, bc, lens = _to_dev(c)
+    n = rows.shape[0]
+    engine.stream_begin(c.read_len, n, has_bc=True, params=Params(K=48))
+    engine.stream_append(rows[: n // 2].clone(), c.read_len, quals=quals[: n // 2].clone(), bc=bc[: n // 2].clone(), lens=lens[: n // 2].clone())
+    res = engine.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, ign_bc_below=c.ign_bc_below)     # takes the arena
+    _check_against(res, c.exp_keys, c.exp_counts, c.exp_ctx, c.exp_unitigs, c.exp_goodlens, c.exp_hist)
+    with pytest.raises(SnkError, match="no open job"):
+        engine.stream_append(rows[n // 2:].clone(), c.read_len, quals=quals[n // 2:].clone(), bc=bc[n // 2:].clone(), lens=lens[n // 2:].clone())
+    with pytest.raises(SnkError, match="no open job"):
+        engine.stream_finish()
+
+
 def test_circle_pool_retry(engine, monkeypatch):
     """Circles inside one chunk take their fragment slots from a small pool; an empty pool must trigger the exact re-run."""
     monkeypatch.setenv("SNK_BL_POOL", "0")
