@@ -243,8 +243,34 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
         // ---- K5-K8 count + filter + gather (+ sort for the global graph stage)
         snk_count_pilot pilot{0.0, nullptr, nullptr};
         const bool want_pilot = adaptive && pass == 0 && !have_hint;
+        // measurement aid: SNK_OVERLAP_PROBE = 1: the partition kernel once more (into scratch) on a second stream NEXT TO the count
+        // kernel; 2: the same launch alone (waited for before the count starts); +4: the second stream has high priority;
+        // SNK_OVERLAP_PROBE_DBG = the relaunched kernel's dbg mode (1 no record stores, 2 no slot atomics, 3 scan only)
+        const uint32_t oprobe = env_u32("SNK_OVERLAP_PROBE", 0);
+        static hipStream_t s2 = nullptr, s2hi = nullptr;
+        hipStream_t sp2 = nullptr;
+        hipEvent_t pe[3] = {nullptr, nullptr, nullptr};
+        if (oprobe) {
+            if (!s2) { SNK_HIP_TRY(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking)); int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); SNK_HIP_TRY(hipStreamCreateWithPriority(&s2hi, hipStreamNonBlocking, hi)); }
+            sp2 = (oprobe & 4u) ? s2hi : s2;
+            for (auto& e : pe) SNK_HIP_TRY(hipEventCreate(&e));
+            SNK_HIP_TRY(hipEventRecord(pe[0], st));
+            SNK_HIP_TRY(hipStreamWaitEvent(sp2, pe[0], 0));
+            SNK_HIP_TRY(hipEventRecord(pe[1], sp2));
+            if ((rc = snk_probe_relaunch_msp(ctx, sp2, env_u32("SNK_OVERLAP_PROBE_DBG", 0), err, errcap))) return rc;
+            SNK_HIP_TRY(hipEventRecord(pe[2], sp2));
+            if ((oprobe & 3u) == 2u) SNK_HIP_TRY(hipStreamSynchronize(sp2));
+        }
         rc = snk_stage_count_table(ctx, st, K, records, part.seg, part.seg + NB, 2 * NB, part.nseg, NB, p->min_freq, (in->bc && !grouped) ? p->min_bc : 0u, grouped ? 1u : 0u,
                                    h_ninst, status, !local_graph, &tab, err, errcap, nullptr, want_pilot ? &pilot : nullptr, part.gidx, local_graph, &hot);
+        if (oprobe) {
+            SNK_HIP_TRY(hipStreamSynchronize(sp2));
+            float pm = 0.f;
+            (void)hipEventElapsedTime(&pm, pe[1], pe[2]);
+            fprintf(stderr, "[snk overlap probe] mode %u: partition kernel (first launch, alone) %.2f ms; relaunched %s %.2f ms; count kernel %.2f ms; count stage %.2f ms\n", oprobe,
+                    part.kernel_ms, (oprobe & 3u) == 2u ? "alone" : "next to the count kernel", pm, tab.count_kernel_ms, tab.count_ms);
+            for (auto& e : pe) (void)hipEventDestroy(e);
+        }
         if (rc == SNK_RETARGET) {
             // everything since the partition goes back to the arena; the good lengths and the status words stay
             snk_ctx_release_since(ctx, mark, nullptr, 0);

@@ -100,6 +100,7 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
                         unsigned long long n_inst, unsigned long long n_live, bool grouped, uint32_t* status, snk_partition* out,
                         char* err, size_t errcap, const unsigned long long* d_plan = nullptr, unsigned long long* h_plan = nullptr,
                         const snk_fused_trim* ft = nullptr, bool allow_dense = false);
+int snk_probe_relaunch_msp(snk_ctx* ctx, hipStream_t s2, uint32_t dbg, char* err, size_t errcap);      // measurement aid (SNK_OVERLAP_PROBE)
 // hot minimiser buckets (snk_hot.hip): their records expanded into single-k-mer records, one virtual bucket per (bucket, hash class)
 struct snk_hot {
     uint32_t n_hot, NBv;           // hot buckets, virtual buckets (0: nothing is hot)

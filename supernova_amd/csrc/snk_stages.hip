@@ -566,6 +566,30 @@ int partition_dense(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_read
 }
 }  // namespace
 
+// ---- measurement aid (SNK_OVERLAP_PROBE, snk_pipeline.hip): the last partition launch once more, into scratch memory of its own, on
+// ANOTHER stream -- next to whatever the caller's stream runs (the count kernel).  Says what the hardware makes of an atomics-bound and a
+// VALU-bound kernel that are resident at the same time.  Results of the call are not touched.
+static snk_msp_args snk_probe_last_msp;
+static uint32_t snk_probe_last_msp_K = 0;
+static uint64_t snk_probe_last_msp_ovf_cap = 0;
+int snk_probe_relaunch_msp(snk_ctx* ctx, hipStream_t s2, uint32_t dbg, char* err, size_t errcap) {
+    if (!snk_probe_last_msp_K) return SNK_OK;
+    snk_msp_args ma = snk_probe_last_msp;
+    const uint32_t NB = ma.NB;
+    int rc;
+    void* q;
+    if ((rc = snk_ctx_alloc(ctx, (NB + 1 + SNK_MSP_HOT_TAB) * 4ull, &q, err, errcap))) return rc; ma.cursor = (uint32_t*)q;
+    if ((rc = snk_ctx_alloc(ctx, ((size_t)NB * ma.cap + 2 * snk_probe_last_msp_ovf_cap) * 32 + 64, &q, err, errcap))) return rc; ma.records = (uint4*)q;
+    if ((rc = snk_ctx_alloc(ctx, snk_probe_last_msp_ovf_cap * 4 + 64, &q, err, errcap))) return rc; ma.ovf_bucket = (uint32_t*)q;
+    if ((rc = snk_ctx_alloc(ctx, SNK_OVF_SUBLISTS * SNK_OVF_CUR_STRIDE * 4 + 64, &q, err, errcap))) return rc; ma.ovf_cursor = (uint32_t*)q;
+    ma.hot_tab = ma.cursor + NB + 1;
+    if (ma.plan) { if ((rc = snk_ctx_alloc(ctx, 2ull * SNK_MSP_PLAN_SLOTS * 8, &q, err, errcap))) return rc; ma.plan = (unsigned long long*)q; SNK_HIP_TRY(hipMemsetAsync(ma.plan, 0, 2ull * SNK_MSP_PLAN_SLOTS * 8, s2)); }
+    ma.dbg = dbg;
+    SNK_HIP_TRY(hipMemsetAsync(ma.cursor, 0, (NB + 1 + SNK_MSP_HOT_TAB) * 4ull, s2));
+    SNK_HIP_TRY(hipMemsetAsync(ma.ovf_cursor, 0, SNK_OVF_SUBLISTS * SNK_OVF_CUR_STRIDE * 4, s2));
+    return snk_launch_msp(snk_probe_last_msp_K, ctx->mlen, s2, ma, err, errcap);
+}
+
 int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_reads* in, const uint16_t* good_len, uint32_t NB,
                         unsigned long long n_inst, unsigned long long n_live, bool grouped, uint32_t* status, snk_partition* out,
                         char* err, size_t errcap, const unsigned long long* d_plan, unsigned long long* h_plan, const snk_fused_trim* ft, bool allow_dense) {
@@ -636,6 +660,7 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
         kt.mark();  // 0
         if ((rc = snk_launch_msp(K, ctx->mlen, st, ma, err, errcap))) return rc;
         kt.mark();  // 1
+        snk_probe_last_msp = ma; snk_probe_last_msp_K = K; snk_probe_last_msp_ovf_cap = ovf_cap;
         // segment 0 (the fixed-capacity slots) and the supermer total need the cursors only: one read-back for everything the
         // host wants to know about this pass (overflow count, supermers, and the caller's trim statistics if asked for)
         SNK_HIP_TRY(hipMemsetAsync(d_total, 0, 64 * 8, st));
