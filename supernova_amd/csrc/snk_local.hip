@@ -241,6 +241,10 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
             uint64_t ktag = 0;
             if (GR) { ktag = kk.lo & 0xFFFFFFFFull; kk.lo &= ~0xFFFFFFFFull; }
             const int first = bit < 4 ? 1 : 0;   // successors share positions 1..K-M, predecessors 0..K-M-1
+            if (do_prune & 2u) {                 // measurement aid (SNK_BL_NOCLASSIFY): every miss is pending, the index resolves them all -- same result
+                if (on && sub == 0) atomicOr(&resL[th], (1u << bit) | (0x100u << bit));
+                continue;
+            }
             uint32_t mk = 0xFFFFFFFFu;
             for (int t = 0; t < PER; ++t) {
                 const int sp = (int)sub * PER + t;
@@ -277,7 +281,7 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
                     snk_kmer_hash_count<(K > 48) || GR>(cn, &h1, &h2);       // the count kernel's split function
                     here = (h2 & split_mask) == ch.id;
                 }
-                if (here) { if (!do_prune) atomicOr(&resL[th], 1u << bit); }
+                if (here) { if (!(do_prune & 1u)) atomicOr(&resL[th], 1u << bit); }
                 else atomicOr(&resL[th], (1u << bit) | (0x100u << bit) | (remote ? (0x10000u << bit) : 0u));
             }
         }
@@ -919,7 +923,7 @@ static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* er
     rg.keys_dense = const_cast<snk_u128*>(tab->keys);
     const bool long_m = ctx->mlen == (uint32_t)SNK_M_LONG;
     hipLaunchKernelGGL((long_m ? bl_prune_kernel<K, SCAP, ST, false, GR, SNK_M_LONG> : bl_prune_kernel<K, SCAP, ST, false, GR, SNK_M_OF(K)>), dim3((nchunks + cpw - 1) / cpw), dim3(ST), 0, st, (const uint4*)B->desc, NBh, sh, rg,
-                       (const uint32_t*)nullptr, nchunks, cpw, tab->keys, tab->vals, B->do_prune, B->ctx, B->counts, B->pend, B->nbr, nbnd,
+                       (const uint32_t*)nullptr, nchunks, cpw, tab->keys, tab->vals, B->do_prune | (snk_env_u32("SNK_BL_NOCLASSIFY", 0) ? 2u : 0u), B->ctx, B->counts, B->pend, B->nbr, nbnd,
                        B->biglist, ctr, (const uint32_t*)nullptr, index0, tg0 - 1);
     SNK_HIP_TRY(hipGetLastError());
     // the chunks that did not fit the one-wave variant (split sub-passes near the table's capacity): their number stays on the
@@ -927,7 +931,7 @@ static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* er
     uint32_t h_nbig = 0;
     SNK_HIP_TRY(hipMemcpyAsync(ctr + 1, ctr, 4, hipMemcpyDeviceToDevice, st));       // (ctr[0] is the small kernel's list cursor)
     hipLaunchKernelGGL((long_m ? bl_prune_kernel<K, BCAP, BT, true, GR, SNK_M_LONG> : bl_prune_kernel<K, BCAP, BT, true, GR, SNK_M_OF(K)>), dim3(2048), dim3(BT), 0, st, (const uint4*)B->desc, NBh, sh, rg,
-                       (const uint32_t*)B->biglist, 0u, 1u, tab->keys, tab->vals, B->do_prune, B->ctx, B->counts, B->pend, B->nbr,
+                       (const uint32_t*)B->biglist, 0u, 1u, tab->keys, tab->vals, B->do_prune | (snk_env_u32("SNK_BL_NOCLASSIFY", 0) ? 2u : 0u), B->ctx, B->counts, B->pend, B->nbr,
                        nbnd, B->biglist, ctr + 2, (const uint32_t*)(ctr + 1), index0, tg0 - 1);
     SNK_HIP_TRY(hipGetLastError());
     if (tab->keys_r) {       // the region-partitioned copy is dead (stream order): later stages may reuse it
