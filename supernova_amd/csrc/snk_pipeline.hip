@@ -28,6 +28,30 @@ __global__ void widen_offsets_kernel(const uint32_t* __restrict__ in, uint64_t* 
     if (i < n) out[i] = in[i];
 }
 
+// A fingerprint of the reads of a resident call: 4096 sixteen-byte samples of the packed rows (and of the quality rows or good lengths)
+// at evenly spread places, mixed with their place and added up -- order independent, one small workgroup.  What it is for: the sizing
+// history of a context (distinct k-mers per instance -> bucket size, retained share -> chunk and region sizes) is a property of the DATA
+// SET; a context that meets other data of the same size used to start from the old data's figures -- 0.6 % errors after the bench's
+// 0.2 %: first call 371 ms instead of 150 (1.2 M of 2 M buckets hash-split), 28x coverage after 56x: 644 ms (the count regions overflow
+// and the kernel runs again).  With another fingerprint the call forgets the history and looks at its first buckets instead.
+__global__ void __launch_bounds__(256) input_fp_kernel(const uint4* __restrict__ rows16, uint64_t n16, const uint4* __restrict__ aux16, uint64_t m16,
+                                                       unsigned long long* __restrict__ out) {
+    unsigned long long acc = 0;
+    for (int s = 0; s < 16; ++s) {
+        const uint64_t q = (uint64_t)(threadIdx.x * 16 + s);
+        if (n16) {
+            const uint64_t at = (n16 / 4096) * q + (q * 0x9E37u) % (n16 / 4096 + 1);
+            if (at < n16) { const uint4 v = rows16[at]; acc += snk_mix64(((unsigned long long)v.x << 32 | v.y) ^ snk_mix64(((unsigned long long)v.z << 32 | v.w) + at)); }
+        }
+        if (m16) {
+            const uint64_t at = (m16 / 4096) * q + (q * 0x79B9u) % (m16 / 4096 + 1);
+            if (at < m16) { const uint4 v = aux16[at]; acc += snk_mix64(((unsigned long long)v.x << 32 | v.y) ^ snk_mix64(((unsigned long long)v.z << 32 | v.w) + at + 0x51ED27ull)); }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+
 typedef snk_phase_timer phase_timer;
 
 #define env_u32 snk_env_u32
@@ -166,12 +190,31 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     // nearly every bucket would overflow its table and be counted in two to four hash-split sub-passes (0.6 % errors: count
     // 46 -> 133 ms).  The ratio is a property of the data set: the previous call's is used if there is one, else the count stage
     // looks at its first 1/64 of the buckets and asks for a second partition when they overflow as a rule.
+    // ---- is this the data set the context's sizing history was made on?  (one 8-byte read-back: ~40 us)
+    bool same_data = true;
+    if (n_reads && p->n_buckets == 0 && env_u32("SNK_INPUT_FP", 1)) {
+        void* q;
+        if ((rc = snk_ctx_alloc(ctx, 64, &q, err, errcap))) return rc;
+        unsigned long long* d_fp = (unsigned long long*)q;
+        SNK_HIP_TRY(hipMemsetAsync(d_fp, 0, 8, st));
+        const uint64_t n16 = (((uintptr_t)in->rows & 15u) == 0) ? n_reads * (uint64_t)in->row_words / 4 : 0;
+        const void* aux = in->quals ? in->quals : in->good_len;
+        const uint64_t m16 = (aux && ((uintptr_t)aux & 15u) == 0) ? (in->quals ? n_reads * (uint64_t)in->qstride : n_reads * 2ull) / 16 : 0;
+        hipLaunchKernelGGL(input_fp_kernel, dim3(1), dim3(256), 0, st, (const uint4*)in->rows, n16, (const uint4*)aux, m16, d_fp);
+        unsigned long long h_fp = 0;
+        SNK_HIP_TRY(hipMemcpyAsync(&h_fp, d_fp, 8, hipMemcpyDeviceToHost, st));
+        SNK_HIP_TRY(snk_sync(st));
+        h_fp ^= snk_mix64(n_reads * 0x9E3779B97F4A7C15ull + in->read_len);
+        same_data = ctx->have_input_fp && ctx->last_input_fp == h_fp;
+        ctx->last_input_fp = h_fp; ctx->have_input_fp = true;
+        if (!same_data) { ctx->last_n_kmers = 0; ctx->last_bnd = 0; }       // (the count regions' and the boundary index's sizes were that data's)
+    }
     const uint32_t default_target = grouped ? 900u : (K == 48 ? 5000u : 3500u);
     const bool target_forced = getenv("SNK_TARGET_INST") && *getenv("SNK_TARGET_INST");
     // ... and the RETAINED k-mers of a bucket are one chunk of the bucket-local graph stage, whose one-wave kernels hold 256 of them
     // (larger chunks take the slower big-chunk variants): at half the coverage twice as many k-mers survive per instance, every other
     // chunk was over the line and the graph stage took 81 instead of ~58 ms.  From the previous call's retained share: chunks of ~150.
-    const double retain = (ctx->retain_ratio > 0.0 && ctx->claim_ratio_reads == n_reads && ctx->claim_ratio_k == K * 2 + (grouped ? 1u : 0u) + 256u * ctx->mlen) ? ctx->retain_ratio : 0.0;
+    const double retain = (same_data && ctx->retain_ratio > 0.0 && ctx->claim_ratio_reads == n_reads && ctx->claim_ratio_k == K * 2 + (grouped ? 1u : 0u) + 256u * ctx->mlen) ? ctx->retain_ratio : 0.0;
     auto target_for = [&](double ratio) -> uint32_t {
         if (target_forced) return env_u32("SNK_TARGET_INST", default_target);
         if (retain > 0.0 && !grouped) {
@@ -196,7 +239,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
         const double t = 0.01 * env_u32("SNK_BUCKET_FILL_PCT", 50) * lim / ratio;
         return t >= (double)default_target ? default_target : (t < 600.0 ? 600u : (uint32_t)t);
     };
-    const bool have_hint = ctx->claim_ratio > 0.0 && ctx->claim_ratio_reads == n_reads && ctx->claim_ratio_k == K * 2 + (grouped ? 1u : 0u) + 256u * ctx->mlen;
+    const bool have_hint = same_data && ctx->claim_ratio > 0.0 && ctx->claim_ratio_reads == n_reads && ctx->claim_ratio_k == K * 2 + (grouped ? 1u : 0u) + 256u * ctx->mlen;
     double ratio = have_hint ? ctx->claim_ratio : 0.0;
     const bool adaptive = p->n_buckets == 0 && !target_forced && !grouped && env_u32("SNK_ADAPTIVE_BUCKETS", 1) != 0;      // (the per-barcode default is tuned at ratio ~1)
     uint32_t NB = 0;
