@@ -282,6 +282,9 @@ typedef struct snk_shard_result {
     uint32_t n_hot_buckets;          /* this rank's minimiser buckets far above their capacity (repeat families, homopolymer runs): re-partitioned
                                         by k-mer hash and counted by a launch of their own, like snk_dev_result.n_hot_buckets */
     uint32_t reserved_u;
+    uint64_t pair_max_bytes[8];      /* per exchange (the order of exchanged_bytes): the most this rank sent to ONE other rank.  xGMI is point to
+                                        point: an exchange takes as long as its fullest pair, so max against exchanged_bytes / (world - 1) is the
+                                        link balance of the step */
 } snk_shard_result;
 /* total_reads: reads of the whole job (sizes the bucket count without an exchange; 0 = the ranks exchange their slab sizes,
  * ignored when p->n_buckets is set).  in->read_index_base = global index of the slab's first read. */

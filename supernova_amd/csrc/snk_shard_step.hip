@@ -268,6 +268,7 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
         return 0;
     }, &ag};
     uint32_t n_hot_buckets = 0;
+    uint64_t pair_max_records = 0;       // the most records (bytes) this rank sends to one other rank
     auto count_pass = [&](bool with_pilot) -> int {
         // ---- trim + one-pass partition over all buckets of the job
         n_inst = 0;
@@ -355,6 +356,12 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
                 }
             }
             exch_records = n_send * 32;
+            pair_max_records = 0;
+            for (uint32_t q = 0; q < W; ++q) {
+                uint64_t to_q = 0;
+                for (uint32_t r = 0; r < R; ++r) to_q += h_rs[(size_t)q * R + r];
+                if (q != me && to_q * 32 > pair_max_records) pair_max_records = to_q * 32;
+            }
             // ---- segment tables: W sources (mine = the slots, in place) + my overflow segment
             const uint32_t nseg = W + (part.n_overflow ? 1u : 0u);
             uint64_t* T;
@@ -528,7 +535,7 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
     TRY(upload(X, frag_off.data(), W + 1, &d_frag_off));
     jt.mark();   // j2 gather links
     bool ranked = false;
-    uint64_t exch_spl = 0, exch_rank = 0;
+    uint64_t exch_spl = 0, exch_rank = 0, pair_max_rank = 0;
     const bool want_partitioned = snk_env_u32("SNK_JOIN_REPLICATED", 0) == 0;
     for (int attempt = 0; want_partitioned && !ranked && attempt < 3; ++attempt) {
         // (a second attempt follows a circle cut: the links changed, everything derived from them is made again)
@@ -575,6 +582,7 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
                 sbeg[q] = (uint64_t)q * rcap * 16; scnt[q] = (rall[(size_t)me * (W + 1) + q] - (ull)q * rcap) * 16;
                 rbeg[q] = n_in * 16; rcnt[q] = (rall[(size_t)q * (W + 1) + me] - (ull)me * cap_q) * 16;
                 n_in += rcnt[q] / 16; n_out += scnt[q] / 16;
+                if (q != me && scnt[q] > pair_max_rank) pair_max_rank = scnt[q];
             }
             uint8_t* rk_in;
             ALLOC(rk_in, uint8_t, n_in * 16 + 32);
@@ -666,6 +674,19 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
     out->exchanged_bytes[5] = exch_rank;
     out->exchanged_bytes[6] = 0; for (uint32_t q = 0; q < W; ++q) if (q != me) out->exchanged_bytes[6] += f_send[q] * 32 + b_send[q];
     out->exchanged_bytes[7] = comm->bytes_sent;
+    {
+        uint64_t* pm = out->pair_max_bytes;
+        pm[0] = pair_max_records;
+        for (uint32_t q = 0; q < W; ++q) if (q != me) {
+            pm[1] = std::max<uint64_t>(pm[1], q_send[q] * 24 + q_recv[q] * 4);
+            pm[2] = std::max<uint64_t>(pm[2], l_send[q] * 24 + l_recv[q] * 4);
+            pm[6] = std::max<uint64_t>(pm[6], f_send[q] * 32 + b_send[q]);
+        }
+        // all-gathers: every other rank gets the same piece
+        pm[3] = W > 1 ? F * 12 : 0;
+        pm[4] = W > 1 ? exch_spl / W : 0;
+        pm[5] = pair_max_rank;
+    }
     for (int q = 0; q < 7; ++q) out->phase_ms[q] = tm.ms(q, q + 1);
     out->phase_ms[7] = tm.ms(0, 7);
     for (int q = 0; q < 5; ++q) out->join_ms[q] = jt.ms(q, q + 1);

@@ -110,7 +110,7 @@ class SnkShardResult(C.Structure):
                 ("exchanged_bytes", C.c_uint64 * 8), ("host_syncs", C.c_uint32), ("ranking", C.c_uint32),
                 ("buckets_split", C.c_uint32), ("max_slots_used", C.c_uint32), ("phase_ms", C.c_float * 8),
                 ("join_ms", C.c_float * 8), ("count_kernel_ms", C.c_float), ("repartitioned", C.c_uint32), ("n_hot_buckets", C.c_uint32),
-                ("reserved_u", C.c_uint32)]
+                ("reserved_u", C.c_uint32), ("pair_max_bytes", C.c_uint64 * 8)]
 
 
 COMM_A2A = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64),

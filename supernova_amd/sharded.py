@@ -275,6 +275,8 @@ class ShardedResult:
         self.join_ms = {JOIN_NAMES[i]: float(raw.join_ms[i]) for i in range(5)}
         self.kernel_ms = {"count": float(raw.count_kernel_ms)}
         self.exchange_bytes = {EXCH_NAMES[i]: int(raw.exchanged_bytes[i]) for i in range(8)}
+        # the most this rank sent to ONE other rank per exchange (xGMI is point to point: an exchange takes as long as its fullest pair)
+        self.pair_max_bytes = {EXCH_NAMES[i]: int(raw.pair_max_bytes[i]) for i in range(7)}
 
     def _dl(self, ptr, nbytes, dtype, shape):
         out = np.empty(shape, dtype=dtype)

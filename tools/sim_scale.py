@@ -16,6 +16,7 @@ bar = threading.Barrier(W)
 rmode = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 sp = synth.synth_params(W * per, seed=0x5EED0002, **({'repeat_mode': rmode} if rmode else {}))
 out = [None] * W
+pairs = [None] * W
 errs = []
 
 def worker(r):
@@ -29,7 +30,13 @@ def worker(r):
             res = sh.count_graph(rows, sp.read_len, quals=quals, bc=bc, params=Params(K=48), read_index_base=r * per, total_reads=W * per)
             torch.cuda.synchronize(); t1 = time.time()
             out[r] = (t1 - t0, res.phase_ms, res.join_ms, res.n_kmers, res.n_frags, res.n_queries, res.n_unitigs, res.n_instances, res.host_syncs, res.exchange_bytes, int(res.raw.n_hot_buckets))
+            pairs[r] = res.pair_max_bytes
             bar.wait()
+            if r == 0 and W > 1:
+                # link balance: per exchange, what the ranks put on the wire in all, the mean per (sender, receiver) pair and the fullest pair
+                print(f"rep{rep} pair balance (MB): " + " | ".join(
+                    f"{k}: total {sum(out[q][9][k] for q in range(W)) / 1e6:.0f} mean/pair {sum(out[q][9][k] for q in range(W)) / (W * (W - 1)) / 1e6:.1f} max pair {max(pairs[q][k] for q in range(W)) / 1e6:.1f}"
+                    for k in pairs[0]), flush=True)
             if r == 0:
                 for q in range(W):
                     w, ph, jm, nk, nf, nq, nu, ni, hs, xb, nh = out[q]
