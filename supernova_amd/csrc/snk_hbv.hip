@@ -22,6 +22,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include <rocprim/rocprim.hpp>
@@ -62,6 +64,13 @@ void hbv_flood_component(const hbv_tables& t, uint64_t e0, int rc0, std::vector<
     q.clear();            // FIFO: [head, size); emptied whenever a component is finished
     size_t head = 0;
     q.push_back(e0 * 2 + rc0);
+    // measurement aid (SNK_HBV_DEPTH=1): the levels of this breadth-first flood -- what a level-synchronous reproduction on the device
+    // would take one round (a launch, or a grid-wide barrier: >= 3 us either way) for each
+    static const bool want_depth = getenv("SNK_HBV_DEPTH") != nullptr;
+    std::vector<uint32_t> lvl;
+    uint64_t visited = 0;
+    uint32_t depth = 0;
+    if (want_depth) lvl.push_back(0);
     while (head < q.size()) {
         // The flood is a chain of cache misses (4U + U + V words touched at random: 250 ns per edge on a 6 M-unitig graph); the queue
         // says what will be touched next, so the lines of the entries 16, 8 and 4 places ahead are asked for now, one level of
@@ -90,6 +99,7 @@ void hbv_flood_component(const hbv_tables& t, uint64_t e0, int rc0, std::vector<
         if (vid[r1] == -1) vid[r1] = next_v++;
         if (vid[r2] == -1) vid[r2] = next_v++;
         const int32_t id = next_e++;
+        if (want_depth) { ++visited; if (lvl[head - 1] > depth) depth = lvl[head - 1]; }
         out->v_left[id] = vid[r1]; out->v_right[id] = vid[r2];
         out->src_unitig[id] = (int32_t)e; out->is_rc[id] = (uint8_t)rc;
         if (!rc || t.pal[e]) out->fwd_xlat[e] = id;
@@ -99,10 +109,12 @@ void hbv_flood_component(const hbv_tables& t, uint64_t e0, int rc0, std::vector<
             for (uint64_t j = t.run_beg[r]; j < t.run_beg[r + 1]; ++j) {
                 const uint64_t ed = t.ee[j] >> 2;
                 const int erc = (int)((t.ee[j] >> 1) & 1u);
-                if (!done(ed, erc)) q.push_back(ed * 2 + erc);
+                if (!done(ed, erc)) { q.push_back(ed * 2 + erc); if (want_depth) lvl.push_back(lvl[head - 1] + 1); }
             }
         }
     }
+    if (want_depth && visited >= 100000)
+        fprintf(stderr, "[snk hbv] component of %llu edge copies: %u breadth-first levels (%.1f copies per level)\n", (unsigned long long)visited, depth + 1, (double)visited / (depth + 1));
 }
 // Fills every array of `out`: every component in seed order.
 int hbv_flood(uint64_t U, const uint8_t* pal, const uint32_t* ee, uint64_t n_ee, const int32_t* vtx_of, const uint64_t* run_beg,
@@ -652,13 +664,36 @@ extern "C" int snk_dev_hbv(snk_ctx* ctx, uint32_t K, uint64_t U, const void* d_u
             SNK_HIP_TRY(fetch_tables());
             SNK_HIP_TRY(snk_sync(st));
             std::vector<int32_t> vid(nruns, -1);
-            std::vector<uint64_t> q;
             const hbv_tables t{U, h_pal.data(), h_ee.data(), h_vtx.data(), h_run.data()};
-            for (const hbv_big& b : h_big) {
-                int32_t next_e = (int32_t)b.be, next_v = (int32_t)b.bv;
-                hbv_flood_component(t, b.root >= U ? b.root - U : b.root, b.root >= U ? 1 : 0, vid, q, next_e, next_v, out);
-                if ((uint32_t)next_e != b.be + b.ce) { snk_hbv_free(out); return snk_fail(SNK_E_INTERNAL, err, errcap, "snk_dev_hbv: a component's flood left its block"); }
+            // Components are independent once their id blocks are known (the device's scans): a host thread each, largest first.  The bulk
+            // of a genome graph is TWO components -- the forward copies' and its mirror image, the reverse copies' -- whose floods are NOT
+            // each other's mirror (a flood pushes the left vertex's edges before the right vertex's), so both are run, side by side.
+            // (Why not on the device: profiles/r05_hbv_depth.log -- 6.1 M edge copies in 1.3 M breadth-first levels, 4.7 per level: a
+            // level-synchronous reproduction is >= 1.3 M rounds of >= 3 us.)
+            std::vector<uint32_t> ord(n_big);
+            for (uint32_t i = 0; i < n_big; ++i) ord[i] = i;
+            std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return h_big[a].ce > h_big[b].ce; });
+            const uint32_t nthr = std::min<uint32_t>(n_big, std::min<uint32_t>(8u, std::max(1u, (uint32_t)snk_host_cpu_budget())));
+            std::atomic<uint32_t> next{0};
+            std::atomic<int> bad{0};
+            auto work = [&]() {
+                std::vector<uint64_t> q;
+                for (;;) {
+                    const uint32_t i = next.fetch_add(1);
+                    if (i >= n_big) break;
+                    const hbv_big& b = h_big[ord[i]];
+                    int32_t next_e = (int32_t)b.be, next_v = (int32_t)b.bv;
+                    hbv_flood_component(t, b.root >= U ? b.root - U : b.root, b.root >= U ? 1 : 0, vid, q, next_e, next_v, out);
+                    if ((uint32_t)next_e != b.be + b.ce) bad = 1;
+                }
+            };
+            if (nthr <= 1) work();
+            else {
+                std::vector<std::thread> th;
+                for (uint32_t i = 0; i < nthr; ++i) th.emplace_back(work);
+                for (auto& x : th) x.join();
             }
+            if (bad) { snk_hbv_free(out); return snk_fail(SNK_E_INTERNAL, err, errcap, "snk_dev_hbv: a component's flood left its block"); }
         }
     }
 flooded:
