@@ -286,6 +286,10 @@ typedef struct snk_shard_result {
                                         point: an exchange takes as long as its fullest pair, so max against exchanged_bytes / (world - 1) is the
                                         link balance of the step */
 } snk_shard_result;
+/* Bucket-range passes of the last snk_dev_count_graph on the context (1 = the one-pass partition).  A job whose supermer slots would not
+ * fit the device is partitioned and counted range by range over one slot array, the reads scanned once per pass -- what the reference
+ * does when its k-mer records do not fit (lib/assembly/src/MapReduceEngine.h:452-468, lib/tada/src/utils.rs:329-341).  Same results. */
+uint32_t snk_ctx_last_partition_passes(const snk_ctx* ctx);
 /* total_reads: reads of the whole job (sizes the bucket count without an exchange; 0 = the ranks exchange their slab sizes,
  * ignored when p->n_buckets is set).  in->read_index_base = global index of the slab's first read. */
 int snk_shard_step(snk_ctx* ctx, snk_comm* comm, const snk_dev_reads* in, const snk_params* p, uint64_t total_reads, uint32_t flags,

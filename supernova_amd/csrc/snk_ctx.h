@@ -57,6 +57,7 @@ struct snk_ctx {
     uint32_t last_extra = 0;                           // split sub-passes the previous call recorded
     uint64_t last_input_fp = 0;                        // fingerprint of the last resident call's reads (snk_pipeline.hip): other data of the same size must not inherit its sizing history
     bool have_input_fp = false;
+    uint32_t last_partition_passes = 1;                // bucket-range passes of the last resident call (snk_ctx_last_partition_passes)
     std::vector<unsigned long long> h_region_off;      // host copy of the count regions' dense offsets (source of an async upload)
     void* shard = nullptr;      // snk_shard_state (snk_dist.hip)
     void* host_io = nullptr;    // pinned staging + device input buffers of the host-pointer entry point (snk_host.hip)

@@ -60,6 +60,11 @@ struct snk_msp_args {
     uint32_t* dense_bkt;
     unsigned long long* dense_cursor;   // [1] records wanted (keeps counting past dense_cap)
     uint64_t dense_cap;
+    // bucket-range passes (b_hi != 0): only the supermers of buckets [b_lo, b_hi) are emitted, bucket b owns records
+    // [(b - b_lo) * cap, (b - b_lo + 1) * cap) -- a job whose slots do not fit the device is partitioned and counted range by range
+    // over the same slot memory, the reads scanned once per pass (what the reference's MapReduce engine does when its records do not
+    // fit: lib/assembly/src/MapReduceEngine.h:452-468)
+    uint32_t b_lo, b_hi;
 };
 constexpr int SNK_MSP_PLAN_SLOTS = 256;
 constexpr uint32_t SNK_OVF_SUBLISTS = 64;

@@ -205,7 +205,7 @@ __device__ __forceinline__ int fused_trim(const snk_msp_args& a, int tid0, uint6
 // (36.0 -> 33.0 ms at 1e8 reads against the 105 registers / four waves per SIMD the compiler picks on its own).  Keeping
 // the minimisers' keys in a second LDS list to save their re-derivation in the emit loop costs the fifth workgroup and
 // was dropped again; six waves per SIMD (80 VGPRs) spill 28 registers.  K=60 (45 keys in registers) stays at four.
-template <int K, int M, bool TRIM, bool DENSE>
+template <int K, int M, bool TRIM, bool DENSE, bool RANGED = false>
 #ifndef SNK_MSP_OCC48
 #define SNK_MSP_OCC48 5
 #endif
@@ -308,7 +308,8 @@ __global__ void __launch_bounds__(BD, K == 48 ? SNK_MSP_OCC48 : 4) snk_msp_kerne
                 {
                     bool ok = true;
                     uint32_t slot = 0;
-                    if (DENSE) {
+                    if (RANGED && (bucket < a.b_lo || bucket >= a.b_hi)) ok = false;      // another pass's bucket
+                    else if (DENSE) {
                         // no slot reservation: records go out densely in read order (a workgroup's block was reserved with ONE atomic,
                         // a thread's records follow each other inside it); which bucket a record belongs to is written next to it and
                         // the count kernel finds a bucket's records through a sorted index list (snk_stages.hip)
@@ -332,7 +333,7 @@ __global__ void __launch_bounds__(BD, K == 48 ? SNK_MSP_OCC48 : 4) snk_msp_kerne
                         if (slot >= a.hot_thr && ((slot - a.hot_thr) & 1023u) == 0u && a.hot_tab)
                             __hip_atomic_store(&a.hot_tab[bucket % SNK_MSP_HOT_TAB], bucket + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
-                    if (slot < a.cap) at = (uint64_t)bucket * a.cap + slot;
+                    if (slot < a.cap) at = (uint64_t)(RANGED ? bucket - a.b_lo : bucket) * a.cap + slot;
                     else {
                         // overflow list: ONE reservation per wave (same-address atomics are served one at a time)
                         const unsigned long long m = __ballot(1);
@@ -566,6 +567,15 @@ static int launch_msp_ktd(hipStream_t st, const snk_msp_args& a, char* err, size
 }
 template <int K, int M, bool TRIM>
 static int launch_msp_kt(hipStream_t st, const snk_msp_args& a, char* err, size_t errcap) {
+    if (a.b_hi) {
+        if (a.dense_bkt) return snk_fail(SNK_E_ARG, err, errcap, "partition: bucket-range passes take the slot layout, not the dense one");
+        size_t lds = snk_msp_lds_bytes(K, M, a.row_words);
+        unsigned nb = (unsigned)((a.n_reads + BD - 1) / BD);
+        SNK_HIP_TRY(hipFuncSetAttribute((const void*)snk_msp_kernel<K, M, TRIM, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((snk_msp_kernel<K, M, TRIM, false, true>), dim3(nb), dim3(BD), lds, st, a);
+        SNK_HIP_TRY(hipGetLastError());
+        return SNK_OK;
+    }
     if (a.dense_bkt) {
         if (!a.dense_cursor || a.dense_cap >= (1ull << 32)) return snk_fail(SNK_E_ARG, err, errcap, "dense partition: needs its cursor and fewer than 2^32 record positions");
         return launch_msp_ktd<K, M, TRIM, true>(st, a, err, errcap);

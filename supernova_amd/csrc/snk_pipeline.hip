@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <math.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "snk_ctx.h"
@@ -269,6 +270,27 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
         out->n_buckets = NB;
         if (pass == 0) tm.mark();  // 2
         h_plan[0] = ub_inst; h_plan[1] = ub_live;
+        // ---- a job whose slots would not fit: bucket-range passes over one slot array (snk_stages.h); the count stage's range hook
+        //      partitions range r right before range r is counted
+        const uint32_t n_passes = (NB >= 2 && !env_u32("SNK_MSP_DENSE", 0)) ? std::min<uint32_t>(snk_partition_passes_needed(ctx, K, NB, ub_inst, ub_live, grouped), NB) : 1u;
+        ctx->last_partition_passes = n_passes;
+        if (n_passes > 1) {
+            snk_partition_passes PS;
+            if ((rc = snk_partition_passes_open(ctx, st, K, in, good_len, fused ? &ft : nullptr, NB, n_passes, ub_inst, ub_live, grouped, &PS, err, errcap))) return rc;
+            if (pass == 0) tm.mark();  // 3 (the partition's time is inside the count stage's here)
+            snk_count_ranges rgs{n_passes, PS.bounds, snk_partition_passes_run, &PS, true};
+            rc = snk_stage_count_table(ctx, st, K, PS.records, PS.seg, PS.seg + NB, 2 * NB, 2u, NB, p->min_freq, (in->bc && !grouped) ? p->min_bc : 0u, grouped ? 1u : 0u,
+                                       ub_inst, status, !local_graph, &tab, err, errcap, &rgs, nullptr, nullptr, local_graph, nullptr);
+            if (rc) return rc;
+            h_ninst = PS.h_plan[0];
+            memset(&part, 0, sizeof part);
+            part.NB = NB; part.cap = PS.cap; part.nseg = 2; part.n_overflow = (uint32_t)std::min<uint64_t>(PS.n_overflow, 0xFFFFFFFFull); part.n_supermers = PS.n_supermers;
+            part.records = PS.records; part.cursor = PS.cursor; part.seg = PS.seg; part.kernel_ms = PS.kernel_ms;
+            out->n_instances = h_ninst;
+            out->n_supermers = part.n_supermers;
+            out->n_overflow = part.n_overflow;
+            break;
+        }
         rc = snk_stage_partition(ctx, st, K, in, good_len, NB, h_plan[0], h_plan[1], grouped, status, &part, err, errcap, nullptr, fused ? h_plan : nullptr,
                                  fused ? &ft : nullptr, true);
         if (rc) return rc;

@@ -55,6 +55,9 @@ struct snk_count_ranges {
     const uint32_t* bounds;
     int (*ready)(void* user, uint32_t r);
     void* user;
+    // replay: the hook MAKES the records of range r (bucket-range passes: snk_partition_passes) -- a run that has to be repeated (count
+    // regions too small) calls it again for every range, and its return code and message are the stage's
+    bool replay = false;
 };
 // pilot: the first 1/64 of the buckets is counted first; if their tables overflow as a rule (more distinct k-mers than the LDS
 // table holds: error-rich reads, shallow coverage) the stage stops there, leaves the distinct k-mers per bucket it saw in
@@ -100,6 +103,24 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
                         unsigned long long n_inst, unsigned long long n_live, bool grouped, uint32_t* status, snk_partition* out,
                         char* err, size_t errcap, const unsigned long long* d_plan = nullptr, unsigned long long* h_plan = nullptr,
                         const snk_fused_trim* ft = nullptr, bool allow_dense = false);
+// ---- the partition in bucket-range passes over ONE slot array sized for a range (a job whose slots do not fit the device; the
+// reference re-scans its input in passes when its records do not fit: MapReduceEngine.h:452-468, lib/tada/src/utils.rs:329-341).
+// open sizes and allocates; snk_partition_passes_run(user = the object, r) is the count stage's range hook: it scans the reads once
+// more and emits the supermers of range r only (the quality trim runs in the first pass), then builds that range's segment tables.
+struct snk_partition_passes {
+    snk_ctx* ctx; hipStream_t st; uint32_t K, NB, cap, P; bool grouped;
+    snk_dev_reads in; const uint16_t* good_len; snk_fused_trim ft; bool fused;
+    uint32_t* cursor; uint64_t* seg; void* records; uint32_t* ovf_bucket; uint32_t* ovf_cur; unsigned long long* d_total; unsigned long long* d_fplan;
+    uint64_t ovf_cap, slots_per_pass;
+    uint32_t bounds[66];
+    unsigned long long h_plan[2]; uint64_t n_supermers, n_overflow; float kernel_ms; uint32_t runs;
+    char* err; size_t errcap;
+};
+int snk_partition_passes_open(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_reads* in, const uint16_t* good_len, const snk_fused_trim* ft, uint32_t NB,
+                              uint32_t passes, unsigned long long n_inst, unsigned long long n_live, bool grouped, snk_partition_passes* S, char* err, size_t errcap);
+int snk_partition_passes_run(void* user, uint32_t r);
+// passes a job of this size needs so that its slots take at most ~a quarter of the device (1: the one-pass partition)
+uint32_t snk_partition_passes_needed(snk_ctx* ctx, uint32_t K, uint32_t NB, unsigned long long n_inst, unsigned long long n_live, bool grouped);
 int snk_probe_relaunch_msp(snk_ctx* ctx, hipStream_t s2, uint32_t dbg, char* err, size_t errcap);      // measurement aid (SNK_OVERLAP_PROBE)
 // hot minimiser buckets (snk_hot.hip): their records expanded into single-k-mer records, one virtual bucket per (bucket, hash class)
 struct snk_hot {

@@ -134,15 +134,15 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
             *retarget = pilot->per_bucket > 0.85 * snk_count_limit(K, grouped) && !h_p[1];
             return SNK_OK;
         };
-        if (attempt == 0 && ranges && ranges->n) {
+        if (ranges && ranges->n && (attempt == 0 || ranges->replay)) {
             // the records of bucket range r may still be on their way: the caller's hook makes the stream wait for
             // them, the ranges before it are being counted meanwhile
             for (uint32_t r = 0; r < ranges->n; ++r) {
-                if (ranges->ready && (rc = ranges->ready(ranges->user, r))) return snk_fail(SNK_E_ARG, err, errcap, "count: the range hook failed for range %u (%d)", r, rc);
+                if (ranges->ready && (rc = ranges->ready(ranges->user, r))) { if (ranges->replay) return rc; return snk_fail(SNK_E_ARG, err, errcap, "count: the range hook failed for range %u (%d)", r, rc); }
                 snk_count_args cr = ca;
                 cr.bucket0 = ranges->bounds[r];
                 cr.NB = ranges->bounds[r + 1];
-                if (r == 0 && pilot && NB >= 16384 && n_inst_hint) {
+                if (r == 0 && attempt == 0 && pilot && NB >= 16384 && n_inst_hint) {
                     const uint32_t NBp = NB / 64 < cr.NB - cr.bucket0 ? NB / 64 : cr.NB - cr.bucket0;
                     bool retarget = false, regrow = false;
                     if ((rc = run_pilot(cr.bucket0, NBp, &retarget, &regrow))) return rc;
@@ -414,7 +414,7 @@ bool snk_fused_trim_ok(const snk_dev_reads* in) {
 
 // expected supermers of a pass and the record slots a bucket gets
 static void partition_capacity(snk_ctx* ctx, uint32_t K, uint32_t NB, unsigned long long n_inst, unsigned long long n_live, bool grouped, double* est_super_out,
-                               uint64_t* cap_out) {
+                               uint64_t* cap_out, uint32_t passes = 1, uint64_t* ideal_out = nullptr) {
     const uint32_t Wm = K - ctx->mlen + 1;
     // a random-order minimiser starts a new supermer every (W+1)/2 k-mers, and every contributing read starts one
     const double est_super = (double)n_inst * 2.0 / (Wm + 1) + (double)n_live;
@@ -431,7 +431,8 @@ static void partition_capacity(snk_ctx* ctx, uint32_t K, uint32_t NB, unsigned l
     cap64 = cap64 * env_u32("SNK_MSP_CAP_PCT", 100) / 100;
     if (cap64 < 2) cap64 = 2;
     cap64 = (cap64 + 1) & ~1ull;
-    {
+    if (ideal_out) *ideal_out = cap64;
+    if (passes <= 1) {
         // not more than ~45 % of the device for the slots: beyond that the capacity shrinks and the overflow list takes the rest
         const uint64_t tot = ctx->device_mem_total;
         if (tot) {
@@ -702,6 +703,131 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
     out->cursor = cursor;
     out->seg = seg;
     out->kernel_ms = kt.ms(0, 1);
+    return SNK_OK;
+}
+
+// ===================================================================================================================
+// Bucket-range passes (snk_stages.h): the same kernel, RANGED; every pass reuses the slot array and the overflow area.
+namespace {
+__global__ void __launch_bounds__(256) seg0_range_kernel(const uint32_t* __restrict__ cursor, uint32_t b_lo, uint32_t b_hi, uint32_t NB, uint32_t cap,
+                                                         uint64_t* __restrict__ seg, unsigned long long* __restrict__ total) {
+    const uint32_t b = b_lo + blockIdx.x * 256 + threadIdx.x;
+    unsigned long long v = 0;
+    if (b < b_hi) {
+        const uint32_t c = cursor[b];
+        v = c < cap ? c : cap;
+        seg[b] = (uint64_t)(b - b_lo) * cap;
+        seg[NB + b] = (uint64_t)(b - b_lo) * cap + v;
+        seg[2ull * NB + b] = 0;
+        seg[3ull * NB + b] = 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&total[(blockIdx.x * 4u + (threadIdx.x >> 6)) & 63u], v);
+}
+}  // namespace
+
+uint32_t snk_partition_passes_needed(snk_ctx* ctx, uint32_t K, uint32_t NB, unsigned long long n_inst, unsigned long long n_live, bool grouped) {
+    const uint32_t forced = env_u32("SNK_PARTITION_PASSES", 0);
+    if (forced) return forced > 64 ? 64u : forced;
+    double est = 0;
+    uint64_t cap = 0, ideal = 0;
+    partition_capacity(ctx, K, NB, n_inst, n_live, grouped, &est, &cap, 1, &ideal);
+    const uint64_t tot = ctx->device_mem_total;
+    if (!tot || ideal * NB * 32ull <= (uint64_t)((double)tot * 0.45)) return 1;       // (the one-pass partition's own limit)
+    const uint64_t per_pass = (uint64_t)((double)tot * 0.25);
+    uint64_t p = (ideal * NB * 32ull + per_pass - 1) / per_pass;
+    return (uint32_t)(p < 2 ? 2 : (p > 64 ? 64 : p));
+}
+
+int snk_partition_passes_open(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_reads* in, const uint16_t* good_len, const snk_fused_trim* ft, uint32_t NB,
+                              uint32_t passes, unsigned long long n_inst, unsigned long long n_live, bool grouped, snk_partition_passes* S, char* err, size_t errcap) {
+    if (passes < 1 || passes > 64 || passes > NB) return snk_fail(SNK_E_ARG, err, errcap, "partition passes: 1..64 (and at most one per bucket)");
+    S->ctx = ctx; S->st = st; S->K = K; S->NB = NB; S->P = passes; S->grouped = grouped; S->in = *in; S->good_len = good_len; S->fused = ft != nullptr;
+    if (ft) S->ft = *ft;
+    S->err = err; S->errcap = errcap; S->n_supermers = 0; S->n_overflow = 0; S->kernel_ms = 0.f; S->runs = 0; S->h_plan[0] = n_inst; S->h_plan[1] = n_live;
+    double est_super = 0;
+    uint64_t cap64 = 0;
+    partition_capacity(ctx, K, NB, n_inst, n_live, grouped, &est_super, &cap64, passes);
+    if (cap64 >= (1ull << 31)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "bucket capacity out of range");
+    S->cap = (uint32_t)cap64;
+    uint32_t widest = 0;
+    for (uint32_t r = 0; r <= passes; ++r) S->bounds[r] = (uint32_t)((uint64_t)NB * r / passes);
+    for (uint32_t r = 0; r < passes; ++r) widest = std::max(widest, S->bounds[r + 1] - S->bounds[r]);
+    S->slots_per_pass = (uint64_t)widest * S->cap;
+    // (nothing can be looked at and run again with a larger list: a generous one, as for a streamed job)
+    S->ovf_cap = ((uint64_t)(est_super / passes / 6) + (1u << 20) + SNK_OVF_SUBLISTS - 1) / SNK_OVF_SUBLISTS * SNK_OVF_SUBLISTS;
+    if (S->ovf_cap >= (1ull << 31)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "supermer overflow list too large");
+    int rc;
+    void* q;
+    if ((rc = snk_ctx_alloc(ctx, (NB + 1 + SNK_MSP_HOT_TAB) * 4ull, &q, err, errcap))) return rc; S->cursor = (uint32_t*)q;
+    if ((rc = snk_ctx_alloc(ctx, 4ull * NB * 8 + 64, &q, err, errcap))) return rc; S->seg = (uint64_t*)q;
+    if ((rc = snk_ctx_alloc(ctx, 64 * 8, &q, err, errcap))) return rc; S->d_total = (unsigned long long*)q;
+    if ((rc = snk_ctx_alloc(ctx, 2ull * SNK_MSP_PLAN_SLOTS * 8, &q, err, errcap))) return rc; S->d_fplan = (unsigned long long*)q;
+    if ((rc = snk_ctx_alloc(ctx, (S->slots_per_pass + 2 * S->ovf_cap) * 32 + 64, &S->records, err, errcap))) return rc;
+    if ((rc = snk_ctx_alloc(ctx, S->ovf_cap * 4 + 64, &q, err, errcap))) return rc; S->ovf_bucket = (uint32_t*)q;
+    if ((rc = snk_ctx_alloc(ctx, SNK_OVF_SUBLISTS * SNK_OVF_CUR_STRIDE * 4 + 64, &q, err, errcap))) return rc; S->ovf_cur = (uint32_t*)q;
+    return SNK_OK;
+}
+
+int snk_partition_passes_run(void* user, uint32_t r) {
+    snk_partition_passes* S = static_cast<snk_partition_passes*>(user);
+    snk_ctx* ctx = S->ctx;
+    hipStream_t st = S->st;
+    char* err = S->err;
+    size_t errcap = S->errcap;
+    if (r >= S->P) return snk_fail(SNK_E_INTERNAL, err, errcap, "partition passes: range %u of %u", r, S->P);
+    const uint32_t NB = S->NB, b_lo = S->bounds[r], b_hi = S->bounds[r + 1];
+    if (r == 0) {       // (a run of all passes starts: also a repeated one)
+        SNK_HIP_TRY(hipMemsetAsync(S->cursor, 0, (NB + 1 + SNK_MSP_HOT_TAB) * 4ull, st));
+        S->n_supermers = 0; S->n_overflow = 0; S->kernel_ms = 0.f;
+        ++S->runs;
+    }
+    SNK_HIP_TRY(hipMemsetAsync(S->ovf_cur, 0, SNK_OVF_SUBLISTS * SNK_OVF_CUR_STRIDE * 4, st));
+    SNK_HIP_TRY(hipMemsetAsync(S->cursor + NB + 1, 0, SNK_MSP_HOT_TAB * 4ull, st));        // (the table of buckets that stopped reserving slots is a pass's own)
+    const bool trim_now = S->fused && r == 0 && S->runs == 1;          // the first pass derives the good lengths, the others read them
+    snk_msp_args ma;
+    memset(&ma, 0, sizeof ma);
+    const snk_dev_reads* in = &S->in;
+    ma.rows = (const uint32_t*)in->rows; ma.row_words = in->row_words; ma.read_len = in->read_len; ma.good_len = S->fused ? S->ft.good_out : S->good_len; ma.bc = (const int32_t*)in->bc;
+    ma.ign_bc_below = in->ign_bc_below; ma.read_index_base = in->read_index_base; ma.n_reads = in->n_reads; ma.NB = NB;
+    ma.group = S->grouped ? (const uint32_t*)in->group : nullptr;
+    ma.cursor = S->cursor; ma.records = (uint4*)S->records; ma.cap = S->cap; ma.ovf_cap = (uint32_t)(S->ovf_cap / SNK_OVF_SUBLISTS);
+    ma.ovf_base = S->slots_per_pass; ma.ovf_bucket = S->ovf_bucket; ma.ovf_cursor = S->ovf_cur;
+    ma.hot_tab = S->cursor + NB + 1; ma.hot_thr = msp_hot_thr(S->cap);
+    ma.b_lo = b_lo; ma.b_hi = b_hi;
+    if (trim_now) {
+        ma.quals = (const uint8_t*)S->ft.quals; ma.qstride = S->ft.qstride; ma.min_qual = S->ft.min_qual;
+        ma.lens = (const uint16_t*)S->ft.lens; ma.good_out = S->ft.good_out; ma.plan = S->d_fplan;
+        SNK_HIP_TRY(hipMemsetAsync(S->d_fplan, 0, 2ull * SNK_MSP_PLAN_SLOTS * 8, st));
+    }
+    snk_phase_timer kt(st);
+    kt.mark();
+    int rc;
+    if ((rc = snk_launch_msp(S->K, ctx->mlen, st, ma, err, errcap))) return rc;
+    kt.mark();
+    SNK_HIP_TRY(hipMemsetAsync(S->d_total, 0, 64 * 8, st));
+    hipLaunchKernelGGL(seg0_range_kernel, dim3((b_hi - b_lo + 255) / 256), dim3(256), 0, st, S->cursor, b_lo, b_hi, NB, S->cap, S->seg, S->d_total);
+    uint32_t h_cur[SNK_OVF_SUBLISTS * SNK_OVF_CUR_STRIDE], h_sub[SNK_OVF_SUBLISTS];
+    unsigned long long h_tot64[64];
+    std::vector<unsigned long long> h_fplan(2 * SNK_MSP_PLAN_SLOTS);
+    SNK_HIP_TRY(hipMemcpyAsync(h_cur, S->ovf_cur, sizeof h_cur, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(hipMemcpyAsync(h_tot64, S->d_total, sizeof h_tot64, hipMemcpyDeviceToHost, st));
+    if (trim_now) SNK_HIP_TRY(hipMemcpyAsync(h_fplan.data(), S->d_fplan, h_fplan.size() * 8, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(snk_sync(st));
+    if (trim_now) {
+        S->h_plan[0] = S->h_plan[1] = 0;
+        for (int q = 0; q < SNK_MSP_PLAN_SLOTS; ++q) { S->h_plan[0] += h_fplan[2 * q]; S->h_plan[1] += h_fplan[2 * q + 1]; }
+    }
+    uint64_t want = 0, mx = 0, tot = 0;
+    for (uint32_t q = 0; q < SNK_OVF_SUBLISTS; ++q) { h_sub[q] = h_cur[q * SNK_OVF_CUR_STRIDE]; want += h_sub[q]; if (h_sub[q] > mx) mx = h_sub[q]; }
+    for (int q = 0; q < 64; ++q) tot += h_tot64[q];
+    if (mx > S->ovf_cap / SNK_OVF_SUBLISTS)
+        return snk_fail(SNK_E_NOMEM, err, errcap, "partition pass %u of %u: %llu supermers beyond their buckets' capacity, the overflow list holds %llu (a few minimisers carry a "
+                        "large share of the data): more passes (SNK_PARTITION_PASSES) give the list more room", r, S->P, (unsigned long long)want, (unsigned long long)S->ovf_cap);
+    S->n_supermers += tot + want;
+    S->n_overflow += want;
+    S->kernel_ms += kt.ms(0, 1);
+    if ((rc = snk_msp_segments(ctx, st, NB, S->cap, S->cursor, (uint4*)S->records, S->slots_per_pass, S->ovf_cap / SNK_OVF_SUBLISTS, S->ovf_bucket, h_sub, S->seg, err, errcap))) return rc;
     return SNK_OK;
 }
 

@@ -219,6 +219,10 @@ class Engine:
             raise _lib.SnkError(rc, err.value.decode(errors="replace"))
         self._ctx = h
 
+    def last_partition_passes(self) -> int:
+        """Bucket-range passes of the last count_graph call (1 = the one-pass partition; snk_ctx_last_partition_passes)."""
+        return int(self.lib.snk_ctx_last_partition_passes(self._ctx))
+
     def release_cache(self):
         """Hand the context's cached, unused device memory back (snk_ctx_trim): for callers that change problem size and share the GPU."""
         self.lib.snk_ctx_trim(self._ctx)

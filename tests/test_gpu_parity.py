@@ -803,6 +803,34 @@ def test_streamed_slabs_equal_the_resident_call(engine, graph_stage, name, cuts)
         engine.stream_append(rows, c.read_len, quals=quals, bc=bc, lens=lens)
 
 
+@pytest.mark.parametrize("passes", [2, 3, 7])
+@pytest.mark.parametrize("name,K", [("adversarial", 48), ("synth_20k_err", 48), ("synth_2k_err", 48)] + [(n, 60) for n in goldens.K60_CASES[:1]])
+def test_bucket_range_passes_equal_the_one_pass_partition(engine, graph_stage, name, K, passes, monkeypatch):
+    """A job whose supermer slots would not fit the device is partitioned and counted in bucket-range passes over ONE slot array, the
+    reads scanned once per pass (snk_partition_passes; the reference re-scans in passes when its records do not fit,
+    MapReduceEngine.h:452-468, utils.rs:329-341).  Forced here at golden size: the result is the golden bit for bit, with the quality
+    trim inside the first pass (rows padded to four bytes) and with the separate trim kernel."""
+    import torch
+    from supernova_amd.engine import Params
+    monkeypatch.setenv("SNK_PARTITION_PASSES", str(passes))
+    g = goldens.Case60(name) if K == 60 else None
+    c = g.base if g else goldens.load(name)
+    rows, quals, bc, lens = _to_dev(c)
+    if name != "adversarial":
+        quals = torch.nn.functional.pad(quals, (0, 160 - quals.shape[1])).contiguous()
+    res = engine.count_graph(rows, c.read_len, quals=quals, bc=bc if K == 48 else None, lens=lens, params=Params(K=K), ign_bc_below=c.ign_bc_below)
+    assert engine.last_partition_passes() == passes
+    if g:
+        assert np.array_equal(res.good_len().astype(np.uint32), g.exp_goodlens) and np.array_equal(res.keys(), g.exp_keys)
+        assert np.array_equal(np.minimum(res.counts(), (1 << 24) - 1), g.exp_counts) and np.array_equal(res.ctx(), g.exp_ctx)
+        assert res.unitigs() == g.exp_unitigs
+    else:
+        _check_against(res, c.exp_keys, c.exp_counts, c.exp_ctx, c.exp_unitigs, c.exp_goodlens, c.exp_hist)
+    monkeypatch.delenv("SNK_PARTITION_PASSES")
+    res = engine.count_graph(rows, c.read_len, quals=quals, bc=bc if K == 48 else None, lens=lens, params=Params(K=K), ign_bc_below=c.ign_bc_below)
+    assert engine.last_partition_passes() == 1
+
+
 def test_open_streamed_job_dies_with_its_arena(engine):
     """A streamed job keeps its slots, cursors and good lengths in the context's arena.  A resident call in between recycles that arena
     (snk_ctx_release_scratch): append / finish must then be refused instead of writing into memory that belongs to the new call
