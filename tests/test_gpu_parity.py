@@ -1060,7 +1060,7 @@ def test_read_paths_with_colliding_fingerprints(engine, monkeypatch, mask):
 
 
 @pytest.mark.parametrize("name", ["synth_2k_err", "adversarial", "synth_4k_dups"])
-def test_unitig_barcode_lists(engine, graph_stage, name):
+def test_unitig_barcode_lists_parity_unpinned_rust(engine, graph_stage, name):
     """The rest of f4: per-unitig barcode lists out of the pather's exact-match parts, against the plain-Python restatement of
     tada's edge -> barcode sets (every k-mer of every barcoded read looked up).  Parity unpinned: the Rust reference cannot be
     built here, the restatement follows lib/tada/src/cmd_main_asm.rs:91-151 / debruijn.rs:115-131."""
