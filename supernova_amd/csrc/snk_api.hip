@@ -377,7 +377,8 @@ void snk_ctx_release_scratch(snk_ctx* ctx) {
         ctx->va_high_prev[1] = ctx->va_high_prev[0];
         ctx->va_high_prev[0] = ctx->va_high;
         ctx->va_high = 0;
-        if (ctx->va_sealed || (recent && ctx->va_mapped > 2 * recent + ((size_t)1 << 30))) va_reset(ctx);
+        // (a call that takes plain hipMalloc blocks -- a multi-rank step -- must not sit next to tens of GB this range still maps: ADVICE r4)
+        if (ctx->va_sealed || (recent && ctx->va_mapped > 2 * recent + ((size_t)1 << 30)) || (ctx->arena_legacy && ctx->va_mapped)) va_reset(ctx);
     }
     // A new top-level call.  Blocks that neither of the last two calls took are sizes the caller has moved away from (a
     // 150 M-read run followed by 15 M-read runs): they go back to the device, where the caller's own allocator may need them.

@@ -669,9 +669,19 @@ extern "C" int snk_dev_ingest_count_graph(snk_ctx* ctx, const char* const* paths
     if (batch_pairs == 0) batch_pairs = 65536;
     const double t0 = now_s();
     uint64_t comp = 0;
-    for (uint32_t i = 0; i < n_files; ++i) { struct stat sb; if (stat(paths[i], &sb) == 0 && sb.st_size > 0) comp += (uint64_t)sb.st_size; }
-    // a read pair is ~650 bytes of text that deflate to ~130; 45 compressed bytes per read is a bound with a margin of a third
-    const uint64_t ub = total_reads_hint ? total_reads_hint : comp / 45 + 8ull * batch_pairs;
+    uint64_t isize_sum = 0;      // text bytes by the files' gzip trailers (exact for the one-member files the reference writes, below 4 GB each)
+    for (uint32_t i = 0; i < n_files; ++i) {
+        struct stat sb;
+        if (stat(paths[i], &sb) == 0 && sb.st_size > 0) {
+            comp += (uint64_t)sb.st_size;
+            if (sb.st_size >= 18) { FILE* f = fopen(paths[i], "rb"); if (f) { uint32_t is = 0; if (fseek(f, -4, SEEK_END) == 0 && fread(&is, 4, 1, f) == 1) isize_sum += is; fclose(f); } }
+        }
+    }
+    // a read pair is ~650 bytes of text that deflate to ~130; 45 compressed bytes per read is a bound with a margin of a third -- unless the
+    // files compress better than usual (binned qualities): the trailers' text sizes bound the reads as well (a read is at least its bases
+    // and qualities with their line ends), and the larger bound counts (the job used to fail late on such files)
+    const uint64_t ub_isize = isize_sum / (2ull * read_len + 2);
+    const uint64_t ub = total_reads_hint ? total_reads_hint : std::max(comp / 45, ub_isize) + 8ull * batch_pairs;
     snk_fasth_stream* fs = nullptr;
     int rc = snk_fasth_open(paths, n_files, stride, batch_pairs, threads, 1u, &fs, err, errcap);
     if (rc) return rc;
