@@ -278,7 +278,9 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
             snk_partition_passes PS;
             if ((rc = snk_partition_passes_open(ctx, st, K, in, good_len, fused ? &ft : nullptr, NB, n_passes, ub_inst, ub_live, grouped, &PS, err, errcap))) return rc;
             if (pass == 0) tm.mark();  // 3 (the partition's time is inside the count stage's here)
-            snk_count_ranges rgs{n_passes, PS.bounds, snk_partition_passes_run, &PS, true};
+            std::vector<snk_hot> pass_hots;
+            PS.hots = &pass_hots;
+            snk_count_ranges rgs{n_passes, PS.bounds, snk_partition_passes_run, &PS, true, &pass_hots};
             rc = snk_stage_count_table(ctx, st, K, PS.records, PS.seg, PS.seg + NB, 2 * NB, 2u, NB, p->min_freq, (in->bc && !grouped) ? p->min_bc : 0u, grouped ? 1u : 0u,
                                        ub_inst, status, !local_graph, &tab, err, errcap, &rgs, nullptr, nullptr, local_graph, nullptr);
             if (rc) return rc;
@@ -289,6 +291,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
             out->n_instances = h_ninst;
             out->n_supermers = part.n_supermers;
             out->n_overflow = part.n_overflow;
+            out->n_hot_buckets = PS.n_hot;
             break;
         }
         rc = snk_stage_partition(ctx, st, K, in, good_len, NB, h_plan[0], h_plan[1], grouped, status, &part, err, errcap, nullptr, fused ? h_plan : nullptr,

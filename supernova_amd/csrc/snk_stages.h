@@ -1,5 +1,7 @@
 // snk_stages.h -- internal stage interfaces shared by snk_pipeline.hip and snk_dist.hip.
 #pragma once
+#include <vector>
+
 #include "snk_ctx.h"
 #include "snk_kernels.h"
 
@@ -58,6 +60,8 @@ struct snk_count_ranges {
     // replay: the hook MAKES the records of range r (bucket-range passes: snk_partition_passes) -- a run that has to be repeated (count
     // regions too small) calls it again for every range, and its return code and message are the stage's
     bool replay = false;
+    // hot minimiser buckets the hook found and expanded in its ranges (bucket-range passes): counted behind the ranged launches, like `hot`
+    const std::vector<snk_hot>* hots = nullptr;
 };
 // pilot: the first 1/64 of the buckets is counted first; if their tables overflow as a rule (more distinct k-mers than the LDS
 // table holds: error-rich reads, shallow coverage) the stage stops there, leaves the distinct k-mers per bucket it saw in
@@ -114,6 +118,7 @@ struct snk_partition_passes {
     uint64_t ovf_cap, slots_per_pass;
     uint32_t bounds[66];
     unsigned long long h_plan[2]; uint64_t n_supermers, n_overflow; float kernel_ms; uint32_t runs;
+    std::vector<snk_hot>* hots; uint32_t n_hot;          // the passes' hot buckets, expanded while their records were there (owned by the caller)
     char* err; size_t errcap;
 };
 int snk_partition_passes_open(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_reads* in, const uint16_t* good_len, const snk_fused_trim* ft, uint32_t NB,

@@ -61,6 +61,7 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
         extra_cap = NB / 8 > (1u << 16) ? NB / 8 : (1u << 16);
         if (ctx->last_extra > extra_cap) extra_cap = ctx->last_extra + ctx->last_extra / 4;
         if (hot) extra_cap += hot->NBv + hot->NBv / 2;          // every virtual bucket reports its chunk through this list
+        if (ranges && ranges->hots) extra_cap += NB / 16 + (1u << 16);      // (bucket-range passes: the hot buckets are only known pass by pass; too small = one repeated run)
     }
     bool pilot_regrown = false;
     for (int attempt = 0; attempt < 4; ++attempt) {
@@ -165,6 +166,15 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
             }
         } else if ((rc = snk_launch_count(K, st, ca, err, errcap))) return rc;
         kt.mark();
+        if (ranges && ranges->hots && !pilot_regrow) {
+            for (const snk_hot& h : *ranges->hots) {
+                if (!h.NBv || !h.records) continue;
+                snk_count_args cv = ca;
+                cv.records = (const uint4*)h.records; cv.seg_beg = h.seg; cv.seg_end = h.seg + h.NBv; cv.seg_stride = h.NBv; cv.nseg = 1; cv.gidx = nullptr;
+                cv.vmeta = h.vmeta; cv.NB = h.NBv; cv.bucket0 = 0;
+                if ((rc = snk_launch_count(K, st, cv, err, errcap))) return rc;
+            }
+        }
         if (hot && !pilot_regrow) {
             // the hot buckets' hash classes: the same kernel over the virtual buckets, appending to the same regions and chunk list
             if (!hot->records) {        // planned, not expanded yet (sharded step): everything the expansion reads has to be there first
@@ -709,6 +719,10 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
 // ===================================================================================================================
 // Bucket-range passes (snk_stages.h): the same kernel, RANGED; every pass reuses the slot array and the overflow area.
 namespace {
+__global__ void __launch_bounds__(256) vmeta_shift_kernel(uint2* __restrict__ vm, uint32_t n, uint32_t add) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) vm[i].x += add;
+}
 __global__ void __launch_bounds__(256) seg0_range_kernel(const uint32_t* __restrict__ cursor, uint32_t b_lo, uint32_t b_hi, uint32_t NB, uint32_t cap,
                                                          uint64_t* __restrict__ seg, unsigned long long* __restrict__ total) {
     const uint32_t b = b_lo + blockIdx.x * 256 + threadIdx.x;
@@ -744,6 +758,7 @@ int snk_partition_passes_open(snk_ctx* ctx, hipStream_t st, uint32_t K, const sn
     if (passes < 1 || passes > 64 || passes > NB) return snk_fail(SNK_E_ARG, err, errcap, "partition passes: 1..64 (and at most one per bucket)");
     S->ctx = ctx; S->st = st; S->K = K; S->NB = NB; S->P = passes; S->grouped = grouped; S->in = *in; S->good_len = good_len; S->fused = ft != nullptr;
     if (ft) S->ft = *ft;
+    S->hots = nullptr; S->n_hot = 0;
     S->err = err; S->errcap = errcap; S->n_supermers = 0; S->n_overflow = 0; S->kernel_ms = 0.f; S->runs = 0; S->h_plan[0] = n_inst; S->h_plan[1] = n_live;
     double est_super = 0;
     uint64_t cap64 = 0;
@@ -779,7 +794,8 @@ int snk_partition_passes_run(void* user, uint32_t r) {
     const uint32_t NB = S->NB, b_lo = S->bounds[r], b_hi = S->bounds[r + 1];
     if (r == 0) {       // (a run of all passes starts: also a repeated one)
         SNK_HIP_TRY(hipMemsetAsync(S->cursor, 0, (NB + 1 + SNK_MSP_HOT_TAB) * 4ull, st));
-        S->n_supermers = 0; S->n_overflow = 0; S->kernel_ms = 0.f;
+        S->n_supermers = 0; S->n_overflow = 0; S->kernel_ms = 0.f; S->n_hot = 0;
+        if (S->hots) S->hots->clear();
         ++S->runs;
     }
     SNK_HIP_TRY(hipMemsetAsync(S->ovf_cur, 0, SNK_OVF_SUBLISTS * SNK_OVF_CUR_STRIDE * 4, st));
@@ -828,6 +844,18 @@ int snk_partition_passes_run(void* user, uint32_t r) {
     S->n_overflow += want;
     S->kernel_ms += kt.ms(0, 1);
     if ((rc = snk_msp_segments(ctx, st, NB, S->cap, S->cursor, (uint4*)S->records, S->slots_per_pass, S->ovf_cap / SNK_OVF_SUBLISTS, S->ovf_bucket, h_sub, S->seg, err, errcap))) return rc;
+    // hot minimiser buckets of this range (snk_hot.hip): planned from the range's part of the segment table and expanded NOW, while their
+    // records are in the slot array; the count stage counts the virtual buckets behind its ranged launches
+    if (S->hots && want) {
+        snk_hot hot;
+        if ((rc = snk_stage_hot_plan(ctx, st, S->K, S->grouped, S->seg + b_lo, S->seg + NB + b_lo, 2 * NB, 2, b_hi - b_lo, S->cap, &hot, err, errcap))) return rc;
+        if (hot.NBv) {
+            hipLaunchKernelGGL(vmeta_shift_kernel, dim3((hot.NBv + 255) / 256), dim3(256), 0, st, const_cast<uint2*>(hot.vmeta), hot.NBv, b_lo);      // (the plan numbered the range's buckets from 0)
+            if ((rc = snk_stage_hot_expand(ctx, st, S->records, &hot, err, errcap))) return rc;
+            S->n_hot += hot.n_hot;
+            S->hots->push_back(hot);
+        } else snk_stage_hot_drop(&hot);
+    }
     return SNK_OK;
 }
 

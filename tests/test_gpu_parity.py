@@ -582,8 +582,9 @@ def test_dense_partition_mode(engine, monkeypatch, name, K):
     assert res.n_overflow == 0 and res.n_supermers > 0
 
 
+@pytest.mark.parametrize("passes", [1, 3])
 @pytest.mark.parametrize("name,K", [("adversarial", 48), ("synth_20k_err", 48), ("adversarial", 60), ("synth_20k_err", 60)])
-def test_hot_buckets_are_repartitioned_by_kmer_hash(engine, monkeypatch, name, K):
+def test_hot_buckets_are_repartitioned_by_kmer_hash(engine, monkeypatch, name, K, passes):
     """snk_hot.hip: a minimiser bucket far above its capacity (a repeat family, a homopolymer run) is expanded into single-k-mer records
     that go to virtual buckets (bucket, hash class), counted by other workgroups in a second launch of the count kernel.  Forced here
     on the goldens by a tiny capacity and a tiny threshold (every overflowing bucket is 'hot', classes of ~300 instances so that they
@@ -593,6 +594,8 @@ def test_hot_buckets_are_repartitioned_by_kmer_hash(engine, monkeypatch, name, K
     monkeypatch.setenv("SNK_HOT_MIN", "8")
     monkeypatch.setenv("SNK_HOT_FACTOR", "1")
     monkeypatch.setenv("SNK_HOT_CLASS_INST", "300")
+    if passes > 1:          # bucket-range passes: the hot buckets of a range are expanded while that range's records are in the slot array
+        monkeypatch.setenv("SNK_PARTITION_PASSES", str(passes))
     if K == 48:
         c = goldens.load(name)
         rows, quals, bc, lens = _to_dev(c)
@@ -605,7 +608,7 @@ def test_hot_buckets_are_repartitioned_by_kmer_hash(engine, monkeypatch, name, K
         res = engine.count_graph(rows, c.read_len, quals=quals, bc=None, lens=lens, params=Params(K=60))
         assert np.array_equal(res.keys(), g.exp_keys) and np.array_equal(np.minimum(res.counts(), (1 << 24) - 1), g.exp_counts)
         assert np.array_equal(res.ctx(), g.exp_ctx) and res.unitigs() == g.exp_unitigs
-    assert res.n_hot_buckets > 0 and res.n_overflow > 0
+    assert res.n_hot_buckets > 0 and res.n_overflow > 0 and engine.last_partition_passes() == passes
 
 
 @pytest.mark.parametrize("persist,n_buckets", [(0, 0), (1, 0), (32, 3), (32, 5000), (1000, 5000)])
