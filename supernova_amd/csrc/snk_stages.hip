@@ -130,6 +130,10 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
                 for (uint32_t r = 0; r < n_regions; ++r) sum += h_rc[r];
                 const uint64_t need = (uint64_t)((double)sum * ((double)(NB - b0) / NBp) * 1.25 / n_regions) + 64;
                 if (need > region_cap && b0 == 0 && !pilot_regrown) { region_cap = need; *regrow = true; return SNK_OK; }
+                // ... and should the caller partition again (retarget), its next run sizes its regions from what survived here, not from the
+                // blanket instances / 12: at 1.5 % errors that is 20 GB of regions mapped for 7 GB of survivors -- on a first call the arena
+                // grows by what is asked for, at the driver's ~30 ms per GB
+                if (b0 == 0 && sum && env_u32("SNK_PILOT_EST", 1)) { ctx->last_n_kmers = (uint64_t)((double)sum * ((double)NB / NBp)); ctx->last_n_instances = n_inst_hint; }
             }
             if (pilot->agree && (r2 = pilot->agree(pilot->user, &pilot->per_bucket))) return snk_fail(SNK_E_INTERNAL, err, errcap, "count: the pilot's exchange failed (%d)", r2);
             *retarget = pilot->per_bucket > 0.85 * snk_count_limit(K, grouped) && !h_p[1];
