@@ -56,3 +56,32 @@ def test_synth_host_is_deterministic_and_shaped(snk):
     # pack/unpack round trip
     codes = synth.unpack_rows(rows, 150)
     assert np.array_equal(synth.pack_rows(codes), rows)
+
+
+def test_bench_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset) re-runs itself under torch.distributed.run on this node --
+    the driver's own N > 1 command line -- and leaves with the ranks' exit code (bench.py::self_launch).  No GPU: the launch is intercepted."""
+    import importlib.util
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    spec = importlib.util.spec_from_file_location("bench_under_test", root / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    class R:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return R()
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1", "--transport", "gloo"])
+    assert bench.self_launch(4) == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-8:] == ["--gpus", "4", "--steps", "2", "--warmup", "1", "--transport", "gloo"]
+    assert Path(cmd[cmd.index("--master-port") + 2]).name == "bench.py"
+    assert seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
