@@ -290,6 +290,10 @@ typedef struct snk_shard_result {
  * fit the device is partitioned and counted range by range over one slot array, the reads scanned once per pass -- what the reference
  * does when its k-mer records do not fit (lib/assembly/src/MapReduceEngine.h:452-468, lib/tada/src/utils.rs:329-341).  Same results. */
 uint32_t snk_ctx_last_partition_passes(const snk_ctx* ctx);
+/* Distinct k-mers one pass over a bucket could hold in the count kernel's table in the last snk_dev_count_graph on the context: 1216 of the 2048
+ * slots with the default kernel, 1920 when the call's data run the tables full (error-rich reads, per-barcode groups) and the waves book
+ * their slots instead of keeping a round's worth free (DESIGN.md 4 "round 5").  Same results either way. */
+uint32_t snk_ctx_last_count_limit(const snk_ctx* ctx);
 /* total_reads: reads of the whole job (sizes the bucket count without an exchange; 0 = the ranks exchange their slab sizes,
  * ignored when p->n_buckets is set).  in->read_index_base = global index of the slab's first read. */
 int snk_shard_step(snk_ctx* ctx, snk_comm* comm, const snk_dev_reads* in, const snk_params* p, uint64_t total_reads, uint32_t flags,

@@ -396,6 +396,7 @@ void snk_ctx_release_scratch(snk_ctx* ctx) {
     }
 }
 extern "C" uint32_t snk_ctx_last_partition_passes(const snk_ctx* ctx) { return ctx ? ctx->last_partition_passes : 0u; }
+extern "C" uint32_t snk_ctx_last_count_limit(const snk_ctx* ctx) { return ctx ? ctx->last_count_limit : 0u; }
 extern "C" void snk_ctx_trim(snk_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);

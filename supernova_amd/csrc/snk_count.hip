@@ -28,6 +28,9 @@ namespace {
 constexpr uint32_t BC_MULTI = 0xFFFFFFFEu;
 constexpr uint32_t BC_IGN = 0xFFFFFFFFu;      // (a read under the ignore rule: larger than BC_MULTI, so the atomicMax of the merges keeps it)
 static_assert(BC_IGN > BC_MULTI, "barcode states are merged with atomicMax");
+#ifndef SNK_TIGHT_TRIES
+#define SNK_TIGHT_TRIES 48
+#endif
 constexpr int MAX_SPLIT_LOG2 = 20;      // (split ids are 24-bit fields; the split stack in ctl[] holds 24 entries)
 #define SNK_COUNT_MAXSEG 32      // record segments per bucket (sharded runs: one per source rank)
 #ifndef SNK_COUNT_THREADS
@@ -82,7 +85,7 @@ typedef __attribute__((address_space(3))) void* snk_lptr;
 // MULTI: more than one record segment per bucket.  GATHER (dense partition, snk_stages.hip): a bucket is a range of an index list, record v of
 // the bucket is records[gidx[v]] -- the LDS-DMA fetch takes a per-lane address, so a gathered batch costs what a contiguous one does
 // plus the (coalesced) read of its indices.
-template <int K, int THREADS, int SLOTS, bool GROUPED, bool MULTI, bool GATHER = false>
+template <int K, int THREADS, int SLOTS, bool GROUPED, bool MULTI, bool GATHER = false, bool TIGHT = false>
 __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a) {
     // supermers staged per batch.  A 4000-instance bucket holds ~270 (sigma ~100): with 512 slots nearly every bucket is
     // ONE batch (with 256, 55 % of the buckets ran a second, mostly empty batch through all the phases below).  K=60 and
@@ -105,7 +108,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     // addresses on both sides.  16-byte aligned (every array before it is a multiple of 16 bytes).
     uint32_t* rec = ctxw + SLOTS / 4;
     uint32_t* ctl = rec + 8 * BATCH;                                                // [64] control words
-    uint32_t* dd = ctl + 64;                                                        // [DD] supermer de-duplication table (leader index + 1)
+    uint32_t* dd = ctl + (TIGHT ? 72 : 64);                                                        // [DD] supermer de-duplication table (leader index + 1)
     uint32_t* wgt = dd + DD;                                                        // [BATCH] copies folded into each leader
     uint16_t* lead = reinterpret_cast<uint16_t*>(wgt + BATCH);                      // [BATCH] r-th leading (non-folded) supermer
     uint16_t* lpre = lead + BATCH;                                                  // [BATCH+2] one past its last k-mer instance
@@ -115,7 +118,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     // minBC > 2 (areEnoughBarcodes counts DISTINCT barcodes for any minBC, BuildReadQGraph48.cc:117-137): six more barcode ids
     // per slot behind the one in bcs[] -- up to seven distinct ids are told apart exactly, an eighth turns the state into MULTI
     // (so min_bc <= 8).  Only allocated for such runs (a.bc_mode > 2); they give up the second workgroup per CU.
-    uint32_t* bcx = reinterpret_cast<uint32_t*>(smem_raw + (((size_t)(reinterpret_cast<unsigned char*>(olist + (SLOTS - THREADS - 64)) - smem_raw) + 15) & ~(size_t)15));   // [SLOTS][6]
+    uint32_t* bcx = reinterpret_cast<uint32_t*>(smem_raw + (((size_t)(reinterpret_cast<unsigned char*>(olist + (TIGHT ? SLOTS - 64 : SLOTS - THREADS - 64)) - smem_raw) + 15) & ~(size_t)15));   // [SLOTS][6]
     const bool bcset = a.bc_mode > 2;
     // ctl[1..2] occupied slots (by pass parity; more than LIMIT = the pass overflows), ctl[3] most slots used so far,
     // ctl[4..7] / ctl[12..15] record bounds of the bucket (segment 0; by bucket parity), ctl[8..9] placement counter (by pass
@@ -123,7 +126,11 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     static_assert(THREADS >= BATCH && THREADS % 64 == 0, "the first BATCH threads own the staged records");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    constexpr uint32_t LIMIT = SLOTS - THREADS - 64;   // distinct k-mers one sub-pass may hold
+    // distinct k-mers one sub-pass may hold.  TIGHT: a wave books a slot for every lane that is about to probe (ctl[64..65], by pass
+    // parity; bit 31 = the pass is over capacity) and hands back what its lanes did not claim, so the table fills to 7/8 and the probe loops
+    // still always find a free slot; otherwise nobody books anything and the margin is one round of every wave (below)
+    const uint32_t LIMIT = TIGHT ? (a.tight & 0xFFFFu) : SLOTS - THREADS - 64;
+    const int tight_tries = (int)(a.tight >> 16);
 #ifdef SNK_COUNT_PROF
     long long prof_t = clock64();
     unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -208,6 +215,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
             ctl[4] = (uint32_t)b0; ctl[5] = (uint32_t)(b0 >> 32); ctl[6] = (uint32_t)e0; ctl[7] = (uint32_t)(e0 >> 32);
             ctl[3] = 0;
             ctl[1] = 0; ctl[2] = 0; ctl[8] = 0; ctl[9] = 0; ctl[10] = 0; ctl[11] = 0;
+            if (TIGHT) { ctl[64] = 0; ctl[65] = 0; }
         }
         for (int s = tid; s < SLOTS; s += THREADS) tag[s] = 0;      // from here on a pass leaves the table empty behind it
         if (MULTI && tid < (int)a.nseg) {
@@ -276,11 +284,12 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
         const uint32_t split_mask = (1u << split_lg) - 1u;
         uint32_t* occ = ctl + 1 + q;            // distinct k-mers of this pass
         uint32_t* place = ctl + 8 + q;          // its survivors
+        uint32_t* resv = ctl + 64 + q;          // (TIGHT) slots booked: claimed + asked for by the rounds in flight
         uint64_t vbeg, vend;
         bucket_range(bcur, segc, vbeg, vend);
         if (vbeg >= vend) {                     // a bucket without records: nothing is staged, what happens behind 'staged' happens here
             lds_barrier();
-            if (tid == 0) { ctl[1 + (q ^ 1u)] = 0; ctl[8 + (q ^ 1u)] = 0; }
+            if (tid == 0) { ctl[1 + (q ^ 1u)] = 0; ctl[8 + (q ^ 1u)] = 0; if (TIGHT) ctl[64 + (q ^ 1u)] = 0; }
             if (seg_pending) {
                 uint64_t nbeg, nend, nsb; uint32_t nse;
                 load_next(nbeg, nend, nsb, nse);
@@ -299,7 +308,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my share of the batch is in LDS (and everything older has landed)
                 lds_barrier();                                       // 'staged'
                 PROF(2);
-                if (tid == 0) { ctl[1 + (q ^ 1u)] = 0; ctl[8 + (q ^ 1u)] = 0; ctl[10 + (bq ^ 1u)] = 0; }
+                if (tid == 0) { ctl[1 + (q ^ 1u)] = 0; ctl[8 + (q ^ 1u)] = 0; ctl[10 + (bq ^ 1u)] = 0; if (TIGHT) ctl[64 + (q ^ 1u)] = 0; }
                 // the next bucket's bounds: asked for here (behind the wait for the batch -- vmcnt counts in order), put down
                 // before the insert phase, read when it is over
                 const bool fetch_next = seg_pending;
@@ -376,7 +385,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                 // looks at the occupancy before each round of 64 insertions and stops above LIMIT, so at most THREADS claims
                 // can follow the one that crossed the line -- LIMIT + THREADS < SLOTS, the probe loops always find a free slot.
                 for (uint32_t g0 = 0; g0 < total; g0 += THREADS) {
-                    if (LDS_LOAD(occ) > LIMIT) break;
+                    if (TIGHT ? (LDS_LOAD(resv) >> 31) != 0u : LDS_LOAD(occ) > LIMIT) break;
                     const uint32_t g = g0 + tid;
                     if (g < total) {
                         uint32_t lr = cidx[g >> 5];
@@ -432,6 +441,42 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                             const lo_type clo = klo_pack<K, GROUPED>(c.lo);
                             const uint32_t mytag = (h2 & ~1u) | 2u;     // never 0; bit 0 = the slot's fields are in place
                             bool claimed = false;
+                            // TIGHT: book one slot per probing lane of this wave (the lanes in here); a booking that does not fit ends the pass
+                            // (the lanes of this round insert nothing: the pass is counted again in halves)
+                            bool go = true;
+                            uint32_t need = 0;
+                            int rl = 0;
+                            if constexpr (TIGHT) {
+                                const unsigned long long pm = __ballot(1);
+                                rl = __ffsll((long long)pm) - 1;
+                                need = (uint32_t)__popcll(pm);
+                                uint32_t r = 0;
+                                if (lane == rl) {
+                                    r = atomicAdd(resv, need);
+                                    if ((r & 0x7FFFFFFFu) + need > LIMIT && !(r >> 31)) {
+                                        // no room next to what the rounds in flight have booked: most of that comes back (their lanes find their
+                                        // k-mers in the table).  Hand the booking back and look again a few times -- a bounded wait, nobody
+                                        // waits while holding a booking -- unless the claims alone leave no room
+                                        atomicSub(resv, need);
+                                        r = 0x80000000u;
+                                        for (int tries = 0; tries < tight_tries; ++tries) {
+                                            if (LDS_LOAD(occ) + need > LIMIT) break;
+                                            const uint32_t rv = LDS_LOAD(resv);
+                                            if (rv >> 31) break;
+                                            if (rv + need <= LIMIT) {
+                                                const uint32_t r2 = atomicAdd(resv, need);
+                                                if (r2 >> 31) break;
+                                                if (r2 + need <= LIMIT) { r = r2; break; }
+                                                atomicSub(resv, need);
+                                            }
+                                            __builtin_amdgcn_s_sleep(2);
+                                        }
+                                        if (r >> 31) atomicOr(resv, 0x80000000u);
+                                    }
+                                }
+                                go = (__shfl(r, rl) >> 31) == 0u;
+                            }
+                            if (go) {
                             // find-or-claim.  The inner loop is the common case and nothing else: step over slots that hold
                             // other fingerprints (one tag load each).  It stops at an empty slot or at my fingerprint.
                             for (;;) {
@@ -465,6 +510,10 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                                 if (khi[slot] == c.hi && klo[slot] == clo) break;
                                 slot = (slot + stride) & (SLOTS - 1);
                             }
+                            if constexpr (TIGHT) {
+                                const uint32_t nc = (uint32_t)__popcll(__ballot(claimed));
+                                if (lane == rl && need > nc) atomicSub(resv, need - nc);      // (bit 31 stays: need - nc <= the count below it)
+                            }
                             if (claimed) {
                                 // one reservation per wave for the lanes that claimed in this round (same-address LDS atomics are served one lane at a time: 43.2 -> 42.5 ms)
                                 const unsigned long long cm = __ballot(1);
@@ -492,6 +541,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                                     }
                                 }
                             }
+                            }
                         }
                     }
                 }
@@ -501,7 +551,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
             }
         }
         // (every batch ends with a barrier: the occupancy and the table are final here)
-        if (LDS_LOAD(occ) > LIMIT) {   // too many distinct k-mers for one table: split this pass in two by one more hash bit
+        if (TIGHT ? (LDS_LOAD(resv) >> 31) != 0u : LDS_LOAD(occ) > LIMIT) {   // too many distinct k-mers for one table: split this pass in two by one more hash bit
             if (split_lg >= MAX_SPLIT_LOG2) { if (tid == 0) atomicExch(&a.status[1], 1u); }
             else {
                 if (tid == 0) {
@@ -568,6 +618,22 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
         }
         lds_barrier();                                               // 'written'
         const uint32_t nvalid = LDS_LOAD(place);
+        if constexpr (TIGHT) {
+            // more survivors than one chunk of the bucket-local graph stage holds: count the pass again in halves (the survivors just written
+            // are overwritten: the cursor stays; the table is empty, the other parity's counters are zero as behind any pass)
+            if (a.chunk_n && nvalid > SNK_GRAPH_CHUNK_MAX && split_lg < MAX_SPLIT_LOG2) {
+                if (tid == 0) {
+                    ctl[16 + 2 * sp] = split_lg + 1; ctl[17 + 2 * sp] = split_id;
+                    ctl[18 + 2 * sp] = split_lg + 1; ctl[19 + 2 * sp] = split_id | (1u << split_lg);
+                }
+                sp += 2;
+                ++splits_done;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the next bucket's first batch, if it was asked for, has landed before rec[] is fetched again)
+                prefetched = false;
+                q ^= 1u;
+                continue;
+            }
+        }
         if (nvalid) {
             rcur += nvalid;                       // keeps counting past the capacity: the host learns what the region needs
             if (tid == 0) {
@@ -605,9 +671,9 @@ template <> struct cfg<48> { static constexpr int THREADS = SNK_COUNT_THREADS; s
 template <> struct cfg<60> { static constexpr int THREADS = SNK_COUNT_THREADS; static constexpr int SLOTS = SNK_COUNT_SLOTS; };
 
 template <int K, bool G>
-size_t lds_bytes(uint32_t bc_mode = 0) {
+size_t lds_bytes(uint32_t bc_mode = 0, bool tight = false) {
     constexpr size_t S = cfg<K>::SLOTS, B = (K == 48 && !G && S >= 2048) ? 512 : 256, DD = 2 * B, NCI = B * (K - SNK_M_MIN_OF(K) + 1) / 32 + 2;
-    return S * (8 + sizeof(typename klo_t<K, G>::type) + 4 + 4 + 4) + S + 4 * (8 * B + 64 + DD + B) + 2 * (B + B + 2 + NCI) + 16 + 2 * 4 * 3 * SNK_COUNT_MAXSEG + 2 * (S - cfg<K>::THREADS - 64) + 16 + (bc_mode > 2 ? S * 24 + 16 : 0);
+    return S * (8 + sizeof(typename klo_t<K, G>::type) + 4 + 4 + 4) + S + 4 * (8 * B + (tight ? 72 : 64) + DD + B) + 2 * (B + B + 2 + NCI) + 16 + 2 * 4 * 3 * SNK_COUNT_MAXSEG + 2 * (tight ? S - 64 : S - cfg<K>::THREADS - 64) + 16 + (bc_mode > 2 ? S * 24 + 16 : 0);
 }
 
 template <int K, bool G>
@@ -617,7 +683,9 @@ int launch(hipStream_t st, const snk_count_args& a, char* err, size_t errcap) {
         if (a.nseg != 1) return snk_fail(SNK_E_INTERNAL, err, errcap, "count: an index list comes with one segment per bucket");
         kern = snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G, false, true>;
     }
-    size_t lds = lds_bytes<K, G>(a.bc_mode);
+    const bool tight = a.tight && !a.gidx;
+    if (tight) kern = a.nseg > 1 ? snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G, true, false, true> : snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G, false, false, true>;
+    size_t lds = lds_bytes<K, G>(a.bc_mode, tight);
     SNK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (a.bucket0 >= a.NB) return SNK_OK;          // the launch covers buckets [bucket0, NB)
     // one workgroup per output region, every launch of a table (the ranged launches of the sharded path) with the same grid:
@@ -678,7 +746,11 @@ int snk_launch_compact_regions(hipStream_t st, const snk_u128* keys_in, const ui
 
 uint32_t snk_count_slots(uint32_t K) { return K == 60 ? cfg<60>::SLOTS : cfg<48>::SLOTS; }
 
-uint32_t snk_count_limit(uint32_t K, uint32_t grouped) { (void)grouped; return K == 48 ? cfg<48>::SLOTS - cfg<48>::THREADS - 64 : cfg<60>::SLOTS - cfg<60>::THREADS - 64; }
+uint32_t snk_count_limit(uint32_t K, uint32_t grouped, uint32_t tight) {
+    (void)grouped;
+    const uint32_t S = K == 48 ? cfg<48>::SLOTS : cfg<60>::SLOTS, T = K == 48 ? cfg<48>::THREADS : cfg<60>::THREADS;
+    return tight ? (tight & 0xFFFFu) : S - T - 64;
+}
 int snk_count_regions(uint32_t K, uint32_t grouped, uint32_t nseg, uint32_t NB, uint32_t bc_mode, uint32_t* n_regions, char* err, size_t errcap) {
     if (grouped) return regions<48, true>(nseg, NB, bc_mode, n_regions, err, errcap);
     if (K == 60) return regions<60, false>(nseg, NB, bc_mode, n_regions, err, errcap);

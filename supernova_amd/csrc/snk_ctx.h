@@ -50,6 +50,7 @@ struct snk_ctx {
     uint64_t last_ovf_reads = 0;
     uint64_t last_dense = 0;                            // supermer records of the last dense partition pass (last_ovf_nb == 0xD0000000)
     double retain_ratio = 0.0;                         // retained k-mers per k-mer instance of the last call (same key as claim_ratio)
+    uint32_t count_tight = 0;                          // this call's count launches book their table slots (error-rich data, per-barcode groups: fuller tables, fewer buckets)
     double claim_ratio = 0.0;                          // distinct k-mers per k-mer instance the count kernel saw in the last call ...
     uint64_t claim_ratio_reads = 0;                    // ... over this many reads ...
     uint32_t claim_ratio_k = 0;                        // ... in this mode (2 K + grouped + 256 x minimiser length)
@@ -57,6 +58,7 @@ struct snk_ctx {
     uint32_t last_extra = 0;                           // split sub-passes the previous call recorded
     uint64_t last_input_fp = 0;                        // fingerprint of the last resident call's reads (snk_pipeline.hip): other data of the same size must not inherit its sizing history
     bool have_input_fp = false;
+    uint32_t last_count_limit = 0;                     // usable table slots of the last resident call's count launches (snk_ctx_last_count_limit)
     uint32_t last_partition_passes = 1;                // bucket-range passes of the last resident call (snk_ctx_last_partition_passes)
     std::vector<unsigned long long> h_region_off;      // host copy of the count regions' dense offsets (source of an async upload)
     void* shard = nullptr;      // snk_shard_state (snk_dist.hip)

@@ -77,6 +77,9 @@ int snk_launch_msp_plan(hipStream_t st, const uint16_t* good_len, uint64_t n_rea
                         char* err, size_t errcap);
 
 // ---- snk_count.hip
+// the most k-mers one chunk of the bucket-local graph stage holds (snk_local.hip: the big-chunk kernels' LDS); a count sub-pass that retains
+// more is counted again in two halves
+constexpr uint32_t SNK_GRAPH_CHUNK_MAX = 1280;
 struct snk_count_args {
     const uint4* records;          // supermer records, 2 x uint4 each
     const uint64_t* seg_beg;       // [nseg][seg_stride] first record of every bucket in every segment (absolute)
@@ -90,6 +93,7 @@ struct snk_count_args {
     uint32_t bc_mode;              // = minBC: 0 no barcode rule, 1: >=1 barcode>0 (or ignore-rule read), 2: >=2 distinct (state machine), 3..8: id sets
     uint32_t bucket0;              // first bucket of this launch (set by the launcher)
     uint32_t bucket_stride;        // set by the launcher (= n_regions): workgroup w counts the buckets == w (mod stride)
+    uint32_t tight;                // the table fills to 7/8: waves book their slots (snk_count.hip, TIGHT)
     uint32_t grouped;              // record word 7 is a group id that becomes the low 32 bits of the key (K=48 only)
     snk_u128* out_keys;            // canonical k-mer values (hi<<64|lo); region r owns [r*region_cap, (r+1)*region_cap):
                                    // one region per workgroup of the (persistent) launch, bucket b goes to region b % n_regions

@@ -791,7 +791,7 @@ static int excl_scan(snk_ctx* ctx, hipStream_t st, const T* in, T* out, size_t c
 }
 
 constexpr int SCAP = 256, ST = 64;      // small chunks: one wave per chunk
-constexpr int BCAP = 1280, BT = 256;    // big chunks (a count sub-pass retains at most SLOTS - THREADS - 64 = 1216 k-mers)
+constexpr int BCAP = SNK_GRAPH_CHUNK_MAX, BT = 256;    // big chunks (a count sub-pass that retains more is counted again in halves: snk_count.hip)
 
 namespace {
 // ---- sharded runs: membership queries for pending neighbours that belong to another rank

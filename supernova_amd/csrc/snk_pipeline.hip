@@ -210,20 +210,38 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
         ctx->last_input_fp = h_fp; ctx->have_input_fp = true;
         if (!same_data) { ctx->last_n_kmers = 0; ctx->last_bnd = 0; }       // (the count regions' and the boundary index's sizes were that data's)
     }
-    const uint32_t default_target = grouped ? 900u : (K == 48 ? 5000u : 3500u);
+    // The count kernel has two ways to keep its probe loops supplied with free slots (snk_count.hip): a margin of one round of every wave
+    // (1216 of 2048 slots usable, nothing to pay per round) or booked slots (15/16 usable, one LDS atomic round trip per wave and round:
+    // 45.1 instead of 43.0 ms on the bench model).  Data whose tables run full -- sequencing errors, per-barcode groups -- are counted the
+    // second way: fewer, fuller buckets (1.5 % errors: 8.4 M -> 5.6 M buckets, 218 -> 188 ms; 0.6 %: 149 -> 136; groups: 183 -> 177).
+    // SNK_COUNT_TIGHT = 0 never, = n always with n usable slots.
+    ctx->count_tight = 0;
+    const uint32_t plain_target = K == 48 ? 5000u : 3500u;
+    auto tight_for = [&](double ratio) -> uint32_t {
+        const uint32_t tries = env_u32("SNK_TIGHT_TRIES", 48) << 16;
+        if (getenv("SNK_COUNT_TIGHT") && *getenv("SNK_COUNT_TIGHT")) {
+            const uint32_t v = env_u32("SNK_COUNT_TIGHT", 0);
+            return v ? (std::min(std::max(v, 256u), snk_count_slots(K) - 64u) | tries) : 0u;
+        }
+        const bool full = grouped || (ratio > 0.0 && 0.65 * (double)snk_count_limit(K, 0u, 0u) / ratio < (double)plain_target);
+        return full ? ((snk_count_slots(K) - snk_count_slots(K) / 16u) | tries) : 0u;
+    };
+    // (per-barcode groups: nearly every instance is a distinct entry, the bucket IS the table: three quarters of its capacity on average)
+    auto default_target_now = [&]() -> uint32_t { return grouped ? (uint32_t)(0.74 * snk_count_limit(K, 1u, ctx->count_tight)) : plain_target; };
     const bool target_forced = getenv("SNK_TARGET_INST") && *getenv("SNK_TARGET_INST");
     // ... and the RETAINED k-mers of a bucket are one chunk of the bucket-local graph stage, whose one-wave kernels hold 256 of them
     // (larger chunks take the slower big-chunk variants): at half the coverage twice as many k-mers survive per instance, every other
     // chunk was over the line and the graph stage took 81 instead of ~58 ms.  From the previous call's retained share: chunks of ~150.
     const double retain = (same_data && ctx->retain_ratio > 0.0 && ctx->claim_ratio_reads == n_reads && ctx->claim_ratio_k == K * 2 + (grouped ? 1u : 0u) + 256u * ctx->mlen) ? ctx->retain_ratio : 0.0;
     auto target_for = [&](double ratio) -> uint32_t {
+        const uint32_t default_target = default_target_now();
         if (target_forced) return env_u32("SNK_TARGET_INST", default_target);
         if (retain > 0.0 && !grouped) {
             const double t = (double)env_u32("SNK_CHUNK_KMERS", 150) / retain;
             if (t < (double)default_target) {
                 uint32_t tt = t < 600.0 ? 600u : (uint32_t)t;
                 if (ratio > 0.0) {           // the tighter of the two limits
-                    const double lim = (double)snk_count_limit(K, 0u);
+                    const double lim = (double)snk_count_limit(K, 0u, ctx->count_tight);
                     if (0.65 * lim / ratio < (double)default_target) {
                         const double t2 = 0.01 * env_u32("SNK_BUCKET_FILL_PCT", 50) * lim / ratio;
                         if (t2 < (double)tt) tt = t2 < 600.0 ? 600u : (uint32_t)t2;
@@ -235,7 +253,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
         if (!(ratio > 0.0)) return default_target;
         // measured: the default size is right while the tables run up to ~65 % full on average (the bench model: 800 of 1216); data
         // that would fill them further do best at ~50 % (0.6 % errors: 239 ms with the default size, 186 at 80 %, 154 at 50 %)
-        const double lim = (double)snk_count_limit(K, grouped ? 1u : 0u);
+        const double lim = (double)snk_count_limit(K, grouped ? 1u : 0u, ctx->count_tight);
         if (0.65 * lim / ratio >= (double)default_target) return default_target;
         const double t = 0.01 * env_u32("SNK_BUCKET_FILL_PCT", 50) * lim / ratio;
         return t >= (double)default_target ? default_target : (t < 600.0 ? 600u : (uint32_t)t);
@@ -252,6 +270,8 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     const unsigned long long ub_inst = h_plan[0], ub_live = h_plan[1];
     for (int pass = 0; pass < 2; ++pass) {
         NB = p->n_buckets;
+        ctx->count_tight = tight_for(adaptive ? ratio : (have_hint ? ctx->claim_ratio : 0.0));
+        ctx->last_count_limit = snk_count_limit(K, grouped ? 1u : 0u, ctx->count_tight);
         if (NB == 0) {
             const uint32_t target = target_for(adaptive ? ratio : 0.0);
             uint64_t nb = (ub_inst + target - 1) / target;
@@ -386,6 +406,7 @@ extern "C" int snk_dev_stream_begin(snk_ctx* ctx, const snk_params* p, uint32_t 
     if (p->K != 48 && p->K != 60) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "K=%u is not supported (48 or 60)", p->K);
     if (p->min_bc > 8) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "min_bc=%u: the device barcode rule tells up to eight distinct barcodes apart (min_bc <= 8)", p->min_bc);
     snk_set_mlen(ctx, p);
+    ctx->count_tight = 0;          // (a streamed job cannot partition again: the default kernel and its bucket rule)
     if (read_len == 0 || read_len > 256 || total_reads_ub == 0) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_stream_begin: read_len 1..256 and an upper bound of the job's reads are needed");
     if ((p->flags & SNK_F_GROUPED)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_dev_stream_begin: per-group graphs take their reads resident (snk_dev_count_graph)");
     SNK_HIP_TRY(hipSetDevice(ctx->device));
@@ -410,7 +431,7 @@ extern "C" int snk_dev_stream_begin(snk_ctx* ctx, const snk_params* p, uint32_t 
         uint32_t target = K == 48 ? 5000u : 3500u;
         if (getenv("SNK_TARGET_INST") && *getenv("SNK_TARGET_INST")) target = env_u32("SNK_TARGET_INST", target);
         else if (ctx->claim_ratio > 0.0 && ctx->claim_ratio_reads == total_reads_ub && ctx->claim_ratio_k == K * 2 + 256u * ctx->mlen) {
-            const double lim = (double)snk_count_limit(K, 0u);
+            const double lim = (double)snk_count_limit(K, 0u, ctx->count_tight);
             if (0.65 * lim / ctx->claim_ratio < (double)target) {
                 const double t = 0.01 * env_u32("SNK_BUCKET_FILL_PCT", 50) * lim / ctx->claim_ratio;
                 target = t < 600.0 ? 600u : (uint32_t)t;

@@ -187,7 +187,7 @@ uint32_t plan_buckets(uint64_t inst_ub, uint32_t world, uint32_t K, uint32_t for
         const char* e = getenv("SNK_TARGET_INST");
         if (!(e && *e) && ratio > 0.0 && snk_env_u32("SNK_ADAPTIVE_BUCKETS", 1)) {
             // (the rule of the one-GPU path, snk_pipeline.hip: smaller buckets when the tables would run more than ~65 % full)
-            const double lim = (double)snk_count_limit(K, 0);
+            const double lim = (double)snk_count_limit(K, 0u, 0u);
             if (0.65 * lim / ratio < (double)dflt) { const double t = 0.01 * snk_env_u32("SNK_BUCKET_FILL_PCT", 50) * lim / ratio; target = t < 600.0 ? 600u : (uint64_t)t; if (target > dflt) target = dflt; }
         }
         nb = (inst_ub + target - 1) / target;
@@ -212,6 +212,7 @@ int excl_scan(step_ctx& X, In in, Out* out, size_t n, Out init) {
 }
 
 int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_params* p, uint64_t total_reads, uint32_t flags, snk_shard_result* out) {
+    X.ctx->count_tight = 0;        // (the ranks size their buckets alike, from one rule: the default count kernel's)
     snk_ctx* ctx = X.ctx;
     snk_comm* comm = X.comm;
     hipStream_t st = X.st;
@@ -807,6 +808,7 @@ extern "C" int snk_shard_stream_begin(snk_ctx* ctx, snk_comm* comm, const snk_pa
     ctx->cur_stream = st;
     const uint32_t W = comm->world, K = p->K;
     ctx->arena_legacy = W > 1;
+    ctx->count_tight = 0;
     snk_set_mlen(ctx, p);
     const uint64_t kpr = read_len >= K ? read_len - K + 1 : 0;
     const uint64_t inst_ub = total_reads * kpr;

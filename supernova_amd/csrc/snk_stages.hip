@@ -86,6 +86,7 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
         ca.min_freq = min_freq;
         ca.bc_mode = bc_mode;
         ca.grouped = grouped;
+        ca.tight = ctx->count_tight;
         ca.bucket0 = 0;
         ca.out_keys = keys_r;
         ca.out_vals = vals_r;
@@ -136,7 +137,7 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
                 if (b0 == 0 && sum && env_u32("SNK_PILOT_EST", 1)) { ctx->last_n_kmers = (uint64_t)((double)sum * ((double)NB / NBp)); ctx->last_n_instances = n_inst_hint; }
             }
             if (pilot->agree && (r2 = pilot->agree(pilot->user, &pilot->per_bucket))) return snk_fail(SNK_E_INTERNAL, err, errcap, "count: the pilot's exchange failed (%d)", r2);
-            *retarget = pilot->per_bucket > 0.85 * snk_count_limit(K, grouped) && !h_p[1];
+            *retarget = pilot->per_bucket > 0.85 * snk_count_limit(K, grouped, ctx->count_tight) && !h_p[1];
             return SNK_OK;
         };
         if (ranges && ranges->n && (attempt == 0 || ranges->replay)) {

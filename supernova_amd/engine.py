@@ -219,6 +219,10 @@ class Engine:
             raise _lib.SnkError(rc, err.value.decode(errors="replace"))
         self._ctx = h
 
+    def last_count_limit(self) -> int:
+        """Usable count-table slots per pass in the last count_graph call (1216, or 1920 with booked slots; snk_ctx_last_count_limit)."""
+        return int(self.lib.snk_ctx_last_count_limit(self._ctx))
+
     def last_partition_passes(self) -> int:
         """Bucket-range passes of the last count_graph call (1 = the one-pass partition; snk_ctx_last_partition_passes)."""
         return int(self.lib.snk_ctx_last_partition_passes(self._ctx))

@@ -207,6 +207,7 @@ def _declare(lib: C.CDLL) -> None:
         "snk_dev_unpack2": (C.c_int, [vp, vp, u64, vp, vp]),
         "snk_host_cpu_budget": (u32, []),
         "snk_ctx_last_partition_passes": (u32, [vp]),
+        "snk_ctx_last_count_limit": (u32, [vp]),
         "snk_fasth_open": (C.c_int, [P(cp), u32, u32, u32, u32, u32, P(vp), cp, sz]),
         "snk_fasth_next": (C.c_int, [vp, P(SnkFasthBatch), cp, sz]),
         "snk_fasth_release": (None, [vp, P(SnkFasthBatch)]),

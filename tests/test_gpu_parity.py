@@ -81,6 +81,32 @@ def test_bucket_count_independence(engine, n_buckets):
     _check_against(res, c.exp_keys, c.exp_counts, c.exp_ctx, c.exp_unitigs, c.exp_goodlens, c.exp_hist)
 
 
+@pytest.mark.parametrize("case,K,n_buckets,slots", [("adversarial", 48, 1, 1920), ("adversarial", 48, 7, 300), ("synth_20k_err", 48, 3, 1920),
+                                                    ("synth_20k_err", 48, 16, 700), ("synth_20k_err", 60, 2, 1920), ("synth_20k_err", 48, 0, 1984)])
+def test_booked_table_slots_count_the_same_table(engine, monkeypatch, case, K, n_buckets, slots):
+    """The count kernel's second variant (snk_count.hip, TIGHT: waves book their slots, the table fills to `slots` of 2048 instead of
+    1216, a pass that retains more than one graph chunk's worth is counted again in halves) gives the table and the unitigs of the
+    default one -- with buckets that overflow and split (few buckets), with a small limit (bookings fail all the time), at K=60."""
+    from supernova_amd.engine import Params
+    g = goldens.Case60(case) if K == 60 else goldens.load(case)
+    c = g.base if K == 60 else g
+    rows, quals, bc, lens = _to_dev(c)
+    monkeypatch.setenv("SNK_COUNT_TIGHT", str(slots))
+    res = engine.count_graph(rows, c.read_len, quals=quals, bc=bc if K == 48 else None, lens=lens, params=Params(K=K, n_buckets=n_buckets),
+                             ign_bc_below=c.ign_bc_below)
+    assert engine.last_count_limit() == slots
+    if n_buckets == 1:
+        assert res.buckets_split >= 1
+    if K == 48:
+        _check_against(res, c.exp_keys, c.exp_counts, c.exp_ctx, c.exp_unitigs, c.exp_goodlens, c.exp_hist)
+    else:
+        assert np.array_equal(res.keys(), g.exp_keys) and np.array_equal(np.minimum(res.counts(), (1 << 24) - 1), g.exp_counts)
+        assert np.array_equal(res.ctx(), g.exp_ctx) and res.unitigs() == g.exp_unitigs
+    monkeypatch.setenv("SNK_COUNT_TIGHT", "0")
+    engine.count_graph(rows, c.read_len, quals=quals, bc=bc if K == 48 else None, lens=lens, params=Params(K=K, n_buckets=n_buckets), ign_bc_below=c.ign_bc_below)
+    assert engine.last_count_limit() == 1216
+
+
 @pytest.mark.parametrize("n_reads,error_free", [(200_000, False), (100_000, True)])
 def test_synth_vs_oracle(engine, n_reads, error_free):
     """Device generator == host generator, and the full path == oracle on a seeded workload of the bench's shape."""
@@ -240,6 +266,7 @@ def test_error_rich_reads_are_repartitioned_into_smaller_buckets(engine, monkeyp
         monkeypatch.setenv("SNK_ADAPTIVE_BUCKETS", "0")
         r0 = e.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48, sorted_table=False))
         assert r0.repartitioned == 0 and r0.buckets_split > r0.n_buckets // 2
+        assert e.last_count_limit() == 1216          # (nothing known about the data: the default kernel)
         ref = table(r0)
         nb0 = r0.n_buckets
         monkeypatch.setenv("SNK_ADAPTIVE_BUCKETS", "1")
@@ -247,6 +274,7 @@ def test_error_rich_reads_are_repartitioned_into_smaller_buckets(engine, monkeyp
         try:
             r1 = e2.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48, sorted_table=False))
             assert r1.repartitioned == 1 and r1.n_buckets > 1.5 * nb0 and r1.buckets_split < r1.n_buckets // 4
+            assert e2.last_count_limit() == 1920     # tables that run full: the second partition is counted with booked slots
             got = table(r1)
             assert all(np.array_equal(a, b) for a, b in zip(ref[:3], got[:3])) and ref[3] == got[3]
             r2 = e2.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48, sorted_table=False))      # the hint: no second partition
