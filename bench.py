@@ -224,7 +224,7 @@ ROBUST = (("errors_0.6pct", dict(sub_ppm=6000)),
           ("crowded_minimiser_space", dict(repeat_mode=16)))
 
 
-def robust_rows(eng, per_gpu, K, headline_ms):
+def robust_rows(eng, per_gpu, K, headline_ms, arena_bytes=0):
     """The same step off the bench's operating point, 100 M reads each, on the SAME engine (arena warm, like the timed
     steps): the first call on the new data (it may look at the first buckets and partition a second time) and the better of the next two
     (the figure: the second call still sizes the arena for the new bucket count).  Every model also exists as a 200 k-read digest of the REFERENCE's result (tests/golden/big_hashes.json robust_*) that
@@ -233,12 +233,14 @@ def robust_rows(eng, per_gpu, K, headline_ms):
     from supernova_amd import synth
     from supernova_amd.engine import Params
     out = {}
+    arena_seen = int(arena_bytes)          # the arena the timed steps left behind
     for name, ov in ROBUST:
         ov = dict(ov) if ov is not None else dict(genome_len=per_gpu * 150 // 28)
         sp = synth.synth_params(per_gpu, seed=0x5EED0042, **ov)
         rows, quals, bc = eng.synth(sp)
         torch.cuda.synchronize()
         calls = []
+        arena_before = arena_seen
         for rep in range(3):        # the first call meets new data (it may partition twice), the second sizes the arena for it, the third is steady state
             t0 = time.perf_counter()
             r = eng.count_graph(rows, sp.read_len, quals=quals, bc=bc, params=Params(K=K, sorted_table=False))
@@ -246,9 +248,13 @@ def robust_rows(eng, per_gpu, K, headline_ms):
             calls.append(((time.perf_counter() - t0) * 1e3, int(r.repartitioned)))
             if rep == 0:
                 first_phases = {k: round(v, 1) for k, v in r.phase_ms.items() if k in ("partition", "count", "graph", "total")}
-                first_phases.update(buckets=int(r.n_buckets), buckets_split=int(r.buckets_split))
+                # (a first call that needs more device memory than anything the context has seen also pays the driver for the arena's
+                # growth, ~25-30 ms per GB of freshly mapped memory, inside whichever stage asks for it)
+                first_phases.update(buckets=int(r.n_buckets), buckets_split=int(r.buckets_split), arena_gb=round(r.scratch_bytes / 2**30, 1),
+                                    arena_grew_gb=round(max(0, r.scratch_bytes - arena_before) / 2**30, 1))
             if calls[-1][0] > 20000:       # a pathological case is reported, not repeated
                 break
+        arena_seen = max(arena_seen, int(r.scratch_bytes))
         ms = min(c[0] for c in calls[1:]) if len(calls) > 1 else calls[0][0]
         out[name] = {"ms": round(ms, 2), "Gkmers_per_s": round(r.n_instances / ms / 1e6, 2), "vs_headline_ms": round(ms / headline_ms, 3),
                      "first_call_ms": round(calls[0][0], 2), "first_call_repartitioned": calls[0][1], "first_call_phases": first_phases, "calls_ms": [round(c[0], 1) for c in calls],
@@ -527,7 +533,7 @@ def main():
                                               "a13_a14_ms": round(sum(tail_ms[-args.steps:]) / max(1, args.steps), 3)}
             if not args.no_robust and not args.error_free and per_gpu >= 10_000_000:
                 try:
-                    out["config"]["robust"] = robust_rows(eng, per_gpu, K, ms_per_step)
+                    out["config"]["robust"] = robust_rows(eng, per_gpu, K, ms_per_step, int(getattr(res, "scratch_bytes", 0)))
                 except Exception as ex:
                     out["config"]["robust"] = {"failed": str(ex)}
             if not args.no_next_rows:
