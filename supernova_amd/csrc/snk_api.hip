@@ -378,7 +378,7 @@ void snk_ctx_release_scratch(snk_ctx* ctx) {
         ctx->va_high_prev[0] = ctx->va_high;
         ctx->va_high = 0;
         // (a call that takes plain hipMalloc blocks -- a multi-rank step -- must not sit next to tens of GB this range still maps: ADVICE r4)
-        if (ctx->va_sealed || (recent && ctx->va_mapped > 2 * recent + ((size_t)1 << 30)) || (ctx->arena_legacy && ctx->va_mapped)) va_reset(ctx);
+        if (ctx->va_sealed || (recent && ctx->va_mapped > std::max(2 * recent + ((size_t)1 << 30), ctx->va_floor)) || (ctx->arena_legacy && ctx->va_mapped)) va_reset(ctx);
     }
     // A new top-level call.  Blocks that neither of the last two calls took are sizes the caller has moved away from (a
     // 150 M-read run followed by 15 M-read runs): they go back to the device, where the caller's own allocator may need them.
@@ -397,8 +397,20 @@ void snk_ctx_release_scratch(snk_ctx* ctx) {
 }
 extern "C" uint32_t snk_ctx_last_partition_passes(const snk_ctx* ctx) { return ctx ? ctx->last_partition_passes : 0u; }
 extern "C" uint32_t snk_ctx_last_count_limit(const snk_ctx* ctx) { return ctx ? ctx->last_count_limit : 0u; }
+extern "C" int snk_ctx_reserve(snk_ctx* ctx, uint64_t bytes, char* err, size_t errcap) {
+    if (!ctx) return snk_fail(SNK_E_ARG, err, errcap, "snk_ctx_reserve: NULL context");
+    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    if (!va_init(ctx)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_ctx_reserve: the growing arena is switched off (SNK_ARENA_VMM=0) or not available");
+    if (ctx->va_sealed && ctx->va_used.empty()) va_reset(ctx);
+    if (ctx->va_state <= 0) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_ctx_reserve: no address range for the arena");
+    if (bytes > ctx->va_mapped && !va_grow(ctx, bytes - ctx->va_mapped))
+        return snk_fail(SNK_E_NOMEM, err, errcap, "snk_ctx_reserve: %.1f GB asked for, %.1f GB mapped", bytes / 1073741824.0, ctx->va_mapped / 1073741824.0);
+    ctx->va_floor = bytes;
+    return SNK_OK;
+}
 extern "C" void snk_ctx_trim(snk_ctx* ctx) {
     if (!ctx) return;
+    ctx->va_floor = 0;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     snk_ctx_trim_cache(ctx);

@@ -36,6 +36,7 @@ struct snk_ctx {
     std::vector<size_t> va_chunk;           // bytes of every mapped chunk (they follow each other from va_base)
     std::vector<vrange> va_free;            // sorted by offset, coalesced
     std::vector<vrange> va_used;
+    size_t va_floor = 0;                    // snk_ctx_reserve: this much stays mapped whatever the last calls used
     int va_state = 0;                       // 0 untried, 1 in use, -1 off
     bool va_sealed = false;                 // chunks were unmapped behind live ranges: no growth until the reservation is replaced
     struct vser { size_t off; uint64_t serial; };

@@ -227,6 +227,14 @@ class Engine:
         """Bucket-range passes of the last count_graph call (1 = the one-pass partition; snk_ctx_last_partition_passes)."""
         return int(self.lib.snk_ctx_last_partition_passes(self._ctx))
 
+    def reserve(self, n_bytes: int):
+        """Map n_bytes of device memory into the context's scratch arena now and keep them mapped between calls (snk_ctx_reserve): a call
+        that outgrows the arena otherwise pays the driver ~25-30 ms per new GB inside the call."""
+        err = C.create_string_buffer(512)
+        rc = self.lib.snk_ctx_reserve(self._ctx, int(n_bytes), err, 512)
+        if rc != 0:
+            raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+
     def release_cache(self):
         """Hand the context's cached, unused device memory back (snk_ctx_trim): for callers that change problem size and share the GPU."""
         self.lib.snk_ctx_trim(self._ctx)

@@ -167,6 +167,7 @@ def _declare(lib: C.CDLL) -> None:
         "snk_ctx_create": (C.c_int, [C.c_int, P(vp), cp, sz]),
         "snk_ctx_destroy": (None, [vp]),
         "snk_ctx_trim": (None, [vp]),
+        "snk_ctx_reserve": (C.c_int, [vp, u64, cp, sz]),
         "snk_synth_default": (None, [P(SnkSynthParams), u64, u64, C.c_int]),
         "snk_synth_set_errors": (None, [P(SnkSynthParams), u32]),
         "snk_synth_host": (C.c_int, [P(SnkSynthParams), u64, u64, vp, u32, vp, u32, vp]),

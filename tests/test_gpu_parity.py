@@ -310,6 +310,32 @@ def test_ctx_trim_gives_memory_back_and_the_context_still_works(engine):
     assert np.array_equal(k1[:, :3], c.exp_keys)
 
 
+def test_ctx_reserve_maps_the_arena_ahead_of_the_calls():
+    """snk_ctx_reserve: the arena holds the reserved bytes before the first call, calls of any size leave them mapped (a small call after a
+    reservation does not hand it back), the results are the ones of an unreserved context, and snk_ctx_trim lets go of it."""
+    import torch
+    from supernova_amd.engine import Engine, Params
+    c = goldens.load("synth_20k_err")
+    rows, quals, bc, lens = _to_dev(c)
+    e = Engine(0)
+    try:
+        free0 = torch.cuda.mem_get_info()[0]
+        e.reserve(6 << 30)
+        assert free0 - torch.cuda.mem_get_info()[0] >= (6 << 30) - (64 << 20)
+        for _ in range(4):
+            r = e.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, params=Params(K=48), ign_bc_below=c.ign_bc_below)
+            assert free0 - torch.cuda.mem_get_info()[0] >= (6 << 30) - (64 << 20)         # (small calls do not hand the reservation back)
+        _check_against(r, c.exp_keys, c.exp_counts, c.exp_ctx, c.exp_unitigs, c.exp_goodlens, c.exp_hist)
+        del r
+        e.release_cache()
+        assert free0 - torch.cuda.mem_get_info()[0] < 2 << 30
+        with pytest.raises(Exception):
+            e.reserve(1 << 50)
+    finally:
+        e.close()
+        torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("name,use_bc", [("adversarial", True), ("synth_20k_err", False)])
 def test_k60_vs_oracle(engine, name, use_bc):
     """K=60 (long-k config): key 120 bit, supermers up to 106 bases.  The reference's BuildReadQGraph60 has no barcode

@@ -7,6 +7,7 @@ from supernova_amd import synth
 from supernova_amd.engine import Engine, Params
 n = 100_000_000
 e = Engine(0)
+if os.environ.get('R5_RESERVE_GB'): e.reserve(int(os.environ['R5_RESERVE_GB']) << 30); print('reserved GB', os.environ['R5_RESERVE_GB'], flush=True)
 models = [("bench", {}), ("e06", dict(sub_ppm=6000)), ("e15", dict(sub_ppm=15000, lowq_tail_ppm=500000)), ("bench", {}), ("e06", dict(sub_ppm=6000)), ("e15", dict(sub_ppm=15000, lowq_tail_ppm=500000))]
 for name, ov in models:
     sp = synth.synth_params(n, seed=0x5EED0042, **ov); rows, quals, bc = e.synth(sp); torch.cuda.synchronize()
