@@ -543,6 +543,46 @@ def test_full_size_properties_1e8(engine, graph_stage):
     assert torch.equal(a["off"], b["off"]) and torch.equal(a["bases"], b["bases"])
 
 
+def test_full_size_booked_slots_1e8(engine, graph_stage, monkeypatch):
+    """100 M reads with 1.5 % substitutions and long low-quality tails (config.robust's second model) at full size: the call that lets the
+    data switch the count kernel to booked table slots (snk_ctx_last_count_limit = 1920: 2.6 x the distinct k-mers of clean reads) gives the
+    table -- checksum over keys, counts and contexts -- and the unitigs of the default kernel on smaller buckets."""
+    import torch
+    from supernova_amd import synth
+    from supernova_amd.engine import Engine, Params
+    if graph_stage == "global":
+        pytest.skip("one pass over the full size is enough")
+    n = 100_000_000
+    sp = synth.synth_params(n, seed=0x5EED0042, sub_ppm=15000, lowq_tail_ppm=500000)
+    e = Engine(0)
+    try:
+        rows, quals, bc = e.synth(sp)
+
+        def run():
+            r = e.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48))
+            nk = r.n_kmers
+            keys = torch.as_tensor(_DevArr(r.raw.keys, 2 * nk, "<i8"), device="cuda").view(nk, 2)
+            cnt = torch.as_tensor(_DevArr(r.raw.counts, nk, "<i4"), device="cuda")
+            ctx = torch.as_tensor(_DevArr(r.raw.ctx, nk, "|u1"), device="cuda")
+            chk = (keys[:, 1] * 0x9E3779B97F4A7C15 + keys[:, 0] * 0x42B2AE3D27D4EB4F + cnt.to(torch.int64) * 0x165667B19E3779F9
+                   + ctx.to(torch.int64) * 0x27D4EB2F165667C5).sum()
+            off = torch.as_tensor(_DevArr(r.raw.unitig_off, r.n_unitigs + 1, "<i8"), device="cuda")
+            bases = torch.as_tensor(_DevArr(r.raw.unitig_bases, r.unitig_total_bases, "|u1"), device="cuda")
+            return dict(n_inst=r.n_instances, nk=nk, chk=int(chk), nu=r.n_unitigs, nb=r.n_buckets, off=off.clone(), bases=bases.clone(), lim=e.last_count_limit())
+
+        run()                       # (the first call looks at the first buckets and partitions again)
+        a = run()
+        assert a["lim"] == 1920 and a["nk"] > 200_000_000
+        monkeypatch.setenv("SNK_COUNT_TIGHT", "0")
+        b = run()
+        assert b["lim"] == 1216 and b["nb"] > a["nb"]
+        assert (a["n_inst"], a["nk"], a["chk"], a["nu"]) == (b["n_inst"], b["nk"], b["chk"], b["nu"])
+        assert torch.equal(a["off"], b["off"]) and torch.equal(a["bases"], b["bases"])
+    finally:
+        e.close()
+        torch.cuda.empty_cache()
+
+
 def test_unsorted_table_mode(engine, graph_stage):
     """SNK_F_UNSORTED_TABLE: same table (as a set) and the same unitigs, keys left in bucket order."""
     from supernova_amd.engine import Params

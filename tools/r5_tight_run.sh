@@ -1,7 +1,7 @@
 #!/bin/bash
-# round 5: the count kernel's TIGHT variant switched on by the data (snk_pipeline.hip): suite + the bench rows
-timeout 2400 python -m pytest tests -m gpu -x -q --timeout 300 2>&1 | tail -4
+# round 5: the TIGHT count kernel with larger buckets on the bench's own (clean) reads
 B="--steps 4 --warmup 2 --no-cpu-baseline --no-next-rows --no-ingest --no-robust"
 P="import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print(round(d['ms_per_step'],2), round(d['value'],2), d['config']['phase_ms_rank0'])"
-for x in "" "--grouped" "--k 60"; do echo -n "auto $x: "; timeout 200 python bench.py $B $x 2>/dev/null | python -c "$P"; done
-timeout 300 python tools/err_probe.py 1e8 e06,e15 2>&1 | grep -v amdgpu | grep "call" | sed "s/^/auto /"
+echo -n "default: "; timeout 200 python bench.py $B 2>/dev/null | python -c "$P"
+for t in 5000 6000 7000 8000 9000; do echo -n "tight=1920 target $t: "; SNK_COUNT_TIGHT=1920 SNK_TARGET_INST=$t timeout 200 python bench.py $B 2>/dev/null | python -c "$P"; done
+for t in 4500 5500; do echo -n "k60 tight=1920 target $t: "; SNK_COUNT_TIGHT=1920 SNK_TARGET_INST=$t timeout 200 python bench.py $B --k 60 2>/dev/null | python -c "$P"; done
