@@ -1,6 +1,4 @@
 #!/bin/bash
-# round 5: TIGHT count kernel, booking sent before the hash (whole-bucket passes) with the bounded wait in place
-for lib in supernova_amd/libsnk.so supernova_amd/variants/libsnk_early.so; do
-export SNK_LIB_PATH=$PWD/$lib
-timeout 300 python tools/err_probe.py 1e8 e06,e15 2>&1 | grep -v amdgpu | grep "call 3" | sed "s|^|$lib |"
-done
+# round 5: thread-0 phase profile of the count kernel (SNK_COUNT_PROF build) on clean / 0.6 % / 1.5 % reads
+export SNK_LIB_PATH=$PWD/supernova_amd/variants/libsnk_prof.so
+timeout 300 python tools/err_probe.py 1e8 headline,e06,e15 2>&1 | grep -v amdgpu | grep "call 3\|snk prof" | tail -40
