@@ -179,15 +179,22 @@ int all_ranges_ready(void* user) {       // the whole exchange has landed (the h
     return 0;
 }
 
-uint32_t plan_buckets(uint64_t inst_ub, uint32_t world, uint32_t K, uint32_t forced, double ratio) {
+uint32_t plan_buckets(uint64_t inst_ub, uint32_t world, uint32_t K, uint32_t forced, double ratio, uint32_t* tight_out = nullptr) {
     uint64_t nb = forced;
+    if (tight_out) *tight_out = 0;
     if (!nb) {
         const uint32_t dflt = K == 48 ? 5000u : 3500u;
         uint64_t target = snk_env_u32("SNK_TARGET_INST", dflt);
         const char* e = getenv("SNK_TARGET_INST");
         if (!(e && *e) && ratio > 0.0 && snk_env_u32("SNK_ADAPTIVE_BUCKETS", 1)) {
             // (the rule of the one-GPU path, snk_pipeline.hip: smaller buckets when the tables would run more than ~65 % full)
-            const double lim = (double)snk_count_limit(K, 0u, 0u);
+            double lim = (double)snk_count_limit(K, 0u, 0u);
+            // (tables that run full are counted with booked slots, as on the one-GPU path: every rank takes the same turn, the ratio is job-wide)
+            const char* te = getenv("SNK_COUNT_TIGHT");
+            if (tight_out && 0.65 * lim / ratio < (double)dflt && !(te && *te == '0')) {
+                *tight_out = (snk_count_slots(K) - snk_count_slots(K) / 16u) | (snk_env_u32("SNK_TIGHT_TRIES", 48) << 16);
+                lim = (double)snk_count_limit(K, 0u, *tight_out);
+            }
             if (0.65 * lim / ratio < (double)dflt) { const double t = 0.01 * snk_env_u32("SNK_BUCKET_FILL_PCT", 50) * lim / ratio; target = t < 600.0 ? 600u : (uint64_t)t; if (target > dflt) target = dflt; }
         }
         nb = (inst_ub + target - 1) / target;
@@ -397,7 +404,7 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
     for (int pass = 0; pass < 2; ++pass) {
         // (a streamed step sized its buckets when it was opened -- the same rule on the same job-wide figures -- and cannot partition twice: its
         // slabs are gone; error-rich data without the group's history are counted in hash-split sub-passes then)
-        NB_total = X.streamed ? snk_shard_state_of(ctx)->NB_total : plan_buckets(inst_ub, W, K, p->n_buckets, adaptive ? ratio : 0.0);
+        { uint32_t tight = 0; NB_total = X.streamed ? snk_shard_state_of(ctx)->NB_total : plan_buckets(inst_ub, W, K, p->n_buckets, adaptive ? ratio : 0.0, &tight); ctx->count_tight = tight; ctx->last_count_limit = snk_count_limit(K, 0u, tight); }
         NBl = NB_total / W;
         tm.n = 1;
         const int rcp = count_pass(adaptive && !have_ratio && pass == 0 && p->n_buckets == 0 && !X.streamed);

@@ -434,7 +434,7 @@ def test_sharded_bucket_size_follows_the_data(snk, n):
             for step in range(2):
                 res = sh.count_graph(rows[lo:hi].contiguous(), 150, quals=quals[lo:hi].contiguous(), bc=bc[lo:hi].contiguous(), params=Params(K=48),
                                      read_index_base=lo, total_reads=n)
-                outs[step][r] = dict(keys=res.keys(), counts=res.counts(), unitigs=res.unitigs(), nb=int(res.raw.n_buckets_total), rep=int(res.raw.repartitioned))
+                outs[step][r] = dict(keys=res.keys(), counts=res.counts(), unitigs=res.unitigs(), nb=int(res.raw.n_buckets_total), rep=int(res.raw.repartitioned), lim=e.last_count_limit())
             e.close()
         except BaseException as ex:  # noqa: BLE001
             errs.append(ex)
@@ -454,7 +454,9 @@ def test_sharded_bucket_size_follows_the_data(snk, n):
         assert np.array_equal(keys[order], ref_keys) and np.array_equal(counts[order], ref_counts)
         assert sorted(u for o in outs[step] for u in o["unitigs"]) == ref_unitigs
         assert outs[step][0]["nb"] == outs[step][1]["nb"]
+    assert all(o["lim"] == 1920 for o in outs[1])        # tables that run full: booked slots, on every rank (snk_count.hip TIGHT)
     if n < 2_000_000:
+        assert outs[0][0]["lim"] == 1216
         assert outs[0][0]["rep"] == 0 and outs[1][0]["nb"] > 1.5 * outs[0][0]["nb"]
     else:
         assert outs[0][0]["rep"] == 1 and outs[0][1]["rep"] == 1 and outs[1][0]["rep"] == 0
