@@ -621,7 +621,8 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
         if constexpr (TIGHT) {
             // more survivors than one chunk of the bucket-local graph stage holds: count the pass again in halves (the survivors just written
             // are overwritten: the cursor stays; the table is empty, the other parity's counters are zero as behind any pass)
-            if (a.chunk_n && nvalid > SNK_GRAPH_CHUNK_MAX && split_lg < MAX_SPLIT_LOG2) {
+            if (a.chunk_n && nvalid > SNK_GRAPH_CHUNK_MAX && split_lg >= MAX_SPLIT_LOG2) { if (tid == 0) atomicExch(&a.status[1], 1u); }      // (the host fails the call)
+            else if (a.chunk_n && nvalid > SNK_GRAPH_CHUNK_MAX) {
                 if (tid == 0) {
                     ctl[16 + 2 * sp] = split_lg + 1; ctl[17 + 2 * sp] = split_id;
                     ctl[18 + 2 * sp] = split_lg + 1; ctl[19 + 2 * sp] = split_id | (1u << split_lg);
