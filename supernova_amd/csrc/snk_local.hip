@@ -45,9 +45,11 @@ struct chunk_src {
     const uint4* extra;
     const unsigned long long* region_off;
     uint32_t NB, n_extra, n_regions;
+    const uint8_t* span;           // [NB] buckets merged into the chunk that starts here (bl_chunk_merge_kernel), or NULL
 };
 struct chunk_t {
     uint32_t bucket, n, lg, id;
+    uint32_t span;                 // > 1: the chunk holds the survivors of `span` consecutive buckets of its count workgroup (bucket, bucket + G, ...)
     uint64_t base;
 };
 // The count kernel leaves its survivors in per-workgroup regions (region r = bucket % n_regions holds region_cursor[r] entries at
@@ -63,10 +65,33 @@ struct bl_regions {
 // sharded runs: this rank owns global buckets [bucket_base, bucket_base + NBl); NBl == 0 -> one GPU owns everything
 struct bl_shard {
     uint32_t bucket_base, NBl, me;
+    uint32_t G;                  // bucket stride of a count workgroup (= the table's regions): the buckets of a merged chunk lie G apart
     uint8_t* premote;            // [n] pending bits whose k-mer belongs to another rank, or NULL
 };
-// one 16-byte record per chunk (dense position, k-mers, bucket, split_lg << 24 | split_id): every chunk kernel starts
-// with ONE load instead of a chain of three dependent ones
+// Small chunks cost the chunk kernels their fixed part (table clear, barriers, an under-filled wave): a count workgroup writes the survivors
+// of its buckets b, b + G, b + 2G, ... behind each other into its region, so neighbouring unsplit buckets ARE one contiguous run of k-mers --
+// they are handed to the graph stage as one chunk while the run fits the one-wave kernels (`cap` k-mers).  More neighbours are found inside
+// a chunk, never fewer; a miss whose bucket is one of the chunk's is absent as before.  An empty bucket ends a run (it may be a split or
+// hot bucket, whose survivors lie elsewhere).  One thread per region; error-rich reads: 5.6 M buckets of ~49 survivors.
+__global__ void __launch_bounds__(256) bl_chunk_merge_kernel(uint32_t* __restrict__ chunk_n, const uint32_t* __restrict__ chunk_base, uint32_t NB, uint32_t G,
+                                                             uint32_t cap, uint8_t* __restrict__ span) {
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= G) return;
+    uint32_t head = NONE, total = 0, m = 0, expect = 0;
+    for (uint32_t b = r; b < NB; b += G) {
+        const uint32_t n = chunk_n[b];
+        span[b] = 1;
+        if (n == 0) { head = NONE; continue; }
+        const uint32_t base = chunk_base[b];
+        if (head != NONE && base == expect && total + n <= cap && m < 255u) {
+            total += n; ++m;
+            chunk_n[head] = total; chunk_n[b] = 0; span[head] = (uint8_t)m;
+        } else { head = b; total = n; m = 1; }
+        expect = base + n;
+    }
+}
+// one 16-byte record per chunk (dense position, k-mers, bucket, split_lg << 24 | split_id -- or 1 << 31 | merged buckets): every chunk
+// kernel starts with ONE load instead of a chain of three dependent ones
 __global__ void __launch_bounds__(256) bl_chunk_desc_kernel(chunk_src cs, uint32_t nchunks, uint4* __restrict__ desc, uint64_t region_cap, uint64_t* __restrict__ desc_src) {
     const uint32_t c = blockIdx.x * 256 + threadIdx.x;
     if (c >= nchunks) return;
@@ -75,6 +100,7 @@ __global__ void __launch_bounds__(256) bl_chunk_desc_kernel(chunk_src cs, uint32
         bucket = c; n = cs.chunk_n[c];
         if (n) off = cs.chunk_base[c];
         region = bucket % cs.n_regions;
+        if (cs.span && n && cs.span[c] > 1) meta = 0x80000000u | cs.span[c];
     } else {
         const uint4 e = cs.extra[c - cs.NB];
         bucket = e.x; off = e.y; n = e.z & 0xFFFu; region = e.z >> 12; meta = e.w;      // (a hot bucket's classes are counted by other workgroups than the bucket's own: snk_hot.hip)
@@ -86,7 +112,8 @@ __global__ void __launch_bounds__(256) bl_chunk_desc_kernel(chunk_src cs, uint32
 __device__ __forceinline__ chunk_t chunk_get(const uint4* __restrict__ desc, uint32_t c) {
     const uint4 d = desc[c];
     chunk_t k;
-    k.base = d.x; k.n = d.y; k.bucket = d.z; k.lg = d.w >> 24; k.id = d.w & 0xFFFFFFu;
+    k.base = d.x; k.n = d.y; k.bucket = d.z; k.lg = d.w >> 24; k.id = d.w & 0xFFFFFFu; k.span = 1;
+    if (d.w >> 31) { k.lg = 0; k.id = 0; k.span = d.w & 0xFFFFu; }
     return k;
 }
 
@@ -271,7 +298,8 @@ __device__ __forceinline__ void bl_prune_chunk(const uint32_t c, const uint4* __
                 const uint32_t nkey = snk_mmer_key_top<MM>(wn);
                 if (nkey < mk) mk = nkey;
                 const uint32_t gb = snk_bucket_of_key(mk ^ (GR ? snk_group_mix((uint32_t)ktag) : 0u), NB);   // (global) bucket of the neighbour
-                bool here = gb == sh.bucket_base + ch.bucket;
+                const uint32_t db = gb - (sh.bucket_base + ch.bucket);          // (wraps below the chunk's first bucket: then no multiple of G below span * G... checked)
+                bool here = ch.span == 1 ? db == 0u : (gb >= sh.bucket_base + ch.bucket && db % sh.G == 0u && db / sh.G < ch.span);
                 const bool remote = sh.NBl && gb / sh.NBl != sh.me;              // lives (if anywhere) on another rank
                 if (here && ch.lg) {
                     const snk_kmer r = snk_kmer_rc<K>(y);
@@ -878,6 +906,17 @@ static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* er
     cs.NB = tab->NB;
     cs.n_extra = tab->n_extra;
     cs.n_regions = tab->n_regions;
+    cs.span = nullptr;
+    // (SNK_CHUNK_MERGE = k-mers a merged chunk may hold, 0 = off: 1.5 % errors graph 43.0 -> 38.9 ms, 0.6 % 33.9 -> 32.9, groups 15.1 -> 13.6,
+    // K=60 29.5 -> 28.2, the bench's reads 29.65 -> 29.4)
+    const uint32_t merge_cap = std::min<uint32_t>(snk_env_u32("SNK_CHUNK_MERGE", (uint32_t)SCAP), (uint32_t)SCAP);
+    if (merge_cap && tab->chunk_n && tab->NB > tab->n_regions) {
+        uint8_t* span;
+        G_ALLOC(span, uint8_t, (uint64_t)tab->NB + 1);
+        hipLaunchKernelGGL(bl_chunk_merge_kernel, dim3((tab->n_regions + 255) / 256), dim3(256), 0, st, const_cast<uint32_t*>(tab->chunk_n), tab->chunk_base, tab->NB, tab->n_regions,
+                           merge_cap, span);
+        cs.span = span;
+    }
     const uint32_t nchunks = tab->NB + tab->n_extra;
     B->nchunks = nchunks;
     G_ALLOC(B->desc, uint4, (uint64_t)nchunks + 1);
@@ -904,6 +943,7 @@ static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* er
     sh.bucket_base = B->premote ? B->rank * B->NBl : 0u;
     sh.NBl = B->premote ? B->NBl : 0u;
     sh.me = B->rank;
+    sh.G = tab->n_regions ? tab->n_regions : 1u;
     sh.premote = B->premote;
     const uint32_t NBh = B->premote ? B->NB_total : tab->NB;      // bucket count of the minimiser hash
     const uint32_t cpw = 1;
