@@ -946,7 +946,7 @@ static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* er
     sh.G = tab->n_regions ? tab->n_regions : 1u;
     sh.premote = B->premote;
     const uint32_t NBh = B->premote ? B->NB_total : tab->NB;      // bucket count of the minimiser hash
-    const uint32_t cpw = 1;
+    const uint32_t cpw = std::max(1u, snk_env_u32("SNK_BL_CPW", 4));      // (chunks per workgroup: merged-away chunks are empty; 1 -> 4: graph 29.2 -> 28.8 ms, 1.5 % errors 38.7 -> 37.6)
     // boundary index, filled by the prune kernel itself: sized from what the previous call of this context found for a table of
     // this size (first call: n / 5); too small = too full -> the separate build pass below redoes it with the exact size
     uint64_t tg0 = 0;
