@@ -85,7 +85,15 @@ typedef __attribute__((address_space(3))) void* snk_lptr;
 // MULTI: more than one record segment per bucket.  GATHER (dense partition, snk_stages.hip): a bucket is a range of an index list, record v of
 // the bucket is records[gidx[v]] -- the LDS-DMA fetch takes a per-lane address, so a gathered batch costs what a contiguous one does
 // plus the (coalesced) read of its indices.
-template <int K, int THREADS, int SLOTS, bool GROUPED, bool MULTI, bool GATHER = false, bool TIGHT = false>
+// SCREEN (per-barcode groups, a.screen = min(min_freq, 3) >= 2): inside one barcode a locus is read once or twice -- nine instances in ten are
+// the only one of their (group, k-mer) and every one of them is a claim, the expensive path, that the filter throws away.  A one-batch bucket
+// of up to SNK_SCREEN_ROUNDS rounds first runs all its instances through a three-level bit filter (three planes of 8192 bits in the memory of the
+// de-duplication table and the weights, which grouped runs do not use: an instance sets its cell's bit in the first plane that does not have it yet), remembers each
+// instance's cell in registers (two per register), and then inserts only the instances whose cell reached the level -- compacted into a list first, so that
+// the insert rounds run with full waves.  A k-mer whose own instances do not reach min_freq cannot be retained; what shares a cell only
+// over-admits (5 % at 3000 instances); the table still counts what is admitted and the filter still decides.  Buckets of more than one batch,
+// of more rounds, or with more candidates than the list holds are counted as before.
+template <int K, int THREADS, int SLOTS, bool GROUPED, bool MULTI, bool GATHER = false, bool TIGHT = false, bool SCREEN = false>
 __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a) {
     // supermers staged per batch.  A 4000-instance bucket holds ~270 (sigma ~100): with 512 slots nearly every bucket is
     // ONE batch (with 256, 55 % of the buckets ran a second, mostly empty batch through all the phases below).  K=60 and
@@ -120,6 +128,14 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     // (so min_bc <= 8).  Only allocated for such runs (a.bc_mode > 2); they give up the second workgroup per CU.
     uint32_t* bcx = reinterpret_cast<uint32_t*>(smem_raw + (((size_t)(reinterpret_cast<unsigned char*>(olist + (TIGHT ? SLOTS - 64 : SLOTS - THREADS - 64)) - smem_raw) + 15) & ~(size_t)15));   // [SLOTS][6]
     const bool bcset = a.bc_mode > 2;
+#ifndef SNK_SCREEN_ROUNDS
+#define SNK_SCREEN_ROUNDS 6
+#endif
+    constexpr int SROUNDS = SNK_SCREEN_ROUNDS;                        // SCREEN: instances per lane (their cells ride in two registers)
+    static_assert(SROUNDS >= 1 && SROUNDS <= 6, "two 13-bit cells per register");
+    constexpr uint32_t SCAND = 1024;                                   // SCREEN: candidate list (instance indices), in bcx's place (grouped runs have no barcode rule)
+    uint16_t* cand = reinterpret_cast<uint16_t*>(bcx);
+    static_assert(!SCREEN || (GROUPED && DD == 512 && BATCH == 256), "the screen's three planes of 8192 bits are the de-duplication table and the weights of grouped runs (neither is used there)");
     // ctl[1..2] occupied slots (by pass parity; more than LIMIT = the pass overflows), ctl[3] most slots used so far,
     // ctl[4..7] / ctl[12..15] record bounds of the bucket (segment 0; by bucket parity), ctl[8..9] placement counter (by pass
     // parity), ctl[10..11] instances | leaders << 16 of the batch (by batch parity), ctl[16..16+2*MAX) split stack (17 levels)
@@ -214,7 +230,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
             if (bucket < a.NB) { b0 = a.seg_beg[bucket]; e0 = a.seg_end[bucket]; }
             ctl[4] = (uint32_t)b0; ctl[5] = (uint32_t)(b0 >> 32); ctl[6] = (uint32_t)e0; ctl[7] = (uint32_t)(e0 >> 32);
             ctl[3] = 0;
-            ctl[1] = 0; ctl[2] = 0; ctl[8] = 0; ctl[9] = 0; ctl[10] = 0; ctl[11] = 0;
+            ctl[1] = 0; ctl[2] = 0; ctl[8] = 0; ctl[9] = 0; ctl[10] = 0; ctl[11] = 0; ctl[0] = 0;      // (ctl[0]: SCREEN's candidate counter)
             if (TIGHT) { ctl[64] = 0; ctl[65] = 0; }
         }
         for (int s = tid; s < SLOTS; s += THREADS) tag[s] = 0;      // from here on a pass leaves the table empty behind it
@@ -303,12 +319,12 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                 // ---- stage one batch of supermer records
                 if (!prefetched) dma_batch(base, vend, bcur, segc);
                 prefetched = false;
-                if (tid < BATCH) wgt[tid] = 1;
+                if (tid < BATCH) wgt[tid] = SCREEN ? 0u : 1u;        // (SCREEN: the third bit plane; nothing folds in grouped runs, every weight is 1)
                 for (int q = tid; q < DD; q += THREADS) dd[q] = 0;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my share of the batch is in LDS (and everything older has landed)
                 lds_barrier();                                       // 'staged'
                 PROF(2);
-                if (tid == 0) { ctl[1 + (q ^ 1u)] = 0; ctl[8 + (q ^ 1u)] = 0; ctl[10 + (bq ^ 1u)] = 0; if (TIGHT) ctl[64 + (q ^ 1u)] = 0; }
+                if (tid == 0) { ctl[1 + (q ^ 1u)] = 0; ctl[8 + (q ^ 1u)] = 0; ctl[10 + (bq ^ 1u)] = 0; if (TIGHT) ctl[64 + (q ^ 1u)] = 0; if (SCREEN) ctl[0] = 0; }
                 // the next bucket's bounds: asked for here (behind the wait for the batch -- vmcnt counts in order), put down
                 // before the insert phase, read when it is over
                 const bool fetch_next = seg_pending;
@@ -384,17 +400,82 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                 // A sub-pass overflows when it holds more than LIMIT distinct k-mers.  Nobody polls a flag while probing: a wave
                 // looks at the occupancy before each round of 64 insertions and stops above LIMIT, so at most THREADS claims
                 // can follow the one that crossed the line -- LIMIT + THREADS < SLOTS, the probe loops always find a free slot.
-                for (uint32_t g0 = 0; g0 < total; g0 += THREADS) {
+                bool screened = false;
+                uint32_t n_iter = total;
+                if constexpr (SCREEN) {
+                    // (uniform) the whole bucket is this batch, and every lane has at most three instances
+                    screened = a.screen >= 2u && vend - vbeg <= (uint64_t)BATCH && total <= (uint32_t)SROUNDS * THREADS;
+                    if (screened) {
+                        uint32_t cpk[(SROUNDS + 1) / 2], inpass = 0;
+#pragma unroll
+                        for (int r = 0; r < (SROUNDS + 1) / 2; ++r) cpk[r] = 0;
+#pragma unroll
+                        for (uint32_t r = 0; r < (uint32_t)SROUNDS; ++r) {
+                            const uint32_t g = r * THREADS + tid;
+                            if (g < total) {
+                                uint32_t lr = cidx[g >> 5];
+                                uint32_t lend = lpre[lr];
+                                while (lend <= g) lend = lpre[++lr];
+                                const uint32_t i = lead[lr];
+                                const uint32_t* rp = rec + 8 * i;
+                                const uint32_t m6 = rp[6];
+                                const uint32_t n_i = m6 & 0x7Fu, hasL = (m6 >> 7) & 1u;
+                                const uint32_t o = hasL + (g + n_i - lend);
+                                const uint32_t wi = o >> 4, sh = (2u * o) & 31u;
+                                const uint32_t* wp = rp + wi;
+                                const uint32_t W0 = wp[0], W1 = wp[1], W2 = wp[2], W3 = wp[3];
+                                snk_kmer f;
+                                f.hi = ((uint64_t)funnel(W0, W1, sh) << 32) | funnel(W1, W2, sh);
+                                if constexpr (K == 48) f.lo = (uint64_t)funnel(W2, W3, sh) << 32;
+                                else f.lo = ((uint64_t)funnel(W2, W3, sh) << 32) | (funnel(W3, wp[4], sh) & 0xFFFFFF00u);
+                                const snk_kmer rk = snk_kmer_rc<K>(f);
+                                snk_kmer c = snk_kmer_lt(rk, f) ? rk : f;
+                                if (GROUPED) c.lo |= (uint64_t)rp[7];
+                                uint32_t h1, h2;
+                                snk_kmer_hash_count<(K > 48) || GROUPED>(c, &h1, &h2);
+                                if ((h2 & split_mask) == split_id) {
+                                    const uint32_t cell = h1 >> 19;                 // 8192 cells (the slot comes from h1's low bits)
+                                    const uint32_t bit = 1u << (cell & 31u);
+                                    uint32_t* w = dd + (cell >> 5);
+                                    if (atomicOr(w, bit) & bit) { if ((atomicOr(w + 256, bit) & bit) && a.screen > 2u) atomicOr(w + 512, bit); }
+                                    cpk[r >> 1] |= cell << (16u * (r & 1u));
+                                    inpass |= 1u << r;
+                                }
+                            }
+                        }
+                        lds_barrier();
+                        const uint32_t* plane = dd + 256 * (a.screen > 2u ? 2 : 1);
+#pragma unroll
+                        for (uint32_t r = 0; r < (uint32_t)SROUNDS; ++r) {
+                            const uint32_t cell = (cpk[r >> 1] >> (16u * (r & 1u))) & 0x1FFFu;
+                            const bool adm = ((inpass >> r) & 1u) && ((plane[cell >> 5] >> (cell & 31u)) & 1u);
+                            const unsigned long long am = __ballot(adm);
+                            if (am) {
+                                const int leader = __ffsll((long long)am) - 1;
+                                uint32_t base = 0;
+                                if (lane == leader) base = atomicAdd(&ctl[0], (uint32_t)__popcll(am));
+                                base = __shfl(base, leader) + (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
+                                if (adm && base < SCAND) cand[base] = (uint16_t)(r * THREADS + tid);
+                            }
+                        }
+                        lds_barrier();
+                        n_iter = LDS_LOAD(&ctl[0]);
+                        if (n_iter > SCAND) { screened = false; n_iter = total; }      // (too many candidates for the list: every instance goes to the table)
+                    }
+                }
+                for (uint32_t g0 = 0; g0 < n_iter; g0 += THREADS) {
                     if (TIGHT ? (LDS_LOAD(resv) >> 31) != 0u : LDS_LOAD(occ) > LIMIT) break;
-                    const uint32_t g = g0 + tid;
-                    if (g < total) {
+                    uint32_t g = g0 + tid;
+                    const bool have = g < n_iter;
+                    if (SCREEN && screened && have) g = cand[g];
+                    if (have) {
                         uint32_t lr = cidx[g >> 5];
                         uint32_t lend = lpre[lr];
                         while (lend <= g) lend = lpre[++lr];         // (the last leader ends at total > g)
                         const uint32_t i = lead[lr];
                         const uint32_t* rp = rec + 8 * i;
                         const uint32_t m6 = rp[6], w7 = rp[7];
-                        const uint32_t wt = wgt[i];
+                        const uint32_t wt = SCREEN ? 1u : wgt[i];
                         const uint32_t n_i = m6 & 0x7Fu, hasL = (m6 >> 7) & 1u, hasR = (m6 >> 8) & 1u;
                         const uint32_t j = g + n_i - lend;
                         const uint32_t bst = GROUPED ? 0u : w7;                   // merged barcode state of the supermer
@@ -672,9 +753,9 @@ template <> struct cfg<48> { static constexpr int THREADS = SNK_COUNT_THREADS; s
 template <> struct cfg<60> { static constexpr int THREADS = SNK_COUNT_THREADS; static constexpr int SLOTS = SNK_COUNT_SLOTS; };
 
 template <int K, bool G>
-size_t lds_bytes(uint32_t bc_mode = 0, bool tight = false) {
+size_t lds_bytes(uint32_t bc_mode = 0, bool tight = false, bool screen = false) {
     constexpr size_t S = cfg<K>::SLOTS, B = (K == 48 && !G && S >= 2048) ? 512 : 256, DD = 2 * B, NCI = B * (K - SNK_M_MIN_OF(K) + 1) / 32 + 2;
-    return S * (8 + sizeof(typename klo_t<K, G>::type) + 4 + 4 + 4) + S + 4 * (8 * B + (tight ? 72 : 64) + DD + B) + 2 * (B + B + 2 + NCI) + 16 + 2 * 4 * 3 * SNK_COUNT_MAXSEG + 2 * (tight ? S - 64 : S - cfg<K>::THREADS - 64) + 16 + (bc_mode > 2 ? S * 24 + 16 : 0);
+    return S * (8 + sizeof(typename klo_t<K, G>::type) + 4 + 4 + 4) + S + 4 * (8 * B + (tight ? 72 : 64) + DD + B) + 2 * (B + B + 2 + NCI) + 16 + 2 * 4 * 3 * SNK_COUNT_MAXSEG + 2 * (tight ? S - 64 : S - cfg<K>::THREADS - 64) + 16 + (bc_mode > 2 ? S * 24 + 16 : 0) + (screen ? 2048 + 16 : 0);
 }
 
 template <int K, bool G>
@@ -685,8 +766,12 @@ int launch(hipStream_t st, const snk_count_args& a, char* err, size_t errcap) {
         kern = snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G, false, true>;
     }
     const bool tight = a.tight && !a.gidx;
-    if (tight) kern = a.nseg > 1 ? snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G, true, false, true> : snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G, false, false, true>;
-    size_t lds = lds_bytes<K, G>(a.bc_mode, tight);
+    const bool screen = G && K == 48 && tight && a.screen >= 2u && a.bc_mode <= 2u;
+    if constexpr (G && K == 48) {
+        if (screen) kern = a.nseg > 1 ? snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G, true, false, true, true> : snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G, false, false, true, true>;
+    }
+    if (tight && !screen) kern = a.nseg > 1 ? snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G, true, false, true> : snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G, false, false, true>;
+    size_t lds = lds_bytes<K, G>(a.bc_mode, tight, screen);
     SNK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (a.bucket0 >= a.NB) return SNK_OK;          // the launch covers buckets [bucket0, NB)
     // one workgroup per output region, every launch of a table (the ranged launches of the sharded path) with the same grid:

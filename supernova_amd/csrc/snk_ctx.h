@@ -46,6 +46,7 @@ struct snk_ctx {
     size_t peak_alloc = 0;      // its maximum during the call
     size_t cached_bytes = 0;    // bytes held by the arena
     uint64_t last_n_kmers = 0, last_n_instances = 0;   // sizing hint from the previous call
+    uint64_t last_region_max = 0, last_region_n = 0;   // ... and its fullest count region (with that many regions): survivors that cluster -- duplicated reads of one barcode -- fill regions unevenly
     uint64_t last_bnd = 0, last_bnd_n = 0;              // boundary k-mers the bucket-local prune found for a table of last_bnd_n k-mers
     uint32_t last_ovf = 0, last_ovf_nb = 0;             // overflow supermers of the last partition pass and its bucket count
     uint64_t last_ovf_reads = 0;

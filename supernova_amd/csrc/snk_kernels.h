@@ -93,6 +93,7 @@ struct snk_count_args {
     uint32_t bc_mode;              // = minBC: 0 no barcode rule, 1: >=1 barcode>0 (or ignore-rule read), 2: >=2 distinct (state machine), 3..8: id sets
     uint32_t bucket0;              // first bucket of this launch (set by the launcher)
     uint32_t bucket_stride;        // set by the launcher (= n_regions): workgroup w counts the buckets == w (mod stride)
+    uint32_t screen;               // per-barcode groups: instances pass a three-level bit filter first (level = min(min_freq, 3); 0 / 1 = off; snk_count.hip SCREEN)
     uint32_t tight;                // the table fills to 7/8: waves book their slots (snk_count.hip, TIGHT)
     uint32_t grouped;              // record word 7 is a group id that becomes the low 32 bits of the key (K=48 only)
     snk_u128* out_keys;            // canonical k-mer values (hi<<64|lo); region r owns [r*region_cap, (r+1)*region_cap):

@@ -208,7 +208,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
         h_fp ^= snk_mix64(n_reads * 0x9E3779B97F4A7C15ull + in->read_len);
         same_data = ctx->have_input_fp && ctx->last_input_fp == h_fp;
         ctx->last_input_fp = h_fp; ctx->have_input_fp = true;
-        if (!same_data) { ctx->last_n_kmers = 0; ctx->last_bnd = 0; }       // (the count regions' and the boundary index's sizes were that data's)
+        if (!same_data) { ctx->last_n_kmers = 0; ctx->last_bnd = 0; ctx->last_region_max = 0; }       // (the count regions' and the boundary index's sizes were that data's)
     }
     // The count kernel has two ways to keep its probe loops supplied with free slots (snk_count.hip): a margin of one round of every wave
     // (1216 of 2048 slots usable, nothing to pay per round) or booked slots (15/16 usable, one LDS atomic round trip per wave and round:
@@ -227,7 +227,11 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
         return full ? ((snk_count_slots(K) - snk_count_slots(K) / 16u) | tries) : 0u;
     };
     // (per-barcode groups: nearly every instance is a distinct entry, the bucket IS the table: three quarters of its capacity on average)
-    auto default_target_now = [&]() -> uint32_t { return grouped ? (uint32_t)(0.74 * snk_count_limit(K, 1u, ctx->count_tight)) : plain_target; };
+    // (... unless the bit filter in front of the table is on -- min_freq >= 2: then the table only sees the (group, k-mer) pairs that can be retained,
+    // one in ten, and a bucket is as large as one batch of records and six instances per lane allow: 3200 is where buckets start to fall out
+    // of the filter -- 106 ms at 2800..3200, 189 at 3600, `profiles/r05_count_screen_groups.log`)
+    const bool group_screen = grouped && env_u32("SNK_COUNT_SCREEN", 1) != 0 && p->min_freq >= (env_u32("SNK_COUNT_SCREEN", 1) >= 2 ? 2u : 3u);
+    auto default_target_now = [&]() -> uint32_t { return grouped ? ((group_screen && ctx->count_tight) ? 2900u : (uint32_t)(0.74 * snk_count_limit(K, 1u, ctx->count_tight))) : plain_target; };
     const bool target_forced = getenv("SNK_TARGET_INST") && *getenv("SNK_TARGET_INST");
     // ... and the RETAINED k-mers of a bucket are one chunk of the bucket-local graph stage, whose one-wave kernels hold 256 of them
     // (larger chunks take the slower big-chunk variants): at half the coverage twice as many k-mers survive per instance, every other
@@ -236,7 +240,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     auto target_for = [&](double ratio) -> uint32_t {
         const uint32_t default_target = default_target_now();
         if (target_forced) return env_u32("SNK_TARGET_INST", default_target);
-        if (retain > 0.0 && !grouped) {
+        if (retain > 0.0 && (!grouped || group_screen)) {       // (groups behind the bit filter: buckets of 2900 instances, unless that many would retain more than a graph chunk holds)
             const double t = (double)env_u32("SNK_CHUNK_KMERS", 150) / retain;
             if (t < (double)default_target) {
                 uint32_t tt = t < 600.0 ? 600u : (uint32_t)t;

@@ -39,6 +39,10 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
     uint64_t est = n_inst_hint / (min_freq > 1 ? 12 : 1) + 4096;     // first call only; a wrong guess costs one re-run
     if (ctx->last_n_kmers && ctx->last_n_instances == n_inst_hint) est = ctx->last_n_kmers + ctx->last_n_kmers / 2 + 4096;
     uint64_t region_cap = est / n_regions + 64;
+    // (a sparse, clustered output -- per-barcode groups at min_freq 4: 155 survivors per region on average, several hundred in some -- overflowed
+    // the average-based capacity in EVERY call and the count kernel ran twice, 127 instead of 64 ms: the fullest region of the last call counts too)
+    if (ctx->last_n_kmers && ctx->last_n_instances == n_inst_hint && ctx->last_region_n == n_regions && ctx->last_region_max + ctx->last_region_max / 4 + 64 > region_cap)
+        region_cap = ctx->last_region_max + ctx->last_region_max / 4 + 64;
     snk_u128 *keys_r = nullptr, *keys_a = nullptr, *keys_b = nullptr;
     uint64_t *vals_r = nullptr, *vals_a = nullptr, *vals_b = nullptr;
     unsigned long long *rcur = nullptr, *roff = nullptr;
@@ -87,6 +91,10 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
         ca.bc_mode = bc_mode;
         ca.grouped = grouped;
         ca.tight = ctx->count_tight;
+        // (per-barcode groups, min_freq >= 3: three reads of one barcode over one k-mer are rare, two -- the mates of a pair -- are not; with
+        // min_freq 2 a quarter of the instances pass the filter and the larger buckets cost more than they save: 428 against 270 ms.
+        // SNK_COUNT_SCREEN: 0 never, 1 at min_freq >= 3, 2 at min_freq >= 2 as well)
+        { const uint32_t sc = grouped ? env_u32("SNK_COUNT_SCREEN", 1) : 0u; ca.screen = (sc && min_freq >= (sc >= 2 ? 2u : 3u)) ? std::min(min_freq, 3u) : 0u; }
         ca.bucket0 = 0;
         ca.out_keys = keys_r;
         ca.out_vals = vals_r;
@@ -266,6 +274,7 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
     out->n = n_kmers;
     ctx->last_n_kmers = n_kmers;
     ctx->last_n_instances = n_inst_hint;
+    { unsigned long long mxr = 0; for (uint32_t r = 0; r < n_regions; ++r) if (h_rcur[r] > mxr) mxr = h_rcur[r]; ctx->last_region_max = mxr; ctx->last_region_n = n_regions; }
     tm.mark();
     out->sorted = want_sort;
     out->NB = NB;

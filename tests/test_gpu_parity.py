@@ -721,9 +721,12 @@ def test_count_launch_shapes(engine, monkeypatch, persist, n_buckets):
     _check_against(res, c.exp_keys, c.exp_counts, c.exp_ctx, c.exp_unitigs, c.exp_goodlens, c.exp_hist)
 
 
-def test_grouped_per_barcode_graphs(engine, graph_stage):
+@pytest.mark.parametrize("min_freq,n_buckets,screen", [(2, 0, "2"), (2, 0, "1"), (3, 0, "1"), (1, 0, "1"), (5, 0, "1"), (3, 40, "1"), (3, 3000, "1"), (3, 0, "0")])
+def test_grouped_per_barcode_graphs(engine, graph_stage, monkeypatch, min_freq, n_buckets, screen):
     """BASELINE config 5: per-group (per-barcode) local graphs.  One grouped run == the oracle applied to every group's
-    reads on its own (frequency rule only): tables, pruned contexts and unitigs per group."""
+    reads on its own (frequency rule only): tables, pruned contexts and unitigs per group.  The count kernel's bit filter in front of the
+    table (snk_count.hip SCREEN: levels 2 and 3; off at min_freq 1; buckets too large for it -- 40 buckets here -- are counted without it)
+    does not change the result."""
     import torch
     from supernova_amd import synth
     from supernova_amd.engine import Params
@@ -737,8 +740,9 @@ def test_grouped_per_barcode_graphs(engine, graph_stage):
     group[rng.random(n) < 0.1] = NG + 3                     # a sparse extra group with a large id gap
     rows, quals, bc, lens = _to_dev(c)
     g_dev = torch.from_numpy(group).to(rows.device)
+    monkeypatch.setenv("SNK_COUNT_SCREEN", screen)
     res = engine.count_graph(rows, c.read_len, quals=quals, bc=None, lens=lens, group=g_dev,
-                             params=Params(K=48, min_freq=2, min_bc=0, grouped=True, sorted_table=False))
+                             params=Params(K=48, min_freq=min_freq, min_bc=0, grouped=True, sorted_table=False, n_buckets=n_buckets))
     k, cnt, ctx = res.keys(), res.counts(), res.ctx()
     off, bases = res.unitig_arrays()
     ug = res.unitig_groups()
@@ -747,7 +751,7 @@ def test_grouped_per_barcode_graphs(engine, graph_stage):
     total = 0
     for gid in np.unique(group):
         sel = group == gid
-        o = oracle_lib.OracleResult(c.codes[sel], c.exp_goodlens[sel], None, min_freq=2, min_bc=0, hbv=False)
+        o = oracle_lib.OracleResult(c.codes[sel], c.exp_goodlens[sel], None, min_freq=min_freq, min_bc=0, hbv=False)
         m = k[:, 3] == gid
         kk, cc, xx = k[m], cnt[m], ctx[m]
         order = np.lexsort((kk[:, 2], kk[:, 1], kk[:, 0]))
