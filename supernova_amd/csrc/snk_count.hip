@@ -98,7 +98,8 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     // supermers staged per batch.  A 4000-instance bucket holds ~270 (sigma ~100): with 512 slots nearly every bucket is
     // ONE batch (with 256, 55 % of the buckets ran a second, mostly empty batch through all the phases below).  K=60 and
     // grouped runs have 64-bit low key words: 256 keeps the workgroup under 80 KB of LDS, i.e. two per CU.
-    constexpr int BATCH = (K == 48 && !GROUPED && SLOTS >= 2048) ? 512 : 256;
+    // (grouped SCREEN with a 1024-slot table -- the table only sees a tenth of the instances -- has the room for 512-record batches as well)
+    constexpr int BATCH = (K == 48 && ((!GROUPED && SLOTS >= 2048) || (GROUPED && SCREEN && SLOTS <= 1024))) ? 512 : 256;
     constexpr int DD = 2 * BATCH;                        // de-duplication table slots
     typedef typename klo_t<K, GROUPED>::type lo_type;
     constexpr int WMAX = K - SNK_M_MIN_OF(K) + 1;                  // k-mers per supermer, at most
@@ -131,11 +132,16 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
 #ifndef SNK_SCREEN_ROUNDS
 #define SNK_SCREEN_ROUNDS 6
 #endif
-    constexpr int SROUNDS = SNK_SCREEN_ROUNDS;                        // SCREEN: instances per lane (their cells ride in two registers)
-    static_assert(SROUNDS >= 1 && SROUNDS <= 6, "two 13-bit cells per register");
-    constexpr uint32_t SCAND = 1024;                                   // SCREEN: candidate list (instance indices), in bcx's place (grouped runs have no barcode rule)
+#ifndef SNK_GSCREEN_SLOTS
+#define SNK_GSCREEN_SLOTS 1024          // table slots of the grouped SCREEN instantiation: the table sees a tenth of the instances, half of it pays for 512-record batches (2048: 256-record batches, 104.6 instead of 92.2 ms)
+#endif
+    constexpr int SROUNDS = (SCREEN && SLOTS <= 1024) ? SNK_SCREEN_ROUNDS + 4 : SNK_SCREEN_ROUNDS;                        // SCREEN: instances per lane (their cells ride in two registers)
+    static_assert(SROUNDS >= 1 && SROUNDS <= 10, "two cells per register");
+    constexpr int SPW = (DD + BATCH) / 3 >= 512 ? 512 : 256;      // words per bit plane (the de-duplication table and the weights hold three)
+    constexpr uint32_t SCB = SPW == 512 ? 18u : 19u;                // cell = the top 14 / 13 bits of h1
+    constexpr uint32_t SCAND = SLOTS <= 1024 ? 2048 : 1024;                                   // SCREEN: candidate list (instance indices), in bcx's place (grouped runs have no barcode rule)
     uint16_t* cand = reinterpret_cast<uint16_t*>(bcx);
-    static_assert(!SCREEN || (GROUPED && DD == 512 && BATCH == 256), "the screen's three planes of 8192 bits are the de-duplication table and the weights of grouped runs (neither is used there)");
+    static_assert(!SCREEN || (GROUPED && 3 * SPW <= DD + BATCH), "the screen's three bit planes are the de-duplication table and the weights of grouped runs (neither is used there)");
     // ctl[1..2] occupied slots (by pass parity; more than LIMIT = the pass overflows), ctl[3] most slots used so far,
     // ctl[4..7] / ctl[12..15] record bounds of the bucket (segment 0; by bucket parity), ctl[8..9] placement counter (by pass
     // parity), ctl[10..11] instances | leaders << 16 of the batch (by batch parity), ctl[16..16+2*MAX) split stack (17 levels)
@@ -145,7 +151,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     // distinct k-mers one sub-pass may hold.  TIGHT: a wave books a slot for every lane that is about to probe (ctl[64..65], by pass
     // parity; bit 31 = the pass is over capacity) and hands back what its lanes did not claim, so the table fills to 7/8 and the probe loops
     // still always find a free slot; otherwise nobody books anything and the margin is one round of every wave (below)
-    const uint32_t LIMIT = TIGHT ? (a.tight & 0xFFFFu) : SLOTS - THREADS - 64;
+    const uint32_t LIMIT = TIGHT ? min(a.tight & 0xFFFFu, (uint32_t)SLOTS - 64u) : SLOTS - THREADS - 64;
     const int tight_tries = (int)(a.tight >> 16);
 #ifdef SNK_COUNT_PROF
     long long prof_t = clock64();
@@ -434,20 +440,20 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                                 uint32_t h1, h2;
                                 snk_kmer_hash_count<(K > 48) || GROUPED>(c, &h1, &h2);
                                 if ((h2 & split_mask) == split_id) {
-                                    const uint32_t cell = h1 >> 19;                 // 8192 cells (the slot comes from h1's low bits)
+                                    const uint32_t cell = h1 >> SCB;                // 8192 / 16384 cells (the slot comes from h1's low bits)
                                     const uint32_t bit = 1u << (cell & 31u);
                                     uint32_t* w = dd + (cell >> 5);
-                                    if (atomicOr(w, bit) & bit) { if ((atomicOr(w + 256, bit) & bit) && a.screen > 2u) atomicOr(w + 512, bit); }
+                                    if (atomicOr(w, bit) & bit) { if ((atomicOr(w + SPW, bit) & bit) && a.screen > 2u) atomicOr(w + 2 * SPW, bit); }
                                     cpk[r >> 1] |= cell << (16u * (r & 1u));
                                     inpass |= 1u << r;
                                 }
                             }
                         }
                         lds_barrier();
-                        const uint32_t* plane = dd + 256 * (a.screen > 2u ? 2 : 1);
+                        const uint32_t* plane = dd + SPW * (a.screen > 2u ? 2 : 1);
 #pragma unroll
                         for (uint32_t r = 0; r < (uint32_t)SROUNDS; ++r) {
-                            const uint32_t cell = (cpk[r >> 1] >> (16u * (r & 1u))) & 0x1FFFu;
+                            const uint32_t cell = (cpk[r >> 1] >> (16u * (r & 1u))) & 0xFFFFu;
                             const bool adm = ((inpass >> r) & 1u) && ((plane[cell >> 5] >> (cell & 31u)) & 1u);
                             const unsigned long long am = __ballot(adm);
                             if (am) {
@@ -754,8 +760,8 @@ template <> struct cfg<60> { static constexpr int THREADS = SNK_COUNT_THREADS; s
 
 template <int K, bool G>
 size_t lds_bytes(uint32_t bc_mode = 0, bool tight = false, bool screen = false) {
-    constexpr size_t S = cfg<K>::SLOTS, B = (K == 48 && !G && S >= 2048) ? 512 : 256, DD = 2 * B, NCI = B * (K - SNK_M_MIN_OF(K) + 1) / 32 + 2;
-    return S * (8 + sizeof(typename klo_t<K, G>::type) + 4 + 4 + 4) + S + 4 * (8 * B + (tight ? 72 : 64) + DD + B) + 2 * (B + B + 2 + NCI) + 16 + 2 * 4 * 3 * SNK_COUNT_MAXSEG + 2 * (tight ? S - 64 : S - cfg<K>::THREADS - 64) + 16 + (bc_mode > 2 ? S * 24 + 16 : 0) + (screen ? 2048 + 16 : 0);
+    const size_t S = (screen && G) ? SNK_GSCREEN_SLOTS : cfg<K>::SLOTS, B = (K == 48 && ((!G && S >= 2048) || (G && screen && S <= 1024))) ? 512 : 256, DD = 2 * B, NCI = B * (K - SNK_M_MIN_OF(K) + 1) / 32 + 2;
+    return S * (8 + sizeof(typename klo_t<K, G>::type) + 4 + 4 + 4) + S + 4 * (8 * B + (tight ? 72 : 64) + DD + B) + 2 * (B + B + 2 + NCI) + 16 + 2 * 4 * 3 * SNK_COUNT_MAXSEG + 2 * (tight ? S - 64 : S - cfg<K>::THREADS - 64) + 16 + (bc_mode > 2 ? S * 24 + 16 : 0) + (screen ? (S <= 1024 ? 4096 : 2048) + 16 : 0);
 }
 
 template <int K, bool G>
@@ -768,7 +774,7 @@ int launch(hipStream_t st, const snk_count_args& a, char* err, size_t errcap) {
     const bool tight = a.tight && !a.gidx;
     const bool screen = G && K == 48 && tight && a.screen >= 2u && a.bc_mode <= 2u;
     if constexpr (G && K == 48) {
-        if (screen) kern = a.nseg > 1 ? snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G, true, false, true, true> : snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G, false, false, true, true>;
+        if (screen) kern = a.nseg > 1 ? snk_count_kernel<K, cfg<K>::THREADS, SNK_GSCREEN_SLOTS, G, true, false, true, true> : snk_count_kernel<K, cfg<K>::THREADS, SNK_GSCREEN_SLOTS, G, false, false, true, true>;
     }
     if (tight && !screen) kern = a.nseg > 1 ? snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G, true, false, true> : snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G, false, false, true>;
     size_t lds = lds_bytes<K, G>(a.bc_mode, tight, screen);

@@ -228,10 +228,10 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     };
     // (per-barcode groups: nearly every instance is a distinct entry, the bucket IS the table: three quarters of its capacity on average)
     // (... unless the bit filter in front of the table is on -- min_freq >= 2: then the table only sees the (group, k-mer) pairs that can be retained,
-    // one in ten, and a bucket is as large as one batch of records and six instances per lane allow: 3200 is where buckets start to fall out
-    // of the filter -- 106 ms at 2800..3200, 189 at 3600, `profiles/r05_count_screen_groups.log`)
+    // one in ten, and a bucket is as large as one batch of 512 records and ten instances per lane allow: beyond 6000 buckets start to fall out
+    // of the filter -- 92.9 ms at 4800, 92.2 at 5600, 94.6 at 6400, `profiles/r05_count_screen_groups.log`)
     const bool group_screen = grouped && env_u32("SNK_COUNT_SCREEN", 1) != 0 && p->min_freq >= (env_u32("SNK_COUNT_SCREEN", 1) >= 2 ? 2u : 3u);
-    auto default_target_now = [&]() -> uint32_t { return grouped ? ((group_screen && ctx->count_tight) ? 2900u : (uint32_t)(0.74 * snk_count_limit(K, 1u, ctx->count_tight))) : plain_target; };
+    auto default_target_now = [&]() -> uint32_t { return grouped ? ((group_screen && ctx->count_tight) ? 5200u : (uint32_t)(0.74 * snk_count_limit(K, 1u, ctx->count_tight))) : plain_target; };
     const bool target_forced = getenv("SNK_TARGET_INST") && *getenv("SNK_TARGET_INST");
     // ... and the RETAINED k-mers of a bucket are one chunk of the bucket-local graph stage, whose one-wave kernels hold 256 of them
     // (larger chunks take the slower big-chunk variants): at half the coverage twice as many k-mers survive per instance, every other
@@ -240,7 +240,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     auto target_for = [&](double ratio) -> uint32_t {
         const uint32_t default_target = default_target_now();
         if (target_forced) return env_u32("SNK_TARGET_INST", default_target);
-        if (retain > 0.0 && (!grouped || group_screen)) {       // (groups behind the bit filter: buckets of 2900 instances, unless that many would retain more than a graph chunk holds)
+        if (retain > 0.0 && (!grouped || group_screen)) {       // (groups behind the bit filter: buckets of 5200 instances, unless that many would retain more than a graph chunk holds)
             const double t = (double)env_u32("SNK_CHUNK_KMERS", 150) / retain;
             if (t < (double)default_target) {
                 uint32_t tt = t < 600.0 ? 600u : (uint32_t)t;
