@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     // ONE batch (with 256, 55 % of the buckets ran a second, mostly empty batch through all the phases below).  K=60 and
     // grouped runs have 64-bit low key words: 256 keeps the workgroup under 80 KB of LDS, i.e. two per CU.
     // (grouped SCREEN with a 1024-slot table -- the table only sees a tenth of the instances -- has the room for 512-record batches as well)
-    constexpr int BATCH = (K == 48 && ((!GROUPED && SLOTS >= 2048) || (GROUPED && SCREEN && SLOTS <= 1024))) ? 512 : 256;
+    constexpr int BATCH = (K == 48 && ((!GROUPED && (SLOTS >= 2048 || SCREEN)) || (GROUPED && SCREEN && SLOTS <= 1024))) ? 512 : 256;
     constexpr int DD = 2 * BATCH;                        // de-duplication table slots
     typedef typename klo_t<K, GROUPED>::type lo_type;
     constexpr int WMAX = K - SNK_M_MIN_OF(K) + 1;                  // k-mers per supermer, at most
@@ -137,11 +137,18 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
 #endif
     constexpr int SROUNDS = (SCREEN && SLOTS <= 1024) ? SNK_SCREEN_ROUNDS + 4 : SNK_SCREEN_ROUNDS;                        // SCREEN: instances per lane (their cells ride in two registers)
     static_assert(SROUNDS >= 1 && SROUNDS <= 10, "two cells per register");
-    constexpr int SPW = (DD + BATCH) / 3 >= 512 ? 512 : 256;      // words per bit plane (the de-duplication table and the weights hold three)
-    constexpr uint32_t SCB = SPW == 512 ? 18u : 19u;                // cell = the top 14 / 13 bits of h1
-    constexpr uint32_t SCAND = SLOTS <= 1024 ? 2048 : 1024;                                   // SCREEN: candidate list (instance indices), in bcx's place (grouped runs have no barcode rule)
+    // words per bit plane.  Grouped runs: the de-duplication table and the weights hold the three planes (neither is used there); ungrouped
+    // runs (error-rich reads; both are in use): their own array behind the candidate list
+#ifndef SNK_NGSCREEN_PLANE_WORDS
+#define SNK_NGSCREEN_PLANE_WORDS 512
+#endif
+    constexpr int SPW = GROUPED ? ((DD + BATCH) / 3 >= 512 ? 512 : 256) : SNK_NGSCREEN_PLANE_WORDS;
+    constexpr uint32_t SCB = SPW == 1024 ? 17u : (SPW == 512 ? 18u : 19u);                // cell = the top 15 / 14 / 13 bits of h1
+    // SCREEN: candidate list (instance indices), in bcx's place (SCREEN runs keep up to two barcodes per slot: no bcx)
+    constexpr uint32_t SCAND = GROUPED ? (SLOTS <= 1024 ? 2048 : 1024) : 4096;
     uint16_t* cand = reinterpret_cast<uint16_t*>(bcx);
-    static_assert(!SCREEN || (GROUPED && 3 * SPW <= DD + BATCH), "the screen's three bit planes are the de-duplication table and the weights of grouped runs (neither is used there)");
+    uint32_t* planes = GROUPED ? dd : reinterpret_cast<uint32_t*>(cand + SCAND);
+    static_assert(!SCREEN || (GROUPED && 3 * SPW <= DD + BATCH) || (!GROUPED && K == 48 && SLOTS <= 1024), "no room for the screen's bit planes");
     // ctl[1..2] occupied slots (by pass parity; more than LIMIT = the pass overflows), ctl[3] most slots used so far,
     // ctl[4..7] / ctl[12..15] record bounds of the bucket (segment 0; by bucket parity), ctl[8..9] placement counter (by pass
     // parity), ctl[10..11] instances | leaders << 16 of the batch (by batch parity), ctl[16..16+2*MAX) split stack (17 levels)
@@ -325,7 +332,8 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                 // ---- stage one batch of supermer records
                 if (!prefetched) dma_batch(base, vend, bcur, segc);
                 prefetched = false;
-                if (tid < BATCH) wgt[tid] = SCREEN ? 0u : 1u;        // (SCREEN: the third bit plane; nothing folds in grouped runs, every weight is 1)
+                if (tid < BATCH) wgt[tid] = (SCREEN && GROUPED) ? 0u : 1u;        // (grouped SCREEN: the third bit plane; nothing folds in grouped runs, every weight is 1)
+                if (SCREEN && !GROUPED) { for (int qq = tid; qq < 3 * SPW; qq += THREADS) planes[qq] = 0; }
                 for (int q = tid; q < DD; q += THREADS) dd[q] = 0;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my share of the batch is in LDS (and everything older has landed)
                 lds_barrier();                                       // 'staged'
@@ -442,15 +450,18 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                                 if ((h2 & split_mask) == split_id) {
                                     const uint32_t cell = h1 >> SCB;                // 8192 / 16384 cells (the slot comes from h1's low bits)
                                     const uint32_t bit = 1u << (cell & 31u);
-                                    uint32_t* w = dd + (cell >> 5);
-                                    if (atomicOr(w, bit) & bit) { if ((atomicOr(w + SPW, bit) & bit) && a.screen > 2u) atomicOr(w + 2 * SPW, bit); }
+                                    uint32_t* w = planes + (cell >> 5);
+                                    // (a folded record stands for wgt copies: as many steps, the level at most)
+                                    const uint32_t steps = GROUPED ? 1u : min(wgt[i], a.screen);
+                                    for (uint32_t k = 0; k < steps; ++k)
+                                        if (atomicOr(w, bit) & bit) { if ((atomicOr(w + SPW, bit) & bit) && a.screen > 2u) atomicOr(w + 2 * SPW, bit); }
                                     cpk[r >> 1] |= cell << (16u * (r & 1u));
                                     inpass |= 1u << r;
                                 }
                             }
                         }
                         lds_barrier();
-                        const uint32_t* plane = dd + SPW * (a.screen > 2u ? 2 : 1);
+                        const uint32_t* plane = planes + SPW * (a.screen > 2u ? 2 : 1);
 #pragma unroll
                         for (uint32_t r = 0; r < (uint32_t)SROUNDS; ++r) {
                             const uint32_t cell = (cpk[r >> 1] >> (16u * (r & 1u))) & 0xFFFFu;
@@ -481,7 +492,7 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
                         const uint32_t i = lead[lr];
                         const uint32_t* rp = rec + 8 * i;
                         const uint32_t m6 = rp[6], w7 = rp[7];
-                        const uint32_t wt = SCREEN ? 1u : wgt[i];
+                        const uint32_t wt = (SCREEN && GROUPED) ? 1u : wgt[i];
                         const uint32_t n_i = m6 & 0x7Fu, hasL = (m6 >> 7) & 1u, hasR = (m6 >> 8) & 1u;
                         const uint32_t j = g + n_i - lend;
                         const uint32_t bst = GROUPED ? 0u : w7;                   // merged barcode state of the supermer
@@ -760,8 +771,8 @@ template <> struct cfg<60> { static constexpr int THREADS = SNK_COUNT_THREADS; s
 
 template <int K, bool G>
 size_t lds_bytes(uint32_t bc_mode = 0, bool tight = false, bool screen = false) {
-    const size_t S = (screen && G) ? SNK_GSCREEN_SLOTS : cfg<K>::SLOTS, B = (K == 48 && ((!G && S >= 2048) || (G && screen && S <= 1024))) ? 512 : 256, DD = 2 * B, NCI = B * (K - SNK_M_MIN_OF(K) + 1) / 32 + 2;
-    return S * (8 + sizeof(typename klo_t<K, G>::type) + 4 + 4 + 4) + S + 4 * (8 * B + (tight ? 72 : 64) + DD + B) + 2 * (B + B + 2 + NCI) + 16 + 2 * 4 * 3 * SNK_COUNT_MAXSEG + 2 * (tight ? S - 64 : S - cfg<K>::THREADS - 64) + 16 + (bc_mode > 2 ? S * 24 + 16 : 0) + (screen ? (S <= 1024 ? 4096 : 2048) + 16 : 0);
+    const size_t S = screen ? SNK_GSCREEN_SLOTS : cfg<K>::SLOTS, B = (K == 48 && ((!G && (S >= 2048 || screen)) || (G && screen && S <= 1024))) ? 512 : 256, DD = 2 * B, NCI = B * (K - SNK_M_MIN_OF(K) + 1) / 32 + 2;
+    return S * (8 + sizeof(typename klo_t<K, G>::type) + 4 + 4 + 4) + S + 4 * (8 * B + (tight ? 72 : 64) + DD + B) + 2 * (B + B + 2 + NCI) + 16 + 2 * 4 * 3 * SNK_COUNT_MAXSEG + 2 * (tight ? S - 64 : S - cfg<K>::THREADS - 64) + 16 + (bc_mode > 2 ? S * 24 + 16 : 0) + (screen ? (G ? (S <= 1024 ? 4096 : 2048) : 8192 + 3 * SNK_NGSCREEN_PLANE_WORDS * 4) + 16 : 0);
 }
 
 template <int K, bool G>
@@ -772,8 +783,9 @@ int launch(hipStream_t st, const snk_count_args& a, char* err, size_t errcap) {
         kern = snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G, false, true>;
     }
     const bool tight = a.tight && !a.gidx;
-    const bool screen = G && K == 48 && tight && a.screen >= 2u && a.bc_mode <= 2u;
-    if constexpr (G && K == 48) {
+    const bool screen = K == 48 && tight && a.screen >= 2u && a.bc_mode <= 2u;
+    static_assert(SNK_GSCREEN_SLOTS <= 1024, "the ungrouped SCREEN instantiation needs the LDS half a table frees");
+    if constexpr (K == 48) {
         if (screen) kern = a.nseg > 1 ? snk_count_kernel<K, cfg<K>::THREADS, SNK_GSCREEN_SLOTS, G, true, false, true, true> : snk_count_kernel<K, cfg<K>::THREADS, SNK_GSCREEN_SLOTS, G, false, false, true, true>;
     }
     if (tight && !screen) kern = a.nseg > 1 ? snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G, true, false, true> : snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G, false, false, true>;
@@ -836,6 +848,7 @@ int snk_launch_compact_regions(hipStream_t st, const snk_u128* keys_in, const ui
     return SNK_OK;
 }
 
+uint32_t snk_count_screen_limit() { return SNK_GSCREEN_SLOTS - 64; }      // usable slots of the SCREEN instantiations' table
 uint32_t snk_count_slots(uint32_t K) { return K == 60 ? cfg<60>::SLOTS : cfg<48>::SLOTS; }
 
 uint32_t snk_count_limit(uint32_t K, uint32_t grouped, uint32_t tight) {

@@ -52,7 +52,9 @@ struct snk_ctx {
     uint64_t last_ovf_reads = 0;
     uint64_t last_dense = 0;                            // supermer records of the last dense partition pass (last_ovf_nb == 0xD0000000)
     double retain_ratio = 0.0;                         // retained k-mers per k-mer instance of the last call (same key as claim_ratio)
+    uint32_t count_screen = 0;                         // ungrouped call: the count launches run their instances through the bit filter first (level; snk_count.hip SCREEN)
     uint32_t count_tight = 0;                          // this call's count launches book their table slots (error-rich data, per-barcode groups: fuller tables, fewer buckets)
+    double screen_ratio = 0.0;                         // the distinct-per-instance ratio an ungrouped screened call was decided on
     double claim_ratio = 0.0;                          // distinct k-mers per k-mer instance the count kernel saw in the last call ...
     uint64_t claim_ratio_reads = 0;                    // ... over this many reads ...
     uint32_t claim_ratio_k = 0;                        // ... in this mode (2 K + grouped + 256 x minimiser length)

@@ -65,7 +65,7 @@ static int graph_tail(snk_ctx* ctx, hipStream_t st, const snk_params* p, uint32_
                       snk_table& tab, const snk_partition& part, snk_dev_result* out, phase_timer& tm, char* err, size_t errcap) {
     int rc;
     void* records = part.records;
-    if (h_ninst) { ctx->claim_ratio = (double)tab.distinct / (double)h_ninst; ctx->claim_ratio_reads = n_reads; ctx->claim_ratio_k = K * 2 + (grouped ? 1u : 0u) + 256u * ctx->mlen;
+    if (h_ninst) { ctx->claim_ratio = (ctx->count_screen && !grouped && ctx->screen_ratio > 0.0) ? ctx->screen_ratio : (double)tab.distinct / (double)h_ninst; ctx->claim_ratio_reads = n_reads; ctx->claim_ratio_k = K * 2 + (grouped ? 1u : 0u) + 256u * ctx->mlen;
                    ctx->retain_ratio = (double)tab.n / (double)h_ninst; }
     snk_ctx_release_block(ctx, records);       // the fixed-capacity supermer slots: the graph stage may reuse the memory
     const uint64_t n_kmers = tab.n;
@@ -240,6 +240,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     auto target_for = [&](double ratio) -> uint32_t {
         const uint32_t default_target = default_target_now();
         if (target_forced) return env_u32("SNK_TARGET_INST", default_target);
+        if (ctx->count_screen && !grouped) return env_u32("SNK_SCREEN_TARGET", 4000);
         if (retain > 0.0 && (!grouped || group_screen)) {       // (groups behind the bit filter: buckets of 5200 instances, unless that many would retain more than a graph chunk holds)
             const double t = (double)env_u32("SNK_CHUNK_KMERS", 150) / retain;
             if (t < (double)default_target) {
@@ -275,7 +276,20 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     for (int pass = 0; pass < 2; ++pass) {
         NB = p->n_buckets;
         ctx->count_tight = tight_for(adaptive ? ratio : (have_hint ? ctx->claim_ratio : 0.0));
-        ctx->last_count_limit = snk_count_limit(K, grouped ? 1u : 0u, ctx->count_tight);
+        // ungrouped reads whose tables run very full (1.5 % errors: 0.41 distinct k-mers per instance, most of them seen once or twice): the bit
+        // filter of the per-barcode groups in front of a 1024-slot table -- the table then sees what can be retained and the bucket is as large
+        // as one batch of records and ten instances per lane allow.  SNK_COUNT_SCREEN_NG: 0 never, 2 always, default: ratio above 0.3
+        // (0.6 % errors, ratio 0.21, lose with it: a fifth of their instances are singletons, the first pass costs more than it saves)
+        {
+            const double r_now = adaptive ? ratio : (have_hint ? ctx->claim_ratio : 0.0);
+            const uint32_t ng = env_u32("SNK_COUNT_SCREEN_NG", 1);
+            ctx->count_screen = (!grouped && K == 48 && p->min_freq >= 3 && (!in->bc || p->min_bc <= 2) && ng && (ng >= 2 || r_now > 0.01 * env_u32("SNK_SCREEN_RATIO_PCT", 30))) ? 3u : 0u;
+            { const char* te = getenv("SNK_COUNT_TIGHT"); if (te && te[0] == '0' && !te[1]) ctx->count_screen = 0; }      // (the filter comes with booked slots)
+            if (ctx->count_screen && !ctx->count_tight) ctx->count_tight = (snk_count_slots(K) - snk_count_slots(K) / 16u) | (env_u32("SNK_TIGHT_TRIES", 48) << 16);
+            if (ctx->count_screen && r_now > 0.0) ctx->screen_ratio = r_now;      // (what the screened call reports is the table's view: the decision keeps the ratio it was made on)
+            ctx->last_count_limit = snk_count_limit(K, grouped ? 1u : 0u, ctx->count_tight);
+            if ((ctx->count_screen || (group_screen && ctx->count_tight)) && K == 48) ctx->last_count_limit = std::min(ctx->last_count_limit, snk_count_screen_limit());
+        }
         if (NB == 0) {
             const uint32_t target = target_for(adaptive ? ratio : 0.0);
             uint64_t nb = (ub_inst + target - 1) / target;
@@ -411,6 +425,7 @@ extern "C" int snk_dev_stream_begin(snk_ctx* ctx, const snk_params* p, uint32_t 
     if (p->min_bc > 8) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "min_bc=%u: the device barcode rule tells up to eight distinct barcodes apart (min_bc <= 8)", p->min_bc);
     snk_set_mlen(ctx, p);
     ctx->count_tight = 0;          // (a streamed job cannot partition again: the default kernel and its bucket rule)
+    ctx->count_screen = 0;
     if (read_len == 0 || read_len > 256 || total_reads_ub == 0) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_stream_begin: read_len 1..256 and an upper bound of the job's reads are needed");
     if ((p->flags & SNK_F_GROUPED)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_dev_stream_begin: per-group graphs take their reads resident (snk_dev_count_graph)");
     SNK_HIP_TRY(hipSetDevice(ctx->device));

@@ -220,6 +220,7 @@ int excl_scan(step_ctx& X, In in, Out* out, size_t n, Out init) {
 
 int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_params* p, uint64_t total_reads, uint32_t flags, snk_shard_result* out) {
     X.ctx->count_tight = 0;        // (the ranks size their buckets alike, from one rule: the default count kernel's)
+    X.ctx->count_screen = 0;
     snk_ctx* ctx = X.ctx;
     snk_comm* comm = X.comm;
     hipStream_t st = X.st;
@@ -816,6 +817,7 @@ extern "C" int snk_shard_stream_begin(snk_ctx* ctx, snk_comm* comm, const snk_pa
     const uint32_t W = comm->world, K = p->K;
     ctx->arena_legacy = W > 1;
     ctx->count_tight = 0;
+    ctx->count_screen = 0;
     snk_set_mlen(ctx, p);
     const uint64_t kpr = read_len >= K ? read_len - K + 1 : 0;
     const uint64_t inst_ub = total_reads * kpr;

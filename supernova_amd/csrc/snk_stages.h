@@ -73,7 +73,8 @@ struct snk_count_pilot {
     int (*agree)(void* user, double* per_bucket);
     void* user;
 };
-uint32_t snk_count_limit(uint32_t K, uint32_t grouped, uint32_t tight);      // distinct k-mers one pass over a bucket may hold
+uint32_t snk_count_limit(uint32_t K, uint32_t grouped, uint32_t tight);
+uint32_t snk_count_screen_limit();      // distinct k-mers one pass over a bucket may hold
 int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* records, const uint64_t* seg_beg,
                           const uint64_t* seg_end, uint32_t seg_stride, uint32_t nseg, uint32_t NB, uint32_t min_freq, uint32_t bc_mode, uint32_t grouped, uint64_t n_inst_hint,
                           uint32_t* status, bool want_sort, snk_table* out, char* err, size_t errcap,

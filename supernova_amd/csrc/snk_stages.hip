@@ -95,6 +95,7 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
         // min_freq 2 a quarter of the instances pass the filter and the larger buckets cost more than they save: 428 against 270 ms.
         // SNK_COUNT_SCREEN: 0 never, 1 at min_freq >= 3, 2 at min_freq >= 2 as well)
         { const uint32_t sc = grouped ? env_u32("SNK_COUNT_SCREEN", 1) : 0u; ca.screen = (sc && min_freq >= (sc >= 2 ? 2u : 3u)) ? std::min(min_freq, 3u) : 0u; }
+        if (!grouped && K == 48 && ctx->count_screen && ctx->count_tight && bc_mode <= 2u) ca.screen = std::min(std::min(min_freq, 3u), ctx->count_screen);
         ca.bucket0 = 0;
         ca.out_keys = keys_r;
         ca.out_vals = vals_r;

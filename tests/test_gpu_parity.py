@@ -273,14 +273,21 @@ def test_error_rich_reads_are_repartitioned_into_smaller_buckets(engine, monkeyp
         e2 = Engine(0)
         try:
             r1 = e2.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48, sorted_table=False))
-            assert r1.repartitioned == 1 and r1.n_buckets > 1.5 * nb0 and r1.buckets_split < r1.n_buckets // 4
-            assert e2.last_count_limit() == 1920     # tables that run full: the second partition is counted with booked slots
+            assert r1.repartitioned == 1 and r1.n_buckets > 1.1 * nb0 and r1.buckets_split < r1.n_buckets // 4
+            # tables that run this full (0.4 distinct k-mers per instance): the second partition is counted behind the bit filter, whose table
+            # has 960 usable slots (SNK_COUNT_SCREEN_NG=0: booked slots alone, 1920, and buckets half the size)
+            assert e2.last_count_limit() in (960, 1920)      # (at this size the pilot's ratio lies around the filter's threshold of 0.3)
             got = table(r1)
             assert all(np.array_equal(a, b) for a, b in zip(ref[:3], got[:3])) and ref[3] == got[3]
             r2 = e2.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48, sorted_table=False))      # the hint: no second partition
-            assert r2.repartitioned == 0 and r2.n_buckets > 1.5 * nb0
+            assert r2.repartitioned == 0 and r2.n_buckets > 1.1 * nb0 and e2.last_count_limit() in (960, 1920)
             got2 = table(r2)
             assert all(np.array_equal(a, b) for a, b in zip(ref[:3], got2[:3])) and ref[3] == got2[3]
+            monkeypatch.setenv("SNK_COUNT_SCREEN_NG", "0")
+            r3 = e2.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48, sorted_table=False))
+            assert e2.last_count_limit() == 1920 and r3.n_buckets > 1.5 * nb0
+            got3 = table(r3)
+            assert all(np.array_equal(a, b) for a, b in zip(ref[:3], got3[:3])) and ref[3] == got3[3]
         finally:
             e2.close()
     finally:
@@ -545,8 +552,9 @@ def test_full_size_properties_1e8(engine, graph_stage):
 
 def test_full_size_booked_slots_1e8(engine, graph_stage, monkeypatch):
     """100 M reads with 1.5 % substitutions and long low-quality tails (config.robust's second model) at full size: the call that lets the
-    data switch the count kernel to booked table slots (snk_ctx_last_count_limit = 1920: 2.6 x the distinct k-mers of clean reads) gives the
-    table -- checksum over keys, counts and contexts -- and the unitigs of the default kernel on smaller buckets."""
+    data switch the count kernel to the bit filter + booked slots (snk_ctx_last_count_limit = 960; 2.6 x the distinct k-mers of clean reads),
+    the one with booked slots alone (1920) and the default kernel on smaller buckets (1216) give the same table -- checksum over keys, counts
+    and contexts -- and the same unitigs."""
     import torch
     from supernova_amd import synth
     from supernova_amd.engine import Engine, Params
@@ -571,13 +579,17 @@ def test_full_size_booked_slots_1e8(engine, graph_stage, monkeypatch):
             return dict(n_inst=r.n_instances, nk=nk, chk=int(chk), nu=r.n_unitigs, nb=r.n_buckets, off=off.clone(), bases=bases.clone(), lim=e.last_count_limit())
 
         run()                       # (the first call looks at the first buckets and partitions again)
-        a = run()
-        assert a["lim"] == 1920 and a["nk"] > 200_000_000
+        a = run()                   # 0.4 distinct k-mers per instance: the bit filter in front of a 1024-slot table
+        assert a["lim"] == 960 and a["nk"] > 200_000_000
+        monkeypatch.setenv("SNK_COUNT_SCREEN_NG", "0")
+        c = run()                   # booked slots alone
+        assert c["lim"] == 1920 and c["nb"] > a["nb"]
         monkeypatch.setenv("SNK_COUNT_TIGHT", "0")
-        b = run()
-        assert b["lim"] == 1216 and b["nb"] > a["nb"]
-        assert (a["n_inst"], a["nk"], a["chk"], a["nu"]) == (b["n_inst"], b["nk"], b["chk"], b["nu"])
-        assert torch.equal(a["off"], b["off"]) and torch.equal(a["bases"], b["bases"])
+        b = run()                   # the default kernel on still smaller buckets
+        assert b["lim"] == 1216 and b["nb"] > c["nb"]
+        for o in (b, c):
+            assert (a["n_inst"], a["nk"], a["chk"], a["nu"]) == (o["n_inst"], o["nk"], o["chk"], o["nu"])
+            assert torch.equal(a["off"], o["off"]) and torch.equal(a["bases"], o["bases"])
     finally:
         e.close()
         torch.cuda.empty_cache()

@@ -10,7 +10,7 @@ from supernova_amd.engine import Engine, Params
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100_000_000
 want = sys.argv[2].split(",") if len(sys.argv) > 2 else ["headline", "e06", "e15"]
 graph = not (len(sys.argv) > 3 and sys.argv[3] == "count")      # "count": stop after the table (a variant whose table outgrows the graph stage's chunks)
-MODELS = {"headline": {}, "e06": dict(sub_ppm=6000), "e15": dict(sub_ppm=15000, lowq_tail_ppm=500000), "cov28": dict(genome_len=n * 150 // 28),
+MODELS = {"headline": {}, "e06": dict(sub_ppm=6000), "e15": dict(sub_ppm=15000, lowq_tail_ppm=500000), "e10": dict(sub_ppm=10000), "e15n": dict(sub_ppm=15000), "e25": dict(sub_ppm=25000), "cov28": dict(genome_len=n * 150 // 28),
           "crowded": dict(repeat_mode=16),      # the bench's reads over a genome with ~1 site per canonical 16-mer value (human: 1.4), at 56x
           "human": dict(genome_len=3_100_000_000)}      # a genome of human size under these reads (4.8x at 1e8 reads: what the minimiser space of configs 3-5 looks like)
 eng = Engine(0)
