@@ -99,7 +99,10 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     // ONE batch (with 256, 55 % of the buckets ran a second, mostly empty batch through all the phases below).  K=60 and
     // grouped runs have 64-bit low key words: 256 keeps the workgroup under 80 KB of LDS, i.e. two per CU.
     // (grouped SCREEN with a 1024-slot table -- the table only sees a tenth of the instances -- has the room for 512-record batches as well)
-    constexpr int BATCH = (K == 48 && ((!GROUPED && (SLOTS >= 2048 || SCREEN)) || (GROUPED && SCREEN && SLOTS <= 1024))) ? 512 : 256;
+#ifndef SNK_GSCREEN_BATCH
+#define SNK_GSCREEN_BATCH 512
+#endif
+    constexpr int BATCH = (GROUPED && SCREEN && SLOTS <= 1024 && K == 48) ? SNK_GSCREEN_BATCH : ((K == 48 && !GROUPED && (SLOTS >= 2048 || SCREEN)) ? 512 : 256);
     constexpr int DD = 2 * BATCH;                        // de-duplication table slots
     typedef typename klo_t<K, GROUPED>::type lo_type;
     constexpr int WMAX = K - SNK_M_MIN_OF(K) + 1;                  // k-mers per supermer, at most
@@ -135,8 +138,11 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
 #ifndef SNK_GSCREEN_SLOTS
 #define SNK_GSCREEN_SLOTS 1024          // table slots of the grouped SCREEN instantiation: the table sees a tenth of the instances, half of it pays for 512-record batches (2048: 256-record batches, 104.6 instead of 92.2 ms)
 #endif
-    constexpr int SROUNDS = (SCREEN && SLOTS <= 1024) ? SNK_SCREEN_ROUNDS + 4 : SNK_SCREEN_ROUNDS;                        // SCREEN: instances per lane (their cells ride in two registers)
-    static_assert(SROUNDS >= 1 && SROUNDS <= 10, "two cells per register");
+#ifndef SNK_GSCREEN_ROUNDS
+#define SNK_GSCREEN_ROUNDS (SNK_SCREEN_ROUNDS + 4)
+#endif
+    constexpr int SROUNDS = (SCREEN && SLOTS <= 1024) ? SNK_GSCREEN_ROUNDS : SNK_SCREEN_ROUNDS;                        // SCREEN: instances per lane (their cells ride in two registers)
+    static_assert(SROUNDS >= 1 && SROUNDS <= 16, "two cells per register");
     // words per bit plane.  Grouped runs: the de-duplication table and the weights hold the three planes (neither is used there); ungrouped
     // runs (error-rich reads; both are in use): their own array behind the candidate list
 #ifndef SNK_NGSCREEN_PLANE_WORDS
@@ -771,7 +777,7 @@ template <> struct cfg<60> { static constexpr int THREADS = SNK_COUNT_THREADS; s
 
 template <int K, bool G>
 size_t lds_bytes(uint32_t bc_mode = 0, bool tight = false, bool screen = false) {
-    const size_t S = screen ? SNK_GSCREEN_SLOTS : cfg<K>::SLOTS, B = (K == 48 && ((!G && (S >= 2048 || screen)) || (G && screen && S <= 1024))) ? 512 : 256, DD = 2 * B, NCI = B * (K - SNK_M_MIN_OF(K) + 1) / 32 + 2;
+    const size_t S = screen ? SNK_GSCREEN_SLOTS : cfg<K>::SLOTS, B = (G && screen && S <= 1024 && K == 48) ? SNK_GSCREEN_BATCH : ((K == 48 && !G && (S >= 2048 || screen)) ? 512 : 256), DD = 2 * B, NCI = B * (K - SNK_M_MIN_OF(K) + 1) / 32 + 2;
     return S * (8 + sizeof(typename klo_t<K, G>::type) + 4 + 4 + 4) + S + 4 * (8 * B + (tight ? 72 : 64) + DD + B) + 2 * (B + B + 2 + NCI) + 16 + 2 * 4 * 3 * SNK_COUNT_MAXSEG + 2 * (tight ? S - 64 : S - cfg<K>::THREADS - 64) + 16 + (bc_mode > 2 ? S * 24 + 16 : 0) + (screen ? (G ? (S <= 1024 ? 4096 : 2048) : 8192 + 3 * SNK_NGSCREEN_PLANE_WORDS * 4) + 16 : 0);
 }
 

@@ -1,6 +1,8 @@
 #!/bin/bash
-# round 5: ungrouped bit filter as committed (auto above 0.3 distinct k-mers per instance, 4000 instances per bucket): suite, forced parity, models
-timeout 2400 python -m pytest tests -m gpu -q --timeout 400 > gpurun_out/r5_suite.log 2>&1; grep -E "passed|failed|error" gpurun_out/r5_suite.log | tail -3
-SNK_COUNT_SCREEN_NG=2 timeout 1200 python -m pytest tests/test_gpu_parity.py -q --timeout 200 -k "golden or oracle or hot or passes or minbc or independence or k60 or booked or full_size" 2>&1 | grep -E "passed|failed|Error|error" | tail -3
-SNK_COUNT_SCREEN_NG=2 timeout 600 python tests/tools/fuzz_parity.py 60 9191 2>&1 | tail -1
-timeout 300 python tools/err_probe.py 1e8 e06,e15 2>&1 | grep -v amdgpu | grep "call"
+# round 5: grouped screen with 768-record batches and 14 rounds per lane (tuning build)
+B="--steps 4 --warmup 2 --no-cpu-baseline --no-next-rows --no-ingest --no-robust --grouped"
+P="import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print(round(d['ms_per_step'],2), round(d['value'],2), d['config']['phase_ms_rank0']['partition'], d['config']['phase_ms_rank0']['count'], d['config']['phase_ms_rank0']['graph'], d['config'].get('retained_kmers_rank0'), d['config'].get('unitigs_rank0'))"
+echo -n "committed (512 records, 10 rounds, 5200): "; timeout 200 python bench.py $B 2>/dev/null | python -c "$P"
+export SNK_LIB_PATH=$PWD/supernova_amd/variants/libsnk_b768.so
+timeout 300 python -m pytest tests/test_gpu_parity.py -x -q --timeout 300 -k "grouped" 2>&1 | grep -E "passed|failed|Error|error" | tail -2
+for t in 5200 6500 7500 8500; do echo -n "768 records target $t: "; SNK_TARGET_INST=$t timeout 200 python bench.py $B 2>/dev/null | python -c "$P"; done
