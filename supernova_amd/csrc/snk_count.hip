@@ -36,6 +36,22 @@ constexpr int MAX_SPLIT_LOG2 = 20;      // (split ids are 24-bit fields; the spl
 #ifndef SNK_COUNT_THREADS
 #define SNK_COUNT_THREADS 768
 #endif
+// ---- build parameters of the SCREEN instantiations (tuning builds: tools/build_variant.sh)
+#ifndef SNK_SCREEN_ROUNDS
+#define SNK_SCREEN_ROUNDS 6
+#endif
+#ifndef SNK_GSCREEN_SLOTS
+#define SNK_GSCREEN_SLOTS 1024          // table slots of the grouped SCREEN instantiation: the table sees a tenth of the instances, half of it pays for 512-record batches (2048: 256-record batches, 104.6 instead of 92.2 ms)
+#endif
+#ifndef SNK_GSCREEN_BATCH
+#define SNK_GSCREEN_BATCH 512
+#endif
+#ifndef SNK_GSCREEN_ROUNDS
+#define SNK_GSCREEN_ROUNDS (SNK_SCREEN_ROUNDS + 4)
+#endif
+#ifndef SNK_NGSCREEN_PLANE_WORDS
+#define SNK_NGSCREEN_PLANE_WORDS 512
+#endif
 #ifndef SNK_COUNT_SLOTS
 #define SNK_COUNT_SLOTS 2048
 #endif
@@ -99,9 +115,6 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     // ONE batch (with 256, 55 % of the buckets ran a second, mostly empty batch through all the phases below).  K=60 and
     // grouped runs have 64-bit low key words: 256 keeps the workgroup under 80 KB of LDS, i.e. two per CU.
     // (grouped SCREEN with a 1024-slot table -- the table only sees a tenth of the instances -- has the room for 512-record batches as well)
-#ifndef SNK_GSCREEN_BATCH
-#define SNK_GSCREEN_BATCH 512
-#endif
     constexpr int BATCH = (GROUPED && SCREEN && SLOTS <= 1024 && K == 48) ? SNK_GSCREEN_BATCH : ((K == 48 && !GROUPED && (SLOTS >= 2048 || SCREEN)) ? 512 : 256);
     constexpr int DD = 2 * BATCH;                        // de-duplication table slots
     typedef typename klo_t<K, GROUPED>::type lo_type;
@@ -132,22 +145,10 @@ __global__ void __launch_bounds__(THREADS, 6) snk_count_kernel(snk_count_args a)
     // (so min_bc <= 8).  Only allocated for such runs (a.bc_mode > 2); they give up the second workgroup per CU.
     uint32_t* bcx = reinterpret_cast<uint32_t*>(smem_raw + (((size_t)(reinterpret_cast<unsigned char*>(olist + (TIGHT ? SLOTS - 64 : SLOTS - THREADS - 64)) - smem_raw) + 15) & ~(size_t)15));   // [SLOTS][6]
     const bool bcset = a.bc_mode > 2;
-#ifndef SNK_SCREEN_ROUNDS
-#define SNK_SCREEN_ROUNDS 6
-#endif
-#ifndef SNK_GSCREEN_SLOTS
-#define SNK_GSCREEN_SLOTS 1024          // table slots of the grouped SCREEN instantiation: the table sees a tenth of the instances, half of it pays for 512-record batches (2048: 256-record batches, 104.6 instead of 92.2 ms)
-#endif
-#ifndef SNK_GSCREEN_ROUNDS
-#define SNK_GSCREEN_ROUNDS (SNK_SCREEN_ROUNDS + 4)
-#endif
     constexpr int SROUNDS = (SCREEN && SLOTS <= 1024) ? SNK_GSCREEN_ROUNDS : SNK_SCREEN_ROUNDS;                        // SCREEN: instances per lane (their cells ride in two registers)
     static_assert(SROUNDS >= 1 && SROUNDS <= 16, "two cells per register");
     // words per bit plane.  Grouped runs: the de-duplication table and the weights hold the three planes (neither is used there); ungrouped
     // runs (error-rich reads; both are in use): their own array behind the candidate list
-#ifndef SNK_NGSCREEN_PLANE_WORDS
-#define SNK_NGSCREEN_PLANE_WORDS 512
-#endif
     constexpr int SPW = GROUPED ? ((DD + BATCH) / 3 >= 512 ? 512 : 256) : SNK_NGSCREEN_PLANE_WORDS;
     constexpr uint32_t SCB = SPW == 1024 ? 17u : (SPW == 512 ? 18u : 19u);                // cell = the top 15 / 14 / 13 bits of h1
     // SCREEN: candidate list (instance indices), in bcx's place (SCREEN runs keep up to two barcodes per slot: no bcx)
