@@ -179,9 +179,11 @@ int all_ranges_ready(void* user) {       // the whole exchange has landed (the h
     return 0;
 }
 
-uint32_t plan_buckets(uint64_t inst_ub, uint32_t world, uint32_t K, uint32_t forced, double ratio, uint32_t* tight_out = nullptr) {
+uint32_t plan_buckets(uint64_t inst_ub, uint32_t world, uint32_t K, uint32_t forced, double ratio, uint32_t* tight_out = nullptr, uint32_t* screen_out = nullptr) {
     uint64_t nb = forced;
     if (tight_out) *tight_out = 0;
+    const bool screen_ok = screen_out && *screen_out;       // (in: the call's parameters allow the bit filter; out: it is taken)
+    if (screen_out) *screen_out = 0;
     if (!nb) {
         const uint32_t dflt = K == 48 ? 5000u : 3500u;
         uint64_t target = snk_env_u32("SNK_TARGET_INST", dflt);
@@ -196,6 +198,9 @@ uint32_t plan_buckets(uint64_t inst_ub, uint32_t world, uint32_t K, uint32_t for
                 lim = (double)snk_count_limit(K, 0u, *tight_out);
             }
             if (0.65 * lim / ratio < (double)dflt) { const double t = 0.01 * snk_env_u32("SNK_BUCKET_FILL_PCT", 50) * lim / ratio; target = t < 600.0 ? 600u : (uint64_t)t; if (target > dflt) target = dflt; }
+            // (... and above 0.3 distinct k-mers per instance behind the bit filter, whose table only sees what can be retained: snk_pipeline.hip)
+            const uint32_t ng = snk_env_u32("SNK_COUNT_SCREEN_NG", 1);
+            if (screen_ok && tight_out && *tight_out && ng && (ng >= 2 || ratio > 0.01 * snk_env_u32("SNK_SCREEN_RATIO_PCT", 30))) { *screen_out = 3; target = snk_env_u32("SNK_SCREEN_TARGET", 4000); }
         }
         nb = (inst_ub + target - 1) / target;
         if (nb < 1) nb = 1;
@@ -405,7 +410,14 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
     for (int pass = 0; pass < 2; ++pass) {
         // (a streamed step sized its buckets when it was opened -- the same rule on the same job-wide figures -- and cannot partition twice: its
         // slabs are gone; error-rich data without the group's history are counted in hash-split sub-passes then)
-        { uint32_t tight = 0; NB_total = X.streamed ? snk_shard_state_of(ctx)->NB_total : plan_buckets(inst_ub, W, K, p->n_buckets, adaptive ? ratio : 0.0, &tight); ctx->count_tight = tight; ctx->last_count_limit = snk_count_limit(K, 0u, tight); }
+        {
+            uint32_t tight = 0, screen = (K == 48 && p->min_freq >= 3 && (!has_bc || p->min_bc <= 2)) ? 1u : 0u;
+            NB_total = X.streamed ? snk_shard_state_of(ctx)->NB_total : plan_buckets(inst_ub, W, K, p->n_buckets, adaptive ? ratio : 0.0, &tight, &screen);
+            if (X.streamed) screen = 0;
+            ctx->count_tight = tight; ctx->count_screen = screen;
+            ctx->last_count_limit = screen ? std::min(snk_count_limit(K, 0u, tight), snk_count_screen_limit()) : snk_count_limit(K, 0u, tight);
+            if (screen && ratio > 0.0) { comm->claim_ratio = ratio; comm->claim_ratio_reads = inst_ub; comm->claim_ratio_k = K * 2 + 256u * ctx->mlen; }      // (a screened step reports the table's view: the group keeps the ratio the decision was made on)
+        }
         NBl = NB_total / W;
         tm.n = 1;
         const int rcp = count_pass(adaptive && !have_ratio && pass == 0 && p->n_buckets == 0 && !X.streamed);
@@ -445,7 +457,7 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
             q_send[q] = qall[(size_t)me * (W + QX) + q]; q_recv[q] = qall[(size_t)q * (W + QX) + me]; all_n[q] = qall[(size_t)q * (W + QX) + W];
             dsum += qall[(size_t)q * (W + QX) + W + 1]; isum += qall[(size_t)q * (W + QX) + W + 2];
         }
-        if (isum) { comm->claim_ratio = (double)dsum / (double)isum; comm->claim_ratio_reads = inst_ub; comm->claim_ratio_k = K * 2 + 256u * ctx->mlen; }      // (job-wide figures, kept with the group: every rank takes the same decision next time)
+        if (isum && !X.ctx->count_screen) { comm->claim_ratio = (double)dsum / (double)isum; comm->claim_ratio_reads = inst_ub; comm->claim_ratio_k = K * 2 + 256u * ctx->mlen; }      // (job-wide figures, kept with the group: every rank takes the same decision next time)
     }
     uint64_t nq = 0, nq_in = 0;
     for (uint32_t q = 0; q < W; ++q) { nq += q_send[q]; nq_in += q_recv[q]; }

@@ -454,10 +454,12 @@ def test_sharded_bucket_size_follows_the_data(snk, n):
         assert np.array_equal(keys[order], ref_keys) and np.array_equal(counts[order], ref_counts)
         assert sorted(u for o in outs[step] for u in o["unitigs"]) == ref_unitigs
         assert outs[step][0]["nb"] == outs[step][1]["nb"]
-    assert all(o["lim"] == 1920 for o in outs[1])        # tables that run full: booked slots, on every rank (snk_count.hip TIGHT)
+    # tables that run this full (0.4 distinct k-mers per instance): the bit filter in front of a 1024-slot table (960 usable), booked slots, on every
+    # rank -- the same turn the one-GPU path takes, from the job-wide ratio
+    assert all(o["lim"] == 960 for o in outs[1])
     if n < 2_000_000:
         assert outs[0][0]["lim"] == 1216
-        assert outs[0][0]["rep"] == 0 and outs[1][0]["nb"] > 1.5 * outs[0][0]["nb"]
+        assert outs[0][0]["rep"] == 0 and outs[1][0]["nb"] > 1.1 * outs[0][0]["nb"]
     else:
         assert outs[0][0]["rep"] == 1 and outs[0][1]["rep"] == 1 and outs[1][0]["rep"] == 0
         assert outs[0][0]["nb"] * W * 5000 > 1.5 * n * 103 and abs(outs[1][0]["nb"] - outs[0][0]["nb"]) < 0.2 * outs[0][0]["nb"]
