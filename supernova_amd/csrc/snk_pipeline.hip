@@ -235,14 +235,14 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     const bool target_forced = getenv("SNK_TARGET_INST") && *getenv("SNK_TARGET_INST");
     // ... and the RETAINED k-mers of a bucket are one chunk of the bucket-local graph stage, whose one-wave kernels hold 256 of them
     // (larger chunks take the slower big-chunk variants): at half the coverage twice as many k-mers survive per instance, every other
-    // chunk was over the line and the graph stage took 81 instead of ~58 ms.  From the previous call's retained share: chunks of ~150.
+    // chunk was over the line and the graph stage took 81 instead of ~58 ms.  From the previous call's retained share: chunks of ~180 (28x coverage, with merged chunks behind it: 153.2 ms at 120, 149.5 at 150, 147.7 at 180, 147.5 at 210).
     const double retain = (same_data && ctx->retain_ratio > 0.0 && ctx->claim_ratio_reads == n_reads && ctx->claim_ratio_k == K * 2 + (grouped ? 1u : 0u) + 256u * ctx->mlen) ? ctx->retain_ratio : 0.0;
     auto target_for = [&](double ratio) -> uint32_t {
         const uint32_t default_target = default_target_now();
         if (target_forced) return env_u32("SNK_TARGET_INST", default_target);
         if (ctx->count_screen && !grouped) return env_u32("SNK_SCREEN_TARGET", 4000);
         if (retain > 0.0 && (!grouped || group_screen)) {       // (groups behind the bit filter: buckets of 5200 instances, unless that many would retain more than a graph chunk holds)
-            const double t = (double)env_u32("SNK_CHUNK_KMERS", 150) / retain;
+            const double t = (double)env_u32("SNK_CHUNK_KMERS", 180) / retain;
             if (t < (double)default_target) {
                 uint32_t tt = t < 600.0 ? 600u : (uint32_t)t;
                 if (ratio > 0.0) {           // the tighter of the two limits
