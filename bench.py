@@ -82,6 +82,10 @@ def parse():
                     help="one-GPU path: device memory mapped into the context's arena before the first call (snk_ctx_reserve), as a host that owns the GPU "
                          "does at start-up; -1 = 1.3 GB per million reads up to 45 %% of the device, 0 = none (every call that outgrows the arena pays "
                          "the driver ~25-30 ms per new GB inside the call)")
+    ap.add_argument("--no-df-seam", action="store_true", help="N=1: skip the untimed b1/b2 row (reads.fastb / .qualp / .bci -> device decode -> unitigs)")
+    ap.add_argument("--df-reads", type=float, default=1e8, help="reads of the df_seam row's stage-input files")
+    ap.add_argument("--df-dir", default="", help="where the df_seam row writes its files (default: $TMPDIR or /tmp)")
+    ap.add_argument("--df-threads", type=int, default=0, help="pread workers of the df_seam row (0 = from the CPU budget, at most 32)")
     ap.add_argument("--ingest-files", type=int, default=64)
     ap.add_argument("--ingest-pairs", type=int, default=100_000, help="read pairs per FASTH file of the f3 row")
     ap.add_argument("--ingest-threads", type=int, default=0, help="decode threads (0 = one per file up to the host's hardware threads)")
@@ -215,6 +219,82 @@ def ingest_row(eng, args, K, step_ms_per_read):
                 "count_graph_on_ingested": {"retained_kmers": n_k, "unitigs": n_u},
                 # how long the device step of the same reads is against their ingest: the share of the ingest the step hides behind
                 "step_over_ingest": (step_ms_per_read * n * 1e-3) / secs, "synth_files_written_in_s": t_write}
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+
+
+def df_seam_row(eng, args, K):
+    """b1/b2 at rate: the ASSEMBLER_DF stage inputs -- reads.fastb / reads.qualp / reads.bci -- of a synthetic data set
+    decoded on the device and streamed into count+graph (snk_df_open / snk_dev_ingest_df_count_graph, what supernova_amd/df_stage.py and
+    snk_mspedges run), against the same reads decoded into resident arrays and counted by one resident call.  Files are written once by the
+    library's own writer (qualities jittered over [30, 38): a quality file of sequencer-like entropy with the same trim), so they sit in the
+    page cache.  Beside it: the rate of the old one-thread host readers on a prefix of the same data."""
+    import hashlib
+    import shutil
+    from supernova_amd import dfin, formats, synth
+    from supernova_amd.engine import Params
+    n = int(args.df_reads) & ~1
+    sp = synth.synth_params(n, seed=0x5EED0DF5, unbarcoded_ppm=0)
+    td = Path(tempfile.mkdtemp(prefix="snk_df_", dir=args.df_dir or os.environ.get("TMPDIR", "/tmp")))
+    params = Params(K=K, sorted_table=False)
+    try:
+        t0 = time.perf_counter()
+        dfin.write_synth_df(td / "reads", sp, qual_jitter=8)
+        t_write = time.perf_counter() - t0
+        n_small = min(n, 2_000_000)
+        dfin.write_synth_df(td / "small", sp, n=n_small, qual_jitter=8)
+        t0 = time.perf_counter()
+        rows_h, lens_h, mx = formats.read_fastb(td / "small.fastb")
+        t_fb = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        formats.read_qualp(td / "small.qualp", n_small, mx)
+        t_qp = time.perf_counter() - t0
+        del rows_h, lens_h
+        with dfin.DfFiles(td / "reads") as f:
+            fb = f.file_bytes
+            # resident: the decode alone (file bytes -> rows / quality rows / lengths / barcode ids in HBM), then one resident count+graph
+            ing = []
+            for _ in range(2):
+                dr = f.ingest(eng, read_len=sp.read_len, threads=args.df_threads)
+                ing.append(dict(dr.stats))
+                if _ == 0:
+                    dr.close()
+            best_ing = min(ing, key=lambda d: d["seconds"])
+            ref = eng.count_graph_reads(dr.dev_reads(), params)
+            want = (int(ref.n_kmers), int(ref.n_unitigs), int(ref.n_instances), hashlib.sha256(ref.bv_image()).hexdigest(), ref.spectrum().tobytes())
+            del ref
+            dr.close()
+            calls, same = [], True
+            for rep in range(3):
+                t0 = time.perf_counter()
+                res, st = f.count_graph(eng, params, read_len=sp.read_len, threads=args.df_threads)
+                img = res.bv_image()
+                wall = time.perf_counter() - t0
+                got = (int(res.n_kmers), int(res.n_unitigs), int(res.n_instances), hashlib.sha256(img).hexdigest(), res.spectrum().tobytes())
+                same = same and got == want
+                calls.append({"wall_s": round(wall, 4), "ingest_partition_s": round(st["seconds"] - (res.phase_ms["count"] + res.phase_ms["graph"]) * 1e-3, 4),
+                              "io_wait_s": round(st["io_wait_seconds"], 4), "setup_s": round(st["setup_seconds"], 4),
+                              "count_graph_ms": round(res.phase_ms["count"] + res.phase_ms["graph"], 2)})
+                n_inst, n_slabs, moved = int(res.n_instances), st["n_slabs"], st["file_bytes"]
+                del res
+            # the decode read_len = 0 (the row length found by a scan of the file's length table), as the stage adapter calls it
+            t0 = time.perf_counter()
+            res, st0 = f.count_graph(eng, params, threads=args.df_threads)
+            res.bv_image()
+            wall_scan = time.perf_counter() - t0
+            del res
+        best = min(calls[1:], key=lambda c: c["wall_s"])
+        return {"reads": n, "dir": str(td.parent), "file_GB": round(fb / 1e9, 3), "bytes_per_read": round(fb / n, 1), "files_written_in_s": round(t_write, 2),
+                "resident_decode": {"seconds": round(best_ing["seconds"], 4), "file_GB_per_s": round(best_ing["text_bytes"] / best_ing["seconds"] / 1e9, 2),
+                                    "reads_per_s": n / best_ing["seconds"], "io_wait_s": round(best_ing["decode_wait_seconds"], 4),
+                                    "first_call_seconds": round(ing[0]["seconds"], 4), "slabs": best_ing["n_batches"]},
+                "fastb_to_unitigs": {"wall_s": best["wall_s"], "file_GB_per_s": round(moved / best["wall_s"] / 1e9, 2), "reads_per_s": n / best["wall_s"],
+                                     "Gkmers_per_s": round(n_inst / best["wall_s"] / 1e9, 2), "slabs": n_slabs, "calls": calls,
+                                     "wall_s_with_length_scan": round(wall_scan, 4), "includes": "open files .. .bv image on the host"},
+                "same_result_as_resident": bool(same),
+                "io_threads": args.df_threads or "auto", "host_threads": os.cpu_count(), "host_cpu_budget": int(eng.lib.snk_host_cpu_budget()),
+                "old_host_readers": {"reads": n_small, "fastb_reads_per_s": n_small / t_fb, "qualp_reads_per_s": n_small / t_qp,
+                                     "both_reads_per_s": n_small / (t_fb + t_qp), "note": "snk_read_fastb / snk_read_qualp, one thread (tests' byte-for-byte check of the device decode)"}}
     finally:
         shutil.rmtree(td, ignore_errors=True)
 
@@ -560,6 +640,11 @@ def main():
                     out["config"]["f3_ingest"] = ingest_row(eng, args, K, ms_per_step / per_gpu)
                 except Exception as ex:
                     out["config"]["f3_ingest"] = {"failed": str(ex)}
+            if not args.no_df_seam:
+                try:
+                    out["config"]["df_seam"] = df_seam_row(eng, args, K)
+                except Exception as ex:
+                    out["config"]["df_seam"] = {"failed": str(ex)}
             if not args.no_robust and not args.error_free and per_gpu >= 10_000_000 and isinstance(out["config"].get("robust"), dict):
                 try:
                     # the first call on a NEW context, same reads, right after the bench's own engine was closed: what it pays for is

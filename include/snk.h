@@ -502,6 +502,47 @@ int snk_read_qualp(const char* path, uint64_t n_reads, uint32_t qstride, uint8_t
  * (10X/ParseBarcodedFastqs.cc:284-293); expanded to one barcode id per read as DF does (10X/DF.cc:464-469). */
 int snk_read_bci(const char* path, uint64_t n_reads, int32_t* bc_per_read, uint64_t* n_barcodes, char* err, size_t errcap);
 
+/* The same three files decoded ON THE DEVICE, at the rate the bytes can be moved (supernova_amd/csrc/snk_dfin.hip): the reference loads
+ * reads.fastb with bases.ReadAll and walks reads.qualp through VirtualMasterVec<PQVec> (10X/DF.cc:265-272,345,595-597; block codec
+ * feudal/PQVec.cc:86-200; barcode index expansion DF.cc:464-469) -- offset-indexed, uncompressed files.  Here the raw byte ranges of a
+ * slab of reads go from the page cache into a page-locked ring (a pool of `threads` pread workers, 0 = chosen from the CPU budget), up in
+ * one copy per section, and three kernels make packed rows, quality rows, lengths and barcode ids of them; the host parses nothing but the
+ * control blocks and the barcode index.
+ *   snk_df_open       control blocks + the barcode index (bci may be NULL: no ids); nothing else is read
+ *   snk_dev_ingest_df reads [first, first + n) -> resident device arrays as snk_dev_ingest_fasth's (release: snk_dev_ingest_free).  A rank
+ *                     of the N-GPU job passes ITS range and touches only those bytes.  read_len = row length in bases, 0 = the longest
+ *                     read of the file (one scan of its length table, on the device; snk_df_max_len does the scan for a range);
+ *                     slab_reads: reads per slab, 0 = 262144
+ *   snk_dev_ingest_df_count_graph   the same slabs appended to a streamed job (snk_dev_stream_*): partitioned while the next slab's bytes
+ *                     are read and copied, the reads never resident as a whole; res as snk_dev_count_graph's, bit-identical to a
+ *                     resident call on the same reads.  stats: rows / quals / lens / bc stay NULL; text_bytes = file bytes moved.
+ * Errors follow the host readers': SNK_E_IO for a bad offset / length / truncated quality block, SNK_E_ARG for a quality chain longer
+ * than a row (the message names the first offending read). */
+typedef struct snk_df_files snk_df_files;
+typedef struct snk_df_info {
+    uint64_t n_reads, n_barcodes;                 /* n_barcodes = entries of the index - 1 (ordinal 0 = unbarcoded), 0 without one */
+    uint64_t fastb_bytes, qualp_bytes, bci_bytes;
+    uint64_t reserved[3];
+} snk_df_info;
+struct snk_dev_ingest;
+int snk_df_open(const char* fastb, const char* qualp, const char* bci, snk_df_files** out, snk_df_info* info, char* err, size_t errcap);
+void snk_df_close(snk_df_files* f);
+int snk_df_max_len(snk_ctx* ctx, snk_df_files* f, uint64_t first, uint64_t n, uint32_t* max_len, char* err, size_t errcap);
+int snk_dev_ingest_df(snk_ctx* ctx, snk_df_files* f, uint64_t first, uint64_t n, uint32_t read_len, uint32_t threads, uint64_t slab_reads,
+                      struct snk_dev_ingest* out, char* err, size_t errcap);
+int snk_dev_ingest_df_count_graph(snk_ctx* ctx, snk_df_files* f, uint64_t first, uint64_t n, uint32_t read_len, uint32_t threads, uint64_t slab_reads,
+                                  const snk_params* p, int64_t ign_bc_below, snk_dev_result* res, struct snk_dev_ingest* stats, char* err, size_t errcap);
+/* Writers of the triple (tests, bench.py's df_seam row, tools): feudal/FeudalFileWriter.cc:18-140, PQVec.cc:86-127,
+ * BinaryWriter::writeFile(vec<int64_t>).  The reads must be ordered by barcode id (>= 0) -- the index holds one read range per ordinal
+ * (10X/ParseBarcodedFastqs.cc:284-293).  The quality block choice is the writer's own (any chain of valid blocks decodes alike);
+ * adversarial != 0 seeds random block cuts and wider-than-needed values, 1 = a block per value (decoder tests).  snk_synth_df_write: reads [first, first + n) of
+ * the synthetic model (sp->unbarcoded_ppm must be 0); qual_jitter > 1 spreads the model's Q30 over [30, 30 + jitter) -- the same trim,
+ * a quality file of realistic entropy. */
+int snk_write_df(const char* head, uint64_t n, const uint32_t* rows, uint32_t row_words, const uint16_t* lens, uint32_t read_len, const uint8_t* quals,
+                 uint32_t qstride, const int32_t* bc, uint32_t threads, uint64_t adversarial, char* err, size_t errcap);
+int snk_synth_df_write(const char* head, const snk_synth_params* sp, uint64_t first, uint64_t n, uint32_t qual_jitter, uint32_t threads, char* err,
+                       size_t errcap);
+
 /* FASTH = the barcode-sorted read-pair text format of the tada stages (MultiFastqIter, lib/tada/src/multifastq.rs:69-127):
  * gzip, 9 lines per pair (header, R1, Q1, R2, Q2, barcode field, 3 ignored lines).  Returns malloc'ed arrays (free with
  * snk_host_free): ASCII bases and raw phred values in rows of `stride` bytes (read 2q = R1, 2q+1 = R2, cmd_msp.rs:160-181),

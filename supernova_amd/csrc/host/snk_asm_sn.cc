@@ -181,32 +181,22 @@ int main(int argc, char** argv) {
         const std::string lr = kv["LR"];
         if (lr.size() < 6 || lr.compare(lr.size() - 6, 6, ".fastb") != 0) fatal(SNK_E_ARG, "file has incorrect extension", lr.c_str());
         const std::string head = lr.substr(0, lr.size() - 6);
-        uint64_t n_all = 0;
-        uint32_t max_len = 0;
-        uint16_t* lens = nullptr;
-        uint32_t* rows = nullptr;
-        if ((rc = snk_read_fastb(lr.c_str(), &n_all, &max_len, &lens, &rows, err, sizeof err))) fatal(rc, "reads", err);
-        if (max_len == 0) max_len = 1;
-        if (max_len > 256) fatal(SNK_E_UNSUPPORTED, "reads", "reads longer than 256 bases are not supported");
-        std::vector<uint8_t> quals((size_t)n_all * max_len);
-        if ((rc = snk_read_qualp((head + ".qualp").c_str(), n_all, max_len, quals.data(), err, sizeof err))) fatal(rc, "quals", err);
-        std::vector<int32_t> bc(n_all);
-        uint64_t n_bc = 0;
-        if ((rc = snk_read_bci((head + ".bci").c_str(), n_all, bc.data(), &n_bc, err, sizeof err))) fatal(rc, "barcode index", err);
+        // the stage inputs are decoded on the device, and this rank touches only the bytes of ITS reads (the offset tables say where they are)
+        snk_df_files* files = nullptr;
+        snk_df_info info;
+        if ((rc = snk_df_open(lr.c_str(), (head + ".qualp").c_str(), (head + ".bci").c_str(), &files, &info, err, sizeof err))) fatal(rc, "reads", err);
+        const uint64_t n_all = info.n_reads;
         total_reads = n_all;
         const uint64_t lo = (n_all / 2 * rank / world) * 2, hi = rank + 1 == world ? n_all : (n_all / 2 * (rank + 1) / world) * 2, n = hi - lo;
-        const uint32_t rw = (max_len + 15) / 16;
-        hip_ok(hipMalloc(&d_rows, (n + 1) * rw * 4ull), "hipMalloc rows");
-        hip_ok(hipMalloc(&d_quals, (n + 1) * (uint64_t)max_len), "hipMalloc quals");
-        hip_ok(hipMalloc(&d_bc, (n + 1) * 4ull), "hipMalloc bc");
-        hip_ok(hipMalloc(&d_lens, (n + 8) * 2ull), "hipMalloc lens");
-        hip_ok(hipMemcpy(d_rows, rows + lo * rw, n * rw * 4ull, hipMemcpyHostToDevice), "upload rows");
-        hip_ok(hipMemcpy(d_quals, quals.data() + lo * max_len, n * (uint64_t)max_len, hipMemcpyHostToDevice), "upload quals");
-        hip_ok(hipMemcpy(d_bc, bc.data() + lo, n * 4ull, hipMemcpyHostToDevice), "upload bc");
-        hip_ok(hipMemcpy(d_lens, lens + lo, n * 2ull, hipMemcpyHostToDevice), "upload lens");
-        in.n_reads = n; in.rows = d_rows; in.row_words = rw; in.read_len = max_len; in.lens = d_lens; in.quals = d_quals; in.qstride = max_len; in.bc = d_bc;
+        // every rank lays its rows out alike: READ_LEN, or the longest read of the FILE (one scan of its length table, 4 of a read's ~50 bytes)
+        const uint32_t read_len = kv.count("READ_LEN") ? (uint32_t)atoi(kv["READ_LEN"].c_str()) : 0u;
+        if ((rc = snk_dev_ingest_df(ctx, files, lo, n, read_len, 0, 0, &ing, err, sizeof err))) fatal(rc, "reads", err);
+        snk_df_close(files);
+        in.n_reads = ing.n_reads; in.rows = ing.rows; in.row_words = ing.row_words; in.read_len = ing.read_len; in.lens = ing.lens;
+        in.quals = ing.quals; in.qstride = ing.qstride; in.bc = ing.bc;
         in.read_index_base = lo;
-        free(lens); free(rows);
+        fprintf(stderr, "snk_asm_sn[%d/%d]: reads [%llu, %llu) of %llu: %.2f GB of file bytes in %.3f s (%.1f GB/s)\n", rank, world, (unsigned long long)lo,
+                (unsigned long long)hi, (unsigned long long)n_all, ing.text_bytes / 1e9, ing.seconds, ing.text_bytes / 1e9 / (ing.seconds > 0 ? ing.seconds : 1));
     }
     if (kv.count("BC_START")) in.ign_bc_below = atoll(kv["BC_START"].c_str());
     const double t_in = now_s() - t_in0;

@@ -13,6 +13,7 @@
 //                          derives from <head>.dti -- the start of the first 10X dataset (DF.cc:358-363) -- or 0 without one
 //   DEVICE=0               GPU ordinal
 //   SPECTRUM=<file.json>   optional: k-mer spectrum as DF writes it to stats/histogram_kmer_count.json
+//   IO_THREADS=<n> SLAB_READS=<n> READ_LEN=<n>   tuning of the ingest (pread workers, reads per slab, row length; defaults: CPU budget, 262144, longest read)
 // Exit codes follow the reference's conventions: 0 ok, 1 fatal (FatalErr), 99 out of memory (system/RunTime.cc:195-221).
 // Only the C ABI of include/snk.h is used -- this file is plain C++ (g++), no HIP, no torch.
 #include <stdint.h>
@@ -80,23 +81,13 @@ int main(int argc, char** argv) {
     snk_ctx* ctx = nullptr;
     if ((rc = snk_ctx_create(atoi(kv["DEVICE"].c_str()), &ctx, err, sizeof err))) fatal(rc, "no usable MI355X (there is no CPU path)", err);
 
-    uint64_t n_reads = 0;
-    uint32_t max_len = 0;
-    uint16_t* lens = nullptr;
-    uint32_t* rows = nullptr;
-    if ((rc = snk_read_fastb(kv["LR"].c_str(), &n_reads, &max_len, &lens, &rows, err, sizeof err))) fatal(rc, "reads", err);
-    if (max_len == 0) max_len = 1;
-    if (max_len > 256) fatal(SNK_E_UNSUPPORTED, "reads", "reads longer than 256 bases are not supported");
-    // the quality rows are three quarters of what crosses PCIe: read them into page-locked memory so the DMA engine takes
-    // them from where they are (pageable memory would be staged through the library's pinned ring)
-    void* qp = nullptr;
-    if ((rc = snk_host_alloc_pinned((size_t)n_reads * max_len, &qp, err, sizeof err))) fatal(rc, "quals", err);
-    uint8_t* quals = (uint8_t*)qp;
-    if ((rc = snk_read_qualp((head + ".qualp").c_str(), n_reads, max_len, quals, err, sizeof err))) fatal(rc, "quals", err);
-    std::vector<int32_t> bc(n_reads);
-    uint64_t n_bc = 0;
-    if ((rc = snk_read_bci((head + ".bci").c_str(), n_reads, bc.data(), &n_bc, err, sizeof err))) fatal(rc, "barcode index", err);
-    fprintf(stderr, "snk_mspedges: %llu reads (max %u bases), %llu barcodes\n", (unsigned long long)n_reads, max_len, (unsigned long long)n_bc);
+    // the three stage inputs are decoded on the device (include/snk.h, snk_df_*): the host moves file bytes, slab by slab, into a streamed job
+    snk_df_files* files = nullptr;
+    snk_df_info info;
+    if ((rc = snk_df_open(kv["LR"].c_str(), (head + ".qualp").c_str(), (head + ".bci").c_str(), &files, &info, err, sizeof err))) fatal(rc, "reads", err);
+    fprintf(stderr, "snk_mspedges: %llu reads, %llu barcodes, %.2f GB of stage inputs\n", (unsigned long long)info.n_reads, (unsigned long long)info.n_barcodes,
+            (info.fastb_bytes + info.qualp_bytes + info.bci_bytes) / 1e9);
+    if (info.n_reads == 0) fatal(SNK_E_ARG, "reads", "the read file is empty");
 
     snk_params p;
     snk_params_default(&p);
@@ -104,46 +95,47 @@ int main(int argc, char** argv) {
     p.min_qual = (uint32_t)atoi(kv["MIN_QUAL"].c_str());
     p.min_freq = (uint32_t)atoi(kv["MIN_FREQ"].c_str());
     p.min_bc = (uint32_t)atoi(kv["MIN_BC"].c_str());
-    p.flags |= SNK_F_NO_TABLE | SNK_F_BV_IMAGE;     // the hand-off is the unitig file (+ the spectrum), not the dictionary
-    snk_reads in;
-    memset(&in, 0, sizeof in);
-    in.n_reads = n_reads;
-    in.read_len = max_len;
-    in.rows = rows;
-    in.lens = lens;
-    in.quals = quals;
-    in.bc = bc.data();
-    in.ign_bc_below = kv.count("BC_START") ? atoll(kv["BC_START"].c_str()) : bc_start_from_dti(head);
-    snk_result r;
+    p.flags |= SNK_F_UNSORTED_TABLE;                 // the hand-off is the unitig file (+ the spectrum), not the dictionary
+    const long long ign_bc_below = kv.count("BC_START") ? atoll(kv["BC_START"].c_str()) : bc_start_from_dti(head);
+    const uint32_t threads = kv.count("IO_THREADS") ? (uint32_t)atoi(kv["IO_THREADS"].c_str()) : 0u;
+    const uint64_t slab = kv.count("SLAB_READS") ? strtoull(kv["SLAB_READS"].c_str(), nullptr, 10) : 0ull;
+    const uint32_t read_len = kv.count("READ_LEN") ? (uint32_t)atoi(kv["READ_LEN"].c_str()) : 0u;      // 0: the longest read of the file
+    snk_dev_result r;
+    std::vector<uint64_t> spectrum;
     const int reps = kv.count("REPEAT") ? atoi(kv["REPEAT"].c_str()) : 1;       // timing aid: the first call sizes the buffers
     for (int rep = 0; rep < reps; ++rep) {
-        if (rep) snk_free(&r);
         struct timespec t0, t1;
         clock_gettime(CLOCK_MONOTONIC, &t0);
-        if ((rc = snk_count_graph(ctx, &in, &p, &r, err, sizeof err))) fatal(rc, "count+graph", err);
+        snk_dev_ingest st;
+        if ((rc = snk_dev_ingest_df_count_graph(ctx, files, 0, info.n_reads, read_len, threads, slab, &p, ign_bc_below, &r, &st, err, sizeof err))) fatal(rc, "count+graph", err);
+        const void* d_image = nullptr;
+        uint64_t image_bytes = 0;
+        if ((rc = snk_dev_bv_image(ctx, p.K, r.n_unitigs, r.unitig_off, r.unitig_bases, 1, &d_image, &image_bytes, nullptr, err, sizeof err))) fatal(rc, "unitig file image", err);
+        std::vector<uint8_t> image(image_bytes);
+        if ((rc = snk_dev_download(ctx, d_image, image.data(), image_bytes, nullptr))) fatal(rc, "download", snk_last_error());
+        spectrum.assign(r.spectrum_bins, 0);
+        if (r.spectrum_bins && (rc = snk_dev_download(ctx, r.spectrum, spectrum.data(), 8ull * r.spectrum_bins, nullptr))) fatal(rc, "download", snk_last_error());
         FILE* f = fopen(kv["OUT"].c_str(), "wb");
-        if (!f || fwrite(r.bv_image, 1, r.bv_bytes, f) != r.bv_bytes || fclose(f) != 0) fatal(SNK_E_IO, "OUT", "cannot write the unitig file");
+        if (!f || fwrite(image.data(), 1, image_bytes, f) != image_bytes || fclose(f) != 0) fatal(SNK_E_IO, "OUT", "cannot write the unitig file");
         clock_gettime(CLOCK_MONOTONIC, &t1);
         const double s = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
-        fprintf(stderr, "snk_mspedges: %llu k-mer instances, %llu retained k-mers, %llu unitigs; device %.1f ms; host arrays -> %s in %.3f s = %.2f Gk-mers/s\n",
-                (unsigned long long)r.n_instances, (unsigned long long)r.n_kmers, (unsigned long long)r.n_unitigs, r.phase_ms[7], kv["OUT"].c_str(), s,
-                r.n_instances / s / 1e9);
+        fprintf(stderr, "snk_mspedges: %llu k-mer instances, %llu retained k-mers, %llu unitigs; %.2f GB of file bytes in %u slabs, %.3f s ingest+partition (%.1f GB/s, "
+                        "%.3f s waiting for file bytes, %.3f s setup), count+graph %.1f ms; files -> %s in %.3f s = %.2f Gk-mers/s\n",
+                (unsigned long long)r.n_instances, (unsigned long long)r.n_kmers, (unsigned long long)r.n_unitigs, st.text_bytes / 1e9, st.n_batches, st.seconds,
+                st.text_bytes / 1e9 / (st.seconds > 0 ? st.seconds : 1), st.decode_wait_seconds, st.setup_seconds, r.phase_ms[7], kv["OUT"].c_str(), s, r.n_instances / s / 1e9);
     }
     if (kv.count("SPECTRUM")) {
         // same shape as WriteHistToJson(kmerspec, 0, max_count, 1, ...) (BuildReadQGraph48.cc:199-216)
         FILE* f = fopen(kv["SPECTRUM"].c_str(), "w");
         if (!f) fatal(SNK_E_IO, "SPECTRUM", "cannot open for writing");
         uint32_t last = 0;
-        for (uint32_t i = 0; i < r.spectrum_bins; ++i) if (r.spectrum[i]) last = i;
+        for (size_t i = 0; i < spectrum.size(); ++i) if (spectrum[i]) last = (uint32_t)i;
         fprintf(f, "{\"name\": \"kmer_count\", \"min\": 0, \"max\": %u, \"binsize\": 1, \"vals\": [", last);
-        for (uint32_t i = 0; i <= last; ++i) fprintf(f, "%s%llu", i ? ", " : "", (unsigned long long)r.spectrum[i]);
+        for (uint32_t i = 0; i <= last && i < spectrum.size(); ++i) fprintf(f, "%s%llu", i ? ", " : "", (unsigned long long)spectrum[i]);
         fprintf(f, "]}\n");
         fclose(f);
     }
-    snk_free(&r);
+    snk_df_close(files);
     snk_ctx_destroy(ctx);
-    snk_host_free_pinned(qp);
-    free(lens);
-    free(rows);
     return 0;
 }

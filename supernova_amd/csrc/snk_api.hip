@@ -438,6 +438,7 @@ extern "C" void snk_ctx_destroy(snk_ctx* ctx) {
     if (ctx->va_base) { va_unmap_from(ctx, 0); (void)hipMemAddressFree(ctx->va_base, ctx->va_size); ctx->va_base = nullptr; }
     if (ctx->shard) snk_shard_state_free(ctx->shard);
     if (ctx->host_io && ctx->host_io_free) ctx->host_io_free(ctx->host_io);
+    if (ctx->df_io && ctx->df_io_free) ctx->df_io_free(ctx->df_io);
     if (ctx->shard_host && ctx->shard_host_free) ctx->shard_host_free(ctx->shard_host);
     if (ctx->stream_job && ctx->stream_job_free) ctx->stream_job_free(ctx->stream_job);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -68,6 +68,8 @@ struct snk_ctx {
     void* shard = nullptr;      // snk_shard_state (snk_dist.hip)
     void* host_io = nullptr;    // pinned staging + device input buffers of the host-pointer entry point (snk_host.hip)
     void (*host_io_free)(void*) = nullptr;
+    void* df_io = nullptr;      // page-locked ring + device mirror of the DF-seam ingest (snk_dfin.hip)
+    void (*df_io_free)(void*) = nullptr;
     void* stream_job = nullptr; // the open streamed job of snk_dev_stream_* (snk_pipeline.hip)
     void (*stream_job_free)(void*) = nullptr;
     void (*stream_job_invalidate)(void*) = nullptr;   // the arena the open job lives in is being recycled: append / finish must fail from now on

@@ -257,7 +257,9 @@ def graph_params_of(args) -> dict:
 
 
 def load_stage_inputs(reads: str, quals: str, bci: str):
-    """fastb/qualp/bci -> (rows, lens, quals, bc, read_len); bc = barcode ordinal per read (10X/DF.cc:464-469)."""
+    """fastb/qualp/bci -> (rows, lens, quals, bc, read_len) through the one-thread HOST readers; bc = barcode ordinal per read
+    (10X/DF.cc:464-469).  The stage itself does not come through here any more (compute_mspedges decodes on the device): this is the
+    byte-for-byte check of that path and a convenience for small inputs."""
     from . import formats
     rows, lens, mx = formats.read_fastb(reads)
     n = rows.shape[0]
@@ -266,44 +268,51 @@ def load_stage_inputs(reads: str, quals: str, bci: str):
     return rows, lens, q, bc, mx
 
 
-def compute_mspedges(args, out_dir: str, device: int = 0, bc_start: int | None = None) -> str:
-    """Unitigs of the stage inputs on the GPU -> <out_dir>/asm_graph.bv (what _ASM_SN.asm_graph would have supplied)."""
+def compute_mspedges(args, out_dir: str, device: int = 0, bc_start: int | None = None, stats: dict | None = None) -> str:
+    """Unitigs of the stage inputs on the GPU -> <out_dir>/asm_graph.bv (what _ASM_SN.asm_graph would have supplied).  The three files are
+    decoded ON THE DEVICE (snk_df_open / snk_dev_ingest_df_count_graph, include/snk.h): raw byte ranges of a slab of reads go up, kernels
+    make rows / quality rows / barcode ids of them and the slab is partitioned while the next one is being read -- the reference's
+    bases.ReadAll + VirtualMasterVec<PQVec> + barcode index expansion (10X/DF.cc:265-272,345,464-469,595-597)."""
     import ctypes as C
-    from . import graphio, lib as _lib
+    from . import lib as _lib
     reads = _get(args, "reads")
-    rows, lens, q, bc, mx = load_stage_inputs(reads, _get(args, "quals"), _get(args, "bci"))
     if bc_start is None:
         bc_start = bc_start_of(reads[:-len(".fastb")])
     gp = graph_params_of(args)
     lib = _lib.load()
-    h = C.c_void_p()
     err = C.create_string_buffer(512)
-    rc = lib.snk_ctx_create(device, C.byref(h), err, 512)
-    if rc:
-        raise _lib.SnkError(rc, err.value.decode(errors="replace"))
-    try:
-        r = _lib.SnkReads()
-        rows = np.ascontiguousarray(rows)
-        r.n_reads, r.read_len = rows.shape[0], max(mx, 1)
-        r.rows, r.lens, r.quals, r.bc = rows.ctypes.data, lens.ctypes.data, q.ctypes.data, bc.ctypes.data
-        r.ign_bc_below = bc_start                      # "barcoded datatypes start at" (RunStages.cc:398, DF.cc:358-363)
-        p = _lib.SnkParams()
-        p.K, p.min_qual, p.min_freq, p.min_bc = gp["K"], gp["MIN_QUAL"], gp["MIN_FREQ"], gp["MIN_BC"]
-        p.flags = 16                                   # SNK_F_NO_TABLE: the hand-off is the unitigs
-        out = _lib.SnkResult()
-        rc = lib.snk_count_graph(h, C.byref(r), C.byref(p), C.byref(out), err, 512)
+
+    def ok(rc):
         if rc:
             raise _lib.SnkError(rc, err.value.decode(errors="replace"))
-        U = out.n_unitigs
-        off = np.ctypeslib.as_array(out.unitig_off, shape=(U + 1,)).copy()
-        tot = int(off[-1])
-        bases = np.ctypeslib.as_array(out.unitig_bases, shape=(max(tot, 1),))[:tot].copy()
-        lib.snk_free(C.byref(out))
+
+    h, files = C.c_void_p(), C.c_void_p()
+    ok(lib.snk_ctx_create(device, C.byref(h), err, 512))
+    try:
+        info = _lib.SnkDfInfo()
+        ok(lib.snk_df_open(reads.encode(), _get(args, "quals").encode(), _get(args, "bci").encode(), C.byref(files), C.byref(info), err, 512))
+        p = _lib.SnkParams()
+        p.K, p.min_qual, p.min_freq, p.min_bc = gp["K"], gp["MIN_QUAL"], gp["MIN_FREQ"], gp["MIN_BC"]
+        p.flags = 2                                    # SNK_F_UNSORTED_TABLE: the hand-off is the unitigs
+        res, st = _lib.SnkDevResult(), _lib.SnkDevIngest()
+        threads = int(_get(args, "__threads") or 0)
+        # "barcoded datatypes start at" (RunStages.cc:398, DF.cc:358-363) = ign_bc_below
+        ok(lib.snk_dev_ingest_df_count_graph(h, files, 0, info.n_reads, 0, min(threads, 64), 0, C.byref(p), bc_start, C.byref(res), C.byref(st), err, 512))
+        d_img, nb = C.c_void_p(0), C.c_uint64(0)
+        ok(lib.snk_dev_bv_image(h, gp["K"], res.n_unitigs, res.unitig_off, res.unitig_bases, 1, C.byref(d_img), C.byref(nb), None, err, 512))
+        image = np.empty(int(nb.value), dtype=np.uint8)
+        _lib.check(lib.snk_dev_download(h, d_img, image.ctypes.data, image.nbytes, None))
+        if stats is not None:
+            stats.update(n_reads=int(st.n_reads), file_bytes=int(st.text_bytes), ingest_seconds=float(st.seconds), n_slabs=int(st.n_batches),
+                         n_unitigs=int(res.n_unitigs), n_kmers=int(res.n_kmers), n_instances=int(res.n_instances), count_graph_ms=float(res.phase_ms[7]))
     finally:
+        if files:
+            lib.snk_df_close(files)
         lib.snk_ctx_destroy(h)
     os.makedirs(out_dir, exist_ok=True)
     path = str(Path(out_dir) / "asm_graph.bv")
-    graphio.write_bv(path, off, bases)
+    with open(path, "wb") as f:
+        f.write(image.tobytes())
     return path
 
 

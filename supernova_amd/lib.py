@@ -100,6 +100,11 @@ class SnkDevIngest(C.Structure):
                 ("decode_wait_seconds", C.c_double), ("n_files", C.c_uint32), ("n_batches", C.c_uint32), ("setup_seconds", C.c_double)]
 
 
+class SnkDfInfo(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("n_barcodes", C.c_uint64), ("fastb_bytes", C.c_uint64), ("qualp_bytes", C.c_uint64),
+                ("bci_bytes", C.c_uint64), ("reserved", C.c_uint64 * 3)]
+
+
 class SnkShardResult(C.Structure):
     _fields_ = [("rank", C.c_uint32), ("world", C.c_uint32), ("n_reads", C.c_uint64), ("n_instances", C.c_uint64),
                 ("n_supermers", C.c_uint64), ("n_buckets_total", C.c_uint64), ("n_kmers", C.c_uint64), ("keys", C.c_void_p),
@@ -217,6 +222,13 @@ def _declare(lib: C.CDLL) -> None:
         "snk_dev_ingest_fasth": (C.c_int, [vp, P(cp), u32, u32, vp, u32, u32, P(SnkDevIngest), cp, sz]),
         "snk_dev_ingest_free": (None, [P(SnkDevIngest)]),
         "snk_dev_ingest_count_graph": (C.c_int, [vp, P(cp), u32, u32, vp, u32, u32, u64, P(SnkParams), P(SnkDevResult), P(SnkDevIngest), cp, sz]),
+        "snk_df_open": (C.c_int, [cp, cp, cp, P(vp), P(SnkDfInfo), cp, sz]),
+        "snk_df_close": (None, [vp]),
+        "snk_df_max_len": (C.c_int, [vp, vp, u64, u64, P(u32), cp, sz]),
+        "snk_dev_ingest_df": (C.c_int, [vp, vp, u64, u64, u32, u32, u64, P(SnkDevIngest), cp, sz]),
+        "snk_dev_ingest_df_count_graph": (C.c_int, [vp, vp, u64, u64, u32, u32, u64, P(SnkParams), C.c_int64, P(SnkDevResult), P(SnkDevIngest), cp, sz]),
+        "snk_write_df": (C.c_int, [cp, u64, vp, u32, vp, u32, vp, u32, vp, u32, u64, cp, sz]),
+        "snk_synth_df_write": (C.c_int, [cp, P(SnkSynthParams), u64, u64, u32, u32, cp, sz]),
         "snk_synth_fasth_write": (C.c_int, [cp, P(SnkSynthParams), u64, u64, C.c_int, P(u64), cp, sz]),
         "snk_synth_bc_seq": (None, [u32, vp]),
         "snk_comm_set_rccl_path": (C.c_int, [cp]),

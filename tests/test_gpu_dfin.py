@@ -1,0 +1,231 @@
+"""b1/b2 at rate: reads.fastb / reads.qualp / reads.bci decoded on the device (snk_dfin.hip) == the host readers of snk_formats.hip byte for byte
+(which are pinned to files the reference's own writers made), on the golden triple, on ragged triples of this repo's writer (every value
+width, multi-block chains, adversarial block cuts), on a >= 1 M-read triple written by the reference (snref_driver ... formats), in rank
+slices -- and the streamed count+graph over the slabs == a resident call on the same reads.
+Reference: lib/assembly/src/10X/DF.cc:265-272,345,464-469,595-597; feudal/PQVec.cc:86-200; feudal/FeudalControlBlock.h:27-166."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import goldens
+import refio
+from test_formats_df import FMT, _random_triple
+
+pytestmark = pytest.mark.gpu
+
+
+def _dl(e, ptr, shape, dt):
+    a = np.empty(shape, dtype=dt)
+    if a.nbytes:
+        e._download(ptr, a.ctypes.data, a.nbytes)
+    return a
+
+
+def _device_arrays(e, dr, with_bc=True):
+    n = dr.n_reads
+    rows = _dl(e, dr.raw.rows, (n, int(dr.raw.row_words)), np.uint32)
+    q = _dl(e, dr.raw.quals, (n, int(dr.raw.qstride)), np.uint8)
+    lens = _dl(e, dr.raw.lens, (n,), np.uint16)
+    bc = _dl(e, dr.raw.bc, (n,), np.int32) if with_bc and dr.raw.bc else None
+    return rows, q, lens, bc
+
+
+def _host_arrays(head, n, qstride):
+    from supernova_amd import formats
+    rows, lens, mx = formats.read_fastb(str(head) + ".fastb")
+    q = formats.read_qualp(str(head) + ".qualp", n, qstride)
+    bc, nb = formats.read_bci(str(head) + ".bci", n)
+    return rows, q, lens, bc, mx
+
+
+def _check_equal(e, f, head, first=0, n=None, **kw):
+    n_all = f.n_reads
+    n = n_all - first if n is None else n
+    dr = f.ingest(e, first=first, n=n, **kw)
+    rows, q, lens, bc = _device_arrays(e, dr)
+    qs = int(dr.raw.qstride)
+    hr, hq, hl, hb, mx = _host_arrays(head, n_all, qs)
+    rw = int(dr.raw.row_words)
+    assert dr.read_len == max(mx, 1) or kw.get("read_len")
+    assert np.array_equal(lens, hl[first:first + n])
+    assert np.array_equal(rows[:, :hr.shape[1]], hr[first:first + n]) and not rows[:, hr.shape[1]:].any()
+    assert np.array_equal(q, hq[first:first + n])           # (rows beyond a read's values are zero on both sides)
+    assert np.array_equal(bc, hb[first:first + n])
+    assert rw * 16 == qs
+    dr.close()
+    return n
+
+
+def test_golden_triple(snk):
+    """the files the reference's writers made (tests/golden/formats): device decode == host readers == the reads they were made from"""
+    from supernova_amd import dfin
+    from supernova_amd.engine import Engine
+    e = Engine(0)
+    c = goldens.load("synth_2k_err")
+    order = np.load(FMT / "order.npy")
+    with dfin.DfFiles(FMT / "reads") as f:
+        assert f.n_reads == 2000 and f.n_barcodes == int(c.bc.max()) + 1 and f.max_len(e) == 150
+        for slab, threads in ((0, 0), (16, 1), (334, 3), (2000, 2)):
+            dr = f.ingest(e, slab_reads=slab, threads=threads)
+            rows, q, lens, bc = _device_arrays(e, dr)
+            assert np.array_equal(rows, c.rows[order]) and np.array_equal(lens, c.lens[order]) and np.array_equal(bc, c.bc[order])
+            assert np.array_equal(q[:, :150], c.quals[order]) and not q[:, 150:].any()
+            dr.close()
+        _check_equal(e, f, FMT / "reads", first=778, n=1001, slab_reads=100)
+    # without the index: no barcode array
+    with dfin.DfFiles(FMT / "reads", with_bci=False) as f:
+        dr = f.ingest(e)
+        assert not dr.raw.bc and dr.n_reads == 2000
+        dr.close()
+    e.close()
+
+
+@pytest.mark.parametrize("adversarial", [0, 0xBAD5EED])
+def test_ragged_triples_every_width(snk, tmp_path, adversarial):
+    """ragged lengths (0, 1, 150), rows of every value width 0..7 (the adversarial writer cuts blocks at random and widens values: nBits up
+    to 7, chains of up to dozens of blocks), barcodes with empty ordinals; whole file, odd slabs, rank slices that start at odd reads"""
+    from supernova_amd import dfin
+    from supernova_amd.engine import Engine
+    n = 70_001
+    rows, lens, q, bc = _random_triple(n, 99 + adversarial)
+    bc[bc > 5] += 3                        # ordinals without reads
+    head = tmp_path / "reads"
+    dfin.write_df(head, rows, q, bc, lens=lens, read_len=150, adversarial=adversarial)
+    e = Engine(0)
+    with dfin.DfFiles(head) as f:
+        assert f.n_reads == n
+        _check_equal(e, f, head)
+        _check_equal(e, f, head, slab_reads=4099, threads=5)
+        for r in range(3):                                  # three "ranks"
+            lo, hi = n * r // 3, n * (r + 1) // 3
+            _check_equal(e, f, head, first=lo, n=hi - lo, slab_reads=10_000)
+        _check_equal(e, f, head, first=n - 1, n=1)
+        _check_equal(e, f, head, first=5, n=0)
+        _check_equal(e, f, head, read_len=160)              # the caller's row length (a job's ranks agree on one)
+        from supernova_amd.lib import SnkError
+        with pytest.raises(SnkError, match="bad length"):
+            f.ingest(e, read_len=100)                       # rows too short for the reads: refused, not truncated
+    e.close()
+
+
+def test_long_quality_chains_split_the_slab(snk, tmp_path):
+    """one-value blocks (3 bytes per value: 450 bytes for a 150-base read) overflow a slot's quality section: the slab is decoded in pieces
+    over the same offset tables"""
+    from supernova_amd import dfin
+    from supernova_amd.engine import Engine
+    n = 30_000
+    rng = np.random.default_rng(5)
+    rows = rng.integers(0, 1 << 32, (n, 10), dtype=np.uint64).astype(np.uint32)
+    rows[:, 9] &= 0xFFFFF000                                # 150 bases: bits beyond the read are zero in a packed row
+    q = rng.integers(2, 64, (n, 150)).astype(np.uint8)
+    head = tmp_path / "chains"
+    dfin.write_df(head, rows, q, np.zeros(n, dtype=np.int32), read_len=150, adversarial=1)       # a block per value
+    assert (tmp_path / "chains.qualp").stat().st_size > n * 450
+    e = Engine(0)
+    with dfin.DfFiles(head) as f:
+        _check_equal(e, f, head, slab_reads=20_000)
+    e.close()
+
+
+def test_bad_files_are_refused(snk, tmp_path):
+    from supernova_amd import dfin
+    from supernova_amd.engine import Engine
+    from supernova_amd.lib import SnkError
+    rows, lens, q, bc = _random_triple(3000, 3)
+    lens[:] = 150
+    q[q == 0] = 9
+    head = tmp_path / "r"
+    dfin.write_df(head, rows, q, bc, lens=lens, read_len=150)
+    e = Engine(0)
+    fb, qp = (tmp_path / "r.fastb").read_bytes(), (tmp_path / "r.qualp").read_bytes()
+    import struct
+    var = struct.unpack_from("<Q", qp, 8)[0]
+    # a quality chain cut short: the terminator of read 1000 and its last block's tail overwritten by a long block header
+    o = struct.unpack_from("<Q", qp, var + 8 * 1001)[0]
+    bad = bytearray(qp)
+    bad[o - 1] = 200
+    (tmp_path / "r.qualp").write_bytes(bytes(bad))
+    with dfin.DfFiles(head) as f, pytest.raises(SnkError, match="truncated quality block|more quality values"):
+        f.ingest(e)
+    (tmp_path / "r.qualp").write_bytes(qp)
+    # a length that its bytes cannot hold
+    fvar, ffix = struct.unpack_from("<QQ", fb, 8)
+    bad = bytearray(fb)
+    struct.pack_into("<I", bad, ffix + 4 * 77, 9999)
+    (tmp_path / "r.fastb").write_bytes(bytes(bad))
+    with dfin.DfFiles(head) as f, pytest.raises(SnkError, match="bad length"):
+        f.ingest(e, read_len=150)
+    # an offset table that runs backwards
+    bad = bytearray(fb)
+    struct.pack_into("<Q", bad, fvar + 8 * 500, 24)
+    (tmp_path / "r.fastb").write_bytes(bytes(bad))
+    with dfin.DfFiles(head) as f, pytest.raises(SnkError, match="offset"):
+        f.ingest(e, read_len=150, slab_reads=64)
+    (tmp_path / "r.fastb").write_bytes(fb)
+    # mismatched read counts, a file that is not feudal, an index of another read set
+    dfin.write_df(tmp_path / "s", rows[:10], q[:10], bc[:10], read_len=150)
+    with pytest.raises(SnkError, match="holds 10 reads"):
+        (tmp_path / "x.fastb").write_bytes(fb); (tmp_path / "x.qualp").write_bytes((tmp_path / "s.qualp").read_bytes()); (tmp_path / "x.bci").write_bytes((tmp_path / "r.bci").read_bytes())
+        dfin.DfFiles(tmp_path / "x")
+    with pytest.raises(SnkError, match="indexes 10 reads"):
+        (tmp_path / "x.qualp").write_bytes(qp); (tmp_path / "x.bci").write_bytes((tmp_path / "s.bci").read_bytes())
+        dfin.DfFiles(tmp_path / "x")
+    with pytest.raises(SnkError):
+        (tmp_path / "y.fastb").write_bytes(b"\0" * 10); (tmp_path / "y.qualp").write_bytes(qp)
+        dfin.DfFiles(tmp_path / "y", with_bci=False)
+    # the good files still decode after all that
+    with dfin.DfFiles(head) as f:
+        _check_equal(e, f, head)
+    e.close()
+
+
+def test_streamed_count_graph_equals_resident(snk, tmp_path):
+    """snk_dev_ingest_df_count_graph: slabs -> streamed job == one resident call on the reads the same files decode to (table, counts,
+    contexts, spectrum, unitigs), whole file and as two 'ranks' halves each against its own resident call; ign_bc_below honoured"""
+    from supernova_amd import dfin, synth
+    from supernova_amd.engine import Engine, Params
+    n = 120_000
+    sp = synth.synth_params(n, seed=0x5EED0DF1, unbarcoded_ppm=0)
+    head = tmp_path / "reads"
+    dfin.write_synth_df(head, sp, qual_jitter=8)
+    e = Engine(0)
+    with dfin.DfFiles(head) as f:
+        for first, cnt, ign in ((0, n, 0), (0, n // 2, 0), (n // 2, n // 2, 0), (0, n, 50_000)):
+            dr = f.ingest(e, first=first, n=cnt)
+            reads = dr.dev_reads()
+            reads.ign_bc_below = ign
+            reads.read_index_base = first
+            ref = e.count_graph_reads(reads, Params(K=48))
+            want = (ref.unitigs(), ref.keys(), ref.counts(), ref.ctx(), ref.spectrum(), ref.good_len())
+            dr.close()
+            for slab in (0, 7000):
+                res, st = f.count_graph(e, Params(K=48), first=first, n=cnt, slab_reads=slab, ign_bc_below=ign)
+                assert st["n_reads"] == cnt and res.n_reads == cnt and st["n_slabs"] == -(-cnt // (slab or 262144))
+                assert res.unitigs() == want[0] and np.array_equal(res.keys(), want[1]) and np.array_equal(res.counts(), want[2])
+                assert np.array_equal(res.ctx(), want[3]) and np.array_equal(res.spectrum(), want[4]) and np.array_equal(res.good_len(), want[5])
+    e.close()
+
+
+@pytest.mark.skipif(not refio.REF_DRIVER.exists(), reason="oracle/_ref/snref_driver not built")
+def test_reference_written_triple_1m(snk, tmp_path):
+    """a 1.05 M-read triple written by the REFERENCE's writers on this box (vecbvec::WriteAll, VecPQVec store, BinaryWriter; snref_driver ...
+    formats): ragged lengths, noisy qualities (the reference's optimal block chains: every width, multi-block), device == host readers"""
+    from supernova_amd import dfin, synth
+    from supernova_amd.engine import Engine
+    n = 1_050_000
+    rows, lens, q, bc = _random_triple(n, 2024, clip=63)      # (the reference's encoder refuses values above 63, PQVec.cc:30-35)
+    bases = synth.unpack_rows(rows, 150)
+    refio.write_snkrd(tmp_path / "in.snkrd", lens, synth.codes_to_ascii(bases), q, bc)
+    out = refio.run_ref(tmp_path / "in.snkrd", tmp_path / "out", threads=32, mode="formats")
+    assert f"reads={n}" in out
+    head = tmp_path / "out" / "reads"
+    e = Engine(0)
+    with dfin.DfFiles(head) as f:
+        assert f.n_reads == n
+        _check_equal(e, f, head)
+        _check_equal(e, f, head, first=n // 3 + 1, n=n // 3, slab_reads=50_000, threads=7)
+    # and against what went in
+    hr, hq, hl, hb, mx = _host_arrays(head, n, 160)
+    assert np.array_equal(hr, rows) and np.array_equal(hl, lens) and np.array_equal(hq[:, :150], q) and np.array_equal(hb, bc)
+    e.close()
