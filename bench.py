@@ -287,7 +287,8 @@ def df_seam_row(eng, args, K):
         return {"reads": n, "dir": str(td.parent), "file_GB": round(fb / 1e9, 3), "bytes_per_read": round(fb / n, 1), "files_written_in_s": round(t_write, 2),
                 "resident_decode": {"seconds": round(best_ing["seconds"], 4), "file_GB_per_s": round(best_ing["text_bytes"] / best_ing["seconds"] / 1e9, 2),
                                     "reads_per_s": n / best_ing["seconds"], "io_wait_s": round(best_ing["decode_wait_seconds"], 4),
-                                    "first_call_seconds": round(ing[0]["seconds"], 4), "slabs": best_ing["n_batches"]},
+                                    "first_call_seconds": round(ing[0]["seconds"], 4), "slabs": best_ing["n_batches"],
+                                    "of_it_device_arrays_allocated_s": round(best_ing["setup_seconds"], 4)},
                 "fastb_to_unitigs": {"wall_s": best["wall_s"], "file_GB_per_s": round(moved / best["wall_s"] / 1e9, 2), "reads_per_s": n / best["wall_s"],
                                      "Gkmers_per_s": round(n_inst / best["wall_s"] / 1e9, 2), "slabs": n_slabs, "calls": calls,
                                      "wall_s_with_length_scan": round(wall_scan, 4), "includes": "open files .. .bv image on the host"},
