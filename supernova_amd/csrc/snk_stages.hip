@@ -598,9 +598,75 @@ int partition_dense(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_read
 static snk_msp_args snk_probe_last_msp;
 static uint32_t snk_probe_last_msp_K = 0;
 static uint64_t snk_probe_last_msp_ovf_cap = 0;
+// lean emitter probe: what the slot reservations + record stores cost without LDS and with few registers (a kernel that can sit NEXT TO
+// the count kernel's two 79-KB workgroups per CU): thread i reserves a slot of pseudo-random bucket hash(i) and stores a 32-byte record
+__global__ void __launch_bounds__(64) probe_lean_emit_kernel(uint32_t* __restrict__ cursor, uint4* __restrict__ records, uint32_t NB, uint32_t cap, uint64_t n, uint32_t per_thread) {
+    const uint64_t t0 = ((uint64_t)blockIdx.x * 64 + threadIdx.x) * per_thread;
+    for (uint32_t k = 0; k < per_thread; ++k) {
+        const uint64_t i = t0 + k;
+        if (i >= n) return;
+        const uint32_t h = snk_mix32((uint32_t)i * 2654435761u + (uint32_t)(i >> 32));
+        const uint32_t b = (uint32_t)(((uint64_t)h * NB) >> 32);
+        const uint32_t slot = atomicAdd(&cursor[b], 1u);
+        if (slot < cap) {
+            uint4* dst = records + ((uint64_t)b * cap + slot) * 2;
+            dst[0] = make_uint4(h, h + 1, h + 2, h + 3);
+            dst[1] = make_uint4(h + 4, h + 5, h + 6, (uint32_t)i);
+        }
+    }
+}
+
+// ... and the same as a PERSISTENT grid of a few waves per SIMD (a grid of millions of tiny workgroups takes every free wave slot and
+// starves the count kernel's 768-thread workgroups: the two then run one after the other): four records in flight per lane
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(24))) probe_lean_emit_persistent(uint32_t* __restrict__ cursor, uint4* __restrict__ records, uint32_t NB, uint32_t cap, uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * 64;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * 64 + threadIdx.x; i0 < n; i0 += 4 * stride) {
+        uint32_t h[4], b[4], slot[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint64_t i = i0 + k * stride;
+            h[k] = snk_mix32((uint32_t)i * 2654435761u + (uint32_t)(i >> 32));
+            b[k] = (uint32_t)(((uint64_t)h[k] * NB) >> 32);
+            slot[k] = i < n ? atomicAdd(&cursor[b[k]], 1u) : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (slot[k] < cap) {
+                uint4* dst = records + ((uint64_t)b[k] * cap + slot[k]) * 2;
+                dst[0] = make_uint4(h[k], h[k] + 1, h[k] + 2, h[k] + 3);
+                dst[1] = make_uint4(h[k] + 4, h[k] + 5, h[k] + 6, h[k] + 7);
+            }
+        }
+    }
+}
+
 int snk_probe_relaunch_msp(snk_ctx* ctx, hipStream_t s2, uint32_t dbg, char* err, size_t errcap) {
     if (!snk_probe_last_msp_K) return SNK_OK;
     snk_msp_args ma = snk_probe_last_msp;
+    if (dbg >= 8) {       // 8: lean emitter, one record per thread; 9: sixteen per thread (fewer, longer-lived waves); 10 / 11: a quarter of the records
+        const uint32_t NB = ma.NB;
+        void* q;
+        int rc2;
+        if ((rc2 = snk_ctx_alloc(ctx, (NB + 1) * 4ull, &q, err, errcap))) return rc2; uint32_t* cur = (uint32_t*)q;
+        if ((rc2 = snk_ctx_alloc(ctx, (size_t)NB * ma.cap * 32 + 64, &q, err, errcap))) return rc2; uint4* recs = (uint4*)q;
+        SNK_HIP_TRY(hipMemsetAsync(cur, 0, (NB + 1) * 4ull, s2));
+        uint64_t n = (uint64_t)(0.98 * (double)NB * ma.cap * 0.55);       // ~ the supermers of the call (slots are ~1.8x the mean)
+        if (dbg >= 10) n /= 4;
+        if (dbg >= 16) {          // 16 + w: persistent grid of w workgroups (waves) per CU, all the records
+            n = (uint64_t)(0.98 * (double)NB * ma.cap * 0.55);
+            const uint32_t wpc = dbg - 16;
+            hipLaunchKernelGGL(probe_lean_emit_persistent, dim3((unsigned)ctx->n_cu * wpc), dim3(64), 0, s2, cur, recs, NB, ma.cap, n);
+            SNK_HIP_TRY(hipGetLastError());
+            fprintf(stderr, "[snk overlap probe] persistent lean emitter: %llu records, %u waves per CU\n", (unsigned long long)n, wpc);
+            return SNK_OK;
+        }
+        const uint32_t per = (dbg & 1u) ? 16u : 1u;
+        const uint64_t threads = (n + per - 1) / per;
+        hipLaunchKernelGGL(probe_lean_emit_kernel, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, s2, cur, recs, NB, ma.cap, n, per);
+        SNK_HIP_TRY(hipGetLastError());
+        fprintf(stderr, "[snk overlap probe] lean emitter: %llu records into %u buckets of %u slots, %u per thread\n", (unsigned long long)n, NB, ma.cap, per);
+        return SNK_OK;
+    }
     const uint32_t NB = ma.NB;
     int rc;
     void* q;

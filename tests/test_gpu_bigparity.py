@@ -33,14 +33,22 @@ def _compare(dg, exp, fields=FIELDS):
     assert not bad, {f: (dg[f], exp[f]) for f in bad}
 
 
-@pytest.mark.parametrize("name", ["c1_2m", "c1_10m", "c1_2m_k60", "c1_10m_k60", "robust_err06_200k", "robust_err15_200k", "robust_cov28_200k",
-                                  "robust_repeats_200k", "robust_repeats_1m", "robust_repeats_200k_k60"])
-def test_one_gpu_vs_reference_digest(snk, name, monkeypatch):
+# the count-kernel instantiations the library picks by itself on error-rich data, forced (tests/test_gpu_parity.py COUNT_VARIANTS)
+VARIANTS = {"default": ({}, None), "screen": ({"SNK_COUNT_SCREEN_NG": "2"}, 960), "tight": ({"SNK_COUNT_TIGHT": "1920", "SNK_COUNT_SCREEN_NG": "0"}, 1920)}
+ROBUST_200K = ["robust_err06_200k", "robust_err15_200k", "robust_cov28_200k", "robust_repeats_200k"]
+
+
+@pytest.mark.parametrize("name,variant", [(n, "default") for n in ["c1_2m", "c1_10m", "c1_2m_k60", "c1_10m_k60", *ROBUST_200K, "robust_repeats_1m", "robust_repeats_200k_k60"]]
+                         + [(n, v) for n in ROBUST_200K + ["c1_2m"] for v in ("screen", "tight")])
+def test_one_gpu_vs_reference_digest(snk, name, variant, monkeypatch):
     import torch
     from supernova_amd import synth
     from supernova_amd.engine import Engine, Params
     exp = _case(name)
     K = exp["K"]
+    env, limit = VARIANTS[variant]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     e = Engine(0)
     try:
         if name == "robust_repeats_1m":
@@ -60,6 +68,8 @@ def test_one_gpu_vs_reference_digest(snk, name, monkeypatch):
             hist = np.bincount(np.minimum(res.counts(), (1 << 24) - 1)).astype(np.int64)
             dg["hist"] = bighash.digest(np.zeros(0), np.zeros((0, 4)), [], [], [], hist)["hist"]
         _compare(dg, exp)
+        if limit is not None:
+            assert e.last_count_limit() == limit          # the forced kernel is the one that ran
         if name == "robust_repeats_1m":
             assert res.n_hot_buckets > 0
     finally:

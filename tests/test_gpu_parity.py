@@ -67,6 +67,46 @@ def test_golden_case(engine, name, long_minimiser):
     _check_against(res, c.exp_keys, c.exp_counts, c.exp_ctx, c.exp_unitigs, c.exp_goodlens, c.exp_hist)
 
 
+# every count-kernel instantiation the library can pick BY ITSELF, forced: env -> the usable table slots the call must report
+COUNT_VARIANTS = {"screen": ({"SNK_COUNT_SCREEN_NG": "2"}, 960),      # bit filter + 1024-slot table (error-rich data: snk_count.hip SCREEN)
+                  "tight": ({"SNK_COUNT_TIGHT": "1920", "SNK_COUNT_SCREEN_NG": "0"}, 1920)}      # booked slots, no filter
+
+
+@pytest.mark.parametrize("variant", sorted(COUNT_VARIANTS))
+@pytest.mark.parametrize("name", goldens.CASES)
+def test_golden_case_count_variants(engine, monkeypatch, name, variant):
+    """test_golden_case with the ungrouped SCREEN / TIGHT count kernels forced (the kernels error-rich production data
+    take were compared in-suite with the default kernel only): the reference's goldens, and the call reports which kernel ran."""
+    from supernova_amd.engine import Params
+    env, limit = COUNT_VARIANTS[variant]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    c = goldens.load(name)
+    rows, quals, bc, lens = _to_dev(c)
+    res = engine.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, params=Params(K=48), ign_bc_below=c.ign_bc_below)
+    assert engine.last_count_limit() == limit
+    _check_against(res, c.exp_keys, c.exp_counts, c.exp_ctx, c.exp_unitigs, c.exp_goodlens, c.exp_hist)
+
+
+@pytest.mark.parametrize("variant", sorted(COUNT_VARIANTS))
+@pytest.mark.parametrize("n_reads,error_free", [(200_000, False), (100_000, True)])
+def test_synth_vs_oracle_count_variants(engine, monkeypatch, n_reads, error_free, variant):
+    from supernova_amd import synth
+    from supernova_amd.engine import Params
+    env, limit = COUNT_VARIANTS[variant]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    sp = synth.synth_params(n_reads, seed=0x5EED0100 + n_reads % 97, error_free=error_free)
+    rows_h, quals_h, bc_h = synth.synth_host(sp, qstride=160)
+    rows_d, quals_d, bc_d = engine.synth(sp, qstride=160)
+    res = engine.count_graph(rows_d, 150, quals=quals_d, bc=bc_d, params=Params(K=48))
+    assert engine.last_count_limit() == limit
+    gl = oracle_lib.good_lens(quals_h, 150)
+    o = oracle_lib.OracleResult(synth.unpack_rows(rows_h, 150), gl, bc_h, hbv=False)
+    hist = np.bincount(np.minimum(o.counts, (1 << 24) - 1)).astype(np.int64)
+    _check_against(res, o.keys[:, :3], np.minimum(o.counts, (1 << 24) - 1), o.ctx, o.unitigs, gl, hist)
+
+
 @pytest.mark.parametrize("n_buckets", [1, 7, 4096])
 def test_bucket_count_independence(engine, n_buckets):
     """Shard assignment is internal: any bucket count gives the same table, including the
@@ -270,17 +310,18 @@ def test_error_rich_reads_are_repartitioned_into_smaller_buckets(engine, monkeyp
         ref = table(r0)
         nb0 = r0.n_buckets
         monkeypatch.setenv("SNK_ADAPTIVE_BUCKETS", "1")
+        monkeypatch.setenv("SNK_SCREEN_RATIO_PCT", "20")        # the filter's threshold: pinned, so that WHICH kernel runs is asserted, not either
         e2 = Engine(0)
         try:
             r1 = e2.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48, sorted_table=False))
             assert r1.repartitioned == 1 and r1.n_buckets > 1.1 * nb0 and r1.buckets_split < r1.n_buckets // 4
             # tables that run this full (0.4 distinct k-mers per instance): the second partition is counted behind the bit filter, whose table
             # has 960 usable slots (SNK_COUNT_SCREEN_NG=0: booked slots alone, 1920, and buckets half the size)
-            assert e2.last_count_limit() in (960, 1920)      # (at this size the pilot's ratio lies around the filter's threshold of 0.3)
+            assert e2.last_count_limit() == 960              # (the threshold pinned below the pilot's ratio, ~0.3 at this size: the filter is on)
             got = table(r1)
             assert all(np.array_equal(a, b) for a, b in zip(ref[:3], got[:3])) and ref[3] == got[3]
             r2 = e2.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48, sorted_table=False))      # the hint: no second partition
-            assert r2.repartitioned == 0 and r2.n_buckets > 1.1 * nb0 and e2.last_count_limit() in (960, 1920)
+            assert r2.repartitioned == 0 and r2.n_buckets > 1.1 * nb0 and e2.last_count_limit() == 960
             got2 = table(r2)
             assert all(np.array_equal(a, b) for a, b in zip(ref[:3], got2[:3])) and ref[3] == got2[3]
             monkeypatch.setenv("SNK_COUNT_SCREEN_NG", "0")
