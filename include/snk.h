@@ -90,6 +90,47 @@ void snk_ctx_trim(snk_ctx* ctx);
  * once, at start-up.  Returns SNK_E_NOMEM when the device cannot give that much (what could be mapped stays usable). */
 int snk_ctx_reserve(snk_ctx* ctx, uint64_t bytes, char* err, size_t errcap);
 
+/* ---- tuning (round 6) ------------------------------------------------------------------------------------------------------------
+ * Every choice the library makes by itself -- which count kernel runs, how large a minimiser bucket is, how many partition passes, the
+ * minimiser length, the thresholds of the hot-bucket path, how reads are looked up -- can be pinned per context, and read back together
+ * with what the context's last call chose.  Nothing on the product path reads the process environment (tracing switches aside); a Martian
+ * stage sets what it wants here and logs snk_ctx_get_tuning.  A zero field = the library's own choice.  Results never depend on any of it.
+ * The long tail (test hooks, probe modes) is reachable by name: snk_ctx_set_option / snk_option_name enumerate them with a one-line
+ * description each; SNK_TUNING="name=value,name=value" in the environment is applied once, when a context is created (shell tools). */
+#define SNK_COUNT_KERNEL_AUTO 0u     /* from the data: the distinct-k-mers-per-instance ratio of the first buckets / the previous call */
+#define SNK_COUNT_KERNEL_MARGIN 1u   /* 1216 of 2048 table slots usable, no bookkeeping (clean, deep data: the bench's operating point) */
+#define SNK_COUNT_KERNEL_BOOKED 2u   /* waves book their slots: count_tight_slots (1920) usable -- error-rich reads, per-barcode groups */
+#define SNK_COUNT_KERNEL_SCREEN 3u   /* bit filter in front of a 1024-slot table with booked slots -- reads whose k-mers are mostly singletons */
+typedef struct snk_tuning {
+    uint32_t count_kernel;            /* SNK_COUNT_KERNEL_* */
+    uint32_t count_tight_slots;       /* BOOKED: usable slots (256 .. 1984), 0 = 1920 */
+    uint32_t count_screen_ratio_pct;  /* AUTO: the filter goes on above this many distinct k-mers per 100 instances (0 = 30) */
+    uint32_t target_inst;             /* k-mer instances per minimiser bucket (0 = 5000 at K=48 / 3500 at K=60, adapted to the data) */
+    uint32_t bucket_fill_pct;         /* adaptive buckets aim at this share of the usable slots (0 = 50) */
+    uint32_t adaptive_buckets;        /* 0 default (on), 1 on, 2 off: look at the first buckets of unknown data, partition again if their tables run full */
+    uint32_t chunk_kmers;             /* retained k-mers per bucket aimed at when the data retain many (0 = 180) */
+    uint32_t minimiser_len;           /* 0 = from snk_params.flags (SNK_F_LONG_MINIMISER), else 16 | 20 */
+    uint32_t partition_passes;        /* bucket-range passes (0 = as many as the device needs) */
+    uint32_t hot_buckets;             /* 0 default (on), 1 on, 2 off: re-partition hot minimiser buckets by k-mer hash */
+    uint32_t hot_min, hot_factor, hot_class_inst;   /* 0 = 8192 records, 8 x the slot capacity, 6000 instances per class */
+    uint32_t exchange_ranges;         /* sharded step: bucket ranges of the record exchange (0 = 4) */
+    uint32_t join_ranking;            /* sharded step: 0 default (partitioned), 1 partitioned, 2 replicated */
+    uint32_t path_lookup;             /* read pathing: 0 = dictionary when it fits, 1 minimiser index, 2 dictionary */
+    uint32_t unitig_bc_cut;           /* entries a unitig's barcode list is cut at (0 = 20000, cmd_main_asm.rs:115) */
+    uint32_t hbv_dev_min, hbv_big;    /* graph ids: below hbv_dev_min unitigs (0 = 65536) / above hbv_big nodes per component (0 = 1024) on the host */
+    uint32_t reserved[9];
+    /* filled by snk_ctx_get_tuning: what the context's last call ran with */
+    uint32_t last_count_kernel, last_count_limit, last_partition_passes, last_minimiser_len;
+} snk_tuning;
+void snk_tuning_default(snk_tuning* t);
+int snk_ctx_set_tuning(snk_ctx* ctx, const snk_tuning* t, char* err, size_t errcap);
+void snk_ctx_get_tuning(const snk_ctx* ctx, snk_tuning* t);
+int snk_ctx_set_option(snk_ctx* ctx, const char* name, long long value, char* err, size_t errcap);
+int snk_ctx_clear_option(snk_ctx* ctx, const char* name);                    /* NULL: every option back to the library's choice */
+int snk_ctx_get_option(const snk_ctx* ctx, const char* name, long long* value);   /* 1 set, 0 not set, < 0 no such option */
+const char* snk_option_name(uint32_t i);                                      /* NULL past the last one */
+const char* snk_option_doc(uint32_t i);
+
 /* ---- synthetic linked reads; counter-based, bit-identical host vs device ---------- */
 typedef struct snk_synth_params {
     uint64_t seed;

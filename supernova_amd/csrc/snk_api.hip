@@ -15,8 +15,7 @@ static thread_local char g_last_error[512] = "";
 
 void snk_set_mlen(snk_ctx* ctx, const snk_params* p) {
     uint32_t m = (p->flags & SNK_F_LONG_MINIMISER) ? (uint32_t)SNK_M_LONG : (uint32_t)SNK_M_OF(p->K);
-    const char* e = getenv("SNK_MINIMISER_LEN");
-    if (e && *e) { const long v = strtol(e, nullptr, 10); if (v == SNK_M_LONG || v == SNK_M_OF(p->K)) m = (uint32_t)v; }
+    if (ctx->opts.set[snk_opt_index("minimiser_len")]) { const long long v = ctx->opts.v[snk_opt_index("minimiser_len")]; if (v == SNK_M_LONG || v == SNK_M_OF(p->K)) m = (uint32_t)v; }
     ctx->mlen = m;
 }
 
@@ -78,6 +77,11 @@ extern "C" int snk_ctx_create(int device, snk_ctx** out, char* err, size_t errca
         return snk_fail(SNK_E_NOGPU, err, errcap, "snk_ctx_create: device %d is %s, libsnk is built for gfx950 only",
                         device, prop.gcnArchName);
     snk_ctx* c = new snk_ctx();
+    snk_opts_init(&c->opts);
+    if (const char* tv = getenv("SNK_TUNING")) {        // shell tools: "name=value,name=value", applied once, here
+        char bad[96] = "";
+        if (snk_opts_parse(&c->opts, tv, bad, sizeof bad)) { delete c; return snk_fail(SNK_E_ARG, err, errcap, "SNK_TUNING: cannot apply '%s' (unknown option or not an integer)", bad); }
+    }
     c->device = device;
     c->n_cu = prop.multiProcessorCount;
     c->device_mem_total = (uint64_t)prop.totalGlobalMem;
@@ -104,9 +108,8 @@ bool va_reserve(snk_ctx* ctx) {
 bool va_init(snk_ctx* ctx) {
     if (ctx->va_state) return ctx->va_state > 0;
     ctx->va_state = -1;
-    // SNK_ARENA_VMM=0: the cached hipMalloc blocks of rounds 1-3
-    const char* on = getenv("SNK_ARENA_VMM");
-    if (on && *on == '0') return false;
+    // option arena_vmm = 0: the cached hipMalloc blocks of rounds 1-3
+    { const int ix = snk_opt_index("arena_vmm"); if (ctx->opts.set[ix] && ctx->opts.v[ix] == 0) return false; }
     if (!va_reserve(ctx)) return false;
     ctx->va_state = 1;
     return true;
@@ -399,7 +402,7 @@ extern "C" uint32_t snk_ctx_last_partition_passes(const snk_ctx* ctx) { return c
 extern "C" uint32_t snk_ctx_last_count_limit(const snk_ctx* ctx) { return ctx ? ctx->last_count_limit : 0u; }
 extern "C" int snk_ctx_reserve(snk_ctx* ctx, uint64_t bytes, char* err, size_t errcap) {
     if (!ctx) return snk_fail(SNK_E_ARG, err, errcap, "snk_ctx_reserve: NULL context");
-    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    SNK_HIP_TRY(snk_enter(ctx));
     if (!va_init(ctx)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_ctx_reserve: the growing arena is switched off (SNK_ARENA_VMM=0) or not available");
     if (ctx->va_sealed && ctx->va_used.empty()) va_reset(ctx);
     if (ctx->va_state <= 0) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_ctx_reserve: no address range for the arena");
@@ -411,7 +414,7 @@ extern "C" int snk_ctx_reserve(snk_ctx* ctx, uint64_t bytes, char* err, size_t e
 extern "C" void snk_ctx_trim(snk_ctx* ctx) {
     if (!ctx) return;
     ctx->va_floor = 0;
-    (void)hipSetDevice(ctx->device);
+    (void)snk_enter(ctx);
     (void)hipDeviceSynchronize();
     snk_ctx_trim_cache(ctx);
 }
@@ -432,7 +435,7 @@ void snk_ctx_trim_cache(snk_ctx* ctx) {
 
 extern "C" void snk_ctx_destroy(snk_ctx* ctx) {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
+    (void)snk_enter(ctx);
     snk_ctx_release_scratch(ctx);
     snk_ctx_trim_cache(ctx);
     if (ctx->va_base) { va_unmap_from(ctx, 0); (void)hipMemAddressFree(ctx->va_base, ctx->va_size); ctx->va_base = nullptr; }

@@ -270,7 +270,7 @@ extern "C" int snk_comm_create_rccl(snk_ctx* ctx, const void* id128, uint32_t ra
     if (!ctx || !id128 || !out || world == 0 || rank >= world) return snk_fail(SNK_E_ARG, err, errcap, "snk_comm_create_rccl: bad argument");
     int rc = rccl_load(err, errcap);
     if (rc) return rc;
-    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    SNK_HIP_TRY(snk_enter(ctx));
     ncclUniqueId id;
     memcpy(&id, id128, 128);
     rccl_comm* c = new rccl_comm();

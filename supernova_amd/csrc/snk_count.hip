@@ -816,7 +816,7 @@ int regions(uint32_t nseg, uint32_t NB, uint32_t bc_mode, uint32_t* out, char* e
     auto kern = nseg > 1 ? snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G, true> : snk_count_kernel<K, cfg<K>::THREADS, cfg<K>::SLOTS, G, false>;
     size_t lds = lds_bytes<K, G>(bc_mode);
     SNK_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    uint32_t persist = snk_env_u32("SNK_COUNT_PERSIST", 32);
+    uint32_t persist = snk_opt_u32("count_persist", 32);
     if (persist == 0) persist = 1;
     int per_cu = 0, dev = 0, n_cu = 256;
     SNK_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, cfg<K>::THREADS, lds));

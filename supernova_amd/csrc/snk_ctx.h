@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/snk.h"
+#include "snk_opts.h"
 
 struct snk_ctx {
     int device = 0;
@@ -65,6 +66,7 @@ struct snk_ctx {
     uint32_t last_count_limit = 0;                     // usable table slots of the last resident call's count launches (snk_ctx_last_count_limit)
     uint32_t last_partition_passes = 1;                // bucket-range passes of the last resident call (snk_ctx_last_partition_passes)
     std::vector<unsigned long long> h_region_off;      // host copy of the count regions' dense offsets (source of an async upload)
+    snk_opts opts;              // what the host pinned (snk_ctx_set_tuning / snk_ctx_set_option / SNK_TUNING at creation); all clear = the library's own choices
     void* shard = nullptr;      // snk_shard_state (snk_dist.hip)
     void* host_io = nullptr;    // pinned staging + device input buffers of the host-pointer entry point (snk_host.hip)
     void (*host_io_free)(void*) = nullptr;
@@ -77,6 +79,8 @@ struct snk_ctx {
     void (*shard_host_free)(void*) = nullptr;
 };
 
+// every top-level entry point: the context's device is current and its options are the calling thread's
+hipError_t snk_enter(snk_ctx* ctx);
 void snk_set_error(char* err, size_t errcap, const char* fmt, ...);
 void snk_set_mlen(snk_ctx* ctx, const snk_params* p);      // ctx->mlen from the call's K and flags (SNK_MINIMISER_LEN=16|20 overrides: tests)
 // every host wait for a stream goes through here: the calling thread's count is what the sharded step reports as

@@ -570,7 +570,7 @@ int prepare(snk_ctx* ctx, snk_df_files* f, uint64_t first, uint64_t n, uint32_t 
             char* err, size_t errcap) {
     if (first > f->fb.n || n > f->fb.n - first) return snk_fail(SNK_E_ARG, err, errcap, "snk_dfin: reads [%llu, +%llu) are not inside the file's %llu", (unsigned long long)first,
                                                                (unsigned long long)n, (unsigned long long)f->fb.n);
-    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    SNK_HIP_TRY(snk_enter(ctx));
     df_io* io;
     int rc = io_of(ctx, &io, err, errcap);
     if (rc) return rc;
@@ -596,7 +596,7 @@ int prepare(snk_ctx* ctx, snk_df_files* f, uint64_t first, uint64_t n, uint32_t 
 extern "C" int snk_df_max_len(snk_ctx* ctx, snk_df_files* f, uint64_t first, uint64_t n, uint32_t* out, char* err, size_t errcap) {
     if (!ctx || !f || !out) return snk_fail(SNK_E_ARG, err, errcap, "snk_df_max_len: NULL argument");
     if (first > f->fb.n || n > f->fb.n - first) return snk_fail(SNK_E_ARG, err, errcap, "snk_df_max_len: range outside the file");
-    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    SNK_HIP_TRY(snk_enter(ctx));
     df_io* io;
     int rc = io_of(ctx, &io, err, errcap);
     if (rc) return rc;

@@ -32,7 +32,7 @@ int snk_shard_begin(snk_ctx* ctx, const snk_dev_reads* in, const snk_params* p, 
     if (world > 0x7FFF) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "world > 32767");
     if (in->n_reads && (!in->rows || in->row_words * 16 < in->read_len || in->read_len > 256 || (!in->quals && !in->good_len)))
         return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_hist: bad reads");
-    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    SNK_HIP_TRY(snk_enter(ctx));
     snk_ctx_release_scratch(ctx);
     snk_shard_state* S = state_of(ctx);
     S->reads = *in;
@@ -79,7 +79,7 @@ int snk_shard_job_open(snk_ctx* ctx, const snk_params* p, uint32_t rank, uint32_
     if (p->min_bc > 8) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "min_bc=%u: the device barcode rule tells up to eight distinct barcodes apart (min_bc <= 8)", p->min_bc);
     if (world == 0 || rank >= world || NB_total == 0 || NB_total % world) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_stream_begin: NB_total must be a positive multiple of world");
     if (read_len == 0 || read_len > 256 || reads_ub == 0) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_stream_begin: read_len 1..256 and an upper bound of this rank's reads are needed");
-    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    SNK_HIP_TRY(snk_enter(ctx));
     snk_ctx_release_scratch(ctx);
     snk_shard_state* S = state_of(ctx);
     memset(&S->reads, 0, sizeof S->reads);
@@ -108,7 +108,7 @@ int snk_shard_job_add(snk_ctx* ctx, const snk_dev_reads* slab, hipStream_t st, c
     if (S->job.n_reads + slab->n_reads > S->job_reads_ub)
         return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_stream_append: more reads than the rank's upper bound (%llu + %llu > %llu)", (unsigned long long)S->job.n_reads,
                         (unsigned long long)slab->n_reads, (unsigned long long)S->job_reads_ub);
-    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    SNK_HIP_TRY(snk_enter(ctx));
     snk_dev_reads r = *slab;
     uint16_t* gl = S->job_good_len + S->job.n_reads;
     int rc;

@@ -236,7 +236,7 @@ static int mark_dups_impl(snk_ctx* ctx, const snk_dev_reads* in, const snk_dev_p
     if (n && (!in->rows || !in->quals || in->read_len < 5 || in->row_words * 16 < in->read_len))
         return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_mark_dups: need packed rows and quality rows of reads with at least five bases");
     memset(out, 0, sizeof *out);
-    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    SNK_HIP_TRY(snk_enter(ctx));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     ctx->cur_stream = st;
     hipEvent_t e0, e1;
@@ -282,7 +282,7 @@ static int mark_dups_impl(snk_ctx* ctx, const snk_dev_reads* in, const snk_dev_p
         const uint32_t ebits = bits_of(emax), obits = m ? bits_of((uint64_t)omax - omin) : 0u, total_bits = ebits + obits + 10u;
         const unsigned long long* skey;
         const uint32_t* sid;
-        const bool one_sort = total_bits <= 62 && !snk_env_u32("SNK_DUPS_TWO_SORTS", 0);
+        const bool one_sort = total_bits <= 62 && !snk_opt_u32("dups_two_sorts", 0);
         if (one_sort) {
             // the reference's record order (edge, offset, mate head, read id) in ONE stable sort over total_bits + 1 bits (the bench graph: 42)
             hipLaunchKernelGGL(dup_composite_kernel, dim3(gn), dim3(256), 0, st, key, head, n, m ? omin : 0u, obits, total_bits);

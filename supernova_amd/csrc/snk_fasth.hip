@@ -512,7 +512,7 @@ extern "C" int snk_dev_ingest_fasth(snk_ctx* ctx, const char* const* paths, uint
     if (!ctx || !paths || !out || n_files == 0) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_ingest_fasth: NULL argument");
     if (read_len == 0 || read_len > 256) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_ingest_fasth: read_len must be 1..256");
     memset(out, 0, sizeof *out);
-    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    SNK_HIP_TRY(snk_enter(ctx));
     const uint32_t stride = (read_len + 15) / 16 * 16, row_words = (read_len + 15) / 16, qstride = stride;
     if (batch_pairs == 0) batch_pairs = 65536;       // (the consumer's per-batch cost -- a dozen runtime calls -- is what limits it once the decode is fast)
     const double t0 = now_s();
@@ -664,7 +664,7 @@ extern "C" int snk_dev_ingest_count_graph(snk_ctx* ctx, const char* const* paths
     if (!ctx || !paths || !out || !p || !res || n_files == 0) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_ingest_count_graph: NULL argument");
     if (read_len == 0 || read_len > 256) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_ingest_count_graph: read_len must be 1..256");
     memset(out, 0, sizeof *out);
-    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    SNK_HIP_TRY(snk_enter(ctx));
     const uint32_t stride = (read_len + 15) / 16 * 16, row_words = (read_len + 15) / 16, qstride = stride;
     if (batch_pairs == 0) batch_pairs = 65536;
     const double t0 = now_s();

@@ -642,7 +642,7 @@ static int rank_lists(snk_ctx* ctx, hipStream_t st, uint32_t* link, uint64_t n, 
                       const uint2** rk_out, uint32_t* n_circles, uint32_t* rounds,
                       char* err, size_t errcap) {
     const uint64_t ns = 2 * n;
-    if (ns < 4096 || snk_env_u32("SNK_RANK_WYLLIE", 0))
+    if (ns < 4096 || snk_opt_u32("rank_wyllie", 0))
         return rank_lists_wyllie(ctx, st, link, n, weights, circ, rk_out, n_circles, rounds, err, errcap);
     uint32_t cut_total = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -652,7 +652,7 @@ static int rank_lists(snk_ctx* ctx, hipStream_t st, uint32_t* link, uint64_t n, 
     G_ALLOC(flag32, uint32_t, ns + 1);
     G_ALLOC(sid, uint32_t, ns + 1);
     SNK_HIP_TRY(hipMemsetAsync(flag32 + ns, 0, 4, st));
-    const uint32_t split_mask = (1u << snk_env_u32("SNK_SPLIT_LOG2", 5)) - 1u;
+    const uint32_t split_mask = (1u << snk_opt_u32("split_log2", 5)) - 1u;
     hipLaunchKernelGGL(spl_mark_kernel, dim3(nblk(ns)), dim3(TB), 0, st, link, ns, split_mask, spl, flag32);
     {
         size_t tb = 0;
@@ -691,7 +691,7 @@ static int rank_lists(snk_ctx* ctx, hipStream_t st, uint32_t* link, uint64_t n, 
     uint2* rk = nullptr;
     bool converged = false, unranked = false;
     G_ALLOC(rk, uint2, ns);
-    const int batch0 = (int)snk_env_u32("SNK_RANK_ROUND_BATCH0", 12);
+    const int batch0 = (int)snk_opt_u32("rank_round_batch0", 12);
     for (int r = 0; r < max_rounds && !converged;) {
         const int upto = r == 0 ? (batch0 < max_rounds ? batch0 : max_rounds) : max_rounds;
         SNK_HIP_TRY(hipMemsetAsync(flags, 0, 8, st));
@@ -1698,7 +1698,7 @@ int snk_prank_begin(snk_ctx* ctx, hipStream_t st, uint64_t F, const uint32_t* nk
     G_ALLOC(flag32, uint32_t, ns + 1);
     G_ALLOC(sid, uint32_t, ns + 1);
     SNK_HIP_TRY(hipMemsetAsync(flag32 + ns, 0, 4, st));
-    const uint32_t split_mask = (1u << snk_env_u32("SNK_SPLIT_LOG2", 5)) - 1u;
+    const uint32_t split_mask = (1u << snk_opt_u32("split_log2", 5)) - 1u;
     if (ns) hipLaunchKernelGGL(spl_mark_kernel, dim3(nblk(ns)), dim3(TB), 0, st, link, ns, split_mask, spl, flag32);
     {
         size_t tb = 0;
@@ -1753,7 +1753,7 @@ int snk_prank_walk(snk_ctx* ctx, hipStream_t st, snk_prank* P, const uint4* w1_a
     while ((1ull << (max_rounds - 1)) < m + 1) ++max_rounds;
     int cur = 0;
     bool converged = false, first = true;
-    const int BATCH_R = (int)snk_env_u32("SNK_RANK_ROUND_BATCH", 8);
+    const int BATCH_R = (int)snk_opt_u32("rank_round_batch", 8);
     for (int r = 0; r < max_rounds && !converged;) {
         int did = 0;
         for (; did < BATCH_R && r < max_rounds && m; ++did, ++r) {

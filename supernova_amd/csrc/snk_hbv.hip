@@ -485,10 +485,6 @@ struct scratch_list {
     ~scratch_list() { for (void* q : p) snk_ctx_release_block(ctx, q); }
 };
 
-uint64_t env_u64(const char* name, uint64_t dflt) {
-    const char* v = getenv(name);
-    return (v && *v) ? strtoull(v, nullptr, 0) : dflt;
-}
 
 template <typename T>
 int dalloc(scratch_list& sl, size_t n, T** out, char* err, size_t errcap) {
@@ -510,7 +506,7 @@ extern "C" int snk_dev_hbv(snk_ctx* ctx, uint32_t K, uint64_t U, const void* d_u
     if (U == 0) return SNK_OK;
     if (!d_unitig_off || !d_unitig_bases) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_hbv: NULL unitig arrays");
     if (U >= (1ull << 30)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_dev_hbv: too many unitigs");
-    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    SNK_HIP_TRY(snk_enter(ctx));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     ctx->cur_stream = st;
     const uint64_t* off = (const uint64_t*)d_unitig_off;
@@ -589,7 +585,7 @@ extern "C" int snk_dev_hbv(snk_ctx* ctx, uint32_t K, uint64_t U, const void* d_u
     // Measured (tools/hbv_scale_probe.py, profiles/r04_hbv_scale.log): 9.5 M unitigs of per-barcode graphs (every component small) 4.8 s
     // -> 0.19 s per call, the flood itself ~5 ms behind the 30 ms of sorts; 6.1 M unitigs of ONE genome (the connected bulk goes to
     // the host either way) 3.15 -> 2.82 s.
-    const uint64_t dev_min = env_u64("SNK_HBV_DEV_MIN", 1ull << 16);
+    const uint64_t dev_min = snk_opt_u64("hbv_dev_min", 1ull << 16);
     if (U < dev_min) {
         SNK_HIP_TRY(hipEventRecord(e1, st));
         SNK_HIP_TRY(fetch_tables());
@@ -609,7 +605,7 @@ extern "C" int snk_dev_hbv(snk_ctx* ctx, uint32_t K, uint64_t U, const void* d_u
         int32_t *d_rev = d_fwd + U, *d_vl = d_rev + U, *d_vr = d_vl + n2, *d_src = d_vr + n2;
         uint8_t* d_isrc = (uint8_t*)(d_src + n2);
         int32_t* d_vid = (int32_t*)flag;
-        const uint32_t big_limit = (uint32_t)env_u64("SNK_HBV_BIG", 1024);
+        const uint32_t big_limit = (uint32_t)snk_opt_u64("hbv_big", 1024);
         const uint32_t big_cap = (uint32_t)(n2 / ((uint64_t)big_limit + 1) + 1);
         hbv_big* d_big;
         uint32_t* d_nbig;                      // [0] components for the host, [1] error flag
@@ -650,7 +646,7 @@ extern "C" int snk_dev_hbv(snk_ctx* ctx, uint32_t K, uint64_t U, const void* d_u
         const uint32_t n_big = h_nb[0];
         if (h_nb[1]) {              // a bounded loop of the device flood ran out (never seen; the flood on the host does not depend on it)
             snk_hbv_free(out);
-            if (getenv("SNK_HBV_STRICT")) return snk_fail(SNK_E_INTERNAL, err, errcap, "snk_dev_hbv: the device flood gave up (flag %u)", h_nb[1]);
+            if (snk_opt_u32("hbv_strict", 0)) return snk_fail(SNK_E_INTERNAL, err, errcap, "snk_dev_hbv: the device flood gave up (flag %u)", h_nb[1]);
             SNK_HIP_TRY(fetch_tables());
             SNK_HIP_TRY(snk_sync(st));
             if ((rc = hbv_flood(U, h_pal.data(), h_ee.data(), n_ee, h_vtx.data(), h_run.data(), nruns, out, err, errcap))) return rc;

@@ -295,7 +295,7 @@ int count_graph_impl(snk_ctx* ctx, const snk_reads* in, const snk_params* p, snk
     if (in->read_len == 0 || in->read_len > 256) return snk_fail(SNK_E_ARG, err, errcap, "snk_count_graph: read_len must be 1..256");
     if (p->K != 48 && p->K != 60) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "K=%u is not supported (48 or 60)", p->K);
     memset(out, 0, sizeof *out);
-    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    SNK_HIP_TRY(snk_enter(ctx));
     hipStream_t st = ctx->stream;
     host_io* io = nullptr;
     int rc = io_of(ctx, &io, err, errcap);
@@ -395,6 +395,7 @@ int snk_unitigs_to_host(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t U, co
     catch (...) { return snk_fail(SNK_E_INTERNAL, err, errcap, "unexpected exception"); }
 
 extern "C" int snk_count_graph(snk_ctx* ctx, const snk_reads* in, const snk_params* p, snk_result* out, char* err, size_t errcap) {
+    if (ctx) snk_opts_enter(&ctx->opts);
     // every error exit of the implementation leaves through here: uploads / kernels it queued are waited for (the caller may free
     // its input right after, and the next call reuses the context's staging buffers) and what it malloc'ed into *out is released
     int rc;
@@ -414,7 +415,7 @@ extern "C" int snk_count_graph(snk_ctx* ctx, const snk_reads* in, const snk_para
 extern "C" int snk_dev_bv_image(snk_ctx* ctx, uint32_t K, uint64_t n_unitigs, const void* d_unitig_off, const void* d_unitig_bases, int by_first_kmer,
                                 const void** d_image, uint64_t* image_bytes, void* stream, char* err, size_t errcap) {
     if (!ctx || !d_image || !image_bytes || (n_unitigs && (!d_unitig_off || !d_unitig_bases))) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_bv_image: NULL argument");
-    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    SNK_HIP_TRY(snk_enter(ctx));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     ctx->cur_stream = st;
     SNK_GUARD(

@@ -301,10 +301,10 @@ int snk_stage_hot_plan(snk_ctx* ctx, hipStream_t st, uint32_t K, bool grouped, u
     if (NB == 0 || nseg == 0) return SNK_OK;
     // hot = more records than eight times the slots of a bucket (and never fewer than SNK_HOT_MIN: a normal hash-split pass or two
     // over a few thousand records is cheaper than the expansion)
-    const uint32_t floor_ = snk_env_u32("SNK_HOT_MIN", 8192);
-    uint64_t thr = (uint64_t)cap * snk_env_u32("SNK_HOT_FACTOR", 8);
+    const uint32_t floor_ = snk_opt_u32("hot_min", 8192);
+    uint64_t thr = (uint64_t)cap * snk_opt_u32("hot_factor", 8);
     if (thr < floor_) thr = floor_;
-    if (thr > 0xFFFFFFFFull || snk_env_u32("SNK_HOT", 1) == 0) return SNK_OK;
+    if (thr > 0xFFFFFFFFull || snk_opt_u32("hot", 1) == 0) return SNK_OK;
     const uint32_t hot_cap = 1u << 16;
     int rc;
     uint32_t *hot_b, *hot_r, *lg, *vbase;
@@ -316,7 +316,7 @@ int snk_stage_hot_plan(snk_ctx* ctx, hipStream_t st, uint32_t K, bool grouped, u
     SNK_HIP_TRY(hipMemsetAsync(ctr, 0, 64, st));
     const seg_tab sg{seg_beg, seg_end, stride, nseg};
     hipLaunchKernelGGL(hot_scan_kernel, dim3((NB + 255) / 256), dim3(256), 0, st, sg, NB, (uint32_t)thr, hot_cap, hot_b, hot_r, ctr);
-    hipLaunchKernelGGL(hot_plan_kernel, dim3(1), dim3(64), 0, st, hot_r, hot_cap, snk_env_u32("SNK_HOT_CLASS_INST", 6000), lg, rbase, vbase, ctr);
+    hipLaunchKernelGGL(hot_plan_kernel, dim3(1), dim3(64), 0, st, hot_r, hot_cap, snk_opt_u32("hot_class_inst", 6000), lg, rbase, vbase, ctr);
     unsigned long long h_ctr[3] = {0, 0, 0};
     SNK_HIP_TRY(hipMemcpyAsync(h_ctr, ctr, 24, hipMemcpyDeviceToHost, st));
     SNK_HIP_TRY(snk_sync(st));

@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(256) bc_ids_kernel(const uint8_t* __restrict__
 extern "C" int snk_bc_index_create(snk_ctx* ctx, const char* whitelist, size_t bytes, snk_bc_index** out, char* err, size_t errcap) {
     if (!ctx || !out || (bytes && !whitelist)) return snk_fail(SNK_E_ARG, err, errcap, "snk_bc_index_create: NULL argument");
     *out = nullptr;
-    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    SNK_HIP_TRY(snk_enter(ctx));
     struct ent { uint64_t h; uint32_t line; std::string s; };
     std::vector<ent> v;
     uint32_t nlines = 0;
@@ -159,7 +159,7 @@ extern "C" int snk_dev_bc_ids(snk_ctx* ctx, const snk_bc_index* ix, const void* 
     if (!ctx || !ix || (n_reads && (!d_fields || !d_ids))) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_bc_ids: NULL argument");
     if (stride == 0 || stride > 256) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_bc_ids: stride must be 1..256");
     if (n_reads == 0) return SNK_OK;
-    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    SNK_HIP_TRY(snk_enter(ctx));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     ctx->cur_stream = st;
     SNK_HIP_TRY(hipMemsetAsync(ix->d_err, 0, 16, st));

@@ -909,7 +909,7 @@ static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* er
     cs.span = nullptr;
     // (SNK_CHUNK_MERGE = k-mers a merged chunk may hold, 0 = off: 1.5 % errors graph 43.0 -> 38.9 ms, 0.6 % 33.9 -> 32.9, groups 15.1 -> 13.6,
     // K=60 29.5 -> 28.2, the bench's reads 29.65 -> 29.4)
-    const uint32_t merge_cap = std::min<uint32_t>(snk_env_u32("SNK_CHUNK_MERGE", (uint32_t)SCAP), (uint32_t)SCAP);
+    const uint32_t merge_cap = std::min<uint32_t>(snk_opt_u32("chunk_merge", (uint32_t)SCAP), (uint32_t)SCAP);
     if (merge_cap && tab->chunk_n && tab->NB > tab->n_regions) {
         uint8_t* span;
         G_ALLOC(span, uint8_t, (uint64_t)tab->NB + 1);
@@ -946,12 +946,12 @@ static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* er
     sh.G = tab->n_regions ? tab->n_regions : 1u;
     sh.premote = B->premote;
     const uint32_t NBh = B->premote ? B->NB_total : tab->NB;      // bucket count of the minimiser hash
-    const uint32_t cpw = std::max(1u, snk_env_u32("SNK_BL_CPW", 4));      // (chunks per workgroup: merged-away chunks are empty; 1 -> 4: graph 29.2 -> 28.8 ms, 1.5 % errors 38.7 -> 37.6)
+    const uint32_t cpw = std::max(1u, snk_opt_u32("bl_cpw", 4));      // (chunks per workgroup: merged-away chunks are empty; 1 -> 4: graph 29.2 -> 28.8 ms, 1.5 % errors 38.7 -> 37.6)
     // boundary index, filled by the prune kernel itself: sized from what the previous call of this context found for a table of
     // this size (first call: n / 5); too small = too full -> the separate build pass below redoes it with the exact size
     uint64_t tg0 = 0;
     unsigned long long* index0 = nullptr;
-    if (snk_env_u32("SNK_BL_INDEX_FUSED", 1)) {
+    if (snk_opt_u32("bl_index_fused", 1)) {
         const uint64_t guess = (ctx->last_bnd_n == n && ctx->last_bnd) ? ctx->last_bnd + ctx->last_bnd / 8 : n / 5;
         tg0 = 1024;
         while (tg0 < 2 * guess) tg0 <<= 1;
@@ -963,7 +963,7 @@ static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* er
     rg.keys_dense = const_cast<snk_u128*>(tab->keys);
     const bool long_m = ctx->mlen == (uint32_t)SNK_M_LONG;
     hipLaunchKernelGGL((long_m ? bl_prune_kernel<K, SCAP, ST, false, GR, SNK_M_LONG> : bl_prune_kernel<K, SCAP, ST, false, GR, SNK_M_OF(K)>), dim3((nchunks + cpw - 1) / cpw), dim3(ST), 0, st, (const uint4*)B->desc, NBh, sh, rg,
-                       (const uint32_t*)nullptr, nchunks, cpw, tab->keys, tab->vals, B->do_prune | (snk_env_u32("SNK_BL_NOCLASSIFY", 0) ? 2u : 0u), B->ctx, B->counts, B->pend, B->nbr, nbnd,
+                       (const uint32_t*)nullptr, nchunks, cpw, tab->keys, tab->vals, B->do_prune | (snk_opt_u32("bl_noclassify", 0) ? 2u : 0u), B->ctx, B->counts, B->pend, B->nbr, nbnd,
                        B->biglist, ctr, (const uint32_t*)nullptr, index0, tg0 - 1);
     SNK_HIP_TRY(hipGetLastError());
     // the chunks that did not fit the one-wave variant (split sub-passes near the table's capacity): their number stays on the
@@ -971,7 +971,7 @@ static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* er
     uint32_t h_nbig = 0;
     SNK_HIP_TRY(hipMemcpyAsync(ctr + 1, ctr, 4, hipMemcpyDeviceToDevice, st));       // (ctr[0] is the small kernel's list cursor)
     hipLaunchKernelGGL((long_m ? bl_prune_kernel<K, BCAP, BT, true, GR, SNK_M_LONG> : bl_prune_kernel<K, BCAP, BT, true, GR, SNK_M_OF(K)>), dim3(2048), dim3(BT), 0, st, (const uint4*)B->desc, NBh, sh, rg,
-                       (const uint32_t*)B->biglist, 0u, 1u, tab->keys, tab->vals, B->do_prune | (snk_env_u32("SNK_BL_NOCLASSIFY", 0) ? 2u : 0u), B->ctx, B->counts, B->pend, B->nbr,
+                       (const uint32_t*)B->biglist, 0u, 1u, tab->keys, tab->vals, B->do_prune | (snk_opt_u32("bl_noclassify", 0) ? 2u : 0u), B->ctx, B->counts, B->pend, B->nbr,
                        nbnd, B->biglist, ctr + 2, (const uint32_t*)(ctr + 1), index0, tg0 - 1);
     SNK_HIP_TRY(hipGetLastError());
     if (tab->keys_r) {       // the region-partitioned copy is dead (stream order): later stages may reuse it
@@ -1055,7 +1055,7 @@ static int bl_fragments_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, cons
     // the open paths' bases: every node once + K-1 per path; circle nodes are not in any path, their bases come from the pool
     unsigned long long* xcur;
     G_ALLOC(xcur, unsigned long long, 2);
-    const uint32_t pool0 = snk_env_u32("SNK_BL_POOL", 4096);                 // SNK_BL_POOL=0: tests force the exact re-run
+    const uint32_t pool0 = snk_opt_u32("bl_pool", 4096);                 // SNK_BL_POOL=0: tests force the exact re-run
     uint64_t xf_cap = pool0 ? pool0 + h_F / 256 : 0, xb_cap = xf_cap * (K + 63);
     unsigned long long h_x[2] = {0, 0};
     for (int attempt = 0; attempt < 2; ++attempt) {

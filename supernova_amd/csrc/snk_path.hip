@@ -1053,7 +1053,7 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
     // where the dictionary takes 6.4 GB).  The dictionary while it fits, the index when it does not (a human-size graph's dictionary
     // is ~85 GB next to the reads: rounds 1-3 refused such a graph); SNK_PATH_INDEX=1 / 0 forces one or the other.  The exhaustive
     // cross-check of the unitig barcode lists reads the dictionary.
-    const uint64_t spk10 = snk_env_u32("SNK_PATH_SLOTS_X10", 30);         // slots per unitig k-mer x 10 (measured: 2.5 -> 67.2 ms pathing, 3 -> 63.5, 4 -> 61.8)
+    const uint64_t spk10 = snk_opt_u32("path_slots_x10", 30);         // slots per unitig k-mer x 10 (measured: 2.5 -> 67.2 ms pathing, 3 -> 63.5, 4 -> 61.8)
     uint64_t cap = ((nk * spk10 / 10 + 1024) + 63) & ~63ull;              // load 1/3: the chain of dependent probes is what a read waits for
     bool dict_fits = true;
     uint64_t free_b = 0;
@@ -1066,19 +1066,18 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
             free_b = (uint64_t)fr + cached;
             dict_fits = cap * 8ull <= free_b;
         }
-        const uint64_t max_mb = snk_env_u32("SNK_PATH_DICT_MAX_KB", 0);     // (tests: a dictionary above this size "does not fit")
+        const uint64_t max_mb = snk_opt_u32("path_dict_max_kb", 0);     // (tests: a dictionary above this size "does not fit")
         if (max_mb && cap * 8ull > (max_mb << 10)) dict_fits = false;
     }
-    const char* ix_env = getenv("SNK_PATH_INDEX");
-    const bool use_index = (ix_env && *ix_env) ? *ix_env == '1' : !dict_fits;
+    const bool use_index = snk_opt_is_set("path_index") ? snk_opt_u32("path_index", 0) == 1u : !dict_fits;
     const bool need_kdict = !use_index || (flags & SNK_PATH_UNITIG_BCS_EXHAUSTIVE);
     unsigned long long* dslot = nullptr;
     unsigned long long fp_mask = 0x3FFFFFFFull;
     if (need_kdict) {
-    if (!dict_fits && !snk_env_u32("SNK_PATH_DICT_MAX_KB", 0))
+    if (!dict_fits && !snk_opt_u32("path_dict_max_kb", 0))
         return snk_fail(SNK_E_NOMEM, err, errcap, "snk_dev_path_reads: the k-mer dictionary of this graph (%llu unitig k-mers, 3 slots of 8 B each) needs %.1f GB, "
-                        "%.1f GB of HBM are free; let the minimiser index take the look-ups (SNK_PATH_INDEX unset or 1)", (unsigned long long)nk, cap * 8ull / 1e9, free_b / 1e9);
-    if (const char* e = getenv("SNK_PATH_FP_MASK")) if (*e) { const unsigned long long m = strtoull(e, nullptr, 0) & 0x3FFFFFFFull; if (m) fp_mask = m; }
+                        "%.1f GB of HBM are free; let the minimiser index take the look-ups (option path_index unset or 1)", (unsigned long long)nk, cap * 8ull / 1e9, free_b / 1e9);
+    if (snk_opt_is_set("path_fp_mask")) { const unsigned long long m = snk_opt_u64("path_fp_mask", 0) & 0x3FFFFFFFull; if (m) fp_mask = m; }
     if ((rc = dev(ctx, cap, &dslot, err, errcap))) return rc;
     SNK_HIP_TRY(hipMemsetAsync(dslot, 0xFF, cap * 8, st));
     if (total_bases) hipLaunchKernelGGL((dict_build_kernel<K>), dim3((unsigned)(((total_bases + DB_RUN - 1) / DB_RUN + 255) / 256)), dim3(256), 0, st, d_uoff, d_ubases, U, total_bases, dslot, cap, fp_mask);
@@ -1122,7 +1121,7 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
             if ((rc = snk_ctx_alloc(ctx, tb2 + 64, &tmp2, err, errcap))) return rc;
             SNK_HIP_TRY(rocprim::exclusive_scan(tmp2, tb2, mhist, mdir, 0u, ((size_t)1 << bits) + 1, rocprim::plus<uint32_t>(), st));
         }
-        G.ment = oval2; G.mdir = mdir; G.mdir_bits = bits; G.idx_dbg = snk_env_u32("SNK_PATH_IDX_DBG", 0);
+        G.ment = oval2; G.mdir = mdir; G.mdir_bits = bits; G.idx_dbg = snk_opt_u32("path_idx_dbg", 0);
         if (!need_kdict) cap = n_ment;
         out->lookup_index = 1;
     }
@@ -1155,7 +1154,7 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
     unsigned long long h_cur[4] = {0, 0, 0, 0};
     ppart* gparts = nullptr;
     uint8_t* gm = nullptr;
-    if (!snk_env_u32("SNK_PATH_FUSED", 0)) {          // default: split first pass (SNK_PATH_FUSED=1: the group kernel does it all)
+    if (!snk_opt_u32("path_fused", 0)) {          // default: split first pass (SNK_PATH_FUSED=1: the group kernel does it all)
         if ((rc = dev(ctx, n * GPARTS + 1, &gparts, err, errcap)) || (rc = dev(ctx, n + 1, &gm, err, errcap))) return rc;
     }
     uint32_t* redo = nullptr;
@@ -1168,15 +1167,15 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
         a.out_off = out_off; a.out_n = out_n; a.out_e0 = out_e0; a.out_start = out_start; a.scratch = scratch; a.cursor = cursor; a.scratch_cap = scap;
         a.bc = want_bcs ? (const int32_t*)in->bc : nullptr; a.ub_first = ubk; a.ub_more = ubk ? ubk + n : nullptr; a.ub_cap = ubcap;
         if (!redo && (rc = dev(ctx, rcap, &redo, err, errcap))) return rc;
-        a.redo = redo; a.redo_cap = rcap; a.n_redo = 0; a.force_redo = snk_env_u32("SNK_PATH_REDO_ALL", 0);
+        a.redo = redo; a.redo_cap = rcap; a.n_redo = 0; a.force_redo = snk_opt_u32("path_redo_all", 0);
         a.gparts = gparts; a.gm = gm;
         if (n) {
             // sixteen lanes per read (eight put twice the reads in flight but the kernel is issue bound: 145.6 ms against 134.5)
             uint64_t grid = (n + 15) / 16;
             const uint64_t gmax = (uint64_t)ctx->n_cu * 64;
             if (grid > gmax) grid = gmax;
-            if (gparts && snk_env_u32("SNK_PATH_TWO_PASS", 1)) {
-                if (snk_env_u32("SNK_PATH_FAST_GS", 8) == 8) {
+            if (gparts && snk_opt_u32("path_two_pass", 1)) {
+                if (snk_opt_u32("path_fast_gs", 8) == 8) {
                     uint64_t g0 = (n + 31) / 32;
                     if (g0 > gmax) g0 = gmax;
                     if (use_index) hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, 0, 8, true>), dim3((unsigned)g0), dim3(256), 0, st, a);
@@ -1310,7 +1309,7 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
             // the reference's cut (cmd_main_asm.rs:115 stops extending an edge's list at 20 000 entries, in the order its shards
             // are visited and with duplicates counted between compactions -- not reproducible without its shard layout); here:
             // a unitig keeps its 20 000 SMALLEST barcode ids.  Lists under the cut -- all but high-copy repeats -- are unaffected.
-            const uint64_t cut = snk_env_u32("SNK_UNITIG_BC_CUT", 20000);
+            const uint64_t cut = snk_opt_u32("unitig_bc_cut", 20000);
             uint64_t *clen, *noff2;
             uint32_t* any;
             if ((rc = dev(ctx, U + 2, &clen, err, errcap)) || (rc = dev(ctx, U + 2, &noff2, err, errcap)) || (rc = dev(ctx, 4, &any, err, errcap))) return rc;
@@ -1357,7 +1356,7 @@ extern "C" int snk_dev_path_reads2(snk_ctx* ctx, uint32_t K, const snk_dev_reads
     if (n_unitigs && (!d_unitig_off || !d_unitig_bases)) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_path_reads: NULL unitig arrays");
     if (n_unitigs >= (1ull << 31)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_dev_path_reads: too many unitigs");
     memset(out, 0, sizeof *out);
-    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    SNK_HIP_TRY(snk_enter(ctx));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     ctx->cur_stream = st;
     // the call's scratch (graph tables, dictionary, parts, sort buffers: ~0.3 KB per read + 40 B per unitig k-mer) goes back to the

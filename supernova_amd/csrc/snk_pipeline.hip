@@ -55,7 +55,6 @@ __global__ void __launch_bounds__(256) input_fp_kernel(const uint4* __restrict__
 
 typedef snk_phase_timer phase_timer;
 
-#define env_u32 snk_env_u32
 
 }  // namespace
 
@@ -132,9 +131,9 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
         if (p->K != 48) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "SNK_F_GROUPED: the group id rides in the 32 key bits that are free at K=48 only");
         if (!in->group) return snk_fail(SNK_E_ARG, err, errcap, "SNK_F_GROUPED: snk_dev_reads.group is NULL");
         if (p->min_bc > 0 && in->bc) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "SNK_F_GROUPED: per-group graphs use the frequency rule only (min_bc = 0)");
-        if ((p->flags & SNK_F_GLOBAL_GRAPH) || snk_env_u32("SNK_GLOBAL_GRAPH", 0)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "SNK_F_GROUPED needs the bucket-local graph stage");
+        if ((p->flags & SNK_F_GLOBAL_GRAPH) || snk_opt_u32("global_graph", 0)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "SNK_F_GROUPED needs the bucket-local graph stage");
     }
-    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    SNK_HIP_TRY(snk_enter(ctx));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     ctx->cur_stream = st;
     ctx->arena_legacy = false;
@@ -193,7 +192,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     // looks at its first 1/64 of the buckets and asks for a second partition when they overflow as a rule.
     // ---- is this the data set the context's sizing history was made on?  (one 8-byte read-back: ~40 us)
     bool same_data = true;
-    if (n_reads && p->n_buckets == 0 && env_u32("SNK_INPUT_FP", 1)) {
+    if (n_reads && p->n_buckets == 0 && snk_opt_u32("input_fp", 1)) {
         void* q;
         if ((rc = snk_ctx_alloc(ctx, 64, &q, err, errcap))) return rc;
         unsigned long long* d_fp = (unsigned long long*)q;
@@ -218,9 +217,9 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     ctx->count_tight = 0;
     const uint32_t plain_target = K == 48 ? 5000u : 3500u;
     auto tight_for = [&](double ratio) -> uint32_t {
-        const uint32_t tries = env_u32("SNK_TIGHT_TRIES", 48) << 16;
-        if (getenv("SNK_COUNT_TIGHT") && *getenv("SNK_COUNT_TIGHT")) {
-            const uint32_t v = env_u32("SNK_COUNT_TIGHT", 0);
+        const uint32_t tries = snk_opt_u32("tight_tries", 48) << 16;
+        if (snk_opt_is_set("count_tight")) {
+            const uint32_t v = snk_opt_u32("count_tight", 0);
             return v ? (std::min(std::max(v, 256u), snk_count_slots(K) - 64u) | tries) : 0u;
         }
         const bool full = grouped || (ratio > 0.0 && 0.65 * (double)snk_count_limit(K, 0u, 0u) / ratio < (double)plain_target);
@@ -230,25 +229,25 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     // (... unless the bit filter in front of the table is on -- min_freq >= 2: then the table only sees the (group, k-mer) pairs that can be retained,
     // one in ten, and a bucket is as large as one batch of 512 records and ten instances per lane allow: beyond 6000 buckets start to fall out
     // of the filter -- 92.9 ms at 4800, 92.2 at 5600, 94.6 at 6400, `profiles/r05_count_screen_groups.log`)
-    const bool group_screen = grouped && env_u32("SNK_COUNT_SCREEN", 1) != 0 && p->min_freq >= (env_u32("SNK_COUNT_SCREEN", 1) >= 2 ? 2u : 3u);
+    const bool group_screen = grouped && snk_opt_u32("count_screen", 1) != 0 && p->min_freq >= (snk_opt_u32("count_screen", 1) >= 2 ? 2u : 3u);
     auto default_target_now = [&]() -> uint32_t { return grouped ? ((group_screen && ctx->count_tight) ? 5200u : (uint32_t)(0.74 * snk_count_limit(K, 1u, ctx->count_tight))) : plain_target; };
-    const bool target_forced = getenv("SNK_TARGET_INST") && *getenv("SNK_TARGET_INST");
+    const bool target_forced = snk_opt_is_set("target_inst");
     // ... and the RETAINED k-mers of a bucket are one chunk of the bucket-local graph stage, whose one-wave kernels hold 256 of them
     // (larger chunks take the slower big-chunk variants): at half the coverage twice as many k-mers survive per instance, every other
     // chunk was over the line and the graph stage took 81 instead of ~58 ms.  From the previous call's retained share: chunks of ~180 (28x coverage, with merged chunks behind it: 153.2 ms at 120, 149.5 at 150, 147.7 at 180, 147.5 at 210).
     const double retain = (same_data && ctx->retain_ratio > 0.0 && ctx->claim_ratio_reads == n_reads && ctx->claim_ratio_k == K * 2 + (grouped ? 1u : 0u) + 256u * ctx->mlen) ? ctx->retain_ratio : 0.0;
     auto target_for = [&](double ratio) -> uint32_t {
         const uint32_t default_target = default_target_now();
-        if (target_forced) return env_u32("SNK_TARGET_INST", default_target);
-        if (ctx->count_screen && !grouped) return env_u32("SNK_SCREEN_TARGET", 4000);
+        if (target_forced) return snk_opt_u32("target_inst", default_target);
+        if (ctx->count_screen && !grouped) return snk_opt_u32("screen_target", 4000);
         if (retain > 0.0 && (!grouped || group_screen)) {       // (groups behind the bit filter: buckets of 5200 instances, unless that many would retain more than a graph chunk holds)
-            const double t = (double)env_u32("SNK_CHUNK_KMERS", 180) / retain;
+            const double t = (double)snk_opt_u32("chunk_kmers", 180) / retain;
             if (t < (double)default_target) {
                 uint32_t tt = t < 600.0 ? 600u : (uint32_t)t;
                 if (ratio > 0.0) {           // the tighter of the two limits
                     const double lim = (double)snk_count_limit(K, 0u, ctx->count_tight);
                     if (0.65 * lim / ratio < (double)default_target) {
-                        const double t2 = 0.01 * env_u32("SNK_BUCKET_FILL_PCT", 50) * lim / ratio;
+                        const double t2 = 0.01 * snk_opt_u32("bucket_fill_pct", 50) * lim / ratio;
                         if (t2 < (double)tt) tt = t2 < 600.0 ? 600u : (uint32_t)t2;
                     }
                 }
@@ -260,17 +259,17 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
         // that would fill them further do best at ~50 % (0.6 % errors: 239 ms with the default size, 186 at 80 %, 154 at 50 %)
         const double lim = (double)snk_count_limit(K, grouped ? 1u : 0u, ctx->count_tight);
         if (0.65 * lim / ratio >= (double)default_target) return default_target;
-        const double t = 0.01 * env_u32("SNK_BUCKET_FILL_PCT", 50) * lim / ratio;
+        const double t = 0.01 * snk_opt_u32("bucket_fill_pct", 50) * lim / ratio;
         return t >= (double)default_target ? default_target : (t < 600.0 ? 600u : (uint32_t)t);
     };
     const bool have_hint = same_data && ctx->claim_ratio > 0.0 && ctx->claim_ratio_reads == n_reads && ctx->claim_ratio_k == K * 2 + (grouped ? 1u : 0u) + 256u * ctx->mlen;
     double ratio = have_hint ? ctx->claim_ratio : 0.0;
-    const bool adaptive = p->n_buckets == 0 && !target_forced && !grouped && env_u32("SNK_ADAPTIVE_BUCKETS", 1) != 0;      // (the per-barcode default is tuned at ratio ~1)
+    const bool adaptive = p->n_buckets == 0 && !target_forced && !grouped && snk_opt_u32("adaptive_buckets", 1) != 0;      // (the per-barcode default is tuned at ratio ~1)
     uint32_t NB = 0;
     snk_partition part;
     snk_table tab;
     void* records = nullptr;
-    const bool local_graph = !(p->flags & SNK_F_GLOBAL_GRAPH) && !env_u32("SNK_GLOBAL_GRAPH", 0);
+    const bool local_graph = !(p->flags & SNK_F_GLOBAL_GRAPH) && !snk_opt_u32("global_graph", 0);
     const uint64_t mark = ctx->alloc_serial;
     const unsigned long long ub_inst = h_plan[0], ub_live = h_plan[1];
     for (int pass = 0; pass < 2; ++pass) {
@@ -282,10 +281,10 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
         // (0.6 % errors, ratio 0.21, lose with it: a fifth of their instances are singletons, the first pass costs more than it saves)
         {
             const double r_now = adaptive ? ratio : (have_hint ? ctx->claim_ratio : 0.0);
-            const uint32_t ng = env_u32("SNK_COUNT_SCREEN_NG", 1);
-            ctx->count_screen = (!grouped && K == 48 && p->min_freq >= 3 && (!in->bc || p->min_bc <= 2) && ng && (ng >= 2 || r_now > 0.01 * env_u32("SNK_SCREEN_RATIO_PCT", 30))) ? 3u : 0u;
-            { const char* te = getenv("SNK_COUNT_TIGHT"); if (te && te[0] == '0' && !te[1]) ctx->count_screen = 0; }      // (the filter comes with booked slots)
-            if (ctx->count_screen && !ctx->count_tight) ctx->count_tight = (snk_count_slots(K) - snk_count_slots(K) / 16u) | (env_u32("SNK_TIGHT_TRIES", 48) << 16);
+            const uint32_t ng = snk_opt_u32("count_screen_ng", 1);
+            ctx->count_screen = (!grouped && K == 48 && p->min_freq >= 3 && (!in->bc || p->min_bc <= 2) && ng && (ng >= 2 || r_now > 0.01 * snk_opt_u32("screen_ratio_pct", 30))) ? 3u : 0u;
+            if (snk_opt_is_set("count_tight") && snk_opt_u32("count_tight", 1) == 0u) ctx->count_screen = 0;      // (the filter comes with booked slots)
+            if (ctx->count_screen && !ctx->count_tight) ctx->count_tight = (snk_count_slots(K) - snk_count_slots(K) / 16u) | (snk_opt_u32("tight_tries", 48) << 16);
             if (ctx->count_screen && r_now > 0.0) ctx->screen_ratio = r_now;      // (what the screened call reports is the table's view: the decision keeps the ratio it was made on)
             ctx->last_count_limit = snk_count_limit(K, grouped ? 1u : 0u, ctx->count_tight);
             if ((ctx->count_screen || (group_screen && ctx->count_tight)) && K == 48) ctx->last_count_limit = std::min(ctx->last_count_limit, snk_count_screen_limit());
@@ -310,7 +309,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
         h_plan[0] = ub_inst; h_plan[1] = ub_live;
         // ---- a job whose slots would not fit: bucket-range passes over one slot array (snk_stages.h); the count stage's range hook
         //      partitions range r right before range r is counted
-        const uint32_t n_passes = (NB >= 2 && !env_u32("SNK_MSP_DENSE", 0)) ? std::min<uint32_t>(snk_partition_passes_needed(ctx, K, NB, ub_inst, ub_live, grouped), NB) : 1u;
+        const uint32_t n_passes = (NB >= 2 && !snk_opt_u32("msp_dense", 0)) ? std::min<uint32_t>(snk_partition_passes_needed(ctx, K, NB, ub_inst, ub_live, grouped), NB) : 1u;
         ctx->last_partition_passes = n_passes;
         if (n_passes > 1) {
             snk_partition_passes PS;
@@ -349,26 +348,29 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
         // ---- K5-K8 count + filter + gather (+ sort for the global graph stage)
         snk_count_pilot pilot{0.0, nullptr, nullptr};
         const bool want_pilot = adaptive && pass == 0 && !have_hint;
+#ifdef SNK_PROBES
         // measurement aid: SNK_OVERLAP_PROBE = 1: the partition kernel once more (into scratch) on a second stream NEXT TO the count
         // kernel; 2: the same launch alone (waited for before the count starts); +4: the second stream has high priority;
         // SNK_OVERLAP_PROBE_DBG = the relaunched kernel's dbg mode (1 no record stores, 2 no slot atomics, 3 scan only)
-        const uint32_t oprobe = env_u32("SNK_OVERLAP_PROBE", 0);
-        static hipStream_t s2 = nullptr, s2hi = nullptr;
+        const uint32_t oprobe = snk_opt_u32("overlap_probe", 0);
+        hipStream_t s2 = nullptr, s2hi = nullptr;      // (a measurement aid of tuning builds: created per probed call, destroyed below)
         hipStream_t sp2 = nullptr;
         hipEvent_t pe[3] = {nullptr, nullptr, nullptr};
         if (oprobe) {
-            if (!s2) { SNK_HIP_TRY(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking)); int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); SNK_HIP_TRY(hipStreamCreateWithPriority(&s2hi, hipStreamNonBlocking, hi)); }
+            { SNK_HIP_TRY(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking)); int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); SNK_HIP_TRY(hipStreamCreateWithPriority(&s2hi, hipStreamNonBlocking, hi)); }
             sp2 = (oprobe & 4u) ? s2hi : s2;
             for (auto& e : pe) SNK_HIP_TRY(hipEventCreate(&e));
             SNK_HIP_TRY(hipEventRecord(pe[0], st));
             SNK_HIP_TRY(hipStreamWaitEvent(sp2, pe[0], 0));
             SNK_HIP_TRY(hipEventRecord(pe[1], sp2));
-            if ((rc = snk_probe_relaunch_msp(ctx, sp2, env_u32("SNK_OVERLAP_PROBE_DBG", 0), err, errcap))) return rc;
+            if ((rc = snk_probe_relaunch_msp(ctx, sp2, snk_opt_u32("overlap_probe_dbg", 0), err, errcap))) return rc;
             SNK_HIP_TRY(hipEventRecord(pe[2], sp2));
             if ((oprobe & 3u) == 2u) SNK_HIP_TRY(hipStreamSynchronize(sp2));
         }
+#endif
         rc = snk_stage_count_table(ctx, st, K, records, part.seg, part.seg + NB, 2 * NB, part.nseg, NB, p->min_freq, (in->bc && !grouped) ? p->min_bc : 0u, grouped ? 1u : 0u,
                                    h_ninst, status, !local_graph, &tab, err, errcap, nullptr, want_pilot ? &pilot : nullptr, part.gidx, local_graph, &hot);
+#ifdef SNK_PROBES
         if (oprobe) {
             SNK_HIP_TRY(hipStreamSynchronize(sp2));
             float pm = 0.f;
@@ -376,7 +378,9 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
             fprintf(stderr, "[snk overlap probe] mode %u: partition kernel (first launch, alone) %.2f ms; relaunched %s %.2f ms; count kernel %.2f ms; count stage %.2f ms\n", oprobe,
                     part.kernel_ms, (oprobe & 3u) == 2u ? "alone" : "next to the count kernel", pm, tab.count_kernel_ms, tab.count_ms);
             for (auto& e : pe) (void)hipEventDestroy(e);
+            (void)hipStreamDestroy(s2); (void)hipStreamDestroy(s2hi);
         }
+#endif
         if (rc == SNK_RETARGET) {
             // everything since the partition goes back to the arena; the good lengths and the status words stay
             snk_ctx_release_since(ctx, mark, nullptr, 0);
@@ -428,7 +432,7 @@ extern "C" int snk_dev_stream_begin(snk_ctx* ctx, const snk_params* p, uint32_t 
     ctx->count_screen = 0;
     if (read_len == 0 || read_len > 256 || total_reads_ub == 0) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_stream_begin: read_len 1..256 and an upper bound of the job's reads are needed");
     if ((p->flags & SNK_F_GROUPED)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_dev_stream_begin: per-group graphs take their reads resident (snk_dev_count_graph)");
-    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    SNK_HIP_TRY(snk_enter(ctx));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     ctx->cur_stream = st;
     ctx->arena_legacy = false;
@@ -448,11 +452,11 @@ extern "C" int snk_dev_stream_begin(snk_ctx* ctx, const snk_params* p, uint32_t 
     uint32_t NB = p->n_buckets;
     if (NB == 0) {
         uint32_t target = K == 48 ? 5000u : 3500u;
-        if (getenv("SNK_TARGET_INST") && *getenv("SNK_TARGET_INST")) target = env_u32("SNK_TARGET_INST", target);
+        if (snk_opt_is_set("target_inst")) target = snk_opt_u32("target_inst", target);
         else if (ctx->claim_ratio > 0.0 && ctx->claim_ratio_reads == total_reads_ub && ctx->claim_ratio_k == K * 2 + 256u * ctx->mlen) {
             const double lim = (double)snk_count_limit(K, 0u, ctx->count_tight);
             if (0.65 * lim / ctx->claim_ratio < (double)target) {
-                const double t = 0.01 * env_u32("SNK_BUCKET_FILL_PCT", 50) * lim / ctx->claim_ratio;
+                const double t = 0.01 * snk_opt_u32("bucket_fill_pct", 50) * lim / ctx->claim_ratio;
                 target = t < 600.0 ? 600u : (uint32_t)t;
             }
         }
@@ -485,7 +489,7 @@ extern "C" int snk_dev_stream_append(snk_ctx* ctx, const snk_dev_reads* slab, vo
     if (j->J.n_reads + slab->n_reads > j->total_ub)
         return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_stream_append: more reads than the job's upper bound (%llu + %llu > %llu)", (unsigned long long)j->J.n_reads,
                         (unsigned long long)slab->n_reads, (unsigned long long)j->total_ub);
-    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    SNK_HIP_TRY(snk_enter(ctx));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     ctx->cur_stream = st;
     snk_dev_reads r = *slab;
@@ -518,7 +522,7 @@ extern "C" int snk_dev_stream_finish(snk_ctx* ctx, snk_dev_result* out, void* st
     if (!ctx || !out) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_stream_finish: NULL argument");
     stream_job* j = static_cast<stream_job*>(ctx->stream_job);
     if (!j || !j->open) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_stream_finish: no open job (snk_dev_stream_begin)");
-    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    SNK_HIP_TRY(snk_enter(ctx));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     ctx->cur_stream = st;
     j->open = false;
@@ -545,7 +549,7 @@ extern "C" int snk_dev_stream_finish(snk_ctx* ctx, snk_dev_result* out, void* st
     out->n_buckets = j->NB;
     out->n_supermers = part.n_supermers;
     out->n_overflow = part.n_overflow;
-    const bool local_graph = !(p->flags & SNK_F_GLOBAL_GRAPH) && !env_u32("SNK_GLOBAL_GRAPH", 0);
+    const bool local_graph = !(p->flags & SNK_F_GLOBAL_GRAPH) && !snk_opt_u32("global_graph", 0);
     snk_hot hot;
     if ((rc = snk_stage_hot(ctx, st, K, false, &part, &hot, err, errcap))) return rc;
     out->n_hot_buckets = hot.n_hot;

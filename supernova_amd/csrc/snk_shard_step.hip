@@ -186,21 +186,20 @@ uint32_t plan_buckets(uint64_t inst_ub, uint32_t world, uint32_t K, uint32_t for
     if (screen_out) *screen_out = 0;
     if (!nb) {
         const uint32_t dflt = K == 48 ? 5000u : 3500u;
-        uint64_t target = snk_env_u32("SNK_TARGET_INST", dflt);
-        const char* e = getenv("SNK_TARGET_INST");
-        if (!(e && *e) && ratio > 0.0 && snk_env_u32("SNK_ADAPTIVE_BUCKETS", 1)) {
+        uint64_t target = snk_opt_u32("target_inst", dflt);
+        if (!snk_opt_is_set("target_inst") && ratio > 0.0 && snk_opt_u32("adaptive_buckets", 1)) {
             // (the rule of the one-GPU path, snk_pipeline.hip: smaller buckets when the tables would run more than ~65 % full)
             double lim = (double)snk_count_limit(K, 0u, 0u);
             // (tables that run full are counted with booked slots, as on the one-GPU path: every rank takes the same turn, the ratio is job-wide)
-            const char* te = getenv("SNK_COUNT_TIGHT");
-            if (tight_out && 0.65 * lim / ratio < (double)dflt && !(te && *te == '0')) {
-                *tight_out = (snk_count_slots(K) - snk_count_slots(K) / 16u) | (snk_env_u32("SNK_TIGHT_TRIES", 48) << 16);
+            const bool tight_off = snk_opt_is_set("count_tight") && snk_opt_u32("count_tight", 1) == 0u;
+            if (tight_out && 0.65 * lim / ratio < (double)dflt && !tight_off) {
+                *tight_out = (snk_count_slots(K) - snk_count_slots(K) / 16u) | (snk_opt_u32("tight_tries", 48) << 16);
                 lim = (double)snk_count_limit(K, 0u, *tight_out);
             }
-            if (0.65 * lim / ratio < (double)dflt) { const double t = 0.01 * snk_env_u32("SNK_BUCKET_FILL_PCT", 50) * lim / ratio; target = t < 600.0 ? 600u : (uint64_t)t; if (target > dflt) target = dflt; }
+            if (0.65 * lim / ratio < (double)dflt) { const double t = 0.01 * snk_opt_u32("bucket_fill_pct", 50) * lim / ratio; target = t < 600.0 ? 600u : (uint64_t)t; if (target > dflt) target = dflt; }
             // (... and above 0.3 distinct k-mers per instance behind the bit filter, whose table only sees what can be retained: snk_pipeline.hip)
-            const uint32_t ng = snk_env_u32("SNK_COUNT_SCREEN_NG", 1);
-            if (screen_ok && tight_out && *tight_out && ng && (ng >= 2 || ratio > 0.01 * snk_env_u32("SNK_SCREEN_RATIO_PCT", 30))) { *screen_out = 3; target = snk_env_u32("SNK_SCREEN_TARGET", 4000); }
+            const uint32_t ng = snk_opt_u32("count_screen_ng", 1);
+            if (screen_ok && tight_out && *tight_out && ng && (ng >= 2 || ratio > 0.01 * snk_opt_u32("screen_ratio_pct", 30))) { *screen_out = 3; target = snk_opt_u32("screen_target", 4000); }
         }
         nb = (inst_ub + target - 1) / target;
         if (nb < 1) nb = 1;
@@ -261,8 +260,7 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
     // Bucket size: from the job-wide ratio of distinct k-mers per instance the previous step exchanged; without that history the
     // count stage looks at its first buckets, the ranks agree on what they saw (one more exchange), and if the tables overflow as
     // a rule the reads are partitioned and exchanged once more into smaller buckets (error-rich reads: see snk_pipeline.hip).
-    const char* forced_target = getenv("SNK_TARGET_INST");
-    const bool adaptive = inst_ub && !(forced_target && *forced_target) && snk_env_u32("SNK_ADAPTIVE_BUCKETS", 1) != 0;
+    const bool adaptive = inst_ub && !snk_opt_is_set("target_inst") && snk_opt_u32("adaptive_buckets", 1) != 0;
     double ratio = have_ratio ? comm->claim_ratio : 0.0;
     uint32_t NB_total = 0, NBl = 0;
     uint64_t n_inst = 0, inst_hint = 0, exch_records = 0;
@@ -298,7 +296,7 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
             // one rank owns every bucket: the slots are counted where they are (exactly the one-GPU path)
             tm.mark();   // 2
             tm.mark();   // 3
-            const uint32_t fake = snk_env_u32("SNK_DBG_FAKE_SEGS", 0);
+            const uint32_t fake = snk_opt_u32("dbg_fake_segs", 0);
             if (fake > 1 && fake <= 32 && part.n_overflow == 0) {
                 uint64_t* T;
                 ALLOC(T, uint64_t, 2ull * fake * NB_total + 2);
@@ -328,7 +326,7 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
             SNK_HIP_TRY(hipMemcpyAsync(hsend_x, part.cursor, (size_t)NB_total * 4, hipMemcpyDeviceToDevice, st));
             SNK_HIP_TRY(hipMemsetAsync(hsend_x + (uint64_t)me * NBl, 0, (size_t)NBl * 4, st));
             SNK_HIP_TRY(hipMemsetAsync(hrecv + (uint64_t)me * NBl, 0, (size_t)NBl * 4, st));
-            uint32_t R = snk_env_u32("SNK_EXCHANGE_RANGES", 4);
+            uint32_t R = snk_opt_u32("exchange_ranges", 4);
             if (R < 1) R = 1;
             if (R > NBl) R = NBl;
             if (R > 64) R = 64;
@@ -557,7 +555,7 @@ int step_impl(step_ctx& X, shard_host& H, const snk_dev_reads* in, const snk_par
     jt.mark();   // j2 gather links
     bool ranked = false;
     uint64_t exch_spl = 0, exch_rank = 0, pair_max_rank = 0;
-    const bool want_partitioned = snk_env_u32("SNK_JOIN_REPLICATED", 0) == 0;
+    const bool want_partitioned = snk_opt_u32("join_replicated", 0) == 0;
     for (int attempt = 0; want_partitioned && !ranked && attempt < 3; ++attempt) {
         // (a second attempt follows a circle cut: the links changed, everything derived from them is made again)
         uint64_t m_spl = 0;
@@ -738,7 +736,7 @@ __global__ void __launch_bounds__(256) shift_offsets_kernel(const uint64_t* __re
 extern "C" int snk_shard_gather_unitigs(snk_ctx* ctx, snk_comm* comm, const snk_shard_result* res, uint32_t K, uint32_t root, uint32_t flags,
                                         snk_result* out, void* stream, char* err, size_t errcap) {
     if (!ctx || !comm || !res || !out || root >= comm->world) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_gather_unitigs: bad argument");
-    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    SNK_HIP_TRY(snk_enter(ctx));
     memset(out, 0, sizeof *out);
     if (!ctx->shard_host) { ctx->shard_host = new shard_host(); ctx->shard_host_free = shard_host_free; }
     shard_host& H = *static_cast<shard_host*>(ctx->shard_host);
@@ -811,6 +809,7 @@ static int shard_step_run(snk_ctx* ctx, snk_comm* comm, const snk_dev_reads* in,
 extern "C" int snk_shard_step(snk_ctx* ctx, snk_comm* comm, const snk_dev_reads* in, const snk_params* p, uint64_t total_reads, uint32_t flags,
                               snk_shard_result* out, void* stream, char* err, size_t errcap) {
     if (!ctx || !comm || !in || !p || !out) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_step: NULL argument");
+    snk_opts_enter(&ctx->opts);
     return shard_step_run(ctx, comm, in, p, total_reads, flags, out, stream, false, err, errcap);
 }
 
@@ -823,7 +822,7 @@ extern "C" int snk_shard_stream_begin(snk_ctx* ctx, snk_comm* comm, const snk_pa
     if (!ctx || !comm || !p) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_stream_begin: NULL argument");
     if (p->flags & SNK_F_GROUPED) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_shard_stream_begin: per-group graphs shard by group (replicas), not by minimiser");
     if (total_reads == 0 && p->n_buckets == 0) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_stream_begin: the job's read total (or n_buckets) is needed: the ranks size the buckets alike from it");
-    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    SNK_HIP_TRY(snk_enter(ctx));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     ctx->cur_stream = st;
     const uint32_t W = comm->world, K = p->K;
@@ -833,14 +832,14 @@ extern "C" int snk_shard_stream_begin(snk_ctx* ctx, snk_comm* comm, const snk_pa
     snk_set_mlen(ctx, p);
     const uint64_t kpr = read_len >= K ? read_len - K + 1 : 0;
     const uint64_t inst_ub = total_reads * kpr;
-    const char* forced_target = getenv("SNK_TARGET_INST");
-    const bool adaptive = inst_ub && !(forced_target && *forced_target) && snk_env_u32("SNK_ADAPTIVE_BUCKETS", 1) != 0;
+    const bool adaptive = inst_ub && !snk_opt_is_set("target_inst") && snk_opt_u32("adaptive_buckets", 1) != 0;
     const bool have_ratio = inst_ub && comm->claim_ratio > 0.0 && comm->claim_ratio_reads == inst_ub && comm->claim_ratio_k == K * 2 + 256u * ctx->mlen;
     const uint32_t NB_total = plan_buckets(inst_ub, W, K, p->n_buckets, adaptive && have_ratio ? comm->claim_ratio : 0.0);
     return snk_shard_job_open(ctx, p, comm->rank, W, NB_total, read_len, rank_reads_ub, total_reads, has_bc, st, err, errcap);
 }
 extern "C" int snk_shard_stream_append(snk_ctx* ctx, const snk_dev_reads* slab, void* stream, char* err, size_t errcap) {
     if (!ctx || !slab) return snk_fail(SNK_E_ARG, err, errcap, "snk_shard_stream_append: NULL argument");
+    snk_opts_enter(&ctx->opts);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     ctx->cur_stream = st;
     return snk_shard_job_add(ctx, slab, st, err, errcap);
@@ -860,7 +859,7 @@ extern "C" int snk_shard_stream_finish(snk_ctx* ctx, snk_comm* comm, uint32_t fl
 static int shard_step_run(snk_ctx* ctx, snk_comm* comm, const snk_dev_reads* in, const snk_params* p, uint64_t total_reads, uint32_t flags, snk_shard_result* out,
                           void* stream, bool streamed, char* err, size_t errcap) {
     if (p->flags & SNK_F_GROUPED) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "snk_shard_step: per-group graphs shard by group (replicas), not by minimiser");
-    SNK_HIP_TRY(hipSetDevice(ctx->device));
+    SNK_HIP_TRY(snk_enter(ctx));
     if (!ctx->shard_host) { ctx->shard_host = new shard_host(); ctx->shard_host_free = shard_host_free; }
     shard_host& H = *static_cast<shard_host*>(ctx->shard_host);
     step_ctx X;

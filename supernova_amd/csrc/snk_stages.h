@@ -49,7 +49,6 @@ struct snk_table {
 };
 
 struct snk_hot;
-uint32_t snk_env_u32(const char* name, uint32_t dflt);
 // optional: the first count launch goes out in bucket ranges [bounds[r], bounds[r+1]); ready(user, r) is called before
 // range r is launched (the sharded path makes the stream wait for that range's records there)
 struct snk_count_ranges {
@@ -127,7 +126,9 @@ int snk_partition_passes_open(snk_ctx* ctx, hipStream_t st, uint32_t K, const sn
 int snk_partition_passes_run(void* user, uint32_t r);
 // passes a job of this size needs so that its slots take at most ~a quarter of the device (1: the one-pass partition)
 uint32_t snk_partition_passes_needed(snk_ctx* ctx, uint32_t K, uint32_t NB, unsigned long long n_inst, unsigned long long n_live, bool grouped);
-int snk_probe_relaunch_msp(snk_ctx* ctx, hipStream_t s2, uint32_t dbg, char* err, size_t errcap);      // measurement aid (SNK_OVERLAP_PROBE)
+#ifdef SNK_PROBES
+int snk_probe_relaunch_msp(snk_ctx* ctx, hipStream_t s2, uint32_t dbg, char* err, size_t errcap);      // measurement aid (tools/overlap_probe*.py)
+#endif
 // hot minimiser buckets (snk_hot.hip): their records expanded into single-k-mer records, one virtual bucket per (bucket, hash class)
 struct snk_hot {
     uint32_t n_hot, NBv;           // hot buckets, virtual buckets (0: nothing is hot)

@@ -15,11 +15,6 @@
 #include "snk_kernels.h"
 #include "snk_stages.h"
 
-uint32_t snk_env_u32(const char* name, uint32_t dflt) {
-    const char* v = getenv(name);
-    return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
-}
-#define env_u32 snk_env_u32
 
 // K5-K8 + gather + sort: supermer records of NB buckets (nseg segments) -> dense retained table sorted by key.
 // status: device u32[16] scratch words.
@@ -28,7 +23,7 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
                           uint32_t* status, bool want_sort, snk_table* out, char* err, size_t errcap, const snk_count_ranges* ranges, snk_count_pilot* pilot,
                           const uint32_t* gidx, bool defer_compact, const snk_hot* hot) {
     if (hot && hot->NBv == 0) hot = nullptr;
-    defer_compact = defer_compact && !want_sort && env_u32("SNK_DEFER_COMPACT", 1) != 0;
+    defer_compact = defer_compact && !want_sort && snk_opt_u32("defer_compact", 1) != 0;
     int rc;
     snk_phase_timer tm(st), kt(st);
     tm.mark();
@@ -94,7 +89,7 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
         // (per-barcode groups, min_freq >= 3: three reads of one barcode over one k-mer are rare, two -- the mates of a pair -- are not; with
         // min_freq 2 a quarter of the instances pass the filter and the larger buckets cost more than they save: 428 against 270 ms.
         // SNK_COUNT_SCREEN: 0 never, 1 at min_freq >= 3, 2 at min_freq >= 2 as well)
-        { const uint32_t sc = grouped ? env_u32("SNK_COUNT_SCREEN", 1) : 0u; ca.screen = (sc && min_freq >= (sc >= 2 ? 2u : 3u)) ? std::min(min_freq, 3u) : 0u; }
+        { const uint32_t sc = grouped ? snk_opt_u32("count_screen", 1) : 0u; ca.screen = (sc && min_freq >= (sc >= 2 ? 2u : 3u)) ? std::min(min_freq, 3u) : 0u; }
         if (!grouped && K == 48 && ctx->count_screen && ctx->count_tight && bc_mode <= 2u) ca.screen = std::min(std::min(min_freq, 3u), ctx->count_screen);
         ca.bucket0 = 0;
         ca.out_keys = keys_r;
@@ -107,7 +102,7 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
         ca.chunk_base = chunk_base;
         ca.extra = extra;
         ca.extra_cap = extra_cap;
-        ca.dbg = env_u32("SNK_COUNT_DBG", 0);
+        ca.dbg = snk_opt_u32("count_dbg", 0);
         ca.prof = nullptr;
 #ifdef SNK_COUNT_PROF
         {
@@ -143,7 +138,7 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
                 // ... and should the caller partition again (retarget), its next run sizes its regions from what survived here, not from the
                 // blanket instances / 12: at 1.5 % errors that is 20 GB of regions mapped for 7 GB of survivors -- on a first call the arena
                 // grows by what is asked for, at the driver's ~30 ms per GB
-                if (b0 == 0 && sum && env_u32("SNK_PILOT_EST", 1)) { ctx->last_n_kmers = (uint64_t)((double)sum * ((double)NB / NBp)); ctx->last_n_instances = n_inst_hint; }
+                if (b0 == 0 && sum && snk_opt_u32("pilot_est", 1)) { ctx->last_n_kmers = (uint64_t)((double)sum * ((double)NB / NBp)); ctx->last_n_instances = n_inst_hint; }
             }
             if (pilot->agree && (r2 = pilot->agree(pilot->user, &pilot->per_bucket))) return snk_fail(SNK_E_INTERNAL, err, errcap, "count: the pilot's exchange failed (%d)", r2);
             *retarget = pilot->per_bucket > 0.85 * snk_count_limit(K, grouped, ctx->count_tight) && !h_p[1];
@@ -333,9 +328,9 @@ __global__ void __launch_bounds__(256) cursor_exact_kernel(const uint64_t* __res
 }
 // slot reservations stop for a bucket that was handed slot hot_thr (SNK_MSP_HOT_FACTOR x capacity, 0 = never)
 static uint32_t msp_hot_thr(uint32_t cap) {
-    const uint64_t f = env_u32("SNK_MSP_HOT_FACTOR", 32);
+    const uint64_t f = snk_opt_u32("msp_hot_factor", 32);
     const uint64_t t = f * cap;
-    const uint64_t lo = env_u32("SNK_MSP_HOT_MIN", 4096);
+    const uint64_t lo = snk_opt_u32("msp_hot_min", 4096);
     return f == 0 ? 0xFFFFFFFFu : (uint32_t)(t < lo ? lo : (t > 0x7FFFFFFFull ? 0x7FFFFFFFull : t));
 }
 // (instances, contributing reads) of one slab added to the streamed job's counters
@@ -434,7 +429,7 @@ int snk_stage_partition_plan(snk_ctx* ctx, hipStream_t st, uint32_t K, const uin
 
 bool snk_fused_trim_ok(const snk_dev_reads* in) {
     return in->quals && !in->good_len && (in->qstride & 3u) == 0 && (((uintptr_t)in->quals) & 3u) == 0 && in->read_len <= 160 && in->qstride >= in->read_len &&
-           (!in->lens || (((uintptr_t)in->lens) & 1u) == 0) && env_u32("SNK_TRIM_FUSED", 1) != 0;
+           (!in->lens || (((uintptr_t)in->lens) & 1u) == 0) && snk_opt_u32("trim_fused", 1) != 0;
 }
 
 // expected supermers of a pass and the record slots a bucket gets
@@ -451,9 +446,9 @@ static void partition_capacity(snk_ctx* ctx, uint32_t K, uint32_t NB, unsigned l
     // ONE site), where 2.5 x mean lost a tenth of the supermers to the overflow list, overran it, and ran the pass twice
     // (78 instead of 34 ms).  c is a property of the data set: 48 covers 70x; per-barcode groups see a site once or twice.
     // Overflowing supermers are correct (segment 1), only slower; the slots that stay empty are never touched.
-    const double site_records = (double)env_u32("SNK_MSP_SITE_RECORDS", grouped ? 3u : 48u);
+    const double site_records = (double)snk_opt_u32("msp_site_records", grouped ? 3u : 48u);
     uint64_t cap64 = (uint64_t)(mean + 5.0 * std::sqrt(mean * site_records) + 16.0);
-    cap64 = cap64 * env_u32("SNK_MSP_CAP_PCT", 100) / 100;
+    cap64 = cap64 * snk_opt_u32("msp_cap_pct", 100) / 100;
     if (cap64 < 2) cap64 = 2;
     cap64 = (cap64 + 1) & ~1ull;
     if (ideal_out) *ideal_out = cap64;
@@ -526,7 +521,7 @@ int partition_dense(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_read
         ma.group = grouped ? (const uint32_t*)in->group : nullptr;
         ma.records = (uint4*)records;
         ma.dense_bkt = bkt; ma.dense_cursor = d_cur; ma.dense_cap = dcap;
-        ma.dbg = env_u32("SNK_MSP_DBG", 0);
+        ma.dbg = snk_opt_u32("msp_dbg", 0);
         if (ft) {
             ma.good_len = ft->good_out; ma.quals = (const uint8_t*)ft->quals; ma.qstride = ft->qstride; ma.min_qual = ft->min_qual;
             ma.lens = (const uint16_t*)ft->lens; ma.good_out = ft->good_out; ma.plan = d_fplan;
@@ -595,6 +590,7 @@ int partition_dense(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_read
 // ---- measurement aid (SNK_OVERLAP_PROBE, snk_pipeline.hip): the last partition launch once more, into scratch memory of its own, on
 // ANOTHER stream -- next to whatever the caller's stream runs (the count kernel).  Says what the hardware makes of an atomics-bound and a
 // VALU-bound kernel that are resident at the same time.  Results of the call are not touched.
+#ifdef SNK_PROBES      // measurement aids (tools/overlap_probe*.py; tuning builds: tools/build_variant.sh probes -DSNK_PROBES): not in the product build
 static snk_msp_args snk_probe_last_msp;
 static uint32_t snk_probe_last_msp_K = 0;
 static uint64_t snk_probe_last_msp_ovf_cap = 0;
@@ -681,6 +677,7 @@ int snk_probe_relaunch_msp(snk_ctx* ctx, hipStream_t s2, uint32_t dbg, char* err
     SNK_HIP_TRY(hipMemsetAsync(ma.ovf_cursor, 0, SNK_OVF_SUBLISTS * SNK_OVF_CUR_STRIDE * 4, s2));
     return snk_launch_msp(snk_probe_last_msp_K, ctx->mlen, s2, ma, err, errcap);
 }
+#endif
 
 int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_reads* in, const uint16_t* good_len, uint32_t NB,
                         unsigned long long n_inst, unsigned long long n_live, bool grouped, uint32_t* status, snk_partition* out,
@@ -690,7 +687,7 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
     double est_super = 0;
     uint64_t cap64 = 0;
     partition_capacity(ctx, K, NB, n_inst, n_live, grouped, &est_super, &cap64);
-    if (allow_dense && est_super * 1.25 + 2e6 < 4.0e9 && env_u32("SNK_MSP_DENSE", 0))
+    if (allow_dense && est_super * 1.25 + 2e6 < 4.0e9 && snk_opt_u32("msp_dense", 0))
         return partition_dense(ctx, st, K, in, good_len, NB, est_super, grouped, status, out, err, errcap, d_plan, h_plan, ft);
     if (cap64 * NB >= (1ull << 40) || cap64 >= (1ull << 31)) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "bucket capacity out of range");
     const uint32_t cap = (uint32_t)cap64;
@@ -742,7 +739,7 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
         ma.cursor = cursor; ma.records = (uint4*)records; ma.cap = cap; ma.ovf_cap = (uint32_t)sub_cap;
         ma.ovf_base = (uint64_t)NB * cap; ma.ovf_bucket = ovf_bucket; ma.ovf_cursor = ovf_cur;
         ma.hot_tab = cursor + NB + 1; ma.hot_thr = msp_hot_thr(cap);
-        ma.dbg = env_u32("SNK_MSP_DBG", 0);
+        ma.dbg = snk_opt_u32("msp_dbg", 0);
         if (ft) {
             ma.good_len = ft->good_out; ma.quals = (const uint8_t*)ft->quals; ma.qstride = ft->qstride; ma.min_qual = ft->min_qual;
             ma.lens = (const uint16_t*)ft->lens; ma.good_out = ft->good_out; ma.plan = d_fplan;
@@ -752,7 +749,9 @@ int snk_stage_partition(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_
         kt.mark();  // 0
         if ((rc = snk_launch_msp(K, ctx->mlen, st, ma, err, errcap))) return rc;
         kt.mark();  // 1
+#ifdef SNK_PROBES
         snk_probe_last_msp = ma; snk_probe_last_msp_K = K; snk_probe_last_msp_ovf_cap = ovf_cap;
+#endif
         // segment 0 (the fixed-capacity slots) and the supermer total need the cursors only: one read-back for everything the
         // host wants to know about this pass (overflow count, supermers, and the caller's trim statistics if asked for)
         SNK_HIP_TRY(hipMemsetAsync(d_total, 0, 64 * 8, st));
@@ -822,7 +821,7 @@ __global__ void __launch_bounds__(256) seg0_range_kernel(const uint32_t* __restr
 }  // namespace
 
 uint32_t snk_partition_passes_needed(snk_ctx* ctx, uint32_t K, uint32_t NB, unsigned long long n_inst, unsigned long long n_live, bool grouped) {
-    const uint32_t forced = env_u32("SNK_PARTITION_PASSES", 0);
+    const uint32_t forced = snk_opt_u32("partition_passes", 0);
     if (forced) return forced > 64 ? 64u : forced;
     double est = 0;
     uint64_t cap = 0, ideal = 0;

@@ -96,6 +96,7 @@ __global__ void __launch_bounds__(256) snk_trim_tile_kernel(const uint8_t* __res
 
 extern "C" int snk_dev_trim(snk_ctx* ctx, const void* d_quals, uint32_t qstride, const void* d_lens, uint32_t read_len,
                             uint64_t n_reads, uint32_t K, uint32_t min_qual, void* d_good_len, void* stream) {
+    if (ctx) snk_opts_enter(&ctx->opts);
     char* err = nullptr;
     size_t errcap = 0;
     if (!ctx || !d_quals || !d_good_len) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_trim: NULL argument");
@@ -104,7 +105,7 @@ extern "C" int snk_dev_trim(snk_ctx* ctx, const void* d_quals, uint32_t qstride,
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     ctx->cur_stream = st;
     uint64_t nb = (n_reads + 255) / 256;
-    const bool tiled = (qstride & 3u) == 0 && qstride <= 160 && (((uintptr_t)d_quals) & 15u) == 0 && !snk_env_u32("SNK_TRIM_ROWWISE", 0);
+    const bool tiled = (qstride & 3u) == 0 && qstride <= 160 && (((uintptr_t)d_quals) & 15u) == 0 && !snk_opt_u32("trim_rowwise", 0);
     if (tiled)
         hipLaunchKernelGGL(snk_trim_tile_kernel, dim3((unsigned)nb), dim3(256), 256 * qstride, st, (const uint8_t*)d_quals, qstride,
                            (const uint16_t*)d_lens, read_len, n_reads, K, min_qual, (uint16_t*)d_good_len);

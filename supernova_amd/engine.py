@@ -205,6 +205,15 @@ class Result:
         return us
 
 
+import weakref as _weakref
+
+_LIVE = _weakref.WeakSet()      # contexts that are open (tests pin options on all of them: tests/conftest.py `tune`)
+
+
+def live_engines():
+    return [e for e in list(_LIVE) if getattr(e, "_ctx", None)]
+
+
 class Engine:
     def __init__(self, device: int | None = None):
         if not torch.cuda.is_available():
@@ -218,6 +227,7 @@ class Engine:
         if rc != 0:
             raise _lib.SnkError(rc, err.value.decode(errors="replace"))
         self._ctx = h
+        _LIVE.add(self)
 
     def last_count_limit(self) -> int:
         """Usable count-table slots per pass in the last count_graph call (1216, or 1920 with booked slots; snk_ctx_last_count_limit)."""
@@ -226,6 +236,54 @@ class Engine:
     def last_partition_passes(self) -> int:
         """Bucket-range passes of the last count_graph call (1 = the one-pass partition; snk_ctx_last_partition_passes)."""
         return int(self.lib.snk_ctx_last_partition_passes(self._ctx))
+
+    # ---- tuning (include/snk.h "tuning"): options live in the context, not in the environment
+    def set_option(self, name: str, value: int):
+        err = C.create_string_buffer(512)
+        rc = self.lib.snk_ctx_set_option(self._ctx, name.encode(), int(value), err, 512)
+        if rc != 0:
+            raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+
+    def clear_option(self, name: str | None = None):
+        """Back to the library's own choice (None: every option)."""
+        self.lib.snk_ctx_clear_option(self._ctx, name.encode() if name is not None else None)
+
+    def get_option(self, name: str):
+        """-> the pinned value, or None when the library chooses."""
+        v = C.c_longlong(0)
+        rc = self.lib.snk_ctx_get_option(self._ctx, name.encode(), C.byref(v))
+        if rc < 0:
+            raise KeyError(name)
+        return int(v.value) if rc == 1 else None
+
+    def options(self) -> dict:
+        """name -> description of every option the library knows."""
+        out, i = {}, 0
+        while True:
+            n = self.lib.snk_option_name(i)
+            if not n:
+                return out
+            out[n.decode()] = self.lib.snk_option_doc(i).decode()
+            i += 1
+
+    def set_tuning(self, **fields):
+        """snk_ctx_set_tuning: the documented knobs as one struct (count_kernel=2, target_inst=4000, ...); unnamed fields = the library's choice."""
+        t = _lib.SnkTuning()
+        self.lib.snk_tuning_default(C.byref(t))
+        for k, v in fields.items():
+            if not hasattr(t, k) or k.startswith("last_") or k == "reserved":
+                raise AttributeError(k)
+            setattr(t, k, int(v))
+        err = C.create_string_buffer(512)
+        rc = self.lib.snk_ctx_set_tuning(self._ctx, C.byref(t), err, 512)
+        if rc != 0:
+            raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+
+    def get_tuning(self) -> dict:
+        """What is pinned (0 = the library chooses) and, in last_*, what the context's last call ran with."""
+        t = _lib.SnkTuning()
+        self.lib.snk_ctx_get_tuning(self._ctx, C.byref(t))
+        return {k: int(getattr(t, k)) for k, _ in _lib.SnkTuning._fields_ if k != "reserved"}
 
     def reserve(self, n_bytes: int):
         """Map n_bytes of device memory into the context's scratch arena now and keep them mapped between calls (snk_ctx_reserve): a call

@@ -100,6 +100,16 @@ class SnkDevIngest(C.Structure):
                 ("decode_wait_seconds", C.c_double), ("n_files", C.c_uint32), ("n_batches", C.c_uint32), ("setup_seconds", C.c_double)]
 
 
+class SnkTuning(C.Structure):
+    _fields_ = [("count_kernel", C.c_uint32), ("count_tight_slots", C.c_uint32), ("count_screen_ratio_pct", C.c_uint32), ("target_inst", C.c_uint32),
+                ("bucket_fill_pct", C.c_uint32), ("adaptive_buckets", C.c_uint32), ("chunk_kmers", C.c_uint32), ("minimiser_len", C.c_uint32),
+                ("partition_passes", C.c_uint32), ("hot_buckets", C.c_uint32), ("hot_min", C.c_uint32), ("hot_factor", C.c_uint32),
+                ("hot_class_inst", C.c_uint32), ("exchange_ranges", C.c_uint32), ("join_ranking", C.c_uint32), ("path_lookup", C.c_uint32),
+                ("unitig_bc_cut", C.c_uint32), ("hbv_dev_min", C.c_uint32), ("hbv_big", C.c_uint32), ("reserved", C.c_uint32 * 9),
+                ("last_count_kernel", C.c_uint32), ("last_count_limit", C.c_uint32), ("last_partition_passes", C.c_uint32),
+                ("last_minimiser_len", C.c_uint32)]
+
+
 class SnkDfInfo(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_barcodes", C.c_uint64), ("fastb_bytes", C.c_uint64), ("qualp_bytes", C.c_uint64),
                 ("bci_bytes", C.c_uint64), ("reserved", C.c_uint64 * 3)]
@@ -173,6 +183,14 @@ def _declare(lib: C.CDLL) -> None:
         "snk_ctx_destroy": (None, [vp]),
         "snk_ctx_trim": (None, [vp]),
         "snk_ctx_reserve": (C.c_int, [vp, u64, cp, sz]),
+        "snk_tuning_default": (None, [P(SnkTuning)]),
+        "snk_ctx_set_tuning": (C.c_int, [vp, P(SnkTuning), cp, sz]),
+        "snk_ctx_get_tuning": (None, [vp, P(SnkTuning)]),
+        "snk_ctx_set_option": (C.c_int, [vp, cp, C.c_longlong, cp, sz]),
+        "snk_ctx_clear_option": (C.c_int, [vp, cp]),
+        "snk_ctx_get_option": (C.c_int, [vp, cp, P(C.c_longlong)]),
+        "snk_option_name": (cp, [u32]),
+        "snk_option_doc": (cp, [u32]),
         "snk_synth_default": (None, [P(SnkSynthParams), u64, u64, C.c_int]),
         "snk_synth_set_errors": (None, [P(SnkSynthParams), u32]),
         "snk_synth_host": (C.c_int, [P(SnkSynthParams), u64, u64, vp, u32, vp, u32, vp]),

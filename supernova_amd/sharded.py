@@ -176,8 +176,8 @@ class TorchComm:
 
 
 # ------------------------------------------------------------------------------------------------ planning helpers
-def plan_buckets(total_inst_upper: int, world: int, K: int) -> int:
-    target = int(os.environ.get("SNK_TARGET_INST", "5000" if K == 48 else "3500"))
+def plan_buckets(total_inst_upper: int, world: int, K: int, target_inst: int = 0) -> int:
+    target = int(target_inst) or (5000 if K == 48 else 3500)
     nb = max(1, -(-total_inst_upper // target))
     nb = min(nb, 1 << 26)
     return -(-nb // world) * world

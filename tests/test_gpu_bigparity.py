@@ -40,7 +40,7 @@ ROBUST_200K = ["robust_err06_200k", "robust_err15_200k", "robust_cov28_200k", "r
 
 @pytest.mark.parametrize("name,variant", [(n, "default") for n in ["c1_2m", "c1_10m", "c1_2m_k60", "c1_10m_k60", *ROBUST_200K, "robust_repeats_1m", "robust_repeats_200k_k60"]]
                          + [(n, v) for n in ROBUST_200K + ["c1_2m"] for v in ("screen", "tight")])
-def test_one_gpu_vs_reference_digest(snk, name, variant, monkeypatch):
+def test_one_gpu_vs_reference_digest(snk, name, variant, monkeypatch, tune):
     import torch
     from supernova_amd import synth
     from supernova_amd.engine import Engine, Params
@@ -48,14 +48,14 @@ def test_one_gpu_vs_reference_digest(snk, name, variant, monkeypatch):
     K = exp["K"]
     env, limit = VARIANTS[variant]
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        tune(k, v)
     e = Engine(0)
     try:
         if name == "robust_repeats_1m":
             # at this size the repeat families are 100 copies deep: with the threshold down, their minimiser buckets take the hot path
             # (snk_hot.hip) the 100 M-read runs of bench.py config.robust take on their own
-            monkeypatch.setenv("SNK_HOT_MIN", "1000")
-            monkeypatch.setenv("SNK_HOT_FACTOR", "1")
+            tune("SNK_HOT_MIN", "1000")
+            tune("SNK_HOT_FACTOR", "1")
         sp = synth.synth_params(exp["n_reads"], seed=exp["seed"], **exp.get("overrides", {}))
         rows, quals, bc = e.synth(sp)
         # the reference's K=60 variant has no barcode rule: run without a barcode vector there

@@ -229,3 +229,45 @@ def test_reference_written_triple_1m(snk, tmp_path):
     hr, hq, hl, hb, mx = _host_arrays(head, n, 160)
     assert np.array_equal(hr, rows) and np.array_equal(hl, lens) and np.array_equal(hq[:, :150], q) and np.array_equal(hb, bc)
     e.close()
+
+
+def test_tuning_struct_and_options(snk, monkeypatch):
+    """snk_ctx_set_tuning / snk_ctx_get_tuning / snk_ctx_set_option (include/snk.h): the count kernel pinned through the struct is the one
+    that runs and is echoed back; unknown names and out-of-range fields are refused; SNK_TUNING is applied when a context is created."""
+    from supernova_amd.engine import Engine, Params
+    from supernova_amd.lib import SnkError
+    c = goldens.load("synth_2k_err")
+    import torch
+    dev = torch.device("cuda", 0)
+    rows = torch.from_numpy(c.rows.view(np.int32)).to(dev); quals = torch.from_numpy(np.ascontiguousarray(c.quals)).to(dev)
+    bc = torch.from_numpy(c.bc.astype(np.int32)).to(dev); lens = torch.from_numpy(c.lens.astype(np.uint16).view(np.int16)).to(dev)
+    e = Engine(0)
+    run = lambda: e.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, params=Params(K=48), ign_bc_below=c.ign_bc_below)
+    want = run().unitigs()
+    assert e.get_tuning()["last_count_kernel"] == 1 and e.get_tuning()["last_count_limit"] == 1216 and e.get_tuning()["count_kernel"] == 0
+    for kernel, slots, limit in ((2, 0, 1920), (2, 1000, 1000), (3, 0, 960), (1, 0, 1216)):
+        e.set_tuning(count_kernel=kernel, count_tight_slots=slots, target_inst=900)
+        assert run().unitigs() == want
+        t = e.get_tuning()
+        assert (t["count_kernel"], t["last_count_kernel"], t["last_count_limit"], t["target_inst"]) == (kernel, kernel, limit, 900), t
+    e.set_tuning()                                  # everything back to the library's choice
+    assert e.get_option("count_tight") is None and e.get_option("target_inst") is None and e.get_tuning()["count_kernel"] == 0
+    e.set_option("minimiser_len", 20)
+    assert run().unitigs() == want and e.get_tuning()["last_minimiser_len"] == 20 and e.get_option("minimiser_len") == 20
+    e.clear_option("minimiser_len")
+    assert run().unitigs() == want and e.get_tuning()["last_minimiser_len"] == 16
+    with pytest.raises(SnkError, match="no option"):
+        e.set_option("no_such_knob", 1)
+    with pytest.raises(SnkError):
+        e.set_tuning(count_kernel=9)
+    with pytest.raises(KeyError):
+        e.get_option("no_such_knob")
+    assert "count_tight" in e.options() and len(e.options()) >= 40
+    e.close()
+    monkeypatch.setenv("SNK_TUNING", "count_tight=1500,hot_min=77")
+    e = Engine(0)
+    assert e.get_option("count_tight") == 1500 and e.get_option("hot_min") == 77 and e.get_tuning()["count_tight_slots"] == 1500
+    e.close()
+    monkeypatch.setenv("SNK_TUNING", "count_tight=1500,bogus=1")
+    with pytest.raises(SnkError, match="SNK_TUNING"):
+        Engine(0)

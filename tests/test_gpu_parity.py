@@ -13,9 +13,9 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(params=["local", "global"], autouse=True)
-def graph_stage(request, monkeypatch):
+def graph_stage(request, monkeypatch, tune):
     """Every parity test runs twice: bucket-local graph stage (default) and the global one (cross-check)."""
-    monkeypatch.setenv("SNK_GLOBAL_GRAPH", "1" if request.param == "global" else "0")
+    tune("SNK_GLOBAL_GRAPH", "1" if request.param == "global" else "0")
     return request.param
 
 
@@ -74,13 +74,13 @@ COUNT_VARIANTS = {"screen": ({"SNK_COUNT_SCREEN_NG": "2"}, 960),      # bit filt
 
 @pytest.mark.parametrize("variant", sorted(COUNT_VARIANTS))
 @pytest.mark.parametrize("name", goldens.CASES)
-def test_golden_case_count_variants(engine, monkeypatch, name, variant):
+def test_golden_case_count_variants(engine, monkeypatch, name, variant, tune):
     """test_golden_case with the ungrouped SCREEN / TIGHT count kernels forced (the kernels error-rich production data
     take were compared in-suite with the default kernel only): the reference's goldens, and the call reports which kernel ran."""
     from supernova_amd.engine import Params
     env, limit = COUNT_VARIANTS[variant]
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        tune(k, v)
     c = goldens.load(name)
     rows, quals, bc, lens = _to_dev(c)
     res = engine.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, params=Params(K=48), ign_bc_below=c.ign_bc_below)
@@ -90,12 +90,12 @@ def test_golden_case_count_variants(engine, monkeypatch, name, variant):
 
 @pytest.mark.parametrize("variant", sorted(COUNT_VARIANTS))
 @pytest.mark.parametrize("n_reads,error_free", [(200_000, False), (100_000, True)])
-def test_synth_vs_oracle_count_variants(engine, monkeypatch, n_reads, error_free, variant):
+def test_synth_vs_oracle_count_variants(engine, monkeypatch, n_reads, error_free, variant, tune):
     from supernova_amd import synth
     from supernova_amd.engine import Params
     env, limit = COUNT_VARIANTS[variant]
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        tune(k, v)
     sp = synth.synth_params(n_reads, seed=0x5EED0100 + n_reads % 97, error_free=error_free)
     rows_h, quals_h, bc_h = synth.synth_host(sp, qstride=160)
     rows_d, quals_d, bc_d = engine.synth(sp, qstride=160)
@@ -123,7 +123,7 @@ def test_bucket_count_independence(engine, n_buckets):
 
 @pytest.mark.parametrize("case,K,n_buckets,slots", [("adversarial", 48, 1, 1920), ("adversarial", 48, 7, 300), ("synth_20k_err", 48, 3, 1920),
                                                     ("synth_20k_err", 48, 16, 700), ("synth_20k_err", 60, 2, 1920), ("synth_20k_err", 48, 0, 1984)])
-def test_booked_table_slots_count_the_same_table(engine, monkeypatch, case, K, n_buckets, slots):
+def test_booked_table_slots_count_the_same_table(engine, monkeypatch, case, K, n_buckets, slots, tune):
     """The count kernel's second variant (snk_count.hip, TIGHT: waves book their slots, the table fills to `slots` of 2048 instead of
     1216, a pass that retains more than one graph chunk's worth is counted again in halves) gives the table and the unitigs of the
     default one -- with buckets that overflow and split (few buckets), with a small limit (bookings fail all the time), at K=60."""
@@ -131,7 +131,7 @@ def test_booked_table_slots_count_the_same_table(engine, monkeypatch, case, K, n
     g = goldens.Case60(case) if K == 60 else goldens.load(case)
     c = g.base if K == 60 else g
     rows, quals, bc, lens = _to_dev(c)
-    monkeypatch.setenv("SNK_COUNT_TIGHT", str(slots))
+    tune("SNK_COUNT_TIGHT", str(slots))
     res = engine.count_graph(rows, c.read_len, quals=quals, bc=bc if K == 48 else None, lens=lens, params=Params(K=K, n_buckets=n_buckets),
                              ign_bc_below=c.ign_bc_below)
     assert engine.last_count_limit() == slots
@@ -142,7 +142,7 @@ def test_booked_table_slots_count_the_same_table(engine, monkeypatch, case, K, n
     else:
         assert np.array_equal(res.keys(), g.exp_keys) and np.array_equal(np.minimum(res.counts(), (1 << 24) - 1), g.exp_counts)
         assert np.array_equal(res.ctx(), g.exp_ctx) and res.unitigs() == g.exp_unitigs
-    monkeypatch.setenv("SNK_COUNT_TIGHT", "0")
+    tune("SNK_COUNT_TIGHT", "0")
     engine.count_graph(rows, c.read_len, quals=quals, bc=bc if K == 48 else None, lens=lens, params=Params(K=K, n_buckets=n_buckets), ign_bc_below=c.ign_bc_below)
     assert engine.last_count_limit() == 1216
 
@@ -232,7 +232,7 @@ def test_pack_ascii_and_trim_kernels(engine):
 
 
 @pytest.mark.parametrize("K", [48, 60])
-def test_trim_inside_the_partition_kernel(engine, K, monkeypatch):
+def test_trim_inside_the_partition_kernel(engine, K, monkeypatch, tune):
     """Quality rows padded to 4 bytes are trimmed by the partition kernel itself (snk_msp.hip, fused trim): the good lengths
     and the instance count it reports must be the trim kernel's / the oracle's (GoodLenTailFinder, BuildReadQGraph48.cc:65-89)
     on clean reads (decided by their last K quals), on reads with low-quality tails and on rows of noise (the bit-mask scan),
@@ -265,7 +265,7 @@ def test_trim_inside_the_partition_kernel(engine, K, monkeypatch):
         params = Params(K=K, min_freq=2, min_qual=mq)
         got = {}
         for fused in ("1", "0"):
-            monkeypatch.setenv("SNK_TRIM_FUSED", fused)
+            tune("SNK_TRIM_FUSED", fused)
             res = engine.count_graph(rows, L, quals=qd, lens=ld, params=params)
             gl = res.good_len().astype(np.uint32)
             assert np.array_equal(gl, want), (mq, fused, np.flatnonzero(gl != want)[:8])
@@ -278,7 +278,7 @@ def test_trim_inside_the_partition_kernel(engine, K, monkeypatch):
         assert np.array_equal(g2.astype(np.uint32), want)
 
 
-def test_error_rich_reads_are_repartitioned_into_smaller_buckets(engine, monkeypatch):
+def test_error_rich_reads_are_repartitioned_into_smaller_buckets(engine, monkeypatch, tune):
     """Bucket size follows the data: when the first buckets hold more distinct k-mers than the count kernel's LDS table takes
     (1.5 % errors here), the one-GPU path partitions a second time into smaller buckets instead of hash-splitting nearly every
     bucket, and later calls on the context start there.  The result does not depend on the bucket count: the same table and the
@@ -303,14 +303,14 @@ def test_error_rich_reads_are_repartitioned_into_smaller_buckets(engine, monkeyp
             o = np.lexsort(tuple(k[:, j] for j in range(k.shape[1] - 1, -1, -1)))
             return k[o], c[o], x[o], sorted(r.unitigs())
 
-        monkeypatch.setenv("SNK_ADAPTIVE_BUCKETS", "0")
+        tune("SNK_ADAPTIVE_BUCKETS", "0")
         r0 = e.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48, sorted_table=False))
         assert r0.repartitioned == 0 and r0.buckets_split > r0.n_buckets // 2
         assert e.last_count_limit() == 1216          # (nothing known about the data: the default kernel)
         ref = table(r0)
         nb0 = r0.n_buckets
-        monkeypatch.setenv("SNK_ADAPTIVE_BUCKETS", "1")
-        monkeypatch.setenv("SNK_SCREEN_RATIO_PCT", "20")        # the filter's threshold: pinned, so that WHICH kernel runs is asserted, not either
+        tune("SNK_ADAPTIVE_BUCKETS", "1")
+        tune("SNK_SCREEN_RATIO_PCT", "20")        # the filter's threshold: pinned, so that WHICH kernel runs is asserted, not either
         e2 = Engine(0)
         try:
             r1 = e2.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48, sorted_table=False))
@@ -324,7 +324,7 @@ def test_error_rich_reads_are_repartitioned_into_smaller_buckets(engine, monkeyp
             assert r2.repartitioned == 0 and r2.n_buckets > 1.1 * nb0 and e2.last_count_limit() == 960
             got2 = table(r2)
             assert all(np.array_equal(a, b) for a, b in zip(ref[:3], got2[:3])) and ref[3] == got2[3]
-            monkeypatch.setenv("SNK_COUNT_SCREEN_NG", "0")
+            tune("SNK_COUNT_SCREEN_NG", "0")
             r3 = e2.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48, sorted_table=False))
             assert e2.last_count_limit() == 1920 and r3.n_buckets > 1.5 * nb0
             got3 = table(r3)
@@ -591,7 +591,7 @@ def test_full_size_properties_1e8(engine, graph_stage):
     assert torch.equal(a["off"], b["off"]) and torch.equal(a["bases"], b["bases"])
 
 
-def test_full_size_booked_slots_1e8(engine, graph_stage, monkeypatch):
+def test_full_size_booked_slots_1e8(engine, graph_stage, monkeypatch, tune):
     """100 M reads with 1.5 % substitutions and long low-quality tails (config.robust's second model) at full size: the call that lets the
     data switch the count kernel to the bit filter + booked slots (snk_ctx_last_count_limit = 960; 2.6 x the distinct k-mers of clean reads),
     the one with booked slots alone (1920) and the default kernel on smaller buckets (1216) give the same table -- checksum over keys, counts
@@ -622,10 +622,10 @@ def test_full_size_booked_slots_1e8(engine, graph_stage, monkeypatch):
         run()                       # (the first call looks at the first buckets and partitions again)
         a = run()                   # 0.4 distinct k-mers per instance: the bit filter in front of a 1024-slot table
         assert a["lim"] == 960 and a["nk"] > 200_000_000
-        monkeypatch.setenv("SNK_COUNT_SCREEN_NG", "0")
+        tune("SNK_COUNT_SCREEN_NG", "0")
         c = run()                   # booked slots alone
         assert c["lim"] == 1920 and c["nb"] > a["nb"]
-        monkeypatch.setenv("SNK_COUNT_TIGHT", "0")
+        tune("SNK_COUNT_TIGHT", "0")
         b = run()                   # the default kernel on still smaller buckets
         assert b["lim"] == 1216 and b["nb"] > c["nb"]
         for o in (b, c):
@@ -671,10 +671,10 @@ def test_unitig_order_is_deterministic(engine, graph_stage):
 
 
 @pytest.mark.parametrize("pct", [100, 60, 10])
-def test_partition_overflow_segment(engine, monkeypatch, pct):
+def test_partition_overflow_segment(engine, monkeypatch, pct, tune):
     """The single-pass minimiser partition gives every bucket a fixed number of record slots; supermers beyond it go
     through the overflow list (second count segment).  Shrinking the capacity must not change any result."""
-    monkeypatch.setenv("SNK_MSP_CAP_PCT", str(pct))
+    tune("SNK_MSP_CAP_PCT", str(pct))
     c = goldens.load("synth_20k_err")
     rows, quals, bc, lens = _to_dev(c)
     res = engine.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, ign_bc_below=c.ign_bc_below)
@@ -685,35 +685,35 @@ def test_partition_overflow_segment(engine, monkeypatch, pct):
 
 @pytest.mark.parametrize("name", ["adversarial", "synth_20k_err"])
 @pytest.mark.parametrize("hot_buckets", [False, True])
-def test_partition_stops_reserving_slots_for_hot_buckets(engine, monkeypatch, name, hot_buckets):
+def test_partition_stops_reserving_slots_for_hot_buckets(engine, monkeypatch, name, hot_buckets, tune):
     """snk_msp.hip: a bucket that was handed a slot far beyond its capacity is noted in a small table; workgroups that start later send its
     supermers to the overflow list without touching its cursor (same-address atomics queue: a homopolymer's bucket held the partition
     for 60 ms).  Forced on the goldens: tiny capacity, noted at the first overflowing slot -- same results, with and without the
     k-mer-hash re-partition of the buckets that end up hot."""
-    monkeypatch.setenv("SNK_MSP_CAP_PCT", "10")
-    monkeypatch.setenv("SNK_MSP_HOT_FACTOR", "1")
-    monkeypatch.setenv("SNK_MSP_HOT_MIN", "1")
+    tune("SNK_MSP_CAP_PCT", "10")
+    tune("SNK_MSP_HOT_FACTOR", "1")
+    tune("SNK_MSP_HOT_MIN", "1")
     if hot_buckets:
-        monkeypatch.setenv("SNK_HOT_MIN", "8")
-        monkeypatch.setenv("SNK_HOT_FACTOR", "1")
-        monkeypatch.setenv("SNK_HOT_CLASS_INST", "300")
+        tune("SNK_HOT_MIN", "8")
+        tune("SNK_HOT_FACTOR", "1")
+        tune("SNK_HOT_CLASS_INST", "300")
     c = goldens.load(name)
     rows, quals, bc, lens = _to_dev(c)
     res = engine.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, ign_bc_below=c.ign_bc_below)
     _check_against(res, c.exp_keys, c.exp_counts, c.exp_ctx, c.exp_unitigs, c.exp_goodlens, c.exp_hist)
     assert res.n_overflow > 0
     assert res.n_supermers == engine.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, ign_bc_below=c.ign_bc_below).n_supermers
-    monkeypatch.setenv("SNK_MSP_HOT_FACTOR", "0")          # never noted: every supermer takes its reservation
+    tune("SNK_MSP_HOT_FACTOR", "0")          # never noted: every supermer takes its reservation
     assert res.n_supermers == engine.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, ign_bc_below=c.ign_bc_below).n_supermers
 
 
 @pytest.mark.parametrize("name,K", [("adversarial", 48), ("synth_20k_err", 48), ("adversarial", 60)])
-def test_dense_partition_mode(engine, monkeypatch, name, K):
+def test_dense_partition_mode(engine, monkeypatch, name, K, tune):
     """SNK_MSP_DENSE=1 (round 4's measured alternative to the slot reservations, DESIGN 4 "round 4"): records leave the scan kernel in
     read order without any per-bucket atomic, (bucket, position) pairs are radix-sorted, the count kernel gathers a bucket's records
     through the sorted positions.  Same results bit for bit; there is no overflow segment in this mode."""
     from supernova_amd.engine import Params
-    monkeypatch.setenv("SNK_MSP_DENSE", "1")
+    tune("SNK_MSP_DENSE", "1")
     if K == 48:
         c = goldens.load(name)
         rows, quals, bc, lens = _to_dev(c)
@@ -731,18 +731,18 @@ def test_dense_partition_mode(engine, monkeypatch, name, K):
 
 @pytest.mark.parametrize("passes", [1, 3])
 @pytest.mark.parametrize("name,K", [("adversarial", 48), ("synth_20k_err", 48), ("adversarial", 60), ("synth_20k_err", 60)])
-def test_hot_buckets_are_repartitioned_by_kmer_hash(engine, monkeypatch, name, K, passes):
+def test_hot_buckets_are_repartitioned_by_kmer_hash(engine, monkeypatch, name, K, passes, tune):
     """snk_hot.hip: a minimiser bucket far above its capacity (a repeat family, a homopolymer run) is expanded into single-k-mer records
     that go to virtual buckets (bucket, hash class), counted by other workgroups in a second launch of the count kernel.  Forced here
     on the goldens by a tiny capacity and a tiny threshold (every overflowing bucket is 'hot', classes of ~300 instances so that they
     split further); same results bit for bit."""
     from supernova_amd.engine import Params
-    monkeypatch.setenv("SNK_MSP_CAP_PCT", "10")
-    monkeypatch.setenv("SNK_HOT_MIN", "8")
-    monkeypatch.setenv("SNK_HOT_FACTOR", "1")
-    monkeypatch.setenv("SNK_HOT_CLASS_INST", "300")
+    tune("SNK_MSP_CAP_PCT", "10")
+    tune("SNK_HOT_MIN", "8")
+    tune("SNK_HOT_FACTOR", "1")
+    tune("SNK_HOT_CLASS_INST", "300")
     if passes > 1:          # bucket-range passes: the hot buckets of a range are expanded while that range's records are in the slot array
-        monkeypatch.setenv("SNK_PARTITION_PASSES", str(passes))
+        tune("SNK_PARTITION_PASSES", str(passes))
     if K == 48:
         c = goldens.load(name)
         rows, quals, bc, lens = _to_dev(c)
@@ -759,11 +759,11 @@ def test_hot_buckets_are_repartitioned_by_kmer_hash(engine, monkeypatch, name, K
 
 
 @pytest.mark.parametrize("persist,n_buckets", [(0, 0), (1, 0), (32, 3), (32, 5000), (1000, 5000)])
-def test_count_launch_shapes(engine, monkeypatch, persist, n_buckets):
+def test_count_launch_shapes(engine, monkeypatch, persist, n_buckets, tune):
     """The count kernel's workgroups walk strided bucket lists (SNK_COUNT_PERSIST residency waves; 0 = one bucket per
     workgroup): fewer buckets than workgroups, one wave, many waves, more waves than buckets -- same results, including
     the split path (3 buckets for 20 k reads overflow the LDS table)."""
-    monkeypatch.setenv("SNK_COUNT_PERSIST", str(persist))
+    tune("SNK_COUNT_PERSIST", str(persist))
     from supernova_amd.engine import Params
     c = goldens.load("synth_20k_err")
     rows, quals, bc, lens = _to_dev(c)
@@ -775,7 +775,7 @@ def test_count_launch_shapes(engine, monkeypatch, persist, n_buckets):
 
 
 @pytest.mark.parametrize("min_freq,n_buckets,screen", [(2, 0, "2"), (2, 0, "1"), (3, 0, "1"), (1, 0, "1"), (5, 0, "1"), (3, 40, "1"), (3, 3000, "1"), (3, 0, "0")])
-def test_grouped_per_barcode_graphs(engine, graph_stage, monkeypatch, min_freq, n_buckets, screen):
+def test_grouped_per_barcode_graphs(engine, graph_stage, monkeypatch, min_freq, n_buckets, screen, tune):
     """BASELINE config 5: per-group (per-barcode) local graphs.  One grouped run == the oracle applied to every group's
     reads on its own (frequency rule only): tables, pruned contexts and unitigs per group.  The count kernel's bit filter in front of the
     table (snk_count.hip SCREEN: levels 2 and 3; off at min_freq 1; buckets too large for it -- 40 buckets here -- are counted without it)
@@ -793,7 +793,7 @@ def test_grouped_per_barcode_graphs(engine, graph_stage, monkeypatch, min_freq, 
     group[rng.random(n) < 0.1] = NG + 3                     # a sparse extra group with a large id gap
     rows, quals, bc, lens = _to_dev(c)
     g_dev = torch.from_numpy(group).to(rows.device)
-    monkeypatch.setenv("SNK_COUNT_SCREEN", screen)
+    tune("SNK_COUNT_SCREEN", screen)
     res = engine.count_graph(rows, c.read_len, quals=quals, bc=None, lens=lens, group=g_dev,
                              params=Params(K=48, min_freq=min_freq, min_bc=0, grouped=True, sorted_table=False, n_buckets=n_buckets))
     k, cnt, ctx = res.keys(), res.counts(), res.ctx()
@@ -959,14 +959,14 @@ def test_streamed_slabs_equal_the_resident_call(engine, graph_stage, name, cuts)
 
 @pytest.mark.parametrize("passes", [2, 3, 7])
 @pytest.mark.parametrize("name,K", [("adversarial", 48), ("synth_20k_err", 48), ("synth_2k_err", 48)] + [(n, 60) for n in goldens.K60_CASES[:1]])
-def test_bucket_range_passes_equal_the_one_pass_partition(engine, graph_stage, name, K, passes, monkeypatch):
+def test_bucket_range_passes_equal_the_one_pass_partition(engine, graph_stage, name, K, passes, monkeypatch, tune):
     """A job whose supermer slots would not fit the device is partitioned and counted in bucket-range passes over ONE slot array, the
     reads scanned once per pass (snk_partition_passes; the reference re-scans in passes when its records do not fit,
     MapReduceEngine.h:452-468, utils.rs:329-341).  Forced here at golden size: the result is the golden bit for bit, with the quality
     trim inside the first pass (rows padded to four bytes) and with the separate trim kernel."""
     import torch
     from supernova_amd.engine import Params
-    monkeypatch.setenv("SNK_PARTITION_PASSES", str(passes))
+    tune("SNK_PARTITION_PASSES", str(passes))
     g = goldens.Case60(name) if K == 60 else None
     c = g.base if g else goldens.load(name)
     rows, quals, bc, lens = _to_dev(c)
@@ -1004,9 +1004,9 @@ def test_open_streamed_job_dies_with_its_arena(engine):
         engine.stream_finish()
 
 
-def test_circle_pool_retry(engine, monkeypatch):
+def test_circle_pool_retry(engine, monkeypatch, tune):
     """Circles inside one chunk take their fragment slots from a small pool; an empty pool must trigger the exact re-run."""
-    monkeypatch.setenv("SNK_BL_POOL", "0")
+    tune("SNK_BL_POOL", "0")
     c = goldens.load("adversarial")
     rows, quals, bc, lens = _to_dev(c)
     res = engine.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, ign_bc_below=c.ign_bc_below)
@@ -1021,7 +1021,7 @@ HBV_FLOODS = {"host": {"SNK_HBV_DEV_MIN": "1000000000"},            # the sequen
 
 @pytest.mark.parametrize("flood", list(HBV_FLOODS))
 @pytest.mark.parametrize("name,K", [(n, 48) for n in goldens.CASES] + [(n, 60) for n in goldens.K60_CASES])
-def test_device_hbv_matches_reference(engine, graph_stage, name, K, flood, monkeypatch):
+def test_device_hbv_matches_reference(engine, graph_stage, name, K, flood, monkeypatch, tune):
     """a14 on the device (snk_dev_hbv): BVComp ranking, (K-1)-mer end keys, vertex classes, connected components and the id
     flood per component in HBM (or, `host`, the flood on the host) -- the text dump equals the reference's buildHBVFromEdges
     output (golden), and the host-array entry point."""
@@ -1030,7 +1030,7 @@ def test_device_hbv_matches_reference(engine, graph_stage, name, K, flood, monke
     if graph_stage == "global" and flood != "device":
         pytest.skip("the flood does not depend on the graph stage")
     for k, v in HBV_FLOODS[flood].items():
-        monkeypatch.setenv(k, v)
+        tune(k, v)
     c = goldens.load(name)
     rows, quals, bc, lens = _to_dev(c)
     exp = c if K == 48 else goldens.Case60(name)
@@ -1052,13 +1052,13 @@ def test_device_hbv_matches_reference(engine, graph_stage, name, K, flood, monke
 
 
 @pytest.mark.parametrize("flood", ["host", "device", "device_big4"])
-def test_device_hbv_many_unitigs(engine, flood, monkeypatch):
+def test_device_hbv_many_unitigs(engine, flood, monkeypatch, tune):
     """Error-rich reads at low coverage: hundreds of thousands of short unitigs, equal lengths everywhere (the BVComp
     tie-break) -- device result == host-array entry point on the BVComp-sorted unitigs."""
     from supernova_amd import graphio, synth
     from supernova_amd.engine import Params
     for k, v in HBV_FLOODS[flood].items():
-        monkeypatch.setenv(k, v)
+        tune(k, v)
     sp = synth.synth_params(400_000, seed=0x5EED0042)
     rows, quals, bc = engine.synth(sp)
     res = engine.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48, min_freq=1, min_bc=0))
@@ -1081,16 +1081,16 @@ def test_device_hbv_many_unitigs(engine, flood, monkeypatch):
 
 @pytest.mark.parametrize("lookup", ["index", "kmer_dictionary"])
 @pytest.mark.parametrize("name", goldens.CASES)
-def test_read_paths_match_reference(engine, graph_stage, name, lookup, monkeypatch):
+def test_read_paths_match_reference(engine, graph_stage, name, lookup, monkeypatch, tune):
     """f1: read pathing on the device (look-ups through the minimiser index over the unitigs -- or, SNK_PATH_INDEX=0, the k-mer
     dictionary of rounds 1-3 --, wave-per-read seed and extend, algorithmTwo, quality-aware extension) against the paths the
     reference binary dumped: offset and HBV edge ids of every read, bit for bit."""
     if graph_stage == "global":
         pytest.skip("pathing reads the unitigs; one graph stage is enough")
     if lookup == "index":       # the k-mer dictionary "does not fit": the call falls back to the index by itself
-        monkeypatch.setenv("SNK_PATH_DICT_MAX_KB", "1")
+        tune("SNK_PATH_DICT_MAX_KB", "1")
     else:
-        monkeypatch.setenv("SNK_PATH_INDEX", "0")
+        tune("SNK_PATH_INDEX", "0")
     c = goldens.load(name)
     rows, quals, bc, lens = _to_dev(c)
     res = engine.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, ign_bc_below=c.ign_bc_below)
@@ -1122,27 +1122,27 @@ def test_mark_dups_match_reference(engine, graph_stage, name):
     assert float(f"{100.0 * d['n_art_pairs'] / len(o_dup):.2g}") == float(f"{c.exp_art_perc:.2g}")
 
 
-def test_read_paths_full_capacity_pass(engine, monkeypatch):
+def test_read_paths_full_capacity_pass(engine, monkeypatch, tune):
     """The pather keeps room for 20 parts / 16 edges per read in LDS and hands reads that need more to a full-capacity second
     pass; SNK_PATH_REDO_ALL sends EVERY read through it: same paths, same duplicate flags, same barcode lists."""
     c = goldens.load("adversarial")
     rows, quals, bc, lens = _to_dev(c)
     res = engine.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, ign_bc_below=c.ign_bc_below)
     off0, ne0, edges0, info0 = res.path_reads(rows, c.read_len, quals, lens=lens, mark_dups=True, bc=bc, unitig_bcs=True)
-    monkeypatch.setenv("SNK_PATH_REDO_ALL", "1")
+    tune("SNK_PATH_REDO_ALL", "1")
     off, ne, edges, info = res.path_reads(rows, c.read_len, quals, lens=lens, mark_dups=True, bc=bc, unitig_bcs=True)
     assert np.array_equal(ne.astype(np.int64), c.exp_path_n) and np.array_equal(edges, c.exp_path_edges) and np.array_equal(off, c.exp_path_off)
     assert np.array_equal(info["dups"]["dup"], c.exp_dup)
     assert np.array_equal(info["unitig_bcs"][0], info0["unitig_bcs"][0]) and np.array_equal(info["unitig_bcs"][1], info0["unitig_bcs"][1])
     # and the group kernel doing the sequential tail itself (SNK_PATH_FUSED) instead of the one-thread-per-read finishing kernel
     monkeypatch.delenv("SNK_PATH_REDO_ALL")
-    monkeypatch.setenv("SNK_PATH_FUSED", "1")
+    tune("SNK_PATH_FUSED", "1")
     off, ne, edges, info = res.path_reads(rows, c.read_len, quals, lens=lens, mark_dups=True, bc=bc, unitig_bcs=True)
     assert np.array_equal(ne.astype(np.int64), c.exp_path_n) and np.array_equal(edges, c.exp_path_edges) and np.array_equal(off, c.exp_path_off)
     assert np.array_equal(info["dups"]["dup"], c.exp_dup)
 
 
-def test_unitig_barcode_lists_two_derivations_200k_parity_unpinned_rust(engine, monkeypatch):
+def test_unitig_barcode_lists_two_derivations_200k_parity_unpinned_rust(engine, monkeypatch, tune):
     """f4, parity unpinned (the reference side is Rust): the per-unitig barcode lists out of the pather's parts against a second,
     independent derivation ON THE DEVICE -- every k-mer of every barcoded read looked up in the f1 dictionary, which is literally
     barcodes_for_sedge (debruijn.rs:115-131) + the union of cmd_main_asm.rs:91-151 -- on 200 k synthetic reads; and the 20 000-entry
@@ -1156,7 +1156,7 @@ def test_unitig_barcode_lists_two_derivations_200k_parity_unpinned_rust(engine, 
     _, _, _, slow = res.path_reads(rows, sp.read_len, quals, bc=bc, unitig_bcs="exhaustive")
     assert len(fast["unitig_bcs"][1]) > 1000
     assert np.array_equal(fast["unitig_bcs"][0], slow["unitig_bcs"][0]) and np.array_equal(fast["unitig_bcs"][1], slow["unitig_bcs"][1])
-    monkeypatch.setenv("SNK_UNITIG_BC_CUT", "3")
+    tune("SNK_UNITIG_BC_CUT", "3")
     _, _, _, cut = res.path_reads(rows, sp.read_len, quals, bc=bc, unitig_bcs=True)
     _, _, _, nocut = res.path_reads(rows, sp.read_len, quals, bc=bc, unitig_bcs=True, bcs_nocut=True)
     assert np.array_equal(nocut["unitig_bcs"][0], fast["unitig_bcs"][0]) and np.array_equal(nocut["unitig_bcs"][1], fast["unitig_bcs"][1])
@@ -1168,7 +1168,7 @@ def test_unitig_barcode_lists_two_derivations_200k_parity_unpinned_rust(engine, 
         assert np.array_equal(cb[int(coff[u]):int(coff[u + 1])], want)
 
 
-def test_read_paths_index_equals_kmer_dictionary_200k_k60(engine, monkeypatch):
+def test_read_paths_index_equals_kmer_dictionary_200k_k60(engine, monkeypatch, tune):
     """The two look-up structures of the pather -- minimiser index (places a unitig k-mer's window picks, verified against the packed
     unitigs) and k-mer dictionary (a slot per unitig k-mer) -- give the same paths, duplicate flags and barcode lists on 200 k reads with
     0.6 % errors at K=48 and on the K=60 golden graph."""
@@ -1179,7 +1179,7 @@ def test_read_paths_index_equals_kmer_dictionary_200k_k60(engine, monkeypatch):
     res = engine.count_graph(rows, sp.read_len, quals=quals, bc=bc)
     out = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("SNK_PATH_INDEX", mode)
+        tune("SNK_PATH_INDEX", mode)
         off, ne, edges, info = res.path_reads(rows, sp.read_len, quals, bc=bc, mark_dups=True, unitig_bcs=True)
         out[mode] = (off, ne, edges, info["dups"]["dup"], info["unitig_bcs"][0], info["unitig_bcs"][1])
     assert int((out["1"][1] > 0).sum()) > 150_000
@@ -1190,7 +1190,7 @@ def test_read_paths_index_equals_kmer_dictionary_200k_k60(engine, monkeypatch):
     res = engine.count_graph(rows, c.read_len, quals=quals, bc=None, lens=lens, params=Params(K=60))
     out = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("SNK_PATH_INDEX", mode)
+        tune("SNK_PATH_INDEX", mode)
         off, ne, edges, info = res.path_reads(rows, c.read_len, quals, lens=lens)
         out[mode] = (off, ne, edges)
     assert int((out["1"][1] > 0).sum()) > 0
@@ -1199,12 +1199,12 @@ def test_read_paths_index_equals_kmer_dictionary_200k_k60(engine, monkeypatch):
 
 
 @pytest.mark.parametrize("mask", ["0xFF", "0x3"])
-def test_read_paths_with_colliding_fingerprints(engine, monkeypatch, mask):
+def test_read_paths_with_colliding_fingerprints(engine, monkeypatch, mask, tune):
     """The dictionary keeps a 64-bit fingerprint per k-mer (16-byte slots) and the pather checks a match against the unitig's
     bases.  SNK_PATH_FP_MASK narrows the fingerprint to 8 / 2 bits: nearly every probe chain now holds false matches, the reads fall
     back to the verified look-up -- and the paths are still the reference's, bit for bit."""
-    monkeypatch.setenv("SNK_PATH_FP_MASK", mask)
-    monkeypatch.setenv("SNK_PATH_INDEX", "0")          # (the minimiser index compares bases on every look-up: it has no fingerprints)
+    tune("SNK_PATH_FP_MASK", mask)
+    tune("SNK_PATH_INDEX", "0")          # (the minimiser index compares bases on every look-up: it has no fingerprints)
     for name in ("adversarial", "synth_20k_err"):
         c = goldens.load(name)
         rows, quals, bc, lens = _to_dev(c)

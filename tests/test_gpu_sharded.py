@@ -103,9 +103,9 @@ def test_sharded_long_minimisers(snk, W, name):
 
 
 @pytest.mark.parametrize("W", [1, 3])
-def test_sharded_replicated_ranking_with_circles(snk, W, monkeypatch):
+def test_sharded_replicated_ranking_with_circles(snk, W, monkeypatch, tune):
     """SNK_JOIN_REPLICATED=1: every rank ranks the whole link structure itself; the circles are cut by the same sparse pass."""
-    monkeypatch.setenv("SNK_JOIN_REPLICATED", "1")
+    tune("SNK_JOIN_REPLICATED", "1")
     c = goldens.load("adversarial")
     out = run_world(W, c)
     check(out, c)
@@ -113,26 +113,26 @@ def test_sharded_replicated_ranking_with_circles(snk, W, monkeypatch):
 
 
 @pytest.mark.parametrize("W", [1, 3])
-def test_sharded_overflowing_buckets_and_the_hot_table(snk, W, monkeypatch):
+def test_sharded_overflowing_buckets_and_the_hot_table(snk, W, monkeypatch, tune):
     """Tiny bucket capacity: most supermers travel through the overflow list, and buckets noted as hot stop counting in their cursors
     (snk_msp.hip) -- the per-bucket histogram the exchange is planned from is rebuilt from the grouped overflow list."""
-    monkeypatch.setenv("SNK_MSP_CAP_PCT", "10")
-    monkeypatch.setenv("SNK_MSP_HOT_FACTOR", "1")
-    monkeypatch.setenv("SNK_MSP_HOT_MIN", "1")
+    tune("SNK_MSP_CAP_PCT", "10")
+    tune("SNK_MSP_HOT_FACTOR", "1")
+    tune("SNK_MSP_HOT_MIN", "1")
     c = goldens.load("synth_20k_err")
     check(run_world(W, c), c)
 
 
 @pytest.mark.parametrize("W", [1, 2, 3])
 @pytest.mark.parametrize("name", ["adversarial", "synth_20k_err"])
-def test_sharded_hot_buckets_are_repartitioned_on_their_owner(snk, W, name, monkeypatch):
+def test_sharded_hot_buckets_are_repartitioned_on_their_owner(snk, W, name, monkeypatch, tune):
     """snk_hot.hip on a rank of the N-GPU job: a minimiser bucket's records arrive as one segment per source rank (+ the owner's own slots
     and overflow); a bucket far above its capacity is planned from the exchanged histograms, its records are expanded into hash classes
     when the exchange is through, and the classes are counted by a launch of their own.  Forced on the goldens by a tiny threshold."""
-    monkeypatch.setenv("SNK_MSP_CAP_PCT", "20")
-    monkeypatch.setenv("SNK_HOT_MIN", "8")
-    monkeypatch.setenv("SNK_HOT_FACTOR", "1")
-    monkeypatch.setenv("SNK_HOT_CLASS_INST", "300")
+    tune("SNK_MSP_CAP_PCT", "20")
+    tune("SNK_HOT_MIN", "8")
+    tune("SNK_HOT_FACTOR", "1")
+    tune("SNK_HOT_CLASS_INST", "300")
     c = goldens.load(name)
     out = run_world(W, c)
     check(out, c)

@@ -54,7 +54,8 @@ for case in range(n_cases):
     cov = float(rng.choice([3, 8, 30, 60]))
     if G >= 1000000: cov = min(cov, 30.0)
     cap_pct = int(rng.choice([100, 100, 100, 60, 10]))       # shrink the partition's bucket capacity: overflow segment
-    os.environ["SNK_MSP_CAP_PCT"] = str(cap_pct)
+    eng.set_option("msp_cap_pct", cap_pct)
+    os.environ["SNK_TUNING"] = f"msp_cap_pct={cap_pct}"       # (the in-process ranks below create their own contexts)
     n = max(10, int(G * cov / L))
     err = float(rng.choice([0.0, 0.002, 0.01]))
     nbc = int(rng.choice([1, 3, 40]))
@@ -94,7 +95,7 @@ for case in range(n_cases):
     tag = f"case {case}: K={K} L={L} G={G} n={n} err={err} nbc={nbc} min_freq={min_freq} min_bc={min_bc} nb={nb} bc={use_bc} cap%={cap_pct} -> {o.keys.shape[0]} k-mers, {len(o.unitigs)} unitigs"
     ok = True
     for glob in (0, 1):
-        os.environ["SNK_GLOBAL_GRAPH"] = str(glob)
+        eng.set_option("global_graph", glob)
         if only >= 0: print("  single leg, global =", glob, flush=True)
         r = eng.count_graph(rows, L, quals=dq, bc=dbc, lens=dl, params=Params(K=K, min_freq=min_freq, min_bc=min_bc, n_buckets=nb))
         if not same(r.keys(), r.counts(), r.ctx(), r.unitigs(), o):
@@ -110,7 +111,7 @@ for case in range(n_cases):
             h2 = graphio.hbv_from_unitigs(K, off2, bases2)
             if ranked != o.unitigs or any(not np.array_equal(h[kx], h2[kx]) for kx in ("v_left", "v_right", "src", "is_rc", "fwd", "rev")):
                 ok = False; print("MISMATCH hbv", "global" if glob else "local", tag, flush=True)
-    os.environ["SNK_GLOBAL_GRAPH"] = "0"
+    eng.set_option("global_graph", 0)
     if K == 48 and rng.random() < 0.4:
         # per-group graphs (BASELINE config 5): one grouped run == the oracle applied to every group's reads on its own
         NG = int(rng.choice([1, 2, 7]))

@@ -13,7 +13,7 @@ sp = synth.synth_params(n, seed=0x5EED0001)
 rows, quals, bc = e.synth(sp)
 modes = tuple(int(x) for x in sys.argv[2].split(',')) if len(sys.argv) > 2 else (0, 1, 2, 4)
 for dbg in modes:
-    os.environ["SNK_COUNT_DBG"] = str(dbg)
+    e.set_option("count_dbg", int(dbg))
     for rep in range(2):
         try:
             res = e.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48, graph=False, sorted_table=False))

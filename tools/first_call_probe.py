@@ -10,7 +10,7 @@ from supernova_amd.engine import Engine, Params
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100_000_000
 # one mode per process (memory a process has freed is slow to get again -- ~30 ms per GB on this stack -- whoever asks for it)
 for vmm in ((sys.argv[2],) if len(sys.argv) > 2 else ("1", "0")):
-    os.environ["SNK_ARENA_VMM"] = vmm
+    e.set_option("arena_vmm", int(vmm))
     e = Engine(0)
     sp = synth.synth_params(n, seed=0x5EED0001)
     rows, quals, bc = e.synth(sp)

@@ -11,7 +11,7 @@ from supernova_amd.engine import Engine, Params
 n = int(float(sys.argv[1]))
 mf = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 if len(sys.argv) > 3 and sys.argv[3] != "-":
-    os.environ["SNK_HBV_BIG"] = sys.argv[3]
+    e.set_option("hbv_big", int(sys.argv[3]))
 grouped = len(sys.argv) > 4 and sys.argv[4] == "grouped"
 e = Engine(0)
 sp = synth.synth_params(n, seed=0x5EED0001)

@@ -11,7 +11,7 @@ e = Engine(0)
 sp = synth.synth_params(n, seed=0x5EED0001)
 rows, quals, bc = e.synth(sp)
 for dbg in [int(x) for x in (sys.argv[2].split(',') if len(sys.argv) > 2 else '0,1,2'.split(','))]:
-    os.environ["SNK_MSP_DBG"] = str(dbg)
+    e.set_option("msp_dbg", int(dbg))
     for rep in range(2):
         try:
             res = e.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48, graph=False, sorted_table=False))

@@ -17,7 +17,7 @@ def run(tag, **kw):
 run("ungrouped, bc rule", bc=bc, params=Params(graph=False, sorted_table=False))
 run("ungrouped, no bc array", bc=None, params=Params(graph=False, sorted_table=False))
 run("grouped (bucket target 900)", bc=None, group=bc, params=Params(graph=False, sorted_table=False, grouped=True, min_bc=0))
-os.environ["SNK_TARGET_INST"] = "4000"
+e.set_option("target_inst", 4000)
 run("grouped, bucket target 4000", bc=None, group=bc, params=Params(graph=False, sorted_table=False, grouped=True, min_bc=0))
 zero = torch.zeros_like(bc)
 run("grouped, one group, target 4000", bc=None, group=zero, params=Params(graph=False, sorted_table=False, grouped=True, min_bc=0))

@@ -19,10 +19,10 @@ for _ in range(3):
     r = e.count_graph(rows, sp.read_len, quals=quals, bc=bc, params=P)
 print("baseline phases", r.phase_ms, "kernels", r.kernel_ms, flush=True)
 for mode, dbg in ((2, 0), (1, 0), (5, 0), (2, 1), (1, 1), (2, 2), (1, 2), (2, 3), (1, 3)):
-    os.environ["SNK_OVERLAP_PROBE"] = str(mode)
-    os.environ["SNK_OVERLAP_PROBE_DBG"] = str(dbg)
+    e.set_option("overlap_probe", int(mode))
+    e.set_option("overlap_probe_dbg", int(dbg))
     print(f"--- SNK_OVERLAP_PROBE={mode} relaunched kernel dbg={dbg} (0 whole kernel, 1 no record stores, 2 no slot atomics, 3 scan only)", flush=True)
     for _ in range(3):
         r = e.count_graph(rows, sp.read_len, quals=quals, bc=bc, params=P)
         torch.cuda.synchronize()
-os.environ["SNK_OVERLAP_PROBE"] = "0"
+e.set_option("overlap_probe", 0)

@@ -22,12 +22,12 @@ for name, mode in (("none", 0), ("families", 1), ("segdups", 2), ("STRs", 4), ("
     if name in ("STRs", "polyA", "all") and len(sys.argv) > 2:
         # where the partition's time goes (results invalid): 3 = the scan alone, 2 = no slot atomics, 1 = no record stores
         for dbg in ("3", "2", "1"):
-            os.environ["SNK_MSP_DBG"] = dbg
+            eng.set_option("msp_dbg", int(dbg))
             try:
                 for rep in range(2):
                     r2 = eng.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48, sorted_table=False))
                 print(f"   SNK_MSP_DBG={dbg}: partition {r2.phase_ms['partition']:.1f} ms", flush=True)
             except Exception as ex:
                 print(f"   SNK_MSP_DBG={dbg}: {type(ex).__name__} {str(ex)[:100]}", flush=True)
-            del os.environ["SNK_MSP_DBG"]
+            eng.clear_option("msp_dbg")
     del rows, quals, bc, r

@@ -10,7 +10,7 @@ rm = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # repeat_mode (15: the re
 e = Engine(0); sp = synth.synth_params(n, seed=0x5EED0001, **({'repeat_mode': rm} if rm else {})); rows, quals, bc = e.synth(sp)
 ref = None
 for passes in ("0", "2", "4", "0"):
-    if passes == "0": os.environ.pop("SNK_PARTITION_PASSES", None)
+    if passes == "0": e.clear_option("partition_passes")
     else: os.environ["SNK_PARTITION_PASSES"] = passes
     for _ in range(3):
         r = e.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48, sorted_table=False))

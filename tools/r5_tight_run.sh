@@ -6,8 +6,8 @@ B="--steps 4 --warmup 2 --no-cpu-baseline --no-next-rows --no-ingest --no-robust
 P="import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print(round(d['ms_per_step'],2), round(d['value'],2), d['config']['phase_ms_rank0'])"
 for x in "" "--k 60" "--grouped"; do
   echo -n "default switches $x: "; timeout 200 python bench.py $B $x 2>/dev/null | python -c "$P"
-  echo -n "SNK_COUNT_TIGHT=0 SNK_COUNT_SCREEN=0 $x: "; SNK_COUNT_TIGHT=0 SNK_COUNT_SCREEN=0 timeout 200 python bench.py $B $x 2>/dev/null | python -c "$P"
+  echo -n "SNK_TUNING=count_tight=0,count_screen=0 $x: "; SNK_TUNING=count_tight=0,count_screen=0 timeout 200 python bench.py $B $x 2>/dev/null | python -c "$P"
 done
-for sw in "" "SNK_COUNT_SCREEN_NG=0" "SNK_COUNT_TIGHT=0"; do
+for sw in "" "SNK_TUNING=count_screen_ng=0" "SNK_TUNING=count_tight=0"; do
   env $sw timeout 400 python tools/err_probe.py 1e8 e06,e15 2>&1 | grep -v amdgpu | grep "call 3" | sed "s/^/[$sw] /"
 done
