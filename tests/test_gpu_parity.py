@@ -980,7 +980,7 @@ def test_bucket_range_passes_equal_the_one_pass_partition(engine, graph_stage, n
         assert res.unitigs() == g.exp_unitigs
     else:
         _check_against(res, c.exp_keys, c.exp_counts, c.exp_ctx, c.exp_unitigs, c.exp_goodlens, c.exp_hist)
-    monkeypatch.delenv("SNK_PARTITION_PASSES")
+    engine.clear_option("partition_passes")
     res = engine.count_graph(rows, c.read_len, quals=quals, bc=bc if K == 48 else None, lens=lens, params=Params(K=K), ign_bc_below=c.ign_bc_below)
     assert engine.last_partition_passes() == 1
 
@@ -1135,7 +1135,7 @@ def test_read_paths_full_capacity_pass(engine, monkeypatch, tune):
     assert np.array_equal(info["dups"]["dup"], c.exp_dup)
     assert np.array_equal(info["unitig_bcs"][0], info0["unitig_bcs"][0]) and np.array_equal(info["unitig_bcs"][1], info0["unitig_bcs"][1])
     # and the group kernel doing the sequential tail itself (SNK_PATH_FUSED) instead of the one-thread-per-read finishing kernel
-    monkeypatch.delenv("SNK_PATH_REDO_ALL")
+    engine.clear_option("path_redo_all")
     tune("SNK_PATH_FUSED", "1")
     off, ne, edges, info = res.path_reads(rows, c.read_len, quals, lens=lens, mark_dups=True, bc=bc, unitig_bcs=True)
     assert np.array_equal(ne.astype(np.int64), c.exp_path_n) and np.array_equal(edges, c.exp_path_edges) and np.array_equal(off, c.exp_path_off)
