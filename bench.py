@@ -559,6 +559,8 @@ def main():
             ach = valu_insts / (count_ms * 1e-3) / 1e9
             kernels["snk_count_kernel"] = {"bound": "valu", "launch_ms": count_ms, "valu_wave_insts": valu_insts, "achieved": ach, "peak": VALU_PEAK_GINST,
                                            "unit": "G wave-instr/s", "frac": ach / VALU_PEAK_GINST,
+                                           # (rounds 2-4 priced the same count against a 2-cycle issue, twice this peak: kept so that rounds stay comparable)
+                                           "frac_at_2_cycle_issue_r4_definition": ach / (2 * VALU_PEAK_GINST),
                                            "valu_insts_per_kmer_instance": valu_insts * 64 / units if units else None,
                                            "salu_wave_insts": salu_insts, "lds_wave_insts": lds_insts,
                                            "hbm_traffic_bytes": traffic, "hbm_frac": (traffic / (count_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None}

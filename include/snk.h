@@ -87,7 +87,9 @@ void snk_ctx_trim(snk_ctx* ctx);
 /* Map `bytes` of device memory into the context's scratch arena now and keep that much mapped between calls (until snk_ctx_trim).  A call
  * that needs more scratch than the context has mapped so far pays the driver for the new memory inside the call (~25-30 ms per GB: 100 M
  * error-rich reads after 100 M clean ones: +20 GB, 745 instead of 228 ms for that one call); a host that owns the GPU reserves its share
- * once, at start-up.  Returns SNK_E_NOMEM when the device cannot give that much (what could be mapped stays usable). */
+ * once, at start-up.  Returns SNK_E_NOMEM when the device cannot give that much (what could be mapped stays usable).  The reservation
+ * outlives the arena's own resets (a sealed range, a shrink after much larger calls): it is mapped again at the start of the next call; only a
+ * multi-rank step (plain device blocks for the xGMI buffers) runs without it, and the call after that step maps it again. */
 int snk_ctx_reserve(snk_ctx* ctx, uint64_t bytes, char* err, size_t errcap);
 
 /* ---- tuning (round 6) ------------------------------------------------------------------------------------------------------------

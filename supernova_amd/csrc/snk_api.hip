@@ -381,7 +381,14 @@ void snk_ctx_release_scratch(snk_ctx* ctx) {
         ctx->va_high_prev[0] = ctx->va_high;
         ctx->va_high = 0;
         // (a call that takes plain hipMalloc blocks -- a multi-rank step -- must not sit next to tens of GB this range still maps: ADVICE r4)
-        if (ctx->va_sealed || (recent && ctx->va_mapped > std::max(2 * recent + ((size_t)1 << 30), ctx->va_floor)) || (ctx->arena_legacy && ctx->va_mapped)) va_reset(ctx);
+        if (ctx->va_sealed || (recent && ctx->va_mapped > std::max(2 * recent + ((size_t)1 << 30), ctx->va_floor)) || (ctx->arena_legacy && ctx->va_mapped)) {
+            va_reset(ctx);
+            // the host's reservation (snk_ctx_reserve) outlives a reset: mapped again right away -- except under a call that takes plain
+            // hipMalloc blocks (a multi-rank step must not sit next to the reserved range; the next call of the other kind maps it again).
+            // A failure here is not an error: the call's own requests grow the arena as far as the device allows
+            if (ctx->va_floor && !ctx->arena_legacy && ctx->va_state > 0) (void)va_grow(ctx, ctx->va_floor);
+        }
+        else if (ctx->va_floor > ctx->va_mapped && !ctx->arena_legacy && ctx->va_state > 0 && !ctx->va_sealed) (void)va_grow(ctx, ctx->va_floor - ctx->va_mapped);
     }
     // A new top-level call.  Blocks that neither of the last two calls took are sizes the caller has moved away from (a
     // 150 M-read run followed by 15 M-read runs): they go back to the device, where the caller's own allocator may need them.

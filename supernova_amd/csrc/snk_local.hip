@@ -73,19 +73,22 @@ struct bl_shard {
 // they are handed to the graph stage as one chunk while the run fits the one-wave kernels (`cap` k-mers).  More neighbours are found inside
 // a chunk, never fewer; a miss whose bucket is one of the chunk's is absent as before.  An empty bucket ends a run (it may be a split or
 // hot bucket, whose survivors lie elsewhere).  One thread per region; error-rich reads: 5.6 M buckets of ~49 survivors.
-__global__ void __launch_bounds__(256) bl_chunk_merge_kernel(uint32_t* __restrict__ chunk_n, const uint32_t* __restrict__ chunk_base, uint32_t NB, uint32_t G,
-                                                             uint32_t cap, uint8_t* __restrict__ span) {
+// (the table's own chunk_n is read only: the merged sizes go to `merged`, which this graph stage's descriptors are made from -- a second
+// prune over the same table, or any later reader of chunk_n, sees the table as the count kernel left it: ADVICE r5)
+__global__ void __launch_bounds__(256) bl_chunk_merge_kernel(const uint32_t* __restrict__ chunk_n, const uint32_t* __restrict__ chunk_base, uint32_t NB, uint32_t G,
+                                                             uint32_t cap, uint8_t* __restrict__ span, uint32_t* __restrict__ merged) {
     const uint32_t r = blockIdx.x * 256 + threadIdx.x;
     if (r >= G) return;
     uint32_t head = NONE, total = 0, m = 0, expect = 0;
     for (uint32_t b = r; b < NB; b += G) {
         const uint32_t n = chunk_n[b];
         span[b] = 1;
+        merged[b] = n;
         if (n == 0) { head = NONE; continue; }
         const uint32_t base = chunk_base[b];
         if (head != NONE && base == expect && total + n <= cap && m < 255u) {
             total += n; ++m;
-            chunk_n[head] = total; chunk_n[b] = 0; span[head] = (uint8_t)m;
+            merged[head] = total; merged[b] = 0; span[head] = (uint8_t)m;
         } else { head = b; total = n; m = 1; }
         expect = base + n;
     }
@@ -912,10 +915,12 @@ static int bl_prune_impl(snk_ctx* ctx, hipStream_t st, snk_bl_state* B, char* er
     const uint32_t merge_cap = std::min<uint32_t>(snk_opt_u32("chunk_merge", (uint32_t)SCAP), (uint32_t)SCAP);
     if (merge_cap && tab->chunk_n && tab->NB > tab->n_regions) {
         uint8_t* span;
+        uint32_t* merged;
         G_ALLOC(span, uint8_t, (uint64_t)tab->NB + 1);
-        hipLaunchKernelGGL(bl_chunk_merge_kernel, dim3((tab->n_regions + 255) / 256), dim3(256), 0, st, const_cast<uint32_t*>(tab->chunk_n), tab->chunk_base, tab->NB, tab->n_regions,
-                           merge_cap, span);
+        G_ALLOC(merged, uint32_t, (uint64_t)tab->NB + 1);
+        hipLaunchKernelGGL(bl_chunk_merge_kernel, dim3((tab->n_regions + 255) / 256), dim3(256), 0, st, tab->chunk_n, tab->chunk_base, tab->NB, tab->n_regions, merge_cap, span, merged);
         cs.span = span;
+        cs.chunk_n = merged;
     }
     const uint32_t nchunks = tab->NB + tab->n_extra;
     B->nchunks = nchunks;

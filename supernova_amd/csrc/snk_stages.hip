@@ -391,6 +391,11 @@ static int snk_msp_segments(snk_ctx* ctx, hipStream_t st, uint32_t NB, uint32_t 
     for (uint32_t q = 0; q < SNK_OVF_SUBLISTS; ++q) { P.pre[q] = (uint32_t)acc; acc += h_sub[q]; }
     P.pre[SNK_OVF_SUBLISTS] = (uint32_t)acc;
     const uint32_t n_ovf = (uint32_t)acc;
+    // the index / key / sort temporaries below are dead behind the gather: handed back here (everything runs on `st`, the arena's reuse is in
+    // stream order), so that bucket-range passes -- up to 64 of them, each replayed run repeating them -- do not pile them up next to the slot
+    // array of a job that was too large for the device in the first place
+    const uint64_t mark = ctx->alloc_serial;
+    struct give_back { snk_ctx* c; uint64_t m; ~give_back() { snk_ctx_release_since(c, m, nullptr, 0); } } _gb{ctx, mark};
     if (n_ovf) {
         uint32_t *idx_in, *idx_out, *key_in, *key_out;
         void* q;
