@@ -581,6 +581,7 @@ def main():
                                    f"({'error-free' if args.error_free else '0.2% substitutions, Q2 tails on 5%'}), "
                                    f"k={K}, {'1xMI355X count+graph' if world == 1 else f'{world}xMI355X minimiser-sharded all-to-all'}",
                        "reads_per_gpu": per_gpu, "k": K, "kmer_instances": int(inst_total),
+                       "scratch_gb": round(getattr(res, "scratch_bytes", 0) / 2**30, 1), "overflow_supermers": int(getattr(res, "n_overflow", 0)),
                        "arena_reserved_gb": round(reserved_gb, 1),      # mapped before the first call (snk_ctx_reserve; --reserve-gb 0 = grow on demand)
                        "retained_kmers_rank0": int(res.n_kmers), "unitigs_rank0": int(res.n_unitigs),
                        "phase_ms_rank0": {k: round(v, 3) for k, v in res.phase_ms.items()},

@@ -381,7 +381,10 @@ void snk_ctx_release_scratch(snk_ctx* ctx) {
         ctx->va_high_prev[0] = ctx->va_high;
         ctx->va_high = 0;
         // (a call that takes plain hipMalloc blocks -- a multi-rank step -- must not sit next to tens of GB this range still maps: ADVICE r4)
-        if (ctx->va_sealed || (recent && ctx->va_mapped > std::max(2 * recent + ((size_t)1 << 30), ctx->va_floor)) || (ctx->arena_legacy && ctx->va_mapped)) {
+        // (the reservation in whole 1-GB chunks, as it is mapped: a floor of 129.6 GB is 130 GB mapped, which must not count as "more than the floor" --
+        // a call that needed less than half the reservation would reset and re-map all of it, ~3 s, every time: found by tools/r6_cap_sigma.sh)
+        const size_t floor_chunks = (ctx->va_floor + (((size_t)1 << 30) - 1)) & ~(((size_t)1 << 30) - 1);
+        if (ctx->va_sealed || (recent && ctx->va_mapped > std::max(2 * recent + ((size_t)1 << 30), floor_chunks)) || (ctx->arena_legacy && ctx->va_mapped)) {
             va_reset(ctx);
             // the host's reservation (snk_ctx_reserve) outlives a reset: mapped again right away -- except under a call that takes plain
             // hipMalloc blocks (a multi-rank step must not sit next to the reserved range; the next call of the other kind maps it again).

@@ -26,6 +26,7 @@ const snk_opt_def snk_opt_defs[] = {
     // ---- partition
     {"partition_passes", "bucket-range passes of the partition: 0 = as many as the device needs (default)"},
     {"msp_cap_pct", "bucket slot capacity in percent of the occupancy model's (100; tests shrink it to force the overflow segment)"},
+    {"msp_sigmas_x10", "bucket slot capacity = mean + this/10 sigma of the occupancy model; unset: 5, or 3 / 1.5 when the slots would take more than 30 % of the device"},
     {"msp_site_records", "supermers per minimiser site in the occupancy model (48; groups 3)"},
     {"msp_dense", "1: reservation-free partition (dense records + sorted index list)"},
     {"msp_hot_factor", "a bucket is noted hot at this multiple of its capacity (32)"},

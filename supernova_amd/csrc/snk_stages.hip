@@ -452,7 +452,20 @@ static void partition_capacity(snk_ctx* ctx, uint32_t K, uint32_t NB, unsigned l
     // (78 instead of 34 ms).  c is a property of the data set: 48 covers 70x; per-barcode groups see a site once or twice.
     // Overflowing supermers are correct (segment 1), only slower; the slots that stay empty are never touched.
     const double site_records = (double)snk_opt_u32("msp_site_records", grouped ? 3u : 48u);
-    uint64_t cap64 = (uint64_t)(mean + 5.0 * std::sqrt(mean * site_records) + 16.0);
+    // ... and how many sigma is a matter of memory: at 5 the slots are 2.9 x the records (100 M reads: 66 GB of slots for 22 GB of records, nothing
+    // overflows); at 3 sigma 0.03 % of the supermers take the overflow list, at 1.2 sigma 2.2 % do, for +1 / +1.5 ms of the 104 ms step
+    // (tools/r6_cap_sigma.sh, profiles/r06_cap_sigma.log).  So: 5 sigma while the slots stay below 30 % of the device, 3 above, 1.5 if those are
+    // still more than 30 % -- only where a bucket holds several sites (the Gaussian regime; a rank of the 8-GPU job has ONE site per bucket and
+    // keeps its 5 sigma, the 45 % budget below and the larger overflow list).  Option msp_sigmas_x10 pins it.
+    double sig = 5.0;
+    const double sigma = std::sqrt(mean * site_records);
+    if (snk_opt_is_set("msp_sigmas_x10")) sig = 0.1 * snk_opt_u32("msp_sigmas_x10", 50);
+    else if (passes <= 1 && ctx->device_mem_total && mean >= 4.0 * site_records) {
+        const double lim = 0.30 * (double)ctx->device_mem_total;
+        if ((mean + 5.0 * sigma + 16.0) * NB * 32.0 > lim) sig = 3.0;
+        if (sig < 5.0 && (mean + 3.0 * sigma + 16.0) * NB * 32.0 > lim) sig = 1.5;
+    }
+    uint64_t cap64 = (uint64_t)(mean + sig * sigma + 16.0);
     cap64 = cap64 * snk_opt_u32("msp_cap_pct", 100) / 100;
     if (cap64 < 2) cap64 = 2;
     cap64 = (cap64 + 1) & ~1ull;

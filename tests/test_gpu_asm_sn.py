@@ -37,6 +37,21 @@ def test_asm_sn_fasth_to_bv(snk, tmp_path):
     assert st["world"] == 1 and st["reads_rank0"] == c.rows.shape[0]
 
 
+def test_asm_sn_df_stage_inputs_to_bv(snk, tmp_path):
+    """LR=<head>.fastb (+ .qualp, .bci: the ASSEMBLER_DF stage inputs, written by the reference's own writers) -> the rank's byte range is
+    decoded on the device (snk_dev_ingest_df) -> one-rank RCCL step -> asm_graph.bv == the reference's unitigs; READ_LEN pins the row length
+    every rank of a job would agree on."""
+    from supernova_amd import graphio
+    fmt = ROOT / "tests" / "golden" / "formats"
+    c = goldens.load("synth_2k_err")
+    for extra in ([], ["READ_LEN=160"]):
+        out = tmp_path / "asm_graph.bv"
+        log = _run([f"LR={fmt / 'reads.fastb'}", f"OUT={out}", "WORLD=1", "RANK=0", *extra])
+        assert "reads [0, 2000) of 2000" in log and "GB of file bytes" in log
+        off, bases = graphio.read_bv(str(out))
+        assert graphio.arrays_to_unitigs(off, bases) == c.exp_unitigs
+
+
 def test_asm_sn_10m_reference_digest(snk, tmp_path):
     """BASELINE config 1 (10 M x 150 bp, seed 0x5EED0001) through the C++ host on a one-rank RCCL communicator: the unitig file's
     content hashes to the reference's own digest (tests/golden/big_hashes.json)."""
