@@ -271,3 +271,53 @@ def test_tuning_struct_and_options(snk, monkeypatch):
     monkeypatch.setenv("SNK_TUNING", "count_tight=1500,bogus=1")
     with pytest.raises(SnkError, match="SNK_TUNING"):
         Engine(0)
+
+
+@pytest.mark.skipif(not refio.REF_DRIVER.exists(), reason="oracle/_ref/snref_driver not built")
+def test_df_seam_end_to_end_vs_reference_200k(snk, tmp_path):
+    """The whole seam against the reference itself, nothing of this repo in between: the reference's writers make reads.fastb / .qualp / .bci
+    (snref_driver ... formats), the reference's createDict + buildEdges make the table and the unitigs of the same reads (snref_driver ...
+    dump); the device decodes the files slab by slab into a streamed job -- good lengths, retained table, contexts, spectrum, unitigs and the
+    .bv file of snk_mspedges equal the reference's, bit for bit.  Reads sorted by barcode (what a .bci index needs), ragged lengths, Q2 tails."""
+    import os
+    import subprocess
+    from supernova_amd import dfin, graphio, synth
+    from supernova_amd.engine import Engine, Params
+    n = 200_000
+    sp = synth.synth_params(n, seed=0x5EED0D5E)
+    rows, quals, bc = synth.synth_host(sp)
+    order = np.argsort(bc, kind="stable")                       # the model's unbarcoded pairs are scattered: the index wants them first
+    order = order.reshape(-1)                                   # (stable: mates stay next to each other, pairs keep their order)
+    rows, quals, bc = rows[order], quals[order], bc[order]
+    rng = np.random.default_rng(7)
+    lens = np.full(n, 150, dtype=np.uint16)
+    short = rng.random(n) < 0.05
+    lens[short] = rng.integers(40, 150, int(short.sum()))
+    codes = synth.unpack_rows(rows, 150)
+    codes[np.arange(150)[None, :] >= lens[:, None]] = 0
+    quals = quals.copy()
+    quals[np.arange(150)[None, :] >= lens[:, None]] = 0
+    refio.write_snkrd(tmp_path / "in.snkrd", lens, synth.codes_to_ascii(codes), quals, bc)
+    th = min(32, os.cpu_count() or 8)
+    refio.run_ref(tmp_path / "in.snkrd", tmp_path / "fmt", threads=th, mode="formats")
+    refio.run_ref(tmp_path / "in.snkrd", tmp_path / "out", threads=th)
+    d = refio.read_ref_dump(tmp_path / "out")
+    hist = np.asarray(d["hist"]["vals"], dtype=np.int64)
+    e = Engine(0)
+    with dfin.DfFiles(tmp_path / "fmt" / "reads") as f:
+        for slab in (0, 30_000):
+            res, st = f.count_graph(e, Params(K=48), slab_reads=slab)
+            assert np.array_equal(res.good_len().astype(np.uint32), d["goodlens"])
+            k = res.keys()
+            assert np.array_equal(k[:, :3], d["kmers"]["k"]) and np.array_equal(np.minimum(res.counts(), (1 << 24) - 1), d["kmers"]["count"])
+            assert np.array_equal(res.ctx(), d["kmers"]["ctx"]) and res.unitigs() == d["unitigs"]
+            spec = res.spectrum()
+            nz = np.nonzero(spec)[0]
+            assert np.array_equal(spec[: nz[-1] + 1].astype(np.int64), hist)
+    e.close()
+    exe = Path(__file__).resolve().parent.parent / "supernova_amd" / "bin" / "snk_mspedges"
+    out = tmp_path / "asm_graph.bv"
+    r = subprocess.run([str(exe), f"LR={tmp_path / 'fmt' / 'reads.fastb'}", f"OUT={out}", "SLAB_READS=50000", "IO_THREADS=3"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    off, bases = graphio.read_bv(str(out))
+    assert sorted(graphio.arrays_to_unitigs(off, bases)) == sorted(d["unitigs"])
