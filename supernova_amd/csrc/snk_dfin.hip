@@ -459,6 +459,8 @@ int run_slabs(snk_ctx* ctx, df_io* io, const snk_df_files* f, uint64_t first, ui
     std::atomic<int> failed{0};
     std::atomic<int> left_offs[NSLOT], left_data[NSLOT];
     for (int s = 0; s < NSLOT; ++s) { left_offs[s].store(0); left_data[s].store(0); }
+    // whatever way this function is left, no worker still writes through these counters (the next slab's offset tables are asked for ahead)
+    struct drain_t { io_pool* p; std::atomic<int>* a; std::atomic<int>* b; ~drain_t() { for (int s = 0; s < NSLOT; ++s) { p->wait(&a[s]); p->wait(&b[s]); } } } drain{io->pool, left_offs, left_data};
     // slab k covers reads [first + k * slab_reads, ...); its offset tables are fetched one slab ahead of its data
     const uint64_t n_slabs = (n + slab_reads - 1) / slab_reads;
     auto slab_n = [&](uint64_t k) { return std::min(slab_reads, n - k * slab_reads); };
