@@ -321,3 +321,55 @@ def test_df_seam_end_to_end_vs_reference_200k(snk, tmp_path):
     assert r.returncode == 0, r.stderr
     off, bases = graphio.read_bv(str(out))
     assert sorted(graphio.arrays_to_unitigs(off, bases)) == sorted(d["unitigs"])
+
+
+def test_corrupted_files_never_get_past_the_decoder(snk, tmp_path):
+    """Random damage to the offset tables, the length table, the quality bytes and the control blocks: every call either fails with an error
+    of the library (SNK_E_IO / SNK_E_ARG / SNK_E_UNSUPPORTED) or decodes -- and what it decodes is what the host readers decode from the same
+    bytes (damage inside a quality block's values is still a valid file).  Nothing hangs, nothing reads outside its buffers."""
+    import struct
+    from supernova_amd import dfin, formats
+    from supernova_amd.engine import Engine
+    from supernova_amd.lib import SnkError
+    rows, lens, q, bc = _random_triple(4000, 17)
+    head = tmp_path / "r"
+    dfin.write_df(head, rows, q, bc, lens=lens, read_len=150)
+    good = {ext: (tmp_path / f"r.{ext}").read_bytes() for ext in ("fastb", "qualp")}
+    rng = np.random.default_rng(99)
+    e = Engine(0)
+    outcomes = {"error": 0, "decoded": 0}
+    for trial in range(40):
+        ext = "fastb" if trial % 2 else "qualp"
+        raw = bytearray(good[ext])
+        var, fix = struct.unpack_from("<QQ", raw, 8)
+        kind = trial % 5
+        if kind == 0:   # an offset
+            at = var + 8 * int(rng.integers(0, 4001))
+            struct.pack_into("<Q", raw, at, int(rng.integers(0, 1 << 40)))
+        elif kind == 1 and ext == "fastb":   # a length
+            struct.pack_into("<I", raw, fix + 4 * int(rng.integers(0, 4000)), int(rng.integers(0, 1 << 20)))
+        elif kind == 2:   # the control block
+            raw[int(rng.integers(0, 24))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 3:   # truncate
+            del raw[int(rng.integers(24, len(raw))):]
+        else:             # a data byte
+            for _ in range(8):
+                raw[int(rng.integers(24, var))] = int(rng.integers(0, 256))
+        (tmp_path / f"r.{ext}").write_bytes(bytes(raw))
+        try:
+            with dfin.DfFiles(head) as f:
+                dr = f.ingest(e, read_len=160, slab_reads=int(rng.choice([0, 333, 1000])))
+                got = _device_arrays(e, dr)
+                dr.close()
+            hr, hl, _ = formats.read_fastb(str(head) + ".fastb")
+            hq = formats.read_qualp(str(head) + ".qualp", 4000, 160)
+            assert np.array_equal(got[0][:, :hr.shape[1]], hr) and np.array_equal(got[2], hl) and np.array_equal(got[1], hq)
+            outcomes["decoded"] += 1
+        except SnkError as ex:
+            assert ex.code in (-1, -5, -6), ex
+            outcomes["error"] += 1
+        (tmp_path / f"r.{ext}").write_bytes(good[ext])
+    assert outcomes["error"] >= 10 and outcomes["decoded"] >= 3, outcomes
+    with dfin.DfFiles(head) as f:
+        _check_equal(e, f, head)
+    e.close()
