@@ -373,3 +373,32 @@ def test_corrupted_files_never_get_past_the_decoder(snk, tmp_path):
     with dfin.DfFiles(head) as f:
         _check_equal(e, f, head)
     e.close()
+
+
+def test_long_reads_250(snk, tmp_path):
+    """rows of 16 words (reads up to 256 bases: the quality rows leave the fused trim's 160-byte limit, the streamed job takes the row-wise
+    trim): decode == host readers on ragged 250-base triples, and the streamed count+graph == a resident call on 250-base synthetic reads"""
+    from supernova_amd import dfin, synth
+    from supernova_amd.engine import Engine, Params
+    n = 20_001
+    rows, lens, q, bc = _random_triple(n, 250, max_len=250)
+    head = tmp_path / "long"
+    dfin.write_df(head, rows, q, bc, lens=lens, read_len=250, adversarial=0x250)
+    e = Engine(0)
+    with dfin.DfFiles(head) as f:
+        assert f.max_len(e) == 250
+        _check_equal(e, f, head, slab_reads=3001)
+        _check_equal(e, f, head, read_len=256)
+    m = 60_000
+    sp = synth.synth_params(m, seed=0x5EED0250, unbarcoded_ppm=0, read_len=250)
+    dfin.write_synth_df(tmp_path / "s250", sp, qual_jitter=4)
+    with dfin.DfFiles(tmp_path / "s250") as f:
+        dr = f.ingest(e)
+        assert dr.read_len == 250 and int(dr.raw.row_words) == 16
+        ref = e.count_graph_reads(dr.dev_reads(), Params(K=48))
+        want = (ref.unitigs(), ref.keys(), ref.counts(), ref.ctx())
+        assert len(want[0]) > 0
+        dr.close()
+        res, st = f.count_graph(e, Params(K=48), slab_reads=9000)
+        assert res.unitigs() == want[0] and np.array_equal(res.keys(), want[1]) and np.array_equal(res.counts(), want[2]) and np.array_equal(res.ctx(), want[3])
+    e.close()
