@@ -225,7 +225,7 @@ def ingest_row(eng, args, K, step_ms_per_read):
 
 def df_seam_row(eng, args, K):
     """b1/b2 at rate: the ASSEMBLER_DF stage inputs -- reads.fastb / reads.qualp / reads.bci -- of a synthetic data set
-    decoded on the device and streamed into count+graph (snk_df_open / snk_dev_ingest_df_count_graph, what supernova_amd/df_stage.py and
+    decoded on the device, slab by slab, and counted+graphed (snk_df_open / snk_dev_ingest_df_count_graph, what supernova_amd/df_stage.py and
     snk_mspedges run), against the same reads decoded into resident arrays and counted by one resident call.  Files are written once by the
     library's own writer (qualities jittered over [30, 38): a quality file of sequencer-like entropy with the same trim), so they sit in the
     page cache.  Beside it: the rate of the old one-thread host readers on a prefix of the same data."""
@@ -277,6 +277,17 @@ def df_seam_row(eng, args, K):
                               "count_graph_ms": round(res.phase_ms["count"] + res.phase_ms["graph"], 2)})
                 n_inst, n_slabs, moved = int(res.n_instances), st["n_slabs"], st["file_bytes"]
                 del res
+            # ... and through a streamed job (option df_stream = 2: every slab partitioned as it arrives, the reads never resident in any form)
+            eng.set_option("df_stream", 2)
+            streamed = []
+            for rep in range(2):
+                t0 = time.perf_counter()
+                res, stc = f.count_graph(eng, params, read_len=sp.read_len, threads=args.df_threads)
+                imgc = res.bv_image()
+                streamed.append(round(time.perf_counter() - t0, 4))
+                same = same and stc["mode"] == "streamed" and hashlib.sha256(imgc).hexdigest() == want[3]
+                del res
+            eng.clear_option("df_stream")
             # the decode read_len = 0 (the row length found by a scan of the file's length table), as the stage adapter calls it
             t0 = time.perf_counter()
             res, st0 = f.count_graph(eng, params, threads=args.df_threads)
@@ -291,7 +302,8 @@ def df_seam_row(eng, args, K):
                                     "of_it_device_arrays_allocated_s": round(best_ing["setup_seconds"], 4)},
                 "fastb_to_unitigs": {"wall_s": best["wall_s"], "file_GB_per_s": round(moved / best["wall_s"] / 1e9, 2), "reads_per_s": n / best["wall_s"],
                                      "Gkmers_per_s": round(n_inst / best["wall_s"] / 1e9, 2), "slabs": n_slabs, "calls": calls,
-                                     "wall_s_with_length_scan": round(wall_scan, 4), "includes": "open files .. .bv image on the host"},
+                                     "wall_s_with_length_scan": round(wall_scan, 4), "includes": "open files .. .bv image on the host",
+                                     "mode": "compact (rows + good lengths + barcode ids stay: 46 B per read; the adaptive resident step)", "streamed_job_wall_s": streamed},
                 "same_result_as_resident": bool(same),
                 "io_threads": args.df_threads or "auto", "host_threads": os.cpu_count(), "host_cpu_budget": int(eng.lib.snk_host_cpu_budget()),
                 "old_host_readers": {"reads": n_small, "fastb_reads_per_s": n_small / t_fb, "qualp_reads_per_s": n_small / t_qp,

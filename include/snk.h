@@ -556,9 +556,13 @@ int snk_read_bci(const char* path, uint64_t n_reads, int32_t* bc_per_read, uint6
  *                     of the N-GPU job passes ITS range and touches only those bytes.  read_len = row length in bases, 0 = the longest
  *                     read of the file (one scan of its length table, on the device; snk_df_max_len does the scan for a range);
  *                     slab_reads: reads per slab, 0 = 262144
- *   snk_dev_ingest_df_count_graph   the same slabs appended to a streamed job (snk_dev_stream_*): partitioned while the next slab's bytes
- *                     are read and copied, the reads never resident as a whole; res as snk_dev_count_graph's, bit-identical to a
- *                     resident call on the same reads.  stats: rows / quals / lens / bc stay NULL; text_bytes = file bytes moved.
+ *   snk_dev_ingest_df_count_graph   the slabs -> unitigs.  Default: a slab's quality rows are trimmed as soon as they are decoded and dropped;
+ *                     packed rows, good lengths and barcode ids of the job stay (46 bytes per read, owned by the context) and the resident
+ *                     step runs on them -- with its look at the first buckets, its second partition and its choice of count kernel, which
+ *                     is what real (error-rich) reads need from the first call of a process on.  Option df_stream = 2: the slabs are
+ *                     appended to a streamed job instead (snk_dev_stream_*: partitioned as they arrive, the reads never resident in any
+ *                     form).  res as snk_dev_count_graph's, bit-identical either way.  stats: rows / quals / lens / bc stay NULL;
+ *                     text_bytes = file bytes moved; n_files = 4 compact, 3 streamed.
  * Errors follow the host readers': SNK_E_IO for a bad offset / length / truncated quality block, SNK_E_ARG for a quality chain longer
  * than a row (the message names the first offending read). */
 typedef struct snk_df_files snk_df_files;

@@ -255,6 +255,11 @@ struct df_io {
     uint32_t* d_errs = nullptr;
     long long* d_bci = nullptr;
     uint64_t bci_cap = 0;
+    // the compact form of a job's reads (packed rows, good lengths, barcode ids: 46 bytes per 150-base read; the quality rows are gone
+    // once a slab is trimmed): what snk_dev_ingest_df_count_graph hands to the resident step when the data are not known to be clean
+    uint32_t* c_rows = nullptr; uint16_t* c_gl = nullptr; int32_t* c_bc = nullptr;
+    uint64_t c_reads = 0; uint32_t c_row_words = 0;
+    void release_compact() { (void)hipFree(c_rows); (void)hipFree(c_gl); (void)hipFree(c_bc); c_rows = nullptr; c_gl = nullptr; c_bc = nullptr; c_reads = 0; c_row_words = 0; }
     hipStream_t cs = nullptr;
     io_pool* pool = nullptr;
     unsigned pool_threads = 0;
@@ -273,6 +278,7 @@ struct df_io {
         for (int s = 0; s < NSLOT; ++s) if (used[s]) (void)hipEventDestroy(used[s]);
         if (d_errs) (void)hipFree(d_errs);
         if (d_bci) (void)hipFree(d_bci);
+        release_compact();
         if (cs) (void)hipStreamDestroy(cs);
         delete pool;
     }
@@ -639,20 +645,32 @@ extern "C" int snk_dev_ingest_df(snk_ctx* ctx, snk_df_files* f, uint64_t first, 
     return SNK_OK;
 }
 
-// the triple -> unitigs with the reads never resident as a whole: every decoded slab is appended to a streamed job (snk_dev_stream_*), i.e.
-// partitioned while the next slab's bytes are read and copied.  first / n: this caller's reads (the whole file: 0, n_reads); ign_bc_below as
-// snk_dev_reads'.  res: as snk_dev_count_graph's.  stats: rows / quals / lens / bc stay NULL.
+// the triple -> unitigs.  Two ways (option df_stream; DfFiles.count_graph reports which):
+//  * COMPACT (default): a slab's quality rows are trimmed as soon as they are decoded and dropped; the packed rows, good lengths and barcode
+//    ids of the job stay (46 bytes per read, context-owned, grow-only) and the RESIDENT step runs on them -- it looks at its first buckets,
+//    partitions a second time when their tables run full and picks the count kernel the data want, none of which a streamed job can do once
+//    its slabs are gone (100 M reads with 0.6 % / 1.5 % errors, first call of a process: 0.72-0.88 / 1.29-1.32 s streamed against 0.50 / 0.59 s
+//    compact; clean reads: 0.46 against 0.43 s; tools/r6_df_errors.py, profiles/r06_df_errors.log);
+//  * STREAMED (df_stream = 2): every decoded slab is appended to a streamed job (snk_dev_stream_*), i.e. partitioned while the next slab's
+//    bytes are read and copied: the reads are never resident in any form (a job whose 46 bytes per read do not fit next to its records).
+// first / n: this caller's reads (the whole file: 0, n_reads); ign_bc_below as snk_dev_reads'.  res: as snk_dev_count_graph's.  stats: rows /
+// quals / lens / bc stay NULL; n_files = 3 streamed, 4 compact.
 extern "C" int snk_dev_ingest_df_count_graph(snk_ctx* ctx, snk_df_files* f, uint64_t first, uint64_t n, uint32_t read_len, uint32_t threads, uint64_t slab_reads,
                                              const snk_params* p, int64_t ign_bc_below, snk_dev_result* res, snk_dev_ingest* out, char* err, size_t errcap) {
     if (!ctx || !f || !p || !res || !out) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_ingest_df_count_graph: NULL argument");
     memset(out, 0, sizeof *out);
     if (n == 0) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_ingest_df_count_graph: no reads");
+    if (p->K != 48 && p->K != 60) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "K=%u is not supported (48 or 60)", p->K);
     const double t0 = now_s();
     df_io* io;
     uint32_t max_len;
     int rc = prepare(ctx, f, first, n, read_len, threads, &slab_reads, &io, &max_len, err, errcap);
     if (rc) return rc;
     const uint32_t row_words = (max_len + 15) / 16, qstride = row_words * 16;
+    // (measured, tools/r6_df_errors.py: on clean data the compact form is as fast as the streamed job -- 0.43 against 0.46 s per 100 M reads:
+    // 382 small partition launches on the copies' stream cost 52 ms, one resident launch 30 -- and on error-rich data much faster.  So the
+    // compact form is what runs unless the caller asks for the streamed job, whose point is that the reads are never resident in any form.)
+    const bool streamed = snk_opt_u32("df_stream", 0) == 2 && !(p->flags & SNK_F_GROUPED);
     struct obuf { uint32_t* rows = nullptr; uint8_t* quals = nullptr; uint16_t* lens = nullptr; int32_t* bc = nullptr; } O[NSLOT];
     auto drop = [&]() {
         (void)hipStreamSynchronize(io->cs);
@@ -661,33 +679,64 @@ extern "C" int snk_dev_ingest_df_count_graph(snk_ctx* ctx, snk_df_files* f, uint
     };
 #define DF_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { drop(); return snk_fail(_e == hipErrorOutOfMemory ? SNK_E_NOMEM : SNK_E_HIP, err, errcap, "%s failed: %s", #expr, hipGetErrorString(_e)); } } while (0)
     for (auto& o : O) {
-        DF_TRY(hipMalloc((void**)&o.rows, (slab_reads + 1) * row_words * 4ull));
+        if (streamed) DF_TRY(hipMalloc((void**)&o.rows, (slab_reads + 1) * row_words * 4ull));
         DF_TRY(hipMalloc((void**)&o.quals, (slab_reads + 16) * (uint64_t)qstride));
         DF_TRY(hipMalloc((void**)&o.lens, (slab_reads + 8) * 2ull));
-        if (f->have_bci) DF_TRY(hipMalloc((void**)&o.bc, (slab_reads + 2) * 4ull));
+        if (streamed && f->have_bci) DF_TRY(hipMalloc((void**)&o.bc, (slab_reads + 2) * 4ull));
+    }
+    if (!streamed && (io->c_reads < n || io->c_row_words != row_words || (f->have_bci && !io->c_bc))) {
+        SNK_HIP_TRY(hipStreamSynchronize(io->cs));
+        io->release_compact();
+        DF_TRY(hipMalloc((void**)&io->c_rows, (n + 1) * row_words * 4ull));
+        DF_TRY(hipMalloc((void**)&io->c_gl, (n + 8) * 2ull));
+        DF_TRY(hipMalloc((void**)&io->c_bc, (n + 2) * 4ull));
+        io->c_reads = n; io->c_row_words = row_words;
     }
 #undef DF_TRY
-    if ((rc = snk_dev_stream_begin(ctx, p, max_len, n, f->have_bci ? 1 : 0, io->cs, err, errcap))) { drop(); return rc; }
-    const double t_ready = now_s();
     df_stats st;
-    rc = run_slabs(ctx, io, f, first, n, slab_reads, max_len, row_words, qstride,
-                   [&](int s, uint64_t, uint64_t, slab_dev* sd) { sd->rows = O[s].rows; sd->quals = O[s].quals; sd->lens = O[s].lens; sd->bc = O[s].bc; return SNK_OK; },
-                   [&](int, const slab_dev& sd) {
-                       snk_dev_reads slab;
-                       memset(&slab, 0, sizeof slab);
-                       slab.n_reads = sd.n; slab.rows = sd.rows; slab.row_words = row_words; slab.read_len = max_len; slab.lens = sd.lens; slab.quals = sd.quals;
-                       slab.qstride = qstride; slab.bc = sd.bc; slab.ign_bc_below = ign_bc_below; slab.read_index_base = sd.first;
-                       return snk_dev_stream_append(ctx, &slab, io->cs, err, errcap);
-                   },
-                   &st, err, errcap);
-    // a bad file must not reach the count: the flags are read before the job is finished
-    if (!rc) rc = check_errs(io, f, qstride, err, errcap);
-    if (!rc) rc = snk_dev_stream_finish(ctx, res, io->cs, err, errcap);
+    double t_ready;
+    if (streamed) {
+        if ((rc = snk_dev_stream_begin(ctx, p, max_len, n, f->have_bci ? 1 : 0, io->cs, err, errcap))) { drop(); return rc; }
+        t_ready = now_s();
+        rc = run_slabs(ctx, io, f, first, n, slab_reads, max_len, row_words, qstride,
+                       [&](int s, uint64_t, uint64_t, slab_dev* sd) { sd->rows = O[s].rows; sd->quals = O[s].quals; sd->lens = O[s].lens; sd->bc = O[s].bc; return SNK_OK; },
+                       [&](int, const slab_dev& sd) {
+                           snk_dev_reads slab;
+                           memset(&slab, 0, sizeof slab);
+                           slab.n_reads = sd.n; slab.rows = sd.rows; slab.row_words = row_words; slab.read_len = max_len; slab.lens = sd.lens; slab.quals = sd.quals;
+                           slab.qstride = qstride; slab.bc = sd.bc; slab.ign_bc_below = ign_bc_below; slab.read_index_base = sd.first;
+                           return snk_dev_stream_append(ctx, &slab, io->cs, err, errcap);
+                       },
+                       &st, err, errcap);
+        // a bad file must not reach the count: the flags are read before the job is finished
+        if (!rc) rc = check_errs(io, f, qstride, err, errcap);
+        if (!rc) rc = snk_dev_stream_finish(ctx, res, io->cs, err, errcap);
+    } else {
+        t_ready = now_s();
+        rc = run_slabs(ctx, io, f, first, n, slab_reads, max_len, row_words, qstride,
+                       [&](int s, uint64_t at, uint64_t, slab_dev* sd) {
+                           sd->rows = io->c_rows + at * row_words; sd->quals = O[s].quals; sd->lens = O[s].lens; sd->bc = f->have_bci ? io->c_bc + at : nullptr;
+                           return SNK_OK;
+                       },
+                       [&](int, const slab_dev& sd) {      // the slab's quality rows are used here and never again
+                           const int r2 = snk_dev_trim(ctx, sd.quals, qstride, sd.lens, max_len, sd.n, p->K, p->min_qual, io->c_gl + (sd.first - first), io->cs);
+                           return r2 ? snk_fail(r2, err, errcap, "%s", snk_last_error()) : SNK_OK;
+                       },
+                       &st, err, errcap);
+        if (!rc) rc = check_errs(io, f, qstride, err, errcap);
+        if (!rc) {
+            snk_dev_reads in;
+            memset(&in, 0, sizeof in);
+            in.n_reads = n; in.rows = io->c_rows; in.row_words = row_words; in.read_len = max_len; in.good_len = io->c_gl; in.bc = f->have_bci ? io->c_bc : nullptr;
+            in.ign_bc_below = ign_bc_below; in.read_index_base = first;
+            rc = snk_dev_count_graph(ctx, &in, p, res, io->cs, err, errcap);
+        }
+    }
     if (!rc && hipStreamSynchronize(io->cs) != hipSuccess) rc = snk_fail(SNK_E_HIP, err, errcap, "snk_dev_ingest_df_count_graph: the stream failed");
     drop();
     if (rc) return rc;
     out->n_reads = n; out->read_len = max_len; out->row_words = row_words; out->qstride = qstride; out->max_len = max_len;
-    out->text_bytes = st.file_bytes; out->compressed_bytes = st.file_bytes; out->n_files = 3; out->n_batches = st.n_slabs;
+    out->text_bytes = st.file_bytes; out->compressed_bytes = st.file_bytes; out->n_files = streamed ? 3 : 4; out->n_batches = st.n_slabs;
     out->seconds = now_s() - t0; out->decode_wait_seconds = st.wait_io; out->setup_seconds = t_ready - t0;
     return SNK_OK;
 }

@@ -68,6 +68,7 @@ const snk_opt_def snk_opt_defs[] = {
     {"hbv_dev_min", "graphs below this many unitigs take the host id hand-out (65536)"},
     {"hbv_big", "components above this many nodes take the host flood (1024)"},
     {"hbv_strict", "1: fail instead of falling back when the device flood gives up"},
+    {"df_stream", "stage-input files -> unitigs: 2 = through a streamed job (the reads never resident in any form); else the compact resident form (rows + good lengths + barcode ids, the adaptive resident step)"},
     // ---- memory
     {"arena_vmm", "growing virtual-memory arena (1); 0 = cached hipMalloc blocks"},
     // ---- kernel debug modes (results invalid unless stated)

@@ -68,7 +68,9 @@ class DfFiles:
 
     def count_graph(self, engine, params=None, first: int = 0, n: int | None = None, read_len: int = 0, threads: int = 0, slab_reads: int = 0,
                     ign_bc_below: int = 0):
-        """-> (Result, stats): the slabs go straight into a streamed job; bit-identical to a resident call on the same reads."""
+        """-> (Result, stats); bit-identical to a resident call on the same reads.  stats["mode"]: "compact" (default: rows + good lengths +
+        barcode ids stay, the resident step with its pilot / second partition / kernel choice runs on them) or "streamed"
+        (engine.set_option("df_stream", 2): the slabs go straight into a streamed job, the reads are never resident in any form)."""
         from .engine import Params, Result
         params = params or Params()
         n = self.n_reads - first if n is None else n
@@ -76,7 +78,8 @@ class DfFiles:
         _check(self.lib.snk_dev_ingest_df_count_graph(engine._ctx, self._h, first, n, read_len, threads, slab_reads, C.byref(p), ign_bc_below,
                                                       C.byref(res), C.byref(raw), err, 512), err)
         stats = dict(n_reads=int(raw.n_reads), file_bytes=int(raw.text_bytes), seconds=float(raw.seconds), io_wait_seconds=float(raw.decode_wait_seconds),
-                     n_slabs=int(raw.n_batches), max_len=int(raw.max_len), setup_seconds=float(raw.setup_seconds))
+                     n_slabs=int(raw.n_batches), max_len=int(raw.max_len), setup_seconds=float(raw.setup_seconds),
+                     mode="streamed" if int(raw.n_files) == 3 else "compact")
         return Result(engine, res, params.K), stats
 
 

@@ -199,11 +199,23 @@ def test_streamed_count_graph_equals_resident(snk, tmp_path):
             ref = e.count_graph_reads(reads, Params(K=48))
             want = (ref.unitigs(), ref.keys(), ref.counts(), ref.ctx(), ref.spectrum(), ref.good_len())
             dr.close()
-            for slab in (0, 7000):
+            for slab, mode in ((0, 2), (7000, 2), (0, 0), (7000, 0), (5000, 1)):
+                e.set_option("df_stream", mode)                 # 2 streamed, 0 compact, 1 the library's choice
                 res, st = f.count_graph(e, Params(K=48), first=first, n=cnt, slab_reads=slab, ign_bc_below=ign)
+                assert st["mode"] == ("streamed" if mode == 2 else "compact")
                 assert st["n_reads"] == cnt and res.n_reads == cnt and st["n_slabs"] == -(-cnt // (slab or 262144))
                 assert res.unitigs() == want[0] and np.array_equal(res.keys(), want[1]) and np.array_equal(res.counts(), want[2])
                 assert np.array_equal(res.ctx(), want[3]) and np.array_equal(res.spectrum(), want[4]) and np.array_equal(res.good_len(), want[5])
+        e.clear_option("df_stream")
+    e.close()
+    # the default is the compact form (the resident step may partition twice and picks its count kernel); the streamed job on request
+    e = Engine(0)
+    with dfin.DfFiles(head) as f:
+        r1, s1 = f.count_graph(e, Params(K=48))
+        u1 = r1.unitigs()
+        e.set_option("df_stream", 2)
+        r2, s2 = f.count_graph(e, Params(K=48))
+        assert (s1["mode"], s2["mode"]) == ("compact", "streamed") and r2.unitigs() == u1
     e.close()
 
 
