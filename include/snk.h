@@ -577,6 +577,10 @@ void snk_df_close(snk_df_files* f);
 int snk_df_max_len(snk_ctx* ctx, snk_df_files* f, uint64_t first, uint64_t n, uint32_t* max_len, char* err, size_t errcap);
 int snk_dev_ingest_df(snk_ctx* ctx, snk_df_files* f, uint64_t first, uint64_t n, uint32_t read_len, uint32_t threads, uint64_t slab_reads,
                       struct snk_dev_ingest* out, char* err, size_t errcap);
+/* reads [first, first + n) in their compact form: packed rows, GOOD LENGTHS (the trim at K / min_qual runs on every slab as it is decoded, the
+ * quality rows are never resident) and barcode ids: 46 instead of 204 bytes per 150-base read, all that count + graph needs (snk_dev_reads.good_len) */
+int snk_dev_ingest_df_trimmed(snk_ctx* ctx, snk_df_files* f, uint64_t first, uint64_t n, uint32_t read_len, uint32_t threads, uint64_t slab_reads, uint32_t K,
+                              uint32_t min_qual, struct snk_dev_ingest* out, char* err, size_t errcap);
 int snk_dev_ingest_df_count_graph(snk_ctx* ctx, snk_df_files* f, uint64_t first, uint64_t n, uint32_t read_len, uint32_t threads, uint64_t slab_reads,
                                   const snk_params* p, int64_t ign_bc_below, snk_dev_result* res, struct snk_dev_ingest* stats, char* err, size_t errcap);
 /* Writers of the triple (tests, bench.py's df_seam row, tools): feudal/FeudalFileWriter.cc:18-140, PQVec.cc:86-127,
@@ -639,6 +643,7 @@ typedef struct snk_dev_ingest {
     double seconds, decode_wait_seconds;   /* whole call; of it, time the consumer waited for a decoded batch */
     uint32_t n_files, n_batches;
     double setup_seconds;                  /* of `seconds`: page-locked batch pool + device arrays allocated, workers started */
+    const void* good_len;                  /* u16 per read: set by snk_dev_ingest_df_trimmed (quals and lens are NULL there), else NULL */
 } snk_dev_ingest;
 int snk_dev_ingest_fasth(snk_ctx* ctx, const char* const* paths, uint32_t n_files, uint32_t read_len, const snk_bc_index* ix, uint32_t threads,
                          uint32_t batch_pairs, snk_dev_ingest* out, char* err, size_t errcap);

@@ -190,10 +190,12 @@ int main(int argc, char** argv) {
         const uint64_t lo = (n_all / 2 * rank / world) * 2, hi = rank + 1 == world ? n_all : (n_all / 2 * (rank + 1) / world) * 2, n = hi - lo;
         // every rank lays its rows out alike: READ_LEN, or the longest read of the FILE (one scan of its length table, 4 of a read's ~50 bytes)
         const uint32_t read_len = kv.count("READ_LEN") ? (uint32_t)atoi(kv["READ_LEN"].c_str()) : 0u;
-        if ((rc = snk_dev_ingest_df(ctx, files, lo, n, read_len, 0, 0, &ing, err, sizeof err))) fatal(rc, "reads", err);
+        // ... in their compact form: packed rows, good lengths (every slab trimmed as it is decoded, its quality rows dropped), barcode ids --
+        // 46 instead of 204 bytes per read of device memory, and all the step needs
+        if ((rc = snk_dev_ingest_df_trimmed(ctx, files, lo, n, read_len, 0, 0, p.K, p.min_qual, &ing, err, sizeof err))) fatal(rc, "reads", err);
         snk_df_close(files);
-        in.n_reads = ing.n_reads; in.rows = ing.rows; in.row_words = ing.row_words; in.read_len = ing.read_len; in.lens = ing.lens;
-        in.quals = ing.quals; in.qstride = ing.qstride; in.bc = ing.bc;
+        in.n_reads = ing.n_reads; in.rows = ing.rows; in.row_words = ing.row_words; in.read_len = ing.read_len; in.good_len = ing.good_len;
+        in.qstride = ing.qstride; in.bc = ing.bc;
         in.read_index_base = lo;
         fprintf(stderr, "snk_asm_sn[%d/%d]: reads [%llu, %llu) of %llu: %.2f GB of file bytes in %.3f s (%.1f GB/s)\n", rank, world, (unsigned long long)lo,
                 (unsigned long long)hi, (unsigned long long)n_all, ing.text_bytes / 1e9, ing.seconds, ing.text_bytes / 1e9 / (ing.seconds > 0 ? ing.seconds : 1));

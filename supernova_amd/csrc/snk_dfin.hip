@@ -599,6 +599,21 @@ int prepare(snk_ctx* ctx, snk_df_files* f, uint64_t first, uint64_t n, uint32_t 
     return SNK_OK;
 }
 
+// reads [first, first + n) -> their compact form: packed rows, good lengths (a slab's quality rows are trimmed as soon as they are decoded,
+// in the caller's per-slot buffers qb / lb, and never kept), barcode ids
+int decode_compact(snk_ctx* ctx, df_io* io, const snk_df_files* f, uint64_t first, uint64_t n, uint64_t slab_reads, uint32_t max_len, uint32_t row_words, uint32_t qstride,
+                   uint32_t K, uint32_t min_qual, uint8_t* const* qb, uint16_t* const* lb, uint32_t* rows, uint16_t* gl, int32_t* bc, df_stats* st, char* err, size_t errcap) {
+    int rc = run_slabs(ctx, io, f, first, n, slab_reads, max_len, row_words, qstride,
+                       [&](int s, uint64_t at, uint64_t, slab_dev* sd) { sd->rows = rows + at * row_words; sd->quals = qb[s]; sd->lens = lb[s]; sd->bc = bc ? bc + at : nullptr; return SNK_OK; },
+                       [&](int, const slab_dev& sd) {      // the slab's quality rows are used here and never again
+                           const int r2 = snk_dev_trim(ctx, sd.quals, qstride, sd.lens, max_len, sd.n, K, min_qual, gl + (sd.first - first), io->cs);
+                           return r2 ? snk_fail(r2, err, errcap, "%s", snk_last_error()) : SNK_OK;
+                       },
+                       st, err, errcap);
+    if (!rc) rc = check_errs(io, f, qstride, err, errcap);
+    return rc;
+}
+
 }  // namespace
 
 extern "C" int snk_df_max_len(snk_ctx* ctx, snk_df_files* f, uint64_t first, uint64_t n, uint32_t* out, char* err, size_t errcap) {
@@ -640,6 +655,46 @@ extern "C" int snk_dev_ingest_df(snk_ctx* ctx, snk_df_files* f, uint64_t first, 
     if (rc) { drop(); return rc; }
     out->n_reads = n; out->read_len = max_len; out->row_words = row_words; out->qstride = qstride; out->max_len = max_len;
     out->rows = rows; out->quals = quals; out->lens = lens; out->bc = bc;
+    out->text_bytes = st.file_bytes; out->compressed_bytes = st.file_bytes; out->n_files = 3; out->n_batches = st.n_slabs;
+    out->seconds = now_s() - t0; out->decode_wait_seconds = st.wait_io; out->setup_seconds = t_ready - t0;
+    return SNK_OK;
+}
+
+// the same reads in their COMPACT form: packed rows, GOOD LENGTHS (the quality trim at K / min_qual, GoodLenTailFinder BuildReadQGraph48.cc:65-89, run on
+// every slab as it is decoded; the quality rows are never resident) and barcode ids -- 46 instead of 204 bytes per 150-base read, and all the
+// count+graph step needs (snk_dev_reads.good_len).  What a rank of the N-GPU job holds of its share of the stage inputs (snk_asm_sn LR=).
+// out->quals and out->lens stay NULL, out->good_len is set; release with snk_dev_ingest_free.
+extern "C" int snk_dev_ingest_df_trimmed(snk_ctx* ctx, snk_df_files* f, uint64_t first, uint64_t n, uint32_t read_len, uint32_t threads, uint64_t slab_reads, uint32_t K,
+                                         uint32_t min_qual, snk_dev_ingest* out, char* err, size_t errcap) {
+    if (!ctx || !f || !out) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_ingest_df_trimmed: NULL argument");
+    memset(out, 0, sizeof *out);
+    if (K != 48 && K != 60) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "K=%u is not supported (48 or 60)", K);
+    const double t0 = now_s();
+    df_io* io;
+    uint32_t max_len;
+    int rc = prepare(ctx, f, first, n, read_len, threads, &slab_reads, &io, &max_len, err, errcap);
+    if (rc) return rc;
+    const uint32_t row_words = (max_len + 15) / 16, qstride = row_words * 16;
+    uint32_t* rows = nullptr; uint16_t* gl = nullptr; int32_t* bc = nullptr;
+    uint8_t* qb[NSLOT] = {nullptr, nullptr, nullptr}; uint16_t* lb[NSLOT] = {nullptr, nullptr, nullptr};
+    auto drop_slots = [&]() { (void)hipStreamSynchronize(io->cs); for (int q = 0; q < NSLOT; ++q) { (void)hipFree(qb[q]); (void)hipFree(lb[q]); } if (ctx->cur_stream == io->cs) ctx->cur_stream = nullptr; };
+    auto drop = [&]() { drop_slots(); (void)hipFree(rows); (void)hipFree(gl); (void)hipFree(bc); };
+#define DF_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { drop(); return snk_fail(_e == hipErrorOutOfMemory ? SNK_E_NOMEM : SNK_E_HIP, err, errcap, "%s failed: %s", #expr, hipGetErrorString(_e)); } } while (0)
+    DF_TRY(hipMalloc((void**)&rows, (n + 1) * row_words * 4ull));
+    DF_TRY(hipMalloc((void**)&gl, (n + 8) * 2ull));
+    if (f->have_bci) DF_TRY(hipMalloc((void**)&bc, (n + 2) * 4ull));
+    for (int q = 0; q < NSLOT; ++q) {
+        DF_TRY(hipMalloc((void**)&qb[q], (slab_reads + 16) * (uint64_t)qstride));
+        DF_TRY(hipMalloc((void**)&lb[q], (slab_reads + 8) * 2ull));
+    }
+#undef DF_TRY
+    const double t_ready = now_s();
+    df_stats st;
+    rc = decode_compact(ctx, io, f, first, n, slab_reads, max_len, row_words, qstride, K, min_qual, qb, lb, rows, gl, bc, &st, err, errcap);
+    if (rc) { drop(); return rc; }
+    drop_slots();
+    out->n_reads = n; out->read_len = max_len; out->row_words = row_words; out->qstride = qstride; out->max_len = max_len;
+    out->rows = rows; out->good_len = gl; out->bc = bc;
     out->text_bytes = st.file_bytes; out->compressed_bytes = st.file_bytes; out->n_files = 3; out->n_batches = st.n_slabs;
     out->seconds = now_s() - t0; out->decode_wait_seconds = st.wait_io; out->setup_seconds = t_ready - t0;
     return SNK_OK;
@@ -713,17 +768,9 @@ extern "C" int snk_dev_ingest_df_count_graph(snk_ctx* ctx, snk_df_files* f, uint
         if (!rc) rc = snk_dev_stream_finish(ctx, res, io->cs, err, errcap);
     } else {
         t_ready = now_s();
-        rc = run_slabs(ctx, io, f, first, n, slab_reads, max_len, row_words, qstride,
-                       [&](int s, uint64_t at, uint64_t, slab_dev* sd) {
-                           sd->rows = io->c_rows + at * row_words; sd->quals = O[s].quals; sd->lens = O[s].lens; sd->bc = f->have_bci ? io->c_bc + at : nullptr;
-                           return SNK_OK;
-                       },
-                       [&](int, const slab_dev& sd) {      // the slab's quality rows are used here and never again
-                           const int r2 = snk_dev_trim(ctx, sd.quals, qstride, sd.lens, max_len, sd.n, p->K, p->min_qual, io->c_gl + (sd.first - first), io->cs);
-                           return r2 ? snk_fail(r2, err, errcap, "%s", snk_last_error()) : SNK_OK;
-                       },
-                       &st, err, errcap);
-        if (!rc) rc = check_errs(io, f, qstride, err, errcap);
+        uint8_t* qb[NSLOT]; uint16_t* lb[NSLOT];
+        for (int q = 0; q < NSLOT; ++q) { qb[q] = O[q].quals; lb[q] = O[q].lens; }
+        rc = decode_compact(ctx, io, f, first, n, slab_reads, max_len, row_words, qstride, p->K, p->min_qual, qb, lb, io->c_rows, io->c_gl, f->have_bci ? io->c_bc : nullptr, &st, err, errcap);
         if (!rc) {
             snk_dev_reads in;
             memset(&in, 0, sizeof in);

@@ -780,6 +780,6 @@ extern "C" int snk_dev_ingest_count_graph(snk_ctx* ctx, const char* const* paths
 
 extern "C" void snk_dev_ingest_free(snk_dev_ingest* r) {
     if (!r) return;
-    (void)hipFree((void*)r->rows); (void)hipFree((void*)r->quals); (void)hipFree((void*)r->lens); (void)hipFree((void*)r->bc);
-    r->rows = r->quals = r->lens = r->bc = nullptr;
+    (void)hipFree((void*)r->rows); (void)hipFree((void*)r->quals); (void)hipFree((void*)r->lens); (void)hipFree((void*)r->bc); (void)hipFree((void*)r->good_len);
+    r->rows = r->quals = r->lens = r->bc = r->good_len = nullptr;
 }

@@ -66,6 +66,14 @@ class DfFiles:
         _check(self.lib.snk_dev_ingest_df(engine._ctx, self._h, first, n, read_len, threads, slab_reads, C.byref(raw), err, 512), err)
         return DeviceReads(self.lib, raw)
 
+    def ingest_trimmed(self, engine, K: int = 48, min_qual: int = 7, first: int = 0, n: int | None = None, read_len: int = 0, threads: int = 0,
+                       slab_reads: int = 0) -> DeviceReads:
+        """The compact form (snk_dev_ingest_df_trimmed): packed rows, good lengths, barcode ids -- no quality rows, no lengths."""
+        n = self.n_reads - first if n is None else n
+        raw, err = _lib.SnkDevIngest(), _err()
+        _check(self.lib.snk_dev_ingest_df_trimmed(engine._ctx, self._h, first, n, read_len, threads, slab_reads, K, min_qual, C.byref(raw), err, 512), err)
+        return DeviceReads(self.lib, raw)
+
     def count_graph(self, engine, params=None, first: int = 0, n: int | None = None, read_len: int = 0, threads: int = 0, slab_reads: int = 0,
                     ign_bc_below: int = 0):
         """-> (Result, stats); bit-identical to a resident call on the same reads.  stats["mode"]: "compact" (default: rows + good lengths +

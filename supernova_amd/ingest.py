@@ -61,6 +61,8 @@ class DeviceReads:
         r = _lib.SnkDevReads()
         r.n_reads, r.rows, r.row_words, r.read_len = self.n_reads, self.raw.rows, self.raw.row_words, self.read_len
         r.lens, r.quals, r.qstride = self.raw.lens, self.raw.quals, self.raw.qstride
+        if self.raw.good_len:                       # the compact form of snk_dev_ingest_df_trimmed: no quality rows, the trim is done
+            r.good_len = self.raw.good_len
         if with_bc and self.raw.bc:
             r.bc = self.raw.bc
         return r

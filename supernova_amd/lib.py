@@ -97,7 +97,7 @@ class SnkDevIngest(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("read_len", C.c_uint32), ("row_words", C.c_uint32), ("qstride", C.c_uint32),
                 ("max_len", C.c_uint32), ("rows", C.c_void_p), ("quals", C.c_void_p), ("lens", C.c_void_p), ("bc", C.c_void_p),
                 ("text_bytes", C.c_uint64), ("compressed_bytes", C.c_uint64), ("seconds", C.c_double),
-                ("decode_wait_seconds", C.c_double), ("n_files", C.c_uint32), ("n_batches", C.c_uint32), ("setup_seconds", C.c_double)]
+                ("decode_wait_seconds", C.c_double), ("n_files", C.c_uint32), ("n_batches", C.c_uint32), ("setup_seconds", C.c_double), ("good_len", C.c_void_p)]
 
 
 class SnkTuning(C.Structure):
@@ -244,6 +244,7 @@ def _declare(lib: C.CDLL) -> None:
         "snk_df_close": (None, [vp]),
         "snk_df_max_len": (C.c_int, [vp, vp, u64, u64, P(u32), cp, sz]),
         "snk_dev_ingest_df": (C.c_int, [vp, vp, u64, u64, u32, u32, u64, P(SnkDevIngest), cp, sz]),
+        "snk_dev_ingest_df_trimmed": (C.c_int, [vp, vp, u64, u64, u32, u32, u64, u32, u32, P(SnkDevIngest), cp, sz]),
         "snk_dev_ingest_df_count_graph": (C.c_int, [vp, vp, u64, u64, u32, u32, u64, P(SnkParams), C.c_int64, P(SnkDevResult), P(SnkDevIngest), cp, sz]),
         "snk_write_df": (C.c_int, [cp, u64, vp, u32, vp, u32, vp, u32, vp, u32, u64, cp, sz]),
         "snk_synth_df_write": (C.c_int, [cp, P(SnkSynthParams), u64, u64, u32, u32, cp, sz]),

@@ -414,3 +414,39 @@ def test_long_reads_250(snk, tmp_path):
         res, st = f.count_graph(e, Params(K=48), slab_reads=9000)
         assert res.unitigs() == want[0] and np.array_equal(res.keys(), want[1]) and np.array_equal(res.counts(), want[2]) and np.array_equal(res.ctx(), want[3])
     e.close()
+
+
+def test_trimmed_compact_form(snk, tmp_path):
+    """snk_dev_ingest_df_trimmed: rows and barcode ids as the full decode's, good lengths == the trim of the full decode's quality rows (and the
+    oracle's GoodLenTailFinder restatement), no quality rows on the device; count+graph on the compact form == on the full form; rank slices."""
+    import oracle_lib
+    from supernova_amd import dfin
+    from supernova_amd.engine import Engine, Params
+    rows, lens, q, bc = _random_triple(30_011, 41)
+    q[:, :] = np.where(np.random.default_rng(3).random(q.shape) < 0.04, 3, np.maximum(q, 8))        # a few low qualities, everything else above min_qual
+    q[np.arange(150)[None, :] >= lens[:, None]] = 0
+    head = tmp_path / "t"
+    dfin.write_df(head, rows, q, bc, lens=lens, read_len=150)
+    e = Engine(0)
+    with dfin.DfFiles(head) as f:
+        n = f.n_reads
+        for K in (48, 60):
+            want_gl = oracle_lib.good_lens(q, lens, K=K) if "K" in oracle_lib.good_lens.__code__.co_varnames else None
+            for first, cnt, slab in ((0, n, 0), (10_001, 9_999, 1234)):
+                dr = f.ingest_trimmed(e, K=K, min_qual=7, first=first, n=cnt, slab_reads=slab)
+                assert not dr.raw.quals and not dr.raw.lens and dr.raw.good_len
+                got_rows = _dl(e, dr.raw.rows, (cnt, int(dr.raw.row_words)), np.uint32)
+                got_gl = _dl(e, dr.raw.good_len, (cnt,), np.uint16)
+                got_bc = _dl(e, dr.raw.bc, (cnt,), np.int32)
+                assert np.array_equal(got_rows, rows[first:first + cnt]) and np.array_equal(got_bc, bc[first:first + cnt])
+                full = f.ingest(e, first=first, n=cnt)
+                r_full = e.count_graph_reads(full.dev_reads(), Params(K=K))
+                assert np.array_equal(got_gl, r_full.good_len())
+                if want_gl is not None:
+                    assert np.array_equal(got_gl.astype(np.uint32), want_gl[first:first + cnt])
+                u_full, k_full = r_full.unitigs(), r_full.keys()
+                full.close()
+                r_c = e.count_graph_reads(dr.dev_reads(), Params(K=K))
+                assert r_c.unitigs() == u_full and np.array_equal(r_c.keys(), k_full)
+                dr.close()
+    e.close()
