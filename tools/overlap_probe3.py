@@ -18,7 +18,8 @@ P = Params(K=48, sorted_table=False)
 for _ in range(3):
     r = e.count_graph(rows, sp.read_len, quals=quals, bc=bc, params=P)
 print("baseline phases", r.phase_ms, "kernels", r.kernel_ms, flush=True)
-for mode, dbg in ((2, 20), (1, 20), (2, 24), (1, 24), (5, 24), (2, 32), (1, 32), (2, 48), (1, 48)):
+VARIANTS = ((2, 17), (1, 17), (2, 18), (1, 18), (2, 20), (1, 20)) if len(sys.argv) > 2 and sys.argv[2] == 'throttled' else ((2, 20), (1, 20), (2, 24), (1, 24), (5, 24), (2, 32), (1, 32), (2, 48), (1, 48))
+for mode, dbg in VARIANTS:
     e.set_option("overlap_probe", int(mode))
     e.set_option("overlap_probe_dbg", int(dbg))
     print(f"--- SNK_OVERLAP_PROBE={mode} (2 alone, 1 next to the count kernel, 5 = 1 with a high-priority stream) lean emitter dbg={dbg}", flush=True)
