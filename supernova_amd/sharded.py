@@ -506,6 +506,19 @@ class ShardedEngine:
             raise _lib.SnkError(rc, err.value.decode(errors="replace"))
         return ShardedResult(e, params.K, raw)
 
+    def count_graph_reads(self, r: "_lib.SnkDevReads", params: Params | None = None, total_reads: int = 0) -> ShardedResult:
+        """The same step for reads described by plain device pointers (e.g. a rank's share of the ASSEMBLER_DF stage inputs in the compact
+        form of snk_dev_ingest_df_trimmed: rows, good lengths, barcode ids; r.read_index_base = global index of the rank's first read)."""
+        e, lib = self.eng, self.lib
+        params = params or Params()
+        err = C.create_string_buffer(512)
+        p = params.to_c()
+        raw = _lib.SnkShardResult()
+        rc = lib.snk_shard_step(e._ctx, self.comm, C.byref(r), C.byref(p), int(total_reads), 0, C.byref(raw), e._stream(), err, 512)
+        if rc != 0:
+            raise _lib.SnkError(rc, err.value.decode(errors="replace"))
+        return ShardedResult(e, params.K, raw)
+
     def count_graph_streamed(self, slabs, read_len, total_reads: int, rank_reads_ub: int, params: Params | None = None, ign_bc_below: int = 0) -> ShardedResult:
         """The same step with this rank's reads arriving slab by slab (snk_shard_stream_*): `slabs` yields dicts with rows, quals / good_len,
         optional lens, bc, and read_index_base (global index of the slab's first read); total_reads = reads of the whole job (every rank

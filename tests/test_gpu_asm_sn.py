@@ -184,3 +184,59 @@ def test_bench_self_launches_its_ranks(extra):
         assert d["config"]["path"] == "grouped-replicas"
     else:
         assert d["config"]["sharded_self_check"] == "passed" and d["config"]["multi_gpu"]["rccl_ranks"] == 2
+
+
+@pytest.mark.parametrize("W", [2, 3])
+def test_ranks_decode_their_own_byte_ranges_of_the_stage_inputs(snk, W):
+    """The N-GPU job at the ASSEMBLER_DF seam, as in-process ranks on one GPU: every rank decodes ITS reads' byte ranges of reads.fastb /
+    .qualp / .bci on the device into the compact form (snk_dev_ingest_df_trimmed: rows, good lengths, barcode ids) and runs snk_shard_step on
+    it; the gathered unitigs are the reference's (the files are the reference's writers' own, tests/golden/formats)."""
+    import ctypes as C
+    import torch
+    from supernova_amd import dfin, graphio, lib as _lib
+    from supernova_amd.engine import Engine, Params
+    from supernova_amd.sharded import ShardedEngine, SimWorld
+    c = goldens.load("synth_2k_err")
+    fmt = ROOT / "tests" / "golden" / "formats" / "reads"
+    world = SimWorld(W)
+    n = 2000
+    bounds = [(n // 2 * r // W) * 2 for r in range(W)] + [n]
+    got, errs = {}, []
+
+    def worker(r):
+        try:
+            torch.cuda.set_device(0)
+            e = Engine(0)
+            lo, hi = bounds[r], bounds[r + 1]
+            with dfin.DfFiles(fmt) as f:
+                dr = f.ingest_trimmed(e, K=48, min_qual=7, first=lo, n=hi - lo, read_len=150, slab_reads=200)
+            reads = dr.dev_reads()
+            assert reads.good_len and not reads.quals
+            reads.read_index_base = lo
+            sh = ShardedEngine(e, world.comm(r))
+            res = sh.count_graph_reads(reads, Params(K=48), total_reads=n)
+            out = _lib.SnkResult()
+            err = C.create_string_buffer(512)
+            rc = e.lib.snk_shard_gather_unitigs(e._ctx, sh.comm, C.byref(res.raw), 48, 0, 0, C.byref(out), e._stream(), err, 512)
+            assert rc == 0, err.value
+            if r == 0:
+                nu = int(out.n_unitigs)
+                off = np.ctypeslib.as_array(out.unitig_off, shape=(nu + 1,)).copy()
+                bases = np.ctypeslib.as_array(out.unitig_bases, shape=(max(int(off[-1]), 1),))[:int(off[-1])].copy()
+                got["unitigs"] = graphio.arrays_to_unitigs(off, bases)
+            e.lib.snk_free(C.byref(out))
+            sh.close()
+            dr.close()
+            e.close()
+        except BaseException as ex:  # noqa: BLE001
+            errs.append(ex)
+            world.barrier_obj.abort()
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(W)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if errs:
+        raise errs[0]
+    assert sorted(got["unitigs"]) == sorted(c.exp_unitigs)
