@@ -27,6 +27,7 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -354,12 +355,14 @@ namespace {
 
 int io_of(snk_ctx* ctx, df_io** out, char* err, size_t errcap) {
     if (!ctx->df_io) {
-        df_io* io = new df_io();
-        ctx->df_io = io;
-        ctx->df_io_free = [](void* p) { delete static_cast<df_io*>(p); };
+        // built in a local owner and published only when every resource exists (a half-made ring must not be what the next call finds)
+        std::unique_ptr<df_io> own(new df_io());
+        df_io* io = own.get();
         SNK_HIP_TRY(hipStreamCreateWithFlags(&io->cs, hipStreamNonBlocking));
         for (int s = 0; s < NSLOT; ++s) SNK_HIP_TRY(hipEventCreateWithFlags(&io->used[s], hipEventDisableTiming));
         SNK_HIP_TRY(hipMalloc((void**)&io->d_errs, 64));
+        ctx->df_io = own.release();
+        ctx->df_io_free = [](void* p) { delete static_cast<df_io*>(p); };
     }
     *out = static_cast<df_io*>(ctx->df_io);
     return SNK_OK;
