@@ -374,13 +374,15 @@ struct slab_layout {        // byte offsets of the sections inside a slot (all 1
 slab_layout layout_for(uint64_t cap, uint32_t max_len) {
     slab_layout L;
     uint64_t at = 0;
+    // the three tables, then the packed bases, then -- right behind the bases a slab really has -- the quality bytes: what goes up is ONE
+    // contiguous range of the slot per slab (five copies of 1-19 MB each before: ~15 % of the ingest was their set-up and the short ones' rate)
     L.foffs = at; at = align16(at + (cap + 1) * 8);
     L.flens = at; at = align16(at + cap * 4);
+    L.qoffs = at; at = align16(at + (cap + 1) * 8);
     L.fdata_cap = cap * ((max_len + 3) / 4 + 1) + 64;
     L.fdata = at; at = align16(at + L.fdata_cap + 16);
-    L.qoffs = at; at = align16(at + (cap + 1) * 8);
     L.qdata_cap = cap * QUAL_BYTES_PER_READ + 4096;
-    L.qdata = at; at = align16(at + L.qdata_cap + 16);
+    L.qdata = at; at = align16(at + L.qdata_cap + 16);      // (the latest place the quality bytes may start: a slab's own start is qdata_at())
     L.end = at;
     return L;
 }
@@ -519,8 +521,9 @@ int run_slabs(snk_ctx* ctx, df_io* io, const snk_df_files* f, uint64_t first, ui
                 SNK_HIP_TRY(hipEventRecord(io->used[s], cs));
                 SNK_HIP_TRY(hipEventSynchronize(io->used[s]));
             }
+            const uint64_t qat = align16(L.fdata + (f1 - f0) + 16);            // this piece's quality bytes start right behind its bases
             io->pool->read(f->fb.fd, f0, io->pin[s] + L.fdata, f1 - f0, &left_data[s], &failed);
-            io->pool->read(f->qp.fd, q0, io->pin[s] + L.qdata, q1 - q0, &left_data[s], &failed);
+            io->pool->read(f->qp.fd, q0, io->pin[s] + qat, q1 - q0, &left_data[s], &failed);
             // the next slab's offset tables ride along (its slot must be free of the device first)
             if (done == 0 && k + 1 < n_slabs) { if ((rc = wait_slot((int)((k + 1) % NSLOT)))) return rc; fetch_offs(k + 1); }
             t0 = now_s();
@@ -530,13 +533,20 @@ int run_slabs(snk_ctx* ctx, df_io* io, const snk_df_files* f, uint64_t first, ui
             // ---- up and through the kernels
             uint8_t* P = io->pin[s];
             uint8_t* D = io->dev[s];
+#ifdef SNK_DF_MULTI_COPY      // (A/B of the single copy, tuning builds)
             if (done == 0) {
                 SNK_HIP_TRY(hipMemcpyAsync(D + L.foffs, P + L.foffs, (c + 1) * 8, hipMemcpyHostToDevice, cs));
                 SNK_HIP_TRY(hipMemcpyAsync(D + L.flens, P + L.flens, c * 4, hipMemcpyHostToDevice, cs));
                 SNK_HIP_TRY(hipMemcpyAsync(D + L.qoffs, P + L.qoffs, (c + 1) * 8, hipMemcpyHostToDevice, cs));
             }
             if (f1 > f0) SNK_HIP_TRY(hipMemcpyAsync(D + L.fdata, P + L.fdata, f1 - f0, hipMemcpyHostToDevice, cs));
-            if (q1 > q0) SNK_HIP_TRY(hipMemcpyAsync(D + L.qdata, P + L.qdata, q1 - q0, hipMemcpyHostToDevice, cs));
+            if (q1 > q0) SNK_HIP_TRY(hipMemcpyAsync(D + qat, P + qat, q1 - q0 + 16, hipMemcpyHostToDevice, cs));
+#else
+            {   // one copy: from the tables (first piece) or from the bases (later pieces of a split slab) to the end of the quality bytes
+                const uint64_t from = done == 0 ? 0 : L.fdata, to = qat + (q1 - q0) + 16;
+                SNK_HIP_TRY(hipMemcpyAsync(D + from, P + from, to - from, hipMemcpyHostToDevice, cs));
+            }
+#endif
             slab_dev sd;
             if ((rc = target(s, a - first + done, take, &sd))) return rc;
             sd.first = a + done; sd.n = take;
@@ -545,7 +555,7 @@ int run_slabs(snk_ctx* ctx, df_io* io, const snk_df_files* f, uint64_t first, ui
                                reinterpret_cast<const uint32_t*>(D + L.flens) + done, reinterpret_cast<const uint32_t*>(D + L.fdata), f0, f1 - f0, take, row_words,
                                max_len, sd.first, sd.rows, sd.lens, io->d_errs);
             hipLaunchKernelGGL((df_quals_kernel<16>), dim3((unsigned)((take + 15) / 16)), dim3(256), 16 * qstride, cs, reinterpret_cast<const uint64_t*>(D + L.qoffs) + done,
-                               D + L.qdata, q0, q1 - q0, take, qstride, sd.first, sd.quals, io->d_errs);
+                               D + qat, q0, q1 - q0, take, qstride, sd.first, sd.quals, io->d_errs);
             if (sd.bc) hipLaunchKernelGGL(df_bc_kernel, dim3((unsigned)((take + 255) / 256)), dim3(256), 0, cs, io->d_bci, m_bci, sd.first, take, sd.bc);
             SNK_HIP_TRY(hipGetLastError());
             if ((rc = consume(s, sd))) return rc;
