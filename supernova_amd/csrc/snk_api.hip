@@ -85,6 +85,7 @@ extern "C" int snk_ctx_create(int device, snk_ctx** out, char* err, size_t errca
     c->device = device;
     c->n_cu = prop.multiProcessorCount;
     c->device_mem_total = (uint64_t)prop.totalGlobalMem;
+    c->plan_mem = c->device_mem_total;
     hipError_t se = hipStreamCreate(&c->stream);   // blocking stream: ordered after work on the legacy default stream
     if (se != hipSuccess) {
         delete c;
@@ -427,6 +428,17 @@ extern "C" void snk_ctx_trim(snk_ctx* ctx) {
     (void)snk_enter(ctx);
     (void)hipDeviceSynchronize();
     snk_ctx_trim_cache(ctx);
+}
+void snk_ctx_plan_mem(snk_ctx* ctx) {
+    // what this context can count on: the device's free memory and what its own arena holds (all of it free at the start of a call).  In
+    // steps of 8 GB so that the plans of a job do not move with a few MB of somebody's allocations; never more than the device
+    size_t fr = 0, tot = 0;
+    ctx->plan_mem = ctx->device_mem_total;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return; }
+    uint64_t avail = (uint64_t)fr + (uint64_t)ctx->cached_bytes;      // (cached_bytes: the arena's mapped chunks and the plain blocks)
+    avail &= ~((8ull << 30) - 1);
+    if (avail < (8ull << 30)) avail = 8ull << 30;
+    if (avail < ctx->plan_mem) ctx->plan_mem = avail;
 }
 void snk_ctx_trim_cache(snk_ctx* ctx) {
     if (ctx->va_state > 0) {

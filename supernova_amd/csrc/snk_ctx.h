@@ -18,6 +18,8 @@ struct snk_ctx {
     int n_cu = 256;
     size_t lds_per_block = 65536;
     uint64_t device_mem_total = 0;   // HBM of the device (sizing decisions that must not depend on what happens to be free)
+    uint64_t plan_mem = 0;           // ... minus what is not this context's to use -- the caller's reads, other contexts -- in whole 8-GB steps, looked at
+                                     //     at the start of a resident call (snk_ctx_plan_mem): what the slot / pass / region plans of a large job divide
     // caching arena for call-scoped scratch: blocks are handed out by best fit, returned to the cache at the
     // start of the next top-level call (no hipFree/hipMalloc in steady state), released on destroy or OOM
     struct block { void* p; size_t bytes; bool used; uint64_t serial = 0; uint64_t epoch = 0; };
@@ -105,5 +107,6 @@ void snk_ctx_release_block(snk_ctx* ctx, const void* p);   // return one block t
 // return every block handed out after `mark` (= ctx->alloc_serial at the call's entry) except the ones in keep[0..n_keep)
 void snk_ctx_release_since(snk_ctx* ctx, uint64_t mark, const void* const* keep, size_t n_keep);
 void snk_ctx_trim_cache(snk_ctx* ctx);        // hipFree every unused cached block
+void snk_ctx_plan_mem(snk_ctx* ctx);          // ctx->plan_mem from the device's free memory + what the arena already holds (call it with the arena released)
 void snk_shard_state_free(void* p);
 void snk_shard_state_invalidate_job(void* p);   // an open streamed step dies with the arena it lives in (snk_ctx_release_scratch)

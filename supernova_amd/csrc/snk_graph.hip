@@ -1202,8 +1202,9 @@ __global__ void __launch_bounds__(256) jemit_kernel(uint64_t F, const uint64_t* 
                                                     const uint32_t* __restrict__ pl_pid, const unsigned long long* __restrict__ pl_koff,
                                                     const uint32_t* __restrict__ nk, const uint64_t* __restrict__ poff, uint32_t pid_base,
                                                     uint32_t K, uint8_t* __restrict__ prov) {
-    const uint64_t f = (uint64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
-    if (f >= F) return;
+    // (a grid-stride loop: eight lanes per fragment are more work items than one launch may have -- 2^32 -- from 2^29 fragments on, and such a
+    // launch is cut short without an error: found at 750 M reads on one GPU, tools/r6_full_job.py)
+    for (uint64_t f = (uint64_t)blockIdx.x * 32 + (threadIdx.x >> 3); f < F; f += (uint64_t)gridDim.x * 32) {
     const uint32_t sub = threadIdx.x & 7u;
     const unsigned long long ko = pl_koff[f];
     const bool rc = (ko & PL_RC) != 0;                  // dst[p] = src[len - 1 - p] ^ 3
@@ -1226,6 +1227,7 @@ __global__ void __launch_bounds__(256) jemit_kernel(uint64_t F, const uint64_t* 
     }
     const uint32_t t0 = head + 4 * ndw;
     if (sub < len - t0) { const uint32_t q = t0 + sub; dst[q] = rc ? (uint8_t)(src[len - 1 - q] ^ 3u) : src[q]; }
+    }
 }
 // canonical form of every unitig (dna/CanonicalForm.h:35-48) decided on the provisional sequence
 __global__ void __launch_bounds__(TB) jform_kernel(const uint64_t* __restrict__ uoff, uint64_t U, const uint8_t* __restrict__ prov,
@@ -1495,6 +1497,24 @@ int snk_join_place(snk_ctx* ctx, hipStream_t st, const uint2* rk, const uint32_t
     return SNK_OK;
 }
 
+// debugging aid (option join_dbg): bases outside 0..3 in a unitig buffer = bytes no fragment / copy wrote (the buffer is pre-filled with 0xEE)
+__global__ void __launch_bounds__(256) jdbg_count_kernel(const uint8_t* __restrict__ b, uint64_t n, unsigned long long* __restrict__ out) {
+    unsigned long long c = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) c += b[i] > 3 ? 1ull : 0ull;
+    if (c) atomicAdd(out, c);
+}
+static int jdbg_count(snk_ctx* ctx, hipStream_t st, const char* what, const uint8_t* b, uint64_t n, char* err, size_t errcap) {
+    unsigned long long* d;
+    G_ALLOC(d, unsigned long long, 1);
+    SNK_HIP_TRY(hipMemsetAsync(d, 0, 8, st));
+    hipLaunchKernelGGL(jdbg_count_kernel, dim3(4096), dim3(256), 0, st, b, n, d);
+    unsigned long long h = 0;
+    SNK_HIP_TRY(hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, st));
+    SNK_HIP_TRY(snk_sync(st));
+    fprintf(stderr, "[snk join dbg] %s: %llu of %llu bytes are not bases\n", what, h, (unsigned long long)n);
+    return SNK_OK;
+}
+
 // Emission of the unitigs whose head fragment is among the F fragments given (one-GPU runs: all of them; sharded runs:
 // the fragments routed to this rank, the owner of their unitig's head): heads -> offsets, every fragment copied into
 // place, circles rotated to the reference's cut, canonical orientation, deterministic order.
@@ -1536,10 +1556,13 @@ int snk_join_emit(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
     if (fgroup) G_ALLOC(ugroup, uint32_t, U + 1);
     G_ALLOC(prov, uint8_t, h_tot + 1);
     G_ALLOC(final_bases, uint8_t, h_tot + 1);
+    const bool jdbg = snk_opt_u32("join_dbg", 0) != 0;
+    if (jdbg) { SNK_HIP_TRY(hipMemsetAsync(prov, 0xEE, h_tot + 1, st)); SNK_HIP_TRY(hipMemsetAsync(final_bases, 0xEE, h_tot + 1, st)); fprintf(stderr, "[snk join dbg] F %llu unitigs %llu bases %llu\n", (unsigned long long)F, (unsigned long long)U, (unsigned long long)h_tot); }
     hipLaunchKernelGGL(jhead_place_kernel, dim3(nblk(F)), dim3(TB), 0, st, pl_pid, pl_circ, hflag, hidx, hoff, F, pid_base, poff, uoff, ucirc, fgroup, ugroup);
     SNK_HIP_TRY(hipMemcpyAsync(uoff + U, hoff + F, 8, hipMemcpyDeviceToDevice, st));
     // copy every fragment into place
-    hipLaunchKernelGGL(jemit_kernel, dim3((unsigned)((F + 31) / 32)), dim3(256), 0, st, F, boff, fbases, pl_pid, pl_koff, nk, poff, pid_base, K, prov);
+    hipLaunchKernelGGL(jemit_kernel, dim3((unsigned)std::min<uint64_t>((F + 31) / 32, 1ull << std::min(22u, snk_opt_u32("emit_grid_log2", 22)))), dim3(256), 0, st, F, boff, fbases, pl_pid, pl_koff, nk, poff, pid_base, K, prov);
+    if (jdbg && (rc = jdbg_count(ctx, st, "provisional bases after the fragments' copies", prov, h_tot, err, errcap))) return rc;
     // circles that were cut at an arbitrary fragment boundary: rotate to the reference's cut (minimum k-mer, forward)
     {
         uint32_t *clist, *ccnt;
@@ -1561,6 +1584,7 @@ int snk_join_emit(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
     if ((rc = chunk_owners(ctx, st, unch, U, &uchoff, &uowner, &utotal, err, errcap, chunks_ub))) return rc;
     if (utotal) hipLaunchKernelGGL(jfinal_kernel, dim3(utotal), dim3(256), 0, st, uoff, uowner, uchoff, urev, prov, final_bases);
     SNK_HIP_TRY(hipGetLastError());
+    if (jdbg && (rc = jdbg_count(ctx, st, "oriented bases", final_bases, h_tot, err, errcap))) return rc;
     // deterministic order (fragment ids depend on the order in which workgroups reserved their output)
     uint64_t* noff = uoff;
     uint8_t* obases = final_bases;
@@ -1595,8 +1619,10 @@ int snk_join_emit(snk_ctx* ctx, hipStream_t st, uint32_t K, uint64_t F, const ui
         SNK_HIP_TRY(hipMemsetAsync(onch + U, 0, 4, st));
         hipLaunchKernelGGL(jchunks_kernel, dim3(nblk(U)), dim3(TB), 0, st, noff, U, onch);
         if ((rc = chunk_owners(ctx, st, onch, U, &ochoff, &oowner, &ototal, err, errcap, chunks_ub))) return rc;
+        if (jdbg) SNK_HIP_TRY(hipMemsetAsync(obases, 0xEE, h_tot + 1, st));
         if (ototal) hipLaunchKernelGGL(jorder_copy_kernel, dim3(ototal), dim3(256), 0, st, oowner, ochoff, noff, uoff, oi_out, final_bases, ucirc, obases, ocirc, (const uint32_t*)ugroup, ogroup);
         SNK_HIP_TRY(hipGetLastError());
+        if (jdbg && (rc = jdbg_count(ctx, st, "ordered bases", obases, h_tot, err, errcap))) return rc;
     }
     // nothing is waited for here: the unitigs are stream-ordered results, the step's closing wait is the caller's
     out->n_unitigs = U;

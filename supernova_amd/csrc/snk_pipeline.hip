@@ -138,6 +138,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     ctx->cur_stream = st;
     ctx->arena_legacy = false;
     snk_ctx_release_scratch(ctx);
+    snk_ctx_plan_mem(ctx);
     memset(out, 0, sizeof *out);
     const uint32_t K = p->K;
     const uint64_t n_reads = in->n_reads;
@@ -292,7 +293,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
         if (NB == 0) {
             const uint32_t target = target_for(adaptive ? ratio : 0.0);
             uint64_t nb = (ub_inst + target - 1) / target;
-            const uint64_t nb_max = grouped ? (1ull << 24) : (1ull << 23);
+            const uint64_t nb_max = 1ull << 24;      // (2^23 until round 6: at 800 M reads that is 9700 instances per bucket, a third of the buckets split)
             if (nb < 1) nb = 1;
             if (nb > nb_max) nb = nb_max;
             NB = (uint32_t)nb;
@@ -318,6 +319,11 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
             std::vector<snk_hot> pass_hots;
             PS.hots = &pass_hots;
             snk_count_ranges rgs{n_passes, PS.bounds, snk_partition_passes_run, &PS, true, &pass_hots};
+            rgs.finished = [](void* u) {
+                snk_partition_passes* S = static_cast<snk_partition_passes*>(u);
+                snk_ctx_release_block(S->ctx, S->records); S->records = nullptr;
+                snk_ctx_release_block(S->ctx, S->ovf_bucket); S->ovf_bucket = nullptr;
+            };
             rc = snk_stage_count_table(ctx, st, K, PS.records, PS.seg, PS.seg + NB, 2 * NB, 2u, NB, p->min_freq, (in->bc && !grouped) ? p->min_bc : 0u, grouped ? 1u : 0u,
                                        ub_inst, status, !local_graph, &tab, err, errcap, &rgs, nullptr, nullptr, local_graph, nullptr);
             if (rc) return rc;

@@ -61,6 +61,9 @@ struct snk_count_ranges {
     bool replay = false;
     // hot minimiser buckets the hook found and expanded in its ranges (bucket-range passes): counted behind the ranged launches, like `hot`
     const std::vector<snk_hot>* hots = nullptr;
+    // the counting is over and will not be repeated (the regions held everything): the hook's record slots can go back to the arena before the
+    // dense table is asked for -- a job in passes is short of exactly that memory
+    void (*finished)(void* user) = nullptr;
 };
 // pilot: the first 1/64 of the buckets is counted first; if their tables overflow as a rule (more distinct k-mers than the LDS
 // table holds: error-rich reads, shallow coverage) the stage stops there, leaves the distinct k-mers per bucket it saw in

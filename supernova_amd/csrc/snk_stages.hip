@@ -32,7 +32,12 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
     uint32_t n_regions = 1;
     if ((rc = snk_count_regions(K, grouped, nseg, NB, bc_mode, &n_regions, err, errcap))) return rc;
     uint64_t est = n_inst_hint / (min_freq > 1 ? 12 : 1) + 4096;     // first call only; a wrong guess costs one re-run
-    if (ctx->last_n_kmers && ctx->last_n_instances == n_inst_hint) est = ctx->last_n_kmers + ctx->last_n_kmers / 2 + 4096;
+    // A job in bucket-range passes is short of memory, and instances / 12 are 2 bytes per instance it may not have (deep coverage retains 1 in 38):
+    // it starts from 1 in 40 and lets its first range say what the data retain (`range0_probe` below: one repeated range when that is more)
+    const bool tight = ranges && ranges->n > 1 && ranges->replay && min_freq > 1 && ctx->plan_mem && (double)est * 24.0 > 0.10 * (double)ctx->plan_mem;
+    if (tight) est = n_inst_hint / 40 + 4096;
+    if (ctx->last_n_kmers && ctx->last_n_instances == n_inst_hint) est = ctx->last_n_kmers + ctx->last_n_kmers / (tight ? 8 : 2) + 4096;
+    bool range0_probe = tight && !(ctx->last_n_kmers && ctx->last_n_instances == n_inst_hint);
     uint64_t region_cap = est / n_regions + 64;
     // (a sparse, clustered output -- per-barcode groups at min_freq 4: 155 survivors per region on average, several hundred in some -- overflowed
     // the average-based capacity in EVERY call and the count kernel ran twice, 127 instead of 64 ms: the fullest region of the last call counts too)
@@ -161,6 +166,19 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
                     cr.bucket0 += NBp;
                 }
                 if (cr.bucket0 < cr.NB && (rc = snk_launch_count(K, st, cr, err, errcap))) return rc;
+                if (r == 0 && range0_probe) {
+                    // every region has taken its share of range 0 (a workgroup's buckets are spread over all ranges): what the fullest holds
+                    // now, times the ranges, is what it will hold -- 15 % on top; larger regions and range 0 once more if that is more than the guess
+                    range0_probe = false;
+                    std::vector<unsigned long long> h_rc(n_regions);
+                    SNK_HIP_TRY(hipMemcpyAsync(h_rc.data(), rcur, n_regions * 8ull, hipMemcpyDeviceToHost, st));
+                    SNK_HIP_TRY(snk_sync(st));
+                    unsigned long long mx0 = 0;
+                    for (uint32_t q2 = 0; q2 < n_regions; ++q2) mx0 = std::max(mx0, h_rc[q2]);
+                    const double share = (double)(ranges->bounds[1] - ranges->bounds[0]) / (double)NB;
+                    const uint64_t need = (uint64_t)((double)mx0 / share * 1.15) + 64;
+                    if (need > region_cap) { region_cap = need; pilot_regrow = true; break; }
+                }
             }
         } else if (attempt == 0 && pilot && NB >= 16384 && n_inst_hint) {
             const uint32_t NBp = NB / 64;
@@ -241,6 +259,7 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
         if (mx > region_cap) region_cap = mx + 64;     // exact requirement is known now (cursors keep counting past the cap)
         if (extra_ovf) extra_cap = h_status[4] + 64;
     }
+    if (ranges && ranges->finished) ranges->finished(ranges->user);
     {
         // exclusive offsets of the regions (host: one region per count workgroup, ~16 k) and the dense gather
         std::vector<unsigned long long>& h_off = ctx->h_region_off;      // lives in the context: the upload below is not waited for
@@ -457,11 +476,14 @@ static void partition_capacity(snk_ctx* ctx, uint32_t K, uint32_t NB, unsigned l
     // (tools/r6_cap_sigma.sh, profiles/r06_cap_sigma.log).  So: 5 sigma while the slots stay below 30 % of the device, 3 above, 1.5 if those are
     // still more than 30 % -- only where a bucket holds several sites (the Gaussian regime; a rank of the 8-GPU job has ONE site per bucket and
     // keeps its 5 sigma, the 45 % budget below and the larger overflow list).  Option msp_sigmas_x10 pins it.
+    // (memory = what this context can count on, ctx->plan_mem: a caller that holds 60 GB of reads leaves less than one that holds 15.)  A job in
+    // bucket-range passes is short of memory by definition: 3 sigma.
     double sig = 5.0;
     const double sigma = std::sqrt(mean * site_records);
     if (snk_opt_is_set("msp_sigmas_x10")) sig = 0.1 * snk_opt_u32("msp_sigmas_x10", 50);
-    else if (passes <= 1 && ctx->device_mem_total && mean >= 4.0 * site_records) {
-        const double lim = 0.30 * (double)ctx->device_mem_total;
+    else if (passes > 1) sig = mean >= 4.0 * site_records ? 3.0 : 5.0;
+    else if (ctx->plan_mem && mean >= 4.0 * site_records) {
+        const double lim = 0.30 * (double)ctx->plan_mem;
         if ((mean + 5.0 * sigma + 16.0) * NB * 32.0 > lim) sig = 3.0;
         if (sig < 5.0 && (mean + 3.0 * sigma + 16.0) * NB * 32.0 > lim) sig = 1.5;
     }
@@ -472,7 +494,7 @@ static void partition_capacity(snk_ctx* ctx, uint32_t K, uint32_t NB, unsigned l
     if (ideal_out) *ideal_out = cap64;
     if (passes <= 1) {
         // not more than ~45 % of the device for the slots: beyond that the capacity shrinks and the overflow list takes the rest
-        const uint64_t tot = ctx->device_mem_total;
+        const uint64_t tot = ctx->plan_mem;
         if (tot) {
             const uint64_t budget = (uint64_t)((double)tot * 0.45);
             if (cap64 * NB * 32ull > budget) {
@@ -844,9 +866,12 @@ uint32_t snk_partition_passes_needed(snk_ctx* ctx, uint32_t K, uint32_t NB, unsi
     double est = 0;
     uint64_t cap = 0, ideal = 0;
     partition_capacity(ctx, K, NB, n_inst, n_live, grouped, &est, &cap, 1, &ideal);
-    const uint64_t tot = ctx->device_mem_total;
+    const uint64_t tot = ctx->plan_mem;
     if (!tot || ideal * NB * 32ull <= (uint64_t)((double)tot * 0.45)) return 1;       // (the one-pass partition's own limit)
-    const uint64_t per_pass = (uint64_t)((double)tot * 0.25);
+    // A pass scans every read again (13 ms per 100 M reads): as few as fit.  A pass's slots (at the capacity a job in passes gets) take a third
+    // of what the context can count on -- next to them the count regions (24 bytes per retained k-mer) and the overflow lists have to fit
+    partition_capacity(ctx, K, NB, n_inst, n_live, grouped, &est, &cap, 2, &ideal);
+    const uint64_t per_pass = (uint64_t)((double)tot * 0.33);
     uint64_t p = (ideal * NB * 32ull + per_pass - 1) / per_pass;
     return (uint32_t)(p < 2 ? 2 : (p > 64 ? 64 : p));
 }

@@ -67,6 +67,19 @@ def test_golden_case(engine, name, long_minimiser):
     _check_against(res, c.exp_keys, c.exp_counts, c.exp_ctx, c.exp_unitigs, c.exp_goodlens, c.exp_hist)
 
 
+@pytest.mark.parametrize("name", goldens.CASES)
+def test_golden_case_strided_fragment_copy(engine, name, tune):
+    """The join's fragment copy with a grid of eight workgroups: the kernel strides over the fragments (as it has to from 2^29 fragments on,
+    where eight lanes per fragment are more work items than a launch may have -- a launch that was cut short silently at 750 M reads on
+    one GPU, tools/r6_full_job.py)."""
+    from supernova_amd.engine import Params
+    c = goldens.load(name)
+    rows, quals, bc, lens = _to_dev(c)
+    tune("emit_grid_log2", 3)
+    res = engine.count_graph(rows, c.read_len, quals=quals, bc=bc, lens=lens, params=Params(K=48), ign_bc_below=c.ign_bc_below)
+    _check_against(res, c.exp_keys, c.exp_counts, c.exp_ctx, c.exp_unitigs, c.exp_goodlens, c.exp_hist)
+
+
 # every count-kernel instantiation the library can pick BY ITSELF, forced: env -> the usable table slots the call must report
 COUNT_VARIANTS = {"screen": ({"SNK_COUNT_SCREEN_NG": "2"}, 960),      # bit filter + 1024-slot table (error-rich data: snk_count.hip SCREEN)
                   "tight": ({"SNK_COUNT_TIGHT": "1920", "SNK_COUNT_SCREEN_NG": "0"}, 1920)}      # booked slots, no filter
