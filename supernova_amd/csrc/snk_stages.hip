@@ -33,9 +33,9 @@ int snk_stage_count_table(snk_ctx* ctx, hipStream_t st, uint32_t K, const void* 
     if ((rc = snk_count_regions(K, grouped, nseg, NB, bc_mode, &n_regions, err, errcap))) return rc;
     uint64_t est = n_inst_hint / (min_freq > 1 ? 12 : 1) + 4096;     // first call only; a wrong guess costs one re-run
     // A job in bucket-range passes is short of memory, and instances / 12 are 2 bytes per instance it may not have (deep coverage retains 1 in 38):
-    // it starts from 1 in 40 and lets its first range say what the data retain (`range0_probe` below: one repeated range when that is more)
+    // it starts from 1 in 32 and lets its first range say what the data retain (`range0_probe` below: one repeated range when that is more)
     const bool tight = ranges && ranges->n > 1 && ranges->replay && min_freq > 1 && ctx->plan_mem && (double)est * 24.0 > 0.10 * (double)ctx->plan_mem;
-    if (tight) est = n_inst_hint / 40 + 4096;
+    if (tight) est = n_inst_hint / 32 + 4096;
     if (ctx->last_n_kmers && ctx->last_n_instances == n_inst_hint) est = ctx->last_n_kmers + ctx->last_n_kmers / (tight ? 8 : 2) + 4096;
     bool range0_probe = tight && !(ctx->last_n_kmers && ctx->last_n_instances == n_inst_hint);
     uint64_t region_cap = est / n_regions + 64;
@@ -493,10 +493,10 @@ static void partition_capacity(snk_ctx* ctx, uint32_t K, uint32_t NB, unsigned l
     cap64 = (cap64 + 1) & ~1ull;
     if (ideal_out) *ideal_out = cap64;
     if (passes <= 1) {
-        // not more than ~45 % of the device for the slots: beyond that the capacity shrinks and the overflow list takes the rest
+        // not more than half of what the context can count on for the slots: beyond that the capacity shrinks and the overflow list takes the rest
         const uint64_t tot = ctx->plan_mem;
         if (tot) {
-            const uint64_t budget = (uint64_t)((double)tot * 0.45);
+            const uint64_t budget = (uint64_t)((double)tot * 0.50);
             if (cap64 * NB * 32ull > budget) {
                 uint64_t c2 = budget / (NB * 32ull);
                 const uint64_t floor_ = (uint64_t)(mean * 1.25 + 8.0);
@@ -867,11 +867,12 @@ uint32_t snk_partition_passes_needed(snk_ctx* ctx, uint32_t K, uint32_t NB, unsi
     uint64_t cap = 0, ideal = 0;
     partition_capacity(ctx, K, NB, n_inst, n_live, grouped, &est, &cap, 1, &ideal);
     const uint64_t tot = ctx->plan_mem;
-    if (!tot || ideal * NB * 32ull <= (uint64_t)((double)tot * 0.45)) return 1;       // (the one-pass partition's own limit)
-    // A pass scans every read again (13 ms per 100 M reads): as few as fit.  A pass's slots (at the capacity a job in passes gets) take a third
-    // of what the context can count on -- next to them the count regions (24 bytes per retained k-mer) and the overflow lists have to fit
+    if (!tot || ideal * NB * 32ull <= (uint64_t)((double)tot * 0.50)) return 1;       // (the one-pass partition's own limit)
+    // A pass scans every read again (13 ms per 100 M reads): as few as fit.  A pass's slots (at the capacity a job in passes gets) take 45 %
+    // of what the context can count on -- next to them the count regions (24 bytes per retained k-mer) and the overflow lists have to fit;
+    // the graph stage that follows needs less than both (800 M reads: 112 + 58 + 15 GB of 248 while counting, 156 GB at the end)
     partition_capacity(ctx, K, NB, n_inst, n_live, grouped, &est, &cap, 2, &ideal);
-    const uint64_t per_pass = (uint64_t)((double)tot * 0.33);
+    const uint64_t per_pass = (uint64_t)((double)tot * 0.45);
     uint64_t p = (ideal * NB * 32ull + per_pass - 1) / per_pass;
     return (uint32_t)(p < 2 ? 2 : (p > 64 ? 64 : p));
 }
