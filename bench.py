@@ -83,6 +83,8 @@ def parse():
                          "does at start-up; -1 = 1.3 GB per million reads up to 45 %% of the device, 0 = none (every call that outgrows the arena pays "
                          "the driver ~25-30 ms per new GB inside the call)")
     ap.add_argument("--no-df-seam", action="store_true", help="N=1: skip the untimed b1/b2 row (reads.fastb / .qualp / .bci -> device decode -> unitigs)")
+    ap.add_argument("--no-large-job", action="store_true", help="skip config.large_job (800 M reads on this GPU in its own process, ~40 s; only the default run has it)")
+    ap.add_argument("--large-job-reads", type=float, default=8e8)
     ap.add_argument("--df-reads", type=float, default=1e8, help="reads of the df_seam row's stage-input files")
     ap.add_argument("--df-dir", default="", help="where the df_seam row writes its files (default: $TMPDIR or /tmp)")
     ap.add_argument("--df-threads", type=int, default=0, help="pread workers of the df_seam row (0 = from the CPU budget, at most 32)")
@@ -221,6 +223,33 @@ def ingest_row(eng, args, K, step_ms_per_read):
                 "step_over_ingest": (step_ms_per_read * n * 1e-3) / secs, "synth_files_written_in_s": t_write}
     finally:
         shutil.rmtree(td, ignore_errors=True)
+
+
+def large_job_row(args):
+    """How far ONE GPU goes: --large-job-reads (800 M = two thirds of BASELINE config 3's whole job) through the resident step in bucket-range
+    passes, reads held in the DF seam's compact form, with the size-independent checks (tools/r6_full_job.py; DESIGN 4 "round 6").  Runs in
+    its own process after everything else of this run has given its device memory back; a failure is reported, never raised."""
+    import subprocess
+    import torch
+    try:
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        t0 = time.perf_counter()
+        pr = subprocess.run([sys.executable, str(ROOT / "tools" / "r6_full_job.py"), str(args.large_job_reads), "5e7", "2"], capture_output=True, text=True, timeout=420)
+        rows_ = [json.loads(l) for l in pr.stdout.splitlines() if l.startswith("{")]
+        if pr.returncode != 0 or not rows_:
+            return {"failed": (pr.stderr or pr.stdout).strip().splitlines()[-1][:300] if (pr.stderr or pr.stdout).strip() else f"exit {pr.returncode}"}
+        d = rows_[-1]
+        return {"reads": int(float(args.large_job_reads)), "held_as": "packed rows + good lengths + barcode ids (46 B per read)", "call": "second of two",
+                "wall_s": d["wall_s"], "Gkmers_per_s": d["Gkmers_per_s"], "instances": d["instances"], "retained_kmers": d["retained_kmers"], "unitigs": d["unitigs"],
+                "bucket_range_passes": d["passes"], "buckets": d["buckets"], "phase_ms": d["phase_ms"], "scratch_gib": d["scratch_gb"], "fragments": d["n_fragments"],
+                "first_call_s": rows_[0]["wall_s"], "checks": {"every_count_at_least_min_freq": d["min_count"] >= 3, "spectrum_adds_up": d["spectrum_adds_up"],
+                                                               "unitig_lengths_add_up": d["unitig_lengths_add_up"], "same_as_first_call": d["same_as_first_call"]},
+                "row_seconds": round(time.perf_counter() - t0, 1),
+                "note": "one MI355X; the north star asks 50 Gk-mers/s of eight for 1.2 B reads; 2^31 retained k-mers (32-bit node states) is the one-GPU limit"}
+    except Exception as ex:
+        return {"failed": str(ex)[:300]}
 
 
 def df_seam_row(eng, args, K):
@@ -698,6 +727,22 @@ def main():
             except Exception as ex:  # the baseline is a report, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "Gk-mers/s", "cores": os.cpu_count(), "kind": "reference",
                                        "sample": f"failed: {ex}"}
+        if (world == 1 and not use_dist and not args.grouped and K == 48 and not args.no_large_job and per_gpu == 100_000_000
+                and not (args.no_robust or args.no_next_rows or args.no_ingest or args.no_df_seam or args.no_cpu_baseline)):
+            # this run's reads, results and arena go back to the device first (the row's process plans with what is free)
+            try:
+                del res
+            except NameError:
+                pass
+            try:
+                del rows, quals, bc
+            except NameError:
+                pass
+            try:
+                eng.close()
+            except Exception:
+                pass
+            out["config"]["large_job"] = large_job_row(args)
         line = json.dumps(out)
     if use_dist:
         if use_dist and not args.grouped and not args.no_verify:         # every rank leaves with the same exit code
