@@ -408,6 +408,7 @@ void snk_ctx_release_scratch(snk_ctx* ctx) {
         }
         ctx->blocks.swap(keep);
     }
+    snk_ctx_plan_mem(ctx);      // what this call's plans may count on (everything the arena holds is free at this point)
 }
 extern "C" uint32_t snk_ctx_last_partition_passes(const snk_ctx* ctx) { return ctx ? ctx->last_partition_passes : 0u; }
 extern "C" uint32_t snk_ctx_last_count_limit(const snk_ctx* ctx) { return ctx ? ctx->last_count_limit : 0u; }
@@ -434,6 +435,7 @@ void snk_ctx_plan_mem(snk_ctx* ctx) {
     // steps of 8 GB so that the plans of a job do not move with a few MB of somebody's allocations; never more than the device
     size_t fr = 0, tot = 0;
     ctx->plan_mem = ctx->device_mem_total;
+    { const int ix = snk_opt_index("plan_mem_mb"); if (ix >= 0 && ctx->opts.set[ix] && ctx->opts.v[ix] > 0) { ctx->plan_mem = (uint64_t)ctx->opts.v[ix] << 20; return; } }      // (tests: a small device)
     if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return; }
     uint64_t avail = (uint64_t)fr + (uint64_t)ctx->cached_bytes;      // (cached_bytes: the arena's mapped chunks and the plain blocks)
     avail &= ~((8ull << 30) - 1);

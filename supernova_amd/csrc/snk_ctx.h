@@ -19,7 +19,7 @@ struct snk_ctx {
     size_t lds_per_block = 65536;
     uint64_t device_mem_total = 0;   // HBM of the device (sizing decisions that must not depend on what happens to be free)
     uint64_t plan_mem = 0;           // ... minus what is not this context's to use -- the caller's reads, other contexts -- in whole 8-GB steps, looked at
-                                     //     at the start of a resident call (snk_ctx_plan_mem): what the slot / pass / region plans of a large job divide
+                                     //     at the start of every top-level call (snk_ctx_release_scratch): what the slot / pass / region plans of a large job divide
     // caching arena for call-scoped scratch: blocks are handed out by best fit, returned to the cache at the
     // start of the next top-level call (no hipFree/hipMalloc in steady state), released on destroy or OOM
     struct block { void* p; size_t bytes; bool used; uint64_t serial = 0; uint64_t epoch = 0; };

@@ -138,7 +138,6 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
     ctx->cur_stream = st;
     ctx->arena_legacy = false;
     snk_ctx_release_scratch(ctx);
-    snk_ctx_plan_mem(ctx);
     memset(out, 0, sizeof *out);
     const uint32_t K = p->K;
     const uint64_t n_reads = in->n_reads;

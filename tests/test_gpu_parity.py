@@ -998,6 +998,34 @@ def test_bucket_range_passes_equal_the_one_pass_partition(engine, graph_stage, n
     assert engine.last_partition_passes() == 1
 
 
+@pytest.mark.parametrize("coverage", [56, 28])
+def test_a_small_device_plans_passes_and_probes_its_regions(engine, graph_stage, coverage, tune):
+    """What a job that approaches the device's memory goes through (800 M reads on one GPU: tools/r6_full_job.py), at 2 M reads on a context that
+    is told it has 256 MB (option plan_mem_mb): bucket-range passes by the library's own plan, 3-sigma slots, count regions from
+    instances / 32 -- enough at 56x coverage, too small at 28x (1 in 19 retained), where the first range's probe makes them larger and that
+    range runs again -- and the record slots handed back before the dense table.  Same table, contexts and unitigs as the one-pass call."""
+    from supernova_amd import synth
+    from supernova_amd.engine import Params
+    if graph_stage == "global":
+        pytest.skip("the plans are the count stage's; one graph stage is enough")
+    n = 2_000_000
+    sp = synth.synth_params(n, seed=0x5EED0A11, genome_len=n * 150 // coverage)
+    rows, quals, bc = engine.synth(sp)
+
+    def sig(res):
+        return res.n_instances, res.keys().tobytes(), res.counts().tobytes(), res.ctx().tobytes(), res.unitigs()
+
+    one = engine.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48))
+    assert engine.last_partition_passes() == 1
+    a = sig(one)
+    assert one.n_kmers > (n * 103 // 32 if coverage == 28 else 0)        # (28x: more survivors than the tight plan's first guess)
+    tune("plan_mem_mb", 256)
+    for _ in range(2):                  # (the second call sizes its regions from the first)
+        res = engine.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48))
+        assert engine.last_partition_passes() > 1
+        assert sig(res) == a
+
+
 def test_open_streamed_job_dies_with_its_arena(engine):
     """A streamed job keeps its slots, cursors and good lengths in the context's arena.  A resident call in between recycles that arena
     (snk_ctx_release_scratch): append / finish must then be refused instead of writing into memory that belongs to the new call

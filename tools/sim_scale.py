@@ -23,6 +23,9 @@ def worker(r):
     try:
         torch.cuda.set_device(0)
         e = Engine(0)
+        # a simulated rank plans as the rank it stands for would: with a device of its own (the W contexts share this one, and a context's
+        # plans divide what it finds free: snk_ctx_plan_mem)
+        e.set_option("plan_mem_mb", torch.cuda.get_device_properties(0).total_memory >> 20)
         rows, quals, bc = e.synth(sp, first=r * per, n=per)
         sh = ShardedEngine(e, world.comm(r))
         for rep in range(reps):
