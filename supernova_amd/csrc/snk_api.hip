@@ -435,6 +435,7 @@ void snk_ctx_plan_mem(snk_ctx* ctx) {
     // steps of 8 GB so that the plans of a job do not move with a few MB of somebody's allocations; never more than the device
     size_t fr = 0, tot = 0;
     ctx->plan_mem = ctx->device_mem_total;
+    ctx->plan_mapped = (uint64_t)ctx->cached_bytes;
     { const int ix = snk_opt_index("plan_mem_mb"); if (ix >= 0 && ctx->opts.set[ix] && ctx->opts.v[ix] > 0) { ctx->plan_mem = (uint64_t)ctx->opts.v[ix] << 20; return; } }      // (tests: a small device)
     if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return; }
     uint64_t avail = (uint64_t)fr + (uint64_t)ctx->cached_bytes;      // (cached_bytes: the arena's mapped chunks and the plain blocks)

@@ -48,6 +48,7 @@ const snk_opt_def snk_opt_defs[] = {
     {"split_log2", "log2 of the ranking's splitter spacing + 1 (5)"},
     {"rank_wyllie", "1: plain pointer jumping instead of the sparse ruling set"},
     {"emit_grid_log2", "log2 of the largest grid of the join's fragment copy (22; tests make it small: the kernel strides)"},
+    {"lean_cold", "0: a context whose arena has not mapped the memory yet still sizes its record slots at 5 sigma (1: 1.5 sigma until the arena has the slack)"},
     {"plan_mem_mb", "the memory (MB) the slot / pass / region plans of a call divide instead of what the device has free (tests: bucket-range passes and their region probe at fixture size)"},
     {"join_dbg", "1: the join counts the bytes of its unitig buffers that nothing wrote (stderr; debugging aid)"},
     {"rank_round_batch", "jumping rounds per read-back, sharded ranking (8)"},

@@ -486,6 +486,14 @@ static void partition_capacity(snk_ctx* ctx, uint32_t K, uint32_t NB, unsigned l
         const double lim = 0.30 * (double)ctx->plan_mem;
         if ((mean + 5.0 * sigma + 16.0) * NB * 32.0 > lim) sig = 3.0;
         if (sig < 5.0 && (mean + 3.0 * sigma + 16.0) * NB * 32.0 > lim) sig = 1.5;
+        // ... and of what the arena already holds.  Memory a process has not mapped yet is not free: the driver clears what another
+        // process used before it hands it out, ~33 ms per GB (a second snk_mspedges run on 100 M reads spent 2.06 s mapping its 62.5 GB of
+        // 5-sigma slots and 0.5 s computing: profiles/r06_oneshot.log) -- 35 GB of slack cost a second, the overflow list it saves 1.5 ms.
+        // So the slack is taken only when the arena has it (a host that wants the last 1.5 ms maps ahead: snk_ctx_reserve, as bench.py does).
+        if (sig > 1.5 && snk_opt_u32("lean_cold", 1)) {
+            const double other = 2.6 * (double)n_inst;          // regions, table, graph stage: ~27 GB per 10 G instances at 56x
+            if ((double)ctx->plan_mapped < (mean + sig * sigma + 16.0) * NB * 32.0 + other) sig = 1.5;
+        }
     }
     uint64_t cap64 = (uint64_t)(mean + sig * sigma + 16.0);
     cap64 = cap64 * snk_opt_u32("msp_cap_pct", 100) / 100;
