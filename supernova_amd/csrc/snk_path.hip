@@ -1194,10 +1194,13 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
                     if ((rc = dev(ctx, n_slow + 1, &slow, err, errcap))) return rc;
                     hipLaunchKernelGGL(slow_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, gm, slow_pos, n, slow);
                     a.slow = slow; a.n_slow = n_slow;
-                    uint64_t g1 = (n_slow + 15) / 16;
+#ifndef SNK_PATH_SLOW_GS
+#define SNK_PATH_SLOW_GS 8           // lanes per read of the slow pass: the pass is bound by its instruction stream (profiles/r06_path_wide_rounds.log), eight reads share a wave's
+#endif                               //   instructions instead of four: 63.3 -> 60.3 ms per 100 M reads (four alternating runs each, same box)
+                    uint64_t g1 = (n_slow + 256 / SNK_PATH_SLOW_GS - 1) / (256 / SNK_PATH_SLOW_GS);
                     if (g1 > gmax) g1 = gmax;
                     if (use_index) hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, 1, 16, true>), dim3((unsigned)g1), dim3(256), 0, st, a);
-                    else hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, 1, 16, false>), dim3((unsigned)g1), dim3(256), 0, st, a);
+                    else hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, 1, SNK_PATH_SLOW_GS, false>), dim3((unsigned)g1), dim3(256), 0, st, a);
                 }
                 out->n_slow = n_slow;
             } else if (use_index) hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, 3, 16, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
