@@ -596,7 +596,8 @@ template <int K, int PC, int PM, int MODE, int GS, bool IDX>
 __global__ void __launch_bounds__(256, MODE == 2 ? 4 : SNK_PATH_OCC) path_kernel(path_args a) {
     constexpr bool SECOND = MODE == 2;
     constexpr int NG = 256 / GS;                      // reads per workgroup
-    constexpr uint32_t GM = GS == 16 ? 0xFFFFu : 0xFFu;
+    constexpr uint32_t GM = (1u << GS) - 1u;
+    static_assert(GS == 16 || GS == 8 || GS == 4, "lanes per read");
     __shared__ uint32_t rowL[NG][20];
     // ordering keys of the read's 16-mers (minimiser index): the fast pass looks the first k-mer up and nothing else
     constexpr uint32_t KEYCAP = !IDX ? 1u : (MODE == 0 ? 64u : 20u * 16u - 15u);
@@ -1175,11 +1176,14 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
             const uint64_t gmax = (uint64_t)ctx->n_cu * 64;
             if (grid > gmax) grid = gmax;
             if (gparts && snk_opt_u32("path_two_pass", 1)) {
+#ifndef SNK_PATH_FAST_GS
+#define SNK_PATH_FAST_GS 4          // lanes per read of the fast pass (the template's 8 of round 3 -> 4: sixteen reads share a wave's instructions; 62.2 -> 57.7 ms with the slow pass at 8)
+#endif
                 if (snk_opt_u32("path_fast_gs", 8) == 8) {
-                    uint64_t g0 = (n + 31) / 32;
+                    uint64_t g0 = (n + 256 / SNK_PATH_FAST_GS - 1) / (256 / SNK_PATH_FAST_GS);
                     if (g0 > gmax) g0 = gmax;
                     if (use_index) hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, 0, 8, true>), dim3((unsigned)g0), dim3(256), 0, st, a);
-                    else hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, 0, 8, false>), dim3((unsigned)g0), dim3(256), 0, st, a);
+                    else hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, 0, SNK_PATH_FAST_GS, false>), dim3((unsigned)g0), dim3(256), 0, st, a);
                 } else if (use_index) hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, 0, 16, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
                 else hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, 0, 16, false>), dim3((unsigned)grid), dim3(256), 0, st, a);
                 // the reads it left, in read order
