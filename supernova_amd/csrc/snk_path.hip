@@ -578,7 +578,7 @@ __device__ __forceinline__ bool dict_find(const path_graph& G, const uint32_t* r
 // instructions whatever the number of active lanes), so four reads share every instruction.  A group's control flow is
 // uniform inside the group; the groups of a wave diverge like threads do.
 #ifndef SNK_PATH_OCC
-#define SNK_PATH_OCC 5
+#define SNK_PATH_OCC 8           // workgroups per CU the register allocation aims at (5 until round 6: with four / eight lanes per read the passes want reads in flight, not registers: 57.6 -> 54.3 ms)
 #endif
 // GS lanes per read (16 or 8): the kernel is latency bound -- a clean read is a chain of ~6 dependent HBM round trips whatever the
 // number of lanes that wait for them -- so eight lanes per read put twice as many reads in flight per wave (round 3: 134 -> see DESIGN);
@@ -1183,7 +1183,10 @@ int path_impl(snk_ctx* ctx, hipStream_t st, const snk_dev_reads* in, uint64_t U,
                     uint64_t g0 = (n + 256 / SNK_PATH_FAST_GS - 1) / (256 / SNK_PATH_FAST_GS);
                     if (g0 > gmax) g0 = gmax;
                     if (use_index) hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, 0, 8, true>), dim3((unsigned)g0), dim3(256), 0, st, a);
-                    else hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, 0, SNK_PATH_FAST_GS, false>), dim3((unsigned)g0), dim3(256), 0, st, a);
+#ifndef SNK_PATH_FAST_PC
+#define SNK_PATH_FAST_PC 4           // parts per read the fast pass has room for (it writes one: 4 KB of LDS per workgroup instead of 20)
+#endif
+                    else hipLaunchKernelGGL((path_kernel<K, SNK_PATH_FAST_PC, PMAX1, 0, SNK_PATH_FAST_GS, false>), dim3((unsigned)g0), dim3(256), 0, st, a);
                 } else if (use_index) hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, 0, 16, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
                 else hipLaunchKernelGGL((path_kernel<K, PCAP1, PMAX1, 0, 16, false>), dim3((unsigned)grid), dim3(256), 0, st, a);
                 // the reads it left, in read order
