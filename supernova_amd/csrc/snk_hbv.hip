@@ -42,6 +42,7 @@ struct hbv_tables {
     const uint32_t* ee;
     const int32_t* vtx_of;
     const uint64_t* run_beg;
+    bool short_q = true;      // option hbv_short_queue, read by the caller (the floods run on host threads of their own)
 };
 int hbv_alloc_out(uint64_t U, uint64_t nruns, snk_hbv* out, char* err, size_t errcap) {
     out->n_vertices = (int32_t)nruns;
@@ -67,6 +68,7 @@ void hbv_flood_component(const hbv_tables& t, uint64_t e0, int rc0, std::vector<
     // measurement aid (SNK_HBV_DEPTH=1): the levels of this breadth-first flood -- what a level-synchronous reproduction on the device
     // would take one round (a launch, or a grid-wide barrier: >= 3 us either way) for each
     static const bool want_depth = getenv("SNK_HBV_DEPTH") != nullptr;
+    const bool short_q = t.short_q;
     std::vector<uint32_t> lvl;
     uint64_t visited = 0;
     uint32_t depth = 0;
@@ -75,21 +77,26 @@ void hbv_flood_component(const hbv_tables& t, uint64_t e0, int rc0, std::vector<
         // The flood is a chain of cache misses (4U + U + V words touched at random: 250 ns per edge on a 6 M-unitig graph); the queue
         // says what will be touched next, so the lines of the entries 16, 8 and 4 places ahead are asked for now, one level of
         // indirection each (classes of an entry; runs and ids of its classes; the ends behind the runs).
-        if (head + 16 < q.size()) __builtin_prefetch(&t.vtx_of[(q[head + 16] >> 1) * 4 + (q[head + 16] & 1) * 2]);
-        if (head + 8 < q.size()) {
-            const uint64_t y = q[head + 8];
+        // The bulk of a genome graph is flooded through a SHORT queue (4.7 edge copies per breadth-first level, profiles/r05_hbv_depth.log): most
+        // of the time there is nothing 16, 8 or 4 places ahead.  An entry's class words are asked for when it is pushed, and with fewer entries
+        // behind the head the same stages run one and two places ahead.
+        auto stage_b = [&](uint64_t y) {
             const uint64_t ye = y >> 1, yrc = (t.pal[ye] && (y & 1)) ? 0 : (y & 1);
             const int32_t a = t.vtx_of[ye * 4 + yrc * 2], b = t.vtx_of[ye * 4 + yrc * 2 + 1];
             __builtin_prefetch(&t.run_beg[a]); __builtin_prefetch(&t.run_beg[b]);
             __builtin_prefetch(&vid[a]); __builtin_prefetch(&vid[b]);
             __builtin_prefetch(&(y & 1 ? out->rev_xlat : out->fwd_xlat)[ye]);
-        }
-        if (head + 4 < q.size()) {
-            const uint64_t y = q[head + 4];
+        };
+        auto stage_c = [&](uint64_t y) {
             const uint64_t ye = y >> 1, yrc = (t.pal[ye] && (y & 1)) ? 0 : (y & 1);
             __builtin_prefetch(&t.ee[t.run_beg[t.vtx_of[ye * 4 + yrc * 2]]]);
             __builtin_prefetch(&t.ee[t.run_beg[t.vtx_of[ye * 4 + yrc * 2 + 1]]]);
-        }
+        };
+        if (head + 16 < q.size()) __builtin_prefetch(&t.vtx_of[(q[head + 16] >> 1) * 4 + (q[head + 16] & 1) * 2]);
+        if (head + 8 < q.size()) stage_b(q[head + 8]);
+        else if (short_q && head + 2 < q.size()) stage_b(q[head + 2]);
+        if (head + 4 < q.size()) stage_c(q[head + 4]);
+        else if (short_q && head + 1 < q.size()) stage_c(q[head + 1]);
         const uint64_t x = q[head++];
         const uint64_t e = x >> 1;
         const int rc = (int)(x & 1);
@@ -109,7 +116,11 @@ void hbv_flood_component(const hbv_tables& t, uint64_t e0, int rc0, std::vector<
             for (uint64_t j = t.run_beg[r]; j < t.run_beg[r + 1]; ++j) {
                 const uint64_t ed = t.ee[j] >> 2;
                 const int erc = (int)((t.ee[j] >> 1) & 1u);
-                if (!done(ed, erc)) { q.push_back(ed * 2 + erc); if (want_depth) lvl.push_back(lvl[head - 1] + 1); }
+                if (!done(ed, erc)) {
+                    q.push_back(ed * 2 + erc);
+                    if (short_q) __builtin_prefetch(&t.vtx_of[ed * 4 + ((t.pal[ed] && erc) ? 0 : erc) * 2]);
+                    if (want_depth) lvl.push_back(lvl[head - 1] + 1);
+                }
             }
         }
     }
@@ -125,7 +136,7 @@ int hbv_flood(uint64_t U, const uint8_t* pal, const uint32_t* ee, uint64_t n_ee,
     std::vector<int32_t> vid(nruns, -1);
     int32_t next_v = 0, next_e = 0;
     std::vector<uint64_t> q;
-    const hbv_tables t{U, pal, ee, vtx_of, run_beg};
+    const hbv_tables t{U, pal, ee, vtx_of, run_beg, snk_opt_u32("hbv_short_queue", 1) != 0};
     (void)n_ee;
     for (int pass = 0; pass < 2; ++pass)
         for (uint64_t e0 = 0; e0 < U; ++e0)
@@ -660,7 +671,7 @@ extern "C" int snk_dev_hbv(snk_ctx* ctx, uint32_t K, uint64_t U, const void* d_u
             SNK_HIP_TRY(fetch_tables());
             SNK_HIP_TRY(snk_sync(st));
             std::vector<int32_t> vid(nruns, -1);
-            const hbv_tables t{U, h_pal.data(), h_ee.data(), h_vtx.data(), h_run.data()};
+            const hbv_tables t{U, h_pal.data(), h_ee.data(), h_vtx.data(), h_run.data(), snk_opt_u32("hbv_short_queue", 1) != 0};
             // Components are independent once their id blocks are known (the device's scans): a host thread each, largest first.  The bulk
             // of a genome graph is TWO components -- the forward copies' and its mirror image, the reverse copies' -- whose floods are NOT
             // each other's mirror (a flood pushes the left vertex's edges before the right vertex's), so both are run, side by side.

@@ -10,10 +10,10 @@ from supernova_amd import synth
 from supernova_amd.engine import Engine, Params
 n = int(float(sys.argv[1]))
 mf = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-if len(sys.argv) > 3 and sys.argv[3] != "-":
-    e.set_option("hbv_big", int(sys.argv[3]))
 grouped = len(sys.argv) > 4 and sys.argv[4] == "grouped"
 e = Engine(0)
+if len(sys.argv) > 3 and sys.argv[3] != "-":
+    e.set_option("hbv_big", int(sys.argv[3]))
 sp = synth.synth_params(n, seed=0x5EED0001)
 rows, quals, bc = e.synth(sp)
 if grouped:
@@ -22,8 +22,9 @@ else:
     res = e.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48, min_freq=mf, min_bc=0 if mf == 1 else 2, sorted_table=False))
 print(f"reads {n} min_freq {mf}{' grouped' if grouped else ''}: unitigs {res.n_unitigs} bases {res.unitig_total_bases}", flush=True)
 ref = None
-for mode, env in (("host flood", {"SNK_HBV_DEV_MIN": "4000000000"}), ("device flood", {"SNK_HBV_DEV_MIN": "0", "SNK_HBV_STRICT": "1"})):
-    os.environ.update(env)
+for mode, opts in (("host flood", {"hbv_dev_min": 4000000000}), ("device flood", {"hbv_dev_min": 0, "hbv_strict": 1})):
+    for k_, v_ in opts.items():
+        e.set_option(k_, v_)
     for rep in range(2):
         t0 = time.perf_counter()
         h = res.hbv()
