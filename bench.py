@@ -457,7 +457,7 @@ def main():
     total_reads = per_gpu * world
     eng = Engine(local_rank)
     reserved_gb = 0.0
-    if world == 1 and not use_dist and args.reserve_gb != 0:
+    if world == 1 and args.reserve_gb != 0:      # (a one-rank step takes the growing arena too; ranks of a larger job keep plain blocks: DESIGN 6)
         cap_gb = 0.45 * torch.cuda.get_device_properties(local_rank).total_memory / 2**30
         reserved_gb = min(cap_gb, 1.3 * per_gpu / 1e6) if args.reserve_gb < 0 else args.reserve_gb
         try:
