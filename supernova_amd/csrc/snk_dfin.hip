@@ -4,7 +4,7 @@
 // 265-272,345,595-597; block codec feudal/PQVec.cc:86-200; control block feudal/FeudalControlBlock.h:27-166; barcode index expansion
 // DF.cc:464-469).  Both files are offset-indexed and uncompressed: a read's bytes are found without looking at any other read.  So the
 // file bytes themselves go to the device -- raw byte ranges of a slab of reads, preads of a thread pool into a page-locked ring, one
-// asynchronous copy per section -- and three kernels turn them into the arrays the count+graph path takes:
+// asynchronous copy per slab -- and three kernels turn them into the arrays the count+graph path takes:
 //   df_bases_kernel   fastb bytes (2 bits per base, base j at bits 2(j%4) of byte j/4: LSB first) -> packed rows (MSB-first words): one
 //                     output word = one unaligned 32-bit load, a reversal of its sixteen 2-bit groups, a mask behind the read's length
 //   df_quals_kernel   PQVec block chains -> raw phred rows: 16 lanes per read walk the chain together (the header bytes are a broadcast
@@ -804,7 +804,7 @@ extern "C" int snk_dev_ingest_df_count_graph(snk_ctx* ctx, snk_df_files* f, uint
 // ---------------------------------------------------------------------------------------------------------------------------------------
 // Writers of the triple (tests, bench.py --df-seam, tools): the layouts of feudal/FeudalFileWriter.cc:18-140 (control block, variable data,
 // (N + 1) offsets, fixed data), feudal/PQVec.cc:86-127 (block chain) and BinaryWriter::writeFile(vec<int64_t>).  The block choice is this
-// file's own (greedy: a value joins the open block unless a block of its own is cheaper); any chain of valid blocks decodes to the same
+// file's own (runs of equal values, merged left to right while one block is not dearer than two: pq_encode); any chain of valid blocks decodes to the same
 // values, and the reference's own choice is covered by files its writer made (tests/golden/formats, snref_driver ... formats).
 namespace {
 
