@@ -123,6 +123,9 @@ int main(int argc, char** argv) {
                         "%.3f s waiting for file bytes, %.3f s setup), count+graph %.1f ms; files -> %s in %.3f s = %.2f Gk-mers/s\n",
                 (unsigned long long)r.n_instances, (unsigned long long)r.n_kmers, (unsigned long long)r.n_unitigs, st.text_bytes / 1e9, st.n_batches, st.seconds,
                 st.text_bytes / 1e9 / (st.seconds > 0 ? st.seconds : 1), st.decode_wait_seconds, st.setup_seconds, r.phase_ms[7], kv["OUT"].c_str(), s, r.n_instances / s / 1e9);
+        if (kv.count("PHASES")) fprintf(stderr, "snk_mspedges: phases (ms): trim %.1f plan %.1f partition %.1f count %.1f sort %.1f graph %.1f | buckets %llu split %llu repartitioned %u scratch %.1f GB\n",
+                                        r.phase_ms[0], r.phase_ms[1], r.phase_ms[2], r.phase_ms[3], r.phase_ms[4], r.phase_ms[5], (unsigned long long)r.n_buckets,
+                                        (unsigned long long)r.buckets_split, (unsigned)r.repartitioned, r.scratch_bytes / 1e9);
     }
     if (kv.count("SPECTRUM")) {
         // same shape as WriteHistToJson(kmerspec, 0, max_count, 1, ...) (BuildReadQGraph48.cc:199-216)
