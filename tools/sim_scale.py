@@ -11,6 +11,8 @@ from supernova_amd.engine import Engine, Params
 from supernova_amd.sharded import ShardedEngine, SimWorld
 
 W = int(sys.argv[1]); per = int(float(sys.argv[2])); reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+torch.cuda.init()
+DEV_MB = torch.cuda.mem_get_info(0)[1] >> 20
 world = SimWorld(W)
 bar = threading.Barrier(W)
 rmode = int(sys.argv[4]) if len(sys.argv) > 4 else 0
@@ -25,7 +27,7 @@ def worker(r):
         e = Engine(0)
         # a simulated rank plans as the rank it stands for would: with a device of its own (the W contexts share this one, and a context's
         # plans divide what it finds free: snk_ctx_plan_mem)
-        e.set_option("plan_mem_mb", torch.cuda.get_device_properties(0).total_memory >> 20)
+        e.set_option("plan_mem_mb", DEV_MB)
         rows, quals, bc = e.synth(sp, first=r * per, n=per)
         sh = ShardedEngine(e, world.comm(r))
         for rep in range(reps):
