@@ -19,6 +19,7 @@
 //        hot path's few thousand: faster than the launches).  Every loop of the device flood is bounded; one that runs out
 //        hands the graph to the host flood.
 #include <stdlib.h>
+#include <sys/mman.h>
 #include <string.h>
 
 #include <algorithm>
@@ -44,14 +45,41 @@ struct hbv_tables {
     const uint64_t* run_beg;
     bool short_q = true;      // option hbv_short_queue, read by the caller (the floods run on host threads of their own)
 };
+// The host flood walks a few hundred MB of tables at random: with 4-KB pages every access is a TLB miss on top of the cache miss.  Large
+// host arrays are asked for on 2-MB boundaries with MADV_HUGEPAGE BEFORE they are touched (transparent huge pages are "madvise" on these
+// hosts); free() releases them.  Best effort: without huge pages the arrays are what they were.
+bool hbv_huge_pages = true;          // option hbv_huge_pages (a measurement switch: set by the entry points, read here)
+void* huge_alloc(size_t bytes) {
+    if (!hbv_huge_pages || bytes < ((size_t)4 << 20)) return malloc(bytes ? bytes : 1);
+    void* p = nullptr;
+    const size_t len = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    if (posix_memalign(&p, (size_t)2 << 20, len) != 0) return malloc(bytes);
+    (void)madvise(p, len, MADV_HUGEPAGE);
+    return p;
+}
+template <typename T>
+struct huge_vec {                      // the little of std::vector the tables need; never value-initialised
+    T* p = nullptr;
+    size_t n = 0;
+    huge_vec() = default;
+    huge_vec(const huge_vec&) = delete;
+    huge_vec& operator=(const huge_vec&) = delete;
+    ~huge_vec() { free(p); }
+    bool resize(size_t m) { free(p); p = (T*)huge_alloc((m ? m : 1) * sizeof(T)); n = p ? m : 0; return p != nullptr; }
+    T* data() { return p; }
+    const T* data() const { return p; }
+    T& operator[](size_t i) { return p[i]; }
+    const T& operator[](size_t i) const { return p[i]; }
+};
+
 int hbv_alloc_out(uint64_t U, uint64_t nruns, snk_hbv* out, char* err, size_t errcap) {
     out->n_vertices = (int32_t)nruns;
-    out->fwd_xlat = (int32_t*)malloc(U * 4);
-    out->rev_xlat = (int32_t*)malloc(U * 4);
-    out->v_left = (int32_t*)malloc(2 * U * 4);
-    out->v_right = (int32_t*)malloc(2 * U * 4);
-    out->src_unitig = (int32_t*)malloc(2 * U * 4);
-    out->is_rc = (uint8_t*)malloc(2 * U);
+    out->fwd_xlat = (int32_t*)huge_alloc(U * 4);
+    out->rev_xlat = (int32_t*)huge_alloc(U * 4);
+    out->v_left = (int32_t*)huge_alloc(2 * U * 4);
+    out->v_right = (int32_t*)huge_alloc(2 * U * 4);
+    out->src_unitig = (int32_t*)huge_alloc(2 * U * 4);
+    out->is_rc = (uint8_t*)huge_alloc(2 * U);
     if (!out->fwd_xlat || !out->rev_xlat || !out->v_left || !out->v_right || !out->src_unitig || !out->is_rc) {
         snk_hbv_free(out);
         return snk_fail(SNK_E_NOMEM, err, errcap, "snk_hbv: host allocation failed");
@@ -59,7 +87,7 @@ int hbv_alloc_out(uint64_t U, uint64_t nruns, snk_hbv* out, char* err, size_t er
     return SNK_OK;
 }
 // the flood of one component from its seed (HBVBuilder::processQueue); ids continue from next_e / next_v
-void hbv_flood_component(const hbv_tables& t, uint64_t e0, int rc0, std::vector<int32_t>& vid, std::vector<uint64_t>& q, int32_t& next_e,
+void hbv_flood_component(const hbv_tables& t, uint64_t e0, int rc0, int32_t* vid, std::vector<uint64_t>& q, int32_t& next_e,
                          int32_t& next_v, snk_hbv* out) {
     auto done = [&](uint64_t e, int rc) { return (rc ? out->rev_xlat : out->fwd_xlat)[e] != -1; };
     q.clear();            // FIFO: [head, size); emptied whenever a component is finished
@@ -133,7 +161,10 @@ int hbv_flood(uint64_t U, const uint8_t* pal, const uint32_t* ee, uint64_t n_ee,
     int rc = hbv_alloc_out(U, nruns, out, err, errcap);
     if (rc) return rc;
     for (uint64_t i = 0; i < U; ++i) out->fwd_xlat[i] = out->rev_xlat[i] = -1;
-    std::vector<int32_t> vid(nruns, -1);
+    huge_vec<int32_t> vidv;
+    if (!vidv.resize(nruns + 1)) { snk_hbv_free(out); return snk_fail(SNK_E_NOMEM, err, errcap, "snk_hbv: host allocation failed"); }
+    int32_t* vid = vidv.data();
+    for (uint64_t i = 0; i < nruns; ++i) vid[i] = -1;
     int32_t next_v = 0, next_e = 0;
     std::vector<uint64_t> q;
     const hbv_tables t{U, pal, ee, vtx_of, run_beg, snk_opt_u32("hbv_short_queue", 1) != 0};
@@ -578,12 +609,14 @@ extern "C" int snk_dev_hbv(snk_ctx* ctx, uint32_t K, uint64_t U, const void* d_u
     uint32_t nruns = 0;
     SNK_HIP_TRY(hipMemcpyAsync(&nruns, cls + (n_ee - 1), 4, hipMemcpyDeviceToHost, st));
     SNK_HIP_TRY(snk_sync(st));
-    std::vector<uint32_t> h_ee, h_order(U);
-    std::vector<int32_t> h_vtx;
-    std::vector<uint8_t> h_pal;
-    std::vector<uint64_t> h_run;
+    hbv_huge_pages = snk_opt_u32("hbv_huge_pages", 1) != 0;
+    std::vector<uint32_t> h_order(U);
+    huge_vec<uint32_t> h_ee;
+    huge_vec<int32_t> h_vtx;
+    huge_vec<uint8_t> h_pal;
+    huge_vec<uint64_t> h_run;
     auto fetch_tables = [&]() -> hipError_t {       // what a flood on the host reads
-        h_ee.resize(n_ee); h_vtx.resize(n4); h_pal.resize(U); h_run.resize((size_t)nruns + 1);
+        if (!h_ee.resize(n_ee) || !h_vtx.resize(n4) || !h_pal.resize(U) || !h_run.resize((size_t)nruns + 1)) return hipErrorOutOfMemory;
         hipError_t e;
         if ((e = hipMemcpyAsync(h_ee.data(), codes2, n_ee * 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
         if ((e = hipMemcpyAsync(h_vtx.data(), vtx_of, n4 * 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
@@ -670,7 +703,10 @@ extern "C" int snk_dev_hbv(snk_ctx* ctx, uint32_t K, uint64_t U, const void* d_u
             SNK_HIP_TRY(hipMemcpyAsync(h_big.data(), d_big, (size_t)n_big * sizeof(hbv_big), hipMemcpyDeviceToHost, st));
             SNK_HIP_TRY(fetch_tables());
             SNK_HIP_TRY(snk_sync(st));
-            std::vector<int32_t> vid(nruns, -1);
+            huge_vec<int32_t> vidv;
+            if (!vidv.resize((size_t)nruns + 1)) { snk_hbv_free(out); return snk_fail(SNK_E_NOMEM, err, errcap, "snk_dev_hbv: host allocation failed"); }
+            int32_t* vid = vidv.data();
+            for (uint64_t i = 0; i < nruns; ++i) vid[i] = -1;
             const hbv_tables t{U, h_pal.data(), h_ee.data(), h_vtx.data(), h_run.data(), snk_opt_u32("hbv_short_queue", 1) != 0};
             // Components are independent once their id blocks are known (the device's scans): a host thread each, largest first.  The bulk
             // of a genome graph is TWO components -- the forward copies' and its mirror image, the reverse copies' -- whose floods are NOT

@@ -50,6 +50,7 @@ const snk_opt_def snk_opt_defs[] = {
     {"emit_grid_log2", "log2 of the largest grid of the join's fragment copy (22; tests make it small: the kernel strides)"},
     {"lean_cold", "0: a context whose arena has not mapped the memory yet still sizes its record slots at 5 sigma (1: 1.5 sigma until the arena has the slack)"},
     {"plan_mem_mb", "the memory (MB) the slot / pass / region plans of a call divide instead of what the device has free (tests: bucket-range passes and their region probe at fixture size)"},
+    {"hbv_huge_pages", "0: the host tables of a14's flood are plain malloc memory (1: 2-MB aligned with MADV_HUGEPAGE)"},
     {"hbv_short_queue", "0: the host flood of a14 prefetches 16 / 8 / 4 queue places ahead only (1: also at push time and one / two places ahead: the bulk of a genome graph has a short queue)"},
     {"join_dbg", "1: the join counts the bytes of its unitig buffers that nothing wrote (stderr; debugging aid)"},
     {"rank_round_batch", "jumping rounds per read-back, sharded ranking (8)"},
