@@ -235,19 +235,24 @@ def large_job_row(args):
         import gc
         gc.collect()
         torch.cuda.empty_cache()
-        t0 = time.perf_counter()
-        pr = subprocess.run([sys.executable, str(ROOT / "tools" / "r6_full_job.py"), str(args.large_job_reads), "5e7", "2"], capture_output=True, text=True, timeout=420)
-        rows_ = [json.loads(l) for l in pr.stdout.splitlines() if l.startswith("{")]
-        if pr.returncode != 0 or not rows_:
-            return {"failed": (pr.stderr or pr.stdout).strip().splitlines()[-1][:300] if (pr.stderr or pr.stdout).strip() else f"exit {pr.returncode}"}
-        d = rows_[-1]
-        return {"reads": int(float(args.large_job_reads)), "held_as": "packed rows + good lengths + barcode ids (46 B per read)", "call": "second of two",
-                "wall_s": d["wall_s"], "Gkmers_per_s": d["Gkmers_per_s"], "instances": d["instances"], "retained_kmers": d["retained_kmers"], "unitigs": d["unitigs"],
-                "bucket_range_passes": d["passes"], "buckets": d["buckets"], "phase_ms": d["phase_ms"], "scratch_gib": d["scratch_gb"], "fragments": d["n_fragments"],
-                "first_call_s": rows_[0]["wall_s"], "checks": {"every_count_at_least_min_freq": d["min_count"] >= 3, "spectrum_adds_up": d["spectrum_adds_up"],
-                                                               "unitig_lengths_add_up": d["unitig_lengths_add_up"], "same_as_first_call": d["same_as_first_call"]},
-                "row_seconds": round(time.perf_counter() - t0, 1),
-                "note": "one MI355X; the north star asks 50 Gk-mers/s of eight for 1.2 B reads; 2^31 retained k-mers (32-bit node states) is the one-GPU limit"}
+        def one(reads, env):
+            t0 = time.perf_counter()
+            pr = subprocess.run([sys.executable, str(ROOT / "tools" / "r6_full_job.py"), str(reads), "5e7", "2"], capture_output=True, text=True, timeout=420, env=dict(os.environ, **env))
+            rows_ = [json.loads(l) for l in pr.stdout.splitlines() if l.startswith("{")]
+            if pr.returncode != 0 or not rows_:
+                return {"failed": (pr.stderr or pr.stdout).strip().splitlines()[-1][:300] if (pr.stderr or pr.stdout).strip() else f"exit {pr.returncode}"}
+            d = rows_[-1]
+            return {"reads": int(float(reads)), "held_as": "packed rows + good lengths + barcode ids (46 B per read)", "call": "second of two",
+                    "wall_s": d["wall_s"], "Gkmers_per_s": d["Gkmers_per_s"], "instances": d["instances"], "retained_kmers": d["retained_kmers"], "unitigs": d["unitigs"],
+                    "bucket_range_passes": d["passes"], "buckets": d["buckets"], "phase_ms": d["phase_ms"], "scratch_gib": d["scratch_gb"], "fragments": d["n_fragments"],
+                    "first_call_s": rows_[0]["wall_s"], "checks": {"every_count_at_least_min_freq": d["min_count"] >= 3, "spectrum_adds_up": d["spectrum_adds_up"],
+                                                                   "unitig_lengths_add_up": d["unitig_lengths_add_up"], "same_as_first_call": d["same_as_first_call"]},
+                    "row_seconds": round(time.perf_counter() - t0, 1)}
+        out = one(args.large_job_reads, {})
+        out["note"] = "one MI355X; the north star asks 50 Gk-mers/s of eight for 1.2 B reads; 2^31 retained k-mers (32-bit node states) is the one-GPU limit"
+        # BASELINE config 5's WHOLE job -- 1.2 B reads as per-barcode local graphs (a barcode's k-mers are few: 0.45 G retained) -- on this one GPU
+        out["config5_whole_job_per_barcode_graphs"] = one(1.2e9, {"GROUPED": "1"})
+        return out
     except Exception as ex:
         return {"failed": str(ex)[:300]}
 

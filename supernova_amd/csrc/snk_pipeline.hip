@@ -292,7 +292,7 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
         if (NB == 0) {
             const uint32_t target = target_for(adaptive ? ratio : 0.0);
             uint64_t nb = (ub_inst + target - 1) / target;
-            const uint64_t nb_max = 1ull << 24;      // (2^23 until round 6: at 800 M reads that is 9700 instances per bucket, a third of the buckets split)
+            const uint64_t nb_max = 1ull << 25;      // (2^23 until round 6: at 800 M reads that is 9700 instances per bucket, a third of the buckets split; 1.2 B reads as per-barcode graphs want 23.5 M)
             if (nb < 1) nb = 1;
             if (nb > nb_max) nb = nb_max;
             NB = (uint32_t)nb;

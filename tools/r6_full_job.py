@@ -3,8 +3,9 @@ The reads are generated slab by slab, trimmed, and kept in the compact form the 
 46 bytes per read: 55 GB); the resident step (snk_dev_count_graph) then runs on them in as many bucket-range passes as its memory plan
 asks for.  Properties checked on the device: every count >= min_freq, the spectrum and the unitig lengths add up to the table size,
 and the second call returns the first one's table checksum and unitigs.
-usage: python tools/r6_full_job.py [reads=1.2e9] [slab=5e7] [calls=2] [minimiser=auto|16|20]"""
+usage: python tools/r6_full_job.py [reads=1.2e9] [slab=5e7] [calls=2] [minimiser=auto|16|20] [debug]      env: GENOME_LEN=, K=60, GROUPED=1 (per-barcode graphs)"""
 import json
+import os
 import sys
 import time
 from pathlib import Path
@@ -30,7 +31,6 @@ def main():
     mini = sys.argv[4] if len(sys.argv) > 4 else "auto"
     e = Engine(0)
     dev = torch.device("cuda", 0)
-    import os
     ov = {"genome_len": int(float(os.environ["GENOME_LEN"]))} if os.environ.get("GENOME_LEN") else {}
     sp = synth.synth_params(n, seed=0x5EED0C30, **ov)
     long_min = mini == "20" or (mini == "auto" and int(sp.genome_len) >= 1_500_000_000)
@@ -41,7 +41,7 @@ def main():
     for first in range(0, n, slab):
         m = min(slab, n - first)
         r, q, b = e.synth(sp, first, m)
-        g = e.trim(q, 150, K=48)
+        g = e.trim(q, 150, K=int(os.environ.get("K", "48")))
         rows[first:first + m] = r
         gl[first:first + m] = g
         bc[first:first + m] = b
@@ -51,13 +51,15 @@ def main():
     free, total = torch.cuda.mem_get_info()
     print(f"reads {n} genome {int(sp.genome_len)} compact form {(rows.nbytes + gl.nbytes + bc.nbytes) / 2**30:.1f} GiB made in {time.perf_counter() - t0:.1f} s; "
           f"device free {free / 2**30:.1f} of {total / 2**30:.1f} GiB; minimisers of {20 if long_min else 16}", flush=True)
-    params = Params(K=48, sorted_table=False, long_minimiser=long_min)
+    K = int(os.environ.get("K", "48"))
+    grouped = os.environ.get("GROUPED") == "1"
+    params = Params(K=K, sorted_table=False, grouped=True, min_bc=0) if grouped else Params(K=K, sorted_table=False, long_minimiser=long_min)
     seen = None
     out = []
     for call in range(calls):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        res = e.count_graph(rows, 150, good_len=gl, bc=bc, params=params)
+        res = e.count_graph(rows, 150, good_len=gl, bc=None, group=bc, params=params) if grouped else e.count_graph(rows, 150, good_len=gl, bc=bc, params=params)
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         nk, nu = res.n_kmers, res.n_unitigs
@@ -75,7 +77,7 @@ def main():
         spec = torch.as_tensor(_DevArr(res.raw.spectrum, int(res.raw.spectrum_bins), "<i8"), device=dev)
         off = torch.as_tensor(_DevArr(res.raw.unitig_off, nu + 1, "<i8"), device=dev)
         ok_spec = int(spec.sum()) == nk
-        ok_len = int((off[1:] - off[:-1] - 47).sum()) == nk
+        ok_len = int((off[1:] - off[:-1] - (K - 1)).sum()) == nk
         ubytes = res.unitig_total_bases
         uchk = 0
         for a in range(0, ubytes, 1 << 26):
