@@ -729,6 +729,7 @@ extern "C" int snk_dev_ingest_df_count_graph(snk_ctx* ctx, snk_df_files* f, uint
     memset(out, 0, sizeof *out);
     if (n == 0) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_ingest_df_count_graph: no reads");
     if (p->K != 48 && p->K != 60) return snk_fail(SNK_E_UNSUPPORTED, err, errcap, "K=%u is not supported (48 or 60)", p->K);
+    if ((p->flags & SNK_F_GROUPED) && !f->have_bci) return snk_fail(SNK_E_ARG, err, errcap, "snk_dev_ingest_df_count_graph: per-barcode graphs need the barcode index (reads.bci)");
     const double t0 = now_s();
     df_io* io;
     uint32_t max_len;
@@ -789,6 +790,9 @@ extern "C" int snk_dev_ingest_df_count_graph(snk_ctx* ctx, snk_df_files* f, uint
             memset(&in, 0, sizeof in);
             in.n_reads = n; in.rows = io->c_rows; in.row_words = row_words; in.read_len = max_len; in.good_len = io->c_gl; in.bc = f->have_bci ? io->c_bc : nullptr;
             in.ign_bc_below = ign_bc_below; in.read_index_base = first;
+            // per-barcode graphs (SNK_F_GROUPED, BASELINE config 5): the group of a read is its barcode's ordinal in reads.bci (reads outside
+            // every range -- ordinal -1 -- are one group of their own)
+            if (p->flags & SNK_F_GROUPED) { in.group = in.bc; in.bc = nullptr; }
             rc = snk_dev_count_graph(ctx, &in, p, res, io->cs, err, errcap);
         }
     }

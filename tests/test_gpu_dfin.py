@@ -219,6 +219,41 @@ def test_streamed_count_graph_equals_resident(snk, tmp_path):
     e.close()
 
 
+def test_per_barcode_graphs_from_the_stage_inputs(snk, tmp_path):
+    """SNK_F_GROUPED through the DF seam: the group of a read is its barcode's ordinal in reads.bci -- the same (group, k-mer) table, counts
+    and unitigs with their groups as the resident grouped call on the arrays the files decode to (BASELINE config 5's shape); without the
+    barcode index the call is refused."""
+    from supernova_amd import dfin, synth
+    from supernova_amd.engine import Engine, Params
+    from supernova_amd.lib import SnkError
+    n = 160_000
+    sp = synth.synth_params(n, seed=0x5EED0DF5, unbarcoded_ppm=0)
+    head = tmp_path / "reads"
+    dfin.write_synth_df(head, sp, qual_jitter=8)
+    e = Engine(0)
+    prm = Params(K=48, grouped=True, min_bc=0, min_freq=2, sorted_table=False)
+    with dfin.DfFiles(head) as f:
+        dr = f.ingest(e)
+        reads = dr.dev_reads()
+        reads.group, reads.bc = reads.bc, None          # the barcode ordinals ARE the groups
+        def sig(r):          # (the table is left in bucket order, and the bucket count is the call's own choice: compared as a set)
+            k, c = r.keys(), r.counts()
+            o = np.lexsort(tuple(k[:, j] for j in range(k.shape[1] - 1, -1, -1)))
+            ug = sorted(zip(r.unitigs(), r.unitig_groups().tolist()))
+            return r.n_kmers, k[o].tobytes(), c[o].tobytes(), ug
+        ref = e.count_graph_reads(reads, prm)
+        want = sig(ref)
+        assert want[0] > 1000
+        del ref
+        dr.close()
+        res, st = f.count_graph(e, prm)
+        assert st["mode"] == "compact"
+        assert sig(res) == want
+    with dfin.DfFiles(head, with_bci=False) as f, pytest.raises(SnkError, match="barcode index"):
+        f.count_graph(e, prm)
+    e.close()
+
+
 @pytest.mark.skipif(not refio.REF_DRIVER.exists(), reason="oracle/_ref/snref_driver not built")
 def test_reference_written_triple_1m(snk, tmp_path):
     """a 1.05 M-read triple written by the REFERENCE's writers on this box (vecbvec::WriteAll, VecPQVec store, BinaryWriter; snref_driver ...
