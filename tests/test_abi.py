@@ -114,3 +114,14 @@ def test_options_registry_and_no_environment_switches(snk):
     t = __import__("supernova_amd.lib", fromlist=["SnkTuning"]).SnkTuning()
     snk.snk_tuning_default(C.byref(t))
     assert t.count_kernel == 0 and t.target_inst == 0
+
+
+def test_tools_and_bench_compile():
+    """bench.py runs tools/r6_full_job.py in a process of its own (config.large_job) and the evidence scripts drive the others: a tool that
+    does not even compile must not wait for a GPU box to be noticed."""
+    import py_compile
+    root = Path(__file__).resolve().parent.parent
+    files = [root / "bench.py", root / "__graft_entry__.py"] + sorted((root / "tools").glob("*.py")) + sorted((root / "tests" / "tools").glob("*.py"))
+    assert (root / "tools" / "r6_full_job.py") in files
+    for f in files:
+        py_compile.compile(str(f), doraise=True)
