@@ -323,8 +323,20 @@ extern "C" int snk_dev_count_graph(snk_ctx* ctx, const snk_dev_reads* in, const 
                 snk_ctx_release_block(S->ctx, S->records); S->records = nullptr;
                 snk_ctx_release_block(S->ctx, S->ovf_bucket); S->ovf_bucket = nullptr;
             };
+            // (the first range's first buckets are the pilot here too: data whose tables run full -- error-rich reads -- are partitioned again into
+            // smaller buckets and get the count kernel they want, as in the one-pass path below)
+            snk_count_pilot pilot_p{0.0, nullptr, nullptr};
+            const bool want_pilot_p = adaptive && pass == 0 && !have_hint;
             rc = snk_stage_count_table(ctx, st, K, PS.records, PS.seg, PS.seg + NB, 2 * NB, 2u, NB, p->min_freq, (in->bc && !grouped) ? p->min_bc : 0u, grouped ? 1u : 0u,
-                                       ub_inst, status, !local_graph, &tab, err, errcap, &rgs, nullptr, nullptr, local_graph, nullptr);
+                                       ub_inst, status, !local_graph, &tab, err, errcap, &rgs, want_pilot_p ? &pilot_p : nullptr, nullptr, local_graph, nullptr);
+            if (rc == SNK_RETARGET) {
+                const unsigned long long inst_now = PS.h_plan[0] ? PS.h_plan[0] : ub_inst;
+                snk_ctx_release_since(ctx, mark, nullptr, 0);
+                SNK_HIP_TRY(hipMemsetAsync(status, 0, 64, st));
+                ratio = inst_now ? pilot_p.per_bucket * (double)NB / (double)inst_now : 0.0;
+                out->repartitioned = 1;
+                continue;
+            }
             if (rc) return rc;
             h_ninst = PS.h_plan[0];
             memset(&part, 0, sizeof part);

@@ -1026,6 +1026,29 @@ def test_a_small_device_plans_passes_and_probes_its_regions(engine, graph_stage,
         assert sig(res) == a
 
 
+def test_a_small_device_lets_its_first_range_choose_the_count_kernel(engine, graph_stage, tune):
+    """Error-rich reads (1.5 % substitutions) on a NEW context that is told it has 256 MB: the job runs in bucket-range passes, the first
+    buckets of its first range are the pilot -- their tables run full, the job is partitioned again into smaller buckets and counted behind
+    the bit filter (960 usable slots), as the one-pass path does -- and the result is the one-pass call's."""
+    from supernova_amd import synth
+    from supernova_amd.engine import Engine, Params
+    if graph_stage == "global":
+        pytest.skip("the plans are the count stage's; one graph stage is enough")
+    n = 2_000_000
+    sp = synth.synth_params(n, seed=0x5EED0A12, sub_ppm=15000, lowq_tail_ppm=500000)
+    rows, quals, bc = engine.synth(sp)
+    one = engine.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48))
+    a = (one.n_instances, one.keys().tobytes(), one.counts().tobytes(), one.ctx().tobytes(), one.unitigs())
+    tune("plan_mem_mb", 256)
+    e2 = Engine(0)
+    try:
+        res = e2.count_graph(rows, 150, quals=quals, bc=bc, params=Params(K=48))
+        assert e2.last_partition_passes() > 1 and res.repartitioned == 1 and e2.last_count_limit() in (960, 1920)
+        assert (res.n_instances, res.keys().tobytes(), res.counts().tobytes(), res.ctx().tobytes(), res.unitigs()) == a
+    finally:
+        e2.close()
+
+
 def test_open_streamed_job_dies_with_its_arena(engine):
     """A streamed job keeps its slots, cursors and good lengths in the context's arena.  A resident call in between recycles that arena
     (snk_ctx_release_scratch): append / finish must then be refused instead of writing into memory that belongs to the new call

@@ -3,7 +3,7 @@ The reads are generated slab by slab, trimmed, and kept in the compact form the 
 46 bytes per read: 55 GB); the resident step (snk_dev_count_graph) then runs on them in as many bucket-range passes as its memory plan
 asks for.  Properties checked on the device: every count >= min_freq, the spectrum and the unitig lengths add up to the table size,
 and the second call returns the first one's table checksum and unitigs.
-usage: python tools/r6_full_job.py [reads=1.2e9] [slab=5e7] [calls=2] [minimiser=auto|16|20] [debug]      env: GENOME_LEN=, K=60, GROUPED=1 (per-barcode graphs)"""
+usage: python tools/r6_full_job.py [reads=1.2e9] [slab=5e7] [calls=2] [minimiser=auto|16|20] [debug]      env: GENOME_LEN=, K=60, GROUPED=1 (per-barcode graphs), SUB_PPM= / LOWQ_TAIL_PPM= (the read model's errors)"""
 import json
 import os
 import sys
@@ -32,6 +32,8 @@ def main():
     e = Engine(0)
     dev = torch.device("cuda", 0)
     ov = {"genome_len": int(float(os.environ["GENOME_LEN"]))} if os.environ.get("GENOME_LEN") else {}
+    if os.environ.get("SUB_PPM"):
+        ov.update(sub_ppm=int(os.environ["SUB_PPM"]), lowq_tail_ppm=int(os.environ.get("LOWQ_TAIL_PPM", "0")))
     sp = synth.synth_params(n, seed=0x5EED0C30, **ov)
     long_min = mini == "20" or (mini == "auto" and int(sp.genome_len) >= 1_500_000_000)
     t0 = time.perf_counter()
@@ -88,7 +90,7 @@ def main():
         sig = (res.n_instances, nk, chk, nu, int(off.sum()), uchk)
         row = dict(call=call, wall_s=round(wall, 3), Gkmers_per_s=round(res.n_instances / wall / 1e9, 2), instances=int(res.n_instances), retained_kmers=int(nk), unitigs=int(nu),
                    passes=e.last_partition_passes(), count_limit=e.last_count_limit(), buckets=int(res.n_buckets), buckets_split=int(res.buckets_split),
-                   scratch_gb=round(res.scratch_bytes / 2**30, 1), n_boundary=res.n_boundary, n_fragments=res.n_fragments, n_circles=res.n_circles, rank_rounds=res.rank_rounds, overflow_supermers=int(getattr(res, "n_overflow", 0)),
+                   scratch_gb=round(res.scratch_bytes / 2**30, 1), repartitioned=int(res.repartitioned), n_boundary=res.n_boundary, n_fragments=res.n_fragments, n_circles=res.n_circles, rank_rounds=res.rank_rounds, overflow_supermers=int(getattr(res, "n_overflow", 0)),
                    phase_ms={k: round(v, 1) for k, v in res.phase_ms.items()}, min_count=cmin, table_checksum=hex(chk), spectrum_adds_up=ok_spec, unitig_lengths_add_up=ok_len,
                    same_as_first_call=(seen is None or sig == seen))
         if len(sys.argv) > 5 and sys.argv[5] == "debug":
