@@ -18,6 +18,7 @@ struct snk_ctx {
     int n_cu = 256;
     size_t lds_per_block = 65536;
     uint64_t device_mem_total = 0;   // HBM of the device (sizing decisions that must not depend on what happens to be free)
+    double pass_sigma = 0.0;         // slot capacity (sigmas of the occupancy model) of a job in bucket-range passes: the largest that does not cost a pass (snk_partition_passes_needed); 0 = not planned
     uint64_t plan_mapped = 0;        // what the arena held when the call began: memory a plan can use without asking the device for more (see snk_stages.hip, partition_capacity)
     uint64_t plan_mem = 0;           // ... minus what is not this context's to use -- the caller's reads, other contexts -- in whole 8-GB steps, looked at
                                      //     at the start of every top-level call (snk_ctx_release_scratch): what the slot / pass / region plans of a large job divide

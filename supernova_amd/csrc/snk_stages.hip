@@ -477,11 +477,13 @@ static void partition_capacity(snk_ctx* ctx, uint32_t K, uint32_t NB, unsigned l
     // still more than 30 % -- only where a bucket holds several sites (the Gaussian regime; a rank of the 8-GPU job has ONE site per bucket and
     // keeps its 5 sigma, the 45 % budget below and the larger overflow list).  Option msp_sigmas_x10 pins it.
     // (memory = what this context can count on, ctx->plan_mem: a caller that holds 60 GB of reads leaves less than one that holds 15.)  A job in
-    // bucket-range passes is short of memory by definition: 3 sigma.
+    // bucket-range passes is short of memory by definition: 1.5 sigma (what saves a pass saves a scan of every read).
     double sig = 5.0;
     const double sigma = std::sqrt(mean * site_records);
     if (snk_opt_is_set("msp_sigmas_x10")) sig = 0.1 * snk_opt_u32("msp_sigmas_x10", 50);
-    else if (passes > 1) sig = mean >= 4.0 * site_records ? 3.0 : 5.0;
+    // (1.5 where that saves a pass -- a pass fewer at 600 and 800 M reads: 73.4 -> 83.3 and 64.5 -> 72.3 Gk-mers/s, 1.5-2 % of the supermers take the overflow lists --
+    // and as much slack as the same number of passes holds otherwise: snk_partition_passes_needed leaves its choice in ctx->pass_sigma)
+    else if (passes > 1) sig = mean >= 4.0 * site_records ? (ctx->pass_sigma > 0.0 ? ctx->pass_sigma : 1.5) : 5.0;
     else if (ctx->plan_mem && mean >= 4.0 * site_records) {
         const double lim = 0.30 * (double)ctx->plan_mem;
         if ((mean + 5.0 * sigma + 16.0) * NB * 32.0 > lim) sig = 3.0;
@@ -870,6 +872,7 @@ __global__ void __launch_bounds__(256) seg0_range_kernel(const uint32_t* __restr
 
 uint32_t snk_partition_passes_needed(snk_ctx* ctx, uint32_t K, uint32_t NB, unsigned long long n_inst, unsigned long long n_live, bool grouped) {
     const uint32_t forced = snk_opt_u32("partition_passes", 0);
+    ctx->pass_sigma = 0.0;
     if (forced) return forced > 64 ? 64u : forced;
     double est = 0;
     uint64_t cap = 0, ideal = 0;
@@ -879,10 +882,16 @@ uint32_t snk_partition_passes_needed(snk_ctx* ctx, uint32_t K, uint32_t NB, unsi
     // A pass scans every read again (13 ms per 100 M reads): as few as fit.  A pass's slots (at the capacity a job in passes gets) take 45 %
     // of what the context can count on -- next to them the count regions (24 bytes per retained k-mer) and the overflow lists have to fit;
     // the graph stage that follows needs less than both (800 M reads: 112 + 58 + 15 GB of 248 while counting, 156 GB at the end)
-    partition_capacity(ctx, K, NB, n_inst, n_live, grouped, &est, &cap, 2, &ideal);
     const uint64_t per_pass = (uint64_t)((double)tot * 0.45);
-    uint64_t p = (ideal * NB * 32ull + per_pass - 1) / per_pass;
-    return (uint32_t)(p < 2 ? 2 : (p > 64 ? 64 : p));
+    auto passes_at = [&](double sg) {
+        ctx->pass_sigma = sg;
+        partition_capacity(ctx, K, NB, n_inst, n_live, grouped, &est, &cap, 2, &ideal);
+        const uint64_t q = (ideal * NB * 32ull + per_pass - 1) / per_pass;
+        return q < 2 ? (uint64_t)2 : q;
+    };
+    const uint64_t p = passes_at(1.5);
+    if (passes_at(5.0) != p && passes_at(3.0) != p) ctx->pass_sigma = 1.5;      // (the last one tried that still gives p passes stays in ctx->pass_sigma)
+    return (uint32_t)(p > 64 ? 64 : p);
 }
 
 int snk_partition_passes_open(snk_ctx* ctx, hipStream_t st, uint32_t K, const snk_dev_reads* in, const uint16_t* good_len, const snk_fused_trim* ft, uint32_t NB,
